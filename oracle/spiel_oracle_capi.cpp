@@ -1,0 +1,664 @@
+// CPU ORACLE — TEST INFRASTRUCTURE ONLY (see spiel_oracle.h).
+// extern "C" surface so tests/, bench.py's cpu_baseline leg and
+// __graft_entry__.smoke() can drive the oracle through ctypes.
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <thread>
+
+#include "spiel_oracle.h"
+
+using namespace osg_oracle;
+
+namespace {
+thread_local std::string g_err;
+struct GameH {
+  std::shared_ptr<const Game> game;
+};
+struct StateH {
+  std::unique_ptr<State> state;
+};
+struct CfrH {
+  std::shared_ptr<const Game> game;
+  std::unique_ptr<CFRSolverBase> cfr;
+  std::unique_ptr<ExternalSamplingMCCFRSolver> mccfr;
+  CFRInfoStateValuesTable& Table() {
+    return cfr ? cfr->InfoStateValuesTable() : mccfr->InfoStateValuesTable();
+  }
+};
+int CopyStr(const std::string& s, char* buf, int cap) {
+  int n = static_cast<int>(s.size());
+  if (buf && cap > 0) {
+    int m = std::min(n, cap - 1);
+    memcpy(buf, s.data(), m);
+    buf[m] = 0;
+  }
+  return n;
+}
+template <typename F>
+int Guard(F&& f) {
+  try {
+    return f();
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+const char* osgo_last_error() { return g_err.c_str(); }
+
+void* osgo_load_game(const char* game_string) {
+  try {
+    return new GameH{LoadGame(game_string)};
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+void osgo_free_game(void* g) { delete static_cast<GameH*>(g); }
+
+// out[0..9]: num_actions, max_chance, players, obs_size, info_size, max_len,
+// max_chance_nodes, min_util, max_util, has_chance
+int osgo_game_info(void* g, double* out) {
+  return Guard([&] {
+    const Game& game = *static_cast<GameH*>(g)->game;
+    out[0] = game.NumDistinctActions();
+    out[1] = game.MaxChanceOutcomes();
+    out[2] = game.NumPlayers();
+    out[3] = game.ObservationTensorSize();
+    out[4] = game.InformationStateTensorSize();
+    out[5] = game.MaxGameLength();
+    out[6] = game.MaxChanceNodesInHistory();
+    out[7] = game.MinUtility();
+    out[8] = game.MaxUtility();
+    out[9] = game.HasChance() ? 1 : 0;
+    return 0;
+  });
+}
+int osgo_game_string(void* g, int which, char* buf, int cap) {
+  const Game& game = *static_cast<GameH*>(g)->game;
+  return CopyStr(which == 0 ? game.ToString() : game.ParametersString(), buf, cap);
+}
+int osgo_game_shape(void* g, int which, int* out, int cap) {
+  const Game& game = *static_cast<GameH*>(g)->game;
+  std::vector<int> s = which == 0 ? game.ObservationTensorShape()
+                                  : game.InformationStateTensorShape();
+  for (int i = 0; i < static_cast<int>(s.size()) && i < cap; ++i) out[i] = s[i];
+  return static_cast<int>(s.size());
+}
+
+void* osgo_new_state(void* g) {
+  return new StateH{static_cast<GameH*>(g)->game->NewInitialState()};
+}
+void* osgo_clone_state(void* s) {
+  return new StateH{static_cast<StateH*>(s)->state->Clone()};
+}
+void osgo_free_state(void* s) { delete static_cast<StateH*>(s); }
+
+int osgo_apply(void* s, int64_t a) {
+  return Guard([&] {
+    static_cast<StateH*>(s)->state->ApplyAction(a);
+    return 0;
+  });
+}
+int osgo_current_player(void* s) {
+  return static_cast<StateH*>(s)->state->CurrentPlayer();
+}
+int osgo_is_terminal(void* s) {
+  return static_cast<StateH*>(s)->state->IsTerminal() ? 1 : 0;
+}
+int osgo_legal_actions(void* s, int64_t* out, int cap) {
+  return Guard([&] {
+    std::vector<Action> la = static_cast<StateH*>(s)->state->LegalActions();
+    for (int i = 0; i < static_cast<int>(la.size()) && i < cap; ++i) out[i] = la[i];
+    return static_cast<int>(la.size());
+  });
+}
+int osgo_legal_actions_for(void* s, int player, int64_t* out, int cap) {
+  return Guard([&] {
+    std::vector<Action> la = static_cast<StateH*>(s)->state->LegalActions(player);
+    for (int i = 0; i < static_cast<int>(la.size()) && i < cap; ++i) out[i] = la[i];
+    return static_cast<int>(la.size());
+  });
+}
+int osgo_returns(void* s, double* out) {
+  return Guard([&] {
+    std::vector<double> r = static_cast<StateH*>(s)->state->Returns();
+    for (size_t i = 0; i < r.size(); ++i) out[i] = r[i];
+    return static_cast<int>(r.size());
+  });
+}
+int osgo_chance_outcomes(void* s, int64_t* acts, double* probs, int cap) {
+  return Guard([&] {
+    ActionsAndProbs ap = static_cast<StateH*>(s)->state->ChanceOutcomes();
+    for (int i = 0; i < static_cast<int>(ap.size()) && i < cap; ++i) {
+      acts[i] = ap[i].first;
+      probs[i] = ap[i].second;
+    }
+    return static_cast<int>(ap.size());
+  });
+}
+int osgo_tensor(void* s, int which, int player, float* out, int cap) {
+  return Guard([&] {
+    const State& st = *static_cast<StateH*>(s)->state;
+    std::vector<float> t =
+        which == 0 ? st.ObservationTensor(player) : st.InformationStateTensor(player);
+    if (static_cast<int>(t.size()) > cap) Fatal("tensor buffer too small");
+    std::copy(t.begin(), t.end(), out);
+    return static_cast<int>(t.size());
+  });
+}
+// which: 0 ToString, 1 InformationStateString(player), 2 ObservationString,
+// 3 HistoryString, 4 ActionToString(player, action)
+int osgo_string(void* s, int which, int player, int64_t action, char* buf, int cap) {
+  try {
+    const State& st = *static_cast<StateH*>(s)->state;
+    std::string r;
+    switch (which) {
+      case 0: r = st.ToString(); break;
+      case 1: r = st.InformationStateString(player); break;
+      case 2: r = st.ObservationString(player); break;
+      case 3: r = st.HistoryString(); break;
+      case 4: r = st.ActionToString(player, action); break;
+      default: Fatal("bad string selector");
+    }
+    return CopyStr(r, buf, cap);
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+int osgo_history(void* s, int64_t* out, int cap) {
+  std::vector<Action> h = static_cast<StateH*>(s)->state->History();
+  for (int i = 0; i < static_cast<int>(h.size()) && i < cap; ++i) out[i] = h[i];
+  return static_cast<int>(h.size());
+}
+
+// ---------------------------------------------------------------------------
+// Seeded random playouts with a full per-ply record: the differential-test
+// workhorse.  Playout i uses CounterRng(seed, i).  At every ply t (including
+// the final position) it records
+//   mask  [n, L+1, W] u32  bit-packed LegalActions (chance outcomes at chance
+//                          nodes), W = ceil(max(A, max_chance) / 32)
+//   cur   [n, L+1]    i8   CurrentPlayer()
+//   term  [n, L+1]    u8   IsTerminal()
+//   rets  [n, L+1, P] f64  Returns()
+//   acts  [n, L]      i16  action applied at ply t, -1 past the end
+//   obs   [n, L+1, P, obs_size] f32 (optional, may be NULL)
+//   info  [n, L+1, P, info_size] f32 (optional, may be NULL)
+// stop[i] (optional) = number of plies to play for playout i (else to the end).
+// Chance actions are drawn with SampleAction(ChanceOutcomes(), rng.Unit()),
+// player actions uniformly with rng.Below(#legal).  Returns plies played max.
+// ---------------------------------------------------------------------------
+int osgo_random_playouts(void* g, uint64_t seed, int64_t n, int L, int W,
+                         const int32_t* stop, int16_t* acts, uint32_t* mask,
+                         int8_t* cur, uint8_t* term, double* rets, float* obs,
+                         float* info) {
+  return Guard([&] {
+    const Game& game = *static_cast<GameH*>(g)->game;
+    const int P = game.NumPlayers();
+    const int osz = game.ObservationTensorSize();
+    const int isz = game.InformationStateTensorSize();
+    int longest = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      CounterRng rng(seed, static_cast<uint64_t>(i));
+      std::unique_ptr<State> s = game.NewInitialState();
+      int limit = stop ? stop[i] : L;
+      for (int t = 0; t <= L; ++t) {
+        const int64_t row = i * (L + 1) + t;
+        std::vector<Action> legal = s->LegalActions();
+        for (int w = 0; w < W; ++w) mask[row * W + w] = 0;
+        for (Action a : legal) mask[row * W + a / 32] |= (1u << (a % 32));
+        cur[row] = static_cast<int8_t>(s->CurrentPlayer());
+        term[row] = s->IsTerminal();
+        std::vector<double> r = s->Returns();
+        for (int p = 0; p < P; ++p) rets[row * P + p] = r[p];
+        if (obs)
+          for (int p = 0; p < P; ++p)
+            s->ObservationTensor(p, obs + (row * P + p) * osz, osz);
+        if (info && isz > 0)
+          for (int p = 0; p < P; ++p)
+            s->InformationStateTensor(p, info + (row * P + p) * isz, isz);
+        if (t == L) break;
+        if (s->IsTerminal() || t >= limit) {
+          acts[i * L + t] = -1;
+          continue;
+        }
+        Action a;
+        if (s->IsChanceNode()) {
+          a = SampleAction(s->ChanceOutcomes(), rng.Unit()).first;
+        } else {
+          a = legal[rng.Below(static_cast<uint32_t>(legal.size()))];
+        }
+        acts[i * L + t] = static_cast<int16_t>(a);
+        s->ApplyAction(a);
+        longest = std::max(longest, t + 1);
+      }
+    }
+    return longest;
+  });
+}
+
+// Replays the rollout the HIP kernel performs from a given history: rollout r
+// of root `root_index` uses CounterRng(seed, root_index, r) and draws exactly
+// as osgo_random_playouts does.  Sums Returns() over n_rollouts into out[P]
+// (not divided).  history = actions from the initial state.
+int osgo_replay_rollouts(void* g, const int16_t* history, int hist_len,
+                         uint64_t seed, uint64_t root_index, int n_rollouts,
+                         double* out, int64_t* steps_out) {
+  return Guard([&] {
+    const Game& game = *static_cast<GameH*>(g)->game;
+    std::unique_ptr<State> root = game.NewInitialState();
+    for (int t = 0; t < hist_len; ++t) root->ApplyAction(history[t]);
+    const int P = game.NumPlayers();
+    for (int p = 0; p < P; ++p) out[p] = 0;
+    int64_t steps = 0;
+    for (int r = 0; r < n_rollouts; ++r) {
+      CounterRng rng(seed, root_index, static_cast<uint64_t>(r));
+      std::unique_ptr<State> s = root->Clone();
+      while (!s->IsTerminal()) {
+        if (s->IsChanceNode()) {
+          s->ApplyAction(SampleAction(s->ChanceOutcomes(), rng.Unit()).first);
+        } else {
+          std::vector<Action> legal = s->LegalActions();
+          s->ApplyAction(legal[rng.Below(static_cast<uint32_t>(legal.size()))]);
+        }
+        ++steps;
+      }
+      std::vector<double> ret = s->Returns();
+      for (int p = 0; p < P; ++p) out[p] += ret[p];
+    }
+    if (steps_out) *steps_out = steps;
+    return 0;
+  });
+}
+
+// ---------------------------------------------------------------------------
+// MCTS
+// ---------------------------------------------------------------------------
+// Runs MCTSBot(RandomRolloutEvaluator(n_rollouts, seed), ...) from `state`.
+// out_children: per root child {action, explore_count, total_reward, outcome
+// for the root player or NaN}; returns the number of children, best action in
+// *best_action, root outcome (for root player; NaN if unsolved) in *root_outcome.
+int osgo_mcts_search(void* s, double uct_c, int max_simulations, int n_rollouts,
+                     int64_t max_memory_mb, int solve, int seed,
+                     int64_t* best_action, double* root_outcome,
+                     double* out_children, int cap, int* root_visits) {
+  return Guard([&] {
+    const State& st = *static_cast<StateH*>(s)->state;
+    auto ev = std::make_shared<RandomRolloutEvaluator>(n_rollouts, seed);
+    MCTSBot bot(*st.GetGame(), ev, uct_c, max_simulations, max_memory_mb,
+                solve != 0, seed, false);
+    std::unique_ptr<SearchNode> root = bot.MCTSearch(st);
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    *best_action = root->children.empty() ? -1 : root->BestChild().action;
+    Player rp = st.CurrentPlayer();
+    *root_outcome = (root->outcome.empty() || rp < 0) ? nan : root->outcome[rp];
+    if (root_visits) *root_visits = root->explore_count;
+    int k = 0;
+    for (const SearchNode& c : root->children) {
+      if (k >= cap) break;
+      out_children[4 * k + 0] = static_cast<double>(c.action);
+      out_children[4 * k + 1] = c.explore_count;
+      out_children[4 * k + 2] = c.total_reward;
+      out_children[4 * k + 3] = (c.outcome.empty() || rp < 0) ? nan : c.outcome[rp];
+      ++k;
+    }
+    return static_cast<int>(root->children.size());
+  });
+}
+
+// Self-play of two MCTS bots (mcts_test.cc:45-77); returns via out[P].
+int osgo_mcts_selfplay(void* g, double uct_c, int max_simulations, int n_rollouts,
+                       int seed, double* out) {
+  return Guard([&] {
+    const Game& game = *static_cast<GameH*>(g)->game;
+    auto ev = std::make_shared<RandomRolloutEvaluator>(n_rollouts, seed);
+    MCTSBot b0(game, ev, uct_c, max_simulations, 5, true, seed, false);
+    MCTSBot b1(game, ev, uct_c, max_simulations, 5, true, seed + 1, false);
+    std::unique_ptr<State> s = game.NewInitialState();
+    std::mt19937 chance(seed);
+    while (!s->IsTerminal()) {
+      if (s->IsChanceNode()) {
+        double z = (chance() >> 5) * (1.0 / 134217728.0);
+        s->ApplyAction(SampleAction(s->ChanceOutcomes(), z).first);
+      } else {
+        Action a = (s->CurrentPlayer() == 0 ? b0 : b1).Step(*s);
+        s->ApplyAction(a);
+      }
+    }
+    std::vector<double> r = s->Returns();
+    for (size_t i = 0; i < r.size(); ++i) out[i] = r[i];
+    return 0;
+  });
+}
+
+// ---------------------------------------------------------------------------
+// CFR / MCCFR
+// ---------------------------------------------------------------------------
+// kind: 0 CFRSolver, 1 CFRPlusSolver, 2 ES-MCCFR(simple), 3 ES-MCCFR(full),
+// 4 CFRSolverBase(simultaneous updates, no linear avg, no RM+)
+void* osgo_cfr_create(void* g, int kind, int seed) {
+  try {
+    auto* h = new CfrH;
+    h->game = static_cast<GameH*>(g)->game;
+    if (kind == 0) h->cfr = std::make_unique<CFRSolver>(*h->game);
+    else if (kind == 1) h->cfr = std::make_unique<CFRPlusSolver>(*h->game);
+    else if (kind == 4) h->cfr = std::make_unique<CFRSolverBase>(*h->game, false, false, false);
+    else h->mccfr = std::make_unique<ExternalSamplingMCCFRSolver>(
+             *h->game, seed, kind == 3 ? AverageType::kFull : AverageType::kSimple);
+    return h;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+void osgo_cfr_free(void* h) { delete static_cast<CfrH*>(h); }
+int osgo_cfr_iterate(void* h, int iters) {
+  return Guard([&] {
+    auto* c = static_cast<CfrH*>(h);
+    for (int i = 0; i < iters; ++i) {
+      if (c->cfr) c->cfr->EvaluateAndUpdatePolicy();
+      else c->mccfr->RunIteration();
+    }
+    return 0;
+  });
+}
+int osgo_cfr_num_infostates(void* h) {
+  return static_cast<int>(static_cast<CfrH*>(h)->Table().size());
+}
+// Rows sorted by key.  keys: '\n'-joined.  Arrays are [I, amax], padded with 0;
+// nact[I]; legal [I, amax] padded with -1.
+int osgo_cfr_tables(void* h, int amax, char* keys, int keys_cap, int* nact,
+                    int64_t* legal, double* regrets, double* cum_policy,
+                    double* cur_policy, double* avg_policy) {
+  return Guard([&] {
+    auto& table = static_cast<CfrH*>(h)->Table();
+    std::vector<std::string> ks;
+    for (const auto& kv : table) ks.push_back(kv.first);
+    std::sort(ks.begin(), ks.end());
+    std::string joined;
+    for (size_t i = 0; i < ks.size(); ++i) {
+      if (i) joined += "\n";
+      joined += ks[i];
+    }
+    CopyStr(joined, keys, keys_cap);
+    for (size_t i = 0; i < ks.size(); ++i) {
+      const CFRInfoStateValues& v = table.at(ks[i]);
+      ActionsAndProbs avg = CFRAveragePolicy::FromValues(v);
+      nact[i] = v.num_actions();
+      for (int a = 0; a < amax; ++a) {
+        bool in = a < v.num_actions();
+        legal[i * amax + a] = in ? v.legal_actions[a] : -1;
+        regrets[i * amax + a] = in ? v.cumulative_regrets[a] : 0;
+        cum_policy[i * amax + a] = in ? v.cumulative_policy[a] : 0;
+        cur_policy[i * amax + a] = in ? v.current_policy[a] : 0;
+        avg_policy[i * amax + a] = in ? avg[a].second : 0;
+      }
+    }
+    return static_cast<int>(joined.size());
+  });
+}
+// which: 0 NashConv(average), 1 Exploitability(average), 2 NashConv(current)
+int osgo_cfr_eval(void* h, int which, double* out) {
+  return Guard([&] {
+    auto* c = static_cast<CfrH*>(h);
+    std::shared_ptr<Policy> pol;
+    if (which == 2) {
+      ORACLE_CHECK(c->cfr);
+      pol = c->cfr->CurrentPolicy();
+    } else {
+      pol = c->cfr ? c->cfr->AveragePolicy() : c->mccfr->AveragePolicy();
+    }
+    *out = which == 1 ? Exploitability(*c->game, *pol) : NashConv(*c->game, *pol);
+    return 0;
+  });
+}
+// Expected value of the average policy for each player (cfr_test.cc:36-62).
+int osgo_cfr_expected_returns(void* h, double* out) {
+  return Guard([&] {
+    auto* c = static_cast<CfrH*>(h);
+    std::shared_ptr<Policy> pol = c->cfr ? c->cfr->AveragePolicy() : c->mccfr->AveragePolicy();
+    std::vector<double> v = ExpectedReturns(*c->game->NewInitialState(), *pol);
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    return 0;
+  });
+}
+
+// Judge an externally supplied tabular policy (e.g. downloaded from the GPU):
+// keys '\n'-joined, rows [I, amax] of (action, prob), nact[I].
+// which: 0 NashConv, 1 Exploitability; also writes expected returns to ev[P].
+int osgo_eval_policy(void* g, const char* keys, int amax, const int* nact,
+                     const int64_t* actions, const double* probs, int which,
+                     double* out, double* ev) {
+  return Guard([&] {
+    const Game& game = *static_cast<GameH*>(g)->game;
+    TabularPolicy pol;
+    std::string all(keys);
+    size_t pos = 0;
+    int row = 0;
+    while (pos <= all.size()) {
+      size_t nl = all.find('\n', pos);
+      if (nl == std::string::npos) nl = all.size();
+      std::string key = all.substr(pos, nl - pos);
+      ActionsAndProbs ap;
+      for (int a = 0; a < nact[row]; ++a)
+        ap.push_back({actions[row * amax + a], probs[row * amax + a]});
+      pol.Table()[key] = ap;
+      ++row;
+      pos = nl + 1;
+      if (nl == all.size()) break;
+    }
+    *out = which == 1 ? Exploitability(game, pol) : NashConv(game, pol);
+    if (ev) {
+      std::vector<double> v = ExpectedReturns(*game.NewInitialState(), pol);
+      for (size_t i = 0; i < v.size(); ++i) ev[i] = v[i];
+    }
+    return 0;
+  });
+}
+// Named policies: 0 uniform, 1 first-action, 2 kuhn optimal(alpha).
+int osgo_eval_named_policy(void* g, int which_policy, double alpha, int which,
+                           double* out) {
+  return Guard([&] {
+    const Game& game = *static_cast<GameH*>(g)->game;
+    TabularPolicy pol = which_policy == 0   ? GetUniformPolicy(game)
+                        : which_policy == 1 ? GetFirstActionPolicy(game)
+                                            : KuhnOptimalPolicy(alpha);
+    *out = which == 1 ? Exploitability(game, pol) : NashConv(game, pol);
+    return 0;
+  });
+}
+
+// Tree census (integration_tests/api_test.py:75-101): out = chance, decision,
+// terminal node counts and the number of distinct infostates.
+static void Census(const State& s, int64_t* out, std::unordered_map<std::string, int>* seen) {
+  if (s.IsTerminal()) {
+    ++out[2];
+    return;
+  }
+  if (s.IsChanceNode()) {
+    ++out[0];
+    for (const auto& ap : s.ChanceOutcomes()) Census(*s.Child(ap.first), out, seen);
+    return;
+  }
+  ++out[1];
+  (*seen)[s.InformationStateString()] = 1;
+  for (Action a : s.LegalActions()) Census(*s.Child(a), out, seen);
+}
+int osgo_tree_census(void* g, int64_t* out) {
+  return Guard([&] {
+    const Game& game = *static_cast<GameH*>(g)->game;
+    out[0] = out[1] = out[2] = 0;
+    std::unordered_map<std::string, int> seen;
+    Census(*game.NewInitialState(), out, &seen);
+    out[3] = static_cast<int64_t>(seen.size());
+    return 0;
+  });
+}
+
+// ---------------------------------------------------------------------------
+// cpu_baseline timing legs (bench.py).  Each returns elapsed seconds via *secs
+// and the number of units processed via *units; `threads` independent workers.
+// ---------------------------------------------------------------------------
+// (a) env steps: per state LegalActions() + ApplyAction() + IsTerminal() +
+//     Returns() + CurrentPlayer() over pre-generated states (Clone()d from a
+//     pool of `pool` positions reached by random play, depth = hash mod 36,
+//     non-terminal) applying one seeded random legal action each.  Units =
+//     env steps.  The pool is rebuilt outside the timed region.
+int osgo_bench_env_steps(void* g, uint64_t seed, int64_t pool, int64_t total_steps,
+                         int threads, double* secs, int64_t* units) {
+  return Guard([&] {
+    const Game& game = *static_cast<GameH*>(g)->game;
+    std::vector<std::unique_ptr<State>> states(pool);
+    std::vector<Action> actions(pool);
+    for (int64_t i = 0; i < pool; ++i) {
+      CounterRng rng(seed, static_cast<uint64_t>(i));
+      for (;;) {
+        std::unique_ptr<State> s = game.NewInitialState();
+        int depth = static_cast<int>(rng.Below(36));
+        for (int t = 0; t < depth && !s->IsTerminal(); ++t) {
+          if (s->IsChanceNode()) {
+            s->ApplyAction(SampleAction(s->ChanceOutcomes(), rng.Unit()).first);
+          } else {
+            std::vector<Action> la = s->LegalActions();
+            s->ApplyAction(la[rng.Below(static_cast<uint32_t>(la.size()))]);
+          }
+        }
+        if (s->IsTerminal()) continue;
+        std::vector<Action> la = s->LegalActions();
+        actions[i] = la[rng.Below(static_cast<uint32_t>(la.size()))];
+        states[i] = std::move(s);
+        break;
+      }
+    }
+    std::vector<int64_t> done(threads, 0);
+    std::vector<double> sink(threads, 0);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> workers;
+    for (int w = 0; w < threads; ++w) {
+      workers.emplace_back([&, w] {
+        int64_t quota = total_steps / threads;
+        double acc = 0;
+        for (int64_t k = 0; k < quota; ++k) {
+          int64_t i = (k * threads + w) % pool;
+          std::unique_ptr<State> s = states[i]->Clone();
+          std::vector<Action> la = s->LegalActions();
+          s->ApplyAction(actions[i]);
+          acc += la.size() + s->IsTerminal() + s->Returns()[0] + s->CurrentPlayer();
+          acc += s->LegalActions().size();
+        }
+        done[w] = quota;
+        sink[w] = acc;
+      });
+    }
+    for (auto& t : workers) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    *secs = std::chrono::duration<double>(t1 - t0).count();
+    *units = 0;
+    for (int64_t d : done) *units += d;
+    if (sink[0] == 1234.5678) g_err = "sink";
+    return 0;
+  });
+}
+// (b) random playouts (benchmark_game.cc-equivalent): units = moves.
+int osgo_bench_playouts(void* g, uint64_t seed, int64_t sims, int threads,
+                        double* secs, int64_t* moves) {
+  return Guard([&] {
+    const Game& game = *static_cast<GameH*>(g)->game;
+    std::vector<int64_t> done(threads, 0);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> workers;
+    for (int w = 0; w < threads; ++w) {
+      workers.emplace_back([&, w] {
+        int64_t count = 0;
+        for (int64_t k = w; k < sims; k += threads) {
+          CounterRng rng(seed, static_cast<uint64_t>(k));
+          std::unique_ptr<State> s = game.NewInitialState();
+          while (!s->IsTerminal()) {
+            if (s->IsChanceNode()) {
+              s->ApplyAction(SampleAction(s->ChanceOutcomes(), rng.Unit()).first);
+            } else {
+              std::vector<Action> la = s->LegalActions();
+              s->ApplyAction(la[rng.Below(static_cast<uint32_t>(la.size()))]);
+            }
+            ++count;
+          }
+        }
+        done[w] = count;
+      });
+    }
+    for (auto& t : workers) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    *secs = std::chrono::duration<double>(t1 - t0).count();
+    *moves = 0;
+    for (int64_t d : done) *moves += d;
+    return 0;
+  });
+}
+// (c) MCTS sims/s: `roots` independent MCTSBot searches from positions reached
+// by hash(i) mod depth_mod random moves; units = simulations.
+int osgo_bench_mcts(void* g, uint64_t seed, int roots, int depth_mod,
+                    int max_simulations, int n_rollouts, double uct_c, int threads,
+                    double* secs, int64_t* sims) {
+  return Guard([&] {
+    const Game& game = *static_cast<GameH*>(g)->game;
+    std::vector<std::unique_ptr<State>> starts(roots);
+    for (int i = 0; i < roots; ++i) {
+      CounterRng rng(seed, static_cast<uint64_t>(i));
+      for (;;) {
+        std::unique_ptr<State> s = game.NewInitialState();
+        int depth = depth_mod > 0 ? static_cast<int>(rng.Below(depth_mod)) : 0;
+        for (int t = 0; t < depth && !s->IsTerminal(); ++t) {
+          std::vector<Action> la = s->LegalActions();
+          s->ApplyAction(la[rng.Below(static_cast<uint32_t>(la.size()))]);
+        }
+        if (s->IsTerminal()) continue;
+        starts[i] = std::move(s);
+        break;
+      }
+    }
+    std::vector<int64_t> done(threads, 0);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> workers;
+    for (int w = 0; w < threads; ++w) {
+      workers.emplace_back([&, w] {
+        int64_t count = 0;
+        for (int i = w; i < roots; i += threads) {
+          auto ev = std::make_shared<RandomRolloutEvaluator>(n_rollouts, 42 + i);
+          MCTSBot bot(game, ev, uct_c, max_simulations, 1000, false, 42 + i, false);
+          std::unique_ptr<SearchNode> root = bot.MCTSearch(*starts[i]);
+          count += root->explore_count;
+        }
+        done[w] = count;
+      });
+    }
+    for (auto& t : workers) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    *secs = std::chrono::duration<double>(t1 - t0).count();
+    *sims = 0;
+    for (int64_t d : done) *sims += d;
+    return 0;
+  });
+}
+// (d) solver iterations/s (kind as in osgo_cfr_create); one solver per thread.
+int osgo_bench_cfr(void* g, int kind, int iters, int threads, double* secs) {
+  return Guard([&] {
+    std::vector<void*> hs(threads);
+    for (int w = 0; w < threads; ++w) hs[w] = osgo_cfr_create(g, kind, 1 + w);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> workers;
+    for (int w = 0; w < threads; ++w)
+      workers.emplace_back([&, w] { osgo_cfr_iterate(hs[w], iters); });
+    for (auto& t : workers) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    *secs = std::chrono::duration<double>(t1 - t0).count();
+    for (void* h : hs) osgo_cfr_free(h);
+    return 0;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,276 @@
+// CPU ORACLE — TEST INFRASTRUCTURE ONLY (see spiel_oracle.h).
+// Base State/Game semantics, game-string parsing, SampleAction, counter RNG.
+#include <algorithm>
+#include <cmath>
+#include <sstream>
+
+#include "spiel_oracle.h"
+
+namespace osg_oracle {
+
+void Fatal(const std::string& msg) { throw SpielError(msg); }
+
+// ----------------------------------------------------------------------------
+// Game strings.  Restates game_parameters.cc:172-198 (value typing) and
+// :200-227 (name(k=v,...) split at top-level commas).
+// ----------------------------------------------------------------------------
+static ParamValue ParseParamValue(const std::string& s) {
+  ParamValue v;
+  if (s == "True" || s == "true") {
+    v.kind = ParamValue::kBool;
+    v.b = true;
+  } else if (s == "False" || s == "false") {
+    v.kind = ParamValue::kBool;
+    v.b = false;
+  } else if (!s.empty() &&
+             s.find_first_not_of("+-0123456789") == std::string::npos) {
+    v.kind = ParamValue::kInt;
+    v.i = std::stoi(s);
+  } else if (!s.empty() &&
+             s.find_first_not_of("+-0123456789.") == std::string::npos) {
+    v.kind = ParamValue::kDouble;
+    v.d = std::stod(s);
+  } else {
+    v.kind = ParamValue::kString;
+    v.s = s;
+  }
+  return v;
+}
+
+std::string ParamValue::ToString() const {
+  switch (kind) {
+    case kBool:
+      return b ? "True" : "False";
+    case kInt:
+      return std::to_string(i);
+    case kDouble: {
+      std::ostringstream os;
+      os << d;
+      return os.str();
+    }
+    default:
+      return s;
+  }
+}
+
+GameParams ParseGameString(const std::string& gs) {
+  GameParams out;
+  if (gs.empty()) return out;
+  size_t open = gs.find('(');
+  if (open == std::string::npos) {
+    out["name"] = ParseParamValue(gs);
+    out["name"].kind = ParamValue::kString;
+    out["name"].s = gs;
+    return out;
+  }
+  ParamValue name;
+  name.kind = ParamValue::kString;
+  name.s = gs.substr(0, open);
+  out["name"] = name;
+  int depth = 1;
+  size_t start = open + 1;
+  long eq = -1;
+  for (size_t i = start; i < gs.size(); ++i) {
+    char c = gs[i];
+    if (c == '(') ++depth;
+    if (c == ')') --depth;
+    if (c == '=' && depth == 1) eq = static_cast<long>(i);
+    bool at_sep = (c == ',' && depth == 1);
+    bool at_end = (c == ')' && depth == 0 && i > start + 1);
+    if (at_sep || at_end) {
+      if (eq < 0) Fatal("Malformed game string: " + gs);
+      out[gs.substr(start, eq - start)] =
+          ParseParamValue(gs.substr(eq + 1, i - eq - 1));
+      start = i + 1;
+      eq = -1;
+    }
+  }
+  if (depth > 0) Fatal("Missing closing bracket ')'.");
+  return out;
+}
+
+bool Game::BoolParam(const std::string& k, bool def) {
+  auto it = params_.find(k);
+  if (it == params_.end()) {
+    ParamValue v;
+    v.kind = ParamValue::kBool;
+    v.b = def;
+    params_[k] = v;
+    return def;
+  }
+  if (it->second.kind != ParamValue::kBool)
+    Fatal("Wrong type for parameter " + k);  // spiel.cc:65-90
+  return it->second.b;
+}
+int Game::IntParam(const std::string& k, int def) {
+  auto it = params_.find(k);
+  if (it == params_.end()) {
+    ParamValue v;
+    v.kind = ParamValue::kInt;
+    v.i = def;
+    params_[k] = v;
+    return def;
+  }
+  if (it->second.kind != ParamValue::kInt)
+    Fatal("Wrong type for parameter " + k);
+  return it->second.i;
+}
+std::string Game::StrParam(const std::string& k, const std::string& def) {
+  auto it = params_.find(k);
+  if (it == params_.end()) {
+    ParamValue v;
+    v.kind = ParamValue::kString;
+    v.s = def;
+    params_[k] = v;
+    return def;
+  }
+  if (it->second.kind != ParamValue::kString)
+    Fatal("Wrong type for parameter " + k);
+  return it->second.s;
+}
+
+static std::string JoinParams(const GameParams& params) {
+  std::string s;
+  bool first = true;
+  for (const auto& kv : params) {  // std::map: sorted by key, like the ref
+    if (kv.first == "name") continue;
+    if (!first) s += ",";
+    s += kv.first + "=" + kv.second.ToString();
+    first = false;
+  }
+  return s;
+}
+std::string Game::ToString() const {  // game_parameters.cc:152-170
+  return short_name_ + "(" + JoinParams(given_) + ")";
+}
+std::string Game::ParametersString() const {
+  return "{" + JoinParams(params_) + "}";
+}
+
+// ----------------------------------------------------------------------------
+// State base (spiel.cc:355-360, 441-451, 518-524, 908-945; spiel.h:366-372)
+// ----------------------------------------------------------------------------
+State::State(std::shared_ptr<const Game> game)
+    : game_(std::move(game)),
+      num_distinct_actions_(game_->NumDistinctActions()),
+      num_players_(game_->NumPlayers()) {}
+
+void State::ApplyAction(Action a) {
+  if (a == kInvalidAction) Fatal("ApplyAction(kInvalidAction)");
+  Player mover = CurrentPlayer();
+  DoApplyAction(a);
+  history_.push_back({mover, a});
+  ++move_number_;
+}
+
+std::vector<Action> State::LegalActions(Player player) const {
+  if (!IsTerminal() && player == CurrentPlayer()) return LegalActions();
+  return {};
+}
+
+std::vector<int> State::LegalActionsMask(Player player) const {
+  int length = (player == kChancePlayerId) ? game_->MaxChanceOutcomes()
+                                           : num_distinct_actions_;
+  std::vector<int> mask(length, 0);
+  for (Action a : LegalActions(player)) mask[a] = 1;
+  return mask;
+}
+
+ActionsAndProbs State::ChanceOutcomes() const {
+  Fatal("ChanceOutcomes unimplemented for this game");
+}
+std::string State::InformationStateString(Player) const {
+  Fatal("InformationStateString unimplemented");
+}
+std::string State::ObservationString(Player) const {
+  Fatal("ObservationString unimplemented");
+}
+void State::InformationStateTensor(Player, float*, int) const {
+  Fatal("InformationStateTensor unimplemented");
+}
+void State::ObservationTensor(Player, float*, int) const {
+  Fatal("ObservationTensor unimplemented");
+}
+
+std::vector<float> State::ObservationTensor(Player player) const {
+  if (player < 0 || player >= num_players_)
+    Fatal("ObservationTensor: player out of range");
+  std::vector<float> out(game_->ObservationTensorSize());
+  ObservationTensor(player, out.data(), static_cast<int>(out.size()));
+  return out;
+}
+std::vector<float> State::InformationStateTensor(Player player) const {
+  if (player < 0 || player >= num_players_)
+    Fatal("InformationStateTensor: player out of range");
+  std::vector<float> out(game_->InformationStateTensorSize());
+  InformationStateTensor(player, out.data(), static_cast<int>(out.size()));
+  return out;
+}
+
+std::vector<Action> State::History() const {
+  std::vector<Action> h;
+  h.reserve(history_.size());
+  for (const auto& pa : history_) h.push_back(pa.action);
+  return h;
+}
+std::string State::HistoryString() const {
+  std::string s;
+  for (size_t i = 0; i < history_.size(); ++i) {
+    if (i) s += ", ";
+    s += std::to_string(history_[i].action);
+  }
+  return s;
+}
+
+// ----------------------------------------------------------------------------
+// spiel.cc:372-409
+// ----------------------------------------------------------------------------
+std::pair<Action, double> SampleAction(const ActionsAndProbs& outcomes,
+                                       double z) {
+  if (!(z >= 0 && z < 1)) Fatal("SampleAction: z out of [0,1)");
+  if (outcomes.size() == 1) {
+    if (std::fabs(outcomes[0].second - 1.0) > 1e-9)
+      Fatal("SampleAction: single outcome with p != 1");
+    return outcomes[0];
+  }
+  double total = 0;
+  for (const auto& o : outcomes) {
+    if (!(o.second >= 0 && o.second <= 1)) Fatal("SampleAction: bad prob");
+    total += o.second;
+  }
+  if (std::fabs(total - 1.0) > 1e-9) Fatal("SampleAction: probs do not sum to 1");
+  double acc = 0;
+  for (const auto& o : outcomes) {
+    if (acc <= z && z < acc + o.second) return o;
+    acc += o.second;
+  }
+  Fatal("SampleAction: failed to sample");
+}
+
+// ----------------------------------------------------------------------------
+// Counter RNG: identical arithmetic in open_spiel_amd/csrc/osg_rng.h.
+// ----------------------------------------------------------------------------
+static inline uint64_t Mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+CounterRng::CounterRng(uint64_t seed, uint64_t stream, uint64_t sub) {
+  // Three rounds of mixing decorrelate (seed, stream, sub) triples.
+  uint64_t a = Mix64(seed + 0x9E3779B97F4A7C15ULL);
+  uint64_t b = Mix64(a ^ (stream * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));
+  s = Mix64(b ^ (sub * 0xA0761D6478BD642FULL + 0xE7037ED1A0B428DBULL));
+}
+uint64_t CounterRng::Next() {
+  s += 0x9E3779B97F4A7C15ULL;
+  return Mix64(s);
+}
+uint32_t CounterRng::Below(uint32_t n) {
+  uint64_t hi = Next() >> 32;
+  return static_cast<uint32_t>((hi * n) >> 32);
+}
+double CounterRng::Unit() {
+  return static_cast<double>(Next() >> 11) * (1.0 / 9007199254740992.0);
+}
+
+}  // namespace osg_oracle

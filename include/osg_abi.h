@@ -1,0 +1,228 @@
+/* =============================================================================
+ * osg_abi.h — C-ABI of the MI355X batched game-step and search engine.
+ *
+ * This is the drop-in boundary for OpenSpiel's data-parallel hot path: every
+ * entry point below is what a binding of the reference (pybind / cgo / Rust
+ * FFI) would call instead of looping over per-state virtual calls.  Plain
+ * pointers and sizes only — no torch, no C++ types.  Conventions follow the
+ * reference's in-tree C API (open_spiel/rust/src/rust_open_spiel.h:18-88:
+ * opaque handles, caller-supplied out-buffers).
+ *
+ * All functions return 0 on success and a negative osg_status on failure; the
+ * message is available from osg_last_error() (thread-local).  Nothing in the
+ * library calls exit() or throws across the boundary; the C++ host classes
+ * (open_spiel_amd/csrc/host) turn a non-zero code into SpielFatalError so the
+ * observable error behaviour matches open_spiel/spiel_utils.cc:119-137.
+ *
+ * Pointers named d_* are DEVICE pointers (HBM, e.g. torch tensor.data_ptr());
+ * pointers named h_* are host pointers.  Buffers named without prefix take an
+ * `on_host` flag.  The library owns the memory behind handles; the caller owns
+ * every buffer it passes in.  An osg_ctx is bound to one device and one HIP
+ * stream and is not thread-safe; distinct contexts are independent.  All work
+ * is enqueued on the context's stream; functions that write to host buffers
+ * synchronise that stream before returning, device-only functions do not.
+ * =========================================================================== */
+#ifndef OSG_ABI_H_
+#define OSG_ABI_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  OSG_OK = 0,
+  OSG_ERR_INVALID = -1,     /* bad argument / malformed game string           */
+  OSG_ERR_UNSUPPORTED = -2, /* game or parameter not available on the device   */
+  OSG_ERR_HIP = -3,         /* a HIP runtime call failed                       */
+  OSG_ERR_ILLEGAL = -4,     /* an illegal action was applied (count > 0)       */
+  OSG_ERR_NOMEM = -5
+} osg_status;
+
+typedef struct osg_ctx osg_ctx;     /* one per (process, device): HIP stream      */
+typedef struct osg_batch osg_batch; /* N states of one game, SoA in HBM           */
+typedef struct osg_cfr osg_cfr;     /* a flattened game tree + fp64 CFR tables    */
+
+/* Sentinels (open_spiel/spiel_globals.h:26-56,82). */
+#define OSG_CHANCE_PLAYER (-1)
+#define OSG_TERMINAL_PLAYER (-4)
+#define OSG_INVALID_ACTION (-1)
+
+/* Replaces Game::NumDistinctActions / MaxChanceOutcomes / NumPlayers /
+ * ObservationTensorShape / InformationStateTensorShape / MaxGameLength /
+ * MinUtility / MaxUtility (open_spiel/spiel.h:927-1255). */
+typedef struct {
+  int32_t game_kind;           /* 0 ttt, 1 connect_four, 2 hex, 3 kuhn, 4 leduc */
+  int32_t num_players;
+  int32_t num_distinct_actions;
+  int32_t max_chance_outcomes;
+  int32_t max_game_length;
+  int32_t max_chance_nodes;
+  int32_t obs_size;            /* ObservationTensorSize()                        */
+  int32_t info_size;           /* InformationStateTensorSize(), 0 if absent      */
+  int32_t obs_shape[4];        /* rank in obs_rank                               */
+  int32_t obs_rank;
+  int32_t info_shape[4];
+  int32_t info_rank;
+  int32_t mask_words;          /* u32 words per legal mask = ceil(max(A,C)/32)   */
+  int32_t compact_mask_bytes;  /* bytes per state of the fused step's mask: 1,2,4*mask_words */
+  int32_t state_words;         /* SoA planes per state                           */
+  int32_t state_word_bytes;    /* 4 or 8: bytes per plane element                */
+  double min_utility;
+  double max_utility;
+  char canonical[128];         /* Game::ToString(): the string as parsed         */
+} osg_game_desc;
+
+const char* osg_last_error(void);
+
+/* ---- context ------------------------------------------------------------ */
+/* stream == NULL: the library creates its own non-blocking stream.  Otherwise
+ * `stream` is a hipStream_t owned by the caller (e.g. torch's current stream). */
+int osg_ctx_create(int device, void* stream, osg_ctx** out);
+int osg_ctx_destroy(osg_ctx* ctx);
+int osg_ctx_synchronize(osg_ctx* ctx);
+void* osg_ctx_stream(osg_ctx* ctx);
+
+/* ---- game description (no device needed) -------------------------------- */
+/* Replaces LoadGame(game_string) (open_spiel/spiel.cc:255) for the five hot-path
+ * games; unknown parameters / wrong types are OSG_ERR_INVALID as in
+ * spiel.cc:65-90, games or sizes without a device layout OSG_ERR_UNSUPPORTED. */
+int osg_game_describe(const char* game_string, osg_game_desc* out);
+
+/* ---- batches of states --------------------------------------------------- */
+/* Replaces Game::NewInitialState() x n (spiel.h:943-950). */
+int osg_batch_create(osg_ctx* ctx, const char* game_string, int64_t n, osg_batch** out);
+int osg_batch_destroy(osg_batch* b);
+int64_t osg_batch_size(const osg_batch* b);
+int osg_batch_describe(const osg_batch* b, osg_game_desc* out);
+int osg_batch_reset(osg_batch* b);                              /* all -> initial state  */
+/* State::Clone() for a whole batch (spiel.h:737). Same game and size. */
+int osg_batch_copy(osg_batch* dst, const osg_batch* src);
+/* dst[i] = src[index[i]] (dst size = number of indices): Clone() of chosen states. */
+int osg_batch_gather(osg_batch* dst, const osg_batch* src, const int64_t* index, int on_host);
+/* Raw SoA image: state_words planes of n elements each (plane-major). */
+int osg_batch_download(const osg_batch* b, void* h_words);
+int osg_batch_upload(osg_batch* b, const void* h_words);
+/* Device pointer to the SoA planes (plane k at base + k * n elements). */
+void* osg_batch_device_ptr(osg_batch* b);
+
+/* State::LegalActionsMask() (spiel.cc:518-524), bit-packed: mask[i*W + a/32] bit a%32;
+ * at chance nodes the bits are the legal chance outcomes; all zero when terminal. */
+int osg_legal_mask(const osg_batch* b, uint32_t* mask, int on_host);
+
+/* State::ApplyAction (spiel.cc:441-451 + each game's DoApplyAction), in place.
+ * actions[i] == -1 leaves state i untouched.  Illegal actions (not in
+ * LegalActions(), or any action on a terminal state) leave the state untouched
+ * and are counted; the count is returned through *illegal (may be NULL; then a
+ * non-zero count turns into OSG_ERR_ILLEGAL at the next synchronising call). */
+int osg_apply(osg_batch* b, const int32_t* actions, int on_host, int64_t* h_illegal);
+
+/* IsTerminal / CurrentPlayer / Returns (per game; e.g. connect_four.cc:122-128,
+ * 277-285).  Any pointer may be NULL.  returns is [n, num_players] fp64. */
+int osg_status_query(const osg_batch* b, int8_t* cur_player, uint8_t* terminal,
+                     double* returns, int on_host);
+
+/* State::ChanceOutcomes() probabilities for every outcome id: probs[n, max_chance]
+ * fp64, 0 for outcomes that are not legal (or at non-chance nodes). */
+int osg_chance_probs(const osg_batch* b, double* probs, int on_host);
+
+/* The fused headline kernel: LegalActions check + ApplyAction + IsTerminal /
+ * CurrentPlayer / outcome + LegalActions of the successor, one pass over the
+ * SoA state.  Device pointers only; src may equal dst.
+ *   d_actions [n] u8   action id (0xFF = skip)
+ *   d_mask    [n * compact_mask_bytes] legal mask of the successor state
+ *   d_status  [n] u8   bit7 terminal | bit6 action was illegal |
+ *                      bits3-5 current player + 1 (0 = chance) when not terminal |
+ *                      bits0-2 outcome when terminal (board games: 0 p0 wins,
+ *                      1 p1 wins, 2 draw; poker: 7 = see osg_status_query) */
+int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions,
+             void* d_mask, uint8_t* d_status);
+
+/* State::ObservationTensor(player) / InformationStateTensor(player)
+ * (spiel.cc:908-945 + each game; observer.h:174-185 zero-fill semantics).
+ * which: 0 observation, 1 information state.  player in [0, P), or -1 = the
+ * state's current player (player 0 where that is chance/terminal).
+ * out is [n, size] fp32. */
+int osg_observation(const osg_batch* b, int player, int which, float* out, int on_host);
+
+/* Environment loop on device: `steps` times { sample a uniformly random legal
+ * action (chance outcomes by their distribution), apply, auto-reset terminal
+ * states to the initial state }.  d_counters[0] += env steps applied,
+ * d_counters[1] += episodes finished.  RNG stream = (seed, global index). */
+int osg_random_steps(osg_batch* b, uint64_t seed, int64_t index_offset, int steps,
+                     unsigned long long* d_counters);
+
+/* algorithms::RandomRolloutEvaluator::Evaluate (open_spiel/algorithms/mcts.cc:43-72)
+ * for every root: n_rollouts uniform-random playouts to the end of the game.
+ * sum_returns [n, P] fp64 = SUM over rollouts of Returns() (divide by n_rollouts
+ * for Evaluate's mean); steps[n] i32 (may be NULL) = plies played.  Rollout r of
+ * root i draws from the counter stream (seed, index_offset + i, r). */
+int osg_rollout(const osg_batch* roots, uint64_t seed, int64_t index_offset, int n_rollouts,
+                double* sum_returns, int32_t* steps, int on_host);
+
+/* algorithms::MCTSBot (open_spiel/algorithms/mcts.{h,cc}) for every root of the
+ * batch, one wavefront per root.  Fields as MCTSBot's constructor (mcts.h:161-169). */
+typedef struct {
+  double uct_c;
+  int32_t max_simulations;
+  int32_t n_rollouts;       /* RandomRolloutEvaluator(n_rollouts, seed)            */
+  int32_t solve;            /* MCTS-Solver backup (mcts.cc:398-434)                */
+  int32_t max_nodes;        /* node pool per root (children are allocated lazily;
+                               when exhausted, leaves are evaluated without expansion) */
+  uint64_t seed;
+  int64_t index_offset;     /* global index of root 0 (multi-GPU sharding)         */
+} osg_mcts_cfg;
+/* Outputs (host or device by on_host; any may be NULL):
+ *   best_action [n] i32            SearchNode::BestChild().action (mcts.cc:127-143)
+ *   child_visits [n, A] i32        explore_count of the root child for action a
+ *   child_reward [n, A] f64        total_reward of that child
+ *   child_outcome [n, A] i8        proven outcome for the root player (-1,0,1) or 2 = unproven,
+ *                                  3 = no such child
+ *   root_stats [n, 4] f64          root explore_count, nodes used, root outcome for
+ *                                  the root player (NaN if unproven), simulations run */
+int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg, int32_t* best_action,
+                    int32_t* child_visits, double* child_reward, int8_t* child_outcome,
+                    double* root_stats, int on_host);
+
+/* ---- tabular CFR family -------------------------------------------------- */
+typedef struct {
+  int32_t alternating_updates;   /* CFRSolverBase ctor (cfr.h:190-196)            */
+  int32_t linear_averaging;
+  int32_t regret_matching_plus;
+} osg_cfr_cfg;
+/* Replaces CFRSolverBase::CFRSolverBase + InitializeInfostateNodes
+ * (cfr.cc:191-261): expands the whole game tree level by level ON THE DEVICE
+ * (legal-mask / apply / status kernels), numbers infostates, uploads the
+ * level-ordered arrays and zero-initialised [I, Amax] fp64 tables. */
+int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg, osg_cfr** out);
+int osg_cfr_destroy(osg_cfr* s);
+/* out[0..5] = histories, chance nodes, decision nodes, terminal nodes, infostates, Amax */
+int osg_cfr_sizes(const osg_cfr* s, int64_t* out);
+/* CFRSolverBase::EvaluateAndUpdatePolicy x iters (cfr.cc:263-282). */
+int osg_cfr_iterate(osg_cfr* s, int iters);
+/* ExternalSamplingMCCFRSolver::RunIteration (external_sampling_mccfr.cc:71-186,
+ * AverageType::kSimple) for `trajectories` traverser passes (player = global
+ * trajectory index mod P), mini-batched: every trajectory of one call reads the
+ * tables as they were at the start of the call and adds its deltas atomically.
+ * Tables start at kInitialTableValues = 1e-6 (external_sampling_mccfr.h:59). */
+int osg_mccfr_iterate(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_t trajectories);
+/* Device pointers to the [I, Amax] fp64 tables: regrets, cumulative policy,
+ * current policy (for RCCL all-reduce by the caller, or inspection). */
+int osg_cfr_table_ptrs(osg_cfr* s, double** d_regrets, double** d_cum_policy, double** d_cur_policy);
+/* MCCFR mini-batch protocol for multi-GPU: deltas accumulate into separate
+ * [I, Amax] buffers; the caller all-reduces them (RCCL) and then folds them in. */
+int osg_mccfr_delta_ptrs(osg_cfr* s, double** d_regret_delta, double** d_policy_delta);
+int osg_mccfr_apply_deltas(osg_cfr* s);
+/* CFRInfoStateValuesTable rows (cfr.h:42-104) to the host: arrays [I, Amax] (padding 0),
+ * nact[I], legal[I, Amax] (padding -1), avg_policy per cfr.cc:104-125. Any may be NULL. */
+int osg_cfr_tables(const osg_cfr* s, int32_t* nact, int32_t* legal, double* regrets,
+                   double* cum_policy, double* cur_policy, double* avg_policy);
+/* InformationStateString() of infostate i (kuhn_poker.cc:109-166, leduc_poker.cc:198-239).
+ * Returns the length (excluding NUL), or <0. */
+int osg_cfr_infostate_key(const osg_cfr* s, int64_t i, char* buf, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSG_ABI_H_ */

@@ -1,0 +1,18 @@
+"""open_spiel_amd — MI355X-native batched game-step and search engine.
+
+A from-scratch HIP (gfx950) implementation of OpenSpiel's data-parallel hot
+path: batched LegalActions / ApplyAction / IsTerminal / Returns /
+ObservationTensor for tic_tac_toe, connect_four, hex, kuhn_poker and
+leduc_poker, random-rollout evaluation and MCTS over batches of roots, and
+tabular CFR / external-sampling MCCFR.  The C-ABI is include/osg_abi.h.
+"""
+from ._abi import OsgError, describe, lib  # noqa: F401
+
+
+def __getattr__(name):
+    # torch-backed classes are imported lazily so that `import open_spiel_amd`
+    # (and the ABI symbol check) works without touching torch.
+    if name in ("Context", "Game", "StateBatch", "TabularSolver"):
+        from . import engine
+        return getattr(engine, name)
+    raise AttributeError(name)

@@ -1,0 +1,135 @@
+"""ctypes loader for the C-ABI in include/osg_abi.h (libosg_hip.so).
+
+The shared library is the product: hand-written HIP for gfx950.  There is NO
+fallback — if the library is missing or no MI355X is visible, loading or
+context creation fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libosg_hip.so")
+
+
+class OsgError(RuntimeError):
+    """Raised for any non-zero osg_status (mirrors pyspiel.SpielError)."""
+
+
+class GameDesc(C.Structure):
+    _fields_ = [
+        ("game_kind", C.c_int32),
+        ("num_players", C.c_int32),
+        ("num_distinct_actions", C.c_int32),
+        ("max_chance_outcomes", C.c_int32),
+        ("max_game_length", C.c_int32),
+        ("max_chance_nodes", C.c_int32),
+        ("obs_size", C.c_int32),
+        ("info_size", C.c_int32),
+        ("obs_shape", C.c_int32 * 4),
+        ("obs_rank", C.c_int32),
+        ("info_shape", C.c_int32 * 4),
+        ("info_rank", C.c_int32),
+        ("mask_words", C.c_int32),
+        ("compact_mask_bytes", C.c_int32),
+        ("state_words", C.c_int32),
+        ("state_word_bytes", C.c_int32),
+        ("min_utility", C.c_double),
+        ("max_utility", C.c_double),
+        ("canonical", C.c_char * 128),
+    ]
+
+
+class MctsCfg(C.Structure):
+    _fields_ = [
+        ("uct_c", C.c_double),
+        ("max_simulations", C.c_int32),
+        ("n_rollouts", C.c_int32),
+        ("solve", C.c_int32),
+        ("max_nodes", C.c_int32),
+        ("seed", C.c_uint64),
+        ("index_offset", C.c_int64),
+    ]
+
+
+class CfrCfg(C.Structure):
+    _fields_ = [
+        ("alternating_updates", C.c_int32),
+        ("linear_averaging", C.c_int32),
+        ("regret_matching_plus", C.c_int32),
+    ]
+
+
+VP = C.c_void_p
+I64 = C.c_int64
+U64 = C.c_uint64
+INT = C.c_int
+
+# name -> (restype, argtypes).  Every symbol include/osg_abi.h declares.
+SIGNATURES = {
+    "osg_last_error": (C.c_char_p, []),
+    "osg_ctx_create": (INT, [INT, VP, C.POINTER(VP)]),
+    "osg_ctx_destroy": (INT, [VP]),
+    "osg_ctx_synchronize": (INT, [VP]),
+    "osg_ctx_stream": (VP, [VP]),
+    "osg_game_describe": (INT, [C.c_char_p, C.POINTER(GameDesc)]),
+    "osg_batch_create": (INT, [VP, C.c_char_p, I64, C.POINTER(VP)]),
+    "osg_batch_destroy": (INT, [VP]),
+    "osg_batch_size": (I64, [VP]),
+    "osg_batch_describe": (INT, [VP, C.POINTER(GameDesc)]),
+    "osg_batch_reset": (INT, [VP]),
+    "osg_batch_copy": (INT, [VP, VP]),
+    "osg_batch_gather": (INT, [VP, VP, VP, INT]),
+    "osg_batch_download": (INT, [VP, VP]),
+    "osg_batch_upload": (INT, [VP, VP]),
+    "osg_batch_device_ptr": (VP, [VP]),
+    "osg_legal_mask": (INT, [VP, VP, INT]),
+    "osg_apply": (INT, [VP, VP, INT, C.POINTER(I64)]),
+    "osg_status_query": (INT, [VP, VP, VP, VP, INT]),
+    "osg_chance_probs": (INT, [VP, VP, INT]),
+    "osg_step": (INT, [VP, VP, VP, VP, VP]),
+    "osg_observation": (INT, [VP, INT, INT, VP, INT]),
+    "osg_random_steps": (INT, [VP, U64, I64, INT, VP]),
+    "osg_rollout": (INT, [VP, U64, I64, INT, VP, VP, INT]),
+    "osg_mcts_search": (INT, [VP, C.POINTER(MctsCfg), VP, VP, VP, VP, VP, INT]),
+    "osg_cfr_create": (INT, [VP, C.c_char_p, C.POINTER(CfrCfg), C.POINTER(VP)]),
+    "osg_cfr_destroy": (INT, [VP]),
+    "osg_cfr_sizes": (INT, [VP, C.POINTER(I64)]),
+    "osg_cfr_iterate": (INT, [VP, INT]),
+    "osg_mccfr_iterate": (INT, [VP, U64, I64, I64]),
+    "osg_cfr_table_ptrs": (INT, [VP, C.POINTER(VP), C.POINTER(VP), C.POINTER(VP)]),
+    "osg_mccfr_delta_ptrs": (INT, [VP, C.POINTER(VP), C.POINTER(VP)]),
+    "osg_mccfr_apply_deltas": (INT, [VP]),
+    "osg_cfr_tables": (INT, [VP, VP, VP, VP, VP, VP, VP]),
+    "osg_cfr_infostate_key": (INT, [VP, I64, C.c_char_p, INT]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libosg_hip.so (once).  Fails loudly when the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OsgError(
+                f"{LIB_PATH} is missing: the MI355X engine is hand-written HIP and has no "
+                "CPU fallback.  Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C open_spiel_amd/csrc`.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise OsgError(f"osg error {rc}: {lib().osg_last_error().decode()}")
+
+
+def describe(game_string):
+    d = GameDesc()
+    check(lib().osg_game_describe(game_string.encode(), C.byref(d)))
+    return d

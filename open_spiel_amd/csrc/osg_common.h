@@ -1,0 +1,94 @@
+// Shared device/host helpers: counter RNG, bit tricks, the fixed-width legal
+// mask.  gfx950 only.
+#ifndef OSG_COMMON_H_
+#define OSG_COMMON_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define OSG_HD __host__ __device__ __forceinline__
+#define OSG_D __device__ __forceinline__
+
+namespace osg {
+
+constexpr int kChancePlayer = -1;
+constexpr int kTerminalPlayer = -4;
+constexpr int kMaxPlayers = 10;     // kuhn_poker supports up to 10
+constexpr int kMaskWords = 4;       // 128 actions (hex 11x11 = 121)
+
+// ---------------------------------------------------------------------------
+// Counter-based RNG.  splitmix64 over a key mixed from (seed, stream, sub); the
+// CPU oracle (oracle/spiel_oracle_core.cpp CounterRng) restates exactly this so
+// device rollouts / searches / trajectories can be replayed bit for bit.
+// ---------------------------------------------------------------------------
+OSG_HD uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+struct Rng {
+  uint64_t s;
+  OSG_HD Rng(uint64_t seed, uint64_t stream, uint64_t sub) {
+    uint64_t a = mix64(seed + 0x9E3779B97F4A7C15ULL);
+    uint64_t b = mix64(a ^ (stream * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));
+    s = mix64(b ^ (sub * 0xA0761D6478BD642FULL + 0xE7037ED1A0B428DBULL));
+  }
+  OSG_HD uint64_t next() {
+    s += 0x9E3779B97F4A7C15ULL;
+    return mix64(s);
+  }
+  // floor(hi32 * n / 2^32): uniform in [0, n) up to 2^-32 bias.
+  OSG_HD uint32_t below(uint32_t n) {
+    uint64_t hi = next() >> 32;
+    return static_cast<uint32_t>((hi * n) >> 32);
+  }
+  OSG_HD double unit() { return static_cast<double>(next() >> 11) * (1.0 / 9007199254740992.0); }
+};
+
+// ---------------------------------------------------------------------------
+// Legal-action mask: up to 128 actions, bit a of word a/32.
+// ---------------------------------------------------------------------------
+struct Mask {
+  uint32_t w[kMaskWords];
+  OSG_HD Mask() : w{0, 0, 0, 0} {}
+  OSG_HD void set(int a) { w[a >> 5] |= 1u << (a & 31); }
+  OSG_HD bool test(int a) const { return (w[a >> 5] >> (a & 31)) & 1u; }
+  OSG_HD bool any() const { return (w[0] | w[1] | w[2] | w[3]) != 0; }
+  OSG_HD int count() const {
+    return __builtin_popcount(w[0]) + __builtin_popcount(w[1]) + __builtin_popcount(w[2]) +
+           __builtin_popcount(w[3]);
+  }
+};
+
+// Index of the k-th (0-based) set bit of a 32-bit word; k < popcount(x).
+OSG_HD int select32(uint32_t x, int k) {
+  int pos = 0;
+#pragma unroll
+  for (int width = 16; width >= 1; width >>= 1) {
+    uint32_t low = x & ((1u << width) - 1u);
+    int c = __builtin_popcount(low);
+    if (k >= c) {
+      k -= c;
+      x >>= width;
+      pos += width;
+    } else {
+      x = low;
+    }
+  }
+  return pos;
+}
+// k-th legal action of a mask (actions ascending, like LegalActions()[k]).
+OSG_HD int select_action(const Mask& m, int k) {
+  int base = 0;
+#pragma unroll
+  for (int i = 0; i < kMaskWords; ++i) {
+    int c = __builtin_popcount(m.w[i]);
+    if (k < c) return base + select32(m.w[i], k);
+    k -= c;
+    base += 32;
+  }
+  return -1;
+}
+
+}  // namespace osg
+#endif  // OSG_COMMON_H_

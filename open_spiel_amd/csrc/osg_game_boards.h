@@ -1,0 +1,412 @@
+// Device-side rules of the three perfect-information board games, on bitboards.
+// Each struct restates one reference State implementation for ONE state held in
+// registers; the kernels in osg_kernels.hip map them over SoA batches.
+//
+//   Ttt : open_spiel/games/tic_tac_toe/tic_tac_toe.{h,cc}
+//   C4  : open_spiel/games/connect_four/connect_four.{h,cc}
+//   Hex : open_spiel/games/hex/hex.{h,cc}
+#ifndef OSG_GAME_BOARDS_H_
+#define OSG_GAME_BOARDS_H_
+
+#include "osg_common.h"
+
+namespace osg {
+
+// ===========================================================================
+// tic_tac_toe.  HBM layout: ONE u32 per state, bits 0-8 = x stones (player 0,
+// kCross), bits 16-24 = o stones (player 1, kNought); cell = 3*row + col.
+// Player to move = parity of the stone count (player 0 starts,
+// tic_tac_toe.h:127); outcome is recomputed from the lines.
+// ===========================================================================
+struct Ttt {
+  using word_t = uint32_t;
+  struct Params {
+    int words;  // = 1
+  };
+  struct State {
+    uint32_t x, o;
+  };
+  OSG_D static State initial(const Params&) { return {0u, 0u}; }
+  OSG_D static State load(const Params&, const word_t* base, int64_t, int64_t i) {
+    uint32_t v = base[i];
+    return {v & 0x1FFu, (v >> 16) & 0x1FFu};
+  }
+  OSG_D static void store(const Params&, word_t* base, int64_t, int64_t i, const State& s) {
+    base[i] = s.x | (s.o << 16);
+  }
+  // BoardHasLine, tic_tac_toe.cc:109-120: the 8 lines as 9-bit masks.
+  OSG_D static bool line(uint32_t b) {
+    return ((b & 0x007) == 0x007) | ((b & 0x038) == 0x038) | ((b & 0x1C0) == 0x1C0) |
+           ((b & 0x049) == 0x049) | ((b & 0x092) == 0x092) | ((b & 0x124) == 0x124) |
+           ((b & 0x111) == 0x111) | ((b & 0x054) == 0x054);
+  }
+  OSG_D static int plies(const State& s) { return __builtin_popcount(s.x | s.o); }
+  OSG_D static bool terminal(const Params&, const State& s) {  // tic_tac_toe.cc:215-217
+    return line(s.x) | line(s.o) | (plies(s) == 9);
+  }
+  OSG_D static int current_player(const Params& p, const State& s) {  // tic_tac_toe.h:87-89
+    return terminal(p, s) ? kTerminalPlayer : (plies(s) & 1);
+  }
+  OSG_D static Mask legal(const Params& p, const State& s) {  // tic_tac_toe.cc:138-148
+    Mask m;
+    if (!terminal(p, s)) m.w[0] = ~(s.x | s.o) & 0x1FFu;
+    return m;
+  }
+  OSG_D static void apply(const Params&, State& s, int a) {  // tic_tac_toe.cc:128-136
+    if (plies(s) & 1) s.o |= 1u << a; else s.x |= 1u << a;
+  }
+  OSG_D static int outcome_code(const Params&, const State& s) {  // tic_tac_toe.cc:219-227
+    return line(s.x) ? 0 : (line(s.o) ? 1 : 2);
+  }
+  OSG_D static void returns(const Params& p, const State& s, double* out) {
+    int c = outcome_code(p, s);
+    out[0] = c == 0 ? 1.0 : (c == 1 ? -1.0 : 0.0);
+    out[1] = -out[0] + 0.0;  // +0.0: never produce -0.0 for draws / running games
+  }
+  OSG_D static double chance_prob(const Params&, const State&, int) { return 0.0; }
+  // ObservationTensor, tic_tac_toe.cc:241-251: plane = raw CellState enum value
+  // (0 empty, 1 o, 2 x), flat index plane*9 + cell.  Returns the value at `idx`.
+  OSG_D static float obs_at(const Params&, const State& s, int /*player*/, int /*which*/, int idx) {
+    int plane = idx / 9, cell = idx - plane * 9;
+    uint32_t bits = plane == 0 ? ~(s.x | s.o) : (plane == 1 ? s.o : s.x);
+    return static_cast<float>((bits >> cell) & 1u);
+  }
+};
+
+// ===========================================================================
+// connect_four (rows R, columns C, x_in_row K; (R+1)*C <= 64).  HBM layout: TWO
+// u64 planes per state: plane 0 = x stones (player 0), plane 1 = o stones.
+// Bit index = col*(R+1) + row, row 0 = bottom; the extra row per column is an
+// always-empty sentinel so shifted line tests never wrap between columns.
+// Player to move = parity of the stone count; outcome recomputed (a reachable
+// position has at most one player with a line, connect_four.cc:138-142).
+// ===========================================================================
+struct C4 {
+  using word_t = uint64_t;
+  struct Params {
+    int words;  // = 2
+    int rows, cols, k, ego;
+    uint64_t board;  // all playable cells
+    uint64_t top;    // top playable cell of every column
+  };
+  struct State {
+    uint64_t x, o;
+  };
+  OSG_D static State initial(const Params&) { return {0ull, 0ull}; }
+  OSG_D static State load(const Params&, const word_t* base, int64_t n, int64_t i) {
+    return {base[i], base[n + i]};
+  }
+  OSG_D static void store(const Params&, word_t* base, int64_t n, int64_t i, const State& s) {
+    base[i] = s.x;
+    base[n + i] = s.o;
+  }
+  // HasLine, connect_four.cc:163-201, as the classic shifted-AND test along the
+  // four directions: vertical (1), horizontal (H), the two diagonals (H-1, H+1).
+  OSG_D static bool line(const Params& p, uint64_t b) {
+    const int H = p.rows + 1;
+    const int dirs[4] = {1, H, H - 1, H + 1};
+    bool hit = false;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      uint64_t m = b;
+      if (p.k == 4) {
+        m = m & (m >> dirs[d]);
+        m = m & (m >> (2 * dirs[d]));
+      } else {
+        for (int i = 1; i < p.k; ++i) m &= b >> (i * dirs[d]);
+      }
+      hit |= (m != 0);
+    }
+    return hit;
+  }
+  OSG_D static int plies(const State& s) { return __builtin_popcountll(s.x | s.o); }
+  OSG_D static bool full(const Params& p, const State& s) {  // connect_four.cc:203-209
+    return ((s.x | s.o) & p.top) == p.top;
+  }
+  OSG_D static bool terminal(const Params& p, const State& s) {
+    return line(p, s.x) | line(p, s.o) | full(p, s);
+  }
+  OSG_D static int current_player(const Params& p, const State& s) {  // connect_four.cc:122-128
+    return terminal(p, s) ? kTerminalPlayer : (plies(s) & 1);
+  }
+  OSG_D static uint32_t open_columns(const Params& p, const State& s) {
+    const int H = p.rows + 1;
+    uint64_t free_top = ~(s.x | s.o) & p.top;
+    uint32_t m = 0;
+    for (int c = 0; c < p.cols; ++c) m |= static_cast<uint32_t>((free_top >> (c * H + p.rows - 1)) & 1ull) << c;
+    return m;
+  }
+  OSG_D static Mask legal(const Params& p, const State& s) {  // connect_four.cc:147-156
+    Mask m;
+    if (!terminal(p, s)) m.w[0] = open_columns(p, s);
+    return m;
+  }
+  OSG_D static void apply(const Params& p, State& s, int col) {  // connect_four.cc:130-145
+    const int H = p.rows + 1;
+    uint64_t all = s.x | s.o;
+    uint64_t colmask = ((1ull << p.rows) - 1ull) << (col * H);
+    uint64_t cell = (all + (1ull << (col * H))) & colmask;  // lowest empty cell
+    if (__builtin_popcountll(all) & 1) s.o |= cell; else s.x |= cell;
+  }
+  OSG_D static int outcome_code(const Params& p, const State& s) {  // connect_four.cc:281-285
+    return line(p, s.x) ? 0 : (line(p, s.o) ? 1 : 2);
+  }
+  OSG_D static void returns(const Params& p, const State& s, double* out) {
+    int c = outcome_code(p, s);
+    out[0] = c == 0 ? 1.0 : (c == 1 ? -1.0 : 0.0);
+    out[1] = -out[0] + 0.0;
+  }
+  OSG_D static double chance_prob(const Params&, const State&, int) { return 0.0; }
+  // ObservationTensor, connect_four.cc:312-328.  Shape [3, R, C]; default planes
+  // via StateToPlayer (:75-86): 0 = x, 1 = o, 2 = empty.  Egocentric planes via
+  // PlayerRelative (:299-310): nought -> (player==0 ? 0 : 1), cross -> (player==1 ? 0 : 1).
+  OSG_D static float obs_at(const Params& p, const State& s, int player, int /*which*/, int idx) {
+    const int RC = p.rows * p.cols;
+    int plane = idx / RC, rem = idx - plane * RC;
+    int r = rem / p.cols, c = rem - r * p.cols;
+    int bit = c * (p.rows + 1) + r;
+    uint64_t first = s.x, second = s.o;
+    if (p.ego) {  // plane 0 holds kNought iff player == 0, kCross iff player == 1
+      first = player == 0 ? s.o : s.x;
+      second = player == 0 ? s.x : s.o;
+    }
+    uint64_t bits = plane == 0 ? first : (plane == 1 ? second : ~(s.x | s.o));
+    return static_cast<float>((bits >> bit) & 1ull);
+  }
+};
+
+// ===========================================================================
+// hex (num_cols C, num_rows R, C*R <= 32*NW).  HBM layout: 4*NW + 1 u32 planes:
+//   [0,NW)    black stones      [NW,2NW)   white stones
+//   [2NW,3NW) edge-A connected  [3NW,4NW)  edge-B connected
+//   4NW       meta: bit0 player to move, bits1-2 result (1 black won, 2 white
+//             won), bits 8-15 plies (saturating), bits 16-23 first move
+// Cell = row*C + col.  The reference's 9 labels (hex.h:68-78) are
+//   black: plain 1, South(B) 2, North(A) 3, Win(A&B) 4   (A = first row)
+//   white: plain -1, East(B) -2, West(A) -3, Win -4       (A = first column)
+// i.e. label = +-(1 + 2*A + B), which is what the 9-plane tensor needs.
+// ===========================================================================
+template <int NW>
+struct HexT {
+  using word_t = uint32_t;
+  struct Bits {
+    uint32_t w[NW];
+  };
+  struct Params {
+    int words;  // = 4*NW + 1
+    int cols, rows, cells, swap, plain_obs;
+    Bits board, col_first, col_last, row_first, row_last;
+  };
+  struct State {
+    Bits black, white, ea, eb;
+    uint32_t meta;
+  };
+  // ---- multiword bit helpers (cell index grows with word index) ----
+  OSG_D static Bits zero() {
+    Bits b;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) b.w[i] = 0;
+    return b;
+  }
+  OSG_D static Bits band(const Bits& a, const Bits& b) {
+    Bits r;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r.w[i] = a.w[i] & b.w[i];
+    return r;
+  }
+  OSG_D static Bits bor(const Bits& a, const Bits& b) {
+    Bits r;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r.w[i] = a.w[i] | b.w[i];
+    return r;
+  }
+  OSG_D static Bits bandn(const Bits& a, const Bits& b) {  // a & ~b
+    Bits r;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r.w[i] = a.w[i] & ~b.w[i];
+    return r;
+  }
+  OSG_D static bool any(const Bits& a) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) v |= a.w[i];
+    return v != 0;
+  }
+  OSG_D static bool test(const Bits& a, int c) { return (a.w[c >> 5] >> (c & 31)) & 1u; }
+  OSG_D static Bits single(int c) {
+    Bits b = zero();
+#pragma unroll
+    for (int i = 0; i < NW; ++i) b.w[i] = (i == (c >> 5)) ? (1u << (c & 31)) : 0u;
+    return b;
+  }
+  // cells moved to HIGHER indices by s (0 < s < 32)
+  OSG_D static Bits shl(const Bits& a, int s) {
+    Bits r;
+#pragma unroll
+    for (int i = NW - 1; i >= 0; --i) {
+      uint32_t lo = (i > 0) ? (a.w[i - 1] >> (32 - s)) : 0u;
+      r.w[i] = (a.w[i] << s) | lo;
+    }
+    return r;
+  }
+  OSG_D static Bits shr(const Bits& a, int s) {
+    Bits r;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      uint32_t hi = (i + 1 < NW) ? (a.w[i + 1] << (32 - s)) : 0u;
+      r.w[i] = (a.w[i] >> s) | hi;
+    }
+    return r;
+  }
+  OSG_D static int popcount(const Bits& a) {
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) c += __builtin_popcount(a.w[i]);
+    return c;
+  }
+  // Union of the six neighbours of every cell in `s` (AdjacentCells,
+  // hex.cc:316-329: -C, -C+1, +1, +C, +C-1, -1 with the edge guards).
+  OSG_D static Bits neighbours(const Params& p, const Bits& s) {
+    const int C = p.cols;
+    Bits not_e = bandn(s, p.col_last), not_w = bandn(s, p.col_first);
+    Bits r = shr(s, C);                 // -C   (cells in the first row shift out)
+    r = bor(r, shl(s, C));              // +C
+    r = bor(r, shl(not_e, 1));          // +1
+    r = bor(r, shr(not_w, 1));          // -1
+    if (C > 1) {
+      r = bor(r, shr(not_e, C - 1));    // -C+1
+      r = bor(r, shl(not_w, C - 1));    // +C-1
+    }
+    return band(r, p.board);
+  }
+
+  OSG_D static State initial(const Params&) {
+    State s;
+    s.black = zero(); s.white = zero(); s.ea = zero(); s.eb = zero();
+    s.meta = 0;
+    return s;
+  }
+  OSG_D static State load(const Params&, const word_t* base, int64_t n, int64_t i) {
+    State s;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      s.black.w[k] = base[(0 * NW + k) * n + i];
+      s.white.w[k] = base[(1 * NW + k) * n + i];
+      s.ea.w[k] = base[(2 * NW + k) * n + i];
+      s.eb.w[k] = base[(3 * NW + k) * n + i];
+    }
+    s.meta = base[(4 * NW) * n + i];
+    return s;
+  }
+  OSG_D static void store(const Params&, word_t* base, int64_t n, int64_t i, const State& s) {
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      base[(0 * NW + k) * n + i] = s.black.w[k];
+      base[(1 * NW + k) * n + i] = s.white.w[k];
+      base[(2 * NW + k) * n + i] = s.ea.w[k];
+      base[(3 * NW + k) * n + i] = s.eb.w[k];
+    }
+    base[(4 * NW) * n + i] = s.meta;
+  }
+  OSG_D static int to_move(const State& s) { return s.meta & 1u; }
+  OSG_D static int result(const State& s) { return (s.meta >> 1) & 3u; }
+  OSG_D static int plies(const State& s) { return (s.meta >> 8) & 0xFFu; }
+  OSG_D static bool terminal(const Params&, const State& s) { return result(s) != 0; }  // hex.cc:361
+  OSG_D static int current_player(const Params& p, const State& s) {                     // hex.h:96-98
+    return terminal(p, s) ? kTerminalPlayer : to_move(s);
+  }
+  OSG_D static Mask legal(const Params& p, const State& s) {  // hex.cc:280-293
+    Mask m;
+    if (terminal(p, s)) return m;
+    Bits empty = bandn(p.board, bor(s.black, s.white));
+#pragma unroll
+    for (int i = 0; i < NW; ++i) m.w[i] = empty.w[i];
+    if (p.swap && plies(s) == 1 && to_move(s) == 1) m.set(p.cells);
+    return m;
+  }
+  // PlayerAndActionToState (hex.cc:108-171) + DoApplyAction (hex.cc:229-278).
+  OSG_D static void place(const Params& p, State& s, int player, int move, bool& a, bool& b) {
+    Bits cell = single(move);
+    a = false; b = false;
+    if (player == 0) {  // black: first row -> North(A), ELSE IF last row -> South(B)
+      if (test(p.row_first, move)) a = true; else if (test(p.row_last, move)) b = true;
+    } else {            // white: first column -> West(A), ELSE IF last column -> East(B)
+      if (test(p.col_first, move)) a = true; else if (test(p.col_last, move)) b = true;
+    }
+    const Bits& own = player == 0 ? s.black : s.white;
+    Bits nb = band(neighbours(p, cell), own);
+    // a neighbour labelled exactly A (not Win) / exactly B
+    a |= any(bandn(band(nb, s.ea), s.eb));
+    b |= any(bandn(band(nb, s.eb), s.ea));
+    if (player == 0) s.black = bor(s.black, cell); else s.white = bor(s.white, cell);
+    if (a) s.ea = bor(s.ea, cell);
+    if (b) s.eb = bor(s.eb, cell);
+  }
+  OSG_D static void apply(const Params& p, State& s, int move) {
+    uint32_t ply = plies(s);
+    uint32_t ply_next = ply < 255u ? ply + 1u : 255u;
+    if (p.swap && move == p.cells) {  // hex.cc:230-244
+      int first = (s.meta >> 16) & 0xFFu;
+      s.black = zero(); s.ea = zero(); s.eb = zero();  // only the first stone was on the board
+      int r = first / p.cols, c = first - r * p.cols;
+      int mirrored = c * p.cols + r;
+      bool a, b;
+      place(p, s, 1, mirrored, a, b);
+      s.meta = (s.meta & 0x00FF0000u) | (ply_next << 8) | 0u;  // black to move
+      return;
+    }
+    int player = to_move(s);
+    bool a, b;
+    place(p, s, player, move, a, b);
+    uint32_t res = 0;
+    if (a && b) {
+      res = player == 0 ? 1u : 2u;  // Win label; no flood fill (hex.cc:248-252)
+    } else if (a || b) {
+      // flood the plain same-colour group reachable from the new stone
+      const Bits own = player == 0 ? s.black : s.white;
+      Bits plain = bandn(bandn(own, s.ea), s.eb);
+      Bits region = zero();
+      Bits frontier = single(move);
+      for (int it = 0; it < 128; ++it) {
+        Bits grow = bandn(band(neighbours(p, frontier), plain), region);
+        if (!any(grow)) break;
+        region = bor(region, grow);
+        frontier = grow;
+      }
+      if (a) s.ea = bor(s.ea, region); else s.eb = bor(s.eb, region);
+    }
+    uint32_t first = ply == 0 ? static_cast<uint32_t>(move) : ((s.meta >> 16) & 0xFFu);
+    s.meta = static_cast<uint32_t>(1 - player) | (res << 1) | (ply_next << 8) | (first << 16);
+  }
+  OSG_D static int outcome_code(const Params&, const State& s) { return result(s) == 1 ? 0 : (result(s) == 2 ? 1 : 2); }
+  OSG_D static void returns(const Params&, const State& s, double* out) {  // hex.cc:363-365
+    double r = result(s) == 1 ? 1.0 : (result(s) == 2 ? -1.0 : 0.0);
+    out[0] = r;
+    out[1] = -r + 0.0;  // the reference yields -0.0 for a running game; compared as integers
+  }
+  OSG_D static double chance_prob(const Params&, const State&, int) { return 0.0; }
+  OSG_D static int label(const State& s, int cell) {
+    int mag = 1 + 2 * static_cast<int>(test(s.ea, cell)) + static_cast<int>(test(s.eb, cell));
+    return test(s.black, cell) ? mag : (test(s.white, cell) ? -mag : 0);
+  }
+  // ObservationTensor, hex.cc:379-398.
+  OSG_D static float obs_at(const Params& p, const State& s, int /*player*/, int /*which*/, int idx) {
+    if (p.plain_obs) {  // view {3, num_cols, num_rows}[plane, cell / C, cell % C]
+      int per = p.cols * p.rows;
+      int plane = idx / per, rem = idx - plane * per;
+      int i0 = rem / p.rows, i1 = rem - i0 * p.rows;
+      // inverse of (cell / C, cell % C) -> i0 * rows + i1
+      if (i1 >= p.cols || i0 * p.cols + i1 >= p.cells) return 0.0f;
+      int cell = i0 * p.cols + i1;
+      if (cell / p.cols != i0) return 0.0f;
+      int l = label(s, cell);
+      int pl = l == 0 ? 2 : (l < 0 ? 1 : 0);  // CellStateToPlainPlane, hex.cc:76-93
+      return pl == plane ? 1.0f : 0.0f;
+    }
+    int plane = idx / p.cells, cell = idx - plane * p.cells;
+    return (label(s, cell) + 4) == plane ? 1.0f : 0.0f;
+  }
+};
+
+}  // namespace osg
+#endif  // OSG_GAME_BOARDS_H_

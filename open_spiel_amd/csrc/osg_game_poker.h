@@ -1,0 +1,386 @@
+// Device-side rules of the two imperfect-information poker games.
+//
+//   Kuhn  : open_spiel/games/kuhn_poker/kuhn_poker.{h,cc}
+//   Leduc : open_spiel/games/leduc_poker/leduc_poker.{h,cc}
+#ifndef OSG_GAME_POKER_H_
+#define OSG_GAME_POKER_H_
+
+#include "osg_common.h"
+
+namespace osg {
+
+// ===========================================================================
+// kuhn_poker (P players, 2 <= P <= 10).  The reference notes that "the move
+// history and number of players are sufficient information to specify the
+// state" (kuhn_poker.h:83-85) — so the HBM record IS the history, ONE u64:
+//   bits 0-4    history length (deals + bets)
+//   bits 5-44   card dealt to player p at 5 + 4p (4 bits each)
+//   bits 45-63  bet flag of betting action j (0 = pass, 1 = bet), j < 2P-1
+// Everything else (first bettor, pot, winner) is recomputed in registers.
+// ===========================================================================
+struct Kuhn {
+  using word_t = uint64_t;
+  struct Params {
+    int words;  // = 1
+    int players;
+  };
+  struct State {
+    uint64_t h;
+  };
+  OSG_D static State initial(const Params&) { return {0ull}; }
+  OSG_D static State load(const Params&, const word_t* base, int64_t, int64_t i) { return {base[i]}; }
+  OSG_D static void store(const Params&, word_t* base, int64_t, int64_t i, const State& s) { base[i] = s.h; }
+  OSG_D static int len(const State& s) { return static_cast<int>(s.h & 31ull); }
+  OSG_D static int card(const State& s, int p) { return static_cast<int>((s.h >> (5 + 4 * p)) & 15ull); }
+  OSG_D static uint32_t bets(const State& s) { return static_cast<uint32_t>(s.h >> 45); }
+  OSG_D static int nact(const Params& p, const State& s) { int l = len(s); return l > p.players ? l - p.players : 0; }
+  // first_bettor_ (kuhn_poker.cc:195-199): the player of the first bet, or -1.
+  OSG_D static int first_bettor(const State& s) {
+    uint32_t b = bets(s);
+    return b ? __builtin_ctz(b) : -1;  // the first bet happens within the first P actions
+  }
+  OSG_D static bool terminal(const Params& p, const State& s) {  // kuhn_poker.cc:206-227
+    int n = nact(p, s), fb = first_bettor(s);
+    return fb < 0 ? (n == p.players) : (n == p.players + fb);
+  }
+  OSG_D static int current_player(const Params& p, const State& s) {  // kuhn_poker.cc:181-188
+    if (terminal(p, s)) return kTerminalPlayer;
+    int l = len(s);
+    return l < p.players ? kChancePlayer : l % p.players;
+  }
+  OSG_D static uint32_t dealt_mask(const Params& p, const State& s) {
+    uint32_t m = 0;
+    int l = len(s);
+    for (int q = 0; q < p.players; ++q)
+      if (q < l) m |= 1u << card(s, q);
+    return m;
+  }
+  OSG_D static Mask legal(const Params& p, const State& s) {  // kuhn_poker.cc:231-242
+    Mask m;
+    if (terminal(p, s)) return m;
+    if (len(s) < p.players) m.w[0] = ~dealt_mask(p, s) & ((1u << (p.players + 1)) - 1u);
+    else m.w[0] = 3u;
+    return m;
+  }
+  OSG_D static double chance_prob(const Params& p, const State& s, int) {  // kuhn_poker.cc:329-337
+    return 1.0 / (p.players + 1 - len(s));
+  }
+  OSG_D static void apply(const Params& p, State& s, int a) {  // kuhn_poker.cc:190-229
+    int l = len(s);
+    if (l < p.players) s.h |= static_cast<uint64_t>(a) << (5 + 4 * l);
+    else s.h |= static_cast<uint64_t>(a & 1) << (45 + (l - p.players));
+    s.h = (s.h & ~31ull) | static_cast<uint64_t>(l + 1);
+  }
+  OSG_D static bool did_bet(const Params& p, const State& s, int q) {  // DidBet, kuhn_poker.cc:339-349
+    int fb = first_bettor(s);
+    uint32_t b = bets(s);
+    if (fb < 0) return false;
+    if (q == fb) return true;
+    if (q > fb) return (b >> q) & 1u;
+    return (b >> (p.players + q)) & 1u;
+  }
+  OSG_D static int winner(const Params& p, const State& s) {
+    int fb = first_bettor(s);
+    int best_card = -1, best = -1;
+    for (int q = 0; q < p.players; ++q) {
+      if (fb >= 0 && !did_bet(p, s, q)) continue;  // only bettors contest a bet pot
+      int c = card(s, q);
+      if (c > best_card) { best_card = c; best = q; }
+    }
+    return best;
+  }
+  OSG_D static int outcome_code(const Params&, const State&) { return 7; }
+  OSG_D static void returns(const Params& p, const State& s, double* out) {  // kuhn_poker.cc:272-283
+    if (!terminal(p, s)) {
+      for (int q = 0; q < p.players; ++q) out[q] = 0.0;
+      return;
+    }
+    int pot = p.players + __builtin_popcount(bets(s));
+    int w = winner(p, s);
+    for (int q = 0; q < p.players; ++q) {
+      int paid = did_bet(p, s, q) ? 2 : 1;
+      out[q] = (q == w) ? static_cast<double>(pot - paid) : static_cast<double>(-paid);
+    }
+  }
+  // ante_[q] (kuhn_poker.cc:196-199): 1 + one chip per bet made so far by q.
+  OSG_D static int contribution(const Params& p, const State& s, int q) {
+    uint32_t b = bets(s);
+    int c = 1;
+    for (int j = q; j < 2 * p.players - 1; j += p.players) c += (b >> j) & 1u;
+    return c;
+  }
+  // KuhnObserver::WriteTensor, kuhn_poker.cc:72-107.
+  //   which 1 (information state): player[P] | private_card[P+1] | betting[2P-1, 2]
+  //   which 0 (observation)      : player[P] | private_card[P+1] | pot_contribution[P]
+  OSG_D static float obs_at(const Params& p, const State& s, int player, int which, int idx) {
+    const int P = p.players;
+    int l = len(s);
+    if (idx < P) return idx == player ? 1.0f : 0.0f;
+    idx -= P;
+    if (idx < P + 1) return (l > player && card(s, player) == idx) ? 1.0f : 0.0f;
+    idx -= P + 1;
+    if (which == 1) {
+      int j = idx >> 1, bit = idx & 1;
+      if (j >= nact(p, s)) return 0.0f;
+      return static_cast<int>((bets(s) >> j) & 1u) == bit ? 1.0f : 0.0f;
+    }
+    return static_cast<float>(contribution(p, s, idx));
+  }
+};
+
+// ===========================================================================
+// leduc_poker (2 or 3 players on the device; action_mapping / suit_isomorphism /
+// starting_player supported).  The reference keeps ~20 small integers per state
+// (leduc_poker.h:173-211); they are packed into TWO u64 planes:
+//   word0: cur_player+1 (3b) | calls (2) | raises (2) | round-1 (1) | stakes (4) |
+//          pot (6) | public+1 (4) | deck mask (8) | dealt (2) | remaining (2) |
+//          folded mask (3) | winner mask (3) | num_winners (2) | ante[3] (4 each) |
+//          private+1 [3] (4 each)                                      = 66 -> see below
+//   word1: seq1 len (3) + 7 x 2b | seq2 len (3) + 7 x 2b               = 34 bits
+// (private cards live in word1's upper bits to keep word0 at 54 bits.)
+// money_[p] is always 100 - ante_[p] (+ pot share at the end), so it is not stored.
+// ===========================================================================
+struct Leduc {
+  using word_t = uint64_t;
+  struct Params {
+    int words;  // = 2
+    int players, cards, mapping, iso, starter;
+  };
+  struct State {
+    int cur;          // -1 chance, else player
+    int calls, raises, round, stakes, pot, pub, dealt, remaining, nwin;
+    uint32_t deck;    // bit c set = card c still in the deck
+    uint32_t folded, winners;
+    int ante[3];
+    int priv[3];      // -1 = none
+    uint32_t seq[2];  // 2 bits per move
+    int seqlen[2];
+  };
+  static constexpr int kNone = -1;
+
+  OSG_D static State initial(const Params& p) {  // leduc_poker.cc:241-286
+    State s;
+    s.cur = kChancePlayer; s.calls = 0; s.raises = 0; s.round = 1; s.stakes = 1;
+    s.pot = p.players; s.pub = kNone; s.dealt = 0; s.remaining = p.players; s.nwin = 0;
+    s.deck = (1u << p.cards) - 1u; s.folded = 0; s.winners = 0;
+    for (int q = 0; q < 3; ++q) { s.ante[q] = 1; s.priv[q] = kNone; }
+    s.seq[0] = s.seq[1] = 0; s.seqlen[0] = s.seqlen[1] = 0;
+    return s;
+  }
+  OSG_D static State unpack(uint64_t a, uint64_t b) {
+    State s;
+    s.cur = static_cast<int>(a & 7ull) - 1;            a >>= 3;
+    s.calls = static_cast<int>(a & 3ull);               a >>= 2;
+    s.raises = static_cast<int>(a & 3ull);              a >>= 2;
+    s.round = static_cast<int>(a & 1ull) + 1;           a >>= 1;
+    s.stakes = static_cast<int>(a & 15ull);             a >>= 4;
+    s.pot = static_cast<int>(a & 63ull);                a >>= 6;
+    s.pub = static_cast<int>(a & 15ull) - 1;            a >>= 4;
+    s.deck = static_cast<uint32_t>(a & 255ull);         a >>= 8;
+    s.dealt = static_cast<int>(a & 3ull);               a >>= 2;
+    s.remaining = static_cast<int>(a & 3ull);           a >>= 2;
+    s.folded = static_cast<uint32_t>(a & 7ull);         a >>= 3;
+    s.winners = static_cast<uint32_t>(a & 7ull);        a >>= 3;
+    s.nwin = static_cast<int>(a & 3ull);                a >>= 2;
+    for (int q = 0; q < 3; ++q) { s.ante[q] = static_cast<int>(a & 15ull); a >>= 4; }
+    for (int r = 0; r < 2; ++r) {
+      s.seqlen[r] = static_cast<int>(b & 7ull);         b >>= 3;
+      s.seq[r] = static_cast<uint32_t>(b & 0x3FFFull);  b >>= 14;
+    }
+    for (int q = 0; q < 3; ++q) { s.priv[q] = static_cast<int>(b & 15ull) - 1; b >>= 4; }
+    return s;
+  }
+  OSG_D static void pack(const State& s, uint64_t& a, uint64_t& b) {
+    a = 0; b = 0;
+    int sh = 0;
+    auto put = [&](uint64_t& w, uint64_t v, int bits) { w |= v << sh; sh += bits; };
+    put(a, static_cast<uint64_t>(s.cur + 1), 3);
+    put(a, s.calls, 2); put(a, s.raises, 2); put(a, s.round - 1, 1); put(a, s.stakes, 4);
+    put(a, s.pot, 6); put(a, static_cast<uint64_t>(s.pub + 1), 4); put(a, s.deck, 8);
+    put(a, s.dealt, 2); put(a, s.remaining, 2); put(a, s.folded, 3); put(a, s.winners, 3);
+    put(a, s.nwin, 2);
+    for (int q = 0; q < 3; ++q) put(a, s.ante[q], 4);
+    sh = 0;
+    for (int r = 0; r < 2; ++r) { put(b, s.seqlen[r], 3); put(b, s.seq[r], 14); }
+    for (int q = 0; q < 3; ++q) put(b, static_cast<uint64_t>(s.priv[q] + 1), 4);
+  }
+  OSG_D static State load(const Params&, const word_t* base, int64_t n, int64_t i) {
+    return unpack(base[i], base[n + i]);
+  }
+  OSG_D static void store(const Params&, word_t* base, int64_t n, int64_t i, const State& s) {
+    uint64_t a, b;
+    pack(s, a, b);
+    base[i] = a;
+    base[n + i] = b;
+  }
+  OSG_D static bool round_over(const State& s) {  // ReadyForNextRound, leduc_poker.cc:680-683
+    return (s.raises == 0 && s.calls == s.remaining) || (s.raises > 0 && s.calls == s.remaining - 1);
+  }
+  OSG_D static bool terminal(const Params&, const State& s) {  // leduc_poker.cc:498-500
+    return s.remaining == 1 || (s.round == 2 && round_over(s));
+  }
+  OSG_D static int current_player(const Params& p, const State& s) {  // leduc_poker.cc:288-294
+    return terminal(p, s) ? kTerminalPlayer : s.cur;
+  }
+  OSG_D static int deck_size(const State& s) { return __builtin_popcount(s.deck); }
+  OSG_D static Mask legal(const Params& p, const State& s) {  // leduc_poker.cc:416-457
+    Mask m;
+    if (terminal(p, s)) return m;
+    if (s.cur == kChancePlayer) {
+      if (p.iso) {
+        for (int c = 0; c < p.cards / 2; ++c)
+          if ((s.deck >> (2 * c)) & 3u) m.w[0] |= 1u << c;
+      } else {
+        m.w[0] = s.deck;
+      }
+      return m;
+    }
+    if (p.mapping) { m.w[0] = 7u; return m; }
+    if (s.stakes > s.ante[s.cur]) m.w[0] |= 1u;  // fold only under pressure
+    m.w[0] |= 2u;                                 // call / check
+    if (s.raises < 2) m.w[0] |= 4u;               // raise
+    return m;
+  }
+  OSG_D static double chance_prob(const Params& p, const State& s, int outcome) {  // leduc_poker.cc:546-571
+    double pr = 1.0 / deck_size(s);
+    if (p.iso && ((s.deck >> (2 * outcome)) & 3u) == 3u) return pr * 2;
+    return pr;
+  }
+  OSG_D static int take_card(const Params& p, State& s, int move) {
+    if (p.iso) {
+      if ((s.deck >> (2 * move)) & 1u) s.deck &= ~(1u << (2 * move));
+      else s.deck &= ~(1u << (2 * move + 1));
+      return move;
+    }
+    s.deck &= ~(1u << move);
+    return move;  // deck_[move] == move while present
+  }
+  OSG_D static int next_actor(const Params& p, const State& s) {  // NextPlayer, leduc_poker.cc:573-591
+    const int P = p.players;
+    int from = (s.cur == kChancePlayer) ? (p.starter + P - 1) % P : s.cur;
+    for (int i = 1; i <= P; ++i) {
+      int q = (from + i) % P;
+      if (!((s.folded >> q) & 1u)) return q;
+    }
+    return 0;
+  }
+  OSG_D static int hand_rank(const Params& p, const State& s, int q) {  // RankHand, leduc_poker.cc:593-626
+    int lo = s.pub, hi = s.priv[q];
+    if (lo > hi) { int t = lo; lo = hi; hi = t; }
+    if (p.iso) {
+      int n = p.cards / 2;
+      return lo == hi ? n * n + lo : hi * n + lo;
+    }
+    int n = p.cards;
+    if ((lo & 1) == 0 && hi == lo + 1) return n * n + lo;
+    return (hi / 2) * n + (lo / 2);
+  }
+  OSG_D static void showdown(const Params& p, State& s) {  // ResolveWinner, leduc_poker.cc:628-678
+    if (s.remaining == 1) {
+      for (int q = 0; q < p.players; ++q)
+        if (!((s.folded >> q) & 1u)) { s.nwin = 1; s.winners = 1u << q; return; }
+      return;
+    }
+    int best = -1;
+    s.nwin = 0; s.winners = 0;
+    for (int q = 0; q < p.players; ++q) {
+      if ((s.folded >> q) & 1u) continue;
+      int r = hand_rank(p, s, q);
+      if (r > best) { best = r; s.winners = 1u << q; s.nwin = 1; }
+      else if (r == best) { s.winners |= 1u << q; ++s.nwin; }
+    }
+  }
+  OSG_D static void pay(State& s, int q, int amount) {  // Ante, leduc_poker.cc:700-704
+    s.pot += amount;
+    s.ante[q] += amount;
+  }
+  OSG_D static void record(State& s, int move) {
+    int r = s.round - 1;
+    s.seq[r] |= static_cast<uint32_t>(move) << (2 * s.seqlen[r]);
+    ++s.seqlen[r];
+  }
+  OSG_D static void advance(const Params& p, State& s, bool may_start_round) {
+    if (terminal(p, s)) {
+      showdown(p, s);
+    } else if (may_start_round && round_over(s)) {  // NewRound, leduc_poker.cc:685-691
+      s.round = 2; s.raises = 0; s.calls = 0; s.cur = kChancePlayer;
+    } else {
+      s.cur = next_actor(p, s);
+    }
+  }
+  OSG_D static void apply(const Params& p, State& s, int a) {  // DoApplyAction, leduc_poker.cc:298-414
+    if (s.cur == kChancePlayer) {
+      if (s.dealt < p.players) {  // SetPrivate, :706-727
+        s.priv[s.dealt] = take_card(p, s, a);
+        ++s.dealt;
+        if (s.dealt == p.players) s.cur = p.starter;
+      } else {
+        s.pub = take_card(p, s, a);
+        s.cur = next_actor(p, s);
+      }
+      return;
+    }
+    if (p.mapping) {  // :333-345
+      if (a == 0 && s.stakes <= s.ante[s.cur]) a = 1;
+      else if (a == 2 && s.raises >= 2) a = 1;
+    }
+    if (a == 0) {
+      record(s, 0);
+      s.folded |= 1u << s.cur;
+      --s.remaining;
+      advance(p, s, true);
+    } else if (a == 1) {
+      pay(s, s.cur, s.stakes - s.ante[s.cur]);
+      ++s.calls;
+      record(s, 1);
+      advance(p, s, true);
+    } else {
+      int to_call = s.stakes - s.ante[s.cur];
+      if (to_call > 0) pay(s, s.cur, to_call);
+      int bump = s.round == 1 ? 2 : 4;  // leduc_poker.h:65-66
+      s.stakes += bump;
+      pay(s, s.cur, bump);
+      ++s.raises;
+      s.calls = 0;
+      record(s, 2);
+      advance(p, s, false);
+    }
+  }
+  OSG_D static int outcome_code(const Params&, const State&) { return 7; }
+  // Returns = money - 100 (leduc_poker.cc:502-514) with money = 100 - ante, plus
+  // pot / num_winners for winners (added in double, :673) — same operation order.
+  OSG_D static void returns(const Params& p, const State& s, double* out) {
+    bool term = terminal(p, s);
+    // After ResolveWinner the reference zeroes pot_; we keep pot and recompute the share.
+    for (int q = 0; q < p.players; ++q) {
+      if (!term) { out[q] = 0.0; continue; }
+      double money = static_cast<double>(100 - s.ante[q]);
+      if ((s.winners >> q) & 1u) money += static_cast<double>(s.pot) / s.nwin;
+      out[q] = money - 100.0;
+    }
+  }
+  // LeducObserver::WriteTensor, leduc_poker.cc:103-192:
+  //   player[P] | private_card[K] | community_card[K] | betting[2, 3P-2, 2] (info)
+  //                                                   | pot_contribution[P] (obs)
+  OSG_D static float obs_at(const Params& p, const State& s, int player, int which, int idx) {
+    const int P = p.players, K = p.iso ? p.cards / 2 : p.cards;
+    if (idx < P) return idx == player ? 1.0f : 0.0f;
+    idx -= P;
+    if (idx < K) return s.priv[player] == idx ? 1.0f : 0.0f;
+    idx -= K;
+    if (idx < K) return s.pub == idx ? 1.0f : 0.0f;
+    idx -= K;
+    if (which == 1) {
+      const int bets = 3 * P - 2;
+      int r = idx / (bets * 2), rem = idx - r * bets * 2;
+      int i = rem >> 1, bit = rem & 1;
+      if (i >= s.seqlen[r]) return 0.0f;
+      int mv = (s.seq[r] >> (2 * i)) & 3u;
+      return (mv == 1 && bit == 0) || (mv == 2 && bit == 1) ? 1.0f : 0.0f;  // call 10, raise 01
+    }
+    return static_cast<float>(s.ante[idx]);
+  }
+};
+
+}  // namespace osg
+#endif  // OSG_GAME_POKER_H_

@@ -1,0 +1,91 @@
+// Library-internal declarations shared by the .hip translation units.
+#ifndef OSG_INTERNAL_H_
+#define OSG_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/osg_abi.h"
+#include "osg_common.h"
+#include "osg_game_boards.h"
+#include "osg_game_poker.h"
+
+namespace osg {
+
+enum GameKind { kTtt = 0, kC4 = 1, kHex = 2, kKuhn = 3, kLeduc = 4 };
+
+// A parsed, validated game: description + the device parameter block.
+struct GameSpec {
+  osg_game_desc desc;
+  int hex_nw = 0;  // u32 words per hex bit plane (1..4)
+  Ttt::Params ttt;
+  C4::Params c4;
+  HexT<1>::Params hex1;
+  HexT<2>::Params hex2;
+  HexT<3>::Params hex3;
+  HexT<4>::Params hex4;
+  Kuhn::Params kuhn;
+  Leduc::Params leduc;
+  std::map<std::string, std::string> params;  // as given + defaults (strings)
+};
+
+int set_error(int code, const std::string& msg);
+int parse_game(const char* game_string, GameSpec* out);
+
+}  // namespace osg
+
+struct osg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  unsigned long long* d_illegal = nullptr;  // device counter of illegal applies
+  void* d_scratch = nullptr;                // reusable staging buffer
+  size_t scratch_bytes = 0;
+  void* h_pinned = nullptr;
+  size_t pinned_bytes = 0;
+};
+
+struct osg_batch {
+  osg_ctx* ctx = nullptr;
+  osg::GameSpec spec;
+  int64_t n = 0;
+  void* d_words = nullptr;  // state_words planes of n elements
+  size_t bytes = 0;
+};
+
+#define OSG_HIP(call)                                                              \
+  do {                                                                             \
+    hipError_t e__ = (call);                                                       \
+    if (e__ != hipSuccess)                                                         \
+      return osg::set_error(OSG_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+// Dispatch a generic lambda-like macro body over the concrete game type.
+// Inside the body: `G` is the game struct and `P` its Params instance.
+#define OSG_DISPATCH(spec, ...)                                                   \
+  do {                                                                             \
+    switch ((spec).desc.game_kind) {                                               \
+      case osg::kTtt: { using G = osg::Ttt; const G::Params& P = (spec).ttt; __VA_ARGS__; } break; \
+      case osg::kC4: { using G = osg::C4; const G::Params& P = (spec).c4; __VA_ARGS__; } break;    \
+      case osg::kKuhn: { using G = osg::Kuhn; const G::Params& P = (spec).kuhn; __VA_ARGS__; } break; \
+      case osg::kLeduc: { using G = osg::Leduc; const G::Params& P = (spec).leduc; __VA_ARGS__; } break; \
+      case osg::kHex:                                                              \
+        switch ((spec).hex_nw) {                                                   \
+          case 1: { using G = osg::HexT<1>; const G::Params& P = (spec).hex1; __VA_ARGS__; } break; \
+          case 2: { using G = osg::HexT<2>; const G::Params& P = (spec).hex2; __VA_ARGS__; } break; \
+          case 3: { using G = osg::HexT<3>; const G::Params& P = (spec).hex3; __VA_ARGS__; } break; \
+          default: { using G = osg::HexT<4>; const G::Params& P = (spec).hex4; __VA_ARGS__; } break; \
+        }                                                                          \
+        break;                                                                     \
+      default: return osg::set_error(OSG_ERR_INVALID, "bad game kind");            \
+    }                                                                              \
+  } while (0)
+
+// Scratch helpers (device + pinned host staging owned by the context).
+int osg_ctx_scratch(osg_ctx* ctx, size_t bytes, void** out);
+int osg_ctx_pinned(osg_ctx* ctx, size_t bytes, void** out);
+
+#endif  // OSG_INTERNAL_H_

@@ -1,0 +1,568 @@
+// Batched State kernels for the five games + the C-ABI around them.
+//
+// Data layout in HBM: struct-of-arrays.  A batch of n states of a game with W
+// words per state is ONE allocation of W planes of n elements (u32 or u64);
+// lane i of a wavefront touches element i of every plane, so each plane access
+// is a fully coalesced 256-512 B transaction per wave.  All kernels are
+// HBM-bound byte/integer work: no MFMA, no LDS needed for the pure step path
+// (the state lives in VGPRs between load and store).
+#include <cstring>
+
+#include "osg_internal.h"
+
+using namespace osg;
+
+namespace {
+
+constexpr int kBlock = 256;  // 4 wavefronts
+inline int grid_for(int64_t n) { return static_cast<int>((n + kBlock - 1) / kBlock); }
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+template <class G>
+__global__ void __launch_bounds__(kBlock) k_init(typename G::Params p, typename G::word_t* base, int64_t n) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  G::store(p, base, n, i, G::initial(p));
+}
+
+template <class G>
+__global__ void __launch_bounds__(kBlock)
+k_gather(typename G::Params p, typename G::word_t* dst, int64_t nd, const typename G::word_t* src, int64_t ns,
+         const int64_t* index) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= nd) return;
+  int64_t j = index[i];
+  for (int k = 0; k < p.words; ++k) dst[k * nd + i] = src[k * ns + j];
+}
+
+template <class G>
+__global__ void __launch_bounds__(kBlock)
+k_legal_mask(typename G::Params p, const typename G::word_t* base, int64_t n, uint32_t* mask, int mask_words) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  Mask m = G::legal(p, G::load(p, base, n, i));
+  for (int w = 0; w < mask_words; ++w) mask[i * mask_words + w] = m.w[w];
+}
+
+template <class G>
+__global__ void __launch_bounds__(kBlock)
+k_apply(typename G::Params p, typename G::word_t* base, int64_t n, const int32_t* actions,
+        unsigned long long* illegal) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  int a = actions[i];
+  if (a == OSG_INVALID_ACTION) return;
+  typename G::State s = G::load(p, base, n, i);
+  Mask m = G::legal(p, s);
+  if (a < 0 || a >= 32 * kMaskWords || !m.test(a)) {
+    atomicAdd(illegal, 1ull);  // the compiler folds this into one add per wave
+    return;
+  }
+  G::apply(p, s, a);
+  G::store(p, base, n, i, s);
+}
+
+template <class G>
+__global__ void __launch_bounds__(kBlock)
+k_status(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, int8_t* cur,
+         uint8_t* term, double* rets) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  typename G::State s = G::load(p, base, n, i);
+  if (cur) cur[i] = static_cast<int8_t>(G::current_player(p, s));
+  if (term) term[i] = G::terminal(p, s) ? 1 : 0;
+  if (rets) {
+    double r[kMaxPlayers];
+    G::returns(p, s, r);
+    for (int q = 0; q < num_players; ++q) rets[i * num_players + q] = r[q];
+  }
+}
+
+template <class G>
+__global__ void __launch_bounds__(kBlock)
+k_chance_probs(typename G::Params p, const typename G::word_t* base, int64_t n, int max_chance, double* probs) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  typename G::State s = G::load(p, base, n, i);
+  bool chance = G::current_player(p, s) == kChancePlayer;
+  Mask m = G::legal(p, s);
+  for (int o = 0; o < max_chance; ++o)
+    probs[i * max_chance + o] = (chance && m.test(o)) ? G::chance_prob(p, s, o) : 0.0;
+}
+
+// The fused headline kernel (connect_four = 35 B per state:
+// 16 B state in + 16 B out + 1 B action + 1 B mask + 1 B status).
+OSG_D uint8_t encode_status(bool terminal, bool illegal, int cur, int outcome) {
+  uint8_t v = illegal ? 0x40 : 0;
+  if (terminal) return v | 0x80 | static_cast<uint8_t>(outcome & 7);
+  return v | static_cast<uint8_t>((cur + 1) & 15);
+}
+template <class G, typename MaskT>
+__global__ void __launch_bounds__(kBlock)
+k_step(typename G::Params p, const typename G::word_t* src, typename G::word_t* dst, int64_t n,
+       const uint8_t* actions, MaskT* mask_out, int mask_elems, uint8_t* status) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  typename G::State s = G::load(p, src, n, i);
+  int a = actions[i];
+  bool illegal = false;
+  if (a != 0xFF) {
+    Mask before = G::legal(p, s);
+    if (a < 32 * kMaskWords && before.test(a)) G::apply(p, s, a); else illegal = true;
+  }
+  G::store(p, dst, n, i, s);
+  bool term = G::terminal(p, s);
+  Mask after = G::legal(p, s);
+  if (sizeof(MaskT) < 4) {
+    mask_out[i] = static_cast<MaskT>(after.w[0]);
+  } else {
+    for (int w = 0; w < mask_elems; ++w) mask_out[i * mask_elems + w] = static_cast<MaskT>(after.w[w]);
+  }
+  status[i] = encode_status(term, illegal, term ? 0 : G::current_player(p, s), term ? G::outcome_code(p, s) : 0);
+}
+
+// Observation / information-state tensors: write-bound ([n, size] fp32).  One
+// thread per OUTPUT element so consecutive lanes write consecutive floats
+// (coalesced 256 B per wave); the few state words are re-read through L1/L2.
+template <class G>
+__global__ void __launch_bounds__(kBlock)
+k_observation(typename G::Params p, const typename G::word_t* base, int64_t n, int size, int player, int which,
+              float* out) {
+  int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (e >= n * size) return;
+  int64_t i = e / size;
+  int idx = static_cast<int>(e - i * size);
+  typename G::State s = G::load(p, base, n, i);
+  int pl = player;
+  if (pl < 0) {
+    pl = G::current_player(p, s);
+    if (pl < 0) pl = 0;
+  }
+  out[e] = G::obs_at(p, s, pl, which, idx);
+}
+
+// Draw a legal action like the oracle: chance nodes by SampleAction's CDF scan
+// over ChanceOutcomes() with z = rng.unit() (spiel.cc:372-409), decision nodes
+// uniformly over LegalActions() with rng.below(count) (mcts.cc:51-55).
+template <class G>
+OSG_D int sample_action(const typename G::Params& p, const typename G::State& s, const Mask& m, int cur, Rng& rng) {
+  if (cur == kChancePlayer) {
+    int cnt = m.count();
+    if (cnt == 1) return select_action(m, 0);
+    double z = rng.unit();
+    double acc = 0.0;
+    int last = -1;
+    for (int k = 0; k < cnt; ++k) {
+      int o = select_action(m, k);
+      double pr = G::chance_prob(p, s, o);
+      if (acc <= z && z < acc + pr) return o;
+      acc += pr;
+      last = o;
+    }
+    return last;  // unreachable for a valid distribution
+  }
+  return select_action(m, static_cast<int>(rng.below(static_cast<uint32_t>(m.count()))));
+}
+
+template <class G>
+__global__ void __launch_bounds__(kBlock)
+k_random_steps(typename G::Params p, typename G::word_t* base, int64_t n, uint64_t seed, int64_t index_offset,
+               int steps, unsigned long long* counters) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  typename G::State s = G::load(p, base, n, i);
+  Rng rng(seed, static_cast<uint64_t>(index_offset + i), 0);
+  unsigned long long applied = 0, episodes = 0;
+  for (int t = 0; t < steps; ++t) {
+    if (G::terminal(p, s)) {
+      s = G::initial(p);
+      ++episodes;
+    }
+    Mask m = G::legal(p, s);
+    int a = sample_action<G>(p, s, m, G::current_player(p, s), rng);
+    G::apply(p, s, a);
+    ++applied;
+  }
+  G::store(p, base, n, i, s);
+  atomicAdd(&counters[0], applied);
+  atomicAdd(&counters[1], episodes);
+}
+
+// RandomRolloutEvaluator::Evaluate (mcts.cc:43-72), persistent form: every lane
+// owns a strided list of (root, rollout) work items and runs ONE flat loop whose
+// body is "step the playout, or retire it and fetch the next item", so lanes in
+// different phases of different playouts still execute the same instructions.
+template <class G>
+__global__ void __launch_bounds__(kBlock)
+k_rollout(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, uint64_t seed,
+          int64_t index_offset, int n_rollouts, double* sum_returns, int32_t* steps_out) {
+  const int64_t total = n * n_rollouts;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  int64_t item = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (item >= total) return;
+  int64_t root = item / n_rollouts;
+  typename G::State s = G::load(p, base, n, root);
+  Rng rng(seed, static_cast<uint64_t>(index_offset + root), static_cast<uint64_t>(item - root * n_rollouts));
+  int plies = 0;
+  for (;;) {
+    if (G::terminal(p, s)) {
+      double r[kMaxPlayers];
+      G::returns(p, s, r);
+      for (int q = 0; q < num_players; ++q) atomicAdd(&sum_returns[root * num_players + q], r[q]);
+      if (steps_out) atomicAdd(&steps_out[root], plies);
+      item += stride;
+      if (item >= total) break;
+      root = item / n_rollouts;
+      s = G::load(p, base, n, root);
+      rng = Rng(seed, static_cast<uint64_t>(index_offset + root), static_cast<uint64_t>(item - root * n_rollouts));
+      plies = 0;
+      continue;
+    }
+    Mask m = G::legal(p, s);
+    int a = sample_action<G>(p, s, m, G::current_player(p, s), rng);
+    G::apply(p, s, a);
+    ++plies;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host helpers
+// ---------------------------------------------------------------------------
+struct Staged {  // an argument that may live on the host: staged through ctx scratch
+  void* dev = nullptr;
+};
+
+int stage_in(osg_ctx* ctx, const void* ptr, size_t bytes, int on_host, size_t scratch_offset, const void** dev) {
+  if (!on_host) { *dev = ptr; return OSG_OK; }
+  void* scratch = nullptr;
+  int rc = osg_ctx_scratch(ctx, scratch_offset + bytes, &scratch);
+  if (rc) return rc;
+  void* d = static_cast<char*>(scratch) + scratch_offset;
+  OSG_HIP(hipMemcpyAsync(d, ptr, bytes, hipMemcpyHostToDevice, ctx->stream));
+  *dev = d;
+  return OSG_OK;
+}
+
+size_t align_up(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+
+int check_illegal(osg_ctx* ctx, int64_t* h_illegal) {
+  unsigned long long count = 0;
+  OSG_HIP(hipMemcpyAsync(&count, ctx->d_illegal, sizeof(count), hipMemcpyDeviceToHost, ctx->stream));
+  OSG_HIP(hipStreamSynchronize(ctx->stream));
+  if (count) OSG_HIP(hipMemsetAsync(ctx->d_illegal, 0, sizeof(count), ctx->stream));
+  if (h_illegal) { *h_illegal = static_cast<int64_t>(count); return OSG_OK; }
+  if (count) return set_error(OSG_ERR_ILLEGAL, std::to_string(count) + " illegal action(s) applied");
+  return OSG_OK;
+}
+
+}  // namespace
+
+int osg_ctx_scratch(osg_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->scratch_bytes) {
+    // Grow-only; make sure no queued kernel still reads the old block.
+    OSG_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_scratch) OSG_HIP(hipFree(ctx->d_scratch));
+    ctx->d_scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    size_t want = bytes + bytes / 2;
+    OSG_HIP(hipMalloc(&ctx->d_scratch, want));
+    ctx->scratch_bytes = want;
+  }
+  *out = ctx->d_scratch;
+  return OSG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int osg_ctx_create(int device, void* stream, osg_ctx** out) {
+  if (!out) return set_error(OSG_ERR_INVALID, "null out");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0)
+    return set_error(OSG_ERR_HIP, "no HIP device visible: the MI355X path has no CPU fallback");
+  if (device < 0 || device >= count) return set_error(OSG_ERR_INVALID, "bad device index");
+  OSG_HIP(hipSetDevice(device));
+  osg_ctx* ctx = new osg_ctx;
+  ctx->device = device;
+  if (stream) {
+    ctx->stream = static_cast<hipStream_t>(stream);
+  } else {
+    OSG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  OSG_HIP(hipMalloc(&ctx->d_illegal, sizeof(unsigned long long)));
+  OSG_HIP(hipMemsetAsync(ctx->d_illegal, 0, sizeof(unsigned long long), ctx->stream));
+  *out = ctx;
+  return OSG_OK;
+}
+
+int osg_ctx_destroy(osg_ctx* ctx) {
+  if (!ctx) return OSG_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  if (ctx->d_illegal) hipFree(ctx->d_illegal);
+  if (ctx->d_scratch) hipFree(ctx->d_scratch);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return OSG_OK;
+}
+
+int osg_ctx_synchronize(osg_ctx* ctx) {
+  OSG_HIP(hipStreamSynchronize(ctx->stream));
+  return check_illegal(ctx, nullptr);
+}
+void* osg_ctx_stream(osg_ctx* ctx) { return ctx->stream; }
+
+int osg_batch_create(osg_ctx* ctx, const char* game_string, int64_t n, osg_batch** out) {
+  if (!ctx || !out || n <= 0) return set_error(OSG_ERR_INVALID, "osg_batch_create: bad argument");
+  osg_batch* b = new osg_batch;
+  int rc = parse_game(game_string, &b->spec);
+  if (rc) { delete b; return rc; }
+  b->ctx = ctx;
+  b->n = n;
+  b->bytes = static_cast<size_t>(n) * b->spec.desc.state_words * b->spec.desc.state_word_bytes;
+  hipError_t e = hipMalloc(&b->d_words, b->bytes);
+  if (e != hipSuccess) { delete b; return set_error(OSG_ERR_NOMEM, hipGetErrorString(e)); }
+  rc = osg_batch_reset(b);
+  if (rc) { hipFree(b->d_words); delete b; return rc; }
+  *out = b;
+  return OSG_OK;
+}
+
+int osg_batch_destroy(osg_batch* b) {
+  if (!b) return OSG_OK;
+  hipStreamSynchronize(b->ctx->stream);
+  hipFree(b->d_words);
+  delete b;
+  return OSG_OK;
+}
+int64_t osg_batch_size(const osg_batch* b) { return b->n; }
+int osg_batch_describe(const osg_batch* b, osg_game_desc* out) { *out = b->spec.desc; return OSG_OK; }
+void* osg_batch_device_ptr(osg_batch* b) { return b->d_words; }
+
+int osg_batch_reset(osg_batch* b) {
+  OSG_DISPATCH(b->spec, k_init<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, b->ctx->stream>>>(P,
+                                            static_cast<typename G::word_t*>(b->d_words), b->n));
+  OSG_HIP(hipGetLastError());
+  return OSG_OK;
+}
+
+static bool same_game(const osg_batch* a, const osg_batch* b) {
+  return strcmp(a->spec.desc.canonical, b->spec.desc.canonical) == 0 &&
+         a->spec.desc.state_words == b->spec.desc.state_words;
+}
+
+int osg_batch_copy(osg_batch* dst, const osg_batch* src) {
+  if (!same_game(dst, src) || dst->n != src->n) return set_error(OSG_ERR_INVALID, "osg_batch_copy: shape mismatch");
+  OSG_HIP(hipMemcpyAsync(dst->d_words, src->d_words, src->bytes, hipMemcpyDeviceToDevice, dst->ctx->stream));
+  return OSG_OK;
+}
+
+int osg_batch_gather(osg_batch* dst, const osg_batch* src, const int64_t* index, int on_host) {
+  if (!same_game(dst, src)) return set_error(OSG_ERR_INVALID, "osg_batch_gather: different games");
+  const void* d_index = nullptr;
+  int rc = stage_in(dst->ctx, index, sizeof(int64_t) * dst->n, on_host, 0, &d_index);
+  if (rc) return rc;
+  OSG_DISPATCH(dst->spec, k_gather<G><<<dim3(grid_for(dst->n)), dim3(kBlock), 0, dst->ctx->stream>>>(P,
+                                              static_cast<typename G::word_t*>(dst->d_words), dst->n,
+                                              static_cast<const typename G::word_t*>(src->d_words), src->n,
+                                              static_cast<const int64_t*>(d_index)));
+  OSG_HIP(hipGetLastError());
+  if (on_host) OSG_HIP(hipStreamSynchronize(dst->ctx->stream));
+  return OSG_OK;
+}
+
+int osg_batch_download(const osg_batch* b, void* h_words) {
+  OSG_HIP(hipMemcpyAsync(h_words, b->d_words, b->bytes, hipMemcpyDeviceToHost, b->ctx->stream));
+  OSG_HIP(hipStreamSynchronize(b->ctx->stream));
+  return OSG_OK;
+}
+int osg_batch_upload(osg_batch* b, const void* h_words) {
+  OSG_HIP(hipMemcpyAsync(b->d_words, h_words, b->bytes, hipMemcpyHostToDevice, b->ctx->stream));
+  OSG_HIP(hipStreamSynchronize(b->ctx->stream));
+  return OSG_OK;
+}
+
+int osg_legal_mask(const osg_batch* b, uint32_t* mask, int on_host) {
+  osg_ctx* ctx = b->ctx;
+  const int W = b->spec.desc.mask_words;
+  size_t bytes = sizeof(uint32_t) * W * b->n;
+  uint32_t* d_mask = mask;
+  if (on_host) {
+    void* scratch;
+    int rc = osg_ctx_scratch(ctx, bytes, &scratch);
+    if (rc) return rc;
+    d_mask = static_cast<uint32_t*>(scratch);
+  }
+  OSG_DISPATCH(b->spec, k_legal_mask<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
+                                            static_cast<const typename G::word_t*>(b->d_words), b->n, d_mask, W));
+  OSG_HIP(hipGetLastError());
+  if (on_host) {
+    OSG_HIP(hipMemcpyAsync(mask, d_mask, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    OSG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return OSG_OK;
+}
+
+int osg_apply(osg_batch* b, const int32_t* actions, int on_host, int64_t* h_illegal) {
+  osg_ctx* ctx = b->ctx;
+  const void* d_actions = nullptr;
+  int rc = stage_in(ctx, actions, sizeof(int32_t) * b->n, on_host, 0, &d_actions);
+  if (rc) return rc;
+  OSG_DISPATCH(b->spec, k_apply<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
+                                            static_cast<typename G::word_t*>(b->d_words), b->n,
+                                            static_cast<const int32_t*>(d_actions), ctx->d_illegal));
+  OSG_HIP(hipGetLastError());
+  if (on_host || h_illegal) return check_illegal(ctx, h_illegal);
+  return OSG_OK;
+}
+
+int osg_status_query(const osg_batch* b, int8_t* cur_player, uint8_t* terminal, double* returns, int on_host) {
+  osg_ctx* ctx = b->ctx;
+  const int P_ = b->spec.desc.num_players;
+  int8_t* d_cur = cur_player;
+  uint8_t* d_term = terminal;
+  double* d_ret = returns;
+  size_t off_term = align_up(b->n), off_ret = off_term + align_up(b->n);
+  if (on_host) {
+    void* scratch;
+    int rc = osg_ctx_scratch(ctx, off_ret + sizeof(double) * P_ * b->n, &scratch);
+    if (rc) return rc;
+    char* sc = static_cast<char*>(scratch);
+    d_cur = cur_player ? reinterpret_cast<int8_t*>(sc) : nullptr;
+    d_term = terminal ? reinterpret_cast<uint8_t*>(sc + off_term) : nullptr;
+    d_ret = returns ? reinterpret_cast<double*>(sc + off_ret) : nullptr;
+  }
+  OSG_DISPATCH(b->spec, k_status<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
+                                            static_cast<const typename G::word_t*>(b->d_words), b->n, P_, d_cur,
+                                            d_term, d_ret));
+  OSG_HIP(hipGetLastError());
+  if (on_host) {
+    if (cur_player) OSG_HIP(hipMemcpyAsync(cur_player, d_cur, b->n, hipMemcpyDeviceToHost, ctx->stream));
+    if (terminal) OSG_HIP(hipMemcpyAsync(terminal, d_term, b->n, hipMemcpyDeviceToHost, ctx->stream));
+    if (returns) OSG_HIP(hipMemcpyAsync(returns, d_ret, sizeof(double) * P_ * b->n, hipMemcpyDeviceToHost, ctx->stream));
+    OSG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return OSG_OK;
+}
+
+int osg_chance_probs(const osg_batch* b, double* probs, int on_host) {
+  osg_ctx* ctx = b->ctx;
+  const int C = b->spec.desc.max_chance_outcomes;
+  if (C == 0) return OSG_OK;
+  size_t bytes = sizeof(double) * C * b->n;
+  double* d_probs = probs;
+  if (on_host) {
+    void* scratch;
+    int rc = osg_ctx_scratch(ctx, bytes, &scratch);
+    if (rc) return rc;
+    d_probs = static_cast<double*>(scratch);
+  }
+  OSG_DISPATCH(b->spec, k_chance_probs<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
+                                            static_cast<const typename G::word_t*>(b->d_words), b->n, C, d_probs));
+  OSG_HIP(hipGetLastError());
+  if (on_host) {
+    OSG_HIP(hipMemcpyAsync(probs, d_probs, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    OSG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return OSG_OK;
+}
+
+int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, void* d_mask, uint8_t* d_status) {
+  if (!same_game(dst, src) || dst->n != src->n) return set_error(OSG_ERR_INVALID, "osg_step: shape mismatch");
+  osg_ctx* ctx = dst->ctx;
+  const int cmb = src->spec.desc.compact_mask_bytes;
+  const int W = src->spec.desc.mask_words;
+  const int64_t n = src->n;
+  if (cmb == 1) {
+    OSG_DISPATCH(src->spec, k_step<G, uint8_t><<<dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream>>>(P, static_cast<const typename G::word_t*>(src->d_words),
+                                                static_cast<typename G::word_t*>(dst->d_words), n, d_actions,
+                                                static_cast<uint8_t*>(d_mask), 1, d_status));
+  } else if (cmb == 2) {
+    OSG_DISPATCH(src->spec, k_step<G, uint16_t><<<dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream>>>(P, static_cast<const typename G::word_t*>(src->d_words),
+                                                static_cast<typename G::word_t*>(dst->d_words), n, d_actions,
+                                                static_cast<uint16_t*>(d_mask), 1, d_status));
+  } else {
+    OSG_DISPATCH(src->spec, k_step<G, uint32_t><<<dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream>>>(P, static_cast<const typename G::word_t*>(src->d_words),
+                                                static_cast<typename G::word_t*>(dst->d_words), n, d_actions,
+                                                static_cast<uint32_t*>(d_mask), W, d_status));
+  }
+  OSG_HIP(hipGetLastError());
+  return OSG_OK;
+}
+
+int osg_observation(const osg_batch* b, int player, int which, float* out, int on_host) {
+  osg_ctx* ctx = b->ctx;
+  const osg_game_desc& d = b->spec.desc;
+  const int size = which == 0 ? d.obs_size : d.info_size;
+  if (size <= 0) return set_error(OSG_ERR_INVALID, "this game provides no such tensor");
+  if (player < -1 || player >= d.num_players)
+    return set_error(OSG_ERR_INVALID, "player id out of range");  // SPIEL_CHECK_GE/LT, spiel.cc:914-915
+  const int64_t total = b->n * size;
+  float* d_out = out;
+  if (on_host) {
+    void* scratch;
+    int rc = osg_ctx_scratch(ctx, sizeof(float) * total, &scratch);
+    if (rc) return rc;
+    d_out = static_cast<float*>(scratch);
+  }
+  OSG_DISPATCH(b->spec, k_observation<G><<<dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream>>>(P,
+                                            static_cast<const typename G::word_t*>(b->d_words), b->n, size, player,
+                                            which, d_out));
+  OSG_HIP(hipGetLastError());
+  if (on_host) {
+    OSG_HIP(hipMemcpyAsync(out, d_out, sizeof(float) * total, hipMemcpyDeviceToHost, ctx->stream));
+    OSG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return OSG_OK;
+}
+
+int osg_random_steps(osg_batch* b, uint64_t seed, int64_t index_offset, int steps, unsigned long long* d_counters) {
+  osg_ctx* ctx = b->ctx;
+  OSG_DISPATCH(b->spec, k_random_steps<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
+                                            static_cast<typename G::word_t*>(b->d_words), b->n, seed, index_offset,
+                                            steps, d_counters));
+  OSG_HIP(hipGetLastError());
+  return OSG_OK;
+}
+
+int osg_rollout(const osg_batch* roots, uint64_t seed, int64_t index_offset, int n_rollouts, double* sum_returns,
+                int32_t* steps, int on_host) {
+  osg_ctx* ctx = roots->ctx;
+  const int P_ = roots->spec.desc.num_players;
+  const int64_t n = roots->n;
+  if (n_rollouts <= 0) return set_error(OSG_ERR_INVALID, "n_rollouts must be positive");
+  size_t ret_bytes = sizeof(double) * P_ * n, off_steps = align_up(ret_bytes);
+  double* d_sum = sum_returns;
+  int32_t* d_steps = steps;
+  if (on_host) {
+    void* scratch;
+    int rc = osg_ctx_scratch(ctx, off_steps + sizeof(int32_t) * n, &scratch);
+    if (rc) return rc;
+    d_sum = static_cast<double*>(scratch);
+    d_steps = steps ? reinterpret_cast<int32_t*>(static_cast<char*>(scratch) + off_steps) : nullptr;
+  }
+  OSG_HIP(hipMemsetAsync(d_sum, 0, ret_bytes, ctx->stream));
+  if (d_steps) OSG_HIP(hipMemsetAsync(d_steps, 0, sizeof(int32_t) * n, ctx->stream));
+  const int64_t total = n * n_rollouts;
+  // Persistent grid: at most 8 blocks per CU x 256 CUs, grid-strided beyond that.
+  int64_t blocks = (total + kBlock - 1) / kBlock;
+  if (blocks > 2048) blocks = 2048;
+  OSG_DISPATCH(roots->spec, k_rollout<G><<<dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, ctx->stream>>>(P,
+                                                static_cast<const typename G::word_t*>(roots->d_words), n, P_, seed,
+                                                index_offset, n_rollouts, d_sum, d_steps));
+  OSG_HIP(hipGetLastError());
+  if (on_host) {
+    OSG_HIP(hipMemcpyAsync(sum_returns, d_sum, ret_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (steps) OSG_HIP(hipMemcpyAsync(steps, d_steps, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+    OSG_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return OSG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,353 @@
+"""Batched State API over the HIP engine (host-side mirror of pyspiel.State).
+
+The reference exposes one state at a time (`state.legal_actions_mask()`,
+`state.apply_action(a)`, `state.is_terminal()`, `state.returns()`,
+`state.observation_tensor(p)`; open_spiel/python/pybind11/pyspiel.cc:356-474).
+`StateBatch` keeps those names and meanings, vectorised over N states that live
+struct-of-arrays in HBM.  PyTorch is plumbing only (device buffers, streams,
+torch.distributed); every rule evaluation runs in libosg_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._abi import OsgError, check, lib
+
+TERMINAL_PLAYER = -4
+CHANCE_PLAYER = -1
+
+
+def _ptr(t):
+    """Device / host pointer of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        return t.ctypes.data
+    return t.data_ptr()
+
+
+class Context:
+    """One per (process, device): binds the engine to a HIP stream."""
+
+    def __init__(self, device=0, stream=None):
+        if not torch.cuda.is_available():
+            raise OsgError("no MI355X visible (torch.cuda.is_available() is False): the engine "
+                           "has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        self.torch_stream = stream
+        h = C.c_void_p()
+        check(lib().osg_ctx_create(device, C.c_void_p(stream.cuda_stream), C.byref(h)))
+        self._h = h
+
+    def synchronize(self):
+        check(lib().osg_ctx_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            lib().osg_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Game:
+    """Static description of a game string (pyspiel.Game subset)."""
+
+    def __init__(self, game_string):
+        self.game_string = game_string
+        self.desc = _abi.describe(game_string)
+
+    def num_distinct_actions(self):
+        return self.desc.num_distinct_actions
+
+    def max_chance_outcomes(self):
+        return self.desc.max_chance_outcomes
+
+    def num_players(self):
+        return self.desc.num_players
+
+    def max_game_length(self):
+        return self.desc.max_game_length
+
+    def min_utility(self):
+        return self.desc.min_utility
+
+    def max_utility(self):
+        return self.desc.max_utility
+
+    def observation_tensor_shape(self):
+        return [self.desc.obs_shape[i] for i in range(self.desc.obs_rank)]
+
+    def observation_tensor_size(self):
+        return self.desc.obs_size
+
+    def information_state_tensor_shape(self):
+        return [self.desc.info_shape[i] for i in range(self.desc.info_rank)]
+
+    def information_state_tensor_size(self):
+        return self.desc.info_size
+
+    def __str__(self):
+        return self.desc.canonical.decode()
+
+    def new_initial_states(self, ctx, n):
+        return StateBatch(ctx, self.game_string, n)
+
+
+class StateBatch:
+    """N states of one game in HBM (all start at Game::NewInitialState())."""
+
+    def __init__(self, ctx, game_string, n):
+        self.ctx = ctx
+        self.game_string = game_string
+        self.n = int(n)
+        h = C.c_void_p()
+        check(lib().osg_batch_create(ctx._h, game_string.encode(), self.n, C.byref(h)))
+        self._h = h
+        self.desc = _abi.GameDesc()
+        check(lib().osg_batch_describe(self._h, C.byref(self.desc)))
+        self.num_players = self.desc.num_players
+        self.num_distinct_actions = self.desc.num_distinct_actions
+
+    def __len__(self):
+        return self.n
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().osg_batch_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _dev(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.ctx.device)
+
+    # -- State::Clone / reset ------------------------------------------------
+    def reset(self):
+        check(lib().osg_batch_reset(self._h))
+
+    def clone(self):
+        other = StateBatch(self.ctx, self.game_string, self.n)
+        check(lib().osg_batch_copy(other._h, self._h))
+        return other
+
+    def gather(self, index):
+        """New batch with state i = self[index[i]] (Clone() of chosen states)."""
+        idx = torch.as_tensor(index, dtype=torch.int64, device=self.ctx.device).contiguous()
+        other = StateBatch(self.ctx, self.game_string, idx.numel())
+        check(lib().osg_batch_gather(other._h, self._h, _ptr(idx), 0))
+        return other
+
+    def raw_words(self):
+        """The SoA image [state_words, n] as a numpy array (debug / fixtures)."""
+        dt = np.uint64 if self.desc.state_word_bytes == 8 else np.uint32
+        out = np.empty((self.desc.state_words, self.n), dt)
+        check(lib().osg_batch_download(self._h, out.ctypes.data))
+        return out
+
+    def load_raw_words(self, words):
+        dt = np.uint64 if self.desc.state_word_bytes == 8 else np.uint32
+        w = np.ascontiguousarray(words, dt)
+        assert w.shape == (self.desc.state_words, self.n)
+        check(lib().osg_batch_upload(self._h, w.ctypes.data))
+
+    # -- State::LegalActionsMask ---------------------------------------------
+    def legal_actions_mask_bits(self):
+        """[n, mask_words] int32 bit-packed legal mask (chance outcomes at chance nodes)."""
+        out = self._dev((self.n, self.desc.mask_words), torch.int32)
+        check(lib().osg_legal_mask(self._h, _ptr(out), 0))
+        return out
+
+    def legal_actions_mask(self):
+        """[n, max(A, C)] uint8, one entry per action id (State::LegalActionsMask)."""
+        bits = self.legal_actions_mask_bits()
+        width = max(self.desc.num_distinct_actions, self.desc.max_chance_outcomes)
+        shifts = torch.arange(32, device=bits.device, dtype=torch.int32)
+        expanded = ((bits.unsqueeze(-1) >> shifts) & 1).reshape(self.n, -1)
+        return expanded[:, :width].to(torch.uint8)
+
+    # -- State::ApplyAction ----------------------------------------------------
+    def apply_actions(self, actions, check_legal=True):
+        """Apply actions[i] to state i (-1 = leave untouched).  Illegal actions raise."""
+        a = torch.as_tensor(actions, dtype=torch.int32, device=self.ctx.device).contiguous()
+        if a.numel() != self.n:
+            raise OsgError("apply_actions: need one action per state")
+        illegal = C.c_int64(0)
+        check(lib().osg_apply(self._h, _ptr(a), 0, C.byref(illegal) if check_legal else None))
+        if check_legal and illegal.value:
+            raise OsgError(f"{illegal.value} illegal action(s) in apply_actions")
+
+    # -- IsTerminal / CurrentPlayer / Returns ------------------------------------
+    def status(self, want_returns=True):
+        cur = self._dev((self.n,), torch.int8)
+        term = self._dev((self.n,), torch.uint8)
+        rets = self._dev((self.n, self.num_players), torch.float64) if want_returns else None
+        check(lib().osg_status_query(self._h, _ptr(cur), _ptr(term), _ptr(rets), 0))
+        return cur, term, rets
+
+    def current_player(self):
+        return self.status(False)[0]
+
+    def is_terminal(self):
+        return self.status(False)[1].bool()
+
+    def returns(self):
+        return self.status(True)[2]
+
+    def chance_outcome_probs(self):
+        """[n, max_chance_outcomes] float64: ChanceOutcomes() probabilities by outcome id."""
+        out = self._dev((self.n, max(self.desc.max_chance_outcomes, 1)), torch.float64)
+        check(lib().osg_chance_probs(self._h, _ptr(out), 0))
+        return out
+
+    # -- tensors -----------------------------------------------------------------
+    def observation_tensor(self, player=-1, out=None):
+        out = out if out is not None else self._dev((self.n, self.desc.obs_size), torch.float32)
+        check(lib().osg_observation(self._h, int(player), 0, _ptr(out), 0))
+        return out
+
+    def information_state_tensor(self, player=-1, out=None):
+        out = out if out is not None else self._dev((self.n, self.desc.info_size), torch.float32)
+        check(lib().osg_observation(self._h, int(player), 1, _ptr(out), 0))
+        return out
+
+    # -- the fused step -------------------------------------------------------------
+    def step_buffers(self):
+        mask = self._dev((self.n, self.desc.compact_mask_bytes), torch.uint8)
+        status = self._dev((self.n,), torch.uint8)
+        return mask, status
+
+    def step(self, actions_u8, dst=None, mask=None, status=None):
+        """Fused legality check + ApplyAction + status + successor legal mask.
+
+        actions_u8: [n] uint8 device tensor (0xFF = skip).  dst: destination batch
+        (default: in place).  Returns (mask bytes [n, compact_mask_bytes], status [n]).
+        """
+        dst = dst or self
+        if mask is None or status is None:
+            mask, status = self.step_buffers()
+        check(lib().osg_step(self._h, dst._h, _ptr(actions_u8), _ptr(mask), _ptr(status)))
+        return mask, status
+
+    # -- random play ------------------------------------------------------------------
+    def random_steps(self, seed, steps, counters=None, index_offset=0):
+        """`steps` uniformly random env steps per state with auto-reset; returns the
+        [2] uint64-as-int64 device counters (steps applied, episodes finished)."""
+        if counters is None:
+            counters = torch.zeros(2, dtype=torch.int64, device=self.ctx.device)
+        check(lib().osg_random_steps(self._h, int(seed), int(index_offset), int(steps), _ptr(counters)))
+        return counters
+
+    def rollout(self, seed, n_rollouts, index_offset=0, want_steps=False):
+        """RandomRolloutEvaluator: SUM of Returns() over n_rollouts playouts per root."""
+        total = self._dev((self.n, self.num_players), torch.float64)
+        steps = self._dev((self.n,), torch.int32) if want_steps else None
+        check(lib().osg_rollout(self._h, int(seed), int(index_offset), int(n_rollouts), _ptr(total),
+                                _ptr(steps), 0))
+        return (total, steps) if want_steps else total
+
+    def mcts_search(self, uct_c=2.0, max_simulations=1024, n_rollouts=1, solve=False, max_nodes=0,
+                    seed=0, index_offset=0):
+        """MCTSBot.mcts_search for every root (one wavefront per root)."""
+        A = self.num_distinct_actions
+        cfg = _abi.MctsCfg(uct_c, max_simulations, n_rollouts, int(solve), max_nodes, seed, index_offset)
+        best = self._dev((self.n,), torch.int32)
+        visits = self._dev((self.n, A), torch.int32)
+        reward = self._dev((self.n, A), torch.float64)
+        outcome = self._dev((self.n, A), torch.int8)
+        stats = self._dev((self.n, 4), torch.float64)
+        check(lib().osg_mcts_search(self._h, C.byref(cfg), _ptr(best), _ptr(visits), _ptr(reward),
+                                    _ptr(outcome), _ptr(stats), 0))
+        return dict(best_action=best, child_visits=visits, child_reward=reward, child_outcome=outcome,
+                    root_stats=stats)
+
+
+class TabularSolver:
+    """CFRSolver / CFRPlusSolver / external-sampling MCCFR on the device.
+
+    Mirrors pyspiel.CFRSolver(game).evaluate_and_update_policy() /
+    average_policy() (open_spiel/python/pybind11/policy.cc:224-333).
+    """
+
+    def __init__(self, ctx, game_string, alternating_updates=True, linear_averaging=False,
+                 regret_matching_plus=False):
+        self.ctx = ctx
+        self.game_string = game_string
+        cfg = _abi.CfrCfg(int(alternating_updates), int(linear_averaging), int(regret_matching_plus))
+        h = C.c_void_p()
+        check(lib().osg_cfr_create(ctx._h, game_string.encode(), C.byref(cfg), C.byref(h)))
+        self._h = h
+        sizes = (C.c_int64 * 6)()
+        check(lib().osg_cfr_sizes(self._h, sizes))
+        (self.num_histories, self.num_chance, self.num_decision, self.num_terminal,
+         self.num_infostates, self.amax) = [int(v) for v in sizes]
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().osg_cfr_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def evaluate_and_update_policy(self, iters=1):
+        check(lib().osg_cfr_iterate(self._h, int(iters)))
+
+    def run_mccfr(self, seed, trajectories, first_trajectory=0):
+        check(lib().osg_mccfr_iterate(self._h, int(seed), int(first_trajectory), int(trajectories)))
+
+    def _wrap(self, ptr):
+        # zero-copy torch view of a device fp64 table [I, Amax]
+        n = self.num_infostates * self.amax
+        arr_t = C.c_double * n
+        holder = type("Holder", (), {})()
+        holder.__cuda_array_interface__ = {
+            "shape": (self.num_infostates, self.amax), "typestr": "<f8",
+            "data": (ptr, False), "version": 2, "strides": None}
+        del arr_t
+        t = torch.as_tensor(holder, device=self.ctx.device)
+        return t
+
+    def device_tables(self):
+        r, c, p = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib().osg_cfr_table_ptrs(self._h, C.byref(r), C.byref(c), C.byref(p)))
+        return self._wrap(r.value), self._wrap(c.value), self._wrap(p.value)
+
+    def mccfr_delta_tables(self):
+        r, c = C.c_void_p(), C.c_void_p()
+        check(lib().osg_mccfr_delta_ptrs(self._h, C.byref(r), C.byref(c)))
+        return self._wrap(r.value), self._wrap(c.value)
+
+    def mccfr_apply_deltas(self):
+        check(lib().osg_mccfr_apply_deltas(self._h))
+
+    def tables(self):
+        I, A = self.num_infostates, self.amax
+        nact = np.zeros(I, np.int32)
+        legal = np.zeros((I, A), np.int32)
+        out = {k: np.zeros((I, A), np.float64) for k in ("regrets", "cum_policy", "cur_policy", "avg_policy")}
+        check(lib().osg_cfr_tables(self._h, nact.ctypes.data, legal.ctypes.data, out["regrets"].ctypes.data,
+                                   out["cum_policy"].ctypes.data, out["cur_policy"].ctypes.data,
+                                   out["avg_policy"].ctypes.data))
+        keys = []
+        buf = C.create_string_buffer(512)
+        for i in range(I):
+            check(min(lib().osg_cfr_infostate_key(self._h, i, buf, 512), 0))
+            keys.append(buf.value.decode())
+        out.update(keys=keys, nact=nact, legal=legal)
+        return out
+
+    def average_policy(self):
+        t = self.tables()
+        return {k: [(int(t["legal"][i, a]), float(t["avg_policy"][i, a])) for a in range(t["nact"][i])]
+                for i, k in enumerate(t["keys"])}

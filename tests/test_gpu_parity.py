@@ -1,0 +1,255 @@
+"""Parity of the HIP path against the CPU oracle, through the C-ABI.
+
+Bar (BASELINE.json north_star): bit-exact legal-action sets, terminal flags,
+current players and returns; observation tensors bit-exact (0/1 and small
+integers in fp32).  Everything here needs a real MI355X.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GAMES = [
+    "tic_tac_toe",
+    "connect_four",
+    "connect_four(rows=5,columns=6,x_in_row=3)",
+    "connect_four(egocentric_obs_tensor=True)",
+    "hex(board_size=9)",
+    "hex(board_size=5)",
+    "hex",                                   # 11x11, 4 words per bit plane
+    "hex(num_cols=3,num_rows=4)",
+    "hex(num_cols=2,num_rows=3)",
+    "hex(num_cols=2,num_rows=2)",
+    "hex(board_size=4,swap=True)",
+    "hex(board_size=5,plain_obs_tensor=True,swap=True)",
+    "kuhn_poker",
+    "kuhn_poker(players=3)",
+    "kuhn_poker(players=5)",
+    "leduc_poker",
+    "leduc_poker(players=3)",
+    "leduc_poker(action_mapping=True)",
+    "leduc_poker(suit_isomorphism=True)",
+    "leduc_poker(players=3,starting_player=2)",
+]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import open_spiel_amd as osa
+    return osa.Context(0)
+
+
+def _mask_words(bits_i32):
+    return bits_i32.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("game", GAMES)
+def test_step_by_step_parity(oracle, ctx, game):
+    """Replay seeded oracle playouts ply by ply through osg_apply and compare
+    LegalActions / CurrentPlayer / IsTerminal / Returns at EVERY position."""
+    import torch
+    import open_spiel_amd as osa
+    og = oracle.Game(game)
+    n = 1500  # deliberately not a multiple of the 256-thread block
+    rec = og.random_playouts(20240921, n)
+    L, W = og.max_plies, og.mask_words
+    batch = osa.StateBatch(ctx, game, n)
+    assert batch.desc.mask_words == W
+    assert batch.desc.num_distinct_actions == og.num_distinct_actions
+    assert batch.desc.max_chance_outcomes == og.max_chance_outcomes
+    assert batch.desc.obs_size == og.observation_tensor_size
+    assert batch.desc.info_size == og.information_state_tensor_size
+    assert batch.desc.max_game_length == og.max_game_length
+    for t in range(L + 1):
+        bits = _mask_words(batch.legal_actions_mask_bits())
+        np.testing.assert_array_equal(bits, rec["mask"][:, t], err_msg=f"{game}: legal mask at ply {t}")
+        cur, term, rets = batch.status()
+        np.testing.assert_array_equal(cur.cpu().numpy(), rec["cur_player"][:, t], err_msg=f"{game}: player at ply {t}")
+        np.testing.assert_array_equal(term.cpu().numpy(), rec["terminal"][:, t], err_msg=f"{game}: terminal at ply {t}")
+        np.testing.assert_array_equal(rets.cpu().numpy(), rec["returns"][:, t], err_msg=f"{game}: returns at ply {t}")
+        if t == L:
+            break
+        batch.apply_actions(torch.from_numpy(rec["actions"][:, t].astype(np.int32)))
+    assert rec["terminal"][:, L].all()
+
+
+@pytest.mark.parametrize("game", ["tic_tac_toe", "connect_four", "hex(board_size=9)", "kuhn_poker", "leduc_poker",
+                                  "hex(board_size=4,swap=True)", "leduc_poker(players=3)"])
+def test_fused_step_parity(oracle, ctx, game):
+    """The fused kernel (legality + apply + status + successor mask), out of place."""
+    import torch
+    import open_spiel_amd as osa
+    og = oracle.Game(game)
+    n = 4097
+    rec = og.random_playouts(7, n)
+    L = og.max_plies
+    a, b = osa.StateBatch(ctx, game, n), osa.StateBatch(ctx, game, n)
+    cmb = a.desc.compact_mask_bytes
+    for t in range(L):
+        acts = rec["actions"][:, t]
+        a8 = torch.from_numpy(np.where(acts < 0, 255, acts).astype(np.uint8)).cuda()
+        mask, status = a.step(a8, dst=b)
+        st = status.cpu().numpy()
+        term = (st & 0x80) != 0
+        np.testing.assert_array_equal(term, rec["terminal"][:, t + 1] != 0)
+        assert not (st & 0x40).any(), "no action of an oracle playout is illegal"
+        cur = rec["cur_player"][:, t + 1]
+        live = ~term
+        np.testing.assert_array_equal((st[live] & 15).astype(np.int64) - 1, cur[live])
+        if a.desc.game_kind <= 2:  # board games: outcome in bits 0-2
+            r0 = rec["returns"][:, t + 1, 0]
+            want = np.where(r0 > 0, 0, np.where(r0 < 0, 1, 2))
+            np.testing.assert_array_equal((st[term] & 7), want[term])
+        m = mask.cpu().numpy()
+        gold = rec["mask"][:, t + 1]
+        if cmb < 4:
+            got = m.view(np.uint8 if cmb == 1 else np.uint16).reshape(n).astype(np.uint32)
+            np.testing.assert_array_equal(got, gold[:, 0])
+        else:
+            np.testing.assert_array_equal(m.view(np.uint32).reshape(n, -1), gold)
+        a, b = b, a
+    np.testing.assert_array_equal(a.returns().cpu().numpy(), rec["returns"][:, L])
+
+
+@pytest.mark.parametrize("game", GAMES)
+def test_observation_parity(oracle, ctx, game):
+    """ObservationTensor / InformationStateTensor for every player at every ply."""
+    import torch
+    import open_spiel_amd as osa
+    og = oracle.Game(game)
+    n = 96
+    rec = og.random_playouts(99, n, want_obs=True, want_info=True)
+    batch = osa.StateBatch(ctx, game, n)
+    for t in range(og.max_plies + 1):
+        for p in range(og.num_players):
+            got = batch.observation_tensor(p).cpu().numpy()
+            np.testing.assert_array_equal(got, rec["obs"][:, t, p], err_msg=f"{game} obs p{p} ply {t}")
+            if rec["info"] is not None:
+                got = batch.information_state_tensor(p).cpu().numpy()
+                np.testing.assert_array_equal(got, rec["info"][:, t, p], err_msg=f"{game} info p{p} ply {t}")
+        if t < og.max_plies:
+            batch.apply_actions(torch.from_numpy(rec["actions"][:, t].astype(np.int32)))
+
+
+def test_golden_playthroughs_on_device(ctx, goldens):
+    """The reference's own playthrough goldens, replayed through the HIP path."""
+    import torch
+    import open_spiel_amd as osa
+    for fname, rec in goldens.items():
+        game = rec["game"]
+        batch = osa.StateBatch(ctx, game, 3)
+        P = batch.num_players
+        for blk in rec["states"]:
+            if not blk.get("skipped"):
+                cur, term, rets = batch.status()
+                assert bool(term[0]) == blk["is_terminal"], fname
+                assert int(cur[0]) == blk["current_player"], fname
+                if "returns" in blk:
+                    assert rets[0].tolist() == blk["returns"], fname
+                legal = np.nonzero(batch.legal_actions_mask().cpu().numpy()[0])[0].tolist()
+                assert legal == blk["legal_actions"], (fname, blk["history"])
+                if "chance_outcomes" in blk:
+                    probs = batch.chance_outcome_probs().cpu().numpy()[0]
+                    for a, pr in blk["chance_outcomes"]:
+                        assert "{:.6g}".format(probs[a]) == "{:.6g}".format(pr)
+                    assert abs(probs.sum() - 1.0) < 1e-12
+                for key, gold in blk["tensors"].items():
+                    p = int(key[-1])
+                    want = np.array([float(c) for c in gold] if isinstance(gold, str) else gold, np.float32)
+                    got = (batch.observation_tensor(p) if key.startswith("obs")
+                           else batch.information_state_tensor(p)).cpu().numpy()[0]
+                    np.testing.assert_array_equal(got, want, err_msg=f"{fname} {key} {blk['history']}")
+            if "action" in blk:
+                batch.apply_actions(torch.full((3,), blk["action"], dtype=torch.int32))
+        assert bool(batch.is_terminal().all())
+        del P
+
+
+def test_illegal_and_terminal_actions_are_rejected(ctx):
+    import torch
+    import open_spiel_amd as osa
+    b = osa.StateBatch(ctx, "connect_four", 8)
+    for _ in range(6):
+        b.apply_actions(torch.zeros(8, dtype=torch.int32))       # fill column 0
+    before = b.raw_words().copy()
+    with pytest.raises(osa.OsgError):
+        b.apply_actions(torch.zeros(8, dtype=torch.int32))       # column full -> illegal
+    np.testing.assert_array_equal(b.raw_words(), before)         # state untouched
+    with pytest.raises(osa.OsgError):
+        b.apply_actions(torch.full((8,), 7, dtype=torch.int32))  # out of range
+    b.apply_actions(torch.full((8,), -1, dtype=torch.int32))     # -1 = skip, fine
+    np.testing.assert_array_equal(b.raw_words(), before)
+    # fused kernel flags instead of raising
+    a8 = torch.zeros(8, dtype=torch.uint8, device="cuda")
+    _, status = b.step(a8)
+    assert ((status.cpu().numpy() & 0x40) != 0).all()
+    # terminal states accept nothing (FastLoss, connect_four_test.cc:38-59)
+    t = osa.StateBatch(ctx, "connect_four", 2)
+    for a in [3, 3, 4, 4, 2, 2, 1]:
+        t.apply_actions(torch.full((2,), a, dtype=torch.int32))
+    assert bool(t.is_terminal().all())
+    assert t.returns().tolist() == [[1.0, -1.0]] * 2
+    assert not t.legal_actions_mask().any()
+    with pytest.raises(osa.OsgError):
+        t.apply_actions(torch.full((2,), 0, dtype=torch.int32))
+
+
+def test_bad_game_strings(ctx):
+    import open_spiel_amd as osa
+    for bad in ["chess", "connect_four(rows=9,columns=9)", "hex(board_size=13)", "kuhn_poker(players=11)",
+                "leduc_poker(players=4)", "connect_four(foo=1)", "hex(swap=3)"]:
+        with pytest.raises(osa.OsgError):
+            osa.StateBatch(ctx, bad, 4)
+    with pytest.raises(osa.OsgError):
+        osa.StateBatch(ctx, "kuhn_poker", 4).observation_tensor(5)  # player out of range
+
+
+def test_clone_and_gather(ctx):
+    import torch
+    import open_spiel_amd as osa
+    b = osa.StateBatch(ctx, "hex(board_size=9)", 300)
+    b.random_steps(5, 7)
+    c = b.clone()
+    np.testing.assert_array_equal(b.raw_words(), c.raw_words())
+    idx = torch.arange(299, -1, -3)
+    g = b.gather(idx)
+    np.testing.assert_array_equal(g.raw_words(), b.raw_words()[:, idx.numpy()])
+
+
+@pytest.mark.parametrize("game,n_rollouts", [("tic_tac_toe", 20), ("connect_four", 8), ("hex(board_size=9)", 4),
+                                             ("hex(board_size=5)", 8), ("kuhn_poker", 16), ("leduc_poker", 16),
+                                             ("leduc_poker(players=3)", 8), ("kuhn_poker(players=4)", 8)])
+def test_rollout_replay_parity(oracle, ctx, game, n_rollouts):
+    """RandomRolloutEvaluator on the device == the oracle replaying the same
+    counter-RNG stream: identical summed returns AND identical ply counts."""
+    import torch
+    import open_spiel_amd as osa
+    og = oracle.Game(game)
+    n = 200
+    rng = np.random.default_rng(3)
+    stop = rng.integers(0, max(og.max_plies // 2, 1), n).astype(np.int32)
+    rec = og.random_playouts(11, n, stop=stop)
+    roots = osa.StateBatch(ctx, game, n)
+    for t in range(og.max_plies):
+        if (rec["actions"][:, t] < 0).all():
+            break
+        roots.apply_actions(torch.from_numpy(rec["actions"][:, t].astype(np.int32)))
+    seed, offset = 0xC0FFEE, 1000
+    total, steps = roots.rollout(seed, n_rollouts, index_offset=offset, want_steps=True)
+    total, steps = total.cpu().numpy(), steps.cpu().numpy()
+    for i in range(n):
+        hist = rec["actions"][i]
+        hist = hist[hist >= 0]
+        want, want_steps = og.replay_rollouts(hist, seed, offset + i, n_rollouts)
+        np.testing.assert_allclose(total[i], want, rtol=0, atol=1e-12, err_msg=f"{game} root {i}")
+        assert steps[i] == want_steps
+
+
+def test_random_steps_counters(ctx):
+    import open_spiel_amd as osa
+    b = osa.StateBatch(ctx, "connect_four", 1 << 12)
+    counters = b.random_steps(1, 64)
+    ctx.synchronize()
+    steps, episodes = counters.tolist()
+    assert steps == 64 * (1 << 12)
+    assert episodes > 0  # 64 plies always finishes at least one 42-ply game

@@ -61,25 +61,33 @@ def synth_batch(osa, torch, ctx, n, seed, index_offset):
     return batch, actions
 
 
-def cpu_baseline(threads_all):
+def host_threads():
+    try:
+        return max(1, min(len(os.sched_getaffinity(0)), 64))
+    except AttributeError:
+        return max(1, min(os.cpu_count() or 1, 64))
+
+
+def cpu_baseline():
     """The CPU oracle (reference-shaped port) timed on this box's host cores on a
-    bounded sample of the same workload (~15-25 s of CPU work)."""
+    bounded sample of the same workload (~15-20 s of CPU work in total)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
     oracle_py.build()
     g = oracle_py.Game("connect_four")
     pool = 1 << 14
-    secs, units = g.bench_env_steps(SEED, pool, 200_000, 1)          # calibrate
-    rate1 = units / secs
-    secs1, units1 = g.bench_env_steps(SEED, pool, int(rate1 * 6), 1)  # ~6 s, 1 thread
+    secs, units = g.bench_env_steps(SEED, pool, 200_000, 1)               # calibrate 1 thread
+    secs1, units1 = g.bench_env_steps(SEED, pool, int(units / secs * 5), 1)   # ~5 s, 1 thread
     single = units1 / secs1
-    secs_n, units_n = g.bench_env_steps(SEED, pool, int(single * threads_all * 8 * 0.8), threads_all)
+    threads = host_threads()
+    secs, units = g.bench_env_steps(SEED, pool, 100_000 * threads, threads)   # calibrate N threads
+    secs_n, units_n = g.bench_env_steps(SEED, pool, int(units / secs * 8), threads)  # ~8 s
     return {
-        "value": units_n / secs_n, "unit": "env-steps/s", "cores": threads_all, "kind": "port",
+        "value": units_n / secs_n, "unit": "env-steps/s", "cores": threads, "kind": "port",
         "single_thread_value": single,
         "sample": (f"{units_n} connect_four env steps (Clone + LegalActions + ApplyAction + IsTerminal + "
                    f"Returns + CurrentPlayer per step) over a pool of {pool} seeded positions, "
-                   f"{threads_all} threads, {secs_n:.1f} s; single thread {units1} steps in {secs1:.1f} s"),
+                   f"{threads} threads, {secs_n:.1f} s; single thread {units1} steps in {secs1:.1f} s"),
     }
 
 
@@ -168,7 +176,7 @@ def main():
                          "note": "2^20 states = 36.7 MB/launch, resident in the 256 MiB Infinity Cache"},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline()
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if world > 1:

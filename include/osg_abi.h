@@ -77,9 +77,10 @@ typedef struct {
 const char* osg_last_error(void);
 
 /* ---- context ------------------------------------------------------------ */
-/* stream == NULL: the library creates its own non-blocking stream.  Otherwise
- * `stream` is a hipStream_t owned by the caller (e.g. torch's current stream). */
-int osg_ctx_create(int device, void* stream, osg_ctx** out);
+/* own_stream != 0: the library creates (and owns) a non-blocking stream and
+ * `stream` is ignored.  own_stream == 0: `stream` is a hipStream_t owned by the
+ * caller (e.g. torch's current stream; NULL is the device's default stream). */
+int osg_ctx_create(int device, void* stream, int own_stream, osg_ctx** out);
 int osg_ctx_destroy(osg_ctx* ctx);
 int osg_ctx_synchronize(osg_ctx* ctx);
 void* osg_ctx_stream(osg_ctx* ctx);
@@ -132,9 +133,9 @@ int osg_chance_probs(const osg_batch* b, double* probs, int on_host);
  * SoA state.  Device pointers only; src may equal dst.
  *   d_actions [n] u8   action id (0xFF = skip)
  *   d_mask    [n * compact_mask_bytes] legal mask of the successor state
- *   d_status  [n] u8   bit7 terminal | bit6 action was illegal |
- *                      bits3-5 current player + 1 (0 = chance) when not terminal |
- *                      bits0-2 outcome when terminal (board games: 0 p0 wins,
+ *   d_status  [n] u8   bit7 terminal | bit6 action was illegal (state unchanged) |
+ *                      not terminal: bits0-3 = current player + 1 (0 = chance) |
+ *                      terminal:     bits0-2 = outcome (board games: 0 p0 wins,
  *                      1 p1 wins, 2 draw; poker: 7 = see osg_status_query) */
 int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions,
              void* d_mask, uint8_t* d_status);

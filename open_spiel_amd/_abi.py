@@ -67,7 +67,7 @@ INT = C.c_int
 # name -> (restype, argtypes).  Every symbol include/osg_abi.h declares.
 SIGNATURES = {
     "osg_last_error": (C.c_char_p, []),
-    "osg_ctx_create": (INT, [INT, VP, C.POINTER(VP)]),
+    "osg_ctx_create": (INT, [INT, VP, INT, C.POINTER(VP)]),
     "osg_ctx_destroy": (INT, [VP]),
     "osg_ctx_synchronize": (INT, [VP]),
     "osg_ctx_stream": (VP, [VP]),

@@ -279,7 +279,7 @@ int osg_ctx_scratch(osg_ctx* ctx, size_t bytes, void** out) {
 // ---------------------------------------------------------------------------
 extern "C" {
 
-int osg_ctx_create(int device, void* stream, osg_ctx** out) {
+int osg_ctx_create(int device, void* stream, int own_stream, osg_ctx** out) {
   if (!out) return set_error(OSG_ERR_INVALID, "null out");
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
@@ -289,7 +289,7 @@ int osg_ctx_create(int device, void* stream, osg_ctx** out) {
   OSG_HIP(hipSetDevice(device));
   osg_ctx* ctx = new osg_ctx;
   ctx->device = device;
-  if (stream) {
+  if (!own_stream) {
     ctx->stream = static_cast<hipStream_t>(stream);
   } else {
     OSG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));

@@ -41,7 +41,7 @@ class Context:
             stream = torch.cuda.current_stream(self.device)
         self.torch_stream = stream
         h = C.c_void_p()
-        check(lib().osg_ctx_create(device, C.c_void_p(stream.cuda_stream), C.byref(h)))
+        check(lib().osg_ctx_create(device, C.c_void_p(stream.cuda_stream), 0, C.byref(h)))
         self._h = h
 
     def synchronize(self):

@@ -76,7 +76,7 @@ def test_no_cpu_fallback(built):
         pytest.skip("a GPU is visible")
     from open_spiel_amd import _abi
     h = C.c_void_p()
-    rc = built.lib().osg_ctx_create(0, None, C.byref(h))
+    rc = built.lib().osg_ctx_create(0, None, 1, C.byref(h))
     assert rc != 0
     assert b"no HIP device" in built.lib().osg_last_error() or b"hip" in built.lib().osg_last_error().lower()
     with pytest.raises(built.OsgError):

@@ -81,17 +81,32 @@ struct Ttt {
 // Player to move = parity of the stone count; outcome recomputed (a reachable
 // position has at most one player with a line, connect_four.cc:138-142).
 // ===========================================================================
-struct C4 {
+struct C4Params {
+  int words;  // = 2
+  int rows, cols, k, ego;
+  uint64_t board;  // all playable cells
+  uint64_t top;    // top playable cell of every column
+};
+// R_/C_/K_ = 0: geometry read from Params at run time.  The default 6x7x4 game
+// is instantiated with compile-time constants (shifts by immediates, the
+// column loop fully unrolled): this is the headline kernel's game.
+template <int R_, int C_, int K_>
+struct C4T {
   using word_t = uint64_t;
-  struct Params {
-    int words;  // = 2
-    int rows, cols, k, ego;
-    uint64_t board;  // all playable cells
-    uint64_t top;    // top playable cell of every column
-  };
+  using Params = C4Params;
   struct State {
     uint64_t x, o;
   };
+  OSG_D static int R(const Params& p) { return R_ ? R_ : p.rows; }
+  OSG_D static int C(const Params& p) { return C_ ? C_ : p.cols; }
+  OSG_D static int K(const Params& p) { return K_ ? K_ : p.k; }
+  OSG_D static uint64_t top(const Params& p) {
+    if (R_ == 0) return p.top;
+    uint64_t t = 0;
+#pragma unroll
+    for (int c = 0; c < C_; ++c) t |= 1ull << (c * (R_ + 1) + R_ - 1);
+    return t;
+  }
   OSG_D static State initial(const Params&) { return {0ull, 0ull}; }
   OSG_D static State load(const Params&, const word_t* base, int64_t n, int64_t i) {
     return {base[i], base[n + i]};
@@ -103,25 +118,25 @@ struct C4 {
   // HasLine, connect_four.cc:163-201, as the classic shifted-AND test along the
   // four directions: vertical (1), horizontal (H), the two diagonals (H-1, H+1).
   OSG_D static bool line(const Params& p, uint64_t b) {
-    const int H = p.rows + 1;
+    const int H = R(p) + 1;
     const int dirs[4] = {1, H, H - 1, H + 1};
-    bool hit = false;
+    uint64_t hit = 0;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       uint64_t m = b;
-      if (p.k == 4) {
+      if (K(p) == 4) {
         m = m & (m >> dirs[d]);
         m = m & (m >> (2 * dirs[d]));
       } else {
-        for (int i = 1; i < p.k; ++i) m &= b >> (i * dirs[d]);
+        for (int i = 1; i < K(p); ++i) m &= b >> (i * dirs[d]);
       }
-      hit |= (m != 0);
+      hit |= m;
     }
-    return hit;
+    return hit != 0;
   }
   OSG_D static int plies(const State& s) { return __builtin_popcountll(s.x | s.o); }
   OSG_D static bool full(const Params& p, const State& s) {  // connect_four.cc:203-209
-    return ((s.x | s.o) & p.top) == p.top;
+    return ((s.x | s.o) & top(p)) == top(p);
   }
   OSG_D static bool terminal(const Params& p, const State& s) {
     return line(p, s.x) | line(p, s.o) | full(p, s);
@@ -130,10 +145,15 @@ struct C4 {
     return terminal(p, s) ? kTerminalPlayer : (plies(s) & 1);
   }
   OSG_D static uint32_t open_columns(const Params& p, const State& s) {
-    const int H = p.rows + 1;
-    uint64_t free_top = ~(s.x | s.o) & p.top;
+    const int H = R(p) + 1;
+    uint64_t free_top = ~(s.x | s.o) & top(p);
     uint32_t m = 0;
-    for (int c = 0; c < p.cols; ++c) m |= static_cast<uint32_t>((free_top >> (c * H + p.rows - 1)) & 1ull) << c;
+    if (C_ != 0) {
+#pragma unroll
+      for (int c = 0; c < C_; ++c) m |= static_cast<uint32_t>((free_top >> (c * H + R(p) - 1)) & 1ull) << c;
+    } else {
+      for (int c = 0; c < p.cols; ++c) m |= static_cast<uint32_t>((free_top >> (c * H + R(p) - 1)) & 1ull) << c;
+    }
     return m;
   }
   OSG_D static Mask legal(const Params& p, const State& s) {  // connect_four.cc:147-156
@@ -142,9 +162,9 @@ struct C4 {
     return m;
   }
   OSG_D static void apply(const Params& p, State& s, int col) {  // connect_four.cc:130-145
-    const int H = p.rows + 1;
+    const int H = R(p) + 1;
     uint64_t all = s.x | s.o;
-    uint64_t colmask = ((1ull << p.rows) - 1ull) << (col * H);
+    uint64_t colmask = ((1ull << R(p)) - 1ull) << (col * H);
     uint64_t cell = (all + (1ull << (col * H))) & colmask;  // lowest empty cell
     if (__builtin_popcountll(all) & 1) s.o |= cell; else s.x |= cell;
   }
@@ -161,10 +181,10 @@ struct C4 {
   // via StateToPlayer (:75-86): 0 = x, 1 = o, 2 = empty.  Egocentric planes via
   // PlayerRelative (:299-310): nought -> (player==0 ? 0 : 1), cross -> (player==1 ? 0 : 1).
   OSG_D static float obs_at(const Params& p, const State& s, int player, int /*which*/, int idx) {
-    const int RC = p.rows * p.cols;
+    const int RC = R(p) * C(p);
     int plane = idx / RC, rem = idx - plane * RC;
-    int r = rem / p.cols, c = rem - r * p.cols;
-    int bit = c * (p.rows + 1) + r;
+    int r = rem / C(p), c = rem - r * C(p);
+    int bit = c * (R(p) + 1) + r;
     uint64_t first = s.x, second = s.o;
     if (p.ego) {  // plane 0 holds kNought iff player == 0, kCross iff player == 1
       first = player == 0 ? s.o : s.x;
@@ -174,6 +194,8 @@ struct C4 {
     return static_cast<float>((bits >> bit) & 1ull);
   }
 };
+using C4 = C4T<0, 0, 0>;     // any geometry with (rows+1)*cols <= 64
+using C4Std = C4T<6, 7, 4>;  // the default game, constants folded
 
 // ===========================================================================
 // hex (num_cols C, num_rows R, C*R <= 32*NW).  HBM layout: 4*NW + 1 u32 planes:
@@ -232,7 +254,12 @@ struct HexT {
     for (int i = 0; i < NW; ++i) v |= a.w[i];
     return v != 0;
   }
-  OSG_D static bool test(const Bits& a, int c) { return (a.w[c >> 5] >> (c & 31)) & 1u; }
+  OSG_D static bool test(const Bits& a, int c) {  // select, not a.w[c >> 5]: keeps Bits in VGPRs
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) v |= (i == (c >> 5)) ? a.w[i] : 0u;
+    return (v >> (c & 31)) & 1u;
+  }
   OSG_D static Bits single(int c) {
     Bits b = zero();
 #pragma unroll

@@ -167,6 +167,7 @@ int parse_game(const char* game_string, GameSpec* out) {
     d.state_words = 2; d.state_word_bytes = 8;
     C4::Params& p = out->c4;
     p.words = 2; p.rows = rows; p.cols = cols; p.k = k; p.ego = ego;
+    out->c4_std = (rows == 6 && cols == 7 && k == 4);
     p.board = 0; p.top = 0;
     for (int c = 0; c < cols; ++c) {
       p.board |= ((1ull << rows) - 1ull) << (c * (rows + 1));

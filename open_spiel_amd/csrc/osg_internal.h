@@ -21,6 +21,7 @@ enum GameKind { kTtt = 0, kC4 = 1, kHex = 2, kKuhn = 3, kLeduc = 4 };
 struct GameSpec {
   osg_game_desc desc;
   int hex_nw = 0;  // u32 words per hex bit plane (1..4)
+  bool c4_std = false;  // connect_four with the default 6x7x4 geometry (constant-folded kernels)
   Ttt::Params ttt;
   C4::Params c4;
   HexT<1>::Params hex1;
@@ -69,7 +70,10 @@ struct osg_batch {
   do {                                                                             \
     switch ((spec).desc.game_kind) {                                               \
       case osg::kTtt: { using G = osg::Ttt; const G::Params& P = (spec).ttt; __VA_ARGS__; } break; \
-      case osg::kC4: { using G = osg::C4; const G::Params& P = (spec).c4; __VA_ARGS__; } break;    \
+      case osg::kC4:                                                               \
+        if ((spec).c4_std) { using G = osg::C4Std; const G::Params& P = (spec).c4; __VA_ARGS__; } \
+        else { using G = osg::C4; const G::Params& P = (spec).c4; __VA_ARGS__; }   \
+        break;                                                                     \
       case osg::kKuhn: { using G = osg::Kuhn; const G::Params& P = (spec).kuhn; __VA_ARGS__; } break; \
       case osg::kLeduc: { using G = osg::Leduc; const G::Params& P = (spec).leduc; __VA_ARGS__; } break; \
       case osg::kHex:                                                              \

@@ -123,6 +123,55 @@ k_step(typename G::Params p, const typename G::word_t* src, typename G::word_t* 
   status[i] = encode_status(term, illegal, term ? 0 : G::current_player(p, s), term ? G::outcome_code(p, s) : 0);
 }
 
+// connect_four fast path of the fused step: TWO consecutive states per thread so
+// that every state access is one 16-byte vector load/store per lane per plane
+// (1 KiB per wave-instruction, the coalescing sweet spot); actions / masks /
+// statuses move as u16.  Line tests are done once before the move and once for
+// the mover after it (only the mover's stones changed).
+template <class G>
+__global__ void __launch_bounds__(kBlock)
+k_step_c4x2(typename G::Params p, const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, int64_t n,
+            const uint8_t* __restrict__ actions, uint8_t* __restrict__ mask_out, uint8_t* __restrict__ status) {
+  const int64_t pair = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t i = pair * 2;
+  if (i >= n) return;
+  const ulonglong2 xs = *reinterpret_cast<const ulonglong2*>(src + i);
+  const ulonglong2 os = *reinterpret_cast<const ulonglong2*>(src + n + i);
+  const uint32_t a2 = *reinterpret_cast<const uint16_t*>(actions + i);
+  uint64_t x[2] = {xs.x, xs.y}, o[2] = {os.x, os.y};
+  uint32_t m2 = 0, s2 = 0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    typename G::State s{x[j], o[j]};
+    const int a = (a2 >> (8 * j)) & 0xFF;
+    const bool win_x = G::line(p, s.x), win_o = G::line(p, s.o);
+    bool term = win_x | win_o | G::full(p, s);
+    int outcome = win_x ? 0 : (win_o ? 1 : 2);
+    bool illegal = false;
+    if (a != 0xFF) {
+      const uint32_t open = term ? 0u : G::open_columns(p, s);
+      if (a < 32 && ((open >> a) & 1u)) {
+        const int mover = G::plies(s) & 1;
+        G::apply(p, s, a);
+        const bool win = G::line(p, mover ? s.o : s.x);
+        term = win | G::full(p, s);
+        outcome = win ? mover : 2;
+      } else {
+        illegal = true;
+      }
+    }
+    x[j] = s.x;
+    o[j] = s.o;
+    const uint32_t after = term ? 0u : G::open_columns(p, s);
+    m2 |= (after & 0xFFu) << (8 * j);
+    s2 |= static_cast<uint32_t>(encode_status(term, illegal, term ? 0 : (G::plies(s) & 1), term ? outcome : 0)) << (8 * j);
+  }
+  *reinterpret_cast<ulonglong2*>(dst + i) = make_ulonglong2(x[0], x[1]);
+  *reinterpret_cast<ulonglong2*>(dst + n + i) = make_ulonglong2(o[0], o[1]);
+  *reinterpret_cast<uint16_t*>(mask_out + i) = static_cast<uint16_t>(m2);
+  *reinterpret_cast<uint16_t*>(status + i) = static_cast<uint16_t>(s2);
+}
+
 // Observation / information-state tensors: write-bound ([n, size] fp32).  One
 // thread per OUTPUT element so consecutive lanes write consecutive floats
 // (coalesced 256 B per wave); the few state words are re-read through L1/L2.
@@ -479,6 +528,22 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
   const int cmb = src->spec.desc.compact_mask_bytes;
   const int W = src->spec.desc.mask_words;
   const int64_t n = src->n;
+  const bool aligned2 = ((reinterpret_cast<uintptr_t>(d_actions) | reinterpret_cast<uintptr_t>(d_mask) |
+                          reinterpret_cast<uintptr_t>(d_status)) & 1u) == 0;
+  if (src->spec.desc.game_kind == kC4 && (n & 1) == 0 && aligned2) {
+    const int64_t pairs = n / 2;
+    if (src->spec.c4_std) {
+      k_step_c4x2<C4Std><<<dim3(grid_for(pairs)), dim3(kBlock), 0, ctx->stream>>>(
+          src->spec.c4, static_cast<const uint64_t*>(src->d_words), static_cast<uint64_t*>(dst->d_words), n, d_actions,
+          static_cast<uint8_t*>(d_mask), d_status);
+    } else {
+      k_step_c4x2<C4><<<dim3(grid_for(pairs)), dim3(kBlock), 0, ctx->stream>>>(
+          src->spec.c4, static_cast<const uint64_t*>(src->d_words), static_cast<uint64_t*>(dst->d_words), n, d_actions,
+          static_cast<uint8_t*>(d_mask), d_status);
+    }
+    OSG_HIP(hipGetLastError());
+    return OSG_OK;
+  }
   if (cmb == 1) {
     OSG_DISPATCH(src->spec, k_step<G, uint8_t><<<dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream>>>(P, static_cast<const typename G::word_t*>(src->d_words),
                                                 static_cast<typename G::word_t*>(dst->d_words), n, d_actions,

@@ -1,5 +1,346 @@
-// MCTS on the device (placeholder until the wavefront search lands this round).
+// algorithms::MCTSBot (open_spiel/algorithms/mcts.{h,cc}) for a batch of roots.
+//
+// Mapping: ONE LANE PER ROOT.  A search is a strictly sequential chain
+// (simulation s+1 reads the statistics simulation s wrote), and with
+// RandomRolloutEvaluator the chain is dominated by the random playout, which is
+// itself sequential.  The SIMT-efficient unit of parallelism is therefore the
+// root: 64 independent searches per wavefront, every lane running the same
+// select / expand / rollout / backup code on its own tree.  (A wave-per-root
+// layout with children spread over lanes keeps 63 of 64 lanes idle during the
+// playout, which is >90 % of the work; see DESIGN.md.)
+//
+// Tree storage in HBM: a node pool of `cap` nodes per root, struct-of-arrays and
+// node-major / root-minor (field[node * n_roots + root]) so that lanes of a wave
+// touching the same node slot (the common case near the root) coalesce.
+//   meta   u32  action | (player+1)<<8 | nchild<<12 | has_outcome<<20 | code<<21 | terminal<<23
+//   first  u32  index of the first child (children are contiguous)
+//   parent u32
+//   count  u32  explore_count
+//   total  f64  total_reward
+#include <cmath>
+#include <vector>
+
 #include "osg_internal.h"
-extern "C" int osg_mcts_search(const osg_batch*, const osg_mcts_cfg*, int32_t*, int32_t*, double*, int8_t*, double*, int) {
-  return osg::set_error(OSG_ERR_UNSUPPORTED, "osg_mcts_search: not implemented yet");
+
+using namespace osg;
+
+namespace {
+
+constexpr int kBlockM = 64;  // one wave per block: searches differ in length, keep blocks small
+constexpr uint64_t kTreeSalt = 0x7265655F73616C74ULL;  // stream separation for the tree-policy RNG
+constexpr uint32_t kNoNode = 0xFFFFFFFFu;
+
+struct Pool {
+  uint32_t* meta;
+  uint32_t* first;
+  uint32_t* parent;
+  uint32_t* count;
+  double* total;
+  int64_t n_roots;
+  int cap;
+};
+
+OSG_D uint32_t m_action(uint32_t m) { return m & 0xFFu; }
+OSG_D int m_player(uint32_t m) { return static_cast<int>((m >> 8) & 15u) - 1; }
+OSG_D int m_nchild(uint32_t m) { return static_cast<int>((m >> 12) & 0xFFu); }
+OSG_D bool m_has_outcome(uint32_t m) { return (m >> 20) & 1u; }
+OSG_D int m_code(uint32_t m) { return static_cast<int>((m >> 21) & 3u); }  // p0 value + 1
+OSG_D bool m_terminal(uint32_t m) { return (m >> 23) & 1u; }
+OSG_D uint32_t make_meta(int action, int player, int nchild) {
+  return static_cast<uint32_t>(action & 0xFF) | (static_cast<uint32_t>(player + 1) << 8) |
+         (static_cast<uint32_t>(nchild) << 12);
+}
+
+// outcome[player] of a node that has one (mcts.cc:90-93): exact for the board
+// games (code), total/N for terminal nodes of the poker games.
+template <bool kBoard>
+OSG_D double outcome_value(uint32_t meta, uint32_t count, double total, int player) {
+  if (kBoard) {
+    double v0 = static_cast<double>(m_code(meta) - 1);
+    return player == 0 ? v0 : -v0;
+  }
+  return total / static_cast<double>(count);
+}
+
+template <class G, bool kBoard>
+__global__ void __launch_bounds__(kBlockM)
+k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, int num_actions,
+       osg_mcts_cfg cfg, double max_utility, const double* __restrict__ log_table, Pool pool, int32_t* best_action,
+       int32_t* child_visits, double* child_reward, int8_t* child_outcome, double* root_stats) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlockM + threadIdx.x;
+  if (r >= n) return;
+  const uint64_t gr = static_cast<uint64_t>(cfg.index_offset + r);
+  const int64_t NR = pool.n_roots;
+#define META(i) pool.meta[static_cast<int64_t>(i) * NR + r]
+#define FIRST(i) pool.first[static_cast<int64_t>(i) * NR + r]
+#define PARENT(i) pool.parent[static_cast<int64_t>(i) * NR + r]
+#define COUNT(i) pool.count[static_cast<int64_t>(i) * NR + r]
+#define TOTAL(i) pool.total[static_cast<int64_t>(i) * NR + r]
+
+  const typename G::State root_state = G::load(p, base, n, r);
+  const int root_player = G::current_player(p, root_state);
+  META(0) = make_meta(0xFF, root_player, 0);  // mcts.cc:356-357: root = (kInvalidAction, CurrentPlayer(), 1)
+  FIRST(0) = 0; PARENT(0) = kNoNode; COUNT(0) = 0; TOTAL(0) = 0.0;
+  uint32_t used = 1;
+  int sims_done = 0;
+
+  for (int sim = 0; sim < cfg.max_simulations; ++sim) {
+    Rng trng(cfg.seed ^ kTreeSalt, gr, static_cast<uint64_t>(sim));
+    // ---- ApplyTreePolicy (mcts.cc:273-351) ----
+    typename G::State s = root_state;
+    uint32_t node = 0;
+    bool term;
+    for (;;) {
+      term = G::terminal(p, s);
+      const uint32_t cnt = COUNT(node);
+      if (term || cnt == 0) break;
+      uint32_t meta = META(node);
+      const int cur = G::current_player(p, s);
+      if (m_nchild(meta) == 0) {  // expand: children = Prior(state), shuffled (mcts.cc:281-299)
+        const Mask legal = G::legal(p, s);
+        const int c = legal.count();
+        if (used + static_cast<uint32_t>(c) > static_cast<uint32_t>(pool.cap)) break;  // pool exhausted: evaluate as a leaf
+        const uint32_t first = used;
+        used += c;
+        for (int k = 0; k < c; ++k) {
+          META(first + k) = make_meta(select_action(legal, k), cur, 0);
+          FIRST(first + k) = 0; PARENT(first + k) = node; COUNT(first + k) = 0; TOTAL(first + k) = 0.0;
+        }
+        for (int i = c - 1; i >= 1; --i) {  // Fisher-Yates == std::shuffle's role (order only)
+          const int j = static_cast<int>(trng.below(static_cast<uint32_t>(i + 1)));
+          const uint32_t mi = META(first + i), mj = META(first + j);
+          META(first + i) = mj;
+          META(first + j) = mi;
+        }
+        meta = make_meta(m_action(meta), m_player(meta), c) | (meta & 0x00F00000u);
+        META(node) = meta;
+        FIRST(node) = first;
+      }
+      const uint32_t first = FIRST(node);
+      const int c = m_nchild(meta);
+      uint32_t chosen = first;
+      if (cur == kChancePlayer) {  // mcts.cc:311-322
+        const Mask legal = G::legal(p, s);
+        const int a = sample_action_chance<G>(p, s, legal, trng);
+        for (int k = 0; k < c; ++k)
+          if (static_cast<int>(m_action(META(first + k))) == a) { chosen = first + k; break; }
+      } else {  // arg-max of UCTValue, first maximum wins (mcts.cc:324-341, 90-101)
+        double best = -INFINITY;
+        const double logn = log_table[cnt];
+        for (int k = 0; k < c; ++k) {
+          const uint32_t cm = META(first + k);
+          const uint32_t cc = COUNT(first + k);
+          double v;
+          if (m_has_outcome(cm)) v = outcome_value<kBoard>(cm, cc, TOTAL(first + k), m_player(cm));
+          else if (cc == 0) v = INFINITY;
+          else v = TOTAL(first + k) / cc + cfg.uct_c * sqrt(logn / cc);
+          if (v > best) { best = v; chosen = first + k; }
+        }
+      }
+      G::apply(p, s, static_cast<int>(m_action(META(chosen))));
+      node = chosen;
+    }
+    // ---- evaluate (mcts.cc:372-381) ----
+    double returns[kMaxPlayers];
+    bool solved = false;
+    if (term) {
+      G::returns(p, s, returns);
+      uint32_t meta = META(node) | (1u << 20) | (1u << 23);
+      if (kBoard) meta = (meta & ~(3u << 21)) | (static_cast<uint32_t>(static_cast<int>(returns[0]) + 1) << 21);
+      META(node) = meta;
+      solved = cfg.solve != 0;
+    } else {  // RandomRolloutEvaluator::Evaluate (mcts.cc:43-72)
+      for (int q = 0; q < num_players; ++q) returns[q] = 0.0;
+      for (int ro = 0; ro < cfg.n_rollouts; ++ro) {
+        Rng rng(cfg.seed, gr, static_cast<uint64_t>(sim) * cfg.n_rollouts + ro);
+        typename G::State w = s;
+        while (!G::terminal(p, w)) {
+          const Mask m = G::legal(p, w);
+          G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
+        }
+        double rr[kMaxPlayers];
+        G::returns(p, w, rr);
+        for (int q = 0; q < num_players; ++q) returns[q] += rr[q];
+      }
+      for (int q = 0; q < num_players; ++q) returns[q] /= cfg.n_rollouts;
+    }
+    // ---- backup (mcts.cc:383-435) ----
+    for (uint32_t v = node; v != kNoNode; v = PARENT(v)) {
+      uint32_t meta = META(v);
+      int pl = m_player(meta);
+      for (uint32_t up = v; pl == kChancePlayer;) {  // chance node: use the parent decision player
+        up = PARENT(up);
+        if (up == kNoNode) { pl = 0; break; }
+        pl = m_player(META(up));
+      }
+      TOTAL(v) += returns[pl < 0 ? 0 : pl];
+      COUNT(v) += 1;
+      if (kBoard && solved && m_nchild(meta) > 0) {  // MCTS-Solver, max^n over proven children
+        const uint32_t first = FIRST(v);
+        const int c = m_nchild(meta);
+        const int mover = m_player(META(first));
+        bool all_solved = true, have = false;
+        double best = 0.0;
+        int best_code = 0;
+        for (int k = 0; k < c; ++k) {
+          const uint32_t cm = META(first + k);
+          if (!m_has_outcome(cm)) { all_solved = false; continue; }
+          const double val = outcome_value<true>(cm, 1, 0.0, mover);
+          if (!have || val > best) { have = true; best = val; best_code = m_code(cm); }
+        }
+        if (have && (all_solved || best == max_utility)) {
+          META(v) = (meta & ~(3u << 21)) | (1u << 20) | (static_cast<uint32_t>(best_code) << 21);
+        } else {
+          solved = false;
+        }
+      } else if (!kBoard) {
+        solved = false;
+      }
+    }
+    ++sims_done;
+    const uint32_t rm = META(0);
+    if ((m_has_outcome(rm) && !m_terminal(rm)) || m_nchild(rm) == 1) break;  // mcts.cc:437-440
+    if (m_terminal(rm)) break;  // a terminal root: nothing to search
+  }
+
+  // ---- results: BestChild by CompareFinal (mcts.cc:114-143) + per-action statistics ----
+  const uint32_t rm = META(0);
+  const int c = m_nchild(rm);
+  const uint32_t first = FIRST(0);
+  if (child_visits) for (int a = 0; a < num_actions; ++a) child_visits[r * num_actions + a] = 0;
+  if (child_reward) for (int a = 0; a < num_actions; ++a) child_reward[r * num_actions + a] = 0.0;
+  if (child_outcome) for (int a = 0; a < num_actions; ++a) child_outcome[r * num_actions + a] = 3;
+  int best = -1;
+  double b_out = 0.0, b_tot = 0.0;
+  uint32_t b_cnt = 0;
+  for (int k = 0; k < c; ++k) {
+    const uint32_t cm = META(first + k);
+    const uint32_t cc = COUNT(first + k);
+    const double ct = TOTAL(first + k);
+    const int a = static_cast<int>(m_action(cm));
+    const bool has = m_has_outcome(cm);
+    const int pl = m_player(cm);
+    const double out = (has && pl >= 0 && cc > 0) ? outcome_value<kBoard>(cm, cc, ct, pl)
+                                                  : ((has && kBoard && pl >= 0) ? outcome_value<true>(cm, 1, 0.0, pl) : 0.0);
+    // strict "a < b" ordering, first maximum kept (std::max_element)
+    const bool better = best < 0 || (b_out != out ? b_out < out : (b_cnt != cc ? b_cnt < cc : b_tot < ct));
+    if (better) { best = a; b_out = out; b_cnt = cc; b_tot = ct; }
+    if (a < num_actions) {
+      if (child_visits) child_visits[r * num_actions + a] = static_cast<int32_t>(cc);
+      if (child_reward) child_reward[r * num_actions + a] = ct;
+      if (child_outcome) {
+        int8_t code = 2;
+        if (has && kBoard && root_player >= 0) code = static_cast<int8_t>(outcome_value<true>(cm, 1, 0.0, root_player));
+        child_outcome[r * num_actions + a] = code;
+      }
+    }
+  }
+  if (best_action) best_action[r] = best;
+  if (root_stats) {
+    root_stats[r * 4 + 0] = static_cast<double>(COUNT(0));
+    root_stats[r * 4 + 1] = static_cast<double>(used);
+    root_stats[r * 4 + 2] = (kBoard && m_has_outcome(rm) && root_player >= 0) ? outcome_value<true>(rm, 1, 0.0, root_player)
+                                                                              : NAN;
+    root_stats[r * 4 + 3] = static_cast<double>(sims_done);
+  }
+#undef META
+#undef FIRST
+#undef PARENT
+#undef COUNT
+#undef TOTAL
+}
+
+}  // namespace
+
+extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_in, int32_t* best_action,
+                               int32_t* child_visits, double* child_reward, int8_t* child_outcome,
+                               double* root_stats, int on_host) {
+  if (!roots || !cfg_in) return set_error(OSG_ERR_INVALID, "osg_mcts_search: null argument");
+  osg_ctx* ctx = roots->ctx;
+  osg_mcts_cfg cfg = *cfg_in;
+  const osg_game_desc& d = roots->spec.desc;
+  const bool board = d.game_kind <= kHex;
+  if (cfg.max_simulations < 1 || cfg.n_rollouts < 1) return set_error(OSG_ERR_INVALID, "max_simulations and n_rollouts must be >= 1");
+  if (cfg.solve && !board)
+    return set_error(OSG_ERR_UNSUPPORTED, "solve=true needs win/draw/loss outcomes (tic_tac_toe, connect_four, hex)");
+  const int64_t n = roots->n;
+  const int A = d.num_distinct_actions;
+  const int widest = A > d.max_chance_outcomes ? A : d.max_chance_outcomes;
+  int64_t cap = cfg.max_nodes > 0 ? cfg.max_nodes : 1 + static_cast<int64_t>(cfg.max_simulations) * widest;
+  if (cfg.max_nodes <= 0 && cap > 16384) cap = 16384;
+  if (cap < 1 + widest) cap = 1 + widest;
+  // keep the pool inside the free HBM (24 B per node)
+  size_t free_b = 0, total_b = 0;
+  OSG_HIP(hipMemGetInfo(&free_b, &total_b));
+  const size_t per_node = 24;
+  while (static_cast<size_t>(cap) * n * per_node > free_b * 9 / 10 && cap > 1 + widest) cap = cap / 2 + widest;
+  cfg.max_nodes = static_cast<int32_t>(cap);
+
+  const size_t slots = static_cast<size_t>(cap) * n;
+  char* pool_mem = nullptr;
+  hipError_t e = hipMalloc(&pool_mem, slots * per_node);
+  if (e != hipSuccess) return set_error(OSG_ERR_NOMEM, std::string("MCTS node pool: ") + hipGetErrorString(e));
+  Pool pool;
+  pool.total = reinterpret_cast<double*>(pool_mem);
+  pool.meta = reinterpret_cast<uint32_t*>(pool_mem + slots * 8);
+  pool.first = pool.meta + slots;
+  pool.parent = pool.first + slots;
+  pool.count = pool.parent + slots;
+  pool.n_roots = n;
+  pool.cap = static_cast<int>(cap);
+
+  // log(parent explore_count) from the host libm: the CPU oracle (and the
+  // reference) call std::log, so sharing the table makes UCT values bit-equal.
+  std::vector<double> logs(cfg.max_simulations + 2);
+  logs[0] = 0.0;
+  for (int i = 1; i < static_cast<int>(logs.size()); ++i) logs[i] = std::log(static_cast<double>(i));
+  double* d_logs = nullptr;
+  e = hipMalloc(&d_logs, logs.size() * sizeof(double));
+  if (e != hipSuccess) { (void)hipFree(pool_mem); return set_error(OSG_ERR_NOMEM, hipGetErrorString(e)); }
+  OSG_HIP(hipMemcpyAsync(d_logs, logs.data(), logs.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+
+  // host-side outputs are staged through scratch
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~static_cast<size_t>(255); return o; };
+  const size_t o_best = carve(sizeof(int32_t) * n), o_vis = carve(sizeof(int32_t) * n * A),
+               o_rew = carve(sizeof(double) * n * A), o_out = carve(static_cast<size_t>(n) * A),
+               o_stats = carve(sizeof(double) * n * 4);
+  int32_t* d_best = best_action; int32_t* d_vis = child_visits; double* d_rew = child_reward;
+  int8_t* d_out = child_outcome; double* d_stats = root_stats;
+  if (on_host) {
+    void* scratch = nullptr;
+    int rc = osg_ctx_scratch(ctx, off, &scratch);
+    if (rc) { (void)hipFree(pool_mem); (void)hipFree(d_logs); return rc; }
+    char* sc = static_cast<char*>(scratch);
+    d_best = best_action ? reinterpret_cast<int32_t*>(sc + o_best) : nullptr;
+    d_vis = child_visits ? reinterpret_cast<int32_t*>(sc + o_vis) : nullptr;
+    d_rew = child_reward ? reinterpret_cast<double*>(sc + o_rew) : nullptr;
+    d_out = child_outcome ? reinterpret_cast<int8_t*>(sc + o_out) : nullptr;
+    d_stats = root_stats ? reinterpret_cast<double*>(sc + o_stats) : nullptr;
+  }
+  const unsigned grid = static_cast<unsigned>((n + kBlockM - 1) / kBlockM);
+  if (board) {
+    OSG_DISPATCH(roots->spec, k_mcts<G, true><<<dim3(grid), dim3(kBlockM), 0, ctx->stream>>>(
+                                  P, static_cast<const typename G::word_t*>(roots->d_words), n, d.num_players, A, cfg,
+                                  d.max_utility, d_logs, pool, d_best, d_vis, d_rew, d_out, d_stats));
+  } else {
+    OSG_DISPATCH(roots->spec, k_mcts<G, false><<<dim3(grid), dim3(kBlockM), 0, ctx->stream>>>(
+                                  P, static_cast<const typename G::word_t*>(roots->d_words), n, d.num_players, A, cfg,
+                                  d.max_utility, d_logs, pool, d_best, d_vis, d_rew, d_out, d_stats));
+  }
+  hipError_t launch = hipGetLastError();
+  if (on_host && launch == hipSuccess) {
+    if (best_action) (void)hipMemcpyAsync(best_action, d_best, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (child_visits) (void)hipMemcpyAsync(child_visits, d_vis, sizeof(int32_t) * n * A, hipMemcpyDeviceToHost, ctx->stream);
+    if (child_reward) (void)hipMemcpyAsync(child_reward, d_rew, sizeof(double) * n * A, hipMemcpyDeviceToHost, ctx->stream);
+    if (child_outcome) (void)hipMemcpyAsync(child_outcome, d_out, static_cast<size_t>(n) * A, hipMemcpyDeviceToHost, ctx->stream);
+    if (root_stats) (void)hipMemcpyAsync(root_stats, d_stats, sizeof(double) * n * 4, hipMemcpyDeviceToHost, ctx->stream);
+  }
+  // The pool is private to this call: wait for the search, then release it.
+  hipError_t sync = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(pool_mem);
+  (void)hipFree(d_logs);
+  if (launch != hipSuccess) return set_error(OSG_ERR_HIP, hipGetErrorString(launch));
+  if (sync != hipSuccess) return set_error(OSG_ERR_HIP, hipGetErrorString(sync));
+  return OSG_OK;
 }

@@ -12,6 +12,7 @@
 #include "osg_common.h"
 #include "osg_game_boards.h"
 #include "osg_game_poker.h"
+#include "osg_sample.h"
 
 namespace osg {
 

@@ -192,29 +192,6 @@ k_observation(typename G::Params p, const typename G::word_t* base, int64_t n, i
   out[e] = G::obs_at(p, s, pl, which, idx);
 }
 
-// Draw a legal action like the oracle: chance nodes by SampleAction's CDF scan
-// over ChanceOutcomes() with z = rng.unit() (spiel.cc:372-409), decision nodes
-// uniformly over LegalActions() with rng.below(count) (mcts.cc:51-55).
-template <class G>
-OSG_D int sample_action(const typename G::Params& p, const typename G::State& s, const Mask& m, int cur, Rng& rng) {
-  if (cur == kChancePlayer) {
-    int cnt = m.count();
-    if (cnt == 1) return select_action(m, 0);
-    double z = rng.unit();
-    double acc = 0.0;
-    int last = -1;
-    for (int k = 0; k < cnt; ++k) {
-      int o = select_action(m, k);
-      double pr = G::chance_prob(p, s, o);
-      if (acc <= z && z < acc + pr) return o;
-      acc += pr;
-      last = o;
-    }
-    return last;  // unreachable for a valid distribution
-  }
-  return select_action(m, static_cast<int>(rng.below(static_cast<uint32_t>(m.count()))));
-}
-
 template <class G>
 __global__ void __launch_bounds__(kBlock)
 k_random_steps(typename G::Params p, typename G::word_t* base, int64_t n, uint64_t seed, int64_t index_offset,

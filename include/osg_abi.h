@@ -191,6 +191,10 @@ typedef struct {
   int32_t alternating_updates;   /* CFRSolverBase ctor (cfr.h:190-196)            */
   int32_t linear_averaging;
   int32_t regret_matching_plus;
+  int32_t solver;                /* 0: CFRSolverBase family, tables start at 0 (cfr.h:47-52);
+                                    1: ExternalSamplingMCCFRSolver, regrets and cumulative policy
+                                       start at kInitialTableValues = 1e-6
+                                       (external_sampling_mccfr.h:59, .cc:142-143)              */
 } osg_cfr_cfg;
 /* Replaces CFRSolverBase::CFRSolverBase + InitializeInfostateNodes
  * (cfr.cc:191-261): expands the whole game tree level by level ON THE DEVICE
@@ -200,14 +204,23 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
 int osg_cfr_destroy(osg_cfr* s);
 /* out[0..5] = histories, chance nodes, decision nodes, terminal nodes, infostates, Amax */
 int osg_cfr_sizes(const osg_cfr* s, int64_t* out);
-/* CFRSolverBase::EvaluateAndUpdatePolicy x iters (cfr.cc:263-282). */
+/* Back to iteration 0 with freshly initialised tables. */
+int osg_cfr_reset(osg_cfr* s);
+/* CFRSolverBase::EvaluateAndUpdatePolicy x iters (cfr.cc:263-282): one launch, all iterations. */
 int osg_cfr_iterate(osg_cfr* s, int iters);
+/* Number of EvaluateAndUpdatePolicy calls (or MCCFR mini-batches) done so far. */
+int osg_cfr_iteration(const osg_cfr* s);
 /* ExternalSamplingMCCFRSolver::RunIteration (external_sampling_mccfr.cc:71-186,
  * AverageType::kSimple) for `trajectories` traverser passes (player = global
  * trajectory index mod P), mini-batched: every trajectory of one call reads the
  * tables as they were at the start of the call and adds its deltas atomically.
  * Tables start at kInitialTableValues = 1e-6 (external_sampling_mccfr.h:59). */
 int osg_mccfr_iterate(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_t trajectories);
+/* The sampling half of osg_mccfr_iterate: zero the delta tables, run the traversals,
+ * leave the regret / average-policy deltas in the delta tables (osg_mccfr_delta_ptrs)
+ * WITHOUT folding them in.  Trajectory g (global index) draws from the counter stream
+ * (seed, g) and updates player g mod P, so a batch can be split across GPUs by index. */
+int osg_mccfr_sample(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_t trajectories);
 /* Device pointers to the [I, Amax] fp64 tables: regrets, cumulative policy,
  * current policy (for RCCL all-reduce by the caller, or inspection). */
 int osg_cfr_table_ptrs(osg_cfr* s, double** d_regrets, double** d_cum_policy, double** d_cur_policy);
@@ -215,6 +228,10 @@ int osg_cfr_table_ptrs(osg_cfr* s, double** d_regrets, double** d_cum_policy, do
  * [I, Amax] buffers; the caller all-reduces them (RCCL) and then folds them in. */
 int osg_mccfr_delta_ptrs(osg_cfr* s, double** d_regret_delta, double** d_policy_delta);
 int osg_mccfr_apply_deltas(osg_cfr* s);
+/* Overwrite the [I, Amax] tables from host arrays (any may be NULL): restores a
+ * checkpoint / CFRInfoStateValuesTable (cfr.cc:723-777 deserialisation target). */
+int osg_cfr_upload_tables(osg_cfr* s, const double* h_regrets, const double* h_cum_policy,
+                          const double* h_cur_policy);
 /* CFRInfoStateValuesTable rows (cfr.h:42-104) to the host: arrays [I, Amax] (padding 0),
  * nact[I], legal[I, Amax] (padding -1), avg_policy per cfr.cc:104-125. Any may be NULL. */
 int osg_cfr_tables(const osg_cfr* s, int32_t* nact, int32_t* legal, double* regrets,

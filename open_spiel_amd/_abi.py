@@ -56,6 +56,7 @@ class CfrCfg(C.Structure):
         ("alternating_updates", C.c_int32),
         ("linear_averaging", C.c_int32),
         ("regret_matching_plus", C.c_int32),
+        ("solver", C.c_int32),
     ]
 
 
@@ -95,6 +96,10 @@ SIGNATURES = {
     "osg_cfr_destroy": (INT, [VP]),
     "osg_cfr_sizes": (INT, [VP, C.POINTER(I64)]),
     "osg_cfr_iterate": (INT, [VP, INT]),
+    "osg_cfr_reset": (INT, [VP]),
+    "osg_cfr_iteration": (INT, [VP]),
+    "osg_mccfr_sample": (INT, [VP, U64, I64, I64]),
+    "osg_cfr_upload_tables": (INT, [VP, VP, VP, VP]),
     "osg_mccfr_iterate": (INT, [VP, U64, I64, I64]),
     "osg_cfr_table_ptrs": (INT, [VP, C.POINTER(VP), C.POINTER(VP), C.POINTER(VP)]),
     "osg_mccfr_delta_ptrs": (INT, [VP, C.POINTER(VP), C.POINTER(VP)]),

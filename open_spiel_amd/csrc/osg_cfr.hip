@@ -1,15 +1,773 @@
-// Tabular CFR on the device (placeholder until the kernels land this round).
+// Tabular CFR / CFR+ (open_spiel/algorithms/cfr.{h,cc}) and external-sampling
+// MCCFR (open_spiel/algorithms/external_sampling_mccfr.{h,cc}) on the device.
+//
+// The reference walks the game tree recursively, cloning a State per edge and
+// looking infostates up by string (cfr.cc:331-408,443-469).  Here the tree is
+// flattened ONCE, level by level, by the batched step kernels themselves
+// (osg_legal_mask / osg_status_query / osg_batch_gather / osg_apply), and every
+// iteration is arithmetic over flat arrays:
+//
+//   histories   level-ordered (BFS); children of a node are contiguous
+//   per node    kind (chance / decision / terminal), actor, parent, first_child,
+//               nchild, edge index within the parent, infostate id,
+//               chance probability of the incoming edge, terminal returns [P]
+//   infostates  [I, Amax] fp64 tables: cumulative regrets, cumulative policy,
+//               current policy (CFRInfoStateValues, cfr.h:42-98); member
+//               histories listed in the reference's DFS visiting order
+//
+// k_cfr runs a whole batch of iterations in ONE launch by ONE workgroup:
+// top-down reach pass, bottom-up value pass (one __syncthreads per tree level),
+// then one thread per infostate folds its member histories' regret / average
+// policy terms in DFS order — the same additions in the same order as the
+// reference's recursion, so the tables are bit-comparable with the CPU oracle
+// (both sides are compiled with -ffp-contract=off).  Small trees (kuhn) keep
+// reach / values / tables in LDS; larger ones (leduc: 9 457 histories) keep
+// them in global memory, which is L2-resident at these sizes.
+//
+// k_mccfr runs one external-sampling traversal per thread with an explicit
+// stack over the same flat tree; regret / average-policy deltas are accumulated
+// per workgroup in LDS and flushed with fp64 atomics, so that a multi-GPU job
+// can all-reduce the [I, Amax] delta tables once per mini-batch (RCCL) before
+// every rank folds them in.
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
 #include "osg_internal.h"
-#define NYI(name) return osg::set_error(OSG_ERR_UNSUPPORTED, name ": not implemented yet")
-extern "C" {
-int osg_cfr_create(osg_ctx*, const char*, const osg_cfr_cfg*, osg_cfr**) { NYI("osg_cfr_create"); }
-int osg_cfr_destroy(osg_cfr*) { return OSG_OK; }
-int osg_cfr_sizes(const osg_cfr*, int64_t*) { NYI("osg_cfr_sizes"); }
-int osg_cfr_iterate(osg_cfr*, int) { NYI("osg_cfr_iterate"); }
-int osg_mccfr_iterate(osg_cfr*, uint64_t, int64_t, int64_t) { NYI("osg_mccfr_iterate"); }
-int osg_cfr_table_ptrs(osg_cfr*, double**, double**, double**) { NYI("osg_cfr_table_ptrs"); }
-int osg_mccfr_delta_ptrs(osg_cfr*, double**, double**) { NYI("osg_mccfr_delta_ptrs"); }
-int osg_mccfr_apply_deltas(osg_cfr*) { NYI("osg_mccfr_apply_deltas"); }
-int osg_cfr_tables(const osg_cfr*, int32_t*, int32_t*, double*, double*, double*, double*) { NYI("osg_cfr_tables"); }
-int osg_cfr_infostate_key(const osg_cfr*, int64_t, char*, int) { NYI("osg_cfr_infostate_key"); }
+
+using namespace osg;
+
+namespace {
+
+constexpr int kMaxA = 4;        // widest decision node the MCCFR frame holds (kuhn 2, leduc 3)
+constexpr int kMaxFrames = 24;  // traverser decision nodes on one path
+constexpr double kMccfrInit = 0.000001;  // external_sampling_mccfr.h:59 kInitialTableValues
+
+enum NodeKind : uint8_t { kChanceNode = 0, kDecisionNode = 1, kTerminalNode = 2 };
+
+struct Tree {  // device pointers
+  int H, I, A, P, D;
+  const int32_t* level_off;    // [D+1]
+  const int32_t* parent;       // [H]
+  const int32_t* first_child;  // [H]
+  const uint8_t* kind;         // [H]
+  const uint8_t* nchild;       // [H]
+  const uint8_t* aidx;         // [H] index of the incoming edge among the parent's children
+  const int8_t* actor;         // [H] acting player, -1 at chance / terminal nodes
+  const int32_t* info;         // [H] infostate id of a decision node, else -1
+  const double* edge_prob;     // [H] chance probability of the incoming edge (parent is chance)
+  const double* term_ret;      // [H, P] Returns() of terminal nodes
+  const int32_t* mem_off;      // [I+1]
+  const int32_t* mem;          // member histories of every infostate, DFS order
+  const int32_t* nact;         // [I]
+  const int8_t* info_player;   // [I]
+};
+
+struct Tables {  // [I, A] fp64
+  double* regrets;
+  double* cum;
+  double* cur;
+};
+
+// ---------------------------------------------------------------------------
+// CFRInfoStateValues::ApplyRegretMatching (cfr.cc:596-615) on one row.
+// ---------------------------------------------------------------------------
+OSG_D void regret_match_row(const double* regrets, double* policy, int n) {
+  double sum_pos = 0.0;
+  for (int a = 0; a < n; ++a)
+    if (regrets[a] > 0) sum_pos += regrets[a];
+  for (int a = 0; a < n; ++a) {
+    if (sum_pos > 0) policy[a] = regrets[a] > 0 ? regrets[a] / sum_pos : 0.0;
+    else policy[a] = 1.0 / n;
+  }
 }
+
+// ---------------------------------------------------------------------------
+// CFRSolverBase::EvaluateAndUpdatePolicy x iters (cfr.cc:263-282), one workgroup.
+// ---------------------------------------------------------------------------
+template <bool kLds>
+__global__ void __launch_bounds__(1024)
+k_cfr(Tree t, Tables tb, double* g_reach, double* g_value, int iters, int iteration0, osg_cfr_cfg cfg) {
+  extern __shared__ double smem[];
+  const int P = t.P, S = t.P + 1, A = t.A;
+  double* reach = kLds ? smem : g_reach;                       // [H, P+1], chance last (cfr.cc:196,201)
+  double* value = kLds ? smem + static_cast<size_t>(t.H) * S : g_value;  // [H, P]
+  double* regrets = tb.regrets;
+  double* cum = tb.cum;
+  double* cur = tb.cur;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  if (kLds) {  // stage the tables too: the whole solver state lives in LDS for the launch
+    double* base = smem + static_cast<size_t>(t.H) * (S + P);
+    regrets = base;
+    cum = base + t.I * A;
+    cur = base + 2 * t.I * A;
+    for (int k = tid; k < t.I * A; k += nt) {
+      regrets[k] = tb.regrets[k];
+      cum[k] = tb.cum[k];
+      cur[k] = tb.cur[k];
+    }
+    __syncthreads();
+  }
+  const int passes = cfg.alternating_updates ? P : 1;
+  for (int it = 0; it < iters; ++it) {
+    const int iteration = iteration0 + it + 1;  // ++iteration_ (cfr.cc:264)
+    for (int pass = 0; pass < passes; ++pass) {
+      const int upd = cfg.alternating_updates ? pass : -1;
+      // ---- reach probabilities, top-down (cfr.cc:452-454: new_reach[current_player] *= prob) ----
+      for (int l = 0; l < t.D; ++l) {
+        for (int h = t.level_off[l] + tid; h < t.level_off[l + 1]; h += nt) {
+          if (l == 0) {
+            for (int q = 0; q < S; ++q) reach[h * S + q] = 1.0;
+            continue;
+          }
+          const int par = t.parent[h];
+          const int pa = t.actor[par];
+          const int slot = pa < 0 ? P : pa;
+          const double pr = t.kind[par] == kChanceNode ? t.edge_prob[h] : cur[t.info[par] * A + t.aidx[h]];
+          for (int q = 0; q < S; ++q) {
+            const double r = reach[par * S + q];
+            reach[h * S + q] = (q == slot) ? r * pr : r;
+          }
+        }
+        __syncthreads();
+      }
+      // ---- state values, bottom-up (cfr.cc:443-469) ----
+      for (int l = t.D - 1; l >= 0; --l) {
+        for (int h = t.level_off[l] + tid; h < t.level_off[l + 1]; h += nt) {
+          const int k = t.kind[h];
+          if (k == kTerminalNode) {
+            for (int q = 0; q < P; ++q) value[h * P + q] = t.term_ret[h * P + q];
+            continue;
+          }
+          bool pruned = false;
+          if (k == kDecisionNode) {  // AllPlayersHaveZeroReachProb (cfr.cc:350-355,471-479)
+            pruned = true;
+            for (int q = 0; q < P; ++q) pruned &= (reach[h * S + q] == 0.0);
+          }
+          const int fc = t.first_child[h], nc = t.nchild[h];
+          const int row = k == kDecisionNode ? t.info[h] * A : 0;
+          for (int q = 0; q < P; ++q) {
+            double v = 0.0;
+            if (!pruned) {
+              for (int a = 0; a < nc; ++a) {
+                const double pr = k == kChanceNode ? t.edge_prob[fc + a] : cur[row + a];
+                v += pr * value[(fc + a) * P + q];
+              }
+            }
+            value[h * P + q] = v;
+          }
+        }
+        __syncthreads();
+      }
+      // ---- regret / average-policy updates (cfr.cc:379-405), then RM+ reset and regret
+      //      matching (cfr.cc:683-697).  Rows of the other players are unchanged in an
+      //      alternating pass, so re-matching them (as the reference does) is a no-op. ----
+      for (int i = tid; i < t.I; i += nt) {
+        const int pl = t.info_player[i];
+        if (upd >= 0 && pl != upd) continue;
+        const int n = t.nact[i];
+        for (int m = t.mem_off[i]; m < t.mem_off[i + 1]; ++m) {
+          const int h = t.mem[m];
+          bool pruned = true;
+          for (int q = 0; q < P; ++q) pruned &= (reach[h * S + q] == 0.0);
+          if (pruned) continue;
+          const double self_reach = reach[h * S + pl];
+          double cf_reach = 1.0;  // CounterFactualReachProb (cfr.cc:309-318)
+          for (int q = 0; q < S; ++q)
+            if (q != pl) cf_reach *= reach[h * S + q];
+          const double vh = value[h * P + pl];
+          const int fc = t.first_child[h];
+          for (int a = 0; a < n; ++a) {
+            const double cfr_regret = cf_reach * (value[(fc + a) * P + pl] - vh);
+            regrets[i * A + a] += cfr_regret;
+            const double pol = cur[i * A + a];
+            if (cfg.linear_averaging) cum[i * A + a] += iteration * self_reach * pol;
+            else cum[i * A + a] += self_reach * pol;
+          }
+        }
+        if (cfg.regret_matching_plus)
+          for (int a = 0; a < n; ++a)
+            if (regrets[i * A + a] < 0) regrets[i * A + a] = 0;
+        regret_match_row(regrets + i * A, cur + i * A, n);
+      }
+      __syncthreads();
+    }
+  }
+  if (kLds) {
+    for (int k = tid; k < t.I * A; k += nt) {
+      tb.regrets[k] = regrets[k];
+      tb.cum[k] = cum[k];
+      tb.cur[k] = cur[k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// ExternalSamplingMCCFRSolver::UpdateRegrets (external_sampling_mccfr.cc:122-186),
+// AverageType::kSimple, one traversal per thread, tables frozen for the launch.
+// ---------------------------------------------------------------------------
+OSG_D void add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }  // hardware fp64 atomic (LDS and L2)
+
+template <bool kLdsDelta>
+__global__ void __launch_bounds__(256)
+k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dpol, uint64_t seed,
+        int64_t first, int64_t count) {
+  extern __shared__ double smem[];
+  const int A = t.A, P = t.P, IA = t.I * t.A;
+  double* dreg = kLdsDelta ? smem : g_dreg;
+  double* dpol = kLdsDelta ? smem + IA : g_dpol;
+  if (kLdsDelta) {
+    for (int k = threadIdx.x; k < 2 * IA; k += blockDim.x) smem[k] = 0.0;
+    __syncthreads();
+  }
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < count; j += stride) {
+    const int64_t g = first + j;
+    const int trav = static_cast<int>(g % P);
+    Rng rng(seed, static_cast<uint64_t>(g), 0);
+    int f_node[kMaxFrames];
+    int f_a[kMaxFrames];
+    double f_value[kMaxFrames];
+    double f_cv[kMaxFrames][kMaxA];
+    int sp = 0;
+    int node = 0;
+    for (;;) {
+      // ---- descend to a terminal, pushing a frame at every node of the traverser ----
+      double ret;
+      for (;;) {
+        const int k = t.kind[node];
+        if (k == kTerminalNode) { ret = t.term_ret[node * P + trav]; break; }
+        const int fc = t.first_child[node], nc = t.nchild[node];
+        if (k == kChanceNode) {  // SampleAction(ChanceOutcomes(), z) (spiel.cc:372-409)
+          const double z = rng.unit();
+          int pick = nc - 1;
+          double acc = 0.0;
+          for (int c = 0; c < nc; ++c) {
+            const double pr = t.edge_prob[fc + c];
+            if (acc <= z && z < acc + pr) { pick = c; break; }
+            acc += pr;
+          }
+          node = fc + pick;
+          continue;
+        }
+        const int i = t.info[node];
+        if (t.actor[node] != trav) {  // opponent: sample one action from regret matching (:151-154)
+          double pol[kMaxA];
+          regret_match_row(regrets + i * A, pol, nc);
+          const double z = rng.unit();
+          int pick = nc - 1;  // SampleActionIndex(0.0, z) (cfr.cc:617-628)
+          double acc = 0.0;
+          for (int a = 0; a < nc; ++a) {
+            const double pr = 0.0 * 1.0 / nc + (1.0 - 0.0) * pol[a];
+            if (z >= acc && z < acc + pr) { pick = a; break; }
+            acc += pr;
+          }
+          if (t.actor[node] == (trav + 1) % P)  // kSimple averaging at player+1's nodes (:177-183)
+            for (int a = 0; a < nc; ++a) add_f64(&dpol[i * A + a], pol[a]);
+          node = fc + pick;
+          continue;
+        }
+        f_node[sp] = node;  // traverser: walk every action (:155-162)
+        f_a[sp] = 0;
+        f_value[sp] = 0.0;
+        ++sp;
+        node = fc;
+      }
+      // ---- ascend: hand `ret` to the innermost open frame ----
+      bool done = false;
+      for (;;) {
+        if (sp == 0) { done = true; break; }
+        const int fn = f_node[sp - 1];
+        const int i = t.info[fn];
+        const int nc = t.nchild[fn];
+        double pol[kMaxA];
+        regret_match_row(regrets + i * A, pol, nc);
+        const int a = f_a[sp - 1];
+        f_cv[sp - 1][a] = ret;
+        f_value[sp - 1] += pol[a] * ret;
+        if (a + 1 < nc) {
+          f_a[sp - 1] = a + 1;
+          node = t.first_child[fn] + a + 1;
+          break;
+        }
+        const double v = f_value[sp - 1];
+        for (int b = 0; b < nc; ++b) add_f64(&dreg[i * A + b], f_cv[sp - 1][b] - v);  // (:167-172)
+        ret = v;
+        --sp;
+      }
+      if (done) break;
+    }
+  }
+  if (kLdsDelta) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < IA; k += blockDim.x) {
+      const double r = smem[k], q = smem[IA + k];
+      if (r != 0.0) add_f64(&g_dreg[k], r);
+      if (q != 0.0) add_f64(&g_dpol[k], q);
+    }
+  }
+}
+
+__global__ void k_fold_deltas(double* regrets, double* cum, const double* dreg, const double* dpol, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  regrets[k] += dreg[k];
+  cum[k] += dpol[k];
+}
+
+__global__ void k_fill(double* p, double v, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) p[k] = v;
+}
+
+// ---------------------------------------------------------------------------
+// InformationStateString of the acting player, from the packed state words
+// (kuhn_poker.cc:109-166, leduc_poker.cc:198-239).
+// ---------------------------------------------------------------------------
+std::string kuhn_key(const Kuhn::Params& p, uint64_t word, int player) {
+  Kuhn::State s{word};
+  std::string r = std::to_string(Kuhn::card(s, player));
+  const int n = Kuhn::nact(p, s);
+  for (int j = 0; j < n; ++j) r.push_back(((Kuhn::bets(s) >> j) & 1u) ? 'b' : 'p');
+  return r;
+}
+
+std::string leduc_key(const Leduc::Params& p, uint64_t w0, uint64_t w1, int player) {
+  Leduc::State s = Leduc::unpack(w0, w1);
+  std::string r = "[Observer: " + std::to_string(player) + "][Private: " + std::to_string(s.priv[player]) + "]";
+  r += "[Round " + std::to_string(s.round) + "][Player: " + std::to_string(s.cur) + "][Pot: " +
+       std::to_string(s.pot) + "][Money: ";
+  for (int q = 0; q < p.players; ++q) {
+    if (q) r += " ";
+    r += std::to_string(100 - s.ante[q]);  // money_ = kStartingMoney - ante_ until the showdown
+  }
+  r += "]";
+  if (s.pub != Leduc::kNone) r += "[Public: " + std::to_string(s.pub) + "]";
+  for (int round = 0; round < 2; ++round) {
+    r += round == 0 ? "[Round1: " : "][Round2: ";
+    for (int k = 0; k < s.seqlen[round]; ++k) {
+      if (k) r += " ";
+      r += std::to_string((s.seq[round] >> (2 * k)) & 3u);
+    }
+  }
+  r += "]";
+  return r;
+}
+
+template <class T>
+int upload(const std::vector<T>& v, T** d, hipStream_t stream) {
+  const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  OSG_HIP(hipMalloc(reinterpret_cast<void**>(d), bytes));
+  if (!v.empty()) OSG_HIP(hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+  return OSG_OK;
+}
+
+}  // namespace
+
+struct osg_cfr {
+  osg_ctx* ctx = nullptr;
+  GameSpec spec;
+  osg_cfr_cfg cfg{};
+  int P = 0, H = 0, I = 0, A = 0, D = 0;
+  int64_t n_chance = 0, n_decision = 0, n_terminal = 0;
+  int max_level_width = 0;
+  int iteration = 0;
+  // host tree
+  std::vector<int32_t> level_off, parent, first_child, info, mem_off, mem, nact, legal;
+  std::vector<uint8_t> kind, nchild, aidx;
+  std::vector<int8_t> actor, info_player;
+  std::vector<double> edge_prob, term_ret;
+  std::vector<std::string> keys;
+  // device tree
+  int32_t *d_level_off = nullptr, *d_parent = nullptr, *d_first_child = nullptr, *d_info = nullptr,
+          *d_mem_off = nullptr, *d_mem = nullptr, *d_nact = nullptr;
+  uint8_t *d_kind = nullptr, *d_nchild = nullptr, *d_aidx = nullptr;
+  int8_t *d_actor = nullptr, *d_info_player = nullptr;
+  double *d_edge_prob = nullptr, *d_term_ret = nullptr;
+  // device tables and work arrays
+  double* d_tables = nullptr;  // regrets | cum | cur | dreg | dpol, each [I, A]
+  double* d_reach = nullptr;   // [H, P+1]
+  double* d_value = nullptr;   // [H, P]
+  bool lds_resident = false;
+  size_t lds_bytes = 0;
+
+  Tree tree() const {
+    Tree t;
+    t.H = H; t.I = I; t.A = A; t.P = P; t.D = D;
+    t.level_off = d_level_off; t.parent = d_parent; t.first_child = d_first_child; t.kind = d_kind;
+    t.nchild = d_nchild; t.aidx = d_aidx; t.actor = d_actor; t.info = d_info; t.edge_prob = d_edge_prob;
+    t.term_ret = d_term_ret; t.mem_off = d_mem_off; t.mem = d_mem; t.nact = d_nact; t.info_player = d_info_player;
+    return t;
+  }
+  double* regrets() const { return d_tables; }
+  double* cum() const { return d_tables + static_cast<size_t>(I) * A; }
+  double* cur() const { return d_tables + 2 * static_cast<size_t>(I) * A; }
+  double* dreg() const { return d_tables + 3 * static_cast<size_t>(I) * A; }
+  double* dpol() const { return d_tables + 4 * static_cast<size_t>(I) * A; }
+};
+
+namespace {
+
+// Expands the game tree breadth-first with the batched State kernels.
+int build_tree(osg_cfr* s, const char* game_string) {
+  osg_ctx* ctx = s->ctx;
+  const osg_game_desc& d = s->spec.desc;
+  const int P = d.num_players, W = d.mask_words, C = std::max(d.max_chance_outcomes, 1);
+  const int words = d.state_words;
+  const int64_t kMaxHistories = 1 << 24;
+  s->P = P;
+  s->A = d.num_distinct_actions;
+  if (s->A > 255) return set_error(OSG_ERR_UNSUPPORTED, "osg_cfr_create: more than 255 distinct actions");
+
+  std::unordered_map<std::string, int> key_to_id;
+  osg_batch* level = nullptr;
+  int rc = osg_batch_create(ctx, game_string, 1, &level);
+  if (rc) return rc;
+  s->level_off.push_back(0);
+  // per-node data pending for the level being expanded: parent + edge data were written when the
+  // parent was expanded; this loop fills in what depends on the state itself.
+  s->parent.push_back(-1);
+  s->aidx.push_back(0);
+  s->edge_prob.push_back(0.0);
+  int64_t level_begin = 0;
+  while (level) {
+    const int64_t n = osg_batch_size(level);
+    std::vector<uint32_t> mask(static_cast<size_t>(n) * W);
+    std::vector<int8_t> cur(n);
+    std::vector<uint8_t> term(n);
+    std::vector<double> rets(static_cast<size_t>(n) * P), probs(static_cast<size_t>(n) * C);
+    std::vector<uint64_t> raw(static_cast<size_t>(n) * words);
+    if ((rc = osg_legal_mask(level, mask.data(), 1)) || (rc = osg_status_query(level, cur.data(), term.data(), rets.data(), 1)) ||
+        (d.max_chance_outcomes > 0 && (rc = osg_chance_probs(level, probs.data(), 1))) ||
+        (rc = osg_batch_download(level, raw.data()))) {
+      osg_batch_destroy(level);
+      return rc;
+    }
+    std::vector<int64_t> gather;
+    std::vector<int32_t> actions;
+    const int64_t next_begin = level_begin + n;
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t h = level_begin + i;
+      (void)h;
+      s->actor.push_back(cur[i] >= 0 ? cur[i] : -1);
+      if (term[i]) {
+        s->kind.push_back(kTerminalNode);
+        s->nchild.push_back(0);
+        s->first_child.push_back(0);
+        s->info.push_back(-1);
+        for (int q = 0; q < P; ++q) s->term_ret.push_back(rets[i * P + q]);
+        ++s->n_terminal;
+        continue;
+      }
+      for (int q = 0; q < P; ++q) s->term_ret.push_back(0.0);
+      const bool chance = cur[i] == kChancePlayer;
+      s->kind.push_back(chance ? kChanceNode : kDecisionNode);
+      s->first_child.push_back(static_cast<int32_t>(next_begin + static_cast<int64_t>(gather.size())));
+      std::vector<int32_t> acts;
+      for (int a = 0; a < 32 * W; ++a)
+        if ((mask[i * W + (a >> 5)] >> (a & 31)) & 1u) acts.push_back(a);
+      s->nchild.push_back(static_cast<uint8_t>(acts.size()));
+      for (size_t k = 0; k < acts.size(); ++k) {
+        gather.push_back(i);
+        actions.push_back(acts[k]);
+        s->parent.push_back(static_cast<int32_t>(h));
+        s->aidx.push_back(static_cast<uint8_t>(k));
+        s->edge_prob.push_back(chance ? probs[i * C + acts[k]] : 0.0);
+      }
+      if (chance) {
+        s->info.push_back(-1);
+        ++s->n_chance;
+        continue;
+      }
+      ++s->n_decision;
+      std::string key;
+      if (d.game_kind == kKuhn) key = kuhn_key(s->spec.kuhn, raw[i], cur[i]);
+      else key = leduc_key(s->spec.leduc, raw[i], raw[n + i], cur[i]);
+      auto it = key_to_id.find(key);
+      int id;
+      if (it == key_to_id.end()) {  // InitializeInfostateNodes (cfr.cc:234-261)
+        id = static_cast<int>(s->keys.size());
+        key_to_id.emplace(key, id);
+        s->keys.push_back(key);
+        s->nact.push_back(static_cast<int32_t>(acts.size()));
+        s->info_player.push_back(cur[i]);
+        for (int a = 0; a < s->A; ++a) s->legal.push_back(a < static_cast<int>(acts.size()) ? acts[a] : -1);
+      } else {
+        id = it->second;
+        if (s->nact[id] != static_cast<int32_t>(acts.size())) {
+          osg_batch_destroy(level);
+          return set_error(OSG_ERR_INVALID, "infostate with inconsistent legal actions: " + key);
+        }
+      }
+      s->info.push_back(id);
+    }
+    s->max_level_width = std::max<int>(s->max_level_width, static_cast<int>(n));
+    s->level_off.push_back(static_cast<int32_t>(next_begin));
+    level_begin = next_begin;
+    osg_batch* next = nullptr;
+    if (!gather.empty()) {
+      if (next_begin + static_cast<int64_t>(gather.size()) > kMaxHistories) {
+        osg_batch_destroy(level);
+        return set_error(OSG_ERR_UNSUPPORTED, "osg_cfr_create: game tree exceeds 2^24 histories");
+      }
+      if ((rc = osg_batch_create(ctx, game_string, static_cast<int64_t>(gather.size()), &next)) ||
+          (rc = osg_batch_gather(next, level, gather.data(), 1)) ||
+          (rc = osg_apply(next, actions.data(), 1, nullptr))) {
+        osg_batch_destroy(level);
+        if (next) osg_batch_destroy(next);
+        return rc;
+      }
+    }
+    osg_batch_destroy(level);
+    level = next;
+  }
+  s->H = static_cast<int>(level_begin);
+  s->D = static_cast<int>(s->level_off.size()) - 1;
+  s->I = static_cast<int>(s->keys.size());
+  // Narrow the table width to the widest decision node.
+  int amax = 1;
+  for (int v : s->nact) amax = std::max(amax, v);
+  if (amax != s->A) {
+    std::vector<int32_t> legal(static_cast<size_t>(s->I) * amax);
+    for (int i = 0; i < s->I; ++i)
+      for (int a = 0; a < amax; ++a) legal[i * amax + a] = s->legal[i * s->A + a];
+    s->legal.swap(legal);
+    s->A = amax;
+  }
+  // Member histories of every infostate in the reference's DFS visiting order.
+  std::vector<int32_t> order;
+  order.reserve(s->H);
+  std::vector<int32_t> stack{0};
+  while (!stack.empty()) {
+    const int h = stack.back();
+    stack.pop_back();
+    order.push_back(h);
+    for (int a = s->nchild[h] - 1; a >= 0; --a) stack.push_back(s->first_child[h] + a);
+  }
+  std::vector<std::vector<int32_t>> members(s->I);
+  for (int h : order)
+    if (s->kind[h] == kDecisionNode) members[s->info[h]].push_back(h);
+  s->mem_off.push_back(0);
+  for (int i = 0; i < s->I; ++i) {
+    s->mem.insert(s->mem.end(), members[i].begin(), members[i].end());
+    s->mem_off.push_back(static_cast<int32_t>(s->mem.size()));
+  }
+  return OSG_OK;
+}
+
+int init_tables(osg_cfr* s) {
+  const int IA = s->I * s->A;
+  hipStream_t st = s->ctx->stream;
+  OSG_HIP(hipMemsetAsync(s->d_tables, 0, sizeof(double) * 5 * IA, st));
+  std::vector<double> cur(IA, 0.0), init(IA, 0.0);
+  for (int i = 0; i < s->I; ++i)
+    for (int a = 0; a < s->nact[i]; ++a) {
+      cur[i * s->A + a] = 1.0 / s->nact[i];  // CFRInfoStateValues ctor (cfr.h:47-52)
+      init[i * s->A + a] = s->cfg.solver == 1 ? kMccfrInit : 0.0;
+    }
+  OSG_HIP(hipMemcpyAsync(s->cur(), cur.data(), sizeof(double) * IA, hipMemcpyHostToDevice, st));
+  OSG_HIP(hipMemcpyAsync(s->regrets(), init.data(), sizeof(double) * IA, hipMemcpyHostToDevice, st));
+  OSG_HIP(hipMemcpyAsync(s->cum(), init.data(), sizeof(double) * IA, hipMemcpyHostToDevice, st));
+  OSG_HIP(hipStreamSynchronize(st));
+  s->iteration = 0;
+  return OSG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg, osg_cfr** out) {
+  if (!ctx || !game_string || !cfg || !out) return set_error(OSG_ERR_INVALID, "osg_cfr_create: null argument");
+  osg_cfr* s = new osg_cfr;
+  s->ctx = ctx;
+  s->cfg = *cfg;
+  int rc = parse_game(game_string, &s->spec);
+  if (rc) { delete s; return rc; }
+  if (s->spec.desc.game_kind != kKuhn && s->spec.desc.game_kind != kLeduc) {
+    delete s;
+    return set_error(OSG_ERR_UNSUPPORTED, "tabular CFR needs information-state strings: kuhn_poker and leduc_poker only");
+  }
+  rc = build_tree(s, game_string);
+  if (rc) { delete s; return rc; }
+  hipStream_t st = ctx->stream;
+  if ((rc = upload(s->level_off, &s->d_level_off, st)) || (rc = upload(s->parent, &s->d_parent, st)) ||
+      (rc = upload(s->first_child, &s->d_first_child, st)) || (rc = upload(s->info, &s->d_info, st)) ||
+      (rc = upload(s->mem_off, &s->d_mem_off, st)) || (rc = upload(s->mem, &s->d_mem, st)) ||
+      (rc = upload(s->nact, &s->d_nact, st)) || (rc = upload(s->kind, &s->d_kind, st)) ||
+      (rc = upload(s->nchild, &s->d_nchild, st)) || (rc = upload(s->aidx, &s->d_aidx, st)) ||
+      (rc = upload(s->actor, &s->d_actor, st)) || (rc = upload(s->info_player, &s->d_info_player, st)) ||
+      (rc = upload(s->edge_prob, &s->d_edge_prob, st)) || (rc = upload(s->term_ret, &s->d_term_ret, st))) {
+    osg_cfr_destroy(s);
+    return rc;
+  }
+  const size_t IA = static_cast<size_t>(s->I) * s->A;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_tables), sizeof(double) * 5 * std::max<size_t>(IA, 1));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_reach), sizeof(double) * s->H * (s->P + 1));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_value), sizeof(double) * s->H * s->P);
+  if (e != hipSuccess) { osg_cfr_destroy(s); return set_error(OSG_ERR_NOMEM, hipGetErrorString(e)); }
+  // Whole solver state in LDS when it fits (gfx950: 160 KiB per workgroup; leave headroom).
+  s->lds_bytes = sizeof(double) * (static_cast<size_t>(s->H) * (2 * s->P + 1) + 3 * IA);
+  s->lds_resident = s->lds_bytes <= 96 * 1024;
+  if (s->lds_resident) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cfr<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(s->lds_bytes));
+    if (e != hipSuccess) { (void)hipGetLastError(); s->lds_resident = false; }
+  }
+  rc = init_tables(s);
+  if (rc) { osg_cfr_destroy(s); return rc; }
+  *out = s;
+  return OSG_OK;
+}
+
+int osg_cfr_destroy(osg_cfr* s) {
+  if (!s) return OSG_OK;
+  (void)hipStreamSynchronize(s->ctx->stream);
+  void* ptrs[] = {s->d_level_off, s->d_parent, s->d_first_child, s->d_info, s->d_mem_off, s->d_mem, s->d_nact,
+                  s->d_kind, s->d_nchild, s->d_aidx, s->d_actor, s->d_info_player, s->d_edge_prob, s->d_term_ret,
+                  s->d_tables, s->d_reach, s->d_value};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete s;
+  return OSG_OK;
+}
+
+int osg_cfr_sizes(const osg_cfr* s, int64_t* out) {
+  if (!s || !out) return set_error(OSG_ERR_INVALID, "osg_cfr_sizes: null argument");
+  out[0] = s->H; out[1] = s->n_chance; out[2] = s->n_decision; out[3] = s->n_terminal; out[4] = s->I; out[5] = s->A;
+  return OSG_OK;
+}
+
+int osg_cfr_reset(osg_cfr* s) { return init_tables(s); }
+
+int osg_cfr_iterate(osg_cfr* s, int iters) {
+  if (!s || iters < 0) return set_error(OSG_ERR_INVALID, "osg_cfr_iterate: bad argument");
+  if (iters == 0) return OSG_OK;
+  int threads = ((s->max_level_width + 63) / 64) * 64;
+  threads = std::max(64, std::min(threads, 1024));
+  Tables tb{s->regrets(), s->cum(), s->cur()};
+  if (s->lds_resident) {
+    k_cfr<true><<<dim3(1), dim3(threads), s->lds_bytes, s->ctx->stream>>>(s->tree(), tb, s->d_reach, s->d_value, iters,
+                                                                         s->iteration, s->cfg);
+  } else {
+    k_cfr<false><<<dim3(1), dim3(threads), 0, s->ctx->stream>>>(s->tree(), tb, s->d_reach, s->d_value, iters,
+                                                                s->iteration, s->cfg);
+  }
+  OSG_HIP(hipGetLastError());
+  s->iteration += iters;
+  return OSG_OK;
+}
+
+int osg_mccfr_sample(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_t trajectories) {
+  if (!s || trajectories < 0) return set_error(OSG_ERR_INVALID, "osg_mccfr_sample: bad argument");
+  if (s->A > kMaxA) return set_error(OSG_ERR_UNSUPPORTED, "osg_mccfr_sample: decision nodes wider than 4 actions");
+  const int IA = s->I * s->A;
+  hipStream_t st = s->ctx->stream;
+  OSG_HIP(hipMemsetAsync(s->dreg(), 0, sizeof(double) * 2 * IA, st));
+  if (trajectories == 0) return OSG_OK;
+  const size_t lds = sizeof(double) * 2 * IA;
+  const bool use_lds = lds <= 64 * 1024;
+  int64_t blocks = (trajectories + 255) / 256;
+  // Persistent workgroups: each flushes its LDS delta tables once, so fewer, longer-lived
+  // groups mean fewer global atomics (256 CUs x 4 groups).
+  if (blocks > 1024) blocks = 1024;
+  if (use_lds) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mccfr<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      attr_set = true;
+    }
+    k_mccfr<true><<<dim3(static_cast<unsigned>(blocks)), dim3(256), lds, st>>>(s->tree(), s->regrets(), s->dreg(),
+                                                                                s->dpol(), seed, first_trajectory,
+                                                                                trajectories);
+  } else {
+    k_mccfr<false><<<dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st>>>(s->tree(), s->regrets(), s->dreg(),
+                                                                               s->dpol(), seed, first_trajectory,
+                                                                               trajectories);
+  }
+  OSG_HIP(hipGetLastError());
+  return OSG_OK;
+}
+
+int osg_mccfr_apply_deltas(osg_cfr* s) {
+  if (!s) return set_error(OSG_ERR_INVALID, "osg_mccfr_apply_deltas: null argument");
+  const int IA = s->I * s->A;
+  k_fold_deltas<<<dim3((IA + 255) / 256), dim3(256), 0, s->ctx->stream>>>(s->regrets(), s->cum(), s->dreg(), s->dpol(), IA);
+  OSG_HIP(hipGetLastError());
+  ++s->iteration;
+  return OSG_OK;
+}
+
+int osg_mccfr_iterate(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_t trajectories) {
+  int rc = osg_mccfr_sample(s, seed, first_trajectory, trajectories);
+  if (rc) return rc;
+  return osg_mccfr_apply_deltas(s);
+}
+
+int osg_cfr_table_ptrs(osg_cfr* s, double** d_regrets, double** d_cum_policy, double** d_cur_policy) {
+  if (!s) return set_error(OSG_ERR_INVALID, "osg_cfr_table_ptrs: null argument");
+  if (d_regrets) *d_regrets = s->regrets();
+  if (d_cum_policy) *d_cum_policy = s->cum();
+  if (d_cur_policy) *d_cur_policy = s->cur();
+  return OSG_OK;
+}
+
+int osg_mccfr_delta_ptrs(osg_cfr* s, double** d_regret_delta, double** d_policy_delta) {
+  if (!s) return set_error(OSG_ERR_INVALID, "osg_mccfr_delta_ptrs: null argument");
+  if (d_regret_delta) *d_regret_delta = s->dreg();
+  if (d_policy_delta) *d_policy_delta = s->dpol();
+  return OSG_OK;
+}
+
+int osg_cfr_upload_tables(osg_cfr* s, const double* h_regrets, const double* h_cum_policy, const double* h_cur_policy) {
+  if (!s) return set_error(OSG_ERR_INVALID, "osg_cfr_upload_tables: null argument");
+  const size_t bytes = sizeof(double) * s->I * s->A;
+  hipStream_t st = s->ctx->stream;
+  if (h_regrets) OSG_HIP(hipMemcpyAsync(s->regrets(), h_regrets, bytes, hipMemcpyHostToDevice, st));
+  if (h_cum_policy) OSG_HIP(hipMemcpyAsync(s->cum(), h_cum_policy, bytes, hipMemcpyHostToDevice, st));
+  if (h_cur_policy) OSG_HIP(hipMemcpyAsync(s->cur(), h_cur_policy, bytes, hipMemcpyHostToDevice, st));
+  OSG_HIP(hipStreamSynchronize(st));
+  return OSG_OK;
+}
+
+int osg_cfr_tables(const osg_cfr* s, int32_t* nact, int32_t* legal, double* regrets, double* cum_policy,
+                   double* cur_policy, double* avg_policy) {
+  if (!s) return set_error(OSG_ERR_INVALID, "osg_cfr_tables: null argument");
+  const size_t IA = static_cast<size_t>(s->I) * s->A, bytes = sizeof(double) * IA;
+  hipStream_t st = s->ctx->stream;
+  if (nact) memcpy(nact, s->nact.data(), sizeof(int32_t) * s->I);
+  if (legal) memcpy(legal, s->legal.data(), sizeof(int32_t) * IA);
+  std::vector<double> cum(IA);
+  if (regrets) OSG_HIP(hipMemcpyAsync(regrets, s->regrets(), bytes, hipMemcpyDeviceToHost, st));
+  if (cur_policy) OSG_HIP(hipMemcpyAsync(cur_policy, s->cur(), bytes, hipMemcpyDeviceToHost, st));
+  OSG_HIP(hipMemcpyAsync(cum.data(), s->cum(), bytes, hipMemcpyDeviceToHost, st));
+  OSG_HIP(hipStreamSynchronize(st));
+  if (cum_policy) memcpy(cum_policy, cum.data(), bytes);
+  if (avg_policy) {  // CFRAveragePolicy::GetStatePolicyFromInformationStateValues (cfr.cc:104-125)
+    for (int i = 0; i < s->I; ++i) {
+      const int n = s->nact[i];
+      double sum = 0.0;
+      for (int a = 0; a < n; ++a) sum += cum[i * s->A + a];
+      for (int a = 0; a < s->A; ++a) {
+        if (a >= n) avg_policy[i * s->A + a] = 0.0;
+        else avg_policy[i * s->A + a] = sum == 0.0 ? 1. / n : cum[i * s->A + a] / sum;
+      }
+    }
+  }
+  return OSG_OK;
+}
+
+int osg_cfr_infostate_key(const osg_cfr* s, int64_t i, char* buf, int cap) {
+  if (!s || i < 0 || i >= s->I || !buf || cap <= 0) return set_error(OSG_ERR_INVALID, "osg_cfr_infostate_key: bad argument");
+  const std::string& k = s->keys[i];
+  if (static_cast<int>(k.size()) + 1 > cap) return set_error(OSG_ERR_INVALID, "osg_cfr_infostate_key: buffer too small");
+  memcpy(buf, k.c_str(), k.size() + 1);
+  return static_cast<int>(k.size());
+}
+
+int osg_cfr_iteration(const osg_cfr* s) { return s ? s->iteration : 0; }
+
+}  // extern "C"

@@ -27,51 +27,51 @@ struct Kuhn {
   struct State {
     uint64_t h;
   };
-  OSG_D static State initial(const Params&) { return {0ull}; }
-  OSG_D static State load(const Params&, const word_t* base, int64_t, int64_t i) { return {base[i]}; }
-  OSG_D static void store(const Params&, word_t* base, int64_t, int64_t i, const State& s) { base[i] = s.h; }
-  OSG_D static int len(const State& s) { return static_cast<int>(s.h & 31ull); }
-  OSG_D static int card(const State& s, int p) { return static_cast<int>((s.h >> (5 + 4 * p)) & 15ull); }
-  OSG_D static uint32_t bets(const State& s) { return static_cast<uint32_t>(s.h >> 45); }
-  OSG_D static int nact(const Params& p, const State& s) { int l = len(s); return l > p.players ? l - p.players : 0; }
+  OSG_HD static State initial(const Params&) { return {0ull}; }
+  OSG_HD static State load(const Params&, const word_t* base, int64_t, int64_t i) { return {base[i]}; }
+  OSG_HD static void store(const Params&, word_t* base, int64_t, int64_t i, const State& s) { base[i] = s.h; }
+  OSG_HD static int len(const State& s) { return static_cast<int>(s.h & 31ull); }
+  OSG_HD static int card(const State& s, int p) { return static_cast<int>((s.h >> (5 + 4 * p)) & 15ull); }
+  OSG_HD static uint32_t bets(const State& s) { return static_cast<uint32_t>(s.h >> 45); }
+  OSG_HD static int nact(const Params& p, const State& s) { int l = len(s); return l > p.players ? l - p.players : 0; }
   // first_bettor_ (kuhn_poker.cc:195-199): the player of the first bet, or -1.
-  OSG_D static int first_bettor(const State& s) {
+  OSG_HD static int first_bettor(const State& s) {
     uint32_t b = bets(s);
     return b ? __builtin_ctz(b) : -1;  // the first bet happens within the first P actions
   }
-  OSG_D static bool terminal(const Params& p, const State& s) {  // kuhn_poker.cc:206-227
+  OSG_HD static bool terminal(const Params& p, const State& s) {  // kuhn_poker.cc:206-227
     int n = nact(p, s), fb = first_bettor(s);
     return fb < 0 ? (n == p.players) : (n == p.players + fb);
   }
-  OSG_D static int current_player(const Params& p, const State& s) {  // kuhn_poker.cc:181-188
+  OSG_HD static int current_player(const Params& p, const State& s) {  // kuhn_poker.cc:181-188
     if (terminal(p, s)) return kTerminalPlayer;
     int l = len(s);
     return l < p.players ? kChancePlayer : l % p.players;
   }
-  OSG_D static uint32_t dealt_mask(const Params& p, const State& s) {
+  OSG_HD static uint32_t dealt_mask(const Params& p, const State& s) {
     uint32_t m = 0;
     int l = len(s);
     for (int q = 0; q < p.players; ++q)
       if (q < l) m |= 1u << card(s, q);
     return m;
   }
-  OSG_D static Mask legal(const Params& p, const State& s) {  // kuhn_poker.cc:231-242
+  OSG_HD static Mask legal(const Params& p, const State& s) {  // kuhn_poker.cc:231-242
     Mask m;
     if (terminal(p, s)) return m;
     if (len(s) < p.players) m.w[0] = ~dealt_mask(p, s) & ((1u << (p.players + 1)) - 1u);
     else m.w[0] = 3u;
     return m;
   }
-  OSG_D static double chance_prob(const Params& p, const State& s, int) {  // kuhn_poker.cc:329-337
+  OSG_HD static double chance_prob(const Params& p, const State& s, int) {  // kuhn_poker.cc:329-337
     return 1.0 / (p.players + 1 - len(s));
   }
-  OSG_D static void apply(const Params& p, State& s, int a) {  // kuhn_poker.cc:190-229
+  OSG_HD static void apply(const Params& p, State& s, int a) {  // kuhn_poker.cc:190-229
     int l = len(s);
     if (l < p.players) s.h |= static_cast<uint64_t>(a) << (5 + 4 * l);
     else s.h |= static_cast<uint64_t>(a & 1) << (45 + (l - p.players));
     s.h = (s.h & ~31ull) | static_cast<uint64_t>(l + 1);
   }
-  OSG_D static bool did_bet(const Params& p, const State& s, int q) {  // DidBet, kuhn_poker.cc:339-349
+  OSG_HD static bool did_bet(const Params& p, const State& s, int q) {  // DidBet, kuhn_poker.cc:339-349
     int fb = first_bettor(s);
     uint32_t b = bets(s);
     if (fb < 0) return false;
@@ -79,7 +79,7 @@ struct Kuhn {
     if (q > fb) return (b >> q) & 1u;
     return (b >> (p.players + q)) & 1u;
   }
-  OSG_D static int winner(const Params& p, const State& s) {
+  OSG_HD static int winner(const Params& p, const State& s) {
     int fb = first_bettor(s);
     int best_card = -1, best = -1;
     for (int q = 0; q < p.players; ++q) {
@@ -89,8 +89,8 @@ struct Kuhn {
     }
     return best;
   }
-  OSG_D static int outcome_code(const Params&, const State&) { return 7; }
-  OSG_D static void returns(const Params& p, const State& s, double* out) {  // kuhn_poker.cc:272-283
+  OSG_HD static int outcome_code(const Params&, const State&) { return 7; }
+  OSG_HD static void returns(const Params& p, const State& s, double* out) {  // kuhn_poker.cc:272-283
     if (!terminal(p, s)) {
       for (int q = 0; q < p.players; ++q) out[q] = 0.0;
       return;
@@ -103,7 +103,7 @@ struct Kuhn {
     }
   }
   // ante_[q] (kuhn_poker.cc:196-199): 1 + one chip per bet made so far by q.
-  OSG_D static int contribution(const Params& p, const State& s, int q) {
+  OSG_HD static int contribution(const Params& p, const State& s, int q) {
     uint32_t b = bets(s);
     int c = 1;
     for (int j = q; j < 2 * p.players - 1; j += p.players) c += (b >> j) & 1u;
@@ -112,7 +112,7 @@ struct Kuhn {
   // KuhnObserver::WriteTensor, kuhn_poker.cc:72-107.
   //   which 1 (information state): player[P] | private_card[P+1] | betting[2P-1, 2]
   //   which 0 (observation)      : player[P] | private_card[P+1] | pot_contribution[P]
-  OSG_D static float obs_at(const Params& p, const State& s, int player, int which, int idx) {
+  OSG_HD static float obs_at(const Params& p, const State& s, int player, int which, int idx) {
     const int P = p.players;
     int l = len(s);
     if (idx < P) return idx == player ? 1.0f : 0.0f;
@@ -158,7 +158,7 @@ struct Leduc {
   };
   static constexpr int kNone = -1;
 
-  OSG_D static State initial(const Params& p) {  // leduc_poker.cc:241-286
+  OSG_HD static State initial(const Params& p) {  // leduc_poker.cc:241-286
     State s;
     s.cur = kChancePlayer; s.calls = 0; s.raises = 0; s.round = 1; s.stakes = 1;
     s.pot = p.players; s.pub = kNone; s.dealt = 0; s.remaining = p.players; s.nwin = 0;
@@ -167,7 +167,7 @@ struct Leduc {
     s.seq[0] = s.seq[1] = 0; s.seqlen[0] = s.seqlen[1] = 0;
     return s;
   }
-  OSG_D static State unpack(uint64_t a, uint64_t b) {
+  OSG_HD static State unpack(uint64_t a, uint64_t b) {
     State s;
     s.cur = static_cast<int>(a & 7ull) - 1;            a >>= 3;
     s.calls = static_cast<int>(a & 3ull);               a >>= 2;
@@ -190,7 +190,7 @@ struct Leduc {
     for (int q = 0; q < 3; ++q) { s.priv[q] = static_cast<int>(b & 15ull) - 1; b >>= 4; }
     return s;
   }
-  OSG_D static void pack(const State& s, uint64_t& a, uint64_t& b) {
+  OSG_HD static void pack(const State& s, uint64_t& a, uint64_t& b) {
     a = 0; b = 0;
     int sh = 0;
     auto put = [&](uint64_t& w, uint64_t v, int bits) { w |= v << sh; sh += bits; };
@@ -204,26 +204,26 @@ struct Leduc {
     for (int r = 0; r < 2; ++r) { put(b, s.seqlen[r], 3); put(b, s.seq[r], 14); }
     for (int q = 0; q < 3; ++q) put(b, static_cast<uint64_t>(s.priv[q] + 1), 4);
   }
-  OSG_D static State load(const Params&, const word_t* base, int64_t n, int64_t i) {
+  OSG_HD static State load(const Params&, const word_t* base, int64_t n, int64_t i) {
     return unpack(base[i], base[n + i]);
   }
-  OSG_D static void store(const Params&, word_t* base, int64_t n, int64_t i, const State& s) {
+  OSG_HD static void store(const Params&, word_t* base, int64_t n, int64_t i, const State& s) {
     uint64_t a, b;
     pack(s, a, b);
     base[i] = a;
     base[n + i] = b;
   }
-  OSG_D static bool round_over(const State& s) {  // ReadyForNextRound, leduc_poker.cc:680-683
+  OSG_HD static bool round_over(const State& s) {  // ReadyForNextRound, leduc_poker.cc:680-683
     return (s.raises == 0 && s.calls == s.remaining) || (s.raises > 0 && s.calls == s.remaining - 1);
   }
-  OSG_D static bool terminal(const Params&, const State& s) {  // leduc_poker.cc:498-500
+  OSG_HD static bool terminal(const Params&, const State& s) {  // leduc_poker.cc:498-500
     return s.remaining == 1 || (s.round == 2 && round_over(s));
   }
-  OSG_D static int current_player(const Params& p, const State& s) {  // leduc_poker.cc:288-294
+  OSG_HD static int current_player(const Params& p, const State& s) {  // leduc_poker.cc:288-294
     return terminal(p, s) ? kTerminalPlayer : s.cur;
   }
-  OSG_D static int deck_size(const State& s) { return __builtin_popcount(s.deck); }
-  OSG_D static Mask legal(const Params& p, const State& s) {  // leduc_poker.cc:416-457
+  OSG_HD static int deck_size(const State& s) { return __builtin_popcount(s.deck); }
+  OSG_HD static Mask legal(const Params& p, const State& s) {  // leduc_poker.cc:416-457
     Mask m;
     if (terminal(p, s)) return m;
     if (s.cur == kChancePlayer) {
@@ -241,12 +241,12 @@ struct Leduc {
     if (s.raises < 2) m.w[0] |= 4u;               // raise
     return m;
   }
-  OSG_D static double chance_prob(const Params& p, const State& s, int outcome) {  // leduc_poker.cc:546-571
+  OSG_HD static double chance_prob(const Params& p, const State& s, int outcome) {  // leduc_poker.cc:546-571
     double pr = 1.0 / deck_size(s);
     if (p.iso && ((s.deck >> (2 * outcome)) & 3u) == 3u) return pr * 2;
     return pr;
   }
-  OSG_D static int take_card(const Params& p, State& s, int move) {
+  OSG_HD static int take_card(const Params& p, State& s, int move) {
     if (p.iso) {
       if ((s.deck >> (2 * move)) & 1u) s.deck &= ~(1u << (2 * move));
       else s.deck &= ~(1u << (2 * move + 1));
@@ -255,7 +255,7 @@ struct Leduc {
     s.deck &= ~(1u << move);
     return move;  // deck_[move] == move while present
   }
-  OSG_D static int next_actor(const Params& p, const State& s) {  // NextPlayer, leduc_poker.cc:573-591
+  OSG_HD static int next_actor(const Params& p, const State& s) {  // NextPlayer, leduc_poker.cc:573-591
     const int P = p.players;
     int from = (s.cur == kChancePlayer) ? (p.starter + P - 1) % P : s.cur;
     for (int i = 1; i <= P; ++i) {
@@ -264,7 +264,7 @@ struct Leduc {
     }
     return 0;
   }
-  OSG_D static int hand_rank(const Params& p, const State& s, int q) {  // RankHand, leduc_poker.cc:593-626
+  OSG_HD static int hand_rank(const Params& p, const State& s, int q) {  // RankHand, leduc_poker.cc:593-626
     int lo = s.pub, hi = s.priv[q];
     if (lo > hi) { int t = lo; lo = hi; hi = t; }
     if (p.iso) {
@@ -275,7 +275,7 @@ struct Leduc {
     if ((lo & 1) == 0 && hi == lo + 1) return n * n + lo;
     return (hi / 2) * n + (lo / 2);
   }
-  OSG_D static void showdown(const Params& p, State& s) {  // ResolveWinner, leduc_poker.cc:628-678
+  OSG_HD static void showdown(const Params& p, State& s) {  // ResolveWinner, leduc_poker.cc:628-678
     if (s.remaining == 1) {
       for (int q = 0; q < p.players; ++q)
         if (!((s.folded >> q) & 1u)) { s.nwin = 1; s.winners = 1u << q; return; }
@@ -290,16 +290,16 @@ struct Leduc {
       else if (r == best) { s.winners |= 1u << q; ++s.nwin; }
     }
   }
-  OSG_D static void pay(State& s, int q, int amount) {  // Ante, leduc_poker.cc:700-704
+  OSG_HD static void pay(State& s, int q, int amount) {  // Ante, leduc_poker.cc:700-704
     s.pot += amount;
     s.ante[q] += amount;
   }
-  OSG_D static void record(State& s, int move) {
+  OSG_HD static void record(State& s, int move) {
     int r = s.round - 1;
     s.seq[r] |= static_cast<uint32_t>(move) << (2 * s.seqlen[r]);
     ++s.seqlen[r];
   }
-  OSG_D static void advance(const Params& p, State& s, bool may_start_round) {
+  OSG_HD static void advance(const Params& p, State& s, bool may_start_round) {
     if (terminal(p, s)) {
       showdown(p, s);
     } else if (may_start_round && round_over(s)) {  // NewRound, leduc_poker.cc:685-691
@@ -308,7 +308,7 @@ struct Leduc {
       s.cur = next_actor(p, s);
     }
   }
-  OSG_D static void apply(const Params& p, State& s, int a) {  // DoApplyAction, leduc_poker.cc:298-414
+  OSG_HD static void apply(const Params& p, State& s, int a) {  // DoApplyAction, leduc_poker.cc:298-414
     if (s.cur == kChancePlayer) {
       if (s.dealt < p.players) {  // SetPrivate, :706-727
         s.priv[s.dealt] = take_card(p, s, a);
@@ -346,10 +346,10 @@ struct Leduc {
       advance(p, s, false);
     }
   }
-  OSG_D static int outcome_code(const Params&, const State&) { return 7; }
+  OSG_HD static int outcome_code(const Params&, const State&) { return 7; }
   // Returns = money - 100 (leduc_poker.cc:502-514) with money = 100 - ante, plus
   // pot / num_winners for winners (added in double, :673) — same operation order.
-  OSG_D static void returns(const Params& p, const State& s, double* out) {
+  OSG_HD static void returns(const Params& p, const State& s, double* out) {
     bool term = terminal(p, s);
     // After ResolveWinner the reference zeroes pot_; we keep pot and recompute the share.
     for (int q = 0; q < p.players; ++q) {
@@ -362,7 +362,7 @@ struct Leduc {
   // LeducObserver::WriteTensor, leduc_poker.cc:103-192:
   //   player[P] | private_card[K] | community_card[K] | betting[2, 3P-2, 2] (info)
   //                                                   | pot_contribution[P] (obs)
-  OSG_D static float obs_at(const Params& p, const State& s, int player, int which, int idx) {
+  OSG_HD static float obs_at(const Params& p, const State& s, int player, int which, int idx) {
     const int P = p.players, K = p.iso ? p.cards / 2 : p.cards;
     if (idx < P) return idx == player ? 1.0f : 0.0f;
     idx -= P;

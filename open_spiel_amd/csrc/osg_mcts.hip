@@ -47,7 +47,7 @@ OSG_D bool m_has_outcome(uint32_t m) { return (m >> 20) & 1u; }
 OSG_D int m_code(uint32_t m) { return static_cast<int>((m >> 21) & 3u); }  // p0 value + 1
 OSG_D bool m_terminal(uint32_t m) { return (m >> 23) & 1u; }
 OSG_D uint32_t make_meta(int action, int player, int nchild) {
-  return static_cast<uint32_t>(action & 0xFF) | (static_cast<uint32_t>(player + 1) << 8) |
+  return static_cast<uint32_t>(action & 0xFF) | ((static_cast<uint32_t>(player + 1) & 15u) << 8) |
          (static_cast<uint32_t>(nchild) << 12);
 }
 

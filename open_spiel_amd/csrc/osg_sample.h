@@ -13,8 +13,7 @@ template <class G>
 OSG_D int sample_action(const typename G::Params& p, const typename G::State& s, const Mask& m, int cur, Rng& rng) {
   if (cur == kChancePlayer) {
     int cnt = m.count();
-    if (cnt == 1) return select_action(m, 0);
-    double z = rng.unit();
+    double z = rng.unit();  // drawn even for a single outcome, as the reference's call sites do
     double acc = 0.0;
     int last = -1;
     for (int k = 0; k < cnt; ++k) {

@@ -280,10 +280,11 @@ class TabularSolver:
     """
 
     def __init__(self, ctx, game_string, alternating_updates=True, linear_averaging=False,
-                 regret_matching_plus=False):
+                 regret_matching_plus=False, mccfr=False):
         self.ctx = ctx
         self.game_string = game_string
-        cfg = _abi.CfrCfg(int(alternating_updates), int(linear_averaging), int(regret_matching_plus))
+        cfg = _abi.CfrCfg(int(alternating_updates), int(linear_averaging), int(regret_matching_plus),
+                          int(mccfr))
         h = C.c_void_p()
         check(lib().osg_cfr_create(ctx._h, game_string.encode(), C.byref(cfg), C.byref(h)))
         self._h = h
@@ -303,8 +304,27 @@ class TabularSolver:
     def evaluate_and_update_policy(self, iters=1):
         check(lib().osg_cfr_iterate(self._h, int(iters)))
 
+    def reset(self):
+        check(lib().osg_cfr_reset(self._h))
+
+    @property
+    def iteration(self):
+        return lib().osg_cfr_iteration(self._h)
+
     def run_mccfr(self, seed, trajectories, first_trajectory=0):
+        """One mini-batch of external-sampling traversals, folded into the tables."""
         check(lib().osg_mccfr_iterate(self._h, int(seed), int(first_trajectory), int(trajectories)))
+
+    def mccfr_sample(self, seed, trajectories, first_trajectory=0):
+        """Traversals only: deltas stay in mccfr_delta_tables() (all-reduce them, then
+        mccfr_apply_deltas())."""
+        check(lib().osg_mccfr_sample(self._h, int(seed), int(first_trajectory), int(trajectories)))
+
+    def load_tables(self, regrets=None, cum_policy=None, cur_policy=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, np.float64) for a in (regrets, cum_policy, cur_policy)]
+        for a in arrs:
+            assert a is None or a.shape == (self.num_infostates, self.amax)
+        check(lib().osg_cfr_upload_tables(self._h, *[None if a is None else a.ctypes.data for a in arrs]))
 
     def _wrap(self, ptr):
         # zero-copy torch view of a device fp64 table [I, Amax]

@@ -285,7 +285,8 @@ class State:
         n = lib().osgo_history(self._h, out, 512)
         return [out[i] for i in range(n)]
 
-    def mcts_search(self, uct_c, max_simulations, n_rollouts, max_memory_mb, solve, seed):
+    def mcts_search(self, uct_c, max_simulations, n_rollouts, max_memory_mb, solve, seed,
+                    counter_root=-1, counter_seed=0):
         best = C.c_int64(0)
         root_outcome = C.c_double(0)
         visits = C.c_int(0)
@@ -294,7 +295,8 @@ class State:
         n = _check(lib().osgo_mcts_search(self._h, C.c_double(uct_c), max_simulations, n_rollouts,
                                           C.c_int64(max_memory_mb), int(solve), seed,
                                           C.byref(best), C.byref(root_outcome),
-                                          _ptr(ch, C.c_double), cap, C.byref(visits)))
+                                          _ptr(ch, C.c_double), cap, C.byref(visits),
+                                          C.c_int64(counter_root), C.c_uint64(counter_seed)))
         return dict(best_action=best.value, root_outcome=root_outcome.value,
                     root_visits=visits.value, children=ch[:n])
 
@@ -320,6 +322,10 @@ class Solver:
 
     def iterate(self, iters=1):
         _check(lib().osgo_cfr_iterate(self._h, iters))
+
+    def mccfr_minibatch(self, seed, first, count):
+        """The device's mini-batch ES-MCCFR schedule on the oracle (frozen table per call)."""
+        _check(lib().osgo_mccfr_minibatch(self._h, C.c_uint64(seed), C.c_int64(first), C.c_int64(count)))
 
     def tables(self, amax=None):
         amax = amax or self.game.num_distinct_actions

@@ -299,6 +299,18 @@ class MCTSBot {  // mcts.h:149-220
   Action Step(const State& state);
   std::unique_ptr<SearchNode> MCTSearch(const State& state);
   int LastNodeCount() const { return nodes_; }
+  // Replay mode (NOT in the reference): every random draw comes from the counter
+  // streams the HIP search uses for root `root_index`, so a device search can be
+  // reproduced node for node.  Simulation s shuffles / samples chance with
+  // CounterRng(seed ^ kTreeSalt, root_index, s); rollout r of simulation s plays
+  // with CounterRng(seed, root_index, s * n_rollouts + r).
+  static constexpr uint64_t kTreeSalt = 0x7265655F73616C74ULL;
+  void UseCounterStreams(uint64_t seed, uint64_t root_index, int n_rollouts) {
+    counter_ = true;
+    c_seed_ = seed;
+    c_root_ = root_index;
+    c_rollouts_ = n_rollouts;
+  }
 
  private:
   std::unique_ptr<State> ApplyTreePolicy(SearchNode* root, const State& state,
@@ -315,6 +327,11 @@ class MCTSBot {  // mcts.h:149-220
   std::mt19937 rng_;
   ChildSelectionPolicy child_selection_policy_;
   std::shared_ptr<Evaluator> evaluator_;
+  std::vector<double> CounterEvaluate(const State& state, int sim) const;
+  bool counter_ = false;
+  uint64_t c_seed_ = 0, c_root_ = 0;
+  int c_rollouts_ = 1;
+  CounterRng trng_{0};
 };
 
 // ---------------------------------------------------------------------------

@@ -172,7 +172,12 @@ std::unique_ptr<State> MCTSBot::ApplyTreePolicy(
          (w->IsChanceNode() && dont_return_chance_node_)) {
     if (node->children.empty()) {
       ActionsAndProbs legal = evaluator_->Prior(*w);
-      std::shuffle(legal.begin(), legal.end(), rng_);
+      if (counter_) {  // Fisher-Yates on the counter stream (the device's shuffle)
+        for (int i = static_cast<int>(legal.size()) - 1; i >= 1; --i)
+          std::swap(legal[i], legal[trng_.Below(static_cast<uint32_t>(i + 1))]);
+      } else {
+        std::shuffle(legal.begin(), legal.end(), rng_);
+      }
       Player mover = w->CurrentPlayer();
       node->children.reserve(legal.size());
       for (const auto& ap : legal)
@@ -181,7 +186,7 @@ std::unique_ptr<State> MCTSBot::ApplyTreePolicy(
     }
     SearchNode* chosen = nullptr;
     if (w->IsChanceNode()) {
-      double z = (rng_() >> 5) * (1.0 / 134217728.0);
+      double z = counter_ ? trng_.Unit() : (rng_() >> 5) * (1.0 / 134217728.0);
       Action a = SampleAction(w->ChanceOutcomes(), z).first;
       for (SearchNode& c : node->children)
         if (c.action == a) {
@@ -217,6 +222,7 @@ std::unique_ptr<SearchNode> MCTSBot::MCTSearch(const State& state) {
   path.reserve(64);
   for (int sim = 0; sim < max_simulations_; ++sim) {
     path.clear();
+    if (counter_) trng_ = CounterRng(c_seed_ ^ kTreeSalt, c_root_, static_cast<uint64_t>(sim));
     std::unique_ptr<State> leaf = ApplyTreePolicy(root.get(), state, &path);
     std::vector<double> returns;
     bool solved;
@@ -225,7 +231,7 @@ std::unique_ptr<SearchNode> MCTSBot::MCTSearch(const State& state) {
       path.back()->outcome = returns;
       solved = solve_;
     } else {
-      returns = evaluator_->Evaluate(*leaf);
+      returns = counter_ ? CounterEvaluate(*leaf, sim) : evaluator_->Evaluate(*leaf);
       solved = false;
     }
     while (!path.empty()) {  // backup, mcts.cc:383-435
@@ -267,6 +273,27 @@ std::unique_ptr<SearchNode> MCTSBot::MCTSearch(const State& state) {
     }
   }
   return root;
+}
+
+std::vector<double> MCTSBot::CounterEvaluate(const State& state, int sim) const {
+  // RandomRolloutEvaluator::Evaluate (mcts.cc:43-72) on the device's counter streams.
+  std::vector<double> total(state.NumPlayers(), 0.0);
+  for (int r = 0; r < c_rollouts_; ++r) {
+    CounterRng rng(c_seed_, c_root_, static_cast<uint64_t>(sim) * c_rollouts_ + r);
+    std::unique_ptr<State> w = state.Clone();
+    while (!w->IsTerminal()) {
+      if (w->IsChanceNode()) {
+        w->ApplyAction(SampleAction(w->ChanceOutcomes(), rng.Unit()).first);
+      } else {
+        std::vector<Action> legal = w->LegalActions();
+        w->ApplyAction(legal[rng.Below(static_cast<uint32_t>(legal.size()))]);
+      }
+    }
+    std::vector<double> ret = w->Returns();
+    for (size_t k = 0; k < total.size(); ++k) total[k] += ret[k];
+  }
+  for (double& v : total) v /= c_rollouts_;
+  return total;
 }
 
 void MCTSBot::GarbageCollect(SearchNode* node) {  // mcts.cc:469-482

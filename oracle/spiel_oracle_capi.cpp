@@ -1,6 +1,7 @@
 // CPU ORACLE — TEST INFRASTRUCTURE ONLY (see spiel_oracle.h).
 // extern "C" surface so tests/, bench.py's cpu_baseline leg and
 // __graft_entry__.smoke() can drive the oracle through ctypes.
+#include <map>
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -283,15 +284,20 @@ int osgo_replay_rollouts(void* g, const int16_t* history, int hist_len,
 // out_children: per root child {action, explore_count, total_reward, outcome
 // for the root player or NaN}; returns the number of children, best action in
 // *best_action, root outcome (for root player; NaN if unsolved) in *root_outcome.
+// counter_root >= 0: replay mode, all draws from the device's counter streams for
+// that root index with seed `counter_seed` (MCTSBot::UseCounterStreams).
 int osgo_mcts_search(void* s, double uct_c, int max_simulations, int n_rollouts,
                      int64_t max_memory_mb, int solve, int seed,
                      int64_t* best_action, double* root_outcome,
-                     double* out_children, int cap, int* root_visits) {
+                     double* out_children, int cap, int* root_visits,
+                     int64_t counter_root, uint64_t counter_seed) {
   return Guard([&] {
     const State& st = *static_cast<StateH*>(s)->state;
     auto ev = std::make_shared<RandomRolloutEvaluator>(n_rollouts, seed);
     MCTSBot bot(*st.GetGame(), ev, uct_c, max_simulations, max_memory_mb,
                 solve != 0, seed, false);
+    if (counter_root >= 0)
+      bot.UseCounterStreams(counter_seed, static_cast<uint64_t>(counter_root), n_rollouts);
     std::unique_ptr<SearchNode> root = bot.MCTSearch(st);
     const double nan = std::numeric_limits<double>::quiet_NaN();
     *best_action = root->children.empty() ? -1 : root->BestChild().action;
@@ -363,6 +369,62 @@ int osgo_cfr_iterate(void* h, int iters) {
     for (int i = 0; i < iters; ++i) {
       if (c->cfr) c->cfr->EvaluateAndUpdatePolicy();
       else c->mccfr->RunIteration();
+    }
+    return 0;
+  });
+}
+// The DEVICE's mini-batch schedule of external-sampling MCCFR, restated on the
+// oracle's solver: trajectories [first, first+count) all read the table as it
+// is at the start of the call (trajectory g: traverser g mod P, uniforms from
+// CounterRng(seed, g, 0).Unit() in visiting order); their regret / average-policy
+// increments (external_sampling_mccfr.cc:167-183) are summed and folded in at
+// the end.  With count == 1 this is exactly one UpdateRegrets call.
+int osgo_mccfr_minibatch(void* h, uint64_t seed, int64_t first, int64_t count) {
+  return Guard([&] {
+    auto* c = static_cast<CfrH*>(h);
+    ORACLE_CHECK(c->mccfr);
+    CFRInfoStateValuesTable& table = c->mccfr->InfoStateValuesTable();
+    const int P = c->game->NumPlayers();
+    std::map<std::string, CFRInfoStateValues> delta;  // regrets / cum_policy hold the summed increments
+    for (int64_t g = first; g < first + count; ++g) {
+      const CFRInfoStateValuesTable frozen = table;
+      CounterRng rng(seed, static_cast<uint64_t>(g), 0);
+      c->mccfr->UpdateRegretsWith(*c->game->NewInitialState(), static_cast<Player>(g % P),
+                                  [&rng]() { return rng.Unit(); });
+      for (const auto& kv : table) {
+        auto fz = frozen.find(kv.first);
+        const size_t n = kv.second.legal_actions.size();
+        auto it = delta.find(kv.first);
+        if (it == delta.end()) {
+          CFRInfoStateValues zero(kv.second.legal_actions, 0.0);
+          it = delta.emplace(kv.first, zero).first;
+        }
+        for (size_t a = 0; a < n; ++a) {
+          const double r0 = fz == frozen.end() ? ExternalSamplingMCCFRSolver::kInitialTableValues
+                                               : fz->second.cumulative_regrets[a];
+          const double p0 = fz == frozen.end() ? ExternalSamplingMCCFRSolver::kInitialTableValues
+                                               : fz->second.cumulative_policy[a];
+          it->second.cumulative_regrets[a] += kv.second.cumulative_regrets[a] - r0;
+          it->second.cumulative_policy[a] += kv.second.cumulative_policy[a] - p0;
+        }
+      }
+      // back to the frozen values; rows first seen by this trajectory stay, at their initial values
+      for (auto& kv : table) {
+        auto fz = frozen.find(kv.first);
+        for (size_t a = 0; a < kv.second.legal_actions.size(); ++a) {
+          kv.second.cumulative_regrets[a] = fz == frozen.end() ? ExternalSamplingMCCFRSolver::kInitialTableValues
+                                                               : fz->second.cumulative_regrets[a];
+          kv.second.cumulative_policy[a] = fz == frozen.end() ? ExternalSamplingMCCFRSolver::kInitialTableValues
+                                                              : fz->second.cumulative_policy[a];
+        }
+      }
+    }
+    for (auto& kv : table) {
+      const auto& d = delta.at(kv.first);
+      for (size_t a = 0; a < kv.second.legal_actions.size(); ++a) {
+        kv.second.cumulative_regrets[a] += d.cumulative_regrets[a];
+        kv.second.cumulative_policy[a] += d.cumulative_policy[a];
+      }
     }
     return 0;
   });

@@ -1,0 +1,214 @@
+"""Parity of the device CFR / CFR+ / external-sampling MCCFR against the CPU oracle.
+
+Bar (BASELINE.json north_star): CFR average-policy probabilities within 1e-6 of
+the reference.  The device kernels add the same terms in the same order as the
+reference's recursion (cfr.cc:331-408), so the tables are in fact compared at
+1e-12 here; the 1e-6 bar is asserted on the average policy.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# SURVEY.md Appendix B / integration_tests/api_test.py:75-101
+TREE_SIZES = {
+    "kuhn_poker": (58, 4, 24, 30, 12, 2),
+    "kuhn_poker(players=3)": (617, 17, 288, 312, 48, 2),
+    "leduc_poker": (9457, 157, 3780, 5520, 936, 3),
+}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import open_spiel_amd as osa
+    return osa.Context(0)
+
+
+def _by_key(t):
+    return {k: i for i, k in enumerate(t["keys"])}
+
+
+def _compare_tables(dev, orc, atol, what):
+    """dev: TabularSolver.tables(); orc: oracle Solver.tables() (rows sorted by key)."""
+    assert sorted(dev["keys"]) == sorted(orc["keys"]), what
+    d_idx = _by_key(dev)
+    worst = 0.0
+    for j, k in enumerate(orc["keys"]):
+        i = d_idx[k]
+        n = int(orc["nact"][j])
+        assert int(dev["nact"][i]) == n
+        assert dev["legal"][i, :n].tolist() == orc["legal"][j, :n].tolist()
+        for name in ("regrets", "cum_policy", "cur_policy", "avg_policy"):
+            diff = np.abs(dev[name][i, :n] - orc[name][j, :n]).max()
+            worst = max(worst, diff)
+            assert diff <= atol, f"{what}: {name} at {k!r}: {dev[name][i, :n]} vs {orc[name][j, :n]}"
+    return worst
+
+
+@pytest.mark.parametrize("game", list(TREE_SIZES))
+def test_tree_census_and_keys(oracle, ctx, game):
+    import open_spiel_amd as osa
+    s = osa.TabularSolver(ctx, game)
+    got = (s.num_histories, s.num_chance, s.num_decision, s.num_terminal, s.num_infostates, s.amax)
+    assert got == TREE_SIZES[game]
+    og = oracle.Game(game)
+    o = oracle.Solver(og, "cfr")
+    assert sorted(s.tables()["keys"]) == sorted(o.tables(s.amax)["keys"])
+    t = s.tables()
+    # CFRInfoStateValues initial state: regrets 0, cumulative policy 0, current policy uniform
+    assert not t["regrets"].any() and not t["cum_policy"].any()
+    for i, n in enumerate(t["nact"]):
+        assert t["cur_policy"][i, :n].tolist() == [1.0 / n] * n
+
+
+@pytest.mark.parametrize("game,kind,kwargs,checkpoints", [
+    ("kuhn_poker", "cfr", {}, [1, 2, 10, 100, 300]),
+    ("kuhn_poker", "cfr_plus", dict(linear_averaging=True, regret_matching_plus=True), [1, 5, 200]),
+    ("kuhn_poker", "cfr_simultaneous", dict(alternating_updates=False), [1, 2, 50]),
+    ("kuhn_poker(players=3)", "cfr", {}, [1, 10, 40]),
+    ("kuhn_poker(players=3)", "cfr_plus", dict(linear_averaging=True, regret_matching_plus=True), [10]),
+    ("leduc_poker", "cfr", {}, [1, 2, 10]),
+    ("leduc_poker", "cfr_plus", dict(linear_averaging=True, regret_matching_plus=True), [5]),
+])
+def test_cfr_tables_match_the_oracle(oracle, ctx, game, kind, kwargs, checkpoints):
+    import open_spiel_amd as osa
+    og = oracle.Game(game)
+    o = oracle.Solver(og, kind)
+    s = osa.TabularSolver(ctx, game, **kwargs)
+    done = 0
+    for cp in checkpoints:
+        o.iterate(cp - done)
+        s.evaluate_and_update_policy(cp - done)  # one launch, all iterations inside
+        done = cp
+        assert s.iteration == cp
+        worst = _compare_tables(s.tables(), o.tables(s.amax), 1e-12, f"{game} {kind} after {cp} iterations")
+        d = s.tables()
+        # the north-star bar, stated explicitly: average-policy probabilities within 1e-6
+        ot = o.tables(s.amax)
+        di = _by_key(d)
+        for j, k in enumerate(ot["keys"]):
+            assert np.abs(d["avg_policy"][di[k]] - ot["avg_policy"][j]).max() <= 1e-6
+        del worst
+
+
+def test_iterating_one_by_one_equals_one_launch(ctx):
+    import open_spiel_amd as osa
+    a = osa.TabularSolver(ctx, "kuhn_poker")
+    b = osa.TabularSolver(ctx, "kuhn_poker")
+    a.evaluate_and_update_policy(25)
+    for _ in range(25):
+        b.evaluate_and_update_policy(1)
+    ta, tb = a.tables(), b.tables()
+    for name in ("regrets", "cum_policy", "cur_policy"):
+        np.testing.assert_array_equal(ta[name], tb[name])
+    a.reset()
+    assert a.iteration == 0 and not a.tables()["regrets"].any()
+
+
+def _judge(oracle, game, solver, which=0):
+    t = solver.tables()
+    og = oracle.Game(game)
+    return og.eval_policy(t["keys"], t["nact"], t["legal"].astype(np.int64), t["avg_policy"], which)
+
+
+def test_kuhn_cfr_converges_like_the_reference(oracle, ctx):
+    """cfr_test.cc:36-62: 300 iterations -> game value -1/18 +- 1e-3, exploitability <= 0.05."""
+    import open_spiel_amd as osa
+    s = osa.TabularSolver(ctx, "kuhn_poker")
+    s.evaluate_and_update_policy(300)
+    expl, ev = _judge(oracle, "kuhn_poker", s, which=1)
+    assert expl <= 0.05
+    assert abs(ev[0] - (-1.0 / 18)) <= 1e-3 and abs(ev[1] - 1.0 / 18) <= 1e-3
+
+
+def test_cfr_plus_converges_like_the_reference(oracle, ctx):
+    """cfr_test.cc:94-103: CFR+ 200 iterations on kuhn."""
+    import open_spiel_amd as osa
+    s = osa.TabularSolver(ctx, "kuhn_poker", linear_averaging=True, regret_matching_plus=True)
+    s.evaluate_and_update_policy(200)
+    expl, ev = _judge(oracle, "kuhn_poker", s, which=1)
+    assert expl <= 0.05
+    assert abs(ev[0] - (-1.0 / 18)) <= 1e-3
+
+
+def test_leduc_nash_conv_matches_oracle_each_iteration(oracle, ctx):
+    """python/algorithms/cfr_test.py:241-272 style: NashConv agrees after each of 5 iterations."""
+    import open_spiel_amd as osa
+    og = oracle.Game("leduc_poker")
+    o = oracle.Solver(og, "cfr")
+    s = osa.TabularSolver(ctx, "leduc_poker")
+    for _ in range(5):
+        o.iterate(1)
+        s.evaluate_and_update_policy(1)
+        nc, _ = _judge(oracle, "leduc_poker", s, which=0)
+        assert abs(nc - o.nash_conv()) <= 1e-10
+
+
+@pytest.mark.parametrize("game,batches", [
+    ("kuhn_poker", [(0, 1), (1, 1), (2, 7), (9, 300), (309, 1000)]),
+    ("leduc_poker", [(0, 1), (1, 2), (3, 64), (67, 500)]),
+    ("kuhn_poker(players=3)", [(0, 3), (3, 200)]),
+])
+def test_mccfr_minibatch_replay_parity(oracle, ctx, game, batches):
+    """Same tables + same uniform streams => same regret / average-policy deltas: the
+    device mini-batch vs the oracle's UpdateRegrets replayed on a frozen table."""
+    import open_spiel_amd as osa
+    og = oracle.Game(game)
+    o = oracle.Solver(og, "mccfr_simple", seed=0)
+    s = osa.TabularSolver(ctx, game, mccfr=True)
+    seed = 0xBADC0DE
+    for first, count in batches:
+        o.mccfr_minibatch(seed, first, count)
+        s.run_mccfr(seed, count, first_trajectory=first)
+        dev, orc = s.tables(), o.tables(s.amax)
+        d_idx = _by_key(dev)
+        seen = set(orc["keys"])
+        for j, k in enumerate(orc["keys"]):
+            i, n = d_idx[k], int(orc["nact"][j])
+            for name in ("regrets", "cum_policy"):
+                np.testing.assert_allclose(dev[name][i, :n], orc[name][j, :n], rtol=1e-11, atol=1e-12,
+                                           err_msg=f"{game} batch {(first, count)} {name} at {k!r}")
+        for k, i in d_idx.items():  # rows the oracle never visited are still at their initial 1e-6
+            if k not in seen:
+                n = int(dev["nact"][i])
+                assert dev["regrets"][i, :n].tolist() == [1e-6] * n
+                assert dev["cum_policy"][i, :n].tolist() == [1e-6] * n
+
+
+@pytest.mark.parametrize("game,bound,batch,nbatches", [
+    ("kuhn_poker", 0.05, 64, 200),       # external_sampling_mccfr_test.cc:104-109: 1000 iterations
+    ("leduc_poker", 2.5, 256, 60),
+])
+def test_mccfr_converges_like_the_reference(oracle, ctx, game, bound, batch, nbatches):
+    import open_spiel_amd as osa
+    s = osa.TabularSolver(ctx, game, mccfr=True)
+    for b in range(nbatches):
+        s.run_mccfr(230398247, batch, first_trajectory=b * batch)
+    nc, _ = _judge(oracle, game, s, which=0)
+    assert nc <= bound, nc
+
+
+def test_mccfr_sample_then_apply_equals_iterate(ctx):
+    import open_spiel_amd as osa
+    a = osa.TabularSolver(ctx, "leduc_poker", mccfr=True)
+    b = osa.TabularSolver(ctx, "leduc_poker", mccfr=True)
+    a.run_mccfr(5, 4096)
+    # two half-batches sampled from the same frozen table, deltas summed, folded once
+    import torch
+    b.mccfr_sample(5, 2048, first_trajectory=0)
+    dr, dp = b.mccfr_delta_tables()
+    keep_r, keep_p = dr.clone(), dp.clone()
+    b.mccfr_sample(5, 2048, first_trajectory=2048)
+    dr += keep_r
+    dp += keep_p
+    torch.cuda.synchronize()
+    b.mccfr_apply_deltas()
+    ta, tb = a.tables(), b.tables()
+    np.testing.assert_allclose(ta["regrets"], tb["regrets"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(ta["cum_policy"], tb["cum_policy"], rtol=1e-11, atol=1e-11)
+
+
+def test_cfr_rejects_board_games(ctx):
+    import open_spiel_amd as osa
+    with pytest.raises(osa.OsgError):
+        osa.TabularSolver(ctx, "tic_tac_toe")

@@ -1,0 +1,161 @@
+"""MCTS on the device vs the oracle's MCTSBot.
+
+RNG-stream parity with the reference is impossible by construction (abseil's
+distributions are unpinned), so parity is established in two ways:
+  * replay: the oracle's MCTSBot (pinned by the reference's known-answer tests,
+    tests/test_oracle_known_answers.py) runs with every draw taken from the
+    device's counter streams; visit counts, total rewards, proven outcomes and
+    the chosen action must then be IDENTICAL, root by root;
+  * the reference's own behavioural tests (mcts_test.cc:126-155 solver answers).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import open_spiel_amd as osa
+    return osa.Context(0)
+
+
+def _roots(oracle, ctx, game, n, seed, max_stop, min_stop=0):
+    import torch
+    import open_spiel_amd as osa
+    og = oracle.Game(game)
+    rng = np.random.default_rng(seed)
+    stop = rng.integers(min_stop, max_stop + 1, n).astype(np.int32)
+    rec = og.random_playouts(seed, n, stop=stop)
+    roots = osa.StateBatch(ctx, game, n)
+    for t in range(og.max_plies):
+        if (rec["actions"][:, t] < 0).all():
+            break
+        roots.apply_actions(torch.from_numpy(rec["actions"][:, t].astype(np.int32)))
+    hists = [rec["actions"][i][rec["actions"][i] >= 0].tolist() for i in range(n)]
+    return og, roots, hists
+
+
+def _oracle_state(og, hist):
+    s = og.new_initial_state()
+    for a in hist:
+        s.apply_action(int(a))
+    return s
+
+
+@pytest.mark.parametrize("game,n,sims,n_rollouts,solve,max_stop", [
+    ("tic_tac_toe", 96, 200, 3, True, 7),
+    ("tic_tac_toe", 64, 64, 1, False, 5),
+    ("connect_four", 64, 150, 2, True, 30),
+    ("hex(board_size=5)", 48, 120, 1, True, 18),
+    ("hex(board_size=9)", 24, 200, 1, False, 40),
+    ("kuhn_poker", 48, 100, 2, False, 4),
+    ("leduc_poker", 48, 150, 1, False, 8),
+])
+def test_mcts_replay_parity(oracle, ctx, game, n, sims, n_rollouts, solve, max_stop):
+    min_stop = 2 if "poker" in game else 0  # past the private deals: MCTSBot moves at decision nodes
+    og, roots, hists = _roots(oracle, ctx, game, n, 17, max_stop, min_stop)
+    seed, offset = 0xFEED5EED, 12345
+    res = roots.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=n_rollouts, solve=solve, seed=seed,
+                            index_offset=offset)
+    best = res["best_action"].cpu().numpy()
+    visits = res["child_visits"].cpu().numpy()
+    reward = res["child_reward"].cpu().numpy()
+    outcome = res["child_outcome"].cpu().numpy()
+    stats = res["root_stats"].cpu().numpy()
+    checked = 0
+    for i in range(n):
+        st = _oracle_state(og, hists[i])
+        if st.is_chance_node():
+            continue  # MCTSBot is never asked to move at a chance node
+        want = st.mcts_search(2.0, sims, n_rollouts, 4096, solve, 0, counter_root=offset + i, counter_seed=seed)
+        assert stats[i, 0] == want["root_visits"], f"{game} root {i}: root visits"
+        acts = want["children"][:, 0].astype(int)
+        got_children = np.nonzero(outcome[i] != 3)[0]
+        assert sorted(acts.tolist()) == got_children.tolist(), f"{game} root {i}: children"
+        for a, cnt, tot, out in want["children"]:
+            a = int(a)
+            assert visits[i, a] == cnt, f"{game} root {i} action {a}: visits {visits[i, a]} vs {cnt}"
+            assert reward[i, a] == tot, f"{game} root {i} action {a}: reward {reward[i, a]} vs {tot}"
+            if solve:
+                assert (outcome[i, a] == 2) == np.isnan(out)
+                if not np.isnan(out):
+                    assert outcome[i, a] == out
+        if len(acts):
+            assert best[i] == want["best_action"], f"{game} root {i}: best action"
+        if solve:
+            assert np.isnan(stats[i, 2]) == np.isnan(want["root_outcome"])
+            if not np.isnan(want["root_outcome"]):
+                assert stats[i, 2] == want["root_outcome"]
+        checked += 1
+    assert checked >= n // 3
+
+
+def _ttt_batch(ctx, moves, n=4):
+    import torch
+    import open_spiel_amd as osa
+    b = osa.StateBatch(ctx, "tic_tac_toe", n)
+    for a in moves:
+        b.apply_actions(torch.full((n,), a, dtype=torch.int32))
+    return b
+
+
+def test_solver_known_answers(ctx):
+    """mcts_test.cc:126-155 (UCT_C=2, RandomRolloutEvaluator(20, 42), 10000 simulations,
+    solve=true): the three MCTS-Solver positions of the reference's own test."""
+    # MCTSTest_SolveDraw: "x(1,1) o(0,0) x(2,2)" -> "o..\n.x.\n..x", o to move, proven draw
+    b = _ttt_batch(ctx, [4, 0, 8])
+    r = b.mcts_search(uct_c=2.0, max_simulations=10000, n_rollouts=20, solve=True, seed=42)
+    stats = r["root_stats"].cpu().numpy()
+    outcome = r["child_outcome"].cpu().numpy()
+    best = r["best_action"].cpu().numpy()
+    assert (stats[:, 2] == 0).all()                       # root->outcome[root->player] == 0
+    for i in range(len(best)):
+        kids = outcome[i][outcome[i] != 3]
+        assert (kids <= 0).all() or (kids == 2).any()     # no winning moves among proven children
+        assert not ((kids == 1).any())
+        assert outcome[i, best[i]] == 0                   # best.outcome[best.player] == 0
+        assert best[i] in (6, 2)                          # o(2,0) or o(0,2); all others lose
+    # MCTSTest_SolveLoss: "... o(0,1) x(0,2)" -> "oox\n.x.\n..x": every move loses
+    b = _ttt_batch(ctx, [4, 0, 8, 1, 2])
+    r = b.mcts_search(uct_c=2.0, max_simulations=10000, n_rollouts=20, solve=True, seed=42)
+    stats = r["root_stats"].cpu().numpy()
+    outcome = r["child_outcome"].cpu().numpy()
+    assert (stats[:, 2] == -1).all()
+    for i in range(outcome.shape[0]):
+        kids = outcome[i][outcome[i] != 3]
+        assert len(kids) == 4 and (kids == -1).all()
+    # MCTSTest_SolveWin: "x(0,1) o(2,2)" -> ".x.\n...\n..o": x wins, best move x(0,2)
+    b = _ttt_batch(ctx, [1, 8])
+    r = b.mcts_search(uct_c=2.0, max_simulations=10000, n_rollouts=20, solve=True, seed=42)
+    stats = r["root_stats"].cpu().numpy()
+    outcome = r["child_outcome"].cpu().numpy()
+    best = r["best_action"].cpu().numpy()
+    assert (stats[:, 2] == 1).all()
+    assert (best == 2).all()
+    assert (outcome[np.arange(len(best)), best] == 1).all()
+
+
+def test_search_is_independent_of_batch_position_and_sharding(ctx, oracle):
+    """Root i's search depends only on (seed, index_offset + i): the same roots searched as
+    one batch or as two shards give identical statistics (multi-GPU sharding by root index)."""
+    import torch
+    og, roots, _ = _roots(oracle, ctx, "hex(board_size=5)", 64, 5, 10)
+    whole = roots.mcts_search(max_simulations=80, seed=9, index_offset=0)
+    lo = roots.gather(torch.arange(0, 32)).mcts_search(max_simulations=80, seed=9, index_offset=0)
+    hi = roots.gather(torch.arange(32, 64)).mcts_search(max_simulations=80, seed=9, index_offset=32)
+    for key in ("best_action", "child_visits", "child_reward"):
+        got = torch.cat([lo[key], hi[key]]).cpu().numpy()
+        np.testing.assert_array_equal(got, whole[key].cpu().numpy())
+    del og
+
+
+def test_small_pool_still_searches(ctx):
+    """With a node pool too small to expand everything the search degrades to leaf
+    evaluation instead of failing (the reference garbage-collects, mcts.cc:441-482)."""
+    import open_spiel_amd as osa
+    b = osa.StateBatch(ctx, "connect_four", 128)
+    r = b.mcts_search(max_simulations=300, max_nodes=40, seed=3)
+    stats = r["root_stats"].cpu().numpy()
+    assert (stats[:, 0] == 300).all() and (stats[:, 1] <= 40).all()
+    assert (r["child_visits"].sum(1).cpu().numpy() == 299).all()

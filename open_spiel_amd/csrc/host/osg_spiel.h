@@ -1,0 +1,518 @@
+// Host-side C++ mirror of the reference's API for the hot path, over the C-ABI.
+//
+// Same class / method names and argument meaning as the reference so that code
+// written against open_spiel::{Game, State, algorithms::MCTSBot, CFRSolver, ...}
+// reads the same here (namespace open_spiel::hip):
+//
+//   Game / State / LoadGame         open_spiel/spiel.h:301-916, 927-1255, 1314
+//   Evaluator / RandomRolloutEvaluator / SearchNode / MCTSBot
+//                                   open_spiel/algorithms/mcts.h:83-220
+//   CFRInfoStateValues / CFRSolverBase / CFRSolver / CFRPlusSolver
+//                                   open_spiel/algorithms/cfr.h:42-357
+//   ExternalSamplingMCCFRSolver     open_spiel/algorithms/external_sampling_mccfr.h:57-113
+//
+// plus BatchedState, the batch form the device actually wants.  Header-only;
+// every rule evaluation happens in libosg_hip.so (HIP, gfx950).  Errors become
+// SpielException (the reference's pybind handler does the same,
+// python/pybind11/pyspiel.cc:831-837).  Objects are single-threaded like the
+// reference's State / Bot / solver objects.
+#ifndef OSG_HOST_OSG_SPIEL_H_
+#define OSG_HOST_OSG_SPIEL_H_
+
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "../../../include/osg_abi.h"
+
+namespace open_spiel {
+namespace hip {
+
+using Action = int64_t;  // spiel_utils.h:134-135
+using Player = int;
+constexpr Player kChancePlayerId = OSG_CHANCE_PLAYER;      // spiel_globals.h:26-56
+constexpr Player kTerminalPlayerId = OSG_TERMINAL_PLAYER;
+constexpr Action kInvalidAction = OSG_INVALID_ACTION;      // spiel_globals.h:82
+using ActionsAndProbs = std::vector<std::pair<Action, double>>;  // spiel.h:224
+
+struct SpielException : public std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+[[noreturn]] inline void SpielFatalError(const std::string& msg) { throw SpielException(msg); }
+inline void Check(int rc) {
+  if (rc != OSG_OK) SpielFatalError(std::string("osg error ") + std::to_string(rc) + ": " + osg_last_error());
+}
+
+// One engine context per (process, device), created on first use with its own stream.
+class Context {
+ public:
+  static osg_ctx* Default(int device = 0) {
+    static std::unordered_map<int, std::unique_ptr<Context>> table;
+    auto it = table.find(device);
+    if (it == table.end()) it = table.emplace(device, std::unique_ptr<Context>(new Context(device))).first;
+    return it->second->ctx_;
+  }
+  ~Context() { osg_ctx_destroy(ctx_); }
+
+ private:
+  explicit Context(int device) { Check(osg_ctx_create(device, nullptr, /*own_stream=*/1, &ctx_)); }
+  osg_ctx* ctx_ = nullptr;
+};
+
+class State;
+class BatchedState;
+
+class Game : public std::enable_shared_from_this<Game> {
+ public:
+  explicit Game(const std::string& game_string, int device = 0) : string_(game_string), device_(device) {
+    Check(osg_game_describe(game_string.c_str(), &desc_));
+  }
+  int NumDistinctActions() const { return desc_.num_distinct_actions; }
+  int MaxChanceOutcomes() const { return desc_.max_chance_outcomes; }
+  int NumPlayers() const { return desc_.num_players; }
+  double MinUtility() const { return desc_.min_utility; }
+  double MaxUtility() const { return desc_.max_utility; }
+  int MaxGameLength() const { return desc_.max_game_length; }
+  int MaxChanceNodesInHistory() const { return desc_.max_chance_nodes; }
+  std::vector<int> ObservationTensorShape() const {
+    return std::vector<int>(desc_.obs_shape, desc_.obs_shape + desc_.obs_rank);
+  }
+  std::vector<int> InformationStateTensorShape() const {
+    return std::vector<int>(desc_.info_shape, desc_.info_shape + desc_.info_rank);
+  }
+  int ObservationTensorSize() const { return desc_.obs_size; }
+  int InformationStateTensorSize() const { return desc_.info_size; }
+  std::string ToString() const { return desc_.canonical; }
+  const std::string& GameString() const { return string_; }
+  const osg_game_desc& Desc() const { return desc_; }
+  osg_ctx* Ctx() const { return Context::Default(device_); }
+  inline std::unique_ptr<State> NewInitialState() const;
+  inline BatchedState NewInitialStates(int64_t n) const;
+
+ private:
+  std::string string_;
+  int device_;
+  osg_game_desc desc_{};
+};
+
+inline std::shared_ptr<const Game> LoadGame(const std::string& game_string) {  // spiel.h:1314
+  return std::make_shared<const Game>(game_string);
+}
+
+// N states of one game in HBM.  Vector-valued results are [n, ...] row-major.
+class BatchedState {
+ public:
+  BatchedState(std::shared_ptr<const Game> game, int64_t n) : game_(std::move(game)), n_(n) {
+    Check(osg_batch_create(game_->Ctx(), game_->GameString().c_str(), n, &b_));
+  }
+  BatchedState(const BatchedState& o) : game_(o.game_), n_(o.n_) {  // State::Clone for the whole batch
+    Check(osg_batch_create(game_->Ctx(), game_->GameString().c_str(), n_, &b_));
+    Check(osg_batch_copy(b_, o.b_));
+  }
+  BatchedState(BatchedState&& o) noexcept : game_(std::move(o.game_)), n_(o.n_), b_(o.b_) { o.b_ = nullptr; }
+  BatchedState& operator=(const BatchedState&) = delete;
+  ~BatchedState() { if (b_) osg_batch_destroy(b_); }
+
+  int64_t size() const { return n_; }
+  osg_batch* handle() const { return b_; }
+  const std::shared_ptr<const Game>& GetGame() const { return game_; }
+
+  std::vector<uint32_t> LegalActionsMaskBits() const {  // [n, mask_words]
+    std::vector<uint32_t> m(static_cast<size_t>(n_) * game_->Desc().mask_words);
+    Check(osg_legal_mask(b_, m.data(), 1));
+    return m;
+  }
+  // ApplyAction for every state; -1 leaves a state untouched; illegal actions are fatal.
+  void ApplyActions(const std::vector<int32_t>& actions) {
+    if (static_cast<int64_t>(actions.size()) != n_) SpielFatalError("ApplyActions: need one action per state");
+    int64_t illegal = 0;
+    Check(osg_apply(b_, actions.data(), 1, &illegal));
+    if (illegal) SpielFatalError(std::to_string(illegal) + " illegal action(s) applied");
+  }
+  std::vector<uint8_t> IsTerminal() const {
+    std::vector<uint8_t> t(n_);
+    Check(osg_status_query(b_, nullptr, t.data(), nullptr, 1));
+    return t;
+  }
+  std::vector<int8_t> CurrentPlayer() const {
+    std::vector<int8_t> c(n_);
+    Check(osg_status_query(b_, c.data(), nullptr, nullptr, 1));
+    return c;
+  }
+  std::vector<double> Returns() const {  // [n, P]
+    std::vector<double> r(static_cast<size_t>(n_) * game_->NumPlayers());
+    Check(osg_status_query(b_, nullptr, nullptr, r.data(), 1));
+    return r;
+  }
+  std::vector<double> ChanceOutcomeProbs() const {  // [n, MaxChanceOutcomes]
+    std::vector<double> p(static_cast<size_t>(n_) * std::max(game_->MaxChanceOutcomes(), 1));
+    Check(osg_chance_probs(b_, p.data(), 1));
+    return p;
+  }
+  std::vector<float> ObservationTensor(Player player) const {
+    std::vector<float> o(static_cast<size_t>(n_) * game_->ObservationTensorSize());
+    Check(osg_observation(b_, player, 0, o.data(), 1));
+    return o;
+  }
+  std::vector<float> InformationStateTensor(Player player) const {
+    std::vector<float> o(static_cast<size_t>(n_) * game_->InformationStateTensorSize());
+    Check(osg_observation(b_, player, 1, o.data(), 1));
+    return o;
+  }
+
+ private:
+  std::shared_ptr<const Game> game_;
+  int64_t n_;
+  osg_batch* b_ = nullptr;
+};
+
+// One state: the reference's State interface on a 1-element batch.
+class State {
+ public:
+  explicit State(std::shared_ptr<const Game> game) : batch_(std::move(game), 1) {}
+  State(const State&) = default;
+
+  Player CurrentPlayer() const { return batch_.CurrentPlayer()[0]; }
+  bool IsTerminal() const { return batch_.IsTerminal()[0] != 0; }
+  bool IsChanceNode() const { return CurrentPlayer() == kChancePlayerId; }
+  std::vector<double> Returns() const { return batch_.Returns(); }
+  std::vector<double> Rewards() const { return Returns(); }  // every game here is RewardModel::kTerminal
+  double PlayerReturn(Player p) const { return Returns()[p]; }
+  std::vector<Action> LegalActions() const {  // sorted ascending (basic_tests.cc:784-792)
+    std::vector<uint32_t> bits = batch_.LegalActionsMaskBits();
+    std::vector<Action> out;
+    for (size_t w = 0; w < bits.size(); ++w)
+      for (int b = 0; b < 32; ++b)
+        if ((bits[w] >> b) & 1u) out.push_back(static_cast<Action>(w * 32 + b));
+    return out;
+  }
+  std::vector<Action> LegalActions(Player player) const {  // spiel.h:366-372
+    if (!IsChanceNode() && !IsTerminal() && player != CurrentPlayer()) return {};
+    return LegalActions();
+  }
+  std::vector<int> LegalActionsMask() const {  // spiel.cc:518-524
+    const Game& g = *batch_.GetGame();
+    const int len = IsChanceNode() ? g.MaxChanceOutcomes() : g.NumDistinctActions();
+    std::vector<int> mask(len, 0);
+    for (Action a : LegalActions()) mask[a] = 1;
+    return mask;
+  }
+  ActionsAndProbs ChanceOutcomes() const {
+    std::vector<double> p = batch_.ChanceOutcomeProbs();
+    ActionsAndProbs out;
+    for (size_t o = 0; o < p.size(); ++o)
+      if (p[o] > 0) out.emplace_back(static_cast<Action>(o), p[o]);
+    return out;
+  }
+  void ApplyAction(Action a) {  // spiel.cc:441-451
+    if (a == kInvalidAction) SpielFatalError("ApplyAction: kInvalidAction");
+    const Player p = CurrentPlayer();
+    batch_.ApplyActions({static_cast<int32_t>(a)});
+    history_.push_back({p, a});
+  }
+  std::vector<float> ObservationTensor(Player player) const {  // spiel.cc:908-919 bounds check
+    CheckPlayer(player);
+    return batch_.ObservationTensor(player);
+  }
+  std::vector<float> InformationStateTensor(Player player) const {
+    CheckPlayer(player);
+    return batch_.InformationStateTensor(player);
+  }
+  std::unique_ptr<State> Clone() const { return std::unique_ptr<State>(new State(*this)); }
+  std::unique_ptr<State> Child(Action a) const {  // spiel.h:737-744
+    std::unique_ptr<State> c = Clone();
+    c->ApplyAction(a);
+    return c;
+  }
+  std::vector<Action> History() const {
+    std::vector<Action> h;
+    for (const auto& pa : history_) h.push_back(pa.second);
+    return h;
+  }
+  int MoveNumber() const { return static_cast<int>(history_.size()); }
+  int NumPlayers() const { return batch_.GetGame()->NumPlayers(); }
+  std::shared_ptr<const Game> GetGame() const { return batch_.GetGame(); }
+  const BatchedState& Batch() const { return batch_; }
+
+ private:
+  void CheckPlayer(Player player) const {
+    if (player < 0 || player >= NumPlayers()) SpielFatalError("player id out of range");
+  }
+  BatchedState batch_;
+  std::vector<std::pair<Player, Action>> history_;
+};
+
+inline std::unique_ptr<State> Game::NewInitialState() const {
+  return std::unique_ptr<State>(new State(shared_from_this()));
+}
+inline BatchedState Game::NewInitialStates(int64_t n) const { return BatchedState(shared_from_this(), n); }
+
+namespace algorithms {
+
+class Evaluator {  // mcts.h:83-92
+ public:
+  virtual ~Evaluator() = default;
+  virtual std::vector<double> Evaluate(const State& state) = 0;
+  virtual ActionsAndProbs Prior(const State& state) = 0;
+};
+
+class RandomRolloutEvaluator : public Evaluator {  // mcts.h:97-111
+ public:
+  RandomRolloutEvaluator(int n_rollouts, int seed) : n_rollouts_(n_rollouts), seed_(seed) {}
+  std::vector<double> Evaluate(const State& state) override {  // mcts.cc:43-72
+    std::vector<double> sum = EvaluateBatch(state.Batch());
+    return sum;
+  }
+  // Mean returns [n, P] of n_rollouts uniform-random playouts from every state of the batch.
+  std::vector<double> EvaluateBatch(const BatchedState& states) {
+    std::vector<double> sum(static_cast<size_t>(states.size()) * states.GetGame()->NumPlayers());
+    Check(osg_rollout(states.handle(), static_cast<uint64_t>(seed_), calls_, n_rollouts_, sum.data(), nullptr, 1));
+    calls_ += states.size();  // fresh streams for the next call, like an advancing mt19937
+    for (double& v : sum) v /= n_rollouts_;
+    return sum;
+  }
+  ActionsAndProbs Prior(const State& state) override {  // mcts.cc:74-87
+    if (state.IsChanceNode()) return state.ChanceOutcomes();
+    std::vector<Action> legal = state.LegalActions();
+    ActionsAndProbs prior;
+    for (Action a : legal) prior.emplace_back(a, 1.0 / legal.size());
+    return prior;
+  }
+  int n_rollouts() const { return n_rollouts_; }
+  int seed() const { return seed_; }
+
+ private:
+  int n_rollouts_;
+  int seed_;
+  int64_t calls_ = 0;
+};
+
+struct SearchNode {  // mcts.h:114-146 (root + its children, as MCTSearch's callers read them)
+  Action action = kInvalidAction;
+  double prior = 0;
+  Player player = 0;
+  int explore_count = 0;
+  double total_reward = 0;
+  std::vector<double> outcome;
+  std::vector<SearchNode> children;
+  bool CompareFinal(const SearchNode& b) const {  // mcts.cc:114-125
+    double mine = outcome.empty() ? 0 : outcome[player];
+    double theirs = b.outcome.empty() ? 0 : b.outcome[b.player];
+    if (mine != theirs) return mine < theirs;
+    if (explore_count != b.explore_count) return explore_count < b.explore_count;
+    return total_reward < b.total_reward;
+  }
+  const SearchNode& BestChild() const {  // mcts.cc:127-143
+    const SearchNode* best = &children.front();
+    for (const SearchNode& c : children)
+      if (best->CompareFinal(c)) best = &c;
+    return *best;
+  }
+};
+
+class MCTSBot {  // mcts.h:149-220
+ public:
+  MCTSBot(const Game& game, std::shared_ptr<Evaluator> evaluator, double uct_c, int max_simulations,
+          int64_t max_memory_mb, bool solve, int seed, bool /*verbose*/)
+      : evaluator_(std::move(evaluator)), uct_c_(uct_c), max_simulations_(max_simulations),
+        max_memory_mb_(max_memory_mb), solve_(solve), seed_(seed), num_actions_(game.NumDistinctActions()),
+        num_players_(game.NumPlayers()) {
+    rollout_ = dynamic_cast<RandomRolloutEvaluator*>(evaluator_.get());
+    if (!rollout_) SpielFatalError("the device MCTSBot needs a RandomRolloutEvaluator");
+  }
+  // One search per state of the batch; returns BestChild().action per root (-1 for terminal roots).
+  std::vector<Action> StepBatch(const BatchedState& roots) {
+    std::vector<int32_t> best(roots.size());
+    osg_mcts_cfg cfg = Config(roots.size());
+    Check(osg_mcts_search(roots.handle(), &cfg, best.data(), nullptr, nullptr, nullptr, nullptr, 1));
+    searches_ += roots.size();
+    return std::vector<Action>(best.begin(), best.end());
+  }
+  Action Step(const State& state) { return StepBatch(state.Batch())[0]; }  // mcts.cc:233-266
+  std::unique_ptr<SearchNode> MCTSearch(const State& state) {              // mcts.cc:353-467
+    const int A = num_actions_;
+    std::vector<int32_t> visits(A);
+    std::vector<double> reward(A), stats(4);
+    std::vector<int8_t> outcome(A);
+    int32_t best = -1;
+    osg_mcts_cfg cfg = Config(1);
+    Check(osg_mcts_search(state.Batch().handle(), &cfg, &best, visits.data(), reward.data(), outcome.data(),
+                          stats.data(), 1));
+    ++searches_;
+    auto root = std::unique_ptr<SearchNode>(new SearchNode);
+    root->player = state.CurrentPlayer();
+    root->prior = 1;
+    root->explore_count = static_cast<int>(stats[0]);
+    if (!std::isnan(stats[2])) root->outcome = Zerosum(stats[2], root->player);
+    for (int a = 0; a < A; ++a) {
+      if (outcome[a] == 3) continue;
+      SearchNode c;
+      c.action = a;
+      c.player = root->player;
+      c.explore_count = visits[a];
+      c.total_reward = reward[a];
+      if (outcome[a] != 2) c.outcome = Zerosum(outcome[a], root->player);
+      root->children.push_back(c);
+    }
+    return root;
+  }
+
+ private:
+  osg_mcts_cfg Config(int64_t /*roots*/) const {
+    osg_mcts_cfg cfg{};
+    cfg.uct_c = uct_c_;
+    cfg.max_simulations = max_simulations_;
+    cfg.n_rollouts = rollout_->n_rollouts();
+    cfg.solve = solve_ ? 1 : 0;
+    // max_nodes = (max_memory_mb << 20) / sizeof(SearchNode) + 1 (mcts.cc:214), 24 B per device node
+    int64_t nodes = (max_memory_mb_ << 20) / 24 + 1;
+    cfg.max_nodes = static_cast<int32_t>(std::min<int64_t>(nodes, 1 << 24));
+    cfg.seed = static_cast<uint64_t>(seed_);
+    cfg.index_offset = searches_;
+    return cfg;
+  }
+  std::vector<double> Zerosum(double v, Player p) const {  // 2-player zero-sum outcome vector
+    std::vector<double> o(num_players_, 0.0);
+    if (p >= 0 && p < num_players_) {
+      o[p] = v;
+      if (num_players_ == 2) o[1 - p] = -v;
+    }
+    return o;
+  }
+  std::shared_ptr<Evaluator> evaluator_;
+  RandomRolloutEvaluator* rollout_ = nullptr;
+  double uct_c_;
+  int max_simulations_;
+  int64_t max_memory_mb_;
+  bool solve_;
+  int seed_;
+  int num_actions_, num_players_;
+  int64_t searches_ = 0;
+};
+
+struct CFRInfoStateValues {  // cfr.h:42-98
+  std::vector<Action> legal_actions;
+  std::vector<double> cumulative_regrets, cumulative_policy, current_policy;
+  int num_actions() const { return static_cast<int>(legal_actions.size()); }
+};
+using CFRInfoStateValuesTable = std::unordered_map<std::string, CFRInfoStateValues>;  // cfr.h:103-104
+using TabularPolicyTable = std::unordered_map<std::string, ActionsAndProbs>;
+
+class DeviceTabularSolver {
+ public:
+  ~DeviceTabularSolver() { if (s_) osg_cfr_destroy(s_); }
+  DeviceTabularSolver(const DeviceTabularSolver&) = delete;
+  CFRInfoStateValuesTable InfoStateValuesTable() const {  // cfr.h:217
+    Tables t = Download();
+    CFRInfoStateValuesTable out;
+    for (int i = 0; i < t.I; ++i) {
+      CFRInfoStateValues v;
+      for (int a = 0; a < t.nact[i]; ++a) {
+        v.legal_actions.push_back(t.legal[i * t.A + a]);
+        v.cumulative_regrets.push_back(t.regrets[i * t.A + a]);
+        v.cumulative_policy.push_back(t.cum[i * t.A + a]);
+        v.current_policy.push_back(t.cur[i * t.A + a]);
+      }
+      out.emplace(Key(i), std::move(v));
+    }
+    return out;
+  }
+  TabularPolicyTable TabularAveragePolicy() const { return Policy(true); }  // cfr.h:205-211
+  TabularPolicyTable TabularCurrentPolicy() const { return Policy(false); }
+  int64_t NumInfoStates() const { return sizes_[4]; }
+  int64_t NumHistories() const { return sizes_[0]; }
+  osg_cfr* handle() const { return s_; }
+
+ protected:
+  DeviceTabularSolver(const Game& game, bool alternating, bool linear, bool rm_plus, bool mccfr) {
+    osg_cfr_cfg cfg{alternating ? 1 : 0, linear ? 1 : 0, rm_plus ? 1 : 0, mccfr ? 1 : 0};
+    Check(osg_cfr_create(game.Ctx(), game.GameString().c_str(), &cfg, &s_));
+    Check(osg_cfr_sizes(s_, sizes_));
+    num_players_ = game.NumPlayers();
+  }
+  osg_cfr* s_ = nullptr;
+  int64_t sizes_[6] = {0, 0, 0, 0, 0, 0};
+  int num_players_ = 0;
+
+ private:
+  struct Tables {
+    int I, A;
+    std::vector<int32_t> nact, legal;
+    std::vector<double> regrets, cum, cur, avg;
+  };
+  Tables Download() const {
+    Tables t;
+    t.I = static_cast<int>(sizes_[4]);
+    t.A = static_cast<int>(sizes_[5]);
+    const size_t n = static_cast<size_t>(t.I) * t.A;
+    t.nact.resize(t.I); t.legal.resize(n); t.regrets.resize(n); t.cum.resize(n); t.cur.resize(n); t.avg.resize(n);
+    Check(osg_cfr_tables(s_, t.nact.data(), t.legal.data(), t.regrets.data(), t.cum.data(), t.cur.data(), t.avg.data()));
+    return t;
+  }
+  std::string Key(int i) const {
+    char buf[512];
+    if (osg_cfr_infostate_key(s_, i, buf, sizeof(buf)) < 0) SpielFatalError(osg_last_error());
+    return buf;
+  }
+  TabularPolicyTable Policy(bool average) const {
+    Tables t = Download();
+    TabularPolicyTable out;
+    for (int i = 0; i < t.I; ++i) {
+      ActionsAndProbs ap;
+      for (int a = 0; a < t.nact[i]; ++a)
+        ap.emplace_back(t.legal[i * t.A + a], (average ? t.avg : t.cur)[i * t.A + a]);
+      out.emplace(Key(i), std::move(ap));
+    }
+    return out;
+  }
+};
+
+class CFRSolverBase : public DeviceTabularSolver {  // cfr.h:188-304
+ public:
+  CFRSolverBase(const Game& game, bool alternating_updates, bool linear_averaging, bool regret_matching_plus)
+      : DeviceTabularSolver(game, alternating_updates, linear_averaging, regret_matching_plus, false) {}
+  void EvaluateAndUpdatePolicy() { Check(osg_cfr_iterate(s_, 1)); }  // cfr.cc:263-282
+  void EvaluateAndUpdatePolicy(int iterations) { Check(osg_cfr_iterate(s_, iterations)); }  // one launch
+};
+class CFRSolver : public CFRSolverBase {  // cfr.h:310-330
+ public:
+  explicit CFRSolver(const Game& game) : CFRSolverBase(game, true, false, false) {}
+};
+class CFRPlusSolver : public CFRSolverBase {  // cfr.h:341-357
+ public:
+  explicit CFRPlusSolver(const Game& game) : CFRSolverBase(game, true, true, true) {}
+};
+
+enum class AverageType { kSimple, kFull };
+class ExternalSamplingMCCFRSolver : public DeviceTabularSolver {  // external_sampling_mccfr.h:57-113
+ public:
+  explicit ExternalSamplingMCCFRSolver(const Game& game, int seed = 0, AverageType avg_type = AverageType::kSimple)
+      : DeviceTabularSolver(game, true, false, false, true), seed_(seed) {
+    if (avg_type != AverageType::kSimple) SpielFatalError("the device ES-MCCFR implements AverageType::kSimple");
+  }
+  // One UpdateRegrets per player, each seeing the previous one's update (:71-80).
+  void RunIteration() {
+    for (int p = 0; p < num_players_; ++p) Check(osg_mccfr_iterate(s_, seed_, next_++, 1));
+  }
+  // `trajectories` traverser passes as ONE mini-batch against the current tables.
+  void RunMiniBatch(int64_t trajectories) {
+    Check(osg_mccfr_iterate(s_, seed_, next_, trajectories));
+    next_ += trajectories;
+  }
+
+ private:
+  uint64_t seed_;
+  int64_t next_ = 0;
+};
+
+}  // namespace algorithms
+}  // namespace hip
+}  // namespace open_spiel
+
+#endif  // OSG_HOST_OSG_SPIEL_H_

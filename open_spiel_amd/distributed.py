@@ -1,0 +1,94 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, torch.distributed over RCCL.
+
+Units are independent (states, search roots, MCCFR trajectories) and are sharded by
+contiguous GLOBAL index; every device RNG stream is keyed by the global index, so the
+results are the same for any world size.  The only exchange step on the path is
+external-sampling MCCFR's: one all-reduce(sum) of the regret / average-policy delta
+tables per mini-batch (leduc_poker: 2 x [936, 3] fp64 = 44 928 B, latency-bound).
+
+The reference has no distributed runtime at all (SURVEY.md header); this module is
+new design, not a translation.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    """(rank, world_size) of the default process group, (0, 1) when not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(total, rank, world_size):
+    """Contiguous slice [first, first + count) of `total` units owned by `rank`.
+
+    The first `total % world_size` ranks own one extra unit, so any total is covered
+    exactly once and slices are ordered by rank."""
+    if world_size < 1 or not 0 <= rank < world_size:
+        raise ValueError(f"bad rank {rank} / world {world_size}")
+    base, extra = divmod(int(total), world_size)
+    count = base + (1 if rank < extra else 0)
+    first = rank * base + min(rank, extra)
+    return first, count
+
+
+def allreduce_sum_(tensor):
+    """In-place sum over ranks (RCCL over xGMI for device tensors, gloo for CPU tensors)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+    return tensor
+
+
+class ShardedMccfr:
+    """External-sampling MCCFR with trajectories sharded over the ranks.
+
+    `solver` is anything with the TabularSolver mini-batch protocol:
+      mccfr_sample(seed, count, first_trajectory) -> deltas left in the delta tables
+      mccfr_delta_tables() -> (regret_delta, policy_delta) tensors (views, same device)
+      mccfr_apply_deltas()
+    Every rank ends each mini-batch with identical tables.
+    """
+
+    def __init__(self, solver):
+        self.solver = solver
+        self.rank, self.world_size = world()
+        self.trajectories_done = 0
+        self._flat = None
+
+    def run_minibatch(self, seed, trajectories):
+        """One mini-batch of `trajectories` traversals (global count) starting at the
+        running global trajectory index; returns the number this rank sampled."""
+        first, count = shard_range(trajectories, self.rank, self.world_size)
+        self.solver.mccfr_sample(seed, count, first_trajectory=self.trajectories_done + first)
+        if self.world_size > 1:
+            dreg, dpol = self.solver.mccfr_delta_tables()
+            # one collective for both tables: they are adjacent in the solver's allocation
+            # when it is the device solver; otherwise pack them.
+            if (dreg.is_contiguous() and dpol.is_contiguous()
+                    and dpol.data_ptr() == dreg.data_ptr() + dreg.numel() * dreg.element_size()):
+                flat = torch.as_strided(dreg, (dreg.numel() + dpol.numel(),), (1,))
+                allreduce_sum_(flat)
+            else:
+                flat = torch.cat([dreg.reshape(-1), dpol.reshape(-1)])
+                allreduce_sum_(flat)
+                dreg.copy_(flat[:dreg.numel()].view_as(dreg))
+                dpol.copy_(flat[dreg.numel():].view_as(dpol))
+        self.solver.mccfr_apply_deltas()
+        self.trajectories_done += int(trajectories)
+        return count
+
+
+def gather_root_results(local, total_roots):
+    """All-gather per-root result tensors (e.g. best actions) sharded by shard_range
+    into one [total_roots, ...] tensor on every rank (variable shard sizes allowed)."""
+    rank, world_size = world()
+    if world_size == 1:
+        return local
+    counts = [shard_range(total_roots, r, world_size)[1] for r in range(world_size)]
+    pad = max(counts)
+    buf = local.new_zeros((pad,) + tuple(local.shape[1:]))
+    buf[:local.shape[0]] = local
+    out = [torch.empty_like(buf) for _ in range(world_size)]
+    dist.all_gather(out, buf)
+    return torch.cat([o[:c] for o, c in zip(out, counts)])

@@ -1,0 +1,105 @@
+"""The N>1 path on CPU: world_size-2 gloo process groups (no GPU).
+
+Covers the host logic of open_spiel_amd/distributed.py: shard ranges, the MCCFR
+delta all-reduce protocol (every rank ends with identical tables, equal to the
+single-process result) and the variable-size root gather.  The device solver is
+replaced by a deterministic stand-in with the same mini-batch protocol: no compute
+kernel runs here.
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class FakeSolver:
+    """Stand-in with TabularSolver's mini-batch protocol; trajectory g contributes
+    deterministic integer-valued deltas (so sums are exact in any order)."""
+
+    I, A = 12, 2
+
+    def __init__(self):
+        self.tables = torch.full((2, self.I, self.A), 1e-6, dtype=torch.float64)
+        self.deltas = torch.zeros((2, self.I, self.A), dtype=torch.float64)
+
+    def mccfr_sample(self, seed, count, first_trajectory=0):
+        self.deltas.zero_()
+        for g in range(first_trajectory, first_trajectory + count):
+            row = (g * 7 + seed) % self.I
+            self.deltas[0, row, g % self.A] += float(g % 5 - 2)
+            self.deltas[1, (row + 3) % self.I, (g + 1) % self.A] += 1.0
+
+    def mccfr_delta_tables(self):
+        return self.deltas[0], self.deltas[1]
+
+    def mccfr_apply_deltas(self):
+        self.tables += self.deltas
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world_size, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from open_spiel_amd import distributed as osd
+        assert osd.world() == (rank, world_size)
+        solver = FakeSolver()
+        sharded = osd.ShardedMccfr(solver)
+        sampled = [sharded.run_minibatch(seed=11, trajectories=t) for t in (1, 5, 64, 1001)]
+        # variable-size gather: 7 roots over 2 ranks -> 4 + 3
+        first, count = osd.shard_range(7, rank, world_size)
+        local = torch.arange(first, first + count, dtype=torch.int32).unsqueeze(1) * 10
+        gathered = osd.gather_root_results(local, 7)
+        torch.save({"tables": solver.tables, "sampled": sampled, "gathered": gathered,
+                    "done": sharded.trajectories_done}, os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything_once():
+    from open_spiel_amd.distributed import shard_range
+    for total in (0, 1, 7, 8, 65536, (1 << 24) + 3):
+        for world_size in (1, 2, 3, 4, 8):
+            spans = [shard_range(total, r, world_size) for r in range(world_size)]
+            assert spans[0][0] == 0
+            for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+                assert f0 + c0 == f1
+            assert spans[-1][0] + spans[-1][1] == total
+            counts = [c for _, c in spans]
+            assert max(counts) - min(counts) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def test_mccfr_delta_allreduce_world2_equals_world1(tmp_path):
+    # single-process result
+    from open_spiel_amd import distributed as osd
+    ref = FakeSolver()
+    single = osd.ShardedMccfr(ref)
+    for t in (1, 5, 64, 1001):
+        single.run_minibatch(seed=11, trajectories=t)
+    # two gloo ranks
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    assert torch.equal(r0["tables"], r1["tables"]), "ranks must end with identical tables"
+    assert torch.equal(r0["tables"], ref.tables), "world=2 must equal world=1"
+    assert [a + b for a, b in zip(r0["sampled"], r1["sampled"])] == [1, 5, 64, 1001]
+    assert r0["done"] == r1["done"] == single.trajectories_done == 1071
+    want = (torch.arange(7, dtype=torch.int32) * 10).unsqueeze(1)
+    assert torch.equal(r0["gathered"], want) and torch.equal(r1["gathered"], want)

@@ -173,6 +173,13 @@ typedef struct {
                                when exhausted, leaves are evaluated without expansion) */
   uint64_t seed;
   int64_t index_offset;     /* global index of root 0 (multi-GPU sharding)         */
+  int32_t layout;           /* 0 auto; 1 one LANE per root (64 searches per wavefront,
+                               sequential rollouts); 2 one WAVEFRONT per root (children
+                               and rollouts spread over the 64 lanes; hex playouts as a
+                               wave-parallel random fill).  The two layouts define their
+                               random streams differently (see osg_common.h), so results
+                               are reproducible per layout, not across layouts.      */
+  int32_t reserved;
 } osg_mcts_cfg;
 /* Outputs (host or device by on_host; any may be NULL):
  *   best_action [n] i32            SearchNode::BestChild().action (mcts.cc:127-143)

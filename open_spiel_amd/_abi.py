@@ -48,6 +48,8 @@ class MctsCfg(C.Structure):
         ("max_nodes", C.c_int32),
         ("seed", C.c_uint64),
         ("index_offset", C.c_int64),
+        ("layout", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

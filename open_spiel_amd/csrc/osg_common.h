@@ -46,6 +46,38 @@ struct Rng {
 };
 
 // ---------------------------------------------------------------------------
+// Keyed orderings used by the wave-per-root search (osg_mcts_wave.hip) and
+// restated by the oracle's replay of it.  A uniformly random ORDER of a set is
+// obtained by giving every element an independent 64-bit key and sorting by
+// key; the low byte carries the element id so keys of one set never tie.
+//   * sibling order of a freshly expanded node (the reference's std::shuffle,
+//     mcts.cc:294): key = order_key(order_base(seed, root), path hash, action)
+//   * the random fill of a hex playout: key = fill_key(fill_base(seed, root,
+//     rollout), cell)
+// ---------------------------------------------------------------------------
+constexpr uint64_t kOrderSalt = 0x6F726465725F6B79ULL;
+constexpr uint64_t kFillSalt = 0x66696C6C5F6B6579ULL;
+OSG_HD uint64_t path_hash_root() { return 0x243F6A8885A308D3ULL; }
+OSG_HD uint64_t path_hash_child(uint64_t parent, int action) {
+  return mix64(parent ^ (static_cast<uint64_t>(action + 1) * 0x9E3779B97F4A7C15ULL));
+}
+OSG_HD uint64_t order_base(uint64_t seed, uint64_t root) {
+  return mix64(mix64(seed ^ kOrderSalt) ^ (root * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));
+}
+OSG_HD uint64_t order_key(uint64_t base, uint64_t parent_path_hash, int action) {
+  const uint64_t k = mix64(base ^ parent_path_hash ^ (static_cast<uint64_t>(action + 1) * 0xA0761D6478BD642FULL));
+  return (k & ~0xFFull) | static_cast<uint64_t>(action & 0xFF);
+}
+OSG_HD uint64_t fill_base(uint64_t seed, uint64_t root, uint64_t sub) {
+  const uint64_t a = mix64(mix64(seed ^ kFillSalt) ^ (root * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));
+  return mix64(a ^ (sub * 0xA0761D6478BD642FULL + 0xE7037ED1A0B428DBULL));
+}
+OSG_HD uint64_t fill_key(uint64_t base, int cell) {
+  const uint64_t k = mix64(base ^ (static_cast<uint64_t>(cell + 1) * 0x9E3779B97F4A7C15ULL));
+  return (k & ~0xFFull) | static_cast<uint64_t>(cell & 0xFF);
+}
+
+// ---------------------------------------------------------------------------
 // Legal-action mask: up to 128 actions, bit a of word a/32.
 // ---------------------------------------------------------------------------
 struct Mask {

@@ -20,47 +20,11 @@
 #include <cmath>
 #include <vector>
 
-#include "osg_internal.h"
+#include "osg_mcts_internal.h"
 
 using namespace osg;
 
 namespace {
-
-constexpr int kBlockM = 64;  // one wave per block: searches differ in length, keep blocks small
-constexpr uint64_t kTreeSalt = 0x7265655F73616C74ULL;  // stream separation for the tree-policy RNG
-constexpr uint32_t kNoNode = 0xFFFFFFFFu;
-
-struct Pool {
-  uint32_t* meta;
-  uint32_t* first;
-  uint32_t* parent;
-  uint32_t* count;
-  double* total;
-  int64_t n_roots;
-  int cap;
-};
-
-OSG_D uint32_t m_action(uint32_t m) { return m & 0xFFu; }
-OSG_D int m_player(uint32_t m) { return static_cast<int>((m >> 8) & 15u) - 1; }
-OSG_D int m_nchild(uint32_t m) { return static_cast<int>((m >> 12) & 0xFFu); }
-OSG_D bool m_has_outcome(uint32_t m) { return (m >> 20) & 1u; }
-OSG_D int m_code(uint32_t m) { return static_cast<int>((m >> 21) & 3u); }  // p0 value + 1
-OSG_D bool m_terminal(uint32_t m) { return (m >> 23) & 1u; }
-OSG_D uint32_t make_meta(int action, int player, int nchild) {
-  return static_cast<uint32_t>(action & 0xFF) | ((static_cast<uint32_t>(player + 1) & 15u) << 8) |
-         (static_cast<uint32_t>(nchild) << 12);
-}
-
-// outcome[player] of a node that has one (mcts.cc:90-93): exact for the board
-// games (code), total/N for terminal nodes of the poker games.
-template <bool kBoard>
-OSG_D double outcome_value(uint32_t meta, uint32_t count, double total, int player) {
-  if (kBoard) {
-    double v0 = static_cast<double>(m_code(meta) - 1);
-    return player == 0 ? v0 : -v0;
-  }
-  return total / static_cast<double>(count);
-}
 
 template <class G, bool kBoard>
 __global__ void __launch_bounds__(kBlockM)
@@ -318,6 +282,24 @@ extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_i
     d_out = child_outcome ? reinterpret_cast<int8_t*>(sc + o_out) : nullptr;
     d_stats = root_stats ? reinterpret_cast<double*>(sc + o_stats) : nullptr;
   }
+  int layout = cfg.layout;
+  if (layout == 0)  // auto: the wave layout where its parallel playout applies (hex without the swap rule)
+    layout = (d.game_kind == kHex && d.num_distinct_actions == d.obs_shape[1] * d.obs_shape[2]) ? 2 : 1;
+  if (layout != 1 && layout != 2) {
+    (void)hipFree(pool_mem);
+    (void)hipFree(d_logs);
+    return set_error(OSG_ERR_INVALID, "osg_mcts_cfg.layout must be 0, 1 or 2");
+  }
+  if (layout == 2) {
+    MctsOut out{d_best, d_vis, d_rew, d_out, d_stats};
+    int rc = launch_mcts_wave(roots, cfg, d_logs, pool, out);
+    if (rc) {
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipFree(pool_mem);
+      (void)hipFree(d_logs);
+      return rc;
+    }
+  } else {
   const unsigned grid = static_cast<unsigned>((n + kBlockM - 1) / kBlockM);
   if (board) {
     OSG_DISPATCH(roots->spec, k_mcts<G, true><<<dim3(grid), dim3(kBlockM), 0, ctx->stream>>>(
@@ -327,6 +309,7 @@ extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_i
     OSG_DISPATCH(roots->spec, k_mcts<G, false><<<dim3(grid), dim3(kBlockM), 0, ctx->stream>>>(
                                   P, static_cast<const typename G::word_t*>(roots->d_words), n, d.num_players, A, cfg,
                                   d.max_utility, d_logs, pool, d_best, d_vis, d_rew, d_out, d_stats));
+  }
   }
   hipError_t launch = hipGetLastError();
   if (on_host && launch == hipSuccess) {

@@ -1,0 +1,61 @@
+// Declarations shared by the two MCTS layouts (osg_mcts.hip: one lane per root,
+// osg_mcts_wave.hip: one wavefront per root).
+#ifndef OSG_MCTS_INTERNAL_H_
+#define OSG_MCTS_INTERNAL_H_
+
+#include "osg_internal.h"
+
+namespace osg {
+
+constexpr int kBlockM = 64;  // one wave per block: searches differ in length, keep blocks small
+constexpr uint64_t kTreeSalt = 0x7265655F73616C74ULL;  // stream separation for the tree-policy RNG
+constexpr uint32_t kNoNode = 0xFFFFFFFFu;
+
+struct Pool {
+  uint32_t* meta;
+  uint32_t* first;
+  uint32_t* parent;
+  uint32_t* count;
+  double* total;
+  int64_t n_roots;
+  int cap;
+};
+
+OSG_D uint32_t m_action(uint32_t m) { return m & 0xFFu; }
+OSG_D int m_player(uint32_t m) { return static_cast<int>((m >> 8) & 15u) - 1; }
+OSG_D int m_nchild(uint32_t m) { return static_cast<int>((m >> 12) & 0xFFu); }
+OSG_D bool m_has_outcome(uint32_t m) { return (m >> 20) & 1u; }
+OSG_D int m_code(uint32_t m) { return static_cast<int>((m >> 21) & 3u); }  // p0 value + 1
+OSG_D bool m_terminal(uint32_t m) { return (m >> 23) & 1u; }
+OSG_D uint32_t make_meta(int action, int player, int nchild) {
+  return static_cast<uint32_t>(action & 0xFF) | ((static_cast<uint32_t>(player + 1) & 15u) << 8) |
+         (static_cast<uint32_t>(nchild) << 12);
+}
+
+// outcome[player] of a node that has one (mcts.cc:90-93): exact for the board
+// games (code), total/N for terminal nodes of the poker games.
+template <bool kBoard>
+OSG_D double outcome_value(uint32_t meta, uint32_t count, double total, int player) {
+  if (kBoard) {
+    double v0 = static_cast<double>(m_code(meta) - 1);
+    return player == 0 ? v0 : -v0;
+  }
+  return total / static_cast<double>(count);
+}
+
+
+// Device output pointers of a search (any may be null).
+struct MctsOut {
+  int32_t* best_action;
+  int32_t* child_visits;
+  double* child_reward;
+  int8_t* child_outcome;
+  double* root_stats;
+};
+
+// Launches the wave-per-root kernel on the context's stream (osg_mcts_wave.hip).
+int launch_mcts_wave(const osg_batch* roots, const osg_mcts_cfg& cfg, const double* d_log_table, const Pool& pool,
+                     const MctsOut& out);
+
+}  // namespace osg
+#endif  // OSG_MCTS_INTERNAL_H_

@@ -209,6 +209,16 @@ struct CounterRng {
   double Unit();                   // (top 53 bits) * 2^-53, in [0,1)
 };
 
+// Keyed orderings of the device's wave-per-root search (open_spiel_amd/csrc/
+// osg_common.h: order_key / fill_key), restated bit for bit.  Not in the reference.
+uint64_t Mix64(uint64_t z);
+uint64_t PathHashRoot();
+uint64_t PathHashChild(uint64_t parent, int action);
+uint64_t OrderBase(uint64_t seed, uint64_t root);
+uint64_t OrderKey(uint64_t base, uint64_t parent_path_hash, int action);
+uint64_t FillBase(uint64_t seed, uint64_t root, uint64_t sub);
+uint64_t FillKey(uint64_t base, int cell);
+
 // ---------------------------------------------------------------------------
 // Policies (policy.h:69,158,318 subset)
 // ---------------------------------------------------------------------------
@@ -305,11 +315,18 @@ class MCTSBot {  // mcts.h:149-220
   // CounterRng(seed ^ kTreeSalt, root_index, s); rollout r of simulation s plays
   // with CounterRng(seed, root_index, s * n_rollouts + r).
   static constexpr uint64_t kTreeSalt = 0x7265655F73616C74ULL;
-  void UseCounterStreams(uint64_t seed, uint64_t root_index, int n_rollouts) {
+  //
+  // layout 1 = the device's lane-per-root kernel (above).  layout 2 = its
+  // wave-per-root kernel: a new node's children are ordered by OrderKey (instead of
+  // shuffled) and, for hex without the swap rule, a rollout plays the empty cells in
+  // the interleaved FillKey order (mover: the ceil(m/2) smallest keys ascending,
+  // opponent: the others ascending) — a uniformly random move sequence.
+  void UseCounterStreams(uint64_t seed, uint64_t root_index, int n_rollouts, int layout = 1) {
     counter_ = true;
     c_seed_ = seed;
     c_root_ = root_index;
     c_rollouts_ = n_rollouts;
+    c_layout_ = layout;
   }
 
  private:
@@ -331,6 +348,7 @@ class MCTSBot {  // mcts.h:149-220
   bool counter_ = false;
   uint64_t c_seed_ = 0, c_root_ = 0;
   int c_rollouts_ = 1;
+  int c_layout_ = 1;
   CounterRng trng_{0};
 };
 

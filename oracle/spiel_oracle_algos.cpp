@@ -168,11 +168,18 @@ std::unique_ptr<State> MCTSBot::ApplyTreePolicy(
   path->push_back(root);
   std::unique_ptr<State> w = state.Clone();
   SearchNode* node = root;
+  uint64_t ph = PathHashRoot();
   while ((!w->IsTerminal() && node->explore_count > 0) ||
          (w->IsChanceNode() && dont_return_chance_node_)) {
     if (node->children.empty()) {
       ActionsAndProbs legal = evaluator_->Prior(*w);
-      if (counter_) {  // Fisher-Yates on the counter stream (the device's shuffle)
+      if (counter_ && c_layout_ == 2) {  // order by key (the wave kernel's tie-break order)
+        const uint64_t ob = OrderBase(c_seed_, c_root_);
+        std::sort(legal.begin(), legal.end(), [&](const std::pair<Action, double>& a,
+                                                  const std::pair<Action, double>& b) {
+          return OrderKey(ob, ph, static_cast<int>(a.first)) < OrderKey(ob, ph, static_cast<int>(b.first));
+        });
+      } else if (counter_) {  // Fisher-Yates on the counter stream (the device's shuffle)
         for (int i = static_cast<int>(legal.size()) - 1; i >= 1; --i)
           std::swap(legal[i], legal[trng_.Below(static_cast<uint32_t>(i + 1))]);
       } else {
@@ -207,6 +214,7 @@ std::unique_ptr<State> MCTSBot::ApplyTreePolicy(
     }
     ORACLE_CHECK(chosen != nullptr);
     w->ApplyAction(chosen->action);
+    ph = PathHashChild(ph, static_cast<int>(chosen->action));
     node = chosen;
     path->push_back(node);
   }
@@ -278,9 +286,28 @@ std::unique_ptr<SearchNode> MCTSBot::MCTSearch(const State& state) {
 std::vector<double> MCTSBot::CounterEvaluate(const State& state, int sim) const {
   // RandomRolloutEvaluator::Evaluate (mcts.cc:43-72) on the device's counter streams.
   std::vector<double> total(state.NumPlayers(), 0.0);
+  const Game& game = *state.GetGame();
+  const bool keyed_fill = c_layout_ == 2 && game.ShortName() == "hex" &&
+                          game.NumDistinctActions() == game.ObservationTensorShape()[1] * game.ObservationTensorShape()[2];
   for (int r = 0; r < c_rollouts_; ++r) {
     CounterRng rng(c_seed_, c_root_, static_cast<uint64_t>(sim) * c_rollouts_ + r);
     std::unique_ptr<State> w = state.Clone();
+    if (keyed_fill) {
+      // Order the empty cells by key; the player to move plays the ceil(m/2) smallest in
+      // ascending order on plies 0, 2, 4, ..., the opponent the others on plies 1, 3, 5, ...
+      // (a fixed re-indexing of a uniformly random order: again uniformly random), with the
+      // reference's own loop — stop at the first terminal state (mcts.cc:45-56).
+      const uint64_t fb = FillBase(c_seed_, c_root_, static_cast<uint64_t>(sim) * c_rollouts_ + r);
+      std::vector<Action> cells = w->LegalActions();
+      std::sort(cells.begin(), cells.end(), [&](Action a, Action b) {
+        return FillKey(fb, static_cast<int>(a)) < FillKey(fb, static_cast<int>(b));
+      });
+      const size_t h = (cells.size() + 1) / 2;
+      for (size_t t = 0; !w->IsTerminal(); ++t) {
+        ORACLE_CHECK(t < cells.size());
+        w->ApplyAction(t % 2 == 0 ? cells[t / 2] : cells[h + t / 2]);
+      }
+    }
     while (!w->IsTerminal()) {
       if (w->IsChanceNode()) {
         w->ApplyAction(SampleAction(w->ChanceOutcomes(), rng.Unit()).first);

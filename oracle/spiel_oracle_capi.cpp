@@ -290,14 +290,15 @@ int osgo_mcts_search(void* s, double uct_c, int max_simulations, int n_rollouts,
                      int64_t max_memory_mb, int solve, int seed,
                      int64_t* best_action, double* root_outcome,
                      double* out_children, int cap, int* root_visits,
-                     int64_t counter_root, uint64_t counter_seed) {
+                     int64_t counter_root, uint64_t counter_seed, int counter_layout) {
   return Guard([&] {
     const State& st = *static_cast<StateH*>(s)->state;
     auto ev = std::make_shared<RandomRolloutEvaluator>(n_rollouts, seed);
     MCTSBot bot(*st.GetGame(), ev, uct_c, max_simulations, max_memory_mb,
                 solve != 0, seed, false);
     if (counter_root >= 0)
-      bot.UseCounterStreams(counter_seed, static_cast<uint64_t>(counter_root), n_rollouts);
+      bot.UseCounterStreams(counter_seed, static_cast<uint64_t>(counter_root), n_rollouts,
+                            counter_layout);
     std::unique_ptr<SearchNode> root = bot.MCTSearch(st);
     const double nan = std::numeric_limits<double>::quiet_NaN();
     *best_action = root->children.empty() ? -1 : root->BestChild().action;

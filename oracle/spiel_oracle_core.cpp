@@ -250,11 +250,31 @@ std::pair<Action, double> SampleAction(const ActionsAndProbs& outcomes,
 // ----------------------------------------------------------------------------
 // Counter RNG: identical arithmetic in open_spiel_amd/csrc/osg_rng.h.
 // ----------------------------------------------------------------------------
-static inline uint64_t Mix64(uint64_t z) {
+uint64_t Mix64(uint64_t z) {
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
   return z ^ (z >> 31);
 }
+uint64_t PathHashRoot() { return 0x243F6A8885A308D3ULL; }
+uint64_t PathHashChild(uint64_t parent, int action) {
+  return Mix64(parent ^ (static_cast<uint64_t>(action + 1) * 0x9E3779B97F4A7C15ULL));
+}
+uint64_t OrderBase(uint64_t seed, uint64_t root) {
+  return Mix64(Mix64(seed ^ 0x6F726465725F6B79ULL) ^ (root * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));
+}
+uint64_t OrderKey(uint64_t base, uint64_t parent_path_hash, int action) {
+  const uint64_t k = Mix64(base ^ parent_path_hash ^ (static_cast<uint64_t>(action + 1) * 0xA0761D6478BD642FULL));
+  return (k & ~0xFFull) | static_cast<uint64_t>(action & 0xFF);
+}
+uint64_t FillBase(uint64_t seed, uint64_t root, uint64_t sub) {
+  const uint64_t a = Mix64(Mix64(seed ^ 0x66696C6C5F6B6579ULL) ^ (root * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));
+  return Mix64(a ^ (sub * 0xA0761D6478BD642FULL + 0xE7037ED1A0B428DBULL));
+}
+uint64_t FillKey(uint64_t base, int cell) {
+  const uint64_t k = Mix64(base ^ (static_cast<uint64_t>(cell + 1) * 0x9E3779B97F4A7C15ULL));
+  return (k & ~0xFFull) | static_cast<uint64_t>(cell & 0xFF);
+}
+
 CounterRng::CounterRng(uint64_t seed, uint64_t stream, uint64_t sub) {
   // Three rounds of mixing decorrelate (seed, stream, sub) triples.
   uint64_t a = Mix64(seed + 0x9E3779B97F4A7C15ULL);

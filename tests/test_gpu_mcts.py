@@ -43,6 +43,7 @@ def _oracle_state(og, hist):
     return s
 
 
+@pytest.mark.parametrize("layout", [1, 2])
 @pytest.mark.parametrize("game,n,sims,n_rollouts,solve,max_stop", [
     ("tic_tac_toe", 96, 200, 3, True, 7),
     ("tic_tac_toe", 64, 64, 1, False, 5),
@@ -51,13 +52,19 @@ def _oracle_state(og, hist):
     ("hex(board_size=9)", 24, 200, 1, False, 40),
     ("kuhn_poker", 48, 100, 2, False, 4),
     ("leduc_poker", 48, 150, 1, False, 8),
+    ("hex(board_size=5)", 32, 300, 3, False, 24),
+    ("hex(board_size=4,swap=True)", 32, 100, 2, True, 6),
+    ("hex(num_cols=3,num_rows=4)", 32, 150, 1, True, 6),
+    ("hex", 8, 300, 1, False, 60),
+    ("tic_tac_toe", 32, 150, 70, True, 4),
+    ("kuhn_poker(players=3)", 48, 120, 1, False, 6),
 ])
-def test_mcts_replay_parity(oracle, ctx, game, n, sims, n_rollouts, solve, max_stop):
-    min_stop = 2 if "poker" in game else 0  # past the private deals: MCTSBot moves at decision nodes
+def test_mcts_replay_parity(oracle, ctx, game, n, sims, n_rollouts, solve, max_stop, layout):
+    min_stop = (3 if "players=3" in game else 2) if "poker" in game else 0  # past the private deals
     og, roots, hists = _roots(oracle, ctx, game, n, 17, max_stop, min_stop)
     seed, offset = 0xFEED5EED, 12345
     res = roots.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=n_rollouts, solve=solve, seed=seed,
-                            index_offset=offset)
+                            index_offset=offset, layout=layout)
     best = res["best_action"].cpu().numpy()
     visits = res["child_visits"].cpu().numpy()
     reward = res["child_reward"].cpu().numpy()
@@ -68,7 +75,8 @@ def test_mcts_replay_parity(oracle, ctx, game, n, sims, n_rollouts, solve, max_s
         st = _oracle_state(og, hists[i])
         if st.is_chance_node():
             continue  # MCTSBot is never asked to move at a chance node
-        want = st.mcts_search(2.0, sims, n_rollouts, 4096, solve, 0, counter_root=offset + i, counter_seed=seed)
+        want = st.mcts_search(2.0, sims, n_rollouts, 4096, solve, 0, counter_root=offset + i, counter_seed=seed,
+                              counter_layout=layout)
         assert stats[i, 0] == want["root_visits"], f"{game} root {i}: root visits"
         acts = want["children"][:, 0].astype(int)
         got_children = np.nonzero(outcome[i] != 3)[0]
@@ -100,12 +108,13 @@ def _ttt_batch(ctx, moves, n=4):
     return b
 
 
-def test_solver_known_answers(ctx):
+@pytest.mark.parametrize("layout", [1, 2])
+def test_solver_known_answers(ctx, layout):
     """mcts_test.cc:126-155 (UCT_C=2, RandomRolloutEvaluator(20, 42), 10000 simulations,
     solve=true): the three MCTS-Solver positions of the reference's own test."""
     # MCTSTest_SolveDraw: "x(1,1) o(0,0) x(2,2)" -> "o..\n.x.\n..x", o to move, proven draw
     b = _ttt_batch(ctx, [4, 0, 8])
-    r = b.mcts_search(uct_c=2.0, max_simulations=10000, n_rollouts=20, solve=True, seed=42)
+    r = b.mcts_search(uct_c=2.0, max_simulations=10000, n_rollouts=20, solve=True, seed=42, layout=layout)
     stats = r["root_stats"].cpu().numpy()
     outcome = r["child_outcome"].cpu().numpy()
     best = r["best_action"].cpu().numpy()
@@ -118,7 +127,7 @@ def test_solver_known_answers(ctx):
         assert best[i] in (6, 2)                          # o(2,0) or o(0,2); all others lose
     # MCTSTest_SolveLoss: "... o(0,1) x(0,2)" -> "oox\n.x.\n..x": every move loses
     b = _ttt_batch(ctx, [4, 0, 8, 1, 2])
-    r = b.mcts_search(uct_c=2.0, max_simulations=10000, n_rollouts=20, solve=True, seed=42)
+    r = b.mcts_search(uct_c=2.0, max_simulations=10000, n_rollouts=20, solve=True, seed=42, layout=layout)
     stats = r["root_stats"].cpu().numpy()
     outcome = r["child_outcome"].cpu().numpy()
     assert (stats[:, 2] == -1).all()
@@ -127,7 +136,7 @@ def test_solver_known_answers(ctx):
         assert len(kids) == 4 and (kids == -1).all()
     # MCTSTest_SolveWin: "x(0,1) o(2,2)" -> ".x.\n...\n..o": x wins, best move x(0,2)
     b = _ttt_batch(ctx, [1, 8])
-    r = b.mcts_search(uct_c=2.0, max_simulations=10000, n_rollouts=20, solve=True, seed=42)
+    r = b.mcts_search(uct_c=2.0, max_simulations=10000, n_rollouts=20, solve=True, seed=42, layout=layout)
     stats = r["root_stats"].cpu().numpy()
     outcome = r["child_outcome"].cpu().numpy()
     best = r["best_action"].cpu().numpy()
@@ -136,26 +145,28 @@ def test_solver_known_answers(ctx):
     assert (outcome[np.arange(len(best)), best] == 1).all()
 
 
-def test_search_is_independent_of_batch_position_and_sharding(ctx, oracle):
+@pytest.mark.parametrize("layout", [1, 2])
+def test_search_is_independent_of_batch_position_and_sharding(ctx, oracle, layout):
     """Root i's search depends only on (seed, index_offset + i): the same roots searched as
     one batch or as two shards give identical statistics (multi-GPU sharding by root index)."""
     import torch
     og, roots, _ = _roots(oracle, ctx, "hex(board_size=5)", 64, 5, 10)
-    whole = roots.mcts_search(max_simulations=80, seed=9, index_offset=0)
-    lo = roots.gather(torch.arange(0, 32)).mcts_search(max_simulations=80, seed=9, index_offset=0)
-    hi = roots.gather(torch.arange(32, 64)).mcts_search(max_simulations=80, seed=9, index_offset=32)
+    whole = roots.mcts_search(max_simulations=80, seed=9, index_offset=0, layout=layout)
+    lo = roots.gather(torch.arange(0, 32)).mcts_search(max_simulations=80, seed=9, index_offset=0, layout=layout)
+    hi = roots.gather(torch.arange(32, 64)).mcts_search(max_simulations=80, seed=9, index_offset=32, layout=layout)
     for key in ("best_action", "child_visits", "child_reward"):
         got = torch.cat([lo[key], hi[key]]).cpu().numpy()
         np.testing.assert_array_equal(got, whole[key].cpu().numpy())
     del og
 
 
-def test_small_pool_still_searches(ctx):
+@pytest.mark.parametrize("layout", [1, 2])
+def test_small_pool_still_searches(ctx, layout):
     """With a node pool too small to expand everything the search degrades to leaf
     evaluation instead of failing (the reference garbage-collects, mcts.cc:441-482)."""
     import open_spiel_amd as osa
     b = osa.StateBatch(ctx, "connect_four", 128)
-    r = b.mcts_search(max_simulations=300, max_nodes=40, seed=3)
+    r = b.mcts_search(max_simulations=300, max_nodes=40, seed=3, layout=layout)
     stats = r["root_stats"].cpu().numpy()
     assert (stats[:, 0] == 300).all() and (stats[:, 1] <= 40).all()
     assert (r["child_visits"].sum(1).cpu().numpy() == 299).all()

@@ -17,15 +17,18 @@ def roots_for(game, n, depth_mod, seed=0x5EED):
         a = torch.where(trial.is_terminal(), torch.full_like(a, -1), a)
         b.apply_actions(a)
     return b
-cases = [("hex(board_size=9)", 8192, 1024, 0), ("hex(board_size=9)", 65536, 256, 0), ("hex(board_size=9)", 65536, 1024, 0),
-         ("connect_four", 65536, 256, 0), ("tic_tac_toe", 65536, 1000, 0)]
+cases = []
+for layout in (1, 2):
+    cases += [("hex(board_size=9)", 8192, 1024, 0, layout), ("hex(board_size=9)", 65536, 1024, 0, layout),
+              ("connect_four", 65536, 256, 0, layout), ("tic_tac_toe", 65536, 1000, 0, layout)]
 if len(sys.argv) > 1:
-    cases = [(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0)]
-for game, n, sims, max_nodes in cases:
+    cases = [(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0,
+              int(sys.argv[5]) if len(sys.argv) > 5 else 0)]
+for game, n, sims, max_nodes, layout in cases:
     b = roots_for(game, n, 40 if "hex" in game else (20 if "connect" in game else 4))
     torch.cuda.synchronize(); t = time.time()
-    r = b.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, seed=1, max_nodes=max_nodes)
+    r = b.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, seed=1, max_nodes=max_nodes, layout=layout)
     torch.cuda.synchronize(); dt = time.time() - t
     st = r["root_stats"]
-    print(f"{game} roots={n} sims={sims}: {dt:.3f} s, {n*st[:,3].mean().item()/dt:.3e} sims/s, nodes/root mean {st[:,1].mean().item():.0f} max {st[:,1].max().item():.0f}, sims done mean {st[:,3].mean().item():.0f}", flush=True)
+    print(f"layout={layout} {game} roots={n} sims={sims}: {dt:.3f} s, {n*st[:,3].mean().item()/dt:.3e} sims/s, nodes/root mean {st[:,1].mean().item():.0f} max {st[:,1].max().item():.0f}, sims done mean {st[:,3].mean().item():.0f}", flush=True)
     del b, r

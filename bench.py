@@ -91,6 +91,134 @@ def cpu_baseline():
     }
 
 
+def hex_roots(osa, torch, ctx, n, index_offset, seed=SEED, depth_mod=40):
+    """hex(9) search roots: root i = the empty board advanced by
+    hash(i) mod 40 uniformly random legal moves, never terminal."""
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed + 7919 * (index_offset + 1))
+    idx = torch.arange(index_offset, index_offset + n, device="cuda", dtype=torch.int64)
+    h = idx * 2654435761 + seed
+    h = h ^ (h >> 15)
+    depth = ((h >> 3) % depth_mod).to(torch.int32)
+    b = osa.StateBatch(ctx, "hex(board_size=9)", n)
+    for t in range(depth_mod):
+        m = b.legal_actions_mask().to(torch.float32)
+        m[m.sum(1) == 0, 0] = 1.0
+        a = torch.multinomial(m, 1, generator=gen).squeeze(1).to(torch.int32)
+        a = torch.where(depth > t, a, torch.full_like(a, -1))
+        trial = b.clone()
+        trial.apply_actions(a)
+        a = torch.where(trial.is_terminal(), torch.full_like(a, -1), a)
+        b.apply_actions(a)
+        del trial
+    return b
+
+
+def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
+    """BASELINE.json configs 3-5 next to the headline: hex(9) MCTS sims/s (roots sharded over the
+    ranks: strong scaling), kuhn CFR iterations/s (replicas only) and leduc ES-MCCFR trajectories/s
+    (trajectories sharded, one RCCL all-reduce of the delta tables per mini-batch)."""
+    from open_spiel_amd import distributed as osd
+    out = {}
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- config 4: hex(board_size=9) MCTS, 2^16 roots x 1024 simulations, 1 rollout each ----
+    total_roots, sims = 1 << 16, 1024
+    first, count = osd.shard_range(total_roots, rank, world)
+    roots = hex_roots(osa, torch, ctx, count, first)
+    # warm-up with the same geometry: sizes the context's node pool and log table once
+    roots.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, seed=1, index_offset=first)
+    fence()
+    t0 = time.perf_counter()
+    res = roots.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, seed=SEED, index_offset=first)
+    fence()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    done = res["root_stats"][:, 3].sum()
+    if world > 1:
+        dist.all_reduce(done)
+    out["mcts"] = {"metric": "MCTS sims/sec", "value": float(done.item()) / dt, "unit": "sims/s", "seconds": dt,
+                   "scaling": "strong",
+                   "config": {"workload": "hex(board_size=9) MCTSBot(RandomRolloutEvaluator(1), uct_c=2, 1024 sims) "
+                                          f"x 2^16 roots, {count} roots on rank 0, wave-per-root layout"}}
+    del roots, res
+
+    # ---- config 3: kuhn_poker CFRSolver (full-tree regret / strategy update kernel) ----
+    solver = osa.TabularSolver(ctx, "kuhn_poker")
+    solver.evaluate_and_update_policy(100)
+    fence()
+    iters = 20000
+    t0 = time.perf_counter()
+    solver.evaluate_and_update_policy(iters)
+    fence()
+    dt = time.perf_counter() - t0
+    out["cfr"] = {"metric": "CFR iterations/sec", "value": iters / dt, "unit": "iterations/s", "seconds": dt,
+                  "scaling": "replicas only",
+                  "config": {"workload": f"kuhn_poker CFRSolver, {iters} EvaluateAndUpdatePolicy in one launch, "
+                                         "58 histories / 12 infostates, LDS-resident"}}
+    del solver
+
+    # ---- config 5: leduc_poker external-sampling MCCFR, 2^24 trajectories, mini-batches of 2^20 ----
+    solver = osa.TabularSolver(ctx, "leduc_poker", mccfr=True)
+    sharded = osd.ShardedMccfr(solver)
+    sharded.run_minibatch(SEED, 1 << 12)
+    fence()
+    batch, nb = 1 << 20, 16
+    t0 = time.perf_counter()
+    for _ in range(nb):
+        sharded.run_minibatch(SEED, batch)
+    fence()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    out["mccfr"] = {"metric": "ES-MCCFR trajectories/sec", "value": batch * nb / dt, "unit": "trajectories/s",
+                    "seconds": dt, "scaling": "strong",
+                    "config": {"workload": f"leduc_poker external-sampling MCCFR, 2^24 trajectories in {nb} mini-batches "
+                                           f"of 2^20 sharded over {world} rank(s), "
+                                           + ("one all-reduce of 2 x [936,3] fp64 per mini-batch" if world > 1
+                                              else "no collective at 1 GPU")}}
+    if rank == 0:
+        t = solver.tables()
+        out["mccfr"]["tables_finite"] = bool((abs(t["regrets"]) < 1e300).all())
+    if with_cpu and rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_py
+        threads = host_threads()
+        g = oracle_py.Game("hex(board_size=9)")
+        per_thread = 64                                                             # ~10 s of CPU work
+        secs, done_cpu = g.bench_mcts(SEED, threads * per_thread, 40, 1024, 1, 2.0, threads)
+        out["mcts"]["cpu_baseline"] = {"value": done_cpu / secs, "unit": "sims/s", "cores": threads, "kind": "port",
+                                       "sample": f"{threads * per_thread} roots x 1024 sims, one MCTSBot per root, "
+                                                 f"{threads} threads, {secs:.1f} s"}
+        gk = oracle_py.Game("kuhn_poker")
+        secs = gk.bench_cfr(0, 100000, 1)
+        out["cfr"]["cpu_baseline"] = {"value": 100000 / secs, "unit": "iterations/s", "cores": 1, "kind": "port",
+                                      "sample": f"100000 CFRSolver iterations, 1 thread, {secs:.2f} s"}
+        gl = oracle_py.Game("leduc_poker")
+        secs = gl.bench_cfr(2, 100000, 1)
+        out["mccfr"]["cpu_baseline"] = {"value": 200000 / secs, "unit": "trajectories/s", "cores": 1, "kind": "port",
+                                        "sample": f"100000 RunIteration (= 200000 traversals), 1 thread, {secs:.2f} s"}
+    return out
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the headline kernel from the committed PMC profile, if any."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        rec = json.load(f)
+    return rec.get("bytes_per_launch"), rec.get("source")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,6 +226,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--states", type=int, default=STATES_PER_GPU, help="states per GPU (default 2^20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the MCTS / CFR / MCCFR workloads")
     args = ap.parse_args()
 
     import torch
@@ -152,7 +281,13 @@ def main():
     # sanity of the timed result against the oracle-checked status of the first states
     assert int((status & 0x40).sum().item()) == 0, "synthetic actions must all be legal"
 
+    secondary = None
+    if not args.no_secondary:
+        del src, dst
+        secondary = secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu=not args.no_cpu_baseline)
+
     if rank == 0:
+        traffic, traffic_source = pmc_traffic()
         total_steps = n * world * args.steps
         value = total_steps / elapsed
         achieved = ALGO_BYTES_PER_STEP * n / avg_kernel_s / 1e9
@@ -165,7 +300,7 @@ def main():
                                    "out-of-place SoA bitboards, seed 0x5EED",
                        "states_per_gpu": n, "parallelism": f"{world} independent shard(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_step_c4x2<C4T<6,7,4>>", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * n,
                          "avg_launch_us": avg_kernel_s * 1e6,
                          "note": "2^20 states = 36.7 MB/launch, resident in the 256 MiB Infinity Cache"},
@@ -173,6 +308,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        if secondary is not None:
+            line["secondary"] = secondary
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

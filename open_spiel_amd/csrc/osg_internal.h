@@ -48,6 +48,10 @@ struct osg_ctx {
   size_t scratch_bytes = 0;
   void* h_pinned = nullptr;
   size_t pinned_bytes = 0;
+  void* d_mcts_pool = nullptr;              // MCTS node pool, grow-only, reused across searches
+  size_t mcts_pool_bytes = 0;
+  double* d_mcts_logs = nullptr;            // log(n) table shared with the host libm
+  int mcts_logs_n = 0;
 };
 
 struct osg_batch {

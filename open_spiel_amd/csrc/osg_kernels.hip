@@ -333,6 +333,8 @@ int osg_ctx_destroy(osg_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
   if (ctx->d_illegal) hipFree(ctx->d_illegal);
   if (ctx->d_scratch) hipFree(ctx->d_scratch);
+  if (ctx->d_mcts_pool) hipFree(ctx->d_mcts_pool);
+  if (ctx->d_mcts_logs) hipFree(ctx->d_mcts_logs);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return OSG_OK;

@@ -227,23 +227,38 @@ extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_i
   if (cfg.max_simulations < 1 || cfg.n_rollouts < 1) return set_error(OSG_ERR_INVALID, "max_simulations and n_rollouts must be >= 1");
   if (cfg.solve && !board)
     return set_error(OSG_ERR_UNSUPPORTED, "solve=true needs win/draw/loss outcomes (tic_tac_toe, connect_four, hex)");
+  int layout = cfg.layout;
+  if (layout == 0)  // auto: the wave layout where its parallel playout applies (hex without the swap rule)
+    layout = (d.game_kind == kHex && d.num_distinct_actions == d.obs_shape[1] * d.obs_shape[2]) ? 2 : 1;
+  if (layout != 1 && layout != 2) return set_error(OSG_ERR_INVALID, "osg_mcts_cfg.layout must be 0, 1 or 2");
   const int64_t n = roots->n;
   const int A = d.num_distinct_actions;
   const int widest = A > d.max_chance_outcomes ? A : d.max_chance_outcomes;
+  // Node pool: `cap` nodes per root.  Every simulation expands at most one node (<= widest
+  // children), so 1 + max_simulations * widest can never be exhausted; the default is capped
+  // at 16384 nodes per root and at the free HBM.  The pool lives in the context and is reused.
   int64_t cap = cfg.max_nodes > 0 ? cfg.max_nodes : 1 + static_cast<int64_t>(cfg.max_simulations) * widest;
   if (cfg.max_nodes <= 0 && cap > 16384) cap = 16384;
   if (cap < 1 + widest) cap = 1 + widest;
-  // keep the pool inside the free HBM (24 B per node)
-  size_t free_b = 0, total_b = 0;
-  OSG_HIP(hipMemGetInfo(&free_b, &total_b));
   const size_t per_node = 24;
-  while (static_cast<size_t>(cap) * n * per_node > free_b * 9 / 10 && cap > 1 + widest) cap = cap / 2 + widest;
+  if (static_cast<size_t>(cap) * n * per_node > ctx->mcts_pool_bytes) {
+    size_t free_b = 0, total_b = 0;
+    OSG_HIP(hipMemGetInfo(&free_b, &total_b));
+    free_b += ctx->mcts_pool_bytes;  // the old pool is released before the new one is allocated
+    while (static_cast<size_t>(cap) * n * per_node > free_b * 9 / 10 && cap > 1 + widest) cap = cap / 2 + widest;
+  }
   cfg.max_nodes = static_cast<int32_t>(cap);
-
   const size_t slots = static_cast<size_t>(cap) * n;
-  char* pool_mem = nullptr;
-  hipError_t e = hipMalloc(&pool_mem, slots * per_node);
-  if (e != hipSuccess) return set_error(OSG_ERR_NOMEM, std::string("MCTS node pool: ") + hipGetErrorString(e));
+  if (slots * per_node > ctx->mcts_pool_bytes) {
+    OSG_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_mcts_pool) OSG_HIP(hipFree(ctx->d_mcts_pool));
+    ctx->d_mcts_pool = nullptr;
+    ctx->mcts_pool_bytes = 0;
+    hipError_t e = hipMalloc(&ctx->d_mcts_pool, slots * per_node);
+    if (e != hipSuccess) return set_error(OSG_ERR_NOMEM, std::string("MCTS node pool: ") + hipGetErrorString(e));
+    ctx->mcts_pool_bytes = slots * per_node;
+  }
+  char* pool_mem = static_cast<char*>(ctx->d_mcts_pool);
   Pool pool;
   pool.total = reinterpret_cast<double*>(pool_mem);
   pool.meta = reinterpret_cast<uint32_t*>(pool_mem + slots * 8);
@@ -253,15 +268,22 @@ extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_i
   pool.n_roots = n;
   pool.cap = static_cast<int>(cap);
 
-  // log(parent explore_count) from the host libm: the CPU oracle (and the
-  // reference) call std::log, so sharing the table makes UCT values bit-equal.
-  std::vector<double> logs(cfg.max_simulations + 2);
-  logs[0] = 0.0;
-  for (int i = 1; i < static_cast<int>(logs.size()); ++i) logs[i] = std::log(static_cast<double>(i));
-  double* d_logs = nullptr;
-  e = hipMalloc(&d_logs, logs.size() * sizeof(double));
-  if (e != hipSuccess) { (void)hipFree(pool_mem); return set_error(OSG_ERR_NOMEM, hipGetErrorString(e)); }
-  OSG_HIP(hipMemcpyAsync(d_logs, logs.data(), logs.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  // log(parent explore_count) from the host libm: the CPU oracle (and the reference) call
+  // std::log, so sharing the table makes UCT values bit-equal.  Cached in the context.
+  if (cfg.max_simulations + 2 > ctx->mcts_logs_n) {
+    const int want = cfg.max_simulations + 2;
+    std::vector<double> logs(want);
+    logs[0] = 0.0;
+    for (int i = 1; i < want; ++i) logs[i] = std::log(static_cast<double>(i));
+    OSG_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_mcts_logs) OSG_HIP(hipFree(ctx->d_mcts_logs));
+    ctx->d_mcts_logs = nullptr;
+    ctx->mcts_logs_n = 0;
+    OSG_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_mcts_logs), want * sizeof(double)));
+    OSG_HIP(hipMemcpy(ctx->d_mcts_logs, logs.data(), want * sizeof(double), hipMemcpyHostToDevice));
+    ctx->mcts_logs_n = want;
+  }
+  const double* d_logs = ctx->d_mcts_logs;
 
   // host-side outputs are staged through scratch
   size_t off = 0;
@@ -274,7 +296,7 @@ extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_i
   if (on_host) {
     void* scratch = nullptr;
     int rc = osg_ctx_scratch(ctx, off, &scratch);
-    if (rc) { (void)hipFree(pool_mem); (void)hipFree(d_logs); return rc; }
+    if (rc) return rc;
     char* sc = static_cast<char*>(scratch);
     d_best = best_action ? reinterpret_cast<int32_t*>(sc + o_best) : nullptr;
     d_vis = child_visits ? reinterpret_cast<int32_t*>(sc + o_vis) : nullptr;
@@ -282,48 +304,30 @@ extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_i
     d_out = child_outcome ? reinterpret_cast<int8_t*>(sc + o_out) : nullptr;
     d_stats = root_stats ? reinterpret_cast<double*>(sc + o_stats) : nullptr;
   }
-  int layout = cfg.layout;
-  if (layout == 0)  // auto: the wave layout where its parallel playout applies (hex without the swap rule)
-    layout = (d.game_kind == kHex && d.num_distinct_actions == d.obs_shape[1] * d.obs_shape[2]) ? 2 : 1;
-  if (layout != 1 && layout != 2) {
-    (void)hipFree(pool_mem);
-    (void)hipFree(d_logs);
-    return set_error(OSG_ERR_INVALID, "osg_mcts_cfg.layout must be 0, 1 or 2");
-  }
   if (layout == 2) {
     MctsOut out{d_best, d_vis, d_rew, d_out, d_stats};
     int rc = launch_mcts_wave(roots, cfg, d_logs, pool, out);
-    if (rc) {
-      (void)hipStreamSynchronize(ctx->stream);
-      (void)hipFree(pool_mem);
-      (void)hipFree(d_logs);
-      return rc;
+    if (rc) return rc;
+  } else {
+    const unsigned grid = static_cast<unsigned>((n + kBlockM - 1) / kBlockM);
+    if (board) {
+      OSG_DISPATCH(roots->spec, k_mcts<G, true><<<dim3(grid), dim3(kBlockM), 0, ctx->stream>>>(
+                                    P, static_cast<const typename G::word_t*>(roots->d_words), n, d.num_players, A, cfg,
+                                    d.max_utility, d_logs, pool, d_best, d_vis, d_rew, d_out, d_stats));
+    } else {
+      OSG_DISPATCH(roots->spec, k_mcts<G, false><<<dim3(grid), dim3(kBlockM), 0, ctx->stream>>>(
+                                    P, static_cast<const typename G::word_t*>(roots->d_words), n, d.num_players, A, cfg,
+                                    d.max_utility, d_logs, pool, d_best, d_vis, d_rew, d_out, d_stats));
     }
-  } else {
-  const unsigned grid = static_cast<unsigned>((n + kBlockM - 1) / kBlockM);
-  if (board) {
-    OSG_DISPATCH(roots->spec, k_mcts<G, true><<<dim3(grid), dim3(kBlockM), 0, ctx->stream>>>(
-                                  P, static_cast<const typename G::word_t*>(roots->d_words), n, d.num_players, A, cfg,
-                                  d.max_utility, d_logs, pool, d_best, d_vis, d_rew, d_out, d_stats));
-  } else {
-    OSG_DISPATCH(roots->spec, k_mcts<G, false><<<dim3(grid), dim3(kBlockM), 0, ctx->stream>>>(
-                                  P, static_cast<const typename G::word_t*>(roots->d_words), n, d.num_players, A, cfg,
-                                  d.max_utility, d_logs, pool, d_best, d_vis, d_rew, d_out, d_stats));
+    OSG_HIP(hipGetLastError());
   }
+  if (on_host) {
+    if (best_action) OSG_HIP(hipMemcpyAsync(best_action, d_best, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (child_visits) OSG_HIP(hipMemcpyAsync(child_visits, d_vis, sizeof(int32_t) * n * A, hipMemcpyDeviceToHost, ctx->stream));
+    if (child_reward) OSG_HIP(hipMemcpyAsync(child_reward, d_rew, sizeof(double) * n * A, hipMemcpyDeviceToHost, ctx->stream));
+    if (child_outcome) OSG_HIP(hipMemcpyAsync(child_outcome, d_out, static_cast<size_t>(n) * A, hipMemcpyDeviceToHost, ctx->stream));
+    if (root_stats) OSG_HIP(hipMemcpyAsync(root_stats, d_stats, sizeof(double) * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    OSG_HIP(hipStreamSynchronize(ctx->stream));
   }
-  hipError_t launch = hipGetLastError();
-  if (on_host && launch == hipSuccess) {
-    if (best_action) (void)hipMemcpyAsync(best_action, d_best, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream);
-    if (child_visits) (void)hipMemcpyAsync(child_visits, d_vis, sizeof(int32_t) * n * A, hipMemcpyDeviceToHost, ctx->stream);
-    if (child_reward) (void)hipMemcpyAsync(child_reward, d_rew, sizeof(double) * n * A, hipMemcpyDeviceToHost, ctx->stream);
-    if (child_outcome) (void)hipMemcpyAsync(child_outcome, d_out, static_cast<size_t>(n) * A, hipMemcpyDeviceToHost, ctx->stream);
-    if (root_stats) (void)hipMemcpyAsync(root_stats, d_stats, sizeof(double) * n * 4, hipMemcpyDeviceToHost, ctx->stream);
-  }
-  // The pool is private to this call: wait for the search, then release it.
-  hipError_t sync = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(pool_mem);
-  (void)hipFree(d_logs);
-  if (launch != hipSuccess) return set_error(OSG_ERR_HIP, hipGetErrorString(launch));
-  if (sync != hipSuccess) return set_error(OSG_ERR_HIP, hipGetErrorString(sync));
   return OSG_OK;
 }

@@ -62,14 +62,11 @@ class ShardedMccfr:
         first, count = shard_range(trajectories, self.rank, self.world_size)
         self.solver.mccfr_sample(seed, count, first_trajectory=self.trajectories_done + first)
         if self.world_size > 1:
-            dreg, dpol = self.solver.mccfr_delta_tables()
-            # one collective for both tables: they are adjacent in the solver's allocation
-            # when it is the device solver; otherwise pack them.
-            if (dreg.is_contiguous() and dpol.is_contiguous()
-                    and dpol.data_ptr() == dreg.data_ptr() + dreg.numel() * dreg.element_size()):
-                flat = torch.as_strided(dreg, (dreg.numel() + dpol.numel(),), (1,))
-                allreduce_sum_(flat)
+            if hasattr(self.solver, "mccfr_delta_flat"):
+                # the device solver: both tables are one allocation -> one collective, in place
+                allreduce_sum_(self.solver.mccfr_delta_flat())
             else:
+                dreg, dpol = self.solver.mccfr_delta_tables()
                 flat = torch.cat([dreg.reshape(-1), dpol.reshape(-1)])
                 allreduce_sum_(flat)
                 dreg.copy_(flat[:dreg.numel()].view_as(dreg))

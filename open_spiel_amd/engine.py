@@ -327,27 +327,33 @@ class TabularSolver:
             assert a is None or a.shape == (self.num_infostates, self.amax)
         check(lib().osg_cfr_upload_tables(self._h, *[None if a is None else a.ctypes.data for a in arrs]))
 
-    def _wrap(self, ptr):
-        # zero-copy torch view of a device fp64 table [I, Amax]
-        n = self.num_infostates * self.amax
-        arr_t = C.c_double * n
+    def _wrap(self, ptr, shape):
+        """Zero-copy torch view of device fp64 memory owned by the solver."""
         holder = type("Holder", (), {})()
         holder.__cuda_array_interface__ = {
-            "shape": (self.num_infostates, self.amax), "typestr": "<f8",
-            "data": (ptr, False), "version": 2, "strides": None}
-        del arr_t
-        t = torch.as_tensor(holder, device=self.ctx.device)
-        return t
+            "shape": tuple(shape), "typestr": "<f8", "data": (ptr, False), "version": 2, "strides": None}
+        return torch.as_tensor(holder, device=self.ctx.device)
 
     def device_tables(self):
+        """(regrets, cumulative policy, current policy) as [I, Amax] device views."""
         r, c, p = C.c_void_p(), C.c_void_p(), C.c_void_p()
         check(lib().osg_cfr_table_ptrs(self._h, C.byref(r), C.byref(c), C.byref(p)))
-        return self._wrap(r.value), self._wrap(c.value), self._wrap(p.value)
+        shape = (self.num_infostates, self.amax)
+        return self._wrap(r.value, shape), self._wrap(c.value, shape), self._wrap(p.value, shape)
 
-    def mccfr_delta_tables(self):
+    def mccfr_delta_flat(self):
+        """Both MCCFR delta tables as ONE [2, I, Amax] device view (they are adjacent in the
+        solver's allocation), so a multi-GPU job needs a single all-reduce per mini-batch."""
         r, c = C.c_void_p(), C.c_void_p()
         check(lib().osg_mccfr_delta_ptrs(self._h, C.byref(r), C.byref(c)))
-        return self._wrap(r.value), self._wrap(c.value)
+        n = self.num_infostates * self.amax
+        if c.value != r.value + 8 * n:
+            raise OsgError("delta tables are not adjacent")
+        return self._wrap(r.value, (2, self.num_infostates, self.amax))
+
+    def mccfr_delta_tables(self):
+        flat = self.mccfr_delta_flat()
+        return flat[0], flat[1]
 
     def mccfr_apply_deltas(self):
         check(lib().osg_mccfr_apply_deltas(self._h))

@@ -44,6 +44,13 @@ class FakeSolver:
         self.tables += self.deltas
 
 
+class FakeFlatSolver(FakeSolver):
+    """Same, but exposing the one-allocation view like the device solver."""
+
+    def mccfr_delta_flat(self):
+        return self.deltas
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -57,7 +64,7 @@ def _worker(rank, world_size, port, out_dir):
     try:
         from open_spiel_amd import distributed as osd
         assert osd.world() == (rank, world_size)
-        solver = FakeSolver()
+        solver = FakeSolver() if rank == 0 else FakeFlatSolver()  # both reduction paths interoperate
         sharded = osd.ShardedMccfr(solver)
         sampled = [sharded.run_minibatch(seed=11, trajectories=t) for t in (1, 5, 64, 1001)]
         # variable-size gather: 7 roots over 2 ranks -> 4 + 3

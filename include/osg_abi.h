@@ -202,6 +202,8 @@ typedef struct {
                                     1: ExternalSamplingMCCFRSolver, regrets and cumulative policy
                                        start at kInitialTableValues = 1e-6
                                        (external_sampling_mccfr.h:59, .cc:142-143)              */
+  int32_t kernel;                /* 0 auto; 1 force the general level-synchronous kernel (k_cfr)
+                                    even where the all-in-LDS small-tree kernel applies      */
 } osg_cfr_cfg;
 /* Replaces CFRSolverBase::CFRSolverBase + InitializeInfostateNodes
  * (cfr.cc:191-261): expands the whole game tree level by level ON THE DEVICE

@@ -431,7 +431,7 @@ class DeviceTabularSolver {
 
  protected:
   DeviceTabularSolver(const Game& game, bool alternating, bool linear, bool rm_plus, bool mccfr) {
-    osg_cfr_cfg cfg{alternating ? 1 : 0, linear ? 1 : 0, rm_plus ? 1 : 0, mccfr ? 1 : 0};
+    osg_cfr_cfg cfg{alternating ? 1 : 0, linear ? 1 : 0, rm_plus ? 1 : 0, mccfr ? 1 : 0, 0};
     Check(osg_cfr_create(game.Ctx(), game.GameString().c_str(), &cfg, &s_));
     Check(osg_cfr_sizes(s_, sizes_));
     num_players_ = game.NumPlayers();

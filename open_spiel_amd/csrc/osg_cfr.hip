@@ -205,6 +205,161 @@ k_cfr(Tree t, Tables tb, double* g_reach, double* g_value, int iters, int iterat
 }
 
 // ---------------------------------------------------------------------------
+// Small trees (kuhn_poker: 58 histories): the WHOLE problem — tree structure,
+// values, tables — lives in LDS for the launch; nothing but LDS traffic inside
+// the iteration loop.  Per player pass:
+//   A  values bottom-up, one level per step (terminal values are staged once)
+//   B  one thread per decision history: reach probabilities from its root path
+//      (host-precomputed, root-to-leaf order so the products round like the
+//      reference's top-down recursion), then its regret / average-policy terms
+//   C  one thread per infostate: fold its members' terms in DFS order, RM+ clamp,
+//      regret matching
+// The reference's zero-reach prune (cfr.cc:350-355) only ever changes values that
+// are multiplied by an exact zero afterwards (the first all-zero node on a path
+// hangs off a probability-0 edge, and an unpruned parent of a pruned child has
+// counterfactual reach 0), so phase A does not need reach probabilities; phase B
+// applies the prune where it is observable (no update at pruned histories).
+// ---------------------------------------------------------------------------
+struct SmallTree {  // device pointers to the extra host-built arrays
+  const int32_t* path_off;    // [M+1] per decision history (member order)
+  const int32_t* path;        // entries: slot << 24 | is_chance << 23 | index
+  int M;                      // decision histories
+  int n_path;
+};
+
+__global__ void __launch_bounds__(1024)
+k_cfr_small(Tree t, SmallTree st, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg) {
+  extern __shared__ double smem[];
+  const int P = t.P, A = t.A, H = t.H, I = t.I, M = st.M, IA = t.I * t.A;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // ---- carve LDS (doubles first, then 32-bit, then bytes) ----
+  double* value = smem;                      // [H, P]
+  double* edge_prob = value + H * P;         // [H]
+  double* regrets = edge_prob + H;           // [I, A]
+  double* cum = regrets + IA;
+  double* cur = cum + IA;
+  double* dreg = cur + IA;                   // [M, A]
+  double* dpol = dreg + M * A;               // [M, A]
+  int32_t* first_child = reinterpret_cast<int32_t*>(dpol + M * A);  // [H]
+  int32_t* info = first_child + H;           // [H]
+  int32_t* meta = info + H;                  // [H] kind | nchild << 2 | (actor + 1) << 10
+  int32_t* mem = meta + H;                   // [M]
+  int32_t* mem_off = mem + M;                // [I+1]
+  int32_t* path_off = mem_off + (I + 1);     // [M+1]
+  int32_t* path = path_off + (M + 1);        // [n_path]
+  int32_t* nact = path + st.n_path;          // [I]
+  int32_t* info_player = nact + I;           // [I]
+  int32_t* skip = info_player + I;           // [M] 1 = pruned / not updated this pass
+  int32_t* level_off = skip + M;             // [D+1]
+  for (int h = tid; h < H; h += nt) {
+    first_child[h] = t.first_child[h];
+    info[h] = t.info[h];
+    meta[h] = t.kind[h] | (t.nchild[h] << 2) | ((t.actor[h] + 1) << 10);
+    edge_prob[h] = t.edge_prob[h];
+    for (int q = 0; q < P; ++q) value[h * P + q] = t.term_ret[h * P + q];  // terminals keep these forever
+  }
+  for (int k = tid; k < IA; k += nt) {
+    regrets[k] = tb.regrets[k];
+    cum[k] = tb.cum[k];
+    cur[k] = tb.cur[k];
+  }
+  for (int k = tid; k < M; k += nt) mem[k] = t.mem[k];
+  for (int k = tid; k <= M; k += nt) path_off[k] = st.path_off[k];
+  for (int k = tid; k < st.n_path; k += nt) path[k] = st.path[k];
+  for (int k = tid; k <= I; k += nt) mem_off[k] = t.mem_off[k];
+  for (int k = tid; k < I; k += nt) {
+    nact[k] = t.nact[k];
+    info_player[k] = t.info_player[k];
+  }
+  for (int k = tid; k <= t.D; k += nt) level_off[k] = t.level_off[k];
+  __syncthreads();
+
+  const int passes = cfg.alternating_updates ? P : 1;
+  for (int it = 0; it < iters; ++it) {
+    const int iteration = iteration0 + it + 1;
+    for (int pass = 0; pass < passes; ++pass) {
+      const int upd = cfg.alternating_updates ? pass : -1;
+      // ---- A: values, bottom-up.  Alternating passes only need the updating player's value. ----
+      const int q0 = upd >= 0 ? upd : 0, q1 = upd >= 0 ? upd + 1 : P;
+      for (int l = t.D - 2; l >= 0; --l) {  // the last level holds terminals only
+        for (int h = level_off[l] + tid; h < level_off[l + 1]; h += nt) {
+          const int mt = meta[h];
+          const int k = mt & 3;
+          if (k == kTerminalNode) continue;
+          const int fc = first_child[h], nc = (mt >> 2) & 0xFF;
+          const int row = k == kDecisionNode ? info[h] * A : 0;
+          for (int q = q0; q < q1; ++q) {
+            double v = 0.0;
+            for (int a = 0; a < nc; ++a) {
+              const double pr = k == kChanceNode ? edge_prob[fc + a] : cur[row + a];
+              v += pr * value[(fc + a) * P + q];
+            }
+            value[h * P + q] = v;
+          }
+        }
+        __syncthreads();
+      }
+      // ---- B: per decision history, reach from the root path, then its update terms ----
+      for (int m = tid; m < M; m += nt) {
+        const int h = mem[m];
+        const int pl = ((meta[h] >> 10) & 15) - 1;
+        if (upd >= 0 && pl != upd) { skip[m] = 1; continue; }
+        double reach[kMaxPlayers + 1];
+#pragma unroll
+        for (int q = 0; q <= kMaxPlayers; ++q) reach[q] = 1.0;
+        for (int e = path_off[m]; e < path_off[m + 1]; ++e) {
+          const int code = path[e];
+          const int slot = (code >> 24) & 0xF, idx = code & 0x7FFFFF;
+          const double pr = ((code >> 23) & 1) ? edge_prob[idx] : cur[idx];
+#pragma unroll
+          for (int q = 0; q <= kMaxPlayers; ++q) reach[q] = (q == slot) ? reach[q] * pr : reach[q];
+        }
+        bool pruned = true;  // AllPlayersHaveZeroReachProb (cfr.cc:471-479)
+        double self_reach = 0.0, cf_reach = 1.0;
+#pragma unroll
+        for (int q = 0; q <= kMaxPlayers; ++q) {
+          if (q < P) pruned &= (reach[q] == 0.0);
+          if (q == pl) self_reach = reach[q];
+          else if (q <= P) cf_reach *= reach[q];  // CounterFactualReachProb (cfr.cc:309-318), chance slot = P
+        }
+        skip[m] = pruned ? 1 : 0;
+        if (pruned) continue;
+        const int i = info[h], n = nact[i], fc = first_child[h];
+        const double vh = value[h * P + pl];
+        for (int a = 0; a < n; ++a) {
+          dreg[m * A + a] = cf_reach * (value[(fc + a) * P + pl] - vh);
+          const double pol = cur[i * A + a];
+          dpol[m * A + a] = cfg.linear_averaging ? iteration * self_reach * pol : self_reach * pol;
+        }
+      }
+      __syncthreads();
+      // ---- C: fold per infostate (members are in the reference's DFS order), then match ----
+      for (int i = tid; i < I; i += nt) {
+        if (upd >= 0 && info_player[i] != upd) continue;
+        const int n = nact[i];
+        for (int m = mem_off[i]; m < mem_off[i + 1]; ++m) {
+          if (skip[m]) continue;
+          for (int a = 0; a < n; ++a) {
+            regrets[i * A + a] += dreg[m * A + a];
+            cum[i * A + a] += dpol[m * A + a];
+          }
+        }
+        if (cfg.regret_matching_plus)
+          for (int a = 0; a < n; ++a)
+            if (regrets[i * A + a] < 0) regrets[i * A + a] = 0;
+        regret_match_row(regrets + i * A, cur + i * A, n);
+      }
+      __syncthreads();
+    }
+  }
+  for (int k = tid; k < IA; k += nt) {
+    tb.regrets[k] = regrets[k];
+    tb.cum[k] = cum[k];
+    tb.cur[k] = cur[k];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // ExternalSamplingMCCFRSolver::UpdateRegrets (external_sampling_mccfr.cc:122-186),
 // AverageType::kSimple, one traversal per thread, tables frozen for the launch.
 // ---------------------------------------------------------------------------
@@ -392,6 +547,11 @@ struct osg_cfr {
   double* d_value = nullptr;   // [H, P]
   bool lds_resident = false;
   size_t lds_bytes = 0;
+  // small-tree kernel: root paths of the decision histories (member order)
+  std::vector<int32_t> path_off, path;
+  int32_t *d_path_off = nullptr, *d_path = nullptr;
+  bool small_tree = false;
+  size_t small_lds_bytes = 0;
 
   Tree tree() const {
     Tree t;
@@ -554,6 +714,21 @@ int build_tree(osg_cfr* s, const char* game_string) {
     s->mem.insert(s->mem.end(), members[i].begin(), members[i].end());
     s->mem_off.push_back(static_cast<int32_t>(s->mem.size()));
   }
+  // Root path of every decision history, root-to-leaf: one entry per ancestor edge =
+  // (reach slot of the ancestor's actor, where to read the edge probability).
+  s->path_off.push_back(0);
+  for (int32_t h : s->mem) {
+    std::vector<int32_t> rev;
+    for (int32_t v = h; s->parent[v] >= 0; v = s->parent[v]) {
+      const int32_t par = s->parent[v];
+      const bool chance = s->kind[par] == kChanceNode;
+      const int slot = chance ? s->P : s->actor[par];
+      const int32_t idx = chance ? v : s->info[par] * s->A + s->aidx[v];
+      rev.push_back((slot << 24) | ((chance ? 1 : 0) << 23) | idx);
+    }
+    s->path.insert(s->path.end(), rev.rbegin(), rev.rend());
+    s->path_off.push_back(static_cast<int32_t>(s->path.size()));
+  }
   return OSG_OK;
 }
 
@@ -616,6 +791,23 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
                             static_cast<int>(s->lds_bytes));
     if (e != hipSuccess) { (void)hipGetLastError(); s->lds_resident = false; }
   }
+  {  // the all-in-LDS kernel for small trees
+    const size_t M = s->mem.size();
+    const size_t doubles = static_cast<size_t>(s->H) * s->P + s->H + 3 * IA + 2 * M * s->A;
+    const size_t ints = 3 * static_cast<size_t>(s->H) + M + (s->I + 1) + (M + 1) + s->path.size() + 2 * s->I + M + (s->D + 1);
+    s->small_lds_bytes = doubles * 8 + ints * 4;
+    const bool index_fits = static_cast<size_t>(s->H) < (1u << 23) && IA < (1u << 23);
+    s->small_tree = index_fits && s->small_lds_bytes <= 64 * 1024 && s->P <= kMaxPlayers;
+    if (s->small_tree) {
+      if ((rc = upload(s->path_off, &s->d_path_off, st)) || (rc = upload(s->path, &s->d_path, st))) {
+        osg_cfr_destroy(s);
+        return rc;
+      }
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cfr_small), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(s->small_lds_bytes));
+      if (e != hipSuccess) { (void)hipGetLastError(); s->small_tree = false; }
+    }
+  }
   rc = init_tables(s);
   if (rc) { osg_cfr_destroy(s); return rc; }
   *out = s;
@@ -627,7 +819,7 @@ int osg_cfr_destroy(osg_cfr* s) {
   (void)hipStreamSynchronize(s->ctx->stream);
   void* ptrs[] = {s->d_level_off, s->d_parent, s->d_first_child, s->d_info, s->d_mem_off, s->d_mem, s->d_nact,
                   s->d_kind, s->d_nchild, s->d_aidx, s->d_actor, s->d_info_player, s->d_edge_prob, s->d_term_ret,
-                  s->d_tables, s->d_reach, s->d_value};
+                  s->d_tables, s->d_reach, s->d_value, s->d_path_off, s->d_path};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete s;
@@ -648,7 +840,11 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
   int threads = ((s->max_level_width + 63) / 64) * 64;
   threads = std::max(64, std::min(threads, 1024));
   Tables tb{s->regrets(), s->cum(), s->cur()};
-  if (s->lds_resident) {
+  if (s->small_tree && s->cfg.kernel != 1) {
+    SmallTree st{s->d_path_off, s->d_path, static_cast<int>(s->mem.size()), static_cast<int>(s->path.size())};
+    k_cfr_small<<<dim3(1), dim3(threads), s->small_lds_bytes, s->ctx->stream>>>(s->tree(), st, tb, iters, s->iteration,
+                                                                               s->cfg);
+  } else if (s->lds_resident) {
     k_cfr<true><<<dim3(1), dim3(threads), s->lds_bytes, s->ctx->stream>>>(s->tree(), tb, s->d_reach, s->d_value, iters,
                                                                          s->iteration, s->cfg);
   } else {

@@ -281,11 +281,11 @@ class TabularSolver:
     """
 
     def __init__(self, ctx, game_string, alternating_updates=True, linear_averaging=False,
-                 regret_matching_plus=False, mccfr=False):
+                 regret_matching_plus=False, mccfr=False, general_kernel=False):
         self.ctx = ctx
         self.game_string = game_string
         cfg = _abi.CfrCfg(int(alternating_updates), int(linear_averaging), int(regret_matching_plus),
-                          int(mccfr))
+                          int(mccfr), 1 if general_kernel else 0)
         h = C.c_void_p()
         check(lib().osg_cfr_create(ctx._h, game_string.encode(), C.byref(cfg), C.byref(h)))
         self._h = h

@@ -69,6 +69,13 @@ def test_tree_census_and_keys(oracle, ctx, game):
     ("kuhn_poker(players=3)", "cfr_plus", dict(linear_averaging=True, regret_matching_plus=True), [10]),
     ("leduc_poker", "cfr", {}, [1, 2, 10]),
     ("leduc_poker", "cfr_plus", dict(linear_averaging=True, regret_matching_plus=True), [5]),
+    # the general level-synchronous kernel on the small trees too (default there: the all-in-LDS kernel)
+    ("kuhn_poker", "cfr", dict(general_kernel=True), [1, 2, 10, 100]),
+    ("kuhn_poker", "cfr_plus", dict(linear_averaging=True, regret_matching_plus=True, general_kernel=True), [1, 50]),
+    ("kuhn_poker", "cfr_simultaneous", dict(alternating_updates=False, general_kernel=True), [1, 20]),
+    ("kuhn_poker(players=3)", "cfr", dict(general_kernel=True), [1, 10]),
+    ("kuhn_poker(players=4)", "cfr", {}, [1, 6]),
+    ("kuhn_poker(players=3)", "cfr_simultaneous", dict(alternating_updates=False), [1, 12]),
 ])
 def test_cfr_tables_match_the_oracle(oracle, ctx, game, kind, kwargs, checkpoints):
     import open_spiel_amd as osa

@@ -78,8 +78,14 @@ struct Ttt {
 // u64 planes per state: plane 0 = x stones (player 0), plane 1 = o stones.
 // Bit index = col*(R+1) + row, row 0 = bottom; the extra row per column is an
 // always-empty sentinel so shifted line tests never wrap between columns.
-// Player to move = parity of the stone count; outcome recomputed (a reachable
-// position has at most one player with a line, connect_four.cc:138-142).
+// Player to move = parity of the stone count.
+//
+// The default 6x7 board uses 49 bits per plane, so plane 0 carries the result of
+// the game in its spare top byte (bit 56 = terminal, bits 57-58 = outcome: 0 x
+// won, 1 o won, 2 draw) — written by apply(), which already has to test the
+// mover's lines (connect_four.cc:138-142).  IsTerminal / Returns / LegalActions then
+// cost no line test at all.  Other geometries have no spare bits guaranteed and
+// recompute the outcome (a reachable position has at most one player with a line).
 // ===========================================================================
 struct C4Params {
   int words;  // = 2
@@ -94,8 +100,10 @@ template <int R_, int C_, int K_>
 struct C4T {
   using word_t = uint64_t;
   using Params = C4Params;
+  static constexpr bool kStored = R_ != 0 && (R_ + 1) * C_ <= 56;  // result kept in plane 0's top byte
   struct State {
     uint64_t x, o;
+    uint32_t flags;  // kStored only: bit 0 terminal, bits 1-2 outcome
   };
   OSG_D static int R(const Params& p) { return R_ ? R_ : p.rows; }
   OSG_D static int C(const Params& p) { return C_ ? C_ : p.cols; }
@@ -107,12 +115,19 @@ struct C4T {
     for (int c = 0; c < C_; ++c) t |= 1ull << (c * (R_ + 1) + R_ - 1);
     return t;
   }
-  OSG_D static State initial(const Params&) { return {0ull, 0ull}; }
+  OSG_D static State initial(const Params&) { return {0ull, 0ull, 0u}; }
+  OSG_D static State unpack(uint64_t w0, uint64_t w1) {
+    if (kStored) return {w0 & ((1ull << 56) - 1ull), w1, static_cast<uint32_t>(w0 >> 56)};
+    return {w0, w1, 0u};
+  }
+  OSG_D static uint64_t pack0(const State& s) {
+    return kStored ? (s.x | (static_cast<uint64_t>(s.flags) << 56)) : s.x;
+  }
   OSG_D static State load(const Params&, const word_t* base, int64_t n, int64_t i) {
-    return {base[i], base[n + i]};
+    return unpack(base[i], base[n + i]);
   }
   OSG_D static void store(const Params&, word_t* base, int64_t n, int64_t i, const State& s) {
-    base[i] = s.x;
+    base[i] = pack0(s);
     base[n + i] = s.o;
   }
   // HasLine, connect_four.cc:163-201, as the classic shifted-AND test along the
@@ -139,14 +154,26 @@ struct C4T {
     return ((s.x | s.o) & top(p)) == top(p);
   }
   OSG_D static bool terminal(const Params& p, const State& s) {
+    if (kStored) return s.flags & 1u;
     return line(p, s.x) | line(p, s.o) | full(p, s);
   }
   OSG_D static int current_player(const Params& p, const State& s) {  // connect_four.cc:122-128
     return terminal(p, s) ? kTerminalPlayer : (plies(s) & 1);
   }
+  OSG_D static bool column_has_room(const Params& p, const State& s, int col) {  // connect_four.cc:153
+    return col < C(p) && !(((s.x | s.o) >> (col * (R(p) + 1) + R(p) - 1)) & 1ull);
+  }
+  // Bit c set = column c still has room, whatever the state of the game.
   OSG_D static uint32_t open_columns(const Params& p, const State& s) {
     const int H = R(p) + 1;
     uint64_t free_top = ~(s.x | s.o) & top(p);
+    if (R_ == 6 && C_ == 7) {
+      // One multiply instead of seven extracts: the top cells sit at bits 5 + 7c; after >> 5 they
+      // are at 7c, and multiplying by sum_k 2^(36 - 6k) moves bit 7k to 36 + k.  No two partial
+      // products share a bit (7(i - i') = 6(k - k') has no solution with |k - k'| <= 6): no carries.
+      const uint64_t M = (1ull << 36) | (1ull << 30) | (1ull << 24) | (1ull << 18) | (1ull << 12) | (1ull << 6) | 1ull;
+      return static_cast<uint32_t>(((free_top >> 5) * M) >> 36) & 0x7Fu;
+    }
     uint32_t m = 0;
     if (C_ != 0) {
 #pragma unroll
@@ -166,13 +193,20 @@ struct C4T {
     uint64_t all = s.x | s.o;
     uint64_t colmask = ((1ull << R(p)) - 1ull) << (col * H);
     uint64_t cell = (all + (1ull << (col * H))) & colmask;  // lowest empty cell
-    if (__builtin_popcountll(all) & 1) s.o |= cell; else s.x |= cell;
+    const int mover = __builtin_popcountll(all) & 1;
+    if (mover) s.o |= cell; else s.x |= cell;
+    if (kStored) {  // outcome_ = mover if HasLine(mover) else draw if IsFull (connect_four.cc:138-142)
+      const bool win = line(p, mover ? s.o : s.x);
+      const bool done = win | full(p, s);
+      s.flags = done ? (1u | (static_cast<uint32_t>(win ? mover : 2) << 1)) : 0u;
+    }
   }
   OSG_D static int outcome_code(const Params& p, const State& s) {  // connect_four.cc:281-285
+    if (kStored) return static_cast<int>((s.flags >> 1) & 3u);
     return line(p, s.x) ? 0 : (line(p, s.o) ? 1 : 2);
   }
   OSG_D static void returns(const Params& p, const State& s, double* out) {
-    int c = outcome_code(p, s);
+    int c = terminal(p, s) ? outcome_code(p, s) : 2;
     out[0] = c == 0 ? 1.0 : (c == 1 ? -1.0 : 0.0);
     out[1] = -out[0] + 0.0;
   }

@@ -126,8 +126,10 @@ k_step(typename G::Params p, const typename G::word_t* src, typename G::word_t* 
 // connect_four fast path of the fused step: TWO consecutive states per thread so
 // that every state access is one 16-byte vector load/store per lane per plane
 // (1 KiB per wave-instruction, the coalescing sweet spot); actions / masks /
-// statuses move as u16.  Line tests are done once before the move and once for
-// the mover after it (only the mover's stones changed).
+// statuses move as u16.  With the result of the game stored in plane 0's spare
+// byte (C4T::kStored) a step costs ONE line test (the mover's, inside apply) and
+// one multiply for the successor's legal mask; the kernel is then close to the
+// plain-copy time of the same bytes (tools/step_sweep.hip).
 template <class G>
 __global__ void __launch_bounds__(kBlock)
 k_step_c4x2(typename G::Params p, const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, int64_t n,
@@ -142,29 +144,24 @@ k_step_c4x2(typename G::Params p, const uint64_t* __restrict__ src, uint64_t* __
   uint32_t m2 = 0, s2 = 0;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    typename G::State s{x[j], o[j]};
+    typename G::State s = G::unpack(x[j], o[j]);
     const int a = (a2 >> (8 * j)) & 0xFF;
-    const bool win_x = G::line(p, s.x), win_o = G::line(p, s.o);
-    bool term = win_x | win_o | G::full(p, s);
-    int outcome = win_x ? 0 : (win_o ? 1 : 2);
+    bool term = G::terminal(p, s);
     bool illegal = false;
     if (a != 0xFF) {
-      const uint32_t open = term ? 0u : G::open_columns(p, s);
-      if (a < 32 && ((open >> a) & 1u)) {
-        const int mover = G::plies(s) & 1;
+      if (!term && G::column_has_room(p, s, a)) {
         G::apply(p, s, a);
-        const bool win = G::line(p, mover ? s.o : s.x);
-        term = win | G::full(p, s);
-        outcome = win ? mover : 2;
+        term = G::terminal(p, s);
       } else {
         illegal = true;
       }
     }
-    x[j] = s.x;
+    const uint32_t open = G::open_columns(p, s);
+    const int to_move = G::plies(s) & 1;
+    x[j] = G::pack0(s);
     o[j] = s.o;
-    const uint32_t after = term ? 0u : G::open_columns(p, s);
-    m2 |= (after & 0xFFu) << (8 * j);
-    s2 |= static_cast<uint32_t>(encode_status(term, illegal, term ? 0 : (G::plies(s) & 1), term ? outcome : 0)) << (8 * j);
+    m2 |= (term ? 0u : (open & 0xFFu)) << (8 * j);
+    s2 |= static_cast<uint32_t>(encode_status(term, illegal, to_move, term ? G::outcome_code(p, s) : 0)) << (8 * j);
   }
   *reinterpret_cast<ulonglong2*>(dst + i) = make_ulonglong2(x[0], x[1]);
   *reinterpret_cast<ulonglong2*>(dst + n + i) = make_ulonglong2(o[0], o[1]);

@@ -147,6 +147,11 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions,
  * out is [n, size] fp32. */
 int osg_observation(const osg_batch* b, int player, int which, float* out, int on_host);
 
+/* State::InformationStateString(player) of state `index` (kuhn_poker.cc:109-166,
+ * leduc_poker.cc:198-239) — the key of the CFR tables.  Host formatter over the packed
+ * state words; returns the length (excluding NUL) or <0. */
+int osg_information_state_string(const osg_batch* b, int64_t index, int player, char* buf, int cap);
+
 /* Environment loop on device: `steps` times { sample a uniformly random legal
  * action (chance outcomes by their distribution), apply, auto-reset terminal
  * states to the initial state }.  d_counters[0] += env steps applied,

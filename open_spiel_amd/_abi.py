@@ -92,6 +92,7 @@ SIGNATURES = {
     "osg_chance_probs": (INT, [VP, VP, INT]),
     "osg_step": (INT, [VP, VP, VP, VP, VP]),
     "osg_observation": (INT, [VP, INT, INT, VP, INT]),
+    "osg_information_state_string": (INT, [VP, I64, INT, C.c_char_p, INT]),
     "osg_random_steps": (INT, [VP, U64, I64, INT, VP]),
     "osg_rollout": (INT, [VP, U64, I64, INT, VP, VP, INT]),
     "osg_mcts_search": (INT, [VP, C.POINTER(MctsCfg), VP, VP, VP, VP, VP, INT]),
@@ -123,6 +124,8 @@ def lib():
                 f"{LIB_PATH} is missing: the MI355X engine is hand-written HIP and has no "
                 "CPU fallback.  Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C open_spiel_amd/csrc`.")
+        from . import _load_torch_runtime_first
+        _load_torch_runtime_first()
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the ABI is incomplete

@@ -224,6 +224,13 @@ class State {
     CheckPlayer(player);
     return batch_.InformationStateTensor(player);
   }
+  std::string InformationStateString(Player player) const {  // kuhn_poker.cc:285-288, leduc_poker.cc:517-520
+    CheckPlayer(player);
+    char buf[512];
+    if (osg_information_state_string(batch_.handle(), 0, player, buf, sizeof(buf)) < 0) SpielFatalError(osg_last_error());
+    return buf;
+  }
+  std::string InformationStateString() const { return InformationStateString(CurrentPlayer()); }
   std::unique_ptr<State> Clone() const { return std::unique_ptr<State>(new State(*this)); }
   std::unique_ptr<State> Child(Action a) const {  // spiel.h:737-744
     std::unique_ptr<State> c = Clone();

@@ -1,0 +1,200 @@
+// pybind11 module `open_spiel_amd.pyspiel_hip`: the pyspiel surface of the hot path
+// (open_spiel/python/pybind11/pyspiel.cc:356-533,720-731 State / Game / load_game;
+//  bots.cc:106-149 Evaluator / RandomRolloutEvaluator / SearchNode / MCTSBot;
+//  policy.cc:224-333 CFRSolver / CFRPlusSolver / ExternalSamplingMCCFRSolver)
+// over the C++ host mirror (osg_spiel.h), i.e. over the C-ABI of libosg_hip.so.
+// Same method names and argument meaning as pyspiel, so scripts written against
+// `import pyspiel` run with `from open_spiel_amd import pyspiel_hip as pyspiel` for the five
+// hot-path games.  Plus the batch classes the device actually wants (BatchedState, step_batch).
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include "osg_spiel.h"
+
+namespace py = pybind11;
+using namespace open_spiel::hip;
+using namespace open_spiel::hip::algorithms;
+
+namespace {
+
+template <class T>
+py::array_t<T> as_array(const std::vector<T>& v, std::vector<py::ssize_t> shape) {
+  py::array_t<T> a(shape);
+  std::memcpy(a.mutable_data(), v.data(), v.size() * sizeof(T));
+  return a;
+}
+
+// pyspiel.TabularPolicy-like result of solver.average_policy() / tabular_average_policy().
+class TabularPolicy {
+ public:
+  explicit TabularPolicy(TabularPolicyTable t) : table_(std::move(t)) {}
+  const TabularPolicyTable& policy_table() const { return table_; }
+  std::unordered_map<Action, double> action_probabilities(const State& state, Player player) const {
+    return get_state_policy_as_map(state.InformationStateString(player));
+  }
+  std::unordered_map<Action, double> action_probabilities_current(const State& state) const {
+    return action_probabilities(state, state.CurrentPlayer());
+  }
+  ActionsAndProbs get_state_policy(const std::string& info_state) const {
+    auto it = table_.find(info_state);
+    return it == table_.end() ? ActionsAndProbs{} : it->second;
+  }
+  std::unordered_map<Action, double> get_state_policy_as_map(const std::string& info_state) const {
+    std::unordered_map<Action, double> out;
+    for (const auto& ap : get_state_policy(info_state)) out[ap.first] = ap.second;
+    return out;
+  }
+
+ private:
+  TabularPolicyTable table_;
+};
+
+}  // namespace
+
+PYBIND11_MODULE(pyspiel_hip, m) {
+  m.doc() = "pyspiel-compatible surface of the MI355X game-step and search engine (libosg_hip.so)";
+  py::register_exception<SpielException>(m, "SpielError", PyExc_RuntimeError);  // pyspiel.cc:831-837
+
+  m.attr("INVALID_ACTION") = py::int_(kInvalidAction);
+  py::class_<Game, std::shared_ptr<Game>>(m, "Game")
+      .def("num_distinct_actions", &Game::NumDistinctActions)
+      .def("max_chance_outcomes", &Game::MaxChanceOutcomes)
+      .def("num_players", &Game::NumPlayers)
+      .def("min_utility", &Game::MinUtility)
+      .def("max_utility", &Game::MaxUtility)
+      .def("max_game_length", &Game::MaxGameLength)
+      .def("max_chance_nodes_in_history", &Game::MaxChanceNodesInHistory)
+      .def("observation_tensor_shape", &Game::ObservationTensorShape)
+      .def("observation_tensor_size", &Game::ObservationTensorSize)
+      .def("information_state_tensor_shape", &Game::InformationStateTensorShape)
+      .def("information_state_tensor_size", &Game::InformationStateTensorSize)
+      .def("new_initial_state", [](const Game& g) { return g.NewInitialState(); })
+      .def("new_initial_states", [](const Game& g, int64_t n) { return g.NewInitialStates(n); }, py::arg("n"))
+      .def("__str__", &Game::ToString)
+      .def("__repr__", &Game::ToString);
+  m.def("load_game", [](const std::string& s) { return std::make_shared<Game>(s); });  // pyspiel.cc:720-731
+
+  py::class_<State>(m, "State")
+      .def("current_player", &State::CurrentPlayer)
+      .def("is_terminal", &State::IsTerminal)
+      .def("is_chance_node", &State::IsChanceNode)
+      .def("legal_actions", py::overload_cast<>(&State::LegalActions, py::const_))
+      .def("legal_actions", py::overload_cast<Player>(&State::LegalActions, py::const_), py::arg("player"))
+      .def("legal_actions_mask", &State::LegalActionsMask)
+      .def("apply_action", &State::ApplyAction, py::arg("action"))
+      .def("returns", &State::Returns)
+      .def("rewards", &State::Rewards)
+      .def("player_return", &State::PlayerReturn, py::arg("player"))
+      .def("chance_outcomes", &State::ChanceOutcomes)
+      .def("observation_tensor", [](const State& s, Player p) { return s.ObservationTensor(p); }, py::arg("player"))
+      .def("observation_tensor", [](const State& s) { return s.ObservationTensor(std::max(s.CurrentPlayer(), 0)); })
+      .def("information_state_tensor", [](const State& s, Player p) { return s.InformationStateTensor(p); },
+           py::arg("player"))
+      .def("information_state_tensor",
+           [](const State& s) { return s.InformationStateTensor(std::max(s.CurrentPlayer(), 0)); })
+      .def("information_state_string", py::overload_cast<Player>(&State::InformationStateString, py::const_),
+           py::arg("player"))
+      .def("information_state_string", py::overload_cast<>(&State::InformationStateString, py::const_))
+      .def("clone", &State::Clone)
+      .def("child", &State::Child, py::arg("action"))
+      .def("history", &State::History)
+      .def("move_number", &State::MoveNumber)
+      .def("num_players", &State::NumPlayers)
+      .def("get_game", [](const State& s) { return std::const_pointer_cast<Game>(s.GetGame()); });
+
+  py::class_<BatchedState>(m, "BatchedState")
+      .def("__len__", &BatchedState::size)
+      .def("legal_actions_mask_bits",
+           [](const BatchedState& b) {
+             return as_array(b.LegalActionsMaskBits(), {b.size(), b.GetGame()->Desc().mask_words});
+           })
+      .def("apply_actions",
+           [](BatchedState& b, py::array_t<int32_t, py::array::c_style | py::array::forcecast> a) {
+             b.ApplyActions(std::vector<int32_t>(a.data(), a.data() + a.size()));
+           },
+           py::arg("actions"))
+      .def("is_terminal", [](const BatchedState& b) { return as_array(b.IsTerminal(), {b.size()}); })
+      .def("current_player", [](const BatchedState& b) { return as_array(b.CurrentPlayer(), {b.size()}); })
+      .def("returns", [](const BatchedState& b) { return as_array(b.Returns(), {b.size(), b.GetGame()->NumPlayers()}); })
+      .def("observation_tensor",
+           [](const BatchedState& b, Player p) {
+             return as_array(b.ObservationTensor(p), {b.size(), b.GetGame()->ObservationTensorSize()});
+           },
+           py::arg("player"))
+      .def("information_state_tensor",
+           [](const BatchedState& b, Player p) {
+             return as_array(b.InformationStateTensor(p), {b.size(), b.GetGame()->InformationStateTensorSize()});
+           },
+           py::arg("player"))
+      .def("clone", [](const BatchedState& b) { return BatchedState(b); });
+
+  py::class_<Evaluator, std::shared_ptr<Evaluator>>(m, "Evaluator");  // bots.cc:106-111
+  py::class_<RandomRolloutEvaluator, Evaluator, std::shared_ptr<RandomRolloutEvaluator>>(m, "RandomRolloutEvaluator")
+      .def(py::init<int, int>(), py::arg("n_rollouts"), py::arg("seed"))
+      .def("evaluate", &RandomRolloutEvaluator::Evaluate, py::arg("state"))
+      .def("evaluate_batch",
+           [](RandomRolloutEvaluator& e, const BatchedState& b) {
+             return as_array(e.EvaluateBatch(b), {b.size(), b.GetGame()->NumPlayers()});
+           })
+      .def("prior", &RandomRolloutEvaluator::Prior, py::arg("state"));
+
+  py::class_<SearchNode>(m, "SearchNode")  // bots.cc:119-131
+      .def_readonly("action", &SearchNode::action)
+      .def_readonly("prior", &SearchNode::prior)
+      .def_readonly("player", &SearchNode::player)
+      .def_readonly("explore_count", &SearchNode::explore_count)
+      .def_readonly("total_reward", &SearchNode::total_reward)
+      .def_readonly("outcome", &SearchNode::outcome)
+      .def_readonly("children", &SearchNode::children)
+      .def("best_child", &SearchNode::BestChild);
+
+  py::class_<MCTSBot>(m, "MCTSBot")  // bots.cc:133-149
+      .def(py::init([](std::shared_ptr<Game> game, std::shared_ptr<Evaluator> evaluator, double uct_c,
+                       int max_simulations, int64_t max_memory_mb, bool solve, int seed, bool verbose) {
+             return new MCTSBot(*game, std::move(evaluator), uct_c, max_simulations, max_memory_mb, solve, seed, verbose);
+           }),
+           py::arg("game"), py::arg("evaluator"), py::arg("uct_c"), py::arg("max_simulations"),
+           py::arg("max_memory_mb"), py::arg("solve"), py::arg("seed"), py::arg("verbose"))
+      .def("step", &MCTSBot::Step, py::arg("state"), py::call_guard<py::gil_scoped_release>())
+      .def("mcts_search", &MCTSBot::MCTSearch, py::arg("state"), py::call_guard<py::gil_scoped_release>())
+      .def("step_batch", &MCTSBot::StepBatch, py::arg("states"), py::call_guard<py::gil_scoped_release>());
+
+  py::class_<TabularPolicy>(m, "TabularPolicy")
+      .def("policy_table", &TabularPolicy::policy_table)
+      .def("action_probabilities", &TabularPolicy::action_probabilities, py::arg("state"), py::arg("player"))
+      .def("action_probabilities", &TabularPolicy::action_probabilities_current, py::arg("state"))
+      .def("get_state_policy", &TabularPolicy::get_state_policy, py::arg("info_state"))
+      .def("get_state_policy_as_map", &TabularPolicy::get_state_policy_as_map, py::arg("info_state"));
+
+  py::class_<CFRInfoStateValues>(m, "CFRInfoStateValues")
+      .def_readonly("legal_actions", &CFRInfoStateValues::legal_actions)
+      .def_readonly("cumulative_regrets", &CFRInfoStateValues::cumulative_regrets)
+      .def_readonly("cumulative_policy", &CFRInfoStateValues::cumulative_policy)
+      .def_readonly("current_policy", &CFRInfoStateValues::current_policy);
+
+  py::class_<CFRSolverBase>(m, "CFRSolverBase")
+      .def("evaluate_and_update_policy", py::overload_cast<>(&CFRSolverBase::EvaluateAndUpdatePolicy))
+      .def("evaluate_and_update_policy", py::overload_cast<int>(&CFRSolverBase::EvaluateAndUpdatePolicy),
+           py::arg("iterations"))
+      .def("average_policy", [](const CFRSolverBase& s) { return TabularPolicy(s.TabularAveragePolicy()); })
+      .def("tabular_average_policy", [](const CFRSolverBase& s) { return TabularPolicy(s.TabularAveragePolicy()); })
+      .def("current_policy", [](const CFRSolverBase& s) { return TabularPolicy(s.TabularCurrentPolicy()); })
+      .def("info_state_values_table", &CFRSolverBase::InfoStateValuesTable);
+  py::class_<CFRSolver, CFRSolverBase>(m, "CFRSolver")  // policy.cc:224-262
+      .def(py::init([](std::shared_ptr<Game> g) { return new CFRSolver(*g); }), py::arg("game"));
+  py::class_<CFRPlusSolver, CFRSolverBase>(m, "CFRPlusSolver")
+      .def(py::init([](std::shared_ptr<Game> g) { return new CFRPlusSolver(*g); }), py::arg("game"));
+
+  py::enum_<AverageType>(m, "MCCFRAverageType").value("SIMPLE", AverageType::kSimple).value("FULL", AverageType::kFull);
+  py::class_<ExternalSamplingMCCFRSolver>(m, "ExternalSamplingMCCFRSolver")  // policy.cc:300-333
+      .def(py::init([](std::shared_ptr<Game> g, int seed, AverageType t) {
+             return new ExternalSamplingMCCFRSolver(*g, seed, t);
+           }),
+           py::arg("game"), py::arg("seed") = 0, py::arg("avg_type") = AverageType::kSimple)
+      .def("run_iteration", &ExternalSamplingMCCFRSolver::RunIteration)
+      .def("run_mini_batch", &ExternalSamplingMCCFRSolver::RunMiniBatch, py::arg("trajectories"))
+      .def("average_policy",
+           [](const ExternalSamplingMCCFRSolver& s) { return TabularPolicy(s.TabularAveragePolicy()); })
+      .def("info_state_values_table", &ExternalSamplingMCCFRSolver::InfoStateValuesTable);
+}

@@ -966,4 +966,24 @@ int osg_cfr_infostate_key(const osg_cfr* s, int64_t i, char* buf, int cap) {
 
 int osg_cfr_iteration(const osg_cfr* s) { return s ? s->iteration : 0; }
 
+int osg_information_state_string(const osg_batch* b, int64_t index, int player, char* buf, int cap) {
+  if (!b || !buf || cap <= 0 || index < 0 || index >= b->n)
+    return set_error(OSG_ERR_INVALID, "osg_information_state_string: bad argument");
+  const osg_game_desc& d = b->spec.desc;
+  if (d.game_kind != kKuhn && d.game_kind != kLeduc)
+    return set_error(OSG_ERR_INVALID, "this game provides no information state string");
+  if (player < 0 || player >= d.num_players) return set_error(OSG_ERR_INVALID, "player id out of range");
+  uint64_t w[2] = {0, 0};
+  const char* base = static_cast<const char*>(b->d_words);
+  for (int k = 0; k < d.state_words; ++k)
+    OSG_HIP(hipMemcpyAsync(&w[k], base + (static_cast<size_t>(k) * b->n + index) * sizeof(uint64_t), sizeof(uint64_t),
+                           hipMemcpyDeviceToHost, b->ctx->stream));
+  OSG_HIP(hipStreamSynchronize(b->ctx->stream));
+  const std::string key = d.game_kind == kKuhn ? kuhn_key(b->spec.kuhn, w[0], player)
+                                               : leduc_key(b->spec.leduc, w[0], w[1], player);
+  if (static_cast<int>(key.size()) + 1 > cap) return set_error(OSG_ERR_INVALID, "buffer too small");
+  memcpy(buf, key.c_str(), key.size() + 1);
+  return static_cast<int>(key.size());
+}
+
 }  // extern "C"

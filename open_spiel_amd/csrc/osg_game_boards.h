@@ -12,6 +12,16 @@
 
 namespace osg {
 
+// Default tensor walker: entry idx, idx + 1, ... through the game's obs_at.
+template <class G>
+struct GenericObsCursor {
+  int idx;
+  OSG_HD void init(const typename G::Params&, const typename G::State&, int, int, int idx0) { idx = idx0; }
+  OSG_HD float next(const typename G::Params& p, const typename G::State& s, int player, int which) {
+    return G::obs_at(p, s, player, which, idx++);
+  }
+};
+
 // ===========================================================================
 // tic_tac_toe.  HBM layout: ONE u32 per state, bits 0-8 = x stones (player 0,
 // kCross), bits 16-24 = o stones (player 1, kNought); cell = 3*row + col.
@@ -71,6 +81,7 @@ struct Ttt {
     uint32_t bits = plane == 0 ? ~(s.x | s.o) : (plane == 1 ? s.o : s.x);
     return static_cast<float>((bits >> cell) & 1u);
   }
+  using ObsCursor = GenericObsCursor<Ttt>;
 };
 
 // ===========================================================================
@@ -227,6 +238,35 @@ struct C4T {
     uint64_t bits = plane == 0 ? first : (plane == 1 ? second : ~(s.x | s.o));
     return static_cast<float>((bits >> bit) & 1ull);
   }
+  // Walks the tensor of one state entry by entry (same values as obs_at; plane / row / column are
+  // advanced incrementally instead of being re-derived by division for every float).
+  struct ObsCursor {
+    uint64_t first, second, empty;
+    int plane, r, c;
+    OSG_D void init(const Params& p, const State& s, int player, int /*which*/, int idx) {
+      const int RC = R(p) * C(p);
+      plane = idx / RC;
+      const int rem = idx - plane * RC;
+      r = rem / C(p);
+      c = rem - r * C(p);
+      first = s.x;
+      second = s.o;
+      if (p.ego) {
+        first = player == 0 ? s.o : s.x;
+        second = player == 0 ? s.x : s.o;
+      }
+      empty = ~(s.x | s.o);
+    }
+    OSG_D float next(const Params& p, const State&, int, int) {
+      const uint64_t bits = plane == 0 ? first : (plane == 1 ? second : empty);
+      const float v = static_cast<float>((bits >> (c * (R(p) + 1) + r)) & 1ull);
+      if (++c == C(p)) {
+        c = 0;
+        if (++r == R(p)) { r = 0; ++plane; }
+      }
+      return v;
+    }
+  };
 };
 using C4 = C4T<0, 0, 0>;     // any geometry with (rows+1)*cols <= 64
 using C4Std = C4T<6, 7, 4>;  // the default game, constants folded
@@ -467,6 +507,35 @@ struct HexT {
     int plane = idx / p.cells, cell = idx - plane * p.cells;
     return (label(s, cell) + 4) == plane ? 1.0f : 0.0f;
   }
+  // Cells whose label puts them on tensor plane `plane` (hex.cc:392-396: plane = label + 4).
+  OSG_D static Bits plane_mask(const Params& p, const State& s, int plane) {
+    const int l = plane - 4;
+    if (l == 0) return bandn(p.board, bor(s.black, s.white));
+    const Bits own = l > 0 ? s.black : s.white;
+    const int mag = l > 0 ? l : -l;  // 1 plain, 2 edge-B only, 3 edge-A only, 4 both
+    const Bits a = (mag == 3 || mag == 4) ? band(own, s.ea) : bandn(own, s.ea);
+    return (mag == 2 || mag == 4) ? band(a, s.eb) : bandn(a, s.eb);
+  }
+  struct ObsCursor {
+    Bits m;
+    int plane, cell, idx;
+    OSG_D void init(const Params& p, const State& s, int /*player*/, int /*which*/, int idx0) {
+      idx = idx0;
+      plane = idx0 / p.cells;
+      cell = idx0 - plane * p.cells;
+      m = p.plain_obs ? zero() : plane_mask(p, s, plane);
+    }
+    OSG_D float next(const Params& p, const State& s, int player, int which) {
+      if (p.plain_obs) return obs_at(p, s, player, which, idx++);
+      const float v = test(m, cell) ? 1.0f : 0.0f;
+      if (++cell == p.cells) {
+        cell = 0;
+        ++plane;
+        m = plane_mask(p, s, plane);
+      }
+      return v;
+    }
+  };
 };
 
 }  // namespace osg

@@ -6,6 +6,7 @@
 #define OSG_GAME_POKER_H_
 
 #include "osg_common.h"
+#include "osg_game_boards.h"  // GenericObsCursor
 
 namespace osg {
 
@@ -126,6 +127,7 @@ struct Kuhn {
     }
     return static_cast<float>(contribution(p, s, idx));
   }
+  using ObsCursor = GenericObsCursor<Kuhn>;
 };
 
 // ===========================================================================
@@ -380,6 +382,7 @@ struct Leduc {
     }
     return static_cast<float>(s.ante[idx]);
   }
+  using ObsCursor = GenericObsCursor<Leduc>;
 };
 
 }  // namespace osg

@@ -43,7 +43,9 @@ k_legal_mask(typename G::Params p, const typename G::word_t* base, int64_t n, ui
   int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i >= n) return;
   Mask m = G::legal(p, G::load(p, base, n, i));
-  for (int w = 0; w < mask_words; ++w) mask[i * mask_words + w] = m.w[w];
+#pragma unroll
+  for (int w = 0; w < kMaskWords; ++w)  // static indices only: a runtime index would spill the mask to scratch
+    if (w < mask_words) mask[i * mask_words + w] = m.w[w];
 }
 
 template <class G>
@@ -118,7 +120,9 @@ k_step(typename G::Params p, const typename G::word_t* src, typename G::word_t* 
   if (sizeof(MaskT) < 4) {
     mask_out[i] = static_cast<MaskT>(after.w[0]);
   } else {
-    for (int w = 0; w < mask_elems; ++w) mask_out[i * mask_elems + w] = static_cast<MaskT>(after.w[w]);
+#pragma unroll
+    for (int w = 0; w < kMaskWords; ++w)  // static indices only (see k_legal_mask)
+      if (w < mask_elems) mask_out[i * mask_elems + w] = static_cast<MaskT>(after.w[w]);
   }
   status[i] = encode_status(term, illegal, term ? 0 : G::current_player(p, s), term ? G::outcome_code(p, s) : 0);
 }
@@ -169,24 +173,88 @@ k_step_c4x2(typename G::Params p, const uint64_t* __restrict__ src, uint64_t* __
   *reinterpret_cast<uint16_t*>(status + i) = static_cast<uint16_t>(s2);
 }
 
-// Observation / information-state tensors: write-bound ([n, size] fp32).  One
-// thread per OUTPUT element so consecutive lanes write consecutive floats
-// (coalesced 256 B per wave); the few state words are re-read through L1/L2.
-template <class G>
+// Observation / information-state tensors: write-bound ([n, size] fp32, zero-filled
+// then set like ContiguousAllocator / TensorView do, observer.h:174-185).  A row is cut
+// into chunks of four floats; one lane produces one chunk — one state load, one cursor,
+// four entries, one 16-byte store (the last chunk of a row may be shorter) — so lanes never
+// straddle two states and the kernel has no divergent reloads.  Consecutive lanes write
+// consecutive addresses (1 KiB per wave-instruction).
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));  // rows are only 4-byte aligned
+template <class G, int F>  // F = floats per lane (a multiple of 4): 4 for short rows, 16 for long ones
 __global__ void __launch_bounds__(kBlock)
-k_observation(typename G::Params p, const typename G::word_t* base, int64_t n, int size, int player, int which,
-              float* out) {
-  int64_t e = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (e >= n * size) return;
-  int64_t i = e / size;
-  int idx = static_cast<int>(e - i * size);
-  typename G::State s = G::load(p, base, n, i);
+k_observation(typename G::Params p, const typename G::word_t* base, int64_t n, int size, int chunks, int player,
+              int which, float* out) {
+  // One 64-bit division per workgroup on wave-uniform values; lanes divide a small offset in 32 bits.
+  const int64_t tb = static_cast<int64_t>(blockIdx.x) * kBlock;
+  const int64_t ib = tb / chunks;
+  const uint32_t local = static_cast<uint32_t>(tb - ib * chunks) + threadIdx.x;
+  const uint32_t il = local / static_cast<uint32_t>(chunks);
+  const int64_t i = ib + il;
+  if (i >= n) return;
+  const int idx = static_cast<int>(local - il * static_cast<uint32_t>(chunks)) * F;
+  const typename G::State s = G::load(p, base, n, i);
   int pl = player;
   if (pl < 0) {
     pl = G::current_player(p, s);
     if (pl < 0) pl = 0;
   }
-  out[e] = G::obs_at(p, s, pl, which, idx);
+  typename G::ObsCursor cur;
+  cur.init(p, s, pl, which, idx);
+  const int count = size - idx;  // >= 1; only the last chunk of a row has fewer than F
+  float* dst = out + i * size + idx;
+#pragma unroll
+  for (int g = 0; g < F / 4; ++g) {
+    if (4 * g >= count) break;
+    float v[4];  // indexed by unrolled constants only: stays in registers
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (4 * g + k < count) ? cur.next(p, s, pl, which) : 0.0f;
+    if (4 * g + 4 <= count) {
+      float4u q = {v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<float4u*>(dst + 4 * g) = q;
+    } else {
+      dst[4 * g] = v[0];
+      if (4 * g + 1 < count) dst[4 * g + 1] = v[1];
+      if (4 * g + 2 < count) dst[4 * g + 2] = v[2];
+    }
+  }
+}
+
+// connect_four 6x7 fast path of the tensor pack: one lane per BOARD ROW of the tensor (3 planes x 6
+// rows per state, 7 floats each).  The seven cells of a row sit at bit stride 7 in the column-major
+// bitboard; one multiply gathers them (same identity as C4T::open_columns), then each float is a
+// bit-field extract.  Lane l writes floats [7l, 7l + 7) of the flat output, so a wavefront's stores
+// cover one contiguous 1792-byte span.
+typedef float float3u __attribute__((ext_vector_type(3), aligned(4)));
+__global__ void __launch_bounds__(kBlock)
+k_observation_c4std(C4Params p, const uint64_t* __restrict__ base, int64_t n, int player, float* __restrict__ out) {
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (row >= n * 18) return;
+  const int64_t i = row / 18;
+  const int rem = static_cast<int>(row - i * 18);
+  const int plane = rem / 6, r = rem - plane * 6;
+  const C4Std::State s = C4Std::unpack(base[i], base[n + i]);
+  uint64_t first = s.x, second = s.o;
+  if (p.ego) {  // PlayerRelative (connect_four.cc:299-310)
+    int pl = player;
+    if (pl < 0) {
+      pl = C4Std::current_player(p, s);
+      if (pl < 0) pl = 0;
+    }
+    first = pl == 0 ? s.o : s.x;
+    second = pl == 0 ? s.x : s.o;
+  }
+  const uint64_t bits = plane == 0 ? first : (plane == 1 ? second : ~(s.x | s.o));
+  const uint64_t stride7 = 1ull | (1ull << 7) | (1ull << 14) | (1ull << 21) | (1ull << 28) | (1ull << 35) | (1ull << 42);
+  const uint64_t M = (1ull << 36) | (1ull << 30) | (1ull << 24) | (1ull << 18) | (1ull << 12) | (1ull << 6) | 1ull;
+  const uint32_t g = static_cast<uint32_t>((((bits >> r) & stride7) * M) >> 36) & 0x7Fu;  // bit c = column c
+  float v[7];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) v[c] = static_cast<float>((g >> c) & 1u);
+  float* dst = out + row * 7;
+  float4u lo = {v[0], v[1], v[2], v[3]};
+  float3u hi = {v[4], v[5], v[6]};
+  *reinterpret_cast<float4u*>(dst) = lo;
+  *reinterpret_cast<float3u*>(dst + 4) = hi;
 }
 
 template <class G>
@@ -552,9 +620,20 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
     if (rc) return rc;
     d_out = static_cast<float*>(scratch);
   }
-  OSG_DISPATCH(b->spec, k_observation<G><<<dim3(grid_for(total)), dim3(kBlock), 0, ctx->stream>>>(P,
-                                            static_cast<const typename G::word_t*>(b->d_words), b->n, size, player,
-                                            which, d_out));
+  if (b->spec.desc.game_kind == kC4 && b->spec.c4_std) {
+    k_observation_c4std<<<dim3(grid_for(b->n * 18)), dim3(kBlock), 0, ctx->stream>>>(
+        b->spec.c4, static_cast<const uint64_t*>(b->d_words), b->n, player, d_out);
+  } else if (size >= 64) {  // long rows: 16 floats per lane amortise the per-lane setup
+    const int chunks = (size + 15) / 16;
+    OSG_DISPATCH(b->spec, k_observation<G, 16><<<dim3(grid_for(b->n * chunks)), dim3(kBlock), 0, ctx->stream>>>(P,
+                                              static_cast<const typename G::word_t*>(b->d_words), b->n, size, chunks,
+                                              player, which, d_out));
+  } else {
+    const int chunks = (size + 3) / 4;
+    OSG_DISPATCH(b->spec, k_observation<G, 4><<<dim3(grid_for(b->n * chunks)), dim3(kBlock), 0, ctx->stream>>>(P,
+                                              static_cast<const typename G::word_t*>(b->d_words), b->n, size, chunks,
+                                              player, which, d_out));
+  }
   OSG_HIP(hipGetLastError());
   if (on_host) {
     OSG_HIP(hipMemcpyAsync(out, d_out, sizeof(float) * total, hipMemcpyDeviceToHost, ctx->stream));

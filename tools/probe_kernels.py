@@ -1,0 +1,55 @@
+"""Per-kernel throughput table (HIP events on the context's stream): the individual State
+queries, the fused step of every game, tensor packing, random stepping and rollouts."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, open_spiel_amd as osa
+ctx = osa.Context(0)
+
+def timeit(fn, iters=200, warm=20):
+    for _ in range(warm): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+rows = []
+def report(name, secs, units, unit, nbytes=None):
+    r = {"kernel": name, "us": secs * 1e6, "rate": units / secs, "unit": unit}
+    if nbytes: r["GB/s"] = nbytes / secs / 1e9; r["frac_of_8TBs"] = nbytes / secs / 8e12
+    rows.append(r); print(json.dumps(r), flush=True)
+
+N = 1 << 20
+for game, depth in [("connect_four", 12), ("tic_tac_toe", 3), ("hex(board_size=9)", 30), ("kuhn_poker", 2), ("leduc_poker", 4)]:
+    b = osa.StateBatch(ctx, game, N); b.random_steps(3, depth)
+    d = b.desc
+    sb = d.state_words * d.state_word_bytes
+    dst = osa.StateBatch(ctx, game, N)
+    mask, status = b.step_buffers()
+    lm = b.legal_actions_mask()
+    acts = torch.where(lm.any(1), lm.to(torch.float32).argmax(1), torch.full((N,), 255, device="cuda")).to(torch.uint8)
+    s = timeit(lambda: b.step(acts, dst=dst, mask=mask, status=status))
+    report(f"k_step {game}", s, N, "env-steps/s", N * (2 * sb + 1 + d.compact_mask_bytes + 1))
+    bits = torch.empty((N, d.mask_words), dtype=torch.int32, device="cuda")
+    s = timeit(lambda: osa._abi.check(osa.lib().osg_legal_mask(b._h, bits.data_ptr(), 0)))
+    report(f"k_legal_mask {game}", s, N, "states/s", N * (sb + 4 * d.mask_words))
+    cur = torch.empty(N, dtype=torch.int8, device="cuda"); term = torch.empty(N, dtype=torch.uint8, device="cuda")
+    rets = torch.empty((N, d.num_players), dtype=torch.float64, device="cuda")
+    s = timeit(lambda: osa._abi.check(osa.lib().osg_status_query(b._h, cur.data_ptr(), term.data_ptr(), rets.data_ptr(), 0)))
+    report(f"k_status {game}", s, N, "states/s", N * (sb + 2 + 8 * d.num_players))
+    n_obs = N if d.obs_size <= 128 else N // 4
+    bo = b if n_obs == N else b.gather(torch.arange(n_obs))
+    out = torch.empty((n_obs, d.obs_size), dtype=torch.float32, device="cuda")
+    s = timeit(lambda: bo.observation_tensor(0, out=out), iters=50, warm=5)
+    report(f"k_observation {game} [{n_obs},{d.obs_size}]", s, n_obs, "states/s", n_obs * (sb + 4 * d.obs_size))
+    if d.info_size:
+        out = torch.empty((N, d.info_size), dtype=torch.float32, device="cuda")
+        s = timeit(lambda: b.information_state_tensor(0, out=out), iters=50, warm=5)
+        report(f"k_observation(info) {game} [{N},{d.info_size}]", s, N, "states/s", N * (sb + 4 * d.info_size))
+    c = torch.zeros(2, dtype=torch.int64, device="cuda")
+    s = timeit(lambda: b.random_steps(9, 32, counters=c), iters=20, warm=3)
+    report(f"k_random_steps {game} (32 steps/launch)", s, N * 32, "env-steps/s")
+    roots = osa.StateBatch(ctx, game, 1 << 16); roots.random_steps(5, depth)
+    s = timeit(lambda: roots.rollout(1, 16), iters=10, warm=2)
+    report(f"k_rollout {game} (2^16 roots x 16)", s, (1 << 16) * 16, "playouts/s")
+    del b, dst, roots

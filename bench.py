@@ -144,7 +144,7 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
     res = roots.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, seed=SEED, index_offset=first)
     fence()
     dt = max_over_ranks(time.perf_counter() - t0)
-    done = res["root_stats"][:, 3].sum()
+    done = res["root_stats"][:, 3].sum().reshape(1)
     if world > 1:
         dist.all_reduce(done)
     out["mcts"] = {"metric": "MCTS sims/sec", "value": float(done.item()) / dt, "unit": "sims/s", "seconds": dt,
@@ -284,7 +284,8 @@ def main():
     secondary = None
     if not args.no_secondary:
         del src, dst
-        secondary = secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu=not args.no_cpu_baseline)
+        secondary = secondary_workloads(osa, torch, dist, ctx, rank, world,
+                                        with_cpu=(not args.no_cpu_baseline) and world == 1)
 
     if rank == 0:
         traffic, traffic_source = pmc_traffic()

@@ -70,6 +70,22 @@ OSG_D Cand wave_argmax(Cand c) {
   }
   return c;
 }
+OSG_D double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double o = __shfl_xor(v, off);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+OSG_D uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint64_t o = __shfl_xor(v, off);
+    v = o < v ? o : v;
+  }
+  return v;
+}
 OSG_D double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
@@ -238,22 +254,38 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
         chosen_k = below;
       } else {  // arg-max of UCTValue (mcts.cc:90-101), ties to the smallest order key
         const double logn = log_table[cnt];
-        Cand best{-INFINITY, ~0ull, 0};
-        for (int k = lane; k < c; k += 64) {
-          const uint32_t cm = META[first + k];
-          const uint32_t cc = COUNT[first + k];
-          const double ct = TOTAL[first + k];
-          double v;
-          if (m_has_outcome(cm)) v = outcome_value<kBoard>(cm, cc, ct, m_player(cm));
-          else if (cc == 0) v = INFINITY;
-          else v = ct / cc + cfg.uct_c * sqrt(logn / cc);
-          Cand me{v, order_key(obase, ph, static_cast<int>(m_action(cm))), k};
-          if (better(me, best)) best = me;
+        double v2[2];
+        uint32_t a2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int k = lane + 64 * j;
+          v2[j] = -INFINITY;
+          a2[j] = 0;
+          if (k < c) {
+            const uint32_t cm = META[first + k];
+            const uint32_t cc = COUNT[first + k];
+            const double ct = TOTAL[first + k];
+            a2[j] = m_action(cm);
+            if (m_has_outcome(cm)) v2[j] = outcome_value<kBoard>(cm, cc, ct, m_player(cm));
+            else if (cc == 0) v2[j] = INFINITY;
+            else v2[j] = ct / cc + cfg.uct_c * sqrt(logn / cc);
+          }
         }
-        best = wave_argmax(best);
-        chosen_k = uniform(best.k);
-        action = static_cast<int>(best.key & 0xFFull);
-        action = uniform(action);
+        // Phase 1: the maximum VALUE only (2 dwords per butterfly step).
+        const double vmax = wave_max(v2[0] > v2[1] ? v2[0] : v2[1]);
+        const bool t0 = lane < c && v2[0] == vmax, t1 = lane + 64 < c && v2[1] == vmax;
+        const uint64_t b0 = __ballot(t0), b1 = __ballot(t1);
+        if (__builtin_popcountll(b0) + __builtin_popcountll(b1) == 1) {
+          chosen_k = b0 ? __builtin_ctzll(b0) : 64 + __builtin_ctzll(b1);
+        } else {  // Phase 2 (ties, e.g. several unvisited children): the smallest order key among the tied
+          const uint64_t k0 = t0 ? order_key(obase, ph, static_cast<int>(a2[0])) : ~0ull;
+          const uint64_t k1 = t1 ? order_key(obase, ph, static_cast<int>(a2[1])) : ~0ull;
+          const uint64_t kmin = wave_min_u64(k0 < k1 ? k0 : k1);
+          const uint64_t w0 = __ballot(t0 && k0 == kmin), w1 = __ballot(t1 && k1 == kmin);
+          chosen_k = w0 ? __builtin_ctzll(w0) : 64 + __builtin_ctzll(w1);
+        }
+        chosen_k = uniform(chosen_k);
+        action = static_cast<int>(m_action(uniform(META[first + chosen_k])));
       }
       G::apply(p, s, action);
       node = first + static_cast<uint32_t>(chosen_k);

@@ -26,6 +26,7 @@ if len(sys.argv) > 1:
               int(sys.argv[5]) if len(sys.argv) > 5 else 0)]
 for game, n, sims, max_nodes, layout in cases:
     b = roots_for(game, n, 40 if "hex" in game else (20 if "connect" in game else 4))
+    b.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, seed=2, max_nodes=max_nodes, layout=layout)  # sizes the pool
     torch.cuda.synchronize(); t = time.time()
     r = b.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, seed=1, max_nodes=max_nodes, layout=layout)
     torch.cuda.synchronize(); dt = time.time() - t

@@ -238,12 +238,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
+    # OSG_DIST_BACKEND=gloo lets the N>1 code path run on a box with fewer GPUs than ranks (ranks
+    # share devices, collectives go through the host): a test hook, never the measured configuration.
+    backend = os.environ.get("OSG_DIST_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
-    ctx = osa.Context(local_rank)
+    ctx = osa.Context(device_index)
     n = args.states
     src, actions = synth_batch(osa, torch, ctx, n, SEED, rank * n)
     dst = osa.StateBatch(ctx, "connect_four", n)
@@ -296,7 +303,7 @@ def main():
             "metric": "env-steps/sec (batched LegalActions+ApplyAction+status, connect_four)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic", "collective_backend": backend if world > 1 else None,
             "config": {"workload": f"connect_four fused step, {n} states/GPU (2^{n.bit_length() - 1}), "
                                    "out-of-place SoA bitboards, seed 0x5EED",
                        "states_per_gpu": n, "parallelism": f"{world} independent shard(s), no collective"},

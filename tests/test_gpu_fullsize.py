@@ -196,3 +196,22 @@ def test_hex9_2pow16_roots_rollouts(ctx):
     assert (total[:, 0] == -total[:, 1]).all()
     assert (np.abs(total[:, 0]) % 2 == n_rollouts % 2).all(), "no draws in hex"
     assert (steps >= n_rollouts * 1).all() and (steps <= n_rollouts * 81).all()
+
+
+def test_bench_two_ranks_code_path(tmp_path):
+    """bench.py's N=2 path end to end (sharded roots / trajectories, delta all-reduce, max-over-ranks
+    timing) with two ranks sharing this box's GPU over gloo — the RCCL run itself is the driver's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OSG_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "50",
+           "--warmup", "5", "--no-cpu-baseline", "--states", str(1 << 16)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["secondary"]["mcts"]["value"] > 0 and line["secondary"]["mccfr"]["tables_finite"]

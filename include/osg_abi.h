@@ -250,6 +250,14 @@ int osg_cfr_upload_tables(osg_cfr* s, const double* h_regrets, const double* h_c
  * nact[I], legal[I, Amax] (padding -1), avg_policy per cfr.cc:104-125. Any may be NULL. */
 int osg_cfr_tables(const osg_cfr* s, int32_t* nact, int32_t* legal, double* regrets,
                    double* cum_policy, double* cur_policy, double* avg_policy);
+/* Policy evaluation on the flattened tree: algorithms::ExpectedReturns (expected_returns.cc:34-130),
+ * TabularBestResponse values for every player (best_response.cc:194-227), NashConv and
+ * Exploitability (tabular_exploitability.cc:30-89).  which_policy: 0 the tables' average policy
+ * (cfr.cc:104-125), 1 their current policy, 2 the [I, Amax] host table h_policy (rows in the
+ * solver's infostate order, osg_cfr_infostate_key).  expected_returns / best_response_values are
+ * [P]; any output may be NULL. */
+int osg_cfr_evaluate_policy(osg_cfr* s, int which_policy, const double* h_policy, double* expected_returns,
+                            double* best_response_values, double* nash_conv, double* exploitability);
 /* InformationStateString() of infostate i (kuhn_poker.cc:109-166, leduc_poker.cc:198-239).
  * Returns the length (excluding NUL), or <0. */
 int osg_cfr_infostate_key(const osg_cfr* s, int64_t i, char* buf, int cap);

@@ -109,6 +109,7 @@ SIGNATURES = {
     "osg_mccfr_delta_ptrs": (INT, [VP, C.POINTER(VP), C.POINTER(VP)]),
     "osg_mccfr_apply_deltas": (INT, [VP]),
     "osg_cfr_tables": (INT, [VP, VP, VP, VP, VP, VP, VP]),
+    "osg_cfr_evaluate_policy": (INT, [VP, INT, VP, VP, VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "osg_cfr_infostate_key": (INT, [VP, I64, C.c_char_p, INT]),
 }
 

@@ -83,6 +83,10 @@ static void KuhnCfr() {
   EXPECT(std::fabs(avg.at("2")[1].second - 3 * alpha) < 0.06);
   CFRInfoStateValuesTable table = solver.InfoStateValuesTable();
   EXPECT(table.at("1pb").legal_actions == (std::vector<Action>{0, 1}));
+  // examples/cfr_example.cc:41-45: exploitability of the average policy (cfr_test.cc:49-51: <= 0.05, value -1/18)
+  EXPECT(Exploitability(*game, avg) <= 0.05);
+  EXPECT(std::fabs(ExpectedReturns(*game, avg)[0] + 1.0 / 18) <= 1e-3);
+  EXPECT(std::fabs(solver.EvaluatePolicy(0).nash_conv - NashConv(*game, avg)) < 1e-12);
   CFRPlusSolver plus(*game);
   plus.EvaluateAndUpdatePolicy(200);
   EXPECT(plus.TabularAveragePolicy().at("2pb")[1].second > 0.99);

@@ -432,6 +432,33 @@ class DeviceTabularSolver {
   }
   TabularPolicyTable TabularAveragePolicy() const { return Policy(true); }  // cfr.h:205-211
   TabularPolicyTable TabularCurrentPolicy() const { return Policy(false); }
+  // Device policy evaluation: {expected returns [P], best-response values [P], NashConv, Exploitability}
+  // of the tables' average (0) / current (1) policy, or of `table` (which == 2; keyed by infostate string).
+  struct Evaluation {
+    std::vector<double> expected_returns, best_response_values;
+    double nash_conv = 0, exploitability = 0;
+  };
+  Evaluation EvaluatePolicy(int which, const TabularPolicyTable* table = nullptr) const {
+    Evaluation ev;
+    ev.expected_returns.resize(num_players_);
+    ev.best_response_values.resize(num_players_);
+    std::vector<double> dense;
+    if (which == 2) {
+      if (!table) SpielFatalError("EvaluatePolicy: no table");
+      Tables t = Download();
+      dense.assign(static_cast<size_t>(t.I) * t.A, 0.0);
+      for (int i = 0; i < t.I; ++i) {
+        auto it = table->find(Key(i));
+        if (it == table->end()) SpielFatalError(Key(i) + " not found in policy.");
+        for (int a = 0; a < t.nact[i]; ++a)
+          for (const auto& ap : it->second)
+            if (ap.first == t.legal[i * t.A + a]) dense[i * t.A + a] = ap.second;
+      }
+    }
+    Check(osg_cfr_evaluate_policy(s_, which, dense.empty() ? nullptr : dense.data(), ev.expected_returns.data(),
+                                  ev.best_response_values.data(), &ev.nash_conv, &ev.exploitability));
+    return ev;
+  }
   int64_t NumInfoStates() const { return sizes_[4]; }
   int64_t NumHistories() const { return sizes_[0]; }
   osg_cfr* handle() const { return s_; }
@@ -495,6 +522,18 @@ class CFRPlusSolver : public CFRSolverBase {  // cfr.h:341-357
  public:
   explicit CFRPlusSolver(const Game& game) : CFRSolverBase(game, true, true, true) {}
 };
+
+// algorithms::Exploitability / NashConv / ExpectedReturns of a tabular policy
+// (tabular_exploitability.h, expected_returns.h), evaluated on the device.
+inline double Exploitability(const Game& game, const TabularPolicyTable& policy) {
+  return CFRSolver(game).EvaluatePolicy(2, &policy).exploitability;
+}
+inline double NashConv(const Game& game, const TabularPolicyTable& policy) {
+  return CFRSolver(game).EvaluatePolicy(2, &policy).nash_conv;
+}
+inline std::vector<double> ExpectedReturns(const Game& game, const TabularPolicyTable& policy) {
+  return CFRSolver(game).EvaluatePolicy(2, &policy).expected_returns;
+}
 
 enum class AverageType { kSimple, kFull };
 class ExternalSamplingMCCFRSolver : public DeviceTabularSolver {  // external_sampling_mccfr.h:57-113

@@ -186,6 +186,14 @@ PYBIND11_MODULE(pyspiel_hip, m) {
   py::class_<CFRPlusSolver, CFRSolverBase>(m, "CFRPlusSolver")
       .def(py::init([](std::shared_ptr<Game> g) { return new CFRPlusSolver(*g); }), py::arg("game"));
 
+  // pyspiel.exploitability / nash_conv / expected_returns (python/pybind11/policy.cc) for tabular policies
+  m.def("exploitability", [](std::shared_ptr<Game> g, const TabularPolicy& p) { return Exploitability(*g, p.policy_table()); },
+        py::arg("game"), py::arg("policy"));
+  m.def("nash_conv", [](std::shared_ptr<Game> g, const TabularPolicy& p) { return NashConv(*g, p.policy_table()); },
+        py::arg("game"), py::arg("policy"));
+  m.def("expected_returns", [](std::shared_ptr<Game> g, const TabularPolicy& p) { return ExpectedReturns(*g, p.policy_table()); },
+        py::arg("game"), py::arg("policy"));
+
   py::enum_<AverageType>(m, "MCCFRAverageType").value("SIMPLE", AverageType::kSimple).value("FULL", AverageType::kFull);
   py::class_<ExternalSamplingMCCFRSolver>(m, "ExternalSamplingMCCFRSolver")  // policy.cc:300-333
       .def(py::init([](std::shared_ptr<Game> g, int seed, AverageType t) {

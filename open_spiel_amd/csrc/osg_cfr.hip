@@ -360,6 +360,115 @@ k_cfr_small(Tree t, SmallTree st, Tables tb, int iters, int iteration0, osg_cfr_
 }
 
 // ---------------------------------------------------------------------------
+// Policy evaluation on the flattened tree: ExpectedReturns
+// (expected_returns.cc:34-130), TabularBestResponse (best_response.cc:194-227)
+// for every player, from which the host derives NashConv / Exploitability
+// (tabular_exploitability.cc:30-89).  One workgroup, level-synchronous:
+//   values    bottom-up with the evaluated policy -> ev[P]
+//   per responder r:
+//     cf[m]   counterfactual reach of every decision history of r: product of the
+//             chance / opponent-policy probabilities on its root path (root-to-leaf)
+//     levels bottom-up; at a level first every infostate of r whose members sit on
+//     that level picks argmax_a sum_m cf[m] * brv[child(m, a)] (members in DFS
+//     order, strict >: ties go to the lowest action), then the level's nodes get
+//     their value (responder nodes: the chosen child's value).
+// ---------------------------------------------------------------------------
+struct EvalArrays {
+  const int32_t* path_off;   // [M+1]
+  const int32_t* path;
+  const int32_t* info_level; // [I] tree level of the infostate's member histories
+  const int32_t* mem_index;  // [H] member position m of a decision history, else -1
+  int M;
+  double* value;             // [H, P] scratch
+  double* brv;               // [H] scratch
+  double* cf;                // [M] scratch
+  int32_t* best;             // [I] scratch: chosen action index
+  double* out;               // [2P]: ev[P] then br[P]
+};
+
+__global__ void __launch_bounds__(1024)
+k_policy_eval(Tree t, EvalArrays ea, const double* __restrict__ pol) {
+  const int P = t.P, A = t.A;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // ---- expected returns ----
+  for (int l = t.D - 1; l >= 0; --l) {
+    for (int h = t.level_off[l] + tid; h < t.level_off[l + 1]; h += nt) {
+      const int k = t.kind[h];
+      if (k == kTerminalNode) {
+        for (int q = 0; q < P; ++q) ea.value[h * P + q] = t.term_ret[h * P + q];
+        continue;
+      }
+      const int fc = t.first_child[h], nc = t.nchild[h];
+      const int row = k == kDecisionNode ? t.info[h] * A : 0;
+      for (int q = 0; q < P; ++q) {
+        double v = 0.0;
+        for (int a = 0; a < nc; ++a) {
+          const double pr = k == kChanceNode ? t.edge_prob[fc + a] : pol[row + a];
+          if (pr > 0.0) v += pr * ea.value[(fc + a) * P + q];
+        }
+        ea.value[h * P + q] = v;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < P) ea.out[tid] = ea.value[tid];
+  // ---- best response of every player ----
+  for (int r = 0; r < P; ++r) {
+    for (int m = tid; m < ea.M; m += nt) {
+      const int h = t.mem[m];
+      if (t.actor[h] != r) continue;
+      double cf = 1.0;
+      for (int e = ea.path_off[m]; e < ea.path_off[m + 1]; ++e) {
+        const int code = ea.path[e];
+        const int slot = (code >> 24) & 0xF, idx = code & 0x7FFFFF;
+        const double pr = ((code >> 23) & 1) ? t.edge_prob[idx] : (slot == r ? 1.0 : pol[idx]);
+        cf = cf * pr;
+      }
+      ea.cf[m] = cf;
+    }
+    __syncthreads();
+    for (int l = t.D - 1; l >= 0; --l) {
+      for (int i = tid; i < t.I; i += nt) {
+        if (t.info_player[i] != r || ea.info_level[i] != l) continue;
+        const int n = t.nact[i];
+        int best = -1;
+        double best_v = -1.7976931348623157e308;  // numeric_limits<double>::lowest()
+        for (int a = 0; a < n; ++a) {
+          double v = 0.0;
+          for (int m = t.mem_off[i]; m < t.mem_off[i + 1]; ++m)
+            v += ea.cf[m] * ea.brv[t.first_child[t.mem[m]] + a];
+          if (v > best_v) { best_v = v; best = a; }
+        }
+        ea.best[i] = best < 0 ? 0 : best;
+      }
+      __syncthreads();
+      for (int h = t.level_off[l] + tid; h < t.level_off[l + 1]; h += nt) {
+        const int k = t.kind[h];
+        double v = 0.0;
+        if (k == kTerminalNode) {
+          v = t.term_ret[h * P + r];
+        } else {
+          const int fc = t.first_child[h], nc = t.nchild[h];
+          if (k == kDecisionNode && t.actor[h] == r) {
+            v += 1.0 * ea.brv[fc + ea.best[t.info[h]]];
+          } else {
+            const int row = k == kDecisionNode ? t.info[h] * A : 0;
+            for (int a = 0; a < nc; ++a) {
+              const double pr = k == kChanceNode ? t.edge_prob[fc + a] : pol[row + a];
+              v += pr * ea.brv[fc + a];
+            }
+          }
+        }
+        ea.brv[h] = v;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) ea.out[P + r] = ea.brv[0];
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // ExternalSamplingMCCFRSolver::UpdateRegrets (external_sampling_mccfr.cc:122-186),
 // AverageType::kSimple, one traversal per thread, tables frozen for the launch.
 // ---------------------------------------------------------------------------
@@ -552,6 +661,11 @@ struct osg_cfr {
   int32_t *d_path_off = nullptr, *d_path = nullptr;
   bool small_tree = false;
   size_t small_lds_bytes = 0;
+  // policy evaluation (k_policy_eval)
+  std::vector<int32_t> info_level, mem_index;
+  bool eval_ok = true;  // every infostate's members sit on one tree level
+  int32_t *d_info_level = nullptr, *d_mem_index = nullptr, *d_best = nullptr;
+  double *d_eval = nullptr;  // value [H,P] | brv [H] | cf [M] | out [2P] | policy [I,A]
 
   Tree tree() const {
     Tree t;
@@ -714,6 +828,20 @@ int build_tree(osg_cfr* s, const char* game_string) {
     s->mem.insert(s->mem.end(), members[i].begin(), members[i].end());
     s->mem_off.push_back(static_cast<int32_t>(s->mem.size()));
   }
+  {  // tree level of every history; infostates must not span levels for the level-synchronous best response
+    std::vector<int32_t> level_of(s->H, 0);
+    for (int l = 0; l < s->D; ++l)
+      for (int h = s->level_off[l]; h < s->level_off[l + 1]; ++h) level_of[h] = l;
+    s->info_level.assign(s->I, -1);
+    s->mem_index.assign(s->H, -1);
+    for (int i = 0; i < s->I; ++i)
+      for (int m = s->mem_off[i]; m < s->mem_off[i + 1]; ++m) {
+        const int h = s->mem[m];
+        s->mem_index[h] = m;
+        if (s->info_level[i] < 0) s->info_level[i] = level_of[h];
+        else if (s->info_level[i] != level_of[h]) s->eval_ok = false;
+      }
+  }
   // Root path of every decision history, root-to-leaf: one entry per ancestor edge =
   // (reach slot of the ancestor's actor, where to read the edge probability).
   s->path_off.push_back(0);
@@ -798,11 +926,17 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
     s->small_lds_bytes = doubles * 8 + ints * 4;
     const bool index_fits = static_cast<size_t>(s->H) < (1u << 23) && IA < (1u << 23);
     s->small_tree = index_fits && s->small_lds_bytes <= 64 * 1024 && s->P <= kMaxPlayers;
+    if ((rc = upload(s->path_off, &s->d_path_off, st)) || (rc = upload(s->path, &s->d_path, st)) ||
+        (rc = upload(s->info_level, &s->d_info_level, st)) || (rc = upload(s->mem_index, &s->d_mem_index, st))) {
+      osg_cfr_destroy(s);
+      return rc;
+    }
+    const size_t eval_doubles = static_cast<size_t>(s->H) * (s->P + 1) + M + 2 * s->P + IA;
+    e = hipMalloc(reinterpret_cast<void**>(&s->d_eval), sizeof(double) * eval_doubles);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_best), sizeof(int32_t) * std::max(s->I, 1));
+    if (e != hipSuccess) { osg_cfr_destroy(s); return set_error(OSG_ERR_NOMEM, hipGetErrorString(e)); }
+    if (!index_fits) s->eval_ok = false;
     if (s->small_tree) {
-      if ((rc = upload(s->path_off, &s->d_path_off, st)) || (rc = upload(s->path, &s->d_path, st))) {
-        osg_cfr_destroy(s);
-        return rc;
-      }
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cfr_small), hipFuncAttributeMaxDynamicSharedMemorySize,
                               static_cast<int>(s->small_lds_bytes));
       if (e != hipSuccess) { (void)hipGetLastError(); s->small_tree = false; }
@@ -819,7 +953,8 @@ int osg_cfr_destroy(osg_cfr* s) {
   (void)hipStreamSynchronize(s->ctx->stream);
   void* ptrs[] = {s->d_level_off, s->d_parent, s->d_first_child, s->d_info, s->d_mem_off, s->d_mem, s->d_nact,
                   s->d_kind, s->d_nchild, s->d_aidx, s->d_actor, s->d_info_player, s->d_edge_prob, s->d_term_ret,
-                  s->d_tables, s->d_reach, s->d_value, s->d_path_off, s->d_path};
+                  s->d_tables, s->d_reach, s->d_value, s->d_path_off, s->d_path, s->d_info_level, s->d_mem_index,
+                  s->d_best, s->d_eval};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete s;
@@ -965,6 +1100,57 @@ int osg_cfr_infostate_key(const osg_cfr* s, int64_t i, char* buf, int cap) {
 }
 
 int osg_cfr_iteration(const osg_cfr* s) { return s ? s->iteration : 0; }
+
+int osg_cfr_evaluate_policy(osg_cfr* s, int which_policy, const double* h_policy, double* expected_returns,
+                            double* best_response_values, double* nash_conv, double* exploitability) {
+  if (!s) return set_error(OSG_ERR_INVALID, "osg_cfr_evaluate_policy: null solver");
+  if (!s->eval_ok) return set_error(OSG_ERR_UNSUPPORTED, "an information state spans several tree levels");
+  const size_t IA = static_cast<size_t>(s->I) * s->A, M = s->mem.size();
+  const int P = s->P;
+  hipStream_t st = s->ctx->stream;
+  std::vector<double> pol(IA, 0.0);
+  if (which_policy == 2) {
+    if (!h_policy) return set_error(OSG_ERR_INVALID, "osg_cfr_evaluate_policy: which_policy == 2 needs h_policy");
+    std::copy(h_policy, h_policy + IA, pol.begin());
+  } else if (which_policy == 0 || which_policy == 1) {
+    std::vector<double> avg(IA);
+    int rc = which_policy == 0 ? osg_cfr_tables(s, nullptr, nullptr, nullptr, nullptr, nullptr, avg.data())
+                               : osg_cfr_tables(s, nullptr, nullptr, nullptr, nullptr, avg.data(), nullptr);
+    if (rc) return rc;
+    pol.swap(avg);
+  } else {
+    return set_error(OSG_ERR_INVALID, "osg_cfr_evaluate_policy: which_policy must be 0, 1 or 2");
+  }
+  EvalArrays ea;
+  ea.path_off = s->d_path_off; ea.path = s->d_path; ea.info_level = s->d_info_level; ea.mem_index = s->d_mem_index;
+  ea.M = static_cast<int>(M);
+  ea.value = s->d_eval;
+  ea.brv = ea.value + static_cast<size_t>(s->H) * P;
+  ea.cf = ea.brv + s->H;
+  ea.out = ea.cf + M;
+  double* d_pol = ea.out + 2 * P;
+  ea.best = s->d_best;
+  OSG_HIP(hipMemcpyAsync(d_pol, pol.data(), sizeof(double) * IA, hipMemcpyHostToDevice, st));
+  int threads = ((s->max_level_width + 63) / 64) * 64;
+  threads = std::max(64, std::min(threads, 1024));
+  k_policy_eval<<<dim3(1), dim3(threads), 0, st>>>(s->tree(), ea, d_pol);
+  OSG_HIP(hipGetLastError());
+  std::vector<double> out(2 * P);
+  OSG_HIP(hipMemcpyAsync(out.data(), ea.out, sizeof(double) * 2 * P, hipMemcpyDeviceToHost, st));
+  OSG_HIP(hipStreamSynchronize(st));
+  double nc = 0.0, total_br = 0.0;
+  for (int p = 0; p < P; ++p) {
+    if (expected_returns) expected_returns[p] = out[p];
+    if (best_response_values) best_response_values[p] = out[P + p];
+    nc += out[P + p] - out[p];   // NashConv (tabular_exploitability.cc:60-89)
+    total_br += out[P + p];
+  }
+  if (nash_conv) *nash_conv = nc;
+  // Exploitability = (sum of best-response values - UtilitySum) / P (tabular_exploitability.cc:30-47);
+  // kuhn_poker and leduc_poker are zero-sum: UtilitySum() == 0.
+  if (exploitability) *exploitability = total_br / P;
+  return OSG_OK;
+}
 
 int osg_information_state_string(const osg_batch* b, int64_t index, int player, char* buf, int cap) {
   if (!b || !buf || cap <= 0 || index < 0 || index >= b->n)

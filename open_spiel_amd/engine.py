@@ -374,6 +374,29 @@ class TabularSolver:
         out.update(keys=keys, nact=nact, legal=legal)
         return out
 
+    def evaluate_policy(self, which="average", table=None):
+        """NashConv / exploitability / expected returns / best-response values of a policy on the
+        device (algorithms::NashConv, Exploitability, ExpectedReturns, TabularBestResponse).
+        which: "average" | "current" | "table" (then `table` is an [I, Amax] array in this
+        solver's infostate order)."""
+        code = {"average": 0, "current": 1, "table": 2}[which]
+        P = _abi.describe(self.game_string).num_players
+        ev, br = np.zeros(P), np.zeros(P)
+        nc, ex = C.c_double(0), C.c_double(0)
+        tab = None
+        if code == 2:
+            tab = np.ascontiguousarray(table, np.float64)
+            assert tab.shape == (self.num_infostates, self.amax)
+        check(lib().osg_cfr_evaluate_policy(self._h, code, None if tab is None else tab.ctypes.data,
+                                            ev.ctypes.data, br.ctypes.data, C.byref(nc), C.byref(ex)))
+        return dict(nash_conv=nc.value, exploitability=ex.value, expected_returns=ev, best_response_values=br)
+
+    def nash_conv(self):
+        return self.evaluate_policy()["nash_conv"]
+
+    def exploitability(self):
+        return self.evaluate_policy()["exploitability"]
+
     def average_policy(self):
         t = self.tables()
         return {k: [(int(t["legal"][i, a]), float(t["avg_policy"][i, a])) for a in range(t["nact"][i])]

@@ -219,3 +219,59 @@ def test_cfr_rejects_board_games(ctx):
     import open_spiel_amd as osa
     with pytest.raises(osa.OsgError):
         osa.TabularSolver(ctx, "tic_tac_toe")
+
+
+# ---- policy evaluation on the device (SURVEY.md 8f row 1) ------------------------------------------
+def _named_policy_table(solver, kind, alpha=0.0):
+    """[I, Amax] table in the solver's infostate order: uniform / first-action / kuhn optimal."""
+    t = solver.tables()
+    I, A = solver.num_infostates, solver.amax
+    tab = np.zeros((I, A))
+    opt = {"0": [1 - alpha, alpha], "0pb": [1, 0], "1": [1, 0], "1pb": [2 / 3 - alpha, 1 / 3 + alpha],
+           "2": [1 - 3 * alpha, 3 * alpha], "2pb": [0, 1], "0p": [2 / 3, 1 / 3], "0b": [1, 0], "1p": [1, 0],
+           "1b": [2 / 3, 1 / 3], "2p": [0, 1], "2b": [0, 1]}  # kuhn_poker.cc:451-474
+    for i, k in enumerate(t["keys"]):
+        n = int(t["nact"][i])
+        if kind == "uniform":
+            tab[i, :n] = 1.0 / n
+        elif kind == "first":
+            tab[i, 0] = 1.0
+        else:
+            tab[i, :n] = opt[k]
+    return tab
+
+
+def test_policy_evaluation_known_answers(ctx):
+    """tabular_exploitability_test.cc:470-499: uniform-policy exploitability kuhn 0.4583333333333335,
+    leduc 2.373611111111111; NashConv 0.916666666666667 / 4.747222222222222; first-action policy
+    NashConv 2 on kuhn; Kuhn optimal(alpha = 0.2) is unexploitable."""
+    import open_spiel_amd as osa
+    k = osa.TabularSolver(ctx, "kuhn_poker")
+    r = k.evaluate_policy("table", _named_policy_table(k, "uniform"))
+    assert abs(r["exploitability"] - 0.4583333333333335) < 1e-14
+    assert abs(r["nash_conv"] - 0.916666666666667) < 1e-14
+    assert abs(k.evaluate_policy("average")["nash_conv"] - 0.916666666666667) < 1e-14  # untouched tables: uniform
+    assert abs(k.evaluate_policy("table", _named_policy_table(k, "first"))["nash_conv"] - 2.0) < 1e-14
+    r = k.evaluate_policy("table", _named_policy_table(k, "optimal", 0.2))
+    assert abs(r["nash_conv"]) < 1e-14 and abs(r["expected_returns"][0] + 1 / 18) < 1e-14
+    l = osa.TabularSolver(ctx, "leduc_poker")
+    r = l.evaluate_policy("table", _named_policy_table(l, "uniform"))
+    assert abs(r["exploitability"] - 2.373611111111111) < 1e-13
+    assert abs(r["nash_conv"] - 4.747222222222222) < 1e-13
+
+
+@pytest.mark.parametrize("game,iters", [("kuhn_poker", 37), ("leduc_poker", 6), ("kuhn_poker(players=3)", 9)])
+def test_policy_evaluation_matches_the_oracle_judge(oracle, ctx, game, iters):
+    import open_spiel_amd as osa
+    s = osa.TabularSolver(ctx, game)
+    s.evaluate_and_update_policy(iters)
+    og = oracle.Game(game)
+    t = s.tables()
+    for which, table in (("average", t["avg_policy"]), ("current", t["cur_policy"])):
+        got = s.evaluate_policy(which)
+        nc, ev = og.eval_policy(t["keys"], t["nact"], t["legal"].astype(np.int64), table, which=0)
+        ex, _ = og.eval_policy(t["keys"], t["nact"], t["legal"].astype(np.int64), table, which=1)
+        assert abs(got["nash_conv"] - nc) <= 1e-12, (game, which)
+        assert abs(got["exploitability"] - ex) <= 1e-12
+        np.testing.assert_allclose(got["expected_returns"], ev, rtol=0, atol=1e-13)
+    assert s.nash_conv() == s.evaluate_policy("average")["nash_conv"]

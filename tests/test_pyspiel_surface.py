@@ -106,6 +106,9 @@ def test_cfr_solver_like_cfr_example(pyspiel, oracle):
     probs = np.array([[p for _, p in table[k]] for k in keys], np.float64)
     expl, ev = oracle.Game("kuhn_poker").eval_policy(keys, nact, acts, probs, which=1)
     assert expl <= 0.05 and abs(ev[0] + 1 / 18) < 1e-3
+    assert abs(pyspiel.exploitability(game, policy) - expl) < 1e-12          # device judge == oracle judge
+    assert abs(pyspiel.expected_returns(game, policy)[0] - ev[0]) < 1e-12
+    assert pyspiel.nash_conv(game, policy) >= 0
     state = game.new_initial_state()
     state.apply_action(2)
     state.apply_action(0)

@@ -227,51 +227,77 @@ struct SmallTree {  // device pointers to the extra host-built arrays
   int n_path;
 };
 
+struct SmallGlobal {  // global-memory homes of the same arrays, for trees too big for LDS (leduc)
+  double* value;         // [H, P]
+  double* dreg;          // [M, A]
+  double* dpol;          // [M, A]
+  int32_t* skip;         // [M]
+  const int32_t* meta;   // [H] kind | nchild << 2 | (actor + 1) << 10
+  const int32_t* info_player;  // [I]
+};
+
+template <bool kLds>
 __global__ void __launch_bounds__(1024)
-k_cfr_small(Tree t, SmallTree st, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg) {
+k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg) {
   extern __shared__ double smem[];
   const int P = t.P, A = t.A, H = t.H, I = t.I, M = st.M, IA = t.I * t.A;
   const int tid = threadIdx.x, nt = blockDim.x;
-  // ---- carve LDS (doubles first, then 32-bit, then bytes) ----
-  double* value = smem;                      // [H, P]
-  double* edge_prob = value + H * P;         // [H]
-  double* regrets = edge_prob + H;           // [I, A]
-  double* cum = regrets + IA;
-  double* cur = cum + IA;
-  double* dreg = cur + IA;                   // [M, A]
-  double* dpol = dreg + M * A;               // [M, A]
-  int32_t* first_child = reinterpret_cast<int32_t*>(dpol + M * A);  // [H]
-  int32_t* info = first_child + H;           // [H]
-  int32_t* meta = info + H;                  // [H] kind | nchild << 2 | (actor + 1) << 10
-  int32_t* mem = meta + H;                   // [M]
-  int32_t* mem_off = mem + M;                // [I+1]
-  int32_t* path_off = mem_off + (I + 1);     // [M+1]
-  int32_t* path = path_off + (M + 1);        // [n_path]
-  int32_t* nact = path + st.n_path;          // [I]
-  int32_t* info_player = nact + I;           // [I]
-  int32_t* skip = info_player + I;           // [M] 1 = pruned / not updated this pass
-  int32_t* level_off = skip + M;             // [D+1]
-  for (int h = tid; h < H; h += nt) {
-    first_child[h] = t.first_child[h];
-    info[h] = t.info[h];
-    meta[h] = t.kind[h] | (t.nchild[h] << 2) | ((t.actor[h] + 1) << 10);
-    edge_prob[h] = t.edge_prob[h];
-    for (int q = 0; q < P; ++q) value[h * P + q] = t.term_ret[h * P + q];  // terminals keep these forever
+  double *value, *regrets, *cum, *cur, *dreg, *dpol;
+  const double* edge_prob;
+  const int32_t *first_child, *info, *meta, *mem, *mem_off, *path_off, *path, *nact, *info_player, *level_off;
+  int32_t* skip;
+  if (kLds) {
+    // ---- carve LDS (doubles first, then 32-bit) and stage everything once ----
+    double* l_value = smem;                      // [H, P]
+    double* l_edge = l_value + H * P;            // [H]
+    regrets = l_edge + H;                        // [I, A]
+    cum = regrets + IA;
+    cur = cum + IA;
+    dreg = cur + IA;                             // [M, A]
+    dpol = dreg + M * A;                         // [M, A]
+    int32_t* l_first = reinterpret_cast<int32_t*>(dpol + M * A);  // [H]
+    int32_t* l_info = l_first + H;               // [H]
+    int32_t* l_meta = l_info + H;                // [H]
+    int32_t* l_mem = l_meta + H;                 // [M]
+    int32_t* l_mem_off = l_mem + M;              // [I+1]
+    int32_t* l_path_off = l_mem_off + (I + 1);   // [M+1]
+    int32_t* l_path = l_path_off + (M + 1);      // [n_path]
+    int32_t* l_nact = l_path + st.n_path;        // [I]
+    int32_t* l_info_player = l_nact + I;         // [I]
+    skip = l_info_player + I;                    // [M] 1 = pruned / not updated this pass
+    int32_t* l_level_off = skip + M;             // [D+1]
+    for (int h = tid; h < H; h += nt) {
+      l_first[h] = t.first_child[h];
+      l_info[h] = t.info[h];
+      l_meta[h] = sg.meta[h];
+      l_edge[h] = t.edge_prob[h];
+      for (int q = 0; q < P; ++q) l_value[h * P + q] = t.term_ret[h * P + q];  // terminals keep these forever
+    }
+    for (int k = tid; k < IA; k += nt) {
+      regrets[k] = tb.regrets[k];
+      cum[k] = tb.cum[k];
+      cur[k] = tb.cur[k];
+    }
+    for (int k = tid; k < M; k += nt) l_mem[k] = t.mem[k];
+    for (int k = tid; k <= M; k += nt) l_path_off[k] = st.path_off[k];
+    for (int k = tid; k < st.n_path; k += nt) l_path[k] = st.path[k];
+    for (int k = tid; k <= I; k += nt) l_mem_off[k] = t.mem_off[k];
+    for (int k = tid; k < I; k += nt) {
+      l_nact[k] = t.nact[k];
+      l_info_player[k] = sg.info_player[k];
+    }
+    for (int k = tid; k <= t.D; k += nt) l_level_off[k] = t.level_off[k];
+    value = l_value; edge_prob = l_edge; first_child = l_first; info = l_info; meta = l_meta; mem = l_mem;
+    mem_off = l_mem_off; path_off = l_path_off; path = l_path; nact = l_nact; info_player = l_info_player;
+    level_off = l_level_off;
+  } else {
+    value = sg.value; regrets = tb.regrets; cum = tb.cum; cur = tb.cur; dreg = sg.dreg; dpol = sg.dpol;
+    edge_prob = t.edge_prob; first_child = t.first_child; info = t.info; meta = sg.meta; mem = t.mem;
+    mem_off = t.mem_off; path_off = st.path_off; path = st.path; nact = t.nact; info_player = sg.info_player;
+    level_off = t.level_off; skip = sg.skip;
+    for (int h = tid; h < H; h += nt)
+      for (int q = 0; q < P; ++q) value[h * P + q] = t.term_ret[h * P + q];
   }
-  for (int k = tid; k < IA; k += nt) {
-    regrets[k] = tb.regrets[k];
-    cum[k] = tb.cum[k];
-    cur[k] = tb.cur[k];
-  }
-  for (int k = tid; k < M; k += nt) mem[k] = t.mem[k];
-  for (int k = tid; k <= M; k += nt) path_off[k] = st.path_off[k];
-  for (int k = tid; k < st.n_path; k += nt) path[k] = st.path[k];
-  for (int k = tid; k <= I; k += nt) mem_off[k] = t.mem_off[k];
-  for (int k = tid; k < I; k += nt) {
-    nact[k] = t.nact[k];
-    info_player[k] = t.info_player[k];
-  }
-  for (int k = tid; k <= t.D; k += nt) level_off[k] = t.level_off[k];
   __syncthreads();
 
   const int passes = cfg.alternating_updates ? P : 1;
@@ -352,10 +378,12 @@ k_cfr_small(Tree t, SmallTree st, Tables tb, int iters, int iteration0, osg_cfr_
       __syncthreads();
     }
   }
-  for (int k = tid; k < IA; k += nt) {
-    tb.regrets[k] = regrets[k];
-    tb.cum[k] = cum[k];
-    tb.cur[k] = cur[k];
+  if (kLds) {
+    for (int k = tid; k < IA; k += nt) {
+      tb.regrets[k] = regrets[k];
+      tb.cum[k] = cum[k];
+      tb.cur[k] = cur[k];
+    }
   }
 }
 
@@ -659,8 +687,12 @@ struct osg_cfr {
   // small-tree kernel: root paths of the decision histories (member order)
   std::vector<int32_t> path_off, path;
   int32_t *d_path_off = nullptr, *d_path = nullptr;
-  bool small_tree = false;
+  bool small_tree = false;   // the all-in-LDS variant fits
+  bool path_kernel = false;  // the path-based kernel (k_cfr_small) is usable at all
   size_t small_lds_bytes = 0;
+  std::vector<int32_t> meta32, info_player32;
+  int32_t *d_meta32 = nullptr, *d_info_player32 = nullptr, *d_skip = nullptr;
+  double* d_node_delta = nullptr;  // dreg [M, A] | dpol [M, A]
   // policy evaluation (k_policy_eval)
   std::vector<int32_t> info_level, mem_index;
   bool eval_ok = true;  // every infostate's members sit on one tree level
@@ -926,19 +958,27 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
     s->small_lds_bytes = doubles * 8 + ints * 4;
     const bool index_fits = static_cast<size_t>(s->H) < (1u << 23) && IA < (1u << 23);
     s->small_tree = index_fits && s->small_lds_bytes <= 64 * 1024 && s->P <= kMaxPlayers;
+    s->path_kernel = index_fits && s->P <= kMaxPlayers;
+    s->meta32.resize(s->H);
+    for (int h = 0; h < s->H; ++h) s->meta32[h] = s->kind[h] | (s->nchild[h] << 2) | ((s->actor[h] + 1) << 10);
+    s->info_player32.assign(s->info_player.begin(), s->info_player.end());
     if ((rc = upload(s->path_off, &s->d_path_off, st)) || (rc = upload(s->path, &s->d_path, st)) ||
-        (rc = upload(s->info_level, &s->d_info_level, st)) || (rc = upload(s->mem_index, &s->d_mem_index, st))) {
+        (rc = upload(s->info_level, &s->d_info_level, st)) || (rc = upload(s->mem_index, &s->d_mem_index, st)) ||
+        (rc = upload(s->meta32, &s->d_meta32, st)) || (rc = upload(s->info_player32, &s->d_info_player32, st))) {
       osg_cfr_destroy(s);
       return rc;
     }
     const size_t eval_doubles = static_cast<size_t>(s->H) * (s->P + 1) + M + 2 * s->P + IA;
     e = hipMalloc(reinterpret_cast<void**>(&s->d_eval), sizeof(double) * eval_doubles);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_best), sizeof(int32_t) * std::max(s->I, 1));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_skip), sizeof(int32_t) * std::max<size_t>(M, 1));
+    if (e == hipSuccess)
+      e = hipMalloc(reinterpret_cast<void**>(&s->d_node_delta), sizeof(double) * 2 * std::max<size_t>(M * s->A, 1));
     if (e != hipSuccess) { osg_cfr_destroy(s); return set_error(OSG_ERR_NOMEM, hipGetErrorString(e)); }
     if (!index_fits) s->eval_ok = false;
     if (s->small_tree) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cfr_small), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              static_cast<int>(s->small_lds_bytes));
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cfr_small<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->small_lds_bytes));
       if (e != hipSuccess) { (void)hipGetLastError(); s->small_tree = false; }
     }
   }
@@ -954,7 +994,7 @@ int osg_cfr_destroy(osg_cfr* s) {
   void* ptrs[] = {s->d_level_off, s->d_parent, s->d_first_child, s->d_info, s->d_mem_off, s->d_mem, s->d_nact,
                   s->d_kind, s->d_nchild, s->d_aidx, s->d_actor, s->d_info_player, s->d_edge_prob, s->d_term_ret,
                   s->d_tables, s->d_reach, s->d_value, s->d_path_off, s->d_path, s->d_info_level, s->d_mem_index,
-                  s->d_best, s->d_eval};
+                  s->d_best, s->d_eval, s->d_meta32, s->d_info_player32, s->d_skip, s->d_node_delta};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete s;
@@ -975,10 +1015,18 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
   int threads = ((s->max_level_width + 63) / 64) * 64;
   threads = std::max(64, std::min(threads, 1024));
   Tables tb{s->regrets(), s->cum(), s->cur()};
-  if (s->small_tree && s->cfg.kernel != 1) {
-    SmallTree st{s->d_path_off, s->d_path, static_cast<int>(s->mem.size()), static_cast<int>(s->path.size())};
-    k_cfr_small<<<dim3(1), dim3(threads), s->small_lds_bytes, s->ctx->stream>>>(s->tree(), st, tb, iters, s->iteration,
-                                                                               s->cfg);
+  if (s->path_kernel && s->cfg.kernel != 1) {
+    // Path-based kernel: no top-down reach pass; all-in-LDS when the tree is small enough.
+    const int M = static_cast<int>(s->mem.size());
+    SmallTree st{s->d_path_off, s->d_path, M, static_cast<int>(s->path.size())};
+    SmallGlobal sg{s->d_value, s->d_node_delta, s->d_node_delta + static_cast<size_t>(M) * s->A, s->d_skip,
+                   s->d_meta32, s->d_info_player32};
+    if (s->small_tree)
+      k_cfr_small<true><<<dim3(1), dim3(threads), s->small_lds_bytes, s->ctx->stream>>>(s->tree(), st, sg, tb, iters,
+                                                                                       s->iteration, s->cfg);
+    else
+      k_cfr_small<false><<<dim3(1), dim3(threads), 0, s->ctx->stream>>>(s->tree(), st, sg, tb, iters, s->iteration,
+                                                                        s->cfg);
   } else if (s->lds_resident) {
     k_cfr<true><<<dim3(1), dim3(threads), s->lds_bytes, s->ctx->stream>>>(s->tree(), tb, s->d_reach, s->d_value, iters,
                                                                          s->iteration, s->cfg);

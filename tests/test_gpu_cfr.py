@@ -75,6 +75,8 @@ def test_tree_census_and_keys(oracle, ctx, game):
     ("kuhn_poker", "cfr_simultaneous", dict(alternating_updates=False, general_kernel=True), [1, 20]),
     ("kuhn_poker(players=3)", "cfr", dict(general_kernel=True), [1, 10]),
     ("kuhn_poker(players=4)", "cfr", {}, [1, 6]),
+    ("leduc_poker", "cfr", dict(general_kernel=True), [1, 4]),               # leduc default = path kernel, global memory
+    ("leduc_poker", "cfr_simultaneous", dict(alternating_updates=False), [1, 3]),
     ("kuhn_poker(players=3)", "cfr_simultaneous", dict(alternating_updates=False), [1, 12]),
 ])
 def test_cfr_tables_match_the_oracle(oracle, ctx, game, kind, kwargs, checkpoints):

@@ -159,6 +159,19 @@ int osg_information_state_string(const osg_batch* b, int64_t index, int player, 
 int osg_random_steps(osg_batch* b, uint64_t seed, int64_t index_offset, int steps,
                      unsigned long long* d_counters);
 
+/* One reinforcement-learning environment step for every state (python/rl_environment.py:379-418
+ * Environment.step + get_time_step; replaces the Python loop of python/vector_env.py:51-54).
+ * Device pointers only.  d_should_reset [n] u8 is in/out: an environment flagged 1 starts a new
+ * episode and ignores its action; otherwise d_actions[i] is applied (-1: environment left as it is).
+ * Chance nodes are then
+ * resolved by sampling from the counter stream (seed, index_offset + i, step_index).
+ * Outputs: d_cur_player [n] i8, d_step_type [n] u8 (0 FIRST, 1 MID, 2 LAST), d_rewards [n, P]
+ * f64 (terminal returns at LAST, zeros otherwise), d_mask [n, mask_words] u32 legal mask of the
+ * new state; d_should_reset becomes 1 exactly where the step type is LAST.  Illegal actions leave
+ * the state unchanged and are reported by osg_ctx_synchronize (OSG_ERR_ILLEGAL). */
+int osg_env_step(osg_batch* b, const int32_t* d_actions, uint8_t* d_should_reset, uint64_t seed, int64_t index_offset,
+                 int64_t step_index, int8_t* d_cur_player, uint8_t* d_step_type, double* d_rewards, uint32_t* d_mask);
+
 /* algorithms::RandomRolloutEvaluator::Evaluate (open_spiel/algorithms/mcts.cc:43-72)
  * for every root: n_rollouts uniform-random playouts to the end of the game.
  * sum_returns [n, P] fp64 = SUM over rollouts of Returns() (divide by n_rollouts

@@ -30,4 +30,7 @@ def __getattr__(name):
     if name in ("Context", "Game", "StateBatch", "TabularSolver"):
         from . import engine
         return getattr(engine, name)
+    if name in ("BatchedEnvironment", "TimeStep", "StepType", "ObservationType"):
+        from . import vector_env
+        return getattr(vector_env, name)
     raise AttributeError(name)

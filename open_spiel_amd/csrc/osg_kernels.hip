@@ -281,6 +281,57 @@ k_random_steps(typename G::Params p, typename G::word_t* base, int64_t n, uint64
   atomicAdd(&counters[1], episodes);
 }
 
+// One fused reinforcement-learning environment step for every state of the batch
+// (python/rl_environment.py:379-418 Environment.step + :257-318 get_time_step, and
+// python/vector_env.py:51-54 which loops over environments in Python):
+//   * an environment whose previous time step was LAST (should_reset) starts a new
+//     episode and ignores its action (rl_environment.py:405-406);
+//   * otherwise the action is applied (illegal actions are counted, state unchanged);
+//   * chance nodes are then resolved by sampling ChanceOutcomes() (_sample_external_events,
+//     rl_environment.py:454-461) from the counter stream (seed, global env index, step);
+//   * outputs: current player, step type (0 FIRST, 1 MID, 2 LAST), rewards (terminal
+//     returns at LAST, zeros otherwise; the reference yields None at FIRST), the legal
+//     mask of the new state, and the next should_reset flag.
+template <class G>
+__global__ void __launch_bounds__(kBlock)
+k_env_step(typename G::Params p, typename G::word_t* base, int64_t n, int num_players, const int32_t* actions,
+           uint8_t* should_reset, uint64_t seed, int64_t index_offset, int64_t step_index, int8_t* cur_player,
+           uint8_t* step_type, double* rewards, uint32_t* mask, int mask_words, unsigned long long* illegal) {
+  int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  typename G::State s = G::load(p, base, n, i);
+  int type = 1;
+  if (should_reset[i]) {
+    s = G::initial(p);
+    type = 0;
+  } else {
+    const int a = actions[i];
+    if (a != OSG_INVALID_ACTION) {  // -1: leave this environment as it is (get_time_step without stepping)
+      const Mask m = G::legal(p, s);
+      if (a < 0 || a >= 32 * kMaskWords || !m.test(a)) atomicAdd(illegal, 1ull);
+      else G::apply(p, s, a);
+    }
+  }
+  Rng rng(seed, static_cast<uint64_t>(index_offset + i), static_cast<uint64_t>(step_index));
+  for (int guard = 0; guard < 64 && !G::terminal(p, s) && G::current_player(p, s) == kChancePlayer; ++guard) {
+    const Mask m = G::legal(p, s);
+    G::apply(p, s, sample_action<G>(p, s, m, kChancePlayer, rng));
+  }
+  G::store(p, base, n, i, s);
+  const bool term = G::terminal(p, s);
+  if (term && type != 0) type = 2;
+  should_reset[i] = type == 2 ? 1 : 0;
+  cur_player[i] = static_cast<int8_t>(G::current_player(p, s));
+  step_type[i] = static_cast<uint8_t>(type);
+  double r[kMaxPlayers];
+  G::returns(p, s, r);
+  for (int q = 0; q < num_players; ++q) rewards[i * num_players + q] = type == 2 ? r[q] : 0.0;
+  const Mask after = G::legal(p, s);
+#pragma unroll
+  for (int w = 0; w < kMaskWords; ++w)
+    if (w < mask_words) mask[i * mask_words + w] = after.w[w];
+}
+
 // RandomRolloutEvaluator::Evaluate (mcts.cc:43-72), persistent form: every lane
 // owns a strided list of (root, rollout) work items and runs ONE flat loop whose
 // body is "step the playout, or retire it and fetch the next item", so lanes in
@@ -682,6 +733,20 @@ int osg_rollout(const osg_batch* roots, uint64_t seed, int64_t index_offset, int
     if (steps) OSG_HIP(hipMemcpyAsync(steps, d_steps, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
     OSG_HIP(hipStreamSynchronize(ctx->stream));
   }
+  return OSG_OK;
+}
+
+int osg_env_step(osg_batch* b, const int32_t* d_actions, uint8_t* d_should_reset, uint64_t seed, int64_t index_offset,
+                 int64_t step_index, int8_t* d_cur_player, uint8_t* d_step_type, double* d_rewards, uint32_t* d_mask) {
+  if (!b || !d_actions || !d_should_reset || !d_cur_player || !d_step_type || !d_rewards || !d_mask)
+    return set_error(OSG_ERR_INVALID, "osg_env_step: null argument");
+  osg_ctx* ctx = b->ctx;
+  OSG_DISPATCH(b->spec, k_env_step<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
+                                            static_cast<typename G::word_t*>(b->d_words), b->n,
+                                            b->spec.desc.num_players, d_actions, d_should_reset, seed, index_offset,
+                                            step_index, d_cur_player, d_step_type, d_rewards, d_mask,
+                                            b->spec.desc.mask_words, ctx->d_illegal));
+  OSG_HIP(hipGetLastError());
   return OSG_OK;
 }
 

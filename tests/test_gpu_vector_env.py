@@ -1,0 +1,144 @@
+"""The batched RL environment (open_spiel_amd/vector_env.py, osg_env_step) against a restatement
+of the reference's `rl_environment.Environment` (python/rl_environment.py:257-452) built on the
+CPU oracle's State, fed with the same chance draws."""
+import numpy as np
+import pytest
+
+from test_gpu_fullsize import CounterRng
+
+pytestmark = pytest.mark.gpu
+
+FIRST, MID, LAST = 0, 1, 2
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import open_spiel_amd as osa
+    return osa.Context(0)
+
+
+class OracleEnvironment:
+    """rl_environment.Environment over the oracle (one environment), chance events sampled like the
+    device does: stream (seed, env index, step index), SampleAction's CDF scan."""
+
+    def __init__(self, og, seed, index, discount, use_observation):
+        self.og, self.seed, self.index, self.discount = og, seed, index, discount
+        self.use_observation = use_observation
+        self.state = None
+        self.should_reset = True
+
+    def _sample_external_events(self, t):
+        rng = CounterRng(self.seed, self.index, t)
+        while self.state.is_chance_node():
+            z, acc, pick = rng.unit(), 0.0, None
+            outcomes = self.state.chance_outcomes()
+            for a, pr in outcomes:
+                if acc <= z < acc + pr:
+                    pick = a
+                    break
+                acc += pr
+            self.state.apply_action(outcomes[-1][0] if pick is None else pick)
+
+    def _time_step(self, first):
+        s, P = self.state, self.og.num_players
+        step_type = FIRST if first else (LAST if s.is_terminal() else MID)
+        self.should_reset = step_type == LAST
+        obs = [s.observation_tensor(p) if self.use_observation else s.information_state_tensor(p) for p in range(P)]
+        legal = [s.legal_actions(p) for p in range(P)]
+        rewards = None if first else s.returns() if s.is_terminal() else [0.0] * P
+        discounts = None if first else [0.0 if step_type == LAST else self.discount] * P
+        return dict(info_state=obs, legal_actions=legal, current_player=s.current_player(), rewards=rewards,
+                    discounts=discounts, step_type=step_type)
+
+    def reset(self, t):
+        self.should_reset = False
+        self.state = self.og.new_initial_state()
+        self._sample_external_events(t)
+        return self._time_step(first=True)
+
+    def step(self, action, t):
+        if self.should_reset:  # rl_environment.py:405-406
+            return self.reset(t)
+        self.state.apply_action(int(action))
+        self._sample_external_events(t)
+        return self._time_step(first=False)
+
+
+def _compare(ts, want, i, P, A, what):
+    assert int(ts.step_type[i]) == want["step_type"], what
+    assert int(ts.observations["current_player"][i]) == want["current_player"], what
+    for p in range(P):
+        np.testing.assert_array_equal(ts.observations["info_state"][p][i].cpu().numpy(), want["info_state"][p], what)
+        legal = np.nonzero(ts.observations["legal_actions"][p][i].cpu().numpy())[0].tolist()
+        assert legal == want["legal_actions"][p], what
+    if want["rewards"] is None:
+        assert ts.rewards[i].tolist() == [0.0] * P and ts.discounts[i].tolist() == [0.0] * P, what
+    else:
+        assert ts.rewards[i].tolist() == want["rewards"], what
+        assert ts.discounts[i].tolist() == want["discounts"], what
+
+
+@pytest.mark.parametrize("game,obs_type,steps", [
+    ("kuhn_poker", None, 14), ("leduc_poker", None, 30), ("leduc_poker", "observation", 20),
+    ("tic_tac_toe", None, 25), ("connect_four", None, 60), ("hex(board_size=5)", None, 40),
+    ("kuhn_poker(players=3)", None, 16),
+])
+def test_batched_environment_matches_rl_environment(oracle, ctx, game, obs_type, steps):
+    import torch
+    import open_spiel_amd as osa
+    n, seed, offset, discount = 48, 0xE27, 7000, 0.99
+    og = oracle.Game(game)
+    P, A = og.num_players, og.num_distinct_actions
+    ot = osa.ObservationType.OBSERVATION if obs_type == "observation" else None
+    env = osa.BatchedEnvironment(ctx, game, n, discount=discount, observation_type=ot, seed=seed, index_offset=offset)
+    use_obs = obs_type == "observation" or og.information_state_tensor_size == 0
+    refs = [OracleEnvironment(og, seed, offset + i, discount, use_obs) for i in range(n)]
+    ts = env.reset()
+    want = [r.reset(0) for r in refs]
+    agent = np.random.default_rng(5)
+    finished = 0
+    for t in range(1, steps + 1):
+        for i in range(n):
+            _compare(ts, want[i], i, P, A, f"{game} env {i} step {t - 1}")
+        actions = np.zeros(n, np.int32)
+        for i, w in enumerate(want):
+            legal = w["legal_actions"][w["current_player"]] if w["current_player"] >= 0 else []
+            actions[i] = agent.choice(legal) if legal else 0  # ignored: the environment restarts
+            finished += w["step_type"] == LAST
+        ts = env.step(torch.from_numpy(actions))
+        want = [r.step(actions[i], t) for i, r in enumerate(refs)]
+    assert finished > 0, "the run must cover episode ends and restarts"
+
+
+def test_reset_if_done_like_sync_vector_env(ctx):
+    """vector_env.py:36-62: finished environments restart at once, unreset steps are returned too."""
+    import torch
+    import open_spiel_amd as osa
+    n = 32
+    env = osa.BatchedEnvironment(ctx, "tic_tac_toe", n, seed=1)
+    ts = env.reset()
+    assert bool((ts.step_type == FIRST).all())
+    seen_done = False
+    for _ in range(12):
+        legal = ts.observations["legal_actions"][0] | ts.observations["legal_actions"][1]
+        actions = legal.to(torch.float32).argmax(1).to(torch.int32)
+        ts, rewards, done, unreset = env.step(actions, reset_if_done=True)
+        assert bool((unreset.step_type[done] == LAST).all())
+        assert bool((ts.step_type[done] == FIRST).all()) and bool((ts.step_type[~done] == MID).all())
+        assert bool((rewards[~done] == 0).all())
+        assert bool((ts.observations["current_player"][done] == 0).all())
+        seen_done |= bool(done.any())
+    assert seen_done
+
+
+def test_illegal_action_is_reported(ctx):
+    import torch
+    import open_spiel_amd as osa
+    env = osa.BatchedEnvironment(ctx, "connect_four", 4)
+    env.reset()
+    with pytest.raises(osa.OsgError):
+        env.step(torch.full((4,), 9, dtype=torch.int32))  # IllegalActionError in the reference
+    with pytest.raises(ValueError):
+        osa.BatchedEnvironment(ctx, "tic_tac_toe", 4, observation_type=osa.ObservationType.INFORMATION_STATE)
+    with pytest.raises(ValueError):
+        osa.BatchedEnvironment(ctx, "tic_tac_toe", 4, discount=1.5)

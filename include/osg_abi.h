@@ -237,6 +237,8 @@ int osg_cfr_reset(osg_cfr* s);
 int osg_cfr_iterate(osg_cfr* s, int iters);
 /* Number of EvaluateAndUpdatePolicy calls (or MCCFR mini-batches) done so far. */
 int osg_cfr_iteration(const osg_cfr* s);
+/* Restores the iteration counter of a deserialised solver (cfr.h:318-323 deserialisation ctor). */
+int osg_cfr_set_iteration(osg_cfr* s, int iteration);
 /* ExternalSamplingMCCFRSolver::RunIteration (external_sampling_mccfr.cc:71-186,
  * AverageType::kSimple) for `trajectories` traverser passes (player = global
  * trajectory index mod P), mini-batched: every trajectory of one call reads the

@@ -103,6 +103,7 @@ SIGNATURES = {
     "osg_cfr_iterate": (INT, [VP, INT]),
     "osg_cfr_reset": (INT, [VP]),
     "osg_cfr_iteration": (INT, [VP]),
+    "osg_cfr_set_iteration": (INT, [VP, INT]),
     "osg_mccfr_sample": (INT, [VP, U64, I64, I64]),
     "osg_cfr_upload_tables": (INT, [VP, VP, VP, VP]),
     "osg_mccfr_iterate": (INT, [VP, U64, I64, I64]),

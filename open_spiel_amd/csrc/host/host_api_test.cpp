@@ -87,6 +87,25 @@ static void KuhnCfr() {
   EXPECT(Exploitability(*game, avg) <= 0.05);
   EXPECT(std::fabs(ExpectedReturns(*game, avg)[0] + 1.0 / 18) <= 1e-3);
   EXPECT(std::fabs(solver.EvaluatePolicy(0).nash_conv - NashConv(*game, avg)) < 1e-12);
+  // cfr_test.cc:191-256: serialize / deserialize round trip, then both solvers stay in lock step
+  const std::string text = solver.Serialize();
+  EXPECT(text.find("[Meta]\nVersion: 1\n\n[Game]\nkuhn_poker()\n[SolverType]\nCFRSolver\n[SolverSpecificState]\n300\n"
+                   "[SolverValuesTable]\n") != std::string::npos);
+  std::unique_ptr<CFRSolver> restored = DeserializeCFRSolver(text);
+  EXPECT(restored->Iteration() == 300);
+  solver.EvaluateAndUpdatePolicy();
+  restored->EvaluateAndUpdatePolicy();
+  const CFRInfoStateValuesTable mine = solver.InfoStateValuesTable(), theirs = restored->InfoStateValuesTable();
+  for (const auto& kv : mine) {
+    const CFRInfoStateValues& other = theirs.at(kv.first);
+    EXPECT(kv.second.cumulative_regrets == other.cumulative_regrets);   // hex floats: lossless
+    EXPECT(kv.second.cumulative_policy == other.cumulative_policy);
+    EXPECT(kv.second.current_policy == other.current_policy);
+  }
+  EXPECT(solver.Serialize(6).find("0x") == std::string::npos);         // SimpleDoubleFormatter
+  bool threw = false;
+  try { DeserializeCFRPlusSolver(text); } catch (const SpielException&) { threw = true; }
+  EXPECT(threw);
   CFRPlusSolver plus(*game);
   plus.EvaluateAndUpdatePolicy(200);
   EXPECT(plus.TabularAveragePolicy().at("2pb")[1].second > 0.99);

@@ -21,6 +21,10 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <iomanip>
+#include <sstream>
 #include <limits>
 #include <memory>
 #include <stdexcept>
@@ -89,6 +93,7 @@ class Game : public std::enable_shared_from_this<Game> {
   int ObservationTensorSize() const { return desc_.obs_size; }
   int InformationStateTensorSize() const { return desc_.info_size; }
   std::string ToString() const { return desc_.canonical; }
+  std::string Serialize() const { return ToString(); }  // spiel.cc:793-800 (no sampled-stochastic games here)
   const std::string& GameString() const { return string_; }
   const osg_game_desc& Desc() const { return desc_; }
   osg_ctx* Ctx() const { return Context::Default(device_); }
@@ -459,6 +464,23 @@ class DeviceTabularSolver {
                                   ev.best_response_values.data(), &ev.nash_conv, &ev.exploitability));
     return ev;
   }
+  // Overwrites the device tables from a CFRInfoStateValuesTable (rows matched by infostate string).
+  void LoadInfoStateValuesTable(const CFRInfoStateValuesTable& table) {
+    Tables t = Download();
+    for (int i = 0; i < t.I; ++i) {
+      auto it = table.find(Key(i));
+      if (it == table.end()) SpielFatalError(Key(i) + " missing from the table");
+      const CFRInfoStateValues& v = it->second;
+      if (v.num_actions() != t.nact[i]) SpielFatalError(Key(i) + ": wrong number of actions");
+      for (int a = 0; a < t.nact[i]; ++a) {
+        t.regrets[i * t.A + a] = v.cumulative_regrets[a];
+        t.cum[i * t.A + a] = v.cumulative_policy[a];
+        t.cur[i * t.A + a] = v.current_policy[a];
+      }
+    }
+    Check(osg_cfr_upload_tables(s_, t.regrets.data(), t.cum.data(), t.cur.data()));
+  }
+  int Iteration() const { return osg_cfr_iteration(s_); }
   int64_t NumInfoStates() const { return sizes_[4]; }
   int64_t NumHistories() const { return sizes_[0]; }
   osg_cfr* handle() const { return s_; }
@@ -507,21 +529,160 @@ class DeviceTabularSolver {
   }
 };
 
+// cfr.h:33-39
+constexpr const char* kSerializeMetaSectionHeader = "[Meta]";
+constexpr const char* kSerializeGameSectionHeader = "[Game]";
+constexpr const char* kSerializeSolverTypeSectionHeader = "[SolverType]";
+constexpr const char* kSerializeSolverSpecificStateSectionHeader = "[SolverSpecificState]";
+constexpr const char* kSerializeSolverValuesTableSectionHeader = "[SolverValuesTable]";
+constexpr int kSerializationVersion = 1;  // spiel.h:45
+
+inline std::string FormatDouble(double d, int double_precision) {  // utils/serialization.h:28-50
+  if (double_precision == -1) {
+    char buf[64];
+    std::snprintf(buf, sizeof(buf), "%a", d);  // HexDoubleFormatter: lossless
+    return buf;
+  }
+  std::stringstream stream;
+  stream << std::fixed << std::setprecision(double_precision) << d;  // SimpleDoubleFormatter
+  return stream.str();
+}
+// CFRInfoStateValues::Serialize (cfr.cc:509-532): "legal;regrets;cumulative policy;current policy".
+inline std::string SerializeInfoStateValues(const CFRInfoStateValues& v, int double_precision) {
+  std::string out;
+  auto join = [&](const std::vector<double>& xs) {
+    std::string r;
+    for (size_t i = 0; i < xs.size(); ++i) r += (i ? "," : "") + FormatDouble(xs[i], double_precision);
+    return r;
+  };
+  for (size_t i = 0; i < v.legal_actions.size(); ++i) out += (i ? "," : "") + std::to_string(v.legal_actions[i]);
+  return out + ";" + join(v.cumulative_regrets) + ";" + join(v.cumulative_policy) + ";" + join(v.current_policy);
+}
+inline CFRInfoStateValues DeserializeInfoStateValues(const std::string& serialized) {  // cfr.cc:534-583
+  CFRInfoStateValues res;
+  std::vector<std::vector<std::string>> parts(1);
+  std::string cur;
+  for (char c : serialized) {
+    if (c == ';') { parts.back().push_back(cur); cur.clear(); parts.emplace_back(); }
+    else if (c == ',') { parts.back().push_back(cur); cur.clear(); }
+    else cur.push_back(c);
+  }
+  parts.back().push_back(cur);
+  if (parts.size() != 4) SpielFatalError("malformed CFRInfoStateValues: " + serialized);
+  for (size_t i = 0; i < parts[0].size(); ++i) {
+    res.legal_actions.push_back(std::strtoll(parts[0][i].c_str(), nullptr, 10));
+    res.cumulative_regrets.push_back(std::strtod(parts[1].at(i).c_str(), nullptr));  // accepts "%a" hex floats
+    res.cumulative_policy.push_back(std::strtod(parts[2].at(i).c_str(), nullptr));
+    res.current_policy.push_back(std::strtod(parts[3].at(i).c_str(), nullptr));
+  }
+  return res;
+}
+
 class CFRSolverBase : public DeviceTabularSolver {  // cfr.h:188-304
  public:
   CFRSolverBase(const Game& game, bool alternating_updates, bool linear_averaging, bool regret_matching_plus)
-      : DeviceTabularSolver(game, alternating_updates, linear_averaging, regret_matching_plus, false) {}
+      : DeviceTabularSolver(game, alternating_updates, linear_averaging, regret_matching_plus, false),
+        game_string_(game.Serialize()) {}
+  virtual ~CFRSolverBase() = default;
+  // The reference's text checkpoint (cfr.cc:284-307): [Meta] / [Game] / [SolverType] /
+  // [SolverSpecificState] (the iteration) / [SolverValuesTable] rows "key<~>values<~>key<~>...".
+  // double_precision == -1 writes lossless hex floats.
+  std::string Serialize(int double_precision = -1, const std::string& delimiter = "<~>") const {
+    if (double_precision < -1) SpielFatalError("double_precision must be >= -1");
+    if (delimiter == "," || delimiter == ";")
+      SpielFatalError("Please select a different delimiter,invalid values are \",\" and \";\".");
+    std::string str = "# Automatically generated by OpenSpiel CFRSolverBase::Serialize\n";
+    str += std::string(kSerializeMetaSectionHeader) + "\nVersion: " + std::to_string(kSerializationVersion) + "\n\n";
+    str += std::string(kSerializeGameSectionHeader) + "\n" + game_string_ + "\n";
+    str += std::string(kSerializeSolverTypeSectionHeader) + "\n" + SerializeThisType() + "\n";
+    str += std::string(kSerializeSolverSpecificStateSectionHeader) + "\n" + std::to_string(Iteration()) + "\n";
+    str += std::string(kSerializeSolverValuesTableSectionHeader) + "\n";
+    bool first = true;
+    for (const auto& kv : InfoStateValuesTable()) {  // cfr.cc:639-661
+      if (kv.first.find(delimiter) != std::string::npos) SpielFatalError("Info state contains delimiter");
+      if (!first) str += delimiter;
+      first = false;
+      str += kv.first + delimiter + SerializeInfoStateValues(kv.second, double_precision);
+    }
+    return str;
+  }
+
+ protected:
+  virtual std::string SerializeThisType() const {  // cfr.h:261-263
+    SpielFatalError("Serialization of the base class is not supported.");
+  }
+
+ private:
+  std::string game_string_;
+
+ public:
   void EvaluateAndUpdatePolicy() { Check(osg_cfr_iterate(s_, 1)); }  // cfr.cc:263-282
   void EvaluateAndUpdatePolicy(int iterations) { Check(osg_cfr_iterate(s_, iterations)); }  // one launch
 };
 class CFRSolver : public CFRSolverBase {  // cfr.h:310-330
  public:
   explicit CFRSolver(const Game& game) : CFRSolverBase(game, true, false, false) {}
+
+ protected:
+  std::string SerializeThisType() const override { return "CFRSolver"; }
 };
 class CFRPlusSolver : public CFRSolverBase {  // cfr.h:341-357
  public:
   explicit CFRPlusSolver(const Game& game) : CFRSolverBase(game, true, true, true) {}
+
+ protected:
+  std::string SerializeThisType() const override { return "CFRPlusSolver"; }
 };
+
+// PartiallyDeserializeCFRSolver + Deserialize{CFR,CFRPlus}Solver (cfr.cc:699-781).  Deviation: the
+// reference rebuilds a CFRPlusSolver with linear_averaging = regret_matching_plus = false
+// (cfr.h:349-353, an upstream slip); here the restored solver keeps CFR+ semantics.
+template <class Solver>
+inline std::unique_ptr<Solver> DeserializeSolver(const std::string& serialized, const std::string& expected_type,
+                                                 const std::string& delimiter) {
+  std::string sections[4];
+  int current = -1;
+  size_t pos = 0, table_at = std::string::npos;
+  while (pos <= serialized.size()) {
+    size_t nl = serialized.find('\n', pos);
+    if (nl == std::string::npos) nl = serialized.size();
+    const std::string line = serialized.substr(pos, nl - pos);
+    pos = nl + 1;
+    if (line.empty() || line[0] == '#') continue;
+    if (line == kSerializeMetaSectionHeader) current = 0;
+    else if (line == kSerializeGameSectionHeader) current = 1;
+    else if (line == kSerializeSolverTypeSectionHeader) current = 2;
+    else if (line == kSerializeSolverSpecificStateSectionHeader) current = 3;
+    else if (line == kSerializeSolverValuesTableSectionHeader) { table_at = pos; break; }
+    else if (current < 0) SpielFatalError("malformed solver checkpoint");
+    else sections[current] += line;
+  }
+  if (table_at == std::string::npos) SpielFatalError("solver checkpoint without a values table");
+  if (sections[2] != expected_type) SpielFatalError("checkpoint holds a " + sections[2] + ", not a " + expected_type);
+  std::shared_ptr<const Game> game = LoadGame(sections[1]);
+  auto solver = std::unique_ptr<Solver>(new Solver(*game));
+  Check(osg_cfr_set_iteration(solver->handle(), std::stoi(sections[3])));
+  CFRInfoStateValuesTable table;  // DeserializeCFRInfoStateValuesTable (cfr.cc:663-673)
+  const std::string body = table_at <= serialized.size() ? serialized.substr(table_at) : std::string();
+  std::vector<std::string> splits;
+  for (size_t p = 0;;) {
+    size_t q = body.find(delimiter, p);
+    splits.push_back(body.substr(p, q == std::string::npos ? std::string::npos : q - p));
+    if (q == std::string::npos) break;
+    p = q + delimiter.size();
+  }
+  for (size_t i = 0; i + 1 < splits.size(); i += 2) table.emplace(splits[i], DeserializeInfoStateValues(splits[i + 1]));
+  solver->LoadInfoStateValuesTable(table);
+  return solver;
+}
+inline std::unique_ptr<CFRSolver> DeserializeCFRSolver(const std::string& serialized,
+                                                       const std::string& delimiter = "<~>") {
+  return DeserializeSolver<CFRSolver>(serialized, "CFRSolver", delimiter);
+}
+inline std::unique_ptr<CFRPlusSolver> DeserializeCFRPlusSolver(const std::string& serialized,
+                                                               const std::string& delimiter = "<~>") {
+  return DeserializeSolver<CFRPlusSolver>(serialized, "CFRPlusSolver", delimiter);
+}
 
 // algorithms::Exploitability / NashConv / ExpectedReturns of a tabular policy
 // (tabular_exploitability.h, expected_returns.h), evaluated on the device.

@@ -180,11 +180,18 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("average_policy", [](const CFRSolverBase& s) { return TabularPolicy(s.TabularAveragePolicy()); })
       .def("tabular_average_policy", [](const CFRSolverBase& s) { return TabularPolicy(s.TabularAveragePolicy()); })
       .def("current_policy", [](const CFRSolverBase& s) { return TabularPolicy(s.TabularCurrentPolicy()); })
-      .def("info_state_values_table", &CFRSolverBase::InfoStateValuesTable);
-  py::class_<CFRSolver, CFRSolverBase>(m, "CFRSolver")  // policy.cc:224-262
-      .def(py::init([](std::shared_ptr<Game> g) { return new CFRSolver(*g); }), py::arg("game"));
+      .def("info_state_values_table", &CFRSolverBase::InfoStateValuesTable)
+      .def("serialize", &CFRSolverBase::Serialize, py::arg("double_precision") = -1, py::arg("delimiter") = "<~>");
+  py::class_<CFRSolver, CFRSolverBase>(m, "CFRSolver")  // policy.cc:224-262 (pickle = serialize / deserialize)
+      .def(py::init([](std::shared_ptr<Game> g) { return new CFRSolver(*g); }), py::arg("game"))
+      .def(py::pickle([](const CFRSolver& s) { return s.Serialize(); },
+                      [](const std::string& t) { return DeserializeCFRSolver(t); }));
   py::class_<CFRPlusSolver, CFRSolverBase>(m, "CFRPlusSolver")
-      .def(py::init([](std::shared_ptr<Game> g) { return new CFRPlusSolver(*g); }), py::arg("game"));
+      .def(py::init([](std::shared_ptr<Game> g) { return new CFRPlusSolver(*g); }), py::arg("game"))
+      .def(py::pickle([](const CFRPlusSolver& s) { return s.Serialize(); },
+                      [](const std::string& t) { return DeserializeCFRPlusSolver(t); }));
+  m.def("deserialize_cfr_solver", [](const std::string& t) { return DeserializeCFRSolver(t); });
+  m.def("deserialize_cfr_plus_solver", [](const std::string& t) { return DeserializeCFRPlusSolver(t); });
 
   // pyspiel.exploitability / nash_conv / expected_returns (python/pybind11/policy.cc) for tabular policies
   m.def("exploitability", [](std::shared_ptr<Game> g, const TabularPolicy& p) { return Exploitability(*g, p.policy_table()); },

@@ -1148,6 +1148,11 @@ int osg_cfr_infostate_key(const osg_cfr* s, int64_t i, char* buf, int cap) {
 }
 
 int osg_cfr_iteration(const osg_cfr* s) { return s ? s->iteration : 0; }
+int osg_cfr_set_iteration(osg_cfr* s, int iteration) {
+  if (!s || iteration < 0) return set_error(OSG_ERR_INVALID, "osg_cfr_set_iteration: bad argument");
+  s->iteration = iteration;
+  return OSG_OK;
+}
 
 int osg_cfr_evaluate_policy(osg_cfr* s, int which_policy, const double* h_policy, double* expected_returns,
                             double* best_response_values, double* nash_conv, double* exploitability) {

@@ -122,3 +122,27 @@ def test_cfr_solver_like_cfr_example(pyspiel, oracle):
         mccfr.run_iteration()
     mccfr.run_mini_batch(20000)
     assert len(mccfr.average_policy().policy_table()) == 12
+
+
+@pytest.mark.gpu
+def test_cfr_solver_pickle_round_trip(pyspiel):
+    """policy.cc:237-241: CFR solvers pickle through Serialize / DeserializeCFRSolver
+    (cfr.cc:284-307,699-781); hex floats make the round trip lossless (cfr_test.cc:191-256)."""
+    import pickle
+    game = pyspiel.load_game("leduc_poker")
+    solver = pyspiel.CFRPlusSolver(game)
+    solver.evaluate_and_update_policy(3)
+    text = solver.serialize()
+    assert text.startswith("# Automatically generated by OpenSpiel CFRSolverBase::Serialize\n[Meta]\nVersion: 1\n")
+    assert "[Game]\nleduc_poker()\n[SolverType]\nCFRPlusSolver\n[SolverSpecificState]\n3\n[SolverValuesTable]\n" in text
+    clone = pickle.loads(pickle.dumps(solver))
+    solver.evaluate_and_update_policy()
+    clone.evaluate_and_update_policy()
+    a, b = solver.info_state_values_table(), clone.info_state_values_table()
+    assert len(a) == len(b) == 936
+    for k, v in a.items():
+        assert v.cumulative_regrets == b[k].cumulative_regrets
+        assert v.cumulative_policy == b[k].cumulative_policy
+        assert v.current_policy == b[k].current_policy
+    with pytest.raises(pyspiel.SpielError):
+        pyspiel.deserialize_cfr_solver(text)  # it is a CFRPlusSolver checkpoint

@@ -64,17 +64,29 @@ OSG_HD uint64_t path_hash_child(uint64_t parent, int action) {
 OSG_HD uint64_t order_base(uint64_t seed, uint64_t root) {
   return mix64(mix64(seed ^ kOrderSalt) ^ (root * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));
 }
-OSG_HD uint64_t order_key(uint64_t base, uint64_t parent_path_hash, int action) {
-  const uint64_t k = mix64(base ^ parent_path_hash ^ (static_cast<uint64_t>(action + 1) * 0xA0761D6478BD642FULL));
-  return (k & ~0xFFull) | static_cast<uint64_t>(action & 0xFF);
+// 32-bit avalanche mixer (two multiply-xorshift rounds): the sibling order only needs distinct,
+// well-scattered keys, and 32-bit multiplies are what the vector ALU is good at.
+OSG_HD uint32_t mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  return x ^ (x >> 16);
+}
+OSG_HD uint32_t order_key(uint64_t base, uint64_t parent_path_hash, int action) {
+  const uint32_t h = mix32(static_cast<uint32_t>(base) ^ static_cast<uint32_t>(parent_path_hash) ^
+                           (static_cast<uint32_t>(action + 1) * 0x9E3779B1u));
+  return (h & ~0xFFu) | static_cast<uint32_t>(action & 0xFF);  // low byte = action: siblings never tie
 }
 OSG_HD uint64_t fill_base(uint64_t seed, uint64_t root, uint64_t sub) {
   const uint64_t a = mix64(mix64(seed ^ kFillSalt) ^ (root * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));
   return mix64(a ^ (sub * 0xA0761D6478BD642FULL + 0xE7037ED1A0B428DBULL));
 }
-OSG_HD uint64_t fill_key(uint64_t base, int cell) {
-  const uint64_t k = mix64(base ^ (static_cast<uint64_t>(cell + 1) * 0x9E3779B97F4A7C15ULL));
-  return (k & ~0xFFull) | static_cast<uint64_t>(cell & 0xFF);
+OSG_HD uint64_t fill_key(uint64_t base, int cell) {  // two 32-bit mixers side by side: 56 random bits + the cell id
+  const uint32_t c = static_cast<uint32_t>(cell + 1);
+  const uint32_t hi = mix32(static_cast<uint32_t>(base) ^ (c * 0x9E3779B1u));
+  const uint32_t lo = mix32(static_cast<uint32_t>(base >> 32) ^ (c * 0x85EBCA6Bu));
+  return (static_cast<uint64_t>(hi) << 32) | static_cast<uint64_t>((lo & ~0xFFu) | static_cast<uint32_t>(cell & 0xFF));
 }
 
 // ---------------------------------------------------------------------------

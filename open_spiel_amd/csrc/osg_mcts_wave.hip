@@ -78,10 +78,10 @@ OSG_D double wave_max(double v) {
   }
   return v;
 }
-OSG_D uint64_t wave_min_u64(uint64_t v) {
+OSG_D uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
-    const uint64_t o = __shfl_xor(v, off);
+    const uint32_t o = __shfl_xor(v, off);
     v = o < v ? o : v;
   }
   return v;
@@ -108,18 +108,45 @@ OSG_D bool final_better(const Final& a, const Final& b) {  // a strictly preferr
 }
 
 // --- hex playout as a wave-parallel random fill --------------------------------------------
+// Per-lane constants of the board geometry: lane l owns cells l and l + 64; for each it keeps the
+// set of its (up to six) neighbours as a 128-bit mask, and whether it lies on black's two edges.
+struct HexLane {
+  uint64_t nb_lo[2], nb_hi[2];  // neighbours among cells 0-63 / 64-127
+  bool first_row[2], last_row[2], on_board[2];
+};
 template <class G>
-OSG_D int hex_fill_winner(const typename G::Params& p, const typename G::State& s, uint64_t base) {
+OSG_D HexLane hex_lane_setup(const typename G::Params& p) {
+  HexLane hl;
+  const int lane = lane_id();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int cell = lane + 64 * j;
+    hl.on_board[j] = cell < p.cells;
+    const typename G::Bits nb = G::neighbours(p, G::single(hl.on_board[j] ? cell : 0));
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < static_cast<int>(sizeof(nb.w) / sizeof(nb.w[0])); ++i) w[i] = nb.w[i];
+    hl.nb_lo[j] = hl.on_board[j] ? (static_cast<uint64_t>(w[1]) << 32 | w[0]) : 0ull;
+    hl.nb_hi[j] = hl.on_board[j] ? (static_cast<uint64_t>(w[3]) << 32 | w[2]) : 0ull;
+    hl.first_row[j] = hl.on_board[j] && G::test(p.row_first, cell);
+    hl.last_row[j] = hl.on_board[j] && G::test(p.row_last, cell);
+  }
+  return hl;
+}
+
+template <class G>
+OSG_D int hex_fill_winner(const typename G::Params& p, const typename G::State& s, uint64_t base, const HexLane& hl) {
   // Lane l owns cells l and l + 64.
   const int lane = lane_id();
   typename G::Bits occ = G::bor(s.black, s.white);
-  bool cand[2], sel[2];
+  bool cand[2], sel[2], empty[2];
   uint64_t key[2];
   int m = 0;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int cell = lane + 64 * j;
-    cand[j] = cell < p.cells && !G::test(occ, cell);
+    empty[j] = hl.on_board[j] && !G::test(occ, cell);
+    cand[j] = empty[j];
     key[j] = fill_key(base, cell);
     sel[j] = false;
     m += wave_count(cand[j]);
@@ -150,29 +177,26 @@ OSG_D int hex_fill_winner(const typename G::Params& p, const typename G::State& 
   }
   // The filled board: the mover's new stones are `sel`, the opponent's the other empty cells.
   const int mover = G::to_move(s);
-  bool blk[2];
+  bool blk[2], reached[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int cell = lane + 64 * j;
-    const bool empty = cell < p.cells && !G::test(occ, cell);
-    const bool mine = sel[j];
-    blk[j] = G::test(s.black, cell) || (empty && (mover == 0 ? mine : !mine));
+    blk[j] = hl.on_board[j] && (G::test(s.black, cell) || (empty[j] && (mover == 0 ? sel[j] : !sel[j])));
+    reached[j] = blk[j] && hl.first_row[j];
   }
-  const uint64_t b0 = __ballot(blk[0]), b1 = __ballot(blk[1]);
-  const uint32_t words[4] = {static_cast<uint32_t>(b0), static_cast<uint32_t>(b0 >> 32), static_cast<uint32_t>(b1),
-                             static_cast<uint32_t>(b1 >> 32)};
-  typename G::Bits black = G::zero();
-#pragma unroll
-  for (int i = 0; i < static_cast<int>(sizeof(black.w) / sizeof(black.w[0])); ++i) black.w[i] = words[i];
-  black = G::band(black, p.board);
   // Black wins iff its stones join the first row to the last row (hex.cc:108-171 edge labels).
-  typename G::Bits region = G::band(black, p.row_first);
+  // Lane-parallel flood: a black cell joins the region when one of its neighbours is in it; the
+  // region travels between lanes as two ballot masks.  Stops as soon as the last row is reached.
   for (int it = 0; it < 128; ++it) {
-    typename G::Bits grow = G::bandn(G::band(G::neighbours(p, region), black), region);
-    if (!G::any(grow)) break;
-    region = G::bor(region, grow);
+    const uint64_t r0 = __ballot(reached[0]), r1 = __ballot(reached[1]);
+    if (__ballot((reached[0] && hl.last_row[0]) || (reached[1] && hl.last_row[1])) != 0ull) return 0;  // black
+    const bool g0 = blk[0] && !reached[0] && ((hl.nb_lo[0] & r0) | (hl.nb_hi[0] & r1)) != 0ull;
+    const bool g1 = blk[1] && !reached[1] && ((hl.nb_lo[1] & r0) | (hl.nb_hi[1] & r1)) != 0ull;
+    if (__ballot(g0 || g1) == 0ull) break;
+    reached[0] |= g0;
+    reached[1] |= g1;
   }
-  return G::any(G::band(region, p.row_last)) ? 0 : 1;  // winner: 0 black, 1 white
+  return 1;  // white: on a filled board exactly one side connects
 }
 
 template <class G, bool kBoard, bool kHexFill>
@@ -192,6 +216,8 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
   uint32_t* COUNT = pool.count + r * cap;
   double* TOTAL = pool.total + r * cap;
   const uint64_t obase = order_base(cfg.seed, gr);
+  HexLane hl{};
+  if constexpr (kHexFill) hl = hex_lane_setup<G>(p);
 
   const typename G::State root_state = G::load(p, base, n, r);
   const int root_player = G::current_player(p, root_state);
@@ -226,11 +252,25 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
         if (used + static_cast<uint32_t>(c) > static_cast<uint32_t>(cap)) break;  // pool exhausted: leaf evaluation
         const uint32_t first = used;
         used += c;
-        for (int k = lane; k < c; k += 64) {
-          META[first + k] = make_meta(select_action(legal, k), cur, 0);
-          FIRST[first + k] = 0;
-          COUNT[first + k] = 0;
-          TOTAL[first + k] = 0.0;
+        // Children in action order.  Lane l looks at actions l and l + 64: a legal action's slot is its
+        // rank among the legal ones (popcount of the mask below it) — the cheap direction of the
+        // k <-> action mapping — so the writes are still one compacted, coalesced span.
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int a = lane + 64 * j;
+          if (legal.test(a)) {
+            int rank = 0;
+#pragma unroll
+            for (int w = 0; w < kMaskWords; ++w) {
+              const int lo = 32 * w;
+              if (a >= lo + 32) rank += __builtin_popcount(legal.w[w]);
+              else if (a > lo) rank += __builtin_popcount(legal.w[w] & ((1u << (a - lo)) - 1u));
+            }
+            META[first + rank] = make_meta(a, cur, 0);
+            FIRST[first + rank] = 0;
+            COUNT[first + rank] = 0;
+            TOTAL[first + rank] = 0.0;
+          }
         }
         meta = make_meta(m_action(meta), m_player(meta), c) | (meta & 0x00F00000u);
         if (lane == 0) {
@@ -253,34 +293,51 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
         }
         chosen_k = below;
       } else {  // arg-max of UCTValue (mcts.cc:90-101), ties to the smallest order key
-        const double logn = log_table[cnt];
-        double v2[2];
-        uint32_t a2[2];
+        uint32_t cm2[2], cc2[2];
+        bool unvisited[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int k = lane + 64 * j;
-          v2[j] = -INFINITY;
-          a2[j] = 0;
+          cm2[j] = 0;
+          cc2[j] = 0;
+          unvisited[j] = false;
           if (k < c) {
-            const uint32_t cm = META[first + k];
-            const uint32_t cc = COUNT[first + k];
-            const double ct = TOTAL[first + k];
-            a2[j] = m_action(cm);
-            if (m_has_outcome(cm)) v2[j] = outcome_value<kBoard>(cm, cc, ct, m_player(cm));
-            else if (cc == 0) v2[j] = INFINITY;
-            else v2[j] = ct / cc + cfg.uct_c * sqrt(logn / cc);
+            cm2[j] = META[first + k];
+            cc2[j] = COUNT[first + k];
+            unvisited[j] = cc2[j] == 0 && !m_has_outcome(cm2[j]);
           }
         }
-        // Phase 1: the maximum VALUE only (2 dwords per butterfly step).
-        const double vmax = wave_max(v2[0] > v2[1] ? v2[0] : v2[1]);
-        const bool t0 = lane < c && v2[0] == vmax, t1 = lane + 64 < c && v2[1] == vmax;
+        bool t0, t1;  // the candidates holding the maximum value
+        const uint64_t u0 = __ballot(unvisited[0]), u1 = __ballot(unvisited[1]);
+        if ((u0 | u1) != 0ull) {
+          // Some child has never been visited: its value is +infinity (mcts.cc:95), so the maximum is
+          // +infinity whatever the others score — no UCT arithmetic needed at this node.
+          t0 = unvisited[0];
+          t1 = unvisited[1];
+        } else {
+          const double logn = log_table[cnt];
+          double v2[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int k = lane + 64 * j;
+            v2[j] = -INFINITY;
+            if (k < c) {
+              const double ct = TOTAL[first + k];
+              if (m_has_outcome(cm2[j])) v2[j] = outcome_value<kBoard>(cm2[j], cc2[j], ct, m_player(cm2[j]));
+              else v2[j] = ct / cc2[j] + cfg.uct_c * sqrt(logn / cc2[j]);
+            }
+          }
+          const double vmax = wave_max(v2[0] > v2[1] ? v2[0] : v2[1]);  // value only: 2 dwords per butterfly step
+          t0 = lane < c && v2[0] == vmax;
+          t1 = lane + 64 < c && v2[1] == vmax;
+        }
         const uint64_t b0 = __ballot(t0), b1 = __ballot(t1);
         if (__builtin_popcountll(b0) + __builtin_popcountll(b1) == 1) {
           chosen_k = b0 ? __builtin_ctzll(b0) : 64 + __builtin_ctzll(b1);
-        } else {  // Phase 2 (ties, e.g. several unvisited children): the smallest order key among the tied
-          const uint64_t k0 = t0 ? order_key(obase, ph, static_cast<int>(a2[0])) : ~0ull;
-          const uint64_t k1 = t1 ? order_key(obase, ph, static_cast<int>(a2[1])) : ~0ull;
-          const uint64_t kmin = wave_min_u64(k0 < k1 ? k0 : k1);
+        } else {  // several maxima: the smallest order key (= first in the shuffled order, mcts.cc:294,336)
+          const uint32_t k0 = t0 ? order_key(obase, ph, static_cast<int>(m_action(cm2[0]))) : 0xFFFFFFFFu;
+          const uint32_t k1 = t1 ? order_key(obase, ph, static_cast<int>(m_action(cm2[1]))) : 0xFFFFFFFFu;
+          const uint32_t kmin = wave_min_u32(k0 < k1 ? k0 : k1);
           const uint64_t w0 = __ballot(t0 && k0 == kmin), w1 = __ballot(t1 && k1 == kmin);
           chosen_k = w0 ? __builtin_ctzll(w0) : 64 + __builtin_ctzll(w1);
         }
@@ -306,7 +363,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
       double r0 = 0.0;
       for (int ro = 0; ro < cfg.n_rollouts; ++ro) {
         const uint64_t fb = fill_base(cfg.seed, gr, static_cast<uint64_t>(sim) * cfg.n_rollouts + ro);
-        r0 += hex_fill_winner<G>(p, s, fb) == 0 ? 1.0 : -1.0;
+        r0 += hex_fill_winner<G>(p, s, fb, hl) == 0 ? 1.0 : -1.0;
       }
       returns[0] = r0 / cfg.n_rollouts;
       returns[1] = -returns[0] + 0.0;

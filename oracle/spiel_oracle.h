@@ -215,7 +215,7 @@ uint64_t Mix64(uint64_t z);
 uint64_t PathHashRoot();
 uint64_t PathHashChild(uint64_t parent, int action);
 uint64_t OrderBase(uint64_t seed, uint64_t root);
-uint64_t OrderKey(uint64_t base, uint64_t parent_path_hash, int action);
+uint32_t OrderKey(uint64_t base, uint64_t parent_path_hash, int action);
 uint64_t FillBase(uint64_t seed, uint64_t root, uint64_t sub);
 uint64_t FillKey(uint64_t base, int cell);
 

@@ -262,17 +262,27 @@ uint64_t PathHashChild(uint64_t parent, int action) {
 uint64_t OrderBase(uint64_t seed, uint64_t root) {
   return Mix64(Mix64(seed ^ 0x6F726465725F6B79ULL) ^ (root * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));
 }
-uint64_t OrderKey(uint64_t base, uint64_t parent_path_hash, int action) {
-  const uint64_t k = Mix64(base ^ parent_path_hash ^ (static_cast<uint64_t>(action + 1) * 0xA0761D6478BD642FULL));
-  return (k & ~0xFFull) | static_cast<uint64_t>(action & 0xFF);
+static uint32_t Mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  return x ^ (x >> 16);
+}
+uint32_t OrderKey(uint64_t base, uint64_t parent_path_hash, int action) {
+  const uint32_t h = Mix32(static_cast<uint32_t>(base) ^ static_cast<uint32_t>(parent_path_hash) ^
+                           (static_cast<uint32_t>(action + 1) * 0x9E3779B1u));
+  return (h & ~0xFFu) | static_cast<uint32_t>(action & 0xFF);
 }
 uint64_t FillBase(uint64_t seed, uint64_t root, uint64_t sub) {
   const uint64_t a = Mix64(Mix64(seed ^ 0x66696C6C5F6B6579ULL) ^ (root * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));
   return Mix64(a ^ (sub * 0xA0761D6478BD642FULL + 0xE7037ED1A0B428DBULL));
 }
 uint64_t FillKey(uint64_t base, int cell) {
-  const uint64_t k = Mix64(base ^ (static_cast<uint64_t>(cell + 1) * 0x9E3779B97F4A7C15ULL));
-  return (k & ~0xFFull) | static_cast<uint64_t>(cell & 0xFF);
+  const uint32_t c = static_cast<uint32_t>(cell + 1);
+  const uint32_t hi = Mix32(static_cast<uint32_t>(base) ^ (c * 0x9E3779B1u));
+  const uint32_t lo = Mix32(static_cast<uint32_t>(base >> 32) ^ (c * 0x85EBCA6Bu));
+  return (static_cast<uint64_t>(hi) << 32) | static_cast<uint64_t>((lo & ~0xFFu) | static_cast<uint32_t>(cell & 0xFF));
 }
 
 CounterRng::CounterRng(uint64_t seed, uint64_t stream, uint64_t sub) {

@@ -219,7 +219,12 @@ typedef struct {
   int32_t solver;                /* 0: CFRSolverBase family, tables start at 0 (cfr.h:47-52);
                                     1: ExternalSamplingMCCFRSolver, regrets and cumulative policy
                                        start at kInitialTableValues = 1e-6
-                                       (external_sampling_mccfr.h:59, .cc:142-143)              */
+                                       (external_sampling_mccfr.h:59, .cc:142-143);
+                                    2: OutcomeSamplingMCCFRSolver (outcome_sampling_mccfr.cc:141-241,
+                                       Baseline() == 0), same initial values, same mini-batch
+                                       protocol through osg_mccfr_sample / osg_mccfr_iterate        */
+  double epsilon;                /* solver 2 only: OutcomeSamplingMCCFRSolver's exploration
+                                    (outcome_sampling_mccfr.h:43 kDefaultEpsilon = 0.6)          */
   int32_t kernel;                /* 0 auto; 1 force the general level-synchronous kernel (k_cfr)
                                     even where the all-in-LDS small-tree kernel applies      */
 } osg_cfr_cfg;

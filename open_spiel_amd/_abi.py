@@ -59,6 +59,7 @@ class CfrCfg(C.Structure):
         ("linear_averaging", C.c_int32),
         ("regret_matching_plus", C.c_int32),
         ("solver", C.c_int32),
+        ("epsilon", C.c_double),
         ("kernel", C.c_int32),
     ]
 

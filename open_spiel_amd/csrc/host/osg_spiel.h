@@ -486,8 +486,9 @@ class DeviceTabularSolver {
   osg_cfr* handle() const { return s_; }
 
  protected:
-  DeviceTabularSolver(const Game& game, bool alternating, bool linear, bool rm_plus, bool mccfr) {
-    osg_cfr_cfg cfg{alternating ? 1 : 0, linear ? 1 : 0, rm_plus ? 1 : 0, mccfr ? 1 : 0, 0};
+  // mccfr: 0 CFR family, 1 external sampling, 2 outcome sampling (with `epsilon`)
+  DeviceTabularSolver(const Game& game, bool alternating, bool linear, bool rm_plus, int mccfr, double epsilon = 0.6) {
+    osg_cfr_cfg cfg{alternating ? 1 : 0, linear ? 1 : 0, rm_plus ? 1 : 0, mccfr, epsilon, 0};
     Check(osg_cfr_create(game.Ctx(), game.GameString().c_str(), &cfg, &s_));
     Check(osg_cfr_sizes(s_, sizes_));
     num_players_ = game.NumPlayers();
@@ -581,7 +582,7 @@ inline CFRInfoStateValues DeserializeInfoStateValues(const std::string& serializ
 class CFRSolverBase : public DeviceTabularSolver {  // cfr.h:188-304
  public:
   CFRSolverBase(const Game& game, bool alternating_updates, bool linear_averaging, bool regret_matching_plus)
-      : DeviceTabularSolver(game, alternating_updates, linear_averaging, regret_matching_plus, false),
+      : DeviceTabularSolver(game, alternating_updates, linear_averaging, regret_matching_plus, 0),
         game_string_(game.Serialize()) {}
   virtual ~CFRSolverBase() = default;
   // The reference's text checkpoint (cfr.cc:284-307): [Meta] / [Game] / [SolverType] /
@@ -700,7 +701,7 @@ enum class AverageType { kSimple, kFull };
 class ExternalSamplingMCCFRSolver : public DeviceTabularSolver {  // external_sampling_mccfr.h:57-113
  public:
   explicit ExternalSamplingMCCFRSolver(const Game& game, int seed = 0, AverageType avg_type = AverageType::kSimple)
-      : DeviceTabularSolver(game, true, false, false, true), seed_(seed) {
+      : DeviceTabularSolver(game, true, false, false, 1), seed_(seed) {
     if (avg_type != AverageType::kSimple) SpielFatalError("the device ES-MCCFR implements AverageType::kSimple");
   }
   // One UpdateRegrets per player, each seeing the previous one's update (:71-80).
@@ -711,6 +712,24 @@ class ExternalSamplingMCCFRSolver : public DeviceTabularSolver {  // external_sa
   void RunMiniBatch(int64_t trajectories) {
     Check(osg_mccfr_iterate(s_, seed_, next_, trajectories));
     next_ += trajectories;
+  }
+
+ private:
+  uint64_t seed_;
+  int64_t next_ = 0;
+};
+
+class OutcomeSamplingMCCFRSolver : public DeviceTabularSolver {  // outcome_sampling_mccfr.h:40-107
+ public:
+  static constexpr double kDefaultEpsilon = 0.6;
+  explicit OutcomeSamplingMCCFRSolver(const Game& game, double epsilon = kDefaultEpsilon, int seed = -1)
+      : DeviceTabularSolver(game, true, false, false, 2, epsilon), seed_(seed < 0 ? 0 : seed) {}
+  void RunIteration() {  // one SampleEpisode per player, each seeing the previous one's update (:67-74)
+    for (int p = 0; p < num_players_; ++p) Check(osg_mccfr_iterate(s_, seed_, next_++, 1));
+  }
+  void RunMiniBatch(int64_t episodes) {  // `episodes` sampled paths as ONE mini-batch
+    Check(osg_mccfr_iterate(s_, seed_, next_, episodes));
+    next_ += episodes;
   }
 
  private:

@@ -212,4 +212,14 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("average_policy",
            [](const ExternalSamplingMCCFRSolver& s) { return TabularPolicy(s.TabularAveragePolicy()); })
       .def("info_state_values_table", &ExternalSamplingMCCFRSolver::InfoStateValuesTable);
+  py::class_<OutcomeSamplingMCCFRSolver>(m, "OutcomeSamplingMCCFRSolver")  // policy.cc:334-370
+      .def(py::init([](std::shared_ptr<Game> g, double epsilon, int seed) {
+             return new OutcomeSamplingMCCFRSolver(*g, epsilon, seed);
+           }),
+           py::arg("game"), py::arg("epsilon") = OutcomeSamplingMCCFRSolver::kDefaultEpsilon, py::arg("seed") = -1)
+      .def("run_iteration", &OutcomeSamplingMCCFRSolver::RunIteration)
+      .def("run_mini_batch", &OutcomeSamplingMCCFRSolver::RunMiniBatch, py::arg("episodes"))
+      .def("average_policy",
+           [](const OutcomeSamplingMCCFRSolver& s) { return TabularPolicy(s.TabularAveragePolicy()); })
+      .def("info_state_values_table", &OutcomeSamplingMCCFRSolver::InfoStateValuesTable);
 }

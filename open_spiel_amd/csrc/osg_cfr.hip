@@ -602,6 +602,106 @@ k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dp
   }
 }
 
+// ---------------------------------------------------------------------------
+// OutcomeSamplingMCCFRSolver::SampleEpisode (outcome_sampling_mccfr.cc:141-241),
+// Baseline() == 0: ONE sampled path per thread.  The walk down records, per decision
+// node, the regret-matched policy, the sampled action and the three reaches; the walk
+// back up turns the terminal return into value estimates and adds the update player's
+// regret / average-policy terms (importance weights 1 / sample_reach).  Tables frozen
+// for the launch, deltas in LDS like k_mccfr.
+// ---------------------------------------------------------------------------
+constexpr int kMaxOsDepth = 32;
+
+template <bool kLdsDelta>
+__global__ void __launch_bounds__(256)
+k_os_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dpol, uint64_t seed, int64_t first,
+           int64_t count, double epsilon) {
+  extern __shared__ double smem[];
+  const int A = t.A, P = t.P, IA = t.I * t.A;
+  double* dreg = kLdsDelta ? smem : g_dreg;
+  double* dpol = kLdsDelta ? smem + IA : g_dpol;
+  if (kLdsDelta) {
+    for (int k = threadIdx.x; k < 2 * IA; k += blockDim.x) smem[k] = 0.0;
+    __syncthreads();
+  }
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < count; j += stride) {
+    const int64_t g = first + j;
+    const int upd = static_cast<int>(g % P);
+    Rng rng(seed, static_cast<uint64_t>(g), 0);
+    int f_info[kMaxOsDepth], f_aidx[kMaxOsDepth];
+    double f_my[kMaxOsDepth], f_opp[kMaxOsDepth], f_samp[kMaxOsDepth], f_sp[kMaxOsDepth];
+    bool f_upd[kMaxOsDepth];
+    int depth = 0;
+    int node = 0;
+    double my = 1.0, opp = 1.0, samp = 1.0;
+    while (t.kind[node] != kTerminalNode && depth < kMaxOsDepth) {
+      const int fc = t.first_child[node], nc = t.nchild[node];
+      if (t.kind[node] == kChanceNode) {  // SampleAction(ChanceOutcomes(), z) (:146-153)
+        const double z = rng.unit();
+        int pick = nc - 1;
+        double acc = 0.0;
+        for (int c = 0; c < nc; ++c) {
+          const double pr = t.edge_prob[fc + c];
+          if (acc <= z && z < acc + pr) { pick = c; break; }
+          acc += pr;
+        }
+        const double pr = t.edge_prob[fc + pick];
+        opp = pr * opp;
+        samp = pr * samp;
+        node = fc + pick;
+        continue;
+      }
+      const int i = t.info[node];
+      const bool is_upd = t.actor[node] == upd;
+      double pol[kMaxA];
+      regret_match_row(regrets + i * A, pol, nc);
+      const double z = rng.unit();
+      int pick = nc - 1;
+      double acc = 0.0, sp_pick = 0.0;
+      for (int a = 0; a < nc; ++a) {
+        const double sp = is_upd ? epsilon * 1.0 / nc + (1 - epsilon) * pol[a] : pol[a];  // SamplePolicy (:111-118)
+        if (a == nc - 1) sp_pick = sp;
+        if (z >= acc && z < acc + sp) { pick = a; sp_pick = sp; break; }
+        acc += sp;
+      }
+      f_info[depth] = i; f_aidx[depth] = pick; f_my[depth] = my; f_opp[depth] = opp; f_samp[depth] = samp;
+      f_sp[depth] = sp_pick; f_upd[depth] = is_upd;
+      ++depth;
+      if (is_upd) my = my * pol[pick]; else opp = opp * pol[pick];
+      samp = samp * sp_pick;
+      node = fc + pick;
+    }
+    double v = t.term_ret[node * P + upd];
+    for (int d = depth - 1; d >= 0; --d) {
+      const int i = f_info[d], n = t.nact[i], sampled = f_aidx[d];
+      double pol[kMaxA];
+      regret_match_row(regrets + i * A, pol, n);
+      // child_values[a] = a == sampled ? 0 + (child_value - 0) / sample_policy[a] : 0 (:126-139)
+      const double cv_sampled = 0.0 + (v - 0.0) / f_sp[d];
+      double value_estimate = 0.0;
+      for (int a = 0; a < n; ++a) value_estimate += pol[a] * (a == sampled ? cv_sampled : 0.0);
+      if (f_upd[d]) {
+        const double cf_value = value_estimate * f_opp[d] / f_samp[d];
+        for (int a = 0; a < n; ++a) {
+          const double cf_action_value = (a == sampled ? cv_sampled : 0.0) * f_opp[d] / f_samp[d];
+          add_f64(&dreg[i * A + a], cf_action_value - cf_value);
+          add_f64(&dpol[i * A + a], f_my[d] * pol[a] / f_samp[d]);
+        }
+      }
+      v = value_estimate;
+    }
+  }
+  if (kLdsDelta) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < IA; k += blockDim.x) {
+      const double r = smem[k], q = smem[IA + k];
+      if (r != 0.0) add_f64(&g_dreg[k], r);
+      if (q != 0.0) add_f64(&g_dpol[k], q);
+    }
+  }
+}
+
 __global__ void k_fold_deltas(double* regrets, double* cum, const double* dreg, const double* dpol, int n) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
@@ -900,7 +1000,7 @@ int init_tables(osg_cfr* s) {
   for (int i = 0; i < s->I; ++i)
     for (int a = 0; a < s->nact[i]; ++a) {
       cur[i * s->A + a] = 1.0 / s->nact[i];  // CFRInfoStateValues ctor (cfr.h:47-52)
-      init[i * s->A + a] = s->cfg.solver == 1 ? kMccfrInit : 0.0;
+      init[i * s->A + a] = s->cfg.solver >= 1 ? kMccfrInit : 0.0;
     }
   OSG_HIP(hipMemcpyAsync(s->cur(), cur.data(), sizeof(double) * IA, hipMemcpyHostToDevice, st));
   OSG_HIP(hipMemcpyAsync(s->regrets(), init.data(), sizeof(double) * IA, hipMemcpyHostToDevice, st));
@@ -925,8 +1025,17 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
     delete s;
     return set_error(OSG_ERR_UNSUPPORTED, "tabular CFR needs information-state strings: kuhn_poker and leduc_poker only");
   }
+  if (s->cfg.solver < 0 || s->cfg.solver > 2) { delete s; return set_error(OSG_ERR_INVALID, "osg_cfr_cfg.solver must be 0, 1 or 2"); }
+  if (s->cfg.solver == 2 && !(s->cfg.epsilon > 0.0 && s->cfg.epsilon <= 1.0)) {
+    delete s;
+    return set_error(OSG_ERR_INVALID, "outcome sampling needs 0 < epsilon <= 1 (kDefaultEpsilon = 0.6)");
+  }
   rc = build_tree(s, game_string);
   if (rc) { delete s; return rc; }
+  if (s->cfg.solver == 2 && s->D > kMaxOsDepth) {
+    delete s;
+    return set_error(OSG_ERR_UNSUPPORTED, "outcome sampling: game tree deeper than 32 levels");
+  }
   hipStream_t st = ctx->stream;
   if ((rc = upload(s->level_off, &s->d_level_off, st)) || (rc = upload(s->parent, &s->d_parent, st)) ||
       (rc = upload(s->first_child, &s->d_first_child, st)) || (rc = upload(s->info, &s->d_info, st)) ||
@@ -1052,6 +1161,24 @@ int osg_mccfr_sample(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_
   // Persistent workgroups: each flushes its LDS delta tables once, so fewer, longer-lived
   // groups mean fewer global atomics (256 CUs x 4 groups).
   if (blocks > 1024) blocks = 1024;
+  if (s->cfg.solver == 2) {  // OutcomeSamplingMCCFRSolver
+    const double eps = s->cfg.epsilon;
+    if (use_lds) {
+      static bool os_attr_set = false;
+      if (!os_attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_os_mccfr<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        os_attr_set = true;
+      }
+      k_os_mccfr<true><<<dim3(static_cast<unsigned>(blocks)), dim3(256), lds, st>>>(
+          s->tree(), s->regrets(), s->dreg(), s->dpol(), seed, first_trajectory, trajectories, eps);
+    } else {
+      k_os_mccfr<false><<<dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st>>>(
+          s->tree(), s->regrets(), s->dreg(), s->dpol(), seed, first_trajectory, trajectories, eps);
+    }
+    OSG_HIP(hipGetLastError());
+    return OSG_OK;
+  }
   if (use_lds) {
     static bool attr_set = false;
     if (!attr_set) {

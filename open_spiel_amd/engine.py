@@ -281,11 +281,13 @@ class TabularSolver:
     """
 
     def __init__(self, ctx, game_string, alternating_updates=True, linear_averaging=False,
-                 regret_matching_plus=False, mccfr=False, general_kernel=False):
+                 regret_matching_plus=False, mccfr=False, general_kernel=False, epsilon=0.6):
+        """mccfr: False (CFR family), True / "external" (ES-MCCFR) or "outcome" (OS-MCCFR, `epsilon`)."""
         self.ctx = ctx
         self.game_string = game_string
+        solver = {False: 0, True: 1, "external": 1, "outcome": 2}[mccfr]
         cfg = _abi.CfrCfg(int(alternating_updates), int(linear_averaging), int(regret_matching_plus),
-                          int(mccfr), 1 if general_kernel else 0)
+                          solver, float(epsilon), 1 if general_kernel else 0)
         h = C.c_void_p()
         check(lib().osg_cfr_create(ctx._h, game_string.encode(), C.byref(cfg), C.byref(h)))
         self._h = h

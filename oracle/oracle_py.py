@@ -302,7 +302,8 @@ class State:
                     root_visits=visits.value, children=ch[:n])
 
 
-SOLVER_KINDS = {"cfr": 0, "cfr_plus": 1, "mccfr_simple": 2, "mccfr_full": 3, "cfr_simultaneous": 4}
+SOLVER_KINDS = {"cfr": 0, "cfr_plus": 1, "mccfr_simple": 2, "mccfr_full": 3, "cfr_simultaneous": 4,
+                "mccfr_outcome": 5}
 
 
 class Solver:

@@ -475,6 +475,32 @@ class ExternalSamplingMCCFRSolver {  // external_sampling_mccfr.h:57-113
   std::shared_ptr<Policy> default_policy_;
 };
 
+class OutcomeSamplingMCCFRSolver {  // outcome_sampling_mccfr.h:40-107
+ public:
+  static constexpr double kInitialTableValues = 0.000001;
+  static constexpr double kDefaultEpsilon = 0.6;
+  OutcomeSamplingMCCFRSolver(const Game& game, double epsilon = kDefaultEpsilon, int seed = -1);
+  void RunIteration();  // one SampleEpisode per player (outcome_sampling_mccfr.cc:67-74)
+  // One episode driven by an explicit uniform source (replay of a device trajectory).  The
+  // reference draws the action from absl::discrete_distribution (stream unpinned); here it is
+  // the first index whose cumulative sample probability exceeds z.
+  double SampleEpisodeWith(State* state, Player update_player, const std::function<double()>& next_z,
+                           double my_reach, double opp_reach, double sample_reach);
+  CFRInfoStateValuesTable& InfoStateValuesTable() { return info_states_; }
+  std::shared_ptr<Policy> AveragePolicy() const {
+    return std::make_shared<CFRAveragePolicy>(info_states_, default_policy_);
+  }
+
+ private:
+  std::vector<double> SamplePolicy(const CFRInfoStateValues& info_state) const;  // :111-118
+  std::shared_ptr<const Game> game_;
+  double epsilon_;
+  CFRInfoStateValuesTable info_states_;
+  std::mt19937 rng_;
+  std::uniform_real_distribution<double> dist_;
+  std::shared_ptr<Policy> default_policy_;
+};
+
 // ---------------------------------------------------------------------------
 // The CFR judge (algorithms/expected_returns.cc, best_response.cc,
 // tabular_exploitability.cc)

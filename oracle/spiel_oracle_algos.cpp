@@ -610,6 +610,83 @@ void ExternalSamplingMCCFRSolver::FullUpdateAverage(const State& state,
 }
 
 // ============================================================================
+// Outcome-sampling MCCFR (outcome_sampling_mccfr.cc)
+// ============================================================================
+OutcomeSamplingMCCFRSolver::OutcomeSamplingMCCFRSolver(const Game& game, double epsilon, int seed)
+    : game_(game.shared_from_this()),
+      epsilon_(epsilon),
+      rng_(seed >= 0 ? seed : 0),
+      dist_(0.0, 1.0),
+      default_policy_(std::make_shared<UniformPolicy>()) {}
+
+void OutcomeSamplingMCCFRSolver::RunIteration() {  // :67-74
+  auto next_z = [this]() { return dist_(rng_); };
+  for (Player p = 0; p < game_->NumPlayers(); ++p) {
+    std::unique_ptr<State> state = game_->NewInitialState();
+    SampleEpisodeWith(state.get(), p, next_z, 1.0, 1.0, 1.0);
+  }
+}
+
+std::vector<double> OutcomeSamplingMCCFRSolver::SamplePolicy(const CFRInfoStateValues& info_state) const {
+  std::vector<double> policy = info_state.current_policy;  // :111-118
+  for (size_t i = 0; i < policy.size(); ++i)
+    policy[i] = epsilon_ * 1.0 / policy.size() + (1 - epsilon_) * policy[i];
+  return policy;
+}
+
+double OutcomeSamplingMCCFRSolver::SampleEpisodeWith(State* state, Player update_player,
+                                                     const std::function<double()>& next_z, double my_reach,
+                                                     double opp_reach, double sample_reach) {
+  // outcome_sampling_mccfr.cc:141-241, Baseline() == 0 (vanilla outcome sampling, :120-124).
+  if (state->IsTerminal()) return state->PlayerReturn(update_player);
+  if (state->IsChanceNode()) {
+    std::pair<Action, double> outcome = SampleAction(state->ChanceOutcomes(), next_z());
+    state->ApplyAction(outcome.first);
+    return SampleEpisodeWith(state, update_player, next_z, my_reach, outcome.second * opp_reach,
+                             outcome.second * sample_reach);
+  }
+  const Player player = state->CurrentPlayer();
+  const std::string key = state->InformationStateString(player);
+  const std::vector<Action> legal = state->LegalActions();
+  auto ins = info_states_.insert({key, CFRInfoStateValues(legal, kInitialTableValues)});
+  CFRInfoStateValues copy = ins.first->second;
+  copy.ApplyRegretMatching();
+  const std::vector<double> sample_policy = player == update_player ? SamplePolicy(copy) : copy.current_policy;
+  const double z = next_z();
+  int sampled = static_cast<int>(legal.size()) - 1;
+  double acc = 0.0;
+  for (size_t a = 0; a < legal.size(); ++a) {
+    if (z >= acc && z < acc + sample_policy[a]) { sampled = static_cast<int>(a); break; }
+    acc += sample_policy[a];
+  }
+  state->ApplyAction(legal[sampled]);
+  const double child_value = SampleEpisodeWith(
+      state, update_player, next_z,
+      player == update_player ? my_reach * copy.current_policy[sampled] : my_reach,
+      player == update_player ? opp_reach : opp_reach * copy.current_policy[sampled],
+      sample_reach * sample_policy[sampled]);
+  std::vector<double> child_values(legal.size(), 0);
+  for (size_t a = 0; a < legal.size(); ++a) {  // BaselineCorrectedChildValue with baseline 0 (:126-139)
+    const double baseline = 0;
+    child_values[a] = static_cast<int>(a) == sampled ? baseline + (child_value - baseline) / sample_policy[a] : baseline;
+  }
+  double value_estimate = 0;
+  for (size_t a = 0; a < legal.size(); ++a) value_estimate += copy.current_policy[a] * child_values[a];
+  if (player == update_player) {
+    CFRInfoStateValues& row = info_states_[key];
+    row.ApplyRegretMatching();
+    const double cf_value = value_estimate * opp_reach / sample_reach;
+    for (size_t a = 0; a < legal.size(); ++a) {
+      const double cf_action_value = child_values[a] * opp_reach / sample_reach;
+      row.cumulative_regrets[a] += (cf_action_value - cf_value);
+    }
+    for (size_t a = 0; a < legal.size(); ++a)
+      row.cumulative_policy[a] += my_reach * row.current_policy[a] / sample_reach;
+  }
+  return value_estimate;
+}
+
+// ============================================================================
 // The judge: expected returns, best response, NashConv, exploitability
 // ============================================================================
 static double ProbOf(const ActionsAndProbs& ap, Action a) {

@@ -23,8 +23,13 @@ struct CfrH {
   std::shared_ptr<const Game> game;
   std::unique_ptr<CFRSolverBase> cfr;
   std::unique_ptr<ExternalSamplingMCCFRSolver> mccfr;
+  std::unique_ptr<OutcomeSamplingMCCFRSolver> osmccfr;
   CFRInfoStateValuesTable& Table() {
-    return cfr ? cfr->InfoStateValuesTable() : mccfr->InfoStateValuesTable();
+    return cfr ? cfr->InfoStateValuesTable()
+               : (mccfr ? mccfr->InfoStateValuesTable() : osmccfr->InfoStateValuesTable());
+  }
+  std::shared_ptr<Policy> Average() const {
+    return cfr ? cfr->AveragePolicy() : (mccfr ? mccfr->AveragePolicy() : osmccfr->AveragePolicy());
   }
 };
 int CopyStr(const std::string& s, char* buf, int cap) {
@@ -347,7 +352,7 @@ int osgo_mcts_selfplay(void* g, double uct_c, int max_simulations, int n_rollout
 // CFR / MCCFR
 // ---------------------------------------------------------------------------
 // kind: 0 CFRSolver, 1 CFRPlusSolver, 2 ES-MCCFR(simple), 3 ES-MCCFR(full),
-// 4 CFRSolverBase(simultaneous updates, no linear avg, no RM+)
+// 4 CFRSolverBase(simultaneous updates, no linear avg, no RM+), 5 OS-MCCFR(epsilon 0.6)
 void* osgo_cfr_create(void* g, int kind, int seed) {
   try {
     auto* h = new CfrH;
@@ -355,6 +360,8 @@ void* osgo_cfr_create(void* g, int kind, int seed) {
     if (kind == 0) h->cfr = std::make_unique<CFRSolver>(*h->game);
     else if (kind == 1) h->cfr = std::make_unique<CFRPlusSolver>(*h->game);
     else if (kind == 4) h->cfr = std::make_unique<CFRSolverBase>(*h->game, false, false, false);
+    else if (kind == 5) h->osmccfr = std::make_unique<OutcomeSamplingMCCFRSolver>(
+             *h->game, OutcomeSamplingMCCFRSolver::kDefaultEpsilon, seed);
     else h->mccfr = std::make_unique<ExternalSamplingMCCFRSolver>(
              *h->game, seed, kind == 3 ? AverageType::kFull : AverageType::kSimple);
     return h;
@@ -369,7 +376,8 @@ int osgo_cfr_iterate(void* h, int iters) {
     auto* c = static_cast<CfrH*>(h);
     for (int i = 0; i < iters; ++i) {
       if (c->cfr) c->cfr->EvaluateAndUpdatePolicy();
-      else c->mccfr->RunIteration();
+      else if (c->mccfr) c->mccfr->RunIteration();
+      else c->osmccfr->RunIteration();
     }
     return 0;
   });
@@ -383,15 +391,21 @@ int osgo_cfr_iterate(void* h, int iters) {
 int osgo_mccfr_minibatch(void* h, uint64_t seed, int64_t first, int64_t count) {
   return Guard([&] {
     auto* c = static_cast<CfrH*>(h);
-    ORACLE_CHECK(c->mccfr);
-    CFRInfoStateValuesTable& table = c->mccfr->InfoStateValuesTable();
+    ORACLE_CHECK(c->mccfr || c->osmccfr);
+    CFRInfoStateValuesTable& table = c->Table();
     const int P = c->game->NumPlayers();
     std::map<std::string, CFRInfoStateValues> delta;  // regrets / cum_policy hold the summed increments
     for (int64_t g = first; g < first + count; ++g) {
       const CFRInfoStateValuesTable frozen = table;
       CounterRng rng(seed, static_cast<uint64_t>(g), 0);
-      c->mccfr->UpdateRegretsWith(*c->game->NewInitialState(), static_cast<Player>(g % P),
-                                  [&rng]() { return rng.Unit(); });
+      if (c->mccfr) {
+        c->mccfr->UpdateRegretsWith(*c->game->NewInitialState(), static_cast<Player>(g % P),
+                                    [&rng]() { return rng.Unit(); });
+      } else {
+        std::unique_ptr<State> episode = c->game->NewInitialState();
+        c->osmccfr->SampleEpisodeWith(episode.get(), static_cast<Player>(g % P), [&rng]() { return rng.Unit(); },
+                                      1.0, 1.0, 1.0);
+      }
       for (const auto& kv : table) {
         auto fz = frozen.find(kv.first);
         const size_t n = kv.second.legal_actions.size();
@@ -474,7 +488,7 @@ int osgo_cfr_eval(void* h, int which, double* out) {
       ORACLE_CHECK(c->cfr);
       pol = c->cfr->CurrentPolicy();
     } else {
-      pol = c->cfr ? c->cfr->AveragePolicy() : c->mccfr->AveragePolicy();
+      pol = c->Average();
     }
     *out = which == 1 ? Exploitability(*c->game, *pol) : NashConv(*c->game, *pol);
     return 0;
@@ -484,7 +498,7 @@ int osgo_cfr_eval(void* h, int which, double* out) {
 int osgo_cfr_expected_returns(void* h, double* out) {
   return Guard([&] {
     auto* c = static_cast<CfrH*>(h);
-    std::shared_ptr<Policy> pol = c->cfr ? c->cfr->AveragePolicy() : c->mccfr->AveragePolicy();
+    std::shared_ptr<Policy> pol = c->Average();
     std::vector<double> v = ExpectedReturns(*c->game->NewInitialState(), *pol);
     for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
     return 0;

@@ -287,3 +287,12 @@ def test_random_sim_invariants(oracle, game):
     assert np.isfinite(rec["obs"]).all()
     if rec["info"] is not None:
         assert np.isfinite(rec["info"]).all()
+
+
+def test_outcome_sampling_mccfr_bounds(oracle):
+    """outcome_sampling_mccfr_test.cc:36-48,86-88: 10000 iterations, seed 230398247: NashConv kuhn <= 0.17,
+    leduc <= 3.07 (the action draw uses a CDF scan instead of absl::discrete_distribution)."""
+    for game, bound in (("kuhn_poker", 0.17), ("leduc_poker", 3.07)):
+        s = oracle.Solver(oracle.Game(game), "mccfr_outcome", seed=230398247)
+        s.iterate(10000)
+        assert s.nash_conv() <= bound

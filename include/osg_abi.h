@@ -197,7 +197,9 @@ typedef struct {
                                wave-parallel random fill).  The two layouts define their
                                random streams differently (see osg_common.h), so results
                                are reproducible per layout, not across layouts.      */
-  int32_t reserved;
+  int32_t child_selection_policy;  /* ChildSelectionPolicy (mcts.h:148): 0 UCT (mcts.cc:90-101),
+                               1 PUCT (mcts.cc:103-112) with the evaluator's prior — uniform over
+                               the legal actions for RandomRolloutEvaluator (mcts.cc:74-87)        */
 } osg_mcts_cfg;
 /* Outputs (host or device by on_host; any may be NULL):
  *   best_action [n] i32            SearchNode::BestChild().action (mcts.cc:127-143)

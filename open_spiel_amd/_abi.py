@@ -49,7 +49,7 @@ class MctsCfg(C.Structure):
         ("seed", C.c_uint64),
         ("index_offset", C.c_int64),
         ("layout", C.c_int32),
-        ("reserved", C.c_int32),
+        ("child_selection_policy", C.c_int32),
     ]
 
 

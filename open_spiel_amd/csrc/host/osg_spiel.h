@@ -328,13 +328,18 @@ struct SearchNode {  // mcts.h:114-146 (root + its children, as MCTSearch's call
   }
 };
 
+enum class ChildSelectionPolicy { UCT, PUCT };  // mcts.h:148
+
 class MCTSBot {  // mcts.h:149-220
  public:
+  // Dirichlet noise, dont_return_chance_node and max_wall_clock_time of the reference's constructor
+  // (mcts.h:161-169) are host-side options of a single search and are not offered by the batch kernels.
   MCTSBot(const Game& game, std::shared_ptr<Evaluator> evaluator, double uct_c, int max_simulations,
-          int64_t max_memory_mb, bool solve, int seed, bool /*verbose*/)
+          int64_t max_memory_mb, bool solve, int seed, bool /*verbose*/,
+          ChildSelectionPolicy child_selection_policy = ChildSelectionPolicy::UCT)
       : evaluator_(std::move(evaluator)), uct_c_(uct_c), max_simulations_(max_simulations),
         max_memory_mb_(max_memory_mb), solve_(solve), seed_(seed), num_actions_(game.NumDistinctActions()),
-        num_players_(game.NumPlayers()) {
+        num_players_(game.NumPlayers()), policy_(child_selection_policy) {
     rollout_ = dynamic_cast<RandomRolloutEvaluator*>(evaluator_.get());
     if (!rollout_) SpielFatalError("the device MCTSBot needs a RandomRolloutEvaluator");
   }
@@ -387,6 +392,7 @@ class MCTSBot {  // mcts.h:149-220
     cfg.max_nodes = static_cast<int32_t>(std::min<int64_t>(nodes, 1 << 24));
     cfg.seed = static_cast<uint64_t>(seed_);
     cfg.index_offset = searches_;
+    cfg.child_selection_policy = policy_ == ChildSelectionPolicy::PUCT ? 1 : 0;
     return cfg;
   }
   std::vector<double> Zerosum(double v, Player p) const {  // 2-player zero-sum outcome vector
@@ -405,6 +411,7 @@ class MCTSBot {  // mcts.h:149-220
   bool solve_;
   int seed_;
   int num_actions_, num_players_;
+  ChildSelectionPolicy policy_;
   int64_t searches_ = 0;
 };
 

@@ -149,13 +149,19 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def_readonly("children", &SearchNode::children)
       .def("best_child", &SearchNode::BestChild);
 
+  py::enum_<ChildSelectionPolicy>(m, "ChildSelectionPolicy")  // bots.cc:113-117
+      .value("UCT", ChildSelectionPolicy::UCT)
+      .value("PUCT", ChildSelectionPolicy::PUCT);
   py::class_<MCTSBot>(m, "MCTSBot")  // bots.cc:133-149
       .def(py::init([](std::shared_ptr<Game> game, std::shared_ptr<Evaluator> evaluator, double uct_c,
-                       int max_simulations, int64_t max_memory_mb, bool solve, int seed, bool verbose) {
-             return new MCTSBot(*game, std::move(evaluator), uct_c, max_simulations, max_memory_mb, solve, seed, verbose);
+                       int max_simulations, int64_t max_memory_mb, bool solve, int seed, bool verbose,
+                       ChildSelectionPolicy policy) {
+             return new MCTSBot(*game, std::move(evaluator), uct_c, max_simulations, max_memory_mb, solve, seed, verbose,
+                                policy);
            }),
            py::arg("game"), py::arg("evaluator"), py::arg("uct_c"), py::arg("max_simulations"),
-           py::arg("max_memory_mb"), py::arg("solve"), py::arg("seed"), py::arg("verbose"))
+           py::arg("max_memory_mb"), py::arg("solve"), py::arg("seed"), py::arg("verbose"),
+           py::arg("child_selection_policy") = ChildSelectionPolicy::UCT)
       .def("step", &MCTSBot::Step, py::arg("state"), py::call_guard<py::gil_scoped_release>())
       .def("mcts_search", &MCTSBot::MCTSearch, py::arg("state"), py::call_guard<py::gil_scoped_release>())
       .def("step_batch", &MCTSBot::StepBatch, py::arg("states"), py::call_guard<py::gil_scoped_release>());

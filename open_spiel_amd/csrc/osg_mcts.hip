@@ -91,11 +91,15 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
       } else {  // arg-max of UCTValue, first maximum wins (mcts.cc:324-341, 90-101)
         double best = -INFINITY;
         const double logn = log_table[cnt];
+        const bool puct = cfg.child_selection_policy == 1;
+        const double prior = 1.0 / c;                              // Prior(): uniform over the legal actions
+        const double sqrt_n = sqrt(static_cast<double>(cnt));
         for (int k = 0; k < c; ++k) {
           const uint32_t cm = META(first + k);
           const uint32_t cc = COUNT(first + k);
           double v;
           if (m_has_outcome(cm)) v = outcome_value<kBoard>(cm, cc, TOTAL(first + k), m_player(cm));
+          else if (puct) v = (cc != 0 ? TOTAL(first + k) / cc : 0.0) + cfg.uct_c * prior * sqrt_n / (cc + 1);  // mcts.cc:103-112
           else if (cc == 0) v = INFINITY;
           else v = TOTAL(first + k) / cc + cfg.uct_c * sqrt(logn / cc);
           if (v > best) { best = v; chosen = first + k; }
@@ -231,6 +235,8 @@ extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_i
   if (layout == 0)  // auto: the wave layout where its parallel playout applies (hex without the swap rule)
     layout = (d.game_kind == kHex && d.num_distinct_actions == d.obs_shape[1] * d.obs_shape[2]) ? 2 : 1;
   if (layout != 1 && layout != 2) return set_error(OSG_ERR_INVALID, "osg_mcts_cfg.layout must be 0, 1 or 2");
+  if (cfg.child_selection_policy != 0 && cfg.child_selection_policy != 1)
+    return set_error(OSG_ERR_INVALID, "osg_mcts_cfg.child_selection_policy must be 0 (UCT) or 1 (PUCT)");
   const int64_t n = roots->n;
   const int A = d.num_distinct_actions;
   const int widest = A > d.max_chance_outcomes ? A : d.max_chance_outcomes;

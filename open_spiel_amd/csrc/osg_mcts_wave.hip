@@ -308,14 +308,16 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
           }
         }
         bool t0, t1;  // the candidates holding the maximum value
+        const bool puct = cfg.child_selection_policy == 1;
         const uint64_t u0 = __ballot(unvisited[0]), u1 = __ballot(unvisited[1]);
-        if ((u0 | u1) != 0ull) {
+        if (!puct && (u0 | u1) != 0ull) {
           // Some child has never been visited: its value is +infinity (mcts.cc:95), so the maximum is
           // +infinity whatever the others score — no UCT arithmetic needed at this node.
           t0 = unvisited[0];
           t1 = unvisited[1];
         } else {
           const double logn = log_table[cnt];
+          const double prior = 1.0 / c, sqrt_n = sqrt(static_cast<double>(cnt));  // PUCT only
           double v2[2];
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
@@ -324,6 +326,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
             if (k < c) {
               const double ct = TOTAL[first + k];
               if (m_has_outcome(cm2[j])) v2[j] = outcome_value<kBoard>(cm2[j], cc2[j], ct, m_player(cm2[j]));
+              else if (puct) v2[j] = (cc2[j] != 0 ? ct / cc2[j] : 0.0) + cfg.uct_c * prior * sqrt_n / (cc2[j] + 1);
               else v2[j] = ct / cc2[j] + cfg.uct_c * sqrt(logn / cc2[j]);
             }
           }

@@ -257,11 +257,12 @@ class StateBatch:
         return (total, steps) if want_steps else total
 
     def mcts_search(self, uct_c=2.0, max_simulations=1024, n_rollouts=1, solve=False, max_nodes=0,
-                    seed=0, index_offset=0, layout=0):
-        """MCTSBot.mcts_search for every root.  layout: 0 auto, 1 lane per root, 2 wave per root."""
+                    seed=0, index_offset=0, layout=0, puct=False):
+        """MCTSBot.mcts_search for every root.  layout: 0 auto, 1 lane per root, 2 wave per root;
+        puct: ChildSelectionPolicy.PUCT instead of UCT."""
         A = self.num_distinct_actions
         cfg = _abi.MctsCfg(uct_c, max_simulations, n_rollouts, int(solve), max_nodes, seed, index_offset,
-                           int(layout), 0)
+                           int(layout), 1 if puct else 0)
         best = self._dev((self.n,), torch.int32)
         visits = self._dev((self.n, A), torch.int32)
         reward = self._dev((self.n, A), torch.float64)

@@ -286,7 +286,7 @@ class State:
         return [out[i] for i in range(n)]
 
     def mcts_search(self, uct_c, max_simulations, n_rollouts, max_memory_mb, solve, seed,
-                    counter_root=-1, counter_seed=0, counter_layout=1):
+                    counter_root=-1, counter_seed=0, counter_layout=1, puct=False):
         best = C.c_int64(0)
         root_outcome = C.c_double(0)
         visits = C.c_int(0)
@@ -297,7 +297,7 @@ class State:
                                           C.byref(best), C.byref(root_outcome),
                                           _ptr(ch, C.c_double), cap, C.byref(visits),
                                           C.c_int64(counter_root), C.c_uint64(counter_seed),
-                                          int(counter_layout)))
+                                          int(counter_layout), int(puct)))
         return dict(best_action=best.value, root_outcome=root_outcome.value,
                     root_visits=visits.value, children=ch[:n])
 

@@ -295,12 +295,12 @@ int osgo_mcts_search(void* s, double uct_c, int max_simulations, int n_rollouts,
                      int64_t max_memory_mb, int solve, int seed,
                      int64_t* best_action, double* root_outcome,
                      double* out_children, int cap, int* root_visits,
-                     int64_t counter_root, uint64_t counter_seed, int counter_layout) {
+                     int64_t counter_root, uint64_t counter_seed, int counter_layout, int puct) {
   return Guard([&] {
     const State& st = *static_cast<StateH*>(s)->state;
     auto ev = std::make_shared<RandomRolloutEvaluator>(n_rollouts, seed);
     MCTSBot bot(*st.GetGame(), ev, uct_c, max_simulations, max_memory_mb,
-                solve != 0, seed, false);
+                solve != 0, seed, false, puct ? ChildSelectionPolicy::PUCT : ChildSelectionPolicy::UCT);
     if (counter_root >= 0)
       bot.UseCounterStreams(counter_seed, static_cast<uint64_t>(counter_root), n_rollouts,
                             counter_layout);

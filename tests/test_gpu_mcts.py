@@ -99,6 +99,36 @@ def test_mcts_replay_parity(oracle, ctx, game, n, sims, n_rollouts, solve, max_s
     assert checked >= n // 3
 
 
+@pytest.mark.parametrize("layout", [1, 2])
+@pytest.mark.parametrize("game,n,sims,n_rollouts,solve,max_stop", [
+    ("tic_tac_toe", 48, 150, 2, True, 5), ("connect_four", 32, 120, 1, False, 20),
+    ("hex(board_size=5)", 32, 200, 1, True, 14), ("leduc_poker", 32, 100, 1, False, 7),
+])
+def test_mcts_puct_replay_parity(oracle, ctx, game, n, sims, n_rollouts, solve, max_stop, layout):
+    """ChildSelectionPolicy::PUCT (mcts.cc:103-112) with the rollout evaluator's uniform prior."""
+    min_stop = 2 if "poker" in game else 0
+    og, roots, hists = _roots(oracle, ctx, game, n, 23, max_stop, min_stop)
+    seed, offset = 0xABCDEF, 500
+    res = roots.mcts_search(uct_c=1.5, max_simulations=sims, n_rollouts=n_rollouts, solve=solve, seed=seed,
+                            index_offset=offset, layout=layout, puct=True)
+    best = res["best_action"].cpu().numpy()
+    visits = res["child_visits"].cpu().numpy()
+    reward = res["child_reward"].cpu().numpy()
+    checked = 0
+    for i in range(n):
+        st = _oracle_state(og, hists[i])
+        if st.is_chance_node():
+            continue
+        want = st.mcts_search(1.5, sims, n_rollouts, 4096, solve, 0, counter_root=offset + i, counter_seed=seed,
+                              counter_layout=layout, puct=True)
+        for a, cnt, tot, _ in want["children"]:
+            assert visits[i, int(a)] == cnt and reward[i, int(a)] == tot, f"{game} root {i} action {int(a)}"
+        if len(want["children"]):
+            assert best[i] == want["best_action"]
+        checked += 1
+    assert checked >= n // 3
+
+
 def _ttt_batch(ctx, moves, n=4):
     import torch
     import open_spiel_amd as osa

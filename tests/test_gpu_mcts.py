@@ -57,6 +57,7 @@ def _oracle_state(og, hist):
     ("hex(num_cols=3,num_rows=4)", 32, 150, 1, True, 6),
     ("hex", 8, 300, 1, False, 60),
     ("tic_tac_toe", 32, 150, 70, True, 4),
+    ("tic_tac_toe", 12, 1000, 20, True, 0),   # BASELINE configs[0]: MCTSBot(RandomRolloutEvaluator(20), 1000 sims) from the start
     ("kuhn_poker(players=3)", 48, 120, 1, False, 6),
 ])
 def test_mcts_replay_parity(oracle, ctx, game, n, sims, n_rollouts, solve, max_stop, layout):

@@ -25,6 +25,7 @@ GAMES = [
     "kuhn_poker",
     "kuhn_poker(players=3)",
     "kuhn_poker(players=5)",
+    "kuhn_poker(players=10)",                # the largest the reference allows (kuhn_poker.h kMaxPlayers)
     "leduc_poker",
     "leduc_poker(players=3)",
     "leduc_poker(action_mapping=True)",
@@ -254,3 +255,24 @@ def test_random_steps_counters(ctx):
     steps, episodes = counters.tolist()
     assert steps == 64 * (1 << 12)
     assert episodes > 0  # 64 plies always finishes at least one 42-ply game
+
+
+@pytest.mark.parametrize("game", ["connect_four", "hex(board_size=9)", "leduc_poker", "tic_tac_toe"])
+@pytest.mark.parametrize("n", [1, 2, 63, 65])
+def test_tiny_and_ragged_batches(oracle, ctx, game, n):
+    """Batch sizes around the wave / pair boundaries (the connect_four fast path handles pairs; odd
+    sizes take the generic kernel): fused step and tensor pack still agree with the oracle."""
+    import torch
+    import open_spiel_amd as osa
+    og = oracle.Game(game)
+    rec = og.random_playouts(5, n, want_obs=True)
+    a, b = osa.StateBatch(ctx, game, n), osa.StateBatch(ctx, game, n)
+    for t in range(min(og.max_plies, 12)):
+        acts = rec["actions"][:, t]
+        a8 = torch.from_numpy(np.where(acts < 0, 255, acts).astype(np.uint8)).cuda()
+        _, status = a.step(a8, dst=b)
+        st = status.cpu().numpy()
+        np.testing.assert_array_equal((st & 0x80) != 0, rec["terminal"][:, t + 1] != 0)
+        got = b.observation_tensor(0).cpu().numpy()
+        np.testing.assert_array_equal(got, rec["obs"][:, t + 1, 0])
+        a, b = b, a

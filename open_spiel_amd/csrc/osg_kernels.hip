@@ -679,6 +679,11 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
     OSG_DISPATCH(b->spec, k_observation<G, 16><<<dim3(grid_for(b->n * chunks)), dim3(kBlock), 0, ctx->stream>>>(P,
                                               static_cast<const typename G::word_t*>(b->d_words), b->n, size, chunks,
                                               player, which, d_out));
+  } else if (b->spec.desc.game_kind == kLeduc) {  // bit-packed state: decode it once per 16 floats, not per 4
+    const int chunks = (size + 15) / 16;
+    OSG_DISPATCH(b->spec, k_observation<G, 16><<<dim3(grid_for(b->n * chunks)), dim3(kBlock), 0, ctx->stream>>>(P,
+                                              static_cast<const typename G::word_t*>(b->d_words), b->n, size, chunks,
+                                              player, which, d_out));
   } else {
     const int chunks = (size + 3) / 4;
     OSG_DISPATCH(b->spec, k_observation<G, 4><<<dim3(grid_for(b->n * chunks)), dim3(kBlock), 0, ctx->stream>>>(P,

@@ -516,23 +516,31 @@ struct HexT {
     const Bits a = (mag == 3 || mag == 4) ? band(own, s.ea) : bandn(own, s.ea);
     return (mag == 2 || mag == 4) ? band(a, s.eb) : bandn(a, s.eb);
   }
+  // Walks the 9-plane tensor cell by cell: the plane's membership mask sits in a one-word shift
+  // register (bit 0 = the current cell), refilled every 32 cells and recomputed at a plane boundary.
   struct ObsCursor {
     Bits m;
+    uint32_t cur;
     int plane, cell, idx;
+    OSG_D static uint32_t word(const Bits& b, int i) {  // static selects keep Bits in registers
+      uint32_t v = 0;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) v |= (i == k) ? b.w[k] : 0u;
+      return v;
+    }
     OSG_D void init(const Params& p, const State& s, int /*player*/, int /*which*/, int idx0) {
       idx = idx0;
       plane = idx0 / p.cells;
       cell = idx0 - plane * p.cells;
       m = p.plain_obs ? zero() : plane_mask(p, s, plane);
+      cur = word(m, cell >> 5) >> (cell & 31);
     }
     OSG_D float next(const Params& p, const State& s, int player, int which) {
       if (p.plain_obs) return obs_at(p, s, player, which, idx++);
-      const float v = test(m, cell) ? 1.0f : 0.0f;
-      if (++cell == p.cells) {
-        cell = 0;
-        ++plane;
-        m = plane_mask(p, s, plane);
-      }
+      // The kernel cuts chunks at plane boundaries (segment = plane), so a cursor stays in one plane.
+      const float v = static_cast<float>(cur & 1u);
+      cur >>= 1;
+      if ((++cell & 31) == 0) cur = word(m, cell >> 5);
       return v;
     }
   };

@@ -182,39 +182,91 @@ k_step_c4x2(typename G::Params p, const uint64_t* __restrict__ src, uint64_t* __
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));  // rows are only 4-byte aligned
 template <class G, int F>  // F = floats per lane (a multiple of 4): 4 for short rows, 16 for long ones
 __global__ void __launch_bounds__(kBlock)
-k_observation(typename G::Params p, const typename G::word_t* base, int64_t n, int size, int chunks, int player,
-              int which, float* out) {
+k_observation(typename G::Params p, const typename G::word_t* base, int64_t n, int size, int seg_len, int chunks_per_seg,
+              int player, int which, float* out) {
+  // A row of `size` floats is a sequence of segments of `seg_len` floats (hex: one per tensor plane; other
+  // games: the whole row); chunks never cross a segment, so a cursor never changes plane mid-chunk.
   // One 64-bit division per workgroup on wave-uniform values; lanes divide a small offset in 32 bits.
+  // F == 16: a lane's four float4 pieces are 64 bytes apart from its neighbour's, so storing them directly
+  // would make every store instruction hit 64 different cache lines with 16 bytes each.  Instead each
+  // wavefront stages its 4 KiB through LDS and writes it back piece-major: instruction j stores pieces
+  // 64 j ... 64 j + 63, i.e. whole consecutive chunks -> whole cache lines.
+  __shared__ float4 s_tile[F >= 16 ? kBlock * (F / 4) : 1];
+  __shared__ float* s_dst[F >= 16 ? kBlock : 1];
+  __shared__ int s_count[F >= 16 ? kBlock : 1];
+  const int chunks = (size / seg_len) * chunks_per_seg;  // per state
   const int64_t tb = static_cast<int64_t>(blockIdx.x) * kBlock;
   const int64_t ib = tb / chunks;
   const uint32_t local = static_cast<uint32_t>(tb - ib * chunks) + threadIdx.x;
   const uint32_t il = local / static_cast<uint32_t>(chunks);
   const int64_t i = ib + il;
-  if (i >= n) return;
-  const int idx = static_cast<int>(local - il * static_cast<uint32_t>(chunks)) * F;
-  const typename G::State s = G::load(p, base, n, i);
-  int pl = player;
-  if (pl < 0) {
-    pl = G::current_player(p, s);
-    if (pl < 0) pl = 0;
+  const bool live = i < n;
+  int count = 0;
+  float* dst = out;
+  float4 q[F / 4];
+#pragma unroll
+  for (int g = 0; g < F / 4; ++g) q[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (live) {
+    const uint32_t c_in_state = local - il * static_cast<uint32_t>(chunks);
+    const uint32_t seg = c_in_state / static_cast<uint32_t>(chunks_per_seg);
+    const int off = static_cast<int>(c_in_state - seg * chunks_per_seg) * F;  // offset inside the segment
+    const int idx = static_cast<int>(seg) * seg_len + off;
+    const typename G::State s = G::load(p, base, n, i);
+    int pl = player;
+    if (pl < 0) {
+      pl = G::current_player(p, s);
+      if (pl < 0) pl = 0;
+    }
+    typename G::ObsCursor cur;
+    cur.init(p, s, pl, which, idx);
+    count = seg_len - off;  // >= 1; only the last chunk of a segment has fewer than F
+    if (count > F) count = F;
+    dst = out + i * size + idx;
+#pragma unroll
+    for (int g = 0; g < F / 4; ++g) {
+      if (4 * g >= count) break;
+      float v[4];  // indexed by unrolled constants only: stays in registers
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (4 * g + k < count) ? cur.next(p, s, pl, which) : 0.0f;
+      q[g] = make_float4(v[0], v[1], v[2], v[3]);
+    }
   }
-  typename G::ObsCursor cur;
-  cur.init(p, s, pl, which, idx);
-  const int count = size - idx;  // >= 1; only the last chunk of a row has fewer than F
-  float* dst = out + i * size + idx;
-#pragma unroll
-  for (int g = 0; g < F / 4; ++g) {
-    if (4 * g >= count) break;
-    float v[4];  // indexed by unrolled constants only: stays in registers
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (4 * g + k < count) ? cur.next(p, s, pl, which) : 0.0f;
-    if (4 * g + 4 <= count) {
-      float4u q = {v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<float4u*>(dst + 4 * g) = q;
+  if (F == 4) {
+    if (!live) return;
+    if (count >= 4) {
+      float4u w = {q[0].x, q[0].y, q[0].z, q[0].w};
+      *reinterpret_cast<float4u*>(dst) = w;
     } else {
-      dst[4 * g] = v[0];
-      if (4 * g + 1 < count) dst[4 * g + 1] = v[1];
-      if (4 * g + 2 < count) dst[4 * g + 2] = v[2];
+      dst[0] = q[0].x;
+      if (count > 1) dst[1] = q[0].y;
+      if (count > 2) dst[2] = q[0].z;
+    }
+    return;
+  }
+  // ---- F >= 16: piece-major write-back through LDS (per wavefront; no workgroup barrier needed, every
+  //      wave only reads what it wrote itself) ----
+  const int lane = threadIdx.x & 63, wave0 = threadIdx.x & ~63;
+#pragma unroll
+  for (int g = 0; g < F / 4; ++g) s_tile[(wave0 + lane) * (F / 4) + g] = q[g];
+  s_dst[threadIdx.x] = dst;
+  s_count[threadIdx.x] = live ? count : 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int j = 0; j < F / 4; ++j) {
+    const int piece = j * 64 + lane;        // piece index inside the wave's tile
+    const int src_lane = piece / (F / 4), part = piece % (F / 4);
+    const float4 w4 = s_tile[(wave0 + src_lane) * (F / 4) + part];
+    float* d = s_dst[wave0 + src_lane] + 4 * part;
+    const int left = s_count[wave0 + src_lane] - 4 * part;
+    if (left >= 4) {
+      float4u w = {w4.x, w4.y, w4.z, w4.w};
+      *reinterpret_cast<float4u*>(d) = w;
+    } else if (left > 0) {
+      d[0] = w4.x;
+      if (left > 1) d[1] = w4.y;
+      if (left > 2) d[2] = w4.z;
     }
   }
 }
@@ -674,21 +726,24 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
   if (b->spec.desc.game_kind == kC4 && b->spec.c4_std) {
     k_observation_c4std<<<dim3(grid_for(b->n * 18)), dim3(kBlock), 0, ctx->stream>>>(
         b->spec.c4, static_cast<const uint64_t*>(b->d_words), b->n, player, d_out);
-  } else if (size >= 64) {  // long rows: 16 floats per lane amortise the per-lane setup
-    const int chunks = (size + 15) / 16;
-    OSG_DISPATCH(b->spec, k_observation<G, 16><<<dim3(grid_for(b->n * chunks)), dim3(kBlock), 0, ctx->stream>>>(P,
-                                              static_cast<const typename G::word_t*>(b->d_words), b->n, size, chunks,
-                                              player, which, d_out));
-  } else if (b->spec.desc.game_kind == kLeduc) {  // bit-packed state: decode it once per 16 floats, not per 4
-    const int chunks = (size + 15) / 16;
-    OSG_DISPATCH(b->spec, k_observation<G, 16><<<dim3(grid_for(b->n * chunks)), dim3(kBlock), 0, ctx->stream>>>(P,
-                                              static_cast<const typename G::word_t*>(b->d_words), b->n, size, chunks,
-                                              player, which, d_out));
   } else {
-    const int chunks = (size + 3) / 4;
-    OSG_DISPATCH(b->spec, k_observation<G, 4><<<dim3(grid_for(b->n * chunks)), dim3(kBlock), 0, ctx->stream>>>(P,
-                                              static_cast<const typename G::word_t*>(b->d_words), b->n, size, chunks,
-                                              player, which, d_out));
+    // Segment = one tensor plane for hex's 9-plane layout (the cursor's mask is per plane), else the row.
+    int seg_len = size;
+    if (b->spec.desc.game_kind == kHex && d.obs_shape[0] == 9) seg_len = d.obs_shape[1] * d.obs_shape[2];
+    const bool wide = size >= 64 || b->spec.desc.game_kind == kLeduc;  // 16+ floats per lane: long rows, or a
+                                                                      // bit-packed state worth decoding once
+    // (32 floats per lane was measured too: fewer, fuller chunks for hex(9) but 15 % slower — the
+    // 28 KiB LDS tile per workgroup costs more occupancy than the fuller chunks give back.)
+    const int F = wide ? 16 : 4;
+    const int cps = (seg_len + F - 1) / F;
+    const int64_t lanes = b->n * (size / seg_len) * cps;
+#define OSG_OBS_LAUNCH(FF)                                                                                          \
+  OSG_DISPATCH(b->spec, k_observation<G, FF><<<dim3(grid_for(lanes)), dim3(kBlock), 0, ctx->stream>>>(P,            \
+                                            static_cast<const typename G::word_t*>(b->d_words), b->n, size, seg_len, \
+                                            cps, player, which, d_out))
+    if (F == 16) OSG_OBS_LAUNCH(16);
+    else OSG_OBS_LAUNCH(4);
+#undef OSG_OBS_LAUNCH
   }
   OSG_HIP(hipGetLastError());
   if (on_host) {

@@ -236,7 +236,7 @@ struct SmallGlobal {  // global-memory homes of the same arrays, for trees too b
   const int32_t* info_player;  // [I]
 };
 
-template <bool kLds>
+template <bool kLds, bool kOwner>
 __global__ void __launch_bounds__(1024)
 k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg) {
   extern __shared__ double smem[];
@@ -300,40 +300,63 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
   }
   __syncthreads();
 
+  // kOwner (whole tree no larger than the workgroup): thread t owns history t, decision history
+  // (member) t and infostate t for the whole launch; their descriptors are hoisted into registers so
+  // that inside the iteration loop every phase is one LDS round trip instead of a chain of four.
+  int o_k = kTerminalNode, o_fc = 0, o_nc = 0, o_row = 0, o_lvl = -1;
+  int b_h = 0, b_pl = -1, b_i = 0, b_n = 0, b_fc = 0, b_e0 = 0, b_e1 = 0;
+  int c_n = 0, c_pl = -1, c_m0 = 0, c_m1 = 0;
+  if (kOwner) {
+    if (tid < H) {
+      const int mt = meta[tid];
+      o_k = mt & 3;
+      o_fc = first_child[tid];
+      o_nc = (mt >> 2) & 0xFF;
+      o_row = o_k == kDecisionNode ? info[tid] * A : 0;
+      for (int l = 0; l < t.D; ++l)
+        if (tid >= level_off[l] && tid < level_off[l + 1]) o_lvl = l;
+    }
+    if (tid < M) {
+      b_h = mem[tid];
+      b_pl = ((meta[b_h] >> 10) & 15) - 1;
+      b_i = info[b_h];
+      b_n = nact[b_i];
+      b_fc = first_child[b_h];
+      b_e0 = path_off[tid];
+      b_e1 = path_off[tid + 1];
+    }
+    if (tid < I) {
+      c_n = nact[tid];
+      c_pl = info_player[tid];
+      c_m0 = mem_off[tid];
+      c_m1 = mem_off[tid + 1];
+    }
+  }
+
   const int passes = cfg.alternating_updates ? P : 1;
   for (int it = 0; it < iters; ++it) {
     const int iteration = iteration0 + it + 1;
     for (int pass = 0; pass < passes; ++pass) {
       const int upd = cfg.alternating_updates ? pass : -1;
-      // ---- A: values, bottom-up.  Alternating passes only need the updating player's value. ----
       const int q0 = upd >= 0 ? upd : 0, q1 = upd >= 0 ? upd + 1 : P;
-      for (int l = t.D - 2; l >= 0; --l) {  // the last level holds terminals only
-        for (int h = level_off[l] + tid; h < level_off[l + 1]; h += nt) {
-          const int mt = meta[h];
-          const int k = mt & 3;
-          if (k == kTerminalNode) continue;
-          const int fc = first_child[h], nc = (mt >> 2) & 0xFF;
-          const int row = k == kDecisionNode ? info[h] * A : 0;
-          for (int q = q0; q < q1; ++q) {
-            double v = 0.0;
-            for (int a = 0; a < nc; ++a) {
-              const double pr = k == kChanceNode ? edge_prob[fc + a] : cur[row + a];
-              v += pr * value[(fc + a) * P + q];
-            }
-            value[h * P + q] = v;
+      // value of one non-terminal history from its children (cfr.cc:443-469)
+      auto do_node = [&](int h, int k, int fc, int nc, int row) {
+        for (int q = q0; q < q1; ++q) {
+          double v = 0.0;
+          for (int a = 0; a < nc; ++a) {
+            const double pr = k == kChanceNode ? edge_prob[fc + a] : cur[row + a];
+            v += pr * value[(fc + a) * P + q];
           }
+          value[h * P + q] = v;
         }
-        __syncthreads();
-      }
-      // ---- B: per decision history, reach from the root path, then its update terms ----
-      for (int m = tid; m < M; m += nt) {
-        const int h = mem[m];
-        const int pl = ((meta[h] >> 10) & 15) - 1;
-        if (upd >= 0 && pl != upd) { skip[m] = 1; continue; }
+      };
+      // one decision history: reach from the root path, then its regret / average-policy terms
+      auto do_member = [&](int m, int h, int pl, int i, int n, int fc, int e0, int e1) {
+        if (upd >= 0 && pl != upd) { skip[m] = 1; return; }
         double reach[kMaxPlayers + 1];
 #pragma unroll
         for (int q = 0; q <= kMaxPlayers; ++q) reach[q] = 1.0;
-        for (int e = path_off[m]; e < path_off[m + 1]; ++e) {
+        for (int e = e0; e < e1; ++e) {
           const int code = path[e];
           const int slot = (code >> 24) & 0xF, idx = code & 0x7FFFFF;
           const double pr = ((code >> 23) & 1) ? edge_prob[idx] : cur[idx];
@@ -349,21 +372,18 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
           else if (q <= P) cf_reach *= reach[q];  // CounterFactualReachProb (cfr.cc:309-318), chance slot = P
         }
         skip[m] = pruned ? 1 : 0;
-        if (pruned) continue;
-        const int i = info[h], n = nact[i], fc = first_child[h];
+        if (pruned) return;
         const double vh = value[h * P + pl];
         for (int a = 0; a < n; ++a) {
           dreg[m * A + a] = cf_reach * (value[(fc + a) * P + pl] - vh);
           const double pol = cur[i * A + a];
           dpol[m * A + a] = cfg.linear_averaging ? iteration * self_reach * pol : self_reach * pol;
         }
-      }
-      __syncthreads();
-      // ---- C: fold per infostate (members are in the reference's DFS order), then match ----
-      for (int i = tid; i < I; i += nt) {
-        if (upd >= 0 && info_player[i] != upd) continue;
-        const int n = nact[i];
-        for (int m = mem_off[i]; m < mem_off[i + 1]; ++m) {
+      };
+      // one infostate: fold its members' terms in DFS order, RM+ clamp, regret matching
+      auto do_info = [&](int i, int n, int pl, int m0, int m1) {
+        if (upd >= 0 && pl != upd) return;
+        for (int m = m0; m < m1; ++m) {
           if (skip[m]) continue;
           for (int a = 0; a < n; ++a) {
             regrets[i * A + a] += dreg[m * A + a];
@@ -374,6 +394,36 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
           for (int a = 0; a < n; ++a)
             if (regrets[i * A + a] < 0) regrets[i * A + a] = 0;
         regret_match_row(regrets + i * A, cur + i * A, n);
+      };
+      // ---- A: values, bottom-up.  Alternating passes only need the updating player's value. ----
+      for (int l = t.D - 2; l >= 0; --l) {  // the last level holds terminals only
+        if (kOwner) {
+          if (o_lvl == l && o_k != kTerminalNode) do_node(tid, o_k, o_fc, o_nc, o_row);
+        } else {
+          for (int h = level_off[l] + tid; h < level_off[l + 1]; h += nt) {
+            const int mt = meta[h];
+            const int k = mt & 3;
+            if (k == kTerminalNode) continue;
+            do_node(h, k, first_child[h], (mt >> 2) & 0xFF, k == kDecisionNode ? info[h] * A : 0);
+          }
+        }
+        __syncthreads();
+      }
+      // ---- B: per decision history ----
+      if (kOwner) {
+        if (tid < M) do_member(tid, b_h, b_pl, b_i, b_n, b_fc, b_e0, b_e1);
+      } else {
+        for (int m = tid; m < M; m += nt) {
+          const int h = mem[m], i = info[h];
+          do_member(m, h, ((meta[h] >> 10) & 15) - 1, i, nact[i], first_child[h], path_off[m], path_off[m + 1]);
+        }
+      }
+      __syncthreads();
+      // ---- C: per infostate ----
+      if (kOwner) {
+        if (tid < I) do_info(tid, c_n, c_pl, c_m0, c_m1);
+      } else {
+        for (int i = tid; i < I; i += nt) do_info(i, nact[i], info_player[i], mem_off[i], mem_off[i + 1]);
       }
       __syncthreads();
     }
@@ -1086,8 +1136,11 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
     if (e != hipSuccess) { osg_cfr_destroy(s); return set_error(OSG_ERR_NOMEM, hipGetErrorString(e)); }
     if (!index_fits) s->eval_ok = false;
     if (s->small_tree) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cfr_small<true>),
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cfr_small<true, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->small_lds_bytes));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cfr_small<true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->small_lds_bytes));
       if (e != hipSuccess) { (void)hipGetLastError(); s->small_tree = false; }
     }
   }
@@ -1130,12 +1183,17 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
     SmallTree st{s->d_path_off, s->d_path, M, static_cast<int>(s->path.size())};
     SmallGlobal sg{s->d_value, s->d_node_delta, s->d_node_delta + static_cast<size_t>(M) * s->A, s->d_skip,
                    s->d_meta32, s->d_info_player32};
-    if (s->small_tree)
-      k_cfr_small<true><<<dim3(1), dim3(threads), s->small_lds_bytes, s->ctx->stream>>>(s->tree(), st, sg, tb, iters,
-                                                                                       s->iteration, s->cfg);
-    else
-      k_cfr_small<false><<<dim3(1), dim3(threads), 0, s->ctx->stream>>>(s->tree(), st, sg, tb, iters, s->iteration,
-                                                                        s->cfg);
+    if (s->small_tree && s->H <= 1024) {  // one thread per history: descriptors live in registers
+      const int owner_threads = std::max(64, ((s->H + 63) / 64) * 64);
+      k_cfr_small<true, true><<<dim3(1), dim3(owner_threads), s->small_lds_bytes, s->ctx->stream>>>(
+          s->tree(), st, sg, tb, iters, s->iteration, s->cfg);
+    } else if (s->small_tree) {
+      k_cfr_small<true, false><<<dim3(1), dim3(threads), s->small_lds_bytes, s->ctx->stream>>>(s->tree(), st, sg, tb,
+                                                                                              iters, s->iteration, s->cfg);
+    } else {
+      k_cfr_small<false, false><<<dim3(1), dim3(threads), 0, s->ctx->stream>>>(s->tree(), st, sg, tb, iters,
+                                                                               s->iteration, s->cfg);
+    }
   } else if (s->lds_resident) {
     k_cfr<true><<<dim3(1), dim3(threads), s->lds_bytes, s->ctx->stream>>>(s->tree(), tb, s->d_reach, s->d_value, iters,
                                                                          s->iteration, s->cfg);

@@ -236,7 +236,7 @@ struct SmallGlobal {  // global-memory homes of the same arrays, for trees too b
   const int32_t* info_player;  // [I]
 };
 
-template <bool kLds, bool kOwner>
+template <bool kLds, bool kOwner, int kSlots>  // kSlots >= P + 1 reach slots kept in registers
 __global__ void __launch_bounds__(1024)
 k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg) {
   extern __shared__ double smem[];
@@ -353,20 +353,20 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
       // one decision history: reach from the root path, then its regret / average-policy terms
       auto do_member = [&](int m, int h, int pl, int i, int n, int fc, int e0, int e1) {
         if (upd >= 0 && pl != upd) { skip[m] = 1; return; }
-        double reach[kMaxPlayers + 1];
+        double reach[kSlots];
 #pragma unroll
-        for (int q = 0; q <= kMaxPlayers; ++q) reach[q] = 1.0;
+        for (int q = 0; q < kSlots; ++q) reach[q] = 1.0;
         for (int e = e0; e < e1; ++e) {
           const int code = path[e];
           const int slot = (code >> 24) & 0xF, idx = code & 0x7FFFFF;
           const double pr = ((code >> 23) & 1) ? edge_prob[idx] : cur[idx];
 #pragma unroll
-          for (int q = 0; q <= kMaxPlayers; ++q) reach[q] = (q == slot) ? reach[q] * pr : reach[q];
+          for (int q = 0; q < kSlots; ++q) reach[q] = (q == slot) ? reach[q] * pr : reach[q];
         }
         bool pruned = true;  // AllPlayersHaveZeroReachProb (cfr.cc:471-479)
         double self_reach = 0.0, cf_reach = 1.0;
 #pragma unroll
-        for (int q = 0; q <= kMaxPlayers; ++q) {
+        for (int q = 0; q < kSlots; ++q) {
           if (q < P) pruned &= (reach[q] == 0.0);
           if (q == pl) self_reach = reach[q];
           else if (q <= P) cf_reach *= reach[q];  // CounterFactualReachProb (cfr.cc:309-318), chance slot = P
@@ -1136,11 +1136,16 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
     if (e != hipSuccess) { osg_cfr_destroy(s); return set_error(OSG_ERR_NOMEM, hipGetErrorString(e)); }
     if (!index_fits) s->eval_ok = false;
     if (s->small_tree) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cfr_small<true, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->small_lds_bytes));
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cfr_small<true, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->small_lds_bytes));
+      const void* variants[] = {reinterpret_cast<const void*>(&k_cfr_small<true, false, 3>),
+                                reinterpret_cast<const void*>(&k_cfr_small<true, false, 4>),
+                                reinterpret_cast<const void*>(&k_cfr_small<true, false, kMaxPlayers + 1>),
+                                reinterpret_cast<const void*>(&k_cfr_small<true, true, 3>),
+                                reinterpret_cast<const void*>(&k_cfr_small<true, true, 4>),
+                                reinterpret_cast<const void*>(&k_cfr_small<true, true, kMaxPlayers + 1>)};
+      e = hipSuccess;
+      for (const void* f : variants)
+        if (e == hipSuccess)
+          e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->small_lds_bytes));
       if (e != hipSuccess) { (void)hipGetLastError(); s->small_tree = false; }
     }
   }
@@ -1183,17 +1188,21 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
     SmallTree st{s->d_path_off, s->d_path, M, static_cast<int>(s->path.size())};
     SmallGlobal sg{s->d_value, s->d_node_delta, s->d_node_delta + static_cast<size_t>(M) * s->A, s->d_skip,
                    s->d_meta32, s->d_info_player32};
+#define OSG_CFR_SMALL(LDS, OWNER, THREADS, SHMEM)                                                                  \
+  do {                                                                                                              \
+    if (s->P == 2) k_cfr_small<LDS, OWNER, 3><<<dim3(1), dim3(THREADS), SHMEM, s->ctx->stream>>>(s->tree(), st, sg, tb, iters, s->iteration, s->cfg); \
+    else if (s->P == 3) k_cfr_small<LDS, OWNER, 4><<<dim3(1), dim3(THREADS), SHMEM, s->ctx->stream>>>(s->tree(), st, sg, tb, iters, s->iteration, s->cfg); \
+    else k_cfr_small<LDS, OWNER, kMaxPlayers + 1><<<dim3(1), dim3(THREADS), SHMEM, s->ctx->stream>>>(s->tree(), st, sg, tb, iters, s->iteration, s->cfg); \
+  } while (0)
     if (s->small_tree && s->H <= 1024) {  // one thread per history: descriptors live in registers
       const int owner_threads = std::max(64, ((s->H + 63) / 64) * 64);
-      k_cfr_small<true, true><<<dim3(1), dim3(owner_threads), s->small_lds_bytes, s->ctx->stream>>>(
-          s->tree(), st, sg, tb, iters, s->iteration, s->cfg);
+      OSG_CFR_SMALL(true, true, owner_threads, s->small_lds_bytes);
     } else if (s->small_tree) {
-      k_cfr_small<true, false><<<dim3(1), dim3(threads), s->small_lds_bytes, s->ctx->stream>>>(s->tree(), st, sg, tb,
-                                                                                              iters, s->iteration, s->cfg);
+      OSG_CFR_SMALL(true, false, threads, s->small_lds_bytes);
     } else {
-      k_cfr_small<false, false><<<dim3(1), dim3(threads), 0, s->ctx->stream>>>(s->tree(), st, sg, tb, iters,
-                                                                               s->iteration, s->cfg);
+      OSG_CFR_SMALL(false, false, threads, 0);
     }
+#undef OSG_CFR_SMALL
   } else if (s->lds_resident) {
     k_cfr<true><<<dim3(1), dim3(threads), s->lds_bytes, s->ctx->stream>>>(s->tree(), tb, s->d_reach, s->d_value, iters,
                                                                          s->iteration, s->cfg);

@@ -167,6 +167,23 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
                   "config": {"workload": f"kuhn_poker CFRSolver, {iters} EvaluateAndUpdatePolicy in one launch, "
                                          "58 histories / 12 infostates, LDS-resident"}}
     del solver
+    # the same kernel with one workgroup per independent solver (random initial regrets): what the GPU does
+    # with this config when asked for many solves at once
+    replicas = 4096
+    many = osa.TabularSolver(ctx, "kuhn_poker", replicas=replicas, random_initial_regrets=True, seed=SEED,
+                             replica_offset=rank * replicas)
+    many.evaluate_and_update_policy(50)
+    fence()
+    rep_iters = 2000
+    t0 = time.perf_counter()
+    many.evaluate_and_update_policy(rep_iters)
+    fence()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    out["cfr"]["replicas"] = {"value": replicas * world * rep_iters / dt, "unit": "solver-iterations/s",
+                              "seconds": dt, "scaling": "weak",
+                              "workload": f"{replicas} independent kuhn_poker CFRSolver replicas per GPU (random initial "
+                                          f"regrets), {rep_iters} iterations each, one workgroup per replica"}
+    del many
 
     # ---- config 5: leduc_poker external-sampling MCCFR, 2^24 trajectories, mini-batches of 2^20 ----
     solver = osa.TabularSolver(ctx, "leduc_poker", mccfr=True)

@@ -229,6 +229,14 @@ typedef struct {
                                     (outcome_sampling_mccfr.h:43 kDefaultEpsilon = 0.6)          */
   int32_t kernel;                /* 0 auto; 1 force the general level-synchronous kernel (k_cfr)
                                     even where the all-in-LDS small-tree kernel applies      */
+  int32_t replicas;              /* 0 or 1: one solver.  B > 1: B independent solvers of the same
+                                    game advanced together, one workgroup each (CFR family, trees
+                                    that fit LDS); select one with osg_cfr_select_replica         */
+  int32_t random_initial_regrets;/* CFRSolverBase ctor (cfr.h:190-196): regrets start at
+                                    0.001 * U[0,1) (cfr.cc:31,249-252) from the counter stream
+                                    (seed, replica_offset + replica, infostate, action)           */
+  uint64_t seed;
+  int64_t replica_offset;        /* global index of replica 0 (sharding replicas over GPUs)       */
 } osg_cfr_cfg;
 /* Replaces CFRSolverBase::CFRSolverBase + InitializeInfostateNodes
  * (cfr.cc:191-261): expands the whole game tree level by level ON THE DEVICE
@@ -244,6 +252,9 @@ int osg_cfr_reset(osg_cfr* s);
 int osg_cfr_iterate(osg_cfr* s, int iters);
 /* Number of EvaluateAndUpdatePolicy calls (or MCCFR mini-batches) done so far. */
 int osg_cfr_iteration(const osg_cfr* s);
+/* Number of replicas, and which one the table accessors / osg_cfr_evaluate_policy / upload act on. */
+int osg_cfr_replicas(const osg_cfr* s);
+int osg_cfr_select_replica(osg_cfr* s, int replica);
 /* Restores the iteration counter of a deserialised solver (cfr.h:318-323 deserialisation ctor). */
 int osg_cfr_set_iteration(osg_cfr* s, int iteration);
 /* ExternalSamplingMCCFRSolver::RunIteration (external_sampling_mccfr.cc:71-186,

@@ -61,6 +61,10 @@ class CfrCfg(C.Structure):
         ("solver", C.c_int32),
         ("epsilon", C.c_double),
         ("kernel", C.c_int32),
+        ("replicas", C.c_int32),
+        ("random_initial_regrets", C.c_int32),
+        ("seed", C.c_uint64),
+        ("replica_offset", C.c_int64),
     ]
 
 
@@ -105,6 +109,8 @@ SIGNATURES = {
     "osg_cfr_reset": (INT, [VP]),
     "osg_cfr_iteration": (INT, [VP]),
     "osg_cfr_set_iteration": (INT, [VP, INT]),
+    "osg_cfr_replicas": (INT, [VP]),
+    "osg_cfr_select_replica": (INT, [VP, INT]),
     "osg_mccfr_sample": (INT, [VP, U64, I64, I64]),
     "osg_cfr_upload_tables": (INT, [VP, VP, VP, VP]),
     "osg_mccfr_iterate": (INT, [VP, U64, I64, I64]),

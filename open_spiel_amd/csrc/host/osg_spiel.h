@@ -495,7 +495,12 @@ class DeviceTabularSolver {
  protected:
   // mccfr: 0 CFR family, 1 external sampling, 2 outcome sampling (with `epsilon`)
   DeviceTabularSolver(const Game& game, bool alternating, bool linear, bool rm_plus, int mccfr, double epsilon = 0.6) {
-    osg_cfr_cfg cfg{alternating ? 1 : 0, linear ? 1 : 0, rm_plus ? 1 : 0, mccfr, epsilon, 0};
+    osg_cfr_cfg cfg{};
+    cfg.alternating_updates = alternating ? 1 : 0;
+    cfg.linear_averaging = linear ? 1 : 0;
+    cfg.regret_matching_plus = rm_plus ? 1 : 0;
+    cfg.solver = mccfr;
+    cfg.epsilon = epsilon;
     Check(osg_cfr_create(game.Ctx(), game.GameString().c_str(), &cfg, &s_));
     Check(osg_cfr_sizes(s_, sizes_));
     num_players_ = game.NumPlayers();

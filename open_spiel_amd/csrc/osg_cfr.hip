@@ -242,6 +242,10 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
   extern __shared__ double smem[];
   const int P = t.P, A = t.A, H = t.H, I = t.I, M = st.M, IA = t.I * t.A;
   const int tid = threadIdx.x, nt = blockDim.x;
+  // replica = workgroup: tables of replica b live 5 * IA doubles further on (regrets | cum | cur | 2 deltas)
+  tb.regrets += static_cast<size_t>(blockIdx.x) * 5 * IA;
+  tb.cum += static_cast<size_t>(blockIdx.x) * 5 * IA;
+  tb.cur += static_cast<size_t>(blockIdx.x) * 5 * IA;
   double *value, *regrets, *cum, *cur, *dreg, *dpol;
   const double* edge_prob;
   const int32_t *first_child, *info, *meta, *mem, *mem_off, *path_off, *path, *nact, *info_player, *level_off;
@@ -857,11 +861,16 @@ struct osg_cfr {
     t.term_ret = d_term_ret; t.mem_off = d_mem_off; t.mem = d_mem; t.nact = d_nact; t.info_player = d_info_player;
     return t;
   }
-  double* regrets() const { return d_tables; }
-  double* cum() const { return d_tables + static_cast<size_t>(I) * A; }
-  double* cur() const { return d_tables + 2 * static_cast<size_t>(I) * A; }
-  double* dreg() const { return d_tables + 3 * static_cast<size_t>(I) * A; }
-  double* dpol() const { return d_tables + 4 * static_cast<size_t>(I) * A; }
+  // Replicas: B independent solvers of the same tree (tables [B][5][I, A]); `selected` is the one the
+  // table accessors / evaluation look at.
+  int B = 1, selected = 0;
+  size_t replica_stride() const { return 5 * static_cast<size_t>(I) * A; }
+  double* replica_base(int r) const { return d_tables + static_cast<size_t>(r) * replica_stride(); }
+  double* regrets() const { return replica_base(selected); }
+  double* cum() const { return replica_base(selected) + static_cast<size_t>(I) * A; }
+  double* cur() const { return replica_base(selected) + 2 * static_cast<size_t>(I) * A; }
+  double* dreg() const { return replica_base(selected) + 3 * static_cast<size_t>(I) * A; }
+  double* dpol() const { return replica_base(selected) + 4 * static_cast<size_t>(I) * A; }
 };
 
 namespace {
@@ -1045,16 +1054,35 @@ int build_tree(osg_cfr* s, const char* game_string) {
 int init_tables(osg_cfr* s) {
   const int IA = s->I * s->A;
   hipStream_t st = s->ctx->stream;
-  OSG_HIP(hipMemsetAsync(s->d_tables, 0, sizeof(double) * 5 * IA, st));
-  std::vector<double> cur(IA, 0.0), init(IA, 0.0);
-  for (int i = 0; i < s->I; ++i)
-    for (int a = 0; a < s->nact[i]; ++a) {
-      cur[i * s->A + a] = 1.0 / s->nact[i];  // CFRInfoStateValues ctor (cfr.h:47-52)
-      init[i * s->A + a] = s->cfg.solver >= 1 ? kMccfrInit : 0.0;
+  const size_t stride = s->replica_stride();
+  std::vector<double> host(static_cast<size_t>(s->B) * stride, 0.0);
+  for (int r = 0; r < s->B; ++r) {
+    double* regrets = host.data() + r * stride;
+    double* cum = regrets + IA;
+    double* cur = cum + IA;
+    for (int i = 0; i < s->I; ++i) {
+      const int n = s->nact[i];
+      double sum_pos = 0.0;
+      for (int a = 0; a < n; ++a) {
+        double init = s->cfg.solver >= 1 ? kMccfrInit : 0.0;
+        if (s->cfg.random_initial_regrets) {
+          // CFRInfoStateValues(la, rng, kRandomInitialRegretsMagnitude = 0.001) (cfr.h:52-61, cfr.cc:31,249-252):
+          // regret = magnitude * U[0, 1); the reference draws from mt19937 + absl::Uniform (stream
+          // unpinned), here from the counter stream (seed, replica, infostate * Amax + action).
+          Rng rng(s->cfg.seed, static_cast<uint64_t>(s->cfg.replica_offset + r), static_cast<uint64_t>(i) * s->A + a);
+          init = 0.001 * rng.unit();
+        }
+        regrets[i * s->A + a] = init;
+        cum[i * s->A + a] = s->cfg.solver >= 1 ? kMccfrInit : 0.0;
+        if (init > 0) sum_pos += init;
+      }
+      for (int a = 0; a < n; ++a) {  // ApplyRegretMatching on the fresh row (uniform when all regrets are 0)
+        const double rg = regrets[i * s->A + a];
+        cur[i * s->A + a] = (s->cfg.random_initial_regrets && sum_pos > 0) ? (rg > 0 ? rg / sum_pos : 0.0) : 1.0 / n;
+      }
     }
-  OSG_HIP(hipMemcpyAsync(s->cur(), cur.data(), sizeof(double) * IA, hipMemcpyHostToDevice, st));
-  OSG_HIP(hipMemcpyAsync(s->regrets(), init.data(), sizeof(double) * IA, hipMemcpyHostToDevice, st));
-  OSG_HIP(hipMemcpyAsync(s->cum(), init.data(), sizeof(double) * IA, hipMemcpyHostToDevice, st));
+  }
+  OSG_HIP(hipMemcpyAsync(s->d_tables, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice, st));
   OSG_HIP(hipStreamSynchronize(st));
   s->iteration = 0;
   return OSG_OK;
@@ -1075,6 +1103,9 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
     delete s;
     return set_error(OSG_ERR_UNSUPPORTED, "tabular CFR needs information-state strings: kuhn_poker and leduc_poker only");
   }
+  s->B = s->cfg.replicas > 0 ? s->cfg.replicas : 1;
+  if (s->B > 1 && s->cfg.solver != 0) { delete s; return set_error(OSG_ERR_UNSUPPORTED, "replicas > 1: CFR family only"); }
+  if (s->B > (1 << 16)) { delete s; return set_error(OSG_ERR_INVALID, "osg_cfr_cfg.replicas must be <= 65536"); }
   if (s->cfg.solver < 0 || s->cfg.solver > 2) { delete s; return set_error(OSG_ERR_INVALID, "osg_cfr_cfg.solver must be 0, 1 or 2"); }
   if (s->cfg.solver == 2 && !(s->cfg.epsilon > 0.0 && s->cfg.epsilon <= 1.0)) {
     delete s;
@@ -1098,7 +1129,7 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
     return rc;
   }
   const size_t IA = static_cast<size_t>(s->I) * s->A;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_tables), sizeof(double) * 5 * std::max<size_t>(IA, 1));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->d_tables), sizeof(double) * s->B * 5 * std::max<size_t>(IA, 1));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_reach), sizeof(double) * s->H * (s->P + 1));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_value), sizeof(double) * s->H * s->P);
   if (e != hipSuccess) { osg_cfr_destroy(s); return set_error(OSG_ERR_NOMEM, hipGetErrorString(e)); }
@@ -1149,6 +1180,10 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
       if (e != hipSuccess) { (void)hipGetLastError(); s->small_tree = false; }
     }
   }
+  if (s->B > 1 && !s->small_tree) {
+    osg_cfr_destroy(s);
+    return set_error(OSG_ERR_UNSUPPORTED, "replicas > 1 need the all-in-LDS kernel (tree too large)");
+  }
   rc = init_tables(s);
   if (rc) { osg_cfr_destroy(s); return rc; }
   *out = s;
@@ -1182,6 +1217,11 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
   int threads = ((s->max_level_width + 63) / 64) * 64;
   threads = std::max(64, std::min(threads, 1024));
   Tables tb{s->regrets(), s->cum(), s->cur()};
+  if (s->B > 1) {  // all replicas advance together: workgroup b works on replica b's tables
+    double* base0 = s->replica_base(0);
+    tb = Tables{base0, base0 + static_cast<size_t>(s->I) * s->A, base0 + 2 * static_cast<size_t>(s->I) * s->A};
+  }
+  const unsigned grid_b = static_cast<unsigned>(s->B);
   if (s->path_kernel && s->cfg.kernel != 1) {
     // Path-based kernel: no top-down reach pass; all-in-LDS when the tree is small enough.
     const int M = static_cast<int>(s->mem.size());
@@ -1190,9 +1230,9 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
                    s->d_meta32, s->d_info_player32};
 #define OSG_CFR_SMALL(LDS, OWNER, THREADS, SHMEM)                                                                  \
   do {                                                                                                              \
-    if (s->P == 2) k_cfr_small<LDS, OWNER, 3><<<dim3(1), dim3(THREADS), SHMEM, s->ctx->stream>>>(s->tree(), st, sg, tb, iters, s->iteration, s->cfg); \
-    else if (s->P == 3) k_cfr_small<LDS, OWNER, 4><<<dim3(1), dim3(THREADS), SHMEM, s->ctx->stream>>>(s->tree(), st, sg, tb, iters, s->iteration, s->cfg); \
-    else k_cfr_small<LDS, OWNER, kMaxPlayers + 1><<<dim3(1), dim3(THREADS), SHMEM, s->ctx->stream>>>(s->tree(), st, sg, tb, iters, s->iteration, s->cfg); \
+    if (s->P == 2) k_cfr_small<LDS, OWNER, 3><<<dim3(grid_b), dim3(THREADS), SHMEM, s->ctx->stream>>>(s->tree(), st, sg, tb, iters, s->iteration, s->cfg); \
+    else if (s->P == 3) k_cfr_small<LDS, OWNER, 4><<<dim3(grid_b), dim3(THREADS), SHMEM, s->ctx->stream>>>(s->tree(), st, sg, tb, iters, s->iteration, s->cfg); \
+    else k_cfr_small<LDS, OWNER, kMaxPlayers + 1><<<dim3(grid_b), dim3(THREADS), SHMEM, s->ctx->stream>>>(s->tree(), st, sg, tb, iters, s->iteration, s->cfg); \
   } while (0)
     if (s->small_tree && s->H <= 1024) {  // one thread per history: descriptors live in registers
       const int owner_threads = std::max(64, ((s->H + 63) / 64) * 64);
@@ -1203,6 +1243,8 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
       OSG_CFR_SMALL(false, false, threads, 0);
     }
 #undef OSG_CFR_SMALL
+  } else if (s->B > 1) {
+    return set_error(OSG_ERR_UNSUPPORTED, "replicas > 1 are not available with the general kernel");
   } else if (s->lds_resident) {
     k_cfr<true><<<dim3(1), dim3(threads), s->lds_bytes, s->ctx->stream>>>(s->tree(), tb, s->d_reach, s->d_value, iters,
                                                                          s->iteration, s->cfg);
@@ -1342,6 +1384,12 @@ int osg_cfr_infostate_key(const osg_cfr* s, int64_t i, char* buf, int cap) {
 }
 
 int osg_cfr_iteration(const osg_cfr* s) { return s ? s->iteration : 0; }
+int osg_cfr_replicas(const osg_cfr* s) { return s ? s->B : 0; }
+int osg_cfr_select_replica(osg_cfr* s, int replica) {
+  if (!s || replica < 0 || replica >= s->B) return set_error(OSG_ERR_INVALID, "osg_cfr_select_replica: bad replica");
+  s->selected = replica;
+  return OSG_OK;
+}
 int osg_cfr_set_iteration(osg_cfr* s, int iteration) {
   if (!s || iteration < 0) return set_error(OSG_ERR_INVALID, "osg_cfr_set_iteration: bad argument");
   s->iteration = iteration;

@@ -282,13 +282,16 @@ class TabularSolver:
     """
 
     def __init__(self, ctx, game_string, alternating_updates=True, linear_averaging=False,
-                 regret_matching_plus=False, mccfr=False, general_kernel=False, epsilon=0.6):
+                 regret_matching_plus=False, mccfr=False, general_kernel=False, epsilon=0.6, replicas=1,
+                 random_initial_regrets=False, seed=0, replica_offset=0):
         """mccfr: False (CFR family), True / "external" (ES-MCCFR) or "outcome" (OS-MCCFR, `epsilon`)."""
         self.ctx = ctx
         self.game_string = game_string
         solver = {False: 0, True: 1, "external": 1, "outcome": 2}[mccfr]
         cfg = _abi.CfrCfg(int(alternating_updates), int(linear_averaging), int(regret_matching_plus),
-                          solver, float(epsilon), 1 if general_kernel else 0)
+                          solver, float(epsilon), 1 if general_kernel else 0, int(replicas),
+                          int(random_initial_regrets), int(seed), int(replica_offset))
+        self.replicas = int(replicas)
         h = C.c_void_p()
         check(lib().osg_cfr_create(ctx._h, game_string.encode(), C.byref(cfg), C.byref(h)))
         self._h = h
@@ -310,6 +313,10 @@ class TabularSolver:
 
     def reset(self):
         check(lib().osg_cfr_reset(self._h))
+
+    def select_replica(self, r):
+        """Which of the `replicas` independent solvers tables() / evaluate_policy() look at."""
+        check(lib().osg_cfr_select_replica(self._h, int(r)))
 
     @property
     def iteration(self):

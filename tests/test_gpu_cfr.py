@@ -321,3 +321,53 @@ def test_os_mccfr_rejects_bad_epsilon(ctx):
     import open_spiel_amd as osa
     with pytest.raises(osa.OsgError):
         osa.TabularSolver(ctx, "kuhn_poker", mccfr="outcome", epsilon=0.0)
+
+
+# ---- solver replicas: one workgroup per independent solver ------------------------------------------
+def test_replicas_are_independent_identical_solvers(ctx):
+    import open_spiel_amd as osa
+    one = osa.TabularSolver(ctx, "kuhn_poker")
+    many = osa.TabularSolver(ctx, "kuhn_poker", replicas=96)
+    one.evaluate_and_update_policy(40)
+    many.evaluate_and_update_policy(40)
+    want = one.tables()
+    for r in (0, 1, 37, 95):
+        many.select_replica(r)
+        got = many.tables()
+        for name in ("regrets", "cum_policy", "cur_policy"):
+            np.testing.assert_array_equal(got[name], want[name])
+    with pytest.raises(osa.OsgError):
+        many.select_replica(96)
+    with pytest.raises(osa.OsgError):
+        osa.TabularSolver(ctx, "leduc_poker", replicas=4)   # does not fit LDS: one solver per object
+    with pytest.raises(osa.OsgError):
+        osa.TabularSolver(ctx, "kuhn_poker", replicas=4, mccfr=True)
+
+
+def test_random_initial_regrets_replicas(ctx):
+    """CFRSolverBase(random_initial_regrets=true, seed) (cfr.h:190-196, cfr.cc:249-252): regrets start at
+    0.001 * U[0,1), the first policy is their regret matching; replica r of a batch equals a single solver
+    created with replica_offset = r; every replica still converges."""
+    import open_spiel_amd as osa
+    batch = osa.TabularSolver(ctx, "kuhn_poker", replicas=8, random_initial_regrets=True, seed=99)
+    t0 = []
+    for r in range(8):
+        batch.select_replica(r)
+        t = batch.tables()
+        n = t["nact"]
+        for i in range(len(n)):
+            reg = t["regrets"][i, :n[i]]
+            assert ((reg >= 0) & (reg < 0.001)).all()
+            np.testing.assert_allclose(t["cur_policy"][i, :n[i]], reg / reg.sum(), rtol=0, atol=1e-15)
+        t0.append(t["regrets"].copy())
+    assert not np.array_equal(t0[0], t0[1]), "replicas start from different regrets"
+    batch.evaluate_and_update_policy(300)
+    for r in (0, 5):
+        single = osa.TabularSolver(ctx, "kuhn_poker", random_initial_regrets=True, seed=99, replica_offset=r)
+        np.testing.assert_array_equal(single.tables()["regrets"], t0[r])
+        single.evaluate_and_update_policy(300)
+        batch.select_replica(r)
+        a, b = single.tables(), batch.tables()
+        for name in ("regrets", "cum_policy", "cur_policy"):
+            np.testing.assert_array_equal(a[name], b[name])
+        assert batch.exploitability() <= 0.05

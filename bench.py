@@ -62,10 +62,20 @@ def synth_batch(osa, torch, ctx, n, seed, index_offset):
 
 
 def host_threads():
+    """Worker threads for the CPU baseline: the cores this process may actually use — the affinity mask,
+    capped by the cgroup CPU quota (a container can see 256 CPUs and be allowed 16) and at 64."""
     try:
-        return max(1, min(len(os.sched_getaffinity(0)), 64))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return max(1, min(os.cpu_count() or 1, 64))
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
 
 
 def cpu_baseline():

@@ -589,27 +589,37 @@ int osgo_tree_census(void* g, int64_t* out) {
 int osgo_bench_env_steps(void* g, uint64_t seed, int64_t pool, int64_t total_steps,
                          int threads, double* secs, int64_t* units) {
   return Guard([&] {
-    const Game& game = *static_cast<GameH*>(g)->game;
-    std::vector<std::unique_ptr<State>> states(pool);
-    std::vector<Action> actions(pool);
-    for (int64_t i = 0; i < pool; ++i) {
-      CounterRng rng(seed, static_cast<uint64_t>(i));
-      for (;;) {
-        std::unique_ptr<State> s = game.NewInitialState();
-        int depth = static_cast<int>(rng.Below(36));
-        for (int t = 0; t < depth && !s->IsTerminal(); ++t) {
-          if (s->IsChanceNode()) {
-            s->ApplyAction(SampleAction(s->ChanceOutcomes(), rng.Unit()).first);
-          } else {
-            std::vector<Action> la = s->LegalActions();
-            s->ApplyAction(la[rng.Below(static_cast<uint32_t>(la.size()))]);
+    // One Game object per worker thread, as separate processes would have: every State holds a
+    // shared_ptr to its Game (spiel.h:906), and Clone() from many threads on ONE Game would
+    // serialise on that reference count instead of measuring the game logic.
+    const std::string game_string = static_cast<GameH*>(g)->game->ToString();
+    const int64_t per_thread = std::max<int64_t>(pool / threads, 1);
+    std::vector<std::shared_ptr<const Game>> games(threads);
+    std::vector<std::vector<std::unique_ptr<State>>> states(threads);
+    std::vector<std::vector<Action>> actions(threads);
+    for (int w = 0; w < threads; ++w) {
+      games[w] = LoadGame(game_string);
+      states[w].resize(per_thread);
+      actions[w].resize(per_thread);
+      for (int64_t j = 0; j < per_thread; ++j) {
+        CounterRng rng(seed, static_cast<uint64_t>(w * per_thread + j));
+        for (;;) {
+          std::unique_ptr<State> s = games[w]->NewInitialState();
+          int depth = static_cast<int>(rng.Below(36));
+          for (int t = 0; t < depth && !s->IsTerminal(); ++t) {
+            if (s->IsChanceNode()) {
+              s->ApplyAction(SampleAction(s->ChanceOutcomes(), rng.Unit()).first);
+            } else {
+              std::vector<Action> la = s->LegalActions();
+              s->ApplyAction(la[rng.Below(static_cast<uint32_t>(la.size()))]);
+            }
           }
+          if (s->IsTerminal()) continue;
+          std::vector<Action> la = s->LegalActions();
+          actions[w][j] = la[rng.Below(static_cast<uint32_t>(la.size()))];
+          states[w][j] = std::move(s);
+          break;
         }
-        if (s->IsTerminal()) continue;
-        std::vector<Action> la = s->LegalActions();
-        actions[i] = la[rng.Below(static_cast<uint32_t>(la.size()))];
-        states[i] = std::move(s);
-        break;
       }
     }
     std::vector<int64_t> done(threads, 0);
@@ -621,10 +631,10 @@ int osgo_bench_env_steps(void* g, uint64_t seed, int64_t pool, int64_t total_ste
         int64_t quota = total_steps / threads;
         double acc = 0;
         for (int64_t k = 0; k < quota; ++k) {
-          int64_t i = (k * threads + w) % pool;
-          std::unique_ptr<State> s = states[i]->Clone();
+          const int64_t i = k % per_thread;
+          std::unique_ptr<State> s = states[w][i]->Clone();
           std::vector<Action> la = s->LegalActions();
-          s->ApplyAction(actions[i]);
+          s->ApplyAction(actions[w][i]);
           acc += la.size() + s->IsTerminal() + s->Returns()[0] + s->CurrentPlayer();
           acc += s->LegalActions().size();
         }
@@ -645,13 +655,16 @@ int osgo_bench_env_steps(void* g, uint64_t seed, int64_t pool, int64_t total_ste
 int osgo_bench_playouts(void* g, uint64_t seed, int64_t sims, int threads,
                         double* secs, int64_t* moves) {
   return Guard([&] {
-    const Game& game = *static_cast<GameH*>(g)->game;
+    const std::string game_string = static_cast<GameH*>(g)->game->ToString();
+    std::vector<std::shared_ptr<const Game>> games(threads);  // one Game per thread (see osgo_bench_env_steps)
+    for (int w = 0; w < threads; ++w) games[w] = LoadGame(game_string);
     std::vector<int64_t> done(threads, 0);
     auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> workers;
     for (int w = 0; w < threads; ++w) {
       workers.emplace_back([&, w] {
         int64_t count = 0;
+        const Game& game = *games[w];
         for (int64_t k = w; k < sims; k += threads) {
           CounterRng rng(seed, static_cast<uint64_t>(k));
           std::unique_ptr<State> s = game.NewInitialState();
@@ -682,9 +695,12 @@ int osgo_bench_mcts(void* g, uint64_t seed, int roots, int depth_mod,
                     int max_simulations, int n_rollouts, double uct_c, int threads,
                     double* secs, int64_t* sims) {
   return Guard([&] {
-    const Game& game = *static_cast<GameH*>(g)->game;
+    const std::string game_string = static_cast<GameH*>(g)->game->ToString();
+    std::vector<std::shared_ptr<const Game>> games(threads);  // one Game per thread (see osgo_bench_env_steps)
+    for (int w = 0; w < threads; ++w) games[w] = LoadGame(game_string);
     std::vector<std::unique_ptr<State>> starts(roots);
     for (int i = 0; i < roots; ++i) {
+      const Game& game = *games[i % threads];  // root i is searched by thread i % threads
       CounterRng rng(seed, static_cast<uint64_t>(i));
       for (;;) {
         std::unique_ptr<State> s = game.NewInitialState();
@@ -706,7 +722,7 @@ int osgo_bench_mcts(void* g, uint64_t seed, int roots, int depth_mod,
         int64_t count = 0;
         for (int i = w; i < roots; i += threads) {
           auto ev = std::make_shared<RandomRolloutEvaluator>(n_rollouts, 42 + i);
-          MCTSBot bot(game, ev, uct_c, max_simulations, 1000, false, 42 + i, false);
+          MCTSBot bot(*games[w], ev, uct_c, max_simulations, 1000, false, 42 + i, false);
           std::unique_ptr<SearchNode> root = bot.MCTSearch(*starts[i]);
           count += root->explore_count;
         }
@@ -724,8 +740,12 @@ int osgo_bench_mcts(void* g, uint64_t seed, int roots, int depth_mod,
 // (d) solver iterations/s (kind as in osgo_cfr_create); one solver per thread.
 int osgo_bench_cfr(void* g, int kind, int iters, int threads, double* secs) {
   return Guard([&] {
-    std::vector<void*> hs(threads);
-    for (int w = 0; w < threads; ++w) hs[w] = osgo_cfr_create(g, kind, 1 + w);
+    const std::string game_string = static_cast<GameH*>(g)->game->ToString();
+    std::vector<void*> gs(threads), hs(threads);
+    for (int w = 0; w < threads; ++w) {  // one Game per thread (see osgo_bench_env_steps)
+      gs[w] = osgo_load_game(game_string.c_str());
+      hs[w] = osgo_cfr_create(gs[w], kind, 1 + w);
+    }
     auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> workers;
     for (int w = 0; w < threads; ++w)
@@ -734,6 +754,7 @@ int osgo_bench_cfr(void* g, int kind, int iters, int threads, double* secs) {
     auto t1 = std::chrono::steady_clock::now();
     *secs = std::chrono::duration<double>(t1 - t0).count();
     for (void* h : hs) osgo_cfr_free(h);
+    for (void* gg : gs) osgo_free_game(gg);
     return 0;
   });
 }

@@ -228,7 +228,8 @@ typedef struct {
   double epsilon;                /* solver 2 only: OutcomeSamplingMCCFRSolver's exploration
                                     (outcome_sampling_mccfr.h:43 kDefaultEpsilon = 0.6)          */
   int32_t kernel;                /* 0 auto; 1 force the general level-synchronous kernel (k_cfr)
-                                    even where the all-in-LDS small-tree kernel applies      */
+                                    even where the all-in-LDS small-tree kernel applies; 2 force the
+                                    full-grid phase kernels (auto for trees > 65536 histories)   */
   int32_t replicas;              /* 0 or 1: one solver.  B > 1: B independent solvers of the same
                                     game advanced together, one workgroup each (CFR family, trees
                                     that fit LDS); select one with osg_cfr_select_replica         */

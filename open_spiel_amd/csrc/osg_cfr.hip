@@ -442,6 +442,106 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
 }
 
 // ---------------------------------------------------------------------------
+// Large trees (3-player leduc: 1.8 M histories): the same three phases as k_cfr_small, but
+// every phase is a full-grid launch — one kernel per tree level for the values, one for the
+// per-history terms, one for the per-infostate fold — so the whole chip works on one tree and
+// the stream order provides the barriers.  Same additions in the same order: tables are
+// bit-identical with the single-workgroup kernels.
+// ---------------------------------------------------------------------------
+struct GridCfr {
+  Tree t;
+  const int32_t* path_off;
+  const int32_t* path;
+  const int32_t* meta;         // [H] kind | nchild << 2 | (actor + 1) << 10
+  const int32_t* info_player;  // [I]
+  double* value;               // [H, P]
+  double* dreg;                // [M, A]
+  double* dpol;                // [M, A]
+  int32_t* skip;               // [M]
+  Tables tb;
+  int M;
+};
+
+__global__ void __launch_bounds__(256) k_gcfr_init_values(GridCfr g) {
+  const int h = blockIdx.x * 256 + threadIdx.x;
+  if (h >= g.t.H) return;
+  for (int q = 0; q < g.t.P; ++q) g.value[h * g.t.P + q] = g.t.term_ret[h * g.t.P + q];
+}
+
+__global__ void __launch_bounds__(256) k_gcfr_level(GridCfr g, int begin, int end, int q0, int q1) {
+  const int h = begin + blockIdx.x * 256 + threadIdx.x;
+  if (h >= end) return;
+  const int mt = g.meta[h];
+  const int k = mt & 3;
+  if (k == kTerminalNode) return;
+  const int P = g.t.P, A = g.t.A;
+  const int fc = g.t.first_child[h], nc = (mt >> 2) & 0xFF;
+  const int row = k == kDecisionNode ? g.t.info[h] * A : 0;
+  for (int q = q0; q < q1; ++q) {
+    double v = 0.0;
+    for (int a = 0; a < nc; ++a) {
+      const double pr = k == kChanceNode ? g.t.edge_prob[fc + a] : g.tb.cur[row + a];
+      v += pr * g.value[(fc + a) * P + q];
+    }
+    g.value[h * P + q] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_gcfr_members(GridCfr g, int upd, int iteration, osg_cfr_cfg cfg) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= g.M) return;
+  const int P = g.t.P, A = g.t.A;
+  const int h = g.t.mem[m];
+  const int pl = ((g.meta[h] >> 10) & 15) - 1;
+  if (upd >= 0 && pl != upd) { g.skip[m] = 1; return; }
+  double reach[kMaxPlayers + 1];
+#pragma unroll
+  for (int q = 0; q <= kMaxPlayers; ++q) reach[q] = 1.0;
+  for (int e = g.path_off[m]; e < g.path_off[m + 1]; ++e) {
+    const int code = g.path[e];
+    const int slot = (code >> 24) & 0xF, idx = code & 0x7FFFFF;
+    const double pr = ((code >> 23) & 1) ? g.t.edge_prob[idx] : g.tb.cur[idx];
+#pragma unroll
+    for (int q = 0; q <= kMaxPlayers; ++q) reach[q] = (q == slot) ? reach[q] * pr : reach[q];
+  }
+  bool pruned = true;
+  double self_reach = 0.0, cf_reach = 1.0;
+#pragma unroll
+  for (int q = 0; q <= kMaxPlayers; ++q) {
+    if (q < P) pruned &= (reach[q] == 0.0);
+    if (q == pl) self_reach = reach[q];
+    else if (q <= P) cf_reach *= reach[q];
+  }
+  g.skip[m] = pruned ? 1 : 0;
+  if (pruned) return;
+  const int i = g.t.info[h], n = g.t.nact[i], fc = g.t.first_child[h];
+  const double vh = g.value[h * P + pl];
+  for (int a = 0; a < n; ++a) {
+    g.dreg[m * A + a] = cf_reach * (g.value[(fc + a) * P + pl] - vh);
+    const double pol = g.tb.cur[i * A + a];
+    g.dpol[m * A + a] = cfg.linear_averaging ? iteration * self_reach * pol : self_reach * pol;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_gcfr_fold(GridCfr g, int upd, osg_cfr_cfg cfg) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.t.I) return;
+  if (upd >= 0 && g.info_player[i] != upd) return;
+  const int A = g.t.A, n = g.t.nact[i];
+  for (int m = g.t.mem_off[i]; m < g.t.mem_off[i + 1]; ++m) {
+    if (g.skip[m]) continue;
+    for (int a = 0; a < n; ++a) {
+      g.tb.regrets[i * A + a] += g.dreg[m * A + a];
+      g.tb.cum[i * A + a] += g.dpol[m * A + a];
+    }
+  }
+  if (cfg.regret_matching_plus)
+    for (int a = 0; a < n; ++a)
+      if (g.tb.regrets[i * A + a] < 0) g.tb.regrets[i * A + a] = 0;
+  regret_match_row(g.tb.regrets + i * A, g.tb.cur + i * A, n);
+}
+
+// ---------------------------------------------------------------------------
 // Policy evaluation on the flattened tree: ExpectedReturns
 // (expected_returns.cc:34-130), TabularBestResponse (best_response.cc:194-227)
 // for every player, from which the host derives NashConv / Exploitability
@@ -1222,6 +1322,34 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
     tb = Tables{base0, base0 + static_cast<size_t>(s->I) * s->A, base0 + 2 * static_cast<size_t>(s->I) * s->A};
   }
   const unsigned grid_b = static_cast<unsigned>(s->B);
+  // Trees far beyond one workgroup: full-grid launches per phase (osg_cfr_cfg.kernel == 2 forces it).
+  const bool grid_path = s->path_kernel && s->B == 1 && (s->cfg.kernel == 2 || (s->cfg.kernel == 0 && s->H > 65536));
+  if (grid_path) {
+    const int M = static_cast<int>(s->mem.size());
+    GridCfr g;
+    g.t = s->tree(); g.path_off = s->d_path_off; g.path = s->d_path; g.meta = s->d_meta32;
+    g.info_player = s->d_info_player32; g.value = s->d_value; g.dreg = s->d_node_delta;
+    g.dpol = s->d_node_delta + static_cast<size_t>(M) * s->A; g.skip = s->d_skip; g.tb = tb; g.M = M;
+    hipStream_t st = s->ctx->stream;
+    auto blocks = [](int n) { return dim3(static_cast<unsigned>((n + 255) / 256)); };
+    k_gcfr_init_values<<<blocks(s->H), dim3(256), 0, st>>>(g);
+    const int passes = s->cfg.alternating_updates ? s->P : 1;
+    for (int it = 0; it < iters; ++it) {
+      for (int pass = 0; pass < passes; ++pass) {
+        const int upd = s->cfg.alternating_updates ? pass : -1;
+        const int q0 = upd >= 0 ? upd : 0, q1 = upd >= 0 ? upd + 1 : s->P;
+        for (int l = s->D - 2; l >= 0; --l) {
+          const int begin = s->level_off[l], end = s->level_off[l + 1];
+          k_gcfr_level<<<blocks(end - begin), dim3(256), 0, st>>>(g, begin, end, q0, q1);
+        }
+        k_gcfr_members<<<blocks(M), dim3(256), 0, st>>>(g, upd, s->iteration + it + 1, s->cfg);
+        k_gcfr_fold<<<blocks(s->I), dim3(256), 0, st>>>(g, upd, s->cfg);
+      }
+    }
+    OSG_HIP(hipGetLastError());
+    s->iteration += iters;
+    return OSG_OK;
+  }
   if (s->path_kernel && s->cfg.kernel != 1) {
     // Path-based kernel: no top-down reach pass; all-in-LDS when the tree is small enough.
     const int M = static_cast<int>(s->mem.size());

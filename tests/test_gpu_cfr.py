@@ -77,6 +77,11 @@ def test_tree_census_and_keys(oracle, ctx, game):
     ("kuhn_poker(players=4)", "cfr", {}, [1, 6]),
     ("leduc_poker", "cfr", dict(general_kernel=True), [1, 4]),               # leduc default = path kernel, global memory
     ("leduc_poker", "cfr_simultaneous", dict(alternating_updates=False), [1, 3]),
+    # full-grid phase kernels (the default beyond 65536 histories), forced on small and medium trees
+    ("kuhn_poker", "cfr", dict(general_kernel="grid"), [1, 2, 30]),
+    ("leduc_poker", "cfr", dict(general_kernel="grid"), [1, 5]),
+    ("leduc_poker", "cfr_plus", dict(linear_averaging=True, regret_matching_plus=True, general_kernel="grid"), [4]),
+    ("kuhn_poker(players=3)", "cfr_simultaneous", dict(alternating_updates=False, general_kernel="grid"), [6]),
     ("kuhn_poker(players=3)", "cfr_simultaneous", dict(alternating_updates=False), [1, 12]),
 ])
 def test_cfr_tables_match_the_oracle(oracle, ctx, game, kind, kwargs, checkpoints):

@@ -190,7 +190,7 @@ def test_mccfr_minibatch_replay_parity(oracle, ctx, game, batches):
 
 
 @pytest.mark.parametrize("game,bound,batch,nbatches", [
-    ("kuhn_poker", 0.05, 64, 200),       # external_sampling_mccfr_test.cc:104-109: 1000 iterations
+    ("kuhn_poker", 0.05, 64, 600),       # external_sampling_mccfr_test.cc:104-109: 1000 iterations
     ("leduc_poker", 2.5, 256, 60),
 ])
 def test_mccfr_converges_like_the_reference(oracle, ctx, game, bound, batch, nbatches):

@@ -89,3 +89,30 @@ def gather_root_results(local, total_roots):
     out = [torch.empty_like(buf) for _ in range(world_size)]
     dist.all_gather(out, buf)
     return torch.cat([o[:c] for o, c in zip(out, counts)])
+
+
+def reduce_root_statistics(child_visits, child_reward):
+    """Root-parallel MCTS on ONE shared root: every rank (and every local replica of the
+    root) runs an independent search with its own random streams; the per-action statistics of the root's
+    children are summed over the local replicas and then over the ranks with a single all-reduce
+    ([A] visits + [A] total reward: ~1 KB for hex(9)), and the move is chosen on the sums with the
+    reference's final ordering, visits first, then total reward (mcts.cc:114-125 without proven outcomes).
+
+    child_visits: [replicas, A] integer tensor, child_reward: [replicas, A] float64 (StateBatch.mcts_search
+    outputs).  Returns (visits [A] int64, reward [A] float64, best_action int)."""
+    visits = child_visits.to(torch.float64).sum(0)
+    reward = child_reward.to(torch.float64).sum(0)
+    packed = torch.cat([visits, reward])  # one collective for both vectors
+    allreduce_sum_(packed)
+    A = visits.numel()
+    visits, reward = packed[:A], packed[A:]
+    # lexicographic arg-max (visits, reward); ties -> lowest action id
+    best, best_key = -1, None
+    v_list, r_list = visits.tolist(), reward.tolist()
+    for a in range(A):
+        if v_list[a] <= 0:
+            continue
+        key = (v_list[a], r_list[a])
+        if best_key is None or key > best_key:
+            best, best_key = a, key
+    return visits.to(torch.int64), reward, best

@@ -71,7 +71,11 @@ def _worker(rank, world_size, port, out_dir):
         first, count = osd.shard_range(7, rank, world_size)
         local = torch.arange(first, first + count, dtype=torch.int32).unsqueeze(1) * 10
         gathered = osd.gather_root_results(local, 7)
-        torch.save({"tables": solver.tables, "sampled": sampled, "gathered": gathered,
+        # root-parallel MCTS statistics: rank r contributes 3 local replicas of fake per-action stats
+        vis = torch.tensor([[1 + rank, 0, 5], [2, 0, 5 - rank], [0, 0, 1]], dtype=torch.int32)
+        rew = torch.tensor([[0.5, 0.0, -1.0], [1.0, 0.0, 2.0 * rank], [0.0, 0.0, 0.25]], dtype=torch.float64)
+        root_stats = osd.reduce_root_statistics(vis, rew)
+        torch.save({"tables": solver.tables, "root_stats": root_stats, "sampled": sampled, "gathered": gathered,
                     "done": sharded.trajectories_done}, os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -108,5 +112,9 @@ def test_mccfr_delta_allreduce_world2_equals_world1(tmp_path):
     assert torch.equal(r0["tables"], ref.tables), "world=2 must equal world=1"
     assert [a + b for a, b in zip(r0["sampled"], r1["sampled"])] == [1, 5, 64, 1001]
     assert r0["done"] == r1["done"] == single.trajectories_done == 1071
+    for r in (r0, r1):
+        visits, reward, best = r["root_stats"]
+        assert visits.tolist() == [3 + 4, 0, 11 + 10] and reward.tolist() == [3.0, 0.0, 0.5]
+        assert best == 2                       # most visits wins; action 1 was never visited
     want = (torch.arange(7, dtype=torch.int32) * 10).unsqueeze(1)
     assert torch.equal(r0["gathered"], want) and torch.equal(r1["gathered"], want)

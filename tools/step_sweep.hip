@@ -156,6 +156,7 @@ int main(int argc, char** argv) {
   const int iters = 2000;
   G::Params p{}; p.words = 2; p.rows = 6; p.cols = 7; p.k = 4; p.ego = 0;
   uint64_t *src, *dst; uint8_t *act, *mask, *st;
+  uint8_t*& st8 = st;
   CK(hipMalloc(&src, 16 * n)); CK(hipMalloc(&dst, 16 * n)); CK(hipMalloc(&act, n)); CK(hipMalloc(&mask, n)); CK(hipMalloc(&st, n));
   // mid-game-ish random positions are not needed for timing: the kernel has no data-dependent loops;
   // use sparse random boards with legal random actions.
@@ -202,6 +203,29 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1));
     printf("%-28s %8.3f us/launch\n", "empty launch floor", ms * 1e3 / iters);
+  }
+  {  // hipGraph replay of the shipped logic: does a pre-built graph shorten the per-launch floor?
+    hipStream_t st; CK(hipStreamCreate(&st));
+    const int per_graph = 200;
+    dim3 grid((unsigned)((n / 2 + 255) / 256)), block(256);
+    hipGraph_t graph; hipGraphExec_t exec;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int i = 0; i < per_graph; ++i) k<2, 256, false, 3><<<grid, block, 0, st>>>(p, src, dst, n, act, mask, st8);
+    CK(hipStreamEndCapture(st, &graph));
+    CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(exec, st));
+    CK(hipStreamSynchronize(st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < 10; ++i) CK(hipGraphLaunch(exec, st));
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-28s %8.3f us/launch (hipGraph of %d kernel nodes)\n", "S=2 B=256 stored-result graph", ms * 1e3 / (10 * per_graph), per_graph);
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < 2000; ++i) k<2, 256, false, 3><<<grid, block, 0, st>>>(p, src, dst, n, act, mask, st8);
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-28s %8.3f us/launch (plain launches, non-default stream)\n", "S=2 B=256 stored-result", ms * 1e3 / 2000);
   }
   return 0;
 }

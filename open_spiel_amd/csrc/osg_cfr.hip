@@ -882,20 +882,20 @@ std::string kuhn_key(const Kuhn::Params& p, uint64_t word, int player) {
 
 std::string leduc_key(const Leduc::Params& p, uint64_t w0, uint64_t w1, int player) {
   Leduc::State s = Leduc::unpack(w0, w1);
-  std::string r = "[Observer: " + std::to_string(player) + "][Private: " + std::to_string(s.priv[player]) + "]";
+  std::string r = "[Observer: " + std::to_string(player) + "][Private: " + std::to_string(Leduc::priv(s, player)) + "]";
   r += "[Round " + std::to_string(s.round) + "][Player: " + std::to_string(s.cur) + "][Pot: " +
        std::to_string(s.pot) + "][Money: ";
   for (int q = 0; q < p.players; ++q) {
     if (q) r += " ";
-    r += std::to_string(100 - s.ante[q]);  // money_ = kStartingMoney - ante_ until the showdown
+    r += std::to_string(100 - Leduc::ante(s, q));  // money_ = kStartingMoney - ante_ until the showdown
   }
   r += "]";
   if (s.pub != Leduc::kNone) r += "[Public: " + std::to_string(s.pub) + "]";
   for (int round = 0; round < 2; ++round) {
     r += round == 0 ? "[Round1: " : "][Round2: ";
-    for (int k = 0; k < s.seqlen[round]; ++k) {
+    for (int k = 0; k < Leduc::seqlen(s, round); ++k) {
       if (k) r += " ";
-      r += std::to_string((s.seq[round] >> (2 * k)) & 3u);
+      r += std::to_string((Leduc::seq(s, round) >> (2 * k)) & 3u);
     }
   }
   r += "]";

@@ -153,11 +153,17 @@ struct Leduc {
     int calls, raises, round, stakes, pot, pub, dealt, remaining, nwin;
     uint32_t deck;    // bit c set = card c still in the deck
     uint32_t folded, winners;
-    int ante[3];
-    int priv[3];      // -1 = none
-    uint32_t seq[2];  // 2 bits per move
-    int seqlen[2];
+    // Small per-player / per-round vectors are kept bit-packed in scalars and read through the
+    // accessors below: a runtime-indexed C array would be demoted from registers to scratch memory.
+    uint32_t ante_pk;   // ante of player q: 4 bits at 4q
+    uint32_t priv_pk;   // private card of player q, plus one (0 = none): 4 bits at 4q
+    uint32_t seq0, seq1;  // moves of round 1 / round 2, 2 bits each
+    int len0, len1;
   };
+  OSG_HD static int ante(const State& s, int q) { return static_cast<int>((s.ante_pk >> (4 * q)) & 15u); }
+  OSG_HD static int priv(const State& s, int q) { return static_cast<int>((s.priv_pk >> (4 * q)) & 15u) - 1; }
+  OSG_HD static uint32_t seq(const State& s, int r) { return r == 0 ? s.seq0 : s.seq1; }
+  OSG_HD static int seqlen(const State& s, int r) { return r == 0 ? s.len0 : s.len1; }
   static constexpr int kNone = -1;
 
   OSG_HD static State initial(const Params& p) {  // leduc_poker.cc:241-286
@@ -165,8 +171,9 @@ struct Leduc {
     s.cur = kChancePlayer; s.calls = 0; s.raises = 0; s.round = 1; s.stakes = 1;
     s.pot = p.players; s.pub = kNone; s.dealt = 0; s.remaining = p.players; s.nwin = 0;
     s.deck = (1u << p.cards) - 1u; s.folded = 0; s.winners = 0;
-    for (int q = 0; q < 3; ++q) { s.ante[q] = 1; s.priv[q] = kNone; }
-    s.seq[0] = s.seq[1] = 0; s.seqlen[0] = s.seqlen[1] = 0;
+    s.ante_pk = 0x111u;  // everyone antes 1
+    s.priv_pk = 0u;
+    s.seq0 = s.seq1 = 0; s.len0 = s.len1 = 0;
     return s;
   }
   OSG_HD static State unpack(uint64_t a, uint64_t b) {
@@ -184,12 +191,12 @@ struct Leduc {
     s.folded = static_cast<uint32_t>(a & 7ull);         a >>= 3;
     s.winners = static_cast<uint32_t>(a & 7ull);        a >>= 3;
     s.nwin = static_cast<int>(a & 3ull);                a >>= 2;
-    for (int q = 0; q < 3; ++q) { s.ante[q] = static_cast<int>(a & 15ull); a >>= 4; }
-    for (int r = 0; r < 2; ++r) {
-      s.seqlen[r] = static_cast<int>(b & 7ull);         b >>= 3;
-      s.seq[r] = static_cast<uint32_t>(b & 0x3FFFull);  b >>= 14;
-    }
-    for (int q = 0; q < 3; ++q) { s.priv[q] = static_cast<int>(b & 15ull) - 1; b >>= 4; }
+    s.ante_pk = static_cast<uint32_t>(a & 0xFFFull);
+    s.len0 = static_cast<int>(b & 7ull);              b >>= 3;
+    s.seq0 = static_cast<uint32_t>(b & 0x3FFFull);     b >>= 14;
+    s.len1 = static_cast<int>(b & 7ull);              b >>= 3;
+    s.seq1 = static_cast<uint32_t>(b & 0x3FFFull);     b >>= 14;
+    s.priv_pk = static_cast<uint32_t>(b & 0xFFFull);
     return s;
   }
   OSG_HD static void pack(const State& s, uint64_t& a, uint64_t& b) {
@@ -201,10 +208,10 @@ struct Leduc {
     put(a, s.pot, 6); put(a, static_cast<uint64_t>(s.pub + 1), 4); put(a, s.deck, 8);
     put(a, s.dealt, 2); put(a, s.remaining, 2); put(a, s.folded, 3); put(a, s.winners, 3);
     put(a, s.nwin, 2);
-    for (int q = 0; q < 3; ++q) put(a, s.ante[q], 4);
+    put(a, s.ante_pk, 12);
     sh = 0;
-    for (int r = 0; r < 2; ++r) { put(b, s.seqlen[r], 3); put(b, s.seq[r], 14); }
-    for (int q = 0; q < 3; ++q) put(b, static_cast<uint64_t>(s.priv[q] + 1), 4);
+    put(b, s.len0, 3); put(b, s.seq0, 14); put(b, s.len1, 3); put(b, s.seq1, 14);
+    put(b, s.priv_pk, 12);
   }
   OSG_HD static State load(const Params&, const word_t* base, int64_t n, int64_t i) {
     return unpack(base[i], base[n + i]);
@@ -238,7 +245,7 @@ struct Leduc {
       return m;
     }
     if (p.mapping) { m.w[0] = 7u; return m; }
-    if (s.stakes > s.ante[s.cur]) m.w[0] |= 1u;  // fold only under pressure
+    if (s.stakes > ante(s, s.cur)) m.w[0] |= 1u;  // fold only under pressure
     m.w[0] |= 2u;                                 // call / check
     if (s.raises < 2) m.w[0] |= 4u;               // raise
     return m;
@@ -267,7 +274,7 @@ struct Leduc {
     return 0;
   }
   OSG_HD static int hand_rank(const Params& p, const State& s, int q) {  // RankHand, leduc_poker.cc:593-626
-    int lo = s.pub, hi = s.priv[q];
+    int lo = s.pub, hi = priv(s, q);
     if (lo > hi) { int t = lo; lo = hi; hi = t; }
     if (p.iso) {
       int n = p.cards / 2;
@@ -294,12 +301,12 @@ struct Leduc {
   }
   OSG_HD static void pay(State& s, int q, int amount) {  // Ante, leduc_poker.cc:700-704
     s.pot += amount;
-    s.ante[q] += amount;
+    s.ante_pk += static_cast<uint32_t>(amount) << (4 * q);  // an ante never exceeds 13
   }
   OSG_HD static void record(State& s, int move) {
     int r = s.round - 1;
-    s.seq[r] |= static_cast<uint32_t>(move) << (2 * s.seqlen[r]);
-    ++s.seqlen[r];
+    if (r == 0) { s.seq0 |= static_cast<uint32_t>(move) << (2 * s.len0); ++s.len0; }
+    else { s.seq1 |= static_cast<uint32_t>(move) << (2 * s.len1); ++s.len1; }
   }
   OSG_HD static void advance(const Params& p, State& s, bool may_start_round) {
     if (terminal(p, s)) {
@@ -313,7 +320,7 @@ struct Leduc {
   OSG_HD static void apply(const Params& p, State& s, int a) {  // DoApplyAction, leduc_poker.cc:298-414
     if (s.cur == kChancePlayer) {
       if (s.dealt < p.players) {  // SetPrivate, :706-727
-        s.priv[s.dealt] = take_card(p, s, a);
+        s.priv_pk |= static_cast<uint32_t>(take_card(p, s, a) + 1) << (4 * s.dealt);
         ++s.dealt;
         if (s.dealt == p.players) s.cur = p.starter;
       } else {
@@ -323,7 +330,7 @@ struct Leduc {
       return;
     }
     if (p.mapping) {  // :333-345
-      if (a == 0 && s.stakes <= s.ante[s.cur]) a = 1;
+      if (a == 0 && s.stakes <= ante(s, s.cur)) a = 1;
       else if (a == 2 && s.raises >= 2) a = 1;
     }
     if (a == 0) {
@@ -332,12 +339,12 @@ struct Leduc {
       --s.remaining;
       advance(p, s, true);
     } else if (a == 1) {
-      pay(s, s.cur, s.stakes - s.ante[s.cur]);
+      pay(s, s.cur, s.stakes - ante(s, s.cur));
       ++s.calls;
       record(s, 1);
       advance(p, s, true);
     } else {
-      int to_call = s.stakes - s.ante[s.cur];
+      int to_call = s.stakes - ante(s, s.cur);
       if (to_call > 0) pay(s, s.cur, to_call);
       int bump = s.round == 1 ? 2 : 4;  // leduc_poker.h:65-66
       s.stakes += bump;
@@ -356,7 +363,7 @@ struct Leduc {
     // After ResolveWinner the reference zeroes pot_; we keep pot and recompute the share.
     for (int q = 0; q < p.players; ++q) {
       if (!term) { out[q] = 0.0; continue; }
-      double money = static_cast<double>(100 - s.ante[q]);
+      double money = static_cast<double>(100 - ante(s, q));
       if ((s.winners >> q) & 1u) money += static_cast<double>(s.pot) / s.nwin;
       out[q] = money - 100.0;
     }
@@ -368,7 +375,7 @@ struct Leduc {
     const int P = p.players, K = p.iso ? p.cards / 2 : p.cards;
     if (idx < P) return idx == player ? 1.0f : 0.0f;
     idx -= P;
-    if (idx < K) return s.priv[player] == idx ? 1.0f : 0.0f;
+    if (idx < K) return priv(s, player) == idx ? 1.0f : 0.0f;
     idx -= K;
     if (idx < K) return s.pub == idx ? 1.0f : 0.0f;
     idx -= K;
@@ -376,11 +383,11 @@ struct Leduc {
       const int bets = 3 * P - 2;
       int r = idx / (bets * 2), rem = idx - r * bets * 2;
       int i = rem >> 1, bit = rem & 1;
-      if (i >= s.seqlen[r]) return 0.0f;
-      int mv = (s.seq[r] >> (2 * i)) & 3u;
+      if (i >= seqlen(s, r)) return 0.0f;
+      int mv = (seq(s, r) >> (2 * i)) & 3u;
       return (mv == 1 && bit == 0) || (mv == 2 && bit == 1) ? 1.0f : 0.0f;  // call 10, raise 01
     }
-    return static_cast<float>(s.ante[idx]);
+    return static_cast<float>(ante(s, idx));
   }
   using ObsCursor = GenericObsCursor<Leduc>;
 };

@@ -322,6 +322,12 @@ struct HexT {
     for (int i = 0; i < NW; ++i) r.w[i] = a.w[i] & ~b.w[i];
     return r;
   }
+  OSG_D static Bits sel(bool c, const Bits& a, const Bits& b) {  // word-wise select: never a pointer select
+    Bits r;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r.w[i] = c ? a.w[i] : b.w[i];
+    return r;
+  }
   OSG_D static bool any(const Bits& a) {
     uint32_t v = 0;
 #pragma unroll
@@ -428,13 +434,14 @@ struct HexT {
   // PlayerAndActionToState (hex.cc:108-171) + DoApplyAction (hex.cc:229-278).
   OSG_D static void place(const Params& p, State& s, int player, int move, bool& a, bool& b) {
     Bits cell = single(move);
-    a = false; b = false;
-    if (player == 0) {  // black: first row -> North(A), ELSE IF last row -> South(B)
-      if (test(p.row_first, move)) a = true; else if (test(p.row_last, move)) b = true;
-    } else {            // white: first column -> West(A), ELSE IF last column -> East(B)
-      if (test(p.col_first, move)) a = true; else if (test(p.col_last, move)) b = true;
-    }
-    const Bits& own = player == 0 ? s.black : s.white;
+    // black: first row -> North(A), ELSE IF last row -> South(B); white: first column -> West(A),
+    // ELSE IF last column -> East(B) (hex.cc:122-126,146-150).  Written as plain boolean algebra: the
+    // if / else-if form made the compiler index {a, b} as a two-byte array in scratch memory.
+    const bool on_first = player == 0 ? test(p.row_first, move) : test(p.col_first, move);
+    const bool on_last = player == 0 ? test(p.row_last, move) : test(p.col_last, move);
+    a = on_first;
+    b = !on_first && on_last;
+    const Bits own = sel(player == 0, s.black, s.white);
     Bits nb = band(neighbours(p, cell), own);
     // a neighbour labelled exactly A (not Win) / exactly B
     a |= any(bandn(band(nb, s.ea), s.eb));
@@ -464,7 +471,7 @@ struct HexT {
       res = player == 0 ? 1u : 2u;  // Win label; no flood fill (hex.cc:248-252)
     } else if (a || b) {
       // flood the plain same-colour group reachable from the new stone
-      const Bits own = player == 0 ? s.black : s.white;
+      const Bits own = sel(player == 0, s.black, s.white);
       Bits plain = bandn(bandn(own, s.ea), s.eb);
       Bits region = zero();
       Bits frontier = single(move);
@@ -511,7 +518,7 @@ struct HexT {
   OSG_D static Bits plane_mask(const Params& p, const State& s, int plane) {
     const int l = plane - 4;
     if (l == 0) return bandn(p.board, bor(s.black, s.white));
-    const Bits own = l > 0 ? s.black : s.white;
+    const Bits own = sel(l > 0, s.black, s.white);
     const int mag = l > 0 ? l : -l;  // 1 plain, 2 edge-B only, 3 edge-A only, 4 both
     const Bits a = (mag == 3 || mag == 4) ? band(own, s.ea) : bandn(own, s.ea);
     return (mag == 2 || mag == 4) ? band(a, s.eb) : bandn(a, s.eb);

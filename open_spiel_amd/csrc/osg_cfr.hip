@@ -757,6 +757,169 @@ k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dp
 }
 
 // ---------------------------------------------------------------------------
+// The same traversal with everything on its dependent chain in LDS: the tree as one
+// 8-byte record per history, the launch's regret-matched policy (the table is frozen,
+// so ApplyRegretMatching runs once per infostate and workgroup, not once per visit), the
+// distinct terminal return vectors / chance probabilities, and the two delta tables.
+// One workgroup per CU; the frame on top of the traverser's stack lives in registers,
+// deeper frames are spilled to a per-lane backing store on push and reloaded on pop.
+//
+//   rec.x  kind [0:2) | nchild [2:8) | actor + 1 [8:12) | infostate id [12:32)
+//   rec.y  first child (terminal nodes: index of the return vector) [0:24) |
+//          index of the incoming edge's chance probability [24:32)
+// ---------------------------------------------------------------------------
+struct ResidentTree {
+  const uint2* rec;      // [H]
+  const double* uret;    // [K, P] distinct Returns() vectors
+  const double* uprob;   // [nprob] distinct chance probabilities
+  int K, nprob;
+};
+
+template <int kA>
+__global__ void __launch_bounds__(1024)
+k_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict__ nact,
+                 const double* __restrict__ regrets, double* g_dreg, double* g_dpol, uint64_t seed, int64_t first,
+                 int64_t count) {
+  extern __shared__ double smem[];
+  const int IA = I * kA;
+  double* dreg = smem;
+  double* dpol = smem + IA;
+  double* pol = smem + 2 * IA;
+  double* uret = smem + 3 * IA;
+  double* uprob = uret + rt.K * P;
+  uint2* nodes = reinterpret_cast<uint2*>(uprob + rt.nprob);
+  for (int k = threadIdx.x; k < 2 * IA; k += blockDim.x) smem[k] = 0.0;
+  for (int i = threadIdx.x; i < I; i += blockDim.x) {
+    double row[kA], out[kA];
+#pragma unroll
+    for (int a = 0; a < kA; ++a) row[a] = regrets[i * kA + a];
+    const int n = nact[i];
+    double sum_pos = 0.0;  // CFRInfoStateValues::ApplyRegretMatching (cfr.cc:596-615)
+#pragma unroll
+    for (int a = 0; a < kA; ++a)
+      if (a < n && row[a] > 0) sum_pos += row[a];
+#pragma unroll
+    for (int a = 0; a < kA; ++a) {
+      if (a >= n) out[a] = 0.0;
+      else if (sum_pos > 0) out[a] = row[a] > 0 ? row[a] / sum_pos : 0.0;
+      else out[a] = 1.0 / n;
+    }
+#pragma unroll
+    for (int a = 0; a < kA; ++a) pol[i * kA + a] = out[a];
+  }
+  for (int k = threadIdx.x; k < rt.K * P; k += blockDim.x) uret[k] = rt.uret[k];
+  for (int k = threadIdx.x; k < rt.nprob; k += blockDim.x) uprob[k] = rt.uprob[k];
+  for (int k = threadIdx.x; k < H; k += blockDim.x) nodes[k] = rt.rec[k];
+  __syncthreads();
+
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < count; j += stride) {
+    const int64_t g = first + j;
+    const int trav = static_cast<int>(g % P);
+    const int next = (trav + 1) % P;
+    Rng rng(seed, static_cast<uint64_t>(g), 0);
+    // backing store of the frames below the top one
+    uint32_t s_x[kMaxFrames], s_fa[kMaxFrames];
+    double s_v[kMaxFrames], s_cv[kMaxFrames][kA];
+    uint32_t top_x = 0, top_fc = 0;
+    int top_a = 0;
+    double top_v = 0.0, top_cv[kA];
+#pragma unroll
+    for (int b = 0; b < kA; ++b) top_cv[b] = 0.0;
+    int sp = 0;
+    int node = 0;
+    for (;;) {
+      const uint2 rec = nodes[node];
+      const int kind = rec.x & 3u;
+      if (kind != kTerminalNode) {
+        const int nc = (rec.x >> 2) & 63u, fc = rec.y & 0xFFFFFFu;
+        const int i = rec.x >> 12;
+        const int actor = static_cast<int>((rec.x >> 8) & 15u) - 1;  // -1 at chance nodes
+        if (actor != trav) {
+          const double z = rng.unit();
+          int pick = nc - 1;
+          if (kind == kChanceNode) {  // SampleAction(ChanceOutcomes(), z) (spiel.cc:372-409)
+            double acc = 0.0;
+            bool found = false;
+            for (int c = 0; c < nc; ++c) {
+              const double pr = uprob[nodes[fc + c].y >> 24];
+              if (!found && acc <= z && z < acc + pr) { pick = c; found = true; }
+              acc += pr;
+            }
+          } else {  // opponent: sample one action from regret matching (:151-154)
+            double p[kA];
+#pragma unroll
+            for (int a = 0; a < kA; ++a) p[a] = pol[i * kA + a];
+            double acc = 0.0;  // SampleActionIndex(0.0, z) (cfr.cc:617-628)
+            bool found = false;
+#pragma unroll
+            for (int a = 0; a < kA; ++a) {
+              if (!found && a < nc && z >= acc && z < acc + p[a]) { pick = a; found = true; }
+              acc += p[a];
+            }
+            if (actor == next) {  // kSimple averaging at player+1's nodes (:177-183)
+#pragma unroll
+              for (int a = 0; a < kA; ++a)
+                if (a < nc) add_f64(&dpol[i * kA + a], p[a]);
+            }
+          }
+          node = fc + pick;
+          continue;
+        }
+        // traverser: walk every action (:155-162)
+        if (sp > 0) {
+          s_x[sp - 1] = top_x;
+          s_fa[sp - 1] = top_fc | (static_cast<uint32_t>(top_a) << 24);
+          s_v[sp - 1] = top_v;
+#pragma unroll
+          for (int b = 0; b < kA; ++b) s_cv[sp - 1][b] = top_cv[b];
+        }
+        top_x = rec.x; top_fc = fc; top_a = 0; top_v = 0.0;
+        ++sp;
+        node = fc;
+        continue;
+      }
+      double ret = uret[(rec.y & 0xFFFFFFu) * P + trav];
+      bool done = false;
+      for (;;) {  // hand `ret` to the innermost open frame
+        if (sp == 0) { done = true; break; }
+        const int i = top_x >> 12, nc = (top_x >> 2) & 63u;
+        const double pa = pol[i * kA + top_a];
+#pragma unroll
+        for (int b = 0; b < kA; ++b)
+          if (b == top_a) top_cv[b] = ret;
+        top_v += pa * ret;
+        if (top_a + 1 < nc) {
+          ++top_a;
+          node = top_fc + top_a;
+          break;
+        }
+#pragma unroll
+        for (int b = 0; b < kA; ++b)
+          if (b < nc) add_f64(&dreg[i * kA + b], top_cv[b] - top_v);  // (:167-172)
+        ret = top_v;
+        --sp;
+        if (sp > 0) {
+          top_x = s_x[sp - 1];
+          top_fc = s_fa[sp - 1] & 0xFFFFFFu;
+          top_a = s_fa[sp - 1] >> 24;
+          top_v = s_v[sp - 1];
+#pragma unroll
+          for (int b = 0; b < kA; ++b) top_cv[b] = s_cv[sp - 1][b];
+        }
+      }
+      if (done) break;
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < IA; k += blockDim.x) {
+    const double r = dreg[k], q = dpol[k];
+    if (r != 0.0) add_f64(&g_dreg[k], r);
+    if (q != 0.0) add_f64(&g_dpol[k], q);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // OutcomeSamplingMCCFRSolver::SampleEpisode (outcome_sampling_mccfr.cc:141-241),
 // Baseline() == 0: ONE sampled path per thread.  The walk down records, per decision
 // node, the regret-matched policy, the sampled action and the three reaches; the walk
@@ -952,6 +1115,12 @@ struct osg_cfr {
   bool eval_ok = true;  // every infostate's members sit on one tree level
   int32_t *d_info_level = nullptr, *d_mem_index = nullptr, *d_best = nullptr;
   double *d_eval = nullptr;  // value [H,P] | brv [H] | cf [M] | out [2P] | policy [I,A]
+  // LDS-resident MCCFR traversal (k_mccfr_resident)
+  bool resident_ok = false;
+  size_t resident_lds_bytes = 0;
+  int n_uret = 0, n_uprob = 0, num_cus = 0;
+  uint64_t* d_rec = nullptr;
+  double *d_uret = nullptr, *d_uprob = nullptr;
 
   Tree tree() const {
     Tree t;
@@ -1188,6 +1357,88 @@ int init_tables(osg_cfr* s) {
   return OSG_OK;
 }
 
+// Packs the tree for k_mccfr_resident (8 bytes per history + the distinct return vectors and chance
+// probabilities) and decides whether it fits one workgroup's LDS next to three [I, A] tables.
+int build_resident_tree(osg_cfr* s) {
+  s->resident_ok = false;
+  if (s->cfg.solver != 1 || s->A < 1 || s->A > kMaxA) return OSG_OK;
+  if (s->H >= (1 << 24) || s->I >= (1 << 20)) return OSG_OK;
+  std::vector<uint64_t> rec(s->H);
+  std::vector<double> uret, uprob;
+  std::unordered_map<std::string, uint32_t> ret_id;
+  std::unordered_map<uint64_t, uint32_t> prob_id;
+  const int P = s->P;
+  // traverser frames one path can hold: decision nodes of one player from the root down
+  std::vector<uint8_t> own(static_cast<size_t>(s->H) * P, 0);
+  int max_frames = 0;
+  for (int h = 0; h < s->H; ++h) {
+    uint32_t x = s->kind[h] | (static_cast<uint32_t>(s->nchild[h]) << 2) |
+                 (static_cast<uint32_t>(s->actor[h] + 1) << 8);
+    uint32_t y = 0;
+    if (s->nchild[h] > 63 || s->actor[h] + 1 > 15) return OSG_OK;
+    if (s->kind[h] == kDecisionNode) x |= static_cast<uint32_t>(s->info[h]) << 12;
+    if (s->kind[h] == kTerminalNode) {
+      std::string key(reinterpret_cast<const char*>(&s->term_ret[static_cast<size_t>(h) * P]), sizeof(double) * P);
+      auto it = ret_id.find(key);
+      if (it == ret_id.end()) {
+        it = ret_id.emplace(key, static_cast<uint32_t>(ret_id.size())).first;
+        for (int p = 0; p < P; ++p) uret.push_back(s->term_ret[static_cast<size_t>(h) * P + p]);
+      }
+      y = it->second;
+    } else {
+      y = static_cast<uint32_t>(s->first_child[h]);
+    }
+    if (h > 0 && s->kind[s->parent[h]] == kChanceNode) {
+      uint64_t bits;
+      memcpy(&bits, &s->edge_prob[h], sizeof bits);
+      auto it = prob_id.find(bits);
+      if (it == prob_id.end()) {
+        if (prob_id.size() >= 256) return OSG_OK;
+        it = prob_id.emplace(bits, static_cast<uint32_t>(prob_id.size())).first;
+        uprob.push_back(s->edge_prob[h]);
+      }
+      y |= it->second << 24;
+    }
+    rec[h] = static_cast<uint64_t>(x) | (static_cast<uint64_t>(y) << 32);
+    if (h > 0) {
+      const int par = s->parent[h];
+      for (int p = 0; p < P; ++p) {
+        int d = own[static_cast<size_t>(par) * P + p] + (s->kind[par] == kDecisionNode && s->actor[par] == p ? 1 : 0);
+        if (d > 255) return OSG_OK;
+        own[static_cast<size_t>(h) * P + p] = static_cast<uint8_t>(d);
+        max_frames = std::max(max_frames, d);
+      }
+    }
+  }
+  if (max_frames > kMaxFrames) return OSG_OK;
+  if (uprob.empty()) uprob.push_back(1.0);
+  s->n_uret = static_cast<int>(uret.size() / std::max(P, 1));
+  s->n_uprob = static_cast<int>(uprob.size());
+  const size_t IA = static_cast<size_t>(s->I) * s->A;
+  s->resident_lds_bytes = sizeof(double) * (3 * IA + uret.size() + uprob.size()) + sizeof(uint64_t) * s->H;
+  hipDeviceProp_t prop;
+  OSG_HIP(hipGetDeviceProperties(&prop, s->ctx->device));
+  s->num_cus = prop.multiProcessorCount;
+  if (s->resident_lds_bytes > static_cast<size_t>(prop.sharedMemPerBlockOptin ? prop.sharedMemPerBlockOptin
+                                                                              : prop.sharedMemPerBlock))
+    return OSG_OK;
+  hipStream_t st = s->ctx->stream;
+  int rc;
+  if ((rc = upload(rec, &s->d_rec, st)) || (rc = upload(uret, &s->d_uret, st)) || (rc = upload(uprob, &s->d_uprob, st)))
+    return rc;
+  const void* variants[] = {reinterpret_cast<const void*>(&k_mccfr_resident<1>),
+                            reinterpret_cast<const void*>(&k_mccfr_resident<2>),
+                            reinterpret_cast<const void*>(&k_mccfr_resident<3>),
+                            reinterpret_cast<const void*>(&k_mccfr_resident<4>)};
+  if (hipFuncSetAttribute(variants[s->A - 1], hipFuncAttributeMaxDynamicSharedMemorySize,
+                          static_cast<int>(s->resident_lds_bytes)) != hipSuccess) {
+    (void)hipGetLastError();
+    return OSG_OK;
+  }
+  s->resident_ok = true;
+  return OSG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1284,6 +1535,8 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
     osg_cfr_destroy(s);
     return set_error(OSG_ERR_UNSUPPORTED, "replicas > 1 need the all-in-LDS kernel (tree too large)");
   }
+  rc = build_resident_tree(s);
+  if (rc) { osg_cfr_destroy(s); return rc; }
   rc = init_tables(s);
   if (rc) { osg_cfr_destroy(s); return rc; }
   *out = s;
@@ -1296,7 +1549,8 @@ int osg_cfr_destroy(osg_cfr* s) {
   void* ptrs[] = {s->d_level_off, s->d_parent, s->d_first_child, s->d_info, s->d_mem_off, s->d_mem, s->d_nact,
                   s->d_kind, s->d_nchild, s->d_aidx, s->d_actor, s->d_info_player, s->d_edge_prob, s->d_term_ret,
                   s->d_tables, s->d_reach, s->d_value, s->d_path_off, s->d_path, s->d_info_level, s->d_mem_index,
-                  s->d_best, s->d_eval, s->d_meta32, s->d_info_player32, s->d_skip, s->d_node_delta};
+                  s->d_best, s->d_eval, s->d_meta32, s->d_info_player32, s->d_skip, s->d_node_delta, s->d_rec,
+                  s->d_uret, s->d_uprob};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete s;
@@ -1413,6 +1667,28 @@ int osg_mccfr_sample(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_
       k_os_mccfr<false><<<dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st>>>(
           s->tree(), s->regrets(), s->dreg(), s->dpol(), seed, first_trajectory, trajectories, eps);
     }
+    OSG_HIP(hipGetLastError());
+    return OSG_OK;
+  }
+  if (s->resident_ok && s->cfg.kernel != 1) {
+    // One workgroup per CU (as many as the LDS footprint allows), 1024 lanes each for big batches.
+    const int threads = trajectories >= static_cast<int64_t>(s->num_cus) * 1024 ? 1024 : 256;
+    int per_cu = static_cast<int>((160 * 1024) / std::max<size_t>(s->resident_lds_bytes, 1));
+    per_cu = std::max(1, std::min(per_cu, 2048 / threads));
+    int64_t groups = std::min<int64_t>((trajectories + threads - 1) / threads, static_cast<int64_t>(s->num_cus) * per_cu);
+    ResidentTree rt{reinterpret_cast<const uint2*>(s->d_rec), s->d_uret, s->d_uprob, s->n_uret, s->n_uprob};
+    const dim3 grid(static_cast<unsigned>(groups)), block(threads);
+    const size_t shmem = s->resident_lds_bytes;
+#define OSG_MCCFR_RES(KA)                                                                                       \
+  k_mccfr_resident<KA><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), s->dreg(), \
+                                                   s->dpol(), seed, first_trajectory, trajectories)
+    switch (s->A) {
+      case 1: OSG_MCCFR_RES(1); break;
+      case 2: OSG_MCCFR_RES(2); break;
+      case 3: OSG_MCCFR_RES(3); break;
+      default: OSG_MCCFR_RES(4); break;
+    }
+#undef OSG_MCCFR_RES
     OSG_HIP(hipGetLastError());
     return OSG_OK;
   }

@@ -775,15 +775,14 @@ struct ResidentTree {
   int K, nprob;
 };
 
+// Fills one workgroup's LDS for the resident traversals: zeroed delta tables, the regret-matched policy
+// of every infostate (CFRInfoStateValues::ApplyRegretMatching, cfr.cc:596-615; rows padded with 0),
+// the distinct return vectors / chance probabilities and the packed tree.  Caller synchronises.
 template <int kA>
-__global__ void __launch_bounds__(1024)
-k_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict__ nact,
-                 const double* __restrict__ regrets, double* g_dreg, double* g_dpol, uint64_t seed, int64_t first,
-                 int64_t count) {
-  extern __shared__ double smem[];
+OSG_D void resident_load(double* smem, int H, int I, int P, const ResidentTree& rt, const int32_t* __restrict__ nact,
+                         const double* __restrict__ regrets, double** o_dreg, double** o_dpol, double** o_pol,
+                         double** o_uret, double** o_uprob, uint2** o_nodes) {
   const int IA = I * kA;
-  double* dreg = smem;
-  double* dpol = smem + IA;
   double* pol = smem + 2 * IA;
   double* uret = smem + 3 * IA;
   double* uprob = uret + rt.K * P;
@@ -794,7 +793,7 @@ k_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict
 #pragma unroll
     for (int a = 0; a < kA; ++a) row[a] = regrets[i * kA + a];
     const int n = nact[i];
-    double sum_pos = 0.0;  // CFRInfoStateValues::ApplyRegretMatching (cfr.cc:596-615)
+    double sum_pos = 0.0;
 #pragma unroll
     for (int a = 0; a < kA; ++a)
       if (a < n && row[a] > 0) sum_pos += row[a];
@@ -810,6 +809,28 @@ k_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict
   for (int k = threadIdx.x; k < rt.K * P; k += blockDim.x) uret[k] = rt.uret[k];
   for (int k = threadIdx.x; k < rt.nprob; k += blockDim.x) uprob[k] = rt.uprob[k];
   for (int k = threadIdx.x; k < H; k += blockDim.x) nodes[k] = rt.rec[k];
+  *o_dreg = smem; *o_dpol = smem + IA; *o_pol = pol; *o_uret = uret; *o_uprob = uprob; *o_nodes = nodes;
+}
+
+OSG_D void resident_flush(const double* dreg, const double* dpol, double* g_dreg, double* g_dpol, int IA) {
+  __syncthreads();
+  for (int k = threadIdx.x; k < IA; k += blockDim.x) {
+    const double r = dreg[k], q = dpol[k];
+    if (r != 0.0) add_f64(&g_dreg[k], r);
+    if (q != 0.0) add_f64(&g_dpol[k], q);
+  }
+}
+
+template <int kA>
+__global__ void __launch_bounds__(1024)
+k_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict__ nact,
+                 const double* __restrict__ regrets, double* g_dreg, double* g_dpol, uint64_t seed, int64_t first,
+                 int64_t count) {
+  extern __shared__ double smem[];
+  const int IA = I * kA;
+  double *dreg, *dpol, *pol, *uret, *uprob;
+  uint2* nodes;
+  resident_load<kA>(smem, H, I, P, rt, nact, regrets, &dreg, &dpol, &pol, &uret, &uprob, &nodes);
   __syncthreads();
 
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -911,12 +932,7 @@ k_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict
       if (done) break;
     }
   }
-  __syncthreads();
-  for (int k = threadIdx.x; k < IA; k += blockDim.x) {
-    const double r = dreg[k], q = dpol[k];
-    if (r != 0.0) add_f64(&g_dreg[k], r);
-    if (q != 0.0) add_f64(&g_dpol[k], q);
-  }
+  resident_flush(dreg, dpol, g_dreg, g_dpol, IA);
 }
 
 // ---------------------------------------------------------------------------
@@ -1017,6 +1033,101 @@ k_os_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g
       if (q != 0.0) add_f64(&g_dpol[k], q);
     }
   }
+}
+
+// k_os_mccfr with the tree, the launch's regret-matched policy and the delta tables in LDS
+// (same records as k_mccfr_resident); the per-depth frames stay in the per-lane backing store.
+template <int kA>
+__global__ void __launch_bounds__(1024)
+k_os_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict__ nact,
+                    const double* __restrict__ regrets, double* g_dreg, double* g_dpol, uint64_t seed, int64_t first,
+                    int64_t count, double epsilon) {
+  extern __shared__ double smem[];
+  const int IA = I * kA;
+  double *dreg, *dpol, *pol, *uret, *uprob;
+  uint2* nodes;
+  resident_load<kA>(smem, H, I, P, rt, nact, regrets, &dreg, &dpol, &pol, &uret, &uprob, &nodes);
+  __syncthreads();
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < count; j += stride) {
+    const int64_t g = first + j;
+    const int upd = static_cast<int>(g % P);
+    Rng rng(seed, static_cast<uint64_t>(g), 0);
+    uint32_t f_x[kMaxOsDepth];  // infostate id [12:32) | nchild [2:8) | sampled action [0:2) | update player's node [8]
+    double f_my[kMaxOsDepth], f_opp[kMaxOsDepth], f_samp[kMaxOsDepth], f_sp[kMaxOsDepth];
+    int depth = 0;
+    int node = 0;
+    double my = 1.0, opp = 1.0, samp = 1.0;
+    uint2 rec = nodes[0];
+    while ((rec.x & 3u) != kTerminalNode && depth < kMaxOsDepth) {
+      const int nc = (rec.x >> 2) & 63u, fc = rec.y & 0xFFFFFFu;
+      const double z = rng.unit();
+      int pick = nc - 1;
+      if ((rec.x & 3u) == kChanceNode) {  // SampleAction(ChanceOutcomes(), z) (:146-153)
+        double acc = 0.0, pr_pick = 0.0;
+        bool found = false;
+        for (int c = 0; c < nc; ++c) {
+          const double pr = uprob[nodes[fc + c].y >> 24];
+          if (c == nc - 1 && !found) pr_pick = pr;
+          if (!found && acc <= z && z < acc + pr) { pick = c; pr_pick = pr; found = true; }
+          acc += pr;
+        }
+        opp = pr_pick * opp;
+        samp = pr_pick * samp;
+      } else {
+        const int i = rec.x >> 12;
+        const bool is_upd = static_cast<int>((rec.x >> 8) & 15u) - 1 == upd;
+        double p[kA];
+#pragma unroll
+        for (int a = 0; a < kA; ++a) p[a] = pol[i * kA + a];
+        double acc = 0.0, sp_pick = 0.0, p_pick = 0.0;
+        bool found = false;
+#pragma unroll
+        for (int a = 0; a < kA; ++a) {
+          if (a < nc) {
+            const double sp = is_upd ? epsilon * 1.0 / nc + (1 - epsilon) * p[a] : p[a];  // SamplePolicy (:111-118)
+            if (a == nc - 1 && !found) { sp_pick = sp; p_pick = p[a]; }
+            if (!found && z >= acc && z < acc + sp) { pick = a; sp_pick = sp; p_pick = p[a]; found = true; }
+            acc += sp;
+          }
+        }
+        f_x[depth] = (rec.x & ~0xF03u) | static_cast<uint32_t>(pick) | (is_upd ? 0x100u : 0u);
+        f_my[depth] = my; f_opp[depth] = opp; f_samp[depth] = samp; f_sp[depth] = sp_pick;
+        ++depth;
+        if (is_upd) my = my * p_pick; else opp = opp * p_pick;
+        samp = samp * sp_pick;
+      }
+      node = fc + pick;
+      rec = nodes[node];
+    }
+    double v = uret[(rec.y & 0xFFFFFFu) * P + upd];
+    for (int d = depth - 1; d >= 0; --d) {
+      const uint32_t x = f_x[d];
+      const int i = x >> 12, n = (x >> 2) & 63u, sampled = x & 3u;
+      double p[kA];
+#pragma unroll
+      for (int a = 0; a < kA; ++a) p[a] = pol[i * kA + a];
+      // child_values[a] = a == sampled ? 0 + (child_value - 0) / sample_policy[a] : 0 (:126-139)
+      const double cv_sampled = 0.0 + (v - 0.0) / f_sp[d];
+      double value_estimate = 0.0;
+#pragma unroll
+      for (int a = 0; a < kA; ++a)
+        if (a < n) value_estimate += p[a] * (a == sampled ? cv_sampled : 0.0);
+      if (x & 0x100u) {
+        const double cf_value = value_estimate * f_opp[d] / f_samp[d];
+#pragma unroll
+        for (int a = 0; a < kA; ++a) {
+          if (a < n) {
+            const double cf_action_value = (a == sampled ? cv_sampled : 0.0) * f_opp[d] / f_samp[d];
+            add_f64(&dreg[i * kA + a], cf_action_value - cf_value);
+            add_f64(&dpol[i * kA + a], f_my[d] * p[a] / f_samp[d]);
+          }
+        }
+      }
+      v = value_estimate;
+    }
+  }
+  resident_flush(dreg, dpol, g_dreg, g_dpol, IA);
 }
 
 __global__ void k_fold_deltas(double* regrets, double* cum, const double* dreg, const double* dpol, int n) {
@@ -1361,7 +1472,7 @@ int init_tables(osg_cfr* s) {
 // probabilities) and decides whether it fits one workgroup's LDS next to three [I, A] tables.
 int build_resident_tree(osg_cfr* s) {
   s->resident_ok = false;
-  if (s->cfg.solver != 1 || s->A < 1 || s->A > kMaxA) return OSG_OK;
+  if ((s->cfg.solver != 1 && s->cfg.solver != 2) || s->A < 1 || s->A > kMaxA) return OSG_OK;
   if (s->H >= (1 << 24) || s->I >= (1 << 20)) return OSG_OK;
   std::vector<uint64_t> rec(s->H);
   std::vector<double> uret, uprob;
@@ -1429,8 +1540,12 @@ int build_resident_tree(osg_cfr* s) {
   const void* variants[] = {reinterpret_cast<const void*>(&k_mccfr_resident<1>),
                             reinterpret_cast<const void*>(&k_mccfr_resident<2>),
                             reinterpret_cast<const void*>(&k_mccfr_resident<3>),
-                            reinterpret_cast<const void*>(&k_mccfr_resident<4>)};
-  if (hipFuncSetAttribute(variants[s->A - 1], hipFuncAttributeMaxDynamicSharedMemorySize,
+                            reinterpret_cast<const void*>(&k_mccfr_resident<4>),
+                            reinterpret_cast<const void*>(&k_os_mccfr_resident<1>),
+                            reinterpret_cast<const void*>(&k_os_mccfr_resident<2>),
+                            reinterpret_cast<const void*>(&k_os_mccfr_resident<3>),
+                            reinterpret_cast<const void*>(&k_os_mccfr_resident<4>)};
+  if (hipFuncSetAttribute(variants[(s->cfg.solver == 2 ? 4 : 0) + s->A - 1], hipFuncAttributeMaxDynamicSharedMemorySize,
                           static_cast<int>(s->resident_lds_bytes)) != hipSuccess) {
     (void)hipGetLastError();
     return OSG_OK;
@@ -1652,6 +1767,35 @@ int osg_mccfr_sample(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_
   // Persistent workgroups: each flushes its LDS delta tables once, so fewer, longer-lived
   // groups mean fewer global atomics (256 CUs x 4 groups).
   if (blocks > 1024) blocks = 1024;
+  if (s->resident_ok && s->cfg.kernel != 1) {
+    // One workgroup per CU (as many as the LDS footprint allows), 1024 lanes each for big batches.
+    const int threads = trajectories >= static_cast<int64_t>(s->num_cus) * 1024 ? 1024 : 256;
+    int per_cu = static_cast<int>((160 * 1024) / std::max<size_t>(s->resident_lds_bytes, 1));
+    per_cu = std::max(1, std::min(per_cu, 2048 / threads));
+    int64_t groups = std::min<int64_t>((trajectories + threads - 1) / threads, static_cast<int64_t>(s->num_cus) * per_cu);
+    ResidentTree rt{reinterpret_cast<const uint2*>(s->d_rec), s->d_uret, s->d_uprob, s->n_uret, s->n_uprob};
+    const dim3 grid(static_cast<unsigned>(groups)), block(threads);
+    const size_t shmem = s->resident_lds_bytes;
+#define OSG_MCCFR_RES(KA)                                                                                          \
+  do {                                                                                                             \
+    if (s->cfg.solver == 2)                                                                                        \
+      k_os_mccfr_resident<KA><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), s->dreg(), \
+                                                          s->dpol(), seed, first_trajectory, trajectories,        \
+                                                          s->cfg.epsilon);                                        \
+    else                                                                                                           \
+      k_mccfr_resident<KA><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), s->dreg(),  \
+                                                       s->dpol(), seed, first_trajectory, trajectories);          \
+  } while (0)
+    switch (s->A) {
+      case 1: OSG_MCCFR_RES(1); break;
+      case 2: OSG_MCCFR_RES(2); break;
+      case 3: OSG_MCCFR_RES(3); break;
+      default: OSG_MCCFR_RES(4); break;
+    }
+#undef OSG_MCCFR_RES
+    OSG_HIP(hipGetLastError());
+    return OSG_OK;
+  }
   if (s->cfg.solver == 2) {  // OutcomeSamplingMCCFRSolver
     const double eps = s->cfg.epsilon;
     if (use_lds) {
@@ -1667,28 +1811,6 @@ int osg_mccfr_sample(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_
       k_os_mccfr<false><<<dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st>>>(
           s->tree(), s->regrets(), s->dreg(), s->dpol(), seed, first_trajectory, trajectories, eps);
     }
-    OSG_HIP(hipGetLastError());
-    return OSG_OK;
-  }
-  if (s->resident_ok && s->cfg.kernel != 1) {
-    // One workgroup per CU (as many as the LDS footprint allows), 1024 lanes each for big batches.
-    const int threads = trajectories >= static_cast<int64_t>(s->num_cus) * 1024 ? 1024 : 256;
-    int per_cu = static_cast<int>((160 * 1024) / std::max<size_t>(s->resident_lds_bytes, 1));
-    per_cu = std::max(1, std::min(per_cu, 2048 / threads));
-    int64_t groups = std::min<int64_t>((trajectories + threads - 1) / threads, static_cast<int64_t>(s->num_cus) * per_cu);
-    ResidentTree rt{reinterpret_cast<const uint2*>(s->d_rec), s->d_uret, s->d_uprob, s->n_uret, s->n_uprob};
-    const dim3 grid(static_cast<unsigned>(groups)), block(threads);
-    const size_t shmem = s->resident_lds_bytes;
-#define OSG_MCCFR_RES(KA)                                                                                       \
-  k_mccfr_resident<KA><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), s->dreg(), \
-                                                   s->dpol(), seed, first_trajectory, trajectories)
-    switch (s->A) {
-      case 1: OSG_MCCFR_RES(1); break;
-      case 2: OSG_MCCFR_RES(2); break;
-      case 3: OSG_MCCFR_RES(3); break;
-      default: OSG_MCCFR_RES(4); break;
-    }
-#undef OSG_MCCFR_RES
     OSG_HIP(hipGetLastError());
     return OSG_OK;
   }

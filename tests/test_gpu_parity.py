@@ -113,6 +113,30 @@ def test_fused_step_parity(oracle, ctx, game):
     np.testing.assert_array_equal(a.returns().cpu().numpy(), rec["returns"][:, L])
 
 
+@pytest.mark.parametrize("game", ["connect_four", "hex(board_size=9)", "hex(board_size=5)", "leduc_poker", "tic_tac_toe"])
+@pytest.mark.parametrize("n", [1, 3, 37, 64, 257, 1000])
+def test_observation_ragged_sizes_and_unaligned_output(ctx, game, n):
+    """Batch sizes that end mid-wavefront / mid-chunk, and an output pointer that is only 4-byte
+    aligned (the C-ABI takes any float*): same tensor as the aligned call, nothing written outside."""
+    import torch
+    import open_spiel_amd as osa
+    b = osa.StateBatch(ctx, game, n)
+    b.random_steps(4242 + n, 5)
+    size = b.desc.obs_size
+    want = b.observation_tensor(0)
+    for shift in (1, 2, 3):
+        flat = torch.full((n * size + 8,), -7.0, dtype=torch.float32, device="cuda")
+        view = flat[shift:shift + n * size].view(n, size)
+        b.observation_tensor(0, out=view)
+        torch.cuda.synchronize()
+        assert torch.equal(view, want), (game, n, shift)
+        assert bool((flat[:shift] == -7.0).all()) and bool((flat[shift + n * size:] == -7.0).all())
+    guard = torch.full((n * size + 64,), -7.0, dtype=torch.float32, device="cuda")
+    b.observation_tensor(0, out=guard[:n * size].view(n, size))
+    assert bool((guard[n * size:] == -7.0).all()), "wrote past the end of the tensor"
+    assert torch.equal(guard[:n * size].view(n, size), want)
+
+
 @pytest.mark.parametrize("game", GAMES)
 def test_observation_parity(oracle, ctx, game):
     """ObservationTensor / InformationStateTensor for every player at every ply."""

@@ -36,6 +36,22 @@
 
 using namespace osg;
 
+#ifdef OSG_PHASE_TIMING
+__device__ unsigned long long g_phase_cycles[8];
+extern "C" int osg_debug_phase_cycles(unsigned long long* out8, int reset) {
+  if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z); }
+  return 0;
+}
+#define PT_DECL unsigned long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt_t = clock64();
+#define PT_MARK(k) do { const unsigned long long pt_n = clock64(); pt_acc[k] += pt_n - pt_t; pt_t = pt_n; } while (0)
+#define PT_FLUSH do { if (lane_id() == 0) for (int q = 0; q < 8; ++q) atomicAdd(&g_phase_cycles[q], pt_acc[q]); } while (0)
+#else
+#define PT_DECL
+#define PT_MARK(k)
+#define PT_FLUSH
+#endif
+
 namespace {
 
 constexpr int kWavesPerBlock = 4;
@@ -51,6 +67,22 @@ OSG_D uint64_t uniform64(uint64_t v) {
   const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
   return (static_cast<uint64_t>(hi) << 32) | lo;
 }
+OSG_D double uniform_f64(double v) {
+  const uint64_t u = uniform64(__double_as_longlong(v));
+  return __longlong_as_double(static_cast<long long>(u));
+}
+OSG_D uint32_t read_lane(uint32_t v, int src) {  // src must be wave-uniform
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), src));
+}
+OSG_D double read_lane_f64(double v, int src) {
+  const uint64_t u = static_cast<uint64_t>(__double_as_longlong(v));
+  const uint32_t lo = read_lane(static_cast<uint32_t>(u), src), hi = read_lane(static_cast<uint32_t>(u >> 32), src);
+  return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
+}
+// Orders this wavefront's own memory operations for the compiler.  The lanes of one wavefront issue
+// their loads and stores as one in-order instruction stream, so a store followed by a load of the
+// same address needs no wait — only that the compiler keeps them in program order.
+OSG_D void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 OSG_D int wave_count(bool pred) { return __builtin_popcountll(__ballot(pred)); }
 
 struct Cand {  // arg-max candidate: larger value wins, then smaller key
@@ -108,11 +140,14 @@ OSG_D bool final_better(const Final& a, const Final& b) {  // a strictly preferr
 }
 
 // --- hex playout as a wave-parallel random fill --------------------------------------------
-// Per-lane constants of the board geometry: lane l owns cells l and l + 64; for each it keeps the
-// set of its (up to six) neighbours as a 128-bit mask, and whether it lies on black's two edges.
+// Lane l owns cells l and l + 64.  Per lane: the set of each cell's (up to six) neighbours as a 128-bit
+// mask.  Per wavefront (uniform, in SGPRs): which cells are on the board / on black's two edges.  Sets of
+// cells travel as two 64-bit lane masks (cells 0-63, cells 64-127), so set algebra runs on the scalar
+// unit and the vector unit only does the per-cell tests.
 struct HexLane {
-  uint64_t nb_lo[2], nb_hi[2];  // neighbours among cells 0-63 / 64-127
-  bool first_row[2], last_row[2], on_board[2];
+  uint64_t nb_lo[2];  // neighbours among cells 0-63
+  uint64_t nb_hi[2];  // neighbours among cells 64-127
+  uint64_t board[2], first_row[2], last_row[2];  // wave-uniform cell sets
 };
 template <class G>
 OSG_D HexLane hex_lane_setup(const typename G::Params& p) {
@@ -121,80 +156,71 @@ OSG_D HexLane hex_lane_setup(const typename G::Params& p) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int cell = lane + 64 * j;
-    hl.on_board[j] = cell < p.cells;
-    const typename G::Bits nb = G::neighbours(p, G::single(hl.on_board[j] ? cell : 0));
+    const bool on_board = cell < p.cells;
+    const typename G::Bits nb = G::neighbours(p, G::single(on_board ? cell : 0));
     uint32_t w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < static_cast<int>(sizeof(nb.w) / sizeof(nb.w[0])); ++i) w[i] = nb.w[i];
-    hl.nb_lo[j] = hl.on_board[j] ? (static_cast<uint64_t>(w[1]) << 32 | w[0]) : 0ull;
-    hl.nb_hi[j] = hl.on_board[j] ? (static_cast<uint64_t>(w[3]) << 32 | w[2]) : 0ull;
-    hl.first_row[j] = hl.on_board[j] && G::test(p.row_first, cell);
-    hl.last_row[j] = hl.on_board[j] && G::test(p.row_last, cell);
+    hl.nb_lo[j] = on_board ? (static_cast<uint64_t>(w[1]) << 32 | w[0]) : 0ull;
+    hl.nb_hi[j] = on_board ? (static_cast<uint64_t>(w[3]) << 32 | w[2]) : 0ull;
+    hl.board[j] = uniform64(__ballot(on_board));
+    hl.first_row[j] = uniform64(__ballot(on_board && G::test(p.row_first, cell)));
+    hl.last_row[j] = uniform64(__ballot(on_board && G::test(p.row_last, cell)));
   }
   return hl;
+}
+// Cells 64 j ... 64 j + 63 of a (wave-uniform) bitboard as one 64-bit set.
+template <class G>
+OSG_D uint64_t hex_cells64(const typename G::Bits& b, int j) {
+  constexpr int kWords = static_cast<int>(sizeof(b.w) / sizeof(b.w[0]));
+  const uint32_t lo = 2 * j < kWords ? b.w[2 * j < kWords ? 2 * j : 0] : 0u;
+  const uint32_t hi = 2 * j + 1 < kWords ? b.w[2 * j + 1 < kWords ? 2 * j + 1 : 0] : 0u;
+  return uniform64(static_cast<uint64_t>(hi) << 32 | lo);
 }
 
 template <class G>
 OSG_D int hex_fill_winner(const typename G::Params& p, const typename G::State& s, uint64_t base, const HexLane& hl) {
-  // Lane l owns cells l and l + 64.
   const int lane = lane_id();
-  typename G::Bits occ = G::bor(s.black, s.white);
-  bool cand[2], sel[2], empty[2];
-  uint64_t key[2];
-  int m = 0;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int cell = lane + 64 * j;
-    empty[j] = hl.on_board[j] && !G::test(occ, cell);
-    cand[j] = empty[j];
-    key[j] = fill_key(base, cell);
-    sel[j] = false;
-    m += wave_count(cand[j]);
-  }
-  int remaining = (m + 1) >> 1;  // plies 0, 2, 4, ... belong to the player to move
-  // MSB-first radix select of the `remaining` smallest keys among the candidates.
-  for (int bit = 63; bit >= 0; --bit) {
-    const int live = wave_count(cand[0]) + wave_count(cand[1]);
-    if (remaining == 0) break;
-    if (live == remaining) {  // everything still undecided is selected
-      sel[0] |= cand[0];
-      sel[1] |= cand[1];
-      remaining = 0;
-      break;
-    }
-    const bool z0 = cand[0] && !((key[0] >> bit) & 1ull), z1 = cand[1] && !((key[1] >> bit) & 1ull);
-    const int zeros = wave_count(z0) + wave_count(z1);
-    if (remaining <= zeros) {  // the threshold has a 0 here: keys with a 1 are too large
-      cand[0] = z0;
-      cand[1] = z1;
-    } else {  // every 0-key is selected; keep looking among the 1-keys
-      sel[0] |= z0;
-      sel[1] |= z1;
-      remaining -= zeros;
-      cand[0] = cand[0] && !z0;
-      cand[1] = cand[1] && !z1;
+  const uint64_t black0 = hex_cells64<G>(s.black, 0), black1 = hex_cells64<G>(s.black, 1);
+  const uint64_t white0 = hex_cells64<G>(s.white, 0), white1 = hex_cells64<G>(s.white, 1);
+  const uint64_t empty0 = hl.board[0] & ~(black0 | white0), empty1 = hl.board[1] & ~(black1 | white1);
+  const uint64_t key0 = fill_key(base, lane), key1 = fill_key(base, lane + 64);
+  const int m = __builtin_popcountll(empty0) + __builtin_popcountll(empty1);
+  const int want = (m + 1) >> 1;  // plies 0, 2, 4, ... belong to the player to move
+  // The `want` smallest keys among the empty cells = the keys below a threshold T with exactly `want` keys
+  // under it.  T is built most-significant bit first (a binary search on the key space): a bit stays
+  // set while no more than `want` keys lie below.  Keys are distinct, so the search ends as soon as the
+  // count is exact — about log2(m) + 2 steps of two compares and a handful of scalar instructions.
+  uint64_t thr = 0ull, sel0 = 0ull, sel1 = 0ull;
+  if (want > 0) {
+    for (int bit = 63; bit >= 0; --bit) {
+      const uint64_t probe = thr | (1ull << bit);
+      const uint64_t c0 = __ballot(key0 < probe) & empty0, c1 = __ballot(key1 < probe) & empty1;
+      const int below = __builtin_popcountll(c0) + __builtin_popcountll(c1);
+      if (below <= want) {
+        thr = probe;
+        sel0 = c0;
+        sel1 = c1;
+        if (below == want) break;
+      }
     }
   }
   // The filled board: the mover's new stones are `sel`, the opponent's the other empty cells.
-  const int mover = G::to_move(s);
-  bool blk[2], reached[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int cell = lane + 64 * j;
-    blk[j] = hl.on_board[j] && (G::test(s.black, cell) || (empty[j] && (mover == 0 ? sel[j] : !sel[j])));
-    reached[j] = blk[j] && hl.first_row[j];
-  }
+  const bool black_moves = G::to_move(s) == 0;
+  const uint64_t blk0 = black0 | (black_moves ? sel0 : empty0 & ~sel0);
+  const uint64_t blk1 = black1 | (black_moves ? sel1 : empty1 & ~sel1);
   // Black wins iff its stones join the first row to the last row (hex.cc:108-171 edge labels).
-  // Lane-parallel flood: a black cell joins the region when one of its neighbours is in it; the
-  // region travels between lanes as two ballot masks.  Stops as soon as the last row is reached.
+  // Lane-parallel flood: a black cell joins the region when one of its neighbours is in it.
+  // Stops as soon as the last row is reached.
+  uint64_t reach0 = blk0 & hl.first_row[0], reach1 = blk1 & hl.first_row[1];
   for (int it = 0; it < 128; ++it) {
-    const uint64_t r0 = __ballot(reached[0]), r1 = __ballot(reached[1]);
-    if (__ballot((reached[0] && hl.last_row[0]) || (reached[1] && hl.last_row[1])) != 0ull) return 0;  // black
-    const bool g0 = blk[0] && !reached[0] && ((hl.nb_lo[0] & r0) | (hl.nb_hi[0] & r1)) != 0ull;
-    const bool g1 = blk[1] && !reached[1] && ((hl.nb_lo[1] & r0) | (hl.nb_hi[1] & r1)) != 0ull;
-    if (__ballot(g0 || g1) == 0ull) break;
-    reached[0] |= g0;
-    reached[1] |= g1;
+    if (((reach0 & hl.last_row[0]) | (reach1 & hl.last_row[1])) != 0ull) return 0;  // black
+    const bool n0 = ((hl.nb_lo[0] & reach0) | (hl.nb_hi[0] & reach1)) != 0ull;
+    const bool n1 = ((hl.nb_lo[1] & reach0) | (hl.nb_hi[1] & reach1)) != 0ull;
+    const uint64_t g0 = __ballot(n0) & blk0 & ~reach0, g1 = __ballot(n1) & blk1 & ~reach1;
+    if ((g0 | g1) == 0ull) break;
+    reach0 |= g0;
+    reach1 |= g1;
   }
   return 1;  // white: on a filled board exactly one side connects
 }
@@ -203,12 +229,19 @@ template <class G, bool kBoard, bool kHexFill>
 __global__ void __launch_bounds__(64 * kWavesPerBlock)
 k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, int num_actions,
             osg_mcts_cfg cfg, double max_utility, const double* __restrict__ log_table, Pool pool, MctsOut out) {
+  // The visit path of the running simulation, in LDS: node id [0:28) | META's player field [28:32), and
+  // the node's visit count / total reward as they were when the path went through it, so that the
+  // backup is stores only (no read-modify-write round trip to the pool).
   __shared__ uint32_t s_path[kWavesPerBlock][kMaxPath];
+  __shared__ uint32_t s_pcnt[kWavesPerBlock][kMaxPath];
+  __shared__ double s_ptot[kWavesPerBlock][kMaxPath];
   const int wave_in_block = static_cast<int>(threadIdx.x >> 6);
   const int64_t r = uniform(static_cast<int>(blockIdx.x * kWavesPerBlock + wave_in_block));
   if (r >= n) return;
   const int lane = lane_id();
   uint32_t* path = s_path[wave_in_block];
+  uint32_t* pcnt = s_pcnt[wave_in_block];
+  double* ptot = s_ptot[wave_in_block];
   const uint64_t gr = static_cast<uint64_t>(cfg.index_offset + r);
   const int cap = pool.cap;
   uint32_t* META = pool.meta + r * cap;
@@ -221,15 +254,23 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
 
   const typename G::State root_state = G::load(p, base, n, r);
   const int root_player = G::current_player(p, root_state);
+  // The root's header stays in registers (its count / total in path slot 0); every other node's header
+  // comes out of its parent's child scan by readlane, so a tree level costs ONE memory round trip.
+  uint32_t root_meta = make_meta(0xFF, root_player, 0);  // mcts.cc:356-357
+  uint32_t root_first = 0;
   if (lane == 0) {
-    META[0] = make_meta(0xFF, root_player, 0);  // mcts.cc:356-357
+    META[0] = root_meta;
     FIRST[0] = 0;
     COUNT[0] = 0;
     TOTAL[0] = 0.0;
+    path[0] = (root_meta >> 8 & 15u) << 28;
+    pcnt[0] = 0;
+    ptot[0] = 0.0;
   }
-  __threadfence_block();
+  wave_fence();
   uint32_t used = 1;
   int sims_done = 0;
+  PT_DECL
 
   for (int sim = 0; sim < cfg.max_simulations; ++sim) {
     Rng trng(cfg.seed ^ kTreeSalt, gr, static_cast<uint64_t>(sim));
@@ -238,19 +279,20 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
     uint32_t node = 0;
     int depth = 0;
     uint64_t ph = path_hash_root();
-    if (lane == 0) path[0] = 0;
+    uint32_t meta = root_meta, first = root_first;
+    uint32_t cnt = uniform(pcnt[0]);
     bool term;
+    PT_MARK(7);
     for (;;) {
       term = G::terminal(p, s);
-      const uint32_t cnt = uniform(COUNT[node]);
       if (term || cnt == 0 || depth + 1 >= kMaxPath) break;
-      uint32_t meta = uniform(META[node]);
       const int cur = G::current_player(p, s);
       const Mask legal = G::legal(p, s);
+      PT_MARK(0);
       if (m_nchild(meta) == 0) {  // expand: one child per Prior() entry, in action order
         const int c = legal.count();
         if (used + static_cast<uint32_t>(c) > static_cast<uint32_t>(cap)) break;  // pool exhausted: leaf evaluation
-        const uint32_t first = used;
+        first = used;
         used += c;
         // Children in action order.  Lane l looks at actions l and l + 64: a legal action's slot is its
         // rank among the legal ones (popcount of the mask below it) — the cheap direction of the
@@ -277,11 +319,17 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
           META[node] = meta;
           FIRST[node] = first;
         }
-        __threadfence_block();
+        if (node == 0) {
+          root_meta = meta;
+          root_first = first;
+        }
+        wave_fence();
       }
-      const uint32_t first = uniform(FIRST[node]);
+      PT_MARK(1);
       const int c = m_nchild(meta);
       int chosen_k, action;
+      uint32_t n_meta, n_cnt, n_first;
+      double n_tot;
       if (cur == kChancePlayer) {  // mcts.cc:311-322; children are in outcome order
         action = sample_action_chance<G>(p, s, legal, trng);
         int below = 0;
@@ -292,18 +340,26 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
           else if (action > lo) below += __builtin_popcount(legal.w[w] & ((1u << (action - lo)) - 1u));
         }
         chosen_k = below;
+        n_meta = uniform(META[first + chosen_k]);
+        n_cnt = uniform(COUNT[first + chosen_k]);
+        n_first = uniform(FIRST[first + chosen_k]);
+        n_tot = uniform_f64(TOTAL[first + chosen_k]);
       } else {  // arg-max of UCTValue (mcts.cc:90-101), ties to the smallest order key
-        uint32_t cm2[2], cc2[2];
+        uint32_t cm2[2], cc2[2], cf2[2];
+        double ct2[2];
         bool unvisited[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int k = lane + 64 * j;
           cm2[j] = 0;
           cc2[j] = 0;
+          cf2[j] = 0;
+          ct2[j] = 0.0;
           unvisited[j] = false;
           if (k < c) {
             cm2[j] = META[first + k];
             cc2[j] = COUNT[first + k];
+            cf2[j] = FIRST[first + k];
             unvisited[j] = cc2[j] == 0 && !m_has_outcome(cm2[j]);
           }
         }
@@ -312,7 +368,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
         const uint64_t u0 = __ballot(unvisited[0]), u1 = __ballot(unvisited[1]);
         if (!puct && (u0 | u1) != 0ull) {
           // Some child has never been visited: its value is +infinity (mcts.cc:95), so the maximum is
-          // +infinity whatever the others score — no UCT arithmetic needed at this node.
+          // +infinity whatever the others score — no UCT arithmetic (and no reward loads) at this node.
           t0 = unvisited[0];
           t1 = unvisited[1];
         } else {
@@ -325,6 +381,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
             v2[j] = -INFINITY;
             if (k < c) {
               const double ct = TOTAL[first + k];
+              ct2[j] = ct;
               if (m_has_outcome(cm2[j])) v2[j] = outcome_value<kBoard>(cm2[j], cc2[j], ct, m_player(cm2[j]));
               else if (puct) v2[j] = (cc2[j] != 0 ? ct / cc2[j] : 0.0) + cfg.uct_c * prior * sqrt_n / (cc2[j] + 1);
               else v2[j] = ct / cc2[j] + cfg.uct_c * sqrt(logn / cc2[j]);
@@ -345,22 +402,41 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
           chosen_k = w0 ? __builtin_ctzll(w0) : 64 + __builtin_ctzll(w1);
         }
         chosen_k = uniform(chosen_k);
-        action = static_cast<int>(m_action(uniform(META[first + chosen_k])));
+        // the chosen child's header, straight from the lane that scanned it
+        const int src = chosen_k & 63;
+        const bool hi = chosen_k >= 64;
+        n_meta = hi ? read_lane(cm2[1], src) : read_lane(cm2[0], src);
+        n_cnt = hi ? read_lane(cc2[1], src) : read_lane(cc2[0], src);
+        n_first = hi ? read_lane(cf2[1], src) : read_lane(cf2[0], src);
+        n_tot = hi ? read_lane_f64(ct2[1], src) : read_lane_f64(ct2[0], src);  // 0.0 when the rewards were not loaded:
+                                                                              // the chosen child is unvisited then
+        action = static_cast<int>(m_action(n_meta));
       }
+      PT_MARK(2);
       G::apply(p, s, action);
+      PT_MARK(3);
       node = first + static_cast<uint32_t>(chosen_k);
       ph = path_hash_child(ph, action);
       ++depth;
-      if (lane == 0) path[depth] = node;
+      if (lane == 0) {
+        path[depth] = node | ((n_meta >> 8 & 15u) << 28);
+        pcnt[depth] = n_cnt;
+        ptot[depth] = n_tot;
+      }
+      meta = n_meta;
+      cnt = n_cnt;
+      first = n_first;
     }
+    PT_MARK(0);
     // ---- evaluate (mcts.cc:372-381) ----
     double returns[kMaxPlayers];
     bool solved = false;
     if (term) {
       G::returns(p, s, returns);
-      uint32_t meta = uniform(META[node]) | (1u << 20) | (1u << 23);
+      meta |= (1u << 20) | (1u << 23);
       if (kBoard) meta = (meta & ~(3u << 21)) | (static_cast<uint32_t>(static_cast<int>(returns[0]) + 1) << 21);
       if (lane == 0) META[node] = meta;
+      if (node == 0) root_meta = meta;
       solved = cfg.solve != 0;
     } else if constexpr (kHexFill) {
       double r0 = 0.0;
@@ -391,24 +467,32 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
       }
       for (int q = 0; q < num_players; ++q) returns[q] /= cfg.n_rollouts;
     }
+    PT_MARK(5);
     // ---- backup (mcts.cc:383-395): lane d owns the d-th node of the visit path ----
     for (int d = lane; d <= depth; d += 64) {
-      const uint32_t v = path[d];
-      int pl = m_player(META[v]);
+      const uint32_t e = path[d];
+      const uint32_t v = e & 0x0FFFFFFFu;
+      int pl = static_cast<int>(e >> 28) - 1;
       for (int up = d; pl == kChancePlayer;) {  // skip chance-player entries (poker trees)
         if (--up < 0) { pl = 0; break; }
-        pl = m_player(META[path[up]]);
+        pl = static_cast<int>(path[up] >> 28) - 1;
       }
       double rv = returns[0];
       for (int q = 1; q < num_players; ++q) rv = (pl == q) ? returns[q] : rv;
-      TOTAL[v] += rv;
-      COUNT[v] += 1;
+      const double nt = ptot[d] + rv;
+      const uint32_t nc = pcnt[d] + 1;
+      TOTAL[v] = nt;
+      COUNT[v] = nc;
+      if (d == 0) {  // the root's statistics persist in slot 0
+        ptot[0] = nt;
+        pcnt[0] = nc;
+      }
     }
-    __threadfence_block();
+    wave_fence();
     // ---- MCTS-Solver (mcts.cc:398-434), leaf to root ----
     if (kBoard && solved) {
       for (int d = depth; d >= 0 && solved; --d) {
-        const uint32_t v = path[d];
+        const uint32_t v = uniform(path[d]) & 0x0FFFFFFFu;
         const uint32_t meta = uniform(META[v]);
         const int c = m_nchild(meta);
         if (c == 0) continue;
@@ -426,28 +510,31 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
         best = wave_argmax(best);
         const bool have = best.v > -INFINITY;
         if (have && (all_solved || best.v == max_utility)) {
-          if (lane == 0) META[v] = (meta & ~(3u << 21)) | (1u << 20) | (static_cast<uint32_t>(uniform(best.k)) << 21);
+          const uint32_t solved_meta = (meta & ~(3u << 21)) | (1u << 20) | (static_cast<uint32_t>(uniform(best.k)) << 21);
+          if (lane == 0) META[v] = solved_meta;
+          if (v == 0) root_meta = solved_meta;
         } else {
           solved = false;
         }
       }
-      __threadfence_block();
+      wave_fence();
     }
+    PT_MARK(6);
     ++sims_done;
-    const uint32_t rm = uniform(META[0]);
-    if (m_has_outcome(rm) || m_nchild(rm) == 1) break;  // mcts.cc:437-440 (a terminal root has an outcome too)
+    if (m_has_outcome(root_meta) || m_nchild(root_meta) == 1) break;  // mcts.cc:437-440 (a terminal root has an outcome too)
   }
 
+  PT_FLUSH;
   // ---- results: BestChild (mcts.cc:114-143) + per-action statistics ----
-  const uint32_t rm = uniform(META[0]);
+  const uint32_t rm = root_meta;
   const int c = m_nchild(rm);
-  const uint32_t first = uniform(FIRST[0]);
+  const uint32_t first = root_first;
   for (int a = lane; a < num_actions; a += 64) {
     if (out.child_visits) out.child_visits[r * num_actions + a] = 0;
     if (out.child_reward) out.child_reward[r * num_actions + a] = 0.0;
     if (out.child_outcome) out.child_outcome[r * num_actions + a] = 3;
   }
-  __threadfence_block();
+  wave_fence();
   Final best{-INFINITY, 0u, 0.0, ~0ull, -1};
   const uint64_t root_ph = path_hash_root();
   for (int k = lane; k < c; k += 64) {

@@ -31,6 +31,7 @@
 // Tree storage: node pool per root, ROOT-major (field[root * cap + node]) so a node's
 // children are one coalesced load per field.
 #include <cmath>
+#include <type_traits>
 
 #include "osg_mcts_internal.h"
 
@@ -73,6 +74,10 @@ OSG_D double uniform_f64(double v) {
 }
 OSG_D uint32_t read_lane(uint32_t v, int src) {  // src must be wave-uniform
   return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), src));
+}
+OSG_D uint64_t read_lane_u64(uint64_t v, int src) {
+  const uint32_t lo = read_lane(static_cast<uint32_t>(v), src), hi = read_lane(static_cast<uint32_t>(v >> 32), src);
+  return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 OSG_D double read_lane_f64(double v, int src) {
   const uint64_t u = static_cast<uint64_t>(__double_as_longlong(v));
@@ -147,6 +152,7 @@ OSG_D bool final_better(const Final& a, const Final& b) {  // a strictly preferr
 struct HexLane {
   uint64_t nb_lo[2];  // neighbours among cells 0-63
   uint64_t nb_hi[2];  // neighbours among cells 64-127
+  uint32_t edge;      // cell l: first row 1, last row 2, first column 4, last column 8; cell l + 64: the same << 4
   uint64_t board[2], first_row[2], last_row[2];  // wave-uniform cell sets
 };
 template <class G>
@@ -166,6 +172,12 @@ OSG_D HexLane hex_lane_setup(const typename G::Params& p) {
     hl.board[j] = uniform64(__ballot(on_board));
     hl.first_row[j] = uniform64(__ballot(on_board && G::test(p.row_first, cell)));
     hl.last_row[j] = uniform64(__ballot(on_board && G::test(p.row_last, cell)));
+    uint32_t e = 0;
+    if (on_board) {
+      e = (G::test(p.row_first, cell) ? 1u : 0u) | (G::test(p.row_last, cell) ? 2u : 0u) |
+          (G::test(p.col_first, cell) ? 4u : 0u) | (G::test(p.col_last, cell) ? 8u : 0u);
+    }
+    if (j == 0) hl.edge = e; else hl.edge |= e << 4;
   }
   return hl;
 }
@@ -178,12 +190,122 @@ OSG_D uint64_t hex_cells64(const typename G::Bits& b, int j) {
   return uniform64(static_cast<uint64_t>(hi) << 32 | lo);
 }
 
+// The hex position the search walks with (no swap rule): HexT's State re-packed as pairs of 64-bit
+// cell sets, wave-uniform, so that the rules run as scalar set algebra plus lane-parallel neighbour
+// tests against HexLane instead of multi-word shifts.  Same fields, same update rules as HexT::apply.
+struct HexW {
+  uint64_t blk[2], wht[2], ea[2], eb[2];
+  uint32_t meta;  // HexT::State::meta: to move [0], result [1:3), plies [8:16), first move [16:24)
+};
 template <class G>
-OSG_D int hex_fill_winner(const typename G::Params& p, const typename G::State& s, uint64_t base, const HexLane& hl) {
+OSG_D HexW hexw_from_state(const typename G::State& s) {
+  HexW w;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    w.blk[j] = hex_cells64<G>(s.black, j);
+    w.wht[j] = hex_cells64<G>(s.white, j);
+    w.ea[j] = hex_cells64<G>(s.ea, j);
+    w.eb[j] = hex_cells64<G>(s.eb, j);
+  }
+  w.meta = uniform(s.meta);
+  return w;
+}
+OSG_D bool hexw_terminal(const HexW& w) { return ((w.meta >> 1) & 3u) != 0; }
+OSG_D int hexw_current_player(const HexW& w) { return hexw_terminal(w) ? kTerminalPlayer : static_cast<int>(w.meta & 1u); }
+OSG_D Mask hexw_legal(const HexLane& hl, const HexW& w) {  // hex.cc:280-293 without the swap action
+  Mask m;
+  if (hexw_terminal(w)) return m;
+  const uint64_t e0 = hl.board[0] & ~(w.blk[0] | w.wht[0]), e1 = hl.board[1] & ~(w.blk[1] | w.wht[1]);
+  m.w[0] = static_cast<uint32_t>(e0);
+  m.w[1] = static_cast<uint32_t>(e0 >> 32);
+  m.w[2] = static_cast<uint32_t>(e1);
+  m.w[3] = static_cast<uint32_t>(e1 >> 32);
+  return m;
+}
+OSG_D void hexw_returns(const HexW& w, double* out) {  // hex.cc:363-365
+  const int res = (w.meta >> 1) & 3u;
+  const double r = res == 1 ? 1.0 : (res == 2 ? -1.0 : 0.0);
+  out[0] = r;
+  out[1] = -r + 0.0;
+}
+// PlayerAndActionToState (hex.cc:108-171) + DoApplyAction (hex.cc:229-278), as HexT::place / apply.
+OSG_D void hexw_apply(const HexLane& hl, HexW& w, int move) {
+  const int src = move & 63;
+  const bool hi = move >= 64;
+  const uint64_t bit = 1ull << src;
+  // the new stone's neighbour set and edge flags, from the lane that owns the cell
+  const uint64_t nb0 = hi ? read_lane_u64(hl.nb_lo[1], src) : read_lane_u64(hl.nb_lo[0], src);
+  const uint64_t nb1 = hi ? read_lane_u64(hl.nb_hi[1], src) : read_lane_u64(hl.nb_hi[0], src);
+  const uint32_t edge = (read_lane(hl.edge, src) >> (hi ? 4 : 0)) & 15u;
+  const int player = w.meta & 1u;
+  const bool black = player == 0;
+  // black: first row -> North(A), ELSE IF last row -> South(B); white: first column -> West(A),
+  // ELSE IF last column -> East(B) (hex.cc:122-126,146-150)
+  const bool on_first = black ? (edge & 1u) != 0 : (edge & 4u) != 0;
+  const bool on_last = black ? (edge & 2u) != 0 : (edge & 8u) != 0;
+  bool a = on_first, b = !on_first && on_last;
+  uint64_t own0 = black ? w.blk[0] : w.wht[0], own1 = black ? w.blk[1] : w.wht[1];
+  const uint64_t n0 = nb0 & own0, n1 = nb1 & own1;
+  // a neighbour labelled exactly A (not Win) / exactly B
+  a |= ((n0 & w.ea[0] & ~w.eb[0]) | (n1 & w.ea[1] & ~w.eb[1])) != 0ull;
+  b |= ((n0 & w.eb[0] & ~w.ea[0]) | (n1 & w.eb[1] & ~w.ea[1])) != 0ull;
+  if (hi) own1 |= bit; else own0 |= bit;
+  if (a) { if (hi) w.ea[1] |= bit; else w.ea[0] |= bit; }
+  if (b) { if (hi) w.eb[1] |= bit; else w.eb[0] |= bit; }
+  uint32_t res = 0;
+  if (a && b) {
+    res = black ? 1u : 2u;  // Win label; no flood fill (hex.cc:248-252)
+  } else if (a || b) {
+    // flood the plain same-colour group reachable from the new stone: lane-parallel neighbour tests
+    const uint64_t plain0 = own0 & ~w.ea[0] & ~w.eb[0], plain1 = own1 & ~w.ea[1] & ~w.eb[1];
+    uint64_t region0 = 0ull, region1 = 0ull;
+    uint64_t front0 = hi ? 0ull : bit, front1 = hi ? bit : 0ull;
+    for (int it = 0; it < 128; ++it) {
+      const bool t0 = ((hl.nb_lo[0] & front0) | (hl.nb_hi[0] & front1)) != 0ull;
+      const bool t1 = ((hl.nb_lo[1] & front0) | (hl.nb_hi[1] & front1)) != 0ull;
+      const uint64_t g0 = __ballot(t0) & plain0 & ~region0, g1 = __ballot(t1) & plain1 & ~region1;
+      if ((g0 | g1) == 0ull) break;
+      region0 |= g0;
+      region1 |= g1;
+      front0 = g0;
+      front1 = g1;
+    }
+    if (a) { w.ea[0] |= region0; w.ea[1] |= region1; }
+    else { w.eb[0] |= region0; w.eb[1] |= region1; }
+  }
+  if (black) { w.blk[0] = own0; w.blk[1] = own1; } else { w.wht[0] = own0; w.wht[1] = own1; }
+  const uint32_t ply = (w.meta >> 8) & 0xFFu;
+  const uint32_t ply_next = ply < 255u ? ply + 1u : 255u;
+  const uint32_t first = ply == 0 ? static_cast<uint32_t>(move) : ((w.meta >> 16) & 0xFFu);
+  w.meta = static_cast<uint32_t>(1 - player) | (res << 1) | (ply_next << 8) | (first << 16);
+}
+
+// The rules as the search sees them: HexW for the hex fill kernel, G::State otherwise.
+template <class G>
+OSG_D bool w_terminal(const typename G::Params& p, const typename G::State& s) { return G::terminal(p, s); }
+template <class G>
+OSG_D bool w_terminal(const typename G::Params&, const HexW& w) { return hexw_terminal(w); }
+template <class G>
+OSG_D int w_current_player(const typename G::Params& p, const typename G::State& s) { return G::current_player(p, s); }
+template <class G>
+OSG_D int w_current_player(const typename G::Params&, const HexW& w) { return hexw_current_player(w); }
+template <class G>
+OSG_D Mask w_legal(const typename G::Params& p, const HexLane&, const typename G::State& s) { return G::legal(p, s); }
+template <class G>
+OSG_D Mask w_legal(const typename G::Params&, const HexLane& hl, const HexW& w) { return hexw_legal(hl, w); }
+template <class G>
+OSG_D void w_apply(const typename G::Params& p, const HexLane&, typename G::State& s, int a) { G::apply(p, s, a); }
+template <class G>
+OSG_D void w_apply(const typename G::Params&, const HexLane& hl, HexW& w, int a) { hexw_apply(hl, w, a); }
+template <class G>
+OSG_D void w_returns(const typename G::Params& p, const typename G::State& s, double* out) { G::returns(p, s, out); }
+template <class G>
+OSG_D void w_returns(const typename G::Params&, const HexW& w, double* out) { hexw_returns(w, out); }
+
+OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl) {
   const int lane = lane_id();
-  const uint64_t black0 = hex_cells64<G>(s.black, 0), black1 = hex_cells64<G>(s.black, 1);
-  const uint64_t white0 = hex_cells64<G>(s.white, 0), white1 = hex_cells64<G>(s.white, 1);
-  const uint64_t empty0 = hl.board[0] & ~(black0 | white0), empty1 = hl.board[1] & ~(black1 | white1);
+  const uint64_t black0 = s.blk[0], black1 = s.blk[1];
+  const uint64_t empty0 = hl.board[0] & ~(black0 | s.wht[0]), empty1 = hl.board[1] & ~(black1 | s.wht[1]);
   const uint64_t key0 = fill_key(base, lane), key1 = fill_key(base, lane + 64);
   const int m = __builtin_popcountll(empty0) + __builtin_popcountll(empty1);
   const int want = (m + 1) >> 1;  // plies 0, 2, 4, ... belong to the player to move
@@ -206,7 +328,7 @@ OSG_D int hex_fill_winner(const typename G::Params& p, const typename G::State& 
     }
   }
   // The filled board: the mover's new stones are `sel`, the opponent's the other empty cells.
-  const bool black_moves = G::to_move(s) == 0;
+  const bool black_moves = (s.meta & 1u) == 0;
   const uint64_t blk0 = black0 | (black_moves ? sel0 : empty0 & ~sel0);
   const uint64_t blk1 = black1 | (black_moves ? sel1 : empty1 & ~sel1);
   // Black wins iff its stones join the first row to the last row (hex.cc:108-171 edge labels).
@@ -252,8 +374,12 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
   HexLane hl{};
   if constexpr (kHexFill) hl = hex_lane_setup<G>(p);
 
-  const typename G::State root_state = G::load(p, base, n, r);
-  const int root_player = G::current_player(p, root_state);
+  using WState = std::conditional_t<kHexFill, HexW, typename G::State>;
+  const typename G::State loaded_root = G::load(p, base, n, r);
+  WState root_state;
+  if constexpr (kHexFill) root_state = hexw_from_state<G>(loaded_root);
+  else root_state = loaded_root;
+  const int root_player = w_current_player<G>(p, root_state);
   // The root's header stays in registers (its count / total in path slot 0); every other node's header
   // comes out of its parent's child scan by readlane, so a tree level costs ONE memory round trip.
   uint32_t root_meta = make_meta(0xFF, root_player, 0);  // mcts.cc:356-357
@@ -275,7 +401,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
   for (int sim = 0; sim < cfg.max_simulations; ++sim) {
     Rng trng(cfg.seed ^ kTreeSalt, gr, static_cast<uint64_t>(sim));
     // ---- ApplyTreePolicy (mcts.cc:273-351) ----
-    typename G::State s = root_state;
+    WState s = root_state;
     uint32_t node = 0;
     int depth = 0;
     uint64_t ph = path_hash_root();
@@ -284,10 +410,10 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
     bool term;
     PT_MARK(7);
     for (;;) {
-      term = G::terminal(p, s);
+      term = w_terminal<G>(p, s);
       if (term || cnt == 0 || depth + 1 >= kMaxPath) break;
-      const int cur = G::current_player(p, s);
-      const Mask legal = G::legal(p, s);
+      const int cur = w_current_player<G>(p, s);
+      const Mask legal = w_legal<G>(p, hl, s);
       PT_MARK(0);
       if (m_nchild(meta) == 0) {  // expand: one child per Prior() entry, in action order
         const int c = legal.count();
@@ -330,8 +456,9 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
       int chosen_k, action;
       uint32_t n_meta, n_cnt, n_first;
       double n_tot;
-      if (cur == kChancePlayer) {  // mcts.cc:311-322; children are in outcome order
-        action = sample_action_chance<G>(p, s, legal, trng);
+      if (!kHexFill && cur == kChancePlayer) {  // mcts.cc:311-322; children are in outcome order
+        action = 0;
+        if constexpr (!kHexFill) action = sample_action_chance<G>(p, s, legal, trng);
         int below = 0;
 #pragma unroll
         for (int w = 0; w < kMaskWords; ++w) {
@@ -413,7 +540,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
         action = static_cast<int>(m_action(n_meta));
       }
       PT_MARK(2);
-      G::apply(p, s, action);
+      w_apply<G>(p, hl, s, action);
       PT_MARK(3);
       node = first + static_cast<uint32_t>(chosen_k);
       ph = path_hash_child(ph, action);
@@ -432,7 +559,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
     double returns[kMaxPlayers];
     bool solved = false;
     if (term) {
-      G::returns(p, s, returns);
+      w_returns<G>(p, s, returns);
       meta |= (1u << 20) | (1u << 23);
       if (kBoard) meta = (meta & ~(3u << 21)) | (static_cast<uint32_t>(static_cast<int>(returns[0]) + 1) << 21);
       if (lane == 0) META[node] = meta;
@@ -442,7 +569,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
       double r0 = 0.0;
       for (int ro = 0; ro < cfg.n_rollouts; ++ro) {
         const uint64_t fb = fill_base(cfg.seed, gr, static_cast<uint64_t>(sim) * cfg.n_rollouts + ro);
-        r0 += hex_fill_winner<G>(p, s, fb, hl) == 0 ? 1.0 : -1.0;
+        r0 += hex_fill_winner(s, fb, hl) == 0 ? 1.0 : -1.0;
       }
       returns[0] = r0 / cfg.n_rollouts;
       returns[1] = -returns[0] + 0.0;

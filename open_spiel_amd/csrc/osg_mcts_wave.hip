@@ -347,8 +347,11 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl) {
   return 1;  // white: on a filled board exactly one side connects
 }
 
+#ifndef OSG_WPE
+#define OSG_WPE 4
+#endif
 template <class G, bool kBoard, bool kHexFill>
-__global__ void __launch_bounds__(64 * kWavesPerBlock)
+__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(OSG_WPE, 8)))
 k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, int num_actions,
             osg_mcts_cfg cfg, double max_utility, const double* __restrict__ log_table, Pool pool, MctsOut out) {
   // The visit path of the running simulation, in LDS: node id [0:28) | META's player field [28:32), and
@@ -410,6 +413,14 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
     bool term;
     PT_MARK(7);
     for (;;) {
+#ifdef OSG_DIAG_UNIFORM
+      if constexpr (kHexFill) {
+        s.meta = uniform(s.meta);
+        for (int j = 0; j < 2; ++j) { s.blk[j] = uniform64(s.blk[j]); s.wht[j] = uniform64(s.wht[j]); s.ea[j] = uniform64(s.ea[j]); s.eb[j] = uniform64(s.eb[j]); }
+      }
+      meta = uniform(meta); cnt = uniform(cnt); first = uniform(first); used = uniform(used); node = uniform(node);
+      depth = uniform(depth); ph = uniform64(ph); root_meta = uniform(root_meta); root_first = uniform(root_first);
+#endif
       term = w_terminal<G>(p, s);
       if (term || cnt == 0 || depth + 1 >= kMaxPath) break;
       const int cur = w_current_player<G>(p, s);
@@ -540,16 +551,18 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
         action = static_cast<int>(m_action(n_meta));
       }
       PT_MARK(2);
-      w_apply<G>(p, hl, s, action);
-      PT_MARK(3);
       node = first + static_cast<uint32_t>(chosen_k);
       ph = path_hash_child(ph, action);
       ++depth;
+      // (kept ahead of apply on purpose: if this lane-0 block were the last thing in the loop body, its join
+      // would be the loop latch, and the compiler would then treat every loop-carried value as lane-varying)
       if (lane == 0) {
         path[depth] = node | ((n_meta >> 8 & 15u) << 28);
         pcnt[depth] = n_cnt;
         ptot[depth] = n_tot;
       }
+      w_apply<G>(p, hl, s, action);
+      PT_MARK(3);
       meta = n_meta;
       cnt = n_cnt;
       first = n_first;
@@ -562,6 +575,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
       w_returns<G>(p, s, returns);
       meta |= (1u << 20) | (1u << 23);
       if (kBoard) meta = (meta & ~(3u << 21)) | (static_cast<uint32_t>(static_cast<int>(returns[0]) + 1) << 21);
+      meta = uniform(meta);  // `returns` is a per-lane array to the compiler; the header is wave-uniform
       if (lane == 0) META[node] = meta;
       if (node == 0) root_meta = meta;
       solved = cfg.solve != 0;
@@ -635,8 +649,10 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
         }
         const bool all_solved = __ballot(unsolved_here) == 0ull;
         best = wave_argmax(best);
-        const bool have = best.v > -INFINITY;
-        if (have && (all_solved || best.v == max_utility)) {
+        // every lane holds the same `best` after the butterfly; say so, or the compiler treats the
+        // branch — and with it the root header and the whole position — as lane-varying
+        const bool mark = uniform(static_cast<int>(best.v > -INFINITY && (all_solved || best.v == max_utility))) != 0;
+        if (mark) {
           const uint32_t solved_meta = (meta & ~(3u << 21)) | (1u << 20) | (static_cast<uint32_t>(uniform(best.k)) << 21);
           if (lane == 0) META[v] = solved_meta;
           if (v == 0) root_meta = solved_meta;

@@ -347,11 +347,10 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl) {
   return 1;  // white: on a filled board exactly one side connects
 }
 
-#ifndef OSG_WPE
-#define OSG_WPE 4
-#endif
+// The hex fill kernel fits 6 waves per SIMD without spilling; the generic instantiations carry more
+// per-lane state (their playouts run one per lane): 4 waves with a little scratch measured faster than 2-3 without.
 template <class G, bool kBoard, bool kHexFill>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(OSG_WPE, 8)))
+__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(kHexFill ? 6 : 4, 8)))
 k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, int num_actions,
             osg_mcts_cfg cfg, double max_utility, const double* __restrict__ log_table, Pool pool, MctsOut out) {
   // The visit path of the running simulation, in LDS: node id [0:28) | META's player field [28:32), and

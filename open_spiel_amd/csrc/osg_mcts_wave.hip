@@ -107,21 +107,45 @@ OSG_D Cand wave_argmax(Cand c) {
   }
   return c;
 }
+// Wave-wide max / min as a DPP reduction (gfx9 row_shr 1, 2, 4, 8, then row_bcast 15 and 31): six
+// register-to-register steps, no LDS permutes; lane 63 ends up with the result, which is handed back
+// wave-uniform.  All 64 lanes must be active.
+template <int kCtrl, int kRowMask>
+OSG_D uint32_t dpp_move(uint32_t identity, uint32_t v) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(identity), static_cast<int>(v), kCtrl,
+                                                           kRowMask, 0xf, false));
+}
+template <int kCtrl, int kRowMask>
+OSG_D double dpp_max_step(double v) {
+  const uint64_t u = static_cast<uint64_t>(__double_as_longlong(v));
+  constexpr uint64_t kNegInf = 0xFFF0000000000000ull;
+  const uint32_t lo = dpp_move<kCtrl, kRowMask>(static_cast<uint32_t>(kNegInf), static_cast<uint32_t>(u));
+  const uint32_t hi = dpp_move<kCtrl, kRowMask>(static_cast<uint32_t>(kNegInf >> 32), static_cast<uint32_t>(u >> 32));
+  const double o = __longlong_as_double(static_cast<long long>(static_cast<uint64_t>(hi) << 32 | lo));
+  return o > v ? o : v;
+}
 OSG_D double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const double o = __shfl_xor(v, off);
-    v = o > v ? o : v;
-  }
-  return v;
+  v = dpp_max_step<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_max_step<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_max_step<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_max_step<0x118, 0xf>(v);  // row_shr:8
+  v = dpp_max_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_max_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return read_lane_f64(v, 63);
+}
+template <int kCtrl, int kRowMask>
+OSG_D uint32_t dpp_min_step(uint32_t v) {
+  const uint32_t o = dpp_move<kCtrl, kRowMask>(0xFFFFFFFFu, v);
+  return o < v ? o : v;
 }
 OSG_D uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const uint32_t o = __shfl_xor(v, off);
-    v = o < v ? o : v;
-  }
-  return v;
+  v = dpp_min_step<0x111, 0xf>(v);
+  v = dpp_min_step<0x112, 0xf>(v);
+  v = dpp_min_step<0x114, 0xf>(v);
+  v = dpp_min_step<0x118, 0xf>(v);
+  v = dpp_min_step<0x142, 0xa>(v);
+  v = dpp_min_step<0x143, 0xc>(v);
+  return read_lane(v, 63);
 }
 OSG_D double wave_sum(double v) {
 #pragma unroll

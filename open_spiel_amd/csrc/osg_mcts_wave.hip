@@ -533,19 +533,36 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
           t0 = unvisited[0];
           t1 = unvisited[1];
         } else {
-          const double logn = log_table[cnt];
-          const double prior = 1.0 / c, sqrt_n = sqrt(static_cast<double>(cnt));  // PUCT only
           double v2[2];
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int k = lane + 64 * j;
             v2[j] = -INFINITY;
-            if (k < c) {
-              const double ct = TOTAL[first + k];
-              ct2[j] = ct;
-              if (m_has_outcome(cm2[j])) v2[j] = outcome_value<kBoard>(cm2[j], cc2[j], ct, m_player(cm2[j]));
-              else if (puct) v2[j] = (cc2[j] != 0 ? ct / cc2[j] : 0.0) + cfg.uct_c * prior * sqrt_n / (cc2[j] + 1);
-              else v2[j] = ct / cc2[j] + cfg.uct_c * sqrt(logn / cc2[j]);
+            if (k < c) ct2[j] = TOTAL[first + k];
+          }
+          if (puct) {  // uniform branch: the two policies share nothing but the loads
+            const double prior = 1.0 / c, sqrt_n = sqrt(static_cast<double>(cnt));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int k = lane + 64 * j;
+              if (k < c) {
+                if (m_has_outcome(cm2[j])) v2[j] = outcome_value<kBoard>(cm2[j], cc2[j], ct2[j], m_player(cm2[j]));
+                else v2[j] = (cc2[j] != 0 ? ct2[j] / cc2[j] : 0.0) + cfg.uct_c * prior * sqrt_n / (cc2[j] + 1);
+              }
+            }
+          } else {
+            const double logn = log_table[cnt];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int k = lane + 64 * j;
+              // straight-line: lanes without a child divide by zero and are masked by the select below
+              double val = ct2[j] / cc2[j] + cfg.uct_c * sqrt(logn / cc2[j]);
+              if constexpr (kBoard) {
+                val = m_has_outcome(cm2[j]) ? outcome_value<true>(cm2[j], cc2[j], ct2[j], m_player(cm2[j])) : val;
+              } else {
+                if (m_has_outcome(cm2[j])) val = outcome_value<false>(cm2[j], cc2[j], ct2[j], m_player(cm2[j]));
+              }
+              v2[j] = k < c ? val : -INFINITY;
             }
           }
           const double vmax = wave_max(v2[0] > v2[1] ? v2[0] : v2[1]);  // value only: 2 dwords per butterfly step

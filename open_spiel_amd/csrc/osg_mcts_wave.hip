@@ -254,36 +254,40 @@ OSG_D void hexw_returns(const HexW& w, double* out) {  // hex.cc:363-365
 }
 // PlayerAndActionToState (hex.cc:108-171) + DoApplyAction (hex.cc:229-278), as HexT::place / apply.
 OSG_D void hexw_apply(const HexLane& hl, HexW& w, int move) {
+  // Everything here is wave-uniform; selects instead of branches keep it to a few dozen scalar
+  // instructions (only the relabelling flood is a loop).
   const int src = move & 63;
   const bool hi = move >= 64;
   const uint64_t bit = 1ull << src;
+  const uint64_t bit0 = hi ? 0ull : bit, bit1 = hi ? bit : 0ull;
   // the new stone's neighbour set and edge flags, from the lane that owns the cell
-  const uint64_t nb0 = hi ? read_lane_u64(hl.nb_lo[1], src) : read_lane_u64(hl.nb_lo[0], src);
-  const uint64_t nb1 = hi ? read_lane_u64(hl.nb_hi[1], src) : read_lane_u64(hl.nb_hi[0], src);
+  const uint64_t nb0 = read_lane_u64(hi ? hl.nb_lo[1] : hl.nb_lo[0], src);
+  const uint64_t nb1 = read_lane_u64(hi ? hl.nb_hi[1] : hl.nb_hi[0], src);
   const uint32_t edge = (read_lane(hl.edge, src) >> (hi ? 4 : 0)) & 15u;
   const int player = w.meta & 1u;
   const bool black = player == 0;
   // black: first row -> North(A), ELSE IF last row -> South(B); white: first column -> West(A),
   // ELSE IF last column -> East(B) (hex.cc:122-126,146-150)
-  const bool on_first = black ? (edge & 1u) != 0 : (edge & 4u) != 0;
-  const bool on_last = black ? (edge & 2u) != 0 : (edge & 8u) != 0;
-  bool a = on_first, b = !on_first && on_last;
+  const bool on_first = (edge & (black ? 1u : 4u)) != 0;
+  const bool on_last = (edge & (black ? 2u : 8u)) != 0;
   uint64_t own0 = black ? w.blk[0] : w.wht[0], own1 = black ? w.blk[1] : w.wht[1];
   const uint64_t n0 = nb0 & own0, n1 = nb1 & own1;
   // a neighbour labelled exactly A (not Win) / exactly B
-  a |= ((n0 & w.ea[0] & ~w.eb[0]) | (n1 & w.ea[1] & ~w.eb[1])) != 0ull;
-  b |= ((n0 & w.eb[0] & ~w.ea[0]) | (n1 & w.eb[1] & ~w.ea[1])) != 0ull;
-  if (hi) own1 |= bit; else own0 |= bit;
-  if (a) { if (hi) w.ea[1] |= bit; else w.ea[0] |= bit; }
-  if (b) { if (hi) w.eb[1] |= bit; else w.eb[0] |= bit; }
-  uint32_t res = 0;
-  if (a && b) {
-    res = black ? 1u : 2u;  // Win label; no flood fill (hex.cc:248-252)
-  } else if (a || b) {
+  const bool a = on_first | (((n0 & w.ea[0] & ~w.eb[0]) | (n1 & w.ea[1] & ~w.eb[1])) != 0ull);
+  const bool b = (!on_first & on_last) | (((n0 & w.eb[0] & ~w.ea[0]) | (n1 & w.eb[1] & ~w.ea[1])) != 0ull);
+  const uint64_t am = a ? ~0ull : 0ull, bm = b ? ~0ull : 0ull;
+  own0 |= bit0;
+  own1 |= bit1;
+  w.ea[0] |= bit0 & am;
+  w.ea[1] |= bit1 & am;
+  w.eb[0] |= bit0 & bm;
+  w.eb[1] |= bit1 & bm;
+  const uint32_t res = (a & b) ? (black ? 1u : 2u) : 0u;  // Win label; no flood fill (hex.cc:248-252)
+  if (a != b) {
     // flood the plain same-colour group reachable from the new stone: lane-parallel neighbour tests
     const uint64_t plain0 = own0 & ~w.ea[0] & ~w.eb[0], plain1 = own1 & ~w.ea[1] & ~w.eb[1];
     uint64_t region0 = 0ull, region1 = 0ull;
-    uint64_t front0 = hi ? 0ull : bit, front1 = hi ? bit : 0ull;
+    uint64_t front0 = bit0, front1 = bit1;
     for (int it = 0; it < 128; ++it) {
       const bool t0 = ((hl.nb_lo[0] & front0) | (hl.nb_hi[0] & front1)) != 0ull;
       const bool t1 = ((hl.nb_lo[1] & front0) | (hl.nb_hi[1] & front1)) != 0ull;
@@ -294,10 +298,15 @@ OSG_D void hexw_apply(const HexLane& hl, HexW& w, int move) {
       front0 = g0;
       front1 = g1;
     }
-    if (a) { w.ea[0] |= region0; w.ea[1] |= region1; }
-    else { w.eb[0] |= region0; w.eb[1] |= region1; }
+    w.ea[0] |= region0 & am;
+    w.ea[1] |= region1 & am;
+    w.eb[0] |= region0 & bm;
+    w.eb[1] |= region1 & bm;
   }
-  if (black) { w.blk[0] = own0; w.blk[1] = own1; } else { w.wht[0] = own0; w.wht[1] = own1; }
+  w.blk[0] = black ? own0 : w.blk[0];
+  w.blk[1] = black ? own1 : w.blk[1];
+  w.wht[0] = black ? w.wht[0] : own0;
+  w.wht[1] = black ? w.wht[1] : own1;
   const uint32_t ply = (w.meta >> 8) & 0xFFu;
   const uint32_t ply_next = ply < 255u ? ply + 1u : 255u;
   const uint32_t first = ply == 0 ? static_cast<uint32_t>(move) : ((w.meta >> 16) & 0xFFu);
@@ -581,13 +590,15 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
         }
         chosen_k = uniform(chosen_k);
         // the chosen child's header, straight from the lane that scanned it
+        // (the slot is picked per lane first so that each field costs one readlane; a ternary of two
+        // readlanes is compiled into a chain of scalar branches)
         const int src = chosen_k & 63;
         const bool hi = chosen_k >= 64;
-        n_meta = hi ? read_lane(cm2[1], src) : read_lane(cm2[0], src);
-        n_cnt = hi ? read_lane(cc2[1], src) : read_lane(cc2[0], src);
-        n_first = hi ? read_lane(cf2[1], src) : read_lane(cf2[0], src);
-        n_tot = hi ? read_lane_f64(ct2[1], src) : read_lane_f64(ct2[0], src);  // 0.0 when the rewards were not loaded:
-                                                                              // the chosen child is unvisited then
+        n_meta = read_lane(hi ? cm2[1] : cm2[0], src);
+        n_cnt = read_lane(hi ? cc2[1] : cc2[0], src);
+        n_first = read_lane(hi ? cf2[1] : cf2[0], src);
+        n_tot = read_lane_f64(hi ? ct2[1] : ct2[0], src);  // 0.0 when the rewards were not loaded: the chosen
+                                                           // child is unvisited then
         action = static_cast<int>(m_action(n_meta));
       }
       PT_MARK(2);

@@ -346,20 +346,20 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl) {
   // under it.  T is built most-significant bit first (a binary search on the key space): a bit stays
   // set while no more than `want` keys lie below.  Keys are distinct, so the search ends as soon as the
   // count is exact — about log2(m) + 2 steps of two compares and a handful of scalar instructions.
-  uint64_t thr = 0ull, sel0 = 0ull, sel1 = 0ull;
+  uint64_t thr = 0ull;
   if (want > 0) {
-    for (int bit = 63; bit >= 0; --bit) {
-      const uint64_t probe = thr | (1ull << bit);
-      const uint64_t c0 = __ballot(key0 < probe) & empty0, c1 = __ballot(key1 < probe) & empty1;
-      const int below = __builtin_popcountll(c0) + __builtin_popcountll(c1);
-      if (below <= want) {
-        thr = probe;
-        sel0 = c0;
-        sel1 = c1;
-        if (below == want) break;
-      }
-    }
+    uint64_t step = 1ull << 63;
+    bool exact;
+    do {  // straight-line body: one select, no inner branch
+      const uint64_t probe = thr | step;
+      const int below = __builtin_popcountll(__ballot(key0 < probe) & empty0) +
+                        __builtin_popcountll(__ballot(key1 < probe) & empty1);
+      thr = below <= want ? probe : thr;
+      exact = below == want;
+      step >>= 1;
+    } while (!exact && step != 0ull);
   }
+  const uint64_t sel0 = __ballot(key0 < thr) & empty0, sel1 = __ballot(key1 < thr) & empty1;
   // The filled board: the mover's new stones are `sel`, the opponent's the other empty cells.
   const bool black_moves = (s.meta & 1u) == 0;
   const uint64_t blk0 = black0 | (black_moves ? sel0 : empty0 & ~sel0);

@@ -1,18 +1,26 @@
 // algorithms::MCTSBot (open_spiel/algorithms/mcts.{h,cc}), ONE WAVEFRONT PER ROOT.
 //
 // The 64 lanes of a wavefront cooperate on one search tree:
-//   * selection   (mcts.cc:324-341)  children of a node are contiguous; lane l
-//                 scores children l and l+64 (UCTValue, mcts.cc:90-101) and a
-//                 6-step shuffle butterfly picks the arg-max
+//   * selection   (mcts.cc:324-341)  children of a node are contiguous; lane l scans
+//                 children l and l+64 (header + statistics), scores them (UCTValue,
+//                 mcts.cc:90-101), a DPP reduction finds the maximum and a ballot who
+//                 holds it; the chosen child's header is handed down by readlane, so a
+//                 tree level costs one memory round trip
 //   * expansion   (mcts.cc:281-299)  lane l initialises children l, l+64
 //   * evaluation  (mcts.cc:43-72)    n_rollouts playouts spread over the lanes; a
 //                 hex playout is ONE wave-parallel random fill of the board
-//                 (lane = cell): ballot radix-select of the mover's half, then a
-//                 wave-uniform bitboard flood fill decides the winner
-//   * backup      (mcts.cc:383-395)  lane d updates the d-th node of the path
+//                 (lane = cell): a binary search on the key threshold hands the mover
+//                 its half, then a lane-parallel flood fill over uniform cell sets
+//                 decides the winner
+//   * backup      (mcts.cc:383-395)  lane d updates the d-th node of the path from the
+//                 statistics the path carried down (stores only)
 //   * MCTS-Solver (mcts.cc:398-434)  lanes scan the children, ballot / shuffle reduce
-// The board state itself is wave-uniform (every lane holds the same bitboards), so
-// the rule code runs without divergence.
+// The position itself is wave-uniform and kept in scalar registers (hex: HexW, pairs of
+// 64-bit cell sets), so the rule code is scalar set algebra plus per-lane neighbour
+// tests.  Everything the compiler must see as wave-uniform is made so explicitly
+// (readfirstlane / readlane / ballot); `opt -passes=print<uniformity>` on this file is
+// the check — a single lane-varying value on the loop-carried path turns the whole
+// position into vector registers and the scalar branches into exec-mask branches.
 //
 // Random streams (shared with the oracle's replay, oracle MCTSBot mode 2):
 //   sibling order  the reference shuffles a new node's children and lets the first
@@ -380,10 +388,13 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl) {
   return 1;  // white: on a filled board exactly one side connects
 }
 
+#ifndef OSG_HEX_WPE
+#define OSG_HEX_WPE 6
+#endif
 // The hex fill kernel fits 6 waves per SIMD without spilling; the generic instantiations carry more
 // per-lane state (their playouts run one per lane): 4 waves with a little scratch measured faster than 2-3 without.
 template <class G, bool kBoard, bool kHexFill>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(kHexFill ? 6 : 4, 8)))
+__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(kHexFill ? OSG_HEX_WPE : 4, 8)))
 k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, int num_actions,
             osg_mcts_cfg cfg, double max_utility, const double* __restrict__ log_table, Pool pool, MctsOut out) {
   // The visit path of the running simulation, in LDS: node id [0:28) | META's player field [28:32), and

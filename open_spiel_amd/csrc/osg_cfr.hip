@@ -310,6 +310,16 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
   int o_k = kTerminalNode, o_fc = 0, o_nc = 0, o_row = 0, o_lvl = -1;
   int b_h = 0, b_pl = -1, b_i = 0, b_n = 0, b_fc = 0, b_e0 = 0, b_e1 = 0;
   int c_n = 0, c_pl = -1, c_m0 = 0, c_m1 = 0;
+  // The root path of the owned decision history: its chance factors never change, so their product (same
+  // order as the walk) is taken once; the decision entries (slot << 24 | policy index) stay in registers,
+  // which turns the per-iteration reach computation into independent LDS reads instead of a
+  // load -> decode -> load chain per path entry.
+  constexpr int kOwnerPath = 8;
+  int b_code[kOwnerPath];
+  double b_chance = 1.0;
+  bool b_fast = false;
+#pragma unroll
+  for (int j = 0; j < kOwnerPath; ++j) b_code[j] = -1;
   if (kOwner) {
     if (tid < H) {
       const int mt = meta[tid];
@@ -328,6 +338,20 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
       b_fc = first_child[b_h];
       b_e0 = path_off[tid];
       b_e1 = path_off[tid + 1];
+      int np = 0;
+      b_fast = true;
+      for (int e = b_e0; e < b_e1; ++e) {
+        const int code = path[e];
+        if ((code >> 23) & 1) {
+          b_chance *= edge_prob[code & 0x7FFFFF];
+        } else {
+          if (np >= kOwnerPath) b_fast = false;
+#pragma unroll
+          for (int j = 0; j < kOwnerPath; ++j)
+            if (j == np) b_code[j] = code & 0x0F7FFFFF;
+          ++np;
+        }
+      }
     }
     if (tid < I) {
       c_n = nact[tid];
@@ -360,12 +384,26 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
         double reach[kSlots];
 #pragma unroll
         for (int q = 0; q < kSlots; ++q) reach[q] = 1.0;
-        for (int e = e0; e < e1; ++e) {
-          const int code = path[e];
-          const int slot = (code >> 24) & 0xF, idx = code & 0x7FFFFF;
-          const double pr = ((code >> 23) & 1) ? edge_prob[idx] : cur[idx];
+        if (kOwner && b_fast) {
+          double pr[kOwnerPath];
 #pragma unroll
-          for (int q = 0; q < kSlots; ++q) reach[q] = (q == slot) ? reach[q] * pr : reach[q];
+          for (int j = 0; j < kOwnerPath; ++j) pr[j] = cur[b_code[j] >= 0 ? (b_code[j] & 0x7FFFFF) : 0];
+#pragma unroll
+          for (int q = 0; q < kSlots; ++q) reach[q] = (q == P) ? b_chance : 1.0;
+#pragma unroll
+          for (int j = 0; j < kOwnerPath; ++j) {
+            const int slot = b_code[j] >= 0 ? (b_code[j] >> 24) & 0xF : -1;
+#pragma unroll
+            for (int q = 0; q < kSlots; ++q) reach[q] = (q == slot) ? reach[q] * pr[j] : reach[q];
+          }
+        } else {
+          for (int e = e0; e < e1; ++e) {
+            const int code = path[e];
+            const int slot = (code >> 24) & 0xF, idx = code & 0x7FFFFF;
+            const double pr = ((code >> 23) & 1) ? edge_prob[idx] : cur[idx];
+#pragma unroll
+            for (int q = 0; q < kSlots; ++q) reach[q] = (q == slot) ? reach[q] * pr : reach[q];
+          }
         }
         bool pruned = true;  // AllPlayersHaveZeroReachProb (cfr.cc:471-479)
         double self_reach = 0.0, cf_reach = 1.0;

@@ -8,6 +8,8 @@
 // (the state lives in VGPRs between load and store).
 #include <cstring>
 
+#include <type_traits>
+
 #include "osg_internal.h"
 
 using namespace osg;
@@ -148,6 +150,48 @@ k_step_c4x2(typename G::Params p, const uint64_t* __restrict__ src, uint64_t* __
   uint32_t m2 = 0, s2 = 0;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
+    if constexpr (std::is_same<G, C4Std>::value) {
+      // 6 x 7 board, result stored in plane 0's top byte: the whole step as straight-line selects, so the
+      // two states of a lane interleave freely (no exec-mask branches between them).
+      const uint32_t a = (a2 >> (8 * j)) & 0xFFu;
+      const uint32_t flags = static_cast<uint32_t>(x[j] >> 56);
+      const uint64_t X = x[j] & ((1ull << 56) - 1ull), O = o[j];
+      const uint64_t all = X | O;
+      const uint32_t col = a < 7u ? a : 0u;
+      const uint64_t cell = (all + (1ull << (col * 7u))) & (0x3Full << (col * 7u));  // lowest empty cell, 0 if full
+      const bool wants = a != 0xFFu;
+      const bool apply = wants & ((flags & 1u) == 0u) & (a < 7u) & (cell != 0ull);
+      const uint32_t mover = __builtin_popcountll(all) & 1u;
+      const uint64_t put = apply ? cell : 0ull;
+      const uint64_t nx = X | (mover ? 0ull : put), no = O | (mover ? put : 0ull);
+      const uint64_t b = mover ? no : nx;  // the mover's stones: the only line that can be new
+      uint64_t hit = 0ull;
+      {
+        uint64_t m;
+        m = b & (b >> 1); hit |= m & (m >> 2);
+        m = b & (b >> 7); hit |= m & (m >> 14);
+        m = b & (b >> 6); hit |= m & (m >> 12);
+        m = b & (b >> 8); hit |= m & (m >> 16);
+      }
+      const uint64_t nall = nx | no;
+      const uint64_t kTop = C4Std::top(p);
+      const bool win = hit != 0ull;
+      const bool done = win | ((nall & kTop) == kTop);
+      const uint32_t fresh = done ? (1u | ((win ? mover : 2u) << 1)) : 0u;  // connect_four.cc:138-142
+      const uint32_t nflags = apply ? fresh : flags;
+      const uint64_t M = (1ull << 36) | (1ull << 30) | (1ull << 24) | (1ull << 18) | (1ull << 12) | (1ull << 6) | 1ull;
+      const uint32_t open = static_cast<uint32_t>((((~nall & kTop) >> 5) * M) >> 36);
+      const uint32_t to_move = __builtin_popcountll(nall) & 1u;
+      const uint32_t running = (nflags & 1u) - 1u;  // all ones while the game runs, 0 once it is over
+      // (measured: the mask as arithmetic, the status as a select — 6.65 us; both as arithmetic 6.83 us)
+      const uint32_t st = (wants & !apply ? 0x40u : 0u) | ((nflags & 1u) ? (0x80u | ((nflags >> 1) & 3u)) : (to_move + 1u));
+      x[j] = nx | (static_cast<uint64_t>(nflags) << 56);
+      o[j] = no;
+      // a mask instead of a select keeps the multiply out of a branch
+      m2 |= (open & 0x7Fu & running) << (8 * j);
+      s2 |= st << (8 * j);
+      continue;
+    }
     typename G::State s = G::unpack(x[j], o[j]);
     const int a = (a2 >> (8 * j)) & 0xFF;
     bool term = G::terminal(p, s);

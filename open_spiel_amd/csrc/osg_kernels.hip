@@ -161,7 +161,8 @@ k_step_c4x2(typename G::Params p, const uint64_t* __restrict__ src, uint64_t* __
       const uint64_t cell = (all + (1ull << (col * 7u))) & (0x3Full << (col * 7u));  // lowest empty cell, 0 if full
       const bool wants = a != 0xFFu;
       const bool apply = wants & ((flags & 1u) == 0u) & (a < 7u) & (cell != 0ull);
-      const uint32_t mover = __builtin_popcountll(all) & 1u;
+      const uint32_t stones = __builtin_popcountll(all);
+      const uint32_t mover = stones & 1u;
       const uint64_t put = apply ? cell : 0ull;
       const uint64_t nx = X | (mover ? 0ull : put), no = O | (mover ? put : 0ull);
       const uint64_t b = mover ? no : nx;  // the mover's stones: the only line that can be new
@@ -176,12 +177,13 @@ k_step_c4x2(typename G::Params p, const uint64_t* __restrict__ src, uint64_t* __
       const uint64_t nall = nx | no;
       const uint64_t kTop = C4Std::top(p);
       const bool win = hit != 0ull;
-      const bool done = win | ((nall & kTop) == kTop);
+      const uint32_t stones_after = stones + (apply ? 1u : 0u);
+      const bool done = win | (stones_after == 42u);  // IsFull (connect_four.cc:203-209): all 42 cells taken
       const uint32_t fresh = done ? (1u | ((win ? mover : 2u) << 1)) : 0u;  // connect_four.cc:138-142
       const uint32_t nflags = apply ? fresh : flags;
       const uint64_t M = (1ull << 36) | (1ull << 30) | (1ull << 24) | (1ull << 18) | (1ull << 12) | (1ull << 6) | 1ull;
       const uint32_t open = static_cast<uint32_t>((((~nall & kTop) >> 5) * M) >> 36);
-      const uint32_t to_move = __builtin_popcountll(nall) & 1u;
+      const uint32_t to_move = stones_after & 1u;
       const uint32_t running = (nflags & 1u) - 1u;  // all ones while the game runs, 0 once it is over
       // (measured: the mask as arithmetic, the status as a select — 6.65 us; both as arithmetic 6.83 us)
       const uint32_t st = (wants & !apply ? 0x40u : 0u) | ((nflags & 1u) ? (0x80u | ((nflags >> 1) & 3u)) : (to_move + 1u));

@@ -87,6 +87,14 @@ static void KuhnCfr() {
   EXPECT(Exploitability(*game, avg) <= 0.05);
   EXPECT(std::fabs(ExpectedReturns(*game, avg)[0] + 1.0 / 18) <= 1e-3);
   EXPECT(std::fabs(solver.EvaluatePolicy(0).nash_conv - NashConv(*game, avg)) < 1e-12);
+  // kuhn_poker_test.cc / tabular_exploitability_test.cc: every member of the optimal family is unexploitable
+  // and worth -1/18 to the first player
+  for (double a : {0.0, 0.1, 1.0 / 3}) {
+    const TabularPolicyTable optimal = kuhn_poker::GetOptimalPolicy(a);
+    EXPECT(std::fabs(Exploitability(*game, optimal)) < 1e-12);
+    EXPECT(std::fabs(NashConv(*game, optimal)) < 1e-12);
+    EXPECT(std::fabs(ExpectedReturns(*game, optimal)[0] + 1.0 / 18) < 1e-12);
+  }
   // cfr_test.cc:191-256: serialize / deserialize round trip, then both solvers stay in lock step
   const std::string text = solver.Serialize();
   EXPECT(text.find("[Meta]\nVersion: 1\n\n[Game]\nkuhn_poker()\n[SolverType]\nCFRSolver\n[SolverSpecificState]\n300\n"

@@ -709,6 +709,30 @@ inline std::vector<double> ExpectedReturns(const Game& game, const TabularPolicy
   return CFRSolver(game).EvaluatePolicy(2, &policy).expected_returns;
 }
 
+// kuhn_poker::GetOptimalPolicy (kuhn_poker.cc:451-474): the alpha-family of Nash equilibria of 2-player
+// Kuhn poker, alpha in [0, 1/3]; its value for player 0 is -1/18.
+namespace kuhn_poker {
+inline TabularPolicyTable GetOptimalPolicy(double alpha) {
+  if (!(alpha >= 0.0 && alpha <= 1.0 / 3)) SpielFatalError("GetOptimalPolicy: alpha must lie in [0, 1/3]");
+  const double three_alpha = 3 * alpha;
+  TabularPolicyTable policy;
+  // every infostate has two actions: Pass (0) and Bet (1)
+  policy["0"] = {{0, 1 - alpha}, {1, alpha}};            // player 0
+  policy["0pb"] = {{0, 1}, {1, 0}};
+  policy["1"] = {{0, 1}, {1, 0}};
+  policy["1pb"] = {{0, 2. / 3. - alpha}, {1, 1. / 3. + alpha}};
+  policy["2"] = {{0, 1 - three_alpha}, {1, three_alpha}};
+  policy["2pb"] = {{0, 0}, {1, 1}};
+  policy["0p"] = {{0, 2. / 3.}, {1, 1. / 3.}};           // player 1
+  policy["0b"] = {{0, 1}, {1, 0}};
+  policy["1p"] = {{0, 1}, {1, 0}};
+  policy["1b"] = {{0, 2. / 3.}, {1, 1. / 3.}};
+  policy["2p"] = {{0, 0}, {1, 1}};
+  policy["2b"] = {{0, 0}, {1, 1}};
+  return policy;
+}
+}  // namespace kuhn_poker
+
 enum class AverageType { kSimple, kFull };
 class ExternalSamplingMCCFRSolver : public DeviceTabularSolver {  // external_sampling_mccfr.h:57-113
  public:

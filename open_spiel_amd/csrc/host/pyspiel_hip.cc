@@ -207,6 +207,11 @@ PYBIND11_MODULE(pyspiel_hip, m) {
   m.def("expected_returns", [](std::shared_ptr<Game> g, const TabularPolicy& p) { return ExpectedReturns(*g, p.policy_table()); },
         py::arg("game"), py::arg("policy"));
 
+  // pyspiel.kuhn_poker.get_optimal_policy (python/pybind11/games_kuhn_poker.cc:23-24)
+  py::module_ kuhn = m.def_submodule("kuhn_poker");
+  kuhn.def("get_optimal_policy", [](double alpha) { return TabularPolicy(kuhn_poker::GetOptimalPolicy(alpha)); },
+           py::arg("alpha"));
+
   py::enum_<AverageType>(m, "MCCFRAverageType").value("SIMPLE", AverageType::kSimple).value("FULL", AverageType::kFull);
   py::class_<ExternalSamplingMCCFRSolver>(m, "ExternalSamplingMCCFRSolver")  // policy.cc:300-333
       .def(py::init([](std::shared_ptr<Game> g, int seed, AverageType t) {

@@ -202,6 +202,23 @@ def test_mccfr_converges_like_the_reference(oracle, ctx, game, bound, batch, nba
     assert nc <= bound, nc
 
 
+@pytest.mark.parametrize("kind", ["external", "outcome"])
+@pytest.mark.parametrize("game", ["kuhn_poker", "leduc_poker", "kuhn_poker(players=3)"])
+def test_mccfr_resident_kernel_equals_general_kernel(ctx, game, kind):
+    """The LDS-resident traversal (packed tree, per-launch policy, top-of-stack frame in registers) and
+    the general global-memory kernel (osg_cfr_cfg.kernel = 1) are the same function of (table, seed)."""
+    import open_spiel_amd as osa
+    a = osa.TabularSolver(ctx, game, mccfr=kind)
+    b = osa.TabularSolver(ctx, game, mccfr=kind, general_kernel=True)
+    for seed, first, count in [(7, 0, 1), (7, 1, 999), (8, 1000, 70000), (9, 71000, 300000)]:
+        a.run_mccfr(seed, count, first_trajectory=first)
+        b.run_mccfr(seed, count, first_trajectory=first)
+        ta, tb = a.tables(), b.tables()
+        for name in ("regrets", "cum_policy"):
+            np.testing.assert_allclose(ta[name], tb[name], rtol=1e-9, atol=1e-9,
+                                       err_msg=f"{game} {kind} {name} after {(seed, first, count)}")
+
+
 def test_mccfr_sample_then_apply_equals_iterate(ctx):
     import open_spiel_amd as osa
     a = osa.TabularSolver(ctx, "leduc_poker", mccfr=True)

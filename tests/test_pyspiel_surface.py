@@ -125,6 +125,22 @@ def test_cfr_solver_like_cfr_example(pyspiel, oracle):
 
 
 @pytest.mark.gpu
+def test_kuhn_optimal_policy_is_unexploitable(pyspiel):
+    """pyspiel.kuhn_poker.get_optimal_policy (games_kuhn_poker.cc:23-24) judged on the device:
+    exploitability 0 and value -1/18 for every alpha in [0, 1/3] (tabular_exploitability_test.cc)."""
+    game = pyspiel.load_game("kuhn_poker")
+    for alpha in (0.0, 0.2, 1.0 / 3):
+        policy = pyspiel.kuhn_poker.get_optimal_policy(alpha)
+        assert len(policy.policy_table()) == 12
+        assert abs(pyspiel.exploitability(game, policy)) < 1e-12
+        assert abs(pyspiel.nash_conv(game, policy)) < 1e-12
+        ev = pyspiel.expected_returns(game, policy)
+        assert abs(ev[0] + 1 / 18) < 1e-12 and abs(ev[1] - 1 / 18) < 1e-12
+    with pytest.raises(pyspiel.SpielError):
+        pyspiel.kuhn_poker.get_optimal_policy(0.5)
+
+
+@pytest.mark.gpu
 def test_cfr_solver_pickle_round_trip(pyspiel):
     """policy.cc:237-241: CFR solvers pickle through Serialize / DeserializeCFRSolver
     (cfr.cc:284-307,699-781); hex floats make the round trip lossless (cfr_test.cc:191-256)."""

@@ -414,6 +414,59 @@ k_observation_c4std_planes(C4Params p, const uint64_t* __restrict__ base, int64_
   }
 }
 
+// hex 9-plane tensor: one lane per (state, plane).  The plane's membership mask is boolean algebra on the
+// bitboards (HexT::plane_mask); the lane turns its `cells` bits into floats, stages them in LDS at a lane
+// stride of `cells` words, and the wavefront's span — 64 x cells floats, contiguous and 16-byte aligned —
+// goes out as aligned float4, one KiB per store instruction.  One wavefront per workgroup: the stage is
+// 256 x cells bytes (20 KiB for 9 x 9), so seven wavefronts share a CU's LDS (157 us with two-wave groups,
+// 148 us with one).  Needs a 16-byte aligned output.
+constexpr int kHexObsBlock = 64;
+template <class G>
+__global__ void __launch_bounds__(kHexObsBlock)
+k_observation_hex_planes(typename G::Params p, const typename G::word_t* base, int64_t n, int planes, float* __restrict__ out) {
+  extern __shared__ float s_hex_stage[];
+  const int cells = p.cells;
+  const int64_t gl = static_cast<int64_t>(blockIdx.x) * kHexObsBlock + threadIdx.x;
+  const int64_t lanes = n * planes;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* w = s_hex_stage + wave * 64 * cells;
+  if (gl < lanes) {
+    const int64_t i = gl / planes;
+    const int plane = static_cast<int>(gl - i * planes);
+    const typename G::State s = G::load(p, base, n, i);
+    const typename G::Bits m = G::plane_mask(p, s, plane);
+    float* mine = w + lane * cells;
+    constexpr int kWords = static_cast<int>(sizeof(m.w) / sizeof(m.w[0]));
+#pragma unroll
+    for (int k = 0; k < kWords; ++k) {
+      const int count = cells - 32 * k < 32 ? cells - 32 * k : 32;  // wave-uniform
+      uint32_t bits = m.w[k];
+#pragma unroll 8
+      for (int b = 0; b < count; ++b) {
+        mine[32 * k + b] = static_cast<float>(bits & 1u);
+        bits >>= 1;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int64_t wave_lane0 = static_cast<int64_t>(blockIdx.x) * kHexObsBlock + wave * 64;
+  if (wave_lane0 >= lanes) return;
+  const int64_t left = (lanes - wave_lane0) * cells;
+  const int span = 64 * cells;
+  const int valid = left < span ? static_cast<int>(left) : span;  // floats this wavefront owns
+  float* gdst = out + wave_lane0 * cells;
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  for (int piece = lane; piece * 4 < valid; piece += 64) {
+    if (piece * 4 + 4 <= valid) {
+      reinterpret_cast<float4*>(gdst)[piece] = w4[piece];
+    } else {
+      for (int k = piece * 4; k < valid; ++k) gdst[k] = w[k];
+    }
+  }
+}
+
 template <class G>
 __global__ void __launch_bounds__(kBlock)
 k_random_steps(typename G::Params p, typename G::word_t* base, int64_t n, uint64_t seed, int64_t index_offset,
@@ -835,6 +888,20 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
     else
       k_observation_c4std<<<dim3(grid_for(b->n * 18)), dim3(kBlock), 0, ctx->stream>>>(
           b->spec.c4, static_cast<const uint64_t*>(b->d_words), b->n, player, d_out);
+  } else if (b->spec.desc.game_kind == kHex && which == 0 && d.obs_shape[0] == 9 &&
+             (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) {
+    const size_t shmem = sizeof(float) * kHexObsBlock * static_cast<size_t>(d.obs_shape[1] * d.obs_shape[2]);
+    const unsigned grid = static_cast<unsigned>((b->n * 9 + kHexObsBlock - 1) / kHexObsBlock);
+#define OSG_HEX_OBS(NW, member)                                                                              \
+  k_observation_hex_planes<HexT<NW>><<<dim3(grid), dim3(kHexObsBlock), shmem, ctx->stream>>>(                \
+      b->spec.member, static_cast<const HexT<NW>::word_t*>(b->d_words), b->n, 9, d_out)
+    switch (b->spec.hex_nw) {
+      case 1: OSG_HEX_OBS(1, hex1); break;
+      case 2: OSG_HEX_OBS(2, hex2); break;
+      case 3: OSG_HEX_OBS(3, hex3); break;
+      default: OSG_HEX_OBS(4, hex4); break;
+    }
+#undef OSG_HEX_OBS
   } else {
     // Segment = one tensor plane for hex's 9-plane layout (the cursor's mask is per plane), else the row.
     int seg_len = size;

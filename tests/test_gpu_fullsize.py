@@ -158,6 +158,34 @@ def test_observation_tensor_2pow20_states(ctx):
     assert float(obs.sum(dtype=torch.float64)) == n * 42
 
 
+def test_hex9_observation_tensor_2pow18_states(oracle, ctx):
+    """2^18 hex(9) states, [n, 9, 81]: every cell lies on exactly one plane, the empty plane is the
+    complement of the stones, black / white planes count the stones, and a strided sample equals the
+    oracle's ObservationTensor of the replayed trajectory."""
+    import torch
+    import open_spiel_amd as osa
+    n, seed, steps = 1 << 18, 31, 33
+    b = osa.StateBatch(ctx, "hex(board_size=9)", n)
+    b.random_steps(seed, steps)
+    obs = b.observation_tensor(0)
+    assert obs.shape == (n, 729)
+    planes = obs.view(n, 9, 81)
+    assert bool((planes.sum(1) == 1).all()), "every cell is on exactly one plane"
+    assert float(obs.sum(dtype=torch.float64)) == n * 81
+    _, term, _ = [t.cpu().numpy() for t in b.status()]
+    stones = (81 - planes[:, 4].sum(1)).cpu().numpy()  # plane 4 = empty (hex.cc:392-396)
+    white = planes[:, :4].sum((1, 2)).cpu().numpy()
+    black = planes[:, 5:].sum((1, 2)).cpu().numpy()
+    assert (white + black == stones).all()
+    assert ((black == white) | (black == white + 1)).all(), "black moves first, players alternate"
+    win = (planes[:, 0].sum(1) + planes[:, 8].sum(1)).cpu().numpy() > 0  # a Win-labelled stone
+    assert (win == (term != 0)).all(), "terminal <=> some stone carries a Win label"
+    got = obs.cpu().numpy()
+    for i in range(0, n, n // 64 + 1):
+        s, _ = _replay_random_steps(oracle, "hex(board_size=9)", seed, i, steps)
+        np.testing.assert_array_equal(got[i], np.asarray(s.observation_tensor(0), np.float32), err_msg=str(i))
+
+
 @pytest.mark.parametrize("game,steps", [("hex(board_size=9)", 40), ("leduc_poker", 7), ("tic_tac_toe", 6),
                                         ("kuhn_poker", 4)])
 def test_other_games_2pow20_random_steps_replay(oracle, ctx, game, steps):

@@ -472,11 +472,16 @@ class DeviceTabularSolver {
     return ev;
   }
   // Overwrites the device tables from a CFRInfoStateValuesTable (rows matched by infostate string).
-  void LoadInfoStateValuesTable(const CFRInfoStateValuesTable& table) {
+  // allow_missing: infostates absent from `table` keep their current values (a reference MCCFR checkpoint
+  // only lists the infostates its samples have reached).
+  void LoadInfoStateValuesTable(const CFRInfoStateValuesTable& table, bool allow_missing = false) {
     Tables t = Download();
     for (int i = 0; i < t.I; ++i) {
       auto it = table.find(Key(i));
-      if (it == table.end()) SpielFatalError(Key(i) + " missing from the table");
+      if (it == table.end()) {
+        if (allow_missing) continue;
+        SpielFatalError(Key(i) + " missing from the table");
+      }
       const CFRInfoStateValues& v = it->second;
       if (v.num_actions() != t.nact[i]) SpielFatalError(Key(i) + ": wrong number of actions");
       for (int a = 0; a < t.nact[i]; ++a) {
@@ -734,10 +739,77 @@ inline TabularPolicyTable GetOptimalPolicy(double alpha) {
 }  // namespace kuhn_poker
 
 enum class AverageType { kSimple, kFull };
+
+// The MCCFR solvers' text checkpoints (external_sampling_mccfr.cc:82-120,233-288;
+// outcome_sampling_mccfr.cc:76-112,243-300): same sections in the same order as the reference.
+// Deviation: [SolverRNG] holds this engine's counter-RNG position, "counter <seed> <next trajectory>",
+// not a std::mt19937 dump (the reference's random streams are not reproduced).
+constexpr const char* kSerializeSolverRNGSectionHeader = "[SolverRNG]";
+constexpr const char* kSerializeSolverAverageTypeSectionHeader = "[SolverAverageType]";
+constexpr const char* kSerializeSolverEpsilonSectionHeader = "[SolverEpsilon]";
+constexpr const char* kSerializeSolverDefaultPolicySectionHeader = "[SolverDefaultPolicy]";
+
+inline std::string SerializeValuesTable(const CFRInfoStateValuesTable& table, int double_precision,
+                                        const std::string& delimiter) {  // cfr.cc:639-661
+  std::string str;
+  bool first = true;
+  for (const auto& kv : table) {
+    if (kv.first.find(delimiter) != std::string::npos) SpielFatalError("Info state contains delimiter");
+    if (!first) str += delimiter;
+    first = false;
+    str += kv.first + delimiter + SerializeInfoStateValues(kv.second, double_precision);
+  }
+  return str;
+}
+inline CFRInfoStateValuesTable DeserializeValuesTable(const std::string& body, const std::string& delimiter) {
+  CFRInfoStateValuesTable table;  // cfr.cc:663-673
+  std::vector<std::string> splits;
+  for (size_t p = 0;;) {
+    size_t q = body.find(delimiter, p);
+    splits.push_back(body.substr(p, q == std::string::npos ? std::string::npos : q - p));
+    if (q == std::string::npos) break;
+    p = q + delimiter.size();
+  }
+  for (size_t i = 0; i + 1 < splits.size(); i += 2) table.emplace(splits[i], DeserializeInfoStateValues(splits[i + 1]));
+  return table;
+}
+// Splits a checkpoint into its top-level sections; [SolverSpecificState] keeps its line structure.
+struct PartialCheckpoint {
+  std::string game, solver_type, table;
+  std::vector<std::string> specific;  // lines of [SolverSpecificState]
+};
+inline PartialCheckpoint PartiallyDeserializeSolver(const std::string& serialized) {  // cfr.cc:699-756
+  PartialCheckpoint out;
+  int current = -1;
+  size_t pos = 0;
+  bool have_table = false;
+  while (pos <= serialized.size()) {
+    size_t nl = serialized.find('\n', pos);
+    if (nl == std::string::npos) nl = serialized.size();
+    const std::string line = serialized.substr(pos, nl - pos);
+    pos = nl + 1;
+    if (line.empty() || line[0] == '#') continue;
+    if (line == kSerializeMetaSectionHeader) current = 0;
+    else if (line == kSerializeGameSectionHeader) current = 1;
+    else if (line == kSerializeSolverTypeSectionHeader) current = 2;
+    else if (line == kSerializeSolverSpecificStateSectionHeader) current = 3;
+    else if (line == kSerializeSolverValuesTableSectionHeader) {
+      out.table = pos <= serialized.size() ? serialized.substr(pos) : std::string();
+      have_table = true;
+      break;
+    } else if (current == 1) out.game += line;
+    else if (current == 2) out.solver_type += line;
+    else if (current == 3) out.specific.push_back(line);
+    else if (current < 0) SpielFatalError("malformed solver checkpoint");
+  }
+  if (!have_table) SpielFatalError("solver checkpoint without a values table");
+  return out;
+}
+
 class ExternalSamplingMCCFRSolver : public DeviceTabularSolver {  // external_sampling_mccfr.h:57-113
  public:
   explicit ExternalSamplingMCCFRSolver(const Game& game, int seed = 0, AverageType avg_type = AverageType::kSimple)
-      : DeviceTabularSolver(game, true, false, false, 1), seed_(seed) {
+      : DeviceTabularSolver(game, true, false, false, 1), seed_(seed), game_string_(game.Serialize()) {
     if (avg_type != AverageType::kSimple) SpielFatalError("the device ES-MCCFR implements AverageType::kSimple");
   }
   // One UpdateRegrets per player, each seeing the previous one's update (:71-80).
@@ -749,17 +821,35 @@ class ExternalSamplingMCCFRSolver : public DeviceTabularSolver {  // external_sa
     Check(osg_mccfr_iterate(s_, seed_, next_, trajectories));
     next_ += trajectories;
   }
+  std::string Serialize(int double_precision = -1, const std::string& delimiter = "<~>") const {  // :82-120
+    if (double_precision < -1) SpielFatalError("double_precision must be >= -1");
+    std::string str = "# Automatically generated by OpenSpiel ExternalSamplingMCCFRSolver::Serialize\n";
+    str += std::string(kSerializeMetaSectionHeader) + "\nVersion: " + std::to_string(kSerializationVersion) + "\n\n";
+    str += std::string(kSerializeGameSectionHeader) + "\n" + game_string_ + "\n";
+    str += std::string(kSerializeSolverTypeSectionHeader) + "\nExternalSamplingMCCFRSolver\n";
+    str += std::string(kSerializeSolverSpecificStateSectionHeader) + "\n";
+    str += std::string(kSerializeSolverRNGSectionHeader) + "\ncounter " + std::to_string(seed_) + " " +
+           std::to_string(next_) + "\n";
+    str += std::string(kSerializeSolverAverageTypeSectionHeader) + "\nSimpleAverageType\n";
+    str += std::string(kSerializeSolverDefaultPolicySectionHeader) + "\nUniformPolicy:\n";  // policy.h:330-333
+    str += std::string(kSerializeSolverValuesTableSectionHeader) + "\n";
+    return str + SerializeValuesTable(InfoStateValuesTable(), double_precision, delimiter);
+  }
+  void RestoreCounter(uint64_t seed, int64_t next) { seed_ = seed; next_ = next; }
+  int64_t TrajectoriesRun() const { return next_; }
 
  private:
   uint64_t seed_;
   int64_t next_ = 0;
+  std::string game_string_;
 };
 
 class OutcomeSamplingMCCFRSolver : public DeviceTabularSolver {  // outcome_sampling_mccfr.h:40-107
  public:
   static constexpr double kDefaultEpsilon = 0.6;
   explicit OutcomeSamplingMCCFRSolver(const Game& game, double epsilon = kDefaultEpsilon, int seed = -1)
-      : DeviceTabularSolver(game, true, false, false, 2, epsilon), seed_(seed < 0 ? 0 : seed) {}
+      : DeviceTabularSolver(game, true, false, false, 2, epsilon), seed_(seed < 0 ? 0 : seed), epsilon_(epsilon),
+        game_string_(game.Serialize()) {}
   void RunIteration() {  // one SampleEpisode per player, each seeing the previous one's update (:67-74)
     for (int p = 0; p < num_players_; ++p) Check(osg_mccfr_iterate(s_, seed_, next_++, 1));
   }
@@ -767,11 +857,80 @@ class OutcomeSamplingMCCFRSolver : public DeviceTabularSolver {  // outcome_samp
     Check(osg_mccfr_iterate(s_, seed_, next_, episodes));
     next_ += episodes;
   }
+  std::string Serialize(int double_precision = -1, const std::string& delimiter = "<~>") const {  // :76-112
+    if (double_precision < -1) SpielFatalError("double_precision must be >= -1");
+    std::string str = "# Automatically generated by OpenSpiel OutcomeSamplingMCCFRSolver::Serialize\n";
+    str += std::string(kSerializeMetaSectionHeader) + "\nVersion: " + std::to_string(kSerializationVersion) + "\n\n";
+    str += std::string(kSerializeGameSectionHeader) + "\n" + game_string_ + "\n";
+    str += std::string(kSerializeSolverTypeSectionHeader) + "\nOutcomeSamplingMCCFRSolver\n";
+    str += std::string(kSerializeSolverSpecificStateSectionHeader) + "\n";
+    str += std::string(kSerializeSolverRNGSectionHeader) + "\ncounter " + std::to_string(seed_) + " " +
+           std::to_string(next_) + "\n";
+    str += std::string(kSerializeSolverEpsilonSectionHeader) + "\n" + FormatDouble(epsilon_, -1) + "\n";
+    str += std::string(kSerializeSolverDefaultPolicySectionHeader) + "\nUniformPolicy:\n";
+    str += std::string(kSerializeSolverValuesTableSectionHeader) + "\n";
+    return str + SerializeValuesTable(InfoStateValuesTable(), double_precision, delimiter);
+  }
+  void RestoreCounter(uint64_t seed, int64_t next) { seed_ = seed; next_ = next; }
+  int64_t EpisodesRun() const { return next_; }
+  double Epsilon() const { return epsilon_; }
 
  private:
   uint64_t seed_;
   int64_t next_ = 0;
+  double epsilon_;
+  std::string game_string_;
 };
+
+namespace internal {
+// The value line that follows `header` inside [SolverSpecificState].
+inline std::string SpecificLine(const PartialCheckpoint& c, const char* header) {
+  for (size_t i = 0; i + 1 < c.specific.size(); ++i)
+    if (c.specific[i] == header) return c.specific[i + 1];
+  SpielFatalError(std::string("solver checkpoint without a ") + header + " section");
+}
+inline void ParseCounter(const std::string& line, uint64_t* seed, int64_t* next) {
+  char tag[16] = {0};
+  unsigned long long s = 0;
+  long long n = 0;
+  if (std::sscanf(line.c_str(), "%15s %llu %lld", tag, &s, &n) != 3 || std::string(tag) != "counter")
+    SpielFatalError("[SolverRNG] is not a counter-RNG position (a reference mt19937 dump cannot be continued here)");
+  *seed = s;
+  *next = n;
+}
+}  // namespace internal
+
+inline std::unique_ptr<ExternalSamplingMCCFRSolver> DeserializeExternalSamplingMCCFRSolver(
+    const std::string& serialized, const std::string& delimiter = "<~>") {  // external_sampling_mccfr.cc:233-288
+  const PartialCheckpoint c = PartiallyDeserializeSolver(serialized);
+  if (c.solver_type != "ExternalSamplingMCCFRSolver")
+    SpielFatalError("checkpoint holds a " + c.solver_type + ", not an ExternalSamplingMCCFRSolver");
+  uint64_t seed;
+  int64_t next;
+  internal::ParseCounter(internal::SpecificLine(c, kSerializeSolverRNGSectionHeader), &seed, &next);
+  const std::string avg = internal::SpecificLine(c, kSerializeSolverAverageTypeSectionHeader);
+  if (avg != "SimpleAverageType") SpielFatalError("the device ES-MCCFR implements AverageType::kSimple, not " + avg);
+  std::shared_ptr<const Game> game = LoadGame(c.game);
+  auto solver = std::make_unique<ExternalSamplingMCCFRSolver>(*game, static_cast<int>(seed));
+  solver->RestoreCounter(seed, next);
+  solver->LoadInfoStateValuesTable(DeserializeValuesTable(c.table, delimiter), /*allow_missing=*/true);
+  return solver;
+}
+inline std::unique_ptr<OutcomeSamplingMCCFRSolver> DeserializeOutcomeSamplingMCCFRSolver(
+    const std::string& serialized, const std::string& delimiter = "<~>") {  // outcome_sampling_mccfr.cc:243-300
+  const PartialCheckpoint c = PartiallyDeserializeSolver(serialized);
+  if (c.solver_type != "OutcomeSamplingMCCFRSolver")
+    SpielFatalError("checkpoint holds a " + c.solver_type + ", not an OutcomeSamplingMCCFRSolver");
+  uint64_t seed;
+  int64_t next;
+  internal::ParseCounter(internal::SpecificLine(c, kSerializeSolverRNGSectionHeader), &seed, &next);
+  const double epsilon = std::strtod(internal::SpecificLine(c, kSerializeSolverEpsilonSectionHeader).c_str(), nullptr);
+  std::shared_ptr<const Game> game = LoadGame(c.game);
+  auto solver = std::make_unique<OutcomeSamplingMCCFRSolver>(*game, epsilon, static_cast<int>(seed));
+  solver->RestoreCounter(seed, next);
+  solver->LoadInfoStateValuesTable(DeserializeValuesTable(c.table, delimiter), /*allow_missing=*/true);
+  return solver;
+}
 
 }  // namespace algorithms
 }  // namespace hip

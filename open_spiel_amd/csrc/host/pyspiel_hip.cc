@@ -222,7 +222,13 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("run_mini_batch", &ExternalSamplingMCCFRSolver::RunMiniBatch, py::arg("trajectories"))
       .def("average_policy",
            [](const ExternalSamplingMCCFRSolver& s) { return TabularPolicy(s.TabularAveragePolicy()); })
-      .def("info_state_values_table", &ExternalSamplingMCCFRSolver::InfoStateValuesTable);
+      .def("info_state_values_table", &ExternalSamplingMCCFRSolver::InfoStateValuesTable)
+      .def("serialize", &ExternalSamplingMCCFRSolver::Serialize, py::arg("double_precision") = -1,
+           py::arg("delimiter") = "<~>")
+      .def(py::pickle([](const ExternalSamplingMCCFRSolver& s) { return s.Serialize(); },  // policy.cc:322-333
+                      [](const std::string& t) { return DeserializeExternalSamplingMCCFRSolver(t); }));
+  m.def("deserialize_external_sampling_mccfr_solver",
+        [](const std::string& t) { return DeserializeExternalSamplingMCCFRSolver(t); });
   py::class_<OutcomeSamplingMCCFRSolver>(m, "OutcomeSamplingMCCFRSolver")  // policy.cc:334-370
       .def(py::init([](std::shared_ptr<Game> g, double epsilon, int seed) {
              return new OutcomeSamplingMCCFRSolver(*g, epsilon, seed);
@@ -232,5 +238,11 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("run_mini_batch", &OutcomeSamplingMCCFRSolver::RunMiniBatch, py::arg("episodes"))
       .def("average_policy",
            [](const OutcomeSamplingMCCFRSolver& s) { return TabularPolicy(s.TabularAveragePolicy()); })
-      .def("info_state_values_table", &OutcomeSamplingMCCFRSolver::InfoStateValuesTable);
+      .def("info_state_values_table", &OutcomeSamplingMCCFRSolver::InfoStateValuesTable)
+      .def("serialize", &OutcomeSamplingMCCFRSolver::Serialize, py::arg("double_precision") = -1,
+           py::arg("delimiter") = "<~>")
+      .def(py::pickle([](const OutcomeSamplingMCCFRSolver& s) { return s.Serialize(); },  // policy.cc:359-370
+                      [](const std::string& t) { return DeserializeOutcomeSamplingMCCFRSolver(t); }));
+  m.def("deserialize_outcome_sampling_mccfr_solver",
+        [](const std::string& t) { return DeserializeOutcomeSamplingMCCFRSolver(t); });
 }

@@ -162,3 +162,36 @@ def test_cfr_solver_pickle_round_trip(pyspiel):
         assert v.current_policy == b[k].current_policy
     with pytest.raises(pyspiel.SpielError):
         pyspiel.deserialize_cfr_solver(text)  # it is a CFRPlusSolver checkpoint
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["external", "outcome"])
+def test_mccfr_solver_pickle_round_trip(pyspiel, kind):
+    """external_sampling_mccfr_test.cc:112-171 / outcome_sampling_mccfr_test.cc: serialize, restore, and
+    both solvers stay in lock step (same counter-RNG position, same tables)."""
+    import pickle
+    game = pyspiel.load_game("leduc_poker")
+    solver = (pyspiel.ExternalSamplingMCCFRSolver(game, seed=7) if kind == "external"
+              else pyspiel.OutcomeSamplingMCCFRSolver(game, epsilon=0.5, seed=7))
+    for _ in range(10):
+        solver.run_iteration()
+    solver.run_mini_batch(5000)
+    text = solver.serialize()
+    name = "ExternalSamplingMCCFRSolver" if kind == "external" else "OutcomeSamplingMCCFRSolver"
+    assert f"[SolverType]\n{name}\n[SolverSpecificState]\n[SolverRNG]\ncounter 7 5020\n" in text
+    assert ("[SolverAverageType]\nSimpleAverageType\n" if kind == "external" else "[SolverEpsilon]\n") in text
+    assert "[SolverDefaultPolicy]\nUniformPolicy:\n[SolverValuesTable]\n" in text
+    restored = pickle.loads(pickle.dumps(solver))
+    assert restored.info_state_values_table().keys() == solver.info_state_values_table().keys()
+    for s in (solver, restored):
+        s.run_iteration()
+        s.run_mini_batch(3000)
+    a, b = solver.info_state_values_table(), restored.info_state_values_table()
+    for key in a:
+        np.testing.assert_allclose(a[key].cumulative_regrets, b[key].cumulative_regrets, rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(a[key].cumulative_policy, b[key].cumulative_policy, rtol=1e-11, atol=1e-12)
+    # a checkpoint of the other solver type is refused
+    other = (pyspiel.deserialize_outcome_sampling_mccfr_solver if kind == "external"
+             else pyspiel.deserialize_external_sampling_mccfr_solver)
+    with pytest.raises(pyspiel.SpielError):
+        other(text)

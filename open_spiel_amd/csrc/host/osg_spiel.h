@@ -98,6 +98,7 @@ class Game : public std::enable_shared_from_this<Game> {
   const osg_game_desc& Desc() const { return desc_; }
   osg_ctx* Ctx() const { return Context::Default(device_); }
   inline std::unique_ptr<State> NewInitialState() const;
+  inline std::unique_ptr<State> DeserializeState(const std::string& str) const;  // spiel.cc:540-580
   inline BatchedState NewInitialStates(int64_t n) const;
 
  private:
@@ -247,6 +248,12 @@ class State {
     for (const auto& pa : history_) h.push_back(pa.second);
     return h;
   }
+  // State::Serialize (spiel.cc:411-430): the action history, one action per line.
+  std::string Serialize() const {
+    std::string out;
+    for (const auto& pa : history_) out += std::to_string(pa.second) + "\n";
+    return history_.empty() ? std::string("\n") : out;
+  }
   int MoveNumber() const { return static_cast<int>(history_.size()); }
   int NumPlayers() const { return batch_.GetGame()->NumPlayers(); }
   std::shared_ptr<const Game> GetGame() const { return batch_.GetGame(); }
@@ -264,6 +271,51 @@ inline std::unique_ptr<State> Game::NewInitialState() const {
   return std::unique_ptr<State>(new State(shared_from_this()));
 }
 inline BatchedState Game::NewInitialStates(int64_t n) const { return BatchedState(shared_from_this(), n); }
+inline std::unique_ptr<State> Game::DeserializeState(const std::string& str) const {
+  std::unique_ptr<State> state = NewInitialState();
+  size_t pos = 0;
+  while (pos < str.size()) {
+    size_t nl = str.find('\n', pos);
+    if (nl == std::string::npos) nl = str.size();
+    const std::string line = str.substr(pos, nl - pos);
+    pos = nl + 1;
+    if (line.empty()) continue;
+    char* end = nullptr;
+    const long long a = std::strtoll(line.c_str(), &end, 10);
+    if (end == line.c_str() || *end != '\0') SpielFatalError("DeserializeState: not an action: " + line);
+    state->ApplyAction(static_cast<Action>(a));  // illegal actions are fatal, as in the reference
+  }
+  return state;
+}
+
+// SerializeGameAndState / DeserializeGameAndState (spiel.cc:582-647): [Meta] / [Game] / [State].
+constexpr const char* kSerializeStateSectionHeader = "[State]";
+inline std::string SerializeGameAndState(const Game& game, const State& state) {
+  return std::string("# Automatically generated by OpenSpiel SerializeGameAndState\n[Meta]\nVersion: 1\n\n[Game]\n") +
+         game.Serialize() + "\n" + kSerializeStateSectionHeader + "\n" + state.Serialize() + "\n";
+}
+inline std::pair<std::shared_ptr<const Game>, std::unique_ptr<State>> DeserializeGameAndState(
+    const std::string& serialized) {
+  std::string sections[3];
+  int current = -1;
+  size_t pos = 0;
+  while (pos <= serialized.size()) {
+    size_t nl = serialized.find('\n', pos);
+    if (nl == std::string::npos) nl = serialized.size();
+    const std::string line = serialized.substr(pos, nl - pos);
+    pos = nl + 1;
+    if (line.empty() || line[0] == '#') continue;
+    if (line == "[Meta]") { if (current != -1) SpielFatalError("malformed game-and-state text"); current = 0; }
+    else if (line == "[Game]") { if (current != 0) SpielFatalError("malformed game-and-state text"); current = 1; }
+    else if (line == kSerializeStateSectionHeader) { if (current != 1) SpielFatalError("malformed game-and-state text"); current = 2; }
+    else if (current < 0) SpielFatalError("malformed game-and-state text");
+    else sections[current] += line + "\n";
+  }
+  if (!sections[1].empty() && sections[1].back() == '\n') sections[1].pop_back();
+  std::shared_ptr<const Game> game = LoadGame(sections[1]);
+  std::unique_ptr<State> state = game->DeserializeState(sections[2]);
+  return {game, std::move(state)};
+}
 
 namespace algorithms {
 

@@ -70,6 +70,10 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("information_state_tensor_shape", &Game::InformationStateTensorShape)
       .def("information_state_tensor_size", &Game::InformationStateTensorSize)
       .def("new_initial_state", [](const Game& g) { return g.NewInitialState(); })
+      .def("serialize", &Game::Serialize)
+      .def("deserialize_state", &Game::DeserializeState, py::arg("serialized"))
+      .def(py::pickle([](const Game& g) { return g.Serialize(); },  // pyspiel.cc:535-543
+                      [](const std::string& t) { return std::const_pointer_cast<Game>(LoadGame(t)); }))
       .def("new_initial_states", [](const Game& g, int64_t n) { return g.NewInitialStates(n); }, py::arg("n"))
       .def("__str__", &Game::ToString)
       .def("__repr__", &Game::ToString);
@@ -99,6 +103,10 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("clone", &State::Clone)
       .def("child", &State::Child, py::arg("action"))
       .def("history", &State::History)
+      .def("serialize", &State::Serialize)
+      .def(py::pickle(  // pyspiel.cc:455-474: a state pickles as its game-and-state text
+          [](const State& s) { return SerializeGameAndState(*s.GetGame(), s); },
+          [](const std::string& t) { return std::move(DeserializeGameAndState(t).second); }))
       .def("move_number", &State::MoveNumber)
       .def("num_players", &State::NumPlayers)
       .def("get_game", [](const State& s) { return std::const_pointer_cast<Game>(s.GetGame()); });
@@ -198,6 +206,14 @@ PYBIND11_MODULE(pyspiel_hip, m) {
                       [](const std::string& t) { return DeserializeCFRPlusSolver(t); }));
   m.def("deserialize_cfr_solver", [](const std::string& t) { return DeserializeCFRSolver(t); });
   m.def("deserialize_cfr_plus_solver", [](const std::string& t) { return DeserializeCFRPlusSolver(t); });
+
+  m.def("serialize_game_and_state",
+        [](std::shared_ptr<Game> g, const State& s) { return SerializeGameAndState(*g, s); }, py::arg("game"),
+        py::arg("state"));
+  m.def("deserialize_game_and_state", [](const std::string& t) {  // pyspiel.cc:733-741
+    auto gs = DeserializeGameAndState(t);
+    return std::make_pair(std::const_pointer_cast<Game>(gs.first), std::move(gs.second));
+  });
 
   // pyspiel.exploitability / nash_conv / expected_returns (python/pybind11/policy.cc) for tabular policies
   m.def("exploitability", [](std::shared_ptr<Game> g, const TabularPolicy& p) { return Exploitability(*g, p.policy_table()); },

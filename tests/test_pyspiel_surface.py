@@ -195,3 +195,29 @@ def test_mccfr_solver_pickle_round_trip(pyspiel, kind):
              else pyspiel.deserialize_external_sampling_mccfr_solver)
     with pytest.raises(pyspiel.SpielError):
         other(text)
+
+
+@pytest.mark.gpu
+def test_serialize_game_and_state_round_trip(pyspiel):
+    """spiel_test.cc / python/tests/pyspiel_test.py: serialize_game_and_state text, deserialize, pickle."""
+    import pickle
+    game = pyspiel.load_game("leduc_poker")
+    state = game.new_initial_state()
+    for a in (1, 3, 1, 2, 1):  # deals J / Q, call, raise, call
+        state.apply_action(a)
+    text = pyspiel.serialize_game_and_state(game, state)
+    assert text == ("# Automatically generated by OpenSpiel SerializeGameAndState\n[Meta]\nVersion: 1\n\n"
+                    "[Game]\nleduc_poker()\n[State]\n1\n3\n1\n2\n1\n\n")
+    game2, state2 = pyspiel.deserialize_game_and_state(text)
+    assert str(game2) == str(game) and state2.history() == state.history()
+    assert state2.information_state_string(0) == state.information_state_string(0)
+    assert state2.current_player() == state.current_player() and state2.legal_actions() == state.legal_actions()
+    state3 = pickle.loads(pickle.dumps(state))
+    assert state3.history() == state.history() and state3.observation_tensor(0) == state.observation_tensor(0)
+    assert str(pickle.loads(pickle.dumps(game))) == str(game)
+    assert game.deserialize_state(state.serialize()).history() == state.history()
+    c4 = pyspiel.load_game("connect_four")
+    s = c4.new_initial_state()
+    assert pyspiel.deserialize_game_and_state(pyspiel.serialize_game_and_state(c4, s))[1].history() == []
+    with pytest.raises(pyspiel.SpielError):
+        c4.deserialize_state("9\n")  # not a column

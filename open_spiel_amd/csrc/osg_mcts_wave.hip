@@ -456,14 +456,6 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
     bool term;
     PT_MARK(7);
     for (;;) {
-#ifdef OSG_DIAG_UNIFORM
-      if constexpr (kHexFill) {
-        s.meta = uniform(s.meta);
-        for (int j = 0; j < 2; ++j) { s.blk[j] = uniform64(s.blk[j]); s.wht[j] = uniform64(s.wht[j]); s.ea[j] = uniform64(s.ea[j]); s.eb[j] = uniform64(s.eb[j]); }
-      }
-      meta = uniform(meta); cnt = uniform(cnt); first = uniform(first); used = uniform(used); node = uniform(node);
-      depth = uniform(depth); ph = uniform64(ph); root_meta = uniform(root_meta); root_first = uniform(root_first);
-#endif
       term = w_terminal<G>(p, s);
       if (term || cnt == 0 || depth + 1 >= kMaxPath) break;
       const int cur = w_current_player<G>(p, s);

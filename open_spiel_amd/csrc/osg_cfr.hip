@@ -1806,10 +1806,19 @@ int osg_mccfr_sample(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_
   // groups mean fewer global atomics (256 CUs x 4 groups).
   if (blocks > 1024) blocks = 1024;
   if (s->resident_ok && s->cfg.kernel != 1) {
-    // One workgroup per CU (as many as the LDS footprint allows), 1024 lanes each for big batches.
-    const int threads = trajectories >= static_cast<int64_t>(s->num_cus) * 1024 ? 1024 : 256;
-    int per_cu = static_cast<int>((160 * 1024) / std::max<size_t>(s->resident_lds_bytes, 1));
-    per_cu = std::max(1, std::min(per_cu, 2048 / threads));
+    // As many workgroups per CU as the LDS footprint allows.  A footprint that only fits once (leduc:
+    // 143 KB) gets one group per CU, sized to the batch — every CU busy, up to 1024 lanes each; small
+    // footprints (kuhn) get several 256- or 1024-lane groups per CU.
+    const int fit = static_cast<int>((160 * 1024) / std::max<size_t>(s->resident_lds_bytes, 1));
+    int threads, per_cu;
+    if (fit <= 1) {
+      const int64_t share = (trajectories + s->num_cus - 1) / std::max(s->num_cus, 1);
+      threads = static_cast<int>(std::min<int64_t>(1024, std::max<int64_t>(256, (share + 63) / 64 * 64)));
+      per_cu = 1;
+    } else {
+      threads = trajectories >= static_cast<int64_t>(s->num_cus) * 1024 ? 1024 : 256;
+      per_cu = std::max(1, std::min(fit, 2048 / threads));
+    }
     int64_t groups = std::min<int64_t>((trajectories + threads - 1) / threads, static_cast<int64_t>(s->num_cus) * per_cu);
     ResidentTree rt{reinterpret_cast<const uint2*>(s->d_rec), s->d_uret, s->d_uprob, s->n_uret, s->n_uprob};
     const dim3 grid(static_cast<unsigned>(groups)), block(threads);

@@ -214,8 +214,12 @@ def test_mccfr_resident_kernel_equals_general_kernel(ctx, game, kind):
         a.run_mccfr(seed, count, first_trajectory=first)
         b.run_mccfr(seed, count, first_trajectory=first)
         ta, tb = a.tables(), b.tables()
+        # Both kernels add the same terms with fp64 atomics, in a different order (different workgroup
+        # shapes).  Outcome sampling's terms carry importance weights 1 / sample_reach — up to ~1e8 next to
+        # sums of ~1e4 — so its sums agree to ~1e-7 relative only; external sampling's are O(1).
+        tol = 1e-6 if kind == "outcome" else 1e-9
         for name in ("regrets", "cum_policy"):
-            np.testing.assert_allclose(ta[name], tb[name], rtol=1e-9, atol=1e-9,
+            np.testing.assert_allclose(ta[name], tb[name], rtol=tol, atol=tol,
                                        err_msg=f"{game} {kind} {name} after {(seed, first, count)}")
 
 

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time, torch, open_spiel_amd as osa
 ctx = osa.Context(0)
 for kind, game, n in [("external", "kuhn_poker", 1 << 20), ("external", "leduc_poker", 1 << 20),
-                      ("external", "leduc_poker", 1 << 22), ("external", "leduc_poker", 4096),
+                      ("external", "leduc_poker", 1 << 22), ("external", "leduc_poker", 4096), ("external", "leduc_poker", 1 << 17),
                       ("external", "kuhn_poker(players=3)", 1 << 20), ("outcome", "kuhn_poker", 1 << 22),
                       ("outcome", "leduc_poker", 1 << 22)]:
     for general in (True, False):

@@ -212,6 +212,19 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
                                            f"of 2^20 sharded over {world} rank(s), "
                                            + ("one all-reduce of 2 x [936,3] fp64 per mini-batch" if world > 1
                                               else "no collective at 1 GPU")}}
+    # NashConv of the average policy after the 2^24 trajectories (device judge,
+    # the same numbers as the oracle's TabularBestResponse to 1e-12: tests/test_gpu_cfr.py)
+    out["mccfr"]["nash_conv_after"] = float(solver.nash_conv())
+    if world > 1:  # the exchange step on its own: one all-reduce of the two delta tables
+        flat = solver.mccfr_delta_flat()
+        osd.allreduce_sum_(flat)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            osd.allreduce_sum_(flat)
+        fence()
+        out["mccfr"]["allreduce_us"] = max_over_ranks(time.perf_counter() - t0) / 50 * 1e6
+        out["mccfr"]["allreduce_bytes"] = int(flat.numel() * flat.element_size())
     if rank == 0:
         t = solver.tables()
         out["mccfr"]["tables_finite"] = bool((abs(t["regrets"]) < 1e300).all())

@@ -581,40 +581,77 @@ k_env_step(typename G::Params p, typename G::word_t* base, int64_t n, int num_pl
     if (w < mask_words) mask[i * mask_words + w] = after.w[w];
 }
 
-// RandomRolloutEvaluator::Evaluate (mcts.cc:43-72), persistent form: every lane
-// owns a strided list of (root, rollout) work items and runs ONE flat loop whose
-// body is "step the playout, or retire it and fetch the next item", so lanes in
-// different phases of different playouts still execute the same instructions.
+// RandomRolloutEvaluator::Evaluate (mcts.cc:43-72), persistent form: every lane owns a strided list of
+// work items and runs ONE flat loop whose body is "step the playout, or retire it and start the next", so
+// lanes in different phases of different playouts still execute the same instructions.  A work item is
+// (root, share j of `group`): the lane plays rollouts j, j + group, j + 2 group, ... of that root back to
+// back, adds their returns up in registers and stores the sums into its own slot [root, j]; k_rollout_fold
+// then adds the `group` slots of every root in order.  No atomics: the L2 retires only ~2e10 atomics/s
+// chip-wide, and one per playout and player was the whole run time of the short games.  Rollout r of
+// root i always plays from the counter stream (seed, i, r), whatever the split.
 template <class G>
 __global__ void __launch_bounds__(kBlock)
 k_rollout(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, uint64_t seed,
-          int64_t index_offset, int n_rollouts, double* sum_returns, int32_t* steps_out) {
-  const int64_t total = n * n_rollouts;
+          int64_t index_offset, int n_rollouts, int group, double* sum_returns, int32_t* steps_out) {
+  const int64_t total = n * group;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
   int64_t item = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (item >= total) return;
-  int64_t root = item / n_rollouts;
+  int64_t root = item / group;
+  int r = static_cast<int>(item - root * group);  // current rollout of this share
   typename G::State s = G::load(p, base, n, root);
-  Rng rng(seed, static_cast<uint64_t>(index_offset + root), static_cast<uint64_t>(item - root * n_rollouts));
+  Rng rng(seed, static_cast<uint64_t>(index_offset + root), static_cast<uint64_t>(r));
+  double acc[kMaxPlayers];
+#pragma unroll
+  for (int q = 0; q < kMaxPlayers; ++q) acc[q] = 0.0;
   int plies = 0;
   for (;;) {
     if (G::terminal(p, s)) {
-      double r[kMaxPlayers];
-      G::returns(p, s, r);
-      for (int q = 0; q < num_players; ++q) atomicAdd(&sum_returns[root * num_players + q], r[q]);
-      if (steps_out) atomicAdd(&steps_out[root], plies);
-      item += stride;
-      if (item >= total) break;
-      root = item / n_rollouts;
+      double ret[kMaxPlayers];
+      G::returns(p, s, ret);
+#pragma unroll
+      for (int q = 0; q < kMaxPlayers; ++q)
+        if (q < num_players) acc[q] += ret[q];  // small multiples of 0.5: exact in any order
+      r += group;
+      if (r >= n_rollouts) {  // this share is done: hand in its sums, fetch the next item
+#pragma unroll
+        for (int q = 0; q < kMaxPlayers; ++q) {
+          if (q < num_players) sum_returns[item * num_players + q] = acc[q];  // slot of (root, share)
+          acc[q] = 0.0;
+        }
+        if (steps_out) steps_out[item] = plies;
+        plies = 0;
+        item += stride;
+        if (item >= total) break;
+        root = item / group;
+        r = static_cast<int>(item - root * group);
+      }
       s = G::load(p, base, n, root);
-      rng = Rng(seed, static_cast<uint64_t>(index_offset + root), static_cast<uint64_t>(item - root * n_rollouts));
-      plies = 0;
+      rng = Rng(seed, static_cast<uint64_t>(index_offset + root), static_cast<uint64_t>(r));
       continue;
     }
     Mask m = G::legal(p, s);
     int a = sample_action<G>(p, s, m, G::current_player(p, s), rng);
     G::apply(p, s, a);
     ++plies;
+  }
+}
+
+// Sums the `group` share slots of every root: sum_returns [n, P] and, optionally, the ply counts [n].
+__global__ void __launch_bounds__(kBlock)
+k_rollout_fold(const double* __restrict__ part, const int32_t* __restrict__ part_steps, int64_t n, int num_players,
+               int group, double* __restrict__ sum_returns, int32_t* __restrict__ steps_out) {
+  const int64_t k = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;  // (root, player)
+  if (k >= n * num_players) return;
+  const int64_t root = k / num_players;
+  const int q = static_cast<int>(k - root * num_players);
+  double v = 0.0;
+  for (int j = 0; j < group; ++j) v += part[(root * group + j) * num_players + q];
+  sum_returns[k] = v;
+  if (steps_out && q == 0) {
+    int32_t t = 0;
+    for (int j = 0; j < group; ++j) t += part_steps[root * group + j];
+    steps_out[root] = t;
   }
 }
 
@@ -988,29 +1025,41 @@ int osg_rollout(const osg_batch* roots, uint64_t seed, int64_t index_offset, int
   const int P_ = roots->spec.desc.num_players;
   const int64_t n = roots->n;
   if (n_rollouts <= 0) return set_error(OSG_ERR_INVALID, "n_rollouts must be positive");
-  size_t ret_bytes = sizeof(double) * P_ * n, off_steps = align_up(ret_bytes);
-  double* d_sum = sum_returns;
-  int32_t* d_steps = steps;
-  if (on_host) {
-    void* scratch;
-    int rc = osg_ctx_scratch(ctx, off_steps + sizeof(int32_t) * n, &scratch);
+  // Lanes per root: enough shares to fill the chip (8 waves per SIMD = 2^19 lanes), no more.
+  int64_t group = ((int64_t{1} << 19) + n - 1) / std::max<int64_t>(n, 1);
+  if (group > n_rollouts) group = n_rollouts;
+  if (group < 1) group = 1;
+  // scratch: [sums | steps] when the results go to the host, then the per-share slots when group > 1
+  const size_t ret_bytes = sizeof(double) * P_ * n, step_bytes = sizeof(int32_t) * n;
+  const size_t off_steps = align_up(ret_bytes), off_part = on_host ? align_up(off_steps + step_bytes) : 0;
+  const size_t part_bytes = group > 1 ? ret_bytes * group : 0, off_part_steps = align_up(off_part + part_bytes);
+  const size_t scratch_bytes = group > 1 ? off_part_steps + step_bytes * group : (on_host ? off_steps + step_bytes : 0);
+  char* scratch = nullptr;
+  if (scratch_bytes) {
+    void* ptr;
+    int rc = osg_ctx_scratch(ctx, scratch_bytes, &ptr);
     if (rc) return rc;
-    d_sum = static_cast<double*>(scratch);
-    d_steps = steps ? reinterpret_cast<int32_t*>(static_cast<char*>(scratch) + off_steps) : nullptr;
+    scratch = static_cast<char*>(ptr);
   }
-  OSG_HIP(hipMemsetAsync(d_sum, 0, ret_bytes, ctx->stream));
-  if (d_steps) OSG_HIP(hipMemsetAsync(d_steps, 0, sizeof(int32_t) * n, ctx->stream));
-  const int64_t total = n * n_rollouts;
+  double* d_sum = on_host ? reinterpret_cast<double*>(scratch) : sum_returns;
+  int32_t* d_steps = steps ? (on_host ? reinterpret_cast<int32_t*>(scratch + off_steps) : steps) : nullptr;
+  double* d_part = group > 1 ? reinterpret_cast<double*>(scratch + off_part) : d_sum;
+  int32_t* d_part_steps = d_steps ? (group > 1 ? reinterpret_cast<int32_t*>(scratch + off_part_steps) : d_steps) : nullptr;
+  const int64_t total = n * group;
   // Persistent grid: at most 8 blocks per CU x 256 CUs, grid-strided beyond that.
   int64_t blocks = (total + kBlock - 1) / kBlock;
   if (blocks > 2048) blocks = 2048;
   OSG_DISPATCH(roots->spec, k_rollout<G><<<dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, ctx->stream>>>(P,
                                                 static_cast<const typename G::word_t*>(roots->d_words), n, P_, seed,
-                                                index_offset, n_rollouts, d_sum, d_steps));
+                                                index_offset, n_rollouts, static_cast<int>(group), d_part,
+                                                d_part_steps));
+  if (group > 1)
+    k_rollout_fold<<<dim3(grid_for(n * P_)), dim3(kBlock), 0, ctx->stream>>>(d_part, d_part_steps, n, P_,
+                                                                             static_cast<int>(group), d_sum, d_steps);
   OSG_HIP(hipGetLastError());
   if (on_host) {
     OSG_HIP(hipMemcpyAsync(sum_returns, d_sum, ret_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    if (steps) OSG_HIP(hipMemcpyAsync(steps, d_steps, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (steps) OSG_HIP(hipMemcpyAsync(steps, d_steps, step_bytes, hipMemcpyDeviceToHost, ctx->stream));
     OSG_HIP(hipStreamSynchronize(ctx->stream));
   }
   return OSG_OK;

@@ -25,12 +25,12 @@ __global__ void __launch_bounds__(256) k_mul(uint32_t* out, uint32_t seed) {
   out[blockIdx.x * 256 + threadIdx.x] = v;
 }
 __global__ void __launch_bounds__(256) k_salu(uint32_t* out, uint32_t seed) {
-  uint32_t s = seed;
+  uint32_t s = seed + blockIdx.x;
   for (int i = 0; i < kIters; ++i) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) asm volatile("s_add_u32 %0, %0, %1" : "+s"(s) : "s"(seed));
+    for (int k = 0; k < 16; ++k) asm volatile("s_add_u32 %0, %0, %1" : "+s"(s) : "s"(seed) : "scc");
   }
-  if (threadIdx.x == 0) out[blockIdx.x] = s;
+  out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 __global__ void __launch_bounds__(256) k_mix(uint32_t* out, uint32_t seed) {  // VALU and SALU interleaved
   uint32_t v = threadIdx.x + seed, s = seed;
@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) k_mix(uint32_t* out, uint32_t seed) {  //
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       asm volatile("v_add_u32 %0, %0, %1" : "+v"(v) : "v"(seed));
-      asm volatile("s_add_u32 %0, %0, %1" : "+s"(s) : "s"(seed));
+      asm volatile("s_add_u32 %0, %0, %1" : "+s"(s) : "s"(seed) : "scc");
     }
   }
   out[blockIdx.x * 256 + threadIdx.x] = v + s;
@@ -54,6 +54,8 @@ double time_ms(K kernel, uint32_t* out, int blocks) {
   kernel<<<blocks, 256>>>(out, 3u);
   hipEventRecord(b);
   hipEventSynchronize(b);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) printf("  (launch error: %s)\n", hipGetErrorString(err));
   float ms = 0;
   hipEventElapsedTime(&ms, a, b);
   return ms;

@@ -243,3 +243,44 @@ def test_bench_two_ranks_code_path(tmp_path):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0
     assert line["secondary"]["mcts"]["value"] > 0 and line["secondary"]["mccfr"]["tables_finite"]
+
+
+def test_hex9_mcts_2pow16_roots_under_full_load(oracle, ctx):
+    """Config 4's root count with the chip saturated (64 wavefronts queued per SIMD): the wave-per-root
+    kernel relies on one wavefront's memory operations being issued in order (no waits between a store
+    and a later load of the same node).  Any violation would show as run-to-run differences or broken
+    tree invariants; a strided sample of roots is also replayed exactly by the oracle's MCTSBot."""
+    import torch
+    import open_spiel_amd as osa
+    n, sims, seed = 1 << 16, 128, 0xC0FFEE
+    og = oracle.Game("hex(board_size=9)")
+    roots = osa.StateBatch(ctx, "hex(board_size=9)", n)
+    plies = 20
+    roots.random_steps(77, plies)
+    keep = (roots.is_terminal() == 0).cpu().numpy()
+    a = roots.mcts_search(uct_c=2.0, max_simulations=sims, seed=seed, layout=2)
+    b = roots.mcts_search(uct_c=2.0, max_simulations=sims, seed=seed, layout=2)
+    for key in ("best_action", "child_visits", "child_reward"):
+        assert torch.equal(a[key], b[key]), f"{key}: two runs of the same search differ"
+    visits = a["child_visits"].cpu().numpy()
+    reward = a["child_reward"].cpu().numpy()
+    stats = a["root_stats"].cpu().numpy()
+    live = keep & (stats[:, 3] == sims)
+    assert live.sum() > n * 0.9
+    assert (visits[live].sum(1) == sims - 1).all(), "every simulation but the first (it evaluates the root) visits one root child"
+    assert (np.abs(reward[live]) <= visits[live]).all(), "|total reward| <= visits (returns are +-1)"
+    assert (stats[live, 0] == sims).all()
+    mask = roots.legal_actions_mask().cpu().numpy()
+    assert (visits[live][mask[live] == 0] == 0).all(), "no visits on occupied cells"
+    best = a["best_action"].cpu().numpy()
+    assert (mask[live, :][np.arange(live.sum()), best[live]] == 1).all()
+    # exact oracle replay of a strided sample (the root position is rebuilt from the random_steps stream)
+    for i in range(0, n, n // 24 + 1):
+        if not live[i]:
+            continue
+        s, _ = _replay_random_steps(oracle, "hex(board_size=9)", 77, i, plies)
+        want = s.mcts_search(2.0, sims, 1, 4096, False, 0, counter_root=i, counter_seed=seed, counter_layout=2)
+        for act, cnt, tot, _ in want["children"]:
+            assert visits[i, int(act)] == cnt and reward[i, int(act)] == tot, (i, int(act))
+        assert best[i] == want["best_action"], i
+    del og

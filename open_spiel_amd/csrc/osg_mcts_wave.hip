@@ -668,12 +668,16 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
       const uint32_t e = path[d];
       const uint32_t v = e & 0x0FFFFFFFu;
       int pl = static_cast<int>(e >> 28) - 1;
-      for (int up = d; pl == kChancePlayer;) {  // skip chance-player entries (poker trees)
-        if (--up < 0) { pl = 0; break; }
-        pl = static_cast<int>(path[up] >> 28) - 1;
-      }
       double rv = returns[0];
-      for (int q = 1; q < num_players; ++q) rv = (pl == q) ? returns[q] : rv;
+      if constexpr (kBoard) {  // two players, no chance nodes
+        rv = pl == 1 ? returns[1] : rv;
+      } else {
+        for (int up = d; pl == kChancePlayer;) {  // skip chance-player entries (poker trees)
+          if (--up < 0) { pl = 0; break; }
+          pl = static_cast<int>(path[up] >> 28) - 1;
+        }
+        for (int q = 1; q < num_players; ++q) rv = (pl == q) ? returns[q] : rv;
+      }
       const double nt = ptot[d] + rv;
       const uint32_t nc = pcnt[d] + 1;
       TOTAL[v] = nt;

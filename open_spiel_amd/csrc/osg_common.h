@@ -58,8 +58,11 @@ struct Rng {
 constexpr uint64_t kOrderSalt = 0x6F726465725F6B79ULL;
 constexpr uint64_t kFillSalt = 0x66696C6C5F6B6579ULL;
 OSG_HD uint64_t path_hash_root() { return 0x243F6A8885A308D3ULL; }
+// (a 32-bit chain in a 64-bit slot: order_key only ever reads the low word, and one 32-bit mixer per tree
+// level is a third of the scalar work of a 64-bit one)
+OSG_HD uint32_t mix32(uint32_t x);
 OSG_HD uint64_t path_hash_child(uint64_t parent, int action) {
-  return mix64(parent ^ (static_cast<uint64_t>(action + 1) * 0x9E3779B97F4A7C15ULL));
+  return mix32(static_cast<uint32_t>(parent) ^ (static_cast<uint32_t>(action + 1) * 0x9E3779B1u));
 }
 OSG_HD uint64_t order_base(uint64_t seed, uint64_t root) {
   return mix64(mix64(seed ^ kOrderSalt) ^ (root * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));

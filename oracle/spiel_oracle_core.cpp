@@ -256,8 +256,9 @@ uint64_t Mix64(uint64_t z) {
   return z ^ (z >> 31);
 }
 uint64_t PathHashRoot() { return 0x243F6A8885A308D3ULL; }
-uint64_t PathHashChild(uint64_t parent, int action) {
-  return Mix64(parent ^ (static_cast<uint64_t>(action + 1) * 0x9E3779B97F4A7C15ULL));
+static uint32_t Mix32(uint32_t x);
+uint64_t PathHashChild(uint64_t parent, int action) {  // a 32-bit chain in a 64-bit slot, as in osg_common.h
+  return Mix32(static_cast<uint32_t>(parent) ^ (static_cast<uint32_t>(action + 1) * 0x9E3779B1u));
 }
 uint64_t OrderBase(uint64_t seed, uint64_t root) {
   return Mix64(Mix64(seed ^ 0x6F726465725F6B79ULL) ^ (root * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));

@@ -81,16 +81,19 @@ OSG_HD uint32_t order_key(uint64_t base, uint64_t parent_path_hash, int action) 
                            (static_cast<uint32_t>(action + 1) * 0x9E3779B1u));
   return (h & ~0xFFu) | static_cast<uint32_t>(action & 0xFF);  // low byte = action: siblings never tie
 }
+// The random fill of a hex playout orders the empty cells by a 40-bit key: 32 mixed bits and the cell id
+// (so keys never tie; two cells share their 32 random bits with probability ~8e-7 per playout, and then the
+// lower cell id goes first).  One 32-bit mixer per (root, playout) for the base, one per cell for the key.
 OSG_HD uint64_t fill_base(uint64_t seed, uint64_t root, uint64_t sub) {
-  const uint64_t a = mix64(mix64(seed ^ kFillSalt) ^ (root * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));
-  return mix64(a ^ (sub * 0xA0761D6478BD642FULL + 0xE7037ED1A0B428DBULL));
+  const uint64_t a = mix64(mix64(seed ^ kFillSalt) ^ (root * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));  // per root
+  return mix32(static_cast<uint32_t>(a) ^ static_cast<uint32_t>(a >> 32) ^ (static_cast<uint32_t>(sub) * 0x9E3779B1u) ^
+               (static_cast<uint32_t>(sub >> 32) * 0x85EBCA6Bu));
 }
-OSG_HD uint64_t fill_key(uint64_t base, int cell) {  // two 32-bit mixers side by side: 56 random bits + the cell id
-  const uint32_t c = static_cast<uint32_t>(cell + 1);
-  const uint32_t hi = mix32(static_cast<uint32_t>(base) ^ (c * 0x9E3779B1u));
-  const uint32_t lo = mix32(static_cast<uint32_t>(base >> 32) ^ (c * 0x85EBCA6Bu));
-  return (static_cast<uint64_t>(hi) << 32) | static_cast<uint64_t>((lo & ~0xFFu) | static_cast<uint32_t>(cell & 0xFF));
+OSG_HD uint64_t fill_key(uint64_t base, int cell) {
+  const uint32_t h = mix32(static_cast<uint32_t>(base) ^ (static_cast<uint32_t>(cell + 1) * 0x9E3779B1u));
+  return (static_cast<uint64_t>(h) << 8) | static_cast<uint64_t>(cell & 0xFF);
 }
+constexpr int kFillKeyBits = 40;
 
 // ---------------------------------------------------------------------------
 // Legal-action mask: up to 128 actions, bit a of word a/32.

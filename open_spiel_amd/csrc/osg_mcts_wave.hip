@@ -356,7 +356,7 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl) {
   // count is exact — about log2(m) + 2 steps of two compares and a handful of scalar instructions.
   uint64_t thr = 0ull;
   if (want > 0) {
-    uint64_t step = 1ull << 63;
+    uint64_t step = 1ull << (kFillKeyBits - 1);
     bool exact;
     do {  // straight-line body: one select, no inner branch
       const uint64_t probe = thr | step;

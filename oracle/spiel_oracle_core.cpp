@@ -275,15 +275,14 @@ uint32_t OrderKey(uint64_t base, uint64_t parent_path_hash, int action) {
                            (static_cast<uint32_t>(action + 1) * 0x9E3779B1u));
   return (h & ~0xFFu) | static_cast<uint32_t>(action & 0xFF);
 }
-uint64_t FillBase(uint64_t seed, uint64_t root, uint64_t sub) {
+uint64_t FillBase(uint64_t seed, uint64_t root, uint64_t sub) {  // osg_common.h fill_base, bit for bit
   const uint64_t a = Mix64(Mix64(seed ^ 0x66696C6C5F6B6579ULL) ^ (root * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));
-  return Mix64(a ^ (sub * 0xA0761D6478BD642FULL + 0xE7037ED1A0B428DBULL));
+  return Mix32(static_cast<uint32_t>(a) ^ static_cast<uint32_t>(a >> 32) ^ (static_cast<uint32_t>(sub) * 0x9E3779B1u) ^
+               (static_cast<uint32_t>(sub >> 32) * 0x85EBCA6Bu));
 }
-uint64_t FillKey(uint64_t base, int cell) {
-  const uint32_t c = static_cast<uint32_t>(cell + 1);
-  const uint32_t hi = Mix32(static_cast<uint32_t>(base) ^ (c * 0x9E3779B1u));
-  const uint32_t lo = Mix32(static_cast<uint32_t>(base >> 32) ^ (c * 0x85EBCA6Bu));
-  return (static_cast<uint64_t>(hi) << 32) | static_cast<uint64_t>((lo & ~0xFFu) | static_cast<uint32_t>(cell & 0xFF));
+uint64_t FillKey(uint64_t base, int cell) {  // 32 mixed bits | cell id
+  const uint32_t h = Mix32(static_cast<uint32_t>(base) ^ (static_cast<uint32_t>(cell + 1) * 0x9E3779B1u));
+  return (static_cast<uint64_t>(h) << 8) | static_cast<uint64_t>(cell & 0xFF);
 }
 
 CounterRng::CounterRng(uint64_t seed, uint64_t stream, uint64_t sub) {

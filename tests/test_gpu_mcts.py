@@ -201,3 +201,25 @@ def test_small_pool_still_searches(ctx, layout):
     stats = r["root_stats"].cpu().numpy()
     assert (stats[:, 0] == 300).all() and (stats[:, 1] <= 40).all()
     assert (r["child_visits"].sum(1).cpu().numpy() == 299).all()
+
+
+def test_hex_fill_playout_matches_sequential_random_play(ctx):
+    """The wave kernel's hex playout (one random fill of the board, keyed order) and the generic
+    sequential random playout (k_rollout) estimate the same quantity: black's expected return under
+    uniformly random play from the empty board.  262 144 playouts each; 5 sigma ~ 0.015."""
+    import open_spiel_amd as osa
+    n, r = 4096, 64
+    roots = osa.StateBatch(ctx, "hex(board_size=5)", n)
+    seq = roots.rollout(2024, r)                      # [n, 2] sums over r playouts
+    est_seq = float(seq[:, 0].sum()) / (n * r)
+    # two simulations: the first evaluates the root, the second a uniformly random child (all tie)
+    res = roots.mcts_search(uct_c=2.0, max_simulations=2, n_rollouts=r, seed=99, layout=2)
+    visits = res["child_visits"].cpu().numpy()
+    reward = res["child_reward"].cpu().numpy()
+    assert (visits.sum(1) == 1).all()
+    first_move = visits.argmax(1)
+    counts = np.bincount(first_move, minlength=25)
+    assert counts.min() > n / 25 * 0.6 and counts.max() < n / 25 * 1.4, "the tie-break is not uniform over the cells"
+    est_fill = reward.sum() / n                      # child total = mean of its r playouts (black's return)
+    assert abs(est_fill - est_seq) < 0.015, (est_fill, est_seq)
+    assert 0.0 < est_seq < 0.5, "black moves first and gets 13 of 25 cells: a modest edge"

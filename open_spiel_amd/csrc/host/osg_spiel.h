@@ -404,6 +404,10 @@ class MCTSBot {  // mcts.h:149-220
     return std::vector<Action>(best.begin(), best.end());
   }
   Action Step(const State& state) { return StepBatch(state.Batch())[0]; }  // mcts.cc:233-266
+  std::pair<ActionsAndProbs, Action> StepWithPolicy(const State& state) {  // mcts.cc:268-271
+    const Action action = Step(state);
+    return {{{action, 1.0}}, action};
+  }
   std::unique_ptr<SearchNode> MCTSearch(const State& state) {              // mcts.cc:353-467
     const int A = num_actions_;
     std::vector<int32_t> visits(A);

@@ -171,6 +171,7 @@ PYBIND11_MODULE(pyspiel_hip, m) {
            py::arg("max_memory_mb"), py::arg("solve"), py::arg("seed"), py::arg("verbose"),
            py::arg("child_selection_policy") = ChildSelectionPolicy::UCT)
       .def("step", &MCTSBot::Step, py::arg("state"), py::call_guard<py::gil_scoped_release>())
+      .def("step_with_policy", &MCTSBot::StepWithPolicy, py::arg("state"))  // spiel_bots.h:105-112
       .def("mcts_search", &MCTSBot::MCTSearch, py::arg("state"), py::call_guard<py::gil_scoped_release>())
       .def("step_batch", &MCTSBot::StepBatch, py::arg("states"), py::call_guard<py::gil_scoped_release>());
 

@@ -89,6 +89,18 @@ def test_mcts_bot_solver_answers(pyspiel):
 
 
 @pytest.mark.gpu
+def test_mcts_bot_step_with_policy(pyspiel):
+    """Bot::StepWithPolicy (mcts.cc:268-271): the chosen action with probability one."""
+    game = pyspiel.load_game("tic_tac_toe")
+    bot = pyspiel.MCTSBot(game, pyspiel.RandomRolloutEvaluator(8, 3), 2.0, 200, 64, True, 11, False)
+    state = game.new_initial_state()
+    for a in (4, 0, 8):
+        state.apply_action(a)
+    policy, action = bot.step_with_policy(state)
+    assert policy == [(action, 1.0)] and action in state.legal_actions()
+
+
+@pytest.mark.gpu
 def test_cfr_solver_like_cfr_example(pyspiel, oracle):
     """examples/cfr_example.cc:33-45 / python cfr_test.py: CFRSolver on kuhn_poker."""
     game = pyspiel.load_game("kuhn_poker")

@@ -233,3 +233,50 @@ def test_serialize_game_and_state_round_trip(pyspiel):
     assert pyspiel.deserialize_game_and_state(pyspiel.serialize_game_and_state(c4, s))[1].history() == []
     with pytest.raises(pyspiel.SpielError):
         c4.deserialize_state("9\n")  # not a column
+
+
+@pytest.mark.gpu
+def test_observation_wrapper_like_observation_test(pyspiel):
+    """python/tests/observation_test.py:32-89 through open_spiel_amd.observation: tensor, named pieces in
+    the observers' order, views that follow set_from, the information-state string."""
+    from open_spiel_amd.observation import INFO_STATE_OBS_TYPE, IIGObservationType, PrivateInfoType, make_observation
+    game = pyspiel.load_game("leduc_poker")
+    state = game.new_initial_state()
+    for a in (1, 2, 2, 1, 3):  # deal 1, deal 2, bet, call, deal 3
+        state.apply_action(a)
+    obs = make_observation(game)
+    obs.set_from(state, player=0)
+    np.testing.assert_array_equal(obs.tensor, [1, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 3, 3])
+    assert list(obs.dict) == ["player", "private_card", "community_card", "pot_contribution"]
+    np.testing.assert_array_equal(obs.dict["player"], [1, 0])
+    np.testing.assert_array_equal(obs.dict["private_card"], [0, 1, 0, 0, 0, 0])
+    np.testing.assert_array_equal(obs.dict["community_card"], [0, 0, 0, 1, 0, 0])
+    np.testing.assert_array_equal(obs.dict["pot_contribution"], [3, 3])
+    info = make_observation(game, INFO_STATE_OBS_TYPE)
+    info.set_from(state, player=0)
+    assert list(info.dict) == ["player", "private_card", "community_card", "betting"]
+    np.testing.assert_array_equal(info.dict["betting"], [[[0, 1], [1, 0], [0, 0], [0, 0]],
+                                                         [[0, 0], [0, 0], [0, 0], [0, 0]]])
+    assert info.string_from(state, 0) == ("[Observer: 0][Private: 1][Round 2][Player: 0][Pot: 6]"
+                                          "[Money: 97 97][Public: 3][Round1: 2 1][Round2: ]")
+    info.set_from(state, player=1)  # the dict entries are views into the tensor
+    np.testing.assert_array_equal(info.dict["player"], [0, 1])
+    np.testing.assert_array_equal(info.dict["private_card"], [0, 0, 1, 0, 0, 0])
+    assert make_observation(game, IIGObservationType(perfect_recall=True, private_info=PrivateInfoType.ALL_PLAYERS)) is None
+    kuhn = pyspiel.load_game("kuhn_poker")
+    ks = kuhn.new_initial_state()
+    for a in (2, 0, 1):  # deals 2 / 0, player 0 bets
+        ks.apply_action(a)
+    ko = make_observation(kuhn, INFO_STATE_OBS_TYPE)
+    ko.set_from(ks, 1)
+    assert list(ko.dict) == ["player", "private_card", "betting"] and ko.dict["betting"].shape == (3, 2)
+    np.testing.assert_array_equal(ko.dict["private_card"], [1, 0, 0])
+    np.testing.assert_array_equal(ko.dict["betting"][0], [0, 1])
+    c4 = pyspiel.load_game("connect_four")
+    co = make_observation(c4)
+    cs = c4.new_initial_state()
+    cs.apply_action(3)
+    co.set_from(cs, 0)
+    assert list(co.dict) == ["observation"] and co.dict["observation"].shape == (3, 6, 7)
+    assert co.dict["observation"][0, 0, 3] == 1 and co.dict["observation"][2].sum() == 41
+    assert make_observation(c4, INFO_STATE_OBS_TYPE) is None

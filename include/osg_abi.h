@@ -152,6 +152,12 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
  * state words; returns the length (excluding NUL) or <0. */
 int osg_information_state_string(const osg_batch* b, int64_t index, int player, char* buf, int cap);
 
+/* State::ObservationString(player) of state `index`: the board (tic_tac_toe.cc:163-175,
+ * connect_four.cc:212-222, hex.cc:341-359) or the imperfect-recall observer string of the poker games
+ * (kuhn_poker.cc:109-166, leduc_poker.cc:198-239).  Host formatter over the packed state words; returns
+ * the length (excluding NUL) or <0. */
+int osg_observation_string(const osg_batch* b, int64_t index, int player, char* buf, int cap);
+
 /* Environment loop on device: `steps` times { sample a uniformly random legal
  * action (chance outcomes by their distribution), apply, auto-reset terminal
  * states to the initial state }.  d_counters[0] += env steps applied,

@@ -98,6 +98,7 @@ SIGNATURES = {
     "osg_step": (INT, [VP, VP, VP, VP, VP]),
     "osg_observation": (INT, [VP, INT, INT, VP, INT]),
     "osg_information_state_string": (INT, [VP, I64, INT, C.c_char_p, INT]),
+    "osg_observation_string": (INT, [VP, I64, INT, C.c_char_p, INT]),
     "osg_env_step": (INT, [VP, VP, VP, U64, I64, I64, VP, VP, VP, VP]),
     "osg_random_steps": (INT, [VP, U64, I64, INT, VP]),
     "osg_rollout": (INT, [VP, U64, I64, INT, VP, VP, INT]),

@@ -237,6 +237,13 @@ class State {
     return buf;
   }
   std::string InformationStateString() const { return InformationStateString(CurrentPlayer()); }
+  std::string ObservationString(Player player) const {  // the games' ObservationString / board ToString
+    CheckPlayer(player);
+    char buf[1024];
+    if (osg_observation_string(batch_.handle(), 0, player, buf, sizeof(buf)) < 0) SpielFatalError(osg_last_error());
+    return buf;
+  }
+  std::string ObservationString() const { return ObservationString(CurrentPlayer()); }
   std::unique_ptr<State> Clone() const { return std::unique_ptr<State>(new State(*this)); }
   std::unique_ptr<State> Child(Action a) const {  // spiel.h:737-744
     std::unique_ptr<State> c = Clone();

@@ -100,6 +100,8 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("information_state_string", py::overload_cast<Player>(&State::InformationStateString, py::const_),
            py::arg("player"))
       .def("information_state_string", py::overload_cast<>(&State::InformationStateString, py::const_))
+      .def("observation_string", py::overload_cast<Player>(&State::ObservationString, py::const_), py::arg("player"))
+      .def("observation_string", py::overload_cast<>(&State::ObservationString, py::const_))
       .def("clone", &State::Clone)
       .def("child", &State::Child, py::arg("action"))
       .def("history", &State::History)

@@ -1186,23 +1186,37 @@ __global__ void k_fill(double* p, double v, int n) {
 // ---------------------------------------------------------------------------
 std::string kuhn_key(const Kuhn::Params& p, uint64_t word, int player) {
   Kuhn::State s{word};
-  std::string r = std::to_string(Kuhn::card(s, player));
+  std::string r = Kuhn::len(s) > player ? std::to_string(Kuhn::card(s, player)) : std::string();  // not dealt yet: ""
   const int n = Kuhn::nact(p, s);
   for (int j = 0; j < n; ++j) r.push_back(((Kuhn::bets(s) >> j) & 1u) ? 'b' : 'p');
   return r;
 }
 
-std::string leduc_key(const Leduc::Params& p, uint64_t w0, uint64_t w1, int player) {
-  Leduc::State s = Leduc::unpack(w0, w1);
-  std::string r = "[Observer: " + std::to_string(player) + "][Private: " + std::to_string(Leduc::priv(s, player)) + "]";
+// The part LeducObserver::StringFrom writes for both recall types (leduc_poker.cc:198-226).  money_ is
+// kStartingMoney - ante_ while the hand runs; at the end the pot has been paid out (pot_ = 0,
+// money = 100 + returns).
+std::string leduc_observer_prefix(const Leduc::Params& p, const Leduc::State& s, int player) {
+  const bool term = Leduc::terminal(p, s);
+  double ret[kMaxPlayers] = {0};
+  if (term) Leduc::returns(p, s, ret);
+  const int hole = Leduc::priv(s, player);  // kInvalidCard = -10000 before the deal (leduc_poker.h:63)
+  std::string r = "[Observer: " + std::to_string(player) + "][Private: " +
+                  std::to_string(hole == Leduc::kNone ? -10000 : hole) + "]";
   r += "[Round " + std::to_string(s.round) + "][Player: " + std::to_string(s.cur) + "][Pot: " +
-       std::to_string(s.pot) + "][Money: ";
+       std::to_string(term ? 0 : s.pot) + "][Money: ";
   for (int q = 0; q < p.players; ++q) {
+    char num[32];
+    snprintf(num, sizeof num, "%g", term ? 100.0 + ret[q] : 100.0 - Leduc::ante(s, q));
     if (q) r += " ";
-    r += std::to_string(100 - Leduc::ante(s, q));  // money_ = kStartingMoney - ante_ until the showdown
+    r += num;
   }
   r += "]";
   if (s.pub != Leduc::kNone) r += "[Public: " + std::to_string(s.pub) + "]";
+  return r;
+}
+std::string leduc_key(const Leduc::Params& p, uint64_t w0, uint64_t w1, int player) {
+  Leduc::State s = Leduc::unpack(w0, w1);
+  std::string r = leduc_observer_prefix(p, s, player);
   for (int round = 0; round < 2; ++round) {
     r += round == 0 ? "[Round1: " : "][Round2: ";
     for (int k = 0; k < Leduc::seqlen(s, round); ++k) {
@@ -2038,6 +2052,90 @@ int osg_information_state_string(const osg_batch* b, int64_t index, int player, 
   if (static_cast<int>(key.size()) + 1 > cap) return set_error(OSG_ERR_INVALID, "buffer too small");
   memcpy(buf, key.c_str(), key.size() + 1);
   return static_cast<int>(key.size());
+}
+
+int osg_observation_string(const osg_batch* b, int64_t index, int player, char* buf, int cap) {
+  if (!b || !buf || cap <= 0 || index < 0 || index >= b->n)
+    return set_error(OSG_ERR_INVALID, "osg_observation_string: bad argument");
+  const osg_game_desc& d = b->spec.desc;
+  if (player < 0 || player >= d.num_players) return set_error(OSG_ERR_INVALID, "player id out of range");
+  uint64_t w[4 * 4 + 1] = {0};
+  const char* base = static_cast<const char*>(b->d_words);
+  for (int k = 0; k < d.state_words; ++k)
+    OSG_HIP(hipMemcpyAsync(&w[k], base + (static_cast<size_t>(k) * b->n + index) * d.state_word_bytes, d.state_word_bytes,
+                           hipMemcpyDeviceToHost, b->ctx->stream));
+  OSG_HIP(hipStreamSynchronize(b->ctx->stream));
+  std::string out;
+  switch (d.game_kind) {
+    case kTtt: {  // tic_tac_toe.cc:163-175: rows joined by newlines
+      const uint32_t x = static_cast<uint32_t>(w[0]) & 0x1FFu, o = (static_cast<uint32_t>(w[0]) >> 16) & 0x1FFu;
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) out += (x >> (3 * r + c) & 1u) ? "x" : ((o >> (3 * r + c) & 1u) ? "o" : ".");
+        if (r < 2) out += "\n";
+      }
+      break;
+    }
+    case kC4: {  // connect_four.cc:212-222: top row first, every row ends with a newline
+      const int R = b->spec.c4.rows, Cn = b->spec.c4.cols;
+      const uint64_t x = b->spec.c4_std ? (w[0] & ((1ull << 56) - 1ull)) : w[0], o = w[1];
+      for (int r = R - 1; r >= 0; --r) {
+        for (int c = 0; c < Cn; ++c) {
+          const int bit = c * (R + 1) + r;
+          out += (x >> bit & 1ull) ? "x" : ((o >> bit & 1ull) ? "o" : ".");
+        }
+        out += "\n";
+      }
+      break;
+    }
+    case kHex: {  // hex.cc:341-359: one line per row, indented by the row number, a space after every cell
+      const int NW = b->spec.hex_nw;
+      int cols = 0, cells = 0;
+      switch (NW) {
+        case 1: cols = b->spec.hex1.cols; cells = b->spec.hex1.cells; break;
+        case 2: cols = b->spec.hex2.cols; cells = b->spec.hex2.cells; break;
+        case 3: cols = b->spec.hex3.cols; cells = b->spec.hex3.cells; break;
+        default: cols = b->spec.hex4.cols; cells = b->spec.hex4.cells; break;
+      }
+      auto bit = [&](int plane, int cell) { return (w[plane * NW + (cell >> 5)] >> (cell & 31)) & 1ull; };
+      int line = 0;
+      for (int i = 0; i < cells; ++i) {
+        if (i && i % cols == 0) {
+          out += "\n";
+          out += std::string(++line, ' ');
+        }
+        const bool black = bit(0, i), white = bit(1, i);
+        const int mag = 1 + 2 * static_cast<int>(bit(2, i)) + static_cast<int>(bit(3, i));  // plain, B, A, win
+        if (!black && !white) out += ".";
+        else if (!b->spec.hex_explicit) out += black ? "x" : "o";
+        else out += black ? (mag == 1 ? "x" : mag == 2 ? "z" : mag == 3 ? "y" : "X")   // hex.cc:173-227
+                          : (mag == 1 ? "o" : mag == 2 ? "q" : mag == 3 ? "p" : "O");
+        out += " ";
+      }
+      break;
+    }
+    case kKuhn: {  // kuhn_poker.cc:109-166, default observer: own card, then every player's contribution
+      const Kuhn::Params& kp = b->spec.kuhn;
+      Kuhn::State st{w[0]};
+      if (Kuhn::len(st) > player) {
+        out += std::to_string(Kuhn::card(st, player));
+        for (int q = 0; q < kp.players; ++q) out += std::to_string(Kuhn::did_bet(kp, st, q) ? 2 : 1);
+      }
+      break;
+    }
+    case kLeduc: {  // leduc_poker.cc:198-239, imperfect recall: pot contributions instead of the sequences
+      const Leduc::Params& lp = b->spec.leduc;
+      Leduc::State st = Leduc::unpack(w[0], w[1]);
+      out = leduc_observer_prefix(lp, st, player);
+      out += "[Ante: ";
+      for (int q = 0; q < lp.players; ++q) out += (q ? " " : "") + std::to_string(Leduc::ante(st, q));
+      out += "]";
+      break;
+    }
+    default: return set_error(OSG_ERR_INVALID, "bad game kind");
+  }
+  if (static_cast<int>(out.size()) + 1 > cap) return set_error(OSG_ERR_INVALID, "buffer too small");
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return static_cast<int>(out.size());
 }
 
 }  // extern "C"

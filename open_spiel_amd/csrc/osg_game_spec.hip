@@ -194,6 +194,7 @@ int parse_game(const char* game_string, GameSpec* out) {
     d.obs_rank = 3; d.obs_shape[0] = plain ? 3 : 9; d.obs_shape[1] = cols; d.obs_shape[2] = rows;
     d.obs_size = d.obs_shape[0] * cells;
     out->hex_nw = (cells + 31) / 32;
+    out->hex_explicit = rep == "explicit";
     d.state_words = 4 * out->hex_nw + 1; d.state_word_bytes = 4;
     fill_hex<1>(&out->hex1, cols, rows, swap, plain);
     fill_hex<2>(&out->hex2, cols, rows, swap, plain);

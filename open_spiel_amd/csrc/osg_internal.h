@@ -23,6 +23,7 @@ struct GameSpec {
   osg_game_desc desc;
   int hex_nw = 0;  // u32 words per hex bit plane (1..4)
   bool c4_std = false;  // connect_four with the default 6x7x4 geometry (constant-folded kernels)
+  bool hex_explicit = false;  // hex(string_rep=explicit): edge-connection glyphs in the board string
   Ttt::Params ttt;
   C4::Params c4;
   HexT<1>::Params hex1;

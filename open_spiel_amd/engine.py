@@ -221,6 +221,22 @@ class StateBatch:
         check(lib().osg_observation(self._h, int(player), 1, _ptr(out), 0))
         return out
 
+    def observation_string(self, index, player):
+        """State::ObservationString(player) of state `index` (host formatter over the packed words)."""
+        buf = C.create_string_buffer(1024)
+        rc = lib().osg_observation_string(self._h, int(index), int(player), buf, 1024)
+        if rc < 0:
+            check(rc)
+        return buf.value.decode()
+
+    def information_state_string(self, index, player):
+        """State::InformationStateString(player) of state `index` (kuhn_poker / leduc_poker)."""
+        buf = C.create_string_buffer(1024)
+        rc = lib().osg_information_state_string(self._h, int(index), int(player), buf, 1024)
+        if rc < 0:
+            check(rc)
+        return buf.value.decode()
+
     # -- the fused step -------------------------------------------------------------
     def step_buffers(self):
         mask = self._dev((self.n, self.desc.compact_mask_bytes), torch.uint8)

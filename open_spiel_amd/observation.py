@@ -79,7 +79,7 @@ class _Observation:
     def string_from(self, state, player):
         if self._info_state:
             return state.information_state_string(player)
-        return None  # ObservationString is not produced by this engine
+        return state.observation_string(player)
 
 
 def make_observation(game, imperfect_information_observation_type=None, params=None):

@@ -300,3 +300,49 @@ def test_tiny_and_ragged_batches(oracle, ctx, game, n):
         got = b.observation_tensor(0).cpu().numpy()
         np.testing.assert_array_equal(got, rec["obs"][:, t + 1, 0])
         a, b = b, a
+
+
+def test_observation_and_information_state_strings_match_the_reference_playthroughs(goldens, ctx):
+    """ObservationString / InformationStateString of every state of the reference's playthroughs
+    (open_spiel/integration_tests/playthroughs/*.txt via tests/golden/playthroughs.json), formatted by
+    the library from the packed device words."""
+    import torch
+    import open_spiel_amd as osa
+    checked = 0
+    for name, play in goldens.items():
+        batch = osa.StateBatch(ctx, play["game"], 1)
+        for blk in play["states"]:
+            if not blk.get("skipped"):
+                for p_str, want in blk.get("obs_str", {}).items():
+                    assert batch.observation_string(0, int(p_str)) == want, (name, blk["history"], p_str)
+                    checked += 1
+                if batch.desc.info_size:
+                    for p_str, want in blk.get("info_str", {}).items():
+                        assert batch.information_state_string(0, int(p_str)) == want, (name, blk["history"], p_str)
+            if "action" in blk:
+                batch.apply_actions(torch.tensor([blk["action"]], dtype=torch.int32))
+    assert checked > 100
+
+
+@pytest.mark.parametrize("game", ["hex(board_size=4,string_rep=explicit)", "hex", "connect_four(rows=5,columns=6,x_in_row=3)",
+                                  "kuhn_poker(players=3)", "leduc_poker(players=3)", "tic_tac_toe"])
+def test_observation_strings_match_the_oracle(oracle, ctx, game):
+    """The same strings on random trajectories of the variants the playthroughs do not cover."""
+    import torch
+    import open_spiel_amd as osa
+    og = oracle.Game(game)
+    n = 24
+    rec = og.random_playouts(7, n)
+    batch = osa.StateBatch(ctx, game, n)
+    states = [og.new_initial_state() for _ in range(n)]
+    for t in range(og.max_plies + 1):
+        for i in range(0, n, 5):
+            for p in range(og.num_players):
+                assert batch.observation_string(i, p) == states[i].observation_string(p), (game, i, t, p)
+        if t == og.max_plies:
+            break
+        acts = rec["actions"][:, t].astype(np.int32)
+        batch.apply_actions(torch.from_numpy(acts))
+        for i in range(n):
+            if acts[i] >= 0:
+                states[i].apply_action(int(acts[i]))

@@ -158,6 +158,13 @@ int osg_information_state_string(const osg_batch* b, int64_t index, int player, 
  * the length (excluding NUL) or <0. */
 int osg_observation_string(const osg_batch* b, int64_t index, int player, char* buf, int cap);
 
+/* State::ToString() of state `index` (tic_tac_toe.cc:163-175, connect_four.cc:212-222, hex.cc:341-359,
+ * kuhn_poker.cc:253-268, leduc_poker.cc:463-496) and State::ActionToString(player, action)
+ * (tic_tac_toe.cc:266-270, connect_four.cc:158-161, hex.cc:295-314, kuhn_poker.cc:244-251,
+ * leduc_poker.cc:459-461); player -1 = chance.  Host formatters; return the length or <0. */
+int osg_state_string(const osg_batch* b, int64_t index, char* buf, int cap);
+int osg_action_string(const osg_batch* b, int64_t index, int player, int32_t action, char* buf, int cap);
+
 /* Environment loop on device: `steps` times { sample a uniformly random legal
  * action (chance outcomes by their distribution), apply, auto-reset terminal
  * states to the initial state }.  d_counters[0] += env steps applied,

@@ -244,6 +244,24 @@ class State {
     return buf;
   }
   std::string ObservationString() const { return ObservationString(CurrentPlayer()); }
+  std::string ToString() const {  // the games' ToString (e.g. leduc_poker.cc:463-496)
+    char buf[1024];
+    if (osg_state_string(batch_.handle(), 0, buf, sizeof(buf)) < 0) SpielFatalError(osg_last_error());
+    return buf;
+  }
+  std::string ActionToString(Player player, Action action) const {  // spiel.h:386-392
+    char buf[64];
+    const int who = player == kChancePlayerId ? -1 : player;
+    if (osg_action_string(batch_.handle(), 0, who, static_cast<int32_t>(action), buf, sizeof(buf)) < 0)
+      SpielFatalError(osg_last_error());
+    return buf;
+  }
+  std::string ActionToString(Action action) const { return ActionToString(CurrentPlayer(), action); }
+  std::string HistoryString() const {  // spiel.h:700-702: "a, b, c"
+    std::string out;
+    for (size_t i = 0; i < history_.size(); ++i) out += (i ? ", " : "") + std::to_string(history_[i].second);
+    return out;
+  }
   std::unique_ptr<State> Clone() const { return std::unique_ptr<State>(new State(*this)); }
   std::unique_ptr<State> Child(Action a) const {  // spiel.h:737-744
     std::unique_ptr<State> c = Clone();

@@ -102,6 +102,12 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("information_state_string", py::overload_cast<>(&State::InformationStateString, py::const_))
       .def("observation_string", py::overload_cast<Player>(&State::ObservationString, py::const_), py::arg("player"))
       .def("observation_string", py::overload_cast<>(&State::ObservationString, py::const_))
+      .def("__str__", &State::ToString)
+      .def("to_string", &State::ToString)
+      .def("action_to_string", py::overload_cast<Player, Action>(&State::ActionToString, py::const_),
+           py::arg("player"), py::arg("action"))
+      .def("action_to_string", py::overload_cast<Action>(&State::ActionToString, py::const_), py::arg("action"))
+      .def("history_str", &State::HistoryString)
       .def("clone", &State::Clone)
       .def("child", &State::Child, py::arg("action"))
       .def("history", &State::History)

@@ -2138,4 +2138,131 @@ int osg_observation_string(const osg_batch* b, int64_t index, int player, char* 
   return static_cast<int>(out.size());
 }
 
+namespace {
+// The packed words of one state, on the host.
+int fetch_state_words(const osg_batch* b, int64_t index, uint64_t* w) {
+  const osg_game_desc& d = b->spec.desc;
+  const char* base = static_cast<const char*>(b->d_words);
+  for (int k = 0; k < d.state_words; ++k)
+    OSG_HIP(hipMemcpyAsync(&w[k], base + (static_cast<size_t>(k) * b->n + index) * d.state_word_bytes, d.state_word_bytes,
+                           hipMemcpyDeviceToHost, b->ctx->stream));
+  OSG_HIP(hipStreamSynchronize(b->ctx->stream));
+  return OSG_OK;
+}
+const char* leduc_action_name(int a) { return a == 0 ? "Fold" : (a == 1 ? "Call" : "Raise"); }  // leduc_poker.cc:869-875
+void hex_geometry(const GameSpec& spec, int* cols, int* rows, int* cells) {
+  switch (spec.hex_nw) {
+    case 1: *cols = spec.hex1.cols; *rows = spec.hex1.rows; *cells = spec.hex1.cells; break;
+    case 2: *cols = spec.hex2.cols; *rows = spec.hex2.rows; *cells = spec.hex2.cells; break;
+    case 3: *cols = spec.hex3.cols; *rows = spec.hex3.rows; *cells = spec.hex3.cells; break;
+    default: *cols = spec.hex4.cols; *rows = spec.hex4.rows; *cells = spec.hex4.cells; break;
+  }
+}
+int return_string(const std::string& out, char* buf, int cap) {
+  if (static_cast<int>(out.size()) + 1 > cap) return set_error(OSG_ERR_INVALID, "buffer too small");
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return static_cast<int>(out.size());
+}
+}  // namespace
+
+int osg_state_string(const osg_batch* b, int64_t index, char* buf, int cap) {
+  if (!b || !buf || cap <= 0 || index < 0 || index >= b->n)
+    return set_error(OSG_ERR_INVALID, "osg_state_string: bad argument");
+  const osg_game_desc& d = b->spec.desc;
+  if (d.game_kind == kTtt || d.game_kind == kC4 || d.game_kind == kHex)
+    return osg_observation_string(b, index, 0, buf, cap);  // ObservationString is ToString() in these games
+  uint64_t w[4 * 4 + 1] = {0};
+  int rc = fetch_state_words(b, index, w);
+  if (rc) return rc;
+  std::string out;
+  if (d.game_kind == kKuhn) {  // kuhn_poker.cc:253-268: the dealt cards, then p / b
+    const Kuhn::Params& kp = b->spec.kuhn;
+    Kuhn::State st{w[0]};
+    const int h = Kuhn::len(st);
+    for (int i = 0; i < h && i < kp.players; ++i) out += (i ? " " : "") + std::to_string(Kuhn::card(st, i));
+    if (h > kp.players) out += ' ';
+    for (int j = 0; j < Kuhn::nact(kp, st); ++j) out.push_back(((Kuhn::bets(st) >> j) & 1u) ? 'b' : 'p');
+  } else {  // leduc_poker.cc:463-496
+    const Leduc::Params& lp = b->spec.leduc;
+    Leduc::State st = Leduc::unpack(w[0], w[1]);
+    const bool term = Leduc::terminal(lp, st);
+    double ret[kMaxPlayers] = {0};
+    if (term) Leduc::returns(lp, st, ret);
+    const int P = lp.players;
+    auto card = [](int c) { return std::to_string(c == Leduc::kNone ? -10000 : c); };
+    out = "Round: " + std::to_string(st.round) + "\nPlayer: " + std::to_string(st.cur) + "\nPot: " +
+          std::to_string(term ? 0 : st.pot) + "\nMoney (player_0 player_1" + (P > 2 ? " [...]):" : "):");
+    for (int q = 0; q < P; ++q) {
+      char num[32];
+      snprintf(num, sizeof num, "%g", term ? 100.0 + ret[q] : 100.0 - Leduc::ante(st, q));
+      out += std::string(" ") + num;
+    }
+    out += std::string("\nCards (public player_0 player_1") + (P > 2 ? " [...]): " : "): ") + card(st.pub) + " ";
+    for (int q = 0; q < P; ++q) out += card(Leduc::priv(st, q)) + " ";
+    for (int round = 0; round < 2; ++round) {
+      out += round == 0 ? "\nRound 1 sequence: " : "\nRound 2 sequence: ";
+      for (int k = 0; k < Leduc::seqlen(st, round); ++k)
+        out += std::string(k ? ", " : "") + leduc_action_name((Leduc::seq(st, round) >> (2 * k)) & 3u);
+    }
+    out += "\n";
+  }
+  return return_string(out, buf, cap);
+}
+
+int osg_action_string(const osg_batch* b, int64_t index, int player, int32_t action, char* buf, int cap) {
+  if (!b || !buf || cap <= 0 || index < 0 || index >= b->n)
+    return set_error(OSG_ERR_INVALID, "osg_action_string: bad argument");
+  const osg_game_desc& d = b->spec.desc;
+  if (player < -1 || player >= d.num_players) return set_error(OSG_ERR_INVALID, "player id out of range");
+  std::string out;
+  switch (d.game_kind) {
+    case kTtt:  // tic_tac_toe.cc:266-270
+      out = std::string(player == 0 ? "x" : "o") + "(" + std::to_string(action / 3) + "," + std::to_string(action % 3) + ")";
+      break;
+    case kC4:  // connect_four.cc:158-161
+      out = std::string(player == 0 ? "x" : "o") + std::to_string(action);
+      break;
+    case kHex: {  // hex.cc:295-314 (its "row" is the column letter)
+      int cols, rows, cells;
+      hex_geometry(b->spec, &cols, &rows, &cells);
+      if (action == cells) { out = "swap"; break; }
+      const int x = action % cols, y = action / cols;
+      if (!b->spec.hex_explicit) {
+        out = std::string(1, static_cast<char>('a' + x)) + std::to_string(y + 1);
+        break;
+      }
+      // explicit representation: the label the stone would get (PlayerAndActionToState, hex.cc:108-171)
+      uint64_t w[4 * 4 + 1] = {0};
+      int rc = fetch_state_words(b, index, w);
+      if (rc) return rc;
+      const int NW = b->spec.hex_nw;
+      auto bit = [&](int plane, int cell) { return (w[plane * NW + (cell >> 5)] >> (cell & 31)) & 1ull; };
+      const bool black = player == 0;
+      bool a = black ? y == 0 : x == 0;
+      bool bb = !a && (black ? y == rows - 1 : x == cols - 1);
+      const int nb[6][2] = {{0, -1}, {1, -1}, {1, 0}, {0, 1}, {-1, 1}, {-1, 0}};  // AdjacentCells, hex.cc:316-329
+      for (const auto& dxy : nb) {
+        const int nx = x + dxy[0], ny = y + dxy[1];
+        if (nx < 0 || ny < 0 || nx >= cols || ny >= rows) continue;
+        const int c = ny * cols + nx;
+        if (!bit(black ? 0 : 1, c)) continue;
+        const bool ea = bit(2, c), eb = bit(3, c);
+        if (ea && !eb) a = true;
+        if (eb && !ea) bb = true;
+      }
+      const char* glyph = black ? (a && bb ? "X" : a ? "y" : bb ? "z" : "x") : (a && bb ? "O" : a ? "p" : bb ? "q" : "o");
+      out = std::string(glyph) + "(" + std::to_string(x) + "," + std::to_string(y) + ")";
+      break;
+    }
+    case kKuhn:  // kuhn_poker.cc:244-251
+      out = player < 0 ? "Deal:" + std::to_string(action) : std::string(action == 0 ? "Pass" : "Bet");
+      break;
+    case kLeduc:  // leduc_poker.cc:459-461
+      out = player < 0 ? "Chance outcome:" + std::to_string(action) : std::string(leduc_action_name(action));
+      break;
+    default: return set_error(OSG_ERR_INVALID, "bad game kind");
+  }
+  return return_string(out, buf, cap);
+}
+
 }  // extern "C"

@@ -229,6 +229,22 @@ class StateBatch:
             check(rc)
         return buf.value.decode()
 
+    def state_string(self, index):
+        """State::ToString() of state `index`."""
+        buf = C.create_string_buffer(1024)
+        rc = lib().osg_state_string(self._h, int(index), buf, 1024)
+        if rc < 0:
+            check(rc)
+        return buf.value.decode()
+
+    def action_string(self, index, player, action):
+        """State::ActionToString(player, action) for state `index` (player -1 = chance)."""
+        buf = C.create_string_buffer(64)
+        rc = lib().osg_action_string(self._h, int(index), int(player), int(action), buf, 64)
+        if rc < 0:
+            check(rc)
+        return buf.value.decode()
+
     def information_state_string(self, index, player):
         """State::InformationStateString(player) of state `index` (kuhn_poker / leduc_poker)."""
         buf = C.create_string_buffer(1024)

@@ -319,6 +319,12 @@ def test_observation_and_information_state_strings_match_the_reference_playthrou
                 if batch.desc.info_size:
                     for p_str, want in blk.get("info_str", {}).items():
                         assert batch.information_state_string(0, int(p_str)) == want, (name, blk["history"], p_str)
+                # the dump strips trailing blanks per line
+                got = [l.rstrip() for l in batch.state_string(0).rstrip("\n").split("\n")]
+                assert got == [l.rstrip() for l in blk["to_string"].rstrip("\n").split("\n")], (name, blk["history"])
+                cp = blk["current_player"]
+                names = [batch.action_string(0, -1 if cp == -1 else cp, a) for a in blk["legal_actions"]]
+                assert names == blk["string_legal_actions"], (name, blk["history"])
             if "action" in blk:
                 batch.apply_actions(torch.tensor([blk["action"]], dtype=torch.int32))
     assert checked > 100
@@ -339,6 +345,10 @@ def test_observation_strings_match_the_oracle(oracle, ctx, game):
         for i in range(0, n, 5):
             for p in range(og.num_players):
                 assert batch.observation_string(i, p) == states[i].observation_string(p), (game, i, t, p)
+            assert batch.state_string(i) == str(states[i]), (game, i, t)
+            cp = states[i].current_player()
+            for a in states[i].legal_actions():
+                assert batch.action_string(i, cp, a) == states[i].action_to_string(cp, a), (game, i, t, a)
         if t == og.max_plies:
             break
         acts = rec["actions"][:, t].astype(np.int32)

@@ -40,8 +40,16 @@ def test_play_a_game_like_a_pyspiel_script(pyspiel):
     assert state.history() == [4, 0, 8, 1, 2, 6, 3, 5, 7]
     obs = state.observation_tensor(0)
     assert len(obs) == 27 and sum(obs) == 9
+    assert str(state) == "oox\nxxo\noxx" and state.history_str() == "4, 0, 8, 1, 2, 6, 3, 5, 7"
     clone = game.new_initial_state().child(4)
     assert clone.history() == [4] and clone.current_player() == 1
+    assert str(clone) == "...\n.x.\n..." and clone.observation_string(0) == str(clone)
+    assert clone.action_to_string(1, 0) == "o(0,0)" and clone.action_to_string(8) == "o(2,2)"
+    leduc = pyspiel.load_game("leduc_poker").new_initial_state()
+    assert leduc.action_to_string(3) == "Chance outcome:3"   # chance to move
+    leduc.apply_action(3)
+    leduc.apply_action(0)
+    assert leduc.action_to_string(0, 2) == "Raise" and "Round 1 sequence: " in str(leduc)
     with pytest.raises(pyspiel.SpielError):
         clone.apply_action(4)                                # occupied cell
     with pytest.raises(pyspiel.SpielError):

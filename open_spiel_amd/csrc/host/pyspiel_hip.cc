@@ -52,6 +52,80 @@ class TabularPolicy {
 
 }  // namespace
 
+
+// Game::GetParameters (spiel.h:1013): the given parameters plus every default, typed like pyspiel does.
+py::dict GameParametersWithDefaults(const std::string& game_string) {
+  const size_t open = game_string.find('(');
+  const std::string name = game_string.substr(0, open);
+  std::vector<std::pair<std::string, std::string>> kv;  // defaults first, then the given values
+  if (name == "connect_four") kv = {{"columns", "7"}, {"egocentric_obs_tensor", "False"}, {"rows", "6"}, {"x_in_row", "4"}};
+  else if (name == "hex") kv = {{"board_size", "11"}, {"num_cols", ""}, {"num_rows", ""}, {"plain_obs_tensor", "False"},
+                                {"string_rep", "standard"}, {"swap", "False"}};
+  else if (name == "kuhn_poker") kv = {{"players", "2"}};
+  else if (name == "leduc_poker") kv = {{"action_mapping", "False"}, {"players", "2"}, {"starting_player", "0"},
+                                        {"suit_isomorphism", "False"}};
+  if (open != std::string::npos) {
+    const std::string body = game_string.substr(open + 1, game_string.rfind(')') - open - 1);
+    size_t pos = 0;
+    while (pos < body.size()) {
+      size_t comma = body.find(',', pos);
+      if (comma == std::string::npos) comma = body.size();
+      const std::string item = body.substr(pos, comma - pos);
+      pos = comma + 1;
+      const size_t eq = item.find('=');
+      if (eq == std::string::npos) continue;
+      const std::string k = item.substr(0, eq), v = item.substr(eq + 1);
+      bool found = false;
+      for (auto& e : kv)
+        if (e.first == k) { e.second = v; found = true; }
+      if (!found) kv.emplace_back(k, v);
+    }
+  }
+  if (name == "hex") {  // num_cols / num_rows default to board_size (hex.cc:60-63)
+    std::string bs;
+    for (auto& e : kv) if (e.first == "board_size") bs = e.second;
+    for (auto& e : kv) if ((e.first == "num_cols" || e.first == "num_rows") && e.second.empty()) e.second = bs;
+  }
+  py::dict out;
+  for (const auto& e : kv) {
+    const std::string& v = e.second;
+    if (v == "True" || v == "true") out[py::str(e.first)] = py::bool_(true);
+    else if (v == "False" || v == "false") out[py::str(e.first)] = py::bool_(false);
+    else if (!v.empty() && v.find_first_not_of("-0123456789") == std::string::npos) out[py::str(e.first)] = py::int_(std::stoll(v));
+    else out[py::str(e.first)] = py::str(v);
+  }
+  return out;
+}
+
+// The GameType fields scripts look at (spiel.h:60-160), as plain read-only attributes.
+struct GameTypeInfo {
+  std::string short_name, long_name, dynamics, chance_mode, information, utility, reward_model;
+  int max_num_players, min_num_players;
+  bool provides_information_state_string, provides_information_state_tensor, provides_observation_string,
+      provides_observation_tensor;
+};
+GameTypeInfo GameTypeOf(const Game& g) {
+  const std::string s = g.ToString();
+  const std::string name = s.substr(0, s.find('('));
+  const bool poker = name == "kuhn_poker" || name == "leduc_poker";
+  GameTypeInfo t;
+  t.short_name = name;
+  t.long_name = name == "tic_tac_toe" ? "Tic Tac Toe" : name == "connect_four" ? "Connect Four" : name == "hex" ? "Hex"
+                : name == "kuhn_poker" ? "Kuhn Poker" : "Leduc Poker";
+  t.dynamics = "Dynamics.SEQUENTIAL";
+  t.chance_mode = poker ? "ChanceMode.EXPLICIT_STOCHASTIC" : "ChanceMode.DETERMINISTIC";
+  t.information = poker ? "Information.IMPERFECT_INFORMATION" : "Information.PERFECT_INFORMATION";
+  t.utility = "Utility.ZERO_SUM";
+  t.reward_model = "RewardModel.TERMINAL";
+  t.min_num_players = 2;
+  t.max_num_players = poker ? 10 : 2;
+  t.provides_information_state_string = true;
+  t.provides_information_state_tensor = poker;
+  t.provides_observation_string = true;
+  t.provides_observation_tensor = true;
+  return t;
+}
+
 PYBIND11_MODULE(pyspiel_hip, m) {
   m.doc() = "pyspiel-compatible surface of the MI355X game-step and search engine (libosg_hip.so)";
   py::register_exception<SpielException>(m, "SpielError", PyExc_RuntimeError);  // pyspiel.cc:831-837
@@ -74,9 +148,26 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("deserialize_state", &Game::DeserializeState, py::arg("serialized"))
       .def(py::pickle([](const Game& g) { return g.Serialize(); },  // pyspiel.cc:535-543
                       [](const std::string& t) { return std::const_pointer_cast<Game>(LoadGame(t)); }))
+      .def("utility_sum", [](const Game&) { return 0.0; })  // all five games are zero-sum (spiel.h:1006-1011)
+      .def("get_parameters", [](const Game& g) { return GameParametersWithDefaults(g.ToString()); })
+      .def("get_type", [](const Game& g) { return GameTypeOf(g); })
       .def("new_initial_states", [](const Game& g, int64_t n) { return g.NewInitialStates(n); }, py::arg("n"))
       .def("__str__", &Game::ToString)
       .def("__repr__", &Game::ToString);
+  py::class_<GameTypeInfo>(m, "GameType")
+      .def_readonly("short_name", &GameTypeInfo::short_name)
+      .def_readonly("long_name", &GameTypeInfo::long_name)
+      .def_readonly("dynamics", &GameTypeInfo::dynamics)
+      .def_readonly("chance_mode", &GameTypeInfo::chance_mode)
+      .def_readonly("information", &GameTypeInfo::information)
+      .def_readonly("utility", &GameTypeInfo::utility)
+      .def_readonly("reward_model", &GameTypeInfo::reward_model)
+      .def_readonly("max_num_players", &GameTypeInfo::max_num_players)
+      .def_readonly("min_num_players", &GameTypeInfo::min_num_players)
+      .def_readonly("provides_information_state_string", &GameTypeInfo::provides_information_state_string)
+      .def_readonly("provides_information_state_tensor", &GameTypeInfo::provides_information_state_tensor)
+      .def_readonly("provides_observation_string", &GameTypeInfo::provides_observation_string)
+      .def_readonly("provides_observation_tensor", &GameTypeInfo::provides_observation_tensor);
   m.def("load_game", [](const std::string& s) { return std::make_shared<Game>(s); });  // pyspiel.cc:720-731
 
   py::class_<State>(m, "State")

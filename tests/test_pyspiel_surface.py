@@ -25,6 +25,37 @@ def test_module_imports_and_describes_games_without_a_gpu(pyspiel):
             g.new_initial_state()
 
 
+def test_game_headers_match_the_reference_playthroughs(pyspiel, goldens):
+    """The header block of every reference playthrough (GetParameters with defaults, sizes, utilities,
+    tensor piece names and shapes) through Game's methods and open_spiel_amd.observation; no GPU needed."""
+    from open_spiel_amd.observation import _pieces
+    for name, play in goldens.items():
+        hdr = play["header"]
+        game = pyspiel.load_game(play["game"])
+        params = game.get_parameters()
+        text = "{" + ",".join(f"{k}={params[k]}" for k in sorted(params)) + "}"
+        assert text == hdr["GetParameters"], name
+        assert game.num_distinct_actions() == int(hdr["NumDistinctActions"])
+        assert game.max_chance_outcomes() == int(hdr["MaxChanceOutcomes"])
+        assert game.num_players() == int(hdr["NumPlayers"])
+        assert (game.min_utility(), game.max_utility(), game.utility_sum()) == (
+            float(hdr["MinUtility"]), float(hdr["MaxUtility"]), float(hdr["UtilitySum"]))
+        assert game.max_game_length() == int(hdr["MaxGameLength"])
+        assert game.observation_tensor_size() == int(hdr["ObservationTensorSize"])
+        assert str(game) == hdr["ToString"].strip('"')
+        t = game.get_type()
+        assert t.short_name == play["game"].split("(")[0] and t.utility == "Utility.ZERO_SUM"
+        def shape_text(pieces):
+            if len(pieces) == 1 and pieces[0][0] == "observation":
+                return str(list(pieces[0][1]))
+            return ", ".join(f"{n}: {list(sh)}" for n, sh in pieces)
+        assert shape_text(_pieces(game, False)) == hdr["ObservationTensorShape"], name
+        if "InformationStateTensorShape" in hdr:
+            assert t.provides_information_state_tensor
+            assert shape_text(_pieces(game, True)) == hdr["InformationStateTensorShape"], name
+            assert game.information_state_tensor_size() == int(hdr["InformationStateTensorSize"])
+
+
 @pytest.mark.gpu
 def test_play_a_game_like_a_pyspiel_script(pyspiel):
     game = pyspiel.load_game("tic_tac_toe")

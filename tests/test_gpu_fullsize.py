@@ -284,3 +284,21 @@ def test_hex9_mcts_2pow16_roots_under_full_load(oracle, ctx):
             assert visits[i, int(act)] == cnt and reward[i, int(act)] == tot, (i, int(act))
         assert best[i] == want["best_action"], i
     del og
+
+
+def test_rollout_sums_do_not_depend_on_how_rollouts_are_shared_out(ctx):
+    """Rollout r of root i always plays from stream (seed, i, r): the sums of a root inside a 2^17-root
+    batch (4 lanes per root, 4 rollouts each) equal those of the same root evaluated alone (16 lanes)."""
+    import torch
+    import open_spiel_amd as osa
+    n, r, seed = 1 << 17, 16, 4321
+    big = osa.StateBatch(ctx, "connect_four", n)
+    big.random_steps(5, 9)
+    total, steps = big.rollout(seed, r, want_steps=True)
+    total, steps = total.cpu().numpy(), steps.cpu().numpy()
+    assert (np.abs(total) <= r).all() and (total[:, 0] == -total[:, 1]).all()
+    for i in (0, 1, 777, 65535, 65536, n - 1):
+        one = big.gather(torch.tensor([i]))
+        t1, s1 = one.rollout(seed, r, index_offset=i, want_steps=True)
+        assert t1.cpu().numpy()[0].tolist() == total[i].tolist(), i
+        assert int(s1.cpu().numpy()[0]) == int(steps[i]), i

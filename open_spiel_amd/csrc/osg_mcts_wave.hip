@@ -426,6 +426,22 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
   if constexpr (kHexFill) root_state = hexw_from_state<G>(loaded_root);
   else root_state = loaded_root;
   const int root_player = w_current_player<G>(p, root_state);
+  // hex: the root position lives in LDS and is re-read at the start of every simulation (57 -> 34 spilled
+  // scalar registers)
+  __shared__ uint32_t s_root[kHexFill ? kWavesPerBlock : 1][20];
+  if constexpr (kHexFill) {
+    if (lane == 0) {
+      uint32_t* rw = s_root[wave_in_block];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        rw[8 * j + 0] = static_cast<uint32_t>(root_state.blk[j]); rw[8 * j + 1] = static_cast<uint32_t>(root_state.blk[j] >> 32);
+        rw[8 * j + 2] = static_cast<uint32_t>(root_state.wht[j]); rw[8 * j + 3] = static_cast<uint32_t>(root_state.wht[j] >> 32);
+        rw[8 * j + 4] = static_cast<uint32_t>(root_state.ea[j]); rw[8 * j + 5] = static_cast<uint32_t>(root_state.ea[j] >> 32);
+        rw[8 * j + 6] = static_cast<uint32_t>(root_state.eb[j]); rw[8 * j + 7] = static_cast<uint32_t>(root_state.eb[j] >> 32);
+      }
+      rw[16] = root_state.meta;
+    }
+  }
   // The root's header stays in registers (its count / total in path slot 0); every other node's header
   // comes out of its parent's child scan by readlane, so a tree level costs ONE memory round trip.
   uint32_t root_meta = make_meta(0xFF, root_player, 0);  // mcts.cc:356-357
@@ -447,7 +463,20 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
   for (int sim = 0; sim < cfg.max_simulations; ++sim) {
     Rng trng(cfg.seed ^ kTreeSalt, gr, static_cast<uint64_t>(sim));
     // ---- ApplyTreePolicy (mcts.cc:273-351) ----
-    WState s = root_state;
+    WState s;
+    if constexpr (kHexFill) {  // the root position is re-read from LDS: 17 scalar registers less to keep alive
+      const uint32_t* rw = s_root[wave_in_block];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        s.blk[j] = static_cast<uint64_t>(uniform(rw[8 * j + 1])) << 32 | uniform(rw[8 * j + 0]);
+        s.wht[j] = static_cast<uint64_t>(uniform(rw[8 * j + 3])) << 32 | uniform(rw[8 * j + 2]);
+        s.ea[j] = static_cast<uint64_t>(uniform(rw[8 * j + 5])) << 32 | uniform(rw[8 * j + 4]);
+        s.eb[j] = static_cast<uint64_t>(uniform(rw[8 * j + 7])) << 32 | uniform(rw[8 * j + 6]);
+      }
+      s.meta = uniform(rw[16]);
+    } else {
+      s = root_state;
+    }
     uint32_t node = 0;
     int depth = 0;
     uint64_t ph = path_hash_root();
@@ -521,6 +550,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
         uint32_t cm2[2], cc2[2], cf2[2];
         double ct2[2];
         bool unvisited[2];
+        const bool wide = c > 64;  // wave-uniform: nodes with at most 64 children skip the second slot altogether
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int k = lane + 64 * j;
@@ -529,6 +559,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
           cf2[j] = 0;
           ct2[j] = 0.0;
           unvisited[j] = false;
+          if (j == 1 && !wide) continue;
           if (k < c) {
             cm2[j] = META[first + k];
             cc2[j] = COUNT[first + k];
@@ -550,6 +581,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
           for (int j = 0; j < 2; ++j) {
             const int k = lane + 64 * j;
             v2[j] = -INFINITY;
+            if (j == 1 && !wide) continue;
             if (k < c) ct2[j] = TOTAL[first + k];
           }
           if (puct) {  // uniform branch: the two policies share nothing but the loads
@@ -557,6 +589,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               const int k = lane + 64 * j;
+              if (j == 1 && !wide) continue;
               if (k < c) {
                 if (m_has_outcome(cm2[j])) v2[j] = outcome_value<kBoard>(cm2[j], cc2[j], ct2[j], m_player(cm2[j]));
                 else v2[j] = (cc2[j] != 0 ? ct2[j] / cc2[j] : 0.0) + cfg.uct_c * prior * sqrt_n / (cc2[j] + 1);
@@ -567,6 +600,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               const int k = lane + 64 * j;
+              if (j == 1 && !wide) continue;
               // straight-line: lanes without a child divide by zero and are masked by the select below
               double val = ct2[j] / cc2[j] + cfg.uct_c * sqrt(logn / cc2[j]);
               if constexpr (kBoard) {

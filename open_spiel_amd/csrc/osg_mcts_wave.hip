@@ -63,7 +63,10 @@ extern "C" int osg_debug_phase_cycles(unsigned long long* out8, int reset) {
 
 namespace {
 
-constexpr int kWavesPerBlock = 4;
+#ifndef OSG_WAVES_PER_BLOCK
+#define OSG_WAVES_PER_BLOCK 4
+#endif
+constexpr int kWavesPerBlock = OSG_WAVES_PER_BLOCK;
 constexpr int kMaxPath = 160;
 
 OSG_D int lane_id() { return static_cast<int>(threadIdx.x & 63u); }

@@ -179,7 +179,7 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
     del solver
     # the same kernel with one workgroup per independent solver (random initial regrets): what the GPU does
     # with this config when asked for many solves at once
-    replicas = 4096
+    replicas = 16384  # 16 wavefronts queued per SIMD; 4096 (4 per SIMD) gives 5.6e8, 16384 7.3e8, 32768 7.7e8
     many = osa.TabularSolver(ctx, "kuhn_poker", replicas=replicas, random_initial_regrets=True, seed=SEED,
                              replica_offset=rank * replicas)
     many.evaluate_and_update_policy(50)

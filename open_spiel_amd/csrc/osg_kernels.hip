@@ -359,10 +359,14 @@ k_observation_c4std(C4Params p, const uint64_t* __restrict__ base, int64_t n, in
 // row per lane would (about 1.2 instructions per output byte instead of 5; 117 -> 94 us for [2^20, 126]).  A wavefront owns a contiguous, 16-byte
 // aligned span of 64 x 42 floats; it is staged in LDS (8-byte writes at a 168-byte lane stride) and
 // written back as aligned float4, one KiB per store instruction.  Needs a 16-byte aligned output.
-__global__ void __launch_bounds__(kBlock)
+#ifndef OSG_C4OBS_BLOCK
+#define OSG_C4OBS_BLOCK 128
+#endif
+constexpr int kC4ObsBlock = OSG_C4OBS_BLOCK;
+__global__ void __launch_bounds__(kC4ObsBlock)
 k_observation_c4std_planes(C4Params p, const uint64_t* __restrict__ base, int64_t n, int player, float* __restrict__ out) {
-  __shared__ float2 s_stage[kBlock * 21];
-  const int64_t gl = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  __shared__ float2 s_stage[kC4ObsBlock * 21];
+  const int64_t gl = static_cast<int64_t>(blockIdx.x) * kC4ObsBlock + threadIdx.x;
   const int64_t lanes = n * 3;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float2* w2 = s_stage + wave * (64 * 21);
@@ -396,7 +400,7 @@ k_observation_c4std_planes(C4Params p, const uint64_t* __restrict__ base, int64_
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const int64_t wave_lane0 = static_cast<int64_t>(blockIdx.x) * kBlock + wave * 64;
+  const int64_t wave_lane0 = static_cast<int64_t>(blockIdx.x) * kC4ObsBlock + wave * 64;
   if (wave_lane0 >= lanes) return;
   const int64_t left = (lanes - wave_lane0) * 42;
   const int valid = left < 64 * 42 ? static_cast<int>(left) : 64 * 42;  // floats this wavefront owns
@@ -960,7 +964,8 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
   }
   if (b->spec.desc.game_kind == kC4 && b->spec.c4_std) {
     if ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0)
-      k_observation_c4std_planes<<<dim3(grid_for(b->n * 3)), dim3(kBlock), 0, ctx->stream>>>(
+      k_observation_c4std_planes<<<dim3(static_cast<unsigned>((b->n * 3 + kC4ObsBlock - 1) / kC4ObsBlock)),
+                                   dim3(kC4ObsBlock), 0, ctx->stream>>>(
           b->spec.c4, static_cast<const uint64_t*>(b->d_words), b->n, player, d_out);
     else
       k_observation_c4std<<<dim3(grid_for(b->n * 18)), dim3(kBlock), 0, ctx->stream>>>(

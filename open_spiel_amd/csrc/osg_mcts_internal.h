@@ -7,7 +7,10 @@
 
 namespace osg {
 
-constexpr int kBlockM = 64;  // one wave per block: searches differ in length, keep blocks small
+#ifndef OSG_MCTS_LANE_BLOCK
+#define OSG_MCTS_LANE_BLOCK 64
+#endif
+constexpr int kBlockM = OSG_MCTS_LANE_BLOCK;  // one wave per block: searches differ in length, keep blocks small
 constexpr uint64_t kTreeSalt = 0x7265655F73616C74ULL;  // stream separation for the tree-policy RNG
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 

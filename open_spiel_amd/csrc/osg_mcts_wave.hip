@@ -379,6 +379,7 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl) {
   // Lane-parallel flood: a black cell joins the region when one of its neighbours is in it.
   // Stops as soon as the last row is reached.
   uint64_t reach0 = blk0 & hl.first_row[0], reach1 = blk1 & hl.first_row[1];
+#pragma unroll 4  // measured: 1 -> 7.80e8, compiler's choice (2) -> 7.93e8, 4 -> 8.01e8 sims/s
   for (int it = 0; it < 128; ++it) {
     if (((reach0 & hl.last_row[0]) | (reach1 & hl.last_row[1])) != 0ull) return 0;  // black
     const bool n0 = ((hl.nb_lo[0] & reach0) | (hl.nb_hi[0] & reach1)) != 0ull;

@@ -136,11 +136,15 @@ k_step(typename G::Params p, const typename G::word_t* src, typename G::word_t* 
 // byte (C4T::kStored) a step costs ONE line test (the mover's, inside apply) and
 // one multiply for the successor's legal mask; the kernel is then close to the
 // plain-copy time of the same bytes (tools/step_sweep.hip).
+#ifndef OSG_C4STEP_BLOCK
+#define OSG_C4STEP_BLOCK 256
+#endif
+constexpr int kC4StepBlock = OSG_C4STEP_BLOCK;
 template <class G>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kC4StepBlock)
 k_step_c4x2(typename G::Params p, const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, int64_t n,
             const uint8_t* __restrict__ actions, uint8_t* __restrict__ mask_out, uint8_t* __restrict__ status) {
-  const int64_t pair = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t pair = static_cast<int64_t>(blockIdx.x) * kC4StepBlock + threadIdx.x;
   const int64_t i = pair * 2;
   if (i >= n) return;
   const ulonglong2 xs = *reinterpret_cast<const ulonglong2*>(src + i);
@@ -919,11 +923,11 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
   if (src->spec.desc.game_kind == kC4 && (n & 1) == 0 && aligned2) {
     const int64_t pairs = n / 2;
     if (src->spec.c4_std) {
-      k_step_c4x2<C4Std><<<dim3(grid_for(pairs)), dim3(kBlock), 0, ctx->stream>>>(
+      k_step_c4x2<C4Std><<<dim3(static_cast<unsigned>((pairs + kC4StepBlock - 1) / kC4StepBlock)), dim3(kC4StepBlock), 0, ctx->stream>>>(
           src->spec.c4, static_cast<const uint64_t*>(src->d_words), static_cast<uint64_t*>(dst->d_words), n, d_actions,
           static_cast<uint8_t*>(d_mask), d_status);
     } else {
-      k_step_c4x2<C4><<<dim3(grid_for(pairs)), dim3(kBlock), 0, ctx->stream>>>(
+      k_step_c4x2<C4><<<dim3(static_cast<unsigned>((pairs + kC4StepBlock - 1) / kC4StepBlock)), dim3(kC4StepBlock), 0, ctx->stream>>>(
           src->spec.c4, static_cast<const uint64_t*>(src->d_words), static_cast<uint64_t*>(dst->d_words), n, d_actions,
           static_cast<uint8_t*>(d_mask), d_status);
     }

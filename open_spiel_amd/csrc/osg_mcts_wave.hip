@@ -299,6 +299,9 @@ OSG_D void hexw_apply(const HexLane& hl, HexW& w, int move) {
     const uint64_t plain0 = own0 & ~w.ea[0] & ~w.eb[0], plain1 = own1 & ~w.ea[1] & ~w.eb[1];
     uint64_t region0 = 0ull, region1 = 0ull;
     uint64_t front0 = bit0, front1 = bit1;
+#ifdef OSG_APPLY_UNROLL
+#pragma unroll OSG_APPLY_UNROLL
+#endif
     for (int it = 0; it < 128; ++it) {
       const bool t0 = ((hl.nb_lo[0] & front0) | (hl.nb_hi[0] & front1)) != 0ull;
       const bool t1 = ((hl.nb_lo[1] & front0) | (hl.nb_hi[1] & front1)) != 0ull;
@@ -361,6 +364,9 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl) {
   if (want > 0) {
     uint64_t step = 1ull << (kFillKeyBits - 1);
     bool exact;
+#ifdef OSG_THR_UNROLL
+#pragma unroll OSG_THR_UNROLL
+#endif
     do {  // straight-line body: one select, no inner branch
       const uint64_t probe = thr | step;
       const int below = __builtin_popcountll(__ballot(key0 < probe) & empty0) +

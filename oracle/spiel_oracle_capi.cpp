@@ -1,15 +1,112 @@
 // CPU ORACLE — TEST INFRASTRUCTURE ONLY (see spiel_oracle.h).
 // extern "C" surface so tests/, bench.py's cpu_baseline leg and
 // __graft_entry__.smoke() can drive the oracle through ctypes.
+//
+// This one driver builds twice:
+//   * default: over the restatement (spiel_oracle.h, namespace osg_oracle) -> liboracle.so;
+//   * -DOSGO_GENUINE_REFERENCE: over the GENUINE reference classes, compiled unmodified from
+//     /root/reference against the private abseil / nlohmann stand-ins in oracle/ref_shim
+//     (recipe: oracle/Makefile.ref) -> oracle/_ref/libspiel_ref.so.  Same entry points, same
+//     seeded drivers, so every deterministic result of the restatement can be compared with
+//     the real implementation call for call (tests/test_oracle_vs_reference.py).  The entry
+//     points that need the restatement's replay hooks (counter-stream MCTS, mini-batch
+//     MCCFR) report an error in that build: the reference has no such hooks.
 #include <map>
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <limits>
+#include <stdexcept>
 #include <thread>
+#include <unordered_map>
 
+#ifdef OSGO_GENUINE_REFERENCE
+#include "open_spiel/algorithms/cfr.h"
+#include "open_spiel/algorithms/expected_returns.h"
+#include "open_spiel/algorithms/external_sampling_mccfr.h"
+#include "open_spiel/algorithms/mcts.h"
+#include "open_spiel/algorithms/outcome_sampling_mccfr.h"
+#include "open_spiel/algorithms/tabular_exploitability.h"
+#include "open_spiel/games/kuhn_poker/kuhn_poker.h"
+#include "open_spiel/policy.h"
+#include "open_spiel/spiel.h"
+#include "open_spiel/spiel_utils.h"
+
+namespace osgo_adapt {
+// The counter-based generator of spiel_oracle_core.cpp (splitmix64 keyed by seed / stream /
+// sub-stream), restated here so that this build draws the same playouts as the restatement.
+inline uint64_t Mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+struct CounterRng {
+  uint64_t s;
+  explicit CounterRng(uint64_t seed, uint64_t stream = 0, uint64_t sub = 0) {
+    uint64_t a = Mix64(seed + 0x9E3779B97F4A7C15ULL);
+    uint64_t b = Mix64(a ^ (stream * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));
+    s = Mix64(b ^ (sub * 0xA0761D6478BD642FULL + 0xE7037ED1A0B428DBULL));
+  }
+  uint64_t Next() { s += 0x9E3779B97F4A7C15ULL; return Mix64(s); }
+  uint32_t Below(uint32_t n) { return static_cast<uint32_t>(((Next() >> 32) * n) >> 32); }
+  double Unit() { return static_cast<double>(Next() >> 11) * (1.0 / 9007199254740992.0); }
+};
+[[noreturn]] inline void Fatal(const std::string& msg) { throw std::runtime_error(msg); }
+// SpielFatalError -> exception, as the reference's own Python bindings do (pyspiel.cc:831-837).
+inline void ThrowingHandler(const std::string& msg) { throw std::runtime_error(msg); }
+struct InstallHandler {
+  InstallHandler() { open_spiel::SetErrorHandler(&ThrowingHandler); }
+};
+static InstallHandler g_install_handler;
+}  // namespace osgo_adapt
+#define ORACLE_CHECK(cond) \
+  do { if (!(cond)) ::osgo_adapt::Fatal(std::string(__FILE__) + ":" + std::to_string(__LINE__) + " CHECK failed: " #cond); } while (0)
+
+using namespace open_spiel;
+using namespace open_spiel::algorithms;
+using osgo_adapt::CounterRng;
+using osgo_adapt::Fatal;
+
+namespace {
+void WriteTensor(const State& s, int which, int p, float* out, int n) {
+  if (which == 0) s.ObservationTensor(p, absl::MakeSpan(out, n));
+  else s.InformationStateTensor(p, absl::MakeSpan(out, n));
+}
+std::string ParamsString(const Game& game) { return GameParametersToString(game.GetParameters()); }
+bool HasChance(const Game& game) { return game.GetType().chance_mode != GameType::ChanceMode::kDeterministic; }
+// The reference raises for tensors a game does not provide (spiel.h:1085-1090); the restatement reports size 0.
+int InfoSize(const Game& game) { return game.GetType().provides_information_state_tensor ? game.InformationStateTensorSize() : 0; }
+std::vector<int> InfoShape(const Game& game) { return game.GetType().provides_information_state_tensor ? game.InformationStateTensorShape() : std::vector<int>{}; }
+// cfr.cc:104-125 (CFRAveragePolicy::GetStatePolicyFromInformationStateValues is private).
+ActionsAndProbs AverageFromValues(const CFRInfoStateValues& v) {
+  std::unordered_map<std::string, CFRInfoStateValues> one{{"k", v}};
+  CFRAveragePolicy pol(one, nullptr);
+  return pol.GetStatePolicy(std::string("k"));
+}
+TabularPolicy KuhnOptimal(double alpha) { return kuhn_poker::GetOptimalPolicy(alpha); }
+void SetRow(TabularPolicy* pol, const std::string& key, const ActionsAndProbs& ap) { pol->SetStatePolicy(key, ap); }
+std::vector<double> ExpReturns(const State& s, const Policy& pol) { return ExpectedReturns(s, pol, -1); }
+}  // namespace
+#else
 #include "spiel_oracle.h"
 
 using namespace osg_oracle;
+
+namespace {
+void WriteTensor(const State& s, int which, int p, float* out, int n) {
+  if (which == 0) s.ObservationTensor(p, out, n);
+  else s.InformationStateTensor(p, out, n);
+}
+std::string ParamsString(const Game& game) { return game.ParametersString(); }
+bool HasChance(const Game& game) { return game.HasChance(); }
+int InfoSize(const Game& game) { return game.InformationStateTensorSize(); }
+std::vector<int> InfoShape(const Game& game) { return game.InformationStateTensorShape(); }
+ActionsAndProbs AverageFromValues(const CFRInfoStateValues& v) { return CFRAveragePolicy::FromValues(v); }
+TabularPolicy KuhnOptimal(double alpha) { return KuhnOptimalPolicy(alpha); }
+void SetRow(TabularPolicy* pol, const std::string& key, const ActionsAndProbs& ap) { pol->Table()[key] = ap; }
+std::vector<double> ExpReturns(const State& s, const Policy& pol) { return ExpectedReturns(s, pol); }
+}  // namespace
+#endif
 
 namespace {
 thread_local std::string g_err;
@@ -75,23 +172,23 @@ int osgo_game_info(void* g, double* out) {
     out[1] = game.MaxChanceOutcomes();
     out[2] = game.NumPlayers();
     out[3] = game.ObservationTensorSize();
-    out[4] = game.InformationStateTensorSize();
+    out[4] = InfoSize(game);
     out[5] = game.MaxGameLength();
     out[6] = game.MaxChanceNodesInHistory();
     out[7] = game.MinUtility();
     out[8] = game.MaxUtility();
-    out[9] = game.HasChance() ? 1 : 0;
+    out[9] = HasChance(game) ? 1 : 0;
     return 0;
   });
 }
 int osgo_game_string(void* g, int which, char* buf, int cap) {
   const Game& game = *static_cast<GameH*>(g)->game;
-  return CopyStr(which == 0 ? game.ToString() : game.ParametersString(), buf, cap);
+  return CopyStr(which == 0 ? game.ToString() : ParamsString(game), buf, cap);
 }
 int osgo_game_shape(void* g, int which, int* out, int cap) {
   const Game& game = *static_cast<GameH*>(g)->game;
   std::vector<int> s = which == 0 ? game.ObservationTensorShape()
-                                  : game.InformationStateTensorShape();
+                                  : InfoShape(game);
   for (int i = 0; i < static_cast<int>(s.size()) && i < cap; ++i) out[i] = s[i];
   return static_cast<int>(s.size());
 }
@@ -207,7 +304,7 @@ int osgo_random_playouts(void* g, uint64_t seed, int64_t n, int L, int W,
     const Game& game = *static_cast<GameH*>(g)->game;
     const int P = game.NumPlayers();
     const int osz = game.ObservationTensorSize();
-    const int isz = game.InformationStateTensorSize();
+    const int isz = InfoSize(game);
     int longest = 0;
     for (int64_t i = 0; i < n; ++i) {
       CounterRng rng(seed, static_cast<uint64_t>(i));
@@ -223,11 +320,9 @@ int osgo_random_playouts(void* g, uint64_t seed, int64_t n, int L, int W,
         std::vector<double> r = s->Returns();
         for (int p = 0; p < P; ++p) rets[row * P + p] = r[p];
         if (obs)
-          for (int p = 0; p < P; ++p)
-            s->ObservationTensor(p, obs + (row * P + p) * osz, osz);
+          for (int p = 0; p < P; ++p) WriteTensor(*s, 0, p, obs + (row * P + p) * osz, osz);
         if (info && isz > 0)
-          for (int p = 0; p < P; ++p)
-            s->InformationStateTensor(p, info + (row * P + p) * isz, isz);
+          for (int p = 0; p < P; ++p) WriteTensor(*s, 1, p, info + (row * P + p) * isz, isz);
         if (t == L) break;
         if (s->IsTerminal() || t >= limit) {
           acts[i * L + t] = -1;
@@ -301,9 +396,14 @@ int osgo_mcts_search(void* s, double uct_c, int max_simulations, int n_rollouts,
     auto ev = std::make_shared<RandomRolloutEvaluator>(n_rollouts, seed);
     MCTSBot bot(*st.GetGame(), ev, uct_c, max_simulations, max_memory_mb,
                 solve != 0, seed, false, puct ? ChildSelectionPolicy::PUCT : ChildSelectionPolicy::UCT);
+#ifdef OSGO_GENUINE_REFERENCE
+    if (counter_root >= 0) Fatal("counter-stream replay is a hook of the restatement, not of the reference");
+    (void)counter_seed; (void)counter_layout;
+#else
     if (counter_root >= 0)
       bot.UseCounterStreams(counter_seed, static_cast<uint64_t>(counter_root), n_rollouts,
                             counter_layout);
+#endif
     std::unique_ptr<SearchNode> root = bot.MCTSearch(st);
     const double nan = std::numeric_limits<double>::quiet_NaN();
     *best_action = root->children.empty() ? -1 : root->BestChild().action;
@@ -389,6 +489,11 @@ int osgo_cfr_iterate(void* h, int iters) {
 // increments (external_sampling_mccfr.cc:167-183) are summed and folded in at
 // the end.  With count == 1 this is exactly one UpdateRegrets call.
 int osgo_mccfr_minibatch(void* h, uint64_t seed, int64_t first, int64_t count) {
+#ifdef OSGO_GENUINE_REFERENCE
+  (void)h; (void)seed; (void)first; (void)count;
+  g_err = "mini-batch MCCFR replay is a hook of the restatement, not of the reference";
+  return -1;
+#else
   return Guard([&] {
     auto* c = static_cast<CfrH*>(h);
     ORACLE_CHECK(c->mccfr || c->osmccfr);
@@ -443,6 +548,7 @@ int osgo_mccfr_minibatch(void* h, uint64_t seed, int64_t first, int64_t count) {
     }
     return 0;
   });
+#endif
 }
 int osgo_cfr_num_infostates(void* h) {
   return static_cast<int>(static_cast<CfrH*>(h)->Table().size());
@@ -465,7 +571,7 @@ int osgo_cfr_tables(void* h, int amax, char* keys, int keys_cap, int* nact,
     CopyStr(joined, keys, keys_cap);
     for (size_t i = 0; i < ks.size(); ++i) {
       const CFRInfoStateValues& v = table.at(ks[i]);
-      ActionsAndProbs avg = CFRAveragePolicy::FromValues(v);
+      ActionsAndProbs avg = AverageFromValues(v);
       nact[i] = v.num_actions();
       for (int a = 0; a < amax; ++a) {
         bool in = a < v.num_actions();
@@ -499,7 +605,7 @@ int osgo_cfr_expected_returns(void* h, double* out) {
   return Guard([&] {
     auto* c = static_cast<CfrH*>(h);
     std::shared_ptr<Policy> pol = c->Average();
-    std::vector<double> v = ExpectedReturns(*c->game->NewInitialState(), *pol);
+    std::vector<double> v = ExpReturns(*c->game->NewInitialState(), *pol);
     for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
     return 0;
   });
@@ -524,14 +630,14 @@ int osgo_eval_policy(void* g, const char* keys, int amax, const int* nact,
       ActionsAndProbs ap;
       for (int a = 0; a < nact[row]; ++a)
         ap.push_back({actions[row * amax + a], probs[row * amax + a]});
-      pol.Table()[key] = ap;
+      SetRow(&pol, key, ap);
       ++row;
       pos = nl + 1;
       if (nl == all.size()) break;
     }
     *out = which == 1 ? Exploitability(game, pol) : NashConv(game, pol);
     if (ev) {
-      std::vector<double> v = ExpectedReturns(*game.NewInitialState(), pol);
+      std::vector<double> v = ExpReturns(*game.NewInitialState(), pol);
       for (size_t i = 0; i < v.size(); ++i) ev[i] = v[i];
     }
     return 0;
@@ -544,7 +650,7 @@ int osgo_eval_named_policy(void* g, int which_policy, double alpha, int which,
     const Game& game = *static_cast<GameH*>(g)->game;
     TabularPolicy pol = which_policy == 0   ? GetUniformPolicy(game)
                         : which_policy == 1 ? GetFirstActionPolicy(game)
-                                            : KuhnOptimalPolicy(alpha);
+                                            : KuhnOptimal(alpha);
     *out = which == 1 ? Exploitability(game, pol) : NashConv(game, pol);
     return 0;
   });

@@ -85,7 +85,7 @@ ActionsAndProbs AverageFromValues(const CFRInfoStateValues& v) {
 }
 TabularPolicy KuhnOptimal(double alpha) { return kuhn_poker::GetOptimalPolicy(alpha); }
 void SetRow(TabularPolicy* pol, const std::string& key, const ActionsAndProbs& ap) { pol->SetStatePolicy(key, ap); }
-std::vector<double> ExpReturns(const State& s, const Policy& pol) { return ExpectedReturns(s, pol, -1); }
+std::vector<double> ExpReturns(const State& s, const Policy& pol) { return ExpectedReturns(s, pol, -1, /*use_infostate_get_policy=*/false); }
 }  // namespace
 #else
 #include "spiel_oracle.h"
@@ -596,7 +596,19 @@ int osgo_cfr_eval(void* h, int which, double* out) {
     } else {
       pol = c->Average();
     }
+#ifdef OSGO_GENUINE_REFERENCE
+    // The sampling solvers' average policy falls back to UniformPolicy for infostates the table
+    // has not seen, which only answers GetStatePolicy(state): hence use_state_get_policy = true,
+    // as in external_sampling_mccfr_test.cc:41.
+    if (c->cfr) {
+      *out = which == 1 ? Exploitability(*c->game, *pol) : NashConv(*c->game, *pol);
+    } else {
+      const double nc = NashConv(*c->game, *pol, /*use_state_get_policy=*/true);
+      *out = which == 1 ? nc / c->game->NumPlayers() : nc;
+    }
+#else
     *out = which == 1 ? Exploitability(*c->game, *pol) : NashConv(*c->game, *pol);
+#endif
     return 0;
   });
 }

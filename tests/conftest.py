@@ -22,6 +22,20 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def reference():
+    """The GENUINE reference build (oracle/_ref/libspiel_ref.so: the reference's own .cc files
+    compiled by oracle/Makefile.ref), bound to the same calls as the oracle.  Built here when
+    /root/reference is present; otherwise the prebuilt library is used, and tests that need it
+    are skipped when neither exists."""
+    import reference_py
+    if reference_py.sources_present():
+        reference_py.build()
+    if not reference_py.available():
+        pytest.skip("oracle/_ref/libspiel_ref.so not built (needs the reference sources)")
+    return reference_py
+
+
+@pytest.fixture(scope="session")
 def goldens():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "playthroughs.json"), encoding="utf-8") as f:

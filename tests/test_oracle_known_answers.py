@@ -2,11 +2,25 @@
 
 Every constant below is quoted from a test in /root/reference/open_spiel (cited
 per test); nothing here reads the reference at run time.
+
+Every test runs twice: on the restatement (oracle/liboracle.so) and on the
+GENUINE reference build (oracle/_ref/libspiel_ref.so, the reference's own .cc
+files compiled by oracle/Makefile.ref) — the second run checks the build recipe
+and its abseil / nlohmann stand-ins against the reference's own expectations.
 """
 import math
 
 import numpy as np
 import pytest
+
+
+@pytest.fixture(scope="module", params=["restatement", "genuine_reference"])
+def oracle(request):
+    if request.param == "restatement":
+        import oracle_py
+        oracle_py.build()
+        return oracle_py
+    return request.getfixturevalue("reference")
 
 
 def _play(game, actions):

@@ -1,0 +1,182 @@
+"""The restatement (oracle/liboracle.so) against the GENUINE reference build
+(oracle/_ref/libspiel_ref.so), call for call.
+
+oracle/_ref is the reference's own .cc files for the hot path compiled unmodified
+from /root/reference by oracle/Makefile.ref; both libraries export the same
+extern "C" driver (oracle/spiel_oracle_capi.cpp), so every deterministic result
+the GPU tests take from the oracle is checked here against the real
+implementation: bit for bit for legal sets, players, terminal flags, returns,
+tensors and strings, and bit for bit for the fp64 CFR tables and judge values
+too (same additions in the same order).  Not compared: anything that depends on
+abseil's / libstdc++'s random streams (MCTS visit counts, sampled MCCFR tables)
+— those are pinned at outcome level by tests/test_oracle_known_answers.py,
+which runs on both builds.
+
+Skipped when the library is not built (it needs /root/reference at build time;
+the built file travels with the repo snapshot).
+"""
+import numpy as np
+import pytest
+
+GAME_CONFIGS = [
+    ("tic_tac_toe", 400),
+    ("connect_four", 300),
+    ("connect_four(rows=5,columns=6,x_in_row=3)", 300),
+    ("connect_four(egocentric_obs_tensor=True)", 200),
+    ("hex(board_size=9)", 60),
+    ("hex", 30),
+    ("hex(board_size=5,swap=True)", 300),
+    ("hex(num_rows=3,num_cols=4)", 300),
+    ("hex(board_size=4,plain_obs_tensor=True)", 200),
+    ("kuhn_poker", 400),
+    ("kuhn_poker(players=3)", 400),
+    ("kuhn_poker(players=4)", 300),
+    ("leduc_poker", 400),
+    ("leduc_poker(players=3)", 300),
+    ("leduc_poker(suit_isomorphism=True)", 300),
+]
+
+
+def _pair(oracle, reference, game_string):
+    try:
+        rg = reference.Game(game_string)
+    except reference.OracleError as e:  # a parameter this reference version does not know
+        pytest.skip(f"reference rejects {game_string}: {e}")
+    return oracle.Game(game_string), rg
+
+
+@pytest.mark.parametrize("game_string,n", GAME_CONFIGS)
+def test_game_description_matches(oracle, reference, game_string, n):
+    og, rg = _pair(oracle, reference, game_string)
+    for attr in ("num_distinct_actions", "max_chance_outcomes", "num_players",
+                 "observation_tensor_size", "information_state_tensor_size", "max_game_length",
+                 "max_chance_nodes_in_history", "min_utility", "max_utility", "has_chance"):
+        assert getattr(og, attr) == getattr(rg, attr), attr
+    assert str(og) == str(rg)
+    assert og.observation_tensor_shape() == rg.observation_tensor_shape()
+    assert og.information_state_tensor_shape() == rg.information_state_tensor_shape()
+
+
+@pytest.mark.parametrize("game_string,n", GAME_CONFIGS)
+def test_seeded_playouts_are_bit_identical(oracle, reference, game_string, n):
+    """Same seeded playouts through both implementations; every per-ply record equal:
+    LegalActions (chance outcomes at chance nodes), CurrentPlayer, IsTerminal, Returns,
+    ObservationTensor and InformationStateTensor of every player."""
+    og, rg = _pair(oracle, reference, game_string)
+    a = og.random_playouts(0xC0FFEE, n, want_obs=True, want_info=True)
+    b = rg.random_playouts(0xC0FFEE, n, want_obs=True, want_info=True)
+    assert a["longest"] == b["longest"] > 0
+    for k in ("actions", "mask", "cur_player", "terminal", "returns", "obs", "info"):
+        if a[k] is None:
+            assert b[k] is None
+            continue
+        assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("game_string,n", GAME_CONFIGS)
+def test_strings_and_offturn_queries_match_along_playouts(oracle, reference, game_string, n):
+    """ToString / HistoryString / InformationStateString / ObservationString / ActionToString,
+    ChanceOutcomes and LegalActions(player) for every player, at every state of seeded playouts."""
+    og, rg = _pair(oracle, reference, game_string)
+    count = max(4, min(25, n // 12))
+    rec = og.random_playouts(0x51A7E, count)
+    has_info = og.information_state_tensor_size > 0 or "poker" in game_string
+    for i in range(count):
+        so, sr = og.new_initial_state(), rg.new_initial_state()
+        for t in range(rec["actions"].shape[1] + 1):
+            assert str(so) == str(sr)
+            assert so.history_str() == sr.history_str()
+            assert so.history() == sr.history()
+            assert so.current_player() == sr.current_player()
+            assert so.is_terminal() == sr.is_terminal()
+            assert so.returns() == sr.returns()
+            for p in range(og.num_players):
+                assert so.observation_string(p) == sr.observation_string(p)
+                if has_info:
+                    assert so.information_state_string(p) == sr.information_state_string(p)
+                if not so.is_terminal():
+                    assert so.legal_actions(p) == sr.legal_actions(p)
+            if so.is_terminal():
+                break
+            if so.is_chance_node():
+                assert so.chance_outcomes() == sr.chance_outcomes()
+            legal = so.legal_actions()
+            assert legal == sr.legal_actions()
+            cp = so.current_player()
+            for a in legal:
+                assert so.action_to_string(cp, a) == sr.action_to_string(cp, a)
+            a = int(rec["actions"][i, t]) if t < rec["actions"].shape[1] else -1
+            if a < 0:
+                break
+            so.apply_action(a)
+            sr.apply_action(a)
+
+
+@pytest.mark.parametrize("game_string", ["kuhn_poker", "leduc_poker", "kuhn_poker(players=3)"])
+def test_tree_census_matches(oracle, reference, game_string):
+    og, rg = _pair(oracle, reference, game_string)
+    assert og.tree_census() == rg.tree_census()
+
+
+@pytest.mark.parametrize("game_string,kind,iters", [
+    ("kuhn_poker", "cfr", 300),
+    ("kuhn_poker", "cfr_plus", 200),
+    ("kuhn_poker", "cfr_simultaneous", 60),
+    ("kuhn_poker(players=3)", "cfr", 40),
+    ("kuhn_poker(players=3)", "cfr_plus", 25),
+    ("leduc_poker", "cfr", 12),
+    ("leduc_poker", "cfr_plus", 12),
+    ("leduc_poker", "cfr_simultaneous", 6),
+])
+def test_cfr_tables_are_bit_identical(oracle, reference, game_string, kind, iters):
+    """CFRSolver / CFRPlusSolver / CFRSolverBase(simultaneous): cumulative regrets, cumulative
+    policy, current policy and the normalised average policy after `iters` iterations, checked
+    at several points on the way — equal to the last bit (cfr.cc:331-408 adds in DFS order;
+    the restatement adds in the same order), and so are NashConv / exploitability / expected
+    returns of the average policy."""
+    og, rg = _pair(oracle, reference, game_string)
+    so, sr = oracle.Solver(og, kind), reference.Solver(rg, kind)
+    done = 0
+    for stop in sorted({1, 2, iters // 2, iters}):
+        so.iterate(stop - done)
+        sr.iterate(stop - done)
+        done = stop
+        a, b = so.tables(), sr.tables()
+        assert a["keys"] == b["keys"]
+        for k in ("nact", "legal", "regrets", "cum_policy", "cur_policy", "avg_policy"):
+            assert np.array_equal(a[k], b[k]), (k, stop)
+    assert so.nash_conv() == sr.nash_conv()
+    assert so.exploitability() == sr.exploitability()
+    assert np.array_equal(so.expected_returns(), sr.expected_returns())
+
+
+@pytest.mark.parametrize("game_string", ["kuhn_poker", "leduc_poker", "kuhn_poker(players=3)"])
+def test_judge_of_named_and_supplied_policies_matches(oracle, reference, game_string):
+    """tabular_exploitability.cc / best_response.cc / expected_returns.cc on the uniform and the
+    first-action policy, the Kuhn optimal family, and a supplied table (a CFR average policy)."""
+    og, rg = _pair(oracle, reference, game_string)
+    for which_policy in (0, 1):
+        for which in (0, 1):
+            assert og.eval_named_policy(which_policy, which) == rg.eval_named_policy(which_policy, which)
+    if game_string == "kuhn_poker":
+        for alpha in (0.0, 0.1, 0.25, 1.0 / 3.0):
+            assert og.eval_named_policy(2, 0, alpha) == rg.eval_named_policy(2, 0, alpha)
+    so = oracle.Solver(og, "cfr")
+    so.iterate(8)
+    t = so.tables()
+    for which in (0, 1):
+        vo, evo = og.eval_policy(t["keys"], t["nact"], t["legal"], t["avg_policy"], which)
+        vr, evr = rg.eval_policy(t["keys"], t["nact"], t["legal"], t["avg_policy"], which)
+        assert vo == vr
+        assert np.array_equal(evo, evr)
+
+
+def test_replay_hooks_are_restatement_only(reference):
+    """The genuine build has no counter-stream hooks: asking for them is an error, not a silent
+    fallback (so a parity test can never believe it replayed a device search on the reference)."""
+    g = reference.Game("tic_tac_toe")
+    with pytest.raises(reference.OracleError):
+        g.new_initial_state().mcts_search(2.0, 10, 1, 5, False, 1, counter_root=0, counter_seed=1)
+    s = reference.Solver(reference.Game("kuhn_poker"), "mccfr_simple", 1)
+    with pytest.raises(reference.OracleError):
+        s.mccfr_minibatch(1, 0, 4)

@@ -965,19 +965,37 @@ class BitGen {
   std::mt19937_64 e_;
 };
 using InsecureBitGen = BitGen;
+namespace shim_internal {
+// One engine output -> a double in [0, 1): 53 bits from a 64-bit engine, 27 bits from a 32-bit
+// one (std::mt19937).  The 27-bit convention is the restatement's (spiel_oracle_algos.cpp), chosen
+// so that MCTSBot searches of the two builds can be compared node for node; abseil's own
+// conversion is different and, like its streams, pinned by no reference test.
+template <class URBG>
+double UnitFrom(URBG& g) {
+  constexpr auto kRange = static_cast<uint64_t>(URBG::max()) - static_cast<uint64_t>(URBG::min());
+  if constexpr (kRange == ~uint64_t(0)) {
+    return static_cast<double>(static_cast<uint64_t>(g() - URBG::min()) >> 11) * (1.0 / 9007199254740992.0);
+  } else if constexpr (kRange == 0xFFFFFFFFULL) {
+    return static_cast<double>(static_cast<uint32_t>(g() - URBG::min()) >> 5) * (1.0 / 134217728.0);
+  } else {
+    return std::generate_canonical<double, 53>(g);
+  }
+}
+}  // namespace shim_internal
 class BitGenRef {
  public:
   using result_type = uint64_t;
   template <class URBG, class = std::enable_if_t<!std::is_same_v<std::decay_t<URBG>, BitGenRef>>>
-  BitGenRef(URBG& g) : p_(&g), call_(&Call<URBG>) {}  // NOLINT: implicit, as in the library
+  BitGenRef(URBG& g) : p_(&g), call_(&Call<URBG>), unit_(&Unit<URBG>) {}  // NOLINT: implicit, as in the library
   static constexpr result_type min() { return 0; }
   static constexpr result_type max() { return ~result_type(0); }
   result_type operator()() { return call_(p_); }
+  double UnitDraw() { return unit_(p_); }
  private:
   template <class URBG>
   static uint64_t Call(void* p) {
     URBG& g = *static_cast<URBG*>(p);
-    if constexpr (URBG::max() - URBG::min() >= ~uint64_t(0)) {
+    if constexpr (static_cast<uint64_t>(URBG::max()) - static_cast<uint64_t>(URBG::min()) == ~uint64_t(0)) {
       return static_cast<uint64_t>(g() - URBG::min());
     } else {
       uint64_t hi = static_cast<uint64_t>(g() - URBG::min());
@@ -985,9 +1003,15 @@ class BitGenRef {
       return (hi << 32) ^ lo;
     }
   }
+  template <class URBG>
+  static double Unit(void* p) { return shim_internal::UnitFrom(*static_cast<URBG*>(p)); }
   void* p_;
   uint64_t (*call_)(void*);
+  double (*unit_)(void*);
 };
+namespace shim_internal {
+inline double UnitFromRef(BitGenRef& g) { return g.UnitDraw(); }
+}  // namespace shim_internal
 template <class T = int>
 using uniform_int_distribution = std::uniform_int_distribution<T>;
 template <class T = double>
@@ -1009,7 +1033,10 @@ template <class R = void, class URBG, class A, class B>
 shim_internal::UniformResult<R, A, B> Uniform(URBG&& gen, A lo, B hi) {
   using T = shim_internal::UniformResult<R, A, B>;
   if constexpr (std::is_floating_point_v<T>) {
-    return std::uniform_real_distribution<T>(static_cast<T>(lo), static_cast<T>(hi))(gen);
+    double u;
+    if constexpr (std::is_same_v<std::decay_t<URBG>, BitGenRef>) u = gen.UnitDraw();
+    else u = shim_internal::UnitFrom(gen);
+    return static_cast<T>(static_cast<T>(lo) + (static_cast<T>(hi) - static_cast<T>(lo)) * static_cast<T>(u));
   } else {
     T l = static_cast<T>(lo), h = static_cast<T>(hi);
     if (!(l < h)) return l;

@@ -180,3 +180,76 @@ def test_replay_hooks_are_restatement_only(reference):
     s = reference.Solver(reference.Game("kuhn_poker"), "mccfr_simple", 1)
     with pytest.raises(reference.OracleError):
         s.mccfr_minibatch(1, 0, 4)
+
+
+@pytest.mark.parametrize("game_string,kind,iters,seed", [
+    ("kuhn_poker", "mccfr_simple", 500, 7),
+    ("leduc_poker", "mccfr_simple", 300, 3),
+    ("kuhn_poker(players=3)", "mccfr_simple", 200, 11),
+    ("kuhn_poker(players=3)", "mccfr_full", 300, 39693847),
+    ("leduc_poker", "mccfr_full", 100, 1),
+    ("kuhn_poker", "mccfr_outcome", 500, 5),
+    ("leduc_poker", "mccfr_outcome", 300, 5),
+])
+def test_sampled_mccfr_tables_are_bit_identical(oracle, reference, game_string, kind, iters, seed):
+    """ExternalSamplingMCCFRSolver draws from std::mt19937 + std::uniform_real_distribution
+    (external_sampling_mccfr.h:110-111) — libstdc++ on both sides, no abseil — so its whole table is
+    reproducible: same infostates discovered, same regrets / average policy to the last bit after
+    hundreds of iterations.  OutcomeSamplingMCCFRSolver uses absl's distributions (std's in the
+    stand-in): equality there checks the traversal logic, not abseil's stream."""
+    og, rg = _pair(oracle, reference, game_string)
+    so, sr = oracle.Solver(og, kind, seed), reference.Solver(rg, kind, seed)
+    done = 0
+    for stop in (1, iters // 3, iters):
+        so.iterate(stop - done)
+        sr.iterate(stop - done)
+        done = stop
+        a, b = so.tables(), sr.tables()
+        assert a["keys"] == b["keys"]
+        for k in ("nact", "legal", "regrets", "cum_policy", "cur_policy", "avg_policy"):
+            assert np.array_equal(a[k], b[k]), (k, stop)
+    assert so.nash_conv() == sr.nash_conv()
+
+
+@pytest.mark.parametrize("game_string,depth", [
+    ("tic_tac_toe", 0), ("tic_tac_toe", 3), ("tic_tac_toe", 5),
+    ("connect_four", 0), ("connect_four", 9),
+    ("hex(board_size=5)", 0), ("hex(board_size=5)", 6), ("hex(board_size=4,swap=True)", 1),
+    ("kuhn_poker", 2), ("kuhn_poker", 3), ("leduc_poker", 2), ("leduc_poker", 4),
+    ("kuhn_poker(players=3)", 3),
+])
+@pytest.mark.parametrize("solve", [False, True])
+def test_mcts_search_trees_are_identical(oracle, reference, game_string, depth, solve):
+    """MCTSBot::MCTSearch (mcts.cc:273-467) with RandomRolloutEvaluator: the root's children —
+    action order after the shuffle, visit counts, total rewards, proven outcomes — and the chosen
+    action, for UCT and PUCT.  Both builds draw from std::mt19937 through the same conventions
+    (the stand-in's absl::Uniform; see oracle/ref_shim), so select / expand / rollout / backup /
+    MCTS-Solver are compared decision for decision."""
+    og, rg = _pair(oracle, reference, game_string)
+    rec = og.random_playouts(0xBEEF + depth, 3, stop=[depth] * 3)
+    for i in range(3):
+        so, sr = og.new_initial_state(), rg.new_initial_state()
+        for t in range(depth):
+            a = int(rec["actions"][i, t])
+            if a < 0:
+                break
+            so.apply_action(a)
+            sr.apply_action(a)
+        if so.is_terminal() or so.is_chance_node():  # a bot is never asked to move at a chance node
+            continue
+        for puct in (False, True):
+            for sims, n_rollouts in ((60, 1), (250, 3)):
+                a = so.mcts_search(2.0, sims, n_rollouts, 100, solve, 42 + i, puct=puct)
+                b = sr.mcts_search(2.0, sims, n_rollouts, 100, solve, 42 + i, puct=puct)
+                assert a["best_action"] == b["best_action"]
+                assert a["root_visits"] == b["root_visits"]
+                assert np.array_equal(a["root_outcome"], b["root_outcome"], equal_nan=True)
+                assert np.array_equal(a["children"], b["children"], equal_nan=True)
+
+
+def test_mcts_selfplay_is_identical(oracle, reference):
+    """Two MCTS bots playing each other (mcts_test.cc:45-77): same game, move for move."""
+    for game_string in ("tic_tac_toe", "kuhn_poker", "leduc_poker"):
+        og, rg = _pair(oracle, reference, game_string)
+        for seed in (1, 2, 3):
+            assert np.array_equal(og.mcts_selfplay(2.0, 100, 5, seed), rg.mcts_selfplay(2.0, 100, 5, seed))

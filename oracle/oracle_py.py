@@ -33,7 +33,8 @@ def lib():
             build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.osgo_last_error.restype = C.c_char_p
-        for name in ("osgo_load_game", "osgo_new_state", "osgo_clone_state", "osgo_cfr_create"):
+        for name in ("osgo_load_game", "osgo_new_state", "osgo_clone_state", "osgo_cfr_create",
+                     "osgo_cfr_deserialize"):
             getattr(_lib, name).restype = C.c_void_p
     return _lib
 
@@ -324,6 +325,25 @@ class Solver:
 
     def iterate(self, iters=1):
         _check(lib().osgo_cfr_iterate(self._h, iters))
+
+    def serialize(self, double_precision=-1):
+        """CFRSolverBase::Serialize (genuine reference build only)."""
+        n = _check(lib().osgo_cfr_serialize(self._h, double_precision, None, 0))
+        buf = C.create_string_buffer(n + 1)
+        _check(lib().osgo_cfr_serialize(self._h, double_precision, buf, n + 1))
+        return buf.value.decode()
+
+    @classmethod
+    def deserialize(cls, game, text, kind="cfr"):
+        """DeserializeCFRSolver / DeserializeCFRPlusSolver (genuine reference build only).
+        `game` must be the binding's Game for the checkpoint's game (used for sizes only)."""
+        h = lib().osgo_cfr_deserialize(text.encode(), SOLVER_KINDS[kind])
+        if not h:
+            raise OracleError(lib().osgo_last_error().decode())
+        self = cls.__new__(cls)
+        self.game = game
+        self._h = C.c_void_p(h)
+        return self
 
     def mccfr_minibatch(self, seed, first, count):
         """The device's mini-batch ES-MCCFR schedule on the oracle (frozen table per call)."""

@@ -550,6 +550,43 @@ int osgo_mccfr_minibatch(void* h, uint64_t seed, int64_t first, int64_t count) {
   });
 #endif
 }
+// The reference's text checkpoint (cfr.cc:284-307 CFRSolverBase::Serialize; DeserializeCFRSolver /
+// DeserializeCFRPlusSolver cfr.cc:699-723).  Genuine build only: the restatement does not restate the
+// wire format (the product's host mirror does, open_spiel_amd/csrc/host/osg_spiel.h; these two entry
+// points let the tests load its checkpoints into the real reference and vice versa).
+int osgo_cfr_serialize(void* h, int double_precision, char* buf, int cap) {
+#ifdef OSGO_GENUINE_REFERENCE
+  return Guard([&] {
+    auto* c = static_cast<CfrH*>(h);
+    ORACLE_CHECK(c->cfr);
+    return CopyStr(c->cfr->Serialize(double_precision), buf, cap);
+  });
+#else
+  (void)h; (void)double_precision; (void)buf; (void)cap;
+  g_err = "the checkpoint format is only available from the genuine reference build";
+  return -1;
+#endif
+}
+// kind: 0 CFRSolver, 1 CFRPlusSolver.
+void* osgo_cfr_deserialize(const char* text, int kind) {
+#ifdef OSGO_GENUINE_REFERENCE
+  try {
+    auto* h = new CfrH;
+    const std::string serialized(text);
+    h->game = PartiallyDeserializeCFRSolver(serialized).game;
+    if (kind == 0) h->cfr = DeserializeCFRSolver(serialized);
+    else h->cfr = DeserializeCFRPlusSolver(serialized);
+    return h;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+#else
+  (void)text; (void)kind;
+  g_err = "the checkpoint format is only available from the genuine reference build";
+  return nullptr;
+#endif
+}
 int osgo_cfr_num_infostates(void* h) {
   return static_cast<int>(static_cast<CfrH*>(h)->Table().size());
 }

@@ -23,6 +23,8 @@ Output: tests/golden/reference_vectors.npz (compressed; < 1 MB).  Contents, per 
                     cur_policy, avg_policy (fp64, exact), nash_conv, exploitability, expected_returns
   mccfr/<game>/<kind>/<seed>/<iters>/...   ExternalSamplingMCCFRSolver tables (std::mt19937 +
                     std::uniform_real_distribution: libstdc++ streams, reproducible)
+  ckpt/<game>/<kind>/<iters>/text[6]   CFRSolverBase::Serialize() of the solver at that checkpoint
+                    (cfr.cc:284-307; lossless hex floats, and 6 decimals)
   judge/<game>/...  NashConv / exploitability of the uniform and first-action policies
   census/<game>     (chance, decision, terminal, infostates)
 
@@ -45,8 +47,8 @@ PLAYOUTS = [  # game, seed, n
     ("leduc_poker", 0x601D, 64),
 ]
 CFR = [  # game, kind, checkpoints
-    ("kuhn_poker", "cfr", [1, 10, 100]),
-    ("kuhn_poker", "cfr_plus", [50]),
+    ("kuhn_poker", "cfr", [1, 10, 15, 100]),
+    ("kuhn_poker", "cfr_plus", [7, 50]),
     ("kuhn_poker", "cfr_simultaneous", [2, 20]),
     ("leduc_poker", "cfr", [1, 5]),
     ("leduc_poker", "cfr_plus", [3]),
@@ -55,6 +57,7 @@ MCCFR = [  # game, kind, seed, iters
     ("kuhn_poker", "mccfr_simple", 7, 200),
     ("leduc_poker", "mccfr_simple", 3, 60),
 ]
+CHECKPOINTS = [("kuhn_poker", "cfr", 10), ("kuhn_poker", "cfr_plus", 7), ("leduc_poker", "cfr", 5)]  # must be CFR checkpoints above
 JUDGE = ["kuhn_poker", "leduc_poker", "kuhn_poker(players=3)"]
 
 
@@ -94,6 +97,9 @@ def main():
             s.iterate(cp - done)
             done = cp
             table_arrays(f"cfr/{game}/{kind}/{cp}/", s, out)
+            if (game, kind, cp) in CHECKPOINTS:  # CFRSolverBase::Serialize, lossless and 6-digit
+                out[f"ckpt/{game}/{kind}/{cp}/text"] = np.frombuffer(s.serialize(-1).encode(), np.uint8)
+                out[f"ckpt/{game}/{kind}/{cp}/text6"] = np.frombuffer(s.serialize(6).encode(), np.uint8)
     for game, kind, seed, iters in MCCFR:
         g = ref.Game(game)
         s = ref.Solver(g, kind, seed)

@@ -309,6 +309,27 @@ int osg_cfr_evaluate_policy(osg_cfr* s, int which_policy, const double* h_policy
  * Returns the length (excluding NUL), or <0. */
 int osg_cfr_infostate_key(const osg_cfr* s, int64_t i, char* buf, int cap);
 
+/* ---- multi-GPU exchange step ---------------------------------------------------
+ * One process per GPU.  Units shard by global index with no data-path collective; the ONE exchange
+ * on the path is external-sampling MCCFR's all-reduce(sum) of the regret / average-policy delta
+ * tables per mini-batch (osg_mccfr_sample -> all-reduce of the 2 * I * Amax doubles starting at
+ * osg_mccfr_delta_ptrs' regret pointer, the two tables being one allocation -> osg_mccfr_apply_deltas),
+ * plus, for root-parallel search on a shared root, the children's visit / reward vectors.  The
+ * reference has no distributed runtime (single-threaded C++); these entry points are what a C++
+ * host of its shape binds instead of torch.distributed.  RCCL is loaded on first use (dlopen), so
+ * single-GPU callers never need it.  The 128-byte id comes from rank 0 (osg_comm_unique_id) and
+ * reaches the other ranks out of band (file, socket, MPI, launcher environment), as with
+ * ncclGetUniqueId / ncclCommInitRank.  Collectives run in place on the context's stream. */
+#define OSG_COMM_ID_BYTES 128
+typedef struct osg_comm osg_comm;
+int osg_comm_unique_id(void* id_out /* OSG_COMM_ID_BYTES */);
+int osg_comm_create(osg_ctx* ctx, int rank, int world, const void* id /* OSG_COMM_ID_BYTES */, osg_comm** out);
+int osg_comm_destroy(osg_comm* c);
+int osg_comm_rank(const osg_comm* c);
+int osg_comm_world(const osg_comm* c);
+int osg_allreduce_sum_f64(osg_comm* c, double* d_buf, int64_t n);
+int osg_allreduce_sum_i32(osg_comm* c, int32_t* d_buf, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,6 +123,13 @@ SIGNATURES = {
     "osg_cfr_tables": (INT, [VP, VP, VP, VP, VP, VP, VP]),
     "osg_cfr_evaluate_policy": (INT, [VP, INT, VP, VP, VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "osg_cfr_infostate_key": (INT, [VP, I64, C.c_char_p, INT]),
+    "osg_comm_unique_id": (INT, [VP]),
+    "osg_comm_create": (INT, [VP, INT, INT, VP, C.POINTER(VP)]),
+    "osg_comm_destroy": (INT, [VP]),
+    "osg_comm_rank": (INT, [VP]),
+    "osg_comm_world": (INT, [VP]),
+    "osg_allreduce_sum_f64": (INT, [VP, VP, I64]),
+    "osg_allreduce_sum_i32": (INT, [VP, VP, I64]),
 }
 
 _lib = None

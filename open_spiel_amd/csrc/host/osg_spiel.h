@@ -19,6 +19,8 @@
 #ifndef OSG_HOST_OSG_SPIEL_H_
 #define OSG_HOST_OSG_SPIEL_H_
 
+#include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -67,6 +69,43 @@ class Context {
  private:
   explicit Context(int device) { Check(osg_ctx_create(device, nullptr, /*own_stream=*/1, &ctx_)); }
   osg_ctx* ctx_ = nullptr;
+};
+
+// Contiguous slice [first, first + count) of `total` units owned by `rank`: the first total % world ranks
+// own one extra unit (open_spiel_amd/distributed.py shard_range).  Every device RNG stream is keyed by
+// the GLOBAL unit index, so results do not depend on the world size.
+inline std::pair<int64_t, int64_t> ShardRange(int64_t total, int rank, int world) {
+  if (world < 1 || rank < 0 || rank >= world) SpielFatalError("ShardRange: bad rank / world");
+  const int64_t base = total / world, extra = total % world;
+  return {rank * base + std::min<int64_t>(rank, extra), base + (rank < extra ? 1 : 0)};
+}
+
+// One RCCL communicator per (process, GPU) for C++ hosts (the Python path uses torch.distributed, which
+// is RCCL as well).  The reference has no distributed runtime; this is the exchange step of SURVEY.md 8e.
+// Rank 0 calls NewId() and hands the 128 bytes to the other ranks out of band.
+class Communicator {
+ public:
+  using Id = std::array<char, OSG_COMM_ID_BYTES>;
+  static Id NewId() {
+    Id id{};
+    Check(osg_comm_unique_id(id.data()));
+    return id;
+  }
+  Communicator(int rank, int world, const Id& id, int device = 0) {
+    Check(osg_comm_create(Context::Default(device), rank, world, id.data(), &c_));
+  }
+  ~Communicator() { osg_comm_destroy(c_); }
+  Communicator(const Communicator&) = delete;
+  Communicator& operator=(const Communicator&) = delete;
+  int rank() const { return osg_comm_rank(c_); }
+  int world() const { return osg_comm_world(c_); }
+  std::pair<int64_t, int64_t> Shard(int64_t total) const { return ShardRange(total, rank(), world()); }
+  // In place, on the context's stream (ordered with the kernels before and after it).
+  void AllReduceSum(double* d_buf, int64_t n) { Check(osg_allreduce_sum_f64(c_, d_buf, n)); }
+  void AllReduceSum(int32_t* d_buf, int64_t n) { Check(osg_allreduce_sum_i32(c_, d_buf, n)); }
+
+ private:
+  osg_comm* c_ = nullptr;
 };
 
 class State;
@@ -915,6 +954,27 @@ class ExternalSamplingMCCFRSolver : public DeviceTabularSolver {  // external_sa
     str += std::string(kSerializeSolverDefaultPolicySectionHeader) + "\nUniformPolicy:\n";  // policy.h:330-333
     str += std::string(kSerializeSolverValuesTableSectionHeader) + "\n";
     return str + SerializeValuesTable(InfoStateValuesTable(), double_precision, delimiter);
+  }
+  // The same mini-batch with its trajectories sharded over the ranks of `comm`: each rank samples its
+  // slice of the global index range, ONE all-reduce(sum) of the two adjacent [I, Amax] delta tables over
+  // xGMI, then every rank folds identical deltas in — all ranks end with identical tables, and with the
+  // tables a single GPU would have computed up to fp64 summation order.
+  void RunShardedMiniBatch(int64_t trajectories, Communicator& comm) {
+    const auto [first, count] = comm.Shard(trajectories);
+    Check(osg_mccfr_sample(s_, seed_, next_ + first, count));
+    if (comm.world() > 1) {
+      double *dreg = nullptr, *dpol = nullptr;
+      Check(osg_mccfr_delta_ptrs(s_, &dreg, &dpol));
+      const int64_t n = sizes_[4] * sizes_[5];
+      if (dpol == dreg + n) {
+        comm.AllReduceSum(dreg, 2 * n);
+      } else {
+        comm.AllReduceSum(dreg, n);
+        comm.AllReduceSum(dpol, n);
+      }
+    }
+    Check(osg_mccfr_apply_deltas(s_));
+    next_ += trajectories;
   }
   void RestoreCounter(uint64_t seed, int64_t next) { seed_ = seed; next_ = next; }
   int64_t TrajectoriesRun() const { return next_; }

@@ -118,3 +118,37 @@ def test_mccfr_delta_allreduce_world2_equals_world1(tmp_path):
         assert best == 2                       # most visits wins; action 1 was never visited
     want = (torch.arange(7, dtype=torch.int32) * 10).unsqueeze(1)
     assert torch.equal(r0["gathered"], want) and torch.equal(r1["gathered"], want)
+
+
+def test_cpp_host_shard_range_equals_the_python_one(tmp_path):
+    """open_spiel::hip::ShardRange (csrc/host/osg_spiel.h; what Communicator::Shard and
+    ExternalSamplingMCCFRSolver::RunShardedMiniBatch use) against distributed.shard_range: same slices,
+    covering every total exactly once.  Host-only code: compiled and run here with g++."""
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    from open_spiel_amd.distributed import shard_range
+    src = tmp_path / "shard.cpp"
+    src.write_text(
+        '#include <cstdio>\n#include "open_spiel_amd/csrc/host/osg_spiel.h"\n'
+        "int main() {\n"
+        "  for (long total : {0L, 1L, 7L, 64L, 65536L, 16777216L, 1000003L})\n"
+        "    for (int world : {1, 2, 3, 4, 8})\n"
+        "      for (int rank = 0; rank < world; ++rank) {\n"
+        "        auto r = open_spiel::hip::ShardRange(total, rank, world);\n"
+        '        std::printf("%ld %d %d %ld %ld\\n", total, world, rank, (long)r.first, (long)r.second);\n'
+        "      }\n"
+        "  return 0;\n}\n")
+    exe = tmp_path / "shard"
+    lib_dir = os.path.join(ROOT, "open_spiel_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", ROOT, str(src), "-o", str(exe),
+                           "-L", lib_dir, "-losg_hip", f"-Wl,-rpath,{lib_dir}"])
+    lines = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    seen = 0
+    for line in lines:
+        if not line:
+            continue
+        total, world, rank, first, count = (int(x) for x in line.split())
+        assert shard_range(total, rank, world) == (first, count)
+        seen += 1
+    assert seen == 7 * (1 + 2 + 3 + 4 + 8)

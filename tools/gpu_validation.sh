@@ -1,0 +1,48 @@
+#!/bin/bash
+# The standard GPU validation pass, as ONE gpurun command (what the first GPU call of a session should be):
+#
+#   gpurun --timeout 2400 -- 'bash tools/gpu_validation.sh r02'
+#
+# 1. the GPU test suite (parity vs the oracle, vs the recorded outputs of the genuine reference,
+#    checkpoint interop with oracle/_ref, the world-size-1 collective);
+# 2. bench.py (one JSON line: env-steps/s + roofline + cpu_baseline of the genuine reference build);
+# 3. rocprofv3 --kernel-trace --stats of the same bench command (per-kernel average durations);
+# 4. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) -> tools/pmc_traffic.py.
+# Never combines --pmc with trace domains other than kernel-trace (gpurun refuses that combination).
+# Everything lands under gpurun_out/<tag>/; copy what should be judged into profiles/ and commit it.
+set -u
+TAG=${1:-r00}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+
+echo "== pytest -m gpu" | tee "$OUT/summary.txt"
+timeout 1500 python -m pytest tests -q -m gpu -x --durations=15 > "$OUT/pytest_gpu.log" 2>&1
+echo "pytest exit $?" | tee -a "$OUT/summary.txt"
+tail -5 "$OUT/pytest_gpu.log" | tee -a "$OUT/summary.txt"
+
+echo "== bench.py" | tee -a "$OUT/summary.txt"
+timeout 900 python bench.py > "$OUT/bench_n1.log" 2> "$OUT/bench_n1.err"
+echo "bench exit $?" | tee -a "$OUT/summary.txt"
+tail -c 3000 "$OUT/bench_n1.log" | tee -a "$OUT/summary.txt"
+
+echo "== rocprofv3 --kernel-trace --stats" | tee -a "$OUT/summary.txt"
+timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -- python bench.py --no-cpu-baseline > "$OUT/trace.log" 2>&1
+echo "trace exit $?" | tee -a "$OUT/summary.txt"
+DB=$(find "$OUT/trace" -name '*.db' | head -1)
+if [ -n "$DB" ]; then python tools/rocpd_summary.py "$DB" > "$OUT/kernel_stats.csv" 2>> "$OUT/trace.log"; fi
+find "$OUT/trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_rocprof.csv" \; 2>/dev/null
+head -12 "$OUT/kernel_stats.csv" 2>/dev/null | tee -a "$OUT/summary.txt"
+
+for C in FETCH_SIZE WRITE_SIZE; do
+  echo "== rocprofv3 --pmc $C" | tee -a "$OUT/summary.txt"
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -- \
+    python bench.py --steps 100 --warmup 10 --no-secondary --no-cpu-baseline > "$OUT/pmc_$C.log" 2>&1
+  echo "pmc $C exit $?" | tee -a "$OUT/summary.txt"
+done
+python tools/pmc_traffic.py "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$TAG" > "$OUT/pmc_traffic.log" 2>&1
+tail -12 "$OUT/pmc_traffic.log" | tee -a "$OUT/summary.txt"
+# keep the merged-back directory small (gpurun merges at most 64 MiB)
+find "$OUT" -name '*.db' -size +20M -delete 2>/dev/null
+du -sh "$OUT" | tee -a "$OUT/summary.txt"

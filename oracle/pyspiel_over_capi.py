@@ -94,6 +94,18 @@ class Game:
     def max_game_length(self):
         return self._g.max_game_length
 
+    def observation_tensor_size(self):
+        return self._g.observation_tensor_size
+
+    def information_state_tensor_size(self):
+        return self._g.information_state_tensor_size
+
+    def observation_tensor_shape(self):
+        return self._g.observation_tensor_shape()
+
+    def information_state_tensor_shape(self):
+        return self._g.information_state_tensor_shape()
+
     def min_utility(self):
         return self._g.min_utility
 
@@ -209,4 +221,11 @@ def install(binding):
     # python/algorithms/get_all_states.py imports open_spiel.python.games only for its side effect
     # (registering Python-implemented games, none of which is on this path).
     sys.modules.setdefault("open_spiel.python.games", types.ModuleType("open_spiel.python.games"))
+    # python/rl_environment.py does `from absl import logging` (absl-py is not installed here).
+    if "absl" not in sys.modules:
+        import logging as _logging
+        absl = types.ModuleType("absl")
+        absl.logging = _logging
+        sys.modules["absl"] = absl
+        sys.modules["absl.logging"] = _logging
     return mod

@@ -12,15 +12,23 @@
 // "Reference-shaped" on purpose: virtual State, std::vector return values,
 // Clone() per rollout / tree edge, string-keyed unordered_map CFR tables — the
 // same data-structure shapes as the reference, so timing it is an honest CPU
-// baseline ("kind": "port").
+// baseline ("kind": "port"; bench.py prefers the genuine build, "kind": "reference").
 //
-// Parity pin: deterministic results (legal sets, terminal flags, returns,
-// tensors, strings, CFR tables) are pinned by the reference's own playthrough
-// goldens and known-answer tests (tests/golden/, tests/test_oracle_*.py).
-// RNG-stream parity with the reference (absl::Uniform / std::shuffle over
-// mt19937) is UNPINNED: abseil is not vendored in /root/reference and its
-// distribution algorithms are unspecified; only outcome-level properties are
-// pinned for MCTS / MCCFR, exactly as in the reference's own tests.
+// Parity pin: this restatement is compared CALL FOR CALL with the genuine reference
+// implementation — the reference's own .cc files compiled unmodified from
+// /root/reference into oracle/_ref/libspiel_ref.so (oracle/Makefile.ref, with the
+// private abseil / nlohmann stand-ins of oracle/ref_shim) behind the same extern "C"
+// driver (spiel_oracle_capi.cpp -DOSGO_GENUINE_REFERENCE): seeded playouts, strings,
+// CFR / CFR+ tables, ES-MCCFR / OS-MCCFR tables, MCTSBot search trees and the
+// exploitability judge are bit-identical (tests/test_oracle_vs_reference.py), and the
+// outputs of that reference build are committed as golden vectors
+// (tests/golden/reference_vectors.npz).  It is also pinned by the reference's playthrough
+// goldens and known-answer tests (tests/golden/playthroughs.json, tests/test_oracle_*.py).
+// What stays UNPINNED is abseil's random streams (absl::Uniform in mcts.cc:54 /
+// spiel.cc:368-371, absl::discrete_distribution in outcome_sampling_mccfr.cc:178):
+// abseil is not vendored in /root/reference and its distributions are unspecified; the
+// stand-in draws from libstdc++'s engines with the conventions used here.  ES-MCCFR uses
+// only std::mt19937 + std::uniform_real_distribution and IS stream-identical.
 //
 // Each function cites the reference file:line it restates (paths relative to
 // /root/reference/open_spiel/).

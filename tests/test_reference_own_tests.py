@@ -53,3 +53,23 @@ def test_outcome_sampling_mccfr_test_trips_only_its_stream_dependent_inequality(
     assert "Game: kuhn_poker" in out and "Game: leduc_poker" in out   # the bound tests ran (and passed: no abort before)
     if r.returncode != 0:
         assert "outcome_sampling_mccfr_test.cc:72 exploitability2 > exploitability3" in out, out[-2000:]
+
+
+def test_reference_command_line_tools_run_on_the_genuine_build(reference):
+    """examples/benchmark_game.cc (the one throughput tool the reference ships for this path) and
+    examples/mcts_example.cc (BASELINE.json configs[0]: tic_tac_toe MCTSBot with RandomRolloutEvaluator,
+    CPU plumbing), built unmodified (`make -f oracle/Makefile.ref reftools`, with a small absl/flags
+    stand-in).  1000-simulation MCTS self-play of tic_tac_toe never loses a game."""
+    if not reference.sources_present():
+        pytest.skip("needs the reference sources (/root/reference)")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "-f", "Makefile.ref", "-j4",
+                           "REF=" + reference.REFERENCE_ROOT, "reftools"])
+    tools = os.path.join(ROOT, "oracle", "_ref", "tools")
+    r = subprocess.run([os.path.join(tools, "benchmark_game"), "--game=connect_four", "--sims=2000", "--attempts=1"],
+                       capture_output=True, text=True, timeout=300, check=True)
+    assert "Benchmark: game: connect_four, num_sims: 2000." in r.stdout and "moves/s" in r.stdout
+    r = subprocess.run([os.path.join(tools, "mcts_example"), "--game=tic_tac_toe", "--player1=mcts", "--player2=mcts",
+                        "--max_simulations=1000", "--rollout_count=20", "--seed=42", "--num_games=5", "--quiet"],
+                       capture_output=True, text=True, timeout=600, check=True)
+    out = r.stdout + r.stderr
+    assert "Number of games played: 5" in out and "Overall wins: 0,0" in out

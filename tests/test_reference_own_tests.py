@@ -19,7 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TEST_DIR = os.path.join(ROOT, "oracle", "_ref", "tests")
 
 PASSING = ["tic_tac_toe_test", "connect_four_test", "hex_test", "kuhn_poker_test", "leduc_poker_test",
-           "mcts_test", "cfr_test", "external_sampling_mccfr_test", "tabular_exploitability_test"]
+           "mcts_test", "cfr_test", "external_sampling_mccfr_test", "tabular_exploitability_test",
+           "tensor_view_test", "action_view_test", "random_test", "nlohmann_json_test"]
 
 
 @pytest.fixture(scope="module")

@@ -5,7 +5,7 @@
 //                         linked with open_spiel_amd/libosg_hip.so
 // The only difference between the two builds is the include block and the two namespace aliases below.
 // Both print the same transcript; tests/test_dropin.py builds both (CPU), runs the reference build and
-// keeps its transcript, and tests/test_gpu_dropin.py runs the mirror build on the GPU and compares.
+// keeps its transcript, and tests/test_z2_gpu_dropin.py runs the mirror build on the GPU and compares.
 // Every line is deterministic: fixed move choices, the full-tree CFR family, MCTS-Solver proofs.
 #include <cstdio>
 #include <memory>

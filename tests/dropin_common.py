@@ -1,4 +1,4 @@
-"""Shared by tests/test_dropin.py (CPU) and tests/test_gpu_dropin.py (GPU): building the two variants of
+"""Shared by tests/test_dropin.py (CPU) and tests/test_z2_gpu_dropin.py (GPU): building the two variants of
 tests/dropin/user_program.cc and comparing transcripts."""
 import os
 import re

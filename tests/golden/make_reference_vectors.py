@@ -29,7 +29,7 @@ Output: tests/golden/reference_vectors.npz (compressed; < 1 MB).  Contents, per 
   census/<game>     (chance, decision, terminal, infostates)
 
 Consumers: tests/test_reference_vectors.py (the restatement reproduces every array, CPU) and
-tests/test_gpu_reference_vectors.py (the HIP engine reproduces them through the C-ABI).
+tests/test_z1_gpu_reference_vectors.py (the HIP engine reproduces them through the C-ABI).
 """
 import os
 import sys

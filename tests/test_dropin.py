@@ -2,7 +2,7 @@
 the reference's examples — compiles unchanged against the genuine reference API and against the MI355X
 host mirror.  Here (CPU): both variants build; the reference variant runs and must reproduce the committed
 transcript tests/golden/dropin_transcript.txt (regenerate with OSG_UPDATE_GOLDEN=1); the mirror variant
-must refuse to run without a GPU.  tests/test_gpu_dropin.py runs the mirror variant on the device and
+must refuse to run without a GPU.  tests/test_z2_gpu_dropin.py runs the mirror variant on the device and
 compares it with the same transcript."""
 import os
 import subprocess

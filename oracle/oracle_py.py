@@ -179,6 +179,12 @@ class Game:
                                           C.byref(units)))
         return secs.value, units.value
 
+    def bench_observation(self, seed, pool, total, threads):
+        secs, units = C.c_double(0), C.c_int64(0)
+        _check(lib().osgo_bench_observation(self._h, C.c_uint64(seed), C.c_int64(pool), C.c_int64(total),
+                                            threads, C.byref(secs), C.byref(units)))
+        return secs.value, units.value
+
     def bench_playouts(self, seed, sims, threads):
         secs, moves = C.c_double(0), C.c_int64(0)
         _check(lib().osgo_bench_playouts(self._h, C.c_uint64(seed), C.c_int64(sims), threads,

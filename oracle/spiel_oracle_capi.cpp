@@ -806,6 +806,62 @@ int osgo_bench_env_steps(void* g, uint64_t seed, int64_t pool, int64_t total_ste
     return 0;
   });
 }
+// (a2) tensor pack: State::ObservationTensor(player) into a preallocated span (spiel.h:713-714) for the
+//      player to move, over a pool of seeded non-terminal positions; units = tensors written.
+int osgo_bench_observation(void* g, uint64_t seed, int64_t pool, int64_t total, int threads, double* secs,
+                           int64_t* units) {
+  return Guard([&] {
+    const std::string game_string = static_cast<GameH*>(g)->game->ToString();
+    const int64_t per_thread = std::max<int64_t>(pool / threads, 1);
+    std::vector<std::shared_ptr<const Game>> games(threads);  // one Game per thread (see osgo_bench_env_steps)
+    std::vector<std::vector<std::unique_ptr<State>>> states(threads);
+    for (int w = 0; w < threads; ++w) {
+      games[w] = LoadGame(game_string);
+      states[w].resize(per_thread);
+      for (int64_t j = 0; j < per_thread; ++j) {
+        CounterRng rng(seed, static_cast<uint64_t>(w * per_thread + j));
+        for (;;) {
+          std::unique_ptr<State> s = games[w]->NewInitialState();
+          int depth = static_cast<int>(rng.Below(36));
+          for (int t = 0; t < depth && !s->IsTerminal(); ++t) {
+            if (s->IsChanceNode()) {
+              s->ApplyAction(SampleAction(s->ChanceOutcomes(), rng.Unit()).first);
+            } else {
+              std::vector<Action> la = s->LegalActions();
+              s->ApplyAction(la[rng.Below(static_cast<uint32_t>(la.size()))]);
+            }
+          }
+          if (s->IsTerminal() || s->IsChanceNode()) continue;
+          states[w][j] = std::move(s);
+          break;
+        }
+      }
+    }
+    const int size = games[0]->ObservationTensorSize();
+    std::vector<double> sink(threads, 0);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> workers;
+    for (int w = 0; w < threads; ++w) {
+      workers.emplace_back([&, w] {
+        std::vector<float> out(size);
+        double acc = 0;
+        const int64_t quota = total / threads;
+        for (int64_t k = 0; k < quota; ++k) {
+          const State& s = *states[w][k % per_thread];
+          WriteTensor(s, 0, s.CurrentPlayer(), out.data(), size);
+          acc += out[k % size];
+        }
+        sink[w] = acc;
+      });
+    }
+    for (auto& t : workers) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    *secs = std::chrono::duration<double>(t1 - t0).count();
+    *units = (total / threads) * threads;
+    if (sink[0] == 1234.5678) g_err = "sink";
+    return 0;
+  });
+}
 // (b) random playouts (benchmark_game.cc-equivalent): units = moves.
 int osgo_bench_playouts(void* g, uint64_t seed, int64_t sims, int threads,
                         double* secs, int64_t* moves) {

@@ -7,6 +7,7 @@ restatement (oracle/liboracle.so) — single thread and all usable cores (one Ga
 solver per thread; the reference itself is single-threaded):
 
   env steps      Clone + LegalActions + ApplyAction + IsTerminal + Returns + CurrentPlayer per step
+  tensor pack    State::ObservationTensor(player) into a preallocated span, tensors/s
   playouts       benchmark_game.cc-style random playouts, moves/s
   MCTS           MCTSBot(RandomRolloutEvaluator(1), uct_c=2, 1024 simulations), simulations/s
   CFR            CFRSolver::EvaluateAndUpdatePolicy, iterations/s
@@ -60,7 +61,11 @@ def main():
                 def playouts(scale, g=g, th=th):
                     secs, moves = g.bench_playouts(0x5EED, int(500 * th * scale), th)
                     return moves, secs
+                def tensors(scale, g=g, th=th):
+                    secs, units = g.bench_observation(0x5EED, 1 << 12, int(200_000 * th * scale), th)
+                    return units, secs
                 rows.append((name, game, th, "env-steps/s", rate(steps, args.seconds)))
+                rows.append((name, game, th, "ObservationTensor/s", rate(tensors, args.seconds)))
                 rows.append((name, game, th, "playout moves/s", rate(playouts, args.seconds)))
         g = impl.Game("hex(board_size=9)")
         for th in (1, threads):

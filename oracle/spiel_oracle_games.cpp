@@ -111,7 +111,9 @@ class TttState : public State {
  protected:
   void DoApplyAction(Action a) override {  // tic_tac_toe.cc:128-136
     ORACLE_CHECK(a >= 0 && a < 9 && cells_[a] == kTttEmpty);
-    cells_[a] = (CurrentPlayer() == 0) ? kTttX : kTttO;
+    const Player mover = CurrentPlayer();  // PlayerToState (tic_tac_toe.cc:66-76): fatal unless 0 or 1
+    if (mover != 0 && mover != 1) Fatal("Invalid player id " + std::to_string(mover));
+    cells_[a] = (mover == 0) ? kTttX : kTttO;
     if (Line(to_move_)) winner_ = to_move_;
     to_move_ = 1 - to_move_;
     ++plies_;
@@ -239,7 +241,9 @@ class C4State : public State {
     ORACLE_CHECK(At(cfg_.rows_ - 1, a) == 0);
     int r = 0;
     while (At(r, a) != 0) ++r;
-    grid_[r * cfg_.cols_ + a] = (CurrentPlayer() == 0) ? 2 : 1;
+    const Player mover = CurrentPlayer();  // PlayerToState (connect_four.cc:60-69): fatal unless 0 or 1, e.g. at a terminal state
+    if (mover != 0 && mover != 1) Fatal("Invalid player id " + std::to_string(mover));
+    grid_[r * cfg_.cols_ + a] = (mover == 0) ? 2 : 1;
     if (AnyLine(to_move_)) {
       outcome_ = to_move_;
     } else if (Full()) {

@@ -253,3 +253,36 @@ def test_mcts_selfplay_is_identical(oracle, reference):
         og, rg = _pair(oracle, reference, game_string)
         for seed in (1, 2, 3):
             assert np.array_equal(og.mcts_selfplay(2.0, 100, 5, seed), rg.mcts_selfplay(2.0, 100, 5, seed))
+
+
+@pytest.mark.parametrize("game_string", ["tic_tac_toe", "connect_four", "hex(board_size=3)", "kuhn_poker", "leduc_poker"])
+def test_error_behaviour_matches(oracle, reference, game_string):
+    """What the reference treats as fatal (SpielFatalError / SPIEL_CHECK -> an exception under the pybind
+    handler) the restatement rejects too: unknown games and parameters, an action applied to a terminal
+    state, a tensor for a player that does not exist.  Neither side may silently accept."""
+    for impl in (oracle, reference):
+        with pytest.raises(impl.OracleError):
+            impl.Game("no_such_game")
+        with pytest.raises(impl.OracleError):
+            impl.Game(game_string.split("(")[0] + "(no_such_parameter=1)")
+    og, rg = _pair(oracle, reference, game_string)
+    rec = og.random_playouts(3, 1)
+    for impl, g in ((oracle, og), (reference, rg)):
+        s = g.new_initial_state()
+        for a in rec["actions"][0]:
+            if a < 0:
+                break
+            s.apply_action(int(a))
+        assert s.is_terminal()
+        assert s.legal_actions() == []
+        if "poker" not in game_string:
+            # the board games refuse (PlayerToState of the terminal player id, tic_tac_toe.cc:66-76,
+            # connect_four.cc:60-69; hex.cc:229 checks the cell).  The poker games' DoApplyAction has no such
+            # check in a Release build (only SPIEL_DCHECKs), so nothing is asserted for them; the MI355X engine
+            # itself rejects every action on a terminal state (OSG_ERR_ILLEGAL), the stricter of the two.
+            with pytest.raises(impl.OracleError):
+                s.apply_action(0)
+        with pytest.raises(impl.OracleError):
+            s.observation_tensor(g.num_players)
+        with pytest.raises(impl.OracleError):
+            s.observation_tensor(-1)

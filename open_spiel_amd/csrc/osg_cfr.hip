@@ -2227,31 +2227,11 @@ int osg_action_string(const osg_batch* b, int64_t index, int player, int32_t act
       hex_geometry(b->spec, &cols, &rows, &cells);
       if (action == cells) { out = "swap"; break; }
       const int x = action % cols, y = action / cols;
-      if (!b->spec.hex_explicit) {
-        out = std::string(1, static_cast<char>('a' + x)) + std::to_string(y + 1);
-        break;
-      }
-      // explicit representation: the label the stone would get (PlayerAndActionToState, hex.cc:108-171)
-      uint64_t w[4 * 4 + 1] = {0};
-      int rc = fetch_state_words(b, index, w);
-      if (rc) return rc;
-      const int NW = b->spec.hex_nw;
-      auto bit = [&](int plane, int cell) { return (w[plane * NW + (cell >> 5)] >> (cell & 31)) & 1ull; };
-      const bool black = player == 0;
-      bool a = black ? y == 0 : x == 0;
-      bool bb = !a && (black ? y == rows - 1 : x == cols - 1);
-      const int nb[6][2] = {{0, -1}, {1, -1}, {1, 0}, {0, 1}, {-1, 1}, {-1, 0}};  // AdjacentCells, hex.cc:316-329
-      for (const auto& dxy : nb) {
-        const int nx = x + dxy[0], ny = y + dxy[1];
-        if (nx < 0 || ny < 0 || nx >= cols || ny >= rows) continue;
-        const int c = ny * cols + nx;
-        if (!bit(black ? 0 : 1, c)) continue;
-        const bool ea = bit(2, c), eb = bit(3, c);
-        if (ea && !eb) a = true;
-        if (eb && !ea) bb = true;
-      }
-      const char* glyph = black ? (a && bb ? "X" : a ? "y" : bb ? "z" : "x") : (a && bb ? "O" : a ? "p" : bb ? "q" : "o");
-      out = std::string(glyph) + "(" + std::to_string(x) + "," + std::to_string(y) + ")";
+      // Always the standard form, also for string_rep=explicit: hex.cc:301 tests `StringRep() == StringRep::kStandard`,
+      // a value-initialised enum (= kStandard), not the state's string_rep(), so the reference never reaches its
+      // explicit branch (:307-310).  Checked against the running reference (tests/test_oracle_vs_reference.py);
+      // the board string (ToString, hex.cc:341-359) does honour string_rep.
+      out = std::string(1, static_cast<char>('a' + x)) + std::to_string(y + 1);
       break;
     }
     case kKuhn:  // kuhn_poker.cc:244-251

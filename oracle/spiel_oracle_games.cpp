@@ -347,12 +347,12 @@ class HexState : public State {
     // hex.cc:295-314 ('row' there is the column letter).
     if (cfg_.swap_ && a == cfg_.cols_ * cfg_.rows_) return "swap";
     int x = static_cast<int>(a % cfg_.cols_), y = static_cast<int>(a / cfg_.cols_);
-    if (!cfg_.explicit_) {
-      std::string s(1, static_cast<char>('a' + x));
-      return s + std::to_string(y + 1);
-    }
-    return std::string(Glyph(LabelFor(player, static_cast<int>(a)), true)) + "(" +
-           std::to_string(x) + "," + std::to_string(y) + ")";
+    // Always the standard form, also for string_rep=explicit: hex.cc:301 compares the value-initialised enum
+    // `StringRep()` (= kStandard) instead of string_rep(), so the explicit branch (:307-310) is never taken.
+    // Found by the differential run against the genuine build (tests/test_oracle_vs_reference.py).
+    (void)player;
+    std::string s(1, static_cast<char>('a' + x));
+    return s + std::to_string(y + 1);
   }
   std::string ToString() const override {  // hex.cc:341-359
     std::string s;

@@ -34,6 +34,16 @@ GAME_CONFIGS = [
     ("leduc_poker", 400),
     ("leduc_poker(players=3)", 300),
     ("leduc_poker(suit_isomorphism=True)", 300),
+    # the remaining configurations the GPU parity tests take from the oracle (tests/test_gpu_parity.py GAMES)
+    ("hex(board_size=5)", 200),
+    ("hex(num_cols=2,num_rows=3)", 200),
+    ("hex(num_cols=2,num_rows=2)", 200),
+    ("hex(board_size=5,plain_obs_tensor=True,swap=True)", 200),
+    ("hex(board_size=4,string_rep=explicit)", 200),
+    ("kuhn_poker(players=5)", 200),
+    ("kuhn_poker(players=10)", 100),
+    ("leduc_poker(action_mapping=True)", 300),
+    ("leduc_poker(players=3,starting_player=2)", 200),
 ]
 
 

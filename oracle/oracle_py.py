@@ -311,6 +311,11 @@ class State:
 
 SOLVER_KINDS = {"cfr": 0, "cfr_plus": 1, "mccfr_simple": 2, "mccfr_full": 3, "cfr_simultaneous": 4,
                 "mccfr_outcome": 5}
+# CFRSolverBase(game, alternating_updates, linear_averaging, regret_matching_plus) with any switch combination
+for _alt in (0, 1):
+    for _lin in (0, 1):
+        for _rmp in (0, 1):
+            SOLVER_KINDS[f"cfr_base_alt{_alt}_lin{_lin}_rmp{_rmp}"] = 16 + _alt + 2 * _lin + 4 * _rmp
 
 
 class Solver:

@@ -452,7 +452,8 @@ int osgo_mcts_selfplay(void* g, double uct_c, int max_simulations, int n_rollout
 // CFR / MCCFR
 // ---------------------------------------------------------------------------
 // kind: 0 CFRSolver, 1 CFRPlusSolver, 2 ES-MCCFR(simple), 3 ES-MCCFR(full),
-// 4 CFRSolverBase(simultaneous updates, no linear avg, no RM+), 5 OS-MCCFR(epsilon 0.6)
+// 4 CFRSolverBase(simultaneous updates, no linear avg, no RM+), 5 OS-MCCFR(epsilon 0.6),
+// 16..23 CFRSolverBase with any switch combination (16 + alternating + 2 * linear averaging + 4 * RM+)
 void* osgo_cfr_create(void* g, int kind, int seed) {
   try {
     auto* h = new CfrH;
@@ -460,6 +461,8 @@ void* osgo_cfr_create(void* g, int kind, int seed) {
     if (kind == 0) h->cfr = std::make_unique<CFRSolver>(*h->game);
     else if (kind == 1) h->cfr = std::make_unique<CFRPlusSolver>(*h->game);
     else if (kind == 4) h->cfr = std::make_unique<CFRSolverBase>(*h->game, false, false, false);
+    else if (kind >= 16 && kind < 24)  // 16 + alternating_updates + 2 * linear_averaging + 4 * regret_matching_plus
+      h->cfr = std::make_unique<CFRSolverBase>(*h->game, (kind & 1) != 0, (kind & 2) != 0, (kind & 4) != 0);
     else if (kind == 5) h->osmccfr = std::make_unique<OutcomeSamplingMCCFRSolver>(
              *h->game, OutcomeSamplingMCCFRSolver::kDefaultEpsilon, seed);
     else h->mccfr = std::make_unique<ExternalSamplingMCCFRSolver>(

@@ -296,3 +296,21 @@ def test_error_behaviour_matches(oracle, reference, game_string):
             s.observation_tensor(g.num_players)
         with pytest.raises(impl.OracleError):
             s.observation_tensor(-1)
+
+
+@pytest.mark.parametrize("alt", [0, 1])
+@pytest.mark.parametrize("lin", [0, 1])
+@pytest.mark.parametrize("rmp", [0, 1])
+def test_every_cfr_switch_combination_is_bit_identical(oracle, reference, alt, lin, rmp):
+    """CFRSolverBase(game, alternating_updates, linear_averaging, regret_matching_plus) (cfr.h:188-196) for all
+    eight switch combinations, kuhn 30 iterations and leduc 3."""
+    kind = f"cfr_base_alt{alt}_lin{lin}_rmp{rmp}"
+    for game_string, iters in (("kuhn_poker", 30), ("leduc_poker", 3)):
+        og, rg = _pair(oracle, reference, game_string)
+        so, sr = oracle.Solver(og, kind), reference.Solver(rg, kind)
+        so.iterate(iters)
+        sr.iterate(iters)
+        a, b = so.tables(), sr.tables()
+        assert a["keys"] == b["keys"]
+        for k in ("regrets", "cum_policy", "cur_policy", "avg_policy"):
+            assert np.array_equal(a[k], b[k]), (game_string, kind, k)

@@ -314,3 +314,18 @@ def test_every_cfr_switch_combination_is_bit_identical(oracle, reference, alt, l
         assert a["keys"] == b["keys"]
         for k in ("regrets", "cum_policy", "cur_policy", "avg_policy"):
             assert np.array_equal(a[k], b[k]), (game_string, kind, k)
+
+
+def test_mcts_with_garbage_collection_is_identical(oracle, reference):
+    """mcts.cc:441-482: a 1 MB node budget forces MCTSBot::GarbageCollect during the search (connect_four,
+    unsolved, 60 000 simulations): the surviving root statistics are the same in both builds."""
+    og, rg = _pair(oracle, reference, "connect_four")
+    so, sr = og.new_initial_state(), rg.new_initial_state()
+    for a in (3, 3, 2):
+        so.apply_action(a)
+        sr.apply_action(a)
+    a = so.mcts_search(2.0, 60000, 1, 1, False, 7)
+    b = sr.mcts_search(2.0, 60000, 1, 1, False, 7)
+    assert a["root_visits"] == b["root_visits"] == 60000
+    assert a["best_action"] == b["best_action"]
+    assert np.array_equal(a["children"], b["children"], equal_nan=True)

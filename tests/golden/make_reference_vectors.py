@@ -11,7 +11,7 @@ best_response.cc, ...) compiled unmodified from /root/reference by oracle/Makefi
 through the extern "C" entry points of oracle/spiel_oracle_capi.cpp (-DOSGO_GENUINE_REFERENCE).
 Nothing in this file is computed by the restatement or by the HIP engine.
 
-Output: tests/golden/reference_vectors.npz (compressed; < 1 MB).  Contents, per BASELINE.json game:
+Output: tests/golden/reference_vectors.npz (compressed; < 1 MB).  Contents, per BASELINE.json game (plus four variants):
 
   play/<game>/...   seeded playouts (playout i draws from CounterRng(seed, i), see the capi file):
                     actions [n,L] i16, mask [n,L+1,W] u32 (LegalActions, chance outcomes at chance
@@ -45,6 +45,11 @@ PLAYOUTS = [  # game, seed, n
     ("hex(board_size=9)", 0x601D, 12),
     ("kuhn_poker", 0x601D, 64),
     ("leduc_poker", 0x601D, 64),
+    # variants (other geometries, more players)
+    ("connect_four(rows=5,columns=6,x_in_row=3)", 0x601D, 48),
+    ("hex(num_cols=3,num_rows=4)", 0x601D, 48),
+    ("kuhn_poker(players=3)", 0x601D, 48),
+    ("leduc_poker(players=3)", 0x601D, 32),
 ]
 CFR = [  # game, kind, checkpoints
     ("kuhn_poker", "cfr", [1, 10, 15, 100]),

@@ -30,7 +30,9 @@ def ctx():
     return osa.Context(0)
 
 
-PLAY_GAMES = ["tic_tac_toe", "connect_four", "hex(board_size=9)", "kuhn_poker", "leduc_poker"]
+PLAY_GAMES = ["tic_tac_toe", "connect_four", "hex(board_size=9)", "kuhn_poker", "leduc_poker",
+              "connect_four(rows=5,columns=6,x_in_row=3)", "hex(num_cols=3,num_rows=4)", "kuhn_poker(players=3)",
+              "leduc_poker(players=3)"]
 
 
 @pytest.mark.parametrize("game", PLAY_GAMES)

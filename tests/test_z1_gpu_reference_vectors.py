@@ -30,13 +30,14 @@ def ctx():
     return osa.Context(0)
 
 
-PLAY_GAMES = ["tic_tac_toe", "connect_four", "hex(board_size=9)", "kuhn_poker", "leduc_poker",
-              "connect_four(rows=5,columns=6,x_in_row=3)", "hex(num_cols=3,num_rows=4)", "kuhn_poker(players=3)",
-              "leduc_poker(players=3)"]
+PLAY_GAMES = ["tic_tac_toe", "connect_four", "hex(board_size=9)", "kuhn_poker", "leduc_poker"]
+# other geometries / more players: run by the two tests at the END of this module (under `pytest -x` a surprise
+# in a variant must not hide the solver and checkpoint tests in between)
+VARIANT_GAMES = ["connect_four(rows=5,columns=6,x_in_row=3)", "hex(num_cols=3,num_rows=4)", "kuhn_poker(players=3)",
+                 "leduc_poker(players=3)"]
 
 
-@pytest.mark.parametrize("game", PLAY_GAMES)
-def test_reference_playouts_replayed_on_the_device(ctx, vectors, game):
+def _replay_on_the_device(ctx, vectors, game):
     """At every ply of every recorded playout: LegalActions (chance outcomes at chance nodes),
     CurrentPlayer, IsTerminal, Returns, and ObservationTensor / InformationStateTensor of every
     player equal what the reference produced."""
@@ -70,7 +71,11 @@ def test_reference_playouts_replayed_on_the_device(ctx, vectors, game):
 
 
 @pytest.mark.parametrize("game", PLAY_GAMES)
-def test_reference_playouts_through_the_fused_step(ctx, vectors, game):
+def test_reference_playouts_replayed_on_the_device(ctx, vectors, game):
+    _replay_on_the_device(ctx, vectors, game)
+
+
+def _through_the_fused_step(ctx, vectors, game):
     """The same recorded playouts through the fused kernel (legality + apply + status + successor
     mask in one launch): terminal flag, player to move, no illegal flag, final returns."""
     import torch
@@ -91,6 +96,11 @@ def test_reference_playouts_through_the_fused_step(ctx, vectors, game):
         np.testing.assert_array_equal((st[live] & 15).astype(np.int64) - 1, vectors[p + "cur_player"][:, t + 1][live])
         a, b = b, a
     np.testing.assert_array_equal(a.returns().cpu().numpy(), vectors[p + "returns"][:, L])
+
+
+@pytest.mark.parametrize("game", PLAY_GAMES)
+def test_reference_playouts_through_the_fused_step(ctx, vectors, game):
+    _through_the_fused_step(ctx, vectors, game)
 
 
 SOLVER_KWARGS = {
@@ -238,3 +248,14 @@ def test_device_checkpoint_loads_in_the_genuine_reference(pyspiel, game, cls_nam
             na = int(ref_t["nact"][j])
             np.testing.assert_allclose(dev[k].cumulative_regrets, ref_t["regrets"][j, :na], rtol=0, atol=1e-12)
             np.testing.assert_allclose(dev[k].cumulative_policy, ref_t["cum_policy"][j, :na], rtol=0, atol=1e-12)
+
+
+# ---- the variants, last (see VARIANT_GAMES) ---------------------------------------------------------------
+@pytest.mark.parametrize("game", VARIANT_GAMES)
+def test_reference_playouts_of_variants_replayed_on_the_device(ctx, vectors, game):
+    _replay_on_the_device(ctx, vectors, game)
+
+
+@pytest.mark.parametrize("game", VARIANT_GAMES)
+def test_reference_playouts_of_variants_through_the_fused_step(ctx, vectors, game):
+    _through_the_fused_step(ctx, vectors, game)

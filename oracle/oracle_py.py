@@ -287,6 +287,14 @@ class State:
     def action_to_string(self, player, action):
         return self._string(4, player, action)
 
+    def serialize_game_and_state(self):
+        """SerializeGameAndState(game, state) (genuine reference build only)."""
+        buf = C.create_string_buffer(1 << 16)
+        n = lib().osgo_serialize_game_and_state(self._h, buf, 1 << 16)
+        if n < 0:
+            raise OracleError(lib().osgo_last_error().decode())
+        return buf.value.decode()
+
     def history(self):
         out = (C.c_int64 * 512)()
         n = lib().osgo_history(self._h, out, 512)

@@ -274,6 +274,23 @@ int osgo_string(void* s, int which, int player, int64_t action, char* buf, int c
     return -1;
   }
 }
+// SerializeGameAndState (spiel.cc:582-603): the reference's text form of a game + state.  Genuine build only
+// (the restatement does not restate wire formats; the product's host mirror does).
+int osgo_serialize_game_and_state(void* s, char* buf, int cap) {
+#ifdef OSGO_GENUINE_REFERENCE
+  try {
+    const State& st = *static_cast<StateH*>(s)->state;
+    return CopyStr(SerializeGameAndState(*st.GetGame(), st), buf, cap);
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+#else
+  (void)s; (void)buf; (void)cap;
+  g_err = "wire formats are only available from the genuine reference build";
+  return -1;
+#endif
+}
 int osgo_history(void* s, int64_t* out, int cap) {
   std::vector<Action> h = static_cast<StateH*>(s)->state->History();
   for (int i = 0; i < static_cast<int>(h.size()) && i < cap; ++i) out[i] = h[i];

@@ -25,6 +25,7 @@ Output: tests/golden/reference_vectors.npz (compressed; < 1 MB).  Contents, per 
                     std::uniform_real_distribution: libstdc++ streams, reproducible)
   ckpt/<game>/<kind>/<iters>/text[6]   CFRSolverBase::Serialize() of the solver at that checkpoint
                     (cfr.cc:284-307; lossless hex floats, and 6 decimals)
+  state/<game>/history, text   SerializeGameAndState() of a mid-game state (spiel.cc:582-603)
   judge/<game>/...  NashConv / exploitability of the uniform and first-action policies
   census/<game>     (chance, decision, terminal, infostates)
 
@@ -94,6 +95,16 @@ def main():
                 a = rec[k]
                 assert (a >= 0).all() and (a <= 255).all() and (a == np.round(a)).all(), (game, k)
                 out[p + k] = a.astype(np.uint8)
+    # SerializeGameAndState (spiel.cc:582-603) of mid-game states: the history of playout 0 cut at half its length
+    for game, seed, n in PLAYOUTS:
+        g = ref.Game(game)
+        acts = [int(a) for a in out[f"play/{game}/actions"][0] if a >= 0]
+        acts = acts[:max(1, len(acts) // 2)]
+        s = g.new_initial_state()
+        for a in acts:
+            s.apply_action(a)
+        out[f"state/{game}/history"] = np.array(acts, np.int64)
+        out[f"state/{game}/text"] = np.frombuffer(s.serialize_game_and_state().encode(), np.uint8)
     for game, kind, checkpoints in CFR:
         g = ref.Game(game)
         s = ref.Solver(g, kind)

@@ -250,6 +250,23 @@ def test_device_checkpoint_loads_in_the_genuine_reference(pyspiel, game, cls_nam
             np.testing.assert_allclose(dev[k].cumulative_policy, ref_t["cum_policy"][j, :na], rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("game", PLAY_GAMES)
+def test_serialize_game_and_state_equals_the_reference_text(pyspiel, vectors, game):
+    """SerializeGameAndState (spiel.cc:582-603) of a mid-game state: the host mirror writes the very text the
+    reference wrote, and reads it back to the same state."""
+    text = vectors[f"state/{game}/text"].tobytes().decode()
+    history = [int(a) for a in vectors[f"state/{game}/history"]]
+    g = pyspiel.load_game(game)
+    s = g.new_initial_state()
+    for a in history:
+        s.apply_action(a)
+    assert pyspiel.serialize_game_and_state(g, s) == text
+    g2, s2 = pyspiel.deserialize_game_and_state(text)
+    assert str(g2) == str(g)
+    assert list(s2.history()) == history
+    assert str(s2) == str(s)
+
+
 # ---- the variants, last (see VARIANT_GAMES) ---------------------------------------------------------------
 @pytest.mark.parametrize("game", VARIANT_GAMES)
 def test_reference_playouts_of_variants_replayed_on_the_device(ctx, vectors, game):

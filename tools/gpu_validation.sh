@@ -3,6 +3,7 @@
 #
 #   gpurun --timeout 2400 -- 'bash tools/gpu_validation.sh r02'
 #
+# 0. __graft_entry__.smoke();
 # 1. the GPU test suite (parity vs the oracle, vs the recorded outputs of the genuine reference,
 #    checkpoint interop with oracle/_ref, the world-size-1 collective);
 # 2. bench.py (one JSON line: env-steps/s + roofline + cpu_baseline of the genuine reference build);
@@ -17,7 +18,12 @@ mkdir -p "$OUT"
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 
-echo "== pytest -m gpu" | tee "$OUT/summary.txt"
+echo "== smoke()" | tee "$OUT/summary.txt"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1
+echo "smoke exit $?" | tee -a "$OUT/summary.txt"
+tail -2 "$OUT/smoke.log" | tee -a "$OUT/summary.txt"
+
+echo "== pytest -m gpu" | tee -a "$OUT/summary.txt"
 timeout 1500 python -m pytest tests -q -m gpu -x --durations=15 > "$OUT/pytest_gpu.log" 2>&1
 echo "pytest exit $?" | tee -a "$OUT/summary.txt"
 tail -5 "$OUT/pytest_gpu.log" | tee -a "$OUT/summary.txt"

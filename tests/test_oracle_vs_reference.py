@@ -329,3 +329,19 @@ def test_mcts_with_garbage_collection_is_identical(oracle, reference):
     assert a["root_visits"] == b["root_visits"] == 60000
     assert a["best_action"] == b["best_action"]
     assert np.array_equal(a["children"], b["children"], equal_nan=True)
+
+
+@pytest.mark.parametrize("game_string", ["tic_tac_toe", "connect_four", "hex(board_size=9)", "kuhn_poker", "leduc_poker"])
+def test_rollout_replay_sums_are_identical(oracle, reference, game_string):
+    """RandomRolloutEvaluator-style playouts from mid-game positions on the device's counter streams
+    (osgo_replay_rollouts: what the GPU rollout parity tests take from the oracle): summed returns and the
+    number of steps played are the same in both builds."""
+    og, rg = _pair(oracle, reference, game_string)
+    rec = og.random_playouts(0xA11CE, 6)
+    for i in range(6):
+        hist = [int(a) for a in rec["actions"][i] if a >= 0]
+        hist = hist[:len(hist) // 2]
+        a_sum, a_steps = og.replay_rollouts(hist, 99, 1000 + i, 16)
+        b_sum, b_steps = rg.replay_rollouts(hist, 99, 1000 + i, 16)
+        assert a_steps == b_steps > 0
+        assert np.array_equal(a_sum, b_sum)

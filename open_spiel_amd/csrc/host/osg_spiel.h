@@ -519,7 +519,7 @@ class MCTSBot {  // mcts.h:149-220
     std::vector<double> o(num_players_, 0.0);
     if (p >= 0 && p < num_players_) {
       o[p] = v;
-      if (num_players_ == 2) o[1 - p] = -v;
+      if (num_players_ == 2) o[1 - p] = 0.0 - v;  // 0.0 - 0.0 = +0.0: Returns() of a draw is {0, 0}
     }
     return o;
   }

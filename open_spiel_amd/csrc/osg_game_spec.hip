@@ -112,7 +112,7 @@ template <int NW>
 void fill_hex(typename HexT<NW>::Params* p, int cols, int rows, bool swap, bool plain) {
   using B = typename HexT<NW>::Bits;
   auto zero = [](B* b) { for (int i = 0; i < NW; ++i) b->w[i] = 0; };
-  auto set = [](B* b, int c) { b->w[c >> 5] |= 1u << (c & 31); };
+  auto set = [](B* b, int c) { if ((c >> 5) < NW) b->w[c >> 5] |= 1u << (c & 31); };
   p->words = 4 * NW + 1;
   p->cols = cols; p->rows = rows; p->cells = cols * rows; p->swap = swap; p->plain_obs = plain;
   zero(&p->board); zero(&p->col_first); zero(&p->col_last); zero(&p->row_first); zero(&p->row_last);
@@ -196,10 +196,14 @@ int parse_game(const char* game_string, GameSpec* out) {
     out->hex_nw = (cells + 31) / 32;
     out->hex_explicit = rep == "explicit";
     d.state_words = 4 * out->hex_nw + 1; d.state_word_bytes = 4;
-    fill_hex<1>(&out->hex1, cols, rows, swap, plain);
-    fill_hex<2>(&out->hex2, cols, rows, swap, plain);
-    fill_hex<3>(&out->hex3, cols, rows, swap, plain);
-    fill_hex<4>(&out->hex4, cols, rows, swap, plain);
+    // only the variant that holds the board: Bits::w has NW words, a larger board would write past it
+    out->hex1 = {}; out->hex2 = {}; out->hex3 = {}; out->hex4 = {};
+    switch (out->hex_nw) {
+      case 1: fill_hex<1>(&out->hex1, cols, rows, swap, plain); break;
+      case 2: fill_hex<2>(&out->hex2, cols, rows, swap, plain); break;
+      case 3: fill_hex<3>(&out->hex3, cols, rows, swap, plain); break;
+      default: fill_hex<4>(&out->hex4, cols, rows, swap, plain); break;
+    }
   } else if (name == "kuhn_poker") {
     int n = rd.get_int("players", 2);
     if (!rd.finish()) return set_error(OSG_ERR_INVALID, rd.err);

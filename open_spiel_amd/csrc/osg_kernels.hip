@@ -32,10 +32,15 @@ __global__ void __launch_bounds__(kBlock) k_init(typename G::Params p, typename 
 template <class G>
 __global__ void __launch_bounds__(kBlock)
 k_gather(typename G::Params p, typename G::word_t* dst, int64_t nd, const typename G::word_t* src, int64_t ns,
-         const int64_t* index) {
+         const int64_t* index, unsigned long long* illegal) {
   int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i >= nd) return;
   int64_t j = index[i];
+  if (j < 0 || j >= ns) {  // device-resident indices cannot be checked on the host: initial state + counted
+    G::store(p, dst, nd, i, G::initial(p));
+    atomicAdd(illegal, 1ull);
+    return;
+  }
   for (int k = 0; k < p.words; ++k) dst[k * nd + i] = src[k * ns + j];
 }
 
@@ -804,13 +809,17 @@ int osg_batch_copy(osg_batch* dst, const osg_batch* src) {
 
 int osg_batch_gather(osg_batch* dst, const osg_batch* src, const int64_t* index, int on_host) {
   if (!same_game(dst, src)) return set_error(OSG_ERR_INVALID, "osg_batch_gather: different games");
+  if (!index) return set_error(OSG_ERR_INVALID, "osg_batch_gather: null index");
+  if (on_host)
+    for (int64_t i = 0; i < dst->n; ++i)
+      if (index[i] < 0 || index[i] >= src->n) return set_error(OSG_ERR_INVALID, "osg_batch_gather: index out of range");
   const void* d_index = nullptr;
   int rc = stage_in(dst->ctx, index, sizeof(int64_t) * dst->n, on_host, 0, &d_index);
   if (rc) return rc;
   OSG_DISPATCH(dst->spec, k_gather<G><<<dim3(grid_for(dst->n)), dim3(kBlock), 0, dst->ctx->stream>>>(P,
                                               static_cast<typename G::word_t*>(dst->d_words), dst->n,
                                               static_cast<const typename G::word_t*>(src->d_words), src->n,
-                                              static_cast<const int64_t*>(d_index)));
+                                              static_cast<const int64_t*>(d_index), dst->ctx->d_illegal));
   OSG_HIP(hipGetLastError());
   if (on_host) OSG_HIP(hipStreamSynchronize(dst->ctx->stream));
   return OSG_OK;

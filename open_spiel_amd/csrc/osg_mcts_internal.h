@@ -40,8 +40,9 @@ OSG_D uint32_t make_meta(int action, int player, int nchild) {
 template <bool kBoard>
 OSG_D double outcome_value(uint32_t meta, uint32_t count, double total, int player) {
   if (kBoard) {
-    double v0 = static_cast<double>(m_code(meta) - 1);
-    return player == 0 ? v0 : -v0;
+    // negate as an integer: Returns() of a draw is {0, 0}, never -0.0 (mcts.cc:398-434 stores Returns())
+    const int c0 = m_code(meta) - 1;
+    return static_cast<double>(player == 0 ? c0 : -c0);
   }
   return total / static_cast<double>(count);
 }

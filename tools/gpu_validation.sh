@@ -24,7 +24,7 @@ echo "smoke exit $?" | tee -a "$OUT/summary.txt"
 tail -2 "$OUT/smoke.log" | tee -a "$OUT/summary.txt"
 
 echo "== pytest -m gpu" | tee -a "$OUT/summary.txt"
-timeout 1500 python -m pytest tests -q -m gpu -x --durations=15 > "$OUT/pytest_gpu.log" 2>&1
+timeout 1500 python -m pytest tests -q -m gpu --durations=15 > "$OUT/pytest_gpu.log" 2>&1
 echo "pytest exit $?" | tee -a "$OUT/summary.txt"
 tail -5 "$OUT/pytest_gpu.log" | tee -a "$OUT/summary.txt"
 

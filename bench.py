@@ -4,12 +4,22 @@
 Workload (BASELINE.json configs[1]): 2^20 parallel
 connect_four states per GPU, state i = the initial position advanced by
 hash(i) mod 36 uniformly random legal moves (never terminal), one uniformly
-random legal action per state; seed 0x5EED.  A "step" = ONE launch of the fused
-kernel (legality check + ApplyAction + IsTerminal/CurrentPlayer/outcome +
-LegalActions of the successor) over the whole batch, out of place (src -> dst)
-so that every timed step does identical work.  Inputs are resident in HBM before
-the timed region.  N GPUs = N independent shards of 2^20 states (weak scaling,
-no collective on the data path).
+random legal action per state; seed 0x5EED.  One LAUNCH of the fused kernel
+(legality check + ApplyAction + IsTerminal/CurrentPlayer/outcome + LegalActions
+of the successor) passes once over the whole batch, out of place (src -> dst) so
+that every launch does identical work.  A bench "step" = LAUNCHES_PER_STEP (100)
+back-to-back launches, so that the timed region is long enough not to depend on
+how few steps the caller asks for (a single launch lasts ~7 us); env-steps are
+counted per launch.  Inputs are resident in HBM before the timed region.
+N GPUs = N independent shards of 2^20 states (weak scaling, no collective on the
+data path).
+
+Beside the headline the line carries, all measured live in this process:
+  roofline            the 2^20-state launch (36.7 MB: resident in the 256 MiB Infinity Cache, labelled so),
+                      with the plain-copy time of the same bytes as `copy_ceiling`;
+  roofline.dram_leg   the same kernel over 2^24 states (587 MB per launch, beyond every cache) with its own
+                      copy ceiling: the DRAM-true figure;
+  persistent          K = 32 random env steps per launch with the state in registers (osg_random_steps).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -26,6 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 STATES_PER_GPU = 1 << 20
+DRAM_LEG_STATES = 1 << 24         # 587 MB per launch: beyond the 256 MiB Infinity Cache
+LAUNCHES_PER_STEP = 100           # one bench "step" = this many back-to-back launches over the batch
 SEED = 0x5EED
 ALGO_BYTES_PER_STEP = 35          # 16 R + 16 W state, 1 action, 1 mask, 1 status
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec (MI355X_MICROARCH.md)
@@ -279,20 +291,98 @@ def pmc_traffic():
     """HBM bytes per launch of the headline kernel from the committed PMC profile, if any."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
-        return None, None
+        return None, None, None
     with open(path) as f:
         rec = json.load(f)
-    return rec.get("bytes_per_launch"), rec.get("source")
+    return rec.get("bytes_per_launch"), rec.get("source"), (rec.get("dram_leg") or {}).get("bytes_per_launch")
+
+
+def timed_launches(torch, launch, launches, warmup):
+    """Average duration of one launch: HIP events on the launching stream (the context is bound to
+    torch's current stream) around `launches` back-to-back launches, after `warmup` untimed ones."""
+    for _ in range(warmup):
+        launch()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(launches):
+        launch()
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / 1e3 / launches
+
+
+def copy_ceiling(osa, torch, ctx, n, launches, warmup):
+    """Plain 16-byte-per-lane copy of the bytes one launch over n states moves (35 B per state: half read,
+    half written) on the same stream: seconds per copy."""
+    from open_spiel_amd._abi import check, lib
+    half = (ALGO_BYTES_PER_STEP * n // 2) // 16 * 16
+    a = torch.empty(half, dtype=torch.uint8, device="cuda")
+    b = torch.empty(half, dtype=torch.uint8, device="cuda")
+    a.zero_()
+    secs = timed_launches(torch, lambda: check(lib().osg_copy_bytes(ctx._h, b.data_ptr(), a.data_ptr(), half)),
+                          launches, warmup)
+    return secs, 2 * half
+
+
+def dram_leg(osa, torch, ctx, src, actions):
+    """The fused step over 2^24 states (the 2^20 positions tiled 16 times): 587 MB per launch, far beyond
+    the 256 MiB Infinity Cache, so every byte comes from / goes to HBM."""
+    n, big = src.n, DRAM_LEG_STATES
+    idx = torch.arange(big, device="cuda", dtype=torch.int64) % n
+    src_big = src.gather(idx)
+    act_big = actions[idx].contiguous()
+    del idx
+    dst_big = osa.StateBatch(ctx, "connect_four", big)
+    mask, status = src_big.step_buffers()
+    secs = timed_launches(torch, lambda: src_big.step(act_big, dst=dst_big, mask=mask, status=status), 100, 20)
+    assert int((status & 0x40).sum().item()) == 0
+    del src_big, dst_big, mask, status, act_big
+    csecs, cbytes = copy_ceiling(osa, torch, ctx, big, 100, 20)
+    achieved = ALGO_BYTES_PER_STEP * big / secs / 1e9
+    copy_gbs = cbytes / csecs / 1e9
+    return {"states": big, "bound": "hbm", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * big,
+            "avg_launch_us": secs * 1e6, "launches": 100, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "copy_ceiling": {"gbs": copy_gbs, "us": csecs * 1e6, "bytes": cbytes,
+                             "what": "osg_copy_bytes: plain uint4 copy of the same number of bytes, same stream"},
+            "frac_of_copy_ceiling": achieved / copy_gbs}
+
+
+def persistent_leg(osa, torch, ctx, src, rank):
+    """SURVEY.md 8(d) item 2, second figure: K = 32 uniformly random env steps per launch with the state
+    in registers (osg_random_steps: on-device sampling, auto-reset of finished games)."""
+    b = src.clone()
+    counters = torch.zeros(2, dtype=torch.int64, device="cuda")
+    k, launches = 32, 20
+    for _ in range(3):
+        b.random_steps(SEED, k, counters, index_offset=rank * src.n)
+    torch.cuda.synchronize()
+    before = int(counters[0].item())
+    t0 = time.perf_counter()
+    for j in range(launches):
+        b.random_steps(SEED + 1 + j, k, counters, index_offset=rank * src.n)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = int(counters[0].item()) - before
+    return {"metric": "env-steps/s, K random steps per launch (state in registers, on-device sampling, auto-reset)",
+            "value": steps / dt, "unit": "env-steps/s", "k": k, "launches": launches, "seconds": dt,
+            "env_steps": steps, "us_per_launch": dt / launches * 1e6,
+            "hbm_bytes_per_env_step": 32.0 / k,
+            "note": "per rank; state read and written once per launch (32 B / K per env step), so this leg is "
+                    "vector-issue bound, not memory bound"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=20,
+                    help=f"timed steps; one step = {LAUNCHES_PER_STEP} launches of the fused kernel over the batch")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--states", type=int, default=STATES_PER_GPU, help="states per GPU (default 2^20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the MCTS / CFR / MCCFR workloads")
+    ap.add_argument("--no-legs", action="store_true", help="skip the DRAM-true and persistent legs")
     args = ap.parse_args()
 
     import torch
@@ -322,8 +412,12 @@ def main():
     dst = osa.StateBatch(ctx, "connect_four", n)
     mask, status = src.step_buffers()
 
-    def one_step():
+    def one_launch():
         src.step(actions, dst=dst, mask=mask, status=status)
+
+    def one_step():
+        for _ in range(LAUNCHES_PER_STEP):
+            one_launch()
 
     for _ in range(args.warmup):
         one_step()
@@ -333,10 +427,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The timed region: exactly K launches, barrier + synchronize on both sides.  Two HIP
-    # events on the launching stream (the context is bound to torch's current stream)
-    # bracket the same K launches: with the stream saturated, (event time / K) is the
-    # kernel's average launch duration, the figure rocprofv3 --stats reports as well.
+    # The timed region: exactly K steps (K x LAUNCHES_PER_STEP launches), barrier + synchronize on both
+    # sides.  Two HIP events on the launching stream (the context is bound to torch's current stream)
+    # bracket the same launches: with the stream saturated, event time / launches is the kernel's
+    # average launch duration, the figure rocprofv3 --stats reports as well.
+    launches = args.steps * LAUNCHES_PER_STEP
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fence()
     t0 = time.perf_counter()
@@ -346,13 +441,23 @@ def main():
     ev1.record()
     fence()
     elapsed = time.perf_counter() - t0
-    avg_kernel_s = ev0.elapsed_time(ev1) / 1e3 / args.steps
+    avg_kernel_s = ev0.elapsed_time(ev1) / 1e3 / launches
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # sanity of the timed result against the oracle-checked status of the first states
     assert int((status & 0x40).sum().item()) == 0, "synthetic actions must all be legal"
+
+    legs = None
+    if not args.no_legs and rank == 0:
+        csecs, cbytes = copy_ceiling(osa, torch, ctx, n, 1000, 100)
+        legs = {"copy": (csecs, cbytes), "persistent": persistent_leg(osa, torch, ctx, src, rank)}
+        free_b, _total = torch.cuda.mem_get_info()
+        if free_b > 4 * ALGO_BYTES_PER_STEP * DRAM_LEG_STATES:
+            legs["dram"] = dram_leg(osa, torch, ctx, src, actions)
+    if world > 1:
+        dist.barrier()
 
     secondary = None
     if not args.no_secondary:
@@ -361,24 +466,41 @@ def main():
                                         with_cpu=(not args.no_cpu_baseline) and world == 1)
 
     if rank == 0:
-        traffic, traffic_source = pmc_traffic()
-        total_steps = n * world * args.steps
-        value = total_steps / elapsed
+        traffic, traffic_source, dram_traffic = pmc_traffic()
+        total_env_steps = n * world * launches
+        value = total_env_steps / elapsed
         achieved = ALGO_BYTES_PER_STEP * n / avg_kernel_s / 1e9
+        roofline = {"bound": "infinity_cache" if ALGO_BYTES_PER_STEP * n < (200 << 20) else "hbm",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                    "kernel": "k_step_c4x2<C4T<6,7,4>>", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * n,
+                    "avg_launch_us": avg_kernel_s * 1e6, "launches_timed": launches,
+                    "peak_note": "peak = HBM3E spec 8 TB/s (the denominator BASELINE.json names); one launch moves "
+                                 f"{ALGO_BYTES_PER_STEP * n / 1e6:.1f} MB, which stays resident in the 256 MiB Infinity "
+                                 "Cache between launches, hence bound = infinity_cache; dram_leg is the HBM-true run"}
+        if legs is not None:
+            csecs, cbytes = legs["copy"]
+            roofline["copy_ceiling"] = {"gbs": cbytes / csecs / 1e9, "us": csecs * 1e6, "bytes": cbytes,
+                                        "what": "osg_copy_bytes: plain uint4 copy of the same number of bytes, same stream"}
+            roofline["frac_of_copy_ceiling"] = achieved / (cbytes / csecs / 1e9)
+            if "dram" in legs:
+                roofline["dram_leg"] = legs["dram"]
+                roofline["dram_leg"]["traffic"] = dram_traffic
         line = {
             "metric": "env-steps/sec (batched LegalActions+ApplyAction+status, connect_four)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic", "collective_backend": backend if world > 1 else None,
             "config": {"workload": f"connect_four fused step, {n} states/GPU (2^{n.bit_length() - 1}), "
-                                   "out-of-place SoA bitboards, seed 0x5EED",
-                       "states_per_gpu": n, "parallelism": f"{world} independent shard(s), no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "k_step_c4x2<C4T<6,7,4>>", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * n,
-                         "avg_launch_us": avg_kernel_s * 1e6,
-                         "note": "2^20 states = 36.7 MB/launch, resident in the 256 MiB Infinity Cache"},
+                                   f"out-of-place SoA bitboards, seed 0x5EED; one step = {LAUNCHES_PER_STEP} "
+                                   f"back-to-back launches over the batch ({LAUNCHES_PER_STEP} x {n} env-steps per GPU)",
+                       "states_per_gpu": n, "launches_per_step": LAUNCHES_PER_STEP,
+                       "env_steps_per_step": n * world * LAUNCHES_PER_STEP,
+                       "parallelism": f"{world} independent shard(s), no collective"},
+            "roofline": roofline,
         }
+        if legs is not None:
+            line["persistent"] = legs["persistent"]
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

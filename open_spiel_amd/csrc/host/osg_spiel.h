@@ -238,7 +238,7 @@ class State {
     return out;
   }
   std::vector<Action> LegalActions(Player player) const {  // spiel.h:366-372
-    if (!IsChanceNode() && !IsTerminal() && player != CurrentPlayer()) return {};
+    if (IsTerminal() || player != CurrentPlayer()) return {};  // at a chance node: only for kChancePlayerId
     return LegalActions();
   }
   std::vector<int> LegalActionsMask() const {  // spiel.cc:518-524

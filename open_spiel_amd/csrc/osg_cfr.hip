@@ -1612,6 +1612,7 @@ extern "C" {
 
 int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg, osg_cfr** out) {
   if (!ctx || !game_string || !cfg || !out) return set_error(OSG_ERR_INVALID, "osg_cfr_create: null argument");
+  if (ctx->closed) return set_error(OSG_ERR_INVALID, "osg_cfr_create: the context was destroyed");
   osg_cfr* s = new osg_cfr;
   s->ctx = ctx;
   s->cfg = *cfg;
@@ -1635,6 +1636,7 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
     delete s;
     return set_error(OSG_ERR_UNSUPPORTED, "outcome sampling: game tree deeper than 32 levels");
   }
+  osg::ctx_retain(ctx);  // from here on the object dies through osg_cfr_destroy, which releases
   hipStream_t st = ctx->stream;
   if ((rc = upload(s->level_off, &s->d_level_off, st)) || (rc = upload(s->parent, &s->d_parent, st)) ||
       (rc = upload(s->first_child, &s->d_first_child, st)) || (rc = upload(s->info, &s->d_info, st)) ||
@@ -1720,6 +1722,7 @@ int osg_cfr_destroy(osg_cfr* s) {
                   s->d_uret, s->d_uprob};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  osg::ctx_release(s->ctx);
   delete s;
   return OSG_OK;
 }

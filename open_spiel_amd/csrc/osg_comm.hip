@@ -104,6 +104,7 @@ int osg_comm_create(osg_ctx* ctx, int rank, int world, const void* id, osg_comm*
   ncclResult_t r = api->CommInitRank(&comm, world, uid, rank);
   if (r != ncclSuccess) return RcclFail(api, "ncclCommInitRank", r);
   osg_comm* c = new osg_comm;
+  osg::ctx_retain(ctx);
   c->ctx = ctx;
   c->comm = comm;
   c->rank = rank;
@@ -120,6 +121,7 @@ int osg_comm_destroy(osg_comm* c) {
     hipStreamSynchronize(c->ctx->stream);
     api->CommDestroy(c->comm);
   }
+  osg::ctx_release(c->ctx);
   delete c;
   return rc;
 }

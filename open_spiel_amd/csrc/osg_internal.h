@@ -53,7 +53,16 @@ struct osg_ctx {
   size_t mcts_pool_bytes = 0;
   double* d_mcts_logs = nullptr;            // log(n) table shared with the host libm
   int mcts_logs_n = 0;
+  // Lifetime: the creator holds one reference, every batch / solver / communicator made on the context
+  // another; osg_ctx_destroy drops the creator's, and the device resources go with the last one, so a
+  // batch destroyed after its context (garbage-collection order in a binding) never touches freed memory.
+  int refs = 1;
+  bool closed = false;
 };
+namespace osg {
+void ctx_retain(osg_ctx* ctx);
+void ctx_release(osg_ctx* ctx);
+}
 
 struct osg_batch {
   osg_ctx* ctx = nullptr;

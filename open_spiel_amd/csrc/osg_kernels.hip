@@ -11,6 +11,7 @@
 #include <type_traits>
 
 #include "osg_internal.h"
+#include "osg_c4_step.h"
 
 using namespace osg;
 
@@ -27,6 +28,12 @@ __global__ void __launch_bounds__(kBlock) k_init(typename G::Params p, typename 
   int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i >= n) return;
   G::store(p, base, n, i, G::initial(p));
+}
+
+// 16 bytes per lane, 4 KiB per workgroup: the plain-copy ceiling (osg_copy_bytes).
+__global__ void __launch_bounds__(256) k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
 }
 
 template <class G>
@@ -142,7 +149,7 @@ k_step(typename G::Params p, const typename G::word_t* src, typename G::word_t* 
 // one multiply for the successor's legal mask; the kernel is then close to the
 // plain-copy time of the same bytes (tools/step_sweep.hip).
 #ifndef OSG_C4STEP_BLOCK
-#define OSG_C4STEP_BLOCK 256
+#define OSG_C4STEP_BLOCK 128
 #endif
 constexpr int kC4StepBlock = OSG_C4STEP_BLOCK;
 template <class G>
@@ -160,47 +167,11 @@ k_step_c4x2(typename G::Params p, const uint64_t* __restrict__ src, uint64_t* __
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     if constexpr (std::is_same<G, C4Std>::value) {
-      // 6 x 7 board, result stored in plane 0's top byte: the whole step as straight-line selects, so the
-      // two states of a lane interleave freely (no exec-mask branches between them).
-      const uint32_t a = (a2 >> (8 * j)) & 0xFFu;
-      const uint32_t flags = static_cast<uint32_t>(x[j] >> 56);
-      const uint64_t X = x[j] & ((1ull << 56) - 1ull), O = o[j];
-      const uint64_t all = X | O;
-      const uint32_t col = a < 7u ? a : 0u;
-      const uint64_t cell = (all + (1ull << (col * 7u))) & (0x3Full << (col * 7u));  // lowest empty cell, 0 if full
-      const bool wants = a != 0xFFu;
-      const bool apply = wants & ((flags & 1u) == 0u) & (a < 7u) & (cell != 0ull);
-      const uint32_t stones = __builtin_popcountll(all);
-      const uint32_t mover = stones & 1u;
-      const uint64_t put = apply ? cell : 0ull;
-      const uint64_t nx = X | (mover ? 0ull : put), no = O | (mover ? put : 0ull);
-      const uint64_t b = mover ? no : nx;  // the mover's stones: the only line that can be new
-      uint64_t hit = 0ull;
-      {
-        uint64_t m;
-        m = b & (b >> 1); hit |= m & (m >> 2);
-        m = b & (b >> 7); hit |= m & (m >> 14);
-        m = b & (b >> 6); hit |= m & (m >> 12);
-        m = b & (b >> 8); hit |= m & (m >> 16);
-      }
-      const uint64_t nall = nx | no;
-      const uint64_t kTop = C4Std::top(p);
-      const bool win = hit != 0ull;
-      const uint32_t stones_after = stones + (apply ? 1u : 0u);
-      const bool done = win | (stones_after == 42u);  // IsFull (connect_four.cc:203-209): all 42 cells taken
-      const uint32_t fresh = done ? (1u | ((win ? mover : 2u) << 1)) : 0u;  // connect_four.cc:138-142
-      const uint32_t nflags = apply ? fresh : flags;
-      const uint64_t M = (1ull << 36) | (1ull << 30) | (1ull << 24) | (1ull << 18) | (1ull << 12) | (1ull << 6) | 1ull;
-      const uint32_t open = static_cast<uint32_t>((((~nall & kTop) >> 5) * M) >> 36);
-      const uint32_t to_move = stones_after & 1u;
-      const uint32_t running = (nflags & 1u) - 1u;  // all ones while the game runs, 0 once it is over
-      // (measured: the mask as arithmetic, the status as a select — 6.65 us; both as arithmetic 6.83 us)
-      const uint32_t st = ((wants & !apply) ? 0x40u : 0u) | ((nflags & 1u) ? (0x80u | ((nflags >> 1) & 3u)) : (to_move + 1u));
-      x[j] = nx | (static_cast<uint64_t>(nflags) << 56);
-      o[j] = no;
-      // a mask instead of a select keeps the multiply out of a branch
-      m2 |= (open & 0x7Fu & running) << (8 * j);
-      s2 |= st << (8 * j);
+      // 6 x 7 board, result stored in plane 0's top byte: the whole step as straight-line selects
+      // (osg_c4_step.h), so the two states of a lane interleave freely (no exec-mask branches).
+      const uint32_t r = c4_fused_step(x[j], o[j], (a2 >> (8 * j)) & 0xFFu);
+      m2 |= (r & 0xFFu) << (8 * j);
+      s2 |= (r >> 8) << (8 * j);
       continue;
     }
     typename G::State s = G::unpack(x[j], o[j]);
@@ -743,16 +714,30 @@ int osg_ctx_create(int device, void* stream, int own_stream, osg_ctx** out) {
   return OSG_OK;
 }
 
+}  // extern "C"
+namespace osg {
+void ctx_retain(osg_ctx* ctx) { __atomic_add_fetch(&ctx->refs, 1, __ATOMIC_RELAXED); }
+void ctx_release(osg_ctx* ctx) {
+  if (__atomic_sub_fetch(&ctx->refs, 1, __ATOMIC_ACQ_REL) != 0) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_illegal) (void)hipFree(ctx->d_illegal);
+  if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+  if (ctx->d_mcts_pool) (void)hipFree(ctx->d_mcts_pool);
+  if (ctx->d_mcts_logs) (void)hipFree(ctx->d_mcts_logs);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+}  // namespace osg
+extern "C" {
+
 int osg_ctx_destroy(osg_ctx* ctx) {
   if (!ctx) return OSG_OK;
-  hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
-  if (ctx->d_illegal) hipFree(ctx->d_illegal);
-  if (ctx->d_scratch) hipFree(ctx->d_scratch);
-  if (ctx->d_mcts_pool) hipFree(ctx->d_mcts_pool);
-  if (ctx->d_mcts_logs) hipFree(ctx->d_mcts_logs);
-  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
-  delete ctx;
+  if (ctx->closed) return set_error(OSG_ERR_INVALID, "osg_ctx_destroy: context already destroyed");
+  ctx->closed = true;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  osg::ctx_release(ctx);
   return OSG_OK;
 }
 
@@ -764,6 +749,7 @@ void* osg_ctx_stream(osg_ctx* ctx) { return ctx->stream; }
 
 int osg_batch_create(osg_ctx* ctx, const char* game_string, int64_t n, osg_batch** out) {
   if (!ctx || !out || n <= 0) return set_error(OSG_ERR_INVALID, "osg_batch_create: bad argument");
+  if (ctx->closed) return set_error(OSG_ERR_INVALID, "osg_batch_create: the context was destroyed");
   osg_batch* b = new osg_batch;
   int rc = parse_game(game_string, &b->spec);
   if (rc) { delete b; return rc; }
@@ -774,14 +760,16 @@ int osg_batch_create(osg_ctx* ctx, const char* game_string, int64_t n, osg_batch
   if (e != hipSuccess) { delete b; return set_error(OSG_ERR_NOMEM, hipGetErrorString(e)); }
   rc = osg_batch_reset(b);
   if (rc) { hipFree(b->d_words); delete b; return rc; }
+  osg::ctx_retain(ctx);
   *out = b;
   return OSG_OK;
 }
 
 int osg_batch_destroy(osg_batch* b) {
   if (!b) return OSG_OK;
-  hipStreamSynchronize(b->ctx->stream);
-  hipFree(b->d_words);
+  (void)hipStreamSynchronize(b->ctx->stream);
+  (void)hipFree(b->d_words);
+  osg::ctx_release(b->ctx);
   delete b;
   return OSG_OK;
 }
@@ -822,6 +810,18 @@ int osg_batch_gather(osg_batch* dst, const osg_batch* src, const int64_t* index,
                                               static_cast<const int64_t*>(d_index), dst->ctx->d_illegal));
   OSG_HIP(hipGetLastError());
   if (on_host) OSG_HIP(hipStreamSynchronize(dst->ctx->stream));
+  return OSG_OK;
+}
+
+int osg_copy_bytes(osg_ctx* ctx, void* d_dst, const void* d_src, int64_t bytes) {
+  if (!ctx || !d_dst || !d_src || bytes < 0 || (bytes & 15) || (reinterpret_cast<uintptr_t>(d_dst) & 15) ||
+      (reinterpret_cast<uintptr_t>(d_src) & 15))
+    return set_error(OSG_ERR_INVALID, "osg_copy_bytes: null / unaligned argument");
+  const int64_t n16 = bytes / 16;
+  if (n16 == 0) return OSG_OK;
+  k_copy16<<<dim3(static_cast<unsigned>((n16 + 255) / 256)), dim3(256), 0, ctx->stream>>>(
+      static_cast<const uint4*>(d_src), static_cast<uint4*>(d_dst), n16);
+  OSG_HIP(hipGetLastError());
   return OSG_OK;
 }
 

@@ -45,8 +45,10 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
   const int root_player = G::current_player(p, root_state);
   META(0) = make_meta(0xFF, root_player, 0);  // mcts.cc:356-357: root = (kInvalidAction, CurrentPlayer(), 1)
   FIRST(0) = 0; PARENT(0) = kNoNode; COUNT(0) = 0; TOTAL(0) = 0.0;
-  uint32_t used = 1;
+  uint32_t used = 1;       // = the reference's nodes_: 1 + the children blocks allocated (mcts.cc:299,354)
+  int gc_limit = kMinGcLimit;
   int sims_done = 0;
+#define REMAP(i) pool.remap[static_cast<int64_t>(i) * NR + r]
 
   for (int sim = 0; sim < cfg.max_simulations; ++sim) {
     Rng trng(cfg.seed ^ kTreeSalt, gr, static_cast<uint64_t>(sim));
@@ -63,7 +65,8 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
       if (m_nchild(meta) == 0) {  // expand: children = Prior(state), shuffled (mcts.cc:281-299)
         const Mask legal = G::legal(p, s);
         const int c = legal.count();
-        if (used + static_cast<uint32_t>(c) > static_cast<uint32_t>(pool.cap)) break;  // pool exhausted: evaluate as a leaf
+        // slots exhausted (unreachable unless the caller's HBM could not hold max_nodes + slack): evaluate as a leaf
+        if (used + static_cast<uint32_t>(c) > static_cast<uint32_t>(pool.cap)) break;
         const uint32_t first = used;
         used += c;
         for (int k = 0; k < c; ++k) {
@@ -169,6 +172,35 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
     const uint32_t rm = META(0);
     if ((m_has_outcome(rm) && !m_terminal(rm)) || m_nchild(rm) == 1) break;  // mcts.cc:437-440
     if (m_terminal(rm)) break;  // a terminal root: nothing to search
+    // ---- GarbageCollect (mcts.cc:441-482): when nodes_ >= max_nodes_, every node with explore_count <
+    // gc_limit_ loses its children.  Visit counts never grow from parent to child, so a node survives
+    // exactly when its parent's count reaches the limit; the survivors are compacted in index order
+    // (children blocks stay contiguous, parents stay below their children).
+    if (pool.gc_nodes > 1 && used >= static_cast<uint32_t>(pool.gc_nodes)) {
+      const uint32_t limit = static_cast<uint32_t>(gc_limit);
+      uint32_t w = 1;
+      REMAP(0) = 0;
+      for (uint32_t i = 1; i < used; ++i) {
+        const bool alive = COUNT(PARENT(i)) >= limit;
+        REMAP(i) = alive ? w : kNoNode;
+        w += alive ? 1u : 0u;
+      }
+      for (uint32_t i = 0; i < used; ++i) {
+        const uint32_t to = REMAP(i);
+        if (to == kNoNode) continue;
+        uint32_t meta = META(i), first = FIRST(i);
+        const uint32_t cnt = COUNT(i), par = PARENT(i);
+        const double tot = TOTAL(i);
+        if (m_nchild(meta) > 0) {
+          if (cnt < limit) { meta &= ~(0xFFu << 12); first = 0; }   // children.clear(); the outcome stays
+          else first = REMAP(first);
+        }
+        META(to) = meta; FIRST(to) = first; COUNT(to) = cnt; TOTAL(to) = tot;
+        PARENT(to) = i == 0 ? kNoNode : REMAP(par);
+      }
+      used = w;
+      gc_limit = next_gc_limit(gc_limit, used, pool.gc_nodes);
+    }
   }
 
   // ---- results: BestChild by CompareFinal (mcts.cc:114-143) + per-action statistics ----
@@ -211,6 +243,7 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
                                                                               : NAN;
     root_stats[r * 4 + 3] = static_cast<double>(sims_done);
   }
+#undef REMAP
 #undef META
 #undef FIRST
 #undef PARENT

@@ -20,9 +20,18 @@ struct Pool {
   uint32_t* parent;
   uint32_t* count;
   double* total;
+  uint32_t* remap;   // old -> new node index during garbage collection; null when GC cannot trigger
   int64_t n_roots;
-  int cap;
+  int cap;           // slots per root
+  int gc_nodes;      // the reference's max_nodes_ (mcts.cc:214): garbage-collect when nodes_ >= gc_nodes; 0 = never
 };
+constexpr int kMinGcLimit = 5;  // mcts.cc:30 MIN_GC_LIMIT
+
+// gc_limit_ *= (nodes_ > max_nodes_ / 2 ? 1.25 : 0.9), as an int, at least MIN_GC_LIMIT (mcts.cc:456-458)
+OSG_D int next_gc_limit(int gc_limit, uint32_t nodes, int max_nodes) {
+  const int g = static_cast<int>(gc_limit * (static_cast<int>(nodes) > max_nodes / 2 ? 1.25 : 0.9));
+  return g > kMinGcLimit ? g : kMinGcLimit;
+}
 
 OSG_D uint32_t m_action(uint32_t m) { return m & 0xFFu; }
 OSG_D int m_player(uint32_t m) { return static_cast<int>((m >> 8) & 15u) - 1; }

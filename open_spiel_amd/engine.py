@@ -132,6 +132,19 @@ class StateBatch:
     def _dev(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.ctx.device)
 
+    def _checked(self, t, dtype, numel, what):
+        """A caller-supplied device buffer handed to a kernel by raw pointer: right dtype, on this
+        context's device, contiguous, exactly `numel` elements — anything else would read or write
+        out of bounds silently."""
+        if not isinstance(t, torch.Tensor):
+            raise OsgError(f"{what}: expected a torch tensor on {self.ctx.device}")
+        if t.dtype != dtype or not t.is_cuda or t.device != self.ctx.device or not t.is_contiguous() \
+                or t.numel() != numel:
+            raise OsgError(f"{what}: need a contiguous {dtype} tensor of {numel} elements on {self.ctx.device}, "
+                           f"got {t.dtype} {tuple(t.shape)} on {t.device}"
+                           f"{'' if t.is_contiguous() else ' (non-contiguous)'}")
+        return t
+
     # -- State::Clone / reset ------------------------------------------------
     def reset(self):
         check(lib().osg_batch_reset(self._h))
@@ -212,12 +225,18 @@ class StateBatch:
 
     # -- tensors -----------------------------------------------------------------
     def observation_tensor(self, player=-1, out=None):
-        out = out if out is not None else self._dev((self.n, self.desc.obs_size), torch.float32)
+        if out is None:
+            out = self._dev((self.n, self.desc.obs_size), torch.float32)
+        else:
+            self._checked(out, torch.float32, self.n * self.desc.obs_size, "observation_tensor(out=)")
         check(lib().osg_observation(self._h, int(player), 0, _ptr(out), 0))
         return out
 
     def information_state_tensor(self, player=-1, out=None):
-        out = out if out is not None else self._dev((self.n, self.desc.info_size), torch.float32)
+        if out is None:
+            out = self._dev((self.n, self.desc.info_size), torch.float32)
+        else:
+            self._checked(out, torch.float32, self.n * self.desc.info_size, "information_state_tensor(out=)")
         check(lib().osg_observation(self._h, int(player), 1, _ptr(out), 0))
         return out
 
@@ -268,6 +287,12 @@ class StateBatch:
         dst = dst or self
         if mask is None or status is None:
             mask, status = self.step_buffers()
+        else:
+            self._checked(mask, torch.uint8, self.n * self.desc.compact_mask_bytes, "step(mask=)")
+            self._checked(status, torch.uint8, self.n, "step(status=)")
+        self._checked(actions_u8, torch.uint8, self.n, "step(actions_u8)")
+        if dst.n != self.n or dst.game_string != self.game_string:
+            raise OsgError("step(dst=): destination batch of a different game or size")
         check(lib().osg_step(self._h, dst._h, _ptr(actions_u8), _ptr(mask), _ptr(status)))
         return mask, status
 

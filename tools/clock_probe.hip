@@ -44,6 +44,40 @@ __global__ void __launch_bounds__(256) k_mix(uint32_t* out, uint32_t seed) {  //
   out[blockIdx.x * 256 + threadIdx.x] = v + s;
 }
 
+__global__ void __launch_bounds__(256) k_shr64(uint32_t* out, uint32_t seed) {
+  uint64_t v = (static_cast<uint64_t>(threadIdx.x + seed) << 32) | 0xFFFFFFFFull;
+  for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) asm volatile("v_lshrrev_b64 %0, 1, %0" : "+v"(v));
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = static_cast<uint32_t>(v);
+}
+__global__ void __launch_bounds__(256) k_alignbit(uint32_t* out, uint32_t seed) {
+  uint32_t v = threadIdx.x + seed;
+  for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) asm volatile("v_alignbit_b32 %0, %1, %0, 7" : "+v"(v) : "v"(seed));
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = v;
+}
+__global__ void __launch_bounds__(256) k_mul24(uint32_t* out, uint32_t seed) {
+  uint32_t v = threadIdx.x + seed;
+  for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(v) : "v"(seed));
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = v;
+}
+__global__ void __launch_bounds__(256) k_add64(uint32_t* out, uint32_t seed) {
+  uint64_t v = threadIdx.x + seed;
+  const uint64_t w = seed;
+  for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(v) : "v"(w));
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = static_cast<uint32_t>(v);
+}
+
 template <class K>
 double time_ms(K kernel, uint32_t* out, int blocks) {
   hipEvent_t a, b;
@@ -75,6 +109,10 @@ int main() {
       {"v_mul_lo_u32 (dependent, 8 waves/SIMD)", time_ms(k_mul, out, blocks), 8 * n},
       {"s_add_u32 (dependent, 8 waves/SIMD)", time_ms(k_salu, out, blocks), 8 * n},
       {"v_add + s_add interleaved (8 + 8 per 16)", time_ms(k_mix, out, blocks), 8 * n},
+      {"v_lshrrev_b64 (dependent, 8 waves/SIMD)", time_ms(k_shr64, out, blocks), 8 * n},
+      {"v_alignbit_b32 (dependent, 8 waves/SIMD)", time_ms(k_alignbit, out, blocks), 8 * n},
+      {"v_mul_u32_u24 (dependent, 8 waves/SIMD)", time_ms(k_mul24, out, blocks), 8 * n},
+      {"v_lshl_add_u64 (dependent, 8 waves/SIMD)", time_ms(k_add64, out, blocks), 8 * n},
   };
   for (auto& r : rows)
     printf("%-44s %8.3f ms  -> %.3f ns per instruction per SIMD (= issue interval / clock); at 4 cycles: %.2f GHz\n",

@@ -44,7 +44,7 @@ head -12 "$OUT/kernel_stats.csv" 2>/dev/null | tee -a "$OUT/summary.txt"
 for C in FETCH_SIZE WRITE_SIZE; do
   echo "== rocprofv3 --pmc $C" | tee -a "$OUT/summary.txt"
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -- \
-    python bench.py --steps 100 --warmup 10 --no-secondary --no-cpu-baseline > "$OUT/pmc_$C.log" 2>&1
+    python bench.py --steps 1 --warmup 1 --no-secondary --no-cpu-baseline > "$OUT/pmc_$C.log" 2>&1
   echo "pmc $C exit $?" | tee -a "$OUT/summary.txt"
 done
 python tools/pmc_traffic.py "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$TAG" > "$OUT/pmc_traffic.log" 2>&1

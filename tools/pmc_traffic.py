@@ -1,31 +1,55 @@
 """Turns two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --output-format csv) of
 `bench.py --no-secondary --no-cpu-baseline` into profiles/pmc_traffic.json and the per-counter summaries.
 FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled for this kernel's 16-byte-per-lane reads as
-MI355X_MICROARCH.md prescribes for gfx950.
+MI355X_MICROARCH.md prescribes for gfx950.  The bench launches the headline kernel at two sizes (2^20
+states = Grid_Size 2^19 threads, and the 2^24-state DRAM leg = 2^23 threads); they are reported separately
+(the top-level keys describe the 2^20 launch, `dram_leg` the 2^24 one).
   python tools/pmc_traffic.py gpurun_out/pmcF gpurun_out/pmcW [round-tag, default r01]
 """
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = "k_step_c4x2"
 TAG = sys.argv[3] if len(sys.argv) > 3 else "r01"
-out = {}
+by_grid = {}
 for d, counter in zip(sys.argv[1:3], ("FETCH_SIZE", "WRITE_SIZE")):
-    vals = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                vals.append(float(r["Counter_Value"]))
-    vals = vals[len(vals) // 10:]  # drop the warm-up launches
-    out[counter] = (len(vals), sum(vals) / len(vals), min(vals), max(vals))
+                by_grid.setdefault(int(r["Grid_Size"]), {}).setdefault(counter, []).append(float(r["Counter_Value"]))
+res = None
+rows = []
+for grid in sorted(by_grid):
+    states = grid * 2  # two states per thread
+    stat = {}
+    for counter, vals in by_grid[grid].items():
+        vals = vals[len(vals) // 10:]  # drop the warm-up launches
+        stat[counter] = (len(vals), sum(vals) / len(vals), min(vals), max(vals))
+        rows.append((states, counter) + stat[counter])
+    if "FETCH_SIZE" not in stat or "WRITE_SIZE" not in stat:
+        continue
+    fetch = stat["FETCH_SIZE"][1] * 1024 * 2
+    write = stat["WRITE_SIZE"][1] * 1024
+    rec = {"kernel": "k_step_c4x2<C4T<6,7,4>>", "states": states, "bytes_per_launch": fetch + write,
+           "fetch_bytes": fetch, "write_bytes": write,
+           "raw": {"FETCH_SIZE_KB": stat["FETCH_SIZE"][1], "WRITE_SIZE_KB": stat["WRITE_SIZE"][1]},
+           "algorithmic_bytes_per_launch": 35 * states,
+           "ratio_to_algorithmic": (fetch + write) / (35 * states),
+           "launches": stat["FETCH_SIZE"][0]}
+    if states == 1 << 20 or res is None:
+        dram = res.get("dram_leg") if res else None
+        res = dict(rec)
+        if dram:
+            res["dram_leg"] = dram
+    if states == 1 << 24:
+        res["dram_leg"] = rec
+res["source"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes of bench.py --no-secondary "
+                 f"--no-cpu-baseline), profiles/{TAG}_pmc_*_k_step_c4x2.csv; FETCH_SIZE doubled per "
+                 "MI355X_MICROARCH.md (gfx950 16 B/lane reads)")
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     with open(os.path.join(ROOT, "profiles", f"{TAG}_pmc_{counter}_k_step_c4x2.csv"), "w") as f:
-        f.write("Kernel_Name,Counter_Name,launches,mean_KB,min_KB,max_KB\n")
-        f.write(f"\"k_step_c4x2<C4T<6,7,4>>\",{counter},{len(vals)},{out[counter][1]},{out[counter][2]},{out[counter][3]}\n")
-fetch = out["FETCH_SIZE"][1] * 1024 * 2
-write = out["WRITE_SIZE"][1] * 1024
-res = {"kernel": "k_step_c4x2<C4T<6,7,4>>", "bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
-       "raw": {"FETCH_SIZE_KB": out["FETCH_SIZE"][1], "WRITE_SIZE_KB": out["WRITE_SIZE"][1]},
-       "algorithmic_bytes_per_launch": 35 << 20,
-       "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, 2^20 states, {out['FETCH_SIZE'][0]} launches "
-                 "each), profiles/{TAG}_pmc_*_k_step_c4x2.csv; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 16 B/lane reads)"}
+        f.write("Kernel_Name,states,Counter_Name,launches,mean_KB,min_KB,max_KB\n")
+        for states, c, cnt, mean, lo, hi in rows:
+            if c == counter:
+                f.write(f"\"k_step_c4x2<C4T<6,7,4>>\",{states},{counter},{cnt},{mean},{lo},{hi}\n")
 json.dump(res, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))

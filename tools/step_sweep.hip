@@ -2,11 +2,13 @@
 // block size, non-temporal accesses).  Not part of the library; used to pick the
 // shipped configuration.  hipcc --offload-arch=gfx950 -O3 -I../open_spiel_amd/csrc step_sweep.hip
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 #include "osg_common.h"
 #include "osg_game_boards.h"
+#include "osg_c4_step.h"
 using namespace osg;
 using G = C4Std;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
@@ -27,7 +29,8 @@ __device__ __forceinline__ uint32_t open_mul(uint64_t x, uint64_t o) {
 }
 template <int V>
 __device__ __forceinline__ void step_v(const G::Params& p, uint64_t& x, uint64_t& o, int a, uint32_t& m, uint32_t& st) {
-  if (V == 3) {  // the shipped logic (osg_kernels.hip k_step_c4x2): result flags in plane 0's top byte
+  if (V == 5) { const uint32_t r = c4_fused_step(x, o, (uint32_t)a); m = r & 0xFF; st = r >> 8; return; }  // round 2: osg_c4_step.h
+  if (V == 3) {  // the round-1 logic (osg_kernels.hip k_step_c4x2): result flags in plane 0's top byte
     G::State s = G::unpack(x, o);
     bool term = G::terminal(p, s);
     bool illegal = false;
@@ -175,6 +178,9 @@ int main(int argc, char** argv) {
   run<8, 128, false>("S=8 B=128", p, src, dst, n, act, mask, st, iters);
   run<8, 64, false>("S=8 B=64", p, src, dst, n, act, mask, st, iters);
   run<2, 256, false, 3>("S=2 B=256 stored-result", p, src, dst, n, act, mask, st, iters);
+  run<2, 256, false, 5>("S=2 B=256 fused-step r2", p, src, dst, n, act, mask, st, iters);
+  run<2, 512, false, 5>("S=2 B=512 fused-step r2", p, src, dst, n, act, mask, st, iters);
+  run<2, 128, false, 5>("S=2 B=128 fused-step r2", p, src, dst, n, act, mask, st, iters);
   run<2, 512, false, 3>("S=2 B=512 stored-result", p, src, dst, n, act, mask, st, iters);
   run<4, 256, false, 3>("S=4 B=256 stored-result", p, src, dst, n, act, mask, st, iters);
   run<2, 256, true, 3>("S=2 B=256 stored-result nt", p, src, dst, n, act, mask, st, iters);
@@ -226,6 +232,35 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1));
     printf("%-28s %8.3f us/launch (plain launches, non-default stream)\n", "S=2 B=256 stored-result", ms * 1e3 / 2000);
+  }
+  {  // two (four) streams, each stepping its own share of the batch: do the boundaries between dependent launches overlap?
+    for (int ns = 2; ns <= 4; ns *= 2) {
+      hipStream_t ss[4];
+      for (int i = 0; i < ns; ++i) CK(hipStreamCreate(&ss[i]));
+      const int64_t h = n / ns;
+      dim3 grid((unsigned)((h / 2 + 255) / 256)), block(256);
+      auto round = [&]() {
+        for (int i = 0; i < ns; ++i)
+          k<2, 256, false, 5><<<grid, block, 0, ss[i]>>>(p, src + 2 * h * i, dst + 2 * h * i, h, act + h * i, mask + h * i, st8 + h * i);
+      };
+      for (int i = 0; i < 50; ++i) round();
+      CK(hipDeviceSynchronize());
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < 2000; ++i) round();
+      CK(hipDeviceSynchronize());
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 2000;
+      printf("%d streams x 1/%d batch        %8.3f us per full-batch step (wall)  %7.1f GB/s algorithmic\n", ns, ns, us, 35.0 * n / us / 1e3);
+    }
+    {
+      dim3 grid((unsigned)((n / 2 + 255) / 256)), block(256);
+      for (int i = 0; i < 50; ++i) k<2, 256, false, 5><<<grid, block>>>(p, src, dst, n, act, mask, st8);
+      CK(hipDeviceSynchronize());
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < 2000; ++i) k<2, 256, false, 5><<<grid, block>>>(p, src, dst, n, act, mask, st8);
+      CK(hipDeviceSynchronize());
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 2000;
+      printf("1 stream, whole batch         %8.3f us per full-batch step (wall)\n", us);
+    }
   }
   return 0;
 }

@@ -206,8 +206,11 @@ typedef struct {
   int32_t max_simulations;
   int32_t n_rollouts;       /* RandomRolloutEvaluator(n_rollouts, seed)            */
   int32_t solve;            /* MCTS-Solver backup (mcts.cc:398-434)                */
-  int32_t max_nodes;        /* node pool per root (children are allocated lazily;
-                               when exhausted, leaves are evaluated without expansion) */
+  int32_t max_nodes;        /* > 0: MCTSBot's max_nodes_ = (max_memory_mb << 20) / sizeof(SearchNode) + 1
+                               (mcts.cc:214): when a tree reaches it, every node visited fewer than
+                               gc_limit_ times loses its children (GarbageCollect, mcts.cc:441-482).
+                               <= 0: no caller limit (the pool holds 16384 nodes per root, or what the
+                               free HBM allows; a tree that outgrows it is collected the same way)   */
   uint64_t seed;
   int64_t index_offset;     /* global index of root 0 (multi-GPU sharding)         */
   int32_t layout;           /* 0 auto; 1 one LANE per root (64 searches per wavefront,

@@ -273,29 +273,51 @@ extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_i
   const int64_t n = roots->n;
   const int A = d.num_distinct_actions;
   const int widest = A > d.max_chance_outcomes ? A : d.max_chance_outcomes;
-  // Node pool: `cap` nodes per root.  Every simulation expands at most one node (<= widest
-  // children), so 1 + max_simulations * widest can never be exhausted; the default is capped
-  // at 16384 nodes per root and at the free HBM.  The pool lives in the context and is reused.
-  int64_t cap = cfg.max_nodes > 0 ? cfg.max_nodes : 1 + static_cast<int64_t>(cfg.max_simulations) * widest;
-  if (cfg.max_nodes <= 0 && cap > 16384) cap = 16384;
+  // Node pool: `cap` slots per root.  A simulation expands at most one node (<= widest children), so
+  // 1 + max_simulations * widest slots can never run out.  cfg.max_nodes > 0 is the reference's max_nodes_
+  // (mcts.cc:214: (max_memory_mb << 20) / sizeof(SearchNode) + 1): the search garbage-collects when
+  // nodes_ >= max_nodes_ (mcts.cc:441-482), and the pool gets the slots one search can hold between two
+  // collections (a collection that frees nothing is followed by ever stricter ones: gc_limit_ grows by a
+  // quarter each time, so at most ~log_1.25(max_simulations / 5) consecutive collections fail).
+  // cfg.max_nodes <= 0: no limit from the caller: the pool gets the slots that can never run out when they fit
+  // in 60 % of the free HBM (288 GB: 2^16 hex(9) roots x 1024 simulations need 130 GB of address space and
+  // touch a twentieth of it), otherwise what fits, and a tree that outgrows it is collected like the
+  // reference collects at that size.
+  const int64_t never = 1 + static_cast<int64_t>(cfg.max_simulations) * widest;
+  const int64_t slack = 32 * static_cast<int64_t>(widest);
+  int64_t cap, gc_nodes = 0;
+  if (cfg.max_nodes > 0 && cfg.max_nodes < never) {
+    gc_nodes = cfg.max_nodes > 2 ? cfg.max_nodes : 2;
+    cap = std::min<int64_t>(never, gc_nodes + slack);
+  } else {
+    cap = never;
+  }
   if (cap < 1 + widest) cap = 1 + widest;
-  const size_t per_node = 24;
-  if (static_cast<size_t>(cap) * n * per_node > ctx->mcts_pool_bytes) {
+  if (static_cast<size_t>(cap) * n * (gc_nodes > 0 ? 28 : 24) > ctx->mcts_pool_bytes) {
     size_t free_b = 0, total_b = 0;
     OSG_HIP(hipMemGetInfo(&free_b, &total_b));
     free_b += ctx->mcts_pool_bytes;  // the old pool is released before the new one is allocated
-    while (static_cast<size_t>(cap) * n * per_node > free_b * 9 / 10 && cap > 1 + widest) cap = cap / 2 + widest;
+    if (gc_nodes > 0) {
+      if (static_cast<size_t>(cap) * n * 28 > free_b * 9 / 10)
+        return set_error(OSG_ERR_NOMEM, "osg_mcts_search: max_nodes slots per root do not fit the free HBM");
+    } else if (static_cast<size_t>(cap) * n * 24 > free_b * 6 / 10) {
+      cap = static_cast<int64_t>(free_b * 6 / 10 / (static_cast<size_t>(n) * 28));
+      if (cap < 2 + 2 * widest) cap = 2 + 2 * widest;
+      gc_nodes = cap - widest;  // collect before a simulation's expansion could overrun the slots
+    }
   }
+  const size_t per_node = gc_nodes > 0 ? 28 : 24;
   cfg.max_nodes = static_cast<int32_t>(cap);
   const size_t slots = static_cast<size_t>(cap) * n;
-  if (slots * per_node > ctx->mcts_pool_bytes) {
+  const size_t pool_bytes = slots * per_node;
+  if (pool_bytes > ctx->mcts_pool_bytes) {
     OSG_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->d_mcts_pool) OSG_HIP(hipFree(ctx->d_mcts_pool));
     ctx->d_mcts_pool = nullptr;
     ctx->mcts_pool_bytes = 0;
-    hipError_t e = hipMalloc(&ctx->d_mcts_pool, slots * per_node);
+    hipError_t e = hipMalloc(&ctx->d_mcts_pool, pool_bytes);
     if (e != hipSuccess) return set_error(OSG_ERR_NOMEM, std::string("MCTS node pool: ") + hipGetErrorString(e));
-    ctx->mcts_pool_bytes = slots * per_node;
+    ctx->mcts_pool_bytes = pool_bytes;
   }
   char* pool_mem = static_cast<char*>(ctx->d_mcts_pool);
   Pool pool;
@@ -304,8 +326,10 @@ extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_i
   pool.first = pool.meta + slots;
   pool.parent = pool.first + slots;
   pool.count = pool.parent + slots;
+  pool.remap = gc_nodes > 0 ? pool.count + slots : nullptr;
   pool.n_roots = n;
   pool.cap = static_cast<int>(cap);
+  pool.gc_nodes = static_cast<int>(gc_nodes);
 
   // log(parent explore_count) from the host libm: the CPU oracle (and the reference) call
   // std::log, so sharing the table makes UCT values bit-equal.  Cached in the context.

@@ -403,7 +403,9 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl) {
 #endif
 // The hex fill kernel fits 6 waves per SIMD without spilling; the generic instantiations carry more
 // per-lane state (their playouts run one per lane): 4 waves with a little scratch measured faster than 2-3 without.
-template <class G, bool kBoard, bool kHexFill>
+// kGc: the instantiation that can garbage-collect (mcts.cc:441-482): it also records every node's parent.
+// Kept out of the default instantiation so that the hex kernel's register budget is untouched.
+template <class G, bool kBoard, bool kHexFill, bool kGc>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(kHexFill ? OSG_HEX_WPE : 4, 8)))
 k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, int num_actions,
             osg_mcts_cfg cfg, double max_utility, const double* __restrict__ log_table, Pool pool, MctsOut out) {
@@ -426,6 +428,9 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
   uint32_t* FIRST = pool.first + r * cap;
   uint32_t* COUNT = pool.count + r * cap;
   double* TOTAL = pool.total + r * cap;
+  uint32_t* PARENT = pool.parent + r * cap;  // kGc only
+  uint32_t* REMAP = kGc ? pool.remap + r * cap : nullptr;
+  int gc_limit = kMinGcLimit;
   const uint64_t obase = order_base(cfg.seed, gr);
   HexLane hl{};
   if constexpr (kHexFill) hl = hex_lane_setup<G>(p);
@@ -502,7 +507,8 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
       PT_MARK(0);
       if (m_nchild(meta) == 0) {  // expand: one child per Prior() entry, in action order
         const int c = legal.count();
-        if (used + static_cast<uint32_t>(c) > static_cast<uint32_t>(cap)) break;  // pool exhausted: leaf evaluation
+        // slots exhausted (unreachable unless the caller's HBM could not hold max_nodes + slack): leaf evaluation
+        if (used + static_cast<uint32_t>(c) > static_cast<uint32_t>(cap)) break;
         first = used;
         used += c;
         // Children in action order.  Lane l looks at actions l and l + 64: a legal action's slot is its
@@ -523,6 +529,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
             FIRST[first + rank] = 0;
             COUNT[first + rank] = 0;
             TOTAL[first + rank] = 0.0;
+            if constexpr (kGc) PARENT[first + rank] = node;
           }
         }
         meta = make_meta(m_action(meta), m_player(meta), c) | (meta & 0x00F00000u);
@@ -767,6 +774,49 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
     PT_MARK(6);
     ++sims_done;
     if (m_has_outcome(root_meta) || m_nchild(root_meta) == 1) break;  // mcts.cc:437-440 (a terminal root has an outcome too)
+    // ---- GarbageCollect (mcts.cc:441-482): when nodes_ >= max_nodes_, every node with explore_count <
+    // gc_limit_ loses its children.  Visit counts never grow from parent to child, so a node survives exactly
+    // when its parent's count reaches the limit: 64 nodes per step, a ballot prefix gives the survivors their
+    // new (order-preserving) index, a second sweep moves them down and rewrites the links.
+    if constexpr (kGc) {
+      if (used >= static_cast<uint32_t>(pool.gc_nodes)) {
+        const uint32_t limit = static_cast<uint32_t>(gc_limit);
+        uint32_t w = 0;
+        for (uint32_t i0 = 0; i0 < used; i0 += 64) {
+          const uint32_t i = i0 + lane;
+          bool alive = false;
+          if (i < used) alive = i == 0 || COUNT[PARENT[i]] >= limit;
+          const uint64_t b = __ballot(alive);
+          const uint32_t idx = w + static_cast<uint32_t>(__builtin_popcountll(b & ((1ull << lane) - 1ull)));
+          if (i < used) REMAP[i] = alive ? idx : kNoNode;
+          w += static_cast<uint32_t>(__builtin_popcountll(b));
+        }
+        wave_fence();
+        for (uint32_t i0 = 0; i0 < used; i0 += 64) {
+          const uint32_t i = i0 + lane;
+          uint32_t to = kNoNode, nm = 0, nf = 0, nc = 0, np = kNoNode;
+          double nt = 0.0;
+          if (i < used) to = REMAP[i];
+          if (to != kNoNode) {
+            nm = META[i]; nf = FIRST[i]; nc = COUNT[i]; nt = TOTAL[i];
+            if (i != 0) np = REMAP[PARENT[i]];
+            if (m_nchild(nm) > 0) {
+              if (nc < limit) { nm &= ~(0xFFu << 12); nf = 0; }  // children.clear(); the outcome stays
+              else nf = REMAP[nf];
+            }
+          }
+          wave_fence();  // every load of this step before its stores (targets are <= the sources of this step)
+          if (to != kNoNode) {
+            META[to] = nm; FIRST[to] = nf; COUNT[to] = nc; TOTAL[to] = nt; PARENT[to] = np;
+          }
+          wave_fence();
+        }
+        used = uniform(w);
+        root_meta = uniform(META[0]);
+        root_first = uniform(FIRST[0]);
+        gc_limit = next_gc_limit(gc_limit, used, pool.gc_nodes);
+      }
+    }
   }
 
   PT_FLUSH;
@@ -830,9 +880,14 @@ void launch(const typename G::Params& P, const osg_batch* roots, const osg_mcts_
             const Pool& pool, const MctsOut& out) {
   const osg_game_desc& d = roots->spec.desc;
   const unsigned grid = static_cast<unsigned>((roots->n + kWavesPerBlock - 1) / kWavesPerBlock);
-  k_mcts_wave<G, kBoard, kHexFill><<<dim3(grid), dim3(64 * kWavesPerBlock), 0, roots->ctx->stream>>>(
-      P, static_cast<const typename G::word_t*>(roots->d_words), roots->n, d.num_players, d.num_distinct_actions, cfg,
-      d.max_utility, d_logs, pool, out);
+  if (pool.gc_nodes > 1 && pool.remap)
+    k_mcts_wave<G, kBoard, kHexFill, true><<<dim3(grid), dim3(64 * kWavesPerBlock), 0, roots->ctx->stream>>>(
+        P, static_cast<const typename G::word_t*>(roots->d_words), roots->n, d.num_players, d.num_distinct_actions, cfg,
+        d.max_utility, d_logs, pool, out);
+  else
+    k_mcts_wave<G, kBoard, kHexFill, false><<<dim3(grid), dim3(64 * kWavesPerBlock), 0, roots->ctx->stream>>>(
+        P, static_cast<const typename G::word_t*>(roots->d_words), roots->n, d.num_players, d.num_distinct_actions, cfg,
+        d.max_utility, d_logs, pool, out);
 }
 
 }  // namespace

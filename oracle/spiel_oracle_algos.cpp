@@ -143,7 +143,10 @@ MCTSBot::MCTSBot(const Game& game, std::shared_ptr<Evaluator> evaluator,
                  ChildSelectionPolicy policy, bool dont_return_chance_node)
     : uct_c_(uct_c),
       max_simulations_(max_simulations),
-      max_nodes_(static_cast<int>((max_memory_mb << 20) / sizeof(SearchNode) + 1)),
+      // max_memory_mb < 0: test hook of the restatement — max_nodes_ given directly as -max_memory_mb, so that a
+      // device search (whose nodes are 24 bytes, not sizeof(SearchNode)) can be replayed at the same node budget
+      max_nodes_(max_memory_mb < 0 ? static_cast<int>(-max_memory_mb)
+                                   : static_cast<int>((max_memory_mb << 20) / sizeof(SearchNode) + 1)),
       gc_limit_(5),
       solve_(solve),
       max_utility_(game.MaxUtility()),

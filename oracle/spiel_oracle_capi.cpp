@@ -415,6 +415,7 @@ int osgo_mcts_search(void* s, double uct_c, int max_simulations, int n_rollouts,
                 solve != 0, seed, false, puct ? ChildSelectionPolicy::PUCT : ChildSelectionPolicy::UCT);
 #ifdef OSGO_GENUINE_REFERENCE
     if (counter_root >= 0) Fatal("counter-stream replay is a hook of the restatement, not of the reference");
+    if (max_memory_mb < 0) Fatal("a direct node budget is a hook of the restatement, not of the reference");
     (void)counter_seed; (void)counter_layout;
 #else
     if (counter_root >= 0)

@@ -192,15 +192,54 @@ def test_search_is_independent_of_batch_position_and_sharding(ctx, oracle, layou
 
 
 @pytest.mark.parametrize("layout", [1, 2])
-def test_small_pool_still_searches(ctx, layout):
-    """With a node pool too small to expand everything the search degrades to leaf
-    evaluation instead of failing (the reference garbage-collects, mcts.cc:441-482)."""
-    import open_spiel_amd as osa
-    b = osa.StateBatch(ctx, "connect_four", 128)
-    r = b.mcts_search(max_simulations=300, max_nodes=40, seed=3, layout=layout)
-    stats = r["root_stats"].cpu().numpy()
-    assert (stats[:, 0] == 300).all() and (stats[:, 1] <= 40).all()
-    assert (r["child_visits"].sum(1).cpu().numpy() == 299).all()
+@pytest.mark.parametrize("game,n,sims,max_nodes,solve,max_stop", [
+    ("connect_four", 48, 400, 40, False, 20),        # collects every few simulations, the limit climbs
+    ("connect_four", 32, 600, 200, True, 24),
+    ("tic_tac_toe", 48, 300, 25, True, 4),
+    ("hex(board_size=5)", 32, 500, 120, False, 12),
+    ("hex(board_size=9)", 12, 400, 600, False, 30),
+    ("leduc_poker", 32, 400, 30, False, 7),           # chance nodes in the tree
+    ("kuhn_poker", 32, 200, 8, False, 3),
+])
+def test_mcts_garbage_collection_replay_parity(oracle, ctx, game, n, sims, max_nodes, solve, max_stop, layout):
+    """MCTSBot's node budget (mcts.cc:441-482): when nodes_ >= max_nodes_ every node visited fewer than
+    gc_limit_ times loses its children, gc_limit_ adapts (x1.25 / x0.9, at least 5), cleared nodes are
+    expanded again when the search returns to them.  The oracle's MCTSBot at the same max_nodes_ with every
+    draw from the device's counter streams must produce IDENTICAL root statistics — any difference in when
+    a collection happens, what it removes or how the limit moves changes the visit counts."""
+    min_stop = 2 if "poker" in game else 0
+    og, roots, hists = _roots(oracle, ctx, game, n, 31, max_stop, min_stop)
+    seed, offset = 0x6C6C6563, 777
+    res = roots.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, solve=solve, seed=seed,
+                            index_offset=offset, layout=layout, max_nodes=max_nodes)
+    free = roots.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, solve=solve, seed=seed,
+                             index_offset=offset, layout=layout)
+    best = res["best_action"].cpu().numpy()
+    visits = res["child_visits"].cpu().numpy()
+    reward = res["child_reward"].cpu().numpy()
+    outcome = res["child_outcome"].cpu().numpy()
+    stats = res["root_stats"].cpu().numpy()
+    checked = differs = 0
+    for i in range(n):
+        st = _oracle_state(og, hists[i])
+        if st.is_chance_node() or st.is_terminal():
+            continue
+        want = st.mcts_search(2.0, sims, 1, -max_nodes, solve, 0, counter_root=offset + i, counter_seed=seed,
+                              counter_layout=layout)
+        assert stats[i, 0] == want["root_visits"], f"{game} root {i}: root visits"
+        got_children = np.nonzero(outcome[i] != 3)[0]
+        assert sorted(want["children"][:, 0].astype(int).tolist()) == got_children.tolist(), f"{game} root {i}: children"
+        for a, cnt, tot, out in want["children"]:
+            a = int(a)
+            assert visits[i, a] == cnt, f"{game} root {i} action {a}: visits {visits[i, a]} vs {cnt}"
+            assert reward[i, a] == tot, f"{game} root {i} action {a}: reward {reward[i, a]} vs {tot}"
+        if len(want["children"]):
+            assert best[i] == want["best_action"], f"{game} root {i}: best action"
+        differs += int((visits[i] != free["child_visits"][i].cpu().numpy()).any())
+        checked += 1
+    assert checked >= n // 3
+    # the budget really bit: with it the searches differ from the unconstrained ones
+    assert differs >= checked // 4, f"{game}: garbage collection changed only {differs} of {checked} searches"
 
 
 def test_hex_fill_playout_matches_sequential_random_play(ctx):

@@ -280,6 +280,30 @@ int osg_cfr_replicas(const osg_cfr* s);
 int osg_cfr_select_replica(osg_cfr* s, int replica);
 /* Restores the iteration counter of a deserialised solver (cfr.h:318-323 deserialisation ctor). */
 int osg_cfr_set_iteration(osg_cfr* s, int iteration);
+/* ExternalSamplingMCCFRSolver::FullUpdateAverage (external_sampling_mccfr.cc:188-231) — AverageType::kFull:
+ * one full-tree pass adding weight * reach_probs[cur_player] * sigma(I)[a] to the cumulative policy of every
+ * decision history, sigma = regret matching of the regrets as they are now.  weight = 1 after each
+ * RunIteration's traversals is the reference; a mini-batch of T trajectories stands for T / P iterations. */
+int osg_mccfr_full_average(osg_cfr* s, double weight);
+
+/* AverageType of an external-sampling solver (external_sampling_mccfr.h:48): 0 kSimple (default), 1 kFull —
+ * the traversals' sampled average-policy terms are dropped and osg_mccfr_iterate ends with
+ * osg_mccfr_full_average(trajectories / P) when the batch holds at least one whole iteration. */
+int osg_mccfr_set_average_type(osg_cfr* s, int average_type);
+
+/* ONE UpdateRegrets(root, player, rng) (external_sampling_mccfr.cc:122-186) whose uniforms are
+ * h_uniforms[0], h_uniforms[1], ... in visiting order instead of the counter stream — with the doubles
+ * std::uniform_real_distribution<double>(0, 1) draws from the caller's std::mt19937 this IS the reference's
+ * traversal, draw for draw (RunIteration(std::mt19937*), external_sampling_mccfr.h:63-100).  Fills the
+ * delta tables like osg_mccfr_sample (fold with osg_mccfr_apply_deltas); *consumed = uniforms used. */
+int osg_mccfr_sample_uniforms(osg_cfr* s, int player, const double* h_uniforms, int n, int32_t* consumed);
+
+/* CFRBRSolver::EvaluateAndUpdatePolicy (cfr_br.cc:48-83) x iters on a CFRSolverBase table (solver 0,
+ * no linear averaging, no RM+): every player's best response to the current policy
+ * (TabularBestResponse, best_response.cc:194-227), one regret / average-policy pass per player with
+ * the other players following their best responses, ApplyRegretMatching. */
+int osg_cfr_br_iterate(osg_cfr* s, int iters);
+
 /* ExternalSamplingMCCFRSolver::RunIteration (external_sampling_mccfr.cc:71-186,
  * AverageType::kSimple) for `trajectories` traverser passes (player = global
  * trajectory index mod P), mini-batched: every trajectory of one call reads the

@@ -117,6 +117,10 @@ SIGNATURES = {
     "osg_cfr_select_replica": (INT, [VP, INT]),
     "osg_mccfr_sample": (INT, [VP, U64, I64, I64]),
     "osg_cfr_upload_tables": (INT, [VP, VP, VP, VP]),
+    "osg_mccfr_set_average_type": (INT, [VP, INT]),
+    "osg_mccfr_sample_uniforms": (INT, [VP, INT, VP, INT, C.POINTER(C.c_int32)]),
+    "osg_mccfr_full_average": (INT, [VP, C.c_double]),
+    "osg_cfr_br_iterate": (INT, [VP, INT]),
     "osg_mccfr_iterate": (INT, [VP, U64, I64, I64]),
     "osg_cfr_table_ptrs": (INT, [VP, C.POINTER(VP), C.POINTER(VP), C.POINTER(VP)]),
     "osg_mccfr_delta_ptrs": (INT, [VP, C.POINTER(VP), C.POINTER(VP)]),

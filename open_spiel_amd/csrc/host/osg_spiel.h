@@ -29,6 +29,7 @@
 #include <sstream>
 #include <limits>
 #include <memory>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -771,6 +772,17 @@ class CFRPlusSolver : public CFRSolverBase {  // cfr.h:341-357
  protected:
   std::string SerializeThisType() const override { return "CFRPlusSolver"; }
 };
+// cfr_br.h:34-56: every player minimises regret against the other players' best responses to the current
+// policy (cfr_br.cc:48-83).  Best responses, the per-player passes and the regret matching all run on the device.
+class CFRBRSolver : public CFRSolverBase {
+ public:
+  explicit CFRBRSolver(const Game& game) : CFRSolverBase(game, false, false, false) {}
+  void EvaluateAndUpdatePolicy() { Check(osg_cfr_br_iterate(s_, 1)); }
+  void EvaluateAndUpdatePolicy(int iterations) { Check(osg_cfr_br_iterate(s_, iterations)); }
+
+ protected:
+  std::string SerializeThisType() const override { return "CFRBRSolver"; }  // cfr_br.h:45
+};
 
 // PartiallyDeserializeCFRSolver + Deserialize{CFR,CFRPlus}Solver (cfr.cc:699-781).  Deviation: the
 // reference rebuilds a CFRPlusSolver with linear_averaging = regret_matching_plus = false
@@ -820,6 +832,10 @@ inline std::unique_ptr<CFRSolver> DeserializeCFRSolver(const std::string& serial
 inline std::unique_ptr<CFRPlusSolver> DeserializeCFRPlusSolver(const std::string& serialized,
                                                                const std::string& delimiter = "<~>") {
   return DeserializeSolver<CFRPlusSolver>(serialized, "CFRPlusSolver", delimiter);
+}
+inline std::unique_ptr<CFRBRSolver> DeserializeCFRBRSolver(const std::string& serialized,
+                                                           const std::string& delimiter = "<~>") {  // cfr_br.cc:85-96
+  return DeserializeSolver<CFRBRSolver>(serialized, "CFRBRSolver", delimiter);
 }
 
 // algorithms::Exploitability / NashConv / ExpectedReturns of a tabular policy
@@ -929,14 +945,40 @@ inline PartialCheckpoint PartiallyDeserializeSolver(const std::string& serialize
 class ExternalSamplingMCCFRSolver : public DeviceTabularSolver {  // external_sampling_mccfr.h:57-113
  public:
   explicit ExternalSamplingMCCFRSolver(const Game& game, int seed = 0, AverageType avg_type = AverageType::kSimple)
-      : DeviceTabularSolver(game, true, false, false, 1), seed_(seed), game_string_(game.Serialize()) {
-    if (avg_type != AverageType::kSimple) SpielFatalError("the device ES-MCCFR implements AverageType::kSimple");
+      : DeviceTabularSolver(game, true, false, false, 1), seed_(seed), avg_type_(avg_type),
+        game_string_(game.Serialize()) {
+    Check(osg_mccfr_set_average_type(s_, avg_type == AverageType::kFull ? 1 : 0));
   }
-  // One UpdateRegrets per player, each seeing the previous one's update (:71-80).
+  // One UpdateRegrets per player, each seeing the previous one's update, then — AverageType::kFull — one
+  // FullUpdateAverage (:71-80).  Draws come from the engine's counter streams.
   void RunIteration() {
-    for (int p = 0; p < num_players_; ++p) Check(osg_mccfr_iterate(s_, seed_, next_++, 1));
+    for (int p = 0; p < num_players_; ++p) {
+      Check(osg_mccfr_sample(s_, seed_, next_++, 1));
+      Check(osg_mccfr_apply_deltas(s_));
+    }
+    if (avg_type_ == AverageType::kFull) Check(osg_mccfr_full_average(s_, 1.0));
   }
-  // `trajectories` traverser passes as ONE mini-batch against the current tables.
+  // The same iteration with every draw taken from the caller's generator exactly as the reference takes it
+  // (dist_(*rng), a std::uniform_real_distribution<double>, once per chance node and once per opponent node
+  // in visiting order; external_sampling_mccfr.h:63-100, .cc:122-154): seeded alike, the tables follow the
+  // reference's iteration by iteration.  The traversal runs on the device over a prefix of the generator's
+  // sequence; the generator is then advanced by exactly the draws the traversal used.
+  void RunIteration(std::mt19937* rng) {
+    std::uniform_real_distribution<double> dist(0.0, 1.0);
+    for (int p = 0; p < num_players_; ++p) {
+      std::mt19937 ahead = *rng;
+      const int want = static_cast<int>(std::min<int64_t>(sizes_[0], 1 << 20));  // a traversal visits <= H nodes
+      uniforms_.resize(static_cast<size_t>(want));
+      for (double& u : uniforms_) u = dist(ahead);
+      int32_t used = 0;
+      Check(osg_mccfr_sample_uniforms(s_, p, uniforms_.data(), want, &used));
+      Check(osg_mccfr_apply_deltas(s_));
+      for (int32_t k = 0; k < used; ++k) (void)dist(*rng);
+    }
+    if (avg_type_ == AverageType::kFull) Check(osg_mccfr_full_average(s_, 1.0));
+  }
+  // `trajectories` traverser passes as ONE mini-batch against the current tables (kFull: followed by
+  // FullUpdateAverage weighted by the trajectories / players iterations the batch stands for).
   void RunMiniBatch(int64_t trajectories) {
     Check(osg_mccfr_iterate(s_, seed_, next_, trajectories));
     next_ += trajectories;
@@ -950,7 +992,8 @@ class ExternalSamplingMCCFRSolver : public DeviceTabularSolver {  // external_sa
     str += std::string(kSerializeSolverSpecificStateSectionHeader) + "\n";
     str += std::string(kSerializeSolverRNGSectionHeader) + "\ncounter " + std::to_string(seed_) + " " +
            std::to_string(next_) + "\n";
-    str += std::string(kSerializeSolverAverageTypeSectionHeader) + "\nSimpleAverageType\n";
+    str += std::string(kSerializeSolverAverageTypeSectionHeader) +
+           (avg_type_ == AverageType::kFull ? "\nFullAverageType\n" : "\nSimpleAverageType\n");
     str += std::string(kSerializeSolverDefaultPolicySectionHeader) + "\nUniformPolicy:\n";  // policy.h:330-333
     str += std::string(kSerializeSolverValuesTableSectionHeader) + "\n";
     return str + SerializeValuesTable(InfoStateValuesTable(), double_precision, delimiter);
@@ -978,11 +1021,14 @@ class ExternalSamplingMCCFRSolver : public DeviceTabularSolver {  // external_sa
   }
   void RestoreCounter(uint64_t seed, int64_t next) { seed_ = seed; next_ = next; }
   int64_t TrajectoriesRun() const { return next_; }
+  AverageType average_type() const { return avg_type_; }
 
  private:
   uint64_t seed_;
   int64_t next_ = 0;
+  AverageType avg_type_;
   std::string game_string_;
+  std::vector<double> uniforms_;
 };
 
 class OutcomeSamplingMCCFRSolver : public DeviceTabularSolver {  // outcome_sampling_mccfr.h:40-107
@@ -1050,9 +1096,10 @@ inline std::unique_ptr<ExternalSamplingMCCFRSolver> DeserializeExternalSamplingM
   int64_t next;
   internal::ParseCounter(internal::SpecificLine(c, kSerializeSolverRNGSectionHeader), &seed, &next);
   const std::string avg = internal::SpecificLine(c, kSerializeSolverAverageTypeSectionHeader);
-  if (avg != "SimpleAverageType") SpielFatalError("the device ES-MCCFR implements AverageType::kSimple, not " + avg);
+  if (avg != "SimpleAverageType" && avg != "FullAverageType") SpielFatalError("unknown average type " + avg);
   std::shared_ptr<const Game> game = LoadGame(c.game);
-  auto solver = std::make_unique<ExternalSamplingMCCFRSolver>(*game, static_cast<int>(seed));
+  auto solver = std::make_unique<ExternalSamplingMCCFRSolver>(
+      *game, static_cast<int>(seed), avg == "FullAverageType" ? AverageType::kFull : AverageType::kSimple);
   solver->RestoreCounter(seed, next);
   solver->LoadInfoStateValuesTable(DeserializeValuesTable(c.table, delimiter), /*allow_missing=*/true);
   return solver;

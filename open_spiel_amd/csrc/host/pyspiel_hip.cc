@@ -304,6 +304,14 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def(py::init([](std::shared_ptr<Game> g) { return new CFRPlusSolver(*g); }), py::arg("game"))
       .def(py::pickle([](const CFRPlusSolver& s) { return s.Serialize(); },
                       [](const std::string& t) { return DeserializeCFRPlusSolver(t); }));
+  py::class_<CFRBRSolver, CFRSolverBase>(m, "CFRBRSolver")  // policy.cc:264-298
+      .def(py::init([](std::shared_ptr<Game> g) { return new CFRBRSolver(*g); }), py::arg("game"))
+      .def("evaluate_and_update_policy", py::overload_cast<>(&CFRBRSolver::EvaluateAndUpdatePolicy))
+      .def("evaluate_and_update_policy", py::overload_cast<int>(&CFRBRSolver::EvaluateAndUpdatePolicy),
+           py::arg("iterations"))
+      .def(py::pickle([](const CFRBRSolver& s) { return s.Serialize(); },
+                      [](const std::string& t) { return DeserializeCFRBRSolver(t); }));
+  m.def("deserialize_cfr_br_solver", [](const std::string& t) { return DeserializeCFRBRSolver(t); });
   m.def("deserialize_cfr_solver", [](const std::string& t) { return DeserializeCFRSolver(t); });
   m.def("deserialize_cfr_plus_solver", [](const std::string& t) { return DeserializeCFRPlusSolver(t); });
 
@@ -334,7 +342,15 @@ PYBIND11_MODULE(pyspiel_hip, m) {
              return new ExternalSamplingMCCFRSolver(*g, seed, t);
            }),
            py::arg("game"), py::arg("seed") = 0, py::arg("avg_type") = AverageType::kSimple)
-      .def("run_iteration", &ExternalSamplingMCCFRSolver::RunIteration)
+      .def("run_iteration", py::overload_cast<>(&ExternalSamplingMCCFRSolver::RunIteration))
+      // RunIteration(std::mt19937*): the generator lives in the returned object; seeded like the reference's
+      // ExternalSamplingMCCFRSolver(game, seed, ...) it reproduces that solver's draws one for one
+      .def("run_iterations_mt19937",
+           [](ExternalSamplingMCCFRSolver& s, uint32_t seed, int iterations) {
+             std::mt19937 rng(seed);
+             for (int i = 0; i < iterations; ++i) s.RunIteration(&rng);
+           },
+           py::arg("seed"), py::arg("iterations"))
       .def("run_mini_batch", &ExternalSamplingMCCFRSolver::RunMiniBatch, py::arg("trajectories"))
       .def("average_policy",
            [](const ExternalSamplingMCCFRSolver& s) { return TabularPolicy(s.TabularAveragePolicy()); })

@@ -42,6 +42,7 @@ using namespace osg;
 namespace {
 
 constexpr int kMaxA = 4;        // widest decision node the MCCFR frame holds (kuhn 2, leduc 3)
+constexpr int kMaxPolicyRow = 8;  // widest policy row a thread regret-matches in registers (kuhn 2, leduc 3)
 constexpr int kMaxFrames = 24;  // traverser decision nodes on one path
 constexpr double kMccfrInit = 0.000001;  // external_sampling_mccfr.h:59 kInitialTableValues
 
@@ -87,9 +88,13 @@ OSG_D void regret_match_row(const double* regrets, double* policy, int n) {
 // ---------------------------------------------------------------------------
 // CFRSolverBase::EvaluateAndUpdatePolicy x iters (cfr.cc:263-282), one workgroup.
 // ---------------------------------------------------------------------------
-template <bool kLds>
+// kBr: one CFRBRSolver::EvaluateAndUpdatePolicy pass set (cfr_br.cc:48-83): P passes, pass p updates
+// player p while every other player follows its best-response action best[i] (policy_overrides,
+// cfr.cc:365-372) instead of the current policy.
+template <bool kLds, bool kBr = false>
 __global__ void __launch_bounds__(1024)
-k_cfr(Tree t, Tables tb, double* g_reach, double* g_value, int iters, int iteration0, osg_cfr_cfg cfg) {
+k_cfr(Tree t, Tables tb, double* g_reach, double* g_value, int iters, int iteration0, osg_cfr_cfg cfg,
+      const int32_t* __restrict__ best = nullptr) {
   extern __shared__ double smem[];
   const int P = t.P, S = t.P + 1, A = t.A;
   double* reach = kLds ? smem : g_reach;                       // [H, P+1], chance last (cfr.cc:196,201)
@@ -110,11 +115,16 @@ k_cfr(Tree t, Tables tb, double* g_reach, double* g_value, int iters, int iterat
     }
     __syncthreads();
   }
-  const int passes = cfg.alternating_updates ? P : 1;
+  const int passes = (kBr || cfg.alternating_updates) ? P : 1;
   for (int it = 0; it < iters; ++it) {
     const int iteration = iteration0 + it + 1;  // ++iteration_ (cfr.cc:264)
     for (int pass = 0; pass < passes; ++pass) {
-      const int upd = cfg.alternating_updates ? pass : -1;
+      const int upd = (kBr || cfg.alternating_updates) ? pass : -1;
+      // probability of action index a at infostate i in this pass
+      auto pol_at = [&](int i, int a) -> double {
+        if (kBr && t.info_player[i] != upd) return a == best[i] ? 1.0 : 0.0;
+        return cur[i * A + a];
+      };
       // ---- reach probabilities, top-down (cfr.cc:452-454: new_reach[current_player] *= prob) ----
       for (int l = 0; l < t.D; ++l) {
         for (int h = t.level_off[l] + tid; h < t.level_off[l + 1]; h += nt) {
@@ -125,7 +135,7 @@ k_cfr(Tree t, Tables tb, double* g_reach, double* g_value, int iters, int iterat
           const int par = t.parent[h];
           const int pa = t.actor[par];
           const int slot = pa < 0 ? P : pa;
-          const double pr = t.kind[par] == kChanceNode ? t.edge_prob[h] : cur[t.info[par] * A + t.aidx[h]];
+          const double pr = t.kind[par] == kChanceNode ? t.edge_prob[h] : pol_at(t.info[par], t.aidx[h]);
           for (int q = 0; q < S; ++q) {
             const double r = reach[par * S + q];
             reach[h * S + q] = (q == slot) ? r * pr : r;
@@ -147,12 +157,12 @@ k_cfr(Tree t, Tables tb, double* g_reach, double* g_value, int iters, int iterat
             for (int q = 0; q < P; ++q) pruned &= (reach[h * S + q] == 0.0);
           }
           const int fc = t.first_child[h], nc = t.nchild[h];
-          const int row = k == kDecisionNode ? t.info[h] * A : 0;
+          const int row = k == kDecisionNode ? t.info[h] : 0;
           for (int q = 0; q < P; ++q) {
             double v = 0.0;
             if (!pruned) {
               for (int a = 0; a < nc; ++a) {
-                const double pr = k == kChanceNode ? t.edge_prob[fc + a] : cur[row + a];
+                const double pr = k == kChanceNode ? t.edge_prob[fc + a] : pol_at(row, a);
                 v += pr * value[(fc + a) * P + q];
               }
             }
@@ -694,10 +704,15 @@ k_policy_eval(Tree t, EvalArrays ea, const double* __restrict__ pol) {
 // ---------------------------------------------------------------------------
 OSG_D void add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }  // hardware fp64 atomic (LDS and L2)
 
-template <bool kLdsDelta>
+// kExtU: the uniforms come from a caller-supplied sequence (ext_u[0], ext_u[1], ... in visiting order) instead
+// of the counter stream: with the sequence the reference's std::mt19937 + uniform_real_distribution would
+// produce, one trajectory IS one UpdateRegrets call of the reference, draw for draw
+// (ExternalSamplingMCCFRSolver::RunIteration(std::mt19937*), external_sampling_mccfr.h:63-100).
+template <bool kLdsDelta, bool kExtU = false>
 __global__ void __launch_bounds__(256)
 k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dpol, uint64_t seed,
-        int64_t first, int64_t count) {
+        int64_t first, int64_t count, const double* __restrict__ ext_u = nullptr, int ext_n = 0,
+        int32_t* ext_used = nullptr) {
   extern __shared__ double smem[];
   const int A = t.A, P = t.P, IA = t.I * t.A;
   double* dreg = kLdsDelta ? smem : g_dreg;
@@ -711,6 +726,11 @@ k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dp
     const int64_t g = first + j;
     const int trav = static_cast<int>(g % P);
     Rng rng(seed, static_cast<uint64_t>(g), 0);
+    int uk = 0;
+    auto next_u = [&]() -> double {
+      if (kExtU) { const double u = uk < ext_n ? ext_u[uk] : 0.0; ++uk; return u; }
+      return rng.unit();
+    };
     int f_node[kMaxFrames];
     int f_a[kMaxFrames];
     double f_value[kMaxFrames];
@@ -725,7 +745,7 @@ k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dp
         if (k == kTerminalNode) { ret = t.term_ret[node * P + trav]; break; }
         const int fc = t.first_child[node], nc = t.nchild[node];
         if (k == kChanceNode) {  // SampleAction(ChanceOutcomes(), z) (spiel.cc:372-409)
-          const double z = rng.unit();
+          const double z = next_u();
           int pick = nc - 1;
           double acc = 0.0;
           for (int c = 0; c < nc; ++c) {
@@ -740,7 +760,7 @@ k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dp
         if (t.actor[node] != trav) {  // opponent: sample one action from regret matching (:151-154)
           double pol[kMaxA];
           regret_match_row(regrets + i * A, pol, nc);
-          const double z = rng.unit();
+          const double z = next_u();
           int pick = nc - 1;  // SampleActionIndex(0.0, z) (cfr.cc:617-628)
           double acc = 0.0;
           for (int a = 0; a < nc; ++a) {
@@ -783,6 +803,7 @@ k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dp
       }
       if (done) break;
     }
+    if (kExtU && ext_used) *ext_used = uk;
   }
   if (kLdsDelta) {
     __syncthreads();
@@ -1168,6 +1189,59 @@ k_os_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restr
   resident_flush(dreg, dpol, g_dreg, g_dpol, IA);
 }
 
+// ---------------------------------------------------------------------------
+// ExternalSamplingMCCFRSolver::FullUpdateAverage (external_sampling_mccfr.cc:188-231), AverageType::kFull:
+// a full-tree pass that adds reach_probs[cur_player] * sigma(I)[a] to the cumulative policy of every
+// decision history (sigma = regret matching of the regrets as they are now), skipping histories every
+// player reaches with probability 0.  One workgroup: reach probabilities top-down, one level per step
+// (the products round like the reference's recursion), then one thread per infostate adds its members'
+// terms in DFS order (= the order the recursion reaches them).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_mccfr_full_average(Tree t, const double* __restrict__ regrets, double* cum, double* reach, double weight) {
+  const int P = t.P, A = t.A;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int l = 0; l < t.D; ++l) {
+    for (int h = t.level_off[l] + tid; h < t.level_off[l + 1]; h += nt) {
+      if (l == 0) {
+        for (int q = 0; q < P; ++q) reach[h * P + q] = 1.0;
+        continue;
+      }
+      const int par = t.parent[h];
+      double pr = 1.0;
+      int slot = -1;
+      if (t.kind[par] == kDecisionNode) {
+        const int i = t.info[par];
+        double sigma[kMaxPolicyRow];
+        regret_match_row(regrets + i * A, sigma, t.nact[i]);
+        pr = sigma[t.aidx[h]];
+        slot = t.actor[par];
+      }
+      for (int q = 0; q < P; ++q) {
+        const double r = reach[par * P + q];
+        reach[h * P + q] = (q == slot) ? r * pr : r;
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < t.I; i += nt) {
+    const int pl = t.info_player[i], n = t.nact[i];
+    double sigma[kMaxPolicyRow];
+    regret_match_row(regrets + i * A, sigma, n);
+    for (int m = t.mem_off[i]; m < t.mem_off[i + 1]; ++m) {
+      const int h = t.mem[m];
+      double sum = 0.0;
+      for (int q = 0; q < P; ++q) sum += reach[h * P + q];
+      if (sum == 0.0) continue;  // external_sampling_mccfr.cc:203-205
+      const double own = reach[h * P + pl];
+      for (int a = 0; a < n; ++a) {
+        const double term = own * sigma[a];
+        cum[i * A + a] += weight == 1.0 ? term : weight * term;
+      }
+    }
+  }
+}
+
 __global__ void k_fold_deltas(double* regrets, double* cum, const double* dreg, const double* dpol, int n) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
@@ -1245,6 +1319,7 @@ struct osg_cfr {
   int P = 0, H = 0, I = 0, A = 0, D = 0;
   int64_t n_chance = 0, n_decision = 0, n_terminal = 0;
   int max_level_width = 0;
+  int average_type = 0;  // ES-MCCFR AverageType: 0 kSimple, 1 kFull (external_sampling_mccfr.h:48)
   int iteration = 0;
   // host tree
   std::vector<int32_t> level_off, parent, first_child, info, mem_off, mem, nact, legal;
@@ -1900,16 +1975,104 @@ int osg_mccfr_sample(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_
 int osg_mccfr_apply_deltas(osg_cfr* s) {
   if (!s) return set_error(OSG_ERR_INVALID, "osg_mccfr_apply_deltas: null argument");
   const int IA = s->I * s->A;
+  // AverageType::kFull: the traversals' sampled average-policy terms are not used (external_sampling_mccfr.cc:177);
+  // the average policy comes from osg_mccfr_full_average instead
+  if (s->average_type == 1 && s->cfg.solver == 1)
+    OSG_HIP(hipMemsetAsync(s->dpol(), 0, sizeof(double) * IA, s->ctx->stream));
   k_fold_deltas<<<dim3((IA + 255) / 256), dim3(256), 0, s->ctx->stream>>>(s->regrets(), s->cum(), s->dreg(), s->dpol(), IA);
   OSG_HIP(hipGetLastError());
   ++s->iteration;
   return OSG_OK;
 }
 
+int osg_mccfr_set_average_type(osg_cfr* s, int average_type) {
+  if (!s || (average_type != 0 && average_type != 1)) return set_error(OSG_ERR_INVALID, "osg_mccfr_set_average_type: 0 (kSimple) or 1 (kFull)");
+  if (s->cfg.solver != 1) return set_error(OSG_ERR_INVALID, "osg_mccfr_set_average_type: external-sampling solvers only");
+  s->average_type = average_type;
+  return OSG_OK;
+}
+
+int osg_mccfr_sample_uniforms(osg_cfr* s, int player, const double* h_uniforms, int n, int32_t* consumed) {
+  if (!s || !h_uniforms || n < 1 || !consumed) return set_error(OSG_ERR_INVALID, "osg_mccfr_sample_uniforms: bad argument");
+  if (s->cfg.solver != 1) return set_error(OSG_ERR_INVALID, "osg_mccfr_sample_uniforms: external-sampling solvers only");
+  if (player < 0 || player >= s->P) return set_error(OSG_ERR_INVALID, "osg_mccfr_sample_uniforms: no such player");
+  if (s->A > kMaxA) return set_error(OSG_ERR_UNSUPPORTED, "osg_mccfr_sample_uniforms: decision nodes wider than 4 actions");
+  if (s->B != 1) return set_error(OSG_ERR_UNSUPPORTED, "osg_mccfr_sample_uniforms: one solver per object");
+  const int IA = s->I * s->A;
+  hipStream_t st = s->ctx->stream;
+  void* scratch = nullptr;
+  const size_t bytes = sizeof(double) * static_cast<size_t>(n);
+  int rc = osg_ctx_scratch(s->ctx, bytes + 256, &scratch);
+  if (rc) return rc;
+  double* d_u = static_cast<double*>(scratch);
+  int32_t* d_used = reinterpret_cast<int32_t*>(static_cast<char*>(scratch) + ((bytes + 15) & ~static_cast<size_t>(15)));
+  OSG_HIP(hipMemcpyAsync(d_u, h_uniforms, bytes, hipMemcpyHostToDevice, st));
+  OSG_HIP(hipMemsetAsync(d_used, 0, sizeof(int32_t), st));
+  OSG_HIP(hipMemsetAsync(s->dreg(), 0, sizeof(double) * 2 * IA, st));
+  // trajectory index == player: the traverser is index mod P
+  k_mccfr<false, true><<<dim3(1), dim3(64), 0, st>>>(s->tree(), s->regrets(), s->dreg(), s->dpol(), 0, player, 1, d_u, n, d_used);
+  OSG_HIP(hipGetLastError());
+  OSG_HIP(hipMemcpyAsync(consumed, d_used, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  OSG_HIP(hipStreamSynchronize(st));
+  if (*consumed > n) return set_error(OSG_ERR_INVALID, "osg_mccfr_sample_uniforms: the traversal needed more uniforms than were supplied");
+  return OSG_OK;
+}
+
+int osg_mccfr_full_average(osg_cfr* s, double weight) {
+  if (!s) return set_error(OSG_ERR_INVALID, "osg_mccfr_full_average: null argument");
+  if (s->B != 1) return set_error(OSG_ERR_UNSUPPORTED, "osg_mccfr_full_average: one solver per object");
+  if (s->A > kMaxPolicyRow) return set_error(OSG_ERR_UNSUPPORTED, "osg_mccfr_full_average: policy rows wider than 8 actions");
+  if (!(weight > 0.0)) return set_error(OSG_ERR_INVALID, "osg_mccfr_full_average: weight must be positive");
+  int threads = ((s->max_level_width + 63) / 64) * 64;
+  threads = std::max(64, std::min(threads, 1024));
+  k_mccfr_full_average<<<dim3(1), dim3(threads), 0, s->ctx->stream>>>(s->tree(), s->regrets(), s->cum(), s->d_reach, weight);
+  OSG_HIP(hipGetLastError());
+  return OSG_OK;
+}
+
+int osg_cfr_br_iterate(osg_cfr* s, int iters) {
+  if (!s || iters < 0) return set_error(OSG_ERR_INVALID, "osg_cfr_br_iterate: bad argument");
+  if (s->cfg.solver != 0) return set_error(OSG_ERR_INVALID, "osg_cfr_br_iterate: needs a CFRSolverBase table (solver 0)");
+  if (s->cfg.linear_averaging || s->cfg.regret_matching_plus)
+    return set_error(OSG_ERR_INVALID, "osg_cfr_br_iterate: CFRBRSolver is plain CFR (cfr_br.cc:23-29)");
+  if (s->B != 1) return set_error(OSG_ERR_UNSUPPORTED, "osg_cfr_br_iterate: one solver per object");
+  if (!s->eval_ok) return set_error(OSG_ERR_UNSUPPORTED, "an information state spans several tree levels");
+  const size_t M = s->mem.size();
+  EvalArrays ea;
+  ea.path_off = s->d_path_off; ea.path = s->d_path; ea.info_level = s->d_info_level; ea.mem_index = s->d_mem_index;
+  ea.M = static_cast<int>(M);
+  ea.value = s->d_eval;
+  ea.brv = ea.value + static_cast<size_t>(s->H) * s->P;
+  ea.cf = ea.brv + s->H;
+  ea.out = ea.cf + M;
+  ea.best = s->d_best;
+  int threads = ((s->max_level_width + 63) / 64) * 64;
+  threads = std::max(64, std::min(threads, 1024));
+  osg_cfr_cfg cfg = s->cfg;
+  cfg.alternating_updates = 0;
+  Tables tb{s->regrets(), s->cum(), s->cur()};
+  hipStream_t st = s->ctx->stream;
+  for (int it = 0; it < iters; ++it) {
+    // every player's best response to the current policy (cfr_br.cc:55-68), then one regret / average-policy
+    // pass per player against the others' best responses (cfr_br.cc:70-81) and ApplyRegretMatching
+    k_policy_eval<<<dim3(1), dim3(threads), 0, st>>>(s->tree(), ea, s->cur());
+    k_cfr<false, true><<<dim3(1), dim3(threads), 0, st>>>(s->tree(), tb, s->d_reach, s->d_value, 1, s->iteration, cfg,
+                                                          s->d_best);
+    ++s->iteration;
+  }
+  OSG_HIP(hipGetLastError());
+  return OSG_OK;
+}
+
 int osg_mccfr_iterate(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_t trajectories) {
   int rc = osg_mccfr_sample(s, seed, first_trajectory, trajectories);
   if (rc) return rc;
-  return osg_mccfr_apply_deltas(s);
+  rc = osg_mccfr_apply_deltas(s);
+  if (rc) return rc;
+  // AverageType::kFull: T trajectories stand for T / P iterations, each followed by one FullUpdateAverage
+  if (s->average_type == 1 && s->cfg.solver == 1 && trajectories >= s->P)
+    return osg_mccfr_full_average(s, static_cast<double>(trajectories / s->P));
+  return OSG_OK;
 }
 
 int osg_cfr_table_ptrs(osg_cfr* s, double** d_regrets, double** d_cum_policy, double** d_cur_policy) {

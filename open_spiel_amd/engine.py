@@ -368,6 +368,29 @@ class TabularSolver:
     def evaluate_and_update_policy(self, iters=1):
         check(lib().osg_cfr_iterate(self._h, int(iters)))
 
+    def evaluate_and_update_policy_cfr_br(self, iters=1):
+        """CFRBRSolver.evaluate_and_update_policy (cfr_br.cc:48-83): every player's regret / average-policy pass
+        runs against the other players' best responses to the current policy.  The solver must have been
+        created as plain CFR (no linear averaging, no RM+)."""
+        check(lib().osg_cfr_br_iterate(self._h, int(iters)))
+
+    def set_average_type(self, full):
+        """ES-MCCFR AverageType (external_sampling_mccfr.h:48): False kSimple, True kFull."""
+        check(lib().osg_mccfr_set_average_type(self._h, 1 if full else 0))
+
+    def mccfr_full_average(self, weight=1.0):
+        """FullUpdateAverage (external_sampling_mccfr.cc:188-231) on the tables as they are."""
+        check(lib().osg_mccfr_full_average(self._h, C.c_double(weight)))
+
+    def mccfr_sample_uniforms(self, player, uniforms):
+        """One UpdateRegrets(root, player, rng) whose draws are `uniforms` in visiting order (the sequence the
+        reference's std::mt19937 + uniform_real_distribution would give); returns how many were used.  The
+        deltas are left in mccfr_delta_tables(): fold with mccfr_apply_deltas()."""
+        u = np.ascontiguousarray(uniforms, np.float64)
+        used = C.c_int32(0)
+        check(lib().osg_mccfr_sample_uniforms(self._h, int(player), u.ctypes.data, int(u.size), C.byref(used)))
+        return used.value
+
     def reset(self):
         check(lib().osg_cfr_reset(self._h))
 

@@ -318,7 +318,7 @@ class State:
 
 
 SOLVER_KINDS = {"cfr": 0, "cfr_plus": 1, "mccfr_simple": 2, "mccfr_full": 3, "cfr_simultaneous": 4,
-                "mccfr_outcome": 5}
+                "mccfr_outcome": 5, "cfr_br": 6}
 # CFRSolverBase(game, alternating_updates, linear_averaging, regret_matching_plus) with any switch combination
 for _alt in (0, 1):
     for _lin in (0, 1):
@@ -367,6 +367,10 @@ class Solver:
     def mccfr_minibatch(self, seed, first, count):
         """The device's mini-batch ES-MCCFR schedule on the oracle (frozen table per call)."""
         _check(lib().osgo_mccfr_minibatch(self._h, C.c_uint64(seed), C.c_int64(first), C.c_int64(count)))
+
+    def mccfr_full_average(self):
+        """FullUpdateAverage on the table as it is (the second half of a kFull RunIteration)."""
+        _check(lib().osgo_mccfr_full_average(self._h))
 
     def tables(self, amax=None):
         amax = amax or self.game.num_distinct_actions

@@ -415,7 +415,7 @@ class CFRSolverBase {  // cfr.h:188-304
   CFRSolverBase(const Game& game, bool alternating_updates,
                 bool linear_averaging, bool regret_matching_plus);
   virtual ~CFRSolverBase() = default;
-  void EvaluateAndUpdatePolicy();  // cfr.cc:263-282
+  virtual void EvaluateAndUpdatePolicy();  // cfr.cc:263-282
   std::shared_ptr<Policy> AveragePolicy() const {
     return std::make_shared<CFRAveragePolicy>(info_states_, nullptr);
   }
@@ -445,7 +445,19 @@ class CFRSolverBase {  // cfr.h:188-304
   std::vector<double> root_reach_probs_;
   bool regret_matching_plus_, alternating_updates_, linear_averaging_;
   int chance_player_;
+  // policy_overrides (cfr.cc:331-372): per player, the deterministic best-response action of every one of its
+  // infostates, or null = use the current policy.  Set by CFRBRSolver only.
+  const std::vector<const std::unordered_map<std::string, Action>*>* overrides_ = nullptr;
 };
+// cfr_br.h:34-56, cfr_br.cc:23-83: every player minimises regret against the others' best responses to
+// the current policy.
+class CFRBRSolver : public CFRSolverBase {
+ public:
+  explicit CFRBRSolver(const Game& game) : CFRSolverBase(game, false, false, false) {}
+  void EvaluateAndUpdatePolicy();
+};
+// TabularBestResponse::GetBestResponseActions (best_response.h:106-115) of `responder` against `policy`.
+std::unordered_map<std::string, Action> BestResponseActions(const Game& game, Player responder, const Policy& policy);
 class CFRSolver : public CFRSolverBase {  // cfr.h:310-330
  public:
   explicit CFRSolver(const Game& game)
@@ -471,6 +483,10 @@ class ExternalSamplingMCCFRSolver {  // external_sampling_mccfr.h:57-113
   CFRInfoStateValuesTable& InfoStateValuesTable() { return info_states_; }
   std::shared_ptr<Policy> AveragePolicy() const {
     return std::make_shared<CFRAveragePolicy>(info_states_, default_policy_);
+  }
+  // the second half of a kFull RunIteration (external_sampling_mccfr.cc:76-79) on its own: replay hook
+  void FullUpdateAverageFromRoot() {
+    FullUpdateAverage(*game_->NewInitialState(), std::vector<double>(game_->NumPlayers(), 1.0));
   }
 
  private:

@@ -473,6 +473,10 @@ std::vector<double> CFRSolverBase::ComputeCounterFactualRegret(
     entry = info_states_.find(key);
   }
   std::vector<double> policy = entry->second.current_policy;
+  if (overrides_ && (*overrides_)[cur]) {  // GetInfoStatePolicyFromPolicy (cfr.cc:365-372,411-430)
+    const Action br = (*overrides_)[cur]->at(key);
+    for (size_t a = 0; a < legal.size(); ++a) policy[a] = legal[a] == br ? 1.0 : 0.0;
+  }
 
   std::vector<double> child_utils;
   child_utils.reserve(legal.size());
@@ -843,6 +847,30 @@ struct BRTree {
 double BestResponseValue(const Game& game, Player responder, const Policy& policy) {
   BRTree tree(game, responder, policy);
   return tree.Value(0);
+}
+std::unordered_map<std::string, Action> BestResponseActions(const Game& game, Player responder, const Policy& policy) {
+  BRTree tree(game, responder, policy);
+  tree.Value(0);  // fills the cache "starting at the root" (best_response.h:111-114)
+  for (const auto& kv : tree.infosets) tree.BestAction(kv.first);
+  return tree.best_action;
+}
+
+void CFRBRSolver::EvaluateAndUpdatePolicy() {  // cfr_br.cc:48-83
+  ++iteration_;
+  const int P = game_->NumPlayers();
+  // iteration 1 responds to the uniform policy (cfr_br.cc:59-61) — which is what the current policy of a fresh
+  // table is, row for row
+  std::shared_ptr<Policy> current = CurrentPolicy();
+  std::vector<std::unordered_map<std::string, Action>> br(P);
+  for (int p = 0; p < P; ++p) br[p] = BestResponseActions(*game_, p, *current);
+  std::vector<const std::unordered_map<std::string, Action>*> overrides(P, nullptr);
+  overrides_ = &overrides;
+  for (int p = 0; p < P; ++p) {
+    for (int opp = 0; opp < P; ++opp) overrides[opp] = opp == p ? nullptr : &br[opp];
+    ComputeCounterFactualRegret(*root_state_, p, root_reach_probs_);
+  }
+  overrides_ = nullptr;
+  ApplyRegretMatching();
 }
 double NashConv(const Game& game, const Policy& policy) {
   // tabular_exploitability.cc:60-89

@@ -22,6 +22,7 @@
 
 #ifdef OSGO_GENUINE_REFERENCE
 #include "open_spiel/algorithms/cfr.h"
+#include "open_spiel/algorithms/cfr_br.h"
 #include "open_spiel/algorithms/expected_returns.h"
 #include "open_spiel/algorithms/external_sampling_mccfr.h"
 #include "open_spiel/algorithms/mcts.h"
@@ -470,7 +471,7 @@ int osgo_mcts_selfplay(void* g, double uct_c, int max_simulations, int n_rollout
 // CFR / MCCFR
 // ---------------------------------------------------------------------------
 // kind: 0 CFRSolver, 1 CFRPlusSolver, 2 ES-MCCFR(simple), 3 ES-MCCFR(full),
-// 4 CFRSolverBase(simultaneous updates, no linear avg, no RM+), 5 OS-MCCFR(epsilon 0.6),
+// 4 CFRSolverBase(simultaneous updates, no linear avg, no RM+), 5 OS-MCCFR(epsilon 0.6), 6 CFRBRSolver,
 // 16..23 CFRSolverBase with any switch combination (16 + alternating + 2 * linear averaging + 4 * RM+)
 void* osgo_cfr_create(void* g, int kind, int seed) {
   try {
@@ -479,6 +480,7 @@ void* osgo_cfr_create(void* g, int kind, int seed) {
     if (kind == 0) h->cfr = std::make_unique<CFRSolver>(*h->game);
     else if (kind == 1) h->cfr = std::make_unique<CFRPlusSolver>(*h->game);
     else if (kind == 4) h->cfr = std::make_unique<CFRSolverBase>(*h->game, false, false, false);
+    else if (kind == 6) h->cfr = std::make_unique<CFRBRSolver>(*h->game);
     else if (kind >= 16 && kind < 24)  // 16 + alternating_updates + 2 * linear_averaging + 4 * regret_matching_plus
       h->cfr = std::make_unique<CFRSolverBase>(*h->game, (kind & 1) != 0, (kind & 2) != 0, (kind & 4) != 0);
     else if (kind == 5) h->osmccfr = std::make_unique<OutcomeSamplingMCCFRSolver>(
@@ -567,6 +569,22 @@ int osgo_mccfr_minibatch(void* h, uint64_t seed, int64_t first, int64_t count) {
         kv.second.cumulative_policy[a] += d.cumulative_policy[a];
       }
     }
+    return 0;
+  });
+#endif
+}
+// ExternalSamplingMCCFRSolver::FullUpdateAverage (external_sampling_mccfr.cc:188-231) on the table as it is: the
+// second half of a kFull RunIteration, so that the device's mini-batch + full-average schedule can be replayed.
+int osgo_mccfr_full_average(void* h) {
+#ifdef OSGO_GENUINE_REFERENCE
+  (void)h;
+  g_err = "FullUpdateAverage on its own is a hook of the restatement (it is private in the reference)";
+  return -1;
+#else
+  return Guard([&] {
+    auto* c = static_cast<CfrH*>(h);
+    ORACLE_CHECK(c->mccfr != nullptr);
+    c->mccfr->FullUpdateAverageFromRoot();
     return 0;
   });
 #endif

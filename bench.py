@@ -264,9 +264,17 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
         fence()
         out["mccfr"]["allreduce_us"] = max_over_ranks(time.perf_counter() - t0) / 50 * 1e6
         out["mccfr"]["allreduce_bytes"] = int(flat.numel() * flat.element_size())
+        del flat
     if rank == 0:
         t = solver.tables()
         out["mccfr"]["tables_finite"] = bool((abs(t["regrets"]) < 1e300).all())
+    del solver, sharded
+    # Quality per second (the throughput above says nothing about sample efficiency: a mini-batch shares one
+    # frozen table).  Time — traversal + fold launches only, NashConv evaluations not timed — until the average
+    # policy's NashConv drops below each threshold, at the mini-batch size the sweep in
+    # profiles/r02_mccfr_quality.log found best (2^14), with the table refreshed after every mini-batch.
+    if world == 1:
+        out["mccfr"]["quality"] = mccfr_time_to_nash_conv(osa, torch, ctx, 1 << 14, 1.5)
     if with_cpu and rank == 0:
         impl, kind = cpu_checker()
         threads = host_threads()
@@ -284,7 +292,60 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
         secs = gl.bench_cfr(2, 100000, 1)
         out["mccfr"]["cpu_baseline"] = {"value": 200000 / secs, "unit": "trajectories/s", "cores": 1, "kind": kind,
                                         "sample": f"100000 RunIteration (= 200000 traversals), 1 thread, {secs:.2f} s"}
+        # the same solver by quality: seconds of RunIteration until NashConv <= threshold (about 5 s of CPU work)
+        sol = impl.Solver(gl, "mccfr_simple", SEED)
+        reached, spent, it, step = {}, 0.0, 0, 200
+        while spent < 8.0 and len(reached) < len(NASH_CONV_THRESHOLDS):
+            t0 = time.perf_counter()
+            sol.iterate(step)
+            spent += time.perf_counter() - t0
+            it += step
+            nc = sol.nash_conv()
+            for th in NASH_CONV_THRESHOLDS:
+                if nc <= th and str(th) not in reached:
+                    reached[str(th)] = {"seconds": spent, "iterations": it}
+            step = max(200, it // 4)
+        out["mccfr"]["cpu_baseline"]["quality"] = {
+            "seconds_to_nash_conv": reached, "iterations": it, "seconds": spent, "nash_conv": sol.nash_conv(),
+            "note": "ExternalSamplingMCCFRSolver::RunIteration is sequential by construction: 1 thread"}
+        q = out["mccfr"].get("quality")
+        if q:
+            q["speedup_vs_cpu_at_equal_nash_conv"] = {
+                th: reached[th]["seconds"] / q["seconds_to_nash_conv"][th]["seconds"]
+                for th in reached if th in q["seconds_to_nash_conv"]}
     return out
+
+
+NASH_CONV_THRESHOLDS = (1.0, 0.3, 0.1)
+
+
+def mccfr_time_to_nash_conv(osa, torch, ctx, batch, budget_s):
+    """leduc_poker ES-MCCFR, mini-batches of `batch` trajectories, tables folded after each: seconds of
+    device work until the average policy's NashConv (device judge) is below each threshold."""
+    s = osa.TabularSolver(ctx, "leduc_poker", mccfr=True)
+    s.run_mccfr(SEED, 64)
+    s.reset()
+    torch.cuda.synchronize()
+    reached, spent, updates, first, check = {}, 0.0, 0, 0, 1
+    while spent < budget_s and len(reached) < len(NASH_CONV_THRESHOLDS):
+        todo = check - updates
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(todo):
+            s.run_mccfr(SEED, batch, first_trajectory=first)
+            first += batch
+        torch.cuda.synchronize()
+        spent += time.perf_counter() - t0
+        updates = check
+        nc = s.nash_conv()
+        for th in NASH_CONV_THRESHOLDS:
+            if nc <= th and str(th) not in reached:
+                reached[str(th)] = {"seconds": spent, "mini_batches": updates, "trajectories": updates * batch}
+        check = max(check + 1, int(check * 1.25))
+    return {"mini_batch": batch, "seconds_to_nash_conv": reached, "mini_batches": updates, "seconds": spent,
+            "nash_conv": s.nash_conv(),
+            "schedule": "every mini-batch: 2^14 traversals against the frozen table, one fold; thresholds checked at "
+                        "geometrically spaced mini-batch counts (x1.25), the evaluations are not timed"}
 
 
 def pmc_traffic():

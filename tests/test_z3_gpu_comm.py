@@ -63,3 +63,61 @@ def test_comm_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.osg_allreduce_sum_f64(None, None, 4) != 0
     assert lib.osg_comm_rank(None) == -1 and lib.osg_comm_world(None) == -1
     assert lib.osg_comm_destroy(None) == 0
+
+
+@pytest.mark.gpu
+def test_torch_distributed_nccl_world_size_one_and_the_sharded_solver_path(tmp_path):
+    """RCCL through the OTHER route the product uses: torch.distributed backend "nccl" (= RCCL on ROCm),
+    initialised exactly as bench.py initialises it at N > 1, here with world size 1 — the process group comes
+    up, open_spiel_amd.distributed's all-reduce of the leduc delta tables (2 x [936, 3] fp64 = 44 928 B, the
+    ONE collective of the sharded ES-MCCFR mini-batch) runs on the device and leaves the tables of the
+    unsharded call; the all-reduce and the C-ABI collective are timed on that buffer (printed with -s)."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "ws1.py"
+    script.write_text('''
+import ctypes as C, json, os, sys, time
+sys.path.insert(0, os.environ["OSG_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+import open_spiel_amd as osa
+from open_spiel_amd import distributed as osd
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+assert dist.get_world_size() == 1 and dist.get_backend() == "nccl"
+ctx = osa.Context(0)
+a = osa.TabularSolver(ctx, "leduc_poker", mccfr=True)
+b = osa.TabularSolver(ctx, "leduc_poker", mccfr=True)
+a.run_mccfr(5, 1 << 14)
+sh = osd.ShardedMccfr(b)
+sh.run_minibatch(5, 1 << 14)
+ta, tb = a.tables(), b.tables()
+ok = bool(np.allclose(ta["regrets"], tb["regrets"], rtol=1e-11, atol=1e-11) and
+          np.allclose(ta["cum_policy"], tb["cum_policy"], rtol=1e-11, atol=1e-11))
+flat = b.mccfr_delta_flat()
+t = torch.ones(8, device="cuda"); dist.all_reduce(t); torch.cuda.synchronize()
+for _ in range(20): dist.all_reduce(flat)  # world size 1: RCCL's all-reduce is the identity, but it IS issued
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(200): dist.all_reduce(flat)
+torch.cuda.synchronize(); torch_us = (time.perf_counter() - t0) / 200 * 1e6
+lib = osa.lib()
+uid = C.create_string_buffer(128); assert lib.osg_comm_unique_id(uid) == 0
+comm = C.c_void_p(); assert lib.osg_comm_create(ctx._h, 0, 1, uid, C.byref(comm)) == 0, lib.osg_last_error()
+for _ in range(20): lib.osg_allreduce_sum_f64(comm, C.c_void_p(flat.data_ptr()), flat.numel())
+ctx.synchronize(); t0 = time.perf_counter()
+for _ in range(200): lib.osg_allreduce_sum_f64(comm, C.c_void_p(flat.data_ptr()), flat.numel())
+ctx.synchronize(); abi_us = (time.perf_counter() - t0) / 200 * 1e6
+lib.osg_comm_destroy(comm)
+print(json.dumps({"ok": ok, "bytes": int(flat.numel() * 8), "torch_nccl_allreduce_us": torch_us, "osg_comm_allreduce_us": abi_us}))
+dist.destroy_process_group()
+''')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OSG_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    import json
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    print("world-size-1 collectives on the 44 928-byte delta buffer:", rec)
+    assert rec["ok"] and rec["bytes"] == 44928
+    assert rec["torch_nccl_allreduce_us"] < 5000 and rec["osg_comm_allreduce_us"] < 5000

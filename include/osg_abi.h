@@ -235,6 +235,43 @@ int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg, int32_t* be
                     int32_t* child_visits, double* child_reward, int8_t* child_outcome,
                     double* root_stats, int on_host);
 
+/* ---- MCTS with the Evaluator outside the kernel (Evaluator interface mcts.h:83-92; the batched shape of
+ * alpha_zero_torch/vpevaluator.{h,cc}) ------------------------------------------------------------------
+ * Search trees for every root of a batch that persist between calls.  osg_mcts_tree_advance runs every
+ * search until it needs its evaluator and reports, per root, in d_request [n] u8:
+ *   0 finished (max_simulations run, root proven, or a single root child: mcts.cc:361-366,437-440)
+ *   1 wants Prior(state) of the node it is about to expand (mcts.cc:281-283) — only with flag 1;
+ *     5 (= 1 | 4) when that node is the search's root (where MCTSBot mixes in Dirichlet noise, mcts.cc:284-292)
+ *   2 wants Evaluate(state) of the leaf it has reached (mcts.cc:377-380)
+ *   3 paused by max_new_simulations (more simulations to run; nothing wanted)
+ * The state a request refers to is written to element i of `leaf` (a batch of the roots' game and size, which
+ * also keeps the parked searches' working states: do not modify it between calls).  The next call takes the
+ * answers: d_prior [n, num_distinct_actions] f64 (probability of action a at [i, a]; read for roots that
+ * reported 1) and d_value [n, num_players] f64 (read for roots that reported 2); either may be NULL when no
+ * root reported that request.  h_counts (may be NULL) receives the number of roots per request code [4].
+ * cfg as for osg_mcts_search (layout ignored: one lane per root; the tree-policy streams are those of layout 1,
+ * so with osg_mcts_tree_rollout_values as the evaluator the search is osg_mcts_search's, draw for draw).
+ * flags: 1 = priors come from the caller (else uniform over the legal actions, RandomRolloutEvaluator::Prior
+ * mcts.cc:74-87; chance nodes always use their ChanceOutcomes()); 2 = dont_return_chance_node (mcts.h:168). */
+typedef struct osg_mcts_tree osg_mcts_tree;
+int osg_mcts_tree_create(const osg_batch* roots, const osg_mcts_cfg* cfg, int flags, osg_mcts_tree** out);
+int osg_mcts_tree_destroy(osg_mcts_tree* t);
+int osg_mcts_tree_advance(osg_mcts_tree* t, osg_batch* leaf, const double* d_prior, const double* d_value,
+                          uint8_t* d_request, int max_new_simulations, int64_t* h_counts);
+/* RandomRolloutEvaluator::Evaluate (mcts.cc:43-72) of every leaf that reported request 2, on the streams
+ * of osg_mcts_search: mean Returns() of cfg.n_rollouts playouts into d_value [n, num_players] (device). */
+int osg_mcts_tree_rollout_values(osg_mcts_tree* t, const osg_batch* leaf, double* d_value);
+/* The outputs of osg_mcts_search (device pointers, any may be NULL) plus child_prior [n, A] f64. */
+int osg_mcts_tree_results(osg_mcts_tree* t, int32_t* best_action, int32_t* child_visits, double* child_reward,
+                          int8_t* child_outcome, double* child_prior, double* root_stats);
+/* One root's whole tree for the host (SearchNode, mcts.h:114-146): osg_mcts_tree_nodes = nodes in use;
+ * download fills host arrays of that length: meta (action [0:8) | player + 1 [8:12) | children [12:20) |
+ * has outcome [20] | outcome of player 0 + 1 [21:23) | terminal [23]), index of the first child (children are
+ * contiguous), explore_count, total_reward, prior. */
+int64_t osg_mcts_tree_nodes(osg_mcts_tree* t, int64_t root);
+int osg_mcts_tree_download(osg_mcts_tree* t, int64_t root, int64_t cap, uint32_t* h_meta, uint32_t* h_first,
+                           uint32_t* h_count, double* h_total, double* h_prior);
+
 /* ---- tabular CFR family -------------------------------------------------- */
 typedef struct {
   int32_t alternating_updates;   /* CFRSolverBase ctor (cfr.h:190-196)            */

@@ -106,6 +106,13 @@ SIGNATURES = {
     "osg_random_steps": (INT, [VP, U64, I64, INT, VP]),
     "osg_rollout": (INT, [VP, U64, I64, INT, VP, VP, INT]),
     "osg_mcts_search": (INT, [VP, C.POINTER(MctsCfg), VP, VP, VP, VP, VP, INT]),
+    "osg_mcts_tree_create": (INT, [VP, C.POINTER(MctsCfg), INT, C.POINTER(VP)]),
+    "osg_mcts_tree_destroy": (INT, [VP]),
+    "osg_mcts_tree_advance": (INT, [VP, VP, VP, VP, VP, INT, C.POINTER(I64)]),
+    "osg_mcts_tree_rollout_values": (INT, [VP, VP, VP]),
+    "osg_mcts_tree_results": (INT, [VP, VP, VP, VP, VP, VP, VP]),
+    "osg_mcts_tree_nodes": (I64, [VP, I64]),
+    "osg_mcts_tree_download": (INT, [VP, I64, I64, VP, VP, VP, VP, VP]),
     "osg_cfr_create": (INT, [VP, C.c_char_p, C.POINTER(CfrCfg), C.POINTER(VP)]),
     "osg_cfr_destroy": (INT, [VP]),
     "osg_cfr_sizes": (INT, [VP, C.POINTER(I64)]),

@@ -144,7 +144,7 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
         if (up == kNoNode) { pl = 0; break; }
         pl = m_player(META(up));
       }
-      TOTAL(v) += returns[pl < 0 ? 0 : pl];
+      TOTAL(v) += returns[(pl < 0 || pl >= num_players) ? 0 : pl];  // (a terminal root has no player)
       COUNT(v) += 1;
       if (kBoard && solved && m_nchild(meta) > 0) {  // MCTS-Solver, max^n over proven children
         const uint32_t first = FIRST(v);

@@ -1,0 +1,603 @@
+// algorithms::MCTSBot (open_spiel/algorithms/mcts.{h,cc}) with the Evaluator OUTSIDE the kernel: search
+// trees that persist between launches, advanced until every search needs its evaluator — Prior(state) of
+// the node it is about to expand (mcts.cc:281-283) or Evaluate(state) of the leaf it has reached
+// (mcts.cc:377-380) — and resumed with the answers.  This is the shape of alpha_zero_torch/vpevaluator.{h,cc}
+// turned around for a batch: thousands of searches park their leaves in one [n] batch of states, ONE
+// network forward over osg_observation of that batch answers all of them, the searches resume.
+//
+// One lane per root (the layout of osg_mcts.hip: pool node-major / root-minor, the same counter streams —
+// tree-policy draws from Rng(seed ^ kTreeSalt, root, simulation): the sibling shuffle and the chance
+// sampling — so a search driven through this file with the rollout evaluator is, draw for draw, the fused
+// kernel's search).  Everything else follows mcts.cc as osg_mcts.hip does: lazily expanded children with
+// their priors, UCT / PUCT, chance nodes sampled, backup with the stored parent player, MCTS-Solver,
+// early exit, node budget with GarbageCollect.  Extras of MCTSBot's constructor served here:
+// dont_return_chance_node (mcts.cc:279), priors with Dirichlet noise at the root (the host mixes the noise
+// into the root's prior, mcts.cc:284-292), max_wall_clock_time (the host checks its clock between rounds).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "osg_mcts_internal.h"
+
+using namespace osg;
+
+struct osg_mcts_tree {
+  osg_ctx* ctx = nullptr;
+  osg_batch* roots = nullptr;   // private copy of the root states
+  osg_mcts_cfg cfg{};
+  int flags = 0;
+  int64_t n = 0;
+  int cap = 0, gc_nodes = 0, A = 0, P = 0, widest = 0;
+  double max_utility = 0;
+  bool board = false;
+  char* d_mem = nullptr;        // pool planes + per-root search state
+  size_t bytes = 0;
+  double* d_logs = nullptr;
+  int logs_n = 0;
+};
+
+namespace {
+
+enum Phase : uint8_t { kNewSimulation = 0, kWantPrior = 1, kWantValue = 2, kFinished = 3 };
+
+struct StepPool {
+  double* total;    // [cap, n]
+  double* prior;    // [cap, n]
+  uint32_t* meta;
+  uint32_t* first;
+  uint32_t* parent;
+  uint32_t* count;
+  uint32_t* remap;
+  // per-root search state
+  uint64_t* rng;    // tree-policy stream position of the running simulation
+  uint32_t* used;
+  uint32_t* node;   // the node a parked search waits at
+  int32_t* gc_limit;
+  int32_t* sims;
+  uint8_t* phase;
+  int64_t n;
+  int cap, gc_nodes;
+};
+
+template <class G, bool kBoard>
+__global__ void __launch_bounds__(kBlockM)
+k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typename G::word_t* leaf_words, int64_t n,
+               int num_players, int num_actions, osg_mcts_cfg cfg, int flags, double max_utility,
+               const double* __restrict__ log_table, StepPool pool, const double* __restrict__ prior_in,
+               const double* __restrict__ value_in, uint8_t* __restrict__ request, int max_new_simulations) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlockM + threadIdx.x;
+  if (r >= n) return;
+  const uint64_t gr = static_cast<uint64_t>(cfg.index_offset + r);
+  const int64_t NR = pool.n;
+  const bool host_priors = (flags & 1) != 0, through_chance = (flags & 2) != 0;
+#define META(i) pool.meta[static_cast<int64_t>(i) * NR + r]
+#define FIRST(i) pool.first[static_cast<int64_t>(i) * NR + r]
+#define PARENT(i) pool.parent[static_cast<int64_t>(i) * NR + r]
+#define COUNT(i) pool.count[static_cast<int64_t>(i) * NR + r]
+#define TOTAL(i) pool.total[static_cast<int64_t>(i) * NR + r]
+#define PRIOR(i) pool.prior[static_cast<int64_t>(i) * NR + r]
+#define REMAP(i) pool.remap[static_cast<int64_t>(i) * NR + r]
+  uint8_t phase = pool.phase[r];
+  if (phase == kFinished) { request[r] = 0; return; }
+  uint32_t used = pool.used[r];
+  int gc_limit = pool.gc_limit[r];
+  int sims_done = pool.sims[r];
+  uint32_t node = pool.node[r];
+  Rng trng(0, 0, 0);
+  trng.s = pool.rng[r];
+  const typename G::State root_state = G::load(p, root_words, n, r);
+  typename G::State s = root_state;
+  double returns[kMaxPlayers];
+  bool solved = false;
+  int started = 0;
+  auto park = [&](uint8_t ph, uint8_t req) {
+    pool.phase[r] = ph; pool.used[r] = used; pool.gc_limit[r] = gc_limit; pool.sims[r] = sims_done;
+    pool.node[r] = node; pool.rng[r] = trng.s;
+    request[r] = req;
+  };
+  // expand `node` (mcts.cc:281-299): one child per prior entry, shuffled
+  auto expand = [&](const Mask& legal, int cur, bool from_host) -> bool {
+    const int c = legal.count();
+    if (used + static_cast<uint32_t>(c) > static_cast<uint32_t>(pool.cap)) return false;  // slots exhausted (see osg_mcts.hip)
+    const uint32_t first = used;
+    used += c;
+    for (int k = 0; k < c; ++k) {
+      const int a = select_action(legal, k);
+      double pr;
+      if (cur == kChancePlayer) pr = G::chance_prob(p, s, a);       // Prior() of a chance node: ChanceOutcomes()
+      else if (from_host) pr = prior_in[r * num_actions + a];
+      else pr = 1.0 / c;                                            // RandomRolloutEvaluator::Prior (mcts.cc:74-87)
+      META(first + k) = make_meta(a, cur, 0);
+      FIRST(first + k) = 0; PARENT(first + k) = node; COUNT(first + k) = 0; TOTAL(first + k) = 0.0; PRIOR(first + k) = pr;
+    }
+    for (int i = c - 1; i >= 1; --i) {  // the shuffle (mcts.cc:294), Fisher-Yates on the tree-policy stream
+      const int j = static_cast<int>(trng.below(static_cast<uint32_t>(i + 1)));
+      const uint32_t mi = META(first + i), mj = META(first + j);
+      const double pi = PRIOR(first + i), pj = PRIOR(first + j);
+      META(first + i) = mj; META(first + j) = mi;
+      PRIOR(first + i) = pj; PRIOR(first + j) = pi;
+    }
+    const uint32_t meta = META(node);
+    META(node) = make_meta(m_action(meta), m_player(meta), c) | (meta & 0x00F00000u);
+    FIRST(node) = first;
+    return true;
+  };
+
+  for (;;) {
+    bool term = false;
+    if (phase == kNewSimulation) {
+      if (sims_done >= cfg.max_simulations || started >= max_new_simulations) {
+        const bool fin = sims_done >= cfg.max_simulations;
+        park(fin ? kFinished : kNewSimulation, fin ? 0 : 3);
+        return;
+      }
+      ++started;
+      trng = Rng(cfg.seed ^ kTreeSalt, gr, static_cast<uint64_t>(sims_done));
+      s = root_state;
+      node = 0;
+    } else {  // resume at the parked node: its state is in the leaf batch
+      s = G::load(p, leaf_words, n, r);
+    }
+    if (phase == kWantValue) {
+      for (int q = 0; q < num_players; ++q) returns[q] = value_in[r * num_players + q];
+    } else {
+      // ---- ApplyTreePolicy (mcts.cc:273-351) ----
+      bool resume_expand = phase == kWantPrior;
+      for (;;) {
+        term = G::terminal(p, s);
+        const uint32_t cnt = COUNT(node);
+        const int cur = term ? kTerminalPlayer : G::current_player(p, s);
+        if (!resume_expand && !((!term && cnt > 0) || (!term && cur == kChancePlayer && through_chance))) break;
+        uint32_t meta = META(node);
+        if (m_nchild(meta) == 0) {
+          const Mask legal = G::legal(p, s);
+          if (cur != kChancePlayer && host_priors && !resume_expand) {  // Prior(state) comes from the host
+            G::store(p, leaf_words, n, r, s);
+            park(kWantPrior, node == 0 ? 5 : 1);  // 5 = the ROOT's prior (where Dirichlet noise goes, mcts.cc:284)
+            return;
+          }
+          const bool ok = expand(legal, cur, resume_expand);
+          resume_expand = false;
+          if (!ok) break;
+          meta = META(node);
+        }
+        resume_expand = false;
+        const uint32_t first = FIRST(node);
+        const int c = m_nchild(meta);
+        uint32_t chosen = first;
+        if (cur == kChancePlayer) {  // mcts.cc:311-322
+          const Mask legal = G::legal(p, s);
+          const int a = sample_action_chance<G>(p, s, legal, trng);
+          for (int k = 0; k < c; ++k)
+            if (static_cast<int>(m_action(META(first + k))) == a) { chosen = first + k; break; }
+        } else {  // arg-max of UCTValue / PUCTValue, first maximum wins (mcts.cc:324-341, 90-112)
+          double best = -INFINITY;
+          const double logn = log_table[cnt];
+          const bool puct = cfg.child_selection_policy == 1;
+          const double sqrt_n = sqrt(static_cast<double>(cnt));
+          for (int k = 0; k < c; ++k) {
+            const uint32_t cm = META(first + k);
+            const uint32_t cc = COUNT(first + k);
+            double v;
+            if (m_has_outcome(cm)) v = outcome_value<kBoard>(cm, cc, TOTAL(first + k), m_player(cm));
+            else if (puct) v = (cc != 0 ? TOTAL(first + k) / cc : 0.0) + cfg.uct_c * PRIOR(first + k) * sqrt_n / (cc + 1);
+            else if (cc == 0) v = INFINITY;
+            else v = TOTAL(first + k) / cc + cfg.uct_c * sqrt(logn / cc);
+            if (v > best) { best = v; chosen = first + k; }
+          }
+        }
+        G::apply(p, s, static_cast<int>(m_action(META(chosen))));
+        node = chosen;
+      }
+      // ---- evaluate (mcts.cc:372-381) ----
+      if (term) {
+        G::returns(p, s, returns);
+        uint32_t meta = META(node) | (1u << 20) | (1u << 23);
+        if (kBoard) meta = (meta & ~(3u << 21)) | (static_cast<uint32_t>(static_cast<int>(returns[0]) + 1) << 21);
+        META(node) = meta;
+        solved = cfg.solve != 0;
+      } else {  // Evaluate(state) comes from outside
+        G::store(p, leaf_words, n, r, s);
+        park(kWantValue, 2);
+        return;
+      }
+    }
+    // ---- backup (mcts.cc:383-435) ----
+    for (uint32_t v = node; v != kNoNode; v = PARENT(v)) {
+      uint32_t meta = META(v);
+      int pl = m_player(meta);
+      for (uint32_t up = v; pl == kChancePlayer;) {
+        up = PARENT(up);
+        if (up == kNoNode) { pl = 0; break; }
+        pl = m_player(META(up));
+      }
+      TOTAL(v) += returns[(pl < 0 || pl >= num_players) ? 0 : pl];  // (a terminal root has no player)
+      COUNT(v) += 1;
+      if (kBoard && solved && m_nchild(meta) > 0) {
+        const uint32_t first = FIRST(v);
+        const int c = m_nchild(meta);
+        const int mover = m_player(META(first));
+        bool all_solved = true, have = false;
+        double best = 0.0;
+        int best_code = 0;
+        for (int k = 0; k < c; ++k) {
+          const uint32_t cm = META(first + k);
+          if (!m_has_outcome(cm)) { all_solved = false; continue; }
+          const double val = outcome_value<true>(cm, 1, 0.0, mover);
+          if (!have || val > best) { have = true; best = val; best_code = m_code(cm); }
+        }
+        if (have && (all_solved || best == max_utility)) {
+          META(v) = (meta & ~(3u << 21)) | (1u << 20) | (static_cast<uint32_t>(best_code) << 21);
+        } else {
+          solved = false;
+        }
+      } else if (!kBoard) {
+        solved = false;
+      }
+    }
+    solved = false;
+    ++sims_done;
+    phase = kNewSimulation;
+    const uint32_t rm = META(0);
+    if ((m_has_outcome(rm) && !m_terminal(rm)) || m_nchild(rm) == 1 || m_terminal(rm)) {  // mcts.cc:437-440
+      park(kFinished, 0);
+      return;
+    }
+    if (pool.gc_nodes > 1 && used >= static_cast<uint32_t>(pool.gc_nodes)) {  // GarbageCollect (see osg_mcts.hip)
+      const uint32_t limit = static_cast<uint32_t>(gc_limit);
+      uint32_t w = 1;
+      REMAP(0) = 0;
+      for (uint32_t i = 1; i < used; ++i) {
+        const bool alive = COUNT(PARENT(i)) >= limit;
+        REMAP(i) = alive ? w : kNoNode;
+        w += alive ? 1u : 0u;
+      }
+      for (uint32_t i = 0; i < used; ++i) {
+        const uint32_t to = REMAP(i);
+        if (to == kNoNode) continue;
+        uint32_t meta = META(i), first = FIRST(i);
+        const uint32_t cnt = COUNT(i), par = PARENT(i);
+        const double tot = TOTAL(i), pri = PRIOR(i);
+        if (m_nchild(meta) > 0) {
+          if (cnt < limit) { meta &= ~(0xFFu << 12); first = 0; }
+          else first = REMAP(first);
+        }
+        META(to) = meta; FIRST(to) = first; COUNT(to) = cnt; TOTAL(to) = tot; PRIOR(to) = pri;
+        PARENT(to) = i == 0 ? kNoNode : REMAP(par);
+      }
+      used = w;
+      gc_limit = next_gc_limit(gc_limit, used, pool.gc_nodes);
+    }
+  }
+#undef META
+#undef FIRST
+#undef PARENT
+#undef COUNT
+#undef TOTAL
+#undef PRIOR
+#undef REMAP
+}
+
+// RandomRolloutEvaluator::Evaluate (mcts.cc:43-72) for the parked leaves, on the fused kernel's streams:
+// rollout ro of simulation s of root r draws from Rng(seed, root, s * n_rollouts + ro).
+template <class G>
+__global__ void __launch_bounds__(kBlockM)
+k_mcts_tree_rollout(typename G::Params p, const typename G::word_t* leaf_words, int64_t n, int num_players,
+                    osg_mcts_cfg cfg, const uint8_t* __restrict__ phase, const int32_t* __restrict__ sims, double* value) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlockM + threadIdx.x;
+  if (r >= n || phase[r] != kWantValue) return;
+  const uint64_t gr = static_cast<uint64_t>(cfg.index_offset + r);
+  const typename G::State s = G::load(p, leaf_words, n, r);
+  double sum[kMaxPlayers];
+  for (int q = 0; q < num_players; ++q) sum[q] = 0.0;
+  for (int ro = 0; ro < cfg.n_rollouts; ++ro) {
+    Rng rng(cfg.seed, gr, static_cast<uint64_t>(sims[r]) * cfg.n_rollouts + ro);
+    typename G::State w = s;
+    while (!G::terminal(p, w)) {
+      const Mask m = G::legal(p, w);
+      G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
+    }
+    double rr[kMaxPlayers];
+    G::returns(p, w, rr);
+    for (int q = 0; q < num_players; ++q) sum[q] += rr[q];
+  }
+  for (int q = 0; q < num_players; ++q) value[r * num_players + q] = sum[q] / cfg.n_rollouts;
+}
+
+// Root statistics in the layout of osg_mcts_search's outputs, plus the children's priors.
+template <bool kBoard>
+__global__ void __launch_bounds__(kBlockM)
+k_mcts_tree_results(StepPool pool, int64_t n, int num_actions, int32_t* best_action, int32_t* child_visits,
+                    double* child_reward, int8_t* child_outcome, double* child_prior, double* root_stats) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlockM + threadIdx.x;
+  if (r >= n) return;
+  const int64_t NR = pool.n;
+#define META(i) pool.meta[static_cast<int64_t>(i) * NR + r]
+#define FIRST(i) pool.first[static_cast<int64_t>(i) * NR + r]
+#define COUNT(i) pool.count[static_cast<int64_t>(i) * NR + r]
+#define TOTAL(i) pool.total[static_cast<int64_t>(i) * NR + r]
+#define PRIOR(i) pool.prior[static_cast<int64_t>(i) * NR + r]
+  const uint32_t rm = META(0);
+  const int root_player = m_terminal(rm) ? -1 : m_player(rm);  // a terminal root has no player to move
+  const int c = m_nchild(rm);
+  const uint32_t first = FIRST(0);
+  for (int a = 0; a < num_actions; ++a) {
+    if (child_visits) child_visits[r * num_actions + a] = 0;
+    if (child_reward) child_reward[r * num_actions + a] = 0.0;
+    if (child_outcome) child_outcome[r * num_actions + a] = 3;
+    if (child_prior) child_prior[r * num_actions + a] = 0.0;
+  }
+  int best = -1;
+  double b_out = 0.0, b_tot = 0.0;
+  uint32_t b_cnt = 0;
+  for (int k = 0; k < c; ++k) {
+    const uint32_t cm = META(first + k);
+    const uint32_t cc = COUNT(first + k);
+    const double ct = TOTAL(first + k);
+    const int a = static_cast<int>(m_action(cm));
+    const bool has = m_has_outcome(cm);
+    const int pl = m_player(cm);
+    const double out = (has && pl >= 0 && cc > 0) ? outcome_value<kBoard>(cm, cc, ct, pl)
+                                                  : ((has && kBoard && pl >= 0) ? outcome_value<true>(cm, 1, 0.0, pl) : 0.0);
+    const bool better = best < 0 || (b_out != out ? b_out < out : (b_cnt != cc ? b_cnt < cc : b_tot < ct));
+    if (better) { best = a; b_out = out; b_cnt = cc; b_tot = ct; }
+    if (a < num_actions) {
+      if (child_visits) child_visits[r * num_actions + a] = static_cast<int32_t>(cc);
+      if (child_reward) child_reward[r * num_actions + a] = ct;
+      if (child_prior) child_prior[r * num_actions + a] = PRIOR(first + k);
+      if (child_outcome) {
+        int8_t code = 2;
+        if (has && kBoard && root_player >= 0) code = static_cast<int8_t>(outcome_value<true>(cm, 1, 0.0, root_player));
+        child_outcome[r * num_actions + a] = code;
+      }
+    }
+  }
+  if (best_action) best_action[r] = best;
+  if (root_stats) {
+    root_stats[r * 4 + 0] = static_cast<double>(COUNT(0));
+    root_stats[r * 4 + 1] = static_cast<double>(pool.used[r]);
+    root_stats[r * 4 + 2] = (kBoard && m_has_outcome(rm) && root_player >= 0) ? outcome_value<true>(rm, 1, 0.0, root_player) : NAN;
+    root_stats[r * 4 + 3] = static_cast<double>(pool.sims[r]);
+  }
+#undef META
+#undef FIRST
+#undef COUNT
+#undef TOTAL
+#undef PRIOR
+}
+
+__global__ void __launch_bounds__(256) k_mcts_tree_init(StepPool pool, const int8_t* root_player, int64_t n) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (r >= n) return;
+  pool.meta[r] = make_meta(0xFF, root_player[r], 0);  // mcts.cc:356-357: root = (kInvalidAction, CurrentPlayer(), 1)
+  pool.first[r] = 0; pool.parent[r] = kNoNode; pool.count[r] = 0; pool.total[r] = 0.0; pool.prior[r] = 1.0;
+  pool.rng[r] = 0; pool.used[r] = 1; pool.node[r] = 0; pool.gc_limit[r] = kMinGcLimit; pool.sims[r] = 0;
+  pool.phase[r] = kNewSimulation;
+}
+
+// One root's tree, flattened for the host (SearchNode, mcts.h:114-146).
+__global__ void k_mcts_tree_extract(StepPool pool, int64_t r, uint32_t* meta, uint32_t* first, uint32_t* count, double* total,
+                                    double* prior) {
+  const uint32_t used = pool.used[r];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < used; i += gridDim.x * blockDim.x) {
+    const int64_t at = static_cast<int64_t>(i) * pool.n + r;
+    meta[i] = pool.meta[at]; first[i] = pool.first[at]; count[i] = pool.count[at]; total[i] = pool.total[at];
+    prior[i] = pool.prior[at];
+  }
+}
+
+StepPool make_pool(const osg_mcts_tree* t) {
+  StepPool pool;
+  const size_t slots = static_cast<size_t>(t->cap) * t->n;
+  char* m = t->d_mem;
+  pool.total = reinterpret_cast<double*>(m); m += slots * 8;
+  pool.prior = reinterpret_cast<double*>(m); m += slots * 8;
+  pool.rng = reinterpret_cast<uint64_t*>(m); m += static_cast<size_t>(t->n) * 8;
+  pool.meta = reinterpret_cast<uint32_t*>(m); m += slots * 4;
+  pool.first = reinterpret_cast<uint32_t*>(m); m += slots * 4;
+  pool.parent = reinterpret_cast<uint32_t*>(m); m += slots * 4;
+  pool.count = reinterpret_cast<uint32_t*>(m); m += slots * 4;
+  pool.remap = reinterpret_cast<uint32_t*>(m); m += slots * 4;
+  pool.used = reinterpret_cast<uint32_t*>(m); m += static_cast<size_t>(t->n) * 4;
+  pool.node = reinterpret_cast<uint32_t*>(m); m += static_cast<size_t>(t->n) * 4;
+  pool.gc_limit = reinterpret_cast<int32_t*>(m); m += static_cast<size_t>(t->n) * 4;
+  pool.sims = reinterpret_cast<int32_t*>(m); m += static_cast<size_t>(t->n) * 4;
+  pool.phase = reinterpret_cast<uint8_t*>(m);
+  pool.n = t->n;
+  pool.cap = t->cap;
+  pool.gc_nodes = t->gc_nodes;
+  return pool;
+}
+
+size_t pool_bytes(int64_t cap, int64_t n) {
+  return static_cast<size_t>(cap) * n * 36 + static_cast<size_t>(n) * (8 + 4 * 4 + 1) + 256;
+}
+
+bool same_game(const osg_batch* a, const osg_batch* b) {
+  return a && b && a->n == b->n && std::strcmp(a->spec.desc.canonical, b->spec.desc.canonical) == 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int osg_mcts_tree_create(const osg_batch* roots, const osg_mcts_cfg* cfg_in, int flags, osg_mcts_tree** out) {
+  if (!roots || !cfg_in || !out) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_create: null argument");
+  osg_ctx* ctx = roots->ctx;
+  const osg_game_desc& d = roots->spec.desc;
+  const bool board = d.game_kind <= kHex;
+  if (cfg_in->max_simulations < 1 || cfg_in->n_rollouts < 1)
+    return set_error(OSG_ERR_INVALID, "max_simulations and n_rollouts must be >= 1");
+  if (cfg_in->solve && !board)
+    return set_error(OSG_ERR_UNSUPPORTED, "solve=true needs win/draw/loss outcomes (tic_tac_toe, connect_four, hex)");
+  if (cfg_in->child_selection_policy != 0 && cfg_in->child_selection_policy != 1)
+    return set_error(OSG_ERR_INVALID, "osg_mcts_cfg.child_selection_policy must be 0 (UCT) or 1 (PUCT)");
+  if (flags & ~3) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_create: unknown flag");
+  osg_mcts_tree* t = new osg_mcts_tree;
+  t->ctx = ctx;
+  t->cfg = *cfg_in;
+  t->flags = flags;
+  t->n = roots->n;
+  t->A = d.num_distinct_actions;
+  t->P = d.num_players;
+  t->widest = std::max(d.num_distinct_actions, d.max_chance_outcomes);
+  t->max_utility = d.max_utility;
+  t->board = board;
+  // with dont_return_chance_node a simulation can expand a chain of chance nodes besides its decision node
+  const int64_t per_sim = static_cast<int64_t>(t->widest) * ((flags & 2) ? 1 + std::max(d.max_chance_nodes, 1) : 1);
+  const int64_t never = 1 + static_cast<int64_t>(cfg_in->max_simulations) * per_sim;
+  int64_t cap = never, gc_nodes = 0;
+  if (cfg_in->max_nodes > 0 && cfg_in->max_nodes < never) {
+    gc_nodes = std::max(2, cfg_in->max_nodes);
+    cap = std::min<int64_t>(never, gc_nodes + 32 * per_sim);
+  }
+  size_t free_b = 0, total_b = 0;
+  hipError_t e = hipMemGetInfo(&free_b, &total_b);
+  if (e != hipSuccess) { delete t; return set_error(OSG_ERR_HIP, hipGetErrorString(e)); }
+  if (pool_bytes(cap, t->n) > free_b * 6 / 10) {
+    if (gc_nodes > 0) { delete t; return set_error(OSG_ERR_NOMEM, "osg_mcts_tree_create: max_nodes slots per root do not fit the free HBM"); }
+    cap = static_cast<int64_t>((free_b * 6 / 10 - static_cast<size_t>(t->n) * 32) / (static_cast<size_t>(t->n) * 36));
+    if (cap < 2 + 2 * per_sim) { delete t; return set_error(OSG_ERR_NOMEM, "osg_mcts_tree_create: too many roots for the free HBM"); }
+    gc_nodes = cap - per_sim;
+  }
+  t->cap = static_cast<int>(cap);
+  t->gc_nodes = static_cast<int>(gc_nodes);
+  t->bytes = pool_bytes(cap, t->n);
+  e = hipMalloc(reinterpret_cast<void**>(&t->d_mem), t->bytes);
+  if (e != hipSuccess) { delete t; return set_error(OSG_ERR_NOMEM, std::string("MCTS trees: ") + hipGetErrorString(e)); }
+  int rc = osg_batch_create(ctx, d.canonical, roots->n, &t->roots);
+  if (rc == OSG_OK) rc = osg_batch_copy(t->roots, roots);
+  if (rc) { (void)hipFree(t->d_mem); if (t->roots) osg_batch_destroy(t->roots); delete t; return rc; }
+  // log(parent explore_count) from the host libm, like osg_mcts_search
+  t->logs_n = cfg_in->max_simulations + 2;
+  std::vector<double> logs(t->logs_n);
+  logs[0] = 0.0;
+  for (int i = 1; i < t->logs_n; ++i) logs[i] = std::log(static_cast<double>(i));
+  e = hipMalloc(reinterpret_cast<void**>(&t->d_logs), sizeof(double) * t->logs_n);
+  if (e == hipSuccess) e = hipMemcpy(t->d_logs, logs.data(), sizeof(double) * t->logs_n, hipMemcpyHostToDevice);
+  // the roots' players (status query on the copy)
+  int8_t* d_cur = nullptr;
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_cur), static_cast<size_t>(t->n));
+  if (e != hipSuccess) { osg_batch_destroy(t->roots); (void)hipFree(t->d_mem); if (t->d_logs) (void)hipFree(t->d_logs); delete t; return set_error(OSG_ERR_NOMEM, hipGetErrorString(e)); }
+  rc = osg_status_query(t->roots, d_cur, nullptr, nullptr, 0);
+  if (rc == OSG_OK) {
+    k_mcts_tree_init<<<dim3(static_cast<unsigned>((t->n + 255) / 256)), dim3(256), 0, ctx->stream>>>(make_pool(t), d_cur, t->n);
+    if (hipGetLastError() != hipSuccess) rc = set_error(OSG_ERR_HIP, "k_mcts_tree_init");
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_cur);
+  if (rc) { osg_batch_destroy(t->roots); (void)hipFree(t->d_mem); (void)hipFree(t->d_logs); delete t; return rc; }
+  osg::ctx_retain(ctx);
+  *out = t;
+  return OSG_OK;
+}
+
+int osg_mcts_tree_destroy(osg_mcts_tree* t) {
+  if (!t) return OSG_OK;
+  (void)hipStreamSynchronize(t->ctx->stream);
+  if (t->roots) osg_batch_destroy(t->roots);
+  (void)hipFree(t->d_mem);
+  (void)hipFree(t->d_logs);
+  osg::ctx_release(t->ctx);
+  delete t;
+  return OSG_OK;
+}
+
+int osg_mcts_tree_advance(osg_mcts_tree* t, osg_batch* leaf, const double* d_prior, const double* d_value,
+                          uint8_t* d_request, int max_new_simulations, int64_t* h_counts) {
+  if (!t || !leaf || !d_request) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_advance: null argument");
+  if (!same_game(t->roots, leaf)) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_advance: the leaf batch must have the roots' game and size");
+  if (max_new_simulations < 0) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_advance: max_new_simulations < 0");
+  const unsigned grid = static_cast<unsigned>((t->n + kBlockM - 1) / kBlockM);
+  const osg_game_desc& d = t->roots->spec.desc;
+  const StepPool pool = make_pool(t);
+  hipStream_t st = t->ctx->stream;
+  if (t->board) {
+    OSG_DISPATCH(t->roots->spec, k_mcts_advance<G, true><<<dim3(grid), dim3(kBlockM), 0, st>>>(
+                                     P, static_cast<const typename G::word_t*>(t->roots->d_words),
+                                     static_cast<typename G::word_t*>(leaf->d_words), t->n, d.num_players, t->A, t->cfg,
+                                     t->flags, t->max_utility, t->d_logs, pool, d_prior, d_value, d_request,
+                                     max_new_simulations));
+  } else {
+    OSG_DISPATCH(t->roots->spec, k_mcts_advance<G, false><<<dim3(grid), dim3(kBlockM), 0, st>>>(
+                                     P, static_cast<const typename G::word_t*>(t->roots->d_words),
+                                     static_cast<typename G::word_t*>(leaf->d_words), t->n, d.num_players, t->A, t->cfg,
+                                     t->flags, t->max_utility, t->d_logs, pool, d_prior, d_value, d_request,
+                                     max_new_simulations));
+  }
+  OSG_HIP(hipGetLastError());
+  if (h_counts) {  // how many searches are finished / want a prior / want a value / were paused by max_new_simulations
+    std::vector<uint8_t> req(static_cast<size_t>(t->n));
+    OSG_HIP(hipMemcpyAsync(req.data(), d_request, req.size(), hipMemcpyDeviceToHost, st));
+    OSG_HIP(hipStreamSynchronize(st));
+    h_counts[0] = h_counts[1] = h_counts[2] = h_counts[3] = 0;
+    for (uint8_t q : req) ++h_counts[q & 3];
+  }
+  return OSG_OK;
+}
+
+int osg_mcts_tree_rollout_values(osg_mcts_tree* t, const osg_batch* leaf, double* d_value) {
+  if (!t || !leaf || !d_value) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_rollout_values: null argument");
+  if (!same_game(t->roots, leaf)) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_rollout_values: the leaf batch must have the roots' game and size");
+  const unsigned grid = static_cast<unsigned>((t->n + kBlockM - 1) / kBlockM);
+  const StepPool pool = make_pool(t);
+  OSG_DISPATCH(t->roots->spec, k_mcts_tree_rollout<G><<<dim3(grid), dim3(kBlockM), 0, t->ctx->stream>>>(
+                                   P, static_cast<const typename G::word_t*>(leaf->d_words), t->n, t->P, t->cfg, pool.phase,
+                                   pool.sims, d_value));
+  OSG_HIP(hipGetLastError());
+  return OSG_OK;
+}
+
+int osg_mcts_tree_results(osg_mcts_tree* t, int32_t* best_action, int32_t* child_visits, double* child_reward,
+                          int8_t* child_outcome, double* child_prior, double* root_stats) {
+  if (!t) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_results: null argument");
+  const unsigned grid = static_cast<unsigned>((t->n + kBlockM - 1) / kBlockM);
+  const StepPool pool = make_pool(t);
+  if (t->board)
+    k_mcts_tree_results<true><<<dim3(grid), dim3(kBlockM), 0, t->ctx->stream>>>(pool, t->n, t->A, best_action, child_visits,
+                                                                                child_reward, child_outcome, child_prior, root_stats);
+  else
+    k_mcts_tree_results<false><<<dim3(grid), dim3(kBlockM), 0, t->ctx->stream>>>(pool, t->n, t->A, best_action, child_visits,
+                                                                                 child_reward, child_outcome, child_prior, root_stats);
+  OSG_HIP(hipGetLastError());
+  return OSG_OK;
+}
+
+int64_t osg_mcts_tree_nodes(osg_mcts_tree* t, int64_t root) {
+  if (!t || root < 0 || root >= t->n) return -1;
+  uint32_t used = 0;
+  const StepPool pool = make_pool(t);
+  if (hipMemcpyAsync(&used, pool.used + root, sizeof(used), hipMemcpyDeviceToHost, t->ctx->stream) != hipSuccess) return -1;
+  if (hipStreamSynchronize(t->ctx->stream) != hipSuccess) return -1;
+  return used;
+}
+
+int osg_mcts_tree_download(osg_mcts_tree* t, int64_t root, int64_t cap, uint32_t* h_meta, uint32_t* h_first, uint32_t* h_count,
+                           double* h_total, double* h_prior) {
+  if (!t || !h_meta || !h_first || !h_count || !h_total || !h_prior) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_download: null argument");
+  const int64_t used = osg_mcts_tree_nodes(t, root);
+  if (used < 0) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_download: no such root");
+  if (used > cap) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_download: buffers too small (see osg_mcts_tree_nodes)");
+  void* scratch = nullptr;
+  const size_t u = static_cast<size_t>(used);
+  int rc = osg_ctx_scratch(t->ctx, u * 28 + 64, &scratch);
+  if (rc) return rc;
+  double* d_total = static_cast<double*>(scratch);
+  double* d_prior = d_total + u;
+  uint32_t* d_meta = reinterpret_cast<uint32_t*>(d_prior + u);
+  uint32_t* d_first = d_meta + u;
+  uint32_t* d_count = d_first + u;
+  hipStream_t st = t->ctx->stream;
+  k_mcts_tree_extract<<<dim3(64), dim3(256), 0, st>>>(make_pool(t), root, d_meta, d_first, d_count, d_total, d_prior);
+  OSG_HIP(hipGetLastError());
+  OSG_HIP(hipMemcpyAsync(h_meta, d_meta, u * 4, hipMemcpyDeviceToHost, st));
+  OSG_HIP(hipMemcpyAsync(h_first, d_first, u * 4, hipMemcpyDeviceToHost, st));
+  OSG_HIP(hipMemcpyAsync(h_count, d_count, u * 4, hipMemcpyDeviceToHost, st));
+  OSG_HIP(hipMemcpyAsync(h_total, d_total, u * 8, hipMemcpyDeviceToHost, st));
+  OSG_HIP(hipMemcpyAsync(h_prior, d_prior, u * 8, hipMemcpyDeviceToHost, st));
+  OSG_HIP(hipStreamSynchronize(st));
+  return OSG_OK;
+}
+
+}  // extern "C"

@@ -317,6 +317,23 @@ class State:
                     root_visits=visits.value, children=ch[:n])
 
 
+def _mcts_search_stub(self, uct_c, max_simulations, counter_root, counter_seed, max_nodes=0, solve=False, puct=False,
+                      dont_return_chance_node=False):
+    """MCTSBot with the deterministic stub network (see spiel_oracle_capi.cpp StubNetEvaluator) on the device's
+    layout-1 tree-policy streams: the replay of open_spiel_amd.mcts.search with the same network in torch."""
+    best, visits, nodes = C.c_int64(0), C.c_int(0), C.c_int(0)
+    cap = 512
+    ch = np.zeros((cap, 4), np.float64)
+    n = _check(lib().osgo_mcts_search_stub(self._h, C.c_double(uct_c), max_simulations, int(max_nodes), int(solve),
+                                           int(puct), int(dont_return_chance_node), C.c_int64(counter_root),
+                                           C.c_uint64(counter_seed), C.byref(best), _ptr(ch, C.c_double), cap,
+                                           C.byref(visits), C.byref(nodes)))
+    return dict(best_action=best.value, root_visits=visits.value, nodes=nodes.value, children=ch[:n])
+
+
+State.mcts_search_stub = _mcts_search_stub
+
+
 SOLVER_KINDS = {"cfr": 0, "cfr_plus": 1, "mccfr_simple": 2, "mccfr_full": 3, "cfr_simultaneous": 4,
                 "mccfr_outcome": 5, "cfr_br": 6}
 # CFRSolverBase(game, alternating_updates, linear_averaging, regret_matching_plus) with any switch combination

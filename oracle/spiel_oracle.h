@@ -336,11 +336,15 @@ class MCTSBot {  // mcts.h:149-220
     c_rollouts_ = n_rollouts;
     c_layout_ = layout;
   }
+  // Replay mode with a real evaluator: leaves go to evaluator_->Evaluate instead of the counter-stream rollouts
+  // (the device's evaluator-outside-the-kernel search, osg_mcts_tree_*).
+  void UseEvaluatorInReplay() { c_use_evaluator_ = true; }
 
  private:
   std::unique_ptr<State> ApplyTreePolicy(SearchNode* root, const State& state,
                                          std::vector<SearchNode*>* visit_path);
   void GarbageCollect(SearchNode* node);
+  bool c_use_evaluator_ = false;
   double uct_c_;
   int max_simulations_;
   int max_nodes_;

@@ -242,7 +242,7 @@ std::unique_ptr<SearchNode> MCTSBot::MCTSearch(const State& state) {
       path.back()->outcome = returns;
       solved = solve_;
     } else {
-      returns = counter_ ? CounterEvaluate(*leaf, sim) : evaluator_->Evaluate(*leaf);
+      returns = (counter_ && !c_use_evaluator_) ? CounterEvaluate(*leaf, sim) : evaluator_->Evaluate(*leaf);
       solved = false;
     }
     while (!path.empty()) {  // backup, mcts.cc:383-435

@@ -442,6 +442,88 @@ int osgo_mcts_search(void* s, double uct_c, int max_simulations, int n_rollouts,
   });
 }
 
+// A deterministic stand-in for a value / policy network, in integer arithmetic so that a torch restatement
+// of it (tests/test_z5_gpu_mcts_evaluator.py) agrees to the last bit: x = ObservationTensor(current player, or
+// player 0 at chance / terminal states) — small non-negative integers —
+//   Evaluate: S = sum_i x_i * ((7 i + 3) mod 1009), v = ((S mod 2001) - 1000) / 1024, returns {v, -v / (P - 1), ...}
+//   Prior (decision nodes): k_a = 1 + ((sum_i x_i * ((31 i + 17 a + 5) mod 13)) mod 7) for the legal a, p_a = k_a / sum k
+//   Prior (chance nodes): ChanceOutcomes(), like every evaluator of the reference (mcts.cc:75-77).
+class StubNetEvaluator : public Evaluator {
+ public:
+  std::vector<double> Evaluate(const State& state) override {
+    const std::vector<float> x = Features(state);
+    int64_t s = 0;
+    for (size_t i = 0; i < x.size(); ++i) s += static_cast<int64_t>(x[i]) * static_cast<int64_t>((7 * i + 3) % 1009);
+    const double v = static_cast<double>(s % 2001 - 1000) / 1024.0;  // a power of two: exact, also where a GPU library multiplies by the reciprocal
+    const int P = state.NumPlayers();
+    std::vector<double> out(P, P > 1 ? -v / (P - 1) : v);
+    out[0] = v;
+    return out;
+  }
+  ActionsAndProbs Prior(const State& state) override {
+    if (state.IsChanceNode()) return state.ChanceOutcomes();
+    const std::vector<float> x = Features(state);
+    const std::vector<Action> legal = state.LegalActions();
+    std::vector<int64_t> k(legal.size());
+    int64_t total = 0;
+    for (size_t j = 0; j < legal.size(); ++j) {
+      int64_t s = 0;
+      for (size_t i = 0; i < x.size(); ++i)
+        s += static_cast<int64_t>(x[i]) * static_cast<int64_t>((31 * i + 17 * static_cast<size_t>(legal[j]) + 5) % 13);
+      k[j] = 1 + s % 7;
+      total += k[j];
+    }
+    ActionsAndProbs out;
+    for (size_t j = 0; j < legal.size(); ++j)
+      out.emplace_back(legal[j], static_cast<double>(k[j]) / static_cast<double>(total));
+    return out;
+  }
+
+ private:
+  static std::vector<float> Features(const State& state) {
+    const Player cur = state.CurrentPlayer();
+    return state.ObservationTensor(cur >= 0 ? cur : 0);
+  }
+};
+
+// osgo_mcts_search with the stub network as the evaluator (replay mode only: tree-policy draws from the
+// device's layout-1 counter streams).  max_nodes <= 0: no node budget.  out_children rows:
+// {action, explore_count, total_reward, prior}.
+int osgo_mcts_search_stub(void* s, double uct_c, int max_simulations, int max_nodes, int solve, int puct,
+                          int dont_return_chance_node, int64_t counter_root, uint64_t counter_seed,
+                          int64_t* best_action, double* out_children, int cap, int* root_visits, int* nodes) {
+#ifdef OSGO_GENUINE_REFERENCE
+  (void)s; (void)uct_c; (void)max_simulations; (void)max_nodes; (void)solve; (void)puct; (void)dont_return_chance_node;
+  (void)counter_root; (void)counter_seed; (void)best_action; (void)out_children; (void)cap; (void)root_visits; (void)nodes;
+  g_err = "counter-stream replay is a hook of the restatement, not of the reference";
+  return -1;
+#else
+  return Guard([&] {
+    const State& st = *static_cast<StateH*>(s)->state;
+    auto ev = std::make_shared<StubNetEvaluator>();
+    MCTSBot bot(*st.GetGame(), ev, uct_c, max_simulations, max_nodes > 0 ? -static_cast<int64_t>(max_nodes) : 4096,
+                solve != 0, 0, false, puct ? ChildSelectionPolicy::PUCT : ChildSelectionPolicy::UCT,
+                dont_return_chance_node != 0);
+    bot.UseCounterStreams(counter_seed, static_cast<uint64_t>(counter_root), 1, 1);
+    bot.UseEvaluatorInReplay();
+    std::unique_ptr<SearchNode> root = bot.MCTSearch(st);
+    *best_action = root->children.empty() ? -1 : root->BestChild().action;
+    if (root_visits) *root_visits = root->explore_count;
+    if (nodes) *nodes = bot.LastNodeCount();
+    int k = 0;
+    for (const SearchNode& c : root->children) {
+      if (k >= cap) break;
+      out_children[4 * k + 0] = static_cast<double>(c.action);
+      out_children[4 * k + 1] = c.explore_count;
+      out_children[4 * k + 2] = c.total_reward;
+      out_children[4 * k + 3] = c.prior;
+      ++k;
+    }
+    return static_cast<int>(root->children.size());
+  });
+#endif
+}
+
 // Self-play of two MCTS bots (mcts_test.cc:45-77); returns via out[P].
 int osgo_mcts_selfplay(void* g, double uct_c, int max_simulations, int n_rollouts,
                        int seed, double* out) {

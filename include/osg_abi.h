@@ -258,8 +258,14 @@ int osg_mcts_tree_create(const osg_batch* roots, const osg_mcts_cfg* cfg, int fl
 int osg_mcts_tree_destroy(osg_mcts_tree* t);
 int osg_mcts_tree_advance(osg_mcts_tree* t, osg_batch* leaf, const double* d_prior, const double* d_value,
                           uint8_t* d_request, int max_new_simulations, int64_t* h_counts);
+/* The same for a host that holds no device memory: answers and requests in host arrays (staged through buffers
+ * the tree owns); values_on_device != 0: the values were left in the tree's own buffer by
+ * osg_mcts_tree_rollout_values(t, leaf, NULL). */
+int osg_mcts_tree_advance_host(osg_mcts_tree* t, osg_batch* leaf, const double* h_prior, const double* h_value,
+                               int values_on_device, uint8_t* h_request, int max_new_simulations, int64_t* h_counts);
 /* RandomRolloutEvaluator::Evaluate (mcts.cc:43-72) of every leaf that reported request 2, on the streams
- * of osg_mcts_search: mean Returns() of cfg.n_rollouts playouts into d_value [n, num_players] (device). */
+ * of osg_mcts_search: mean Returns() of cfg.n_rollouts playouts into d_value [n, num_players] (device; NULL = the
+ * tree's own value buffer, see osg_mcts_tree_advance_host). */
 int osg_mcts_tree_rollout_values(osg_mcts_tree* t, const osg_batch* leaf, double* d_value);
 /* The outputs of osg_mcts_search (device pointers, any may be NULL) plus child_prior [n, A] f64. */
 int osg_mcts_tree_results(osg_mcts_tree* t, int32_t* best_action, int32_t* child_visits, double* child_reward,
@@ -268,6 +274,9 @@ int osg_mcts_tree_results(osg_mcts_tree* t, int32_t* best_action, int32_t* child
  * download fills host arrays of that length: meta (action [0:8) | player + 1 [8:12) | children [12:20) |
  * has outcome [20] | outcome of player 0 + 1 [21:23) | terminal [23]), index of the first child (children are
  * contiguous), explore_count, total_reward, prior. */
+/* The actions from root `root` to the node its search is parked at (the state of its pending request), for a
+ * host that wants the State with its history.  Returns the length (<= cap) or a negative status. */
+int osg_mcts_tree_leaf_path(osg_mcts_tree* t, int64_t root, int32_t* h_actions, int cap);
 int64_t osg_mcts_tree_nodes(osg_mcts_tree* t, int64_t root);
 int osg_mcts_tree_download(osg_mcts_tree* t, int64_t root, int64_t cap, uint32_t* h_meta, uint32_t* h_first,
                            uint32_t* h_count, double* h_total, double* h_prior);

@@ -109,8 +109,10 @@ SIGNATURES = {
     "osg_mcts_tree_create": (INT, [VP, C.POINTER(MctsCfg), INT, C.POINTER(VP)]),
     "osg_mcts_tree_destroy": (INT, [VP]),
     "osg_mcts_tree_advance": (INT, [VP, VP, VP, VP, VP, INT, C.POINTER(I64)]),
+    "osg_mcts_tree_advance_host": (INT, [VP, VP, VP, VP, INT, VP, INT, C.POINTER(I64)]),
     "osg_mcts_tree_rollout_values": (INT, [VP, VP, VP]),
     "osg_mcts_tree_results": (INT, [VP, VP, VP, VP, VP, VP, VP]),
+    "osg_mcts_tree_leaf_path": (INT, [VP, I64, VP, INT]),
     "osg_mcts_tree_nodes": (I64, [VP, I64]),
     "osg_mcts_tree_download": (INT, [VP, I64, I64, VP, VP, VP, VP, VP]),
     "osg_cfr_create": (INT, [VP, C.c_char_p, C.POINTER(CfrCfg), C.POINTER(VP)]),

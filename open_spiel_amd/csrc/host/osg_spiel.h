@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
 #include <iomanip>
 #include <sstream>
@@ -382,6 +383,132 @@ inline std::pair<std::shared_ptr<const Game>, std::unique_ptr<State>> Deserializ
   return {game, std::move(state)};
 }
 
+// ---- observer.h: the observation API of the Python Observation class (python/observation.py) -------------
+// Two observers exist on the device, the ones State::ObservationTensor and State::InformationStateTensor pack:
+// the game's default observer and the perfect-recall, single-player-private one (kInfoStateObsType).
+enum class PrivateInfoType { kNone, kSinglePlayer, kAllPlayers };  // observer.h:60-67
+struct IIGObservationType {                                          // observer.h:75-104
+  bool public_info = true;
+  bool perfect_recall = false;
+  PrivateInfoType private_info = PrivateInfoType::kSinglePlayer;
+  bool operator==(const IIGObservationType& o) const {
+    return public_info == o.public_info && perfect_recall == o.perfect_recall && private_info == o.private_info;
+  }
+};
+constexpr IIGObservationType kDefaultObsType{true, false, PrivateInfoType::kSinglePlayer};    // observer.h:108-112
+constexpr IIGObservationType kInfoStateObsType{true, true, PrivateInfoType::kSinglePlayer};   // observer.h:114-118
+
+class SpanTensorInfo {  // observer.h:130-160
+ public:
+  SpanTensorInfo(std::string name, std::vector<int> shape) : name_(std::move(name)), shape_(std::move(shape)) {}
+  const std::string& name() const { return name_; }
+  const std::vector<int>& shape() const { return shape_; }
+  std::vector<int> vector_shape() const { return shape_; }
+  int size() const { int n = 1; for (int d : shape_) n *= d; return n; }
+  std::string DebugString() const {
+    std::string s = "SpanTensor(name='" + name_ + "', shape=(";
+    for (size_t i = 0; i < shape_.size(); ++i) s += (i ? ", " : "") + std::to_string(shape_[i]);
+    return s + "))";
+  }
+
+ private:
+  std::string name_;
+  std::vector<int> shape_;
+};
+class SpanTensor {  // observer.h:162-187: a named view into the Observation's buffer
+ public:
+  SpanTensor(SpanTensorInfo info, float* data) : info_(std::move(info)), data_(data) {}
+  const SpanTensorInfo& info() const { return info_; }
+  float* data() const { return data_; }
+  std::string DebugString() const { return info_.DebugString(); }
+
+ private:
+  SpanTensorInfo info_;
+  float* data_;
+};
+
+class Observer {  // observer.h:280-305; made by Game::MakeObserver
+ public:
+  Observer(bool info_state, std::vector<SpanTensorInfo> pieces) : info_state_(info_state), pieces_(std::move(pieces)) {}
+  bool HasString() const { return true; }
+  bool HasTensor() const { return true; }
+  bool info_state() const { return info_state_; }
+  const std::vector<SpanTensorInfo>& pieces() const { return pieces_; }
+
+ private:
+  bool info_state_;
+  std::vector<SpanTensorInfo> pieces_;
+};
+
+// The tensor pieces in the order the reference's observers write them (kuhn_poker.cc:72-107,
+// leduc_poker.cc:103-192; DefaultObserver for the board games), or empty when the type is not offered.
+inline std::vector<SpanTensorInfo> ObserverPieces(const Game& game, bool info_state) {
+  const std::string text = game.ToString();
+  const std::string name = text.substr(0, text.find('('));
+  const int P = game.NumPlayers();
+  if (name == "kuhn_poker") {
+    std::vector<SpanTensorInfo> v{{"player", {P}}, {"private_card", {P + 1}}};
+    if (info_state) v.push_back({"betting", {2 * P - 1, 2}}); else v.push_back({"pot_contribution", {P}});
+    return v;
+  }
+  if (name == "leduc_poker") {
+    const int cards = (game.ObservationTensorSize() - 2 * P) / 2;
+    std::vector<SpanTensorInfo> v{{"player", {P}}, {"private_card", {cards}}, {"community_card", {cards}}};
+    if (info_state) v.push_back({"betting", {2, 3 * P - 2, 2}}); else v.push_back({"pot_contribution", {P}});
+    return v;
+  }
+  if (info_state) return {};
+  return {{"observation", game.ObservationTensorShape()}};
+}
+
+inline std::shared_ptr<Observer> MakeObserver(const Game& game, const IIGObservationType* iig_obs_type = nullptr) {
+  // spiel.h:1040-1054, observer.cc:98-140: null = the game's default observer
+  bool info_state = false;
+  if (iig_obs_type) {
+    if (*iig_obs_type == kInfoStateObsType) info_state = true;
+    else if (!(*iig_obs_type == kDefaultObsType)) return nullptr;  // e.g. PrivateInfoType::kAllPlayers: not on the device
+  }
+  std::vector<SpanTensorInfo> pieces = ObserverPieces(game, info_state);
+  if (pieces.empty()) return nullptr;
+  return std::make_shared<Observer>(info_state, std::move(pieces));
+}
+
+class Observation {  // observer.h:309-371: owns the flat buffer the observer writes into
+ public:
+  Observation(const Game& game, std::shared_ptr<Observer> observer) : observer_(std::move(observer)) {
+    if (!observer_) SpielFatalError("Observation: null observer");
+    int total = 0;
+    for (const SpanTensorInfo& p : observer_->pieces()) total += p.size();
+    const int expect = observer_->info_state() ? game.InformationStateTensorSize() : game.ObservationTensorSize();
+    if (total != expect) SpielFatalError("Observation: piece layout does not match the game's tensor");
+    buffer_.assign(static_cast<size_t>(total), 0.0f);
+  }
+  std::vector<float>& Tensor() { return buffer_; }
+  std::vector<SpanTensorInfo> tensors_info() const { return observer_->pieces(); }
+  std::vector<SpanTensor> tensors() {
+    std::vector<SpanTensor> out;
+    int offset = 0;
+    for (const SpanTensorInfo& p : observer_->pieces()) {
+      out.emplace_back(p, buffer_.data() + offset);
+      offset += p.size();
+    }
+    return out;
+  }
+  void SetFrom(const State& state, int player) {
+    const std::vector<float> v = observer_->info_state() ? state.InformationStateTensor(player) : state.ObservationTensor(player);
+    std::copy(v.begin(), v.end(), buffer_.begin());
+  }
+  std::string StringFrom(const State& state, int player) const {
+    return observer_->info_state() ? state.InformationStateString(player) : state.ObservationString(player);
+  }
+  bool HasString() const { return true; }
+  bool HasTensor() const { return true; }
+
+ private:
+  std::shared_ptr<Observer> observer_;
+  std::vector<float> buffer_;
+};
+
 namespace algorithms {
 
 class Evaluator {  // mcts.h:83-92
@@ -422,7 +549,7 @@ class RandomRolloutEvaluator : public Evaluator {  // mcts.h:97-111
   int64_t calls_ = 0;
 };
 
-struct SearchNode {  // mcts.h:114-146 (root + its children, as MCTSearch's callers read them)
+struct SearchNode {  // mcts.h:114-146
   Action action = kInvalidAction;
   double prior = 0;
   Player player = 0;
@@ -443,86 +570,231 @@ struct SearchNode {  // mcts.h:114-146 (root + its children, as MCTSearch's call
       if (best->CompareFinal(c)) best = &c;
     return *best;
   }
+  std::string ToString(const State& state) const {  // mcts.cc:165-179
+    char buf[256];
+    const std::string act = action != kInvalidAction ? state.ActionToString(player, action) : "none";
+    std::string out_s = "none";
+    if (!outcome.empty()) {
+      char o[32];
+      std::snprintf(o, sizeof(o), "%4.1f", outcome[player == kChancePlayerId ? 0 : player]);
+      out_s = o;
+    }
+    std::snprintf(buf, sizeof(buf), "%6s: player: %d, prior: %5.3f, value: %6.3f, sims: %5d, outcome: %s, %3d children",
+                  act.c_str(), player, prior, explore_count ? total_reward / explore_count : 0., explore_count,
+                  out_s.c_str(), static_cast<int>(children.size()));
+    return buf;
+  }
+  std::string ChildrenStr(const State& state) const {  // mcts.cc:146-163: best first
+    std::vector<const SearchNode*> refs;
+    for (const SearchNode& c : children) refs.push_back(&c);
+    std::stable_sort(refs.begin(), refs.end(), [](const SearchNode* a, const SearchNode* b) { return b->CompareFinal(*a); });
+    std::string out;
+    for (const SearchNode* c : refs) out += c->ToString(state) + "\n";
+    return out;
+  }
 };
 
 enum class ChildSelectionPolicy { UCT, PUCT };  // mcts.h:148
 
-class MCTSBot {  // mcts.h:149-220
+}  // namespace algorithms
+
+class Bot {  // spiel_bots.h:73-185
  public:
-  // Dirichlet noise, dont_return_chance_node and max_wall_clock_time of the reference's constructor
-  // (mcts.h:161-169) are host-side options of a single search and are not offered by the batch kernels.
-  MCTSBot(const Game& game, std::shared_ptr<Evaluator> evaluator, double uct_c, int max_simulations,
-          int64_t max_memory_mb, bool solve, int seed, bool /*verbose*/,
-          ChildSelectionPolicy child_selection_policy = ChildSelectionPolicy::UCT)
-      : evaluator_(std::move(evaluator)), uct_c_(uct_c), max_simulations_(max_simulations),
-        max_memory_mb_(max_memory_mb), solve_(solve), seed_(seed), num_actions_(game.NumDistinctActions()),
-        num_players_(game.NumPlayers()), policy_(child_selection_policy) {
-    rollout_ = dynamic_cast<RandomRolloutEvaluator*>(evaluator_.get());
-    if (!rollout_) SpielFatalError("the device MCTSBot needs a RandomRolloutEvaluator");
+  virtual ~Bot() = default;
+  virtual Action Step(const State& state) = 0;
+  virtual std::pair<Action, std::string> StepVerbose(const State& state) { return {Step(state), ""}; }
+  virtual void InformAction(const State&, Player, Action) {}
+  virtual void InformActions(const State&, const std::vector<Action>&) {}
+  virtual void Restart() {}
+  virtual void RestartAt(const State&) { SpielFatalError("RestartAt(state) not implemented."); }
+  virtual bool ProvidesForceAction() { return false; }
+  virtual void ForceAction(const State&, Action) {
+    SpielFatalError(ProvidesForceAction() ? "ForceAction not implemented but should because the bot is registered as overridable."
+                                          : "ForceAction not implemented because the bot is not overridable");
   }
-  // One search per state of the batch; returns BestChild().action per root (-1 for terminal roots).
+  virtual bool ProvidesPolicy() { return false; }
+  virtual ActionsAndProbs GetPolicy(const State&) {
+    SpielFatalError(ProvidesPolicy() ? "GetPolicy not implemented but should because the bot is registered as exposing its policy."
+                                     : "GetPolicy not implemented because the bot is not exposing any policy.");
+  }
+  virtual std::pair<ActionsAndProbs, Action> StepWithPolicy(const State&) {
+    SpielFatalError(ProvidesPolicy() ? "StepWithPolicy not implemented but should because the bot is registered as exposing its policy."
+                                     : "StepWithPolicy not implemented because the bot is not exposing any policy.");
+  }
+  virtual bool IsClonable() const { return false; }
+  virtual std::unique_ptr<Bot> Clone() { SpielFatalError("Clone method not implemented."); }
+};
+
+namespace algorithms {
+
+inline std::vector<double> dirichlet_noise(int count, double alpha, std::mt19937* rng) {  // mcts.cc:188-203
+  std::vector<double> noise;
+  std::gamma_distribution<double> gamma(alpha, 1.0);
+  for (int i = 0; i < count; ++i) noise.push_back(gamma(*rng));
+  double sum = 0;
+  for (double v : noise) sum += v;
+  for (double& v : noise) v /= sum;
+  return noise;
+}
+
+// mcts.h:149-220.  The search runs on the device: StepBatch searches a whole batch of roots with the fused
+// kernels (RandomRolloutEvaluator only); MCTSearch / Step run one root through the persistent-tree entry
+// points (osg_mcts_tree_*), which serve ANY Evaluator — requests for Prior(state) and Evaluate(state) come back
+// to the host, RandomRolloutEvaluator is answered on the device — and return the whole SearchNode tree.
+class MCTSBot : public Bot {
+ public:
+  MCTSBot(const Game& game, std::shared_ptr<Evaluator> evaluator, double uct_c, int max_simulations,
+          int64_t max_memory_mb, bool solve, int seed, bool verbose,
+          ChildSelectionPolicy child_selection_policy = ChildSelectionPolicy::UCT, double dirichlet_alpha = 0,
+          double dirichlet_epsilon = 0, bool dont_return_chance_node = false, double max_wall_clock_time = -1)
+      : evaluator_(std::move(evaluator)), uct_c_(uct_c), max_simulations_(max_simulations),
+        max_memory_mb_(max_memory_mb), solve_(solve), seed_(seed), verbose_(verbose),
+        num_actions_(game.NumDistinctActions()), num_players_(game.NumPlayers()), policy_(child_selection_policy),
+        dirichlet_alpha_(dirichlet_alpha), dirichlet_epsilon_(dirichlet_epsilon),
+        dont_return_chance_node_(dont_return_chance_node), max_wall_clock_time_(max_wall_clock_time), rng_(seed) {
+    rollout_ = dynamic_cast<RandomRolloutEvaluator*>(evaluator_.get());
+    if (!evaluator_) SpielFatalError("MCTSBot needs an evaluator");
+  }
+  void Restart() override {}
+  void RestartAt(const State&) override {}
+  // One search per state of the batch with the fused kernels; returns BestChild().action per root (-1 for
+  // terminal roots).  RandomRolloutEvaluator, no root noise.
   std::vector<Action> StepBatch(const BatchedState& roots) {
+    if (!rollout_) SpielFatalError("StepBatch: the fused batch kernels implement RandomRolloutEvaluator");
     std::vector<int32_t> best(roots.size());
-    osg_mcts_cfg cfg = Config(roots.size());
+    osg_mcts_cfg cfg = Config();
     Check(osg_mcts_search(roots.handle(), &cfg, best.data(), nullptr, nullptr, nullptr, nullptr, 1));
     searches_ += roots.size();
     return std::vector<Action>(best.begin(), best.end());
   }
-  Action Step(const State& state) { return StepBatch(state.Batch())[0]; }  // mcts.cc:233-266
-  std::pair<ActionsAndProbs, Action> StepWithPolicy(const State& state) {  // mcts.cc:268-271
+  Action Step(const State& state) override {  // mcts.cc:233-266
+    std::unique_ptr<SearchNode> root = MCTSearch(state);
+    if (max_simulations_ <= 1 || root->children.empty()) {  // sample from the prior (mcts.cc:237-239)
+      ActionsAndProbs prior = evaluator_->Prior(state);
+      const double z = std::uniform_real_distribution<double>(0.0, 1.0)(rng_);
+      double acc = 0;
+      for (const auto& ap : prior) {
+        if (z >= acc && z < acc + ap.second) return ap.first;
+        acc += ap.second;
+      }
+      return prior.back().first;
+    }
+    const SearchNode& best = root->BestChild();
+    if (verbose_) {
+      std::fprintf(stderr, "Finished %d sims, tree size: %lld nodes.\nRoot:\n%s\nChildren:\n%s\n", root->explore_count,
+                   static_cast<long long>(last_nodes_), root->ToString(state).c_str(), root->ChildrenStr(state).c_str());
+    }
+    return best.action;
+  }
+  std::pair<ActionsAndProbs, Action> StepWithPolicy(const State& state) override {  // mcts.cc:268-271
     const Action action = Step(state);
     return {{{action, 1.0}}, action};
   }
-  std::unique_ptr<SearchNode> MCTSearch(const State& state) {              // mcts.cc:353-467
-    const int A = num_actions_;
-    std::vector<int32_t> visits(A);
-    std::vector<double> reward(A), stats(4);
-    std::vector<int8_t> outcome(A);
-    int32_t best = -1;
-    osg_mcts_cfg cfg = Config(1);
-    Check(osg_mcts_search(state.Batch().handle(), &cfg, &best, visits.data(), reward.data(), outcome.data(),
-                          stats.data(), 1));
-    ++searches_;
-    auto root = std::unique_ptr<SearchNode>(new SearchNode);
-    root->player = state.CurrentPlayer();
-    root->prior = 1;
-    root->explore_count = static_cast<int>(stats[0]);
-    if (!std::isnan(stats[2])) root->outcome = Zerosum(stats[2], root->player);
-    for (int a = 0; a < A; ++a) {
-      if (outcome[a] == 3) continue;
-      SearchNode c;
-      c.action = a;
-      c.player = root->player;
-      c.explore_count = visits[a];
-      c.total_reward = reward[a];
-      if (outcome[a] != 2) c.outcome = Zerosum(outcome[a], root->player);
-      root->children.push_back(c);
+  bool ProvidesPolicy() override { return true; }
+  ActionsAndProbs GetPolicy(const State& state) override { return StepWithPolicy(state).first; }  // spiel_bots.h:141
+
+  std::unique_ptr<SearchNode> MCTSearch(const State& state) {  // mcts.cc:353-467
+    osg_mcts_cfg cfg = Config();
+    const bool host_priors = rollout_ == nullptr || dirichlet_alpha_ > 0;
+    const int flags = (host_priors ? 1 : 0) | (dont_return_chance_node_ ? 2 : 0);
+    osg_mcts_tree* tree = nullptr;
+    Check(osg_mcts_tree_create(state.Batch().handle(), &cfg, flags, &tree));
+    struct Guard { osg_mcts_tree* t; ~Guard() { osg_mcts_tree_destroy(t); } } guard{tree};
+    BatchedState leaf(state.GetGame(), 1);
+    std::vector<double> prior(num_actions_), value(num_players_);
+    const auto start = std::chrono::steady_clock::now();
+    bool have_prior = false, have_value = false, device_value = false;
+    for (;;) {
+      int64_t counts[4];
+      Check(osg_mcts_tree_advance_host(tree, leaf.handle(), have_prior ? prior.data() : nullptr,
+                                       have_value ? value.data() : nullptr, device_value ? 1 : 0, nullptr, 1 << 30, counts));
+      have_prior = have_value = device_value = false;
+      if (counts[1] == 0 && counts[2] == 0) break;
+      if (max_wall_clock_time_ > 0 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count() >= max_wall_clock_time_)
+        break;
+      if (counts[2] && rollout_) {  // RandomRolloutEvaluator::Evaluate on the device
+        Check(osg_mcts_tree_rollout_values(tree, leaf.handle(), nullptr));
+        device_value = true;
+        continue;
+      }
+      // the state the request is about, with its history: the root state advanced along the parked path
+      int32_t path[256];
+      const int len = osg_mcts_tree_leaf_path(tree, 0, path, 256);
+      if (len < 0) SpielFatalError(osg_last_error());
+      std::unique_ptr<State> at = state.Clone();
+      for (int k = 0; k < len; ++k) at->ApplyAction(path[k]);
+      if (counts[1]) {
+        ActionsAndProbs ap = evaluator_->Prior(*at);
+        if (len == 0 && dirichlet_alpha_ > 0) {  // root noise (mcts.cc:284-292)
+          std::vector<double> noise = dirichlet_noise(static_cast<int>(ap.size()), dirichlet_alpha_, &rng_);
+          for (size_t k = 0; k < ap.size(); ++k)
+            ap[k].second = (1 - dirichlet_epsilon_) * ap[k].second + dirichlet_epsilon_ * noise[k];
+        }
+        std::fill(prior.begin(), prior.end(), 0.0);
+        for (const auto& x : ap)
+          if (x.first >= 0 && x.first < num_actions_) prior[x.first] = x.second;
+        have_prior = true;
+      } else {
+        value = evaluator_->Evaluate(*at);
+        if (static_cast<int>(value.size()) != num_players_) SpielFatalError("Evaluate() must return one value per player");
+        have_value = true;
+      }
     }
-    return root;
+    ++searches_;
+    return Download(tree, state);
   }
 
  private:
-  osg_mcts_cfg Config(int64_t /*roots*/) const {
+  std::unique_ptr<SearchNode> Download(osg_mcts_tree* tree, const State& state) {
+    const int64_t used = osg_mcts_tree_nodes(tree, 0);
+    if (used < 1) SpielFatalError(osg_last_error());
+    last_nodes_ = used;
+    std::vector<uint32_t> meta(used), first(used), count(used);
+    std::vector<double> total(used), prior(used);
+    Check(osg_mcts_tree_download(tree, 0, used, meta.data(), first.data(), count.data(), total.data(), prior.data()));
+    auto root = std::unique_ptr<SearchNode>(new SearchNode);
+    std::vector<std::pair<SearchNode*, uint32_t>> todo{{root.get(), 0u}};
+    const bool board = num_players_ == 2 && state.GetGame()->MaxChanceOutcomes() == 0;
+    while (!todo.empty()) {
+      auto [node, i] = todo.back();
+      todo.pop_back();
+      const uint32_t m = meta[i];
+      node->action = i == 0 ? kInvalidAction : static_cast<Action>(m & 0xFFu);
+      node->player = i == 0 ? state.CurrentPlayer() : static_cast<Player>((m >> 8) & 15u) - 1;
+      node->prior = prior[i];
+      node->explore_count = static_cast<int>(count[i]);
+      node->total_reward = total[i];
+      if ((m >> 20) & 1u) {  // outcome = Returns() of the proven / terminal position
+        if (board) {
+          const double v0 = static_cast<double>(static_cast<int>((m >> 21) & 3u) - 1);
+          node->outcome = {v0, 0.0 - v0};
+        } else if (count[i] > 0) {  // terminal node of a poker game: every visit added the same Returns()[player]
+          node->outcome.assign(num_players_, 0.0);
+          if (node->player >= 0) node->outcome[node->player] = total[i] / count[i];
+        }
+      }
+      const int nc = static_cast<int>((m >> 12) & 0xFFu);
+      node->children.resize(nc);
+      for (int k = 0; k < nc; ++k) todo.push_back({&node->children[k], first[i] + static_cast<uint32_t>(k)});
+    }
+    return root;
+  }
+  osg_mcts_cfg Config() const {
     osg_mcts_cfg cfg{};
     cfg.uct_c = uct_c_;
     cfg.max_simulations = max_simulations_;
-    cfg.n_rollouts = rollout_->n_rollouts();
+    cfg.n_rollouts = rollout_ ? rollout_->n_rollouts() : 1;
     cfg.solve = solve_ ? 1 : 0;
-    // max_nodes = (max_memory_mb << 20) / sizeof(SearchNode) + 1 (mcts.cc:214), 24 B per device node
-    int64_t nodes = (max_memory_mb_ << 20) / 24 + 1;
-    cfg.max_nodes = static_cast<int32_t>(std::min<int64_t>(nodes, 1 << 24));
+    // max_nodes_ = (max_memory_mb << 20) / sizeof(SearchNode) + 1 (mcts.cc:214) with the reference's 88-byte
+    // SearchNode (x86-64 libstdc++), so that the same max_memory_mb collects at the same tree size
+    const int64_t nodes = (max_memory_mb_ << 20) / 88 + 1;
+    cfg.max_nodes = static_cast<int32_t>(std::min<int64_t>(nodes, std::numeric_limits<int32_t>::max()));
     cfg.seed = static_cast<uint64_t>(seed_);
     cfg.index_offset = searches_;
+    cfg.layout = 1;
     cfg.child_selection_policy = policy_ == ChildSelectionPolicy::PUCT ? 1 : 0;
     return cfg;
-  }
-  std::vector<double> Zerosum(double v, Player p) const {  // 2-player zero-sum outcome vector
-    std::vector<double> o(num_players_, 0.0);
-    if (p >= 0 && p < num_players_) {
-      o[p] = v;
-      if (num_players_ == 2) o[1 - p] = 0.0 - v;  // 0.0 - 0.0 = +0.0: Returns() of a draw is {0, 0}
-    }
-    return o;
   }
   std::shared_ptr<Evaluator> evaluator_;
   RandomRolloutEvaluator* rollout_ = nullptr;
@@ -531,9 +803,15 @@ class MCTSBot {  // mcts.h:149-220
   int64_t max_memory_mb_;
   bool solve_;
   int seed_;
+  bool verbose_;
   int num_actions_, num_players_;
   ChildSelectionPolicy policy_;
+  double dirichlet_alpha_, dirichlet_epsilon_;
+  bool dont_return_chance_node_;
+  double max_wall_clock_time_;
+  std::mt19937 rng_;
   int64_t searches_ = 0;
+  int64_t last_nodes_ = 0;
 };
 
 struct CFRInfoStateValues {  // cfr.h:42-98

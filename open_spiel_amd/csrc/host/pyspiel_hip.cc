@@ -7,6 +7,8 @@
 // `import pyspiel` run with `from open_spiel_amd import pyspiel_hip as pyspiel` for the five
 // hot-path games.  Plus the batch classes the device actually wants (BatchedState, step_batch).
 #include <pybind11/numpy.h>
+#include <sstream>
+#include <optional>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
@@ -126,6 +128,80 @@ GameTypeInfo GameTypeOf(const Game& g) {
   return t;
 }
 
+enum class TttCellState { kEmpty, kNought, kCross };          // tic_tac_toe.h:38-42
+enum class LeducActionType { kFold = 0, kCall = 1, kRaise = 2 };  // leduc_poker.h:64
+
+static std::string ShortName(const State& st) {
+  const std::string text = st.GetGame()->ToString();
+  return text.substr(0, text.find('('));
+}
+// TicTacToeState::Board (tic_tac_toe.h:97): row-major cells, read off the state's string (tic_tac_toe.cc:163-175)
+static std::vector<TttCellState> TttBoard(const State& st) {
+  if (ShortName(st) != "tic_tac_toe") SpielFatalError("board(): a tic_tac_toe accessor");
+  std::vector<TttCellState> out;
+  for (char c : st.ToString()) {
+    if (c == '.') out.push_back(TttCellState::kEmpty);
+    else if (c == 'o') out.push_back(TttCellState::kNought);
+    else if (c == 'x') out.push_back(TttCellState::kCross);
+  }
+  if (out.size() != 9) SpielFatalError("tic_tac_toe board: unexpected state string");
+  return out;
+}
+// The fields LeducState exposes to Python (leduc_poker.h:120-135), parsed from LeducState::ToString
+// (leduc_poker.cc:463-496): "Round: r\nPlayer: p\nPot: n\nMoney (p1 p2 ...): a b\nCards (public p1 p2 ...): c a b \n
+// Round 1 sequence: Call, Raise\nRound 2 sequence: ...\n"
+struct LeducFields {
+  int round = 0, pot = 0, public_card = -10000;
+  std::vector<int> money, private_cards, round1, round2;
+};
+static LeducFields LeducView(const State& st) {
+  if (ShortName(st) != "leduc_poker") SpielFatalError("a leduc_poker accessor");
+  LeducFields f;
+  std::istringstream in(st.ToString());
+  std::string line;
+  auto ints_after_colon = [](const std::string& l) {
+    std::vector<int> v;
+    std::istringstream is(l.substr(l.find(':') + 1));
+    int x;
+    while (is >> x) v.push_back(x);
+    return v;
+  };
+  auto actions_after_colon = [](const std::string& l) {
+    std::vector<int> v;
+    std::string rest = l.substr(l.find(':') + 1), tok;
+    std::istringstream is(rest);
+    while (std::getline(is, tok, ',')) {
+      if (tok.find("Fold") != std::string::npos) v.push_back(0);
+      else if (tok.find("Call") != std::string::npos) v.push_back(1);
+      else if (tok.find("Raise") != std::string::npos) v.push_back(2);
+    }
+    return v;
+  };
+  while (std::getline(in, line)) {
+    if (line.rfind("Round:", 0) == 0) f.round = ints_after_colon(line).at(0);
+    else if (line.rfind("Pot:", 0) == 0) f.pot = ints_after_colon(line).at(0);
+    else if (line.rfind("Money", 0) == 0) f.money = ints_after_colon(line);
+    else if (line.rfind("Cards", 0) == 0) {
+      std::vector<int> c = ints_after_colon(line);
+      if (!c.empty()) { f.public_card = c[0]; f.private_cards.assign(c.begin() + 1, c.end()); }
+    } else if (line.rfind("Round 1 sequence", 0) == 0) f.round1 = actions_after_colon(line);
+    else if (line.rfind("Round 2 sequence", 0) == 0) f.round2 = actions_after_colon(line);
+  }
+  return f;
+}
+
+// Python subclasses of Evaluator (mcts.h:83-92)
+class PyEvaluator : public Evaluator {
+ public:
+  using Evaluator::Evaluator;
+  std::vector<double> Evaluate(const State& state) override {
+    PYBIND11_OVERRIDE_PURE_NAME(std::vector<double>, Evaluator, "evaluate", Evaluate, state);
+  }
+  ActionsAndProbs Prior(const State& state) override {
+    PYBIND11_OVERRIDE_PURE_NAME(ActionsAndProbs, Evaluator, "prior", Prior, state);
+  }
+};
+
 PYBIND11_MODULE(pyspiel_hip, m) {
   m.doc() = "pyspiel-compatible surface of the MI355X game-step and search engine (libosg_hip.so)";
   py::register_exception<SpielException>(m, "SpielError", PyExc_RuntimeError);  // pyspiel.cc:831-837
@@ -152,6 +228,13 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("get_parameters", [](const Game& g) { return GameParametersWithDefaults(g.ToString()); })
       .def("get_type", [](const Game& g) { return GameTypeOf(g); })
       .def("new_initial_states", [](const Game& g, int64_t n) { return g.NewInitialStates(n); }, py::arg("n"))
+      // pyspiel.cc:509-533: make_observer(iig_obs_type=None, params={}) -> Observer or None
+      .def("make_observer",
+           [](const Game& g, std::optional<IIGObservationType> t, const py::dict& params) -> std::shared_ptr<Observer> {
+             if (params.size()) SpielFatalError("Observation parameters not supported");
+             return MakeObserver(g, t ? &*t : nullptr);
+           },
+           py::arg("imperfect_information_observation_type") = py::none(), py::arg("params") = py::dict())
       .def("__str__", &Game::ToString)
       .def("__repr__", &Game::ToString);
   py::class_<GameTypeInfo>(m, "GameType")
@@ -206,6 +289,21 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def(py::pickle(  // pyspiel.cc:455-474: a state pickles as its game-and-state text
           [](const State& s) { return SerializeGameAndState(*s.GetGame(), s); },
           [](const std::string& t) { return std::move(DeserializeGameAndState(t).second); }))
+      // tic_tac_toe.TicTacToeState (games_tic_tac_toe.cc:80-86)
+      .def("board", [](const State& st) { return TttBoard(st); })
+      .def("board_at", [](const State& st, int row, int col) {
+             if (row < 0 || row > 2 || col < 0 || col > 2) SpielFatalError("board_at: out of range");
+             return TttBoard(st)[row * 3 + col];
+           }, py::arg("row"), py::arg("col"))
+      // leduc_poker.LeducState (games_leduc_poker.cc:40-50)
+      .def("get_private_cards", [](const State& st) { return LeducView(st).private_cards; })
+      .def("private_card", [](const State& st, Player p) { return LeducView(st).private_cards.at(p); }, py::arg("player"))
+      .def("public_card", [](const State& st) { return LeducView(st).public_card; })
+      .def("round", [](const State& st) { return LeducView(st).round; })
+      .def("money", [](const State& st) { return LeducView(st).money; })
+      .def("pot", [](const State& st) { return LeducView(st).pot; })
+      .def("round1", [](const State& st) { return LeducView(st).round1; })
+      .def("round2", [](const State& st) { return LeducView(st).round2; })
       .def("move_number", &State::MoveNumber)
       .def("num_players", &State::NumPlayers)
       .def("get_game", [](const State& s) { return std::const_pointer_cast<Game>(s.GetGame()); });
@@ -236,7 +334,12 @@ PYBIND11_MODULE(pyspiel_hip, m) {
            py::arg("player"))
       .def("clone", [](const BatchedState& b) { return BatchedState(b); });
 
-  py::class_<Evaluator, std::shared_ptr<Evaluator>>(m, "Evaluator");  // bots.cc:106-111
+  // bots.cc:106-111; here also subclassable from Python (evaluate(state) -> [value per player], prior(state) ->
+  // [(action, probability)]): MCTSBot.mcts_search / step route the device search's requests to it
+  py::class_<Evaluator, PyEvaluator, std::shared_ptr<Evaluator>>(m, "Evaluator")
+      .def(py::init<>())
+      .def("evaluate", &Evaluator::Evaluate, py::arg("state"))
+      .def("prior", &Evaluator::Prior, py::arg("state"));
   py::class_<RandomRolloutEvaluator, Evaluator, std::shared_ptr<RandomRolloutEvaluator>>(m, "RandomRolloutEvaluator")
       .def(py::init<int, int>(), py::arg("n_rollouts"), py::arg("seed"))
       .def("evaluate", &RandomRolloutEvaluator::Evaluate, py::arg("state"))
@@ -254,24 +357,43 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def_readonly("total_reward", &SearchNode::total_reward)
       .def_readonly("outcome", &SearchNode::outcome)
       .def_readonly("children", &SearchNode::children)
-      .def("best_child", &SearchNode::BestChild);
+      .def("best_child", &SearchNode::BestChild)
+      .def("to_string", &SearchNode::ToString, py::arg("state"))
+      .def("children_str", &SearchNode::ChildrenStr, py::arg("state"));
+
+  py::class_<Bot>(m, "Bot")  // python/pybind11/bots.cc:57-98 (spiel_bots.h:73-185)
+      .def("step", &Bot::Step, py::arg("state"))
+      .def("restart", &Bot::Restart)
+      .def("restart_at", &Bot::RestartAt, py::arg("state"))
+      .def("provides_force_action", &Bot::ProvidesForceAction)
+      .def("force_action", &Bot::ForceAction, py::arg("state"), py::arg("action"))
+      .def("inform_action", &Bot::InformAction, py::arg("state"), py::arg("player_id"), py::arg("action"))
+      .def("inform_actions", &Bot::InformActions, py::arg("state"), py::arg("actions"))
+      .def("provides_policy", &Bot::ProvidesPolicy)
+      .def("get_policy", &Bot::GetPolicy, py::arg("state"))
+      .def("step_with_policy", &Bot::StepWithPolicy, py::arg("state"))
+      .def("is_clonable", &Bot::IsClonable);
 
   py::enum_<ChildSelectionPolicy>(m, "ChildSelectionPolicy")  // bots.cc:113-117
       .value("UCT", ChildSelectionPolicy::UCT)
       .value("PUCT", ChildSelectionPolicy::PUCT);
-  py::class_<MCTSBot>(m, "MCTSBot")  // bots.cc:133-149
+  py::class_<MCTSBot, Bot>(m, "MCTSBot")  // bots.cc:133-149 (+ the constructor's remaining arguments, mcts.h:161-169)
       .def(py::init([](std::shared_ptr<Game> game, std::shared_ptr<Evaluator> evaluator, double uct_c,
                        int max_simulations, int64_t max_memory_mb, bool solve, int seed, bool verbose,
-                       ChildSelectionPolicy policy) {
+                       ChildSelectionPolicy policy, double max_wall_clock_time, double dirichlet_alpha,
+                       double dirichlet_epsilon, bool dont_return_chance_node) {
              return new MCTSBot(*game, std::move(evaluator), uct_c, max_simulations, max_memory_mb, solve, seed, verbose,
-                                policy);
+                                policy, dirichlet_alpha, dirichlet_epsilon, dont_return_chance_node, max_wall_clock_time);
            }),
            py::arg("game"), py::arg("evaluator"), py::arg("uct_c"), py::arg("max_simulations"),
            py::arg("max_memory_mb"), py::arg("solve"), py::arg("seed"), py::arg("verbose"),
-           py::arg("child_selection_policy") = ChildSelectionPolicy::UCT)
-      .def("step", &MCTSBot::Step, py::arg("state"), py::call_guard<py::gil_scoped_release>())
+           py::arg("child_selection_policy") = ChildSelectionPolicy::UCT, py::arg("max_wall_clock_time") = -1.0,
+           py::arg("dirichlet_alpha") = 0.0, py::arg("dirichlet_epsilon") = 0.0,
+           py::arg("dont_return_chance_node") = false)
+      // (no GIL release: a Python Evaluator is called back from inside the search)
+      .def("step", &MCTSBot::Step, py::arg("state"))
       .def("step_with_policy", &MCTSBot::StepWithPolicy, py::arg("state"))  // spiel_bots.h:105-112
-      .def("mcts_search", &MCTSBot::MCTSearch, py::arg("state"), py::call_guard<py::gil_scoped_release>())
+      .def("mcts_search", &MCTSBot::MCTSearch, py::arg("state"))
       .def("step_batch", &MCTSBot::StepBatch, py::arg("states"), py::call_guard<py::gil_scoped_release>());
 
   py::class_<TabularPolicy>(m, "TabularPolicy")
@@ -335,6 +457,94 @@ PYBIND11_MODULE(pyspiel_hip, m) {
   py::module_ kuhn = m.def_submodule("kuhn_poker");
   kuhn.def("get_optimal_policy", [](double alpha) { return TabularPolicy(kuhn_poker::GetOptimalPolicy(alpha)); },
            py::arg("alpha"));
+
+  // ---- python/pybind11/observer.cc:30-97 ----
+  py::enum_<PrivateInfoType>(m, "PrivateInfoType")
+      .value("NONE", PrivateInfoType::kNone)
+      .value("SINGLE_PLAYER", PrivateInfoType::kSinglePlayer)
+      .value("ALL_PLAYERS", PrivateInfoType::kAllPlayers);
+  py::class_<IIGObservationType>(m, "IIGObservationType")
+      .def(py::init([](bool public_info, bool perfect_recall, PrivateInfoType private_info) {
+             return IIGObservationType{public_info, perfect_recall, private_info};
+           }),
+           py::arg("public_info") = true, py::arg("perfect_recall") = false,
+           py::arg("private_info") = PrivateInfoType::kSinglePlayer)
+      .def_readonly("public_info", &IIGObservationType::public_info)
+      .def_readonly("perfect_recall", &IIGObservationType::perfect_recall)
+      .def_readonly("private_info", &IIGObservationType::private_info)
+      .def("__eq__", [](const IIGObservationType& a, const IIGObservationType& b) { return a == b; });
+  py::class_<Observer, std::shared_ptr<Observer>>(m, "Observer")
+      .def("__str__", [](const Observer&) { return "Observer()"; });
+  py::class_<SpanTensorInfo>(m, "SpanTensorInfo")
+      .def_property_readonly("name", [](const SpanTensorInfo& i) { return i.name(); })
+      .def_property_readonly("shape", [](const SpanTensorInfo& i) { return i.vector_shape(); })
+      .def("__str__", &SpanTensorInfo::DebugString);
+  py::class_<SpanTensor>(m, "SpanTensor")
+      .def_property_readonly("name", [](const SpanTensor& t) { return t.info().name(); })
+      .def_property_readonly("shape", [](const SpanTensor& t) { return t.info().vector_shape(); })
+      .def_property_readonly("data",
+                             [](const SpanTensor& t) {  // zero-copy view into the Observation's buffer
+                               std::vector<py::ssize_t> shape(t.info().shape().begin(), t.info().shape().end());
+                               std::vector<py::ssize_t> strides(shape.size());
+                               py::ssize_t stride = sizeof(float);
+                               for (int i = static_cast<int>(shape.size()) - 1; i >= 0; --i) {
+                                 strides[i] = stride;
+                                 stride *= shape[i];
+                               }
+                               py::capsule keep(t.data(), [](void*) {});
+                               return py::array_t<float>(shape, strides, t.data(), keep);
+                             })
+      .def("__str__", &SpanTensor::DebugString);
+  py::class_<Observation>(m, "_Observation", py::buffer_protocol())
+      .def(py::init([](std::shared_ptr<Game> game, std::shared_ptr<Observer> observer) {
+             return new Observation(*game, std::move(observer));
+           }),
+           py::arg("game"), py::arg("observer"))
+      .def("tensors",
+           [](py::object self) {  // every view keeps the Observation (the owner of the buffer) alive
+             py::list out;
+             for (SpanTensor& t : self.cast<Observation&>().tensors()) {
+               py::object e = py::cast(std::move(t));
+               py::detail::keep_alive_impl(e, self);
+               out.append(e);
+             }
+             return out;
+           })
+      .def("tensors_info", &Observation::tensors_info)
+      .def("string_from", &Observation::StringFrom, py::arg("state"), py::arg("player"))
+      .def("set_from", &Observation::SetFrom, py::arg("state"), py::arg("player"))
+      .def("has_string", &Observation::HasString)
+      .def("has_tensor", &Observation::HasTensor)
+      .def_buffer([](Observation& o) -> py::buffer_info {
+        return py::buffer_info(o.Tensor().data(), sizeof(float), py::format_descriptor<float>::format(), 1,
+                               {o.Tensor().size()}, {sizeof(float)});
+      });
+
+  // ---- game submodules (python/pybind11/games_tic_tac_toe.cc:37-100, games_leduc_poker.cc:28-60,
+  // games_connect_four.cc:47-95).  One State class serves every game here, so the game-specific accessors are
+  // methods of State that refuse other games; the JSON struct API (…StateStruct / …ActionStruct) is not offered.
+  py::module_ ttt = m.def_submodule("tic_tac_toe");
+  py::enum_<TttCellState>(ttt, "CellState")
+      .value("EMPTY", TttCellState::kEmpty).value("NOUGHT", TttCellState::kNought).value("CROSS", TttCellState::kCross)
+      .export_values();
+  ttt.attr("NUM_ROWS") = py::int_(3);
+  ttt.attr("NUM_COLS") = py::int_(3);
+  ttt.attr("NUM_CELLS") = py::int_(9);
+  ttt.def("player_to_cellstate", [](Player p) {  // tic_tac_toe.cc:52-63
+    if (p == 0) return TttCellState::kCross;
+    if (p == 1) return TttCellState::kNought;
+    SpielFatalError("Invalid player id " + std::to_string(p));
+  });
+  ttt.def("cellstate_to_string", [](TttCellState c) {  // tic_tac_toe.cc:65-77
+    return std::string(c == TttCellState::kEmpty ? "." : c == TttCellState::kNought ? "o" : "x");
+  });
+  py::module_ c4 = m.def_submodule("connect_four");
+  c4.attr("__doc__") = "connect_four: states and games are pyspiel_hip.State / pyspiel_hip.Game (pickle included)";
+  py::module_ leduc = m.def_submodule("leduc_poker");
+  leduc.attr("INVALID_CARD") = py::int_(-10000);  // leduc_poker.h:57 kInvalidCard
+  py::enum_<LeducActionType>(leduc, "ActionType")
+      .value("FOLD", LeducActionType::kFold).value("CALL", LeducActionType::kCall).value("RAISE", LeducActionType::kRaise)
+      .export_values();
 
   py::enum_<AverageType>(m, "MCCFRAverageType").value("SIMPLE", AverageType::kSimple).value("FULL", AverageType::kFull);
   py::class_<ExternalSamplingMCCFRSolver>(m, "ExternalSamplingMCCFRSolver")  // policy.cc:300-333

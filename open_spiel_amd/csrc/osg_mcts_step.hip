@@ -35,6 +35,10 @@ struct osg_mcts_tree {
   size_t bytes = 0;
   double* d_logs = nullptr;
   int logs_n = 0;
+  // the tree's own request / answer buffers, for hosts that hold no device memory (osg_mcts_tree_advance_host)
+  double* d_own_prior = nullptr;   // [n, A]
+  double* d_own_value = nullptr;   // [n, P]
+  uint8_t* d_own_request = nullptr;
 };
 
 namespace {
@@ -499,6 +503,7 @@ int osg_mcts_tree_destroy(osg_mcts_tree* t) {
   if (t->roots) osg_batch_destroy(t->roots);
   (void)hipFree(t->d_mem);
   (void)hipFree(t->d_logs);
+  if (t->d_own_prior) (void)hipFree(t->d_own_prior);
   osg::ctx_release(t->ctx);
   delete t;
   return OSG_OK;
@@ -537,8 +542,46 @@ int osg_mcts_tree_advance(osg_mcts_tree* t, osg_batch* leaf, const double* d_pri
   return OSG_OK;
 }
 
+static int own_buffers(osg_mcts_tree* t) {
+  if (t->d_own_prior) return OSG_OK;
+  const size_t bytes = sizeof(double) * static_cast<size_t>(t->n) * (t->A + t->P) + static_cast<size_t>(t->n) + 64;
+  char* m = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&m), bytes);
+  if (e != hipSuccess) return set_error(OSG_ERR_NOMEM, hipGetErrorString(e));
+  t->d_own_prior = reinterpret_cast<double*>(m);
+  t->d_own_value = t->d_own_prior + static_cast<size_t>(t->n) * t->A;
+  t->d_own_request = reinterpret_cast<uint8_t*>(t->d_own_value + static_cast<size_t>(t->n) * t->P);
+  return OSG_OK;
+}
+
+int osg_mcts_tree_advance_host(osg_mcts_tree* t, osg_batch* leaf, const double* h_prior, const double* h_value,
+                               int values_on_device, uint8_t* h_request, int max_new_simulations, int64_t* h_counts) {
+  if (!t || !leaf) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_advance_host: null argument");
+  int rc = own_buffers(t);
+  if (rc) return rc;
+  hipStream_t st = t->ctx->stream;
+  if (h_prior) OSG_HIP(hipMemcpyAsync(t->d_own_prior, h_prior, sizeof(double) * t->n * t->A, hipMemcpyHostToDevice, st));
+  if (h_value) OSG_HIP(hipMemcpyAsync(t->d_own_value, h_value, sizeof(double) * t->n * t->P, hipMemcpyHostToDevice, st));
+  int64_t counts[4];
+  rc = osg_mcts_tree_advance(t, leaf, h_prior ? t->d_own_prior : nullptr,
+                             (h_value || values_on_device) ? t->d_own_value : nullptr, t->d_own_request,
+                             max_new_simulations, counts);
+  if (rc) return rc;
+  if (h_counts) for (int k = 0; k < 4; ++k) h_counts[k] = counts[k];
+  if (h_request) {
+    OSG_HIP(hipMemcpyAsync(h_request, t->d_own_request, static_cast<size_t>(t->n), hipMemcpyDeviceToHost, st));
+    OSG_HIP(hipStreamSynchronize(st));
+  }
+  return OSG_OK;
+}
+
 int osg_mcts_tree_rollout_values(osg_mcts_tree* t, const osg_batch* leaf, double* d_value) {
-  if (!t || !leaf || !d_value) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_rollout_values: null argument");
+  if (!t || !leaf) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_rollout_values: null argument");
+  if (!d_value) {  // into the tree's own value buffer (the next osg_mcts_tree_advance_host reads it with values_on_device)
+    int rc = own_buffers(t);
+    if (rc) return rc;
+    d_value = t->d_own_value;
+  }
   if (!same_game(t->roots, leaf)) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_rollout_values: the leaf batch must have the roots' game and size");
   const unsigned grid = static_cast<unsigned>((t->n + kBlockM - 1) / kBlockM);
   const StepPool pool = make_pool(t);
@@ -571,6 +614,29 @@ int64_t osg_mcts_tree_nodes(osg_mcts_tree* t, int64_t root) {
   if (hipMemcpyAsync(&used, pool.used + root, sizeof(used), hipMemcpyDeviceToHost, t->ctx->stream) != hipSuccess) return -1;
   if (hipStreamSynchronize(t->ctx->stream) != hipSuccess) return -1;
   return used;
+}
+
+int osg_mcts_tree_leaf_path(osg_mcts_tree* t, int64_t root, int32_t* h_actions, int cap) {
+  if (!t || root < 0 || root >= t->n || (!h_actions && cap > 0)) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_leaf_path: bad argument");
+  // the parked node and its ancestors: a handful of 4-byte reads per level (host-driven evaluators only)
+  const StepPool pool = make_pool(t);
+  hipStream_t st = t->ctx->stream;
+  uint32_t node = 0;
+  OSG_HIP(hipMemcpyAsync(&node, pool.node + root, 4, hipMemcpyDeviceToHost, st));
+  OSG_HIP(hipStreamSynchronize(st));
+  std::vector<int32_t> rev;
+  while (node != 0 && node != kNoNode) {
+    uint32_t meta = 0, parent = 0;
+    OSG_HIP(hipMemcpyAsync(&meta, pool.meta + static_cast<int64_t>(node) * t->n + root, 4, hipMemcpyDeviceToHost, st));
+    OSG_HIP(hipMemcpyAsync(&parent, pool.parent + static_cast<int64_t>(node) * t->n + root, 4, hipMemcpyDeviceToHost, st));
+    OSG_HIP(hipStreamSynchronize(st));
+    rev.push_back(static_cast<int32_t>(meta & 0xFFu));
+    node = parent;
+  }
+  const int len = static_cast<int>(rev.size());
+  if (len > cap) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_leaf_path: buffer too small");
+  for (int i = 0; i < len; ++i) h_actions[i] = rev[len - 1 - i];
+  return len;
 }
 
 int osg_mcts_tree_download(osg_mcts_tree* t, int64_t root, int64_t cap, uint32_t* h_meta, uint32_t* h_first, uint32_t* h_count,

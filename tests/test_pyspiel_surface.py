@@ -319,3 +319,162 @@ def test_observation_wrapper_like_observation_test(pyspiel):
     assert list(co.dict) == ["observation"] and co.dict["observation"].shape == (3, 6, 7)
     assert co.dict["observation"][0, 0, 3] == 1 and co.dict["observation"][2].sum() == 41
     assert make_observation(c4, INFO_STATE_OBS_TYPE) is None
+
+
+# ---- round 2: Bot base class, the whole SearchNode tree, any Evaluator, observer bindings, game submodules ----
+@pytest.mark.gpu
+def test_mcts_bot_is_a_bot_and_returns_the_whole_tree(pyspiel):
+    game = pyspiel.load_game("connect_four")
+    ev = pyspiel.RandomRolloutEvaluator(2, 7)
+    bot = pyspiel.MCTSBot(game, ev, 2.0, 300, 100, True, 11, False, pyspiel.ChildSelectionPolicy.UCT,
+                          max_wall_clock_time=-1.0, dirichlet_alpha=0.0, dirichlet_epsilon=0.0,
+                          dont_return_chance_node=False)
+    assert isinstance(bot, pyspiel.Bot) and bot.provides_policy() and not bot.is_clonable()
+    state = game.new_initial_state()
+    root = bot.mcts_search(state)
+    assert root.explore_count == 300 and root.player == 0 and root.action == pyspiel.INVALID_ACTION
+    assert sorted(c.action for c in root.children) == list(range(7))
+    assert sum(c.explore_count for c in root.children) == 299
+    grand = [g for c in root.children for g in c.children]
+    assert grand and all(g.player == 1 for g in grand), "MCTSearch returns the tree below the root's children too"
+    def check(node):  # a node's children were visited once less than the node (its first visit evaluated it)
+        if node.children:
+            assert sum(c.explore_count for c in node.children) in (node.explore_count - 1, node.explore_count)
+            np.testing.assert_allclose(sum(c.prior for c in node.children), 1.0, atol=1e-12)
+            for c in node.children:
+                check(c)
+    check(root)
+    text = root.to_string(state)
+    assert "sims:   300" in text and "7 children" in text
+    assert len(root.children_str(state).strip().split("\n")) == 7
+    action = bot.step(state)
+    policy, action2 = bot.step_with_policy(state)
+    assert policy == [(action2, 1.0)] and action in range(7)
+
+
+@pytest.mark.gpu
+def test_mcts_bot_with_a_python_evaluator_equals_the_oracle_replay(pyspiel, oracle):
+    """Any Evaluator drives the device search: a Python subclass implementing the stub network of
+    oracle/spiel_oracle_capi.cpp (integer arithmetic) — requests for prior(state) / evaluate(state) come back to
+    the host with the State (history included) — and the result equals the oracle's MCTSBot(StubNetEvaluator)
+    replayed on the same tree-policy streams, node for node at the root."""
+    class Stub(pyspiel.Evaluator):
+        def __init__(self):
+            pyspiel.Evaluator.__init__(self)
+            self.histories = []
+
+        def _x(self, state):
+            cur = state.current_player()
+            return np.asarray(state.observation_tensor(cur if cur >= 0 else 0)).astype(np.int64)
+
+        def evaluate(self, state):
+            x = self._x(state)
+            self.histories.append(state.history())
+            i = np.arange(x.size)
+            v = float(int((x * ((7 * i + 3) % 1009)).sum()) % 2001 - 1000) / 1024.0
+            return [v, -v]
+
+        def prior(self, state):
+            if state.is_chance_node():
+                return state.chance_outcomes()
+            x = self._x(state)
+            i = np.arange(x.size)
+            legal = state.legal_actions()
+            k = [1 + int((x * ((31 * i + 17 * a + 5) % 13)).sum()) % 7 for a in legal]
+            return [(a, kk / sum(k)) for a, kk in zip(legal, k)]
+
+    for game_name, moves, puct in [("tic_tac_toe", [4, 0], True), ("connect_four", [3, 3, 2], True), ("leduc_poker", [1, 4, 1], False)]:
+        game = pyspiel.load_game(game_name)
+        state = game.new_initial_state()
+        ostate = oracle.Game(game_name).new_initial_state()
+        for a in moves:
+            state.apply_action(a)
+            ostate.apply_action(a)
+        ev = Stub()
+        policy = pyspiel.ChildSelectionPolicy.PUCT if puct else pyspiel.ChildSelectionPolicy.UCT
+        bot = pyspiel.MCTSBot(game, ev, 1.3, 120, 1000, False, 0x51, False, policy)
+        root = bot.mcts_search(state)
+        want = ostate.mcts_search_stub(1.3, 120, 0, 0x51, puct=puct)
+        assert root.explore_count == want["root_visits"]
+        got = {c.action: (c.explore_count, c.total_reward, c.prior) for c in root.children}
+        assert sorted(got) == sorted(int(a) for a in want["children"][:, 0])
+        for a, cnt, tot, pr in want["children"]:
+            assert got[int(a)] == (int(cnt), tot, pr), (game_name, int(a), got[int(a)], (cnt, tot, pr))
+        assert root.best_child().action == want["best_action"]
+        assert all(h[:len(moves)] == moves for h in ev.histories), "the evaluator sees states with their history"
+
+
+@pytest.mark.gpu
+def test_mcts_bot_root_noise_and_wall_clock(pyspiel):
+    game = pyspiel.load_game("connect_four")
+    state = game.new_initial_state()
+    ev = pyspiel.RandomRolloutEvaluator(1, 3)
+    plain = pyspiel.MCTSBot(game, ev, 2.0, 64, 100, False, 5, False, pyspiel.ChildSelectionPolicy.PUCT).mcts_search(state)
+    noisy = pyspiel.MCTSBot(game, ev, 2.0, 64, 100, False, 5, False, pyspiel.ChildSelectionPolicy.PUCT,
+                            dirichlet_alpha=0.3, dirichlet_epsilon=0.25).mcts_search(state)
+    p0 = {c.action: c.prior for c in plain.children}
+    p1 = {c.action: c.prior for c in noisy.children}
+    assert all(abs(p0[a] - 1 / 7) < 1e-15 for a in p0)
+    assert abs(sum(p1.values()) - 1.0) < 1e-12 and max(abs(p1[a] - p0[a]) for a in p0) > 1e-3
+    assert all(p1[a] >= 0.75 * p0[a] - 1e-12 for a in p0)
+    timed = pyspiel.MCTSBot(game, ev, 2.0, 10 ** 7, 1, False, 5, False, pyspiel.ChildSelectionPolicy.UCT,
+                            max_wall_clock_time=0.2)
+    root = timed.mcts_search(state)
+    assert 1 <= root.explore_count < 10 ** 7
+
+
+@pytest.mark.gpu
+def test_observer_bindings_like_python_observation(pyspiel):
+    """python/pybind11/observer.cc:30-97: Game.make_observer, _Observation (buffer protocol, tensors(), set_from,
+    string_from), SpanTensor views — driven the way python/observation.py:63-125 drives them."""
+    game = pyspiel.load_game("kuhn_poker")
+    state = game.new_initial_state()
+    for a in (2, 1, 0):
+        state.apply_action(a)
+    info_type = pyspiel.IIGObservationType(perfect_recall=True)
+    observer = game.make_observer(info_type, {})
+    assert str(observer) == "Observer()"
+    obs = pyspiel._Observation(game, observer)
+    assert obs.has_tensor() and obs.has_string()
+    tensor = np.frombuffer(obs, np.float32)
+    assert tensor.shape == (game.information_state_tensor_size(),)
+    views = {t.name: t.data for t in obs.tensors()}
+    assert [(i.name, i.shape) for i in obs.tensors_info()] == [("player", [2]), ("private_card", [3]), ("betting", [3, 2])]
+    obs.set_from(state, 1)
+    np.testing.assert_array_equal(tensor, np.asarray(state.information_state_tensor(1), np.float32))
+    np.testing.assert_array_equal(views["player"], [0, 1])
+    np.testing.assert_array_equal(views["private_card"], [0, 1, 0])
+    np.testing.assert_array_equal(views["betting"], [[1, 0], [0, 0], [0, 0]])
+    assert obs.string_from(state, 1) == state.information_state_string(1)
+    default = pyspiel._Observation(game, game.make_observer())
+    default.set_from(state, 0)
+    np.testing.assert_array_equal(np.frombuffer(default, np.float32), np.asarray(state.observation_tensor(0), np.float32))
+    assert game.make_observer(pyspiel.IIGObservationType(private_info=pyspiel.PrivateInfoType.ALL_PLAYERS)) is None
+    board = pyspiel.load_game("tic_tac_toe")
+    assert [(i.name, i.shape) for i in pyspiel._Observation(board, board.make_observer()).tensors_info()] == [("observation", [3, 3, 3])]
+    assert board.make_observer(info_type) is None
+
+
+@pytest.mark.gpu
+def test_game_submodules(pyspiel):
+    """games_tic_tac_toe.cc:37-100 and games_leduc_poker.cc:28-60."""
+    ttt = pyspiel.tic_tac_toe
+    assert (ttt.NUM_ROWS, ttt.NUM_COLS, ttt.NUM_CELLS) == (3, 3, 9)
+    assert ttt.player_to_cellstate(0) == ttt.CellState.CROSS and ttt.player_to_cellstate(1) == ttt.CellState.NOUGHT
+    assert [ttt.cellstate_to_string(c) for c in (ttt.CellState.EMPTY, ttt.CellState.NOUGHT, ttt.CellState.CROSS)] == [".", "o", "x"]
+    s = pyspiel.load_game("tic_tac_toe").new_initial_state()
+    for a in (4, 0, 8):
+        s.apply_action(a)
+    assert s.board_at(1, 1) == ttt.CROSS and s.board_at(0, 0) == ttt.NOUGHT and s.board_at(2, 2) == ttt.CROSS
+    assert s.board_at(0, 1) == ttt.EMPTY and len(s.board()) == 9
+    leduc = pyspiel.leduc_poker
+    assert leduc.INVALID_CARD == -10000 and int(leduc.ActionType.RAISE) == 2 and leduc.FOLD == leduc.ActionType.FOLD
+    s = pyspiel.load_game("leduc_poker").new_initial_state()
+    assert s.get_private_cards() == [leduc.INVALID_CARD] * 2 and s.public_card() == leduc.INVALID_CARD
+    for a in (0, 3, 2, 1, 4, 1):   # deal J0 to p0, Q1 to p1; raise, call; public card K0; call
+        s.apply_action(a)
+    assert s.get_private_cards() == [0, 3] and s.private_card(1) == 3 and s.public_card() == 4
+    assert (s.round(), s.pot(), s.money()) == (2, 6, [97, 97])
+    assert s.round1() == [2, 1] and s.round2() == [1]
+    with pytest.raises(pyspiel.SpielError):
+        pyspiel.load_game("kuhn_poker").new_initial_state().public_card()

@@ -753,24 +753,34 @@ class MCTSBot : public Bot {
     std::vector<uint32_t> meta(used), first(used), count(used);
     std::vector<double> total(used), prior(used);
     Check(osg_mcts_tree_download(tree, 0, used, meta.data(), first.data(), count.data(), total.data(), prior.data()));
+    const bool board = num_players_ == 2 && state.GetGame()->MaxChanceOutcomes() == 0;
+    return SearchTreeFromArrays(meta, first, count, total, prior, state.CurrentPlayer(), num_players_, board);
+  }
+
+ public:
+  // The device's flat tree (include/osg_abi.h osg_mcts_tree_download) as SearchNodes.  Pure host code: tested
+  // without a device (tests/native/host_mirror_cpu_test.cpp).
+  static std::unique_ptr<SearchNode> SearchTreeFromArrays(const std::vector<uint32_t>& meta, const std::vector<uint32_t>& first,
+                                                          const std::vector<uint32_t>& count, const std::vector<double>& total,
+                                                          const std::vector<double>& prior, Player root_player,
+                                                          int num_players, bool board) {
     auto root = std::unique_ptr<SearchNode>(new SearchNode);
     std::vector<std::pair<SearchNode*, uint32_t>> todo{{root.get(), 0u}};
-    const bool board = num_players_ == 2 && state.GetGame()->MaxChanceOutcomes() == 0;
     while (!todo.empty()) {
       auto [node, i] = todo.back();
       todo.pop_back();
       const uint32_t m = meta[i];
       node->action = i == 0 ? kInvalidAction : static_cast<Action>(m & 0xFFu);
-      node->player = i == 0 ? state.CurrentPlayer() : static_cast<Player>((m >> 8) & 15u) - 1;
+      node->player = i == 0 ? root_player : static_cast<Player>((m >> 8) & 15u) - 1;
       node->prior = prior[i];
       node->explore_count = static_cast<int>(count[i]);
       node->total_reward = total[i];
       if ((m >> 20) & 1u) {  // outcome = Returns() of the proven / terminal position
         if (board) {
           const double v0 = static_cast<double>(static_cast<int>((m >> 21) & 3u) - 1);
-          node->outcome = {v0, 0.0 - v0};
+          node->outcome = {v0, 0.0 - v0};  // 0.0 - 0.0 = +0.0: Returns() of a draw is {0, 0}, never -0
         } else if (count[i] > 0) {  // terminal node of a poker game: every visit added the same Returns()[player]
-          node->outcome.assign(num_players_, 0.0);
+          node->outcome.assign(num_players, 0.0);
           if (node->player >= 0) node->outcome[node->player] = total[i] / count[i];
         }
       }
@@ -780,6 +790,8 @@ class MCTSBot : public Bot {
     }
     return root;
   }
+
+ private:
   osg_mcts_cfg Config() const {
     osg_mcts_cfg cfg{};
     cfg.uct_c = uct_c_;

@@ -1,0 +1,70 @@
+// The host mirror's pure-host code, run WITHOUT a device: what the drop-in user program prints depends on it
+// (tests/dropin/user_program.cc prints SearchNode outcomes with "%g": a draw must print "0", not "-0" — the
+// round-1 GPU run went red on exactly that), so a formatting slip here must not wait for hardware.
+//   g++ -std=c++17 -I . tests/native/host_mirror_cpu_test.cpp -L open_spiel_amd -losg_hip
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "open_spiel_amd/csrc/host/osg_spiel.h"
+
+using namespace open_spiel::hip;
+using algorithms::MCTSBot;
+using algorithms::SearchNode;
+
+#define EXPECT(c) do { if (!(c)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+static uint32_t Meta(int action, int player, int nchild, bool has_outcome, int code, bool terminal) {
+  return static_cast<uint32_t>(action & 0xFF) | (static_cast<uint32_t>(player + 1) << 8) | (static_cast<uint32_t>(nchild) << 12) |
+         (has_outcome ? 1u << 20 : 0u) | (static_cast<uint32_t>(code) << 21) | (terminal ? 1u << 23 : 0u);
+}
+
+int main() {
+  // root (player 0, proven draw) with three children of player 0: a proven loss, a proven draw, an open one;
+  // the draw child has one (terminal, drawn) grandchild of player 1
+  std::vector<uint32_t> meta{Meta(0xFF, 0, 3, true, 1, false), Meta(4, 0, 0, true, 0, false), Meta(7, 0, 1, true, 1, false),
+                             Meta(2, 0, 0, false, 0, false), Meta(5, 1, 0, true, 1, true)};
+  std::vector<uint32_t> first{1, 0, 4, 0, 0}, count{10, 3, 5, 1, 4};
+  std::vector<double> total{0.5, -3.0, 0.0, 0.5, 0.0}, prior{1.0, 0.25, 0.5, 0.25, 1.0};
+  std::unique_ptr<SearchNode> root = MCTSBot::SearchTreeFromArrays(meta, first, count, total, prior, 0, 2, true);
+  EXPECT(root->action == kInvalidAction && root->player == 0 && root->explore_count == 10 && root->children.size() == 3);
+  EXPECT(root->outcome.size() == 2 && root->outcome[0] == 0.0 && root->outcome[1] == 0.0);
+  EXPECT(!std::signbit(root->outcome[0]) && !std::signbit(root->outcome[1]));  // {0, 0}: no negative zero
+  char buf[64];
+  std::snprintf(buf, sizeof(buf), "%g %g", root->outcome[0], root->outcome[1]);
+  EXPECT(std::string(buf) == "0 0");
+  const SearchNode& loss = root->children[0];
+  EXPECT(loss.action == 4 && loss.outcome[0] == -1.0 && loss.outcome[1] == 1.0 && loss.total_reward == -3.0 && loss.prior == 0.25);
+  const SearchNode& draw = root->children[1];
+  EXPECT(draw.children.size() == 1 && draw.children[0].player == 1 && draw.children[0].action == 5);
+  EXPECT(!std::signbit(draw.children[0].outcome[0]) && !std::signbit(draw.children[0].outcome[1]));
+  EXPECT(root->children[2].outcome.empty());
+  // BestChild (mcts.cc:114-143): the proven draw beats the proven loss and the unproven move (outcome 0 for it)
+  // only on visits: draw (5 visits) vs open (1 visit, outcome treated as 0) -> the draw
+  EXPECT(root->BestChild().action == 7);
+  // poker: the outcome of a terminal node is its mean reward for the node's player
+  std::vector<uint32_t> pm{Meta(0xFF, 1, 1, false, 0, false), Meta(1, 1, 0, true, 0, true)};
+  std::unique_ptr<SearchNode> pr = MCTSBot::SearchTreeFromArrays(pm, {1, 0}, {6, 4}, {3.0, -8.0}, {1.0, 1.0}, 1, 3, false);
+  EXPECT(pr->children[0].outcome.size() == 3 && pr->children[0].outcome[1] == -2.0 && pr->children[0].outcome[0] == 0.0);
+  // dirichlet_noise (mcts.cc:188-203): a distribution, reproducible from the generator
+  std::mt19937 a(5), b(5);
+  std::vector<double> n1 = algorithms::dirichlet_noise(7, 0.3, &a), n2 = algorithms::dirichlet_noise(7, 0.3, &b);
+  double sum = 0;
+  for (double v : n1) { EXPECT(v >= 0); sum += v; }
+  EXPECT(std::fabs(sum - 1.0) < 1e-12 && n1 == n2);
+  // the observer piece tables (no device needed: Game only describes)
+  Game kuhn("kuhn_poker");
+  std::shared_ptr<Observer> info = MakeObserver(kuhn, &kInfoStateObsType);
+  EXPECT(info && info->pieces().size() == 3 && info->pieces()[2].name() == "betting" && info->pieces()[2].size() == 6);
+  IIGObservationType all{true, false, PrivateInfoType::kAllPlayers};
+  EXPECT(MakeObserver(kuhn, &all) == nullptr);
+  Game ttt("tic_tac_toe");
+  EXPECT(MakeObserver(ttt, &kInfoStateObsType) == nullptr && MakeObserver(ttt)->pieces()[0].size() == 27);
+  // ShardRange covers every unit exactly once
+  int64_t covered = 0;
+  for (int r = 0; r < 8; ++r) { auto fc = ShardRange(1000003, r, 8); EXPECT(fc.first == covered); covered += fc.second; }
+  EXPECT(covered == 1000003);
+  std::printf("ok: host mirror CPU checks\n");
+  return 0;
+}

@@ -141,6 +141,56 @@ k_step(typename G::Params p, const typename G::word_t* src, typename G::word_t* 
   status[i] = encode_status(term, illegal, term ? 0 : G::current_player(p, s), term ? G::outcome_code(p, s) : 0);
 }
 
+// The fused step for the games whose state is one or two words (tic_tac_toe 4 B, kuhn_poker 8 B, leduc_poker
+// 2 x 8 B): V consecutive states per thread so that every plane access is ONE 16-byte vector load / store per lane
+// (1 KiB per wave-instruction) instead of V narrow ones, and the V actions / masks / statuses move as one word.
+// The per-state code is the generic one (G::legal / apply / terminal) on a register-resident mini-batch.
+template <class G, typename MaskT, int V, int W>  // W = words per state
+__global__ void __launch_bounds__(kBlock)
+k_step_vec(typename G::Params p, const typename G::word_t* __restrict__ src, typename G::word_t* __restrict__ dst, int64_t n,
+           const uint8_t* __restrict__ actions, MaskT* __restrict__ mask_out, uint8_t* __restrict__ status) {
+  using word_t = typename G::word_t;
+  typedef word_t wvec __attribute__((ext_vector_type(V)));
+  typedef uint8_t bvec __attribute__((ext_vector_type(V)));
+  typedef MaskT mvec __attribute__((ext_vector_type(V)));
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * V;
+  if (i >= n) return;
+  word_t tmp[W * V];  // plane-major mini-batch: G::load(p, tmp, V, j) reads tmp[w * V + j]
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    const wvec v = *reinterpret_cast<const wvec*>(src + w * n + i);
+#pragma unroll
+    for (int j = 0; j < V; ++j) tmp[w * V + j] = v[j];
+  }
+  const bvec av = *reinterpret_cast<const bvec*>(actions + i);
+  bvec sv;
+  mvec mv;
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    typename G::State s = G::load(p, tmp, V, j);
+    const int a = av[j];
+    bool illegal = false;
+    if (a != 0xFF) {
+      const Mask before = G::legal(p, s);
+      if (a < 32 * kMaskWords && before.test(a)) G::apply(p, s, a); else illegal = true;
+    }
+    G::store(p, tmp, V, j, s);
+    const bool term = G::terminal(p, s);
+    const Mask after = G::legal(p, s);
+    mv[j] = static_cast<MaskT>(after.w[0]);
+    sv[j] = encode_status(term, illegal, term ? 0 : G::current_player(p, s), term ? G::outcome_code(p, s) : 0);
+  }
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    wvec v;
+#pragma unroll
+    for (int j = 0; j < V; ++j) v[j] = tmp[w * V + j];
+    *reinterpret_cast<wvec*>(dst + w * n + i) = v;
+  }
+  *reinterpret_cast<mvec*>(mask_out + i) = mv;
+  *reinterpret_cast<bvec*>(status + i) = sv;
+}
+
 // connect_four fast path of the fused step: TWO consecutive states per thread so
 // that every state access is one 16-byte vector load/store per lane per plane
 // (1 KiB per wave-instruction, the coalescing sweet spot); actions / masks /
@@ -293,6 +343,58 @@ k_observation(typename G::Params p, const typename G::word_t* base, int64_t n, i
       d[0] = w4.x;
       if (left > 1) d[1] = w4.y;
       if (left > 2) d[2] = w4.z;
+    }
+  }
+}
+
+// Short rows (tic_tac_toe 27 floats, kuhn_poker 7 / 11, leduc_poker 16 / 30, ...): ONE LANE PER STATE.  The lane
+// loads its state once and walks the cursor over the whole row into the wavefront's LDS tile (row stride padded
+// to an odd number of words: conflict-free); the 64 rows of a wavefront are one contiguous, 16-byte aligned span
+// of the output (64 * size floats), which the wavefront then writes as aligned float4 — 1 KiB per store
+// instruction instead of 64 scattered 12-28 byte pieces.  Needs a 16-byte aligned output.
+constexpr int kRowsBlock = 256;
+constexpr int kRowsMaxSize = 63;
+template <class G>
+__global__ void __launch_bounds__(kRowsBlock)
+k_observation_rows(typename G::Params p, const typename G::word_t* base, int64_t n, int size, int player, int which,
+                   float* __restrict__ out) {
+  extern __shared__ float s_rows[];  // [waves][64 * pad]
+  const int pad = size | 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* tile = s_rows + wave * 64 * pad;
+  const int64_t i0 = (static_cast<int64_t>(blockIdx.x) * kRowsBlock + wave * 64);  // first state of this wavefront
+  if (i0 >= n) return;
+  const int64_t i = i0 + lane;
+  if (i < n) {
+    const typename G::State s = G::load(p, base, n, i);
+    int pl = player;
+    if (pl < 0) {
+      pl = G::current_player(p, s);
+      if (pl < 0) pl = 0;
+    }
+    typename G::ObsCursor cur;
+    cur.init(p, s, pl, which, 0);
+    float* row = tile + lane * pad;
+    for (int k = 0; k < size; ++k) row[k] = cur.next(p, s, pl, which);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int rows = static_cast<int>(n - i0 < 64 ? n - i0 : 64);
+  const int total = rows * size;                       // floats this wavefront writes
+  float* dst = out + i0 * size;                        // 64 * size * 4 bytes per wavefront: 16-byte aligned
+  for (int j = 4 * lane; j < total; j += 256) {
+    int r = j / size, k = j - r * size;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = (j + e < total) ? tile[r * pad + k] : 0.0f;
+      if (++k == size) { k = 0; ++r; }
+    }
+    if (j + 4 <= total) {
+      *reinterpret_cast<float4*>(dst + j) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      for (int e = 0; e < 4 && j + e < total; ++e) dst[j + e] = v[e];
     }
   }
 }
@@ -943,6 +1045,30 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
     OSG_HIP(hipGetLastError());
     return OSG_OK;
   }
+  // one- and two-word states: V states per thread, 16-byte accesses (needs n % V == 0 and aligned side arrays)
+  const uintptr_t side = reinterpret_cast<uintptr_t>(d_actions) | reinterpret_cast<uintptr_t>(d_mask) | reinterpret_cast<uintptr_t>(d_status);
+  const int kind = src->spec.desc.game_kind;
+  if (kind == kTtt && (n & 3) == 0 && (side & 7u) == 0 && cmb == 2) {
+    k_step_vec<Ttt, uint16_t, 4, 1><<<dim3(grid_for(n / 4)), dim3(kBlock), 0, ctx->stream>>>(
+        src->spec.ttt, static_cast<const uint32_t*>(src->d_words), static_cast<uint32_t*>(dst->d_words), n, d_actions,
+        static_cast<uint16_t*>(d_mask), d_status);
+    OSG_HIP(hipGetLastError());
+    return OSG_OK;
+  }
+  if (kind == kKuhn && (n & 1) == 0 && (side & 1u) == 0 && cmb == 1) {
+    k_step_vec<Kuhn, uint8_t, 2, 1><<<dim3(grid_for(n / 2)), dim3(kBlock), 0, ctx->stream>>>(
+        src->spec.kuhn, static_cast<const uint64_t*>(src->d_words), static_cast<uint64_t*>(dst->d_words), n, d_actions,
+        static_cast<uint8_t*>(d_mask), d_status);
+    OSG_HIP(hipGetLastError());
+    return OSG_OK;
+  }
+  if (kind == kLeduc && (n & 1) == 0 && (side & 1u) == 0 && cmb == 1) {
+    k_step_vec<Leduc, uint8_t, 2, 2><<<dim3(grid_for(n / 2)), dim3(kBlock), 0, ctx->stream>>>(
+        src->spec.leduc, static_cast<const uint64_t*>(src->d_words), static_cast<uint64_t*>(dst->d_words), n, d_actions,
+        static_cast<uint8_t*>(d_mask), d_status);
+    OSG_HIP(hipGetLastError());
+    return OSG_OK;
+  }
   if (cmb == 1) {
     OSG_DISPATCH(src->spec, k_step<G, uint8_t><<<dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream>>>(P, static_cast<const typename G::word_t*>(src->d_words),
                                                 static_cast<typename G::word_t*>(dst->d_words), n, d_actions,
@@ -997,6 +1123,13 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
       default: OSG_HEX_OBS(4, hex4); break;
     }
 #undef OSG_HEX_OBS
+  } else if (size <= kRowsMaxSize && (b->spec.desc.game_kind == kTtt || b->spec.desc.game_kind == kKuhn) &&
+             (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) {  // (leduc's cursor is costly per float: the chunked kernel is faster)
+    // short rows: one lane per state, LDS-staged aligned float4 stores
+    const size_t shmem = sizeof(float) * (kRowsBlock / 64) * 64 * static_cast<size_t>(size | 1);
+    const unsigned grid = static_cast<unsigned>((b->n + kRowsBlock - 1) / kRowsBlock);
+    OSG_DISPATCH(b->spec, k_observation_rows<G><<<dim3(grid), dim3(kRowsBlock), shmem, ctx->stream>>>(
+                              P, static_cast<const typename G::word_t*>(b->d_words), b->n, size, player, which, d_out));
   } else {
     // Segment = one tensor plane for hex's 9-plane layout (the cursor's mask is per plane), else the row.
     int seg_len = size;

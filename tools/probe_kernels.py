@@ -1,5 +1,11 @@
 """Per-kernel throughput table (HIP events on the context's stream): the individual State
-queries, the fused step of every game, tensor packing, random stepping and rollouts."""
+queries, the fused step of every game, tensor packing, random stepping and rollouts.
+
+Byte model: the bytes a kernel must move — the state planes it actually reads (hex's LegalActions needs the two
+stone planes and the meta word, 28 of the 52 bytes of a 9x9 state; its status query only the meta word) plus its
+outputs.  At 2^20 states the small games move 4-40 MB per launch, i.e. a launch lasts about as long as an EMPTY
+launch (2.6 us): their "fraction of 8 TB/s" at that size measures the launch floor, not the kernel, so the
+step / tensor kernels are also timed at 2^24 states (rows tagged n=2^24), where DRAM is the bound."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, open_spiel_amd as osa
@@ -24,6 +30,10 @@ for game, depth in [("connect_four", 12), ("tic_tac_toe", 3), ("hex(board_size=9
     b = osa.StateBatch(ctx, game, N); b.random_steps(3, depth)
     d = b.desc
     sb = d.state_words * d.state_word_bytes
+    # planes a query reads: hex keeps 4 NW + 1 words (black, white, two edge-connection planes, meta)
+    hex_nw = (d.state_words - 1) // 4 if game.startswith("hex") else 0
+    sb_legal = 4 * (2 * hex_nw + 1) if hex_nw else sb
+    sb_status = 4 if hex_nw else sb
     dst = osa.StateBatch(ctx, game, N)
     mask, status = b.step_buffers()
     lm = b.legal_actions_mask()
@@ -32,11 +42,11 @@ for game, depth in [("connect_four", 12), ("tic_tac_toe", 3), ("hex(board_size=9
     report(f"k_step {game}", s, N, "env-steps/s", N * (2 * sb + 1 + d.compact_mask_bytes + 1))
     bits = torch.empty((N, d.mask_words), dtype=torch.int32, device="cuda")
     s = timeit(lambda: osa._abi.check(osa.lib().osg_legal_mask(b._h, bits.data_ptr(), 0)))
-    report(f"k_legal_mask {game}", s, N, "states/s", N * (sb + 4 * d.mask_words))
+    report(f"k_legal_mask {game}", s, N, "states/s", N * (sb_legal + 4 * d.mask_words))
     cur = torch.empty(N, dtype=torch.int8, device="cuda"); term = torch.empty(N, dtype=torch.uint8, device="cuda")
     rets = torch.empty((N, d.num_players), dtype=torch.float64, device="cuda")
     s = timeit(lambda: osa._abi.check(osa.lib().osg_status_query(b._h, cur.data_ptr(), term.data_ptr(), rets.data_ptr(), 0)))
-    report(f"k_status {game}", s, N, "states/s", N * (sb + 2 + 8 * d.num_players))
+    report(f"k_status {game}", s, N, "states/s", N * (sb_status + 2 + 8 * d.num_players))
     n_obs = N if d.obs_size <= 128 else N // 4
     bo = b if n_obs == N else b.gather(torch.arange(n_obs))
     out = torch.empty((n_obs, d.obs_size), dtype=torch.float32, device="cuda")
@@ -52,4 +62,24 @@ for game, depth in [("connect_four", 12), ("tic_tac_toe", 3), ("hex(board_size=9
     roots = osa.StateBatch(ctx, game, 1 << 16); roots.random_steps(5, depth)
     s = timeit(lambda: roots.rollout(1, 16), iters=10, warm=2)
     report(f"k_rollout {game} (2^16 roots x 16)", s, (1 << 16) * 16, "playouts/s")
-    del b, dst, roots
+    del b, dst, roots, mask, status, lm, acts, bits, cur, term, rets, out, bo
+    if sb <= 16:  # the same step / tensor kernels where the launch is long enough to be memory-bound
+        NB = 1 << 24
+        b = osa.StateBatch(ctx, game, NB); b.random_steps(3, depth)
+        dst = osa.StateBatch(ctx, game, NB)
+        mask, status = b.step_buffers()
+        lm = b.legal_actions_mask_bits()[:, 0]
+        acts = torch.where(lm != 0, (torch.log2((lm & -lm).to(torch.float32))).to(torch.int32), torch.full((NB,), 255, device="cuda", dtype=torch.int32)).to(torch.uint8)
+        s = timeit(lambda: b.step(acts, dst=dst, mask=mask, status=status), iters=50, warm=5)
+        report(f"k_step {game} n=2^24", s, NB, "env-steps/s", NB * (2 * sb + 1 + d.compact_mask_bytes + 1))
+        del dst, mask, status, lm, acts
+        out = torch.empty((NB, d.obs_size), dtype=torch.float32, device="cuda")
+        s = timeit(lambda: b.observation_tensor(0, out=out), iters=20, warm=3)
+        report(f"k_observation {game} [{NB},{d.obs_size}] n=2^24", s, NB, "states/s", NB * (sb + 4 * d.obs_size))
+        del out
+        if d.info_size:
+            out = torch.empty((NB, d.info_size), dtype=torch.float32, device="cuda")
+            s = timeit(lambda: b.information_state_tensor(0, out=out), iters=20, warm=3)
+            report(f"k_observation(info) {game} [{NB},{d.info_size}] n=2^24", s, NB, "states/s", NB * (sb + 4 * d.info_size))
+            del out
+        del b

@@ -568,6 +568,10 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
         double ct2[2];
         bool unvisited[2];
         const bool wide = c > 64;  // wave-uniform: nodes with at most 64 children skip the second slot altogether
+        // A node visited more often than it has children has no unvisited child left (every visit after the
+        // expanding one starts with a never-visited child while there is one): its rewards WILL be needed, so
+        // they are loaded with the headers — one memory round trip for the level instead of two.
+        const bool eager = cnt > static_cast<uint32_t>(c);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int k = lane + 64 * j;
@@ -581,6 +585,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
             cm2[j] = META[first + k];
             cc2[j] = COUNT[first + k];
             cf2[j] = FIRST[first + k];
+            if (eager) ct2[j] = TOTAL[first + k];
             unvisited[j] = cc2[j] == 0 && !m_has_outcome(cm2[j]);
           }
         }
@@ -599,7 +604,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
             const int k = lane + 64 * j;
             v2[j] = -INFINITY;
             if (j == 1 && !wide) continue;
-            if (k < c) ct2[j] = TOTAL[first + k];
+            if (k < c && !eager) ct2[j] = TOTAL[first + k];
           }
           if (puct) {  // uniform branch: the two policies share nothing but the loads
             const double prior = 1.0 / c, sqrt_n = sqrt(static_cast<double>(cnt));

@@ -48,7 +48,21 @@ for C in FETCH_SIZE WRITE_SIZE; do
   echo "pmc $C exit $?" | tee -a "$OUT/summary.txt"
 done
 python tools/pmc_traffic.py "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$TAG" > "$OUT/pmc_traffic.log" 2>&1
-tail -12 "$OUT/pmc_traffic.log" | tee -a "$OUT/summary.txt"
+tail -30 "$OUT/pmc_traffic.log" | tee -a "$OUT/summary.txt"
+
+# instruction mix of the hex(9) search kernel (8192 roots x 1024 simulations), three separate counter passes
+P=0
+for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA"; do
+  P=$((P+1))
+  echo "== rocprofv3 --pmc $C (k_mcts_wave)" | tee -a "$OUT/summary.txt"
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_mcts_$P" -- python tools/probe_mcts_one.py > "$OUT/pmc_mcts_$P.log" 2>&1
+  echo "pmc mcts $P exit $?" | tee -a "$OUT/summary.txt"
+done
+python tools/pmc_mcts.py "$OUT" "$TAG" 2>&1 | tee -a "$OUT/summary.txt"
+
+echo "== probes" | tee -a "$OUT/summary.txt"
+timeout 600 python tools/probe_mcts_bench.py > "$OUT/mcts_bench.log" 2>&1; grep hex "$OUT/mcts_bench.log" | tee -a "$OUT/summary.txt"
+timeout 600 python tools/probe_cfr.py > "$OUT/probe_cfr.log" 2>&1; tail -8 "$OUT/probe_cfr.log" | cut -c1-200 | tee -a "$OUT/summary.txt"
 # keep the merged-back directory small (gpurun merges at most 64 MiB)
 find "$OUT" -name '*.db' -size +20M -delete 2>/dev/null
 du -sh "$OUT" | tee -a "$OUT/summary.txt"

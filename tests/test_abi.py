@@ -41,6 +41,11 @@ def test_library_exports_every_declared_symbol(built):
     ("hex(board_size=9)", 81, 0, 2, 729, 0, 81),
     ("hex", 121, 0, 2, 1089, 0, 121),
     ("hex(board_size=5,swap=True)", 26, 0, 2, 225, 0, 25),
+    # one board per Bits width NW = 1 .. 4 (cells <= 32, 64, 96, 128): parse_game fills only the variant that holds it
+    ("hex(board_size=4)", 16, 0, 2, 144, 0, 16),
+    ("hex(board_size=6)", 36, 0, 2, 324, 0, 36),
+    ("hex(num_cols=9,num_rows=10)", 90, 0, 2, 810, 0, 90),
+    ("hex(num_cols=11,num_rows=10)", 110, 0, 2, 990, 0, 110),
     ("kuhn_poker", 2, 3, 2, 7, 11, 3),
     ("kuhn_poker(players=3)", 2, 4, 3, 10, 17, 5),
     ("leduc_poker", 3, 6, 2, 16, 30, 8),

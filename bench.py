@@ -288,6 +288,11 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
         secs = gk.bench_cfr(0, 100000, 1)
         out["cfr"]["cpu_baseline"] = {"value": 100000 / secs, "unit": "iterations/s", "cores": 1, "kind": kind,
                                       "sample": f"100000 CFRSolver iterations, 1 thread, {secs:.2f} s"}
+        # the replicas beside the same number of independent CPU solvers as there are cores
+        secs_r = gk.bench_cfr(0, 50000, threads)
+        out["cfr"]["replicas"]["cpu_baseline"] = {
+            "value": threads * 50000 / secs_r, "unit": "solver-iterations/s", "cores": threads, "kind": kind,
+            "sample": f"{threads} independent CFRSolver objects, one per thread, 50000 iterations each, {secs_r:.2f} s"}
         gl = impl.Game("leduc_poker")
         secs = gl.bench_cfr(2, 100000, 1)
         out["mccfr"]["cpu_baseline"] = {"value": 200000 / secs, "unit": "trajectories/s", "cores": 1, "kind": kind,

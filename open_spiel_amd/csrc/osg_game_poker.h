@@ -389,7 +389,42 @@ struct Leduc {
     }
     return static_cast<float>(ante(s, idx));
   }
-  using ObsCursor = GenericObsCursor<Leduc>;
+  // The tensor walker: every entry but the pot contributions is 0 or 1, so the row is built ONCE as a bit set
+  // (player, private card, community card, the two betting rounds' call / raise pairs) and an entry is a bit
+  // test — ~120 instructions per row instead of ~30 per float through obs_at.
+  struct ObsCursor {
+    uint64_t bits;
+    int idx, nbits;
+    OSG_HD void init(const Params& p, const State& s, int player, int which, int idx0) {
+      const int P = p.players, K = p.iso ? p.cards / 2 : p.cards;
+      idx = idx0;
+      bits = 1ull << player;
+      const int pc = priv(s, player);
+      if (pc >= 0) bits |= 1ull << (P + pc);
+      if (s.pub >= 0) bits |= 1ull << (P + K + s.pub);
+      nbits = P + 2 * K;
+      if (which == 1) {
+        const int bets = 3 * P - 2;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const uint32_t q = seq(s, r);
+          const int len = seqlen(s, r);
+          const int base = P + 2 * K + r * bets * 2;
+          for (int i = 0; i < len; ++i) {
+            const uint32_t mv = (q >> (2 * i)) & 3u;               // 1 call -> "10", 2 raise -> "01"
+            if (mv == 1) bits |= 1ull << (base + 2 * i);
+            else if (mv == 2) bits |= 1ull << (base + 2 * i + 1);
+          }
+        }
+        nbits += 2 * bets * 2;
+      }
+    }
+    OSG_HD float next(const Params&, const State& s, int, int) {
+      const int k = idx++;
+      if (k < nbits) return static_cast<float>((bits >> k) & 1ull);
+      return static_cast<float>(ante(s, k - nbits));                // observation tensor: pot_contribution[P]
+    }
+  };
 };
 
 }  // namespace osg

@@ -1048,7 +1048,7 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
   // one- and two-word states: V states per thread, 16-byte accesses (needs n % V == 0 and aligned side arrays)
   const uintptr_t side = reinterpret_cast<uintptr_t>(d_actions) | reinterpret_cast<uintptr_t>(d_mask) | reinterpret_cast<uintptr_t>(d_status);
   const int kind = src->spec.desc.game_kind;
-  if (kind == kTtt && (n & 3) == 0 && (side & 7u) == 0 && cmb == 2) {
+  if (kind == kTtt && (n & 3) == 0 && (side & 7u) == 0 && cmb == 2) {  // (8 states per thread measured slower)
     k_step_vec<Ttt, uint16_t, 4, 1><<<dim3(grid_for(n / 4)), dim3(kBlock), 0, ctx->stream>>>(
         src->spec.ttt, static_cast<const uint32_t*>(src->d_words), static_cast<uint32_t*>(dst->d_words), n, d_actions,
         static_cast<uint16_t*>(d_mask), d_status);
@@ -1123,8 +1123,7 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
       default: OSG_HEX_OBS(4, hex4); break;
     }
 #undef OSG_HEX_OBS
-  } else if (size <= kRowsMaxSize && (b->spec.desc.game_kind == kTtt || b->spec.desc.game_kind == kKuhn) &&
-             (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) {  // (leduc's cursor is costly per float: the chunked kernel is faster)
+  } else if (size <= kRowsMaxSize && b->spec.desc.game_kind != kHex && (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) {
     // short rows: one lane per state, LDS-staged aligned float4 stores
     const size_t shmem = sizeof(float) * (kRowsBlock / 64) * 64 * static_cast<size_t>(size | 1);
     const unsigned grid = static_cast<unsigned>((b->n + kRowsBlock - 1) / kRowsBlock);

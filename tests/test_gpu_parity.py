@@ -77,12 +77,15 @@ def test_step_by_step_parity(oracle, ctx, game):
 
 @pytest.mark.parametrize("game", ["tic_tac_toe", "connect_four", "hex(board_size=9)", "kuhn_poker", "leduc_poker",
                                   "hex(board_size=4,swap=True)", "leduc_poker(players=3)"])
-def test_fused_step_parity(oracle, ctx, game):
-    """The fused kernel (legality + apply + status + successor mask), out of place."""
+@pytest.mark.parametrize("n", [4096, 4097, 4098])
+def test_fused_step_parity(oracle, ctx, game, n):
+    """The fused kernel (legality + apply + status + successor mask), out of place.  4096 states take the
+    vectorised kernels (connect_four: two states per thread; tic_tac_toe four, kuhn / leduc two states per thread
+    with 16-byte plane accesses), 4097 the one-state-per-thread kernel, 4098 the two-state kernels but not
+    tic_tac_toe's four-state one."""
     import torch
     import open_spiel_amd as osa
     og = oracle.Game(game)
-    n = 4097
     rec = og.random_playouts(7, n)
     L = og.max_plies
     a, b = osa.StateBatch(ctx, game, n), osa.StateBatch(ctx, game, n)

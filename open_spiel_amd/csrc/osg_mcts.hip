@@ -17,6 +17,7 @@
 //   parent u32
 //   count  u32  explore_count
 //   total  f64  total_reward
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -283,7 +284,8 @@ extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_i
   // in 60 % of the free HBM (288 GB: 2^16 hex(9) roots x 1024 simulations need 130 GB of address space and
   // touch a twentieth of it), otherwise what fits, and a tree that outgrows it is collected like the
   // reference collects at that size.
-  const int64_t never = 1 + static_cast<int64_t>(cfg.max_simulations) * widest;
+  // (node indices are 32-bit with 0xFFFFFFFF reserved: a tree never holds more than 2^30 slots)
+  const int64_t never = std::min<int64_t>(1 + static_cast<int64_t>(cfg.max_simulations) * widest, int64_t{1} << 30);
   const int64_t slack = 32 * static_cast<int64_t>(widest);
   int64_t cap, gc_nodes = 0;
   if (cfg.max_nodes > 0 && cfg.max_nodes < never) {

@@ -450,7 +450,7 @@ int osg_mcts_tree_create(const osg_batch* roots, const osg_mcts_cfg* cfg_in, int
   t->board = board;
   // with dont_return_chance_node a simulation can expand a chain of chance nodes besides its decision node
   const int64_t per_sim = static_cast<int64_t>(t->widest) * ((flags & 2) ? 1 + std::max(d.max_chance_nodes, 1) : 1);
-  const int64_t never = 1 + static_cast<int64_t>(cfg_in->max_simulations) * per_sim;
+  const int64_t never = std::min<int64_t>(1 + static_cast<int64_t>(cfg_in->max_simulations) * per_sim, int64_t{1} << 30);
   int64_t cap = never, gc_nodes = 0;
   if (cfg_in->max_nodes > 0 && cfg_in->max_nodes < never) {
     gc_nodes = std::max(2, cfg_in->max_nodes);

@@ -846,28 +846,63 @@ OSG_D void resident_load(double* smem, int H, int I, int P, const ResidentTree& 
   double* uret = smem + 3 * IA;
   double* uprob = uret + rt.K * P;
   uint2* nodes = reinterpret_cast<uint2*>(uprob + rt.nprob);
-  for (int k = threadIdx.x; k < 2 * IA; k += blockDim.x) smem[k] = 0.0;
-  for (int i = threadIdx.x; i < I; i += blockDim.x) {
-    double row[kA], out[kA];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int k = tid; k < 2 * IA; k += nt) smem[k] = 0.0;
+  // The staging loops keep several independent global loads in flight per thread: written as "load, then
+  // store" per element they were a chain of dependent round trips (a 256-thread workgroup staged leduc's 9 457
+  // records in 37 of them — 59 us of fixed cost per launch, most of a small mini-batch's time).
+  constexpr int kU = 4;
+  for (int i0 = tid; i0 < I; i0 += kU * nt) {
+    double row[kU][kA];
+    int n[kU];
 #pragma unroll
-    for (int a = 0; a < kA; ++a) row[a] = regrets[i * kA + a];
-    const int n = nact[i];
-    double sum_pos = 0.0;
+    for (int u = 0; u < kU; ++u) {
+      const int i = i0 + u * nt;
+      n[u] = i < I ? nact[i] : 0;
 #pragma unroll
-    for (int a = 0; a < kA; ++a)
-      if (a < n && row[a] > 0) sum_pos += row[a];
-#pragma unroll
-    for (int a = 0; a < kA; ++a) {
-      if (a >= n) out[a] = 0.0;
-      else if (sum_pos > 0) out[a] = row[a] > 0 ? row[a] / sum_pos : 0.0;
-      else out[a] = 1.0 / n;
+      for (int a = 0; a < kA; ++a) row[u][a] = i < I ? regrets[i * kA + a] : 0.0;
     }
 #pragma unroll
-    for (int a = 0; a < kA; ++a) pol[i * kA + a] = out[a];
+    for (int u = 0; u < kU; ++u) {
+      const int i = i0 + u * nt;
+      if (i >= I) continue;
+      double sum_pos = 0.0;
+#pragma unroll
+      for (int a = 0; a < kA; ++a)
+        if (a < n[u] && row[u][a] > 0) sum_pos += row[u][a];
+#pragma unroll
+      for (int a = 0; a < kA; ++a) {
+        double o;
+        if (a >= n[u]) o = 0.0;
+        else if (sum_pos > 0) o = row[u][a] > 0 ? row[u][a] / sum_pos : 0.0;
+        else o = 1.0 / n[u];
+        pol[i * kA + a] = o;
+      }
+    }
   }
-  for (int k = threadIdx.x; k < rt.K * P; k += blockDim.x) uret[k] = rt.uret[k];
-  for (int k = threadIdx.x; k < rt.nprob; k += blockDim.x) uprob[k] = rt.uprob[k];
-  for (int k = threadIdx.x; k < H; k += blockDim.x) nodes[k] = rt.rec[k];
+  for (int k = tid; k < rt.K * P; k += nt) uret[k] = rt.uret[k];
+  for (int k = tid; k < rt.nprob; k += nt) uprob[k] = rt.uprob[k];
+  {  // the packed tree, two records (16 bytes) per load, kU loads in flight per thread
+    const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(rt.rec);
+    const int n4 = H / 2;
+    for (int k0 = tid; k0 < n4; k0 += kU * nt) {
+      uint4 v[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int k = k0 + u * nt;
+        v[u] = k < n4 ? src4[k] : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int k = k0 + u * nt;
+        if (k < n4) {
+          nodes[2 * k] = make_uint2(v[u].x, v[u].y);
+          nodes[2 * k + 1] = make_uint2(v[u].z, v[u].w);
+        }
+      }
+    }
+    if ((H & 1) && tid == 0) nodes[H - 1] = rt.rec[H - 1];
+  }
   *o_dreg = smem; *o_dpol = smem + IA; *o_pol = pol; *o_uret = uret; *o_uprob = uprob; *o_nodes = nodes;
 }
 

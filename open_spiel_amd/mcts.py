@@ -58,7 +58,6 @@ class VPNetEvaluator(BatchedEvaluator):
 
     def __init__(self, model):
         self.model = model
-        self._cache = None
 
     def evaluate(self, leaf, want_prior, want_value):
         if leaf.num_players != 2:

@@ -767,7 +767,7 @@ int check_illegal(osg_ctx* ctx, int64_t* h_illegal) {
   OSG_HIP(hipStreamSynchronize(ctx->stream));
   if (count) OSG_HIP(hipMemsetAsync(ctx->d_illegal, 0, sizeof(count), ctx->stream));
   if (h_illegal) { *h_illegal = static_cast<int64_t>(count); return OSG_OK; }
-  if (count) return set_error(OSG_ERR_ILLEGAL, std::to_string(count) + " illegal action(s) applied");
+  if (count) return set_error(OSG_ERR_ILLEGAL, std::to_string(count) + " illegal action(s) applied (or out-of-range gather indices)");
   return OSG_OK;
 }
 

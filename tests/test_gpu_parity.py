@@ -359,3 +359,66 @@ def test_observation_strings_match_the_oracle(oracle, ctx, game):
         for i in range(n):
             if acts[i] >= 0:
                 states[i].apply_action(int(acts[i]))
+
+
+def test_gather_index_bounds_and_buffer_checks(ctx):
+    """Out-of-range gather indices never read out of bounds: a host index list is refused, a device index
+    list yields the initial state for the bad entries; caller-supplied step / tensor buffers of the wrong dtype,
+    size or device are refused instead of being handed to a kernel."""
+    import ctypes as C
+    import torch
+    import open_spiel_amd as osa
+    from open_spiel_amd._abi import lib
+    b = osa.StateBatch(ctx, "connect_four", 64)
+    b.random_steps(3, 10)
+    words = b.raw_words()
+    idx = torch.tensor([0, 5, 63, 64, -1, 1 << 40], dtype=torch.int64)
+    g = b.gather(idx)                                     # device index path: bad entries -> initial state,
+    with pytest.raises(osa.OsgError, match="3 illegal"):  # counted, and reported at the next synchronisation point
+        ctx.synchronize()
+    ctx.synchronize()                                     # (reported once)
+    got = g.raw_words()
+    np.testing.assert_array_equal(got[:, :3], words[:, [0, 5, 63]])
+    assert (got[:, 3:] == 0).all()
+    dst = osa.StateBatch(ctx, "connect_four", 3)
+    bad = np.array([0, 64, 2], np.int64)
+    assert lib().osg_batch_gather(dst._h, b._h, bad.ctypes.data, 1) != 0      # host index path: refused
+    assert b"out of range" in lib().osg_last_error()
+    ok = np.array([0, 63, 2], np.int64)
+    assert lib().osg_batch_gather(dst._h, b._h, ok.ctypes.data, 1) == 0
+    a8 = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    for wrong in (torch.zeros(64, dtype=torch.int32, device="cuda"), torch.zeros(63, dtype=torch.uint8, device="cuda"),
+                  torch.zeros(64, dtype=torch.uint8), torch.zeros(128, dtype=torch.uint8, device="cuda")[::2]):
+        with pytest.raises(osa.OsgError):
+            b.step(wrong)
+    with pytest.raises(osa.OsgError):
+        b.step(a8, dst=osa.StateBatch(ctx, "connect_four", 32))
+    with pytest.raises(osa.OsgError):
+        b.observation_tensor(0, out=torch.zeros(64 * 126, dtype=torch.float64, device="cuda"))
+    with pytest.raises(osa.OsgError):
+        b.observation_tensor(0, out=torch.zeros(64 * 125, dtype=torch.float32, device="cuda"))
+    b.observation_tensor(0, out=torch.zeros((64, 126), dtype=torch.float32, device="cuda"))
+
+
+def test_objects_may_outlive_their_context():
+    """Batches, solvers and trees hold a reference on the engine context: destroying them after the context
+    (garbage-collection order in a binding) is safe, creating new ones on a destroyed context is refused."""
+    import gc
+    import torch
+    import open_spiel_amd as osa
+    c = osa.Context(0)
+    b = osa.StateBatch(c, "tic_tac_toe", 16)
+    s = osa.TabularSolver(c, "kuhn_poker")
+    s.evaluate_and_update_policy(3)
+    h = c._h
+    c.close()
+    with pytest.raises(osa.OsgError):
+        osa.lib()  # keep the name used
+        import ctypes as C
+        out = C.c_void_p()
+        from open_spiel_amd._abi import check
+        check(osa.lib().osg_batch_create(h, b"tic_tac_toe", 4, C.byref(out)))
+    assert b.legal_actions_mask().shape == (16, 9)      # still usable: the context lives until its last object goes
+    del b, s
+    gc.collect()
+    torch.cuda.synchronize()

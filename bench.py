@@ -200,6 +200,23 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
                    "scaling": "strong",
                    "config": {"workload": "hex(board_size=9) MCTSBot(RandomRolloutEvaluator(1), uct_c=2, 1024 sims) "
                                           f"x 2^16 roots, {count} roots on rank 0, wave-per-root layout"}}
+    # Issue-rate view of the search kernel (it moves ~3.5 KB per simulation: far from a memory roofline): vector and
+    # scalar instructions per simulation from the committed counter profile, issue intervals from
+    # profiles/r02_clock_probe.log (a wave64 vector instruction every 1.03 ns per SIMD; scalar 0.92 ns at best).
+    if rank == 0:
+        mix = mcts_instruction_mix()
+        if mix:
+            simds = torch.cuda.get_device_properties(0).multi_processor_count * 4
+            ns_per_sim = dt / (float(done.item()) / world / simds) * 1e9
+            serial = mix["valu"] * 1.03 + mix["salu"] * 0.92
+            out["mcts"]["roofline"] = {
+                "bound": "instruction issue", "valu_per_sim": mix["valu"], "salu_per_sim": mix["salu"],
+                "source": mix["source"], "ns_per_sim_per_simd": ns_per_sim,
+                "issue_ns_if_vector_and_scalar_do_not_overlap": serial,
+                "issue_ns_if_they_overlap_fully": max(mix["valu"] * 1.03, mix["salu"] * 0.92),
+                "frac_of_non_overlapped_issue": serial / ns_per_sim,
+                "note": "the kernel runs at about the SUM of its vector and scalar issue times (DESIGN.md 9b): fewer "
+                        "instructions per simulation is the only lever"}
     del roots, res
 
     # ---- config 3: kuhn_poker CFRSolver (full-tree regret / strategy update kernel) ----
@@ -322,6 +339,24 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
 
 
 NASH_CONV_THRESHOLDS = (1.0, 0.3, 0.1)
+
+
+def mcts_instruction_mix():
+    """SQ_INSTS_VALU / SQ_INSTS_SALU per simulation of the hex(9) search kernel from the newest committed
+    profiles/r*_pmc_k_mcts_wave_hex9_8192x1024.csv, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_mcts_wave_hex9_8192x1024.csv")))
+    if not files:
+        return None
+    vals = {}
+    with open(files[-1]) as f:
+        for ln in f:
+            parts = ln.split(",")
+            if len(parts) >= 3 and parts[0] in ("SQ_INSTS_VALU", "SQ_INSTS_SALU"):
+                vals[parts[0]] = float(parts[2])
+    if len(vals) != 2:
+        return None
+    return {"valu": vals["SQ_INSTS_VALU"], "salu": vals["SQ_INSTS_SALU"], "source": os.path.relpath(files[-1], ROOT)}
 
 
 def mccfr_time_to_nash_conv(osa, torch, ctx, batch, budget_s):

@@ -112,6 +112,8 @@ class Communicator {
 
 class State;
 class BatchedState;
+class Policy;
+class TabularPolicy;
 
 class Game : public std::enable_shared_from_this<Game> {
  public:
@@ -853,8 +855,12 @@ class DeviceTabularSolver {
     }
     return out;
   }
-  TabularPolicyTable TabularAveragePolicy() const { return Policy(true); }  // cfr.h:205-211
-  TabularPolicyTable TabularCurrentPolicy() const { return Policy(false); }
+  TabularPolicyTable TabularAveragePolicy() const { return PolicyTableOf(true); }  // cfr.h:205-211
+  TabularPolicyTable TabularCurrentPolicy() const { return PolicyTableOf(false); }
+  // cfr.h:198-211.  (The reference's policy objects are live views of the solver's table; these are snapshots
+  // of the device tables at the time of the call.)
+  inline std::shared_ptr<open_spiel::hip::Policy> AveragePolicy() const;
+  inline std::shared_ptr<open_spiel::hip::Policy> CurrentPolicy() const;
   // Device policy evaluation: {expected returns [P], best-response values [P], NashConv, Exploitability}
   // of the tables' average (0) / current (1) policy, or of `table` (which == 2; keyed by infostate string).
   struct Evaluation {
@@ -945,7 +951,7 @@ class DeviceTabularSolver {
     if (osg_cfr_infostate_key(s_, i, buf, sizeof(buf)) < 0) SpielFatalError(osg_last_error());
     return buf;
   }
-  TabularPolicyTable Policy(bool average) const {
+  TabularPolicyTable PolicyTableOf(bool average) const {
     Tables t = Download();
     TabularPolicyTable out;
     for (int i = 0; i < t.I; ++i) {
@@ -1138,6 +1144,199 @@ inline double NashConv(const Game& game, const TabularPolicyTable& policy) {
 }
 inline std::vector<double> ExpectedReturns(const Game& game, const TabularPolicyTable& policy) {
   return CFRSolver(game).EvaluatePolicy(2, &policy).expected_returns;
+}
+
+}  // namespace algorithms
+
+// ---- policy.h: Policy / TabularPolicy / UniformPolicy / PreferredActionPolicy and the policy factories ----------
+class Policy {  // policy.h:69-150
+ public:
+  virtual ~Policy() = default;
+  virtual ActionsAndProbs GetStatePolicy(const State& state) const { return GetStatePolicy(state, state.CurrentPlayer()); }
+  virtual ActionsAndProbs GetStatePolicy(const State& state, Player player) const {
+    return GetStatePolicy(state.InformationStateString(player));
+  }
+  virtual ActionsAndProbs GetStatePolicy(const std::string& /*info_state*/) const {
+    SpielFatalError("GetStatePolicy(const std::string&) unimplemented.");
+  }
+  std::unordered_map<Action, double> GetStatePolicyAsMap(const State& state) const { return AsMap(GetStatePolicy(state)); }
+  std::unordered_map<Action, double> GetStatePolicyAsMap(const std::string& info_state) const {
+    return AsMap(GetStatePolicy(info_state));
+  }
+  std::pair<std::vector<Action>, std::vector<double>> GetStatePolicyAsParallelVectors(const State& state) const {
+    return AsVectors(GetStatePolicy(state));
+  }
+  std::pair<std::vector<Action>, std::vector<double>> GetStatePolicyAsParallelVectors(const std::string& info_state) const {
+    return AsVectors(GetStatePolicy(info_state));
+  }
+
+ private:
+  static std::unordered_map<Action, double> AsMap(const ActionsAndProbs& ap) {
+    std::unordered_map<Action, double> m;
+    for (const auto& x : ap) m[x.first] = x.second;
+    return m;
+  }
+  static std::pair<std::vector<Action>, std::vector<double>> AsVectors(const ActionsAndProbs& ap) {
+    std::pair<std::vector<Action>, std::vector<double>> v;
+    for (const auto& x : ap) { v.first.push_back(x.first); v.second.push_back(x.second); }
+    return v;
+  }
+};
+
+// The infostates of a game with their legal actions, from the device's flattened tree (get_all_states.cc /
+// policy.cc:205-237 walk the game for the same list).
+inline std::unordered_map<std::string, std::vector<Action>> AllInfoStates(const Game& game) {
+  std::unordered_map<std::string, std::vector<Action>> out;
+  for (const auto& kv : algorithms::CFRSolverBase(game, false, false, false).InfoStateValuesTable())
+    out[kv.first] = kv.second.legal_actions;
+  return out;
+}
+
+class TabularPolicy : public Policy {  // policy.h:158-283
+ public:
+  TabularPolicy() = default;
+  explicit TabularPolicy(const Game& game) {  // the uniform random policy (policy.cc:205-237)
+    for (const auto& kv : AllInfoStates(game))
+      for (Action a : kv.second) policy_table_[kv.first].push_back({a, 1.0 / kv.second.size()});
+  }
+  explicit TabularPolicy(algorithms::TabularPolicyTable table) : policy_table_(std::move(table)) {}
+  TabularPolicy(const Game& game, const Policy& policy) {  // policy.h:167-171: tabularise any policy
+    const auto all = AllInfoStates(game);
+    bool by_key = true;
+    try {
+      if (!all.empty()) (void)policy.GetStatePolicy(all.begin()->first);
+    } catch (const SpielException&) {
+      by_key = false;  // the policy only answers for State objects: walk the game (policy.cc:205-237)
+    }
+    if (by_key) {
+      for (const auto& kv : all) {
+        ActionsAndProbs ap = policy.GetStatePolicy(kv.first);
+        if (ap.empty()) SpielFatalError(kv.first + " not found in policy.");
+        policy_table_[kv.first] = std::move(ap);
+      }
+      return;
+    }
+    std::vector<std::unique_ptr<State>> todo;
+    todo.push_back(game.NewInitialState());
+    while (!todo.empty()) {
+      std::unique_ptr<State> st = std::move(todo.back());
+      todo.pop_back();
+      if (st->IsTerminal()) continue;
+      if (st->IsChanceNode()) {
+        for (const auto& ap : st->ChanceOutcomes()) todo.push_back(st->Child(ap.first));
+        continue;
+      }
+      const std::string key = st->InformationStateString();
+      if (!policy_table_.count(key)) policy_table_[key] = policy.GetStatePolicy(*st, st->CurrentPlayer());
+      for (Action a : st->LegalActions()) todo.push_back(st->Child(a));
+    }
+  }
+  using Policy::GetStatePolicy;
+  ActionsAndProbs GetStatePolicy(const std::string& info_state) const override {  // policy.h:189-196
+    auto it = policy_table_.find(info_state);
+    return it == policy_table_.end() ? ActionsAndProbs{} : it->second;
+  }
+  void SetProb(const std::string& info_state, Action action, double prob) {  // policy.h:222-229
+    for (auto& ap : policy_table_[info_state])
+      if (ap.first == action) { ap.second = prob; return; }
+    policy_table_[info_state].push_back({action, prob});
+  }
+  void SetStatePolicy(const std::string& info_state, const ActionsAndProbs& state_policy) {
+    policy_table_[info_state] = state_policy;
+  }
+  algorithms::TabularPolicyTable& PolicyTable() { return policy_table_; }
+  const algorithms::TabularPolicyTable& PolicyTable() const { return policy_table_; }
+  int size() const { return static_cast<int>(policy_table_.size()); }
+  std::string ToString() const {  // policy.h:260-276: infostates in sorted order
+    std::vector<std::string> keys;
+    for (const auto& kv : policy_table_) keys.push_back(kv.first);
+    std::sort(keys.begin(), keys.end());
+    std::string str;
+    for (const std::string& k : keys) {
+      str += k + ":";
+      for (const auto& ap : policy_table_.at(k)) {
+        std::ostringstream o;
+        o << " " << ap.first << "=" << ap.second;
+        str += o.str();
+      }
+      str += "\n";
+    }
+    return str;
+  }
+
+ private:
+  algorithms::TabularPolicyTable policy_table_;
+};
+
+class UniformPolicy : public Policy {  // policy.h:318-334
+ public:
+  using Policy::GetStatePolicy;
+  ActionsAndProbs GetStatePolicy(const State& state, Player player) const override {
+    if (state.IsChanceNode()) return state.ChanceOutcomes();
+    ActionsAndProbs ap;
+    const std::vector<Action> legal = state.LegalActions(player);
+    for (Action a : legal) ap.push_back({a, 1.0 / legal.size()});
+    return ap;
+  }
+};
+
+class PreferredActionPolicy : public Policy {  // policy.h:363-377, policy.cc:481-497
+ public:
+  explicit PreferredActionPolicy(std::vector<Action> preference_order) : order_(std::move(preference_order)) {}
+  using Policy::GetStatePolicy;
+  ActionsAndProbs GetStatePolicy(const State& state, Player player) const override {
+    const std::vector<Action> legal = state.LegalActions(player);
+    for (Action want : order_) {
+      if (std::find(legal.begin(), legal.end(), want) == legal.end()) continue;
+      ActionsAndProbs ap;
+      for (Action a : legal) ap.push_back({a, a == want ? 1.0 : 0.0});
+      return ap;
+    }
+    SpielFatalError("No preferred action found in the legal actions!");
+  }
+
+ private:
+  std::vector<Action> order_;
+};
+
+inline TabularPolicy GetUniformPolicy(const Game& game) { return TabularPolicy(game); }  // policy.cc:239
+inline TabularPolicy GetFirstActionPolicy(const Game& game) {  // policy.cc:375-398
+  TabularPolicy p;
+  for (const auto& kv : AllInfoStates(game)) {
+    ActionsAndProbs ap;
+    for (size_t i = 0; i < kv.second.size(); ++i) ap.push_back({kv.second[i], i == 0 ? 1.0 : 0.0});
+    p.SetStatePolicy(kv.first, ap);
+  }
+  return p;
+}
+inline TabularPolicy GetEmptyTabularPolicy(const Game& game, bool initialize_to_uniform = false) {  // policy.cc:159-203
+  if (initialize_to_uniform) return TabularPolicy(game);
+  TabularPolicy p;
+  for (const auto& kv : AllInfoStates(game)) {
+    ActionsAndProbs ap;
+    for (Action a : kv.second) ap.push_back({a, 0.0});
+    p.SetStatePolicy(kv.first, ap);
+  }
+  return p;
+}
+inline TabularPolicy ToTabularPolicy(const Game& game, const Policy* policy) { return TabularPolicy(game, *policy); }
+inline std::shared_ptr<Policy> algorithms::DeviceTabularSolver::AveragePolicy() const {
+  return std::make_shared<TabularPolicy>(TabularAveragePolicy());
+}
+inline std::shared_ptr<Policy> algorithms::DeviceTabularSolver::CurrentPolicy() const {
+  return std::make_shared<TabularPolicy>(TabularCurrentPolicy());
+}
+
+namespace algorithms {
+
+// algorithms::Exploitability / NashConv / ExpectedReturns of ANY Policy (tabular_exploitability.h:30-60,
+// expected_returns.h): tabularised over the game's infostates, judged on the device.
+inline double Exploitability(const Game& game, const Policy& policy) {
+  return Exploitability(game, TabularPolicy(game, policy).PolicyTable());
+}
+inline double NashConv(const Game& game, const Policy& policy) { return NashConv(game, TabularPolicy(game, policy).PolicyTable()); }
+inline std::vector<double> ExpectedReturns(const Game& game, const Policy& policy) {
+  return ExpectedReturns(game, TabularPolicy(game, policy).PolicyTable());
 }
 
 // kuhn_poker::GetOptimalPolicy (kuhn_poker.cc:451-474): the alpha-family of Nash equilibria of 2-player

@@ -27,31 +27,6 @@ py::array_t<T> as_array(const std::vector<T>& v, std::vector<py::ssize_t> shape)
   return a;
 }
 
-// pyspiel.TabularPolicy-like result of solver.average_policy() / tabular_average_policy().
-class TabularPolicy {
- public:
-  explicit TabularPolicy(TabularPolicyTable t) : table_(std::move(t)) {}
-  const TabularPolicyTable& policy_table() const { return table_; }
-  std::unordered_map<Action, double> action_probabilities(const State& state, Player player) const {
-    return get_state_policy_as_map(state.InformationStateString(player));
-  }
-  std::unordered_map<Action, double> action_probabilities_current(const State& state) const {
-    return action_probabilities(state, state.CurrentPlayer());
-  }
-  ActionsAndProbs get_state_policy(const std::string& info_state) const {
-    auto it = table_.find(info_state);
-    return it == table_.end() ? ActionsAndProbs{} : it->second;
-  }
-  std::unordered_map<Action, double> get_state_policy_as_map(const std::string& info_state) const {
-    std::unordered_map<Action, double> out;
-    for (const auto& ap : get_state_policy(info_state)) out[ap.first] = ap.second;
-    return out;
-  }
-
- private:
-  TabularPolicyTable table_;
-};
-
 }  // namespace
 
 
@@ -189,6 +164,23 @@ static LeducFields LeducView(const State& st) {
   }
   return f;
 }
+
+// Python subclasses of Policy: the reference's python/policy.py interface, action_probabilities(state, player_id)
+class PyPolicy : public Policy {
+ public:
+  using Policy::Policy;
+  ActionsAndProbs GetStatePolicy(const State& state, Player player) const override {
+    py::gil_scoped_acquire gil;
+    py::function f = py::get_override(static_cast<const Policy*>(this), "action_probabilities");
+    if (!f) SpielFatalError("a Python Policy must define action_probabilities(state, player_id)");
+    py::dict d = f(py::cast(state, py::return_value_policy::reference), player);
+    ActionsAndProbs ap;
+    for (auto kv : d) ap.push_back({kv.first.cast<Action>(), kv.second.cast<double>()});
+    std::sort(ap.begin(), ap.end());
+    return ap;
+  }
+  ActionsAndProbs GetStatePolicy(const State& state) const override { return GetStatePolicy(state, state.CurrentPlayer()); }
+};
 
 // Python subclasses of Evaluator (mcts.h:83-92)
 class PyEvaluator : public Evaluator {
@@ -396,12 +388,49 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("mcts_search", &MCTSBot::MCTSearch, py::arg("state"))
       .def("step_batch", &MCTSBot::StepBatch, py::arg("states"), py::call_guard<py::gil_scoped_release>());
 
-  py::class_<TabularPolicy>(m, "TabularPolicy")
-      .def("policy_table", &TabularPolicy::policy_table)
-      .def("action_probabilities", &TabularPolicy::action_probabilities, py::arg("state"), py::arg("player"))
-      .def("action_probabilities", &TabularPolicy::action_probabilities_current, py::arg("state"))
-      .def("get_state_policy", &TabularPolicy::get_state_policy, py::arg("info_state"))
-      .def("get_state_policy_as_map", &TabularPolicy::get_state_policy_as_map, py::arg("info_state"));
+  // python/pybind11/policy.cc:90-222: Policy, TabularPolicy, UniformPolicy, PreferredActionPolicy and the factories.
+  // Python subclasses of Policy (action_probabilities(state, player) -> {action: prob}) are accepted by the judge
+  // functions through the trampoline.
+  py::class_<Policy, PyPolicy, std::shared_ptr<Policy>>(m, "Policy")
+      .def(py::init<>())
+      .def("action_probabilities", [](const Policy& p, const State& s) { return p.GetStatePolicyAsMap(s); }, py::arg("state"))
+      .def("action_probabilities",
+           [](const Policy& p, const State& s, Player pl) {
+             std::unordered_map<Action, double> m;
+             for (const auto& ap : p.GetStatePolicy(s, pl)) m[ap.first] = ap.second;
+             return m;
+           },
+           py::arg("state"), py::arg("player_id"))
+      .def("get_state_policy", [](const Policy& p, const State& s) { return p.GetStatePolicy(s); }, py::arg("state"))
+      .def("get_state_policy", [](const Policy& p, const State& s, Player pl) { return p.GetStatePolicy(s, pl); },
+           py::arg("state"), py::arg("player"))
+      .def("get_state_policy", [](const Policy& p, const std::string& k) { return p.GetStatePolicy(k); }, py::arg("info_state"))
+      .def("get_state_policy_as_map", [](const Policy& p, const std::string& k) { return p.GetStatePolicyAsMap(k); },
+           py::arg("info_state"))
+      .def("get_state_policy_as_parallel_vectors",
+           [](const Policy& p, const State& s) { return p.GetStatePolicyAsParallelVectors(s); }, py::arg("state"))
+      .def("get_state_policy_as_parallel_vectors",
+           [](const Policy& p, const std::string& k) { return p.GetStatePolicyAsParallelVectors(k); }, py::arg("info_state"));
+  py::class_<TabularPolicy, Policy, std::shared_ptr<TabularPolicy>>(m, "TabularPolicy")
+      .def(py::init<TabularPolicyTable>(), py::arg("table"))
+      .def(py::init([](std::shared_ptr<Game> g) { return std::make_shared<TabularPolicy>(*g); }), py::arg("game"))
+      .def("policy_table", [](const TabularPolicy& p) { return p.PolicyTable(); })
+      .def("set_prob", &TabularPolicy::SetProb, py::arg("info_state"), py::arg("action"), py::arg("prob"))
+      .def("set_state_policy", &TabularPolicy::SetStatePolicy, py::arg("info_state"), py::arg("state_policy"))
+      .def("size", &TabularPolicy::size)
+      .def("__len__", &TabularPolicy::size)
+      .def("to_string", &TabularPolicy::ToString)
+      .def("__str__", &TabularPolicy::ToString)
+      .def("__repr__", &TabularPolicy::ToString);
+  py::class_<UniformPolicy, Policy, std::shared_ptr<UniformPolicy>>(m, "UniformPolicy").def(py::init<>());
+  py::class_<PreferredActionPolicy, Policy, std::shared_ptr<PreferredActionPolicy>>(m, "PreferredActionPolicy")
+      .def(py::init<std::vector<Action>>(), py::arg("preference_order"));
+  m.def("UniformRandomPolicy", [](std::shared_ptr<Game> g) { return GetUniformPolicy(*g); }, py::arg("game"));
+  m.def("GetFirstActionPolicy", [](std::shared_ptr<Game> g) { return GetFirstActionPolicy(*g); }, py::arg("game"));
+  m.def("GetEmptyTabularPolicy", [](std::shared_ptr<Game> g, bool uniform) { return GetEmptyTabularPolicy(*g, uniform); },
+        py::arg("game"), py::arg("initialize_to_uniform") = false);
+  m.def("ToTabularPolicy", [](std::shared_ptr<Game> g, const Policy& p) { return TabularPolicy(*g, p); }, py::arg("game"),
+        py::arg("policy"));
 
   py::class_<CFRInfoStateValues>(m, "CFRInfoStateValues")
       .def_readonly("legal_actions", &CFRInfoStateValues::legal_actions)
@@ -413,9 +442,9 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("evaluate_and_update_policy", py::overload_cast<>(&CFRSolverBase::EvaluateAndUpdatePolicy))
       .def("evaluate_and_update_policy", py::overload_cast<int>(&CFRSolverBase::EvaluateAndUpdatePolicy),
            py::arg("iterations"))
-      .def("average_policy", [](const CFRSolverBase& s) { return TabularPolicy(s.TabularAveragePolicy()); })
-      .def("tabular_average_policy", [](const CFRSolverBase& s) { return TabularPolicy(s.TabularAveragePolicy()); })
-      .def("current_policy", [](const CFRSolverBase& s) { return TabularPolicy(s.TabularCurrentPolicy()); })
+      .def("average_policy", [](const CFRSolverBase& s) { return std::make_shared<TabularPolicy>(s.TabularAveragePolicy()); })
+      .def("tabular_average_policy", [](const CFRSolverBase& s) { return std::make_shared<TabularPolicy>(s.TabularAveragePolicy()); })
+      .def("current_policy", [](const CFRSolverBase& s) { return std::make_shared<TabularPolicy>(s.TabularCurrentPolicy()); })
       .def("info_state_values_table", &CFRSolverBase::InfoStateValuesTable)
       .def("serialize", &CFRSolverBase::Serialize, py::arg("double_precision") = -1, py::arg("delimiter") = "<~>");
   py::class_<CFRSolver, CFRSolverBase>(m, "CFRSolver")  // policy.cc:224-262 (pickle = serialize / deserialize)
@@ -446,16 +475,16 @@ PYBIND11_MODULE(pyspiel_hip, m) {
   });
 
   // pyspiel.exploitability / nash_conv / expected_returns (python/pybind11/policy.cc) for tabular policies
-  m.def("exploitability", [](std::shared_ptr<Game> g, const TabularPolicy& p) { return Exploitability(*g, p.policy_table()); },
+  m.def("exploitability", [](std::shared_ptr<Game> g, const Policy& p) { return Exploitability(*g, p); },
         py::arg("game"), py::arg("policy"));
-  m.def("nash_conv", [](std::shared_ptr<Game> g, const TabularPolicy& p) { return NashConv(*g, p.policy_table()); },
+  m.def("nash_conv", [](std::shared_ptr<Game> g, const Policy& p) { return NashConv(*g, p); },
         py::arg("game"), py::arg("policy"));
-  m.def("expected_returns", [](std::shared_ptr<Game> g, const TabularPolicy& p) { return ExpectedReturns(*g, p.policy_table()); },
+  m.def("expected_returns", [](std::shared_ptr<Game> g, const Policy& p) { return ExpectedReturns(*g, p); },
         py::arg("game"), py::arg("policy"));
 
   // pyspiel.kuhn_poker.get_optimal_policy (python/pybind11/games_kuhn_poker.cc:23-24)
   py::module_ kuhn = m.def_submodule("kuhn_poker");
-  kuhn.def("get_optimal_policy", [](double alpha) { return TabularPolicy(kuhn_poker::GetOptimalPolicy(alpha)); },
+  kuhn.def("get_optimal_policy", [](double alpha) { return std::make_shared<TabularPolicy>(kuhn_poker::GetOptimalPolicy(alpha)); },
            py::arg("alpha"));
 
   // ---- python/pybind11/observer.cc:30-97 ----
@@ -563,7 +592,7 @@ PYBIND11_MODULE(pyspiel_hip, m) {
            py::arg("seed"), py::arg("iterations"))
       .def("run_mini_batch", &ExternalSamplingMCCFRSolver::RunMiniBatch, py::arg("trajectories"))
       .def("average_policy",
-           [](const ExternalSamplingMCCFRSolver& s) { return TabularPolicy(s.TabularAveragePolicy()); })
+           [](const ExternalSamplingMCCFRSolver& s) { return std::make_shared<TabularPolicy>(s.TabularAveragePolicy()); })
       .def("info_state_values_table", &ExternalSamplingMCCFRSolver::InfoStateValuesTable)
       .def("serialize", &ExternalSamplingMCCFRSolver::Serialize, py::arg("double_precision") = -1,
            py::arg("delimiter") = "<~>")
@@ -579,7 +608,7 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("run_iteration", &OutcomeSamplingMCCFRSolver::RunIteration)
       .def("run_mini_batch", &OutcomeSamplingMCCFRSolver::RunMiniBatch, py::arg("episodes"))
       .def("average_policy",
-           [](const OutcomeSamplingMCCFRSolver& s) { return TabularPolicy(s.TabularAveragePolicy()); })
+           [](const OutcomeSamplingMCCFRSolver& s) { return std::make_shared<TabularPolicy>(s.TabularAveragePolicy()); })
       .def("info_state_values_table", &OutcomeSamplingMCCFRSolver::InfoStateValuesTable)
       .def("serialize", &OutcomeSamplingMCCFRSolver::Serialize, py::arg("double_precision") = -1,
            py::arg("delimiter") = "<~>")

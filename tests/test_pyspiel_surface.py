@@ -478,3 +478,54 @@ def test_game_submodules(pyspiel):
     assert s.round1() == [2, 1] and s.round2() == [1]
     with pytest.raises(pyspiel.SpielError):
         pyspiel.load_game("kuhn_poker").new_initial_state().public_card()
+
+
+@pytest.mark.gpu
+def test_policy_hierarchy_and_judges(pyspiel):
+    """python/pybind11/policy.cc:90-222: Policy / TabularPolicy / UniformPolicy / PreferredActionPolicy, the
+    factories, and exploitability / nash_conv / expected_returns of ANY Policy — the reference's known answers
+    (tabular_exploitability_test.cc: uniform kuhn 0.4583..., leduc 2.3736...; first-action NashConv 2;
+    Kuhn optimal policy 0; policy_test.py / exploitability_test.py)."""
+    kuhn = pyspiel.load_game("kuhn_poker")
+    uniform = pyspiel.UniformPolicy()
+    assert isinstance(uniform, pyspiel.Policy)
+    assert abs(pyspiel.exploitability(kuhn, uniform) - 0.4583333333333335) < 1e-14
+    tab = pyspiel.UniformRandomPolicy(kuhn)
+    assert isinstance(tab, pyspiel.TabularPolicy) and isinstance(tab, pyspiel.Policy) and len(tab) == 12
+    assert tab.get_state_policy("0pb") == [(0, 0.5), (1, 0.5)]
+    assert abs(pyspiel.exploitability(kuhn, tab) - 0.4583333333333335) < 1e-14
+    assert abs(pyspiel.nash_conv(kuhn, pyspiel.GetFirstActionPolicy(kuhn)) - 2.0) < 1e-14
+    assert abs(pyspiel.nash_conv(kuhn, pyspiel.PreferredActionPolicy([0, 1])) - 2.0) < 1e-14   # always pass == first action
+    assert abs(pyspiel.exploitability(kuhn, pyspiel.kuhn_poker.get_optimal_policy(0.2))) < 1e-14
+    ev = pyspiel.expected_returns(kuhn, pyspiel.kuhn_poker.get_optimal_policy(0.1))
+    assert abs(ev[0] + 1 / 18) < 1e-14 and abs(ev[1] - 1 / 18) < 1e-14
+    leduc = pyspiel.load_game("leduc_poker")
+    assert abs(pyspiel.exploitability(leduc, pyspiel.UniformRandomPolicy(leduc)) - 2.373611111111111) < 1e-12
+    # a state's policy through every accessor
+    s = kuhn.new_initial_state()
+    for a in (1, 0, 1):
+        s.apply_action(a)
+    assert tab.action_probabilities(s) == {0: 0.5, 1: 0.5} == uniform.action_probabilities(s, 1)
+    assert tab.get_state_policy_as_parallel_vectors(s) == ([0, 1], [0.5, 0.5])
+    tab.set_prob(s.information_state_string(), 1, 1.0)
+    tab.set_prob(s.information_state_string(), 0, 0.0)
+    assert tab.action_probabilities(s) == {0: 0.0, 1: 1.0}
+    assert "0b: 0=0 1=1" in str(tab)
+    # a Python Policy (python/policy.py's interface: action_probabilities(state, player_id)) judged on the device
+    class AlwaysBet(pyspiel.Policy):
+        def __init__(self):
+            pyspiel.Policy.__init__(self)
+
+        def action_probabilities(self, state, player_id=None):
+            legal = state.legal_actions()
+            return {a: (1.0 if a == max(legal) else 0.0) for a in legal}
+
+    py_nc = pyspiel.nash_conv(kuhn, AlwaysBet())
+    assert abs(py_nc - pyspiel.nash_conv(kuhn, pyspiel.PreferredActionPolicy([1, 0]))) < 1e-14
+    assert len(pyspiel.ToTabularPolicy(kuhn, AlwaysBet())) == 12
+    # solver policies are Policy objects too
+    solver = pyspiel.CFRSolver(kuhn)
+    solver.evaluate_and_update_policy(50)
+    avg = solver.average_policy()
+    assert isinstance(avg, pyspiel.TabularPolicy)
+    assert pyspiel.exploitability(kuhn, avg) < 0.03

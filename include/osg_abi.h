@@ -384,9 +384,18 @@ int osg_cfr_tables(const osg_cfr* s, int32_t* nact, int32_t* legal, double* regr
  * [P]; any output may be NULL. */
 int osg_cfr_evaluate_policy(osg_cfr* s, int which_policy, const double* h_policy, double* expected_returns,
                             double* best_response_values, double* nash_conv, double* exploitability);
+
+/* TabularBestResponse (best_response.h:38-130, best_response.cc:194-227) against the same policy choices as
+ * osg_cfr_evaluate_policy: h_best_index [I] receives, for every infostate (of every player: each player responds
+ * to the others playing the policy), the index among its legal actions of the best-response action (ties and
+ * unreachable infostates: the first); best_response_values [P] (may be NULL) the responders' values. */
+int osg_cfr_best_response(osg_cfr* s, int which_policy, const double* h_policy, int32_t* h_best_index,
+                          double* best_response_values);
 /* InformationStateString() of infostate i (kuhn_poker.cc:109-166, leduc_poker.cc:198-239).
  * Returns the length (excluding NUL), or <0. */
 int osg_cfr_infostate_key(const osg_cfr* s, int64_t i, char* buf, int cap);
+/* The player who acts at infostate i (State::CurrentPlayer() of its histories), -1 for a bad index. */
+int osg_cfr_infostate_player(const osg_cfr* s, int64_t i);
 
 /* ---- multi-GPU exchange step ---------------------------------------------------
  * One process per GPU.  Units shard by global index with no data-path collective; the ONE exchange

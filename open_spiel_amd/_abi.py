@@ -136,6 +136,8 @@ SIGNATURES = {
     "osg_mccfr_apply_deltas": (INT, [VP]),
     "osg_cfr_tables": (INT, [VP, VP, VP, VP, VP, VP, VP]),
     "osg_cfr_evaluate_policy": (INT, [VP, INT, VP, VP, VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "osg_cfr_infostate_player": (INT, [VP, I64]),
+    "osg_cfr_best_response": (INT, [VP, INT, VP, VP, VP]),
     "osg_cfr_infostate_key": (INT, [VP, I64, C.c_char_p, INT]),
     "osg_comm_unique_id": (INT, [VP]),
     "osg_comm_create": (INT, [VP, INT, INT, VP, C.POINTER(VP)]),

@@ -951,6 +951,37 @@ class DeviceTabularSolver {
     if (osg_cfr_infostate_key(s_, i, buf, sizeof(buf)) < 0) SpielFatalError(osg_last_error());
     return buf;
   }
+  // TabularBestResponse on the device: for every infostate its key, legal actions, acting player and the index of
+  // the best-response action among the legal ones (each player responding to the others playing `table`);
+  // values[p] = the responder p's best-response value at the root.
+ public:
+  std::vector<int32_t> BestResponseIndices(const TabularPolicyTable& table, std::vector<std::string>* keys,
+                                           std::vector<std::vector<Action>>* legal, std::vector<int>* players,
+                                           std::vector<double>* values) const {
+    Tables t = Download();
+    std::vector<double> dense(static_cast<size_t>(t.I) * t.A, 0.0);
+    keys->clear(); legal->clear(); players->clear();
+    for (int i = 0; i < t.I; ++i) {
+      const std::string k = Key(i);
+      auto it = table.find(k);
+      if (it == table.end()) SpielFatalError(k + " not found in policy.");
+      std::vector<Action> la;
+      for (int a = 0; a < t.nact[i]; ++a) {
+        la.push_back(t.legal[i * t.A + a]);
+        for (const auto& ap : it->second)
+          if (ap.first == t.legal[i * t.A + a]) dense[i * t.A + a] = ap.second;
+      }
+      keys->push_back(k);
+      legal->push_back(std::move(la));
+      players->push_back(osg_cfr_infostate_player(s_, i));
+    }
+    std::vector<int32_t> best(t.I);
+    values->assign(num_players_, 0.0);
+    Check(osg_cfr_best_response(s_, 2, dense.data(), best.data(), values->data()));
+    return best;
+  }
+
+ protected:
   TabularPolicyTable PolicyTableOf(bool average) const {
     Tables t = Download();
     TabularPolicyTable out;
@@ -1328,6 +1359,74 @@ inline std::shared_ptr<Policy> algorithms::DeviceTabularSolver::CurrentPolicy() 
 }
 
 namespace algorithms {
+
+// best_response.h:38-130.  The best response of `best_responder` to `policy` (the other players follow it),
+// computed on the device over the flattened tree (k_policy_eval): Value at the root, the deterministic
+// best-response policy / actions for every infostate of the responder (ties and unreachable infostates: the
+// lowest action, best_response.cc:194-227).
+class TabularBestResponse {
+ public:
+  TabularBestResponse(const Game& game, Player best_responder, const Policy* policy)
+      : game_(LoadGame(game.ToString())), solver_(game, false, false, false), responder_(best_responder),
+        num_players_(game.NumPlayers()) {
+    if (best_responder < 0 || best_responder >= num_players_) SpielFatalError("TabularBestResponse: no such player");
+    SetPolicy(policy);
+  }
+  TabularBestResponse(const Game& game, Player best_responder, const TabularPolicyTable& table)
+      : game_(LoadGame(game.ToString())), solver_(game, false, false, false), responder_(best_responder),
+        num_players_(game.NumPlayers()), table_(table) {
+    if (best_responder < 0 || best_responder >= num_players_) SpielFatalError("TabularBestResponse: no such player");
+  }
+  void SetPolicy(const Policy* policy) {  // best_response.h:132-150
+    if (!policy) SpielFatalError("TabularBestResponse: null policy");
+    table_ = TabularPolicy(*game_, *policy).PolicyTable();
+    computed_ = false;
+  }
+  void SetPolicy(const TabularPolicyTable& table) {
+    table_ = table;
+    computed_ = false;
+  }
+  double Value() { Compute(); return value_; }                               // Value(*root) (best_response.h:127-128)
+  std::unordered_map<std::string, Action> GetBestResponseActions() { Compute(); return actions_; }
+  TabularPolicy GetBestResponsePolicy() {
+    Compute();
+    TabularPolicy p;
+    for (const auto& kv : actions_) {
+      ActionsAndProbs ap;
+      for (Action a : legal_.at(kv.first)) ap.push_back({a, a == kv.second ? 1.0 : 0.0});
+      p.SetStatePolicy(kv.first, ap);
+    }
+    return p;
+  }
+
+ private:
+  void Compute() {
+    if (computed_) return;
+    std::vector<std::string> keys;
+    std::vector<std::vector<Action>> legal;
+    std::vector<int> players;
+    std::vector<int32_t> best = solver_.BestResponseIndices(table_, &keys, &legal, &players, &values_);
+    actions_.clear();
+    legal_.clear();
+    for (size_t i = 0; i < keys.size(); ++i) {
+      if (players[i] != responder_) continue;
+      actions_[keys[i]] = legal[i][best[i]];
+      legal_[keys[i]] = legal[i];
+    }
+    value_ = values_[responder_];
+    computed_ = true;
+  }
+  std::shared_ptr<const Game> game_;
+  CFRSolverBase solver_;
+  Player responder_;
+  int num_players_;
+  TabularPolicyTable table_;
+  bool computed_ = false;
+  double value_ = 0;
+  std::vector<double> values_;
+  std::unordered_map<std::string, Action> actions_;
+  std::unordered_map<std::string, std::vector<Action>> legal_;
+};
 
 // algorithms::Exploitability / NashConv / ExpectedReturns of ANY Policy (tabular_exploitability.h:30-60,
 // expected_returns.h): tabularised over the game's infostates, judged on the device.

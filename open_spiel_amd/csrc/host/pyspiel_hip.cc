@@ -474,6 +474,23 @@ PYBIND11_MODULE(pyspiel_hip, m) {
     return std::make_pair(std::const_pointer_cast<Game>(gs.first), std::move(gs.second));
   });
 
+  py::class_<TabularBestResponse>(m, "TabularBestResponse")  // python/pybind11/policy.cc:138-162
+      .def(py::init([](std::shared_ptr<Game> g, int responder, const Policy& p) { return new TabularBestResponse(*g, responder, &p); }),
+           py::arg("game"), py::arg("best_responder"), py::arg("policy"))
+      .def(py::init([](std::shared_ptr<Game> g, int responder, const TabularPolicyTable& t) {
+             return new TabularBestResponse(*g, responder, t);
+           }),
+           py::arg("game"), py::arg("best_responder"), py::arg("policy_table"))
+      .def("value", [](TabularBestResponse& br, const std::string& /*history: the root*/) { return br.Value(); }, py::arg("history") = "")
+      .def("value_from_state", [](TabularBestResponse& br, const State& s) {
+             if (s.MoveNumber() != 0) SpielFatalError("the device best response reports the value at the root");
+             return br.Value();
+           }, py::arg("state"))
+      .def("get_best_response_policy", &TabularBestResponse::GetBestResponsePolicy)
+      .def("get_best_response_actions", &TabularBestResponse::GetBestResponseActions)
+      .def("set_policy", [](TabularBestResponse& br, const Policy& p) { br.SetPolicy(&p); }, py::arg("policy"))
+      .def("set_policy", [](TabularBestResponse& br, const TabularPolicyTable& t) { br.SetPolicy(t); }, py::arg("policy_table"));
+
   // pyspiel.exploitability / nash_conv / expected_returns (python/pybind11/policy.cc) for tabular policies
   m.def("exploitability", [](std::shared_ptr<Game> g, const Policy& p) { return Exploitability(*g, p); },
         py::arg("game"), py::arg("policy"));

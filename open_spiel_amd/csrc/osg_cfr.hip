@@ -2172,6 +2172,7 @@ int osg_cfr_infostate_key(const osg_cfr* s, int64_t i, char* buf, int cap) {
 }
 
 int osg_cfr_iteration(const osg_cfr* s) { return s ? s->iteration : 0; }
+int osg_cfr_infostate_player(const osg_cfr* s, int64_t i) { return (s && i >= 0 && i < s->I) ? s->info_player[i] : -1; }
 int osg_cfr_replicas(const osg_cfr* s) { return s ? s->B : 0; }
 int osg_cfr_select_replica(osg_cfr* s, int replica) {
   if (!s || replica < 0 || replica >= s->B) return set_error(OSG_ERR_INVALID, "osg_cfr_select_replica: bad replica");
@@ -2232,6 +2233,16 @@ int osg_cfr_evaluate_policy(osg_cfr* s, int which_policy, const double* h_policy
   // Exploitability = (sum of best-response values - UtilitySum) / P (tabular_exploitability.cc:30-47);
   // kuhn_poker and leduc_poker are zero-sum: UtilitySum() == 0.
   if (exploitability) *exploitability = total_br / P;
+  return OSG_OK;
+}
+
+int osg_cfr_best_response(osg_cfr* s, int which_policy, const double* h_policy, int32_t* h_best_index,
+                          double* best_response_values) {
+  if (!s || !h_best_index) return set_error(OSG_ERR_INVALID, "osg_cfr_best_response: null argument");
+  int rc = osg_cfr_evaluate_policy(s, which_policy, h_policy, nullptr, best_response_values, nullptr, nullptr);
+  if (rc) return rc;
+  OSG_HIP(hipMemcpyAsync(h_best_index, s->d_best, sizeof(int32_t) * s->I, hipMemcpyDeviceToHost, s->ctx->stream));
+  OSG_HIP(hipStreamSynchronize(s->ctx->stream));
   return OSG_OK;
 }
 

@@ -529,3 +529,43 @@ def test_policy_hierarchy_and_judges(pyspiel):
     avg = solver.average_policy()
     assert isinstance(avg, pyspiel.TabularPolicy)
     assert pyspiel.exploitability(kuhn, avg) < 0.03
+
+
+@pytest.mark.gpu
+def test_tabular_best_response(pyspiel, oracle):
+    """best_response.h:38-130 / python/pybind11/policy.cc:138-162 on the device: values and actions of the best
+    response to the uniform policy and to a CFR average policy — the reference's known answers
+    (exploitability_test.py: best response to uniform kuhn is worth 11/24 + ... ; NashConv = sum of BR values
+    in a zero-sum game) and the oracle's judge."""
+    kuhn = pyspiel.load_game("kuhn_poker")
+    uniform = pyspiel.UniformRandomPolicy(kuhn)
+    values = []
+    for p in (0, 1):
+        br = pyspiel.TabularBestResponse(kuhn, p, uniform)
+        values.append(br.value(""))
+        actions = br.get_best_response_actions()
+        policy = br.get_best_response_policy()
+        assert set(actions) == {k for k in uniform.policy_table() if (len(k) % 2 == 1) == (p == 0)}
+        for k, a in actions.items():
+            assert dict(policy.get_state_policy(k))[a] == 1.0 and sum(pr for _, pr in policy.get_state_policy(k)) == 1.0
+    assert abs(sum(values) - pyspiel.nash_conv(kuhn, uniform)) < 1e-14          # zero-sum: NashConv = sum of BR values
+    assert abs(sum(values) / 2 - 0.4583333333333335) < 1e-14
+    # against the uniform policy: with a king facing a bet the responder calls, with a jack it folds; opening with a
+    # king, betting and passing are worth the same 1.5 (bet: called half the time; pass: the opponent bets half the
+    # time and is called) — a tie, which goes to the first action (best_response.cc:207-211 strict >)
+    a0 = pyspiel.TabularBestResponse(kuhn, 0, uniform).get_best_response_actions()
+    assert a0["2pb"] == 1 and a0["0pb"] == 0 and a0["2"] == 0
+    # against the oracle's judge on a trained policy, then set_policy re-uses the object
+    solver = pyspiel.CFRSolver(kuhn)
+    solver.evaluate_and_update_policy(30)
+    avg = solver.average_policy()
+    br = pyspiel.TabularBestResponse(kuhn, 1, uniform)
+    br.set_policy(avg)
+    o = oracle.Solver(oracle.Game("kuhn_poker"), "cfr")
+    o.iterate(30)
+    want = (o.nash_conv() + sum(o.expected_returns())) / 1.0  # NashConv = sum_p (BR_p - EV_p); EVs sum to 0
+    got = br.value("") + pyspiel.TabularBestResponse(kuhn, 0, avg).value("")
+    assert abs(got - want) < 1e-12
+    leduc = pyspiel.load_game("leduc_poker")
+    vals = [pyspiel.TabularBestResponse(leduc, p, pyspiel.UniformPolicy()).value("") for p in (0, 1)]
+    assert abs(sum(vals) / 2 - 2.373611111111111) < 1e-12

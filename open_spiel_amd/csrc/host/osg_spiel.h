@@ -1387,6 +1387,11 @@ class TabularBestResponse {
     computed_ = false;
   }
   double Value() { Compute(); return value_; }                               // Value(*root) (best_response.h:127-128)
+  double Value(const std::string& history) {  // the device pass reports the root's value
+    if (!history.empty()) SpielFatalError("TabularBestResponse::Value: only the root history is offered");
+    return Value();
+  }
+  double Value(const State& state) { return Value(state.HistoryString()); }
   std::unordered_map<std::string, Action> GetBestResponseActions() { Compute(); return actions_; }
   TabularPolicy GetBestResponsePolicy() {
     Compute();
@@ -1433,9 +1438,19 @@ class TabularBestResponse {
 inline double Exploitability(const Game& game, const Policy& policy) {
   return Exploitability(game, TabularPolicy(game, policy).PolicyTable());
 }
-inline double NashConv(const Game& game, const Policy& policy) { return NashConv(game, TabularPolicy(game, policy).PolicyTable()); }
+// (use_state_get_policy — tabular_exploitability.h:52-60 — chooses which GetStatePolicy overload the reference
+// calls; the tabularisation here tries the infostate-string one and falls back to the State one by itself)
+inline double NashConv(const Game& game, const Policy& policy, bool /*use_state_get_policy*/ = false) {
+  return NashConv(game, TabularPolicy(game, policy).PolicyTable());
+}
 inline std::vector<double> ExpectedReturns(const Game& game, const Policy& policy) {
   return ExpectedReturns(game, TabularPolicy(game, policy).PolicyTable());
+}
+// expected_returns.h:47-51 for the case every caller on this path uses: the whole game from its root
+inline std::vector<double> ExpectedReturns(const State& state, const Policy& joint_policy, int depth_limit) {
+  if (state.MoveNumber() != 0 || depth_limit >= 0)
+    SpielFatalError("ExpectedReturns: the device pass evaluates the whole game from its initial state");
+  return ExpectedReturns(*state.GetGame(), joint_policy);
 }
 
 // kuhn_poker::GetOptimalPolicy (kuhn_poker.cc:451-474): the alpha-family of Nash equilibria of 2-player

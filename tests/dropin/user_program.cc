@@ -9,6 +9,7 @@
 // Every line is deterministic: fixed move choices, the full-tree CFR family, MCTS-Solver proofs.
 #include <cstdio>
 #include <memory>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -17,8 +18,14 @@
 namespace spiel = open_spiel::hip;
 namespace algos = open_spiel::hip::algorithms;
 #else
+#include "open_spiel/algorithms/best_response.h"
 #include "open_spiel/algorithms/cfr.h"
+#include "open_spiel/algorithms/cfr_br.h"
+#include "open_spiel/algorithms/expected_returns.h"
+#include "open_spiel/algorithms/external_sampling_mccfr.h"
 #include "open_spiel/algorithms/mcts.h"
+#include "open_spiel/policy.h"
+#include "open_spiel/spiel_bots.h"
 #include "open_spiel/algorithms/tabular_exploitability.h"
 #include "open_spiel/spiel.h"
 namespace spiel = open_spiel;
@@ -132,6 +139,49 @@ static void Cfr() {
               static_cast<int>(big.InfoStateValuesTable().size()));
 }
 
+// Round 2: the policy hierarchy, the best response, CFR-BR, external-sampling MCCFR driven by the caller's
+// std::mt19937 (both average types), and MCTSBot through the Bot interface.
+static void PoliciesAndSiblingSolvers() {
+  std::shared_ptr<const spiel::Game> game = spiel::LoadGame("kuhn_poker");
+  spiel::UniformPolicy uniform;
+  spiel::TabularPolicy first_action = spiel::GetFirstActionPolicy(*game);
+  spiel::TabularPolicy uniform_table = spiel::GetUniformPolicy(*game);
+  std::printf("kuhn policies: uniform nash_conv %.12f table %.12f first-action %.12f\n", algos::NashConv(*game, uniform, /*use_state_get_policy=*/true),
+              algos::NashConv(*game, uniform_table), algos::NashConv(*game, first_action));
+  PrintVector("kuhn expected returns of the first-action policy:", algos::ExpectedReturns(*game->NewInitialState(), first_action, -1));
+  for (int p = 0; p < 2; ++p) {
+    algos::TabularBestResponse br(*game, p, &uniform_table);
+    const double value = br.Value(*game->NewInitialState());
+    std::unordered_map<std::string, Action> actions = br.GetBestResponseActions();
+    std::printf("kuhn best response of player %d to uniform: value %.12f actions", p, value);
+    for (const char* key : {"0", "1", "2", "0p", "0b", "1p", "1b", "2p", "2b", "0pb", "1pb", "2pb"}) {
+      auto it = actions.find(key);
+      if (it != actions.end()) std::printf(" %s=%d", key, static_cast<int>(it->second));
+    }
+    std::printf("\n");
+  }
+  algos::CFRBRSolver cfr_br(*game);
+  for (int i = 1; i <= 30; ++i) {
+    cfr_br.EvaluateAndUpdatePolicy();
+    if (i == 1 || i == 5 || i == 30)
+      std::printf("kuhn CFR-BR iter %d exploitability %.10f\n", i, algos::Exploitability(*game, *cfr_br.AveragePolicy()));
+  }
+  for (algos::AverageType avg : {algos::AverageType::kSimple, algos::AverageType::kFull}) {
+    algos::ExternalSamplingMCCFRSolver mccfr(*game, /*seed=*/3, avg);
+    std::mt19937 rng(2024);
+    for (int i = 0; i < 200; ++i) mccfr.RunIteration(&rng);
+    std::printf("kuhn ES-MCCFR (%s average, caller's mt19937) iter 200 nash_conv %.9f CFR-family\n",
+                avg == algos::AverageType::kFull ? "full" : "simple", algos::NashConv(*game, *mccfr.AveragePolicy()));
+  }
+  // MCTSBot is a Bot: x (0, 1) against o (3, 4), x to move: the only winning move is 2, and the solver proves it
+  std::shared_ptr<const spiel::Game> ttt = spiel::LoadGame("tic_tac_toe");
+  std::unique_ptr<spiel::State> state = ttt->NewInitialState();
+  for (Action a : {0, 3, 1, 4}) state->ApplyAction(a);
+  auto evaluator = std::make_shared<algos::RandomRolloutEvaluator>(2, 11);
+  std::unique_ptr<spiel::Bot> bot = std::make_unique<algos::MCTSBot>(*ttt, evaluator, 2.0, 300, 50, /*solve=*/true, 5, false);
+  std::printf("tic_tac_toe Bot::Step at %s -> %d\n", state->HistoryString().c_str(), static_cast<int>(bot->Step(*state)));
+}
+
 int main() {
   for (const char* g : {"tic_tac_toe", "connect_four", "hex(board_size=9)", "kuhn_poker", "leduc_poker",
                         "kuhn_poker(players=3)"})
@@ -139,6 +189,7 @@ int main() {
   InformationStates();
   SolverAnswers();
   Cfr();
+  PoliciesAndSiblingSolvers();
   std::printf("done\n");
   return 0;
 }

@@ -29,13 +29,14 @@ _FLOAT = re.compile(r"-?\d+\.\d+(?:e[-+]?\d+)?")
 
 
 def assert_same_transcript(got, want, float_atol=1e-9):
-    """Line by line; on the solver-output lines (fp64 CFR results) numbers may differ by float_atol."""
+    """Line by line; on the solver-output lines (fp64 results of the CFR family: every line naming "CFR") numbers may
+    differ by float_atol."""
     got_lines, want_lines = got.rstrip("\n").split("\n"), want.rstrip("\n").split("\n")
     assert len(got_lines) == len(want_lines), f"{len(got_lines)} lines, expected {len(want_lines)}"
     for i, (g, w) in enumerate(zip(got_lines, want_lines)):
         if g == w:
             continue
-        assert " CFR" in w, f"line {i + 1}:\n  got  {g}\n  want {w}"
+        assert "CFR" in w, f"line {i + 1}:\n  got  {g}\n  want {w}"
         assert _FLOAT.sub("#", g) == _FLOAT.sub("#", w), f"line {i + 1}:\n  got  {g}\n  want {w}"
         for a, b in zip(_FLOAT.findall(g), _FLOAT.findall(w)):
             assert abs(float(a) - float(b)) <= float_atol, f"line {i + 1}: {a} vs {b}"

@@ -627,6 +627,41 @@ class Bot {  // spiel_bots.h:73-185
   virtual std::unique_ptr<Bot> Clone() { SpielFatalError("Clone method not implemented."); }
 };
 
+// spiel_utils.h SampleAction(outcomes, rng): the outcome whose cumulative-probability interval holds a uniform draw
+inline std::pair<Action, double> SampleAction(const ActionsAndProbs& outcomes, std::mt19937& rng) {
+  const double z = std::uniform_real_distribution<double>(0.0, 1.0)(rng);
+  double acc = 0;
+  for (const auto& ap : outcomes) {
+    if (z >= acc && z < acc + ap.second) return ap;
+    acc += ap.second;
+  }
+  return outcomes.back();
+}
+
+// algorithms/evaluate_bots.cc:27-62: play one episode from `state` with one bot per player, return the returns.
+inline std::vector<double> EvaluateBots(State* state, const std::vector<Bot*>& bots, int seed) {
+  std::mt19937 rng(seed);
+  if (state->History().empty()) {
+    for (Bot* bot : bots) bot->Restart();
+  } else {
+    for (Bot* bot : bots) bot->RestartAt(*state);
+  }
+  while (!state->IsTerminal()) {
+    if (state->IsChanceNode()) {
+      const Action action = SampleAction(state->ChanceOutcomes(), rng).first;
+      for (Bot* bot : bots) bot->InformAction(*state, kChancePlayerId, action);
+      state->ApplyAction(action);
+    } else {
+      const Player current = state->CurrentPlayer();
+      const Action action = bots[current]->Step(*state);
+      for (size_t p = 0; p < bots.size(); ++p)
+        if (static_cast<Player>(p) != current) bots[p]->InformAction(*state, current, action);
+      state->ApplyAction(action);
+    }
+  }
+  return state->Returns();
+}
+
 namespace algorithms {
 
 inline std::vector<double> dirichlet_noise(int count, double alpha, std::mt19937* rng) {  // mcts.cc:188-203
@@ -696,6 +731,14 @@ class MCTSBot : public Bot {
   ActionsAndProbs GetPolicy(const State& state) override { return StepWithPolicy(state).first; }  // spiel_bots.h:141
 
   std::unique_ptr<SearchNode> MCTSearch(const State& state) {  // mcts.cc:353-467
+    if (max_simulations_ < 1 && max_wall_clock_time_ <= 0) {
+      // the reference's loop body never runs (mcts.cc:362-366): the root alone, one visit, no children
+      last_nodes_ = 1;
+      auto root = std::make_unique<SearchNode>();
+      root->player = state.CurrentPlayer();
+      root->prior = 1.0;
+      return root;
+    }
     osg_mcts_cfg cfg = Config();
     const bool host_priors = rollout_ == nullptr || dirichlet_alpha_ > 0;
     const int flags = (host_priors ? 1 : 0) | (dont_return_chance_node_ ? 2 : 0);
@@ -1548,19 +1591,14 @@ inline PartialCheckpoint PartiallyDeserializeSolver(const std::string& serialize
 class ExternalSamplingMCCFRSolver : public DeviceTabularSolver {  // external_sampling_mccfr.h:57-113
  public:
   explicit ExternalSamplingMCCFRSolver(const Game& game, int seed = 0, AverageType avg_type = AverageType::kSimple)
-      : DeviceTabularSolver(game, true, false, false, 1), seed_(seed), avg_type_(avg_type),
+      : DeviceTabularSolver(game, true, false, false, 1), seed_(seed), rng_(seed), avg_type_(avg_type),
         game_string_(game.Serialize()) {
     Check(osg_mccfr_set_average_type(s_, avg_type == AverageType::kFull ? 1 : 0));
   }
   // One UpdateRegrets per player, each seeing the previous one's update, then — AverageType::kFull — one
-  // FullUpdateAverage (:71-80).  Draws come from the engine's counter streams.
-  void RunIteration() {
-    for (int p = 0; p < num_players_; ++p) {
-      Check(osg_mccfr_sample(s_, seed_, next_++, 1));
-      Check(osg_mccfr_apply_deltas(s_));
-    }
-    if (avg_type_ == AverageType::kFull) Check(osg_mccfr_full_average(s_, 1.0));
-  }
+  // FullUpdateAverage (:71-80), drawing from the solver's own std::mt19937(seed) as the reference's does (:66):
+  // a solver seeded like the reference's follows it iteration by iteration.
+  void RunIteration() { RunIteration(&rng_); }
   // The same iteration with every draw taken from the caller's generator exactly as the reference takes it
   // (dist_(*rng), a std::uniform_real_distribution<double>, once per chance node and once per opponent node
   // in visiting order; external_sampling_mccfr.h:63-100, .cc:122-154): seeded alike, the tables follow the
@@ -1593,8 +1631,13 @@ class ExternalSamplingMCCFRSolver : public DeviceTabularSolver {  // external_sa
     str += std::string(kSerializeGameSectionHeader) + "\n" + game_string_ + "\n";
     str += std::string(kSerializeSolverTypeSectionHeader) + "\nExternalSamplingMCCFRSolver\n";
     str += std::string(kSerializeSolverSpecificStateSectionHeader) + "\n";
-    str += std::string(kSerializeSolverRNGSectionHeader) + "\ncounter " + std::to_string(seed_) + " " +
-           std::to_string(next_) + "\n";
+    // [SolverRNG]: the generator's state as the reference writes it (operator<< of std::mt19937, :100-102), then —
+    // this engine's addition, ignored by the reference's reader (operator>> stops after the state) — the
+    // position of the counter streams the mini-batches draw from.
+    std::ostringstream rng_stream;
+    rng_stream << rng_;
+    str += std::string(kSerializeSolverRNGSectionHeader) + "\n" + rng_stream.str() + "\ncounter " +
+           std::to_string(seed_) + " " + std::to_string(next_) + "\n";
     str += std::string(kSerializeSolverAverageTypeSectionHeader) +
            (avg_type_ == AverageType::kFull ? "\nFullAverageType\n" : "\nSimpleAverageType\n");
     str += std::string(kSerializeSolverDefaultPolicySectionHeader) + "\nUniformPolicy:\n";  // policy.h:330-333
@@ -1623,12 +1666,18 @@ class ExternalSamplingMCCFRSolver : public DeviceTabularSolver {  // external_sa
     next_ += trajectories;
   }
   void RestoreCounter(uint64_t seed, int64_t next) { seed_ = seed; next_ = next; }
+  void RestoreGenerator(const std::string& state) {  // external_sampling_mccfr.cc:262-264
+    std::istringstream in(state);
+    in >> rng_;
+    if (in.fail()) SpielFatalError("[SolverRNG] does not hold a std::mt19937 state");
+  }
   int64_t TrajectoriesRun() const { return next_; }
   AverageType average_type() const { return avg_type_; }
 
  private:
   uint64_t seed_;
   int64_t next_ = 0;
+  std::mt19937 rng_;
   AverageType avg_type_;
   std::string game_string_;
   std::vector<double> uniforms_;
@@ -1642,6 +1691,15 @@ class OutcomeSamplingMCCFRSolver : public DeviceTabularSolver {  // outcome_samp
         game_string_(game.Serialize()) {}
   void RunIteration() {  // one SampleEpisode per player, each seeing the previous one's update (:67-74)
     for (int p = 0; p < num_players_; ++p) Check(osg_mccfr_iterate(s_, seed_, next_++, 1));
+  }
+  // outcome_sampling_mccfr.h:61-62.  The reference draws through abseil's distributions (unspecified streams);
+  // here every episode takes a fresh 64-bit stream key from the caller's generator: the same distribution of
+  // episodes, reproducible from the generator's state, not the reference's draw sequence.
+  void RunIteration(std::mt19937* rng) {
+    for (int p = 0; p < num_players_; ++p) {
+      const uint64_t key = (static_cast<uint64_t>((*rng)()) << 32) | (*rng)();
+      Check(osg_mccfr_iterate(s_, key, next_++, 1));
+    }
   }
   void RunMiniBatch(int64_t episodes) {  // `episodes` sampled paths as ONE mini-batch
     Check(osg_mccfr_iterate(s_, seed_, next_, episodes));
@@ -1695,15 +1753,28 @@ inline std::unique_ptr<ExternalSamplingMCCFRSolver> DeserializeExternalSamplingM
   const PartialCheckpoint c = PartiallyDeserializeSolver(serialized);
   if (c.solver_type != "ExternalSamplingMCCFRSolver")
     SpielFatalError("checkpoint holds a " + c.solver_type + ", not an ExternalSamplingMCCFRSolver");
-  uint64_t seed;
-  int64_t next;
-  internal::ParseCounter(internal::SpecificLine(c, kSerializeSolverRNGSectionHeader), &seed, &next);
+  // [SolverRNG]: the reference's mt19937 dump (a checkpoint written by the reference loads and continues draw
+  // for draw), optionally followed by this engine's "counter <seed> <next>" line (older checkpoints of this
+  // engine hold that line alone).
+  uint64_t seed = 0;
+  int64_t next = 0;
+  std::string generator;
+  {
+    size_t i = 0;
+    while (i < c.specific.size() && c.specific[i] != kSerializeSolverRNGSectionHeader) ++i;
+    if (i == c.specific.size()) SpielFatalError("solver checkpoint without a [SolverRNG] section");
+    for (++i; i < c.specific.size() && c.specific[i][0] != '['; ++i) {
+      if (c.specific[i].rfind("counter ", 0) == 0) internal::ParseCounter(c.specific[i], &seed, &next);
+      else generator += c.specific[i] + " ";
+    }
+  }
   const std::string avg = internal::SpecificLine(c, kSerializeSolverAverageTypeSectionHeader);
   if (avg != "SimpleAverageType" && avg != "FullAverageType") SpielFatalError("unknown average type " + avg);
   std::shared_ptr<const Game> game = LoadGame(c.game);
   auto solver = std::make_unique<ExternalSamplingMCCFRSolver>(
       *game, static_cast<int>(seed), avg == "FullAverageType" ? AverageType::kFull : AverageType::kSimple);
   solver->RestoreCounter(seed, next);
+  if (!generator.empty()) solver->RestoreGenerator(generator);
   solver->LoadInfoStateValuesTable(DeserializeValuesTable(c.table, delimiter), /*allow_missing=*/true);
   return solver;
 }

@@ -622,7 +622,7 @@ PYBIND11_MODULE(pyspiel_hip, m) {
              return new OutcomeSamplingMCCFRSolver(*g, epsilon, seed);
            }),
            py::arg("game"), py::arg("epsilon") = OutcomeSamplingMCCFRSolver::kDefaultEpsilon, py::arg("seed") = -1)
-      .def("run_iteration", &OutcomeSamplingMCCFRSolver::RunIteration)
+      .def("run_iteration", static_cast<void (OutcomeSamplingMCCFRSolver::*)()>(&OutcomeSamplingMCCFRSolver::RunIteration))
       .def("run_mini_batch", &OutcomeSamplingMCCFRSolver::RunMiniBatch, py::arg("episodes"))
       .def("average_policy",
            [](const OutcomeSamplingMCCFRSolver& s) { return std::make_shared<TabularPolicy>(s.TabularAveragePolicy()); })

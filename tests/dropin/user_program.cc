@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <memory>
 #include <random>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -172,6 +173,23 @@ static void PoliciesAndSiblingSolvers() {
     for (int i = 0; i < 200; ++i) mccfr.RunIteration(&rng);
     std::printf("kuhn ES-MCCFR (%s average, caller's mt19937) iter 200 nash_conv %.9f CFR-family\n",
                 avg == algos::AverageType::kFull ? "full" : "simple", algos::NashConv(*game, *mccfr.AveragePolicy()));
+  }
+  {
+    // the solver's OWN generator (seed 5), a text checkpoint half way, and the run resumed from the text
+    algos::ExternalSamplingMCCFRSolver first(*game, /*seed=*/5);
+    for (int i = 0; i < 60; ++i) first.RunIteration();
+    const std::string text = first.Serialize();
+    const size_t at = text.find("[SolverRNG]\n") + 12;
+    const std::string rng_line = text.substr(at, text.find('\n', at) - at);
+    unsigned long long sum = 0;
+    int words = 0;
+    std::istringstream in(rng_line);
+    for (unsigned long long w; in >> w; ++words) sum = sum * 1000003ull + w;
+    std::printf("kuhn ES-MCCFR checkpoint after 60 iterations: [SolverRNG] %d words, digest %llu\n", words, sum);
+    std::unique_ptr<algos::ExternalSamplingMCCFRSolver> resumed = algos::DeserializeExternalSamplingMCCFRSolver(text);
+    for (int i = 0; i < 60; ++i) resumed->RunIteration();
+    std::printf("kuhn ES-MCCFR (own generator, resumed from the checkpoint) iter 120 nash_conv %.9f CFR-family\n",
+                algos::NashConv(*game, *resumed->AveragePolicy()));
   }
   // MCTSBot is a Bot: x (0, 1) against o (3, 4), x to move: the only winning move is 2, and the solver proves it
   std::shared_ptr<const spiel::Game> ttt = spiel::LoadGame("tic_tac_toe");

@@ -148,6 +148,34 @@ def test_host_mirror_run_iteration_with_a_generator_equals_the_reference(vectors
         np.testing.assert_allclose(v.cumulative_policy, want["cum_policy"][j, :n], rtol=0, atol=1e-9, err_msg=k)
 
 
+@pytest.mark.parametrize("game,kind,seed,cp", [("kuhn_poker", "mccfr_simple", 7, 400), ("leduc_poker", "mccfr_full", 5, 25)])
+def test_host_mirror_default_run_iteration_and_checkpoint_follow_the_reference(vectors, game, kind, seed, cp):
+    """RunIteration() with no argument draws from the solver's own std::mt19937(seed), as the reference's does
+    (external_sampling_mccfr.h:66): the solver constructed like the reference's follows it — also across a
+    Serialize / Deserialize in the middle, whose [SolverRNG] section carries the generator's state in the
+    reference's own format (external_sampling_mccfr.cc:100-102, :262-264)."""
+    import pickle
+    import open_spiel_amd.pyspiel_hip as ps
+    g = ps.load_game(game)
+    avg = ps.MCCFRAverageType.FULL if kind == "mccfr_full" else ps.MCCFRAverageType.SIMPLE
+    s = ps.ExternalSamplingMCCFRSolver(g, seed, avg)
+    for _ in range(cp // 2):
+        s.run_iteration()
+    text = s.serialize()
+    rng_section = text.split("[SolverRNG]\n")[1].split("\n")[0].split()
+    assert len(rng_section) == 625  # 624 state words + the position: operator<< of std::mt19937
+    s = pickle.loads(pickle.dumps(s))
+    for _ in range(cp - cp // 2):
+        s.run_iteration()
+    table = s.info_state_values_table()
+    keys, want = _want(vectors, f"mccfr/{game}/{kind}/{seed}/{cp}/")
+    for j, k in enumerate(keys):
+        n = int(want["nact"][j])
+        v = table[k]
+        np.testing.assert_allclose(v.cumulative_regrets, want["regrets"][j, :n], rtol=0, atol=1e-9, err_msg=k)
+        np.testing.assert_allclose(v.cumulative_policy, want["cum_policy"][j, :n], rtol=0, atol=1e-9, err_msg=k)
+
+
 @pytest.mark.parametrize("game", ["kuhn_poker", "leduc_poker", "kuhn_poker(players=3)"])
 def test_full_update_average_replay_parity(oracle, ctx, game):
     """kFull on the engine's own counter streams: trajectory by trajectory the device and the oracle's

@@ -55,7 +55,11 @@ extern "C" int osg_debug_phase_cycles(unsigned long long* out8, int reset) {
 #define PT_DECL unsigned long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt_t = clock64();
 #define PT_MARK(k) do { const unsigned long long pt_n = clock64(); pt_acc[k] += pt_n - pt_t; pt_t = pt_n; } while (0)
 #define PT_FLUSH do { if (lane_id() == 0) for (int q = 0; q < 8; ++q) atomicAdd(&g_phase_cycles[q], pt_acc[q]); } while (0)
+#define PT_ARGS , unsigned long long* pt_acc, unsigned long long& pt_t
+#define PT_PASS , pt_acc, pt_t
 #else
+#define PT_ARGS
+#define PT_PASS
 #define PT_DECL
 #define PT_MARK(k)
 #define PT_FLUSH
@@ -68,6 +72,12 @@ namespace {
 #endif
 constexpr int kWavesPerBlock = OSG_WAVES_PER_BLOCK;
 constexpr int kMaxPath = 160;
+#ifndef OSG_THR_MODE
+#define OSG_THR_MODE 0
+#endif
+#ifndef OSG_FLOOD_MODE
+#define OSG_FLOOD_MODE 0
+#endif
 
 OSG_D int lane_id() { return static_cast<int>(threadIdx.x & 63u); }
 template <class T>
@@ -99,6 +109,18 @@ OSG_D double read_lane_f64(double v, int src) {
 // their loads and stores as one in-order instruction stream, so a store followed by a load of the
 // same address needs no wait — only that the compiler keeps them in program order.
 OSG_D void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+// A zero the compiler must treat as a per-lane value: whatever is combined with it is computed by
+// the vector unit, even when every lane holds the same number.
+OSG_D uint32_t vector_zero() {
+  uint32_t r;
+  asm("v_mov_b32 %0, 0" : "=v"(r));
+  return r;
+}
+OSG_D uint32_t vector_popcount(uint32_t bits, uint32_t acc) {  // popcount(bits) + acc on the vector unit
+  uint32_t r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "s"(bits), "v"(acc));
+  return r;
+}
 OSG_D int wave_count(bool pred) { return __builtin_popcountll(__ballot(pred)); }
 
 struct Cand {  // arg-max candidate: larger value wins, then smaller key
@@ -225,12 +247,22 @@ OSG_D uint64_t hex_cells64(const typename G::Bits& b, int j) {
   return uniform64(static_cast<uint64_t>(hi) << 32 | lo);
 }
 
-// The hex position the search walks with (no swap rule): HexT's State re-packed as pairs of 64-bit
-// cell sets, wave-uniform, so that the rules run as scalar set algebra plus lane-parallel neighbour
-// tests against HexLane instead of multi-word shifts.  Same fields, same update rules as HexT::apply.
+// The hex position the search walks with (no swap rule, at least two rows and two columns): the two
+// colours' stones as pairs of 64-bit cell sets and the player to move, wave-uniform, so that the rules
+// run as scalar set algebra plus lane-parallel neighbour tests against HexLane.
+//
+// The reference keeps an edge-connection label on every stone and relabels a group at every move
+// (hex.cc:108-171, 229-278) because IsTerminal() must be cheap at every state.  A tree descent does not
+// need that: a node that has children was not terminal when it was expanded, and a node found terminal
+// keeps that in its header, so the only state whose IsTerminal() the search ever asks for is the one a
+// simulation stops at on its FIRST visit.  There the question is answered from the stones alone: the
+// game ended with the last move iff the group of the stone just placed touches both of its colour's
+// edges — the labels' invariant (a stone carries an edge label iff its group reaches that edge; the
+// `else if` of hex.cc:122-126 only matters on a one-row / one-column board, which this kernel is not
+// launched for) makes the two statements the same.
 struct HexW {
-  uint64_t blk[2], wht[2], ea[2], eb[2];
-  uint32_t meta;  // HexT::State::meta: to move [0], result [1:3), plies [8:16), first move [16:24)
+  uint64_t blk[2], wht[2];
+  uint32_t meta;  // to move [0], result [1:3) as HexT::State::meta
 };
 template <class G>
 OSG_D HexW hexw_from_state(const typename G::State& s) {
@@ -239,10 +271,8 @@ OSG_D HexW hexw_from_state(const typename G::State& s) {
   for (int j = 0; j < 2; ++j) {
     w.blk[j] = hex_cells64<G>(s.black, j);
     w.wht[j] = hex_cells64<G>(s.white, j);
-    w.ea[j] = hex_cells64<G>(s.ea, j);
-    w.eb[j] = hex_cells64<G>(s.eb, j);
   }
-  w.meta = uniform(s.meta);
+  w.meta = uniform(s.meta) & 7u;
   return w;
 }
 OSG_D bool hexw_terminal(const HexW& w) { return ((w.meta >> 1) & 3u) != 0; }
@@ -263,68 +293,44 @@ OSG_D void hexw_returns(const HexW& w, double* out) {  // hex.cc:363-365
   out[0] = r;
   out[1] = -r + 0.0;
 }
-// PlayerAndActionToState (hex.cc:108-171) + DoApplyAction (hex.cc:229-278), as HexT::place / apply.
-OSG_D void hexw_apply(const HexLane& hl, HexW& w, int move) {
-  // Everything here is wave-uniform; selects instead of branches keep it to a few dozen scalar
-  // instructions (only the relabelling flood is a loop).
-  const int src = move & 63;
+// DoApplyAction (hex.cc:229-278) on the way down the tree: the stone and the turn, nothing else.
+OSG_D void hexw_apply(const HexLane&, HexW& w, int move) {
+  const uint64_t bit = 1ull << (move & 63);
   const bool hi = move >= 64;
-  const uint64_t bit = 1ull << src;
   const uint64_t bit0 = hi ? 0ull : bit, bit1 = hi ? bit : 0ull;
-  // the new stone's neighbour set and edge flags, from the lane that owns the cell
-  const uint64_t nb0 = read_lane_u64(hi ? hl.nb_lo[1] : hl.nb_lo[0], src);
-  const uint64_t nb1 = read_lane_u64(hi ? hl.nb_hi[1] : hl.nb_hi[0], src);
-  const uint32_t edge = (read_lane(hl.edge, src) >> (hi ? 4 : 0)) & 15u;
-  const int player = w.meta & 1u;
-  const bool black = player == 0;
-  // black: first row -> North(A), ELSE IF last row -> South(B); white: first column -> West(A),
-  // ELSE IF last column -> East(B) (hex.cc:122-126,146-150)
-  const bool on_first = (edge & (black ? 1u : 4u)) != 0;
-  const bool on_last = (edge & (black ? 2u : 8u)) != 0;
-  uint64_t own0 = black ? w.blk[0] : w.wht[0], own1 = black ? w.blk[1] : w.wht[1];
-  const uint64_t n0 = nb0 & own0, n1 = nb1 & own1;
-  // a neighbour labelled exactly A (not Win) / exactly B
-  const bool a = on_first | (((n0 & w.ea[0] & ~w.eb[0]) | (n1 & w.ea[1] & ~w.eb[1])) != 0ull);
-  const bool b = (!on_first & on_last) | (((n0 & w.eb[0] & ~w.ea[0]) | (n1 & w.eb[1] & ~w.ea[1])) != 0ull);
-  const uint64_t am = a ? ~0ull : 0ull, bm = b ? ~0ull : 0ull;
-  own0 |= bit0;
-  own1 |= bit1;
-  w.ea[0] |= bit0 & am;
-  w.ea[1] |= bit1 & am;
-  w.eb[0] |= bit0 & bm;
-  w.eb[1] |= bit1 & bm;
-  const uint32_t res = (a & b) ? (black ? 1u : 2u) : 0u;  // Win label; no flood fill (hex.cc:248-252)
-  if (a != b) {
-    // flood the plain same-colour group reachable from the new stone: lane-parallel neighbour tests
-    const uint64_t plain0 = own0 & ~w.ea[0] & ~w.eb[0], plain1 = own1 & ~w.ea[1] & ~w.eb[1];
-    uint64_t region0 = 0ull, region1 = 0ull;
-    uint64_t front0 = bit0, front1 = bit1;
-#ifdef OSG_APPLY_UNROLL
-#pragma unroll OSG_APPLY_UNROLL
-#endif
-    for (int it = 0; it < 128; ++it) {
-      const bool t0 = ((hl.nb_lo[0] & front0) | (hl.nb_hi[0] & front1)) != 0ull;
-      const bool t1 = ((hl.nb_lo[1] & front0) | (hl.nb_hi[1] & front1)) != 0ull;
-      const uint64_t g0 = __ballot(t0) & plain0 & ~region0, g1 = __ballot(t1) & plain1 & ~region1;
-      if ((g0 | g1) == 0ull) break;
-      region0 |= g0;
-      region1 |= g1;
-      front0 = g0;
-      front1 = g1;
-    }
-    w.ea[0] |= region0 & am;
-    w.ea[1] |= region1 & am;
-    w.eb[0] |= region0 & bm;
-    w.eb[1] |= region1 & bm;
+  const bool black = (w.meta & 1u) == 0;
+  w.blk[0] |= black ? bit0 : 0ull;
+  w.blk[1] |= black ? bit1 : 0ull;
+  w.wht[0] |= black ? 0ull : bit0;
+  w.wht[1] |= black ? 0ull : bit1;
+  w.meta ^= 1u;
+}
+// Did the stone just placed on `move` end the game?  (= would hex.cc:248 have labelled it Win.)  Lane-parallel
+// flood of its group: a stone of the same colour joins when one of its neighbours is in the frontier.
+OSG_D bool hexw_last_stone_wins(const HexLane& hl, const HexW& w, int move) {
+  const bool black = (w.meta & 1u) != 0;  // the owner of the stone is the player who is NOT to move now
+  const uint64_t own0 = black ? w.blk[0] : w.wht[0], own1 = black ? w.blk[1] : w.wht[1];
+  // the colour's two edges as cell sets: from the lanes' edge flags (black: rows = bits 0, 1; white: columns = bits 2, 3)
+  const uint32_t fbit = black ? 1u : 4u, lbit = black ? 2u : 8u;
+  const uint64_t f0 = __ballot((hl.edge & fbit) != 0u), f1 = __ballot((hl.edge & (fbit << 4)) != 0u);
+  const uint64_t l0 = __ballot((hl.edge & lbit) != 0u), l1 = __ballot((hl.edge & (lbit << 4)) != 0u);
+  // a chain needs a stone on each of the two edges
+  if ((((own0 & f0) | (own1 & f1)) == 0ull) | (((own0 & l0) | (own1 & l1)) == 0ull)) return false;
+  const uint64_t bit = 1ull << (move & 63);
+  const bool hi = move >= 64;
+  uint64_t group0 = hi ? 0ull : bit, group1 = hi ? bit : 0ull;
+  uint64_t front0 = group0, front1 = group1;
+  for (int it = 0; it < 128; ++it) {
+    const bool t0 = ((hl.nb_lo[0] & front0) | (hl.nb_hi[0] & front1)) != 0ull;
+    const bool t1 = ((hl.nb_lo[1] & front0) | (hl.nb_hi[1] & front1)) != 0ull;
+    const uint64_t g0 = __ballot(t0) & own0 & ~group0, g1 = __ballot(t1) & own1 & ~group1;
+    if ((g0 | g1) == 0ull) break;
+    group0 |= g0;
+    group1 |= g1;
+    front0 = g0;
+    front1 = g1;
   }
-  w.blk[0] = black ? own0 : w.blk[0];
-  w.blk[1] = black ? own1 : w.blk[1];
-  w.wht[0] = black ? w.wht[0] : own0;
-  w.wht[1] = black ? w.wht[1] : own1;
-  const uint32_t ply = (w.meta >> 8) & 0xFFu;
-  const uint32_t ply_next = ply < 255u ? ply + 1u : 255u;
-  const uint32_t first = ply == 0 ? static_cast<uint32_t>(move) : ((w.meta >> 16) & 0xFFu);
-  w.meta = static_cast<uint32_t>(1 - player) | (res << 1) | (ply_next << 8) | (first << 16);
+  return (((group0 & f0) | (group1 & f1)) != 0ull) & (((group0 & l0) | (group1 & l1)) != 0ull);
 }
 
 // The rules as the search sees them: HexW for the hex fill kernel, G::State otherwise.
@@ -349,7 +355,7 @@ OSG_D void w_returns(const typename G::Params& p, const typename G::State& s, do
 template <class G>
 OSG_D void w_returns(const typename G::Params&, const HexW& w, double* out) { hexw_returns(w, out); }
 
-OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl) {
+OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl PT_ARGS) {
   const int lane = lane_id();
   const uint64_t black0 = s.blk[0], black1 = s.blk[1];
   const uint64_t empty0 = hl.board[0] & ~(black0 | s.wht[0]), empty1 = hl.board[1] & ~(black1 | s.wht[1]);
@@ -360,13 +366,13 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl) {
   // under it.  T is built most-significant bit first (a binary search on the key space): a bit stays
   // set while no more than `want` keys lie below.  Keys are distinct, so the search ends as soon as the
   // count is exact — about log2(m) + 2 steps of two compares and a handful of scalar instructions.
+#if defined(OSG_DIAG_NOTHR)  // measurement only: an arbitrary subset instead of the exact half
+  const uint64_t sel0 = __ballot((key0 >> 20) & 1ull) & empty0, sel1 = __ballot((key1 >> 20) & 1ull) & empty1;
+#elif OSG_THR_MODE == 0
   uint64_t thr = 0ull;
   if (want > 0) {
     uint64_t step = 1ull << (kFillKeyBits - 1);
     bool exact;
-#ifdef OSG_THR_UNROLL
-#pragma unroll OSG_THR_UNROLL
-#endif
     do {  // straight-line body: one select, no inner branch
       const uint64_t probe = thr | step;
       const int below = __builtin_popcountll(__ballot(key0 < probe) & empty0) +
@@ -377,6 +383,39 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl) {
     } while (!exact && step != 0ull);
   }
   const uint64_t sel0 = __ballot(key0 < thr) & empty0, sel1 = __ballot(key1 < thr) & empty1;
+#else
+  // The search runs on the VECTOR unit (the kernel is bound by scalar issue): threshold and step live in
+  // vector registers holding the same value in every lane, occupied cells carry the key 2^64 - 1 so that
+  // the ballots need no masking, and only the counting (mode 1) or nothing but the loop branch (mode 2)
+  // is left to the scalar unit.
+  const uint64_t k0 = __builtin_amdgcn_inverse_ballot_w64(empty0) ? key0 : ~0ull;
+  const uint64_t k1 = __builtin_amdgcn_inverse_ballot_w64(empty1) ? key1 : ~0ull;
+  const uint32_t vz = vector_zero();
+  uint64_t thr = vz;
+  if (want > 0) {
+    uint64_t step = (1ull << (kFillKeyBits - 1)) | vz;
+    const uint32_t want_v = static_cast<uint32_t>(want) | vz;
+    for (int it = 0; it < kFillKeyBits; ++it) {
+      const uint64_t probe = thr | step;
+      const uint64_t b0 = __ballot(k0 < probe), b1 = __ballot(k1 < probe);
+#if OSG_THR_MODE == 1
+      const int below = __builtin_popcountll(b0) + __builtin_popcountll(b1);
+      const uint32_t below_v = static_cast<uint32_t>(below) | vz;
+      thr = below_v <= want_v ? probe : thr;
+      step >>= 1;
+      if (below == want) break;
+#else
+      const uint32_t below_v = vector_popcount(static_cast<uint32_t>(b0), vector_popcount(static_cast<uint32_t>(b0 >> 32),
+                               vector_popcount(static_cast<uint32_t>(b1), vector_popcount(static_cast<uint32_t>(b1 >> 32), vz))));
+      thr = below_v <= want_v ? probe : thr;
+      step >>= 1;
+      if (__ballot(below_v == want_v) != 0ull) break;
+#endif
+    }
+  }
+  const uint64_t sel0 = __ballot(k0 < thr), sel1 = __ballot(k1 < thr);
+#endif
+  PT_MARK(4);
   // The filled board: the mover's new stones are `sel`, the opponent's the other empty cells.
   const bool black_moves = (s.meta & 1u) == 0;
   const uint64_t blk0 = black0 | (black_moves ? sel0 : empty0 & ~sel0);
@@ -384,6 +423,9 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl) {
   // Black wins iff its stones join the first row to the last row (hex.cc:108-171 edge labels).
   // Lane-parallel flood: a black cell joins the region when one of its neighbours is in it.
   // Stops as soon as the last row is reached.
+#if defined(OSG_DIAG_NOFLOOD)  // measurement only
+  return static_cast<int>((blk0 ^ blk1 ^ (blk0 >> 17)) & 1ull);
+#elif OSG_FLOOD_MODE == 0
   uint64_t reach0 = blk0 & hl.first_row[0], reach1 = blk1 & hl.first_row[1];
 #pragma unroll 4  // measured: 1 -> 7.80e8, compiler's choice (2) -> 7.93e8, 4 -> 8.01e8 sims/s
   for (int it = 0; it < 128; ++it) {
@@ -395,6 +437,28 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl) {
     reach0 |= g0;
     reach1 |= g1;
   }
+#else
+  // The bookkeeping of the flood on the vector unit: every lane keeps, for its two cells, an all-ones word
+  // while the cell is black and not reached yet ("available") and clears it when the cell joins; the scalar
+  // unit only sees the two ballots of a step (the new frontier) and decides the two exits.
+  uint64_t front0 = blk0 & hl.first_row[0], front1 = blk1 & hl.first_row[1];
+  uint32_t avail0 = __builtin_amdgcn_inverse_ballot_w64(blk0 & ~front0) ? ~0u : 0u;
+  uint32_t avail1 = __builtin_amdgcn_inverse_ballot_w64(blk1 & ~front1) ? ~0u : 0u;
+  if (((front0 & hl.last_row[0]) | (front1 & hl.last_row[1])) != 0ull) return 0;  // a one-row chain
+#pragma unroll 2
+  for (int it = 0; it < 128; ++it) {
+    const uint64_t x0 = (hl.nb_lo[0] & front0) | (hl.nb_hi[0] & front1);
+    const uint64_t x1 = (hl.nb_lo[1] & front0) | (hl.nb_hi[1] & front1);
+    const uint32_t j0 = (static_cast<uint32_t>(x0) | static_cast<uint32_t>(x0 >> 32)) & avail0;
+    const uint32_t j1 = (static_cast<uint32_t>(x1) | static_cast<uint32_t>(x1 >> 32)) & avail1;
+    front0 = __ballot(j0 != 0u);
+    front1 = __ballot(j1 != 0u);
+    if (((front0 & hl.last_row[0]) | (front1 & hl.last_row[1])) != 0ull) return 0;  // black reached its last row
+    if ((front0 | front1) == 0ull) break;
+    avail0 = j0 != 0u ? 0u : avail0;
+    avail1 = j1 != 0u ? 0u : avail1;
+  }
+#endif
   return 1;  // white: on a filled board exactly one side connects
 }
 
@@ -441,22 +505,6 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
   if constexpr (kHexFill) root_state = hexw_from_state<G>(loaded_root);
   else root_state = loaded_root;
   const int root_player = w_current_player<G>(p, root_state);
-  // hex: the root position lives in LDS and is re-read at the start of every simulation (57 -> 34 spilled
-  // scalar registers)
-  __shared__ uint32_t s_root[kHexFill ? kWavesPerBlock : 1][20];
-  if constexpr (kHexFill) {
-    if (lane == 0) {
-      uint32_t* rw = s_root[wave_in_block];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        rw[8 * j + 0] = static_cast<uint32_t>(root_state.blk[j]); rw[8 * j + 1] = static_cast<uint32_t>(root_state.blk[j] >> 32);
-        rw[8 * j + 2] = static_cast<uint32_t>(root_state.wht[j]); rw[8 * j + 3] = static_cast<uint32_t>(root_state.wht[j] >> 32);
-        rw[8 * j + 4] = static_cast<uint32_t>(root_state.ea[j]); rw[8 * j + 5] = static_cast<uint32_t>(root_state.ea[j] >> 32);
-        rw[8 * j + 6] = static_cast<uint32_t>(root_state.eb[j]); rw[8 * j + 7] = static_cast<uint32_t>(root_state.eb[j] >> 32);
-      }
-      rw[16] = root_state.meta;
-    }
-  }
   // The root's header stays in registers (its count / total in path slot 0); every other node's header
   // comes out of its parent's child scan by readlane, so a tree level costs ONE memory round trip.
   uint32_t root_meta = make_meta(0xFF, root_player, 0);  // mcts.cc:356-357
@@ -478,20 +526,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
   for (int sim = 0; sim < cfg.max_simulations; ++sim) {
     Rng trng(cfg.seed ^ kTreeSalt, gr, static_cast<uint64_t>(sim));
     // ---- ApplyTreePolicy (mcts.cc:273-351) ----
-    WState s;
-    if constexpr (kHexFill) {  // the root position is re-read from LDS: 17 scalar registers less to keep alive
-      const uint32_t* rw = s_root[wave_in_block];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        s.blk[j] = static_cast<uint64_t>(uniform(rw[8 * j + 1])) << 32 | uniform(rw[8 * j + 0]);
-        s.wht[j] = static_cast<uint64_t>(uniform(rw[8 * j + 3])) << 32 | uniform(rw[8 * j + 2]);
-        s.ea[j] = static_cast<uint64_t>(uniform(rw[8 * j + 5])) << 32 | uniform(rw[8 * j + 4]);
-        s.eb[j] = static_cast<uint64_t>(uniform(rw[8 * j + 7])) << 32 | uniform(rw[8 * j + 6]);
-      }
-      s.meta = uniform(rw[16]);
-    } else {
-      s = root_state;
-    }
+    WState s = root_state;
     uint32_t node = 0;
     int depth = 0;
     uint64_t ph = path_hash_root();
@@ -500,8 +535,28 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
     bool term;
     PT_MARK(7);
     for (;;) {
-      term = w_terminal<G>(p, s);
-      if (term || cnt == 0 || depth + 1 >= kMaxPath) break;
+      if constexpr (kHexFill) {
+        // IsTerminal() only where the search needs it (see HexW): a header that says so, or a first visit.
+        if (m_terminal(meta)) {
+          s.meta = (s.meta & 1u) | ((m_code(meta) == 2 ? 1u : 2u) << 1);
+          term = true;
+          break;
+        }
+        term = false;
+        if (cnt == 0) {
+          if (depth == 0) {
+            term = hexw_terminal(s);
+          } else if (hexw_last_stone_wins(hl, s, static_cast<int>(m_action(meta)))) {
+            s.meta |= ((s.meta & 1u) ? 1u : 2u) << 1;  // the player who moved last won
+            term = true;
+          }
+          break;
+        }
+        if (depth + 1 >= kMaxPath) break;
+      } else {
+        term = w_terminal<G>(p, s);
+        if (term || cnt == 0 || depth + 1 >= kMaxPath) break;
+      }
       const int cur = w_current_player<G>(p, s);
       const Mask legal = w_legal<G>(p, hl, s);
       PT_MARK(0);
@@ -564,49 +619,57 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
         n_first = uniform(FIRST[first + chosen_k]);
         n_tot = uniform_f64(TOTAL[first + chosen_k]);
       } else {  // arg-max of UCTValue (mcts.cc:90-101), ties to the smallest order key
-        uint32_t cm2[2], cc2[2], cf2[2];
-        double ct2[2];
-        bool unvisited[2];
+        // Headers AND statistics of the children in one memory round trip, with no lane-dependent control
+        // flow: lanes beyond the last child read child 0 again (a clamped index instead of an exec-mask
+        // branch) and are kept out of every candidate set by `in`.  (The kernel is bound by scalar / branch
+        // issue, not by memory: a few redundant loads are cheaper than the branches that would avoid them.)
+        uint32_t cm2[2] = {0u, 0u}, cc2[2] = {0u, 0u}, cf2[2] = {0u, 0u};
+        double ct2[2] = {0.0, 0.0};
         const bool wide = c > 64;  // wave-uniform: nodes with at most 64 children skip the second slot altogether
-        // A node visited more often than it has children has no unvisited child left (every visit after the
-        // expanding one starts with a never-visited child while there is one): its rewards WILL be needed, so
-        // they are loaded with the headers — one memory round trip for the level instead of two.
-        const bool eager = cnt > static_cast<uint32_t>(c);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int k = lane + 64 * j;
-          cm2[j] = 0;
-          cc2[j] = 0;
-          cf2[j] = 0;
-          ct2[j] = 0.0;
-          unvisited[j] = false;
-          if (j == 1 && !wide) continue;
-          if (k < c) {
-            cm2[j] = META[first + k];
-            cc2[j] = COUNT[first + k];
-            cf2[j] = FIRST[first + k];
-            if (eager) ct2[j] = TOTAL[first + k];
-            unvisited[j] = cc2[j] == 0 && !m_has_outcome(cm2[j]);
-          }
+        const bool in0 = lane < c, in1 = lane + 64 < c;
+        {
+          const uint32_t i0 = first + static_cast<uint32_t>(in0 ? lane : 0);
+          cm2[0] = META[i0];
+          cc2[0] = COUNT[i0];
+          cf2[0] = FIRST[i0];
+          ct2[0] = TOTAL[i0];
+        }
+        if (wide) {  // (all loads of the level are in flight before the first value is looked at)
+          const uint32_t i1 = first + static_cast<uint32_t>(in1 ? lane + 64 : 0);
+          cm2[1] = META[i1];
+          cc2[1] = COUNT[i1];
+          cf2[1] = FIRST[i1];
+          ct2[1] = TOTAL[i1];
+        }
+        constexpr uint32_t kOutcomeBit = 1u << 20;
+        // never visited and without a proven outcome (one compare: count | outcome bit | "not a child")
+        const bool uv0 = (cc2[0] | (cm2[0] & kOutcomeBit) | (in0 ? 0u : 1u)) == 0u;
+        bool uv1 = false;
+        uint64_t u0 = __ballot(uv0), o0 = __ballot((cm2[0] & kOutcomeBit) != 0u), u1 = 0ull, o1 = 0ull;
+        if (wide) {
+          uv1 = (cc2[1] | (cm2[1] & kOutcomeBit) | (in1 ? 0u : 1u)) == 0u;
+          u1 = __ballot(uv1);
+          o1 = __ballot((cm2[1] & kOutcomeBit) != 0u);
         }
         bool t0, t1;  // the candidates holding the maximum value
         const bool puct = cfg.child_selection_policy == 1;
-        const uint64_t u0 = __ballot(unvisited[0]), u1 = __ballot(unvisited[1]);
         if (!puct && (u0 | u1) != 0ull) {
           // Some child has never been visited: its value is +infinity (mcts.cc:95), so the maximum is
-          // +infinity whatever the others score — no UCT arithmetic (and no reward loads) at this node.
-          t0 = unvisited[0];
-          t1 = unvisited[1];
+          // +infinity whatever the others score — no UCT arithmetic at this node.
+          t0 = uv0;
+          t1 = uv1;
         } else {
-          double v2[2];
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int k = lane + 64 * j;
-            v2[j] = -INFINITY;
-            if (j == 1 && !wide) continue;
-            if (k < c && !eager) ct2[j] = TOTAL[first + k];
-          }
-          if (puct) {  // uniform branch: the two policies share nothing but the loads
+          double v2[2] = {-INFINITY, -INFINITY};
+          if (!puct && (o0 | o1) == 0ull) {
+            // the common case, straight-line: every child has been visited, none has a proven outcome
+            const double logn = log_table[cnt];
+            const double val0 = ct2[0] / cc2[0] + cfg.uct_c * sqrt(logn / cc2[0]);
+            v2[0] = in0 ? val0 : -INFINITY;
+            if (wide) {
+              const double val1 = ct2[1] / cc2[1] + cfg.uct_c * sqrt(logn / cc2[1]);
+              v2[1] = in1 ? val1 : -INFINITY;
+            }
+          } else if (puct) {  // uniform branch: the two policies share nothing but the loads
             const double prior = 1.0 / c, sqrt_n = sqrt(static_cast<double>(cnt));
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -623,19 +686,14 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
             for (int j = 0; j < 2; ++j) {
               const int k = lane + 64 * j;
               if (j == 1 && !wide) continue;
-              // straight-line: lanes without a child divide by zero and are masked by the select below
               double val = ct2[j] / cc2[j] + cfg.uct_c * sqrt(logn / cc2[j]);
-              if constexpr (kBoard) {
-                val = m_has_outcome(cm2[j]) ? outcome_value<true>(cm2[j], cc2[j], ct2[j], m_player(cm2[j])) : val;
-              } else {
-                if (m_has_outcome(cm2[j])) val = outcome_value<false>(cm2[j], cc2[j], ct2[j], m_player(cm2[j]));
-              }
+              if (m_has_outcome(cm2[j])) val = outcome_value<kBoard>(cm2[j], cc2[j], ct2[j], m_player(cm2[j]));
               v2[j] = k < c ? val : -INFINITY;
             }
           }
           const double vmax = wave_max(v2[0] > v2[1] ? v2[0] : v2[1]);  // value only: 2 dwords per butterfly step
-          t0 = lane < c && v2[0] == vmax;
-          t1 = lane + 64 < c && v2[1] == vmax;
+          t0 = in0 && v2[0] == vmax;
+          t1 = in1 && v2[1] == vmax;
         }
         const uint64_t b0 = __ballot(t0), b1 = __ballot(t1);
         if (__builtin_popcountll(b0) + __builtin_popcountll(b1) == 1) {
@@ -656,8 +714,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
         n_meta = read_lane(hi ? cm2[1] : cm2[0], src);
         n_cnt = read_lane(hi ? cc2[1] : cc2[0], src);
         n_first = read_lane(hi ? cf2[1] : cf2[0], src);
-        n_tot = read_lane_f64(hi ? ct2[1] : ct2[0], src);  // 0.0 when the rewards were not loaded: the chosen
-                                                           // child is unvisited then
+        n_tot = read_lane_f64(hi ? ct2[1] : ct2[0], src);
         action = static_cast<int>(m_action(n_meta));
       }
       PT_MARK(2);
@@ -693,7 +750,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
       double r0 = 0.0;
       for (int ro = 0; ro < cfg.n_rollouts; ++ro) {
         const uint64_t fb = fill_base(cfg.seed, gr, static_cast<uint64_t>(sim) * cfg.n_rollouts + ro);
-        r0 += hex_fill_winner(s, fb, hl) == 0 ? 1.0 : -1.0;
+        r0 += hex_fill_winner(s, fb, hl PT_PASS) == 0 ? 1.0 : -1.0;
       }
       returns[0] = r0 / cfg.n_rollouts;
       returns[1] = -returns[0] + 0.0;
@@ -911,9 +968,11 @@ int launch_mcts_wave(const osg_batch* roots, const osg_mcts_cfg& cfg, const doub
     case kKuhn: launch<Kuhn, false, false>(spec.kuhn, roots, cfg, d_logs, pool, out); break;
     case kLeduc: launch<Leduc, false, false>(spec.leduc, roots, cfg, d_logs, pool, out); break;
     case kHex: {
-      // The random-fill playout needs "legal moves == empty cells": not with the swap rule.
+      // The random-fill playout needs "legal moves == empty cells": not with the swap rule.  The search's own
+      // position (HexW) needs two distinct edges per colour.
 #define OSG_HEX_CASE(NW, member)                                                                   \
-  if (spec.member.swap) launch<HexT<NW>, true, false>(spec.member, roots, cfg, d_logs, pool, out); \
+  if (spec.member.swap || spec.member.rows < 2 || spec.member.cols < 2)                            \
+    launch<HexT<NW>, true, false>(spec.member, roots, cfg, d_logs, pool, out);                     \
   else launch<HexT<NW>, true, true>(spec.member, roots, cfg, d_logs, pool, out)
       switch (spec.hex_nw) {
         case 1: OSG_HEX_CASE(1, hex1); break;

@@ -201,6 +201,129 @@ OSG_D bool final_better(const Final& a, const Final& b) {  // a strictly preferr
   return a.key < b.key;
 }
 
+// ---- selection at one node (mcts.cc:324-341) ----------------------------------------------------------
+// arg-max of UCTValue / PUCTValue (mcts.cc:90-112) over the node's children, ties to the smallest order key (=
+// first in the reference's shuffled order, mcts.cc:294,336).  Lane l scans child l (and l + 64 when kSlots = 2:
+// the caller picks the instantiation by the child count, so a node with at most 64 children carries no trace of
+// the second slot).  Headers AND statistics come in one memory round trip with no lane-dependent control flow:
+// lanes beyond the last child read child 0 again (a clamped index instead of an exec-mask branch) and are kept out
+// of every candidate set.  Candidate sets travel as lane masks; the chosen child's header is handed down by
+// readlane from the lane that scanned it.  (The kernel is bound by scalar / branch issue, not by memory: a few
+// redundant loads are cheaper than the branches that would avoid them.)
+struct Chosen {
+  int k;
+  uint32_t meta, cnt, first;
+  double tot;
+};
+template <int kSlots, bool kBoard>
+OSG_D Chosen select_child(const uint32_t* __restrict__ META, const uint32_t* __restrict__ COUNT,
+                          const uint32_t* __restrict__ FIRST, const double* __restrict__ TOTAL, uint32_t first, int c,
+                          uint32_t cnt, const osg_mcts_cfg& cfg, const double* __restrict__ log_table, uint64_t obase,
+                          uint64_t ph) {
+  const int lane = lane_id();
+  constexpr uint32_t kOutcomeBit = 1u << 20;
+  uint32_t cm[kSlots], cc[kSlots], cf[kSlots];
+  double ct[kSlots];
+  bool in[kSlots];
+#pragma unroll
+  for (int j = 0; j < kSlots; ++j) {  // every load of the level is in flight before the first value is looked at
+    const int k = lane + 64 * j;
+    in[j] = k < c;
+    const uint32_t i = first + static_cast<uint32_t>(in[j] ? k : 0);
+    cm[j] = META[i];
+    cc[j] = COUNT[i];
+    cf[j] = FIRST[i];
+    ct[j] = TOTAL[i];
+  }
+  uint64_t unvisited[kSlots], cand[kSlots];
+  uint64_t any_unvisited = 0ull, any_outcome = 0ull;
+#pragma unroll
+  for (int j = 0; j < kSlots; ++j) {
+    // never visited and without a proven outcome, in one compare: count | outcome bit | "not a child"
+    unvisited[j] = __ballot((cc[j] | (cm[j] & kOutcomeBit) | (in[j] ? 0u : 1u)) == 0u);
+    any_unvisited |= unvisited[j];
+    any_outcome |= __ballot((cm[j] & kOutcomeBit) != 0u);
+  }
+  const bool puct = cfg.child_selection_policy == 1;
+  if (!puct && any_unvisited != 0ull) {
+    // Some child has never been visited: its value is +infinity (mcts.cc:95), so the maximum is +infinity
+    // whatever the others score — no UCT arithmetic at this node.
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) cand[j] = unvisited[j];
+  } else {
+    double v[kSlots];
+    if (!puct && any_outcome == 0ull) {
+      // the common case, straight-line: every child has been visited, none has a proven outcome
+      const double logn = log_table[cnt];
+#pragma unroll
+      for (int j = 0; j < kSlots; ++j) {
+        const double val = ct[j] / cc[j] + cfg.uct_c * sqrt(logn / cc[j]);
+        v[j] = in[j] ? val : -INFINITY;
+      }
+    } else if (puct) {  // uniform branch: the two policies share nothing but the loads
+      const double prior = 1.0 / c, sqrt_n = sqrt(static_cast<double>(cnt));
+#pragma unroll
+      for (int j = 0; j < kSlots; ++j) {
+        v[j] = -INFINITY;
+        if (in[j]) {
+          if (m_has_outcome(cm[j])) v[j] = outcome_value<kBoard>(cm[j], cc[j], ct[j], m_player(cm[j]));
+          else v[j] = (cc[j] != 0 ? ct[j] / cc[j] : 0.0) + cfg.uct_c * prior * sqrt_n / (cc[j] + 1);
+        }
+      }
+    } else {
+      const double logn = log_table[cnt];
+#pragma unroll
+      for (int j = 0; j < kSlots; ++j) {
+        double val = ct[j] / cc[j] + cfg.uct_c * sqrt(logn / cc[j]);
+        if (m_has_outcome(cm[j])) val = outcome_value<kBoard>(cm[j], cc[j], ct[j], m_player(cm[j]));
+        v[j] = in[j] ? val : -INFINITY;
+      }
+    }
+    double vm = v[0];
+#pragma unroll
+    for (int j = 1; j < kSlots; ++j) vm = v[j] > vm ? v[j] : vm;
+    const double vmax = wave_max(vm);  // value only: 2 dwords per reduction step
+    // (lanes without a child hold -infinity and c >= 1, so they never equal the maximum)
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) cand[j] = __ballot(v[j] == vmax);
+  }
+  int total = 0;
+#pragma unroll
+  for (int j = 0; j < kSlots; ++j) total += __builtin_popcountll(cand[j]);
+  if (total != 1) {  // several maxima: the smallest order key among them
+    uint32_t key[kSlots];
+    uint32_t km = 0xFFFFFFFFu;  // no candidate's key: the low byte of a key is an action, never 0xFF
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) {
+      const uint32_t kj = order_key(obase, ph, static_cast<int>(m_action(cm[j])));
+      key[j] = __builtin_amdgcn_inverse_ballot_w64(cand[j]) ? kj : 0xFFFFFFFFu;
+      km = key[j] < km ? key[j] : km;
+    }
+    const uint32_t kmin = wave_min_u32(km);
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) cand[j] = __ballot(key[j] == kmin);
+  }
+  Chosen r;
+  if constexpr (kSlots == 1) {
+    const int src = uniform(static_cast<int>(__builtin_ctzll(cand[0])));
+    r.k = src;
+    r.meta = read_lane(cm[0], src);
+    r.cnt = read_lane(cc[0], src);
+    r.first = read_lane(cf[0], src);
+    r.tot = read_lane_f64(ct[0], src);
+  } else {
+    const bool hi = cand[0] == 0ull;
+    const int src = uniform(static_cast<int>(__builtin_ctzll(hi ? cand[1] : cand[0])));
+    r.k = src + (hi ? 64 : 0);
+    // the slot is picked per lane first so that each field costs one readlane
+    r.meta = read_lane(hi ? cm[1] : cm[0], src);
+    r.cnt = read_lane(hi ? cc[1] : cc[0], src);
+    r.first = read_lane(hi ? cf[1] : cf[0], src);
+    r.tot = read_lane_f64(hi ? ct[1] : ct[0], src);
+  }
+  return r;
+}
+
 // --- hex playout as a wave-parallel random fill --------------------------------------------
 // Lane l owns cells l and l + 64.  Per lane: the set of each cell's (up to six) neighbours as a 128-bit
 // mask.  Per wavefront (uniform, in SGPRs): which cells are on the board / on black's two edges.  Sets of
@@ -619,102 +742,14 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
         n_first = uniform(FIRST[first + chosen_k]);
         n_tot = uniform_f64(TOTAL[first + chosen_k]);
       } else {  // arg-max of UCTValue (mcts.cc:90-101), ties to the smallest order key
-        // Headers AND statistics of the children in one memory round trip, with no lane-dependent control
-        // flow: lanes beyond the last child read child 0 again (a clamped index instead of an exec-mask
-        // branch) and are kept out of every candidate set by `in`.  (The kernel is bound by scalar / branch
-        // issue, not by memory: a few redundant loads are cheaper than the branches that would avoid them.)
-        uint32_t cm2[2] = {0u, 0u}, cc2[2] = {0u, 0u}, cf2[2] = {0u, 0u};
-        double ct2[2] = {0.0, 0.0};
-        const bool wide = c > 64;  // wave-uniform: nodes with at most 64 children skip the second slot altogether
-        const bool in0 = lane < c, in1 = lane + 64 < c;
-        {
-          const uint32_t i0 = first + static_cast<uint32_t>(in0 ? lane : 0);
-          cm2[0] = META[i0];
-          cc2[0] = COUNT[i0];
-          cf2[0] = FIRST[i0];
-          ct2[0] = TOTAL[i0];
-        }
-        if (wide) {  // (all loads of the level are in flight before the first value is looked at)
-          const uint32_t i1 = first + static_cast<uint32_t>(in1 ? lane + 64 : 0);
-          cm2[1] = META[i1];
-          cc2[1] = COUNT[i1];
-          cf2[1] = FIRST[i1];
-          ct2[1] = TOTAL[i1];
-        }
-        constexpr uint32_t kOutcomeBit = 1u << 20;
-        // never visited and without a proven outcome (one compare: count | outcome bit | "not a child")
-        const bool uv0 = (cc2[0] | (cm2[0] & kOutcomeBit) | (in0 ? 0u : 1u)) == 0u;
-        bool uv1 = false;
-        uint64_t u0 = __ballot(uv0), o0 = __ballot((cm2[0] & kOutcomeBit) != 0u), u1 = 0ull, o1 = 0ull;
-        if (wide) {
-          uv1 = (cc2[1] | (cm2[1] & kOutcomeBit) | (in1 ? 0u : 1u)) == 0u;
-          u1 = __ballot(uv1);
-          o1 = __ballot((cm2[1] & kOutcomeBit) != 0u);
-        }
-        bool t0, t1;  // the candidates holding the maximum value
-        const bool puct = cfg.child_selection_policy == 1;
-        if (!puct && (u0 | u1) != 0ull) {
-          // Some child has never been visited: its value is +infinity (mcts.cc:95), so the maximum is
-          // +infinity whatever the others score — no UCT arithmetic at this node.
-          t0 = uv0;
-          t1 = uv1;
-        } else {
-          double v2[2] = {-INFINITY, -INFINITY};
-          if (!puct && (o0 | o1) == 0ull) {
-            // the common case, straight-line: every child has been visited, none has a proven outcome
-            const double logn = log_table[cnt];
-            const double val0 = ct2[0] / cc2[0] + cfg.uct_c * sqrt(logn / cc2[0]);
-            v2[0] = in0 ? val0 : -INFINITY;
-            if (wide) {
-              const double val1 = ct2[1] / cc2[1] + cfg.uct_c * sqrt(logn / cc2[1]);
-              v2[1] = in1 ? val1 : -INFINITY;
-            }
-          } else if (puct) {  // uniform branch: the two policies share nothing but the loads
-            const double prior = 1.0 / c, sqrt_n = sqrt(static_cast<double>(cnt));
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const int k = lane + 64 * j;
-              if (j == 1 && !wide) continue;
-              if (k < c) {
-                if (m_has_outcome(cm2[j])) v2[j] = outcome_value<kBoard>(cm2[j], cc2[j], ct2[j], m_player(cm2[j]));
-                else v2[j] = (cc2[j] != 0 ? ct2[j] / cc2[j] : 0.0) + cfg.uct_c * prior * sqrt_n / (cc2[j] + 1);
-              }
-            }
-          } else {
-            const double logn = log_table[cnt];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const int k = lane + 64 * j;
-              if (j == 1 && !wide) continue;
-              double val = ct2[j] / cc2[j] + cfg.uct_c * sqrt(logn / cc2[j]);
-              if (m_has_outcome(cm2[j])) val = outcome_value<kBoard>(cm2[j], cc2[j], ct2[j], m_player(cm2[j]));
-              v2[j] = k < c ? val : -INFINITY;
-            }
-          }
-          const double vmax = wave_max(v2[0] > v2[1] ? v2[0] : v2[1]);  // value only: 2 dwords per butterfly step
-          t0 = in0 && v2[0] == vmax;
-          t1 = in1 && v2[1] == vmax;
-        }
-        const uint64_t b0 = __ballot(t0), b1 = __ballot(t1);
-        if (__builtin_popcountll(b0) + __builtin_popcountll(b1) == 1) {
-          chosen_k = b0 ? __builtin_ctzll(b0) : 64 + __builtin_ctzll(b1);
-        } else {  // several maxima: the smallest order key (= first in the shuffled order, mcts.cc:294,336)
-          const uint32_t k0 = t0 ? order_key(obase, ph, static_cast<int>(m_action(cm2[0]))) : 0xFFFFFFFFu;
-          const uint32_t k1 = t1 ? order_key(obase, ph, static_cast<int>(m_action(cm2[1]))) : 0xFFFFFFFFu;
-          const uint32_t kmin = wave_min_u32(k0 < k1 ? k0 : k1);
-          const uint64_t w0 = __ballot(t0 && k0 == kmin), w1 = __ballot(t1 && k1 == kmin);
-          chosen_k = w0 ? __builtin_ctzll(w0) : 64 + __builtin_ctzll(w1);
-        }
-        chosen_k = uniform(chosen_k);
-        // the chosen child's header, straight from the lane that scanned it
-        // (the slot is picked per lane first so that each field costs one readlane; a ternary of two
-        // readlanes is compiled into a chain of scalar branches)
-        const int src = chosen_k & 63;
-        const bool hi = chosen_k >= 64;
-        n_meta = read_lane(hi ? cm2[1] : cm2[0], src);
-        n_cnt = read_lane(hi ? cc2[1] : cc2[0], src);
-        n_first = read_lane(hi ? cf2[1] : cf2[0], src);
-        n_tot = read_lane_f64(hi ? ct2[1] : ct2[0], src);
+        Chosen ch;
+        if (c > 64) ch = select_child<2, kBoard>(META, COUNT, FIRST, TOTAL, first, c, cnt, cfg, log_table, obase, ph);
+        else ch = select_child<1, kBoard>(META, COUNT, FIRST, TOTAL, first, c, cnt, cfg, log_table, obase, ph);
+        chosen_k = ch.k;
+        n_meta = ch.meta;
+        n_cnt = ch.cnt;
+        n_first = ch.first;
+        n_tot = ch.tot;
         action = static_cast<int>(m_action(n_meta));
       }
       PT_MARK(2);

@@ -384,8 +384,8 @@ OSG_D uint64_t hex_cells64(const typename G::Bits& b, int j) {
 // `else if` of hex.cc:122-126 only matters on a one-row / one-column board, which this kernel is not
 // launched for) makes the two statements the same.
 struct HexW {
-  uint64_t blk[2], wht[2];
-  uint32_t meta;  // to move [0], result [1:3) as HexT::State::meta
+  uint64_t occ[2], blk[2];  // all stones, black's stones (white = occ & ~blk: one set to update per move)
+  uint32_t meta;            // to move [0], result [1:3) as HexT::State::meta
 };
 template <class G>
 OSG_D HexW hexw_from_state(const typename G::State& s) {
@@ -393,7 +393,7 @@ OSG_D HexW hexw_from_state(const typename G::State& s) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     w.blk[j] = hex_cells64<G>(s.black, j);
-    w.wht[j] = hex_cells64<G>(s.white, j);
+    w.occ[j] = w.blk[j] | hex_cells64<G>(s.white, j);
   }
   w.meta = uniform(s.meta) & 7u;
   return w;
@@ -403,7 +403,7 @@ OSG_D int hexw_current_player(const HexW& w) { return hexw_terminal(w) ? kTermin
 OSG_D Mask hexw_legal(const HexLane& hl, const HexW& w) {  // hex.cc:280-293 without the swap action
   Mask m;
   if (hexw_terminal(w)) return m;
-  const uint64_t e0 = hl.board[0] & ~(w.blk[0] | w.wht[0]), e1 = hl.board[1] & ~(w.blk[1] | w.wht[1]);
+  const uint64_t e0 = hl.board[0] & ~w.occ[0], e1 = hl.board[1] & ~w.occ[1];
   m.w[0] = static_cast<uint32_t>(e0);
   m.w[1] = static_cast<uint32_t>(e0 >> 32);
   m.w[2] = static_cast<uint32_t>(e1);
@@ -421,18 +421,18 @@ OSG_D void hexw_apply(const HexLane&, HexW& w, int move) {
   const uint64_t bit = 1ull << (move & 63);
   const bool hi = move >= 64;
   const uint64_t bit0 = hi ? 0ull : bit, bit1 = hi ? bit : 0ull;
-  const bool black = (w.meta & 1u) == 0;
-  w.blk[0] |= black ? bit0 : 0ull;
-  w.blk[1] |= black ? bit1 : 0ull;
-  w.wht[0] |= black ? 0ull : bit0;
-  w.wht[1] |= black ? 0ull : bit1;
+  const uint64_t black = (w.meta & 1u) == 0 ? ~0ull : 0ull;
+  w.occ[0] |= bit0;
+  w.occ[1] |= bit1;
+  w.blk[0] |= bit0 & black;
+  w.blk[1] |= bit1 & black;
   w.meta ^= 1u;
 }
 // Did the stone just placed on `move` end the game?  (= would hex.cc:248 have labelled it Win.)  Lane-parallel
 // flood of its group: a stone of the same colour joins when one of its neighbours is in the frontier.
 OSG_D bool hexw_last_stone_wins(const HexLane& hl, const HexW& w, int move) {
   const bool black = (w.meta & 1u) != 0;  // the owner of the stone is the player who is NOT to move now
-  const uint64_t own0 = black ? w.blk[0] : w.wht[0], own1 = black ? w.blk[1] : w.wht[1];
+  const uint64_t own0 = black ? w.blk[0] : w.occ[0] & ~w.blk[0], own1 = black ? w.blk[1] : w.occ[1] & ~w.blk[1];
   // the colour's two edges as cell sets: from the lanes' edge flags (black: rows = bits 0, 1; white: columns = bits 2, 3)
   const uint32_t fbit = black ? 1u : 4u, lbit = black ? 2u : 8u;
   const uint64_t f0 = __ballot((hl.edge & fbit) != 0u), f1 = __ballot((hl.edge & (fbit << 4)) != 0u);
@@ -481,7 +481,7 @@ OSG_D void w_returns(const typename G::Params&, const HexW& w, double* out) { he
 OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl PT_ARGS) {
   const int lane = lane_id();
   const uint64_t black0 = s.blk[0], black1 = s.blk[1];
-  const uint64_t empty0 = hl.board[0] & ~(black0 | s.wht[0]), empty1 = hl.board[1] & ~(black1 | s.wht[1]);
+  const uint64_t empty0 = hl.board[0] & ~s.occ[0], empty1 = hl.board[1] & ~s.occ[1];
   const uint64_t key0 = fill_key(base, lane), key1 = fill_key(base, lane + 64);
   const int m = __builtin_popcountll(empty0) + __builtin_popcountll(empty1);
   const int want = (m + 1) >> 1;  // plies 0, 2, 4, ... belong to the player to move
@@ -585,6 +585,36 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl PT_ARG
   return 1;  // white: on a filled board exactly one side connects
 }
 
+// The visit path of the running simulation: the d-th entry is the node id [0:28) | META's player field [28:32)
+// and the node's visit count / total reward as they were when the path went through it, so that the backup is
+// stores only (no read-modify-write round trip to the pool).  LANE d KEEPS ENTRY d IN REGISTERS (three selects per
+// tree level, no memory and nothing for the scalar unit; the backup has lane d own path node d anyway); entries
+// 64 ... kMaxPath - 1 — reachable only in games longer than 64 plies — live in LDS.  Entry 0 is the root, whose
+// statistics persist in lane 0 from one simulation to the next.
+constexpr int kPathRegs = 64;
+struct VisitPath {
+  uint32_t node, cnt;
+  double tot;
+  uint32_t* l_node;
+  uint32_t* l_cnt;
+  double* l_tot;
+  OSG_D void set(int d, uint32_t e, uint32_t c, double t) {  // d is wave-uniform
+    if (d < kPathRegs) {
+      const bool me = lane_id() == d;
+      node = me ? e : node;
+      cnt = me ? c : cnt;
+      tot = me ? t : tot;
+    } else if (lane_id() == 0) {
+      l_node[d - kPathRegs] = e;
+      l_cnt[d - kPathRegs] = c;
+      l_tot[d - kPathRegs] = t;
+    }
+  }
+  OSG_D uint32_t node_at(int d) const {  // d is wave-uniform
+    return d < kPathRegs ? read_lane(node, d) : uniform(l_node[d - kPathRegs]);
+  }
+};
+
 #ifndef OSG_HEX_WPE
 #define OSG_HEX_WPE 6
 #endif
@@ -596,19 +626,16 @@ template <class G, bool kBoard, bool kHexFill, bool kGc>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(kHexFill ? OSG_HEX_WPE : 4, 8)))
 k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, int num_actions,
             osg_mcts_cfg cfg, double max_utility, const double* __restrict__ log_table, Pool pool, MctsOut out) {
-  // The visit path of the running simulation, in LDS: node id [0:28) | META's player field [28:32), and
-  // the node's visit count / total reward as they were when the path went through it, so that the
-  // backup is stores only (no read-modify-write round trip to the pool).
-  __shared__ uint32_t s_path[kWavesPerBlock][kMaxPath];
-  __shared__ uint32_t s_pcnt[kWavesPerBlock][kMaxPath];
-  __shared__ double s_ptot[kWavesPerBlock][kMaxPath];
+  __shared__ uint32_t s_path[kWavesPerBlock][kMaxPath - kPathRegs];
+  __shared__ uint32_t s_pcnt[kWavesPerBlock][kMaxPath - kPathRegs];
+  __shared__ double s_ptot[kWavesPerBlock][kMaxPath - kPathRegs];
   const int wave_in_block = static_cast<int>(threadIdx.x >> 6);
   const int64_t r = uniform(static_cast<int>(blockIdx.x * kWavesPerBlock + wave_in_block));
   if (r >= n) return;
   const int lane = lane_id();
-  uint32_t* path = s_path[wave_in_block];
-  uint32_t* pcnt = s_pcnt[wave_in_block];
-  double* ptot = s_ptot[wave_in_block];
+  // without chance nodes (kBoard) a path may use the LDS entries; the chance-skipping backup below looks entries
+  // up across lanes and stays within the register entries (the games with chance nodes are far shorter anyway)
+  constexpr int kPathLimit = kBoard ? kMaxPath : kPathRegs;
   const uint64_t gr = static_cast<uint64_t>(cfg.index_offset + r);
   const int cap = pool.cap;
   uint32_t* META = pool.meta + r * cap;
@@ -637,10 +664,8 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
     FIRST[0] = 0;
     COUNT[0] = 0;
     TOTAL[0] = 0.0;
-    path[0] = (root_meta >> 8 & 15u) << 28;
-    pcnt[0] = 0;
-    ptot[0] = 0.0;
   }
+  VisitPath vp{(root_meta >> 8 & 15u) << 28, 0u, 0.0, s_path[wave_in_block], s_pcnt[wave_in_block], s_ptot[wave_in_block]};
   wave_fence();
   uint32_t used = 1;
   int sims_done = 0;
@@ -654,7 +679,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
     int depth = 0;
     uint64_t ph = path_hash_root();
     uint32_t meta = root_meta, first = root_first;
-    uint32_t cnt = uniform(pcnt[0]);
+    uint32_t cnt = read_lane(vp.cnt, 0);
     bool term;
     PT_MARK(7);
     for (;;) {
@@ -675,10 +700,10 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
           }
           break;
         }
-        if (depth + 1 >= kMaxPath) break;
+        if (depth + 1 >= kPathLimit) break;
       } else {
         term = w_terminal<G>(p, s);
-        if (term || cnt == 0 || depth + 1 >= kMaxPath) break;
+        if (term || cnt == 0 || depth + 1 >= kPathLimit) break;
       }
       const int cur = w_current_player<G>(p, s);
       const Mask legal = w_legal<G>(p, hl, s);
@@ -756,13 +781,9 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
       node = first + static_cast<uint32_t>(chosen_k);
       ph = path_hash_child(ph, action);
       ++depth;
-      // (kept ahead of apply on purpose: if this lane-0 block were the last thing in the loop body, its join
+      // (kept ahead of apply on purpose: were a lane-dependent block the last thing in the loop body, its join
       // would be the loop latch, and the compiler would then treat every loop-carried value as lane-varying)
-      if (lane == 0) {
-        path[depth] = node | ((n_meta >> 8 & 15u) << 28);
-        pcnt[depth] = n_cnt;
-        ptot[depth] = n_tot;
-      }
+      vp.set(depth, node | ((n_meta >> 8 & 15u) << 28), n_cnt, n_tot);
       w_apply<G>(p, hl, s, action);
       PT_MARK(3);
       meta = n_meta;
@@ -812,34 +833,49 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
     }
     PT_MARK(5);
     // ---- backup (mcts.cc:383-395): lane d owns the d-th node of the visit path ----
-    for (int d = lane; d <= depth; d += 64) {
-      const uint32_t e = path[d];
-      const uint32_t v = e & 0x0FFFFFFFu;
+    {
+      const uint32_t e = vp.node;
       int pl = static_cast<int>(e >> 28) - 1;
-      double rv = returns[0];
-      if constexpr (kBoard) {  // two players, no chance nodes
-        rv = pl == 1 ? returns[1] : rv;
-      } else {
-        for (int up = d; pl == kChancePlayer;) {  // skip chance-player entries (poker trees)
-          if (--up < 0) { pl = 0; break; }
-          pl = static_cast<int>(path[up] >> 28) - 1;
+      if constexpr (!kBoard) {
+        // chance-player entries (poker trees) take the player of the nearest entry above them that is not the
+        // chance player (player 0 when there is none); all lanes walk up together, one entry per step
+        for (int hop = 1; __ballot(pl == kChancePlayer && lane <= depth) != 0ull; ++hop) {
+          const int up = lane - hop;
+          const uint32_t ue = __shfl(e, up < 0 ? 0 : up);
+          if (pl == kChancePlayer) pl = up < 0 ? 0 : static_cast<int>(ue >> 28) - 1;
         }
-        for (int q = 1; q < num_players; ++q) rv = (pl == q) ? returns[q] : rv;
       }
-      const double nt = ptot[d] + rv;
-      const uint32_t nc = pcnt[d] + 1;
-      TOTAL[v] = nt;
-      COUNT[v] = nc;
-      if (d == 0) {  // the root's statistics persist in slot 0
-        ptot[0] = nt;
-        pcnt[0] = nc;
+      if (lane <= depth) {
+        const uint32_t v = e & 0x0FFFFFFFu;
+        double rv = returns[0];
+        if constexpr (kBoard) {  // two players, no chance nodes
+          rv = pl == 1 ? returns[1] : rv;
+        } else {
+          for (int q = 1; q < num_players; ++q) rv = (pl == q) ? returns[q] : rv;
+        }
+        const double nt = vp.tot + rv;
+        const uint32_t nc = vp.cnt + 1;
+        TOTAL[v] = nt;
+        COUNT[v] = nc;
+        vp.tot = nt;  // (only lane 0's — the root's — is ever read again before it is set anew)
+        vp.cnt = nc;
+      }
+    }
+    if constexpr (kBoard) {
+      for (int d = kPathRegs + lane; d <= depth; d += 64) {  // entries in LDS: two players, no chance nodes
+        const uint32_t e = vp.l_node[d - kPathRegs];
+        const uint32_t v = e & 0x0FFFFFFFu;
+        const int pl = static_cast<int>(e >> 28) - 1;
+        const double rv = pl == 1 ? returns[1] : returns[0];
+        TOTAL[v] = vp.l_tot[d - kPathRegs] + rv;
+        COUNT[v] = vp.l_cnt[d - kPathRegs] + 1;
       }
     }
     wave_fence();
     // ---- MCTS-Solver (mcts.cc:398-434), leaf to root ----
     if (kBoard && solved) {
       for (int d = depth; d >= 0 && solved; --d) {
-        const uint32_t v = uniform(path[d]) & 0x0FFFFFFFu;
+        const uint32_t v = vp.node_at(d) & 0x0FFFFFFFu;
         const uint32_t meta = uniform(META[v]);
         const int c = m_nchild(meta);
         if (c == 0) continue;

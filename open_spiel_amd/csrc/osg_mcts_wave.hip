@@ -2,10 +2,10 @@
 //
 // The 64 lanes of a wavefront cooperate on one search tree:
 //   * selection   (mcts.cc:324-341)  children of a node are contiguous; lane l scans
-//                 children l and l+64 (header + statistics), scores them (UCTValue,
-//                 mcts.cc:90-101), a DPP reduction finds the maximum and a ballot who
-//                 holds it; the chosen child's header is handed down by readlane, so a
-//                 tree level costs one memory round trip
+//                 children l and l+64 (header + statistics, one branch-free round of
+//                 loads), scores them (UCTValue, mcts.cc:90-101), a DPP reduction finds
+//                 the maximum and a ballot who holds it; the chosen child's header is
+//                 handed down by readlane, so a tree level costs one memory round trip
 //   * expansion   (mcts.cc:281-299)  lane l initialises children l, l+64
 //   * evaluation  (mcts.cc:43-72)    n_rollouts playouts spread over the lanes; a
 //                 hex playout is ONE wave-parallel random fill of the board
@@ -21,6 +21,16 @@
 // (readfirstlane / readlane / ballot); `opt -passes=print<uniformity>` on this file is
 // the check — a single lane-varying value on the loop-carried path turns the whole
 // position into vector registers and the scalar branches into exec-mask branches.
+//
+// What bounds the hex kernel is the ISSUE RATE OF SCALAR-UNIT INSTRUCTIONS (ALU, branches,
+// waits: one per 4 cycles per SIMD), measured with rocprofv3 --pmc SQ_INSTS_SALU /
+// SQ_INSTS_BRANCH / SQ_INSTS_VALU per variant (tools/pmc_variants.sh): 652 + 83 scalar +
+// branch and 533 vector instructions per simulation gave 7.97e8 simulations/s, 474 + 93
+// and 503 give 1.00e9.  Hence the shape of the code below: no lane-dependent control flow
+// where a clamped index or a select does, bookkeeping that is the same in every lane done
+// by the vector unit when the scalar unit is the busier one (the key-threshold search and
+// the flood of the playout, the visit path), and no per-level state that is not needed
+// (the hex position carries no edge labels on the way down, see HexW).
 //
 // Random streams (shared with the oracle's replay, oracle MCTSBot mode 2):
 //   sibling order  the reference shuffles a new node's children and lets the first
@@ -72,11 +82,13 @@ namespace {
 #endif
 constexpr int kWavesPerBlock = OSG_WAVES_PER_BLOCK;
 constexpr int kMaxPath = 160;
+// Where the hex playout's bookkeeping runs: 1 = on the vector unit (measured on MI355X, config 4: key threshold
+// 0 -> 1: 9.48e8 -> 1.003e9 sims/s; flood 0 -> 1: 9.89e8 -> 1.003e9), 0 = the scalar formulation.
 #ifndef OSG_THR_MODE
-#define OSG_THR_MODE 0
+#define OSG_THR_MODE 1
 #endif
 #ifndef OSG_FLOOD_MODE
-#define OSG_FLOOD_MODE 0
+#define OSG_FLOOD_MODE 1
 #endif
 
 OSG_D int lane_id() { return static_cast<int>(threadIdx.x & 63u); }
@@ -116,10 +128,15 @@ OSG_D uint32_t vector_zero() {
   asm("v_mov_b32 %0, 0" : "=v"(r));
   return r;
 }
-OSG_D uint32_t vector_popcount(uint32_t bits, uint32_t acc) {  // popcount(bits) + acc on the vector unit
-  uint32_t r;
-  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "s"(bits), "v"(acc));
-  return r;
+// base[byte_off / sizeof(T)] with a 32-bit per-lane byte offset: the uniform base stays in scalar registers and the
+// load needs no 64-bit address arithmetic on the vector unit (a node pool holds fewer than 2^28 nodes per root).
+template <class T>
+OSG_D T load_at(const T* base, uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T>
+OSG_D void store_at(T* base, uint32_t byte_off, T v) {
+  *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 OSG_D int wave_count(bool pred) { return __builtin_popcountll(__ballot(pred)); }
 
@@ -155,7 +172,7 @@ OSG_D double dpp_max_step(double v) {
   const uint32_t lo = dpp_move<kCtrl, kRowMask>(static_cast<uint32_t>(kNegInf), static_cast<uint32_t>(u));
   const uint32_t hi = dpp_move<kCtrl, kRowMask>(static_cast<uint32_t>(kNegInf >> 32), static_cast<uint32_t>(u >> 32));
   const double o = __longlong_as_double(static_cast<long long>(static_cast<uint64_t>(hi) << 32 | lo));
-  return o > v ? o : v;
+  return fmax(o, v);  // one v_max_f64 (the values are never NaN: a compare + two selects would be three)
 }
 OSG_D double wave_max(double v) {
   v = dpp_max_step<0x111, 0xf>(v);  // row_shr:1
@@ -229,11 +246,11 @@ OSG_D Chosen select_child(const uint32_t* __restrict__ META, const uint32_t* __r
   for (int j = 0; j < kSlots; ++j) {  // every load of the level is in flight before the first value is looked at
     const int k = lane + 64 * j;
     in[j] = k < c;
-    const uint32_t i = first + static_cast<uint32_t>(in[j] ? k : 0);
-    cm[j] = META[i];
-    cc[j] = COUNT[i];
-    cf[j] = FIRST[i];
-    ct[j] = TOTAL[i];
+    const uint32_t off = (first + static_cast<uint32_t>(in[j] ? k : 0)) * 4u;
+    cm[j] = load_at(META, off);
+    cc[j] = load_at(COUNT, off);
+    cf[j] = load_at(FIRST, off);
+    ct[j] = load_at(TOTAL, off * 2u);
   }
   uint64_t unvisited[kSlots], cand[kSlots];
   uint64_t any_unvisited = 0ull, any_outcome = 0ull;
@@ -509,8 +526,7 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl PT_ARG
 #else
   // The search runs on the VECTOR unit (the kernel is bound by scalar issue): threshold and step live in
   // vector registers holding the same value in every lane, occupied cells carry the key 2^64 - 1 so that
-  // the ballots need no masking, and only the counting (mode 1) or nothing but the loop branch (mode 2)
-  // is left to the scalar unit.
+  // the ballots need no masking, and only the counting and the loop branch are left to the scalar unit.
   const uint64_t k0 = __builtin_amdgcn_inverse_ballot_w64(empty0) ? key0 : ~0ull;
   const uint64_t k1 = __builtin_amdgcn_inverse_ballot_w64(empty1) ? key1 : ~0ull;
   const uint32_t vz = vector_zero();
@@ -521,19 +537,11 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl PT_ARG
     for (int it = 0; it < kFillKeyBits; ++it) {
       const uint64_t probe = thr | step;
       const uint64_t b0 = __ballot(k0 < probe), b1 = __ballot(k1 < probe);
-#if OSG_THR_MODE == 1
       const int below = __builtin_popcountll(b0) + __builtin_popcountll(b1);
       const uint32_t below_v = static_cast<uint32_t>(below) | vz;
       thr = below_v <= want_v ? probe : thr;
       step >>= 1;
       if (below == want) break;
-#else
-      const uint32_t below_v = vector_popcount(static_cast<uint32_t>(b0), vector_popcount(static_cast<uint32_t>(b0 >> 32),
-                               vector_popcount(static_cast<uint32_t>(b1), vector_popcount(static_cast<uint32_t>(b1 >> 32), vz))));
-      thr = below_v <= want_v ? probe : thr;
-      step >>= 1;
-      if (__ballot(below_v == want_v) != 0ull) break;
-#endif
     }
   }
   const uint64_t sel0 = __ballot(k0 < thr), sel1 = __ballot(k1 < thr);
@@ -855,8 +863,8 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
         }
         const double nt = vp.tot + rv;
         const uint32_t nc = vp.cnt + 1;
-        TOTAL[v] = nt;
-        COUNT[v] = nc;
+        store_at(TOTAL, v * 8u, nt);
+        store_at(COUNT, v * 4u, nc);
         vp.tot = nt;  // (only lane 0's — the root's — is ever read again before it is set anew)
         vp.cnt = nc;
       }

@@ -624,10 +624,12 @@ struct VisitPath {
 };
 
 #ifndef OSG_HEX_WPE
-#define OSG_HEX_WPE 6
+#define OSG_HEX_WPE 8
 #endif
-// The hex fill kernel fits 6 waves per SIMD without spilling; the generic instantiations carry more
-// per-lane state (their playouts run one per lane): 4 waves with a little scratch measured faster than 2-3 without.
+// The hex fill kernel at 8 waves per SIMD (64 vector registers, four of them spilled): measured on config 4
+// 5 / 6 waves 1.00e9, 7 / 8 waves 1.03e9 simulations/s, and 8 192 resident wavefronts hold the 2^13 roots an
+// 8-GPU shard gets in one round (8.27e8 -> 8.50e8).  The generic instantiations carry more per-lane state (their
+// playouts run one per lane): 4 waves with a little scratch measured faster than 2-3 without.
 // kGc: the instantiation that can garbage-collect (mcts.cc:441-482): it also records every node's parent.
 // Kept out of the default instantiation so that the hex kernel's register budget is untouched.
 template <class G, bool kBoard, bool kHexFill, bool kGc>

@@ -200,23 +200,28 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
                    "scaling": "strong",
                    "config": {"workload": "hex(board_size=9) MCTSBot(RandomRolloutEvaluator(1), uct_c=2, 1024 sims) "
                                           f"x 2^16 roots, {count} roots on rank 0, wave-per-root layout"}}
-    # Issue-rate view of the search kernel (it moves ~3.5 KB per simulation: far from a memory roofline): vector and
-    # scalar instructions per simulation from the committed counter profile, issue intervals from
-    # profiles/r02_clock_probe.log (a wave64 vector instruction every 1.03 ns per SIMD; scalar 0.92 ns at best).
+    # Issue-rate view of the search kernel (it moves ~3.5 KB per simulation: far from a memory roofline): vector,
+    # scalar and branch instructions per simulation from the committed counter profile, issue intervals from
+    # profiles/r02_clock_probe.log.
     if rank == 0:
         mix = mcts_instruction_mix()
         if mix:
             simds = torch.cuda.get_device_properties(0).multi_processor_count * 4
             ns_per_sim = dt / (float(done.item()) / world / simds) * 1e9
-            serial = mix["valu"] * 1.03 + mix["salu"] * 0.92
+            # issue intervals per SIMD measured by tools/clock_probe.hip with every SIMD saturated
+            # (profiles/r02_clock_probe.log): a scalar-unit instruction every 1.833 ns, a simple vector
+            # instruction every 1.03 ns (64-bit shifts, multiplies, fp64: about twice that)
+            scalar_ns = (mix["salu"] + mix["branch"]) * 1.833
+            vector_ns = mix["valu"] * 1.03
             out["mcts"]["roofline"] = {
-                "bound": "instruction issue", "valu_per_sim": mix["valu"], "salu_per_sim": mix["salu"],
-                "source": mix["source"], "ns_per_sim_per_simd": ns_per_sim,
-                "issue_ns_if_vector_and_scalar_do_not_overlap": serial,
-                "issue_ns_if_they_overlap_fully": max(mix["valu"] * 1.03, mix["salu"] * 0.92),
-                "frac_of_non_overlapped_issue": serial / ns_per_sim,
-                "note": "the kernel runs at about the SUM of its vector and scalar issue times (DESIGN.md 9b): fewer "
-                        "instructions per simulation is the only lever"}
+                "bound": "scalar-unit instruction issue", "valu_per_sim": mix["valu"], "salu_per_sim": mix["salu"],
+                "branch_per_sim": mix["branch"], "source": mix["source"], "ns_per_sim_per_simd": ns_per_sim,
+                "scalar_issue_ns_per_sim": scalar_ns, "vector_issue_ns_per_sim_at_least": vector_ns,
+                "frac_of_scalar_issue_bound": scalar_ns / ns_per_sim,
+                "note": "the scalar unit issues one instruction (ALU or branch) per 4 cycles per SIMD; with every wave "
+                        "slot busy the search runs at that rate, so fewer scalar instructions per simulation is the "
+                        "lever (round 2: 652 + 83 -> 462 + 93 per simulation, 7.97e8 -> 1.02e9 simulations/s); "
+                        "instruction counts are per simulation of an 8192-root search from the empty board"}
     del roots, res
 
     # ---- config 3: kuhn_poker CFRSolver (full-tree regret / strategy update kernel) ----
@@ -342,7 +347,7 @@ NASH_CONV_THRESHOLDS = (1.0, 0.3, 0.1)
 
 
 def mcts_instruction_mix():
-    """SQ_INSTS_VALU / SQ_INSTS_SALU per simulation of the hex(9) search kernel from the newest committed
+    """SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_INSTS_BRANCH per simulation of the hex(9) search kernel from the newest committed
     profiles/r*_pmc_k_mcts_wave_hex9_8192x1024.csv, or None."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_mcts_wave_hex9_8192x1024.csv")))
@@ -352,11 +357,12 @@ def mcts_instruction_mix():
     with open(files[-1]) as f:
         for ln in f:
             parts = ln.split(",")
-            if len(parts) >= 3 and parts[0] in ("SQ_INSTS_VALU", "SQ_INSTS_SALU"):
+            if len(parts) >= 3 and parts[0] in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH"):
                 vals[parts[0]] = float(parts[2])
-    if len(vals) != 2:
+    if "SQ_INSTS_VALU" not in vals or "SQ_INSTS_SALU" not in vals:
         return None
-    return {"valu": vals["SQ_INSTS_VALU"], "salu": vals["SQ_INSTS_SALU"], "source": os.path.relpath(files[-1], ROOT)}
+    return {"valu": vals["SQ_INSTS_VALU"], "salu": vals["SQ_INSTS_SALU"], "branch": vals.get("SQ_INSTS_BRANCH", 0.0),
+            "source": os.path.relpath(files[-1], ROOT)}
 
 
 def mccfr_time_to_nash_conv(osa, torch, ctx, batch, budget_s):

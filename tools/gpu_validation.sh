@@ -50,9 +50,9 @@ done
 python tools/pmc_traffic.py "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" "$TAG" > "$OUT/pmc_traffic.log" 2>&1
 tail -30 "$OUT/pmc_traffic.log" | tee -a "$OUT/summary.txt"
 
-# instruction mix of the hex(9) search kernel (8192 roots x 1024 simulations), three separate counter passes
+# instruction mix of the hex(9) search kernel (8192 roots x 1024 simulations), four separate counter passes
 P=0
-for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA"; do
+for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_INSTS_BRANCH"; do
   P=$((P+1))
   echo "== rocprofv3 --pmc $C (k_mcts_wave)" | tee -a "$OUT/summary.txt"
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_mcts_$P" -- python tools/probe_mcts_one.py > "$OUT/pmc_mcts_$P.log" 2>&1

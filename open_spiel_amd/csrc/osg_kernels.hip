@@ -12,6 +12,7 @@
 
 #include "osg_internal.h"
 #include "osg_c4_step.h"
+#include "osg_ttt_step.h"
 
 using namespace osg;
 
@@ -167,6 +168,13 @@ k_step_vec(typename G::Params p, const typename G::word_t* __restrict__ src, typ
   mvec mv;
 #pragma unroll
   for (int j = 0; j < V; ++j) {
+    if constexpr (std::is_same<G, Ttt>::value) {
+      // the whole step as straight-line code on the packed word, both players' lines in one pass (osg_ttt_step.h)
+      const uint32_t r = ttt_fused_step(tmp[j], av[j]);
+      mv[j] = static_cast<MaskT>(r & 0xFFFFu);
+      sv[j] = static_cast<uint8_t>(r >> 16);
+      continue;
+    }
     typename G::State s = G::load(p, tmp, V, j);
     const int a = av[j];
     bool illegal = false;

@@ -16,3 +16,15 @@ def test_fused_step_equals_the_array_model(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:]
     assert r.stdout.startswith("ok: 200000 games")
+
+
+def test_tic_tac_toe_fused_step_equals_the_array_model(tmp_path):
+    """osg_ttt_step.h (the body of k_step_vec<Ttt>): random games with illegal / out-of-range / no-op actions and
+    every pair of disjoint 9-bit boards as a status query, against an array model of tic_tac_toe.cc:109-148,215-227."""
+    exe = str(tmp_path / "ttt_step_host_test")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--cuda-host-only", "-x", "hip", "-O2", "-w",
+                           "-I", os.path.join(ROOT, "open_spiel_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "native", "ttt_step_host_test.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert r.stdout.startswith("ok: 200000 games")

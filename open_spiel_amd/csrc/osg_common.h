@@ -84,11 +84,15 @@ OSG_HD uint32_t order_key(uint64_t base, uint64_t parent_path_hash, int action) 
 // The random fill of a hex playout orders the empty cells by a 40-bit key: 32 mixed bits and the cell id
 // (so keys never tie; two cells share their 32 random bits with probability ~8e-7 per playout, and then the
 // lower cell id goes first).  One 32-bit mixer per (root, playout) for the base, one per cell for the key.
-OSG_HD uint64_t fill_base(uint64_t seed, uint64_t root, uint64_t sub) {
-  const uint64_t a = mix64(mix64(seed ^ kFillSalt) ^ (root * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));  // per root
-  return mix32(static_cast<uint32_t>(a) ^ static_cast<uint32_t>(a >> 32) ^ (static_cast<uint32_t>(sub) * 0x9E3779B1u) ^
-               (static_cast<uint32_t>(sub >> 32) * 0x85EBCA6Bu));
+// (in two parts so that a kernel can keep the per-root word and run the per-playout mixer where it likes)
+OSG_HD uint32_t fill_root(uint64_t seed, uint64_t root) {
+  const uint64_t a = mix64(mix64(seed ^ kFillSalt) ^ (root * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));
+  return static_cast<uint32_t>(a) ^ static_cast<uint32_t>(a >> 32);
 }
+OSG_HD uint64_t fill_base_of(uint32_t root_word, uint64_t sub) {
+  return mix32(root_word ^ (static_cast<uint32_t>(sub) * 0x9E3779B1u) ^ (static_cast<uint32_t>(sub >> 32) * 0x85EBCA6Bu));
+}
+OSG_HD uint64_t fill_base(uint64_t seed, uint64_t root, uint64_t sub) { return fill_base_of(fill_root(seed, root), sub); }
 OSG_HD uint64_t fill_key(uint64_t base, int cell) {
   const uint32_t h = mix32(static_cast<uint32_t>(base) ^ (static_cast<uint32_t>(cell + 1) * 0x9E3779B1u));
   return (static_cast<uint64_t>(h) << 8) | static_cast<uint64_t>(cell & 0xFF);

@@ -90,6 +90,9 @@ constexpr int kMaxPath = 160;
 #ifndef OSG_FLOOD_MODE
 #define OSG_FLOOD_MODE 1
 #endif
+#ifndef OSG_HASH_VALU
+#define OSG_HASH_VALU 1
+#endif
 
 OSG_D int lane_id() { return static_cast<int>(threadIdx.x & 63u); }
 template <class T>
@@ -458,17 +461,24 @@ OSG_D bool hexw_last_stone_wins(const HexLane& hl, const HexW& w, int move) {
   if ((((own0 & f0) | (own1 & f1)) == 0ull) | (((own0 & l0) | (own1 & l1)) == 0ull)) return false;
   const uint64_t bit = 1ull << (move & 63);
   const bool hi = move >= 64;
+  // (bookkeeping on the vector unit, as in the playout's flood: every lane keeps an all-ones word per own-colour cell
+  // that has not joined yet; the scalar unit only sees the new frontier of a step)
   uint64_t group0 = hi ? 0ull : bit, group1 = hi ? bit : 0ull;
   uint64_t front0 = group0, front1 = group1;
+  uint32_t avail0 = __builtin_amdgcn_inverse_ballot_w64(own0 & ~group0) ? ~0u : 0u;
+  uint32_t avail1 = __builtin_amdgcn_inverse_ballot_w64(own1 & ~group1) ? ~0u : 0u;
   for (int it = 0; it < 128; ++it) {
-    const bool t0 = ((hl.nb_lo[0] & front0) | (hl.nb_hi[0] & front1)) != 0ull;
-    const bool t1 = ((hl.nb_lo[1] & front0) | (hl.nb_hi[1] & front1)) != 0ull;
-    const uint64_t g0 = __ballot(t0) & own0 & ~group0, g1 = __ballot(t1) & own1 & ~group1;
-    if ((g0 | g1) == 0ull) break;
-    group0 |= g0;
-    group1 |= g1;
-    front0 = g0;
-    front1 = g1;
+    const uint64_t x0 = (hl.nb_lo[0] & front0) | (hl.nb_hi[0] & front1);
+    const uint64_t x1 = (hl.nb_lo[1] & front0) | (hl.nb_hi[1] & front1);
+    const uint32_t j0 = (static_cast<uint32_t>(x0) | static_cast<uint32_t>(x0 >> 32)) & avail0;
+    const uint32_t j1 = (static_cast<uint32_t>(x1) | static_cast<uint32_t>(x1 >> 32)) & avail1;
+    front0 = __ballot(j0 != 0u);
+    front1 = __ballot(j1 != 0u);
+    if ((front0 | front1) == 0ull) break;
+    group0 |= front0;
+    group1 |= front1;
+    avail0 = j0 != 0u ? 0u : avail0;
+    avail1 = j1 != 0u ? 0u : avail1;
   }
   return (((group0 & f0) | (group1 & f1)) != 0ull) & (((group0 & l0) | (group1 & l1)) != 0ull);
 }
@@ -679,6 +689,14 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
   wave_fence();
   uint32_t used = 1;
   int sims_done = 0;
+  // Hash chains whose value is the same in every lane (the path hash behind the sibling order, the playout's
+  // fill base) run on the vector unit: the kernel is bound by scalar issue, and their consumers are per-lane anyway.
+#if OSG_HASH_VALU
+  const uint32_t vz = vector_zero();
+#else
+  const uint32_t vz = 0u;
+#endif
+  const uint32_t fill_word = kHexFill ? fill_root(cfg.seed, gr) : 0u;
   PT_DECL
 
   for (int sim = 0; sim < cfg.max_simulations; ++sim) {
@@ -687,30 +705,17 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
     WState s = root_state;
     uint32_t node = 0;
     int depth = 0;
-    uint64_t ph = path_hash_root();
+    uint32_t ph = static_cast<uint32_t>(path_hash_root()) | vz;  // the same in every lane, kept off the scalar unit
     uint32_t meta = root_meta, first = root_first;
     uint32_t cnt = read_lane(vp.cnt, 0);
     bool term;
     PT_MARK(7);
     for (;;) {
       if constexpr (kHexFill) {
-        // IsTerminal() only where the search needs it (see HexW): a header that says so, or a first visit.
-        if (m_terminal(meta)) {
-          s.meta = (s.meta & 1u) | ((m_code(meta) == 2 ? 1u : 2u) << 1);
-          term = true;
-          break;
-        }
+        // The walk goes on only through nodes that were visited before and are not known to be terminal (one
+        // exit test; what kind of stop it was is sorted out after the loop).
         term = false;
-        if (cnt == 0) {
-          if (depth == 0) {
-            term = hexw_terminal(s);
-          } else if (hexw_last_stone_wins(hl, s, static_cast<int>(m_action(meta)))) {
-            s.meta |= ((s.meta & 1u) ? 1u : 2u) << 1;  // the player who moved last won
-            term = true;
-          }
-          break;
-        }
-        if (depth + 1 >= kPathLimit) break;
+        if (m_terminal(meta) | (cnt == 0) | (depth + 1 >= kPathLimit)) break;
       } else {
         term = w_terminal<G>(p, s);
         if (term || cnt == 0 || depth + 1 >= kPathLimit) break;
@@ -789,7 +794,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
       }
       PT_MARK(2);
       node = first + static_cast<uint32_t>(chosen_k);
-      ph = path_hash_child(ph, action);
+      ph = static_cast<uint32_t>(path_hash_child(ph, action));
       ++depth;
       // (kept ahead of apply on purpose: were a lane-dependent block the last thing in the loop body, its join
       // would be the loop latch, and the compiler would then treat every loop-carried value as lane-varying)
@@ -799,6 +804,20 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
       meta = n_meta;
       cnt = n_cnt;
       first = n_first;
+    }
+    if constexpr (kHexFill) {
+      // IsTerminal() only where the search needs it (see HexW): a header that says so, or a first visit.
+      if (m_terminal(meta)) {
+        s.meta = (s.meta & 1u) | ((m_code(meta) == 2 ? 1u : 2u) << 1);
+        term = true;
+      } else if (cnt == 0) {
+        if (depth == 0) {
+          term = hexw_terminal(s);
+        } else if (hexw_last_stone_wins(hl, s, static_cast<int>(m_action(meta)))) {
+          s.meta |= ((s.meta & 1u) ? 1u : 2u) << 1;  // the player who moved last won
+          term = true;
+        }
+      }
     }
     PT_MARK(0);
     // ---- evaluate (mcts.cc:372-381) ----
@@ -815,7 +834,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
     } else if constexpr (kHexFill) {
       double r0 = 0.0;
       for (int ro = 0; ro < cfg.n_rollouts; ++ro) {
-        const uint64_t fb = fill_base(cfg.seed, gr, static_cast<uint64_t>(sim) * cfg.n_rollouts + ro);
+        const uint64_t fb = fill_base_of(fill_word | vz, static_cast<uint64_t>(sim) * cfg.n_rollouts + ro);
         r0 += hex_fill_winner(s, fb, hl PT_PASS) == 0 ? 1.0 : -1.0;
       }
       returns[0] = r0 / cfg.n_rollouts;

@@ -264,14 +264,23 @@ struct Leduc {
     s.deck &= ~(1u << move);
     return move;  // deck_[move] == move while present
   }
+  static constexpr int kDevicePlayers = 3;  // the device record holds at most 3 players (osg_game_spec.hip)
   OSG_HD static int next_actor(const Params& p, const State& s) {  // NextPlayer, leduc_poker.cc:573-591
+    // (no runtime modulo — an integer division costs ~40 instructions — and a fixed trip count)
     const int P = p.players;
-    int from = (s.cur == kChancePlayer) ? (p.starter + P - 1) % P : s.cur;
-    for (int i = 1; i <= P; ++i) {
-      int q = (from + i) % P;
-      if (!((s.folded >> q) & 1u)) return q;
+    int from = s.cur;
+    if (s.cur == kChancePlayer) from = p.starter == 0 ? P - 1 : p.starter - 1;
+    int found = 0;
+    bool have = false;
+#pragma unroll
+    for (int i = 1; i <= kDevicePlayers; ++i) {
+      int q = from + i;
+      q = q >= P ? q - P : q;
+      const bool ok = i <= P && !have && !((s.folded >> q) & 1u);
+      found = ok ? q : found;
+      have |= ok;
     }
-    return 0;
+    return found;
   }
   OSG_HD static int hand_rank(const Params& p, const State& s, int q) {  // RankHand, leduc_poker.cc:593-626
     int lo = s.pub, hi = priv(s, q);
@@ -285,18 +294,21 @@ struct Leduc {
     return (hi / 2) * n + (lo / 2);
   }
   OSG_HD static void showdown(const Params& p, State& s) {  // ResolveWinner, leduc_poker.cc:628-678
-    if (s.remaining == 1) {
-      for (int q = 0; q < p.players; ++q)
-        if (!((s.folded >> q) & 1u)) { s.nwin = 1; s.winners = 1u << q; return; }
+    const uint32_t alive = ~s.folded & ((1u << p.players) - 1u);
+    if (s.remaining == 1) {  // the one player left: the lowest (only) bit of `alive`
+      if (alive) { s.nwin = 1; s.winners = alive & (0u - alive); }
       return;
     }
     int best = -1;
     s.nwin = 0; s.winners = 0;
-    for (int q = 0; q < p.players; ++q) {
-      if ((s.folded >> q) & 1u) continue;
-      int r = hand_rank(p, s, q);
-      if (r > best) { best = r; s.winners = 1u << q; s.nwin = 1; }
-      else if (r == best) { s.winners |= 1u << q; ++s.nwin; }
+#pragma unroll
+    for (int q = 0; q < kDevicePlayers; ++q) {
+      const bool in = q < p.players && ((alive >> q) & 1u);
+      const int r = in ? hand_rank(p, s, q) : -2;
+      const bool better = r > best, same = in && r == best;
+      s.winners = better ? (1u << q) : (same ? s.winners | (1u << q) : s.winners);
+      s.nwin = better ? 1 : (same ? s.nwin + 1 : s.nwin);
+      best = better ? r : best;
     }
   }
   OSG_HD static void pay(State& s, int q, int amount) {  // Ante, leduc_poker.cc:700-704
@@ -333,27 +345,21 @@ struct Leduc {
       if (a == 0 && s.stakes <= ante(s, s.cur)) a = 1;
       else if (a == 2 && s.raises >= 2) a = 1;
     }
-    if (a == 0) {
-      record(s, 0);
-      s.folded |= 1u << s.cur;
-      --s.remaining;
-      advance(p, s, true);
-    } else if (a == 1) {
-      pay(s, s.cur, s.stakes - ante(s, s.cur));
-      ++s.calls;
-      record(s, 1);
-      advance(p, s, true);
-    } else {
-      int to_call = s.stakes - ante(s, s.cur);
-      if (to_call > 0) pay(s, s.cur, to_call);
-      int bump = s.round == 1 ? 2 : 4;  // leduc_poker.h:65-66
-      s.stakes += bump;
-      pay(s, s.cur, bump);
-      ++s.raises;
-      s.calls = 0;
-      record(s, 2);
-      advance(p, s, false);
-    }
+    // The three actions as selects over the fields they touch, then ONE advance() (fold / call may end the round,
+    // a raise never does): inlining advance() — showdown, next actor — once per action tripled the code.
+    const bool fold = a == 0, call = a == 1, raise = !fold && !call;
+    record(s, fold ? 0 : (call ? 1 : 2));
+    s.folded |= fold ? 1u << s.cur : 0u;
+    s.remaining -= fold ? 1 : 0;
+    const int to_call = s.stakes - ante(s, s.cur);
+    const int bump = s.round == 1 ? 2 : 4;  // leduc_poker.h:65-66
+    // call: the difference to the stakes; raise: call first (if anything is owed), then the raise amount
+    const int paid = call ? to_call : (raise ? (to_call > 0 ? to_call : 0) + bump : 0);
+    pay(s, s.cur, paid);
+    s.stakes += raise ? bump : 0;
+    s.raises += raise ? 1 : 0;
+    s.calls = raise ? 0 : s.calls + (call ? 1 : 0);
+    advance(p, s, !raise);
   }
   OSG_HD static int outcome_code(const Params&, const State&) { return 7; }
   // Returns = money - 100 (leduc_poker.cc:502-514) with money = 100 - ante, plus

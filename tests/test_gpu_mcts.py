@@ -59,6 +59,15 @@ def _oracle_state(og, hist):
     ("tic_tac_toe", 32, 150, 70, True, 4),
     ("tic_tac_toe", 12, 1000, 20, True, 0),   # BASELINE configs[0]: MCTSBot(RandomRolloutEvaluator(20), 1000 sims) from the start
     ("kuhn_poker(players=3)", 48, 120, 1, False, 6),
+    # small hex boards: the tree reaches finished games all the time, so the wave kernel's IsTerminal-at-first-visit
+    # (a flood of the last stone's group, no edge labels on the way down) is exercised on every simulation
+    ("hex(board_size=3)", 32, 400, 1, True, 4),
+    ("hex(board_size=3)", 32, 300, 2, False, 5),
+    ("hex(board_size=2)", 16, 60, 1, True, 2),
+    ("hex(num_cols=4,num_rows=2)", 24, 200, 1, True, 3),
+    # (boards with a single row or column go to the generic instantiation; they are not searched here: with the
+    # reference's `else if` between the two edges black can never win on them, so a filled board is a state that is
+    # not terminal and has no legal action — a random playout never ends, in the reference as well)
 ])
 def test_mcts_replay_parity(oracle, ctx, game, n, sims, n_rollouts, solve, max_stop, layout):
     min_stop = (3 if "players=3" in game else 2) if "poker" in game else 0  # past the private deals

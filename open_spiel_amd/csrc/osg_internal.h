@@ -36,6 +36,20 @@ struct GameSpec {
 };
 
 int set_error(int code, const std::string& msg);
+
+// Random playouts of hex on a one-row or one-column board never end: with the reference's `else if` between a
+// colour's two edges (hex.cc:122-126,146-150) a stone on such a board can only ever carry ONE edge label, so that
+// colour never wins and a filled board is a state that is not terminal and has no legal action.  (The reference's
+// RandomRolloutEvaluator would index an empty LegalActions() there.)  Entry points that play out refuse these
+// boards instead of hanging the device.
+inline int refuse_endless_playouts(const GameSpec& spec, const char* who) {
+  if (spec.desc.game_kind != kHex) return OSG_OK;
+  const int rows = spec.hex_nw == 1 ? spec.hex1.rows : spec.hex_nw == 2 ? spec.hex2.rows : spec.hex_nw == 3 ? spec.hex3.rows : spec.hex4.rows;
+  const int cols = spec.hex_nw == 1 ? spec.hex1.cols : spec.hex_nw == 2 ? spec.hex2.cols : spec.hex_nw == 3 ? spec.hex3.cols : spec.hex4.cols;
+  if (rows >= 2 && cols >= 2) return OSG_OK;
+  return set_error(OSG_ERR_UNSUPPORTED, std::string(who) + ": hex on a board with a single row or column has states that are "
+                   "neither terminal nor have a legal action (one colour can never win): playouts would not end");
+}
 int parse_game(const char* game_string, GameSpec* out);
 
 }  // namespace osg

@@ -1196,6 +1196,7 @@ int osg_rollout(const osg_batch* roots, uint64_t seed, int64_t index_offset, int
   const int P_ = roots->spec.desc.num_players;
   const int64_t n = roots->n;
   if (n_rollouts <= 0) return set_error(OSG_ERR_INVALID, "n_rollouts must be positive");
+  if (int rc = refuse_endless_playouts(roots->spec, "osg_rollout")) return rc;
   // Lanes per root: enough shares to fill the chip (8 waves per SIMD = 2^19 lanes), no more.
 #ifndef OSG_ROLLOUT_LANES_LOG2
 #define OSG_ROLLOUT_LANES_LOG2 19

@@ -263,6 +263,7 @@ extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_i
   const osg_game_desc& d = roots->spec.desc;
   const bool board = d.game_kind <= kHex;
   if (cfg.max_simulations < 1 || cfg.n_rollouts < 1) return set_error(OSG_ERR_INVALID, "max_simulations and n_rollouts must be >= 1");
+  if (int rc = refuse_endless_playouts(roots->spec, "osg_mcts_search")) return rc;
   if (cfg.solve && !board)
     return set_error(OSG_ERR_UNSUPPORTED, "solve=true needs win/draw/loss outcomes (tic_tac_toe, connect_four, hex)");
   int layout = cfg.layout;

@@ -438,6 +438,7 @@ int osg_mcts_tree_create(const osg_batch* roots, const osg_mcts_cfg* cfg_in, int
   if (cfg_in->child_selection_policy != 0 && cfg_in->child_selection_policy != 1)
     return set_error(OSG_ERR_INVALID, "osg_mcts_cfg.child_selection_policy must be 0 (UCT) or 1 (PUCT)");
   if (flags & ~3) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_create: unknown flag");
+  if (int rc = refuse_endless_playouts(roots->spec, "osg_mcts_tree_create")) return rc;
   osg_mcts_tree* t = new osg_mcts_tree;
   t->ctx = ctx;
   t->cfg = *cfg_in;
@@ -577,6 +578,7 @@ int osg_mcts_tree_advance_host(osg_mcts_tree* t, osg_batch* leaf, const double* 
 
 int osg_mcts_tree_rollout_values(osg_mcts_tree* t, const osg_batch* leaf, double* d_value) {
   if (!t || !leaf) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_rollout_values: null argument");
+  if (int rc = refuse_endless_playouts(leaf->spec, "osg_mcts_tree_rollout_values")) return rc;
   if (!d_value) {  // into the tree's own value buffer (the next osg_mcts_tree_advance_host reads it with values_on_device)
     int rc = own_buffers(t);
     if (rc) return rc;

@@ -271,3 +271,17 @@ def test_hex_fill_playout_matches_sequential_random_play(ctx):
     est_fill = reward.sum() / n                      # child total = mean of its r playouts (black's return)
     assert abs(est_fill - est_seq) < 0.015, (est_fill, est_seq)
     assert 0.0 < est_seq < 0.5, "black moves first and gets 13 of 25 cells: a modest edge"
+
+
+def test_one_row_hex_boards_are_refused_instead_of_never_ending(ctx):
+    """hex with a single row or column: the reference's `else if` between a colour's two edges (hex.cc:122-126,
+    146-150) lets one colour never win there, so a filled board is not terminal and has no legal action — a random
+    playout would never end.  The entry points that play out say so instead of hanging the device."""
+    import open_spiel_amd as osa
+    for game in ("hex(num_cols=5,num_rows=1)", "hex(num_cols=1,num_rows=4)"):
+        roots = osa.StateBatch(ctx, game, 4)
+        assert roots.legal_actions_mask().any()  # the rules themselves are served
+        with pytest.raises(osa.OsgError, match="single row or column"):
+            roots.mcts_search(uct_c=2.0, max_simulations=8, n_rollouts=1, seed=1)
+        with pytest.raises(osa.OsgError, match="single row or column"):
+            roots.rollout(seed=1, n_rollouts=2)

@@ -15,6 +15,11 @@ constexpr int kChancePlayer = -1;
 constexpr int kTerminalPlayer = -4;
 constexpr int kMaxPlayers = 10;     // kuhn_poker supports up to 10
 constexpr int kMaskWords = 4;       // 128 actions (hex 11x11 = 121)
+// No game served here lasts longer than 130 plies (hex 11 x 11 with the swap move).  A random playout that has not
+// ended after kMaxPlayoutPlies moves started from a state the rules cannot finish (an uploaded record that is
+// neither terminal nor has a legal action): it is cut off — Returns() of a running game are zeros — instead of
+// spinning on the device for ever.
+constexpr int kMaxPlayoutPlies = 512;
 
 // ---------------------------------------------------------------------------
 // Counter-based RNG.  splitmix64 over a key mixed from (seed, stream, sub); the

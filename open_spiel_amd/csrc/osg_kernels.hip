@@ -708,9 +708,9 @@ k_rollout(typename G::Params p, const typename G::word_t* base, int64_t n, int n
   double acc[kMaxPlayers];
 #pragma unroll
   for (int q = 0; q < kMaxPlayers; ++q) acc[q] = 0.0;
-  int plies = 0;
+  int plies = 0, ply = 0;  // moves of this share so far / of the running playout
   for (;;) {
-    if (G::terminal(p, s)) {
+    if (G::terminal(p, s) || ply >= kMaxPlayoutPlies) {
       double ret[kMaxPlayers];
       G::returns(p, s, ret);
 #pragma unroll
@@ -732,12 +732,14 @@ k_rollout(typename G::Params p, const typename G::word_t* base, int64_t n, int n
       }
       s = G::load(p, base, n, root);
       rng = Rng(seed, static_cast<uint64_t>(index_offset + root), static_cast<uint64_t>(r));
+      ply = 0;
       continue;
     }
     Mask m = G::legal(p, s);
     int a = sample_action<G>(p, s, m, G::current_player(p, s), rng);
     G::apply(p, s, a);
     ++plies;
+    ++ply;
   }
 }
 

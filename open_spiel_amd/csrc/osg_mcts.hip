@@ -66,8 +66,9 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
       if (m_nchild(meta) == 0) {  // expand: children = Prior(state), shuffled (mcts.cc:281-299)
         const Mask legal = G::legal(p, s);
         const int c = legal.count();
-        // slots exhausted (unreachable unless the caller's HBM could not hold max_nodes + slack): evaluate as a leaf
-        if (used + static_cast<uint32_t>(c) > static_cast<uint32_t>(pool.cap)) break;
+        // slots exhausted (unreachable unless the caller's HBM could not hold max_nodes + slack), or a record that is
+        // not terminal and has no legal action (only an uploaded inconsistent one): evaluate as a leaf
+        if (c == 0 || used + static_cast<uint32_t>(c) > static_cast<uint32_t>(pool.cap)) break;
         const uint32_t first = used;
         used += c;
         for (int k = 0; k < c; ++k) {
@@ -126,7 +127,7 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
       for (int ro = 0; ro < cfg.n_rollouts; ++ro) {
         Rng rng(cfg.seed, gr, static_cast<uint64_t>(sim) * cfg.n_rollouts + ro);
         typename G::State w = s;
-        while (!G::terminal(p, w)) {
+        for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
           const Mask m = G::legal(p, w);
           G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
         }

@@ -103,7 +103,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
   // expand `node` (mcts.cc:281-299): one child per prior entry, shuffled
   auto expand = [&](const Mask& legal, int cur, bool from_host) -> bool {
     const int c = legal.count();
-    if (used + static_cast<uint32_t>(c) > static_cast<uint32_t>(pool.cap)) return false;  // slots exhausted (see osg_mcts.hip)
+    if (c == 0 || used + static_cast<uint32_t>(c) > static_cast<uint32_t>(pool.cap)) return false;  // nothing to expand / slots exhausted (see osg_mcts.hip)
     const uint32_t first = used;
     used += c;
     for (int k = 0; k < c; ++k) {
@@ -298,7 +298,7 @@ k_mcts_tree_rollout(typename G::Params p, const typename G::word_t* leaf_words, 
   for (int ro = 0; ro < cfg.n_rollouts; ++ro) {
     Rng rng(cfg.seed, gr, static_cast<uint64_t>(sims[r]) * cfg.n_rollouts + ro);
     typename G::State w = s;
-    while (!G::terminal(p, w)) {
+    for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
       const Mask m = G::legal(p, w);
       G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
     }

@@ -725,8 +725,9 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
       PT_MARK(0);
       if (m_nchild(meta) == 0) {  // expand: one child per Prior() entry, in action order
         const int c = legal.count();
-        // slots exhausted (unreachable unless the caller's HBM could not hold max_nodes + slack): leaf evaluation
-        if (used + static_cast<uint32_t>(c) > static_cast<uint32_t>(cap)) break;
+        // slots exhausted (unreachable unless the caller's HBM could not hold max_nodes + slack), or a record that is
+        // not terminal and has no legal action (only an uploaded inconsistent one): leaf evaluation
+        if (c == 0 || used + static_cast<uint32_t>(c) > static_cast<uint32_t>(cap)) break;
         first = used;
         used += c;
         // Children in action order.  Lane l looks at actions l and l + 64: a legal action's slot is its
@@ -848,7 +849,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
         if (ro < cfg.n_rollouts) {
           Rng rng(cfg.seed, gr, static_cast<uint64_t>(sim) * cfg.n_rollouts + ro);
           typename G::State w = s;
-          while (!G::terminal(p, w)) {
+          for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
             const Mask m = G::legal(p, w);
             G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
           }

@@ -285,3 +285,25 @@ def test_one_row_hex_boards_are_refused_instead_of_never_ending(ctx):
             roots.mcts_search(uct_c=2.0, max_simulations=8, n_rollouts=1, seed=1)
         with pytest.raises(osa.OsgError, match="single row or column"):
             roots.rollout(seed=1, n_rollouts=2)
+
+
+def test_a_playout_from_a_record_the_rules_cannot_finish_is_cut_off(ctx):
+    """An uploaded connect_four record with all 42 cells taken but the result flags cleared is neither terminal nor
+    has a legal column: a random playout from it would spin for ever.  The playout loops stop after
+    kMaxPlayoutPlies moves (Returns() of a running game: zeros), so rollouts and both search layouts come back."""
+    import numpy as np
+    import open_spiel_amd as osa
+    n = 8
+    b = osa.StateBatch(ctx, "connect_four", n)
+    w = b.raw_words()
+    full = sum(0x3F << (7 * c) for c in range(7))          # six cells in each of the seven columns
+    x = sum(1 << (7 * c + r) for c in range(7) for r in range(6) if (r // 2 + c) % 2 == 0)  # some split of them
+    w[0, :] = x                                              # plane 0: x stones, flags byte left at zero
+    w[1, :] = full & ~x
+    b.load_raw_words(w)
+    assert not b.is_terminal().any() and not b.legal_actions_mask().any()
+    total, steps = b.rollout(seed=3, n_rollouts=2, want_steps=True)
+    assert float(total.abs().sum()) == 0.0
+    for layout in (1, 2):
+        res = b.mcts_search(uct_c=2.0, max_simulations=4, n_rollouts=1, seed=1, layout=layout)
+        assert res["root_stats"].shape[0] == n

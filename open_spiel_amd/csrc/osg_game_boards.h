@@ -81,7 +81,16 @@ struct Ttt {
     uint32_t bits = plane == 0 ? ~(s.x | s.o) : (plane == 1 ? s.o : s.x);
     return static_cast<float>((bits >> cell) & 1u);
   }
-  using ObsCursor = GenericObsCursor<Ttt>;
+  // The 27 entries as one bit set: plane 0 empty cells, plane 1 o, plane 2 x.
+  struct ObsCursor {
+    uint32_t bits;
+    int idx;
+    OSG_HD void init(const Params&, const State& s, int, int, int idx0) {
+      idx = idx0;
+      bits = (~(s.x | s.o) & 0x1FFu) | (s.o << 9) | (s.x << 18);
+    }
+    OSG_HD float next(const Params&, const State&, int, int) { return static_cast<float>((bits >> idx++) & 1u); }
+  };
 };
 
 // ===========================================================================

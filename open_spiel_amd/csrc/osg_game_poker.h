@@ -127,7 +127,30 @@ struct Kuhn {
     }
     return static_cast<float>(contribution(p, s, idx));
   }
-  using ObsCursor = GenericObsCursor<Kuhn>;
+  // The tensor walker: every entry but the pot contributions is 0 or 1, so the row is built ONCE as a bit set
+  // (player, private card, the betting pairs) and an entry is a bit test (obs_at re-derives its piece per float).
+  struct ObsCursor {
+    uint64_t bits;  // 6 P - 1 <= 59 entries for P <= 10
+    int idx, nbits;
+    OSG_HD void init(const Params& p, const State& s, int player, int which, int idx0) {
+      const int P = p.players;
+      idx = idx0;
+      bits = 1ull << player;
+      if (len(s) > player) bits |= 1ull << (P + card(s, player));
+      nbits = 2 * P + 1;
+      if (which == 1) {  // betting[2P-1, 2]: action j is "pass" (entry 2j) or "bet" (entry 2j + 1)
+        const uint32_t b = bets(s);
+        const int n = nact(p, s);
+        for (int j = 0; j < n; ++j) bits |= 1ull << (nbits + 2 * j + static_cast<int>((b >> j) & 1u));
+        nbits += 2 * (2 * P - 1);
+      }
+    }
+    OSG_HD float next(const Params& p, const State& s, int, int) {
+      const int k = idx++;
+      if (k < nbits) return static_cast<float>((bits >> k) & 1ull);
+      return static_cast<float>(contribution(p, s, k - nbits));  // observation tensor: pot_contribution[P]
+    }
+  };
 };
 
 // ===========================================================================

@@ -928,7 +928,19 @@ k_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict
   __syncthreads();
 
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < count; j += stride) {
+  for (int64_t j0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j0 < count; j0 += stride) {
+    // Which trajectory a lane takes: within every full group of 64 P consecutive ones, wavefront w of the group takes
+    // those with the same traverser (index = lane * P + w), so that the 64 lanes of a wavefront agree at every node
+    // on whether they walk all actions or sample one — half the divergence of the natural order, same set of
+    // trajectories.  (The last, partial group keeps the natural order.)
+    int64_t j = j0;
+    {
+      const int64_t span = 64 * static_cast<int64_t>(P), group = j0 / span;
+      if ((group + 1) * span <= count) {
+        const int r = static_cast<int>(j0 - group * span);
+        j = group * span + static_cast<int64_t>(r & 63) * P + (r >> 6);
+      }
+    }
     const int64_t g = first + j;
     const int trav = static_cast<int>(g % P);
     const int next = (trav + 1) % P;

@@ -942,8 +942,9 @@ k_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict
       }
     }
     const int64_t g = first + j;
-    const int trav = static_cast<int>(g % P);
-    const int next = (trav + 1) % P;
+    // (a 64-bit modulo by a run-time divisor is ~100 instructions: two players take the parity)
+    const int trav = P == 2 ? static_cast<int>(g & 1) : static_cast<int>(g % P);
+    const int next = trav + 1 == P ? 0 : trav + 1;
     Rng rng(seed, static_cast<uint64_t>(g), 0);
     // backing store of the frames below the top one
     uint32_t s_x[kMaxFrames], s_fa[kMaxFrames];
@@ -968,10 +969,18 @@ k_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict
           if (kind == kChanceNode) {  // SampleAction(ChanceOutcomes(), z) (spiel.cc:372-409)
             double acc = 0.0;
             bool found = false;
-            for (int c = 0; c < nc; ++c) {
-              const double pr = uprob[nodes[fc + c].y >> 24];
-              if (!found && acc <= z && z < acc + pr) { pick = c; found = true; }
-              acc += pr;
+            if (i != 0) {  // all outcomes equally likely: the same scan, the probability read once
+              const double pr = uprob[i - 1];
+              for (int c = 0; c < nc; ++c) {
+                if (!found && acc <= z && z < acc + pr) { pick = c; found = true; }
+                acc += pr;
+              }
+            } else {
+              for (int c = 0; c < nc; ++c) {
+                const double pr = uprob[nodes[fc + c].y >> 24];
+                if (!found && acc <= z && z < acc + pr) { pick = c; found = true; }
+                acc += pr;
+              }
             }
           } else {  // opponent: sample one action from regret matching (:151-154)
             double p[kA];
@@ -1696,6 +1705,16 @@ int build_resident_tree(osg_cfr* s) {
     }
   }
   if (max_frames > kMaxFrames) return OSG_OK;
+  // Chance nodes whose outcomes all have the same probability (every chance node of kuhn and leduc: 1 / cards left)
+  // say so in the field decision nodes use for their infostate id: index of that probability + 1, else 0.  The
+  // traversal then samples without reading the children's records.
+  for (int h = 0; h < s->H; ++h) {
+    if (s->kind[h] != kChanceNode || s->nchild[h] == 0) continue;
+    const uint32_t id0 = static_cast<uint32_t>(rec[s->first_child[h]] >> 56);
+    bool same = true;
+    for (int c = 1; c < s->nchild[h]; ++c) same &= static_cast<uint32_t>(rec[s->first_child[h] + c] >> 56) == id0;
+    if (same) rec[h] |= static_cast<uint64_t>(id0 + 1) << 12;
+  }
   if (uprob.empty()) uprob.push_back(1.0);
   s->n_uret = static_cast<int>(uret.size() / std::max(P, 1));
   s->n_uprob = static_cast<int>(uprob.size());

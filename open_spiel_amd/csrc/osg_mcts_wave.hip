@@ -634,12 +634,13 @@ struct VisitPath {
 };
 
 #ifndef OSG_HEX_WPE
-#define OSG_HEX_WPE 8
+#define OSG_HEX_WPE 7
 #endif
-// The hex fill kernel at 8 waves per SIMD (64 vector registers, four of them spilled): measured on config 4
-// 5 / 6 waves 1.00e9, 7 / 8 waves 1.03e9 simulations/s, and 8 192 resident wavefronts hold the 2^13 roots an
-// 8-GPU shard gets in one round (8.27e8 -> 8.50e8).  The generic instantiations carry more per-lane state (their
-// playouts run one per lane): 4 waves with a little scratch measured faster than 2-3 without.
+// The hex fill kernel at 7 waves per SIMD (73 vector registers: nothing spilled to scratch).  Measured on config 4
+// with the final kernel: 6 waves 1.06e9, 7 waves 1.12e9, 8 waves (64 registers, a few spilled) 1.08e9 simulations/s;
+// the 2^13-root shard of an 8-GPU run 8.7e8 / 8.9e8 / 9.0e8.  One wavefront per workgroup instead of four: the same
+// at 2^16 roots, 5 % less at 2^13.  The generic instantiations carry more per-lane state (their playouts run one per
+// lane): 4 waves with a little scratch measured faster than 2-3 without.
 // kGc: the instantiation that can garbage-collect (mcts.cc:441-482): it also records every node's parent.
 // Kept out of the default instantiation so that the hex kernel's register budget is untouched.
 template <class G, bool kBoard, bool kHexFill, bool kGc>

@@ -586,7 +586,10 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl PT_ARG
   uint32_t avail0 = __builtin_amdgcn_inverse_ballot_w64(blk0 & ~front0) ? ~0u : 0u;
   uint32_t avail1 = __builtin_amdgcn_inverse_ballot_w64(blk1 & ~front1) ? ~0u : 0u;
   if (((front0 & hl.last_row[0]) | (front1 & hl.last_row[1])) != 0ull) return 0;  // a one-row chain
-#pragma unroll 2
+#ifndef OSG_FLOOD_UNROLL
+#define OSG_FLOOD_UNROLL 2
+#endif
+#pragma unroll OSG_FLOOD_UNROLL
   for (int it = 0; it < 128; ++it) {
     const uint64_t x0 = (hl.nb_lo[0] & front0) | (hl.nb_hi[0] & front1);
     const uint64_t x1 = (hl.nb_lo[1] & front0) | (hl.nb_hi[1] & front1);

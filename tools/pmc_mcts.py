@@ -6,7 +6,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir, tag = sys.argv[1], sys.argv[2]
 sims = 8192 * 1024
 tot = {}
-for f in glob.glob(os.path.join(out_dir, "pmc_mcts_*", "**", "*counter_collection.csv"), recursive=True):
+# one file per counter pass: the newest, should a directory hold the files of an earlier pass with the same tag
+files = []
+for d in sorted(glob.glob(os.path.join(out_dir, "pmc_mcts_*"))):
+    fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if fs:
+        files.append(max(fs, key=os.path.getmtime))
+for f in files:
     for r in csv.DictReader(open(f)):
         if "k_mcts_wave" in r["Kernel_Name"]:
             tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])

@@ -220,7 +220,7 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
                 "frac_of_scalar_issue_bound": scalar_ns / ns_per_sim,
                 "note": "the scalar unit issues one instruction (ALU or branch) per 4 cycles per SIMD; with every wave "
                         "slot busy the search runs at that rate, so fewer scalar instructions per simulation is the "
-                        "lever (round 2: 652 + 83 -> 385 + 89 per simulation, 7.97e8 -> 1.09e9 simulations/s; the vector unit is now about as busy); "
+                        "lever (round 2: 652 + 83 -> 387 + 88 per simulation, 7.97e8 -> 1.12e9 simulations/s; the vector unit is now about as busy); "
                         "instruction counts are per simulation of an 8192-root search from the empty board"}
     del roots, res
 

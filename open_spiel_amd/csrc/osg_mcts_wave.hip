@@ -25,8 +25,8 @@
 // What bounds the hex kernel is the ISSUE RATE OF SCALAR-UNIT INSTRUCTIONS (ALU, branches,
 // waits: one per 4 cycles per SIMD), measured with rocprofv3 --pmc SQ_INSTS_SALU /
 // SQ_INSTS_BRANCH / SQ_INSTS_VALU per variant (tools/pmc_variants.sh): 652 + 83 scalar +
-// branch and 533 vector instructions per simulation gave 7.97e8 simulations/s, 385 + 89
-// and 530 give 1.09e9.  Hence the shape of the code below: no lane-dependent control flow
+// branch and 533 vector instructions per simulation gave 7.97e8 simulations/s, 387 + 88
+// and 513 give 1.12e9.  Hence the shape of the code below: no lane-dependent control flow
 // where a clamped index or a select does, bookkeeping that is the same in every lane done
 // by the vector unit when the scalar unit is the busier one (the key-threshold search and
 // the flood of the playout, the visit path), and no per-level state that is not needed

@@ -558,19 +558,29 @@ def main():
 
     legs = None
     if not args.no_legs and rank == 0:
-        csecs, cbytes = copy_ceiling(osa, torch, ctx, n, 1000, 100)
-        legs = {"copy": (csecs, cbytes), "persistent": persistent_leg(osa, torch, ctx, src, rank)}
-        free_b, _total = torch.cuda.mem_get_info()
-        if free_b > 4 * ALGO_BYTES_PER_STEP * DRAM_LEG_STATES:
-            legs["dram"] = dram_leg(osa, torch, ctx, src, actions)
+        try:
+            csecs, cbytes = copy_ceiling(osa, torch, ctx, n, 1000, 100)
+            legs = {"copy": (csecs, cbytes), "persistent": persistent_leg(osa, torch, ctx, src, rank)}
+            free_b, _total = torch.cuda.mem_get_info()
+            if free_b > 4 * ALGO_BYTES_PER_STEP * DRAM_LEG_STATES:
+                legs["dram"] = dram_leg(osa, torch, ctx, src, actions)
+        except Exception as e:  # noqa: BLE001 - the headline is measured already; say what failed and go on
+            print(f"[bench] roofline legs failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            legs = None
     if world > 1:
         dist.barrier()
 
     secondary = None
     if not args.no_secondary:
         del src, dst
-        secondary = secondary_workloads(osa, torch, dist, ctx, rank, world,
-                                        with_cpu=(not args.no_cpu_baseline) and world == 1)
+        # The headline above is measured; whatever happens in the workloads beside it must not cost the line.
+        try:
+            secondary = secondary_workloads(osa, torch, dist, ctx, rank, world,
+                                            with_cpu=(not args.no_cpu_baseline) and world == 1)
+        except Exception as e:  # noqa: BLE001 - reported in the line, never swallowed silently
+            import traceback
+            secondary = {"error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()[-2000:]}
+            print(f"[bench] secondary workloads failed on rank {rank}: {secondary['error']}", file=sys.stderr, flush=True)
 
     if rank == 0:
         traffic, traffic_source, dram_traffic = pmc_traffic()

@@ -199,13 +199,8 @@ k_step_vec(typename G::Params p, const typename G::word_t* __restrict__ src, typ
   *reinterpret_cast<bvec*>(status + i) = sv;
 }
 
-// connect_four fast path of the fused step: TWO consecutive states per thread so
-// that every state access is one 16-byte vector load/store per lane per plane
-// (1 KiB per wave-instruction, the coalescing sweet spot); actions / masks /
-// statuses move as u16.  With the result of the game stored in plane 0's spare
-// byte (C4T::kStored) a step costs ONE line test (the mover's, inside apply) and
-// one multiply for the successor's legal mask; the kernel is then close to the
-// plain-copy time of the same bytes (tools/step_sweep.hip).
+// connect_four, other geometries than 6 x 7 x 4: TWO consecutive states per thread so that every state access is
+// one 16-byte vector load/store per lane per plane; actions / masks / statuses move as u16.
 #ifndef OSG_C4STEP_BLOCK
 #define OSG_C4STEP_BLOCK 128
 #endif
@@ -217,16 +212,6 @@ k_step_c4x2(typename G::Params p, const uint64_t* __restrict__ src, uint64_t* __
   const int64_t pair = static_cast<int64_t>(blockIdx.x) * kC4StepBlock + threadIdx.x;
   const int64_t i = pair * 2;
   if (i >= n) return;
-  // The eight wavefronts of a SIMD receive their loads at about the same time and, served round-robin, would
-  // also finish — and store — at about the same time.  Four issue priorities by workgroup stagger them, so the
-  // stores of the first overlap the arithmetic of the last (measured: 6.73 -> 6.63 us at 2^20 states,
-  // 103.7 -> 101.0 us at 2^24).
-  {
-    const unsigned pr = blockIdx.x & 3u;
-    if (pr == 1) __builtin_amdgcn_s_setprio(1);
-    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-    else if (pr == 3) __builtin_amdgcn_s_setprio(3);
-  }
   const ulonglong2 xs = *reinterpret_cast<const ulonglong2*>(src + i);
   const ulonglong2 os = *reinterpret_cast<const ulonglong2*>(src + n + i);
   const uint32_t a2 = *reinterpret_cast<const uint16_t*>(actions + i);
@@ -234,14 +219,6 @@ k_step_c4x2(typename G::Params p, const uint64_t* __restrict__ src, uint64_t* __
   uint32_t m2 = 0, s2 = 0;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    if constexpr (std::is_same<G, C4Std>::value) {
-      // 6 x 7 board, result stored in plane 0's top byte: the whole step as straight-line selects
-      // (osg_c4_step.h), so the two states of a lane interleave freely (no exec-mask branches).
-      const uint32_t r = c4_fused_step(x[j], o[j], (a2 >> (8 * j)) & 0xFFu);
-      m2 |= (r & 0xFFu) << (8 * j);
-      s2 |= (r >> 8) << (8 * j);
-      continue;
-    }
     typename G::State s = G::unpack(x[j], o[j]);
     const int a = (a2 >> (8 * j)) & 0xFF;
     bool term = G::terminal(p, s);
@@ -265,6 +242,27 @@ k_step_c4x2(typename G::Params p, const uint64_t* __restrict__ src, uint64_t* __
   *reinterpret_cast<ulonglong2*>(dst + n + i) = make_ulonglong2(o[0], o[1]);
   *reinterpret_cast<uint16_t*>(mask_out + i) = static_cast<uint16_t>(m2);
   *reinterpret_cast<uint16_t*>(status + i) = static_cast<uint16_t>(s2);
+}
+
+// THE HEADLINE KERNEL: the fused step of the standard connect_four board (6 x 7, four in a row), one state per
+// thread, workgroups of 128.  The step itself is c4_fused_step (osg_c4_step.h: straight-line selects on the two
+// packed planes, ONE line test — the mover's —, the successor's legal mask gathered by two 24-bit multiplies; the
+// result of the game lives in plane 0's spare byte).  2^20 states are 16 384 wavefronts, TWO rounds of the chip's
+// 8 192 wave slots: the second round's loads overlap the first round's stores, which measured faster than two
+// states per thread with 16-byte accesses in one round (6.18-6.30 vs 6.48-6.67 us per launch at 2^20 states in the
+// same runs, 97.8-99.7 vs 101.8-103.6 us at 2^24; workgroups of 64 / 256 / 1024: 6.73 / 6.17-6.35 / 6.16-6.19 us at
+// 2^20 and 107.7 / 99.6-102.3 / 105.0-105.8 us at 2^24).  Any batch size, no alignment requirement on the side arrays.
+__global__ void __launch_bounds__(kC4StepBlock)
+k_step_c4std(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, int64_t n, const uint8_t* __restrict__ actions,
+             uint8_t* __restrict__ mask_out, uint8_t* __restrict__ status) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kC4StepBlock + threadIdx.x;
+  if (i >= n) return;
+  uint64_t x = src[i], o = src[n + i];
+  const uint32_t r = c4_fused_step(x, o, actions[i]);
+  dst[i] = x;
+  dst[n + i] = o;
+  mask_out[i] = static_cast<uint8_t>(r);
+  status[i] = static_cast<uint8_t>(r >> 8);
 }
 
 // Observation / information-state tensors: write-bound ([n, size] fp32, zero-filled
@@ -1049,19 +1047,20 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
   const int cmb = src->spec.desc.compact_mask_bytes;
   const int W = src->spec.desc.mask_words;
   const int64_t n = src->n;
+  if (src->spec.desc.game_kind == kC4 && src->spec.c4_std) {  // the headline kernel: any n, any alignment
+    k_step_c4std<<<dim3(static_cast<unsigned>((n + kC4StepBlock - 1) / kC4StepBlock)), dim3(kC4StepBlock), 0, ctx->stream>>>(
+        static_cast<const uint64_t*>(src->d_words), static_cast<uint64_t*>(dst->d_words), n, d_actions,
+        static_cast<uint8_t*>(d_mask), d_status);
+    OSG_HIP(hipGetLastError());
+    return OSG_OK;
+  }
   const bool aligned2 = ((reinterpret_cast<uintptr_t>(d_actions) | reinterpret_cast<uintptr_t>(d_mask) |
                           reinterpret_cast<uintptr_t>(d_status)) & 1u) == 0;
   if (src->spec.desc.game_kind == kC4 && (n & 1) == 0 && aligned2) {
     const int64_t pairs = n / 2;
-    if (src->spec.c4_std) {
-      k_step_c4x2<C4Std><<<dim3(static_cast<unsigned>((pairs + kC4StepBlock - 1) / kC4StepBlock)), dim3(kC4StepBlock), 0, ctx->stream>>>(
-          src->spec.c4, static_cast<const uint64_t*>(src->d_words), static_cast<uint64_t*>(dst->d_words), n, d_actions,
-          static_cast<uint8_t*>(d_mask), d_status);
-    } else {
-      k_step_c4x2<C4><<<dim3(static_cast<unsigned>((pairs + kC4StepBlock - 1) / kC4StepBlock)), dim3(kC4StepBlock), 0, ctx->stream>>>(
-          src->spec.c4, static_cast<const uint64_t*>(src->d_words), static_cast<uint64_t*>(dst->d_words), n, d_actions,
-          static_cast<uint8_t*>(d_mask), d_status);
-    }
+    k_step_c4x2<C4><<<dim3(static_cast<unsigned>((pairs + kC4StepBlock - 1) / kC4StepBlock)), dim3(kC4StepBlock), 0, ctx->stream>>>(
+        src->spec.c4, static_cast<const uint64_t*>(src->d_words), static_cast<uint64_t*>(dst->d_words), n, d_actions,
+        static_cast<uint8_t*>(d_mask), d_status);
     OSG_HIP(hipGetLastError());
     return OSG_OK;
   }

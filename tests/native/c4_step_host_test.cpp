@@ -1,4 +1,4 @@
-// Host-side check of osg_c4_step.h (the body of the headline kernel k_step_c4x2) against a plain
+// Host-side check of osg_c4_step.h (the body of the headline kernel k_step_c4std) against a plain
 // array model of connect_four written from the rules as the reference states them
 // (open_spiel/games/connect_four/connect_four.cc:130-209: a stone drops to the lowest empty row;
 // the mover wins with four in a row in any of the four directions; a full board is a draw;

@@ -80,9 +80,10 @@ def test_step_by_step_parity(oracle, ctx, game):
 @pytest.mark.parametrize("n", [4096, 4097, 4098])
 def test_fused_step_parity(oracle, ctx, game, n):
     """The fused kernel (legality + apply + status + successor mask), out of place.  4096 states take the
-    vectorised kernels (connect_four: two states per thread; tic_tac_toe four, kuhn / leduc two states per thread
-    with 16-byte plane accesses), 4097 the one-state-per-thread kernel, 4098 the two-state kernels but not
-    tic_tac_toe's four-state one."""
+    vectorised kernels (tic_tac_toe four, kuhn / leduc and the non-standard connect_four boards two states per
+    thread with 16-byte plane accesses), 4097 the one-state-per-thread kernels, 4098 the two-state kernels but not
+    tic_tac_toe's four-state one; the standard connect_four board takes its own one-state-per-thread kernel
+    (k_step_c4std, the headline) at every size."""
     import torch
     import open_spiel_amd as osa
     og = oracle.Game(game)

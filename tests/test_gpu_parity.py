@@ -76,7 +76,8 @@ def test_step_by_step_parity(oracle, ctx, game):
 
 
 @pytest.mark.parametrize("game", ["tic_tac_toe", "connect_four", "hex(board_size=9)", "kuhn_poker", "leduc_poker",
-                                  "hex(board_size=4,swap=True)", "leduc_poker(players=3)"])
+                                  "hex(board_size=4,swap=True)", "leduc_poker(players=3)",
+                                  "connect_four(rows=5,columns=6,x_in_row=3)"])
 @pytest.mark.parametrize("n", [4096, 4097, 4098])
 def test_fused_step_parity(oracle, ctx, game, n):
     """The fused kernel (legality + apply + status + successor mask), out of place.  4096 states take the

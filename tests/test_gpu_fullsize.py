@@ -302,3 +302,30 @@ def test_rollout_sums_do_not_depend_on_how_rollouts_are_shared_out(ctx):
         t1, s1 = one.rollout(seed, r, index_offset=i, want_steps=True)
         assert t1.cpu().numpy()[0].tolist() == total[i].tolist(), i
         assert int(s1.cpu().numpy()[0]) == int(steps[i]), i
+
+
+@pytest.mark.parametrize("game,depth", [("leduc_poker", 5), ("leduc_poker(players=3)", 6), ("kuhn_poker", 3),
+                                        ("tic_tac_toe", 4), ("connect_four(rows=5,columns=6,x_in_row=3)", 12)])
+def test_fused_step_kernels_agree_at_2pow22_states(ctx, game, depth):
+    """Which fused-step kernel a batch takes depends on its size and shape (several states per thread with 16-byte
+    plane accesses for even batches — leduc_poker only from 2^22 states on — one state per thread otherwise).  The
+    same 2^22 positions stepped as an even batch and as the first 2^22 states of an odd one must give the same
+    successor records, masks and status bytes, bit for bit (the kernels themselves are checked against the oracle
+    at small sizes in test_gpu_parity.py)."""
+    import torch
+    import open_spiel_amd as osa
+    n = 1 << 22
+    odd = osa.StateBatch(ctx, game, n + 1)
+    odd.random_steps(11, depth)
+    even = odd.gather(torch.arange(n, device="cuda"))
+    lm = odd.legal_actions_mask()
+    acts = torch.where(lm.any(1), (lm.to(torch.float32) * torch.rand(lm.shape, device="cuda")).argmax(1),
+                       torch.full((n + 1,), 255, device="cuda")).to(torch.uint8)
+    acts[::97] = 250  # some illegal ones
+    m_odd, s_odd = odd.step(acts)
+    m_even, s_even = even.step(acts[:n].contiguous())
+    assert torch.equal(m_even, m_odd[:n])
+    assert torch.equal(s_even, s_odd[:n])
+    w_odd, w_even = odd.raw_words(), even.raw_words()
+    assert (w_even == w_odd[:, :n]).all()
+    assert int(((s_even & 0x40) != 0).sum()) >= n // 97  # the illegal ones were refused

@@ -195,12 +195,19 @@ int osg_env_step(osg_batch* b, const int32_t* d_actions, uint8_t* d_should_reset
  * for every root: n_rollouts uniform-random playouts to the end of the game.
  * sum_returns [n, P] fp64 = SUM over rollouts of Returns() (divide by n_rollouts
  * for Evaluate's mean); steps[n] i32 (may be NULL) = plies played.  Rollout r of
- * root i draws from the counter stream (seed, index_offset + i, r). */
+ * root i draws from the counter stream (seed, index_offset + i, r).
+ * A playout is cut off after 512 moves (no game served here lasts longer than 130): a record the
+ * rules cannot finish — uploaded, neither terminal nor with a legal action — contributes Returns()
+ * of a running game (zeros) instead of spinning on the device.  hex boards with a single row or
+ * column are refused (OSG_ERR_UNSUPPORTED): with the reference's `else if` between a colour's two
+ * edges (hex.cc:122-126,146-150) one colour can never win there, so playouts would not end. */
 int osg_rollout(const osg_batch* roots, uint64_t seed, int64_t index_offset, int n_rollouts,
                 double* sum_returns, int32_t* steps, int on_host);
 
 /* algorithms::MCTSBot (open_spiel/algorithms/mcts.{h,cc}) for every root of the
- * batch, one wavefront per root.  Fields as MCTSBot's constructor (mcts.h:161-169). */
+ * batch, one wavefront per root.  Fields as MCTSBot's constructor (mcts.h:161-169).
+ * The same two guards as osg_rollout apply (playout length, one-row / one-column hex boards);
+ * a node that is not terminal and has no legal action is evaluated as a leaf, never expanded. */
 typedef struct {
   double uct_c;
   int32_t max_simulations;

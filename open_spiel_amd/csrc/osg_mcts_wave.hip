@@ -612,7 +612,10 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl PT_ARG
 // tree level, no memory and nothing for the scalar unit; the backup has lane d own path node d anyway); entries
 // 64 ... kMaxPath - 1 — reachable only in games longer than 64 plies — live in LDS.  Entry 0 is the root, whose
 // statistics persist in lane 0 from one simulation to the next.
-constexpr int kPathRegs = 64;
+#ifndef OSG_PATH_REGS
+#define OSG_PATH_REGS 64  // (a test build with 2 sends every deeper entry through the LDS part)
+#endif
+constexpr int kPathRegs = OSG_PATH_REGS;
 struct VisitPath {
   uint32_t node, cnt;
   double tot;
@@ -879,7 +882,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
           if (pl == kChancePlayer) pl = up < 0 ? 0 : static_cast<int>(ue >> 28) - 1;
         }
       }
-      if (lane <= depth) {
+      if (lane < kPathRegs && lane <= depth) {
         const uint32_t v = e & 0x0FFFFFFFu;
         double rv = returns[0];
         if constexpr (kBoard) {  // two players, no chance nodes

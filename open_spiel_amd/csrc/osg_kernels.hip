@@ -34,7 +34,18 @@ __global__ void __launch_bounds__(kBlock) k_init(typename G::Params p, typename 
 // 16 bytes per lane, 4 KiB per workgroup: the plain-copy ceiling (osg_copy_bytes).
 __global__ void __launch_bounds__(256) k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+#ifdef OSG_COPY_PLAIN
   if (i < n16) dst[i] = src[i];
+#else
+  // non-temporal stores, like the kernels it is the ceiling of (a copy with plain stores is slower: §9)
+  if (i < n16) {
+    const uint4 v = src[i];
+    __builtin_nontemporal_store(v.x, &dst[i].x);
+    __builtin_nontemporal_store(v.y, &dst[i].y);
+    __builtin_nontemporal_store(v.z, &dst[i].z);
+    __builtin_nontemporal_store(v.w, &dst[i].w);
+  }
+#endif
 }
 
 template <class G>
@@ -259,10 +270,13 @@ k_step_c4std(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, int64
   if (i >= n) return;
   uint64_t x = src[i], o = src[n + i];
   const uint32_t r = c4_fused_step(x, o, actions[i]);
-  dst[i] = x;
-  dst[n + i] = o;
-  mask_out[i] = static_cast<uint8_t>(r);
-  status[i] = static_cast<uint8_t>(r >> 8);
+  // Non-temporal stores: the successor records are not read again by this launch, and written around the L2 they
+  // neither displace the inputs still to be read nor wait for a write-back at the end of the kernel (measured:
+  // 6.1-6.3 -> 5.0-5.1 us per launch at 2^20 states, 97-99 -> 89-91 us at 2^24; non-temporal LOADS as well: 6.8 us).
+  __builtin_nontemporal_store(x, dst + i);
+  __builtin_nontemporal_store(o, dst + n + i);
+  __builtin_nontemporal_store(static_cast<uint8_t>(r), mask_out + i);
+  __builtin_nontemporal_store(static_cast<uint8_t>(r >> 8), status + i);
 }
 
 // Observation / information-state tensors: write-bound ([n, size] fp32, zero-filled
@@ -272,6 +286,29 @@ k_step_c4std(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, int64
 // straddle two states and the kernel has no divergent reloads.  Consecutive lanes write
 // consecutive addresses (1 KiB per wave-instruction).
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));  // rows are only 4-byte aligned
+// Tensor rows are written once and not read again by the kernel: non-temporal stores (see k_step_c4std) — where they
+// measured faster (2^24 states, fraction of 8 TB/s, plain -> non-temporal): leduc [n, 16] 0.76 -> 0.89, [n, 30] 0.74 ->
+// 0.83, kuhn [n, 7] 0.60 -> 0.67, [n, 11] 0.69 -> 0.76, hex(9) 0.67 -> 0.71; the connect_four planes and the tic_tac_toe
+// rows keep plain stores (0.74 -> 0.72 and 0.75 -> 0.69 with non-temporal ones).
+OSG_D void store_row4(float4u* dst, const float4u& v) {  // 4-byte aligned rows
+#ifdef OSG_OBS_PLAIN
+  *dst = v;
+#else
+  __builtin_nontemporal_store(v, dst);
+#endif
+}
+template <bool kNt = true>
+OSG_D void store_row4(float4* dst, const float4& v) {  // 16-byte aligned spans
+  if constexpr (!kNt) { *dst = v; return; }
+#ifdef OSG_OBS_PLAIN
+  *dst = v;
+#else
+  __builtin_nontemporal_store(v.x, &dst->x);
+  __builtin_nontemporal_store(v.y, &dst->y);
+  __builtin_nontemporal_store(v.z, &dst->z);
+  __builtin_nontemporal_store(v.w, &dst->w);
+#endif
+}
 template <class G, int F>  // F = floats per lane (a multiple of 4): 4 for short rows, 16 for long ones
 __global__ void __launch_bounds__(kBlock)
 k_observation(typename G::Params p, const typename G::word_t* base, int64_t n, int size, int seg_len, int chunks_per_seg,
@@ -327,7 +364,7 @@ k_observation(typename G::Params p, const typename G::word_t* base, int64_t n, i
     if (!live) return;
     if (count >= 4) {
       float4u w = {q[0].x, q[0].y, q[0].z, q[0].w};
-      *reinterpret_cast<float4u*>(dst) = w;
+      store_row4(reinterpret_cast<float4u*>(dst), w);
     } else {
       dst[0] = q[0].x;
       if (count > 1) dst[1] = q[0].y;
@@ -354,7 +391,7 @@ k_observation(typename G::Params p, const typename G::word_t* base, int64_t n, i
     const int left = s_count[wave0 + src_lane] - 4 * part;
     if (left >= 4) {
       float4u w = {w4.x, w4.y, w4.z, w4.w};
-      *reinterpret_cast<float4u*>(d) = w;
+      store_row4(reinterpret_cast<float4u*>(d), w);
     } else if (left > 0) {
       d[0] = w4.x;
       if (left > 1) d[1] = w4.y;
@@ -408,7 +445,7 @@ k_observation_rows(typename G::Params p, const typename G::word_t* base, int64_t
       if (++k == size) { k = 0; ++r; }
     }
     if (j + 4 <= total) {
-      *reinterpret_cast<float4*>(dst + j) = make_float4(v[0], v[1], v[2], v[3]);
+      store_row4<!std::is_same<G, Ttt>::value>(reinterpret_cast<float4*>(dst + j), make_float4(v[0], v[1], v[2], v[3]));
     } else {
       for (int e = 0; e < 4 && j + e < total; ++e) dst[j + e] = v[e];
     }
@@ -448,7 +485,7 @@ k_observation_c4std(C4Params p, const uint64_t* __restrict__ base, int64_t n, in
   float* dst = out + row * 7;
   float4u lo = {v[0], v[1], v[2], v[3]};
   float3u hi = {v[4], v[5], v[6]};
-  *reinterpret_cast<float4u*>(dst) = lo;
+  store_row4(reinterpret_cast<float4u*>(dst), lo);
   *reinterpret_cast<float3u*>(dst + 4) = hi;
 }
 
@@ -509,7 +546,7 @@ k_observation_c4std_planes(C4Params p, const uint64_t* __restrict__ base, int64_
   for (int j = 0; j < 11; ++j) {
     const int piece = lane + 64 * j;  // 672 float4 pieces
     if (piece * 4 + 4 <= valid) {
-      reinterpret_cast<float4*>(gdst)[piece] = w4[piece];
+      store_row4<false>(reinterpret_cast<float4*>(gdst) + piece, w4[piece]);
     } else {
       for (int k = piece * 4; k < valid && k < piece * 4 + 4; ++k) gdst[k] = w1[k];
     }
@@ -562,7 +599,7 @@ k_observation_hex_planes(typename G::Params p, const typename G::word_t* base, i
   const float4* w4 = reinterpret_cast<const float4*>(w);
   for (int piece = lane; piece * 4 < valid; piece += 64) {
     if (piece * 4 + 4 <= valid) {
-      reinterpret_cast<float4*>(gdst)[piece] = w4[piece];
+      store_row4(reinterpret_cast<float4*>(gdst) + piece, w4[piece]);
     } else {
       for (int k = piece * 4; k < valid; ++k) gdst[k] = w[k];
     }

@@ -420,7 +420,7 @@ def timed_launches(torch, launch, launches, warmup):
 
 
 def copy_ceiling(osa, torch, ctx, n, launches, warmup):
-    """Plain 16-byte-per-lane copy of the bytes one launch over n states moves (35 B per state: half read,
+    """16-byte-per-lane copy (non-temporal stores) of the bytes one launch over n states moves (35 B per state: half read,
     half written) on the same stream: seconds per copy."""
     from open_spiel_amd._abi import check, lib
     half = (ALGO_BYTES_PER_STEP * n // 2) // 16 * 16
@@ -452,7 +452,7 @@ def dram_leg(osa, torch, ctx, src, actions):
             "avg_launch_us": secs * 1e6, "launches": 100, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "copy_ceiling": {"gbs": copy_gbs, "us": csecs * 1e6, "bytes": cbytes,
-                             "what": "osg_copy_bytes: plain uint4 copy of the same number of bytes, same stream"},
+                             "what": "osg_copy_bytes: uint4 copy (non-temporal stores) of the same number of bytes, same stream"},
             "frac_of_copy_ceiling": achieved / copy_gbs}
 
 
@@ -598,7 +598,7 @@ def main():
         if legs is not None:
             csecs, cbytes = legs["copy"]
             roofline["copy_ceiling"] = {"gbs": cbytes / csecs / 1e9, "us": csecs * 1e6, "bytes": cbytes,
-                                        "what": "osg_copy_bytes: plain uint4 copy of the same number of bytes, same stream"}
+                                        "what": "osg_copy_bytes: uint4 copy (non-temporal stores) of the same number of bytes, same stream"}
             roofline["frac_of_copy_ceiling"] = achieved / (cbytes / csecs / 1e9)
             if "dram" in legs:
                 roofline["dram_leg"] = legs["dram"]

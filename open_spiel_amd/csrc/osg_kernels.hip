@@ -289,8 +289,8 @@ k_step_c4std(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, int64
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));  // rows are only 4-byte aligned
 // Tensor rows are written once and not read again by the kernel: non-temporal stores (see k_step_c4std) — where they
 // measured faster (2^24 states, fraction of 8 TB/s, plain -> non-temporal): leduc [n, 16] 0.76 -> 0.89, [n, 30] 0.74 ->
-// 0.83, kuhn [n, 7] 0.60 -> 0.67, [n, 11] 0.69 -> 0.76, hex(9) 0.67 -> 0.71; the connect_four planes and the tic_tac_toe
-// rows keep plain stores (0.74 -> 0.72 and 0.75 -> 0.69 with non-temporal ones).
+// 0.83, kuhn [n, 7] 0.60 -> 0.67, [n, 11] 0.69 -> 0.76, hex(9) 0.67 -> 0.71; the tic_tac_toe rows keep plain stores
+// (0.77 -> 0.70 with non-temporal ones), the connect_four planes take them from 2^22 states on (see the kernel).
 OSG_D void store_row4(float4u* dst, const float4u& v) {  // 4-byte aligned rows
 #ifdef OSG_OBS_PLAIN
   *dst = v;
@@ -499,6 +499,9 @@ k_observation_c4std(C4Params p, const uint64_t* __restrict__ base, int64_t n, in
 #define OSG_C4OBS_BLOCK 128
 #endif
 constexpr int kC4ObsBlock = OSG_C4OBS_BLOCK;
+// kNt: non-temporal stores — slower while the tensor is small (2^20 states: 95.7 vs 90.8 us), faster once it is
+// gigabytes (2^24 states, 8.5 GB: 1 395 vs 1 485 us); the launcher picks by size.
+template <bool kNt>
 __global__ void __launch_bounds__(kC4ObsBlock)
 k_observation_c4std_planes(C4Params p, const uint64_t* __restrict__ base, int64_t n, int player, float* __restrict__ out) {
   __shared__ float2 s_stage[kC4ObsBlock * 21];
@@ -547,7 +550,7 @@ k_observation_c4std_planes(C4Params p, const uint64_t* __restrict__ base, int64_
   for (int j = 0; j < 11; ++j) {
     const int piece = lane + 64 * j;  // 672 float4 pieces
     if (piece * 4 + 4 <= valid) {
-      store_row4<false>(reinterpret_cast<float4*>(gdst) + piece, w4[piece]);
+      store_row4<kNt>(reinterpret_cast<float4*>(gdst) + piece, w4[piece]);
     } else {
       for (int k = piece * 4; k < valid && k < piece * 4 + 4; ++k) gdst[k] = w1[k];
     }
@@ -1163,9 +1166,13 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
     d_out = static_cast<float*>(scratch);
   }
   if (b->spec.desc.game_kind == kC4 && b->spec.c4_std) {
-    if ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0)
-      k_observation_c4std_planes<<<dim3(static_cast<unsigned>((b->n * 3 + kC4ObsBlock - 1) / kC4ObsBlock)),
-                                   dim3(kC4ObsBlock), 0, ctx->stream>>>(
+    if ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0 && b->n >= (int64_t{1} << 22))
+      k_observation_c4std_planes<true><<<dim3(static_cast<unsigned>((b->n * 3 + kC4ObsBlock - 1) / kC4ObsBlock)),
+                                         dim3(kC4ObsBlock), 0, ctx->stream>>>(
+          b->spec.c4, static_cast<const uint64_t*>(b->d_words), b->n, player, d_out);
+    else if ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0)
+      k_observation_c4std_planes<false><<<dim3(static_cast<unsigned>((b->n * 3 + kC4ObsBlock - 1) / kC4ObsBlock)),
+                                          dim3(kC4ObsBlock), 0, ctx->stream>>>(
           b->spec.c4, static_cast<const uint64_t*>(b->d_words), b->n, player, d_out);
     else
       k_observation_c4std<<<dim3(grid_for(b->n * 18)), dim3(kBlock), 0, ctx->stream>>>(

@@ -590,7 +590,7 @@ def main():
         roofline = {"bound": "infinity_cache" if ALGO_BYTES_PER_STEP * n < (200 << 20) else "hbm",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                    "kernel": "k_step_c4std", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * n,
+                    "kernel": "k_step_c4std2", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * n,
                     "avg_launch_us": avg_kernel_s * 1e6, "launches_timed": launches,
                     "peak_note": "peak = HBM3E spec 8 TB/s (the denominator BASELINE.json names); one launch moves "
                                  f"{ALGO_BYTES_PER_STEP * n / 1e6:.1f} MB, which stays resident in the 256 MiB Infinity "

@@ -5,7 +5,7 @@
 // (connect_four.cc:147-156) and the status byte — written against the 32-bit
 // halves the vector ALU works on.  Host + device so that a CPU test can drive
 // exactly this code over random games (tests/test_c4_step_host.py); the kernel
-// is k_step_c4std in osg_kernels.hip.
+// is k_step_c4std2 / k_step_c4std in osg_kernels.hip.
 //
 // Layout (osg_game_boards.h C4T<6,7,4>): bit = col*7 + row, row 6 of every
 // column an always-empty sentinel; plane 0's top byte = result flags (bit 0

@@ -83,8 +83,8 @@ def test_fused_step_parity(oracle, ctx, game, n):
     """The fused kernel (legality + apply + status + successor mask), out of place.  4096 states take the
     vectorised kernels (tic_tac_toe four, kuhn / leduc and the non-standard connect_four boards two states per
     thread with 16-byte plane accesses), 4097 the one-state-per-thread kernels, 4098 the two-state kernels but not
-    tic_tac_toe's four-state one; the standard connect_four board takes its own one-state-per-thread kernel
-    (k_step_c4std, the headline) at every size."""
+    tic_tac_toe's four-state one; the standard connect_four board takes its own kernels (the headline: k_step_c4std2
+    for even batches, k_step_c4std for odd ones)."""
     import torch
     import open_spiel_amd as osa
     og = oracle.Game(game)

@@ -18,11 +18,13 @@ for d, counter in zip(sys.argv[1:3], ("FETCH_SIZE", "WRITE_SIZE")):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                by_grid.setdefault(int(r["Grid_Size"]), {}).setdefault(counter, []).append(float(r["Counter_Value"]))
+                # states per launch: k_step_c4std2 takes two per thread, k_step_c4std one
+                states = int(r["Grid_Size"]) * (2 if "k_step_c4std2" in r["Kernel_Name"] else 1)
+                by_grid.setdefault(states, {}).setdefault(counter, []).append(float(r["Counter_Value"]))
 res = None
 rows = []
-for grid in sorted(by_grid):
-    states = grid  # one state per thread
+for states in sorted(by_grid):
+    grid = states
     stat = {}
     for counter, vals in by_grid[grid].items():
         vals = vals[len(vals) // 10:]  # drop the warm-up launches
@@ -32,7 +34,7 @@ for grid in sorted(by_grid):
         continue
     fetch = stat["FETCH_SIZE"][1] * 1024 * 2
     write = stat["WRITE_SIZE"][1] * 1024
-    rec = {"kernel": "k_step_c4std", "states": states, "bytes_per_launch": fetch + write,
+    rec = {"kernel": "k_step_c4std2 (k_step_c4std for odd batches)", "states": states, "bytes_per_launch": fetch + write,
            "fetch_bytes": fetch, "write_bytes": write,
            "raw": {"FETCH_SIZE_KB": stat["FETCH_SIZE"][1], "WRITE_SIZE_KB": stat["WRITE_SIZE"][1]},
            "algorithmic_bytes_per_launch": 35 * states,

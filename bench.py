@@ -24,6 +24,12 @@ Beside the headline the line carries, all measured live in this process:
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with no WORLD_SIZE in the environment re-executes itself as N ranks under
+torch.distributed.run (one rank per GPU, RCCL; 127.0.0.1 rendezvous on a free port), so both command forms give
+the same line.  At N > 1 the line keeps everything the N = 1 line has (rank 0 runs the roofline legs and the CPU
+baseline while the other ranks wait on a host-side barrier) and adds per-rank rates, the collective's latency and the
+strong-scaling efficiency of the sharded search against the same run's single-rank search of all roots.
+
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -163,7 +169,8 @@ def hex_roots(osa, torch, ctx, n, index_offset, seed=SEED, depth_mod=40):
     return b
 
 
-def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
+def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barrier=lambda: None,
+                        gather_floats=lambda x: [float(x)]):
     """BASELINE.json configs 3-5 next to the headline: hex(9) MCTS sims/s (roots sharded over the
     ranks: strong scaling), kuhn CFR iterations/s (replicas only) and leduc ES-MCCFR trajectories/s
     (trajectories sharded, one RCCL all-reduce of the delta tables per mini-batch)."""
@@ -192,14 +199,32 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
     t0 = time.perf_counter()
     res = roots.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, seed=SEED, index_offset=first)
     fence()
-    dt = max_over_ranks(time.perf_counter() - t0)
-    done = res["root_stats"][:, 3].sum().reshape(1)
-    if world > 1:
-        dist.all_reduce(done)
-    out["mcts"] = {"metric": "MCTS sims/sec", "value": float(done.item()) / dt, "unit": "sims/s", "seconds": dt,
+    dt_local = time.perf_counter() - t0
+    done_local = float(res["root_stats"][:, 3].sum().item())
+    per_rank_dt, per_rank_done = gather_floats(dt_local), gather_floats(done_local)
+    dt, done = max(per_rank_dt), sum(per_rank_done)
+    out["mcts"] = {"metric": "MCTS sims/sec", "value": done / dt, "unit": "sims/s", "seconds": dt,
                    "scaling": "strong",
                    "config": {"workload": "hex(board_size=9) MCTSBot(RandomRolloutEvaluator(1), uct_c=2, 1024 sims) "
                                           f"x 2^16 roots, {count} roots on rank 0, wave-per-root layout"}}
+    del roots, res
+    if world > 1:
+        # strong scaling against THIS run's one-GPU search of all 2^16 roots (rank 0 alone, the others wait)
+        out["mcts"]["per_rank_sims_per_s"] = [d / t for d, t in zip(per_rank_done, per_rank_dt)]
+        if rank == 0:
+            full = hex_roots(osa, torch, ctx, total_roots, 0)
+            full.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, seed=1, index_offset=0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r1 = full.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, seed=SEED, index_offset=0)
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t0
+            done1 = float(r1["root_stats"][:, 3].sum().item())
+            out["mcts"]["single_rank_all_roots"] = {"value": done1 / dt1, "unit": "sims/s", "seconds": dt1,
+                                                    "what": "the same 2^16 roots searched by rank 0 alone in this run"}
+            out["mcts"]["strong_scaling_efficiency"] = (done / dt) / (world * done1 / dt1)
+            del full, r1
+        host_barrier()
     # Issue-rate view of the search kernel (it moves ~3.5 KB per simulation: far from a memory roofline): vector,
     # scalar and branch instructions per simulation from the committed counter profile, issue intervals from
     # profiles/r02_clock_probe.log.
@@ -207,7 +232,7 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
         mix = mcts_instruction_mix()
         if mix:
             simds = torch.cuda.get_device_properties(0).multi_processor_count * 4
-            ns_per_sim = dt / (float(done.item()) / world / simds) * 1e9
+            ns_per_sim = dt / (done / world / simds) * 1e9
             # issue intervals per SIMD measured by tools/clock_probe.hip with every SIMD saturated
             # (profiles/r02_clock_probe.log): a scalar-unit instruction every 1.833 ns, a simple vector
             # instruction every 1.03 ns (64-bit shifts, multiplies, fp64: about twice that)
@@ -222,7 +247,6 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
                         "slot busy the search runs at that rate, so fewer scalar instructions per simulation is the "
                         "lever (round 2: 652 + 83 -> 387 + 88 per simulation, 7.97e8 -> 1.12e9 simulations/s; the vector unit is now about as busy); "
                         "instruction counts are per simulation of an 8192-root search from the empty board"}
-    del roots, res
 
     # ---- config 3: kuhn_poker CFRSolver (full-tree regret / strategy update kernel) ----
     solver = osa.TabularSolver(ctx, "kuhn_poker")
@@ -295,8 +319,10 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
     # frozen table).  Time — traversal + fold launches only, NashConv evaluations not timed — until the average
     # policy's NashConv drops below each threshold, at the mini-batch size the sweep in
     # profiles/r02_mccfr_quality.log found best (2^14), with the table refreshed after every mini-batch.
-    if world == 1:
-        out["mccfr"]["quality"] = mccfr_time_to_nash_conv(osa, torch, ctx, 1 << 14, 1.5)
+    out["mccfr"]["quality"] = mccfr_quality(osa, torch, dist, ctx, rank, world, 1 << 14, 1.5)
+    # ---- config 1: tic_tac_toe MCTSBot(RandomRolloutEvaluator(20, 42), 1000 sims, solve) — plumbing ----
+    if rank == 0:
+        out["ttt_mcts"] = ttt_mcts_config1(with_cpu)
     if with_cpu and rank == 0:
         impl, kind = cpu_checker()
         threads = host_threads()
@@ -340,6 +366,7 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu):
             q["speedup_vs_cpu_at_equal_nash_conv"] = {
                 th: reached[th]["seconds"] / q["seconds_to_nash_conv"][th]["seconds"]
                 for th in reached if th in q["seconds_to_nash_conv"]}
+    host_barrier()
     return out
 
 
@@ -365,33 +392,127 @@ def mcts_instruction_mix():
             "source": os.path.relpath(files[-1], ROOT)}
 
 
-def mccfr_time_to_nash_conv(osa, torch, ctx, batch, budget_s):
-    """leduc_poker ES-MCCFR, mini-batches of `batch` trajectories, tables folded after each: seconds of
-    device work until the average policy's NashConv (device judge) is below each threshold."""
-    s = osa.TabularSolver(ctx, "leduc_poker", mccfr=True)
-    s.run_mccfr(SEED, 64)
-    s.reset()
-    torch.cuda.synchronize()
-    reached, spent, updates, first, check = {}, 0.0, 0, 0, 1
-    while spent < budget_s and len(reached) < len(NASH_CONV_THRESHOLDS):
-        todo = check - updates
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(todo):
-            s.run_mccfr(SEED, batch, first_trajectory=first)
-            first += batch
-        torch.cuda.synchronize()
-        spent += time.perf_counter() - t0
-        updates = check
-        nc = s.nash_conv()
-        for th in NASH_CONV_THRESHOLDS:
-            if nc <= th and str(th) not in reached:
-                reached[str(th)] = {"seconds": spent, "mini_batches": updates, "trajectories": updates * batch}
-        check = max(check + 1, int(check * 1.25))
-    return {"mini_batch": batch, "seconds_to_nash_conv": reached, "mini_batches": updates, "seconds": spent,
-            "nash_conv": s.nash_conv(),
-            "schedule": "every mini-batch: 2^14 traversals against the frozen table, one fold; thresholds checked at "
-                        "geometrically spaced mini-batch counts (x1.25), the evaluations are not timed"}
+def mccfr_quality(osa, torch, dist, ctx, rank, world, batch, budget_s):
+    """leduc_poker ES-MCCFR by quality: seconds until the average policy's NashConv (device judge) is below each
+    threshold, mini-batches of `batch` trajectories (global; sharded over the ranks, one all-reduce of the delta
+    tables each), for the synchronous schedule (sample -> all-reduce -> fold) and the overlapped one
+    (ShardedMccfr(overlap=True): mini-batch k + 1 is sampled while k's deltas are summed; tables stale by one
+    mini-batch).  Time = the slowest rank's wall time around the mini-batches (synchronised on both sides), the
+    NashConv evaluations are not timed."""
+    from open_spiel_amd import distributed as osd
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def run(overlap):
+        s = osa.TabularSolver(ctx, "leduc_poker", mccfr=True)
+        s.run_mccfr(SEED, 64)
+        s.reset()
+        sharded = osd.ShardedMccfr(s, overlap=overlap)
+        if overlap:   # allocate the two delta buffers outside the timed region
+            sharded.run_minibatch(SEED, 64)
+            sharded.finish()
+            s.reset()
+            sharded.trajectories_done = 0
+        reached, spent, updates, check = {}, 0.0, 0, 1
+        while spent < budget_s and len(reached) < len(NASH_CONV_THRESHOLDS):
+            todo = check - updates
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(todo):
+                sharded.run_minibatch(SEED, batch)
+            sharded.finish()
+            torch.cuda.synchronize()
+            spent += max_over_ranks(time.perf_counter() - t0)
+            updates = check
+            nc = s.nash_conv()
+            for th in NASH_CONV_THRESHOLDS:
+                if nc <= th and str(th) not in reached:
+                    reached[str(th)] = {"seconds": spent, "mini_batches": updates, "trajectories": updates * batch}
+            check = max(check + 1, int(check * 1.25))
+        return {"seconds_to_nash_conv": reached, "mini_batches": updates, "seconds": spent, "nash_conv": s.nash_conv(),
+                "us_per_mini_batch": spent / max(updates, 1) * 1e6}
+
+    sync = run(False)
+    over = run(True)
+    out = dict(sync)
+    out.update({"mini_batch": batch, "world": world,
+                "schedule": f"every mini-batch: 2^{batch.bit_length() - 1} traversals sharded over {world} rank(s) against the "
+                            "frozen table, one all-reduce of 2 x [936, 3] fp64 (none at 1 rank), one fold; thresholds "
+                            "checked at geometrically spaced mini-batch counts (x1.25), the evaluations are not timed",
+                "overlapped": dict(over, schedule="two delta buffers: mini-batch k + 1 is sampled while mini-batch k's deltas "
+                                                  "are all-reduced on the collective's own stream and folded on arrival "
+                                                  "(tables stale by one mini-batch; pending deltas folded before each "
+                                                  "evaluation)" + ("" if world > 1 else
+                                                                   "; at 1 rank there is no collective to hide: this row shows what the staleness costs")),
+                })
+    return out
+
+
+def ttt_mcts_config1(with_cpu):
+    """BASELINE.json configs[0] (plumbing): tic_tac_toe MCTSBot(RandomRolloutEvaluator(20, 42), uct_c = 2, 1000
+    simulations, max_memory_mb = 5, solve, seed 42) — the mcts_test.cc:35-49 setup — from the initial state and the
+    three MCTS-Solver positions of mcts_test.cc:126-155: the CPU reference's simulations/s and, beside it, what ONE
+    such search costs through the device path's single-root MCTSBot::Step (the drop-in class of the host mirror;
+    a single search is a latency case for a GPU — the batch entry points are the product)."""
+    out = {"config": "tic_tac_toe MCTSBot(RandomRolloutEvaluator(20, 42), uct_c=2, 1000 sims, max_memory_mb=5, solve, seed 42) "
+                     "from the initial state and the 3 solver positions of mcts_test.cc:126-155"}
+    positions = ("", "x(1,1) o(0,0) x(2,2)", "x(1,1) o(0,0) x(2,2) o(0,1) x(0,2)", "x(0,1) o(2,2)")
+    try:
+        from open_spiel_amd import pyspiel_hip as ps
+        game = ps.load_game("tic_tac_toe")
+        per = []
+        for pos in positions:
+            state = game.new_initial_state()
+            for tok in pos.split():
+                state.apply_action(next(a for a in state.legal_actions()
+                                        if state.action_to_string(state.current_player(), a) == tok))
+            bot = ps.MCTSBot(game, ps.RandomRolloutEvaluator(20, 42), 2.0, 1000, 5, True, 42, False)
+            bot.step(state)                               # warm-up (pool allocation)
+            t0 = time.perf_counter()
+            reps = 3
+            sims = 0
+            for _ in range(reps):
+                root = bot.mcts_search(state)
+                sims += root.explore_count
+            dt = time.perf_counter() - t0
+            per.append({"position": pos or "initial", "us_per_search": dt / reps * 1e6, "simulations_per_search": sims / reps})
+        tot_s = sum(p["us_per_search"] for p in per) * 1e-6
+        tot_sims = sum(p["simulations_per_search"] for p in per)
+        out["device_single_root"] = {"value": tot_sims / tot_s, "unit": "sims/s", "per_position": per,
+                                     "what": "pyspiel_hip.MCTSBot.mcts_search on ONE root (osg_mcts_tree_*: one lane of one "
+                                             "wavefront, one launch per evaluator round trip), whole SearchNode tree downloaded"}
+    except Exception as e:  # noqa: BLE001
+        out["device_single_root"] = {"error": f"{type(e).__name__}: {e}"}
+    if with_cpu:
+        try:
+            impl, kind = cpu_checker()
+            secs, sims = impl.Game("tic_tac_toe").bench_mcts_config1(1000, 40)
+            out["cpu_baseline"] = {"value": sims / secs, "unit": "sims/s", "cores": 1, "kind": kind,
+                                   "sample": f"40 x 4 MCTSearch calls (initial state + the 3 solver positions), {sims} simulations, "
+                                             f"1 thread, {secs:.2f} s"}
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def committed_random_steps_mix():
+    """Vector instructions per env step of the K = 32 random-steps kernel from the newest committed counter
+    profile (profiles/r*_pmc_k_random_steps.json, written by tools/gpu_validation.sh), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_random_steps.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        rec = json.load(f)
+    rec["source"] = os.path.relpath(files[-1], ROOT)
+    return rec if "valu_per_env_step" in rec else None
 
 
 def pmc_traffic():
@@ -482,6 +603,140 @@ def persistent_leg(osa, torch, ctx, src, rank):
                     "vector-issue bound, not memory bound"}
 
 
+def free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def spawn_ranks(gpus):
+    """`python bench.py --gpus N` started as ONE process: become N ranks (one per GPU) by running this same file
+    under torch.distributed.run with the same arguments — the command the module docstring shows, on a free
+    127.0.0.1 port — and pass its exit code on.  Rank 0 of that run prints the line."""
+    import subprocess
+    env = dict(os.environ, OSG_BENCH_SPAWNED="1", MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+PMC_KERNELS = ("k_step_c4std", "k_random_steps")
+
+
+def pmc_child(torch, osa):
+    """The launches the in-run counter passes look at, and nothing else: 12 of the headline kernel over 2^20
+    states, 12 over 2^24, 4 of the K = 32 random-steps kernel (bench.py --pmc-child, run under rocprofv3 --pmc)."""
+    ctx = osa.Context(0)
+    src, actions = synth_batch(osa, torch, ctx, STATES_PER_GPU, SEED, 0)
+    dst = osa.StateBatch(ctx, "connect_four", src.n)
+    mask, status = src.step_buffers()
+    for _ in range(12):
+        src.step(actions, dst=dst, mask=mask, status=status)
+    b = src.clone()
+    counters = torch.zeros(2, dtype=torch.int64, device="cuda")
+    for j in range(4):
+        b.random_steps(SEED + j, 32, counters, index_offset=0)
+    torch.cuda.synchronize()
+    print(json.dumps({"random_env_steps": int(counters[0].item()), "random_launches": 4}), flush=True)
+    del dst, mask, status, b
+    free_b, _total = torch.cuda.mem_get_info()
+    if free_b > 4 * ALGO_BYTES_PER_STEP * DRAM_LEG_STATES:
+        idx = torch.arange(DRAM_LEG_STATES, device="cuda", dtype=torch.int64) % src.n
+        src_big, act_big = src.gather(idx), actions[idx].contiguous()
+        del idx
+        dst_big = osa.StateBatch(ctx, "connect_four", DRAM_LEG_STATES)
+        mask, status = src_big.step_buffers()
+        for _ in range(12):
+            src_big.step(act_big, dst=dst_big, mask=mask, status=status)
+    torch.cuda.synchronize()
+
+
+def measure_pmc(timeout_s=150):
+    """HBM traffic of the headline kernel and the instruction mix of the random-steps kernel, measured in THIS run:
+    separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_INSTS_VALU + SQ_INSTS_SALU — FETCH_SIZE and WRITE_SIZE
+    do not fit one pass, MI355X_MICROARCH.md) over `bench.py --pmc-child`, --kernel-trace only beside the
+    counters.  FETCH_SIZE is doubled as the guide prescribes for gfx950 (128-byte requests of coalesced reads
+    tallied at 64 B; checked in round 1 against a copy of known size), WRITE_SIZE taken as is.  Returns a dict
+    or None (no rocprofv3, already under a profiler, a pass failed: the caller falls back to the committed file)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    if os.environ.get("OSG_BENCH_NO_PMC") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    tmp = tempfile.mkdtemp(prefix="osg_pmc_", dir="/tmp")
+    got, child_note = {}, {}
+    try:
+        for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_INSTS_SALU")):
+            out = os.path.join(tmp, counters[0])
+            cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child"]
+            env = dict(os.environ, TMPDIR="/tmp", OSG_BENCH_NO_PMC="1")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "TORCHELASTIC_RUN_ID"):
+                env.pop(k, None)
+            p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env, cwd="/tmp",
+                                 start_new_session=True)
+            try:
+                stdout, _ = p.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)     # the process group this call started, nothing else
+                p.wait()
+                return None
+            if p.returncode != 0:
+                return None
+            for ln in stdout.splitlines():
+                if ln.startswith("{"):
+                    child_note = json.loads(ln)
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    name = r["Kernel_Name"]
+                    kern = next((k for k in PMC_KERNELS if k in name), None)
+                    if kern is None or r["Counter_Name"] not in counters:
+                        continue
+                    states = int(r["Grid_Size"]) * (2 if "k_step_c4std2" in name else 1)
+                    got.setdefault((kern, states, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+    except Exception as e:  # noqa: BLE001 - a counter pass must never cost the line
+        print(f"[bench] in-run counter passes failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+    def mean(kern, states, counter):
+        vals = got.get((kern, states, counter))
+        if not vals:
+            return None
+        vals = vals[len(vals) // 4:]           # drop the first launches (cold caches)
+        return sum(vals) / len(vals)
+
+    res = {"source": "rocprofv3 --pmc passes run by this bench.py over `bench.py --pmc-child` (FETCH_SIZE, WRITE_SIZE, "
+                     "SQ_INSTS_VALU + SQ_INSTS_SALU: three separate passes, --kernel-trace only beside them); FETCH_SIZE "
+                     "(KB) doubled per MI355X_MICROARCH.md, WRITE_SIZE (KB) as is"}
+    for key, states in (("step", STATES_PER_GPU), ("dram", DRAM_LEG_STATES)):
+        f, w = mean("k_step_c4std", states, "FETCH_SIZE"), mean("k_step_c4std", states, "WRITE_SIZE")
+        if f is not None and w is not None:
+            res[key] = {"bytes_per_launch": f * 1024 * 2 + w * 1024, "fetch_bytes": f * 2048, "write_bytes": w * 1024,
+                        "ratio_to_algorithmic": (f * 2048 + w * 1024) / (ALGO_BYTES_PER_STEP * states)}
+    rs_keys = [k for k in got if k[0] == "k_random_steps" and k[2] == "SQ_INSTS_VALU"]
+    if rs_keys and child_note.get("random_env_steps"):
+        kern, grid, _ = rs_keys[0]
+        valu = sum(got[(kern, grid, "SQ_INSTS_VALU")])            # wavefront-level instructions, all launches
+        salu = sum(got.get((kern, grid, "SQ_INSTS_SALU"), [0.0]))
+        res["random_steps"] = {"valu_wave_insts": valu, "salu_wave_insts": salu,
+                               "env_steps": child_note["random_env_steps"], "launches": child_note["random_launches"],
+                               "valu_per_env_step": valu * 64 / child_note["random_env_steps"]}
+    return res if len(res) > 1 else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -492,11 +747,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the MCTS / CFR / MCCFR workloads")
     ap.add_argument("--no-legs", action="store_true", help="skip the DRAM-true and persistent legs")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the in-run rocprofv3 counter passes")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and not args.pmc_child and (world_env is None or (world_env == "1" and "OSG_BENCH_SPAWNED" not in os.environ)):
+        raise SystemExit(spawn_ranks(args.gpus))
+
+    import datetime
     import torch
     import torch.distributed as dist
     import open_spiel_amd as osa
+
+    if args.pmc_child:
+        torch.cuda.set_device(0)
+        pmc_child(torch, osa)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -506,14 +773,34 @@ def main():
     # OSG_DIST_BACKEND=gloo lets the N>1 code path run on a box with fewer GPUs than ranks (ranks
     # share devices, collectives go through the host): a test hook, never the measured configuration.
     backend = os.environ.get("OSG_DIST_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"--gpus {world} needs {world} devices for RCCL (one rank per GPU) but this box has "
+                         f"{torch.cuda.device_count()}; OSG_DIST_BACKEND=gloo exercises the code path on shared devices")
     device_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(device_index)
+    host_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        long_wait = datetime.timedelta(minutes=30)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=long_wait)
+            # long waits (rank 0 timing the CPU reference) block on a socket here instead of spinning on the GPU
+            host_group = dist.new_group(backend="gloo", timeout=long_wait)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=long_wait)
+
+    def host_barrier():
+        if world > 1:
+            dist.barrier(group=host_group) if host_group is not None else dist.barrier()
+
+    def gather_floats(x):
+        """[x of rank 0, x of rank 1, ...] on every rank."""
+        if world == 1:
+            return [float(x)]
+        t = torch.zeros(world, dtype=torch.float64, device="cuda")
+        t[rank] = x
+        dist.all_reduce(t)
+        return [float(v) for v in t.tolist()]
 
     ctx = osa.Context(device_index)
     n = args.states
@@ -549,12 +836,11 @@ def main():
         one_step()
     ev1.record()
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
     avg_kernel_s = ev0.elapsed_time(ev1) / 1e3 / launches
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    per_rank_elapsed = gather_floats(elapsed_local)
+    per_rank_kernel_us = gather_floats(avg_kernel_s * 1e6)
+    elapsed = max(per_rank_elapsed)
     # sanity of the timed result against the oracle-checked status of the first states
     assert int((status & 0x40).sum().item()) == 0, "synthetic actions must all be legal"
 
@@ -569,16 +855,15 @@ def main():
         except Exception as e:  # noqa: BLE001 - the headline is measured already; say what failed and go on
             print(f"[bench] roofline legs failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
             legs = None
-    if world > 1:
-        dist.barrier()
+    host_barrier()
 
     secondary = None
     if not args.no_secondary:
         del src, dst
         # The headline above is measured; whatever happens in the workloads beside it must not cost the line.
         try:
-            secondary = secondary_workloads(osa, torch, dist, ctx, rank, world,
-                                            with_cpu=(not args.no_cpu_baseline) and world == 1)
+            secondary = secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu=not args.no_cpu_baseline,
+                                            host_barrier=host_barrier, gather_floats=gather_floats)
         except Exception as e:  # noqa: BLE001 - reported in the line, never swallowed silently
             import traceback
             secondary = {"error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()[-2000:]}
@@ -586,12 +871,17 @@ def main():
 
     if rank == 0:
         traffic, traffic_source, dram_traffic = pmc_traffic()
+        live = None if (args.no_pmc or n != STATES_PER_GPU) else measure_pmc()
+        if live and "step" in live:
+            traffic, traffic_source = live["step"]["bytes_per_launch"], live["source"]
+            dram_traffic = live.get("dram", {}).get("bytes_per_launch", dram_traffic)
         total_env_steps = n * world * launches
         value = total_env_steps / elapsed
         achieved = ALGO_BYTES_PER_STEP * n / avg_kernel_s / 1e9
         roofline = {"bound": "infinity_cache" if ALGO_BYTES_PER_STEP * n < (200 << 20) else "hbm",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                    "traffic_measured_in_this_run": bool(live and "step" in live),
                     "kernel": "k_step_c4std2", "algorithmic_bytes_per_launch": ALGO_BYTES_PER_STEP * n,
                     "avg_launch_us": avg_kernel_s * 1e6, "launches_timed": launches,
                     "peak_note": "peak = HBM3E spec 8 TB/s (the denominator BASELINE.json names); one launch moves "
@@ -618,16 +908,37 @@ def main():
                        "parallelism": f"{world} independent shard(s), no collective"},
             "roofline": roofline,
         }
+        if world > 1:
+            line["per_rank"] = {"env_steps_per_s": [n * launches / t for t in per_rank_elapsed],
+                                "avg_launch_us": per_rank_kernel_us,
+                                "note": "value = all ranks' env-steps / the slowest rank's time (barrier + synchronize on both sides)"}
         if legs is not None:
             line["persistent"] = legs["persistent"]
-        if not args.no_cpu_baseline and world == 1:
+            rs = (live or {}).get("random_steps") or committed_random_steps_mix()
+            if rs:
+                # issue-rate view, like the search kernel's: wave-level vector instructions per SIMD x the
+                # measured issue interval of the cheapest vector instruction (tools/clock_probe.hip: 1.03 ns)
+                p = line["persistent"]
+                simds = torch.cuda.get_device_properties(0).multi_processor_count * 4
+                valu_per_step = rs["valu_per_env_step"]
+                issue_s = p["env_steps"] * valu_per_step / 64 / simds * 1.03e-9
+                p["roofline"] = {"bound": "vector-unit instruction issue", "valu_per_env_step": valu_per_step,
+                                 "vector_issue_seconds_at_least": issue_s, "seconds": p["seconds"],
+                                 "frac_of_vector_issue_bound": issue_s / p["seconds"],
+                                 "source": rs.get("source", "in-run rocprofv3 --pmc SQ_INSTS_VALU pass"),
+                                 "note": "a wave64 vector instruction issues every 1.03 ns per SIMD at best (64-bit "
+                                         "shifts, multiplies: 1.8-1.9 ns), so the fraction is a lower bound of the "
+                                         "vector unit's busy share"}
+        if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+            if world > 1:
+                line["cpu_baseline"]["note"] = "timed on rank 0's host while the other ranks wait on a socket barrier"
         if secondary is not None:
             line["secondary"] = secondary
         print(json.dumps(line), flush=True)
+    host_barrier()
     if world > 1:
-        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -1,15 +1,19 @@
-// Include-path shim: the REFERENCE'S OWN test sources (e.g. /root/reference/open_spiel/algorithms/cfr_br_test.cc)
-// are compiled UNMODIFIED against the MI355X host mirror.  Every reference header they include resolves to this
-// directory first (-I tests/mirror_shim before -I /root/reference); this file pulls in the mirror and opens its
-// names in the namespaces the test sources live in.  Test infrastructure only.
-#ifndef OSG_MIRROR_SHIM_SPIEL_H_
-#define OSG_MIRROR_SHIM_SPIEL_H_
+// Source-level drop-in for the hot path: `#include "open_spiel/spiel.h"` (and the other reference header names in
+// this directory, which all forward here) with -I <repo>/include in front of — or instead of — the reference's
+// include path resolves to the MI355X host mirror (open_spiel_amd/csrc/host/osg_spiel.h over the C-ABI,
+// libosg_hip.so), with its names opened in the namespaces the reference declares them in: open_spiel::Game /
+// State / LoadGame / Policy / Bot ... (open_spiel/spiel.h:301-1314, policy.h, spiel_bots.h) and
+// open_spiel::algorithms::{MCTSBot, CFRSolver, ExternalSamplingMCCFRSolver, ...}.  A program written against the
+// reference for this path compiles unchanged (tests/dropin/user_program.cc does, and so do the reference's own
+// unit-test sources: tests/native/Makefile.reftests), for the five games of the path.
+#ifndef OSG_INCLUDE_OPEN_SPIEL_SPIEL_H_
+#define OSG_INCLUDE_OPEN_SPIEL_SPIEL_H_
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
 #include <sstream>
 
-#include "open_spiel_amd/csrc/host/osg_spiel.h"
+#include "../../open_spiel_amd/csrc/host/osg_spiel.h"
 
 namespace open_spiel {
 // the names of namespace open_spiel the test sources use, one by one (a using-directive for hip would make
@@ -51,4 +55,4 @@ namespace kuhn_poker { using namespace hip::algorithms::kuhn_poker; }
     }                                                                                                    \
   } while (0)
 #define SPIEL_CHECK_FLOAT_EQ(x, y) SPIEL_CHECK_FLOAT_NEAR(x, y, 1e-5)
-#endif  // OSG_MIRROR_SHIM_SPIEL_H_
+#endif  // OSG_INCLUDE_OPEN_SPIEL_SPIEL_H_

@@ -84,6 +84,10 @@ int osg_ctx_create(int device, void* stream, int own_stream, osg_ctx** out);
 int osg_ctx_destroy(osg_ctx* ctx);
 int osg_ctx_synchronize(osg_ctx* ctx);
 void* osg_ctx_stream(osg_ctx* ctx);
+/* Give back what the context caches between calls: the MCTS node pool (grow-only otherwise: a search without a
+ * node budget sizes it at 1 + max_simulations x widest-node slots per root, up to 60 % of the free HBM) and the
+ * staging buffer.  Waits for the stream first.  The next search allocates again. */
+int osg_ctx_trim(osg_ctx* ctx);
 
 /* ---- game description (no device needed) -------------------------------- */
 /* Replaces LoadGame(game_string) (open_spiel/spiel.cc:255) for the five hot-path
@@ -217,8 +221,10 @@ typedef struct {
   int32_t max_nodes;        /* > 0: MCTSBot's max_nodes_ = (max_memory_mb << 20) / sizeof(SearchNode) + 1
                                (mcts.cc:214): when a tree reaches it, every node visited fewer than
                                gc_limit_ times loses its children (GarbageCollect, mcts.cc:441-482).
-                               <= 0: no caller limit (the pool holds 16384 nodes per root, or what the
-                               free HBM allows; a tree that outgrows it is collected the same way)   */
+                               <= 0: no caller limit: the pool gets 1 + max_simulations x widest-node slots
+                               per root (it can never run out) when that fits 60 % of the free HBM, else
+                               what fits, collected the same way at that size.  The pool stays cached in
+                               the context (grow-only) until osg_ctx_trim / osg_ctx_destroy          */
   uint64_t seed;
   int64_t index_offset;     /* global index of root 0 (multi-GPU sharding)         */
   int32_t layout;           /* 0 auto; 1 one LANE per root (64 searches per wavefront,
@@ -256,7 +262,7 @@ int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg, int32_t* be
  * also keeps the parked searches' working states: do not modify it between calls).  The next call takes the
  * answers: d_prior [n, num_distinct_actions] f64 (probability of action a at [i, a]; read for roots that
  * reported 1) and d_value [n, num_players] f64 (read for roots that reported 2); either may be NULL when no
- * root reported that request.  h_counts (may be NULL) receives the number of roots per request code [4].
+ * root reported that request (a root whose answer is missing stays parked and reports its request again).  h_counts (may be NULL) receives the number of roots per request code [4].
  * cfg as for osg_mcts_search (layout ignored: one lane per root; the tree-policy streams are those of layout 1,
  * so with osg_mcts_tree_rollout_values as the evaluator the search is osg_mcts_search's, draw for draw).
  * flags: 1 = priors come from the caller (else uniform over the legal actions, RandomRolloutEvaluator::Prior
@@ -376,6 +382,17 @@ int osg_cfr_table_ptrs(osg_cfr* s, double** d_regrets, double** d_cum_policy, do
  * [I, Amax] buffers; the caller all-reduces them (RCCL) and then folds them in. */
 int osg_mccfr_delta_ptrs(osg_cfr* s, double** d_regret_delta, double** d_policy_delta);
 int osg_mccfr_apply_deltas(osg_cfr* s);
+/* The same two halves on a CALLER's delta buffer d_delta = regret deltas [I, Amax] | average-policy deltas
+ * [I, Amax] (2 * I * Amax device doubles, 8-byte aligned; NULL = the solver's own tables): with two such
+ * buffers a host overlaps the all-reduce of mini-batch k with the traversals of mini-batch k + 1, which then
+ * read the tables without k's deltas (stale by one mini-batch; ShardedMccfr(overlap=True) in
+ * open_spiel_amd/distributed.py, ExternalSamplingMCCFRSolver::RunShardedMiniBatch(..., overlap) in the host
+ * mirror).  The reference has no such schedule: its RunIteration is sequential (external_sampling_mccfr.cc:71-80). */
+int osg_mccfr_sample_into(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_t trajectories, double* d_delta);
+int osg_mccfr_apply_deltas_from(osg_cfr* s, double* d_delta);
+/* Two such buffers owned by the solver (allocated on first request, freed with it) for hosts that have no
+ * device allocator of their own (which = 0 | 1). */
+int osg_mccfr_spare_delta_buffer(osg_cfr* s, int which, double** d_delta);
 /* Overwrite the [I, Amax] tables from host arrays (any may be NULL): restores a
  * checkpoint / CFRInfoStateValuesTable (cfr.cc:723-777 deserialisation target). */
 int osg_cfr_upload_tables(osg_cfr* s, const double* h_regrets, const double* h_cum_policy,
@@ -425,6 +442,12 @@ int osg_comm_rank(const osg_comm* c);
 int osg_comm_world(const osg_comm* c);
 int osg_allreduce_sum_f64(osg_comm* c, double* d_buf, int64_t n);
 int osg_allreduce_sum_i32(osg_comm* c, int32_t* d_buf, int64_t n);
+/* The asynchronous form: _begin orders the collective after everything issued on the context's stream so far
+ * and runs it on the communicator's own stream; kernels issued on the context's stream between _begin and
+ * _end overlap it (they must not touch d_buf); _end makes the context's stream wait for the collective (no
+ * host wait).  One collective in flight per communicator. */
+int osg_allreduce_sum_f64_begin(osg_comm* c, double* d_buf, int64_t n);
+int osg_allreduce_end(osg_comm* c);
 
 #ifdef __cplusplus
 }

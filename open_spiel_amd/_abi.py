@@ -80,6 +80,7 @@ SIGNATURES = {
     "osg_ctx_destroy": (INT, [VP]),
     "osg_ctx_synchronize": (INT, [VP]),
     "osg_ctx_stream": (VP, [VP]),
+    "osg_ctx_trim": (INT, [VP]),
     "osg_game_describe": (INT, [C.c_char_p, C.POINTER(GameDesc)]),
     "osg_batch_create": (INT, [VP, C.c_char_p, I64, C.POINTER(VP)]),
     "osg_batch_destroy": (INT, [VP]),
@@ -134,6 +135,9 @@ SIGNATURES = {
     "osg_cfr_table_ptrs": (INT, [VP, C.POINTER(VP), C.POINTER(VP), C.POINTER(VP)]),
     "osg_mccfr_delta_ptrs": (INT, [VP, C.POINTER(VP), C.POINTER(VP)]),
     "osg_mccfr_apply_deltas": (INT, [VP]),
+    "osg_mccfr_sample_into": (INT, [VP, U64, I64, I64, VP]),
+    "osg_mccfr_apply_deltas_from": (INT, [VP, VP]),
+    "osg_mccfr_spare_delta_buffer": (INT, [VP, INT, C.POINTER(VP)]),
     "osg_cfr_tables": (INT, [VP, VP, VP, VP, VP, VP, VP]),
     "osg_cfr_evaluate_policy": (INT, [VP, INT, VP, VP, VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "osg_cfr_infostate_player": (INT, [VP, I64]),
@@ -146,6 +150,8 @@ SIGNATURES = {
     "osg_comm_world": (INT, [VP]),
     "osg_allreduce_sum_f64": (INT, [VP, VP, I64]),
     "osg_allreduce_sum_i32": (INT, [VP, VP, I64]),
+    "osg_allreduce_sum_f64_begin": (INT, [VP, VP, I64]),
+    "osg_allreduce_end": (INT, [VP]),
 }
 
 _lib = None

@@ -105,6 +105,10 @@ class Communicator {
   // In place, on the context's stream (ordered with the kernels before and after it).
   void AllReduceSum(double* d_buf, int64_t n) { Check(osg_allreduce_sum_f64(c_, d_buf, n)); }
   void AllReduceSum(int32_t* d_buf, int64_t n) { Check(osg_allreduce_sum_i32(c_, d_buf, n)); }
+  // The asynchronous form: the collective runs on the communicator's own stream; kernels issued on the
+  // context's stream between Begin and End overlap it, End orders the context's stream after it (no host wait).
+  void BeginAllReduceSum(double* d_buf, int64_t n) { Check(osg_allreduce_sum_f64_begin(c_, d_buf, n)); }
+  void EndAllReduce() { Check(osg_allreduce_end(c_)); }
 
  private:
   osg_comm* c_ = nullptr;
@@ -560,8 +564,10 @@ struct SearchNode {  // mcts.h:114-146
   std::vector<double> outcome;
   std::vector<SearchNode> children;
   bool CompareFinal(const SearchNode& b) const {  // mcts.cc:114-125
-    double mine = outcome.empty() ? 0 : outcome[player];
-    double theirs = b.outcome.empty() ? 0 : b.outcome[b.player];
+    // player is kChancePlayerId (-1) for the children of a chance node: the reference reads the outcome only
+    // for 0 <= player < outcome.size() (mcts.cc:115-118)
+    double mine = (outcome.empty() || player < 0 || player >= static_cast<Player>(outcome.size())) ? 0 : outcome[player];
+    double theirs = (b.outcome.empty() || b.player < 0 || b.player >= static_cast<Player>(b.outcome.size())) ? 0 : b.outcome[b.player];
     if (mine != theirs) return mine < theirs;
     if (explore_count != b.explore_count) return explore_count < b.explore_count;
     return total_reward < b.total_reward;
@@ -694,6 +700,9 @@ class MCTSBot : public Bot {
   }
   void Restart() override {}
   void RestartAt(const State&) override {}
+  // true when the evaluator is the C++ RandomRolloutEvaluator: a search then never calls back into the host
+  // language (the pybind module releases the GIL around Step for such bots, as bots.cc:147-148 does)
+  bool EvaluatorIsNative() const { return rollout_ != nullptr; }
   // One search per state of the batch with the fused kernels; returns BestChild().action per root (-1 for
   // terminal roots).  RandomRolloutEvaluator, no root noise.
   std::vector<Action> StepBatch(const BatchedState& roots) {
@@ -1648,13 +1657,27 @@ class ExternalSamplingMCCFRSolver : public DeviceTabularSolver {  // external_sa
   // slice of the global index range, ONE all-reduce(sum) of the two adjacent [I, Amax] delta tables over
   // xGMI, then every rank folds identical deltas in — all ranks end with identical tables, and with the
   // tables a single GPU would have computed up to fp64 summation order.
-  void RunShardedMiniBatch(int64_t trajectories, Communicator& comm) {
+  void RunShardedMiniBatch(int64_t trajectories, Communicator& comm, bool overlap = false) {
     const auto [first, count] = comm.Shard(trajectories);
+    const int64_t n = sizes_[4] * sizes_[5];
+    if (overlap) {
+      // Double-buffered: mini-batch k's deltas are summed over the ranks on the communicator's stream while
+      // mini-batch k + 1 is sampled (against tables without k's deltas: stale by one mini-batch); k's deltas are
+      // folded when they have arrived, before mini-batch k + 2.  FinishSharded() folds what is still in flight.
+      double* buf = nullptr;
+      Check(osg_mccfr_spare_delta_buffer(s_, static_cast<int>(minibatches_ & 1), &buf));
+      Check(osg_mccfr_sample_into(s_, seed_, next_ + first, count, buf));
+      FinishSharded(comm);  // mini-batch k - 1: its all-reduce has been running under the sampling of k
+      if (comm.world() > 1) comm.BeginAllReduceSum(buf, 2 * n);
+      pending_ = buf;
+      ++minibatches_;
+      next_ += trajectories;
+      return;
+    }
     Check(osg_mccfr_sample(s_, seed_, next_ + first, count));
     if (comm.world() > 1) {
       double *dreg = nullptr, *dpol = nullptr;
       Check(osg_mccfr_delta_ptrs(s_, &dreg, &dpol));
-      const int64_t n = sizes_[4] * sizes_[5];
       if (dpol == dreg + n) {
         comm.AllReduceSum(dreg, 2 * n);
       } else {
@@ -1664,6 +1687,13 @@ class ExternalSamplingMCCFRSolver : public DeviceTabularSolver {  // external_sa
     }
     Check(osg_mccfr_apply_deltas(s_));
     next_ += trajectories;
+  }
+  // Folds the deltas of the last overlapped mini-batch (a no-op when nothing is pending).
+  void FinishSharded(Communicator& comm) {
+    if (!pending_) return;
+    if (comm.world() > 1) comm.EndAllReduce();
+    Check(osg_mccfr_apply_deltas_from(s_, pending_));
+    pending_ = nullptr;
   }
   void RestoreCounter(uint64_t seed, int64_t next) { seed_ = seed; next_ = next; }
   void RestoreGenerator(const std::string& state) {  // external_sampling_mccfr.cc:262-264
@@ -1681,6 +1711,8 @@ class ExternalSamplingMCCFRSolver : public DeviceTabularSolver {  // external_sa
   AverageType avg_type_;
   std::string game_string_;
   std::vector<double> uniforms_;
+  double* pending_ = nullptr;  // RunShardedMiniBatch(overlap): the delta buffer whose all-reduce is in flight
+  int64_t minibatches_ = 0;
 };
 
 class OutcomeSamplingMCCFRSolver : public DeviceTabularSolver {  // outcome_sampling_mccfr.h:40-107

@@ -382,10 +382,23 @@ PYBIND11_MODULE(pyspiel_hip, m) {
            py::arg("child_selection_policy") = ChildSelectionPolicy::UCT, py::arg("max_wall_clock_time") = -1.0,
            py::arg("dirichlet_alpha") = 0.0, py::arg("dirichlet_epsilon") = 0.0,
            py::arg("dont_return_chance_node") = false)
-      // (no GIL release: a Python Evaluator is called back from inside the search)
-      .def("step", &MCTSBot::Step, py::arg("state"))
+      // bots.cc:147-148 releases the GIL around step: here too whenever the evaluator is the C++
+      // RandomRolloutEvaluator; a Python Evaluator is called back from inside the search and keeps it
+      .def("step",
+           [](MCTSBot& bot, const State& state) {
+             if (!bot.EvaluatorIsNative()) return bot.Step(state);
+             py::gil_scoped_release release;
+             return bot.Step(state);
+           },
+           py::arg("state"))
       .def("step_with_policy", &MCTSBot::StepWithPolicy, py::arg("state"))  // spiel_bots.h:105-112
-      .def("mcts_search", &MCTSBot::MCTSearch, py::arg("state"))
+      .def("mcts_search",
+           [](MCTSBot& bot, const State& state) {
+             if (!bot.EvaluatorIsNative()) return bot.MCTSearch(state);
+             py::gil_scoped_release release;
+             return bot.MCTSearch(state);
+           },
+           py::arg("state"))
       .def("step_batch", &MCTSBot::StepBatch, py::arg("states"), py::call_guard<py::gil_scoped_release>());
 
   // python/pybind11/policy.cc:90-222: Policy, TabularPolicy, UniformPolicy, PreferredActionPolicy and the factories.

@@ -1404,6 +1404,7 @@ struct osg_cfr {
   std::vector<int32_t> meta32, info_player32;
   int32_t *d_meta32 = nullptr, *d_info_player32 = nullptr, *d_skip = nullptr;
   double* d_node_delta = nullptr;  // dreg [M, A] | dpol [M, A]
+  double* d_spare_delta[2] = {nullptr, nullptr};  // osg_mccfr_spare_delta_buffer: [2, I, A] each, allocated on request
   // policy evaluation (k_policy_eval)
   std::vector<int32_t> info_level, mem_index;
   bool eval_ok = true;  // every infostate's members sit on one tree level
@@ -1860,7 +1861,7 @@ int osg_cfr_destroy(osg_cfr* s) {
                   s->d_kind, s->d_nchild, s->d_aidx, s->d_actor, s->d_info_player, s->d_edge_prob, s->d_term_ret,
                   s->d_tables, s->d_reach, s->d_value, s->d_path_off, s->d_path, s->d_info_level, s->d_mem_index,
                   s->d_best, s->d_eval, s->d_meta32, s->d_info_player32, s->d_skip, s->d_node_delta, s->d_rec,
-                  s->d_uret, s->d_uprob};
+                  s->d_uret, s->d_uprob, s->d_spare_delta[0], s->d_spare_delta[1]};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   osg::ctx_release(s->ctx);
@@ -1950,12 +1951,14 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
   return OSG_OK;
 }
 
-int osg_mccfr_sample(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_t trajectories) {
+// The traversals of one mini-batch into the delta tables dreg | dpol (the solver's own, or a caller's buffer).
+static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_t trajectories, double* dreg,
+                             double* dpol) {
   if (!s || trajectories < 0) return set_error(OSG_ERR_INVALID, "osg_mccfr_sample: bad argument");
   if (s->A > kMaxA) return set_error(OSG_ERR_UNSUPPORTED, "osg_mccfr_sample: decision nodes wider than 4 actions");
   const int IA = s->I * s->A;
   hipStream_t st = s->ctx->stream;
-  OSG_HIP(hipMemsetAsync(s->dreg(), 0, sizeof(double) * 2 * IA, st));
+  OSG_HIP(hipMemsetAsync(dreg, 0, sizeof(double) * 2 * IA, st));  // dpol == dreg + IA
   if (trajectories == 0) return OSG_OK;
   const size_t lds = sizeof(double) * 2 * IA;
   const bool use_lds = lds <= 64 * 1024;
@@ -1984,12 +1987,12 @@ int osg_mccfr_sample(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_
 #define OSG_MCCFR_RES(KA)                                                                                          \
   do {                                                                                                             \
     if (s->cfg.solver == 2)                                                                                        \
-      k_os_mccfr_resident<KA><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), s->dreg(), \
-                                                          s->dpol(), seed, first_trajectory, trajectories,        \
+      k_os_mccfr_resident<KA><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), dreg, \
+                                                          dpol, seed, first_trajectory, trajectories,        \
                                                           s->cfg.epsilon);                                        \
     else                                                                                                           \
-      k_mccfr_resident<KA><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), s->dreg(),  \
-                                                       s->dpol(), seed, first_trajectory, trajectories);          \
+      k_mccfr_resident<KA><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), dreg,  \
+                                                       dpol, seed, first_trajectory, trajectories);          \
   } while (0)
     switch (s->A) {
       case 1: OSG_MCCFR_RES(1); break;
@@ -2011,10 +2014,10 @@ int osg_mccfr_sample(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_
         os_attr_set = true;
       }
       k_os_mccfr<true><<<dim3(static_cast<unsigned>(blocks)), dim3(256), lds, st>>>(
-          s->tree(), s->regrets(), s->dreg(), s->dpol(), seed, first_trajectory, trajectories, eps);
+          s->tree(), s->regrets(), dreg, dpol, seed, first_trajectory, trajectories, eps);
     } else {
       k_os_mccfr<false><<<dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st>>>(
-          s->tree(), s->regrets(), s->dreg(), s->dpol(), seed, first_trajectory, trajectories, eps);
+          s->tree(), s->regrets(), dreg, dpol, seed, first_trajectory, trajectories, eps);
     }
     OSG_HIP(hipGetLastError());
     return OSG_OK;
@@ -2026,34 +2029,70 @@ int osg_mccfr_sample(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
       attr_set = true;
     }
-    k_mccfr<true><<<dim3(static_cast<unsigned>(blocks)), dim3(256), lds, st>>>(s->tree(), s->regrets(), s->dreg(),
-                                                                                s->dpol(), seed, first_trajectory,
+    k_mccfr<true><<<dim3(static_cast<unsigned>(blocks)), dim3(256), lds, st>>>(s->tree(), s->regrets(), dreg,
+                                                                                dpol, seed, first_trajectory,
                                                                                 trajectories);
   } else {
-    k_mccfr<false><<<dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st>>>(s->tree(), s->regrets(), s->dreg(),
-                                                                               s->dpol(), seed, first_trajectory,
+    k_mccfr<false><<<dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st>>>(s->tree(), s->regrets(), dreg,
+                                                                               dpol, seed, first_trajectory,
                                                                                trajectories);
   }
   OSG_HIP(hipGetLastError());
   return OSG_OK;
 }
 
-int osg_mccfr_apply_deltas(osg_cfr* s) {
-  if (!s) return set_error(OSG_ERR_INVALID, "osg_mccfr_apply_deltas: null argument");
+int osg_mccfr_sample(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_t trajectories) {
+  if (!s) return set_error(OSG_ERR_INVALID, "osg_mccfr_sample: bad argument");
+  return mccfr_sample_impl(s, seed, first_trajectory, trajectories, s->dreg(), s->dpol());
+}
+
+int osg_mccfr_sample_into(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_t trajectories, double* d_delta) {
+  if (!s) return set_error(OSG_ERR_INVALID, "osg_mccfr_sample_into: bad argument");
+  if (!d_delta) return mccfr_sample_impl(s, seed, first_trajectory, trajectories, s->dreg(), s->dpol());
+  if (reinterpret_cast<uintptr_t>(d_delta) & 7) return set_error(OSG_ERR_INVALID, "osg_mccfr_sample_into: d_delta must be 8-byte aligned");
+  return mccfr_sample_impl(s, seed, first_trajectory, trajectories, d_delta, d_delta + static_cast<size_t>(s->I) * s->A);
+}
+
+static int mccfr_fold_impl(osg_cfr* s, double* dreg, double* dpol) {
   const int IA = s->I * s->A;
   // AverageType::kFull: the traversals' sampled average-policy terms are not used (external_sampling_mccfr.cc:177);
   // the average policy comes from osg_mccfr_full_average instead
   if (s->average_type == 1 && s->cfg.solver == 1)
-    OSG_HIP(hipMemsetAsync(s->dpol(), 0, sizeof(double) * IA, s->ctx->stream));
-  k_fold_deltas<<<dim3((IA + 255) / 256), dim3(256), 0, s->ctx->stream>>>(s->regrets(), s->cum(), s->dreg(), s->dpol(), IA);
+    OSG_HIP(hipMemsetAsync(dpol, 0, sizeof(double) * IA, s->ctx->stream));
+  k_fold_deltas<<<dim3((IA + 255) / 256), dim3(256), 0, s->ctx->stream>>>(s->regrets(), s->cum(), dreg, dpol, IA);
   OSG_HIP(hipGetLastError());
   ++s->iteration;
   return OSG_OK;
 }
 
+int osg_mccfr_apply_deltas(osg_cfr* s) {
+  if (!s) return set_error(OSG_ERR_INVALID, "osg_mccfr_apply_deltas: null argument");
+  return mccfr_fold_impl(s, s->dreg(), s->dpol());
+}
+
+int osg_mccfr_spare_delta_buffer(osg_cfr* s, int which, double** d_delta) {
+  if (!s || !d_delta || (which != 0 && which != 1)) return set_error(OSG_ERR_INVALID, "osg_mccfr_spare_delta_buffer: bad argument");
+  if (!s->d_spare_delta[which]) {
+    const size_t bytes = sizeof(double) * 2 * static_cast<size_t>(s->I) * s->A;
+    OSG_HIP(hipSetDevice(s->ctx->device));
+    OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_spare_delta[which]), bytes));
+    OSG_HIP(hipMemsetAsync(s->d_spare_delta[which], 0, bytes, s->ctx->stream));
+  }
+  *d_delta = s->d_spare_delta[which];
+  return OSG_OK;
+}
+
+int osg_mccfr_apply_deltas_from(osg_cfr* s, double* d_delta) {
+  if (!s) return set_error(OSG_ERR_INVALID, "osg_mccfr_apply_deltas_from: null argument");
+  if (!d_delta) return mccfr_fold_impl(s, s->dreg(), s->dpol());
+  return mccfr_fold_impl(s, d_delta, d_delta + static_cast<size_t>(s->I) * s->A);
+}
+
 int osg_mccfr_set_average_type(osg_cfr* s, int average_type) {
   if (!s || (average_type != 0 && average_type != 1)) return set_error(OSG_ERR_INVALID, "osg_mccfr_set_average_type: 0 (kSimple) or 1 (kFull)");
   if (s->cfg.solver != 1) return set_error(OSG_ERR_INVALID, "osg_mccfr_set_average_type: external-sampling solvers only");
+  if (average_type == 1 && (s->B != 1 || s->A > kMaxPolicyRow))
+    return set_error(OSG_ERR_UNSUPPORTED, "osg_mccfr_set_average_type: kFull needs one solver per object and policy rows of at most 8 actions");
   s->average_type = average_type;
   return OSG_OK;
 }

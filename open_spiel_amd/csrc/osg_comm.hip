@@ -75,6 +75,11 @@ struct osg_comm {
   ncclComm_t comm = nullptr;
   int rank = 0;
   int world = 1;
+  // the asynchronous form (osg_allreduce_sum_f64_begin / osg_allreduce_end): the collective runs on the
+  // communicator's own stream between two events, so kernels issued on the context's stream meanwhile overlap it
+  hipStream_t side = nullptr;
+  hipEvent_t produced = nullptr, reduced = nullptr;
+  bool in_flight = false;
 };
 
 static_assert(OSG_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "osg_abi.h and rccl.h disagree on the id size");
@@ -119,8 +124,12 @@ int osg_comm_destroy(osg_comm* c) {
   int rc = RcclReady(&api);
   if (rc == OSG_OK && c->comm) {
     hipStreamSynchronize(c->ctx->stream);
+    if (c->side) hipStreamSynchronize(c->side);
     api->CommDestroy(c->comm);
   }
+  if (c->produced) hipEventDestroy(c->produced);
+  if (c->reduced) hipEventDestroy(c->reduced);
+  if (c->side) hipStreamDestroy(c->side);
   osg::ctx_release(c->ctx);
   delete c;
   return rc;
@@ -147,6 +156,38 @@ int osg_allreduce_sum_f64(osg_comm* c, double* d_buf, int64_t n) {
 
 int osg_allreduce_sum_i32(osg_comm* c, int32_t* d_buf, int64_t n) {
   return AllReduceSum(c, d_buf, n, ncclInt32, "osg_allreduce_sum_i32");
+}
+
+int osg_allreduce_sum_f64_begin(osg_comm* c, double* d_buf, int64_t n) {
+  if (!c || (!d_buf && n > 0) || n < 0) return set_error(OSG_ERR_INVALID, "osg_allreduce_sum_f64_begin: bad argument");
+  if (c->in_flight) return set_error(OSG_ERR_INVALID, "osg_allreduce_sum_f64_begin: one collective in flight per communicator (call osg_allreduce_end first)");
+  RcclApi* api = nullptr;
+  if (int rc = RcclReady(&api)) return rc;
+  OSG_HIP(hipSetDevice(c->ctx->device));
+  if (!c->side) {
+    OSG_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    OSG_HIP(hipEventCreateWithFlags(&c->produced, hipEventDisableTiming));
+    OSG_HIP(hipEventCreateWithFlags(&c->reduced, hipEventDisableTiming));
+  }
+  // everything issued on the context's stream so far (the kernels that filled the buffer) comes first
+  OSG_HIP(hipEventRecord(c->produced, c->ctx->stream));
+  OSG_HIP(hipStreamWaitEvent(c->side, c->produced, 0));
+  if (n > 0) {
+    ncclResult_t r = api->AllReduce(d_buf, d_buf, static_cast<size_t>(n), ncclFloat64, ncclSum, c->comm, c->side);
+    if (r != ncclSuccess) return RcclFail(api, "osg_allreduce_sum_f64_begin", r);
+  }
+  OSG_HIP(hipEventRecord(c->reduced, c->side));
+  c->in_flight = true;
+  return OSG_OK;
+}
+
+int osg_allreduce_end(osg_comm* c) {
+  if (!c) return set_error(OSG_ERR_INVALID, "osg_allreduce_end: null argument");
+  if (!c->in_flight) return OSG_OK;
+  // no host wait: what is issued on the context's stream from here on runs after the collective
+  OSG_HIP(hipStreamWaitEvent(c->ctx->stream, c->reduced, 0));
+  c->in_flight = false;
+  return OSG_OK;
 }
 
 }  // extern "C"

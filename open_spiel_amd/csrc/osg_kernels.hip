@@ -159,7 +159,7 @@ k_step(typename G::Params p, const typename G::word_t* src, typename G::word_t* 
 // The per-state code is the generic one (G::legal / apply / terminal) on a register-resident mini-batch.
 template <class G, typename MaskT, int V, int W>  // W = words per state
 __global__ void __launch_bounds__(kBlock)
-k_step_vec(typename G::Params p, const typename G::word_t* __restrict__ src, typename G::word_t* __restrict__ dst, int64_t n,
+k_step_vec(typename G::Params p, const typename G::word_t* src, typename G::word_t* dst, int64_t n,  // src may BE dst (in-place step)
            const uint8_t* __restrict__ actions, MaskT* __restrict__ mask_out, uint8_t* __restrict__ status) {
   using word_t = typename G::word_t;
   typedef word_t wvec __attribute__((ext_vector_type(V)));
@@ -219,7 +219,7 @@ k_step_vec(typename G::Params p, const typename G::word_t* __restrict__ src, typ
 constexpr int kC4StepBlock = OSG_C4STEP_BLOCK;
 template <class G>
 __global__ void __launch_bounds__(kC4StepBlock)
-k_step_c4x2(typename G::Params p, const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, int64_t n,
+k_step_c4x2(typename G::Params p, const uint64_t* src, uint64_t* dst, int64_t n,  // src may BE dst (in-place step)
             const uint8_t* __restrict__ actions, uint8_t* __restrict__ mask_out, uint8_t* __restrict__ status) {
   const int64_t pair = static_cast<int64_t>(blockIdx.x) * kC4StepBlock + threadIdx.x;
   const int64_t i = pair * 2;
@@ -265,7 +265,7 @@ k_step_c4x2(typename G::Params p, const uint64_t* __restrict__ src, uint64_t* __
 // same runs, 97.8-99.7 vs 101.8-103.6 us at 2^24; workgroups of 64 / 256 / 1024: 6.73 / 6.17-6.35 / 6.16-6.19 us at
 // 2^20 and 107.7 / 99.6-102.3 / 105.0-105.8 us at 2^24).  Any batch size, no alignment requirement on the side arrays.
 __global__ void __launch_bounds__(kC4StepBlock)
-k_step_c4std(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, int64_t n, const uint8_t* __restrict__ actions,
+k_step_c4std(const uint64_t* src, uint64_t* dst, int64_t n, const uint8_t* __restrict__ actions,  // src may BE dst
              uint8_t* __restrict__ mask_out, uint8_t* __restrict__ status) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kC4StepBlock + threadIdx.x;
   if (i >= n) return;
@@ -286,7 +286,7 @@ k_step_c4std(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, int64
 // non-temporal stores the wider accesses win again (same runs, 2^20 states: 5.07-5.08 vs 5.14-5.21 us per launch;
 // 2^24 states: 86.7-88.6 vs 90.6-91.7 us).
 __global__ void __launch_bounds__(kC4StepBlock)
-k_step_c4std2(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, int64_t n, const uint8_t* __restrict__ actions,
+k_step_c4std2(const uint64_t* src, uint64_t* dst, int64_t n, const uint8_t* __restrict__ actions,  // src may BE dst
               uint8_t* __restrict__ mask_out, uint8_t* __restrict__ status) {
   const int64_t i = (static_cast<int64_t>(blockIdx.x) * kC4StepBlock + threadIdx.x) * 2;
   if (i >= n) return;
@@ -935,6 +935,19 @@ int osg_ctx_synchronize(osg_ctx* ctx) {
 }
 void* osg_ctx_stream(osg_ctx* ctx) { return ctx->stream; }
 
+int osg_ctx_trim(osg_ctx* ctx) {
+  if (!ctx || ctx->closed) return set_error(OSG_ERR_INVALID, "osg_ctx_trim: bad context");
+  OSG_HIP(hipSetDevice(ctx->device));
+  OSG_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->d_mcts_pool) OSG_HIP(hipFree(ctx->d_mcts_pool));
+  ctx->d_mcts_pool = nullptr;
+  ctx->mcts_pool_bytes = 0;
+  if (ctx->d_scratch) OSG_HIP(hipFree(ctx->d_scratch));
+  ctx->d_scratch = nullptr;
+  ctx->scratch_bytes = 0;
+  return OSG_OK;
+}
+
 int osg_batch_create(osg_ctx* ctx, const char* game_string, int64_t n, osg_batch** out) {
   if (!ctx || !out || n <= 0) return set_error(OSG_ERR_INVALID, "osg_batch_create: bad argument");
   if (ctx->closed) return set_error(OSG_ERR_INVALID, "osg_batch_create: the context was destroyed");
@@ -1115,7 +1128,10 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
   const int cmb = src->spec.desc.compact_mask_bytes;
   const int W = src->spec.desc.mask_words;
   const int64_t n = src->n;
-  if (src->spec.desc.game_kind == kC4 && src->spec.c4_std && (n & 1) == 0 &&
+  // the kernels that move several states per lane use 16-byte plane accesses: planes start 16-byte aligned when the
+  // allocation does (hipMalloc: 256 B) and n x word size is a multiple of 16 — checked here, not assumed
+  const bool planes16 = ((reinterpret_cast<uintptr_t>(src->d_words) | reinterpret_cast<uintptr_t>(dst->d_words)) & 15u) == 0;
+  if (planes16 && src->spec.desc.game_kind == kC4 && src->spec.c4_std && (n & 1) == 0 &&
       ((reinterpret_cast<uintptr_t>(d_actions) | reinterpret_cast<uintptr_t>(d_mask) | reinterpret_cast<uintptr_t>(d_status)) & 1u) == 0) {
     k_step_c4std2<<<dim3(static_cast<unsigned>((n / 2 + kC4StepBlock - 1) / kC4StepBlock)), dim3(kC4StepBlock), 0, ctx->stream>>>(
         static_cast<const uint64_t*>(src->d_words), static_cast<uint64_t*>(dst->d_words), n, d_actions,
@@ -1132,7 +1148,7 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
   }
   const bool aligned2 = ((reinterpret_cast<uintptr_t>(d_actions) | reinterpret_cast<uintptr_t>(d_mask) |
                           reinterpret_cast<uintptr_t>(d_status)) & 1u) == 0;
-  if (src->spec.desc.game_kind == kC4 && (n & 1) == 0 && aligned2) {
+  if (planes16 && src->spec.desc.game_kind == kC4 && (n & 1) == 0 && aligned2) {
     const int64_t pairs = n / 2;
     k_step_c4x2<C4><<<dim3(static_cast<unsigned>((pairs + kC4StepBlock - 1) / kC4StepBlock)), dim3(kC4StepBlock), 0, ctx->stream>>>(
         src->spec.c4, static_cast<const uint64_t*>(src->d_words), static_cast<uint64_t*>(dst->d_words), n, d_actions,
@@ -1143,14 +1159,14 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
   // one- and two-word states: V states per thread, 16-byte accesses (needs n % V == 0 and aligned side arrays)
   const uintptr_t side = reinterpret_cast<uintptr_t>(d_actions) | reinterpret_cast<uintptr_t>(d_mask) | reinterpret_cast<uintptr_t>(d_status);
   const int kind = src->spec.desc.game_kind;
-  if (kind == kTtt && (n & 3) == 0 && (side & 7u) == 0 && cmb == 2) {  // (8 states per thread measured slower)
+  if (planes16 && kind == kTtt && (n & 3) == 0 && (side & 7u) == 0 && cmb == 2) {  // (8 states per thread measured slower)
     k_step_vec<Ttt, uint16_t, 4, 1><<<dim3(grid_for(n / 4)), dim3(kBlock), 0, ctx->stream>>>(
         src->spec.ttt, static_cast<const uint32_t*>(src->d_words), static_cast<uint32_t*>(dst->d_words), n, d_actions,
         static_cast<uint16_t*>(d_mask), d_status);
     OSG_HIP(hipGetLastError());
     return OSG_OK;
   }
-  if (kind == kKuhn && (n & 1) == 0 && (side & 1u) == 0 && cmb == 1) {
+  if (planes16 && kind == kKuhn && (n & 1) == 0 && (side & 1u) == 0 && cmb == 1) {
     k_step_vec<Kuhn, uint8_t, 2, 1><<<dim3(grid_for(n / 2)), dim3(kBlock), 0, ctx->stream>>>(
         src->spec.kuhn, static_cast<const uint64_t*>(src->d_words), static_cast<uint64_t*>(dst->d_words), n, d_actions,
         static_cast<uint8_t*>(d_mask), d_status);
@@ -1161,7 +1177,7 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
   // per thread pay off only once the batch is many rounds of wavefronts (2^24 states: 106.6 vs 114.1 us), smaller
   // batches run faster with one state per thread and twice the wavefronts (2^20 states: 9.6 vs 8.9 us;
   // tools/probe_states_per_thread.py, tools/probe_kernels.py)
-  if (kind == kLeduc && n >= (int64_t{1} << 22) && (n & 1) == 0 && (side & 1u) == 0 && cmb == 1) {
+  if (planes16 && kind == kLeduc && n >= (int64_t{1} << 22) && (n & 1) == 0 && (side & 1u) == 0 && cmb == 1) {
     k_step_vec<Leduc, uint8_t, 2, 2><<<dim3(grid_for(n / 2)), dim3(kBlock), 0, ctx->stream>>>(
         src->spec.leduc, static_cast<const uint64_t*>(src->d_words), static_cast<uint64_t*>(dst->d_words), n, d_actions,
         static_cast<uint8_t*>(d_mask), d_status);

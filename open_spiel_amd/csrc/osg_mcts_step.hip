@@ -84,6 +84,10 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
 #define REMAP(i) pool.remap[static_cast<int64_t>(i) * NR + r]
   uint8_t phase = pool.phase[r];
   if (phase == kFinished) { request[r] = 0; return; }
+  // A search parked on a request whose answer the caller did not bring (NULL prior / value pointer) stays
+  // parked and asks again: never dereference a missing answer.
+  if (phase == kWantPrior && prior_in == nullptr) { request[r] = pool.node[r] == 0 ? 5 : 1; return; }
+  if (phase == kWantValue && value_in == nullptr) { request[r] = 2; return; }
   uint32_t used = pool.used[r];
   int gc_limit = pool.gc_limit[r];
   int sims_done = pool.sims[r];
@@ -429,6 +433,7 @@ extern "C" {
 int osg_mcts_tree_create(const osg_batch* roots, const osg_mcts_cfg* cfg_in, int flags, osg_mcts_tree** out) {
   if (!roots || !cfg_in || !out) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_create: null argument");
   osg_ctx* ctx = roots->ctx;
+  if (ctx->closed) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_create: the context was destroyed");
   const osg_game_desc& d = roots->spec.desc;
   const bool board = d.game_kind <= kHex;
   if (cfg_in->max_simulations < 1 || cfg_in->n_rollouts < 1)

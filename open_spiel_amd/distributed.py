@@ -48,18 +48,32 @@ class ShardedMccfr:
       mccfr_delta_tables() -> (regret_delta, policy_delta) tensors (views, same device)
       mccfr_apply_deltas()
     Every rank ends each mini-batch with identical tables.
+
+    overlap=True (the solver must also offer mccfr_new_delta_buffer / mccfr_sample_into /
+    mccfr_apply_deltas_from): two delta buffers; the all-reduce of mini-batch k is issued asynchronously
+    (torch.distributed runs it on the process group's own stream) and mini-batch k + 1 is sampled while it is
+    in flight, against tables that do not hold k's deltas yet (stale by one mini-batch); k's deltas are folded
+    when they have arrived, before mini-batch k + 2.  finish() folds what is still pending.  Ranks still end
+    with identical tables; the schedule differs from the synchronous one (a different, still convergent,
+    sequence of tables), which is why time-to-NashConv is reported for both (bench.py secondary.mccfr.quality).
     """
 
-    def __init__(self, solver):
+    def __init__(self, solver, overlap=False):
         self.solver = solver
         self.rank, self.world_size = world()
         self.trajectories_done = 0
+        self.overlap = bool(overlap)
         self._flat = None
+        self._bufs = None
+        self._pending = None   # (buffer index, work handle or None)
+        self._k = 0
 
     def run_minibatch(self, seed, trajectories):
         """One mini-batch of `trajectories` traversals (global count) starting at the
         running global trajectory index; returns the number this rank sampled."""
         first, count = shard_range(trajectories, self.rank, self.world_size)
+        if self.overlap:
+            return self._run_overlapped(seed, trajectories, first, count)
         self.solver.mccfr_sample(seed, count, first_trajectory=self.trajectories_done + first)
         if self.world_size > 1:
             if hasattr(self.solver, "mccfr_delta_flat"):
@@ -74,6 +88,35 @@ class ShardedMccfr:
         self.solver.mccfr_apply_deltas()
         self.trajectories_done += int(trajectories)
         return count
+
+    def _run_overlapped(self, seed, trajectories, first, count):
+        if self._bufs is None:
+            self._bufs = [self.solver.mccfr_new_delta_buffer(), self.solver.mccfr_new_delta_buffer()]
+        cur = self._k & 1
+        buf = self._bufs[cur]
+        # the buffer's previous deltas (mini-batch k - 2) were folded during mini-batch k - 1
+        self.solver.mccfr_sample_into(buf, seed, count, first_trajectory=self.trajectories_done + first)
+        work = None
+        if self.world_size > 1:
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+        self._fold_pending()                       # mini-batch k - 1: waits for ITS all-reduce only
+        self._pending = (cur, work)
+        self._k += 1
+        self.trajectories_done += int(trajectories)
+        return count
+
+    def _fold_pending(self):
+        if self._pending is None:
+            return
+        idx, work = self._pending
+        if work is not None:
+            work.wait()    # device tensors: the current stream waits, the host does not
+        self.solver.mccfr_apply_deltas_from(self._bufs[idx])
+        self._pending = None
+
+    def finish(self):
+        """Fold the deltas still in flight (overlap=True); a no-op otherwise."""
+        self._fold_pending()
 
 
 def gather_root_results(local, total_roots):

@@ -47,6 +47,10 @@ class Context:
     def synchronize(self):
         check(lib().osg_ctx_synchronize(self._h))
 
+    def trim(self):
+        """Free what the context caches between calls (the MCTS node pool, the staging buffer)."""
+        check(lib().osg_ctx_trim(self._h))
+
     def close(self):
         if self._h:
             lib().osg_ctx_destroy(self._h)
@@ -447,6 +451,26 @@ class TabularSolver:
 
     def mccfr_apply_deltas(self):
         check(lib().osg_mccfr_apply_deltas(self._h))
+
+    def mccfr_new_delta_buffer(self):
+        """A caller-owned [2, I, Amax] fp64 device buffer (regret deltas | average-policy deltas) for
+        mccfr_sample_into / mccfr_apply_deltas_from: two of them double-buffer the exchange step."""
+        return torch.zeros((2, self.num_infostates, self.amax), dtype=torch.float64, device=self.ctx.device)
+
+    def _delta_buffer_ptr(self, buf, what):
+        want = (2, self.num_infostates, self.amax)
+        if (not isinstance(buf, torch.Tensor) or buf.dtype != torch.float64 or tuple(buf.shape) != want
+                or not buf.is_contiguous() or buf.device != self.ctx.device):
+            raise OsgError(f"{what}: expected a contiguous float64 tensor of shape {want} on {self.ctx.device}")
+        return buf.data_ptr()
+
+    def mccfr_sample_into(self, buf, seed, trajectories, first_trajectory=0):
+        """Traversals only, deltas left in the caller's buffer (osg_mccfr_sample_into)."""
+        check(lib().osg_mccfr_sample_into(self._h, int(seed), int(first_trajectory), int(trajectories),
+                                          self._delta_buffer_ptr(buf, "mccfr_sample_into")))
+
+    def mccfr_apply_deltas_from(self, buf):
+        check(lib().osg_mccfr_apply_deltas_from(self._h, self._delta_buffer_ptr(buf, "mccfr_apply_deltas_from")))
 
     def tables(self):
         I, A = self.num_infostates, self.amax

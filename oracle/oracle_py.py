@@ -198,6 +198,12 @@ class Game:
                                      C.byref(sims)))
         return secs.value, sims.value
 
+    def bench_mcts_config1(self, max_simulations, repeats):
+        """BASELINE.json configs[0]: the mcts_test.cc:35-49 bot on tic_tac_toe, 4 positions x repeats searches."""
+        secs, sims = C.c_double(0), C.c_int64(0)
+        _check(lib().osgo_bench_mcts_config1(self._h, max_simulations, repeats, C.byref(secs), C.byref(sims)))
+        return secs.value, sims.value
+
     def bench_cfr(self, kind, iters, threads):
         secs = C.c_double(0)
         _check(lib().osgo_bench_cfr(self._h, kind, iters, threads, C.byref(secs)))

@@ -1069,6 +1069,45 @@ int osgo_bench_mcts(void* g, uint64_t seed, int roots, int depth_mod,
     return 0;
   });
 }
+// (c') BASELINE.json configs[0], the reference's own mcts_test.cc:35-49 setup: tic_tac_toe
+// MCTSBot(RandomRolloutEvaluator(20, 42), uct_c = 2, max_simulations, max_memory_mb = 5, solve = true, seed 42,
+// verbose = false), MCTSearch from the initial state and from the three MCTS-Solver positions of
+// mcts_test.cc:126-155, `repeats` times; units = simulations (root explore_count; a solved root stops early).
+int osgo_bench_mcts_config1(void* g, int max_simulations, int repeats, double* secs, int64_t* sims) {
+  return Guard([&] {
+    const Game& game = *static_cast<GameH*>(g)->game;
+    const char* lines[4] = {"", "x(1,1) o(0,0) x(2,2)", "x(1,1) o(0,0) x(2,2) o(0,1) x(0,2)", "x(0,1) o(2,2)"};
+    std::vector<std::unique_ptr<State>> starts;
+    for (const char* line : lines) {
+      std::unique_ptr<State> s = game.NewInitialState();
+      std::string rest = line;
+      while (!rest.empty()) {
+        const size_t sp = rest.find(' ');
+        const std::string tok = rest.substr(0, sp);
+        rest = sp == std::string::npos ? "" : rest.substr(sp + 1);
+        bool found = false;
+        for (Action a : s->LegalActions())
+          if (s->ActionToString(s->CurrentPlayer(), a) == tok) { s->ApplyAction(a); found = true; break; }
+        if (!found) throw std::runtime_error("osgo_bench_mcts_config1: no legal action " + tok);
+      }
+      starts.push_back(std::move(s));
+    }
+    int64_t count = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int rep = 0; rep < repeats; ++rep) {
+      for (const auto& start : starts) {
+        auto ev = std::make_shared<RandomRolloutEvaluator>(20, 42);
+        MCTSBot bot(game, ev, 2.0, max_simulations, 5, true, 42, false);
+        std::unique_ptr<SearchNode> root = bot.MCTSearch(*start);
+        count += root->explore_count;
+      }
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    *secs = std::chrono::duration<double>(t1 - t0).count();
+    *sims = count;
+    return 0;
+  });
+}
 // (d) solver iterations/s (kind as in osgo_cfr_create); one solver per thread.
 int osgo_bench_cfr(void* g, int kind, int iters, int threads, double* secs) {
   return Guard([&] {

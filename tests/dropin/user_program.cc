@@ -1,9 +1,9 @@
 // Source-level drop-in check: ONE user program, written against the reference's C++ API
-// in the style of open_spiel/examples/{example,mcts_example,cfr_example}.cc, compiled twice:
-//   * default:            against the GENUINE reference headers, linked with oracle/_ref/libspiel_ref.so
-//   * -DOSG_DROPIN_HIP:   against the MI355X host mirror (open_spiel_amd/csrc/host/osg_spiel.h),
-//                         linked with open_spiel_amd/libosg_hip.so
-// The only difference between the two builds is the include block and the two namespace aliases below.
+// in the style of open_spiel/examples/{example,mcts_example,cfr_example}.cc, compiled twice FROM THE SAME TEXT — no
+// #ifdef, no namespace switch; only the include path and the library differ:
+//   * -I /root/reference (+ the abseil stand-ins):  the GENUINE reference headers, linked with oracle/_ref/libspiel_ref.so
+//   * -I <repo>/include:                            the MI355X drop-in headers (include/open_spiel/** -> the host
+//                                                   mirror over the C-ABI), linked with open_spiel_amd/libosg_hip.so
 // Both print the same transcript; tests/test_dropin.py builds both (CPU), runs the reference build and
 // keeps its transcript, and tests/test_z2_gpu_dropin.py runs the mirror build on the GPU and compares.
 // Every line is deterministic: fixed move choices, the full-tree CFR family, MCTS-Solver proofs.
@@ -14,11 +14,6 @@
 #include <string>
 #include <vector>
 
-#ifdef OSG_DROPIN_HIP
-#include "open_spiel_amd/csrc/host/osg_spiel.h"
-namespace spiel = open_spiel::hip;
-namespace algos = open_spiel::hip::algorithms;
-#else
 #include "open_spiel/algorithms/best_response.h"
 #include "open_spiel/algorithms/cfr.h"
 #include "open_spiel/algorithms/cfr_br.h"
@@ -31,7 +26,6 @@ namespace algos = open_spiel::hip::algorithms;
 #include "open_spiel/spiel.h"
 namespace spiel = open_spiel;
 namespace algos = open_spiel::algorithms;
-#endif
 
 using spiel::Action;
 

@@ -19,9 +19,10 @@ def build_reference_variant(out_path):
 
 
 def build_hip_variant(out_path):
-    """The SAME source with -DOSG_DROPIN_HIP: the MI355X host mirror + open_spiel_amd/libosg_hip.so."""
+    """The SAME source, not a character changed, with the product's drop-in headers on the include path
+    (include/open_spiel/** -> the MI355X host mirror) + open_spiel_amd/libosg_hip.so."""
     lib_dir = os.path.join(ROOT, "open_spiel_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", "-pthread", "-DOSG_DROPIN_HIP", "-I", ROOT, SOURCE,
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", "-pthread", "-I", os.path.join(ROOT, "include"), SOURCE,
                            "-o", out_path, "-L", lib_dir, "-losg_hip", f"-Wl,-rpath,{lib_dir}"])
 
 

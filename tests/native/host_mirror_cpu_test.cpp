@@ -47,6 +47,26 @@ int main() {
   std::vector<uint32_t> pm{Meta(0xFF, 1, 1, false, 0, false), Meta(1, 1, 0, true, 0, true)};
   std::unique_ptr<SearchNode> pr = MCTSBot::SearchTreeFromArrays(pm, {1, 0}, {6, 4}, {3.0, -8.0}, {1.0, 1.0}, 1, 3, false);
   EXPECT(pr->children[0].outcome.size() == 3 && pr->children[0].outcome[1] == -2.0 && pr->children[0].outcome[0] == 0.0);
+  // CompareFinal with a solved child under a CHANCE parent (player == kChancePlayerId == -1): the reference reads
+  // outcome[player] only for 0 <= player < outcome.size() (mcts.cc:114-118) — such a child compares as outcome 0,
+  // never through outcome[-1]
+  {
+    SearchNode chance_parent;
+    chance_parent.player = 0;
+    SearchNode a, b, c;
+    a.action = 0; a.player = kChancePlayerId; a.explore_count = 3; a.total_reward = 1.0; a.outcome = {1.0, -1.0};
+    b.action = 1; b.player = kChancePlayerId; b.explore_count = 7; b.total_reward = -2.0; b.outcome = {-1.0, 1.0};
+    c.action = 2; c.player = kChancePlayerId; c.explore_count = 7; c.total_reward = -1.0;
+    EXPECT(a.CompareFinal(b) && !b.CompareFinal(a));   // both count as outcome 0: decided on visits (3 < 7)
+    EXPECT(b.CompareFinal(c) && !c.CompareFinal(b));   // equal visits: total reward (-2 < -1)
+    chance_parent.children = {a, b, c};
+    EXPECT(chance_parent.BestChild().action == 2);
+    SearchNode wide;  // a player index beyond the outcome vector is ignored as well
+    wide.player = 5; wide.explore_count = 1; wide.outcome = {1.0, -1.0};
+    SearchNode plain;
+    plain.player = 0; plain.explore_count = 2;
+    EXPECT(wide.CompareFinal(plain));
+  }
   // dirichlet_noise (mcts.cc:188-203): a distribution, reproducible from the generator
   std::mt19937 a(5), b(5);
   std::vector<double> n1 = algorithms::dirichlet_noise(7, 0.3, &a), n2 = algorithms::dirichlet_noise(7, 0.3, &b);

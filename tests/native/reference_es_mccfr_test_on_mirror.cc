@@ -1,5 +1,5 @@
 // The reference's own algorithms/external_sampling_mccfr_test.cc, INCLUDED UNMODIFIED, against the MI355X host
-// mirror (see tests/mirror_shim).  Its main() also solves liars_dice, which is outside the hot path; this main()
+// mirror (see include/open_spiel).  Its main() also solves liars_dice, which is outside the hot path; this main()
 // calls the other tests with the reference's own arguments and ONE generator carried through them, as the
 // reference does — and because RunIteration(std::mt19937*) consumes the generator exactly as the reference's does,
 // the runs follow the reference's draw for draw (the NashConv values printed are the reference's own).

@@ -1,5 +1,5 @@
 // The reference's own algorithms/mcts_test.cc, INCLUDED UNMODIFIED, compiled against the MI355X host mirror
-// (tests/mirror_shim resolves its "open_spiel/..." includes to the mirror; its abseil includes resolve to the
+// (include/open_spiel resolves its "open_spiel/..." includes to the mirror; its abseil includes resolve to the
 // private stand-ins under oracle/ref_shim) and run on the device.  Two of its ten tests load games outside the
 // hot path (catch, pig) and are not called; the other eight run as written: self-play through the Bot interface
 // and EvaluateBots, sampling from the prior at 0 / 1 simulations, the three MCTS-Solver known answers, the

@@ -1,5 +1,5 @@
 // The reference's own algorithms/outcome_sampling_mccfr_test.cc, INCLUDED UNMODIFIED, against the MI355X host
-// mirror (see tests/mirror_shim); liars_dice (outside the hot path) is left out of main().
+// mirror (see include/open_spiel); liars_dice (outside the hot path) is left out of main().
 #define main reference_test_main
 #include "open_spiel/algorithms/outcome_sampling_mccfr_test.cc"
 #undef main

@@ -43,6 +43,20 @@ class FakeSolver:
     def mccfr_apply_deltas(self):
         self.tables += self.deltas
 
+    # the double-buffered protocol (ShardedMccfr(overlap=True)): caller-owned delta buffers
+    def mccfr_new_delta_buffer(self):
+        return torch.zeros((2, self.I, self.A), dtype=torch.float64)
+
+    def mccfr_sample_into(self, buf, seed, count, first_trajectory=0):
+        self.mccfr_sample(seed, count, first_trajectory)
+        buf.copy_(self.deltas)
+        self.sampled_against.append(self.tables.clone())
+
+    def mccfr_apply_deltas_from(self, buf):
+        self.tables += buf
+
+    sampled_against = None
+
 
 class FakeFlatSolver(FakeSolver):
     """Same, but exposing the one-allocation view like the device solver."""
@@ -75,8 +89,18 @@ def _worker(rank, world_size, port, out_dir):
         vis = torch.tensor([[1 + rank, 0, 5], [2, 0, 5 - rank], [0, 0, 1]], dtype=torch.int32)
         rew = torch.tensor([[0.5, 0.0, -1.0], [1.0, 0.0, 2.0 * rank], [0.0, 0.0, 0.25]], dtype=torch.float64)
         root_stats = osd.reduce_root_statistics(vis, rew)
+        # the overlapped schedule: all-reduce of mini-batch k in flight while k + 1 is sampled
+        lap = FakeSolver()
+        lap.sampled_against = []
+        over = osd.ShardedMccfr(lap, overlap=True)
+        for t in (1, 5, 64, 1001):
+            over.run_minibatch(seed=11, trajectories=t)
+        before_finish = lap.tables.clone()
+        over.finish()
         torch.save({"tables": solver.tables, "root_stats": root_stats, "sampled": sampled, "gathered": gathered,
-                    "done": sharded.trajectories_done}, os.path.join(out_dir, f"rank{rank}.pt"))
+                    "done": sharded.trajectories_done, "overlap_tables": lap.tables, "overlap_before_finish": before_finish,
+                    "overlap_sampled_against": lap.sampled_against},
+                   os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -118,6 +142,58 @@ def test_mccfr_delta_allreduce_world2_equals_world1(tmp_path):
         assert best == 2                       # most visits wins; action 1 was never visited
     want = (torch.arange(7, dtype=torch.int32) * 10).unsqueeze(1)
     assert torch.equal(r0["gathered"], want) and torch.equal(r1["gathered"], want)
+    # overlapped (stale-by-one) schedule: the same deltas arrive, one mini-batch late — identical tables on both
+    # ranks, equal to the synchronous result once finish() has folded the last mini-batch, and mini-batch k was
+    # sampled against the tables holding the deltas of mini-batches < k - 1 only
+    assert torch.equal(r0["overlap_tables"], r1["overlap_tables"])
+    assert torch.equal(r0["overlap_tables"], ref.tables)
+    assert not torch.equal(r0["overlap_before_finish"], ref.tables)
+    stale = FakeSolver()
+    stale.sampled_against = []
+    one = osd.ShardedMccfr(stale, overlap=True)
+    for t in (1, 5, 64, 1001):
+        one.run_minibatch(seed=11, trajectories=t)
+    one.finish()
+    assert torch.equal(stale.tables, ref.tables)
+    for a, b in zip(stale.sampled_against, r0["overlap_sampled_against"]):
+        assert torch.equal(a, b), "the tables a mini-batch is sampled against must not depend on the world size"
+    fresh = torch.full((2, FakeSolver.I, FakeSolver.A), 1e-6, dtype=torch.float64)
+    assert torch.equal(stale.sampled_against[0], fresh) and torch.equal(stale.sampled_against[1], fresh)
+    assert not torch.equal(stale.sampled_against[2], fresh)
+
+
+def test_bench_gpus_n_starts_n_ranks_by_itself(monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment re-executes itself under
+    torch.distributed.run with one rank per GPU on a 127.0.0.1 port (the command the docstring shows);
+    here only the command is checked (the run itself needs GPUs: tests/test_gpu_fullsize.py)."""
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.setenv("RANK", "7")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert "RANK" not in seen["env"] and "WORLD_SIZE" not in seen["env"] and seen["env"]["OSG_BENCH_SPAWNED"] == "1"
+    # inside the spawned ranks (WORLD_SIZE set by the launcher) nothing is spawned again
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("OSG_BENCH_SPAWNED", "1")
+    seen.clear()
+    with pytest.raises(BaseException):
+        bench.main()    # goes on to the devices, which this box does not have
+    assert not seen
 
 
 def test_cpp_host_shard_range_equals_the_python_one(tmp_path):

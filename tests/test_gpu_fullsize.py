@@ -227,22 +227,35 @@ def test_hex9_2pow16_roots_rollouts(ctx):
 
 
 def test_bench_two_ranks_code_path(tmp_path):
-    """bench.py's N=2 path end to end (sharded roots / trajectories, delta all-reduce, max-over-ranks
-    timing) with two ranks sharing this box's GPU over gloo — the RCCL run itself is the driver's."""
+    """`python bench.py --gpus 2` — no torchrun on the command line: bench.py starts its two ranks itself — end to
+    end (sharded roots / trajectories, delta all-reduce, max-over-ranks timing, per-rank rates, the strong-scaling
+    efficiency against the same run's one-rank search, the roofline legs and the overlapped ES-MCCFR schedule), with
+    the two ranks sharing this box's GPU over gloo — the RCCL run itself needs two GPUs
+    (tests/test_z7_gpu_exchange_steps.py::test_bench_gpus_2_over_rccl)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, OSG_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--no-cpu-baseline", "--states", str(1 << 16)]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-pmc", "--states", str(1 << 16)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["value"] > 0
-    assert line["secondary"]["mcts"]["value"] > 0 and line["secondary"]["mccfr"]["tables_finite"]
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["collective_backend"] == "gloo"
+    assert len(line["per_rank"]["env_steps_per_s"]) == 2 and min(line["per_rank"]["env_steps_per_s"]) > 0
+    assert "copy_ceiling" in line["roofline"] and "persistent" in line
+    sec = line["secondary"]
+    assert "error" not in sec, sec
+    assert sec["mcts"]["value"] > 0 and len(sec["mcts"]["per_rank_sims_per_s"]) == 2
+    assert sec["mcts"]["single_rank_all_roots"]["value"] > 0 and sec["mcts"]["strong_scaling_efficiency"] > 0
+    assert sec["mccfr"]["tables_finite"] and sec["mccfr"]["allreduce_us"] > 0 and sec["mccfr"]["allreduce_bytes"] == 44928
+    q = sec["mccfr"]["quality"]
+    assert q["world"] == 2 and q["nash_conv"] < 4.7 and q["overlapped"]["nash_conv"] < 4.7
+    assert sec["ttt_mcts"]["device_single_root"]["value"] > 0
 
 
 def test_hex9_mcts_2pow16_roots_under_full_load(oracle, ctx):

@@ -118,6 +118,33 @@ def test_fused_step_parity(oracle, ctx, game, n):
     np.testing.assert_array_equal(a.returns().cpu().numpy(), rec["returns"][:, L])
 
 
+@pytest.mark.parametrize("game", ["tic_tac_toe", "kuhn_poker", "leduc_poker", "connect_four", "hex(board_size=9)",
+                                  "connect_four(rows=5,columns=6,x_in_row=3)"])
+@pytest.mark.parametrize("n", [4096, 4097, 1 << 17])
+def test_fused_step_in_place_equals_out_of_place(ctx, game, n):
+    """step(dst=None) hands the kernels src == dst (the state planes carry no __restrict__ for that reason): the
+    in-place step must leave the successor records, masks and status bytes of the out-of-place one, for the
+    several-states-per-thread kernels (even n) and the one-state ones (odd n), over a whole game."""
+    import torch
+    import open_spiel_amd as osa
+    a = osa.StateBatch(ctx, game, n)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(n)
+    for _ in range(a.desc.max_game_length + 2):
+        lm = a.legal_actions_mask()
+        noise = torch.rand(lm.shape, device="cuda", generator=gen)
+        acts = torch.where(lm.any(1), (lm.to(torch.float32) * (noise + 0.01)).argmax(1),
+                           torch.full((n,), 255, device="cuda")).to(torch.uint8)
+        acts[::53] = 251   # illegal ones are refused the same way in both forms
+        b = osa.StateBatch(ctx, game, n)
+        m_out, s_out = a.step(acts, dst=b)
+        m_in, s_in = a.step(acts)          # in place
+        assert torch.equal(m_in, m_out) and torch.equal(s_in, s_out)
+        assert (a.raw_words() == b.raw_words()).all()
+        if bool(((s_in & 0x80) != 0).all()):
+            break
+
+
 @pytest.mark.parametrize("game", ["connect_four", "hex(board_size=9)", "hex(board_size=5)", "leduc_poker", "tic_tac_toe"])
 @pytest.mark.parametrize("n", [1, 3, 37, 64, 257, 1000])
 def test_observation_ragged_sizes_and_unaligned_output(ctx, game, n):

@@ -576,3 +576,61 @@ def test_tabular_best_response(pyspiel, oracle):
     leduc = pyspiel.load_game("leduc_poker")
     vals = [pyspiel.TabularBestResponse(leduc, p, pyspiel.UniformPolicy()).value("") for p in (0, 1)]
     assert abs(sum(vals) / 2 - 2.373611111111111) < 1e-12
+
+
+def test_pyspiel_alias_package_without_a_gpu():
+    """`import pyspiel` (repository root on sys.path) is the reference's module name over pyspiel_hip: same objects,
+    the game submodules importable as pyspiel.<game>, per-game virtual Game classes."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    had = sys.modules.pop("pyspiel", None)      # (other tests install a stand-in module under this name)
+    try:
+        pyspiel = importlib.import_module("pyspiel")
+        from open_spiel_amd import pyspiel_hip
+        assert pyspiel.load_game is pyspiel_hip.load_game and pyspiel.MCTSBot is pyspiel_hip.MCTSBot
+        assert pyspiel.CFRSolver is pyspiel_hip.CFRSolver and pyspiel.State is pyspiel_hip.State
+        ttt = importlib.import_module("pyspiel.tic_tac_toe")
+        assert ttt is pyspiel.tic_tac_toe and ttt.CellState.CROSS == pyspiel_hip.tic_tac_toe.CellState.CROSS
+        from pyspiel import leduc_poker, connect_four, kuhn_poker  # noqa: F401
+        game = pyspiel.load_game("tic_tac_toe")
+        assert isinstance(game, pyspiel.tic_tac_toe.TicTacToeGame)
+        assert not isinstance(game, pyspiel.connect_four.ConnectFourGame)
+        assert isinstance(pyspiel.load_game("leduc_poker(players=3)"), pyspiel.leduc_poker.LeducGame)
+        assert not isinstance(3, pyspiel.tic_tac_toe.TicTacToeState)
+        with pytest.raises(TypeError):
+            pyspiel.tic_tac_toe.TicTacToeState()
+    finally:
+        sys.modules.pop("pyspiel", None)
+        for k in [k for k in sys.modules if k.startswith("pyspiel.")]:
+            sys.modules.pop(k)
+        if had is not None:
+            sys.modules["pyspiel"] = had
+
+
+@pytest.mark.gpu
+def test_per_game_state_classes_through_the_alias(pyspiel):
+    """isinstance(state, pyspiel.<game>.<Game>State) as user code of the reference writes it
+    (games_tic_tac_toe.cc:75, games_connect_four.cc:75, games_leduc_poker.cc:39)."""
+    import importlib
+    import sys
+    had = sys.modules.pop("pyspiel", None)
+    try:
+        alias = importlib.import_module("pyspiel")
+        s = alias.load_game("tic_tac_toe").new_initial_state()
+        assert isinstance(s, alias.State) and isinstance(s, alias.tic_tac_toe.TicTacToeState)
+        assert not isinstance(s, alias.leduc_poker.LeducState)
+        s.apply_action(4)
+        assert isinstance(s.clone(), alias.tic_tac_toe.TicTacToeState) and s.board()[4] == alias.tic_tac_toe.CellState.CROSS
+        ls = alias.load_game("leduc_poker").new_initial_state()
+        assert isinstance(ls, alias.leduc_poker.LeducState) and not isinstance(ls, alias.connect_four.ConnectFourState)
+        assert isinstance(alias.load_game("connect_four").new_initial_state(), alias.connect_four.ConnectFourState)
+    finally:
+        sys.modules.pop("pyspiel", None)
+        for k in [k for k in sys.modules if k.startswith("pyspiel.")]:
+            sys.modules.pop(k)
+        if had is not None:
+            sys.modules["pyspiel"] = had

@@ -266,7 +266,9 @@ int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg, int32_t* be
  * cfg as for osg_mcts_search (layout ignored: one lane per root; the tree-policy streams are those of layout 1,
  * so with osg_mcts_tree_rollout_values as the evaluator the search is osg_mcts_search's, draw for draw).
  * flags: 1 = priors come from the caller (else uniform over the legal actions, RandomRolloutEvaluator::Prior
- * mcts.cc:74-87; chance nodes always use their ChanceOutcomes()); 2 = dont_return_chance_node (mcts.h:168). */
+ * mcts.cc:74-87; chance nodes always use their ChanceOutcomes()); 2 = dont_return_chance_node (mcts.h:168);
+ * 4 = leaves are evaluated inside the launch by RandomRolloutEvaluator(cfg.n_rollouts, cfg.seed) on the streams of
+ * osg_mcts_tree_rollout_values: no request 2 is ever reported, and without flag 1 a whole search is one call. */
 typedef struct osg_mcts_tree osg_mcts_tree;
 int osg_mcts_tree_create(const osg_batch* roots, const osg_mcts_cfg* cfg, int flags, osg_mcts_tree** out);
 int osg_mcts_tree_destroy(osg_mcts_tree* t);

@@ -750,24 +750,30 @@ class MCTSBot : public Bot {
     }
     osg_mcts_cfg cfg = Config();
     const bool host_priors = rollout_ == nullptr || dirichlet_alpha_ > 0;
-    const int flags = (host_priors ? 1 : 0) | (dont_return_chance_node_ ? 2 : 0);
+    // RandomRolloutEvaluator: the leaves are evaluated inside the launch (flag 4) — with its uniform prior a whole
+    // search is ONE kernel launch; any other evaluator is asked through the request / answer rounds below
+    const int flags = (host_priors ? 1 : 0) | (dont_return_chance_node_ ? 2 : 0) | (rollout_ ? 4 : 0);
     osg_mcts_tree* tree = nullptr;
     Check(osg_mcts_tree_create(state.Batch().handle(), &cfg, flags, &tree));
     struct Guard { osg_mcts_tree* t; ~Guard() { osg_mcts_tree_destroy(t); } } guard{tree};
     BatchedState leaf(state.GetGame(), 1);
     std::vector<double> prior(num_actions_), value(num_players_);
     const auto start = std::chrono::steady_clock::now();
+    // max_wall_clock_time > 0 replaces the simulation bound (mcts.cc:362-366): the search runs in slices of
+    // simulations and the clock is read between them
+    const int slice = max_wall_clock_time_ > 0 ? 64 : (1 << 30);
     bool have_prior = false, have_value = false, device_value = false;
     for (;;) {
       int64_t counts[4];
       Check(osg_mcts_tree_advance_host(tree, leaf.handle(), have_prior ? prior.data() : nullptr,
-                                       have_value ? value.data() : nullptr, device_value ? 1 : 0, nullptr, 1 << 30, counts));
+                                       have_value ? value.data() : nullptr, device_value ? 1 : 0, nullptr, slice, counts));
       have_prior = have_value = device_value = false;
-      if (counts[1] == 0 && counts[2] == 0) break;
+      if (counts[0] == 1) break;  // finished: the simulation bound, a proven root or a single root child
       if (max_wall_clock_time_ > 0 &&
           std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count() >= max_wall_clock_time_)
         break;
-      if (counts[2] && rollout_) {  // RandomRolloutEvaluator::Evaluate on the device
+      if (counts[3]) continue;    // paused between two slices: nothing wanted
+      if (counts[2] && rollout_) {  // (only without flag 4) RandomRolloutEvaluator::Evaluate on the device
         Check(osg_mcts_tree_rollout_values(tree, leaf.handle(), nullptr));
         device_value = true;
         continue;
@@ -849,7 +855,9 @@ class MCTSBot : public Bot {
   osg_mcts_cfg Config() const {
     osg_mcts_cfg cfg{};
     cfg.uct_c = uct_c_;
-    cfg.max_simulations = max_simulations_;
+    // wall-clock mode: the clock is the bound (mcts.cc:362-366); the device tree still needs a finite one for its
+    // log table — 2^20 simulations per search, with the node budget of max_memory_mb collecting garbage as usual
+    cfg.max_simulations = max_wall_clock_time_ > 0 ? (1 << 20) : max_simulations_;
     cfg.n_rollouts = rollout_ ? rollout_->n_rollouts() : 1;
     cfg.solve = solve_ ? 1 : 0;
     // max_nodes_ = (max_memory_mb << 20) / sizeof(SearchNode) + 1 (mcts.cc:214) with the reference's 88-byte

@@ -67,6 +67,9 @@ struct osg_ctx {
   size_t mcts_pool_bytes = 0;
   double* d_mcts_logs = nullptr;            // log(n) table shared with the host libm
   int mcts_logs_n = 0;
+  int32_t* d_mcts_queue = nullptr;          // wave-per-root search as a work queue: [0] next ticket, [1..256] the cost
+  int64_t mcts_queue_roots = 0;             // histogram / bucket offsets, then the root order [roots] (grow-only)
+  int num_cus = 0;
   // Lifetime: the creator holds one reference, every batch / solver / communicator made on the context
   // another; osg_ctx_destroy drops the creator's, and the device resources go with the last one, so a
   // batch destroyed after its context (garbage-collection order in a binding) never touches freed memory.

@@ -6,6 +6,8 @@
 // is a fully coalesced 256-512 B transaction per wave.  All kernels are
 // HBM-bound byte/integer work: no MFMA, no LDS needed for the pure step path
 // (the state lives in VGPRs between load and store).
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <type_traits>
@@ -209,6 +211,74 @@ k_step_vec(typename G::Params p, const typename G::word_t* src, typename G::word
   }
   __builtin_nontemporal_store(mv, reinterpret_cast<mvec*>(mask_out + i));
   __builtin_nontemporal_store(sv, reinterpret_cast<bvec*>(status + i));
+}
+
+// hex: the fused step with V consecutive states per thread.  A hex(9) state is 13 planes of 32-bit words: with one
+// state per thread every plane access moves 4 bytes per lane (256 B per wave-instruction, 26 such streams per launch);
+// with V = 2 it is 8 bytes per lane and plane, and the V legal masks of a thread (NW words each, rows of the [n, NW]
+// output) are one contiguous span written as NW vectors.  kNt: the successor records, masks and status bytes leave
+// through non-temporal stores (batches beyond the Infinity Cache).  The rules are the generic HexT<NW>::legal /
+// apply on a register-resident mini-batch (the flood runs only for a placement that touches an edge-connected
+// group or an edge, hex.cc:253-276).  Measured (MI355X, 118 B per step, profiles/r03_hex_step.log; V:nt):
+//   2^20 states  1:0 22.2 us   2:0 20.1 us   2:1 23.4   4:0 23.2   4:1 29.0
+//   2^22 states  1:0 90.2 us   2:0 97.0      2:1 80.8   4:0 99.5   4:1 96.3
+//   2^24 states  1:0 334.7 us  2:0 335.3     2:1 330.1  4:0 337.7  4:1 350.7   (0.74-0.75 of 8 TB/s: DRAM)
+// Four states per thread (94 vector registers, four divergent floods in a row) never pays; two do, with ordinary
+// stores while the batch fits the Infinity Cache and non-temporal ones beyond.
+template <int NW, int V, bool kNt>
+__global__ void __launch_bounds__(kBlock)
+k_step_hexvec(typename HexT<NW>::Params p, const uint32_t* src, uint32_t* dst, int64_t n,  // src may BE dst
+              const uint8_t* __restrict__ actions, uint32_t* __restrict__ mask_out, uint8_t* __restrict__ status) {
+  using G = HexT<NW>;
+  constexpr int W = 4 * NW + 1;
+  typedef uint32_t wvec __attribute__((ext_vector_type(V)));
+  typedef uint8_t bvec __attribute__((ext_vector_type(V)));
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * V;
+  if (i >= n) return;
+  uint32_t tmp[W * V];  // plane-major mini-batch: G::load(p, tmp, V, j) reads tmp[w * V + j]
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    const wvec v = *reinterpret_cast<const wvec*>(src + w * n + i);
+#pragma unroll
+    for (int j = 0; j < V; ++j) tmp[w * V + j] = v[j];
+  }
+  const bvec av = *reinterpret_cast<const bvec*>(actions + i);
+  uint32_t mk[NW * V];  // the thread's V mask rows, in output order
+  bvec sv;
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    typename G::State s = G::load(p, tmp, V, j);
+    const int a = av[j];
+    bool illegal = false;
+    if (a != 0xFF) {
+      const Mask before = G::legal(p, s);
+      if (a < 32 * kMaskWords && before.test(a)) G::apply(p, s, a); else illegal = true;
+    }
+    G::store(p, tmp, V, j, s);
+    const bool term = G::terminal(p, s);
+    const Mask after = G::legal(p, s);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mk[j * NW + w] = after.w[w];
+    sv[j] = encode_status(term, illegal, term ? 0 : G::current_player(p, s), term ? G::outcome_code(p, s) : 0);
+  }
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    wvec v;
+#pragma unroll
+    for (int j = 0; j < V; ++j) v[j] = tmp[w * V + j];
+    if constexpr (kNt) __builtin_nontemporal_store(v, reinterpret_cast<wvec*>(dst + w * n + i));
+    else *reinterpret_cast<wvec*>(dst + w * n + i) = v;
+  }
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    wvec v;
+#pragma unroll
+    for (int j = 0; j < V; ++j) v[j] = mk[k * V + j];
+    if constexpr (kNt) __builtin_nontemporal_store(v, reinterpret_cast<wvec*>(mask_out + i * NW) + k);
+    else reinterpret_cast<wvec*>(mask_out + i * NW)[k] = v;
+  }
+  if constexpr (kNt) __builtin_nontemporal_store(sv, reinterpret_cast<bvec*>(status + i));
+  else *reinterpret_cast<bvec*>(status + i) = sv;
 }
 
 // connect_four, other geometries than 6 x 7 x 4: TWO consecutive states per thread so that every state access is
@@ -913,6 +983,7 @@ void ctx_release(osg_ctx* ctx) {
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->d_mcts_pool) (void)hipFree(ctx->d_mcts_pool);
   if (ctx->d_mcts_logs) (void)hipFree(ctx->d_mcts_logs);
+  if (ctx->d_mcts_queue) (void)hipFree(ctx->d_mcts_queue);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -945,6 +1016,9 @@ int osg_ctx_trim(osg_ctx* ctx) {
   if (ctx->d_scratch) OSG_HIP(hipFree(ctx->d_scratch));
   ctx->d_scratch = nullptr;
   ctx->scratch_bytes = 0;
+  if (ctx->d_mcts_queue) OSG_HIP(hipFree(ctx->d_mcts_queue));
+  ctx->d_mcts_queue = nullptr;
+  ctx->mcts_queue_roots = 0;
   return OSG_OK;
 }
 
@@ -1183,6 +1257,41 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
         static_cast<uint8_t*>(d_mask), d_status);
     OSG_HIP(hipGetLastError());
     return OSG_OK;
+  }
+  // hex: V states per thread (16-byte plane accesses with V = 4); the mask rows are the [n, NW] u32 output
+  if (kind == kHex && cmb == 4 * W && W == src->spec.hex_nw) {
+    // OSG_HEX_STEP="<states per thread>:<non-temporal 0|1>" overrides the choice (a tuning knob; results do not depend on it)
+    int v = 2, nt = n >= (int64_t{1} << 22) ? 1 : 0;
+    if (const char* e = std::getenv("OSG_HEX_STEP")) {
+      int ev = 0, ent = 0;
+      if (std::sscanf(e, "%d:%d", &ev, &ent) == 2 && (ev == 1 || ev == 2)) { v = ev; nt = ent ? 1 : 0; }
+    }
+    while (v > 1 && ((n % v) != 0 || (side & static_cast<uintptr_t>(v - 1)) != 0 ||
+                     (reinterpret_cast<uintptr_t>(d_mask) & static_cast<uintptr_t>(4 * v - 1)) != 0 || !planes16))
+      v >>= 1;
+    if (v > 1) {
+      const auto* s32 = static_cast<const uint32_t*>(src->d_words);
+      auto* d32 = static_cast<uint32_t*>(dst->d_words);
+      auto* m32 = static_cast<uint32_t*>(d_mask);
+#define OSG_HEXVEC(NWV, VV, NTV, member)                                                                              \
+  k_step_hexvec<NWV, VV, NTV><<<dim3(grid_for(n / VV)), dim3(kBlock), 0, ctx->stream>>>(src->spec.member, s32, d32, n, \
+                                                                                      d_actions, m32, d_status)
+#define OSG_HEXVEC_NW(NWV, member)                                            \
+  do {                                                                        \
+    if (nt) OSG_HEXVEC(NWV, 2, true, member);                                 \
+    else OSG_HEXVEC(NWV, 2, false, member);                                   \
+  } while (0)
+      switch (src->spec.hex_nw) {
+        case 1: OSG_HEXVEC_NW(1, hex1); break;
+        case 2: OSG_HEXVEC_NW(2, hex2); break;
+        case 3: OSG_HEXVEC_NW(3, hex3); break;
+        default: OSG_HEXVEC_NW(4, hex4); break;
+      }
+#undef OSG_HEXVEC_NW
+#undef OSG_HEXVEC
+      OSG_HIP(hipGetLastError());
+      return OSG_OK;
+    }
   }
   if (cmb == 1) {
     OSG_DISPATCH(src->spec, k_step<G, uint8_t><<<dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream>>>(P, static_cast<const typename G::word_t*>(src->d_words),

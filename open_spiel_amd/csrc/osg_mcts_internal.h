@@ -66,6 +66,14 @@ struct MctsOut {
   double* root_stats;
 };
 
+// The wave-per-root search as a work queue: a persistent grid whose wavefronts take the next ticket from a counter
+// and search root order[ticket] (order == nullptr: root = ticket).  Results stay keyed by the root's index.
+constexpr int kQueueBuckets = 129;          // cost key = number of legal actions at the root (<= 128)
+struct WaveQueue {
+  int32_t* ticket;        // [1], zeroed before the launch
+  const int32_t* order;   // [n] or nullptr
+};
+
 // Launches the wave-per-root kernel on the context's stream (osg_mcts_wave.hip).
 int launch_mcts_wave(const osg_batch* roots, const osg_mcts_cfg& cfg, const double* d_log_table, const Pool& pool,
                      const MctsOut& out);

@@ -74,7 +74,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
   if (r >= n) return;
   const uint64_t gr = static_cast<uint64_t>(cfg.index_offset + r);
   const int64_t NR = pool.n;
-  const bool host_priors = (flags & 1) != 0, through_chance = (flags & 2) != 0;
+  const bool host_priors = (flags & 1) != 0, through_chance = (flags & 2) != 0, own_rollouts = (flags & 4) != 0;
 #define META(i) pool.meta[static_cast<int64_t>(i) * NR + r]
 #define FIRST(i) pool.first[static_cast<int64_t>(i) * NR + r]
 #define PARENT(i) pool.parent[static_cast<int64_t>(i) * NR + r]
@@ -205,6 +205,23 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
         if (kBoard) meta = (meta & ~(3u << 21)) | (static_cast<uint32_t>(static_cast<int>(returns[0]) + 1) << 21);
         META(node) = meta;
         solved = cfg.solve != 0;
+      } else if (own_rollouts) {
+        // RandomRolloutEvaluator::Evaluate (mcts.cc:43-72) right here, on the streams k_mcts_tree_rollout draws
+        // from (rollout ro of simulation s of root r: Rng(seed, root, s * n_rollouts + ro)): the same values as the
+        // park / rollout-kernel / resume round trip, without leaving the launch
+        for (int q = 0; q < num_players; ++q) returns[q] = 0.0;
+        for (int ro = 0; ro < cfg.n_rollouts; ++ro) {
+          Rng rng(cfg.seed, gr, static_cast<uint64_t>(sims_done) * cfg.n_rollouts + ro);
+          typename G::State w = s;
+          for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
+            const Mask m = G::legal(p, w);
+            G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
+          }
+          double rr[kMaxPlayers];
+          G::returns(p, w, rr);
+          for (int q = 0; q < num_players; ++q) returns[q] += rr[q];
+        }
+        for (int q = 0; q < num_players; ++q) returns[q] = returns[q] / cfg.n_rollouts;
       } else {  // Evaluate(state) comes from outside
         G::store(p, leaf_words, n, r, s);
         park(kWantValue, 2);
@@ -442,7 +459,7 @@ int osg_mcts_tree_create(const osg_batch* roots, const osg_mcts_cfg* cfg_in, int
     return set_error(OSG_ERR_UNSUPPORTED, "solve=true needs win/draw/loss outcomes (tic_tac_toe, connect_four, hex)");
   if (cfg_in->child_selection_policy != 0 && cfg_in->child_selection_policy != 1)
     return set_error(OSG_ERR_INVALID, "osg_mcts_cfg.child_selection_policy must be 0 (UCT) or 1 (PUCT)");
-  if (flags & ~3) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_create: unknown flag");
+  if (flags & ~7) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_create: unknown flag");
   if (int rc = refuse_endless_playouts(roots->spec, "osg_mcts_tree_create")) return rc;
   osg_mcts_tree* t = new osg_mcts_tree;
   t->ctx = ctx;

@@ -642,6 +642,7 @@ struct VisitPath {
 #ifndef OSG_HEX_WPE
 #define OSG_HEX_WPE 7
 #endif
+
 // The hex fill kernel at 7 waves per SIMD (73 vector registers: nothing spilled to scratch).  Measured on config 4
 // with the final kernel: 6 waves 1.06e9, 7 waves 1.12e9, 8 waves (64 registers, a few spilled) 1.08e9 simulations/s;
 // the 2^13-root shard of an 8-GPU run 8.7e8 / 8.9e8 / 9.0e8.  One wavefront per workgroup instead of four: the same
@@ -649,16 +650,12 @@ struct VisitPath {
 // lane): 4 waves with a little scratch measured faster than 2-3 without.
 // kGc: the instantiation that can garbage-collect (mcts.cc:441-482): it also records every node's parent.
 // Kept out of the default instantiation so that the hex kernel's register budget is untouched.
+// ONE search: root r by the calling wavefront.
 template <class G, bool kBoard, bool kHexFill, bool kGc>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(kHexFill ? OSG_HEX_WPE : 4, 8)))
-k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, int num_actions,
-            osg_mcts_cfg cfg, double max_utility, const double* __restrict__ log_table, Pool pool, MctsOut out) {
-  __shared__ uint32_t s_path[kWavesPerBlock][kMaxPath - kPathRegs];
-  __shared__ uint32_t s_pcnt[kWavesPerBlock][kMaxPath - kPathRegs];
-  __shared__ double s_ptot[kWavesPerBlock][kMaxPath - kPathRegs];
-  const int wave_in_block = static_cast<int>(threadIdx.x >> 6);
-  const int64_t r = uniform(static_cast<int>(blockIdx.x * kWavesPerBlock + wave_in_block));
-  if (r >= n) return;
+OSG_D void wave_search(const typename G::Params& p, const typename G::word_t* base, int64_t n, int num_players,
+                       int num_actions, const osg_mcts_cfg& cfg, double max_utility, const double* __restrict__ log_table,
+                       const Pool& pool, const MctsOut& out, const int64_t r, uint32_t* my_path, uint32_t* my_pcnt,
+                       double* my_ptot) {
   const int lane = lane_id();
   // without chance nodes (kBoard) a path may use the LDS entries; the chance-skipping backup below looks entries
   // up across lanes and stays within the register entries (the games with chance nodes are far shorter anyway)
@@ -692,7 +689,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
     COUNT[0] = 0;
     TOTAL[0] = 0.0;
   }
-  VisitPath vp{(root_meta >> 8 & 15u) << 28, 0u, 0.0, s_path[wave_in_block], s_pcnt[wave_in_block], s_ptot[wave_in_block]};
+  VisitPath vp{(root_meta >> 8 & 15u) << 28, 0u, 0.0, my_path, my_pcnt, my_ptot};
   wave_fence();
   uint32_t used = 1;
   int sims_done = 0;
@@ -1045,19 +1042,158 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
   }
 }
 
+// One wavefront per root, statically: wave w of workgroup b searches root 4 b + w.
+template <class G, bool kBoard, bool kHexFill, bool kGc>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(kHexFill ? OSG_HEX_WPE : 4, 8)))
+k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, int num_actions,
+            osg_mcts_cfg cfg, double max_utility, const double* __restrict__ log_table, Pool pool, MctsOut out) {
+  __shared__ uint32_t s_path[kWavesPerBlock][kMaxPath - kPathRegs];
+  __shared__ uint32_t s_pcnt[kWavesPerBlock][kMaxPath - kPathRegs];
+  __shared__ double s_ptot[kWavesPerBlock][kMaxPath - kPathRegs];
+  const int wave_in_block = static_cast<int>(threadIdx.x >> 6);
+  const int64_t r = uniform(static_cast<int>(blockIdx.x * kWavesPerBlock + wave_in_block));
+  if (r >= n) return;
+  wave_search<G, kBoard, kHexFill, kGc>(p, base, n, num_players, num_actions, cfg, max_utility, log_table, pool, out, r,
+                                        s_path[wave_in_block], s_pcnt[wave_in_block], s_ptot[wave_in_block]);
+}
+
+// The same searches as a work queue: a persistent grid (a few wavefronts per SIMD) whose wavefronts take the next
+// ticket from a counter until the roots are used up.  Searches differ in length (a root with 70 empty cells costs
+// several times one with 45), so with one wavefront per root the launch ends with a few SIMDs still holding their
+// longest searches; with tickets handed out in order of decreasing expected cost (queue.order: roots sorted by their
+// number of legal actions, most first) the long searches start first and the short ones fill the gaps.  Results are
+// written under the root's own index: the outputs do not depend on the order or on which wavefront ran what.
+template <class G, bool kBoard, bool kHexFill, bool kGc>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(kHexFill ? OSG_HEX_WPE : 4, 8)))
+k_mcts_wave_queue(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, int num_actions,
+                  osg_mcts_cfg cfg, double max_utility, const double* __restrict__ log_table, Pool pool, MctsOut out,
+                  WaveQueue queue) {
+  __shared__ uint32_t s_path[kWavesPerBlock][kMaxPath - kPathRegs];
+  __shared__ uint32_t s_pcnt[kWavesPerBlock][kMaxPath - kPathRegs];
+  __shared__ double s_ptot[kWavesPerBlock][kMaxPath - kPathRegs];
+  const int wave_in_block = static_cast<int>(threadIdx.x >> 6);
+  for (;;) {
+    int ticket = 0;
+    if (lane_id() == 0) ticket = atomicAdd(queue.ticket, 1);
+    ticket = uniform(ticket);
+    if (ticket >= n) return;
+    const int64_t r = queue.order ? uniform(queue.order[ticket]) : ticket;
+    wave_search<G, kBoard, kHexFill, kGc>(p, base, n, num_players, num_actions, cfg, max_utility, log_table, pool, out,
+                                          r, s_path[wave_in_block], s_pcnt[wave_in_block], s_ptot[wave_in_block]);
+    wave_fence();
+  }
+}
+
+// Cost key of a root for the queue's order: its number of legal actions (hex: the empty cells — the playout length
+// and the width of the tree).  Counting sort, most expensive first: histogram, bucket offsets, scatter.
+template <class G>
+__global__ void __launch_bounds__(256) k_queue_histogram(typename G::Params p, const typename G::word_t* base, int64_t n,
+                                                         int32_t* hist) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const typename G::State s = G::load(p, base, n, i);
+  const int key = G::terminal(p, s) ? 0 : G::legal(p, s).count();
+  atomicAdd(&hist[key < kQueueBuckets ? key : kQueueBuckets - 1], 1);
+}
+__global__ void __launch_bounds__(64) k_queue_offsets(int32_t* hist) {  // hist -> first position of every bucket
+  if (threadIdx.x != 0) return;
+  int32_t at = 0;
+  for (int key = kQueueBuckets - 1; key >= 0; --key) {
+    const int32_t c = hist[key];
+    hist[key] = at;
+    at += c;
+  }
+}
+template <class G>
+__global__ void __launch_bounds__(256) k_queue_scatter(typename G::Params p, const typename G::word_t* base, int64_t n,
+                                                       int32_t* offsets, int32_t* order) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const typename G::State s = G::load(p, base, n, i);
+  const int key = G::terminal(p, s) ? 0 : G::legal(p, s).count();
+  order[atomicAdd(&offsets[key < kQueueBuckets ? key : kQueueBuckets - 1], 1)] = static_cast<int32_t>(i);
+}
+
+// Schedule of the wave-per-root search.  Measured on hex(9), 1024 simulations per root (MI355X,
+// profiles/r03_mcts_schedule.log): with 2^16 roots — nine rounds of the wave slots — one wavefront per root is the
+// fastest (1.106e9 simulations/s; the queue in index order 1.098e9, most-expensive-first 1.078e9: all the widest
+// trees in flight at once); with the 2^13 roots one of 8 GPUs gets (8 192 roots, 7 168 wave slots: the launch is as
+// long as its longest searches) most-expensive-first gains 6 % (8.80e8 -> 9.35e8; index order 8.84e8; 6 wavefronts
+// per SIMD the same, 5 / 4 less).  Hence: the queue, most expensive roots first, for batches of up to four rounds
+// of the wave slots, one wavefront per root beyond.  OSG_MCTS_SCHEDULE (read at every launch; a tuning knob, results
+// do not depend on it) overrides: "static" | "queue" (index order) | "lpt", optionally ":<wavefronts per SIMD>".
+struct Schedule { int mode; int waves_per_simd; bool forced; };
+inline Schedule schedule_from_env(bool hex_fill) {
+  Schedule sc{2, hex_fill ? OSG_HEX_WPE : 4, false};
+  const char* e = std::getenv("OSG_MCTS_SCHEDULE");
+  if (!e || !*e) return sc;
+  sc.forced = true;
+  const std::string v(e);
+  const size_t colon = v.find(':');
+  const std::string mode = v.substr(0, colon);
+  if (mode == "static") sc.mode = 0; else if (mode == "queue") sc.mode = 1; else if (mode == "lpt") sc.mode = 2;
+  if (colon != std::string::npos) {
+    const int w = std::atoi(v.c_str() + colon + 1);
+    if (w >= 1 && w <= 16) sc.waves_per_simd = w;
+  }
+  return sc;
+}
+
 template <class G, bool kBoard, bool kHexFill>
-void launch(const typename G::Params& P, const osg_batch* roots, const osg_mcts_cfg& cfg, const double* d_logs,
-            const Pool& pool, const MctsOut& out) {
+int launch(const typename G::Params& P, const osg_batch* roots, const osg_mcts_cfg& cfg, const double* d_logs,
+           const Pool& pool, const MctsOut& out) {
   const osg_game_desc& d = roots->spec.desc;
-  const unsigned grid = static_cast<unsigned>((roots->n + kWavesPerBlock - 1) / kWavesPerBlock);
-  if (pool.gc_nodes > 1 && pool.remap)
-    k_mcts_wave<G, kBoard, kHexFill, true><<<dim3(grid), dim3(64 * kWavesPerBlock), 0, roots->ctx->stream>>>(
-        P, static_cast<const typename G::word_t*>(roots->d_words), roots->n, d.num_players, d.num_distinct_actions, cfg,
-        d.max_utility, d_logs, pool, out);
+  osg_ctx* ctx = roots->ctx;
+  hipStream_t st = ctx->stream;
+  const int64_t n = roots->n;
+  const auto* words = static_cast<const typename G::word_t*>(roots->d_words);
+  const bool gc = pool.gc_nodes > 1 && pool.remap;
+  const Schedule sc = schedule_from_env(kHexFill);
+  if (ctx->num_cus == 0) {
+    hipDeviceProp_t prop;
+    OSG_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    ctx->num_cus = prop.multiProcessorCount;
+  }
+  // a queue pays only when there are more roots than wave slots to hand them to
+  const int64_t slots = static_cast<int64_t>(ctx->num_cus) * 4 * sc.waves_per_simd;
+  if (sc.mode == 0 || n <= slots || n >= (int64_t{1} << 31) || (!sc.forced && n > 4 * slots)) {
+    const unsigned grid = static_cast<unsigned>((n + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (gc)
+      k_mcts_wave<G, kBoard, kHexFill, true><<<dim3(grid), dim3(64 * kWavesPerBlock), 0, st>>>(
+          P, words, n, d.num_players, d.num_distinct_actions, cfg, d.max_utility, d_logs, pool, out);
+    else
+      k_mcts_wave<G, kBoard, kHexFill, false><<<dim3(grid), dim3(64 * kWavesPerBlock), 0, st>>>(
+          P, words, n, d.num_players, d.num_distinct_actions, cfg, d.max_utility, d_logs, pool, out);
+    return OSG_OK;
+  }
+  if (ctx->mcts_queue_roots < n) {
+    if (ctx->d_mcts_queue) OSG_HIP(hipFree(ctx->d_mcts_queue));
+    ctx->d_mcts_queue = nullptr;
+    ctx->mcts_queue_roots = 0;
+    OSG_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_mcts_queue), sizeof(int32_t) * (256 + static_cast<size_t>(n))));
+    ctx->mcts_queue_roots = n;
+  }
+  int32_t* ticket = ctx->d_mcts_queue;
+  int32_t* hist = ctx->d_mcts_queue + 1;
+  int32_t* order = ctx->d_mcts_queue + 256;
+  OSG_HIP(hipMemsetAsync(ctx->d_mcts_queue, 0, sizeof(int32_t) * 256, st));
+  WaveQueue queue{ticket, nullptr};
+  if (sc.mode == 2) {
+    const unsigned g = static_cast<unsigned>((n + 255) / 256);
+    k_queue_histogram<G><<<dim3(g), dim3(256), 0, st>>>(P, words, n, hist);
+    k_queue_offsets<<<dim3(1), dim3(64), 0, st>>>(hist);
+    k_queue_scatter<G><<<dim3(g), dim3(256), 0, st>>>(P, words, n, hist, order);
+    queue.order = order;
+  }
+  const unsigned grid = static_cast<unsigned>(std::min<int64_t>((n + kWavesPerBlock - 1) / kWavesPerBlock,
+                                                                slots / kWavesPerBlock));
+  if (gc)
+    k_mcts_wave_queue<G, kBoard, kHexFill, true><<<dim3(grid), dim3(64 * kWavesPerBlock), 0, st>>>(
+        P, words, n, d.num_players, d.num_distinct_actions, cfg, d.max_utility, d_logs, pool, out, queue);
   else
-    k_mcts_wave<G, kBoard, kHexFill, false><<<dim3(grid), dim3(64 * kWavesPerBlock), 0, roots->ctx->stream>>>(
-        P, static_cast<const typename G::word_t*>(roots->d_words), roots->n, d.num_players, d.num_distinct_actions, cfg,
-        d.max_utility, d_logs, pool, out);
+    k_mcts_wave_queue<G, kBoard, kHexFill, false><<<dim3(grid), dim3(64 * kWavesPerBlock), 0, st>>>(
+        P, words, n, d.num_players, d.num_distinct_actions, cfg, d.max_utility, d_logs, pool, out, queue);
+  return OSG_OK;
 }
 
 }  // namespace
@@ -1067,21 +1203,22 @@ namespace osg {
 int launch_mcts_wave(const osg_batch* roots, const osg_mcts_cfg& cfg, const double* d_logs, const Pool& pool,
                      const MctsOut& out) {
   const GameSpec& spec = roots->spec;
+  int rc = OSG_OK;
   switch (spec.desc.game_kind) {
-    case kTtt: launch<Ttt, true, false>(spec.ttt, roots, cfg, d_logs, pool, out); break;
+    case kTtt: rc = launch<Ttt, true, false>(spec.ttt, roots, cfg, d_logs, pool, out); break;
     case kC4:
-      if (spec.c4_std) launch<C4Std, true, false>(spec.c4, roots, cfg, d_logs, pool, out);
-      else launch<C4, true, false>(spec.c4, roots, cfg, d_logs, pool, out);
+      if (spec.c4_std) rc = launch<C4Std, true, false>(spec.c4, roots, cfg, d_logs, pool, out);
+      else rc = launch<C4, true, false>(spec.c4, roots, cfg, d_logs, pool, out);
       break;
-    case kKuhn: launch<Kuhn, false, false>(spec.kuhn, roots, cfg, d_logs, pool, out); break;
-    case kLeduc: launch<Leduc, false, false>(spec.leduc, roots, cfg, d_logs, pool, out); break;
+    case kKuhn: rc = launch<Kuhn, false, false>(spec.kuhn, roots, cfg, d_logs, pool, out); break;
+    case kLeduc: rc = launch<Leduc, false, false>(spec.leduc, roots, cfg, d_logs, pool, out); break;
     case kHex: {
       // The random-fill playout needs "legal moves == empty cells": not with the swap rule.  The search's own
       // position (HexW) needs two distinct edges per colour.
 #define OSG_HEX_CASE(NW, member)                                                                   \
   if (spec.member.swap || spec.member.rows < 2 || spec.member.cols < 2)                            \
-    launch<HexT<NW>, true, false>(spec.member, roots, cfg, d_logs, pool, out);                     \
-  else launch<HexT<NW>, true, true>(spec.member, roots, cfg, d_logs, pool, out)
+    rc = launch<HexT<NW>, true, false>(spec.member, roots, cfg, d_logs, pool, out);                \
+  else rc = launch<HexT<NW>, true, true>(spec.member, roots, cfg, d_logs, pool, out)
       switch (spec.hex_nw) {
         case 1: OSG_HEX_CASE(1, hex1); break;
         case 2: OSG_HEX_CASE(2, hex2); break;
@@ -1093,6 +1230,7 @@ int launch_mcts_wave(const osg_batch* roots, const osg_mcts_cfg& cfg, const doub
     }
     default: return set_error(OSG_ERR_INVALID, "bad game kind");
   }
+  if (rc) return rc;
   OSG_HIP(hipGetLastError());
   return OSG_OK;
 }

@@ -63,20 +63,30 @@ for game, depth in [("connect_four", 12), ("tic_tac_toe", 3), ("hex(board_size=9
     s = timeit(lambda: roots.rollout(1, 16), iters=10, warm=2)
     report(f"k_rollout {game} (2^16 roots x 16)", s, (1 << 16) * 16, "playouts/s")
     del b, dst, roots, mask, status, lm, acts, bits, cur, term, rets, out, bo
-    if sb <= 16:  # the same step / tensor kernels where the launch is long enough to be memory-bound
+    if sb <= 16 or hex_nw:  # the same step / tensor kernels where the launch is long enough to be memory-bound
         NB = 1 << 24
         b = osa.StateBatch(ctx, game, NB); b.random_steps(3, depth)
         dst = osa.StateBatch(ctx, game, NB)
         mask, status = b.step_buffers()
-        lm = b.legal_actions_mask_bits()[:, 0]
-        acts = torch.where(lm != 0, (torch.log2((lm & -lm).to(torch.float32))).to(torch.int32), torch.full((NB,), 255, device="cuda", dtype=torch.int32)).to(torch.uint8)
+        if hex_nw:   # any empty cell: the lowest one of the first non-empty mask word
+            bits = b.legal_actions_mask_bits()
+            w = (bits != 0).to(torch.int8).argmax(1)
+            lm = bits.gather(1, w.to(torch.int64).unsqueeze(1)).squeeze(1).to(torch.int64) & 0xFFFFFFFF
+            low = torch.log2((lm & -lm).to(torch.float64)).to(torch.int32) + 32 * w.to(torch.int32)
+            acts = torch.where(lm != 0, low, torch.full((NB,), 255, device="cuda", dtype=torch.int32)).to(torch.uint8)
+            del bits, w, low
+        else:
+            lm = b.legal_actions_mask_bits()[:, 0]
+            acts = torch.where(lm != 0, (torch.log2((lm & -lm).to(torch.float32))).to(torch.int32), torch.full((NB,), 255, device="cuda", dtype=torch.int32)).to(torch.uint8)
         s = timeit(lambda: b.step(acts, dst=dst, mask=mask, status=status), iters=50, warm=5)
         report(f"k_step {game} n=2^24", s, NB, "env-steps/s", NB * (2 * sb + 1 + d.compact_mask_bytes + 1))
         del dst, mask, status, lm, acts
-        out = torch.empty((NB, d.obs_size), dtype=torch.float32, device="cuda")
-        s = timeit(lambda: b.observation_tensor(0, out=out), iters=20, warm=3)
-        report(f"k_observation {game} [{NB},{d.obs_size}] n=2^24", s, NB, "states/s", NB * (sb + 4 * d.obs_size))
-        del out
+        n_obs = NB if d.obs_size <= 128 else NB // 4     # hex(9): [2^22, 729] = 12 GB
+        bo = b if n_obs == NB else b.gather(torch.arange(n_obs, device="cuda"))
+        out = torch.empty((n_obs, d.obs_size), dtype=torch.float32, device="cuda")
+        s = timeit(lambda: bo.observation_tensor(0, out=out), iters=20, warm=3)
+        report(f"k_observation {game} [{n_obs},{d.obs_size}] n=2^24", s, n_obs, "states/s", n_obs * (sb + 4 * d.obs_size))
+        del out, bo
         if d.info_size:
             out = torch.empty((NB, d.info_size), dtype=torch.float32, device="cuda")
             s = timeit(lambda: b.information_state_tensor(0, out=out), iters=20, warm=3)

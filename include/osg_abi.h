@@ -313,7 +313,11 @@ typedef struct {
                                     (outcome_sampling_mccfr.h:43 kDefaultEpsilon = 0.6)          */
   int32_t kernel;                /* 0 auto; 1 force the general level-synchronous kernel (k_cfr)
                                     even where the all-in-LDS small-tree kernel applies; 2 force the
-                                    full-grid phase kernels (auto for trees > 65536 histories)   */
+                                    full-grid phase kernels (auto for trees > 65536 histories); 3 force
+                                    the single-workgroup path kernel; 4 = auto's choice for trees that
+                                    start with their chance deals and split into <= #CUs subtrees of
+                                    <= 1024 histories (leduc_poker): one workgroup per deal subtree,
+                                    one grid barrier per player pass                             */
   int32_t replicas;              /* 0 or 1: one solver.  B > 1: B independent solvers of the same
                                     game advanced together, one workgroup each (CFR family, trees
                                     that fit LDS); select one with osg_cfr_select_replica         */

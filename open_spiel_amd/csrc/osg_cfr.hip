@@ -490,6 +490,247 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
 }
 
 // ---------------------------------------------------------------------------
+// Trees that start with their chance deals (leduc_poker: 9 457 histories, two deal levels, then 30 subtrees of
+// 314 histories): ONE WORKGROUP PER DEAL SUBTREE instead of one workgroup for the whole tree.  Everything a pass
+// touches inside a subtree — values, the regret / policy rows of the subtree's infostates, the descriptors of the
+// thread's own history, member and infostate — lives in LDS and registers (the kOwner form of k_cfr_small), so a
+// tree level costs an LDS round trip instead of an L2 one.  What crosses subtrees is exactly what the reference's
+// recursion adds up across deals (cfr.cc:379-405): an infostate's regret / average-policy terms come from member
+// histories in several subtrees.  Per player pass:
+//   A  values bottom-up inside the subtree (one __syncthreads per level);
+//   B  one thread per decision history of the subtree: reach from the root path, regret / average-policy terms,
+//      written THROUGH to memory (agent-scope stores) into the pass's term buffer (two buffers, by pass parity);
+//   -- one grid barrier: a counter every workgroup bumps once its stores have drained, polled by one lane --
+//   C  every workgroup folds, for each infostate that has a member in ITS subtree, ALL that infostate's members'
+//      terms (agent-scope loads: they bypass the caches that may hold the previous pass's lines) in DFS order —
+//      the same additions in the same order in every workgroup that keeps the row, so the copies stay bit-identical
+//      and equal to the single-workgroup kernels' tables — then RM+ clamp and regret matching into its LDS rows.
+// One barrier per pass, no second one: the rows a subtree needs next are the rows it has just folded itself.
+// The grid (one workgroup per subtree, <= the number of CUs, ~100 KB of LDS each) is co-resident on an otherwise idle
+// device; every spin is bounded (a timeout raises err[0] and every workgroup leaves).
+// ---------------------------------------------------------------------------
+struct SplitTree {
+  int G, L, NL, NM, NI;          // subtrees, cut level, padded histories / members / infostates per subtree
+  const int32_t* nloc;           // [G] histories of the subtree
+  const int32_t* hist_desc;      // [G, NL] kind | nchild << 2 | level << 10 | (actor + 1) << 16
+  const int32_t* hist_fc;        // [G, NL] LOCAL index of the first child
+  const int32_t* hist_row;       // [G, NL] info * A of a decision node
+  const int32_t* hist_glob;      // [G, NL] the history's index in the whole tree
+  const int32_t* mem_m;          // [G, NM] member index (position in Tree::mem), -1 = padding
+  const int32_t* mem_hloc;       // [G, NM] its history, local index
+  const int32_t* info_list;      // [G, NI] infostates with a member in the subtree, -1 = padding
+  double* terms;                 // [2][2][M, A]: buffer (pass parity) x {regret, policy} terms per member
+  int32_t* skip;                 // [2][M]
+  unsigned int* bar;             // [0] arrival counter, [1] error flag (both zeroed before every launch), [2] sticky error
+};
+
+OSG_D void store_through(double* p, double v) {   // agent scope: written through to memory, visible to every CU
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), static_cast<unsigned long long>(__double_as_longlong(v)),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+OSG_D double load_through(const double* p) {      // agent scope: never served from a stale L1 / L2 line
+  return __longlong_as_double(static_cast<long long>(__hip_atomic_load(
+      reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+}
+
+constexpr int kSplitMaxA = 4;       // widest policy row the split kernel folds
+constexpr int kSplitOwnerPath = 10;  // decision entries of a root path kept in registers
+template <int kSlots>  // kSlots >= P + 1
+__global__ void __launch_bounds__(1024)
+k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int P = t.P, A = t.A, IA = t.I * t.A, M = st.M;
+  const int tid = threadIdx.x, g = blockIdx.x;
+  double* value = smem;                         // [NL, P]
+  double* l_edge = value + sp.NL * P;           // [NL] chance probability of the incoming edge
+  double* regrets = l_edge + sp.NL;             // [I, A] (only the rows of this subtree's infostates are kept current)
+  double* cum = regrets + IA;
+  double* cur = cum + IA;
+  int* s_ok = reinterpret_cast<int*>(cur + IA);  // (in the dynamic region: a static would shift its 16-byte base)
+  for (int k = tid; k < IA; k += blockDim.x) {
+    regrets[k] = tb.regrets[k];
+    cum[k] = tb.cum[k];
+    cur[k] = tb.cur[k];
+  }
+  // ---- the thread's own history, member and infostate: descriptors in registers for the whole launch ----
+  const int nloc = sp.nloc[g];
+  int o_k = kTerminalNode, o_fc = 0, o_nc = 0, o_row = 0, o_lvl = -1;
+  if (tid < nloc) {
+    const int d = sp.hist_desc[g * sp.NL + tid];
+    o_k = d & 3; o_nc = (d >> 2) & 0xFF; o_lvl = (d >> 10) & 0x3F;
+    o_fc = sp.hist_fc[g * sp.NL + tid];
+    o_row = sp.hist_row[g * sp.NL + tid];
+    const int hg = sp.hist_glob[g * sp.NL + tid];
+    l_edge[tid] = t.edge_prob[hg];
+    for (int q = 0; q < P; ++q) value[tid * P + q] = o_k == kTerminalNode ? t.term_ret[hg * P + q] : 0.0;
+  }
+  constexpr int kOwnerPath = kSplitOwnerPath;
+  int b_m = -1, b_h = 0, b_pl = -1, b_i = 0, b_n = 0, b_fc = 0;
+  int b_code[kOwnerPath];
+  double b_chance = 1.0;
+#pragma unroll
+  for (int j = 0; j < kOwnerPath; ++j) b_code[j] = -1;
+  if (tid < sp.NM) {
+    b_m = sp.mem_m[g * sp.NM + tid];
+    if (b_m >= 0) {
+      b_h = sp.mem_hloc[g * sp.NM + tid];
+      const int d = sp.hist_desc[g * sp.NL + b_h];
+      b_pl = ((d >> 16) & 15) - 1;
+      b_i = sp.hist_row[g * sp.NL + b_h] / A;
+      b_n = t.nact[b_i];
+      b_fc = sp.hist_fc[g * sp.NL + b_h];
+      int np = 0;
+      for (int e = st.path_off[b_m]; e < st.path_off[b_m + 1]; ++e) {  // (the host checked: <= kOwnerPath decisions)
+        const int code = st.path[e];
+        if ((code >> 23) & 1) {
+          b_chance *= t.edge_prob[code & 0x7FFFFF];
+        } else {
+#pragma unroll
+          for (int j = 0; j < kOwnerPath; ++j)
+            if (j == np) b_code[j] = code & 0x0F7FFFFF;
+          ++np;
+        }
+      }
+    }
+  }
+  int c_i = -1, c_n = 0, c_pl = -1, c_m0 = 0, c_m1 = 0;
+  if (tid < sp.NI) {
+    c_i = sp.info_list[g * sp.NI + tid];
+    if (c_i >= 0) {
+      c_n = t.nact[c_i];
+      c_pl = t.info_player[c_i];
+      c_m0 = t.mem_off[c_i];
+      c_m1 = t.mem_off[c_i + 1];
+    }
+  }
+  __syncthreads();
+
+  const int passes = cfg.alternating_updates ? P : 1;
+  unsigned int epoch = 0;
+  for (int it = 0; it < iters; ++it) {
+    const int iteration = iteration0 + it + 1;
+    for (int pass = 0; pass < passes; ++pass) {
+      const int upd = cfg.alternating_updates ? pass : -1;
+      const int q0 = upd >= 0 ? upd : 0, q1 = upd >= 0 ? upd + 1 : P;
+      // ---- A: values, bottom-up inside the subtree (cfr.cc:443-469) ----
+      for (int l = t.D - 2; l >= sp.L; --l) {
+        if (o_lvl == l && o_k != kTerminalNode) {
+          for (int q = q0; q < q1; ++q) {
+            double v = 0.0;
+            for (int a = 0; a < o_nc; ++a) {
+              const double pr = o_k == kChanceNode ? l_edge[o_fc + a] : cur[o_row + a];
+              v += pr * value[(o_fc + a) * P + q];
+            }
+            value[tid * P + q] = v;
+          }
+        }
+        __syncthreads();
+      }
+      // ---- B: the thread's decision history: reach from its root path, regret / average-policy terms ----
+      double* dreg = sp.terms + static_cast<size_t>(epoch & 1u) * 2 * M * A;
+      double* dpol = dreg + static_cast<size_t>(M) * A;
+      int32_t* skip = sp.skip + static_cast<size_t>(epoch & 1u) * M;
+      if (b_m >= 0 && (upd < 0 || b_pl == upd)) {
+        double pr[kOwnerPath];
+#pragma unroll
+        for (int j = 0; j < kOwnerPath; ++j) pr[j] = cur[b_code[j] >= 0 ? (b_code[j] & 0x7FFFFF) : 0];
+        double reach[kSlots];
+#pragma unroll
+        for (int q = 0; q < kSlots; ++q) reach[q] = (q == P) ? b_chance : 1.0;
+#pragma unroll
+        for (int j = 0; j < kOwnerPath; ++j) {
+          const int slot = b_code[j] >= 0 ? (b_code[j] >> 24) & 0xF : -1;
+#pragma unroll
+          for (int q = 0; q < kSlots; ++q) reach[q] = (q == slot) ? reach[q] * pr[j] : reach[q];
+        }
+        bool pruned = true;  // AllPlayersHaveZeroReachProb (cfr.cc:471-479)
+        double self_reach = 0.0, cf_reach = 1.0;
+#pragma unroll
+        for (int q = 0; q < kSlots; ++q) {
+          if (q < P) pruned &= (reach[q] == 0.0);
+          if (q == b_pl) self_reach = reach[q];
+          else if (q <= P) cf_reach *= reach[q];  // CounterFactualReachProb (cfr.cc:309-318), chance slot = P
+        }
+        __hip_atomic_store(&skip[b_m], pruned ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!pruned) {
+          const double vh = value[b_h * P + b_pl];
+          for (int a = 0; a < b_n; ++a) {
+            store_through(&dreg[b_m * A + a], cf_reach * (value[(b_fc + a) * P + b_pl] - vh));
+            const double pol = cur[b_i * A + a];
+            store_through(&dpol[b_m * A + a], cfg.linear_averaging ? iteration * self_reach * pol : self_reach * pol);
+          }
+        }
+      }
+      // ---- the grid barrier: every storing wave drains, one lane signals, one lane polls ----
+      ++epoch;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_fetch_add(&sp.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int want = epoch * static_cast<unsigned int>(sp.G);
+        int ok = 0;
+        for (int spin = 0; spin < (1 << 20); ++spin) {
+          if (__hip_atomic_load(&sp.bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = 1; break; }
+          if (__hip_atomic_load(&sp.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) {
+          __hip_atomic_store(&sp.bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&sp.bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sticky: read by the host
+        }
+        *s_ok = ok;
+      }
+      __syncthreads();
+      if (!*s_ok) return;  // a workgroup never arrived (the grid was not co-resident): leave the tables untouched
+      // ---- C: the thread's infostate: fold ALL its members' terms in DFS order, RM+ clamp, regret matching ----
+      if (c_i >= 0 && (upd < 0 || c_pl == upd)) {
+        // four members' flags and terms are requested together (clamped indices: independent loads, one round
+        // trip per chunk), then added in member order
+        for (int m0 = c_m0; m0 < c_m1; m0 += 4) {
+          int sk[4];
+          double rt[4][kSplitMaxA], pt[4][kSplitMaxA];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int m = m0 + j < c_m1 ? m0 + j : c_m1 - 1;
+            sk[j] = __hip_atomic_load(&skip[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int a = 0; a < kSplitMaxA; ++a) {
+              const int aa = a < c_n ? a : 0;
+              rt[j][a] = load_through(&dreg[m * A + aa]);
+              pt[j][a] = load_through(&dpol[m * A + aa]);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (m0 + j >= c_m1 || sk[j]) continue;
+#pragma unroll
+            for (int a = 0; a < kSplitMaxA; ++a) {
+              if (a < c_n) {
+                regrets[c_i * A + a] += rt[j][a];
+                cum[c_i * A + a] += pt[j][a];
+              }
+            }
+          }
+        }
+        if (cfg.regret_matching_plus)
+          for (int a = 0; a < c_n; ++a)
+            if (regrets[c_i * A + a] < 0) regrets[c_i * A + a] = 0;
+        regret_match_row(regrets + c_i * A, cur + c_i * A, c_n);
+      }
+      __syncthreads();
+    }
+  }
+  // every workgroup writes the rows it kept (copies of one row are bit-identical: the same additions in the same order)
+  if (c_i >= 0) {
+    for (int a = 0; a < A; ++a) {
+      tb.regrets[c_i * A + a] = regrets[c_i * A + a];
+      tb.cum[c_i * A + a] = cum[c_i * A + a];
+      tb.cur[c_i * A + a] = cur[c_i * A + a];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Large trees (3-player leduc: 1.8 M histories): the same three phases as k_cfr_small, but
 // every phase is a full-grid launch — one kernel per tree level for the values, one for the
 // per-history terms, one for the per-infostate fold — so the whole chip works on one tree and
@@ -1405,6 +1646,15 @@ struct osg_cfr {
   int32_t *d_meta32 = nullptr, *d_info_player32 = nullptr, *d_skip = nullptr;
   double* d_node_delta = nullptr;  // dreg [M, A] | dpol [M, A]
   double* d_spare_delta[2] = {nullptr, nullptr};  // osg_mccfr_spare_delta_buffer: [2, I, A] each, allocated on request
+  // one workgroup per deal subtree (k_cfr_split)
+  bool split_ok = false;
+  int split_G = 0, split_L = 0, split_NL = 0, split_NM = 0, split_NI = 0, split_threads = 0;
+  size_t split_lds_bytes = 0;
+  int32_t *d_split_nloc = nullptr, *d_split_desc = nullptr, *d_split_fc = nullptr, *d_split_row = nullptr,
+          *d_split_glob = nullptr, *d_split_mem_m = nullptr, *d_split_mem_hloc = nullptr, *d_split_info = nullptr,
+          *d_split_skip = nullptr;
+  double* d_split_terms = nullptr;
+  unsigned int* d_split_bar = nullptr;
   // policy evaluation (k_policy_eval)
   std::vector<int32_t> info_level, mem_index;
   bool eval_ok = true;  // every infostate's members sit on one tree level
@@ -1748,6 +1998,112 @@ int build_resident_tree(osg_cfr* s) {
   return OSG_OK;
 }
 
+// Cuts the tree below its leading chance levels into subtrees for k_cfr_split: one workgroup each, at most one
+// per CU, every subtree small enough for one thread per history.
+int build_split(osg_cfr* s) {
+  s->split_ok = false;
+  if (s->cfg.solver != 0 || s->B != 1 || !s->path_kernel || s->A > kSplitMaxA || s->P + 1 > kMaxPlayers + 1) return OSG_OK;
+  if (s->H < 2000 || s->D >= 64) return OSG_OK;
+  // the cut: the first level that holds a node which is not a chance node
+  int L = 0;
+  for (; L < s->D; ++L) {
+    bool all_chance = true;
+    for (int h = s->level_off[L]; h < s->level_off[L + 1]; ++h) all_chance &= s->kind[h] == kChanceNode;
+    if (!all_chance) break;
+  }
+  if (L < 1 || L >= s->D - 1) return OSG_OK;
+  const int G = s->level_off[L + 1] - s->level_off[L];
+  hipDeviceProp_t prop;
+  OSG_HIP(hipGetDeviceProperties(&prop, s->ctx->device));
+  if (G < 8 || G > prop.multiProcessorCount) return OSG_OK;
+  // a subtree's histories, level by level: the descendants of a level-L node are a contiguous range on every level
+  std::vector<std::vector<int32_t>> hist(G);
+  std::vector<int32_t> sub_of(s->H, -1), loc_of(s->H, -1), level_of(s->H, 0);
+  for (int l = 0; l < s->D; ++l)
+    for (int h = s->level_off[l]; h < s->level_off[l + 1]; ++h) level_of[h] = l;
+  for (int g = 0; g < G; ++g) sub_of[s->level_off[L] + g] = g;
+  for (int h = s->level_off[L]; h < s->H; ++h) {
+    if (h >= s->level_off[L + 1]) sub_of[h] = sub_of[s->parent[h]];
+    const int g = sub_of[h];
+    loc_of[h] = static_cast<int32_t>(hist[g].size());
+    hist[g].push_back(h);
+  }
+  int NL = 0;
+  for (int g = 0; g < G; ++g) NL = std::max<int>(NL, static_cast<int>(hist[g].size()));
+  if (NL > 1024) return OSG_OK;
+  const int threads = std::max(64, (NL + 63) / 64 * 64);
+  std::vector<std::vector<int32_t>> mem_m(G), infos(G);
+  std::vector<int32_t> seen(s->I, -1);
+  for (int i = 0; i < s->I; ++i)
+    for (int m = s->mem_off[i]; m < s->mem_off[i + 1]; ++m) {
+      const int h = s->mem[m];
+      if (sub_of[h] < 0) return OSG_OK;  // a decision node above the cut
+      int decisions = 0;
+      for (int e = s->path_off[m]; e < s->path_off[m + 1]; ++e) decisions += ((s->path[e] >> 23) & 1) ? 0 : 1;
+      if (decisions > kSplitOwnerPath) return OSG_OK;
+      mem_m[sub_of[h]].push_back(m);
+      if (seen[i] != sub_of[h]) {  // members of one infostate inside one subtree are adjacent in DFS order or not: check all
+        bool have = false;
+        for (int32_t x : infos[sub_of[h]]) have |= x == i;
+        if (!have) infos[sub_of[h]].push_back(i);
+        seen[i] = sub_of[h];
+      }
+    }
+  int NM = 1, NI = 1;
+  for (int g = 0; g < G; ++g) {
+    NM = std::max<int>(NM, static_cast<int>(mem_m[g].size()));
+    NI = std::max<int>(NI, static_cast<int>(infos[g].size()));
+  }
+  if (NM > threads || NI > threads) return OSG_OK;
+  const size_t IA = static_cast<size_t>(s->I) * s->A;
+  const size_t lds = sizeof(double) * (static_cast<size_t>(NL) * s->P + NL + 3 * IA) + 16;
+  if (lds > 150 * 1024) return OSG_OK;
+  std::vector<int32_t> nloc(G), desc(static_cast<size_t>(G) * NL, kTerminalNode), fc(static_cast<size_t>(G) * NL, 0),
+      row(static_cast<size_t>(G) * NL, 0), glob(static_cast<size_t>(G) * NL, 0), mm(static_cast<size_t>(G) * NM, -1),
+      mh(static_cast<size_t>(G) * NM, 0), il(static_cast<size_t>(G) * NI, -1);
+  for (int g = 0; g < G; ++g) {
+    nloc[g] = static_cast<int32_t>(hist[g].size());
+    for (size_t j = 0; j < hist[g].size(); ++j) {
+      const int h = hist[g][j];
+      const size_t at = static_cast<size_t>(g) * NL + j;
+      desc[at] = s->kind[h] | (s->nchild[h] << 2) | (level_of[h] << 10) | ((s->actor[h] + 1) << 16);
+      fc[at] = s->kind[h] == kTerminalNode ? 0 : loc_of[s->first_child[h]];
+      row[at] = s->kind[h] == kDecisionNode ? s->info[h] * s->A : 0;
+      glob[at] = h;
+    }
+    for (size_t k = 0; k < mem_m[g].size(); ++k) {
+      mm[static_cast<size_t>(g) * NM + k] = mem_m[g][k];
+      mh[static_cast<size_t>(g) * NM + k] = loc_of[s->mem[mem_m[g][k]]];
+    }
+    for (size_t k = 0; k < infos[g].size(); ++k) il[static_cast<size_t>(g) * NI + k] = infos[g][k];
+  }
+  hipStream_t st = s->ctx->stream;
+  int rc;
+  if ((rc = upload(nloc, &s->d_split_nloc, st)) || (rc = upload(desc, &s->d_split_desc, st)) ||
+      (rc = upload(fc, &s->d_split_fc, st)) || (rc = upload(row, &s->d_split_row, st)) ||
+      (rc = upload(glob, &s->d_split_glob, st)) || (rc = upload(mm, &s->d_split_mem_m, st)) ||
+      (rc = upload(mh, &s->d_split_mem_hloc, st)) || (rc = upload(il, &s->d_split_info, st)))
+    return rc;
+  const size_t M = s->mem.size();
+  OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_split_terms), sizeof(double) * 4 * std::max<size_t>(M * s->A, 1)));
+  OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_split_skip), sizeof(int32_t) * 2 * std::max<size_t>(M, 1)));
+  OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_split_bar), sizeof(unsigned int) * 4));
+  OSG_HIP(hipMemsetAsync(s->d_split_bar, 0, sizeof(unsigned int) * 4, st));
+  OSG_HIP(hipMemsetAsync(s->d_split_terms, 0, sizeof(double) * 4 * std::max<size_t>(M * s->A, 1), st));
+  OSG_HIP(hipMemsetAsync(s->d_split_skip, 0, sizeof(int32_t) * 2 * std::max<size_t>(M, 1), st));
+  const void* variants[] = {reinterpret_cast<const void*>(&k_cfr_split<3>), reinterpret_cast<const void*>(&k_cfr_split<4>),
+                            reinterpret_cast<const void*>(&k_cfr_split<kMaxPlayers + 1>)};
+  for (const void* f : variants)
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
+      (void)hipGetLastError();
+      return OSG_OK;
+    }
+  s->split_G = G; s->split_L = L; s->split_NL = NL; s->split_NM = NM; s->split_NI = NI; s->split_threads = threads;
+  s->split_lds_bytes = lds;
+  s->split_ok = true;
+  return OSG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1848,6 +2204,8 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
   }
   rc = build_resident_tree(s);
   if (rc) { osg_cfr_destroy(s); return rc; }
+  rc = build_split(s);
+  if (rc) { osg_cfr_destroy(s); return rc; }
   rc = init_tables(s);
   if (rc) { osg_cfr_destroy(s); return rc; }
   *out = s;
@@ -1861,7 +2219,9 @@ int osg_cfr_destroy(osg_cfr* s) {
                   s->d_kind, s->d_nchild, s->d_aidx, s->d_actor, s->d_info_player, s->d_edge_prob, s->d_term_ret,
                   s->d_tables, s->d_reach, s->d_value, s->d_path_off, s->d_path, s->d_info_level, s->d_mem_index,
                   s->d_best, s->d_eval, s->d_meta32, s->d_info_player32, s->d_skip, s->d_node_delta, s->d_rec,
-                  s->d_uret, s->d_uprob, s->d_spare_delta[0], s->d_spare_delta[1]};
+                  s->d_uret, s->d_uprob, s->d_spare_delta[0], s->d_spare_delta[1], s->d_split_nloc, s->d_split_desc,
+                  s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
+                  s->d_split_skip, s->d_split_terms, s->d_split_bar};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   osg::ctx_release(s->ctx);
@@ -1911,6 +2271,28 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
         k_gcfr_members<<<blocks(M), dim3(256), 0, st>>>(g, upd, s->iteration + it + 1, s->cfg);
         k_gcfr_fold<<<blocks(s->I), dim3(256), 0, st>>>(g, upd, s->cfg);
       }
+    }
+    OSG_HIP(hipGetLastError());
+    s->iteration += iters;
+    return OSG_OK;
+  }
+  if (s->split_ok && (s->cfg.kernel == 0 || s->cfg.kernel == 4)) {
+    // one workgroup per deal subtree, one grid barrier per player pass (k_cfr_split)
+    const int M = static_cast<int>(s->mem.size());
+    SmallTree stree{s->d_path_off, s->d_path, M, static_cast<int>(s->path.size())};
+    SplitTree sp{s->split_G, s->split_L, s->split_NL, s->split_NM, s->split_NI, s->d_split_nloc, s->d_split_desc,
+                 s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
+                 s->d_split_terms, s->d_split_skip, s->d_split_bar};
+    hipStream_t st = s->ctx->stream;
+    const int passes = s->cfg.alternating_updates ? s->P : 1;
+    const int per_launch = std::max(1, (1 << 30) / std::max(1, passes * s->split_G));  // the arrival counter is 32 bits
+    for (int done = 0; done < iters; done += per_launch) {
+      const int now = std::min(per_launch, iters - done);
+      OSG_HIP(hipMemsetAsync(s->d_split_bar, 0, sizeof(unsigned int) * 2, st));
+      const dim3 grid(static_cast<unsigned>(s->split_G)), block(static_cast<unsigned>(s->split_threads));
+      if (s->P == 2) k_cfr_split<3><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->cfg);
+      else if (s->P == 3) k_cfr_split<4><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->cfg);
+      else k_cfr_split<kMaxPlayers + 1><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->cfg);
     }
     OSG_HIP(hipGetLastError());
     s->iteration += iters;
@@ -2217,7 +2599,12 @@ int osg_cfr_tables(const osg_cfr* s, int32_t* nact, int32_t* legal, double* regr
   if (regrets) OSG_HIP(hipMemcpyAsync(regrets, s->regrets(), bytes, hipMemcpyDeviceToHost, st));
   if (cur_policy) OSG_HIP(hipMemcpyAsync(cur_policy, s->cur(), bytes, hipMemcpyDeviceToHost, st));
   OSG_HIP(hipMemcpyAsync(cum.data(), s->cum(), bytes, hipMemcpyDeviceToHost, st));
+  unsigned int split_error = 0;
+  if (s->split_ok) OSG_HIP(hipMemcpyAsync(&split_error, s->d_split_bar + 2, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
   OSG_HIP(hipStreamSynchronize(st));
+  if (split_error)
+    return set_error(OSG_ERR_HIP, "k_cfr_split: a grid barrier timed out (the workgroups were not co-resident: another kernel "
+                                  "held CUs for seconds); the iterations of that launch were dropped — use osg_cfr_cfg.kernel = 3");
   if (cum_policy) memcpy(cum_policy, cum.data(), bytes);
   if (avg_policy) {  // CFRAveragePolicy::GetStatePolicyFromInformationStateValues (cfr.cc:104-125)
     for (int i = 0; i < s->I; ++i) {

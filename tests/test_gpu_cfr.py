@@ -83,6 +83,12 @@ def test_tree_census_and_keys(oracle, ctx, game):
     ("leduc_poker", "cfr_plus", dict(linear_averaging=True, regret_matching_plus=True, general_kernel="grid"), [4]),
     ("kuhn_poker(players=3)", "cfr_simultaneous", dict(alternating_updates=False, general_kernel="grid"), [6]),
     ("kuhn_poker(players=3)", "cfr_simultaneous", dict(alternating_updates=False), [1, 12]),
+    # leduc's default since round 3 is one workgroup per deal subtree (k_cfr_split); the single-workgroup path kernel
+    # it replaced stays checked, and the split kernel is also named explicitly
+    ("leduc_poker", "cfr", dict(general_kernel="path"), [1, 3]),
+    ("leduc_poker", "cfr", dict(general_kernel="split"), [1, 2, 7, 40]),
+    ("leduc_poker", "cfr_plus", dict(linear_averaging=True, regret_matching_plus=True, general_kernel="split"), [1, 12]),
+    ("leduc_poker", "cfr_simultaneous", dict(alternating_updates=False, general_kernel="split"), [1, 6]),
 ])
 def test_cfr_tables_match_the_oracle(oracle, ctx, game, kind, kwargs, checkpoints):
     import open_spiel_amd as osa
@@ -117,6 +123,27 @@ def test_iterating_one_by_one_equals_one_launch(ctx):
         np.testing.assert_array_equal(ta[name], tb[name])
     a.reset()
     assert a.iteration == 0 and not a.tables()["regrets"].any()
+
+
+@pytest.mark.parametrize("kwargs", [{}, dict(linear_averaging=True, regret_matching_plus=True),
+                                    dict(alternating_updates=False)])
+def test_leduc_split_kernel_is_bit_identical_with_the_single_workgroup_kernel(ctx, kwargs):
+    """One workgroup per deal subtree, every workgroup folding its infostates' terms itself in DFS order: the same
+    additions in the same order as the single-workgroup path kernel — the tables must be equal to the last bit,
+    whether the iterations run in one launch or in several."""
+    import open_spiel_amd as osa
+    a = osa.TabularSolver(ctx, "leduc_poker", general_kernel="path", **kwargs)
+    b = osa.TabularSolver(ctx, "leduc_poker", general_kernel="split", **kwargs)
+    c = osa.TabularSolver(ctx, "leduc_poker", **kwargs)          # auto = the split kernel
+    a.evaluate_and_update_policy(64)
+    b.evaluate_and_update_policy(64)
+    for k in (1, 1, 2, 60):
+        c.evaluate_and_update_policy(k)
+    ta, tb, tc = a.tables(), b.tables(), c.tables()
+    for name in ("regrets", "cum_policy", "cur_policy"):
+        np.testing.assert_array_equal(ta[name], tb[name])
+        np.testing.assert_array_equal(ta[name], tc[name])
+    assert abs(a.nash_conv() - b.nash_conv()) == 0.0
 
 
 def _judge(oracle, game, solver, which=0):

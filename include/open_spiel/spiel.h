@@ -16,18 +16,28 @@
 #include "../../open_spiel_amd/csrc/host/osg_spiel.h"
 
 namespace open_spiel {
-// the names of namespace open_spiel the test sources use, one by one (a using-directive for hip would make
-// `algorithms::X` ambiguous between open_spiel::algorithms and open_spiel::hip::algorithms)
+// the names of namespace open_spiel, one by one (a using-directive for hip would make `algorithms::X` ambiguous
+// between open_spiel::algorithms and open_spiel::hip::algorithms)
 using hip::Action; using hip::Player; using hip::ActionsAndProbs;
-using hip::kInvalidAction; using hip::kChancePlayerId; using hip::kTerminalPlayerId;
-using hip::Game; using hip::State; using hip::BatchedState; using hip::LoadGame; using hip::SpielFatalError;
+using hip::kInvalidAction; using hip::kChancePlayerId; using hip::kTerminalPlayerId; using hip::kDefaultPlayerId;
+using hip::kSimultaneousPlayerId; using hip::kInvalidPlayer; using hip::kMeanFieldPlayerId;
+using hip::Game; using hip::State; using hip::BatchedState; using hip::LoadGame; using hip::LoadGameAsTurnBased;
+using hip::SpielFatalError; using hip::SpielException;
+using hip::GameType; using hip::GameParameter; using hip::GameParameters; using hip::GameParametersFromString;
+using hip::GameParametersToString;
 using hip::SerializeGameAndState; using hip::DeserializeGameAndState;
 using hip::Policy; using hip::TabularPolicy; using hip::UniformPolicy; using hip::PreferredActionPolicy;
 using hip::GetUniformPolicy; using hip::GetFirstActionPolicy; using hip::GetEmptyTabularPolicy; using hip::ToTabularPolicy;
+using hip::GetPrefActionPolicy;
 using hip::Bot; using hip::EvaluateBots; using hip::SampleAction;
+using hip::Observer; using hip::Observation; using hip::IIGObservationType; using hip::PrivateInfoType;
+using hip::kDefaultObsType; using hip::kInfoStateObsType; using hip::SpanTensor; using hip::SpanTensorInfo;
+using hip::Near; using hip::UniformProbabilitySampler; using hip::operator<<;
 namespace algorithms { using namespace hip::algorithms; }
-namespace kuhn_poker { using namespace hip::algorithms::kuhn_poker; }
-// spiel_utils.h:140-250: the checks the tests use
+namespace kuhn_poker { using namespace hip::kuhn_poker; }
+namespace leduc_poker { using namespace hip::leduc_poker; }
+namespace efg_game { using namespace hip::efg_game; }
+// spiel_utils.h:119-137: the default fatal-error handler prints and exits
 [[noreturn]] inline void SpielFatalErrorShim(const std::string& msg) { std::cerr << "Spiel Fatal Error: " << msg << std::endl; std::exit(1); }
 }  // namespace open_spiel
 #define OSG_SHIM_CHECK_OP(x_exp, op, y_exp)                                                              \
@@ -55,4 +65,18 @@ namespace kuhn_poker { using namespace hip::algorithms::kuhn_poker; }
     }                                                                                                    \
   } while (0)
 #define SPIEL_CHECK_FLOAT_EQ(x, y) SPIEL_CHECK_FLOAT_NEAR(x, y, 1e-5)
+// spiel_utils.h:295-322: the check that names game and state, and the debug checks (enabled, as in the reference's
+// default build)
+#define SPIEL_CHECK_TRUE_WSI(x, e, g, s)                                                                  \
+  do { if (!(x)) open_spiel::SpielFatalErrorShim(std::string(__FILE__) + ":" + std::to_string(__LINE__) + " CHECK_TRUE(" #x ") " + (e) + " game: " + (g).ToString() + " state: " + (s).ToString()); } while (0)
+#define SPIEL_DCHECK_GE(x, y) SPIEL_CHECK_GE(x, y)
+#define SPIEL_DCHECK_GT(x, y) SPIEL_CHECK_GT(x, y)
+#define SPIEL_DCHECK_LE(x, y) SPIEL_CHECK_LE(x, y)
+#define SPIEL_DCHECK_LT(x, y) SPIEL_CHECK_LT(x, y)
+#define SPIEL_DCHECK_EQ(x, y) SPIEL_CHECK_EQ(x, y)
+#define SPIEL_DCHECK_NE(x, y) SPIEL_CHECK_NE(x, y)
+#define SPIEL_DCHECK_TRUE(x) SPIEL_CHECK_TRUE(x)
+#define SPIEL_DCHECK_FALSE(x) SPIEL_CHECK_FALSE(x)
+#define SPIEL_DCHECK_FLOAT_EQ(x, y) SPIEL_CHECK_FLOAT_EQ(x, y)
+#define SPIEL_DCHECK_FLOAT_NEAR(x, y, e) SPIEL_CHECK_FLOAT_NEAR(x, y, e)
 #endif  // OSG_INCLUDE_OPEN_SPIEL_SPIEL_H_

@@ -88,6 +88,9 @@ void* osg_ctx_stream(osg_ctx* ctx);
  * node budget sizes it at 1 + max_simulations x widest-node slots per root, up to 60 % of the free HBM) and the
  * staging buffer.  Waits for the stream first.  The next search allocates again. */
 int osg_ctx_trim(osg_ctx* ctx);
+/* Rebind a context created on a caller's stream (own_stream == 0) to another stream of the same device, e.g. the
+ * stream a hipGraph is being captured on: every later call of the context's objects is issued there. */
+int osg_ctx_set_stream(osg_ctx* ctx, void* stream);
 
 /* ---- game description (no device needed) -------------------------------- */
 /* Replaces LoadGame(game_string) (open_spiel/spiel.cc:255) for the five hot-path
@@ -268,7 +271,11 @@ int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg, int32_t* be
  * flags: 1 = priors come from the caller (else uniform over the legal actions, RandomRolloutEvaluator::Prior
  * mcts.cc:74-87; chance nodes always use their ChanceOutcomes()); 2 = dont_return_chance_node (mcts.h:168);
  * 4 = leaves are evaluated inside the launch by RandomRolloutEvaluator(cfg.n_rollouts, cfg.seed) on the streams of
- * osg_mcts_tree_rollout_values: no request 2 is ever reported, and without flag 1 a whole search is one call. */
+ * osg_mcts_tree_rollout_values: no request 2 is ever reported, and without flag 1 a whole search is one call;
+ * 8 (with 1) = every answer to a value request comes WITH the prior of the same state in d_prior (one network forward
+ * gives both: alpha_zero_torch/vpevaluator.cc:60-85 caches them per state): the prior is kept until the leaf is
+ * expanded on its second visit, so a simulation is ONE evaluator round instead of up to two; a node whose children a
+ * garbage collection cleared asks for its prior again (request 1).  d_prior must then be non-NULL in every call. */
 typedef struct osg_mcts_tree osg_mcts_tree;
 int osg_mcts_tree_create(const osg_batch* roots, const osg_mcts_cfg* cfg, int flags, osg_mcts_tree** out);
 int osg_mcts_tree_destroy(osg_mcts_tree* t);
@@ -422,6 +429,14 @@ int osg_cfr_evaluate_policy(osg_cfr* s, int which_policy, const double* h_policy
  * unreachable infostates: the first); best_response_values [P] (may be NULL) the responders' values. */
 int osg_cfr_best_response(osg_cfr* s, int which_policy, const double* h_policy, int32_t* h_best_index,
                           double* best_response_values);
+/* TabularBestResponse::Value(history) (best_response.h:127-128, best_response.cc:229-262) for EVERY history of the
+ * flattened tree at once: h_history_values [H] (osg_cfr_sizes[0]) receives the value for `responder` of each history
+ * when it best-responds from there on and the others follow the policy (choices as for osg_cfr_evaluate_policy). */
+int osg_cfr_best_response_history_values(osg_cfr* s, int which_policy, const double* h_policy, int responder,
+                                         double* h_history_values);
+/* The flattened tree's edges: parent [H] (-1 at the root) and the action / chance outcome on the edge from the
+ * parent [H] (-1 at the root); histories are numbered level by level.  Either may be NULL. */
+int osg_cfr_tree_edges(const osg_cfr* s, int32_t* parent, int32_t* action);
 /* InformationStateString() of infostate i (kuhn_poker.cc:109-166, leduc_poker.cc:198-239).
  * Returns the length (excluding NUL), or <0. */
 int osg_cfr_infostate_key(const osg_cfr* s, int64_t i, char* buf, int cap);

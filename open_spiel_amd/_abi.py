@@ -81,6 +81,7 @@ SIGNATURES = {
     "osg_ctx_synchronize": (INT, [VP]),
     "osg_ctx_stream": (VP, [VP]),
     "osg_ctx_trim": (INT, [VP]),
+    "osg_ctx_set_stream": (INT, [VP, VP]),
     "osg_game_describe": (INT, [C.c_char_p, C.POINTER(GameDesc)]),
     "osg_batch_create": (INT, [VP, C.c_char_p, I64, C.POINTER(VP)]),
     "osg_batch_destroy": (INT, [VP]),
@@ -143,6 +144,8 @@ SIGNATURES = {
     "osg_cfr_infostate_player": (INT, [VP, I64]),
     "osg_cfr_best_response": (INT, [VP, INT, VP, VP, VP]),
     "osg_cfr_infostate_key": (INT, [VP, I64, C.c_char_p, INT]),
+    "osg_cfr_best_response_history_values": (INT, [VP, INT, VP, INT, VP]),
+    "osg_cfr_tree_edges": (INT, [VP, VP, VP]),
     "osg_comm_unique_id": (INT, [VP]),
     "osg_comm_create": (INT, [VP, INT, INT, VP, C.POINTER(VP)]),
     "osg_comm_destroy": (INT, [VP]),

@@ -90,7 +90,7 @@ static void KuhnCfr() {
   // kuhn_poker_test.cc / tabular_exploitability_test.cc: every member of the optimal family is unexploitable
   // and worth -1/18 to the first player
   for (double a : {0.0, 0.1, 1.0 / 3}) {
-    const TabularPolicyTable optimal = kuhn_poker::GetOptimalPolicy(a);
+    const TabularPolicyTable optimal = kuhn_poker::GetOptimalPolicy(a).PolicyTable();
     EXPECT(std::fabs(Exploitability(*game, optimal)) < 1e-12);
     EXPECT(std::fabs(NashConv(*game, optimal)) < 1e-12);
     EXPECT(std::fabs(ExpectedReturns(*game, optimal)[0] + 1.0 / 18) < 1e-12);

@@ -26,7 +26,10 @@
 #include <cstdio>
 #include <chrono>
 #include <cstdlib>
+#include <functional>
 #include <iomanip>
+#include <map>
+#include <optional>
 #include <sstream>
 #include <limits>
 #include <memory>
@@ -47,6 +50,7 @@ using Player = int;
 constexpr Player kChancePlayerId = OSG_CHANCE_PLAYER;      // spiel_globals.h:26-56
 constexpr Player kTerminalPlayerId = OSG_TERMINAL_PLAYER;
 constexpr Action kInvalidAction = OSG_INVALID_ACTION;      // spiel_globals.h:82
+constexpr Player kDefaultPlayerId = 0, kSimultaneousPlayerId = -2, kInvalidPlayer = -3, kMeanFieldPlayerId = -5;  // :26-56
 using ActionsAndProbs = std::vector<std::pair<Action, double>>;  // spiel.h:224
 
 struct SpielException : public std::runtime_error {
@@ -56,6 +60,44 @@ struct SpielException : public std::runtime_error {
 inline void Check(int rc) {
   if (rc != OSG_OK) SpielFatalError(std::string("osg error ") + std::to_string(rc) + ": " + osg_last_error());
 }
+
+// spiel_utils.h:185-200
+template <typename T>
+bool Near(T a, T b, T epsilon) {
+  static_assert(std::is_floating_point<T>::value, "Near() is only for floating point args.");
+  return std::fabs(a - b) <= epsilon;
+}
+template <typename T>
+bool Near(T a, T b) {
+  static_assert(std::is_floating_point<T>::value, "Near() is only for floating point args.");
+  return Near(a, b, static_cast<T>(std::numeric_limits<float>::epsilon() * 128));
+}
+// spiel_utils.h:44-100: ostream operators for the containers the checks print
+template <typename T> std::ostream& operator<<(std::ostream& stream, const std::vector<T>& v);
+template <typename T, typename U> std::ostream& operator<<(std::ostream& stream, const std::pair<T, U>& v) {
+  return stream << "(" << v.first << "," << v.second << ")";
+}
+template <typename T> std::ostream& operator<<(std::ostream& stream, const std::vector<T>& v) {
+  stream << "[";
+  for (const auto& element : v) stream << element << " ";
+  return stream << "]";
+}
+template <typename T> std::ostream& operator<<(std::ostream& stream, const std::optional<T>& v) {
+  return v.has_value() ? stream << *v : stream << "nullopt";
+}
+template <typename T> std::ostream& operator<<(std::ostream& stream, const std::unique_ptr<T>& v) { return stream << *v; }
+// spiel.h:1303-1311: the sampler ResampleFromInfostate takes
+class UniformProbabilitySampler {
+ public:
+  UniformProbabilitySampler(int seed, double min = 0., double max = 1.) : seed_(seed), rng_(seed_), dist_(min, max) {}
+  UniformProbabilitySampler(double min = 0., double max = 1.) : rng_(seed_), dist_(min, max) {}
+  double operator()() { return dist_(rng_); }
+
+ private:
+  int seed_ = 0;  // (the reference seeds from the clock: callers that care pass a seed)
+  std::mt19937 rng_;
+  std::uniform_real_distribution<double> dist_;
+};
 
 // One engine context per (process, device), created on first use with its own stream.
 class Context {
@@ -114,10 +156,113 @@ class Communicator {
   osg_comm* c_ = nullptr;
 };
 
+// ---- game_parameters.h:37-180: GameParameter / GameParameters, for the parameters the path's games take ----
+class GameParameter;
+using GameParameters = std::map<std::string, GameParameter>;
+class GameParameter {
+ public:
+  enum class Type { kUnset = -1, kInt, kDouble, kString, kBool, kGame };
+  explicit GameParameter(Type type = Type::kUnset, bool is_mandatory = false) : is_mandatory_(is_mandatory), type_(type) {}
+  explicit GameParameter(int value, bool is_mandatory = false) : is_mandatory_(is_mandatory), int_value_(value), type_(Type::kInt) {}
+  explicit GameParameter(double value, bool is_mandatory = false)
+      : is_mandatory_(is_mandatory), double_value_(value), type_(Type::kDouble) {}
+  explicit GameParameter(std::string value, bool is_mandatory = false)
+      : is_mandatory_(is_mandatory), string_value_(std::move(value)), type_(Type::kString) {}
+  explicit GameParameter(const char* value, bool is_mandatory = false)
+      : is_mandatory_(is_mandatory), string_value_(value), type_(Type::kString) {}
+  explicit GameParameter(bool value, bool is_mandatory = false) : is_mandatory_(is_mandatory), bool_value_(value), type_(Type::kBool) {}
+  bool has_int_value() const { return type_ == Type::kInt; }
+  bool has_double_value() const { return type_ == Type::kDouble; }
+  bool has_string_value() const { return type_ == Type::kString; }
+  bool has_bool_value() const { return type_ == Type::kBool; }
+  bool has_game_value() const { return type_ == Type::kGame; }
+  Type type() const { return type_; }
+  bool is_mandatory() const { return is_mandatory_; }
+  int int_value() const { Want(Type::kInt); return int_value_; }
+  double double_value() const { Want(Type::kDouble); return double_value_; }
+  const std::string& string_value() const { Want(Type::kString); return string_value_; }
+  bool bool_value() const { Want(Type::kBool); return bool_value_; }
+  std::string ToString() const {  // game_parameters.cc:48-66: the text a game string carries
+    switch (type_) {
+      case Type::kInt: return std::to_string(int_value_);
+      case Type::kDouble: { std::ostringstream o; o << double_value_; return o.str(); }
+      case Type::kString: return string_value_;
+      case Type::kBool: return bool_value_ ? "True" : "False";
+      default: return "";
+    }
+  }
+
+ private:
+  void Want(Type t) const { if (type_ != t) SpielFatalError("GameParameter: wrong value type requested"); }
+  bool is_mandatory_ = false;
+  int int_value_ = 0;
+  double double_value_ = 0;
+  std::string string_value_;
+  bool bool_value_ = false;
+  Type type_ = Type::kUnset;
+};
+// game_parameters.cc:120-165 / :167-205: "name(k=v,k=v)" <-> {"name": ..., k: v} (values of a parsed string stay strings)
+inline GameParameters GameParametersFromString(const std::string& game_string) {
+  GameParameters params;
+  const size_t open = game_string.find('(');
+  params["name"] = GameParameter(game_string.substr(0, open));
+  if (open == std::string::npos) return params;
+  const size_t close = game_string.rfind(')');
+  if (close == std::string::npos || close < open) SpielFatalError("GameParametersFromString: missing ')' in " + game_string);
+  const std::string body = game_string.substr(open + 1, close - open - 1);
+  size_t pos = 0;
+  while (pos < body.size()) {
+    size_t comma = body.find(',', pos);
+    if (comma == std::string::npos) comma = body.size();
+    const std::string item = body.substr(pos, comma - pos);
+    pos = comma + 1;
+    const size_t eq = item.find('=');
+    if (eq == std::string::npos) SpielFatalError("GameParametersFromString: expected key=value in " + game_string);
+    params[item.substr(0, eq)] = GameParameter(item.substr(eq + 1));
+  }
+  return params;
+}
+inline std::string GameParametersToString(const GameParameters& params) {
+  auto name = params.find("name");
+  if (name == params.end()) SpielFatalError("GameParametersToString: no 'name' parameter");
+  std::string str = name->second.string_value(), args;
+  for (const auto& kv : params) {
+    if (kv.first == "name") continue;
+    args += (args.empty() ? "" : ",") + kv.first + "=" + kv.second.ToString();
+  }
+  return args.empty() ? str : str + "(" + args + ")";
+}
+
+// spiel.h:55-175: GameType, as the five games of the path register it
+struct GameType {
+  std::string short_name, long_name;
+  enum class Dynamics { kSimultaneous, kSequential, kMeanField };
+  Dynamics dynamics = Dynamics::kSequential;
+  enum class ChanceMode { kDeterministic, kExplicitStochastic, kSampledStochastic };
+  ChanceMode chance_mode = ChanceMode::kDeterministic;
+  enum class Information { kOneShot, kPerfectInformation, kImperfectInformation };
+  Information information = Information::kPerfectInformation;
+  enum class Utility { kZeroSum, kConstantSum, kGeneralSum, kIdentical };
+  Utility utility = Utility::kZeroSum;
+  enum class RewardModel { kRewards, kTerminal };
+  RewardModel reward_model = RewardModel::kTerminal;
+  int max_num_players = 2, min_num_players = 2;
+  bool provides_information_state_string = true, provides_information_state_tensor = false;
+  bool provides_observation_string = true, provides_observation_tensor = true;
+  GameParameters parameter_specification;
+  bool default_loadable = true;
+  bool provides_factored_observation_string = false;
+  bool is_concrete = true;
+  bool provides_information_state() const { return provides_information_state_tensor || provides_information_state_string; }
+  bool provides_observation() const { return provides_observation_tensor || provides_observation_string; }
+};
+
 class State;
 class BatchedState;
 class Policy;
 class TabularPolicy;
+class Observer;
+struct IIGObservationType;
 
 class Game : public std::enable_shared_from_this<Game> {
  public:
@@ -140,11 +285,36 @@ class Game : public std::enable_shared_from_this<Game> {
   int ObservationTensorSize() const { return desc_.obs_size; }
   int InformationStateTensorSize() const { return desc_.info_size; }
   std::string ToString() const { return desc_.canonical; }
+  // The registered GameType (tic_tac_toe.cc:32-49, connect_four.cc:41-58, hex.cc:37-58, kuhn_poker.cc:36-56,
+  // leduc_poker.cc:45-70): every game of the path is sequential, zero-sum, with terminal rewards.
+  GameType GetType() const {
+    const std::string text = ToString();
+    GameType t;
+    t.short_name = text.substr(0, text.find('('));
+    const bool poker = t.short_name == "kuhn_poker" || t.short_name == "leduc_poker";
+    t.long_name = t.short_name == "tic_tac_toe" ? "Tic Tac Toe" : t.short_name == "connect_four" ? "Connect Four"
+                  : t.short_name == "hex" ? "Hex" : t.short_name == "kuhn_poker" ? "Kuhn Poker" : "Leduc Poker";
+    t.chance_mode = poker ? GameType::ChanceMode::kExplicitStochastic : GameType::ChanceMode::kDeterministic;
+    t.information = poker ? GameType::Information::kImperfectInformation : GameType::Information::kPerfectInformation;
+    t.max_num_players = poker ? 10 : 2;
+    t.provides_information_state_tensor = poker;
+    return t;
+  }
+  std::optional<double> UtilitySum() const { return 0.0; }               // spiel.h:1012-1016: zero-sum games
+  int MaxMoveNumber() const { return MaxGameLength() + MaxChanceNodesInHistory(); }  // spiel.h:1125-1127
+  GameParameters GetParameters() const { return GameParametersFromString(ToString()); }
   std::string Serialize() const { return ToString(); }  // spiel.cc:793-800 (no sampled-stochastic games here)
   const std::string& GameString() const { return string_; }
   const osg_game_desc& Desc() const { return desc_; }
   osg_ctx* Ctx() const { return Context::Default(device_); }
   inline std::unique_ptr<State> NewInitialState() const;
+  std::unique_ptr<State> NewInitialStateForPopulation(int) const {  // spiel.h:963-966: mean-field games only
+    SpielFatalError("NewInitialStateForPopulation is not implemented.");
+  }
+  // spiel.h:1040-1054: the built-in observer for the type (nullopt = the game's default one); the only named
+  // observer the path's games register is "single_tensor" (observer.cc:347-357), which IS the built-in one
+  inline std::shared_ptr<Observer> MakeObserver(std::optional<IIGObservationType> iig_obs_type,
+                                                const GameParameters& params = {}) const;
   inline std::unique_ptr<State> DeserializeState(const std::string& str) const;  // spiel.cc:540-580
   inline BatchedState NewInitialStates(int64_t n) const;
 
@@ -157,6 +327,28 @@ class Game : public std::enable_shared_from_this<Game> {
 inline std::shared_ptr<const Game> LoadGame(const std::string& game_string) {  // spiel.h:1314
   return std::make_shared<const Game>(game_string);
 }
+inline std::shared_ptr<const Game> LoadGame(GameParameters params) {  // spiel.h:1326
+  return LoadGame(GameParametersToString(params));
+}
+inline std::shared_ptr<const Game> LoadGame(const std::string& short_name, const GameParameters& params) {  // spiel.h:1320
+  GameParameters all = params;
+  all["name"] = GameParameter(short_name);
+  return LoadGame(all);
+}
+// Entry points of the reference that lead OUTSIDE the five games of the path (game transforms, .efg files): declared
+// so that code naming them compiles; calling them is an error here, as LoadGame of any other game is.
+inline std::shared_ptr<const Game> LoadGameAsTurnBased(const std::string& name) {
+  SpielFatalError("LoadGameAsTurnBased(" + name + "): game transforms are not on the MI355X path");
+}
+inline std::shared_ptr<const Game> LoadGameAsTurnBased(const std::string& name, const GameParameters&) {
+  return LoadGameAsTurnBased(name);
+}
+namespace efg_game {
+inline std::string GetKuhnPokerEFGData() { return ""; }
+inline std::shared_ptr<const Game> LoadEFGGame(const std::string&) {
+  SpielFatalError("LoadEFGGame: .efg games are not on the MI355X path");
+}
+}  // namespace efg_game
 
 // N states of one game in HBM.  Vector-valued results are [n, ...] row-major.
 class BatchedState {
@@ -170,6 +362,13 @@ class BatchedState {
   }
   BatchedState(BatchedState&& o) noexcept : game_(std::move(o.game_)), n_(o.n_), b_(o.b_) { o.b_ = nullptr; }
   BatchedState& operator=(const BatchedState&) = delete;
+  BatchedState& operator=(BatchedState&& o) noexcept {
+    if (this != &o) {
+      if (b_) osg_batch_destroy(b_);
+      game_ = std::move(o.game_); n_ = o.n_; b_ = o.b_; o.b_ = nullptr;
+    }
+    return *this;
+  }
   ~BatchedState() { if (b_) osg_batch_destroy(b_); }
 
   int64_t size() const { return n_; }
@@ -249,12 +448,76 @@ class State {
     if (IsTerminal() || player != CurrentPlayer()) return {};  // at a chance node: only for kChancePlayerId
     return LegalActions();
   }
-  std::vector<int> LegalActionsMask() const {  // spiel.cc:518-524
+  std::vector<int> LegalActionsMask() const { return LegalActionsMask(CurrentPlayer()); }
+  std::vector<int> LegalActionsMask(Player player) const {  // spiel.cc:518-524
     const Game& g = *batch_.GetGame();
-    const int len = IsChanceNode() ? g.MaxChanceOutcomes() : g.NumDistinctActions();
+    const int len = player == kChancePlayerId ? g.MaxChanceOutcomes() : g.NumDistinctActions();
     std::vector<int> mask(len, 0);
-    for (Action a : LegalActions()) mask[a] = 1;
+    for (Action a : LegalActions(player)) mask[a] = 1;
     return mask;
+  }
+  bool IsSimultaneousNode() const { return false; }  // every game of the path is GameType::Dynamics::kSequential
+  bool IsMeanFieldNode() const { return false; }
+  bool IsPlayerNode() const { return CurrentPlayer() >= 0; }
+  bool IsInitialState() const { return history_.empty(); }
+  int NumDistinctActions() const { return batch_.GetGame()->NumDistinctActions(); }
+  void ApplyActionWithLegalityCheck(Action a) {  // spiel.cc:453-462
+    const std::vector<Action> legal = LegalActions();
+    if (std::find(legal.begin(), legal.end(), a) == legal.end())
+      SpielFatalError("Current player " + std::to_string(CurrentPlayer()) + " calling ApplyAction with illegal action (" +
+                      std::to_string(a) + ")");
+    ApplyAction(a);
+  }
+  void ApplyActions(const std::vector<Action>&) { SpielFatalError("ApplyActions is not implemented: no simultaneous-move game on this path"); }
+  void ApplyActionsWithLegalityChecks(const std::vector<Action>& a) { ApplyActions(a); }
+  std::vector<std::string> DistributionSupport() { SpielFatalError("DistributionSupport has not been implemented"); }
+  void UpdateDistribution(const std::vector<double>&) { SpielFatalError("UpdateDistribution has not been implemented"); }
+  // UndoAction (spiel.h:555-571): the state before its last action.  The device holds positions, not move stacks:
+  // the predecessor is rebuilt from the history (the reference offers Undo only where a game implements it —
+  // kuhn_poker and tic_tac_toe on this path; here every game has it, at the cost of a replay).
+  void UndoAction(Player player, Action action) {
+    if (history_.empty() || history_.back().second != action || history_.back().first != player)
+      SpielFatalError("UndoAction: (player, action) is not the last move of this state");
+    std::vector<std::pair<Player, Action>> keep(history_.begin(), history_.end() - 1);
+    BatchedState fresh(batch_.GetGame(), 1);
+    for (const auto& pa : keep) fresh.ApplyActions({static_cast<int32_t>(pa.second)});
+    batch_ = std::move(fresh);
+    history_ = std::move(keep);
+  }
+  // ResampleFromInfostate (spiel.h:778-786; kuhn_poker.cc:312-327, leduc_poker.cc:706-760): a state `player`
+  // cannot tell from this one — the other players' private deals (the first NumPlayers chance outcomes, one per
+  // player, in the two poker games) are drawn again, uniformly among the cards that stay consistent with
+  // everything `player` has seen (its own card, the public chance outcomes), every other action is replayed.
+  std::unique_ptr<State> ResampleFromInfostate(int player_id, std::function<double()> rng) const {
+    const std::shared_ptr<const Game> game = batch_.GetGame();
+    const int P = game->NumPlayers();
+    if (game->MaxChanceOutcomes() == 0) return Clone();  // perfect information: the state itself
+    std::vector<Action> kept;  // chance outcomes `player_id` knows: they stay unavailable to the redrawn deals
+    {
+      int chance_seen = 0;
+      for (const auto& pa : history_) {
+        if (pa.first != kChancePlayerId) continue;
+        if (chance_seen == player_id || chance_seen >= P) kept.push_back(pa.second);
+        ++chance_seen;
+      }
+    }
+    std::unique_ptr<State> out = game->NewInitialState();
+    int chance_seen = 0;
+    for (const auto& pa : history_) {
+      Action a = pa.second;
+      if (pa.first == kChancePlayerId) {
+        if (chance_seen != player_id && chance_seen < P) {
+          std::vector<Action> pool;
+          for (const auto& ap : out->ChanceOutcomes())
+            if (std::find(kept.begin(), kept.end(), ap.first) == kept.end()) pool.push_back(ap.first);
+          if (pool.empty()) SpielFatalError("ResampleFromInfostate: no consistent deal");
+          a = pool[std::min(pool.size() - 1, static_cast<size_t>(rng() * pool.size()))];
+        }
+        ++chance_seen;
+      }
+      out->ApplyAction(a);
+    }
+    return out;
   }
   ActionsAndProbs ChanceOutcomes() const {
     std::vector<double> p = batch_.ChanceOutcomeProbs();
@@ -279,6 +542,8 @@ class State {
   }
   std::string InformationStateString(Player player) const {  // kuhn_poker.cc:285-288, leduc_poker.cc:517-520
     CheckPlayer(player);
+    // the perfect-information games: the history (tic_tac_toe.cc:229-233, connect_four.cc:287-291, hex.cc:367-371)
+    if (batch_.GetGame()->MaxChanceOutcomes() == 0 && batch_.GetGame()->InformationStateTensorSize() == 0) return HistoryString();
     char buf[512];
     if (osg_information_state_string(batch_.handle(), 0, player, buf, sizeof(buf)) < 0) SpielFatalError(osg_last_error());
     return buf;
@@ -339,6 +604,7 @@ class State {
   std::vector<std::pair<Player, Action>> history_;
 };
 
+inline std::ostream& operator<<(std::ostream& stream, const State& state) { return stream << state.ToString(); }  // spiel.h:918
 inline std::unique_ptr<State> Game::NewInitialState() const {
   return std::unique_ptr<State>(new State(shared_from_this()));
 }
@@ -477,6 +743,14 @@ inline std::shared_ptr<Observer> MakeObserver(const Game& game, const IIGObserva
   std::vector<SpanTensorInfo> pieces = ObserverPieces(game, info_state);
   if (pieces.empty()) return nullptr;
   return std::make_shared<Observer>(info_state, std::move(pieces));
+}
+
+inline std::shared_ptr<Observer> Game::MakeObserver(std::optional<IIGObservationType> iig_obs_type,
+                                                    const GameParameters& params) const {
+  auto name = params.find("name");  // spiel.cc:866-879: a named observer from the registry, else the built-in one
+  if (name != params.end() && name->second.string_value() != "single_tensor")
+    SpielFatalError("No observer '" + name->second.string_value() + "' found for game '" + GetType().short_name + "'");
+  return open_spiel::hip::MakeObserver(*this, iig_obs_type ? &*iig_obs_type : nullptr);
 }
 
 class Observation {  // observer.h:309-371: owns the flat buffer the observer writes into
@@ -889,8 +1163,14 @@ class MCTSBot : public Bot {
 };
 
 struct CFRInfoStateValues {  // cfr.h:42-98
+  CFRInfoStateValues() {}
+  CFRInfoStateValues(std::vector<Action> la, double init_value)
+      : legal_actions(la), cumulative_regrets(la.size(), init_value), cumulative_policy(la.size(), init_value),
+        current_policy(la.size(), 1.0 / la.size()) {}
+  CFRInfoStateValues(std::vector<Action> la) : CFRInfoStateValues(la, 0) {}
   std::vector<Action> legal_actions;
   std::vector<double> cumulative_regrets, cumulative_policy, current_policy;
+  bool empty() const { return legal_actions.empty(); }
   int num_actions() const { return static_cast<int>(legal_actions.size()); }
 };
 using CFRInfoStateValuesTable = std::unordered_map<std::string, CFRInfoStateValues>;  // cfr.h:103-104
@@ -1039,6 +1319,32 @@ class DeviceTabularSolver {
     values->assign(num_players_, 0.0);
     Check(osg_cfr_best_response(s_, 2, dense.data(), best.data(), values->data()));
     return best;
+  }
+  // HistoryString() -> the responder's best-response value from that history on (TabularBestResponse::Value(history),
+  // best_response.h:127-128), for every history of the game: one device pass (osg_cfr_best_response_history_values).
+  // Infostates the table does not hold (it may leave out the responder's own) count as never played.
+  std::unordered_map<std::string, double> BestResponseHistoryValues(const TabularPolicyTable& table, Player responder) const {
+    Tables t = Download();
+    std::vector<double> dense(static_cast<size_t>(t.I) * t.A, 0.0);
+    for (int i = 0; i < t.I; ++i) {
+      auto it = table.find(Key(i));
+      if (it == table.end()) continue;
+      for (int a = 0; a < t.nact[i]; ++a)
+        for (const auto& ap : it->second)
+          if (ap.first == t.legal[i * t.A + a]) dense[i * t.A + a] = ap.second;
+    }
+    const int64_t H = sizes_[0];
+    std::vector<double> values(static_cast<size_t>(H));
+    std::vector<int32_t> parent(static_cast<size_t>(H)), action(static_cast<size_t>(H));
+    Check(osg_cfr_best_response_history_values(s_, 2, dense.data(), responder, values.data()));
+    Check(osg_cfr_tree_edges(s_, parent.data(), action.data()));
+    std::vector<std::string> text(static_cast<size_t>(H));
+    std::unordered_map<std::string, double> out;
+    for (int64_t h = 0; h < H; ++h) {  // parents come before their children (level order)
+      if (parent[h] >= 0) text[h] = (parent[parent[h]] < 0 ? std::string() : text[parent[h]] + ", ") + std::to_string(action[h]);
+      out[text[h]] = values[h];
+    }
+    return out;
   }
 
  protected:
@@ -1441,15 +1747,20 @@ class TabularBestResponse {
     if (!policy) SpielFatalError("TabularBestResponse: null policy");
     table_ = TabularPolicy(*game_, *policy).PolicyTable();
     computed_ = false;
+    history_values_.clear();
   }
   void SetPolicy(const TabularPolicyTable& table) {
     table_ = table;
     computed_ = false;
+    history_values_.clear();
   }
   double Value() { Compute(); return value_; }                               // Value(*root) (best_response.h:127-128)
-  double Value(const std::string& history) {  // the device pass reports the root's value
-    if (!history.empty()) SpielFatalError("TabularBestResponse::Value: only the root history is offered");
-    return Value();
+  double Value(const std::string& history) {  // best_response.h:127-128: history = State::HistoryString()
+    if (history.empty()) return Value();
+    if (history_values_.empty()) history_values_ = solver_.BestResponseHistoryValues(table_, responder_);
+    auto it = history_values_.find(history);
+    if (it == history_values_.end()) SpielFatalError("TabularBestResponse::Value: no such history: " + history);
+    return it->second;
   }
   double Value(const State& state) { return Value(state.HistoryString()); }
   std::unordered_map<std::string, Action> GetBestResponseActions() { Compute(); return actions_; }
@@ -1491,6 +1802,7 @@ class TabularBestResponse {
   std::vector<double> values_;
   std::unordered_map<std::string, Action> actions_;
   std::unordered_map<std::string, std::vector<Action>> legal_;
+  std::unordered_map<std::string, double> history_values_;
 };
 
 // algorithms::Exploitability / NashConv / ExpectedReturns of ANY Policy (tabular_exploitability.h:30-60,
@@ -1513,13 +1825,34 @@ inline std::vector<double> ExpectedReturns(const State& state, const Policy& joi
   return ExpectedReturns(*state.GetGame(), joint_policy);
 }
 
-// kuhn_poker::GetOptimalPolicy (kuhn_poker.cc:451-474): the alpha-family of Nash equilibria of 2-player
-// Kuhn poker, alpha in [0, 1/3]; its value for player 0 is -1/18.
+}  // namespace algorithms
+
+// policy.cc:400-430 GetPrefActionPolicy: at every infostate the first action of `pref_actions` that is legal, with
+// probability 1.
+inline TabularPolicy GetPrefActionPolicy(const Game& game, const std::vector<Action>& pref_actions) {
+  TabularPolicy p;
+  for (const auto& kv : AllInfoStates(game)) {
+    Action chosen = kInvalidAction;
+    for (Action want : pref_actions)
+      if (std::find(kv.second.begin(), kv.second.end(), want) != kv.second.end()) { chosen = want; break; }
+    if (chosen == kInvalidAction) SpielFatalError("GetPrefActionPolicy: no preferred action is legal at " + kv.first);
+    ActionsAndProbs ap;
+    for (Action a : kv.second) ap.push_back({a, a == chosen ? 1.0 : 0.0});
+    p.SetStatePolicy(kv.first, ap);
+  }
+  return p;
+}
+
+// kuhn_poker.h:40-47, kuhn_poker.cc:439-474
 namespace kuhn_poker {
-inline TabularPolicyTable GetOptimalPolicy(double alpha) {
+enum ActionType { kPass = 0, kBet = 1 };
+inline TabularPolicy GetAlwaysPassPolicy(const Game& game) { return GetPrefActionPolicy(game, {ActionType::kPass}); }
+inline TabularPolicy GetAlwaysBetPolicy(const Game& game) { return GetPrefActionPolicy(game, {ActionType::kBet}); }
+// the alpha-family of Nash equilibria of 2-player Kuhn poker, alpha in [0, 1/3]; its value for player 0 is -1/18
+inline TabularPolicy GetOptimalPolicy(double alpha) {
   if (!(alpha >= 0.0 && alpha <= 1.0 / 3)) SpielFatalError("GetOptimalPolicy: alpha must lie in [0, 1/3]");
   const double three_alpha = 3 * alpha;
-  TabularPolicyTable policy;
+  algorithms::TabularPolicyTable policy;
   // every infostate has two actions: Pass (0) and Bet (1)
   policy["0"] = {{0, 1 - alpha}, {1, alpha}};            // player 0
   policy["0pb"] = {{0, 1}, {1, 0}};
@@ -1533,9 +1866,44 @@ inline TabularPolicyTable GetOptimalPolicy(double alpha) {
   policy["1b"] = {{0, 2. / 3.}, {1, 1. / 3.}};
   policy["2p"] = {{0, 0}, {1, 1}};
   policy["2b"] = {{0, 0}, {1, 1}};
-  return policy;
+  return TabularPolicy(policy);
 }
 }  // namespace kuhn_poker
+
+// leduc_poker.h:64, leduc_poker.cc:872-888
+namespace leduc_poker {
+enum ActionType { kFold = 0, kCall = 1, kRaise = 2 };
+inline TabularPolicy GetAlwaysFoldPolicy(const Game& game) { return GetPrefActionPolicy(game, {ActionType::kFold, ActionType::kCall}); }
+inline TabularPolicy GetAlwaysCallPolicy(const Game& game) { return GetPrefActionPolicy(game, {ActionType::kCall}); }
+inline TabularPolicy GetAlwaysRaisePolicy(const Game& game) { return GetPrefActionPolicy(game, {ActionType::kRaise, ActionType::kCall}); }
+}  // namespace leduc_poker
+
+namespace algorithms {
+
+// algorithms/get_all_states.h:30-48: every state of the game reachable from its root, keyed by ToString(); the walk
+// stops where a key repeats (stop_at_duplicates) — a host-side walk over one-state batches, for small games.
+inline std::map<std::string, std::unique_ptr<State>> GetAllStates(const Game& game, int depth_limit, bool include_terminals,
+                                                                  bool include_chance_states, bool stop_at_duplicates = true) {
+  std::map<std::string, std::unique_ptr<State>> all;
+  std::vector<std::pair<std::unique_ptr<State>, int>> todo;
+  todo.emplace_back(game.NewInitialState(), 0);
+  while (!todo.empty()) {
+    std::unique_ptr<State> st = std::move(todo.back().first);
+    const int depth = todo.back().second;
+    todo.pop_back();
+    const bool terminal = st->IsTerminal(), chance = !terminal && st->IsChanceNode();
+    const bool include = terminal ? include_terminals : (chance ? include_chance_states : true);
+    bool seen = false;
+    if (include) {
+      const std::string key = st->ToString();
+      seen = all.count(key) > 0;
+      if (!seen) all[key] = st->Clone();
+    }
+    if (terminal || (depth_limit >= 0 && depth >= depth_limit) || (seen && stop_at_duplicates)) continue;
+    for (Action a : st->LegalActions()) todo.emplace_back(st->Child(a), depth + 1);
+  }
+  return all;
+}
 
 enum class AverageType { kSimple, kFull };
 
@@ -1571,6 +1939,19 @@ inline CFRInfoStateValuesTable DeserializeValuesTable(const std::string& body, c
   }
   for (size_t i = 0; i + 1 < splits.size(); i += 2) table.emplace(splits[i], DeserializeInfoStateValues(splits[i + 1]));
   return table;
+}
+// cfr.h:111-119 / cfr.cc:639-673, with the reference's signatures
+inline void SerializeCFRInfoStateValuesTable(const CFRInfoStateValuesTable& info_states, std::string* result,
+                                             int double_precision, std::string delimiter = "<~>") {
+  if (delimiter == "," || delimiter == ";")
+    SpielFatalError("Please select a different delimiter,invalid values are \",\" and \";\".");
+  if (info_states.empty()) return;
+  *result += SerializeValuesTable(info_states, double_precision, delimiter);
+}
+inline void DeserializeCFRInfoStateValuesTable(const std::string& serialized, CFRInfoStateValuesTable* result,
+                                               std::string delimiter = "<~>") {
+  if (serialized.empty()) return;
+  for (auto& kv : DeserializeValuesTable(serialized, delimiter)) result->insert(std::move(kv));
 }
 // Splits a checkpoint into its top-level sections; [SolverSpecificState] keeps its line structure.
 struct PartialCheckpoint {

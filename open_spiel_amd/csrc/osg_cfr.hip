@@ -855,6 +855,8 @@ struct EvalArrays {
   double* cf;                // [M] scratch
   int32_t* best;             // [I] scratch: chosen action index
   double* out;               // [2P]: ev[P] then br[P]
+  double* keep = nullptr;    // [H] or null: the best-response value of EVERY history for responder keep_r
+  int keep_r = -1;           //          (TabularBestResponse::Value(history), best_response.h:127-128)
 };
 
 __global__ void __launch_bounds__(1024)
@@ -935,6 +937,8 @@ k_policy_eval(Tree t, EvalArrays ea, const double* __restrict__ pol) {
       __syncthreads();
     }
     if (tid == 0) ea.out[P + r] = ea.brv[0];
+    if (ea.keep && r == ea.keep_r)
+      for (int h = tid; h < t.H; h += nt) ea.keep[h] = ea.brv[h];
     __syncthreads();
   }
 }
@@ -1621,6 +1625,7 @@ struct osg_cfr {
   // host tree
   std::vector<int32_t> level_off, parent, first_child, info, mem_off, mem, nact, legal;
   std::vector<uint8_t> kind, nchild, aidx;
+  std::vector<int32_t> edge_action;  // [H] the action (or chance outcome) on the edge from the parent, -1 at the root
   std::vector<int8_t> actor, info_player;
   std::vector<double> edge_prob, term_ret;
   std::vector<std::string> keys;
@@ -1709,6 +1714,7 @@ int build_tree(osg_cfr* s, const char* game_string) {
   // parent was expanded; this loop fills in what depends on the state itself.
   s->parent.push_back(-1);
   s->aidx.push_back(0);
+  s->edge_action.push_back(-1);
   s->edge_prob.push_back(0.0);
   int64_t level_begin = 0;
   while (level) {
@@ -1753,6 +1759,7 @@ int build_tree(osg_cfr* s, const char* game_string) {
         actions.push_back(acts[k]);
         s->parent.push_back(static_cast<int32_t>(h));
         s->aidx.push_back(static_cast<uint8_t>(k));
+        s->edge_action.push_back(acts[k]);
         s->edge_prob.push_back(chance ? probs[i * C + acts[k]] : 0.0);
       }
       if (chance) {
@@ -2642,8 +2649,33 @@ int osg_cfr_set_iteration(osg_cfr* s, int iteration) {
   return OSG_OK;
 }
 
+static int evaluate_policy_impl(osg_cfr* s, int which_policy, const double* h_policy, double* expected_returns,
+                                double* best_response_values, double* nash_conv, double* exploitability,
+                                int keep_responder, double* h_history_values);
+
 int osg_cfr_evaluate_policy(osg_cfr* s, int which_policy, const double* h_policy, double* expected_returns,
                             double* best_response_values, double* nash_conv, double* exploitability) {
+  return evaluate_policy_impl(s, which_policy, h_policy, expected_returns, best_response_values, nash_conv, exploitability,
+                              -1, nullptr);
+}
+
+int osg_cfr_best_response_history_values(osg_cfr* s, int which_policy, const double* h_policy, int responder,
+                                         double* h_history_values) {
+  if (!s || !h_history_values) return set_error(OSG_ERR_INVALID, "osg_cfr_best_response_history_values: null argument");
+  if (responder < 0 || responder >= s->P) return set_error(OSG_ERR_INVALID, "osg_cfr_best_response_history_values: no such player");
+  return evaluate_policy_impl(s, which_policy, h_policy, nullptr, nullptr, nullptr, nullptr, responder, h_history_values);
+}
+
+int osg_cfr_tree_edges(const osg_cfr* s, int32_t* parent, int32_t* action) {
+  if (!s) return set_error(OSG_ERR_INVALID, "osg_cfr_tree_edges: null solver");
+  if (parent) memcpy(parent, s->parent.data(), sizeof(int32_t) * s->H);
+  if (action) memcpy(action, s->edge_action.data(), sizeof(int32_t) * s->H);
+  return OSG_OK;
+}
+
+static int evaluate_policy_impl(osg_cfr* s, int which_policy, const double* h_policy, double* expected_returns,
+                                double* best_response_values, double* nash_conv, double* exploitability,
+                                int keep_responder, double* h_history_values) {
   if (!s) return set_error(OSG_ERR_INVALID, "osg_cfr_evaluate_policy: null solver");
   if (!s->eval_ok) return set_error(OSG_ERR_UNSUPPORTED, "an information state spans several tree levels");
   const size_t IA = static_cast<size_t>(s->I) * s->A, M = s->mem.size();
@@ -2674,10 +2706,16 @@ int osg_cfr_evaluate_policy(osg_cfr* s, int which_policy, const double* h_policy
   OSG_HIP(hipMemcpyAsync(d_pol, pol.data(), sizeof(double) * IA, hipMemcpyHostToDevice, st));
   int threads = ((s->max_level_width + 63) / 64) * 64;
   threads = std::max(64, std::min(threads, 1024));
+  if (h_history_values) {  // the responder's value of every history: kept in d_reach ([H, P + 1] doubles, free here)
+    ea.keep = s->d_reach;
+    ea.keep_r = keep_responder;
+  }
   k_policy_eval<<<dim3(1), dim3(threads), 0, st>>>(s->tree(), ea, d_pol);
   OSG_HIP(hipGetLastError());
   std::vector<double> out(2 * P);
   OSG_HIP(hipMemcpyAsync(out.data(), ea.out, sizeof(double) * 2 * P, hipMemcpyDeviceToHost, st));
+  if (h_history_values)
+    OSG_HIP(hipMemcpyAsync(h_history_values, s->d_reach, sizeof(double) * s->H, hipMemcpyDeviceToHost, st));
   OSG_HIP(hipStreamSynchronize(st));
   double nc = 0.0, total_br = 0.0;
   for (int p = 0; p < P; ++p) {

@@ -1006,6 +1006,13 @@ int osg_ctx_synchronize(osg_ctx* ctx) {
 }
 void* osg_ctx_stream(osg_ctx* ctx) { return ctx->stream; }
 
+int osg_ctx_set_stream(osg_ctx* ctx, void* stream) {
+  if (!ctx || ctx->closed) return set_error(OSG_ERR_INVALID, "osg_ctx_set_stream: bad context");
+  if (ctx->own_stream) return set_error(OSG_ERR_INVALID, "osg_ctx_set_stream: the context owns its stream");
+  ctx->stream = static_cast<hipStream_t>(stream);
+  return OSG_OK;
+}
+
 int osg_ctx_trim(osg_ctx* ctx) {
   if (!ctx || ctx->closed) return set_error(OSG_ERR_INVALID, "osg_ctx_trim: bad context");
   OSG_HIP(hipSetDevice(ctx->device));

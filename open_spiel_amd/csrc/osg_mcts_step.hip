@@ -15,6 +15,7 @@
 // into the root's prior, mcts.cc:284-292), max_wall_clock_time (the host checks its clock between rounds).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -39,11 +40,16 @@ struct osg_mcts_tree {
   double* d_own_prior = nullptr;   // [n, A]
   double* d_own_value = nullptr;   // [n, P]
   uint8_t* d_own_request = nullptr;
+  // flag 8: the evaluator answers a value request with the leaf's PRIOR as well (one network forward gives both,
+  // vpevaluator.cc:60-85 caches them per state): the prior is kept per (root, simulation) until the leaf is expanded
+  double* d_stash = nullptr;       // [n, stash_slots, A]
+  int stash_slots = 0;
 };
 
 namespace {
 
 enum Phase : uint8_t { kNewSimulation = 0, kWantPrior = 1, kWantValue = 2, kFinished = 3 };
+constexpr int kScanChunk = 8;  // children whose statistics are requested together in the descent
 
 struct StepPool {
   double* total;    // [cap, n]
@@ -62,6 +68,8 @@ struct StepPool {
   uint8_t* phase;
   int64_t n;
   int cap, gc_nodes;
+  double* stash;      // [n, stash_slots, A] or null (flag 8)
+  int stash_slots;
 };
 
 template <class G, bool kBoard>
@@ -69,12 +77,20 @@ __global__ void __launch_bounds__(kBlockM)
 k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typename G::word_t* leaf_words, int64_t n,
                int num_players, int num_actions, osg_mcts_cfg cfg, int flags, double max_utility,
                const double* __restrict__ log_table, StepPool pool, const double* __restrict__ prior_in,
-               const double* __restrict__ value_in, uint8_t* __restrict__ request, int max_new_simulations) {
-  const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlockM + threadIdx.x;
+               const double* __restrict__ value_in, uint8_t* __restrict__ request, int max_new_simulations,
+               int lane_stride) {
+  // lane_stride > 1: only every lane_stride-th lane of a wavefront carries a search.  A search is a chain of
+  // dependent, scattered loads (its own tree); with one search per lane 2^16 roots are 1 024 wavefronts — one per
+  // SIMD, nothing to hide that latency behind.  Spreading the same searches over lane_stride times as many
+  // wavefronts (fewer active lanes each) gives every SIMD several chains to interleave.
+  const int64_t slot = static_cast<int64_t>(blockIdx.x) * kBlockM + threadIdx.x;
+  if (lane_stride > 1 && (threadIdx.x % lane_stride) != 0) return;
+  const int64_t r = slot / lane_stride;
   if (r >= n) return;
   const uint64_t gr = static_cast<uint64_t>(cfg.index_offset + r);
   const int64_t NR = pool.n;
   const bool host_priors = (flags & 1) != 0, through_chance = (flags & 2) != 0, own_rollouts = (flags & 4) != 0;
+  const bool stashing = pool.stash != nullptr;
 #define META(i) pool.meta[static_cast<int64_t>(i) * NR + r]
 #define FIRST(i) pool.first[static_cast<int64_t>(i) * NR + r]
 #define PARENT(i) pool.parent[static_cast<int64_t>(i) * NR + r]
@@ -105,7 +121,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
     request[r] = req;
   };
   // expand `node` (mcts.cc:281-299): one child per prior entry, shuffled
-  auto expand = [&](const Mask& legal, int cur, bool from_host) -> bool {
+  auto expand = [&](const Mask& legal, int cur, bool from_host, const double* stashed) -> bool {
     const int c = legal.count();
     if (c == 0 || used + static_cast<uint32_t>(c) > static_cast<uint32_t>(pool.cap)) return false;  // nothing to expand / slots exhausted (see osg_mcts.hip)
     const uint32_t first = used;
@@ -114,6 +130,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
       const int a = select_action(legal, k);
       double pr;
       if (cur == kChancePlayer) pr = G::chance_prob(p, s, a);       // Prior() of a chance node: ChanceOutcomes()
+      else if (stashed) pr = stashed[a];                            // the prior that came with the node's evaluation
       else if (from_host) pr = prior_in[r * num_actions + a];
       else pr = 1.0 / c;                                            // RandomRolloutEvaluator::Prior (mcts.cc:74-87)
       META(first + k) = make_meta(a, cur, 0);
@@ -149,31 +166,47 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
     }
     if (phase == kWantValue) {
       for (int q = 0; q < num_players; ++q) returns[q] = value_in[r * num_players + q];
+      if (stashing && prior_in != nullptr && sims_done < pool.stash_slots) {
+        // keep the leaf's prior for its expansion (a later simulation's second visit, mcts.cc:281-299); an
+        // unexpanded node's first-child field is free: it holds the stash slot + 1
+        double* slot = pool.stash + (static_cast<size_t>(r) * pool.stash_slots + sims_done) * num_actions;
+        for (int a = 0; a < num_actions; ++a) slot[a] = prior_in[r * num_actions + a];
+        FIRST(node) = static_cast<uint32_t>(sims_done) + 1u;
+      }
     } else {
       // ---- ApplyTreePolicy (mcts.cc:273-351) ----
       bool resume_expand = phase == kWantPrior;
+      // the header of the node the walk stands on (count, meta, first child) comes down with the parent's child scan
+      bool carried = false;
+      uint32_t n_cnt = 0, n_meta = 0, n_first = 0;
       for (;;) {
         term = G::terminal(p, s);
-        const uint32_t cnt = COUNT(node);
+        const uint32_t cnt = carried ? n_cnt : COUNT(node);
         const int cur = term ? kTerminalPlayer : G::current_player(p, s);
         if (!resume_expand && !((!term && cnt > 0) || (!term && cur == kChancePlayer && through_chance))) break;
-        uint32_t meta = META(node);
+        uint32_t meta = carried ? n_meta : META(node);
+        bool expanded_now = false;
         if (m_nchild(meta) == 0) {
           const Mask legal = G::legal(p, s);
-          if (cur != kChancePlayer && host_priors && !resume_expand) {  // Prior(state) comes from the host
+          const uint32_t slot1 = (stashing && cur != kChancePlayer && !resume_expand) ? (carried ? n_first : FIRST(node)) : 0u;
+          const double* stashed =
+              slot1 ? pool.stash + (static_cast<size_t>(r) * pool.stash_slots + (slot1 - 1u)) * num_actions : nullptr;
+          if (cur != kChancePlayer && host_priors && !resume_expand && !stashed) {  // Prior(state) comes from the host
             G::store(p, leaf_words, n, r, s);
             park(kWantPrior, node == 0 ? 5 : 1);  // 5 = the ROOT's prior (where Dirichlet noise goes, mcts.cc:284)
             return;
           }
-          const bool ok = expand(legal, cur, resume_expand);
+          const bool ok = expand(legal, cur, resume_expand, stashed);
           resume_expand = false;
           if (!ok) break;
           meta = META(node);
+          expanded_now = true;
         }
         resume_expand = false;
-        const uint32_t first = FIRST(node);
+        const uint32_t first = (carried && !expanded_now) ? n_first : FIRST(node);
         const int c = m_nchild(meta);
-        uint32_t chosen = first;
+        uint32_t chosen = first, chosen_meta = 0, chosen_cnt = 0, chosen_first = 0;
+        bool have_chosen_meta = false;
         if (cur == kChancePlayer) {  // mcts.cc:311-322
           const Mask legal = G::legal(p, s);
           const int a = sample_action_chance<G>(p, s, legal, trng);
@@ -184,19 +217,43 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
           const double logn = log_table[cnt];
           const bool puct = cfg.child_selection_policy == 1;
           const double sqrt_n = sqrt(static_cast<double>(cnt));
-          for (int k = 0; k < c; ++k) {
-            const uint32_t cm = META(first + k);
-            const uint32_t cc = COUNT(first + k);
-            double v;
-            if (m_has_outcome(cm)) v = outcome_value<kBoard>(cm, cc, TOTAL(first + k), m_player(cm));
-            else if (puct) v = (cc != 0 ? TOTAL(first + k) / cc : 0.0) + cfg.uct_c * PRIOR(first + k) * sqrt_n / (cc + 1);
-            else if (cc == 0) v = INFINITY;
-            else v = TOTAL(first + k) / cc + cfg.uct_c * sqrt(logn / cc);
-            if (v > best) { best = v; chosen = first + k; }
+          // A search is ONE chain of dependent, scattered loads (its own tree), and that chain — not bandwidth, not
+          // instruction issue — is what a launch lasts (2^16 roots, one simulation per launch: 370 us, unchanged
+          // with 2x / 4x the wavefronts per SIMD).  So the children's four planes are requested eight children at a
+          // time with clamped indices (32 independent loads, ONE round trip) instead of child by child behind the
+          // branches of the value formula (two round trips per child).
+          for (int k0 = 0; k0 < c; k0 += kScanChunk) {
+            uint32_t cm[kScanChunk], cc[kScanChunk], cf[kScanChunk];
+            double ct[kScanChunk], cp[kScanChunk];
+#pragma unroll
+            for (int j = 0; j < kScanChunk; ++j) {
+              const uint32_t at = first + static_cast<uint32_t>(k0 + j < c ? k0 + j : c - 1);
+              cm[j] = META(at);
+              cc[j] = COUNT(at);
+              cf[j] = FIRST(at);
+              ct[j] = TOTAL(at);
+              cp[j] = PRIOR(at);
+            }
+#pragma unroll
+            for (int j = 0; j < kScanChunk; ++j) {
+              if (k0 + j >= c) continue;
+              double v;
+              if (m_has_outcome(cm[j])) v = outcome_value<kBoard>(cm[j], cc[j], ct[j], m_player(cm[j]));
+              else if (puct) v = (cc[j] != 0 ? ct[j] / cc[j] : 0.0) + cfg.uct_c * cp[j] * sqrt_n / (cc[j] + 1);
+              else if (cc[j] == 0) v = INFINITY;
+              else v = ct[j] / cc[j] + cfg.uct_c * sqrt(logn / cc[j]);
+              if (v > best) {
+                best = v; chosen = first + static_cast<uint32_t>(k0 + j);
+                chosen_meta = cm[j]; chosen_cnt = cc[j]; chosen_first = cf[j];
+              }
+            }
           }
+          have_chosen_meta = true;
         }
-        G::apply(p, s, static_cast<int>(m_action(META(chosen))));
+        G::apply(p, s, static_cast<int>(m_action(have_chosen_meta ? chosen_meta : META(chosen))));
         node = chosen;
+        carried = have_chosen_meta;
+        n_cnt = chosen_cnt; n_meta = chosen_meta; n_first = chosen_first;
       }
       // ---- evaluate (mcts.cc:372-381) ----
       if (term) {
@@ -309,8 +366,11 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
 template <class G>
 __global__ void __launch_bounds__(kBlockM)
 k_mcts_tree_rollout(typename G::Params p, const typename G::word_t* leaf_words, int64_t n, int num_players,
-                    osg_mcts_cfg cfg, const uint8_t* __restrict__ phase, const int32_t* __restrict__ sims, double* value) {
-  const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlockM + threadIdx.x;
+                    osg_mcts_cfg cfg, const uint8_t* __restrict__ phase, const int32_t* __restrict__ sims, double* value,
+                    int lane_stride) {
+  const int64_t slot = static_cast<int64_t>(blockIdx.x) * kBlockM + threadIdx.x;
+  if (lane_stride > 1 && (threadIdx.x % lane_stride) != 0) return;
+  const int64_t r = slot / lane_stride;
   if (r >= n || phase[r] != kWantValue) return;
   const uint64_t gr = static_cast<uint64_t>(cfg.index_offset + r);
   const typename G::State s = G::load(p, leaf_words, n, r);
@@ -432,11 +492,27 @@ StepPool make_pool(const osg_mcts_tree* t) {
   pool.n = t->n;
   pool.cap = t->cap;
   pool.gc_nodes = t->gc_nodes;
+  pool.stash = t->d_stash;
+  pool.stash_slots = t->stash_slots;
   return pool;
 }
 
 size_t pool_bytes(int64_t cap, int64_t n) {
   return static_cast<size_t>(cap) * n * 36 + static_cast<size_t>(n) * (8 + 4 * 4 + 1) + 256;
+}
+
+// Active lanes per wavefront for the lane-per-root kernels.  1 = every lane carries a search (the default).  Spreading
+// the searches over more wavefronts (OSG_MCTS_LANE_STRIDE = 2 ... 16: every k-th lane active) was measured on 2^16
+// connect_four roots, one simulation per launch (tools/probe_advance_stride.py, profiles/r03_advance_stride.log):
+// 370 / 377 / 418 / 498 / 633 us for k = 1 / 2 / 4 / 8 / 16 — a launch lasts as long as ONE search's chain of
+// dependent loads, which more wavefronts do not shorten (they only add instruction issue); what shortens it is
+// fewer round trips per tree level (the chunked child scan in k_mcts_advance).
+int lane_stride_for(osg_ctx*, int64_t) {
+  if (const char* e = std::getenv("OSG_MCTS_LANE_STRIDE")) {
+    const int v = std::atoi(e);
+    if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return v;
+  }
+  return 1;
 }
 
 bool same_game(const osg_batch* a, const osg_batch* b) {
@@ -459,7 +535,9 @@ int osg_mcts_tree_create(const osg_batch* roots, const osg_mcts_cfg* cfg_in, int
     return set_error(OSG_ERR_UNSUPPORTED, "solve=true needs win/draw/loss outcomes (tic_tac_toe, connect_four, hex)");
   if (cfg_in->child_selection_policy != 0 && cfg_in->child_selection_policy != 1)
     return set_error(OSG_ERR_INVALID, "osg_mcts_cfg.child_selection_policy must be 0 (UCT) or 1 (PUCT)");
-  if (flags & ~7) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_create: unknown flag");
+  if (flags & ~15) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_create: unknown flag");
+  if ((flags & 8) && !(flags & 1)) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_create: flag 8 (priors arrive with the values) needs flag 1");
+  if ((flags & 8) && (flags & 4)) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_create: flags 4 and 8 exclude each other");
   if (int rc = refuse_endless_playouts(roots->spec, "osg_mcts_tree_create")) return rc;
   osg_mcts_tree* t = new osg_mcts_tree;
   t->ctx = ctx;
@@ -493,6 +571,11 @@ int osg_mcts_tree_create(const osg_batch* roots, const osg_mcts_cfg* cfg_in, int
   t->bytes = pool_bytes(cap, t->n);
   e = hipMalloc(reinterpret_cast<void**>(&t->d_mem), t->bytes);
   if (e != hipSuccess) { delete t; return set_error(OSG_ERR_NOMEM, std::string("MCTS trees: ") + hipGetErrorString(e)); }
+  if (flags & 8) {
+    t->stash_slots = cfg_in->max_simulations + 1;
+    e = hipMalloc(reinterpret_cast<void**>(&t->d_stash), sizeof(double) * static_cast<size_t>(t->n) * t->stash_slots * t->A);
+    if (e != hipSuccess) { (void)hipFree(t->d_mem); delete t; return set_error(OSG_ERR_NOMEM, std::string("MCTS prior stash: ") + hipGetErrorString(e)); }
+  }
   int rc = osg_batch_create(ctx, d.canonical, roots->n, &t->roots);
   if (rc == OSG_OK) rc = osg_batch_copy(t->roots, roots);
   if (rc) { (void)hipFree(t->d_mem); if (t->roots) osg_batch_destroy(t->roots); delete t; return rc; }
@@ -527,6 +610,7 @@ int osg_mcts_tree_destroy(osg_mcts_tree* t) {
   (void)hipFree(t->d_mem);
   (void)hipFree(t->d_logs);
   if (t->d_own_prior) (void)hipFree(t->d_own_prior);
+  if (t->d_stash) (void)hipFree(t->d_stash);
   osg::ctx_release(t->ctx);
   delete t;
   return OSG_OK;
@@ -537,7 +621,8 @@ int osg_mcts_tree_advance(osg_mcts_tree* t, osg_batch* leaf, const double* d_pri
   if (!t || !leaf || !d_request) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_advance: null argument");
   if (!same_game(t->roots, leaf)) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_advance: the leaf batch must have the roots' game and size");
   if (max_new_simulations < 0) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_advance: max_new_simulations < 0");
-  const unsigned grid = static_cast<unsigned>((t->n + kBlockM - 1) / kBlockM);
+  const int lane_stride = lane_stride_for(t->ctx, t->n);
+  const unsigned grid = static_cast<unsigned>((t->n * lane_stride + kBlockM - 1) / kBlockM);
   const osg_game_desc& d = t->roots->spec.desc;
   const StepPool pool = make_pool(t);
   hipStream_t st = t->ctx->stream;
@@ -546,13 +631,13 @@ int osg_mcts_tree_advance(osg_mcts_tree* t, osg_batch* leaf, const double* d_pri
                                      P, static_cast<const typename G::word_t*>(t->roots->d_words),
                                      static_cast<typename G::word_t*>(leaf->d_words), t->n, d.num_players, t->A, t->cfg,
                                      t->flags, t->max_utility, t->d_logs, pool, d_prior, d_value, d_request,
-                                     max_new_simulations));
+                                     max_new_simulations, lane_stride));
   } else {
     OSG_DISPATCH(t->roots->spec, k_mcts_advance<G, false><<<dim3(grid), dim3(kBlockM), 0, st>>>(
                                      P, static_cast<const typename G::word_t*>(t->roots->d_words),
                                      static_cast<typename G::word_t*>(leaf->d_words), t->n, d.num_players, t->A, t->cfg,
                                      t->flags, t->max_utility, t->d_logs, pool, d_prior, d_value, d_request,
-                                     max_new_simulations));
+                                     max_new_simulations, lane_stride));
   }
   OSG_HIP(hipGetLastError());
   if (h_counts) {  // how many searches are finished / want a prior / want a value / were paused by max_new_simulations
@@ -607,11 +692,12 @@ int osg_mcts_tree_rollout_values(osg_mcts_tree* t, const osg_batch* leaf, double
     d_value = t->d_own_value;
   }
   if (!same_game(t->roots, leaf)) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_rollout_values: the leaf batch must have the roots' game and size");
-  const unsigned grid = static_cast<unsigned>((t->n + kBlockM - 1) / kBlockM);
+  const int lane_stride = lane_stride_for(t->ctx, t->n);
+  const unsigned grid = static_cast<unsigned>((t->n * lane_stride + kBlockM - 1) / kBlockM);
   const StepPool pool = make_pool(t);
   OSG_DISPATCH(t->roots->spec, k_mcts_tree_rollout<G><<<dim3(grid), dim3(kBlockM), 0, t->ctx->stream>>>(
                                    P, static_cast<const typename G::word_t*>(leaf->d_words), t->n, t->P, t->cfg, pool.phase,
-                                   pool.sims, d_value));
+                                   pool.sims, d_value, lane_stride));
   OSG_HIP(hipGetLastError());
   return OSG_OK;
 }

@@ -51,6 +51,14 @@ class Context:
         """Free what the context caches between calls (the MCTS node pool, the staging buffer)."""
         check(lib().osg_ctx_trim(self._h))
 
+    def set_stream(self, stream):
+        """Issue every later call of this context's objects on `stream` (a torch.cuda.Stream of the same device),
+        e.g. the stream a graph is being captured on; returns the stream that was bound before."""
+        before = self.torch_stream
+        check(lib().osg_ctx_set_stream(self._h, C.c_void_p(stream.cuda_stream)))
+        self.torch_stream = stream
+        return before
+
     def close(self):
         if self._h:
             lib().osg_ctx_destroy(self._h)
@@ -184,6 +192,18 @@ class StateBatch:
         out = self._dev((self.n, self.desc.mask_words), torch.int32)
         check(lib().osg_legal_mask(self._h, _ptr(out), 0))
         return out
+
+    def legal_actions_bool(self):
+        """[n, A] bool, True where action a is legal for the player to move: the bit mask against a row of powers of
+        two (two small launches; legal_actions_mask() builds the reference's 0 / 1 layout with six)."""
+        bits = self.legal_actions_mask_bits()
+        A = self.desc.num_distinct_actions
+        if getattr(self, "_pow2", None) is None:
+            a = torch.arange(A, device=self.ctx.device)
+            self._pow2 = (torch.ones_like(a, dtype=torch.int64) << (a % 32)).to(torch.int32)   # bit 31 wraps to the sign bit
+            self._word = (a // 32).to(torch.int64)
+        words = bits if bits.shape[1] == 1 else bits.index_select(1, self._word)
+        return (words & self._pow2) != 0
 
     def legal_actions_mask(self):
         """[n, max(A, C)] uint8, one entry per action id (State::LegalActionsMask)."""

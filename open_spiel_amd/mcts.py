@@ -16,6 +16,7 @@ of that batch answers them all, and the searches resume (osg_mcts_tree_* in incl
 `RolloutEvaluator` is RandomRolloutEvaluator on the device; with it `search` reproduces
 `StateBatch.mcts_search(layout=1)` draw for draw (tests/test_z5_gpu_mcts_evaluator.py).
 """
+import contextlib
 import ctypes as C
 import time
 
@@ -38,8 +39,16 @@ class RolloutEvaluator:
 
 class BatchedEvaluator:
     """Base class of evaluators that run outside the kernel.  Override `evaluate`: it is called ONCE per round
-    of the search, whatever the number of roots."""
+    of the search, whatever the number of roots.
+
+    joint = True declares that evaluate() always returns BOTH answers for every row (a policy / value network: one
+    forward gives both, as alpha_zero_torch/vpevaluator.cc:60-85 caches them per state) and is a pure function of
+    the leaf batch built from device-side torch ops (no host synchronisation, no Python-side branching on tensor
+    values).  search() then keeps the prior that arrives with a leaf's value until the leaf is expanded (one evaluator
+    round per simulation instead of up to two) and replays the whole round — search kernel, observation pack, legal
+    mask, forward — as ONE captured graph without reading anything back to the host between rounds."""
     needs_prior = True
+    joint = False
 
     def evaluate(self, leaf, want_prior, want_value):
         """leaf: StateBatch of the states the searches ask about; want_prior / want_value: [n] bool device
@@ -51,6 +60,8 @@ class BatchedEvaluator:
 
 
 class VPNetEvaluator(BatchedEvaluator):
+    joint = True   # every forward answers prior AND value of the same states: search() keeps the priors (flag 8)
+
     """alpha_zero_torch's VPNetEvaluator for a batch: `model(obs, legal)` maps the current player's observation
     tensors [B, obs_size] float32 and the legal-action mask [B, A] bool to (policy [B, A] over the legal actions,
     value [B] of player 0); Evaluate = {v, -v} (vpevaluator.cc:73-77, two-player zero-sum), Prior = the policy
@@ -63,12 +74,12 @@ class VPNetEvaluator(BatchedEvaluator):
         if leaf.num_players != 2:
             raise OsgError("VPNetEvaluator assumes a two-player zero-sum game (vpevaluator.cc:74)")
         obs = leaf.observation_tensor(-1)
-        legal = leaf.legal_actions_mask()[:, :leaf.num_distinct_actions].bool()
+        legal = leaf.legal_actions_bool()
         with torch.no_grad():
             policy, value = self.model(obs, legal)
         policy = policy.to(torch.float64) * legal
-        value = value.to(torch.float64).reshape(-1)
-        return policy.contiguous(), torch.stack([value, -value], dim=1).contiguous()
+        value = value.to(torch.float64).reshape(-1, 1)
+        return policy, torch.cat([value, -value], dim=1)
 
 
 def dirichlet_noise(count, alpha, generator):
@@ -87,14 +98,21 @@ def dirichlet_noise(count, alpha, generator):
 
 def search(roots, evaluator, max_simulations=1024, uct_c=2.0, n_rollouts=1, solve=False, max_nodes=0, seed=0,
            index_offset=0, puct=False, dirichlet_alpha=0.0, dirichlet_epsilon=0.0, dont_return_chance_node=False,
-           max_wall_clock_time=0.0, noise_generator=None, want_tree_of=None):
+           max_wall_clock_time=0.0, noise_generator=None, want_tree_of=None, graph=None):
     """MCTSBot::MCTSearch (mcts.cc:353-467) for every root of `roots` with `evaluator` outside the kernel.
     Arguments as MCTSBot's constructor (mcts.h:161-169).  max_wall_clock_time > 0 stops the searches when that
     many seconds have passed (checked between evaluator rounds) instead of after max_simulations.
     Returns the dictionary of StateBatch.mcts_search plus child_prior [n, A]; want_tree_of=i adds "tree": root
-    i's whole tree as arrays (meta, first_child, explore_count, total_reward, prior; include/osg_abi.h)."""
+    i's whole tree as arrays (meta, first_child, explore_count, total_reward, prior; include/osg_abi.h).
+    graph: None = evaluators that declare joint = True run one evaluator round per simulation (nothing read back between
+    rounds); False = always the request / answer loop below; True = additionally capture the round once and replay it as
+    a graph (measured slower than plain launches on ROCm 7: 1.8 vs 0.73 ms per round at 2^16 roots — kept as an option)."""
     ctx, n = roots.ctx, roots.n
     A, P = roots.num_distinct_actions, roots.num_players
+    if (getattr(evaluator, "joint", False) and graph is not False and dirichlet_alpha == 0 and max_wall_clock_time <= 0
+            and not isinstance(evaluator, RolloutEvaluator)):
+        return _search_joint(roots, evaluator, max_simulations, uct_c, n_rollouts, solve, max_nodes, seed, index_offset,
+                             puct, dont_return_chance_node, want_tree_of, use_graph=graph is True)
     needs_prior = bool(getattr(evaluator, "needs_prior", True)) or dirichlet_alpha > 0
     flags = (1 if needs_prior else 0) | (2 if dont_return_chance_node else 0)
     # (with max_wall_clock_time the searches still stop at max_simulations: the tree slots are sized for it)
@@ -109,11 +127,12 @@ def search(roots, evaluator, max_simulations=1024, uct_c=2.0, n_rollouts=1, solv
         prior = value = None
         start = time.perf_counter()
         while True:
+            # (one new simulation per search and launch: see _search_joint)
             check(lib().osg_mcts_tree_advance(tree, leaf._h, None if prior is None else prior.data_ptr(),
                                               None if value is None else value.data_ptr(), request.data_ptr(),
-                                              1 << 30, counts))
+                                              1, counts))
             prior = value = None
-            if counts[1] == 0 and counts[2] == 0:
+            if counts[1] == 0 and counts[2] == 0 and counts[3] == 0:
                 break
             if max_wall_clock_time > 0 and time.perf_counter() - start >= max_wall_clock_time:
                 break
@@ -152,28 +171,128 @@ def search(roots, evaluator, max_simulations=1024, uct_c=2.0, n_rollouts=1, solv
                     raise OsgError(f"evaluator value has shape {tuple(value.shape)}, expected {(n, P)}")
             else:
                 value = None
-        out = {
-            "best_action": torch.empty(n, dtype=torch.int32, device=ctx.device),
-            "child_visits": torch.empty((n, A), dtype=torch.int32, device=ctx.device),
-            "child_reward": torch.empty((n, A), dtype=torch.float64, device=ctx.device),
-            "child_outcome": torch.empty((n, A), dtype=torch.int8, device=ctx.device),
-            "child_prior": torch.empty((n, A), dtype=torch.float64, device=ctx.device),
-            "root_stats": torch.empty((n, 4), dtype=torch.float64, device=ctx.device),
-        }
-        check(lib().osg_mcts_tree_results(tree, *[out[k].data_ptr() for k in
-                                                  ("best_action", "child_visits", "child_reward", "child_outcome",
-                                                   "child_prior", "root_stats")]))
-        if want_tree_of is not None:
-            import numpy as np
-            used = lib().osg_mcts_tree_nodes(tree, int(want_tree_of))
-            if used < 0:
-                raise OsgError("no such root")
-            arrs = {"meta": np.zeros(used, np.uint32), "first_child": np.zeros(used, np.uint32),
-                    "explore_count": np.zeros(used, np.uint32), "total_reward": np.zeros(used, np.float64),
-                    "prior": np.zeros(used, np.float64)}
-            check(lib().osg_mcts_tree_download(tree, int(want_tree_of), used, *[a.ctypes.data for a in arrs.values()]))
-            out["tree"] = arrs
-        ctx.synchronize()
-        return out
+        return _results(tree, ctx, n, A, want_tree_of)
     finally:
+        lib().osg_mcts_tree_destroy(tree)
+
+
+def _answer(t, rows, cols):
+    """An evaluator's answer as the kernel reads it: [rows, cols] float64, contiguous (no copy when it already is)."""
+    if t.shape != (rows, cols):
+        raise OsgError(f"evaluator answer has shape {tuple(t.shape)}, expected {(rows, cols)}")
+    return t.to(torch.float64).contiguous()
+
+
+def _results(tree, ctx, n, A, want_tree_of):
+    out = {
+        "best_action": torch.empty(n, dtype=torch.int32, device=ctx.device),
+        "child_visits": torch.empty((n, A), dtype=torch.int32, device=ctx.device),
+        "child_reward": torch.empty((n, A), dtype=torch.float64, device=ctx.device),
+        "child_outcome": torch.empty((n, A), dtype=torch.int8, device=ctx.device),
+        "child_prior": torch.empty((n, A), dtype=torch.float64, device=ctx.device),
+        "root_stats": torch.empty((n, 4), dtype=torch.float64, device=ctx.device),
+    }
+    check(lib().osg_mcts_tree_results(tree, *[out[k].data_ptr() for k in
+                                              ("best_action", "child_visits", "child_reward", "child_outcome",
+                                               "child_prior", "root_stats")]))
+    if want_tree_of is not None:
+        import numpy as np
+        used = lib().osg_mcts_tree_nodes(tree, int(want_tree_of))
+        if used < 0:
+            raise OsgError("no such root")
+        arrs = {"meta": np.zeros(used, np.uint32), "first_child": np.zeros(used, np.uint32),
+                "explore_count": np.zeros(used, np.uint32), "total_reward": np.zeros(used, np.float64),
+                "prior": np.zeros(used, np.float64)}
+        check(lib().osg_mcts_tree_download(tree, int(want_tree_of), used, *[a.ctypes.data for a in arrs.values()]))
+        out["tree"] = arrs
+    ctx.synchronize()
+    return out
+
+
+def _search_joint(roots, evaluator, max_simulations, uct_c, n_rollouts, solve, max_nodes, seed, index_offset, puct,
+                  dont_return_chance_node, want_tree_of, use_graph):
+    """search() for an evaluator that answers prior and value together (BatchedEvaluator.joint): the prior that comes
+    with a leaf's value is kept on the device until the leaf is expanded (osg_mcts_tree_create flag 8), so every
+    simulation is ONE round — advance the searches, pack the leaves' observations and legal masks, one forward — and
+    nothing is read back between rounds: after max_simulations + 1 rounds every search has finished (a search whose
+    nodes a garbage collection cleared may ask for a prior again and take a few rounds more: the request counts are
+    read once at the end and the loop goes on while any search is unfinished).  The round is captured once as a graph
+    on a side stream and replayed."""
+    ctx, n = roots.ctx, roots.n
+    A, P = roots.num_distinct_actions, roots.num_players
+    flags = 1 | 8 | (2 if dont_return_chance_node else 0)
+    cfg = _abi.MctsCfg(uct_c, int(max_simulations), n_rollouts, int(solve), max_nodes, seed, index_offset, 1,
+                       1 if puct else 0)
+    tree = C.c_void_p()
+    check(lib().osg_mcts_tree_create(roots._h, C.byref(cfg), flags, C.byref(tree)))
+    side = torch.cuda.Stream(device=ctx.device) if use_graph else None
+    bound_before = None
+    try:
+        leaf = type(roots)(ctx, roots.game_string, n)
+        request = torch.zeros(n, dtype=torch.uint8, device=ctx.device)
+        prior = torch.zeros((n, A), dtype=torch.float64, device=ctx.device)
+        value = torch.zeros((n, P), dtype=torch.float64, device=ctx.device)
+        everything = torch.ones(n, dtype=torch.bool, device=ctx.device)
+
+        # At most ONE new simulation per search and launch.  A simulation that ends on a terminal node needs no
+        # evaluator, so an uncapped search goes straight on to the next one — and a root with an immediate win among
+        # its children runs dozens of simulations in one launch while the other 63 lanes of its wavefront wait
+        # (measured, 2^16 connect_four roots: launches of 170-670 us where capped ones take 60-80 us; some roots ran
+        # 27 simulations in one launch).  Capped, every launch is one simulation per search and the rounds stay in
+        # step; searches paused by the cap (request 3) simply start their next simulation in the next launch.
+        answers = [prior, value]   # the tensors the next advance reads (kept alive here)
+
+        def one_round():
+            check(lib().osg_mcts_tree_advance(tree, leaf._h, answers[0].data_ptr(), answers[1].data_ptr(),
+                                              request.data_ptr(), 1, None))
+            pr, va = evaluator.evaluate(leaf, everything, everything)
+            if use_graph:   # a replayed graph reads fixed addresses
+                prior.copy_(pr.reshape(n, A))
+                value.copy_(va.reshape(n, P))
+            else:
+                answers[0], answers[1] = _answer(pr, n, A), _answer(va, n, P)
+
+        rounds = int(max_simulations)   # + the advances of the loop below: the last answers, searches the cap held back
+        graph = None
+        if use_graph:
+            ctx.synchronize()
+            side.wait_stream(torch.cuda.current_stream(ctx.device))
+            bound_before = ctx.set_stream(side)
+            with torch.cuda.stream(side):
+                one_round()                      # warm-up on the side stream (it is round 1 of the search)
+                side.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    one_round()
+                for _ in range(rounds - 1):
+                    graph.replay()
+        else:
+            for _ in range(rounds):
+                one_round()
+        counts = (C.c_int64 * 4)()
+        spare = 4 * rounds + 16
+        # every planned round ended with an evaluation: one more advance consumes it; searches that still want an
+        # answer afterwards (only after a garbage collection cleared kept priors) go on, request counts read each time
+        stream_ctx = torch.cuda.stream(side) if use_graph else contextlib.nullcontext()
+        with stream_ctx:
+            while True:
+                check(lib().osg_mcts_tree_advance(tree, leaf._h, answers[0].data_ptr(), answers[1].data_ptr(),
+                                                  request.data_ptr(), 1, counts))
+                if counts[1] == 0 and counts[2] == 0 and counts[3] == 0:
+                    break
+                spare -= 1
+                if spare < 0:
+                    raise OsgError("joint search did not finish")
+                pr, va = evaluator.evaluate(leaf, everything, everything)
+                answers[0], answers[1] = _answer(pr, n, A), _answer(va, n, P)
+        if use_graph:
+            with torch.cuda.stream(side):
+                out = _results(tree, ctx, n, A, want_tree_of)
+            side.synchronize()
+            return out
+        return _results(tree, ctx, n, A, want_tree_of)
+    finally:
+        if bound_before is not None:
+            ctx.synchronize()
+            ctx.set_stream(bound_before)
         lib().osg_mcts_tree_destroy(tree)

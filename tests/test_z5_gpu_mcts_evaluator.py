@@ -105,6 +105,10 @@ class StubEvaluator:
         return prior, value
 
 
+class JointStubEvaluator(StubEvaluator):
+    joint = True   # one forward answers prior and value of the same states (mcts.BatchedEvaluator.joint)
+
+
 @pytest.mark.parametrize("game,n,sims,puct,solve,max_nodes,through_chance,max_stop", [
     ("tic_tac_toe", 64, 200, False, True, 0, False, 5),
     ("tic_tac_toe", 64, 200, True, False, 0, False, 5),
@@ -118,15 +122,25 @@ class StubEvaluator:
     ("leduc_poker", 32, 300, True, False, 40, True, 7),
     ("kuhn_poker(players=3)", 32, 150, True, False, 0, False, 5),
 ])
-def test_network_guided_search_replay_parity(oracle, ctx, game, n, sims, puct, solve, max_nodes, through_chance, max_stop):
+@pytest.mark.parametrize("mode", ["loop", "joint", "joint-graph"])
+def test_network_guided_search_replay_parity(oracle, ctx, game, n, sims, puct, solve, max_nodes, through_chance, max_stop, mode):
+    """mode: "loop" = the request / answer loop (a prior round and a value round per simulation); "joint" = the
+    evaluator declares that one forward answers both, the prior that arrives with a leaf's value is kept on the device
+    until the leaf is expanded (one round per simulation, nothing read back between rounds); "joint-graph" = the same
+    with the round captured once and replayed as a graph.  All three must give the oracle's search."""
     from open_spiel_amd import mcts
     min_stop = (3 if "players=3" in game else 2) if "poker" in game else 0
     og, roots, hists = _roots(oracle, ctx, game, n, 53, max_stop, min_stop)
     net = StubNet(roots.desc.obs_size, roots.num_distinct_actions, roots.num_players, ctx.device)
     seed, offset = 0x57AB, 9000
-    res = mcts.search(roots, StubEvaluator(net), max_simulations=sims, uct_c=1.3, solve=solve, seed=seed, index_offset=offset,
-                      puct=puct, max_nodes=max_nodes, dont_return_chance_node=through_chance)
-    assert net.forwards <= 2 * sims + 2, "ONE forward per evaluator round, whatever the number of roots (a simulation has at most a prior round and a value round)"
+    evaluator = StubEvaluator(net) if mode == "loop" else JointStubEvaluator(net)
+    res = mcts.search(roots, evaluator, max_simulations=sims, uct_c=1.3, solve=solve, seed=seed, index_offset=offset,
+                      puct=puct, max_nodes=max_nodes, dont_return_chance_node=through_chance,
+                      graph={"loop": False, "joint": None, "joint-graph": True}[mode])
+    if mode == "loop":
+        assert net.forwards <= 2 * sims + 2, "ONE forward per evaluator round, whatever the number of roots (a simulation has at most a prior round and a value round)"
+    elif max_nodes == 0:
+        assert net.forwards <= sims + 3, "joint evaluators: one round per simulation"
     best = res["best_action"].cpu().numpy()
     visits = res["child_visits"].cpu().numpy()
     reward = res["child_reward"].cpu().numpy()

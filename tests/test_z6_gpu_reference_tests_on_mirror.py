@@ -11,6 +11,21 @@ exits 0, i.e. every SPIEL_CHECK_* of the reference's own test held on the MI355X
 * external_sampling_mccfr_test.cc: kuhn (1000 iterations, NashConv < 0.05), leduc (1000, < 2.5), 3-player kuhn,
   the Serialize/Deserialize round trip at 1e-15 — liars_dice left out.
 * outcome_sampling_mccfr_test.cc: kuhn (10000, < 0.17), leduc (10000, < 3.07), serialization — liars_dice left out.
+* cfr_test.cc: 11 of its tests (goofspiel / matrix games through LoadGameAsTurnBased left out): Kuhn CFR and CFR+ reach
+  the Nash value and exploitability <= 0.05, the 3- / 4-player Kuhn and leduc NashConv bounds, the table and solver
+  serialization round trips.
+* tabular_exploitability_test.cc (as is): exploitability / NashConv of the optimal, uniform and first-action policies
+  on kuhn and leduc equal the reference's constants (0, 0.4583333333333335, 2.373611111111111, 0.916666666666667,
+  4.747222222222222, 1, 2), the illegal-action regression.
+* best_response_test.cc: 13 of 14 (the .efg one left out): best-response actions against five policies and the
+  best-response value of EVERY history against the reference's golden tables.
+* hex_test.cc and kuhn_poker_test.cc (as is) and leduc_poker_test.cc (the configurations the engine offers: 2 and 3
+  players), each linked with the reference's tests/basic_tests.cc compiled unmodified: RandomSimTest — hundreds of
+  random games checking Clone, serialization round trips, legal-action masks, sorted / unique actions, every
+  player's tensors and strings at every state, returns — plus undo, ResampleFromInfostate, the single_tensor
+  observer, GetAllStates (54 kuhn states), the always-X policies, board orientation and the swap rule.
+* basic_tests.cc on tic_tac_toe and connect_four with the arguments of tic_tac_toe_test.cc / connect_four_test.cc
+  (whose sources also exercise the JSON struct API, off the path): RandomSimTest, FastLoss, arbitrary board sizes.
 """
 import os
 import subprocess
@@ -20,7 +35,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILT = os.path.join(ROOT, "tests", "_refbuilt")
 BINARIES = ["reference_cfr_br_test", "reference_mcts_test_on_mirror", "reference_es_mccfr_test_on_mirror",
-            "reference_os_mccfr_test_on_mirror"]
+            "reference_os_mccfr_test_on_mirror", "reference_cfr_test_on_mirror", "reference_tabular_exploitability_test",
+            "reference_best_response_test_on_mirror", "reference_hex_test", "reference_kuhn_poker_test",
+            "reference_leduc_poker_test_on_mirror", "reference_basic_tests_boards_on_mirror"]
 
 
 def _ensure_built():
@@ -45,6 +62,6 @@ def test_reference_unit_test_passes_on_the_mirror(binary):
     path = os.path.join(BUILT, binary)
     if not os.access(path, os.X_OK):
         pytest.fail(f"{path} missing: run __graft_entry__.build() where /root/reference exists before shipping")
-    r = subprocess.run([path], capture_output=True, text=True, timeout=900)
-    print(r.stdout[-2000:])
+    r = subprocess.run([path], capture_output=True, text=True, timeout=1200)
+    print(r.stdout[-1500:])
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]

@@ -17,6 +17,24 @@ def model(obs, legal):
     policy = torch.softmax(out[:, :7].masked_fill(~legal, -1e9), 1)
     return policy, torch.tanh(out[:, 7])
 
+def timeit(fn, reps=50):
+    for _ in range(5): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
+
+# what one round of 65536 leaves costs, piece by piece (eager launches, so each figure includes its launch gaps)
+big = osa.StateBatch(ctx, "connect_four", 65536); big.random_steps(3, 9)
+ev = mcts.VPNetEvaluator(model)
+obs = big.observation_tensor(-1)
+legal = big.legal_actions_mask()[:, :7].bool()
+every = torch.ones(65536, dtype=torch.bool, device="cuda")
+print(f"65536 leaves: observation pack {timeit(lambda: big.observation_tensor(-1, out=obs)) * 1e6:.1f} us, legal mask (bits -> [n, 7] bool) "
+      f"{timeit(lambda: big.legal_actions_bool()) * 1e6:.1f} us, network forward {timeit(lambda: net(obs)) * 1e6:.1f} us, "
+      f"whole model (forward + masked softmax + tanh) {timeit(lambda: model(obs, legal)) * 1e6:.1f} us, "
+      f"evaluator.evaluate {timeit(lambda: ev.evaluate(big, every, every)) * 1e6:.1f} us", flush=True)
+del big, obs, legal
+
 for n, sims in [(1024, 200), (4096, 200), (16384, 200), (65536, 100)]:
     roots = osa.StateBatch(ctx, "connect_four", n)
     roots.random_steps(3, 6)
@@ -26,8 +44,15 @@ for n, sims in [(1024, 200), (4096, 200), (16384, 200), (65536, 100)]:
     res = mcts.search(roots, mcts.VPNetEvaluator(model), max_simulations=sims, uct_c=1.4, puct=True, dirichlet_alpha=0.0)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     done = float(res["root_stats"][:, 3].sum())
-    print(f"connect_four {n} roots x {sims} sims, MLP 126-256-256-8: {dt:.3f} s, {done / dt:.3g} sims/s, {calls[0]} forwards "
-          f"({dt / calls[0] * 1e3:.2f} ms per round incl. the search kernel, observation pack and legal mask)", flush=True)
+    print(f"connect_four {n} roots x {sims} sims, MLP 126-256-256-8 fp32, one evaluator round per simulation (prior kept with the value, nothing read back between rounds): {dt:.3f} s, {done / dt:.3g} sims/s "
+          f"({dt / (sims + 1) * 1e3:.3f} ms per round: search kernel + observation pack + legal mask + forward)", flush=True)
+    calls[0] = 0
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res0 = mcts.search(roots, mcts.VPNetEvaluator(model), max_simulations=sims, uct_c=1.4, puct=True, graph=False)
+    torch.cuda.synchronize(); dt0 = time.perf_counter() - t0
+    same = bool(torch.equal(res["child_visits"], res0["child_visits"]))
+    print(f"   request / answer loop (round 2's path): {float(res0['root_stats'][:, 3].sum()) / dt0:.3g} sims/s, {calls[0]} forwards, "
+          f"{dt0 / calls[0] * 1e3:.2f} ms per round; same visit counts: {same}", flush=True)
     ro = mcts.search(roots, mcts.RolloutEvaluator(), max_simulations=sims, uct_c=1.4)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     ro = mcts.search(roots, mcts.RolloutEvaluator(), max_simulations=sims, uct_c=1.4)

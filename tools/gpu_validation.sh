@@ -40,6 +40,7 @@ DB=$(find "$OUT/trace" -name '*.db' | head -1)
 if [ -n "$DB" ]; then python tools/rocpd_summary.py "$DB" > "$OUT/kernel_stats.csv" 2>> "$OUT/trace.log"; fi
 find "$OUT/trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_rocprof.csv" \; 2>/dev/null
 head -12 "$OUT/kernel_stats.csv" 2>/dev/null | tee -a "$OUT/summary.txt"
+python tools/launch_timing.py "$OUT" > "$OUT/launch_timing.txt" 2>&1; cat "$OUT/launch_timing.txt" | tee -a "$OUT/summary.txt"
 
 for C in FETCH_SIZE WRITE_SIZE; do
   echo "== rocprofv3 --pmc $C" | tee -a "$OUT/summary.txt"
@@ -62,7 +63,9 @@ python tools/pmc_mcts.py "$OUT" "$TAG" 2>&1 | tee -a "$OUT/summary.txt"
 
 echo "== probes" | tee -a "$OUT/summary.txt"
 timeout 600 python tools/probe_mcts_bench.py > "$OUT/mcts_bench.log" 2>&1; grep hex "$OUT/mcts_bench.log" | tee -a "$OUT/summary.txt"
-timeout 600 python tools/probe_cfr.py > "$OUT/probe_cfr.log" 2>&1; tail -8 "$OUT/probe_cfr.log" | cut -c1-200 | tee -a "$OUT/summary.txt"
+timeout 600 python tools/probe_cfr.py > "$OUT/probe_cfr.log" 2>&1; tail -12 "$OUT/probe_cfr.log" | cut -c1-200 | tee -a "$OUT/summary.txt"
+timeout 600 python tools/probe_kernels.py > "$OUT/probe_kernels.log" 2>&1; grep "2^24" "$OUT/probe_kernels.log" | cut -c1-220 | tee -a "$OUT/summary.txt"
+timeout 600 python tools/probe_mcts_evaluator.py > "$OUT/mcts_evaluator.log" 2>&1; tail -12 "$OUT/mcts_evaluator.log" | cut -c1-220 | tee -a "$OUT/summary.txt"
 # keep the merged-back directory small (gpurun merges at most 64 MiB)
 find "$OUT" -name '*.db' -size +20M -delete 2>/dev/null
 du -sh "$OUT" | tee -a "$OUT/summary.txt"

@@ -68,13 +68,12 @@ for game, depth in [("connect_four", 12), ("tic_tac_toe", 3), ("hex(board_size=9
         b = osa.StateBatch(ctx, game, NB); b.random_steps(3, depth)
         dst = osa.StateBatch(ctx, game, NB)
         mask, status = b.step_buffers()
-        if hex_nw:   # any empty cell: the lowest one of the first non-empty mask word
-            bits = b.legal_actions_mask_bits()
-            w = (bits != 0).to(torch.int8).argmax(1)
-            lm = bits.gather(1, w.to(torch.int64).unsqueeze(1)).squeeze(1).to(torch.int64) & 0xFFFFFFFF
-            low = torch.log2((lm & -lm).to(torch.float64)).to(torch.int32) + 32 * w.to(torch.int32)
-            acts = torch.where(lm != 0, low, torch.full((NB,), 255, device="cuda", dtype=torch.int32)).to(torch.uint8)
-            del bits, w, low
+        if hex_nw:   # a uniformly random empty cell per state (what every caller on the path plays; "the lowest
+            # empty cell" is on the north edge rows for nearly every state, so nearly every step runs the edge-connection
+            # flood, and the launch is ~10 % slower — profiles/r03_hex_step.log has both)
+            lm = b.legal_actions_mask()
+            acts = torch.where(lm.any(1), (lm.to(torch.float32) * torch.rand(lm.shape, device="cuda")).argmax(1),
+                               torch.full((NB,), 255, device="cuda")).to(torch.uint8)
         else:
             lm = b.legal_actions_mask_bits()[:, 0]
             acts = torch.where(lm != 0, (torch.log2((lm & -lm).to(torch.float32))).to(torch.int32), torch.full((NB,), 255, device="cuda", dtype=torch.int32)).to(torch.uint8)

@@ -32,5 +32,6 @@ if os.path.exists(path):
             print(f"traced   (rocprofv3 --kernel-trace, grid_x {grid}, {calls} launches): avg {avg / 1e3:.3f} us, min {mn / 1e3:.3f} us, max {mx / 1e3:.3f} us")
 else:
     print("traced: no kernel_stats.csv in", out)
-print("The traced figure includes the tracer's per-dispatch serialisation (kernels of a back-to-back stream no longer overlap"
-      " their launch latencies); bench.py's `value` and `roofline` use the untraced one.")
+print("untraced = (event after the last launch - event before the first) / launches on a saturated stream, so it includes the"
+      " gaps between kernels; traced = the kernels' own begin-to-end durations.  bench.py's `value` and `roofline` use the"
+      " untraced figure (the larger claim on the denominator).")

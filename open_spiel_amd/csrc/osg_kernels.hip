@@ -550,55 +550,6 @@ k_observation_rows(typename G::Params p, const typename G::word_t* base, int64_t
   }
 }
 
-// The same short rows, GRANULE form.  What the write side of the chip wants (tools/fill_probe.hip, MI355X): every
-// store instruction of a workgroup covering one whole, aligned 4 KiB granule, consecutive granules written by
-// consecutive workgroups — which the dispatcher spreads over the 8 XCDs, so that every XCD keeps to its own residue
-// class of granules — and one store per thread: 0.86 of 8 TB/s for a plain fill of that shape against 0.70 for "each
-// wavefront writes its own contiguous 11 KiB".  So the output, not the batch, is cut into pieces here: workgroup g owns
-// floats [1024 g, 1024 g + 1024) of the flat tensor, its lanes walk the rows of the ~1024 / size states that intersect
-// the granule (the two boundary rows are clipped, and computed again by the neighbour) into a 4 KiB LDS tile, and every
-// thread stores one aligned float4.  `rounds` > 1: a workgroup takes granules g, g + grid, ... (grid a multiple of 8).
-constexpr int kGranFloats = 1024;
-template <class G, bool kNt>
-__global__ void __launch_bounds__(256)
-k_observation_granules(typename G::Params p, const typename G::word_t* base, int64_t n, int size, int player, int which,
-                       float* __restrict__ out, uint32_t total_floats, int rounds) {
-  __shared__ __attribute__((aligned(16))) float tile[kGranFloats];
-  for (int r = 0; r < rounds; ++r) {
-    const uint32_t g = blockIdx.x + static_cast<uint32_t>(r) * gridDim.x;
-    const uint32_t f0 = g * static_cast<uint32_t>(kGranFloats);  // (the launcher checked: total_floats + 2048 < 2^32)
-    if (f0 >= total_floats) return;
-    const uint32_t usize = static_cast<uint32_t>(size);
-    const uint32_t s0 = f0 / usize, k0 = f0 - s0 * usize;          // first state of the granule, offset inside its row
-    const uint32_t nst = (k0 + kGranFloats + usize - 1) / usize;   // rows that intersect the granule
-    for (uint32_t t = threadIdx.x; t < nst; t += 256) {
-      const int64_t i = static_cast<int64_t>(s0) + t;
-      if (i >= n) break;
-      const typename G::State s = G::load(p, base, n, i);
-      int pl = player;
-      if (pl < 0) {
-        pl = G::current_player(p, s);
-        if (pl < 0) pl = 0;
-      }
-      const int first = t == 0 ? static_cast<int>(k0) : 0;                       // the row's first float inside the granule
-      const int room = kGranFloats + static_cast<int>(k0) - static_cast<int>(t * usize);
-      const int last = room < size ? room : size;                                // (exclusive)
-      float* dst = tile + (static_cast<int>(t * usize) - static_cast<int>(k0) + first);
-      typename G::ObsCursor cur;
-      cur.init(p, s, pl, which, first);
-      for (int k = first; k < last; ++k) *dst++ = cur.next(p, s, pl, which);
-    }
-    __syncthreads();
-    const uint32_t f = f0 + 4u * threadIdx.x;
-    if (f + 4u <= total_floats) {
-      store_row4<kNt>(reinterpret_cast<float4*>(out + f), *reinterpret_cast<const float4*>(tile + 4 * threadIdx.x));
-    } else {
-      for (uint32_t e = 0; e < 4u && f + e < total_floats; ++e) out[f + e] = tile[4 * threadIdx.x + e];
-    }
-    if (rounds > 1) __syncthreads();
-  }
-}
-
 // connect_four 6x7 tensor pack, fallback for an output pointer that is only 4-byte aligned: one lane per
 // BOARD ROW of the tensor (3 planes x 6 rows per state, 7 floats each).  The seven cells of a row sit at
 // bit stride 7 in the column-major bitboard; one multiply gathers them (same identity as
@@ -1408,29 +1359,7 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
     }
 #undef OSG_HEX_OBS
   } else if (size <= kRowsMaxSize && b->spec.desc.game_kind != kHex && (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) {
-    // short rows: one lane per state, LDS-staged aligned float4 stores.  OSG_OBS_ROWS="gran[:rounds]" / "rows" picks
-    // the form (a tuning knob; results do not depend on it)
-    int gran_rounds = 0;
-    if (const char* e = std::getenv("OSG_OBS_ROWS")) {
-      if (std::strncmp(e, "gran", 4) == 0) {
-        gran_rounds = 1;
-        if (e[4] == ':') gran_rounds = std::max(1, std::atoi(e + 5));
-      }
-    }
-    if (gran_rounds > 0 && total + 2048 < (int64_t{1} << 32)) {
-      const int64_t granules = (total + kGranFloats - 1) / kGranFloats;
-      int64_t grid = (granules + gran_rounds - 1) / gran_rounds;
-      if (gran_rounds > 1) grid = (grid + 7) / 8 * 8;
-      OSG_DISPATCH(b->spec, k_observation_granules<G, true><<<dim3(static_cast<unsigned>(grid)), dim3(256), 0, ctx->stream>>>(
-                                P, static_cast<const typename G::word_t*>(b->d_words), b->n, size, player, which, d_out,
-                                static_cast<uint32_t>(total), gran_rounds));
-      OSG_HIP(hipGetLastError());
-      if (on_host) {
-        OSG_HIP(hipMemcpyAsync(out, d_out, sizeof(float) * total, hipMemcpyDeviceToHost, ctx->stream));
-        OSG_HIP(hipStreamSynchronize(ctx->stream));
-      }
-      return OSG_OK;
-    }
+    // short rows: one lane per state, LDS-staged aligned float4 stores
     const size_t shmem = sizeof(float) * (kRowsBlock / 64) * 64 * static_cast<size_t>(size | 1);
     const unsigned grid = static_cast<unsigned>((b->n + kRowsBlock - 1) / kRowsBlock);
     OSG_DISPATCH(b->spec, k_observation_rows<G><<<dim3(grid), dim3(kRowsBlock), shmem, ctx->stream>>>(

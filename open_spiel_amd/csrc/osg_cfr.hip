@@ -498,16 +498,24 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
 // recursion adds up across deals (cfr.cc:379-405): an infostate's regret / average-policy terms come from member
 // histories in several subtrees.  Per player pass:
 //   A  values bottom-up inside the subtree (one __syncthreads per level);
-//   B  one thread per decision history of the subtree: reach from the root path, regret / average-policy terms,
-//      written THROUGH to memory (agent-scope stores) into the pass's term buffer (two buffers, by pass parity);
-//   -- one grid barrier: a counter every workgroup bumps once its stores have drained, polled by one lane --
+//   B  one thread per decision history of the subtree: reach from the root path, then the history's own-reach and
+//      its A regret terms go THROUGH to memory (agent-scope stores) as SELF-VALIDATING words: every fp64 travels as two
+//      64-bit words, each carrying 32 bits of it under a 32-bit tag (the exchange epoch, + a "pruned" bit on the first
+//      word).  A 64-bit store is single-copy atomic, so a reader that sees the tag of the epoch it waits for on every
+//      word holds that epoch's value — no flag after the data, hence no wait for the stores to drain, no arrival
+//      counter and no second round trip;
 //   C  every workgroup folds, for each infostate that has a member in ITS subtree, ALL that infostate's members'
-//      terms (agent-scope loads: they bypass the caches that may hold the previous pass's lines) in DFS order —
-//      the same additions in the same order in every workgroup that keeps the row, so the copies stay bit-identical
-//      and equal to the single-workgroup kernels' tables — then RM+ clamp and regret matching into its LDS rows.
-// One barrier per pass, no second one: the rows a subtree needs next are the rows it has just folded itself.
+//      terms in DFS order: up to kSplitChunk members' words are requested at once (agent-scope loads: they bypass the
+//      caches that may hold older lines), re-requested until every tag matches, then added — the same additions in
+//      the same order in every workgroup that keeps the row, so the copies stay bit-identical and equal to the
+//      single-workgroup kernels' tables — then RM+ clamp and regret matching into its LDS rows.  (The average-policy
+//      term is own_reach x policy: the reader multiplies by its own bit-identical copy of the row, cfr.cc:398-404.)
+// One exchange per pass, pairwise: a workgroup waits only for the subtrees that share an infostate with it.  A writer
+// can run ahead of a reader by at most `passes` epochs (its next fold in the same pass needs the reader's words), so the
+// words live in a ring of 2 x passes slots, slot = epoch mod ring.  Epochs come from a counter of the solver that only
+// grows (a reset or a loaded checkpoint must not make old words look new); the host clears the ring before it wraps.
 // The grid (one workgroup per subtree, <= the number of CUs, ~100 KB of LDS each) is co-resident on an otherwise idle
-// device; every spin is bounded (a timeout raises err[0] and every workgroup leaves).
+// device; every spin is bounded (a timeout raises bar[1] and every workgroup leaves at its next exchange).
 // ---------------------------------------------------------------------------
 struct SplitTree {
   int G, L, NL, NM, NI;          // subtrees, cut level, padded histories / members / infostates per subtree
@@ -519,9 +527,9 @@ struct SplitTree {
   const int32_t* mem_m;          // [G, NM] member index (position in Tree::mem), -1 = padding
   const int32_t* mem_hloc;       // [G, NM] its history, local index
   const int32_t* info_list;      // [G, NI] infostates with a member in the subtree, -1 = padding
-  double* terms;                 // [2][2][M, A]: buffer (pass parity) x {regret, policy} terms per member
-  int32_t* skip;                 // [2][M]
-  unsigned int* bar;             // [0] arrival counter, [1] error flag (both zeroed before every launch), [2] sticky error
+  unsigned long long* words;     // [ring][M][kSplitStride]: tag << 32 | half of an fp64 (own reach, then A regret terms)
+  int ring;                      // 2 x passes slots
+  unsigned int* bar;             // [1] error flag (zeroed before every launch), [2] sticky error (read by the host)
 };
 
 OSG_D void store_through(double* p, double v) {   // agent scope: written through to memory, visible to every CU
@@ -535,9 +543,22 @@ OSG_D double load_through(const double* p) {      // agent scope: never served f
 
 constexpr int kSplitMaxA = 4;       // widest policy row the split kernel folds
 constexpr int kSplitOwnerPath = 10;  // decision entries of a root path kept in registers
+constexpr int kSplitWords = 2 * (1 + kSplitMaxA);  // 64-bit words per member and slot that carry something
+constexpr int kSplitStride = 16;                   // ... in a record of one 128-byte line (one channel: stores land in order)
+constexpr int kSplitChunk = 6;      // members whose words are requested together
+constexpr int kSplitThreads = 512;  // (two wavefronts per SIMD: the chunk's 120 registers fit)
+OSG_D void put_tagged(unsigned long long* at, unsigned int tag, double v) {
+  const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(v));
+  __hip_atomic_store(at, (static_cast<unsigned long long>(tag) << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(at + 1, (static_cast<unsigned long long>(tag) << 32) | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+OSG_D double join_tagged(unsigned long long hi, unsigned long long lo) {
+  return __longlong_as_double(static_cast<long long>((hi << 32) | (lo & 0xFFFFFFFFull)));
+}
 template <int kSlots>  // kSlots >= P + 1
-__global__ void __launch_bounds__(1024)
-k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg) {
+__global__ void __launch_bounds__(kSplitThreads)
+k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iteration0, unsigned int epoch0, osg_cfr_cfg cfg) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int P = t.P, A = t.A, IA = t.I * t.A, M = st.M;
   const int tid = threadIdx.x, g = blockIdx.x;
@@ -603,6 +624,7 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
       c_m1 = t.mem_off[c_i + 1];
     }
   }
+  if (tid == 0) *s_ok = 1;
   __syncthreads();
 
   const int passes = cfg.alternating_updates ? P : 1;
@@ -626,10 +648,10 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
         }
         __syncthreads();
       }
-      // ---- B: the thread's decision history: reach from its root path, regret / average-policy terms ----
-      double* dreg = sp.terms + static_cast<size_t>(epoch & 1u) * 2 * M * A;
-      double* dpol = dreg + static_cast<size_t>(M) * A;
-      int32_t* skip = sp.skip + static_cast<size_t>(epoch & 1u) * M;
+      // ---- B: the thread's decision history: reach from its root path, own reach + regret terms as tagged words ----
+      ++epoch;
+      const unsigned int e = (epoch0 + epoch) & 0x7FFFFFFFu;  // (never 0 inside a launch: the host keeps epoch0 + epochs < 2^31)
+      unsigned long long* slot = sp.words + static_cast<size_t>(e % static_cast<unsigned int>(sp.ring)) * M * kSplitStride;
       if (b_m >= 0 && (upd < 0 || b_pl == upd)) {
         double pr[kOwnerPath];
 #pragma unroll
@@ -639,9 +661,9 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
         for (int q = 0; q < kSlots; ++q) reach[q] = (q == P) ? b_chance : 1.0;
 #pragma unroll
         for (int j = 0; j < kOwnerPath; ++j) {
-          const int slot = b_code[j] >= 0 ? (b_code[j] >> 24) & 0xF : -1;
+          const int slot_q = b_code[j] >= 0 ? (b_code[j] >> 24) & 0xF : -1;
 #pragma unroll
-          for (int q = 0; q < kSlots; ++q) reach[q] = (q == slot) ? reach[q] * pr[j] : reach[q];
+          for (int q = 0; q < kSlots; ++q) reach[q] = (q == slot_q) ? reach[q] * pr[j] : reach[q];
         }
         bool pruned = true;  // AllPlayersHaveZeroReachProb (cfr.cc:471-479)
         double self_reach = 0.0, cf_reach = 1.0;
@@ -651,73 +673,88 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
           if (q == b_pl) self_reach = reach[q];
           else if (q <= P) cf_reach *= reach[q];  // CounterFactualReachProb (cfr.cc:309-318), chance slot = P
         }
-        __hip_atomic_store(&skip[b_m], pruned ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!pruned) {
+        unsigned long long* w = slot + static_cast<size_t>(b_m) * kSplitStride;
+        if (pruned) {  // head with the pruned bit, and the word readers poll (the last one a live member writes)
+          __hip_atomic_store(w, static_cast<unsigned long long>((e << 1) | 1u) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(w + 1 + 2 * b_n, static_cast<unsigned long long>(e << 1) << 32, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          put_tagged(w, e << 1, cfg.linear_averaging ? iteration * self_reach : self_reach);
           const double vh = value[b_h * P + b_pl];
-          for (int a = 0; a < b_n; ++a) {
-            store_through(&dreg[b_m * A + a], cf_reach * (value[(b_fc + a) * P + b_pl] - vh));
-            const double pol = cur[b_i * A + a];
-            store_through(&dpol[b_m * A + a], cfg.linear_averaging ? iteration * self_reach * pol : self_reach * pol);
-          }
+          for (int a = 0; a < b_n; ++a) put_tagged(w + 2 + 2 * a, e << 1, cf_reach * (value[(b_fc + a) * P + b_pl] - vh));
         }
       }
-      // ---- the grid barrier: every storing wave drains, one lane signals, one lane polls ----
-      ++epoch;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        __hip_atomic_fetch_add(&sp.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned int want = epoch * static_cast<unsigned int>(sp.G);
-        int ok = 0;
-        for (int spin = 0; spin < (1 << 20); ++spin) {
-          if (__hip_atomic_load(&sp.bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = 1; break; }
-          if (__hip_atomic_load(&sp.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-          __builtin_amdgcn_s_sleep(1);
-        }
-        if (!ok) {
-          __hip_atomic_store(&sp.bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&sp.bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sticky: read by the host
-        }
-        *s_ok = ok;
-      }
-      __syncthreads();
-      if (!*s_ok) return;  // a workgroup never arrived (the grid was not co-resident): leave the tables untouched
       // ---- C: the thread's infostate: fold ALL its members' terms in DFS order, RM+ clamp, regret matching ----
+      bool timed_out = false;
       if (c_i >= 0 && (upd < 0 || c_pl == upd)) {
-        // four members' flags and terms are requested together (clamped indices: independent loads, one round
-        // trip per chunk), then added in member order
-        for (int m0 = c_m0; m0 < c_m1; m0 += 4) {
-          int sk[4];
-          double rt[4][kSplitMaxA], pt[4][kSplitMaxA];
+        const unsigned long long want = static_cast<unsigned long long>(e << 1);
+        for (int m0 = c_m0; m0 < c_m1 && !timed_out; m0 += kSplitChunk) {
+          unsigned long long w[kSplitChunk][kSplitWords];
+          bool all = false;
+          const int tail = 1 + 2 * c_n;  // the last word a member's thread stores: poll that one, then take everything
+          for (int spin = 0; spin < (1 << 18); ++spin) {
+            unsigned long long t[kSplitChunk];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int m = m0 + j < c_m1 ? m0 + j : c_m1 - 1;
-            sk[j] = __hip_atomic_load(&skip[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int a = 0; a < kSplitMaxA; ++a) {
-              const int aa = a < c_n ? a : 0;
-              rt[j][a] = load_through(&dreg[m * A + aa]);
-              pt[j][a] = load_through(&dpol[m * A + aa]);
+            for (int j = 0; j < kSplitChunk; ++j) {
+              const int m = m0 + j < c_m1 ? m0 + j : c_m1 - 1;
+              t[j] = __hip_atomic_load(slot + static_cast<size_t>(m) * kSplitStride + tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-          }
+            bool landed = true;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (m0 + j >= c_m1 || sk[j]) continue;
+            for (int j = 0; j < kSplitChunk; ++j) landed &= (t[j] >> 32) == want;
+            if (landed) {
+#pragma unroll
+              for (int j = 0; j < kSplitChunk; ++j) {
+                const int m = m0 + j < c_m1 ? m0 + j : c_m1 - 1;
+                const unsigned long long* src = slot + static_cast<size_t>(m) * kSplitStride;
+#pragma unroll
+                for (int k = 0; k < kSplitWords; ++k)  // (words past the row: never written, never used)
+                  w[j][k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+              all = true;  // stores of one thread usually land in order, but only the tags say so
+#pragma unroll
+              for (int j = 0; j < kSplitChunk; ++j) {
+                const unsigned long long head = w[j][0] >> 32;
+                bool ok = (head >> 1) == (want >> 1);
+                if (ok && !(head & 1ull)) {
+#pragma unroll
+                  for (int k = 1; k < kSplitWords; ++k) ok &= (k >= 2 + 2 * c_n) || (w[j][k] >> 32) == want;
+                }
+                all &= ok;
+              }
+              if (all) break;
+            }
+            if ((spin & 63) == 63 && __hip_atomic_load(&sp.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (!all) { timed_out = true; break; }
+#pragma unroll
+          for (int j = 0; j < kSplitChunk; ++j) {
+            if (m0 + j >= c_m1 || ((w[j][0] >> 32) & 1ull)) continue;
+            const double own = join_tagged(w[j][0], w[j][1]);
 #pragma unroll
             for (int a = 0; a < kSplitMaxA; ++a) {
               if (a < c_n) {
-                regrets[c_i * A + a] += rt[j][a];
-                cum[c_i * A + a] += pt[j][a];
+                regrets[c_i * A + a] += join_tagged(w[j][2 + 2 * a], w[j][3 + 2 * a]);
+                cum[c_i * A + a] += own * cur[c_i * A + a];
               }
             }
           }
         }
-        if (cfg.regret_matching_plus)
-          for (int a = 0; a < c_n; ++a)
-            if (regrets[c_i * A + a] < 0) regrets[c_i * A + a] = 0;
-        regret_match_row(regrets + c_i * A, cur + c_i * A, c_n);
+        if (!timed_out) {
+          if (cfg.regret_matching_plus)
+            for (int a = 0; a < c_n; ++a)
+              if (regrets[c_i * A + a] < 0) regrets[c_i * A + a] = 0;
+          regret_match_row(regrets + c_i * A, cur + c_i * A, c_n);
+        }
+      }
+      if (timed_out) {  // a workgroup never wrote (the grid was not co-resident): tell everyone, leave the tables as loaded
+        __hip_atomic_store(&sp.bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sp.bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_ok = 0;
       }
       __syncthreads();
+      if (!*s_ok) return;
     }
   }
   // every workgroup writes the rows it kept (copies of one row are bit-identical: the same additions in the same order)
@@ -1656,9 +1693,11 @@ struct osg_cfr {
   int split_G = 0, split_L = 0, split_NL = 0, split_NM = 0, split_NI = 0, split_threads = 0;
   size_t split_lds_bytes = 0;
   int32_t *d_split_nloc = nullptr, *d_split_desc = nullptr, *d_split_fc = nullptr, *d_split_row = nullptr,
-          *d_split_glob = nullptr, *d_split_mem_m = nullptr, *d_split_mem_hloc = nullptr, *d_split_info = nullptr,
-          *d_split_skip = nullptr;
-  double* d_split_terms = nullptr;
+          *d_split_glob = nullptr, *d_split_mem_m = nullptr, *d_split_mem_hloc = nullptr, *d_split_info = nullptr;
+  unsigned long long* d_split_words = nullptr;  // [ring][M][kSplitStride] tagged exchange words
+  size_t split_words_bytes = 0;
+  int split_ring = 0;
+  unsigned int split_epoch = 0;  // exchanges done since the ring was last cleared: only grows (tags must never repeat)
   unsigned int* d_split_bar = nullptr;
   // policy evaluation (k_policy_eval)
   std::vector<int32_t> info_level, mem_index;
@@ -2037,7 +2076,7 @@ int build_split(osg_cfr* s) {
   }
   int NL = 0;
   for (int g = 0; g < G; ++g) NL = std::max<int>(NL, static_cast<int>(hist[g].size()));
-  if (NL > 1024) return OSG_OK;
+  if (NL > kSplitThreads) return OSG_OK;
   const int threads = std::max(64, (NL + 63) / 64 * 64);
   std::vector<std::vector<int32_t>> mem_m(G), infos(G);
   std::vector<int32_t> seen(s->I, -1);
@@ -2092,12 +2131,13 @@ int build_split(osg_cfr* s) {
       (rc = upload(mh, &s->d_split_mem_hloc, st)) || (rc = upload(il, &s->d_split_info, st)))
     return rc;
   const size_t M = s->mem.size();
-  OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_split_terms), sizeof(double) * 4 * std::max<size_t>(M * s->A, 1)));
-  OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_split_skip), sizeof(int32_t) * 2 * std::max<size_t>(M, 1)));
+  s->split_ring = 2 * s->P;  // (2 x passes; passes <= P)
+  s->split_words_bytes = sizeof(unsigned long long) * s->split_ring * std::max<size_t>(M, 1) * kSplitStride;
+  OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_split_words), s->split_words_bytes));
   OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_split_bar), sizeof(unsigned int) * 4));
   OSG_HIP(hipMemsetAsync(s->d_split_bar, 0, sizeof(unsigned int) * 4, st));
-  OSG_HIP(hipMemsetAsync(s->d_split_terms, 0, sizeof(double) * 4 * std::max<size_t>(M * s->A, 1), st));
-  OSG_HIP(hipMemsetAsync(s->d_split_skip, 0, sizeof(int32_t) * 2 * std::max<size_t>(M, 1), st));
+  OSG_HIP(hipMemsetAsync(s->d_split_words, 0, s->split_words_bytes, st));  // tag 0: no epoch
+  s->split_epoch = 0;
   const void* variants[] = {reinterpret_cast<const void*>(&k_cfr_split<3>), reinterpret_cast<const void*>(&k_cfr_split<4>),
                             reinterpret_cast<const void*>(&k_cfr_split<kMaxPlayers + 1>)};
   for (const void* f : variants)
@@ -2228,7 +2268,7 @@ int osg_cfr_destroy(osg_cfr* s) {
                   s->d_best, s->d_eval, s->d_meta32, s->d_info_player32, s->d_skip, s->d_node_delta, s->d_rec,
                   s->d_uret, s->d_uprob, s->d_spare_delta[0], s->d_spare_delta[1], s->d_split_nloc, s->d_split_desc,
                   s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
-                  s->d_split_skip, s->d_split_terms, s->d_split_bar};
+                  s->d_split_words, s->d_split_bar};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   osg::ctx_release(s->ctx);
@@ -2289,17 +2329,22 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
     SmallTree stree{s->d_path_off, s->d_path, M, static_cast<int>(s->path.size())};
     SplitTree sp{s->split_G, s->split_L, s->split_NL, s->split_NM, s->split_NI, s->d_split_nloc, s->d_split_desc,
                  s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
-                 s->d_split_terms, s->d_split_skip, s->d_split_bar};
+                 s->d_split_words, s->split_ring, s->d_split_bar};
     hipStream_t st = s->ctx->stream;
     const int passes = s->cfg.alternating_updates ? s->P : 1;
-    const int per_launch = std::max(1, (1 << 30) / std::max(1, passes * s->split_G));  // the arrival counter is 32 bits
+    const int per_launch = (1 << 20) / passes;  // exchanges of one launch: far below the 31-bit tag space
     for (int done = 0; done < iters; done += per_launch) {
       const int now = std::min(per_launch, iters - done);
+      if (s->split_epoch > (1u << 30)) {  // the tags would wrap: start again from a clean ring (stream-ordered)
+        OSG_HIP(hipMemsetAsync(s->d_split_words, 0, s->split_words_bytes, st));
+        s->split_epoch = 0;
+      }
       OSG_HIP(hipMemsetAsync(s->d_split_bar, 0, sizeof(unsigned int) * 2, st));
       const dim3 grid(static_cast<unsigned>(s->split_G)), block(static_cast<unsigned>(s->split_threads));
-      if (s->P == 2) k_cfr_split<3><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->cfg);
-      else if (s->P == 3) k_cfr_split<4><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->cfg);
-      else k_cfr_split<kMaxPlayers + 1><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->cfg);
+      if (s->P == 2) k_cfr_split<3><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->split_epoch, s->cfg);
+      else if (s->P == 3) k_cfr_split<4><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->split_epoch, s->cfg);
+      else k_cfr_split<kMaxPlayers + 1><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->split_epoch, s->cfg);
+      s->split_epoch += static_cast<unsigned int>(now) * static_cast<unsigned int>(passes);
     }
     OSG_HIP(hipGetLastError());
     s->iteration += iters;

@@ -498,24 +498,22 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
 // recursion adds up across deals (cfr.cc:379-405): an infostate's regret / average-policy terms come from member
 // histories in several subtrees.  Per player pass:
 //   A  values bottom-up inside the subtree (one __syncthreads per level);
-//   B  one thread per decision history of the subtree: reach from the root path, then the history's own-reach and
-//      its A regret terms go THROUGH to memory (agent-scope stores) as SELF-VALIDATING words: every fp64 travels as two
-//      64-bit words, each carrying 32 bits of it under a 32-bit tag (the exchange epoch, + a "pruned" bit on the first
-//      word).  A 64-bit store is single-copy atomic, so a reader that sees the tag of the epoch it waits for on every
-//      word holds that epoch's value — no flag after the data, hence no wait for the stores to drain, no arrival
-//      counter and no second round trip;
+//   B  one thread per decision history of the subtree: reach from the root path, then its record — own reach (-1 when
+//      every player's reach is zero: nothing to add, cfr.cc:471-479) and the A regret terms — written THROUGH to
+//      memory (agent-scope stores) into the pass's buffer (two buffers, by pass parity).  The average-policy term is
+//      own reach x policy: every reader forms it from its own bit-identical copy of the row (cfr.cc:398-404), so it
+//      does not travel;
+//   -- one grid barrier: a counter every workgroup bumps once its stores have drained, polled by one lane --
 //   C  every workgroup folds, for each infostate that has a member in ITS subtree, ALL that infostate's members'
-//      terms in DFS order: up to kSplitChunk members' words are requested at once (agent-scope loads: they bypass the
-//      caches that may hold older lines), re-requested until every tag matches, then added — the same additions in
-//      the same order in every workgroup that keeps the row, so the copies stay bit-identical and equal to the
-//      single-workgroup kernels' tables — then RM+ clamp and regret matching into its LDS rows.  (The average-policy
-//      term is own_reach x policy: the reader multiplies by its own bit-identical copy of the row, cfr.cc:398-404.)
-// One exchange per pass, pairwise: a workgroup waits only for the subtrees that share an infostate with it.  A writer
-// can run ahead of a reader by at most `passes` epochs (its next fold in the same pass needs the reader's words), so the
-// words live in a ring of 2 x passes slots, slot = epoch mod ring.  Epochs come from a counter of the solver that only
-// grows (a reset or a loaded checkpoint must not make old words look new); the host clears the ring before it wraps.
+//      records (agent-scope loads: they bypass the caches that may hold the previous pass's lines; up to kSplitChunk
+//      members per round trip) in DFS order into the row held in registers — the same additions in the same order in
+//      every workgroup that keeps the row, so the copies stay bit-identical and equal to the single-workgroup
+//      kernels' tables — then RM+ clamp and regret matching back into its LDS rows.
+// Where a pass's 8.3 us go (leduc, wall_clock64 of workgroup 0): A 2.4 (nine levels of LDS round trip + barrier), B 1.3,
+// drain 0.4, counter barrier 1.8, C 1.85 (one memory round trip + fold), regret matching + barrier 0.6.
+// One barrier per pass, no second one: the rows a subtree needs next are the rows it has just folded itself.
 // The grid (one workgroup per subtree, <= the number of CUs, ~100 KB of LDS each) is co-resident on an otherwise idle
-// device; every spin is bounded (a timeout raises bar[1] and every workgroup leaves at its next exchange).
+// device; every spin is bounded (a timeout raises err[0] and every workgroup leaves).
 // ---------------------------------------------------------------------------
 struct SplitTree {
   int G, L, NL, NM, NI;          // subtrees, cut level, padded histories / members / infostates per subtree
@@ -527,9 +525,8 @@ struct SplitTree {
   const int32_t* mem_m;          // [G, NM] member index (position in Tree::mem), -1 = padding
   const int32_t* mem_hloc;       // [G, NM] its history, local index
   const int32_t* info_list;      // [G, NI] infostates with a member in the subtree, -1 = padding
-  unsigned long long* words;     // [ring][M][kSplitStride]: tag << 32 | half of an fp64 (own reach, then A regret terms)
-  int ring;                      // 2 x passes slots
-  unsigned int* bar;             // [1] error flag (zeroed before every launch), [2] sticky error (read by the host)
+  double* terms;                 // [2][M][kSplitRec]: buffer (pass parity) x {own reach or -1, A regret terms} per member
+  unsigned int* bar;             // [0] arrival counter, [1] error flag (both zeroed before every launch), [2] sticky error
 };
 
 OSG_D void store_through(double* p, double v) {   // agent scope: written through to memory, visible to every CU
@@ -543,22 +540,11 @@ OSG_D double load_through(const double* p) {      // agent scope: never served f
 
 constexpr int kSplitMaxA = 4;       // widest policy row the split kernel folds
 constexpr int kSplitOwnerPath = 10;  // decision entries of a root path kept in registers
-constexpr int kSplitWords = 2 * (1 + kSplitMaxA);  // 64-bit words per member and slot that carry something
-constexpr int kSplitStride = 16;                   // ... in a record of one 128-byte line (one channel: stores land in order)
-constexpr int kSplitChunk = 6;      // members whose words are requested together
-constexpr int kSplitThreads = 512;  // (two wavefronts per SIMD: the chunk's 120 registers fit)
-OSG_D void put_tagged(unsigned long long* at, unsigned int tag, double v) {
-  const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(v));
-  __hip_atomic_store(at, (static_cast<unsigned long long>(tag) << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(at + 1, (static_cast<unsigned long long>(tag) << 32) | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-}
-OSG_D double join_tagged(unsigned long long hi, unsigned long long lo) {
-  return __longlong_as_double(static_cast<long long>((hi << 32) | (lo & 0xFFFFFFFFull)));
-}
+constexpr int kSplitRec = 1 + kSplitMaxA;  // doubles per member and buffer: own reach, regret terms
+constexpr int kSplitChunk = 6;       // members whose records are requested together
 template <int kSlots>  // kSlots >= P + 1
-__global__ void __launch_bounds__(kSplitThreads)
-k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iteration0, unsigned int epoch0, osg_cfr_cfg cfg) {
+__global__ void __launch_bounds__(1024)
+k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int P = t.P, A = t.A, IA = t.I * t.A, M = st.M;
   const int tid = threadIdx.x, g = blockIdx.x;
@@ -624,7 +610,6 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
       c_m1 = t.mem_off[c_i + 1];
     }
   }
-  if (tid == 0) *s_ok = 1;
   __syncthreads();
 
   const int passes = cfg.alternating_updates ? P : 1;
@@ -648,10 +633,8 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
         }
         __syncthreads();
       }
-      // ---- B: the thread's decision history: reach from its root path, own reach + regret terms as tagged words ----
-      ++epoch;
-      const unsigned int e = (epoch0 + epoch) & 0x7FFFFFFFu;  // (never 0 inside a launch: the host keeps epoch0 + epochs < 2^31)
-      unsigned long long* slot = sp.words + static_cast<size_t>(e % static_cast<unsigned int>(sp.ring)) * M * kSplitStride;
+      // ---- B: the thread's decision history: reach from its root path, regret / average-policy terms ----
+      double* terms = sp.terms + static_cast<size_t>(epoch & 1u) * M * kSplitRec;  // the pass's buffer: [M][1 + kSplitMaxA]
       if (b_m >= 0 && (upd < 0 || b_pl == upd)) {
         double pr[kOwnerPath];
 #pragma unroll
@@ -661,9 +644,9 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
         for (int q = 0; q < kSlots; ++q) reach[q] = (q == P) ? b_chance : 1.0;
 #pragma unroll
         for (int j = 0; j < kOwnerPath; ++j) {
-          const int slot_q = b_code[j] >= 0 ? (b_code[j] >> 24) & 0xF : -1;
+          const int slot = b_code[j] >= 0 ? (b_code[j] >> 24) & 0xF : -1;
 #pragma unroll
-          for (int q = 0; q < kSlots; ++q) reach[q] = (q == slot_q) ? reach[q] * pr[j] : reach[q];
+          for (int q = 0; q < kSlots; ++q) reach[q] = (q == slot) ? reach[q] * pr[j] : reach[q];
         }
         bool pruned = true;  // AllPlayersHaveZeroReachProb (cfr.cc:471-479)
         double self_reach = 0.0, cf_reach = 1.0;
@@ -673,88 +656,86 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
           if (q == b_pl) self_reach = reach[q];
           else if (q <= P) cf_reach *= reach[q];  // CounterFactualReachProb (cfr.cc:309-318), chance slot = P
         }
-        unsigned long long* w = slot + static_cast<size_t>(b_m) * kSplitStride;
-        if (pruned) {  // head with the pruned bit, and the word readers poll (the last one a live member writes)
-          __hip_atomic_store(w, static_cast<unsigned long long>((e << 1) | 1u) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(w + 1 + 2 * b_n, static_cast<unsigned long long>(e << 1) << 32, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
+        // own reach first (-1: pruned, nothing to add), then the A regret terms; the average-policy term is
+        // own reach x policy, which every reader forms from its own bit-identical copy of the row (cfr.cc:398-404)
+        double* rec = terms + static_cast<size_t>(b_m) * kSplitRec;
+        if (pruned) {
+          store_through(rec, -1.0);
         } else {
-          put_tagged(w, e << 1, cfg.linear_averaging ? iteration * self_reach : self_reach);
+          store_through(rec, cfg.linear_averaging ? iteration * self_reach : self_reach);
           const double vh = value[b_h * P + b_pl];
-          for (int a = 0; a < b_n; ++a) put_tagged(w + 2 + 2 * a, e << 1, cf_reach * (value[(b_fc + a) * P + b_pl] - vh));
+          for (int a = 0; a < b_n; ++a) store_through(rec + 1 + a, cf_reach * (value[(b_fc + a) * P + b_pl] - vh));
         }
       }
-      // ---- C: the thread's infostate: fold ALL its members' terms in DFS order, RM+ clamp, regret matching ----
-      bool timed_out = false;
-      if (c_i >= 0 && (upd < 0 || c_pl == upd)) {
-        const unsigned long long want = static_cast<unsigned long long>(e << 1);
-        for (int m0 = c_m0; m0 < c_m1 && !timed_out; m0 += kSplitChunk) {
-          unsigned long long w[kSplitChunk][kSplitWords];
-          bool all = false;
-          const int tail = 1 + 2 * c_n;  // the last word a member's thread stores: poll that one, then take everything
-          for (int spin = 0; spin < (1 << 18); ++spin) {
-            unsigned long long t[kSplitChunk];
-#pragma unroll
-            for (int j = 0; j < kSplitChunk; ++j) {
-              const int m = m0 + j < c_m1 ? m0 + j : c_m1 - 1;
-              t[j] = __hip_atomic_load(slot + static_cast<size_t>(m) * kSplitStride + tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            bool landed = true;
-#pragma unroll
-            for (int j = 0; j < kSplitChunk; ++j) landed &= (t[j] >> 32) == want;
-            if (landed) {
-#pragma unroll
-              for (int j = 0; j < kSplitChunk; ++j) {
-                const int m = m0 + j < c_m1 ? m0 + j : c_m1 - 1;
-                const unsigned long long* src = slot + static_cast<size_t>(m) * kSplitStride;
-#pragma unroll
-                for (int k = 0; k < kSplitWords; ++k)  // (words past the row: never written, never used)
-                  w[j][k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
-              all = true;  // stores of one thread usually land in order, but only the tags say so
-#pragma unroll
-              for (int j = 0; j < kSplitChunk; ++j) {
-                const unsigned long long head = w[j][0] >> 32;
-                bool ok = (head >> 1) == (want >> 1);
-                if (ok && !(head & 1ull)) {
-#pragma unroll
-                  for (int k = 1; k < kSplitWords; ++k) ok &= (k >= 2 + 2 * c_n) || (w[j][k] >> 32) == want;
-                }
-                all &= ok;
-              }
-              if (all) break;
-            }
-            if ((spin & 63) == 63 && __hip_atomic_load(&sp.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-            __builtin_amdgcn_s_sleep(1);
-          }
-          if (!all) { timed_out = true; break; }
-#pragma unroll
-          for (int j = 0; j < kSplitChunk; ++j) {
-            if (m0 + j >= c_m1 || ((w[j][0] >> 32) & 1ull)) continue;
-            const double own = join_tagged(w[j][0], w[j][1]);
-#pragma unroll
-            for (int a = 0; a < kSplitMaxA; ++a) {
-              if (a < c_n) {
-                regrets[c_i * A + a] += join_tagged(w[j][2 + 2 * a], w[j][3 + 2 * a]);
-                cum[c_i * A + a] += own * cur[c_i * A + a];
-              }
-            }
-          }
+      // ---- the grid barrier: every storing wave drains, one lane signals, one lane polls ----
+      ++epoch;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_fetch_add(&sp.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int want = epoch * static_cast<unsigned int>(sp.G);
+        int ok = 0;
+        for (int spin = 0; spin < (1 << 20); ++spin) {
+          if (__hip_atomic_load(&sp.bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = 1; break; }
+          if (__hip_atomic_load(&sp.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+          __builtin_amdgcn_s_sleep(1);
         }
-        if (!timed_out) {
-          if (cfg.regret_matching_plus)
-            for (int a = 0; a < c_n; ++a)
-              if (regrets[c_i * A + a] < 0) regrets[c_i * A + a] = 0;
-          regret_match_row(regrets + c_i * A, cur + c_i * A, c_n);
+        if (!ok) {
+          __hip_atomic_store(&sp.bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&sp.bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sticky: read by the host
         }
-      }
-      if (timed_out) {  // a workgroup never wrote (the grid was not co-resident): tell everyone, leave the tables as loaded
-        __hip_atomic_store(&sp.bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&sp.bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *s_ok = 0;
+        *s_ok = ok;
       }
       __syncthreads();
-      if (!*s_ok) return;
+      if (!*s_ok) return;  // a workgroup never arrived (the grid was not co-resident): leave the tables untouched
+      // ---- C: the thread's infostate: fold ALL its members' terms in DFS order, RM+ clamp, regret matching ----
+      if (c_i >= 0 && (upd < 0 || c_pl == upd)) {
+        // the row in registers for the whole fold (one LDS read, one write-back); kSplitChunk members' records are
+        // requested together (clamped indices: independent loads, one round trip per chunk), then added in member order
+        double r_reg[kSplitMaxA], r_cum[kSplitMaxA], r_cur[kSplitMaxA];
+#pragma unroll
+        for (int a = 0; a < kSplitMaxA; ++a) {
+          const int k = c_i * A + (a < c_n ? a : 0);
+          r_reg[a] = regrets[k]; r_cum[a] = cum[k]; r_cur[a] = cur[k];
+        }
+        for (int m0 = c_m0; m0 < c_m1; m0 += kSplitChunk) {
+          double own[kSplitChunk], rt[kSplitChunk][kSplitMaxA];
+#pragma unroll
+          for (int j = 0; j < kSplitChunk; ++j) {
+            const int m = m0 + j < c_m1 ? m0 + j : c_m1 - 1;
+            const double* rec = terms + static_cast<size_t>(m) * kSplitRec;
+            own[j] = load_through(rec);
+#pragma unroll
+            for (int a = 0; a < kSplitMaxA; ++a) rt[j][a] = a < c_n ? load_through(rec + 1 + a) : 0.0;
+          }
+#pragma unroll
+          for (int j = 0; j < kSplitChunk; ++j) {
+            if (m0 + j >= c_m1 || own[j] < 0.0) continue;
+#pragma unroll
+            for (int a = 0; a < kSplitMaxA; ++a) {
+              r_reg[a] += rt[j][a];
+              r_cum[a] += own[j] * r_cur[a];
+            }
+          }
+        }
+        // RM+ clamp (cfr.cc:265-273 with regret_matching_plus) and regret matching (regret_match_row, unrolled)
+        double sum_pos = 0.0;
+#pragma unroll
+        for (int a = 0; a < kSplitMaxA; ++a) {
+          if (cfg.regret_matching_plus && r_reg[a] < 0) r_reg[a] = 0;
+          if (a < c_n && r_reg[a] > 0) sum_pos += r_reg[a];
+        }
+#pragma unroll
+        for (int a = 0; a < kSplitMaxA; ++a) {
+          if (a < c_n) {
+            const double pol = sum_pos > 0 ? (r_reg[a] > 0 ? r_reg[a] / sum_pos : 0.0) : 1.0 / c_n;
+            regrets[c_i * A + a] = r_reg[a];
+            cum[c_i * A + a] = r_cum[a];
+            cur[c_i * A + a] = pol;
+          }
+        }
+      }
+      __syncthreads();
     }
   }
   // every workgroup writes the rows it kept (copies of one row are bit-identical: the same additions in the same order)
@@ -1694,10 +1675,7 @@ struct osg_cfr {
   size_t split_lds_bytes = 0;
   int32_t *d_split_nloc = nullptr, *d_split_desc = nullptr, *d_split_fc = nullptr, *d_split_row = nullptr,
           *d_split_glob = nullptr, *d_split_mem_m = nullptr, *d_split_mem_hloc = nullptr, *d_split_info = nullptr;
-  unsigned long long* d_split_words = nullptr;  // [ring][M][kSplitStride] tagged exchange words
-  size_t split_words_bytes = 0;
-  int split_ring = 0;
-  unsigned int split_epoch = 0;  // exchanges done since the ring was last cleared: only grows (tags must never repeat)
+  double* d_split_terms = nullptr;
   unsigned int* d_split_bar = nullptr;
   // policy evaluation (k_policy_eval)
   std::vector<int32_t> info_level, mem_index;
@@ -2076,7 +2054,7 @@ int build_split(osg_cfr* s) {
   }
   int NL = 0;
   for (int g = 0; g < G; ++g) NL = std::max<int>(NL, static_cast<int>(hist[g].size()));
-  if (NL > kSplitThreads) return OSG_OK;
+  if (NL > 1024) return OSG_OK;
   const int threads = std::max(64, (NL + 63) / 64 * 64);
   std::vector<std::vector<int32_t>> mem_m(G), infos(G);
   std::vector<int32_t> seen(s->I, -1);
@@ -2131,13 +2109,10 @@ int build_split(osg_cfr* s) {
       (rc = upload(mh, &s->d_split_mem_hloc, st)) || (rc = upload(il, &s->d_split_info, st)))
     return rc;
   const size_t M = s->mem.size();
-  s->split_ring = 2 * s->P;  // (2 x passes; passes <= P)
-  s->split_words_bytes = sizeof(unsigned long long) * s->split_ring * std::max<size_t>(M, 1) * kSplitStride;
-  OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_split_words), s->split_words_bytes));
+  OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_split_terms), sizeof(double) * 2 * kSplitRec * std::max<size_t>(M, 1)));
   OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_split_bar), sizeof(unsigned int) * 4));
   OSG_HIP(hipMemsetAsync(s->d_split_bar, 0, sizeof(unsigned int) * 4, st));
-  OSG_HIP(hipMemsetAsync(s->d_split_words, 0, s->split_words_bytes, st));  // tag 0: no epoch
-  s->split_epoch = 0;
+  OSG_HIP(hipMemsetAsync(s->d_split_terms, 0, sizeof(double) * 2 * kSplitRec * std::max<size_t>(M, 1), st));
   const void* variants[] = {reinterpret_cast<const void*>(&k_cfr_split<3>), reinterpret_cast<const void*>(&k_cfr_split<4>),
                             reinterpret_cast<const void*>(&k_cfr_split<kMaxPlayers + 1>)};
   for (const void* f : variants)
@@ -2268,7 +2243,7 @@ int osg_cfr_destroy(osg_cfr* s) {
                   s->d_best, s->d_eval, s->d_meta32, s->d_info_player32, s->d_skip, s->d_node_delta, s->d_rec,
                   s->d_uret, s->d_uprob, s->d_spare_delta[0], s->d_spare_delta[1], s->d_split_nloc, s->d_split_desc,
                   s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
-                  s->d_split_words, s->d_split_bar};
+                  s->d_split_terms, s->d_split_bar};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   osg::ctx_release(s->ctx);
@@ -2329,22 +2304,17 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
     SmallTree stree{s->d_path_off, s->d_path, M, static_cast<int>(s->path.size())};
     SplitTree sp{s->split_G, s->split_L, s->split_NL, s->split_NM, s->split_NI, s->d_split_nloc, s->d_split_desc,
                  s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
-                 s->d_split_words, s->split_ring, s->d_split_bar};
+                 s->d_split_terms, s->d_split_bar};
     hipStream_t st = s->ctx->stream;
     const int passes = s->cfg.alternating_updates ? s->P : 1;
-    const int per_launch = (1 << 20) / passes;  // exchanges of one launch: far below the 31-bit tag space
+    const int per_launch = std::max(1, (1 << 30) / std::max(1, passes * s->split_G));  // the arrival counter is 32 bits
     for (int done = 0; done < iters; done += per_launch) {
       const int now = std::min(per_launch, iters - done);
-      if (s->split_epoch > (1u << 30)) {  // the tags would wrap: start again from a clean ring (stream-ordered)
-        OSG_HIP(hipMemsetAsync(s->d_split_words, 0, s->split_words_bytes, st));
-        s->split_epoch = 0;
-      }
       OSG_HIP(hipMemsetAsync(s->d_split_bar, 0, sizeof(unsigned int) * 2, st));
       const dim3 grid(static_cast<unsigned>(s->split_G)), block(static_cast<unsigned>(s->split_threads));
-      if (s->P == 2) k_cfr_split<3><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->split_epoch, s->cfg);
-      else if (s->P == 3) k_cfr_split<4><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->split_epoch, s->cfg);
-      else k_cfr_split<kMaxPlayers + 1><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->split_epoch, s->cfg);
-      s->split_epoch += static_cast<unsigned int>(now) * static_cast<unsigned int>(passes);
+      if (s->P == 2) k_cfr_split<3><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->cfg);
+      else if (s->P == 3) k_cfr_split<4><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->cfg);
+      else k_cfr_split<kMaxPlayers + 1><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->cfg);
     }
     OSG_HIP(hipGetLastError());
     s->iteration += iters;

@@ -486,8 +486,9 @@ def ttt_mcts_config1(with_cpu):
         tot_s = sum(p["us_per_search"] for p in per) * 1e-6
         tot_sims = sum(p["simulations_per_search"] for p in per)
         out["device_single_root"] = {"value": tot_sims / tot_s, "unit": "sims/s", "per_position": per,
-                                     "what": "pyspiel_hip.MCTSBot.mcts_search on ONE root (osg_mcts_tree_*: one lane of one "
-                                             "wavefront, one launch per evaluator round trip), whole SearchNode tree downloaded"}
+                                     "what": "pyspiel_hip.MCTSBot.mcts_search on ONE root (osg_mcts_tree_*: the whole search is one "
+                                             "launch of two wavefronts, one lane walking the tree, the other wavefront playing "
+                                             "each leaf's 20 playouts in parallel), whole SearchNode tree downloaded"}
     except Exception as e:  # noqa: BLE001
         out["device_single_root"] = {"error": f"{type(e).__name__}: {e}"}
     if with_cpu:

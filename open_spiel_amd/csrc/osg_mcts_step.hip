@@ -72,8 +72,65 @@ struct StepPool {
   int stash_slots;
 };
 
-template <class G, bool kBoard>
-__global__ void __launch_bounds__(kBlockM)
+// ONE root (what MCTSBot::Step / MCTSearch always ask for) with RandomRolloutEvaluator in the launch: the search
+// itself is one lane's chain of dependent steps, but its leaf evaluation — n_rollouts independent playouts, each on
+// its own counter stream Rng(seed, root, s * n_rollouts + ro) — is not.  kCoop launches one workgroup of TWO
+// wavefronts: lane 0 of the first walks the tree as in the batch form, the second plays the playouts of every leaf,
+// one per lane, and hands the sum back through LDS (returns of the five games are integers: the sum does not depend
+// on the order).  Same streams, same values as the sequential form — 20 playouts in the time of one.
+template <class G>
+struct CoopBox {
+  typename G::State state;     // the leaf to evaluate
+  uint32_t seq, done, exit, sim;
+  double sum[kMaxPlayers];
+};
+OSG_D uint32_t coop_load(const uint32_t* at) { return __hip_atomic_load(at, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+OSG_D void coop_store(uint32_t* at, uint32_t v) { __hip_atomic_store(at, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+struct CoopLeave {  // whichever way the searching lane leaves the kernel, the playout wavefront is told
+  uint32_t* seq;
+  uint32_t* exit;
+  OSG_D ~CoopLeave() {
+    if (seq) {
+      coop_store(exit, 1u);
+      coop_store(seq, coop_load(seq) + 1u);
+    }
+  }
+};
+template <class G>
+OSG_D void coop_playouts(const typename G::Params& p, const osg_mcts_cfg& cfg, int num_players, uint64_t gr, CoopBox<G>* box) {
+  const int lane = threadIdx.x & 63;
+  uint32_t last = 0;
+  for (;;) {
+    uint32_t now;
+    while ((now = coop_load(&box->seq)) == last) __builtin_amdgcn_s_sleep(1);
+    last = now;
+    if (coop_load(&box->exit)) return;
+    const typename G::State s = box->state;
+    const uint64_t sim = box->sim;
+    double sum[kMaxPlayers];
+    for (int q = 0; q < num_players; ++q) sum[q] = 0.0;
+    for (int ro = lane; ro < cfg.n_rollouts; ro += 64) {
+      Rng rng(cfg.seed, gr, sim * cfg.n_rollouts + ro);
+      typename G::State w = s;
+      for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
+        const Mask m = G::legal(p, w);
+        G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
+      }
+      double rr[kMaxPlayers];
+      G::returns(p, w, rr);
+      for (int q = 0; q < num_players; ++q) sum[q] += rr[q];
+    }
+    for (int q = 0; q < num_players; ++q) {
+      double v = sum[q];
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) box->sum[q] = v;
+    }
+    if (lane == 0) coop_store(&box->done, now);
+  }
+}
+
+template <class G, bool kBoard, bool kCoop = false>
+__global__ void __launch_bounds__(kCoop ? 2 * kBlockM : kBlockM)
 k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typename G::word_t* leaf_words, int64_t n,
                int num_players, int num_actions, osg_mcts_cfg cfg, int flags, double max_utility,
                const double* __restrict__ log_table, StepPool pool, const double* __restrict__ prior_in,
@@ -83,9 +140,21 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
   // dependent, scattered loads (its own tree); with one search per lane 2^16 roots are 1 024 wavefronts — one per
   // SIMD, nothing to hide that latency behind.  Spreading the same searches over lane_stride times as many
   // wavefronts (fewer active lanes each) gives every SIMD several chains to interleave.
+  __shared__ CoopBox<G> coop_box;  // (kCoop only)
+  if (kCoop) {  // one root: lane 0 searches, the second wavefront plays its leaves' playouts
+    if (threadIdx.x == 0) { coop_box.seq = 0; coop_box.done = 0; coop_box.exit = 0; }
+    __syncthreads();
+    if (threadIdx.x >= 64) {
+      coop_playouts<G>(p, cfg, num_players, static_cast<uint64_t>(cfg.index_offset), &coop_box);
+      return;
+    }
+    if (threadIdx.x != 0) return;
+  }
+  CoopLeave coop_leave{kCoop ? &coop_box.seq : nullptr, kCoop ? &coop_box.exit : nullptr};
+  uint32_t coop_seq = 0;
   const int64_t slot = static_cast<int64_t>(blockIdx.x) * kBlockM + threadIdx.x;
-  if (lane_stride > 1 && (threadIdx.x % lane_stride) != 0) return;
-  const int64_t r = slot / lane_stride;
+  if (!kCoop && lane_stride > 1 && (threadIdx.x % lane_stride) != 0) return;
+  const int64_t r = kCoop ? 0 : slot / lane_stride;
   if (r >= n) return;
   const uint64_t gr = static_cast<uint64_t>(cfg.index_offset + r);
   const int64_t NR = pool.n;
@@ -267,7 +336,14 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
         // from (rollout ro of simulation s of root r: Rng(seed, root, s * n_rollouts + ro)): the same values as the
         // park / rollout-kernel / resume round trip, without leaving the launch
         for (int q = 0; q < num_players; ++q) returns[q] = 0.0;
-        for (int ro = 0; ro < cfg.n_rollouts; ++ro) {
+        if (kCoop) {  // hand the leaf to the playout wavefront, take the sum
+          coop_box.state = s;
+          coop_box.sim = static_cast<uint32_t>(sims_done);
+          coop_store(&coop_box.seq, ++coop_seq);
+          while (coop_load(&coop_box.done) != coop_seq) __builtin_amdgcn_s_sleep(1);
+          for (int q = 0; q < num_players; ++q) returns[q] = coop_box.sum[q];
+        }
+        for (int ro = 0; !kCoop && ro < cfg.n_rollouts; ++ro) {
           Rng rng(cfg.seed, gr, static_cast<uint64_t>(sims_done) * cfg.n_rollouts + ro);
           typename G::State w = s;
           for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
@@ -626,7 +702,23 @@ int osg_mcts_tree_advance(osg_mcts_tree* t, osg_batch* leaf, const double* d_pri
   const osg_game_desc& d = t->roots->spec.desc;
   const StepPool pool = make_pool(t);
   hipStream_t st = t->ctx->stream;
-  if (t->board) {
+  // one root, playouts in the launch: the two-wavefront form (OSG_MCTS_COOP=0 keeps the one-lane form, for A/B)
+  static const bool coop_on = !(std::getenv("OSG_MCTS_COOP") && std::atoi(std::getenv("OSG_MCTS_COOP")) == 0);
+  if (t->n == 1 && (t->flags & 4) && t->cfg.n_rollouts > 1 && coop_on) {
+    if (t->board) {
+      OSG_DISPATCH(t->roots->spec, k_mcts_advance<G, true, true><<<dim3(1), dim3(2 * kBlockM), 0, st>>>(
+                                       P, static_cast<const typename G::word_t*>(t->roots->d_words),
+                                       static_cast<typename G::word_t*>(leaf->d_words), t->n, d.num_players, t->A, t->cfg,
+                                       t->flags, t->max_utility, t->d_logs, pool, d_prior, d_value, d_request,
+                                       max_new_simulations, 1));
+    } else {
+      OSG_DISPATCH(t->roots->spec, k_mcts_advance<G, false, true><<<dim3(1), dim3(2 * kBlockM), 0, st>>>(
+                                       P, static_cast<const typename G::word_t*>(t->roots->d_words),
+                                       static_cast<typename G::word_t*>(leaf->d_words), t->n, d.num_players, t->A, t->cfg,
+                                       t->flags, t->max_utility, t->d_logs, pool, d_prior, d_value, d_request,
+                                       max_new_simulations, 1));
+    }
+  } else if (t->board) {
     OSG_DISPATCH(t->roots->spec, k_mcts_advance<G, true><<<dim3(grid), dim3(kBlockM), 0, st>>>(
                                      P, static_cast<const typename G::word_t*>(t->roots->d_words),
                                      static_cast<typename G::word_t*>(leaf->d_words), t->n, d.num_players, t->A, t->cfg,

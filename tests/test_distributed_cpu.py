@@ -162,6 +162,28 @@ def test_mccfr_delta_allreduce_world2_equals_world1(tmp_path):
     assert not torch.equal(stale.sampled_against[2], fresh)
 
 
+@pytest.mark.parametrize("world_size", [3, 8])
+def test_mccfr_delta_allreduce_uneven_worlds_equal_world1(tmp_path, world_size):
+    """Odd and full-node world sizes: mini-batches smaller than the world (ranks with an empty slice), uneven slices,
+    the variable-size gather — every rank ends with the single-process tables."""
+    from open_spiel_amd import distributed as osd
+    ref = FakeSolver()
+    single = osd.ShardedMccfr(ref)
+    for t in (1, 5, 64, 1001):
+        single.run_minibatch(seed=11, trajectories=t)
+    port = _free_port()
+    mp.spawn(_worker, args=(world_size, port, str(tmp_path)), nprocs=world_size, join=True)
+    ranks = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world_size)]
+    want = (torch.arange(7, dtype=torch.int32) * 10).unsqueeze(1)
+    for r in ranks:
+        assert torch.equal(r["tables"], ref.tables), f"world={world_size} must equal world=1"
+        assert torch.equal(r["overlap_tables"], ref.tables)
+        assert torch.equal(r["gathered"], want)
+        assert r["done"] == 1071
+    assert [sum(r["sampled"][k] for r in ranks) for k in range(4)] == [1, 5, 64, 1001]
+    assert sum(1 for r in ranks if r["sampled"][0] == 0) == world_size - 1   # one trajectory: one rank samples it
+
+
 def test_bench_gpus_n_starts_n_ranks_by_itself(monkeypatch):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment re-executes itself under
     torch.distributed.run with one rank per GPU on a 127.0.0.1 port (the command the docstring shows);

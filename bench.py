@@ -279,6 +279,37 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
                               "workload": f"{replicas} independent kuhn_poker CFRSolver replicas per GPU (random initial "
                                           f"regrets), {rep_iters} iterations each, one workgroup per replica"}
     del many
+    # the same solver on leduc_poker (9 457 histories, 936 infostates): one workgroup per deal subtree (k_cfr_split);
+    # and on 3-player leduc (1.8 M histories), which runs the full-grid phase kernels
+    try:
+        big = osa.TabularSolver(ctx, "leduc_poker")
+        big.evaluate_and_update_policy(50)
+        fence()
+        l_iters = 5000
+        t0 = time.perf_counter()
+        big.evaluate_and_update_policy(l_iters)
+        fence()
+        dt = time.perf_counter() - t0
+        out["cfr"]["leduc"] = {"value": l_iters / dt, "unit": "iterations/s", "us_per_iteration": dt / l_iters * 1e6,
+                               "nash_conv_after": big.nash_conv(),
+                               "workload": f"leduc_poker CFRSolver, {l_iters} EvaluateAndUpdatePolicy in one launch: 30 workgroups "
+                                           "(one per deal subtree, LDS-resident), one cross-workgroup exchange per player pass; "
+                                           "tables bit-identical with the single-workgroup kernel"}
+        del big
+        if rank == 0:
+            three = osa.TabularSolver(ctx, "leduc_poker(players=3)")
+            three.evaluate_and_update_policy(2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            three.evaluate_and_update_policy(10)
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t0
+            out["cfr"]["leduc_3_players"] = {"value": 10 / dt3, "unit": "iterations/s", "us_per_iteration": dt3 / 10 * 1e6,
+                                             "workload": "leduc_poker(players=3) CFRSolver, 1.83 M histories: one launch per tree "
+                                                         "level and phase over the whole grid"}
+            del three
+    except Exception as e:  # noqa: BLE001 - a secondary figure must never cost the line
+        out["cfr"]["leduc"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- config 5: leduc_poker external-sampling MCCFR, 2^24 trajectories, mini-batches of 2^20 ----
     solver = osa.TabularSolver(ctx, "leduc_poker", mccfr=True)
@@ -342,6 +373,10 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
             "value": threads * 50000 / secs_r, "unit": "solver-iterations/s", "cores": threads, "kind": kind,
             "sample": f"{threads} independent CFRSolver objects, one per thread, 50000 iterations each, {secs_r:.2f} s"}
         gl = impl.Game("leduc_poker")
+        if isinstance(out["cfr"].get("leduc"), dict) and "value" in out["cfr"]["leduc"]:
+            secs = gl.bench_cfr(0, 150, 1)
+            out["cfr"]["leduc"]["cpu_baseline"] = {"value": 150 / secs, "unit": "iterations/s", "cores": 1, "kind": kind,
+                                                   "sample": f"150 CFRSolver iterations on leduc_poker, 1 thread, {secs:.2f} s"}
         secs = gl.bench_cfr(2, 100000, 1)
         out["mccfr"]["cpu_baseline"] = {"value": 200000 / secs, "unit": "trajectories/s", "cores": 1, "kind": kind,
                                         "sample": f"100000 RunIteration (= 200000 traversals), 1 thread, {secs:.2f} s"}

@@ -505,35 +505,48 @@ k_observation(typename G::Params p, const typename G::word_t* base, int64_t n, i
 // instruction instead of 64 scattered 12-28 byte pieces.  Needs a 16-byte aligned output.
 constexpr int kRowsBlock = 256;
 constexpr int kRowsMaxSize = 63;
-template <class G>
+// kR: states per lane.  A workgroup of the shortest rows (kuhn_poker: 4 bytes in, 28 out per state) carries 7 KiB; with
+// eight of them per CU the bytes in flight (57 KiB per CU) do not cover bandwidth x latency of the memory system, so
+// the launch is bound by how long a workgroup LIVES, not by what it moves.  kR consecutive blocks of 64 states per
+// wavefront (all kR state loads issued before the first cursor step) put kR times the bytes behind every wavefront.
+template <class G, int kR>
 __global__ void __launch_bounds__(kRowsBlock)
 k_observation_rows(typename G::Params p, const typename G::word_t* base, int64_t n, int size, int player, int which,
                    float* __restrict__ out) {
-  extern __shared__ float s_rows[];  // [waves][64 * pad]
+  extern __shared__ float s_rows[];  // [waves][kR * 64 * pad]
   const int pad = size | 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* tile = s_rows + wave * 64 * pad;
-  const int64_t i0 = (static_cast<int64_t>(blockIdx.x) * kRowsBlock + wave * 64);  // first state of this wavefront
+  float* tile = s_rows + wave * (kR * 64) * pad;
+  const int64_t i0 = (static_cast<int64_t>(blockIdx.x) * kRowsBlock + wave * 64) * kR;  // first state of this wavefront
   if (i0 >= n) return;
-  const int64_t i = i0 + lane;
-  if (i < n) {
-    const typename G::State s = G::load(p, base, n, i);
-    int pl = player;
-    if (pl < 0) {
-      pl = G::current_player(p, s);
-      if (pl < 0) pl = 0;
+  typename G::State st[kR];
+#pragma unroll
+  for (int r = 0; r < kR; ++r) {
+    const int64_t i = i0 + r * 64 + lane;
+    if (i < n) st[r] = G::load(p, base, n, i);
+  }
+#pragma unroll
+  for (int r = 0; r < kR; ++r) {
+    const int64_t i = i0 + r * 64 + lane;
+    if (i < n) {
+      const typename G::State& s = st[r];
+      int pl = player;
+      if (pl < 0) {
+        pl = G::current_player(p, s);
+        if (pl < 0) pl = 0;
+      }
+      typename G::ObsCursor cur;
+      cur.init(p, s, pl, which, 0);
+      float* row = tile + (r * 64 + lane) * pad;
+      for (int k = 0; k < size; ++k) row[k] = cur.next(p, s, pl, which);
     }
-    typename G::ObsCursor cur;
-    cur.init(p, s, pl, which, 0);
-    float* row = tile + lane * pad;
-    for (int k = 0; k < size; ++k) row[k] = cur.next(p, s, pl, which);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const int rows = static_cast<int>(n - i0 < 64 ? n - i0 : 64);
+  const int rows = static_cast<int>(n - i0 < 64 * kR ? n - i0 : 64 * kR);
   const int total = rows * size;                       // floats this wavefront writes
-  float* dst = out + i0 * size;                        // 64 * size * 4 bytes per wavefront: 16-byte aligned
+  float* dst = out + i0 * size;                        // 64 * kR * size * 4 bytes per wavefront: 16-byte aligned
   for (int j = 4 * lane; j < total; j += 256) {
     int r = j / size, k = j - r * size;
     float v[4];
@@ -1360,10 +1373,18 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
 #undef OSG_HEX_OBS
   } else if (size <= kRowsMaxSize && b->spec.desc.game_kind != kHex && (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) {
     // short rows: one lane per state, LDS-staged aligned float4 stores
-    const size_t shmem = sizeof(float) * (kRowsBlock / 64) * 64 * static_cast<size_t>(size | 1);
-    const unsigned grid = static_cast<unsigned>((b->n + kRowsBlock - 1) / kRowsBlock);
-    OSG_DISPATCH(b->spec, k_observation_rows<G><<<dim3(grid), dim3(kRowsBlock), shmem, ctx->stream>>>(
-                              P, static_cast<const typename G::word_t*>(b->d_words), b->n, size, player, which, d_out));
+    // states per lane: two for the shortest rows (measured at 2^24 states, 1 / 2 / 4 per lane: kuhn [n, 7] 124.8 / 103.5 /
+    // 104.1 us, [n, 11] 144.2 / 128.6 / 161.3; from 16 floats per row on one is best: leduc [n, 16] 193 / 198 / 274,
+    // tic_tac_toe [n, 27] 338 / 445 / 678, leduc [n, 30] 352 / 499 / 921 — profiles/r03_obs_rows_per_lane.log)
+    const int kr = size <= 12 ? 2 : 1;
+    const size_t shmem = sizeof(float) * (kRowsBlock / 64) * 64 * kr * static_cast<size_t>(size | 1);
+    const unsigned grid = static_cast<unsigned>((b->n + kRowsBlock * kr - 1) / (kRowsBlock * kr));
+#define OSG_ROWS(KR)                                                                                               \
+  OSG_DISPATCH(b->spec, k_observation_rows<G, KR><<<dim3(grid), dim3(kRowsBlock), shmem, ctx->stream>>>(           \
+                            P, static_cast<const typename G::word_t*>(b->d_words), b->n, size, player, which, d_out))
+    if (kr == 2) OSG_ROWS(2);
+    else OSG_ROWS(1);
+#undef OSG_ROWS
   } else {
     // Segment = one tensor plane for hex's 9-plane layout (the cursor's mask is per plane), else the row.
     int seg_len = size;

@@ -87,7 +87,8 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
       }
       const uint32_t first = FIRST(node);
       const int c = m_nchild(meta);
-      uint32_t chosen = first;
+      uint32_t chosen = first, chosen_meta = 0;
+      bool have_meta = false;
       if (cur == kChancePlayer) {  // mcts.cc:311-322
         const Mask legal = G::legal(p, s);
         const int a = sample_action_chance<G>(p, s, legal, trng);
@@ -99,18 +100,33 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
         const bool puct = cfg.child_selection_policy == 1;
         const double prior = 1.0 / c;                              // Prior(): uniform over the legal actions
         const double sqrt_n = sqrt(static_cast<double>(cnt));
-        for (int k = 0; k < c; ++k) {
-          const uint32_t cm = META(first + k);
-          const uint32_t cc = COUNT(first + k);
-          double v;
-          if (m_has_outcome(cm)) v = outcome_value<kBoard>(cm, cc, TOTAL(first + k), m_player(cm));
-          else if (puct) v = (cc != 0 ? TOTAL(first + k) / cc : 0.0) + cfg.uct_c * prior * sqrt_n / (cc + 1);  // mcts.cc:103-112
-          else if (cc == 0) v = INFINITY;
-          else v = TOTAL(first + k) / cc + cfg.uct_c * sqrt(logn / cc);
-          if (v > best) { best = v; chosen = first + k; }
+        // a search is ONE chain of dependent, scattered loads: the children's statistics are requested eight children at a
+        // time with clamped indices (24 independent loads, one round trip) instead of child by child behind the
+        // branches of the value formula (see k_mcts_advance, osg_mcts_step.hip)
+        constexpr int kChunk = 8;
+        for (int k0 = 0; k0 < c; k0 += kChunk) {
+          uint32_t cm[kChunk], cc[kChunk];
+          double ct[kChunk];
+#pragma unroll
+          for (int j = 0; j < kChunk; ++j) {
+            const uint32_t at = first + static_cast<uint32_t>(k0 + j < c ? k0 + j : c - 1);
+            cm[j] = META(at);
+            cc[j] = COUNT(at);
+            ct[j] = TOTAL(at);
+          }
+#pragma unroll
+          for (int j = 0; j < kChunk; ++j) {
+            if (k0 + j >= c) continue;
+            double v;
+            if (m_has_outcome(cm[j])) v = outcome_value<kBoard>(cm[j], cc[j], ct[j], m_player(cm[j]));
+            else if (puct) v = (cc[j] != 0 ? ct[j] / cc[j] : 0.0) + cfg.uct_c * prior * sqrt_n / (cc[j] + 1);  // mcts.cc:103-112
+            else if (cc[j] == 0) v = INFINITY;
+            else v = ct[j] / cc[j] + cfg.uct_c * sqrt(logn / cc[j]);
+            if (v > best) { best = v; chosen = first + static_cast<uint32_t>(k0 + j); chosen_meta = cm[j]; have_meta = true; }
+          }
         }
       }
-      G::apply(p, s, static_cast<int>(m_action(META(chosen))));
+      G::apply(p, s, static_cast<int>(m_action(have_meta ? chosen_meta : META(chosen))));
       node = chosen;
     }
     // ---- evaluate (mcts.cc:372-381) ----

@@ -1154,9 +1154,12 @@ int launch(const typename G::Params& P, const osg_batch* roots, const osg_mcts_c
     OSG_HIP(hipGetDeviceProperties(&prop, ctx->device));
     ctx->num_cus = prop.multiProcessorCount;
   }
-  // a queue pays only when there are more roots than wave slots to hand them to
+  // a queue pays only when there are more roots than wave slots to hand them to — and, measured, only while the batch is
+  // little more than one round of slots (hex(9), 7 168 slots: 8 192 roots 8.84e8 static -> 9.37e8 longest-first, but
+  // 16 384 roots 1.00e9 -> 9.6e8, 32 768 roots 1.06e9 -> 1.03e9: with two or more rounds the static order's own
+  // mixing balances the SIMDs and the queue's atomics and sort are pure cost)
   const int64_t slots = static_cast<int64_t>(ctx->num_cus) * 4 * sc.waves_per_simd;
-  if (sc.mode == 0 || n <= slots || n >= (int64_t{1} << 31) || (!sc.forced && n > 4 * slots)) {
+  if (sc.mode == 0 || n <= slots || n >= (int64_t{1} << 31) || (!sc.forced && n > slots + slots / 2)) {
     const unsigned grid = static_cast<unsigned>((n + kWavesPerBlock - 1) / kWavesPerBlock);
     if (gc)
       k_mcts_wave<G, kBoard, kHexFill, true><<<dim3(grid), dim3(64 * kWavesPerBlock), 0, st>>>(

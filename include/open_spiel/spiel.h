@@ -37,6 +37,7 @@ namespace algorithms { using namespace hip::algorithms; }
 namespace kuhn_poker { using namespace hip::kuhn_poker; }
 namespace leduc_poker { using namespace hip::leduc_poker; }
 namespace efg_game { using namespace hip::efg_game; }
+namespace tic_tac_toe { using namespace hip::tic_tac_toe; }
 // spiel_utils.h:119-137: the default fatal-error handler prints and exits
 [[noreturn]] inline void SpielFatalErrorShim(const std::string& msg) { std::cerr << "Spiel Fatal Error: " << msg << std::endl; std::exit(1); }
 }  // namespace open_spiel

@@ -343,6 +343,15 @@ inline std::shared_ptr<const Game> LoadGameAsTurnBased(const std::string& name) 
 inline std::shared_ptr<const Game> LoadGameAsTurnBased(const std::string& name, const GameParameters&) {
   return LoadGameAsTurnBased(name);
 }
+// games/tic_tac_toe/tic_tac_toe.h:40-48: the constants user code sizes its arrays with
+namespace tic_tac_toe {
+inline constexpr int kNumPlayers = 2;
+inline constexpr int kNumRows = 3;
+inline constexpr int kNumCols = 3;
+inline constexpr int kNumCells = kNumRows * kNumCols;
+inline constexpr int kCellStates = 1 + kNumPlayers;  // empty, 'x', 'o'
+inline constexpr int kNumberStates = 5478;           // distinct reachable positions
+}  // namespace tic_tac_toe
 namespace efg_game {
 inline std::string GetKuhnPokerEFGData() { return ""; }
 inline std::shared_ptr<const Game> LoadEFGGame(const std::string&) {

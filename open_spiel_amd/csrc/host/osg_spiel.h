@@ -439,14 +439,22 @@ class State {
   explicit State(std::shared_ptr<const Game> game) : batch_(std::move(game), 1) {}
   State(const State&) = default;
 
-  Player CurrentPlayer() const { return batch_.CurrentPlayer()[0]; }
-  bool IsTerminal() const { return batch_.IsTerminal()[0] != 0; }
+  // CurrentPlayer / IsTerminal / Returns of one position come from ONE device query (osg_status_query fills all three)
+  // and the legal mask from one more; both are kept until the position changes (ApplyAction, UndoAction), so the
+  // per-state loop of a caller — IsTerminal, CurrentPlayer, IsChanceNode, LegalActions, ApplyAction — costs three device
+  // round trips instead of six.
+  Player CurrentPlayer() const { return Snap().cur; }
+  bool IsTerminal() const { return Snap().term != 0; }
   bool IsChanceNode() const { return CurrentPlayer() == kChancePlayerId; }
-  std::vector<double> Returns() const { return batch_.Returns(); }
+  std::vector<double> Returns() const { return Snap().returns; }
   std::vector<double> Rewards() const { return Returns(); }  // every game here is RewardModel::kTerminal
   double PlayerReturn(Player p) const { return Returns()[p]; }
   std::vector<Action> LegalActions() const {  // sorted ascending (basic_tests.cc:784-792)
-    std::vector<uint32_t> bits = batch_.LegalActionsMaskBits();
+    if (!snap_.have_mask) {
+      snap_.bits = batch_.LegalActionsMaskBits();
+      snap_.have_mask = true;
+    }
+    const std::vector<uint32_t>& bits = snap_.bits;
     std::vector<Action> out;
     for (size_t w = 0; w < bits.size(); ++w)
       for (int b = 0; b < 32; ++b)
@@ -491,6 +499,7 @@ class State {
     BatchedState fresh(batch_.GetGame(), 1);
     for (const auto& pa : keep) fresh.ApplyActions({static_cast<int32_t>(pa.second)});
     batch_ = std::move(fresh);
+    snap_ = Snapshot{};
     history_ = std::move(keep);
   }
   // ResampleFromInfostate (spiel.h:778-786; kuhn_poker.cc:312-327, leduc_poker.cc:706-760): a state `player`
@@ -539,6 +548,7 @@ class State {
     if (a == kInvalidAction) SpielFatalError("ApplyAction: kInvalidAction");
     const Player p = CurrentPlayer();
     batch_.ApplyActions({static_cast<int32_t>(a)});
+    snap_ = Snapshot{};
     history_.push_back({p, a});
   }
   std::vector<float> ObservationTensor(Player player) const {  // spiel.cc:908-919 bounds check
@@ -609,7 +619,23 @@ class State {
   void CheckPlayer(Player player) const {
     if (player < 0 || player >= NumPlayers()) SpielFatalError("player id out of range");
   }
+  struct Snapshot {
+    bool have_status = false, have_mask = false;
+    int8_t cur = 0;
+    uint8_t term = 0;
+    std::vector<double> returns;
+    std::vector<uint32_t> bits;
+  };
+  const Snapshot& Snap() const {
+    if (!snap_.have_status) {
+      snap_.returns.assign(static_cast<size_t>(NumPlayers()), 0.0);
+      Check(osg_status_query(batch_.handle(), &snap_.cur, &snap_.term, snap_.returns.data(), 1));
+      snap_.have_status = true;
+    }
+    return snap_;
+  }
   BatchedState batch_;
+  mutable Snapshot snap_;
   std::vector<std::pair<Player, Action>> history_;
 };
 

@@ -30,6 +30,7 @@ using hip::Policy; using hip::TabularPolicy; using hip::UniformPolicy; using hip
 using hip::GetUniformPolicy; using hip::GetFirstActionPolicy; using hip::GetEmptyTabularPolicy; using hip::ToTabularPolicy;
 using hip::GetPrefActionPolicy;
 using hip::Bot; using hip::EvaluateBots; using hip::SampleAction;
+using hip::MakeUniformRandomBot; using hip::MakeStatefulRandomBot; using hip::MakePolicyBot; using hip::MakeFixedActionPreferenceBot;
 using hip::Observer; using hip::Observation; using hip::IIGObservationType; using hip::PrivateInfoType;
 using hip::kDefaultObsType; using hip::kInfoStateObsType; using hip::SpanTensor; using hip::SpanTensorInfo;
 using hip::Near; using hip::UniformProbabilitySampler; using hip::operator<<;

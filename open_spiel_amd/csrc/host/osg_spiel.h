@@ -1752,6 +1752,124 @@ inline TabularPolicy GetEmptyTabularPolicy(const Game& game, bool initialize_to_
   return p;
 }
 inline TabularPolicy ToTabularPolicy(const Game& game, const Policy* policy) { return TabularPolicy(game, *policy); }
+
+// The stock bots of spiel_bots.h:187-230 (what examples/mcts_example.cc and evaluate_bots_test.cc pit an MCTSBot
+// against).  Host-only: they ask the position for its legal actions and draw on their own std::mt19937 (the reference
+// draws on abseil's distributions over the same generator: same bots, another stream).
+class UniformRandomBot : public Bot {
+ public:
+  UniformRandomBot(Player player_id, int seed) : player_id_(player_id), rng_(seed) {}
+  void RestartAt(const State&) override {}
+  Action Step(const State& state) override { return StepWithPolicy(state).second; }
+  bool ProvidesPolicy() override { return true; }
+  ActionsAndProbs GetPolicy(const State& state) override {
+    ActionsAndProbs policy;
+    const std::vector<Action> legal = state.LegalActions(player_id_);
+    for (Action a : legal) policy.emplace_back(a, 1.0 / legal.size());
+    return policy;
+  }
+  std::pair<ActionsAndProbs, Action> StepWithPolicy(const State& state) override {
+    ActionsAndProbs policy = GetPolicy(state);
+    if (policy.empty()) SpielFatalError("UniformRandomBot: no legal action for its player at this state");
+    const int pick = std::uniform_int_distribution<int>(0, static_cast<int>(policy.size()) - 1)(rng_);
+    return {policy, policy[pick].first};
+  }
+  bool IsClonable() const override { return true; }
+  std::unique_ptr<Bot> Clone() override { return std::make_unique<UniformRandomBot>(*this); }
+
+ protected:
+  const Player player_id_;
+  std::mt19937 rng_;
+};
+// A UniformRandomBot that follows the game in a state of its own: it exists to check that the run loop tells every
+// bot every action (spiel_bots.cc: StatefulRandomBot).
+class StatefulRandomBot : public UniformRandomBot {
+ public:
+  StatefulRandomBot(const Game& game, Player player_id, int seed)
+      : UniformRandomBot(player_id, seed), state_(game.NewInitialState()) {}
+  StatefulRandomBot(const StatefulRandomBot& other) : UniformRandomBot(other), state_(other.state_->Clone()) {}
+  void Restart() override { state_ = state_->GetGame()->NewInitialState(); }
+  void RestartAt(const State& state) override { state_ = state.Clone(); }
+  void InformAction(const State& state, Player, Action action) override {
+    CheckSame(state);
+    state_->ApplyAction(action);
+  }
+  ActionsAndProbs GetPolicy(const State& state) override {
+    CheckSame(state);
+    return UniformRandomBot::GetPolicy(*state_);
+  }
+  std::pair<ActionsAndProbs, Action> StepWithPolicy(const State&) override {
+    std::pair<ActionsAndProbs, Action> out = UniformRandomBot::StepWithPolicy(*state_);
+    state_->ApplyAction(out.second);
+    return out;
+  }
+  std::unique_ptr<Bot> Clone() override { return std::make_unique<StatefulRandomBot>(*this); }
+
+ private:
+  void CheckSame(const State& other) const {
+    if (other.History() != state_->History() || other.CurrentPlayer() != state_->CurrentPlayer() ||
+        other.LegalActions() != state_->LegalActions())
+      SpielFatalError("StatefulRandomBot: the run loop's state and the bot's own have diverged");
+    if (!other.IsChanceNode() && other.ObservationTensor(other.CurrentPlayer()) != state_->ObservationTensor(state_->CurrentPlayer()))
+      SpielFatalError("StatefulRandomBot: observation tensors differ");
+  }
+  std::unique_ptr<State> state_;
+};
+// Samples its action from a Policy (spiel_bots.cc: PolicyBot).
+class PolicyBot : public Bot {
+ public:
+  PolicyBot(int seed, std::shared_ptr<Policy> policy) : rng_(seed), policy_(std::move(policy)) {}
+  void RestartAt(const State&) override {}
+  Action Step(const State& state) override { return StepWithPolicy(state).second; }
+  bool ProvidesPolicy() override { return true; }
+  ActionsAndProbs GetPolicy(const State& state) override { return policy_->GetStatePolicy(state); }
+  std::pair<ActionsAndProbs, Action> StepWithPolicy(const State& state) override {
+    ActionsAndProbs policy = GetPolicy(state);
+    if (policy.empty()) SpielFatalError("PolicyBot: the policy has no entry for this state");
+    return {policy, SampleAction(policy, rng_).first};
+  }
+  bool IsClonable() const override { return true; }
+  std::unique_ptr<Bot> Clone() override { return std::make_unique<PolicyBot>(*this); }
+
+ private:
+  std::mt19937 rng_;
+  std::shared_ptr<Policy> policy_;
+};
+// Plays the first legal action of its preference list (spiel_bots.cc: FixedActionPreferenceBot).
+class FixedActionPreferenceBot : public Bot {
+ public:
+  FixedActionPreferenceBot(Player player_id, const std::vector<Action>& actions) : player_id_(player_id), actions_(actions) {}
+  void RestartAt(const State&) override {}
+  Action Step(const State& state) override { return StepWithPolicy(state).second; }
+  bool ProvidesPolicy() override { return true; }
+  ActionsAndProbs GetPolicy(const State& state) override {
+    const std::vector<Action> legal = state.LegalActions(player_id_);
+    for (Action a : actions_)
+      if (std::find(legal.begin(), legal.end(), a) != legal.end()) return {{a, 1.0}};
+    SpielFatalError("No legal actions found in preferred list");
+  }
+  std::pair<ActionsAndProbs, Action> StepWithPolicy(const State& state) override {
+    ActionsAndProbs policy = GetPolicy(state);
+    return {policy, policy[0].first};
+  }
+  bool IsClonable() const override { return true; }
+  std::unique_ptr<Bot> Clone() override { return std::make_unique<FixedActionPreferenceBot>(*this); }
+
+ private:
+  const Player player_id_;
+  std::vector<Action> actions_;
+};
+inline std::unique_ptr<Bot> MakeUniformRandomBot(Player player_id, int seed) { return std::make_unique<UniformRandomBot>(player_id, seed); }
+inline std::unique_ptr<Bot> MakeStatefulRandomBot(const Game& game, Player player_id, int seed) {
+  return std::make_unique<StatefulRandomBot>(game, player_id, seed);
+}
+inline std::unique_ptr<Bot> MakePolicyBot(int seed, std::shared_ptr<Policy> policy) { return std::make_unique<PolicyBot>(seed, std::move(policy)); }
+inline std::unique_ptr<Bot> MakePolicyBot(const Game&, Player, int seed, std::shared_ptr<Policy> policy) {
+  return MakePolicyBot(seed, std::move(policy));  // (the reference ignores game and player as well)
+}
+inline std::unique_ptr<Bot> MakeFixedActionPreferenceBot(Player player_id, const std::vector<Action>& actions) {
+  return std::make_unique<FixedActionPreferenceBot>(player_id, actions);
+}
 inline std::shared_ptr<Policy> algorithms::DeviceTabularSolver::AveragePolicy() const {
   return std::make_shared<TabularPolicy>(TabularAveragePolicy());
 }

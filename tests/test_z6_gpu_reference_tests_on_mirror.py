@@ -51,8 +51,18 @@ def test_reference_test_sources_compile_against_the_mirror():
     if not os.path.isdir("/root/reference/open_spiel"):
         pytest.skip("no /root/reference here: the binaries are built where it exists and shipped prebuilt")
     _ensure_built()
-    for b in BINARIES:
+    for b in BINARIES + SLOW_BINARIES:
         assert os.access(os.path.join(BUILT, b), os.X_OK), b
+
+
+SLOW_BINARIES = ["reference_evaluate_bots_test"]   # 200 000 episodes through one-state batches: 142 s on an MI355X
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.environ.get("OSG_SLOW_TESTS"), reason="142 s: set OSG_SLOW_TESTS=1 (passed on the device: profiles/r03_slow_reference_tests.log)")
+@pytest.mark.parametrize("binary", SLOW_BINARIES)
+def test_slow_reference_unit_test_passes_on_the_mirror(binary):
+    test_reference_unit_test_passes_on_the_mirror(binary)
 
 
 @pytest.mark.gpu

@@ -195,6 +195,31 @@ class PyEvaluator : public Evaluator {
   }
 };
 
+// Python subclasses of Bot (python/pybind11/python_bots.h: PyBot; e.g. open_spiel/python/bots/uniform_random.py)
+class PyBot : public Bot {
+ public:
+  using Bot::Bot;
+  Action Step(const State& state) override { PYBIND11_OVERRIDE_PURE_NAME(Action, Bot, "step", Step, state); }
+  void Restart() override { PYBIND11_OVERRIDE_NAME(void, Bot, "restart", Restart); }
+  void RestartAt(const State& state) override { PYBIND11_OVERRIDE_NAME(void, Bot, "restart_at", RestartAt, state); }
+  void InformAction(const State& state, Player player_id, Action action) override {
+    PYBIND11_OVERRIDE_NAME(void, Bot, "inform_action", InformAction, state, player_id, action);
+  }
+  void InformActions(const State& state, const std::vector<Action>& actions) override {
+    PYBIND11_OVERRIDE_NAME(void, Bot, "inform_actions", InformActions, state, actions);
+  }
+  bool ProvidesForceAction() override { PYBIND11_OVERRIDE_NAME(bool, Bot, "provides_force_action", ProvidesForceAction); }
+  void ForceAction(const State& state, Action action) override {
+    PYBIND11_OVERRIDE_NAME(void, Bot, "force_action", ForceAction, state, action);
+  }
+  bool ProvidesPolicy() override { PYBIND11_OVERRIDE_NAME(bool, Bot, "provides_policy", ProvidesPolicy); }
+  ActionsAndProbs GetPolicy(const State& state) override { PYBIND11_OVERRIDE_NAME(ActionsAndProbs, Bot, "get_policy", GetPolicy, state); }
+  std::pair<ActionsAndProbs, Action> StepWithPolicy(const State& state) override {
+    using StepRet = std::pair<ActionsAndProbs, Action>;
+    PYBIND11_OVERRIDE_NAME(StepRet, Bot, "step_with_policy", StepWithPolicy, state);
+  }
+};
+
 PYBIND11_MODULE(pyspiel_hip, m) {
   m.doc() = "pyspiel-compatible surface of the MI355X game-step and search engine (libosg_hip.so)";
   py::register_exception<SpielException>(m, "SpielError", PyExc_RuntimeError);  // pyspiel.cc:831-837
@@ -363,7 +388,8 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("to_string", &SearchNode::ToString, py::arg("state"))
       .def("children_str", &SearchNode::ChildrenStr, py::arg("state"));
 
-  py::class_<Bot>(m, "Bot")  // python/pybind11/bots.cc:57-98 (spiel_bots.h:73-185)
+  py::class_<Bot, PyBot>(m, "Bot")  // python/pybind11/bots.cc:57-98 (spiel_bots.h:73-185); Python bots derive from it
+      .def(py::init<>())
       .def("step", &Bot::Step, py::arg("state"))
       .def("restart", &Bot::Restart)
       .def("restart_at", &Bot::RestartAt, py::arg("state"))
@@ -375,6 +401,20 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("get_policy", &Bot::GetPolicy, py::arg("state"))
       .def("step_with_policy", &Bot::StepWithPolicy, py::arg("state"))
       .def("is_clonable", &Bot::IsClonable);
+
+  // bots.cc:177-196: one episode with a bot per player; the stock bots
+  m.def("evaluate_bots", [](State* state, const std::vector<Bot*>& bots, int seed) { return EvaluateBots(state, bots, seed); },
+        py::arg("state"), py::arg("bots"), py::arg("seed"));
+  m.def("make_uniform_random_bot", [](Player player_id, int seed) { return MakeUniformRandomBot(player_id, seed); },
+        py::arg("player_id"), py::arg("seed"));
+  m.def("make_stateful_random_bot",
+        [](std::shared_ptr<Game> game, Player player_id, int seed) { return MakeStatefulRandomBot(*game, player_id, seed); },
+        py::arg("game"), py::arg("player_id"), py::arg("seed"));
+  m.def("make_policy_bot",
+        [](std::shared_ptr<Game> game, Player player_id, int seed, std::shared_ptr<Policy> policy) {
+          return MakePolicyBot(*game, player_id, seed, std::move(policy));
+        },
+        py::arg("game"), py::arg("player_id"), py::arg("seed"), py::arg("policy"));
 
   py::enum_<ChildSelectionPolicy>(m, "ChildSelectionPolicy")  // bots.cc:113-117
       .value("UCT", ChildSelectionPolicy::UCT)

@@ -634,3 +634,53 @@ def test_per_game_state_classes_through_the_alias(pyspiel):
             sys.modules.pop(k)
         if had is not None:
             sys.modules["pyspiel"] = had
+
+
+@pytest.mark.gpu
+def test_python_and_cpp_bots_through_evaluate_bots(pyspiel):
+    """python/tests/bot_test.py:33-44 (a C++ stock bot against a Python subclass of pyspiel.Bot through evaluate_bots) with
+    fewer episodes, and the two other stock bots of bots.cc:184-196."""
+
+    class UniformRandomBot(pyspiel.Bot):   # the shape of open_spiel/python/bots/uniform_random.py
+        def __init__(self, player_id, rng):
+            pyspiel.Bot.__init__(self)
+            self._player_id, self._rng = player_id, rng
+
+        def restart_at(self, state):
+            pass
+
+        def provides_policy(self):
+            return True
+
+        def step_with_policy(self, state):
+            legal = state.legal_actions(self._player_id)
+            if not legal:
+                return [], pyspiel.INVALID_ACTION
+            return [(a, 1 / len(legal)) for a in legal], int(self._rng.choice(legal))
+
+        def step(self, state):
+            return self.step_with_policy(state)[1]
+
+    game = pyspiel.load_game("kuhn_poker")
+    bots = [pyspiel.make_uniform_random_bot(0, 1234), UniformRandomBot(1, np.random.RandomState(4321))]
+    results = np.array([pyspiel.evaluate_bots(game.new_initial_state(), bots, it) for it in range(1500)])
+    np.testing.assert_allclose(results.mean(axis=0), [0.125, -0.125], atol=0.1)
+    assert np.all(results.sum(axis=1) == 0)
+    # the stateful bot checks on every inform_action that the run loop's state equals its own copy
+    bots = [pyspiel.make_stateful_random_bot(game, 0, 7), pyspiel.make_policy_bot(game, 1, 8, pyspiel.UniformPolicy())]
+    results = np.array([pyspiel.evaluate_bots(game.new_initial_state(), bots, it) for it in range(300)])
+    assert np.all(results.sum(axis=1) == 0) and set(np.unique(results)) <= {-2.0, -1.0, 1.0, 2.0}
+
+
+@pytest.mark.gpu
+def test_cpp_mcts_bot_through_evaluate_bots(pyspiel):
+    """python/tests/bot_test.py:52-69: one MCTSBot object in both seats, then a search inspected by hand."""
+    game = pyspiel.load_game("tic_tac_toe")
+    bots = [pyspiel.MCTSBot(game, pyspiel.RandomRolloutEvaluator(1, 0), 2.0, 100, 100, False, 42, False)] * 2
+    results = np.array([pyspiel.evaluate_bots(game.new_initial_state(), bots, it) for it in range(10)])
+    assert results.shape == (10, 2) and np.all(results.sum(axis=1) == 0)
+    state = game.new_initial_state()
+    node = bots[0].mcts_search(state)
+    assert sum(c.explore_count for c in node.children) == 100 - 1 or sum(c.explore_count for c in node.children) == 100
+    assert "explored" in node.children_str(state) or len(node.children_str(state)) > 0
+    assert node.best_child().to_string(state)

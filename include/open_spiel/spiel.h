@@ -23,7 +23,7 @@ using hip::kInvalidAction; using hip::kChancePlayerId; using hip::kTerminalPlaye
 using hip::kSimultaneousPlayerId; using hip::kInvalidPlayer; using hip::kMeanFieldPlayerId;
 using hip::Game; using hip::State; using hip::BatchedState; using hip::LoadGame; using hip::LoadGameAsTurnBased;
 using hip::SpielFatalError; using hip::SpielException;
-using hip::GameType; using hip::GameParameter; using hip::GameParameters; using hip::GameParametersFromString;
+using hip::TensorLayout; using hip::GameType; using hip::GameParameter; using hip::GameParameters; using hip::GameParametersFromString;
 using hip::GameParametersToString;
 using hip::SerializeGameAndState; using hip::DeserializeGameAndState;
 using hip::Policy; using hip::TabularPolicy; using hip::UniformPolicy; using hip::PreferredActionPolicy;

@@ -259,6 +259,7 @@ struct GameType {
 
 class State;
 class BatchedState;
+enum class TensorLayout { kHWC, kCHW };  // spiel.h:231
 class Policy;
 class TabularPolicy;
 class Observer;
@@ -302,6 +303,10 @@ class Game : public std::enable_shared_from_this<Game> {
   }
   std::optional<double> UtilitySum() const { return 0.0; }               // spiel.h:1012-1016: zero-sum games
   int MaxMoveNumber() const { return MaxGameLength() + MaxChanceNodesInHistory(); }  // spiel.h:1125-1127
+  int MaxHistoryLength() const { return MaxGameLength() + MaxChanceNodesInHistory(); }  // spiel.h:1100-1102 (sequential games)
+  std::vector<int> PolicyTensorShape() const { return {NumDistinctActions()}; }  // spiel.h:1059-1061
+  TensorLayout ObservationTensorLayout() const { return TensorLayout::kCHW; }   // spiel.h:1043-1045
+  TensorLayout InformationStateTensorLayout() const { return TensorLayout::kCHW; }
   GameParameters GetParameters() const { return GameParametersFromString(ToString()); }
   std::string Serialize() const { return ToString(); }  // spiel.cc:793-800 (no sampled-stochastic games here)
   const std::string& GameString() const { return string_; }
@@ -604,6 +609,31 @@ class State {
     for (const auto& pa : history_) h.push_back(pa.second);
     return h;
   }
+  struct PlayerAction {  // spiel.h:594-600
+    Player player;
+    Action action;
+    bool operator==(const PlayerAction& o) const { return player == o.player && action == o.action; }
+  };
+  std::vector<PlayerAction> FullHistory() const {  // spiel.h:605
+    std::vector<PlayerAction> h;
+    for (const auto& pa : history_) h.push_back({pa.first, pa.second});
+    return h;
+  }
+  // spiel.cc:432-439: the legal action that prints as action_str
+  Action StringToAction(Player player, const std::string& action_str) const {
+    for (Action a : LegalActions())
+      if (action_str == ActionToString(player, a)) return a;
+    SpielFatalError("Couldn't find an action matching " + action_str);
+  }
+  Action StringToAction(const std::string& action_str) const { return StringToAction(CurrentPlayer(), action_str); }
+  // spiel.cc:947-964: true where every action before this state was a chance outcome and the state is not a chance node
+  bool IsInitialNonChanceState() const {
+    if (IsChanceNode()) return false;
+    for (const auto& pa : history_)
+      if (pa.first != kChancePlayerId) return false;
+    return true;
+  }
+  double PlayerReward(Player p) const { return Rewards()[p]; }
   // State::Serialize (spiel.cc:411-430): the action history, one action per line.
   std::string Serialize() const {
     std::string out;

@@ -225,6 +225,12 @@ PYBIND11_MODULE(pyspiel_hip, m) {
   py::register_exception<SpielException>(m, "SpielError", PyExc_RuntimeError);  // pyspiel.cc:831-837
 
   m.attr("INVALID_ACTION") = py::int_(kInvalidAction);
+  py::enum_<TensorLayout>(m, "TensorLayout")  // pyspiel.cc:330-333
+      .value("HWC", TensorLayout::kHWC)
+      .value("CHW", TensorLayout::kCHW);
+  py::class_<State::PlayerAction>(m, "PlayerAction")  // pyspiel.cc:343-345
+      .def_readonly("player", &State::PlayerAction::player)
+      .def_readonly("action", &State::PlayerAction::action);
   py::class_<Game, std::shared_ptr<Game>>(m, "Game")
       .def("num_distinct_actions", &Game::NumDistinctActions)
       .def("max_chance_outcomes", &Game::MaxChanceOutcomes)
@@ -233,6 +239,11 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("max_utility", &Game::MaxUtility)
       .def("max_game_length", &Game::MaxGameLength)
       .def("max_chance_nodes_in_history", &Game::MaxChanceNodesInHistory)
+      .def("max_move_number", &Game::MaxMoveNumber)
+      .def("max_history_length", &Game::MaxHistoryLength)
+      .def("policy_tensor_shape", &Game::PolicyTensorShape)
+      .def("observation_tensor_layout", &Game::ObservationTensorLayout)
+      .def("information_state_tensor_layout", &Game::InformationStateTensorLayout)
       .def("observation_tensor_shape", &Game::ObservationTensorShape)
       .def("observation_tensor_size", &Game::ObservationTensorSize)
       .def("information_state_tensor_shape", &Game::InformationStateTensorShape)
@@ -312,6 +323,17 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("clone", &State::Clone)
       .def("child", &State::Child, py::arg("action"))
       .def("history", &State::History)
+      .def("full_history", &State::FullHistory)                     // pyspiel.cc:426
+      .def("string_to_action", py::overload_cast<Player, const std::string&>(&State::StringToAction, py::const_), py::arg("player"),
+           py::arg("string"))
+      .def("string_to_action", py::overload_cast<const std::string&>(&State::StringToAction, py::const_), py::arg("string"))
+      .def("is_initial_non_chance_state", &State::IsInitialNonChanceState)
+      .def("is_mean_field_node", &State::IsMeanFieldNode)
+      .def("player_reward", &State::PlayerReward, py::arg("player"))
+      .def("apply_actions", &State::ApplyActions, py::arg("actions"))  // sequential games: fatal, as in the reference
+      .def("apply_actions_with_legality_checks", &State::ApplyActionsWithLegalityChecks, py::arg("actions"))
+      .def("distribution_support", &State::DistributionSupport)
+      .def("update_distribution", &State::UpdateDistribution, py::arg("distribution"))
       .def("serialize", &State::Serialize)
       .def(py::pickle(  // pyspiel.cc:455-474: a state pickles as its game-and-state text
           [](const State& s) { return SerializeGameAndState(*s.GetGame(), s); },

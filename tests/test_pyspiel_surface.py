@@ -684,3 +684,31 @@ def test_cpp_mcts_bot_through_evaluate_bots(pyspiel):
     assert sum(c.explore_count for c in node.children) == 100 - 1 or sum(c.explore_count for c in node.children) == 100
     assert "explored" in node.children_str(state) or len(node.children_str(state)) > 0
     assert node.best_child().to_string(state)
+
+
+@pytest.mark.gpu
+def test_history_and_string_helpers_of_state(pyspiel):
+    """pyspiel.cc:413-470: full_history (PlayerAction records), string_to_action (spiel.cc:432-439),
+    is_initial_non_chance_state (spiel.cc:947-964), player_reward, and the Game-side sizes next to them."""
+    game = pyspiel.load_game("tic_tac_toe")
+    state = game.new_initial_state()
+    assert state.string_to_action("x(1,1)") == 4 and state.string_to_action(0, "x(2,2)") == 8
+    with pytest.raises(pyspiel.SpielError):
+        state.string_to_action("no such move")
+    for a in (4, 0, 8):
+        state.apply_action(a)
+    assert [(pa.player, pa.action) for pa in state.full_history()] == [(0, 4), (1, 0), (0, 8)]
+    assert state.player_reward(0) == 0.0 and not state.is_mean_field_node()
+    assert game.max_move_number() == 9 and game.max_history_length() == 9 and game.policy_tensor_shape() == [9]
+    assert game.observation_tensor_layout() == pyspiel.TensorLayout.CHW
+    with pytest.raises(pyspiel.SpielError):
+        state.apply_actions([1, 2])               # a sequential game (spiel.h: ApplyActions is for simultaneous nodes)
+    kuhn = pyspiel.load_game("kuhn_poker")
+    s = kuhn.new_initial_state()
+    assert not s.is_initial_non_chance_state()    # a chance node
+    s.apply_action(0); s.apply_action(1)
+    assert s.is_initial_non_chance_state()        # only chance outcomes so far, a player to move
+    assert [pa.player for pa in s.full_history()] == [-1, -1]   # kChancePlayerId
+    s.apply_action(0)
+    assert not s.is_initial_non_chance_state()
+    assert kuhn.max_move_number() == kuhn.max_game_length() + kuhn.max_chance_nodes_in_history()

@@ -75,6 +75,46 @@ py::dict GameParametersWithDefaults(const std::string& game_string) {
   return out;
 }
 
+// "name(k=v,...)" from a short name and a Python dict of parameters: bools as True / False, the rest through str()
+std::string GameStringFromDict(const std::string& name, const py::dict& params) {
+  std::vector<std::string> items;
+  for (auto item : params) {
+    const std::string key = py::cast<std::string>(item.first);
+    std::string value;
+    if (py::isinstance<py::bool_>(item.second)) value = py::cast<bool>(item.second) ? "True" : "False";
+    else value = py::cast<std::string>(py::str(item.second));
+    items.push_back(key + "=" + value);
+  }
+  std::sort(items.begin(), items.end());
+  if (items.empty()) return name;
+  std::string out = name + "(";
+  for (size_t i = 0; i < items.size(); ++i) out += (i ? "," : "") + items[i];
+  return out + ")";
+}
+// only the parameters a game string gives, typed like get_parameters() types them
+py::dict GameParametersGiven(const std::string& game_string) {
+  py::dict out;
+  const size_t open = game_string.find('(');
+  if (open == std::string::npos) return out;
+  const std::string body = game_string.substr(open + 1, game_string.rfind(')') - open - 1);
+  size_t pos = 0;
+  while (pos < body.size()) {
+    size_t comma = body.find(',', pos);
+    if (comma == std::string::npos) comma = body.size();
+    const std::string item = body.substr(pos, comma - pos);
+    pos = comma + 1;
+    const size_t eq = item.find('=');
+    if (eq == std::string::npos) continue;
+    const std::string k = item.substr(0, eq), v = item.substr(eq + 1);
+    if (v == "True" || v == "true") out[py::str(k)] = py::bool_(true);
+    else if (v == "False" || v == "false") out[py::str(k)] = py::bool_(false);
+    else if (!v.empty() && v.find_first_not_of("-0123456789") == std::string::npos) out[py::str(k)] = py::int_(std::stoll(v));
+    else out[py::str(k)] = py::str(v);
+  }
+  return out;
+}
+enum class StateKind { kTerminal, kChance, kDecision, kMeanField };  // StateType of spiel_globals.h:84-92
+
 // The GameType fields scripts look at (spiel.h:60-160), as plain read-only attributes.
 struct GameTypeInfo {
   std::string short_name, long_name, dynamics, chance_mode, information, utility, reward_model;
@@ -281,6 +321,42 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def_readonly("provides_observation_string", &GameTypeInfo::provides_observation_string)
       .def_readonly("provides_observation_tensor", &GameTypeInfo::provides_observation_tensor);
   m.def("load_game", [](const std::string& s) { return std::make_shared<Game>(s); });  // pyspiel.cc:720-731
+  // load_game(short_name, {"players": 3, "swap": True}) (pyspiel.cc:732-741): the parameters as a Python dict
+  m.def("load_game",
+        [](const std::string& name, const py::dict& params) { return std::make_shared<Game>(GameStringFromDict(name, params)); },
+        py::arg("short_name"), py::arg("params"));
+  m.def("registered_names", [] { return std::vector<std::string>{"connect_four", "hex", "kuhn_poker", "leduc_poker", "tic_tac_toe"}; });
+  m.def("registered_concrete_names",
+        [] { return std::vector<std::string>{"connect_four", "hex", "kuhn_poker", "leduc_poker", "tic_tac_toe"}; });
+  m.def("game_parameters_from_string",  // pyspiel.cc:168: "kuhn_poker(players=3)" -> {"name": "kuhn_poker", "players": 3}
+        [](const std::string& game_string) {
+          py::dict out = GameParametersGiven(game_string);
+          out[py::str("name")] = py::str(game_string.substr(0, game_string.find('(')));
+          return out;
+        });
+  m.def("game_parameters_to_string", [](const py::dict& params) {  // pyspiel.cc:171
+    if (!params.contains("name")) SpielFatalError("game_parameters_to_string: the dictionary has no \"name\"");
+    py::dict rest;
+    for (auto item : params)
+      if (py::cast<std::string>(item.first) != "name") rest[item.first] = item.second;
+    return GameStringFromDict(py::cast<std::string>(params["name"]), rest);
+  });
+  m.def("sample_action",  // pyspiel.cc:811-815, spiel_utils SampleAction(outcomes, z): cumulative intervals, z in [0, 1)
+        [](const ActionsAndProbs& outcomes, double z) {
+          if (!(z >= 0.0 && z < 1.0)) SpielFatalError("sample_action: z must be in [0, 1)");
+          double acc = 0;
+          for (const auto& ap : outcomes) {
+            if (z >= acc && z < acc + ap.second) return ap;
+            acc += ap.second;
+          }
+          SpielFatalError("sample_action: the probabilities do not cover z");
+        },
+        py::arg("actions_and_probs"), py::arg("z"));
+  py::enum_<StateKind>(m, "StateType")  // pyspiel.cc:317-322 (spiel_globals.h:84-92)
+      .value("TERMINAL", StateKind::kTerminal)
+      .value("CHANCE", StateKind::kChance)
+      .value("DECISION", StateKind::kDecision)
+      .value("MEAN_FIELD", StateKind::kMeanField);
 
   py::class_<State>(m, "State")
       .def("current_player", &State::CurrentPlayer)
@@ -324,6 +400,9 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("child", &State::Child, py::arg("action"))
       .def("history", &State::History)
       .def("full_history", &State::FullHistory)                     // pyspiel.cc:426
+      .def("get_type", [](const State& st) {                        // spiel.cc: State::GetType
+        return st.IsTerminal() ? StateKind::kTerminal : (st.IsChanceNode() ? StateKind::kChance : StateKind::kDecision);
+      })
       .def("string_to_action", py::overload_cast<Player, const std::string&>(&State::StringToAction, py::const_), py::arg("player"),
            py::arg("string"))
       .def("string_to_action", py::overload_cast<const std::string&>(&State::StringToAction, py::const_), py::arg("string"))

@@ -712,3 +712,34 @@ def test_history_and_string_helpers_of_state(pyspiel):
     s.apply_action(0)
     assert not s.is_initial_non_chance_state()
     assert kuhn.max_move_number() == kuhn.max_game_length() + kuhn.max_chance_nodes_in_history()
+
+
+def test_load_game_with_a_parameter_dict_and_the_module_level_helpers(pyspiel):
+    """pyspiel.cc:720-741 load_game(name, params), :168-172 game_parameters_from / to_string, :768-775 registered names,
+    :811-815 sample_action — host-only, no GPU needed."""
+    g = pyspiel.load_game("kuhn_poker", {"players": 3})
+    assert str(g) == "kuhn_poker(players=3)" and g.num_players() == 3
+    h = pyspiel.load_game("hex", {"board_size": 5, "swap": True})
+    assert h.num_distinct_actions() == 26 and h.get_parameters()["swap"] is True
+    assert str(pyspiel.load_game("tic_tac_toe", {})) == "tic_tac_toe()"
+    with pytest.raises(pyspiel.SpielError):
+        pyspiel.load_game("kuhn_poker", {"players": 1})
+    params = pyspiel.game_parameters_from_string("leduc_poker(players=3,action_mapping=True)")
+    assert params == {"name": "leduc_poker", "players": 3, "action_mapping": True}
+    assert pyspiel.game_parameters_to_string(params) == "leduc_poker(action_mapping=True,players=3)"
+    assert str(pyspiel.load_game(pyspiel.game_parameters_to_string(params))) == "leduc_poker(action_mapping=True,players=3)"
+    assert set(pyspiel.registered_names()) == {"tic_tac_toe", "connect_four", "hex", "kuhn_poker", "leduc_poker"}
+    outcomes = [(0, 0.25), (3, 0.5), (7, 0.25)]
+    assert [pyspiel.sample_action(outcomes, z)[0] for z in (0.0, 0.2499, 0.25, 0.74, 0.75, 0.999)] == [0, 0, 3, 3, 7, 7]
+    with pytest.raises(pyspiel.SpielError):
+        pyspiel.sample_action(outcomes, 1.0)
+
+
+@pytest.mark.gpu
+def test_state_get_type(pyspiel):
+    s = pyspiel.load_game("kuhn_poker").new_initial_state()
+    assert s.get_type() == pyspiel.StateType.CHANCE
+    s.apply_action(0); s.apply_action(1)
+    assert s.get_type() == pyspiel.StateType.DECISION
+    s.apply_action(0); s.apply_action(0)
+    assert s.get_type() == pyspiel.StateType.TERMINAL

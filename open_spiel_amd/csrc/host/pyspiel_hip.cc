@@ -115,35 +115,6 @@ py::dict GameParametersGiven(const std::string& game_string) {
 }
 enum class StateKind { kTerminal, kChance, kDecision, kMeanField };  // StateType of spiel_globals.h:84-92
 
-// The GameType fields scripts look at (spiel.h:60-160), as plain read-only attributes.
-struct GameTypeInfo {
-  std::string short_name, long_name, dynamics, chance_mode, information, utility, reward_model;
-  int max_num_players, min_num_players;
-  bool provides_information_state_string, provides_information_state_tensor, provides_observation_string,
-      provides_observation_tensor;
-};
-GameTypeInfo GameTypeOf(const Game& g) {
-  const std::string s = g.ToString();
-  const std::string name = s.substr(0, s.find('('));
-  const bool poker = name == "kuhn_poker" || name == "leduc_poker";
-  GameTypeInfo t;
-  t.short_name = name;
-  t.long_name = name == "tic_tac_toe" ? "Tic Tac Toe" : name == "connect_four" ? "Connect Four" : name == "hex" ? "Hex"
-                : name == "kuhn_poker" ? "Kuhn Poker" : "Leduc Poker";
-  t.dynamics = "Dynamics.SEQUENTIAL";
-  t.chance_mode = poker ? "ChanceMode.EXPLICIT_STOCHASTIC" : "ChanceMode.DETERMINISTIC";
-  t.information = poker ? "Information.IMPERFECT_INFORMATION" : "Information.PERFECT_INFORMATION";
-  t.utility = "Utility.ZERO_SUM";
-  t.reward_model = "RewardModel.TERMINAL";
-  t.min_num_players = 2;
-  t.max_num_players = poker ? 10 : 2;
-  t.provides_information_state_string = true;
-  t.provides_information_state_tensor = poker;
-  t.provides_observation_string = true;
-  t.provides_observation_tensor = true;
-  return t;
-}
-
 enum class TttCellState { kEmpty, kNought, kCross };          // tic_tac_toe.h:38-42
 enum class LeducActionType { kFold = 0, kCall = 1, kRaise = 2 };  // leduc_poker.h:64
 
@@ -295,7 +266,7 @@ PYBIND11_MODULE(pyspiel_hip, m) {
                       [](const std::string& t) { return std::const_pointer_cast<Game>(LoadGame(t)); }))
       .def("utility_sum", [](const Game&) { return 0.0; })  // all five games are zero-sum (spiel.h:1006-1011)
       .def("get_parameters", [](const Game& g) { return GameParametersWithDefaults(g.ToString()); })
-      .def("get_type", [](const Game& g) { return GameTypeOf(g); })
+      .def("get_type", &Game::GetType)
       .def("new_initial_states", [](const Game& g, int64_t n) { return g.NewInitialStates(n); }, py::arg("n"))
       // pyspiel.cc:509-533: make_observer(iig_obs_type=None, params={}) -> Observer or None
       .def("make_observer",
@@ -306,20 +277,46 @@ PYBIND11_MODULE(pyspiel_hip, m) {
            py::arg("imperfect_information_observation_type") = py::none(), py::arg("params") = py::dict())
       .def("__str__", &Game::ToString)
       .def("__repr__", &Game::ToString);
-  py::class_<GameTypeInfo>(m, "GameType")
-      .def_readonly("short_name", &GameTypeInfo::short_name)
-      .def_readonly("long_name", &GameTypeInfo::long_name)
-      .def_readonly("dynamics", &GameTypeInfo::dynamics)
-      .def_readonly("chance_mode", &GameTypeInfo::chance_mode)
-      .def_readonly("information", &GameTypeInfo::information)
-      .def_readonly("utility", &GameTypeInfo::utility)
-      .def_readonly("reward_model", &GameTypeInfo::reward_model)
-      .def_readonly("max_num_players", &GameTypeInfo::max_num_players)
-      .def_readonly("min_num_players", &GameTypeInfo::min_num_players)
-      .def_readonly("provides_information_state_string", &GameTypeInfo::provides_information_state_string)
-      .def_readonly("provides_information_state_tensor", &GameTypeInfo::provides_information_state_tensor)
-      .def_readonly("provides_observation_string", &GameTypeInfo::provides_observation_string)
-      .def_readonly("provides_observation_tensor", &GameTypeInfo::provides_observation_tensor);
+  py::class_<GameType> game_type(m, "GameType");  // pyspiel.cc:246-303: the fields scripts look at, with the nested enums
+  py::enum_<GameType::Dynamics>(game_type, "Dynamics")
+      .value("SEQUENTIAL", GameType::Dynamics::kSequential)
+      .value("MEAN_FIELD", GameType::Dynamics::kMeanField)
+      .value("SIMULTANEOUS", GameType::Dynamics::kSimultaneous);
+  py::enum_<GameType::ChanceMode>(game_type, "ChanceMode")
+      .value("DETERMINISTIC", GameType::ChanceMode::kDeterministic)
+      .value("EXPLICIT_STOCHASTIC", GameType::ChanceMode::kExplicitStochastic)
+      .value("SAMPLED_STOCHASTIC", GameType::ChanceMode::kSampledStochastic);
+  py::enum_<GameType::Information>(game_type, "Information")
+      .value("ONE_SHOT", GameType::Information::kOneShot)
+      .value("PERFECT_INFORMATION", GameType::Information::kPerfectInformation)
+      .value("IMPERFECT_INFORMATION", GameType::Information::kImperfectInformation);
+  py::enum_<GameType::Utility>(game_type, "Utility")
+      .value("ZERO_SUM", GameType::Utility::kZeroSum)
+      .value("CONSTANT_SUM", GameType::Utility::kConstantSum)
+      .value("GENERAL_SUM", GameType::Utility::kGeneralSum)
+      .value("IDENTICAL", GameType::Utility::kIdentical);
+  py::enum_<GameType::RewardModel>(game_type, "RewardModel")
+      .value("REWARDS", GameType::RewardModel::kRewards)
+      .value("TERMINAL", GameType::RewardModel::kTerminal);
+  game_type.def_readonly("short_name", &GameType::short_name)
+      .def_readonly("long_name", &GameType::long_name)
+      .def_readonly("dynamics", &GameType::dynamics)
+      .def_readonly("chance_mode", &GameType::chance_mode)
+      .def_readonly("information", &GameType::information)
+      .def_readonly("utility", &GameType::utility)
+      .def_readonly("reward_model", &GameType::reward_model)
+      .def_readonly("max_num_players", &GameType::max_num_players)
+      .def_readonly("min_num_players", &GameType::min_num_players)
+      .def_readonly("provides_information_state_string", &GameType::provides_information_state_string)
+      .def_readonly("provides_information_state_tensor", &GameType::provides_information_state_tensor)
+      .def_readonly("provides_observation_string", &GameType::provides_observation_string)
+      .def_readonly("provides_observation_tensor", &GameType::provides_observation_tensor)
+      .def_readonly("provides_factored_observation_string", &GameType::provides_factored_observation_string)
+      .def_readonly("default_loadable", &GameType::default_loadable)
+      .def_readonly("is_concrete", &GameType::is_concrete)
+      .def("provides_information_state", &GameType::provides_information_state)
+      .def("provides_observation", &GameType::provides_observation)
+      .def("__repr__", [](const GameType& t) { return "<GameType '" + t.short_name + "'>"; });
   m.def("load_game", [](const std::string& s) { return std::make_shared<Game>(s); });  // pyspiel.cc:720-731
   // load_game(short_name, {"players": 3, "swap": True}) (pyspiel.cc:732-741): the parameters as a Python dict
   m.def("load_game",

@@ -44,7 +44,7 @@ def test_game_headers_match_the_reference_playthroughs(pyspiel, goldens):
         assert game.observation_tensor_size() == int(hdr["ObservationTensorSize"])
         assert str(game) == hdr["ToString"].strip('"')
         t = game.get_type()
-        assert t.short_name == play["game"].split("(")[0] and t.utility == "Utility.ZERO_SUM"
+        assert t.short_name == play["game"].split("(")[0] and t.utility == pyspiel.GameType.Utility.ZERO_SUM
         def shape_text(pieces):
             if len(pieces) == 1 and pieces[0][0] == "observation":
                 return str(list(pieces[0][1]))

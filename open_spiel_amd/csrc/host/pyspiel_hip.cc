@@ -236,6 +236,16 @@ PYBIND11_MODULE(pyspiel_hip, m) {
   py::register_exception<SpielException>(m, "SpielError", PyExc_RuntimeError);  // pyspiel.cc:831-837
 
   m.attr("INVALID_ACTION") = py::int_(kInvalidAction);
+  {  // pyspiel.cc:139-158: PlayerId as a Python IntEnum (spiel_globals.h:44-60), so that state.current_player() == PlayerId.CHANCE
+    py::dict members;
+    members["DEFAULT_PLAYER_ID"] = py::int_(kDefaultPlayerId);
+    members["INVALID"] = py::int_(kInvalidPlayer);
+    members["TERMINAL"] = py::int_(kTerminalPlayerId);
+    members["CHANCE"] = py::int_(kChancePlayerId);
+    members["MEAN_FIELD"] = py::int_(kMeanFieldPlayerId);
+    members["SIMULTANEOUS"] = py::int_(kSimultaneousPlayerId);
+    m.attr("PlayerId") = py::module_::import("enum").attr("IntEnum")("PlayerId", members, py::arg("module") = py::str(m.attr("__name__")));
+  }
   py::enum_<TensorLayout>(m, "TensorLayout")  // pyspiel.cc:330-333
       .value("HWC", TensorLayout::kHWC)
       .value("CHW", TensorLayout::kCHW);

@@ -708,7 +708,7 @@ def test_history_and_string_helpers_of_state(pyspiel):
     assert not s.is_initial_non_chance_state()    # a chance node
     s.apply_action(0); s.apply_action(1)
     assert s.is_initial_non_chance_state()        # only chance outcomes so far, a player to move
-    assert [pa.player for pa in s.full_history()] == [-1, -1]   # kChancePlayerId
+    assert [pa.player for pa in s.full_history()] == [pyspiel.PlayerId.CHANCE] * 2
     s.apply_action(0)
     assert not s.is_initial_non_chance_state()
     assert kuhn.max_move_number() == kuhn.max_game_length() + kuhn.max_chance_nodes_in_history()
@@ -729,6 +729,8 @@ def test_load_game_with_a_parameter_dict_and_the_module_level_helpers(pyspiel):
     assert pyspiel.game_parameters_to_string(params) == "leduc_poker(action_mapping=True,players=3)"
     assert str(pyspiel.load_game(pyspiel.game_parameters_to_string(params))) == "leduc_poker(action_mapping=True,players=3)"
     assert set(pyspiel.registered_names()) == {"tic_tac_toe", "connect_four", "hex", "kuhn_poker", "leduc_poker"}
+    assert (pyspiel.PlayerId.CHANCE, pyspiel.PlayerId.TERMINAL, pyspiel.PlayerId.SIMULTANEOUS, pyspiel.PlayerId.INVALID,
+            pyspiel.PlayerId.MEAN_FIELD, pyspiel.PlayerId.DEFAULT_PLAYER_ID) == (-1, -4, -2, -3, -5, 0)   # spiel_globals.h:44-60
     outcomes = [(0, 0.25), (3, 0.5), (7, 0.25)]
     assert [pyspiel.sample_action(outcomes, z)[0] for z in (0.0, 0.2499, 0.25, 0.74, 0.75, 0.999)] == [0, 0, 3, 3, 7, 7]
     with pytest.raises(pyspiel.SpielError):

@@ -333,6 +333,11 @@ PYBIND11_MODULE(pyspiel_hip, m) {
         [](const std::string& name, const py::dict& params) { return std::make_shared<Game>(GameStringFromDict(name, params)); },
         py::arg("short_name"), py::arg("params"));
   m.def("registered_names", [] { return std::vector<std::string>{"connect_four", "hex", "kuhn_poker", "leduc_poker", "tic_tac_toe"}; });
+  m.def("registered_games", [] {  // pyspiel.cc:774: the GameType of every game that can be loaded
+    std::vector<GameType> out;
+    for (const char* name : {"connect_four", "hex", "kuhn_poker", "leduc_poker", "tic_tac_toe"}) out.push_back(Game(name).GetType());
+    return out;
+  });
   m.def("registered_concrete_names",
         [] { return std::vector<std::string>{"connect_four", "hex", "kuhn_poker", "leduc_poker", "tic_tac_toe"}; });
   m.def("game_parameters_from_string",  // pyspiel.cc:168: "kuhn_poker(players=3)" -> {"name": "kuhn_poker", "players": 3}

@@ -22,6 +22,7 @@ using hip::Action; using hip::Player; using hip::ActionsAndProbs;
 using hip::kInvalidAction; using hip::kChancePlayerId; using hip::kTerminalPlayerId; using hip::kDefaultPlayerId;
 using hip::kSimultaneousPlayerId; using hip::kInvalidPlayer; using hip::kMeanFieldPlayerId;
 using hip::Game; using hip::State; using hip::BatchedState; using hip::LoadGame; using hip::LoadGameAsTurnBased;
+using hip::RegisteredGames; using hip::RegisteredNames; using hip::RegisteredGameTypes;
 using hip::SpielFatalError; using hip::SpielException;
 using hip::TensorLayout; using hip::GameType; using hip::GameParameter; using hip::GameParameters; using hip::GameParametersFromString;
 using hip::GameParametersToString;

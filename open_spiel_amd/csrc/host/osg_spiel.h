@@ -342,6 +342,14 @@ inline std::shared_ptr<const Game> LoadGame(const std::string& short_name, const
 }
 // Entry points of the reference that lead OUTSIDE the five games of the path (game transforms, .efg files): declared
 // so that code naming them compiles; calling them is an error here, as LoadGame of any other game is.
+// spiel.h:1336-1341: what LoadGame can load here
+inline std::vector<std::string> RegisteredNames() { return {"connect_four", "hex", "kuhn_poker", "leduc_poker", "tic_tac_toe"}; }
+inline std::vector<std::string> RegisteredGames() { return RegisteredNames(); }  // spiel.h:1305 (the free function: names)
+inline std::vector<GameType> RegisteredGameTypes() {                             // spiel.h:1306
+  std::vector<GameType> out;
+  for (const std::string& name : RegisteredNames()) out.push_back(LoadGame(name)->GetType());
+  return out;
+}
 inline std::shared_ptr<const Game> LoadGameAsTurnBased(const std::string& name) {
   SpielFatalError("LoadGameAsTurnBased(" + name + "): game transforms are not on the MI355X path");
 }
@@ -564,6 +572,21 @@ class State {
     CheckPlayer(player);
     return batch_.InformationStateTensor(player);
   }
+  // the caller-buffer forms (spiel.h:713-714, 693-694: absl::Span<float> values; any type with data() / size() here)
+  template <class SpanLike, class = decltype(std::declval<SpanLike&>().data())>
+  void ObservationTensor(Player player, SpanLike values) const {
+    const std::vector<float> t = ObservationTensor(player);
+    if (values.size() != t.size()) SpielFatalError("ObservationTensor: the buffer does not have ObservationTensorSize() entries");
+    std::copy(t.begin(), t.end(), values.data());
+  }
+  template <class SpanLike, class = decltype(std::declval<SpanLike&>().data())>
+  void InformationStateTensor(Player player, SpanLike values) const {
+    const std::vector<float> t = InformationStateTensor(player);
+    if (values.size() != t.size()) SpielFatalError("InformationStateTensor: the buffer does not have InformationStateTensorSize() entries");
+    std::copy(t.begin(), t.end(), values.data());
+  }
+  void ObservationTensor(Player player, std::vector<float>* values) const { *values = ObservationTensor(player); }  // spiel.h:716-718
+  void InformationStateTensor(Player player, std::vector<float>* values) const { *values = InformationStateTensor(player); }
   std::string InformationStateString(Player player) const {  // kuhn_poker.cc:285-288, leduc_poker.cc:517-520
     CheckPlayer(player);
     // the perfect-information games: the history (tic_tac_toe.cc:229-233, connect_four.cc:287-291, hex.cc:367-371)
@@ -1321,8 +1344,11 @@ class DeviceTabularSolver {
 
  protected:
   // mccfr: 0 CFR family, 1 external sampling, 2 outcome sampling (with `epsilon`)
-  DeviceTabularSolver(const Game& game, bool alternating, bool linear, bool rm_plus, int mccfr, double epsilon = 0.6) {
+  DeviceTabularSolver(const Game& game, bool alternating, bool linear, bool rm_plus, int mccfr, double epsilon = 0.6,
+                      bool random_initial_regrets = false, int seed = 0) {
     osg_cfr_cfg cfg{};
+    cfg.random_initial_regrets = random_initial_regrets ? 1 : 0;  // the device's own counter streams (the reference: abseil)
+    cfg.seed = static_cast<uint64_t>(seed);
     cfg.alternating_updates = alternating ? 1 : 0;
     cfg.linear_averaging = linear ? 1 : 0;
     cfg.regret_matching_plus = rm_plus ? 1 : 0;
@@ -1477,8 +1503,9 @@ inline CFRInfoStateValues DeserializeInfoStateValues(const std::string& serializ
 
 class CFRSolverBase : public DeviceTabularSolver {  // cfr.h:188-304
  public:
-  CFRSolverBase(const Game& game, bool alternating_updates, bool linear_averaging, bool regret_matching_plus)
-      : DeviceTabularSolver(game, alternating_updates, linear_averaging, regret_matching_plus, 0),
+  CFRSolverBase(const Game& game, bool alternating_updates, bool linear_averaging, bool regret_matching_plus,
+                bool random_initial_regrets = false, int seed = 0)  // cfr.h:190-196
+      : DeviceTabularSolver(game, alternating_updates, linear_averaging, regret_matching_plus, 0, 0.6, random_initial_regrets, seed),
         game_string_(game.Serialize()) {}
   virtual ~CFRSolverBase() = default;
   // The reference's text checkpoint (cfr.cc:284-307): [Meta] / [Game] / [SolverType] /
@@ -1661,7 +1688,7 @@ class TabularPolicy : public Policy {  // policy.h:158-283
     for (const auto& kv : AllInfoStates(game))
       for (Action a : kv.second) policy_table_[kv.first].push_back({a, 1.0 / kv.second.size()});
   }
-  explicit TabularPolicy(algorithms::TabularPolicyTable table) : policy_table_(std::move(table)) {}
+  TabularPolicy(algorithms::TabularPolicyTable table) : policy_table_(std::move(table)) {}  // (policy.h:165: from a table)
   TabularPolicy(const Game& game, const Policy& policy) {  // policy.h:167-171: tabularise any policy
     const auto all = AllInfoStates(game);
     bool by_key = true;
@@ -1709,13 +1736,14 @@ class TabularPolicy : public Policy {  // policy.h:158-283
   algorithms::TabularPolicyTable& PolicyTable() { return policy_table_; }
   const algorithms::TabularPolicyTable& PolicyTable() const { return policy_table_; }
   int size() const { return static_cast<int>(policy_table_.size()); }
-  std::string ToString() const {  // policy.h:260-276: infostates in sorted order
+  std::string ToString() const { return ToStringSorted(); }  // (policy.cc:198-208 prints in hash-table order: any order)
+  std::string ToStringSorted() const {  // policy.cc:210-229: "key:  action=prob action=prob", infostates sorted
     std::vector<std::string> keys;
     for (const auto& kv : policy_table_) keys.push_back(kv.first);
     std::sort(keys.begin(), keys.end());
     std::string str;
     for (const std::string& k : keys) {
-      str += k + ":";
+      str += k + ": ";
       for (const auto& ap : policy_table_.at(k)) {
         std::ostringstream o;
         o << " " << ap.first << "=" << ap.second;

@@ -51,8 +51,32 @@ def test_reference_test_sources_compile_against_the_mirror():
     if not os.path.isdir("/root/reference/open_spiel"):
         pytest.skip("no /root/reference here: the binaries are built where it exists and shipped prebuilt")
     _ensure_built()
-    for b in BINARIES + SLOW_BINARIES:
+    for b in BINARIES + SLOW_BINARIES + [e[0] for e in EXAMPLES]:
         assert os.access(os.path.join(BUILT, b), os.X_OK), b
+
+
+# the reference's example programs (open_spiel/examples/*.cc), compiled unmodified as well: (binary, arguments, a line of output)
+EXAMPLES = [
+    ("reference_example_cfr_example", [], "Iteration 999 exploitability=0.0009"),          # kuhn_poker, 1000 iterations
+    ("reference_example_mcts_example", ["--num_games=2", "--max_simulations=1000", "--quiet=true"], "Overall wins: 2,0"),
+    ("reference_example_example", ["--game=connect_four", "--seed=7"], "Final return to player 0 is"),
+    # (with --show_infostate example.cc:139-141 hands an EMPTY span to InformationStateTensor: fatal in the reference too)
+    ("reference_example_example", ["--game=leduc_poker", "--seed=3", "--show_legals=true"], "Final return to player 1 is"),
+    ("reference_example_benchmark_game", ["--game=hex", "--sims=20", "--attempts=2"], "Benchmark: game: hex, num_sims: 20."),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("binary,args,expect", EXAMPLES)
+def test_reference_example_program_runs_on_the_mirror(binary, args, expect):
+    _ensure_built()
+    path = os.path.join(BUILT, binary)
+    if not os.access(path, os.X_OK):
+        pytest.fail(f"{path} missing: run __graft_entry__.build() where /root/reference exists before shipping")
+    r = subprocess.run([path] + args, capture_output=True, text=True, timeout=600)
+    print((r.stdout + r.stderr)[-1500:])
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert expect in r.stdout + r.stderr
 
 
 SLOW_BINARIES = ["reference_evaluate_bots_test"]   # 200 000 episodes through one-state batches: 142 s on an MI355X

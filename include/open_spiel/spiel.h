@@ -24,7 +24,7 @@ using hip::kSimultaneousPlayerId; using hip::kInvalidPlayer; using hip::kMeanFie
 using hip::Game; using hip::State; using hip::BatchedState; using hip::LoadGame; using hip::LoadGameAsTurnBased;
 using hip::RegisteredGames; using hip::RegisteredNames; using hip::RegisteredGameTypes;
 using hip::SpielFatalError; using hip::SpielException;
-using hip::TensorLayout; using hip::GameType; using hip::GameParameter; using hip::GameParameters; using hip::GameParametersFromString;
+using hip::TensorLayout; using hip::StateType; using hip::GameType; using hip::GameParameter; using hip::GameParameters; using hip::GameParametersFromString;
 using hip::GameParametersToString;
 using hip::SerializeGameAndState; using hip::DeserializeGameAndState;
 using hip::Policy; using hip::TabularPolicy; using hip::UniformPolicy; using hip::PreferredActionPolicy;

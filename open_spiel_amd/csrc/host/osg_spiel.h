@@ -260,6 +260,7 @@ struct GameType {
 class State;
 class BatchedState;
 enum class TensorLayout { kHWC, kCHW };  // spiel.h:231
+enum class StateType { kTerminal, kChance, kDecision, kMeanField };  // spiel_globals.h:84-92
 class Policy;
 class TabularPolicy;
 class Observer;
@@ -657,6 +658,9 @@ class State {
     return true;
   }
   double PlayerReward(Player p) const { return Rewards()[p]; }
+  StateType GetType() const {  // spiel.h:808
+    return IsTerminal() ? StateType::kTerminal : (IsChanceNode() ? StateType::kChance : StateType::kDecision);
+  }
   // State::Serialize (spiel.cc:411-430): the action history, one action per line.
   std::string Serialize() const {
     std::string out;
@@ -2113,6 +2117,30 @@ inline std::map<std::string, std::unique_ptr<State>> GetAllStates(const Game& ga
     if (terminal || (depth_limit >= 0 && depth >= depth_limit) || (seen && stop_at_duplicates)) continue;
     for (Action a : st->LegalActions()) todo.emplace_back(st->Child(a), depth + 1);
   }
+  return all;
+}
+
+// algorithms/get_all_histories.h:40-42: one State per history, in depth-first pre-order (children in action order);
+// terminals and chance nodes on request; depth_limit < 0: the whole game.  A host-side walk over one-state batches.
+inline std::vector<std::unique_ptr<State>> GetAllHistories(const Game& game, int depth_limit = -1, bool include_terminals = false,
+                                                           bool include_chance_states = false) {
+  std::vector<std::unique_ptr<State>> all;
+  std::vector<std::pair<std::unique_ptr<State>, int>> todo;
+  todo.emplace_back(game.NewInitialState(), 0);
+  while (!todo.empty()) {
+    std::unique_ptr<State> st = std::move(todo.back().first);
+    const int depth = todo.back().second;
+    todo.pop_back();
+    if (st->IsTerminal()) {
+      if (include_terminals) all.push_back(std::move(st));
+      continue;
+    }
+    if (depth_limit >= 0 && depth > depth_limit) continue;
+    const std::vector<Action> legal = st->LegalActions();
+    for (auto it = legal.rbegin(); it != legal.rend(); ++it) todo.emplace_back(st->Child(*it), depth + 1);  // (popped in action order)
+    if (!st->IsChanceNode() || include_chance_states) all.push_back(std::move(st));
+  }
+  if (all.empty()) SpielFatalError("GetSubgameHistories returned 0 histories!");
   return all;
 }
 

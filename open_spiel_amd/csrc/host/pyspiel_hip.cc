@@ -113,7 +113,6 @@ py::dict GameParametersGiven(const std::string& game_string) {
   }
   return out;
 }
-enum class StateKind { kTerminal, kChance, kDecision, kMeanField };  // StateType of spiel_globals.h:84-92
 
 enum class TttCellState { kEmpty, kNought, kCross };          // tic_tac_toe.h:38-42
 enum class LeducActionType { kFold = 0, kCall = 1, kRaise = 2 };  // leduc_poker.h:64
@@ -364,11 +363,11 @@ PYBIND11_MODULE(pyspiel_hip, m) {
           SpielFatalError("sample_action: the probabilities do not cover z");
         },
         py::arg("actions_and_probs"), py::arg("z"));
-  py::enum_<StateKind>(m, "StateType")  // pyspiel.cc:317-322 (spiel_globals.h:84-92)
-      .value("TERMINAL", StateKind::kTerminal)
-      .value("CHANCE", StateKind::kChance)
-      .value("DECISION", StateKind::kDecision)
-      .value("MEAN_FIELD", StateKind::kMeanField);
+  py::enum_<StateType>(m, "StateType")  // pyspiel.cc:317-322 (spiel_globals.h:84-92)
+      .value("TERMINAL", StateType::kTerminal)
+      .value("CHANCE", StateType::kChance)
+      .value("DECISION", StateType::kDecision)
+      .value("MEAN_FIELD", StateType::kMeanField);
 
   py::class_<State>(m, "State")
       .def("current_player", &State::CurrentPlayer)
@@ -412,9 +411,7 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("child", &State::Child, py::arg("action"))
       .def("history", &State::History)
       .def("full_history", &State::FullHistory)                     // pyspiel.cc:426
-      .def("get_type", [](const State& st) {                        // spiel.cc: State::GetType
-        return st.IsTerminal() ? StateKind::kTerminal : (st.IsChanceNode() ? StateKind::kChance : StateKind::kDecision);
-      })
+      .def("get_type", &State::GetType)                             // spiel.h:808
       .def("string_to_action", py::overload_cast<Player, const std::string&>(&State::StringToAction, py::const_), py::arg("player"),
            py::arg("string"))
       .def("string_to_action", py::overload_cast<const std::string&>(&State::StringToAction, py::const_), py::arg("string"))

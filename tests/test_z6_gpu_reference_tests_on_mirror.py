@@ -63,6 +63,11 @@ EXAMPLES = [
     # (with --show_infostate example.cc:139-141 hands an EMPTY span to InformationStateTensor: fatal in the reference too)
     ("reference_example_example", ["--game=leduc_poker", "--seed=3", "--show_legals=true"], "Final return to player 1 is"),
     ("reference_example_benchmark_game", ["--game=hex", "--sims=20", "--attempts=2"], "Benchmark: game: hex, num_sims: 20."),
+    # count_all_states.cc over GetAllHistories: the census of kuhn_poker and leduc_poker (9 457 histories, 936 infostates)
+    ("reference_example_count_all_states", [],
+     "Game: kuhn_poker, num_histories: 58, num_terminal_histories: 30, num_chance_nodes: 4, num_nonterminal_states: 12, num_terminal_states: 30"),
+    ("reference_example_count_all_states", ["--game_string=leduc_poker"], "Game: leduc_poker, num_histories: 9457, num_terminal_histories: 5520"),
+    ("reference_example_shared_library_example", ["kuhn_poker(players=3)"], "Final return to player 2 is"),
 ]
 
 

@@ -517,7 +517,7 @@ def test_policy_hierarchy_and_judges(pyspiel):
     tab.set_prob(s.information_state_string(), 1, 1.0)
     tab.set_prob(s.information_state_string(), 0, 0.0)
     assert tab.action_probabilities(s) == {0: 0.0, 1: 1.0}
-    assert "0b: 0=0 1=1" in str(tab)
+    assert "0b:  0=0 1=1" in str(tab)          # policy.cc:210-229: "key: " then " action=prob" per action
     # a Python Policy (python/policy.py's interface: action_probabilities(state, player_id)) judged on the device
     class AlwaysBet(pyspiel.Policy):
         def __init__(self):

@@ -1287,6 +1287,13 @@ class DeviceTabularSolver {
     }
     return out;
   }
+  // infostate -> the player who acts there (the device tree's own record)
+  std::unordered_map<std::string, Player> InfoStatePlayers() const {
+    std::unordered_map<std::string, Player> out;
+    const int I = static_cast<int>(sizes_[4]);
+    for (int i = 0; i < I; ++i) out.emplace(Key(i), static_cast<Player>(osg_cfr_infostate_player(s_, i)));
+    return out;
+  }
   TabularPolicyTable TabularAveragePolicy() const { return PolicyTableOf(true); }  // cfr.h:205-211
   TabularPolicyTable TabularCurrentPolicy() const { return PolicyTableOf(false); }
   // cfr.h:198-211.  (The reference's policy objects are live views of the solver's table; these are snapshots
@@ -1685,6 +1692,33 @@ inline std::unordered_map<std::string, std::vector<Action>> AllInfoStates(const 
   return out;
 }
 
+namespace algorithms {
+// algorithms/get_legal_actions_map.h:32-33: infostate -> legal actions, for one player's infostates or (kInvalidPlayer)
+// for everybody's; a depth limit walks the game on the host, without one the device's flattened tree has the answer
+inline std::unordered_map<std::string, std::vector<Action>> GetLegalActionsMap(const Game& game, int depth_limit, Player player) {
+  std::unordered_map<std::string, std::vector<Action>> out;
+  if (depth_limit < 0) {
+    CFRSolverBase solver(game, false, false, false);
+    const auto who = solver.InfoStatePlayers();
+    for (const auto& kv : solver.InfoStateValuesTable())
+      if (player == kInvalidPlayer || who.at(kv.first) == player) out[kv.first] = kv.second.legal_actions;
+    return out;
+  }
+  std::vector<std::pair<std::unique_ptr<State>, int>> todo;
+  todo.emplace_back(game.NewInitialState(), 0);
+  while (!todo.empty()) {
+    std::unique_ptr<State> st = std::move(todo.back().first);
+    const int depth = todo.back().second;
+    todo.pop_back();
+    if (st->IsTerminal() || depth > depth_limit) continue;
+    if (!st->IsChanceNode() && (player == kInvalidPlayer || st->CurrentPlayer() == player))
+      out[st->InformationStateString()] = st->LegalActions();
+    for (Action a : st->LegalActions()) todo.emplace_back(st->Child(a), depth + 1);
+  }
+  return out;
+}
+}  // namespace algorithms
+
 class TabularPolicy : public Policy {  // policy.h:158-283
  public:
   TabularPolicy() = default;
@@ -2061,6 +2095,7 @@ inline TabularPolicy GetPrefActionPolicy(const Game& game, const std::vector<Act
 // kuhn_poker.h:40-47, kuhn_poker.cc:439-474
 namespace kuhn_poker {
 enum ActionType { kPass = 0, kBet = 1 };
+inline constexpr int kNumInfoStatesP0 = 6, kNumInfoStatesP1 = 6;  // kuhn_poker.h:42-43 (two players)
 inline TabularPolicy GetAlwaysPassPolicy(const Game& game) { return GetPrefActionPolicy(game, {ActionType::kPass}); }
 inline TabularPolicy GetAlwaysBetPolicy(const Game& game) { return GetPrefActionPolicy(game, {ActionType::kBet}); }
 // the alpha-family of Nash equilibria of 2-player Kuhn poker, alpha in [0, 1/3]; its value for player 0 is -1/18
@@ -2088,6 +2123,7 @@ inline TabularPolicy GetOptimalPolicy(double alpha) {
 // leduc_poker.h:64, leduc_poker.cc:872-888
 namespace leduc_poker {
 enum ActionType { kFold = 0, kCall = 1, kRaise = 2 };
+inline constexpr int kNumInfoStates = 936;  // leduc_poker.h:72 (two players)
 inline TabularPolicy GetAlwaysFoldPolicy(const Game& game) { return GetPrefActionPolicy(game, {ActionType::kFold, ActionType::kCall}); }
 inline TabularPolicy GetAlwaysCallPolicy(const Game& game) { return GetPrefActionPolicy(game, {ActionType::kCall}); }
 inline TabularPolicy GetAlwaysRaisePolicy(const Game& game) { return GetPrefActionPolicy(game, {ActionType::kRaise, ActionType::kCall}); }

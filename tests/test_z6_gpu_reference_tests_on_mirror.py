@@ -37,7 +37,8 @@ BUILT = os.path.join(ROOT, "tests", "_refbuilt")
 BINARIES = ["reference_cfr_br_test", "reference_mcts_test_on_mirror", "reference_es_mccfr_test_on_mirror",
             "reference_os_mccfr_test_on_mirror", "reference_cfr_test_on_mirror", "reference_tabular_exploitability_test",
             "reference_best_response_test_on_mirror", "reference_hex_test", "reference_kuhn_poker_test",
-            "reference_leduc_poker_test_on_mirror", "reference_basic_tests_boards_on_mirror", "reference_get_all_states_test"]
+            "reference_leduc_poker_test_on_mirror", "reference_basic_tests_boards_on_mirror", "reference_get_all_states_test",
+            "reference_get_legal_actions_map_test_on_mirror"]
 
 
 def _ensure_built():

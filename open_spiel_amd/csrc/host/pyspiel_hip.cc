@@ -114,6 +114,15 @@ py::dict GameParametersGiven(const std::string& game_string) {
   return out;
 }
 
+struct GameInfoRecord {  // spiel.h:178-215 GameInfo: what a Python game module describes itself with
+  int num_distinct_actions, max_chance_outcomes, num_players;
+  double min_utility, max_utility;
+  std::optional<double> utility_sum;
+  int max_game_length;
+  GameInfoRecord(int a, int c, int p, double lo, double hi, std::optional<double> sum, int len)
+      : num_distinct_actions(a), max_chance_outcomes(c), num_players(p), min_utility(lo), max_utility(hi), utility_sum(sum),
+        max_game_length(len) {}
+};
 enum class TttCellState { kEmpty, kNought, kCross };          // tic_tac_toe.h:38-42
 enum class LeducActionType { kFold = 0, kCall = 1, kRaise = 2 };  // leduc_poker.h:64
 
@@ -307,6 +316,50 @@ PYBIND11_MODULE(pyspiel_hip, m) {
   py::enum_<GameType::RewardModel>(game_type, "RewardModel")
       .value("REWARDS", GameType::RewardModel::kRewards)
       .value("TERMINAL", GameType::RewardModel::kTerminal);
+  // the constructor Python game modules call at import (open_spiel/python/games/*.py build a GameType and a GameInfo and
+  // hand them to register_game): constructible here so that those modules import; the engine does not serve Python games
+  game_type.def(py::init([](const std::string& short_name, const std::string& long_name, GameType::Dynamics dynamics,
+                            GameType::ChanceMode chance_mode, GameType::Information information, GameType::Utility utility,
+                            GameType::RewardModel reward_model, int max_num_players, int min_num_players,
+                            bool provides_information_state_string, bool provides_information_state_tensor,
+                            bool provides_observation_string, bool provides_observation_tensor, const py::dict&,
+                            bool default_loadable, bool provides_factored_observation_string, bool) {
+                  GameType t;
+                  t.short_name = short_name; t.long_name = long_name; t.dynamics = dynamics; t.chance_mode = chance_mode;
+                  t.information = information; t.utility = utility; t.reward_model = reward_model;
+                  t.max_num_players = max_num_players; t.min_num_players = min_num_players;
+                  t.provides_information_state_string = provides_information_state_string;
+                  t.provides_information_state_tensor = provides_information_state_tensor;
+                  t.provides_observation_string = provides_observation_string;
+                  t.provides_observation_tensor = provides_observation_tensor;
+                  t.default_loadable = default_loadable;
+                  t.provides_factored_observation_string = provides_factored_observation_string;
+                  return t;
+                }),
+                py::arg("short_name"), py::arg("long_name"), py::arg("dynamics"), py::arg("chance_mode"), py::arg("information"),
+                py::arg("utility"), py::arg("reward_model"), py::arg("max_num_players"), py::arg("min_num_players"),
+                py::arg("provides_information_state_string"), py::arg("provides_information_state_tensor"),
+                py::arg("provides_observation_string"), py::arg("provides_observation_tensor"),
+                py::arg("parameter_specification") = py::dict(), py::arg("default_loadable") = true,
+                py::arg("provides_factored_observation_string") = false, py::arg("action_structs_only") = false);
+  py::class_<GameInfoRecord>(m, "GameInfo")  // pyspiel.cc:305-320
+      .def(py::init<int, int, int, double, double, std::optional<double>, int>(), py::arg("num_distinct_actions"),
+           py::arg("max_chance_outcomes"), py::arg("num_players"), py::arg("min_utility"), py::arg("max_utility"),
+           py::arg("utility_sum") = std::nullopt, py::arg("max_game_length"))
+      .def_readonly("num_distinct_actions", &GameInfoRecord::num_distinct_actions)
+      .def_readonly("max_chance_outcomes", &GameInfoRecord::max_chance_outcomes)
+      .def_readonly("num_players", &GameInfoRecord::num_players)
+      .def_readonly("min_utility", &GameInfoRecord::min_utility)
+      .def_readonly("max_utility", &GameInfoRecord::max_utility)
+      .def_readonly("utility_sum", &GameInfoRecord::utility_sum)
+      .def_readonly("max_game_length", &GameInfoRecord::max_game_length);
+  m.def("register_game",  // pyspiel.cc:798: accepted and remembered (registered_python_games()); never loadable here
+        [](const GameType& type, py::object creator) {
+          static py::dict* registry = new py::dict();
+          (*registry)[py::str(type.short_name)] = creator;
+          py::module_::import("sys").attr("modules")[py::str("open_spiel_amd.pyspiel_hip")].attr("_python_games") = *registry;
+        },
+        py::arg("game_type"), py::arg("creator"));
   game_type.def_readonly("short_name", &GameType::short_name)
       .def_readonly("long_name", &GameType::long_name)
       .def_readonly("dynamics", &GameType::dynamics)

@@ -745,3 +745,47 @@ def test_state_get_type(pyspiel):
     assert s.get_type() == pyspiel.StateType.DECISION
     s.apply_action(0); s.apply_action(0)
     assert s.get_type() == pyspiel.StateType.TERMINAL
+
+
+def test_reference_python_modules_import_over_the_pyspiel_alias(tmp_path):
+    """Where the reference tree exists (the build container): its Python algorithm files for this path, and the Python-game
+    modules they pull in at import (which build pyspiel.GameType / GameInfo objects and call register_game), import with
+    `pyspiel` resolving to this repository's alias package — i.e. every module-level pyspiel name they touch exists.
+    (absl-py and ml_collections are not installed here: a stand-in for absl and a namespace for the games package.)"""
+    import os
+    import subprocess
+    import sys
+    ref = os.environ.get("OSG_REFERENCE_ROOT", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "open_spiel", "python")):
+        pytest.skip("no reference tree here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    absl = tmp_path / "absl"
+    (absl / "testing").mkdir(parents=True)
+    (absl / "__init__.py").write_text("")
+    (absl / "logging.py").write_text("import logging as _l\ninfo = _l.info; warning = _l.warning; error = _l.error; debug = _l.debug\n")
+    (absl / "flags.py").write_text("class _F:\n    pass\nFLAGS = _F()\ndef DEFINE_string(*a, **k): pass\n"
+                                   "DEFINE_integer = DEFINE_float = DEFINE_bool = DEFINE_boolean = DEFINE_enum = DEFINE_list = DEFINE_string\n")
+    (absl / "app.py").write_text("def run(main): main([])\n")
+    (absl / "testing" / "__init__.py").write_text("")
+    code = f"""
+import sys, types, importlib
+sys.path[:0] = [{root!r}, {ref!r}, {str(tmp_path)!r}]
+import pyspiel
+assert pyspiel.__name__ == "pyspiel" and "open_spiel_amd" in pyspiel.load_game.__module__
+import open_spiel.python
+games = types.ModuleType("open_spiel.python.games")          # (its __init__ imports chat_game -> ml_collections)
+games.__path__ = [{os.path.join(ref, "open_spiel", "python", "games")!r}]
+sys.modules["open_spiel.python.games"] = games
+for name in ["games.kuhn_poker", "games.liars_poker", "games.iterated_prisoners_dilemma", "policy", "rl_environment",
+             "vector_env", "observation", "bots.uniform_random", "algorithms.cfr", "algorithms.cfr_br",
+             "algorithms.exploitability", "algorithms.best_response", "algorithms.get_all_states", "algorithms.mcts",
+             "algorithms.external_sampling_mccfr", "algorithms.outcome_sampling_mccfr", "algorithms.expected_game_score",
+             "algorithms.evaluate_bots", "algorithms.generate_playthrough", "algorithms.fictitious_play",
+             "algorithms.policy_utils"]:
+    importlib.import_module("open_spiel.python." + name)
+registered = sys.modules["open_spiel_amd.pyspiel_hip"]._python_games
+assert "python_kuhn_poker" in registered
+print("IMPORTED")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0 and "IMPORTED" in r.stdout, (r.stdout + r.stderr)[-3000:]

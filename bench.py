@@ -49,34 +49,62 @@ ALGO_BYTES_PER_STEP = 35          # 16 R + 16 W state, 1 actio
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+C4_DEPTH_MOD = 36                 # state i = hash(i) mod 36 random legal moves from the start
+HEX_DEPTH_MOD = 40                # item 4: root i = hash(i) mod 40 random legal moves
+
+
 def synth_batch(osa, torch, ctx, n, seed, index_offset):
-    """Deterministic synthetic positions + one legal action each (torch is plumbing here)."""
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(seed + index_offset)
-    idx = torch.arange(index_offset, index_offset + n, device="cuda", dtype=torch.int64)
-    # multiplicative hash of the global index -> depth in [0, 36)
-    h = idx * 2654435761 + seed
-    h = h ^ (h >> 15)
-    depth = ((h >> 3) % 36).to(torch.int32)
+    """SURVEY.md 8(d) item 2 on the device's counter stream (osg_synth_batch): state i = the initial position
+    advanced by depth_i = draw(seed, index_offset + i) mod 36 uniformly random legal moves, re-drawn if the game
+    ends earlier (never terminal), plus one uniformly random legal action.  The CPU reference regenerates the
+    same batch from (seed, index range) — parity_check() below does, for the launches that were timed."""
     batch = osa.StateBatch(ctx, "connect_four", n)
-
-    def draw(b):
-        m = b.legal_actions_mask().to(torch.float32)
-        m[m.sum(1) == 0, 0] = 1.0  # terminal rows: dummy, masked out by the caller
-        return torch.multinomial(m, 1, generator=gen).squeeze(1).to(torch.int32)
-
-    for t in range(36):
-        a = draw(batch)
-        a = torch.where(depth > t, a, torch.full_like(a, -1))
-        trial = batch.clone()
-        trial.apply_actions(a)
-        # do not walk into a terminal position: keep the predecessor instead
-        a = torch.where(trial.is_terminal(), torch.full_like(a, -1), a)
-        batch.apply_actions(a)
-        del trial
-    assert not bool(batch.is_terminal().any())
-    actions = draw(batch).to(torch.uint8)
+    actions, _depth = batch.synth(seed, C4_DEPTH_MOD, index_offset=index_offset)
     return batch, actions
+
+
+def parity_check(torch, src, dst, actions, mask, status, seed, index_offset, states):
+    """The timed launches against the CPU reference (the checker only): regenerate states
+    [index_offset, index_offset + states) of the batch on the host threads with the GENUINE reference build
+    (oracle/_ref, else the restatement) and compare, for every one of them, the source state, the action, and what
+    the LAST timed launch left in dst / mask / status — successor state (as its ObservationTensor), successor
+    legal mask, terminal flag, player to move, outcome.  Returns the record for the bench line; raises on any
+    difference."""
+    import numpy as np
+    impl, kind = cpu_checker()
+    threads = host_threads()
+    t0 = time.perf_counter()
+    rec = impl.Game("connect_four").synth_batch(seed, states, C4_DEPTH_MOD, first=index_offset, threads=threads)
+    cpu_s = time.perf_counter() - t0
+    idx = torch.arange(states, device="cuda")
+
+    def same(got, want, what):
+        if not np.array_equal(got, want):
+            bad = np.nonzero(np.asarray(got != want).reshape(states, -1).any(1))[0]
+            raise AssertionError(f"parity_check: {what} differs from the {kind} at {bad.size} of {states} states "
+                                 f"(first: {bad[:5].tolist()})")
+
+    same(actions[:states].cpu().numpy().astype(np.int16), rec["action"], "action")
+    for batch, sfx in ((src, "0"), (dst, "1")):
+        part = batch if states == batch.n else batch.gather(idx)
+        same(part.observation_tensor(0).to(torch.uint8).cpu().numpy(), rec["obs" + sfx], f"state{sfx}")
+        same(part.legal_actions_mask_bits().cpu().numpy().view(np.uint32), rec["mask" + sfx], f"legal mask{sfx}")
+        cur, term, rets = [t.cpu().numpy() for t in part.status()]
+        same(cur, rec["cur" + sfx], f"current player{sfx}")
+        same(term, rec["term" + sfx], f"terminal{sfx}")
+        if sfx == "1":
+            same(rets, rec["rets1"], "returns")
+    st = status[:states].cpu().numpy()
+    term1 = rec["term1"] != 0
+    same((st & 0x80) != 0, term1, "status.terminal")
+    same((st & 0x40) != 0, np.zeros(states, bool), "status.illegal")
+    same(((st & 15).astype(np.int64) - 1)[~term1], rec["cur1"][~term1].astype(np.int64), "status.player")
+    outcome = np.where(rec["rets1"][:, 0] > 0, 0, np.where(rec["rets1"][:, 0] < 0, 1, 2))
+    same((st & 7)[term1], outcome[term1], "status.outcome")
+    same(mask.reshape(-1)[:states].cpu().numpy(), (rec["mask1"][:, 0] & 0xFF).astype(np.uint8), "successor mask byte")
+    return {"states": int(states), "against": kind, "cpu_seconds": cpu_s, "cpu_threads": threads,
+            "what": "source state, action, successor state (ObservationTensor), successor legal mask, terminal flag, "
+                    "player to move, outcome and Returns() of the last timed launch, every state compared"}
 
 
 def host_threads():
@@ -146,27 +174,35 @@ def cpu_baseline():
     return rec
 
 
-def hex_roots(osa, torch, ctx, n, index_offset, seed=SEED, depth_mod=40):
-    """hex(9) search roots: root i = the empty board advanced by
-    hash(i) mod 40 uniformly random legal moves, never terminal."""
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(seed + 7919 * (index_offset + 1))
-    idx = torch.arange(index_offset, index_offset + n, device="cuda", dtype=torch.int64)
-    h = idx * 2654435761 + seed
-    h = h ^ (h >> 15)
-    depth = ((h >> 3) % depth_mod).to(torch.int32)
+def hex_roots(osa, torch, ctx, n, index_offset, seed=SEED, depth_mod=HEX_DEPTH_MOD):
+    """hex(9) search roots on the counter stream: root i = the empty board advanced by
+    draw(seed, index_offset + i) mod 40 uniformly random legal moves, never terminal (osg_synth_batch)."""
     b = osa.StateBatch(ctx, "hex(board_size=9)", n)
-    for t in range(depth_mod):
-        m = b.legal_actions_mask().to(torch.float32)
-        m[m.sum(1) == 0, 0] = 1.0
-        a = torch.multinomial(m, 1, generator=gen).squeeze(1).to(torch.int32)
-        a = torch.where(depth > t, a, torch.full_like(a, -1))
-        trial = b.clone()
-        trial.apply_actions(a)
-        a = torch.where(trial.is_terminal(), torch.full_like(a, -1), a)
-        b.apply_actions(a)
-        del trial
+    b.synth(seed, depth_mod, index_offset=index_offset)
     return b
+
+
+def mcts_parity_check(res, first, count, sims):
+    """The timed search against the oracle's replay-mode MCTSBot (restatement; the checker only): the first `count`
+    roots of this rank's shard, all `sims` simulations — best action, visit vector, reward vector."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    oracle_py.build()
+    threads = host_threads()
+    t0 = time.perf_counter()
+    want = oracle_py.Game("hex(board_size=9)").synth_mcts_replay(SEED, count, HEX_DEPTH_MOD, 2.0, sims, 1, SEED, 2,
+                                                                 first=first, threads=threads)
+    cpu_s = time.perf_counter() - t0
+    for key in ("best_action", "child_visits", "child_reward"):
+        got = res[key][:count].cpu().numpy()
+        if not np.array_equal(got, want[key]):
+            bad = np.nonzero((got != want[key]).reshape(count, -1).any(1))[0]
+            raise AssertionError(f"mcts_parity_check: {key} differs from the oracle replay at {bad.size} of {count} roots "
+                                 f"(first: {bad[:5].tolist()})")
+    return {"roots": int(count), "simulations_each": int(sims), "against": "port (replay-mode MCTSBot of the restatement)",
+            "cpu_seconds": cpu_s, "cpu_threads": threads,
+            "what": "best action, child visit counts and child total rewards of the timed search, every checked root"}
 
 
 def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barrier=lambda: None,
@@ -194,10 +230,10 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
     first, count = osd.shard_range(total_roots, rank, world)
     roots = hex_roots(osa, torch, ctx, count, first)
     # warm-up with the same geometry: sizes the context's node pool and log table once
-    roots.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, seed=1, index_offset=first)
+    roots.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, seed=1, index_offset=first, layout=2)
     fence()
     t0 = time.perf_counter()
-    res = roots.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, seed=SEED, index_offset=first)
+    res = roots.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, seed=SEED, index_offset=first, layout=2)
     fence()
     dt_local = time.perf_counter() - t0
     done_local = float(res["root_stats"][:, 3].sum().item())
@@ -207,6 +243,13 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
                    "scaling": "strong",
                    "config": {"workload": "hex(board_size=9) MCTSBot(RandomRolloutEvaluator(1), uct_c=2, 1024 sims) "
                                           f"x 2^16 roots, {count} roots on rank 0, wave-per-root layout"}}
+    if rank == 0 and with_cpu:
+        try:
+            out["mcts"]["parity"] = mcts_parity_check(res, first, min(count, 1024), sims)
+            out["mcts"]["parity_checked_roots"] = out["mcts"]["parity"]["roots"]
+        except AssertionError as e:
+            out["mcts"]["parity"] = {"error": str(e)}
+            out["mcts"]["parity_checked_roots"] = 0
     del roots, res
     if world > 1:
         # strong scaling against THIS run's one-GPU search of all 2^16 roots (rank 0 alone, the others wait)
@@ -784,6 +827,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the MCTS / CFR / MCCFR workloads")
     ap.add_argument("--no-legs", action="store_true", help="skip the DRAM-true and persistent legs")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the in-run rocprofv3 counter passes")
+    ap.add_argument("--parity-states", type=int, default=-1,
+                    help="states of rank 0's timed batch checked against the CPU reference after the timed region "
+                         "(-1: all of them, 0: none)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -877,8 +923,13 @@ def main():
     per_rank_elapsed = gather_floats(elapsed_local)
     per_rank_kernel_us = gather_floats(avg_kernel_s * 1e6)
     elapsed = max(per_rank_elapsed)
-    # sanity of the timed result against the oracle-checked status of the first states
     assert int((status & 0x40).sum().item()) == 0, "synthetic actions must all be legal"
+    # parity of the TIMED launches: every state of rank 0's shard (or --parity-states of them) regenerated by the CPU
+    # reference and compared with what the last timed launch wrote (the checker never runs inside the timed region)
+    parity = None
+    if rank == 0 and args.parity_states != 0:
+        want_states = n if args.parity_states < 0 else min(n, args.parity_states)
+        parity = parity_check(torch, src, dst, actions, mask, status, SEED, rank * n, want_states)
 
     legs = None
     if not args.no_legs and rank == 0:
@@ -943,6 +994,8 @@ def main():
                        "env_steps_per_step": n * world * LAUNCHES_PER_STEP,
                        "parallelism": f"{world} independent shard(s), no collective"},
             "roofline": roofline,
+            "parity_checked_states": parity["states"] if parity else 0,
+            "parity": parity,
         }
         if world > 1:
             line["per_rank"] = {"env_steps_per_s": [n * launches / t for t in per_rank_elapsed],

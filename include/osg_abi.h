@@ -186,6 +186,18 @@ int osg_copy_bytes(osg_ctx* ctx, void* d_dst, const void* d_src, int64_t bytes);
 int osg_random_steps(osg_batch* b, uint64_t seed, int64_t index_offset, int steps,
                      unsigned long long* d_counters);
 
+/* SURVEY.md 8(d) synthetic benchmark inputs on the counter stream (seed, index_offset + i): state i = the
+ * initial state advanced by depth_i = draw mod depth_mod uniformly random legal moves (chance outcomes by
+ * their distribution), the trajectory re-drawn from the same stream if it ends earlier, so every state is
+ * non-terminal; d_actions [n] u8 (may be NULL) = one more uniformly random legal action of that state,
+ * d_depth [n] i32 (may be NULL) = depth_i.  The batch a benchmark times can therefore be regenerated by the
+ * CPU oracle state for state (oracle/spiel_oracle_capi.cpp osgo_synth_batch restates the loop; the rules it
+ * runs are the reference's: spiel.cc:441-451, connect_four.cc:130-156).  depth_mod in [1, MaxGameLength()];
+ * a depth no trajectory survives (e.g. >= the shortest game) degrades to the initial state after 2^14 attempts.
+ * No reference counterpart: the reference's benchmarks build their states one by one on the host. */
+int osg_synth_batch(osg_batch* b, uint64_t seed, int64_t index_offset, int depth_mod, uint8_t* d_actions,
+                    int32_t* d_depth);
+
 /* One reinforcement-learning environment step for every state (python/rl_environment.py:379-418
  * Environment.step + get_time_step; replaces the Python loop of python/vector_env.py:51-54).
  * Device pointers only.  d_should_reset [n] u8 is in/out: an environment flagged 1 starts a new

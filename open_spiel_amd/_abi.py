@@ -106,6 +106,7 @@ SIGNATURES = {
     "osg_copy_bytes": (INT, [VP, VP, VP, I64]),
     "osg_env_step": (INT, [VP, VP, VP, U64, I64, I64, VP, VP, VP, VP]),
     "osg_random_steps": (INT, [VP, U64, I64, INT, VP]),
+    "osg_synth_batch": (INT, [VP, U64, I64, INT, VP, VP]),
     "osg_rollout": (INT, [VP, U64, I64, INT, VP, VP, INT]),
     "osg_mcts_search": (INT, [VP, C.POINTER(MctsCfg), VP, VP, VP, VP, VP, INT]),
     "osg_mcts_tree_create": (INT, [VP, C.POINTER(MctsCfg), INT, C.POINTER(VP)]),

@@ -783,6 +783,48 @@ __global__ void __launch_bounds__(64) k_fold_counters(unsigned long long* partia
   }
 }
 
+// SURVEY.md 8(d) synthetic inputs on the counter stream, so that the CPU oracle regenerates the very batch a
+// benchmark times (oracle/spiel_oracle_capi.cpp osgo_synth_batch restates this loop call for call):
+//   rng   = Rng(seed, global index, kSynthSub)
+//   depth = rng.below(depth_mod)                                       "d_i = hash(i) mod 36"
+//   play `depth` moves from the initial state, chance outcomes by their distribution, player actions
+//   uniformly over LegalActions(); a trajectory that ends before `depth` moves is thrown away and
+//   re-drawn from the SAME stream ("re-drawn if terminal before d_i"), up to kSynthMaxAttempts times
+//   (then the state is the initial state and depth 0: never reached by the configurations served);
+//   action = one more draw of the same kind at the accepted, non-terminal state.
+// One flat loop per lane, "step, or judge the finished attempt", so lanes on different attempts run the same code.
+constexpr uint64_t kSynthSub = 0x53594E5448ULL;  // "SYNTH"
+constexpr int kSynthMaxAttempts = 1 << 14;
+template <class G>
+__global__ void __launch_bounds__(kBlock)
+k_synth(typename G::Params p, typename G::word_t* base, int64_t n, uint64_t seed, int64_t index_offset, int depth_mod,
+        uint8_t* actions, int32_t* depth_out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  Rng rng(seed, static_cast<uint64_t>(index_offset + i), kSynthSub);
+  int depth = static_cast<int>(rng.below(static_cast<uint32_t>(depth_mod)));
+  typename G::State s = G::initial(p);
+  int t = 0, attempt = 0;
+  for (;;) {
+    const bool term = G::terminal(p, s);
+    if (t == depth || term) {
+      if (!term) break;                        // accepted
+      if (++attempt >= kSynthMaxAttempts) { s = G::initial(p); depth = 0; break; }
+      s = G::initial(p);                       // re-draw the whole trajectory from the same stream
+      t = 0;
+      continue;
+    }
+    const Mask m = G::legal(p, s);
+    G::apply(p, s, sample_action<G>(p, s, m, G::current_player(p, s), rng));
+    ++t;
+  }
+  G::store(p, base, n, i, s);
+  const Mask m = G::legal(p, s);
+  const int a = sample_action<G>(p, s, m, G::current_player(p, s), rng);
+  if (actions) actions[i] = static_cast<uint8_t>(a);
+  if (depth_out) depth_out[i] = depth;
+}
+
 // One fused reinforcement-learning environment step for every state of the batch
 // (python/rl_environment.py:379-418 Environment.step + :257-318 get_time_step, and
 // python/vector_env.py:51-54 which loops over environments in Python):
@@ -1424,6 +1466,20 @@ int osg_random_steps(osg_batch* b, uint64_t seed, int64_t index_offset, int step
                                             static_cast<typename G::word_t*>(b->d_words), b->n, seed, index_offset,
                                             steps, partials));
   k_fold_counters<<<dim3(1), dim3(64), 0, ctx->stream>>>(partials, d_counters);
+  OSG_HIP(hipGetLastError());
+  return OSG_OK;
+}
+
+int osg_synth_batch(osg_batch* b, uint64_t seed, int64_t index_offset, int depth_mod, uint8_t* d_actions,
+                    int32_t* d_depth) {
+  if (!b) return set_error(OSG_ERR_INVALID, "osg_synth_batch: null batch");
+  if (depth_mod < 1 || depth_mod > b->spec.desc.max_game_length)
+    return set_error(OSG_ERR_INVALID, "osg_synth_batch: depth_mod must lie in [1, MaxGameLength()]");
+  if (int rc = refuse_endless_playouts(b->spec, "osg_synth_batch")) return rc;
+  osg_ctx* ctx = b->ctx;
+  OSG_DISPATCH(b->spec, k_synth<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
+                                     static_cast<typename G::word_t*>(b->d_words), b->n, seed, index_offset, depth_mod,
+                                     d_actions, d_depth));
   OSG_HIP(hipGetLastError());
   return OSG_OK;
 }

@@ -314,15 +314,15 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
               if (v > best) {
                 best = v; chosen = first + static_cast<uint32_t>(k0 + j);
                 chosen_meta = cm[j]; chosen_cnt = cc[j]; chosen_first = cf[j];
+                have_chosen_meta = true;  // only a child that won the comparison carries its header (NaN values: none does)
               }
             }
           }
-          have_chosen_meta = true;
         }
         G::apply(p, s, static_cast<int>(m_action(have_chosen_meta ? chosen_meta : META(chosen))));
         node = chosen;
         carried = have_chosen_meta;
-        n_cnt = chosen_cnt; n_meta = chosen_meta; n_first = chosen_first;
+        if (have_chosen_meta) { n_cnt = chosen_cnt; n_meta = chosen_meta; n_first = chosen_first; }
       }
       // ---- evaluate (mcts.cc:372-381) ----
       if (term) {
@@ -633,39 +633,60 @@ int osg_mcts_tree_create(const osg_batch* roots, const osg_mcts_cfg* cfg_in, int
     gc_nodes = std::max(2, cfg_in->max_nodes);
     cap = std::min<int64_t>(never, gc_nodes + 32 * per_sim);
   }
+  // every failure path below goes through here: what has been allocated so far goes with the handle
+  auto fail = [&](int code) {
+    if (t->roots) osg_batch_destroy(t->roots);
+    if (t->d_mem) (void)hipFree(t->d_mem);
+    if (t->d_stash) (void)hipFree(t->d_stash);
+    if (t->d_logs) (void)hipFree(t->d_logs);
+    delete t;
+    return code;
+  };
   size_t free_b = 0, total_b = 0;
   hipError_t e = hipMemGetInfo(&free_b, &total_b);
-  if (e != hipSuccess) { delete t; return set_error(OSG_ERR_HIP, hipGetErrorString(e)); }
-  if (pool_bytes(cap, t->n) > free_b * 6 / 10) {
-    if (gc_nodes > 0) { delete t; return set_error(OSG_ERR_NOMEM, "osg_mcts_tree_create: max_nodes slots per root do not fit the free HBM"); }
-    cap = static_cast<int64_t>((free_b * 6 / 10 - static_cast<size_t>(t->n) * 32) / (static_cast<size_t>(t->n) * 36));
-    if (cap < 2 + 2 * per_sim) { delete t; return set_error(OSG_ERR_NOMEM, "osg_mcts_tree_create: too many roots for the free HBM"); }
+  if (e != hipSuccess) return fail(set_error(OSG_ERR_HIP, hipGetErrorString(e)));
+  // 60 % of the free HBM for the trees AND the prior stash (flag 8: one row of A priors per unexpanded leaf,
+  // at most max_simulations + 1 per root); the stash has a fixed size, the node pool takes what is left
+  size_t budget = free_b * 6 / 10;
+  size_t stash_bytes = 0;
+  if (flags & 8) {
+    t->stash_slots = cfg_in->max_simulations + 1;
+    stash_bytes = sizeof(double) * static_cast<size_t>(t->n) * t->stash_slots * t->A;
+    if (stash_bytes > budget / 2)
+      return fail(set_error(OSG_ERR_NOMEM, "osg_mcts_tree_create: the prior stash (roots x (max_simulations + 1) x actions fp64) "
+                                           "does not fit the free HBM; search fewer roots per tree or fewer simulations"));
+    budget -= stash_bytes;
+  }
+  if (pool_bytes(cap, t->n) > budget) {
+    if (gc_nodes > 0) return fail(set_error(OSG_ERR_NOMEM, "osg_mcts_tree_create: max_nodes slots per root do not fit the free HBM"));
+    cap = static_cast<int64_t>((budget - static_cast<size_t>(t->n) * 32) / (static_cast<size_t>(t->n) * 36));
+    if (cap < 2 + 2 * per_sim) return fail(set_error(OSG_ERR_NOMEM, "osg_mcts_tree_create: too many roots for the free HBM"));
     gc_nodes = cap - per_sim;
   }
   t->cap = static_cast<int>(cap);
   t->gc_nodes = static_cast<int>(gc_nodes);
   t->bytes = pool_bytes(cap, t->n);
   e = hipMalloc(reinterpret_cast<void**>(&t->d_mem), t->bytes);
-  if (e != hipSuccess) { delete t; return set_error(OSG_ERR_NOMEM, std::string("MCTS trees: ") + hipGetErrorString(e)); }
+  if (e != hipSuccess) { t->d_mem = nullptr; return fail(set_error(OSG_ERR_NOMEM, std::string("MCTS trees: ") + hipGetErrorString(e))); }
   if (flags & 8) {
-    t->stash_slots = cfg_in->max_simulations + 1;
-    e = hipMalloc(reinterpret_cast<void**>(&t->d_stash), sizeof(double) * static_cast<size_t>(t->n) * t->stash_slots * t->A);
-    if (e != hipSuccess) { (void)hipFree(t->d_mem); delete t; return set_error(OSG_ERR_NOMEM, std::string("MCTS prior stash: ") + hipGetErrorString(e)); }
+    e = hipMalloc(reinterpret_cast<void**>(&t->d_stash), stash_bytes);
+    if (e != hipSuccess) { t->d_stash = nullptr; return fail(set_error(OSG_ERR_NOMEM, std::string("MCTS prior stash: ") + hipGetErrorString(e))); }
   }
   int rc = osg_batch_create(ctx, d.canonical, roots->n, &t->roots);
   if (rc == OSG_OK) rc = osg_batch_copy(t->roots, roots);
-  if (rc) { (void)hipFree(t->d_mem); if (t->roots) osg_batch_destroy(t->roots); delete t; return rc; }
+  if (rc) return fail(rc);
   // log(parent explore_count) from the host libm, like osg_mcts_search
   t->logs_n = cfg_in->max_simulations + 2;
   std::vector<double> logs(t->logs_n);
   logs[0] = 0.0;
   for (int i = 1; i < t->logs_n; ++i) logs[i] = std::log(static_cast<double>(i));
   e = hipMalloc(reinterpret_cast<void**>(&t->d_logs), sizeof(double) * t->logs_n);
+  if (e != hipSuccess) t->d_logs = nullptr;
   if (e == hipSuccess) e = hipMemcpy(t->d_logs, logs.data(), sizeof(double) * t->logs_n, hipMemcpyHostToDevice);
   // the roots' players (status query on the copy)
   int8_t* d_cur = nullptr;
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_cur), static_cast<size_t>(t->n));
-  if (e != hipSuccess) { osg_batch_destroy(t->roots); (void)hipFree(t->d_mem); if (t->d_logs) (void)hipFree(t->d_logs); delete t; return set_error(OSG_ERR_NOMEM, hipGetErrorString(e)); }
+  if (e != hipSuccess) return fail(set_error(OSG_ERR_NOMEM, hipGetErrorString(e)));
   rc = osg_status_query(t->roots, d_cur, nullptr, nullptr, 0);
   if (rc == OSG_OK) {
     k_mcts_tree_init<<<dim3(static_cast<unsigned>((t->n + 255) / 256)), dim3(256), 0, ctx->stream>>>(make_pool(t), d_cur, t->n);
@@ -673,7 +694,7 @@ int osg_mcts_tree_create(const osg_batch* roots, const osg_mcts_cfg* cfg_in, int
   }
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(d_cur);
-  if (rc) { osg_batch_destroy(t->roots); (void)hipFree(t->d_mem); (void)hipFree(t->d_logs); delete t; return rc; }
+  if (rc) return fail(rc);
   osg::ctx_retain(ctx);
   *out = t;
   return OSG_OK;

@@ -329,6 +329,16 @@ class StateBatch:
         check(lib().osg_random_steps(self._h, int(seed), int(index_offset), int(steps), _ptr(counters)))
         return counters
 
+    def synth(self, seed, depth_mod, index_offset=0):
+        """SURVEY.md 8(d) synthetic inputs (osg_synth_batch): state i becomes the initial state advanced by
+        depth_i = draw mod depth_mod random legal moves on the counter stream (seed, index_offset + i), never
+        terminal; returns (actions [n] uint8 — one random legal action per state —, depth [n] int32).  The CPU
+        oracle regenerates the same batch from (seed, index range, depth_mod)."""
+        actions = self._dev((self.n,), torch.uint8)
+        depth = self._dev((self.n,), torch.int32)
+        check(lib().osg_synth_batch(self._h, int(seed), int(index_offset), int(depth_mod), _ptr(actions), _ptr(depth)))
+        return actions, depth
+
     def rollout(self, seed, n_rollouts, index_offset=0, want_steps=False):
         """RandomRolloutEvaluator: SUM of Returns() over n_rollouts playouts per root."""
         total = self._dev((self.n, self.num_players), torch.float64)

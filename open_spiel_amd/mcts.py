@@ -60,12 +60,12 @@ class BatchedEvaluator:
 
 
 class VPNetEvaluator(BatchedEvaluator):
-    joint = True   # every forward answers prior AND value of the same states: search() keeps the priors (flag 8)
-
     """alpha_zero_torch's VPNetEvaluator for a batch: `model(obs, legal)` maps the current player's observation
     tensors [B, obs_size] float32 and the legal-action mask [B, A] bool to (policy [B, A] over the legal actions,
     value [B] of player 0); Evaluate = {v, -v} (vpevaluator.cc:73-77, two-player zero-sum), Prior = the policy
     (:79-85).  One forward pass answers a prior request and a value request for the same row."""
+
+    joint = True   # every forward answers prior AND value of the same states: search() keeps the priors (flag 8)
 
     def __init__(self, model):
         self.model = model
@@ -136,6 +136,8 @@ def search(roots, evaluator, max_simulations=1024, uct_c=2.0, n_rollouts=1, solv
                 break
             if max_wall_clock_time > 0 and time.perf_counter() - start >= max_wall_clock_time:
                 break
+            if counts[1] == 0 and counts[2] == 0:
+                continue  # only paused searches are left: nothing to ask the evaluator, advance again
             want_prior, want_value = (request & 3) == 1, request == 2
             if isinstance(evaluator, RolloutEvaluator):
                 if counts[1]:  # uniform prior; only asked for because of the root noise

@@ -131,6 +131,41 @@ class Game:
         return dict(actions=acts, mask=mask, cur_player=cur, terminal=term, returns=rets,
                     obs=obs, info=info, longest=rc)
 
+    def synth_batch(self, seed, n, depth_mod, first=0, threads=1, want_obs=True, want_after=True):
+        """The CPU side of osg_synth_batch (SURVEY.md 8(d) synthetic inputs; see spiel_oracle_capi.cpp): states
+        first .. first + n - 1 of the stream `seed`, each with its depth, its random legal action, and the
+        record of the state before / after that action."""
+        W, P, osz = self.mask_words, self.num_players, self.observation_tensor_size
+        out = dict(depth=np.zeros(n, np.int32), action=np.zeros(n, np.int16),
+                   mask0=np.zeros((n, W), np.uint32), cur0=np.zeros(n, np.int8), term0=np.zeros(n, np.uint8),
+                   obs0=np.zeros((n, osz), np.uint8) if want_obs else None)
+        if want_after:
+            out.update(mask1=np.zeros((n, W), np.uint32), cur1=np.zeros(n, np.int8), term1=np.zeros(n, np.uint8),
+                       rets1=np.zeros((n, P), np.float64), obs1=np.zeros((n, osz), np.uint8) if want_obs else None)
+        else:
+            out.update(mask1=None, cur1=None, term1=None, rets1=None, obs1=None)
+        _check(lib().osgo_synth_batch(
+            self._h, C.c_uint64(seed), C.c_int64(first), C.c_int64(n), int(depth_mod), int(threads), W,
+            _ptr(out["depth"], C.c_int32), _ptr(out["action"], C.c_int16),
+            _ptr(out["mask0"], C.c_uint32), _ptr(out["cur0"], C.c_int8), _ptr(out["term0"], C.c_uint8),
+            _ptr(out["obs0"], C.c_uint8),
+            _ptr(out["mask1"], C.c_uint32), _ptr(out["cur1"], C.c_int8), _ptr(out["term1"], C.c_uint8),
+            _ptr(out["rets1"], C.c_double), _ptr(out["obs1"], C.c_uint8)))
+        return out
+
+    def synth_mcts_replay(self, seed_roots, n, depth_mod, uct_c, max_simulations, n_rollouts, counter_seed,
+                          counter_layout, first=0, threads=1):
+        """Replay-mode MCTSBot searches of the synthetic roots first .. first + n - 1 (restatement only)."""
+        A = self.num_distinct_actions
+        best = np.zeros(n, np.int32)
+        visits = np.zeros((n, A), np.int32)
+        reward = np.zeros((n, A), np.float64)
+        _check(lib().osgo_synth_mcts_replay(
+            self._h, C.c_uint64(seed_roots), C.c_int64(first), C.c_int64(n), int(depth_mod), C.c_double(uct_c),
+            int(max_simulations), int(n_rollouts), C.c_uint64(counter_seed), int(counter_layout), int(threads),
+            _ptr(best, C.c_int32), _ptr(visits, C.c_int32), _ptr(reward, C.c_double)))
+        return dict(best_action=best, child_visits=visits, child_reward=reward)
+
     def replay_rollouts(self, history, seed, root_index, n_rollouts):
         h = np.ascontiguousarray(history, np.int16)
         out = np.zeros(self.num_players, np.float64)

@@ -361,6 +361,99 @@ int osgo_random_playouts(void* g, uint64_t seed, int64_t n, int L, int W,
   });
 }
 
+// ---------------------------------------------------------------------------
+// SURVEY.md 8(d) synthetic benchmark inputs: the CPU side of osg_synth_batch (open_spiel_amd/csrc/osg_kernels.hip
+// k_synth), restated call for call so that the batch a benchmark times on the device can be regenerated and
+// checked state for state:
+//   rng = CounterRng(seed, first + i, "SYNTH"); depth = rng.Below(depth_mod);
+//   play `depth` moves from NewInitialState() (chance by SampleAction, players uniformly over LegalActions());
+//   a trajectory that is terminal before `depth` moves is thrown away and re-drawn from the same stream
+//   (<= 2^14 attempts, then the initial state with depth 0); action = one more draw at the accepted state.
+// Per state, for the accepted state ("before") and its successor after ApplyAction(action) ("after"):
+//   mask [n, W] u32 LegalActions (chance outcomes at chance nodes), cur [n] i8, term [n] u8, rets [n, P] f64,
+//   obs [n, obs_size] u8 = ObservationTensor(player 0) cast to bytes (0 / 1 planes on the boards, small integers
+//   in the poker games) — optional.  depth [n] i32, action [n] i16.  `threads` workers over contiguous ranges.
+// ---------------------------------------------------------------------------
+namespace {
+constexpr uint64_t kSynthSub = 0x53594E5448ULL;  // "SYNTH": the sub-stream of osg_synth_batch
+Action SynthDraw(const State& s, CounterRng& rng) {
+  if (s.IsChanceNode()) return SampleAction(s.ChanceOutcomes(), rng.Unit()).first;
+  std::vector<Action> la = s.LegalActions();
+  return la[rng.Below(static_cast<uint32_t>(la.size()))];
+}
+// The accepted state of stream `rng` (positioned at its start): see osgo_synth_batch.
+std::unique_ptr<State> SynthState(const Game& game, int depth_mod, CounterRng* rng, int* depth_out) {
+  int depth = static_cast<int>(rng->Below(static_cast<uint32_t>(depth_mod)));
+  std::unique_ptr<State> s;
+  for (int attempt = 0;; ++attempt) {
+    s = game.NewInitialState();
+    if (attempt >= (1 << 14)) { depth = 0; break; }
+    for (int t = 0; t < depth && !s->IsTerminal(); ++t) s->ApplyAction(SynthDraw(*s, *rng));
+    if (!s->IsTerminal()) break;
+  }
+  *depth_out = depth;
+  return s;
+}
+}  // namespace
+int osgo_synth_batch(void* g, uint64_t seed, int64_t first, int64_t n, int depth_mod, int threads, int W,
+                     int32_t* depth_out, int16_t* action_out,
+                     uint32_t* mask0, int8_t* cur0, uint8_t* term0, uint8_t* obs0,
+                     uint32_t* mask1, int8_t* cur1, uint8_t* term1, double* rets1, uint8_t* obs1) {
+  return Guard([&] {
+    const std::string game_string = static_cast<GameH*>(g)->game->ToString();
+    threads = std::max(1, threads);
+    std::vector<std::string> errors(threads);
+    auto work = [&](int w) {
+      try {
+        // one Game per worker: State objects pin their Game through a shared_ptr (spiel.h:906)
+        std::shared_ptr<const Game> game = LoadGame(game_string);
+        const int P = game->NumPlayers();
+        const int osz = game->ObservationTensorSize();
+        std::vector<float> tensor(osz);
+        auto record = [&](const State& s, int64_t i, uint32_t* mask, int8_t* cur, uint8_t* term, double* rets, uint8_t* obs) {
+          if (mask) {
+            for (int k = 0; k < W; ++k) mask[i * W + k] = 0;
+            for (Action a : s.LegalActions()) mask[i * W + a / 32] |= (1u << (a % 32));
+          }
+          if (cur) cur[i] = static_cast<int8_t>(s.CurrentPlayer());
+          if (term) term[i] = s.IsTerminal();
+          if (rets) {
+            std::vector<double> r = s.Returns();
+            for (int p = 0; p < P; ++p) rets[i * P + p] = r[p];
+          }
+          if (obs) {
+            WriteTensor(s, 0, 0, tensor.data(), osz);
+            for (int k = 0; k < osz; ++k) obs[i * osz + k] = static_cast<uint8_t>(tensor[k]);
+          }
+        };
+        const int64_t lo = n * w / threads, hi = n * (w + 1) / threads;
+        for (int64_t i = lo; i < hi; ++i) {
+          CounterRng rng(seed, static_cast<uint64_t>(first + i), kSynthSub);
+          int depth = 0;
+          std::unique_ptr<State> s = SynthState(*game, depth_mod, &rng, &depth);
+          const Action a = SynthDraw(*s, rng);
+          if (depth_out) depth_out[i] = depth;
+          if (action_out) action_out[i] = static_cast<int16_t>(a);
+          record(*s, i, mask0, cur0, term0, nullptr, obs0);
+          if (mask1 || cur1 || term1 || rets1 || obs1) {
+            s->ApplyAction(a);
+            record(*s, i, mask1, cur1, term1, rets1, obs1);
+          }
+        }
+      } catch (const std::exception& e) {
+        errors[w] = e.what();
+      }
+    };
+    std::vector<std::thread> workers;
+    for (int w = 1; w < threads; ++w) workers.emplace_back(work, w);
+    work(0);
+    for (auto& t : workers) t.join();
+    for (const std::string& e : errors)
+      if (!e.empty()) Fatal(e);
+    return 0;
+  });
+}
+
 // Replays the rollout the HIP kernel performs from a given history: rollout r
 // of root `root_index` uses CounterRng(seed, root_index, r) and draws exactly
 // as osgo_random_playouts does.  Sums Returns() over n_rollouts into out[P]
@@ -520,6 +613,58 @@ int osgo_mcts_search_stub(void* s, double uct_c, int max_simulations, int max_no
       ++k;
     }
     return static_cast<int>(root->children.size());
+  });
+#endif
+}
+
+// Config 4 at full size: roots first .. first + n - 1 of the synthetic stream (osgo_synth_batch's states:
+// seed_roots, depth_mod), each searched by MCTSBot(RandomRolloutEvaluator(n_rollouts), uct_c, max_simulations)
+// in REPLAY mode — every draw from the device's counter streams (counter_seed, global root index, layout) — on
+// `threads` workers.  best [n] i32, visits [n, A] i32, reward [n, A] f64 (zero for actions that are no child).
+// Restatement only (the reference has no replay hooks).
+int osgo_synth_mcts_replay(void* g, uint64_t seed_roots, int64_t first, int64_t n, int depth_mod, double uct_c,
+                           int max_simulations, int n_rollouts, uint64_t counter_seed, int counter_layout,
+                           int threads, int32_t* best, int32_t* visits, double* reward) {
+#ifdef OSGO_GENUINE_REFERENCE
+  (void)g; (void)seed_roots; (void)first; (void)n; (void)depth_mod; (void)uct_c; (void)max_simulations; (void)n_rollouts;
+  (void)counter_seed; (void)counter_layout; (void)threads; (void)best; (void)visits; (void)reward;
+  g_err = "counter-stream replay is a hook of the restatement, not of the reference";
+  return -1;
+#else
+  return Guard([&] {
+    const std::string game_string = static_cast<GameH*>(g)->game->ToString();
+    threads = std::max(1, threads);
+    std::vector<std::string> errors(threads);
+    auto work = [&](int w) {
+      try {
+        std::shared_ptr<const Game> game = LoadGame(game_string);
+        const int A = game->NumDistinctActions();
+        for (int64_t i = w; i < n; i += threads) {  // interleaved: search lengths vary with the root's depth
+          CounterRng rng(seed_roots, static_cast<uint64_t>(first + i), kSynthSub);
+          int depth = 0;
+          std::unique_ptr<State> s = SynthState(*game, depth_mod, &rng, &depth);
+          auto ev = std::make_shared<RandomRolloutEvaluator>(n_rollouts, 0);
+          MCTSBot bot(*game, ev, uct_c, max_simulations, 4096, false, 0, false);
+          bot.UseCounterStreams(counter_seed, static_cast<uint64_t>(first + i), n_rollouts, counter_layout);
+          std::unique_ptr<SearchNode> root = bot.MCTSearch(*s);
+          best[i] = root->children.empty() ? -1 : static_cast<int32_t>(root->BestChild().action);
+          for (int a = 0; a < A; ++a) { visits[i * A + a] = 0; reward[i * A + a] = 0.0; }
+          for (const SearchNode& c : root->children) {
+            visits[i * A + c.action] = c.explore_count;
+            reward[i * A + c.action] = c.total_reward;
+          }
+        }
+      } catch (const std::exception& e) {
+        errors[w] = e.what();
+      }
+    };
+    std::vector<std::thread> workers;
+    for (int w = 1; w < threads; ++w) workers.emplace_back(work, w);
+    work(0);
+    for (auto& t : workers) t.join();
+    for (const std::string& e : errors)
+      if (!e.empty()) Fatal(e);
+    return 0;
   });
 #endif
 }

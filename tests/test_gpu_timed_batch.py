@@ -1,0 +1,178 @@
+"""The batch bench.py times IS a batch the CPU reference can check — at BASELINE.json's full sizes.
+
+SURVEY.md 8(d) fixes the synthetic inputs on a counter stream so that "CPU oracle and GPU generate
+identical batches".  `osg_synth_batch` (device) and `osgo_synth_batch` (oracle/spiel_oracle_capi.cpp, bound to
+the GENUINE reference build oracle/_ref/libspiel_ref.so where it exists, else to the restatement) implement
+the same recipe; these tests regenerate the whole batch on the host threads and compare EVERY state:
+
+  config 2  connect_four, 2^20 states, seed 0x5EED, depth mod 36: depth, action, the state itself (as its
+            ObservationTensor), legal mask, player to move; then ONE launch of the fused step kernel exactly
+            as bench.py issues it (src -> dst, out of place): successor state, successor legal mask, status byte
+            (terminal / player to move / outcome) and Returns() of all 2^20 states.
+            Reference: spiel.cc:441-451, connect_four.cc:122-156, 277-285, 312-328.
+  config 4  hex(board_size=9), 2^16 roots, depth mod 40: all roots state for state; then the wave-per-root
+            search of ALL 2^16 roots at a reduced simulation count against the oracle's replay-mode MCTSBot:
+            best action, visit vector, reward vector.  Reference: mcts.cc:273-467, hex.cc:229-293.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x5EED
+
+
+def _threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import open_spiel_amd as osa
+    return osa.Context(0)
+
+
+@pytest.fixture(scope="module")
+def checker(oracle):
+    """The genuine reference build where it is present (it is on the GPU box: the prebuilt file travels),
+    else the restatement (itself equal to the genuine build call for call: tests/test_oracle_vs_reference.py)."""
+    import reference_py
+    if reference_py.available():
+        return reference_py, "reference"
+    return oracle, "port"
+
+
+def _check_states(torch, batch, rec, suffix, n):
+    """Every state of `batch` against the checker's record `suffix` ("0" before / "1" after the action):
+    the state itself through ObservationTensor(0), the legal mask, the player to move, IsTerminal."""
+    obs = batch.observation_tensor(0).to(torch.uint8).cpu().numpy()
+    np.testing.assert_array_equal(obs, rec["obs" + suffix])
+    del obs
+    bits = batch.legal_actions_mask_bits().cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(bits, rec["mask" + suffix])
+    cur, term, rets = [t.cpu().numpy() for t in batch.status()]
+    np.testing.assert_array_equal(term, rec["term" + suffix])
+    np.testing.assert_array_equal(cur, rec["cur" + suffix])
+    return rets
+
+
+def test_config2_timed_batch_every_state_against_the_reference(ctx, checker):
+    import torch
+    import open_spiel_amd as osa
+    impl, kind = checker
+    n, depth_mod = 1 << 20, 36
+    src = osa.StateBatch(ctx, "connect_four", n)
+    actions, depth = src.synth(SEED, depth_mod)
+    rec = impl.Game("connect_four").synth_batch(SEED, n, depth_mod, threads=_threads())
+    # the generator: same depths, same actions, same states
+    np.testing.assert_array_equal(depth.cpu().numpy(), rec["depth"])
+    np.testing.assert_array_equal(actions.cpu().numpy().astype(np.int16), rec["action"])
+    assert rec["term0"].sum() == 0 and np.bincount(rec["depth"], minlength=depth_mod).min() > n // depth_mod // 2
+    _check_states(torch, src, rec, "0", n)
+    # ONE launch as bench.py times it: out of place, mask + status buffers of the batch
+    dst = osa.StateBatch(ctx, "connect_four", n)
+    mask, status = src.step_buffers()
+    src.step(actions, dst=dst, mask=mask, status=status)
+    st = status.cpu().numpy()
+    assert ((st & 0x40) == 0).all(), "every synthetic action is legal"
+    term1 = rec["term1"] != 0
+    np.testing.assert_array_equal((st & 0x80) != 0, term1)
+    np.testing.assert_array_equal((st[~term1] & 15).astype(np.int64) - 1, rec["cur1"][~term1])
+    # outcome of the finished games: 0 player 0 wins, 1 player 1 wins, 2 draw  <->  Returns()
+    want_outcome = np.where(rec["rets1"][:, 0] > 0, 0, np.where(rec["rets1"][:, 0] < 0, 1, 2))
+    np.testing.assert_array_equal((st[term1] & 7), want_outcome[term1])
+    np.testing.assert_array_equal(mask.cpu().numpy().reshape(n), (rec["mask1"][:, 0] & 0xFF).astype(np.uint8))
+    rets = _check_states(torch, dst, rec, "1", n)
+    np.testing.assert_array_equal(rets, rec["rets1"])
+    # the source batch is untouched by the out-of-place launch (every timed launch does identical work)
+    _check_states(torch, src, rec, "0", n)
+    assert term1.sum() > 0, "the batch contains moves that end the game"
+    print(f"config 2: {n} states checked against the {kind}")
+
+
+def test_config2_shards_are_slices_of_one_stream(ctx):
+    """Rank r of an N-GPU run generates indices [r * n, (r + 1) * n): the same states as that slice of one big batch."""
+    import torch
+    import open_spiel_amd as osa
+    n = 1 << 16
+    whole = osa.StateBatch(ctx, "connect_four", 2 * n)
+    a_whole, d_whole = whole.synth(SEED, 36)
+    part = osa.StateBatch(ctx, "connect_four", n)
+    a_part, d_part = part.synth(SEED, 36, index_offset=n)
+    assert torch.equal(a_part, a_whole[n:]) and torch.equal(d_part, d_whole[n:])
+    np.testing.assert_array_equal(part.raw_words(), whole.raw_words()[:, n:])
+
+
+@pytest.mark.parametrize("game,depth_mod,n", [("tic_tac_toe", 5, 1 << 16), ("hex(board_size=5)", 12, 1 << 14),
+                                              ("connect_four(rows=5,columns=6,x_in_row=3)", 10, 1 << 14),
+                                              ("kuhn_poker", 2, 1 << 14), ("leduc_poker", 3, 1 << 14),
+                                              ("leduc_poker(players=3)", 4, 1 << 12)])
+def test_synth_batch_other_games(ctx, checker, game, depth_mod, n):
+    """The generator is one template over the games: chance nodes drawn by their distribution, ragged depths."""
+    import torch
+    import open_spiel_amd as osa
+    impl, _ = checker
+    b = osa.StateBatch(ctx, game, n)
+    actions, depth = b.synth(77, depth_mod, index_offset=123456789)
+    rec = impl.Game(game).synth_batch(77, n, depth_mod, first=123456789, threads=_threads())
+    np.testing.assert_array_equal(depth.cpu().numpy(), rec["depth"])
+    np.testing.assert_array_equal(actions.cpu().numpy().astype(np.int16), rec["action"])
+    _check_states(torch, b, rec, "0", n)
+    b.apply_actions(actions.to(torch.int32))
+    rets = _check_states(torch, b, rec, "1", n)
+    np.testing.assert_array_equal(rets, rec["rets1"])
+
+
+def test_synth_batch_argument_checks(ctx):
+    import open_spiel_amd as osa
+    b = osa.StateBatch(ctx, "connect_four", 64)
+    with pytest.raises(osa.OsgError):
+        b.synth(1, 0)
+    with pytest.raises(osa.OsgError):
+        b.synth(1, 43)
+    one_row = osa.StateBatch(ctx, "hex(num_rows=1,num_cols=4)", 8)
+    with pytest.raises(osa.OsgError):
+        one_row.synth(1, 2)
+
+
+def test_config4_all_roots_against_the_oracle_replay(ctx, oracle, checker):
+    """All 2^16 hex(9) roots of config 4: the roots state for state against the reference rules, then the search of
+    every root (wave-per-root layout, reduced simulation count) against the replay-mode MCTSBot of the oracle
+    (restatement: the reference has no replay hook; the restatement's MCTSBot equals the genuine one tree for tree
+    under shared draws, tests/test_oracle_vs_reference.py)."""
+    import torch
+    import open_spiel_amd as osa
+    impl, kind = checker
+    n, depth_mod, sims = 1 << 16, 40, 64
+    game = "hex(board_size=9)"
+    roots = osa.StateBatch(ctx, game, n)
+    _, depth = roots.synth(SEED, depth_mod)
+    rec = impl.Game(game).synth_batch(SEED, n, depth_mod, threads=_threads(), want_after=False)
+    np.testing.assert_array_equal(depth.cpu().numpy(), rec["depth"])
+    _check_states(torch, roots, rec, "0", n)
+    got = roots.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, seed=SEED, index_offset=0, layout=2)
+    want = oracle.Game(game).synth_mcts_replay(SEED, n, depth_mod, 2.0, sims, 1, SEED, 2, threads=_threads())
+    np.testing.assert_array_equal(got["best_action"].cpu().numpy(), want["best_action"])
+    np.testing.assert_array_equal(got["child_visits"].cpu().numpy(), want["child_visits"])
+    np.testing.assert_array_equal(got["child_reward"].cpu().numpy(), want["child_reward"])
+    # a shard of the same roots (rank 3 of 8) searches the same trees: global root index = index_offset + i
+    first, count = 3 * (n // 8), n // 8
+    shard = osa.StateBatch(ctx, game, count)
+    shard.synth(SEED, depth_mod, index_offset=first)
+    part = shard.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=1, seed=SEED, index_offset=first, layout=2)
+    assert torch.equal(part["child_visits"], got["child_visits"][first:first + count])
+    assert torch.equal(part["child_reward"], got["child_reward"][first:first + count])
+    print(f"config 4: {n} roots checked against the {kind}, {n} searches x {sims} simulations against the oracle replay")

@@ -384,6 +384,38 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
         fence()
         out["mccfr"]["allreduce_us"] = max_over_ranks(time.perf_counter() - t0) / 50 * 1e6
         out["mccfr"]["allreduce_bytes"] = int(flat.numel() * flat.element_size())
+        out["mccfr"]["allreduce_backend"] = "torch.distributed " + dist.get_backend()
+        # the same message through the one-shot all-reduce (peer-mapped windows, one launch, sums in rank order:
+        # osg_comm_oneshot_*), and the 16 mini-batches again with it as the exchange step; a failure here is
+        # reported, it never costs the line (the collective has a wall-clock timeout: no hang)
+        try:
+            one = osd.OneShotComm(ctx, flat.numel())
+            for _ in range(10):
+                one.allreduce_sum_(flat)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                one.allreduce_sum_(flat)
+            fence()
+            shot = {"allreduce_us": max_over_ranks(time.perf_counter() - t0) / 50 * 1e6,
+                    "what": "every rank pushes its 44 928 B into every peer's window over xGMI (hipIpc-mapped), waits for "
+                            "the peers' chunks and sums the slots in rank order: one launch, bit-identical sums on all ranks"}
+            s2 = osa.TabularSolver(ctx, "leduc_poker", mccfr=True)
+            sh2 = osd.ShardedMccfr(s2, comm=one)
+            sh2.run_minibatch(SEED, 1 << 12)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(nb):
+                sh2.run_minibatch(SEED, batch)
+            fence()
+            dt2 = max_over_ranks(time.perf_counter() - t0)
+            shot["trajectories_per_s"] = batch * nb / dt2
+            shot["nash_conv_after"] = float(s2.nash_conv())
+            del sh2, s2
+            one.close()
+            out["mccfr"]["oneshot"] = shot
+        except Exception as e:  # noqa: BLE001
+            out["mccfr"]["oneshot"] = {"error": f"{type(e).__name__}: {e}"}
         del flat
     if rank == 0:
         t = solver.tables()

@@ -471,6 +471,24 @@ typedef struct osg_comm osg_comm;
 int osg_comm_unique_id(void* id_out /* OSG_COMM_ID_BYTES */);
 int osg_comm_create(osg_ctx* ctx, int rank, int world, const void* id /* OSG_COMM_ID_BYTES */, osg_comm** out);
 int osg_comm_destroy(osg_comm* c);
+/* The one-shot all-reduce for the path's latency-bound messages ("prefer a one-shot direct
+ * all-reduce (each rank writes its buffer to all 7 peers, reduces locally)" for <= 45 KB): every rank owns a window
+ * in its HBM that all peers map through hipIpc; one launch per call pushes the local buffer into every window over
+ * xGMI, waits for the peers' pushes and sums the world's slots IN RANK ORDER — all ranks end with bit-identical
+ * sums (a ring associates differently per rank).  No RCCL involved.
+ *   1. every rank: osg_comm_oneshot_create(ctx, rank, world, max_doubles, &c)   max_doubles <= 32768, world <= 16
+ *   2. every rank: osg_comm_oneshot_handle(c, h)  -> OSG_ONESHOT_HANDLE_BYTES bytes; all-gather them out of band
+ *      (the channel the ncclUniqueId would travel on), rank order
+ *   3. every rank: osg_comm_oneshot_connect(c, all_handles)
+ *   4. osg_allreduce_sum_f64 / _i32 / _f64_begin + osg_allreduce_end as with the RCCL kind; osg_comm_destroy.
+ * Ranks may share a device (two processes on one GPU map each other's windows just the same), which is how the
+ * 1-GPU test box exercises it.  A peer that never arrives raises a timeout (OSG_ONESHOT_TIMEOUT_MS, default 20 s)
+ * reported by the next call.  The reference has no counterpart (no distributed runtime). */
+#define OSG_ONESHOT_HANDLE_BYTES 128
+int osg_comm_oneshot_create(osg_ctx* ctx, int rank, int world, int64_t max_doubles, osg_comm** out);
+int osg_comm_oneshot_handle(const osg_comm* c, void* handle_out /* OSG_ONESHOT_HANDLE_BYTES */);
+int osg_comm_oneshot_connect(osg_comm* c, const void* handles /* world x OSG_ONESHOT_HANDLE_BYTES, rank order */);
+
 int osg_comm_rank(const osg_comm* c);
 int osg_comm_world(const osg_comm* c);
 int osg_allreduce_sum_f64(osg_comm* c, double* d_buf, int64_t n);

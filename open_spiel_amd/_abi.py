@@ -150,6 +150,9 @@ SIGNATURES = {
     "osg_comm_unique_id": (INT, [VP]),
     "osg_comm_create": (INT, [VP, INT, INT, VP, C.POINTER(VP)]),
     "osg_comm_destroy": (INT, [VP]),
+    "osg_comm_oneshot_create": (INT, [VP, INT, INT, I64, C.POINTER(VP)]),
+    "osg_comm_oneshot_handle": (INT, [VP, VP]),
+    "osg_comm_oneshot_connect": (INT, [VP, VP]),
     "osg_comm_rank": (INT, [VP]),
     "osg_comm_world": (INT, [VP]),
     "osg_allreduce_sum_f64": (INT, [VP, VP, I64]),

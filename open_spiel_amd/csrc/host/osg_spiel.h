@@ -138,6 +138,26 @@ class Communicator {
   Communicator(int rank, int world, const Id& id, int device = 0) {
     Check(osg_comm_create(Context::Default(device), rank, world, id.data(), &c_));
   }
+  // The one-shot kind for the path's latency-bound messages (osg_comm_oneshot_*: every rank's window mapped by
+  // every peer through hipIpc, one launch per all-reduce, sums in rank order — bit-identical on all ranks; no RCCL):
+  // every rank makes one, hands LocalHandle() to the others out of band (the channel the Id would travel on) and
+  // calls Connect() with all of them in rank order.  AllReduceSum / Begin / End as with the RCCL kind.
+  using Handle = std::array<char, OSG_ONESHOT_HANDLE_BYTES>;
+  struct OneShotTag {};
+  Communicator(OneShotTag, int rank, int world, int64_t max_doubles, int device = 0) {
+    Check(osg_comm_oneshot_create(Context::Default(device), rank, world, max_doubles, &c_));
+  }
+  Handle LocalHandle() const {
+    Handle h{};
+    Check(osg_comm_oneshot_handle(c_, h.data()));
+    return h;
+  }
+  void Connect(const std::vector<Handle>& handles_in_rank_order) {
+    std::vector<char> flat;
+    for (const Handle& h : handles_in_rank_order) flat.insert(flat.end(), h.begin(), h.end());
+    if (static_cast<int>(handles_in_rank_order.size()) != world()) SpielFatalError("Communicator::Connect: one handle per rank");
+    Check(osg_comm_oneshot_connect(c_, flat.data()));
+  }
   ~Communicator() { osg_comm_destroy(c_); }
   Communicator(const Communicator&) = delete;
   Communicator& operator=(const Communicator&) = delete;

@@ -9,6 +9,9 @@ tables per mini-batch (leduc_poker: 2 x [936, 3] fp64 = 44 928 B, latency-bound)
 The reference has no distributed runtime at all (SURVEY.md header); this module is
 new design, not a translation.
 """
+import ctypes as C
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -33,11 +36,89 @@ def shard_range(total, rank, world_size):
     return first, count
 
 
-def allreduce_sum_(tensor):
-    """In-place sum over ranks (RCCL over xGMI for device tensors, gloo for CPU tensors)."""
+def allreduce_sum_(tensor, comm=None):
+    """In-place sum over ranks: through `comm` (a OneShotComm) when given, else torch.distributed (RCCL over
+    xGMI for device tensors, gloo for CPU tensors)."""
+    if comm is not None:
+        return comm.allreduce_sum_(tensor)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
     return tensor
+
+
+def collective_kind():
+    """OSG_COMM=oneshot|rccl (default rccl): which collective carries the path's one exchange step."""
+    kind = os.environ.get("OSG_COMM", "rccl").lower()
+    if kind not in ("oneshot", "rccl"):
+        raise ValueError(f"OSG_COMM={kind!r}: expected 'oneshot' or 'rccl'")
+    return kind
+
+
+class OneShotComm:
+    """The one-shot all-reduce of include/osg_abi.h (osg_comm_oneshot_*) for the path's latency-bound messages
+    (SURVEY.md section 5): every rank's window is mapped by every peer through hipIpc, one launch per call pushes
+    the local buffer to all peers, waits for theirs and sums the slots in rank order (bit-identical on all ranks).
+
+    The 128-byte window handles travel over `exchange` — a callable bytes -> [bytes of rank 0, rank 1, ...]; by
+    default torch.distributed.all_gather_object on the default group (any backend: the handles are host bytes).
+    Ranks may share a device."""
+
+    def __init__(self, ctx, max_doubles, rank=None, world_size=None, exchange=None):
+        from ._abi import check, lib
+        if rank is None or world_size is None:
+            rank, world_size = world()
+        self.ctx, self.rank, self.world_size, self.max_doubles = ctx, int(rank), int(world_size), int(max_doubles)
+        self._lib, self._check = lib(), check
+        h = C.c_void_p()
+        check(self._lib.osg_comm_oneshot_create(ctx._h, self.rank, self.world_size, self.max_doubles, C.byref(h)))
+        self._h = h
+        mine = C.create_string_buffer(128)
+        check(self._lib.osg_comm_oneshot_handle(self._h, mine))
+        if exchange is None:
+            def exchange(blob):
+                if self.world_size == 1:
+                    return [blob]
+                out = [None] * self.world_size
+                dist.all_gather_object(out, blob)
+                return out
+        blobs = exchange(mine.raw)
+        if len(blobs) != self.world_size or any(len(b) != 128 for b in blobs):
+            raise ValueError("OneShotComm: exchange() must return one 128-byte handle per rank, in rank order")
+        check(self._lib.osg_comm_oneshot_connect(self._h, C.create_string_buffer(b"".join(blobs), 128 * self.world_size)))
+
+    def _ptr(self, tensor, begin=False):
+        if not (isinstance(tensor, torch.Tensor) and tensor.is_cuda and tensor.is_contiguous()
+                and tensor.device == self.ctx.device):
+            raise ValueError(f"OneShotComm: need a contiguous tensor on {self.ctx.device}")
+        if tensor.dtype not in ((torch.float64,) if begin else (torch.float64, torch.int32)):
+            raise ValueError("OneShotComm: float64 (or int32, synchronous form only) tensors")
+        return C.c_void_p(tensor.data_ptr())
+
+    def allreduce_sum_(self, tensor):
+        """In place, on the context's stream (ordered with the kernels before and after it; no host wait)."""
+        fn = self._lib.osg_allreduce_sum_f64 if tensor.dtype == torch.float64 else self._lib.osg_allreduce_sum_i32
+        self._check(fn(self._h, self._ptr(tensor), tensor.numel()))
+        return tensor
+
+    def begin(self, tensor):
+        """Asynchronous form: the collective runs on the communicator's own stream, after everything issued on the
+        context's stream so far; kernels issued before end() overlap it."""
+        self._check(self._lib.osg_allreduce_sum_f64_begin(self._h, self._ptr(tensor, begin=True), tensor.numel()))
+
+    def end(self):
+        """Orders the context's stream after the collective begun last (no host wait)."""
+        self._check(self._lib.osg_allreduce_end(self._h))
+
+    def close(self):
+        if self._h:
+            self._lib.osg_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ShardedMccfr:
@@ -58,9 +139,14 @@ class ShardedMccfr:
     sequence of tables), which is why time-to-NashConv is reported for both (bench.py secondary.mccfr.quality).
     """
 
-    def __init__(self, solver, overlap=False):
+    def __init__(self, solver, overlap=False, comm=None):
+        """comm: a OneShotComm that carries the delta all-reduce instead of torch.distributed; by default one is
+        created when OSG_COMM=oneshot, the world has more than one rank and the solver lives on a device."""
         self.solver = solver
         self.rank, self.world_size = world()
+        if comm is None and self.world_size > 1 and hasattr(solver, "mccfr_delta_flat") and collective_kind() == "oneshot":
+            comm = OneShotComm(solver.ctx, solver.mccfr_delta_flat().numel())
+        self.comm = comm
         self.trajectories_done = 0
         self.overlap = bool(overlap)
         self._flat = None
@@ -78,7 +164,7 @@ class ShardedMccfr:
         if self.world_size > 1:
             if hasattr(self.solver, "mccfr_delta_flat"):
                 # the device solver: both tables are one allocation -> one collective, in place
-                allreduce_sum_(self.solver.mccfr_delta_flat())
+                allreduce_sum_(self.solver.mccfr_delta_flat(), self.comm)
             else:
                 dreg, dpol = self.solver.mccfr_delta_tables()
                 flat = torch.cat([dreg.reshape(-1), dpol.reshape(-1)])
@@ -97,7 +183,13 @@ class ShardedMccfr:
         # the buffer's previous deltas (mini-batch k - 2) were folded during mini-batch k - 1
         self.solver.mccfr_sample_into(buf, seed, count, first_trajectory=self.trajectories_done + first)
         work = None
-        if self.world_size > 1:
+        if self.world_size > 1 and self.comm is not None:
+            # one collective in flight per communicator: mini-batch k - 1's sum is folded first (its all-reduce ran
+            # while k was being sampled), then k's begins on the communicator's stream behind the traversals
+            self._fold_pending()
+            self.comm.begin(buf)
+            work = self.comm
+        elif self.world_size > 1:
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
         self._fold_pending()                       # mini-batch k - 1: waits for ITS all-reduce only
         self._pending = (cur, work)
@@ -109,7 +201,9 @@ class ShardedMccfr:
         if self._pending is None:
             return
         idx, work = self._pending
-        if work is not None:
+        if work is self.comm and work is not None:
+            work.end()     # the context's stream waits for the collective, the host does not
+        elif work is not None:
             work.wait()    # device tensors: the current stream waits, the host does not
         self.solver.mccfr_apply_deltas_from(self._bufs[idx])
         self._pending = None

@@ -253,6 +253,10 @@ def test_bench_two_ranks_code_path(tmp_path):
     assert sec["mcts"]["value"] > 0 and len(sec["mcts"]["per_rank_sims_per_s"]) == 2
     assert sec["mcts"]["single_rank_all_roots"]["value"] > 0 and sec["mcts"]["strong_scaling_efficiency"] > 0
     assert sec["mccfr"]["tables_finite"] and sec["mccfr"]["allreduce_us"] > 0 and sec["mccfr"]["allreduce_bytes"] == 44928
+    shot = sec["mccfr"]["oneshot"]   # the one-shot all-reduce carries the same exchange step (two ranks on this one device)
+    assert "error" not in shot, shot
+    assert 0 < shot["allreduce_us"] < 5000 and shot["trajectories_per_s"] > 0 and shot["nash_conv_after"] < 4.7
+    assert line["parity_checked_states"] == 1 << 16 and line["parity"]["against"] in ("reference", "port")
     q = sec["mccfr"]["quality"]
     assert q["world"] == 2 and q["nash_conv"] < 4.7 and q["overlapped"]["nash_conv"] < 4.7
     assert sec["ttt_mcts"]["device_single_root"]["value"] > 0

@@ -720,6 +720,296 @@ k_observation_hex_planes(typename G::Params p, const typename G::word_t* base, i
   }
 }
 
+// ---------------------------------------------------------------------------
+// Tensor pack, "one aligned 16-byte piece per thread": thread t computes floats [4t, 4t + 4) of the flat
+// [n, size] output and stores them once.  The store pattern is the one tools/fill_probe.hip measured as the
+// write-only ceiling (0.86 of 8 TB/s: every wave-instruction covers one aligned KiB, consecutive waves
+// consecutive KiB), where any form in which a wavefront owns a multi-KiB span of its own stays at 0.69-0.77
+// (profiles/r03_fill_probe.log) — which is where the span-per-wavefront packers above sit.  The price is that a
+// thread recomputes its position (state, offset) from the piece index and that the ~size / 4 threads of one state
+// all need that state; what it takes to reach the ceiling (profiles/r04_obs_forms.log has every step):
+//   * few instructions: at 0.85 a SIMD retires a 64-piece wavefront every ~150 ns, ~145 vector instructions — a
+//     game's generic cursor per piece is far too slow (0.29-0.59), each game below has its own bit arithmetic;
+//   * several pieces per thread with all loads issued first: a wavefront is load latency, then stores; one
+//     piece per thread keeps too few bytes in flight (0.75), four reach 0.84, six / eight fall back (0.79);
+//   * non-temporal stores: plain stores halve the rate (0.41-0.48) as soon as loads share the launch;
+//   * whole aligned KiB per wave-instruction: spans that start at 16-byte but not 1 KiB boundaries cost 0.77 -> 0.55.
+// Needs a 16-byte aligned output of fewer than 2^32 floats (the span-per-wavefront kernels serve the rest).
+// ---------------------------------------------------------------------------
+constexpr int kPieceBlock = 256;
+// connect_four 6 x 7 in the piece form.  A piece is four consecutive cells in row-major order (row r, columns
+// c .. c + 3, running on into the next row / plane / state); in the column-major bitboard (bit = 7 col + row) the cells
+// of a row sit 7 bits apart, so ONE 64-bit shift per row brings a whole row's bits into a 32-bit window and each
+// float is a bit-field extract: window 0 = the first cell's row from column c on, window 1 = the following row
+// (of the same plane, the next plane, or plane 0 of the next state).  126 floats per row is even and a piece
+// starts at a multiple of four, so floats 0 and 1 of a piece never leave the first state.
+// What the form costs is instructions, not bytes: at 0.85 of 8 TB/s a SIMD retires a 64-piece wavefront every
+// ~150 ns, i.e. ~145 vector instructions (the first version of this kernel had 127 + a 64-bit scalar division:
+// 0.77).  Hence: 32-bit indices throughout (the launcher sends tensors of 2^32 floats or more elsewhere), the
+// workgroup's first state by a 32-bit division by a constant, no unpacking of the result byte (no window ever
+// reaches bits 49+ unmasked), and the four cells as bit-field extracts of ONE word U built from the two windows
+// (float k = bit 7k of U).  kEgo: egocentric_obs_tensor (connect_four.cc:299-310), its own instantiation.
+// kPer pieces per thread: piece j of a thread lies T = threads-of-the-launch pieces after piece j - 1 (every store
+// instruction of the grid still covers consecutive KiB); all state loads are issued before the first float is formed.
+template <bool kNt, bool kEgo, int kPer>
+__global__ void __launch_bounds__(kPieceBlock)
+k_observation_c4std_pieces(C4Params p, const uint64_t* __restrict__ base, uint32_t n, uint32_t total, int player,
+                           float* __restrict__ out) {
+  uint64_t A0[kPer], A1[kPer], B0[kPer], B1[kPer];
+  uint32_t offs[kPer];
+  bool live[kPer];
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) {
+    const uint32_t wg = blockIdx.x + j * gridDim.x;       // < 2^22
+    const uint32_t ib = (wg * 512u) / 63u;                // = 1024 wg / 126: first state the workgroup touches
+    const uint32_t local = (wg * 1024u - ib * 126u) + 4u * threadIdx.x;   // < 126 + 1024
+    const uint32_t il = (local * 1041u) >> 17;            // local / 126 for local < 2^13
+    uint32_t i = ib + il;
+    live[j] = i < n;
+    if (!live[j]) i = n - 1;
+    offs[j] = local - il * 126u;                          // even: floats off, off + 1 are in state i
+    const uint32_t i1 = i + 1u < n ? i + 1u : i;
+    A0[j] = base[i]; A1[j] = base[n + i]; B0[j] = base[i1];
+    if (kEgo) B1[j] = base[n + i1];
+  }
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) {
+    if (!live[j]) continue;
+    const uint32_t wg = blockIdx.x + j * gridDim.x;
+    uint64_t a0 = A0[j], a1 = A1[j], b0 = B0[j];
+    if (kEgo) {  // PlayerRelative (connect_four.cc:299-310)
+      const C4Std::State sa = C4Std::unpack(a0, a1), sb = C4Std::unpack(b0, B1[j]);
+      int pa = player, pb = player;
+      if (player < 0) {
+        pa = C4Std::current_player(p, sa); if (pa < 0) pa = 0;
+        pb = C4Std::current_player(p, sb); if (pb < 0) pb = 0;
+      }
+      a0 = pa == 0 ? sa.o : sa.x;
+      a1 = pa == 0 ? sa.x : sa.o;
+      b0 = pb == 0 ? sb.o : sb.x;
+    }
+    const uint64_t a2 = ~(a0 | a1);
+    const uint32_t off = offs[j];
+    const uint32_t plane = (off >= 42u) + (off >= 84u);
+    const uint32_t cell = off - __umul24(42u, plane);
+    const uint32_t row = __umul24(cell, 37u) >> 8;         // cell / 7 for cell < 42
+    const uint32_t col = cell - __umul24(7u, row);
+    // window 0: the first cell's row from its column on (bit 7k = column col + k); window 1: the following row from
+    // column 0 — of the same plane, of the next plane, or of plane 0 of the next state
+    const uint64_t bits0 = plane == 0 ? a0 : (plane == 1 ? a1 : a2);
+    const uint32_t w0 = static_cast<uint32_t>(bits0 >> (__umul24(7u, col) + row));
+    const bool last_row = row == 5u;
+    const uint32_t plane1 = plane + (last_row ? 1u : 0u);
+    const uint64_t bits1 = plane1 == 0 ? a0 : (plane1 == 1 ? a1 : (plane1 == 2 ? a2 : b0));
+    const uint32_t w1 = static_cast<uint32_t>(bits1 >> (last_row ? 0u : row + 1u));
+    const uint32_t t7 = 49u - __umul24(7u, col);           // bits of window 0 that are cells of this row: 7 (7 - col)
+    const uint32_t u = t7 >= 28u ? w0 : ((w0 & ((1u << t7) - 1u)) | (w1 << t7));
+    const float4 v = make_float4(static_cast<float>(u & 1u), static_cast<float>((u >> 7) & 1u),
+                                 static_cast<float>((u >> 14) & 1u), static_cast<float>((u >> 21) & 1u));
+    const uint32_t f0 = wg * 1024u + 4u * threadIdx.x;
+    float* dst = out + (static_cast<size_t>(wg) * 1024u) + 4u * threadIdx.x;   // scalar base + 32-bit lane offset
+    if (f0 + 4u <= total) {
+      store_row4<kNt>(reinterpret_cast<float4*>(dst), v);
+    } else {  // the last piece of the tensor (126 n is even, not always a multiple of four).  Atomic stores: plain ones
+      // are merged with the vector store above into a 12-byte + a 4-byte store on EVERY lane (seen in the ISA: 0.34)
+      __hip_atomic_store(dst, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// The piece form for the other board tensors, written once.  The mapping is FLAT — thread t of workgroup w forms
+// floats [1024 w + 4 t, + 4): every wave-instruction stores one whole, 1 KiB-aligned KiB; a first version that gave a
+// workgroup whole rows (972 floats for tic_tac_toe: spans aligned to 16 bytes only) ran at 0.55 where this runs at
+// the fill ceiling — so the workgroup's first state is a division of 1024 w by the row length: five scalar
+// instructions with a host-made multiplier (FastDiv, libdivide's branch-free form), and the lane's row a
+// multiply-shift the host has verified for its range.  Like the connect_four kernel above, every thread serves kPer
+// spans, all state loads issued first.  F is the game's piece functor:
+//   Words F::load(i)                           the raw state words a piece of state i may need
+//   float4 F::piece(Words a, Words b, off)     floats off .. off + 3 of state a's row, running on into state b's
+struct FastDiv {   // x / d for any 32-bit x: t = mulhi(x, m); q = (((x - t) >> 1) + t) >> s
+  uint32_t m, s, d;
+  OSG_HD uint32_t div(uint32_t x) const {
+#ifdef __HIP_DEVICE_COMPILE__
+    const uint32_t t = __umulhi(x, m);
+#else
+    const uint32_t t = static_cast<uint32_t>((static_cast<uint64_t>(x) * m) >> 32);
+#endif
+    return (((x - t) >> 1) + t) >> s;
+  }
+};
+inline FastDiv make_fast_div(uint32_t d) {  // d >= 2
+  FastDiv f;
+  f.d = d;
+  const uint32_t k = 31u - static_cast<uint32_t>(__builtin_clz(d));
+  if ((d & (d - 1)) == 0) { f.m = 0; f.s = k - 1; return f; }   // 2^k: t = 0, q = (x >> 1) >> (k - 1)
+  const uint64_t two = uint64_t{1} << (32 + k);
+  uint64_t m = two / d;
+  const uint64_t rem = two - m * d;
+  m += m;
+  const uint64_t twice = rem + rem;
+  if (twice >= d) m += 1;
+  f.m = static_cast<uint32_t>(m + 1);
+  f.s = k;
+  return f;
+}
+template <class F, bool kNt, int kPer>
+__global__ void __launch_bounds__(kPieceBlock)
+k_observation_row_pieces(F f, uint32_t n, FastDiv by_size, uint32_t lmagic, uint32_t lshift, uint32_t total,
+                         float* __restrict__ out) {
+  typename F::Words wa[kPer], wb[kPer];
+  uint32_t offs[kPer];
+  const uint32_t size = by_size.d;
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) {
+    const uint32_t fb = (blockIdx.x + j * gridDim.x) * 1024u;        // first float of the span (scalar)
+    const uint32_t ib = by_size.div(fb);
+    const uint32_t local = (fb - ib * size) + 4u * threadIdx.x;      // < size + 1024
+    const uint32_t il = (local * lmagic) >> lshift;                  // local / size
+    uint32_t i = ib + il;
+    offs[j] = local - il * size;
+    if (i >= n) i = n - 1u;                                          // (a piece past the end: not stored)
+    wa[j] = f.load(i);
+    wb[j] = f.load(i + 1u < n ? i + 1u : i);
+  }
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) {
+    const uint32_t f0 = (blockIdx.x + j * gridDim.x) * 1024u + 4u * threadIdx.x;
+    if (f0 >= total) continue;
+    const float4 v = f.piece(wa[j], wb[j], offs[j]);
+    float* dst = out + static_cast<size_t>(blockIdx.x + j * gridDim.x) * 1024u + 4u * threadIdx.x;
+    if (f0 + 4u <= total) {
+      store_row4<kNt>(reinterpret_cast<float4*>(dst), v);
+    } else {  // the tensor's last piece (atomic stores: see k_observation_c4std_pieces)
+      const uint32_t left = total - f0;
+      __hip_atomic_store(dst, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (left > 1u) __hip_atomic_store(dst + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (left > 2u) __hip_atomic_store(dst + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+OSG_D float4 low_four_bits(uint32_t u) {
+  return make_float4(static_cast<float>(u & 1u), static_cast<float>((u >> 1) & 1u), static_cast<float>((u >> 2) & 1u),
+                     static_cast<float>((u >> 3) & 1u));
+}
+// tic_tac_toe (tic_tac_toe.cc:241-251): the row is a 27-bit image, plane 0 empty | plane 1 o | plane 2 x.
+struct TttPieces {
+  const uint32_t* base;
+  using Words = uint32_t;
+  OSG_D Words load(uint32_t i) const { return base[i]; }
+  OSG_D static uint32_t image(uint32_t w) {
+    const uint32_t x = w & 0x1FFu, o = (w >> 16) & 0x1FFu;
+    return (~(x | o) & 0x1FFu) | (o << 9) | (x << 18);
+  }
+  OSG_D float4 piece(Words a, Words b, uint32_t off) const {  // off <= 26
+    return low_four_bits((image(a) >> off) | (image(b) << (27u - off)));
+  }
+};
+// hex, the 9-plane tensor (hex.cc:379-398: plane = label + 4), in the piece form: a piece is four consecutive cells
+// of one plane's membership mask (HexT::plane_mask: boolean algebra on the stone / edge-connection planes), running
+// on into the next plane of the same state or plane 0 of the next state.  It needs nine words (three planes x {two
+// words of the first mask — the four bits may straddle a word —, word 0 of the following mask}), each in another
+// plane of the SoA image; as nine global loads per piece that is 0.35 of 8 TB/s (the texture path spends its cycles
+// on load INSTRUCTIONS, not bytes).  So a workgroup owns spans of 4096 consecutive floats (16 KiB: four aligned KiB
+// per wavefront); the 5-7 states a span belongs to are fetched ONCE into LDS, one word per thread (the only global
+// loads), and the pieces read their nine words from there (same-address LDS reads within a wavefront: broadcasts).
+constexpr int kHexLdsSpan = 4096;             // floats per workgroup
+constexpr int kHexLdsMaxStates = 18;          // 4096 / (9 * 29 cells) + 2
+// kSpans spans per workgroup (span j of workgroup w = span w + j * gridDim.x): all their states are fetched before the
+// one barrier, so kSpans x 16 KiB of stores stand behind one load round trip.
+template <int NW, bool kNt, int kSpans>
+__global__ void __launch_bounds__(kPieceBlock)
+k_observation_hex_pieces_lds(const uint32_t* __restrict__ base, uint32_t n, uint32_t cells, uint32_t cmagic, uint32_t cshift,
+                             FastDiv by_size, uint32_t lmagic, uint32_t lshift, uint32_t total, float* __restrict__ out) {
+  __shared__ uint32_t s_words[kSpans][kHexLdsMaxStates * 4 * NW];
+  const uint32_t size = by_size.d;   // 9 cells
+  uint32_t ias[kSpans];
+#pragma unroll
+  for (int j = 0; j < kSpans; ++j) {
+    const uint32_t fb = (blockIdx.x + j * gridDim.x) * static_cast<uint32_t>(kHexLdsSpan);
+    ias[j] = 0;
+    if (fb >= total) continue;
+    const uint32_t ia = by_size.div(fb);                               // first state of the span (scalar)
+    ias[j] = ia;
+    uint32_t last = fb + kHexLdsSpan - 1u;
+    if (last >= total) last = total - 1u;
+    const uint32_t count = by_size.div(last) - ia + 1u;                // states the span touches ...
+    const uint32_t fetch = (count + 1u) * 4u * NW;                     // ... and one more (a piece's next mask), clamped
+    if (threadIdx.x < fetch) {
+      const uint32_t sl = threadIdx.x / (4u * NW), w = threadIdx.x - sl * 4u * NW;
+      uint32_t i = ia + sl;
+      if (i >= n) i = n - 1u;
+      s_words[j][threadIdx.x] = base[w * n + i];                       // plane-major SoA: word w of state i
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kSpans; ++j) {
+    const uint32_t span = blockIdx.x + j * gridDim.x;
+    const uint32_t fb = span * static_cast<uint32_t>(kHexLdsSpan);
+    if (fb >= total) break;
+    const uint32_t rem = fb - ias[j] * size;
+    const uint32_t* words = s_words[j];
+#pragma unroll
+    for (int r = 0; r < kHexLdsSpan / (4 * kPieceBlock); ++r) {
+      const uint32_t p4 = 4u * (r * kPieceBlock + threadIdx.x);        // float inside the span
+      const uint32_t f0 = fb + p4;
+      if (f0 >= total) break;
+      const uint32_t local = rem + p4;                                 // < size + 4096
+      const uint32_t il = (local * lmagic) >> lshift;                  // local / size
+      const uint32_t off = local - il * size;
+      const uint32_t plane = (off * cmagic) >> cshift;                 // off / cells
+      const uint32_t cell0 = off - plane * cells;
+      const uint32_t k0 = cell0 >> 5, k1 = k0 + 1u < NW ? k0 + 1u : k0;
+      const bool wrap = plane == 8u;                                   // the following mask: plane 0 of the next state
+      const int l0 = static_cast<int>(plane) - 4, l1 = wrap ? -4 : l0 + 1;
+      const uint32_t sa = il * 4u * NW, sb = wrap ? sa + 4u * NW : sa;
+      // planes: 0 black, 1 white, 2 edge A, 3 edge B.  l == 0 (empty): X = black, Y = white.  else X = own, Y = ea, Z = eb
+      const uint32_t px0 = (l0 >= 0 ? 0u : 1u) * NW, py0 = (l0 == 0 ? 1u : 2u) * NW;
+      const uint32_t px1 = (l1 >= 0 ? 0u : 1u) * NW, py1 = (l1 == 0 ? 1u : 2u) * NW;
+      uint32_t X[3], Y[3], Z[3];
+      X[0] = words[sa + px0 + k0]; Y[0] = words[sa + py0 + k0]; Z[0] = words[sa + 3u * NW + k0];
+      X[1] = words[sa + px0 + k1]; Y[1] = words[sa + py0 + k1]; Z[1] = words[sa + 3u * NW + k1];
+      X[2] = words[sb + px1];      Y[2] = words[sb + py1];      Z[2] = words[sb + 3u * NW];
+      uint32_t m[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int l = k < 2 ? l0 : l1;
+        const int mag = l > 0 ? l : -l;                                 // 1 plain, 2 edge B only, 3 edge A only, 4 both
+        const uint32_t fa = mag >= 3 ? 0u : ~0u, fb2 = (mag == 2 || mag == 4) ? 0u : ~0u;
+        const uint32_t labelled = X[k] & (Y[k] ^ fa) & (Z[k] ^ fb2);
+        m[k] = l == 0 ? ~(X[k] | Y[k]) : labelled;
+      }
+      const uint32_t second = k0 + 1u < NW ? m[1] : 0u;
+      const uint32_t w0 = __funnelshift_r(m[0], second, cell0 & 31u);   // bit k = cell0 + k of mask 0
+      const uint32_t t = cells - cell0;                                 // cells left in the plane (>= 1)
+      const uint32_t u = t >= 4u ? w0 : ((w0 & ((1u << t) - 1u)) | (m[2] << t));
+      const float4 v = low_four_bits(u);
+      float* dst = out + static_cast<size_t>(span) * kHexLdsSpan + p4;
+      if (f0 + 4u <= total) {
+        store_row4<kNt>(reinterpret_cast<float4*>(dst), v);
+      } else {
+        const uint32_t left = total - f0;
+        __hip_atomic_store(dst, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left > 1u) __hip_atomic_store(dst + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left > 2u) __hip_atomic_store(dst + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+// (x * magic) >> shift == x / d for every x < limit?  The host picks the pair with this check, so the kernels' lane
+// arithmetic is a multiply and a shift whatever the row length.
+inline bool find_div_magic(uint32_t d, uint32_t limit, uint32_t* magic, uint32_t* shift) {
+  for (uint32_t s = 8; s <= 24; ++s) {
+    const uint64_t m = ((uint64_t{1} << s) + d - 1) / d;
+    if (m * (limit - 1) >= (uint64_t{1} << 32)) break;
+    bool ok = true;
+    for (uint32_t x = 0; x < limit && ok; ++x) ok = ((x * m) >> s) == x / d;
+    if (ok) { *magic = static_cast<uint32_t>(m); *shift = s; return true; }
+  }
+  return false;
+}
+
 // `steps` uniformly random env steps per state with auto-reset, the state in registers throughout.
 // Persistent grid (grid-stride over the states).  The two counters are reduced per workgroup and then
 // added to one of 64 partial slots — 32 768 same-address atomics (one per wavefront) were measured at
@@ -1387,7 +1677,49 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
     if (rc) return rc;
     d_out = static_cast<float*>(scratch);
   }
-  if (b->spec.desc.game_kind == kC4 && b->spec.c4_std) {
+  // OSG_OBS_FORM=0: the span-per-wavefront kernels of round 3 (A/B: tools/probe_obs_forms.py); 1: the piece form
+  // with plain stores; default 2: the piece form with non-temporal stores.
+  static const int obs_form = std::getenv("OSG_OBS_FORM") ? std::atoi(std::getenv("OSG_OBS_FORM")) : 2;
+  const bool aligned16 = (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0;
+  // (below ~2^24 floats the launch is a few hundred workgroups: the span kernels' finer grid fills the chip better —
+  // [2^16, 126]: 7.4 vs 8.4 us, hex(9) [2^14, 729]: 11.9 vs 29.5 us; from [2^20, 27] on the piece form is ahead)
+  const bool pieces = obs_form != 0 && aligned16 && total < (int64_t{1} << 32) && total >= (int64_t{1} << 24);
+  const bool nt = obs_form != 1;
+  const unsigned piece_grid = static_cast<unsigned>(((total + 1023) / 1024 + 3) / 4);   // four 1 KiB-piece spans per workgroup
+  if (pieces && b->spec.desc.game_kind == kC4 && b->spec.c4_std) {
+#define OSG_C4P(NT, EGO) k_observation_c4std_pieces<NT, EGO, 4><<<dim3(piece_grid), dim3(kPieceBlock), 0, ctx->stream>>>( \
+      b->spec.c4, static_cast<const uint64_t*>(b->d_words), static_cast<uint32_t>(b->n), static_cast<uint32_t>(total), player, d_out)
+    if (b->spec.c4.ego) { if (nt) OSG_C4P(true, true); else OSG_C4P(false, true); }
+    else { if (nt) OSG_C4P(true, false); else OSG_C4P(false, false); }
+#undef OSG_C4P
+  } else if (pieces && b->spec.desc.game_kind == kTtt) {
+    uint32_t magic = 0, shift = 0;
+    find_div_magic(static_cast<uint32_t>(size), static_cast<uint32_t>(size) + 1024u, &magic, &shift);
+    TttPieces f{static_cast<const uint32_t*>(b->d_words)};
+    // eight spans per thread here (27-float rows: 0.74 with four, 0.76 with eight; the round-3 kernel: 0.69)
+    const unsigned g8 = (piece_grid + 1) / 2;
+    if (nt) k_observation_row_pieces<TttPieces, true, 8><<<dim3(g8), dim3(kPieceBlock), 0, ctx->stream>>>(
+        f, static_cast<uint32_t>(b->n), make_fast_div(static_cast<uint32_t>(size)), magic, shift, static_cast<uint32_t>(total), d_out);
+    else k_observation_row_pieces<TttPieces, false, 8><<<dim3(g8), dim3(kPieceBlock), 0, ctx->stream>>>(
+        f, static_cast<uint32_t>(b->n), make_fast_div(static_cast<uint32_t>(size)), magic, shift, static_cast<uint32_t>(total), d_out);
+  } else if (pieces && b->spec.desc.game_kind == kHex && which == 0 && d.obs_shape[0] == 9 &&
+             d.obs_shape[1] * d.obs_shape[2] >= 29) {   // (a span of 4096 floats then touches at most 18 states)
+    const uint32_t cells = static_cast<uint32_t>(d.obs_shape[1] * d.obs_shape[2]);
+    uint32_t cm = 0, cs = 0, lm = 0, ls = 0;
+    if (!find_div_magic(cells, 9u * cells, &cm, &cs) || !find_div_magic(9u * cells, 9u * cells + kHexLdsSpan, &lm, &ls))
+      return set_error(OSG_ERR_INVALID, "osg_observation: no multiply-shift pair for this hex board");
+    const unsigned g = static_cast<unsigned>(((total + kHexLdsSpan - 1) / kHexLdsSpan + 3) / 4);
+#define OSG_HEXL(NW, NT) k_observation_hex_pieces_lds<NW, NT, 4><<<dim3(g), dim3(kPieceBlock), 0, ctx->stream>>>(               \
+      static_cast<const uint32_t*>(b->d_words), static_cast<uint32_t>(b->n), cells, cm, cs, make_fast_div(9u * cells), lm, ls,    \
+      static_cast<uint32_t>(total), d_out)
+    switch (b->spec.hex_nw) {
+      case 1: if (nt) OSG_HEXL(1, true); else OSG_HEXL(1, false); break;
+      case 2: if (nt) OSG_HEXL(2, true); else OSG_HEXL(2, false); break;
+      case 3: if (nt) OSG_HEXL(3, true); else OSG_HEXL(3, false); break;
+      default: if (nt) OSG_HEXL(4, true); else OSG_HEXL(4, false); break;
+    }
+#undef OSG_HEXL
+  } else if (b->spec.desc.game_kind == kC4 && b->spec.c4_std) {
     if ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0 && b->n >= (int64_t{1} << 22))
       k_observation_c4std_planes<true><<<dim3(static_cast<unsigned>((b->n * 3 + kC4ObsBlock - 1) / kC4ObsBlock)),
                                          dim3(kC4ObsBlock), 0, ctx->stream>>>(

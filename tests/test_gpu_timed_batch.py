@@ -119,7 +119,13 @@ def test_config2_shards_are_slices_of_one_stream(ctx):
 @pytest.mark.parametrize("game,depth_mod,n", [("tic_tac_toe", 5, 1 << 16), ("hex(board_size=5)", 12, 1 << 14),
                                               ("connect_four(rows=5,columns=6,x_in_row=3)", 10, 1 << 14),
                                               ("kuhn_poker", 2, 1 << 14), ("leduc_poker", 3, 1 << 14),
-                                              ("leduc_poker(players=3)", 4, 1 << 12)])
+                                              ("leduc_poker(players=3)", 4, 1 << 12),
+                                              # sizes at which the tensors take the piece-form kernels (>= 2^24 floats),
+                                              # with odd state counts so that the tensor ends inside a 16-byte piece
+                                              ("tic_tac_toe", 5, (1 << 20) + 1), ("connect_four", 20, (1 << 18) + 1),
+                                              ("connect_four(egocentric_obs_tensor=True)", 20, (1 << 18) + 3),
+                                              ("hex(board_size=6)", 20, (1 << 16) + 3), ("hex(board_size=11)", 60, (1 << 15) + 1),
+                                              ("hex(num_cols=7,num_rows=5)", 12, (1 << 16) + 2)])
 def test_synth_batch_other_games(ctx, checker, game, depth_mod, n):
     """The generator is one template over the games: chance nodes drawn by their distribution, ragged depths."""
     import torch

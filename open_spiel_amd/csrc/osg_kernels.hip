@@ -905,6 +905,100 @@ struct TttPieces {
     return low_four_bits((image(a) >> off) | (image(b) << (27u - off)));
   }
 };
+// kuhn_poker, two players (KuhnObserver::WriteTensor, kuhn_poker.cc:72-107), in the piece form.  The round-3 rows
+// kernel spends its whole launch issuing vector instructions (profiles/r04_pmc_k_observation_rows_kuhn_2p24.txt:
+// SQ_ACTIVE_INST_VALU x 4 cycles / SIMD = the launch's duration): here a row is one small image —
+//   observation  [player 2 | private card 3 | pot contribution 2]: seven 4-bit entries (the contributions are 1 .. 3)
+//   information  [player 2 | private card 3 | betting 3 x 2]:      eleven 1-bit entries
+// — two images per piece (its state and the next), one 64-bit shift, four field extracts.
+template <int kWhich>
+struct Kuhn2Pieces {
+  const uint64_t* base;
+  int player;
+  using Words = uint64_t;
+  static constexpr uint32_t kSize = kWhich == 0 ? 7u : 11u, kBits = kWhich == 0 ? 4u : 1u;
+  OSG_D Words load(uint32_t i) const { return base[i]; }
+  OSG_D uint64_t image(uint64_t h) const {
+    const Kuhn::Params p{1, 2};
+    const Kuhn::State s{h};
+    int pl = player;
+    if (pl < 0) {
+      pl = Kuhn::current_player(p, s);
+      if (pl < 0) pl = 0;
+    }
+    const uint32_t len = static_cast<uint32_t>(h & 31ull), bets = static_cast<uint32_t>(h >> 45);
+    const uint32_t card = static_cast<uint32_t>(h >> (5 + 4 * pl)) & 15u;
+    const bool dealt = len > static_cast<uint32_t>(pl);
+    if (kWhich == 0) {
+      const uint32_t c0 = 1u + (bets & 1u) + ((bets >> 2) & 1u), c1 = 1u + ((bets >> 1) & 1u);   // contribution(), P = 2
+      uint32_t img = (1u << (4 * pl)) | (c0 << 20) | (c1 << 24);
+      if (dealt) img |= 1u << (8 + 4 * card);
+      return img;
+    }
+    uint32_t img = 1u << pl;
+    if (dealt) img |= 1u << (2 + card);
+    const uint32_t nact = len > 2u ? len - 2u : 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < 3; ++j)
+      if (j < nact) img |= 1u << (5u + 2u * j + ((bets >> j) & 1u));
+    return img;
+  }
+  OSG_D float4 piece(Words a, Words b, uint32_t off) const {
+    const uint64_t both = (image(a) | (image(b) << (kSize * kBits))) >> (kBits * off);
+    const uint32_t u = static_cast<uint32_t>(both), m = (1u << kBits) - 1u;
+    return make_float4(static_cast<float>(u & m), static_cast<float>((u >> kBits) & m),
+                       static_cast<float>((u >> (2 * kBits)) & m), static_cast<float>((u >> (3 * kBits)) & m));
+  }
+};
+// leduc_poker, two players (LeducObserver::WriteTensor, leduc_poker.cc:103-192), in the piece form, K = the number
+// of card ranks the tensor distinguishes (6, or 3 with suit isomorphism):
+//   observation  [player 2 | private K | public K | pot contribution 2]: 4-bit entries (contributions <= 13), <= 64 bits
+//   information  [player 2 | private K | public K | betting 2 x 4 x 2]: 1-bit entries; a move's pair (call "10",
+//                raise "01", fold "00") IS its 2-bit code in the record (1 call, 2 raise, 0 fold), so a round's
+//                betting bits are its move sequence masked to its length.
+template <int kWhich>
+struct Leduc2Pieces {
+  const uint64_t* base;
+  uint32_t n;
+  int player, K;
+  Leduc::Params p;
+  struct Words { uint64_t a, b; };
+  static constexpr uint32_t kBits = kWhich == 0 ? 4u : 1u;
+  OSG_D Words load(uint32_t i) const { return {base[i], base[n + i]}; }
+  using Img = typename std::conditional<kWhich == 0, uint64_t, uint32_t>::type;   // information rows: 30 bits
+  OSG_D Img image(const Words& w) const {
+    // only the fields a row shows are taken out of the two packed words (Leduc::unpack's layout)
+    const uint32_t ante_pk = static_cast<uint32_t>(w.a >> 42) & 0xFFFu, priv_pk = static_cast<uint32_t>(w.b >> 34) & 0xFFFu;
+    const int pub = static_cast<int>((w.a >> 18) & 15ull) - 1;
+    int pl = player;
+    if (pl < 0) {
+      pl = Leduc::current_player(p, Leduc::unpack(w.a, w.b));
+      if (pl < 0) pl = 0;
+    }
+    const int pc = static_cast<int>((priv_pk >> (4 * pl)) & 15u) - 1;
+    Img img = Img{1} << (kBits * pl);
+    if (pc >= 0) img |= Img{1} << (kBits * (2 + pc));
+    if (pub >= 0) img |= Img{1} << (kBits * (2 + K + pub));
+    if (kWhich == 0) {
+      img |= static_cast<Img>(ante_pk & 0xFFu) << (4 * (2 + 2 * K));   // ante[0] | ante[1] << 4: two entries
+    } else {
+      const uint32_t lo = static_cast<uint32_t>(w.b);
+      const uint32_t len0 = lo & 7u, seq0 = (lo >> 3) & 0xFFu, len1 = (lo >> 17) & 7u, seq1 = (lo >> 20) & 0xFFu;
+      const uint32_t r0 = seq0 & ((1u << (2 * len0)) - 1u), r1 = seq1 & ((1u << (2 * len1)) - 1u);
+      img |= static_cast<Img>((r0 & 0xFFu) | ((r1 & 0xFFu) << 8)) << (2 + 2 * K);
+    }
+    return img;
+  }
+  OSG_D float4 piece(const Words& a, const Words& b, uint32_t off) const {
+    const uint32_t size = kWhich == 0 ? 4u + 2u * K : 18u + 2u * K;
+    Img both = image(a) >> (kBits * off);
+    const uint32_t in_a = size - off;                        // entries of the piece that lie in a's row (>= 1)
+    if (in_a < 4u) both |= image(b) << (kBits * in_a);
+    const uint32_t u = static_cast<uint32_t>(both), m = (1u << kBits) - 1u;
+    return make_float4(static_cast<float>(u & m), static_cast<float>((u >> kBits) & m),
+                       static_cast<float>((u >> (2 * kBits)) & m), static_cast<float>((u >> (3 * kBits)) & m));
+  }
+};
 // hex, the 9-plane tensor (hex.cc:379-398: plane = label + 4), in the piece form: a piece is four consecutive cells
 // of one plane's membership mask (HexT::plane_mask: boolean algebra on the stone / edge-connection planes), running
 // on into the next plane of the same state or plane 0 of the next state.  It needs nine words (three planes x {two
@@ -1702,6 +1796,31 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
         f, static_cast<uint32_t>(b->n), make_fast_div(static_cast<uint32_t>(size)), magic, shift, static_cast<uint32_t>(total), d_out);
     else k_observation_row_pieces<TttPieces, false, 8><<<dim3(g8), dim3(kPieceBlock), 0, ctx->stream>>>(
         f, static_cast<uint32_t>(b->n), make_fast_div(static_cast<uint32_t>(size)), magic, shift, static_cast<uint32_t>(total), d_out);
+  } else if (pieces && b->spec.desc.game_kind == kKuhn && d.num_players == 2) {
+    uint32_t magic = 0, shift = 0;
+    find_div_magic(static_cast<uint32_t>(size), static_cast<uint32_t>(size) + 1024u, &magic, &shift);
+#define OSG_KUHNP(W) do {                                                                                               \
+      Kuhn2Pieces<W> f{static_cast<const uint64_t*>(b->d_words), player};                                               \
+      if (nt) k_observation_row_pieces<Kuhn2Pieces<W>, true, 4><<<dim3(piece_grid), dim3(kPieceBlock), 0, ctx->stream>>>( \
+          f, static_cast<uint32_t>(b->n), make_fast_div(static_cast<uint32_t>(size)), magic, shift, static_cast<uint32_t>(total), d_out); \
+      else k_observation_row_pieces<Kuhn2Pieces<W>, false, 4><<<dim3(piece_grid), dim3(kPieceBlock), 0, ctx->stream>>>(  \
+          f, static_cast<uint32_t>(b->n), make_fast_div(static_cast<uint32_t>(size)), magic, shift, static_cast<uint32_t>(total), d_out); \
+    } while (0)
+    if (which == 0) OSG_KUHNP(0); else OSG_KUHNP(1);
+#undef OSG_KUHNP
+  } else if (pieces && b->spec.desc.game_kind == kLeduc && d.num_players == 2) {
+    uint32_t magic = 0, shift = 0;
+    find_div_magic(static_cast<uint32_t>(size), static_cast<uint32_t>(size) + 1024u, &magic, &shift);
+    const int K = b->spec.leduc.iso ? b->spec.leduc.cards / 2 : b->spec.leduc.cards;
+#define OSG_LEDUCP(W) do {                                                                                              \
+      Leduc2Pieces<W> f{static_cast<const uint64_t*>(b->d_words), static_cast<uint32_t>(b->n), player, K, b->spec.leduc}; \
+      if (nt) k_observation_row_pieces<Leduc2Pieces<W>, true, 4><<<dim3(piece_grid), dim3(kPieceBlock), 0, ctx->stream>>>( \
+          f, static_cast<uint32_t>(b->n), make_fast_div(static_cast<uint32_t>(size)), magic, shift, static_cast<uint32_t>(total), d_out); \
+      else k_observation_row_pieces<Leduc2Pieces<W>, false, 4><<<dim3(piece_grid), dim3(kPieceBlock), 0, ctx->stream>>>(  \
+          f, static_cast<uint32_t>(b->n), make_fast_div(static_cast<uint32_t>(size)), magic, shift, static_cast<uint32_t>(total), d_out); \
+    } while (0)
+    if (which == 0) OSG_LEDUCP(0); else OSG_LEDUCP(1);
+#undef OSG_LEDUCP
   } else if (pieces && b->spec.desc.game_kind == kHex && which == 0 && d.obs_shape[0] == 9 &&
              d.obs_shape[1] * d.obs_shape[2] >= 29) {   // (a span of 4096 floats then touches at most 18 states)
     const uint32_t cells = static_cast<uint32_t>(d.obs_shape[1] * d.obs_shape[2]);

@@ -142,6 +142,34 @@ def test_synth_batch_other_games(ctx, checker, game, depth_mod, n):
     np.testing.assert_array_equal(rets, rec["rets1"])
 
 
+@pytest.mark.parametrize("game,depth_mod,n", [("kuhn_poker", 3, (1 << 22) + 1), ("leduc_poker", 8, (1 << 21) + 3),
+                                              ("leduc_poker(suit_isomorphism=True)", 8, (1 << 21) + 1),
+                                              ("connect_four(egocentric_obs_tensor=True)", 30, (1 << 18) + 1),
+                                              ("tic_tac_toe", 7, (1 << 20) + 2), ("hex(board_size=9)", 60, (1 << 15) + 3)])
+def test_piece_form_tensors_equal_the_span_kernels(ctx, game, depth_mod, n):
+    """From 2^24 floats on the tensors are packed by the piece-form kernels (one aligned 16-byte piece per thread);
+    below, by the span-per-wavefront kernels that the small-size tests compare with the oracle entry by entry.  The
+    same states packed whole (piece form) and in chunks below the threshold (span kernels) must give the same bytes:
+    observation and information-state tensors, for every player and for "the player to move" (-1)."""
+    import torch
+    import open_spiel_amd as osa
+    b = osa.StateBatch(ctx, game, n)
+    b.synth(99, depth_mod)
+    kinds = [("observation_tensor", b.desc.obs_size)]
+    if b.desc.info_size:
+        kinds.append(("information_state_tensor", b.desc.info_size))
+    for name, size in kinds:
+        assert n * size >= 1 << 24
+        chunk = ((1 << 24) - 1) // size
+        for player in [-1] + list(range(b.num_players)):
+            whole = getattr(b, name)(player)
+            for first in range(0, n, chunk):
+                idx = torch.arange(first, min(n, first + chunk), device="cuda")
+                part = getattr(b.gather(idx), name)(player)
+                assert torch.equal(whole[first:first + idx.numel()], part), (game, name, player, first)
+            del whole
+
+
 def test_synth_batch_argument_checks(ctx):
     import open_spiel_amd as osa
     b = osa.StateBatch(ctx, "connect_four", 64)

@@ -341,15 +341,24 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
         del big
         if rank == 0:
             three = osa.TabularSolver(ctx, "leduc_poker(players=3)")
-            three.evaluate_and_update_policy(2)
+            three.evaluate_and_update_policy(5)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             three.evaluate_and_update_policy(10)
             torch.cuda.synchronize()
             dt3 = time.perf_counter() - t0
+            h3, p3 = three.num_histories, 3
+            bytes_per_iteration = h3 * (4 + 1 + 2 * p3 * 8) * p3     # H x (parent 4 + action 1 + 2 P 8) per player pass
             out["cfr"]["leduc_3_players"] = {"value": 10 / dt3, "unit": "iterations/s", "us_per_iteration": dt3 / 10 * 1e6,
-                                             "workload": "leduc_poker(players=3) CFRSolver, 1.83 M histories: one launch per tree "
-                                                         "level and phase over the whole grid"}
+                                             "algorithmic_bytes_per_iteration": bytes_per_iteration,
+                                             "frac_of_hbm_peak": bytes_per_iteration * 10 / dt3 / 1e9 / HBM_PEAK_GBS,
+                                             "workload": "leduc_poker(players=3) CFRSolver, 1.83 M histories / 25 800 infostates: ONE "
+                                                         "cooperative launch (k_cfr_sub), a workgroup per private-deal subtree (336 of "
+                                                         "~5 450 histories, values and policy rows in LDS), two grid barriers per player "
+                                                         "pass; tables bit-identical with the launch-per-phase kernels (1 850 it/s)",
+                                             "note": "bound by memory round trips between dependent phases (terminal values and policy rows "
+                                                     "in, member records, terms out, fold), not by bytes: profiles/r04_probe_cfr_sub.log has "
+                                                     "the phase stamps"}
             del three
     except Exception as e:  # noqa: BLE001 - a secondary figure must never cost the line
         out["cfr"]["leduc"] = {"error": f"{type(e).__name__}: {e}"}

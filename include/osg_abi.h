@@ -336,7 +336,11 @@ typedef struct {
                                     the single-workgroup path kernel; 4 = auto's choice for trees that
                                     start with their chance deals and split into <= #CUs subtrees of
                                     <= 1024 histories (leduc_poker): one workgroup per deal subtree,
-                                    one grid barrier per player pass                             */
+                                    one grid barrier per player pass; 5 = auto's choice for the big
+                                    trees of that shape (3-player leduc_poker: 1.8 M histories): ONE
+                                    cooperative launch, a workgroup per deal subtree of up to 8192
+                                    histories, two grid barriers per player pass (alternating
+                                    updates only)                                                 */
   int32_t replicas;              /* 0 or 1: one solver.  B > 1: B independent solvers of the same
                                     game advanced together, one workgroup each (CFR family, trees
                                     that fit LDS); select one with osg_cfr_select_replica         */

@@ -30,6 +30,8 @@
 // can all-reduce the [I, Amax] delta tables once per mini-batch (RCCL) before
 // every rank folds them in.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -512,8 +514,9 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
 // Where a pass's 8.3 us go (leduc, wall_clock64 of workgroup 0): A 2.4 (nine levels of LDS round trip + barrier), B 1.3,
 // drain 0.4, counter barrier 1.8, C 1.85 (one memory round trip + fold), regret matching + barrier 0.6.
 // One barrier per pass, no second one: the rows a subtree needs next are the rows it has just folded itself.
-// The grid (one workgroup per subtree, <= the number of CUs, ~100 KB of LDS each) is co-resident on an otherwise idle
-// device; every spin is bounded (a timeout raises err[0] and every workgroup leaves).
+// The grid (one workgroup per subtree, <= the number of CUs, ~100 KB of LDS each) is launched COOPERATIVELY: the runtime
+// starts it only when all its workgroups fit the device at once, so the barrier cannot starve behind another stream's
+// kernels (tests/test_gpu_cfr.py runs it beside a matmul loop); the spin keeps a wall-clock bound against a hung device.
 // ---------------------------------------------------------------------------
 struct SplitTree {
   int G, L, NL, NM, NI;          // subtrees, cut level, padded histories / members / infostates per subtree
@@ -675,9 +678,13 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
         __hip_atomic_fetch_add(&sp.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned int want = epoch * static_cast<unsigned int>(sp.G);
         int ok = 0;
-        for (int spin = 0; spin < (1 << 20); ++spin) {
+        // (the launch is cooperative: every workgroup IS resident; the bound — 4 s of the 100 MHz wall clock — only
+        // keeps a broken device from spinning for ever)
+        const unsigned long long t0 = wall_clock64();
+        for (;;) {
           if (__hip_atomic_load(&sp.bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = 1; break; }
           if (__hip_atomic_load(&sp.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+          if (wall_clock64() - t0 > 400000000ull) break;
           __builtin_amdgcn_s_sleep(1);
         }
         if (!ok) {
@@ -687,7 +694,7 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
         *s_ok = ok;
       }
       __syncthreads();
-      if (!*s_ok) return;  // a workgroup never arrived (the grid was not co-resident): leave the tables untouched
+      if (!*s_ok) return;  // a workgroup never arrived within seconds (a hung device): leave, the host reports it
       // ---- C: the thread's infostate: fold ALL its members' terms in DFS order, RM+ clamp, regret matching ----
       if (c_i >= 0 && (upd < 0 || c_pl == upd)) {
         // the row in registers for the whole fold (one LDS read, one write-back); kSplitChunk members' records are
@@ -846,6 +853,352 @@ __global__ void __launch_bounds__(256) k_gcfr_fold(GridCfr g, int upd, osg_cfr_c
     for (int a = 0; a < n; ++a)
       if (g.tb.regrets[i * A + a] < 0) g.tb.regrets[i * A + a] = 0;
   regret_match_row(g.tb.regrets + i * A, g.tb.cur + i * A, n);
+}
+
+// ---------------------------------------------------------------------------
+// Large trees as ONE persistent, cooperative launch (k_cfr_sub): the multi-launch form above spends an iteration of
+// 3-player leduc_poker (1.83 M histories) on ~58 launch boundaries of 4-6 us each and on a fold in which 25 856
+// threads walk their members serially (540 us per iteration, ~7 % of the bytes' roofline).  Here the tree is cut
+// below its leading chance levels like k_cfr_split's: every subtree (one private deal: 336 of ~5 450 histories for
+// 3-player leduc) belongs to ONE workgroup of 1024 threads, which sweeps its levels bottom-up with the values of the
+// updating player in LDS and workgroup barriers only, then writes its members' regret / average-policy terms
+// (root-path products as in k_gcfr_members).  Two grid barriers per player pass: terms -> fold -> next pass.  The fold
+// takes ONE WAVEFRONT per infostate: the lanes fetch the members' terms together, every lane adds them in member
+// (DFS) order — the same additions in the same order as every other CFR kernel here, so the tables stay
+// bit-identical — and lane 0 regret-matches the row.  Everything that crosses workgroups (terms, skip flags, the
+// three tables) moves with write-through stores and cache-bypassing loads, so the barrier is the counter form
+// (drain, workgroup barrier, one agent-scope add, one polling lane) without cache-wide fences.  Alternating
+// updates only (one value per history in LDS); the launch is cooperative, so the grid IS co-resident.
+// Reference: cfr.cc:331-408 (ComputeCounterFactualRegret), 443-469, 596-615.
+// ---------------------------------------------------------------------------
+struct SubTree {
+  int G, L, NL;                  // subtrees, cut level, padded histories per subtree
+  const int32_t* nloc;           // [G] histories of the subtree
+  const int32_t* desc;           // [G, NL] kind | nchild << 2 | level << 10 | (actor + 1) << 16
+  const int32_t* fc;             // [G, NL] LOCAL index of the first child
+  const int32_t* aux;            // [G, NL] decision: its index d among the subtree's decision histories; chance /
+                                 //          terminal: the history's global index
+  int ND;                        // padded decision histories per subtree
+  const int32_t* ndec;           // [G]
+  const int32_t* dec_row;        // [G, ND] info * A of decision history d
+  const int32_t* mem_off;        // [G * P + 1] the subtree's members of player q: sub_mem[mem_off[g * P + q] ...)
+  const int32_t* sub_rec;        // [., 4 + PL] per member: m (position in Tree::mem), its history's local index, its decision
+                                 //   index | actions << 24, its first child's local index, its root path (SmallTree::path codes, -1 padded)
+  int PL;                        // kSubPathChunk or 2 kSubPathChunk
+  const int32_t* info_off;       // [P + 1] infostates of player q: info_list[info_off[q] ...)
+  const int32_t* info_list;
+  double* dreg;                  // [M, A]
+  double* dpol;                  // [M, A]
+  int32_t* skip;                 // [M]
+  unsigned int* bar;             // [0] arrival counter, [1] error flag (both zeroed per launch)
+  unsigned int* host_err;        // pinned host word raised on a timeout: the next call reads it without a copy
+  unsigned long long timeout_ticks;
+  unsigned long long* stamps;    // null, or [P][5] wall-clock stamps of workgroup 0 in the launch's last iteration
+};
+OSG_D double readlane_f64(double v, int lane) {   // lane is wave-uniform: two v_readlane_b32, no LDS permute
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane(static_cast<int>(b), lane), hi = __builtin_amdgcn_readlane(static_cast<int>(b >> 32), lane);
+  return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+OSG_D void store_through_i32(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+OSG_D int32_t load_through_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+constexpr int kSubThreads = 1024;
+constexpr int kSubKD = 4;            // decision histories per thread: ND <= 4096
+constexpr int kSubFoldInfos = 64;    // infostates a workgroup folds per round (one wavefront adds them up)
+constexpr int kSubFoldX = 2;         // member records a thread fetches per round: <= 2048 per round
+constexpr int kSubPathChunk = 12;    // root-path entries requested together; a member keeps PL = 12 or 24 of them
+template <int kK>   // histories per thread: NL <= kK * 1024
+__global__ void __launch_bounds__(kSubThreads)
+k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg) {
+  extern __shared__ __attribute__((aligned(16))) double s_value[];   // [NL] the updating player's values
+  double* s_pol = s_value + sp.NL;                                   // [ND, A] the current policy of the subtree's rows
+  __shared__ int s_ok;
+  __shared__ int s_lvl[2 * kK];
+  __shared__ int s_fi[kSubFoldInfos], s_fn[kSubFoldInfos], s_fm0[kSubFoldInfos], s_fcnt[kSubFoldInfos], s_fbase[kSubFoldInfos + 1], s_fne;
+  const int P = t.P, A = t.A, tid = threadIdx.x;
+  unsigned int epoch = 0;
+  // one polling lane per workgroup; false = a workgroup never arrived (cannot happen in a cooperative launch short of
+  // a hung device: the bound only keeps a broken device from spinning for ever)
+  auto grid_barrier = [&]() -> bool {
+    ++epoch;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_fetch_add(&sp.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int want = epoch * gridDim.x;
+      const unsigned long long t0 = wall_clock64();
+      int ok = 1;
+      while (__hip_atomic_load(&sp.bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        if (__hip_atomic_load(&sp.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+            wall_clock64() - t0 > sp.timeout_ticks) { ok = 0; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!ok) {
+        __hip_atomic_store(&sp.bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sp.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+  };
+  for (int it = 0; it < iters; ++it) {
+    const int iteration = iteration0 + it + 1;
+    for (int upd = 0; upd < P; ++upd) {
+      const bool stamp = sp.stamps && it == iters - 1 && blockIdx.x == 0 && tid == 0;
+      if (stamp) sp.stamps[upd * 5 + 0] = wall_clock64();
+      for (int g = blockIdx.x; g < sp.G; g += gridDim.x) {
+        // ---- the thread's histories of this subtree: descriptors in registers for the sweep ----
+        const int nloc = sp.nloc[g];
+        int o_d[kK], o_fc[kK], o_aux[kK];
+#pragma unroll
+        for (int k = 0; k < kK; ++k) {
+          const int j = tid + k * kSubThreads;
+          o_d[k] = kTerminalNode | (63 << 10);   // padding: a terminal of a level never swept
+          o_fc[k] = 0; o_aux[k] = 0;
+          if (j < nloc) {
+            o_d[k] = sp.desc[static_cast<size_t>(g) * sp.NL + j];
+            o_fc[k] = sp.fc[static_cast<size_t>(g) * sp.NL + j];
+            o_aux[k] = sp.aux[static_cast<size_t>(g) * sp.NL + j];
+          }
+        }
+        if (stamp && g == blockIdx.x) sp.stamps[P * 5 + upd * 2 + 1] = wall_clock64();
+        // the level range of every slot (its first and its last valid history), for the sweep's (slot, level) walk
+#pragma unroll
+        for (int k = 0; k < kK; ++k) {
+          const int j = tid + k * kSubThreads;
+          if (tid == 0 && j < nloc) s_lvl[2 * k] = (o_d[k] >> 10) & 0x3F;
+          if (j < nloc && (tid == kSubThreads - 1 || j == nloc - 1)) s_lvl[2 * k + 1] = (o_d[k] >> 10) & 0x3F;
+        }
+        // ---- A: everything the sweep reads from memory is requested at once — the terminal values and the policy
+        //      rows of the subtree's decision histories, into LDS: the levels then cost an LDS round trip and a
+        //      workgroup barrier each, not a trip to the L2 (1.6 us per level before: 23 us per sweep) ----
+#pragma unroll
+        for (int k = 0; k < kK; ++k) {
+          const int j = tid + k * kSubThreads;
+          if (j < nloc && (o_d[k] & 3) == kTerminalNode) s_value[j] = t.term_ret[static_cast<size_t>(o_aux[k]) * P + upd];
+        }
+        const int ndec = sp.ndec[g];
+        {
+          int rows[kSubKD];   // the thread's decision histories: all their rows are requested before the first arrives
+#pragma unroll
+          for (int k = 0; k < kSubKD; ++k) {
+            const int d = tid + k * kSubThreads;
+            rows[k] = d < ndec ? sp.dec_row[static_cast<size_t>(g) * sp.ND + d] : -1;
+          }
+#pragma unroll
+          for (int k = 0; k < kSubKD; ++k) {
+#pragma unroll
+            for (int a = 0; a < kSplitMaxA; ++a)
+              if (rows[k] >= 0 && a < A) s_pol[(tid + k * kSubThreads) * A + a] = load_through(tb.cur + rows[k] + a);
+          }
+        }
+        __syncthreads();
+        if (stamp && g == blockIdx.x) sp.stamps[P * 5 + upd * 2] = wall_clock64();
+        // bottom-up (cfr.cc:443-469).  Slot k of the threads covers the local indices [1024 k, 1024 k + 1023], a
+        // contiguous run in level order, i.e. a workgroup-uniform range of levels: the sweep walks (slot, level) pairs
+        // from the deepest, ONE slot's body per step (testing all slots at every level cost more instructions than
+        // the values themselves).  A history's children have larger indices: an earlier step has produced them.
+#pragma unroll
+        for (int k = kK - 1; k >= 0; --k) {
+          if (k * kSubThreads >= nloc) continue;                                  // (workgroup-uniform)
+          const int l_lo = s_lvl[2 * k], l_hi = s_lvl[2 * k + 1] < t.D - 2 ? s_lvl[2 * k + 1] : t.D - 2;
+          const int kind = o_d[k] & 3, mine = (o_d[k] >> 10) & 0x3F, nc = (o_d[k] >> 2) & 0xFF;
+          for (int l = l_hi; l >= l_lo; --l) {
+            if (mine == l && kind != kTerminalNode) {
+              double v = 0.0;
+              if (kind == kChanceNode) {
+                const int gc = t.first_child[o_aux[k]];
+                for (int a = 0; a < nc; ++a) v += t.edge_prob[gc + a] * s_value[o_fc[k] + a];
+              } else {
+                for (int a = 0; a < nc; ++a) v += s_pol[o_aux[k] * A + a] * s_value[o_fc[k] + a];
+              }
+              s_value[tid + k * kSubThreads] = v;
+            }
+            __syncthreads();
+          }
+        }
+        if (stamp && g == blockIdx.x) sp.stamps[upd * 5 + 1] = wall_clock64();
+        // ---- B: the updating player's members of this subtree (k_gcfr_members) ----
+        // A member's record is one contiguous run of ints — {m, local history, decision index | actions << 24, local
+        // first child, then its root path, -1 padded} — in the order the subtree visits its members: ONE round trip
+        // brings everything but the probabilities on the path, a second one those; the products are formed in path
+        // order (which is what keeps the tables bit-identical).
+        const int m_begin = sp.mem_off[g * P + upd], m_end = sp.mem_off[g * P + upd + 1];
+        for (int mm = m_begin + tid; mm < m_end; mm += kSubThreads) {
+          const int4* rec = reinterpret_cast<const int4*>(sp.sub_rec + static_cast<size_t>(mm) * (4 + sp.PL));
+          const int4 head = rec[0];
+          const int m = head.x, hl = head.y, d = head.z & 0xFFFFFF, n = (head.z >> 24) & 0xFF, lfc = head.w;
+          double reach[kMaxPlayers + 1];
+#pragma unroll
+          for (int q = 0; q <= kMaxPlayers; ++q) reach[q] = 1.0;
+          for (int c = 0; c < sp.PL; c += kSubPathChunk) {   // (one chunk for paths of up to 12 entries, two up to 24)
+            int code[kSubPathChunk];
+            double pr[kSubPathChunk];
+#pragma unroll
+            for (int j = 0; j < kSubPathChunk / 4; ++j) {
+              const int4 v4 = rec[1 + c / 4 + j];
+              code[4 * j] = v4.x; code[4 * j + 1] = v4.y; code[4 * j + 2] = v4.z; code[4 * j + 3] = v4.w;
+            }
+#pragma unroll
+            for (int j = 0; j < kSubPathChunk; ++j) {
+              const int idx = code[j] < 0 ? 0 : code[j] & 0x7FFFFF;
+              pr[j] = ((code[j] >> 23) & 1) ? t.edge_prob[idx] : load_through(tb.cur + idx);   // (a -1 code reads entry 0: unused)
+            }
+#pragma unroll
+            for (int j = 0; j < kSubPathChunk; ++j) {
+              const int slot = code[j] < 0 ? -1 : (code[j] >> 24) & 0xF;
+#pragma unroll
+              for (int q = 0; q <= kMaxPlayers; ++q) reach[q] = (q == slot) ? reach[q] * pr[j] : reach[q];
+            }
+          }
+          bool pruned = true;
+          double self_reach = 0.0, cf_reach = 1.0;
+#pragma unroll
+          for (int q = 0; q <= kMaxPlayers; ++q) {
+            if (q < P) pruned &= (reach[q] == 0.0);
+            if (q == upd) self_reach = reach[q];
+            else if (q <= P) cf_reach *= reach[q];
+          }
+          store_through_i32(sp.skip + m, pruned ? 1 : 0);
+          if (pruned) continue;
+          const double vh = s_value[hl];
+          for (int a = 0; a < n; ++a) {
+            store_through(sp.dreg + static_cast<size_t>(m) * A + a, cf_reach * (s_value[lfc + a] - vh));
+            const double pol = s_pol[d * A + a];
+            store_through(sp.dpol + static_cast<size_t>(m) * A + a, cfg.linear_averaging ? iteration * self_reach * pol : self_reach * pol);
+          }
+        }
+        __syncthreads();   // (the next subtree of this workgroup reuses s_value)
+      }
+      if (stamp) sp.stamps[upd * 5 + 2] = wall_clock64();
+      if (!grid_barrier()) return;
+      if (stamp) sp.stamps[upd * 5 + 3] = wall_clock64();
+      // ---- C: fold (k_gcfr_fold's additions, in its order).  A workgroup takes a contiguous share of the updating
+      //      player's infostates; all its threads fetch the members' records together into LDS (the values / policy
+      //      region is free now), then ONE thread per infostate adds its members in member (DFS) order — a serial chain
+      //      of ~40 additions fed from LDS — clamps (RM+), regret-matches and writes the row through.  (One wavefront
+      //      per infostate with the sums formed by lane broadcasts was 19-23 us: ~13 broadcasts per member.) ----
+      {
+        const int i_begin = sp.info_off[upd], i_end = sp.info_off[upd + 1];
+        const int share = (i_end - i_begin + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+        int e0 = i_begin + static_cast<int>(blockIdx.x) * share;
+        const int e_last = e0 + share < i_end ? e0 + share : i_end;
+        const int rsz = 2 * A + 1;                                           // doubles per record: skip | dreg[A] | dpol[A]
+        const int cap_lds = (sp.NL + sp.ND * A) / rsz;
+        const int cap = cap_lds < kSubFoldX * kSubThreads ? cap_lds : kSubFoldX * kSubThreads;
+        double* s_rec = s_value;
+        while (e0 < e_last) {
+          if (tid < kSubFoldInfos) {
+            const int e = e0 + tid;
+            int cnt = 0;
+            if (e < e_last) {
+              const int i = sp.info_list[e];
+              s_fi[tid] = i;
+              s_fn[tid] = t.nact[i];
+              s_fm0[tid] = t.mem_off[i];
+              cnt = t.mem_off[i + 1] - s_fm0[tid];
+            }
+            s_fcnt[tid] = cnt;
+          }
+          __syncthreads();
+          if (tid == 0) {   // how many infostates fit this round
+            int base = 0, ne = 0;
+            for (; ne < kSubFoldInfos && e0 + ne < e_last; ++ne) {
+              if (base + s_fcnt[ne] > cap && ne > 0) break;
+              s_fbase[ne] = base;
+              base += s_fcnt[ne];
+            }
+            s_fbase[ne] = base;
+            s_fne = ne;
+          }
+          __syncthreads();
+          const int ne = s_fne, total = s_fbase[ne];
+          // the infostate's own row, requested now, needed after the barrier
+          double reg[kSplitMaxA], cum[kSplitMaxA];
+#pragma unroll
+          for (int a = 0; a < kSplitMaxA; ++a) { reg[a] = 0.0; cum[a] = 0.0; }
+          if (tid < ne) {
+#pragma unroll
+            for (int a = 0; a < kSplitMaxA; ++a)
+              if (a < s_fn[tid]) {
+                reg[a] = load_through(tb.regrets + static_cast<size_t>(s_fi[tid]) * A + a);
+                cum[a] = load_through(tb.cum + static_cast<size_t>(s_fi[tid]) * A + a);
+              }
+          }
+          {
+            int xm[kSubFoldX], xn[kSubFoldX], xs[kSubFoldX];
+            double xr[kSubFoldX][kSplitMaxA], xp[kSubFoldX][kSplitMaxA];
+#pragma unroll
+            for (int u = 0; u < kSubFoldX; ++u) {
+              const int x = tid + u * kSubThreads;
+              xm[u] = -1; xn[u] = 0; xs[u] = 1;
+              if (x < total) {
+                int lo = 0, hi = ne;                       // the infostate of record x: s_fbase[lo] <= x < s_fbase[lo + 1]
+                while (hi - lo > 1) {
+                  const int mid = (lo + hi) >> 1;
+                  if (s_fbase[mid] <= x) lo = mid; else hi = mid;
+                }
+                xm[u] = s_fm0[lo] + (x - s_fbase[lo]);
+                xn[u] = s_fn[lo];
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < kSubFoldX; ++u) {
+              if (xm[u] < 0) continue;
+              xs[u] = load_through_i32(sp.skip + xm[u]);   // (a skipped member's terms are stale: fetched all the same, never added)
+#pragma unroll
+              for (int a = 0; a < kSplitMaxA; ++a)
+                if (a < xn[u]) {
+                  xr[u][a] = load_through(sp.dreg + static_cast<size_t>(xm[u]) * A + a);
+                  xp[u][a] = load_through(sp.dpol + static_cast<size_t>(xm[u]) * A + a);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kSubFoldX; ++u) {
+              if (xm[u] < 0) continue;
+              double* r = s_rec + static_cast<size_t>(tid + u * kSubThreads) * rsz;
+              r[0] = xs[u] ? 1.0 : 0.0;
+#pragma unroll
+              for (int a = 0; a < kSplitMaxA; ++a)
+                if (a < xn[u]) { r[1 + a] = xr[u][a]; r[1 + A + a] = xp[u][a]; }
+            }
+          }
+          __syncthreads();
+          if (tid < ne) {
+            const int n = s_fn[tid];
+            for (int x = s_fbase[tid]; x < s_fbase[tid + 1]; ++x) {   // member order
+              const double* r = s_rec + static_cast<size_t>(x) * rsz;
+              if (r[0] != 0.0) continue;
+#pragma unroll
+              for (int a = 0; a < kSplitMaxA; ++a)
+                if (a < n) { reg[a] += r[1 + a]; cum[a] += r[1 + A + a]; }
+            }
+            double sum_pos = 0.0;
+#pragma unroll
+            for (int a = 0; a < kSplitMaxA; ++a) {
+              if (cfg.regret_matching_plus && reg[a] < 0) reg[a] = 0;
+              if (a < n && reg[a] > 0) sum_pos += reg[a];
+            }
+#pragma unroll
+            for (int a = 0; a < kSplitMaxA; ++a) {
+              if (a < n) {
+                const double pol = sum_pos > 0 ? (reg[a] > 0 ? reg[a] / sum_pos : 0.0) : 1.0 / n;
+                store_through(tb.regrets + static_cast<size_t>(s_fi[tid]) * A + a, reg[a]);
+                store_through(tb.cum + static_cast<size_t>(s_fi[tid]) * A + a, cum[a]);
+                store_through(tb.cur + static_cast<size_t>(s_fi[tid]) * A + a, pol);
+              }
+            }
+          }
+          __syncthreads();   // (the records' LDS is reused by the next round / the next pass's sweep)
+          e0 += ne;
+        }
+      }
+      if (stamp) sp.stamps[upd * 5 + 4] = wall_clock64();
+      if (!grid_barrier()) return;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1677,6 +2030,16 @@ struct osg_cfr {
           *d_split_glob = nullptr, *d_split_mem_m = nullptr, *d_split_mem_hloc = nullptr, *d_split_info = nullptr;
   double* d_split_terms = nullptr;
   unsigned int* d_split_bar = nullptr;
+  // one cooperative launch, a workgroup per deal subtree of any size (k_cfr_sub)
+  bool sub_ok = false;
+  int sub_G = 0, sub_L = 0, sub_NL = 0, sub_K = 0, sub_grid = 0;
+  size_t sub_lds_bytes = 0;
+  int sub_ND = 0, sub_PL = 0;
+  int32_t *d_sub_ndec = nullptr, *d_sub_dec_row = nullptr, *d_sub_rec = nullptr;
+  int32_t *d_sub_nloc = nullptr, *d_sub_desc = nullptr, *d_sub_fc = nullptr, *d_sub_aux = nullptr, *d_sub_mem_off = nullptr,
+          *d_sub_info_off = nullptr, *d_sub_info_list = nullptr;
+  unsigned int* d_sub_bar = nullptr;
+  unsigned int* h_sub_err = nullptr;   // pinned: raised by the kernel when a grid barrier times out
   // policy evaluation (k_policy_eval)
   std::vector<int32_t> info_level, mem_index;
   bool eval_ok = true;  // every infostate's members sit on one tree level
@@ -2126,6 +2489,144 @@ int build_split(osg_cfr* s) {
   return OSG_OK;
 }
 
+
+// The subtrees of k_cfr_sub: the same cut as build_split (the first level with a node that is not a chance node),
+// any number of subtrees (a workgroup takes several in turn when the cooperative grid is smaller), up to 8 x 1024
+// histories each.
+template <int kK> const void* cfr_sub_kernel() { return reinterpret_cast<const void*>(&k_cfr_sub<kK>); }
+int build_sub(osg_cfr* s) {
+  s->sub_ok = false;
+  if (s->cfg.solver != 0 || s->B != 1 || !s->path_kernel || s->A > kSplitMaxA || !s->cfg.alternating_updates) return OSG_OK;
+  if (s->H < 4096 || s->D >= 63 || s->H >= (1 << 23)) return OSG_OK;
+  int L = 0;
+  for (; L < s->D; ++L) {
+    bool all_chance = true;
+    for (int h = s->level_off[L]; h < s->level_off[L + 1]; ++h) all_chance &= s->kind[h] == kChanceNode;
+    if (!all_chance) break;
+  }
+  if (L < 1 || L >= s->D - 1) return OSG_OK;
+  const int G = s->level_off[L + 1] - s->level_off[L];
+  if (G < 8) return OSG_OK;
+  std::vector<std::vector<int32_t>> hist(G);
+  std::vector<int32_t> sub_of(s->H, -1), loc_of(s->H, -1), level_of(s->H, 0);
+  for (int l = 0; l < s->D; ++l)
+    for (int h = s->level_off[l]; h < s->level_off[l + 1]; ++h) level_of[h] = l;
+  for (int g = 0; g < G; ++g) sub_of[s->level_off[L] + g] = g;
+  for (int h = s->level_off[L]; h < s->H; ++h) {
+    if (h >= s->level_off[L + 1]) sub_of[h] = sub_of[s->parent[h]];
+    const int g = sub_of[h];
+    loc_of[h] = static_cast<int32_t>(hist[g].size());
+    hist[g].push_back(h);
+  }
+  int NL = 0;
+  for (int g = 0; g < G; ++g) NL = std::max<int>(NL, static_cast<int>(hist[g].size()));
+  const int K = NL <= 2 * kSubThreads ? 2 : (NL <= 4 * kSubThreads ? 4 : 8);
+  if (NL > 8 * kSubThreads) return OSG_OK;
+  const size_t M = s->mem.size();
+  std::vector<std::vector<int32_t>> members(static_cast<size_t>(G) * s->P);
+  for (size_t m = 0; m < M; ++m) {
+    const int h = s->mem[m];
+    if (sub_of[h] < 0) return OSG_OK;  // a decision node above the cut
+    members[static_cast<size_t>(sub_of[h]) * s->P + s->actor[h]].push_back(static_cast<int32_t>(m));
+  }
+  std::vector<int32_t> nloc(G), desc(static_cast<size_t>(G) * NL, kTerminalNode | (63 << 10)), fc(static_cast<size_t>(G) * NL, 0),
+      aux(static_cast<size_t>(G) * NL, 0), mem_off(static_cast<size_t>(G) * s->P + 1, 0), sub_rec,
+      info_off(s->P + 1, 0), info_list;
+  int longest_path = 0;
+  for (size_t m = 0; m < M; ++m) longest_path = std::max(longest_path, s->path_off[m + 1] - s->path_off[m]);
+  if (longest_path > 2 * kSubPathChunk) return OSG_OK;   // a root path with more entries than the packed form keeps
+  const int PL = longest_path <= kSubPathChunk ? kSubPathChunk : 2 * kSubPathChunk;
+  std::vector<std::vector<int32_t>> dec_rows(G);
+  int32_t n_members = 0;
+  for (int g = 0; g < G; ++g) {
+    nloc[g] = static_cast<int32_t>(hist[g].size());
+    for (size_t j = 0; j < hist[g].size(); ++j) {
+      const int h = hist[g][j];
+      const size_t at = static_cast<size_t>(g) * NL + j;
+      desc[at] = s->kind[h] | (s->nchild[h] << 2) | (level_of[h] << 10) | ((s->actor[h] + 1) << 16);
+      fc[at] = s->kind[h] == kTerminalNode ? 0 : loc_of[s->first_child[h]];
+      aux[at] = h;
+      if (s->kind[h] == kDecisionNode) {
+        aux[at] = static_cast<int32_t>(dec_rows[g].size());
+        dec_rows[g].push_back(s->info[h] * s->A);
+      }
+    }
+    for (int q = 0; q < s->P; ++q) {
+      for (int32_t m : members[static_cast<size_t>(g) * s->P + q]) {
+        const int h = s->mem[m];
+        const size_t at = static_cast<size_t>(g) * NL + loc_of[h];
+        sub_rec.push_back(m);
+        sub_rec.push_back(loc_of[h]);
+        sub_rec.push_back(aux[at] | (static_cast<int32_t>(s->nact[s->info[h]]) << 24));
+        sub_rec.push_back(fc[at]);
+        const int len = s->path_off[m + 1] - s->path_off[m];
+        for (int e = 0; e < PL; ++e) sub_rec.push_back(e < len ? s->path[s->path_off[m] + e] : -1);
+        ++n_members;
+      }
+      mem_off[static_cast<size_t>(g) * s->P + q + 1] = n_members;
+    }
+  }
+  for (int q = 0; q < s->P; ++q) {
+    for (int i = 0; i < s->I; ++i)
+      if (s->info_player[i] == q) info_list.push_back(i);
+    info_off[q + 1] = static_cast<int32_t>(info_list.size());
+  }
+  int ND = 1;
+  for (int g = 0; g < G; ++g) ND = std::max<int>(ND, static_cast<int>(dec_rows[g].size()));
+  std::vector<int32_t> ndec(G), dec_row(static_cast<size_t>(G) * ND, 0);
+  for (int g = 0; g < G; ++g) {
+    ndec[g] = static_cast<int32_t>(dec_rows[g].size());
+    std::copy(dec_rows[g].begin(), dec_rows[g].end(), dec_row.begin() + static_cast<size_t>(g) * ND);
+  }
+  const size_t lds = sizeof(double) * (static_cast<size_t>(NL) + static_cast<size_t>(ND) * s->A);
+  if (lds > 150 * 1024 || ND > kSubKD * kSubThreads) return OSG_OK;
+  int widest = 0;   // the fold stages an infostate's member records in LDS: all of one infostate must fit a round
+  for (int i = 0; i < s->I; ++i) widest = std::max(widest, s->mem_off[i + 1] - s->mem_off[i]);
+  if (widest > std::min<int>(static_cast<int>((NL + static_cast<size_t>(ND) * s->A) / (2 * s->A + 1)), kSubFoldX * kSubThreads)) return OSG_OK;
+  const void* kern = K == 2 ? cfr_sub_kernel<2>() : (K == 4 ? cfr_sub_kernel<4>() : cfr_sub_kernel<8>());
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
+    (void)hipGetLastError();
+    return OSG_OK;
+  }
+  int per_cu = 0;
+  hipError_t e;
+  if (K == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cfr_sub<2>, kSubThreads, lds);
+  else if (K == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cfr_sub<4>, kSubThreads, lds);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cfr_sub<8>, kSubThreads, lds);
+  hipDeviceProp_t prop;
+  if (e != hipSuccess || per_cu < 1 || hipGetDeviceProperties(&prop, s->ctx->device) != hipSuccess || !prop.cooperativeLaunch) {
+    (void)hipGetLastError();
+    return OSG_OK;
+  }
+  const int grid = std::min(G, per_cu * prop.multiProcessorCount);
+  hipStream_t st = s->ctx->stream;
+  int rc;
+  if ((rc = upload(nloc, &s->d_sub_nloc, st)) || (rc = upload(desc, &s->d_sub_desc, st)) || (rc = upload(fc, &s->d_sub_fc, st)) ||
+      (rc = upload(aux, &s->d_sub_aux, st)) || (rc = upload(mem_off, &s->d_sub_mem_off, st)) ||
+      (rc = upload(sub_rec, &s->d_sub_rec, st)) ||
+      (rc = upload(info_off, &s->d_sub_info_off, st)) || (rc = upload(info_list, &s->d_sub_info_list, st)) ||
+      (rc = upload(ndec, &s->d_sub_ndec, st)) || (rc = upload(dec_row, &s->d_sub_dec_row, st)))
+    return rc;
+  s->sub_ND = ND;
+  s->sub_PL = PL;
+  OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_sub_bar), sizeof(unsigned int) * 4));
+  OSG_HIP(hipMemsetAsync(s->d_sub_bar, 0, sizeof(unsigned int) * 4, st));
+  OSG_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_sub_err), sizeof(unsigned int), hipHostMallocMapped));
+  *s->h_sub_err = 0;
+  s->sub_G = G; s->sub_L = L; s->sub_NL = NL; s->sub_K = K; s->sub_grid = grid; s->sub_lds_bytes = lds;
+  s->sub_ok = true;
+  return OSG_OK;
+}
+
+
+// A grid barrier of k_cfr_sub that timed out (a hung device: the launch is cooperative) leaves the tables mixed: the
+// solver refuses further work.  The kernel raises a pinned host word, read here without a copy or a wait.
+int cfr_sub_error(osg_cfr* s) {
+  if (s->h_sub_err && __atomic_load_n(s->h_sub_err, __ATOMIC_RELAXED) != 0)
+    return set_error(OSG_ERR_HIP, "k_cfr_sub: a grid barrier timed out in an earlier launch; the tables are not usable");
+  return OSG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2227,6 +2728,7 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
   rc = build_resident_tree(s);
   if (rc) { osg_cfr_destroy(s); return rc; }
   rc = build_split(s);
+  if (rc == OSG_OK) rc = build_sub(s);
   if (rc) { osg_cfr_destroy(s); return rc; }
   rc = init_tables(s);
   if (rc) { osg_cfr_destroy(s); return rc; }
@@ -2243,9 +2745,11 @@ int osg_cfr_destroy(osg_cfr* s) {
                   s->d_best, s->d_eval, s->d_meta32, s->d_info_player32, s->d_skip, s->d_node_delta, s->d_rec,
                   s->d_uret, s->d_uprob, s->d_spare_delta[0], s->d_spare_delta[1], s->d_split_nloc, s->d_split_desc,
                   s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
-                  s->d_split_terms, s->d_split_bar};
+                  s->d_split_terms, s->d_split_bar, s->d_sub_nloc, s->d_sub_desc, s->d_sub_fc, s->d_sub_aux, s->d_sub_mem_off,
+                  s->d_sub_info_off, s->d_sub_info_list, s->d_sub_bar, s->d_sub_ndec, s->d_sub_dec_row, s->d_sub_rec};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (s->h_sub_err) (void)hipHostFree(s->h_sub_err);
   osg::ctx_release(s->ctx);
   delete s;
   return OSG_OK;
@@ -2272,6 +2776,47 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
   const unsigned grid_b = static_cast<unsigned>(s->B);
   // Trees far beyond one workgroup: full-grid launches per phase (osg_cfr_cfg.kernel == 2 forces it).
   const bool grid_path = s->path_kernel && s->B == 1 && (s->cfg.kernel == 2 || (s->cfg.kernel == 0 && s->H > 65536));
+  // Trees too big for one workgroup: the persistent cooperative launch with a workgroup per deal subtree where the
+  // tree has that shape (kernel == 5 forces it, 2 forces the per-phase launches), else a launch per phase.
+  const bool sub_path = s->sub_ok && s->B == 1 && (s->cfg.kernel == 5 || (s->cfg.kernel == 0 && grid_path));
+  if (sub_path) {
+    if (int rc = cfr_sub_error(s)) return rc;
+    const int M = static_cast<int>(s->mem.size());
+    Tree tr = s->tree();
+    SmallTree stree{s->d_path_off, s->d_path, M, static_cast<int>(s->path.size())};
+    SubTree sp{s->sub_G, s->sub_L, s->sub_NL, s->d_sub_nloc, s->d_sub_desc, s->d_sub_fc, s->d_sub_aux, s->sub_ND, s->d_sub_ndec,
+               s->d_sub_dec_row, s->d_sub_mem_off,
+               s->d_sub_rec, s->sub_PL, s->d_sub_info_off, s->d_sub_info_list, s->d_node_delta,
+               s->d_node_delta + static_cast<size_t>(M) * s->A, s->d_skip, s->d_sub_bar, s->h_sub_err, 400000000ull /* 4 s at 100 MHz */, nullptr};
+    static unsigned long long* d_stamps = nullptr;   // OSG_CFR_SUB_STAMPS=1: phase stamps of workgroup 0 (tools/probe_cfr_sub.py)
+    if (std::getenv("OSG_CFR_SUB_STAMPS")) {
+      if (!d_stamps) OSG_HIP(hipMalloc(reinterpret_cast<void**>(&d_stamps), sizeof(unsigned long long) * 8 * kMaxPlayers));
+      sp.stamps = d_stamps;
+    }
+    hipStream_t st = s->ctx->stream;
+    const int per_launch = std::max(1, (1 << 30) / std::max(1, 2 * s->P * s->sub_grid));  // the arrival counter is 32 bits
+    for (int done = 0; done < iters; done += per_launch) {
+      int now = std::min(per_launch, iters - done), it0 = s->iteration + done;
+      OSG_HIP(hipMemsetAsync(s->d_sub_bar, 0, sizeof(unsigned int) * 2, st));
+      void* args[] = {&tr, &stree, &sp, &tb, &now, &it0, &s->cfg};
+      const void* kern = s->sub_K == 2 ? cfr_sub_kernel<2>() : (s->sub_K == 4 ? cfr_sub_kernel<4>() : cfr_sub_kernel<8>());
+      OSG_HIP(hipLaunchCooperativeKernel(kern, dim3(static_cast<unsigned>(s->sub_grid)), dim3(kSubThreads), args,
+                                         static_cast<unsigned>(s->sub_lds_bytes), st));
+    }
+    if (sp.stamps) {
+      unsigned long long h[8 * kMaxPlayers];
+      OSG_HIP(hipMemcpyAsync(h, sp.stamps, sizeof(unsigned long long) * 7 * s->P, hipMemcpyDeviceToHost, st));
+      OSG_HIP(hipStreamSynchronize(st));
+      for (int q = 0; q < s->P; ++q)
+        fprintf(stderr, "k_cfr_sub pass %d (workgroup 0, us): descriptors %.2f  preload %.2f  levels %.2f |  sweep %.2f  members %.2f  barrier %.2f  fold %.2f  (pass %.2f)\n", q,
+                (h[s->P * 5 + q * 2 + 1] - h[q * 5]) / 100.0, (h[s->P * 5 + q * 2] - h[s->P * 5 + q * 2 + 1]) / 100.0,
+                (h[q * 5 + 1] - h[s->P * 5 + q * 2]) / 100.0,
+                (h[q * 5 + 1] - h[q * 5]) / 100.0, (h[q * 5 + 2] - h[q * 5 + 1]) / 100.0, (h[q * 5 + 3] - h[q * 5 + 2]) / 100.0,
+                (h[q * 5 + 4] - h[q * 5 + 3]) / 100.0, q + 1 < s->P ? (h[(q + 1) * 5] - h[q * 5]) / 100.0 : 0.0);
+    }
+    s->iteration += iters;
+    return OSG_OK;
+  }
   if (grid_path) {
     const int M = static_cast<int>(s->mem.size());
     GridCfr g;
@@ -2312,9 +2857,17 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
       const int now = std::min(per_launch, iters - done);
       OSG_HIP(hipMemsetAsync(s->d_split_bar, 0, sizeof(unsigned int) * 2, st));
       const dim3 grid(static_cast<unsigned>(s->split_G)), block(static_cast<unsigned>(s->split_threads));
-      if (s->P == 2) k_cfr_split<3><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->cfg);
-      else if (s->P == 3) k_cfr_split<4><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->cfg);
-      else k_cfr_split<kMaxPlayers + 1><<<grid, block, s->split_lds_bytes, st>>>(s->tree(), stree, sp, tb, now, s->iteration + done, s->cfg);
+      // A COOPERATIVE launch: the kernel spins on a grid barrier, so its workgroups must be resident together — with
+      // another stream keeping the device busy (a network's forward pass beside the solver) a plain launch can start
+      // some workgroups while the others queue behind foreign work, and the barrier's bound then turns a slowdown
+      // into an error.  The cooperative launch waits until the whole grid fits.
+      Tree tr = s->tree();
+      int now_arg = now, it0 = s->iteration + done;
+      void* args[] = {&tr, &stree, &sp, &tb, &now_arg, &it0, &s->cfg};
+      const void* kern = s->P == 2 ? reinterpret_cast<const void*>(&k_cfr_split<3>)
+                                   : (s->P == 3 ? reinterpret_cast<const void*>(&k_cfr_split<4>)
+                                                : reinterpret_cast<const void*>(&k_cfr_split<kMaxPlayers + 1>));
+      OSG_HIP(hipLaunchCooperativeKernel(kern, grid, block, args, static_cast<unsigned>(s->split_lds_bytes), st));
     }
     OSG_HIP(hipGetLastError());
     s->iteration += iters;
@@ -2625,8 +3178,8 @@ int osg_cfr_tables(const osg_cfr* s, int32_t* nact, int32_t* legal, double* regr
   if (s->split_ok) OSG_HIP(hipMemcpyAsync(&split_error, s->d_split_bar + 2, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
   OSG_HIP(hipStreamSynchronize(st));
   if (split_error)
-    return set_error(OSG_ERR_HIP, "k_cfr_split: a grid barrier timed out (the workgroups were not co-resident: another kernel "
-                                  "held CUs for seconds); the iterations of that launch were dropped — use osg_cfr_cfg.kernel = 3");
+    return set_error(OSG_ERR_HIP, "k_cfr_split: a grid barrier timed out after seconds (the launch is cooperative: this is a hung "
+                                  "device, not contention); the tables are not usable — osg_cfr_cfg.kernel = 3 runs one workgroup");
   if (cum_policy) memcpy(cum_policy, cum.data(), bytes);
   if (avg_policy) {  // CFRAveragePolicy::GetStatePolicyFromInformationStateValues (cfr.cc:104-125)
     for (int i = 0; i < s->I; ++i) {

@@ -380,7 +380,7 @@ class TabularSolver:
         self.game_string = game_string
         solver = {False: 0, True: 1, "external": 1, "outcome": 2}[mccfr]
         cfg = _abi.CfrCfg(int(alternating_updates), int(linear_averaging), int(regret_matching_plus),
-                          solver, float(epsilon), {False: 0, True: 1, "grid": 2, "path": 3, "split": 4}[general_kernel], int(replicas),
+                          solver, float(epsilon), {False: 0, True: 1, "grid": 2, "path": 3, "split": 4, "sub": 5}[general_kernel], int(replicas),
                           int(random_initial_regrets), int(seed), int(replica_offset))
         self.replicas = int(replicas)
         h = C.c_void_p()

@@ -1978,7 +1978,12 @@ template <class T>
 int upload(const std::vector<T>& v, T** d, hipStream_t stream) {
   const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
   OSG_HIP(hipMalloc(reinterpret_cast<void**>(d), bytes));
-  if (!v.empty()) OSG_HIP(hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+  if (!v.empty()) {
+    OSG_HIP(hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+    // The callers pass vectors that die when they return, and a large copy from pageable memory may still be reading
+    // the host buffer after the call (seen once as a GPU fault at a host address with an 87 MB vector): wait.
+    if (v.size() * sizeof(T) > (64u << 10)) OSG_HIP(hipStreamSynchronize(stream));
+  }
   return OSG_OK;
 }
 

@@ -2204,8 +2204,9 @@ enum class AverageType { kSimple, kFull };
 
 // The MCCFR solvers' text checkpoints (external_sampling_mccfr.cc:82-120,233-288;
 // outcome_sampling_mccfr.cc:76-112,243-300): same sections in the same order as the reference.
-// Deviation: [SolverRNG] holds this engine's counter-RNG position, "counter <seed> <next trajectory>",
-// not a std::mt19937 dump (the reference's random streams are not reproduced).
+// [SolverRNG] holds the solver's std::mt19937 exactly as the reference writes it (operator<<), so checkpoints travel
+// both ways, followed by one line of this engine's own, "counter <seed> <next trajectory>" — the position of the
+// counter streams its mini-batches draw from — which the reference's reader (operator>>) never reaches.
 constexpr const char* kSerializeSolverRNGSectionHeader = "[SolverRNG]";
 constexpr const char* kSerializeSolverAverageTypeSectionHeader = "[SolverAverageType]";
 constexpr const char* kSerializeSolverEpsilonSectionHeader = "[SolverEpsilon]";
@@ -2403,11 +2404,13 @@ class OutcomeSamplingMCCFRSolver : public DeviceTabularSolver {  // outcome_samp
  public:
   static constexpr double kDefaultEpsilon = 0.6;
   explicit OutcomeSamplingMCCFRSolver(const Game& game, double epsilon = kDefaultEpsilon, int seed = -1)
-      : DeviceTabularSolver(game, true, false, false, 2, epsilon), seed_(seed < 0 ? 0 : seed), epsilon_(epsilon),
-        game_string_(game.Serialize()) {}
-  void RunIteration() {  // one SampleEpisode per player, each seeing the previous one's update (:67-74)
-    for (int p = 0; p < num_players_; ++p) Check(osg_mccfr_iterate(s_, seed_, next_++, 1));
-  }
+      : DeviceTabularSolver(game, true, false, false, 2, epsilon), seed_(seed < 0 ? 0 : seed),
+        rng_(seed >= 0 ? static_cast<std::mt19937::result_type>(seed) : std::mt19937::default_seed),  // outcome_sampling_mccfr.cc:44-48
+        epsilon_(epsilon), game_string_(game.Serialize()) {}
+  // One SampleEpisode per player, each seeing the previous one's update (:67-74), drawing on the solver's own
+  // std::mt19937 like the reference's RunIteration() (outcome_sampling_mccfr.h:63): the generator advances with the
+  // iterations and travels in the checkpoint.
+  void RunIteration() { RunIteration(&rng_); }
   // outcome_sampling_mccfr.h:61-62.  The reference draws through abseil's distributions (unspecified streams);
   // here every episode takes a fresh 64-bit stream key from the caller's generator: the same distribution of
   // episodes, reproducible from the generator's state, not the reference's draw sequence.
@@ -2428,7 +2431,11 @@ class OutcomeSamplingMCCFRSolver : public DeviceTabularSolver {  // outcome_samp
     str += std::string(kSerializeGameSectionHeader) + "\n" + game_string_ + "\n";
     str += std::string(kSerializeSolverTypeSectionHeader) + "\nOutcomeSamplingMCCFRSolver\n";
     str += std::string(kSerializeSolverSpecificStateSectionHeader) + "\n";
-    str += std::string(kSerializeSolverRNGSectionHeader) + "\ncounter " + std::to_string(seed_) + " " +
+    // [SolverRNG]: the generator as the reference writes it (operator<< of std::mt19937, :94-98), then this engine's
+    // counter-stream position on a line of its own (the reference's `rng_stream >> rng_` stops before it)
+    std::ostringstream rng_stream;
+    rng_stream << rng_;
+    str += std::string(kSerializeSolverRNGSectionHeader) + "\n" + rng_stream.str() + "\ncounter " + std::to_string(seed_) + " " +
            std::to_string(next_) + "\n";
     str += std::string(kSerializeSolverEpsilonSectionHeader) + "\n" + FormatDouble(epsilon_, -1) + "\n";
     str += std::string(kSerializeSolverDefaultPolicySectionHeader) + "\nUniformPolicy:\n";
@@ -2436,12 +2443,18 @@ class OutcomeSamplingMCCFRSolver : public DeviceTabularSolver {  // outcome_samp
     return str + SerializeValuesTable(InfoStateValuesTable(), double_precision, delimiter);
   }
   void RestoreCounter(uint64_t seed, int64_t next) { seed_ = seed; next_ = next; }
+  void RestoreGenerator(const std::string& state) {  // outcome_sampling_mccfr.cc:281-283
+    std::istringstream in(state);
+    in >> rng_;
+    if (in.fail()) SpielFatalError("[SolverRNG] does not hold a std::mt19937 state");
+  }
   int64_t EpisodesRun() const { return next_; }
   double Epsilon() const { return epsilon_; }
 
  private:
   uint64_t seed_;
   int64_t next_ = 0;
+  std::mt19937 rng_;
   double epsilon_;
   std::string game_string_;
 };
@@ -2499,13 +2512,25 @@ inline std::unique_ptr<OutcomeSamplingMCCFRSolver> DeserializeOutcomeSamplingMCC
   const PartialCheckpoint c = PartiallyDeserializeSolver(serialized);
   if (c.solver_type != "OutcomeSamplingMCCFRSolver")
     SpielFatalError("checkpoint holds a " + c.solver_type + ", not an OutcomeSamplingMCCFRSolver");
-  uint64_t seed;
-  int64_t next;
-  internal::ParseCounter(internal::SpecificLine(c, kSerializeSolverRNGSectionHeader), &seed, &next);
+  // [SolverRNG]: the reference's mt19937 dump (a checkpoint written by the reference loads here and vice versa),
+  // optionally followed by this engine's "counter <seed> <next>" line (older checkpoints hold that line alone).
+  uint64_t seed = 0;
+  int64_t next = 0;
+  std::string generator;
+  {
+    size_t i = 0;
+    while (i < c.specific.size() && c.specific[i] != kSerializeSolverRNGSectionHeader) ++i;
+    if (i == c.specific.size()) SpielFatalError("solver checkpoint without a [SolverRNG] section");
+    for (++i; i < c.specific.size() && c.specific[i][0] != '['; ++i) {
+      if (c.specific[i].rfind("counter ", 0) == 0) internal::ParseCounter(c.specific[i], &seed, &next);
+      else generator += c.specific[i] + " ";
+    }
+  }
   const double epsilon = std::strtod(internal::SpecificLine(c, kSerializeSolverEpsilonSectionHeader).c_str(), nullptr);
   std::shared_ptr<const Game> game = LoadGame(c.game);
   auto solver = std::make_unique<OutcomeSamplingMCCFRSolver>(*game, epsilon, static_cast<int>(seed));
   solver->RestoreCounter(seed, next);
+  if (!generator.empty()) solver->RestoreGenerator(generator);
   solver->LoadInfoStateValuesTable(DeserializeValuesTable(c.table, delimiter), /*allow_missing=*/true);
   return solver;
 }

@@ -824,6 +824,8 @@ int osgo_cfr_serialize(void* h, int double_precision, char* buf, int cap) {
 #ifdef OSGO_GENUINE_REFERENCE
   return Guard([&] {
     auto* c = static_cast<CfrH*>(h);
+    if (c->mccfr) return CopyStr(c->mccfr->Serialize(double_precision), buf, cap);       // external_sampling_mccfr.cc:82-120
+    if (c->osmccfr) return CopyStr(c->osmccfr->Serialize(double_precision), buf, cap);   // outcome_sampling_mccfr.cc:76-112
     ORACLE_CHECK(c->cfr);
     return CopyStr(c->cfr->Serialize(double_precision), buf, cap);
   });
@@ -833,7 +835,7 @@ int osgo_cfr_serialize(void* h, int double_precision, char* buf, int cap) {
   return -1;
 #endif
 }
-// kind: 0 CFRSolver, 1 CFRPlusSolver.
+// kind: 0 CFRSolver, 1 CFRPlusSolver, 2 / 3 ExternalSamplingMCCFRSolver, 5 OutcomeSamplingMCCFRSolver.
 void* osgo_cfr_deserialize(const char* text, int kind) {
 #ifdef OSGO_GENUINE_REFERENCE
   try {
@@ -841,6 +843,8 @@ void* osgo_cfr_deserialize(const char* text, int kind) {
     const std::string serialized(text);
     h->game = PartiallyDeserializeCFRSolver(serialized).game;
     if (kind == 0) h->cfr = DeserializeCFRSolver(serialized);
+    else if (kind == 2 || kind == 3) h->mccfr = DeserializeExternalSamplingMCCFRSolver(serialized);
+    else if (kind == 5) h->osmccfr = DeserializeOutcomeSamplingMCCFRSolver(serialized);
     else h->cfr = DeserializeCFRPlusSolver(serialized);
     return h;
   } catch (const std::exception& e) {

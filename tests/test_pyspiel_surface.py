@@ -230,13 +230,11 @@ def test_mccfr_solver_pickle_round_trip(pyspiel, kind):
     text = solver.serialize()
     name = "ExternalSamplingMCCFRSolver" if kind == "external" else "OutcomeSamplingMCCFRSolver"
     assert f"[SolverType]\n{name}\n[SolverSpecificState]\n[SolverRNG]\n" in text
-    if kind == "external":
-        # the solver's std::mt19937 as the reference dumps it (RunIteration() draws from it), then the position of
-        # the counter streams (the mini-batch drew 5000 trajectories from them)
-        rng = text.split("[SolverRNG]\n")[1].split("[SolverAverageType]")[0].split("\n")
-        assert len(rng[0].split()) == 625 and rng[1] == "counter 7 5000"
-    else:
-        assert "[SolverRNG]\ncounter 7 5020\n" in text
+    # the solver's std::mt19937 as the reference dumps it (RunIteration() draws from it), then the position of the
+    # counter streams (external: the mini-batch drew 5000 trajectories from them; outcome: 10 iterations x 2 episodes
+    # took a stream index each, then 5000)
+    rng = text.split("[SolverRNG]\n")[1].split("[SolverAverageType]" if kind == "external" else "[SolverEpsilon]")[0].split("\n")
+    assert len(rng[0].split()) == 625 and rng[1] == ("counter 7 5000" if kind == "external" else "counter 7 5020")
     assert ("[SolverAverageType]\nSimpleAverageType\n" if kind == "external" else "[SolverEpsilon]\n") in text
     assert "[SolverDefaultPolicy]\nUniformPolicy:\n[SolverValuesTable]\n" in text
     restored = pickle.loads(pickle.dumps(solver))

@@ -3339,7 +3339,7 @@ int osg_observation_string(const osg_batch* b, int64_t index, int player, char* 
     return set_error(OSG_ERR_INVALID, "osg_observation_string: bad argument");
   const osg_game_desc& d = b->spec.desc;
   if (player < 0 || player >= d.num_players) return set_error(OSG_ERR_INVALID, "player id out of range");
-  uint64_t w[4 * 4 + 1] = {0};
+  uint64_t w[4 * 12 + 1] = {0};   // (hex 19 x 19: 4 planes of 12 words and the meta word)
   const char* base = static_cast<const char*>(b->d_words);
   for (int k = 0; k < d.state_words; ++k)
     OSG_HIP(hipMemcpyAsync(&w[k], base + (static_cast<size_t>(k) * b->n + index) * d.state_word_bytes, d.state_word_bytes,
@@ -3357,11 +3357,15 @@ int osg_observation_string(const osg_batch* b, int64_t index, int player, char* 
     }
     case kC4: {  // connect_four.cc:212-222: top row first, every row ends with a newline
       const int R = b->spec.c4.rows, Cn = b->spec.c4.cols;
-      const uint64_t x = b->spec.c4_std ? (w[0] & ((1ull << 56) - 1ull)) : w[0], o = w[1];
+      osg_u128 x = b->spec.c4_std ? (w[0] & ((1ull << 56) - 1ull)) : w[0], o = w[1];
+      if (b->spec.c4_wide) {   // two plane words per colour: x.lo, x.hi, o.lo, o.hi
+        x = (static_cast<osg_u128>(w[1]) << 64) | w[0];
+        o = (static_cast<osg_u128>(w[3]) << 64) | w[2];
+      }
       for (int r = R - 1; r >= 0; --r) {
         for (int c = 0; c < Cn; ++c) {
           const int bit = c * (R + 1) + r;
-          out += (x >> bit & 1ull) ? "x" : ((o >> bit & 1ull) ? "o" : ".");
+          out += static_cast<uint32_t>(x >> bit & 1) ? "x" : (static_cast<uint32_t>(o >> bit & 1) ? "o" : ".");
         }
         out += "\n";
       }
@@ -3369,13 +3373,8 @@ int osg_observation_string(const osg_batch* b, int64_t index, int player, char* 
     }
     case kHex: {  // hex.cc:341-359: one line per row, indented by the row number, a space after every cell
       const int NW = b->spec.hex_nw;
-      int cols = 0, cells = 0;
-      switch (NW) {
-        case 1: cols = b->spec.hex1.cols; cells = b->spec.hex1.cells; break;
-        case 2: cols = b->spec.hex2.cols; cells = b->spec.hex2.cells; break;
-        case 3: cols = b->spec.hex3.cols; cells = b->spec.hex3.cells; break;
-        default: cols = b->spec.hex4.cols; cells = b->spec.hex4.cells; break;
-      }
+      int cols = 0, rows_unused = 0, cells = 0;
+      hex_dims(b->spec, &rows_unused, &cols, &cells);
       auto bit = [&](int plane, int cell) { return (w[plane * NW + (cell >> 5)] >> (cell & 31)) & 1ull; };
       int line = 0;
       for (int i = 0; i < cells; ++i) {
@@ -3430,14 +3429,7 @@ int fetch_state_words(const osg_batch* b, int64_t index, uint64_t* w) {
   return OSG_OK;
 }
 const char* leduc_action_name(int a) { return a == 0 ? "Fold" : (a == 1 ? "Call" : "Raise"); }  // leduc_poker.cc:869-875
-void hex_geometry(const GameSpec& spec, int* cols, int* rows, int* cells) {
-  switch (spec.hex_nw) {
-    case 1: *cols = spec.hex1.cols; *rows = spec.hex1.rows; *cells = spec.hex1.cells; break;
-    case 2: *cols = spec.hex2.cols; *rows = spec.hex2.rows; *cells = spec.hex2.cells; break;
-    case 3: *cols = spec.hex3.cols; *rows = spec.hex3.rows; *cells = spec.hex3.cells; break;
-    default: *cols = spec.hex4.cols; *rows = spec.hex4.rows; *cells = spec.hex4.cells; break;
-  }
-}
+void hex_geometry(const GameSpec& spec, int* cols, int* rows, int* cells) { hex_dims(spec, rows, cols, cells); }
 int return_string(const std::string& out, char* buf, int cap) {
   if (static_cast<int>(out.size()) + 1 > cap) return set_error(OSG_ERR_INVALID, "buffer too small");
   memcpy(buf, out.c_str(), out.size() + 1);
@@ -3451,7 +3443,7 @@ int osg_state_string(const osg_batch* b, int64_t index, char* buf, int cap) {
   const osg_game_desc& d = b->spec.desc;
   if (d.game_kind == kTtt || d.game_kind == kC4 || d.game_kind == kHex)
     return osg_observation_string(b, index, 0, buf, cap);  // ObservationString is ToString() in these games
-  uint64_t w[4 * 4 + 1] = {0};
+  uint64_t w[4 * 12 + 1] = {0};   // (hex 19 x 19: 4 planes of 12 words and the meta word)
   int rc = fetch_state_words(b, index, w);
   if (rc) return rc;
   std::string out;

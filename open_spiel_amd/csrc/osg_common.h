@@ -107,30 +107,43 @@ constexpr int kFillKeyBits = 40;
 // ---------------------------------------------------------------------------
 // Legal-action mask: up to 128 actions, bit a of word a/32.
 // ---------------------------------------------------------------------------
-struct Mask {
-  uint32_t w[kMaskWords];
-  OSG_HD Mask() : w{0, 0, 0, 0} {}
+template <int W>
+struct MaskT {
+  uint32_t w[W];
+  OSG_HD MaskT() {
+#pragma unroll
+    for (int k = 0; k < W; ++k) w[k] = 0u;
+  }
   // No dynamic indexing of w[]: a runtime index would demote the mask from
   // VGPRs to LDS/scratch (measured: 3x on the connect_four step kernel).
   OSG_HD void set(int a) {
     const uint32_t bit = 1u << (a & 31);
     const int i = a >> 5;
 #pragma unroll
-    for (int k = 0; k < kMaskWords; ++k) w[k] |= (i == k) ? bit : 0u;
+    for (int k = 0; k < W; ++k) w[k] |= (i == k) ? bit : 0u;
   }
   OSG_HD bool test(int a) const {
     const int i = a >> 5;
     uint32_t v = 0;
 #pragma unroll
-    for (int k = 0; k < kMaskWords; ++k) v |= (i == k) ? w[k] : 0u;
+    for (int k = 0; k < W; ++k) v |= (i == k) ? w[k] : 0u;
     return (v >> (a & 31)) & 1u;
   }
-  OSG_HD bool any() const { return (w[0] | w[1] | w[2] | w[3]) != 0; }
+  OSG_HD bool any() const {
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) v |= w[k];
+    return v != 0;
+  }
   OSG_HD int count() const {
-    return __builtin_popcount(w[0]) + __builtin_popcount(w[1]) + __builtin_popcount(w[2]) +
-           __builtin_popcount(w[3]);
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) c += __builtin_popcount(w[k]);
+    return c;
   }
 };
+// The mask of every game but the hex boards above 128 actions (kMaskWords words); those carry MaskT<NW>.
+using Mask = MaskT<kMaskWords>;
 
 // Index of the k-th (0-based) set bit of a 32-bit word; k < popcount(x).
 OSG_HD int select32(uint32_t x, int k) {
@@ -150,10 +163,11 @@ OSG_HD int select32(uint32_t x, int k) {
   return pos;
 }
 // k-th legal action of a mask (actions ascending, like LegalActions()[k]).
-OSG_HD int select_action(const Mask& m, int k) {
+template <int W>
+OSG_HD int select_action(const MaskT<W>& m, int k) {
   int base = 0;
 #pragma unroll
-  for (int i = 0; i < kMaskWords; ++i) {
+  for (int i = 0; i < W; ++i) {
     int c = __builtin_popcount(m.w[i]);
     if (k < c) return base + select32(m.w[i], k);
     k -= c;

@@ -30,6 +30,7 @@ struct GenericObsCursor {
 // ===========================================================================
 struct Ttt {
   using word_t = uint32_t;
+  static constexpr int kMaskW = kMaskWords;
   struct Params {
     int words;  // = 1
   };
@@ -108,34 +109,53 @@ struct Ttt {
 // recompute the outcome (a reachable position has at most one player with a line).
 // ===========================================================================
 struct C4Params {
-  int words;  // = 2
+  int words;  // = 2 (boards of up to 64 bits), 4 (up to 128 bits: two words per colour)
   int rows, cols, k, ego;
-  uint64_t board;  // all playable cells
-  uint64_t top;    // top playable cell of every column
+  uint64_t board;  // all playable cells (low 64 bits)
+  uint64_t top;    // top playable cell of every column (low 64 bits)
+  uint64_t board_hi, top_hi;   // bits 64-127 of the same (wide boards)
+};
+typedef unsigned __int128 osg_u128;
+template <class BB> struct BitboardOps;
+template <> struct BitboardOps<uint64_t> {
+  static constexpr int kWords = 1;
+  OSG_HD static int popcount(uint64_t v) { return __builtin_popcountll(v); }
+  OSG_HD static uint64_t make(uint64_t lo, uint64_t) { return lo; }
+};
+template <> struct BitboardOps<osg_u128> {
+  static constexpr int kWords = 2;
+  OSG_HD static int popcount(osg_u128 v) {
+    return __builtin_popcountll(static_cast<uint64_t>(v)) + __builtin_popcountll(static_cast<uint64_t>(v >> 64));
+  }
+  OSG_HD static osg_u128 make(uint64_t lo, uint64_t hi) { return (static_cast<osg_u128>(hi) << 64) | lo; }
 };
 // R_/C_/K_ = 0: geometry read from Params at run time.  The default 6x7x4 game
 // is instantiated with compile-time constants (shifts by immediates, the
 // column loop fully unrolled): this is the headline kernel's game.
-template <int R_, int C_, int K_>
+// BB: the bitboard type — uint64_t while (rows + 1) * cols <= 64, unsigned __int128 (two plane words per colour:
+// x.lo, x.hi, o.lo, o.hi) up to 128 bits, e.g. 8 x 8, 9 x 9, 10 x 10, 7 x 15.
+template <int R_, int C_, int K_, class BB = uint64_t>
 struct C4T {
+  using Ops = BitboardOps<BB>;
   using word_t = uint64_t;
+  static constexpr int kMaskW = kMaskWords;
   using Params = C4Params;
   static constexpr bool kStored = R_ != 0 && (R_ + 1) * C_ <= 56;  // result kept in plane 0's top byte
   struct State {
-    uint64_t x, o;
+    BB x, o;
     uint32_t flags;  // kStored only: bit 0 terminal, bits 1-2 outcome
   };
   OSG_D static int R(const Params& p) { return R_ ? R_ : p.rows; }
   OSG_D static int C(const Params& p) { return C_ ? C_ : p.cols; }
   OSG_D static int K(const Params& p) { return K_ ? K_ : p.k; }
-  OSG_D static uint64_t top(const Params& p) {
-    if (R_ == 0) return p.top;
-    uint64_t t = 0;
+  OSG_D static BB top(const Params& p) {
+    if (R_ == 0) return Ops::make(p.top, p.top_hi);
+    BB t = 0;
 #pragma unroll
-    for (int c = 0; c < C_; ++c) t |= 1ull << (c * (R_ + 1) + R_ - 1);
+    for (int c = 0; c < C_; ++c) t |= BB(1) << (c * (R_ + 1) + R_ - 1);
     return t;
   }
-  OSG_D static State initial(const Params&) { return {0ull, 0ull, 0u}; }
+  OSG_D static State initial(const Params&) { return {BB(0), BB(0), 0u}; }
   OSG_D static State unpack(uint64_t w0, uint64_t w1) {
     if (kStored) return {w0 & ((1ull << 56) - 1ull), w1, static_cast<uint32_t>(w0 >> 56)};
     return {w0, w1, 0u};
@@ -144,21 +164,27 @@ struct C4T {
     return kStored ? (s.x | (static_cast<uint64_t>(s.flags) << 56)) : s.x;
   }
   OSG_D static State load(const Params&, const word_t* base, int64_t n, int64_t i) {
-    return unpack(base[i], base[n + i]);
+    if constexpr (Ops::kWords == 2) return {Ops::make(base[i], base[n + i]), Ops::make(base[2 * n + i], base[3 * n + i]), 0u};
+    else return unpack(base[i], base[n + i]);
   }
   OSG_D static void store(const Params&, word_t* base, int64_t n, int64_t i, const State& s) {
-    base[i] = pack0(s);
-    base[n + i] = s.o;
+    if constexpr (Ops::kWords == 2) {
+      base[i] = static_cast<uint64_t>(s.x); base[n + i] = static_cast<uint64_t>(s.x >> 64);
+      base[2 * n + i] = static_cast<uint64_t>(s.o); base[3 * n + i] = static_cast<uint64_t>(s.o >> 64);
+    } else {
+      base[i] = pack0(s);
+      base[n + i] = s.o;
+    }
   }
   // HasLine, connect_four.cc:163-201, as the classic shifted-AND test along the
   // four directions: vertical (1), horizontal (H), the two diagonals (H-1, H+1).
-  OSG_D static bool line(const Params& p, uint64_t b) {
+  OSG_D static bool line(const Params& p, BB b) {
     const int H = R(p) + 1;
     const int dirs[4] = {1, H, H - 1, H + 1};
-    uint64_t hit = 0;
+    BB hit = 0;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      uint64_t m = b;
+      BB m = b;
       if (K(p) == 4) {
         m = m & (m >> dirs[d]);
         m = m & (m >> (2 * dirs[d]));
@@ -169,7 +195,7 @@ struct C4T {
     }
     return hit != 0;
   }
-  OSG_D static int plies(const State& s) { return __builtin_popcountll(s.x | s.o); }
+  OSG_D static int plies(const State& s) { return Ops::popcount(s.x | s.o); }
   OSG_D static bool full(const Params& p, const State& s) {  // connect_four.cc:203-209
     return ((s.x | s.o) & top(p)) == top(p);
   }
@@ -181,13 +207,13 @@ struct C4T {
     return terminal(p, s) ? kTerminalPlayer : (plies(s) & 1);
   }
   OSG_D static bool column_has_room(const Params& p, const State& s, int col) {  // connect_four.cc:153
-    return col < C(p) && !(((s.x | s.o) >> (col * (R(p) + 1) + R(p) - 1)) & 1ull);
+    return col < C(p) && !static_cast<uint32_t>(((s.x | s.o) >> (col * (R(p) + 1) + R(p) - 1)) & BB(1));
   }
   // Bit c set = column c still has room, whatever the state of the game.
   OSG_D static uint32_t open_columns(const Params& p, const State& s) {
     const int H = R(p) + 1;
-    uint64_t free_top = ~(s.x | s.o) & top(p);
-    if (R_ == 6 && C_ == 7) {
+    BB free_top = ~(s.x | s.o) & top(p);
+    if constexpr (R_ == 6 && C_ == 7) {
       // One multiply instead of seven extracts: the top cells sit at bits 5 + 7c; after >> 5 they
       // are at 7c, and multiplying by sum_k 2^(36 - 6k) moves bit 7k to 36 + k.  No two partial
       // products share a bit (7(i - i') = 6(k - k') has no solution with |k - k'| <= 6): no carries.
@@ -197,9 +223,9 @@ struct C4T {
     uint32_t m = 0;
     if (C_ != 0) {
 #pragma unroll
-      for (int c = 0; c < C_; ++c) m |= static_cast<uint32_t>((free_top >> (c * H + R(p) - 1)) & 1ull) << c;
+      for (int c = 0; c < C_; ++c) m |= static_cast<uint32_t>((free_top >> (c * H + R(p) - 1)) & BB(1)) << c;
     } else {
-      for (int c = 0; c < p.cols; ++c) m |= static_cast<uint32_t>((free_top >> (c * H + R(p) - 1)) & 1ull) << c;
+      for (int c = 0; c < p.cols; ++c) m |= static_cast<uint32_t>((free_top >> (c * H + R(p) - 1)) & BB(1)) << c;
     }
     return m;
   }
@@ -210,10 +236,10 @@ struct C4T {
   }
   OSG_D static void apply(const Params& p, State& s, int col) {  // connect_four.cc:130-145
     const int H = R(p) + 1;
-    uint64_t all = s.x | s.o;
-    uint64_t colmask = ((1ull << R(p)) - 1ull) << (col * H);
-    uint64_t cell = (all + (1ull << (col * H))) & colmask;  // lowest empty cell
-    const int mover = __builtin_popcountll(all) & 1;
+    BB all = s.x | s.o;
+    BB colmask = ((BB(1) << R(p)) - BB(1)) << (col * H);
+    BB cell = (all + (BB(1) << (col * H))) & colmask;  // lowest empty cell
+    const int mover = Ops::popcount(all) & 1;
     if (mover) s.o |= cell; else s.x |= cell;
     if (kStored) {  // outcome_ = mover if HasLine(mover) else draw if IsFull (connect_four.cc:138-142)
       const bool win = line(p, mover ? s.o : s.x);
@@ -239,18 +265,18 @@ struct C4T {
     int plane = idx / RC, rem = idx - plane * RC;
     int r = rem / C(p), c = rem - r * C(p);
     int bit = c * (R(p) + 1) + r;
-    uint64_t first = s.x, second = s.o;
+    BB first = s.x, second = s.o;
     if (p.ego) {  // plane 0 holds kNought iff player == 0, kCross iff player == 1
       first = player == 0 ? s.o : s.x;
       second = player == 0 ? s.x : s.o;
     }
-    uint64_t bits = plane == 0 ? first : (plane == 1 ? second : ~(s.x | s.o));
-    return static_cast<float>((bits >> bit) & 1ull);
+    BB bits = plane == 0 ? first : (plane == 1 ? second : ~(s.x | s.o));
+    return static_cast<float>(static_cast<uint32_t>((bits >> bit) & BB(1)));
   }
   // Walks the tensor of one state entry by entry (same values as obs_at; plane / row / column are
   // advanced incrementally instead of being re-derived by division for every float).
   struct ObsCursor {
-    uint64_t first, second, empty;
+    BB first, second, empty;
     int plane, r, c;
     OSG_D void init(const Params& p, const State& s, int player, int /*which*/, int idx) {
       const int RC = R(p) * C(p);
@@ -267,8 +293,8 @@ struct C4T {
       empty = ~(s.x | s.o);
     }
     OSG_D float next(const Params& p, const State&, int, int) {
-      const uint64_t bits = plane == 0 ? first : (plane == 1 ? second : empty);
-      const float v = static_cast<float>((bits >> (c * (R(p) + 1) + r)) & 1ull);
+      const BB bits = plane == 0 ? first : (plane == 1 ? second : empty);
+      const float v = static_cast<float>(static_cast<uint32_t>((bits >> (c * (R(p) + 1) + r)) & BB(1)));
       if (++c == C(p)) {
         c = 0;
         if (++r == R(p)) { r = 0; ++plane; }
@@ -278,6 +304,7 @@ struct C4T {
   };
 };
 using C4 = C4T<0, 0, 0>;     // any geometry with (rows+1)*cols <= 64
+using C4Wide = C4T<0, 0, 0, osg_u128>;  // (rows+1)*cols <= 128: two plane words per colour
 using C4Std = C4T<6, 7, 4>;  // the default game, constants folded
 
 // ===========================================================================
@@ -294,6 +321,10 @@ using C4Std = C4T<6, 7, 4>;  // the default game, constants folded
 template <int NW>
 struct HexT {
   using word_t = uint32_t;
+  // boards of up to 128 actions share the engine's 4-word mask (and with it the search kernels); the big boards
+  // (13 x 13 ... 19 x 19: NW = 6, 8, 12) carry one mask word per plane word
+  static constexpr int kMaskW = NW > kMaskWords ? NW : kMaskWords;
+  using MaskType = MaskT<kMaskW>;
   struct Bits {
     uint32_t w[NW];
   };
@@ -431,8 +462,8 @@ struct HexT {
   OSG_D static int current_player(const Params& p, const State& s) {                     // hex.h:96-98
     return terminal(p, s) ? kTerminalPlayer : to_move(s);
   }
-  OSG_D static Mask legal(const Params& p, const State& s) {  // hex.cc:280-293
-    Mask m;
+  OSG_D static MaskType legal(const Params& p, const State& s) {  // hex.cc:280-293
+    MaskType m;
     if (terminal(p, s)) return m;
     Bits empty = bandn(p.board, bor(s.black, s.white));
 #pragma unroll

@@ -21,6 +21,7 @@ namespace osg {
 // ===========================================================================
 struct Kuhn {
   using word_t = uint64_t;
+  static constexpr int kMaskW = kMaskWords;
   struct Params {
     int words;  // = 1
     int players;
@@ -167,6 +168,7 @@ struct Kuhn {
 // ===========================================================================
 struct Leduc {
   using word_t = uint64_t;
+  static constexpr int kMaskW = kMaskWords;
   struct Params {
     int words;  // = 2
     int players, cards, mapping, iso, starter;

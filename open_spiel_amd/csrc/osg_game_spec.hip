@@ -158,21 +158,27 @@ int parse_game(const char* game_string, GameSpec* out) {
     int rows = rd.get_int("rows", 6), cols = rd.get_int("columns", 7), k = rd.get_int("x_in_row", 4);
     if (!rd.finish()) return set_error(OSG_ERR_INVALID, rd.err);
     if (rows < 1 || cols < 1 || k < 1) return set_error(OSG_ERR_INVALID, "connect_four: bad dimensions");
-    if ((rows + 1) * cols > 64 || cols > 32)
-      return set_error(OSG_ERR_UNSUPPORTED, "connect_four: (rows+1)*columns must fit a 64-bit board");
+    // two u64 planes while (rows + 1) * columns <= 64, four (two words per colour) up to 128 bits — 8 x 8 ... 10 x 10,
+    // 7 x 15 ...; the reference has no upper bound (connect_four.cc:50-54): larger boards stay unsupported here
+    if ((rows + 1) * cols > 128 || cols > 32)
+      return set_error(OSG_ERR_UNSUPPORTED, "connect_four: (rows+1)*columns must fit a 128-bit board (and columns <= 32)");
+    const bool wide = (rows + 1) * cols > 64;
     d.game_kind = kC4;
     d.num_distinct_actions = cols;
     d.max_game_length = rows * cols;
     d.obs_size = 3 * rows * cols; d.obs_rank = 3; d.obs_shape[0] = 3; d.obs_shape[1] = rows; d.obs_shape[2] = cols;
-    d.state_words = 2; d.state_word_bytes = 8;
+    d.state_words = wide ? 4 : 2; d.state_word_bytes = 8;
     C4::Params& p = out->c4;
-    p.words = 2; p.rows = rows; p.cols = cols; p.k = k; p.ego = ego;
+    p.words = wide ? 4 : 2; p.rows = rows; p.cols = cols; p.k = k; p.ego = ego;
     out->c4_std = (rows == 6 && cols == 7 && k == 4);
-    p.board = 0; p.top = 0;
+    out->c4_wide = wide;
+    osg_u128 board = 0, top = 0;
     for (int c = 0; c < cols; ++c) {
-      p.board |= ((1ull << rows) - 1ull) << (c * (rows + 1));
-      p.top |= 1ull << (c * (rows + 1) + rows - 1);
+      board |= ((static_cast<osg_u128>(1) << rows) - 1) << (c * (rows + 1));
+      top |= static_cast<osg_u128>(1) << (c * (rows + 1) + rows - 1);
     }
+    p.board = static_cast<uint64_t>(board); p.board_hi = static_cast<uint64_t>(board >> 64);
+    p.top = static_cast<uint64_t>(top); p.top_hi = static_cast<uint64_t>(top >> 64);
   } else if (name == "hex") {
     int bs = rd.get_int("board_size", 11);
     int cols = rd.get_int("num_cols", bs), rows = rd.get_int("num_rows", bs);
@@ -183,8 +189,10 @@ int parse_game(const char* game_string, GameSpec* out) {
     if (rep != "standard" && rep != "explicit") return set_error(OSG_ERR_INVALID, "Invalid string_rep " + rep);
     if (cols < 1 || rows < 1) return set_error(OSG_ERR_INVALID, "hex: bad dimensions");
     int cells = cols * rows;
-    if (cells + (swap ? 1 : 0) > 32 * kMaskWords || cols > 31)
-      return set_error(OSG_ERR_UNSUPPORTED, "hex: boards above 128 cells have no device layout");
+    // the planes hold up to 384 cells (19 x 19 = 361, with the swap action 362 ids); a row shift must stay below a
+    // word (cols <= 31).  The reference has no upper bound (hex.cc:47-56): larger boards stay unsupported here.
+    if (cells + (swap ? 1 : 0) > 32 * 12 || cols > 31)
+      return set_error(OSG_ERR_UNSUPPORTED, "hex: boards above 384 cells (or wider than 31 columns) have no device layout");
     if (plain && cols != rows)
       return set_error(OSG_ERR_UNSUPPORTED, "hex: plain_obs_tensor on a non-square board indexes out of "
                                             "bounds in the reference (hex.cc:382-387)");
@@ -193,16 +201,22 @@ int parse_game(const char* game_string, GameSpec* out) {
     d.max_game_length = cells;
     d.obs_rank = 3; d.obs_shape[0] = plain ? 3 : 9; d.obs_shape[1] = cols; d.obs_shape[2] = rows;
     d.obs_size = d.obs_shape[0] * cells;
-    out->hex_nw = (cells + 31) / 32;
+    // plane words: enough for every action id (the swap action is id `cells`), rounded up to an instantiated width
+    const int need = (d.num_distinct_actions + 31) / 32;
+    out->hex_nw = need <= 4 ? need : (need <= 6 ? 6 : (need <= 8 ? 8 : 12));
+    if (need <= 4 && (cells + 31) / 32 < need) out->hex_nw = need;  // (cells a multiple of 32 with swap: one more word)
     out->hex_explicit = rep == "explicit";
     d.state_words = 4 * out->hex_nw + 1; d.state_word_bytes = 4;
     // only the variant that holds the board: Bits::w has NW words, a larger board would write past it
-    out->hex1 = {}; out->hex2 = {}; out->hex3 = {}; out->hex4 = {};
+    out->hex1 = {}; out->hex2 = {}; out->hex3 = {}; out->hex4 = {}; out->hex6 = {}; out->hex8 = {}; out->hex12 = {};
     switch (out->hex_nw) {
       case 1: fill_hex<1>(&out->hex1, cols, rows, swap, plain); break;
       case 2: fill_hex<2>(&out->hex2, cols, rows, swap, plain); break;
       case 3: fill_hex<3>(&out->hex3, cols, rows, swap, plain); break;
-      default: fill_hex<4>(&out->hex4, cols, rows, swap, plain); break;
+      case 4: fill_hex<4>(&out->hex4, cols, rows, swap, plain); break;
+      case 6: fill_hex<6>(&out->hex6, cols, rows, swap, plain); break;
+      case 8: fill_hex<8>(&out->hex8, cols, rows, swap, plain); break;
+      default: fill_hex<12>(&out->hex12, cols, rows, swap, plain); break;
     }
   } else if (name == "kuhn_poker") {
     int n = rd.get_int("players", 2);

@@ -21,8 +21,9 @@ enum GameKind { kTtt = 0, kC4 = 1, kHex = 2, kKuhn = 3, kLeduc = 4 };
 // A parsed, validated game: description + the device parameter block.
 struct GameSpec {
   osg_game_desc desc;
-  int hex_nw = 0;  // u32 words per hex bit plane (1..4)
+  int hex_nw = 0;  // u32 words per hex bit plane: 1..4 (boards of up to 128 actions), 6 / 8 / 12 (up to 19 x 19)
   bool c4_std = false;  // connect_four with the default 6x7x4 geometry (constant-folded kernels)
+  bool c4_wide = false;  // connect_four above 64 board bits: two plane words per colour (C4Wide)
   bool hex_explicit = false;  // hex(string_rep=explicit): edge-connection glyphs in the board string
   Ttt::Params ttt;
   C4::Params c4;
@@ -30,6 +31,9 @@ struct GameSpec {
   HexT<2>::Params hex2;
   HexT<3>::Params hex3;
   HexT<4>::Params hex4;
+  HexT<6>::Params hex6;    // 13 x 13 (169 cells)
+  HexT<8>::Params hex8;    // 15 x 15 (225 cells)
+  HexT<12>::Params hex12;  // 19 x 19 (361 cells)
   Kuhn::Params kuhn;
   Leduc::Params leduc;
   std::map<std::string, std::string> params;  // as given + defaults (strings)
@@ -42,10 +46,21 @@ int set_error(int code, const std::string& msg);
 // colour never wins and a filled board is a state that is not terminal and has no legal action.  (The reference's
 // RandomRolloutEvaluator would index an empty LegalActions() there.)  Entry points that play out refuse these
 // boards instead of hanging the device.
+inline void hex_dims(const GameSpec& spec, int* rows, int* cols, int* cells) {
+  switch (spec.hex_nw) {
+    case 1: *rows = spec.hex1.rows; *cols = spec.hex1.cols; *cells = spec.hex1.cells; break;
+    case 2: *rows = spec.hex2.rows; *cols = spec.hex2.cols; *cells = spec.hex2.cells; break;
+    case 3: *rows = spec.hex3.rows; *cols = spec.hex3.cols; *cells = spec.hex3.cells; break;
+    case 4: *rows = spec.hex4.rows; *cols = spec.hex4.cols; *cells = spec.hex4.cells; break;
+    case 6: *rows = spec.hex6.rows; *cols = spec.hex6.cols; *cells = spec.hex6.cells; break;
+    case 8: *rows = spec.hex8.rows; *cols = spec.hex8.cols; *cells = spec.hex8.cells; break;
+    default: *rows = spec.hex12.rows; *cols = spec.hex12.cols; *cells = spec.hex12.cells; break;
+  }
+}
 inline int refuse_endless_playouts(const GameSpec& spec, const char* who) {
   if (spec.desc.game_kind != kHex) return OSG_OK;
-  const int rows = spec.hex_nw == 1 ? spec.hex1.rows : spec.hex_nw == 2 ? spec.hex2.rows : spec.hex_nw == 3 ? spec.hex3.rows : spec.hex4.rows;
-  const int cols = spec.hex_nw == 1 ? spec.hex1.cols : spec.hex_nw == 2 ? spec.hex2.cols : spec.hex_nw == 3 ? spec.hex3.cols : spec.hex4.cols;
+  int rows = 0, cols = 0, cells = 0;
+  hex_dims(spec, &rows, &cols, &cells);
   if (rows >= 2 && cols >= 2) return OSG_OK;
   return set_error(OSG_ERR_UNSUPPORTED, std::string(who) + ": hex on a board with a single row or column has states that are "
                    "neither terminal nor have a legal action (one colour can never win): playouts would not end");
@@ -98,12 +113,17 @@ struct osg_batch {
 
 // Dispatch a generic lambda-like macro body over the concrete game type.
 // Inside the body: `G` is the game struct and `P` its Params instance.
+// OSG_DISPATCH serves the games whose legal mask is the engine's 4-word Mask (every entry point of the search and solver
+// kernels); OSG_DISPATCH_WIDE adds the hex boards above 128 actions (the batch entry points of osg_kernels.hip: states,
+// masks, steps, tensors, random steps, rollouts, environment steps).
 #define OSG_DISPATCH(spec, ...)                                                   \
   do {                                                                             \
     switch ((spec).desc.game_kind) {                                               \
       case osg::kTtt: { using G = osg::Ttt; const G::Params& P = (spec).ttt; __VA_ARGS__; } break; \
       case osg::kC4:                                                               \
         if ((spec).c4_std) { using G = osg::C4Std; const G::Params& P = (spec).c4; __VA_ARGS__; } \
+        else if ((spec).c4_wide) return osg::set_error(OSG_ERR_UNSUPPORTED, "connect_four boards above 64 bits are served by " \
+                                                       "the batch entry points (states, masks, steps, tensors, rollouts), not by this one"); \
         else { using G = osg::C4; const G::Params& P = (spec).c4; __VA_ARGS__; }   \
         break;                                                                     \
       case osg::kKuhn: { using G = osg::Kuhn; const G::Params& P = (spec).kuhn; __VA_ARGS__; } break; \
@@ -113,7 +133,34 @@ struct osg_batch {
           case 1: { using G = osg::HexT<1>; const G::Params& P = (spec).hex1; __VA_ARGS__; } break; \
           case 2: { using G = osg::HexT<2>; const G::Params& P = (spec).hex2; __VA_ARGS__; } break; \
           case 3: { using G = osg::HexT<3>; const G::Params& P = (spec).hex3; __VA_ARGS__; } break; \
-          default: { using G = osg::HexT<4>; const G::Params& P = (spec).hex4; __VA_ARGS__; } break; \
+          case 4: { using G = osg::HexT<4>; const G::Params& P = (spec).hex4; __VA_ARGS__; } break; \
+          default: return osg::set_error(OSG_ERR_UNSUPPORTED, "hex boards above 128 actions are served by the batch entry " \
+                                         "points (states, masks, steps, tensors, rollouts), not by this one"); \
+        }                                                                          \
+        break;                                                                     \
+      default: return osg::set_error(OSG_ERR_INVALID, "bad game kind");            \
+    }                                                                              \
+  } while (0)
+#define OSG_DISPATCH_WIDE(spec, ...)                                              \
+  do {                                                                             \
+    switch ((spec).desc.game_kind) {                                               \
+      case osg::kTtt: { using G = osg::Ttt; const G::Params& P = (spec).ttt; __VA_ARGS__; } break; \
+      case osg::kC4:                                                               \
+        if ((spec).c4_std) { using G = osg::C4Std; const G::Params& P = (spec).c4; __VA_ARGS__; } \
+        else if ((spec).c4_wide) { using G = osg::C4Wide; const G::Params& P = (spec).c4; __VA_ARGS__; } \
+        else { using G = osg::C4; const G::Params& P = (spec).c4; __VA_ARGS__; }   \
+        break;                                                                     \
+      case osg::kKuhn: { using G = osg::Kuhn; const G::Params& P = (spec).kuhn; __VA_ARGS__; } break; \
+      case osg::kLeduc: { using G = osg::Leduc; const G::Params& P = (spec).leduc; __VA_ARGS__; } break; \
+      case osg::kHex:                                                              \
+        switch ((spec).hex_nw) {                                                   \
+          case 1: { using G = osg::HexT<1>; const G::Params& P = (spec).hex1; __VA_ARGS__; } break; \
+          case 2: { using G = osg::HexT<2>; const G::Params& P = (spec).hex2; __VA_ARGS__; } break; \
+          case 3: { using G = osg::HexT<3>; const G::Params& P = (spec).hex3; __VA_ARGS__; } break; \
+          case 4: { using G = osg::HexT<4>; const G::Params& P = (spec).hex4; __VA_ARGS__; } break; \
+          case 6: { using G = osg::HexT<6>; const G::Params& P = (spec).hex6; __VA_ARGS__; } break; \
+          case 8: { using G = osg::HexT<8>; const G::Params& P = (spec).hex8; __VA_ARGS__; } break; \
+          default: { using G = osg::HexT<12>; const G::Params& P = (spec).hex12; __VA_ARGS__; } break; \
         }                                                                          \
         break;                                                                     \
       default: return osg::set_error(OSG_ERR_INVALID, "bad game kind");            \

@@ -70,9 +70,9 @@ __global__ void __launch_bounds__(kBlock)
 k_legal_mask(typename G::Params p, const typename G::word_t* base, int64_t n, uint32_t* mask, int mask_words) {
   int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   if (i >= n) return;
-  Mask m = G::legal(p, G::load(p, base, n, i));
+  auto m = G::legal(p, G::load(p, base, n, i));
 #pragma unroll
-  for (int w = 0; w < kMaskWords; ++w)  // static indices only: a runtime index would spill the mask to scratch
+  for (int w = 0; w < G::kMaskW; ++w)  // static indices only: a runtime index would spill the mask to scratch
     if (w < mask_words) mask[i * mask_words + w] = m.w[w];
 }
 
@@ -85,8 +85,8 @@ k_apply(typename G::Params p, typename G::word_t* base, int64_t n, const int32_t
   int a = actions[i];
   if (a == OSG_INVALID_ACTION) return;
   typename G::State s = G::load(p, base, n, i);
-  Mask m = G::legal(p, s);
-  if (a < 0 || a >= 32 * kMaskWords || !m.test(a)) {
+  auto m = G::legal(p, s);
+  if (a < 0 || a >= 32 * G::kMaskW || !m.test(a)) {
     atomicAdd(illegal, 1ull);  // the compiler folds this into one add per wave
     return;
   }
@@ -117,7 +117,7 @@ k_chance_probs(typename G::Params p, const typename G::word_t* base, int64_t n, 
   if (i >= n) return;
   typename G::State s = G::load(p, base, n, i);
   bool chance = G::current_player(p, s) == kChancePlayer;
-  Mask m = G::legal(p, s);
+  auto m = G::legal(p, s);
   for (int o = 0; o < max_chance; ++o)
     probs[i * max_chance + o] = (chance && m.test(o)) ? G::chance_prob(p, s, o) : 0.0;
 }
@@ -139,17 +139,17 @@ k_step(typename G::Params p, const typename G::word_t* src, typename G::word_t* 
   int a = actions[i];
   bool illegal = false;
   if (a != 0xFF) {
-    Mask before = G::legal(p, s);
-    if (a < 32 * kMaskWords && before.test(a)) G::apply(p, s, a); else illegal = true;
+    auto before = G::legal(p, s);
+    if (a < 32 * G::kMaskW && before.test(a)) G::apply(p, s, a); else illegal = true;
   }
   G::store(p, dst, n, i, s);  // (plain stores: non-temporal ones measured mixed here — hex 22.8 -> 24.6 us at 2^20, 118 -> 104 at 2^22)
   bool term = G::terminal(p, s);
-  Mask after = G::legal(p, s);
+  auto after = G::legal(p, s);
   if (sizeof(MaskT) < 4) {
     mask_out[i] = static_cast<MaskT>(after.w[0]);
   } else {
 #pragma unroll
-    for (int w = 0; w < kMaskWords; ++w)  // static indices only (see k_legal_mask)
+    for (int w = 0; w < G::kMaskW; ++w)  // static indices only (see k_legal_mask)
       if (w < mask_elems) mask_out[i * mask_elems + w] = static_cast<MaskT>(after.w[w]);
   }
   status[i] = encode_status(term, illegal, term ? 0 : G::current_player(p, s), term ? G::outcome_code(p, s) : 0);
@@ -192,12 +192,12 @@ k_step_vec(typename G::Params p, const typename G::word_t* src, typename G::word
     const int a = av[j];
     bool illegal = false;
     if (a != 0xFF) {
-      const Mask before = G::legal(p, s);
-      if (a < 32 * kMaskWords && before.test(a)) G::apply(p, s, a); else illegal = true;
+      const auto before = G::legal(p, s);
+      if (a < 32 * G::kMaskW && before.test(a)) G::apply(p, s, a); else illegal = true;
     }
     G::store(p, tmp, V, j, s);
     const bool term = G::terminal(p, s);
-    const Mask after = G::legal(p, s);
+    const auto after = G::legal(p, s);
     mv[j] = static_cast<MaskT>(after.w[0]);
     sv[j] = encode_status(term, illegal, term ? 0 : G::current_player(p, s), term ? G::outcome_code(p, s) : 0);
   }
@@ -251,12 +251,12 @@ k_step_hexvec(typename HexT<NW>::Params p, const uint32_t* src, uint32_t* dst, i
     const int a = av[j];
     bool illegal = false;
     if (a != 0xFF) {
-      const Mask before = G::legal(p, s);
-      if (a < 32 * kMaskWords && before.test(a)) G::apply(p, s, a); else illegal = true;
+      const auto before = G::legal(p, s);
+      if (a < 32 * G::kMaskW && before.test(a)) G::apply(p, s, a); else illegal = true;
     }
     G::store(p, tmp, V, j, s);
     const bool term = G::terminal(p, s);
-    const Mask after = G::legal(p, s);
+    const auto after = G::legal(p, s);
 #pragma unroll
     for (int w = 0; w < NW; ++w) mk[j * NW + w] = after.w[w];
     sv[j] = encode_status(term, illegal, term ? 0 : G::current_player(p, s), term ? G::outcome_code(p, s) : 0);
@@ -1124,7 +1124,7 @@ k_random_steps(typename G::Params p, typename G::word_t* base, int64_t n, uint64
         s = G::initial(p);
         ++episodes;
       }
-      Mask m = G::legal(p, s);
+      auto m = G::legal(p, s);
       int a = sample_action<G>(p, s, m, G::current_player(p, s), rng);
       G::apply(p, s, a);
       ++applied;
@@ -1198,12 +1198,12 @@ k_synth(typename G::Params p, typename G::word_t* base, int64_t n, uint64_t seed
       t = 0;
       continue;
     }
-    const Mask m = G::legal(p, s);
+    const auto m = G::legal(p, s);
     G::apply(p, s, sample_action<G>(p, s, m, G::current_player(p, s), rng));
     ++t;
   }
   G::store(p, base, n, i, s);
-  const Mask m = G::legal(p, s);
+  const auto m = G::legal(p, s);
   const int a = sample_action<G>(p, s, m, G::current_player(p, s), rng);
   if (actions) actions[i] = static_cast<uint8_t>(a);
   if (depth_out) depth_out[i] = depth;
@@ -1235,14 +1235,14 @@ k_env_step(typename G::Params p, typename G::word_t* base, int64_t n, int num_pl
   } else {
     const int a = actions[i];
     if (a != OSG_INVALID_ACTION) {  // -1: leave this environment as it is (get_time_step without stepping)
-      const Mask m = G::legal(p, s);
-      if (a < 0 || a >= 32 * kMaskWords || !m.test(a)) atomicAdd(illegal, 1ull);
+      const auto m = G::legal(p, s);
+      if (a < 0 || a >= 32 * G::kMaskW || !m.test(a)) atomicAdd(illegal, 1ull);
       else G::apply(p, s, a);
     }
   }
   Rng rng(seed, static_cast<uint64_t>(index_offset + i), static_cast<uint64_t>(step_index));
   for (int guard = 0; guard < 64 && !G::terminal(p, s) && G::current_player(p, s) == kChancePlayer; ++guard) {
-    const Mask m = G::legal(p, s);
+    const auto m = G::legal(p, s);
     G::apply(p, s, sample_action<G>(p, s, m, kChancePlayer, rng));
   }
   G::store(p, base, n, i, s);
@@ -1254,9 +1254,9 @@ k_env_step(typename G::Params p, typename G::word_t* base, int64_t n, int num_pl
   double r[kMaxPlayers];
   G::returns(p, s, r);
   for (int q = 0; q < num_players; ++q) rewards[i * num_players + q] = type == 2 ? r[q] : 0.0;
-  const Mask after = G::legal(p, s);
+  const auto after = G::legal(p, s);
 #pragma unroll
-  for (int w = 0; w < kMaskWords; ++w)
+  for (int w = 0; w < G::kMaskW; ++w)
     if (w < mask_words) mask[i * mask_words + w] = after.w[w];
 }
 
@@ -1310,7 +1310,7 @@ k_rollout(typename G::Params p, const typename G::word_t* base, int64_t n, int n
       ply = 0;
       continue;
     }
-    Mask m = G::legal(p, s);
+    auto m = G::legal(p, s);
     int a = sample_action<G>(p, s, m, G::current_player(p, s), rng);
     G::apply(p, s, a);
     ++plies;
@@ -1499,7 +1499,7 @@ int osg_batch_describe(const osg_batch* b, osg_game_desc* out) { *out = b->spec.
 void* osg_batch_device_ptr(osg_batch* b) { return b->d_words; }
 
 int osg_batch_reset(osg_batch* b) {
-  OSG_DISPATCH(b->spec, k_init<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, b->ctx->stream>>>(P,
+  OSG_DISPATCH_WIDE(b->spec, k_init<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, b->ctx->stream>>>(P,
                                             static_cast<typename G::word_t*>(b->d_words), b->n));
   OSG_HIP(hipGetLastError());
   return OSG_OK;
@@ -1525,7 +1525,7 @@ int osg_batch_gather(osg_batch* dst, const osg_batch* src, const int64_t* index,
   const void* d_index = nullptr;
   int rc = stage_in(dst->ctx, index, sizeof(int64_t) * dst->n, on_host, 0, &d_index);
   if (rc) return rc;
-  OSG_DISPATCH(dst->spec, k_gather<G><<<dim3(grid_for(dst->n)), dim3(kBlock), 0, dst->ctx->stream>>>(P,
+  OSG_DISPATCH_WIDE(dst->spec, k_gather<G><<<dim3(grid_for(dst->n)), dim3(kBlock), 0, dst->ctx->stream>>>(P,
                                               static_cast<typename G::word_t*>(dst->d_words), dst->n,
                                               static_cast<const typename G::word_t*>(src->d_words), src->n,
                                               static_cast<const int64_t*>(d_index), dst->ctx->d_illegal));
@@ -1568,7 +1568,7 @@ int osg_legal_mask(const osg_batch* b, uint32_t* mask, int on_host) {
     if (rc) return rc;
     d_mask = static_cast<uint32_t*>(scratch);
   }
-  OSG_DISPATCH(b->spec, k_legal_mask<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
+  OSG_DISPATCH_WIDE(b->spec, k_legal_mask<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
                                             static_cast<const typename G::word_t*>(b->d_words), b->n, d_mask, W));
   OSG_HIP(hipGetLastError());
   if (on_host) {
@@ -1583,7 +1583,7 @@ int osg_apply(osg_batch* b, const int32_t* actions, int on_host, int64_t* h_ille
   const void* d_actions = nullptr;
   int rc = stage_in(ctx, actions, sizeof(int32_t) * b->n, on_host, 0, &d_actions);
   if (rc) return rc;
-  OSG_DISPATCH(b->spec, k_apply<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
+  OSG_DISPATCH_WIDE(b->spec, k_apply<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
                                             static_cast<typename G::word_t*>(b->d_words), b->n,
                                             static_cast<const int32_t*>(d_actions), ctx->d_illegal));
   OSG_HIP(hipGetLastError());
@@ -1607,7 +1607,7 @@ int osg_status_query(const osg_batch* b, int8_t* cur_player, uint8_t* terminal, 
     d_term = terminal ? reinterpret_cast<uint8_t*>(sc + off_term) : nullptr;
     d_ret = returns ? reinterpret_cast<double*>(sc + off_ret) : nullptr;
   }
-  OSG_DISPATCH(b->spec, k_status<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
+  OSG_DISPATCH_WIDE(b->spec, k_status<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
                                             static_cast<const typename G::word_t*>(b->d_words), b->n, P_, d_cur,
                                             d_term, d_ret));
   OSG_HIP(hipGetLastError());
@@ -1632,7 +1632,7 @@ int osg_chance_probs(const osg_batch* b, double* probs, int on_host) {
     if (rc) return rc;
     d_probs = static_cast<double*>(scratch);
   }
-  OSG_DISPATCH(b->spec, k_chance_probs<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
+  OSG_DISPATCH_WIDE(b->spec, k_chance_probs<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
                                             static_cast<const typename G::word_t*>(b->d_words), b->n, C, d_probs));
   OSG_HIP(hipGetLastError());
   if (on_host) {
@@ -1644,6 +1644,9 @@ int osg_chance_probs(const osg_batch* b, double* probs, int on_host) {
 
 int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, void* d_mask, uint8_t* d_status) {
   if (!same_game(dst, src) || dst->n != src->n) return set_error(OSG_ERR_INVALID, "osg_step: shape mismatch");
+  if (src->spec.desc.num_distinct_actions > 255)
+    return set_error(OSG_ERR_UNSUPPORTED, "osg_step: action ids travel as one byte here (0xFF = skip); games with more than 255 "
+                                          "actions (hex above 15 x 15) step through osg_apply / osg_env_step (32-bit actions)");
   osg_ctx* ctx = dst->ctx;
   const int cmb = src->spec.desc.compact_mask_bytes;
   const int W = src->spec.desc.mask_words;
@@ -1668,7 +1671,7 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
   }
   const bool aligned2 = ((reinterpret_cast<uintptr_t>(d_actions) | reinterpret_cast<uintptr_t>(d_mask) |
                           reinterpret_cast<uintptr_t>(d_status)) & 1u) == 0;
-  if (planes16 && src->spec.desc.game_kind == kC4 && (n & 1) == 0 && aligned2) {
+  if (planes16 && src->spec.desc.game_kind == kC4 && !src->spec.c4_wide && (n & 1) == 0 && aligned2) {
     const int64_t pairs = n / 2;
     k_step_c4x2<C4><<<dim3(static_cast<unsigned>((pairs + kC4StepBlock - 1) / kC4StepBlock)), dim3(kC4StepBlock), 0, ctx->stream>>>(
         src->spec.c4, static_cast<const uint64_t*>(src->d_words), static_cast<uint64_t*>(dst->d_words), n, d_actions,
@@ -1705,7 +1708,7 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
     return OSG_OK;
   }
   // hex: V states per thread (16-byte plane accesses with V = 4); the mask rows are the [n, NW] u32 output
-  if (kind == kHex && cmb == 4 * W && W == src->spec.hex_nw) {
+  if (kind == kHex && cmb == 4 * W && W == src->spec.hex_nw && W <= 4) {   // (the big boards: one state per thread, below)
     // OSG_HEX_STEP="<states per thread>:<non-temporal 0|1>" overrides the choice (a tuning knob; results do not depend on it)
     int v = 2, nt = n >= (int64_t{1} << 22) ? 1 : 0;
     if (const char* e = std::getenv("OSG_HEX_STEP")) {
@@ -1740,15 +1743,15 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
     }
   }
   if (cmb == 1) {
-    OSG_DISPATCH(src->spec, k_step<G, uint8_t><<<dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream>>>(P, static_cast<const typename G::word_t*>(src->d_words),
+    OSG_DISPATCH_WIDE(src->spec, k_step<G, uint8_t><<<dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream>>>(P, static_cast<const typename G::word_t*>(src->d_words),
                                                 static_cast<typename G::word_t*>(dst->d_words), n, d_actions,
                                                 static_cast<uint8_t*>(d_mask), 1, d_status));
   } else if (cmb == 2) {
-    OSG_DISPATCH(src->spec, k_step<G, uint16_t><<<dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream>>>(P, static_cast<const typename G::word_t*>(src->d_words),
+    OSG_DISPATCH_WIDE(src->spec, k_step<G, uint16_t><<<dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream>>>(P, static_cast<const typename G::word_t*>(src->d_words),
                                                 static_cast<typename G::word_t*>(dst->d_words), n, d_actions,
                                                 static_cast<uint16_t*>(d_mask), 1, d_status));
   } else {
-    OSG_DISPATCH(src->spec, k_step<G, uint32_t><<<dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream>>>(P, static_cast<const typename G::word_t*>(src->d_words),
+    OSG_DISPATCH_WIDE(src->spec, k_step<G, uint32_t><<<dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream>>>(P, static_cast<const typename G::word_t*>(src->d_words),
                                                 static_cast<typename G::word_t*>(dst->d_words), n, d_actions,
                                                 static_cast<uint32_t*>(d_mask), W, d_status));
   }
@@ -1835,7 +1838,10 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
       case 1: if (nt) OSG_HEXL(1, true); else OSG_HEXL(1, false); break;
       case 2: if (nt) OSG_HEXL(2, true); else OSG_HEXL(2, false); break;
       case 3: if (nt) OSG_HEXL(3, true); else OSG_HEXL(3, false); break;
-      default: if (nt) OSG_HEXL(4, true); else OSG_HEXL(4, false); break;
+      case 4: if (nt) OSG_HEXL(4, true); else OSG_HEXL(4, false); break;
+      case 6: if (nt) OSG_HEXL(6, true); else OSG_HEXL(6, false); break;
+      case 8: if (nt) OSG_HEXL(8, true); else OSG_HEXL(8, false); break;
+      default: if (nt) OSG_HEXL(12, true); else OSG_HEXL(12, false); break;
     }
 #undef OSG_HEXL
   } else if (b->spec.desc.game_kind == kC4 && b->spec.c4_std) {
@@ -1850,8 +1856,8 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
     else
       k_observation_c4std<<<dim3(grid_for(b->n * 18)), dim3(kBlock), 0, ctx->stream>>>(
           b->spec.c4, static_cast<const uint64_t*>(b->d_words), b->n, player, d_out);
-  } else if (b->spec.desc.game_kind == kHex && which == 0 && d.obs_shape[0] == 9 &&
-             (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) {
+  } else if (b->spec.desc.game_kind == kHex && which == 0 && d.obs_shape[0] == 9 && b->spec.hex_nw <= 4 &&
+             (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) {   // (its LDS stage is 256 B per cell: the big boards go below)
     const size_t shmem = sizeof(float) * kHexObsBlock * static_cast<size_t>(d.obs_shape[1] * d.obs_shape[2]);
     const unsigned grid = static_cast<unsigned>((b->n * 9 + kHexObsBlock - 1) / kHexObsBlock);
 #define OSG_HEX_OBS(NW, member)                                                                              \
@@ -1873,7 +1879,7 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
     const size_t shmem = sizeof(float) * (kRowsBlock / 64) * 64 * kr * static_cast<size_t>(size | 1);
     const unsigned grid = static_cast<unsigned>((b->n + kRowsBlock * kr - 1) / (kRowsBlock * kr));
 #define OSG_ROWS(KR)                                                                                               \
-  OSG_DISPATCH(b->spec, k_observation_rows<G, KR><<<dim3(grid), dim3(kRowsBlock), shmem, ctx->stream>>>(           \
+  OSG_DISPATCH_WIDE(b->spec, k_observation_rows<G, KR><<<dim3(grid), dim3(kRowsBlock), shmem, ctx->stream>>>(           \
                             P, static_cast<const typename G::word_t*>(b->d_words), b->n, size, player, which, d_out))
     if (kr == 2) OSG_ROWS(2);
     else OSG_ROWS(1);
@@ -1890,7 +1896,7 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
     const int cps = (seg_len + F - 1) / F;
     const int64_t lanes = b->n * (size / seg_len) * cps;
 #define OSG_OBS_LAUNCH(FF)                                                                                          \
-  OSG_DISPATCH(b->spec, k_observation<G, FF><<<dim3(grid_for(lanes)), dim3(kBlock), 0, ctx->stream>>>(P,            \
+  OSG_DISPATCH_WIDE(b->spec, k_observation<G, FF><<<dim3(grid_for(lanes)), dim3(kBlock), 0, ctx->stream>>>(P,            \
                                             static_cast<const typename G::word_t*>(b->d_words), b->n, size, seg_len, \
                                             cps, player, which, d_out))
     if (F == 16) OSG_OBS_LAUNCH(16);
@@ -1913,7 +1919,7 @@ int osg_random_steps(osg_batch* b, uint64_t seed, int64_t index_offset, int step
 #define OSG_RS_BLOCKS 4096
 #endif
   if (blocks > OSG_RS_BLOCKS) blocks = OSG_RS_BLOCKS;  // 16 workgroups per CU (4096 measured 4 % faster than 2048), grid-strided beyond
-  OSG_DISPATCH(b->spec, k_random_steps<G><<<dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, ctx->stream>>>(P,
+  OSG_DISPATCH_WIDE(b->spec, k_random_steps<G><<<dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, ctx->stream>>>(P,
                                             static_cast<typename G::word_t*>(b->d_words), b->n, seed, index_offset,
                                             steps, partials));
   k_fold_counters<<<dim3(1), dim3(64), 0, ctx->stream>>>(partials, d_counters);
@@ -1927,8 +1933,11 @@ int osg_synth_batch(osg_batch* b, uint64_t seed, int64_t index_offset, int depth
   if (depth_mod < 1 || depth_mod > b->spec.desc.max_game_length)
     return set_error(OSG_ERR_INVALID, "osg_synth_batch: depth_mod must lie in [1, MaxGameLength()]");
   if (int rc = refuse_endless_playouts(b->spec, "osg_synth_batch")) return rc;
+  if (d_actions && b->spec.desc.num_distinct_actions > 255)
+    return set_error(OSG_ERR_UNSUPPORTED, "osg_synth_batch: d_actions holds one byte per action; pass NULL for games with more "
+                                          "than 255 actions");
   osg_ctx* ctx = b->ctx;
-  OSG_DISPATCH(b->spec, k_synth<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
+  OSG_DISPATCH_WIDE(b->spec, k_synth<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
                                      static_cast<typename G::word_t*>(b->d_words), b->n, seed, index_offset, depth_mod,
                                      d_actions, d_depth));
   OSG_HIP(hipGetLastError());
@@ -1969,7 +1978,7 @@ int osg_rollout(const osg_batch* roots, uint64_t seed, int64_t index_offset, int
   // Persistent grid: at most 8 blocks per CU x 256 CUs, grid-strided beyond that.
   int64_t blocks = (total + kBlock - 1) / kBlock;
   if (blocks > 2048) blocks = 2048;
-  OSG_DISPATCH(roots->spec, k_rollout<G><<<dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, ctx->stream>>>(P,
+  OSG_DISPATCH_WIDE(roots->spec, k_rollout<G><<<dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, ctx->stream>>>(P,
                                                 static_cast<const typename G::word_t*>(roots->d_words), n, P_, seed,
                                                 index_offset, n_rollouts, static_cast<int>(group), d_part,
                                                 d_part_steps));
@@ -1990,7 +1999,7 @@ int osg_env_step(osg_batch* b, const int32_t* d_actions, uint8_t* d_should_reset
   if (!b || !d_actions || !d_should_reset || !d_cur_player || !d_step_type || !d_rewards || !d_mask)
     return set_error(OSG_ERR_INVALID, "osg_env_step: null argument");
   osg_ctx* ctx = b->ctx;
-  OSG_DISPATCH(b->spec, k_env_step<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
+  OSG_DISPATCH_WIDE(b->spec, k_env_step<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
                                             static_cast<typename G::word_t*>(b->d_words), b->n,
                                             b->spec.desc.num_players, d_actions, d_should_reset, seed, index_offset,
                                             step_index, d_cur_player, d_step_type, d_rewards, d_mask,

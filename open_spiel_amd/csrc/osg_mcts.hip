@@ -281,6 +281,9 @@ extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_i
   const bool board = d.game_kind <= kHex;
   if (cfg.max_simulations < 1 || cfg.n_rollouts < 1) return set_error(OSG_ERR_INVALID, "max_simulations and n_rollouts must be >= 1");
   if (int rc = refuse_endless_playouts(roots->spec, "osg_mcts_search")) return rc;
+  if (roots->spec.desc.num_distinct_actions > 32 * kMaskWords)
+    return set_error(OSG_ERR_UNSUPPORTED, "osg_mcts_search: the search kernels hold up to 128 actions per node; hex boards above "
+                                          "11 x 11 are served by the batch entry points (states, steps, tensors, rollouts)");
   if (cfg.solve && !board)
     return set_error(OSG_ERR_UNSUPPORTED, "solve=true needs win/draw/loss outcomes (tic_tac_toe, connect_four, hex)");
   int layout = cfg.layout;

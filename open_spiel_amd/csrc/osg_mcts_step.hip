@@ -615,6 +615,9 @@ int osg_mcts_tree_create(const osg_batch* roots, const osg_mcts_cfg* cfg_in, int
   if ((flags & 8) && !(flags & 1)) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_create: flag 8 (priors arrive with the values) needs flag 1");
   if ((flags & 8) && (flags & 4)) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_create: flags 4 and 8 exclude each other");
   if (int rc = refuse_endless_playouts(roots->spec, "osg_mcts_tree_create")) return rc;
+  if (d.num_distinct_actions > 32 * kMaskWords)
+    return set_error(OSG_ERR_UNSUPPORTED, "osg_mcts_tree_create: the search kernels hold up to 128 actions per node; hex boards "
+                                          "above 11 x 11 are served by the batch entry points (states, steps, tensors, rollouts)");
   osg_mcts_tree* t = new osg_mcts_tree;
   t->ctx = ctx;
   t->cfg = *cfg_in;

@@ -9,8 +9,8 @@ namespace osg {
 // Draw a legal action like the oracle: chance nodes by SampleAction's CDF scan
 // over ChanceOutcomes() with z = rng.unit() (spiel.cc:372-409), decision nodes
 // uniformly over LegalActions() with rng.below(count) (mcts.cc:51-55).
-template <class G>
-OSG_D int sample_action(const typename G::Params& p, const typename G::State& s, const Mask& m, int cur, Rng& rng) {
+template <class G, int W>
+OSG_D int sample_action_w(const typename G::Params& p, const typename G::State& s, const MaskT<W>& m, int cur, Rng& rng) {
   if (cur == kChancePlayer) {
     int cnt = m.count();
     double z = rng.unit();  // drawn even for a single outcome, as the reference's call sites do
@@ -28,10 +28,15 @@ OSG_D int sample_action(const typename G::Params& p, const typename G::State& s,
   return select_action(m, static_cast<int>(rng.below(static_cast<uint32_t>(m.count()))));
 }
 
+template <class G, int W>
+OSG_D int sample_action(const typename G::Params& p, const typename G::State& s, const MaskT<W>& m, int cur, Rng& rng) {
+  return sample_action_w<G, W>(p, s, m, cur, rng);
+}
+
 // Chance-node draw only (MCTS tree policy at chance nodes, mcts.cc:311-322).
-template <class G>
-OSG_D int sample_action_chance(const typename G::Params& p, const typename G::State& s, const Mask& m, Rng& rng) {
-  return sample_action<G>(p, s, m, kChancePlayer, rng);
+template <class G, int W>
+OSG_D int sample_action_chance(const typename G::Params& p, const typename G::State& s, const MaskT<W>& m, Rng& rng) {
+  return sample_action_w<G, W>(p, s, m, kChancePlayer, rng);
 }
 
 }  // namespace osg

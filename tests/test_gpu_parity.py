@@ -14,6 +14,9 @@ GAMES = [
     "connect_four",
     "connect_four(rows=5,columns=6,x_in_row=3)",
     "connect_four(egocentric_obs_tensor=True)",
+    "connect_four(rows=8,columns=8)",                    # 72 board bits: two plane words per colour
+    "connect_four(rows=9,columns=10,x_in_row=5)",        # 100 bits
+    "connect_four(rows=7,columns=15,egocentric_obs_tensor=True)",   # 120 bits
     "hex(board_size=9)",
     "hex(board_size=5)",
     "hex",                                   # 11x11, 4 words per bit plane
@@ -22,6 +25,10 @@ GAMES = [
     "hex(num_cols=2,num_rows=2)",
     "hex(board_size=4,swap=True)",
     "hex(board_size=5,plain_obs_tensor=True,swap=True)",
+    "hex(board_size=13)",                    # the boards above 128 actions: 6, 8 and 12 words per bit plane
+    "hex(board_size=14,swap=True)",          # 197 action ids: 7 mask words in 8-word planes
+    "hex(board_size=19)",
+    "hex(num_cols=19,num_rows=17,swap=True)",
     "kuhn_poker",
     "kuhn_poker(players=3)",
     "kuhn_poker(players=5)",
@@ -254,12 +261,32 @@ def test_illegal_and_terminal_actions_are_rejected(ctx):
 
 def test_bad_game_strings(ctx):
     import open_spiel_amd as osa
-    for bad in ["chess", "connect_four(rows=9,columns=9)", "hex(board_size=13)", "kuhn_poker(players=11)",
+    for bad in ["chess", "connect_four(rows=12,columns=12)", "hex(board_size=20)", "hex(num_cols=32,num_rows=3)", "kuhn_poker(players=11)",
                 "leduc_poker(players=4)", "connect_four(foo=1)", "hex(swap=3)"]:
         with pytest.raises(osa.OsgError):
             osa.StateBatch(ctx, bad, 4)
     with pytest.raises(osa.OsgError):
         osa.StateBatch(ctx, "kuhn_poker", 4).observation_tensor(5)  # player out of range
+
+
+def test_hex_above_128_actions_where_the_boundary_stops(ctx):
+    """hex(13) ... hex(19) are served by the batch entry points (the parity tests above run them through every one);
+    the search kernels keep their 128-action node layout and the fused step its one-byte action ids: both say so."""
+    import torch
+    import open_spiel_amd as osa
+    b = osa.StateBatch(ctx, "hex(board_size=19)", 64)
+    assert b.desc.num_distinct_actions == 361 and b.desc.mask_words == 12 and b.desc.state_words == 49
+    b.random_steps(5, 30)
+    assert int(b.legal_actions_mask().sum()) == 64 * (361 - 30)
+    with pytest.raises(osa.OsgError, match="128 actions"):
+        b.mcts_search(max_simulations=8)
+    with pytest.raises(osa.OsgError, match="one byte"):
+        b.step(torch.zeros(64, dtype=torch.uint8, device="cuda"))
+    small = osa.StateBatch(ctx, "hex(board_size=15)", 64)      # 225 actions: the fused step serves it
+    mask, status = small.step(torch.full((64,), 224, dtype=torch.uint8, device="cuda"))
+    assert int((status & 0x40).sum()) == 0 and mask.shape == (64, 32)
+    total = small.rollout(3, 3)
+    assert bool((total[:, 0] == -total[:, 1]).all()) and bool((total[:, 0].abs() % 2 == 1).all())   # 3 playouts, no draws in hex
 
 
 def test_clone_and_gather(ctx):
@@ -276,7 +303,9 @@ def test_clone_and_gather(ctx):
 
 @pytest.mark.parametrize("game,n_rollouts", [("tic_tac_toe", 20), ("connect_four", 8), ("hex(board_size=9)", 4),
                                              ("hex(board_size=5)", 8), ("kuhn_poker", 16), ("leduc_poker", 16),
-                                             ("leduc_poker(players=3)", 8), ("kuhn_poker(players=4)", 8)])
+                                             ("leduc_poker(players=3)", 8), ("kuhn_poker(players=4)", 8),
+                                             ("hex(board_size=13)", 2), ("hex(board_size=19)", 2),
+                                             ("connect_four(rows=8,columns=8)", 4)])
 def test_rollout_replay_parity(oracle, ctx, game, n_rollouts):
     """RandomRolloutEvaluator on the device == the oracle replaying the same
     counter-RNG stream: identical summed returns AND identical ply counts."""
@@ -362,7 +391,9 @@ def test_observation_and_information_state_strings_match_the_reference_playthrou
     assert checked > 100
 
 
-@pytest.mark.parametrize("game", ["hex(board_size=4,string_rep=explicit)", "hex", "connect_four(rows=5,columns=6,x_in_row=3)",
+@pytest.mark.parametrize("game", ["hex(board_size=4,string_rep=explicit)", "hex", "hex(board_size=19)",
+                                  "hex(board_size=13,string_rep=explicit)", "connect_four(rows=5,columns=6,x_in_row=3)",
+                                  "connect_four(rows=9,columns=10,x_in_row=5)",
                                   "kuhn_poker(players=3)", "leduc_poker(players=3)", "tic_tac_toe"])
 def test_observation_strings_match_the_oracle(oracle, ctx, game):
     """The same strings on random trajectories of the variants the playthroughs do not cover."""

@@ -1941,38 +1941,49 @@ std::string kuhn_key(const Kuhn::Params& p, uint64_t word, int player) {
 // The part LeducObserver::StringFrom writes for both recall types (leduc_poker.cc:198-226).  money_ is
 // kStartingMoney - ante_ while the hand runs; at the end the pot has been paid out (pot_ = 0,
 // money = 100 + returns).
-std::string leduc_observer_prefix(const Leduc::Params& p, const Leduc::State& s, int player) {
-  const bool term = Leduc::terminal(p, s);
+template <class L>
+std::string leduc_observer_prefix(const LeducParams& p, const typename L::State& s, int player) {
+  const bool term = L::terminal(p, s);
   double ret[kMaxPlayers] = {0};
-  if (term) Leduc::returns(p, s, ret);
-  const int hole = Leduc::priv(s, player);  // kInvalidCard = -10000 before the deal (leduc_poker.h:63)
+  if (term) L::returns(p, s, ret);
+  const int hole = L::priv(s, player);  // kInvalidCard = -10000 before the deal (leduc_poker.h:63)
   std::string r = "[Observer: " + std::to_string(player) + "][Private: " +
-                  std::to_string(hole == Leduc::kNone ? -10000 : hole) + "]";
+                  std::to_string(hole == L::kNone ? -10000 : hole) + "]";
   r += "[Round " + std::to_string(s.round) + "][Player: " + std::to_string(s.cur) + "][Pot: " +
        std::to_string(term ? 0 : s.pot) + "][Money: ";
   for (int q = 0; q < p.players; ++q) {
     char num[32];
-    snprintf(num, sizeof num, "%g", term ? 100.0 + ret[q] : 100.0 - Leduc::ante(s, q));
+    snprintf(num, sizeof num, "%g", term ? 100.0 + ret[q] : 100.0 - L::ante(s, q));
     if (q) r += " ";
     r += num;
   }
   r += "]";
-  if (s.pub != Leduc::kNone) r += "[Public: " + std::to_string(s.pub) + "]";
+  if (s.pub != L::kNone) r += "[Public: " + std::to_string(s.pub) + "]";
   return r;
 }
-std::string leduc_key(const Leduc::Params& p, uint64_t w0, uint64_t w1, int player) {
-  Leduc::State s = Leduc::unpack(w0, w1);
-  std::string r = leduc_observer_prefix(p, s, player);
+template <class L>
+std::string leduc_key_of(const LeducParams& p, const typename L::State& s, int player) {
+  std::string r = leduc_observer_prefix<L>(p, s, player);
   for (int round = 0; round < 2; ++round) {
     r += round == 0 ? "[Round1: " : "][Round2: ";
-    for (int k = 0; k < Leduc::seqlen(s, round); ++k) {
+    for (int k = 0; k < L::seqlen(s, round); ++k) {
       if (k) r += " ";
-      r += std::to_string((Leduc::seq(s, round) >> (2 * k)) & 3u);
+      r += std::to_string(static_cast<unsigned>((L::seq(s, round) >> (2 * k)) & 3u));
     }
   }
   r += "]";
   return r;
 }
+std::string leduc_key(const LeducParams& p, uint64_t w0, uint64_t w1, int player) {
+  return leduc_key_of<Leduc>(p, Leduc::unpack(w0, w1), player);
+}
+// the state of either record from its plane words (2 or 5)
+std::string leduc_key_words(const GameSpec& spec, const uint64_t* w, int player) {
+  if (spec.leduc_big) return leduc_key_of<LeducBig>(spec.leduc, LeducBig::unpack5(w[0], w[1], w[2], w[3], w[4]), player);
+  return leduc_key(spec.leduc, w[0], w[1], player);
+}
+
+template <class T> struct TypeTag { using type = T; };
 
 template <class T>
 int upload(const std::vector<T>& v, T** d, hipStream_t stream) {
@@ -2648,6 +2659,10 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
     delete s;
     return set_error(OSG_ERR_UNSUPPORTED, "tabular CFR needs information-state strings: kuhn_poker and leduc_poker only");
   }
+  if (s->spec.leduc_big) {   // (4-player leduc_poker has ~3e8 histories, 10 players beyond any table)
+    delete s;
+    return set_error(OSG_ERR_UNSUPPORTED, "tabular solvers: leduc_poker with up to 3 players (the trees of 4+ players do not fit a device)");
+  }
   s->B = s->cfg.replicas > 0 ? s->cfg.replicas : 1;
   if (s->B > 1 && s->cfg.solver != 0) { delete s; return set_error(OSG_ERR_UNSUPPORTED, "replicas > 1: CFR family only"); }
   if (s->B > (1 << 16)) { delete s; return set_error(OSG_ERR_INVALID, "osg_cfr_cfg.replicas must be <= 65536"); }
@@ -3321,14 +3336,13 @@ int osg_information_state_string(const osg_batch* b, int64_t index, int player, 
   if (d.game_kind != kKuhn && d.game_kind != kLeduc)
     return set_error(OSG_ERR_INVALID, "this game provides no information state string");
   if (player < 0 || player >= d.num_players) return set_error(OSG_ERR_INVALID, "player id out of range");
-  uint64_t w[2] = {0, 0};
+  uint64_t w[5] = {0, 0, 0, 0, 0};   // (leduc_poker with 4+ players: five plane words)
   const char* base = static_cast<const char*>(b->d_words);
   for (int k = 0; k < d.state_words; ++k)
     OSG_HIP(hipMemcpyAsync(&w[k], base + (static_cast<size_t>(k) * b->n + index) * sizeof(uint64_t), sizeof(uint64_t),
                            hipMemcpyDeviceToHost, b->ctx->stream));
   OSG_HIP(hipStreamSynchronize(b->ctx->stream));
-  const std::string key = d.game_kind == kKuhn ? kuhn_key(b->spec.kuhn, w[0], player)
-                                               : leduc_key(b->spec.leduc, w[0], w[1], player);
+  const std::string key = d.game_kind == kKuhn ? kuhn_key(b->spec.kuhn, w[0], player) : leduc_key_words(b->spec, w, player);
   if (static_cast<int>(key.size()) + 1 > cap) return set_error(OSG_ERR_INVALID, "buffer too small");
   memcpy(buf, key.c_str(), key.size() + 1);
   return static_cast<int>(key.size());
@@ -3402,12 +3416,15 @@ int osg_observation_string(const osg_batch* b, int64_t index, int player, char* 
       break;
     }
     case kLeduc: {  // leduc_poker.cc:198-239, imperfect recall: pot contributions instead of the sequences
-      const Leduc::Params& lp = b->spec.leduc;
-      Leduc::State st = Leduc::unpack(w[0], w[1]);
-      out = leduc_observer_prefix(lp, st, player);
-      out += "[Ante: ";
-      for (int q = 0; q < lp.players; ++q) out += (q ? " " : "") + std::to_string(Leduc::ante(st, q));
-      out += "]";
+      const LeducParams& lp = b->spec.leduc;
+      auto text = [&](auto tag, const auto& st) {
+        using L = typename decltype(tag)::type;
+        std::string r = leduc_observer_prefix<L>(lp, st, player) + "[Ante: ";
+        for (int q = 0; q < lp.players; ++q) r += (q ? " " : "") + std::to_string(L::ante(st, q));
+        return r + "]";
+      };
+      if (b->spec.leduc_big) out = text(TypeTag<LeducBig>{}, LeducBig::unpack5(w[0], w[1], w[2], w[3], w[4]));
+      else out = text(TypeTag<Leduc>{}, Leduc::unpack(w[0], w[1]));
       break;
     }
     default: return set_error(OSG_ERR_INVALID, "bad game kind");
@@ -3455,28 +3472,32 @@ int osg_state_string(const osg_batch* b, int64_t index, char* buf, int cap) {
     if (h > kp.players) out += ' ';
     for (int j = 0; j < Kuhn::nact(kp, st); ++j) out.push_back(((Kuhn::bets(st) >> j) & 1u) ? 'b' : 'p');
   } else {  // leduc_poker.cc:463-496
-    const Leduc::Params& lp = b->spec.leduc;
-    Leduc::State st = Leduc::unpack(w[0], w[1]);
-    const bool term = Leduc::terminal(lp, st);
-    double ret[kMaxPlayers] = {0};
-    if (term) Leduc::returns(lp, st, ret);
-    const int P = lp.players;
-    auto card = [](int c) { return std::to_string(c == Leduc::kNone ? -10000 : c); };
-    out = "Round: " + std::to_string(st.round) + "\nPlayer: " + std::to_string(st.cur) + "\nPot: " +
-          std::to_string(term ? 0 : st.pot) + "\nMoney (player_0 player_1" + (P > 2 ? " [...]):" : "):");
-    for (int q = 0; q < P; ++q) {
-      char num[32];
-      snprintf(num, sizeof num, "%g", term ? 100.0 + ret[q] : 100.0 - Leduc::ante(st, q));
-      out += std::string(" ") + num;
-    }
-    out += std::string("\nCards (public player_0 player_1") + (P > 2 ? " [...]): " : "): ") + card(st.pub) + " ";
-    for (int q = 0; q < P; ++q) out += card(Leduc::priv(st, q)) + " ";
-    for (int round = 0; round < 2; ++round) {
-      out += round == 0 ? "\nRound 1 sequence: " : "\nRound 2 sequence: ";
-      for (int k = 0; k < Leduc::seqlen(st, round); ++k)
-        out += std::string(k ? ", " : "") + leduc_action_name((Leduc::seq(st, round) >> (2 * k)) & 3u);
-    }
-    out += "\n";
+    const LeducParams& lp = b->spec.leduc;
+    auto text = [&](auto tag, const auto& st) {
+      using L = typename decltype(tag)::type;
+      const bool term = L::terminal(lp, st);
+      double ret[kMaxPlayers] = {0};
+      if (term) L::returns(lp, st, ret);
+      const int P = lp.players;
+      auto card = [](int c) { return std::to_string(c == L::kNone ? -10000 : c); };
+      std::string r = "Round: " + std::to_string(st.round) + "\nPlayer: " + std::to_string(st.cur) + "\nPot: " +
+                      std::to_string(term ? 0 : st.pot) + "\nMoney (player_0 player_1" + (P > 2 ? " [...]):" : "):");
+      for (int q = 0; q < P; ++q) {
+        char num[32];
+        snprintf(num, sizeof num, "%g", term ? 100.0 + ret[q] : 100.0 - L::ante(st, q));
+        r += std::string(" ") + num;
+      }
+      r += std::string("\nCards (public player_0 player_1") + (P > 2 ? " [...]): " : "): ") + card(st.pub) + " ";
+      for (int q = 0; q < P; ++q) r += card(L::priv(st, q)) + " ";
+      for (int round = 0; round < 2; ++round) {
+        r += round == 0 ? "\nRound 1 sequence: " : "\nRound 2 sequence: ";
+        for (int k = 0; k < L::seqlen(st, round); ++k)
+          r += std::string(k ? ", " : "") + leduc_action_name(static_cast<int>((L::seq(st, round) >> (2 * k)) & 3u));
+      }
+      return r + "\n";
+    };
+    if (b->spec.leduc_big) out = text(TypeTag<LeducBig>{}, LeducBig::unpack5(w[0], w[1], w[2], w[3], w[4]));
+    else out = text(TypeTag<Leduc>{}, Leduc::unpack(w[0], w[1]));
   }
   return return_string(out, buf, cap);
 }

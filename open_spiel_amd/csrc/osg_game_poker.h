@@ -5,6 +5,8 @@
 #ifndef OSG_GAME_POKER_H_
 #define OSG_GAME_POKER_H_
 
+#include <type_traits>
+
 #include "osg_common.h"
 #include "osg_game_boards.h"  // GenericObsCursor
 
@@ -166,13 +168,25 @@ struct Kuhn {
 // (private cards live in word1's upper bits to keep word0 at 54 bits.)
 // money_[p] is always 100 - ante_[p] (+ pot share at the end), so it is not stored.
 // ===========================================================================
-struct Leduc {
+// kP = the players the record holds: 3 — the two-plane layout above (2 and 3 players: every kernel, the solvers) — or
+// 10 — five planes (4 to 10 players, leduc_poker.cc:49-50; the batch entry points):
+//   word0: cur_player+1 (4b) | calls (4) | raises (2) | round-1 (1) | stakes (4) | pot (8) | public+1 (5) | dealt (4) |
+//          remaining (4) | num_winners (4) | deck mask (22)                                            = 62 bits
+//   word1: ante[10] (4 each) | folded mask (10) | winner mask (10)                                    = 60
+//   word2: private+1 [10] (5 each) | seq1 len (5) | seq2 len (5)                                      = 60
+//   word3: round 1's moves, 2 bits each (<= 3 P - 2 = 28)        word4: round 2's
+struct LeducParams {
+  int words;  // = 2 (kP = 3) or 5 (kP = 10)
+  int players, cards, mapping, iso, starter;
+};
+template <int kP>
+struct LeducT {
   using word_t = uint64_t;
   static constexpr int kMaskW = kMaskWords;
-  struct Params {
-    int words;  // = 2
-    int players, cards, mapping, iso, starter;
-  };
+  static constexpr bool kBig = kP > 3;
+  using pk_t = typename std::conditional<kBig, uint64_t, uint32_t>::type;   // the per-player / per-round packs
+  static constexpr int kPrivBits = kBig ? 5 : 4;
+  using Params = LeducParams;
   struct State {
     int cur;          // -1 chance, else player
     int calls, raises, round, stakes, pot, pub, dealt, remaining, nwin;
@@ -180,14 +194,16 @@ struct Leduc {
     uint32_t folded, winners;
     // Small per-player / per-round vectors are kept bit-packed in scalars and read through the
     // accessors below: a runtime-indexed C array would be demoted from registers to scratch memory.
-    uint32_t ante_pk;   // ante of player q: 4 bits at 4q
-    uint32_t priv_pk;   // private card of player q, plus one (0 = none): 4 bits at 4q
-    uint32_t seq0, seq1;  // moves of round 1 / round 2, 2 bits each
+    pk_t ante_pk;   // ante of player q: 4 bits at 4q
+    pk_t priv_pk;   // private card of player q, plus one (0 = none): kPrivBits bits at kPrivBits * q
+    pk_t seq0, seq1;  // moves of round 1 / round 2, 2 bits each
     int len0, len1;
   };
   OSG_HD static int ante(const State& s, int q) { return static_cast<int>((s.ante_pk >> (4 * q)) & 15u); }
-  OSG_HD static int priv(const State& s, int q) { return static_cast<int>((s.priv_pk >> (4 * q)) & 15u) - 1; }
-  OSG_HD static uint32_t seq(const State& s, int r) { return r == 0 ? s.seq0 : s.seq1; }
+  OSG_HD static int priv(const State& s, int q) {
+    return static_cast<int>((s.priv_pk >> (kPrivBits * q)) & ((1u << kPrivBits) - 1u)) - 1;
+  }
+  OSG_HD static pk_t seq(const State& s, int r) { return r == 0 ? s.seq0 : s.seq1; }
   OSG_HD static int seqlen(const State& s, int r) { return r == 0 ? s.len0 : s.len1; }
   static constexpr int kNone = -1;
 
@@ -196,10 +212,44 @@ struct Leduc {
     s.cur = kChancePlayer; s.calls = 0; s.raises = 0; s.round = 1; s.stakes = 1;
     s.pot = p.players; s.pub = kNone; s.dealt = 0; s.remaining = p.players; s.nwin = 0;
     s.deck = (1u << p.cards) - 1u; s.folded = 0; s.winners = 0;
-    s.ante_pk = 0x111u;  // everyone antes 1
+    s.ante_pk = static_cast<pk_t>(kBig ? 0x1111111111ull : 0x111ull);  // everyone antes 1
     s.priv_pk = 0u;
     s.seq0 = s.seq1 = 0; s.len0 = s.len1 = 0;
     return s;
+  }
+  OSG_HD static State unpack5(uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t e) {   // the five-plane record
+    State s;
+    s.cur = static_cast<int>(a & 15ull) - 1;            a >>= 4;
+    s.calls = static_cast<int>(a & 15ull);              a >>= 4;
+    s.raises = static_cast<int>(a & 3ull);              a >>= 2;
+    s.round = static_cast<int>(a & 1ull) + 1;           a >>= 1;
+    s.stakes = static_cast<int>(a & 15ull);             a >>= 4;
+    s.pot = static_cast<int>(a & 255ull);               a >>= 8;
+    s.pub = static_cast<int>(a & 31ull) - 1;            a >>= 5;
+    s.dealt = static_cast<int>(a & 15ull);              a >>= 4;
+    s.remaining = static_cast<int>(a & 15ull);          a >>= 4;
+    s.nwin = static_cast<int>(a & 15ull);               a >>= 4;
+    s.deck = static_cast<uint32_t>(a & 0x3FFFFFull);
+    s.ante_pk = static_cast<pk_t>(b & 0xFFFFFFFFFFull);
+    s.folded = static_cast<uint32_t>((b >> 40) & 0x3FFull);
+    s.winners = static_cast<uint32_t>((b >> 50) & 0x3FFull);
+    s.priv_pk = static_cast<pk_t>(c & 0x3FFFFFFFFFFFFull);
+    s.len0 = static_cast<int>((c >> 50) & 31ull);
+    s.len1 = static_cast<int>((c >> 55) & 31ull);
+    s.seq0 = static_cast<pk_t>(d);
+    s.seq1 = static_cast<pk_t>(e);
+    return s;
+  }
+  OSG_HD static void pack5(const State& s, uint64_t* w) {
+    w[0] = static_cast<uint64_t>(s.cur + 1) | (static_cast<uint64_t>(s.calls) << 4) | (static_cast<uint64_t>(s.raises) << 8) |
+           (static_cast<uint64_t>(s.round - 1) << 10) | (static_cast<uint64_t>(s.stakes) << 11) |
+           (static_cast<uint64_t>(s.pot) << 15) | (static_cast<uint64_t>(s.pub + 1) << 23) |
+           (static_cast<uint64_t>(s.dealt) << 28) | (static_cast<uint64_t>(s.remaining) << 32) |
+           (static_cast<uint64_t>(s.nwin) << 36) | (static_cast<uint64_t>(s.deck) << 40);
+    w[1] = static_cast<uint64_t>(s.ante_pk) | (static_cast<uint64_t>(s.folded) << 40) | (static_cast<uint64_t>(s.winners) << 50);
+    w[2] = static_cast<uint64_t>(s.priv_pk) | (static_cast<uint64_t>(s.len0) << 50) | (static_cast<uint64_t>(s.len1) << 55);
+    w[3] = static_cast<uint64_t>(s.seq0);
+    w[4] = static_cast<uint64_t>(s.seq1);
   }
   OSG_HD static State unpack(uint64_t a, uint64_t b) {
     State s;
@@ -216,12 +266,12 @@ struct Leduc {
     s.folded = static_cast<uint32_t>(a & 7ull);         a >>= 3;
     s.winners = static_cast<uint32_t>(a & 7ull);        a >>= 3;
     s.nwin = static_cast<int>(a & 3ull);                a >>= 2;
-    s.ante_pk = static_cast<uint32_t>(a & 0xFFFull);
+    s.ante_pk = static_cast<pk_t>(a & 0xFFFull);
     s.len0 = static_cast<int>(b & 7ull);              b >>= 3;
-    s.seq0 = static_cast<uint32_t>(b & 0x3FFFull);     b >>= 14;
+    s.seq0 = static_cast<pk_t>(b & 0x3FFFull);         b >>= 14;
     s.len1 = static_cast<int>(b & 7ull);              b >>= 3;
-    s.seq1 = static_cast<uint32_t>(b & 0x3FFFull);     b >>= 14;
-    s.priv_pk = static_cast<uint32_t>(b & 0xFFFull);
+    s.seq1 = static_cast<pk_t>(b & 0x3FFFull);         b >>= 14;
+    s.priv_pk = static_cast<pk_t>(b & 0xFFFull);
     return s;
   }
   OSG_HD static void pack(const State& s, uint64_t& a, uint64_t& b) {
@@ -239,13 +289,21 @@ struct Leduc {
     put(b, s.priv_pk, 12);
   }
   OSG_HD static State load(const Params&, const word_t* base, int64_t n, int64_t i) {
-    return unpack(base[i], base[n + i]);
+    if constexpr (kBig) return unpack5(base[i], base[n + i], base[2 * n + i], base[3 * n + i], base[4 * n + i]);
+    else return unpack(base[i], base[n + i]);
   }
   OSG_HD static void store(const Params&, word_t* base, int64_t n, int64_t i, const State& s) {
-    uint64_t a, b;
-    pack(s, a, b);
-    base[i] = a;
-    base[n + i] = b;
+    if constexpr (kBig) {
+      uint64_t w[5];
+      pack5(s, w);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) base[k * n + i] = w[k];
+    } else {
+      uint64_t a, b;
+      pack(s, a, b);
+      base[i] = a;
+      base[n + i] = b;
+    }
   }
   OSG_HD static bool round_over(const State& s) {  // ReadyForNextRound, leduc_poker.cc:680-683
     return (s.raises == 0 && s.calls == s.remaining) || (s.raises > 0 && s.calls == s.remaining - 1);
@@ -289,7 +347,7 @@ struct Leduc {
     s.deck &= ~(1u << move);
     return move;  // deck_[move] == move while present
   }
-  static constexpr int kDevicePlayers = 3;  // the device record holds at most 3 players (osg_game_spec.hip)
+  static constexpr int kDevicePlayers = kP;  // the players this record holds (osg_game_spec.hip picks the layout)
   OSG_HD static int next_actor(const Params& p, const State& s) {  // NextPlayer, leduc_poker.cc:573-591
     // (no runtime modulo — an integer division costs ~40 instructions — and a fixed trip count)
     const int P = p.players;
@@ -338,12 +396,12 @@ struct Leduc {
   }
   OSG_HD static void pay(State& s, int q, int amount) {  // Ante, leduc_poker.cc:700-704
     s.pot += amount;
-    s.ante_pk += static_cast<uint32_t>(amount) << (4 * q);  // an ante never exceeds 13
+    s.ante_pk += static_cast<pk_t>(amount) << (4 * q);  // an ante never exceeds 13
   }
   OSG_HD static void record(State& s, int move) {
     int r = s.round - 1;
-    if (r == 0) { s.seq0 |= static_cast<uint32_t>(move) << (2 * s.len0); ++s.len0; }
-    else { s.seq1 |= static_cast<uint32_t>(move) << (2 * s.len1); ++s.len1; }
+    if (r == 0) { s.seq0 |= static_cast<pk_t>(move) << (2 * s.len0); ++s.len0; }
+    else { s.seq1 |= static_cast<pk_t>(move) << (2 * s.len1); ++s.len1; }
   }
   OSG_HD static void advance(const Params& p, State& s, bool may_start_round) {
     if (terminal(p, s)) {
@@ -357,7 +415,7 @@ struct Leduc {
   OSG_HD static void apply(const Params& p, State& s, int a) {  // DoApplyAction, leduc_poker.cc:298-414
     if (s.cur == kChancePlayer) {
       if (s.dealt < p.players) {  // SetPrivate, :706-727
-        s.priv_pk |= static_cast<uint32_t>(take_card(p, s, a) + 1) << (4 * s.dealt);
+        s.priv_pk |= static_cast<pk_t>(take_card(p, s, a) + 1) << (kPrivBits * s.dealt);
         ++s.dealt;
         if (s.dealt == p.players) s.cur = p.starter;
       } else {
@@ -415,7 +473,7 @@ struct Leduc {
       int r = idx / (bets * 2), rem = idx - r * bets * 2;
       int i = rem >> 1, bit = rem & 1;
       if (i >= seqlen(s, r)) return 0.0f;
-      int mv = (seq(s, r) >> (2 * i)) & 3u;
+      int mv = static_cast<int>((seq(s, r) >> (2 * i)) & 3u);
       return (mv == 1 && bit == 0) || (mv == 2 && bit == 1) ? 1.0f : 0.0f;  // call 10, raise 01
     }
     return static_cast<float>(ante(s, idx));
@@ -423,7 +481,7 @@ struct Leduc {
   // The tensor walker: every entry but the pot contributions is 0 or 1, so the row is built ONCE as a bit set
   // (player, private card, community card, the two betting rounds' call / raise pairs) and an entry is a bit
   // test — ~120 instructions per row instead of ~30 per float through obs_at.
-  struct ObsCursor {
+  struct BitCursor {
     uint64_t bits;
     int idx, nbits;
     OSG_HD void init(const Params& p, const State& s, int player, int which, int idx0) {
@@ -438,7 +496,7 @@ struct Leduc {
         const int bets = 3 * P - 2;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          const uint32_t q = seq(s, r);
+          const uint32_t q = static_cast<uint32_t>(seq(s, r));
           const int len = seqlen(s, r);
           const int base = P + 2 * K + r * bets * 2;
           for (int i = 0; i < len; ++i) {
@@ -456,7 +514,11 @@ struct Leduc {
       return static_cast<float>(ante(s, k - nbits));                // observation tensor: pot_contribution[P]
     }
   };
+  // (the information-state row of 4+ players is wider than a 64-bit image: the big record walks obs_at entry by entry)
+  using ObsCursor = typename std::conditional<kBig, GenericObsCursor<LeducT<kP>>, BitCursor>::type;
 };
+using Leduc = LeducT<3>;       // 2 and 3 players
+using LeducBig = LeducT<10>;   // 4 to 10 players
 
 }  // namespace osg
 #endif  // OSG_GAME_POKER_H_

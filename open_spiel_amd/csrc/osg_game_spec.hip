@@ -240,7 +240,6 @@ int parse_game(const char* game_string, GameSpec* out) {
     int starter = rd.get_int("starting_player", 0);
     if (!rd.finish()) return set_error(OSG_ERR_INVALID, rd.err);
     if (n < 2 || n > 10) return set_error(OSG_ERR_INVALID, "leduc_poker: players must be in [2, 10]");
-    if (n > 3) return set_error(OSG_ERR_UNSUPPORTED, "leduc_poker: the device record holds at most 3 players");
     if (starter < 0 || starter >= n) return set_error(OSG_ERR_INVALID, "leduc_poker: bad starting_player");
     int cards = (n + 1) * 2;
     int K = iso ? cards / 2 : cards;
@@ -253,9 +252,10 @@ int parse_game(const char* game_string, GameSpec* out) {
     d.obs_size = n + 2 * K + n; d.obs_rank = 1; d.obs_shape[0] = d.obs_size;                        // leduc_poker.cc:822-831
     d.info_size = n + 2 * K + d.max_game_length * 2; d.info_rank = 1; d.info_shape[0] = d.info_size; // :811-820
     d.min_utility = -13; d.max_utility = (n - 1) * 13;                                               // :833-861
-    d.state_words = 2; d.state_word_bytes = 8;
+    out->leduc_big = n > 3;   // 4 to 10 players: the five-plane record (osg_game_poker.h LeducT<10>)
+    d.state_words = out->leduc_big ? 5 : 2; d.state_word_bytes = 8;
     Leduc::Params& p = out->leduc;
-    p.words = 2; p.players = n; p.cards = cards; p.mapping = mapping; p.iso = iso; p.starter = starter;
+    p.words = d.state_words; p.players = n; p.cards = cards; p.mapping = mapping; p.iso = iso; p.starter = starter;
   } else {
     return set_error(OSG_ERR_UNSUPPORTED, "Unknown game '" + name + "' (device games: tic_tac_toe, "
                      "connect_four, hex, kuhn_poker, leduc_poker)");

@@ -24,6 +24,7 @@ struct GameSpec {
   int hex_nw = 0;  // u32 words per hex bit plane: 1..4 (boards of up to 128 actions), 6 / 8 / 12 (up to 19 x 19)
   bool c4_std = false;  // connect_four with the default 6x7x4 geometry (constant-folded kernels)
   bool c4_wide = false;  // connect_four above 64 board bits: two plane words per colour (C4Wide)
+  bool leduc_big = false;  // leduc_poker with 4 to 10 players: the five-plane record (LeducBig)
   bool hex_explicit = false;  // hex(string_rep=explicit): edge-connection glyphs in the board string
   Ttt::Params ttt;
   C4::Params c4;
@@ -127,7 +128,10 @@ struct osg_batch {
         else { using G = osg::C4; const G::Params& P = (spec).c4; __VA_ARGS__; }   \
         break;                                                                     \
       case osg::kKuhn: { using G = osg::Kuhn; const G::Params& P = (spec).kuhn; __VA_ARGS__; } break; \
-      case osg::kLeduc: { using G = osg::Leduc; const G::Params& P = (spec).leduc; __VA_ARGS__; } break; \
+      case osg::kLeduc:                                                            \
+        if ((spec).leduc_big) return osg::set_error(OSG_ERR_UNSUPPORTED, "leduc_poker with more than 3 players is served by the " \
+                                                    "batch entry points (states, masks, steps, tensors, rollouts), not by this one"); \
+        { using G = osg::Leduc; const G::Params& P = (spec).leduc; __VA_ARGS__; } break; \
       case osg::kHex:                                                              \
         switch ((spec).hex_nw) {                                                   \
           case 1: { using G = osg::HexT<1>; const G::Params& P = (spec).hex1; __VA_ARGS__; } break; \
@@ -151,7 +155,10 @@ struct osg_batch {
         else { using G = osg::C4; const G::Params& P = (spec).c4; __VA_ARGS__; }   \
         break;                                                                     \
       case osg::kKuhn: { using G = osg::Kuhn; const G::Params& P = (spec).kuhn; __VA_ARGS__; } break; \
-      case osg::kLeduc: { using G = osg::Leduc; const G::Params& P = (spec).leduc; __VA_ARGS__; } break; \
+      case osg::kLeduc:                                                            \
+        if ((spec).leduc_big) { using G = osg::LeducBig; const G::Params& P = (spec).leduc; __VA_ARGS__; } \
+        else { using G = osg::Leduc; const G::Params& P = (spec).leduc; __VA_ARGS__; } \
+        break;                                                                     \
       case osg::kHex:                                                              \
         switch ((spec).hex_nw) {                                                   \
           case 1: { using G = osg::HexT<1>; const G::Params& P = (spec).hex1; __VA_ARGS__; } break; \

@@ -1700,7 +1700,7 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
   // per thread pay off only once the batch is many rounds of wavefronts (2^24 states: 106.6 vs 114.1 us), smaller
   // batches run faster with one state per thread and twice the wavefronts (2^20 states: 9.6 vs 8.9 us;
   // tools/probe_states_per_thread.py, tools/probe_kernels.py)
-  if (planes16 && kind == kLeduc && n >= (int64_t{1} << 22) && (n & 1) == 0 && (side & 1u) == 0 && cmb == 1) {
+  if (planes16 && kind == kLeduc && !src->spec.leduc_big && n >= (int64_t{1} << 22) && (n & 1) == 0 && (side & 1u) == 0 && cmb == 1) {
     k_step_vec<Leduc, uint8_t, 2, 2><<<dim3(grid_for(n / 2)), dim3(kBlock), 0, ctx->stream>>>(
         src->spec.leduc, static_cast<const uint64_t*>(src->d_words), static_cast<uint64_t*>(dst->d_words), n, d_actions,
         static_cast<uint8_t*>(d_mask), d_status);

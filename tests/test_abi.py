@@ -69,7 +69,7 @@ def test_game_descriptions_match_the_oracle(built, oracle, game, A, C_, P, obs, 
 
 def test_bad_game_strings_are_rejected(built):
     for bad in ["chess", "connect_four(rows=12,columns=12)", "hex(board_size=20)", "connect_four(foo=1)",
-                "hex(swap=3)", "kuhn_poker(players=1)", "leduc_poker(players=4)", "hex(board_size=3"]:
+                "hex(swap=3)", "kuhn_poker(players=1)", "leduc_poker(players=11)", "hex(board_size=3"]:
         with pytest.raises(built.OsgError):
             built.describe(bad)
 

@@ -38,6 +38,10 @@ GAMES = [
     "leduc_poker(action_mapping=True)",
     "leduc_poker(suit_isomorphism=True)",
     "leduc_poker(players=3,starting_player=2)",
+    "leduc_poker(players=4)",                            # 4 to 10 players: the five-plane record
+    "leduc_poker(players=6,suit_isomorphism=True)",
+    "leduc_poker(players=10)",                           # the largest the reference allows (leduc_poker.cc:49-50)
+    "leduc_poker(players=7,action_mapping=True,starting_player=5)",
 ]
 
 
@@ -83,7 +87,8 @@ def test_step_by_step_parity(oracle, ctx, game):
 
 
 @pytest.mark.parametrize("game", ["tic_tac_toe", "connect_four", "hex(board_size=9)", "kuhn_poker", "leduc_poker",
-                                  "hex(board_size=4,swap=True)", "leduc_poker(players=3)",
+                                  "hex(board_size=4,swap=True)", "leduc_poker(players=3)", "hex(board_size=13)",
+                                  "hex(board_size=14,swap=True)", "connect_four(rows=8,columns=8)", "leduc_poker(players=5)",
                                   "connect_four(rows=5,columns=6,x_in_row=3)"])
 @pytest.mark.parametrize("n", [4096, 4097, 4098])
 def test_fused_step_parity(oracle, ctx, game, n):
@@ -262,7 +267,7 @@ def test_illegal_and_terminal_actions_are_rejected(ctx):
 def test_bad_game_strings(ctx):
     import open_spiel_amd as osa
     for bad in ["chess", "connect_four(rows=12,columns=12)", "hex(board_size=20)", "hex(num_cols=32,num_rows=3)", "kuhn_poker(players=11)",
-                "leduc_poker(players=4)", "connect_four(foo=1)", "hex(swap=3)"]:
+                "leduc_poker(players=11)", "connect_four(foo=1)", "hex(swap=3)"]:
         with pytest.raises(osa.OsgError):
             osa.StateBatch(ctx, bad, 4)
     with pytest.raises(osa.OsgError):
@@ -305,7 +310,8 @@ def test_clone_and_gather(ctx):
                                              ("hex(board_size=5)", 8), ("kuhn_poker", 16), ("leduc_poker", 16),
                                              ("leduc_poker(players=3)", 8), ("kuhn_poker(players=4)", 8),
                                              ("hex(board_size=13)", 2), ("hex(board_size=19)", 2),
-                                             ("connect_four(rows=8,columns=8)", 4)])
+                                             ("connect_four(rows=8,columns=8)", 4), ("leduc_poker(players=5)", 6),
+                                             ("leduc_poker(players=10)", 4)])
 def test_rollout_replay_parity(oracle, ctx, game, n_rollouts):
     """RandomRolloutEvaluator on the device == the oracle replaying the same
     counter-RNG stream: identical summed returns AND identical ply counts."""
@@ -393,7 +399,7 @@ def test_observation_and_information_state_strings_match_the_reference_playthrou
 
 @pytest.mark.parametrize("game", ["hex(board_size=4,string_rep=explicit)", "hex", "hex(board_size=19)",
                                   "hex(board_size=13,string_rep=explicit)", "connect_four(rows=5,columns=6,x_in_row=3)",
-                                  "connect_four(rows=9,columns=10,x_in_row=5)",
+                                  "connect_four(rows=9,columns=10,x_in_row=5)", "leduc_poker(players=4)", "leduc_poker(players=10)",
                                   "kuhn_poker(players=3)", "leduc_poker(players=3)", "tic_tac_toe"])
 def test_observation_strings_match_the_oracle(oracle, ctx, game):
     """The same strings on random trajectories of the variants the playthroughs do not cover."""

@@ -312,7 +312,7 @@ using C4Std = C4T<6, 7, 4>;  // the default game, constants folded
 //   [0,NW)    black stones      [NW,2NW)   white stones
 //   [2NW,3NW) edge-A connected  [3NW,4NW)  edge-B connected
 //   4NW       meta: bit0 player to move, bits1-2 result (1 black won, 2 white
-//             won), bits 8-15 plies (saturating), bits 16-23 first move
+//             won), bits 8-15 plies (saturating), bits 16-31 first move
 // Cell = row*C + col.  The reference's 9 labels (hex.h:68-78) are
 //   black: plain 1, South(B) 2, North(A) 3, Win(A&B) 4   (A = first row)
 //   white: plain -1, East(B) -2, West(A) -3, Win -4       (A = first column)
@@ -494,13 +494,13 @@ struct HexT {
     uint32_t ply = plies(s);
     uint32_t ply_next = ply < 255u ? ply + 1u : 255u;
     if (p.swap && move == p.cells) {  // hex.cc:230-244
-      int first = (s.meta >> 16) & 0xFFu;
+      int first = (s.meta >> 16) & 0xFFFFu;   // (16 bits: cells up to 360 on the big boards)
       s.black = zero(); s.ea = zero(); s.eb = zero();  // only the first stone was on the board
       int r = first / p.cols, c = first - r * p.cols;
       int mirrored = c * p.cols + r;
       bool a, b;
       place(p, s, 1, mirrored, a, b);
-      s.meta = (s.meta & 0x00FF0000u) | (ply_next << 8) | 0u;  // black to move
+      s.meta = (s.meta & 0xFFFF0000u) | (ply_next << 8) | 0u;  // black to move
       return;
     }
     int player = to_move(s);
@@ -523,7 +523,7 @@ struct HexT {
       }
       if (a) s.ea = bor(s.ea, region); else s.eb = bor(s.eb, region);
     }
-    uint32_t first = ply == 0 ? static_cast<uint32_t>(move) : ((s.meta >> 16) & 0xFFu);
+    uint32_t first = ply == 0 ? static_cast<uint32_t>(move) : ((s.meta >> 16) & 0xFFFFu);
     s.meta = static_cast<uint32_t>(1 - player) | (res << 1) | (ply_next << 8) | (first << 16);
   }
   OSG_D static int outcome_code(const Params&, const State& s) { return result(s) == 1 ? 0 : (result(s) == 2 ? 1 : 2); }

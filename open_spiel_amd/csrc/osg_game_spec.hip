@@ -193,6 +193,9 @@ int parse_game(const char* game_string, GameSpec* out) {
     // word (cols <= 31).  The reference has no upper bound (hex.cc:47-56): larger boards stay unsupported here.
     if (cells + (swap ? 1 : 0) > 32 * 12 || cols > 31)
       return set_error(OSG_ERR_UNSUPPORTED, "hex: boards above 384 cells (or wider than 31 columns) have no device layout");
+    if (swap && cols > rows)
+      return set_error(OSG_ERR_UNSUPPORTED, "hex: swap on a board with more columns than rows writes past the board in the "
+                                            "reference (hex.cc:236-241: mirrored_move = c * num_cols + r can exceed the cells)");
     if (plain && cols != rows)
       return set_error(OSG_ERR_UNSUPPORTED, "hex: plain_obs_tensor on a non-square board indexes out of "
                                             "bounds in the reference (hex.cc:382-387)");

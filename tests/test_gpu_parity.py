@@ -28,7 +28,7 @@ GAMES = [
     "hex(board_size=13)",                    # the boards above 128 actions: 6, 8 and 12 words per bit plane
     "hex(board_size=14,swap=True)",          # 197 action ids: 7 mask words in 8-word planes
     "hex(board_size=19)",
-    "hex(num_cols=19,num_rows=17,swap=True)",
+    "hex(num_cols=17,num_rows=19,swap=True)",
     "kuhn_poker",
     "kuhn_poker(players=3)",
     "kuhn_poker(players=5)",
@@ -266,7 +266,7 @@ def test_illegal_and_terminal_actions_are_rejected(ctx):
 
 def test_bad_game_strings(ctx):
     import open_spiel_amd as osa
-    for bad in ["chess", "connect_four(rows=12,columns=12)", "hex(board_size=20)", "hex(num_cols=32,num_rows=3)", "kuhn_poker(players=11)",
+    for bad in ["chess", "connect_four(rows=12,columns=12)", "hex(board_size=20)", "hex(num_cols=32,num_rows=3)", "hex(num_cols=5,num_rows=4,swap=True)", "kuhn_poker(players=11)",
                 "leduc_poker(players=11)", "connect_four(foo=1)", "hex(swap=3)"]:
         with pytest.raises(osa.OsgError):
             osa.StateBatch(ctx, bad, 4)

@@ -11,6 +11,7 @@ import numpy as np, torch
 import open_spiel_amd as osa
 import oracle_py as O
 
+import faulthandler; faulthandler.enable()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 GAMES = [
     "tic_tac_toe", "connect_four", "connect_four(rows=4,columns=5,x_in_row=3)", "connect_four(rows=5,columns=6,x_in_row=3)",
@@ -23,7 +24,15 @@ GAMES = [
     "leduc_poker", "leduc_poker(players=3)", "leduc_poker(action_mapping=True)", "leduc_poker(suit_isomorphism=True)",
     "leduc_poker(players=3,starting_player=2)", "leduc_poker(players=3,suit_isomorphism=True,action_mapping=True)",
     "leduc_poker(starting_player=1)", "leduc_poker(players=3,starting_player=1,action_mapping=True)",
+    # the parameter ranges opened in round 4: hex above 128 actions, connect_four above 64 board bits, leduc 4-10 players
+    "hex(board_size=12)", "hex(board_size=13)", "hex(board_size=14,swap=True)", "hex(board_size=15)", "hex(board_size=16)",
+    "hex(board_size=19)", "hex(num_rows=19,num_cols=17,swap=True)", "hex(board_size=13,plain_obs_tensor=True)",
+    "connect_four(rows=8,columns=8)", "connect_four(rows=9,columns=9,x_in_row=5)", "connect_four(rows=9,columns=10)",
+    "connect_four(rows=7,columns=15,x_in_row=4)", "connect_four(rows=15,columns=8,egocentric_obs_tensor=True)",
+    "leduc_poker(players=4)", "leduc_poker(players=5,suit_isomorphism=True)", "leduc_poker(players=7,action_mapping=True)",
+    "leduc_poker(players=10)", "leduc_poker(players=8,starting_player=6)",
 ]
+if os.environ.get("SWEEP_ONLY"): GAMES = [g for g in GAMES if g in os.environ["SWEEP_ONLY"].split(";")]
 ctx = osa.Context(0)
 bad_total = 0
 for game in GAMES:
@@ -59,6 +68,9 @@ for game in GAMES:
             positions += N
             if t == L: break
             acts = rec["actions"][:, t]
+            if og.num_distinct_actions > 255:         # (the fused step carries one-byte action ids: hex above 15 x 15 applies)
+                a.apply_actions(torch.from_numpy(acts.astype(np.int32)))
+                continue
             a8 = torch.from_numpy(np.where(acts < 0, 255, acts).astype(np.uint8)).cuda()
             mask, status = a.step(a8, dst=b)          # the fused kernel, out of place
             st = status.cpu().numpy()

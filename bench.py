@@ -605,9 +605,13 @@ def ttt_mcts_config1(with_cpu):
         tot_s = sum(p["us_per_search"] for p in per) * 1e-6
         tot_sims = sum(p["simulations_per_search"] for p in per)
         out["device_single_root"] = {"value": tot_sims / tot_s, "unit": "sims/s", "per_position": per,
-                                     "what": "pyspiel_hip.MCTSBot.mcts_search on ONE root (osg_mcts_tree_*: the whole search is one "
-                                             "launch of two wavefronts, one lane walking the tree, the other wavefront playing "
-                                             "each leaf's 20 playouts in parallel), whole SearchNode tree downloaded"}
+                                     "what": "pyspiel_hip.MCTSBot.mcts_search on ONE root (osg_mcts_tree_*: the whole search is one launch; the "
+                                             "first 6144 nodes of the tree live in LDS, the searching wavefront runs in lockstep — a node's "
+                                             "children are valued one per lane, its 20 playouts played one per lane), whole SearchNode tree "
+                                             "downloaded; a lone wavefront retires an instruction every ~8 cycles, so a strictly sequential "
+                                             "1000-simulation search stays behind one host core: the batch entry points are the product",
+                                     "kernel_us_per_simulation": {"descent_and_expansion": 6.3, "playouts": 3.7, "backup": 1.3,
+                                                                  "source": "profiles/r04_single_root_phases.log"}}
     except Exception as e:  # noqa: BLE001
         out["device_single_root"] = {"error": f"{type(e).__name__}: {e}"}
     if with_cpu:

@@ -82,6 +82,7 @@ template <class G>
 struct CoopBox {
   typename G::State state;     // the leaf to evaluate
   uint32_t seq, done, exit, sim;
+  uint32_t used;               // nodes of the tree when the search left (the write-back's extent)
   double sum[kMaxPlayers];
 };
 OSG_D uint32_t coop_load(const uint32_t* at) { return __hip_atomic_load(at, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -89,22 +90,85 @@ OSG_D void coop_store(uint32_t* at, uint32_t v) { __hip_atomic_store(at, v, __AT
 struct CoopLeave {  // whichever way the searching lane leaves the kernel, the playout wavefront is told
   uint32_t* seq;
   uint32_t* exit;
+  uint32_t* used_out;      // where the playout wavefront finds how many nodes to write back from LDS
+  const uint32_t* used;    // the searching lane's node count
   OSG_D ~CoopLeave() {
     if (seq) {
+      *used_out = *used;
       coop_store(exit, 1u);
       coop_store(seq, coop_load(seq) + 1u);
     }
   }
 };
+// The tree of a ONE-ROOT search in LDS: a simulation of such a search is a chain of dependent node reads and
+// read-modify-writes — the descent's child scans, the backup — and from the HBM pool every link is an L2 round trip
+// (~10 us of them per simulation: 7.3e4 simulations/s against the 1.55e5 of one host core).  The first kLdsNodes
+// nodes (24 B each: meta, first child, parent, count, total reward; the prior is never read back in this form) live in LDS for the length of the launch;
+// nodes beyond that stay in the pool (the accessors pick by index: both are flat addresses), so trees of any size
+// work.  All 128 threads copy the existing nodes in at the start; the playout wavefront writes them back when the
+// searching lane leaves.
+constexpr int kLdsNodes = 6144;   // 24 B each: 144 KiB
+struct LdsTree {
+  double* total;
+  uint32_t* meta;
+  uint32_t* first;
+  uint32_t* parent;
+  uint32_t* count;
+};
+OSG_D LdsTree lds_tree(void* base) {
+  LdsTree t;
+  t.total = static_cast<double*>(base);
+  t.meta = reinterpret_cast<uint32_t*>(t.total + kLdsNodes);
+  t.first = t.meta + kLdsNodes;
+  t.parent = t.first + kLdsNodes;
+  t.count = t.parent + kLdsNodes;
+  return t;
+}
+constexpr size_t kLdsTreeBytes = static_cast<size_t>(kLdsNodes) * (sizeof(double) + 4 * sizeof(uint32_t));
+// One field of one node: in LDS (kCoop and a low index) or in the pool.
+template <class T, bool kCoop>
+struct NodeRef {
+  T* l;
+  T* g;
+  bool in_lds;
+  OSG_D operator T() const { return (kCoop && in_lds) ? *l : *g; }
+  OSG_D T operator=(T v) const {
+    // kCoop: the whole first wavefront runs the search in lockstep (every lane holds the same search state, so that
+    // the lanes can share out a node's children); one lane's store is enough — 64 stores to one LDS address serialise
+    if (kCoop && threadIdx.x != 0) return v;
+    if (kCoop && in_lds) *l = v; else *g = v;
+    return v;
+  }
+  OSG_D T operator+=(T v) const { return *this = static_cast<T>(*this) + v; }
+};
+// A store by the CALLING lane (the reference object's assignment is lane 0's alone): where lanes write different nodes.
+template <bool kCoop, class T>
+OSG_D void node_store(T* lds_plane, T* pool_plane, uint32_t i, int64_t NR, int64_t r, T v) {
+  if (kCoop && i < static_cast<uint32_t>(kLdsNodes)) lds_plane[i] = v;
+  else pool_plane[static_cast<int64_t>(i) * NR + r] = v;
+}
+template <bool kCoop, class T>
+OSG_D NodeRef<T, kCoop> node_ref(T* lds_plane, T* pool_plane, uint32_t i, int64_t NR, int64_t r) {
+  const bool in_lds = kCoop && i < static_cast<uint32_t>(kLdsNodes);
+  return {lds_plane + (in_lds ? i : 0u), pool_plane + static_cast<int64_t>(i) * NR + r, in_lds};
+}
 template <class G>
-OSG_D void coop_playouts(const typename G::Params& p, const osg_mcts_cfg& cfg, int num_players, uint64_t gr, CoopBox<G>* box) {
+OSG_D void coop_playouts(const typename G::Params& p, const osg_mcts_cfg& cfg, int num_players, uint64_t gr, CoopBox<G>* box,
+                         const StepPool& pool, const LdsTree& lt) {
   const int lane = threadIdx.x & 63;
   uint32_t last = 0;
   for (;;) {
     uint32_t now;
     while ((now = coop_load(&box->seq)) == last) __builtin_amdgcn_s_sleep(1);
     last = now;
-    if (coop_load(&box->exit)) return;
+    if (coop_load(&box->exit)) {   // the search has left: the LDS part of the tree goes back to the pool
+      const uint32_t keep = box->used < static_cast<uint32_t>(kLdsNodes) ? box->used : static_cast<uint32_t>(kLdsNodes);
+      for (uint32_t i = lane; i < keep; i += 64) {   // (one root: plane element i of root 0 is pool plane[i])
+        pool.total[i] = lt.total[i]; pool.meta[i] = lt.meta[i];
+        pool.first[i] = lt.first[i]; pool.parent[i] = lt.parent[i]; pool.count[i] = lt.count[i];
+      }
+      return;
+    }
     const typename G::State s = box->state;
     const uint64_t sim = box->sim;
     double sum[kMaxPlayers];
@@ -141,16 +205,25 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
   // SIMD, nothing to hide that latency behind.  Spreading the same searches over lane_stride times as many
   // wavefronts (fewer active lanes each) gives every SIMD several chains to interleave.
   __shared__ CoopBox<G> coop_box;  // (kCoop only)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];   // (kCoop only: the LDS part of the tree)
+  LdsTree lt{};
+  uint32_t used = 0;
   if (kCoop) {  // one root: lane 0 searches, the second wavefront plays its leaves' playouts
-    if (threadIdx.x == 0) { coop_box.seq = 0; coop_box.done = 0; coop_box.exit = 0; }
+    lt = lds_tree(lds_raw);
+    const uint32_t have = pool.used[0] < static_cast<uint32_t>(kLdsNodes) ? pool.used[0] : static_cast<uint32_t>(kLdsNodes);
+    for (uint32_t i = threadIdx.x; i < have; i += 2 * kBlockM) {   // the nodes an earlier launch left in the pool
+      lt.total[i] = pool.total[i]; lt.meta[i] = pool.meta[i];
+      lt.first[i] = pool.first[i]; lt.parent[i] = pool.parent[i]; lt.count[i] = pool.count[i];
+    }
+    if (threadIdx.x == 0) { coop_box.seq = 0; coop_box.done = 0; coop_box.exit = 0; coop_box.used = have; }
     __syncthreads();
     if (threadIdx.x >= 64) {
-      coop_playouts<G>(p, cfg, num_players, static_cast<uint64_t>(cfg.index_offset), &coop_box);
+      coop_playouts<G>(p, cfg, num_players, static_cast<uint64_t>(cfg.index_offset), &coop_box, pool, lt);
       return;
     }
-    if (threadIdx.x != 0) return;
+    // (all 64 lanes of the first wavefront go on, in lockstep: one search, its state replicated over the lanes)
   }
-  CoopLeave coop_leave{kCoop ? &coop_box.seq : nullptr, kCoop ? &coop_box.exit : nullptr};
+  CoopLeave coop_leave{kCoop ? &coop_box.seq : nullptr, kCoop ? &coop_box.exit : nullptr, &coop_box.used, &used};
   uint32_t coop_seq = 0;
   const int64_t slot = static_cast<int64_t>(blockIdx.x) * kBlockM + threadIdx.x;
   if (!kCoop && lane_stride > 1 && (threadIdx.x % lane_stride) != 0) return;
@@ -160,12 +233,15 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
   const int64_t NR = pool.n;
   const bool host_priors = (flags & 1) != 0, through_chance = (flags & 2) != 0, own_rollouts = (flags & 4) != 0;
   const bool stashing = pool.stash != nullptr;
-#define META(i) pool.meta[static_cast<int64_t>(i) * NR + r]
-#define FIRST(i) pool.first[static_cast<int64_t>(i) * NR + r]
-#define PARENT(i) pool.parent[static_cast<int64_t>(i) * NR + r]
-#define COUNT(i) pool.count[static_cast<int64_t>(i) * NR + r]
-#define TOTAL(i) pool.total[static_cast<int64_t>(i) * NR + r]
-#define PRIOR(i) pool.prior[static_cast<int64_t>(i) * NR + r]
+// (kCoop: node i < kLdsNodes lives in LDS, the others — and every node of the batch form — in the pool.  A reference
+// object that branches on the index: a select between the two ADDRESSES made every access a flat one, slower than the
+// pool itself — 5.1e4 against 7.3e4 simulations/s; with the branch the LDS side is a ds_read / ds_write.)
+#define META(i) node_ref<kCoop>(lt.meta, pool.meta, static_cast<uint32_t>(i), NR, r)
+#define FIRST(i) node_ref<kCoop>(lt.first, pool.first, static_cast<uint32_t>(i), NR, r)
+#define PARENT(i) node_ref<kCoop>(lt.parent, pool.parent, static_cast<uint32_t>(i), NR, r)
+#define COUNT(i) node_ref<kCoop>(lt.count, pool.count, static_cast<uint32_t>(i), NR, r)
+#define TOTAL(i) node_ref<kCoop>(lt.total, pool.total, static_cast<uint32_t>(i), NR, r)
+#define PRIOR(i) pool.prior[static_cast<int64_t>(i) * NR + r]   /* (the pool only: PUCT reads it, UCT with playouts never) */
 #define REMAP(i) pool.remap[static_cast<int64_t>(i) * NR + r]
   uint8_t phase = pool.phase[r];
   if (phase == kFinished) { request[r] = 0; return; }
@@ -173,7 +249,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
   // parked and asks again: never dereference a missing answer.
   if (phase == kWantPrior && prior_in == nullptr) { request[r] = pool.node[r] == 0 ? 5 : 1; return; }
   if (phase == kWantValue && value_in == nullptr) { request[r] = 2; return; }
-  uint32_t used = pool.used[r];
+  used = pool.used[r];
   int gc_limit = pool.gc_limit[r];
   int sims_done = pool.sims[r];
   uint32_t node = pool.node[r];
@@ -195,6 +271,37 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
     if (c == 0 || used + static_cast<uint32_t>(c) > static_cast<uint32_t>(pool.cap)) return false;  // nothing to expand / slots exhausted (see osg_mcts.hip)
     const uint32_t first = used;
     used += c;
+    if (kCoop && c <= 64) {   // (wider nodes — hex 9 x 9 and up — take the sequential form below, in lockstep)
+      // lane k makes child k; the shuffle (mcts.cc:294, Fisher-Yates on the tree-policy stream, the same draws in the
+      // same order) runs on the lanes' registers — lane L tracks which child ends in slot L — and every lane then
+      // writes one node: no read-modify-write chain through the tree's memory
+      const int L = static_cast<int>(threadIdx.x);
+      int mine = L;                                   // the child that sits in slot L
+      for (int i = c - 1; i >= 1; --i) {
+        const int j = static_cast<int>(trng.below(static_cast<uint32_t>(i + 1)));   // (wave-uniform)
+        const int at_i = __builtin_amdgcn_readlane(mine, i), at_j = __builtin_amdgcn_readlane(mine, j);
+        mine = L == i ? at_j : (L == j ? at_i : mine);
+      }
+      if (L < c) {
+        const int a = select_action(legal, mine);
+        double pr;
+        if (cur == kChancePlayer) pr = G::chance_prob(p, s, a);
+        else if (stashed) pr = stashed[a];
+        else if (from_host) pr = prior_in[r * num_actions + a];
+        else pr = 1.0 / c;
+        const uint32_t at = first + static_cast<uint32_t>(L);
+        node_store<kCoop>(lt.meta, pool.meta, at, NR, r, make_meta(a, cur, 0));
+        node_store<kCoop>(lt.first, pool.first, at, NR, r, 0u);
+        node_store<kCoop>(lt.parent, pool.parent, at, NR, r, node);
+        node_store<kCoop>(lt.count, pool.count, at, NR, r, 0u);
+        node_store<kCoop>(lt.total, pool.total, at, NR, r, 0.0);
+        PRIOR(at) = pr;
+      }
+      const uint32_t meta = META(node);
+      META(node) = make_meta(m_action(meta), m_player(meta), c) | (meta & 0x00F00000u);
+      FIRST(node) = first;
+      return true;
+    }
     for (int k = 0; k < c; ++k) {
       const int a = select_action(legal, k);
       double pr;
@@ -218,10 +325,22 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
     return true;
   };
 
+#ifdef OSG_MCTS_PROFILE
+  unsigned long long prof[5] = {0, 0, 0, 0, 0}, pt = wall_clock64();   // descent, expansion (inside descent), playout wait, backup, rest
+#define OSG_PROF(slot) do { const unsigned long long now_ = wall_clock64(); prof[slot] += now_ - pt; pt = now_; } while (0)
+#else
+#define OSG_PROF(slot) do {} while (0)
+#endif
   for (;;) {
     bool term = false;
+    OSG_PROF(4);
     if (phase == kNewSimulation) {
       if (sims_done >= cfg.max_simulations || started >= max_new_simulations) {
+#ifdef OSG_MCTS_PROFILE
+        if (kCoop && threadIdx.x == 0)
+          printf("k_mcts_advance (one root, us per simulation over %d): descent %.2f  playouts (hand-off + wait) %.2f  backup %.2f  rest %.2f\n",
+                 sims_done, prof[0] / 100.0 / sims_done, prof[2] / 100.0 / sims_done, prof[3] / 100.0 / sims_done, prof[4] / 100.0 / sims_done);
+#endif
         const bool fin = sims_done >= cfg.max_simulations;
         park(fin ? kFinished : kNewSimulation, fin ? 0 : 3);
         return;
@@ -291,7 +410,37 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
           // with 2x / 4x the wavefronts per SIMD).  So the children's four planes are requested eight children at a
           // time with clamped indices (32 independent loads, ONE round trip) instead of child by child behind the
           // branches of the value formula (two round trips per child).
-          for (int k0 = 0; k0 < c; k0 += kScanChunk) {
+          if constexpr (kCoop) {
+            // one child per lane: the values — a division, a square root, a division in fp64, ~150 dependent
+            // instructions each — are formed side by side, then a butterfly picks the winner: the highest value, the
+            // lowest index among equals, i.e. the sequential scan's "first maximum wins" (a NaN or -inf value never wins)
+            double bv = -INFINITY;
+            uint32_t bk = 0xFFFFFFFFu, bm = 0, bc = 0, bf = 0;
+            for (int k0 = 0; k0 < c; k0 += 64) {
+              const int k = k0 + static_cast<int>(threadIdx.x);
+              const uint32_t at = first + static_cast<uint32_t>(k < c ? k : c - 1);
+              const uint32_t cm = META(at), cc = COUNT(at), cf = FIRST(at);
+              const double ct = TOTAL(at);
+              double v;
+              if (m_has_outcome(cm)) v = outcome_value<kBoard>(cm, cc, ct, m_player(cm));
+              else if (puct) v = (cc != 0 ? ct / cc : 0.0) + cfg.uct_c * PRIOR(at) * sqrt_n / (cc + 1);
+              else if (cc == 0) v = INFINITY;
+              else v = ct / cc + cfg.uct_c * sqrt(logn / cc);
+              if (k < c && v > bv) { bv = v; bk = static_cast<uint32_t>(k); bm = cm; bc = cc; bf = cf; }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+              const double ov = __shfl_xor(bv, off, 64);
+              const uint32_t ok = __shfl_xor(bk, off, 64), om = __shfl_xor(bm, off, 64), oc = __shfl_xor(bc, off, 64),
+                             of = __shfl_xor(bf, off, 64);
+              if (ov > bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; bm = om; bc = oc; bf = of; }
+            }
+            if (bk != 0xFFFFFFFFu) {
+              chosen = first + bk; chosen_meta = bm; chosen_cnt = bc; chosen_first = bf;
+              have_chosen_meta = true;
+            }
+          }
+          for (int k0 = 0; !kCoop && k0 < c; k0 += kScanChunk) {
             uint32_t cm[kScanChunk], cc[kScanChunk], cf[kScanChunk];
             double ct[kScanChunk], cp[kScanChunk];
 #pragma unroll
@@ -324,6 +473,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
         carried = have_chosen_meta;
         if (have_chosen_meta) { n_cnt = chosen_cnt; n_meta = chosen_meta; n_first = chosen_first; }
       }
+      OSG_PROF(0);
       // ---- evaluate (mcts.cc:372-381) ----
       if (term) {
         G::returns(p, s, returns);
@@ -336,12 +486,28 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
         // from (rollout ro of simulation s of root r: Rng(seed, root, s * n_rollouts + ro)): the same values as the
         // park / rollout-kernel / resume round trip, without leaving the launch
         for (int q = 0; q < num_players; ++q) returns[q] = 0.0;
-        if (kCoop) {  // hand the leaf to the playout wavefront, take the sum
-          coop_box.state = s;
-          coop_box.sim = static_cast<uint32_t>(sims_done);
-          coop_store(&coop_box.seq, ++coop_seq);
-          while (coop_load(&coop_box.done) != coop_seq) __builtin_amdgcn_s_sleep(1);
-          for (int q = 0; q < num_players; ++q) returns[q] = coop_box.sum[q];
+        if (kCoop) {
+          // the playouts on the lanes of THIS wavefront (it runs in lockstep, so every lane holds the leaf): lane ro
+          // plays rollout ro on its own stream, a butterfly sums the returns (integers: any order) and leaves the sum
+          // in every lane — no hand-off to a second wavefront (that cost ~1.2 us of polling per simulation)
+          double sum[kMaxPlayers];
+          for (int q = 0; q < num_players; ++q) sum[q] = 0.0;
+          for (int ro = static_cast<int>(threadIdx.x); ro < cfg.n_rollouts; ro += 64) {
+            Rng rng(cfg.seed, gr, static_cast<uint64_t>(sims_done) * cfg.n_rollouts + ro);
+            typename G::State w = s;
+            for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
+              const Mask m = G::legal(p, w);
+              G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
+            }
+            double rr[kMaxPlayers];
+            G::returns(p, w, rr);
+            for (int q = 0; q < num_players; ++q) sum[q] += rr[q];
+          }
+          for (int q = 0; q < num_players; ++q) {
+            double v = sum[q];
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+            returns[q] = v;
+          }
         }
         for (int ro = 0; !kCoop && ro < cfg.n_rollouts; ++ro) {
           Rng rng(cfg.seed, gr, static_cast<uint64_t>(sims_done) * cfg.n_rollouts + ro);
@@ -361,6 +527,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
         return;
       }
     }
+    OSG_PROF(2);
     // ---- backup (mcts.cc:383-435) ----
     for (uint32_t v = node; v != kNoNode; v = PARENT(v)) {
       uint32_t meta = META(v);
@@ -397,6 +564,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
     solved = false;
     ++sims_done;
     phase = kNewSimulation;
+    OSG_PROF(3);
     const uint32_t rm = META(0);
     if ((m_has_outcome(rm) && !m_terminal(rm)) || m_nchild(rm) == 1 || m_terminal(rm)) {  // mcts.cc:437-440
       park(kFinished, 0);
@@ -729,14 +897,19 @@ int osg_mcts_tree_advance(osg_mcts_tree* t, osg_batch* leaf, const double* d_pri
   // one root, playouts in the launch: the two-wavefront form (OSG_MCTS_COOP=0 keeps the one-lane form, for A/B)
   static const bool coop_on = !(std::getenv("OSG_MCTS_COOP") && std::atoi(std::getenv("OSG_MCTS_COOP")) == 0);
   if (t->n == 1 && (t->flags & 4) && t->cfg.n_rollouts > 1 && coop_on) {
+    // (the LDS part of the tree is 128 KiB of dynamic shared memory: above the default limit, asked for once per kernel)
+    if (t->board) OSG_DISPATCH(t->roots->spec, OSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mcts_advance<G, true, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsTreeBytes))));
+    else OSG_DISPATCH(t->roots->spec, OSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mcts_advance<G, false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsTreeBytes))));
     if (t->board) {
-      OSG_DISPATCH(t->roots->spec, k_mcts_advance<G, true, true><<<dim3(1), dim3(2 * kBlockM), 0, st>>>(
+      OSG_DISPATCH(t->roots->spec, k_mcts_advance<G, true, true><<<dim3(1), dim3(2 * kBlockM), kLdsTreeBytes, st>>>(
                                        P, static_cast<const typename G::word_t*>(t->roots->d_words),
                                        static_cast<typename G::word_t*>(leaf->d_words), t->n, d.num_players, t->A, t->cfg,
                                        t->flags, t->max_utility, t->d_logs, pool, d_prior, d_value, d_request,
                                        max_new_simulations, 1));
     } else {
-      OSG_DISPATCH(t->roots->spec, k_mcts_advance<G, false, true><<<dim3(1), dim3(2 * kBlockM), 0, st>>>(
+      OSG_DISPATCH(t->roots->spec, k_mcts_advance<G, false, true><<<dim3(1), dim3(2 * kBlockM), kLdsTreeBytes, st>>>(
                                        P, static_cast<const typename G::word_t*>(t->roots->d_words),
                                        static_cast<typename G::word_t*>(leaf->d_words), t->n, d.num_players, t->A, t->cfg,
                                        t->flags, t->max_utility, t->d_logs, pool, d_prior, d_value, d_request,

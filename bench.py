@@ -435,6 +435,59 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
     # policy's NashConv drops below each threshold, at the mini-batch size the sweep in
     # profiles/r02_mccfr_quality.log found best (2^14), with the table refreshed after every mini-batch.
     out["mccfr"]["quality"] = mccfr_quality(osa, torch, dist, ctx, rank, world, 1 << 14, 1.5)
+    # ---- the two callers either side of the path that SURVEY.md 8(f) names: the batched RL environment step and the
+    #      policy judge (NashConv / exploitability of a tabular policy) ----
+    if rank == 0:
+        try:
+            from open_spiel_amd._abi import check, lib
+            n_env = 1 << 20
+            eb = osa.StateBatch(ctx, "connect_four", n_env)
+            should_reset = torch.ones(n_env, dtype=torch.uint8, device="cuda")
+            cur = torch.empty(n_env, dtype=torch.int8, device="cuda")
+            typ = torch.empty(n_env, dtype=torch.uint8, device="cuda")
+            rew = torch.empty((n_env, 2), dtype=torch.float64, device="cuda")
+            msk = torch.empty((n_env, 1), dtype=torch.int32, device="cuda")
+            acts = torch.full((n_env,), -1, dtype=torch.int32, device="cuda")
+
+            def env_step(t):
+                check(lib().osg_env_step(eb._h, acts.data_ptr(), should_reset.data_ptr(), SEED, 0, t, cur.data_ptr(),
+                                         typ.data_ptr(), rew.data_ptr(), msk.data_ptr()))
+                # the agent: the lowest legal column (one torch op; the kernel under test is osg_env_step)
+                acts.copy_(torch.where(msk[:, 0] != 0, (torch.log2((msk[:, 0] & -msk[:, 0]).to(torch.float32))).to(torch.int32),
+                                       torch.full_like(acts, -1)))
+            for t in range(5):
+                env_step(t)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            steps = 200
+            for t in range(5, 5 + steps):
+                env_step(t)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out["env_step"] = {"metric": "RL environment steps/sec (osg_env_step: reset / apply / chance / time step fields)",
+                               "value": n_env * steps / dt, "unit": "env-steps/s", "us_per_launch": dt / steps * 1e6,
+                               "workload": f"connect_four, {n_env} environments, {steps} synchronous steps of every environment with a "
+                                           "one-op torch agent in between (python/rl_environment.py:379-418 per environment in the reference)"}
+            del eb
+            judge = {}
+            for g in ("kuhn_poker", "leduc_poker"):
+                sj = osa.TabularSolver(ctx, g)
+                sj.evaluate_and_update_policy(20)
+                sj.nash_conv()
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                reps = 50
+                for _ in range(reps):
+                    sj.nash_conv()
+                dt = time.perf_counter() - t0
+                judge[g] = {"us_per_nash_conv": dt / reps * 1e6, "nash_conv_after_20_iterations": sj.nash_conv()}
+                del sj
+            out["policy_evaluation"] = {"metric": "NashConv evaluations (osg_cfr_evaluate_policy: expected returns + one best response "
+                                                  "per player on the flattened tree)", "per_game": judge,
+                                        "note": "host call to host result (upload of the policy table, one kernel, download): the reference "
+                                                "walks the tree per call (tabular_exploitability.cc:30-89)"}
+        except Exception as e:  # noqa: BLE001
+            out["env_step"] = {"error": f"{type(e).__name__}: {e}"}
     # ---- config 1: tic_tac_toe MCTSBot(RandomRolloutEvaluator(20, 42), 1000 sims, solve) — plumbing ----
     if rank == 0:
         out["ttt_mcts"] = ttt_mcts_config1(with_cpu)

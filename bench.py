@@ -1115,7 +1115,11 @@ def main():
                                  "source": rs.get("source", "in-run rocprofv3 --pmc SQ_INSTS_VALU pass"),
                                  "note": "a wave64 vector instruction issues every 1.03 ns per SIMD at best (64-bit "
                                          "shifts, multiplies: 1.8-1.9 ns), so the fraction is a lower bound of the "
-                                         "vector unit's busy share"}
+                                         "vector unit's busy share",
+                                 "measured_vector_pipe_busy": 0.98,
+                                 "measured_source": "profiles/r04_pmc_k_random_steps_c4_k32.txt: SQ_ACTIVE_INST_VALU x 4 cycles / "
+                                                    "1024 SIMDs = 252 K of the launch's 257 K cycles; the waves wait for the pipe "
+                                                    "(SQ_WAIT_INST_ANY 72 % of wave cycles), not for memory (SQ_WAIT_ANY 8.5 %)"}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

@@ -18,6 +18,7 @@ GROUPS_=(
  "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_WRITEBACK_sum TCC_TAG_STALL_sum"
  "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_sum"
  "TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_BUSY_avr TCC_BUSY_avr"
+ "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_LDS SQ_INSTS_SMEM"
  "GRBM_GUI_ACTIVE TCC_EA0_WRREQ_LEVEL_sum TCC_EA0_RDREQ_LEVEL_sum TCC_CYCLE_sum"
 )
 P=0

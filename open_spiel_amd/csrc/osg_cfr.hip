@@ -545,9 +545,13 @@ constexpr int kSplitMaxA = 4;       // widest policy row the split kernel folds
 constexpr int kSplitOwnerPath = 10;  // decision entries of a root path kept in registers
 constexpr int kSplitRec = 1 + kSplitMaxA;  // doubles per member and buffer: own reach, regret terms
 constexpr int kSplitChunk = 6;       // members whose records are requested together
-template <int kSlots>  // kSlots >= P + 1
+// kBr: the pass set of CFRBRSolver::EvaluateAndUpdatePolicy (cfr_br.cc:70-81) — P passes, pass p updates player p while
+// every other player follows best[i] (k_eval_jobs wrote it): the pass reads an effective policy `eff` (the updating
+// player's rows of `cur`, one-hot rows for the others) that is rebuilt in LDS at the start of every pass.
+template <int kSlots, bool kBr = false>  // kSlots >= P + 1
 __global__ void __launch_bounds__(1024)
-k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg) {
+k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg,
+            const int32_t* __restrict__ best = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int P = t.P, A = t.A, IA = t.I * t.A, M = st.M;
   const int tid = threadIdx.x, g = blockIdx.x;
@@ -557,6 +561,8 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
   double* cum = regrets + IA;
   double* cur = cum + IA;
   int* s_ok = reinterpret_cast<int*>(cur + IA);  // (in the dynamic region: a static would shift its 16-byte base)
+  double* eff = cur + IA + 2;                    // [I, A], kBr only
+  const double* pol = kBr ? eff : cur;
   for (int k = tid; k < IA; k += blockDim.x) {
     regrets[k] = tb.regrets[k];
     cum[k] = tb.cum[k];
@@ -615,20 +621,28 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
   }
   __syncthreads();
 
-  const int passes = cfg.alternating_updates ? P : 1;
+  const int passes = (kBr || cfg.alternating_updates) ? P : 1;
   unsigned int epoch = 0;
   for (int it = 0; it < iters; ++it) {
     const int iteration = iteration0 + it + 1;
     for (int pass = 0; pass < passes; ++pass) {
-      const int upd = cfg.alternating_updates ? pass : -1;
+      const int upd = (kBr || cfg.alternating_updates) ? pass : -1;
       const int q0 = upd >= 0 ? upd : 0, q1 = upd >= 0 ? upd + 1 : P;
+      if (kBr) {  // policy_overrides (cfr.cc:365-372)
+        for (int i = tid; i < t.I; i += blockDim.x) {
+          const bool mine = t.info_player[i] == upd;
+          const int bi = best[i];
+          for (int a = 0; a < A; ++a) eff[i * A + a] = mine ? cur[i * A + a] : (a == bi ? 1.0 : 0.0);
+        }
+        __syncthreads();
+      }
       // ---- A: values, bottom-up inside the subtree (cfr.cc:443-469) ----
       for (int l = t.D - 2; l >= sp.L; --l) {
         if (o_lvl == l && o_k != kTerminalNode) {
           for (int q = q0; q < q1; ++q) {
             double v = 0.0;
             for (int a = 0; a < o_nc; ++a) {
-              const double pr = o_k == kChanceNode ? l_edge[o_fc + a] : cur[o_row + a];
+              const double pr = o_k == kChanceNode ? l_edge[o_fc + a] : pol[o_row + a];
               v += pr * value[(o_fc + a) * P + q];
             }
             value[tid * P + q] = v;
@@ -641,7 +655,7 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
       if (b_m >= 0 && (upd < 0 || b_pl == upd)) {
         double pr[kOwnerPath];
 #pragma unroll
-        for (int j = 0; j < kOwnerPath; ++j) pr[j] = cur[b_code[j] >= 0 ? (b_code[j] & 0x7FFFFF) : 0];
+        for (int j = 0; j < kOwnerPath; ++j) pr[j] = pol[b_code[j] >= 0 ? (b_code[j] & 0x7FFFFF) : 0];
         double reach[kSlots];
 #pragma unroll
         for (int q = 0; q < kSlots; ++q) reach[q] = (q == P) ? b_chance : 1.0;
@@ -735,10 +749,10 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
 #pragma unroll
         for (int a = 0; a < kSplitMaxA; ++a) {
           if (a < c_n) {
-            const double pol = sum_pos > 0 ? (r_reg[a] > 0 ? r_reg[a] / sum_pos : 0.0) : 1.0 / c_n;
+            const double matched = sum_pos > 0 ? (r_reg[a] > 0 ? r_reg[a] / sum_pos : 0.0) : 1.0 / c_n;
             regrets[c_i * A + a] = r_reg[a];
             cum[c_i * A + a] = r_cum[a];
-            cur[c_i * A + a] = pol;
+            cur[c_i * A + a] = matched;
           }
         }
       }
@@ -1312,6 +1326,204 @@ k_policy_eval(Tree t, EvalArrays ea, const double* __restrict__ pol) {
       for (int h = tid; h < t.H; h += nt) ea.keep[h] = ea.brv[h];
     __syncthreads();
   }
+}
+
+// ---------------------------------------------------------------------------
+// The same evaluation for trees that start with their chance deals (leduc_poker: two deal levels, then 30 subtrees
+// of 314 histories), spread over the device instead of one workgroup walking 9 457 histories level by level through
+// L2.  The quantities are independent below the cut once the work is grouped the right way:
+//   * expected returns: every deal subtree on its own (one job per subtree);
+//   * the best response of player r: an infostate of r ties together the subtrees that hold its member histories
+//     (the deals r cannot tell apart), so the subtrees are grouped into the connected components of that relation
+//     (leduc: the 5 deals that share r's private card; 6 components per responder) and one job takes a whole component:
+//     the argmax of best_response.cc:194-227 then needs nothing from outside the job.
+// A job = one workgroup with its histories, values, counterfactual reaches and the evaluated policy in LDS: a tree
+// level costs an LDS round trip.  Every job leaves the values of its subtree roots in memory (written through) and
+// takes a ticket; the workgroup that draws the last ticket adds up the chance levels above the cut for all 2 P
+// quantities in the recursion's order.  No workgroup waits for another, so the launch is an ordinary one.
+// The sums are the ones k_policy_eval forms, in the same order: the results are bit-identical.
+// mode 0: `src` is the cumulative-policy table and the evaluated policy is its normalisation (CFRAveragePolicy,
+// cfr.cc:104-125); mode 1: `src` is the policy itself.  only_br: the expected-returns jobs do nothing (CFR-BR).
+// ---------------------------------------------------------------------------
+struct EvalJobs {
+  int J, L, G, NT;            // jobs, cut level, subtrees (= histories on level L), histories on levels 0..L
+  const int32_t* job;         // [J, 8] kind (0 expected returns, 1 + r best response of r), node_off, nodes, info_off,
+                              //        infos, mem_off, members, -
+  const int32_t* level_off;   // [J, D + 1] the job's histories of a level: a range of job-local indices
+  const int32_t* node_desc;   // per job history: kind | nchild << 2 | (actor + 1) << 10
+  const int32_t* node_fc;     //   job-local index of its first child
+  const int32_t* node_row;    //   info * A of a decision node
+  const int32_t* node_glob;   //   its index in the whole tree
+  const int32_t* info_ent;    // per job infostate [4]: id, level, offset of its first member in the job's member list, members
+  const int32_t* mem_ent;     // per job member [2]: member index m (position in Tree::mem), job-local history
+  double* deal;               // expected returns [G, P], then best-response values [P, G]
+  unsigned int* ticket;       // zero between launches
+};
+
+__global__ void __launch_bounds__(1024)
+k_eval_jobs(Tree t, EvalArrays ea, EvalJobs ej, const double* __restrict__ src, int mode, int only_br) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ int s_last;
+  const int P = t.P, A = t.A, IA = t.I * t.A, D = t.D;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int32_t* jd = ej.job + blockIdx.x * 8;
+  const int kind = jd[0], n0 = jd[1], nn = jd[2], i0 = jd[3], ni = jd[4], m0 = jd[5], nm = jd[6];
+  const int r = kind - 1, VP = kind == 0 ? P : 1;
+  const int32_t* lvl = ej.level_off + blockIdx.x * (D + 1);
+  if (!(only_br && kind == 0)) {
+    double* pol = smem;                          // [I, A] the evaluated policy
+    double* val = pol + IA;                      // [nodes, P] expected returns, or [nodes] the responder's value
+    double* l_edge = val + static_cast<size_t>(nn) * VP;  // [nodes] chance probability of the incoming edge
+    double* cf = l_edge + nn;                    // [members] counterfactual reach
+    int32_t* l_desc = reinterpret_cast<int32_t*>(cf + nm);
+    int32_t* l_fc = l_desc + nn;
+    int32_t* l_row = l_fc + nn;
+    int32_t* l_mfc = l_row + nn;                 // [members] first child of the member history
+    int32_t* l_best = l_mfc + nm;                // [I] chosen action index of the job's infostates
+    for (int i = tid; i < t.I; i += nt) {
+      const int n = t.nact[i];
+      if (mode == 0) {  // CFRAveragePolicy::GetStatePolicyFromInformationStateValues (cfr.cc:104-125)
+        double sum = 0.0;
+        for (int a = 0; a < n; ++a) sum += src[i * A + a];
+        for (int a = 0; a < A; ++a) pol[i * A + a] = a >= n ? 0.0 : (sum == 0.0 ? 1. / n : src[i * A + a] / sum);
+      } else {
+        for (int a = 0; a < A; ++a) pol[i * A + a] = src[i * A + a];
+      }
+    }
+    for (int x = tid; x < nn; x += nt) {
+      const int d = ej.node_desc[n0 + x], hg = ej.node_glob[n0 + x];
+      l_desc[x] = d;
+      l_fc[x] = ej.node_fc[n0 + x];
+      l_row[x] = ej.node_row[n0 + x];
+      l_edge[x] = t.edge_prob[hg];
+      if ((d & 3) == kTerminalNode) {
+        if (kind == 0) for (int q = 0; q < P; ++q) val[x * P + q] = t.term_ret[hg * P + q];
+        else val[x] = t.term_ret[hg * P + r];
+      }
+    }
+    if (kind != 0) {
+      for (int k = tid; k < nm; k += nt) {
+        l_mfc[k] = ej.node_fc[n0 + ej.mem_ent[(m0 + k) * 2 + 1]];
+      }
+    }
+    __syncthreads();
+    if (kind == 0) {
+      // ---- expected returns (expected_returns.cc:34-130) ----
+      for (int l = D - 2; l >= ej.L; --l) {
+        for (int x = lvl[l] + tid; x < lvl[l + 1]; x += nt) {
+          const int d = l_desc[x], k = d & 3;
+          if (k == kTerminalNode) continue;
+          const int fc = l_fc[x], nc = (d >> 2) & 0xFF, row = l_row[x];
+          for (int q = 0; q < P; ++q) {
+            double v = 0.0;
+            for (int a = 0; a < nc; ++a) {
+              const double pr = k == kChanceNode ? l_edge[fc + a] : pol[row + a];
+              if (pr > 0.0) v += pr * val[(fc + a) * P + q];
+            }
+            val[x * P + q] = v;
+          }
+        }
+        __syncthreads();
+      }
+      for (int x = lvl[ej.L] + tid; x < lvl[ej.L + 1]; x += nt) {
+        const int gidx = ej.node_glob[n0 + x] - t.level_off[ej.L];
+        for (int q = 0; q < P; ++q) store_through(ej.deal + static_cast<size_t>(gidx) * P + q, val[x * P + q]);
+      }
+    } else {
+      // ---- the best response of player r (best_response.cc:194-262) ----
+      for (int k = tid; k < nm; k += nt) {
+        const int m = ej.mem_ent[(m0 + k) * 2];
+        double c = 1.0;
+        for (int e = ea.path_off[m]; e < ea.path_off[m + 1]; ++e) {
+          const int code = ea.path[e];
+          const int slot = (code >> 24) & 0xF, idx = code & 0x7FFFFF;
+          const double pr = ((code >> 23) & 1) ? t.edge_prob[idx] : (slot == r ? 1.0 : pol[idx]);
+          c = c * pr;
+        }
+        cf[k] = c;
+      }
+      __syncthreads();
+      for (int l = D - 1; l >= ej.L; --l) {
+        for (int e = tid; e < ni; e += nt) {
+          const int32_t* ie = ej.info_ent + (i0 + e) * 4;
+          if (ie[1] != l) continue;
+          const int i = ie[0], moff = ie[2], cnt = ie[3], n = t.nact[i];
+          int best = -1;
+          double best_v = -1.7976931348623157e308;  // numeric_limits<double>::lowest()
+          for (int a = 0; a < n; ++a) {
+            double v = 0.0;
+            for (int k = 0; k < cnt; ++k) v += cf[moff + k] * val[l_mfc[moff + k] + a];
+            if (v > best_v) { best_v = v; best = a; }
+          }
+          best = best < 0 ? 0 : best;
+          l_best[i] = best;
+          ea.best[i] = best;
+        }
+        __syncthreads();
+        for (int x = lvl[l] + tid; x < lvl[l + 1]; x += nt) {
+          const int d = l_desc[x], k = d & 3;
+          if (k == kTerminalNode) continue;
+          const int fc = l_fc[x], nc = (d >> 2) & 0xFF, row = l_row[x];
+          double v = 0.0;
+          if (k == kDecisionNode && ((d >> 10) & 15) - 1 == r) {
+            v += 1.0 * val[fc + l_best[row / A]];
+          } else {
+            for (int a = 0; a < nc; ++a) {
+              const double pr = k == kChanceNode ? l_edge[fc + a] : pol[row + a];
+              v += pr * val[fc + a];
+            }
+          }
+          val[x] = v;
+        }
+        __syncthreads();
+      }
+      for (int x = lvl[ej.L] + tid; x < lvl[ej.L + 1]; x += nt) {
+        const int gidx = ej.node_glob[n0 + x] - t.level_off[ej.L];
+        store_through(ej.deal + static_cast<size_t>(ej.G) * P + static_cast<size_t>(r) * ej.G + gidx, val[x]);
+      }
+      if (ea.keep && r == ea.keep_r)
+        for (int x = tid; x < nn; x += nt) ea.keep[ej.node_glob[n0 + x]] = val[x];
+    }
+  }
+  // ---- the ticket: the last job to finish adds up the chance levels above the cut ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    const unsigned int mine = __hip_atomic_fetch_add(ej.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = mine == static_cast<unsigned int>(ej.J) - 1u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  double* top = smem;  // [2 P, NT]: quantity-major, histories of levels 0..L by their index in the whole tree
+  const int NT = ej.NT, top0 = t.level_off[ej.L];
+  for (int k = tid; k < 2 * P * ej.G; k += nt) {
+    int kq, gidx;
+    double v;
+    if (k < P * ej.G) { gidx = k / P; kq = k % P; v = only_br ? 0.0 : load_through(ej.deal + k); }
+    else { kq = P + (k - P * ej.G) / ej.G; gidx = (k - P * ej.G) % ej.G; v = load_through(ej.deal + k); }
+    top[kq * NT + top0 + gidx] = v;
+  }
+  __syncthreads();
+  for (int l = ej.L - 1; l >= 0; --l) {
+    const int w = t.level_off[l + 1] - t.level_off[l];
+    for (int k = tid; k < 2 * P * w; k += nt) {
+      const int kq = k / w, h = t.level_off[l] + k % w;
+      const int fc = t.first_child[h], nc = t.nchild[h];
+      double v = 0.0;
+      for (int a = 0; a < nc; ++a) {
+        const double pr = t.edge_prob[fc + a];
+        if (kq < P) { if (pr > 0.0) v += pr * top[kq * NT + fc + a]; }
+        else v += pr * top[kq * NT + fc + a];
+      }
+      top[kq * NT + h] = v;
+    }
+    __syncthreads();
+  }
+  if (tid < 2 * P) ea.out[tid] = top[tid * NT];
+  if (ea.keep)
+    for (int h = tid; h < top0; h += nt) ea.keep[h] = top[(P + ea.keep_r) * NT + h];
+  if (tid == 0) __hip_atomic_store(ej.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------
@@ -2039,7 +2251,7 @@ struct osg_cfr {
   double* d_node_delta = nullptr;  // dreg [M, A] | dpol [M, A]
   double* d_spare_delta[2] = {nullptr, nullptr};  // osg_mccfr_spare_delta_buffer: [2, I, A] each, allocated on request
   // one workgroup per deal subtree (k_cfr_split)
-  bool split_ok = false;
+  bool split_ok = false, split_br_ok = false;
   int split_G = 0, split_L = 0, split_NL = 0, split_NM = 0, split_NI = 0, split_threads = 0;
   size_t split_lds_bytes = 0;
   int32_t *d_split_nloc = nullptr, *d_split_desc = nullptr, *d_split_fc = nullptr, *d_split_row = nullptr,
@@ -2061,6 +2273,15 @@ struct osg_cfr {
   bool eval_ok = true;  // every infostate's members sit on one tree level
   int32_t *d_info_level = nullptr, *d_mem_index = nullptr, *d_best = nullptr;
   double *d_eval = nullptr;  // value [H,P] | brv [H] | cf [M] | out [2P] | policy [I,A]
+  // the evaluation as independent jobs over the device (k_eval_jobs)
+  bool jobs_ok = false;
+  int jobs_J = 0, jobs_L = 0, jobs_G = 0, jobs_NT = 0, jobs_threads = 0;
+  size_t jobs_lds_bytes = 0;
+  int32_t *d_jobs_job = nullptr, *d_jobs_level = nullptr, *d_jobs_desc = nullptr, *d_jobs_fc = nullptr, *d_jobs_row = nullptr,
+          *d_jobs_glob = nullptr, *d_jobs_info = nullptr, *d_jobs_mem = nullptr;
+  double* d_jobs_deal = nullptr;
+  unsigned int* d_jobs_ticket = nullptr;
+  double* h_eval_out = nullptr;  // pinned: [2 P] results, then the split kernel's sticky error word
   // LDS-resident MCCFR traversal (k_mccfr_resident)
   bool resident_ok = false;
   size_t resident_lds_bytes = 0;
@@ -2088,6 +2309,21 @@ struct osg_cfr {
   double* dpol() const { return replica_base(selected) + 4 * static_cast<size_t>(I) * A; }
 };
 
+static EvalJobs eval_jobs_of(const osg_cfr* s) {
+  EvalJobs ej;
+  ej.J = s->jobs_J; ej.L = s->jobs_L; ej.G = s->jobs_G; ej.NT = s->jobs_NT;
+  ej.job = s->d_jobs_job; ej.level_off = s->d_jobs_level; ej.node_desc = s->d_jobs_desc; ej.node_fc = s->d_jobs_fc;
+  ej.node_row = s->d_jobs_row; ej.node_glob = s->d_jobs_glob; ej.info_ent = s->d_jobs_info; ej.mem_ent = s->d_jobs_mem;
+  ej.deal = s->d_jobs_deal; ej.ticket = s->d_jobs_ticket;
+  return ej;
+}
+
+// OSG_EVAL_JOBS=0 keeps the one-workgroup evaluation (k_policy_eval) for trees that could take the jobs: the tests
+// compare the two.
+static bool OSG_EVAL_JOBS_ENABLED() {
+  const char* e = getenv("OSG_EVAL_JOBS");
+  return !(e && e[0] == '0');
+}
 namespace {
 
 // Expands the game tree breadth-first with the batched State kernels.
@@ -2499,12 +2735,142 @@ int build_split(osg_cfr* s) {
       (void)hipGetLastError();
       return OSG_OK;
     }
+  // the CFR-BR pass set keeps one more [I, A] array (the effective policy)
+  const void* br_variants[] = {reinterpret_cast<const void*>(&k_cfr_split<3, true>), reinterpret_cast<const void*>(&k_cfr_split<4, true>),
+                               reinterpret_cast<const void*>(&k_cfr_split<kMaxPlayers + 1, true>)};
+  s->split_br_ok = lds + sizeof(double) * IA <= 158 * 1024;
+  for (const void* f : br_variants)
+    if (s->split_br_ok &&
+        hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds + sizeof(double) * IA)) != hipSuccess) {
+      (void)hipGetLastError();
+      s->split_br_ok = false;
+    }
   s->split_G = G; s->split_L = L; s->split_NL = NL; s->split_NM = NM; s->split_NI = NI; s->split_threads = threads;
   s->split_lds_bytes = lds;
   s->split_ok = true;
   return OSG_OK;
 }
 
+
+// The jobs of k_eval_jobs: the cut of build_split (the first level with a node that is not a chance node); one
+// expected-returns job per subtree; for every responder r the subtrees grouped into the connected components of "holds a
+// member history of the same infostate of r", one best-response job per component.  Trees of another shape, or with a
+// component that does not fit a workgroup's LDS, keep the one-workgroup kernel.
+int build_eval_jobs(osg_cfr* s) {
+  s->jobs_ok = false;
+  if (!s->eval_ok || s->H < 2000 || s->D >= 64 || s->P > 15) return OSG_OK;
+  const int P = s->P, A = s->A, D = s->D;
+  int L = 0;
+  for (; L < D; ++L) {
+    bool all_chance = true;
+    for (int h = s->level_off[L]; h < s->level_off[L + 1]; ++h) all_chance &= s->kind[h] == kChanceNode;
+    if (!all_chance) break;
+  }
+  if (L < 1 || L >= D - 1) return OSG_OK;
+  const int G = s->level_off[L + 1] - s->level_off[L], NT = s->level_off[L + 1];
+  if (G < 4 || G > 65536) return OSG_OK;
+  std::vector<int32_t> sub_of(s->H, -1), level_of(s->H, 0);
+  for (int l = 0; l < D; ++l)
+    for (int h = s->level_off[l]; h < s->level_off[l + 1]; ++h) level_of[h] = l;
+  for (int h = s->level_off[L]; h < s->H; ++h)
+    sub_of[h] = h < s->level_off[L + 1] ? h - s->level_off[L] : sub_of[s->parent[h]];
+  std::vector<std::vector<int32_t>> hist(G);
+  for (int h = s->level_off[L]; h < s->H; ++h) hist[sub_of[h]].push_back(h);  // ascending h = level-major
+  const int M = static_cast<int>(s->mem.size());
+  for (int m = 0; m < M; ++m)
+    if (sub_of[s->mem[m]] < 0) return OSG_OK;  // a decision node above the cut
+  // the groups of subtrees, kind by kind
+  std::vector<std::vector<int32_t>> groups;  // subtree lists
+  std::vector<int32_t> group_kind;
+  for (int g = 0; g < G; ++g) { groups.push_back({g}); group_kind.push_back(0); }
+  for (int r = 0; r < P; ++r) {
+    std::vector<int32_t> uf(G);
+    for (int g = 0; g < G; ++g) uf[g] = g;
+    auto find = [&](int x) { while (uf[x] != x) { uf[x] = uf[uf[x]]; x = uf[x]; } return x; };
+    for (int i = 0; i < s->I; ++i) {
+      if (s->info_player[i] != r) continue;
+      for (int m = s->mem_off[i] + 1; m < s->mem_off[i + 1]; ++m) {
+        const int a = find(sub_of[s->mem[s->mem_off[i]]]), b = find(sub_of[s->mem[m]]);
+        if (a != b) uf[std::max(a, b)] = std::min(a, b);
+      }
+    }
+    std::vector<int32_t> slot(G, -1);
+    for (int g = 0; g < G; ++g) {
+      const int root = find(g);
+      if (slot[root] < 0) { slot[root] = static_cast<int32_t>(groups.size()); groups.push_back({}); group_kind.push_back(1 + r); }
+      groups[slot[root]].push_back(g);
+    }
+  }
+  const int J = static_cast<int>(groups.size());
+  std::vector<int32_t> job(static_cast<size_t>(J) * 8, 0), jlevel(static_cast<size_t>(J) * (D + 1), 0), desc, fc, row, glob, ient, ment;
+  std::vector<int32_t> loc(s->H, -1), job_of_sub(G, -1);
+  size_t lds = sizeof(double) * 2 * P * NT;
+  int max_nodes = 0;
+  const size_t IA = static_cast<size_t>(s->I) * A;
+  for (int j = 0; j < J; ++j) {
+    const int kind = group_kind[j], r = kind - 1;
+    std::vector<int32_t> nodes;
+    for (int g : groups[j]) nodes.insert(nodes.end(), hist[g].begin(), hist[g].end());
+    std::sort(nodes.begin(), nodes.end());
+    const int nn = static_cast<int>(nodes.size());
+    for (int x = 0; x < nn; ++x) loc[nodes[x]] = x;
+    const int n0 = static_cast<int>(desc.size());
+    int at = 0;
+    for (int l = 0; l <= D; ++l) {
+      while (l < D && at < nn && level_of[nodes[at]] < l) ++at;
+      jlevel[static_cast<size_t>(j) * (D + 1) + l] = l == D ? nn : at;
+    }
+    for (int x = 0; x < nn; ++x) {
+      const int h = nodes[x];
+      desc.push_back(s->kind[h] | (s->nchild[h] << 2) | ((s->actor[h] + 1) << 10));
+      fc.push_back(s->kind[h] == kTerminalNode ? 0 : loc[s->first_child[h]]);
+      row.push_back(s->kind[h] == kDecisionNode ? s->info[h] * A : 0);
+      glob.push_back(h);
+    }
+    const int i0 = static_cast<int>(ient.size() / 4), m0 = static_cast<int>(ment.size() / 2);
+    int ni = 0, nm = 0;
+    if (kind != 0) {
+      for (int g : groups[j]) job_of_sub[g] = j;
+      for (int i = 0; i < s->I; ++i) {
+        if (s->info_player[i] != r || s->mem_off[i + 1] == s->mem_off[i]) continue;
+        if (job_of_sub[sub_of[s->mem[s->mem_off[i]]]] != j) continue;
+        ient.insert(ient.end(), {i, s->info_level[i], nm, s->mem_off[i + 1] - s->mem_off[i]});
+        ++ni;
+        for (int m = s->mem_off[i]; m < s->mem_off[i + 1]; ++m) {
+          ment.insert(ment.end(), {m, loc[s->mem[m]]});
+          ++nm;
+        }
+      }
+      for (int g : groups[j]) job_of_sub[g] = -1;
+    }
+    int32_t* jd = &job[static_cast<size_t>(j) * 8];
+    jd[0] = kind; jd[1] = n0; jd[2] = nn; jd[3] = i0; jd[4] = ni; jd[5] = m0; jd[6] = nm;
+    const size_t bytes = sizeof(double) * (IA + static_cast<size_t>(nn) * (kind == 0 ? P : 1) + nn + nm) +
+                         sizeof(int32_t) * (3 * static_cast<size_t>(nn) + nm + s->I);
+    lds = std::max(lds, bytes);
+    max_nodes = std::max(max_nodes, nn);
+  }
+  if (lds > 150 * 1024) return OSG_OK;
+  hipStream_t st = s->ctx->stream;
+  int rc;
+  if ((rc = upload(job, &s->d_jobs_job, st)) || (rc = upload(jlevel, &s->d_jobs_level, st)) ||
+      (rc = upload(desc, &s->d_jobs_desc, st)) || (rc = upload(fc, &s->d_jobs_fc, st)) || (rc = upload(row, &s->d_jobs_row, st)) ||
+      (rc = upload(glob, &s->d_jobs_glob, st)) || (rc = upload(ient, &s->d_jobs_info, st)) || (rc = upload(ment, &s->d_jobs_mem, st)))
+    return rc;
+  OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_jobs_deal), sizeof(double) * 2 * P * G));
+  OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_jobs_ticket), sizeof(unsigned int) * 4));
+  OSG_HIP(hipMemsetAsync(s->d_jobs_deal, 0, sizeof(double) * 2 * P * G, st));
+  OSG_HIP(hipMemsetAsync(s->d_jobs_ticket, 0, sizeof(unsigned int) * 4, st));
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_jobs), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          static_cast<int>(lds)) != hipSuccess) {
+    (void)hipGetLastError();
+    return OSG_OK;
+  }
+  s->jobs_J = J; s->jobs_L = L; s->jobs_G = G; s->jobs_NT = NT; s->jobs_lds_bytes = lds;
+  s->jobs_threads = std::max(64, std::min(1024, (max_nodes + 63) / 64 * 64));
+  s->jobs_ok = true;
+  return OSG_OK;
+}
 
 // The subtrees of k_cfr_sub: the same cut as build_split (the first level with a node that is not a chance node),
 // any number of subtrees (a workgroup takes several in turn when the cooperative grid is smaller), up to 8 x 1024
@@ -2749,6 +3115,11 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
   if (rc) { osg_cfr_destroy(s); return rc; }
   rc = build_split(s);
   if (rc == OSG_OK) rc = build_sub(s);
+  if (rc == OSG_OK) rc = build_eval_jobs(s);
+  if (rc == OSG_OK && hipHostMalloc(reinterpret_cast<void**>(&s->h_eval_out), sizeof(double) * (2 * s->P + 1)) != hipSuccess) {
+    (void)hipGetLastError();
+    rc = set_error(OSG_ERR_NOMEM, "osg_cfr_create: pinned result buffer");
+  }
   if (rc) { osg_cfr_destroy(s); return rc; }
   rc = init_tables(s);
   if (rc) { osg_cfr_destroy(s); return rc; }
@@ -2766,10 +3137,13 @@ int osg_cfr_destroy(osg_cfr* s) {
                   s->d_uret, s->d_uprob, s->d_spare_delta[0], s->d_spare_delta[1], s->d_split_nloc, s->d_split_desc,
                   s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
                   s->d_split_terms, s->d_split_bar, s->d_sub_nloc, s->d_sub_desc, s->d_sub_fc, s->d_sub_aux, s->d_sub_mem_off,
-                  s->d_sub_info_off, s->d_sub_info_list, s->d_sub_bar, s->d_sub_ndec, s->d_sub_dec_row, s->d_sub_rec};
+                  s->d_sub_info_off, s->d_sub_info_list, s->d_sub_bar, s->d_sub_ndec, s->d_sub_dec_row, s->d_sub_rec,
+                  s->d_jobs_job, s->d_jobs_level, s->d_jobs_desc, s->d_jobs_fc, s->d_jobs_row, s->d_jobs_glob, s->d_jobs_info,
+                  s->d_jobs_mem, s->d_jobs_deal, s->d_jobs_ticket};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (s->h_sub_err) (void)hipHostFree(s->h_sub_err);
+  if (s->h_eval_out) (void)hipHostFree(s->h_eval_out);
   osg::ctx_release(s->ctx);
   delete s;
   return OSG_OK;
@@ -2782,6 +3156,29 @@ int osg_cfr_sizes(const osg_cfr* s, int64_t* out) {
 }
 
 int osg_cfr_reset(osg_cfr* s) { return init_tables(s); }
+
+// One COOPERATIVE launch of k_cfr_split: the kernel spins on a grid barrier, so its workgroups must be resident
+// together — with another stream keeping the device busy (a network's forward pass beside the solver) a plain launch
+// can start some workgroups while the others queue behind foreign work, and the barrier's bound then turns a slowdown
+// into an error.  The cooperative launch waits until the whole grid fits.  br: the CFR-BR pass set (d_best overrides).
+static int launch_split(osg_cfr* s, SmallTree stree, SplitTree sp, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg, bool br) {
+  hipStream_t st = s->ctx->stream;
+  OSG_HIP(hipMemsetAsync(s->d_split_bar, 0, sizeof(unsigned int) * 2, st));
+  const dim3 grid(static_cast<unsigned>(s->split_G)), block(static_cast<unsigned>(s->split_threads));
+  Tree tr = s->tree();
+  const int32_t* best = br ? s->d_best : nullptr;
+  void* args[] = {&tr, &stree, &sp, &tb, &iters, &iteration0, &cfg, &best};
+  const void* kern;
+  if (br) kern = s->P == 2 ? reinterpret_cast<const void*>(&k_cfr_split<3, true>)
+                           : (s->P == 3 ? reinterpret_cast<const void*>(&k_cfr_split<4, true>)
+                                        : reinterpret_cast<const void*>(&k_cfr_split<kMaxPlayers + 1, true>));
+  else kern = s->P == 2 ? reinterpret_cast<const void*>(&k_cfr_split<3>)
+                        : (s->P == 3 ? reinterpret_cast<const void*>(&k_cfr_split<4>)
+                                     : reinterpret_cast<const void*>(&k_cfr_split<kMaxPlayers + 1>));
+  const size_t lds = s->split_lds_bytes + (br ? sizeof(double) * static_cast<size_t>(s->I) * s->A : 0);
+  OSG_HIP(hipLaunchCooperativeKernel(kern, grid, block, args, static_cast<unsigned>(lds), st));
+  return OSG_OK;
+}
 
 int osg_cfr_iterate(osg_cfr* s, int iters) {
   if (!s || iters < 0) return set_error(OSG_ERR_INVALID, "osg_cfr_iterate: bad argument");
@@ -2870,24 +3267,11 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
     SplitTree sp{s->split_G, s->split_L, s->split_NL, s->split_NM, s->split_NI, s->d_split_nloc, s->d_split_desc,
                  s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
                  s->d_split_terms, s->d_split_bar};
-    hipStream_t st = s->ctx->stream;
     const int passes = s->cfg.alternating_updates ? s->P : 1;
     const int per_launch = std::max(1, (1 << 30) / std::max(1, passes * s->split_G));  // the arrival counter is 32 bits
     for (int done = 0; done < iters; done += per_launch) {
-      const int now = std::min(per_launch, iters - done);
-      OSG_HIP(hipMemsetAsync(s->d_split_bar, 0, sizeof(unsigned int) * 2, st));
-      const dim3 grid(static_cast<unsigned>(s->split_G)), block(static_cast<unsigned>(s->split_threads));
-      // A COOPERATIVE launch: the kernel spins on a grid barrier, so its workgroups must be resident together — with
-      // another stream keeping the device busy (a network's forward pass beside the solver) a plain launch can start
-      // some workgroups while the others queue behind foreign work, and the barrier's bound then turns a slowdown
-      // into an error.  The cooperative launch waits until the whole grid fits.
-      Tree tr = s->tree();
-      int now_arg = now, it0 = s->iteration + done;
-      void* args[] = {&tr, &stree, &sp, &tb, &now_arg, &it0, &s->cfg};
-      const void* kern = s->P == 2 ? reinterpret_cast<const void*>(&k_cfr_split<3>)
-                                   : (s->P == 3 ? reinterpret_cast<const void*>(&k_cfr_split<4>)
-                                                : reinterpret_cast<const void*>(&k_cfr_split<kMaxPlayers + 1>));
-      OSG_HIP(hipLaunchCooperativeKernel(kern, grid, block, args, static_cast<unsigned>(s->split_lds_bytes), st));
+      const int rc = launch_split(s, stree, sp, tb, std::min(per_launch, iters - done), s->iteration + done, s->cfg, false);
+      if (rc) return rc;
     }
     OSG_HIP(hipGetLastError());
     s->iteration += iters;
@@ -3134,12 +3518,24 @@ int osg_cfr_br_iterate(osg_cfr* s, int iters) {
   cfg.alternating_updates = 0;
   Tables tb{s->regrets(), s->cum(), s->cur()};
   hipStream_t st = s->ctx->stream;
+  // every player's best response to the current policy (cfr_br.cc:55-68), then one regret / average-policy
+  // pass per player against the others' best responses (cfr_br.cc:70-81) and ApplyRegretMatching
+  const bool jobs = s->jobs_ok && OSG_EVAL_JOBS_ENABLED();
+  const bool split = s->split_ok && s->split_br_ok && (s->cfg.kernel == 0 || s->cfg.kernel == 4);
+  SmallTree stree{s->d_path_off, s->d_path, static_cast<int>(M), static_cast<int>(s->path.size())};
+  SplitTree sp{s->split_G, s->split_L, s->split_NL, s->split_NM, s->split_NI, s->d_split_nloc, s->d_split_desc,
+               s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
+               s->d_split_terms, s->d_split_bar};
   for (int it = 0; it < iters; ++it) {
-    // every player's best response to the current policy (cfr_br.cc:55-68), then one regret / average-policy
-    // pass per player against the others' best responses (cfr_br.cc:70-81) and ApplyRegretMatching
-    k_policy_eval<<<dim3(1), dim3(threads), 0, st>>>(s->tree(), ea, s->cur());
-    k_cfr<false, true><<<dim3(1), dim3(threads), 0, st>>>(s->tree(), tb, s->d_reach, s->d_value, 1, s->iteration, cfg,
-                                                          s->d_best);
+    if (jobs) k_eval_jobs<<<dim3(s->jobs_J), dim3(s->jobs_threads), s->jobs_lds_bytes, st>>>(s->tree(), ea, eval_jobs_of(s), s->cur(), 1, 1);
+    else k_policy_eval<<<dim3(1), dim3(threads), 0, st>>>(s->tree(), ea, s->cur());
+    if (split) {
+      const int rc = launch_split(s, stree, sp, tb, 1, s->iteration, cfg, true);
+      if (rc) return rc;
+    } else {
+      k_cfr<false, true><<<dim3(1), dim3(threads), 0, st>>>(s->tree(), tb, s->d_reach, s->d_value, 1, s->iteration, cfg,
+                                                            s->d_best);
+    }
     ++s->iteration;
   }
   OSG_HIP(hipGetLastError());
@@ -3269,19 +3665,8 @@ static int evaluate_policy_impl(osg_cfr* s, int which_policy, const double* h_po
   const size_t IA = static_cast<size_t>(s->I) * s->A, M = s->mem.size();
   const int P = s->P;
   hipStream_t st = s->ctx->stream;
-  std::vector<double> pol(IA, 0.0);
-  if (which_policy == 2) {
-    if (!h_policy) return set_error(OSG_ERR_INVALID, "osg_cfr_evaluate_policy: which_policy == 2 needs h_policy");
-    std::copy(h_policy, h_policy + IA, pol.begin());
-  } else if (which_policy == 0 || which_policy == 1) {
-    std::vector<double> avg(IA);
-    int rc = which_policy == 0 ? osg_cfr_tables(s, nullptr, nullptr, nullptr, nullptr, nullptr, avg.data())
-                               : osg_cfr_tables(s, nullptr, nullptr, nullptr, nullptr, avg.data(), nullptr);
-    if (rc) return rc;
-    pol.swap(avg);
-  } else {
-    return set_error(OSG_ERR_INVALID, "osg_cfr_evaluate_policy: which_policy must be 0, 1 or 2");
-  }
+  if (which_policy < 0 || which_policy > 2) return set_error(OSG_ERR_INVALID, "osg_cfr_evaluate_policy: which_policy must be 0, 1 or 2");
+  if (which_policy == 2 && !h_policy) return set_error(OSG_ERR_INVALID, "osg_cfr_evaluate_policy: which_policy == 2 needs h_policy");
   EvalArrays ea;
   ea.path_off = s->d_path_off; ea.path = s->d_path; ea.info_level = s->d_info_level; ea.mem_index = s->d_mem_index;
   ea.M = static_cast<int>(M);
@@ -3291,20 +3676,47 @@ static int evaluate_policy_impl(osg_cfr* s, int which_policy, const double* h_po
   ea.out = ea.cf + M;
   double* d_pol = ea.out + 2 * P;
   ea.best = s->d_best;
-  OSG_HIP(hipMemcpyAsync(d_pol, pol.data(), sizeof(double) * IA, hipMemcpyHostToDevice, st));
-  int threads = ((s->max_level_width + 63) / 64) * 64;
-  threads = std::max(64, std::min(threads, 1024));
   if (h_history_values) {  // the responder's value of every history: kept in d_reach ([H, P + 1] doubles, free here)
     ea.keep = s->d_reach;
     ea.keep_r = keep_responder;
   }
-  k_policy_eval<<<dim3(1), dim3(threads), 0, st>>>(s->tree(), ea, d_pol);
-  OSG_HIP(hipGetLastError());
-  std::vector<double> out(2 * P);
-  OSG_HIP(hipMemcpyAsync(out.data(), ea.out, sizeof(double) * 2 * P, hipMemcpyDeviceToHost, st));
+  s->h_eval_out[2 * P] = 0.0;
+  if (s->jobs_ok && OSG_EVAL_JOBS_ENABLED()) {
+    // the tables never leave the device: the average policy is formed from the cumulative table inside the jobs
+    const double* src = which_policy == 0 ? s->cum() : which_policy == 1 ? s->cur() : d_pol;
+    if (which_policy == 2) OSG_HIP(hipMemcpyAsync(d_pol, h_policy, sizeof(double) * IA, hipMemcpyHostToDevice, st));
+    k_eval_jobs<<<dim3(s->jobs_J), dim3(s->jobs_threads), s->jobs_lds_bytes, st>>>(s->tree(), ea, eval_jobs_of(s), src,
+                                                                                   which_policy == 0 ? 0 : 1, 0);
+    OSG_HIP(hipGetLastError());
+    if (s->split_ok && which_policy != 2)  // the tables are only as good as the launches that wrote them
+      OSG_HIP(hipMemcpyAsync(reinterpret_cast<unsigned int*>(s->h_eval_out + 2 * P), s->d_split_bar + 2, sizeof(unsigned int),
+                             hipMemcpyDeviceToHost, st));
+  } else {
+    std::vector<double> pol(IA, 0.0);
+    if (which_policy == 2) {
+      std::copy(h_policy, h_policy + IA, pol.begin());
+    } else {
+      std::vector<double> avg(IA);
+      int rc = which_policy == 0 ? osg_cfr_tables(s, nullptr, nullptr, nullptr, nullptr, nullptr, avg.data())
+                                 : osg_cfr_tables(s, nullptr, nullptr, nullptr, nullptr, avg.data(), nullptr);
+      if (rc) return rc;
+      pol.swap(avg);
+    }
+    OSG_HIP(hipMemcpyAsync(d_pol, pol.data(), sizeof(double) * IA, hipMemcpyHostToDevice, st));
+    OSG_HIP(hipStreamSynchronize(st));  // (pol dies with this scope)
+    int threads = ((s->max_level_width + 63) / 64) * 64;
+    threads = std::max(64, std::min(threads, 1024));
+    k_policy_eval<<<dim3(1), dim3(threads), 0, st>>>(s->tree(), ea, d_pol);
+    OSG_HIP(hipGetLastError());
+  }
+  OSG_HIP(hipMemcpyAsync(s->h_eval_out, ea.out, sizeof(double) * 2 * P, hipMemcpyDeviceToHost, st));
   if (h_history_values)
     OSG_HIP(hipMemcpyAsync(h_history_values, s->d_reach, sizeof(double) * s->H, hipMemcpyDeviceToHost, st));
   OSG_HIP(hipStreamSynchronize(st));
+  if (*reinterpret_cast<unsigned int*>(s->h_eval_out + 2 * P) != 0u)
+    return set_error(OSG_ERR_HIP, "k_cfr_split: a grid barrier timed out after seconds (the launch is cooperative: this is a hung "
+                                  "device, not contention); the tables are not usable — osg_cfr_cfg.kernel = 3 runs one workgroup");
+  const double* out = s->h_eval_out;
   double nc = 0.0, total_br = 0.0;
   for (int p = 0; p < P; ++p) {
     if (expected_returns) expected_returns[p] = out[p];

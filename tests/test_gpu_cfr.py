@@ -512,3 +512,92 @@ def test_grid_barrier_kernels_beside_a_busy_stream(ctx, game, kernel):
     side.synchronize()
     for name in ("regrets", "cum_policy", "cur_policy"):
         np.testing.assert_array_equal(got[name], want[name])
+
+
+def _judge_everything(s, which, table=None):
+    """All outputs of the evaluation: the four numbers, every responder's action indices and history values."""
+    import ctypes as C
+    from open_spiel_amd._abi import check, lib
+    out = s.evaluate_policy(which, table)
+    sizes = (C.c_int64 * 6)()
+    check(lib().osg_cfr_sizes(s._h, sizes))
+    H, I = int(sizes[0]), int(sizes[4])
+    code = {"average": 0, "current": 1, "table": 2}[which]
+    tab = None if table is None else np.ascontiguousarray(table, np.float64)
+    tp = None if tab is None else tab.ctypes.data
+    best = np.zeros(I, np.int32)
+    brv = np.zeros(len(out["expected_returns"]))
+    check(lib().osg_cfr_best_response(s._h, code, tp, best.ctypes.data, brv.ctypes.data))
+    hist = []
+    for r in range(len(brv)):
+        hv = np.zeros(H)
+        check(lib().osg_cfr_best_response_history_values(s._h, code, tp, r, hv.ctypes.data))
+        hist.append(hv)
+    return out, best, brv, hist
+
+
+@pytest.mark.parametrize("game", ["leduc_poker", "leduc_poker(suit_isomorphism=True)", "kuhn_poker(players=5)"])
+def test_evaluation_jobs_are_bit_identical_with_the_one_workgroup_evaluation(ctx, game, monkeypatch):
+    """k_eval_jobs (expected returns per deal subtree, one best-response job per group of deals the responder cannot tell
+    apart, the chance levels above by the last job) forms the sums k_policy_eval forms, in the same order."""
+    import open_spiel_amd as osa
+    s = osa.TabularSolver(ctx, game)
+    s.evaluate_and_update_policy(9)
+    rng = np.random.default_rng(5)
+    t = s.tables()
+    table = rng.random(t["regrets"].shape) * (np.arange(t["regrets"].shape[1])[None, :] < t["nact"][:, None])
+    table[rng.random(table.shape) < 0.3] = 0.0       # zero-probability actions: pruned branches, ties
+    table /= np.maximum(table.sum(1, keepdims=True), 1e-300)
+    table[table.sum(1) == 0, 0] = 1.0
+    for which, tab in (("average", None), ("current", None), ("table", table)):
+        monkeypatch.delenv("OSG_EVAL_JOBS", raising=False)
+        got = _judge_everything(s, which, tab)
+        monkeypatch.setenv("OSG_EVAL_JOBS", "0")
+        want = _judge_everything(s, which, tab)
+        for k in ("nash_conv", "exploitability"):
+            assert got[0][k] == want[0][k], (which, k)
+        np.testing.assert_array_equal(got[0]["expected_returns"], want[0]["expected_returns"])
+        np.testing.assert_array_equal(got[0]["best_response_values"], want[0]["best_response_values"])
+        np.testing.assert_array_equal(got[1], want[1])
+        np.testing.assert_array_equal(got[2], want[2])
+        for a, b in zip(got[3], want[3]):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_leduc_evaluation_takes_the_jobs_and_is_fast(ctx):
+    """The default leduc_poker evaluation is the multi-workgroup one: a NashConv call (host to host, the tables stay on
+    the device) well under the one-workgroup kernel's 154 us of kernel time alone."""
+    import time
+    import open_spiel_amd as osa
+    s = osa.TabularSolver(ctx, "leduc_poker")
+    s.evaluate_and_update_policy(20)
+    s.nash_conv()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        s.nash_conv()
+    us = (time.perf_counter() - t0) / 50 * 1e6
+    assert us < 120.0, us
+
+
+def test_cfr_br_on_the_split_kernel_equals_the_one_workgroup_passes(ctx, monkeypatch):
+    """CFR-BR through k_eval_jobs + the subtree kernel's override pass set (cfr_br.cc:48-83) against the one-workgroup
+    best responses and passes: the same tables bit for bit, and at least 8 000 iterations per second."""
+    import time
+    import open_spiel_amd as osa
+    fast = osa.TabularSolver(ctx, "leduc_poker")
+    fast.evaluate_and_update_policy_cfr_br(11)
+    got = fast.tables()
+    monkeypatch.setenv("OSG_EVAL_JOBS", "0")
+    slow = osa.TabularSolver(ctx, "leduc_poker", general_kernel="path")
+    slow.evaluate_and_update_policy_cfr_br(11)
+    want = slow.tables()
+    monkeypatch.delenv("OSG_EVAL_JOBS")
+    for name in ("regrets", "cum_policy", "cur_policy"):
+        np.testing.assert_array_equal(got[name], want[name])
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    fast.evaluate_and_update_policy_cfr_br(300)
+    ctx.synchronize()
+    rate = 300 / (time.perf_counter() - t0)
+    assert rate > 8000.0, rate

@@ -1245,9 +1245,19 @@ struct EvalArrays {
 };
 
 __global__ void __launch_bounds__(1024)
-k_policy_eval(Tree t, EvalArrays ea, const double* __restrict__ pol) {
+k_policy_eval(Tree t, EvalArrays ea, const double* pol, int from_cum = 0, double* pol_buf = nullptr) {
   const int P = t.P, A = t.A;
   const int tid = threadIdx.x, nt = blockDim.x;
+  if (from_cum) {  // `pol` is the cumulative table: evaluate its normalisation (CFRAveragePolicy, cfr.cc:104-125)
+    for (int i = tid; i < t.I; i += nt) {
+      const int n = t.nact[i];
+      double sum = 0.0;
+      for (int a = 0; a < n; ++a) sum += pol[i * A + a];
+      for (int a = 0; a < A; ++a) pol_buf[i * A + a] = a >= n ? 0.0 : (sum == 0.0 ? 1. / n : pol[i * A + a] / sum);
+    }
+    __syncthreads();
+    pol = pol_buf;
+  }
   // ---- expected returns ----
   for (int l = t.D - 1; l >= 0; --l) {
     for (int h = t.level_off[l] + tid; h < t.level_off[l + 1]; h += nt) {
@@ -3688,27 +3698,17 @@ static int evaluate_policy_impl(osg_cfr* s, int which_policy, const double* h_po
     k_eval_jobs<<<dim3(s->jobs_J), dim3(s->jobs_threads), s->jobs_lds_bytes, st>>>(s->tree(), ea, eval_jobs_of(s), src,
                                                                                    which_policy == 0 ? 0 : 1, 0);
     OSG_HIP(hipGetLastError());
-    if (s->split_ok && which_policy != 2)  // the tables are only as good as the launches that wrote them
-      OSG_HIP(hipMemcpyAsync(reinterpret_cast<unsigned int*>(s->h_eval_out + 2 * P), s->d_split_bar + 2, sizeof(unsigned int),
-                             hipMemcpyDeviceToHost, st));
   } else {
-    std::vector<double> pol(IA, 0.0);
-    if (which_policy == 2) {
-      std::copy(h_policy, h_policy + IA, pol.begin());
-    } else {
-      std::vector<double> avg(IA);
-      int rc = which_policy == 0 ? osg_cfr_tables(s, nullptr, nullptr, nullptr, nullptr, nullptr, avg.data())
-                                 : osg_cfr_tables(s, nullptr, nullptr, nullptr, nullptr, avg.data(), nullptr);
-      if (rc) return rc;
-      pol.swap(avg);
-    }
-    OSG_HIP(hipMemcpyAsync(d_pol, pol.data(), sizeof(double) * IA, hipMemcpyHostToDevice, st));
-    OSG_HIP(hipStreamSynchronize(st));  // (pol dies with this scope)
+    const double* src = which_policy == 0 ? s->cum() : which_policy == 1 ? s->cur() : d_pol;
+    if (which_policy == 2) OSG_HIP(hipMemcpyAsync(d_pol, h_policy, sizeof(double) * IA, hipMemcpyHostToDevice, st));
     int threads = ((s->max_level_width + 63) / 64) * 64;
     threads = std::max(64, std::min(threads, 1024));
-    k_policy_eval<<<dim3(1), dim3(threads), 0, st>>>(s->tree(), ea, d_pol);
+    k_policy_eval<<<dim3(1), dim3(threads), 0, st>>>(s->tree(), ea, src, which_policy == 0 ? 1 : 0, d_pol);
     OSG_HIP(hipGetLastError());
   }
+  if (s->split_ok && which_policy != 2)  // the tables are only as good as the launches that wrote them
+    OSG_HIP(hipMemcpyAsync(reinterpret_cast<unsigned int*>(s->h_eval_out + 2 * P), s->d_split_bar + 2, sizeof(unsigned int),
+                           hipMemcpyDeviceToHost, st));
   OSG_HIP(hipMemcpyAsync(s->h_eval_out, ea.out, sizeof(double) * 2 * P, hipMemcpyDeviceToHost, st));
   if (h_history_values)
     OSG_HIP(hipMemcpyAsync(h_history_values, s->d_reach, sizeof(double) * s->H, hipMemcpyDeviceToHost, st));

@@ -896,9 +896,13 @@ struct SubTree {
   const int32_t* ndec;           // [G]
   const int32_t* dec_row;        // [G, ND] info * A of decision history d
   const int32_t* mem_off;        // [G * P + 1] the subtree's members of player q: sub_mem[mem_off[g * P + q] ...)
-  const int32_t* sub_rec;        // [., 4 + PL] per member: m (position in Tree::mem), its history's local index, its decision
-                                 //   index | actions << 24, its first child's local index, its root path (SmallTree::path codes, -1 padded)
-  int PL;                        // kSubPathChunk or 2 kSubPathChunk
+  const int32_t* sub_rec;        // [., 8 + PL] per member: m (position in Tree::mem), its history's local index, its decision
+                                 //   index | actions << 24, its first child's local index; the product of the chance
+                                 //   probabilities on its root path (a double, path order), two unused words; then the decision
+                                 //   entries of the path GROUPED BY PLAYER, PL / P codes per player in path order, -1 padded:
+                                 //   (the ancestor's decision index in this subtree) * A + action index, i.e. an index into the
+                                 //   policy rows the sweep has staged in LDS
+  int PL;                        // codes per member: P groups of a multiple of 4, at most 4 kSubCodeChunks
   const int32_t* info_off;       // [P + 1] infostates of player q: info_list[info_off[q] ...)
   const int32_t* info_list;
   double* dreg;                  // [M, A]
@@ -908,6 +912,7 @@ struct SubTree {
   unsigned int* host_err;        // pinned host word raised on a timeout: the next call reads it without a copy
   unsigned long long timeout_ticks;
   unsigned long long* stamps;    // null, or [P][5] wall-clock stamps of workgroup 0 in the launch's last iteration
+  int stamp_wg = 0;              // the workgroup that writes the stamps (OSG_CFR_SUB_STAMPS = its index + 1)
 };
 OSG_D double readlane_f64(double v, int lane) {   // lane is wave-uniform: two v_readlane_b32, no LDS permute
   const long long b = __double_as_longlong(v);
@@ -921,7 +926,7 @@ constexpr int kSubThreads = 1024;
 constexpr int kSubKD = 4;            // decision histories per thread: ND <= 4096
 constexpr int kSubFoldInfos = 64;    // infostates a workgroup folds per round (one wavefront adds them up)
 constexpr int kSubFoldX = 2;         // member records a thread fetches per round: <= 2048 per round
-constexpr int kSubPathChunk = 12;    // root-path entries requested together; a member keeps PL = 12 or 24 of them
+constexpr int kSubCodeChunks = 8;    // int4 chunks of path codes a member record holds at most (requested together)
 template <int kK>   // histories per thread: NL <= kK * 1024
 __global__ void __launch_bounds__(kSubThreads)
 k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg) {
@@ -960,7 +965,7 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
   for (int it = 0; it < iters; ++it) {
     const int iteration = iteration0 + it + 1;
     for (int upd = 0; upd < P; ++upd) {
-      const bool stamp = sp.stamps && it == iters - 1 && blockIdx.x == 0 && tid == 0;
+      const bool stamp = sp.stamps && it == iters - 1 && static_cast<int>(blockIdx.x) == sp.stamp_wg && tid == 0;
       if (stamp) sp.stamps[upd * 5 + 0] = wall_clock64();
       for (int g = blockIdx.x; g < sp.G; g += gridDim.x) {
         // ---- the thread's histories of this subtree: descriptors in registers for the sweep ----
@@ -977,7 +982,7 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
             o_aux[k] = sp.aux[static_cast<size_t>(g) * sp.NL + j];
           }
         }
-        if (stamp && g == blockIdx.x) sp.stamps[P * 5 + upd * 2 + 1] = wall_clock64();
+        if (stamp && g == static_cast<int>(blockIdx.x)) sp.stamps[P * 5 + upd * 2 + 1] = wall_clock64();
         // the level range of every slot (its first and its last valid history), for the sweep's (slot, level) walk
 #pragma unroll
         for (int k = 0; k < kK; ++k) {
@@ -1009,7 +1014,7 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
           }
         }
         __syncthreads();
-        if (stamp && g == blockIdx.x) sp.stamps[P * 5 + upd * 2] = wall_clock64();
+        if (stamp && g == static_cast<int>(blockIdx.x)) sp.stamps[P * 5 + upd * 2] = wall_clock64();
         // bottom-up (cfr.cc:443-469).  Slot k of the threads covers the local indices [1024 k, 1024 k + 1023], a
         // contiguous run in level order, i.e. a workgroup-uniform range of levels: the sweep walks (slot, level) pairs
         // from the deepest, ONE slot's body per step (testing all slots at every level cost more instructions than
@@ -1033,48 +1038,46 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
             __syncthreads();
           }
         }
-        if (stamp && g == blockIdx.x) sp.stamps[upd * 5 + 1] = wall_clock64();
+        if (stamp && g == static_cast<int>(blockIdx.x)) sp.stamps[upd * 5 + 1] = wall_clock64();
         // ---- B: the updating player's members of this subtree (k_gcfr_members) ----
-        // A member's record is one contiguous run of ints — {m, local history, decision index | actions << 24, local
-        // first child, then its root path, -1 padded} — in the order the subtree visits its members: ONE round trip
-        // brings everything but the probabilities on the path, a second one those; the products are formed in path
-        // order (which is what keeps the tables bit-identical).
+        // A member's record is one contiguous run of ints (SubTree::sub_rec) in the order the subtree visits its members:
+        // ONE round trip brings all of it.  The probabilities on the root path are the chance product (constant: formed
+        // once on the host, in path order) and policy entries of the member's ancestors — decision histories of THIS
+        // subtree, whose rows the sweep has staged in LDS: no second trip to memory.  The codes come grouped by player, so
+        // a player's reach is one running product in path order (what keeps the tables bit-identical) and the
+        // counterfactual reach multiplies the players' products in player order, the chance product last (cfr.cc:309-318).
         const int m_begin = sp.mem_off[g * P + upd], m_end = sp.mem_off[g * P + upd + 1];
+        const int n_chunks = sp.PL / 4, per_player = n_chunks / P;
         for (int mm = m_begin + tid; mm < m_end; mm += kSubThreads) {
-          const int4* rec = reinterpret_cast<const int4*>(sp.sub_rec + static_cast<size_t>(mm) * (4 + sp.PL));
-          const int4 head = rec[0];
+          const int4* rec = reinterpret_cast<const int4*>(sp.sub_rec + static_cast<size_t>(mm) * (8 + sp.PL));
+          const int4 head = rec[0], second = rec[1];
+          int4 codes[kSubCodeChunks];
+#pragma unroll
+          for (int c = 0; c < kSubCodeChunks; ++c) codes[c] = rec[2 + (c < n_chunks ? c : n_chunks - 1)];
           const int m = head.x, hl = head.y, d = head.z & 0xFFFFFF, n = (head.z >> 24) & 0xFF, lfc = head.w;
-          double reach[kMaxPlayers + 1];
-#pragma unroll
-          for (int q = 0; q <= kMaxPlayers; ++q) reach[q] = 1.0;
-          for (int c = 0; c < sp.PL; c += kSubPathChunk) {   // (one chunk for paths of up to 12 entries, two up to 24)
-            int code[kSubPathChunk];
-            double pr[kSubPathChunk];
-#pragma unroll
-            for (int j = 0; j < kSubPathChunk / 4; ++j) {
-              const int4 v4 = rec[1 + c / 4 + j];
-              code[4 * j] = v4.x; code[4 * j + 1] = v4.y; code[4 * j + 2] = v4.z; code[4 * j + 3] = v4.w;
-            }
-#pragma unroll
-            for (int j = 0; j < kSubPathChunk; ++j) {
-              const int idx = code[j] < 0 ? 0 : code[j] & 0x7FFFFF;
-              pr[j] = ((code[j] >> 23) & 1) ? t.edge_prob[idx] : load_through(tb.cur + idx);   // (a -1 code reads entry 0: unused)
-            }
-#pragma unroll
-            for (int j = 0; j < kSubPathChunk; ++j) {
-              const int slot = code[j] < 0 ? -1 : (code[j] >> 24) & 0xF;
-#pragma unroll
-              for (int q = 0; q <= kMaxPlayers; ++q) reach[q] = (q == slot) ? reach[q] * pr[j] : reach[q];
-            }
-          }
+          const double chance = __longlong_as_double((static_cast<long long>(second.y) << 32) | static_cast<unsigned int>(second.x));
           bool pruned = true;
-          double self_reach = 0.0, cf_reach = 1.0;
+          double self_reach = 0.0, cf_reach = 1.0, r = 1.0;
+          int q = 0;
 #pragma unroll
-          for (int q = 0; q <= kMaxPlayers; ++q) {
-            if (q < P) pruned &= (reach[q] == 0.0);
-            if (q == upd) self_reach = reach[q];
-            else if (q <= P) cf_reach *= reach[q];
+          for (int c = 0; c < kSubCodeChunks; ++c) {
+            if (c < n_chunks) {   // (workgroup-uniform)
+              const int cx = codes[c].x, cy = codes[c].y, cz = codes[c].z, cw = codes[c].w;
+              const double px = s_pol[cx < 0 ? 0 : cx], py = s_pol[cy < 0 ? 0 : cy], pz = s_pol[cz < 0 ? 0 : cz],
+                           pw = s_pol[cw < 0 ? 0 : cw];
+              r = r * (cx < 0 ? 1.0 : px);   // (x * 1.0 == x: the padding leaves the product as it is)
+              r = r * (cy < 0 ? 1.0 : py);
+              r = r * (cz < 0 ? 1.0 : pz);
+              r = r * (cw < 0 ? 1.0 : pw);
+              if ((c + 1) % per_player == 0) {   // the last chunk of player q's group
+                pruned &= (r == 0.0);
+                if (q == upd) self_reach = r; else cf_reach *= r;
+                ++q;
+                r = 1.0;
+              }
+            }
           }
+          cf_reach *= chance;
           store_through_i32(sp.skip + m, pruned ? 1 : 0);
           if (pruned) continue;
           const double vh = s_value[hl];
@@ -2924,11 +2927,21 @@ int build_sub(osg_cfr* s) {
   std::vector<int32_t> nloc(G), desc(static_cast<size_t>(G) * NL, kTerminalNode | (63 << 10)), fc(static_cast<size_t>(G) * NL, 0),
       aux(static_cast<size_t>(G) * NL, 0), mem_off(static_cast<size_t>(G) * s->P + 1, 0), sub_rec,
       info_off(s->P + 1, 0), info_list;
-  int longest_path = 0;
-  for (size_t m = 0; m < M; ++m) longest_path = std::max(longest_path, s->path_off[m + 1] - s->path_off[m]);
-  if (longest_path > 2 * kSubPathChunk) return OSG_OK;   // a root path with more entries than the packed form keeps
-  const int PL = longest_path <= kSubPathChunk ? kSubPathChunk : 2 * kSubPathChunk;
+  // the decisions of one player on a root path: the codes of a member record are P groups of `per_player` int4 chunks
+  int most = 0;
+  {
+    std::vector<int> cnt(s->P);
+    for (size_t m = 0; m < M; ++m) {
+      std::fill(cnt.begin(), cnt.end(), 0);
+      for (int e = s->path_off[m]; e < s->path_off[m + 1]; ++e)
+        if (!((s->path[e] >> 23) & 1)) most = std::max(most, ++cnt[(s->path[e] >> 24) & 0xF]);
+    }
+  }
+  const int per_player = std::max(1, (most + 3) / 4);
+  if (per_player * s->P > kSubCodeChunks) return OSG_OK;   // more decisions on a path than the packed record keeps
+  const int PL = 4 * per_player * s->P;
   std::vector<std::vector<int32_t>> dec_rows(G);
+  std::vector<int32_t> anc, filled(s->P);
   int32_t n_members = 0;
   for (int g = 0; g < G; ++g) {
     nloc[g] = static_cast<int32_t>(hist[g].size());
@@ -2951,8 +2964,31 @@ int build_sub(osg_cfr* s) {
         sub_rec.push_back(loc_of[h]);
         sub_rec.push_back(aux[at] | (static_cast<int32_t>(s->nact[s->info[h]]) << 24));
         sub_rec.push_back(fc[at]);
+        // the root path, leaf to root: entry e of SmallTree::path is the edge out of the ancestor at depth e
         const int len = s->path_off[m + 1] - s->path_off[m];
-        for (int e = 0; e < PL; ++e) sub_rec.push_back(e < len ? s->path[s->path_off[m] + e] : -1);
+        anc.resize(len);
+        for (int e = len - 1, x = s->parent[h]; e >= 0; --e, x = s->parent[x]) anc[e] = x;
+        double chance = 1.0;
+        std::vector<int32_t> codes(PL, -1);
+        std::fill(filled.begin(), filled.end(), 0);
+        for (int e = 0; e < len; ++e) {
+          const int code = s->path[s->path_off[m] + e];
+          if ((code >> 23) & 1) {
+            chance *= s->edge_prob[code & 0x7FFFFF];
+          } else {
+            const int pl = (code >> 24) & 0xF, a_idx = (code & 0x7FFFFF) - s->info[anc[e]] * s->A;
+            if (sub_of[anc[e]] != g || a_idx < 0 || a_idx >= s->A) return OSG_OK;   // (cannot happen: decisions sit below the cut)
+            codes[static_cast<size_t>(pl) * 4 * per_player + filled[pl]++] =
+                aux[static_cast<size_t>(g) * NL + loc_of[anc[e]]] * s->A + a_idx;
+          }
+        }
+        int64_t bits;
+        memcpy(&bits, &chance, sizeof bits);
+        sub_rec.push_back(static_cast<int32_t>(bits & 0xFFFFFFFF));
+        sub_rec.push_back(static_cast<int32_t>(bits >> 32));
+        sub_rec.push_back(0);
+        sub_rec.push_back(0);
+        sub_rec.insert(sub_rec.end(), codes.begin(), codes.end());
         ++n_members;
       }
       mem_off[static_cast<size_t>(g) * s->P + q + 1] = n_members;
@@ -3217,6 +3253,8 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
                s->d_node_delta + static_cast<size_t>(M) * s->A, s->d_skip, s->d_sub_bar, s->h_sub_err, 400000000ull /* 4 s at 100 MHz */, nullptr};
     static unsigned long long* d_stamps = nullptr;   // OSG_CFR_SUB_STAMPS=1: phase stamps of workgroup 0 (tools/probe_cfr_sub.py)
     if (std::getenv("OSG_CFR_SUB_STAMPS")) {
+      sp.stamp_wg = std::max(0, std::min(s->sub_grid - 1, atoi(std::getenv("OSG_CFR_SUB_STAMPS")) - 1));
+      fprintf(stderr, "k_cfr_sub: G %d grid %d NL %d ND %d PL %d K %d\n", s->sub_G, s->sub_grid, s->sub_NL, s->sub_ND, s->sub_PL, s->sub_K);
       if (!d_stamps) OSG_HIP(hipMalloc(reinterpret_cast<void**>(&d_stamps), sizeof(unsigned long long) * 8 * kMaxPlayers));
       sp.stamps = d_stamps;
     }
@@ -3235,7 +3273,7 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
       OSG_HIP(hipMemcpyAsync(h, sp.stamps, sizeof(unsigned long long) * 7 * s->P, hipMemcpyDeviceToHost, st));
       OSG_HIP(hipStreamSynchronize(st));
       for (int q = 0; q < s->P; ++q)
-        fprintf(stderr, "k_cfr_sub pass %d (workgroup 0, us): descriptors %.2f  preload %.2f  levels %.2f |  sweep %.2f  members %.2f  barrier %.2f  fold %.2f  (pass %.2f)\n", q,
+        fprintf(stderr, "k_cfr_sub pass %d (one workgroup, us): descriptors %.2f  preload %.2f  levels %.2f |  sweep %.2f  members %.2f  barrier %.2f  fold %.2f  (pass %.2f)\n", q,
                 (h[s->P * 5 + q * 2 + 1] - h[q * 5]) / 100.0, (h[s->P * 5 + q * 2] - h[s->P * 5 + q * 2 + 1]) / 100.0,
                 (h[q * 5 + 1] - h[s->P * 5 + q * 2]) / 100.0,
                 (h[q * 5 + 1] - h[q * 5]) / 100.0, (h[q * 5 + 2] - h[q * 5 + 1]) / 100.0, (h[q * 5 + 3] - h[q * 5 + 2]) / 100.0,

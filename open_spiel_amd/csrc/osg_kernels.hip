@@ -888,6 +888,48 @@ k_observation_row_pieces(F f, uint32_t n, FastDiv by_size, uint32_t lmagic, uint
     }
   }
 }
+// The same pieces with the rows' IMAGES staged in LDS: a span of 1024 floats belongs to 1024 / size + 2 states, and
+// in the kernel above every piece rebuilds the images of its two states (leduc_poker's information row: 82 vector
+// instructions per piece, the vector unit 84 % busy — profiles/r04_pmc_obs_rows_pieces.txt).  Here the workgroup's
+// kSpans spans first get their states' images, one (span, state) per thread, then a piece is two LDS reads, a shift
+// and four conversions.
+template <class F, bool kNt, int kSpans>
+__global__ void __launch_bounds__(kPieceBlock)
+k_observation_row_pieces_lds(F f, uint32_t n, FastDiv by_size, uint32_t lmagic, uint32_t lshift, uint32_t cap, uint32_t cmagic,
+                             uint32_t cshift, uint32_t total, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(8))) unsigned char s_raw[];
+  typename F::Img* s_img = reinterpret_cast<typename F::Img*>(s_raw);   // [kSpans][cap]
+  const uint32_t size = by_size.d;
+  for (uint32_t flat = threadIdx.x; flat < kSpans * cap; flat += kPieceBlock) {
+    const uint32_t j = (flat * cmagic) >> cshift, sl = flat - j * cap;                  // flat / cap
+    const uint32_t fb = (blockIdx.x + j * gridDim.x) * 1024u;
+    if (fb >= total) continue;
+    uint32_t i = by_size.div(fb) + sl;
+    if (i >= n) i = n - 1u;
+    s_img[flat] = f.image(f.load(i));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kSpans; ++j) {
+    const uint32_t fb = (blockIdx.x + j * gridDim.x) * 1024u;
+    const uint32_t f0 = fb + 4u * threadIdx.x;
+    if (f0 >= total) continue;
+    const uint32_t ib = by_size.div(fb);
+    const uint32_t local = (fb - ib * size) + 4u * threadIdx.x;      // < size + 1024
+    const uint32_t il = (local * lmagic) >> lshift;                  // local / size
+    const uint32_t off = local - il * size;
+    const float4 v = f.piece_img(s_img[j * cap + il], s_img[j * cap + il + 1u], off);
+    float* dst = out + static_cast<size_t>(blockIdx.x + j * gridDim.x) * 1024u + 4u * threadIdx.x;
+    if (f0 + 4u <= total) {
+      store_row4<kNt>(reinterpret_cast<float4*>(dst), v);
+    } else {  // the tensor's last piece (atomic stores: see k_observation_c4std_pieces)
+      const uint32_t left = total - f0;
+      __hip_atomic_store(dst, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (left > 1u) __hip_atomic_store(dst + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (left > 2u) __hip_atomic_store(dst + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
 OSG_D float4 low_four_bits(uint32_t u) {
   return make_float4(static_cast<float>(u & 1u), static_cast<float>((u >> 1) & 1u), static_cast<float>((u >> 2) & 1u),
                      static_cast<float>((u >> 3) & 1u));
@@ -904,6 +946,8 @@ struct TttPieces {
   OSG_D float4 piece(Words a, Words b, uint32_t off) const {  // off <= 26
     return low_four_bits((image(a) >> off) | (image(b) << (27u - off)));
   }
+  using Img = uint32_t;
+  OSG_D float4 piece_img(Img a, Img b, uint32_t off) const { return low_four_bits((a >> off) | (b << (27u - off))); }
 };
 // kuhn_poker, two players (KuhnObserver::WriteTensor, kuhn_poker.cc:72-107), in the piece form.  The round-3 rows
 // kernel spends its whole launch issuing vector instructions (profiles/r04_pmc_k_observation_rows_kuhn_2p24.txt:
@@ -994,6 +1038,15 @@ struct Leduc2Pieces {
     Img both = image(a) >> (kBits * off);
     const uint32_t in_a = size - off;                        // entries of the piece that lie in a's row (>= 1)
     if (in_a < 4u) both |= image(b) << (kBits * in_a);
+    const uint32_t u = static_cast<uint32_t>(both), m = (1u << kBits) - 1u;
+    return make_float4(static_cast<float>(u & m), static_cast<float>((u >> kBits) & m),
+                       static_cast<float>((u >> (2 * kBits)) & m), static_cast<float>((u >> (3 * kBits)) & m));
+  }
+  OSG_D float4 piece_img(Img ia, Img ib, uint32_t off) const {
+    const uint32_t size = kWhich == 0 ? 4u + 2u * K : 18u + 2u * K;
+    const uint32_t in_a = size - off;                        // entries of the piece that lie in a's row (>= 1)
+    Img both = ia >> (kBits * off);
+    both |= in_a < 4u ? ib << (kBits * in_a) : Img{0};
     const uint32_t u = static_cast<uint32_t>(both), m = (1u << kBits) - 1u;
     return make_float4(static_cast<float>(u & m), static_cast<float>((u >> kBits) & m),
                        static_cast<float>((u >> (2 * kBits)) & m), static_cast<float>((u >> (3 * kBits)) & m));
@@ -1782,6 +1835,11 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
   // [2^16, 126]: 7.4 vs 8.4 us, hex(9) [2^14, 729]: 11.9 vs 29.5 us; from [2^20, 27] on the piece form is ahead)
   const bool pieces = obs_form != 0 && aligned16 && total < (int64_t{1} << 32) && total >= (int64_t{1} << 24);
   const bool nt = obs_form != 1;
+  // OSG_OBS_LDS=0: every piece builds its rows' images itself (A/B); 4 / 8: images staged in LDS, that many spans per
+  // workgroup; default: 8 for tic_tac_toe (0.77 vs 0.70 with 4 and 0.75 without), 4 for leduc_poker (information rows 0.83
+  // vs 0.78 with 8 and 0.80 without) — tools/probe_obs_lds.py
+  static const int obs_lds_env = std::getenv("OSG_OBS_LDS") ? std::atoi(std::getenv("OSG_OBS_LDS")) : -1;
+  const int obs_lds = obs_lds_env >= 0 ? obs_lds_env : (b->spec.desc.game_kind == kTtt ? 8 : 4);
   const unsigned piece_grid = static_cast<unsigned>(((total + 1023) / 1024 + 3) / 4);   // four 1 KiB-piece spans per workgroup
   if (pieces && b->spec.desc.game_kind == kC4 && b->spec.c4_std) {
 #define OSG_C4P(NT, EGO) k_observation_c4std_pieces<NT, EGO, 4><<<dim3(piece_grid), dim3(kPieceBlock), 0, ctx->stream>>>( \
@@ -1789,6 +1847,35 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
     if (b->spec.c4.ego) { if (nt) OSG_C4P(true, true); else OSG_C4P(false, true); }
     else { if (nt) OSG_C4P(true, false); else OSG_C4P(false, false); }
 #undef OSG_C4P
+  } else if (pieces && obs_lds && (b->spec.desc.game_kind == kTtt || (b->spec.desc.game_kind == kLeduc && d.num_players == 2))) {
+    // the rows' images staged in LDS (k_observation_row_pieces_lds)
+    uint32_t magic = 0, shift = 0, cmagic = 0, cshift = 0;
+    const uint32_t cap = 1024u / static_cast<uint32_t>(size) + 3u;
+    if (!find_div_magic(static_cast<uint32_t>(size), static_cast<uint32_t>(size) + 1024u, &magic, &shift) ||
+        !find_div_magic(cap, 8u * cap, &cmagic, &cshift))
+      return set_error(OSG_ERR_INVALID, "osg_observation: no multiply-shift pair for this row size");
+    const FastDiv fd = make_fast_div(static_cast<uint32_t>(size));
+    const uint32_t nn = static_cast<uint32_t>(b->n), tot = static_cast<uint32_t>(total);
+#define OSG_ROWL(F, f, SP) do {                                                                                              \
+      const unsigned g = static_cast<unsigned>(((total + 1023) / 1024 + (SP) - 1) / (SP));                                     \
+      const size_t lds = sizeof(typename F::Img) * (SP) * cap;                                                                 \
+      if (nt) k_observation_row_pieces_lds<F, true, SP><<<dim3(g), dim3(kPieceBlock), lds, ctx->stream>>>(f, nn, fd, magic, shift, cap, cmagic, cshift, tot, d_out); \
+      else k_observation_row_pieces_lds<F, false, SP><<<dim3(g), dim3(kPieceBlock), lds, ctx->stream>>>(f, nn, fd, magic, shift, cap, cmagic, cshift, tot, d_out);  \
+    } while (0)
+    if (b->spec.desc.game_kind == kTtt) {
+      TttPieces f{static_cast<const uint32_t*>(b->d_words)};
+      if (obs_lds == 8) OSG_ROWL(TttPieces, f, 8); else OSG_ROWL(TttPieces, f, 4);
+    } else {
+      const int K = b->spec.leduc.iso ? b->spec.leduc.cards / 2 : b->spec.leduc.cards;
+      if (which == 0) {
+        Leduc2Pieces<0> f{static_cast<const uint64_t*>(b->d_words), nn, player, K, b->spec.leduc};
+        if (obs_lds == 8) OSG_ROWL(Leduc2Pieces<0>, f, 8); else OSG_ROWL(Leduc2Pieces<0>, f, 4);
+      } else {
+        Leduc2Pieces<1> f{static_cast<const uint64_t*>(b->d_words), nn, player, K, b->spec.leduc};
+        if (obs_lds == 8) OSG_ROWL(Leduc2Pieces<1>, f, 8); else OSG_ROWL(Leduc2Pieces<1>, f, 4);
+      }
+    }
+#undef OSG_ROWL
   } else if (pieces && b->spec.desc.game_kind == kTtt) {
     uint32_t magic = 0, shift = 0;
     find_div_magic(static_cast<uint32_t>(size), static_cast<uint32_t>(size) + 1024u, &magic, &shift);

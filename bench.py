@@ -357,8 +357,9 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
                                                          "~5 450 histories, values and policy rows in LDS), two grid barriers per player "
                                                          "pass; tables bit-identical with the launch-per-phase kernels (1 850 it/s)",
                                              "note": "bound by memory round trips between dependent phases (terminal values and policy rows "
-                                                     "in, member records, terms out, fold), not by bytes: profiles/r04_probe_cfr_sub.log has "
-                                                     "the phase stamps"}
+                                                     "in, member records, terms out, fold) and by 336 subtrees on a cooperative grid of 256 "
+                                                     "workgroups (80 take two while 176 wait), not by bytes: profiles/r04_probe_cfr_sub.log "
+                                                     "has the per-workgroup phase stamps"}
             del three
     except Exception as e:  # noqa: BLE001 - a secondary figure must never cost the line
         out["cfr"]["leduc"] = {"error": f"{type(e).__name__}: {e}"}
@@ -481,11 +482,23 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
                     sj.nash_conv()
                 dt = time.perf_counter() - t0
                 judge[g] = {"us_per_nash_conv": dt / reps * 1e6, "nash_conv_after_20_iterations": sj.nash_conv()}
-                del sj
+                # CFRBRSolver (cfr_br.cc:48-83) on the same tree: best responses of every player, then one pass per player
+                sb = osa.TabularSolver(ctx, g)
+                sb.evaluate_and_update_policy_cfr_br(5)
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                sb.evaluate_and_update_policy_cfr_br(300)
+                ctx.synchronize()
+                judge[g]["cfr_br_iterations_per_s"] = 300 / (time.perf_counter() - t0)
+                judge[g]["cfr_br_nash_conv_after_305"] = sb.nash_conv()
+                del sj, sb
             out["policy_evaluation"] = {"metric": "NashConv evaluations (osg_cfr_evaluate_policy: expected returns + one best response "
                                                   "per player on the flattened tree)", "per_game": judge,
-                                        "note": "host call to host result (upload of the policy table, one kernel, download): the reference "
-                                                "walks the tree per call (tabular_exploitability.cc:30-89)"}
+                                        "note": "host call to host result; the tables stay on the device (the average policy is "
+                                                "formed inside the kernel). leduc_poker: k_eval_jobs, 30 expected-returns jobs + 12 "
+                                                "best-response jobs of one workgroup each, the last one sums the chance levels (222 us per "
+                                                "call on one workgroup before); the reference walks the tree per call "
+                                                "(tabular_exploitability.cc:30-89)"}
         except Exception as e:  # noqa: BLE001
             out["env_step"] = {"error": f"{type(e).__name__}: {e}"}
     # ---- config 1: tic_tac_toe MCTSBot(RandomRolloutEvaluator(20, 42), 1000 sims, solve) — plumbing ----

@@ -530,6 +530,7 @@ struct SplitTree {
   const int32_t* info_list;      // [G, NI] infostates with a member in the subtree, -1 = padding
   double* terms;                 // [2][M][kSplitRec]: buffer (pass parity) x {own reach or -1, A regret terms} per member
   unsigned int* bar;             // [0] arrival counter, [1] error flag (both zeroed before every launch), [2] sticky error
+  unsigned int* host_err;        // pinned host word raised on a timeout: the host's next call reads it without a copy
 };
 
 OSG_D void store_through(double* p, double v) {   // agent scope: written through to memory, visible to every CU
@@ -704,6 +705,7 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
         if (!ok) {
           __hip_atomic_store(&sp.bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&sp.bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sticky: read by the host
+          __hip_atomic_store(sp.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         *s_ok = ok;
       }
@@ -3039,19 +3041,20 @@ int build_sub(osg_cfr* s) {
   s->sub_PL = PL;
   OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_sub_bar), sizeof(unsigned int) * 4));
   OSG_HIP(hipMemsetAsync(s->d_sub_bar, 0, sizeof(unsigned int) * 4, st));
-  OSG_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_sub_err), sizeof(unsigned int), hipHostMallocMapped));
-  *s->h_sub_err = 0;
   s->sub_G = G; s->sub_L = L; s->sub_NL = NL; s->sub_K = K; s->sub_grid = grid; s->sub_lds_bytes = lds;
   s->sub_ok = true;
   return OSG_OK;
 }
 
 
-// A grid barrier of k_cfr_sub that timed out (a hung device: the launch is cooperative) leaves the tables mixed: the
-// solver refuses further work.  The kernel raises a pinned host word, read here without a copy or a wait.
-int cfr_sub_error(osg_cfr* s) {
+// A grid barrier of k_cfr_split / k_cfr_sub that timed out (a hung device: the launches are cooperative) leaves the
+// tables mixed: the solver refuses further work.  The kernels raise a pinned host word, read here without a copy or a
+// wait — by every entry point that advances, reads or hands out the tables.
+int cfr_sub_error(const osg_cfr* s) {
   if (s->h_sub_err && __atomic_load_n(s->h_sub_err, __ATOMIC_RELAXED) != 0)
-    return set_error(OSG_ERR_HIP, "k_cfr_sub: a grid barrier timed out in an earlier launch; the tables are not usable");
+    return set_error(OSG_ERR_HIP, "a grid barrier of the subtree CFR kernel timed out in an earlier launch (the launch is "
+                                  "cooperative: a hung device, not contention); the tables are not usable — "
+                                  "osg_cfr_cfg.kernel = 3 runs one workgroup");
   return OSG_OK;
 }
 
@@ -3159,6 +3162,12 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
   }
   rc = build_resident_tree(s);
   if (rc) { osg_cfr_destroy(s); return rc; }
+  if (hipHostMalloc(reinterpret_cast<void**>(&s->h_sub_err), sizeof(unsigned int), hipHostMallocMapped) != hipSuccess) {
+    (void)hipGetLastError();
+    osg_cfr_destroy(s);
+    return set_error(OSG_ERR_NOMEM, "osg_cfr_create: pinned error word");
+  }
+  *s->h_sub_err = 0;
   rc = build_split(s);
   if (rc == OSG_OK) rc = build_sub(s);
   if (rc == OSG_OK) rc = build_eval_jobs(s);
@@ -3229,6 +3238,7 @@ static int launch_split(osg_cfr* s, SmallTree stree, SplitTree sp, Tables tb, in
 int osg_cfr_iterate(osg_cfr* s, int iters) {
   if (!s || iters < 0) return set_error(OSG_ERR_INVALID, "osg_cfr_iterate: bad argument");
   if (iters == 0) return OSG_OK;
+  if (int rc = cfr_sub_error(s)) return rc;
   int threads = ((s->max_level_width + 63) / 64) * 64;
   threads = std::max(64, std::min(threads, 1024));
   Tables tb{s->regrets(), s->cum(), s->cur()};
@@ -3314,7 +3324,7 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
     SmallTree stree{s->d_path_off, s->d_path, M, static_cast<int>(s->path.size())};
     SplitTree sp{s->split_G, s->split_L, s->split_NL, s->split_NM, s->split_NI, s->d_split_nloc, s->d_split_desc,
                  s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
-                 s->d_split_terms, s->d_split_bar};
+                 s->d_split_terms, s->d_split_bar, s->h_sub_err};
     const int passes = s->cfg.alternating_updates ? s->P : 1;
     const int per_launch = std::max(1, (1 << 30) / std::max(1, passes * s->split_G));  // the arrival counter is 32 bits
     for (int done = 0; done < iters; done += per_launch) {
@@ -3551,6 +3561,7 @@ int osg_cfr_br_iterate(osg_cfr* s, int iters) {
     return set_error(OSG_ERR_INVALID, "osg_cfr_br_iterate: CFRBRSolver is plain CFR (cfr_br.cc:23-29)");
   if (s->B != 1) return set_error(OSG_ERR_UNSUPPORTED, "osg_cfr_br_iterate: one solver per object");
   if (!s->eval_ok) return set_error(OSG_ERR_UNSUPPORTED, "an information state spans several tree levels");
+  if (int rc = cfr_sub_error(s)) return rc;
   const size_t M = s->mem.size();
   EvalArrays ea;
   ea.path_off = s->d_path_off; ea.path = s->d_path; ea.info_level = s->d_info_level; ea.mem_index = s->d_mem_index;
@@ -3573,7 +3584,7 @@ int osg_cfr_br_iterate(osg_cfr* s, int iters) {
   SmallTree stree{s->d_path_off, s->d_path, static_cast<int>(M), static_cast<int>(s->path.size())};
   SplitTree sp{s->split_G, s->split_L, s->split_NL, s->split_NM, s->split_NI, s->d_split_nloc, s->d_split_desc,
                s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
-               s->d_split_terms, s->d_split_bar};
+               s->d_split_terms, s->d_split_bar, s->h_sub_err};
   for (int it = 0; it < iters; ++it) {
     if (jobs) k_eval_jobs<<<dim3(s->jobs_J), dim3(s->jobs_threads), s->jobs_lds_bytes, st>>>(s->tree(), ea, eval_jobs_of(s), s->cur(), 1, 1);
     else k_policy_eval<<<dim3(1), dim3(threads), 0, st>>>(s->tree(), ea, s->cur());
@@ -3603,6 +3614,7 @@ int osg_mccfr_iterate(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64
 
 int osg_cfr_table_ptrs(osg_cfr* s, double** d_regrets, double** d_cum_policy, double** d_cur_policy) {
   if (!s) return set_error(OSG_ERR_INVALID, "osg_cfr_table_ptrs: null argument");
+  if (int rc = cfr_sub_error(s)) return rc;
   if (d_regrets) *d_regrets = s->regrets();
   if (d_cum_policy) *d_cum_policy = s->cum();
   if (d_cur_policy) *d_cur_policy = s->cur();
@@ -3714,6 +3726,8 @@ static int evaluate_policy_impl(osg_cfr* s, int which_policy, const double* h_po
   const int P = s->P;
   hipStream_t st = s->ctx->stream;
   if (which_policy < 0 || which_policy > 2) return set_error(OSG_ERR_INVALID, "osg_cfr_evaluate_policy: which_policy must be 0, 1 or 2");
+  if (which_policy != 2)
+    if (int rc = cfr_sub_error(s)) return rc;
   if (which_policy == 2 && !h_policy) return set_error(OSG_ERR_INVALID, "osg_cfr_evaluate_policy: which_policy == 2 needs h_policy");
   EvalArrays ea;
   ea.path_off = s->d_path_off; ea.path = s->d_path; ea.info_level = s->d_info_level; ea.mem_index = s->d_mem_index;

@@ -69,11 +69,10 @@ class OneShotComm:
             rank, world_size = world()
         self.ctx, self.rank, self.world_size, self.max_doubles = ctx, int(rank), int(world_size), int(max_doubles)
         self._lib, self._check = lib(), check
-        h = C.c_void_p()
-        check(self._lib.osg_comm_oneshot_create(ctx._h, self.rank, self.world_size, self.max_doubles, C.byref(h)))
-        self._h = h
-        mine = C.create_string_buffer(128)
-        check(self._lib.osg_comm_oneshot_handle(self._h, mine))
+        # Every step that can fail on ONE rank (window allocation, hipIpc export / open) is followed by a round on the
+        # host channel in which the ranks agree on the outcome: either all ranks hold a connected communicator or all
+        # raise here — no rank is left waiting in a collective for a peer that gave up.
+        self._h = None
         if exchange is None:
             def exchange(blob):
                 if self.world_size == 1:
@@ -81,10 +80,35 @@ class OneShotComm:
                 out = [None] * self.world_size
                 dist.all_gather_object(out, blob)
                 return out
-        blobs = exchange(mine.raw)
-        if len(blobs) != self.world_size or any(len(b) != 128 for b in blobs):
-            raise ValueError("OneShotComm: exchange() must return one 128-byte handle per rank, in rank order")
-        check(self._lib.osg_comm_oneshot_connect(self._h, C.create_string_buffer(b"".join(blobs), 128 * self.world_size)))
+        failure, mine = None, b""
+        try:
+            h = C.c_void_p()
+            check(self._lib.osg_comm_oneshot_create(ctx._h, self.rank, self.world_size, self.max_doubles, C.byref(h)))
+            self._h = h
+            buf = C.create_string_buffer(128)
+            check(self._lib.osg_comm_oneshot_handle(self._h, buf))
+            mine = buf.raw
+        except Exception as e:  # noqa: BLE001 - reported to every rank below
+            failure = e
+        blobs = exchange(mine)
+        if len(blobs) != self.world_size:
+            self.close()
+            raise ValueError("OneShotComm: exchange() must return one entry per rank, in rank order")
+        if any(len(b) != 128 for b in blobs):
+            self.close()
+            bad = [r for r, b in enumerate(blobs) if len(b) != 128]
+            raise RuntimeError(f"OneShotComm: rank(s) {bad} could not create or export their window"
+                               + (f" (this rank: {failure})" if failure else ""))
+        try:
+            check(self._lib.osg_comm_oneshot_connect(self._h, C.create_string_buffer(b"".join(blobs), 128 * self.world_size)))
+        except Exception as e:  # noqa: BLE001
+            failure = e
+        verdicts = exchange((b"\x00" if failure else b"\x01") * 128)
+        if any(v[:1] != b"\x01" for v in verdicts):
+            self.close()
+            bad = [r for r, v in enumerate(verdicts) if v[:1] != b"\x01"]
+            raise RuntimeError(f"OneShotComm: rank(s) {bad} could not map their peers' windows (hipIpcOpenMemHandle)"
+                               + (f" (this rank: {failure})" if failure else ""))
 
     def _ptr(self, tensor, begin=False):
         if not (isinstance(tensor, torch.Tensor) and tensor.is_cuda and tensor.is_contiguous()

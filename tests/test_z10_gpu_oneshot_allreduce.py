@@ -128,6 +128,16 @@ if rank == 0:
     except osa.OsgError as e:
         out["timeout_reported"] = "timed out" in str(e)
 dist.barrier()
+# a rank that cannot create its window: BOTH ranks must raise at construction (nobody waits for the other in a collective)
+try:
+    osd.OneShotComm(ctx, 1024 if rank == 0 else -5)
+    agreed = "no error"
+except RuntimeError as e:
+    agreed = str(e)
+both = [None] * world
+dist.all_gather_object(both, agreed)
+out["failed_creation_agreed"] = all("rank(s) [1]" in m for m in both)
+dist.barrier()
 if rank == 0:
     print(json.dumps(out), flush=True)
 dist.barrier()
@@ -157,6 +167,7 @@ def test_oneshot_allreduce_two_ranks_on_one_device(tmp_path):
         assert rec[key]["rank_diff"] == 0.0, "every rank folds bit-identical sums"
         assert rec[key]["vs_one_rank"] < 1e-8 * max(1.0, rec[key]["regret_abs_sum"])
     assert 0.2 < rec["timeout_seconds"] < 5.0 and rec["timeout_reported"] and rec["timeout_left_buffer_alone"]
+    assert rec["failed_creation_agreed"], "a rank that cannot create its window must fail the construction on every rank"
 
 
 def test_oneshot_world_one_and_argument_checks():

@@ -642,7 +642,8 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
         if (o_lvl == l && o_k != kTerminalNode) {
           for (int q = q0; q < q1; ++q) {
             double v = 0.0;
-            for (int a = 0; a < o_nc; ++a) {
+            for (int a = 0; a < o_nc; ++a) {   // (six children per round trip with clamped indices: 18.6 vs 16.9 us per
+              // iteration — the sweep is bound by the instructions of a lone wavefront, not by LDS round trips)
               const double pr = o_k == kChanceNode ? l_edge[o_fc + a] : pol[o_row + a];
               v += pr * value[(o_fc + a) * P + q];
             }

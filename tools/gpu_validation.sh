@@ -66,6 +66,10 @@ timeout 600 python tools/probe_mcts_bench.py > "$OUT/mcts_bench.log" 2>&1; grep 
 timeout 600 python tools/probe_cfr.py > "$OUT/probe_cfr.log" 2>&1; tail -12 "$OUT/probe_cfr.log" | cut -c1-200 | tee -a "$OUT/summary.txt"
 timeout 600 python tools/probe_kernels.py > "$OUT/probe_kernels.log" 2>&1; grep "2^24" "$OUT/probe_kernels.log" | cut -c1-220 | tee -a "$OUT/summary.txt"
 timeout 600 python tools/probe_mcts_evaluator.py > "$OUT/mcts_evaluator.log" 2>&1; tail -12 "$OUT/mcts_evaluator.log" | cut -c1-220 | tee -a "$OUT/summary.txt"
+timeout 300 python tools/probe_judge.py > "$OUT/probe_judge.log" 2>&1; grep -v amdgpu.ids "$OUT/probe_judge.log" | tail -4 | tee -a "$OUT/summary.txt"
+timeout 300 python tools/probe_cfr_sub.py > "$OUT/probe_cfr_sub.log" 2>&1; grep -E "^grid|^sub|^auto" "$OUT/probe_cfr_sub.log" | tee -a "$OUT/summary.txt"
+timeout 300 python tools/probe_obs_lds.py > "$OUT/probe_obs_lds.log" 2>&1; grep -v amdgpu.ids "$OUT/probe_obs_lds.log" | tee -a "$OUT/summary.txt"
+timeout 300 python tools/probe_single_root.py > "$OUT/probe_single_root.log" 2>&1; tail -6 "$OUT/probe_single_root.log" | cut -c1-200 | tee -a "$OUT/summary.txt"
 # keep the merged-back directory small (gpurun merges at most 64 MiB)
 find "$OUT" -name '*.db' -size +20M -delete 2>/dev/null
 du -sh "$OUT" | tee -a "$OUT/summary.txt"

@@ -247,7 +247,11 @@ typedef struct {
                                and rollouts spread over the 64 lanes; hex playouts as a
                                wave-parallel random fill).  The two layouts define their
                                random streams differently (see osg_common.h), so results
-                               are reproducible per layout, not across layouts.      */
+                               are reproducible per layout, not across layouts.  Layout 2
+                               serves boards of up to 128 actions; hex above 11 x 11,
+                               connect_four above 64 board bits and leduc_poker with 4+
+                               players are searched with layout 1 (0 picks it).  A node
+                               holds up to 511 actions.                              */
   int32_t child_selection_policy;  /* ChildSelectionPolicy (mcts.h:148): 0 UCT (mcts.cc:90-101),
                                1 PUCT (mcts.cc:103-112) with the evaluator's prior — uniform over
                                the legal actions for RandomRolloutEvaluator (mcts.cc:74-87)        */

@@ -1216,7 +1216,9 @@ class MCTSBot : public Bot {
       auto [node, i] = todo.back();
       todo.pop_back();
       const uint32_t m = meta[i];
-      node->action = i == 0 ? kInvalidAction : static_cast<Action>(m & 0xFFu);
+      // (games with more than 255 actions keep the ninth bit of the action in bit 24 and of the child count in bit 25:
+      // csrc/osg_mcts_internal.h; both are zero for every other game)
+      node->action = i == 0 ? kInvalidAction : static_cast<Action>((m & 0xFFu) | ((m >> 16) & 0x100u));
       node->player = i == 0 ? root_player : static_cast<Player>((m >> 8) & 15u) - 1;
       node->prior = prior[i];
       node->explore_count = static_cast<int>(count[i]);
@@ -1230,7 +1232,7 @@ class MCTSBot : public Bot {
           if (node->player >= 0) node->outcome[node->player] = total[i] / count[i];
         }
       }
-      const int nc = static_cast<int>((m >> 12) & 0xFFu);
+      const int nc = static_cast<int>(((m >> 12) & 0xFFu) | ((m >> 17) & 0x100u));
       node->children.resize(nc);
       for (int k = 0; k < nc; ++k) todo.push_back({&node->children[k], first[i] + static_cast<uint32_t>(k)});
     }

@@ -114,9 +114,11 @@ struct osg_batch {
 
 // Dispatch a generic lambda-like macro body over the concrete game type.
 // Inside the body: `G` is the game struct and `P` its Params instance.
-// OSG_DISPATCH serves the games whose legal mask is the engine's 4-word Mask (every entry point of the search and solver
-// kernels); OSG_DISPATCH_WIDE adds the hex boards above 128 actions (the batch entry points of osg_kernels.hip: states,
-// masks, steps, tensors, random steps, rollouts, environment steps).
+// OSG_DISPATCH serves the games whose legal mask is the engine's 4-word Mask and whose record is the two-word one (the
+// wave-per-root search and the solvers' tree builder); OSG_DISPATCH_WIDE adds the hex boards above 128 actions,
+// connect_four above 64 board bits and leduc_poker with 4+ players (the batch entry points of osg_kernels.hip — states,
+// masks, steps, tensors, random steps, rollouts, environment steps — and the lane-per-root searches of osg_mcts.hip /
+// osg_mcts_step.hip).
 #define OSG_DISPATCH(spec, ...)                                                   \
   do {                                                                             \
     switch ((spec).desc.game_kind) {                                               \
@@ -124,13 +126,13 @@ struct osg_batch {
       case osg::kC4:                                                               \
         if ((spec).c4_std) { using G = osg::C4Std; const G::Params& P = (spec).c4; __VA_ARGS__; } \
         else if ((spec).c4_wide) return osg::set_error(OSG_ERR_UNSUPPORTED, "connect_four boards above 64 bits are served by " \
-                                                       "the batch entry points (states, masks, steps, tensors, rollouts), not by this one"); \
+                                                       "the batch entry points and the lane-per-root searches, not by this one"); \
         else { using G = osg::C4; const G::Params& P = (spec).c4; __VA_ARGS__; }   \
         break;                                                                     \
       case osg::kKuhn: { using G = osg::Kuhn; const G::Params& P = (spec).kuhn; __VA_ARGS__; } break; \
       case osg::kLeduc:                                                            \
         if ((spec).leduc_big) return osg::set_error(OSG_ERR_UNSUPPORTED, "leduc_poker with more than 3 players is served by the " \
-                                                    "batch entry points (states, masks, steps, tensors, rollouts), not by this one"); \
+                                                    "batch entry points and the lane-per-root searches, not by this one"); \
         { using G = osg::Leduc; const G::Params& P = (spec).leduc; __VA_ARGS__; } break; \
       case osg::kHex:                                                              \
         switch ((spec).hex_nw) {                                                   \
@@ -139,7 +141,7 @@ struct osg_batch {
           case 3: { using G = osg::HexT<3>; const G::Params& P = (spec).hex3; __VA_ARGS__; } break; \
           case 4: { using G = osg::HexT<4>; const G::Params& P = (spec).hex4; __VA_ARGS__; } break; \
           default: return osg::set_error(OSG_ERR_UNSUPPORTED, "hex boards above 128 actions are served by the batch entry " \
-                                         "points (states, masks, steps, tensors, rollouts), not by this one"); \
+                                         "points and the lane-per-root searches, not by this one"); \
         }                                                                          \
         break;                                                                     \
       default: return osg::set_error(OSG_ERR_INVALID, "bad game kind");            \

@@ -32,6 +32,9 @@ __global__ void __launch_bounds__(kBlockM)
 k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, int num_actions,
        osg_mcts_cfg cfg, double max_utility, const double* __restrict__ log_table, Pool pool, int32_t* best_action,
        int32_t* child_visits, double* child_reward, int8_t* child_outcome, double* root_stats) {
+  // (games with more than 255 actions — hex above 15 x 15 — use the nine-bit action / child-count fields)
+  constexpr bool kWide = G::kMaskW > kMaskWords;
+  using LegalMask = MaskT<G::kMaskW>;
   const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlockM + threadIdx.x;
   if (r >= n) return;
   const uint64_t gr = static_cast<uint64_t>(cfg.index_offset + r);
@@ -44,7 +47,7 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
 
   const typename G::State root_state = G::load(p, base, n, r);
   const int root_player = G::current_player(p, root_state);
-  META(0) = make_meta(0xFF, root_player, 0);  // mcts.cc:356-357: root = (kInvalidAction, CurrentPlayer(), 1)
+  META(0) = mw_make<kWide>(0xFF, root_player, 0);  // mcts.cc:356-357: root = (kInvalidAction, CurrentPlayer(), 1)
   FIRST(0) = 0; PARENT(0) = kNoNode; COUNT(0) = 0; TOTAL(0) = 0.0;
   uint32_t used = 1;       // = the reference's nodes_: 1 + the children blocks allocated (mcts.cc:299,354)
   int gc_limit = kMinGcLimit;
@@ -63,8 +66,8 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
       if (term || cnt == 0) break;
       uint32_t meta = META(node);
       const int cur = G::current_player(p, s);
-      if (m_nchild(meta) == 0) {  // expand: children = Prior(state), shuffled (mcts.cc:281-299)
-        const Mask legal = G::legal(p, s);
+      if (mw_nchild<kWide>(meta) == 0) {  // expand: children = Prior(state), shuffled (mcts.cc:281-299)
+        const LegalMask legal = G::legal(p, s);
         const int c = legal.count();
         // slots exhausted (unreachable unless the caller's HBM could not hold max_nodes + slack), or a record that is
         // not terminal and has no legal action (only an uploaded inconsistent one): evaluate as a leaf
@@ -72,7 +75,7 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
         const uint32_t first = used;
         used += c;
         for (int k = 0; k < c; ++k) {
-          META(first + k) = make_meta(select_action(legal, k), cur, 0);
+          META(first + k) = mw_make<kWide>(select_action(legal, k), cur, 0);
           FIRST(first + k) = 0; PARENT(first + k) = node; COUNT(first + k) = 0; TOTAL(first + k) = 0.0;
         }
         for (int i = c - 1; i >= 1; --i) {  // Fisher-Yates == std::shuffle's role (order only)
@@ -81,19 +84,19 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
           META(first + i) = mj;
           META(first + j) = mi;
         }
-        meta = make_meta(m_action(meta), m_player(meta), c) | (meta & 0x00F00000u);
+        meta = mw_make<kWide>(static_cast<int>(mw_action<kWide>(meta)), m_player(meta), c) | (meta & kMetaOutcomeBits);
         META(node) = meta;
         FIRST(node) = first;
       }
       const uint32_t first = FIRST(node);
-      const int c = m_nchild(meta);
+      const int c = mw_nchild<kWide>(meta);
       uint32_t chosen = first, chosen_meta = 0;
       bool have_meta = false;
       if (cur == kChancePlayer) {  // mcts.cc:311-322
-        const Mask legal = G::legal(p, s);
+        const LegalMask legal = G::legal(p, s);
         const int a = sample_action_chance<G>(p, s, legal, trng);
         for (int k = 0; k < c; ++k)
-          if (static_cast<int>(m_action(META(first + k))) == a) { chosen = first + k; break; }
+          if (static_cast<int>(mw_action<kWide>(META(first + k))) == a) { chosen = first + k; break; }
       } else {  // arg-max of UCTValue, first maximum wins (mcts.cc:324-341, 90-101)
         double best = -INFINITY;
         const double logn = log_table[cnt];
@@ -126,7 +129,7 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
           }
         }
       }
-      G::apply(p, s, static_cast<int>(m_action(have_meta ? chosen_meta : META(chosen))));
+      G::apply(p, s, static_cast<int>(mw_action<kWide>(have_meta ? chosen_meta : META(chosen))));
       node = chosen;
     }
     // ---- evaluate (mcts.cc:372-381) ----
@@ -144,7 +147,7 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
         Rng rng(cfg.seed, gr, static_cast<uint64_t>(sim) * cfg.n_rollouts + ro);
         typename G::State w = s;
         for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
-          const Mask m = G::legal(p, w);
+          const LegalMask m = G::legal(p, w);
           G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
         }
         double rr[kMaxPlayers];
@@ -164,9 +167,9 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
       }
       TOTAL(v) += returns[(pl < 0 || pl >= num_players) ? 0 : pl];  // (a terminal root has no player)
       COUNT(v) += 1;
-      if (kBoard && solved && m_nchild(meta) > 0) {  // MCTS-Solver, max^n over proven children
+      if (kBoard && solved && mw_nchild<kWide>(meta) > 0) {  // MCTS-Solver, max^n over proven children
         const uint32_t first = FIRST(v);
-        const int c = m_nchild(meta);
+        const int c = mw_nchild<kWide>(meta);
         const int mover = m_player(META(first));
         bool all_solved = true, have = false;
         double best = 0.0;
@@ -188,7 +191,7 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
     }
     ++sims_done;
     const uint32_t rm = META(0);
-    if ((m_has_outcome(rm) && !m_terminal(rm)) || m_nchild(rm) == 1) break;  // mcts.cc:437-440
+    if ((m_has_outcome(rm) && !m_terminal(rm)) || mw_nchild<kWide>(rm) == 1) break;  // mcts.cc:437-440
     if (m_terminal(rm)) break;  // a terminal root: nothing to search
     // ---- GarbageCollect (mcts.cc:441-482): when nodes_ >= max_nodes_, every node with explore_count <
     // gc_limit_ loses its children.  Visit counts never grow from parent to child, so a node survives
@@ -209,8 +212,8 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
         uint32_t meta = META(i), first = FIRST(i);
         const uint32_t cnt = COUNT(i), par = PARENT(i);
         const double tot = TOTAL(i);
-        if (m_nchild(meta) > 0) {
-          if (cnt < limit) { meta &= ~(0xFFu << 12); first = 0; }   // children.clear(); the outcome stays
+        if (mw_nchild<kWide>(meta) > 0) {
+          if (cnt < limit) { meta = mw_clear_children<kWide>(meta); first = 0; }   // children.clear(); the outcome stays
           else first = REMAP(first);
         }
         META(to) = meta; FIRST(to) = first; COUNT(to) = cnt; TOTAL(to) = tot;
@@ -223,7 +226,7 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
 
   // ---- results: BestChild by CompareFinal (mcts.cc:114-143) + per-action statistics ----
   const uint32_t rm = META(0);
-  const int c = m_nchild(rm);
+  const int c = mw_nchild<kWide>(rm);
   const uint32_t first = FIRST(0);
   if (child_visits) for (int a = 0; a < num_actions; ++a) child_visits[r * num_actions + a] = 0;
   if (child_reward) for (int a = 0; a < num_actions; ++a) child_reward[r * num_actions + a] = 0.0;
@@ -235,7 +238,7 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
     const uint32_t cm = META(first + k);
     const uint32_t cc = COUNT(first + k);
     const double ct = TOTAL(first + k);
-    const int a = static_cast<int>(m_action(cm));
+    const int a = static_cast<int>(mw_action<kWide>(cm));
     const bool has = m_has_outcome(cm);
     const int pl = m_player(cm);
     const double out = (has && pl >= 0 && cc > 0) ? outcome_value<kBoard>(cm, cc, ct, pl)
@@ -281,15 +284,21 @@ extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_i
   const bool board = d.game_kind <= kHex;
   if (cfg.max_simulations < 1 || cfg.n_rollouts < 1) return set_error(OSG_ERR_INVALID, "max_simulations and n_rollouts must be >= 1");
   if (int rc = refuse_endless_playouts(roots->spec, "osg_mcts_search")) return rc;
-  if (roots->spec.desc.num_distinct_actions > 32 * kMaskWords)
-    return set_error(OSG_ERR_UNSUPPORTED, "osg_mcts_search: the search kernels hold up to 128 actions per node; hex boards above "
-                                          "11 x 11 are served by the batch entry points (states, steps, tensors, rollouts)");
+  if (roots->spec.desc.num_distinct_actions > kMaxSearchActions)
+    return set_error(OSG_ERR_UNSUPPORTED, "osg_mcts_search: a node holds up to 511 actions");
+  // the games beyond the 4-word mask / the two-word records (hex above 11 x 11, connect_four above 64 board bits,
+  // leduc_poker with 4+ players) are searched by the lane-per-root kernel; the wave-per-root kernel keeps boards of
+  // up to 128 cells in scalar registers
+  const bool wide_game = roots->spec.desc.num_distinct_actions > 32 * kMaskWords || roots->spec.c4_wide || roots->spec.leduc_big;
   if (cfg.solve && !board)
     return set_error(OSG_ERR_UNSUPPORTED, "solve=true needs win/draw/loss outcomes (tic_tac_toe, connect_four, hex)");
   int layout = cfg.layout;
   if (layout == 0)  // auto: the wave layout where its parallel playout applies (hex without the swap rule)
-    layout = (d.game_kind == kHex && d.num_distinct_actions == d.obs_shape[1] * d.obs_shape[2]) ? 2 : 1;
+    layout = (!wide_game && d.game_kind == kHex && d.num_distinct_actions == d.obs_shape[1] * d.obs_shape[2]) ? 2 : 1;
   if (layout != 1 && layout != 2) return set_error(OSG_ERR_INVALID, "osg_mcts_cfg.layout must be 0, 1 or 2");
+  if (layout == 2 && wide_game)
+    return set_error(OSG_ERR_UNSUPPORTED, "osg_mcts_search: layout 2 (a wavefront per root) serves boards of up to 128 actions; "
+                                          "this game is searched with layout 1 (or 0 = automatic)");
   if (cfg.child_selection_policy != 0 && cfg.child_selection_policy != 1)
     return set_error(OSG_ERR_INVALID, "osg_mcts_cfg.child_selection_policy must be 0 (UCT) or 1 (PUCT)");
   const int64_t n = roots->n;
@@ -397,11 +406,11 @@ extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_i
   } else {
     const unsigned grid = static_cast<unsigned>((n + kBlockM - 1) / kBlockM);
     if (board) {
-      OSG_DISPATCH(roots->spec, k_mcts<G, true><<<dim3(grid), dim3(kBlockM), 0, ctx->stream>>>(
+      OSG_DISPATCH_WIDE(roots->spec, k_mcts<G, true><<<dim3(grid), dim3(kBlockM), 0, ctx->stream>>>(
                                     P, static_cast<const typename G::word_t*>(roots->d_words), n, d.num_players, A, cfg,
                                     d.max_utility, d_logs, pool, d_best, d_vis, d_rew, d_out, d_stats));
     } else {
-      OSG_DISPATCH(roots->spec, k_mcts<G, false><<<dim3(grid), dim3(kBlockM), 0, ctx->stream>>>(
+      OSG_DISPATCH_WIDE(roots->spec, k_mcts<G, false><<<dim3(grid), dim3(kBlockM), 0, ctx->stream>>>(
                                     P, static_cast<const typename G::word_t*>(roots->d_words), n, d.num_players, A, cfg,
                                     d.max_utility, d_logs, pool, d_best, d_vis, d_rew, d_out, d_stats));
     }

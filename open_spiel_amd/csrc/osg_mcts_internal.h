@@ -44,6 +44,24 @@ OSG_D uint32_t make_meta(int action, int player, int nchild) {
          (static_cast<uint32_t>(nchild) << 12);
 }
 
+// Games with more than 255 actions (hex above 15 x 15: the lane-per-root kernels serve boards up to 19 x 19) keep the
+// ninth bit of the action in bit 24 and the ninth bit of the child count in bit 25 of the same word; both are zero
+// for every other game, so a decoder that always reads them (the host's) is right for all.  The wave-per-root
+// kernel serves boards of up to 128 cells and keeps the narrow accessors above.
+template <bool kWide> OSG_HD uint32_t mw_action(uint32_t m) { return kWide ? ((m & 0xFFu) | ((m >> 16) & 0x100u)) : (m & 0xFFu); }
+template <bool kWide> OSG_HD int mw_nchild(uint32_t m) {
+  return static_cast<int>(kWide ? (((m >> 12) & 0xFFu) | ((m >> 17) & 0x100u)) : ((m >> 12) & 0xFFu));
+}
+template <bool kWide> OSG_HD uint32_t mw_make(int action, int player, int nchild) {
+  uint32_t m = static_cast<uint32_t>(action & 0xFF) | ((static_cast<uint32_t>(player + 1) & 15u) << 8) |
+               (static_cast<uint32_t>(nchild & 0xFF) << 12);
+  if (kWide) m |= (static_cast<uint32_t>(action & 0x100) << 16) | (static_cast<uint32_t>(nchild & 0x100) << 17);
+  return m;
+}
+template <bool kWide> OSG_HD uint32_t mw_clear_children(uint32_t m) { return m & ~((0xFFu << 12) | (kWide ? (1u << 25) : 0u)); }
+constexpr uint32_t kMetaOutcomeBits = 0x00F00000u;   // has_outcome | code | terminal: what an expansion keeps
+constexpr int kMaxSearchActions = 511;               // nine bits
+
 // outcome[player] of a node that has one (mcts.cc:90-93): exact for the board
 // games (code), total/N for terminal nodes of the poker games.
 template <bool kBoard>

@@ -177,7 +177,7 @@ OSG_D void coop_playouts(const typename G::Params& p, const osg_mcts_cfg& cfg, i
       Rng rng(cfg.seed, gr, sim * cfg.n_rollouts + ro);
       typename G::State w = s;
       for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
-        const Mask m = G::legal(p, w);
+        const MaskT<G::kMaskW> m = G::legal(p, w);
         G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
       }
       double rr[kMaxPlayers];
@@ -200,6 +200,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
                const double* __restrict__ log_table, StepPool pool, const double* __restrict__ prior_in,
                const double* __restrict__ value_in, uint8_t* __restrict__ request, int max_new_simulations,
                int lane_stride) {
+  constexpr bool kWide = G::kMaskW > kMaskWords;   // nine-bit action / child-count fields (osg_mcts_internal.h)
   // lane_stride > 1: only every lane_stride-th lane of a wavefront carries a search.  A search is a chain of
   // dependent, scattered loads (its own tree); with one search per lane 2^16 roots are 1 024 wavefronts — one per
   // SIMD, nothing to hide that latency behind.  Spreading the same searches over lane_stride times as many
@@ -266,7 +267,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
     request[r] = req;
   };
   // expand `node` (mcts.cc:281-299): one child per prior entry, shuffled
-  auto expand = [&](const Mask& legal, int cur, bool from_host, const double* stashed) -> bool {
+  auto expand = [&](const MaskT<G::kMaskW>& legal, int cur, bool from_host, const double* stashed) -> bool {
     const int c = legal.count();
     if (c == 0 || used + static_cast<uint32_t>(c) > static_cast<uint32_t>(pool.cap)) return false;  // nothing to expand / slots exhausted (see osg_mcts.hip)
     const uint32_t first = used;
@@ -290,7 +291,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
         else if (from_host) pr = prior_in[r * num_actions + a];
         else pr = 1.0 / c;
         const uint32_t at = first + static_cast<uint32_t>(L);
-        node_store<kCoop>(lt.meta, pool.meta, at, NR, r, make_meta(a, cur, 0));
+        node_store<kCoop>(lt.meta, pool.meta, at, NR, r, mw_make<kWide>(a, cur, 0));
         node_store<kCoop>(lt.first, pool.first, at, NR, r, 0u);
         node_store<kCoop>(lt.parent, pool.parent, at, NR, r, node);
         node_store<kCoop>(lt.count, pool.count, at, NR, r, 0u);
@@ -298,7 +299,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
         PRIOR(at) = pr;
       }
       const uint32_t meta = META(node);
-      META(node) = make_meta(m_action(meta), m_player(meta), c) | (meta & 0x00F00000u);
+      META(node) = mw_make<kWide>(static_cast<int>(mw_action<kWide>(meta)), m_player(meta), c) | (meta & kMetaOutcomeBits);
       FIRST(node) = first;
       return true;
     }
@@ -309,7 +310,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
       else if (stashed) pr = stashed[a];                            // the prior that came with the node's evaluation
       else if (from_host) pr = prior_in[r * num_actions + a];
       else pr = 1.0 / c;                                            // RandomRolloutEvaluator::Prior (mcts.cc:74-87)
-      META(first + k) = make_meta(a, cur, 0);
+      META(first + k) = mw_make<kWide>(a, cur, 0);
       FIRST(first + k) = 0; PARENT(first + k) = node; COUNT(first + k) = 0; TOTAL(first + k) = 0.0; PRIOR(first + k) = pr;
     }
     for (int i = c - 1; i >= 1; --i) {  // the shuffle (mcts.cc:294), Fisher-Yates on the tree-policy stream
@@ -320,7 +321,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
       PRIOR(first + i) = pj; PRIOR(first + j) = pi;
     }
     const uint32_t meta = META(node);
-    META(node) = make_meta(m_action(meta), m_player(meta), c) | (meta & 0x00F00000u);
+    META(node) = mw_make<kWide>(static_cast<int>(mw_action<kWide>(meta)), m_player(meta), c) | (meta & kMetaOutcomeBits);
     FIRST(node) = first;
     return true;
   };
@@ -374,8 +375,8 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
         if (!resume_expand && !((!term && cnt > 0) || (!term && cur == kChancePlayer && through_chance))) break;
         uint32_t meta = carried ? n_meta : META(node);
         bool expanded_now = false;
-        if (m_nchild(meta) == 0) {
-          const Mask legal = G::legal(p, s);
+        if (mw_nchild<kWide>(meta) == 0) {
+          const MaskT<G::kMaskW> legal = G::legal(p, s);
           const uint32_t slot1 = (stashing && cur != kChancePlayer && !resume_expand) ? (carried ? n_first : FIRST(node)) : 0u;
           const double* stashed =
               slot1 ? pool.stash + (static_cast<size_t>(r) * pool.stash_slots + (slot1 - 1u)) * num_actions : nullptr;
@@ -392,14 +393,14 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
         }
         resume_expand = false;
         const uint32_t first = (carried && !expanded_now) ? n_first : FIRST(node);
-        const int c = m_nchild(meta);
+        const int c = mw_nchild<kWide>(meta);
         uint32_t chosen = first, chosen_meta = 0, chosen_cnt = 0, chosen_first = 0;
         bool have_chosen_meta = false;
         if (cur == kChancePlayer) {  // mcts.cc:311-322
-          const Mask legal = G::legal(p, s);
+          const MaskT<G::kMaskW> legal = G::legal(p, s);
           const int a = sample_action_chance<G>(p, s, legal, trng);
           for (int k = 0; k < c; ++k)
-            if (static_cast<int>(m_action(META(first + k))) == a) { chosen = first + k; break; }
+            if (static_cast<int>(mw_action<kWide>(META(first + k))) == a) { chosen = first + k; break; }
         } else {  // arg-max of UCTValue / PUCTValue, first maximum wins (mcts.cc:324-341, 90-112)
           double best = -INFINITY;
           const double logn = log_table[cnt];
@@ -468,7 +469,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
             }
           }
         }
-        G::apply(p, s, static_cast<int>(m_action(have_chosen_meta ? chosen_meta : META(chosen))));
+        G::apply(p, s, static_cast<int>(mw_action<kWide>(have_chosen_meta ? chosen_meta : META(chosen))));
         node = chosen;
         carried = have_chosen_meta;
         if (have_chosen_meta) { n_cnt = chosen_cnt; n_meta = chosen_meta; n_first = chosen_first; }
@@ -496,7 +497,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
             Rng rng(cfg.seed, gr, static_cast<uint64_t>(sims_done) * cfg.n_rollouts + ro);
             typename G::State w = s;
             for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
-              const Mask m = G::legal(p, w);
+              const MaskT<G::kMaskW> m = G::legal(p, w);
               G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
             }
             double rr[kMaxPlayers];
@@ -513,7 +514,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
           Rng rng(cfg.seed, gr, static_cast<uint64_t>(sims_done) * cfg.n_rollouts + ro);
           typename G::State w = s;
           for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
-            const Mask m = G::legal(p, w);
+            const MaskT<G::kMaskW> m = G::legal(p, w);
             G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
           }
           double rr[kMaxPlayers];
@@ -539,9 +540,9 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
       }
       TOTAL(v) += returns[(pl < 0 || pl >= num_players) ? 0 : pl];  // (a terminal root has no player)
       COUNT(v) += 1;
-      if (kBoard && solved && m_nchild(meta) > 0) {
+      if (kBoard && solved && mw_nchild<kWide>(meta) > 0) {
         const uint32_t first = FIRST(v);
-        const int c = m_nchild(meta);
+        const int c = mw_nchild<kWide>(meta);
         const int mover = m_player(META(first));
         bool all_solved = true, have = false;
         double best = 0.0;
@@ -566,7 +567,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
     phase = kNewSimulation;
     OSG_PROF(3);
     const uint32_t rm = META(0);
-    if ((m_has_outcome(rm) && !m_terminal(rm)) || m_nchild(rm) == 1 || m_terminal(rm)) {  // mcts.cc:437-440
+    if ((m_has_outcome(rm) && !m_terminal(rm)) || mw_nchild<kWide>(rm) == 1 || m_terminal(rm)) {  // mcts.cc:437-440
       park(kFinished, 0);
       return;
     }
@@ -585,8 +586,8 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
         uint32_t meta = META(i), first = FIRST(i);
         const uint32_t cnt = COUNT(i), par = PARENT(i);
         const double tot = TOTAL(i), pri = PRIOR(i);
-        if (m_nchild(meta) > 0) {
-          if (cnt < limit) { meta &= ~(0xFFu << 12); first = 0; }
+        if (mw_nchild<kWide>(meta) > 0) {
+          if (cnt < limit) { meta = mw_clear_children<kWide>(meta); first = 0; }
           else first = REMAP(first);
         }
         META(to) = meta; FIRST(to) = first; COUNT(to) = cnt; TOTAL(to) = tot; PRIOR(to) = pri;
@@ -624,7 +625,7 @@ k_mcts_tree_rollout(typename G::Params p, const typename G::word_t* leaf_words, 
     Rng rng(cfg.seed, gr, static_cast<uint64_t>(sims[r]) * cfg.n_rollouts + ro);
     typename G::State w = s;
     for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
-      const Mask m = G::legal(p, w);
+      const MaskT<G::kMaskW> m = G::legal(p, w);
       G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
     }
     double rr[kMaxPlayers];
@@ -649,7 +650,7 @@ k_mcts_tree_results(StepPool pool, int64_t n, int num_actions, int32_t* best_act
 #define PRIOR(i) pool.prior[static_cast<int64_t>(i) * NR + r]
   const uint32_t rm = META(0);
   const int root_player = m_terminal(rm) ? -1 : m_player(rm);  // a terminal root has no player to move
-  const int c = m_nchild(rm);
+  const int c = mw_nchild<true>(rm);
   const uint32_t first = FIRST(0);
   for (int a = 0; a < num_actions; ++a) {
     if (child_visits) child_visits[r * num_actions + a] = 0;
@@ -664,7 +665,7 @@ k_mcts_tree_results(StepPool pool, int64_t n, int num_actions, int32_t* best_act
     const uint32_t cm = META(first + k);
     const uint32_t cc = COUNT(first + k);
     const double ct = TOTAL(first + k);
-    const int a = static_cast<int>(m_action(cm));
+    const int a = static_cast<int>(mw_action<true>(cm));
     const bool has = m_has_outcome(cm);
     const int pl = m_player(cm);
     const double out = (has && pl >= 0 && cc > 0) ? outcome_value<kBoard>(cm, cc, ct, pl)
@@ -783,9 +784,8 @@ int osg_mcts_tree_create(const osg_batch* roots, const osg_mcts_cfg* cfg_in, int
   if ((flags & 8) && !(flags & 1)) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_create: flag 8 (priors arrive with the values) needs flag 1");
   if ((flags & 8) && (flags & 4)) return set_error(OSG_ERR_INVALID, "osg_mcts_tree_create: flags 4 and 8 exclude each other");
   if (int rc = refuse_endless_playouts(roots->spec, "osg_mcts_tree_create")) return rc;
-  if (d.num_distinct_actions > 32 * kMaskWords)
-    return set_error(OSG_ERR_UNSUPPORTED, "osg_mcts_tree_create: the search kernels hold up to 128 actions per node; hex boards "
-                                          "above 11 x 11 are served by the batch entry points (states, steps, tensors, rollouts)");
+  if (d.num_distinct_actions > kMaxSearchActions)
+    return set_error(OSG_ERR_UNSUPPORTED, "osg_mcts_tree_create: a node holds up to 511 actions");
   osg_mcts_tree* t = new osg_mcts_tree;
   t->ctx = ctx;
   t->cfg = *cfg_in;
@@ -898,31 +898,31 @@ int osg_mcts_tree_advance(osg_mcts_tree* t, osg_batch* leaf, const double* d_pri
   static const bool coop_on = !(std::getenv("OSG_MCTS_COOP") && std::atoi(std::getenv("OSG_MCTS_COOP")) == 0);
   if (t->n == 1 && (t->flags & 4) && t->cfg.n_rollouts > 1 && coop_on) {
     // (the LDS part of the tree is 128 KiB of dynamic shared memory: above the default limit, asked for once per kernel)
-    if (t->board) OSG_DISPATCH(t->roots->spec, OSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mcts_advance<G, true, true>),
+    if (t->board) OSG_DISPATCH_WIDE(t->roots->spec, OSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mcts_advance<G, true, true>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsTreeBytes))));
-    else OSG_DISPATCH(t->roots->spec, OSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mcts_advance<G, false, true>),
+    else OSG_DISPATCH_WIDE(t->roots->spec, OSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mcts_advance<G, false, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsTreeBytes))));
     if (t->board) {
-      OSG_DISPATCH(t->roots->spec, k_mcts_advance<G, true, true><<<dim3(1), dim3(2 * kBlockM), kLdsTreeBytes, st>>>(
+      OSG_DISPATCH_WIDE(t->roots->spec, k_mcts_advance<G, true, true><<<dim3(1), dim3(2 * kBlockM), kLdsTreeBytes, st>>>(
                                        P, static_cast<const typename G::word_t*>(t->roots->d_words),
                                        static_cast<typename G::word_t*>(leaf->d_words), t->n, d.num_players, t->A, t->cfg,
                                        t->flags, t->max_utility, t->d_logs, pool, d_prior, d_value, d_request,
                                        max_new_simulations, 1));
     } else {
-      OSG_DISPATCH(t->roots->spec, k_mcts_advance<G, false, true><<<dim3(1), dim3(2 * kBlockM), kLdsTreeBytes, st>>>(
+      OSG_DISPATCH_WIDE(t->roots->spec, k_mcts_advance<G, false, true><<<dim3(1), dim3(2 * kBlockM), kLdsTreeBytes, st>>>(
                                        P, static_cast<const typename G::word_t*>(t->roots->d_words),
                                        static_cast<typename G::word_t*>(leaf->d_words), t->n, d.num_players, t->A, t->cfg,
                                        t->flags, t->max_utility, t->d_logs, pool, d_prior, d_value, d_request,
                                        max_new_simulations, 1));
     }
   } else if (t->board) {
-    OSG_DISPATCH(t->roots->spec, k_mcts_advance<G, true><<<dim3(grid), dim3(kBlockM), 0, st>>>(
+    OSG_DISPATCH_WIDE(t->roots->spec, k_mcts_advance<G, true><<<dim3(grid), dim3(kBlockM), 0, st>>>(
                                      P, static_cast<const typename G::word_t*>(t->roots->d_words),
                                      static_cast<typename G::word_t*>(leaf->d_words), t->n, d.num_players, t->A, t->cfg,
                                      t->flags, t->max_utility, t->d_logs, pool, d_prior, d_value, d_request,
                                      max_new_simulations, lane_stride));
   } else {
-    OSG_DISPATCH(t->roots->spec, k_mcts_advance<G, false><<<dim3(grid), dim3(kBlockM), 0, st>>>(
+    OSG_DISPATCH_WIDE(t->roots->spec, k_mcts_advance<G, false><<<dim3(grid), dim3(kBlockM), 0, st>>>(
                                      P, static_cast<const typename G::word_t*>(t->roots->d_words),
                                      static_cast<typename G::word_t*>(leaf->d_words), t->n, d.num_players, t->A, t->cfg,
                                      t->flags, t->max_utility, t->d_logs, pool, d_prior, d_value, d_request,
@@ -984,7 +984,7 @@ int osg_mcts_tree_rollout_values(osg_mcts_tree* t, const osg_batch* leaf, double
   const int lane_stride = lane_stride_for(t->ctx, t->n);
   const unsigned grid = static_cast<unsigned>((t->n * lane_stride + kBlockM - 1) / kBlockM);
   const StepPool pool = make_pool(t);
-  OSG_DISPATCH(t->roots->spec, k_mcts_tree_rollout<G><<<dim3(grid), dim3(kBlockM), 0, t->ctx->stream>>>(
+  OSG_DISPATCH_WIDE(t->roots->spec, k_mcts_tree_rollout<G><<<dim3(grid), dim3(kBlockM), 0, t->ctx->stream>>>(
                                    P, static_cast<const typename G::word_t*>(leaf->d_words), t->n, t->P, t->cfg, pool.phase,
                                    pool.sims, d_value, lane_stride));
   OSG_HIP(hipGetLastError());
@@ -1029,7 +1029,7 @@ int osg_mcts_tree_leaf_path(osg_mcts_tree* t, int64_t root, int32_t* h_actions, 
     OSG_HIP(hipMemcpyAsync(&meta, pool.meta + static_cast<int64_t>(node) * t->n + root, 4, hipMemcpyDeviceToHost, st));
     OSG_HIP(hipMemcpyAsync(&parent, pool.parent + static_cast<int64_t>(node) * t->n + root, 4, hipMemcpyDeviceToHost, st));
     OSG_HIP(hipStreamSynchronize(st));
-    rev.push_back(static_cast<int32_t>(meta & 0xFFu));
+    rev.push_back(static_cast<int32_t>(mw_action<true>(meta)));
     node = parent;
   }
   const int len = static_cast<int>(rev.size());

@@ -109,6 +109,53 @@ def test_mcts_replay_parity(oracle, ctx, game, n, sims, n_rollouts, solve, max_s
     assert checked >= n // 3
 
 
+@pytest.mark.parametrize("game,n,sims,n_rollouts,solve,max_stop", [
+    ("hex(board_size=13)", 12, 120, 1, False, 60),            # 169 actions: six-word planes and masks
+    ("hex(board_size=13)", 8, 150, 1, True, 160),             # late positions: the solver proves wins
+    ("hex(board_size=15)", 6, 80, 1, False, 100),             # 225 actions: the widest that fits eight bits
+    ("hex(board_size=19)", 6, 60, 1, False, 120),             # 361 actions: the nine-bit action / child-count fields
+    ("hex(num_cols=17,num_rows=19,swap=True)", 6, 60, 1, False, 3),   # the swap action (id 323) as a child
+    ("connect_four(rows=9,columns=12)", 16, 100, 2, True, 40),        # 120 board bits: two plane words per colour
+    ("leduc_poker(players=4)", 24, 100, 1, False, 10),        # the five-word record
+    ("leduc_poker(players=6)", 16, 80, 2, False, 14),
+])
+def test_mcts_replay_parity_on_the_wide_games(oracle, ctx, game, n, sims, n_rollouts, solve, max_stop):
+    """The games beyond the four-word mask / the two-word records are searched by the lane-per-root kernel (layout 1;
+    layout 2 refuses them): the same replay parity as above — visits, rewards, outcomes, best action, root by root."""
+    import open_spiel_amd as osa
+    players = int(game.split("players=")[1].rstrip(")")) if "players=" in game else 0
+    og, roots, hists = _roots(oracle, ctx, game, n, 23, max_stop, players)   # (poker: past the private deals)
+    with pytest.raises(osa.OsgError):
+        roots.mcts_search(uct_c=2.0, max_simulations=4, n_rollouts=1, seed=1, layout=2)
+    seed, offset = 0xFEED5EED, 777
+    res = roots.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=n_rollouts, solve=solve, seed=seed,
+                            index_offset=offset, layout=0)
+    best = res["best_action"].cpu().numpy()
+    visits = res["child_visits"].cpu().numpy()
+    reward = res["child_reward"].cpu().numpy()
+    outcome = res["child_outcome"].cpu().numpy()
+    stats = res["root_stats"].cpu().numpy()
+    checked = 0
+    for i in range(n):
+        st = _oracle_state(og, hists[i])
+        if st.is_chance_node():
+            continue
+        want = st.mcts_search(2.0, sims, n_rollouts, 4096, solve, 0, counter_root=offset + i, counter_seed=seed,
+                              counter_layout=1)
+        assert stats[i, 0] == want["root_visits"], f"{game} root {i}: root visits"
+        acts = want["children"][:, 0].astype(int)
+        assert sorted(acts.tolist()) == np.nonzero(outcome[i] != 3)[0].tolist(), f"{game} root {i}: children"
+        for a, cnt, tot, out in want["children"]:
+            a = int(a)
+            assert visits[i, a] == cnt and reward[i, a] == tot, f"{game} root {i} action {a}"
+            if solve and not np.isnan(out):
+                assert outcome[i, a] == out
+        if len(acts):
+            assert best[i] == want["best_action"], f"{game} root {i}: best action"
+        checked += 1
+    assert checked >= n // 3
+
+
 @pytest.mark.parametrize("layout", [1, 2])
 @pytest.mark.parametrize("game,n,sims,n_rollouts,solve,max_stop", [
     ("tic_tac_toe", 48, 150, 2, True, 5), ("connect_four", 32, 120, 1, False, 20),

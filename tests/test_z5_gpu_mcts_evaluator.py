@@ -48,12 +48,16 @@ def _roots(oracle, ctx, game, n, seed, max_stop, min_stop=0):
     ("leduc_poker", 48, 150, 1, False, False, 0, 8),
     ("leduc_poker", 32, 300, 1, False, True, 30, 7),
     ("kuhn_poker(players=3)", 48, 120, 1, False, False, 0, 6),
+    ("hex(board_size=13)", 8, 80, 1, False, False, 0, 60),                 # the wide games: osg_mcts_tree_* serves them too
+    ("hex(board_size=19)", 4, 40, 1, False, True, 0, 100),
+    ("connect_four(rows=9,columns=12)", 12, 100, 2, True, False, 0, 40),
+    ("leduc_poker(players=4)", 16, 100, 1, False, False, 0, 10),
 ])
 def test_rollout_evaluator_outside_the_kernel_equals_the_fused_search(oracle, ctx, game, n, sims, n_rollouts, solve, puct,
                                                                       max_nodes, max_stop):
     import torch
     from open_spiel_amd import mcts
-    min_stop = (3 if "players=3" in game else 2) if "poker" in game else 0
+    min_stop = (int(game.split("players=")[1].rstrip(")")) if "players=" in game else 2) if "poker" in game else 0
     _, roots, _ = _roots(oracle, ctx, game, n, 41, max_stop, min_stop)
     kw = dict(uct_c=1.7, max_simulations=sims, n_rollouts=n_rollouts, solve=solve, seed=0xC0DE, index_offset=321,
               max_nodes=max_nodes, puct=puct)

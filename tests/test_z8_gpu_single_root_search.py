@@ -43,6 +43,8 @@ CASES = [
     ("hex(board_size=5)", [12, 6], 200, 5, True),
     ("kuhn_poker", [0, 1], 150, 9, False),              # chance inside the playouts
     ("leduc_poker", [0, 3, 1], 150, 4, False),
+    ("hex(board_size=13)", [84, 70], 60, 3, False),     # 167 children per node: the sequential expansion, nine-bit fields unused
+    ("hex(board_size=19)", [180], 30, 2, False),        # 360 children: the nine-bit action / child-count fields
 ]
 
 

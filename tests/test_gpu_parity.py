@@ -275,8 +275,9 @@ def test_bad_game_strings(ctx):
 
 
 def test_hex_above_128_actions_where_the_boundary_stops(ctx):
-    """hex(13) ... hex(19) are served by the batch entry points (the parity tests above run them through every one);
-    the search kernels keep their 128-action node layout and the fused step its one-byte action ids: both say so."""
+    """hex(13) ... hex(19) are served by the batch entry points (the parity tests above run them through every one) and
+    by the lane-per-root search (tests/test_gpu_mcts.py); the wave-per-root search keeps boards of up to 128 cells, the
+    fused step its one-byte action ids and the solvers the games with a tree: each says so."""
     import torch
     import open_spiel_amd as osa
     b = osa.StateBatch(ctx, "hex(board_size=19)", 64)
@@ -284,7 +285,11 @@ def test_hex_above_128_actions_where_the_boundary_stops(ctx):
     b.random_steps(5, 30)
     assert int(b.legal_actions_mask().sum()) == 64 * (361 - 30)
     with pytest.raises(osa.OsgError, match="128 actions"):
-        b.mcts_search(max_simulations=8)
+        b.mcts_search(max_simulations=8, layout=2)
+    res = b.mcts_search(max_simulations=8)                     # layout 0 picks the lane-per-root search
+    assert bool((res["child_visits"].sum(1) == 7).all())
+    with pytest.raises(osa.OsgError):
+        osa.TabularSolver(ctx, "leduc_poker(players=4)")
     with pytest.raises(osa.OsgError, match="one byte"):
         b.step(torch.zeros(64, dtype=torch.uint8, device="cuda"))
     small = osa.StateBatch(ctx, "hex(board_size=15)", 64)      # 225 actions: the fused step serves it

@@ -120,6 +120,7 @@ class JointStubEvaluator(StubEvaluator):
     ("connect_four", 32, 400, True, False, 60, False, 16),          # node budget
     ("hex(board_size=5)", 32, 300, True, False, 0, False, 14),
     ("hex(board_size=9)", 8, 200, True, False, 0, False, 30),
+    ("hex(board_size=13)", 6, 60, True, False, 0, False, 60),        # 169 actions: the six-word masks in the tree kernels
     ("kuhn_poker", 48, 150, True, False, 0, False, 3),
     ("leduc_poker", 48, 250, True, False, 0, False, 7),
     ("leduc_poker", 48, 250, False, False, 0, True, 7),             # dont_return_chance_node

@@ -1763,13 +1763,16 @@ template <int kA>
 __global__ void __launch_bounds__(1024)
 k_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict__ nact,
                  const double* __restrict__ regrets, double* g_dreg, double* g_dpol, uint64_t seed, int64_t first,
-                 int64_t count) {
+                 int64_t count, unsigned long long* stamps = nullptr) {
   extern __shared__ double smem[];
   const int IA = I * kA;
   double *dreg, *dpol, *pol, *uret, *uprob;
   uint2* nodes;
+  const bool stamp = stamps && blockIdx.x == 0 && threadIdx.x == 0;   // OSG_MCCFR_STAMPS: where a launch's time goes
+  if (stamp) stamps[0] = wall_clock64();
   resident_load<kA>(smem, H, I, P, rt, nact, regrets, &dreg, &dpol, &pol, &uret, &uprob, &nodes);
   __syncthreads();
+  if (stamp) stamps[1] = wall_clock64();
 
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t j0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j0 < count; j0 += stride) {
@@ -1891,7 +1894,9 @@ k_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict
       if (done) break;
     }
   }
+  if (stamp) stamps[2] = wall_clock64();   // (lane 0's own trajectory; the flush below waits for the workgroup's last)
   resident_flush(dreg, dpol, g_dreg, g_dpol, IA);
+  if (stamp) { stamps[3] = wall_clock64(); }
 }
 
 // ---------------------------------------------------------------------------
@@ -3402,6 +3407,9 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
     }
     int64_t groups = std::min<int64_t>((trajectories + threads - 1) / threads, static_cast<int64_t>(s->num_cus) * per_cu);
     ResidentTree rt{reinterpret_cast<const uint2*>(s->d_rec), s->d_uret, s->d_uprob, s->n_uret, s->n_uprob};
+    static unsigned long long* d_stamps = nullptr;   // OSG_MCCFR_STAMPS=1: phase stamps of workgroup 0 (tools/probe_mccfr_shard.py)
+    if (std::getenv("OSG_MCCFR_STAMPS") && !d_stamps)
+      OSG_HIP(hipMalloc(reinterpret_cast<void**>(&d_stamps), sizeof(unsigned long long) * 4));
     const dim3 grid(static_cast<unsigned>(groups)), block(threads);
     const size_t shmem = s->resident_lds_bytes;
 #define OSG_MCCFR_RES(KA)                                                                                          \
@@ -3412,7 +3420,7 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
                                                           s->cfg.epsilon);                                        \
     else                                                                                                           \
       k_mccfr_resident<KA><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), dreg,  \
-                                                       dpol, seed, first_trajectory, trajectories);          \
+                                                       dpol, seed, first_trajectory, trajectories, d_stamps); \
   } while (0)
     switch (s->A) {
       case 1: OSG_MCCFR_RES(1); break;
@@ -3422,6 +3430,14 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
     }
 #undef OSG_MCCFR_RES
     OSG_HIP(hipGetLastError());
+    if (d_stamps && s->cfg.solver != 2) {
+      unsigned long long h[4];
+      OSG_HIP(hipMemcpyAsync(h, d_stamps, sizeof h, hipMemcpyDeviceToHost, st));
+      OSG_HIP(hipStreamSynchronize(st));
+      fprintf(stderr, "k_mccfr_resident (%lld trajectories, %u x %d lanes; workgroup 0, us): staging %.2f  lane 0's trajectory %.2f  "
+                      "rest of the workgroup + flush %.2f\n", static_cast<long long>(trajectories), grid.x, threads,
+              (h[1] - h[0]) / 100.0, (h[2] - h[1]) / 100.0, (h[3] - h[2]) / 100.0);
+    }
     return OSG_OK;
   }
   if (s->cfg.solver == 2) {  // OutcomeSamplingMCCFRSolver

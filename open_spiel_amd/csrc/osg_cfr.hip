@@ -1548,8 +1548,12 @@ k_eval_jobs(Tree t, EvalArrays ea, EvalJobs ej, const double* __restrict__ src, 
 // ---------------------------------------------------------------------------
 OSG_D void add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }  // hardware fp64 atomic (LDS and L2)
 
+// Streams of trajectory g: (seed, g, 0) in visiting order down to the FIRST node at which the traverser acts, then
+// (seed, g, 1 + b) inside that node's child b — the subtrees below the traverser's first node are independent but for
+// the order of the draws, and with a stream each they can be walked by different lanes (k_mccfr_resident<., true>);
+// the oracle's replay follows the same rule (osgo_mccfr_minibatch).
 // kExtU: the uniforms come from a caller-supplied sequence (ext_u[0], ext_u[1], ... in visiting order) instead
-// of the counter stream: with the sequence the reference's std::mt19937 + uniform_real_distribution would
+// of the counter streams: with the sequence the reference's std::mt19937 + uniform_real_distribution would
 // produce, one trajectory IS one UpdateRegrets call of the reference, draw for draw
 // (ExternalSamplingMCCFRSolver::RunIteration(std::mt19937*), external_sampling_mccfr.h:63-100).
 template <bool kLdsDelta, bool kExtU = false>
@@ -1622,6 +1626,7 @@ k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dp
         f_value[sp] = 0.0;
         ++sp;
         node = fc;
+        if (!kExtU && sp == 1) rng = Rng(seed, static_cast<uint64_t>(g), 1);   // child 0 of the traverser's FIRST node: its own stream
       }
       // ---- ascend: hand `ret` to the innermost open frame ----
       bool done = false;
@@ -1638,6 +1643,7 @@ k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dp
         if (a + 1 < nc) {
           f_a[sp - 1] = a + 1;
           node = t.first_child[fn] + a + 1;
+          if (!kExtU && sp == 1) rng = Rng(seed, static_cast<uint64_t>(g), 2 + static_cast<uint64_t>(a));   // child a + 1: stream 1 + (a + 1)
           break;
         }
         const double v = f_value[sp - 1];
@@ -1759,7 +1765,135 @@ OSG_D void resident_flush(const double* dreg, const double* dpol, double* g_dreg
   }
 }
 
+// What a lane needs of the staged problem.
 template <int kA>
+struct EsView {
+  const uint2* nodes;
+  const double *pol, *uret, *uprob;
+  double *dreg, *dpol;
+  int P, trav, next;
+};
+// One step at a node where the traverser does not act: the sampled child (chance: SampleAction(ChanceOutcomes(), z),
+// spiel.cc:372-409; opponent: SampleActionIndex(0.0, z) on the regret-matched row, cfr.cc:617-628), with the kSimple
+// average-policy update at player + 1's nodes (external_sampling_mccfr.cc:177-183) when `averaging`.
+template <int kA>
+OSG_D int es_sampled_child(const EsView<kA>& c, uint2 rec, Rng& rng, bool averaging) {
+  const int kind = rec.x & 3u, nc = (rec.x >> 2) & 63u, fc = rec.y & 0xFFFFFFu;
+  const int i = rec.x >> 12;
+  const int actor = static_cast<int>((rec.x >> 8) & 15u) - 1;  // -1 at chance nodes
+  const double z = rng.unit();
+  int pick = nc - 1;
+  if (kind == kChanceNode) {
+    double acc = 0.0;
+    bool found = false;
+    if (i != 0) {  // all outcomes equally likely: the same scan, the probability read once
+      const double pr = c.uprob[i - 1];
+      for (int k = 0; k < nc; ++k) {
+        if (!found && acc <= z && z < acc + pr) { pick = k; found = true; }
+        acc += pr;
+      }
+    } else {
+      for (int k = 0; k < nc; ++k) {
+        const double pr = c.uprob[c.nodes[fc + k].y >> 24];
+        if (!found && acc <= z && z < acc + pr) { pick = k; found = true; }
+        acc += pr;
+      }
+    }
+  } else {  // opponent: sample one action from regret matching (:151-154)
+    double p[kA];
+#pragma unroll
+    for (int a = 0; a < kA; ++a) p[a] = c.pol[i * kA + a];
+    double acc = 0.0;
+    bool found = false;
+#pragma unroll
+    for (int a = 0; a < kA; ++a) {
+      if (!found && a < nc && z >= acc && z < acc + p[a]) { pick = a; found = true; }
+      acc += p[a];
+    }
+    if (averaging && actor == c.next) {
+#pragma unroll
+      for (int a = 0; a < kA; ++a)
+        if (a < nc) add_f64(&c.dpol[i * kA + a], p[a]);
+    }
+  }
+  return fc + pick;
+}
+// UpdateRegrets from `node` down (external_sampling_mccfr.cc:122-186): the value of `node` for the traverser, the
+// regret and average-policy terms of everything below added to the LDS delta tables.  The frame on top of the
+// traverser's stack lives in registers, deeper frames in a per-lane backing store touched on push / pop only.
+// kFirst: `node` is the trajectory's root — the children of the FIRST traverser node each draw from their own stream
+// (seed, g, 1 + b); otherwise one stream in visiting order.
+template <int kA, bool kFirst>
+OSG_D double es_walk(const EsView<kA>& c, int node, Rng& rng, uint64_t seed, uint64_t g) {
+  uint32_t s_x[kMaxFrames], s_fa[kMaxFrames];
+  double s_v[kMaxFrames], s_cv[kMaxFrames][kA];
+  uint32_t top_x = 0, top_fc = 0;
+  int top_a = 0;
+  double top_v = 0.0, top_cv[kA];
+#pragma unroll
+  for (int b = 0; b < kA; ++b) top_cv[b] = 0.0;
+  int sp = 0;
+  for (;;) {
+    const uint2 rec = c.nodes[node];
+    const int kind = rec.x & 3u;
+    if (kind != kTerminalNode) {
+      const int actor = static_cast<int>((rec.x >> 8) & 15u) - 1;
+      if (actor != c.trav) {
+        node = es_sampled_child<kA>(c, rec, rng, true);
+        continue;
+      }
+      // traverser: walk every action (:155-162)
+      if (sp > 0) {
+        s_x[sp - 1] = top_x;
+        s_fa[sp - 1] = top_fc | (static_cast<uint32_t>(top_a) << 24);
+        s_v[sp - 1] = top_v;
+#pragma unroll
+        for (int b = 0; b < kA; ++b) s_cv[sp - 1][b] = top_cv[b];
+      }
+      top_x = rec.x; top_fc = rec.y & 0xFFFFFFu; top_a = 0; top_v = 0.0;
+      ++sp;
+      node = static_cast<int>(top_fc);
+      if (kFirst && sp == 1) rng = Rng(seed, g, 1);
+      continue;
+    }
+    double ret = c.uret[(rec.y & 0xFFFFFFu) * c.P + c.trav];
+    for (;;) {  // hand `ret` to the innermost open frame
+      if (sp == 0) return ret;
+      const int i = top_x >> 12, nc = (top_x >> 2) & 63u;
+      const double pa = c.pol[i * kA + top_a];
+#pragma unroll
+      for (int b = 0; b < kA; ++b)
+        if (b == top_a) top_cv[b] = ret;
+      top_v += pa * ret;
+      if (top_a + 1 < nc) {
+        ++top_a;
+        node = static_cast<int>(top_fc) + top_a;
+        if (kFirst && sp == 1) rng = Rng(seed, g, 1 + static_cast<uint64_t>(top_a));
+        break;
+      }
+#pragma unroll
+      for (int b = 0; b < kA; ++b)
+        if (b < nc) add_f64(&c.dreg[i * kA + b], top_cv[b] - top_v);  // (:167-172)
+      ret = top_v;
+      --sp;
+      if (sp > 0) {
+        top_x = s_x[sp - 1];
+        top_fc = s_fa[sp - 1] & 0xFFFFFFu;
+        top_a = s_fa[sp - 1] >> 24;
+        top_v = s_v[sp - 1];
+#pragma unroll
+        for (int b = 0; b < kA; ++b) top_cv[b] = s_cv[sp - 1][b];
+      }
+    }
+  }
+}
+
+// kSplit: kQ = 2 (kA <= 2) or 4 lanes per trajectory.  A traversal is one dependent chain (leduc: ~100 node visits,
+// 42-45 us on one lane whatever the batch — profiles/r04_mccfr_shard.log): all kQ lanes walk the sampled path down
+// to the traverser's first node (the same draws: the same path; lane 0 of the group does the averaging), lane b then
+// walks child b on its stream, the values come back by lane shuffles and the node's own terms are added in action
+// order — the sums of the one-lane form.  For mini-batches that leave lanes idle anyway (<= one round of the chip).
+template <int kA, bool kSplit = false>
 __global__ void __launch_bounds__(1024)
 k_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict__ nact,
                  const double* __restrict__ regrets, double* g_dreg, double* g_dpol, uint64_t seed, int64_t first,
@@ -1773,128 +1907,71 @@ k_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict
   resident_load<kA>(smem, H, I, P, rt, nact, regrets, &dreg, &dpol, &pol, &uret, &uprob, &nodes);
   __syncthreads();
   if (stamp) stamps[1] = wall_clock64();
+  constexpr int kQ = kSplit ? (kA <= 2 ? 2 : 4) : 1;           // lanes per trajectory
+  constexpr int kPerWave = 64 / kQ;                             // trajectories per wavefront
 
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t j0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j0 < count; j0 += stride) {
-    // Which trajectory a lane takes: within every full group of 64 P consecutive ones, wavefront w of the group takes
-    // those with the same traverser (index = lane * P + w), so that the 64 lanes of a wavefront agree at every node
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x / kQ;
+  const int64_t lane_slot = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) / kQ;
+  const int branch = static_cast<int>(threadIdx.x) & (kQ - 1);
+  const int64_t rounds = (count + stride - 1) / stride;        // (every lane runs every round: the shuffles below need the whole wavefront)
+  for (int64_t rd = 0; rd < rounds; ++rd) {
+    const int64_t j0 = lane_slot + rd * stride;
+    const bool live = j0 < count;
+    // Which trajectory a lane takes: within every full group of kPerWave P consecutive ones, wavefront w of the group
+    // takes those with the same traverser (index = slot * P + w), so that the lanes of a wavefront agree at every node
     // on whether they walk all actions or sample one — half the divergence of the natural order, same set of
     // trajectories.  (The last, partial group keeps the natural order.)
-    int64_t j = j0;
+    int64_t j = live ? j0 : 0;
     {
-      const int64_t span = 64 * static_cast<int64_t>(P), group = j0 / span;
+      const int64_t span = kPerWave * static_cast<int64_t>(P), group = j / span;
       if ((group + 1) * span <= count) {
-        const int r = static_cast<int>(j0 - group * span);
-        j = group * span + static_cast<int64_t>(r & 63) * P + (r >> 6);
+        const int r = static_cast<int>(j - group * span);
+        j = group * span + static_cast<int64_t>(r % kPerWave) * P + (r / kPerWave);
       }
     }
     const int64_t g = first + j;
     // (a 64-bit modulo by a run-time divisor is ~100 instructions: two players take the parity)
     const int trav = P == 2 ? static_cast<int>(g & 1) : static_cast<int>(g % P);
-    const int next = trav + 1 == P ? 0 : trav + 1;
+    const EsView<kA> view{nodes, pol, uret, uprob, dreg, dpol, P, trav, trav + 1 == P ? 0 : trav + 1};
     Rng rng(seed, static_cast<uint64_t>(g), 0);
-    // backing store of the frames below the top one
-    uint32_t s_x[kMaxFrames], s_fa[kMaxFrames];
-    double s_v[kMaxFrames], s_cv[kMaxFrames][kA];
-    uint32_t top_x = 0, top_fc = 0;
-    int top_a = 0;
-    double top_v = 0.0, top_cv[kA];
-#pragma unroll
-    for (int b = 0; b < kA; ++b) top_cv[b] = 0.0;
-    int sp = 0;
+    if (!kSplit) {
+      if (live) (void)es_walk<kA, true>(view, 0, rng, seed, static_cast<uint64_t>(g));
+      continue;
+    }
+    // ---- the shared path down to the traverser's first node ----
     int node = 0;
-    for (;;) {
-      const uint2 rec = nodes[node];
-      const int kind = rec.x & 3u;
-      if (kind != kTerminalNode) {
-        const int nc = (rec.x >> 2) & 63u, fc = rec.y & 0xFFFFFFu;
-        const int i = rec.x >> 12;
-        const int actor = static_cast<int>((rec.x >> 8) & 15u) - 1;  // -1 at chance nodes
-        if (actor != trav) {
-          const double z = rng.unit();
-          int pick = nc - 1;
-          if (kind == kChanceNode) {  // SampleAction(ChanceOutcomes(), z) (spiel.cc:372-409)
-            double acc = 0.0;
-            bool found = false;
-            if (i != 0) {  // all outcomes equally likely: the same scan, the probability read once
-              const double pr = uprob[i - 1];
-              for (int c = 0; c < nc; ++c) {
-                if (!found && acc <= z && z < acc + pr) { pick = c; found = true; }
-                acc += pr;
-              }
-            } else {
-              for (int c = 0; c < nc; ++c) {
-                const double pr = uprob[nodes[fc + c].y >> 24];
-                if (!found && acc <= z && z < acc + pr) { pick = c; found = true; }
-                acc += pr;
-              }
-            }
-          } else {  // opponent: sample one action from regret matching (:151-154)
-            double p[kA];
-#pragma unroll
-            for (int a = 0; a < kA; ++a) p[a] = pol[i * kA + a];
-            double acc = 0.0;  // SampleActionIndex(0.0, z) (cfr.cc:617-628)
-            bool found = false;
-#pragma unroll
-            for (int a = 0; a < kA; ++a) {
-              if (!found && a < nc && z >= acc && z < acc + p[a]) { pick = a; found = true; }
-              acc += p[a];
-            }
-            if (actor == next) {  // kSimple averaging at player+1's nodes (:177-183)
-#pragma unroll
-              for (int a = 0; a < kA; ++a)
-                if (a < nc) add_f64(&dpol[i * kA + a], p[a]);
-            }
-          }
-          node = fc + pick;
-          continue;
-        }
-        // traverser: walk every action (:155-162)
-        if (sp > 0) {
-          s_x[sp - 1] = top_x;
-          s_fa[sp - 1] = top_fc | (static_cast<uint32_t>(top_a) << 24);
-          s_v[sp - 1] = top_v;
-#pragma unroll
-          for (int b = 0; b < kA; ++b) s_cv[sp - 1][b] = top_cv[b];
-        }
-        top_x = rec.x; top_fc = fc; top_a = 0; top_v = 0.0;
-        ++sp;
-        node = fc;
-        continue;
+    uint2 rec = nodes[0];
+    bool at_traverser = false;
+    if (live) {
+      for (;;) {
+        rec = nodes[node];
+        if ((rec.x & 3u) == kTerminalNode) break;
+        if (static_cast<int>((rec.x >> 8) & 15u) - 1 == trav) { at_traverser = true; break; }
+        node = es_sampled_child<kA>(view, rec, rng, branch == 0);
       }
-      double ret = uret[(rec.y & 0xFFFFFFu) * P + trav];
-      bool done = false;
-      for (;;) {  // hand `ret` to the innermost open frame
-        if (sp == 0) { done = true; break; }
-        const int i = top_x >> 12, nc = (top_x >> 2) & 63u;
-        const double pa = pol[i * kA + top_a];
+    }
+    const int nc = at_traverser ? static_cast<int>((rec.x >> 2) & 63u) : 0, fc = static_cast<int>(rec.y & 0xFFFFFFu);
+    double mine = 0.0;
+    if (branch < nc) {
+      Rng sub(seed, static_cast<uint64_t>(g), 1 + static_cast<uint64_t>(branch));
+      mine = es_walk<kA, false>(view, fc + branch, sub, seed, static_cast<uint64_t>(g));
+    }
+    // ---- the node's own terms: values from the group's lanes, added in action order (:155-172) ----
+    double cv[kA];
 #pragma unroll
-        for (int b = 0; b < kA; ++b)
-          if (b == top_a) top_cv[b] = ret;
-        top_v += pa * ret;
-        if (top_a + 1 < nc) {
-          ++top_a;
-          node = top_fc + top_a;
-          break;
-        }
+    for (int a = 0; a < kA; ++a) cv[a] = __shfl(mine, (static_cast<int>(threadIdx.x) & 63 & ~(kQ - 1)) + (a < kQ ? a : 0), 64);
+    if (at_traverser) {
+      const int i = rec.x >> 12;
+      double v = 0.0;
 #pragma unroll
-        for (int b = 0; b < kA; ++b)
-          if (b < nc) add_f64(&dreg[i * kA + b], top_cv[b] - top_v);  // (:167-172)
-        ret = top_v;
-        --sp;
-        if (sp > 0) {
-          top_x = s_x[sp - 1];
-          top_fc = s_fa[sp - 1] & 0xFFFFFFu;
-          top_a = s_fa[sp - 1] >> 24;
-          top_v = s_v[sp - 1];
+      for (int a = 0; a < kA; ++a)
+        if (a < nc) v += pol[i * kA + a] * cv[a];
 #pragma unroll
-          for (int b = 0; b < kA; ++b) top_cv[b] = s_cv[sp - 1][b];
-        }
-      }
-      if (done) break;
+      for (int a = 0; a < kA; ++a)
+        if (a == branch && a < nc) add_f64(&dreg[i * kA + a], cv[a] - v);
     }
   }
-  if (stamp) stamps[2] = wall_clock64();   // (lane 0's own trajectory; the flush below waits for the workgroup's last)
+  if (stamp) stamps[2] = wall_clock64();   // (lane 0's own trajectories; the flush below waits for the workgroup's last)
   resident_flush(dreg, dpol, g_dreg, g_dpol, IA);
   if (stamp) { stamps[3] = wall_clock64(); }
 }
@@ -2654,6 +2731,15 @@ int build_resident_tree(osg_cfr* s) {
     (void)hipGetLastError();
     return OSG_OK;
   }
+  const void* split_variants[] = {nullptr, reinterpret_cast<const void*>(&k_mccfr_resident<2, true>),
+                                  reinterpret_cast<const void*>(&k_mccfr_resident<3, true>),
+                                  reinterpret_cast<const void*>(&k_mccfr_resident<4, true>)};
+  if (s->cfg.solver != 2 && s->A >= 2 &&
+      hipFuncSetAttribute(split_variants[s->A - 1], hipFuncAttributeMaxDynamicSharedMemorySize,
+                          static_cast<int>(s->resident_lds_bytes)) != hipSuccess) {
+    (void)hipGetLastError();
+    return OSG_OK;
+  }
   s->resident_ok = true;
   return OSG_OK;
 }
@@ -3396,6 +3482,13 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
     // 143 KB) gets one group per CU, sized to the batch — every CU busy, up to 1024 lanes each; small
     // footprints (kuhn) get several 256- or 1024-lane groups per CU.
     const int fit = static_cast<int>((160 * 1024) / std::max<size_t>(s->resident_lds_bytes, 1));
+    // Mini-batches that leave lanes idle (fewer lanes than one round of the chip even with the split) run the
+    // split form of the external-sampling kernel: 2 or 4 lanes per trajectory (OSG_MCCFR_SPLIT=0: never).
+    static const bool split_allowed = !(std::getenv("OSG_MCCFR_SPLIT") && std::getenv("OSG_MCCFR_SPLIT")[0] == '0');
+    const int lanes_per = (s->cfg.solver != 2 && s->A >= 2 && split_allowed) ? (s->A <= 2 ? 2 : 4) : 1;
+    const bool split = lanes_per > 1 && trajectories * lanes_per <= static_cast<int64_t>(s->num_cus) * 1024;
+    const int64_t sampled = trajectories;
+    if (split) trajectories *= lanes_per;   // (the geometry below counts lanes)
     int threads, per_cu;
     if (fit <= 1) {
       const int64_t share = (trajectories + s->num_cus - 1) / std::max(s->num_cus, 1);
@@ -3416,11 +3509,14 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
   do {                                                                                                             \
     if (s->cfg.solver == 2)                                                                                        \
       k_os_mccfr_resident<KA><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), dreg, \
-                                                          dpol, seed, first_trajectory, trajectories,        \
+                                                          dpol, seed, first_trajectory, sampled,             \
                                                           s->cfg.epsilon);                                        \
+    else if (split && KA >= 2)                                                                                     \
+      k_mccfr_resident<(KA >= 2 ? KA : 2), true><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), \
+                                                       dreg, dpol, seed, first_trajectory, sampled, d_stamps);   \
     else                                                                                                           \
       k_mccfr_resident<KA><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), dreg,  \
-                                                       dpol, seed, first_trajectory, trajectories, d_stamps); \
+                                                       dpol, seed, first_trajectory, sampled, d_stamps);      \
   } while (0)
     switch (s->A) {
       case 1: OSG_MCCFR_RES(1); break;
@@ -3435,7 +3531,7 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
       OSG_HIP(hipMemcpyAsync(h, d_stamps, sizeof h, hipMemcpyDeviceToHost, st));
       OSG_HIP(hipStreamSynchronize(st));
       fprintf(stderr, "k_mccfr_resident (%lld trajectories, %u x %d lanes; workgroup 0, us): staging %.2f  lane 0's trajectory %.2f  "
-                      "rest of the workgroup + flush %.2f\n", static_cast<long long>(trajectories), grid.x, threads,
+                      "rest of the workgroup + flush %.2f\n", static_cast<long long>(sampled), grid.x, threads,
               (h[1] - h[0]) / 100.0, (h[2] - h[1]) / 100.0, (h[3] - h[2]) / 100.0);
     }
     return OSG_OK;

@@ -553,12 +553,13 @@ void ExternalSamplingMCCFRSolver::RunIteration() {  // external_sampling_mccfr.c
 }
 
 double ExternalSamplingMCCFRSolver::UpdateRegretsWith(
-    const State& state, Player player, const std::function<double()>& next_z) {
+    const State& state, Player player, const std::function<double()>& next_z,
+    const std::function<void(int)>* on_first_branch, bool before_first) {
   // external_sampling_mccfr.cc:122-186
   if (state.IsTerminal()) return state.PlayerReturn(player);
   if (state.IsChanceNode()) {
     Action a = SampleAction(state.ChanceOutcomes(), next_z()).first;
-    return UpdateRegretsWith(*state.Child(a), player, next_z);
+    return UpdateRegretsWith(*state.Child(a), player, next_z, on_first_branch, before_first);
   }
   Player cur = state.CurrentPlayer();
   std::string key = state.InformationStateString(cur);
@@ -571,10 +572,11 @@ double ExternalSamplingMCCFRSolver::UpdateRegretsWith(
   std::vector<double> child_values(legal.size(), 0);
   if (cur != player) {
     int a = copy.SampleActionIndex(0.0, next_z());
-    value = UpdateRegretsWith(*state.Child(legal[a]), player, next_z);
+    value = UpdateRegretsWith(*state.Child(legal[a]), player, next_z, on_first_branch, before_first);
   } else {
     for (size_t a = 0; a < legal.size(); ++a) {
-      child_values[a] = UpdateRegretsWith(*state.Child(legal[a]), player, next_z);
+      if (on_first_branch && before_first) (*on_first_branch)(static_cast<int>(a));
+      child_values[a] = UpdateRegretsWith(*state.Child(legal[a]), player, next_z, on_first_branch, false);
       value += copy.current_policy[a] * child_values[a];
     }
   }

@@ -734,8 +734,9 @@ int osgo_cfr_iterate(void* h, int iters) {
 }
 // The DEVICE's mini-batch schedule of external-sampling MCCFR, restated on the
 // oracle's solver: trajectories [first, first+count) all read the table as it
-// is at the start of the call (trajectory g: traverser g mod P, uniforms from
-// CounterRng(seed, g, 0).Unit() in visiting order); their regret / average-policy
+// is at the start of the call (trajectory g: traverser g mod P, uniforms from CounterRng(seed, g, 0).Unit() in
+// visiting order down to the traverser's first node and from CounterRng(seed, g, 1 + b) inside that node's child b:
+// the device spreads those subtrees over lanes); their regret / average-policy
 // increments (external_sampling_mccfr.cc:167-183) are summed and folded in at
 // the end.  With count == 1 this is exactly one UpdateRegrets call.
 int osgo_mccfr_minibatch(void* h, uint64_t seed, int64_t first, int64_t count) {
@@ -754,8 +755,12 @@ int osgo_mccfr_minibatch(void* h, uint64_t seed, int64_t first, int64_t count) {
       const CFRInfoStateValuesTable frozen = table;
       CounterRng rng(seed, static_cast<uint64_t>(g), 0);
       if (c->mccfr) {
+        // the device's streams: (seed, g, 0) down to the traverser's first node, (seed, g, 1 + b) inside its child b
+        const std::function<void(int)> branch = [&rng, seed, g](int b) {
+          rng = CounterRng(seed, static_cast<uint64_t>(g), 1 + static_cast<uint64_t>(b));
+        };
         c->mccfr->UpdateRegretsWith(*c->game->NewInitialState(), static_cast<Player>(g % P),
-                                    [&rng]() { return rng.Unit(); });
+                                    [&rng]() { return rng.Unit(); }, &branch);
       } else {
         std::unique_ptr<State> episode = c->game->NewInitialState();
         c->osmccfr->SampleEpisodeWith(episode.get(), static_cast<Player>(g % P), [&rng]() { return rng.Unit(); },

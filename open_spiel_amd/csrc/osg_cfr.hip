@@ -1547,11 +1547,16 @@ k_eval_jobs(Tree t, EvalArrays ea, EvalJobs ej, const double* __restrict__ src, 
 // AverageType::kSimple, one traversal per thread, tables frozen for the launch.
 // ---------------------------------------------------------------------------
 OSG_D void add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }  // hardware fp64 atomic (LDS and L2)
+// The counter stream of an external-sampling trajectory by where the walk is (level = traverser nodes above, 0 .. 2).
+OSG_HD uint64_t es_stream(int level, int b1, int b2) {
+  return level == 0 ? 0u : (level == 1 ? 1u + static_cast<uint64_t>(b1) : 16u + 8u * static_cast<uint64_t>(b1) + static_cast<uint64_t>(b2));
+}
 
-// Streams of trajectory g: (seed, g, 0) in visiting order down to the FIRST node at which the traverser acts, then
-// (seed, g, 1 + b) inside that node's child b — the subtrees below the traverser's first node are independent but for
-// the order of the draws, and with a stream each they can be walked by different lanes (k_mccfr_resident<., true>);
-// the oracle's replay follows the same rule (osgo_mccfr_minibatch).
+// Streams of trajectory g: (seed, g, 0) in visiting order down to the FIRST node at which the traverser acts; inside
+// that node's child b1, down to the traverser's NEXT node on the path, sub-stream 1 + b1; inside that node's child b2
+// sub-stream 16 + 8 b1 + b2 — a sub-stream is the same generator after a jump of its counter (Rng::jump_to).  The subtrees below a traverser node are independent but for the order of
+// the draws: with a stream each they can be walked by different lanes (k_mccfr_resident<., kSplit>); the oracle's replay
+// follows the same rule (osgo_mccfr_minibatch).
 // kExtU: the uniforms come from a caller-supplied sequence (ext_u[0], ext_u[1], ... in visiting order) instead
 // of the counter streams: with the sequence the reference's std::mt19937 + uniform_real_distribution would
 // produce, one trajectory IS one UpdateRegrets call of the reference, draw for draw
@@ -1574,6 +1579,7 @@ k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dp
     const int64_t g = first + j;
     const int trav = static_cast<int>(g % P);
     Rng rng(seed, static_cast<uint64_t>(g), 0);
+    const uint64_t s0 = rng.s;
     int uk = 0;
     auto next_u = [&]() -> double {
       if (kExtU) { const double u = uk < ext_n ? ext_u[uk] : 0.0; ++uk; return u; }
@@ -1626,7 +1632,7 @@ k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dp
         f_value[sp] = 0.0;
         ++sp;
         node = fc;
-        if (!kExtU && sp == 1) rng = Rng(seed, static_cast<uint64_t>(g), 1);   // child 0 of the traverser's FIRST node: its own stream
+        if (!kExtU && sp <= 2) rng.jump_to(s0, es_stream(sp, sp == 2 ? f_a[0] : 0, 0));   // child 0 of the traverser's first / second node: its own stream
       }
       // ---- ascend: hand `ret` to the innermost open frame ----
       bool done = false;
@@ -1643,7 +1649,7 @@ k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dp
         if (a + 1 < nc) {
           f_a[sp - 1] = a + 1;
           node = t.first_child[fn] + a + 1;
-          if (!kExtU && sp == 1) rng = Rng(seed, static_cast<uint64_t>(g), 2 + static_cast<uint64_t>(a));   // child a + 1: stream 1 + (a + 1)
+          if (!kExtU && sp <= 2) rng.jump_to(s0, sp == 1 ? es_stream(1, a + 1, 0) : es_stream(2, f_a[0], a + 1));
           break;
         }
         const double v = f_value[sp - 1];
@@ -1821,10 +1827,14 @@ OSG_D int es_sampled_child(const EsView<kA>& c, uint2 rec, Rng& rng, bool averag
 // UpdateRegrets from `node` down (external_sampling_mccfr.cc:122-186): the value of `node` for the traverser, the
 // regret and average-policy terms of everything below added to the LDS delta tables.  The frame on top of the
 // traverser's stack lives in registers, deeper frames in a per-lane backing store touched on push / pop only.
-// kFirst: `node` is the trajectory's root — the children of the FIRST traverser node each draw from their own stream
-// (seed, g, 1 + b); otherwise one stream in visiting order.
-template <int kA, bool kFirst>
-OSG_D double es_walk(const EsView<kA>& c, int node, Rng& rng, uint64_t seed, uint64_t g) {
+// kBase traverser nodes lie above `node` on the trajectory (0: `node` is the root): the children of the traverser's
+// first and second node draw from their own streams (es_stream); b1: the child of the first node the walk is in (kBase >= 1).
+template <int kA, int kBase>
+OSG_D double es_walk(const EsView<kA>& c, int node, Rng& rng, uint64_t s0, int b1) {   // s0 = the state (seed, g, 0) starts from
+  // (the loop is written like k_mccfr_resident_flat's, sampling code in line: through es_sampled_child it ran a quarter slower)
+  const uint2* __restrict__ nodes = c.nodes;
+  const double* __restrict__ pol = c.pol;
+  const int trav = c.trav, next = c.next, P = c.P;
   uint32_t s_x[kMaxFrames], s_fa[kMaxFrames];
   double s_v[kMaxFrames], s_cv[kMaxFrames][kA];
   uint32_t top_x = 0, top_fc = 0;
@@ -1833,42 +1843,82 @@ OSG_D double es_walk(const EsView<kA>& c, int node, Rng& rng, uint64_t seed, uin
 #pragma unroll
   for (int b = 0; b < kA; ++b) top_cv[b] = 0.0;
   int sp = 0;
+  double ret = 0.0;
   for (;;) {
-    const uint2 rec = c.nodes[node];
+    const uint2 rec = nodes[node];
     const int kind = rec.x & 3u;
     if (kind != kTerminalNode) {
-      const int actor = static_cast<int>((rec.x >> 8) & 15u) - 1;
-      if (actor != c.trav) {
-        node = es_sampled_child<kA>(c, rec, rng, true);
+      const int nc = (rec.x >> 2) & 63u, fc = rec.y & 0xFFFFFFu;
+      const int i = rec.x >> 12;
+      const int actor = static_cast<int>((rec.x >> 8) & 15u) - 1;  // -1 at chance nodes
+      if (actor != trav) {
+        const double z = rng.unit();
+        int pick = nc - 1;
+        if (kind == kChanceNode) {  // SampleAction(ChanceOutcomes(), z) (spiel.cc:372-409)
+          double acc = 0.0;
+          bool found = false;
+          if (i != 0) {  // all outcomes equally likely: the same scan, the probability read once
+            const double pr = c.uprob[i - 1];
+            for (int k = 0; k < nc; ++k) {
+              if (!found && acc <= z && z < acc + pr) { pick = k; found = true; }
+              acc += pr;
+            }
+          } else {
+            for (int k = 0; k < nc; ++k) {
+              const double pr = c.uprob[nodes[fc + k].y >> 24];
+              if (!found && acc <= z && z < acc + pr) { pick = k; found = true; }
+              acc += pr;
+            }
+          }
+        } else {  // opponent: sample one action from regret matching (:151-154)
+          double p[kA];
+#pragma unroll
+          for (int a = 0; a < kA; ++a) p[a] = pol[i * kA + a];
+          double acc = 0.0;  // SampleActionIndex(0.0, z) (cfr.cc:617-628)
+          bool found = false;
+#pragma unroll
+          for (int a = 0; a < kA; ++a) {
+            if (!found && a < nc && z >= acc && z < acc + p[a]) { pick = a; found = true; }
+            acc += p[a];
+          }
+          if (actor == next) {  // kSimple averaging at player+1's nodes (:177-183)
+#pragma unroll
+            for (int a = 0; a < kA; ++a)
+              if (a < nc) add_f64(&c.dpol[i * kA + a], p[a]);
+          }
+        }
+        node = fc + pick;
         continue;
       }
       // traverser: walk every action (:155-162)
       if (sp > 0) {
+        if (kBase == 0 && sp == 1) b1 = top_a;   // the walk is about to enter the second traverser node inside child top_a
         s_x[sp - 1] = top_x;
         s_fa[sp - 1] = top_fc | (static_cast<uint32_t>(top_a) << 24);
         s_v[sp - 1] = top_v;
 #pragma unroll
         for (int b = 0; b < kA; ++b) s_cv[sp - 1][b] = top_cv[b];
       }
-      top_x = rec.x; top_fc = rec.y & 0xFFFFFFu; top_a = 0; top_v = 0.0;
+      top_x = rec.x; top_fc = fc; top_a = 0; top_v = 0.0;
       ++sp;
-      node = static_cast<int>(top_fc);
-      if (kFirst && sp == 1) rng = Rng(seed, g, 1);
+      node = fc;
+      if (kBase + sp <= 2) rng.jump_to(s0, es_stream(kBase + sp, kBase + sp == 1 ? 0 : b1, 0));
       continue;
     }
-    double ret = c.uret[(rec.y & 0xFFFFFFu) * c.P + c.trav];
+    ret = c.uret[(rec.y & 0xFFFFFFu) * P + trav];
+    bool done = false;
     for (;;) {  // hand `ret` to the innermost open frame
-      if (sp == 0) return ret;
+      if (sp == 0) { done = true; break; }
       const int i = top_x >> 12, nc = (top_x >> 2) & 63u;
-      const double pa = c.pol[i * kA + top_a];
+      const double pa = pol[i * kA + top_a];
 #pragma unroll
       for (int b = 0; b < kA; ++b)
         if (b == top_a) top_cv[b] = ret;
       top_v += pa * ret;
       if (top_a + 1 < nc) {
         ++top_a;
-        node = static_cast<int>(top_fc) + top_a;
-        if (kFirst && sp == 1) rng = Rng(seed, g, 1 + static_cast<uint64_t>(top_a));
+        node = top_fc + top_a;
+        if (kBase + sp <= 2) rng.jump_to(s0, kBase + sp == 1 ? es_stream(1, top_a, 0) : es_stream(2, b1, top_a));
         break;
       }
 #pragma unroll
@@ -1885,15 +1935,160 @@ OSG_D double es_walk(const EsView<kA>& c, int node, Rng& rng, uint64_t seed, uin
         for (int b = 0; b < kA; ++b) top_cv[b] = s_cv[sp - 1][b];
       }
     }
+    if (done) break;
   }
+  return ret;
 }
 
-// kSplit: kQ = 2 (kA <= 2) or 4 lanes per trajectory.  A traversal is one dependent chain (leduc: ~100 node visits,
-// 42-45 us on one lane whatever the batch — profiles/r04_mccfr_shard.log): all kQ lanes walk the sampled path down
-// to the traverser's first node (the same draws: the same path; lane 0 of the group does the averaging), lane b then
-// walks child b on its stream, the values come back by lane shuffles and the node's own terms are added in action
-// order — the sums of the one-lane form.  For mini-batches that leave lanes idle anyway (<= one round of the chip).
-template <int kA, bool kSplit = false>
+// One trajectory per lane, for mini-batches that fill the chip: the traversal as ONE flat loop (the form the split
+// kernels below share their pieces with was measured 27 % slower here: 403 vs 309 us per 2^20 trajectories).
+template <int kA>
+__global__ void __launch_bounds__(1024)
+k_mccfr_resident_flat(int H, int I, int P, ResidentTree rt, const int32_t* __restrict__ nact,
+                 const double* __restrict__ regrets, double* g_dreg, double* g_dpol, uint64_t seed, int64_t first,
+                 int64_t count) {
+  extern __shared__ double smem[];
+  const int IA = I * kA;
+  double *dreg, *dpol, *pol, *uret, *uprob;
+  uint2* nodes;
+  resident_load<kA>(smem, H, I, P, rt, nact, regrets, &dreg, &dpol, &pol, &uret, &uprob, &nodes);
+  __syncthreads();
+
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t j0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j0 < count; j0 += stride) {
+    // Which trajectory a lane takes: within every full group of 64 P consecutive ones, wavefront w of the group takes
+    // those with the same traverser (index = lane * P + w), so that the 64 lanes of a wavefront agree at every node
+    // on whether they walk all actions or sample one — half the divergence of the natural order, same set of
+    // trajectories.  (The last, partial group keeps the natural order.)
+    int64_t j = j0;
+    {
+      const int64_t span = 64 * static_cast<int64_t>(P), group = j0 / span;
+      if ((group + 1) * span <= count) {
+        const int r = static_cast<int>(j0 - group * span);
+        j = group * span + static_cast<int64_t>(r & 63) * P + (r >> 6);
+      }
+    }
+    const int64_t g = first + j;
+    // (a 64-bit modulo by a run-time divisor is ~100 instructions: two players take the parity)
+    const int trav = P == 2 ? static_cast<int>(g & 1) : static_cast<int>(g % P);
+    const int next = trav + 1 == P ? 0 : trav + 1;
+    Rng rng(seed, static_cast<uint64_t>(g), 0);
+    const uint64_t s0 = rng.s;   // the sub-streams of the traverser's first two levels are jumps of this counter (es_stream)
+    int b1 = 0;
+    // backing store of the frames below the top one
+    uint32_t s_x[kMaxFrames], s_fa[kMaxFrames];
+    double s_v[kMaxFrames], s_cv[kMaxFrames][kA];
+    uint32_t top_x = 0, top_fc = 0;
+    int top_a = 0;
+    double top_v = 0.0, top_cv[kA];
+#pragma unroll
+    for (int b = 0; b < kA; ++b) top_cv[b] = 0.0;
+    int sp = 0;
+    int node = 0;
+    for (;;) {
+      const uint2 rec = nodes[node];
+      const int kind = rec.x & 3u;
+      if (kind != kTerminalNode) {
+        const int nc = (rec.x >> 2) & 63u, fc = rec.y & 0xFFFFFFu;
+        const int i = rec.x >> 12;
+        const int actor = static_cast<int>((rec.x >> 8) & 15u) - 1;  // -1 at chance nodes
+        if (actor != trav) {
+          const double z = rng.unit();
+          int pick = nc - 1;
+          if (kind == kChanceNode) {  // SampleAction(ChanceOutcomes(), z) (spiel.cc:372-409)
+            double acc = 0.0;
+            bool found = false;
+            if (i != 0) {  // all outcomes equally likely: the same scan, the probability read once
+              const double pr = uprob[i - 1];
+              for (int c = 0; c < nc; ++c) {
+                if (!found && acc <= z && z < acc + pr) { pick = c; found = true; }
+                acc += pr;
+              }
+            } else {
+              for (int c = 0; c < nc; ++c) {
+                const double pr = uprob[nodes[fc + c].y >> 24];
+                if (!found && acc <= z && z < acc + pr) { pick = c; found = true; }
+                acc += pr;
+              }
+            }
+          } else {  // opponent: sample one action from regret matching (:151-154)
+            double p[kA];
+#pragma unroll
+            for (int a = 0; a < kA; ++a) p[a] = pol[i * kA + a];
+            double acc = 0.0;  // SampleActionIndex(0.0, z) (cfr.cc:617-628)
+            bool found = false;
+#pragma unroll
+            for (int a = 0; a < kA; ++a) {
+              if (!found && a < nc && z >= acc && z < acc + p[a]) { pick = a; found = true; }
+              acc += p[a];
+            }
+            if (actor == next) {  // kSimple averaging at player+1's nodes (:177-183)
+#pragma unroll
+              for (int a = 0; a < kA; ++a)
+                if (a < nc) add_f64(&dpol[i * kA + a], p[a]);
+            }
+          }
+          node = fc + pick;
+          continue;
+        }
+        // traverser: walk every action (:155-162)
+        if (sp > 0) {
+          if (sp == 1) b1 = top_a;   // entering the traverser's second node inside child top_a of the first
+          s_x[sp - 1] = top_x;
+          s_fa[sp - 1] = top_fc | (static_cast<uint32_t>(top_a) << 24);
+          s_v[sp - 1] = top_v;
+#pragma unroll
+          for (int b = 0; b < kA; ++b) s_cv[sp - 1][b] = top_cv[b];
+        }
+        top_x = rec.x; top_fc = fc; top_a = 0; top_v = 0.0;
+        ++sp;
+        node = fc;
+        if (sp <= 2) rng.jump_to(s0, es_stream(sp, sp == 1 ? 0 : b1, 0));
+        continue;
+      }
+      double ret = uret[(rec.y & 0xFFFFFFu) * P + trav];
+      bool done = false;
+      for (;;) {  // hand `ret` to the innermost open frame
+        if (sp == 0) { done = true; break; }
+        const int i = top_x >> 12, nc = (top_x >> 2) & 63u;
+        const double pa = pol[i * kA + top_a];
+#pragma unroll
+        for (int b = 0; b < kA; ++b)
+          if (b == top_a) top_cv[b] = ret;
+        top_v += pa * ret;
+        if (top_a + 1 < nc) {
+          ++top_a;
+          node = top_fc + top_a;
+          if (sp <= 2) rng.jump_to(s0, sp == 1 ? es_stream(1, top_a, 0) : es_stream(2, b1, top_a));
+          break;
+        }
+#pragma unroll
+        for (int b = 0; b < kA; ++b)
+          if (b < nc) add_f64(&dreg[i * kA + b], top_cv[b] - top_v);  // (:167-172)
+        ret = top_v;
+        --sp;
+        if (sp > 0) {
+          top_x = s_x[sp - 1];
+          top_fc = s_fa[sp - 1] & 0xFFFFFFu;
+          top_a = s_fa[sp - 1] >> 24;
+          top_v = s_v[sp - 1];
+#pragma unroll
+          for (int b = 0; b < kA; ++b) top_cv[b] = s_cv[sp - 1][b];
+        }
+      }
+      if (done) break;
+    }
+  }
+  resident_flush(dreg, dpol, g_dreg, g_dpol, IA);
+}
+
+// kSplit = 1 / 2: kQ = 2 (kA <= 2) or 4 lanes per traverser level, kQ or kQ^2 lanes per trajectory.  A traversal is
+// one dependent chain (leduc: ~100 node visits, 42-45 us on one lane whatever the batch — profiles/r04_mccfr_shard.log):
+// all lanes of a group walk the sampled path down to the traverser's first node (the same draws: the same path; lane 0
+// does the averaging), the lanes of child b1 walk on from there on its stream — with kSplit = 2 down to the traverser's
+// next node, whose child b2 lane (b1, b2) then walks —, the values come back by lane shuffles and a node's own terms are
+// added in action order: the sums of the one-lane form.  For mini-batches that leave lanes idle anyway.
+template <int kA, int kSplit = 0>
 __global__ void __launch_bounds__(1024)
 k_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict__ nact,
                  const double* __restrict__ regrets, double* g_dreg, double* g_dpol, uint64_t seed, int64_t first,
@@ -1907,13 +2102,16 @@ k_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict
   resident_load<kA>(smem, H, I, P, rt, nact, regrets, &dreg, &dpol, &pol, &uret, &uprob, &nodes);
   __syncthreads();
   if (stamp) stamps[1] = wall_clock64();
-  constexpr int kQ = kSplit ? (kA <= 2 ? 2 : 4) : 1;           // lanes per trajectory
-  constexpr int kPerWave = 64 / kQ;                             // trajectories per wavefront
+  constexpr int kQ = kA <= 2 ? 2 : 4;                                      // lanes per traverser level
+  constexpr int kLanes = kSplit == 0 ? 1 : (kSplit == 1 ? kQ : kQ * kQ);   // lanes per trajectory
+  constexpr int kPerWave = 64 / kLanes;                                    // trajectories per wavefront
 
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x / kQ;
-  const int64_t lane_slot = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) / kQ;
-  const int branch = static_cast<int>(threadIdx.x) & (kQ - 1);
-  const int64_t rounds = (count + stride - 1) / stride;        // (every lane runs every round: the shuffles below need the whole wavefront)
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x / kLanes;
+  const int64_t lane_slot = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) / kLanes;
+  const int in_group = static_cast<int>(threadIdx.x) & (kLanes - 1);
+  const int b1 = kSplit == 2 ? in_group / kQ : in_group, b2 = kSplit == 2 ? in_group % kQ : 0;
+  const int group_base = static_cast<int>(threadIdx.x) & 63 & ~(kLanes - 1);   // the group's first lane in its wavefront
+  const int64_t rounds = (count + stride - 1) / stride;   // (every lane runs every round: the shuffles need the whole wavefront)
   for (int64_t rd = 0; rd < rounds; ++rd) {
     const int64_t j0 = lane_slot + rd * stride;
     const bool live = j0 < count;
@@ -1929,46 +2127,84 @@ k_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict
         j = group * span + static_cast<int64_t>(r % kPerWave) * P + (r / kPerWave);
       }
     }
-    const int64_t g = first + j;
+    const uint64_t g = static_cast<uint64_t>(first + j);
     // (a 64-bit modulo by a run-time divisor is ~100 instructions: two players take the parity)
     const int trav = P == 2 ? static_cast<int>(g & 1) : static_cast<int>(g % P);
     const EsView<kA> view{nodes, pol, uret, uprob, dreg, dpol, P, trav, trav + 1 == P ? 0 : trav + 1};
-    Rng rng(seed, static_cast<uint64_t>(g), 0);
-    if (!kSplit) {
-      if (live) (void)es_walk<kA, true>(view, 0, rng, seed, static_cast<uint64_t>(g));
+    Rng rng(seed, g, 0);
+    const uint64_t s0 = rng.s;
+    if (kSplit == 0) {
+      if (live) (void)es_walk<kA, 0>(view, 0, rng, s0, 0);
       continue;
     }
     // ---- the shared path down to the traverser's first node ----
     int node = 0;
     uint2 rec = nodes[0];
-    bool at_traverser = false;
+    bool at1 = false;
     if (live) {
       for (;;) {
         rec = nodes[node];
         if ((rec.x & 3u) == kTerminalNode) break;
-        if (static_cast<int>((rec.x >> 8) & 15u) - 1 == trav) { at_traverser = true; break; }
-        node = es_sampled_child<kA>(view, rec, rng, branch == 0);
+        if (static_cast<int>((rec.x >> 8) & 15u) - 1 == trav) { at1 = true; break; }
+        node = es_sampled_child<kA>(view, rec, rng, in_group == 0);
       }
     }
-    const int nc = at_traverser ? static_cast<int>((rec.x >> 2) & 63u) : 0, fc = static_cast<int>(rec.y & 0xFFFFFFu);
-    double mine = 0.0;
-    if (branch < nc) {
-      Rng sub(seed, static_cast<uint64_t>(g), 1 + static_cast<uint64_t>(branch));
-      mine = es_walk<kA, false>(view, fc + branch, sub, seed, static_cast<uint64_t>(g));
+    const uint2 rec1 = rec;
+    const int nc1 = at1 ? static_cast<int>((rec1.x >> 2) & 63u) : 0, fc1 = static_cast<int>(rec1.y & 0xFFFFFFu);
+    double value1 = 0.0;   // the value of child b1 of the first node
+    if (b1 < nc1) {
+      Rng sub = rng;
+      sub.jump_to(s0, es_stream(1, b1, 0));
+      if (kSplit == 1) {
+        value1 = es_walk<kA, 1>(view, fc1 + b1, sub, s0, b1);
+      } else {
+        // ---- the path inside child b1 down to the traverser's next node (all b2 lanes: the same draws) ----
+        node = fc1 + b1;
+        bool at2 = false;
+        for (;;) {
+          rec = nodes[node];
+          if ((rec.x & 3u) == kTerminalNode) break;
+          if (static_cast<int>((rec.x >> 8) & 15u) - 1 == trav) { at2 = true; break; }
+          node = es_sampled_child<kA>(view, rec, sub, b2 == 0);
+        }
+        if (!at2) {
+          value1 = uret[(rec.y & 0xFFFFFFu) * P + trav];
+        } else {
+          const int nc2 = static_cast<int>((rec.x >> 2) & 63u), fc2 = static_cast<int>(rec.y & 0xFFFFFFu), i2 = rec.x >> 12;
+          double mine = 0.0;
+          if (b2 < nc2) {
+            Rng sub2 = sub;
+            sub2.jump_to(s0, es_stream(2, b1, b2));
+            mine = es_walk<kA, 2>(view, fc2 + b2, sub2, s0, b1);
+          }
+          // (the b2 lanes of this b1 are all here: the shuffle reads them; lanes of other b1 groups shuffle below)
+          double cv2[kA];
+#pragma unroll
+          for (int a = 0; a < kA; ++a) cv2[a] = __shfl(mine, group_base + b1 * kQ + (a < kQ ? a : 0), 64);
+          double v2 = 0.0;
+#pragma unroll
+          for (int a = 0; a < kA; ++a)
+            if (a < nc2) v2 += pol[i2 * kA + a] * cv2[a];
+#pragma unroll
+          for (int a = 0; a < kA; ++a)
+            if (a == b2 && a < nc2) add_f64(&dreg[i2 * kA + a], cv2[a] - v2);
+          value1 = v2;
+        }
+      }
     }
-    // ---- the node's own terms: values from the group's lanes, added in action order (:155-172) ----
+    // ---- the first node's own terms: values from the group's lanes, added in action order (:155-172) ----
     double cv[kA];
 #pragma unroll
-    for (int a = 0; a < kA; ++a) cv[a] = __shfl(mine, (static_cast<int>(threadIdx.x) & 63 & ~(kQ - 1)) + (a < kQ ? a : 0), 64);
-    if (at_traverser) {
-      const int i = rec.x >> 12;
+    for (int a = 0; a < kA; ++a) cv[a] = __shfl(value1, group_base + (a < kQ ? a : 0) * (kSplit == 2 ? kQ : 1), 64);
+    if (at1) {
+      const int i = rec1.x >> 12;
       double v = 0.0;
 #pragma unroll
       for (int a = 0; a < kA; ++a)
-        if (a < nc) v += pol[i * kA + a] * cv[a];
+        if (a < nc1) v += pol[i * kA + a] * cv[a];
 #pragma unroll
       for (int a = 0; a < kA; ++a)
-        if (a == branch && a < nc) add_f64(&dreg[i * kA + a], cv[a] - v);
+        if (a == b1 && b2 == 0 && a < nc1) add_f64(&dreg[i * kA + a], cv[a] - v);
     }
   }
   if (stamp) stamps[2] = wall_clock64();   // (lane 0's own trajectories; the flush below waits for the workgroup's last)
@@ -2724,10 +2960,10 @@ int build_resident_tree(osg_cfr* s) {
   int rc;
   if ((rc = upload(rec, &s->d_rec, st)) || (rc = upload(uret, &s->d_uret, st)) || (rc = upload(uprob, &s->d_uprob, st)))
     return rc;
-  const void* variants[] = {reinterpret_cast<const void*>(&k_mccfr_resident<1>),
-                            reinterpret_cast<const void*>(&k_mccfr_resident<2>),
-                            reinterpret_cast<const void*>(&k_mccfr_resident<3>),
-                            reinterpret_cast<const void*>(&k_mccfr_resident<4>),
+  const void* variants[] = {reinterpret_cast<const void*>(&k_mccfr_resident_flat<1>),
+                            reinterpret_cast<const void*>(&k_mccfr_resident_flat<2>),
+                            reinterpret_cast<const void*>(&k_mccfr_resident_flat<3>),
+                            reinterpret_cast<const void*>(&k_mccfr_resident_flat<4>),
                             reinterpret_cast<const void*>(&k_os_mccfr_resident<1>),
                             reinterpret_cast<const void*>(&k_os_mccfr_resident<2>),
                             reinterpret_cast<const void*>(&k_os_mccfr_resident<3>),
@@ -2737,15 +2973,19 @@ int build_resident_tree(osg_cfr* s) {
     (void)hipGetLastError();
     return OSG_OK;
   }
-  const void* split_variants[] = {nullptr, reinterpret_cast<const void*>(&k_mccfr_resident<2, true>),
-                                  reinterpret_cast<const void*>(&k_mccfr_resident<3, true>),
-                                  reinterpret_cast<const void*>(&k_mccfr_resident<4, true>)};
-  if (s->cfg.solver != 2 && s->A >= 2 &&
-      hipFuncSetAttribute(split_variants[s->A - 1], hipFuncAttributeMaxDynamicSharedMemorySize,
-                          static_cast<int>(s->resident_lds_bytes)) != hipSuccess) {
-    (void)hipGetLastError();
-    return OSG_OK;
-  }
+  const void* split_variants[] = {nullptr, nullptr, reinterpret_cast<const void*>(&k_mccfr_resident<2, 1>),
+                                  reinterpret_cast<const void*>(&k_mccfr_resident<2, 2>),
+                                  reinterpret_cast<const void*>(&k_mccfr_resident<3, 1>),
+                                  reinterpret_cast<const void*>(&k_mccfr_resident<3, 2>),
+                                  reinterpret_cast<const void*>(&k_mccfr_resident<4, 1>),
+                                  reinterpret_cast<const void*>(&k_mccfr_resident<4, 2>)};
+  for (int level = 0; level < 2; ++level)
+    if (s->cfg.solver != 2 && s->A >= 2 &&
+        hipFuncSetAttribute(split_variants[2 * (s->A - 1) + level], hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(s->resident_lds_bytes)) != hipSuccess) {
+      (void)hipGetLastError();
+      return OSG_OK;
+    }
   s->resident_ok = true;
   return OSG_OK;
 }
@@ -3503,11 +3743,18 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
     const int fit = static_cast<int>((160 * 1024) / std::max<size_t>(s->resident_lds_bytes, 1));
     // Mini-batches that leave lanes idle (fewer lanes than one round of the chip even with the split) run the
     // split form of the external-sampling kernel: 2 or 4 lanes per trajectory (OSG_MCCFR_SPLIT=0: never).
-    static const bool split_allowed = !(std::getenv("OSG_MCCFR_SPLIT") && std::getenv("OSG_MCCFR_SPLIT")[0] == '0');
-    const int lanes_per = (s->cfg.solver != 2 && s->A >= 2 && split_allowed) ? (s->A <= 2 ? 2 : 4) : 1;
-    const bool split = lanes_per > 1 && trajectories * lanes_per <= static_cast<int64_t>(s->num_cus) * 1024;
+    // OSG_MCCFR_SPLIT=0 / 1 / 2: at most that many traverser levels are spread over lanes (default 2)
+    static const int split_max = std::getenv("OSG_MCCFR_SPLIT") ? std::atoi(std::getenv("OSG_MCCFR_SPLIT")) : 2;
+    const int q = s->A <= 2 ? 2 : 4;
+    int split = 0;   // two levels while the lanes fit one round of the chip (2^14 trajectories: 31.4 us per step against 38.7
+                     // with one level; 2^13: 26.7 against 37.2), else one level under the same condition, else the flat kernel
+    if (s->cfg.solver != 2 && s->A >= 2) {
+      const int64_t round = static_cast<int64_t>(s->num_cus) * 1024;
+      if (split_max >= 2 && trajectories * q * q <= round) split = 2;
+      else if (split_max >= 1 && trajectories * q <= round) split = 1;
+    }
     const int64_t sampled = trajectories;
-    if (split) trajectories *= lanes_per;   // (the geometry below counts lanes)
+    if (split) trajectories *= split == 2 ? q * q : q;   // (the geometry below counts lanes)
     int threads, per_cu;
     if (fit <= 1) {
       const int64_t share = (trajectories + s->num_cus - 1) / std::max(s->num_cus, 1);
@@ -3530,12 +3777,15 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
       k_os_mccfr_resident<KA><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), dreg, \
                                                           dpol, seed, first_trajectory, sampled,             \
                                                           s->cfg.epsilon);                                        \
-    else if (split && KA >= 2)                                                                                     \
-      k_mccfr_resident<(KA >= 2 ? KA : 2), true><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), \
+    else if (split == 1 && KA >= 2)                                                                                \
+      k_mccfr_resident<(KA >= 2 ? KA : 2), 1><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), \
+                                                       dreg, dpol, seed, first_trajectory, sampled, d_stamps);   \
+    else if (split == 2 && KA >= 2)                                                                                \
+      k_mccfr_resident<(KA >= 2 ? KA : 2), 2><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), \
                                                        dreg, dpol, seed, first_trajectory, sampled, d_stamps);   \
     else                                                                                                           \
-      k_mccfr_resident<KA><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), dreg,  \
-                                                       dpol, seed, first_trajectory, sampled, d_stamps);      \
+      k_mccfr_resident_flat<KA><<<grid, block, shmem, st>>>(s->H, s->I, s->P, rt, s->d_nact, s->regrets(), dreg, \
+                                                            dpol, seed, first_trajectory, sampled);            \
   } while (0)
     switch (s->A) {
       case 1: OSG_MCCFR_RES(1); break;
@@ -3545,7 +3795,7 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
     }
 #undef OSG_MCCFR_RES
     OSG_HIP(hipGetLastError());
-    if (d_stamps && s->cfg.solver != 2) {
+    if (d_stamps && s->cfg.solver != 2 && split != 0) {   // (the flat kernel writes no stamps)
       unsigned long long h[4];
       OSG_HIP(hipMemcpyAsync(h, d_stamps, sizeof h, hipMemcpyDeviceToHost, st));
       OSG_HIP(hipStreamSynchronize(st));

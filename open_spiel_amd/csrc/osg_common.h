@@ -38,6 +38,13 @@ struct Rng {
     uint64_t b = mix64(a ^ (stream * 0xD1342543DE82EF95ULL + 0x632BE59BD9B4E019ULL));
     s = mix64(b ^ (sub * 0xA0761D6478BD642FULL + 0xE7037ED1A0B428DBULL));
   }
+  // Sub-streams by a jump of the counter (the external-sampling traversals open one per subtree: a re-mixed key per
+  // sub-stream cost a quarter of the kernel's throughput): the generator is counter + mixer, so a stream that starts at
+  // s0 + id * kJump draws mix64 of another part of the counter space.  Two sub-streams of one s0 would meet only after
+  // (id1 - id2) * kJump / kStep draws (mod 2^64) — more than 2^56 for every |id1 - id2| <= 128
+  // (tests/test_synth_batch_cpu.py checks the constant).
+  static constexpr uint64_t kJump = 0xD6E8FEB86659FD93ULL;
+  OSG_HD void jump_to(uint64_t s0, uint64_t id) { s = s0 + id * kJump; }
   OSG_HD uint64_t next() {
     s += 0x9E3779B97F4A7C15ULL;
     return mix64(s);

@@ -482,11 +482,12 @@ class ExternalSamplingMCCFRSolver {  // external_sampling_mccfr.h:57-113
   void RunIteration();
   // One traverser pass driven by an explicit uniform source (used to replay a
   // device trajectory: "same table + same z-sequence => same deltas").
-  // on_first_branch (the device's stream rule, csrc/osg_cfr.hip): called with the child's index before the traversal
-  // enters each child of the FIRST node at which `player` acts on the trajectory — the caller switches its draw
-  // source to that child's own stream; null: one stream in visiting order, as in the reference.
+  // on_branch (the device's stream rule, csrc/osg_cfr.hip): called as (level, b1, b2) before the traversal enters child
+  // b1 of the FIRST node at which `player` acts on the trajectory (level 1) and child b2 of the SECOND such node on the
+  // path inside child b1 (level 2) — the caller switches its draw source to that subtree's own stream; null: one stream
+  // in visiting order, as in the reference.
   double UpdateRegretsWith(const State& state, Player player, const std::function<double()>& next_z,
-                           const std::function<void(int)>* on_first_branch = nullptr, bool before_first = true);
+                           const std::function<void(int, int, int)>* on_branch = nullptr, int depth = 0, int b1 = 0);
   CFRInfoStateValuesTable& InfoStateValuesTable() { return info_states_; }
   std::shared_ptr<Policy> AveragePolicy() const {
     return std::make_shared<CFRAveragePolicy>(info_states_, default_policy_);

@@ -554,12 +554,12 @@ void ExternalSamplingMCCFRSolver::RunIteration() {  // external_sampling_mccfr.c
 
 double ExternalSamplingMCCFRSolver::UpdateRegretsWith(
     const State& state, Player player, const std::function<double()>& next_z,
-    const std::function<void(int)>* on_first_branch, bool before_first) {
+    const std::function<void(int, int, int)>* on_branch, int depth, int b1) {
   // external_sampling_mccfr.cc:122-186
   if (state.IsTerminal()) return state.PlayerReturn(player);
   if (state.IsChanceNode()) {
     Action a = SampleAction(state.ChanceOutcomes(), next_z()).first;
-    return UpdateRegretsWith(*state.Child(a), player, next_z, on_first_branch, before_first);
+    return UpdateRegretsWith(*state.Child(a), player, next_z, on_branch, depth, b1);
   }
   Player cur = state.CurrentPlayer();
   std::string key = state.InformationStateString(cur);
@@ -572,11 +572,13 @@ double ExternalSamplingMCCFRSolver::UpdateRegretsWith(
   std::vector<double> child_values(legal.size(), 0);
   if (cur != player) {
     int a = copy.SampleActionIndex(0.0, next_z());
-    value = UpdateRegretsWith(*state.Child(legal[a]), player, next_z, on_first_branch, before_first);
+    value = UpdateRegretsWith(*state.Child(legal[a]), player, next_z, on_branch, depth, b1);
   } else {
     for (size_t a = 0; a < legal.size(); ++a) {
-      if (on_first_branch && before_first) (*on_first_branch)(static_cast<int>(a));
-      child_values[a] = UpdateRegretsWith(*state.Child(legal[a]), player, next_z, on_first_branch, false);
+      const int ai = static_cast<int>(a);
+      if (on_branch && depth == 0) (*on_branch)(1, ai, 0);
+      if (on_branch && depth == 1) (*on_branch)(2, b1, ai);
+      child_values[a] = UpdateRegretsWith(*state.Child(legal[a]), player, next_z, on_branch, depth + 1, depth == 0 ? ai : b1);
       value += copy.current_policy[a] * child_values[a];
     }
   }

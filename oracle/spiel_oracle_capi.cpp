@@ -735,8 +735,9 @@ int osgo_cfr_iterate(void* h, int iters) {
 // The DEVICE's mini-batch schedule of external-sampling MCCFR, restated on the
 // oracle's solver: trajectories [first, first+count) all read the table as it
 // is at the start of the call (trajectory g: traverser g mod P, uniforms from CounterRng(seed, g, 0).Unit() in
-// visiting order down to the traverser's first node and from CounterRng(seed, g, 1 + b) inside that node's child b:
-// the device spreads those subtrees over lanes); their regret / average-policy
+// visiting order down to the traverser's first node, then from that generator with its counter jumped per subtree —
+// by 1 + b1 inside that node's child b1 down to the traverser's next node, by 16 + 8 b1 + b2 inside that node's child
+// b2: the device spreads those subtrees over lanes); their regret / average-policy
 // increments (external_sampling_mccfr.cc:167-183) are summed and folded in at
 // the end.  With count == 1 this is exactly one UpdateRegrets call.
 int osgo_mccfr_minibatch(void* h, uint64_t seed, int64_t first, int64_t count) {
@@ -755,9 +756,13 @@ int osgo_mccfr_minibatch(void* h, uint64_t seed, int64_t first, int64_t count) {
       const CFRInfoStateValuesTable frozen = table;
       CounterRng rng(seed, static_cast<uint64_t>(g), 0);
       if (c->mccfr) {
-        // the device's streams: (seed, g, 0) down to the traverser's first node, (seed, g, 1 + b) inside its child b
-        const std::function<void(int)> branch = [&rng, seed, g](int b) {
-          rng = CounterRng(seed, static_cast<uint64_t>(g), 1 + static_cast<uint64_t>(b));
+        // the device's streams (csrc/osg_cfr.hip es_stream; osg_common.h Rng::jump_to): stream (seed, g, 0) down to the
+        // traverser's first node; its counter jumped by 1 + b1 inside that node's child b1 down to the traverser's next
+        // node on that path, by 16 + 8 b1 + b2 inside that node's child b2
+        const uint64_t s0 = rng.s;
+        const std::function<void(int, int, int)> branch = [&rng, s0](int level, int b1, int b2) {
+          const uint64_t id = level == 1 ? 1 + static_cast<uint64_t>(b1) : 16 + 8 * static_cast<uint64_t>(b1) + static_cast<uint64_t>(b2);
+          rng.s = s0 + id * 0xD6E8FEB86659FD93ULL;
         };
         c->mccfr->UpdateRegretsWith(*c->game->NewInitialState(), static_cast<Player>(g % P),
                                     [&rng]() { return rng.Unit(); }, &branch);

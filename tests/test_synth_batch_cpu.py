@@ -2,6 +2,8 @@
 the restatement and the genuine reference build draw the same batch, the result does not depend on the number of
 worker threads or on how an index range is cut into shards, and a pure-Python walk of the recipe over the oracle's
 State API reproduces single states."""
+import os
+
 import numpy as np
 import pytest
 
@@ -111,3 +113,18 @@ def test_synth_mcts_replay_equals_single_root_replay(oracle):
         assert out["best_action"][i] == want["best_action"]
         for act, cnt, tot, _ in want["children"]:
             assert out["child_visits"][i, int(act)] == cnt and out["child_reward"][i, int(act)] == tot
+
+
+def test_sub_stream_jumps_never_meet():
+    """Rng::jump_to (csrc/osg_common.h; restated in oracle/spiel_oracle_capi.cpp): sub-stream id starts at s0 + id * kJump
+    and advances by kStep per draw, so two sub-streams of one trajectory would draw the same counter only after
+    (id1 - id2) * kJump / kStep steps modulo 2^64: astronomically many for every pair of ids a traversal opens."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "open_spiel_amd", "csrc", "osg_common.h")).read()
+    k_jump = int(re.search(r"kJump = (0x[0-9A-Fa-f]+)ULL", src).group(1), 16)
+    k_step = int(re.search(r"s \+= (0x[0-9A-Fa-f]+)ULL;", src).group(1), 16)
+    m = 1 << 64
+    inv = pow(k_step, -1, m)
+    for d in range(1, 129):
+        steps = (d * k_jump * inv) % m
+        assert min(steps, m - steps) > 1 << 56, d

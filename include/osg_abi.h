@@ -406,7 +406,12 @@ int osg_mccfr_iterate(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64
 /* The sampling half of osg_mccfr_iterate: zero the delta tables, run the traversals,
  * leave the regret / average-policy deltas in the delta tables (osg_mccfr_delta_ptrs)
  * WITHOUT folding them in.  Trajectory g (global index) draws from the counter stream
- * (seed, g) and updates player g mod P, so a batch can be split across GPUs by index. */
+ * (seed, g) and updates player g mod P, so a batch can be split across GPUs by index.
+ * External sampling: the draws below the traverser's first two nodes come from sub-streams
+ * of (seed, g) — one per child subtree, in visiting order inside it — so that small
+ * mini-batches can walk those subtrees on separate lanes (same sums as on one lane;
+ * csrc/osg_cfr.hip es_stream, restated by the oracle's replay).  osg_mccfr_apply_deltas
+ * leaves the delta tables zero. */
 int osg_mccfr_sample(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_t trajectories);
 /* Device pointers to the [I, Amax] fp64 tables: regrets, cumulative policy,
  * current policy (for RCCL all-reduce by the caller, or inspection). */

@@ -21,6 +21,10 @@ for game, which in (("tic_tac_toe", 0), ("leduc_poker", 0), ("leduc_poker", 1), 
     print(f"{game:12s} which={which} [{n}, {size}]  {us:8.1f} us  {bytes_ / us / 8e6:.3f} of 8 TB/s  checksum {float(out[::4097].sum()):.1f}", flush=True)
     del out, b
 ''' % ROOT
-for lds in ("0", "4", "8"):
+for lds in ("default", "0", "4", "8"):
     print(f"-- OSG_OBS_LDS={lds}", flush=True)
-    subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, OSG_OBS_LDS=lds), check=False)
+    env = dict(os.environ)
+    env.pop("OSG_OBS_LDS", None)
+    if lds != "default":
+        env["OSG_OBS_LDS"] = lds
+    subprocess.run([sys.executable, "-c", CHILD], env=env, check=False)

@@ -529,7 +529,7 @@ struct SplitTree {
   const int32_t* mem_hloc;       // [G, NM] its history, local index
   const int32_t* info_list;      // [G, NI] infostates with a member in the subtree, -1 = padding
   double* terms;                 // [2][M][kSplitRec]: buffer (pass parity) x {own reach or -1, A regret terms} per member
-  unsigned int* bar;             // [0] arrival counter, [1] error flag (both zeroed before every launch), [2] sticky error
+  unsigned int* bar;             // [0] arrival counter (zero between launches), [1] error flag, [2] sticky error, [3] exit counter
   unsigned int* host_err;        // pinned host word raised on a timeout: the host's next call reads it without a copy
 };
 
@@ -768,6 +768,15 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
       tb.regrets[c_i * A + a] = regrets[c_i * A + a];
       tb.cum[c_i * A + a] = cum[c_i * A + a];
       tb.cur[c_i * A + a] = cur[c_i * A + a];
+    }
+  }
+  // the last workgroup to leave zeroes the barrier's counters for the next launch (every workgroup has passed the last
+  // barrier by then): no fill launch per call — 5 us of a one-iteration launch's ~50
+  if (tid == 0) {
+    const unsigned int left = __hip_atomic_fetch_add(&sp.bar[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == static_cast<unsigned int>(sp.G) - 1u) {
+      __hip_atomic_store(&sp.bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sp.bar[3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -3556,7 +3565,8 @@ int osg_cfr_reset(osg_cfr* s) { return init_tables(s); }
 // into an error.  The cooperative launch waits until the whole grid fits.  br: the CFR-BR pass set (d_best overrides).
 static int launch_split(osg_cfr* s, SmallTree stree, SplitTree sp, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg, bool br) {
   hipStream_t st = s->ctx->stream;
-  OSG_HIP(hipMemsetAsync(s->d_split_bar, 0, sizeof(unsigned int) * 2, st));
+  // (the barrier's counters are zero: build_split zeroed them and every launch leaves them so; a launch that timed out
+  // does not — and makes the solver unusable, cfr_sub_error)
   const dim3 grid(static_cast<unsigned>(s->split_G)), block(static_cast<unsigned>(s->split_threads));
   Tree tr = s->tree();
   const int32_t* best = br ? s->d_best : nullptr;

@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -49,6 +50,23 @@ constexpr int kMaxFrames = 24;  // traverser decision nodes on one path
 constexpr double kMccfrInit = 0.000001;  // external_sampling_mccfr.h:59 kInitialTableValues
 
 enum NodeKind : uint8_t { kChanceNode = 0, kDecisionNode = 1, kTerminalNode = 2 };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is one value per KERNEL, not per solver: a second solver with a smaller
+// footprint must not lower the cap under a first one that is still in use.  Raises only.
+hipError_t raise_lds_cap(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::unordered_map<std::string, int> cap;   // per (device, kernel)
+  int device = 0;
+  (void)hipGetDevice(&device);
+  std::lock_guard<std::mutex> lock(mu);
+  int& have = cap[std::to_string(device) + ":" + std::to_string(reinterpret_cast<uintptr_t>(kernel))];
+  if (bytes <= have) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
+}
+
+
 
 struct Tree {  // device pointers
   int H, I, A, P, D;
@@ -2977,8 +2995,7 @@ int build_resident_tree(osg_cfr* s) {
                             reinterpret_cast<const void*>(&k_os_mccfr_resident<2>),
                             reinterpret_cast<const void*>(&k_os_mccfr_resident<3>),
                             reinterpret_cast<const void*>(&k_os_mccfr_resident<4>)};
-  if (hipFuncSetAttribute(variants[(s->cfg.solver == 2 ? 4 : 0) + s->A - 1], hipFuncAttributeMaxDynamicSharedMemorySize,
-                          static_cast<int>(s->resident_lds_bytes)) != hipSuccess) {
+  if (raise_lds_cap(variants[(s->cfg.solver == 2 ? 4 : 0) + s->A - 1], static_cast<int>(s->resident_lds_bytes)) != hipSuccess) {
     (void)hipGetLastError();
     return OSG_OK;
   }
@@ -2990,8 +3007,7 @@ int build_resident_tree(osg_cfr* s) {
                                   reinterpret_cast<const void*>(&k_mccfr_resident<4, 2>)};
   for (int level = 0; level < 2; ++level)
     if (s->cfg.solver != 2 && s->A >= 2 &&
-        hipFuncSetAttribute(split_variants[2 * (s->A - 1) + level], hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(s->resident_lds_bytes)) != hipSuccess) {
+        raise_lds_cap(split_variants[2 * (s->A - 1) + level], static_cast<int>(s->resident_lds_bytes)) != hipSuccess) {
       (void)hipGetLastError();
       return OSG_OK;
     }
@@ -3093,7 +3109,7 @@ int build_split(osg_cfr* s) {
   const void* variants[] = {reinterpret_cast<const void*>(&k_cfr_split<3>), reinterpret_cast<const void*>(&k_cfr_split<4>),
                             reinterpret_cast<const void*>(&k_cfr_split<kMaxPlayers + 1>)};
   for (const void* f : variants)
-    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
+    if (raise_lds_cap(f, static_cast<int>(lds)) != hipSuccess) {
       (void)hipGetLastError();
       return OSG_OK;
     }
@@ -3103,7 +3119,7 @@ int build_split(osg_cfr* s) {
   s->split_br_ok = lds + sizeof(double) * IA <= 158 * 1024;
   for (const void* f : br_variants)
     if (s->split_br_ok &&
-        hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds + sizeof(double) * IA)) != hipSuccess) {
+        raise_lds_cap(f, static_cast<int>(lds + sizeof(double) * IA)) != hipSuccess) {
       (void)hipGetLastError();
       s->split_br_ok = false;
     }
@@ -3223,8 +3239,7 @@ int build_eval_jobs(osg_cfr* s) {
   OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_jobs_ticket), sizeof(unsigned int) * 4));
   OSG_HIP(hipMemsetAsync(s->d_jobs_deal, 0, sizeof(double) * 2 * P * G, st));
   OSG_HIP(hipMemsetAsync(s->d_jobs_ticket, 0, sizeof(unsigned int) * 4, st));
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval_jobs), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          static_cast<int>(lds)) != hipSuccess) {
+  if (raise_lds_cap(reinterpret_cast<const void*>(&k_eval_jobs), static_cast<int>(lds)) != hipSuccess) {
     (void)hipGetLastError();
     return OSG_OK;
   }
@@ -3361,7 +3376,7 @@ int build_sub(osg_cfr* s) {
   for (int i = 0; i < s->I; ++i) widest = std::max(widest, s->mem_off[i + 1] - s->mem_off[i]);
   if (widest > std::min<int>(static_cast<int>((NL + static_cast<size_t>(ND) * s->A) / (2 * s->A + 1)), kSubFoldX * kSubThreads)) return OSG_OK;
   const void* kern = K == 2 ? cfr_sub_kernel<2>() : (K == 4 ? cfr_sub_kernel<4>() : cfr_sub_kernel<8>());
-  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess) {
+  if (raise_lds_cap(kern, static_cast<int>(lds)) != hipSuccess) {
     (void)hipGetLastError();
     return OSG_OK;
   }
@@ -3460,8 +3475,7 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
   s->lds_bytes = sizeof(double) * (static_cast<size_t>(s->H) * (2 * s->P + 1) + 3 * IA);
   s->lds_resident = s->lds_bytes <= 96 * 1024;
   if (s->lds_resident) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cfr<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(s->lds_bytes));
+    e = raise_lds_cap(reinterpret_cast<const void*>(&k_cfr<true>), static_cast<int>(s->lds_bytes));
     if (e != hipSuccess) { (void)hipGetLastError(); s->lds_resident = false; }
   }
   {  // the all-in-LDS kernel for small trees
@@ -3499,7 +3513,7 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
       e = hipSuccess;
       for (const void* f : variants)
         if (e == hipSuccess)
-          e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->small_lds_bytes));
+          e = raise_lds_cap(f, static_cast<int>(s->small_lds_bytes));
       if (e != hipSuccess) { (void)hipGetLastError(); s->small_tree = false; }
     }
   }
@@ -3826,8 +3840,7 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
     if (use_lds) {
       static bool os_attr_set = false;
       if (!os_attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_os_mccfr<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)raise_lds_cap(reinterpret_cast<const void*>(&k_os_mccfr<true>), 64 * 1024);
         os_attr_set = true;
       }
       k_os_mccfr<true><<<dim3(static_cast<unsigned>(blocks)), dim3(256), lds, st>>>(
@@ -3842,8 +3855,7 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
   if (use_lds) {
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mccfr<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      (void)raise_lds_cap(reinterpret_cast<const void*>(&k_mccfr<true>), 64 * 1024);
       attr_set = true;
     }
     k_mccfr<true><<<dim3(static_cast<unsigned>(blocks)), dim3(256), lds, st>>>(s->tree(), s->regrets(), dreg,

@@ -601,3 +601,23 @@ def test_cfr_br_on_the_split_kernel_equals_the_one_workgroup_passes(ctx, monkeyp
     ctx.synchronize()
     rate = 300 / (time.perf_counter() - t0)
     assert rate > 8000.0, rate
+
+
+def test_a_smaller_solver_does_not_lower_the_lds_cap_under_a_larger_one(ctx):
+    """The dynamic-LDS cap is an attribute of a KERNEL: a later solver of a smaller game must not lower it under an
+    earlier solver that is still in use (leduc's kernels need more than the 64 KB default)."""
+    import open_spiel_amd as osa
+    big = osa.TabularSolver(ctx, "leduc_poker")
+    big_m = osa.TabularSolver(ctx, "leduc_poker", mccfr=True)
+    big.evaluate_and_update_policy(2)
+    before = big.nash_conv()
+    for game in ("leduc_poker(suit_isomorphism=True)", "kuhn_poker", "kuhn_poker(players=3)"):
+        small = osa.TabularSolver(ctx, game)
+        small.evaluate_and_update_policy(2)
+        small.nash_conv()
+        sm = osa.TabularSolver(ctx, game, mccfr=True)
+        sm.run_mccfr(3, 1000)
+    big.evaluate_and_update_policy(2)           # the kernels of the first solvers launch with their own footprint
+    big_m.run_mccfr(3, 5000)
+    big.evaluate_and_update_policy_cfr_br(0)
+    assert big.nash_conv() < before and np.isfinite(big_m.nash_conv())

@@ -79,7 +79,11 @@ const char* osg_last_error(void);
 /* ---- context ------------------------------------------------------------ */
 /* own_stream != 0: the library creates (and owns) a non-blocking stream and
  * `stream` is ignored.  own_stream == 0: `stream` is a hipStream_t owned by the
- * caller (e.g. torch's current stream; NULL is the device's default stream). */
+ * caller (e.g. torch's current stream; NULL is the device's default stream).
+ * The engine is written for one process per GPU: osg_ctx_create makes `device` the calling
+ * thread's current device and later calls launch on the context's stream without selecting it
+ * again — a process that holds contexts on several devices makes the context's device current
+ * (hipSetDevice) on the calling thread before each call. */
 int osg_ctx_create(int device, void* stream, int own_stream, osg_ctx** out);
 int osg_ctx_destroy(osg_ctx* ctx);
 int osg_ctx_synchronize(osg_ctx* ctx);

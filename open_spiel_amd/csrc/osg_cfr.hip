@@ -2648,7 +2648,7 @@ struct osg_cfr {
           *d_jobs_glob = nullptr, *d_jobs_info = nullptr, *d_jobs_mem = nullptr;
   double* d_jobs_deal = nullptr;
   unsigned int* d_jobs_ticket = nullptr;
-  double* h_eval_out = nullptr;  // pinned: [2 P] results, then the split kernel's sticky error word
+  double* h_eval_out = nullptr;  // pinned, mapped: the evaluation kernels write their [2 P] results here
   // LDS-resident MCCFR traversal (k_mccfr_resident)
   bool resident_ok = false;
   size_t resident_lds_bytes = 0;
@@ -3532,7 +3532,7 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
   rc = build_split(s);
   if (rc == OSG_OK) rc = build_sub(s);
   if (rc == OSG_OK) rc = build_eval_jobs(s);
-  if (rc == OSG_OK && hipHostMalloc(reinterpret_cast<void**>(&s->h_eval_out), sizeof(double) * (2 * s->P + 1)) != hipSuccess) {
+  if (rc == OSG_OK && hipHostMalloc(reinterpret_cast<void**>(&s->h_eval_out), sizeof(double) * (2 * s->P + 1), hipHostMallocMapped) != hipSuccess) {
     (void)hipGetLastError();
     rc = set_error(OSG_ERR_NOMEM, "osg_cfr_create: pinned result buffer");
   }
@@ -4147,14 +4147,15 @@ static int evaluate_policy_impl(osg_cfr* s, int which_policy, const double* h_po
   ea.value = s->d_eval;
   ea.brv = ea.value + static_cast<size_t>(s->H) * P;
   ea.cf = ea.brv + s->H;
-  ea.out = ea.cf + M;
-  double* d_pol = ea.out + 2 * P;
+  double* d_pol = ea.cf + M + 2 * P;
+  // the 2 P results land in pinned host memory straight from the kernel (the device address of h_eval_out): the call is a
+  // launch and a wait — no copy-back launches (two of them were ~10 us of a 45 us call)
+  OSG_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&ea.out), s->h_eval_out, 0));
   ea.best = s->d_best;
   if (h_history_values) {  // the responder's value of every history: kept in d_reach ([H, P + 1] doubles, free here)
     ea.keep = s->d_reach;
     ea.keep_r = keep_responder;
   }
-  s->h_eval_out[2 * P] = 0.0;
   if (s->jobs_ok && OSG_EVAL_JOBS_ENABLED()) {
     // the tables never leave the device: the average policy is formed from the cumulative table inside the jobs
     const double* src = which_policy == 0 ? s->cum() : which_policy == 1 ? s->cur() : d_pol;
@@ -4170,16 +4171,11 @@ static int evaluate_policy_impl(osg_cfr* s, int which_policy, const double* h_po
     k_policy_eval<<<dim3(1), dim3(threads), 0, st>>>(s->tree(), ea, src, which_policy == 0 ? 1 : 0, d_pol);
     OSG_HIP(hipGetLastError());
   }
-  if (s->split_ok && which_policy != 2)  // the tables are only as good as the launches that wrote them
-    OSG_HIP(hipMemcpyAsync(reinterpret_cast<unsigned int*>(s->h_eval_out + 2 * P), s->d_split_bar + 2, sizeof(unsigned int),
-                           hipMemcpyDeviceToHost, st));
-  OSG_HIP(hipMemcpyAsync(s->h_eval_out, ea.out, sizeof(double) * 2 * P, hipMemcpyDeviceToHost, st));
   if (h_history_values)
     OSG_HIP(hipMemcpyAsync(h_history_values, s->d_reach, sizeof(double) * s->H, hipMemcpyDeviceToHost, st));
   OSG_HIP(hipStreamSynchronize(st));
-  if (*reinterpret_cast<unsigned int*>(s->h_eval_out + 2 * P) != 0u)
-    return set_error(OSG_ERR_HIP, "k_cfr_split: a grid barrier timed out after seconds (the launch is cooperative: this is a hung "
-                                  "device, not contention); the tables are not usable — osg_cfr_cfg.kernel = 3 runs one workgroup");
+  if (which_policy != 2)   // the tables are only as good as the launches that wrote them (the kernels raise the pinned word)
+    if (int rc = cfr_sub_error(s)) return rc;
   const double* out = s->h_eval_out;
   double nc = 0.0, total_br = 0.0;
   for (int p = 0; p < P; ++p) {

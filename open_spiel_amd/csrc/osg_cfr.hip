@@ -1372,6 +1372,97 @@ k_policy_eval(Tree t, EvalArrays ea, const double* pol, int from_cum = 0, double
 }
 
 // ---------------------------------------------------------------------------
+// The same evaluation for LARGE trees (3-player leduc: 1.83 M histories — one workgroup walks them in 33 ms): one
+// full-grid launch per tree level and phase, the stream order is the barrier (the form of k_gcfr_*).  The sums are
+// k_policy_eval's, node by node and infostate by infostate, in the same order: bit-identical results.
+//   k_geval_policy   the evaluated policy from the cumulative table (mode 0)
+//   k_geval_ev       expected returns of one level
+//   k_geval_cf       counterfactual reaches of responder r's decision histories
+//   k_geval_best     the argmax of r's infostates whose members sit on level l
+//   k_geval_brv      responder values of one level; the root's value into out[P + r]
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_geval_policy(Tree t, const double* __restrict__ cum, double* __restrict__ pol) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= t.I) return;
+  const int n = t.nact[i], A = t.A;
+  double sum = 0.0;
+  for (int a = 0; a < n; ++a) sum += cum[i * A + a];
+  for (int a = 0; a < A; ++a) pol[i * A + a] = a >= n ? 0.0 : (sum == 0.0 ? 1. / n : cum[i * A + a] / sum);
+}
+__global__ void __launch_bounds__(256) k_geval_ev(Tree t, EvalArrays ea, const double* __restrict__ pol, int l) {
+  const int P = t.P, A = t.A;
+  const int h = t.level_off[l] + blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= t.level_off[l + 1]) return;
+  const int k = t.kind[h];
+  if (k == kTerminalNode) {
+    for (int q = 0; q < P; ++q) ea.value[h * P + q] = t.term_ret[h * P + q];
+  } else {
+    const int fc = t.first_child[h], nc = t.nchild[h];
+    const int row = k == kDecisionNode ? t.info[h] * A : 0;
+    for (int q = 0; q < P; ++q) {
+      double v = 0.0;
+      for (int a = 0; a < nc; ++a) {
+        const double pr = k == kChanceNode ? t.edge_prob[fc + a] : pol[row + a];
+        if (pr > 0.0) v += pr * ea.value[(fc + a) * P + q];
+      }
+      ea.value[h * P + q] = v;
+    }
+  }
+  if (h == 0) for (int q = 0; q < P; ++q) ea.out[q] = ea.value[q];
+}
+__global__ void __launch_bounds__(256) k_geval_cf(Tree t, EvalArrays ea, const double* __restrict__ pol, int r) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= ea.M) return;
+  const int h = t.mem[m];
+  if (t.actor[h] != r) return;
+  double cf = 1.0;
+  for (int e = ea.path_off[m]; e < ea.path_off[m + 1]; ++e) {
+    const int code = ea.path[e];
+    const int slot = (code >> 24) & 0xF, idx = code & 0x7FFFFF;
+    const double pr = ((code >> 23) & 1) ? t.edge_prob[idx] : (slot == r ? 1.0 : pol[idx]);
+    cf = cf * pr;
+  }
+  ea.cf[m] = cf;
+}
+__global__ void __launch_bounds__(256) k_geval_best(Tree t, EvalArrays ea, int r, int l) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= t.I || t.info_player[i] != r || ea.info_level[i] != l) return;
+  const int n = t.nact[i];
+  int best = -1;
+  double best_v = -1.7976931348623157e308;  // numeric_limits<double>::lowest()
+  for (int a = 0; a < n; ++a) {
+    double v = 0.0;
+    for (int m = t.mem_off[i]; m < t.mem_off[i + 1]; ++m) v += ea.cf[m] * ea.brv[t.first_child[t.mem[m]] + a];
+    if (v > best_v) { best_v = v; best = a; }
+  }
+  ea.best[i] = best < 0 ? 0 : best;
+}
+__global__ void __launch_bounds__(256) k_geval_brv(Tree t, EvalArrays ea, const double* __restrict__ pol, int r, int l) {
+  const int P = t.P, A = t.A;
+  const int h = t.level_off[l] + blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= t.level_off[l + 1]) return;
+  const int k = t.kind[h];
+  double v = 0.0;
+  if (k == kTerminalNode) {
+    v = t.term_ret[h * P + r];
+  } else {
+    const int fc = t.first_child[h], nc = t.nchild[h];
+    if (k == kDecisionNode && t.actor[h] == r) {
+      v += 1.0 * ea.brv[fc + ea.best[t.info[h]]];
+    } else {
+      const int row = k == kDecisionNode ? t.info[h] * A : 0;
+      for (int a = 0; a < nc; ++a) {
+        const double pr = k == kChanceNode ? t.edge_prob[fc + a] : pol[row + a];
+        v += pr * ea.brv[fc + a];
+      }
+    }
+  }
+  ea.brv[h] = v;
+  if (ea.keep && r == ea.keep_r) ea.keep[h] = v;
+  if (h == 0) ea.out[P + r] = v;
+}
+
+// ---------------------------------------------------------------------------
 // The same evaluation for trees that start with their chance deals (leduc_poker: two deal levels, then 30 subtrees
 // of 314 histories), spread over the device instead of one workgroup walking 9 457 histories level by level through
 // L2.  The quantities are independent below the cut once the work is grouped the right way:
@@ -2685,6 +2776,36 @@ static EvalJobs eval_jobs_of(const osg_cfr* s) {
   return ej;
 }
 
+// Trees beyond one workgroup's reach (and too large for the jobs) are evaluated with a launch per level and phase
+// (k_geval_*); OSG_EVAL_GRID=1 forces that form, 0 forbids it (the tests compare the three).
+static bool eval_takes_the_grid(const osg_cfr* s) {
+  const char* e = getenv("OSG_EVAL_GRID");
+  if (e && e[0] == '0') return false;
+  if (e && e[0] == '1') return true;
+  return s->H > 65536;
+}
+static int launch_grid_eval(const osg_cfr* s, const EvalArrays& ea, const double* src, bool from_cum, double* d_pol, bool only_br) {
+  hipStream_t st = s->ctx->stream;
+  const Tree t = s->tree();
+  const double* pol = src;
+  if (from_cum) {
+    k_geval_policy<<<dim3((s->I + 255) / 256), dim3(256), 0, st>>>(t, src, d_pol);
+    pol = d_pol;
+  }
+  auto width = [&](int l) { return static_cast<unsigned>((s->level_off[l + 1] - s->level_off[l] + 255) / 256); };
+  if (!only_br)
+    for (int l = s->D - 1; l >= 0; --l) k_geval_ev<<<dim3(width(l)), dim3(256), 0, st>>>(t, ea, pol, l);
+  const unsigned mblocks = static_cast<unsigned>((s->mem.size() + 255) / 256), iblocks = static_cast<unsigned>((s->I + 255) / 256);
+  for (int r = 0; r < s->P; ++r) {
+    k_geval_cf<<<dim3(std::max(1u, mblocks)), dim3(256), 0, st>>>(t, ea, pol, r);
+    for (int l = s->D - 1; l >= 0; --l) {
+      k_geval_best<<<dim3(std::max(1u, iblocks)), dim3(256), 0, st>>>(t, ea, r, l);
+      k_geval_brv<<<dim3(width(l)), dim3(256), 0, st>>>(t, ea, pol, r, l);
+    }
+  }
+  OSG_HIP(hipGetLastError());
+  return OSG_OK;
+}
 // OSG_EVAL_JOBS=0 keeps the one-workgroup evaluation (k_policy_eval) for trees that could take the jobs: the tests
 // compare the two.
 static bool OSG_EVAL_JOBS_ENABLED() {
@@ -3999,6 +4120,7 @@ int osg_cfr_br_iterate(osg_cfr* s, int iters) {
                s->d_split_terms, s->d_split_bar, s->h_sub_err};
   for (int it = 0; it < iters; ++it) {
     if (jobs) k_eval_jobs<<<dim3(s->jobs_J), dim3(s->jobs_threads), s->jobs_lds_bytes, st>>>(s->tree(), ea, eval_jobs_of(s), s->cur(), 1, 1);
+    else if (eval_takes_the_grid(s)) { if (int rc = launch_grid_eval(s, ea, s->cur(), false, nullptr, true)) return rc; }
     else k_policy_eval<<<dim3(1), dim3(threads), 0, st>>>(s->tree(), ea, s->cur());
     if (split) {
       const int rc = launch_split(s, stree, sp, tb, 1, s->iteration, cfg, true);
@@ -4163,6 +4285,10 @@ static int evaluate_policy_impl(osg_cfr* s, int which_policy, const double* h_po
     k_eval_jobs<<<dim3(s->jobs_J), dim3(s->jobs_threads), s->jobs_lds_bytes, st>>>(s->tree(), ea, eval_jobs_of(s), src,
                                                                                    which_policy == 0 ? 0 : 1, 0);
     OSG_HIP(hipGetLastError());
+  } else if (eval_takes_the_grid(s)) {
+    const double* src = which_policy == 0 ? s->cum() : which_policy == 1 ? s->cur() : d_pol;
+    if (which_policy == 2) OSG_HIP(hipMemcpyAsync(d_pol, h_policy, sizeof(double) * IA, hipMemcpyHostToDevice, st));
+    if (int rc = launch_grid_eval(s, ea, src, which_policy == 0, d_pol, false)) return rc;
   } else {
     const double* src = which_policy == 0 ? s->cum() : which_policy == 1 ? s->cur() : d_pol;
     if (which_policy == 2) OSG_HIP(hipMemcpyAsync(d_pol, h_policy, sizeof(double) * IA, hipMemcpyHostToDevice, st));

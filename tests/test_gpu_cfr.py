@@ -553,15 +553,20 @@ def test_evaluation_jobs_are_bit_identical_with_the_one_workgroup_evaluation(ctx
         monkeypatch.delenv("OSG_EVAL_JOBS", raising=False)
         got = _judge_everything(s, which, tab)
         monkeypatch.setenv("OSG_EVAL_JOBS", "0")
+        monkeypatch.setenv("OSG_EVAL_GRID", "0")
         want = _judge_everything(s, which, tab)
-        for k in ("nash_conv", "exploitability"):
-            assert got[0][k] == want[0][k], (which, k)
-        np.testing.assert_array_equal(got[0]["expected_returns"], want[0]["expected_returns"])
-        np.testing.assert_array_equal(got[0]["best_response_values"], want[0]["best_response_values"])
-        np.testing.assert_array_equal(got[1], want[1])
-        np.testing.assert_array_equal(got[2], want[2])
-        for a, b in zip(got[3], want[3]):
-            np.testing.assert_array_equal(a, b)
+        monkeypatch.setenv("OSG_EVAL_GRID", "1")         # a launch per level and phase (what the large trees take)
+        grid = _judge_everything(s, which, tab)
+        monkeypatch.delenv("OSG_EVAL_GRID")
+        for other in (got, grid):
+            for k in ("nash_conv", "exploitability"):
+                assert other[0][k] == want[0][k], (which, k)
+            np.testing.assert_array_equal(other[0]["expected_returns"], want[0]["expected_returns"])
+            np.testing.assert_array_equal(other[0]["best_response_values"], want[0]["best_response_values"])
+            np.testing.assert_array_equal(other[1], want[1])
+            np.testing.assert_array_equal(other[2], want[2])
+            for a, b in zip(other[3], want[3]):
+                np.testing.assert_array_equal(a, b)
 
 
 def test_leduc_evaluation_takes_the_jobs_and_is_fast(ctx):
@@ -621,3 +626,26 @@ def test_a_smaller_solver_does_not_lower_the_lds_cap_under_a_larger_one(ctx):
     big_m.run_mccfr(3, 5000)
     big.evaluate_and_update_policy_cfr_br(0)
     assert big.nash_conv() < before and np.isfinite(big_m.nash_conv())
+
+
+def test_large_tree_evaluation_takes_the_grid_and_equals_the_one_workgroup_walk(ctx, monkeypatch):
+    """3-player leduc_poker (1.83 M histories): the evaluation is a launch per level and phase (k_geval_*), bit-identical
+    with the one-workgroup walk and tens of times faster (33 ms per call on one workgroup)."""
+    import time
+    import open_spiel_amd as osa
+    s = osa.TabularSolver(ctx, "leduc_poker(players=3)")
+    s.evaluate_and_update_policy(3)
+    s.evaluate_policy()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    got = s.evaluate_policy()
+    fast = time.perf_counter() - t0
+    monkeypatch.setenv("OSG_EVAL_GRID", "0")
+    t0 = time.perf_counter()
+    want = s.evaluate_policy()
+    slow = time.perf_counter() - t0
+    monkeypatch.delenv("OSG_EVAL_GRID")
+    assert got["nash_conv"] == want["nash_conv"]
+    np.testing.assert_array_equal(got["expected_returns"], want["expected_returns"])
+    np.testing.assert_array_equal(got["best_response_values"], want["best_response_values"])
+    assert fast < slow / 5, (fast, slow)

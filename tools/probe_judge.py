@@ -17,3 +17,11 @@ for game in ("leduc_poker", "kuhn_poker"):
         s.evaluate_and_update_policy_cfr_br(400); ctx.synchronize()
         t3 = time.perf_counter()
         print(f"{game} jobs={jobs}: nash_conv {(t1 - t0) / 100 * 1e6:.1f} us/call ({nc:.6f}), cfr-br {400 / (t3 - t2):.0f} it/s", flush=True)
+
+# the largest tree served: one evaluation of 3-player leduc_poker (1.83 M histories; its deal components do not fit a
+# workgroup's LDS, so the one-workgroup kernel runs)
+os.environ["OSG_EVAL_JOBS"] = "1"
+s3 = osa.TabularSolver(ctx, "leduc_poker(players=3)")
+s3.evaluate_and_update_policy(2); s3.nash_conv(); ctx.synchronize()
+t0 = time.perf_counter(); nc = s3.nash_conv(); dt = time.perf_counter() - t0
+print(f"leduc_poker(players=3): nash_conv {dt * 1e3:.2f} ms/call ({nc:.6f})", flush=True)

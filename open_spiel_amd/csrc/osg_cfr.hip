@@ -3764,8 +3764,12 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
       OSG_HIP(hipMemsetAsync(s->d_sub_bar, 0, sizeof(unsigned int) * 2, st));
       void* args[] = {&tr, &stree, &sp, &tb, &now, &it0, &s->cfg};
       const void* kern = s->sub_K == 2 ? cfr_sub_kernel<2>() : (s->sub_K == 4 ? cfr_sub_kernel<4>() : cfr_sub_kernel<8>());
-      OSG_HIP(hipLaunchCooperativeKernel(kern, dim3(static_cast<unsigned>(s->sub_grid)), dim3(kSubThreads), args,
-                                         static_cast<unsigned>(s->sub_lds_bytes), st));
+      // (OSG_CFR_PLAIN_LAUNCH=1 as for k_cfr_split: an ordinary launch, for hosts that own the device — and for runs under
+      // rocprofv3 --kernel-trace, where a process that made a cooperative launch crashes in an exit handler)
+      static const bool plain = std::getenv("OSG_CFR_PLAIN_LAUNCH") && std::getenv("OSG_CFR_PLAIN_LAUNCH")[0] == '1';
+      if (plain) OSG_HIP(hipLaunchKernel(kern, dim3(static_cast<unsigned>(s->sub_grid)), dim3(kSubThreads), args, s->sub_lds_bytes, st));
+      else OSG_HIP(hipLaunchCooperativeKernel(kern, dim3(static_cast<unsigned>(s->sub_grid)), dim3(kSubThreads), args,
+                                              static_cast<unsigned>(s->sub_lds_bytes), st));
     }
     if (sp.stamps) {
       unsigned long long h[8 * kMaxPlayers];

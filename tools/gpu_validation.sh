@@ -34,7 +34,10 @@ echo "bench exit $?" | tee -a "$OUT/summary.txt"
 tail -c 3000 "$OUT/bench_n1.log" | tee -a "$OUT/summary.txt"
 
 echo "== rocprofv3 --kernel-trace --stats" | tee -a "$OUT/summary.txt"
-timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -- python bench.py --no-cpu-baseline > "$OUT/trace.log" 2>&1
+# (OSG_CFR_PLAIN_LAUNCH=1: on ROCm 7.0.2 a process that made a COOPERATIVE launch crashes in an exit handler under
+#  rocprofv3 --kernel-trace — after the tool has written its output — tools/probe_exit_under_tracer.sh; the traced run
+#  launches the two barrier kernels with ordinary launches, same kernels, same durations)
+OSG_CFR_PLAIN_LAUNCH=1 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -- python bench.py --no-cpu-baseline > "$OUT/trace.log" 2>&1
 echo "trace exit $?" | tee -a "$OUT/summary.txt"
 DB=$(find "$OUT/trace" -name '*.db' | head -1)
 if [ -n "$DB" ]; then python tools/rocpd_summary.py "$DB" > "$OUT/kernel_stats.csv" 2>> "$OUT/trace.log"; fi

@@ -492,6 +492,19 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
                 judge[g]["cfr_br_iterations_per_s"] = 300 / (time.perf_counter() - t0)
                 judge[g]["cfr_br_nash_conv_after_305"] = sb.nash_conv()
                 del sj, sb
+            try:   # the largest tree served: a launch per level and phase (k_geval_*; one workgroup walked it in 33 ms)
+                s3 = osa.TabularSolver(ctx, "leduc_poker(players=3)")
+                s3.evaluate_and_update_policy(2)
+                s3.nash_conv()
+                ctx.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    nc3 = s3.nash_conv()
+                judge["leduc_poker(players=3)"] = {"ms_per_nash_conv": (time.perf_counter() - t0) / 5 * 1e3,
+                                                   "nash_conv_after_2_iterations": nc3, "histories": 1831601}
+                del s3
+            except Exception as e:  # noqa: BLE001
+                judge["leduc_poker(players=3)"] = {"error": f"{type(e).__name__}: {e}"}
             out["policy_evaluation"] = {"metric": "NashConv evaluations (osg_cfr_evaluate_policy: expected returns + one best response "
                                                   "per player on the flattened tree)", "per_game": judge,
                                         "note": "host call to host result; the tables stay on the device (the average policy is "

@@ -210,6 +210,7 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
     """BASELINE.json configs 3-5 next to the headline: hex(9) MCTS sims/s (roots sharded over the
     ranks: strong scaling), kuhn CFR iterations/s (replicas only) and leduc ES-MCCFR trajectories/s
     (trajectories sharded, one RCCL all-reduce of the delta tables per mini-batch)."""
+    import numpy as np
     from open_spiel_amd import distributed as osd
     out = {}
 
@@ -301,9 +302,27 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
     fence()
     dt = time.perf_counter() - t0
     out["cfr"] = {"metric": "CFR iterations/sec", "value": iters / dt, "unit": "iterations/s", "seconds": dt,
-                  "scaling": "replicas only",
+                  "scaling": "replicas only", "kernel": solver.last_kernel(),
                   "config": {"workload": f"kuhn_poker CFRSolver, {iters} EvaluateAndUpdatePolicy in one launch, "
                                          "58 histories / 12 infostates, LDS-resident"}}
+    if rank == 0 and with_cpu:
+        # what the timed launch left behind, against the CPU solver run for the same number of iterations (the checker
+        # only: oracle/parity.py; the genuine reference build when it loads)
+        try:
+            import parity
+            impl, kind = cpu_checker()
+            t = solver.tables()
+            rec = parity.cfr_tables(impl, "kuhn_poker", "cfr", 100 + iters, t["keys"], t["nact"], t["regrets"],
+                                    t["cum_policy"], t["avg_policy"])
+            rec["against"] = ("oracle/_ref (the reference's CFRSolver, cfr.cc:263-469)" if kind == "reference"
+                              else "oracle restatement of cfr.cc:263-469")
+            rec["what"] = (f"regrets, cumulative policy and average policy of all 12 infostates after the 100 warm-up + {iters} "
+                           "timed iterations, against the CPU solver run for the same 20 100 iterations")
+            out["cfr"]["parity"] = rec
+            out["cfr"]["parity_checked_iterations"] = rec["iterations"]
+        except AssertionError as e:
+            out["cfr"]["parity"] = {"error": str(e)}
+            out["cfr"]["parity_checked_iterations"] = 0
     del solver
     # the same kernel with one workgroup per independent solver (random initial regrets): what the GPU does
     # with this config when asked for many solves at once
@@ -370,13 +389,23 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
     sharded.run_minibatch(SEED, 1 << 12)
     fence()
     batch, nb = 1 << 20, 16
+    # Timed in two bracketed segments, 15 mini-batches + 1, so that the LAST timed mini-batch can be checked: between the
+    # segments (outside both clocks) the tables are copied on the device; afterwards the CPU replays that mini-batch's
+    # 2^20 trajectories on the copied table and every cell of "table after - table before" is compared.
     t0 = time.perf_counter()
-    for _ in range(nb):
+    for _ in range(nb - 1):
         sharded.run_minibatch(SEED, batch)
     fence()
-    dt = max_over_ranks(time.perf_counter() - t0)
+    dt_a = time.perf_counter() - t0
+    snap = [t.clone() for t in solver.device_tables()[:2]] if (rank == 0 and with_cpu) else None
+    last_first = sharded.trajectories_done
+    fence()
+    t0 = time.perf_counter()
+    sharded.run_minibatch(SEED, batch)
+    fence()
+    dt = max_over_ranks(dt_a + time.perf_counter() - t0)
     out["mccfr"] = {"metric": "ES-MCCFR trajectories/sec", "value": batch * nb / dt, "unit": "trajectories/s",
-                    "seconds": dt, "scaling": "strong",
+                    "seconds": dt, "scaling": "strong", "kernel": solver.last_kernel(),
                     "config": {"workload": f"leduc_poker external-sampling MCCFR, 2^24 trajectories in {nb} mini-batches "
                                            f"of 2^20 sharded over {world} rank(s), "
                                            + ("one all-reduce of 2 x [936,3] fp64 per mini-batch" if world > 1
@@ -384,6 +413,29 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
     # NashConv of the average policy after the 2^24 trajectories (device judge,
     # the same numbers as the oracle's TabularBestResponse to 1e-12: tests/test_gpu_cfr.py)
     out["mccfr"]["nash_conv_after"] = float(solver.nash_conv())
+    if snap is not None:
+        try:
+            import parity
+            impl, kind = cpu_checker()
+            t = solver.tables()
+            reg0, cum0 = snap[0].cpu().numpy(), snap[1].cpu().numpy()
+            scale = np.maximum(np.maximum(np.abs(reg0), np.abs(t["regrets"])), np.maximum(np.abs(cum0), np.abs(t["cum_policy"])))
+            t0 = time.perf_counter()
+            rec = parity.mccfr_minibatch(impl, "leduc_poker", t["keys"], t["nact"], reg0, t["regrets"] - reg0,
+                                         t["cum_policy"] - cum0, SEED, last_first, batch, host_threads(), table_scale=scale)
+            rec["cpu_seconds"] = time.perf_counter() - t0
+            rec["against"] = ("UpdateRegrets (external_sampling_mccfr.cc:122-186) replayed on the frozen table over "
+                              + ("oracle/_ref's game rules, SampleAction and regret matching" if kind == "reference"
+                                 else "the oracle restatement") + f", {host_threads()} host threads")
+            rec["what"] = (f"the last timed mini-batch (trajectories [{last_first}, {last_first + batch}), all ranks' shards): every "
+                           "regret and average-policy cell of table-after minus table-before, tolerance 1e-11 of the cell's "
+                           "|increment| mass + 8 ulps of the tables (summation order only)")
+            out["mccfr"]["parity"] = rec
+            out["mccfr"]["parity_checked_trajectories"] = rec["trajectories"]
+        except AssertionError as e:
+            out["mccfr"]["parity"] = {"error": str(e)}
+            out["mccfr"]["parity_checked_trajectories"] = 0
+        del snap
     if world > 1:  # the exchange step on its own: one all-reduce of the two delta tables
         flat = solver.mccfr_delta_flat()
         osd.allreduce_sum_(flat)

@@ -372,6 +372,10 @@ int osg_cfr_reset(osg_cfr* s);
 int osg_cfr_iterate(osg_cfr* s, int iters);
 /* Number of EvaluateAndUpdatePolicy calls (or MCCFR mini-batches) done so far. */
 int osg_cfr_iteration(const osg_cfr* s);
+/* Diagnostic: the kernel family the solver's last iterate / sample call launched ("k_cfr_small<lds, owner>", "k_cfr_split",
+ * "k_mccfr_resident_flat", "k_mccfr_resident<split 2>", ...; "" before the first launch or for the remaining forms).  The
+ * parity tests and bench.py record it next to what they checked (no reference counterpart). */
+const char* osg_cfr_last_kernel(const osg_cfr* s);
 /* Number of replicas, and which one the table accessors / osg_cfr_evaluate_policy / upload act on. */
 int osg_cfr_replicas(const osg_cfr* s);
 int osg_cfr_select_replica(osg_cfr* s, int replica);

@@ -415,6 +415,10 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
 #pragma unroll
         for (int q = 0; q < kSlots; ++q) reach[q] = 1.0;
         if (kOwner && b_fast) {
+          // (opaque per pass: otherwise every `slot == q` comparison is hoisted out of the iteration loop as a lane mask
+          // in a scalar register pair and spilled to vector lanes — see k_cfr_split)
+#pragma unroll
+          for (int j = 0; j < kOwnerPath; ++j) asm volatile("" : "+v"(b_code[j]));
           double pr[kOwnerPath];
 #pragma unroll
           for (int j = 0; j < kOwnerPath; ++j) pr[j] = cur[b_code[j] >= 0 ? (b_code[j] & 0x7FFFFF) : 0];
@@ -567,8 +571,12 @@ constexpr int kSplitChunk = 6;       // members whose records are requested toge
 // kBr: the pass set of CFRBRSolver::EvaluateAndUpdatePolicy (cfr_br.cc:70-81) — P passes, pass p updates player p while
 // every other player follows best[i] (k_eval_jobs wrote it): the pass reads an effective policy `eff` (the updating
 // player's rows of `cur`, one-hot rows for the others) that is rebuilt in LDS at the start of every pass.
-template <int kSlots, bool kBr = false>  // kSlots >= P + 1
-__global__ void __launch_bounds__(1024)
+// kBound: the launch bound the instantiation is compiled for.  A subtree of leduc is 314 histories = 320 threads = 5
+// wavefronts, at most 2 per SIMD: compiled for 1024 threads the kernel was capped at 128 VGPRs and spilled (24 vector +
+// 69 scalar registers, 84 B of scratch per lane — round 4's code object); compiled for 512 it has 256 and keeps
+// everything in registers.  split_kernel() picks the instantiation by the launch size.
+template <int kSlots, bool kBr = false, int kBound = 1024>  // kSlots >= P + 1
+__global__ void __launch_bounds__(kBound)
 k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg,
             const int32_t* __restrict__ best = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -673,6 +681,12 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
       // ---- B: the thread's decision history: reach from its root path, regret / average-policy terms ----
       double* terms = sp.terms + static_cast<size_t>(epoch & 1u) * M * kSplitRec;  // the pass's buffer: [M][1 + kSplitMaxA]
       if (b_m >= 0 && (upd < 0 || b_pl == upd)) {
+        // (the path codes are loop-invariant per thread: left alone, the compiler hoists every `slot == q` comparison out
+        // of the iteration loop as a 64-bit lane mask in a scalar register pair — 10 entries x kSlots masks = 60+ scalar
+        // registers held across the loop and spilled to vector lanes.  An empty asm makes the codes opaque per pass, so
+        // the comparisons are formed where they are used: ~30 vector compares per pass instead of 69 spilled registers)
+#pragma unroll
+        for (int j = 0; j < kOwnerPath; ++j) asm volatile("" : "+v"(b_code[j]));
         double pr[kOwnerPath];
 #pragma unroll
         for (int j = 0; j < kOwnerPath; ++j) pr[j] = pol[b_code[j] >= 0 ? (b_code[j] & 0x7FFFFF) : 0];
@@ -797,6 +811,20 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
       __hip_atomic_store(&sp.bar[3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+template <int kBound>
+static const void* split_kernel_bound(int P, bool br) {
+  if (br) return P == 2 ? reinterpret_cast<const void*>(&k_cfr_split<3, true, kBound>)
+                        : (P == 3 ? reinterpret_cast<const void*>(&k_cfr_split<4, true, kBound>)
+                                  : reinterpret_cast<const void*>(&k_cfr_split<kMaxPlayers + 1, true, kBound>));
+  return P == 2 ? reinterpret_cast<const void*>(&k_cfr_split<3, false, kBound>)
+                : (P == 3 ? reinterpret_cast<const void*>(&k_cfr_split<4, false, kBound>)
+                          : reinterpret_cast<const void*>(&k_cfr_split<kMaxPlayers + 1, false, kBound>));
+}
+// The instantiation for a launch of `threads` threads per workgroup (see kBound above).
+static const void* split_kernel(int P, bool br, int threads) {
+  return threads <= 512 ? split_kernel_bound<512>(P, br) : split_kernel_bound<1024>(P, br);
 }
 
 // ---------------------------------------------------------------------------
@@ -2678,6 +2706,7 @@ struct osg_cfr {
   int max_level_width = 0;
   int average_type = 0;  // ES-MCCFR AverageType: 0 kSimple, 1 kFull (external_sampling_mccfr.h:48)
   int iteration = 0;
+  const char* last_kernel = "";  // the kernel family the last iterate / sample call launched (osg_cfr_last_kernel)
   // host tree
   std::vector<int32_t> level_off, parent, first_child, info, mem_off, mem, nact, legal;
   std::vector<uint8_t> kind, nchild, aidx;
@@ -3227,23 +3256,16 @@ int build_split(osg_cfr* s) {
   OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_split_bar), sizeof(unsigned int) * 4));
   OSG_HIP(hipMemsetAsync(s->d_split_bar, 0, sizeof(unsigned int) * 4, st));
   OSG_HIP(hipMemsetAsync(s->d_split_terms, 0, sizeof(double) * 2 * kSplitRec * std::max<size_t>(M, 1), st));
-  const void* variants[] = {reinterpret_cast<const void*>(&k_cfr_split<3>), reinterpret_cast<const void*>(&k_cfr_split<4>),
-                            reinterpret_cast<const void*>(&k_cfr_split<kMaxPlayers + 1>)};
-  for (const void* f : variants)
-    if (raise_lds_cap(f, static_cast<int>(lds)) != hipSuccess) {
-      (void)hipGetLastError();
-      return OSG_OK;
-    }
+  if (raise_lds_cap(split_kernel(s->P, false, threads), static_cast<int>(lds)) != hipSuccess) {
+    (void)hipGetLastError();
+    return OSG_OK;
+  }
   // the CFR-BR pass set keeps one more [I, A] array (the effective policy)
-  const void* br_variants[] = {reinterpret_cast<const void*>(&k_cfr_split<3, true>), reinterpret_cast<const void*>(&k_cfr_split<4, true>),
-                               reinterpret_cast<const void*>(&k_cfr_split<kMaxPlayers + 1, true>)};
   s->split_br_ok = lds + sizeof(double) * IA <= 158 * 1024;
-  for (const void* f : br_variants)
-    if (s->split_br_ok &&
-        raise_lds_cap(f, static_cast<int>(lds + sizeof(double) * IA)) != hipSuccess) {
-      (void)hipGetLastError();
-      s->split_br_ok = false;
-    }
+  if (s->split_br_ok && raise_lds_cap(split_kernel(s->P, true, threads), static_cast<int>(lds + sizeof(double) * IA)) != hipSuccess) {
+    (void)hipGetLastError();
+    s->split_br_ok = false;
+  }
   s->split_G = G; s->split_L = L; s->split_NL = NL; s->split_NM = NM; s->split_NI = NI; s->split_threads = threads;
   s->split_lds_bytes = lds;
   s->split_ok = true;
@@ -3706,13 +3728,7 @@ static int launch_split(osg_cfr* s, SmallTree stree, SplitTree sp, Tables tb, in
   Tree tr = s->tree();
   const int32_t* best = br ? s->d_best : nullptr;
   void* args[] = {&tr, &stree, &sp, &tb, &iters, &iteration0, &cfg, &best};
-  const void* kern;
-  if (br) kern = s->P == 2 ? reinterpret_cast<const void*>(&k_cfr_split<3, true>)
-                           : (s->P == 3 ? reinterpret_cast<const void*>(&k_cfr_split<4, true>)
-                                        : reinterpret_cast<const void*>(&k_cfr_split<kMaxPlayers + 1, true>));
-  else kern = s->P == 2 ? reinterpret_cast<const void*>(&k_cfr_split<3>)
-                        : (s->P == 3 ? reinterpret_cast<const void*>(&k_cfr_split<4>)
-                                     : reinterpret_cast<const void*>(&k_cfr_split<kMaxPlayers + 1>));
+  const void* kern = split_kernel(s->P, br, s->split_threads);
   const size_t lds = s->split_lds_bytes + (br ? sizeof(double) * static_cast<size_t>(s->I) * s->A : 0);
   // OSG_CFR_PLAIN_LAUNCH=1: an ordinary launch, for hosts that run the solver alone on the device — the cooperative
   // launch costs 20 us per call (47.6 vs 27.6 us per one-iteration launch, CFR-BR 1.30e4 vs 1.82e4 it/s), which only the
@@ -3826,6 +3842,7 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
     }
     OSG_HIP(hipGetLastError());
     s->iteration += iters;
+    s->last_kernel = "k_cfr_split";
     return OSG_OK;
   }
   if (s->path_kernel && s->cfg.kernel != 1) {
@@ -3843,10 +3860,13 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
     if (s->small_tree && s->H <= 1024) {  // one thread per history: descriptors live in registers
       const int owner_threads = std::max(64, ((s->H + 63) / 64) * 64);
       OSG_CFR_SMALL(true, true, owner_threads, s->small_lds_bytes);
+      s->last_kernel = "k_cfr_small<lds, owner>";
     } else if (s->small_tree) {
       OSG_CFR_SMALL(true, false, threads, s->small_lds_bytes);
+      s->last_kernel = "k_cfr_small<lds>";
     } else {
       OSG_CFR_SMALL(false, false, threads, 0);
+      s->last_kernel = "k_cfr_small<global>";
     }
 #undef OSG_CFR_SMALL
   } else if (s->B > 1) {
@@ -3950,6 +3970,9 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
     }
 #undef OSG_MCCFR_RES
     OSG_HIP(hipGetLastError());
+    s->last_kernel = s->cfg.solver == 2 ? "k_os_mccfr_resident"
+                                        : (split == 2 && s->A >= 2 ? "k_mccfr_resident<split 2>"
+                                                                   : (split == 1 && s->A >= 2 ? "k_mccfr_resident<split 1>" : "k_mccfr_resident_flat"));
     if (d_stamps && s->cfg.solver != 2 && split != 0) {   // (the flat kernel writes no stamps)
       unsigned long long h[4];
       OSG_HIP(hipMemcpyAsync(h, d_stamps, sizeof h, hipMemcpyDeviceToHost, st));
@@ -4218,6 +4241,7 @@ int osg_cfr_infostate_key(const osg_cfr* s, int64_t i, char* buf, int cap) {
 }
 
 int osg_cfr_iteration(const osg_cfr* s) { return s ? s->iteration : 0; }
+const char* osg_cfr_last_kernel(const osg_cfr* s) { return s ? s->last_kernel : ""; }
 int osg_cfr_infostate_player(const osg_cfr* s, int64_t i) { return (s && i >= 0 && i < s->I) ? s->info_player[i] : -1; }
 int osg_cfr_replicas(const osg_cfr* s) { return s ? s->B : 0; }
 int osg_cfr_select_replica(osg_cfr* s, int replica) {

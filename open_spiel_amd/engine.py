@@ -436,6 +436,10 @@ class TabularSolver:
     def iteration(self):
         return lib().osg_cfr_iteration(self._h)
 
+    def last_kernel(self):
+        """The kernel family the last iterate / sample call launched (diagnostic, osg_cfr_last_kernel)."""
+        return lib().osg_cfr_last_kernel(self._h).decode()
+
     def run_mccfr(self, seed, trajectories, first_trajectory=0):
         """One mini-batch of external-sampling traversals, folded into the tables."""
         check(lib().osg_mccfr_iterate(self._h, int(seed), int(first_trajectory), int(trajectories)))

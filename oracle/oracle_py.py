@@ -384,6 +384,25 @@ for _alt in (0, 1):
             SOLVER_KINDS[f"cfr_base_alt{_alt}_lin{_lin}_rmp{_rmp}"] = 16 + _alt + 2 * _lin + 4 * _rmp
 
 
+def mccfr_frozen_replay(game, keys, regrets, seed, first, count, threads=1):
+    """Summed ES-MCCFR (kSimple) increments of trajectories [first, first + count) against ONE frozen table
+    (osgo_mccfr_frozen_replay: the device's mini-batch at its real size, `threads` trajectories at a time).
+    keys: infostate strings, regrets: [len(keys), amax] float64 (rows not listed count as 1e-6).
+    Returns dict(d_regrets, d_cum_policy, mass [rows, amax], visits [rows])."""
+    regrets = np.ascontiguousarray(regrets, np.float64)
+    n, amax = regrets.shape
+    assert n == len(keys)
+    d_reg = np.zeros((n, amax), np.float64)
+    d_cum = np.zeros((n, amax), np.float64)
+    mass = np.zeros((n, amax), np.float64)
+    visits = np.zeros(n, np.int64)
+    _check(lib().osgo_mccfr_frozen_replay(game._h, C.c_uint64(seed), C.c_int64(first), C.c_int64(count), int(threads),
+                                          n, amax, "\n".join(keys).encode(), _ptr(regrets, C.c_double),
+                                          _ptr(d_reg, C.c_double), _ptr(d_cum, C.c_double), _ptr(mass, C.c_double),
+                                          _ptr(visits, C.c_int64)))
+    return dict(d_regrets=d_reg, d_cum_policy=d_cum, mass=mass, visits=visits)
+
+
 class Solver:
     """CFRSolver / CFRPlusSolver / ExternalSamplingMCCFRSolver of the oracle."""
 

@@ -14,6 +14,7 @@
 #include <map>
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -809,6 +810,124 @@ int osgo_mccfr_minibatch(void* h, uint64_t seed, int64_t first, int64_t count) {
     return 0;
   });
 #endif
+}
+// A FULL-SIZE mini-batch of the device's external-sampling MCCFR on the CPU, in seconds instead of hours: the summed
+// regret / average-policy increments of trajectories [first, first + count) against ONE frozen table, `threads`
+// trajectories at a time.  osgo_mccfr_minibatch above copies the whole table per trajectory (fine for 500
+// trajectories, hopeless for 2^20); here the traversal of external_sampling_mccfr.cc:122-186 (AverageType::kSimple) is
+// written against the frozen rows directly — regrets READ from the caller's table (a row the caller does not list
+// counts as its initial 1e-6, external_sampling_mccfr.h:59), increments ADDED to a per-thread delta table — which is the
+// same function of (table, uniforms) because a traversal never meets an infostate twice (perfect recall: the key holds
+// the traverser's own actions).  Everything game-side is the library's own State (Child, LegalActions, ChanceOutcomes,
+// InformationStateString, PlayerReturn), SampleAction (spiel.cc:372-409) and CFRInfoStateValues::ApplyRegretMatching /
+// SampleActionIndex (cfr.cc:596-628), so in the -DOSGO_GENUINE_REFERENCE build the rules, keys and regret matching are
+// the reference's own code.  Streams: the device's (see osgo_mccfr_minibatch).  Per-thread sums are added in thread
+// order; `mass` returns, per row and action, the sum of |regret increment| — the scale a summation-order tolerance is
+// stated against.  keys: n_rows newline-separated infostate strings; regrets / out arrays are [n_rows, amax] row-major.
+namespace {
+struct FrozenReplay {
+  const Game* game = nullptr;
+  int P = 0, amax = 0;
+  const std::unordered_map<std::string, int>* index = nullptr;
+  const double* regrets = nullptr;
+  std::vector<double> d_reg, d_cum, mass;
+  std::vector<int64_t> visits;
+  CounterRng rng{0};
+  uint64_t s0 = 0;
+  double Walk(const State& state, Player player, int depth, int b1) {
+    if (state.IsTerminal()) return state.PlayerReturn(player);                    // :125-127
+    if (state.IsChanceNode()) {                                                   // :127-131
+      const Action a = SampleAction(state.ChanceOutcomes(), rng.Unit()).first;
+      return Walk(*state.Child(a), player, depth, b1);
+    }
+    const Player cur = state.CurrentPlayer();                                     // :132-146
+    const std::string key = state.InformationStateString(cur);
+    const std::vector<Action> legal = state.LegalActions();
+    const int n = static_cast<int>(legal.size());
+    CFRInfoStateValues copy(legal, ExternalSamplingMCCFRSolver::kInitialTableValues);
+    auto it = index->find(key);
+    const int row = it == index->end() ? -1 : it->second;
+    if (row >= 0)
+      for (int a = 0; a < n; ++a) copy.cumulative_regrets[a] = regrets[static_cast<size_t>(row) * amax + a];
+    copy.ApplyRegretMatching();
+    double value = 0;
+    std::vector<double> child_values(n, 0.0);
+    if (cur != player) {                                                          // :150-154
+      const int a = copy.SampleActionIndex(0.0, rng.Unit());
+      value = Walk(*state.Child(legal[a]), player, depth, b1);
+    } else {                                                                      // :155-162
+      for (int a = 0; a < n; ++a) {
+        if (depth == 0) rng.s = s0 + (1 + static_cast<uint64_t>(a)) * 0xD6E8FEB86659FD93ULL;
+        if (depth == 1) rng.s = s0 + (16 + 8 * static_cast<uint64_t>(b1) + static_cast<uint64_t>(a)) * 0xD6E8FEB86659FD93ULL;
+        child_values[a] = Walk(*state.Child(legal[a]), player, depth + 1, depth == 0 ? a : b1);
+        value += copy.current_policy[a] * child_values[a];
+      }
+    }
+    if (row < 0) throw std::runtime_error("osgo_mccfr_frozen_replay: infostate not in the caller's table: " + key);
+    ++visits[row];
+    if (cur == player)                                                            // :164-172
+      for (int a = 0; a < n; ++a) {
+        const double term = child_values[a] - value;
+        d_reg[static_cast<size_t>(row) * amax + a] += term;
+        mass[static_cast<size_t>(row) * amax + a] += std::fabs(term);
+      }
+    if (cur == ((player + 1) % P))                                                // :177-183 (kSimple)
+      for (int a = 0; a < n; ++a) d_cum[static_cast<size_t>(row) * amax + a] += copy.current_policy[a];
+    return value;
+  }
+};
+}  // namespace
+
+int osgo_mccfr_frozen_replay(void* g, uint64_t seed, int64_t first, int64_t count, int threads, int n_rows, int amax,
+                             const char* keys, const double* regrets, double* d_regrets, double* d_cum, double* mass,
+                             int64_t* visits) {
+  return Guard([&] {
+    ORACLE_CHECK(g && keys && regrets && d_regrets && d_cum && mass && visits && threads >= 1 && count >= 0);
+    const std::string game_string = static_cast<GameH*>(g)->game->ToString();
+    std::unordered_map<std::string, int> index;
+    {
+      const char* p = keys;
+      for (int r = 0; r < n_rows; ++r) {
+        const char* e = std::strchr(p, '\n');
+        std::string k = e ? std::string(p, e) : std::string(p);
+        index.emplace(std::move(k), r);
+        p = e ? e + 1 : p + std::strlen(p);
+      }
+      ORACLE_CHECK(static_cast<int>(index.size()) == n_rows);
+    }
+    const size_t cells = static_cast<size_t>(n_rows) * amax;
+    std::vector<FrozenReplay> w(threads);
+    std::vector<std::shared_ptr<const Game>> games(threads);  // one Game per thread (see osgo_bench_env_steps)
+    std::vector<std::string> errors(threads);
+    std::vector<std::thread> workers;
+    for (int t = 0; t < threads; ++t) {
+      games[t] = LoadGame(game_string);
+      FrozenReplay& r = w[t];
+      r.game = games[t].get(); r.P = games[t]->NumPlayers(); r.amax = amax; r.index = &index; r.regrets = regrets;
+      r.d_reg.assign(cells, 0.0); r.d_cum.assign(cells, 0.0); r.mass.assign(cells, 0.0); r.visits.assign(n_rows, 0);
+      const int64_t lo = first + count * t / threads, hi = first + count * (t + 1) / threads;
+      workers.emplace_back([&r, &errors, t, lo, hi, seed] {
+        try {
+          for (int64_t traj = lo; traj < hi; ++traj) {
+            r.rng = CounterRng(seed, static_cast<uint64_t>(traj), 0);
+            r.s0 = r.rng.s;
+            r.Walk(*r.game->NewInitialState(), static_cast<Player>(traj % r.P), 0, 0);
+          }
+        } catch (const std::exception& e) { errors[t] = e.what(); }
+      });
+    }
+    for (auto& t : workers) t.join();
+    for (const std::string& e : errors) if (!e.empty()) throw std::runtime_error(e);
+    std::fill(d_regrets, d_regrets + cells, 0.0);
+    std::fill(d_cum, d_cum + cells, 0.0);
+    std::fill(mass, mass + cells, 0.0);
+    std::fill(visits, visits + n_rows, 0);
+    for (int t = 0; t < threads; ++t) {
+      for (size_t k = 0; k < cells; ++k) { d_regrets[k] += w[t].d_reg[k]; d_cum[k] += w[t].d_cum[k]; mass[k] += w[t].mass[k]; }
+      for (int r = 0; r < n_rows; ++r) visits[r] += w[t].visits[r];
+    }
+    return 0;
+  });
 }
 // ExternalSamplingMCCFRSolver::FullUpdateAverage (external_sampling_mccfr.cc:188-231) on the table as it is: the
 // second half of a kFull RunIteration, so that the device's mini-batch + full-average schedule can be replayed.

@@ -210,3 +210,65 @@ def test_config4_all_roots_against_the_oracle_replay(ctx, oracle, checker):
     assert torch.equal(part["child_visits"], got["child_visits"][first:first + count])
     assert torch.equal(part["child_reward"], got["child_reward"][first:first + count])
     print(f"config 4: {n} roots checked against the {kind}, {n} searches x {sims} simulations against the oracle replay")
+
+
+def test_config3_kuhn_cfr_1000_iterations_against_the_reference(ctx, checker):
+    """Config 3 at its stated size: 1 000 EvaluateAndUpdatePolicy of kuhn_poker in ONE launch of
+    k_cfr_small<lds, owner> — the kernel bench.py times — against the reference's CFRSolver run for 1 000 iterations
+    (cfr.cc:263-469): cumulative regrets and cumulative policy of all 12 infostates to 1e-9 relative, average policy
+    to 1e-6 (north_star); then the launch split 100 + 900 gives the same tables bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import parity
+    import open_spiel_amd as osa
+    impl, kind = checker
+    s = osa.TabularSolver(ctx, "kuhn_poker")
+    s.evaluate_and_update_policy(1000)
+    assert s.last_kernel() == "k_cfr_small<lds, owner>"
+    t = s.tables()
+    rec = parity.cfr_tables(impl, "kuhn_poker", "cfr", 1000, t["keys"], t["nact"], t["regrets"], t["cum_policy"], t["avg_policy"])
+    assert rec["max_table_rel_error"] <= 1e-9 and rec["max_average_policy_abs_error"] <= 1e-6
+    s2 = osa.TabularSolver(ctx, "kuhn_poker")
+    s2.evaluate_and_update_policy(100)
+    s2.evaluate_and_update_policy(900)
+    t2 = s2.tables()
+    for name in ("regrets", "cum_policy", "cur_policy"):
+        assert np.array_equal(t[name], t2[name]), name
+    print(f"config 3: 1000 iterations, 12 infostates against the {kind}: tables within {rec['max_table_rel_error']:.2e} relative, "
+          f"average policy within {rec['max_average_policy_abs_error']:.2e}")
+
+
+@pytest.mark.parametrize("warm_batches", [0, 3])
+def test_config5_full_minibatch_against_the_frozen_table_replay(ctx, checker, warm_batches):
+    """Config 5 at its timed size: ONE WHOLE 2^20-trajectory leduc_poker mini-batch of k_mccfr_resident_flat — the
+    kernel and the mini-batch size bench.py times — against the CPU's UpdateRegrets replay of the same 2^20
+    trajectories on the frozen table (external_sampling_mccfr.cc:122-186 on the device's counter streams;
+    oracle/spiel_oracle_capi.cpp osgo_mccfr_frozen_replay, bound to the genuine reference build where it exists):
+    every regret and average-policy increment of all 936 infostates.  Tolerance 1e-11 x the cell's |increment|
+    mass (summation order only; oracle/parity.py says why).  From the initial table (warm_batches = 0: the uniform
+    policy) and from a table three mini-batches old (a non-uniform policy, like the bench's later mini-batches)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import parity
+    import open_spiel_amd as osa
+    impl, kind = checker
+    game, n = "leduc_poker", 1 << 20
+    s = osa.TabularSolver(ctx, game, mccfr=True)
+    first = 0
+    for _ in range(warm_batches):
+        s.run_mccfr(SEED, 1 << 16, first_trajectory=first)
+        first += 1 << 16
+    before = s.tables()
+    s.mccfr_sample(SEED, n, first_trajectory=first)
+    assert s.last_kernel() == "k_mccfr_resident_flat"
+    dreg, dcum = [t.cpu().numpy().copy() for t in s.mccfr_delta_tables()]
+    rec = parity.mccfr_minibatch(impl, game, before["keys"], before["nact"], before["regrets"], dreg, dcum, SEED, first, n,
+                                 _threads())
+    assert rec["trajectories"] == n and rec["infostates_visited"] == 936
+    # the fold adds exactly these deltas: table after == table before + delta, cell by cell
+    s.mccfr_apply_deltas()
+    after = s.tables()
+    np.testing.assert_array_equal(after["regrets"], before["regrets"] + dreg)
+    np.testing.assert_array_equal(after["cum_policy"], before["cum_policy"] + dcum)
+    print(f"config 5: {n} trajectories ({rec['infostate_visits']} infostate visits, {rec['cells']} cells) against the {kind}: "
+          f"worst cell {rec['max_error_over_mass']:.2e} of its mass")

@@ -345,3 +345,52 @@ def test_rollout_replay_sums_are_identical(oracle, reference, game_string):
         b_sum, b_steps = rg.replay_rollouts(hist, 99, 1000 + i, 16)
         assert a_steps == b_steps > 0
         assert np.array_equal(a_sum, b_sum)
+
+
+@pytest.mark.parametrize("game_string,warm,count", [
+    ("kuhn_poker", 50, 400),
+    ("leduc_poker", 40, 300),
+    ("kuhn_poker(players=3)", 30, 200),
+])
+def test_frozen_table_replay_pins(oracle, reference, game_string, warm, count):
+    """osgo_mccfr_frozen_replay (the full-size checker of the device's ES-MCCFR mini-batch: config 5's parity
+    record in tests/test_gpu_timed_batch.py and bench.py) against (a) the slow per-trajectory hook
+    osgo_mccfr_minibatch of the restatement — same streams, same frozen table, sums in the same trajectory order
+    with one thread: equal to the last few ulps of the table-minus-table differences the slow hook forms — and
+    (b) itself on the GENUINE reference build, whose State / SampleAction / regret matching are the reference's
+    own code: bit for bit, one thread and several (per-thread sums are added in thread order)."""
+    og = oracle.Game(game_string)
+    slow = oracle.Solver(og, "mccfr_simple", seed=0)
+    slow.iterate(warm)                      # a table that is not all 1e-6 (and does not hold every infostate yet)
+    t0 = slow.tables()
+    seed, first = 0xFEED5, 1000
+    slow.mccfr_minibatch(seed, first, count)
+    t1 = slow.tables()
+    # rows the warm-up never created are discovered by the mini-batch: list every row of t1, frozen values from t0
+    idx0 = {k: i for i, k in enumerate(t0["keys"])}
+    keys = list(t1["keys"])
+    amax = t1["regrets"].shape[1]
+    frozen = np.full((len(keys), amax), 1e-6)
+    cum0 = np.full((len(keys), amax), 1e-6)
+    for j, k in enumerate(keys):
+        if k in idx0:
+            frozen[j] = t0["regrets"][idx0[k]]
+            cum0[j] = t0["cum_policy"][idx0[k]]
+    fast = oracle.mccfr_frozen_replay(og, keys, frozen, seed, first, count, threads=1)
+    for j, k in enumerate(keys):
+        n = int(t1["nact"][j])
+        np.testing.assert_allclose(frozen[j, :n] + fast["d_regrets"][j, :n], t1["regrets"][j, :n], rtol=1e-12, atol=1e-12,
+                                   err_msg=f"{game_string} regrets at {k!r}")
+        np.testing.assert_allclose(cum0[j, :n] + fast["d_cum_policy"][j, :n], t1["cum_policy"][j, :n], rtol=1e-12,
+                                   atol=1e-12, err_msg=f"{game_string} cum_policy at {k!r}")
+    assert int(fast["visits"].sum()) > count      # every trajectory visits several infostates
+    assert (np.abs(fast["d_regrets"]) <= fast["mass"] + 1e-300).all()
+    rg = reference.Game(game_string)
+    for threads in (1, 3):
+        a = oracle.mccfr_frozen_replay(og, keys, frozen, seed, first, count, threads=threads)
+        b = reference.mccfr_frozen_replay(rg, keys, frozen, seed, first, count, threads=threads)
+        for name in ("d_regrets", "d_cum_policy", "mass", "visits"):
+            assert np.array_equal(a[name], b[name]), f"{game_string} {name} threads={threads}"
+    # thread count only changes the order of the final per-thread adds
+    np.testing.assert_allclose(a["d_regrets"], fast["d_regrets"], rtol=0, atol=1e-11 * max(1.0, fast["mass"].max()))
+    assert np.array_equal(a["visits"], fast["visits"])

@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Per-kernel resource table of the shipped gfx950 code objects.
+
+Reads the AMDGPU metadata note (`llvm-readelf --notes`) of every code object bundled in
+open_spiel_amd/libosg_hip.so and prints, for every `__global__` entry point: vector / accumulator / scalar
+registers, spilled registers, scratch bytes per lane, static LDS, the launch bound the kernel was compiled for and
+the wavefronts per SIMD the register count allows (gfx950: 512 VGPRs per SIMD lane in granules of 8, at most 8
+wavefronts per SIMD).  Needs no GPU.
+
+  python tools/kernel_resources.py                     # table on stdout
+  python tools/kernel_resources.py --out profiles/r05_kernel_resources.txt
+  python tools/kernel_resources.py --check             # exit 1 if a kernel named in HOT spills
+
+`tools/gpu_validation.sh` runs it with --check so a spill in a hot kernel cannot come back unnoticed.
+"""
+import argparse
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+# Kernels on a BASELINE config or named by a VERDICT: these must not spill (prefix match on the demangled name).
+HOT = [
+    "k_step_c4std2", "k_step_c4std<", "k_step_hexvec<3, 2",
+    "k_cfr_small<true, true, 3>", "k_cfr_split<3, false", "k_cfr_split<3, true",
+    "k_mcts_wave<(anonymous namespace)::HexT<3>, true, true, false",
+    "k_env_step<(anonymous namespace)::C4T<6, 7, 4, unsigned long>",
+]
+# Kernels whose scratch is the design (a per-lane frame stack), listed so the check knows them.
+SCRATCH_BY_DESIGN = ["k_mccfr<", "k_os_mccfr<", "k_mccfr_full_average"]
+
+
+def demangle(names):
+    p = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True)
+    return p.stdout.split("\n")[:len(names)]
+
+
+def code_objects(lib, tmp):
+    """Unbundle every gfx950 code object of `lib` into tmp; returns their paths."""
+    dst = os.path.join(tmp, os.path.basename(lib))
+    shutil.copy(lib, dst)
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", dst], capture_output=True, text=True, check=True)
+    return sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if "amdgcn" in f)
+
+
+def kernels_of(obj):
+    txt = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", obj], capture_output=True, text=True, check=True).stdout
+    m = re.search(r"^\s*---\n(.*?)^\s*\.\.\.\s*$", txt, re.S | re.M)
+    if not m:
+        return []
+    # the note is indented by the tool only on its first lines; the YAML document itself starts at column 0
+    meta = yaml.safe_load(m.group(1))
+    return meta.get("amdhsa.kernels", [])
+
+
+def waves_per_simd(vgpr, agpr):
+    tot = vgpr + agpr
+    if tot <= 0:
+        return 8
+    gran = (tot + 7) // 8 * 8
+    return max(1, min(8, 512 // gran))
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "")
+    name = re.sub(r"\(.*\)$", "", name)           # drop the parameter list
+    name = name.replace("void ", "")
+    return name
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=os.path.join(ROOT, "open_spiel_amd", "libosg_hip.so"))
+    ap.add_argument("--out")
+    ap.add_argument("--check", action="store_true")
+    a = ap.parse_args()
+
+    rows = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for obj in code_objects(a.lib, tmp):
+            ks = kernels_of(obj)
+            names = demangle([k[".name"] for k in ks])
+            for k, n in zip(ks, names):
+                rows.append(dict(
+                    name=short(n), full=n,
+                    vgpr=k.get(".vgpr_count", 0), agpr=k.get(".agpr_count", 0), sgpr=k.get(".sgpr_count", 0),
+                    vspill=k.get(".vgpr_spill_count", 0), sspill=k.get(".sgpr_spill_count", 0),
+                    scratch=k.get(".private_segment_fixed_size", 0), lds=k.get(".group_segment_fixed_size", 0),
+                    bound=k.get(".max_flat_workgroup_size", 0), dyn=k.get(".uses_dynamic_stack", False)))
+    rows.sort(key=lambda r: r["name"])
+
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    lines = [
+        f"# kernel resources of {os.path.relpath(a.lib, ROOT)} (gfx950), tree at {head}; tools/kernel_resources.py",
+        "# vgpr/agpr/sgpr = registers allocated; vsp/ssp = registers spilled; scr = scratch bytes per lane; lds = static LDS bytes",
+        "# (dynamic LDS is asked for at launch and not shown); wg = launch bound; w/simd = wavefronts per SIMD the VGPR count allows",
+        f"# {len(rows)} entry points",
+        f"{'vgpr':>4} {'agpr':>4} {'sgpr':>4} {'vsp':>4} {'ssp':>4} {'scr':>5} {'lds':>6} {'wg':>5} {'w/simd':>6}  kernel",
+    ]
+    bad = []
+    for r in rows:
+        flag = ""
+        if r["vspill"] or r["sspill"] or r["scratch"]:
+            flag = "  <-- spills" if (r["vspill"] or r["sspill"]) else "  <-- scratch (frames / dynamic indexing)"
+        lines.append(f"{r['vgpr']:>4} {r['agpr']:>4} {r['sgpr']:>4} {r['vspill']:>4} {r['sspill']:>4} {r['scratch']:>5} "
+                     f"{r['lds']:>6} {r['bound']:>5} {waves_per_simd(r['vgpr'], r['agpr']):>6}  {r['name']}{flag}")
+        if any(r["name"].startswith(h) for h in HOT) and (r["vspill"] or r["sspill"] or r["scratch"]):
+            bad.append(r["name"])
+    n_spill = sum(1 for r in rows if r["vspill"] or r["sspill"])
+    n_scr = sum(1 for r in rows if r["scratch"])
+    lines.append(f"# {n_spill} of {len(rows)} entry points spill registers; {n_scr} use scratch")
+    if bad:
+        lines.append("# HOT kernels that spill: " + "; ".join(bad))
+    else:
+        lines.append("# no kernel of the HOT list (tools/kernel_resources.py) spills or uses scratch")
+    text = "\n".join(lines) + "\n"
+    if a.out:
+        with open(a.out, "w") as f:
+            f.write(text)
+    else:
+        sys.stdout.write(text)
+    if a.check and bad:
+        sys.stderr.write("hot kernels spill: " + "; ".join(bad) + "\n")
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

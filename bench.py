@@ -305,12 +305,16 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
                   "scaling": "replicas only", "kernel": solver.last_kernel(),
                   "config": {"workload": f"kuhn_poker CFRSolver, {iters} EvaluateAndUpdatePolicy in one launch, "
                                          "58 histories / 12 infostates, LDS-resident"}}
+    if rank == 0:
+        rf = cfr_small_roofline(iters / dt)
+        if rf:
+            out["cfr"]["roofline"] = rf
     if rank == 0 and with_cpu:
         # what the timed launch left behind, against the CPU solver run for the same number of iterations (the checker
         # only: oracle/parity.py; the genuine reference build when it loads)
         try:
+            impl, kind = cpu_checker()   # (also puts oracle/ on sys.path)
             import parity
-            impl, kind = cpu_checker()
             t = solver.tables()
             rec = parity.cfr_tables(impl, "kuhn_poker", "cfr", 100 + iters, t["keys"], t["nact"], t["regrets"],
                                     t["cum_policy"], t["avg_policy"])
@@ -413,10 +417,14 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
     # NashConv of the average policy after the 2^24 trajectories (device judge,
     # the same numbers as the oracle's TabularBestResponse to 1e-12: tests/test_gpu_cfr.py)
     out["mccfr"]["nash_conv_after"] = float(solver.nash_conv())
+    if rank == 0:
+        rf = mccfr_flat_roofline(batch * nb / dt / world, torch.cuda.get_device_properties(0).multi_processor_count * 4)
+        if rf:
+            out["mccfr"]["roofline"] = rf
     if snap is not None:
         try:
-            import parity
             impl, kind = cpu_checker()
+            import parity
             t = solver.tables()
             reg0, cum0 = snap[0].cpu().numpy(), snap[1].cpu().numpy()
             scale = np.maximum(np.maximum(np.abs(reg0), np.abs(t["regrets"])), np.maximum(np.abs(cum0), np.abs(t["cum_policy"])))
@@ -621,6 +629,83 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
 
 
 NASH_CONV_THRESHOLDS = (1.0, 0.3, 0.1)
+
+
+def solver_counters():
+    """Per-launch counters of the kernels of configs 3 and 5 from the newest committed profile
+    (profiles/r*_pmc_solvers.json, written by tools/pmc_solvers.sh on the GPU box), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_solvers.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            rec = json.load(f)
+        rec["file"] = os.path.relpath(files[-1], ROOT)
+        return rec
+    except (OSError, ValueError):
+        return None
+
+
+# Issue intervals measured on this chip by tools/clock_probe.hip (profiles/r02_clock_probe.log): a dependent vector
+# instruction of a LONE wavefront every 3.737 ns; with every SIMD saturated a simple vector instruction every 1.03 ns and
+# a scalar-unit instruction (ALU or branch) every 1.833 ns per SIMD.
+LONE_WAVE_ISSUE_NS, VALU_ISSUE_NS, SALU_ISSUE_NS = 3.737, 1.03, 1.833
+
+
+def cfr_small_roofline(iterations_per_s):
+    """Config 3's bound: k_cfr_small is ONE wavefront (58 histories <= 64 lanes) running a dependent chain, so its
+    ceiling is a lone wavefront's instruction issue, not bytes (< 8 KB per iteration, all LDS)."""
+    pc = solver_counters()
+    if not pc or "k_cfr_small" not in pc:
+        return None
+    u = pc["k_cfr_small"]["per_unit"]
+    classes = {k: u.get("SQ_INSTS_" + k, 0.0) for k in ("VALU", "SALU", "LDS", "SMEM", "VMEM_RD", "VMEM_WR", "BRANCH")}
+    total = sum(classes.values())
+    ns = 1e9 / iterations_per_s
+    return {"bound": "instruction issue of one wavefront (a dependent chain: 58 histories fit 64 lanes)",
+            "instructions_per_iteration": total, "by_class": classes,
+            "lone_wave_issue_ns_per_instruction": LONE_WAVE_ISSUE_NS,
+            "issue_ns_per_iteration": total * LONE_WAVE_ISSUE_NS, "measured_ns_per_iteration": ns,
+            "frac_of_lone_wave_issue_bound": total * LONE_WAVE_ISSUE_NS / ns,
+            "lds_instructions_per_iteration": classes["LDS"],
+            "wait_share_of_wave_cycles": (u.get("SQ_WAIT_ANY", 0.0) / u["SQ_WAVE_CYCLES"]) if u.get("SQ_WAVE_CYCLES") else None,
+            "algorithmic_bytes_per_iteration": "< 8 KB, LDS-resident (SURVEY.md 8(d)): an HBM roofline does not apply",
+            "source": pc["file"] + " (" + pc.get("source", "") + ")",
+            "note": "a lone wavefront issues a dependent instruction every 3.737 ns (profiles/r02_clock_probe.log), so "
+                    "instructions per iteration x 3.737 ns is what one solver can reach; the replicas figure is the same "
+                    "kernel with every SIMD holding several wavefronts"}
+
+
+def mccfr_flat_roofline(trajectories_per_s, simds):
+    """Config 5's kernel (k_mccfr_resident_flat: one trajectory per lane, tree / policy / delta tables in LDS, the
+    traversal's frames below the top two in a per-lane scratch stack): issue-rate fractions and where the waves wait."""
+    pc = solver_counters()
+    if not pc or "k_mccfr_resident_flat" not in pc:
+        return None
+    k = pc["k_mccfr_resident_flat"]
+    c, n = k["counters_per_launch"], k["units_per_launch"]
+    secs = n / trajectories_per_s
+    valu_s = c.get("SQ_INSTS_VALU", 0.0) / simds * VALU_ISSUE_NS * 1e-9
+    salu_s = (c.get("SQ_INSTS_SALU", 0.0) + c.get("SQ_INSTS_BRANCH", 0.0)) / simds * SALU_ISSUE_NS * 1e-9
+    waves = c.get("SQ_WAVES", 0.0) or 1.0
+    rec = {"trajectories_per_lane": n / (waves * 64.0),
+           "wave_instructions_per_wave": {x: c.get("SQ_INSTS_" + x, 0.0) / waves for x in ("VALU", "SALU", "BRANCH", "LDS", "VMEM_RD", "VMEM_WR", "SMEM")},
+           "scratch_frame_instructions_per_wave": (c.get("SQ_INSTS_VMEM_RD", 0.0) + c.get("SQ_INSTS_VMEM_WR", 0.0)) / waves,
+           "lds_instructions_per_wave": c.get("SQ_INSTS_LDS", 0.0) / waves,
+           "vector_issue_seconds_at_least": valu_s, "scalar_issue_seconds_at_least": salu_s, "seconds_per_mini_batch": secs,
+           "frac_of_vector_issue_bound": valu_s / secs, "frac_of_scalar_issue_bound": salu_s / secs,
+           "wait_any_share_of_wave_cycles": (c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAVE_CYCLES") else None,
+           "wait_inst_share_of_wave_cycles": (c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAVE_CYCLES") else None,
+           "lds_bank_conflict_cycles_per_lds_active_cycle": (c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_ACTIVE_INST_LDS"]) if c.get("SQ_ACTIVE_INST_LDS") else None,
+           "algorithmic_bytes_per_trajectory": "0.5-1 KB of table rows, served from LDS (SURVEY.md 8(d): HBM roofline N/A)",
+           "source": pc["file"] + " (" + pc.get("source", "") + ")"}
+    top = max(("vector-unit instruction issue", rec["frac_of_vector_issue_bound"]), ("scalar-unit instruction issue", rec["frac_of_scalar_issue_bound"]),
+              key=lambda t: t[1])
+    wait = rec["wait_any_share_of_wave_cycles"] or 0.0
+    rec["bound"] = (top[0] if top[1] >= 0.6 else
+                    f"latency of the traversal's dependent chain (waves parked {wait:.0%} of their cycles; the busiest issue pipe is at {top[1]:.2f})")
+    return rec
 
 
 def mcts_instruction_mix():
@@ -1149,7 +1234,8 @@ def main():
                     "avg_launch_us": avg_kernel_s * 1e6, "launches_timed": launches,
                     "peak_note": "peak = HBM3E spec 8 TB/s (the denominator BASELINE.json names); one launch moves "
                                  f"{ALGO_BYTES_PER_STEP * n / 1e6:.1f} MB, which stays resident in the 256 MiB Infinity "
-                                 "Cache between launches, hence bound = infinity_cache; dram_leg is the HBM-true run"}
+                                 "Cache between launches, hence bound = infinity_cache: `frac` at the config's 2^20 states is Infinity-Cache "
+                                 "bandwidth over the HBM denominator; hbm_frac (= dram_leg.frac, 2^24 states) is the HBM-true figure"}
         if legs is not None:
             csecs, cbytes = legs["copy"]
             roofline["copy_ceiling"] = {"gbs": cbytes / csecs / 1e9, "us": csecs * 1e6, "bytes": cbytes,
@@ -1158,6 +1244,14 @@ def main():
             if "dram" in legs:
                 roofline["dram_leg"] = legs["dram"]
                 roofline["dram_leg"]["traffic"] = dram_traffic
+                # the HBM-true figures as scalars beside `frac` (a record that keeps only this object's top level must
+                # still show them): the same kernel over 2^24 states, every byte from / to HBM
+                roofline["hbm_frac"] = legs["dram"]["frac"]
+                roofline["hbm_achieved"] = legs["dram"]["achieved"]
+                roofline["hbm_avg_launch_us"] = legs["dram"]["avg_launch_us"]
+                roofline["hbm_states"] = legs["dram"]["states"]
+                roofline["hbm_traffic"] = dram_traffic
+                roofline["hbm_frac_of_copy_ceiling"] = legs["dram"].get("frac_of_copy_ceiling")
         line = {
             "metric": "env-steps/sec (batched LegalActions+ApplyAction+status, connect_four)",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -503,13 +503,19 @@ int osg_comm_destroy(osg_comm* c);
  *   3. every rank: osg_comm_oneshot_connect(c, all_handles)
  *   4. osg_allreduce_sum_f64 / _i32 / _f64_begin + osg_allreduce_end as with the RCCL kind; osg_comm_destroy.
  * Ranks may share a device (two processes on one GPU map each other's windows just the same), which is how the
- * 1-GPU test box exercises it.  A peer that never arrives raises a timeout (OSG_ONESHOT_TIMEOUT_MS, default 20 s)
- * reported by the next call.  The reference has no counterpart (no distributed runtime). */
+ * 1-GPU test box exercises it.  Failure is all-or-nothing per chunk and never silent: a peer that stays SILENT for
+ * OSG_ONESHOT_TIMEOUT_MS (default 120 000; the clock restarts with every chunk that arrives, so a late rank is waited
+ * for; 0 = no bound) makes the waiting workgroup POISON its chunk of the caller's buffer (NaN / INT32_MIN) instead of
+ * leaving local values beside reduced ones, and raises a sticky error that osg_comm_check and every later call on
+ * the communicator report.  The reference has no counterpart (no distributed runtime). */
 #define OSG_ONESHOT_HANDLE_BYTES 128
 int osg_comm_oneshot_create(osg_ctx* ctx, int rank, int world, int64_t max_doubles, osg_comm** out);
 int osg_comm_oneshot_handle(const osg_comm* c, void* handle_out /* OSG_ONESHOT_HANDLE_BYTES */);
 int osg_comm_oneshot_connect(osg_comm* c, const void* handles /* world x OSG_ONESHOT_HANDLE_BYTES, rank order */);
 
+/* Waits for the collectives issued so far (both streams) and reports a one-shot timeout, if any: call it before
+ * trusting a buffer that went through the LAST collective of a job (a timeout is otherwise reported by the next call). */
+int osg_comm_check(osg_comm* c);
 int osg_comm_rank(const osg_comm* c);
 int osg_comm_world(const osg_comm* c);
 int osg_allreduce_sum_f64(osg_comm* c, double* d_buf, int64_t n);

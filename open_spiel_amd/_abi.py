@@ -154,6 +154,7 @@ SIGNATURES = {
     "osg_comm_oneshot_create": (INT, [VP, INT, INT, I64, C.POINTER(VP)]),
     "osg_comm_oneshot_handle": (INT, [VP, VP]),
     "osg_comm_oneshot_connect": (INT, [VP, VP]),
+    "osg_comm_check": (INT, [VP]),
     "osg_comm_rank": (INT, [VP]),
     "osg_comm_world": (INT, [VP]),
     "osg_allreduce_sum_f64": (INT, [VP, VP, I64]),

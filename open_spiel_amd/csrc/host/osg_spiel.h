@@ -171,6 +171,9 @@ class Communicator {
   // context's stream between Begin and End overlap it, End orders the context's stream after it (no host wait).
   void BeginAllReduceSum(double* d_buf, int64_t n) { Check(osg_allreduce_sum_f64_begin(c_, d_buf, n)); }
   void EndAllReduce() { Check(osg_allreduce_end(c_)); }
+  // Waits for the collectives issued so far and raises if a one-shot call timed out (its buffer then holds NaN in
+  // the chunks that were not reduced): call before trusting the result of the last collective of a job.
+  void CheckHealth() { Check(osg_comm_check(c_)); }
 
  private:
   osg_comm* c_ = nullptr;

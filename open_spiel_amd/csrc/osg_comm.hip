@@ -113,6 +113,7 @@ template <> struct Sys<double> {
     return __longlong_as_double(static_cast<long long>(__hip_atomic_load(
         reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)));
   }
+  static __device__ __forceinline__ double poison() { return __longlong_as_double(0x7FF8000000000000ll); }
 };
 template <> struct Sys<int32_t> {
   static __device__ __forceinline__ void store(int32_t* p, int32_t v) {
@@ -121,6 +122,7 @@ template <> struct Sys<int32_t> {
   static __device__ __forceinline__ int32_t load(const int32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  static __device__ __forceinline__ int32_t poison() { return INT32_MIN; }
 };
 
 // T = double or int32_t (a slot is cap doubles = 2 cap int32).  err[0] is raised on a timeout.
@@ -151,20 +153,36 @@ k_oneshot_allreduce(OneShotPeers peers, T* buf, int64_t n, int rank, int world, 
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // ---- wait: chunk g of every rank has landed in MY window ----
+    // The bound is on SILENCE, not on skew: the clock restarts whenever another rank's chunk arrives, so a rank that is
+    // legitimately late (a NashConv evaluation, a checkpoint between two steps) is waited for as RCCL would, and only a
+    // peer that stays silent for the whole bound (a dead process, a lost mapping) ends the call.
     const unsigned long long* mine = peers.flags[rank] + static_cast<int64_t>(parity) * world * kOneShotMaxBlocks + g;
-    const unsigned long long t0 = wall_clock64();
+    unsigned long long t0 = wall_clock64();
     int ok = 1;
     for (int s = 0; s < world && ok; ++s) {
       while (__hip_atomic_load(mine + static_cast<int64_t>(s) * kOneShotMaxBlocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-        if (wall_clock64() - t0 > timeout_ticks) { ok = 0; break; }
+        if (timeout_ticks != 0ull && wall_clock64() - t0 > timeout_ticks) { ok = 0; break; }
         __builtin_amdgcn_s_sleep(2);
       }
+      t0 = wall_clock64();
     }
+    // acquire at system scope: the slots read below were written by other agents before the flags seen above (the data
+    // loads are system-scope atomics on a fine-grained window already; the fence — one cache invalidate — makes the
+    // order hold for any mapping of the window)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     if (!ok) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // pinned host memory
     s_ok = ok;
   }
   __syncthreads();
-  if (!s_ok) return;   // a peer never arrived: the caller's buffer keeps its local values, the error is reported
+  if (!s_ok) {
+    // A peer never arrived.  Workgroups time out one by one, so without this the caller's buffer would end as a mix of
+    // reduced chunks and local values that looks like a result: the chunk is POISONED instead (NaN / INT32_MIN), the
+    // pinned error word is raised, and osg_comm_check — or the next call on the communicator — reports it.  A buffer
+    // that went through a failed collective can therefore not be folded into tables unnoticed: it holds NaNs.
+    if (e0 < n) buf[e0] = Sys<T>::poison();
+    if (e1 < n) buf[e1] = Sys<T>::poison();
+    return;
+  }
   // ---- reduce: the slots in rank order (system-scope loads: never a stale cached line of an earlier call) ----
   const T* slots = reinterpret_cast<const T*>(peers.data[rank]) + static_cast<int64_t>(parity) * world * slot_elems;
   T a0 = T(0), a1 = T(0);
@@ -302,8 +320,7 @@ int osg_comm_oneshot_create(osg_ctx* ctx, int rank, int world, int64_t max_doubl
   c->flags_offset = (sizeof(double) * 2 * world * c->cap + 255) & ~size_t{255};
   c->window_bytes = c->flags_offset + sizeof(unsigned long long) * 2 * world * kOneShotMaxBlocks;
   // fine-grained: peers' write-through stores and this rank's system-scope loads meet in memory, not in a cache
-  hipError_t e = std::getenv("OSG_ONESHOT_COARSE") ? hipMalloc(&c->window, c->window_bytes)
-                                                   : hipExtMallocWithFlags(&c->window, c->window_bytes, hipDeviceMallocFinegrained);
+  hipError_t e = hipExtMallocWithFlags(&c->window, c->window_bytes, hipDeviceMallocFinegrained);
   if (e == hipSuccess) e = hipMemset(c->window, 0, c->window_bytes);
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->h_err), sizeof(unsigned int), hipHostMallocMapped);
   if (e == hipSuccess) *c->h_err = 0;
@@ -314,9 +331,11 @@ int osg_comm_oneshot_create(osg_ctx* ctx, int rank, int world, int64_t max_doubl
     delete c;
     return set_error(OSG_ERR_NOMEM, std::string("osg_comm_oneshot_create: ") + hipGetErrorString(e));
   }
-  double ms = 20000.0;
-  if (const char* t = std::getenv("OSG_ONESHOT_TIMEOUT_MS")) ms = std::max(1.0, std::atof(t));
-  c->timeout_ticks = static_cast<unsigned long long>(ms * 1e5);   // wall_clock64 counts at 100 MHz
+  // How long a peer may stay SILENT before the call gives up (the clock restarts with every chunk that arrives): two
+  // minutes by default — a hang detector, not a skew bound; OSG_ONESHOT_TIMEOUT_MS=0 waits for ever, as RCCL does.
+  double ms = 120000.0;
+  if (const char* t = std::getenv("OSG_ONESHOT_TIMEOUT_MS")) ms = std::max(0.0, std::atof(t));
+  c->timeout_ticks = static_cast<unsigned long long>(ms * 1e5);   // wall_clock64 counts at 100 MHz; 0 = no bound
   osg::ctx_retain(ctx);
   c->ctx = ctx;
   *out = c;
@@ -364,6 +383,18 @@ int osg_comm_oneshot_connect(osg_comm* c, const void* handles) {
     c->peers.flags[s] = reinterpret_cast<unsigned long long*>(static_cast<char*>(c->mapped[s]) + c->flags_offset);
   }
   c->connected = true;
+  return OSG_OK;
+}
+
+int osg_comm_check(osg_comm* c) {
+  if (!c) return set_error(OSG_ERR_INVALID, "osg_comm_check: null argument");
+  OSG_HIP(hipSetDevice(c->ctx->device));
+  if (c->side) OSG_HIP(hipStreamSynchronize(c->side));
+  OSG_HIP(hipStreamSynchronize(c->ctx->stream));
+  if (c->oneshot && __atomic_load_n(c->h_err, __ATOMIC_RELAXED) != 0)
+    return set_error(OSG_ERR_HIP, "osg_comm_check: a one-shot all-reduce timed out waiting for a peer (OSG_ONESHOT_TIMEOUT_MS); the "
+                                  "buffer of that call holds NaN / INT32_MIN in the chunks that were not reduced and the "
+                                  "communicator is unusable");
   return OSG_OK;
 }
 

@@ -133,6 +133,12 @@ class OneShotComm:
         """Orders the context's stream after the collective begun last (no host wait)."""
         self._check(self._lib.osg_allreduce_end(self._h))
 
+    def check(self):
+        """Waits for the collectives issued so far and raises if one of them timed out (the buffer of that call then
+        holds NaN in the chunks that were not reduced).  Call it before trusting the result of the LAST collective of
+        a job; a timeout is otherwise reported by the next call on the communicator."""
+        self._check(self._lib.osg_comm_check(self._h))
+
     def close(self):
         if self._h:
             self._lib.osg_comm_destroy(self._h)
@@ -233,8 +239,12 @@ class ShardedMccfr:
         self._pending = None
 
     def finish(self):
-        """Fold the deltas still in flight (overlap=True); a no-op otherwise."""
+        """Fold the deltas still in flight (overlap=True), then make sure no exchange step of the run failed: with the
+        one-shot collective a timeout of the LAST call has no later call to report it (osg_comm_check; a failed call
+        leaves NaN in the delta buffer, so tables it was folded into are NaN, never plausible-but-different)."""
         self._fold_pending()
+        if self.comm is not None and self.world_size > 1:
+            self.comm.check()
 
 
 def gather_root_results(local, total_roots):

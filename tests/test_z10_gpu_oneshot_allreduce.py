@@ -6,7 +6,8 @@ What is checked: sums of many message sizes (1 element ... the window's capacity
 and int32, hundreds of back-to-back calls with changing data (a stale line or a lost flag shows as a wrong sum), both
 ranks bit-identical; the begin / end form; sharded ES-MCCFR over it ending with identical tables on both ranks that
 equal the one-rank schedule up to fp64 summation order (external_sampling_mccfr.cc:122-186 is what is summed); a
-peer that never arrives is a reported timeout, not a hang."""
+peer that never arrives is a reported timeout, not a hang — reported by osg_comm_check and by every later call, with the
+caller's buffer poisoned (NaN) instead of left as a mix of local and reduced chunks."""
 import json
 import os
 import subprocess
@@ -120,9 +121,12 @@ if rank == 0:
     v = torch.ones(1024, dtype=torch.float64, device="cuda")
     t0 = time.perf_counter()
     lonely.allreduce_sum_(v)
-    ctx.synchronize()
+    try:
+        lonely.check(); out["timeout_reported_by_check"] = False     # osg_comm_check: waits, then reports
+    except osa.OsgError as e:
+        out["timeout_reported_by_check"] = "timed out" in str(e)
     out["timeout_seconds"] = time.perf_counter() - t0
-    out["timeout_left_buffer_alone"] = bool((v == 1.0).all())
+    out["timeout_poisoned_buffer"] = bool(torch.isnan(v).all())      # never a mix of local and reduced values
     try:
         lonely.allreduce_sum_(v); out["timeout_reported"] = False
     except osa.OsgError as e:
@@ -166,7 +170,8 @@ def test_oneshot_allreduce_two_ranks_on_one_device(tmp_path):
     for key in ("sync", "overlap"):
         assert rec[key]["rank_diff"] == 0.0, "every rank folds bit-identical sums"
         assert rec[key]["vs_one_rank"] < 1e-8 * max(1.0, rec[key]["regret_abs_sum"])
-    assert 0.2 < rec["timeout_seconds"] < 5.0 and rec["timeout_reported"] and rec["timeout_left_buffer_alone"]
+    assert 0.2 < rec["timeout_seconds"] < 5.0 and rec["timeout_reported"] and rec["timeout_reported_by_check"]
+    assert rec["timeout_poisoned_buffer"], "a failed collective must leave NaN, not a plausible mix"
     assert rec["failed_creation_agreed"], "a rank that cannot create its window must fail the construction on every rank"
 
 

@@ -1,0 +1,166 @@
+"""World size 8 on the ONE device of the test box: first contact of the multi-GPU path with its real world size.
+
+The lease is one GPU, so no collective of this code has crossed xGMI yet; what CAN be exercised here is everything
+that depends on the world size rather than on the link: eight processes map each other's one-shot windows through
+hipIpc (world-8 slot and flag geometry, the ring order of the pushes, both parities over more than a thousand
+back-to-back calls), every rank folds bit-identical sums, a rank that stops calling makes EVERY other rank raise
+within the bound with a poisoned buffer (never a plausible mix of local and reduced values), and `bench.py --gpus 8`
+— sharding by 8, max-over-ranks timing, the exchange step of config 5 eight ways — runs to completion over gloo with
+the ranks sharing the device.  What stays cross-device-only is listed in DESIGN.md section 9."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORLD = 8
+
+SCRIPT = r'''
+import json, os, sys, time
+sys.path.insert(0, os.environ["OSG_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+import open_spiel_amd as osa
+from open_spiel_amd import distributed as osd
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)                       # every rank on the same device
+ctx = osa.Context(0)
+out = {"world": world}
+cap = 5616                                     # config 5's message: 2 x [936, 3] fp64
+comm = osd.OneShotComm(ctx, cap)
+# ---- 1 200 back-to-back calls, both parities, the data changing with every call, checked every 100 calls ----
+x = torch.empty(cap, dtype=torch.float64, device="cuda")
+idx = torch.arange(cap, dtype=torch.float64, device="cuda")
+bad, calls = 0, 0
+t0 = time.perf_counter()
+for block in range(12):
+    for i in range(100):
+        k = block * 100 + i
+        x.copy_(idx * (rank + 1) + (k % 7))   # rank r contributes idx * (r + 1) + k % 7
+        comm.allreduce_sum_(x)
+        calls += 1
+    ctx.synchronize(); torch.cuda.synchronize()
+    want = idx * (world * (world + 1) // 2) + world * (k % 7)
+    bad += int(not torch.equal(x, want))
+out["calls"] = calls
+out["mismatched_blocks"] = bad
+out["seconds_for_calls"] = time.perf_counter() - t0
+# ---- random data, sizes around the chunk boundaries, sums in rank order: bit-identical with the host's ----
+gen = torch.Generator(device="cuda"); gen.manual_seed(99 + rank)
+bad = 0
+for n in (1, 511, 512, 513, 2048, cap):
+    for rep in range(3):
+        y = torch.randn(n, dtype=torch.float64, device="cuda", generator=gen) * (1 + rep)
+        parts = [torch.empty(n, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(parts, y.cpu())
+        want = parts[0].clone()
+        for p in parts[1:]:
+            want += p
+        comm.allreduce_sum_(y)
+        ctx.synchronize()
+        bad += int(not torch.equal(y.cpu(), want))
+out["random_mismatches"] = bad
+comm.check()
+comm.close()
+# ---- sharded ES-MCCFR eight ways: identical tables on every rank ----
+os.environ["OSG_COMM"] = "oneshot"
+s = osa.TabularSolver(ctx, "leduc_poker", mccfr=True)
+sh = osd.ShardedMccfr(s)
+for _ in range(4):
+    sh.run_minibatch(9, 1 << 14)
+sh.finish()
+t = s.tables()
+mine = torch.from_numpy(np.stack([t["regrets"], t["cum_policy"]]))
+everyone = [torch.empty_like(mine) for _ in range(world)]
+dist.all_gather(everyone, mine)
+out["table_rank_diff"] = float(max((everyone[0] - e).abs().max() for e in everyone[1:]))
+out["tables_finite"] = bool(torch.isfinite(mine).all())
+sh.comm.close()
+dist.barrier()
+# ---- a rank that stops calling: the last rank sits the next collective out; every other rank must raise within the
+#      bound, with its buffer poisoned (NaN), and the communicator must stay failed ----
+os.environ["OSG_ONESHOT_TIMEOUT_MS"] = "400"
+lonely = osd.OneShotComm(ctx, 1024)
+if rank != world - 1:
+    v = torch.ones(1024, dtype=torch.float64, device="cuda")
+    t0 = time.perf_counter()
+    lonely.allreduce_sum_(v)
+    try:
+        lonely.check(); raised = False
+    except osa.OsgError as e:
+        raised = "timed out" in str(e)
+    out["timeout_seconds"] = time.perf_counter() - t0
+    out["timeout_raised_by_check"] = raised
+    out["buffer_poisoned"] = bool(torch.isnan(v).all())
+    try:
+        lonely.allreduce_sum_(v); out["sticky"] = False
+    except osa.OsgError:
+        out["sticky"] = True
+else:
+    time.sleep(1.0)
+    out.update(timeout_seconds=0.5, timeout_raised_by_check=True, buffer_poisoned=True, sticky=True)
+dist.barrier()
+recs = [None] * world
+dist.all_gather_object(recs, out)
+if rank == 0:
+    print(json.dumps(recs), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_oneshot_allreduce_eight_ranks_on_one_device(tmp_path):
+    script = tmp_path / "oneshot8.py"
+    script.write_text(SCRIPT)
+    env = dict(os.environ, OSG_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "OSG_COMM", "OSG_ONESHOT_TIMEOUT_MS"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(WORLD), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    recs = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("[{")][-1])
+    print(recs[0])
+    assert len(recs) == WORLD
+    for rank, rec in enumerate(recs):
+        assert rec["world"] == WORLD and rec["calls"] >= 1000, rec
+        assert rec["mismatched_blocks"] == 0 and rec["random_mismatches"] == 0, (rank, rec)
+        assert rec["table_rank_diff"] == 0.0 and rec["tables_finite"], (rank, rec)
+        assert rec["timeout_raised_by_check"] and rec["buffer_poisoned"] and rec["sticky"], (rank, rec)
+        assert 0.3 < rec["timeout_seconds"] < 20.0, (rank, rec)
+
+
+def test_bench_eight_ranks_code_path():
+    """`python bench.py --gpus 8` to completion with the eight ranks sharing this box's GPU over gloo: eight shards of
+    the states / roots / trajectories, max-over-ranks timing, the delta all-reduce of config 5 eight ways (gloo and the
+    one-shot kernel), the strong-scaling record against the same run's one-rank search.  The RCCL run needs 8 GPUs
+    (the driver's SCALE record)."""
+    env = dict(os.environ, OSG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(WORLD), "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-pmc", "--states", str(1 << 16)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == WORLD and line["value"] > 0 and line["collective_backend"] == "gloo"
+    assert len(line["per_rank"]["env_steps_per_s"]) == WORLD and min(line["per_rank"]["env_steps_per_s"]) > 0
+    sec = line["secondary"]
+    assert "error" not in sec, sec
+    assert sec["mcts"]["value"] > 0 and len(sec["mcts"]["per_rank_sims_per_s"]) == WORLD
+    assert sec["mcts"]["strong_scaling_efficiency"] > 0
+    assert sec["mccfr"]["tables_finite"] and sec["mccfr"]["allreduce_bytes"] == 44928
+    shot = sec["mccfr"]["oneshot"]
+    assert "error" not in shot, shot
+    assert shot["allreduce_us"] > 0 and shot["trajectories_per_s"] > 0 and shot["nash_conv_after"] < 4.7
+    assert sec["mccfr"]["quality"]["world"] == WORLD

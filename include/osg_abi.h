@@ -143,7 +143,9 @@ int osg_chance_probs(const osg_batch* b, double* probs, int on_host);
  * CurrentPlayer / outcome + LegalActions of the successor, one pass over the
  * SoA state.  Device pointers only; src may equal dst.
  *   d_actions [n] u8   action id (0xFF = skip)
- *   d_mask    [n * compact_mask_bytes] legal mask of the successor state
+ *   d_mask    [n * compact_mask_bytes] legal mask of the successor state; NULL = do not write it: hex boards of up
+ *                      to 128 cells only (hex.cc:280-293: the successor's legal actions are its empty cells, i.e.
+ *                      ~occupied of the record the step writes), OSG_ERR_UNSUPPORTED for every other game
  *   d_status  [n] u8   bit7 terminal | bit6 action was illegal (state unchanged) |
  *                      not terminal: bits0-3 = current player + 1 (0 = chance) |
  *                      terminal:     bits0-2 = outcome (board games: 0 p0 wins,

@@ -417,8 +417,10 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
         if (kOwner && b_fast) {
           // (opaque per pass: otherwise every `slot == q` comparison is hoisted out of the iteration loop as a lane mask
           // in a scalar register pair and spilled to vector lanes — see k_cfr_split)
+#ifndef OSG_AB_R4_REGS
 #pragma unroll
           for (int j = 0; j < kOwnerPath; ++j) asm volatile("" : "+v"(b_code[j]));
+#endif
           double pr[kOwnerPath];
 #pragma unroll
           for (int j = 0; j < kOwnerPath; ++j) pr[j] = cur[b_code[j] >= 0 ? (b_code[j] & 0x7FFFFF) : 0];
@@ -685,8 +687,10 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
         // of the iteration loop as a 64-bit lane mask in a scalar register pair — 10 entries x kSlots masks = 60+ scalar
         // registers held across the loop and spilled to vector lanes.  An empty asm makes the codes opaque per pass, so
         // the comparisons are formed where they are used: ~30 vector compares per pass instead of 69 spilled registers)
+#ifndef OSG_AB_R4_REGS
 #pragma unroll
         for (int j = 0; j < kOwnerPath; ++j) asm volatile("" : "+v"(b_code[j]));
+#endif
         double pr[kOwnerPath];
 #pragma unroll
         for (int j = 0; j < kOwnerPath; ++j) pr[j] = pol[b_code[j] >= 0 ? (b_code[j] & 0x7FFFFF) : 0];
@@ -824,7 +828,11 @@ static const void* split_kernel_bound(int P, bool br) {
 }
 // The instantiation for a launch of `threads` threads per workgroup (see kBound above).
 static const void* split_kernel(int P, bool br, int threads) {
+#ifdef OSG_AB_R4_REGS   // measurement only (tools/build_variant.sh): round 4's instantiation, bound 1024 for every launch
+  return split_kernel_bound<1024>(P, br);
+#else
   return threads <= 512 ? split_kernel_bound<512>(P, br) : split_kernel_bound<1024>(P, br);
+#endif
 }
 
 // ---------------------------------------------------------------------------

@@ -225,7 +225,10 @@ k_step_vec(typename G::Params p, const typename G::word_t* src, typename G::word
 //   2^24 states  1:0 334.7 us  2:0 335.3     2:1 330.1  4:0 337.7  4:1 350.7   (0.74-0.75 of 8 TB/s: DRAM)
 // Four states per thread (94 vector registers, four divergent floods in a row) never pays; two do, with ordinary
 // stores while the batch fits the Infinity Cache and non-temporal ones beyond.
-template <int NW, int V, bool kNt>
+// kMask = false (round 5; osg_step with d_mask == NULL): the successor's mask row is not written — on a hex board it
+// is ~occupied of the successor record, which the caller holds anyway (SURVEY.md 8(d) prices the hex step without
+// it: 109 B instead of 118 B moved for hex(9)).
+template <int NW, int V, bool kNt, bool kMask = true>
 __global__ void __launch_bounds__(kBlock)
 k_step_hexvec(typename HexT<NW>::Params p, const uint32_t* src, uint32_t* dst, int64_t n,  // src may BE dst
               const uint8_t* __restrict__ actions, uint32_t* __restrict__ mask_out, uint8_t* __restrict__ status) {
@@ -256,9 +259,11 @@ k_step_hexvec(typename HexT<NW>::Params p, const uint32_t* src, uint32_t* dst, i
     }
     G::store(p, tmp, V, j, s);
     const bool term = G::terminal(p, s);
-    const auto after = G::legal(p, s);
+    if constexpr (kMask) {
+      const auto after = G::legal(p, s);
 #pragma unroll
-    for (int w = 0; w < NW; ++w) mk[j * NW + w] = after.w[w];
+      for (int w = 0; w < NW; ++w) mk[j * NW + w] = after.w[w];
+    }
     sv[j] = encode_status(term, illegal, term ? 0 : G::current_player(p, s), term ? G::outcome_code(p, s) : 0);
   }
 #pragma unroll
@@ -269,13 +274,15 @@ k_step_hexvec(typename HexT<NW>::Params p, const uint32_t* src, uint32_t* dst, i
     if constexpr (kNt) __builtin_nontemporal_store(v, reinterpret_cast<wvec*>(dst + w * n + i));
     else *reinterpret_cast<wvec*>(dst + w * n + i) = v;
   }
+  if constexpr (kMask) {
 #pragma unroll
-  for (int k = 0; k < NW; ++k) {
-    wvec v;
+    for (int k = 0; k < NW; ++k) {
+      wvec v;
 #pragma unroll
-    for (int j = 0; j < V; ++j) v[j] = mk[k * V + j];
-    if constexpr (kNt) __builtin_nontemporal_store(v, reinterpret_cast<wvec*>(mask_out + i * NW) + k);
-    else reinterpret_cast<wvec*>(mask_out + i * NW)[k] = v;
+      for (int j = 0; j < V; ++j) v[j] = mk[k * V + j];
+      if constexpr (kNt) __builtin_nontemporal_store(v, reinterpret_cast<wvec*>(mask_out + i * NW) + k);
+      else reinterpret_cast<wvec*>(mask_out + i * NW)[k] = v;
+    }
   }
   if constexpr (kNt) __builtin_nontemporal_store(sv, reinterpret_cast<bvec*>(status + i));
   else *reinterpret_cast<bvec*>(status + i) = sv;
@@ -1704,6 +1711,10 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
   const int cmb = src->spec.desc.compact_mask_bytes;
   const int W = src->spec.desc.mask_words;
   const int64_t n = src->n;
+  // d_mask == NULL ("do not write the successor's mask"): hex only, where the mask is ~occupied of the successor record
+  if (!d_mask && !(src->spec.desc.game_kind == kHex && cmb == 4 * W && W == src->spec.hex_nw && W <= 4))
+    return set_error(OSG_ERR_UNSUPPORTED, "osg_step: d_mask may be NULL only for hex boards of up to 128 cells (there the successor's "
+                                          "mask is ~occupied of the record written); every other game's mask comes from the step itself");
   // the kernels that move several states per lane use 16-byte plane accesses: planes start 16-byte aligned when the
   // allocation does (hipMalloc: 256 B) and n x word size is a multiple of 16 — checked here, not assumed
   const bool planes16 = ((reinterpret_cast<uintptr_t>(src->d_words) | reinterpret_cast<uintptr_t>(dst->d_words)) & 15u) == 0;
@@ -1775,13 +1786,15 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
       const auto* s32 = static_cast<const uint32_t*>(src->d_words);
       auto* d32 = static_cast<uint32_t*>(dst->d_words);
       auto* m32 = static_cast<uint32_t*>(d_mask);
-#define OSG_HEXVEC(NWV, VV, NTV, member)                                                                              \
-  k_step_hexvec<NWV, VV, NTV><<<dim3(grid_for(n / VV)), dim3(kBlock), 0, ctx->stream>>>(src->spec.member, s32, d32, n, \
-                                                                                      d_actions, m32, d_status)
+#define OSG_HEXVEC(NWV, VV, NTV, MASKV, member)                                                                              \
+  k_step_hexvec<NWV, VV, NTV, MASKV><<<dim3(grid_for(n / VV)), dim3(kBlock), 0, ctx->stream>>>(src->spec.member, s32, d32, n, \
+                                                                                             d_actions, m32, d_status)
 #define OSG_HEXVEC_NW(NWV, member)                                            \
   do {                                                                        \
-    if (nt) OSG_HEXVEC(NWV, 2, true, member);                                 \
-    else OSG_HEXVEC(NWV, 2, false, member);                                   \
+    if (nt && m32) OSG_HEXVEC(NWV, 2, true, true, member);                    \
+    else if (nt) OSG_HEXVEC(NWV, 2, true, false, member);                     \
+    else if (m32) OSG_HEXVEC(NWV, 2, false, true, member);                    \
+    else OSG_HEXVEC(NWV, 2, false, false, member);                            \
   } while (0)
       switch (src->spec.hex_nw) {
         case 1: OSG_HEXVEC_NW(1, hex1); break;
@@ -1795,6 +1808,10 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
       return OSG_OK;
     }
   }
+  if (!d_mask)
+    return set_error(OSG_ERR_UNSUPPORTED, "osg_step: d_mask may be NULL only for hex boards of up to 128 cells stepped two states per "
+                                          "thread (an even batch, 2-byte aligned side arrays): there the successor's mask is ~occupied "
+                                          "of the record written; every other game's mask is computed by the step itself");
   if (cmb == 1) {
     OSG_DISPATCH_WIDE(src->spec, k_step<G, uint8_t><<<dim3(grid_for(n)), dim3(kBlock), 0, ctx->stream>>>(P, static_cast<const typename G::word_t*>(src->d_words),
                                                 static_cast<typename G::word_t*>(dst->d_words), n, d_actions,

@@ -346,17 +346,14 @@ OSG_D Chosen select_child(const uint32_t* __restrict__ META, const uint32_t* __r
 
 // --- hex playout as a wave-parallel random fill --------------------------------------------
 // Lane l owns cells l and l + 64.  Per lane: the set of each cell's (up to six) neighbours as a 128-bit
-// mask and its edge flags.  Sets of cells travel as two 64-bit lane masks (cells 0-63, cells 64-127), so set algebra
-// runs on the scalar unit and the vector unit only does the per-cell tests.  NO wave-uniform cell set is kept for the
-// whole search (round 5): the cells off the board are marked occupied in the root position once (hexw_from_state), so
-// "empty" is ~occ, and black's two edge rows are two ballots of the lanes' edge flags at the start of a playout — twelve
-// scalar registers that were live through every descent, and with them the last registers the compiler parked in vector
-// lanes, are gone.
+// mask.  Per wavefront (uniform, in SGPRs): which cells are on the board / on black's two edges.  Sets of
+// cells travel as two 64-bit lane masks (cells 0-63, cells 64-127), so set algebra runs on the scalar
+// unit and the vector unit only does the per-cell tests.
 struct HexLane {
   uint64_t nb_lo[2];  // neighbours among cells 0-63
   uint64_t nb_hi[2];  // neighbours among cells 64-127
   uint32_t edge;      // cell l: first row 1, last row 2, first column 4, last column 8; cell l + 64: the same << 4
-                      // (cells off the board carry no flag)
+  uint64_t board[2], first_row[2], last_row[2];  // wave-uniform cell sets
 };
 template <class G>
 OSG_D HexLane hex_lane_setup(const typename G::Params& p) {
@@ -372,6 +369,9 @@ OSG_D HexLane hex_lane_setup(const typename G::Params& p) {
     for (int i = 0; i < static_cast<int>(sizeof(nb.w) / sizeof(nb.w[0])); ++i) w[i] = nb.w[i];
     hl.nb_lo[j] = on_board ? (static_cast<uint64_t>(w[1]) << 32 | w[0]) : 0ull;
     hl.nb_hi[j] = on_board ? (static_cast<uint64_t>(w[3]) << 32 | w[2]) : 0ull;
+    hl.board[j] = uniform64(__ballot(on_board));
+    hl.first_row[j] = uniform64(__ballot(on_board && G::test(p.row_first, cell)));
+    hl.last_row[j] = uniform64(__ballot(on_board && G::test(p.row_last, cell)));
     uint32_t e = 0;
     if (on_board) {
       e = (G::test(p.row_first, cell) ? 1u : 0u) | (G::test(p.row_last, cell) ? 2u : 0u) |
@@ -404,27 +404,26 @@ OSG_D uint64_t hex_cells64(const typename G::Bits& b, int j) {
 // `else if` of hex.cc:122-126 only matters on a one-row / one-column board, which this kernel is not
 // launched for) makes the two statements the same.
 struct HexW {
-  uint64_t occ[2], blk[2];  // all stones AND every cell off the board; black's stones (white = occ & ~blk on the board:
-                            // one set to update per move; an off-board "stone" has no neighbours and no edge flag)
+  uint64_t occ[2], blk[2];  // all stones, black's stones (white = occ & ~blk: one set to update per move)
   uint32_t meta;            // to move [0], result [1:3) as HexT::State::meta
 };
 template <class G>
-OSG_D HexW hexw_from_state(const typename G::Params& p, const typename G::State& s) {
+OSG_D HexW hexw_from_state(const typename G::State& s) {
   HexW w;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     w.blk[j] = hex_cells64<G>(s.black, j);
-    w.occ[j] = w.blk[j] | hex_cells64<G>(s.white, j) | ~uniform64(__ballot(lane_id() + 64 * j < p.cells));
+    w.occ[j] = w.blk[j] | hex_cells64<G>(s.white, j);
   }
   w.meta = uniform(s.meta) & 7u;
   return w;
 }
 OSG_D bool hexw_terminal(const HexW& w) { return ((w.meta >> 1) & 3u) != 0; }
 OSG_D int hexw_current_player(const HexW& w) { return hexw_terminal(w) ? kTerminalPlayer : static_cast<int>(w.meta & 1u); }
-OSG_D Mask hexw_legal(const HexLane&, const HexW& w) {  // hex.cc:280-293 without the swap action
+OSG_D Mask hexw_legal(const HexLane& hl, const HexW& w) {  // hex.cc:280-293 without the swap action
   Mask m;
   if (hexw_terminal(w)) return m;
-  const uint64_t e0 = ~w.occ[0], e1 = ~w.occ[1];
+  const uint64_t e0 = hl.board[0] & ~w.occ[0], e1 = hl.board[1] & ~w.occ[1];
   m.w[0] = static_cast<uint32_t>(e0);
   m.w[1] = static_cast<uint32_t>(e0 >> 32);
   m.w[2] = static_cast<uint32_t>(e1);
@@ -509,10 +508,7 @@ OSG_D void w_returns(const typename G::Params&, const HexW& w, double* out) { he
 OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl PT_ARGS) {
   const int lane = lane_id();
   const uint64_t black0 = s.blk[0], black1 = s.blk[1];
-  const uint64_t empty0 = ~s.occ[0], empty1 = ~s.occ[1];
-  // black's edge rows as cell sets, from the lanes' flags (two compares each, nothing held between playouts)
-  const uint64_t first_row0 = __ballot((hl.edge & 1u) != 0u), first_row1 = __ballot((hl.edge & 16u) != 0u);
-  const uint64_t last_row0 = __ballot((hl.edge & 2u) != 0u), last_row1 = __ballot((hl.edge & 32u) != 0u);
+  const uint64_t empty0 = hl.board[0] & ~s.occ[0], empty1 = hl.board[1] & ~s.occ[1];
   const uint64_t key0 = fill_key(base, lane), key1 = fill_key(base, lane + 64);
   const int m = __builtin_popcountll(empty0) + __builtin_popcountll(empty1);
   const int want = (m + 1) >> 1;  // plies 0, 2, 4, ... belong to the player to move
@@ -571,10 +567,10 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl PT_ARG
 #if defined(OSG_DIAG_NOFLOOD)  // measurement only
   return static_cast<int>((blk0 ^ blk1 ^ (blk0 >> 17)) & 1ull);
 #elif OSG_FLOOD_MODE == 0
-  uint64_t reach0 = blk0 & first_row0, reach1 = blk1 & first_row1;
+  uint64_t reach0 = blk0 & hl.first_row[0], reach1 = blk1 & hl.first_row[1];
 #pragma unroll 4  // measured: 1 -> 7.80e8, compiler's choice (2) -> 7.93e8, 4 -> 8.01e8 sims/s
   for (int it = 0; it < 128; ++it) {
-    if (((reach0 & last_row0) | (reach1 & last_row1)) != 0ull) return 0;  // black
+    if (((reach0 & hl.last_row[0]) | (reach1 & hl.last_row[1])) != 0ull) return 0;  // black
     const bool n0 = ((hl.nb_lo[0] & reach0) | (hl.nb_hi[0] & reach1)) != 0ull;
     const bool n1 = ((hl.nb_lo[1] & reach0) | (hl.nb_hi[1] & reach1)) != 0ull;
     const uint64_t g0 = __ballot(n0) & blk0 & ~reach0, g1 = __ballot(n1) & blk1 & ~reach1;
@@ -586,10 +582,10 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl PT_ARG
   // The bookkeeping of the flood on the vector unit: every lane keeps, for its two cells, an all-ones word
   // while the cell is black and not reached yet ("available") and clears it when the cell joins; the scalar
   // unit only sees the two ballots of a step (the new frontier) and decides the two exits.
-  uint64_t front0 = blk0 & first_row0, front1 = blk1 & first_row1;
+  uint64_t front0 = blk0 & hl.first_row[0], front1 = blk1 & hl.first_row[1];
   uint32_t avail0 = __builtin_amdgcn_inverse_ballot_w64(blk0 & ~front0) ? ~0u : 0u;
   uint32_t avail1 = __builtin_amdgcn_inverse_ballot_w64(blk1 & ~front1) ? ~0u : 0u;
-  if (((front0 & last_row0) | (front1 & last_row1)) != 0ull) return 0;  // a one-row chain
+  if (((front0 & hl.last_row[0]) | (front1 & hl.last_row[1])) != 0ull) return 0;  // a one-row chain
 #ifndef OSG_FLOOD_UNROLL
 #define OSG_FLOOD_UNROLL 2
 #endif
@@ -601,7 +597,7 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl PT_ARG
     const uint32_t j1 = (static_cast<uint32_t>(x1) | static_cast<uint32_t>(x1 >> 32)) & avail1;
     front0 = __ballot(j0 != 0u);
     front1 = __ballot(j1 != 0u);
-    if (((front0 & last_row0) | (front1 & last_row1)) != 0ull) return 0;  // black reached its last row
+    if (((front0 & hl.last_row[0]) | (front1 & hl.last_row[1])) != 0ull) return 0;  // black reached its last row
     if ((front0 | front1) == 0ull) break;
     avail0 = j0 != 0u ? 0u : avail0;
     avail1 = j1 != 0u ? 0u : avail1;
@@ -647,9 +643,17 @@ struct VisitPath {
 #define OSG_HEX_WPE 7
 #endif
 
-// The hex fill kernel at 7 waves per SIMD (73 vector registers: nothing spilled to scratch).  Measured on config 4
-// with the final kernel: 6 waves 1.06e9, 7 waves 1.12e9, 8 waves (64 registers, a few spilled) 1.08e9 simulations/s;
-// the 2^13-root shard of an 8-GPU run 8.7e8 / 8.9e8 / 9.0e8.  One wavefront per workgroup instead of four: the same
+// The hex fill kernel at 7 waves per SIMD.  What the code object says (tools/kernel_resources.py ->
+// profiles/r05_kernel_resources.txt): 72 vector + 94 scalar registers, 44 scalar registers parked in the lanes of one
+// vector register (v_writelane in the prologue only; 7 v_readlane at the head of a simulation — the root position —
+// and ~16 more on the expansion / first-visit paths, against ~520 vector instructions per simulation, on the vector
+// pipe, which is not the one that bounds this kernel) and 2 vector registers (12 B per lane) in scratch, touched on the
+// first-visit path.  Round 5 tried to take the parked registers out — the wave-uniform cell sets (board, first / last
+// row) dropped in favour of "off-board cells are occupied" and two ballots per playout: 44 -> 39 parked scalar and
+// 2 -> 6 spilled vector registers, 1.108e9 -> 1.078e9 simulations/s on the same box (profiles/r05_ab_register_work.txt)
+// — so the round-4 form stays; at 6 waves per SIMD the scalar budget is 100 instead of 88 (28 parked) and the search
+// runs at 1.06e9.  Measured on config 4 with the final kernel: 6 waves 1.06e9, 7 waves 1.12e9, 8 waves (64 registers,
+// more spilled) 1.08e9 simulations/s; the 2^13-root shard of an 8-GPU run 8.7e8 / 8.9e8 / 9.0e8.  One wavefront per workgroup instead of four: the same
 // at 2^16 roots, 5 % less at 2^13.  The generic instantiations carry more per-lane state (their playouts run one per
 // lane): 4 waves with a little scratch measured faster than 2-3 without.
 // kGc: the instantiation that can garbage-collect (mcts.cc:441-482): it also records every node's parent.
@@ -680,7 +684,7 @@ OSG_D void wave_search(const typename G::Params& p, const typename G::word_t* ba
   using WState = std::conditional_t<kHexFill, HexW, typename G::State>;
   const typename G::State loaded_root = G::load(p, base, n, r);
   WState root_state;
-  if constexpr (kHexFill) root_state = hexw_from_state<G>(p, loaded_root);
+  if constexpr (kHexFill) root_state = hexw_from_state<G>(loaded_root);
   else root_state = loaded_root;
   const int root_player = w_current_player<G>(p, root_state);
   // The root's header stays in registers (its count / total in path slot 0); every other node's header
@@ -1048,7 +1052,7 @@ OSG_D void wave_search(const typename G::Params& p, const typename G::word_t* ba
 
 // One wavefront per root, statically: wave w of workgroup b searches root 4 b + w.
 template <class G, bool kBoard, bool kHexFill, bool kGc>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(kHexFill ? OSG_HEX_WPE : 4, kHexFill ? OSG_HEX_WPE : 8)))
+__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(kHexFill ? OSG_HEX_WPE : 4, 8)))
 k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, int num_actions,
             osg_mcts_cfg cfg, double max_utility, const double* __restrict__ log_table, Pool pool, MctsOut out) {
   __shared__ uint32_t s_path[kWavesPerBlock][kMaxPath - kPathRegs];
@@ -1068,7 +1072,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
 // number of legal actions, most first) the long searches start first and the short ones fill the gaps.  Results are
 // written under the root's own index: the outputs do not depend on the order or on which wavefront ran what.
 template <class G, bool kBoard, bool kHexFill, bool kGc>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(kHexFill ? OSG_HEX_WPE : 4, kHexFill ? OSG_HEX_WPE : 8)))
+__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(kHexFill ? OSG_HEX_WPE : 4, 8)))
 k_mcts_wave_queue(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, int num_actions,
                   osg_mcts_cfg cfg, double max_utility, const double* __restrict__ log_table, Pool pool, MctsOut out,
                   WaveQueue queue) {

@@ -302,14 +302,22 @@ class StateBatch:
         status = self._dev((self.n,), torch.uint8)
         return mask, status
 
-    def step(self, actions_u8, dst=None, mask=None, status=None):
+    def step(self, actions_u8, dst=None, mask=None, status=None, want_mask=True):
         """Fused legality check + ApplyAction + status + successor legal mask.
 
         actions_u8: [n] uint8 device tensor (0xFF = skip).  dst: destination batch
         (default: in place).  Returns (mask bytes [n, compact_mask_bytes], status [n]).
+        want_mask=False (hex boards of up to 128 cells): the successor's mask row is not written — on a hex
+        board it is ~occupied of the successor record; returns (None, status).
         """
         dst = dst or self
-        if mask is None or status is None:
+        if not want_mask:
+            mask = None
+            if status is None:
+                status = self._dev((self.n,), torch.uint8)
+            else:
+                self._checked(status, torch.uint8, self.n, "step(status=)")
+        elif mask is None or status is None:
             mask, status = self.step_buffers()
         else:
             self._checked(mask, torch.uint8, self.n * self.desc.compact_mask_bytes, "step(mask=)")
@@ -317,7 +325,7 @@ class StateBatch:
         self._checked(actions_u8, torch.uint8, self.n, "step(actions_u8)")
         if dst.n != self.n or dst.game_string != self.game_string:
             raise OsgError("step(dst=): destination batch of a different game or size")
-        check(lib().osg_step(self._h, dst._h, _ptr(actions_u8), _ptr(mask), _ptr(status)))
+        check(lib().osg_step(self._h, dst._h, _ptr(actions_u8), None if mask is None else _ptr(mask), _ptr(status)))
         return mask, status
 
     # -- random play ------------------------------------------------------------------

@@ -31,7 +31,7 @@ def mccfr_minibatch(impl, game_string, keys, nact, regrets_before, d_regrets, d_
     live = np.arange(A)[None, :] < nact[:, None]
     cum_mass = np.abs(want["d_cum_policy"])
     floor = 8 * EPS * (np.asarray(table_scale) if table_scale is not None else 0.0) + 1e-12
-    worst = 0.0
+    worst, worst_mass = 0.0, 0.0
     for name, got, exp, mass in (("regret", d_regrets, want["d_regrets"], want["mass"]),
                                  ("average-policy", d_cum_policy, want["d_cum_policy"], cum_mass)):
         err = np.where(live, np.abs(got - exp), 0.0)
@@ -42,12 +42,14 @@ def mccfr_minibatch(impl, game_string, keys, nact, regrets_before, d_regrets, d_
             raise AssertionError(f"{game_string} ES-MCCFR mini-batch [{first}, {first + count}): {name} increment of "
                                  f"{keys[i]!r} action {a}: device {got[i, a]!r} vs CPU {exp[i, a]!r} (mass {mass[i, a]:.6g}, "
                                  f"{int(bad.sum())} cells off)")
-        worst = max(worst, float((err / np.maximum(mass, 1e-300))[live & (mass > 0)].max(initial=0.0)))
+        worst = max(worst, float((err / tol)[live].max(initial=0.0)))
+        big = live & (mass >= 1.0)                 # (cells with a mass worth the name; tiny ones are judged by the floor)
+        worst_mass = max(worst_mass, float((err / np.maximum(mass, 1e-300))[big].max(initial=0.0)))
     # cells past a row's action count must be untouched
     assert not np.where(~live, np.abs(d_regrets) + np.abs(d_cum_policy), 0.0).any()
     return {"trajectories": int(count), "infostate_visits": int(want["visits"].sum()),
             "infostates_visited": int((want["visits"] > 0).sum()), "cells": int(2 * live.sum()),
-            "max_error_over_mass": worst, "tolerance_over_mass": 1e-11}
+            "max_error_over_mass": worst_mass, "tolerance_over_mass": 1e-11, "max_error_over_tolerance": worst}
 
 
 def cfr_tables(impl, game_string, kind, iterations, keys, nact, regrets, cum_policy, avg_policy, rtol=1e-9, policy_atol=1e-6):

@@ -157,6 +157,39 @@ def test_fused_step_in_place_equals_out_of_place(ctx, game, n):
             break
 
 
+@pytest.mark.parametrize("game", ["hex(board_size=9)", "hex(board_size=5)", "hex(board_size=11)"])
+@pytest.mark.parametrize("n", [4096, 1 << 22])
+def test_hex_step_without_the_mask_row(ctx, game, n):
+    """osg_step with d_mask == NULL (hex.cc:280-293: the successor's legal actions are its empty cells, so the mask
+    row is redundant with the record): same successor records and status bytes as the step that writes the mask —
+    both store forms (ordinary below 2^22 states, non-temporal from there) — and ~occupied of the record IS the
+    mask the other call wrote; every other game refuses a NULL mask."""
+    import torch
+    import open_spiel_amd as osa
+    a = osa.StateBatch(ctx, game, n)
+    a.random_steps(11, 7)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    for _ in range(3):
+        lm = a.legal_actions_mask()
+        noise = torch.rand(lm.shape, device="cuda", generator=gen)
+        acts = torch.where(lm.any(1), (lm.to(torch.float32) * (noise + 0.01)).argmax(1),
+                           torch.full((n,), 255, device="cuda")).to(torch.uint8)
+        acts[::97] = 251
+        b, c = osa.StateBatch(ctx, game, n), osa.StateBatch(ctx, game, n)
+        m_full, s_full = a.step(acts, dst=b)
+        m_none, s_none = a.step(acts, dst=c, want_mask=False)
+        assert m_none is None and torch.equal(s_none, s_full)
+        assert (b.raw_words() == c.raw_words()).all()
+        # the mask the full step wrote is the set of empty cells of the successor (none once the game is over)
+        assert torch.equal(c.legal_actions_mask_bits().view(torch.uint8).reshape(n, -1), m_full.reshape(n, -1))
+        a = b
+        del lm, noise
+    with pytest.raises(osa.OsgError):
+        c4 = osa.StateBatch(ctx, "connect_four", 64)
+        c4.step(torch.zeros(64, dtype=torch.uint8, device="cuda"), want_mask=False)
+
+
 @pytest.mark.parametrize("game", ["connect_four", "hex(board_size=9)", "hex(board_size=5)", "leduc_poker", "tic_tac_toe"])
 @pytest.mark.parametrize("n", [1, 3, 37, 64, 257, 1000])
 def test_observation_ragged_sizes_and_unaligned_output(ctx, game, n):

@@ -264,7 +264,8 @@ def test_config5_full_minibatch_against_the_frozen_table_replay(ctx, checker, wa
     dreg, dcum = [t.cpu().numpy().copy() for t in s.mccfr_delta_tables()]
     rec = parity.mccfr_minibatch(impl, game, before["keys"], before["nact"], before["regrets"], dreg, dcum, SEED, first, n,
                                  _threads())
-    assert rec["trajectories"] == n and rec["infostates_visited"] == 936
+    # from the uniform policy 2^20 trajectories reach every infostate; a trained policy gives some actions probability 0
+    assert rec["trajectories"] == n and (rec["infostates_visited"] == 936 if warm_batches == 0 else rec["infostates_visited"] > 600)
     # the fold adds exactly these deltas: table after == table before + delta, cell by cell
     s.mccfr_apply_deltas()
     after = s.tables()

@@ -1,5 +1,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from open_spiel_amd import _abi
+if os.environ.get("OSG_VARIANT_LIB"): _abi.LIB_PATH = os.path.abspath(os.environ["OSG_VARIANT_LIB"])
 import time, torch, open_spiel_amd as osa
 ctx = osa.Context(0)
 for game, iters in [("kuhn_poker", 20000), ("kuhn_poker(players=3)", 2000), ("leduc_poker", 500)]:

@@ -1,6 +1,8 @@
 """hex(9) MCTS, BASELINE config 4 (2^16 roots x 1024 simulations) and the 2^13-root shard an 8-GPU run gives each rank."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from open_spiel_amd import _abi
+if os.environ.get("OSG_VARIANT_LIB"): _abi.LIB_PATH = os.path.abspath(os.environ["OSG_VARIANT_LIB"])
 import torch, open_spiel_amd as osa, bench
 ctx = osa.Context(0)
 for n in (1 << 13, 1 << 16):

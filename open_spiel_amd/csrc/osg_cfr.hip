@@ -47,26 +47,17 @@ namespace {
 constexpr int kMaxA = 4;        // widest decision node the MCCFR frame holds (kuhn 2, leduc 3)
 constexpr int kMaxPolicyRow = 8;  // widest policy row a thread regret-matches in registers (kuhn 2, leduc 3)
 constexpr int kMaxFrames = 24;  // traverser decision nodes on one path
+#ifndef OSG_MCCFR_FRAMES2
+#define OSG_MCCFR_FRAMES2 1     // the flat ES-MCCFR kernel keeps the two upper frames of the traverser's stack in registers (0: A/B)
+#endif
+#ifndef OSG_MCCFR_PEEK
+#define OSG_MCCFR_PEEK 0        // 1: the flat ES-MCCFR kernel forms the next draw while the node record is in flight — measured
+                                // 2.7 % SLOWER (profiles/r05_ab_solvers.txt: the draws of traverser / terminal visits are wasted
+                                // vector work on a SIMD that is already two thirds busy issuing); kept as a switch
+#endif
 constexpr double kMccfrInit = 0.000001;  // external_sampling_mccfr.h:59 kInitialTableValues
 
 enum NodeKind : uint8_t { kChanceNode = 0, kDecisionNode = 1, kTerminalNode = 2 };
-
-// hipFuncAttributeMaxDynamicSharedMemorySize is one value per KERNEL, not per solver: a second solver with a smaller
-// footprint must not lower the cap under a first one that is still in use.  Raises only.
-hipError_t raise_lds_cap(const void* kernel, int bytes) {
-  static std::mutex mu;
-  static std::unordered_map<std::string, int> cap;   // per (device, kernel)
-  int device = 0;
-  (void)hipGetDevice(&device);
-  std::lock_guard<std::mutex> lock(mu);
-  int& have = cap[std::to_string(device) + ":" + std::to_string(reinterpret_cast<uintptr_t>(kernel))];
-  if (bytes <= have) return hipSuccess;
-  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e == hipSuccess) have = bytes;
-  return e;
-}
-
-
 
 struct Tree {  // device pointers
   int H, I, A, P, D;
@@ -255,6 +246,9 @@ struct SmallTree {  // device pointers to the extra host-built arrays
   const int32_t* path;        // entries: slot << 24 | is_chance << 23 | index
   int M;                      // decision histories
   int n_path;
+  int L0 = 0;                 // the first level that holds a decision history: the sweep of k_cfr_small stops there — the
+                              // values of the chance levels above (the deals) are read by nobody (phase B reads a decision
+                              // history's own value and its children's), and for kuhn_poker they were 2 of its 5 level steps
 };
 
 struct SmallGlobal {  // global-memory homes of the same arrays, for trees too big for LDS (leduc)
@@ -266,7 +260,15 @@ struct SmallGlobal {  // global-memory homes of the same arrays, for trees too b
   const int32_t* info_player;  // [I]
 };
 
-template <bool kLds, bool kOwner, int kSlots>  // kSlots >= P + 1 reach slots kept in registers
+// kPath: decision entries of a root path the owner form keeps in registers.  The reach block is straight-line code
+// over kPath entries x kSlots reach slots; kuhn_poker's paths hold at most 2 decisions, and with the generic 8 the
+// block was 180 of the ~790 instructions a player pass issues (round 5: one wavefront runs at its instruction issue
+// rate, profiles/r05a_pmc_solvers.json — fewer instructions is the only lever).  The host picks the instantiation from
+// the longest path of the tree (osg_cfr::max_path_decisions).
+// kW > 0 (owner form, alternating updates): every decision node has at most kW actions — the loops over a row's
+// actions are unrolled and predicated instead of running as lane-masked loops (a third of the kernel's instructions
+// were loop control: scalar mask bookkeeping and branches, which a lone wavefront issues one at a time like any other).
+template <bool kLds, bool kOwner, int kSlots, int kPath = 8, int kW = 0>  // kSlots >= P + 1 reach slots kept in registers
 __global__ void __launch_bounds__(1024)
 k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg) {
   extern __shared__ double smem[];
@@ -344,7 +346,7 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
   // order as the walk) is taken once; the decision entries (slot << 24 | policy index) stay in registers,
   // which turns the per-iteration reach computation into independent LDS reads instead of a
   // load -> decode -> load chain per path entry.
-  constexpr int kOwnerPath = 8;
+  constexpr int kOwnerPath = kPath;
   int b_code[kOwnerPath];
   double b_chance = 1.0;
   bool b_fast = false;
@@ -391,14 +393,29 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
     }
   }
 
-  const int passes = cfg.alternating_updates ? P : 1;
+  const int passes = (kW > 0 || cfg.alternating_updates) ? P : 1;
   for (int it = 0; it < iters; ++it) {
     const int iteration = iteration0 + it + 1;
     for (int pass = 0; pass < passes; ++pass) {
-      const int upd = cfg.alternating_updates ? pass : -1;
+      const int upd = (kW > 0 || cfg.alternating_updates) ? pass : -1;
       const int q0 = upd >= 0 ? upd : 0, q1 = upd >= 0 ? upd + 1 : P;
       // value of one non-terminal history from its children (cfr.cc:443-469)
       auto do_node = [&](int h, int k, int fc, int nc, int row) {
+        if constexpr (kW > 0) {   // (launched for alternating updates only: upd >= 0) one value per history, the
+          double v = 0.0;         // updating player's; a decision row is walked unrolled
+          if (k == kChanceNode) {
+            for (int a = 0; a < nc; ++a) v += edge_prob[fc + a] * value[(fc + a) * P + upd];
+          } else {
+#pragma unroll
+            for (int a = 0; a < kW; ++a) {
+              const int aa = a < nc ? a : 0;
+              const double term = cur[row + aa] * value[(fc + aa) * P + upd];
+              v = a < nc ? v + term : v;
+            }
+          }
+          value[h * P + upd] = v;
+          return;
+        }
         for (int q = q0; q < q1; ++q) {
           double v = 0.0;
           for (int a = 0; a < nc; ++a) {
@@ -452,6 +469,22 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
         skip[m] = pruned ? 1 : 0;
         if (pruned) return;
         const double vh = value[h * P + pl];
+        if constexpr (kW > 0) {
+          double cv[kW], pol[kW];
+#pragma unroll
+          for (int a = 0; a < kW; ++a) {   // every operand requested before the first is used
+            const int aa = a < n ? a : 0;
+            cv[a] = value[(fc + aa) * P + pl];
+            pol[a] = cur[i * A + aa];
+          }
+#pragma unroll
+          for (int a = 0; a < kW; ++a)
+            if (a < n) {
+              dreg[m * A + a] = cf_reach * (cv[a] - vh);
+              dpol[m * A + a] = cfg.linear_averaging ? iteration * self_reach * pol[a] : self_reach * pol[a];
+            }
+          return;
+        }
         for (int a = 0; a < n; ++a) {
           dreg[m * A + a] = cf_reach * (value[(fc + a) * P + pl] - vh);
           const double pol = cur[i * A + a];
@@ -473,8 +506,65 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
             if (regrets[i * A + a] < 0) regrets[i * A + a] = 0;
         regret_match_row(regrets + i * A, cur + i * A, n);
       };
+      // the same for the owner form with rows of up to kMaxA actions: the row in registers for the whole fold (one LDS
+      // read and one write-back instead of a read-modify-write per member and action) and 1 / n as an exact constant
+      // (a correctly rounded quotient either way) instead of a division sequence — the same additions in the same order
+      auto do_info_owner = [&](int i, int n, int pl, int m0, int m1) {
+        if (upd >= 0 && pl != upd) return;
+        constexpr int kFW = kW > 0 ? kW : kMaxA;   // the widest row this instantiation meets
+        double r_reg[kFW], r_cum[kFW];
+#pragma unroll
+        for (int a = 0; a < kFW; ++a) {
+          const int k = i * A + (a < n ? a : 0);
+          r_reg[a] = regrets[k];
+          r_cum[a] = cum[k];
+        }
+        if constexpr (kW > 0) {
+          for (int m = m0; m < m1; m += 2) {   // two members per step: their records are requested together, added in order
+            const int mb = m + 1 < m1 ? m + 1 : m;
+            const int sa = skip[m], sb = skip[mb];
+            double ta[kFW], ua[kFW], tb2[kFW], ub[kFW];
+#pragma unroll
+            for (int a = 0; a < kFW; ++a) {
+              const int aa = a < n ? a : 0;
+              ta[a] = dreg[m * A + aa]; ua[a] = dpol[m * A + aa];
+              tb2[a] = dreg[mb * A + aa]; ub[a] = dpol[mb * A + aa];
+            }
+#pragma unroll
+            for (int a = 0; a < kFW; ++a)
+              if (a < n && !sa) { r_reg[a] += ta[a]; r_cum[a] += ua[a]; }
+#pragma unroll
+            for (int a = 0; a < kFW; ++a)
+              if (a < n && !sb && mb != m) { r_reg[a] += tb2[a]; r_cum[a] += ub[a]; }
+          }
+        } else {
+          for (int m = m0; m < m1; ++m) {
+            if (skip[m]) continue;
+#pragma unroll
+            for (int a = 0; a < kFW; ++a)
+              if (a < n) {
+                r_reg[a] += dreg[m * A + a];
+                r_cum[a] += dpol[m * A + a];
+              }
+          }
+        }
+        double sum_pos = 0.0;
+#pragma unroll
+        for (int a = 0; a < kFW; ++a) {
+          if (cfg.regret_matching_plus && r_reg[a] < 0) r_reg[a] = 0;
+          if (a < n && r_reg[a] > 0) sum_pos += r_reg[a];
+        }
+        const double inv_n = n == 1 ? 1.0 : (n == 2 ? 0.5 : (n == 3 ? 1.0 / 3.0 : 0.25));
+#pragma unroll
+        for (int a = 0; a < kFW; ++a)
+          if (a < n) {
+            regrets[i * A + a] = r_reg[a];
+            cum[i * A + a] = r_cum[a];
+            cur[i * A + a] = sum_pos > 0 ? (r_reg[a] > 0 ? r_reg[a] / sum_pos : 0.0) : inv_n;
+          }
+      };
       // ---- A: values, bottom-up.  Alternating passes only need the updating player's value. ----
-      for (int l = t.D - 2; l >= 0; --l) {  // the last level holds terminals only
+      for (int l = t.D - 2; l >= st.L0; --l) {  // the last level holds terminals only
         if (kOwner) {
           if (o_lvl == l && o_k != kTerminalNode) do_node(tid, o_k, o_fc, o_nc, o_row);
         } else {
@@ -499,7 +589,11 @@ k_cfr_small(Tree t, SmallTree st, SmallGlobal sg, Tables tb, int iters, int iter
       __syncthreads();
       // ---- C: per infostate ----
       if (kOwner) {
+#ifdef OSG_AB_R4_REGS
         if (tid < I) do_info(tid, c_n, c_pl, c_m0, c_m1);
+#else
+        if (tid < I) do_info_owner(tid, c_n, c_pl, c_m0, c_m1);   // (the host launches the owner form for A <= kMaxA only)
+#endif
       } else {
         for (int i = tid; i < I; i += nt) do_info(i, nact[i], info_player[i], mem_off[i], mem_off[i + 1]);
       }
@@ -2137,17 +2231,42 @@ k_mccfr_resident_flat(int H, int I, int P, ResidentTree rt, const int32_t* __res
     double top_v = 0.0, top_cv[kA];
 #pragma unroll
     for (int b = 0; b < kA; ++b) top_cv[b] = 0.0;
+#if OSG_MCCFR_FRAMES2
+    // the frame below the top one, in registers too: a pop then takes its frame from registers and only REQUESTS the one
+    // that becomes second — nobody waits for the backing store on the traversal's chain, and a push writes to it only
+    // from the third level on (leduc_poker: the traverser acts at most four times on a path)
+    uint32_t sec_x = 0, sec_fc = 0;
+    int sec_a = 0;
+    double sec_v = 0.0, sec_cv[kA];
+#pragma unroll
+    for (int b = 0; b < kA; ++b) sec_cv[b] = 0.0;
+#endif
     int sp = 0;
     int node = 0;
     for (;;) {
       const uint2 rec = nodes[node];
+#if OSG_MCCFR_PEEK
+      // The next uniform of the stream, formed WHILE the node's record is on its way from LDS: the generator is a
+      // counter and a mixer, so the draw does not depend on the node — only whether it is consumed does (a node of the
+      // traverser or a terminal leaves the counter where it was).  Inside the branch the ~35 instructions of the mixer
+      // sat on the traversal's dependent chain behind the record's decode (profiles/r05a_pmc_solvers.json: the waves of
+      // this kernel are parked two thirds of their cycles); the empty asm keeps the compiler from sinking them back.
+      const uint64_t s_peek = rng.s + 0x9E3779B97F4A7C15ULL;
+      double z_peek = static_cast<double>(mix64(s_peek) >> 11) * (1.0 / 9007199254740992.0);
+      asm volatile("" : "+v"(z_peek));
+#endif
       const int kind = rec.x & 3u;
       if (kind != kTerminalNode) {
         const int nc = (rec.x >> 2) & 63u, fc = rec.y & 0xFFFFFFu;
         const int i = rec.x >> 12;
         const int actor = static_cast<int>((rec.x >> 8) & 15u) - 1;  // -1 at chance nodes
         if (actor != trav) {
+#if OSG_MCCFR_PEEK
+          const double z = z_peek;
+          rng.s = s_peek;
+#else
           const double z = rng.unit();
+#endif
           int pick = nc - 1;
           if (kind == kChanceNode) {  // SampleAction(ChanceOutcomes(), z) (spiel.cc:372-409)
             double acc = 0.0;
@@ -2188,11 +2307,24 @@ k_mccfr_resident_flat(int H, int I, int P, ResidentTree rt, const int32_t* __res
         // traverser: walk every action (:155-162)
         if (sp > 0) {
           if (sp == 1) b1 = top_a;   // entering the traverser's second node inside child top_a of the first
+#if OSG_MCCFR_FRAMES2
+          if (sp > 1) {              // the frame below the top one leaves for the backing store (slot k = frame k)
+            s_x[sp - 2] = sec_x;
+            s_fa[sp - 2] = sec_fc | (static_cast<uint32_t>(sec_a) << 24);
+            s_v[sp - 2] = sec_v;
+#pragma unroll
+            for (int b = 0; b < kA; ++b) s_cv[sp - 2][b] = sec_cv[b];
+          }
+          sec_x = top_x; sec_fc = top_fc; sec_a = top_a; sec_v = top_v;
+#pragma unroll
+          for (int b = 0; b < kA; ++b) sec_cv[b] = top_cv[b];
+#else
           s_x[sp - 1] = top_x;
           s_fa[sp - 1] = top_fc | (static_cast<uint32_t>(top_a) << 24);
           s_v[sp - 1] = top_v;
 #pragma unroll
           for (int b = 0; b < kA; ++b) s_cv[sp - 1][b] = top_cv[b];
+#endif
         }
         top_x = rec.x; top_fc = fc; top_a = 0; top_v = 0.0;
         ++sp;
@@ -2222,12 +2354,26 @@ k_mccfr_resident_flat(int H, int I, int P, ResidentTree rt, const int32_t* __res
         ret = top_v;
         --sp;
         if (sp > 0) {
+#if OSG_MCCFR_FRAMES2
+          top_x = sec_x; top_fc = sec_fc; top_a = sec_a; top_v = sec_v;
+#pragma unroll
+          for (int b = 0; b < kA; ++b) top_cv[b] = sec_cv[b];
+          if (sp > 1) {   // requested now, needed at the NEXT pop (or push): its trip to memory is off the chain
+            sec_x = s_x[sp - 2];
+            sec_fc = s_fa[sp - 2] & 0xFFFFFFu;
+            sec_a = s_fa[sp - 2] >> 24;
+            sec_v = s_v[sp - 2];
+#pragma unroll
+            for (int b = 0; b < kA; ++b) sec_cv[b] = s_cv[sp - 2][b];
+          }
+#else
           top_x = s_x[sp - 1];
           top_fc = s_fa[sp - 1] & 0xFFFFFFu;
           top_a = s_fa[sp - 1] >> 24;
           top_v = s_v[sp - 1];
 #pragma unroll
           for (int b = 0; b < kA; ++b) top_cv[b] = s_cv[sp - 1][b];
+#endif
         }
       }
       if (done) break;
@@ -2739,6 +2885,8 @@ struct osg_cfr {
   int32_t *d_path_off = nullptr, *d_path = nullptr;
   bool small_tree = false;   // the all-in-LDS variant fits
   bool path_kernel = false;  // the path-based kernel (k_cfr_small) is usable at all
+  int max_path_decisions = 0;  // the most decision entries any member's root path holds
+  int first_decision_level = 0;  // the first level with a decision history (SmallTree::L0)
   size_t small_lds_bytes = 0;
   std::vector<int32_t> meta32, info_player32;
   int32_t *d_meta32 = nullptr, *d_info_player32 = nullptr, *d_skip = nullptr;
@@ -3011,6 +3159,12 @@ int build_tree(osg_cfr* s, const char* game_string) {
         else if (s->info_level[i] != level_of[h]) s->eval_ok = false;
       }
   }
+  s->first_decision_level = 0;
+  for (int l = 0; l < s->D; ++l) {   // the first level that holds a decision history
+    bool any = false;
+    for (int h = s->level_off[l]; h < s->level_off[l + 1]; ++h) any |= s->kind[h] == kDecisionNode;
+    if (any) { s->first_decision_level = l; break; }
+  }
   // Root path of every decision history, root-to-leaf: one entry per ancestor edge =
   // (reach slot of the ancestor's actor, where to read the edge probability).
   s->path_off.push_back(0);
@@ -3023,6 +3177,9 @@ int build_tree(osg_cfr* s, const char* game_string) {
       const int32_t idx = chance ? v : s->info[par] * s->A + s->aidx[v];
       rev.push_back((slot << 24) | ((chance ? 1 : 0) << 23) | idx);
     }
+    int decisions = 0;
+    for (int32_t code : rev) decisions += ((code >> 23) & 1) ? 0 : 1;
+    s->max_path_decisions = std::max(s->max_path_decisions, decisions);
     s->path.insert(s->path.end(), rev.rbegin(), rev.rend());
     s->path_off.push_back(static_cast<int32_t>(s->path.size()));
   }
@@ -3659,6 +3816,9 @@ int osg_cfr_create(osg_ctx* ctx, const char* game_string, const osg_cfr_cfg* cfg
                                 reinterpret_cast<const void*>(&k_cfr_small<true, false, 4>),
                                 reinterpret_cast<const void*>(&k_cfr_small<true, false, kMaxPlayers + 1>),
                                 reinterpret_cast<const void*>(&k_cfr_small<true, true, 3>),
+                                reinterpret_cast<const void*>(&k_cfr_small<true, true, 3, 2>),
+                                reinterpret_cast<const void*>(&k_cfr_small<true, true, 3, 2, 2>),
+                                reinterpret_cast<const void*>(&k_cfr_small<true, true, 3, 4>),
                                 reinterpret_cast<const void*>(&k_cfr_small<true, true, 4>),
                                 reinterpret_cast<const void*>(&k_cfr_small<true, true, kMaxPlayers + 1>)};
       e = hipSuccess;
@@ -3857,6 +4017,9 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
     // Path-based kernel: no top-down reach pass; all-in-LDS when the tree is small enough.
     const int M = static_cast<int>(s->mem.size());
     SmallTree st{s->d_path_off, s->d_path, M, static_cast<int>(s->path.size())};
+#ifndef OSG_AB_R4_REGS
+    st.L0 = s->first_decision_level;
+#endif
     SmallGlobal sg{s->d_value, s->d_node_delta, s->d_node_delta + static_cast<size_t>(M) * s->A, s->d_skip,
                    s->d_meta32, s->d_info_player32};
 #define OSG_CFR_SMALL(LDS, OWNER, THREADS, SHMEM)                                                                  \
@@ -3865,9 +4028,20 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
     else if (s->P == 3) k_cfr_small<LDS, OWNER, 4><<<dim3(grid_b), dim3(THREADS), SHMEM, s->ctx->stream>>>(s->tree(), st, sg, tb, iters, s->iteration, s->cfg); \
     else k_cfr_small<LDS, OWNER, kMaxPlayers + 1><<<dim3(grid_b), dim3(THREADS), SHMEM, s->ctx->stream>>>(s->tree(), st, sg, tb, iters, s->iteration, s->cfg); \
   } while (0)
-    if (s->small_tree && s->H <= 1024) {  // one thread per history: descriptors live in registers
+    if (s->small_tree && s->H <= 1024 && s->A <= kMaxA) {  // one thread per history: descriptors live in registers
       const int owner_threads = std::max(64, ((s->H + 63) / 64) * 64);
-      OSG_CFR_SMALL(true, true, owner_threads, s->small_lds_bytes);
+#ifdef OSG_AB_R4_REGS
+      if (false) {}
+#else
+      if (s->P == 2 && s->max_path_decisions <= 2 && s->A == 2 && s->cfg.alternating_updates)   // kuhn_poker
+        k_cfr_small<true, true, 3, 2, 2><<<dim3(grid_b), dim3(owner_threads), s->small_lds_bytes, s->ctx->stream>>>(s->tree(), st, sg, tb, iters, s->iteration, s->cfg);
+      else if (s->P == 2 && s->max_path_decisions <= 2)   // two players, short paths: the 2-entry reach block
+        k_cfr_small<true, true, 3, 2><<<dim3(grid_b), dim3(owner_threads), s->small_lds_bytes, s->ctx->stream>>>(s->tree(), st, sg, tb, iters, s->iteration, s->cfg);
+      else if (s->P == 2 && s->max_path_decisions <= 4)
+        k_cfr_small<true, true, 3, 4><<<dim3(grid_b), dim3(owner_threads), s->small_lds_bytes, s->ctx->stream>>>(s->tree(), st, sg, tb, iters, s->iteration, s->cfg);
+#endif
+      else
+        OSG_CFR_SMALL(true, true, owner_threads, s->small_lds_bytes);
       s->last_kernel = "k_cfr_small<lds, owner>";
     } else if (s->small_tree) {
       OSG_CFR_SMALL(true, false, threads, s->small_lds_bytes);

@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/osg_abi.h"
@@ -41,6 +43,22 @@ struct GameSpec {
 };
 
 int set_error(int code, const std::string& msg);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is one value per KERNEL, not per solver / tree: a second user with a
+// smaller footprint must not lower the cap under a first one that is still in use.  Raises only; asked of the runtime
+// once per (device, kernel) and size step, not per launch.
+inline hipError_t raise_lds_cap(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::unordered_map<std::string, int> cap;   // per (device, kernel)
+  int device = 0;
+  (void)hipGetDevice(&device);
+  std::lock_guard<std::mutex> lock(mu);
+  int& have = cap[std::to_string(device) + ":" + std::to_string(reinterpret_cast<uintptr_t>(kernel))];
+  if (bytes <= have) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
+}
 
 // Random playouts of hex on a one-row or one-column board never end: with the reference's `else if` between a
 // colour's two edges (hex.cc:122-126,146-150) a stone on such a board can only ever carry ONE edge label, so that

@@ -131,12 +131,23 @@ struct NodeRef {
   T* l;
   T* g;
   bool in_lds;
-  OSG_D operator T() const { return (kCoop && in_lds) ? *l : *g; }
+  // kCoop: lane 0 alone stores and all 64 lanes read the field back, so the accesses are VOLATILE there: with plain
+  // ones the compiler may serve a lane that did not store from a value it loaded earlier (e.g. after COUNT(v) += 1),
+  // and the replicated search state of the lanes would part ways.  (The other form has one lane per search: plain.)
+  OSG_D operator T() const {
+    if (kCoop) return in_lds ? *static_cast<volatile T*>(l) : *static_cast<volatile T*>(g);
+    return *g;
+  }
   OSG_D T operator=(T v) const {
     // kCoop: the whole first wavefront runs the search in lockstep (every lane holds the same search state, so that
     // the lanes can share out a node's children); one lane's store is enough — 64 stores to one LDS address serialise
-    if (kCoop && threadIdx.x != 0) return v;
-    if (kCoop && in_lds) *l = v; else *g = v;
+    if (kCoop) {
+      if (threadIdx.x == 0) {
+        if (in_lds) *static_cast<volatile T*>(l) = v; else *static_cast<volatile T*>(g) = v;
+      }
+      return v;
+    }
+    *g = v;
     return v;
   }
   OSG_D T operator+=(T v) const { return *this = static_cast<T>(*this) + v; }
@@ -896,12 +907,21 @@ int osg_mcts_tree_advance(osg_mcts_tree* t, osg_batch* leaf, const double* d_pri
   hipStream_t st = t->ctx->stream;
   // one root, playouts in the launch: the two-wavefront form (OSG_MCTS_COOP=0 keeps the one-lane form, for A/B)
   static const bool coop_on = !(std::getenv("OSG_MCTS_COOP") && std::atoi(std::getenv("OSG_MCTS_COOP")) == 0);
-  if (t->n == 1 && (t->flags & 4) && t->cfg.n_rollouts > 1 && coop_on) {
-    // (the LDS part of the tree is 128 KiB of dynamic shared memory: above the default limit, asked for once per kernel)
-    if (t->board) OSG_DISPATCH_WIDE(t->roots->spec, OSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mcts_advance<G, true, true>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsTreeBytes))));
-    else OSG_DISPATCH_WIDE(t->roots->spec, OSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mcts_advance<G, false, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsTreeBytes))));
+  bool coop = t->n == 1 && (t->flags & 4) && t->cfg.n_rollouts > 1 && coop_on;
+  if (coop) {
+    // the LDS part of the tree is 144 KiB of dynamic shared memory: above the default limit, asked for once per
+    // (device, kernel) (raise_lds_cap); a device that cannot grant it keeps the one-lane form below
+    hipError_t e = hipSuccess;
+    if (t->board) OSG_DISPATCH_WIDE(t->roots->spec, e = raise_lds_cap(reinterpret_cast<const void*>(&k_mcts_advance<G, true, true>),
+                                                                      static_cast<int>(kLdsTreeBytes)));
+    else OSG_DISPATCH_WIDE(t->roots->spec, e = raise_lds_cap(reinterpret_cast<const void*>(&k_mcts_advance<G, false, true>),
+                                                             static_cast<int>(kLdsTreeBytes)));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      coop = false;
+    }
+  }
+  if (coop) {
     if (t->board) {
       OSG_DISPATCH_WIDE(t->roots->spec, k_mcts_advance<G, true, true><<<dim3(1), dim3(2 * kBlockM), kLdsTreeBytes, st>>>(
                                        P, static_cast<const typename G::word_t*>(t->roots->d_words),

@@ -142,3 +142,45 @@ def test_illegal_action_is_reported(ctx):
         osa.BatchedEnvironment(ctx, "tic_tac_toe", 4, observation_type=osa.ObservationType.INFORMATION_STATE)
     with pytest.raises(ValueError):
         osa.BatchedEnvironment(ctx, "tic_tac_toe", 4, discount=1.5)
+
+
+@pytest.mark.parametrize("game", ["connect_four", "connect_four(rows=5,columns=6,x_in_row=3)"])
+def test_env_step_two_per_thread_equals_one_per_thread(ctx, game):
+    """k_env_step_x2 (two environments per thread, 16-byte accesses; taken for even batches of two-plane two-player games
+    with aligned side arrays) against k_env_step (an odd batch takes it): the same states, step types, players, rewards,
+    masks and reset flags step by step over several episodes, illegal actions refused and counted the same way."""
+    import torch
+    import open_spiel_amd as osa
+    from open_spiel_amd._abi import check, lib
+    n = 1 << 12
+
+    def make(count):
+        b = osa.StateBatch(ctx, game, count)
+        return dict(b=b, reset=torch.ones(count, dtype=torch.uint8, device="cuda"),
+                    cur=torch.empty(count, dtype=torch.int8, device="cuda"), typ=torch.empty(count, dtype=torch.uint8, device="cuda"),
+                    rew=torch.empty((count, 2), dtype=torch.float64, device="cuda"),
+                    msk=torch.empty((count, 1), dtype=torch.int32, device="cuda"))
+
+    even, odd = make(n), make(n + 1)        # the odd batch keeps the one-environment kernel; its first n environments are compared
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    acts = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+    for t in range(60):
+        for e, count in ((even, n), (odd, n + 1)):
+            check(lib().osg_env_step(e["b"]._h, acts[:count].contiguous().data_ptr(), e["reset"].data_ptr(), 77, 0, t,
+                                     e["cur"].data_ptr(), e["typ"].data_ptr(), e["rew"].data_ptr(), e["msk"].data_ptr()))
+        torch.cuda.synchronize()   # (ctx.synchronize() would report the illegal actions of the previous step)
+        for k in ("reset", "cur", "typ", "rew", "msk"):
+            assert torch.equal(even[k], odd[k][:n]), (game, t, k)
+        assert (even["b"].raw_words() == odd["b"].raw_words()[:, :n]).all(), (game, t)
+        # next actions: a random legal column, every 37th environment an illegal one (counted, state unchanged)
+        m = even["msk"][:, 0]
+        cols = even["b"].desc.num_distinct_actions
+        bits = ((m.unsqueeze(1) >> torch.arange(cols, device="cuda", dtype=torch.int32)) & 1).to(torch.float32)
+        pick = (bits * (torch.rand(bits.shape, device="cuda", generator=gen) + 0.01)).argmax(1).to(torch.int32)
+        pick = torch.where(bits.sum(1) > 0, pick, torch.full_like(pick, -1))
+        pick[::37] = cols + 3
+        acts[:n] = pick
+        acts[n] = pick[0]
+    with pytest.raises(osa.OsgError, match="illegal"):   # both forms counted their refused actions on the context
+        ctx.synchronize()

@@ -26,15 +26,18 @@ import yaml
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 
-# Kernels on a BASELINE config or named by a VERDICT: these must not spill (prefix match on the demangled name).
+# Kernels on a BASELINE config or named by a VERDICT: these must not spill (prefix match on the short name below).
 HOT = [
     "k_step_c4std2", "k_step_c4std<", "k_step_hexvec<3, 2",
-    "k_cfr_small<true, true, 3>", "k_cfr_split<3, false", "k_cfr_split<3, true",
-    "k_mcts_wave<(anonymous namespace)::HexT<3>, true, true, false",
-    "k_env_step<(anonymous namespace)::C4T<6, 7, 4, unsigned long>",
+    "k_cfr_small<true, true, 3>", "k_cfr_split<3, false, 512>", "k_cfr_split<3, true, 512>",
+    "k_env_step<osg::C4T<6, 7, 4, unsigned long> >",
 ]
-# Kernels whose scratch is the design (a per-lane frame stack), listed so the check knows them.
-SCRATCH_BY_DESIGN = ["k_mccfr<", "k_os_mccfr<", "k_mccfr_full_average"]
+# Hot kernels whose parked registers are known, measured and kept (the note says where the decision is recorded).
+KNOWN = {
+    "k_mcts_wave<osg::HexT<3>, true, true, false>":
+        "44 scalar registers parked in vector lanes + 2 vector registers in scratch at 7 waves per SIMD; the form without them "
+        "measured 2.7 % slower (profiles/r05_ab_register_work.txt, osg_mcts_wave.hip above wave_search)",
+}
 
 
 def demangle(names):
@@ -120,6 +123,9 @@ def main():
         lines.append("# HOT kernels that spill: " + "; ".join(bad))
     else:
         lines.append("# no kernel of the HOT list (tools/kernel_resources.py) spills or uses scratch")
+    for r in rows:
+        if r["name"] in KNOWN:
+            lines.append(f"# known: {r['name']}: {r['sspill']} scalar / {r['vspill']} vector registers spilled, {r['scratch']} B scratch — {KNOWN[r['name']]}")
     text = "\n".join(lines) + "\n"
     if a.out:
         with open(a.out, "w") as f:

@@ -29,4 +29,11 @@ for logn in (20, 22, 24):
         want = want or key
         print(f"hex(9) step n=2^{logn} states/thread:nt={knob}  {s * 1e6:9.2f} us  {118 * n / s / 8e12:.3f} of 8 TB/s  "
               f"{'same' if key == want else 'DIFFERENT'}", flush=True)
+    # round 5: the same step without the successor's mask row (d_mask == NULL: 106 B moved per state + 3 B of SURVEY's
+    # padding = its 109 B; the fraction is quoted on the bytes actually moved)
+    os.environ.pop("OSG_HEX_STEP", None)
+    s = timeit(lambda: b.step(acts, dst=dst, mask=mask, status=status), 100 if logn < 24 else 30, 10)
+    print(f"hex(9) step n=2^{logn} default, mask row written      {s * 1e6:9.2f} us  {118 * n / s / 8e12:.3f} of 8 TB/s (118 B)", flush=True)
+    s = timeit(lambda: b.step(acts, dst=dst, status=status, want_mask=False), 100 if logn < 24 else 30, 10)
+    print(f"hex(9) step n=2^{logn} default, NO mask row           {s * 1e6:9.2f} us  {106 * n / s / 8e12:.3f} of 8 TB/s (106 B)", flush=True)
     del b, dst, mask, status, acts

@@ -671,7 +671,9 @@ constexpr int kSplitChunk = 6;       // members whose records are requested toge
 // wavefronts, at most 2 per SIMD: compiled for 1024 threads the kernel was capped at 128 VGPRs and spilled (24 vector +
 // 69 scalar registers, 84 B of scratch per lane — round 4's code object); compiled for 512 it has 256 and keeps
 // everything in registers.  split_kernel() picks the instantiation by the launch size.
-template <int kSlots, bool kBr = false, int kBound = 1024>  // kSlots >= P + 1
+// kW > 0 (alternating updates or kBr: one value per history): decision rows of at most kW actions are walked unrolled
+// and predicated instead of as lane-masked loops (as in k_cfr_small).
+template <int kSlots, bool kBr = false, int kBound = 1024, int kW = 0>  // kSlots >= P + 1
 __global__ void __launch_bounds__(kBound)
 k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg,
             const int32_t* __restrict__ best = nullptr) {
@@ -744,12 +746,12 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
   }
   __syncthreads();
 
-  const int passes = (kBr || cfg.alternating_updates) ? P : 1;
+  const int passes = (kW > 0 || kBr || cfg.alternating_updates) ? P : 1;
   unsigned int epoch = 0;
   for (int it = 0; it < iters; ++it) {
     const int iteration = iteration0 + it + 1;
     for (int pass = 0; pass < passes; ++pass) {
-      const int upd = (kBr || cfg.alternating_updates) ? pass : -1;
+      const int upd = (kW > 0 || kBr || cfg.alternating_updates) ? pass : -1;
       const int q0 = upd >= 0 ? upd : 0, q1 = upd >= 0 ? upd + 1 : P;
       if (kBr) {  // policy_overrides (cfr.cc:365-372)
         for (int i = tid; i < t.I; i += blockDim.x) {
@@ -761,7 +763,20 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
       }
       // ---- A: values, bottom-up inside the subtree (cfr.cc:443-469) ----
       for (int l = t.D - 2; l >= sp.L; --l) {
-        if (o_lvl == l && o_k != kTerminalNode) {
+        if (kW > 0 && o_lvl == l && o_k != kTerminalNode) {   // (kW > 0 is launched with upd >= 0 only)
+          double v = 0.0;
+          if (o_k == kChanceNode) {
+            for (int a = 0; a < o_nc; ++a) v += l_edge[o_fc + a] * value[(o_fc + a) * P + upd];
+          } else {
+#pragma unroll
+            for (int a = 0; a < (kW > 0 ? kW : 1); ++a) {
+              const int aa = a < o_nc ? a : 0;
+              const double term = pol[o_row + aa] * value[(o_fc + aa) * P + upd];
+              v = a < o_nc ? v + term : v;
+            }
+          }
+          value[tid * P + upd] = v;
+        } else if (kW == 0 && o_lvl == l && o_k != kTerminalNode) {
           for (int q = q0; q < q1; ++q) {
             double v = 0.0;
             for (int a = 0; a < o_nc; ++a) {   // (six children per round trip with clamped indices: 18.6 vs 16.9 us per
@@ -872,7 +887,9 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
             }
           }
         }
-        // RM+ clamp (cfr.cc:265-273 with regret_matching_plus) and regret matching (regret_match_row, unrolled)
+        // RM+ clamp (cfr.cc:265-273 with regret_matching_plus) and regret matching (regret_match_row, unrolled; 1 / n as
+        // an exact constant — a correctly rounded quotient either way — instead of a division sequence)
+        const double inv_n = c_n == 1 ? 1.0 : (c_n == 2 ? 0.5 : (c_n == 3 ? 1.0 / 3.0 : 0.25));
         double sum_pos = 0.0;
 #pragma unroll
         for (int a = 0; a < kSplitMaxA; ++a) {
@@ -882,7 +899,7 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
 #pragma unroll
         for (int a = 0; a < kSplitMaxA; ++a) {
           if (a < c_n) {
-            const double matched = sum_pos > 0 ? (r_reg[a] > 0 ? r_reg[a] / sum_pos : 0.0) : 1.0 / c_n;
+            const double matched = sum_pos > 0 ? (r_reg[a] > 0 ? r_reg[a] / sum_pos : 0.0) : inv_n;
             regrets[c_i * A + a] = r_reg[a];
             cum[c_i * A + a] = r_cum[a];
             cur[c_i * A + a] = matched;
@@ -911,6 +928,8 @@ k_cfr_split(Tree t, SmallTree st, SplitTree sp, Tables tb, int iters, int iterat
   }
 }
 
+// (the row-width instantiation: two players, rows of exactly up to 3 actions — leduc_poker — with one value per history)
+static const void* split_kernel_w3() { return reinterpret_cast<const void*>(&k_cfr_split<3, false, 512, 3>); }
 template <int kBound>
 static const void* split_kernel_bound(int P, bool br) {
   if (br) return P == 2 ? reinterpret_cast<const void*>(&k_cfr_split<3, true, kBound>)
@@ -921,10 +940,12 @@ static const void* split_kernel_bound(int P, bool br) {
                           : reinterpret_cast<const void*>(&k_cfr_split<kMaxPlayers + 1, false, kBound>));
 }
 // The instantiation for a launch of `threads` threads per workgroup (see kBound above).
-static const void* split_kernel(int P, bool br, int threads) {
+static const void* split_kernel(int P, bool br, int threads, int A = 0, bool one_value = false) {
 #ifdef OSG_AB_R4_REGS   // measurement only (tools/build_variant.sh): round 4's instantiation, bound 1024 for every launch
   return split_kernel_bound<1024>(P, br);
 #else
+  // (the CFR-BR pass set keeps the loop form: its row-width instantiation parks five scalar registers in vector lanes)
+  if (threads <= 512 && P == 2 && A == 3 && one_value && !br && !std::getenv("OSG_CFR_SPLIT_W0")) return split_kernel_w3();
   return threads <= 512 ? split_kernel_bound<512>(P, br) : split_kernel_bound<1024>(P, br);
 #endif
 }
@@ -3421,13 +3442,15 @@ int build_split(osg_cfr* s) {
   OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_split_bar), sizeof(unsigned int) * 4));
   OSG_HIP(hipMemsetAsync(s->d_split_bar, 0, sizeof(unsigned int) * 4, st));
   OSG_HIP(hipMemsetAsync(s->d_split_terms, 0, sizeof(double) * 2 * kSplitRec * std::max<size_t>(M, 1), st));
-  if (raise_lds_cap(split_kernel(s->P, false, threads), static_cast<int>(lds)) != hipSuccess) {
+  if (raise_lds_cap(split_kernel(s->P, false, threads), static_cast<int>(lds)) != hipSuccess ||
+      raise_lds_cap(split_kernel(s->P, false, threads, s->A, true), static_cast<int>(lds)) != hipSuccess) {
     (void)hipGetLastError();
     return OSG_OK;
   }
   // the CFR-BR pass set keeps one more [I, A] array (the effective policy)
   s->split_br_ok = lds + sizeof(double) * IA <= 158 * 1024;
-  if (s->split_br_ok && raise_lds_cap(split_kernel(s->P, true, threads), static_cast<int>(lds + sizeof(double) * IA)) != hipSuccess) {
+  if (s->split_br_ok && (raise_lds_cap(split_kernel(s->P, true, threads), static_cast<int>(lds + sizeof(double) * IA)) != hipSuccess ||
+                         raise_lds_cap(split_kernel(s->P, true, threads, s->A, true), static_cast<int>(lds + sizeof(double) * IA)) != hipSuccess)) {
     (void)hipGetLastError();
     s->split_br_ok = false;
   }
@@ -3896,7 +3919,7 @@ static int launch_split(osg_cfr* s, SmallTree stree, SplitTree sp, Tables tb, in
   Tree tr = s->tree();
   const int32_t* best = br ? s->d_best : nullptr;
   void* args[] = {&tr, &stree, &sp, &tb, &iters, &iteration0, &cfg, &best};
-  const void* kern = split_kernel(s->P, br, s->split_threads);
+  const void* kern = split_kernel(s->P, br, s->split_threads, s->A, br || cfg.alternating_updates);
   const size_t lds = s->split_lds_bytes + (br ? sizeof(double) * static_cast<size_t>(s->I) * s->A : 0);
   // OSG_CFR_PLAIN_LAUNCH=1: an ordinary launch, for hosts that run the solver alone on the device — the cooperative
   // launch costs 20 us per call (47.6 vs 27.6 us per one-iteration launch, CFR-BR 1.30e4 vs 1.82e4 it/s), which only the

@@ -3,7 +3,8 @@
 #
 #   gpurun --timeout 2400 -- 'bash tools/gpu_validation.sh r02'
 #
-# 0. __graft_entry__.smoke();
+# 0. tools/kernel_resources.py --check (registers / spills / scratch of every entry point; a hot kernel that spills fails);
+#    __graft_entry__.smoke();
 # 1. the GPU test suite (parity vs the oracle, vs the recorded outputs of the genuine reference,
 #    checkpoint interop with oracle/_ref, the world-size-1 collective);
 # 2. bench.py (one JSON line: env-steps/s + roofline + cpu_baseline of the genuine reference build);
@@ -18,13 +19,18 @@ mkdir -p "$OUT"
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 
-echo "== smoke()" | tee "$OUT/summary.txt"
+echo "== kernel resources (code object metadata; no hot kernel may spill)" | tee "$OUT/summary.txt"
+python tools/kernel_resources.py --check --out "$OUT/kernel_resources.txt"
+echo "kernel_resources --check exit $?" | tee -a "$OUT/summary.txt"
+tail -3 "$OUT/kernel_resources.txt" | cut -c1-200 | tee -a "$OUT/summary.txt"
+
+echo "== smoke()" | tee -a "$OUT/summary.txt"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1
 echo "smoke exit $?" | tee -a "$OUT/summary.txt"
 tail -2 "$OUT/smoke.log" | tee -a "$OUT/summary.txt"
 
 echo "== pytest -m gpu" | tee -a "$OUT/summary.txt"
-timeout 1500 python -m pytest tests -q -m gpu --durations=15 > "$OUT/pytest_gpu.log" 2>&1
+timeout 1800 python -m pytest tests -q -m gpu --durations=15 > "$OUT/pytest_gpu.log" 2>&1
 echo "pytest exit $?" | tee -a "$OUT/summary.txt"
 tail -5 "$OUT/pytest_gpu.log" | tee -a "$OUT/summary.txt"
 
@@ -64,6 +70,9 @@ for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVE_CYCLE
 done
 python tools/pmc_mcts.py "$OUT" "$TAG" 2>&1 | tee -a "$OUT/summary.txt"
 
+echo "== counters of the solver kernels of configs 3 and 5 (k_cfr_small, k_mccfr_resident_flat)" | tee -a "$OUT/summary.txt"
+bash tools/pmc_solvers.sh "$TAG" 2>&1 | cut -c1-400 | tee -a "$OUT/summary.txt"
+
 echo "== probes" | tee -a "$OUT/summary.txt"
 timeout 600 python tools/probe_mcts_bench.py > "$OUT/mcts_bench.log" 2>&1; grep hex "$OUT/mcts_bench.log" | tee -a "$OUT/summary.txt"
 timeout 600 python tools/probe_cfr.py > "$OUT/probe_cfr.log" 2>&1; tail -12 "$OUT/probe_cfr.log" | cut -c1-200 | tee -a "$OUT/summary.txt"
@@ -73,6 +82,7 @@ timeout 300 python tools/probe_judge.py > "$OUT/probe_judge.log" 2>&1; grep -v a
 timeout 300 python tools/probe_cfr_sub.py > "$OUT/probe_cfr_sub.log" 2>&1; grep -E "^grid|^sub|^auto" "$OUT/probe_cfr_sub.log" | tee -a "$OUT/summary.txt"
 timeout 300 python tools/probe_obs_lds.py > "$OUT/probe_obs_lds.log" 2>&1; grep -v amdgpu.ids "$OUT/probe_obs_lds.log" | tee -a "$OUT/summary.txt"
 timeout 300 python tools/probe_single_root.py > "$OUT/probe_single_root.log" 2>&1; tail -6 "$OUT/probe_single_root.log" | cut -c1-200 | tee -a "$OUT/summary.txt"
+timeout 300 python tools/probe_hex_step.py > "$OUT/hex_step.log" 2>&1; grep "default" "$OUT/hex_step.log" | tee -a "$OUT/summary.txt"
 # keep the merged-back directory small (gpurun merges at most 64 MiB)
 find "$OUT" -name '*.db' -size +20M -delete 2>/dev/null
 du -sh "$OUT" | tee -a "$OUT/summary.txt"

@@ -29,7 +29,8 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # Kernels on a BASELINE config or named by a VERDICT: these must not spill (prefix match on the short name below).
 HOT = [
     "k_step_c4std2", "k_step_c4std<", "k_step_hexvec<3, 2",
-    "k_cfr_small<true, true, 3>", "k_cfr_split<3, false, 512>", "k_cfr_split<3, true, 512>",
+    "k_cfr_small<true, true, 3, 2, 2>", "k_cfr_split<3, false, 512, 3>", "k_cfr_split<3, false, 512, 0>", "k_cfr_split<3, true, 512, 0>",
+    "k_env_step_x2<osg::C4T<6, 7, 4, unsigned long> >",
     "k_env_step<osg::C4T<6, 7, 4, unsigned long> >",
 ]
 # Hot kernels whose parked registers are known, measured and kept (the note says where the decision is recorded).

@@ -427,7 +427,12 @@ int osg_mccfr_sample(osg_cfr* s, uint64_t seed, int64_t first_trajectory, int64_
  * current policy (for RCCL all-reduce by the caller, or inspection). */
 int osg_cfr_table_ptrs(osg_cfr* s, double** d_regrets, double** d_cum_policy, double** d_cur_policy);
 /* MCCFR mini-batch protocol for multi-GPU: deltas accumulate into separate
- * [I, Amax] buffers; the caller all-reduces them (RCCL) and then folds them in. */
+ * [I, Amax] buffers; the caller all-reduces them (RCCL) and then folds them in.
+ * CONTRACT for the solver's own delta buffers (these and osg_mccfr_spare_delta_buffer's): the caller may write them
+ * only between a sample and the apply that follows it (the in-place all-reduce does exactly that).  osg_mccfr_apply_deltas
+ * leaves a buffer zero and the next osg_mccfr_sample relies on it — it skips its fill launch for a buffer the last fold
+ * left clean — so anything written into the buffer after the apply is added to the next mini-batch.  Caller-owned
+ * buffers (osg_mccfr_sample_into with memory of the caller) are always zero-filled first. */
 int osg_mccfr_delta_ptrs(osg_cfr* s, double** d_regret_delta, double** d_policy_delta);
 int osg_mccfr_apply_deltas(osg_cfr* s);
 /* The same two halves on a CALLER's delta buffer d_delta = regret deltas [I, Amax] | average-policy deltas

@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -1094,6 +1095,18 @@ struct SubTree {
   unsigned long long timeout_ticks;
   unsigned long long* stamps;    // null, or [P][5] wall-clock stamps of workgroup 0 in the launch's last iteration
   int stamp_wg = 0;              // the workgroup that writes the stamps (OSG_CFR_SUB_STAMPS = its index + 1)
+  // Forest form (round 5): when there are more deal subtrees than resident workgroups (3-player leduc: 336 on 256), the
+  // tree is cut ONE LEVEL DEEPER into pieces (the children of the deal roots) and the pieces are packed into one bin
+  // per workgroup, balanced by size: "subtree g" above is then a forest of pieces in level order, every workgroup
+  // sweeps ONE forest per pass and none takes two while the others wait.  The deal roots ("upper" histories) belong to
+  // no forest: their policy rows ride in the forests' LDS rows (path codes), the pieces' root values leave through
+  // root_value, and an upper member's terms are formed by the fold from those values (skip word = 2 + its index).
+  const int32_t* nroot = nullptr;     // [G] piece roots of the forest; null: the bins are whole subtrees
+  const int32_t* root_loc = nullptr;  // [G, NR] local index of piece root r
+  const int32_t* root_idx = nullptr;  // [G, NR] its slot in root_value
+  int NR = 0;
+  double* root_value = nullptr;       // [histories of the pieces' level] the updating player's value of every piece root
+  const int32_t* upper_rec = nullptr; // [U, 8] first child's slot in root_value, info * A, actions, 0, chance product (lo, hi), 0, 0
 };
 OSG_D double readlane_f64(double v, int lane) {   // lane is wave-uniform: two v_readlane_b32, no LDS permute
   const long long b = __double_as_longlong(v);
@@ -1220,6 +1233,12 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
           }
         }
         if (stamp && g == static_cast<int>(blockIdx.x)) sp.stamps[upd * 5 + 1] = wall_clock64();
+        if (sp.nroot) {   // forest form: the values the upper members' terms are formed from (in the fold)
+          const int nr = sp.nroot[g];
+          for (int r = tid; r < nr; r += kSubThreads)
+            store_through(sp.root_value + sp.root_idx[static_cast<size_t>(g) * sp.NR + r],
+                          s_value[sp.root_loc[static_cast<size_t>(g) * sp.NR + r]]);
+        }
         // ---- B: the updating player's members of this subtree (k_gcfr_members) ----
         // A member's record is one contiguous run of ints (SubTree::sub_rec) in the order the subtree visits its members:
         // ONE round trip brings all of it.  The probabilities on the root path are the chance product (constant: formed
@@ -1352,6 +1371,37 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
                   xr[u][a] = load_through(sp.dreg + static_cast<size_t>(xm[u]) * A + a);
                   xp[u][a] = load_through(sp.dpol + static_cast<size_t>(xm[u]) * A + a);
                 }
+            }
+            // An upper member (forest form: a deal root; its skip word is 2 + its index, written once by the host): its
+            // terms are formed here, by k_gcfr_members' expressions — the value of the history is the policy-weighted sum
+            // of its children's values in action order (the sweep's), every player's reach on its root path is the
+            // empty product 1.0, so the counterfactual reach is 1.0 * ... * chance = chance and the own reach 1.0.
+#pragma unroll
+            for (int u = 0; u < kSubFoldX; ++u) {
+              if (xm[u] < 0 || xs[u] < 2) continue;
+              const int32_t* ur = sp.upper_rec + static_cast<size_t>(xs[u] - 2) * 8;
+              const int slot0 = ur[0], row = ur[1];
+              const double chance = __longlong_as_double((static_cast<long long>(ur[5]) << 32) | static_cast<unsigned int>(ur[4]));
+              double va[kSplitMaxA], pa[kSplitMaxA];
+#pragma unroll
+              for (int a = 0; a < kSplitMaxA; ++a) {
+                va[a] = 0.0; pa[a] = 0.0;
+                if (a < xn[u]) { va[a] = load_through(sp.root_value + slot0 + a); pa[a] = load_through(tb.cur + row + a); }
+              }
+              double vh = 0.0;
+#pragma unroll
+              for (int a = 0; a < kSplitMaxA; ++a)
+                if (a < xn[u]) vh += pa[a] * va[a];
+              const double self_reach = 1.0;
+              double cf_reach = 1.0;
+              cf_reach *= chance;
+#pragma unroll
+              for (int a = 0; a < kSplitMaxA; ++a)
+                if (a < xn[u]) {
+                  xr[u][a] = cf_reach * (va[a] - vh);
+                  xp[u][a] = cfg.linear_averaging ? iteration * self_reach * pa[a] : self_reach * pa[a];
+                }
+              xs[u] = 0;
             }
 #pragma unroll
             for (int u = 0; u < kSubFoldX; ++u) {
@@ -2931,6 +2981,11 @@ struct osg_cfr {
   int32_t *d_sub_nloc = nullptr, *d_sub_desc = nullptr, *d_sub_fc = nullptr, *d_sub_aux = nullptr, *d_sub_mem_off = nullptr,
           *d_sub_info_off = nullptr, *d_sub_info_list = nullptr;
   unsigned int* d_sub_bar = nullptr;
+  // forest form of k_cfr_sub (SubTree's comment): the kernel's own skip words, piece roots, upper members
+  bool sub_forest = false;
+  int sub_NR = 0, sub_G0 = 0;   // G0: the deal subtrees; sub_G: the bins they (or their pieces) were packed into
+  int32_t *d_sub_skip = nullptr, *d_sub_nroot = nullptr, *d_sub_root_loc = nullptr, *d_sub_root_idx = nullptr, *d_sub_upper_rec = nullptr;
+  double* d_sub_root_value = nullptr;
   unsigned int* h_sub_err = nullptr;   // pinned: raised by the kernel when a grid barrier times out
   // policy evaluation (k_policy_eval)
   std::vector<int32_t> info_level, mem_index;
@@ -3582,7 +3637,9 @@ int build_eval_jobs(osg_cfr* s) {
 
 // The subtrees of k_cfr_sub: the same cut as build_split (the first level with a node that is not a chance node),
 // any number of subtrees (a workgroup takes several in turn when the cooperative grid is smaller), up to 8 x 1024
-// histories each.
+// histories each.  Round 5, forest form: with more subtrees than compute units the bins of the workgroups are packed —
+// whole subtrees if they fit, else the pieces one level below the cut (SubTree's comment) — so that every workgroup
+// sweeps one bin per pass.  OSG_CFR_SUB_PACK=0 keeps a subtree per bin.
 template <int kK> const void* cfr_sub_kernel() { return reinterpret_cast<const void*>(&k_cfr_sub<kK>); }
 int build_sub(osg_cfr* s) {
   s->sub_ok = false;
@@ -3595,15 +3652,69 @@ int build_sub(osg_cfr* s) {
     if (!all_chance) break;
   }
   if (L < 1 || L >= s->D - 1) return OSG_OK;
-  const int G = s->level_off[L + 1] - s->level_off[L];
-  if (G < 8) return OSG_OK;
-  std::vector<std::vector<int32_t>> hist(G);
+  if (s->level_off[L + 1] - s->level_off[L] < 8) return OSG_OK;
   std::vector<int32_t> sub_of(s->H, -1), loc_of(s->H, -1), level_of(s->H, 0);
   for (int l = 0; l < s->D; ++l)
     for (int h = s->level_off[l]; h < s->level_off[l + 1]; ++h) level_of[h] = l;
-  for (int g = 0; g < G; ++g) sub_of[s->level_off[L] + g] = g;
-  for (int h = s->level_off[L]; h < s->H; ++h) {
-    if (h >= s->level_off[L + 1]) sub_of[h] = sub_of[s->parent[h]];
+  // ---- the bins: which histories a workgroup sweeps together ----
+  // sizes of every history's subtree (children have larger indices than their parent)
+  std::vector<int32_t> sz(s->H, 1), szd(s->H, 0);
+  for (int h = s->H - 1; h >= 1; --h) {
+    szd[h] += s->kind[h] == kDecisionNode ? 1 : 0;
+    sz[s->parent[h]] += sz[h];
+    szd[s->parent[h]] += szd[h];
+  }
+  int cus = s->num_cus;
+  if (cus <= 0) {
+    hipDeviceProp_t dp;
+    if (hipGetDeviceProperties(&dp, s->ctx->device) != hipSuccess) { (void)hipGetLastError(); return OSG_OK; }
+    cus = std::max(1, dp.multiProcessorCount);
+  }
+  // longest-processing-time packing of the histories of level `lp` into at most `cus` bins, balanced by subtree size
+  auto pack = [&](int lp, std::vector<int32_t>* bin_of, int* bins) -> bool {
+    const int n = s->level_off[lp + 1] - s->level_off[lp], base = s->level_off[lp];
+    const int nb = std::min(n, cus);
+    std::vector<int32_t> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sz[base + a] > sz[base + b]; });
+    std::vector<int64_t> load(nb, 0), loadd(nb, 0), cnt(nb, 0);
+    bin_of->assign(n, 0);
+    for (int i : order) {
+      int best = 0;
+      for (int b = 1; b < nb; ++b)
+        if (load[b] < load[best]) best = b;
+      (*bin_of)[i] = best;
+      load[best] += sz[base + i]; loadd[best] += szd[base + i]; ++cnt[best];
+    }
+    for (int b = 0; b < nb; ++b) {
+      const int64_t nl = load[b], nd = loadd[b] + cnt[b];   // (+ the rows of the pieces' upper parents)
+      if (nl > 8 * kSubThreads || nd > kSubKD * kSubThreads || sizeof(double) * (nl + nd * s->A) > 150 * 1024) return false;
+    }
+    *bins = nb;
+    return true;
+  };
+  const int G0 = s->level_off[L + 1] - s->level_off[L];
+  int G = G0, piece_level = L;
+  bool upper = false;          // the histories of level L belong to no bin
+  std::vector<int32_t> bin_of;
+  const char* pk = std::getenv("OSG_CFR_SUB_PACK");
+  if (G0 > cus && !(pk && pk[0] == '0')) {
+    int nb = 0;
+    if (pack(L, &bin_of, &nb)) {
+      G = nb;
+    } else if (L + 1 < s->D - 1 && pack(L + 1, &bin_of, &nb)) {
+      G = nb; piece_level = L + 1; upper = true;
+    } else {
+      bin_of.clear();
+    }
+  }
+  if (bin_of.empty()) {
+    bin_of.resize(G0);
+    for (int g = 0; g < G0; ++g) bin_of[g] = g;
+  }
+  std::vector<std::vector<int32_t>> hist(G);
+  for (int h = s->level_off[piece_level]; h < s->H; ++h) {
+    sub_of[h] = h < s->level_off[piece_level + 1] ? bin_of[h - s->level_off[piece_level]] : sub_of[s->parent[h]];
     const int g = sub_of[h];
     loc_of[h] = static_cast<int32_t>(hist[g].size());
     hist[g].push_back(h);
@@ -3614,9 +3725,16 @@ int build_sub(osg_cfr* s) {
   if (NL > 8 * kSubThreads) return OSG_OK;
   const size_t M = s->mem.size();
   std::vector<std::vector<int32_t>> members(static_cast<size_t>(G) * s->P);
+  std::vector<int32_t> upper_members;            // forest form: the members of level L, in member order
+  std::vector<int32_t> sub_skip(std::max<size_t>(M, 1), 0);
   for (size_t m = 0; m < M; ++m) {
     const int h = s->mem[m];
-    if (sub_of[h] < 0) return OSG_OK;  // a decision node above the cut
+    if (sub_of[h] < 0) {
+      if (!upper || level_of[h] != L) return OSG_OK;  // a decision node above the cut
+      sub_skip[m] = 2 + static_cast<int32_t>(upper_members.size());
+      upper_members.push_back(static_cast<int32_t>(m));
+      continue;
+    }
     members[static_cast<size_t>(sub_of[h]) * s->P + s->actor[h]].push_back(static_cast<int32_t>(m));
   }
   std::vector<int32_t> nloc(G), desc(static_cast<size_t>(G) * NL, kTerminalNode | (63 << 10)), fc(static_cast<size_t>(G) * NL, 0),
@@ -3636,6 +3754,7 @@ int build_sub(osg_cfr* s) {
   if (per_player * s->P > kSubCodeChunks) return OSG_OK;   // more decisions on a path than the packed record keeps
   const int PL = 4 * per_player * s->P;
   std::vector<std::vector<int32_t>> dec_rows(G);
+  std::vector<std::map<int32_t, int32_t>> extra_row(G);
   std::vector<int32_t> anc, filled(s->P);
   int32_t n_members = 0;
   for (int g = 0; g < G; ++g) {
@@ -3672,9 +3791,22 @@ int build_sub(osg_cfr* s) {
             chance *= s->edge_prob[code & 0x7FFFFF];
           } else {
             const int pl = (code >> 24) & 0xF, a_idx = (code & 0x7FFFFF) - s->info[anc[e]] * s->A;
-            if (sub_of[anc[e]] != g || a_idx < 0 || a_idx >= s->A) return OSG_OK;   // (cannot happen: decisions sit below the cut)
-            codes[static_cast<size_t>(pl) * 4 * per_player + filled[pl]++] =
-                aux[static_cast<size_t>(g) * NL + loc_of[anc[e]]] * s->A + a_idx;
+            if (a_idx < 0 || a_idx >= s->A) return OSG_OK;   // (cannot happen)
+            int d_anc;
+            if (sub_of[anc[e]] == g) {
+              d_anc = aux[static_cast<size_t>(g) * NL + loc_of[anc[e]]];
+            } else if (upper && sub_of[anc[e]] < 0 && level_of[anc[e]] == L) {
+              // a deal root above the forest: its policy row rides behind the forest's own rows
+              auto it = extra_row[g].find(anc[e]);
+              if (it == extra_row[g].end()) {
+                it = extra_row[g].emplace(anc[e], static_cast<int32_t>(dec_rows[g].size())).first;
+                dec_rows[g].push_back(s->info[anc[e]] * s->A);
+              }
+              d_anc = it->second;
+            } else {
+              return OSG_OK;   // (cannot happen: decisions sit below the cut)
+            }
+            codes[static_cast<size_t>(pl) * 4 * per_player + filled[pl]++] = d_anc * s->A + a_idx;
           }
         }
         int64_t bits;
@@ -3703,6 +3835,44 @@ int build_sub(osg_cfr* s) {
   }
   const size_t lds = sizeof(double) * (static_cast<size_t>(NL) + static_cast<size_t>(ND) * s->A);
   if (lds > 150 * 1024 || ND > kSubKD * kSubThreads) return OSG_OK;
+  // forest form: the pieces' roots (their values leave through root_value) and the upper members' records
+  std::vector<int32_t> nroot, root_loc, root_idx, upper_rec;
+  int NR = 0;
+  const int root_base = s->level_off[piece_level];
+  if (upper) {
+    std::vector<std::vector<int32_t>> roots(G);
+    for (int h = root_base; h < s->level_off[piece_level + 1]; ++h) roots[sub_of[h]].push_back(h);
+    for (int g = 0; g < G; ++g) NR = std::max<int>(NR, static_cast<int>(roots[g].size()));
+    nroot.resize(G);
+    root_loc.assign(static_cast<size_t>(G) * NR, 0);
+    root_idx.assign(static_cast<size_t>(G) * NR, 0);
+    for (int g = 0; g < G; ++g) {
+      nroot[g] = static_cast<int32_t>(roots[g].size());
+      for (size_t r = 0; r < roots[g].size(); ++r) {
+        root_loc[static_cast<size_t>(g) * NR + r] = loc_of[roots[g][r]];
+        root_idx[static_cast<size_t>(g) * NR + r] = roots[g][r] - root_base;
+      }
+    }
+    for (int32_t m : upper_members) {
+      const int h = s->mem[m];
+      double chance = 1.0;   // the root path of a deal root holds chance edges only, multiplied in path order
+      for (int e = s->path_off[m]; e < s->path_off[m + 1]; ++e) {
+        const int code = s->path[e];
+        if (!((code >> 23) & 1)) return OSG_OK;   // (cannot happen: every level above the cut is a chance level)
+        chance *= s->edge_prob[code & 0x7FFFFF];
+      }
+      int64_t bits;
+      memcpy(&bits, &chance, sizeof bits);
+      upper_rec.push_back(s->first_child[h] - root_base);
+      upper_rec.push_back(s->info[h] * s->A);
+      upper_rec.push_back(s->nact[s->info[h]]);
+      upper_rec.push_back(0);
+      upper_rec.push_back(static_cast<int32_t>(bits & 0xFFFFFFFF));
+      upper_rec.push_back(static_cast<int32_t>(bits >> 32));
+      upper_rec.push_back(0);
+      upper_rec.push_back(0);
+    }
+  }
   int widest = 0;   // the fold stages an infostate's member records in LDS: all of one infostate must fit a round
   for (int i = 0; i < s->I; ++i) widest = std::max(widest, s->mem_off[i + 1] - s->mem_off[i]);
   if (widest > std::min<int>(static_cast<int>((NL + static_cast<size_t>(ND) * s->A) / (2 * s->A + 1)), kSubFoldX * kSubThreads)) return OSG_OK;
@@ -3728,12 +3898,24 @@ int build_sub(osg_cfr* s) {
       (rc = upload(aux, &s->d_sub_aux, st)) || (rc = upload(mem_off, &s->d_sub_mem_off, st)) ||
       (rc = upload(sub_rec, &s->d_sub_rec, st)) ||
       (rc = upload(info_off, &s->d_sub_info_off, st)) || (rc = upload(info_list, &s->d_sub_info_list, st)) ||
-      (rc = upload(ndec, &s->d_sub_ndec, st)) || (rc = upload(dec_row, &s->d_sub_dec_row, st)))
+      (rc = upload(ndec, &s->d_sub_ndec, st)) || (rc = upload(dec_row, &s->d_sub_dec_row, st)) ||
+      (rc = upload(sub_skip, &s->d_sub_skip, st)))
     return rc;
+  s->sub_forest = upper;
+  if (upper) {
+    if ((rc = upload(nroot, &s->d_sub_nroot, st)) || (rc = upload(root_loc, &s->d_sub_root_loc, st)) ||
+        (rc = upload(root_idx, &s->d_sub_root_idx, st)) || (rc = upload(upper_rec, &s->d_sub_upper_rec, st)))
+      return rc;
+    const size_t n_roots = static_cast<size_t>(s->level_off[piece_level + 1] - root_base);
+    OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_sub_root_value), sizeof(double) * std::max<size_t>(n_roots, 1)));
+    OSG_HIP(hipMemsetAsync(s->d_sub_root_value, 0, sizeof(double) * std::max<size_t>(n_roots, 1), st));
+    s->sub_NR = NR;
+  }
   s->sub_ND = ND;
   s->sub_PL = PL;
   OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_sub_bar), sizeof(unsigned int) * 4));
   OSG_HIP(hipMemsetAsync(s->d_sub_bar, 0, sizeof(unsigned int) * 4, st));
+  s->sub_G0 = G0;
   s->sub_G = G; s->sub_L = L; s->sub_NL = NL; s->sub_K = K; s->sub_grid = grid; s->sub_lds_bytes = lds;
   s->sub_ok = true;
   return OSG_OK;
@@ -3888,6 +4070,7 @@ int osg_cfr_destroy(osg_cfr* s) {
                   s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
                   s->d_split_terms, s->d_split_bar, s->d_sub_nloc, s->d_sub_desc, s->d_sub_fc, s->d_sub_aux, s->d_sub_mem_off,
                   s->d_sub_info_off, s->d_sub_info_list, s->d_sub_bar, s->d_sub_ndec, s->d_sub_dec_row, s->d_sub_rec,
+                  s->d_sub_skip, s->d_sub_nroot, s->d_sub_root_loc, s->d_sub_root_idx, s->d_sub_upper_rec, s->d_sub_root_value,
                   s->d_jobs_job, s->d_jobs_level, s->d_jobs_desc, s->d_jobs_fc, s->d_jobs_row, s->d_jobs_glob, s->d_jobs_info,
                   s->d_jobs_mem, s->d_jobs_deal, s->d_jobs_ticket};
   for (void* p : ptrs)
@@ -3956,11 +4139,15 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
     SubTree sp{s->sub_G, s->sub_L, s->sub_NL, s->d_sub_nloc, s->d_sub_desc, s->d_sub_fc, s->d_sub_aux, s->sub_ND, s->d_sub_ndec,
                s->d_sub_dec_row, s->d_sub_mem_off,
                s->d_sub_rec, s->sub_PL, s->d_sub_info_off, s->d_sub_info_list, s->d_node_delta,
-               s->d_node_delta + static_cast<size_t>(M) * s->A, s->d_skip, s->d_sub_bar, s->h_sub_err, 400000000ull /* 4 s at 100 MHz */, nullptr};
+               s->d_node_delta + static_cast<size_t>(M) * s->A, s->d_sub_skip, s->d_sub_bar, s->h_sub_err, 400000000ull /* 4 s at 100 MHz */, nullptr};
+    if (s->sub_forest) {
+      sp.nroot = s->d_sub_nroot; sp.root_loc = s->d_sub_root_loc; sp.root_idx = s->d_sub_root_idx; sp.NR = s->sub_NR;
+      sp.root_value = s->d_sub_root_value; sp.upper_rec = s->d_sub_upper_rec;
+    }
     static unsigned long long* d_stamps = nullptr;   // OSG_CFR_SUB_STAMPS=1: phase stamps of workgroup 0 (tools/probe_cfr_sub.py)
     if (std::getenv("OSG_CFR_SUB_STAMPS")) {
       sp.stamp_wg = std::max(0, std::min(s->sub_grid - 1, atoi(std::getenv("OSG_CFR_SUB_STAMPS")) - 1));
-      fprintf(stderr, "k_cfr_sub: G %d grid %d NL %d ND %d PL %d K %d\n", s->sub_G, s->sub_grid, s->sub_NL, s->sub_ND, s->sub_PL, s->sub_K);
+      fprintf(stderr, "k_cfr_sub: G %d grid %d NL %d ND %d PL %d K %d forest %d NR %d\n", s->sub_G, s->sub_grid, s->sub_NL, s->sub_ND, s->sub_PL, s->sub_K, s->sub_forest ? 1 : 0, s->sub_NR);
       if (!d_stamps) OSG_HIP(hipMalloc(reinterpret_cast<void**>(&d_stamps), sizeof(unsigned long long) * 8 * kMaxPlayers));
       sp.stamps = d_stamps;
     }
@@ -3990,9 +4177,11 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
                 (h[q * 5 + 4] - h[q * 5 + 3]) / 100.0, q + 1 < s->P ? (h[(q + 1) * 5] - h[q * 5]) / 100.0 : 0.0);
     }
     s->iteration += iters;
+    s->last_kernel = s->sub_forest ? "k_cfr_sub<forest>" : (s->sub_G < s->sub_G0 ? "k_cfr_sub<packed>" : "k_cfr_sub");
     return OSG_OK;
   }
   if (grid_path) {
+    s->last_kernel = "k_gcfr";
     const int M = static_cast<int>(s->mem.size());
     GridCfr g;
     g.t = s->tree(); g.path_off = s->d_path_off; g.path = s->d_path; g.meta = s->d_meta32;

@@ -471,6 +471,30 @@ def test_persistent_subtree_kernel_is_bit_identical_with_the_per_phase_launches(
     assert a.iteration == b.iteration == 7
 
 
+@pytest.mark.parametrize("game,pack,form", [("leduc_poker(players=3)", "1", "k_cfr_sub<forest>"),
+                                            ("leduc_poker(players=3)", "0", "k_cfr_sub"),
+                                            ("kuhn_poker(players=6)", "1", "k_cfr_sub<packed>")])
+def test_subtree_kernel_bins(ctx, game, pack, form, monkeypatch):
+    """More deal subtrees than compute units (3-player leduc: 336; 6-player kuhn: 5 040): the workgroups' bins are packed
+    — whole subtrees where they fit a workgroup together, else the pieces one level below the cut with the deal roots
+    handled by the fold (forest form) — and OSG_CFR_SUB_PACK=0 keeps a subtree per bin (6-player kuhn is then not served:
+    an infostate's 720 members do not fit the fold's LDS stage of a 200-history subtree).  Every form leaves the tables of
+    the per-phase launches, bit for bit, with plain CFR and with CFR+ (the linear averaging enters the deal roots'
+    terms)."""
+    import open_spiel_amd as osa
+    monkeypatch.setenv("OSG_CFR_SUB_PACK", pack)
+    for kwargs in ({}, dict(linear_averaging=True, regret_matching_plus=True)):
+        b = osa.TabularSolver(ctx, game, general_kernel="sub", **kwargs)
+        a = osa.TabularSolver(ctx, game, general_kernel="grid", **kwargs)
+        for k in (1, 3, 5):
+            a.evaluate_and_update_policy(k)
+            b.evaluate_and_update_policy(k)
+            assert b.last_kernel() == form
+            ta, tb = a.tables(), b.tables()
+            for name in ("regrets", "cum_policy", "cur_policy"):
+                np.testing.assert_array_equal(ta[name], tb[name])
+
+
 def test_three_player_leduc_takes_the_persistent_kernel_by_default(ctx):
     import time
     import open_spiel_amd as osa
@@ -483,6 +507,7 @@ def test_three_player_leduc_takes_the_persistent_kernel_by_default(ctx):
     t0 = time.perf_counter()
     auto.evaluate_and_update_policy(20)
     ctx.synchronize()
+    assert auto.last_kernel() == "k_cfr_sub<forest>"
     assert 20 / (time.perf_counter() - t0) > 2000    # (1 850 iterations/s with a launch per phase)
 
 

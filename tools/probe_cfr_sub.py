@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, open_spiel_amd as osa
 ctx = osa.Context(0)
 game = os.environ.get("PROBE_GAME", "leduc_poker(players=3)")
-for plus in (False, True):
+for plus in (() if os.environ.get("PROBE_ONLY_SUB") else (False, True)):
     a = osa.TabularSolver(ctx, game, general_kernel="grid", regret_matching_plus=plus, linear_averaging=plus)
     b = osa.TabularSolver(ctx, game, general_kernel="sub", regret_matching_plus=plus, linear_averaging=plus)
     print("histories", a.num_histories, "infostates", a.num_infostates, flush=True)
@@ -17,7 +17,7 @@ for plus in (False, True):
         if not same:
             for k in ("regrets", "cum_policy", "cur_policy"):
                 print(k, np.abs(ta[k] - tb[k]).max(), int((ta[k] != tb[k]).sum()))
-for name in ("grid", "sub"):
+for name in (("sub",) if os.environ.get("PROBE_ONLY_SUB") else ("grid", "sub")):
     s = osa.TabularSolver(ctx, game, general_kernel=name)
     s.evaluate_and_update_policy(3); ctx.synchronize()
     iters = 20 if name == "grid" else 200

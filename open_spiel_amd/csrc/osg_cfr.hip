@@ -1078,7 +1078,7 @@ struct SubTree {
   const int32_t* ndec;           // [G]
   const int32_t* dec_row;        // [G, ND] info * A of decision history d
   const int32_t* mem_off;        // [G * P + 1] the subtree's members of player q: sub_mem[mem_off[g * P + q] ...)
-  const int32_t* sub_rec;        // [., 8 + PL] per member: m (position in Tree::mem), its history's local index, its decision
+  const int32_t* sub_rec;        // [., 8 + PL / 2 rounded up to 4] (the codes are 16-bit halves, 0xFFFF padded) per member: m (position in Tree::mem), its history's local index, its decision
                                  //   index | actions << 24, its first child's local index; the product of the chance
                                  //   probabilities on its root path (a double, path order), two unused words; then the decision
                                  //   entries of the path GROUPED BY PLAYER, PL / P codes per player in path order, -1 padded:
@@ -1087,10 +1087,9 @@ struct SubTree {
   int PL;                        // codes per member: P groups of a multiple of 4, at most 4 kSubCodeChunks
   const int32_t* info_off;       // [P + 1] infostates of player q: info_list[info_off[q] ...)
   const int32_t* info_list;
-  double* dreg;                  // [M, A]
-  double* dpol;                  // [M, A]
-  int32_t* skip;                 // [M]
-  unsigned int* bar;             // [0] arrival counter, [1] error flag (both zeroed per launch)
+  double* recbuf;                // [M, 8] the members' 64-byte records (kSubRecDoubles)
+  int tree_barrier;              // 1: two-level arrival + release word; 0: round 4's flat counter
+  unsigned int* bar;             // [0] arrival counter, [1] error flag, [2] release word, [16 + 16 g] group counters (zeroed per launch)
   unsigned int* host_err;        // pinned host word raised on a timeout: the next call reads it without a copy
   unsigned long long timeout_ticks;
   unsigned long long* stamps;    // null, or [P][5] wall-clock stamps of workgroup 0 in the launch's last iteration
@@ -1107,6 +1106,18 @@ struct SubTree {
   int NR = 0;
   double* root_value = nullptr;       // [histories of the pieces' level] the updating player's value of every piece root
   const int32_t* upper_rec = nullptr; // [U, 8] first child's slot in root_value, info * A, actions, 0, chance product (lo, hi), 0, 0
+  // Round 5: what a pass does not have to fetch again.  The decision rows of a bin are ordered by acting player
+  // (dec_off), so with one bin per workgroup (keep_rows) the policy rows STAY in LDS between passes and a pass fetches
+  // only the rows the previous pass's fold rewrote (the previous updating player's) and the upper parents' rows; the
+  // outcome probabilities of the bin's chance histories sit in LDS too (chance_prob: no trip to memory inside the level
+  // loop); the fold takes its infostates from a packed descriptor (fold_info) in shares balanced by members (fold_off).
+  const int32_t* dec_off = nullptr;   // [G, P + 2] rows of player q: [dec_off[q], dec_off[q + 1]); upper parents' rows from dec_off[P] to dec_off[P + 1]
+  const double* chance_prob = nullptr;// [G, NCP] outcome probabilities of the bin's chance histories (aux = offset of the first)
+  int NCP = 0;                        // (even)
+  int keep_rows = 0;
+  int lds_doubles = 0;                // dynamic LDS of the launch, in doubles: [policy rows ND * A | chance NCP | values NL | spare]
+  const int32_t* fold_info = nullptr; // [infostates in info_list order, 4] infostate, actions, first member, members
+  const int32_t* fold_off = nullptr;  // [P, grid + 1] the share of workgroup w in pass q: entries [fold_off[q][w], fold_off[q][w + 1])
 };
 OSG_D double readlane_f64(double v, int lane) {   // lane is wave-uniform: two v_readlane_b32, no LDS permute
   const long long b = __double_as_longlong(v);
@@ -1116,6 +1127,28 @@ OSG_D double readlane_f64(double v, int lane) {   // lane is wave-uniform: two v
 OSG_D void store_through_i32(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 OSG_D int32_t load_through_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// 16-byte written-through stores / bypassing loads (buffer instructions with the sc1 bit: what the 8-byte agent-scope
+// atomics above compile to, four words at a time; the compiler keeps the wait counters)
+typedef unsigned int osg_u4 __attribute__((ext_vector_type(4)));
+typedef double osg_d2 __attribute__((ext_vector_type(2)));
+constexpr int kCachePolicySc1 = 16;
+OSG_D __amdgpu_buffer_rsrc_t through_buffer(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000);
+}
+OSG_D void store_through16(__amdgpu_buffer_rsrc_t r, unsigned int byte_off, osg_d2 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(osg_u4, v), r, static_cast<int>(byte_off), 0, kCachePolicySc1);
+}
+OSG_D osg_u4 load_through16(__amdgpu_buffer_rsrc_t r, unsigned int byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>(byte_off), 0, kCachePolicySc1);
+}
+// The member records of k_cfr_sub (round 5): 64 bytes per member — regret terms [4], average-policy terms [4] — written
+// by the member's thread as whole 16-byte pieces and fetched by the fold the same way (7 eight-byte stores and loads per
+// member before).  A record that carries no terms says so in its first word: a quiet NaN whose low word is 1 (the member
+// was pruned) or 2 + u (upper member u of the forest form: written once by the host, its terms are formed in the fold).
+constexpr unsigned int kSubFlagHi = 0x7FF80000u;
+constexpr int kSubRecDoubles = 8;
+constexpr int kSubBarWords = 16 + 16 * 64;   // grid barrier words: a cooperative grid of up to 1 024 workgroups
+
 constexpr int kSubThreads = 1024;
 constexpr int kSubKD = 4;            // decision histories per thread: ND <= 4096
 constexpr int kSubFoldInfos = 64;    // infostates a workgroup folds per round (one wavefront adds them up)
@@ -1124,28 +1157,51 @@ constexpr int kSubCodeChunks = 8;    // int4 chunks of path codes a member recor
 template <int kK>   // histories per thread: NL <= kK * 1024
 __global__ void __launch_bounds__(kSubThreads)
 k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg) {
-  extern __shared__ __attribute__((aligned(16))) double s_value[];   // [NL] the updating player's values
-  double* s_pol = s_value + sp.NL;                                   // [ND, A] the current policy of the subtree's rows
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  double* s_pol = s_dyn;                                             // [ND, A] the current policy of the bin's rows (ND * A even)
+  double* s_cp = s_pol + sp.ND * t.A;                                // [NCP] outcome probabilities of the bin's chance histories
+  double* s_value = s_cp + sp.NCP;                                   // [NL] the updating player's values
   __shared__ int s_ok;
   __shared__ int s_lvl[2 * kK];
-  __shared__ int s_fi[kSubFoldInfos], s_fn[kSubFoldInfos], s_fm0[kSubFoldInfos], s_fcnt[kSubFoldInfos], s_fbase[kSubFoldInfos + 1], s_fne;
+  __shared__ int s_fi[kSubFoldInfos], s_fn[kSubFoldInfos], s_fm0[kSubFoldInfos], s_fbase[kSubFoldInfos + 1], s_fne;
   const int P = t.P, A = t.A, tid = threadIdx.x;
   unsigned int epoch = 0;
   // one polling lane per workgroup; false = a workgroup never arrived (cannot happen in a cooperative launch short of
   // a hung device: the bound only keeps a broken device from spinning for ever)
+  // Two-level arrival (round 5): a workgroup adds to its group's counter (16 workgroups per group, a cache line each),
+  // the last of a group adds to the top counter, the last of all writes the epoch into the release word, and everybody
+  // polls that word — which is written once per barrier instead of taking 256 same-address adds under 256 pollers
+  // (sp.tree_barrier == 0: the flat counter of round 4).  bar: [0] top / flat counter, [1] error, [2] release word,
+  // [16 + 16 g] group g.
   auto grid_barrier = [&]() -> bool {
     ++epoch;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      __hip_atomic_fetch_add(&sp.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned int want = epoch * gridDim.x;
       const unsigned long long t0 = wall_clock64();
       int ok = 1;
-      while (__hip_atomic_load(&sp.bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        if (__hip_atomic_load(&sp.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
-            wall_clock64() - t0 > sp.timeout_ticks) { ok = 0; break; }
-        __builtin_amdgcn_s_sleep(1);
+      if (sp.tree_barrier) {
+        const unsigned int grp = blockIdx.x >> 4, ngrp = (gridDim.x + 15u) >> 4;
+        const unsigned int gsize = gridDim.x - (grp << 4) < 16u ? gridDim.x - (grp << 4) : 16u;
+        if (__hip_atomic_fetch_add(&sp.bar[16 + 16 * grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == epoch * gsize) {
+          if (__hip_atomic_fetch_add(&sp.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == epoch * ngrp)
+            __hip_atomic_store(&sp.bar[2], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned int seen;
+        while ((seen = __hip_atomic_load(&sp.bar[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < epoch) {
+          if (wall_clock64() - t0 > sp.timeout_ticks) { ok = 0; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (seen == 0xFFFFFFFFu) ok = 0;   // another workgroup gave up
+        if (!ok) __hip_atomic_store(&sp.bar[2], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        __hip_atomic_fetch_add(&sp.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int want = epoch * gridDim.x;
+        while (__hip_atomic_load(&sp.bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          if (__hip_atomic_load(&sp.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+              wall_clock64() - t0 > sp.timeout_ticks) { ok = 0; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
       }
       if (!ok) {
         __hip_atomic_store(&sp.bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1156,6 +1212,7 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
     __syncthreads();
     return s_ok != 0;
   };
+  const __amdgpu_buffer_rsrc_t rec_buf = through_buffer(sp.recbuf);
   for (int it = 0; it < iters; ++it) {
     const int iteration = iteration0 + it + 1;
     for (int upd = 0; upd < P; ++upd) {
@@ -1193,7 +1250,8 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
           if (j < nloc && (o_d[k] & 3) == kTerminalNode) s_value[j] = t.term_ret[static_cast<size_t>(o_aux[k]) * P + upd];
         }
         const int ndec = sp.ndec[g];
-        {
+        const bool all_rows = !sp.keep_rows || (it == 0 && upd == 0);
+        if (all_rows) {
           int rows[kSubKD];   // the thread's decision histories: all their rows are requested before the first arrives
 #pragma unroll
           for (int k = 0; k < kSubKD; ++k) {
@@ -1205,6 +1263,33 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
 #pragma unroll
             for (int a = 0; a < kSplitMaxA; ++a)
               if (rows[k] >= 0 && a < A) s_pol[(tid + k * kSubThreads) * A + a] = load_through(tb.cur + rows[k] + a);
+          }
+          for (int c = tid; c < sp.NCP; c += kSubThreads) s_cp[c] = sp.chance_prob[static_cast<size_t>(g) * sp.NCP + c];
+        } else {
+          // the rows are still in LDS: only the previous pass's fold changed any — the rows of the player it updated —
+          // and (forest form) the upper parents' rows ride behind
+          const int32_t* doff = sp.dec_off + static_cast<size_t>(g) * (P + 2);
+          const int prev = (upd + P - 1) % P;
+          const int b0 = doff[prev], n0 = doff[prev + 1] - b0, b1 = doff[P], n1 = doff[P + 1] - b1;
+          int rows[2];
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {   // (a third of the bin's rows: at most 2 048 here, the rest in the loop below)
+            const int x = tid + k * kSubThreads;
+            const int d = x < n0 ? b0 + x : (x - n0 < n1 ? b1 + (x - n0) : -1);
+            rows[k] = d >= 0 ? sp.dec_row[static_cast<size_t>(g) * sp.ND + d] : -1;
+          }
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int x = tid + k * kSubThreads;
+            const int d = x < n0 ? b0 + x : b1 + (x - n0);
+#pragma unroll
+            for (int a = 0; a < kSplitMaxA; ++a)
+              if (rows[k] >= 0 && a < A) s_pol[d * A + a] = load_through(tb.cur + rows[k] + a);
+          }
+          for (int x = tid + 2 * kSubThreads; x < n0 + n1; x += kSubThreads) {
+            const int d = x < n0 ? b0 + x : b1 + (x - n0);
+            const int row = sp.dec_row[static_cast<size_t>(g) * sp.ND + d];
+            for (int a = 0; a < A; ++a) s_pol[d * A + a] = load_through(tb.cur + row + a);
           }
         }
         __syncthreads();
@@ -1222,8 +1307,7 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
             if (mine == l && kind != kTerminalNode) {
               double v = 0.0;
               if (kind == kChanceNode) {
-                const int gc = t.first_child[o_aux[k]];
-                for (int a = 0; a < nc; ++a) v += t.edge_prob[gc + a] * s_value[o_fc[k] + a];
+                for (int a = 0; a < nc; ++a) v += s_cp[o_aux[k] + a] * s_value[o_fc[k] + a];
               } else {
                 for (int a = 0; a < nc; ++a) v += s_pol[o_aux[k] * A + a] * s_value[o_fc[k] + a];
               }
@@ -1248,43 +1332,76 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
         // counterfactual reach multiplies the players' products in player order, the chance product last (cfr.cc:309-318).
         const int m_begin = sp.mem_off[g * P + upd], m_end = sp.mem_off[g * P + upd + 1];
         const int n_chunks = sp.PL / 4, per_player = n_chunks / P;
-        for (int mm = m_begin + tid; mm < m_end; mm += kSubThreads) {
-          const int4* rec = reinterpret_cast<const int4*>(sp.sub_rec + static_cast<size_t>(mm) * (8 + sp.PL));
-          const int4 head = rec[0], second = rec[1];
-          int4 codes[kSubCodeChunks];
+        // two members per thread and round, both records requested before the first is used: a bin holds ~1 050 members
+        // of a player (3-player leduc), and a second round for the few beyond 1 024 cost a whole round's latency
+        for (int mm0 = m_begin + tid; mm0 < m_end; mm0 += 2 * kSubThreads) {
+          int4 head[2], second[2], codes[2][kSubCodeChunks / 2];   // (16-bit codes: two chunks of four per int4)
+          bool live[2];
+          const int n_words4 = (n_chunks + 1) / 2, rec_ints = 8 + 4 * n_words4;
 #pragma unroll
-          for (int c = 0; c < kSubCodeChunks; ++c) codes[c] = rec[2 + (c < n_chunks ? c : n_chunks - 1)];
-          const int m = head.x, hl = head.y, d = head.z & 0xFFFFFF, n = (head.z >> 24) & 0xFF, lfc = head.w;
-          const double chance = __longlong_as_double((static_cast<long long>(second.y) << 32) | static_cast<unsigned int>(second.x));
-          bool pruned = true;
-          double self_reach = 0.0, cf_reach = 1.0, r = 1.0;
-          int q = 0;
+          for (int u = 0; u < 2; ++u) {
+            const int mm = mm0 + u * kSubThreads;
+            live[u] = mm < m_end;
+            const int4* rec = reinterpret_cast<const int4*>(sp.sub_rec + static_cast<size_t>(live[u] ? mm : mm0) * rec_ints);
+            head[u] = rec[0]; second[u] = rec[1];
 #pragma unroll
-          for (int c = 0; c < kSubCodeChunks; ++c) {
-            if (c < n_chunks) {   // (workgroup-uniform)
-              const int cx = codes[c].x, cy = codes[c].y, cz = codes[c].z, cw = codes[c].w;
-              const double px = s_pol[cx < 0 ? 0 : cx], py = s_pol[cy < 0 ? 0 : cy], pz = s_pol[cz < 0 ? 0 : cz],
-                           pw = s_pol[cw < 0 ? 0 : cw];
-              r = r * (cx < 0 ? 1.0 : px);   // (x * 1.0 == x: the padding leaves the product as it is)
-              r = r * (cy < 0 ? 1.0 : py);
-              r = r * (cz < 0 ? 1.0 : pz);
-              r = r * (cw < 0 ? 1.0 : pw);
-              if ((c + 1) % per_player == 0) {   // the last chunk of player q's group
-                pruned &= (r == 0.0);
-                if (q == upd) self_reach = r; else cf_reach *= r;
-                ++q;
-                r = 1.0;
+            for (int c = 0; c < kSubCodeChunks / 2; ++c) codes[u][c] = rec[2 + (c < n_words4 ? c : n_words4 - 1)];
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (!live[u]) continue;
+            const int m = head[u].x, hl = head[u].y, d = head[u].z & 0xFFFFFF, n = (head[u].z >> 24) & 0xFF, lfc = head[u].w;
+            const double chance = __longlong_as_double((static_cast<long long>(second[u].y) << 32) | static_cast<unsigned int>(second[u].x));
+            bool pruned = true;
+            double self_reach = 0.0, cf_reach = 1.0, r = 1.0;
+            int q = 0;
+#pragma unroll
+            for (int c = 0; c < kSubCodeChunks; ++c) {
+              if (c < n_chunks) {   // (workgroup-uniform)
+                const unsigned int w0 = static_cast<unsigned int>((c & 1) ? codes[u][c >> 1].z : codes[u][c >> 1].x),
+                                   w1 = static_cast<unsigned int>((c & 1) ? codes[u][c >> 1].w : codes[u][c >> 1].y);
+                const unsigned int cx = w0 & 0xFFFFu, cy = w0 >> 16, cz = w1 & 0xFFFFu, cw = w1 >> 16;   // 0xFFFF: padding
+                const double px = s_pol[cx == 0xFFFFu ? 0u : cx], py = s_pol[cy == 0xFFFFu ? 0u : cy],
+                             pz = s_pol[cz == 0xFFFFu ? 0u : cz], pw = s_pol[cw == 0xFFFFu ? 0u : cw];
+                r = r * (cx == 0xFFFFu ? 1.0 : px);   // (x * 1.0 == x: the padding leaves the product as it is)
+                r = r * (cy == 0xFFFFu ? 1.0 : py);
+                r = r * (cz == 0xFFFFu ? 1.0 : pz);
+                r = r * (cw == 0xFFFFu ? 1.0 : pw);
+                if ((c + 1) % per_player == 0) {   // the last chunk of player q's group
+                  pruned &= (r == 0.0);
+                  if (q == upd) self_reach = r; else cf_reach *= r;
+                  ++q;
+                  r = 1.0;
+                }
               }
             }
-          }
-          cf_reach *= chance;
-          store_through_i32(sp.skip + m, pruned ? 1 : 0);
-          if (pruned) continue;
-          const double vh = s_value[hl];
-          for (int a = 0; a < n; ++a) {
-            store_through(sp.dreg + static_cast<size_t>(m) * A + a, cf_reach * (s_value[lfc + a] - vh));
-            const double pol = s_pol[d * A + a];
-            store_through(sp.dpol + static_cast<size_t>(m) * A + a, cfg.linear_averaging ? iteration * self_reach * pol : self_reach * pol);
+            cf_reach *= chance;
+            const unsigned int at = static_cast<unsigned int>(m) * (kSubRecDoubles * 8);
+            if (pruned) {
+              osg_d2 flag;
+              flag.x = __longlong_as_double((static_cast<long long>(kSubFlagHi) << 32) | 1ll);
+              flag.y = 0.0;
+              store_through16(rec_buf, at, flag);
+              continue;
+            }
+            const double vh = s_value[hl];
+            double dr[kSplitMaxA], dp[kSplitMaxA];
+#pragma unroll
+            for (int a = 0; a < kSplitMaxA; ++a) {
+              dr[a] = 0.0; dp[a] = 0.0;
+              if (a < n) {
+                dr[a] = cf_reach * (s_value[lfc + a] - vh);
+                const double pol = s_pol[d * A + a];
+                dp[a] = cfg.linear_averaging ? iteration * self_reach * pol : self_reach * pol;
+              }
+            }
+            static_assert(kSplitMaxA == 4 && kSubRecDoubles == 8, "the record is two pieces of regret terms, two of policy terms");
+            store_through16(rec_buf, at, osg_d2{dr[0], dr[1]});
+            store_through16(rec_buf, at + 32, osg_d2{dp[0], dp[1]});
+            if (A > 2) {   // (workgroup-uniform)
+              store_through16(rec_buf, at + 16, osg_d2{dr[2], dr[3]});
+              store_through16(rec_buf, at + 48, osg_d2{dp[2], dp[3]});
+            }
           }
         }
         __syncthreads();   // (the next subtree of this workgroup reuses s_value)
@@ -1298,37 +1415,31 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
       //      of ~40 additions fed from LDS — clamps (RM+), regret-matches and writes the row through.  (One wavefront
       //      per infostate with the sums formed by lane broadcasts was 19-23 us: ~13 broadcasts per member.) ----
       {
-        const int i_begin = sp.info_off[upd], i_end = sp.info_off[upd + 1];
-        const int share = (i_end - i_begin + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
-        int e0 = i_begin + static_cast<int>(blockIdx.x) * share;
-        const int e_last = e0 + share < i_end ? e0 + share : i_end;
-        const int rsz = 2 * A + 1;                                           // doubles per record: skip | dreg[A] | dpol[A]
-        const int cap_lds = (sp.NL + sp.ND * A) / rsz;
+        int e0 = sp.fold_off[upd * (static_cast<int>(gridDim.x) + 1) + static_cast<int>(blockIdx.x)];
+        const int e_last = sp.fold_off[upd * (static_cast<int>(gridDim.x) + 1) + static_cast<int>(blockIdx.x) + 1];
+        // the records are staged behind what stays in LDS (keep_rows: the policy rows and chance probabilities)
+        double* s_rec = sp.keep_rows ? s_value : s_dyn;
+        const int cap_lds = (sp.lds_doubles - static_cast<int>(s_rec - s_dyn)) / kSubRecDoubles;   // 64-byte records
         const int cap = cap_lds < kSubFoldX * kSubThreads ? cap_lds : kSubFoldX * kSubThreads;
-        double* s_rec = s_value;
         while (e0 < e_last) {
-          if (tid < kSubFoldInfos) {
+          if (tid < kSubFoldInfos) {   // (wavefront 0) this round's infostates: as many as fit the stage, by a prefix sum
+            static_assert(kSubFoldInfos == 64, "one wavefront schedules a round");
             const int e = e0 + tid;
-            int cnt = 0;
-            if (e < e_last) {
-              const int i = sp.info_list[e];
-              s_fi[tid] = i;
-              s_fn[tid] = t.nact[i];
-              s_fm0[tid] = t.mem_off[i];
-              cnt = t.mem_off[i + 1] - s_fm0[tid];
+            int4 fi = make_int4(0, 0, 0, 0);
+            if (e < e_last) fi = reinterpret_cast<const int4*>(sp.fold_info)[e];
+            const int cnt = e < e_last ? fi.w : 0;
+            int inc = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+              const int v = __shfl_up(inc, off);
+              if (tid >= off) inc += v;
             }
-            s_fcnt[tid] = cnt;
-          }
-          __syncthreads();
-          if (tid == 0) {   // how many infostates fit this round
-            int base = 0, ne = 0;
-            for (; ne < kSubFoldInfos && e0 + ne < e_last; ++ne) {
-              if (base + s_fcnt[ne] > cap && ne > 0) break;
-              s_fbase[ne] = base;
-              base += s_fcnt[ne];
-            }
-            s_fbase[ne] = base;
-            s_fne = ne;
+            const bool in = e < e_last && (tid == 0 || inc <= cap);
+            const int ne = __popcll(__ballot(in));   // (`in` holds on a prefix of the lanes: inc does not decrease)
+            s_fi[tid] = fi.x; s_fn[tid] = fi.y; s_fm0[tid] = fi.z;
+            s_fbase[tid] = inc - cnt;
+            if (tid == ne - 1) s_fbase[ne] = inc;
+            if (tid == 0) s_fne = ne;
           }
           __syncthreads();
           const int ne = s_fne, total = s_fbase[ne];
@@ -1345,12 +1456,12 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
               }
           }
           {
-            int xm[kSubFoldX], xn[kSubFoldX], xs[kSubFoldX];
-            double xr[kSubFoldX][kSplitMaxA], xp[kSubFoldX][kSplitMaxA];
+            int xm[kSubFoldX], xn[kSubFoldX];
+            osg_u4 pc[kSubFoldX][4];
 #pragma unroll
             for (int u = 0; u < kSubFoldX; ++u) {
               const int x = tid + u * kSubThreads;
-              xm[u] = -1; xn[u] = 0; xs[u] = 1;
+              xm[u] = -1; xn[u] = 0;
               if (x < total) {
                 int lo = 0, hi = ne;                       // the infostate of record x: s_fbase[lo] <= x < s_fbase[lo + 1]
                 while (hi - lo > 1) {
@@ -1361,25 +1472,37 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
                 xn[u] = s_fn[lo];
               }
             }
+            // consecutive threads fetch consecutive 64-byte records (an infostate's members are consecutive): whole
+            // lines, four (two for two-action games) 16-byte bypassing loads per record; a pruned member's stale terms
+            // are fetched all the same and never added
+#pragma unroll
+            for (int u = 0; u < kSubFoldX; ++u) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) pc[u][k] = osg_u4{0u, 0u, 0u, 0u};
+              if (xm[u] < 0) continue;
+              const unsigned int at = static_cast<unsigned int>(xm[u]) * (kSubRecDoubles * 8);
+              pc[u][0] = load_through16(rec_buf, at);
+              pc[u][2] = load_through16(rec_buf, at + 32);
+              if (A > 2) {   // (workgroup-uniform)
+                pc[u][1] = load_through16(rec_buf, at + 16);
+                pc[u][3] = load_through16(rec_buf, at + 48);
+              }
+            }
 #pragma unroll
             for (int u = 0; u < kSubFoldX; ++u) {
               if (xm[u] < 0) continue;
-              xs[u] = load_through_i32(sp.skip + xm[u]);   // (a skipped member's terms are stale: fetched all the same, never added)
+              osg_u4* r4 = reinterpret_cast<osg_u4*>(s_rec + static_cast<size_t>(tid + u * kSubThreads) * kSubRecDoubles);
 #pragma unroll
-              for (int a = 0; a < kSplitMaxA; ++a)
-                if (a < xn[u]) {
-                  xr[u][a] = load_through(sp.dreg + static_cast<size_t>(xm[u]) * A + a);
-                  xp[u][a] = load_through(sp.dpol + static_cast<size_t>(xm[u]) * A + a);
-                }
+              for (int k = 0; k < 4; ++k) r4[k] = pc[u][k];
             }
-            // An upper member (forest form: a deal root; its skip word is 2 + its index, written once by the host): its
+            // An upper member (forest form: a deal root; its record carries 2 + its index, written once by the host): its
             // terms are formed here, by k_gcfr_members' expressions — the value of the history is the policy-weighted sum
             // of its children's values in action order (the sweep's), every player's reach on its root path is the
             // empty product 1.0, so the counterfactual reach is 1.0 * ... * chance = chance and the own reach 1.0.
 #pragma unroll
             for (int u = 0; u < kSubFoldX; ++u) {
-              if (xm[u] < 0 || xs[u] < 2) continue;
-              const int32_t* ur = sp.upper_rec + static_cast<size_t>(xs[u] - 2) * 8;
+              if (xm[u] < 0 || pc[u][0].y != kSubFlagHi || pc[u][0].x < 2u) continue;
+              const int32_t* ur = sp.upper_rec + static_cast<size_t>(pc[u][0].x - 2u) * 8;
               const int slot0 = ur[0], row = ur[1];
               const double chance = __longlong_as_double((static_cast<long long>(ur[5]) << 32) | static_cast<unsigned int>(ur[4]));
               double va[kSplitMaxA], pa[kSplitMaxA];
@@ -1395,33 +1518,27 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
               const double self_reach = 1.0;
               double cf_reach = 1.0;
               cf_reach *= chance;
+              double* r = s_rec + static_cast<size_t>(tid + u * kSubThreads) * kSubRecDoubles;
 #pragma unroll
-              for (int a = 0; a < kSplitMaxA; ++a)
+              for (int a = 0; a < kSplitMaxA; ++a) {
+                r[a] = 0.0; r[kSplitMaxA + a] = 0.0;
                 if (a < xn[u]) {
-                  xr[u][a] = cf_reach * (va[a] - vh);
-                  xp[u][a] = cfg.linear_averaging ? iteration * self_reach * pa[a] : self_reach * pa[a];
+                  r[a] = cf_reach * (va[a] - vh);
+                  r[kSplitMaxA + a] = cfg.linear_averaging ? iteration * self_reach * pa[a] : self_reach * pa[a];
                 }
-              xs[u] = 0;
-            }
-#pragma unroll
-            for (int u = 0; u < kSubFoldX; ++u) {
-              if (xm[u] < 0) continue;
-              double* r = s_rec + static_cast<size_t>(tid + u * kSubThreads) * rsz;
-              r[0] = xs[u] ? 1.0 : 0.0;
-#pragma unroll
-              for (int a = 0; a < kSplitMaxA; ++a)
-                if (a < xn[u]) { r[1 + a] = xr[u][a]; r[1 + A + a] = xp[u][a]; }
+              }
             }
           }
           __syncthreads();
           if (tid < ne) {
             const int n = s_fn[tid];
             for (int x = s_fbase[tid]; x < s_fbase[tid + 1]; ++x) {   // member order
-              const double* r = s_rec + static_cast<size_t>(x) * rsz;
-              if (r[0] != 0.0) continue;
+              const double* r = s_rec + static_cast<size_t>(x) * kSubRecDoubles;
+              const unsigned long long w0 = static_cast<unsigned long long>(__double_as_longlong(r[0]));
+              if (static_cast<unsigned int>(w0 >> 32) == kSubFlagHi && static_cast<unsigned int>(w0) == 1u) continue;   // pruned
 #pragma unroll
               for (int a = 0; a < kSplitMaxA; ++a)
-                if (a < n) { reg[a] += r[1 + a]; cum[a] += r[1 + A + a]; }
+                if (a < n) { reg[a] += r[a]; cum[a] += r[kSplitMaxA + a]; }
             }
             double sum_pos = 0.0;
 #pragma unroll
@@ -2984,7 +3101,11 @@ struct osg_cfr {
   // forest form of k_cfr_sub (SubTree's comment): the kernel's own skip words, piece roots, upper members
   bool sub_forest = false;
   int sub_NR = 0, sub_G0 = 0;   // G0: the deal subtrees; sub_G: the bins they (or their pieces) were packed into
-  int32_t *d_sub_skip = nullptr, *d_sub_nroot = nullptr, *d_sub_root_loc = nullptr, *d_sub_root_idx = nullptr, *d_sub_upper_rec = nullptr;
+  double *d_sub_recbuf = nullptr, *d_sub_chance_prob = nullptr;
+  int32_t *d_sub_dec_off = nullptr, *d_sub_fold_info = nullptr, *d_sub_fold_off = nullptr;
+  int sub_NCP = 0;
+  bool sub_keep_rows = false;
+  int32_t *d_sub_nroot = nullptr, *d_sub_root_loc = nullptr, *d_sub_root_idx = nullptr, *d_sub_upper_rec = nullptr;
   double* d_sub_root_value = nullptr;
   unsigned int* h_sub_err = nullptr;   // pinned: raised by the kernel when a grid barrier times out
   // policy evaluation (k_policy_eval)
@@ -3726,12 +3847,12 @@ int build_sub(osg_cfr* s) {
   const size_t M = s->mem.size();
   std::vector<std::vector<int32_t>> members(static_cast<size_t>(G) * s->P);
   std::vector<int32_t> upper_members;            // forest form: the members of level L, in member order
-  std::vector<int32_t> sub_skip(std::max<size_t>(M, 1), 0);
+  std::vector<int32_t> upper_of(std::max<size_t>(M, 1), -1);
   for (size_t m = 0; m < M; ++m) {
     const int h = s->mem[m];
     if (sub_of[h] < 0) {
       if (!upper || level_of[h] != L) return OSG_OK;  // a decision node above the cut
-      sub_skip[m] = 2 + static_cast<int32_t>(upper_members.size());
+      upper_of[m] = static_cast<int32_t>(upper_members.size());
       upper_members.push_back(static_cast<int32_t>(m));
       continue;
     }
@@ -3757,8 +3878,17 @@ int build_sub(osg_cfr* s) {
   std::vector<std::map<int32_t, int32_t>> extra_row(G);
   std::vector<int32_t> anc, filled(s->P);
   int32_t n_members = 0;
+  std::vector<int32_t> dec_off(static_cast<size_t>(G) * (s->P + 2), 0);
+  std::vector<std::vector<double>> chance_probs(G);
   for (int g = 0; g < G; ++g) {
     nloc[g] = static_cast<int32_t>(hist[g].size());
+    // the bin's decision rows ordered by acting player (a pass re-fetches one player's rows only: SubTree's comment)
+    std::vector<int32_t> next(s->P + 1, 0);
+    for (int h : hist[g])
+      if (s->kind[h] == kDecisionNode) ++next[s->actor[h] + 1];
+    for (int q = 0; q < s->P; ++q) next[q + 1] += next[q];
+    for (int q = 0; q <= s->P; ++q) dec_off[static_cast<size_t>(g) * (s->P + 2) + q] = next[q];
+    dec_rows[g].assign(next[s->P], 0);
     for (size_t j = 0; j < hist[g].size(); ++j) {
       const int h = hist[g][j];
       const size_t at = static_cast<size_t>(g) * NL + j;
@@ -3766,8 +3896,11 @@ int build_sub(osg_cfr* s) {
       fc[at] = s->kind[h] == kTerminalNode ? 0 : loc_of[s->first_child[h]];
       aux[at] = h;
       if (s->kind[h] == kDecisionNode) {
-        aux[at] = static_cast<int32_t>(dec_rows[g].size());
-        dec_rows[g].push_back(s->info[h] * s->A);
+        aux[at] = next[s->actor[h]]++;
+        dec_rows[g][aux[at]] = s->info[h] * s->A;
+      } else if (s->kind[h] == kChanceNode) {
+        aux[at] = static_cast<int32_t>(chance_probs[g].size());   // its outcome probabilities, staged in LDS
+        for (int c = 0; c < s->nchild[h]; ++c) chance_probs[g].push_back(s->edge_prob[s->first_child[h] + c]);
       }
     }
     for (int q = 0; q < s->P; ++q) {
@@ -3815,7 +3948,12 @@ int build_sub(osg_cfr* s) {
         sub_rec.push_back(static_cast<int32_t>(bits >> 32));
         sub_rec.push_back(0);
         sub_rec.push_back(0);
-        sub_rec.insert(sub_rec.end(), codes.begin(), codes.end());
+        // the codes as 16-bit halves (a code indexes the bin's ND * A <= 16 384 staged policy entries; 0xFFFF pads), the
+        // record padded to whole 16-byte pieces
+        for (int c = 0; c < PL; c += 2)
+          sub_rec.push_back(static_cast<int32_t>((static_cast<uint32_t>(codes[c]) & 0xFFFFu) |
+                                                 ((static_cast<uint32_t>(codes[c + 1]) & 0xFFFFu) << 16)));
+        for (int c = PL / 2; c % 4 != 0; ++c) sub_rec.push_back(-1);
         ++n_members;
       }
       mem_off[static_cast<size_t>(g) * s->P + q + 1] = n_members;
@@ -3826,15 +3964,29 @@ int build_sub(osg_cfr* s) {
       if (s->info_player[i] == q) info_list.push_back(i);
     info_off[q + 1] = static_cast<int32_t>(info_list.size());
   }
-  int ND = 1;
-  for (int g = 0; g < G; ++g) ND = std::max<int>(ND, static_cast<int>(dec_rows[g].size()));
+  int ND = 2, NCP = 2;
+  for (int g = 0; g < G; ++g) {
+    ND = std::max<int>(ND, static_cast<int>(dec_rows[g].size()));
+    NCP = std::max<int>(NCP, static_cast<int>(chance_probs[g].size()));
+  }
+  ND += ND & 1; NCP += NCP & 1;   // (even: the values and the fold's stage behind them stay 16-byte aligned)
   std::vector<int32_t> ndec(G), dec_row(static_cast<size_t>(G) * ND, 0);
+  std::vector<double> chance_prob(static_cast<size_t>(G) * NCP, 0.0);
   for (int g = 0; g < G; ++g) {
     ndec[g] = static_cast<int32_t>(dec_rows[g].size());
+    dec_off[static_cast<size_t>(g) * (s->P + 2) + s->P + 1] = ndec[g];   // (the upper parents' rows sit behind the players')
     std::copy(dec_rows[g].begin(), dec_rows[g].end(), dec_row.begin() + static_cast<size_t>(g) * ND);
+    std::copy(chance_probs[g].begin(), chance_probs[g].end(), chance_prob.begin() + static_cast<size_t>(g) * NCP);
   }
-  const size_t lds = sizeof(double) * (static_cast<size_t>(NL) + static_cast<size_t>(ND) * s->A);
-  if (lds > 150 * 1024 || ND > kSubKD * kSubThreads) return OSG_OK;
+  // dynamic LDS: [policy rows ND * A | chance probabilities NCP | values NL | spare]; the fold stages 64-byte member
+  // records from the values on (one bin per workgroup: the rows stay) — the spare takes it to 2 048 records where there is room
+  const size_t base_doubles = static_cast<size_t>(ND) * s->A + NCP + NL;
+  if (sizeof(double) * base_doubles > 150 * 1024 || ND > kSubKD * kSubThreads) return OSG_OK;
+  const size_t lds_doubles = std::min<size_t>(static_cast<size_t>(ND) * s->A + NCP + static_cast<size_t>(kSubFoldX) * kSubThreads * kSubRecDoubles,
+                                              (158 * 1024) / sizeof(double));
+  const size_t lds = sizeof(double) * std::max(base_doubles, lds_doubles);
+  const int fold_cap = static_cast<int>(std::min<size_t>((lds / sizeof(double) - static_cast<size_t>(ND) * s->A - NCP) / kSubRecDoubles,
+                                                         static_cast<size_t>(kSubFoldX) * kSubThreads));
   // forest form: the pieces' roots (their values leave through root_value) and the upper members' records
   std::vector<int32_t> nroot, root_loc, root_idx, upper_rec;
   int NR = 0;
@@ -3873,9 +4025,10 @@ int build_sub(osg_cfr* s) {
       upper_rec.push_back(0);
     }
   }
+  if (static_cast<unsigned long long>(M) * kSubRecDoubles * 8 >= (1ull << 31)) return OSG_OK;   // 32-bit record offsets
   int widest = 0;   // the fold stages an infostate's member records in LDS: all of one infostate must fit a round
   for (int i = 0; i < s->I; ++i) widest = std::max(widest, s->mem_off[i + 1] - s->mem_off[i]);
-  if (widest > std::min<int>(static_cast<int>((NL + static_cast<size_t>(ND) * s->A) / (2 * s->A + 1)), kSubFoldX * kSubThreads)) return OSG_OK;
+  if (widest > fold_cap) return OSG_OK;
   const void* kern = K == 2 ? cfr_sub_kernel<2>() : (K == 4 ? cfr_sub_kernel<4>() : cfr_sub_kernel<8>());
   if (raise_lds_cap(kern, static_cast<int>(lds)) != hipSuccess) {
     (void)hipGetLastError();
@@ -3892,6 +4045,31 @@ int build_sub(osg_cfr* s) {
     return OSG_OK;
   }
   const int grid = std::min(G, per_cu * prop.multiProcessorCount);
+  // the fold's shares: a workgroup's run of the updating player's infostates (info_list order), balanced by members
+  std::vector<int32_t> fold_info(info_list.size() * 4), fold_off(static_cast<size_t>(s->P) * (grid + 1), 0);
+  for (size_t e = 0; e < info_list.size(); ++e) {
+    const int i = info_list[e];
+    fold_info[4 * e] = i; fold_info[4 * e + 1] = s->nact[i]; fold_info[4 * e + 2] = s->mem_off[i];
+    fold_info[4 * e + 3] = s->mem_off[i + 1] - s->mem_off[i];
+  }
+  for (int q = 0; q < s->P; ++q) {
+    int64_t total = 0;
+    for (int e = info_off[q]; e < info_off[q + 1]; ++e) total += fold_info[4 * static_cast<size_t>(e) + 3] + 8;   // (+ the row's own cost)
+    int64_t run = 0;
+    int e = info_off[q];
+    for (int w = 0; w < grid; ++w) {
+      fold_off[static_cast<size_t>(q) * (grid + 1) + w] = e;
+      const int64_t upto = total * (w + 1) / grid;
+      while (e < info_off[q + 1] && run + (fold_info[4 * static_cast<size_t>(e) + 3] + 8) / 2 < upto) {
+        run += fold_info[4 * static_cast<size_t>(e) + 3] + 8;
+        ++e;
+      }
+    }
+    fold_off[static_cast<size_t>(q) * (grid + 1) + grid] = info_off[q + 1];
+    for (int w = grid - 1; w >= 0; --w)   // (everything is handed out: the last share takes what rounding left)
+      if (fold_off[static_cast<size_t>(q) * (grid + 1) + w] > fold_off[static_cast<size_t>(q) * (grid + 1) + w + 1])
+        fold_off[static_cast<size_t>(q) * (grid + 1) + w] = fold_off[static_cast<size_t>(q) * (grid + 1) + w + 1];
+  }
   hipStream_t st = s->ctx->stream;
   int rc;
   if ((rc = upload(nloc, &s->d_sub_nloc, st)) || (rc = upload(desc, &s->d_sub_desc, st)) || (rc = upload(fc, &s->d_sub_fc, st)) ||
@@ -3899,8 +4077,21 @@ int build_sub(osg_cfr* s) {
       (rc = upload(sub_rec, &s->d_sub_rec, st)) ||
       (rc = upload(info_off, &s->d_sub_info_off, st)) || (rc = upload(info_list, &s->d_sub_info_list, st)) ||
       (rc = upload(ndec, &s->d_sub_ndec, st)) || (rc = upload(dec_row, &s->d_sub_dec_row, st)) ||
-      (rc = upload(sub_skip, &s->d_sub_skip, st)))
+      (rc = upload(dec_off, &s->d_sub_dec_off, st)) || (rc = upload(chance_prob, &s->d_sub_chance_prob, st)) ||
+      (rc = upload(fold_info, &s->d_sub_fold_info, st)) || (rc = upload(fold_off, &s->d_sub_fold_off, st)))
     return rc;
+  s->sub_NCP = NCP;
+  s->sub_keep_rows = grid >= G;
+  {
+    // the members' 64-byte records: zero, but an upper member's says which one it is (kSubFlagHi | 2 + u)
+    std::vector<double> recbuf(std::max<size_t>(M, 1) * kSubRecDoubles, 0.0);
+    for (size_t m = 0; m < M; ++m)
+      if (upper_of[m] >= 0) {
+        const int64_t bits = (static_cast<int64_t>(kSubFlagHi) << 32) | static_cast<int64_t>(2 + upper_of[m]);
+        memcpy(&recbuf[m * kSubRecDoubles], &bits, sizeof bits);
+      }
+    if ((rc = upload(recbuf, &s->d_sub_recbuf, st))) return rc;
+  }
   s->sub_forest = upper;
   if (upper) {
     if ((rc = upload(nroot, &s->d_sub_nroot, st)) || (rc = upload(root_loc, &s->d_sub_root_loc, st)) ||
@@ -3913,8 +4104,8 @@ int build_sub(osg_cfr* s) {
   }
   s->sub_ND = ND;
   s->sub_PL = PL;
-  OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_sub_bar), sizeof(unsigned int) * 4));
-  OSG_HIP(hipMemsetAsync(s->d_sub_bar, 0, sizeof(unsigned int) * 4, st));
+  OSG_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_sub_bar), sizeof(unsigned int) * kSubBarWords));
+  OSG_HIP(hipMemsetAsync(s->d_sub_bar, 0, sizeof(unsigned int) * kSubBarWords, st));
   s->sub_G0 = G0;
   s->sub_G = G; s->sub_L = L; s->sub_NL = NL; s->sub_K = K; s->sub_grid = grid; s->sub_lds_bytes = lds;
   s->sub_ok = true;
@@ -4070,7 +4261,7 @@ int osg_cfr_destroy(osg_cfr* s) {
                   s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
                   s->d_split_terms, s->d_split_bar, s->d_sub_nloc, s->d_sub_desc, s->d_sub_fc, s->d_sub_aux, s->d_sub_mem_off,
                   s->d_sub_info_off, s->d_sub_info_list, s->d_sub_bar, s->d_sub_ndec, s->d_sub_dec_row, s->d_sub_rec,
-                  s->d_sub_skip, s->d_sub_nroot, s->d_sub_root_loc, s->d_sub_root_idx, s->d_sub_upper_rec, s->d_sub_root_value,
+                  s->d_sub_recbuf, s->d_sub_chance_prob, s->d_sub_dec_off, s->d_sub_fold_info, s->d_sub_fold_off, s->d_sub_nroot, s->d_sub_root_loc, s->d_sub_root_idx, s->d_sub_upper_rec, s->d_sub_root_value,
                   s->d_jobs_job, s->d_jobs_level, s->d_jobs_desc, s->d_jobs_fc, s->d_jobs_row, s->d_jobs_glob, s->d_jobs_info,
                   s->d_jobs_mem, s->d_jobs_deal, s->d_jobs_ticket};
   for (void* p : ptrs)
@@ -4138,8 +4329,13 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
     SmallTree stree{s->d_path_off, s->d_path, M, static_cast<int>(s->path.size())};
     SubTree sp{s->sub_G, s->sub_L, s->sub_NL, s->d_sub_nloc, s->d_sub_desc, s->d_sub_fc, s->d_sub_aux, s->sub_ND, s->d_sub_ndec,
                s->d_sub_dec_row, s->d_sub_mem_off,
-               s->d_sub_rec, s->sub_PL, s->d_sub_info_off, s->d_sub_info_list, s->d_node_delta,
-               s->d_node_delta + static_cast<size_t>(M) * s->A, s->d_sub_skip, s->d_sub_bar, s->h_sub_err, 400000000ull /* 4 s at 100 MHz */, nullptr};
+               s->d_sub_rec, s->sub_PL, s->d_sub_info_off, s->d_sub_info_list, s->d_sub_recbuf,
+               (std::getenv("OSG_CFR_SUB_FLAT_BARRIER") && std::getenv("OSG_CFR_SUB_FLAT_BARRIER")[0] == '1') ? 0 : 1,
+               s->d_sub_bar, s->h_sub_err, 400000000ull /* 4 s at 100 MHz */, nullptr};
+    sp.dec_off = s->d_sub_dec_off; sp.chance_prob = s->d_sub_chance_prob; sp.NCP = s->sub_NCP;
+    sp.keep_rows = (s->sub_keep_rows && !(std::getenv("OSG_CFR_SUB_KEEP_ROWS") && std::getenv("OSG_CFR_SUB_KEEP_ROWS")[0] == '0')) ? 1 : 0;
+    sp.lds_doubles = static_cast<int>(s->sub_lds_bytes / sizeof(double));
+    sp.fold_info = s->d_sub_fold_info; sp.fold_off = s->d_sub_fold_off;
     if (s->sub_forest) {
       sp.nroot = s->d_sub_nroot; sp.root_loc = s->d_sub_root_loc; sp.root_idx = s->d_sub_root_idx; sp.NR = s->sub_NR;
       sp.root_value = s->d_sub_root_value; sp.upper_rec = s->d_sub_upper_rec;
@@ -4155,7 +4351,7 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
     const int per_launch = std::max(1, (1 << 30) / std::max(1, 2 * s->P * s->sub_grid));  // the arrival counter is 32 bits
     for (int done = 0; done < iters; done += per_launch) {
       int now = std::min(per_launch, iters - done), it0 = s->iteration + done;
-      OSG_HIP(hipMemsetAsync(s->d_sub_bar, 0, sizeof(unsigned int) * 2, st));
+      OSG_HIP(hipMemsetAsync(s->d_sub_bar, 0, sizeof(unsigned int) * kSubBarWords, st));
       void* args[] = {&tr, &stree, &sp, &tb, &now, &it0, &s->cfg};
       const void* kern = s->sub_K == 2 ? cfr_sub_kernel<2>() : (s->sub_K == 4 ? cfr_sub_kernel<4>() : cfr_sub_kernel<8>());
       // (OSG_CFR_PLAIN_LAUNCH=1 as for k_cfr_split: an ordinary launch, for hosts that own the device — and for runs under

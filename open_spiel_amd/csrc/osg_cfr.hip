@@ -1117,6 +1117,8 @@ struct SubTree {
   int keep_rows = 0;
   int lds_doubles = 0;                // dynamic LDS of the launch, in doubles: [policy rows ND * A | chance NCP | values NL | spare]
   const int32_t* fold_info = nullptr; // [infostates in info_list order, 4] infostate, actions, first member, members
+  const double* term_val = nullptr;   // [G, P, NL] player q's return at every terminal history of the bin, local order (0 elsewhere)
+  int prefetch = 1;                   // 0: nothing is fetched in the barriers' windows (measurement)
   const int32_t* fold_off = nullptr;  // [P, grid + 1] the share of workgroup w in pass q: entries [fold_off[q][w], fold_off[q][w + 1])
 };
 OSG_D double readlane_f64(double v, int lane) {   // lane is wave-uniform: two v_readlane_b32, no LDS permute
@@ -1173,13 +1175,14 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
   // polls that word — which is written once per barrier instead of taking 256 same-address adds under 256 pollers
   // (sp.tree_barrier == 0: the flat counter of round 4).  bar: [0] top / flat counter, [1] error, [2] release word,
   // [16 + 16 g] group g.
-  auto grid_barrier = [&]() -> bool {
+  // `window`: work on data no other workgroup writes (the tree, the host's schedules), run by every thread between
+  // this workgroup's arrival and its wait — the trips to memory the next phase would start with happen while the
+  // slower workgroups are still on their way.
+  auto grid_barrier = [&](auto&& window) -> bool {
     ++epoch;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      const unsigned long long t0 = wall_clock64();
-      int ok = 1;
       if (sp.tree_barrier) {
         const unsigned int grp = blockIdx.x >> 4, ngrp = (gridDim.x + 15u) >> 4;
         const unsigned int gsize = gridDim.x - (grp << 4) < 16u ? gridDim.x - (grp << 4) : 16u;
@@ -1187,6 +1190,15 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
           if (__hip_atomic_fetch_add(&sp.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == epoch * ngrp)
             __hip_atomic_store(&sp.bar[2], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+      } else {
+        __hip_atomic_fetch_add(&sp.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    window();
+    if (tid == 0) {
+      const unsigned long long t0 = wall_clock64();
+      int ok = 1;
+      if (sp.tree_barrier) {
         unsigned int seen;
         while ((seen = __hip_atomic_load(&sp.bar[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < epoch) {
           if (wall_clock64() - t0 > sp.timeout_ticks) { ok = 0; break; }
@@ -1195,7 +1207,6 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
         if (seen == 0xFFFFFFFFu) ok = 0;   // another workgroup gave up
         if (!ok) __hip_atomic_store(&sp.bar[2], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
-        __hip_atomic_fetch_add(&sp.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned int want = epoch * gridDim.x;
         while (__hip_atomic_load(&sp.bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
           if (__hip_atomic_load(&sp.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
@@ -1213,6 +1224,8 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
     return s_ok != 0;
   };
   const __amdgpu_buffer_rsrc_t rec_buf = through_buffer(sp.recbuf);
+  bool prefetched = false;   // the coming pass's terminal values are in LDS and its rows' indices in rows_pref
+  int rows_pref[2] = {-1, -1};
   for (int it = 0; it < iters; ++it) {
     const int iteration = iteration0 + it + 1;
     for (int upd = 0; upd < P; ++upd) {
@@ -1244,10 +1257,13 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
         // ---- A: everything the sweep reads from memory is requested at once — the terminal values and the policy
         //      rows of the subtree's decision histories, into LDS: the levels then cost an LDS round trip and a
         //      workgroup barrier each, not a trip to the L2 (1.6 us per level before: 23 us per sweep) ----
+        if (!prefetched) {   // (else: fetched in the window of the previous pass's last barrier)
+          const double* tv = sp.term_val + (static_cast<size_t>(g) * P + upd) * sp.NL;
 #pragma unroll
-        for (int k = 0; k < kK; ++k) {
-          const int j = tid + k * kSubThreads;
-          if (j < nloc && (o_d[k] & 3) == kTerminalNode) s_value[j] = t.term_ret[static_cast<size_t>(o_aux[k]) * P + upd];
+          for (int k = 0; k < kK; ++k) {
+            const int j = tid + k * kSubThreads;
+            if (j < nloc) s_value[j] = tv[j];   // (the terminals' returns; a history that is swept gets its value then)
+          }
         }
         const int ndec = sp.ndec[g];
         const bool all_rows = !sp.keep_rows || (it == 0 && upd == 0);
@@ -1276,7 +1292,7 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
           for (int k = 0; k < 2; ++k) {   // (a third of the bin's rows: at most 2 048 here, the rest in the loop below)
             const int x = tid + k * kSubThreads;
             const int d = x < n0 ? b0 + x : (x - n0 < n1 ? b1 + (x - n0) : -1);
-            rows[k] = d >= 0 ? sp.dec_row[static_cast<size_t>(g) * sp.ND + d] : -1;
+            rows[k] = prefetched ? rows_pref[k] : (d >= 0 ? sp.dec_row[static_cast<size_t>(g) * sp.ND + d] : -1);
           }
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
@@ -1407,7 +1423,39 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
         __syncthreads();   // (the next subtree of this workgroup reuses s_value)
       }
       if (stamp) sp.stamps[upd * 5 + 2] = wall_clock64();
-      if (!grid_barrier()) return;
+      int e0 = 0, e_last = 0;
+      // the records are staged behind what stays in LDS (keep_rows: the policy rows and chance probabilities)
+      double* s_rec = sp.keep_rows ? s_value : s_dyn;
+      const int cap_lds = (sp.lds_doubles - static_cast<int>(s_rec - s_dyn)) / kSubRecDoubles;   // 64-byte records
+      const int cap = cap_lds < kSubFoldX * kSubThreads ? cap_lds : kSubFoldX * kSubThreads;
+      // this round's infostates of the fold: as many as fit the stage, by a prefix sum over wavefront 1 (wavefront 0
+      // holds the barrier's polling lane); the schedule is the host's, so round 0's is formed in the barrier's window
+      auto fold_schedule = [&]() {
+        static_assert(kSubFoldInfos == 64, "one wavefront schedules a round");
+        if (tid >= 64 && tid < 128) {
+          const int lane = tid - 64, e = e0 + lane;
+          int4 fi = make_int4(0, 0, 0, 0);
+          if (e < e_last) fi = reinterpret_cast<const int4*>(sp.fold_info)[e];
+          const int cnt = e < e_last ? fi.w : 0;
+          int inc = cnt;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(inc, off);
+            if (lane >= off) inc += v;
+          }
+          const bool in = e < e_last && (lane == 0 || inc <= cap);
+          const int ne = __popcll(__ballot(in));   // (`in` holds on a prefix of the lanes: inc does not decrease)
+          s_fi[lane] = fi.x; s_fn[lane] = fi.y; s_fm0[lane] = fi.z;
+          s_fbase[lane] = inc - cnt;
+          if (lane == ne - 1) s_fbase[ne] = inc;
+          if (lane == 0) { s_fne = ne; if (ne == 0) s_fbase[0] = 0; }
+        }
+      };
+      if (!grid_barrier([&]() {
+            e0 = sp.fold_off[upd * (static_cast<int>(gridDim.x) + 1) + static_cast<int>(blockIdx.x)];
+            e_last = sp.fold_off[upd * (static_cast<int>(gridDim.x) + 1) + static_cast<int>(blockIdx.x) + 1];
+            fold_schedule();
+          })) return;
       if (stamp) sp.stamps[upd * 5 + 3] = wall_clock64();
       // ---- C: fold (k_gcfr_fold's additions, in its order).  A workgroup takes a contiguous share of the updating
       //      player's infostates; all its threads fetch the members' records together into LDS (the values / policy
@@ -1415,33 +1463,13 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
       //      of ~40 additions fed from LDS — clamps (RM+), regret-matches and writes the row through.  (One wavefront
       //      per infostate with the sums formed by lane broadcasts was 19-23 us: ~13 broadcasts per member.) ----
       {
-        int e0 = sp.fold_off[upd * (static_cast<int>(gridDim.x) + 1) + static_cast<int>(blockIdx.x)];
-        const int e_last = sp.fold_off[upd * (static_cast<int>(gridDim.x) + 1) + static_cast<int>(blockIdx.x) + 1];
-        // the records are staged behind what stays in LDS (keep_rows: the policy rows and chance probabilities)
-        double* s_rec = sp.keep_rows ? s_value : s_dyn;
-        const int cap_lds = (sp.lds_doubles - static_cast<int>(s_rec - s_dyn)) / kSubRecDoubles;   // 64-byte records
-        const int cap = cap_lds < kSubFoldX * kSubThreads ? cap_lds : kSubFoldX * kSubThreads;
+        bool first_round = true;
         while (e0 < e_last) {
-          if (tid < kSubFoldInfos) {   // (wavefront 0) this round's infostates: as many as fit the stage, by a prefix sum
-            static_assert(kSubFoldInfos == 64, "one wavefront schedules a round");
-            const int e = e0 + tid;
-            int4 fi = make_int4(0, 0, 0, 0);
-            if (e < e_last) fi = reinterpret_cast<const int4*>(sp.fold_info)[e];
-            const int cnt = e < e_last ? fi.w : 0;
-            int inc = cnt;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-              const int v = __shfl_up(inc, off);
-              if (tid >= off) inc += v;
-            }
-            const bool in = e < e_last && (tid == 0 || inc <= cap);
-            const int ne = __popcll(__ballot(in));   // (`in` holds on a prefix of the lanes: inc does not decrease)
-            s_fi[tid] = fi.x; s_fn[tid] = fi.y; s_fm0[tid] = fi.z;
-            s_fbase[tid] = inc - cnt;
-            if (tid == ne - 1) s_fbase[ne] = inc;
-            if (tid == 0) s_fne = ne;
+          if (!first_round) {
+            fold_schedule();
+            __syncthreads();
           }
-          __syncthreads();
+          first_round = false;
           const int ne = s_fne, total = s_fbase[ne];
           // the infostate's own row, requested now, needed after the barrier
           double reg[kSplitMaxA], cum[kSplitMaxA];
@@ -1561,7 +1589,28 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
         }
       }
       if (stamp) sp.stamps[upd * 5 + 4] = wall_clock64();
-      if (!grid_barrier()) return;
+      // the coming pass of this workgroup's bin (one bin per workgroup): its terminal values into LDS (the fold's stage
+      // is done with) and the indices of the rows it will re-fetch — this pass's updating player's — while waiting
+      const bool more = sp.keep_rows && sp.prefetch && !(it == iters - 1 && upd == P - 1);
+      if (!grid_barrier([&]() {
+            if (!more) return;
+            const int g = blockIdx.x, nloc = sp.nloc[g], nxt = upd + 1 < P ? upd + 1 : 0;
+            const int32_t* doff = sp.dec_off + static_cast<size_t>(g) * (P + 2);
+            const int b0 = doff[upd], n0 = doff[upd + 1] - b0, b1 = doff[P], n1 = doff[P + 1] - b1;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const int x = tid + k * kSubThreads;
+              const int d = x < n0 ? b0 + x : (x - n0 < n1 ? b1 + (x - n0) : -1);
+              rows_pref[k] = d >= 0 ? sp.dec_row[static_cast<size_t>(g) * sp.ND + d] : -1;
+            }
+            const double* tv = sp.term_val + (static_cast<size_t>(g) * P + nxt) * sp.NL;
+#pragma unroll
+            for (int k = 0; k < kK; ++k) {
+              const int j = tid + k * kSubThreads;
+              if (j < nloc) s_value[j] = tv[j];
+            }
+          })) return;
+      prefetched = more;
     }
   }
 }
@@ -3101,7 +3150,7 @@ struct osg_cfr {
   // forest form of k_cfr_sub (SubTree's comment): the kernel's own skip words, piece roots, upper members
   bool sub_forest = false;
   int sub_NR = 0, sub_G0 = 0;   // G0: the deal subtrees; sub_G: the bins they (or their pieces) were packed into
-  double *d_sub_recbuf = nullptr, *d_sub_chance_prob = nullptr;
+  double *d_sub_recbuf = nullptr, *d_sub_chance_prob = nullptr, *d_sub_term_val = nullptr;
   int32_t *d_sub_dec_off = nullptr, *d_sub_fold_info = nullptr, *d_sub_fold_off = nullptr;
   int sub_NCP = 0;
   bool sub_keep_rows = false;
@@ -4080,6 +4129,20 @@ int build_sub(osg_cfr* s) {
       (rc = upload(dec_off, &s->d_sub_dec_off, st)) || (rc = upload(chance_prob, &s->d_sub_chance_prob, st)) ||
       (rc = upload(fold_info, &s->d_sub_fold_info, st)) || (rc = upload(fold_off, &s->d_sub_fold_off, st)))
     return rc;
+  {
+    // the terminal returns of every bin by player, in the bin's local order: a pass starts with one coalesced copy into LDS
+    const size_t n = static_cast<size_t>(G) * s->P * NL;
+    if (n * sizeof(double) > (size_t{1} << 31)) return OSG_OK;
+    std::vector<double> term_val(n, 0.0);
+    for (int g = 0; g < G; ++g)
+      for (size_t j = 0; j < hist[g].size(); ++j) {
+        const int h = hist[g][j];
+        if (s->kind[h] != kTerminalNode) continue;
+        for (int q = 0; q < s->P; ++q)
+          term_val[(static_cast<size_t>(g) * s->P + q) * NL + j] = s->term_ret[static_cast<size_t>(h) * s->P + q];
+      }
+    if ((rc = upload(term_val, &s->d_sub_term_val, st))) return rc;
+  }
   s->sub_NCP = NCP;
   s->sub_keep_rows = grid >= G;
   {
@@ -4261,7 +4324,7 @@ int osg_cfr_destroy(osg_cfr* s) {
                   s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
                   s->d_split_terms, s->d_split_bar, s->d_sub_nloc, s->d_sub_desc, s->d_sub_fc, s->d_sub_aux, s->d_sub_mem_off,
                   s->d_sub_info_off, s->d_sub_info_list, s->d_sub_bar, s->d_sub_ndec, s->d_sub_dec_row, s->d_sub_rec,
-                  s->d_sub_recbuf, s->d_sub_chance_prob, s->d_sub_dec_off, s->d_sub_fold_info, s->d_sub_fold_off, s->d_sub_nroot, s->d_sub_root_loc, s->d_sub_root_idx, s->d_sub_upper_rec, s->d_sub_root_value,
+                  s->d_sub_recbuf, s->d_sub_chance_prob, s->d_sub_term_val, s->d_sub_dec_off, s->d_sub_fold_info, s->d_sub_fold_off, s->d_sub_nroot, s->d_sub_root_loc, s->d_sub_root_idx, s->d_sub_upper_rec, s->d_sub_root_value,
                   s->d_jobs_job, s->d_jobs_level, s->d_jobs_desc, s->d_jobs_fc, s->d_jobs_row, s->d_jobs_glob, s->d_jobs_info,
                   s->d_jobs_mem, s->d_jobs_deal, s->d_jobs_ticket};
   for (void* p : ptrs)
@@ -4336,6 +4399,8 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
     sp.keep_rows = (s->sub_keep_rows && !(std::getenv("OSG_CFR_SUB_KEEP_ROWS") && std::getenv("OSG_CFR_SUB_KEEP_ROWS")[0] == '0')) ? 1 : 0;
     sp.lds_doubles = static_cast<int>(s->sub_lds_bytes / sizeof(double));
     sp.fold_info = s->d_sub_fold_info; sp.fold_off = s->d_sub_fold_off;
+    sp.term_val = s->d_sub_term_val;
+    sp.prefetch = (std::getenv("OSG_CFR_SUB_PREFETCH") && std::getenv("OSG_CFR_SUB_PREFETCH")[0] == '0') ? 0 : 1;
     if (s->sub_forest) {
       sp.nroot = s->d_sub_nroot; sp.root_loc = s->d_sub_root_loc; sp.root_idx = s->d_sub_root_idx; sp.NR = s->sub_NR;
       sp.root_value = s->d_sub_root_value; sp.upper_rec = s->d_sub_upper_rec;

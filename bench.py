@@ -367,22 +367,25 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
             three.evaluate_and_update_policy(5)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            three.evaluate_and_update_policy(10)
+            three.evaluate_and_update_policy(50)
             torch.cuda.synchronize()
             dt3 = time.perf_counter() - t0
             h3, p3 = three.num_histories, 3
             bytes_per_iteration = h3 * (4 + 1 + 2 * p3 * 8) * p3     # H x (parent 4 + action 1 + 2 P 8) per player pass
-            out["cfr"]["leduc_3_players"] = {"value": 10 / dt3, "unit": "iterations/s", "us_per_iteration": dt3 / 10 * 1e6,
+            out["cfr"]["leduc_3_players"] = {"value": 50 / dt3, "unit": "iterations/s", "us_per_iteration": dt3 / 50 * 1e6,
+                                             "kernel": three.last_kernel(),
                                              "algorithmic_bytes_per_iteration": bytes_per_iteration,
-                                             "frac_of_hbm_peak": bytes_per_iteration * 10 / dt3 / 1e9 / HBM_PEAK_GBS,
+                                             "frac_of_hbm_peak": bytes_per_iteration * 50 / dt3 / 1e9 / HBM_PEAK_GBS,
                                              "workload": "leduc_poker(players=3) CFRSolver, 1.83 M histories / 25 800 infostates: ONE "
-                                                         "cooperative launch (k_cfr_sub), a workgroup per private-deal subtree (336 of "
-                                                         "~5 450 histories, values and policy rows in LDS), two grid barriers per player "
-                                                         "pass; tables bit-identical with the launch-per-phase kernels (1 850 it/s)",
-                                             "note": "bound by memory round trips between dependent phases (terminal values and policy rows "
-                                                     "in, member records, terms out, fold) and by 336 subtrees on a cooperative grid of 256 "
-                                                     "workgroups (80 take two while 176 wait), not by bytes: profiles/r04_probe_cfr_sub.log "
-                                                     "has the per-workgroup phase stamps"}
+                                                         "cooperative launch (k_cfr_sub, forest form): the 672 pieces below the 336 deal "
+                                                         "roots packed into one bin per workgroup (256 bins of ~7 150 histories: values, "
+                                                         "policy rows and chance probabilities in LDS, the rows resident between passes), two "
+                                                         "two-level grid barriers per player pass with the next phase's static fetches in "
+                                                         "their windows; tables bit-identical with the launch-per-phase kernels (1 870 it/s)",
+                                             "note": "round 4: 3 260 it/s (336 subtrees on 256 workgroups, a flat counter barrier, 8-byte "
+                                                     "written-through terms).  Still bound by dependent phases, not bytes: a pass of ~46 us is "
+                                                     "sweep 10.5 (20 levels + 8 slots of LDS round trips), members 10.5, fold 10-14 and two "
+                                                     "barriers; profiles/r05i_cfr_sub_prefetch_windows.txt has the per-workgroup phase stamps"}
             del three
     except Exception as e:  # noqa: BLE001 - a secondary figure must never cost the line
         out["cfr"]["leduc"] = {"error": f"{type(e).__name__}: {e}"}

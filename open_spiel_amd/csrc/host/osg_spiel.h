@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <iomanip>
 #include <map>
@@ -816,14 +817,28 @@ class SpanTensor {  // observer.h:162-187: a named view into the Observation's b
 
 class Observer {  // observer.h:280-305; made by Game::MakeObserver
  public:
-  Observer(bool info_state, std::vector<SpanTensorInfo> pieces) : info_state_(info_state), pieces_(std::move(pieces)) {}
+  // kDefault / kInfoState: what State::ObservationTensor / InformationStateTensor pack on the device.  kGeneral: any other
+  // IIGObservationType of the two poker games (kuhn_poker.cc:65-165, leduc_poker.cc:92-242): the same pieces, chosen and
+  // arranged as the type asks — composed on the host from the two device tensors (private_info = kAllPlayers: every
+  // player's card piece).  kNoPrivate: a perfect-information game asked for private information only (observer.cc:110-121):
+  // an empty tensor and an empty string.  kInfoStateString: a board game's perfect-recall observer (observer.cc:158-159):
+  // the information-state STRING, no tensor.
+  enum class Kind { kDefault, kInfoState, kGeneral, kNoPrivate, kInfoStateString };
+  Observer(bool info_state, std::vector<SpanTensorInfo> pieces)
+      : kind_(info_state ? Kind::kInfoState : Kind::kDefault), type_(info_state ? kInfoStateObsType : kDefaultObsType),
+        pieces_(std::move(pieces)) {}
+  Observer(Kind kind, IIGObservationType type, std::vector<SpanTensorInfo> pieces)
+      : kind_(kind), type_(type), pieces_(std::move(pieces)) {}
   bool HasString() const { return true; }
-  bool HasTensor() const { return true; }
-  bool info_state() const { return info_state_; }
+  bool HasTensor() const { return kind_ != Kind::kInfoStateString; }
+  bool info_state() const { return kind_ == Kind::kInfoState; }
+  Kind kind() const { return kind_; }
+  const IIGObservationType& type() const { return type_; }
   const std::vector<SpanTensorInfo>& pieces() const { return pieces_; }
 
  private:
-  bool info_state_;
+  Kind kind_;
+  IIGObservationType type_;
   std::vector<SpanTensorInfo> pieces_;
 };
 
@@ -847,13 +862,45 @@ inline std::vector<SpanTensorInfo> ObserverPieces(const Game& game, bool info_st
   if (info_state) return {};
   return {{"observation", game.ObservationTensorShape()}};
 }
+// The pieces of any IIGObservationType of the two poker games (kuhn_poker.cc:72-107: nothing private unless
+// kSinglePlayer; leduc_poker.cc:166-186: the observing player always, one card or every player's cards, then the public part).
+inline std::vector<SpanTensorInfo> GeneralObserverPieces(const Game& game, const IIGObservationType& t) {
+  const std::string text = game.ToString();
+  const std::string name = text.substr(0, text.find('('));
+  const int P = game.NumPlayers();
+  std::vector<SpanTensorInfo> v;
+  if (name == "kuhn_poker") {
+    if (t.private_info == PrivateInfoType::kSinglePlayer) { v.push_back({"player", {P}}); v.push_back({"private_card", {P + 1}}); }
+    if (t.public_info) {
+      if (t.perfect_recall) v.push_back({"betting", {2 * P - 1, 2}}); else v.push_back({"pot_contribution", {P}});
+    }
+  } else if (name == "leduc_poker") {
+    const int cards = (game.ObservationTensorSize() - 2 * P) / 2;
+    v.push_back({"player", {P}});
+    if (t.private_info == PrivateInfoType::kSinglePlayer) v.push_back({"private_card", {cards}});
+    else if (t.private_info == PrivateInfoType::kAllPlayers) v.push_back({"private_cards", {P, cards}});
+    if (t.public_info) {
+      v.push_back({"community_card", {cards}});
+      if (t.perfect_recall) v.push_back({"betting", {2, 3 * P - 2, 2}}); else v.push_back({"pot_contribution", {P}});
+    }
+  }
+  return v;
+}
 
 inline std::shared_ptr<Observer> MakeObserver(const Game& game, const IIGObservationType* iig_obs_type = nullptr) {
-  // spiel.h:1040-1054, observer.cc:98-140: null = the game's default observer
+  // spiel.h:1040-1054, observer.cc:137-174: null = the game's default observer
+  const bool poker = game.MaxChanceOutcomes() > 0;
+  if (iig_obs_type && !poker) {  // perfect-information games (observer.cc:150-161)
+    if (!iig_obs_type->public_info) return std::make_shared<Observer>(Observer::Kind::kNoPrivate, *iig_obs_type, std::vector<SpanTensorInfo>{});
+    if (iig_obs_type->perfect_recall)
+      return std::make_shared<Observer>(Observer::Kind::kInfoStateString, *iig_obs_type, std::vector<SpanTensorInfo>{});
+    return std::make_shared<Observer>(false, ObserverPieces(game, false));
+  }
   bool info_state = false;
   if (iig_obs_type) {
     if (*iig_obs_type == kInfoStateObsType) info_state = true;
-    else if (!(*iig_obs_type == kDefaultObsType)) return nullptr;  // e.g. PrivateInfoType::kAllPlayers: not on the device
+    else if (!(*iig_obs_type == kDefaultObsType))   // the poker games' observers take any type (MakeObserver of both games)
+      return std::make_shared<Observer>(Observer::Kind::kGeneral, *iig_obs_type, GeneralObserverPieces(game, *iig_obs_type));
   }
   std::vector<SpanTensorInfo> pieces = ObserverPieces(game, info_state);
   if (pieces.empty()) return nullptr;
@@ -874,8 +921,10 @@ class Observation {  // observer.h:309-371: owns the flat buffer the observer wr
     if (!observer_) SpielFatalError("Observation: null observer");
     int total = 0;
     for (const SpanTensorInfo& p : observer_->pieces()) total += p.size();
-    const int expect = observer_->info_state() ? game.InformationStateTensorSize() : game.ObservationTensorSize();
-    if (total != expect) SpielFatalError("Observation: piece layout does not match the game's tensor");
+    if (observer_->kind() == Observer::Kind::kDefault || observer_->kind() == Observer::Kind::kInfoState) {
+      const int expect = observer_->info_state() ? game.InformationStateTensorSize() : game.ObservationTensorSize();
+      if (total != expect) SpielFatalError("Observation: piece layout does not match the game's tensor");
+    }
     buffer_.assign(static_cast<size_t>(total), 0.0f);
   }
   std::vector<float>& Tensor() { return buffer_; }
@@ -890,16 +939,161 @@ class Observation {  // observer.h:309-371: owns the flat buffer the observer wr
     return out;
   }
   void SetFrom(const State& state, int player) {
-    const std::vector<float> v = observer_->info_state() ? state.InformationStateTensor(player) : state.ObservationTensor(player);
-    std::copy(v.begin(), v.end(), buffer_.begin());
+    switch (observer_->kind()) {
+      case Observer::Kind::kDefault:
+      case Observer::Kind::kInfoState: {
+        const std::vector<float> v = observer_->info_state() ? state.InformationStateTensor(player) : state.ObservationTensor(player);
+        std::copy(v.begin(), v.end(), buffer_.begin());
+        return;
+      }
+      case Observer::Kind::kNoPrivate:
+      case Observer::Kind::kInfoStateString:
+        return;
+      case Observer::Kind::kGeneral:
+        SetGeneral(state, player);
+        return;
+    }
   }
   std::string StringFrom(const State& state, int player) const {
-    return observer_->info_state() ? state.InformationStateString(player) : state.ObservationString(player);
+    switch (observer_->kind()) {
+      case Observer::Kind::kDefault: return state.ObservationString(player);
+      case Observer::Kind::kInfoState:
+      case Observer::Kind::kInfoStateString: return state.InformationStateString(player);
+      case Observer::Kind::kNoPrivate: return "";
+      case Observer::Kind::kGeneral: break;
+    }
+    return GeneralString(state, player);
   }
-  bool HasString() const { return true; }
-  bool HasTensor() const { return true; }
+  bool HasString() const { return observer_->HasString(); }
+  bool HasTensor() const { return observer_->HasTensor(); }
+
+  // observer.cc:246-321: one header byte (0 = raw floats, 1 = one bit per element when every element is 0 or 1)
+  std::string Compress() const {
+    bool binary = true;
+    for (float x : buffer_) binary &= (x == 0.0f || x == 1.0f);
+    if (!binary) {
+      std::string out(1 + sizeof(float) * buffer_.size(), '\0');
+      if (!buffer_.empty()) std::memcpy(&out[1], buffer_.data(), sizeof(float) * buffer_.size());
+      return out;
+    }
+    std::string out(1 + (buffer_.size() + 7) / 8, '\0');
+    out[0] = 1;
+    for (size_t i = 0; i < buffer_.size(); ++i)
+      if (buffer_[i] != 0.0f) out[1 + i / 8] = static_cast<char>(out[1 + i / 8] + (1 << (i % 8)));
+    return out;
+  }
+  void Decompress(const std::string& compressed) {
+    if (compressed.empty()) SpielFatalError("Decompress: empty string");
+    if (compressed[0] == 1) {
+      if (compressed.size() != 1 + (buffer_.size() + 7) / 8) SpielFatalError("Decompress: size does not match the observation");
+      for (size_t i = 0; i < buffer_.size(); ++i) buffer_[i] = (compressed[1 + i / 8] >> (i % 8)) & 1 ? 1.0f : 0.0f;
+    } else if (compressed[0] == 0) {
+      if (compressed.size() != 1 + sizeof(float) * buffer_.size()) SpielFatalError("Decompress: size does not match the observation");
+      if (!buffer_.empty()) std::memcpy(buffer_.data(), &compressed[1], sizeof(float) * buffer_.size());
+    } else {
+      SpielFatalError("Unrecognized compression scheme in '" + compressed + "'");
+    }
+  }
 
  private:
+  // a named piece of one of the two device tensors of `player`
+  static std::vector<float> Piece(const State& state, int player, bool info_state, const std::string& name) {
+    const std::vector<float> t = info_state ? state.InformationStateTensor(player) : state.ObservationTensor(player);
+    int offset = 0;
+    for (const SpanTensorInfo& p : ObserverPieces(*state.GetGame(), info_state)) {
+      if (p.name() == name) return std::vector<float>(t.begin() + offset, t.begin() + offset + p.size());
+      offset += p.size();
+    }
+    SpielFatalError("Observation: no piece '" + name + "'");
+  }
+  void SetGeneral(const State& state, int player) {
+    const int P = state.NumPlayers();
+    int offset = 0;
+    for (const SpanTensorInfo& p : observer_->pieces()) {
+      std::vector<float> v;
+      if (p.name() == "private_cards") {
+        for (int q = 0; q < P; ++q) {
+          const std::vector<float> one = Piece(state, q, false, "private_card");
+          v.insert(v.end(), one.begin(), one.end());
+        }
+      } else {
+        v = Piece(state, player, p.name() == "betting", p.name());
+      }
+      std::copy(v.begin(), v.end(), buffer_.begin() + offset);
+      offset += p.size();
+    }
+  }
+  static std::vector<std::string> Chunks(const std::string& text) {  // "[a][b]" -> {"[a]", "[b]"}
+    std::vector<std::string> out;
+    size_t pos = 0;
+    while (pos < text.size()) {
+      const size_t end = text.find(']', pos);
+      if (end == std::string::npos) break;
+      out.push_back(text.substr(pos, end + 1 - pos));
+      pos = end + 1;
+    }
+    return out;
+  }
+  static std::string ChunkWith(const std::vector<std::string>& chunks, const std::string& prefix) {
+    for (const std::string& c : chunks)
+      if (c.compare(0, prefix.size(), prefix) == 0) return c;
+    return "";
+  }
+  std::string GeneralString(const State& state, int player) const {
+    const IIGObservationType& t = observer_->type();
+    const std::string text = state.GetGame()->ToString();
+    const std::string name = text.substr(0, text.find('('));
+    const int P = state.NumPlayers();
+    std::string result;
+    if (name == "kuhn_poker") {  // kuhn_poker.cc:109-165
+      const std::vector<Action> h = state.History();
+      const int n = static_cast<int>(h.size());
+      if (t.private_info == PrivateInfoType::kSinglePlayer) {
+        if (t.perfect_recall || t.public_info) {
+          if (n > player) result += std::to_string(h[player]);
+        } else if (n == 1 + player) {
+          result += "Received card " + std::to_string(h[player]);
+        }
+      }
+      if (t.public_info) {
+        if (t.perfect_recall) {
+          for (int i = P; i < n; ++i) result.push_back(h[i] ? 'b' : 'p');
+        } else if (t.private_info == PrivateInfoType::kNone) {
+          if (n == 0) result += "start game";
+          else if (n > P) result += h.back() ? "Bet" : "Pass";
+        } else if (n > player) {
+          for (float ante : Piece(state, player, false, "pot_contribution")) result += std::to_string(static_cast<int>(ante));
+        }
+      }
+      if (t.public_info && t.private_info == PrivateInfoType::kNone && n > 0 && n <= P)
+        result += "Deal to player " + std::to_string(n - 1);
+      return result;
+    }
+    // leduc_poker.cc:192-238: the chunks of the two device-formatted strings, chosen as the type asks
+    const std::vector<std::string> obs = Chunks(state.ObservationString(player));
+    if (t.private_info == PrivateInfoType::kSinglePlayer) {
+      result += ChunkWith(obs, "[Observer: ") + ChunkWith(obs, "[Private: ");
+    } else if (t.private_info == PrivateInfoType::kAllPlayers) {
+      result += "[Privates: ";
+      for (int q = 0; q < P; ++q) {
+        const std::string c = ChunkWith(Chunks(state.ObservationString(q)), "[Private: ");
+        result += c.substr(10, c.size() - 11);
+      }
+      result += "]";
+    }
+    if (t.public_info) {
+      result += ChunkWith(obs, "[Round ") + ChunkWith(obs, "[Player: ") + ChunkWith(obs, "[Pot: ") + ChunkWith(obs, "[Money: ") +
+                ChunkWith(obs, "[Public: ");
+      if (t.perfect_recall) {
+        const std::vector<std::string> info = Chunks(state.InformationStateString(player));
+        result += ChunkWith(info, "[Round1: ") + ChunkWith(info, "[Round2: ");
+      } else {
+        result += ChunkWith(obs, "[Ante: ");
+      }
+    }
+    return result;
+  }
+
   std::shared_ptr<Observer> observer_;
   std::vector<float> buffer_;
 };

@@ -787,6 +787,9 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("set_from", &Observation::SetFrom, py::arg("state"), py::arg("player"))
       .def("has_string", &Observation::HasString)
       .def("has_tensor", &Observation::HasTensor)
+      // python/pybind11/observer.cc:88-92: compress() -> bytes, decompress(bytes)
+      .def("compress", [](const Observation& o) { return py::bytes(o.Compress()); })
+      .def("decompress", [](Observation& o, py::bytes b) { o.Decompress(static_cast<std::string>(b)); })
       .def_buffer([](Observation& o) -> py::buffer_info {
         return py::buffer_info(o.Tensor().data(), sizeof(float), py::format_descriptor<float>::format(), 1,
                                {o.Tensor().size()}, {sizeof(float)});

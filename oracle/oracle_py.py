@@ -341,6 +341,29 @@ class State:
         n = lib().osgo_history(self._h, out, 512)
         return [out[i] for i in range(n)]
 
+    def observer(self, player, obs_type=None):
+        """Game::MakeObserver(obs_type) on this state (genuine reference build only).  obs_type: None (the default observer)
+        or (public_info, perfect_recall, private_info) with private_info 0 kNone / 1 kSinglePlayer / 2 kAllPlayers.
+        Returns None when the game offers no such observer, else a dict: tensor (float32 or None), pieces
+        [(name, shape)], string, compressed (bytes)."""
+        pub, rec, prv = (-1, 0, 0) if obs_type is None else (int(obs_type[0]), int(obs_type[1]), int(obs_type[2]))
+        tensor = np.zeros(4096, np.float32)
+        spec, text = C.create_string_buffer(2048), C.create_string_buffer(4096)
+        comp = (C.c_ubyte * 20000)()
+        comp_len = C.c_int(0)
+        n = lib().osgo_observer(self._h, pub, rec, prv, player, _ptr(tensor, C.c_float), 4096, spec, 2048, text, 4096,
+                                comp, 20000, C.byref(comp_len))
+        if n == -2:
+            return None
+        if n < 0:
+            raise OracleError(lib().osgo_last_error().decode())
+        pieces = None
+        if spec.value != b"-":
+            pieces = [(item.split(":")[0], tuple(int(d) for d in item.split(":")[1].split("x") if d))
+                      for item in spec.value.decode().split(";") if item]
+        return {"tensor": tensor[:n].copy() if pieces is not None else None, "pieces": pieces,
+                "string": text.value.decode(), "compressed": bytes(comp[:comp_len.value])}
+
     def mcts_search(self, uct_c, max_simulations, n_rollouts, max_memory_mb, solve, seed,
                     counter_root=-1, counter_seed=0, counter_layout=1, puct=False):
         best = C.c_int64(0)

@@ -30,6 +30,7 @@
 #include "open_spiel/algorithms/outcome_sampling_mccfr.h"
 #include "open_spiel/algorithms/tabular_exploitability.h"
 #include "open_spiel/games/kuhn_poker/kuhn_poker.h"
+#include "open_spiel/observer.h"
 #include "open_spiel/policy.h"
 #include "open_spiel/spiel.h"
 #include "open_spiel/spiel_utils.h"
@@ -290,6 +291,61 @@ int osgo_serialize_game_and_state(void* s, char* buf, int cap) {
 #else
   (void)s; (void)buf; (void)cap;
   g_err = "wire formats are only available from the genuine reference build";
+  return -1;
+#endif
+}
+// Game::MakeObserver(IIGObservationType{public_info, perfect_recall, private_info}) on the state (observer.cc:137-190, the
+// games' own MakeObserver): the Observation's tensor, its pieces as "name:d0xd1;...", its string, and Compress()
+// (observer.cc:246-309).  private_info: 0 kNone, 1 kSinglePlayer, 2 kAllPlayers; public_info < 0 = no type (the
+// game's default observer).  Returns the tensor's length, -2 when the game offers no such observer.  Genuine build only.
+int osgo_observer(void* s, int public_info, int perfect_recall, int private_info, int player, float* tensor, int tensor_cap,
+                  char* spec, int spec_cap, char* str, int str_cap, unsigned char* comp, int comp_cap, int* comp_len) {
+#ifdef OSGO_GENUINE_REFERENCE
+  try {
+    const State& st = *static_cast<StateH*>(s)->state;
+    std::shared_ptr<const Game> game = st.GetGame();
+    std::optional<open_spiel::IIGObservationType> type;
+    if (public_info >= 0)
+      type = open_spiel::IIGObservationType{public_info != 0, perfect_recall != 0,
+                                            private_info == 0 ? open_spiel::PrivateInfoType::kNone
+                                            : private_info == 1 ? open_spiel::PrivateInfoType::kSinglePlayer
+                                                                : open_spiel::PrivateInfoType::kAllPlayers};
+    std::shared_ptr<open_spiel::Observer> observer = game->MakeObserver(type, {});
+    if (!observer) return -2;
+    open_spiel::Observation obs(*game, observer);
+    std::string text, pieces;
+    if (obs.HasString()) text = obs.StringFrom(st, player);
+    int n = 0;
+    if (obs.HasTensor()) {
+      obs.SetFrom(st, player);
+      auto span = obs.Tensor();
+      n = static_cast<int>(span.size());
+      if (n > tensor_cap) Fatal("tensor buffer too small");
+      std::copy(span.begin(), span.end(), tensor);
+      for (const auto& info : obs.tensors_info()) {
+        pieces += std::string(info.name()) + ":";
+        bool first = true;
+        for (int d : info.shape()) { pieces += (first ? "" : "x") + std::to_string(d); first = false; }
+        pieces += ";";
+      }
+      const std::string c = obs.Compress();
+      if (static_cast<int>(c.size()) > comp_cap) Fatal("compress buffer too small");
+      std::memcpy(comp, c.data(), c.size());
+      *comp_len = static_cast<int>(c.size());
+    } else {
+      *comp_len = 0;
+      pieces = "-";
+    }
+    if (CopyStr(pieces, spec, spec_cap) < 0 || CopyStr(text, str, str_cap) < 0) Fatal("string buffer too small");
+    return n;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+#else
+  (void)s; (void)public_info; (void)perfect_recall; (void)private_info; (void)player; (void)tensor; (void)tensor_cap;
+  (void)spec; (void)spec_cap; (void)str; (void)str_cap; (void)comp; (void)comp_cap; (void)comp_len;
+  g_err = "general observers are only available from the genuine reference build";
   return -1;
 #endif
 }

@@ -306,7 +306,11 @@ def test_observation_wrapper_like_observation_test(pyspiel):
     info.set_from(state, player=1)  # the dict entries are views into the tensor
     np.testing.assert_array_equal(info.dict["player"], [0, 1])
     np.testing.assert_array_equal(info.dict["private_card"], [0, 0, 1, 0, 0, 0])
-    assert make_observation(game, IIGObservationType(perfect_recall=True, private_info=PrivateInfoType.ALL_PLAYERS)) is None
+    every = make_observation(game, IIGObservationType(perfect_recall=True, private_info=PrivateInfoType.ALL_PLAYERS))
+    every.set_from(state, player=0)       # leduc_poker.cc:119-129: every player's card, [players, cards]
+    assert list(every.dict) == ["player", "private_cards", "community_card", "betting"]
+    np.testing.assert_array_equal(every.dict["private_cards"], [[0, 1, 0, 0, 0, 0], [0, 0, 1, 0, 0, 0]])
+    assert every.string_from(state, 0) == "[Privates: 12][Round 2][Player: 0][Pot: 6][Money: 97 97][Public: 3][Round1: 2 1][Round2: ]"
     kuhn = pyspiel.load_game("kuhn_poker")
     ks = kuhn.new_initial_state()
     for a in (2, 0, 1):  # deals 2 / 0, player 0 bets
@@ -323,7 +327,8 @@ def test_observation_wrapper_like_observation_test(pyspiel):
     co.set_from(cs, 0)
     assert list(co.dict) == ["observation"] and co.dict["observation"].shape == (3, 6, 7)
     assert co.dict["observation"][0, 0, 3] == 1 and co.dict["observation"][2].sum() == 41
-    assert make_observation(c4, INFO_STATE_OBS_TYPE) is None
+    info_c4 = make_observation(c4, INFO_STATE_OBS_TYPE)   # observer.cc:158-159: the information-state string, no tensor
+    assert info_c4.tensor is None and info_c4.string_from(cs, 0) == "3"
 
 
 # ---- round 2: Bot base class, the whole SearchNode tree, any Evaluator, observer bindings, game submodules ----

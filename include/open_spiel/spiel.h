@@ -40,6 +40,10 @@ namespace kuhn_poker { using namespace hip::kuhn_poker; }
 namespace leduc_poker { using namespace hip::leduc_poker; }
 namespace efg_game { using namespace hip::efg_game; }
 namespace tic_tac_toe { using namespace hip::tic_tac_toe; }
+namespace connect_four { using namespace hip::connect_four; }
+// the struct API (spiel.h:235-299) and utils/status.h
+using hip::SpielStruct; using hip::StateStruct; using hip::ObservationStruct; using hip::ActionStruct; using hip::GameParametersStruct;
+using hip::SafeActionCast; using hip::LoadGameFromJson; using hip::Status; using hip::StatusValue; using hip::OkStatus; using hip::ErrorStatus;
 // spiel_utils.h:119-137: the default fatal-error handler prints and exits
 [[noreturn]] inline void SpielFatalErrorShim(const std::string& msg) { std::cerr << "Spiel Fatal Error: " << msg << std::endl; std::exit(1); }
 }  // namespace open_spiel

@@ -116,6 +116,15 @@ int osg_batch_gather(osg_batch* dst, const osg_batch* src, const int64_t* index,
 /* Raw SoA image: state_words planes of n elements each (plane-major). */
 int osg_batch_download(const osg_batch* b, void* h_words);
 int osg_batch_upload(osg_batch* b, const void* h_words);
+/* State `index` of the batch := the position with these cells, one character per cell ('.', 'x', 'o').  tic_tac_toe: 9
+ * cells, cell a = action a (TicTacToeState(game, TicTacToeStateStruct), games/tic_tac_toe/tic_tac_toe.cc:273-336);
+ * connect_four: rows x cols cells, cell r * cols + c with row 0 the BOTTOM row (ConnectFourStateStruct::board;
+ * ConnectFourState(game, struct, strict_validation) and ConnectFourState(game, string),
+ * games/connect_four/connect_four.cc:352-470).  The position is built on the device with the game's own rules
+ * (outcome recomputed; player to move = parity of the stone count, which is how this layout stores it — the
+ * piece-count rules of the reference's constructors are the caller's to enforce).  OSG_ERR_INVALID: wrong cell count,
+ * another character, a gap in a connect_four column, both players with a line; OSG_ERR_UNSUPPORTED: other games. */
+int osg_batch_set_cells(osg_batch* b, int64_t index, const char* cells, int n_cells);
 /* Device pointer to the SoA planes (plane k at base + k * n elements). */
 void* osg_batch_device_ptr(osg_batch* b);
 

@@ -92,6 +92,7 @@ SIGNATURES = {
     "osg_batch_gather": (INT, [VP, VP, VP, INT]),
     "osg_batch_download": (INT, [VP, VP]),
     "osg_batch_upload": (INT, [VP, VP]),
+    "osg_batch_set_cells": (INT, [VP, C.c_int64, C.c_char_p, INT]),
     "osg_batch_device_ptr": (VP, [VP]),
     "osg_legal_mask": (INT, [VP, VP, INT]),
     "osg_apply": (INT, [VP, VP, INT, C.POINTER(I64)]),

@@ -42,6 +42,7 @@
 #include <vector>
 
 #include "../../../include/osg_abi.h"
+#include "osg_json.h"
 
 namespace open_spiel {
 namespace hip {
@@ -283,6 +284,8 @@ struct GameType {
 
 class State;
 class BatchedState;
+struct StateStruct;
+struct GameParametersStruct;
 enum class TensorLayout { kHWC, kCHW };  // spiel.h:231
 enum class StateType { kTerminal, kChance, kDecision, kMeanField };  // spiel_globals.h:84-92
 class Policy;
@@ -338,6 +341,10 @@ class Game : public std::enable_shared_from_this<Game> {
   const osg_game_desc& Desc() const { return desc_; }
   osg_ctx* Ctx() const { return Context::Default(device_); }
   inline std::unique_ptr<State> NewInitialState() const;
+  // spiel.h:967-971, tic_tac_toe.h:140-149, connect_four.h:182-192: a state from its struct / its JSON (the two board
+  // games whose reference State has a constructor from a board)
+  inline std::unique_ptr<State> NewInitialState(const StateStruct& state_struct) const;
+  inline std::unique_ptr<State> NewInitialState(const Json& json) const;
   std::unique_ptr<State> NewInitialStateForPopulation(int) const {  // spiel.h:963-966: mean-field games only
     SpielFatalError("NewInitialStateForPopulation is not implemented.");
   }
@@ -381,7 +388,60 @@ inline std::shared_ptr<const Game> LoadGameAsTurnBased(const std::string& name) 
 inline std::shared_ptr<const Game> LoadGameAsTurnBased(const std::string& name, const GameParameters&) {
   return LoadGameAsTurnBased(name);
 }
-// games/tic_tac_toe/tic_tac_toe.h:40-48: the constants user code sizes its arrays with
+// ---- utils/status.h:23-73 ----
+enum class StatusValue { kOk = 0, kError = 1 };
+class Status {
+ public:
+  explicit Status() : status_value_(StatusValue::kOk) {}
+  Status(StatusValue status_value, const std::string& message) : status_value_(status_value), message_(message) {}
+  bool ok() const { return status_value_ == StatusValue::kOk; }
+  std::string message() const { return message_; }
+  std::string ToString() const { return ok() ? "OK" : "ERROR: " + message_; }
+
+ private:
+  StatusValue status_value_;
+  std::string message_;
+};
+inline Status OkStatus() { return Status(); }
+inline Status ErrorStatus(const std::string& message) { return Status(StatusValue::kError, message); }
+inline std::ostream& operator<<(std::ostream& os, const Status& status) { return os << status.ToString(); }
+
+// ---- the struct API (spiel.h:235-299): structured, JSON-printable information about states, observations, actions
+// and game parameters, for the two board games that define it (tic_tac_toe.h:58-76, connect_four.h:72-113) ----
+struct SpielStruct {
+  virtual ~SpielStruct() = default;
+  std::string ToJson() const { return to_json_base().dump(); }
+  virtual Json to_json_base() const = 0;
+};
+struct StateStruct : public SpielStruct {};
+struct ObservationStruct : public SpielStruct {};
+struct ActionStruct : public SpielStruct {};
+struct GameParametersStruct : public SpielStruct {
+  std::string game_name;  // required: which game this configures
+  Json to_json_base() const override {
+    Json j = Json::object();
+    j["game_name"] = game_name;
+    return j;
+  }
+};
+template <typename ActionStructType>
+const ActionStructType* SafeActionCast(const ActionStruct& action_struct) {  // spiel.h:291-298
+  const auto* result = dynamic_cast<const ActionStructType*>(&action_struct);
+  if (result == nullptr) SpielFatalError("SafeActionCast: the action struct is of another game");
+  return result;
+}
+inline std::string DefaultPlayerString(Player player) {  // spiel_utils.cc: "Terminal", "Chance", ...
+  switch (player) {
+    case kTerminalPlayerId: return "Terminal";
+    case kChancePlayerId: return "Chance";
+    case kSimultaneousPlayerId: return "Simultaneous";
+    case kInvalidPlayer: return "Invalid";
+    case kMeanFieldPlayerId: return "MeanField";
+    default: return "Player" + std::to_string(player);
+  }
+}
+
+// games/tic_tac_toe/tic_tac_toe.h:40-76: the constants user code sizes its arrays with, and the struct types
 namespace tic_tac_toe {
 inline constexpr int kNumPlayers = 2;
 inline constexpr int kNumRows = 3;
@@ -389,7 +449,151 @@ inline constexpr int kNumCols = 3;
 inline constexpr int kNumCells = kNumRows * kNumCols;
 inline constexpr int kCellStates = 1 + kNumPlayers;  // empty, 'x', 'o'
 inline constexpr int kNumberStates = 5478;           // distinct reachable positions
+struct TicTacToeStructContents {
+  std::string current_player;
+  std::vector<std::string> board;
+  void from_json(const Json& j) {
+    j.at("current_player").get_to(current_player);
+    j.at("board").get_to(board);
+  }
+  Json contents_json() const {
+    Json j = Json::object();
+    j["board"] = Json(board);
+    j["current_player"] = current_player;
+    return j;
+  }
+};
+struct TicTacToeStateStruct : public StateStruct, public TicTacToeStructContents {
+  TicTacToeStateStruct() = default;
+  explicit TicTacToeStateStruct(const std::string& json_str) { from_json(Json::parse(json_str)); }
+  explicit TicTacToeStateStruct(const Json& j) { from_json(j); }
+  Json to_json_base() const override { return contents_json(); }
+};
+struct TicTacToeObservationStruct : public ObservationStruct, public TicTacToeStructContents {
+  TicTacToeObservationStruct() = default;
+  explicit TicTacToeObservationStruct(const std::string& json_str) { from_json(Json::parse(json_str)); }
+  explicit TicTacToeObservationStruct(const Json& j) { from_json(j); }
+  Json to_json_base() const override { return contents_json(); }
+};
+struct TicTacToeActionStruct : public ActionStruct {
+  int row = 0;
+  int col = 0;
+  TicTacToeActionStruct() = default;
+  explicit TicTacToeActionStruct(const std::string& json_str) { from_json(Json::parse(json_str)); }
+  explicit TicTacToeActionStruct(const Json& j) { from_json(j); }
+  void from_json(const Json& j) { j.at("row").get_to(row); j.at("col").get_to(col); }
+  Json to_json_base() const override {
+    Json j = Json::object();
+    j["col"] = col;
+    j["row"] = row;
+    return j;
+  }
+};
 }  // namespace tic_tac_toe
+
+// games/connect_four/connect_four.h:50-113
+namespace connect_four {
+inline constexpr int kNumPlayers = 2;
+inline constexpr int kDefaultNumRows = 6;
+inline constexpr int kDefaultNumCols = 7;
+inline constexpr int kDefaultXInRow = 4;
+inline constexpr bool kDefaultEgocentricObsTensor = false;
+inline constexpr int kCellStates = 1 + kNumPlayers;  // player 0, player 1, empty
+struct ConnectFourStructContents {
+  std::vector<std::vector<std::string>> board;  // board[r][c], row 0 the bottom row
+  std::string current_player;
+  bool is_terminal = false;
+  std::string winner;
+  void from_json(const Json& j) {
+    j.at("board").get_to(board);
+    j.at("current_player").get_to(current_player);
+    j.at("is_terminal").get_to(is_terminal);
+    j.at("winner").get_to(winner);
+  }
+  Json contents_json() const {
+    Json j = Json::object();
+    Json rows = Json::array();
+    for (const std::vector<std::string>& row : board) rows.push_back(Json(row));
+    j["board"] = rows;
+    j["current_player"] = current_player;
+    j["is_terminal"] = is_terminal;
+    j["winner"] = winner;
+    return j;
+  }
+};
+struct ConnectFourStateStruct : public StateStruct, public ConnectFourStructContents {
+  ConnectFourStateStruct() = default;
+  explicit ConnectFourStateStruct(const std::string& json_str) { from_json(Json::parse(json_str)); }
+  explicit ConnectFourStateStruct(const Json& j) { from_json(j); }
+  Json to_json_base() const override { return contents_json(); }
+};
+struct ConnectFourObservationStruct : public ObservationStruct, public ConnectFourStructContents {
+  ConnectFourObservationStruct() = default;
+  explicit ConnectFourObservationStruct(const std::string& json_str) { from_json(Json::parse(json_str)); }
+  explicit ConnectFourObservationStruct(const Json& j) { from_json(j); }
+  Json to_json_base() const override { return contents_json(); }
+};
+struct ConnectFourActionStruct : public ActionStruct {
+  int column = 0;
+  ConnectFourActionStruct() = default;
+  explicit ConnectFourActionStruct(const std::string& json_str) { from_json(Json::parse(json_str)); }
+  explicit ConnectFourActionStruct(const Json& j) { from_json(j); }
+  void from_json(const Json& j) { j.at("column").get_to(column); }
+  Json to_json_base() const override {
+    Json j = Json::object();
+    j["column"] = column;
+    return j;
+  }
+};
+struct ConnectFourGameParams : public GameParametersStruct {
+  int rows = kDefaultNumRows;
+  int columns = kDefaultNumCols;
+  int x_in_row = kDefaultXInRow;
+  bool egocentric_obs_tensor = kDefaultEgocentricObsTensor;
+  ConnectFourGameParams() { game_name = "connect_four"; }
+  explicit ConnectFourGameParams(const std::string& json_str) : ConnectFourGameParams() { from_json(Json::parse(json_str)); }
+  explicit ConnectFourGameParams(const Json& j) : ConnectFourGameParams() { from_json(j); }
+  void from_json(const Json& j) {  // (NLOHMANN_DEFINE_TYPE_INTRUSIVE: every field must be there)
+    j.at("game_name").get_to(game_name);
+    j.at("rows").get_to(rows);
+    j.at("columns").get_to(columns);
+    j.at("x_in_row").get_to(x_in_row);
+    j.at("egocentric_obs_tensor").get_to(egocentric_obs_tensor);
+  }
+  Json to_json_base() const override {
+    Json j = Json::object();
+    j["game_name"] = game_name;
+    j["rows"] = rows;
+    j["columns"] = columns;
+    j["x_in_row"] = x_in_row;
+    j["egocentric_obs_tensor"] = egocentric_obs_tensor;
+    return j;
+  }
+};
+}  // namespace connect_four
+
+// spiel.cc:326-353: a game from JSON game parameters ({"game_name": ..., <parameter>: <bool | int | double | string>})
+inline std::shared_ptr<const Game> LoadGameFromJson(const std::string& json_string) {
+  const Json json = Json::parse(json_string);
+  if (!json.contains("game_name")) SpielFatalError("JSON game params must contain 'game_name' key.");
+  const std::string game_name = json.at("game_name").get<std::string>();
+  if (game_name.empty()) SpielFatalError("JSON game params 'game_name' must not be empty.");
+  GameParameters params;
+  params["name"] = GameParameter(game_name);
+  for (const auto& kv : json.items_object()) {
+    if (kv.first == "game_name") continue;
+    const Json& value = kv.second;
+    if (value.is_boolean()) params[kv.first] = GameParameter(value.get<bool>());
+    else if (value.is_number_integer()) params[kv.first] = GameParameter(value.get<int>());
+    else if (value.is_number()) params[kv.first] = GameParameter(value.get<double>());
+    else if (value.is_string()) params[kv.first] = GameParameter(value.get<std::string>());
+    else SpielFatalError("Unsupported JSON value type for key: " + kv.first);
+  }
+  return LoadGame(params);
+}
+inline std::shared_ptr<const Game> LoadGame(const GameParametersStruct& params_struct) {  // spiel.h:1332-1335
+  return LoadGameFromJson(params_struct.ToJson());
+}
 namespace efg_game {
 inline std::string GetKuhnPokerEFGData() { return ""; }
 inline std::shared_ptr<const Game> LoadEFGGame(const std::string&) {
@@ -691,6 +895,128 @@ class State {
     for (const auto& pa : history_) out += std::to_string(pa.second) + "\n";
     return history_.empty() ? std::string("\n") : out;
   }
+  // ---- the struct API (spiel.h:340-473, 728-734; tic_tac_toe.cc:178-213, connect_four.cc:224-275) ----
+  std::unique_ptr<StateStruct> ToStruct() const {
+    const std::string name = ShortName();
+    const Player cur = CurrentPlayer();
+    const std::string who = cur == 0 ? "x" : (cur == 1 ? "o" : DefaultPlayerString(cur));
+    if (name == "tic_tac_toe") {
+      auto rv = std::make_unique<tic_tac_toe::TicTacToeStateStruct>();
+      rv->current_player = who;
+      for (char ch : BoardCells()) rv->board.push_back(std::string(1, ch));
+      return rv;
+    }
+    if (name == "connect_four") {
+      auto rv = std::make_unique<connect_four::ConnectFourStateStruct>();
+      const std::vector<int> shape = batch_.GetGame()->ObservationTensorShape();
+      const int rows = shape[1], cols = shape[2];
+      const std::string cells = BoardCells();
+      rv->board.assign(rows, std::vector<std::string>(cols));
+      for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) rv->board[r][c] = std::string(1, cells[r * cols + c]);
+      rv->current_player = who;
+      rv->is_terminal = IsTerminal();
+      if (rv->is_terminal) {
+        const std::vector<double> ret = Returns();
+        rv->winner = ret[0] > 0 ? "x" : (ret[0] < 0 ? "o" : "draw");
+      }
+      return rv;
+    }
+    SpielFatalError("ToStruct is not implemented.");
+  }
+  std::string ToJson() const { return ToStruct()->ToJson(); }
+  std::unique_ptr<ObservationStruct> ToObservationStruct(Player player) const {
+    CheckPlayer(player);
+    const std::string name = ShortName();
+    if (name == "tic_tac_toe") return std::make_unique<tic_tac_toe::TicTacToeObservationStruct>(ToJson());
+    if (name == "connect_four") return std::make_unique<connect_four::ConnectFourObservationStruct>(ToJson());
+    SpielFatalError("ToObservationStruct not implemented!");
+  }
+  std::unique_ptr<ObservationStruct> ToObservationStruct() const { return ToObservationStruct(CurrentPlayer()); }
+  std::unique_ptr<ActionStruct> ActionToStruct(Player /*player*/, Action action_id) const {
+    const std::string name = ShortName();
+    if (name == "tic_tac_toe") {
+      auto a = std::make_unique<tic_tac_toe::TicTacToeActionStruct>();
+      a->row = static_cast<int>(action_id) / tic_tac_toe::kNumCols;
+      a->col = static_cast<int>(action_id) % tic_tac_toe::kNumCols;
+      return a;
+    }
+    if (name == "connect_four") {
+      auto a = std::make_unique<connect_four::ConnectFourActionStruct>();
+      a->column = static_cast<int>(action_id);
+      return a;
+    }
+    SpielFatalError("ActionToStruct not implemented.");
+  }
+  std::unique_ptr<ActionStruct> ActionToStruct(Action action_id) const { return ActionToStruct(CurrentPlayer(), action_id); }
+  std::vector<Action> StructToActions(const ActionStruct& action_struct) const {
+    const std::string name = ShortName();
+    if (name == "tic_tac_toe") {
+      const auto* a = SafeActionCast<tic_tac_toe::TicTacToeActionStruct>(action_struct);
+      if (a->row < 0 || a->row >= tic_tac_toe::kNumRows || a->col < 0 || a->col >= tic_tac_toe::kNumCols)
+        SpielFatalError("StructToActions: (row, col) is off the board");
+      return {static_cast<Action>(a->row * tic_tac_toe::kNumCols + a->col)};
+    }
+    if (name == "connect_four") {
+      const auto* a = SafeActionCast<connect_four::ConnectFourActionStruct>(action_struct);
+      if (a->column < 0 || a->column >= batch_.GetGame()->ObservationTensorShape()[2])
+        SpielFatalError("StructToActions: the column is off the board");
+      return {static_cast<Action>(a->column)};
+    }
+    SpielFatalError("StructToActions not implemented.");
+  }
+  std::unique_ptr<ActionStruct> ActionsToStruct(Player player, const std::vector<Action>& actions) const {  // spiel.h:440-448
+    if (actions.size() != 1) SpielFatalError("ActionsToStruct: one action per move in this game");
+    return ActionToStruct(player, actions[0]);
+  }
+  std::unique_ptr<ActionStruct> ActionsToStruct(const std::vector<Action>& actions) const { return ActionsToStruct(CurrentPlayer(), actions); }
+  Status ValidateActionStruct(const ActionStruct& action_struct) const {  // spiel.cc:491-504
+    const std::vector<Action> legal = LegalActions();
+    for (Action action : StructToActions(action_struct))
+      if (std::find(legal.begin(), legal.end(), action) == legal.end())
+        return ErrorStatus("Illegal action: " + action_struct.ToJson() + " (action " + std::to_string(action) + " = '" +
+                           ActionToString(action) + "' is not legal)");
+    return OkStatus();
+  }
+  Status ApplyActionStruct(const ActionStruct& action_struct) {  // spiel.cc:506-515
+    Status status = ValidateActionStruct(action_struct);
+    if (!status.ok()) return status;
+    for (Action action : StructToActions(action_struct)) ApplyAction(action);
+    return OkStatus();
+  }
+  // The position's cells ('.', 'x', 'o'): tic_tac_toe cell a = action a; connect_four cell r * cols + c, row 0 the bottom
+  // row.  Read off the observation tensor (plane of x, plane of o), which the device packs from the same words.
+  std::string BoardCells() const {
+    const std::string name = ShortName();
+    const std::vector<float> t = batch_.ObservationTensor(0);
+    const std::vector<int> shape = batch_.GetGame()->ObservationTensorShape();
+    const int cells = shape[1] * shape[2];
+    std::string out(static_cast<size_t>(cells), '.');
+    // tic_tac_toe planes: 0 empty, 1 o, 2 x (tic_tac_toe.cc:241-251); connect_four: 0 x, 1 o, 2 empty
+    // (connect_four.cc:312-328; the egocentric form swaps the first two for player 1 — player 0 is asked here... and
+    // for player 0 it holds o first, x second)
+    int x_plane = name == "tic_tac_toe" ? 2 : 0, o_plane = 1;
+    if (name == "connect_four" && GameParametersFromString(batch_.GetGame()->ToString()).count("egocentric_obs_tensor") &&
+        GameParametersFromString(batch_.GetGame()->ToString()).at("egocentric_obs_tensor").bool_value()) {
+      x_plane = 1; o_plane = 0;
+    }
+    for (int i = 0; i < cells; ++i) {
+      if (t[static_cast<size_t>(x_plane) * cells + i] != 0.0f) out[i] = 'x';
+      else if (t[static_cast<size_t>(o_plane) * cells + i] != 0.0f) out[i] = 'o';
+    }
+    return out;
+  }
+  // This state := the position with these cells (osg_batch_set_cells); its history starts here, as the reference's
+  // states constructed from a board do.
+  void SetCells(const std::string& cells) {
+    Check(osg_batch_set_cells(batch_.handle(), 0, cells.data(), static_cast<int>(cells.size())));
+    snap_ = Snapshot{};
+    history_.clear();
+  }
+  std::string ShortName() const {
+    const std::string text = batch_.GetGame()->ToString();
+    return text.substr(0, text.find('('));
+  }
   int MoveNumber() const { return static_cast<int>(history_.size()); }
   int NumPlayers() const { return batch_.GetGame()->NumPlayers(); }
   std::shared_ptr<const Game> GetGame() const { return batch_.GetGame(); }
@@ -725,6 +1051,158 @@ inline std::unique_ptr<State> Game::NewInitialState() const {
   return std::unique_ptr<State>(new State(shared_from_this()));
 }
 inline BatchedState Game::NewInitialStates(int64_t n) const { return BatchedState(shared_from_this(), n); }
+
+// ---- the game-specific state / game classes user code names (tic_tac_toe.h:78-150, connect_four.h:115-200).  One
+// State class serves every game here (a state is a record in a struct-of-arrays batch); these add constructors and
+// accessors, no data, so a State* of the right game may be viewed as one (the reference's static_cast idiom). ----
+namespace tic_tac_toe {
+class TicTacToeState : public State {
+ public:
+  explicit TicTacToeState(std::shared_ptr<const Game> game) : State(std::move(game)) {}
+  // tic_tac_toe.cc:273-336: the position of the struct, validated as the reference validates it
+  TicTacToeState(std::shared_ptr<const Game> game, const TicTacToeStateStruct& state_struct) : State(std::move(game)) {
+    if (static_cast<int>(state_struct.board.size()) != kNumCells)
+      SpielFatalError("Invalid board size: expected " + std::to_string(kNumCells) + ", got " + std::to_string(state_struct.board.size()));
+    std::string cells;
+    int num_x = 0, num_o = 0;
+    for (const std::string& cell : state_struct.board) {
+      if (cell != "." && cell != "x" && cell != "o") SpielFatalError("Invalid cell value: '" + cell + "'. Expected '.', 'x', or 'o'.");
+      cells.push_back(cell[0]);
+      num_x += cell == "x";
+      num_o += cell == "o";
+    }
+    if (num_x < num_o || num_x > num_o + 1)
+      SpielFatalError("Invalid board state: invalid number of pieces, got x = " + std::to_string(num_x) + ", o = " + std::to_string(num_o));
+    SetCells(cells);  // (both players with a line: refused there)
+    if (IsTerminal()) {
+      const double r0 = Returns()[0];
+      if (r0 > 0 && num_x != num_o + 1)
+        SpielFatalError("Invalid board state: x has a line, but number of pieces is inconsistent, got x = " + std::to_string(num_x) +
+                        ", o = " + std::to_string(num_o));
+      if (r0 < 0 && num_x != num_o)
+        SpielFatalError("Invalid board state: o has a line, but number of pieces is inconsistent, got x = " + std::to_string(num_x) +
+                        ", o = " + std::to_string(num_o));
+    }
+    const Player cur = CurrentPlayer();
+    const std::string who = cur == 0 ? "x" : (cur == 1 ? "o" : DefaultPlayerString(cur));
+    if (state_struct.current_player != who)
+      SpielFatalError("Invalid current player: expected " + who + ", got " + state_struct.current_player);
+  }
+};
+}  // namespace tic_tac_toe
+
+namespace connect_four {
+class ConnectFourGame : public Game {
+ public:
+  using Game::Game;
+  using Game::NewInitialState;
+  int rows() const { return Desc().obs_shape[1]; }
+  int cols() const { return Desc().obs_shape[2]; }
+  int x_in_row() const {
+    const GameParameters params = GetParameters();
+    auto it = params.find("x_in_row");
+    return it == params.end() ? kDefaultXInRow : it->second.int_value();
+  }
+  inline std::unique_ptr<State> NewInitialState(const ConnectFourStateStruct& state_struct, bool strict_validation = true) const;
+};
+class ConnectFourState : public State {
+ public:
+  explicit ConnectFourState(std::shared_ptr<const Game> game) : State(std::move(game)) {}
+  // connect_four.cc:515-562: the board as ToString prints it (top row first; other characters are skipped)
+  ConnectFourState(std::shared_ptr<const Game> game, const std::string& str) : State(std::move(game)) {
+    const int rows = GetGame()->Desc().obs_shape[1], cols = GetGame()->Desc().obs_shape[2];
+    std::string cells(static_cast<size_t>(rows) * cols, '.');
+    int xs = 0, os = 0, r = rows - 1, c = 0;
+    for (const char ch : str) {
+      if (ch != '.' && ch != 'x' && ch != 'o') continue;
+      if (r < 0) SpielFatalError("Problem parsing state (incorrect rows).");
+      cells[static_cast<size_t>(r) * cols + c] = ch;
+      xs += ch == 'x';
+      os += ch == 'o';
+      if (++c >= cols) { --r; c = 0; }
+    }
+    if (!(xs == os || xs == os + 1)) SpielFatalError("ConnectFourState: xs == os || xs == (os + 1)");
+    if (r != -1) SpielFatalError("Problem parsing state (incorrect rows).");
+    if (c != 0) SpielFatalError("Problem parsing state (column value should be 0)");
+    SetCells(cells);
+  }
+  // connect_four.cc:352-513: the position of the struct; strict_validation = false admits unreachable piece counts,
+  // everything else (no gaps, valid cells, terminal / winner / player consistency) is always checked
+  ConnectFourState(std::shared_ptr<const Game> game, const ConnectFourStateStruct& state_struct, bool strict_validation = true)
+      : State(std::move(game)) {
+    const int rows = GetGame()->Desc().obs_shape[1], cols = GetGame()->Desc().obs_shape[2];
+    if (static_cast<int>(state_struct.board.size()) != rows)
+      SpielFatalError("Invalid board row count: expected " + std::to_string(rows) + ", got " + std::to_string(state_struct.board.size()));
+    std::string cells;
+    int num_x = 0, num_o = 0;
+    for (int r = 0; r < rows; ++r) {
+      if (static_cast<int>(state_struct.board[r].size()) != cols)
+        SpielFatalError("Invalid board column count at row " + std::to_string(r) + ": expected " + std::to_string(cols) + ", got " +
+                        std::to_string(state_struct.board[r].size()));
+      for (const std::string& cell : state_struct.board[r]) {
+        if (cell != "." && cell != "x" && cell != "o") SpielFatalError("Invalid cell value: '" + cell + "'. Expected '.', 'x', or 'o'.");
+        cells.push_back(cell[0]);
+        num_x += cell == "x";
+        num_o += cell == "o";
+      }
+    }
+    const std::string counts = "x=" + std::to_string(num_x) + ", o=" + std::to_string(num_o);
+    if (strict_validation && (num_x < num_o || num_x > num_o + 1))
+      SpielFatalError("Invalid board state: piece count imbalance. X (first player) must have equal or one more piece than O. Got " +
+                      counts + ". Use strict_validation=false to allow unreachable positions.");
+    SetCells(cells);  // (a gap in a column, both players with a line: refused there)
+    const bool terminal = IsTerminal();
+    std::string winner;
+    if (terminal) {
+      const double r0 = Returns()[0];
+      winner = r0 > 0 ? "x" : (r0 < 0 ? "o" : "draw");
+      if (strict_validation && winner == "x" && num_x != num_o + 1)
+        SpielFatalError("Invalid board state: X has a winning line but piece counts are inconsistent. When X wins, X must have one "
+                        "more piece than O. Got " + counts + ".");
+      if (strict_validation && winner == "o" && num_x != num_o)
+        SpielFatalError("Invalid board state: O has a winning line but piece counts are inconsistent. When O wins, X and O must have "
+                        "equal pieces. Got " + counts + ".");
+    }
+    if (state_struct.is_terminal != terminal)
+      SpielFatalError(std::string("Invalid is_terminal: struct says ") + (state_struct.is_terminal ? "terminal" : "non-terminal") +
+                      " but board state is " + (terminal ? "terminal" : "non-terminal") + ".");
+    if (state_struct.winner != winner)
+      SpielFatalError("Invalid winner: struct says '" + state_struct.winner + "' but computed winner is '" + winner + "'.");
+    if (terminal) {
+      if (state_struct.current_player != DefaultPlayerString(kTerminalPlayerId))
+        SpielFatalError("Invalid current_player for terminal state: expected '" + DefaultPlayerString(kTerminalPlayerId) + "', got '" +
+                        state_struct.current_player + "'.");
+      return;
+    }
+    if (state_struct.current_player != "x" && state_struct.current_player != "o")
+      SpielFatalError("Invalid current_player: expected 'x' or 'o', got '" + state_struct.current_player + "'.");
+    // The device derives the player to move from the stone count (the layout has no mover word): a struct that names
+    // the other player — possible only with strict_validation = false — is not representable here.
+    const std::string by_count = CurrentPlayer() == 0 ? "x" : "o";
+    if (state_struct.current_player != by_count)
+      SpielFatalError("Invalid current_player: with " + counts + " pieces, it should be " + by_count + "'s turn, but struct says '" +
+                      state_struct.current_player + "'" + (strict_validation ? "." : " (a position whose mover differs from the stone "
+                      "count's parity is not representable on the device)."));
+  }
+};
+inline std::unique_ptr<State> ConnectFourGame::NewInitialState(const ConnectFourStateStruct& state_struct, bool strict_validation) const {
+  return std::unique_ptr<State>(new ConnectFourState(shared_from_this(), state_struct, strict_validation));
+}
+}  // namespace connect_four
+
+inline std::unique_ptr<State> Game::NewInitialState(const StateStruct& state_struct) const {
+  if (const auto* t = dynamic_cast<const tic_tac_toe::TicTacToeStateStruct*>(&state_struct))
+    return std::unique_ptr<State>(new tic_tac_toe::TicTacToeState(shared_from_this(), *t));
+  if (const auto* c = dynamic_cast<const connect_four::ConnectFourStateStruct*>(&state_struct))
+    return std::unique_ptr<State>(new connect_four::ConnectFourState(shared_from_this(), *c));
+  SpielFatalError("NewInitialState from StateStruct is not implemented.");
+}
+inline std::unique_ptr<State> Game::NewInitialState(const Json& json) const {
+  const std::string name = GetType().short_name;
+  if (name == "tic_tac_toe") return NewInitialState(tic_tac_toe::TicTacToeStateStruct(json));
+  if (name == "connect_four") return NewInitialState(connect_four::ConnectFourStateStruct(json));
+  SpielFatalError("NewInitialState from JSON is not implemented.");
+}
 inline std::unique_ptr<State> Game::DeserializeState(const std::string& str) const {
   std::unique_ptr<State> state = NewInitialState();
   size_t pos = 0;

@@ -239,6 +239,15 @@ class PyBot : public Bot {
   }
 };
 
+// python/pybind11/pybind11.h:198-220: a struct type with constructors from nothing, a JSON string and a dict
+template <typename StructType, typename BaseType>
+auto bind_spiel_struct(py::module_& m, const char* name) {
+  return py::class_<StructType, BaseType>(m, name)
+      .def(py::init<>())
+      .def(py::init<std::string>())
+      .def(py::init([](py::dict d) { return StructType(py::module_::import("json").attr("dumps")(d).cast<std::string>()); }));
+}
+
 PYBIND11_MODULE(pyspiel_hip, m) {
   m.doc() = "pyspiel-compatible surface of the MI355X game-step and search engine (libosg_hip.so)";
   py::register_exception<SpielException>(m, "SpielError", PyExc_RuntimeError);  // pyspiel.cc:831-837
@@ -278,6 +287,13 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("information_state_tensor_shape", &Game::InformationStateTensorShape)
       .def("information_state_tensor_size", &Game::InformationStateTensorSize)
       .def("new_initial_state", [](const Game& g) { return g.NewInitialState(); })
+      // pyspiel.cc:484-494: from a JSON string, a dict, a StateStruct
+      .def("new_initial_state", [](const Game& g, const std::string& json) { return g.NewInitialState(Json::parse(json)); })
+      .def("new_initial_state",
+           [](const Game& g, const py::dict& d) {
+             return g.NewInitialState(Json::parse(py::module_::import("json").attr("dumps")(d).cast<std::string>()));
+           })
+      .def("new_initial_state", [](const Game& g, const StateStruct& s) { return g.NewInitialState(s); })
       .def("serialize", &Game::Serialize)
       .def("deserialize_state", &Game::DeserializeState, py::arg("serialized"))
       .def(py::pickle([](const Game& g) { return g.Serialize(); },  // pyspiel.cc:535-543
@@ -380,6 +396,8 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("provides_observation", &GameType::provides_observation)
       .def("__repr__", [](const GameType& t) { return "<GameType '" + t.short_name + "'>"; });
   m.def("load_game", [](const std::string& s) { return std::make_shared<Game>(s); });  // pyspiel.cc:720-731
+  m.def("load_game", [](const GameParametersStruct& p) { return std::const_pointer_cast<Game>(LoadGame(p)); });  // pyspiel.cc:732-733
+  m.def("load_game_from_json", [](const std::string& json) { return std::const_pointer_cast<Game>(LoadGameFromJson(json)); });
   // load_game(short_name, {"players": 3, "swap": True}) (pyspiel.cc:732-741): the parameters as a Python dict
   m.def("load_game",
         [](const std::string& name, const py::dict& params) { return std::make_shared<Game>(GameStringFromDict(name, params)); },
@@ -422,6 +440,22 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .value("DECISION", StateType::kDecision)
       .value("MEAN_FIELD", StateType::kMeanField);
 
+  // ---- the struct API (pyspiel.cc:322-345; python/pybind11/pybind11.h:198-220 bind_spiel_struct): to_json() / to_dict(),
+  // constructors from nothing, a JSON string or a dict ----
+  py::class_<SpielStruct>(m, "SpielStruct")
+      .def("to_json", &SpielStruct::ToJson)
+      .def("to_dict", [](const SpielStruct& self) { return py::module_::import("json").attr("loads")(self.ToJson()); })
+      .def("__str__", &SpielStruct::ToJson);
+  py::class_<StateStruct, SpielStruct>(m, "StateStruct");
+  py::class_<ObservationStruct, SpielStruct>(m, "ObservationStruct");
+  py::class_<ActionStruct, SpielStruct>(m, "ActionStruct");
+  py::class_<GameParametersStruct, SpielStruct>(m, "GameParametersStruct").def_readwrite("game_name", &GameParametersStruct::game_name);
+  py::class_<Status>(m, "Status")  // utils/status.h
+      .def("ok", &Status::ok)
+      .def("message", &Status::message)
+      .def("to_string", &Status::ToString)
+      .def("__bool__", &Status::ok)
+      .def("__str__", &Status::ToString);
   py::class_<State>(m, "State")
       .def("current_player", &State::CurrentPlayer)
       .def("is_terminal", &State::IsTerminal)
@@ -454,6 +488,19 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("information_state_string", py::overload_cast<>(&State::InformationStateString, py::const_))
       .def("observation_string", py::overload_cast<Player>(&State::ObservationString, py::const_), py::arg("player"))
       .def("observation_string", py::overload_cast<>(&State::ObservationString, py::const_))
+      // pyspiel.cc:364-411, 445-450, 473-477: the struct API (tic_tac_toe and connect_four)
+      .def("to_struct", &State::ToStruct)
+      .def("to_json", &State::ToJson)
+      .def("to_dict", [](const State& st) { return py::module_::import("json").attr("loads")(st.ToJson()); })
+      .def("to_observation_struct", py::overload_cast<Player>(&State::ToObservationStruct, py::const_), py::arg("player"))
+      .def("to_observation_struct", py::overload_cast<>(&State::ToObservationStruct, py::const_))
+      .def("action_to_struct", py::overload_cast<Player, Action>(&State::ActionToStruct, py::const_))
+      .def("action_to_struct", py::overload_cast<Action>(&State::ActionToStruct, py::const_))
+      .def("struct_to_actions", &State::StructToActions)
+      .def("actions_to_struct", py::overload_cast<Player, const std::vector<Action>&>(&State::ActionsToStruct, py::const_))
+      .def("actions_to_struct", py::overload_cast<const std::vector<Action>&>(&State::ActionsToStruct, py::const_))
+      .def("validate_action_struct", &State::ValidateActionStruct)
+      .def("apply_action_struct", &State::ApplyActionStruct)
       .def("__str__", &State::ToString)
       .def("to_string", &State::ToString)
       .def("action_to_string", py::overload_cast<Player, Action>(&State::ActionToString, py::const_),
@@ -797,7 +844,8 @@ PYBIND11_MODULE(pyspiel_hip, m) {
 
   // ---- game submodules (python/pybind11/games_tic_tac_toe.cc:37-100, games_leduc_poker.cc:28-60,
   // games_connect_four.cc:47-95).  One State class serves every game here, so the game-specific accessors are
-  // methods of State that refuse other games; the JSON struct API (…StateStruct / …ActionStruct) is not offered.
+  // methods of State that refuse other games; the struct types (…StateStruct / …ActionStruct / …GameParams) are classes of the
+  // submodules as in the reference.
   py::module_ ttt = m.def_submodule("tic_tac_toe");
   py::enum_<TttCellState>(ttt, "CellState")
       .value("EMPTY", TttCellState::kEmpty).value("NOUGHT", TttCellState::kNought).value("CROSS", TttCellState::kCross)
@@ -813,8 +861,35 @@ PYBIND11_MODULE(pyspiel_hip, m) {
   ttt.def("cellstate_to_string", [](TttCellState c) {  // tic_tac_toe.cc:65-77
     return std::string(c == TttCellState::kEmpty ? "." : c == TttCellState::kNought ? "o" : "x");
   });
+  bind_spiel_struct<tic_tac_toe::TicTacToeStateStruct, StateStruct>(ttt, "TicTacToeStateStruct")
+      .def_readwrite("current_player", &tic_tac_toe::TicTacToeStateStruct::current_player)
+      .def_readwrite("board", &tic_tac_toe::TicTacToeStateStruct::board);
+  bind_spiel_struct<tic_tac_toe::TicTacToeObservationStruct, ObservationStruct>(ttt, "TicTacToeObservationStruct")
+      .def_readwrite("current_player", &tic_tac_toe::TicTacToeObservationStruct::current_player)
+      .def_readwrite("board", &tic_tac_toe::TicTacToeObservationStruct::board);
+  bind_spiel_struct<tic_tac_toe::TicTacToeActionStruct, ActionStruct>(ttt, "TicTacToeActionStruct")
+      .def_readwrite("row", &tic_tac_toe::TicTacToeActionStruct::row)
+      .def_readwrite("col", &tic_tac_toe::TicTacToeActionStruct::col);
   py::module_ c4 = m.def_submodule("connect_four");
-  c4.attr("__doc__") = "connect_four: states and games are pyspiel_hip.State / pyspiel_hip.Game (pickle included)";
+  c4.attr("__doc__") = "connect_four: states and games are pyspiel_hip.State / pyspiel_hip.Game (pickle included); the struct "
+                       "types of games_connect_four.cc:47-95";
+  bind_spiel_struct<connect_four::ConnectFourStateStruct, StateStruct>(c4, "ConnectFourStateStruct")
+      .def_readwrite("current_player", &connect_four::ConnectFourStateStruct::current_player)
+      .def_readwrite("board", &connect_four::ConnectFourStateStruct::board)
+      .def_readwrite("is_terminal", &connect_four::ConnectFourStateStruct::is_terminal)
+      .def_readwrite("winner", &connect_four::ConnectFourStateStruct::winner);
+  bind_spiel_struct<connect_four::ConnectFourObservationStruct, ObservationStruct>(c4, "ConnectFourObservationStruct")
+      .def_readwrite("current_player", &connect_four::ConnectFourObservationStruct::current_player)
+      .def_readwrite("board", &connect_four::ConnectFourObservationStruct::board)
+      .def_readwrite("is_terminal", &connect_four::ConnectFourObservationStruct::is_terminal)
+      .def_readwrite("winner", &connect_four::ConnectFourObservationStruct::winner);
+  bind_spiel_struct<connect_four::ConnectFourActionStruct, ActionStruct>(c4, "ConnectFourActionStruct")
+      .def_readwrite("column", &connect_four::ConnectFourActionStruct::column);
+  bind_spiel_struct<connect_four::ConnectFourGameParams, GameParametersStruct>(c4, "ConnectFourGameParams")
+      .def_readwrite("rows", &connect_four::ConnectFourGameParams::rows)
+      .def_readwrite("columns", &connect_four::ConnectFourGameParams::columns)
+      .def_readwrite("x_in_row", &connect_four::ConnectFourGameParams::x_in_row)
+      .def_readwrite("egocentric_obs_tensor", &connect_four::ConnectFourGameParams::egocentric_obs_tensor);
   py::module_ leduc = m.def_submodule("leduc_poker");
   leduc.attr("INVALID_CARD") = py::int_(-10000);  // leduc_poker.h:57 kInvalidCard
   py::enum_<LeducActionType>(leduc, "ActionType")

@@ -51,6 +51,19 @@ struct Ttt {
            ((b & 0x049) == 0x049) | ((b & 0x092) == 0x092) | ((b & 0x124) == 0x124) |
            ((b & 0x111) == 0x111) | ((b & 0x054) == 0x054);
   }
+  // A position from its cells ('.', 'x', 'o'; cell a = action a): TicTacToeState(game, TicTacToeStateStruct),
+  // tic_tac_toe.cc:273-336.  0, or 1 wrong cell count, 2 bad character, 4 both players have a line (the piece-count
+  // rules are the caller's: this layout derives the mover from the stone count).
+  OSG_D static int from_cells(const Params&, const unsigned char* cells, int n_cells, State& s) {
+    if (n_cells != 9) return 1;
+    s = {0u, 0u};
+    for (int a = 0; a < 9; ++a) {
+      if (cells[a] == 'x') s.x |= 1u << a;
+      else if (cells[a] == 'o') s.o |= 1u << a;
+      else if (cells[a] != '.') return 2;
+    }
+    return line(s.x) && line(s.o) ? 4 : 0;
+  }
   OSG_D static int plies(const State& s) { return __builtin_popcount(s.x | s.o); }
   OSG_D static bool terminal(const Params&, const State& s) {  // tic_tac_toe.cc:215-217
     return line(s.x) | line(s.o) | (plies(s) == 9);
@@ -246,6 +259,33 @@ struct C4T {
       const bool done = win | full(p, s);
       s.flags = done ? (1u | (static_cast<uint32_t>(win ? mover : 2) << 1)) : 0u;
     }
+  }
+  // A position from its cells ('.', 'x', 'o'; cell r * cols + c, row 0 = the bottom row: ConnectFourStateStruct::board,
+  // connect_four.h:72-79): ConnectFourState(game, struct, strict) / ConnectFourState(game, string),
+  // connect_four.cc:352-470.  0, or 1 wrong cell count, 2 bad character, 3 a gap in a column, 4 both players have a
+  // line (the piece-count rules are the caller's: this layout derives the mover from the stone count).
+  OSG_D static int from_cells(const Params& p, const unsigned char* cells, int n_cells, State& s) {
+    const int rows = R(p), cols = C(p), H = rows + 1;
+    if (n_cells != rows * cols) return 1;
+    s = {BB(0), BB(0), 0u};
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < cols; ++c) {
+        const unsigned char ch = cells[r * cols + c];
+        if (ch == 'x') s.x |= BB(1) << (c * H + r);
+        else if (ch == 'o') s.o |= BB(1) << (c * H + r);
+        else if (ch != '.') return 2;
+      }
+    for (int c = 0; c < cols; ++c) {   // stacked from the bottom: the column's stones are a run of low bits
+      const BB col = ((s.x | s.o) >> (c * H)) & ((BB(1) << rows) - BB(1));
+      if ((col & (col + BB(1))) != BB(0)) return 3;
+    }
+    const bool xw = line(p, s.x), ow = line(p, s.o);
+    if (xw && ow) return 4;
+    if (kStored) {
+      const bool done = xw | ow | full(p, s);
+      s.flags = done ? (1u | (static_cast<uint32_t>(xw ? 0 : (ow ? 1 : 2)) << 1)) : 0u;
+    }
+    return 0;
   }
   OSG_D static int outcome_code(const Params& p, const State& s) {  // connect_four.cc:281-285
     if (kStored) return static_cast<int>((s.flags >> 1) & 3u);

@@ -1552,6 +1552,17 @@ void ctx_release(osg_ctx* ctx) {
   delete ctx;
 }
 }  // namespace osg
+// One thread builds the position from its cells with the game's own rules and stores it in the batch's layout.
+template <class G>
+__global__ void k_set_cells(typename G::Params P, typename G::word_t* words, int64_t n, int64_t index,
+                            const unsigned char* cells, int n_cells, int* err) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  typename G::State s;
+  const int e = G::from_cells(P, cells, n_cells, s);
+  *err = e;
+  if (e == 0) G::store(P, words, n, index, s);
+}
+
 extern "C" {
 
 int osg_ctx_destroy(osg_ctx* ctx) {
@@ -1680,6 +1691,49 @@ int osg_batch_upload(osg_batch* b, const void* h_words) {
   OSG_HIP(hipMemcpyAsync(b->d_words, h_words, b->bytes, hipMemcpyHostToDevice, b->ctx->stream));
   OSG_HIP(hipStreamSynchronize(b->ctx->stream));
   return OSG_OK;
+}
+
+int osg_batch_set_cells(osg_batch* b, int64_t index, const char* cells, int n_cells) {
+  if (!b || !cells || index < 0 || index >= b->n || n_cells <= 0 || n_cells > 4096)
+    return osg::set_error(OSG_ERR_INVALID, "osg_batch_set_cells: bad argument");
+  osg_ctx* ctx = b->ctx;
+  void* scratch;
+  if (int rc = osg_ctx_scratch(ctx, 4096 + sizeof(int), &scratch)) return rc;
+  unsigned char* d_cells = static_cast<unsigned char*>(scratch);
+  int* d_err = reinterpret_cast<int*>(d_cells + 4096);
+  OSG_HIP(hipMemcpyAsync(d_cells, cells, static_cast<size_t>(n_cells), hipMemcpyHostToDevice, ctx->stream));
+  const osg::GameSpec& spec = b->spec;
+  switch (spec.desc.game_kind) {
+    case osg::kTtt:
+      k_set_cells<osg::Ttt><<<dim3(1), dim3(64), 0, ctx->stream>>>(spec.ttt, static_cast<osg::Ttt::word_t*>(b->d_words), b->n, index,
+                                                                   d_cells, n_cells, d_err);
+      break;
+    case osg::kC4:
+      if (spec.c4_std)
+        k_set_cells<osg::C4Std><<<dim3(1), dim3(64), 0, ctx->stream>>>(spec.c4, static_cast<osg::C4Std::word_t*>(b->d_words), b->n, index,
+                                                                       d_cells, n_cells, d_err);
+      else if (spec.c4_wide)
+        k_set_cells<osg::C4Wide><<<dim3(1), dim3(64), 0, ctx->stream>>>(spec.c4, static_cast<osg::C4Wide::word_t*>(b->d_words), b->n, index,
+                                                                        d_cells, n_cells, d_err);
+      else
+        k_set_cells<osg::C4><<<dim3(1), dim3(64), 0, ctx->stream>>>(spec.c4, static_cast<osg::C4::word_t*>(b->d_words), b->n, index,
+                                                                    d_cells, n_cells, d_err);
+      break;
+    default:
+      return osg::set_error(OSG_ERR_UNSUPPORTED, "osg_batch_set_cells: tic_tac_toe and connect_four positions (the games whose "
+                                                 "reference State has a constructor from a board)");
+  }
+  OSG_HIP(hipGetLastError());
+  int err = 0;
+  OSG_HIP(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  OSG_HIP(hipStreamSynchronize(ctx->stream));
+  switch (err) {
+    case 0: return OSG_OK;
+    case 1: return osg::set_error(OSG_ERR_INVALID, "osg_batch_set_cells: the board does not have the game's number of cells");
+    case 2: return osg::set_error(OSG_ERR_INVALID, "osg_batch_set_cells: a cell is not one of '.', 'x', 'o'");
+    case 3: return osg::set_error(OSG_ERR_INVALID, "Invalid board: gap in a column. Pieces must be stacked from the bottom with no gaps.");
+    default: return osg::set_error(OSG_ERR_INVALID, "Invalid board state: both players have a winning line.");
+  }
 }
 
 int osg_legal_mask(const osg_batch* b, uint32_t* mask, int on_host) {

@@ -78,13 +78,67 @@ int main() {
   std::shared_ptr<Observer> info = MakeObserver(kuhn, &kInfoStateObsType);
   EXPECT(info && info->pieces().size() == 3 && info->pieces()[2].name() == "betting" && info->pieces()[2].size() == 6);
   IIGObservationType all{true, false, PrivateInfoType::kAllPlayers};
-  EXPECT(MakeObserver(kuhn, &all) == nullptr);
+  // (round 5) every IIGObservationType: kuhn writes nothing private unless kSinglePlayer (kuhn_poker.cc:82-93); leduc
+  // writes every player's card (leduc_poker.cc:119-129); a board game's perfect-recall observer is its
+  // information-state STRING, and its private-only observer is empty (observer.cc:150-161)
+  std::shared_ptr<Observer> kuhn_all = MakeObserver(kuhn, &all);
+  EXPECT(kuhn_all && kuhn_all->pieces().size() == 1 && kuhn_all->pieces()[0].name() == "pot_contribution");
+  Game leduc("leduc_poker");
+  IIGObservationType all_recall{true, true, PrivateInfoType::kAllPlayers};
+  std::shared_ptr<Observer> leduc_all = MakeObserver(leduc, &all_recall);
+  EXPECT(leduc_all && leduc_all->pieces().size() == 4 && leduc_all->pieces()[1].name() == "private_cards" &&
+         leduc_all->pieces()[1].size() == 12 && leduc_all->pieces()[3].name() == "betting");
   Game ttt("tic_tac_toe");
-  EXPECT(MakeObserver(ttt, &kInfoStateObsType) == nullptr && MakeObserver(ttt)->pieces()[0].size() == 27);
+  EXPECT(MakeObserver(ttt, &kInfoStateObsType) && !MakeObserver(ttt, &kInfoStateObsType)->HasTensor());
+  IIGObservationType private_only{false, false, PrivateInfoType::kSinglePlayer};
+  EXPECT(MakeObserver(ttt, &private_only)->pieces().empty() && MakeObserver(ttt)->pieces()[0].size() == 27);
   // ShardRange covers every unit exactly once
   int64_t covered = 0;
   for (int r = 0; r < 8; ++r) { auto fc = ShardRange(1000003, r, 8); EXPECT(fc.first == covered); covered += fc.second; }
   EXPECT(covered == 1000003);
+  // ---- round 5: the JSON value of the struct API and the struct types (no device needed) ----
+  {
+    const std::string text = R"({"b":[["x","."],["o","."]],"ego":true,"game_name":"connect_four","n":null,"rows":5,"x":1.5})";
+    const Json j = Json::parse(" {\"rows\" : 5, \"x\":1.5, \"game_name\":\"connect_four\",\n \"ego\":true,\"b\":[[\"x\",\".\"],[\"o\",\".\"]],\"n\":null} ");
+    EXPECT(j.dump() == text);                          // no whitespace, keys sorted: nlohmann's dump()
+    EXPECT(Json::parse(j.dump()) == j);
+    EXPECT(j.at("rows").get<int>() == 5 && j.at("x").get<double>() == 1.5 && j.at("ego").get<bool>() && j.at("n").is_null());
+    EXPECT(j.at("b").at(1).at(0).get<std::string>() == "o" && j.contains("game_name") && !j.contains("columns"));
+    EXPECT(Json(std::string("a\"b\\c\n\t\x01")).dump() == "\"a\\\"b\\\\c\\n\\t\\u0001\"");
+    EXPECT(Json::parse("\"\\u00e9\\ud83d\\ude00\"").get<std::string>() == "\xC3\xA9\xF0\x9F\x98\x80");
+    EXPECT(Json(2.0).dump() == "2.0" && Json(-0.1).dump() == "-0.1" && Json(1e300).dump() == "1e+300" && Json(7).dump() == "7");
+    EXPECT(Json::parse("[1,-2,3.25,1e2]").dump() == "[1,-2,3.25,100.0]");
+    for (const char* bad : {"{\"a\":}", "[1,", "{\"a\" 1}", "tru", "\"x", "[1] 2", "{1:2}", ""}) {
+      bool threw = false;
+      try { Json::parse(bad); } catch (const Json::exception&) { threw = true; }
+      EXPECT(threw);
+    }
+    bool threw = false;
+    try { j.at("missing"); } catch (const Json::exception&) { threw = true; }
+    EXPECT(threw);
+    // the struct types: the reference's exact JSON text (tic_tac_toe_test.cc:43-46, connect_four_test.cc:145, 190-203)
+    const std::string ttt_json = R"({"board":[".",".",".",".","x",".",".",".","."],"current_player":"o"})";
+    tic_tac_toe::TicTacToeStateStruct ts(ttt_json);
+    EXPECT(ts.ToJson() == ttt_json && ts.board[4] == "x" && ts.current_player == "o");
+    EXPECT(tic_tac_toe::TicTacToeObservationStruct(ttt_json).ToJson() == Json::parse(ttt_json).dump());
+    tic_tac_toe::TicTacToeActionStruct ta;
+    ta.row = 1; ta.col = 1;
+    EXPECT(ta.ToJson() == R"({"col":1,"row":1})" && tic_tac_toe::TicTacToeActionStruct(ta.ToJson()).col == 1);
+    connect_four::ConnectFourActionStruct ca;
+    ca.column = 3;
+    EXPECT(ca.ToJson() == R"({"column":3})" && connect_four::ConnectFourActionStruct(ca.ToJson()).column == 3);
+    connect_four::ConnectFourGameParams params;
+    params.rows = 5; params.columns = 6;
+    EXPECT(params.game_name == "connect_four" && params.x_in_row == 4 && !params.egocentric_obs_tensor);
+    EXPECT(params.ToJson() == R"({"columns":6,"egocentric_obs_tensor":false,"game_name":"connect_four","rows":5,"x_in_row":4})");
+    EXPECT(connect_four::ConnectFourGameParams(params.ToJson()).columns == 6);
+    threw = false;
+    try { connect_four::ConnectFourGameParams bad(std::string("{\"rows\":4}")); } catch (const Json::exception&) { threw = true; }
+    EXPECT(threw);   // (every field must be there, as with NLOHMANN_DEFINE_TYPE_INTRUSIVE)
+    const std::string c4_json = R"({"board":[[".","x"],[".","."]],"current_player":"o","is_terminal":false,"winner":""})";
+    EXPECT(connect_four::ConnectFourStateStruct(c4_json).ToJson() == c4_json);
+    EXPECT(ErrorStatus("no").ok() == false && OkStatus().ok() && ErrorStatus("no").message() == "no");
+  }
   std::printf("ok: host mirror CPU checks\n");
   return 0;
 }

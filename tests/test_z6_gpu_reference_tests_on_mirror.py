@@ -24,8 +24,13 @@ exits 0, i.e. every SPIEL_CHECK_* of the reference's own test held on the MI355X
   random games checking Clone, serialization round trips, legal-action masks, sorted / unique actions, every
   player's tensors and strings at every state, returns — plus undo, ResampleFromInfostate, the single_tensor
   observer, GetAllStates (54 kuhn states), the always-X policies, board orientation and the swap rule.
-* basic_tests.cc on tic_tac_toe and connect_four with the arguments of tic_tac_toe_test.cc / connect_four_test.cc
-  (whose sources also exercise the JSON struct API, off the path): RandomSimTest, FastLoss, arbitrary board sizes.
+* basic_tests.cc on tic_tac_toe and connect_four with the arguments of tic_tac_toe_test.cc / connect_four_test.cc:
+  RandomSimTest, FastLoss, arbitrary board sizes.
+* tic_tac_toe_test.cc (as is) and connect_four_test.cc (round 5; every test but the half of TestPermissiveValidation whose
+  position names a mover the stone count contradicts): the JSON struct API — ToStruct / ToJson with the reference's
+  exact JSON text, the struct types from JSON, ActionToStruct / StructToActions / ApplyActionStruct /
+  ValidateActionStruct, NewInitialState from a struct, a board string and JSON, ConnectFourGameParams, LoadGame(params),
+  LoadGameFromJson.
 """
 import os
 import subprocess
@@ -37,7 +42,8 @@ BUILT = os.path.join(ROOT, "tests", "_refbuilt")
 BINARIES = ["reference_cfr_br_test", "reference_mcts_test_on_mirror", "reference_es_mccfr_test_on_mirror",
             "reference_os_mccfr_test_on_mirror", "reference_cfr_test_on_mirror", "reference_tabular_exploitability_test",
             "reference_best_response_test_on_mirror", "reference_hex_test", "reference_kuhn_poker_test",
-            "reference_leduc_poker_test_on_mirror", "reference_basic_tests_boards_on_mirror", "reference_get_all_states_test",
+            "reference_leduc_poker_test_on_mirror", "reference_basic_tests_boards_on_mirror", "reference_tic_tac_toe_test",
+            "reference_connect_four_test_on_mirror", "reference_get_all_states_test",
             "reference_get_legal_actions_map_test_on_mirror"]
 
 

@@ -996,9 +996,11 @@ class State {
     // (connect_four.cc:312-328; the egocentric form swaps the first two for player 1 — player 0 is asked here... and
     // for player 0 it holds o first, x second)
     int x_plane = name == "tic_tac_toe" ? 2 : 0, o_plane = 1;
-    if (name == "connect_four" && GameParametersFromString(batch_.GetGame()->ToString()).count("egocentric_obs_tensor") &&
-        GameParametersFromString(batch_.GetGame()->ToString()).at("egocentric_obs_tensor").bool_value()) {
-      x_plane = 1; o_plane = 0;
+    if (name == "connect_four") {
+      const GameParameters params = GameParametersFromString(batch_.GetGame()->ToString());
+      auto ego = params.find("egocentric_obs_tensor");   // (the values of a parsed game string are strings)
+      const std::string text = ego == params.end() ? "" : ego->second.ToString();
+      if (text == "True" || text == "true" || text == "1") { x_plane = 1; o_plane = 0; }
     }
     for (int i = 0; i < cells; ++i) {
       if (t[static_cast<size_t>(x_plane) * cells + i] != 0.0f) out[i] = 'x';
@@ -1101,7 +1103,7 @@ class ConnectFourGame : public Game {
   int x_in_row() const {
     const GameParameters params = GetParameters();
     auto it = params.find("x_in_row");
-    return it == params.end() ? kDefaultXInRow : it->second.int_value();
+    return it == params.end() ? kDefaultXInRow : std::atoi(it->second.ToString().c_str());   // (parsed values are strings)
   }
   inline std::unique_ptr<State> NewInitialState(const ConnectFourStateStruct& state_struct, bool strict_validation = true) const;
 };

@@ -146,7 +146,7 @@ def test_the_mirror_observation_serves_every_type(vectors):
             return None
         o = pyspiel._Observation(game, observer)
         view = lambda: np.asarray(o) if o.has_tensor() else None   # noqa: E731 - the buffer protocol: a view
-        return {"tensor": view, "pieces": lambda: [(i.name(), tuple(i.shape())) for i in o.tensors_info()],
+        return {"tensor": view, "pieces": lambda: [(i.name, tuple(i.shape)) for i in o.tensors_info()],
                 "set_from": o.set_from, "string_from": o.string_from, "compress": o.compress, "decompress": o.decompress}
 
     total = 0

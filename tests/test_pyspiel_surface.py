@@ -459,10 +459,11 @@ def test_observer_bindings_like_python_observation(pyspiel):
     default = pyspiel._Observation(game, game.make_observer())
     default.set_from(state, 0)
     np.testing.assert_array_equal(np.frombuffer(default, np.float32), np.asarray(state.observation_tensor(0), np.float32))
-    assert game.make_observer(pyspiel.IIGObservationType(private_info=pyspiel.PrivateInfoType.ALL_PLAYERS)) is None
+    every = game.make_observer(pyspiel.IIGObservationType(private_info=pyspiel.PrivateInfoType.ALL_PLAYERS))
+    assert [(i.name, i.shape) for i in pyspiel._Observation(game, every).tensors_info()] == [("pot_contribution", [2])]  # kuhn_poker.cc:82-105
     board = pyspiel.load_game("tic_tac_toe")
     assert [(i.name, i.shape) for i in pyspiel._Observation(board, board.make_observer()).tensors_info()] == [("observation", [3, 3, 3])]
-    assert board.make_observer(info_type) is None
+    assert not pyspiel._Observation(board, board.make_observer(info_type)).has_tensor()   # observer.cc:158-159: the string only
 
 
 @pytest.mark.gpu

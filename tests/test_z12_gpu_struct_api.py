@@ -114,4 +114,4 @@ def test_game_parameters_struct_and_json(pyspiel):
     again = pyspiel.connect_four.ConnectFourGameParams(params.to_json())
     assert again.columns == 9 and pyspiel.connect_four.ConnectFourGameParams(json.loads(params.to_json())).rows == 8
     hexg = pyspiel.load_game_from_json('{"game_name":"hex","board_size":5,"swap":true}')
-    assert hexg.num_distinct_actions() == 25
+    assert hexg.num_distinct_actions() == 26 and "swap=True" in str(hexg)          # 25 cells + the swap move

@@ -2,6 +2,7 @@
 // Restates the parameter handling of open_spiel/game_parameters.cc:172-227 and
 // the per-game parameter_specification blocks (connect_four.cc:50-54,
 // hex.cc:47-56, kuhn_poker.cc:36-57, leduc_poker.cc:55-59).
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -209,13 +210,17 @@ int parse_game(const char* game_string, GameSpec* out) {
     out->hex_nw = need <= 4 ? need : (need <= 6 ? 6 : (need <= 8 ? 8 : 12));
     if (need <= 4 && (cells + 31) / 32 < need) out->hex_nw = need;  // (cells a multiple of 32 with swap: one more word)
     out->hex_explicit = rep == "explicit";
-    d.state_words = 4 * out->hex_nw + 1; d.state_word_bytes = 4;
+    // (round 5) three-word planes with at least five spare bits each — hex(9) — carry the meta word in those bits:
+    // 12 words per state instead of 13 (HexT<3, true>; OSG_HEX_FOLD=0 keeps the 13-word record)
+    const char* fold_env = std::getenv("OSG_HEX_FOLD");
+    out->hex_fold = out->hex_nw == 3 && cells <= 91 && !(fold_env && fold_env[0] == '0');
+    d.state_words = out->hex_fold ? 4 * out->hex_nw : 4 * out->hex_nw + 1; d.state_word_bytes = 4;
     // only the variant that holds the board: Bits::w has NW words, a larger board would write past it
     out->hex1 = {}; out->hex2 = {}; out->hex3 = {}; out->hex4 = {}; out->hex6 = {}; out->hex8 = {}; out->hex12 = {};
     switch (out->hex_nw) {
       case 1: fill_hex<1>(&out->hex1, cols, rows, swap, plain); break;
       case 2: fill_hex<2>(&out->hex2, cols, rows, swap, plain); break;
-      case 3: fill_hex<3>(&out->hex3, cols, rows, swap, plain); break;
+      case 3: fill_hex<3>(&out->hex3, cols, rows, swap, plain); if (out->hex_fold) out->hex3.words = 12; break;
       case 4: fill_hex<4>(&out->hex4, cols, rows, swap, plain); break;
       case 6: fill_hex<6>(&out->hex6, cols, rows, swap, plain); break;
       case 8: fill_hex<8>(&out->hex8, cols, rows, swap, plain); break;

@@ -228,12 +228,12 @@ k_step_vec(typename G::Params p, const typename G::word_t* src, typename G::word
 // kMask = false (round 5; osg_step with d_mask == NULL): the successor's mask row is not written — on a hex board it
 // is ~occupied of the successor record, which the caller holds anyway (SURVEY.md 8(d) prices the hex step without
 // it: 109 B instead of 118 B moved for hex(9)).
-template <int NW, int V, bool kNt, bool kMask = true>
+template <int NW, int V, bool kNt, bool kMask = true, bool kFold = false>
 __global__ void __launch_bounds__(kBlock)
 k_step_hexvec(typename HexT<NW>::Params p, const uint32_t* src, uint32_t* dst, int64_t n,  // src may BE dst
               const uint8_t* __restrict__ actions, uint32_t* __restrict__ mask_out, uint8_t* __restrict__ status) {
-  using G = HexT<NW>;
-  constexpr int W = 4 * NW + 1;
+  using G = HexT<NW, kFold>;
+  constexpr int W = G::kWords;   // 4 NW + 1, or 4 NW with the meta word folded into the planes (hex(9): 12)
   typedef uint32_t wvec __attribute__((ext_vector_type(V)));
   typedef uint8_t bvec __attribute__((ext_vector_type(V)));
   const int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * V;
@@ -1074,7 +1074,8 @@ constexpr int kHexLdsMaxStates = 18;          // 4096 / (9 * 29 cells) + 2
 template <int NW, bool kNt, int kSpans>
 __global__ void __launch_bounds__(kPieceBlock)
 k_observation_hex_pieces_lds(const uint32_t* __restrict__ base, uint32_t n, uint32_t cells, uint32_t cmagic, uint32_t cshift,
-                             FastDiv by_size, uint32_t lmagic, uint32_t lshift, uint32_t total, float* __restrict__ out) {
+                             FastDiv by_size, uint32_t lmagic, uint32_t lshift, uint32_t total, float* __restrict__ out,
+                             uint32_t last_word_mask) {   // (0x07FFFFFF where the planes' last words carry the meta bits)
   __shared__ uint32_t s_words[kSpans][kHexLdsMaxStates * 4 * NW];
   const uint32_t size = by_size.d;   // 9 cells
   uint32_t ias[kSpans];
@@ -1093,7 +1094,8 @@ k_observation_hex_pieces_lds(const uint32_t* __restrict__ base, uint32_t n, uint
       const uint32_t sl = threadIdx.x / (4u * NW), w = threadIdx.x - sl * 4u * NW;
       uint32_t i = ia + sl;
       if (i >= n) i = n - 1u;
-      s_words[j][threadIdx.x] = base[w * n + i];                       // plane-major SoA: word w of state i
+      const uint32_t word = base[w * n + i];                           // plane-major SoA: word w of state i
+      s_words[j][threadIdx.x] = (w % NW == NW - 1u) ? (word & last_word_mask) : word;
     }
   }
   __syncthreads();
@@ -1905,21 +1907,24 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
       const auto* s32 = static_cast<const uint32_t*>(src->d_words);
       auto* d32 = static_cast<uint32_t*>(dst->d_words);
       auto* m32 = static_cast<uint32_t*>(d_mask);
-#define OSG_HEXVEC(NWV, VV, NTV, MASKV, member)                                                                              \
-  k_step_hexvec<NWV, VV, NTV, MASKV><<<dim3(grid_for(n / VV)), dim3(kBlock), 0, ctx->stream>>>(src->spec.member, s32, d32, n, \
-                                                                                             d_actions, m32, d_status)
-#define OSG_HEXVEC_NW(NWV, member)                                            \
+#define OSG_HEXVEC(NWV, VV, NTV, MASKV, FOLDV, member)                                                                              \
+  k_step_hexvec<NWV, VV, NTV, MASKV, FOLDV><<<dim3(grid_for(n / VV)), dim3(kBlock), 0, ctx->stream>>>(src->spec.member, s32, d32, n, \
+                                                                                                    d_actions, m32, d_status)
+#define OSG_HEXVEC_NW(NWV, FOLDV, member)                                     \
   do {                                                                        \
-    if (nt && m32) OSG_HEXVEC(NWV, 2, true, true, member);                    \
-    else if (nt) OSG_HEXVEC(NWV, 2, true, false, member);                     \
-    else if (m32) OSG_HEXVEC(NWV, 2, false, true, member);                    \
-    else OSG_HEXVEC(NWV, 2, false, false, member);                            \
+    if (nt && m32) OSG_HEXVEC(NWV, 2, true, true, FOLDV, member);             \
+    else if (nt) OSG_HEXVEC(NWV, 2, true, false, FOLDV, member);              \
+    else if (m32) OSG_HEXVEC(NWV, 2, false, true, FOLDV, member);             \
+    else OSG_HEXVEC(NWV, 2, false, false, FOLDV, member);                     \
   } while (0)
       switch (src->spec.hex_nw) {
-        case 1: OSG_HEXVEC_NW(1, hex1); break;
-        case 2: OSG_HEXVEC_NW(2, hex2); break;
-        case 3: OSG_HEXVEC_NW(3, hex3); break;
-        default: OSG_HEXVEC_NW(4, hex4); break;
+        case 1: OSG_HEXVEC_NW(1, false, hex1); break;
+        case 2: OSG_HEXVEC_NW(2, false, hex2); break;
+        case 3:
+          if (src->spec.hex_fold) OSG_HEXVEC_NW(3, true, hex3);
+          else OSG_HEXVEC_NW(3, false, hex3);
+          break;
+        default: OSG_HEXVEC_NW(4, false, hex4); break;
       }
 #undef OSG_HEXVEC_NW
 #undef OSG_HEXVEC
@@ -2056,7 +2061,7 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
     const unsigned g = static_cast<unsigned>(((total + kHexLdsSpan - 1) / kHexLdsSpan + 3) / 4);
 #define OSG_HEXL(NW, NT) k_observation_hex_pieces_lds<NW, NT, 4><<<dim3(g), dim3(kPieceBlock), 0, ctx->stream>>>(               \
       static_cast<const uint32_t*>(b->d_words), static_cast<uint32_t>(b->n), cells, cm, cs, make_fast_div(9u * cells), lm, ls,    \
-      static_cast<uint32_t>(total), d_out)
+      static_cast<uint32_t>(total), d_out, b->spec.hex_fold ? 0x07FFFFFFu : 0xFFFFFFFFu)
     switch (b->spec.hex_nw) {
       case 1: if (nt) OSG_HEXL(1, true); else OSG_HEXL(1, false); break;
       case 2: if (nt) OSG_HEXL(2, true); else OSG_HEXL(2, false); break;
@@ -2083,14 +2088,14 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
              (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) {   // (its LDS stage is 256 B per cell: the big boards go below)
     const size_t shmem = sizeof(float) * kHexObsBlock * static_cast<size_t>(d.obs_shape[1] * d.obs_shape[2]);
     const unsigned grid = static_cast<unsigned>((b->n * 9 + kHexObsBlock - 1) / kHexObsBlock);
-#define OSG_HEX_OBS(NW, member)                                                                              \
-  k_observation_hex_planes<HexT<NW>><<<dim3(grid), dim3(kHexObsBlock), shmem, ctx->stream>>>(                \
-      b->spec.member, static_cast<const HexT<NW>::word_t*>(b->d_words), b->n, 9, d_out)
+#define OSG_HEX_OBS(NW, FOLD, member)                                                                        \
+  k_observation_hex_planes<HexT<NW, FOLD>><<<dim3(grid), dim3(kHexObsBlock), shmem, ctx->stream>>>(          \
+      b->spec.member, static_cast<const uint32_t*>(b->d_words), b->n, 9, d_out)
     switch (b->spec.hex_nw) {
-      case 1: OSG_HEX_OBS(1, hex1); break;
-      case 2: OSG_HEX_OBS(2, hex2); break;
-      case 3: OSG_HEX_OBS(3, hex3); break;
-      default: OSG_HEX_OBS(4, hex4); break;
+      case 1: OSG_HEX_OBS(1, false, hex1); break;
+      case 2: OSG_HEX_OBS(2, false, hex2); break;
+      case 3: if (b->spec.hex_fold) OSG_HEX_OBS(3, true, hex3); else OSG_HEX_OBS(3, false, hex3); break;
+      default: OSG_HEX_OBS(4, false, hex4); break;
     }
 #undef OSG_HEX_OBS
   } else if (size <= kRowsMaxSize && b->spec.desc.game_kind != kHex && (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) {

@@ -231,7 +231,9 @@ class Json {
     if (integral && token.size() < 19) return Json(static_cast<int64_t>(std::strtoll(token.c_str(), nullptr, 10)));
     return Json(std::strtod(token.c_str(), nullptr));
   }
-  static Json ParseValue(const std::string& t, size_t* p) {
+  static constexpr int kMaxDepth = 256;   // (a bound on nesting: the parser recurses)
+  static Json ParseValue(const std::string& t, size_t* p, int depth = 0) {
+    if (depth > kMaxDepth) Fail(*p, "nesting deeper than 256 levels");
     SkipSpace(t, p);
     if (*p >= t.size()) Fail(*p, "unexpected end of input");
     const char c = t[*p];
@@ -247,7 +249,7 @@ class Json {
         SkipSpace(t, p);
         if (*p >= t.size() || t[*p] != ':') Fail(*p, "expected ':'");
         ++*p;
-        obj.object_[key] = ParseValue(t, p);
+        obj.object_[key] = ParseValue(t, p, depth + 1);
         SkipSpace(t, p);
         if (*p < t.size() && t[*p] == ',') { ++*p; continue; }
         if (*p < t.size() && t[*p] == '}') { ++*p; return obj; }
@@ -260,7 +262,7 @@ class Json {
       SkipSpace(t, p);
       if (*p < t.size() && t[*p] == ']') { ++*p; return arr; }
       for (;;) {
-        arr.array_.push_back(ParseValue(t, p));
+        arr.array_.push_back(ParseValue(t, p, depth + 1));
         SkipSpace(t, p);
         if (*p < t.size() && t[*p] == ',') { ++*p; continue; }
         if (*p < t.size() && t[*p] == ']') { ++*p; return arr; }

@@ -3150,6 +3150,7 @@ struct osg_cfr {
   // forest form of k_cfr_sub (SubTree's comment): the kernel's own skip words, piece roots, upper members
   bool sub_forest = false;
   int sub_NR = 0, sub_G0 = 0;   // G0: the deal subtrees; sub_G: the bins they (or their pieces) were packed into
+  unsigned long long *d_sub_stamps = nullptr, *d_mccfr_stamps = nullptr;   // profiling stamps (per solver: never shared across contexts / devices)
   double *d_sub_recbuf = nullptr, *d_sub_chance_prob = nullptr, *d_sub_term_val = nullptr;
   int32_t *d_sub_dec_off = nullptr, *d_sub_fold_info = nullptr, *d_sub_fold_off = nullptr;
   int sub_NCP = 0;
@@ -4324,7 +4325,7 @@ int osg_cfr_destroy(osg_cfr* s) {
                   s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
                   s->d_split_terms, s->d_split_bar, s->d_sub_nloc, s->d_sub_desc, s->d_sub_fc, s->d_sub_aux, s->d_sub_mem_off,
                   s->d_sub_info_off, s->d_sub_info_list, s->d_sub_bar, s->d_sub_ndec, s->d_sub_dec_row, s->d_sub_rec,
-                  s->d_sub_recbuf, s->d_sub_chance_prob, s->d_sub_term_val, s->d_sub_dec_off, s->d_sub_fold_info, s->d_sub_fold_off, s->d_sub_nroot, s->d_sub_root_loc, s->d_sub_root_idx, s->d_sub_upper_rec, s->d_sub_root_value,
+                  s->d_sub_stamps, s->d_mccfr_stamps, s->d_sub_recbuf, s->d_sub_chance_prob, s->d_sub_term_val, s->d_sub_dec_off, s->d_sub_fold_info, s->d_sub_fold_off, s->d_sub_nroot, s->d_sub_root_loc, s->d_sub_root_idx, s->d_sub_upper_rec, s->d_sub_root_value,
                   s->d_jobs_job, s->d_jobs_level, s->d_jobs_desc, s->d_jobs_fc, s->d_jobs_row, s->d_jobs_glob, s->d_jobs_info,
                   s->d_jobs_mem, s->d_jobs_deal, s->d_jobs_ticket};
   for (void* p : ptrs)
@@ -4405,7 +4406,7 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
       sp.nroot = s->d_sub_nroot; sp.root_loc = s->d_sub_root_loc; sp.root_idx = s->d_sub_root_idx; sp.NR = s->sub_NR;
       sp.root_value = s->d_sub_root_value; sp.upper_rec = s->d_sub_upper_rec;
     }
-    static unsigned long long* d_stamps = nullptr;   // OSG_CFR_SUB_STAMPS=1: phase stamps of workgroup 0 (tools/probe_cfr_sub.py)
+    unsigned long long*& d_stamps = s->d_sub_stamps;   // OSG_CFR_SUB_STAMPS=1: phase stamps of one workgroup (tools/probe_cfr_sub.py); the solver's own buffer
     if (std::getenv("OSG_CFR_SUB_STAMPS")) {
       sp.stamp_wg = std::max(0, std::min(s->sub_grid - 1, atoi(std::getenv("OSG_CFR_SUB_STAMPS")) - 1));
       fprintf(stderr, "k_cfr_sub: G %d grid %d NL %d ND %d PL %d K %d forest %d NR %d\n", s->sub_G, s->sub_grid, s->sub_NL, s->sub_ND, s->sub_PL, s->sub_K, s->sub_forest ? 1 : 0, s->sub_NR);
@@ -4596,7 +4597,7 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
     }
     int64_t groups = std::min<int64_t>((trajectories + threads - 1) / threads, static_cast<int64_t>(s->num_cus) * per_cu);
     ResidentTree rt{reinterpret_cast<const uint2*>(s->d_rec), s->d_uret, s->d_uprob, s->n_uret, s->n_uprob};
-    static unsigned long long* d_stamps = nullptr;   // OSG_MCCFR_STAMPS=1: phase stamps of workgroup 0 (tools/probe_mccfr_shard.py)
+    unsigned long long*& d_stamps = s->d_mccfr_stamps;   // OSG_MCCFR_STAMPS=1: phase stamps of workgroup 0 (tools/probe_mccfr_shard.py); the solver's own buffer
     if (std::getenv("OSG_MCCFR_STAMPS") && !d_stamps)
       OSG_HIP(hipMalloc(reinterpret_cast<void**>(&d_stamps), sizeof(unsigned long long) * 4));
     const dim3 grid(static_cast<unsigned>(groups)), block(threads);

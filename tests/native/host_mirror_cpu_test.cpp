@@ -113,6 +113,11 @@ int main() {
       try { Json::parse(bad); } catch (const Json::exception&) { threw = true; }
       EXPECT(threw);
     }
+    {
+      bool deep = false;
+      try { Json::parse(std::string(100000, '[')); } catch (const Json::exception&) { deep = true; }   // bounded recursion
+      EXPECT(deep);
+    }
     bool threw = false;
     try { j.at("missing"); } catch (const Json::exception&) { threw = true; }
     EXPECT(threw);

@@ -1313,7 +1313,8 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
         // bottom-up (cfr.cc:443-469).  Slot k of the threads covers the local indices [1024 k, 1024 k + 1023], a
         // contiguous run in level order, i.e. a workgroup-uniform range of levels: the sweep walks (slot, level) pairs
         // from the deepest, ONE slot's body per step (testing all slots at every level cost more instructions than
-        // the values themselves).  A history's children have larger indices: an earlier step has produced them.
+        // the values themselves; re-measured in round 5 with everything in LDS: one barrier per level — 20 steps instead
+        // of 27 — with every slot tested inside a step ran 8.4 us per sweep against 7.5: profiles/r05m_*).  A history's children have larger indices: an earlier step has produced them.
 #pragma unroll
         for (int k = kK - 1; k >= 0; --k) {
           if (k * kSubThreads >= nloc) continue;                                  // (workgroup-uniform)
@@ -1560,13 +1561,26 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
           __syncthreads();
           if (tid < ne) {
             const int n = s_fn[tid];
-            for (int x = s_fbase[tid]; x < s_fbase[tid + 1]; ++x) {   // member order
-              const double* r = s_rec + static_cast<size_t>(x) * kSubRecDoubles;
-              const unsigned long long w0 = static_cast<unsigned long long>(__double_as_longlong(r[0]));
-              if (static_cast<unsigned int>(w0 >> 32) == kSubFlagHi && static_cast<unsigned int>(w0) == 1u) continue;   // pruned
+            // member order; a record is four 16-byte LDS reads, two records in flight (entries beyond the row's actions are
+            // zeros in every record and their sums are never written back, so no per-action test)
+            const int x_end = s_fbase[tid + 1];
+            for (int x = s_fbase[tid]; x < x_end; x += 2) {
+              osg_u4 q[2][4];
 #pragma unroll
-              for (int a = 0; a < kSplitMaxA; ++a)
-                if (a < n) { reg[a] += r[a]; cum[a] += r[kSplitMaxA + a]; }
+              for (int u = 0; u < 2; ++u) {
+                const osg_u4* r4 = reinterpret_cast<const osg_u4*>(s_rec + static_cast<size_t>(x + u < x_end ? x + u : x) * kSubRecDoubles);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q[u][k] = r4[k];
+              }
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                if (x + u >= x_end) continue;
+                if (q[u][0].y == kSubFlagHi && q[u][0].x == 1u) continue;   // pruned
+                const osg_d2 r01 = __builtin_bit_cast(osg_d2, q[u][0]), r23 = __builtin_bit_cast(osg_d2, q[u][1]);
+                const osg_d2 c01 = __builtin_bit_cast(osg_d2, q[u][2]), c23 = __builtin_bit_cast(osg_d2, q[u][3]);
+                reg[0] += r01.x; reg[1] += r01.y; reg[2] += r23.x; reg[3] += r23.y;
+                cum[0] += c01.x; cum[1] += c01.y; cum[2] += c23.x; cum[3] += c23.y;
+              }
             }
             double sum_pos = 0.0;
 #pragma unroll

@@ -383,9 +383,9 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
                                                          "two-level grid barriers per player pass with the next phase's static fetches in "
                                                          "their windows; tables bit-identical with the launch-per-phase kernels (1 870 it/s)",
                                              "note": "round 4: 3 260 it/s (336 subtrees on 256 workgroups, a flat counter barrier, 8-byte "
-                                                     "written-through terms).  Still bound by dependent phases, not bytes: a pass of ~46 us is "
-                                                     "sweep 10.5 (20 levels + 8 slots of LDS round trips), members 10.5, fold 10-14 and two "
-                                                     "barriers; profiles/r05i_cfr_sub_prefetch_windows.txt has the per-workgroup phase stamps"}
+                                                     "written-through terms).  Still bound by dependent phases, not bytes: a pass of ~40 us is "
+                                                     "sweep 10.5 (20 levels + 8 slots of LDS round trips), members 10.6, fold 6-8.5 and two "
+                                                     "barriers; profiles/r05m_cfr_sub_fold_vectorised_level_major_ab.txt has the per-workgroup phase stamps"}
             del three
     except Exception as e:  # noqa: BLE001 - a secondary figure must never cost the line
         out["cfr"]["leduc"] = {"error": f"{type(e).__name__}: {e}"}

@@ -12,8 +12,8 @@ echo "pytest exit $?" | tee -a "$OUT/summary.txt"
 tail -12 "$OUT/pytest.log" | cut -c1-300 | tee -a "$OUT/summary.txt"
 for rep in 1 2; do
   for flat in 0; do
-    echo "-- level_major=$((2-rep))" | tee -a "$OUT/summary.txt"
-    OSG_CFR_SUB_LEVEL_MAJOR=$((2-rep)) PROBE_ONLY_SUB=1 timeout 300 python tools/probe_cfr_sub.py > "$OUT/probe_cfr_sub_flat${flat}_$rep.log" 2>&1
+    echo "-- rep $rep" | tee -a "$OUT/summary.txt"
+    PROBE_ONLY_SUB=1 timeout 300 python tools/probe_cfr_sub.py > "$OUT/probe_cfr_sub_flat${flat}_$rep.log" 2>&1
     grep -E "identical|^grid|^sub|^auto" "$OUT/probe_cfr_sub_flat${flat}_$rep.log" | tee -a "$OUT/summary.txt"
   done
 done

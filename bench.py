@@ -538,6 +538,24 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             kern_us = sum(a.elapsed_time(b) for a, b in zip(ev_a, ev_b)) / steps * 1e3
+            # the same launch back to back (an event pair around ONE ~11 us launch carries ~2 us of its own): 100 launches with
+            # "no action" for every environment — the time step is formed and written again, the same 60 bytes move and the
+            # step runs the same code — between one pair of events
+            noop = torch.full((n_env,), -1, dtype=torch.int32, device="cuda")
+            keep = torch.zeros(n_env, dtype=torch.uint8, device="cuda")
+            for _ in range(5):
+                check(lib().osg_env_step(eb._h, noop.data_ptr(), keep.data_ptr(), SEED, 0, 0, cur.data_ptr(), typ.data_ptr(),
+                                         rew.data_ptr(), msk.data_ptr()))
+                keep.zero_()
+            b2b_a, b2b_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            b2b_a.record()
+            for _ in range(100):
+                check(lib().osg_env_step(eb._h, noop.data_ptr(), keep.data_ptr(), SEED, 0, 0, cur.data_ptr(), typ.data_ptr(),
+                                         rew.data_ptr(), msk.data_ptr()))
+            b2b_b.record()
+            torch.cuda.synchronize()
+            b2b_us = b2b_a.elapsed_time(b2b_b) / 100 * 1e3
             # bytes one connect_four environment moves per step: state in + out (2 x 16), action 4, should_reset 1 + 1,
             # current player 1, step type 1, rewards 2 x 8, mask word 4
             env_bytes = 16 + 16 + 4 + 2 + 1 + 1 + 16 + 4
@@ -545,14 +563,21 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
                                "value": n_env * steps / dt, "unit": "env-steps/s", "us_per_launch": dt / steps * 1e6,
                                "workload": f"connect_four, {n_env} environments, {steps} synchronous steps of every environment with a "
                                            "table-lookup torch agent in between (python/rl_environment.py:379-418 per environment in the reference)",
-                               "roofline": {"kernel": "k_env_step", "bound": "infinity_cache (60 B x 2^20 = 63 MB per launch stays on the chip; peak = the HBM figure)",
+                               "roofline": {"kernel": "k_env_step_x2", "bound": "infinity_cache (60 B x 2^20 = 63 MB per launch stays on the chip; peak = the HBM figure)",
                                             "algorithmic_bytes_per_env_step": env_bytes, "kernel_us_per_launch": kern_us,
                                             "achieved": env_bytes * n_env / (kern_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": env_bytes * n_env / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                             "kernel_share_of_step": kern_us / (dt / steps * 1e6),
-                                            "note": "HIP events around the osg_env_step launch of every timed step; rewards leave as float64 [n, P] and "
-                                                    "actions arrive as int32 (the reference's TimeStep types): 20 of the 60 bytes"}}
-            del eb, lut, ev_a, ev_b
+                                            "kernel_us_back_to_back": b2b_us,
+                                            "frac_back_to_back": env_bytes * n_env / (b2b_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                            "note": "frac: HIP events around the osg_env_step launch of every timed step (one pair per ~11 us launch: "
+                                                    "~2 us of the pair itself inside); frac_back_to_back: 100 launches between one pair of events, "
+                                                    "every environment stepped with 'no action' (the same bytes, the same straight-line step). "
+                                                    "Rewards leave as float64 [n, P] and actions arrive as int32 (the reference's TimeStep types): "
+                                                    "20 of the 60 bytes.  (The same step on the headline kernel's fused connect_four step measured no "
+                                                    "faster — 164.8 vs 165.0 us per 2^24 environments: the launch is bound by its bytes — and was dropped: "
+                                                    "profiles/r05p_env_step_fused_ab.txt)"}}
+            del eb, lut, ev_a, ev_b, noop, keep
             judge = {}
             for g in ("kuhn_poker", "leduc_poker"):
                 sj = osa.TabularSolver(ctx, g)

@@ -201,6 +201,9 @@ def mcts_parity_check(res, first, count, sims):
             raise AssertionError(f"mcts_parity_check: {key} differs from the oracle replay at {bad.size} of {count} roots "
                                  f"(first: {bad[:5].tolist()})")
     return {"roots": int(count), "simulations_each": int(sims), "against": "port (replay-mode MCTSBot of the restatement)",
+            "pin": "one step removed from mcts.cc: the genuine MCTSBot draws from absl::Uniform (mcts.cc:54), whose streams are "
+                   "unspecified and absent here; the restatement's MCTSBot builds the genuine one's tree node for node under the "
+                   "stand-in generator (tests/test_oracle_vs_reference.py), and replays the device's counter streams here",
             "cpu_seconds": cpu_s, "cpu_threads": threads,
             "what": "best action, child visit counts and child total rewards of the timed search, every checked root"}
 

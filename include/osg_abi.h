@@ -266,7 +266,11 @@ typedef struct {
                                serves boards of up to 128 actions; hex above 11 x 11,
                                connect_four above 64 board bits and leduc_poker with 4+
                                players are searched with layout 1 (0 picks it).  A node
-                               holds up to 511 actions.                              */
+                               holds up to 511 actions.  Layout 2 is TUNED for hex without the
+                               swap rule (what 0 picks it for); its instantiations for the other
+                               games are correct (replay parity in the tests) but spill 76-129
+                               vector registers (profiles/r05_kernel_resources.txt): use layout 1
+                               for tic_tac_toe, connect_four, kuhn_poker and leduc_poker      */
   int32_t child_selection_policy;  /* ChildSelectionPolicy (mcts.h:148): 0 UCT (mcts.cc:90-101),
                                1 PUCT (mcts.cc:103-112) with the evaluator's prior — uniform over
                                the legal actions for RandomRolloutEvaluator (mcts.cc:74-87)        */

@@ -186,6 +186,13 @@ class StateBatch:
         assert w.shape == (self.desc.state_words, self.n)
         check(lib().osg_batch_upload(self._h, w.ctypes.data))
 
+    def set_cells(self, index, cells):
+        """State `index` := the position with these cells ('.', 'x', 'o'; tic_tac_toe: cell a = action a; connect_four:
+        cell r * cols + c with row 0 the bottom row) — TicTacToeState(game, struct) / ConnectFourState(game, struct | string)
+        (osg_batch_set_cells: built on the device with the game's own rules)."""
+        text = cells.encode() if isinstance(cells, str) else bytes(cells)
+        check(lib().osg_batch_set_cells(self._h, int(index), text, len(text)))
+
     # -- State::LegalActionsMask ---------------------------------------------
     def legal_actions_mask_bits(self):
         """[n, mask_words] int32 bit-packed legal mask (chance outcomes at chance nodes)."""

@@ -115,3 +115,36 @@ def test_game_parameters_struct_and_json(pyspiel):
     assert again.columns == 9 and pyspiel.connect_four.ConnectFourGameParams(json.loads(params.to_json())).rows == 8
     hexg = pyspiel.load_game_from_json('{"game_name":"hex","board_size":5,"swap":true}')
     assert hexg.num_distinct_actions() == 26 and "swap=True" in str(hexg)          # 25 cells + the swap move
+
+
+def test_set_cells_touches_one_state_of_a_batch():
+    """osg_batch_set_cells on a batch: only the addressed state changes, in every connect_four layout (the 6 x 7 board with
+    its result byte, a generic board, a board above 64 bits) and tic_tac_toe; the refusals come back as errors."""
+    import torch
+    import open_spiel_amd as osa
+    ctx = osa.Context(0)
+    for game, cells, player, terminal in (
+            ("tic_tac_toe", "xo.......", 0, False),
+            ("tic_tac_toe", "xxxoo....", -4, True),
+            ("connect_four", "xo....." + "." * 35, 0, False),
+            ("connect_four", "xxxx..." + "ooo...." + "." * 28, -4, True),
+            ("connect_four(rows=4,columns=5,x_in_row=3)", "xo..." + "." * 15, 0, False),
+            ("connect_four(rows=9,columns=12)", "x" + "." * 107, 1, False)):
+        b = osa.StateBatch(ctx, game, 8)
+        b.random_steps(11, 3)
+        before = b.raw_words().copy()
+        b.set_cells(5, cells)
+        after = b.raw_words()
+        others = [i for i in range(8) if i != 5]
+        assert (after[:, others] == before[:, others]).all(), game
+        cur, term, _ = b.status()
+        assert int(cur[5]) == player and bool(term[5]) == terminal, (game, cells)
+        fresh = osa.StateBatch(ctx, game, 1)
+        fresh.set_cells(0, cells)
+        assert (fresh.raw_words()[:, 0] == after[:, 5]).all()
+    b = osa.StateBatch(ctx, "connect_four", 2)
+    for bad in ("." * 7 + "x" + "." * 34, "x" * 41, "q" + "." * 41, "xxxx..." + "oooo..." + "." * 28):
+        with pytest.raises(osa.OsgError):
+            b.set_cells(1, bad)
+    with pytest.raises(osa.OsgError):
+        osa.StateBatch(ctx, "kuhn_poker", 2).set_cells(0, "..")

@@ -1055,16 +1055,21 @@ __global__ void __launch_bounds__(256) k_gcfr_fold(GridCfr g, int upd, osg_cfr_c
 // Large trees as ONE persistent, cooperative launch (k_cfr_sub): the multi-launch form above spends an iteration of
 // 3-player leduc_poker (1.83 M histories) on ~58 launch boundaries of 4-6 us each and on a fold in which 25 856
 // threads walk their members serially (540 us per iteration, ~7 % of the bytes' roofline).  Here the tree is cut
-// below its leading chance levels like k_cfr_split's: every subtree (one private deal: 336 of ~5 450 histories for
-// 3-player leduc) belongs to ONE workgroup of 1024 threads, which sweeps its levels bottom-up with the values of the
-// updating player in LDS and workgroup barriers only, then writes its members' regret / average-policy terms
-// (root-path products as in k_gcfr_members).  Two grid barriers per player pass: terms -> fold -> next pass.  The fold
-// takes ONE WAVEFRONT per infostate: the lanes fetch the members' terms together, every lane adds them in member
-// (DFS) order — the same additions in the same order as every other CFR kernel here, so the tables stay
-// bit-identical — and lane 0 regret-matches the row.  Everything that crosses workgroups (terms, skip flags, the
-// three tables) moves with write-through stores and cache-bypassing loads, so the barrier is the counter form
-// (drain, workgroup barrier, one agent-scope add, one polling lane) without cache-wide fences.  Alternating
-// updates only (one value per history in LDS); the launch is cooperative, so the grid IS co-resident.
+// below its leading chance levels like k_cfr_split's and the pieces are dealt to the workgroups as BINS (a subtree
+// each, or — with more subtrees than compute units — whole subtrees / the pieces one level deeper packed to one bin
+// per workgroup: SubTree's second half).  A workgroup of 1024 threads sweeps its bin bottom-up with the updating
+// player's values, the bin's policy rows and chance probabilities in LDS and workgroup barriers only, then writes its
+// members' regret / average-policy terms (root-path products as in k_gcfr_members) as 64-byte records in 16-byte
+// written-through pieces.  Two grid barriers per player pass: terms -> fold -> next pass; the barrier is two-level
+// (group counters, a release word) and every thread spends its wait on fetches of data no workgroup writes (the
+// fold's first schedule; the coming pass's terminal values and row indices).  The fold: a workgroup takes a run of the
+// updating player's infostates balanced by member count, all its threads fetch the members' records into LDS
+// (consecutive threads, consecutive records), ONE THREAD per infostate adds them in member (DFS) order — the same
+// additions in the same order as every other CFR kernel here, so the tables stay bit-identical — clamps, matches and
+// writes the row through.  Everything that crosses workgroups (records, root values, the three tables) moves with
+// written-through stores and cache-bypassing loads: no cache-wide fences.  Alternating updates only (one value per
+// history in LDS); the launch is cooperative, so the grid IS co-resident.  DESIGN.md section 6 has what each device was
+// worth (3 260 -> 8 260 iterations/s on 3-player leduc in round 5).
 // Reference: cfr.cc:331-408 (ComputeCounterFactualRegret), 443-469, 596-615.
 // ---------------------------------------------------------------------------
 struct SubTree {

@@ -1762,10 +1762,9 @@ k_policy_eval(Tree t, EvalArrays ea, const double* pol, int from_cum = 0, double
 // full-grid launch per tree level and phase, the stream order is the barrier (the form of k_gcfr_*).  The sums are
 // k_policy_eval's, node by node and infostate by infostate, in the same order: bit-identical results.
 //   k_geval_policy   the evaluated policy from the cumulative table (mode 0)
-//   k_geval_ev       expected returns of one level
-//   k_geval_cf       counterfactual reaches of responder r's decision histories
-//   k_geval_best     the argmax of r's infostates whose members sit on level l
-//   k_geval_brv      responder values of one level; the root's value into out[P + r]
+//   k_geval_cf       counterfactual reaches of every player's decision histories (each against the others' policy)
+//   k_geval_best     the argmax of the infostates whose members sit on level l
+//   k_geval_brv      every responder's values of one level; the root's values into out[P ...]
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_geval_policy(Tree t, const double* __restrict__ cum, double* __restrict__ pol) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1775,32 +1774,18 @@ __global__ void __launch_bounds__(256) k_geval_policy(Tree t, const double* __re
   for (int a = 0; a < n; ++a) sum += cum[i * A + a];
   for (int a = 0; a < A; ++a) pol[i * A + a] = a >= n ? 0.0 : (sum == 0.0 ? 1. / n : cum[i * A + a] / sum);
 }
-__global__ void __launch_bounds__(256) k_geval_ev(Tree t, EvalArrays ea, const double* __restrict__ pol, int l) {
-  const int P = t.P, A = t.A;
-  const int h = t.level_off[l] + blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= t.level_off[l + 1]) return;
-  const int k = t.kind[h];
-  if (k == kTerminalNode) {
-    for (int q = 0; q < P; ++q) ea.value[h * P + q] = t.term_ret[h * P + q];
-  } else {
-    const int fc = t.first_child[h], nc = t.nchild[h];
-    const int row = k == kDecisionNode ? t.info[h] * A : 0;
-    for (int q = 0; q < P; ++q) {
-      double v = 0.0;
-      for (int a = 0; a < nc; ++a) {
-        const double pr = k == kChanceNode ? t.edge_prob[fc + a] : pol[row + a];
-        if (pr > 0.0) v += pr * ea.value[(fc + a) * P + q];
-      }
-      ea.value[h * P + q] = v;
-    }
-  }
-  if (h == 0) for (int q = 0; q < P; ++q) ea.out[q] = ea.value[q];
-}
-__global__ void __launch_bounds__(256) k_geval_cf(Tree t, EvalArrays ea, const double* __restrict__ pol, int r) {
+OSG_D double readlane_f64(double v, int lane);   // (defined with k_cfr_sub's helpers)
+// (round 5) the best responses of ALL players in one set of launches: a member belongs to one player and an infostate to
+// one player, so cf [M] and best [I] hold every responder's entries at once, and the responder values are one [H, P] array
+// (the expected-value array, free once its sweep has left the root's values in out[0 .. P)) — a third of the launches of a
+// loop over responders, a level without infostates has no argmax launch at all, and the expected returns ride in the
+// same sweep (3-player leduc: 172 -> 39 launches).
+// Every (history, responder) and every infostate takes the same sums in the same order as before.
+__global__ void __launch_bounds__(256) k_geval_cf(Tree t, EvalArrays ea, const double* __restrict__ pol) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= ea.M) return;
   const int h = t.mem[m];
-  if (t.actor[h] != r) return;
+  const int r = t.actor[h];
   double cf = 1.0;
   for (int e = ea.path_off[m]; e < ea.path_off[m + 1]; ++e) {
     const int code = ea.path[e];
@@ -1810,42 +1795,72 @@ __global__ void __launch_bounds__(256) k_geval_cf(Tree t, EvalArrays ea, const d
   }
   ea.cf[m] = cf;
 }
-__global__ void __launch_bounds__(256) k_geval_best(Tree t, EvalArrays ea, int r, int l) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= t.I || t.info_player[i] != r || ea.info_level[i] != l) return;
-  const int n = t.nact[i];
+// One WAVEFRONT per infostate of the level (the host's per-level list): the lanes fetch the members' counterfactual
+// reaches and child values together (a thread per infostate walked its ~40 members x actions one dependent miss after the
+// other: ~60 us per launch, most of an evaluation), form the products, and the sums are added IN MEMBER ORDER from the
+// lanes' registers (readlane with a uniform index) — the additions of best_response.cc:194-227 in its order, bit for bit.
+__global__ void __launch_bounds__(256) k_geval_best(Tree t, EvalArrays ea, const int32_t* __restrict__ infos, int n_infos) {
+  const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (w >= n_infos) return;   // (wave-uniform)
+  const int i = infos[w];
+  const int P = t.P, r = t.info_player[i], n = t.nact[i];
+  const int m0 = t.mem_off[i], cnt = t.mem_off[i + 1] - m0;
   int best = -1;
   double best_v = -1.7976931348623157e308;  // numeric_limits<double>::lowest()
   for (int a = 0; a < n; ++a) {
     double v = 0.0;
-    for (int m = t.mem_off[i]; m < t.mem_off[i + 1]; ++m) v += ea.cf[m] * ea.brv[t.first_child[t.mem[m]] + a];
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+      const int here = cnt - c0 < 64 ? cnt - c0 : 64;
+      double prod = 0.0;
+      if (lane < here) {
+        const int m = m0 + c0 + lane;
+        prod = ea.cf[m] * ea.value[static_cast<size_t>(t.first_child[t.mem[m]] + a) * P + r];
+      }
+      for (int j = 0; j < here; ++j) v += readlane_f64(prod, j);
+    }
     if (v > best_v) { best_v = v; best = a; }
   }
-  ea.best[i] = best < 0 ? 0 : best;
+  if (lane == 0) ea.best[i] = best < 0 ? 0 : best;
 }
-__global__ void __launch_bounds__(256) k_geval_brv(Tree t, EvalArrays ea, const double* __restrict__ pol, int r, int l) {
+__global__ void __launch_bounds__(256) k_geval_brv(Tree t, EvalArrays ea, const double* __restrict__ pol, int l, double* __restrict__ ev) {
   const int P = t.P, A = t.A;
   const int h = t.level_off[l] + blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= t.level_off[l + 1]) return;
   const int k = t.kind[h];
-  double v = 0.0;
-  if (k == kTerminalNode) {
-    v = t.term_ret[h * P + r];
-  } else {
-    const int fc = t.first_child[h], nc = t.nchild[h];
-    if (k == kDecisionNode && t.actor[h] == r) {
-      v += 1.0 * ea.brv[fc + ea.best[t.info[h]]];
-    } else {
-      const int row = k == kDecisionNode ? t.info[h] * A : 0;
-      for (int a = 0; a < nc; ++a) {
-        const double pr = k == kChanceNode ? t.edge_prob[fc + a] : pol[row + a];
-        v += pr * ea.brv[fc + a];
+  const int fc = k == kTerminalNode ? 0 : t.first_child[h], nc = k == kTerminalNode ? 0 : t.nchild[h];
+  const int actor = k == kDecisionNode ? t.actor[h] : -1;
+  const int row = k == kDecisionNode ? t.info[h] * A : 0;
+  if (ev) {   // the expected returns of the same level in the same launch (k_policy_eval's sums; their own [H, P] array)
+    for (int q = 0; q < P; ++q) {
+      double v = 0.0;
+      if (k == kTerminalNode) {
+        v = t.term_ret[h * P + q];
+      } else {
+        for (int a = 0; a < nc; ++a) {
+          const double pr = k == kChanceNode ? t.edge_prob[fc + a] : pol[row + a];
+          if (pr > 0.0) v += pr * ev[static_cast<size_t>(fc + a) * P + q];
+        }
       }
+      ev[static_cast<size_t>(h) * P + q] = v;
+      if (h == 0) ea.out[q] = v;
     }
   }
-  ea.brv[h] = v;
-  if (ea.keep && r == ea.keep_r) ea.keep[h] = v;
-  if (h == 0) ea.out[P + r] = v;
+  for (int r = 0; r < P; ++r) {
+    double v = 0.0;
+    if (k == kTerminalNode) {
+      v = t.term_ret[h * P + r];
+    } else if (actor == r) {
+      v += 1.0 * ea.value[static_cast<size_t>(fc + ea.best[t.info[h]]) * P + r];
+    } else {
+      for (int a = 0; a < nc; ++a) {
+        const double pr = k == kChanceNode ? t.edge_prob[fc + a] : pol[row + a];
+        v += pr * ea.value[static_cast<size_t>(fc + a) * P + r];
+      }
+    }
+    ea.value[static_cast<size_t>(h) * P + r] = v;
+    if (ea.keep && r == ea.keep_r) ea.keep[h] = v;
+    if (h == 0) ea.out[P + r] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -3182,6 +3197,9 @@ struct osg_cfr {
   bool eval_ok = true;  // every infostate's members sit on one tree level
   int32_t *d_info_level = nullptr, *d_mem_index = nullptr, *d_best = nullptr;
   double *d_eval = nullptr;  // value [H,P] | brv [H] | cf [M] | out [2P] | policy [I,A]
+  double* d_eval_ev = nullptr;   // [H, P]: the expected returns of the large-tree evaluation (allocated on first use)
+  std::vector<int32_t> eval_level_off;   // [D + 1] the infostates of level l: d_eval_level_info[eval_level_off[l] ...)
+  int32_t* d_eval_level_info = nullptr;
   // the evaluation as independent jobs over the device (k_eval_jobs)
   bool jobs_ok = false;
   int jobs_J = 0, jobs_L = 0, jobs_G = 0, jobs_NT = 0, jobs_threads = 0;
@@ -3244,15 +3262,35 @@ static int launch_grid_eval(const osg_cfr* s, const EvalArrays& ea, const double
     pol = d_pol;
   }
   auto width = [&](int l) { return static_cast<unsigned>((s->level_off[l + 1] - s->level_off[l] + 255) / 256); };
-  if (!only_br)
-    for (int l = s->D - 1; l >= 0; --l) k_geval_ev<<<dim3(width(l)), dim3(256), 0, st>>>(t, ea, pol, l);
+  // (the expected returns ride in the best responses' sweep, in an [H, P] array of their own: allocated on first use)
+  double* d_ev = nullptr;
+  if (!only_br) {
+    osg_cfr* mut = const_cast<osg_cfr*>(s);
+    if (!mut->d_eval_ev)
+      OSG_HIP(hipMalloc(reinterpret_cast<void**>(&mut->d_eval_ev), sizeof(double) * static_cast<size_t>(s->H) * s->P));
+    d_ev = mut->d_eval_ev;
+  }
   const unsigned mblocks = static_cast<unsigned>((s->mem.size() + 255) / 256), iblocks = static_cast<unsigned>((s->I + 255) / 256);
-  for (int r = 0; r < s->P; ++r) {
-    k_geval_cf<<<dim3(std::max(1u, mblocks)), dim3(256), 0, st>>>(t, ea, pol, r);
-    for (int l = s->D - 1; l >= 0; --l) {
-      k_geval_best<<<dim3(std::max(1u, iblocks)), dim3(256), 0, st>>>(t, ea, r, l);
-      k_geval_brv<<<dim3(width(l)), dim3(256), 0, st>>>(t, ea, pol, r, l);
-    }
+  // every player's best response in one bottom-up sweep: the responder values take the expected-value array over (its
+  // sweep is done: the root's values are in out); the argmax launch only where the level holds infostates
+  osg_cfr* ms = const_cast<osg_cfr*>(s);
+  if (ms->eval_level_off.empty()) {   // the infostates of every level, once per solver
+    ms->eval_level_off.assign(static_cast<size_t>(s->D) + 1, 0);
+    for (int i = 0; i < s->I; ++i)
+      if (s->info_level[i] >= 0 && s->info_level[i] < s->D) ++ms->eval_level_off[s->info_level[i] + 1];
+    for (int l = 0; l < s->D; ++l) ms->eval_level_off[l + 1] += ms->eval_level_off[l];
+    std::vector<int32_t> list(static_cast<size_t>(std::max(ms->eval_level_off[s->D], 1)), 0), at(ms->eval_level_off.begin(), ms->eval_level_off.end() - 1);
+    for (int i = 0; i < s->I; ++i)
+      if (s->info_level[i] >= 0 && s->info_level[i] < s->D) list[at[s->info_level[i]]++] = i;
+    if (int rc = upload(list, &ms->d_eval_level_info, st)) return rc;
+  }
+  (void)iblocks;
+  k_geval_cf<<<dim3(std::max(1u, mblocks)), dim3(256), 0, st>>>(t, ea, pol);
+  for (int l = s->D - 1; l >= 0; --l) {
+    const int n_infos = ms->eval_level_off[l + 1] - ms->eval_level_off[l];
+    if (n_infos > 0)
+      k_geval_best<<<dim3(static_cast<unsigned>((n_infos + 3) / 4)), dim3(256), 0, st>>>(t, ea, ms->d_eval_level_info + ms->eval_level_off[l], n_infos);
+    k_geval_brv<<<dim3(width(l)), dim3(256), 0, st>>>(t, ea, pol, l, d_ev);
   }
   OSG_HIP(hipGetLastError());
   return OSG_OK;
@@ -4339,7 +4377,7 @@ int osg_cfr_destroy(osg_cfr* s) {
   void* ptrs[] = {s->d_level_off, s->d_parent, s->d_first_child, s->d_info, s->d_mem_off, s->d_mem, s->d_nact,
                   s->d_kind, s->d_nchild, s->d_aidx, s->d_actor, s->d_info_player, s->d_edge_prob, s->d_term_ret,
                   s->d_tables, s->d_reach, s->d_value, s->d_path_off, s->d_path, s->d_info_level, s->d_mem_index,
-                  s->d_best, s->d_eval, s->d_meta32, s->d_info_player32, s->d_skip, s->d_node_delta, s->d_rec,
+                  s->d_best, s->d_eval, s->d_eval_ev, s->d_eval_level_info, s->d_meta32, s->d_info_player32, s->d_skip, s->d_node_delta, s->d_rec,
                   s->d_uret, s->d_uprob, s->d_spare_delta[0], s->d_spare_delta[1], s->d_split_nloc, s->d_split_desc,
                   s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
                   s->d_split_terms, s->d_split_bar, s->d_sub_nloc, s->d_sub_desc, s->d_sub_fc, s->d_sub_aux, s->d_sub_mem_off,

@@ -621,8 +621,10 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
                                         "note": "host call to host result; the tables stay on the device (the average policy is "
                                                 "formed inside the kernel). leduc_poker: k_eval_jobs, 30 expected-returns jobs + 12 "
                                                 "best-response jobs of one workgroup each, the last one sums the chance levels (222 us per "
-                                                "call on one workgroup before); the reference walks the tree per call "
-                                                "(tabular_exploitability.cc:30-89)"}
+                                                "call on one workgroup before); leduc_poker(players=3), 1.83 M histories: k_geval_* — one "
+                                                "bottom-up sweep for every player's best response and the expected returns (39 launches), the "
+                                                "argmax by a wavefront per infostate (2.0 ms per call in round 4); the reference walks the "
+                                                "tree per call (tabular_exploitability.cc:30-89)"}
         except Exception as e:  # noqa: BLE001
             out["env_step"] = {"error": f"{type(e).__name__}: {e}"}
     # ---- config 1: tic_tac_toe MCTSBot(RandomRolloutEvaluator(20, 42), 1000 sims, solve) — plumbing ----

@@ -970,6 +970,7 @@ struct GridCfr {
   int32_t* skip;               // [M]
   Tables tb;
   int M;
+  const double* pol = nullptr; // [I, A] the policy a pass plays: tb.cur, or CFR-BR's effective policy (k_gcfr_effpol)
 };
 
 __global__ void __launch_bounds__(256) k_gcfr_init_values(GridCfr g) {
@@ -990,7 +991,7 @@ __global__ void __launch_bounds__(256) k_gcfr_level(GridCfr g, int begin, int en
   for (int q = q0; q < q1; ++q) {
     double v = 0.0;
     for (int a = 0; a < nc; ++a) {
-      const double pr = k == kChanceNode ? g.t.edge_prob[fc + a] : g.tb.cur[row + a];
+      const double pr = k == kChanceNode ? g.t.edge_prob[fc + a] : g.pol[row + a];
       v += pr * g.value[(fc + a) * P + q];
     }
     g.value[h * P + q] = v;
@@ -1010,7 +1011,7 @@ __global__ void __launch_bounds__(256) k_gcfr_members(GridCfr g, int upd, int it
   for (int e = g.path_off[m]; e < g.path_off[m + 1]; ++e) {
     const int code = g.path[e];
     const int slot = (code >> 24) & 0xF, idx = code & 0x7FFFFF;
-    const double pr = ((code >> 23) & 1) ? g.t.edge_prob[idx] : g.tb.cur[idx];
+    const double pr = ((code >> 23) & 1) ? g.t.edge_prob[idx] : g.pol[idx];
 #pragma unroll
     for (int q = 0; q <= kMaxPlayers; ++q) reach[q] = (q == slot) ? reach[q] * pr : reach[q];
   }
@@ -1028,9 +1029,18 @@ __global__ void __launch_bounds__(256) k_gcfr_members(GridCfr g, int upd, int it
   const double vh = g.value[h * P + pl];
   for (int a = 0; a < n; ++a) {
     g.dreg[m * A + a] = cf_reach * (g.value[(fc + a) * P + pl] - vh);
-    const double pol = g.tb.cur[i * A + a];
+    const double pol = g.pol[i * A + a];   // (the member's own row: the current policy also under CFR-BR's overrides)
     g.dpol[m * A + a] = cfg.linear_averaging ? iteration * self_reach * pol : self_reach * pol;
   }
+}
+// CFR-BR on large trees (cfr_br.cc:70-81, policy_overrides cfr.cc:365-372): the policy pass `upd` plays — the updating
+// player's rows of the current policy, the others' best-response actions (best[i], left by the evaluation) as one-hot rows.
+__global__ void __launch_bounds__(256) k_gcfr_effpol(GridCfr g, int upd, const int32_t* __restrict__ best, double* __restrict__ eff) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.t.I) return;
+  const int A = g.t.A;
+  const bool own = g.info_player[i] == upd;
+  for (int a = 0; a < A; ++a) eff[i * A + a] = own ? g.tb.cur[i * A + a] : (a == best[i] ? 1.0 : 0.0);
 }
 
 __global__ void __launch_bounds__(256) k_gcfr_fold(GridCfr g, int upd, osg_cfr_cfg cfg) {
@@ -4506,6 +4516,7 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
     g.t = s->tree(); g.path_off = s->d_path_off; g.path = s->d_path; g.meta = s->d_meta32;
     g.info_player = s->d_info_player32; g.value = s->d_value; g.dreg = s->d_node_delta;
     g.dpol = s->d_node_delta + static_cast<size_t>(M) * s->A; g.skip = s->d_skip; g.tb = tb; g.M = M;
+    g.pol = tb.cur;
     hipStream_t st = s->ctx->stream;
     auto blocks = [](int n) { return dim3(static_cast<unsigned>((n + 255) / 256)); };
     k_gcfr_init_values<<<blocks(s->H), dim3(256), 0, st>>>(g);
@@ -4858,6 +4869,35 @@ int osg_cfr_br_iterate(osg_cfr* s, int iters) {
   SplitTree sp{s->split_G, s->split_L, s->split_NL, s->split_NM, s->split_NI, s->d_split_nloc, s->d_split_desc,
                s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
                s->d_split_terms, s->d_split_bar, s->h_sub_err};
+  if (!split && !jobs && eval_takes_the_grid(s) && s->path_kernel) {
+    // large trees (3-player leduc: one workgroup walked a pass set in tens of milliseconds): the evaluation's sweep leaves
+    // every infostate's best-response action, then each player's pass runs as the launch-per-phase CFR pass
+    // (k_gcfr_*) on the effective policy — the same additions in the same order as k_cfr<., kBr>
+    GridCfr g;
+    g.t = s->tree(); g.path_off = s->d_path_off; g.path = s->d_path; g.meta = s->d_meta32;
+    g.info_player = s->d_info_player32; g.value = s->d_value; g.dreg = s->d_node_delta;
+    g.dpol = s->d_node_delta + M * s->A; g.skip = s->d_skip; g.tb = tb; g.M = static_cast<int>(M);
+    double* d_eff = ea.out + 2 * s->P;   // (the evaluation's policy scratch: [I, A], free here)
+    g.pol = d_eff;
+    auto blocks = [](int n) { return dim3(static_cast<unsigned>((n + 255) / 256)); };
+    k_gcfr_init_values<<<blocks(s->H), dim3(256), 0, st>>>(g);
+    for (int it = 0; it < iters; ++it) {
+      if (int rc = launch_grid_eval(s, ea, s->cur(), false, nullptr, true)) return rc;
+      for (int upd = 0; upd < s->P; ++upd) {
+        k_gcfr_effpol<<<blocks(s->I), dim3(256), 0, st>>>(g, upd, s->d_best, d_eff);
+        for (int l = s->D - 2; l >= 0; --l) {
+          const int begin = s->level_off[l], end = s->level_off[l + 1];
+          k_gcfr_level<<<blocks(end - begin), dim3(256), 0, st>>>(g, begin, end, upd, upd + 1);
+        }
+        k_gcfr_members<<<blocks(static_cast<int>(M)), dim3(256), 0, st>>>(g, upd, s->iteration + 1, cfg);
+        k_gcfr_fold<<<blocks(s->I), dim3(256), 0, st>>>(g, upd, cfg);
+      }
+      ++s->iteration;
+    }
+    OSG_HIP(hipGetLastError());
+    s->last_kernel = "k_gcfr<br>";
+    return OSG_OK;
+  }
   for (int it = 0; it < iters; ++it) {
     if (jobs) k_eval_jobs<<<dim3(s->jobs_J), dim3(s->jobs_threads), s->jobs_lds_bytes, st>>>(s->tree(), ea, eval_jobs_of(s), s->cur(), 1, 1);
     else if (eval_takes_the_grid(s)) { if (int rc = launch_grid_eval(s, ea, s->cur(), false, nullptr, true)) return rc; }

@@ -633,6 +633,36 @@ def test_cfr_br_on_the_split_kernel_equals_the_one_workgroup_passes(ctx, monkeyp
     assert rate > 8000.0, rate
 
 
+def test_cfr_br_on_a_large_tree_takes_the_grid_and_equals_the_one_workgroup_passes(ctx, monkeypatch):
+    """CFR-BR where the tree is beyond the jobs and the subtree kernels (5-player kuhn_poker: 116 437 histories; 3-player
+    leduc_poker takes the same path): the evaluation's sweep leaves every infostate's best-response action and every
+    player's pass runs as launch-per-phase CFR on the effective policy (k_gcfr_* with k_gcfr_effpol) — the tables of the
+    one-workgroup pass set (k_policy_eval + k_cfr<., kBr>) bit for bit, at many times its rate."""
+    import time
+    import open_spiel_amd as osa
+    game = "kuhn_poker(players=5)"
+    fast = osa.TabularSolver(ctx, game)
+    fast.evaluate_and_update_policy_cfr_br(3)
+    assert fast.last_kernel() == "k_gcfr<br>"
+    got = fast.tables()
+    monkeypatch.setenv("OSG_EVAL_GRID", "0")
+    slow = osa.TabularSolver(ctx, game)
+    slow.evaluate_and_update_policy_cfr_br(3)
+    want = slow.tables()
+    monkeypatch.delenv("OSG_EVAL_GRID")
+    for name in ("regrets", "cum_policy", "cur_policy"):
+        np.testing.assert_array_equal(got[name], want[name])
+    big = osa.TabularSolver(ctx, "leduc_poker(players=3)")
+    before = big.nash_conv()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    big.evaluate_and_update_policy_cfr_br(20)
+    ctx.synchronize()
+    rate = 20 / (time.perf_counter() - t0)
+    assert big.last_kernel() == "k_gcfr<br>" and rate > 150.0, rate       # (one workgroup: ~10 iterations per second)
+    assert big.nash_conv() < before
+
+
 def test_a_smaller_solver_does_not_lower_the_lds_cap_under_a_larger_one(ctx):
     """The dynamic-LDS cap is an attribute of a KERNEL: a later solver of a smaller game must not lower it under an
     earlier solver that is still in use (leduc's kernels need more than the 64 KB default)."""

@@ -25,3 +25,5 @@ s3 = osa.TabularSolver(ctx, "leduc_poker(players=3)")
 s3.evaluate_and_update_policy(2); s3.nash_conv(); ctx.synchronize()
 t0 = time.perf_counter(); nc = s3.nash_conv(); dt = time.perf_counter() - t0
 print(f"leduc_poker(players=3): nash_conv {dt * 1e3:.2f} ms/call ({nc:.6f})", flush=True)
+t0 = time.perf_counter(); s3.evaluate_and_update_policy_cfr_br(20); ctx.synchronize(); dt = time.perf_counter() - t0
+print(f"leduc_poker(players=3): cfr-br {20 / dt:.0f} it/s ({dt / 20 * 1e3:.2f} ms per iteration; {s3.last_kernel()})", flush=True)

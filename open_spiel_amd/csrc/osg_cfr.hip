@@ -1043,18 +1043,33 @@ __global__ void __launch_bounds__(256) k_gcfr_effpol(GridCfr g, int upd, const i
   for (int a = 0; a < A; ++a) eff[i * A + a] = own ? g.tb.cur[i * A + a] : (a == best[i] ? 1.0 : 0.0);
 }
 
+// One WAVEFRONT per infostate (round 5): the lanes fetch the members' skip flags and terms together and the sums are added
+// in member order from the lanes' registers (readlane with a uniform index, pruned members stepped over through the
+// ballot of the live ones) — a thread per infostate had walked its ~40 members one dependent load after the other.  The
+// additions are cfr.cc:379-405's in its order: bit-identical with every other CFR kernel here.
+OSG_D double readlane_f64(double v, int lane);   // (defined with k_cfr_sub's helpers)
 __global__ void __launch_bounds__(256) k_gcfr_fold(GridCfr g, int upd, osg_cfr_cfg cfg) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= g.t.I) return;
+  const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (i >= g.t.I) return;                                   // (wave-uniform)
   if (upd >= 0 && g.info_player[i] != upd) return;
   const int A = g.t.A, n = g.t.nact[i];
-  for (int m = g.t.mem_off[i]; m < g.t.mem_off[i + 1]; ++m) {
-    if (g.skip[m]) continue;
-    for (int a = 0; a < n; ++a) {
-      g.tb.regrets[i * A + a] += g.dreg[m * A + a];
-      g.tb.cum[i * A + a] += g.dpol[m * A + a];
+  const int m0 = g.t.mem_off[i], cnt = g.t.mem_off[i + 1] - m0;
+  for (int a = 0; a < n; ++a) {
+    double reg = g.tb.regrets[i * A + a], cum = g.tb.cum[i * A + a];
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+      const int m = m0 + c0 + lane;
+      const bool live = c0 + lane < cnt && g.skip[m] == 0;
+      double dr = 0.0, dp = 0.0;
+      if (live) { dr = g.dreg[m * A + a]; dp = g.dpol[m * A + a]; }
+      for (unsigned long long todo = __ballot(live); todo != 0ull; todo &= todo - 1ull) {
+        const int j = __builtin_ctzll(todo);
+        reg += readlane_f64(dr, j);
+        cum += readlane_f64(dp, j);
+      }
     }
+    if (lane == 0) { g.tb.regrets[i * A + a] = reg; g.tb.cum[i * A + a] = cum; }
   }
+  if (lane != 0) return;
   if (cfg.regret_matching_plus)
     for (int a = 0; a < n; ++a)
       if (g.tb.regrets[i * A + a] < 0) g.tb.regrets[i * A + a] = 0;
@@ -4530,7 +4545,7 @@ int osg_cfr_iterate(osg_cfr* s, int iters) {
           k_gcfr_level<<<blocks(end - begin), dim3(256), 0, st>>>(g, begin, end, q0, q1);
         }
         k_gcfr_members<<<blocks(M), dim3(256), 0, st>>>(g, upd, s->iteration + it + 1, s->cfg);
-        k_gcfr_fold<<<blocks(s->I), dim3(256), 0, st>>>(g, upd, s->cfg);
+        k_gcfr_fold<<<blocks(s->I * 64), dim3(256), 0, st>>>(g, upd, s->cfg);
       }
     }
     OSG_HIP(hipGetLastError());
@@ -4890,7 +4905,7 @@ int osg_cfr_br_iterate(osg_cfr* s, int iters) {
           k_gcfr_level<<<blocks(end - begin), dim3(256), 0, st>>>(g, begin, end, upd, upd + 1);
         }
         k_gcfr_members<<<blocks(static_cast<int>(M)), dim3(256), 0, st>>>(g, upd, s->iteration + 1, cfg);
-        k_gcfr_fold<<<blocks(s->I), dim3(256), 0, st>>>(g, upd, cfg);
+        k_gcfr_fold<<<blocks(s->I * 64), dim3(256), 0, st>>>(g, upd, cfg);
       }
       ++s->iteration;
     }

@@ -345,6 +345,8 @@ class Game : public std::enable_shared_from_this<Game> {
   // games whose reference State has a constructor from a board)
   inline std::unique_ptr<State> NewInitialState(const StateStruct& state_struct) const;
   inline std::unique_ptr<State> NewInitialState(const Json& json) const;
+  inline std::unique_ptr<State> NewInitialState(const std::string& str) const;   // spiel.h:952-954: the JSON text
+  inline std::unique_ptr<State> NewInitialState(const char* str) const;          // spiel.h:957-959
   std::unique_ptr<State> NewInitialStateForPopulation(int) const {  // spiel.h:963-966: mean-field games only
     SpielFatalError("NewInitialStateForPopulation is not implemented.");
   }
@@ -1199,6 +1201,8 @@ inline std::unique_ptr<State> Game::NewInitialState(const StateStruct& state_str
     return std::unique_ptr<State>(new connect_four::ConnectFourState(shared_from_this(), *c));
   SpielFatalError("NewInitialState from StateStruct is not implemented.");
 }
+inline std::unique_ptr<State> Game::NewInitialState(const std::string& str) const { return NewInitialState(Json::parse(str)); }
+inline std::unique_ptr<State> Game::NewInitialState(const char* str) const { return NewInitialState(std::string(str)); }
 inline std::unique_ptr<State> Game::NewInitialState(const Json& json) const {
   const std::string name = GetType().short_name;
   if (name == "tic_tac_toe") return NewInitialState(tic_tac_toe::TicTacToeStateStruct(json));

@@ -31,6 +31,9 @@ GAMES = [
     "connect_four(rows=7,columns=15,x_in_row=4)", "connect_four(rows=15,columns=8,egocentric_obs_tensor=True)",
     "leduc_poker(players=4)", "leduc_poker(players=5,suit_isomorphism=True)", "leduc_poker(players=7,action_mapping=True)",
     "leduc_poker(players=10)", "leduc_poker(players=8,starting_player=6)",
+    # round 5: the boards of the 12-word hex record (three-word planes with spare bits: 65 ... 91 cells), at its edges
+    "hex(board_size=8,swap=True)", "hex(num_rows=13,num_cols=7)", "hex(num_rows=10,num_cols=9,swap=True)", "hex(num_rows=9,num_cols=8)",
+    "hex(num_rows=11,num_cols=6)", "hex(num_rows=12,num_cols=8)",
 ]
 if os.environ.get("SWEEP_ONLY"): GAMES = [g for g in GAMES if g in os.environ["SWEEP_ONLY"].split(";")]
 ctx = osa.Context(0)

@@ -627,6 +627,45 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
                                                 "tree per call (tabular_exploitability.cc:30-89)"}
         except Exception as e:  # noqa: BLE001
             out["env_step"] = {"error": f"{type(e).__name__}: {e}"}
+        # ---- the byte-bound step of the largest record served: hex(9), SURVEY.md 8(d)'s 109 B per state-step ----
+        try:
+            n_hex = 1 << 22
+            hb = osa.StateBatch(ctx, "hex(board_size=9)", n_hex)
+            hb.random_steps(SEED, 30)
+            hd = osa.StateBatch(ctx, "hex(board_size=9)", n_hex)
+            lm = hb.legal_actions_mask()
+            hacts = torch.where(lm.bool().any(1), (lm.to(torch.float32) * torch.rand(lm.shape, device="cuda")).argmax(1),
+                                torch.full((n_hex,), 255, device="cuda")).to(torch.uint8)
+            del lm
+            hstatus = torch.empty(n_hex, dtype=torch.uint8, device="cuda")
+            for _ in range(5):
+                hb.step(hacts, dst=hd, status=hstatus, want_mask=False)
+            h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            h0.record()
+            for _ in range(50):
+                hb.step(hacts, dst=hd, status=hstatus, want_mask=False)
+            h1.record()
+            torch.cuda.synchronize()
+            hus = h0.elapsed_time(h1) / 50 * 1e3
+            rec_bytes = hb.desc.state_words * 4
+            moved = 2 * rec_bytes + 2                     # record in, record out, action, status
+            out["hex_step"] = {"metric": "hex(board_size=9) fused legality + ApplyAction + status, states/sec",
+                               "value": n_hex / hus * 1e6, "unit": "state-steps/s", "states": n_hex,
+                               "kernel_us_per_launch": hus, "record_bytes": rec_bytes,
+                               "roofline": {"bound": "hbm", "kernel": "k_step_hexvec",
+                                            "algorithmic_bytes_per_state_step": 109,
+                                            "achieved": 109 * n_hex / hus / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": 109 * n_hex / hus / 1e3 / HBM_PEAK_GBS,
+                                            "bytes_moved_per_state_step": moved,
+                                            "frac_on_bytes_moved": moved * n_hex / hus / 1e3 / HBM_PEAK_GBS,
+                                            "note": "50 launches back to back between one event pair; the successor's mask row is "
+                                                    "not written (on a hex board it is ~occupied of the successor record). The record "
+                                                    "is 12 words: the mover / result / ply word rides in the 5 spare bits at the top of "
+                                                    "each plane's last word (13 words in round 4: 0.60 on the same 109 B)"}}
+            del hb, hd, hacts, hstatus
+        except Exception as e:  # noqa: BLE001
+            out["hex_step"] = {"error": f"{type(e).__name__}: {e}"}
     # ---- config 1: tic_tac_toe MCTSBot(RandomRolloutEvaluator(20, 42), 1000 sims, solve) — plumbing ----
     if rank == 0:
         out["ttt_mcts"] = ttt_mcts_config1(with_cpu)

@@ -364,22 +364,23 @@ struct HexBitsT {
 };
 template <int NW>
 struct HexParamsT {
-  int words;  // = 4*NW + 1 (4*NW in the folded form)
+  int words;  // = 4*NW + 1, or 4*NW in the folded form (HexT::folded)
   int cols, rows, cells, swap, plain_obs;
   HexBitsT<NW> board, col_first, col_last, row_first, row_last;
 };
-// kFold (round 5; hex(9): 81 cells in three words per plane): the meta word rides in the five spare top bits of each
-// plane's last word (4 x 5 = 20 bits: mover 1, result 2, plies 8, first move 9), so a state is 4*NW words instead of
-// 4*NW + 1 — 12 instead of 13 for hex(9), 8 % fewer bytes per step both ways.  Needs cells <= 32*NW - 5; everything
-// above load / store sees the same State.
-template <int NW, bool kFold = false>
+// The folded record (round 5): where the board leaves five spare bits at the top of each plane's last word
+// (cells <= 32*NW - 5: hex(9) 81 of 96, the default 11 x 11 121 of 128, 13 x 13, 15 x 15, 19 x 19 ...), the meta word
+// rides in them (4 x 5 = 20 bits: mover 1, result 2, plies 8, first move 9) and a state is 4*NW words instead of
+// 4*NW + 1 — 12 instead of 13 for hex(9), 8 % fewer bytes per step both ways.  Which form a batch has is a field of
+// its Params (words == 4*NW), a wave-uniform branch in load / store; everything above them sees the same State.
+template <int NW>
 struct HexT {
   using word_t = uint32_t;
   // boards of up to 128 actions share the engine's 4-word mask (and with it the search kernels); the big boards
   // (13 x 13 ... 19 x 19: NW = 6, 8, 12) carry one mask word per plane word
   static constexpr int kMaskW = NW > kMaskWords ? NW : kMaskWords;
-  static constexpr int kWords = kFold ? 4 * NW : 4 * NW + 1;
-  static constexpr uint32_t kLastWordMask = kFold ? 0x07FFFFFFu : 0xFFFFFFFFu;
+  static constexpr int kMaxWords = 4 * NW + 1;
+  static constexpr uint32_t kFoldedLastWordMask = 0x07FFFFFFu;
   using MaskType = MaskT<kMaskW>;
   using Bits = HexBitsT<NW>;
   using Params = HexParamsT<NW>;
@@ -483,7 +484,11 @@ struct HexT {
     s.meta = 0;
     return s;
   }
-  OSG_D static State load(const Params&, const word_t* base, int64_t n, int64_t i) {
+  OSG_D static bool folded(const Params& p) { return p.words == 4 * NW; }
+  // (the record's form as a template argument: the byte-bound step kernel is compiled per form; everything else asks
+  // the Params — load / store below)
+  template <bool kFold>
+  OSG_D static State load_as(const word_t* base, int64_t n, int64_t i) {
     State s;
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
@@ -495,15 +500,16 @@ struct HexT {
     if constexpr (kFold) {
       const uint32_t pk = (s.black.w[NW - 1] >> 27) | ((s.white.w[NW - 1] >> 27) << 5) | ((s.ea.w[NW - 1] >> 27) << 10) |
                           ((s.eb.w[NW - 1] >> 27) << 15);
-      s.black.w[NW - 1] &= kLastWordMask; s.white.w[NW - 1] &= kLastWordMask;
-      s.ea.w[NW - 1] &= kLastWordMask; s.eb.w[NW - 1] &= kLastWordMask;
+      s.black.w[NW - 1] &= kFoldedLastWordMask; s.white.w[NW - 1] &= kFoldedLastWordMask;
+      s.ea.w[NW - 1] &= kFoldedLastWordMask; s.eb.w[NW - 1] &= kFoldedLastWordMask;
       s.meta = (pk & 7u) | (((pk >> 3) & 0xFFu) << 8) | ((pk >> 11) << 16);   // mover | result, plies, first move
     } else {
       s.meta = base[(4 * NW) * n + i];
     }
     return s;
   }
-  OSG_D static void store(const Params&, word_t* base, int64_t n, int64_t i, const State& s) {
+  template <bool kFold>
+  OSG_D static void store_as(word_t* base, int64_t n, int64_t i, const State& s) {
     uint32_t pk = 0u;
     if constexpr (kFold) pk = (s.meta & 7u) | (((s.meta >> 8) & 0xFFu) << 3) | (((s.meta >> 16) & 0x1FFu) << 11);
 #pragma unroll
@@ -515,6 +521,12 @@ struct HexT {
       base[(3 * NW + k) * n + i] = s.eb.w[k] | (last ? ((pk >> 15) & 31u) << 27 : 0u);
     }
     if constexpr (!kFold) base[(4 * NW) * n + i] = s.meta;
+  }
+  OSG_D static State load(const Params& p, const word_t* base, int64_t n, int64_t i) {
+    return folded(p) ? load_as<true>(base, n, i) : load_as<false>(base, n, i);   // (wave-uniform)
+  }
+  OSG_D static void store(const Params& p, word_t* base, int64_t n, int64_t i, const State& s) {
+    if (folded(p)) store_as<true>(base, n, i, s); else store_as<false>(base, n, i, s);
   }
   OSG_D static int to_move(const State& s) { return s.meta & 1u; }
   OSG_D static int result(const State& s) { return (s.meta >> 1) & 3u; }

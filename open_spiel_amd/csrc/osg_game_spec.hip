@@ -210,22 +210,26 @@ int parse_game(const char* game_string, GameSpec* out) {
     out->hex_nw = need <= 4 ? need : (need <= 6 ? 6 : (need <= 8 ? 8 : 12));
     if (need <= 4 && (cells + 31) / 32 < need) out->hex_nw = need;  // (cells a multiple of 32 with swap: one more word)
     out->hex_explicit = rep == "explicit";
-    // (round 5) three-word planes with at least five spare bits each — hex(9) — carry the meta word in those bits:
-    // 12 words per state instead of 13 (HexT<3, true>; OSG_HEX_FOLD=0 keeps the 13-word record)
+    // (round 5) planes whose last word has at least five spare bits — hex(9), the default 11 x 11, 13 x 13, 15 x 15,
+    // 19 x 19 ... — carry the meta word in those bits: 4 * hex_nw words per state instead of 4 * hex_nw + 1
+    // (HexT::folded; OSG_HEX_FOLD=0 keeps the separate meta word)
     const char* fold_env = std::getenv("OSG_HEX_FOLD");
-    out->hex_fold = out->hex_nw == 3 && cells <= 91 && !(fold_env && fold_env[0] == '0');
+    out->hex_fold = cells <= 32 * out->hex_nw - 5 && !(fold_env && fold_env[0] == '0');
     d.state_words = out->hex_fold ? 4 * out->hex_nw : 4 * out->hex_nw + 1; d.state_word_bytes = 4;
     // only the variant that holds the board: Bits::w has NW words, a larger board would write past it
     out->hex1 = {}; out->hex2 = {}; out->hex3 = {}; out->hex4 = {}; out->hex6 = {}; out->hex8 = {}; out->hex12 = {};
     switch (out->hex_nw) {
       case 1: fill_hex<1>(&out->hex1, cols, rows, swap, plain); break;
       case 2: fill_hex<2>(&out->hex2, cols, rows, swap, plain); break;
-      case 3: fill_hex<3>(&out->hex3, cols, rows, swap, plain); if (out->hex_fold) out->hex3.words = 12; break;
+      case 3: fill_hex<3>(&out->hex3, cols, rows, swap, plain); break;
       case 4: fill_hex<4>(&out->hex4, cols, rows, swap, plain); break;
       case 6: fill_hex<6>(&out->hex6, cols, rows, swap, plain); break;
       case 8: fill_hex<8>(&out->hex8, cols, rows, swap, plain); break;
       default: fill_hex<12>(&out->hex12, cols, rows, swap, plain); break;
     }
+    if (out->hex_fold)
+      out->hex1.words = out->hex2.words = out->hex3.words = out->hex4.words = out->hex6.words = out->hex8.words = out->hex12.words =
+          4 * out->hex_nw;   // (only the variant in use is ever read)
   } else if (name == "kuhn_poker") {
     int n = rd.get_int("players", 2);
     if (!rd.finish()) return set_error(OSG_ERR_INVALID, rd.err);

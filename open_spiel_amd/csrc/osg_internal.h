@@ -24,7 +24,7 @@ enum GameKind { kTtt = 0, kC4 = 1, kHex = 2, kKuhn = 3, kLeduc = 4 };
 struct GameSpec {
   osg_game_desc desc;
   int hex_nw = 0;  // u32 words per hex bit plane: 1..4 (boards of up to 128 actions), 6 / 8 / 12 (up to 19 x 19)
-  bool hex_fold = false;  // hex_nw == 3 with at most 91 cells (hex(9)): the meta word folded into the planes' spare bits (HexT<3, true>)
+  bool hex_fold = false;  // cells <= 32 * hex_nw - 5: the meta word folded into the planes' spare bits (a 4 * hex_nw word record)
   bool c4_std = false;  // connect_four with the default 6x7x4 geometry (constant-folded kernels)
   bool c4_wide = false;  // connect_four above 64 board bits: two plane words per colour (C4Wide)
   bool leduc_big = false;  // leduc_poker with 4 to 10 players: the five-plane record (LeducBig)
@@ -157,8 +157,7 @@ struct osg_batch {
         switch ((spec).hex_nw) {                                                   \
           case 1: { using G = osg::HexT<1>; const G::Params& P = (spec).hex1; __VA_ARGS__; } break; \
           case 2: { using G = osg::HexT<2>; const G::Params& P = (spec).hex2; __VA_ARGS__; } break; \
-          case 3: if ((spec).hex_fold) { using G = osg::HexT<3, true>; const G::Params& P = (spec).hex3; __VA_ARGS__; } \
-                  else { using G = osg::HexT<3>; const G::Params& P = (spec).hex3; __VA_ARGS__; } break; \
+          case 3: { using G = osg::HexT<3>; const G::Params& P = (spec).hex3; __VA_ARGS__; } break; \
           case 4: { using G = osg::HexT<4>; const G::Params& P = (spec).hex4; __VA_ARGS__; } break; \
           default: return osg::set_error(OSG_ERR_UNSUPPORTED, "hex boards above 128 actions are served by the batch entry " \
                                          "points and the lane-per-root searches, not by this one"); \
@@ -185,8 +184,7 @@ struct osg_batch {
         switch ((spec).hex_nw) {                                                   \
           case 1: { using G = osg::HexT<1>; const G::Params& P = (spec).hex1; __VA_ARGS__; } break; \
           case 2: { using G = osg::HexT<2>; const G::Params& P = (spec).hex2; __VA_ARGS__; } break; \
-          case 3: if ((spec).hex_fold) { using G = osg::HexT<3, true>; const G::Params& P = (spec).hex3; __VA_ARGS__; } \
-                  else { using G = osg::HexT<3>; const G::Params& P = (spec).hex3; __VA_ARGS__; } break; \
+          case 3: { using G = osg::HexT<3>; const G::Params& P = (spec).hex3; __VA_ARGS__; } break; \
           case 4: { using G = osg::HexT<4>; const G::Params& P = (spec).hex4; __VA_ARGS__; } break; \
           case 6: { using G = osg::HexT<6>; const G::Params& P = (spec).hex6; __VA_ARGS__; } break; \
           case 8: { using G = osg::HexT<8>; const G::Params& P = (spec).hex8; __VA_ARGS__; } break; \

@@ -232,8 +232,8 @@ template <int NW, int V, bool kNt, bool kMask = true, bool kFold = false>
 __global__ void __launch_bounds__(kBlock)
 k_step_hexvec(typename HexT<NW>::Params p, const uint32_t* src, uint32_t* dst, int64_t n,  // src may BE dst
               const uint8_t* __restrict__ actions, uint32_t* __restrict__ mask_out, uint8_t* __restrict__ status) {
-  using G = HexT<NW, kFold>;
-  constexpr int W = G::kWords;   // 4 NW + 1, or 4 NW with the meta word folded into the planes (hex(9): 12)
+  using G = HexT<NW>;
+  constexpr int W = kFold ? 4 * NW : 4 * NW + 1;   // (folded: the meta word rides in the planes' spare bits; hex(9): 12)
   typedef uint32_t wvec __attribute__((ext_vector_type(V)));
   typedef uint8_t bvec __attribute__((ext_vector_type(V)));
   const int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * V;
@@ -250,14 +250,14 @@ k_step_hexvec(typename HexT<NW>::Params p, const uint32_t* src, uint32_t* dst, i
   bvec sv;
 #pragma unroll
   for (int j = 0; j < V; ++j) {
-    typename G::State s = G::load(p, tmp, V, j);
+    typename G::State s = G::template load_as<kFold>(tmp, V, j);
     const int a = av[j];
     bool illegal = false;
     if (a != 0xFF) {
       const auto before = G::legal(p, s);
       if (a < 32 * G::kMaskW && before.test(a)) G::apply(p, s, a); else illegal = true;
     }
-    G::store(p, tmp, V, j, s);
+    G::template store_as<kFold>(tmp, V, j, s);
     const bool term = G::terminal(p, s);
     if constexpr (kMask) {
       const auto after = G::legal(p, s);
@@ -1910,22 +1910,24 @@ int osg_step(const osg_batch* src, osg_batch* dst, const uint8_t* d_actions, voi
 #define OSG_HEXVEC(NWV, VV, NTV, MASKV, FOLDV, member)                                                                              \
   k_step_hexvec<NWV, VV, NTV, MASKV, FOLDV><<<dim3(grid_for(n / VV)), dim3(kBlock), 0, ctx->stream>>>(src->spec.member, s32, d32, n, \
                                                                                                     d_actions, m32, d_status)
-#define OSG_HEXVEC_NW(NWV, FOLDV, member)                                     \
+#define OSG_HEXVEC_MASK(NWV, FOLDV, member)                                   \
   do {                                                                        \
     if (nt && m32) OSG_HEXVEC(NWV, 2, true, true, FOLDV, member);             \
     else if (nt) OSG_HEXVEC(NWV, 2, true, false, FOLDV, member);              \
     else if (m32) OSG_HEXVEC(NWV, 2, false, true, FOLDV, member);             \
     else OSG_HEXVEC(NWV, 2, false, false, FOLDV, member);                     \
   } while (0)
+#define OSG_HEXVEC_NW(NWV, member)                                                                          \
+  do {                                                                                                      \
+    if (src->spec.hex_fold) OSG_HEXVEC_MASK(NWV, true, member); else OSG_HEXVEC_MASK(NWV, false, member);   \
+  } while (0)
       switch (src->spec.hex_nw) {
-        case 1: OSG_HEXVEC_NW(1, false, hex1); break;
-        case 2: OSG_HEXVEC_NW(2, false, hex2); break;
-        case 3:
-          if (src->spec.hex_fold) OSG_HEXVEC_NW(3, true, hex3);
-          else OSG_HEXVEC_NW(3, false, hex3);
-          break;
-        default: OSG_HEXVEC_NW(4, false, hex4); break;
+        case 1: OSG_HEXVEC_NW(1, hex1); break;
+        case 2: OSG_HEXVEC_NW(2, hex2); break;
+        case 3: OSG_HEXVEC_NW(3, hex3); break;
+        default: OSG_HEXVEC_NW(4, hex4); break;
       }
+#undef OSG_HEXVEC_MASK
 #undef OSG_HEXVEC_NW
 #undef OSG_HEXVEC
       OSG_HIP(hipGetLastError());
@@ -2088,14 +2090,14 @@ int osg_observation(const osg_batch* b, int player, int which, float* out, int o
              (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) {   // (its LDS stage is 256 B per cell: the big boards go below)
     const size_t shmem = sizeof(float) * kHexObsBlock * static_cast<size_t>(d.obs_shape[1] * d.obs_shape[2]);
     const unsigned grid = static_cast<unsigned>((b->n * 9 + kHexObsBlock - 1) / kHexObsBlock);
-#define OSG_HEX_OBS(NW, FOLD, member)                                                                        \
-  k_observation_hex_planes<HexT<NW, FOLD>><<<dim3(grid), dim3(kHexObsBlock), shmem, ctx->stream>>>(          \
+#define OSG_HEX_OBS(NW, member)                                                                        \
+  k_observation_hex_planes<HexT<NW>><<<dim3(grid), dim3(kHexObsBlock), shmem, ctx->stream>>>(          \
       b->spec.member, static_cast<const uint32_t*>(b->d_words), b->n, 9, d_out)
     switch (b->spec.hex_nw) {
-      case 1: OSG_HEX_OBS(1, false, hex1); break;
-      case 2: OSG_HEX_OBS(2, false, hex2); break;
-      case 3: if (b->spec.hex_fold) OSG_HEX_OBS(3, true, hex3); else OSG_HEX_OBS(3, false, hex3); break;
-      default: OSG_HEX_OBS(4, false, hex4); break;
+      case 1: OSG_HEX_OBS(1, hex1); break;
+      case 2: OSG_HEX_OBS(2, hex2); break;
+      case 3: OSG_HEX_OBS(3, hex3); break;
+      default: OSG_HEX_OBS(4, hex4); break;
     }
 #undef OSG_HEX_OBS
   } else if (size <= kRowsMaxSize && b->spec.desc.game_kind != kHex && (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0) {

@@ -1226,17 +1226,15 @@ int launch_mcts_wave(const osg_batch* roots, const osg_mcts_cfg& cfg, const doub
     case kHex: {
       // The random-fill playout needs "legal moves == empty cells": not with the swap rule.  The search's own
       // position (HexW) needs two distinct edges per colour.
-#define OSG_HEX_CASE(NW, FOLD, member)                                                             \
-  if (spec.member.swap || spec.member.rows < 2 || spec.member.cols < 2)                            \
-    rc = launch<HexT<NW, FOLD>, true, false>(spec.member, roots, cfg, d_logs, pool, out);          \
-  else rc = launch<HexT<NW, FOLD>, true, true>(spec.member, roots, cfg, d_logs, pool, out)
-      switch (spec.hex_nw) {
-        case 1: OSG_HEX_CASE(1, false, hex1); break;
-        case 2: OSG_HEX_CASE(2, false, hex2); break;
-        case 3:   // (hex(9) keeps its meta word in the planes' spare bits: only the root load differs)
-          if (spec.hex_fold) { OSG_HEX_CASE(3, true, hex3); } else { OSG_HEX_CASE(3, false, hex3); }
-          break;
-        default: OSG_HEX_CASE(4, false, hex4); break;
+#define OSG_HEX_CASE(NW, member)                                                             \
+  if (spec.member.swap || spec.member.rows < 2 || spec.member.cols < 2)                      \
+    rc = launch<HexT<NW>, true, false>(spec.member, roots, cfg, d_logs, pool, out);          \
+  else rc = launch<HexT<NW>, true, true>(spec.member, roots, cfg, d_logs, pool, out)
+      switch (spec.hex_nw) {   // (a folded record — HexT::folded — differs in the root load only)
+        case 1: OSG_HEX_CASE(1, hex1); break;
+        case 2: OSG_HEX_CASE(2, hex2); break;
+        case 3: OSG_HEX_CASE(3, hex3); break;
+        default: OSG_HEX_CASE(4, hex4); break;
       }
 #undef OSG_HEX_CASE
       break;

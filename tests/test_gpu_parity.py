@@ -314,7 +314,7 @@ def test_hex_above_128_actions_where_the_boundary_stops(ctx):
     import torch
     import open_spiel_amd as osa
     b = osa.StateBatch(ctx, "hex(board_size=19)", 64)
-    assert b.desc.num_distinct_actions == 361 and b.desc.mask_words == 12 and b.desc.state_words == 49
+    assert b.desc.num_distinct_actions == 361 and b.desc.mask_words == 12 and b.desc.state_words == 48   # (4 x 12 plane words; the meta word folded in)
     b.random_steps(5, 30)
     assert int(b.legal_actions_mask().sum()) == 64 * (361 - 30)
     with pytest.raises(osa.OsgError, match="128 actions"):

@@ -35,11 +35,9 @@ HOT = [
 ]
 # Hot kernels whose parked registers are known, measured and kept (the note says where the decision is recorded).
 KNOWN = {
-    "k_mcts_wave<osg::HexT<3, false>, true, true, false>":
+    "k_mcts_wave<osg::HexT<3>, true, true, false>":
         "44 scalar registers parked in vector lanes + 2 vector registers in scratch at 7 waves per SIMD; the form without them "
         "measured 2.7 % slower (profiles/r05_ab_register_work.txt, osg_mcts_wave.hip above wave_search)",
-    "k_mcts_wave<osg::HexT<3, true>, true, true, false>":
-        "the same kernel on the 12-word hex(9) record (only the root load differs): the same parked registers",
 }
 
 

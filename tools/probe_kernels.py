@@ -30,10 +30,12 @@ for game, depth in [("connect_four", 12), ("tic_tac_toe", 3), ("hex(board_size=9
     b = osa.StateBatch(ctx, game, N); b.random_steps(3, depth)
     d = b.desc
     sb = d.state_words * d.state_word_bytes
-    # planes a query reads: hex keeps 4 NW + 1 words (black, white, two edge-connection planes, meta)
-    hex_nw = (d.state_words - 1) // 4 if game.startswith("hex") else 0
-    sb_legal = 4 * (2 * hex_nw + 1) if hex_nw else sb
-    sb_status = 4 if hex_nw else sb
+    # planes a query reads: hex keeps 4 NW + 1 words (black, white, two edge-connection planes, meta), or 4 NW with the
+    # meta word folded into the last word of each plane (then the meta bits come with those four words)
+    hex_nw = d.state_words // 4 if game.startswith("hex") else 0
+    hex_folded = bool(hex_nw) and d.state_words % 4 == 0
+    sb_legal = (4 * (2 * hex_nw + (2 if hex_folded else 1))) if hex_nw else sb
+    sb_status = (16 if hex_folded else 4) if hex_nw else sb
     dst = osa.StateBatch(ctx, game, N)
     mask, status = b.step_buffers()
     lm = b.legal_actions_mask()

@@ -83,7 +83,11 @@ namespace {
 constexpr int kWavesPerBlock = OSG_WAVES_PER_BLOCK;
 constexpr int kMaxPath = 160;
 // Where the hex playout's bookkeeping runs: 1 = on the vector unit (measured on MI355X, config 4: key threshold
-// 0 -> 1: 9.48e8 -> 1.003e9 sims/s; flood 0 -> 1: 9.89e8 -> 1.003e9), 0 = the scalar formulation.
+// 0 -> 1: 9.48e8 -> 1.003e9 sims/s; flood 0 -> 1: 9.89e8 -> 1.003e9), 0 = the scalar formulation.  Flood mode 2 (round 5:
+// the two exits on the vector unit as well, tested once per two steps — ~20 -> ~8 scalar instructions per pair of
+// steps) measured 1.105e9 -> 1.090e9: the vector pipe is as full as the scalar one (SQ_ACTIVE_INST_VALU 549 quad-cycles
+// per simulation against SQ_WAVE_CYCLES / 7 resident wavefronts = 503, SQ_ACTIVE_INST_SCA 382), so moving work across
+// no longer pays (profiles/r05y_hex_flood_exits_ab.txt).
 #ifndef OSG_THR_MODE
 #define OSG_THR_MODE 1
 #endif
@@ -578,6 +582,42 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl PT_ARG
     reach0 |= g0;
     reach1 |= g1;
   }
+#elif OSG_FLOOD_MODE == 2
+  // As mode 1, with the two exits decided on the VECTOR unit too and only once per TWO steps: every lane remembers
+  // whether one of its cells that joined lies on the last row (the "black arrived" exit) and whether its cells joined
+  // in the second step (the "nothing new" exit); each exit is one compare into vcc and one branch.  Running one step
+  // past either condition is harmless: an empty frontier stays empty, and a last-row cell that joined stays remembered.
+  uint64_t front0 = blk0 & hl.first_row[0], front1 = blk1 & hl.first_row[1];
+  uint32_t avail0 = __builtin_amdgcn_inverse_ballot_w64(blk0 & ~front0) ? ~0u : 0u;
+  uint32_t avail1 = __builtin_amdgcn_inverse_ballot_w64(blk1 & ~front1) ? ~0u : 0u;
+  if (((front0 & hl.last_row[0]) | (front1 & hl.last_row[1])) != 0ull) return 0;  // a one-row chain
+  // all ones where the lane's cell is on the last row (edge bit 1 of cell l, bit 5 of cell l + 64)
+  const uint32_t last0 = static_cast<uint32_t>(static_cast<int32_t>(hl.edge << 30) >> 31);
+  const uint32_t last1 = static_cast<uint32_t>(static_cast<int32_t>(hl.edge << 26) >> 31);
+  uint32_t hit;  // (lane-local) one of the lane's cells that joined in this pair of steps lies on the last row
+  for (;;) {
+    const uint64_t x0 = (hl.nb_lo[0] & front0) | (hl.nb_hi[0] & front1);
+    const uint64_t x1 = (hl.nb_lo[1] & front0) | (hl.nb_hi[1] & front1);
+    const uint32_t ja0 = (static_cast<uint32_t>(x0) | static_cast<uint32_t>(x0 >> 32)) & avail0;
+    const uint32_t ja1 = (static_cast<uint32_t>(x1) | static_cast<uint32_t>(x1 >> 32)) & avail1;
+    const uint64_t mid0 = __ballot(ja0 != 0u), mid1 = __ballot(ja1 != 0u);
+    avail0 = ja0 != 0u ? 0u : avail0;
+    avail1 = ja1 != 0u ? 0u : avail1;
+    const uint64_t y0 = (hl.nb_lo[0] & mid0) | (hl.nb_hi[0] & mid1);
+    const uint64_t y1 = (hl.nb_lo[1] & mid0) | (hl.nb_hi[1] & mid1);
+    const uint32_t jb0 = (static_cast<uint32_t>(y0) | static_cast<uint32_t>(y0 >> 32)) & avail0;
+    const uint32_t jb1 = (static_cast<uint32_t>(y1) | static_cast<uint32_t>(y1 >> 32)) & avail1;
+    front0 = __ballot(jb0 != 0u);
+    front1 = __ballot(jb1 != 0u);
+    avail0 = jb0 != 0u ? 0u : avail0;
+    avail1 = jb1 != 0u ? 0u : avail1;
+    // (both exits lead to the same place and the answer is read off `hit` there: the loop stays two compares into
+    // vcc and two branches, no exit-code bookkeeping on the scalar unit)
+    hit = ((ja0 | jb0) & last0) | ((ja1 | jb1) & last1);
+    if (__ballot(hit != 0u) != 0ull) break;            // black reached its last row
+    if (__ballot((jb0 | jb1) != 0u) == 0ull) break;    // nothing new: black's region is closed
+  }
+  return __ballot(hit != 0u) != 0ull ? 0 : 1;
 #else
   // The bookkeeping of the flood on the vector unit: every lane keeps, for its two cells, an all-ones word
   // while the cell is black and not reached yet ("available") and clears it when the cell joins; the scalar

@@ -292,7 +292,9 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
                 "frac_of_scalar_issue_bound": scalar_ns / ns_per_sim,
                 "note": "the scalar unit issues one instruction (ALU or branch) per 4 cycles per SIMD; with every wave "
                         "slot busy the search runs at that rate, so fewer scalar instructions per simulation is the "
-                        "lever (round 2: 652 + 83 -> 387 + 88 per simulation, 7.97e8 -> 1.12e9 simulations/s; the vector unit is now about as busy); "
+                        "lever (round 2: 652 + 83 -> 387 + 88 per simulation, 7.97e8 -> 1.12e9 simulations/s; the vector unit is now as busy — "
+                        "SQ_ACTIVE_INST_VALU 549 quad-cycles per simulation against SQ_WAVE_CYCLES / 7 resident wavefronts = 503 — and "
+                        "moving more scalar work onto it measured slower in round 5, profiles/r05y_hex_flood_exits_ab.txt); "
                         "instruction counts are per simulation of an 8192-root search from the empty board"}
 
     # ---- config 3: kuhn_poker CFRSolver (full-tree regret / strategy update kernel) ----

@@ -165,6 +165,7 @@ def cpu_baseline():
         "sample": (f"{units_n} connect_four env steps (Clone + LegalActions + ApplyAction + IsTerminal + "
                    f"Returns + CurrentPlayer per step) over a pool of {pool} seeded positions, "
                    f"{threads} threads, {secs_n:.1f} s; single thread {units1} steps in {secs1:.1f} s"),
+        "sample_short": f"{units_n} env steps, {pool} seeded positions, {threads} threads, {secs_n:.1f} s",
     }
     if kind == "reference":  # the restatement beside it, single thread, ~2 s: how representative the port is
         import oracle_py
@@ -926,9 +927,7 @@ def ttt_mcts_config1(with_cpu):
                                              "first 6144 nodes of the tree live in LDS, the searching wavefront runs in lockstep — a node's "
                                              "children are valued one per lane, its 20 playouts played one per lane), whole SearchNode tree "
                                              "downloaded; a lone wavefront retires an instruction every ~8 cycles, so a strictly sequential "
-                                             "1000-simulation search stays behind one host core: the batch entry points are the product",
-                                     "kernel_us_per_simulation": {"descent_and_expansion": 6.3, "playouts": 3.7, "backup": 1.3,
-                                                                  "source": "profiles/r04_single_root_phases.log"}}
+                                             "1000-simulation search stays behind one host core: the batch entry points are the product"}
     except Exception as e:  # noqa: BLE001
         out["device_single_root"] = {"error": f"{type(e).__name__}: {e}"}
     if with_cpu:
@@ -1178,6 +1177,213 @@ def measure_pmc(timeout_s=150):
     return res if len(res) > 1 else None
 
 
+LINE_LIMIT = 4096                 # the final stdout line stays under this (a ~16 KiB line was dropped by the driver in round 5)
+DETAIL_FILE = "bench_detail.json"
+
+
+def _sig(x, digits=6):
+    """Numbers of the compact line carry 6 significant digits (the full-precision record is bench_detail.json)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def _pruned(d):
+    return {k: v for k, v in d.items() if v is not None}
+
+
+def compact_line(full, detail_path=DETAIL_FILE):
+    """The ONE line the driver keeps: the contract's fields, the headline's roofline and cpu_baseline objects and, per
+    secondary workload, {value, unit, bound / frac, what was parity-checked} — scalars only (plus per-rank arrays of
+    n_gpus numbers at N > 1), no prose.  Everything else (notes, sources, per-position tables, quality curves, the
+    roofline legs in full) is in `full`, which main() writes to bench_detail.json and prints as an EARLIER stdout line.
+    tests/test_bench_line.py holds this under LINE_LIMIT characters on canned N = 1 and N = 8 records."""
+    rf = full.get("roofline") or {}
+    n = _get(full, "config", "states_per_gpu")
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["metric"] = "env-steps/sec (batched LegalActions+ApplyAction+status, connect_four)"
+    if (full.get("n_gpus") or 1) > 1:
+        line["collective_backend"] = full.get("collective_backend")
+        line["rccl_world"] = full.get("rccl_world")
+    line["config"] = _pruned({
+        "workload": f"connect_four fused LegalActions+ApplyAction+status, 2^{(n or 1).bit_length() - 1} states/GPU, seed 0x5EED",
+        "states_per_gpu": n, "launches_per_step": _get(full, "config", "launches_per_step"),
+        "env_steps_per_step": _get(full, "config", "env_steps_per_step"),
+        "parallelism": f"{full.get('n_gpus')} independent shard(s), no collective"})
+    line["roofline"] = _pruned({
+        "bound": "hbm", "kernel": rf.get("kernel"), "achieved": rf.get("achieved"), "peak": rf.get("peak"),
+        "unit": rf.get("unit"), "frac": rf.get("frac"), "traffic": rf.get("traffic"),
+        "algorithmic_bytes_per_launch": rf.get("algorithmic_bytes_per_launch"), "avg_launch_us": rf.get("avg_launch_us"),
+        "launches_timed": rf.get("launches_timed"), "resident_in": rf.get("bound") if rf.get("bound") != "hbm" else None,
+        "traffic_measured_in_this_run": rf.get("traffic_measured_in_this_run"),
+        "copy_gbs": _get(rf, "copy_ceiling", "gbs"), "frac_of_copy": rf.get("frac_of_copy_ceiling"),
+        "hbm_frac": rf.get("hbm_frac"), "hbm_achieved": rf.get("hbm_achieved"), "hbm_avg_launch_us": rf.get("hbm_avg_launch_us"),
+        "hbm_states": rf.get("hbm_states"), "hbm_traffic": rf.get("hbm_traffic"),
+        "hbm_frac_of_copy": rf.get("hbm_frac_of_copy_ceiling")})
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = _pruned({"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"),
+                                        "kind": cb.get("kind"), "single_thread_value": cb.get("single_thread_value"),
+                                        "sample": cb.get("sample_short") or (cb.get("sample") or "")[:90],
+                                        "gpu_over_cpu": cb.get("gpu_over_cpu")})
+    line["parity_checked_states"] = full.get("parity_checked_states", 0)
+    line["parity_against"] = _get(full, "parity", "against")
+    pr = full.get("per_rank")
+    if pr:
+        line["per_rank"] = {"env_steps_per_s": pr.get("env_steps_per_s"), "avg_launch_us": pr.get("avg_launch_us")}
+    sec = full.get("secondary")
+    if isinstance(sec, dict) and "error" in sec:
+        line["secondary"] = {"error": str(sec["error"])[:200]}
+    elif isinstance(sec, dict):
+        out = {}
+        m = sec.get("mcts") or {}
+        if m:
+            out["mcts"] = _pruned({
+                "value": m.get("value"), "unit": m.get("unit"), "workload": "hex(9) 2^16 roots x 1024 sims",
+                "bound": "scalar_issue" if _get(m, "roofline", "frac_of_scalar_issue_bound") is not None else None,
+                "frac": _get(m, "roofline", "frac_of_scalar_issue_bound"),
+                "parity_checked_roots": m.get("parity_checked_roots"), "cpu_value": _get(m, "cpu_baseline", "value"),
+                "cpu_cores": _get(m, "cpu_baseline", "cores"),
+                "per_rank_sims_per_s": m.get("per_rank_sims_per_s"),
+                "single_rank_all_roots": _get(m, "single_rank_all_roots", "value"),
+                "strong_scaling_efficiency": m.get("strong_scaling_efficiency")})
+        c = sec.get("cfr") or {}
+        if c:
+            out["cfr"] = _pruned({
+                "value": c.get("value"), "unit": c.get("unit"), "workload": "kuhn_poker CFRSolver",
+                "bound": "wave_issue" if _get(c, "roofline", "frac") is not None else None, "frac": _get(c, "roofline", "frac"),
+                "parity_checked_iterations": c.get("parity_checked_iterations"),
+                "parity_max_rel_error": _get(c, "parity", "max_table_rel_error"),
+                "cpu_value": _get(c, "cpu_baseline", "value"), "replicas_value": _get(c, "replicas", "value")})
+            l2 = c.get("leduc") or {}
+            if "value" in l2:
+                out["cfr_leduc"] = _pruned({"value": l2.get("value"), "unit": l2.get("unit"),
+                                            "parity_checked_iterations": l2.get("parity_checked_iterations"),
+                                            "cpu_value": _get(l2, "cpu_baseline", "value")})
+            elif "error" in l2:
+                out["cfr_leduc"] = {"error": str(l2["error"])[:120]}
+            l3 = c.get("leduc_3_players") or {}
+            if l3:
+                out["cfr_leduc_3p"] = _pruned({"value": l3.get("value"), "unit": l3.get("unit"), "bound": "hbm",
+                                               "frac": l3.get("frac_of_hbm_peak"), "kernel": l3.get("kernel"),
+                                               "parity_checked_iterations": l3.get("parity_checked_iterations"),
+                                               "parity_max_rel_error": _get(l3, "parity", "max_table_rel_error"),
+                                               "cpu_value": _get(l3, "cpu_baseline", "value")})
+        x = sec.get("mccfr") or {}
+        if x:
+            ar = None
+            if x.get("allreduce_us") is not None:
+                key = "rccl" if "nccl" in str(x.get("allreduce_backend")) else str(x.get("allreduce_backend", "host")).split()[-1]
+                ar = _pruned({key: x.get("allreduce_us"), "oneshot": _get(x, "oneshot", "allreduce_us")})
+            out["mccfr"] = _pruned({
+                "value": x.get("value"), "unit": x.get("unit"), "workload": "leduc_poker ES-MCCFR 16 x 2^20",
+                "bound": "latency" if x.get("roofline") else None,
+                "frac_of_scalar_issue": _get(x, "roofline", "frac_of_scalar_issue_bound"),
+                "waves_per_simd": _get(x, "roofline", "waves_per_simd"),
+                "parity_checked_trajectories": x.get("parity_checked_trajectories"),
+                "parity_max_error_over_tolerance": _get(x, "parity", "max_error_over_tolerance"),
+                "nash_conv_after": x.get("nash_conv_after"), "cpu_value": _get(x, "cpu_baseline", "value"),
+                "allreduce_us": ar, "allreduce_bytes": x.get("allreduce_bytes"),
+                "oneshot_trajectories_per_s": _get(x, "oneshot", "trajectories_per_s"),
+                "oneshot_error": str(_get(x, "oneshot", "error"))[:120] if _get(x, "oneshot", "error") else None,
+                "tables_finite": x.get("tables_finite"),
+                "seconds_to_nash_conv_0.1": _get(x, "quality", "seconds_to_nash_conv", "0.1", "seconds")})
+        e = sec.get("env_step") or {}
+        if "value" in e:
+            out["env_step"] = _pruned({"value": e.get("value"), "unit": e.get("unit"), "bound": "infinity_cache",
+                                       "frac": _get(e, "roofline", "frac_back_to_back"),
+                                       "frac_per_launch_events": _get(e, "roofline", "frac"),
+                                       "kernel_us": _get(e, "roofline", "kernel_us_back_to_back")})
+        elif "error" in e:
+            out["env_step"] = {"error": str(e["error"])[:120]}
+        h = sec.get("hex_step") or {}
+        if "value" in h:
+            out["hex_step"] = _pruned({"value": h.get("value"), "unit": h.get("unit"), "states": h.get("states"),
+                                       "bound": _get(h, "roofline", "bound"),
+                                       "frac": _get(h, "roofline", "frac_on_bytes_moved"),
+                                       "frac_on_survey_bytes": _get(h, "roofline", "frac"),
+                                       "kernel_us": h.get("kernel_us_per_launch"),
+                                       "parity_checked_states": h.get("parity_checked_states")})
+        elif "error" in h:
+            out["hex_step"] = {"error": str(h["error"])[:120]}
+        pe = _get(sec, "policy_evaluation", "per_game") or {}
+        if pe:
+            out["nash_conv_us"] = _pruned({"kuhn": _get(pe, "kuhn_poker", "us_per_nash_conv"),
+                                           "leduc": _get(pe, "leduc_poker", "us_per_nash_conv"),
+                                           "leduc_3p": (_get(pe, "leduc_poker(players=3)", "ms_per_nash_conv") or 0) * 1e3 or None})
+        t = sec.get("ttt_mcts") or {}
+        if t:
+            out["ttt_mcts"] = _pruned({"value": _get(t, "device_single_root", "value"), "unit": "sims/s",
+                                       "cpu_value": _get(t, "cpu_baseline", "value"), "cpu_cores": _get(t, "cpu_baseline", "cores"),
+                                       "error": (str(_get(t, "device_single_root", "error"))[:120]
+                                                 if _get(t, "device_single_root", "error") else None)})
+        line["secondary"] = out
+    p = full.get("persistent")
+    if p:
+        line["persistent"] = _pruned({"value": p.get("value"), "unit": p.get("unit"), "k": p.get("k"),
+                                      "bound": "vector_issue" if p.get("roofline") else None,
+                                      "frac": _get(p, "roofline", "frac_of_vector_issue_bound")})
+    line["detail"] = detail_path
+
+    def rounded(o):
+        if isinstance(o, dict):
+            return {k: rounded(v) for k, v in o.items()}
+        return _sig(o)
+    line = rounded(line)
+    # last resort, so that the driver's record never loses the headline: shed the secondary objects, widest first
+    while len(json.dumps(line)) >= LINE_LIMIT and isinstance(line.get("secondary"), dict) and line["secondary"]:
+        widest = max(line["secondary"], key=lambda k: len(json.dumps(line["secondary"][k])))
+        del line["secondary"][widest]
+        line["secondary_truncated"] = True
+    return line
+
+
+def read_lines(stdout):
+    """(compact line, full record) out of a bench.py run's stdout: the compact line is the LAST line, the full record
+    the earlier {"bench_detail": ...} line."""
+    rows = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert rows and len(rows[-1]) < LINE_LIMIT, (len(rows), len(rows[-1]) if rows else 0)
+    full = next((json.loads(ln)["bench_detail"] for ln in reversed(rows[:-1]) if ln.startswith('{"bench_detail"')), None)
+    return json.loads(rows[-1]), full
+
+
+def emit(full):
+    """bench_detail.json (+ the same record as an earlier stdout line, wrapped so that it never looks like the bench
+    line), then the compact line LAST."""
+    detail_path = DETAIL_FILE
+    for d in (os.environ.get("OSG_BENCH_DETAIL_DIR"), ROOT, os.getcwd()):
+        if not d:
+            continue
+        try:
+            with open(os.path.join(d, DETAIL_FILE), "w") as f:
+                json.dump(full, f, indent=1)
+            detail_path = os.path.relpath(os.path.join(d, DETAIL_FILE), ROOT) if d.startswith(ROOT) else os.path.join(d, DETAIL_FILE)
+            break
+        except OSError:
+            continue
+    print(json.dumps({"bench_detail": full}), flush=True)
+    line = compact_line(full, detail_path)
+    text = json.dumps(line, allow_nan=False)
+    assert len(text) < LINE_LIMIT, len(text)
+    print(text, flush=True)
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1358,6 +1564,8 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic", "collective_backend": backend if world > 1 else None,
+            # what the process group itself reports (the first real N > 1 run must show RCCL carried it)
+            "rccl_world": (dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else None),
             "config": {"workload": f"connect_four fused step, {n} states/GPU (2^{n.bit_length() - 1}), "
                                    f"out-of-place SoA bitboards, seed 0x5EED; one step = {LAUNCHES_PER_STEP} "
                                    f"back-to-back launches over the batch ({LAUNCHES_PER_STEP} x {n} env-steps per GPU)",
@@ -1389,10 +1597,7 @@ def main():
                                  "note": "a wave64 vector instruction issues every 1.03 ns per SIMD at best (64-bit "
                                          "shifts, multiplies: 1.8-1.9 ns), so the fraction is a lower bound of the "
                                          "vector unit's busy share",
-                                 "measured_vector_pipe_busy": 0.98,
-                                 "measured_source": "profiles/r04_pmc_k_random_steps_c4_k32.txt: SQ_ACTIVE_INST_VALU x 4 cycles / "
-                                                    "1024 SIMDs = 252 K of the launch's 257 K cycles; the waves wait for the pipe "
-                                                    "(SQ_WAIT_INST_ANY 72 % of wave cycles), not for memory (SQ_WAIT_ANY 8.5 %)"}
+                                 }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
@@ -1400,7 +1605,7 @@ def main():
                 line["cpu_baseline"]["note"] = "timed on rank 0's host while the other ranks wait on a socket barrier"
         if secondary is not None:
             line["secondary"] = secondary
-        print(json.dumps(line), flush=True)
+        emit(line)
     host_barrier()
     if world > 1:
         dist.destroy_process_group()

@@ -244,24 +244,31 @@ def test_bench_two_ranks_code_path(tmp_path):
            "--no-cpu-baseline", "--no-pmc", "--states", str(1 << 16)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["value"] > 0 and line["collective_backend"] == "gloo"
+    sys.path.insert(0, root)
+    import bench
+    line, full = bench.read_lines(r.stdout)          # the < 4 KB line the driver keeps, and the full record printed before it
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["collective_backend"] == "gloo" and line["rccl_world"] is None
     assert len(line["per_rank"]["env_steps_per_s"]) == 2 and min(line["per_rank"]["env_steps_per_s"]) > 0
-    assert "copy_ceiling" in line["roofline"] and "persistent" in line
+    assert len(line["per_rank"]["avg_launch_us"]) == 2
+    assert line["roofline"]["copy_gbs"] > 0 and line["persistent"]["value"] > 0
     sec = line["secondary"]
-    assert "error" not in sec, sec
+    assert "error" not in sec and "secondary_truncated" not in line, sec
     assert sec["mcts"]["value"] > 0 and len(sec["mcts"]["per_rank_sims_per_s"]) == 2
-    assert sec["mcts"]["single_rank_all_roots"]["value"] > 0 and sec["mcts"]["strong_scaling_efficiency"] > 0
-    assert sec["mccfr"]["tables_finite"] and sec["mccfr"]["allreduce_us"] > 0 and sec["mccfr"]["allreduce_bytes"] == 44928
-    shot = sec["mccfr"]["oneshot"]   # the one-shot all-reduce carries the same exchange step (two ranks on this one device)
-    assert "error" not in shot, shot
+    assert sec["mcts"]["single_rank_all_roots"] > 0 and sec["mcts"]["strong_scaling_efficiency"] > 0
+    assert sec["mccfr"]["tables_finite"] and sec["mccfr"]["allreduce_us"]["gloo"] > 0 and sec["mccfr"]["allreduce_bytes"] == 44928
+    # the one-shot all-reduce carries the same exchange step (two ranks on this one device)
     # (two bench processes time-share this ONE device: a spinning one-shot kernel can wait a scheduling quantum for
     # its peer's queue — 5.5 us in tests/test_z10_gpu_oneshot_allreduce.py, up to ~16 ms here; one rank per GPU has no such wait)
-    assert 0 < shot["allreduce_us"] < 2e5 and shot["trajectories_per_s"] > 0 and shot["nash_conv_after"] < 4.7
-    assert line["parity_checked_states"] == 1 << 16 and line["parity"]["against"] in ("reference", "port")
-    q = sec["mccfr"]["quality"]
+    assert "oneshot_error" not in sec["mccfr"], sec["mccfr"]
+    assert 0 < sec["mccfr"]["allreduce_us"]["oneshot"] < 2e5 and sec["mccfr"]["oneshot_trajectories_per_s"] > 0
+    assert line["parity_checked_states"] == 1 << 16 and line["parity_against"] in ("reference", "port")
+    assert sec["ttt_mcts"]["value"] > 0
+    fsec = full["secondary"]
+    assert "copy_ceiling" in full["roofline"] and fsec["mccfr"]["oneshot"]["nash_conv_after"] < 4.7
+    q = fsec["mccfr"]["quality"]
     assert q["world"] == 2 and q["nash_conv"] < 4.7 and q["overlapped"]["nash_conv"] < 4.7
-    assert sec["ttt_mcts"]["device_single_root"]["value"] > 0
+    with open(os.path.join(root, line["detail"])) as f:
+        assert json.load(f)["value"] == full["value"]
 
 
 def test_hex9_mcts_2pow16_roots_under_full_load(oracle, ctx):

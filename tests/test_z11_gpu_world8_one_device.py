@@ -152,15 +152,17 @@ def test_bench_eight_ranks_code_path():
            "--no-cpu-baseline", "--no-pmc", "--states", str(1 << 16)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == WORLD and line["value"] > 0 and line["collective_backend"] == "gloo"
+    import bench
+    line, full = bench.read_lines(r.stdout)          # the line is < 4 KB with eight ranks' arrays in it
+    assert line["n_gpus"] == WORLD and line["value"] > 0 and line["collective_backend"] == "gloo" and "rccl_world" in line
     assert len(line["per_rank"]["env_steps_per_s"]) == WORLD and min(line["per_rank"]["env_steps_per_s"]) > 0
     sec = line["secondary"]
-    assert "error" not in sec, sec
+    assert "error" not in sec and "secondary_truncated" not in line, sec
     assert sec["mcts"]["value"] > 0 and len(sec["mcts"]["per_rank_sims_per_s"]) == WORLD
     assert sec["mcts"]["strong_scaling_efficiency"] > 0
     assert sec["mccfr"]["tables_finite"] and sec["mccfr"]["allreduce_bytes"] == 44928
-    shot = sec["mccfr"]["oneshot"]
-    assert "error" not in shot, shot
-    assert shot["allreduce_us"] > 0 and shot["trajectories_per_s"] > 0 and shot["nash_conv_after"] < 4.7
-    assert sec["mccfr"]["quality"]["world"] == WORLD
+    assert "oneshot_error" not in sec["mccfr"], sec["mccfr"]
+    assert sec["mccfr"]["allreduce_us"]["gloo"] > 0 and sec["mccfr"]["allreduce_us"]["oneshot"] > 0
+    assert sec["mccfr"]["oneshot_trajectories_per_s"] > 0
+    assert full["secondary"]["mccfr"]["oneshot"]["nash_conv_after"] < 4.7
+    assert full["secondary"]["mccfr"]["quality"]["world"] == WORLD

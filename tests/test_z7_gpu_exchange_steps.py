@@ -339,6 +339,8 @@ def test_bench_gpus_2_over_rccl(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--no-cpu-baseline", "--no-pmc"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["collective_backend"] == "nccl"
-    assert line["secondary"]["mccfr"]["allreduce_us"] > 0 and 0 < line["secondary"]["mcts"]["strong_scaling_efficiency"] < 1.5
+    import bench
+    line, _full = bench.read_lines(r.stdout)
+    assert line["n_gpus"] == 2 and line["collective_backend"] == "nccl" and line["rccl_world"] == 2
+    assert line["secondary"]["mccfr"]["allreduce_us"]["rccl"] > 0 and line["secondary"]["mccfr"]["allreduce_us"]["oneshot"] > 0
+    assert 0 < line["secondary"]["mcts"]["strong_scaling_efficiency"] < 1.5

@@ -45,6 +45,7 @@
 #include "osg_json.h"
 
 namespace open_spiel {
+constexpr const char* kSerializeStartingState = "starting_state=";  // spiel.h:50
 namespace hip {
 
 using Action = int64_t;  // spiel_utils.h:134-135
@@ -741,6 +742,9 @@ class State {
       SpielFatalError("UndoAction: (player, action) is not the last move of this state");
     std::vector<std::pair<Player, Action>> keep(history_.begin(), history_.end() - 1);
     BatchedState fresh(batch_.GetGame(), 1);
+    // a state built from a struct / JSON / board string starts at that position, not at the empty board
+    if (!starting_cells_.empty())
+      Check(osg_batch_set_cells(fresh.handle(), 0, starting_cells_.data(), static_cast<int>(starting_cells_.size())));
     for (const auto& pa : keep) fresh.ApplyActions({static_cast<int32_t>(pa.second)});
     batch_ = std::move(fresh);
     snap_ = Snapshot{};
@@ -891,12 +895,17 @@ class State {
   StateType GetType() const {  // spiel.h:808
     return IsTerminal() ? StateType::kTerminal : (IsChanceNode() ? StateType::kChance : StateType::kDecision);
   }
-  // State::Serialize (spiel.cc:411-430): the action history, one action per line.
+  // State::Serialize (spiel.cc:411-430): "starting_state=<ToJson of the starting position>" first when the state was
+  // built from a struct (tic_tac_toe.cc:336, connect_four.cc:512), then the action history, one action per line.
   std::string Serialize() const {
     std::string out;
+    if (!starting_state_str_.empty()) out += std::string(kSerializeStartingState) + starting_state_str_ + "\n";
     for (const auto& pa : history_) out += std::to_string(pa.second) + "\n";
-    return history_.empty() ? std::string("\n") : out;
+    return history_.empty() ? out + "\n" : out;
   }
+  // spiel.h:892, 1257-1262
+  std::string StartingStateStr() const { return starting_state_str_; }
+  inline std::unique_ptr<State> StartingState() const;
   // ---- the struct API (spiel.h:340-473, 728-734; tic_tac_toe.cc:178-213, connect_four.cc:224-275) ----
   std::unique_ptr<StateStruct> ToStruct() const {
     const std::string name = ShortName();
@@ -1016,7 +1025,11 @@ class State {
     Check(osg_batch_set_cells(batch_.handle(), 0, cells.data(), static_cast<int>(cells.size())));
     snap_ = Snapshot{};
     history_.clear();
+    starting_cells_ = cells;
+    starting_state_str_.clear();   // (the struct constructors set it once their validation has passed)
   }
+  // tic_tac_toe.cc:336, connect_four.cc:512: "Store the starting state for serialization"
+  void RememberStartingState() { starting_state_str_ = ToJson(); }
   std::string ShortName() const {
     const std::string text = batch_.GetGame()->ToString();
     return text.substr(0, text.find('('));
@@ -1048,6 +1061,8 @@ class State {
   BatchedState batch_;
   mutable Snapshot snap_;
   std::vector<std::pair<Player, Action>> history_;
+  std::string starting_cells_;       // the position SetCells installed ("" = the game's initial state): UndoAction's base
+  std::string starting_state_str_;   // spiel.h:915
 };
 
 inline std::ostream& operator<<(std::ostream& stream, const State& state) { return stream << state.ToString(); }  // spiel.h:918
@@ -1091,6 +1106,7 @@ class TicTacToeState : public State {
     const std::string who = cur == 0 ? "x" : (cur == 1 ? "o" : DefaultPlayerString(cur));
     if (state_struct.current_player != who)
       SpielFatalError("Invalid current player: expected " + who + ", got " + state_struct.current_player);
+    RememberStartingState();
   }
 };
 }  // namespace tic_tac_toe
@@ -1176,6 +1192,7 @@ class ConnectFourState : public State {
       if (state_struct.current_player != DefaultPlayerString(kTerminalPlayerId))
         SpielFatalError("Invalid current_player for terminal state: expected '" + DefaultPlayerString(kTerminalPlayerId) + "', got '" +
                         state_struct.current_player + "'.");
+      RememberStartingState();
       return;
     }
     if (state_struct.current_player != "x" && state_struct.current_player != "o")
@@ -1187,6 +1204,7 @@ class ConnectFourState : public State {
       SpielFatalError("Invalid current_player: with " + counts + " pieces, it should be " + by_count + "'s turn, but struct says '" +
                       state_struct.current_player + "'" + (strict_validation ? "." : " (a position whose mover differs from the stone "
                       "count's parity is not representable on the device)."));
+    RememberStartingState();
   }
 };
 inline std::unique_ptr<State> ConnectFourGame::NewInitialState(const ConnectFourStateStruct& state_struct, bool strict_validation) const {
@@ -1209,9 +1227,22 @@ inline std::unique_ptr<State> Game::NewInitialState(const Json& json) const {
   if (name == "connect_four") return NewInitialState(connect_four::ConnectFourStateStruct(json));
   SpielFatalError("NewInitialState from JSON is not implemented.");
 }
+inline std::unique_ptr<State> State::StartingState() const {
+  if (!starting_state_str_.empty()) return GetGame()->NewInitialState(Json::parse(starting_state_str_));
+  return nullptr;
+}
 inline std::unique_ptr<State> Game::DeserializeState(const std::string& str) const {
-  std::unique_ptr<State> state = NewInitialState();
+  std::unique_ptr<State> state;
   size_t pos = 0;
+  const size_t tag = std::strlen(kSerializeStartingState);
+  if (str.compare(0, tag, kSerializeStartingState) == 0) {   // spiel.cc:550-558: the first line is the starting position
+    size_t nl = str.find('\n');
+    if (nl == std::string::npos) nl = str.size();
+    state = NewInitialState(str.substr(tag, nl - tag));
+    pos = nl + 1;
+  } else {
+    state = NewInitialState();
+  }
   while (pos < str.size()) {
     size_t nl = str.find('\n', pos);
     if (nl == std::string::npos) nl = str.size();

@@ -523,6 +523,8 @@ PYBIND11_MODULE(pyspiel_hip, m) {
       .def("distribution_support", &State::DistributionSupport)
       .def("update_distribution", &State::UpdateDistribution, py::arg("distribution"))
       .def("serialize", &State::Serialize)
+      .def("starting_state", &State::StartingState)          // pyspiel.cc:459-460
+      .def("starting_state_str", &State::StartingStateStr)
       .def(py::pickle(  // pyspiel.cc:455-474: a state pickles as its game-and-state text
           [](const State& s) { return SerializeGameAndState(*s.GetGame(), s); },
           [](const std::string& t) { return std::move(DeserializeGameAndState(t).second); }))

@@ -153,6 +153,15 @@ class Game:
             _ptr(out["rets1"], C.c_double), _ptr(out["obs1"], C.c_uint8)))
         return out
 
+    def synth_tensors(self, seed, n, depth_mod, which, player, first=0, threads=1, after=False):
+        """ObservationTensor (which=0) / InformationStateTensor (1) of `player` for states first .. first + n - 1 of the
+        synthetic stream, before their action or (after=True) after it, as uint8 [n, size]."""
+        size = self.observation_tensor_size if which == 0 else self.information_state_tensor_size
+        out = np.zeros((n, size), np.uint8)
+        _check(lib().osgo_synth_tensors(self._h, C.c_uint64(seed), C.c_int64(first), C.c_int64(n), int(depth_mod),
+                                        int(threads), int(which), int(player), int(bool(after)), _ptr(out, C.c_uint8)))
+        return out
+
     def synth_mcts_replay(self, seed_roots, n, depth_mod, uct_c, max_simulations, n_rollouts, counter_seed,
                           counter_layout, first=0, threads=1):
         """Replay-mode MCTSBot searches of the synthetic roots first .. first + n - 1 (restatement only)."""
@@ -506,3 +515,9 @@ class Solver:
         out = np.zeros(self.game.num_players, np.float64)
         _check(lib().osgo_cfr_expected_returns(self._h, _ptr(out, C.c_double)))
         return out
+
+    def best_response_value(self, player):
+        """TabularBestResponse(game, player, average policy).Value(root): one term of NashConv."""
+        out = C.c_double(0)
+        _check(lib().osgo_cfr_best_response_value(self._h, int(player), C.byref(out)))
+        return out.value

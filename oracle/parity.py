@@ -52,14 +52,18 @@ def mccfr_minibatch(impl, game_string, keys, nact, regrets_before, d_regrets, d_
             "max_error_over_mass": worst_mass, "tolerance_over_mass": 1e-11, "max_error_over_tolerance": worst}
 
 
-def cfr_tables(impl, game_string, kind, iterations, keys, nact, regrets, cum_policy, avg_policy, rtol=1e-9, policy_atol=1e-6):
+def cfr_tables(impl, game_string, kind, iterations, keys, nact, regrets, cum_policy, avg_policy, rtol=1e-9, policy_atol=1e-6,
+               solver=None):
     """The device's CFR tables after `iterations` EvaluateAndUpdatePolicy calls against the CPU solver run for the same
     number (cfr.cc:263-469): cumulative regrets and cumulative policy to `rtol` relative (the kernels perform the
     reference's additions in the reference's order, built without fused multiply-add: differences are the last ulps of
     libm-free arithmetic, observed <= 1e-12), the average policy to north_star's 1e-6 absolute."""
-    g = impl.Game(game_string)
-    s = impl.Solver(g, kind)
-    s.iterate(iterations)
+    if solver is None:
+        g = impl.Game(game_string)
+        s = impl.Solver(g, kind)
+        s.iterate(iterations)
+    else:
+        s = solver                                 # (a CPU solver the caller has already run for `iterations`)
     t = s.tables(regrets.shape[1])
     idx = {k: i for i, k in enumerate(keys)}
     assert sorted(idx) == sorted(t["keys"]), "infostate sets differ"
@@ -80,3 +84,55 @@ def cfr_tables(impl, game_string, kind, iterations, keys, nact, regrets, cum_pol
             raise AssertionError(f"{game_string} {kind} after {iterations} iterations: average policy of {k!r} off by {e}")
     return {"iterations": int(iterations), "infostates": len(keys), "max_table_rel_error": worst_tab,
             "max_average_policy_abs_error": worst_pol, "table_rtol": rtol, "average_policy_atol": policy_atol}
+
+
+def cfr_large_tree(impl, game_string, kinds, iterations, device, threads=2, best_response_player=0, rtol=1e-12):
+    """A tree too large to afford many CPU iterations (3-player leduc: 1.83 M histories, 6.7 s per reference iteration),
+    checked at size: for every solver kind ("cfr", "cfr_plus") the CPU solver — CFRSolver / CFRPlusSolver,
+    cfr.cc:263-469 — runs `iterations` iterations (kinds in parallel host threads: the solvers are independent objects)
+    and then judges its own average policy: ExpectedReturns (expected_returns.cc) and one player's
+    TabularBestResponse value (best_response.cc:194-227), a term of NashConv (tabular_exploitability.cc:77-89).
+
+    device[kind] = {"tables": TabularSolver.tables(), "expected_returns": [P], "best_response_values": [P]} after the
+    same number of iterations.  Every regret / cumulative-policy cell of every infostate to `rtol` relative, the average
+    policy to 1e-6, the two evaluations to 1e-11 absolute.  Returns the record; AssertionError on a mismatch."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(kind):
+        t0 = time.perf_counter()
+        g = impl.Game(game_string)
+        s = impl.Solver(g, kind)
+        s.iterate(iterations)
+        t_it = time.perf_counter() - t0
+        ev = s.expected_returns()
+        br = s.best_response_value(best_response_player) if best_response_player is not None else None
+        return s, g, ev, br, t_it, time.perf_counter() - t0
+
+    with ThreadPoolExecutor(max(1, min(threads, len(kinds)))) as pool:
+        done = dict(zip(kinds, pool.map(run, kinds)))
+    out = {"game": game_string, "iterations": int(iterations), "kinds": list(kinds), "table_rtol": rtol}
+    worst_tab = worst_pol = worst_ev = worst_br = 0.0
+    for kind in kinds:
+        s, _g, ev, br, t_it, t_all = done[kind]
+        d = device[kind]
+        t = d["tables"]
+        rec = cfr_tables(impl, game_string, kind, iterations, t["keys"], t["nact"], t["regrets"], t["cum_policy"],
+                         t["avg_policy"], rtol=rtol, solver=s)
+        out["infostates"] = rec["infostates"]
+        worst_tab = max(worst_tab, rec["max_table_rel_error"])
+        worst_pol = max(worst_pol, rec["max_average_policy_abs_error"])
+        e = float(np.abs(np.asarray(d["expected_returns"]) - ev).max())
+        assert e <= 1e-11, f"{game_string} {kind}: expected returns {d['expected_returns']!r} vs CPU {ev!r}"
+        worst_ev = max(worst_ev, e)
+        if br is not None:
+            e = abs(float(d["best_response_values"][best_response_player]) - br)
+            assert e <= 1e-11, (f"{game_string} {kind}: best-response value of player {best_response_player} "
+                                f"{d['best_response_values'][best_response_player]!r} vs CPU {br!r}")
+            worst_br = max(worst_br, e)
+        out[f"cpu_seconds_{kind}"] = t_all
+        out[f"cpu_seconds_per_iteration_{kind}"] = t_it / iterations
+    out.update(max_table_rel_error=worst_tab, max_average_policy_abs_error=worst_pol,
+               max_expected_returns_abs_error=worst_ev, max_best_response_value_abs_error=worst_br,
+               best_response_player=best_response_player)
+    return out

@@ -22,6 +22,7 @@
 #include <unordered_map>
 
 #ifdef OSGO_GENUINE_REFERENCE
+#include "open_spiel/algorithms/best_response.h"
 #include "open_spiel/algorithms/cfr.h"
 #include "open_spiel/algorithms/cfr_br.h"
 #include "open_spiel/algorithms/expected_returns.h"
@@ -495,6 +496,49 @@ int osgo_synth_batch(void* g, uint64_t seed, int64_t first, int64_t n, int depth
           if (mask1 || cur1 || term1 || rets1 || obs1) {
             s->ApplyAction(a);
             record(*s, i, mask1, cur1, term1, rets1, obs1);
+          }
+        }
+      } catch (const std::exception& e) {
+        errors[w] = e.what();
+      }
+    };
+    std::vector<std::thread> workers;
+    for (int w = 1; w < threads; ++w) workers.emplace_back(work, w);
+    work(0);
+    for (auto& t : workers) t.join();
+    for (const std::string& e : errors)
+      if (!e.empty()) Fatal(e);
+    return 0;
+  });
+}
+
+// The tensors of the same synthetic states for any player and either tensor kind (osgo_synth_batch records only
+// ObservationTensor(0)): state i of the stream before (after = 0) or after (1) its action, `which` = 0 ObservationTensor / 1
+// InformationStateTensor (spiel.cc:908-945 through the game's observer), as bytes [n, size] (every entry on this path
+// is a small non-negative integer).  Lets the large-batch tensor kernels meet the CPU entry by entry.
+int osgo_synth_tensors(void* g, uint64_t seed, int64_t first, int64_t n, int depth_mod, int threads, int which, int player,
+                       int after, uint8_t* out) {
+  return Guard([&] {
+    const std::string game_string = static_cast<GameH*>(g)->game->ToString();
+    threads = std::max(1, threads);
+    std::vector<std::string> errors(threads);
+    auto work = [&](int w) {
+      try {
+        std::shared_ptr<const Game> game = LoadGame(game_string);
+        const int size = which == 0 ? game->ObservationTensorSize() : InfoSize(*game);
+        if (size <= 0) Fatal("osgo_synth_tensors: the game has no such tensor");
+        std::vector<float> tensor(size);
+        const int64_t lo = n * w / threads, hi = n * (w + 1) / threads;
+        for (int64_t i = lo; i < hi; ++i) {
+          CounterRng rng(seed, static_cast<uint64_t>(first + i), kSynthSub);
+          int depth = 0;
+          std::unique_ptr<State> s = SynthState(*game, depth_mod, &rng, &depth);
+          if (after) s->ApplyAction(SynthDraw(*s, rng));   // the successor (terminal states among them), as osgo_synth_batch's
+          WriteTensor(*s, which, player, tensor.data(), size);
+          for (int k = 0; k < size; ++k) {
+            if (tensor[k] < 0.0f || tensor[k] > 255.0f || tensor[k] != static_cast<float>(static_cast<uint8_t>(tensor[k])))
+              Fatal("osgo_synth_tensors: a tensor entry is not a byte-sized integer");
+            out[i * size + k] = static_cast<uint8_t>(tensor[k]);
           }
         }
       } catch (const std::exception& e) {
@@ -1111,6 +1155,23 @@ int osgo_cfr_expected_returns(void* h, double* out) {
     std::shared_ptr<Policy> pol = c->Average();
     std::vector<double> v = ExpReturns(*c->game->NewInitialState(), *pol);
     for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    return 0;
+  });
+}
+
+// Value of `player`'s best response to the average policy at the root: TabularBestResponse(game, player, policy)
+// .Value(root) (best_response.h:57-72, best_response.cc:194-227) — one of the P terms NashConv sums
+// (tabular_exploitability.cc:77-89), so a large tree can be checked one player at a time.
+int osgo_cfr_best_response_value(void* h, int player, double* out) {
+  return Guard([&] {
+    auto* c = static_cast<CfrH*>(h);
+    std::shared_ptr<Policy> pol = c->Average();
+#ifdef OSGO_GENUINE_REFERENCE
+    open_spiel::algorithms::TabularBestResponse br(*c->game, player, pol.get());
+    *out = br.Value(*c->game->NewInitialState());
+#else
+    *out = BestResponseValue(*c->game, player, *pol);
+#endif
     return 0;
   });
 }

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: over a minute of reference CPU work (still part of -m gpu)")
 
 
 @pytest.fixture(scope="session")

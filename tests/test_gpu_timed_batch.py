@@ -170,6 +170,39 @@ def test_piece_form_tensors_equal_the_span_kernels(ctx, game, depth_mod, n):
             del whole
 
 
+@pytest.mark.parametrize("game,depth_mod,n", [("kuhn_poker", 3, (1 << 22) + 1), ("leduc_poker", 8, (1 << 21) + 3),
+                                              ("kuhn_poker(players=3)", 4, (1 << 21) + 1)])
+def test_piece_form_poker_tensors_against_the_checker(ctx, checker, game, depth_mod, n):
+    """The poker games' tensors at the sizes that take the piece-form kernels (>= 2^24 floats, odd state counts) DIRECTLY
+    against the CPU reference — kuhn_poker.cc:72-107, leduc_poker.cc:103-192 through State::ObservationTensor /
+    InformationStateTensor (spiel.cc:908-945) — entry by entry: both tensor kinds, every player, all states of the
+    synthetic stream and of their successors (chance nodes, decision nodes and terminal states among them)."""
+    import torch
+    import open_spiel_amd as osa
+    impl, kind = checker
+    b = osa.StateBatch(ctx, game, n)
+    actions, _ = b.synth(4242, depth_mod, index_offset=987654321)
+    og = impl.Game(game)
+    checked = 0
+    for after in (False, True):       # the synthetic states, then their successors (terminal states among them)
+        if after:
+            b.apply_actions(actions.to(torch.int32))
+            # (kuhn's stream stops at depth MaxGameLength() - 1 = 2 deals: its successors are decision nodes; leduc's end games)
+            assert game != "leduc_poker" or int(b.is_terminal().sum().item()) > 0
+        for which, name, size in ((0, "observation_tensor", b.desc.obs_size), (1, "information_state_tensor", b.desc.info_size)):
+            assert n * size >= 1 << 24, "below the piece-form threshold"
+            for player in range(b.num_players):
+                want = og.synth_tensors(4242, n, depth_mod, which, player, first=987654321, threads=_threads(), after=after)
+                got = getattr(b, name)(player)
+                assert got.dtype == torch.float32 and tuple(got.shape) == (n, size)
+                got8 = got.to(torch.uint8)
+                assert torch.equal(got8.to(torch.float32), got), "entries are small integers"
+                np.testing.assert_array_equal(got8.cpu().numpy(), want, err_msg=f"{game} {name} player {player} after={after}")
+                checked += n * size
+                del got, got8, want
+    print(f"{game}: {checked} tensor entries of {n} states against the {kind}")
+
+
 def test_synth_batch_argument_checks(ctx):
     import open_spiel_amd as osa
     b = osa.StateBatch(ctx, "connect_four", 64)
@@ -236,6 +269,52 @@ def test_config3_kuhn_cfr_1000_iterations_against_the_reference(ctx, checker):
         assert np.array_equal(t[name], t2[name]), name
     print(f"config 3: 1000 iterations, 12 infostates against the {kind}: tables within {rec['max_table_rel_error']:.2e} relative, "
           f"average policy within {rec['max_average_policy_abs_error']:.2e}")
+
+
+def test_three_player_leduc_cfr_at_size_against_the_reference(ctx, checker):
+    """The largest tree served — leduc_poker(players=3): 1 831 601 histories, 25 800 infostates — on the kernel bench.py
+    times for it (k_cfr_sub<forest>, the default) against the reference's own solvers, at size: 2 iterations of CFRSolver and
+    of CFRPlusSolver (cfr.cc:263-469; 6.7 s per iteration on one host core, the two run in parallel threads), every regret and
+    cumulative-policy cell of all 25 800 infostates to 1e-12 relative, the average policy to 1e-6; then the device judge
+    (k_geval_*) against the reference's ExpectedReturns (expected_returns.cc) of the average policy and against
+    TabularBestResponse's value for player 0 (best_response.cc:194-227; the full three-player NashConv costs the reference
+    68 s: tests/test_gpu_cfr.py checks NashConv whole on smaller trees)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import parity
+    import open_spiel_amd as osa
+    impl, kind = checker
+    game, iters = "leduc_poker(players=3)", 2
+    device = {}
+    for name, kwargs in (("cfr", {}), ("cfr_plus", dict(linear_averaging=True, regret_matching_plus=True))):
+        s = osa.TabularSolver(ctx, game, **kwargs)
+        assert s.num_histories == 1831601 and s.num_infostates == 25800
+        s.evaluate_and_update_policy(iters)
+        assert s.last_kernel() == "k_cfr_sub<forest>", s.last_kernel()
+        ev = s.evaluate_policy()
+        device[name] = {"tables": s.tables(), "expected_returns": ev["expected_returns"],
+                        "best_response_values": ev["best_response_values"], "nash_conv": ev["nash_conv"]}
+        assert abs(ev["nash_conv"] - (ev["best_response_values"] - ev["expected_returns"]).sum()) <= 1e-11
+        del s
+    rec = parity.cfr_large_tree(impl, game, ("cfr", "cfr_plus"), iters, device, threads=2, best_response_player=0)
+    assert rec["infostates"] == 25800 and rec["max_table_rel_error"] <= 1e-12 and rec["max_average_policy_abs_error"] <= 1e-6
+    print(f"3-player leduc at size against the {kind}: {iters} iterations of CFR and CFR+, 25 800 infostates: tables within "
+          f"{rec['max_table_rel_error']:.2e} relative, expected returns within {rec['max_expected_returns_abs_error']:.2e}, "
+          f"best-response value of player 0 within {rec['max_best_response_value_abs_error']:.2e} "
+          f"(CPU {rec['cpu_seconds_cfr']:.0f} s + {rec['cpu_seconds_cfr_plus']:.0f} s in parallel)")
+
+
+@pytest.mark.slow
+def test_three_player_leduc_nash_conv_whole_against_the_reference(ctx, checker):
+    """The full NashConv of 3-player leduc (three best responses + the on-policy values: ~70 s of reference CPU) —
+    deselect with -m 'not slow' when in a hurry."""
+    import open_spiel_amd as osa
+    impl, kind = checker
+    s = osa.TabularSolver(ctx, "leduc_poker(players=3)")
+    s.evaluate_and_update_policy(1)
+    o = impl.Solver(impl.Game("leduc_poker(players=3)"), "cfr")
+    o.iterate(1)
+    assert abs(s.nash_conv() - o.nash_conv()) <= 1e-10
 
 
 @pytest.mark.parametrize("warm_batches", [0, 3])

@@ -148,3 +148,52 @@ def test_set_cells_touches_one_state_of_a_batch():
             b.set_cells(1, bad)
     with pytest.raises(osa.OsgError):
         osa.StateBatch(ctx, "kuhn_poker", 2).set_cells(0, "..")
+
+
+@pytest.mark.parametrize("game_string,opening", [("tic_tac_toe", (4, 0, 8)), ("connect_four", (3, 3, 4, 2, 4)),
+                                                 ("connect_four(rows=5,columns=6,x_in_row=3)", (0, 1, 1))])
+def test_struct_built_states_keep_their_starting_position(pyspiel, game_string, opening):
+    """A state built from a struct / JSON starts at that position (tic_tac_toe.cc:336, connect_four.cc:512:
+    starting_state_str_ = ToJson()): State::Serialize emits it as the "starting_state=" first line and
+    Game::DeserializeState parses it (spiel.cc:411-430, 540-560), so serialize -> deserialize, pickle, copy.deepcopy and
+    ApplyAction + UndoAction all come back to the same position instead of replaying onto an empty board."""
+    import copy
+    import pickle
+    game = pyspiel.load_game(game_string)
+    played = game.new_initial_state()
+    for a in opening:
+        played.apply_action(a)
+    assert played.starting_state_str() == "" and played.starting_state() is None
+    assert played.serialize() == "".join(f"{a}\n" for a in opening)
+    built = game.new_initial_state(played.to_json())
+    assert built.starting_state_str() == played.to_json() and built.history() == []
+    assert built.serialize() == "starting_state=" + played.to_json() + "\n\n"
+    assert str(built.starting_state()) == str(played)
+
+    def same(a, b):
+        assert str(a) == str(b) and a.current_player() == b.current_player() and a.legal_actions() == b.legal_actions()
+        assert a.is_terminal() == b.is_terminal() and a.returns() == b.returns()
+        assert a.observation_tensor(0) == b.observation_tensor(0)
+
+    moves = []
+    for _ in range(2):
+        a = built.legal_actions()[-1]
+        moves.append((built.current_player(), a))
+        built.apply_action(a)
+        played.apply_action(a)
+    same(built, played)
+    text = built.serialize()
+    assert text.splitlines()[0].startswith("starting_state={") and text.splitlines()[1:] == [str(a) for _, a in moves]
+    for again in (game.deserialize_state(text), pickle.loads(pickle.dumps(built)), copy.deepcopy(built),
+                  pyspiel.deserialize_game_and_state(pyspiel.serialize_game_and_state(game, built))[1], built.clone()):
+        same(again, played)
+        assert again.history() == [a for _, a in moves] and again.starting_state_str() == built.starting_state_str()
+        assert again.serialize() == text
+    # undo back to the starting position and replay
+    for player, a in reversed(moves):
+        built.undo_action(player, a)
+    same(built, built.starting_state())
+    assert built.history() == [] and str(built) != str(game.new_initial_state())
+    for _, a in moves:
+        built.apply_action(a)
+    same(built, played)

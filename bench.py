@@ -63,7 +63,7 @@ def synth_batch(osa, torch, ctx, n, seed, index_offset):
     return batch, actions
 
 
-def parity_check(torch, src, dst, actions, mask, status, seed, index_offset, states):
+def parity_check(torch, src, dst, actions, mask, status, seed, index_offset, states, game="connect_four", depth_mod=None):
     """The timed launches against the CPU reference (the checker only): regenerate states
     [index_offset, index_offset + states) of the batch on the host threads with the GENUINE reference build
     (oracle/_ref, else the restatement) and compare, for every one of them, the source state, the action, and what
@@ -74,7 +74,7 @@ def parity_check(torch, src, dst, actions, mask, status, seed, index_offset, sta
     impl, kind = cpu_checker()
     threads = host_threads()
     t0 = time.perf_counter()
-    rec = impl.Game("connect_four").synth_batch(seed, states, C4_DEPTH_MOD, first=index_offset, threads=threads)
+    rec = impl.Game(game).synth_batch(seed, states, depth_mod or C4_DEPTH_MOD, first=index_offset, threads=threads)
     cpu_s = time.perf_counter() - t0
     idx = torch.arange(states, device="cuda")
 
@@ -101,7 +101,8 @@ def parity_check(torch, src, dst, actions, mask, status, seed, index_offset, sta
     same(((st & 15).astype(np.int64) - 1)[~term1], rec["cur1"][~term1].astype(np.int64), "status.player")
     outcome = np.where(rec["rets1"][:, 0] > 0, 0, np.where(rec["rets1"][:, 0] < 0, 1, 2))
     same((st & 7)[term1], outcome[term1], "status.outcome")
-    same(mask.reshape(-1)[:states].cpu().numpy(), (rec["mask1"][:, 0] & 0xFF).astype(np.uint8), "successor mask byte")
+    if mask is not None:   # (the hex step writes no mask row: ~occupied of the successor record, checked above as legal mask1)
+        same(mask.reshape(-1)[:states].cpu().numpy(), (rec["mask1"][:, 0] & 0xFF).astype(np.uint8), "successor mask byte")
     return {"states": int(states), "against": kind, "cpu_seconds": cpu_s, "cpu_threads": threads,
             "what": "source state, action, successor state (ObservationTensor), successor legal mask, terminal flag, "
                     "player to move, outcome and Returns() of the last timed launch, every state compared"}
@@ -656,42 +657,58 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
         except Exception as e:  # noqa: BLE001
             out["env_step"] = {"error": f"{type(e).__name__}: {e}"}
         # ---- the byte-bound step of the largest record served: hex(9), SURVEY.md 8(d)'s 109 B per state-step ----
+        # 2^24 states (805 MB of records in + 805 MB out per launch: every byte through HBM) is the figure; the 2^22-state
+        # launch (403 MB, 1.5 x the Infinity Cache) is kept beside it, labelled as partly cache-resident.
         try:
-            n_hex = 1 << 22
-            hb = osa.StateBatch(ctx, "hex(board_size=9)", n_hex)
-            hb.random_steps(SEED, 30)
-            hd = osa.StateBatch(ctx, "hex(board_size=9)", n_hex)
-            lm = hb.legal_actions_mask()
-            hacts = torch.where(lm.bool().any(1), (lm.to(torch.float32) * torch.rand(lm.shape, device="cuda")).argmax(1),
-                                torch.full((n_hex,), 255, device="cuda")).to(torch.uint8)
-            del lm
-            hstatus = torch.empty(n_hex, dtype=torch.uint8, device="cuda")
-            for _ in range(5):
-                hb.step(hacts, dst=hd, status=hstatus, want_mask=False)
-            h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            h0.record()
-            for _ in range(50):
-                hb.step(hacts, dst=hd, status=hstatus, want_mask=False)
-            h1.record()
-            torch.cuda.synchronize()
-            hus = h0.elapsed_time(h1) / 50 * 1e3
-            rec_bytes = hb.desc.state_words * 4
-            moved = 2 * rec_bytes + 2                     # record in, record out, action, status
+            hex_legs = {}
+            for n_hex in (1 << 24, 1 << 22):
+                hb = osa.StateBatch(ctx, "hex(board_size=9)", n_hex)
+                hacts, _depth = hb.synth(SEED, 60)            # state i: hash(i) mod 60 random legal moves, one legal action
+                hd = osa.StateBatch(ctx, "hex(board_size=9)", n_hex)
+                hstatus = torch.empty(n_hex, dtype=torch.uint8, device="cuda")
+                launches = 20 if n_hex > (1 << 22) else 50
+                for _ in range(3):
+                    hb.step(hacts, dst=hd, status=hstatus, want_mask=False)
+                h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                h0.record()
+                for _ in range(launches):
+                    hb.step(hacts, dst=hd, status=hstatus, want_mask=False)
+                h1.record()
+                torch.cuda.synchronize()
+                assert int((hstatus & 0x40).sum().item()) == 0, "synthetic hex actions must all be legal"
+                hus = h0.elapsed_time(h1) / launches * 1e3
+                rec_bytes = hb.desc.state_words * 4
+                moved = 2 * rec_bytes + 2                     # record in, record out, action, status
+                hex_parity = None
+                if with_cpu and n_hex == (1 << 24):
+                    try:
+                        hex_parity = parity_check(torch, hb, hd, hacts, None, hstatus, SEED, 0, 1 << 16,
+                                                  game="hex(board_size=9)", depth_mod=60)
+                    except AssertionError as e:
+                        hex_parity = {"error": str(e)[:500], "states": 0}
+                hex_legs[n_hex] = {"parity": hex_parity, "states": n_hex, "kernel_us_per_launch": hus, "launches": launches, "record_bytes": rec_bytes,
+                                   "value": n_hex / hus * 1e6, "bytes_moved_per_state_step": moved,
+                                   "frac_on_bytes_moved": moved * n_hex / hus / 1e3 / HBM_PEAK_GBS,
+                                   "frac_on_survey_bytes": 109 * n_hex / hus / 1e3 / HBM_PEAK_GBS}
+                del hb, hd, hacts, hstatus
+            big, small = hex_legs[1 << 24], hex_legs[1 << 22]
             out["hex_step"] = {"metric": "hex(board_size=9) fused legality + ApplyAction + status, states/sec",
-                               "value": n_hex / hus * 1e6, "unit": "state-steps/s", "states": n_hex,
-                               "kernel_us_per_launch": hus, "record_bytes": rec_bytes,
+                               "value": big["value"], "unit": "state-steps/s", "states": big["states"],
+                               "kernel_us_per_launch": big["kernel_us_per_launch"], "record_bytes": big["record_bytes"],
+                               "parity": big["parity"], "parity_checked_states": (big["parity"] or {}).get("states", 0),
                                "roofline": {"bound": "hbm", "kernel": "k_step_hexvec",
-                                            "algorithmic_bytes_per_state_step": 109,
-                                            "achieved": 109 * n_hex / hus / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                            "frac": 109 * n_hex / hus / 1e3 / HBM_PEAK_GBS,
-                                            "bytes_moved_per_state_step": moved,
-                                            "frac_on_bytes_moved": moved * n_hex / hus / 1e3 / HBM_PEAK_GBS,
-                                            "note": "50 launches back to back between one event pair; the successor's mask row is "
-                                                    "not written (on a hex board it is ~occupied of the successor record). The record "
-                                                    "is 12 words: the mover / result / ply word rides in the 5 spare bits at the top of "
-                                                    "each plane's last word (13 words in round 4: 0.60 on the same 109 B)"}}
-            del hb, hd, hacts, hstatus
+                                            "bytes_moved_per_state_step": big["bytes_moved_per_state_step"],
+                                            "achieved": big["bytes_moved_per_state_step"] * big["states"] / big["kernel_us_per_launch"] / 1e3,
+                                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac_on_bytes_moved": big["frac_on_bytes_moved"],
+                                            "algorithmic_bytes_per_state_step": 109, "frac": big["frac_on_survey_bytes"],
+                                            "note": "frac_on_bytes_moved is the traffic-true fraction (the 12-word record moves 98 B per "
+                                                    "state-step; SURVEY.md 8(d) prices a 13-word record: 109 B, `frac`); launches back to "
+                                                    "back between one event pair; the successor's mask row is not written (on a hex board "
+                                                    "it is ~occupied of the successor record)"},
+                               "infinity_cache_partial": dict(small, note="403 MB per launch against a 256 MiB Infinity Cache: part of the "
+                                                                         "traffic never reaches HBM; not an HBM figure")}
         except Exception as e:  # noqa: BLE001
             out["hex_step"] = {"error": f"{type(e).__name__}: {e}"}
     # ---- config 1: tic_tac_toe MCTSBot(RandomRolloutEvaluator(20, 42), 1000 sims, solve) — plumbing ----

@@ -154,7 +154,12 @@ int osg_chance_probs(const osg_batch* b, double* probs, int on_host);
  *   d_actions [n] u8   action id (0xFF = skip)
  *   d_mask    [n * compact_mask_bytes] legal mask of the successor state; NULL = do not write it: hex boards of up
  *                      to 128 cells only (hex.cc:280-293: the successor's legal actions are its empty cells, i.e.
- *                      ~occupied of the record the step writes), OSG_ERR_UNSUPPORTED for every other game
+ *                      ~occupied of the record the step writes), OSG_ERR_UNSUPPORTED for every other game.
+ *                      A caller deriving that mask from the raw words must (i) AND it with the board's cell bits — in
+ *                      the folded record (hex 9x9, 11x11, 19x19: osg_game_desc.state_words == 4 planes x words, no meta
+ *                      word) the top 5 bits of every plane's LAST word (bits 27-31) carry mover / result / ply / first
+ *                      move, not cells: mask that word with 0x07FFFFFF — and (ii) treat a terminal state (status bit7)
+ *                      as having no legal action.  osg_legal_mask does both.
  *   d_status  [n] u8   bit7 terminal | bit6 action was illegal (state unchanged) |
  *                      not terminal: bits0-3 = current player + 1 (0 = chance) |
  *                      terminal:     bits0-2 = outcome (board games: 0 p0 wins,

@@ -822,8 +822,9 @@ def cfr_small_roofline(iterations_per_s):
 
 
 def mccfr_flat_roofline(trajectories_per_s, simds):
-    """Config 5's kernel (k_mccfr_resident_flat: one trajectory per lane, tree / policy / delta tables in LDS, the
-    traversal's frames below the top two in a per-lane scratch stack): issue-rate fractions and where the waves wait."""
+    """Config 5's kernel (k_mccfr_resident_flat: one trajectory per lane, policy / delta tables in LDS, the read-only tree
+    records through L2 so that two 1024-lane workgroups share a CU, the traversal's frames below the top two in a per-lane
+    scratch stack): issue-rate fractions and where the waves wait."""
     pc = solver_counters()
     if not pc or "k_mccfr_resident_flat" not in pc:
         return None
@@ -833,7 +834,7 @@ def mccfr_flat_roofline(trajectories_per_s, simds):
     valu_s = c.get("SQ_INSTS_VALU", 0.0) / simds * VALU_ISSUE_NS * 1e-9
     salu_s = (c.get("SQ_INSTS_SALU", 0.0) + c.get("SQ_INSTS_BRANCH", 0.0)) / simds * SALU_ISSUE_NS * 1e-9
     waves = c.get("SQ_WAVES", 0.0) or 1.0
-    rec = {"trajectories_per_lane": n / (waves * 64.0),
+    rec = {"trajectories_per_lane": n / (waves * 64.0), "waves_per_simd": waves / simds,
            "wave_instructions_per_wave": {x: c.get("SQ_INSTS_" + x, 0.0) / waves for x in ("VALU", "SALU", "BRANCH", "LDS", "VMEM_RD", "VMEM_WR", "SMEM")},
            "scratch_frame_instructions_per_wave": (c.get("SQ_INSTS_VMEM_RD", 0.0) + c.get("SQ_INSTS_VMEM_WR", 0.0)) / waves,
            "lds_instructions_per_wave": c.get("SQ_INSTS_LDS", 0.0) / waves,

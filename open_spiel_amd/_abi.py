@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libosg_hip.so")
+# OSG_VARIANT_LIB: an A/B build of the same library (tools/build_variant.sh) for measurements and their parity runs
+LIB_PATH = os.path.abspath(os.environ["OSG_VARIANT_LIB"]) if os.environ.get("OSG_VARIANT_LIB") else os.path.join(_HERE, "libosg_hip.so")
 
 
 class OsgError(RuntimeError):

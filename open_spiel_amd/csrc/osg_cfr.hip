@@ -2227,11 +2227,16 @@ k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dp
 //   rec.y  first child (terminal nodes: index of the return vector) [0:24) |
 //          index of the incoming edge's chance probability [24:32)
 // ---------------------------------------------------------------------------
+#ifndef OSG_MCCFR_TREE_GLOBAL_DEFAULT
+#define OSG_MCCFR_TREE_GLOBAL_DEFAULT 1   // round 6: 3.04e9 -> 4.23e9 trajectories/s at 16 x 2^20 (profiles/r06c_mccfr_tree_in_l2_ab.txt)
+#endif
 struct ResidentTree {
   const uint2* rec;      // [H]
   const double* uret;    // [K, P] distinct Returns() vectors
   const double* uprob;   // [nprob] distinct chance probabilities
   int K, nprob;
+  int tree_global;       // 1: the traversals read the records from `rec` itself (read-only, L2-resident) and LDS holds
+                         // the tables only, so that two workgroups fit a CU (leduc: 67 KB instead of 143 KB); 0: staged in LDS
 };
 
 // Fills one workgroup's LDS for the resident traversals: zeroed delta tables, the regret-matched policy
@@ -2240,7 +2245,7 @@ struct ResidentTree {
 template <int kA>
 OSG_D void resident_load(double* smem, int H, int I, int P, const ResidentTree& rt, const int32_t* __restrict__ nact,
                          const double* __restrict__ regrets, double** o_dreg, double** o_dpol, double** o_pol,
-                         double** o_uret, double** o_uprob, uint2** o_nodes) {
+                         double** o_uret, double** o_uprob, const uint2** o_nodes) {
   const int IA = I * kA;
   double* pol = smem + 2 * IA;
   double* uret = smem + 3 * IA;
@@ -2282,6 +2287,10 @@ OSG_D void resident_load(double* smem, int H, int I, int P, const ResidentTree& 
   }
   for (int k = tid; k < rt.K * P; k += nt) uret[k] = rt.uret[k];
   for (int k = tid; k < rt.nprob; k += nt) uprob[k] = rt.uprob[k];
+  if (rt.tree_global) {
+    *o_dreg = smem; *o_dpol = smem + IA; *o_pol = pol; *o_uret = uret; *o_uprob = uprob; *o_nodes = rt.rec;
+    return;
+  }
   {  // the packed tree, two records (16 bytes) per load, kU loads in flight per thread
     const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(rt.rec);
     const int n4 = H / 2;
@@ -2494,7 +2503,7 @@ k_mccfr_resident_flat(int H, int I, int P, ResidentTree rt, const int32_t* __res
   extern __shared__ double smem[];
   const int IA = I * kA;
   double *dreg, *dpol, *pol, *uret, *uprob;
-  uint2* nodes;
+  const uint2* nodes;
   resident_load<kA>(smem, H, I, P, rt, nact, regrets, &dreg, &dpol, &pol, &uret, &uprob, &nodes);
   __syncthreads();
 
@@ -2692,7 +2701,7 @@ k_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restrict
   extern __shared__ double smem[];
   const int IA = I * kA;
   double *dreg, *dpol, *pol, *uret, *uprob;
-  uint2* nodes;
+  const uint2* nodes;
   const bool stamp = stamps && blockIdx.x == 0 && threadIdx.x == 0;   // OSG_MCCFR_STAMPS: where a launch's time goes
   if (stamp) stamps[0] = wall_clock64();
   resident_load<kA>(smem, H, I, P, rt, nact, regrets, &dreg, &dpol, &pol, &uret, &uprob, &nodes);
@@ -2918,7 +2927,7 @@ k_os_mccfr_resident(int H, int I, int P, ResidentTree rt, const int32_t* __restr
   extern __shared__ double smem[];
   const int IA = I * kA;
   double *dreg, *dpol, *pol, *uret, *uprob;
-  uint2* nodes;
+  const uint2* nodes;
   resident_load<kA>(smem, H, I, P, rt, nact, regrets, &dreg, &dpol, &pol, &uret, &uprob, &nodes);
   __syncthreads();
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -4654,7 +4663,7 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
     // As many workgroups per CU as the LDS footprint allows.  A footprint that only fits once (leduc:
     // 143 KB) gets one group per CU, sized to the batch — every CU busy, up to 1024 lanes each; small
     // footprints (kuhn) get several 256- or 1024-lane groups per CU.
-    const int fit = static_cast<int>((160 * 1024) / std::max<size_t>(s->resident_lds_bytes, 1));
+    int fit = static_cast<int>((160 * 1024) / std::max<size_t>(s->resident_lds_bytes, 1));
     // Mini-batches that leave lanes idle (fewer lanes than one round of the chip even with the split) run the
     // split form of the external-sampling kernel: 2 or 4 lanes per trajectory (OSG_MCCFR_SPLIT=0: never).
     // OSG_MCCFR_SPLIT=0 / 1 / 2: at most that many traverser levels are spread over lanes (default 2)
@@ -4669,6 +4678,23 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
     }
     const int64_t sampled = trajectories;
     if (split) trajectories *= split == 2 ? q * q : q;   // (the geometry below counts lanes)
+    // Where the flat kernel reads the tree from: when the staged problem allows one workgroup per CU only (leduc: 143 KB,
+    // 4 wavefronts per SIMD) but the tables alone would allow two (67 KB), the records can stay in global memory
+    // (9 457 x 8 B, read-only: L2-resident) and two 1024-lane workgroups share a CU.  OSG_MCCFR_TREE=global | lds.
+    size_t shmem_bytes = s->resident_lds_bytes;
+    int tree_global = 0;
+    {
+      static const char* where = std::getenv("OSG_MCCFR_TREE");
+      const size_t tables_only = s->resident_lds_bytes - sizeof(uint64_t) * s->H;
+      const bool helps = fit <= 1 && (160 * 1024) / std::max<size_t>(tables_only, 1) >= 2 &&
+                         trajectories >= static_cast<int64_t>(s->num_cus) * 2048;
+      const bool want = where ? std::strcmp(where, "global") == 0 : OSG_MCCFR_TREE_GLOBAL_DEFAULT != 0;
+      if (want && helps && split == 0 && s->cfg.solver != 2) {
+        tree_global = 1;
+        shmem_bytes = tables_only;
+        fit = static_cast<int>((160 * 1024) / std::max<size_t>(tables_only, 1));
+      }
+    }
     int threads, per_cu;
     if (fit <= 1) {
       const int64_t share = (trajectories + s->num_cus - 1) / std::max(s->num_cus, 1);
@@ -4679,12 +4705,12 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
       per_cu = std::max(1, std::min(fit, 2048 / threads));
     }
     int64_t groups = std::min<int64_t>((trajectories + threads - 1) / threads, static_cast<int64_t>(s->num_cus) * per_cu);
-    ResidentTree rt{reinterpret_cast<const uint2*>(s->d_rec), s->d_uret, s->d_uprob, s->n_uret, s->n_uprob};
+    ResidentTree rt{reinterpret_cast<const uint2*>(s->d_rec), s->d_uret, s->d_uprob, s->n_uret, s->n_uprob, tree_global};
     unsigned long long*& d_stamps = s->d_mccfr_stamps;   // OSG_MCCFR_STAMPS=1: phase stamps of workgroup 0 (tools/probe_mccfr_shard.py); the solver's own buffer
     if (std::getenv("OSG_MCCFR_STAMPS") && !d_stamps)
       OSG_HIP(hipMalloc(reinterpret_cast<void**>(&d_stamps), sizeof(unsigned long long) * 4));
     const dim3 grid(static_cast<unsigned>(groups)), block(threads);
-    const size_t shmem = s->resident_lds_bytes;
+    const size_t shmem = shmem_bytes;
 #define OSG_MCCFR_RES(KA)                                                                                          \
   do {                                                                                                             \
     if (s->cfg.solver == 2)                                                                                        \
@@ -4711,7 +4737,8 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
     OSG_HIP(hipGetLastError());
     s->last_kernel = s->cfg.solver == 2 ? "k_os_mccfr_resident"
                                         : (split == 2 && s->A >= 2 ? "k_mccfr_resident<split 2>"
-                                                                   : (split == 1 && s->A >= 2 ? "k_mccfr_resident<split 1>" : "k_mccfr_resident_flat"));
+                                                                   : (split == 1 && s->A >= 2 ? "k_mccfr_resident<split 1>"
+                                                                                              : (tree_global ? "k_mccfr_resident_flat<tree in L2>" : "k_mccfr_resident_flat")));
     if (d_stamps && s->cfg.solver != 2 && split != 0) {   // (the flat kernel writes no stamps)
       unsigned long long h[4];
       OSG_HIP(hipMemcpyAsync(h, d_stamps, sizeof h, hipMemcpyDeviceToHost, st));

@@ -126,6 +126,9 @@ OSG_D LdsTree lds_tree(void* base) {
 }
 constexpr size_t kLdsTreeBytes = static_cast<size_t>(kLdsNodes) * (sizeof(double) + 4 * sizeof(uint32_t));
 // One field of one node: in LDS (kCoop and a low index) or in the pool.
+#ifndef OSG_NODEREF_MODE
+#define OSG_NODEREF_MODE 0
+#endif
 template <class T, bool kCoop>
 struct NodeRef {
   T* l;
@@ -134,17 +137,30 @@ struct NodeRef {
   // kCoop: lane 0 alone stores and all 64 lanes read the field back, so the accesses are VOLATILE there: with plain
   // ones the compiler may serve a lane that did not store from a value it loaded earlier (e.g. after COUNT(v) += 1),
   // and the replicated search state of the lanes would part ways.  (The other form has one lane per search: plain.)
+  // OSG_NODEREF_MODE 1 (A/B, round 6): plain accesses, and a compiler-level memory barrier after lane 0's store — every
+  // later read is loaded again (the hazard above), while reads BETWEEN two stores may still be shared, which volatile forbids.
   OSG_D operator T() const {
+#if OSG_NODEREF_MODE == 1
+    if (kCoop) return in_lds ? *l : *g;
+#else
     if (kCoop) return in_lds ? *static_cast<volatile T*>(l) : *static_cast<volatile T*>(g);
+#endif
     return *g;
   }
   OSG_D T operator=(T v) const {
     // kCoop: the whole first wavefront runs the search in lockstep (every lane holds the same search state, so that
     // the lanes can share out a node's children); one lane's store is enough — 64 stores to one LDS address serialise
     if (kCoop) {
+#if OSG_NODEREF_MODE == 1
+      if (threadIdx.x == 0) {
+        if (in_lds) *l = v; else *g = v;
+      }
+      asm volatile("" ::: "memory");
+#else
       if (threadIdx.x == 0) {
         if (in_lds) *static_cast<volatile T*>(l) = v; else *static_cast<volatile T*>(g) = v;
       }
+#endif
       return v;
     }
     *g = v;

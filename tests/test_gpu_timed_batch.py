@@ -339,7 +339,8 @@ def test_config5_full_minibatch_against_the_frozen_table_replay(ctx, checker, wa
         first += 1 << 16
     before = s.tables()
     s.mccfr_sample(SEED, n, first_trajectory=first)
-    assert s.last_kernel() == "k_mccfr_resident_flat"
+    # the form bench.py times: tables in LDS, the read-only tree records read through L2 (two workgroups per CU)
+    assert s.last_kernel() == os.environ.get("OSG_EXPECT_MCCFR_KERNEL", "k_mccfr_resident_flat<tree in L2>")
     dreg, dcum = [t.cpu().numpy().copy() for t in s.mccfr_delta_tables()]
     rec = parity.mccfr_minibatch(impl, game, before["keys"], before["nact"], before["regrets"], dreg, dcum, SEED, first, n,
                                  _threads())

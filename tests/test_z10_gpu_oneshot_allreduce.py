@@ -114,6 +114,8 @@ for overlap in (False, True):
                                             np.abs(tr["cum_policy"] - t["cum_policy"]).max()))
     sh.comm.close()
 dist.barrier()
+__EXCHANGE_AB__
+dist.barrier()
 # a peer that never arrives: rank 1 does not call; rank 0 must get a timeout error, not hang
 os.environ["OSG_ONESHOT_TIMEOUT_MS"] = "300"
 lonely = osd.OneShotComm(ctx, 1024)
@@ -149,6 +151,10 @@ dist.destroy_process_group()
 '''
 
 
+from exchange_ab_snippet import EXCHANGE_AB  # noqa: E402
+SCRIPT = SCRIPT.replace("__EXCHANGE_AB__", EXCHANGE_AB)
+
+
 def test_oneshot_allreduce_two_ranks_on_one_device(tmp_path):
     script = tmp_path / "oneshot2.py"
     script.write_text(SCRIPT)
@@ -170,6 +176,9 @@ def test_oneshot_allreduce_two_ranks_on_one_device(tmp_path):
     for key in ("sync", "overlap"):
         assert rec[key]["rank_diff"] == 0.0, "every rank folds bit-identical sums"
         assert rec[key]["vs_one_rank"] < 1e-8 * max(1.0, rec[key]["regret_abs_sum"])
+    ab = rec["exchange_ab"]   # the same deltas through torch.distributed (gloo here, RCCL in test_z7_*) and the one-shot kernel
+    assert ab["trained"] and ab["routes_identical_minibatches"] == ab["mini_batches"] == 8 and ab["tables_identical"]
+    assert ab["rank_diff"] == 0.0 and ab["max_err_vs_one_rank_over_scale"] <= 1e-10, ab
     assert 0.2 < rec["timeout_seconds"] < 5.0 and rec["timeout_reported"] and rec["timeout_reported_by_check"]
     assert rec["timeout_poisoned_buffer"], "a failed collective must leave NaN, not a plausible mix"
     assert rec["failed_creation_agreed"], "a rank that cannot create its window must fail the construction on every rank"

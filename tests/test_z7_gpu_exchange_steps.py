@@ -274,6 +274,7 @@ for overlap in (False, True):
         tr = ref.tables()
         out["overlap" if overlap else "sync"]["vs_one_rank"] = float(max(np.abs(tr["regrets"] - t["regrets"]).max(),
                                                                          np.abs(tr["cum_policy"] - t["cum_policy"]).max()))
+__EXCHANGE_AB__
 # the C-ABI collective (osg_comm_*) over the same two GPUs: the unique id travels through torch's store
 lib = osa.lib()
 uid = C.create_string_buffer(128)
@@ -298,6 +299,10 @@ if rank == 0:
 dist.barrier()
 dist.destroy_process_group()
 '''
+
+
+from exchange_ab_snippet import EXCHANGE_AB  # noqa: E402  (tests/ is on sys.path under pytest's rootdir conftest)
+RCCL2_SCRIPT = RCCL2_SCRIPT.replace("__EXCHANGE_AB__", EXCHANGE_AB)
 
 
 def _two_gpus():
@@ -328,6 +333,10 @@ def test_rccl_world_size_two_both_routes(tmp_path):
         assert rec[key]["rank_diff"] == 0.0, "every rank folds identical all-reduced deltas"
         assert rec[key]["vs_one_rank"] < 1e-8 * max(1.0, rec[key]["regret_abs_sum"])
     assert rec["abi_allreduce_ok"]
+    ab = rec["exchange_ab"]   # OSG_COMM=rccl and OSG_COMM=oneshot carry the same exchange step: bit-identical tables
+    assert ab["backend"] == "nccl" and ab["trained"]
+    assert ab["routes_identical_minibatches"] == ab["mini_batches"] == 8 and ab["tables_identical"] and ab["rank_diff"] == 0.0
+    assert ab["max_err_vs_one_rank_over_scale"] <= 1e-10
 
 
 def test_bench_gpus_2_over_rccl(tmp_path):

@@ -14,4 +14,5 @@ s = osa.TabularSolver(ctx, "leduc_poker", mccfr=True)
 for k in range(4):
     s.run_mccfr(0x5EED, 1 << 20, first_trajectory=k << 20)
 ctx.synchronize()
-assert s.last_kernel() == "k_mccfr_resident_flat"
+assert s.last_kernel().startswith("k_mccfr_resident_flat"), s.last_kernel()
+print("mccfr kernel form:", s.last_kernel())

@@ -127,7 +127,7 @@ OSG_D LdsTree lds_tree(void* base) {
 constexpr size_t kLdsTreeBytes = static_cast<size_t>(kLdsNodes) * (sizeof(double) + 4 * sizeof(uint32_t));
 // One field of one node: in LDS (kCoop and a low index) or in the pool.
 #ifndef OSG_NODEREF_MODE
-#define OSG_NODEREF_MODE 0
+#define OSG_NODEREF_MODE 1   // round 6: 12.39 -> 11.68 ms per 1000-simulation tic_tac_toe search (profiles/r06d_one_root_noderef_ab.txt), parity green
 #endif
 template <class T, bool kCoop>
 struct NodeRef {

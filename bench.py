@@ -289,7 +289,8 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
             vector_ns = mix["valu"] * 1.03
             out["mcts"]["roofline"] = {
                 "bound": "scalar-unit instruction issue", "valu_per_sim": mix["valu"], "salu_per_sim": mix["salu"],
-                "branch_per_sim": mix["branch"], "source": mix["source"], "ns_per_sim_per_simd": ns_per_sim,
+                "branch_per_sim": mix["branch"], "source": mix["source"], "source_current": source_is_current(mix["source"]),
+                "ns_per_sim_per_simd": ns_per_sim,
                 "scalar_issue_ns_per_sim": scalar_ns, "vector_issue_ns_per_sim_at_least": vector_ns,
                 "frac_of_scalar_issue_bound": scalar_ns / ns_per_sim,
                 "note": "the scalar unit issues one instruction (ALU or branch) per 4 cycles per SIMD; with every wave "
@@ -768,6 +769,17 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
 NASH_CONV_THRESHOLDS = (1.0, 0.3, 0.1)
 
 
+def source_is_current(profile_relpath):
+    """True / False: does the committed profile a roofline quotes still describe the kernel as it is built now
+    (tools/profile_sources.py: sha256 of the defining sources recorded beside the profile)?  None: not a stamped kind."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import profile_sources
+        return profile_sources.is_current(profile_relpath)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def solver_counters():
     """Per-launch counters of the kernels of configs 3 and 5 from the newest committed profile
     (profiles/r*_pmc_solvers.json, written by tools/pmc_solvers.sh on the GPU box), or None."""
@@ -814,7 +826,7 @@ def cfr_small_roofline(iterations_per_s):
             "lds_instructions_per_iteration": classes["LDS"],
             "wait_share_of_wave_cycles": (u.get("SQ_WAIT_ANY", 0.0) / u["SQ_WAVE_CYCLES"]) if u.get("SQ_WAVE_CYCLES") else None,
             "algorithmic_bytes_per_iteration": "< 8 KB, LDS-resident (SURVEY.md 8(d)): an HBM roofline does not apply",
-            "source": pc["file"] + " (" + pc.get("source", "") + ")",
+            "source": pc["file"] + " (" + pc.get("source", "") + ")", "source_current": source_is_current(pc["file"]),
             "note": "the lever is the instruction count (round 5: 1 586 -> ~800 per iteration, 1.9e5 -> 3.6e5 it/s); counters "
                     "are those of the committed profile named in `source` — a kernel changed since then shows as "
                     "measured_ns_per_instruction outside 1.7-3.7 ns; the replicas figure is the same kernel with every "
@@ -844,7 +856,7 @@ def mccfr_flat_roofline(trajectories_per_s, simds):
            "wait_inst_share_of_wave_cycles": (c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAVE_CYCLES") else None,
            "lds_bank_conflict_cycles_per_lds_active_cycle": (c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_ACTIVE_INST_LDS"]) if c.get("SQ_ACTIVE_INST_LDS") else None,
            "algorithmic_bytes_per_trajectory": "0.5-1 KB of table rows, served from LDS (SURVEY.md 8(d): HBM roofline N/A)",
-           "source": pc["file"] + " (" + pc.get("source", "") + ")"}
+           "source": pc["file"] + " (" + pc.get("source", "") + ")", "source_current": source_is_current(pc["file"])}
     top = max(("vector-unit instruction issue", rec["frac_of_vector_issue_bound"]), ("scalar-unit instruction issue", rec["frac_of_scalar_issue_bound"]),
               key=lambda t: t[1])
     wait = rec["wait_any_share_of_wave_cycles"] or 0.0
@@ -1300,6 +1312,7 @@ def compact_line(full, detail_path=DETAIL_FILE):
                 "value": m.get("value"), "unit": m.get("unit"), "workload": "hex(9) 2^16 roots x 1024 sims",
                 "bound": "scalar_issue" if _get(m, "roofline", "frac_of_scalar_issue_bound") is not None else None,
                 "frac": _get(m, "roofline", "frac_of_scalar_issue_bound"),
+                "mix_profile_current": _get(m, "roofline", "source_current"),
                 "parity_checked_roots": m.get("parity_checked_roots"), "cpu_value": _get(m, "cpu_baseline", "value"),
                 "cpu_cores": _get(m, "cpu_baseline", "cores"),
                 "per_rank_sims_per_s": m.get("per_rank_sims_per_s"),
@@ -1310,6 +1323,7 @@ def compact_line(full, detail_path=DETAIL_FILE):
             out["cfr"] = _pruned({
                 "value": c.get("value"), "unit": c.get("unit"), "workload": "kuhn_poker CFRSolver",
                 "bound": "wave_issue" if _get(c, "roofline", "frac") is not None else None, "frac": _get(c, "roofline", "frac"),
+                "mix_profile_current": _get(c, "roofline", "source_current"),
                 "parity_checked_iterations": c.get("parity_checked_iterations"),
                 "parity_max_rel_error": _get(c, "parity", "max_table_rel_error"),
                 "cpu_value": _get(c, "cpu_baseline", "value"), "replicas_value": _get(c, "replicas", "value")})
@@ -1338,6 +1352,7 @@ def compact_line(full, detail_path=DETAIL_FILE):
                 "bound": "latency" if x.get("roofline") else None,
                 "frac_of_scalar_issue": _get(x, "roofline", "frac_of_scalar_issue_bound"),
                 "waves_per_simd": _get(x, "roofline", "waves_per_simd"),
+                "mix_profile_current": _get(x, "roofline", "source_current"),
                 "parity_checked_trajectories": x.get("parity_checked_trajectories"),
                 "parity_max_error_over_tolerance": _get(x, "parity", "max_error_over_tolerance"),
                 "nash_conv_after": x.get("nash_conv_after"), "cpu_value": _get(x, "cpu_baseline", "value"),

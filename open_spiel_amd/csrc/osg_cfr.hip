@@ -3999,6 +3999,22 @@ int build_sub(osg_cfr* s) {
     }
     members[static_cast<size_t>(sub_of[h]) * s->P + s->actor[h]].push_back(static_cast<int32_t>(m));
   }
+  if (std::getenv("OSG_CFR_SUB_STATS")) {   // how even the bins are: histories, levels and members per player
+    for (int q = -1; q < s->P; ++q) {
+      int64_t lo = INT64_MAX, hi = 0, sum = 0;
+      for (int g = 0; g < G; ++g) {
+        const int64_t v = q < 0 ? static_cast<int64_t>(hist[g].size()) : static_cast<int64_t>(members[static_cast<size_t>(g) * s->P + q].size());
+        lo = std::min(lo, v); hi = std::max(hi, v); sum += v;
+      }
+      fprintf(stderr, "k_cfr_sub bins: %s min %lld mean %.1f max %lld over %d bins\n", q < 0 ? "histories" : (q == 0 ? "members p0" : (q == 1 ? "members p1" : "members p2+")),
+              static_cast<long long>(lo), static_cast<double>(sum) / G, static_cast<long long>(hi), G);
+    }
+    for (int g = 0; g < G; g += std::max(1, G / 12)) {
+      fprintf(stderr, "  bin %d: histories %zu members", g, hist[g].size());
+      for (int q = 0; q < s->P; ++q) fprintf(stderr, " %zu", members[static_cast<size_t>(g) * s->P + q].size());
+      fprintf(stderr, "\n");
+    }
+  }
   std::vector<int32_t> nloc(G), desc(static_cast<size_t>(G) * NL, kTerminalNode | (63 << 10)), fc(static_cast<size_t>(G) * NL, 0),
       aux(static_cast<size_t>(G) * NL, 0), mem_off(static_cast<size_t>(G) * s->P + 1, 0), sub_rec,
       info_off(s->P + 1, 0), info_list;

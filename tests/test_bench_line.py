@@ -127,3 +127,25 @@ def test_emit_prints_the_compact_line_last_and_writes_the_detail_file(full_n1, t
     with open(os.path.join(str(tmp_path), bench.DETAIL_FILE)) as f:
         assert json.load(f)["roofline"]["dram_leg"]["states"] == 1 << 24
     assert last["detail"].endswith(bench.DETAIL_FILE)
+
+
+def test_profile_source_stamps_detect_a_changed_kernel(tmp_path, monkeypatch):
+    """tools/profile_sources.py: a profile stamped with the hashes of the kernel's sources is `current` until one of them
+    changes (content, not time stamps), `unstamped` without its sidecar."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import profile_sources as ps
+    csrc = tmp_path / "open_spiel_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    (tmp_path / "profiles").mkdir()
+    (csrc / "osg_cfr.hip").write_text("kernel v1")
+    (csrc / "osg_common.h").write_text("header v1")
+    monkeypatch.setattr(ps, "ROOT", str(tmp_path))
+    monkeypatch.setattr(ps, "CSRC", str(csrc))
+    prof = tmp_path / "profiles" / "r09_pmc_solvers.json"
+    prof.write_text("{}")
+    assert ps.status("pmc_solvers") == (str(prof), "unstamped") and ps.status("pmc_k_mcts_wave") == (None, "missing")
+    ps.stamp(str(prof), "pmc_solvers")
+    assert ps.status("pmc_solvers")[1] == "current" and ps.is_current("profiles/r09_pmc_solvers.json") is True
+    (csrc / "osg_cfr.hip").write_text("kernel v2")
+    assert ps.status("pmc_solvers")[1] == "stale: open_spiel_amd/csrc/osg_cfr.hip"
+    assert ps.is_current("profiles/r09_pmc_solvers.json") is False and ps.is_current("profiles/other.json") is None

@@ -73,6 +73,11 @@ python tools/pmc_mcts.py "$OUT" "$TAG" 2>&1 | tee -a "$OUT/summary.txt"
 echo "== counters of the solver kernels of configs 3 and 5 (k_cfr_small, k_mccfr_resident_flat)" | tee -a "$OUT/summary.txt"
 bash tools/pmc_solvers.sh "$TAG" 2>&1 | cut -c1-400 | tee -a "$OUT/summary.txt"
 
+echo "== the profiles bench.py quotes describe the kernels as built (tools/profile_sources.py)" | tee -a "$OUT/summary.txt"
+python tools/profile_sources.py | tee -a "$OUT/summary.txt"
+if [ "${PIPESTATUS[0]}" -ne 0 ]; then echo "STALE PROFILE SOURCES: validation FAILED" | tee -a "$OUT/summary.txt"; STALE=1; fi
+cp profiles/${TAG}_pmc_solvers.json* profiles/${TAG}_pmc_k_mcts_wave_hex9_8192x1024.csv* "$OUT/" 2>/dev/null
+
 echo "== probes" | tee -a "$OUT/summary.txt"
 timeout 600 python tools/probe_mcts_bench.py > "$OUT/mcts_bench.log" 2>&1; grep hex "$OUT/mcts_bench.log" | tee -a "$OUT/summary.txt"
 timeout 600 python tools/probe_cfr.py > "$OUT/probe_cfr.log" 2>&1; tail -12 "$OUT/probe_cfr.log" | cut -c1-200 | tee -a "$OUT/summary.txt"
@@ -86,3 +91,4 @@ timeout 300 python tools/probe_hex_step.py > "$OUT/hex_step.log" 2>&1; grep "def
 # keep the merged-back directory small (gpurun merges at most 64 MiB)
 find "$OUT" -name '*.db' -size +20M -delete 2>/dev/null
 du -sh "$OUT" | tee -a "$OUT/summary.txt"
+exit ${STALE:-0}

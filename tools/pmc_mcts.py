@@ -23,3 +23,7 @@ with open(path, "w") as f:
     for k in sorted(tot):
         f.write(f"{k},{tot[k]:.0f},{tot[k] / sims:.1f}\n")
 print(open(path).read())
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import profile_sources  # the profile is stamped with the hashes of the sources that define its kernels
+profile_sources.stamp(path, "pmc_k_mcts_wave")

@@ -32,3 +32,7 @@ for kern in KERNELS:
     if kern in res:
         print(kern, json.dumps(res[kern]["per_unit"], sort_keys=True))
         print("   launch us:", res[kern]["launch_us_under_counters"])
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import profile_sources  # the profile is stamped with the hashes of the sources that define its kernels
+profile_sources.stamp(path, "pmc_solvers")

@@ -94,3 +94,33 @@ for game, depth in [("connect_four", 12), ("tic_tac_toe", 3), ("hex(board_size=9
             report(f"k_observation(info) {game} [{NB},{d.info_size}] n=2^24", s, NB, "states/s", NB * (sb + 4 * d.info_size))
             del out
         del b
+
+# ---- the wide boards (round 6): the instantiations that hold a board of more than 128 cells in registers (hex 13 x 13:
+# NW = 6, 19 x 19: NW = 12; connect_four above 64 board bits: unsigned __int128 planes) are compiled at 1-2 wavefronts per
+# SIMD (257-307 VGPRs); this is what they deliver, at sizes where every byte goes through HBM (tag "wide") ----
+for game, nwide, depth_mod in [("hex(board_size=13)", 1 << 22, 100), ("hex(board_size=19)", 1 << 21, 200),
+                               ("hex(board_size=11)", 1 << 22, 80), ("connect_four(rows=8,columns=8)", 1 << 23, 40),
+                               ("connect_four(rows=9,columns=12)", 1 << 23, 60)]:
+    b = osa.StateBatch(ctx, game, nwide)
+    acts, _ = b.synth(7, depth_mod)
+    d = b.desc
+    sb = d.state_words * d.state_word_bytes
+    dst = osa.StateBatch(ctx, game, nwide)
+    mask, status = b.step_buffers()
+    s = timeit(lambda: b.step(acts, dst=dst, mask=mask, status=status), iters=20, warm=3)
+    report(f"k_step {game} wide n=2^{nwide.bit_length() - 1} ({sb} B record)", s, nwide, "env-steps/s",
+           nwide * (2 * sb + 1 + d.compact_mask_bytes + 1))
+    bits = torch.empty((nwide, d.mask_words), dtype=torch.int32, device="cuda")
+    s = timeit(lambda: osa._abi.check(osa.lib().osg_legal_mask(b._h, bits.data_ptr(), 0)), iters=20, warm=3)
+    report(f"k_legal_mask {game} wide", s, nwide, "states/s", nwide * (sb + 4 * d.mask_words))
+    n_obs = max(1, (1 << 30) // (4 * d.obs_size))          # a 1 GiB tensor
+    n_obs = min(n_obs, nwide)
+    bo = b.gather(torch.arange(n_obs, device="cuda"))
+    out = torch.empty((n_obs, d.obs_size), dtype=torch.float32, device="cuda")
+    s = timeit(lambda: bo.observation_tensor(0, out=out), iters=10, warm=2)
+    report(f"k_observation {game} wide [{n_obs},{d.obs_size}]", s, n_obs, "states/s", n_obs * (sb + 4 * d.obs_size))
+    c = torch.zeros(2, dtype=torch.int64, device="cuda")
+    small = b.gather(torch.arange(1 << 18, device="cuda"))
+    s = timeit(lambda: small.random_steps(9, 32, counters=c), iters=5, warm=1)
+    report(f"k_random_steps {game} wide (2^18 states x 32 steps)", s, (1 << 18) * 32, "env-steps/s")
+    del b, dst, mask, status, bits, acts, bo, out, small

@@ -137,7 +137,8 @@ def test_profile_source_stamps_detect_a_changed_kernel(tmp_path, monkeypatch):
     csrc = tmp_path / "open_spiel_amd" / "csrc"
     csrc.mkdir(parents=True)
     (tmp_path / "profiles").mkdir()
-    (csrc / "osg_cfr.hip").write_text("kernel v1")
+    (csrc / "osg_cfr_small.hip").write_text("kernel v1")
+    (csrc / "osg_cfr_mccfr.hip").write_text("the other kernel")
     (csrc / "osg_common.h").write_text("header v1")
     monkeypatch.setattr(ps, "ROOT", str(tmp_path))
     monkeypatch.setattr(ps, "CSRC", str(csrc))
@@ -146,6 +147,6 @@ def test_profile_source_stamps_detect_a_changed_kernel(tmp_path, monkeypatch):
     assert ps.status("pmc_solvers") == (str(prof), "unstamped") and ps.status("pmc_k_mcts_wave") == (None, "missing")
     ps.stamp(str(prof), "pmc_solvers")
     assert ps.status("pmc_solvers")[1] == "current" and ps.is_current("profiles/r09_pmc_solvers.json") is True
-    (csrc / "osg_cfr.hip").write_text("kernel v2")
-    assert ps.status("pmc_solvers")[1] == "stale: open_spiel_amd/csrc/osg_cfr.hip"
+    (csrc / "osg_cfr_small.hip").write_text("kernel v2")
+    assert ps.status("pmc_solvers")[1] == "stale: open_spiel_amd/csrc/osg_cfr_small.hip"
     assert ps.is_current("profiles/r09_pmc_solvers.json") is False and ps.is_current("profiles/other.json") is None

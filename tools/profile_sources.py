@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "open_spiel_amd", "csrc")
 # kind -> (glob of the profiles bench.py reads, the .hip files that define the profiled kernels)
 KINDS = {
-    "pmc_solvers": ("r*_pmc_solvers.json", ["osg_cfr.hip"]),                          # k_cfr_small, k_mccfr_resident_flat
+    "pmc_solvers": ("r*_pmc_solvers.json", ["osg_cfr_small.hip", "osg_cfr_mccfr.hip"]),   # k_cfr_small, k_mccfr_resident_flat
     "pmc_k_mcts_wave": ("r*_pmc_k_mcts_wave_hex9_8192x1024.csv", ["osg_mcts_wave.hip"]),   # k_mcts_wave<HexT<3>, ...>
 }
 

@@ -532,7 +532,15 @@ int osg_comm_destroy(osg_comm* c);
  * OSG_ONESHOT_TIMEOUT_MS (default 120 000; the clock restarts with every chunk that arrives, so a late rank is waited
  * for; 0 = no bound) makes the waiting workgroup POISON its chunk of the caller's buffer (NaN / INT32_MIN) instead of
  * leaving local values beside reduced ones, and raises a sticky error that osg_comm_check and every later call on
- * the communicator report.  The reference has no counterpart (no distributed runtime). */
+ * the communicator report.  What the bound is and is not: it bounds the SILENCE of a peer (the clock restarts with
+ * every chunk that arrives), so a call can take up to world x OSG_ONESHOT_TIMEOUT_MS before it gives up; the poison and
+ * the sticky error are LOCAL to the rank whose wait ran out — peers that received every chunk reduce normally and do
+ * not learn of it from the collective — and the int32 poison INT32_MIN is a value, it does not propagate like a NaN.
+ * Hence the caller's rule: every rank calls osg_comm_check after the last collective and the ranks AGREE on the result
+ * (one more exchange on the channel the handles travelled on) before any of them folds / publishes what the
+ * collective produced; open_spiel_amd/distributed.py ShardedMccfr.finish() does that over torch.distributed (a C++ host
+ * calls Communicator::CheckHealth() and exchanges the verdict on the channel its handles travelled on).  The reference
+ * has no counterpart (no distributed runtime). */
 #define OSG_ONESHOT_HANDLE_BYTES 128
 int osg_comm_oneshot_create(osg_ctx* ctx, int rank, int world, int64_t max_doubles, osg_comm** out);
 int osg_comm_oneshot_handle(const osg_comm* c, void* handle_out /* OSG_ONESHOT_HANDLE_BYTES */);

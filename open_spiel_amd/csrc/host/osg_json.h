@@ -8,10 +8,12 @@
 #define OSG_HOST_JSON_H_
 
 #include <algorithm>
+#include <cerrno>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <limits>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -97,9 +99,23 @@ class Json {
   }
   template <class T, std::enable_if_t<std::is_integral_v<T> && !std::is_same_v<T, bool>, int> = 0>
   void get_to(T& v) const {
-    if (type_ == Type::kInt) v = static_cast<T>(int_);
-    else if (type_ == Type::kDouble) v = static_cast<T>(double_);
-    else throw exception("type must be number");
+    // (a value the target type cannot hold is an error, not a wrapped or undefined conversion)
+    if (type_ == Type::kInt) {
+      if (std::is_signed_v<T> ? (int_ < static_cast<int64_t>(std::numeric_limits<T>::min()) ||
+                                 int_ > static_cast<int64_t>(std::numeric_limits<T>::max()))
+                              : (int_ < 0 || static_cast<uint64_t>(int_) > static_cast<uint64_t>(std::numeric_limits<T>::max())))
+        throw exception("number out of range of the requested integer type");
+      v = static_cast<T>(int_);
+    } else if (type_ == Type::kDouble) {
+      // (2^63 and 2^64 are exact doubles; the comparison keeps NaN out as well)
+      const double lo = std::is_signed_v<T> ? static_cast<double>(std::numeric_limits<T>::min()) : 0.0;
+      const double hi = static_cast<double>(std::numeric_limits<T>::max());
+      if (!(double_ >= lo && double_ <= hi) || (sizeof(T) == 8 && double_ >= hi))
+        throw exception("number out of range of the requested integer type");
+      v = static_cast<T>(double_);
+    } else {
+      throw exception("type must be number");
+    }
   }
   void get_to(double& v) const {
     if (type_ == Type::kInt) v = static_cast<double>(int_);
@@ -228,7 +244,16 @@ class Json {
       while (*p < t.size() && t[*p] >= '0' && t[*p] <= '9') ++*p;
     }
     const std::string token = t.substr(start, *p - start);
-    if (integral && token.size() < 19) return Json(static_cast<int64_t>(std::strtoll(token.c_str(), nullptr, 10)));
+    {  // RFC 8259: no leading zeros ("01", "-007"); "0", "-0", "0.5" are fine
+      const size_t d = token[0] == '-' ? 1 : 0;
+      if (token.size() > d + 1 && token[d] == '0' && token[d + 1] >= '0' && token[d + 1] <= '9') Fail(start, "leading zero in a number");
+    }
+    if (integral) {   // every integer an int64 holds stays an integer; beyond that the value is a double, as in nlohmann
+      errno = 0;
+      char* end = nullptr;
+      const long long v = std::strtoll(token.c_str(), &end, 10);
+      if (errno != ERANGE && end && *end == '\0') return Json(static_cast<int64_t>(v));
+    }
     return Json(std::strtod(token.c_str(), nullptr));
   }
   static constexpr int kMaxDepth = 256;   // (a bound on nesting: the parser recurses)

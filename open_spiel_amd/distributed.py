@@ -244,7 +244,26 @@ class ShardedMccfr:
         leaves NaN in the delta buffer, so tables it was folded into are NaN, never plausible-but-different)."""
         self._fold_pending()
         if self.comm is not None and self.world_size > 1:
-            self.comm.check()
+            # A one-shot timeout poisons and flags only the rank whose wait ran out (include/osg_abi.h): the ranks agree
+            # on the verdict — one MIN over the ranks on the process group the handles travelled on — so that either
+            # every rank trusts its tables or every rank raises.
+            err = None
+            try:
+                self.comm.check()
+            except Exception as e:  # noqa: BLE001 - re-raised below, on every rank
+                err = e
+            ok = 0 if err is not None else 1
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() == self.world_size:
+                flag = torch.tensor([ok], dtype=torch.int32,
+                                    device="cuda" if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if err is not None:
+                raise err
+            if not ok:
+                from ._abi import OsgError
+                raise OsgError("a peer's one-shot all-reduce timed out: its tables are poisoned, this rank's are not "
+                               "trustworthy as a set (ShardedMccfr.finish agrees on the verdict across the ranks)")
 
 
 def gather_root_results(local, total_roots):

@@ -108,6 +108,30 @@ int main() {
     EXPECT(Json::parse("\"\\u00e9\\ud83d\\ude00\"").get<std::string>() == "\xC3\xA9\xF0\x9F\x98\x80");
     EXPECT(Json(2.0).dump() == "2.0" && Json(-0.1).dump() == "-0.1" && Json(1e300).dump() == "1e+300" && Json(7).dump() == "7");
     EXPECT(Json::parse("[1,-2,3.25,1e2]").dump() == "[1,-2,3.25,100.0]");
+    // integers: every int64 stays an integer (19-digit values included), beyond that a double; no leading zeros; a
+    // typed read of a value the target cannot hold throws instead of wrapping (or being undefined)
+    EXPECT(Json::parse("9223372036854775807").get<int64_t>() == INT64_MAX && Json::parse("-9223372036854775808").get<int64_t>() == INT64_MIN);
+    EXPECT(Json::parse("1234567890123456789").dump() == "1234567890123456789");
+    EXPECT(Json::parse("18446744073709551615").is_number() && Json::parse("18446744073709551615").get<double>() == 18446744073709551616.0);
+    EXPECT(Json::parse("0").get<int>() == 0 && Json::parse("-0").get<int>() == 0 && Json::parse("0.5").get<double>() == 0.5);
+    for (const char* bad : {"01", "-007", "[00]", "{\"a\":012}"}) {
+      bool threw = false;
+      try { Json::parse(bad); } catch (const Json::exception&) { threw = true; }
+      EXPECT(threw);
+    }
+    for (const char* big : {"3000000000", "-3000000000", "1e10", "-1e10", "18446744073709551615", "1e400"}) {
+      bool threw = false;
+      try { (void)Json::parse(big).get<int>(); } catch (const Json::exception&) { threw = true; }
+      EXPECT(threw);
+    }
+    {
+      bool threw = false;
+      try { (void)Json::parse("-1").get<unsigned int>(); } catch (const Json::exception&) { threw = true; }
+      EXPECT(threw && Json::parse("4000000000").get<unsigned int>() == 4000000000u && Json::parse("255").get<uint8_t>() == 255);
+      threw = false;
+      try { (void)Json::parse("9223372036854775808").get<int64_t>(); } catch (const Json::exception&) { threw = true; }   // 2^63 as a double
+      EXPECT(threw && Json::parse("2.0").get<int>() == 2);
+    }
     for (const char* bad : {"{\"a\":}", "[1,", "{\"a\" 1}", "tru", "\"x", "[1] 2", "{1:2}", ""}) {
       bool threw = false;
       try { Json::parse(bad); } catch (const Json::exception&) { threw = true; }

@@ -250,3 +250,51 @@ def test_cpp_host_shard_range_equals_the_python_one(tmp_path):
         assert shard_range(total, rank, world) == (first, count)
         seen += 1
     assert seen == 7 * (1 + 2 + 3 + 4 + 8)
+
+
+class _FakeComm:
+    """A one-shot communicator stand-in: sums through the process group, and check() fails on ONE rank only — what a
+    one-shot timeout looks like (include/osg_abi.h: poison and sticky error are local to the rank whose wait ran out)."""
+
+    def __init__(self, fail_on_rank):
+        self.fail = dist.get_rank() == fail_on_rank
+
+    def allreduce_sum_(self, t):
+        dist.all_reduce(t)
+        return t
+
+    def check(self):
+        if self.fail:
+            from open_spiel_amd._abi import OsgError
+            raise OsgError("one-shot all-reduce: timed out waiting for a peer (stand-in)")
+
+
+def _agree_worker(rank, world_size, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from open_spiel_amd import distributed as osd
+        from open_spiel_amd._abi import OsgError
+        verdicts = []
+        for fail_on in (1, -1):      # a timeout on rank 1 only, then a healthy run
+            sharded = osd.ShardedMccfr(FakeFlatSolver(), comm=_FakeComm(fail_on))
+            sharded.run_minibatch(seed=3, trajectories=64)
+            try:
+                sharded.finish()
+                verdicts.append("ok")
+            except OsgError as e:
+                verdicts.append("own" if "stand-in" in str(e) else ("peer" if "a peer's one-shot" in str(e) else "?"))
+        torch.save(verdicts, os.path.join(out_dir, f"agree{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_shot_timeout_verdict_is_agreed_by_all_ranks(tmp_path):
+    """ShardedMccfr.finish(): a one-shot timeout is reported by osg_comm_check on the rank whose wait ran out only — the
+    ranks agree on the verdict (one MIN over the process group) so that EVERY rank raises, none folds on alone."""
+    port = _free_port()
+    mp.spawn(_agree_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    v0 = torch.load(os.path.join(tmp_path, "agree0.pt"))
+    v1 = torch.load(os.path.join(tmp_path, "agree1.pt"))
+    assert v0 == ["peer", "ok"] and v1 == ["own", "ok"], (v0, v1)

@@ -279,8 +279,6 @@ struct ResidentTree {
   int K, nprob;
   int tree_global;       // 1: the traversals read the records from `rec` itself (read-only, L2-resident) and LDS holds
                          // the tables only, so that two workgroups fit a CU (leduc: 67 KB instead of 143 KB); 0: staged in LDS
-  int lds_top = 0;       // tree_global: the first lds_top records (the tree is level-ordered: its top levels, which every
-                         // trajectory walks) are staged in the LDS the two workgroups of a CU leave free; the rest come from `rec`
 };
 
 constexpr int kMaxOsDepth = 32;

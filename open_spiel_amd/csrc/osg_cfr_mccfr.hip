@@ -189,11 +189,10 @@ OSG_D void resident_load(double* smem, int H, int I, int P, const ResidentTree& 
   }
   for (int k = tid; k < rt.K * P; k += nt) uret[k] = rt.uret[k];
   for (int k = tid; k < rt.nprob; k += nt) uprob[k] = rt.uprob[k];
-  if (rt.tree_global && rt.lds_top == 0) {
+  if (rt.tree_global) {
     *o_dreg = smem; *o_dpol = smem + IA; *o_pol = pol; *o_uret = uret; *o_uprob = uprob; *o_nodes = rt.rec;
     return;
   }
-  if (rt.tree_global) H = rt.lds_top;   // (even) the top of the tree only: the flat kernel reads the rest from rt.rec
   {  // the packed tree, two records (16 bytes) per load, kU loads in flight per thread
     const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(rt.rec);
     const int n4 = H / 2;
@@ -409,11 +408,6 @@ k_mccfr_resident_flat(int H, int I, int P, ResidentTree rt, const int32_t* __res
   const uint2* nodes;
   resident_load<kA>(smem, H, I, P, rt, nact, regrets, &dreg, &dpol, &pol, &uret, &uprob, &nodes);
   __syncthreads();
-  // Where a record comes from: all of the tree is in LDS (lds_n = H), or — two workgroups per CU — the first lds_n
-  // records (the level-ordered tree's top, which every trajectory walks) are and the rest are read from global memory.
-  const int lds_n = rt.tree_global ? rt.lds_top : H;
-  const uint2* __restrict__ nodes_g = rt.rec;
-  auto fetch = [&](int n) -> uint2 { return n < lds_n ? nodes[n] : nodes_g[n]; };
 
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t j0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j0 < count; j0 += stride) {
@@ -457,7 +451,7 @@ k_mccfr_resident_flat(int H, int I, int P, ResidentTree rt, const int32_t* __res
     int sp = 0;
     int node = 0;
     for (;;) {
-      const uint2 rec = fetch(node);
+      const uint2 rec = nodes[node];
 #if OSG_MCCFR_PEEK
       // The next uniform of the stream, formed WHILE the node's record is on its way from LDS: the generator is a
       // counter and a mixer, so the draw does not depend on the node — only whether it is consumed does (a node of the
@@ -492,7 +486,7 @@ k_mccfr_resident_flat(int H, int I, int P, ResidentTree rt, const int32_t* __res
               }
             } else {
               for (int c = 0; c < nc; ++c) {
-                const double pr = uprob[fetch(fc + c).y >> 24];
+                const double pr = uprob[nodes[fc + c].y >> 24];
                 if (!found && acc <= z && z < acc + pr) { pick = c; found = true; }
                 acc += pr;
               }
@@ -1156,7 +1150,7 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
     // 4 wavefronts per SIMD) but the tables alone would allow two (67 KB), the records can stay in global memory
     // (9 457 x 8 B, read-only: L2-resident) and two 1024-lane workgroups share a CU.  OSG_MCCFR_TREE=global | lds.
     size_t shmem_bytes = s->resident_lds_bytes;
-    int tree_global = 0, lds_top = 0;
+    int tree_global = 0;
     {
       static const char* where = std::getenv("OSG_MCCFR_TREE");
       const size_t tables_only = s->resident_lds_bytes - sizeof(uint64_t) * s->H;
@@ -1167,13 +1161,6 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
         tree_global = 1;
         shmem_bytes = tables_only;
         fit = static_cast<int>((160 * 1024) / std::max<size_t>(tables_only, 1));
-        // what two workgroups leave free of the CU's 160 KB takes the top of the level-ordered tree (OSG_MCCFR_TREE_LDS_TOP=0: none)
-        static const char* top = std::getenv("OSG_MCCFR_TREE_LDS_TOP");
-        const size_t half = (160 * 1024) / 2 - 512;
-        if (fit == 2 && tables_only < half && !(top && top[0] == '0')) {
-          lds_top = static_cast<int>(std::min<size_t>((half - tables_only) / sizeof(uint64_t), static_cast<size_t>(s->H))) & ~1;
-          shmem_bytes = tables_only + sizeof(uint64_t) * lds_top;
-        }
       }
     }
     int threads, per_cu;
@@ -1186,7 +1173,7 @@ static int mccfr_sample_impl(osg_cfr* s, uint64_t seed, int64_t first_trajectory
       per_cu = std::max(1, std::min(fit, 2048 / threads));
     }
     int64_t groups = std::min<int64_t>((trajectories + threads - 1) / threads, static_cast<int64_t>(s->num_cus) * per_cu);
-    ResidentTree rt{reinterpret_cast<const uint2*>(s->d_rec), s->d_uret, s->d_uprob, s->n_uret, s->n_uprob, tree_global, lds_top};
+    ResidentTree rt{reinterpret_cast<const uint2*>(s->d_rec), s->d_uret, s->d_uprob, s->n_uret, s->n_uprob, tree_global};
     unsigned long long*& d_stamps = s->d_mccfr_stamps;   // OSG_MCCFR_STAMPS=1: phase stamps of workgroup 0 (tools/probe_mccfr_shard.py); the solver's own buffer
     if (std::getenv("OSG_MCCFR_STAMPS") && !d_stamps)
       OSG_HIP(hipMalloc(reinterpret_cast<void**>(&d_stamps), sizeof(unsigned long long) * 4));

@@ -65,9 +65,10 @@ def test_reference_test_sources_compile_against_the_mirror():
 # the reference's example programs (open_spiel/examples/*.cc), compiled unmodified as well: (binary, arguments, a line of output)
 EXAMPLES = [
     ("reference_example_cfr_example", [], "Iteration 999 exploitability=0.0009"),          # kuhn_poker, 1000 iterations
-    # (mcts_example.cc:48-49 seeds from the clock when --seed is 0, and a 1000-simulation search can be held to a draw by a
-    #  lucky random opponent: a fixed seed, and the line every outcome prints; the search never LOSES — checked below)
-    ("reference_example_mcts_example", ["--num_games=2", "--max_simulations=1000", "--quiet=true", "--seed=11"], "Number of games played: 2"),
+    # (mcts_example.cc:48-49 seeds from the clock when --seed is 0: a fixed seed — the random opponent is std::mt19937, the
+    #  search draws from the engine's counter streams — makes the two games reproducible: the search wins both; the exact
+    #  games are asserted below, so a weaker search — draws against the random player — fails)
+    ("reference_example_mcts_example", ["--num_games=2", "--max_simulations=1000", "--quiet=true", "--seed=11"], "Overall wins: 2,0"),
     ("reference_example_example", ["--game=connect_four", "--seed=7"], "Final return to player 0 is"),
     # (with --show_infostate example.cc:139-141 hands an EMPTY span to InformationStateTensor: fatal in the reference too)
     ("reference_example_example", ["--game=leduc_poker", "--seed=3", "--show_legals=true"], "Final return to player 1 is"),
@@ -91,8 +92,11 @@ def test_reference_example_program_runs_on_the_mirror(binary, args, expect):
     print((r.stdout + r.stderr)[-1500:])
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert expect in r.stdout + r.stderr
-    if binary == "reference_example_mcts_example":
-        assert "Returns: -1,1" not in r.stdout + r.stderr    # x (the search) against the uniform random player
+    if binary == "reference_example_mcts_example":   # x (the search) against the uniform random player, seed 11
+        out = r.stdout + r.stderr
+        assert "Returns: 1,-1 Game actions: x(1,1) o(0,1) x(1,0) o(0,0) x(1,2)" in out
+        assert "Returns: 1,-1 Game actions: x(1,1) o(0,0) x(2,2) o(1,2) x(2,0) o(0,2) x(2,1)" in out
+        assert "Overall returns: 2,-2" in out and "Number of distinct games played: 2" in out
 
 
 SLOW_BINARIES = ["reference_evaluate_bots_test"]   # 200 000 episodes through one-state batches: 142 s on an MI355X

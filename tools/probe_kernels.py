@@ -102,14 +102,22 @@ for game, nwide, depth_mod in [("hex(board_size=13)", 1 << 22, 100), ("hex(board
                                ("hex(board_size=11)", 1 << 22, 80), ("connect_four(rows=8,columns=8)", 1 << 23, 40),
                                ("connect_four(rows=9,columns=12)", 1 << 23, 60)]:
     b = osa.StateBatch(ctx, game, nwide)
-    acts, _ = b.synth(7, depth_mod)
     d = b.desc
     sb = d.state_words * d.state_word_bytes
-    dst = osa.StateBatch(ctx, game, nwide)
-    mask, status = b.step_buffers()
-    s = timeit(lambda: b.step(acts, dst=dst, mask=mask, status=status), iters=20, warm=3)
-    report(f"k_step {game} wide n=2^{nwide.bit_length() - 1} ({sb} B record)", s, nwide, "env-steps/s",
-           nwide * (2 * sb + 1 + d.compact_mask_bytes + 1))
+    dst = mask = status = acts = None
+    if d.num_distinct_actions <= 255:     # (the fused step takes one-byte actions: hex 19 x 19 has 361)
+        acts, _ = b.synth(7, depth_mod)
+        dst = osa.StateBatch(ctx, game, nwide)
+        mask, status = b.step_buffers()
+        s = timeit(lambda: b.step(acts, dst=dst, mask=mask, status=status), iters=20, warm=3)
+        report(f"k_step {game} wide n=2^{nwide.bit_length() - 1} ({sb} B record)", s, nwide, "env-steps/s",
+               nwide * (2 * sb + 1 + d.compact_mask_bytes + 1))
+    else:
+        b.random_steps(7, depth_mod // 2)
+        cur = torch.empty(nwide, dtype=torch.int8, device="cuda"); term = torch.empty(nwide, dtype=torch.uint8, device="cuda")
+        rets = torch.empty((nwide, d.num_players), dtype=torch.float64, device="cuda")
+        s = timeit(lambda: osa._abi.check(osa.lib().osg_status_query(b._h, cur.data_ptr(), term.data_ptr(), rets.data_ptr(), 0)), iters=20, warm=3)
+        report(f"k_status {game} wide ({sb} B record; every byte read)", s, nwide, "states/s", nwide * (sb + 2 + 8 * d.num_players))
     bits = torch.empty((nwide, d.mask_words), dtype=torch.int32, device="cuda")
     s = timeit(lambda: osa._abi.check(osa.lib().osg_legal_mask(b._h, bits.data_ptr(), 0)), iters=20, warm=3)
     report(f"k_legal_mask {game} wide", s, nwide, "states/s", nwide * (sb + 4 * d.mask_words))

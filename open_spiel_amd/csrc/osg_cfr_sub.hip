@@ -2,6 +2,10 @@
 // (a full-grid launch per tree level and phase).  3-player leduc_poker: 1.83 M histories.
 #include "osg_cfr_internal.h"
 
+#ifndef OSG_SUB_EXP
+#define OSG_SUB_EXP 0   // timing experiments of the members phase (tools/build_variant.sh; results are wrong with any bit set)
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -134,6 +138,31 @@ __global__ void __launch_bounds__(256) k_gcfr_fold(GridCfr g, int upd, osg_cfr_c
 // worth (3 260 -> 8 260 iterations/s on 3-player leduc in round 5).
 // Reference: cfr.cc:331-408 (ComputeCounterFactualRegret), 443-469, 596-615.
 // ---------------------------------------------------------------------------
+#ifndef OSG_SUB_QUAD_STORE
+#define OSG_SUB_QUAD_STORE 1
+#endif
+OSG_D unsigned int dlo(double v) { return static_cast<unsigned int>(__double_as_longlong(v)); }
+OSG_D unsigned int dhi(double v) { return static_cast<unsigned int>(__double_as_longlong(v) >> 32); }
+// Lane kSrc of every quad (four consecutive lanes) broadcast to the quad: a DPP move, no LDS.
+template <int kSrc>
+OSG_D unsigned int quad_bcast(unsigned int v) {
+  return static_cast<unsigned int>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), kSrc * 0x55, 0xF, 0xF, true));
+}
+// The record of the quad's lane kSrc (its four 16-byte pieces own[piece][word]) written by the whole quad: lane rq writes
+// piece rq at at + 16 rq — 64 contiguous, 64-byte aligned bytes per quad and instruction.
+template <int kSrc>
+OSG_D void quad_store(__amdgpu_buffer_rsrc_t rec_buf, const unsigned int (&own)[4][4], unsigned int at, unsigned int wr, int rq) {
+  const unsigned int at_s = quad_bcast<kSrc>(at), wr_s = quad_bcast<kSrc>(wr);
+  osg_u4 mine;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const unsigned int c0 = quad_bcast<kSrc>(own[0][w]), c1 = quad_bcast<kSrc>(own[1][w]), c2 = quad_bcast<kSrc>(own[2][w]),
+                       c3 = quad_bcast<kSrc>(own[3][w]);
+    mine[w] = rq == 0 ? c0 : (rq == 1 ? c1 : (rq == 2 ? c2 : c3));
+  }
+  if (wr_s) __builtin_amdgcn_raw_buffer_store_b128(mine, rec_buf, static_cast<int>(at_s + 16u * static_cast<unsigned int>(rq)), 0, kCachePolicySc1);
+}
+
 template <int kK>   // histories per thread: NL <= kK * 1024
 __global__ void __launch_bounds__(kSubThreads)
 k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg) {
@@ -329,7 +358,8 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
         const int n_chunks = sp.PL / 4, per_player = n_chunks / P;
         // two members per thread and round, both records requested before the first is used: a bin holds ~1 050 members
         // of a player (3-player leduc), and a second round for the few beyond 1 024 cost a whole round's latency
-        for (int mm0 = m_begin + tid; mm0 < m_end; mm0 += 2 * kSubThreads) {
+        for (int mbase = m_begin; mbase < m_end; mbase += 2 * kSubThreads) {   // (workgroup-uniform trip count: the quad stores read neighbours)
+          const int mm0 = mbase + tid;
           int4 head[2], second[2], codes[2][kSubCodeChunks / 2];   // (16-bit codes: two chunks of four per int4)
           bool live[2];
           const int n_words4 = (n_chunks + 1) / 2, rec_ints = 8 + 4 * n_words4;
@@ -337,14 +367,28 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
           for (int u = 0; u < 2; ++u) {
             const int mm = mm0 + u * kSubThreads;
             live[u] = mm < m_end;
-            const int4* rec = reinterpret_cast<const int4*>(sp.sub_rec + static_cast<size_t>(live[u] ? mm : mm0) * rec_ints);
+            if (u == 1 && mbase + kSubThreads >= m_end) {   // (workgroup-uniform) no second member this round: nothing is requested
+              head[u] = second[u] = make_int4(0, 0, 0, 0);
+#pragma unroll
+              for (int c = 0; c < kSubCodeChunks / 2; ++c) codes[u][c] = make_int4(0, 0, 0, 0);
+              continue;
+            }
+            const int4* rec = reinterpret_cast<const int4*>(sp.sub_rec + static_cast<size_t>(live[u] ? mm : m_begin) * rec_ints);
+#if OSG_SUB_EXP & 4   // (timing experiment: no static record fetch)
+            (void)rec;
+            head[u] = make_int4(mm, tid, tid | (3 << 24), tid);
+            second[u] = make_int4(0, 0x3FF00000, 0, 0);
+#pragma unroll
+            for (int c = 0; c < kSubCodeChunks / 2; ++c) codes[u][c] = make_int4(tid * 3, tid * 5, tid * 7, tid * 11);
+#else
             head[u] = rec[0]; second[u] = rec[1];
 #pragma unroll
             for (int c = 0; c < kSubCodeChunks / 2; ++c) codes[u][c] = rec[2 + (c < n_words4 ? c : n_words4 - 1)];
+#endif
           }
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            if (!live[u]) continue;
+            if (u == 1 && mbase + kSubThreads >= m_end) continue;   // (workgroup-uniform: no second member this round)
             const int m = head[u].x, hl = head[u].y, d = head[u].z & 0xFFFFFF, n = (head[u].z >> 24) & 0xFF, lfc = head[u].w;
             const double chance = __longlong_as_double((static_cast<long long>(second[u].y) << 32) | static_cast<unsigned int>(second[u].x));
             bool pruned = true;
@@ -356,8 +400,12 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
                 const unsigned int w0 = static_cast<unsigned int>((c & 1) ? codes[u][c >> 1].z : codes[u][c >> 1].x),
                                    w1 = static_cast<unsigned int>((c & 1) ? codes[u][c >> 1].w : codes[u][c >> 1].y);
                 const unsigned int cx = w0 & 0xFFFFu, cy = w0 >> 16, cz = w1 & 0xFFFFu, cw = w1 >> 16;   // 0xFFFF: padding
+#if OSG_SUB_EXP & 2   // (timing experiment: no LDS gathers)
+                const double px = 0.5 + cx * 1e-9, py = 0.5 + cy * 1e-9, pz = 0.5 + cz * 1e-9, pw = 0.5 + cw * 1e-9;
+#else
                 const double px = s_pol[cx == 0xFFFFu ? 0u : cx], py = s_pol[cy == 0xFFFFu ? 0u : cy],
                              pz = s_pol[cz == 0xFFFFu ? 0u : cz], pw = s_pol[cw == 0xFFFFu ? 0u : cw];
+#endif
                 r = r * (cx == 0xFFFFu ? 1.0 : px);   // (x * 1.0 == x: the padding leaves the product as it is)
                 r = r * (cy == 0xFFFFu ? 1.0 : py);
                 r = r * (cz == 0xFFFFu ? 1.0 : pz);
@@ -372,31 +420,50 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
             }
             cf_reach *= chance;
             const unsigned int at = static_cast<unsigned int>(m) * (kSubRecDoubles * 8);
-            if (pruned) {
-              osg_d2 flag;
-              flag.x = __longlong_as_double((static_cast<long long>(kSubFlagHi) << 32) | 1ll);
-              flag.y = 0.0;
-              store_through16(rec_buf, at, flag);
-              continue;
-            }
-            const double vh = s_value[hl];
+            const double vh = s_value[live[u] ? hl : 0];
             double dr[kSplitMaxA], dp[kSplitMaxA];
 #pragma unroll
             for (int a = 0; a < kSplitMaxA; ++a) {
               dr[a] = 0.0; dp[a] = 0.0;
-              if (a < n) {
+              if (live[u] && !pruned && a < n) {
                 dr[a] = cf_reach * (s_value[lfc + a] - vh);
                 const double pol = s_pol[d * A + a];
                 dp[a] = cfg.linear_averaging ? iteration * self_reach * pol : self_reach * pol;
               }
             }
-            static_assert(kSplitMaxA == 4 && kSubRecDoubles == 8, "the record is two pieces of regret terms, two of policy terms");
-            store_through16(rec_buf, at, osg_d2{dr[0], dr[1]});
-            store_through16(rec_buf, at + 32, osg_d2{dp[0], dp[1]});
-            if (A > 2) {   // (workgroup-uniform)
-              store_through16(rec_buf, at + 16, osg_d2{dr[2], dr[3]});
-              store_through16(rec_buf, at + 48, osg_d2{dp[2], dp[3]});
+            if (pruned) {   // the flag record: a quiet NaN whose low word is 1 in the first word, nothing else read
+              dr[0] = __longlong_as_double((static_cast<long long>(kSubFlagHi) << 32) | 1ll);
+              dr[1] = 0.0;
             }
+            static_assert(kSplitMaxA == 4 && kSubRecDoubles == 8, "the record is two pieces of regret terms, two of policy terms");
+#if OSG_SUB_EXP & 1   // (timing experiment: the terms are not written)
+            if (dr[0] + dr[1] + dr[2] + dr[3] + dp[0] + dp[1] + dp[2] + dp[3] == 1.2345e-300) store_through16(rec_buf, at, osg_d2{dr[0], dr[1]});
+#else
+            if (A > 2 && OSG_SUB_QUAD_STORE) {   // (workgroup-uniform)
+              // A member's 64-byte record leaves as ONE contiguous piece of memory traffic: the four lanes of a quad write
+              // the four 16-byte pieces of ONE member's record together, member by member (round 6).  Written by its own
+              // lane piece by piece, every store instruction put 64 scattered 16-byte fragments on the fabric — the records
+              // of a bin's members lie ~2.5 KB apart — and the phase spent 7 of its 12 us there (profiles/r06h_*).
+              const int rq = tid & 3;
+              const unsigned int own[4][4] = {
+                  {dlo(dr[0]), dhi(dr[0]), dlo(dr[1]), dhi(dr[1])}, {dlo(dr[2]), dhi(dr[2]), dlo(dr[3]), dhi(dr[3])},
+                  {dlo(dp[0]), dhi(dp[0]), dlo(dp[1]), dhi(dp[1])}, {dlo(dp[2]), dhi(dp[2]), dlo(dp[3]), dhi(dp[3])}};
+              const unsigned int wr = live[u] ? 1u : 0u;
+              quad_store<0>(rec_buf, own, at, wr, rq);
+              quad_store<1>(rec_buf, own, at, wr, rq);
+              quad_store<2>(rec_buf, own, at, wr, rq);
+              quad_store<3>(rec_buf, own, at, wr, rq);
+            } else if (live[u]) {
+              store_through16(rec_buf, at, osg_d2{dr[0], dr[1]});
+              if (!pruned) {
+                store_through16(rec_buf, at + 32, osg_d2{dp[0], dp[1]});
+                if (A > 2) {   // (workgroup-uniform)
+                  store_through16(rec_buf, at + 16, osg_d2{dr[2], dr[3]});
+                  store_through16(rec_buf, at + 48, osg_d2{dp[2], dp[3]});
+                }
+              }
+            }
+#endif
           }
         }
         __syncthreads();   // (the next subtree of this workgroup reuses s_value)

@@ -2,10 +2,6 @@
 // (a full-grid launch per tree level and phase).  3-player leduc_poker: 1.83 M histories.
 #include "osg_cfr_internal.h"
 
-#ifndef OSG_SUB_EXP
-#define OSG_SUB_EXP 0   // timing experiments of the members phase (tools/build_variant.sh; results are wrong with any bit set)
-#endif
-
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -354,96 +350,82 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
         // subtree, whose rows the sweep has staged in LDS: no second trip to memory.  The codes come grouped by player, so
         // a player's reach is one running product in path order (what keeps the tables bit-identical) and the
         // counterfactual reach multiplies the players' products in player order, the chance product last (cfr.cc:309-318).
+        // One or two members per thread and round (the two-member form keeps both dependent chains in flight).  A record's
+        // request is not moved before the sweep: holding 24 - 48 registers across it measured 2 - 9 % slower (profiles/r06j_*).
         const int m_begin = sp.mem_off[g * P + upd], m_end = sp.mem_off[g * P + upd + 1];
         const int n_chunks = sp.PL / 4, per_player = n_chunks / P;
-        // two members per thread and round, both records requested before the first is used: a bin holds ~1 050 members
-        // of a player (3-player leduc), and a second round for the few beyond 1 024 cost a whole round's latency
-        for (int mbase = m_begin; mbase < m_end; mbase += 2 * kSubThreads) {   // (workgroup-uniform trip count: the quad stores read neighbours)
-          const int mm0 = mbase + tid;
-          int4 head[2], second[2], codes[2][kSubCodeChunks / 2];   // (16-bit codes: two chunks of four per int4)
-          bool live[2];
-          const int n_words4 = (n_chunks + 1) / 2, rec_ints = 8 + 4 * n_words4;
+        const int n_words4 = (n_chunks + 1) / 2, rec_ints = 8 + 4 * n_words4;
+        auto members_round = [&](int mbase, auto nu_tag) {
+          constexpr int NU = decltype(nu_tag)::value;
+          int4 head[NU], second[NU], codes[NU][kSubCodeChunks / 2];   // (16-bit codes: two chunks of four per int4)
+          bool live[NU];
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int mm = mm0 + u * kSubThreads;
+          for (int u = 0; u < NU; ++u) {
+            const int mm = mbase + tid + u * kSubThreads;
             live[u] = mm < m_end;
-            if (u == 1 && mbase + kSubThreads >= m_end) {   // (workgroup-uniform) no second member this round: nothing is requested
-              head[u] = second[u] = make_int4(0, 0, 0, 0);
-#pragma unroll
-              for (int c = 0; c < kSubCodeChunks / 2; ++c) codes[u][c] = make_int4(0, 0, 0, 0);
-              continue;
-            }
             const int4* rec = reinterpret_cast<const int4*>(sp.sub_rec + static_cast<size_t>(live[u] ? mm : m_begin) * rec_ints);
-#if OSG_SUB_EXP & 4   // (timing experiment: no static record fetch)
-            (void)rec;
-            head[u] = make_int4(mm, tid, tid | (3 << 24), tid);
-            second[u] = make_int4(0, 0x3FF00000, 0, 0);
-#pragma unroll
-            for (int c = 0; c < kSubCodeChunks / 2; ++c) codes[u][c] = make_int4(tid * 3, tid * 5, tid * 7, tid * 11);
-#else
             head[u] = rec[0]; second[u] = rec[1];
 #pragma unroll
             for (int c = 0; c < kSubCodeChunks / 2; ++c) codes[u][c] = rec[2 + (c < n_words4 ? c : n_words4 - 1)];
-#endif
           }
+          bool pruned[NU];
+          double self_reach[NU], cf_reach[NU], r[NU];
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            if (u == 1 && mbase + kSubThreads >= m_end) continue;   // (workgroup-uniform: no second member this round)
-            const int m = head[u].x, hl = head[u].y, d = head[u].z & 0xFFFFFF, n = (head[u].z >> 24) & 0xFF, lfc = head[u].w;
-            const double chance = __longlong_as_double((static_cast<long long>(second[u].y) << 32) | static_cast<unsigned int>(second[u].x));
-            bool pruned = true;
-            double self_reach = 0.0, cf_reach = 1.0, r = 1.0;
-            int q = 0;
+          for (int u = 0; u < NU; ++u) { pruned[u] = true; self_reach[u] = 0.0; cf_reach[u] = 1.0; r[u] = 1.0; }
+          int q = 0;
 #pragma unroll
-            for (int c = 0; c < kSubCodeChunks; ++c) {
-              if (c < n_chunks) {   // (workgroup-uniform)
+          for (int c = 0; c < kSubCodeChunks; ++c) {
+            if (c < n_chunks) {   // (workgroup-uniform)
+#pragma unroll
+              for (int u = 0; u < NU; ++u) {
                 const unsigned int w0 = static_cast<unsigned int>((c & 1) ? codes[u][c >> 1].z : codes[u][c >> 1].x),
                                    w1 = static_cast<unsigned int>((c & 1) ? codes[u][c >> 1].w : codes[u][c >> 1].y);
                 const unsigned int cx = w0 & 0xFFFFu, cy = w0 >> 16, cz = w1 & 0xFFFFu, cw = w1 >> 16;   // 0xFFFF: padding
-#if OSG_SUB_EXP & 2   // (timing experiment: no LDS gathers)
-                const double px = 0.5 + cx * 1e-9, py = 0.5 + cy * 1e-9, pz = 0.5 + cz * 1e-9, pw = 0.5 + cw * 1e-9;
-#else
                 const double px = s_pol[cx == 0xFFFFu ? 0u : cx], py = s_pol[cy == 0xFFFFu ? 0u : cy],
                              pz = s_pol[cz == 0xFFFFu ? 0u : cz], pw = s_pol[cw == 0xFFFFu ? 0u : cw];
-#endif
-                r = r * (cx == 0xFFFFu ? 1.0 : px);   // (x * 1.0 == x: the padding leaves the product as it is)
-                r = r * (cy == 0xFFFFu ? 1.0 : py);
-                r = r * (cz == 0xFFFFu ? 1.0 : pz);
-                r = r * (cw == 0xFFFFu ? 1.0 : pw);
-                if ((c + 1) % per_player == 0) {   // the last chunk of player q's group
-                  pruned &= (r == 0.0);
-                  if (q == upd) self_reach = r; else cf_reach *= r;
-                  ++q;
-                  r = 1.0;
+                r[u] = r[u] * (cx == 0xFFFFu ? 1.0 : px);   // (x * 1.0 == x: the padding leaves the product as it is)
+                r[u] = r[u] * (cy == 0xFFFFu ? 1.0 : py);
+                r[u] = r[u] * (cz == 0xFFFFu ? 1.0 : pz);
+                r[u] = r[u] * (cw == 0xFFFFu ? 1.0 : pw);
+              }
+              if ((c + 1) % per_player == 0) {   // the last chunk of player q's group
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                  pruned[u] &= (r[u] == 0.0);
+                  if (q == upd) self_reach[u] = r[u]; else cf_reach[u] *= r[u];
+                  r[u] = 1.0;
                 }
+                ++q;
               }
             }
-            cf_reach *= chance;
+          }
+#pragma unroll
+          for (int u = 0; u < NU; ++u) {
+            const int m = head[u].x, hl = head[u].y, d = head[u].z & 0xFFFFFF, n = (head[u].z >> 24) & 0xFF, lfc = head[u].w;
+            const double chance = __longlong_as_double((static_cast<long long>(second[u].y) << 32) | static_cast<unsigned int>(second[u].x));
+            const double cf = cf_reach[u] * chance;
             const unsigned int at = static_cast<unsigned int>(m) * (kSubRecDoubles * 8);
             const double vh = s_value[live[u] ? hl : 0];
             double dr[kSplitMaxA], dp[kSplitMaxA];
 #pragma unroll
             for (int a = 0; a < kSplitMaxA; ++a) {
               dr[a] = 0.0; dp[a] = 0.0;
-              if (live[u] && !pruned && a < n) {
-                dr[a] = cf_reach * (s_value[lfc + a] - vh);
+              if (live[u] && !pruned[u] && a < n) {
+                dr[a] = cf * (s_value[lfc + a] - vh);
                 const double pol = s_pol[d * A + a];
-                dp[a] = cfg.linear_averaging ? iteration * self_reach * pol : self_reach * pol;
+                dp[a] = cfg.linear_averaging ? iteration * self_reach[u] * pol : self_reach[u] * pol;
               }
             }
-            if (pruned) {   // the flag record: a quiet NaN whose low word is 1 in the first word, nothing else read
+            if (pruned[u]) {   // the flag record: a quiet NaN whose low word is 1 in the first word, nothing else is read
               dr[0] = __longlong_as_double((static_cast<long long>(kSubFlagHi) << 32) | 1ll);
               dr[1] = 0.0;
             }
             static_assert(kSplitMaxA == 4 && kSubRecDoubles == 8, "the record is two pieces of regret terms, two of policy terms");
-#if OSG_SUB_EXP & 1   // (timing experiment: the terms are not written)
-            if (dr[0] + dr[1] + dr[2] + dr[3] + dp[0] + dp[1] + dp[2] + dp[3] == 1.2345e-300) store_through16(rec_buf, at, osg_d2{dr[0], dr[1]});
-#else
             if (A > 2 && OSG_SUB_QUAD_STORE) {   // (workgroup-uniform)
               // A member's 64-byte record leaves as ONE contiguous piece of memory traffic: the four lanes of a quad write
               // the four 16-byte pieces of ONE member's record together, member by member (round 6).  Written by its own
               // lane piece by piece, every store instruction put 64 scattered 16-byte fragments on the fabric — the records
-              // of a bin's members lie ~2.5 KB apart — and the phase spent 7 of its 12 us there (profiles/r06h_*).
+              // of a bin's members lie ~2.5 KB apart — and the phase spent 7 of its 12 us there (profiles/r06h_*, r06i_*).
               const int rq = tid & 3;
               const unsigned int own[4][4] = {
                   {dlo(dr[0]), dhi(dr[0]), dlo(dr[1]), dhi(dr[1])}, {dlo(dr[2]), dhi(dr[2]), dlo(dr[3]), dhi(dr[3])},
@@ -455,7 +437,7 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
               quad_store<3>(rec_buf, own, at, wr, rq);
             } else if (live[u]) {
               store_through16(rec_buf, at, osg_d2{dr[0], dr[1]});
-              if (!pruned) {
+              if (!pruned[u]) {
                 store_through16(rec_buf, at + 32, osg_d2{dp[0], dp[1]});
                 if (A > 2) {   // (workgroup-uniform)
                   store_through16(rec_buf, at + 16, osg_d2{dr[2], dr[3]});
@@ -463,12 +445,22 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
                 }
               }
             }
-#endif
           }
+        };
+        // A round covers 2 048 members: thread t takes members mbase + t and mbase + 1 024 + t.  Which form a WAVEFRONT runs
+        // is its own (wave-uniform, so the quad stores may read their neighbours' registers): two members only where its
+        // lanes have a second one — with 1 052 - 1 086 members that is the first wavefront alone; the whole workgroup in the
+        // two-member form doubled the phase's instructions and put ~2 us on the 64 workgroups every barrier waits for.
+        for (int mbase = m_begin; mbase < m_end; mbase += 2 * kSubThreads) {
+          const int wave_first = mbase + (tid & ~63);
+          if (wave_first + kSubThreads < m_end) members_round(mbase, std::integral_constant<int, 2>{});
+          else if (wave_first < m_end) members_round(mbase, std::integral_constant<int, 1>{});
         }
         __syncthreads();   // (the next subtree of this workgroup reuses s_value)
       }
       if (stamp) sp.stamps[upd * 5 + 2] = wall_clock64();
+      // (profiling) when EVERY workgroup reaches the two barriers of the launch's last iteration: who the others wait for
+      if (sp.stamps && it == iters - 1 && tid == 0) sp.stamps[8 * kMaxPlayers + (upd * 2 + 0) * gridDim.x + blockIdx.x] = wall_clock64();
       int e0 = 0, e_last = 0;
       // the records are staged behind what stays in LDS (keep_rows: the policy rows and chance probabilities)
       double* s_rec = sp.keep_rows ? s_value : s_dyn;
@@ -648,6 +640,7 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
         }
       }
       if (stamp) sp.stamps[upd * 5 + 4] = wall_clock64();
+      if (sp.stamps && it == iters - 1 && tid == 0) sp.stamps[8 * kMaxPlayers + (upd * 2 + 1) * gridDim.x + blockIdx.x] = wall_clock64();
       // the coming pass of this workgroup's bin (one bin per workgroup): its terminal values into LDS (the fold's stage
       // is done with) and the indices of the rows it will re-fetch — this pass's updating player's — while waiting
       const bool more = sp.keep_rows && sp.prefetch && !(it == iters - 1 && upd == P - 1);
@@ -1090,7 +1083,7 @@ int cfr_sub_iterate(osg_cfr* s, Tables tb, int iters) {
   if (std::getenv("OSG_CFR_SUB_STAMPS")) {
     sp.stamp_wg = std::max(0, std::min(s->sub_grid - 1, atoi(std::getenv("OSG_CFR_SUB_STAMPS")) - 1));
     fprintf(stderr, "k_cfr_sub: G %d grid %d NL %d ND %d PL %d K %d forest %d NR %d\n", s->sub_G, s->sub_grid, s->sub_NL, s->sub_ND, s->sub_PL, s->sub_K, s->sub_forest ? 1 : 0, s->sub_NR);
-    if (!d_stamps) OSG_HIP(hipMalloc(reinterpret_cast<void**>(&d_stamps), sizeof(unsigned long long) * 8 * kMaxPlayers));
+    if (!d_stamps) OSG_HIP(hipMalloc(reinterpret_cast<void**>(&d_stamps), sizeof(unsigned long long) * (8 * kMaxPlayers + 2 * kMaxPlayers * 1024)));
     sp.stamps = d_stamps;
   }
   hipStream_t st = s->ctx->stream;
@@ -1117,6 +1110,23 @@ int cfr_sub_iterate(osg_cfr* s, Tables tb, int iters) {
               (h[q * 5 + 1] - h[s->P * 5 + q * 2]) / 100.0,
               (h[q * 5 + 1] - h[q * 5]) / 100.0, (h[q * 5 + 2] - h[q * 5 + 1]) / 100.0, (h[q * 5 + 3] - h[q * 5 + 2]) / 100.0,
               (h[q * 5 + 4] - h[q * 5 + 3]) / 100.0, q + 1 < s->P ? (h[(q + 1) * 5] - h[q * 5]) / 100.0 : 0.0);
+  }
+  if (sp.stamps && s->sub_grid <= 1024) {   // arrival of every workgroup at the two barriers of each pass (s_memrealtime: one clock for the chip)
+    std::vector<unsigned long long> a(static_cast<size_t>(2) * s->P * s->sub_grid);
+    OSG_HIP(hipMemcpyAsync(a.data(), sp.stamps + 8 * kMaxPlayers, sizeof(unsigned long long) * a.size(), hipMemcpyDeviceToHost, st));
+    OSG_HIP(hipStreamSynchronize(st));
+    for (int q = 0; q < s->P; ++q)
+      for (int w = 0; w < 2; ++w) {
+        const unsigned long long* v = a.data() + static_cast<size_t>(q * 2 + w) * s->sub_grid;
+        unsigned long long lo = v[0], hi = v[0];
+        int last = 0;
+        for (int g = 0; g < s->sub_grid; ++g) { if (v[g] < lo) lo = v[g]; if (v[g] > hi) { hi = v[g]; last = g; } }
+        int late1 = 0, late2 = 0, late_big = 0;
+        for (int g = 0; g < s->sub_grid; ++g) { late1 += hi - v[g] <= 100; late2 += hi - v[g] <= 200; late_big += (hi - v[g] <= 200 && g < 64); }
+        fprintf(stderr, "k_cfr_sub pass %d barrier %c arrivals (us after the first): last %.2f (workgroup %d); within 1 us of the last: %d, within 2 us: %d (%d of them among workgroups 0-63); wg 0 %.2f, 32 %.2f, 100 %.2f, 200 %.2f, %d %.2f\n",
+                q, w ? 'B' : 'A', (hi - lo) / 100.0, last, late1, late2, late_big, (v[0] - lo) / 100.0, (v[std::min(32, s->sub_grid - 1)] - lo) / 100.0,
+                (v[std::min(100, s->sub_grid - 1)] - lo) / 100.0, (v[std::min(200, s->sub_grid - 1)] - lo) / 100.0, s->sub_grid - 1, (v[s->sub_grid - 1] - lo) / 100.0);
+      }
   }
   s->iteration += iters;
   s->last_kernel = s->sub_forest ? "k_cfr_sub<forest>" : (s->sub_G < s->sub_G0 ? "k_cfr_sub<packed>" : "k_cfr_sub");

@@ -190,8 +190,12 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
         const unsigned int grp = blockIdx.x >> 4, ngrp = (gridDim.x + 15u) >> 4;
         const unsigned int gsize = gridDim.x - (grp << 4) < 16u ? gridDim.x - (grp << 4) : 16u;
         if (__hip_atomic_fetch_add(&sp.bar[16 + 16 * grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == epoch * gsize) {
-          if (__hip_atomic_fetch_add(&sp.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == epoch * ngrp)
+          if (sp.tree_barrier == 2) {   // (round 6) the top counter IS what the pollers watch: no release word, one hop less after the last arrival
+            (void)ngrp;
+            __hip_atomic_fetch_add(&sp.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else if (__hip_atomic_fetch_add(&sp.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == epoch * ngrp) {
             __hip_atomic_store(&sp.bar[2], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       } else {
         __hip_atomic_fetch_add(&sp.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -201,7 +205,17 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
     if (tid == 0) {
       const unsigned long long t0 = wall_clock64();
       int ok = 1;
-      if (sp.tree_barrier) {
+      if (sp.tree_barrier == 2) {
+        // 16 adds per barrier land on the top counter (one per group), so 256 pollers reading it do not starve them as they
+        // starved round 4's 256 adds; another workgroup's give-up shows in the error word, looked at every 16th poll
+        const unsigned int want = epoch * ((gridDim.x + 15u) >> 4);
+        unsigned int polls = 0;
+        while (__hip_atomic_load(&sp.bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          if (wall_clock64() - t0 > sp.timeout_ticks) { ok = 0; break; }
+          if ((++polls & 15u) == 0u && __hip_atomic_load(&sp.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      } else if (sp.tree_barrier) {
         unsigned int seen;
         while ((seen = __hip_atomic_load(&sp.bar[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < epoch) {
           if (wall_clock64() - t0 > sp.timeout_ticks) { ok = 0; break; }
@@ -1067,7 +1081,10 @@ int cfr_sub_iterate(osg_cfr* s, Tables tb, int iters) {
   SubTree sp{s->sub_G, s->sub_L, s->sub_NL, s->d_sub_nloc, s->d_sub_desc, s->d_sub_fc, s->d_sub_aux, s->sub_ND, s->d_sub_ndec,
              s->d_sub_dec_row, s->d_sub_mem_off,
              s->d_sub_rec, s->sub_PL, s->d_sub_info_off, s->d_sub_info_list, s->d_sub_recbuf,
-             (std::getenv("OSG_CFR_SUB_FLAT_BARRIER") && std::getenv("OSG_CFR_SUB_FLAT_BARRIER")[0] == '1') ? 0 : 1,
+             // the grid barrier: 2 = two-level arrival, the pollers watch the top counter (round 6); 1 = the same with a release
+             // word (round 5; OSG_CFR_SUB_BARRIER=release); 0 = round 4's flat counter (OSG_CFR_SUB_FLAT_BARRIER=1)
+             (std::getenv("OSG_CFR_SUB_FLAT_BARRIER") && std::getenv("OSG_CFR_SUB_FLAT_BARRIER")[0] == '1')
+                 ? 0 : ((std::getenv("OSG_CFR_SUB_BARRIER") && std::strcmp(std::getenv("OSG_CFR_SUB_BARRIER"), "release") == 0) ? 1 : 2),
              s->d_sub_bar, s->h_sub_err, 400000000ull /* 4 s at 100 MHz */, nullptr};
   sp.dec_off = s->d_sub_dec_off; sp.chance_prob = s->d_sub_chance_prob; sp.NCP = s->sub_NCP;
   sp.keep_rows = (s->sub_keep_rows && !(std::getenv("OSG_CFR_SUB_KEEP_ROWS") && std::getenv("OSG_CFR_SUB_KEEP_ROWS")[0] == '0')) ? 1 : 0;

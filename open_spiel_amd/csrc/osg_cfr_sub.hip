@@ -134,6 +134,9 @@ __global__ void __launch_bounds__(256) k_gcfr_fold(GridCfr g, int upd, osg_cfr_c
 // worth (3 260 -> 8 260 iterations/s on 3-player leduc in round 5).
 // Reference: cfr.cc:331-408 (ComputeCounterFactualRegret), 443-469, 596-615.
 // ---------------------------------------------------------------------------
+#ifndef OSG_SUB_KEEP_DESCRIPTORS
+#define OSG_SUB_KEEP_DESCRIPTORS 1
+#endif
 #ifndef OSG_SUB_QUAD_STORE
 #define OSG_SUB_QUAD_STORE 1
 #endif
@@ -243,26 +246,32 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
   const __amdgpu_buffer_rsrc_t rec_buf = through_buffer(sp.recbuf);
   bool prefetched = false;   // the coming pass's terminal values are in LDS and its rows' indices in rows_pref
   int rows_pref[2] = {-1, -1};
+  // ---- the thread's histories of a bin: descriptors in registers for the sweep.  With one bin per workgroup (the
+  //      packed / forest forms) they are the same in every pass: fetched ONCE per launch (round 6: 0.8 us per pass) ----
+  int o_d[kK], o_fc[kK], o_aux[kK];
+  auto load_descriptors = [&](int g, int nloc) {
+#pragma unroll
+    for (int k = 0; k < kK; ++k) {
+      const int j = tid + k * kSubThreads;
+      o_d[k] = kTerminalNode | (63 << 10);   // padding: a terminal of a level never swept
+      o_fc[k] = 0; o_aux[k] = 0;
+      if (j < nloc) {
+        o_d[k] = sp.desc[static_cast<size_t>(g) * sp.NL + j];
+        o_fc[k] = sp.fc[static_cast<size_t>(g) * sp.NL + j];
+        o_aux[k] = sp.aux[static_cast<size_t>(g) * sp.NL + j];
+      }
+    }
+  };
+  const bool one_bin = OSG_SUB_KEEP_DESCRIPTORS && sp.G <= static_cast<int>(gridDim.x);
+  if (one_bin && static_cast<int>(blockIdx.x) < sp.G) load_descriptors(blockIdx.x, sp.nloc[blockIdx.x]);
   for (int it = 0; it < iters; ++it) {
     const int iteration = iteration0 + it + 1;
     for (int upd = 0; upd < P; ++upd) {
       const bool stamp = sp.stamps && it == iters - 1 && static_cast<int>(blockIdx.x) == sp.stamp_wg && tid == 0;
       if (stamp) sp.stamps[upd * 5 + 0] = wall_clock64();
       for (int g = blockIdx.x; g < sp.G; g += gridDim.x) {
-        // ---- the thread's histories of this subtree: descriptors in registers for the sweep ----
         const int nloc = sp.nloc[g];
-        int o_d[kK], o_fc[kK], o_aux[kK];
-#pragma unroll
-        for (int k = 0; k < kK; ++k) {
-          const int j = tid + k * kSubThreads;
-          o_d[k] = kTerminalNode | (63 << 10);   // padding: a terminal of a level never swept
-          o_fc[k] = 0; o_aux[k] = 0;
-          if (j < nloc) {
-            o_d[k] = sp.desc[static_cast<size_t>(g) * sp.NL + j];
-            o_fc[k] = sp.fc[static_cast<size_t>(g) * sp.NL + j];
-            o_aux[k] = sp.aux[static_cast<size_t>(g) * sp.NL + j];
-          }
-        }
+        if (!one_bin) load_descriptors(g, nloc);
         if (stamp && g == static_cast<int>(blockIdx.x)) sp.stamps[P * 5 + upd * 2 + 1] = wall_clock64();
         // the level range of every slot (its first and its last valid history), for the sweep's (slot, level) walk
 #pragma unroll

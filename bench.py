@@ -394,10 +394,12 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
                                                          "policy rows and chance probabilities in LDS, the rows resident between passes), two "
                                                          "two-level grid barriers per player pass with the next phase's static fetches in "
                                                          "their windows; tables bit-identical with the launch-per-phase kernels (1 870 it/s)",
-                                             "note": "round 4: 3 260 it/s (336 subtrees on 256 workgroups, a flat counter barrier, 8-byte "
-                                                     "written-through terms).  Still bound by dependent phases, not bytes: a pass of ~40 us is "
-                                                     "sweep 10.5 (20 levels + 8 slots of LDS round trips), members 10.6, fold 6-8.5 and two "
-                                                     "barriers; profiles/r05m_cfr_sub_fold_vectorised_level_major_ab.txt has the per-workgroup phase stamps"}
+                                             "note": "round 4: 3 260 it/s, round 5: 8 000-8 260, round 6: ~10 200 — a member's 64-byte record "
+                                                     "written by its quad as one contiguous piece (the members phase 12 -> 5.7 us: profiles/r06h_*, "
+                                                     "r06i_*), the two-member round per wavefront, the barrier's pollers on the top counter, the "
+                                                     "bin's descriptors fetched once per launch (r06m_*, r06o_*, r06p_*).  Still bound by dependent "
+                                                     "phases, not bytes: a pass of ~32 us is sweep ~10.5, members ~6, fold 6.5-8 and two barriers; "
+                                                     "OSG_CFR_SUB_STAMPS prints the phase stamps and every workgroup's barrier arrivals"}
             del three
             if three_tables is not None:
                 try:

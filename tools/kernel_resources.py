@@ -26,18 +26,40 @@ import yaml
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 
-# Kernels on a BASELINE config or named by a VERDICT: these must not spill (prefix match on the short name below).
+# Every kernel the bench line names (headline, legs and secondary workloads), plus the evaluator / judge kernels of the
+# same configs (prefix match on the short name below): each either spills nothing and uses no scratch, or stands in
+# KNOWN with the measurement that justified keeping it as it is.
 HOT = [
     "k_step_c4std2", "k_step_c4std<", "k_step_hexvec<3, 2",
     "k_cfr_small<true, true, 3, 2, 2>", "k_cfr_split<3, false, 512, 3>", "k_cfr_split<3, false, 512, 0>", "k_cfr_split<3, true, 512, 0>",
     "k_env_step_x2<osg::C4T<6, 7, 4, unsigned long> >",
     "k_env_step<osg::C4T<6, 7, 4, unsigned long> >",
+    "k_random_steps<osg::C4T<6, 7, 4, unsigned long> >",
+    "k_cfr_sub<8>", "k_mccfr_resident_flat<3>", "k_mcts_advance<osg::Ttt, true, true>", "k_mcts_wave<osg::HexT<3>, true, true, false>",
+    "k_rollout<osg::HexT<3> >", "k_eval_jobs", "k_geval_", "k_policy_eval", "k_oneshot_allreduce<double>",
+    "k_observation_rows<osg::C4T<6, 7, 4, unsigned long>", "k_fold_deltas",
 ]
-# Hot kernels whose parked registers are known, measured and kept (the note says where the decision is recorded).
+# Hot kernels whose parked registers / scratch are known, measured and kept (the note says where the decision is recorded).
 KNOWN = {
     "k_mcts_wave<osg::HexT<3>, true, true, false>":
         "44 scalar registers parked in vector lanes + 2 vector registers in scratch at 7 waves per SIMD; the form without them "
         "measured 2.7 % slower (profiles/r05_ab_register_work.txt, osg_mcts_wave.hip above wave_search)",
+    "k_cfr_sub<8>":
+        "the bin's 24 history descriptors stay in registers across the passes of a launch (round 6): that pushes 52 vector "
+        "registers into scratch around the fold and still measured 9 730 -> 10 240 iterations/s against fetching them every "
+        "pass with no scratch (profiles/r06p_*); ~180 scalar registers (the kernel's ~40 argument pointers) are parked in "
+        "vector lanes: a v_readlane each (693 of the kernel's 5 500 instructions, no memory) — fetching them with s_load "
+        "at their uses would put a scalar-cache round trip on the phases' dependent chains instead",
+    "k_mccfr_resident_flat<3>":
+        "976 B of scratch per lane BY DESIGN: the traverser's frames below the top two (40 B x 24 levels) have no room in "
+        "LDS (tables 67 KB x 2 workgroups per CU) — two frames in registers measured -3.3 % (profiles/r05_ab_solvers.txt); no register spills",
+    "k_mcts_advance<osg::Ttt, true, true>":
+        "the one-root search: ONE searching wavefront per launch by construction (1 wave per SIMD is its occupancy whatever "
+        "the register count), 72 scalar registers parked in vector lanes; round 6 took its node accesses off volatile "
+        "(12.39 -> 11.68 ms per 1000-simulation search, profiles/r06d_one_root_noderef_ab.txt)",
+    "k_rollout<osg::HexT<3> >":
+        "41 scalar registers parked in vector lanes (v_readlane, no memory), no scratch, 6 waves per SIMD; RandomRolloutEvaluator "
+        "of hex(9) outside the search kernel (config 4's playouts run inside k_mcts_wave) — no form without them has been measured",
 }
 
 
@@ -115,7 +137,7 @@ def main():
             flag = "  <-- spills" if (r["vspill"] or r["sspill"]) else "  <-- scratch (frames / dynamic indexing)"
         lines.append(f"{r['vgpr']:>4} {r['agpr']:>4} {r['sgpr']:>4} {r['vspill']:>4} {r['sspill']:>4} {r['scratch']:>5} "
                      f"{r['lds']:>6} {r['bound']:>5} {waves_per_simd(r['vgpr'], r['agpr']):>6}  {r['name']}{flag}")
-        if any(r["name"].startswith(h) for h in HOT) and (r["vspill"] or r["sspill"] or r["scratch"]):
+        if any(r["name"].startswith(h) for h in HOT) and (r["vspill"] or r["sspill"] or r["scratch"]) and r["name"] not in KNOWN:
             bad.append(r["name"])
     n_spill = sum(1 for r in rows if r["vspill"] or r["sspill"])
     n_scr = sum(1 for r in rows if r["scratch"])
@@ -123,7 +145,7 @@ def main():
     if bad:
         lines.append("# HOT kernels that spill: " + "; ".join(bad))
     else:
-        lines.append("# no kernel of the HOT list (tools/kernel_resources.py) spills or uses scratch")
+        lines.append("# every kernel of the HOT list (tools/kernel_resources.py) either spills nothing and uses no scratch or is listed under `known` below")
     for r in rows:
         if r["name"] in KNOWN:
             lines.append(f"# known: {r['name']}: {r['sspill']} scalar / {r['vspill']} vector registers spilled, {r['scratch']} B scratch — {KNOWN[r['name']]}")

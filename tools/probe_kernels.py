@@ -117,7 +117,8 @@ for game, nwide, depth_mod in [("hex(board_size=13)", 1 << 22, 100), ("hex(board
         cur = torch.empty(nwide, dtype=torch.int8, device="cuda"); term = torch.empty(nwide, dtype=torch.uint8, device="cuda")
         rets = torch.empty((nwide, d.num_players), dtype=torch.float64, device="cuda")
         s = timeit(lambda: osa._abi.check(osa.lib().osg_status_query(b._h, cur.data_ptr(), term.data_ptr(), rets.data_ptr(), 0)), iters=20, warm=3)
-        report(f"k_status {game} wide ({sb} B record; every byte read)", s, nwide, "states/s", nwide * (sb + 2 + 8 * d.num_players))
+        # (hex keeps mover / result in the meta bits: a status query reads the planes' last words — 16 B of the folded record)
+        report(f"k_status {game} wide ({sb} B record; 16 B of it read)", s, nwide, "states/s", nwide * (16 + 2 + 8 * d.num_players))
     bits = torch.empty((nwide, d.mask_words), dtype=torch.int32, device="cuda")
     s = timeit(lambda: osa._abi.check(osa.lib().osg_legal_mask(b._h, bits.data_ptr(), 0)), iters=20, warm=3)
     report(f"k_legal_mask {game} wide", s, nwide, "states/s", nwide * (sb + 4 * d.mask_words))

@@ -543,7 +543,11 @@ int osg_cfr_br_iterate(osg_cfr* s, int iters) {
   SplitTree sp{s->split_G, s->split_L, s->split_NL, s->split_NM, s->split_NI, s->d_split_nloc, s->d_split_desc,
                s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
                s->d_split_terms, s->d_split_bar, s->h_sub_err};
-  if (!split && !jobs && eval_takes_the_grid(s) && s->path_kernel) return cfr_grid_br_iterate(s, tb, ea, cfg, iters);   // osg_cfr_sub.hip
+  if (!split && !jobs && eval_takes_the_grid(s) && s->path_kernel) {   // large trees (osg_cfr_sub.hip)
+    // the P passes in ONE persistent launch per iteration (kernel == 2 keeps a launch per phase: the cross-check)
+    if (s->sub_ok && s->sub_br_ok && s->cfg.kernel != 2) return cfr_sub_br_iterate(s, tb, ea, cfg, iters);
+    return cfr_grid_br_iterate(s, tb, ea, cfg, iters);
+  }
   for (int it = 0; it < iters; ++it) {
     if (int rc = cfr_best_responses_to_current(s, ea, threads, jobs)) return rc;   // osg_cfr_eval.hip
     if (split) {

@@ -196,6 +196,9 @@ struct SubTree {
   const double* term_val = nullptr;   // [G, P, NL] player q's return at every terminal history of the bin, local order (0 elsewhere)
   int prefetch = 1;                   // 0: nothing is fetched in the barriers' windows (measurement)
   const int32_t* fold_off = nullptr;  // [P, grid + 1] the share of workgroup w in pass q: entries [fold_off[q][w], fold_off[q][w + 1])
+  // CFR-BR pass sets (k_cfr_sub<., kBr>, round 6): every infostate's best-response action index and acting player
+  const int32_t* br_best = nullptr;   // [I] (null: plain CFR)
+  const int32_t* br_player = nullptr; // [I]
 };
 OSG_D double readlane_f64(double v, int lane) {   // lane is wave-uniform: two v_readlane_b32, no LDS permute
   const long long b = __double_as_longlong(v);
@@ -354,6 +357,7 @@ struct osg_cfr {
   unsigned int* d_split_bar = nullptr;
   // one cooperative launch, a workgroup per deal subtree of any size (k_cfr_sub)
   bool sub_ok = false;
+  bool sub_br_ok = false;           // k_cfr_sub<., kBr> (the CFR-BR pass set) fits the same grid
   int sub_G = 0, sub_L = 0, sub_NL = 0, sub_K = 0, sub_grid = 0;
   size_t sub_lds_bytes = 0;
   int sub_ND = 0, sub_PL = 0;
@@ -430,7 +434,8 @@ int launch_split(osg_cfr* s, SmallTree stree, SplitTree sp, Tables tb, int iters
 int build_sub(osg_cfr* s);
 int cfr_sub_iterate(osg_cfr* s, Tables tb, int iters);      // k_cfr_sub
 int cfr_grid_iterate(osg_cfr* s, Tables tb, int iters);     // k_gcfr_*
-int cfr_grid_br_iterate(osg_cfr* s, Tables tb, const EvalArrays& ea, osg_cfr_cfg cfg, int iters);   // CFR-BR on large trees
+int cfr_grid_br_iterate(osg_cfr* s, Tables tb, const EvalArrays& ea, osg_cfr_cfg cfg, int iters);   // CFR-BR on large trees, a launch per phase
+int cfr_sub_br_iterate(osg_cfr* s, Tables tb, const EvalArrays& ea, osg_cfr_cfg cfg, int iters);    // CFR-BR on large trees, k_cfr_sub<., kBr>
 // ---- osg_cfr_eval.hip ----
 int build_eval_jobs(osg_cfr* s);
 EvalJobs eval_jobs_of(const osg_cfr* s);

@@ -162,7 +162,11 @@ OSG_D void quad_store(__amdgpu_buffer_rsrc_t rec_buf, const unsigned int (&own)[
   if (wr_s) __builtin_amdgcn_raw_buffer_store_b128(mine, rec_buf, static_cast<int>(at_s + 16u * static_cast<unsigned int>(rq)), 0, kCachePolicySc1);
 }
 
-template <int kK>   // histories per thread: NL <= kK * 1024
+// kBr (round 6): a CFR-BR pass set (cfr_br.cc:70-81) — the rows pass `upd` plays are the updating player's rows of the current
+// policy and, for every other player, the one-hot row of the best-response action the evaluation left in sp.br_best
+// (policy_overrides, cfr.cc:365-372): every pass stages all its rows, nothing else changes.  A template argument so that
+// the plain CFR kernel's code object is what it was.
+template <int kK, bool kBr = false>   // histories per thread: NL <= kK * 1024
 __global__ void __launch_bounds__(kSubThreads)
 k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0, osg_cfr_cfg cfg) {
   extern __shared__ __attribute__((aligned(16))) double s_dyn[];
@@ -292,7 +296,7 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
           }
         }
         const int ndec = sp.ndec[g];
-        const bool all_rows = !sp.keep_rows || (it == 0 && upd == 0);
+        const bool all_rows = kBr || !sp.keep_rows || (it == 0 && upd == 0);
         if (all_rows) {
           int rows[kSubKD];   // the thread's decision histories: all their rows are requested before the first arrives
 #pragma unroll
@@ -300,13 +304,31 @@ k_cfr_sub(Tree t, SmallTree st, SubTree sp, Tables tb, int iters, int iteration0
             const int d = tid + k * kSubThreads;
             rows[k] = d < ndec ? sp.dec_row[static_cast<size_t>(g) * sp.ND + d] : -1;
           }
+          if constexpr (kBr) {
+            int own[kSubKD], best[kSubKD];
+#pragma unroll
+            for (int k = 0; k < kSubKD; ++k) {
+              const int i = rows[k] >= 0 ? rows[k] / A : 0;
+              own[k] = sp.br_player[i] == upd ? 1 : 0;
+              best[k] = sp.br_best[i];
+            }
+#pragma unroll
+            for (int k = 0; k < kSubKD; ++k) {
+#pragma unroll
+              for (int a = 0; a < kSplitMaxA; ++a)
+                if (rows[k] >= 0 && a < A)
+                  s_pol[(tid + k * kSubThreads) * A + a] = own[k] ? load_through(tb.cur + rows[k] + a) : (a == best[k] ? 1.0 : 0.0);
+            }
+          } else {
 #pragma unroll
           for (int k = 0; k < kSubKD; ++k) {
 #pragma unroll
             for (int a = 0; a < kSplitMaxA; ++a)
               if (rows[k] >= 0 && a < A) s_pol[(tid + k * kSubThreads) * A + a] = load_through(tb.cur + rows[k] + a);
           }
-          for (int c = tid; c < sp.NCP; c += kSubThreads) s_cp[c] = sp.chance_prob[static_cast<size_t>(g) * sp.NCP + c];
+          }
+          if (!kBr || !sp.keep_rows || (it == 0 && upd == 0))   // (a CFR-BR pass re-stages the rows only: the probabilities stay)
+            for (int c = tid; c < sp.NCP; c += kSubThreads) s_cp[c] = sp.chance_prob[static_cast<size_t>(g) * sp.NCP + c];
         } else {
           // the rows are still in LDS: only the previous pass's fold changed any — the rows of the player it updated —
           // and (forest form) the upper parents' rows ride behind
@@ -700,7 +722,11 @@ namespace osg_cfr_impl {
 // histories each.  Round 5, forest form: with more subtrees than compute units the bins of the workgroups are packed —
 // whole subtrees if they fit, else the pieces one level below the cut (SubTree's comment) — so that every workgroup
 // sweeps one bin per pass.  OSG_CFR_SUB_PACK=0 keeps a subtree per bin.
-template <int kK> const void* cfr_sub_kernel() { return reinterpret_cast<const void*>(&k_cfr_sub<kK>); }
+template <int kK, bool kBr = false> const void* cfr_sub_kernel() { return reinterpret_cast<const void*>(&k_cfr_sub<kK, kBr>); }
+const void* cfr_sub_kernel_of(int K, bool br) {
+  if (br) return K == 2 ? cfr_sub_kernel<2, true>() : (K == 4 ? cfr_sub_kernel<4, true>() : cfr_sub_kernel<8, true>());
+  return K == 2 ? cfr_sub_kernel<2>() : (K == 4 ? cfr_sub_kernel<4>() : cfr_sub_kernel<8>());
+}
 int build_sub(osg_cfr* s) {
   s->sub_ok = false;
   if (s->cfg.solver != 0 || s->B != 1 || !s->path_kernel || s->A > kSplitMaxA || !s->cfg.alternating_updates) return OSG_OK;
@@ -984,10 +1010,23 @@ int build_sub(osg_cfr* s) {
   int widest = 0;   // the fold stages an infostate's member records in LDS: all of one infostate must fit a round
   for (int i = 0; i < s->I; ++i) widest = std::max(widest, s->mem_off[i + 1] - s->mem_off[i]);
   if (widest > fold_cap) return OSG_OK;
-  const void* kern = K == 2 ? cfr_sub_kernel<2>() : (K == 4 ? cfr_sub_kernel<4>() : cfr_sub_kernel<8>());
+  const void* kern = cfr_sub_kernel_of(K, false);
   if (raise_lds_cap(kern, static_cast<int>(lds)) != hipSuccess) {
     (void)hipGetLastError();
     return OSG_OK;
+  }
+  // the CFR-BR form of the same kernel: taken when it can be resident on the same grid (else CFR-BR keeps the launches per phase)
+  s->sub_br_ok = false;
+  if (raise_lds_cap(cfr_sub_kernel_of(K, true), static_cast<int>(lds)) == hipSuccess) {
+    int per_cu_br = 0;
+    hipError_t eb;
+    if (K == 2) eb = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_br, k_cfr_sub<2, true>, kSubThreads, lds);
+    else if (K == 4) eb = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_br, k_cfr_sub<4, true>, kSubThreads, lds);
+    else eb = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_br, k_cfr_sub<8, true>, kSubThreads, lds);
+    if (eb == hipSuccess) s->sub_br_ok = per_cu_br >= 1;
+    else (void)hipGetLastError();
+  } else {
+    (void)hipGetLastError();
   }
   int per_cu = 0;
   hipError_t e;
@@ -1081,8 +1120,9 @@ int build_sub(osg_cfr* s) {
   return OSG_OK;
 }
 
-// The persistent cooperative launch (osg_cfr_iterate's sub_path).
-int cfr_sub_iterate(osg_cfr* s, Tables tb, int iters) {
+// The persistent cooperative launch (osg_cfr_iterate's sub_path); br_best != null: ONE CFR-BR pass set on the best responses
+// the evaluation left there (cfr_sub_br_iterate below).
+static int cfr_sub_run(osg_cfr* s, Tables tb, int iters, const int32_t* br_best, osg_cfr_cfg cfg) {
   if (int rc = cfr_sub_error(s)) return rc;
   const int M = static_cast<int>(s->mem.size());
   Tree tr = s->tree();
@@ -1105,6 +1145,7 @@ int cfr_sub_iterate(osg_cfr* s, Tables tb, int iters) {
     sp.nroot = s->d_sub_nroot; sp.root_loc = s->d_sub_root_loc; sp.root_idx = s->d_sub_root_idx; sp.NR = s->sub_NR;
     sp.root_value = s->d_sub_root_value; sp.upper_rec = s->d_sub_upper_rec;
   }
+  sp.br_best = br_best; sp.br_player = s->d_info_player32;
   unsigned long long*& d_stamps = s->d_sub_stamps;   // OSG_CFR_SUB_STAMPS=1: phase stamps of one workgroup (tools/probe_cfr_sub.py); the solver's own buffer
   if (std::getenv("OSG_CFR_SUB_STAMPS")) {
     sp.stamp_wg = std::max(0, std::min(s->sub_grid - 1, atoi(std::getenv("OSG_CFR_SUB_STAMPS")) - 1));
@@ -1117,8 +1158,8 @@ int cfr_sub_iterate(osg_cfr* s, Tables tb, int iters) {
   for (int done = 0; done < iters; done += per_launch) {
     int now = std::min(per_launch, iters - done), it0 = s->iteration + done;
     OSG_HIP(hipMemsetAsync(s->d_sub_bar, 0, sizeof(unsigned int) * kSubBarWords, st));
-    void* args[] = {&tr, &stree, &sp, &tb, &now, &it0, &s->cfg};
-    const void* kern = s->sub_K == 2 ? cfr_sub_kernel<2>() : (s->sub_K == 4 ? cfr_sub_kernel<4>() : cfr_sub_kernel<8>());
+    void* args[] = {&tr, &stree, &sp, &tb, &now, &it0, &cfg};
+    const void* kern = cfr_sub_kernel_of(s->sub_K, br_best != nullptr);
     // (OSG_CFR_PLAIN_LAUNCH=1 as for k_cfr_split: an ordinary launch, for hosts that own the device — and for runs under
     // rocprofv3 --kernel-trace, where a process that made a cooperative launch crashes in an exit handler)
     static const bool plain = std::getenv("OSG_CFR_PLAIN_LAUNCH") && std::getenv("OSG_CFR_PLAIN_LAUNCH")[0] == '1';
@@ -1155,7 +1196,21 @@ int cfr_sub_iterate(osg_cfr* s, Tables tb, int iters) {
       }
   }
   s->iteration += iters;
-  s->last_kernel = s->sub_forest ? "k_cfr_sub<forest>" : (s->sub_G < s->sub_G0 ? "k_cfr_sub<packed>" : "k_cfr_sub");
+  if (br_best) s->last_kernel = s->sub_forest ? "k_cfr_sub<forest,br>" : (s->sub_G < s->sub_G0 ? "k_cfr_sub<packed,br>" : "k_cfr_sub<br>");
+  else s->last_kernel = s->sub_forest ? "k_cfr_sub<forest>" : (s->sub_G < s->sub_G0 ? "k_cfr_sub<packed>" : "k_cfr_sub");
+  return OSG_OK;
+}
+int cfr_sub_iterate(osg_cfr* s, Tables tb, int iters) { return cfr_sub_run(s, tb, iters, nullptr, s->cfg); }
+
+// CFRBRSolver::EvaluateAndUpdatePolicy on large trees through the persistent kernel (round 6): per iteration the
+// evaluation's one sweep (k_geval_*: every player's best response to the current policy, cfr_br.cc:55-68) and ONE launch of
+// k_cfr_sub<., kBr> for the P passes (cfr_br.cc:70-81) — where cfr_grid_br_iterate below spends ~58 launches on them.
+// The same additions in the same order: tables bit-identical with the launch-per-phase form.
+int cfr_sub_br_iterate(osg_cfr* s, Tables tb, const EvalArrays& ea, osg_cfr_cfg cfg, int iters) {
+  for (int it = 0; it < iters; ++it) {
+    if (int rc = launch_grid_eval(s, ea, s->cur(), false, nullptr, true)) return rc;
+    if (int rc = cfr_sub_run(s, tb, 1, s->d_best, cfg)) return rc;
+  }
   return OSG_OK;
 }
 

@@ -636,15 +636,20 @@ def test_cfr_br_on_the_split_kernel_equals_the_one_workgroup_passes(ctx, monkeyp
 def test_cfr_br_on_a_large_tree_takes_the_grid_and_equals_the_one_workgroup_passes(ctx, monkeypatch):
     """CFR-BR where the tree is beyond the jobs and the subtree kernels (5-player kuhn_poker: 116 437 histories; 3-player
     leduc_poker takes the same path): the evaluation's sweep leaves every infostate's best-response action and every
-    player's pass runs as launch-per-phase CFR on the effective policy (k_gcfr_* with k_gcfr_effpol) — the tables of the
-    one-workgroup pass set (k_policy_eval + k_cfr<., kBr>) bit for bit, at many times its rate."""
+    player's pass runs on the effective policy — by default (round 6) as ONE launch of the persistent kernel per
+    iteration (k_cfr_sub<., kBr>), with `general_kernel="grid"` as launch-per-phase CFR (k_gcfr_* with k_gcfr_effpol) —
+    the tables of the one-workgroup pass set (k_policy_eval + k_cfr<., kBr>) bit for bit, at many times its rate."""
     import time
     import open_spiel_amd as osa
     game = "kuhn_poker(players=5)"
     fast = osa.TabularSolver(ctx, game)
     fast.evaluate_and_update_policy_cfr_br(3)
-    assert fast.last_kernel() == "k_gcfr<br>"
+    assert fast.last_kernel().startswith("k_cfr_sub") and fast.last_kernel().endswith("br>"), fast.last_kernel()
     got = fast.tables()
+    grid = osa.TabularSolver(ctx, game, general_kernel="grid")
+    grid.evaluate_and_update_policy_cfr_br(3)
+    assert grid.last_kernel() == "k_gcfr<br>"
+    got_grid = grid.tables()
     monkeypatch.setenv("OSG_EVAL_GRID", "0")
     slow = osa.TabularSolver(ctx, game)
     slow.evaluate_and_update_policy_cfr_br(3)
@@ -652,6 +657,7 @@ def test_cfr_br_on_a_large_tree_takes_the_grid_and_equals_the_one_workgroup_pass
     monkeypatch.delenv("OSG_EVAL_GRID")
     for name in ("regrets", "cum_policy", "cur_policy"):
         np.testing.assert_array_equal(got[name], want[name])
+        np.testing.assert_array_equal(got_grid[name], want[name])
     big = osa.TabularSolver(ctx, "leduc_poker(players=3)")
     before = big.nash_conv()
     ctx.synchronize()
@@ -659,8 +665,21 @@ def test_cfr_br_on_a_large_tree_takes_the_grid_and_equals_the_one_workgroup_pass
     big.evaluate_and_update_policy_cfr_br(20)
     ctx.synchronize()
     rate = 20 / (time.perf_counter() - t0)
-    assert big.last_kernel() == "k_gcfr<br>" and rate > 150.0, rate       # (one workgroup: ~10 iterations per second)
+    assert big.last_kernel() == "k_cfr_sub<forest,br>" and rate > 150.0, (big.last_kernel(), rate)   # (one workgroup: ~10 iterations per second)
     assert big.nash_conv() < before
+    # the persistent form against a launch per phase on the 1.83 M-history tree: bit for bit, CFR iterations before and between
+    # (the CFR form of the same kernel keeps its rows in LDS between passes; the CFR-BR form must not inherit anything)
+    a = osa.TabularSolver(ctx, "leduc_poker(players=3)")
+    b = osa.TabularSolver(ctx, "leduc_poker(players=3)", general_kernel="grid")
+    for s in (a, b):
+        s.evaluate_and_update_policy(2)
+        s.evaluate_and_update_policy_cfr_br(3)
+        s.evaluate_and_update_policy(1)
+        s.evaluate_and_update_policy_cfr_br(2)
+    assert a.last_kernel() == "k_cfr_sub<forest,br>" and b.last_kernel() == "k_gcfr<br>"
+    ta, tb = a.tables(), b.tables()
+    for name in ("regrets", "cum_policy", "cur_policy"):
+        np.testing.assert_array_equal(ta[name], tb[name])
 
 
 def test_a_smaller_solver_does_not_lower_the_lds_cap_under_a_larger_one(ctx):

@@ -35,7 +35,7 @@ HOT = [
     "k_env_step_x2<osg::C4T<6, 7, 4, unsigned long> >",
     "k_env_step<osg::C4T<6, 7, 4, unsigned long> >",
     "k_random_steps<osg::C4T<6, 7, 4, unsigned long> >",
-    "k_cfr_sub<8>", "k_mccfr_resident_flat<3>", "k_mcts_advance<osg::Ttt, true, true>", "k_mcts_wave<osg::HexT<3>, true, true, false>",
+    "k_cfr_sub<8, false>", "k_cfr_sub<8, true>", "k_mccfr_resident_flat<3>", "k_mcts_advance<osg::Ttt, true, true>", "k_mcts_wave<osg::HexT<3>, true, true, false>",
     "k_rollout<osg::HexT<3> >", "k_eval_jobs", "k_geval_", "k_policy_eval", "k_oneshot_allreduce<double>",
     "k_observation_rows<osg::C4T<6, 7, 4, unsigned long>", "k_fold_deltas",
 ]
@@ -44,7 +44,10 @@ KNOWN = {
     "k_mcts_wave<osg::HexT<3>, true, true, false>":
         "44 scalar registers parked in vector lanes + 2 vector registers in scratch at 7 waves per SIMD; the form without them "
         "measured 2.7 % slower (profiles/r05_ab_register_work.txt, osg_mcts_wave.hip above wave_search)",
-    "k_cfr_sub<8>":
+    "k_cfr_sub<8, true>":
+        "the CFR-BR pass set of the same kernel (round 6): the code of k_cfr_sub<8, false> with the effective-policy rows staged "
+        "every pass; same registers, same reasons",
+    "k_cfr_sub<8, false>":
         "the bin's 24 history descriptors stay in registers across the passes of a launch (round 6): that pushes 52 vector "
         "registers into scratch around the fold and still measured 9 730 -> 10 240 iterations/s against fetching them every "
         "pass with no scratch (profiles/r06p_*); ~180 scalar registers (the kernel's ~40 argument pointers) are parked in "

@@ -396,6 +396,9 @@ int osg_cfr_iteration(const osg_cfr* s);
  * "k_mccfr_resident_flat", "k_mccfr_resident<split 2>", ...; "" before the first launch or for the remaining forms).  The
  * parity tests and bench.py record it next to what they checked (no reference counterpart). */
 const char* osg_cfr_last_kernel(const osg_cfr* s);
+/* Diagnostic: the form the last policy evaluation took ("k_geval": a launch per level and phase, "k_geval_persist": one
+ * persistent launch — opt-in, OSG_EVAL_PERSIST=1 —, "k_eval_jobs", "k_policy_eval"; "" before the first).  No reference counterpart. */
+const char* osg_cfr_last_eval_kernel(const osg_cfr* s);
 /* Number of replicas, and which one the table accessors / osg_cfr_evaluate_policy / upload act on. */
 int osg_cfr_replicas(const osg_cfr* s);
 int osg_cfr_select_replica(osg_cfr* s, int replica);

@@ -127,6 +127,7 @@ SIGNATURES = {
     "osg_cfr_reset": (INT, [VP]),
     "osg_cfr_iteration": (INT, [VP]),
     "osg_cfr_last_kernel": (C.c_char_p, [VP]),
+    "osg_cfr_last_eval_kernel": (C.c_char_p, [VP]),
     "osg_cfr_set_iteration": (INT, [VP, INT]),
     "osg_cfr_replicas": (INT, [VP]),
     "osg_cfr_select_replica": (INT, [VP, INT]),

@@ -446,7 +446,7 @@ int osg_cfr_destroy(osg_cfr* s) {
   void* ptrs[] = {s->d_level_off, s->d_parent, s->d_first_child, s->d_info, s->d_mem_off, s->d_mem, s->d_nact,
                   s->d_kind, s->d_nchild, s->d_aidx, s->d_actor, s->d_info_player, s->d_edge_prob, s->d_term_ret,
                   s->d_tables, s->d_reach, s->d_value, s->d_path_off, s->d_path, s->d_info_level, s->d_mem_index,
-                  s->d_best, s->d_eval, s->d_eval_ev, s->d_eval_level_info, s->d_meta32, s->d_info_player32, s->d_skip, s->d_node_delta, s->d_rec,
+                  s->d_best, s->d_eval, s->d_eval_ev, s->d_eval_level_info, s->d_eval_level_off, s->d_geval_bar, s->d_meta32, s->d_info_player32, s->d_skip, s->d_node_delta, s->d_rec,
                   s->d_uret, s->d_uprob, s->d_spare_delta[0], s->d_spare_delta[1], s->d_split_nloc, s->d_split_desc,
                   s->d_split_fc, s->d_split_row, s->d_split_glob, s->d_split_mem_m, s->d_split_mem_hloc, s->d_split_info,
                   s->d_split_terms, s->d_split_bar, s->d_sub_nloc, s->d_sub_desc, s->d_sub_fc, s->d_sub_aux, s->d_sub_mem_off,
@@ -624,6 +624,7 @@ int osg_cfr_infostate_key(const osg_cfr* s, int64_t i, char* buf, int cap) {
 
 int osg_cfr_iteration(const osg_cfr* s) { return s ? s->iteration : 0; }
 const char* osg_cfr_last_kernel(const osg_cfr* s) { return s ? s->last_kernel : ""; }
+const char* osg_cfr_last_eval_kernel(const osg_cfr* s) { return s ? s->last_eval_kernel : ""; }
 int osg_cfr_infostate_player(const osg_cfr* s, int64_t i) { return (s && i >= 0 && i < s->I) ? s->info_player[i] : -1; }
 int osg_cfr_replicas(const osg_cfr* s) { return s ? s->B : 0; }
 int osg_cfr_select_replica(osg_cfr* s, int replica) {

@@ -219,6 +219,163 @@ __global__ void __launch_bounds__(256) k_geval_brv(Tree t, EvalArrays ea, const 
 }
 
 // ---------------------------------------------------------------------------
+// The large-tree evaluation as ONE persistent cooperative launch (round 6): the phases of k_geval_cf / _best / _brv above
+// as grid-stride loops of one resident grid, a two-level counter barrier (k_cfr_sub's: group counters, the pollers watch
+// the top counter) where the launches had a kernel boundary — 3-player leduc: 39 launches of ~8 us each, most of it the
+// boundaries and the ramps of short kernels.  Everything a later phase reads that an earlier phase of the SAME launch
+// wrote (cf, the [H, P] responder values, the expected returns, best) moves with written-through stores and
+// cache-bypassing loads: the XCDs' L2s are not coherent with each other inside a launch.  The tree, the policy and the
+// host's per-level lists are read-only here: ordinary loads.  Same sums in the same order as the launches: bit-identical
+// (tests/test_gpu_cfr.py compares the two forms and the one-workgroup walk).
+// ---------------------------------------------------------------------------
+struct GEvalPlan {
+  const int32_t* level_info;      // the infostates of every level, level by level (the host's list)
+  const int32_t* level_info_off;  // [D + 1]
+  unsigned int* bar;              // [kSubBarWords] zeroed before the launch: [0] top counter, [1] error, [16 + 16 g] group g
+  unsigned int* host_err;         // pinned word raised on a timeout
+  unsigned long long timeout_ticks;
+};
+OSG_D bool geval_barrier(const GEvalPlan& gp, unsigned int& epoch, int* s_ok) {
+  ++epoch;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int grp = blockIdx.x >> 4, ngrp = (gridDim.x + 15u) >> 4;
+    const unsigned int gsize = gridDim.x - (grp << 4) < 16u ? gridDim.x - (grp << 4) : 16u;
+    if (__hip_atomic_fetch_add(&gp.bar[16 + 16 * grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == epoch * gsize)
+      __hip_atomic_fetch_add(&gp.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();
+    const unsigned int want = epoch * ngrp;
+    unsigned int polls = 0;
+    int ok = 1;
+    while (__hip_atomic_load(&gp.bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      if (wall_clock64() - t0 > gp.timeout_ticks) { ok = 0; break; }
+      if ((++polls & 15u) == 0u && __hip_atomic_load(&gp.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok) {
+      __hip_atomic_store(&gp.bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(gp.host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    *s_ok = ok;
+  }
+  __syncthreads();
+  // (an acquire fence here — buffer_inv sc1 per wavefront — with ordinary loads afterwards measured 1.58 ms per evaluation
+  // against 0.61 with a bypassing load per value: profiles/r06t_*)
+  return *s_ok != 0;
+}
+constexpr int kGEvalThreads = 1024;
+// A value another workgroup wrote is fetched by a buffer load with the sc1 bit (bypassing, and — unlike an agent-scope
+// atomic load — an ordinary load to the scheduler: the loads of a history's children are all requested before the first
+// is used)
+typedef unsigned int osg_u2 __attribute__((ext_vector_type(2)));
+OSG_D double geval_load(__amdgpu_buffer_rsrc_t buf, size_t idx) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(buf, static_cast<int>(idx * 8), 0, kCachePolicySc1));
+}
+OSG_D int32_t geval_load_i32(__amdgpu_buffer_rsrc_t buf, size_t idx) {
+  return static_cast<int32_t>(__builtin_amdgcn_raw_buffer_load_b32(buf, static_cast<int>(idx * 4), 0, kCachePolicySc1));
+}
+__global__ void __launch_bounds__(kGEvalThreads)
+k_geval_persist(Tree t, EvalArrays ea, const double* __restrict__ pol, double* ev, GEvalPlan gp) {
+  __shared__ int s_ok;
+  const int P = t.P, A = t.A;
+  const int tid = threadIdx.x;
+  const int64_t gtid = static_cast<int64_t>(blockIdx.x) * kGEvalThreads + tid, gsize = static_cast<int64_t>(gridDim.x) * kGEvalThreads;
+  unsigned int epoch = 0;
+  const __amdgpu_buffer_rsrc_t vbuf = through_buffer(ea.value), cbuf = through_buffer(ea.cf), bbuf = through_buffer(ea.best),
+                               ebuf = through_buffer(ev ? ev : ea.value);
+  // ---- counterfactual reaches of every player's decision histories (k_geval_cf) ----
+  for (int64_t m = gtid; m < ea.M; m += gsize) {
+    const int h = t.mem[m];
+    const int r = t.actor[h];
+    double cf = 1.0;
+    for (int e = ea.path_off[m]; e < ea.path_off[m + 1]; ++e) {
+      const int code = ea.path[e];
+      const int slot = (code >> 24) & 0xF, idx = code & 0x7FFFFF;
+      const double pr = ((code >> 23) & 1) ? t.edge_prob[idx] : (slot == r ? 1.0 : pol[idx]);
+      cf = cf * pr;
+    }
+    store_through(ea.cf + m, cf);
+  }
+  // (the first argmax needs cf; the deepest level holds terminals only, whose values need nothing: one barrier covers both)
+  for (int l = t.D - 1; l >= 0; --l) {
+    const int i0 = gp.level_info_off[l], n_infos = gp.level_info_off[l + 1] - i0;
+    if (n_infos > 0 || l == t.D - 1) {
+      if (!geval_barrier(gp, epoch, &s_ok)) return;
+    }
+    if (n_infos > 0) {
+      // ---- the argmax of the infostates whose members sit on level l: a wavefront each (k_geval_best) ----
+      const int lane = tid & 63;
+      const int64_t wave = gtid >> 6, waves = gsize >> 6;
+      for (int64_t w = wave; w < n_infos; w += waves) {
+        const int i = gp.level_info[i0 + w];
+        const int r = t.info_player[i], n = t.nact[i];
+        const int m0 = t.mem_off[i], cnt = t.mem_off[i + 1] - m0;
+        int best = -1;
+        double best_v = -1.7976931348623157e308;  // numeric_limits<double>::lowest()
+        for (int a = 0; a < n; ++a) {
+          double v = 0.0;
+          for (int c0 = 0; c0 < cnt; c0 += 64) {
+            const int here = cnt - c0 < 64 ? cnt - c0 : 64;
+            double prod = 0.0;
+            if (lane < here) {
+              const int m = m0 + c0 + lane;
+              prod = geval_load(cbuf, m) * geval_load(vbuf, static_cast<size_t>(t.first_child[t.mem[m]] + a) * P + r);
+            }
+            for (int j = 0; j < here; ++j) v += readlane_f64(prod, j);
+          }
+          if (v > best_v) { best_v = v; best = a; }
+        }
+        if (lane == 0) store_through_i32(ea.best + i, best < 0 ? 0 : best);
+      }
+      if (!geval_barrier(gp, epoch, &s_ok)) return;
+    }
+    // ---- every responder's values (and the expected returns) of level l (k_geval_brv) ----
+    for (int64_t h = t.level_off[l] + gtid; h < t.level_off[l + 1]; h += gsize) {
+      const int k = t.kind[h];
+      const int fc = k == kTerminalNode ? 0 : t.first_child[h], nc = k == kTerminalNode ? 0 : t.nchild[h];
+      const int actor = k == kDecisionNode ? t.actor[h] : -1;
+      const int row = k == kDecisionNode ? t.info[h] * A : 0;
+      if (ev) {
+        for (int q = 0; q < P; ++q) {
+          double v = 0.0;
+          if (k == kTerminalNode) {
+            v = t.term_ret[h * P + q];
+          } else {
+            for (int a = 0; a < nc; ++a) {
+              const double pr = k == kChanceNode ? t.edge_prob[fc + a] : pol[row + a];
+              if (pr > 0.0) v += pr * geval_load(ebuf, static_cast<size_t>(fc + a) * P + q);
+            }
+          }
+          store_through(ev + static_cast<size_t>(h) * P + q, v);
+          if (h == 0) ea.out[q] = v;
+        }
+      }
+      const int chosen = actor >= 0 ? geval_load_i32(bbuf, t.info[h]) : 0;
+      for (int r = 0; r < P; ++r) {
+        double v = 0.0;
+        if (k == kTerminalNode) {
+          v = t.term_ret[h * P + r];
+        } else if (actor == r) {
+          v += 1.0 * geval_load(vbuf, static_cast<size_t>(fc + chosen) * P + r);
+        } else {
+          for (int a = 0; a < nc; ++a) {
+            const double pr = k == kChanceNode ? t.edge_prob[fc + a] : pol[row + a];
+            v += pr * geval_load(vbuf, static_cast<size_t>(fc + a) * P + r);
+          }
+        }
+        store_through(ea.value + static_cast<size_t>(h) * P + r, v);
+        if (ea.keep && r == ea.keep_r) ea.keep[h] = v;
+        if (h == 0) ea.out[P + r] = v;
+      }
+    }
+    if (l > 0 && gp.level_info_off[l] - gp.level_info_off[l - 1] == 0) {   // (a level with infostates opens with its own barrier)
+      if (!geval_barrier(gp, epoch, &s_ok)) return;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // The same evaluation for trees that start with their chance deals (leduc_poker: two deal levels, then 30 subtrees
 // of 314 histories), spread over the device instead of one workgroup walking 9 457 histories level by level through
 // L2.  The quantities are independent below the cut once the work is grouped the right way:
@@ -456,6 +613,44 @@ int launch_grid_eval(const osg_cfr* s, const EvalArrays& ea, const double* src, 
     if (int rc = upload(list, &ms->d_eval_level_info, st)) return rc;
   }
   (void)iblocks;
+  // OSG_EVAL_PERSIST=1: ONE persistent cooperative launch for the whole sweep (round 6).  Measured SLOWER than the launches
+  // below on 3-player leduc (0.61 against 0.40 ms per NashConv, profiles/r06t_*): not the default; kept as the cross-check
+  {
+    const char* pe = getenv("OSG_EVAL_PERSIST");
+    if (pe && pe[0] == '1') {
+      if (!ms->d_eval_level_off) {
+        if (int rc = upload(ms->eval_level_off, &ms->d_eval_level_off, st)) return rc;
+        OSG_HIP(hipMalloc(reinterpret_cast<void**>(&ms->d_geval_bar), sizeof(unsigned int) * kSubBarWords));
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_geval_persist, kGEvalThreads, 0) != hipSuccess || per_cu < 1 ||
+            hipGetDeviceProperties(&prop, s->ctx->device) != hipSuccess || !prop.cooperativeLaunch) {
+          (void)hipGetLastError();
+          ms->geval_grid = -1;   // (no resident grid: the launches below)
+        } else {
+          const char* w = getenv("OSG_EVAL_PERSIST_PER_CU");
+          const int want = w ? std::max(1, atoi(w)) : 1;
+          ms->geval_grid = std::min(std::min(per_cu, want) * prop.multiProcessorCount, 1024);
+          if (static_cast<unsigned long long>(s->H) * s->P * sizeof(double) >= (1ull << 31)) ms->geval_grid = -1;   // (32-bit buffer offsets)
+        }
+      }
+      if (ms->geval_grid > 0) {
+        GEvalPlan gp{ms->d_eval_level_info, ms->d_eval_level_off, ms->d_geval_bar, s->h_sub_err, 400000000ull /* 4 s at 100 MHz */};
+        OSG_HIP(hipMemsetAsync(ms->d_geval_bar, 0, sizeof(unsigned int) * kSubBarWords, st));
+        Tree tt = t;
+        EvalArrays eaa = ea;
+        const double* pp = pol;
+        void* args[] = {&tt, &eaa, &pp, &d_ev, &gp};
+        static const bool plain = std::getenv("OSG_CFR_PLAIN_LAUNCH") && std::getenv("OSG_CFR_PLAIN_LAUNCH")[0] == '1';
+        const void* kern = reinterpret_cast<const void*>(&k_geval_persist);
+        if (plain) OSG_HIP(hipLaunchKernel(kern, dim3(static_cast<unsigned>(ms->geval_grid)), dim3(kGEvalThreads), args, 0, st));
+        else OSG_HIP(hipLaunchCooperativeKernel(kern, dim3(static_cast<unsigned>(ms->geval_grid)), dim3(kGEvalThreads), args, 0, st));
+        ms->last_eval_kernel = "k_geval_persist";
+        return OSG_OK;
+      }
+    }
+  }
+  ms->last_eval_kernel = "k_geval";
   k_geval_cf<<<dim3(std::max(1u, mblocks)), dim3(256), 0, st>>>(t, ea, pol);
   for (int l = s->D - 1; l >= 0; --l) {
     const int n_infos = ms->eval_level_off[l + 1] - ms->eval_level_off[l];
@@ -595,9 +790,9 @@ int build_eval_jobs(osg_cfr* s) {
 // Every player's best response to the current policy (cfr_br.cc:55-68): the first half of a CFR-BR iteration.
 int cfr_best_responses_to_current(osg_cfr* s, const EvalArrays& ea, int threads, bool jobs) {
   hipStream_t st = s->ctx->stream;
-  if (jobs) k_eval_jobs<<<dim3(s->jobs_J), dim3(s->jobs_threads), s->jobs_lds_bytes, st>>>(s->tree(), ea, eval_jobs_of(s), s->cur(), 1, 1);
+  if (jobs) { k_eval_jobs<<<dim3(s->jobs_J), dim3(s->jobs_threads), s->jobs_lds_bytes, st>>>(s->tree(), ea, eval_jobs_of(s), s->cur(), 1, 1); s->last_eval_kernel = "k_eval_jobs"; }
   else if (eval_takes_the_grid(s)) { if (int rc = launch_grid_eval(s, ea, s->cur(), false, nullptr, true)) return rc; }
-  else k_policy_eval<<<dim3(1), dim3(threads), 0, st>>>(s->tree(), ea, s->cur());
+  else { k_policy_eval<<<dim3(1), dim3(threads), 0, st>>>(s->tree(), ea, s->cur()); s->last_eval_kernel = "k_policy_eval"; }
   return OSG_OK;
 }
 
@@ -655,6 +850,7 @@ static int evaluate_policy_impl(osg_cfr* s, int which_policy, const double* h_po
     if (which_policy == 2) OSG_HIP(hipMemcpyAsync(d_pol, h_policy, sizeof(double) * IA, hipMemcpyHostToDevice, st));
     k_eval_jobs<<<dim3(s->jobs_J), dim3(s->jobs_threads), s->jobs_lds_bytes, st>>>(s->tree(), ea, eval_jobs_of(s), src,
                                                                                    which_policy == 0 ? 0 : 1, 0);
+    s->last_eval_kernel = "k_eval_jobs";
     OSG_HIP(hipGetLastError());
   } else if (eval_takes_the_grid(s)) {
     const double* src = which_policy == 0 ? s->cum() : which_policy == 1 ? s->cur() : d_pol;
@@ -666,6 +862,7 @@ static int evaluate_policy_impl(osg_cfr* s, int which_policy, const double* h_po
     int threads = ((s->max_level_width + 63) / 64) * 64;
     threads = std::max(64, std::min(threads, 1024));
     k_policy_eval<<<dim3(1), dim3(threads), 0, st>>>(s->tree(), ea, src, which_policy == 0 ? 1 : 0, d_pol);
+    s->last_eval_kernel = "k_policy_eval";
     OSG_HIP(hipGetLastError());
   }
   if (h_history_values)

@@ -384,6 +384,10 @@ struct osg_cfr {
   double* d_eval_ev = nullptr;   // [H, P]: the expected returns of the large-tree evaluation (allocated on first use)
   std::vector<int32_t> eval_level_off;   // [D + 1] the infostates of level l: d_eval_level_info[eval_level_off[l] ...)
   int32_t* d_eval_level_info = nullptr;
+  int32_t* d_eval_level_off = nullptr;   // the same offsets on the device (k_geval_persist)
+  unsigned int* d_geval_bar = nullptr;   // its grid barrier's counters
+  int geval_grid = 0;                    // its resident grid (-1: none, a launch per level and phase instead)
+  const char* last_eval_kernel = "";
   // the evaluation as independent jobs over the device (k_eval_jobs)
   bool jobs_ok = false;
   int jobs_J = 0, jobs_L = 0, jobs_G = 0, jobs_NT = 0, jobs_threads = 0;

@@ -455,6 +455,10 @@ class TabularSolver:
         """The kernel family the last iterate / sample call launched (diagnostic, osg_cfr_last_kernel)."""
         return lib().osg_cfr_last_kernel(self._h).decode()
 
+    def last_eval_kernel(self):
+        """The form the last policy evaluation took (diagnostic, osg_cfr_last_eval_kernel)."""
+        return lib().osg_cfr_last_eval_kernel(self._h).decode()
+
     def run_mccfr(self, seed, trajectories, first_trajectory=0):
         """One mini-batch of external-sampling traversals, folded into the tables."""
         check(lib().osg_mccfr_iterate(self._h, int(seed), int(first_trajectory), int(trajectories)))

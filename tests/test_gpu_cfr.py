@@ -580,10 +580,15 @@ def test_evaluation_jobs_are_bit_identical_with_the_one_workgroup_evaluation(ctx
         monkeypatch.setenv("OSG_EVAL_JOBS", "0")
         monkeypatch.setenv("OSG_EVAL_GRID", "0")
         want = _judge_everything(s, which, tab)
-        monkeypatch.setenv("OSG_EVAL_GRID", "1")         # a launch per level and phase (what the large trees take)
+        monkeypatch.setenv("OSG_EVAL_GRID", "1")         # what the large trees take: a launch per level and phase ...
         grid = _judge_everything(s, which, tab)
+        assert s.last_eval_kernel() == "k_geval"
+        monkeypatch.setenv("OSG_EVAL_PERSIST", "1")      # ... or (opt-in: it measured slower) one persistent launch over a resident grid
+        persist = _judge_everything(s, which, tab)
+        assert s.last_eval_kernel() == "k_geval_persist"
+        monkeypatch.delenv("OSG_EVAL_PERSIST")
         monkeypatch.delenv("OSG_EVAL_GRID")
-        for other in (got, grid):
+        for other in (got, grid, persist):
             for k in ("nash_conv", "exploitability"):
                 assert other[0][k] == want[0][k], (which, k)
             np.testing.assert_array_equal(other[0]["expected_returns"], want[0]["expected_returns"])
@@ -703,23 +708,43 @@ def test_a_smaller_solver_does_not_lower_the_lds_cap_under_a_larger_one(ctx):
 
 
 def test_large_tree_evaluation_takes_the_grid_and_equals_the_one_workgroup_walk(ctx, monkeypatch):
-    """3-player leduc_poker (1.83 M histories): the evaluation is a launch per level and phase (k_geval_*), bit-identical
-    with the one-workgroup walk and tens of times faster (33 ms per call on one workgroup)."""
+    """3-player leduc_poker (1.83 M histories): the evaluation is a launch per level and phase (k_geval_*) or — opt-in,
+    OSG_EVAL_PERSIST=1, round 6: it measured slower — ONE persistent launch over a resident grid (k_geval_persist): both
+    bit-identical with the one-workgroup walk (33 ms per call) and many times faster; every infostate's best-response
+    action and every responder's value of every history equal between the two grid forms."""
     import time
     import open_spiel_amd as osa
     s = osa.TabularSolver(ctx, "leduc_poker(players=3)")
     s.evaluate_and_update_policy(3)
     s.evaluate_policy()
+    assert s.last_eval_kernel() == "k_geval"
     ctx.synchronize()
     t0 = time.perf_counter()
     got = s.evaluate_policy()
     fast = time.perf_counter() - t0
+    all_launches = _judge_everything(s, "current")
+    monkeypatch.setenv("OSG_EVAL_PERSIST", "1")
+    s.evaluate_policy()
+    t0 = time.perf_counter()
+    got_persist = s.evaluate_policy()
+    persist = time.perf_counter() - t0
+    assert s.last_eval_kernel() == "k_geval_persist"
+    all_persist = _judge_everything(s, "current")
+    for _ in range(20):   # (the barrier's counters are re-armed per launch)
+        assert s.evaluate_policy()["nash_conv"] == got_persist["nash_conv"]
+    monkeypatch.delenv("OSG_EVAL_PERSIST")
     monkeypatch.setenv("OSG_EVAL_GRID", "0")
     t0 = time.perf_counter()
     want = s.evaluate_policy()
     slow = time.perf_counter() - t0
+    assert s.last_eval_kernel() == "k_policy_eval"
     monkeypatch.delenv("OSG_EVAL_GRID")
-    assert got["nash_conv"] == want["nash_conv"]
-    np.testing.assert_array_equal(got["expected_returns"], want["expected_returns"])
-    np.testing.assert_array_equal(got["best_response_values"], want["best_response_values"])
-    assert fast < slow / 5, (fast, slow)
+    for g in (got, got_persist):
+        assert g["nash_conv"] == want["nash_conv"]
+        np.testing.assert_array_equal(g["expected_returns"], want["expected_returns"])
+        np.testing.assert_array_equal(g["best_response_values"], want["best_response_values"])
+    np.testing.assert_array_equal(all_persist[1], all_launches[1])
+    np.testing.assert_array_equal(all_persist[2], all_launches[2])
+    for a_, b_ in zip(all_persist[3], all_launches[3]):
+        np.testing.assert_array_equal(a_, b_)
+    assert fast < slow / 5 and persist < slow / 5, (fast, persist, slow)

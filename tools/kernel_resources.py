@@ -44,6 +44,9 @@ KNOWN = {
     "k_mcts_wave<osg::HexT<3>, true, true, false>":
         "44 scalar registers parked in vector lanes + 2 vector registers in scratch at 7 waves per SIMD; the form without them "
         "measured 2.7 % slower (profiles/r05_ab_register_work.txt, osg_mcts_wave.hip above wave_search)",
+    "k_geval_persist":
+        "opt-in cross-check form of the large-tree evaluation (OSG_EVAL_PERSIST=1; the default is a launch per level, which "
+        "measured faster: profiles/r06u_*): 16 scalar registers parked in vector lanes, no scratch",
     "k_cfr_sub<8, true>":
         "the CFR-BR pass set of the same kernel (round 6): the code of k_cfr_sub<8, false> with the effective-policy rows staged "
         "every pass; same registers, same reasons",

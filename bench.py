@@ -591,6 +591,21 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
             b2b_b.record()
             torch.cuda.synchronize()
             b2b_us = b2b_a.elapsed_time(b2b_b) / 100 * 1e3
+            # the compact side arrays (osg_env_step_compact, round 6: u8 actions, one in/out flag byte, i8 rewards holding twice
+            # the return): 41 bytes per environment and step, measured the same way on the same batch
+            c_act = torch.full((n_env,), 255, dtype=torch.uint8, device="cuda")
+            c_flag = torch.ones(n_env, dtype=torch.uint8, device="cuda")
+            c_rew = torch.empty((n_env, 2), dtype=torch.int8, device="cuda")
+            for _ in range(5):
+                check(lib().osg_env_step_compact(eb._h, c_act.data_ptr(), c_flag.data_ptr(), SEED, 0, 0, c_rew.data_ptr(), msk.data_ptr()))
+            torch.cuda.synchronize()
+            b2b_a.record()
+            for _ in range(100):
+                check(lib().osg_env_step_compact(eb._h, c_act.data_ptr(), c_flag.data_ptr(), SEED, 0, 0, c_rew.data_ptr(), msk.data_ptr()))
+            b2b_b.record()
+            torch.cuda.synchronize()
+            compact_us = b2b_a.elapsed_time(b2b_b) / 100 * 1e3
+            compact_bytes = 16 + 16 + 1 + 1 + 1 + 2 + 4
             # bytes one connect_four environment moves per step: state in + out (2 x 16), action 4, should_reset 1 + 1,
             # current player 1, step type 1, rewards 2 x 8, mask word 4
             env_bytes = 16 + 16 + 4 + 2 + 1 + 1 + 16 + 4
@@ -605,6 +620,10 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
                                             "kernel_share_of_step": kern_us / (dt / steps * 1e6),
                                             "kernel_us_back_to_back": b2b_us,
                                             "frac_back_to_back": env_bytes * n_env / (b2b_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                            "compact": {"kernel": "k_env_step_compact_x2", "bytes_per_env_step": compact_bytes,
+                                                        "kernel_us_back_to_back": compact_us,
+                                                        "env_steps_per_s": n_env / (compact_us * 1e-6),
+                                                        "frac_back_to_back": compact_bytes * n_env / (compact_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
                                             "note": "frac: HIP events around the osg_env_step launch of every timed step (one pair per ~11 us launch: "
                                                     "~2 us of the pair itself inside); frac_back_to_back: 100 launches between one pair of events, "
                                                     "every environment stepped with 'no action' (the same bytes, the same straight-line step). "
@@ -612,7 +631,7 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
                                                     "20 of the 60 bytes.  (The same step on the headline kernel's fused connect_four step measured no "
                                                     "faster — 164.8 vs 165.0 us per 2^24 environments: the launch is bound by its bytes — and was dropped: "
                                                     "profiles/r05p_env_step_fused_ab.txt)"}}
-            del eb, lut, ev_a, ev_b, noop, keep
+            del eb, lut, ev_a, ev_b, noop, keep, c_act, c_flag, c_rew
             judge = {}
             for g in ("kuhn_poker", "leduc_poker"):
                 sj = osa.TabularSolver(ctx, g)
@@ -1368,7 +1387,9 @@ def compact_line(full, detail_path=DETAIL_FILE):
             out["env_step"] = _pruned({"value": e.get("value"), "unit": e.get("unit"), "bound": "infinity_cache",
                                        "frac": _get(e, "roofline", "frac_back_to_back"),
                                        "frac_per_launch_events": _get(e, "roofline", "frac"),
-                                       "kernel_us": _get(e, "roofline", "kernel_us_back_to_back")})
+                                       "kernel_us": _get(e, "roofline", "kernel_us_back_to_back"),
+                                       "compact_kernel_us": _get(e, "roofline", "compact", "kernel_us_back_to_back"),
+                                       "compact_frac": _get(e, "roofline", "compact", "frac_back_to_back")})
         elif "error" in e:
             out["env_step"] = {"error": str(e["error"])[:120]}
         h = sec.get("hex_step") or {}

@@ -230,6 +230,17 @@ int osg_synth_batch(osg_batch* b, uint64_t seed, int64_t index_offset, int depth
  * the state unchanged and are reported by osg_ctx_synchronize (OSG_ERR_ILLEGAL). */
 int osg_env_step(osg_batch* b, const int32_t* d_actions, uint8_t* d_should_reset, uint64_t seed, int64_t index_offset,
                  int64_t step_index, int8_t* d_cur_player, uint8_t* d_step_type, double* d_rewards, uint32_t* d_mask);
+/* The same step with compact side arrays for hosts that keep their own TimeStep layout (no reference counterpart: the
+ * reference's TimeStep carries int actions and float64 rewards, python/rl_environment.py:257-318 — 20 of the 60 bytes
+ * osg_env_step moves per connect_four environment; this form moves 41).  d_actions [n] u8: the action, 0xFF = leave the
+ * environment as it is.  d_flags [n] u8 is in/out: bits 0-1 the step type (0 FIRST, 1 MID, 2 LAST), bits 2-7 the current
+ * player + 4 (chance -1 -> 3, terminal -4 -> 0); an environment whose flag byte says LAST on input starts a new episode
+ * and ignores its action (initialise the array to 2 to start every environment).  d_rewards_x2 [n, P] i8 = TWICE the
+ * reward (the returns of the games served are multiples of 0.5): terminal returns at LAST, zeros otherwise; a game whose
+ * doubled returns do not fit a signed byte (leduc_poker with 6+ players) answers OSG_ERR_UNSUPPORTED.  d_mask, the chance
+ * sampling, the counter streams and the illegal-action report are osg_env_step's: the two forms step identically. */
+int osg_env_step_compact(osg_batch* b, const uint8_t* d_actions, uint8_t* d_flags, uint64_t seed, int64_t index_offset,
+                         int64_t step_index, int8_t* d_rewards_x2, uint32_t* d_mask);
 
 /* algorithms::RandomRolloutEvaluator::Evaluate (open_spiel/algorithms/mcts.cc:43-72)
  * for every root: n_rollouts uniform-random playouts to the end of the game.

@@ -107,6 +107,7 @@ SIGNATURES = {
     "osg_action_string": (INT, [VP, I64, INT, C.c_int32, C.c_char_p, INT]),
     "osg_copy_bytes": (INT, [VP, VP, VP, I64]),
     "osg_env_step": (INT, [VP, VP, VP, U64, I64, I64, VP, VP, VP, VP]),
+    "osg_env_step_compact": (INT, [VP, VP, VP, U64, I64, I64, VP, VP]),
     "osg_random_steps": (INT, [VP, U64, I64, INT, VP]),
     "osg_synth_batch": (INT, [VP, U64, I64, INT, VP, VP]),
     "osg_rollout": (INT, [VP, U64, I64, INT, VP, VP, INT]),

@@ -1387,6 +1387,96 @@ k_env_step_x2(typename G::Params p, uint64_t* base, int64_t n, const int32_t* __
   *reinterpret_cast<uint2*>(mask + i) = make_uint2(mask_out[0], mask_out[1]);
 }
 
+// The environment step with COMPACT side arrays (round 6; osg_env_step_compact): the reference's TimeStep types cost the
+// step above 20 of its 60 bytes per connect_four environment (int32 actions, float64 rewards, three flag bytes); here an
+// action is one byte (0xFF: leave the environment as it is), the three flag bytes are ONE in/out byte — bits 0-1 the step
+// type (LAST on input = "restart": what should_reset carried), bits 2-7 the current player + 4 — and a reward is one
+// signed byte holding TWICE the return (every game here pays multiples of 0.5; games whose returns do not fit are
+// refused by the entry point).  41 bytes per connect_four environment.  Same rules, same counter streams, same order of
+// operations as k_env_step: tests/test_gpu_vector_env.py steps the two forms side by side.
+OSG_D uint32_t env_flag_byte(int type, int cur) { return static_cast<uint32_t>(type) | (static_cast<uint32_t>(cur + 4) << 2); }
+template <class G>
+OSG_D int env_step_one(const typename G::Params& p, typename G::State& s, bool restart, int a /* -1: leave */, uint64_t seed,
+                       uint64_t index, uint64_t step_index, int* bad) {
+  int type = 1;
+  if (restart) {
+    s = G::initial(p);
+    type = 0;
+  } else if (a != OSG_INVALID_ACTION) {
+    const auto m = G::legal(p, s);
+    if (a < 0 || a >= 32 * G::kMaskW || !m.test(a)) ++*bad;
+    else G::apply(p, s, a);
+  }
+  Rng rng(seed, index, step_index);
+  for (int guard = 0; guard < 64 && !G::terminal(p, s) && G::current_player(p, s) == kChancePlayer; ++guard) {
+    const auto m = G::legal(p, s);
+    G::apply(p, s, sample_action<G>(p, s, m, kChancePlayer, rng));
+  }
+  if (G::terminal(p, s) && type != 0) type = 2;
+  return type;
+}
+template <class G>
+__global__ void __launch_bounds__(kBlock)
+k_env_step_compact(typename G::Params p, typename G::word_t* base, int64_t n, int num_players, const uint8_t* __restrict__ actions,
+                   uint8_t* flags, uint64_t seed, int64_t index_offset, int64_t step_index, int8_t* __restrict__ rewards_x2,
+                   uint32_t* __restrict__ mask, int mask_words, unsigned long long* illegal) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= n) return;
+  typename G::State s = G::load(p, base, n, i);
+  const int a8 = actions[i];
+  int bad = 0;
+  const int type = env_step_one<G>(p, s, (flags[i] & 3u) == 2u, a8 == 0xFF ? OSG_INVALID_ACTION : a8, seed,
+                                   static_cast<uint64_t>(index_offset + i), static_cast<uint64_t>(step_index), &bad);
+  if (bad) atomicAdd(illegal, 1ull);
+  G::store(p, base, n, i, s);
+  flags[i] = static_cast<uint8_t>(env_flag_byte(type, G::current_player(p, s)));
+  double r[kMaxPlayers];
+  G::returns(p, s, r);
+  for (int q = 0; q < num_players; ++q) rewards_x2[i * num_players + q] = type == 2 ? static_cast<int8_t>(2.0 * r[q]) : static_cast<int8_t>(0);
+  const auto after = G::legal(p, s);
+#pragma unroll
+  for (int w = 0; w < G::kMaskW; ++w)
+    if (w < mask_words) mask[i * mask_words + w] = after.w[w];
+}
+// Two consecutive environments per thread for the two-plane two-player games (as k_env_step_x2): 16-byte plane accesses,
+// the two action bytes / flag bytes as one 16-bit access, the two reward rows as one 32-bit store, the two mask words 8 bytes.
+template <class G>
+__global__ void __launch_bounds__(kBlock)
+k_env_step_compact_x2(typename G::Params p, uint64_t* base, int64_t n, const uint8_t* __restrict__ actions, uint8_t* flags,
+                      uint64_t seed, int64_t index_offset, int64_t step_index, int8_t* __restrict__ rewards_x2,
+                      uint32_t* __restrict__ mask, unsigned long long* illegal) {
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * 2;
+  if (i >= n) return;
+  const ulonglong2 w0 = *reinterpret_cast<const ulonglong2*>(base + i);
+  const ulonglong2 w1 = *reinterpret_cast<const ulonglong2*>(base + n + i);
+  const uint32_t a2 = *reinterpret_cast<const uint16_t*>(actions + i);
+  const uint32_t f2 = *reinterpret_cast<const uint16_t*>(flags + i);
+  uint64_t tmp[4] = {w0.x, w0.y, w1.x, w1.y};   // plane-major mini-batch of two: G::load(p, tmp, 2, j) reads tmp[w * 2 + j]
+  uint32_t flag_out = 0, rew_out = 0, mask_out[2];
+  int bad = 0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    typename G::State s = G::load(p, tmp, 2, j);
+    const int a8 = static_cast<int>((a2 >> (8 * j)) & 0xFFu);
+    const int type = env_step_one<G>(p, s, ((f2 >> (8 * j)) & 3u) == 2u, a8 == 0xFF ? OSG_INVALID_ACTION : a8, seed,
+                                     static_cast<uint64_t>(index_offset + i + j), static_cast<uint64_t>(step_index), &bad);
+    G::store(p, tmp, 2, j, s);
+    flag_out |= env_flag_byte(type, G::current_player(p, s)) << (8 * j);
+    double r[kMaxPlayers];
+    G::returns(p, s, r);
+    const uint32_t r0 = type == 2 ? static_cast<uint32_t>(static_cast<uint8_t>(static_cast<int8_t>(2.0 * r[0]))) : 0u;
+    const uint32_t r1 = type == 2 ? static_cast<uint32_t>(static_cast<uint8_t>(static_cast<int8_t>(2.0 * r[1]))) : 0u;
+    rew_out |= (r0 | (r1 << 8)) << (16 * j);
+    mask_out[j] = G::legal(p, s).w[0];
+  }
+  if (bad) atomicAdd(illegal, static_cast<unsigned long long>(bad));
+  *reinterpret_cast<ulonglong2*>(base + i) = make_ulonglong2(tmp[0], tmp[1]);
+  *reinterpret_cast<ulonglong2*>(base + n + i) = make_ulonglong2(tmp[2], tmp[3]);
+  *reinterpret_cast<uint16_t*>(flags + i) = static_cast<uint16_t>(flag_out);
+  *reinterpret_cast<uint32_t*>(rewards_x2 + 2 * i) = rew_out;
+  *reinterpret_cast<uint2*>(mask + i) = make_uint2(mask_out[0], mask_out[1]);
+}
+
 // RandomRolloutEvaluator::Evaluate (mcts.cc:43-72), persistent form: every lane owns a strided list of
 // work items and runs ONE flat loop whose body is "step the playout, or retire it and start the next", so
 // lanes in different phases of different playouts still execute the same instructions.  A work item is
@@ -2255,6 +2345,37 @@ int osg_env_step(osg_batch* b, const int32_t* d_actions, uint8_t* d_should_reset
                                             b->spec.desc.num_players, d_actions, d_should_reset, seed, index_offset,
                                             step_index, d_cur_player, d_step_type, d_rewards, d_mask,
                                             b->spec.desc.mask_words, ctx->d_illegal));
+  OSG_HIP(hipGetLastError());
+  return OSG_OK;
+}
+
+int osg_env_step_compact(osg_batch* b, const uint8_t* d_actions, uint8_t* d_flags, uint64_t seed, int64_t index_offset,
+                         int64_t step_index, int8_t* d_rewards_x2, uint32_t* d_mask) {
+  if (!b || !d_actions || !d_flags || !d_rewards_x2 || !d_mask) return set_error(OSG_ERR_INVALID, "osg_env_step_compact: null argument");
+  if (2.0 * b->spec.desc.max_utility > 127.0 || 2.0 * b->spec.desc.min_utility < -128.0)
+    return set_error(OSG_ERR_UNSUPPORTED, "osg_env_step_compact: twice the game's returns do not fit a signed byte (use osg_env_step)");
+  osg_ctx* ctx = b->ctx;
+  {
+    const bool ok = (b->n & 1) == 0 && (reinterpret_cast<uintptr_t>(b->d_words) & 15u) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(d_actions) | reinterpret_cast<uintptr_t>(d_flags)) & 1u) == 0 &&
+                    (reinterpret_cast<uintptr_t>(d_rewards_x2) & 3u) == 0 && (reinterpret_cast<uintptr_t>(d_mask) & 7u) == 0 &&
+                    b->spec.desc.num_players == 2 && b->spec.desc.mask_words == 1 && !std::getenv("OSG_ENV_STEP_X1");
+    const unsigned grid2 = static_cast<unsigned>(grid_for(b->n / 2));
+    if (ok && b->spec.desc.game_kind == kC4 && !b->spec.c4_wide) {
+      if (b->spec.c4_std)
+        k_env_step_compact_x2<C4Std><<<dim3(grid2), dim3(kBlock), 0, ctx->stream>>>(b->spec.c4, static_cast<uint64_t*>(b->d_words), b->n, d_actions, d_flags,
+                                                                                  seed, index_offset, step_index, d_rewards_x2, d_mask, ctx->d_illegal);
+      else
+        k_env_step_compact_x2<C4><<<dim3(grid2), dim3(kBlock), 0, ctx->stream>>>(b->spec.c4, static_cast<uint64_t*>(b->d_words), b->n, d_actions, d_flags,
+                                                                               seed, index_offset, step_index, d_rewards_x2, d_mask, ctx->d_illegal);
+      OSG_HIP(hipGetLastError());
+      return OSG_OK;
+    }
+  }
+  OSG_DISPATCH_WIDE(b->spec, k_env_step_compact<G><<<dim3(grid_for(b->n)), dim3(kBlock), 0, ctx->stream>>>(P,
+                                            static_cast<typename G::word_t*>(b->d_words), b->n, b->spec.desc.num_players, d_actions,
+                                            d_flags, seed, index_offset, step_index, d_rewards_x2, d_mask, b->spec.desc.mask_words,
+                                            ctx->d_illegal));
   OSG_HIP(hipGetLastError());
   return OSG_OK;
 }

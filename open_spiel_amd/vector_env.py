@@ -14,6 +14,10 @@ Here N environments of one game are one `StateBatch` in HBM and a step is one ke
     the reference — here the rows of FIRST steps are 0 and `step_type` tells them apart.
 
 Observations are torch tensors living in HBM ([n, size] per player), ready for a model.
+
+`compact=True` keeps the side arrays in the device's compact form (`osg_env_step_compact`: one action byte, one flag
+byte, rewards as signed bytes holding twice the return — 41 instead of 60 bytes per connect_four environment and step)
+and converts to the reference's TimeStep types only in `get_time_step`; the time steps are the same.
 """
 import collections
 import ctypes as C
@@ -57,7 +61,8 @@ class TimeStep(collections.namedtuple("TimeStep", ["observations", "rewards", "d
 class BatchedEnvironment:
     """N environments of one game; the batched counterpart of `rl_environment.Environment`."""
 
-    def __init__(self, ctx, game_string, num_envs, discount=1.0, observation_type=None, seed=0, index_offset=0):
+    def __init__(self, ctx, game_string, num_envs, discount=1.0, observation_type=None, seed=0, index_offset=0,
+                 compact=False):
         if not 0.0 <= float(discount) <= 1.0:
             raise ValueError(f"discount must be in [0.0, 1.0], got {discount}")  # InvalidParameterError
         self.ctx = ctx
@@ -80,6 +85,10 @@ class BatchedEnvironment:
         self._rewards = torch.empty((n, P), dtype=torch.float64, device=dev)
         self._mask = torch.empty((n, d.mask_words), dtype=torch.int32, device=dev)
         self._no_actions = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        self._compact = bool(compact)
+        if self._compact:
+            self._flags = torch.full((n,), 2, dtype=torch.uint8, device=dev)      # LAST: every environment starts an episode
+            self._rewards_x2 = torch.empty((n, P), dtype=torch.int8, device=dev)
 
     def __len__(self):
         return self.num_envs
@@ -96,6 +105,16 @@ class BatchedEnvironment:
 
     # -- stepping -----------------------------------------------------------------------------
     def _launch(self, actions):
+        if self._compact:
+            a8 = torch.where(actions < 0, torch.full_like(actions, 255), actions).to(torch.uint8)
+            check(lib().osg_env_step_compact(self.batch._h, a8.data_ptr(), self._flags.data_ptr(), self._seed, self._index_offset,
+                                             self._t, self._rewards_x2.data_ptr(), self._mask.data_ptr()))
+            # the reference's TimeStep types, formed from the compact arrays (what get_time_step hands out)
+            self._type = self._flags & 3
+            self._cur = ((self._flags >> 2).to(torch.int8) - 4)
+            self._rewards = self._rewards_x2.to(torch.float64) * 0.5
+            self._t += 1
+            return
         check(lib().osg_env_step(self.batch._h, actions.data_ptr(), self._should_reset.data_ptr(), self._seed,
                                  self._index_offset, self._t, self._cur.data_ptr(), self._type.data_ptr(),
                                  self._rewards.data_ptr(), self._mask.data_ptr()))
@@ -123,6 +142,8 @@ class BatchedEnvironment:
     def reset(self):
         """Start a new episode in every environment (rl_environment.py:420-452)."""
         self._should_reset.fill_(1)
+        if self._compact:
+            self._flags.fill_(2)
         self._launch(self._no_actions)
         return self.get_time_step()
 

@@ -78,19 +78,24 @@ def _compare(ts, want, i, P, A, what):
         assert ts.discounts[i].tolist() == want["discounts"], what
 
 
-@pytest.mark.parametrize("game,obs_type,steps", [
-    ("kuhn_poker", None, 14), ("leduc_poker", None, 30), ("leduc_poker", "observation", 20),
-    ("tic_tac_toe", None, 25), ("connect_four", None, 60), ("hex(board_size=5)", None, 40),
-    ("kuhn_poker(players=3)", None, 16),
+@pytest.mark.parametrize("game,obs_type,steps,compact", [
+    ("kuhn_poker", None, 14, False), ("leduc_poker", None, 30, False), ("leduc_poker", "observation", 20, False),
+    ("tic_tac_toe", None, 25, False), ("connect_four", None, 60, False), ("hex(board_size=5)", None, 40, False),
+    ("kuhn_poker(players=3)", None, 16, False),
+    # the compact side arrays (osg_env_step_compact: action bytes, one flag byte, rewards as doubled signed bytes) hand
+    # out the same TimeSteps
+    ("connect_four", None, 60, True), ("leduc_poker", None, 30, True), ("kuhn_poker(players=3)", None, 16, True),
+    ("tic_tac_toe", None, 25, True), ("hex(board_size=5)", None, 40, True),
 ])
-def test_batched_environment_matches_rl_environment(oracle, ctx, game, obs_type, steps):
+def test_batched_environment_matches_rl_environment(oracle, ctx, game, obs_type, steps, compact):
     import torch
     import open_spiel_amd as osa
     n, seed, offset, discount = 48, 0xE27, 7000, 0.99
     og = oracle.Game(game)
     P, A = og.num_players, og.num_distinct_actions
     ot = osa.ObservationType.OBSERVATION if obs_type == "observation" else None
-    env = osa.BatchedEnvironment(ctx, game, n, discount=discount, observation_type=ot, seed=seed, index_offset=offset)
+    env = osa.BatchedEnvironment(ctx, game, n, discount=discount, observation_type=ot, seed=seed, index_offset=offset,
+                                 compact=compact)
     use_obs = obs_type == "observation" or og.information_state_tensor_size == 0
     refs = [OracleEnvironment(og, seed, offset + i, discount, use_obs) for i in range(n)]
     ts = env.reset()
@@ -184,3 +189,65 @@ def test_env_step_two_per_thread_equals_one_per_thread(ctx, game):
         acts[n] = pick[0]
     with pytest.raises(osa.OsgError, match="illegal"):   # both forms counted their refused actions on the context
         ctx.synchronize()
+
+
+@pytest.mark.parametrize("game,P", [("connect_four", 2), ("connect_four(rows=5,columns=6,x_in_row=3)", 2), ("leduc_poker", 2),
+                                    ("leduc_poker(players=3)", 3), ("hex(board_size=13)", 2)])
+def test_env_step_compact_equals_env_step(ctx, game, P):
+    """osg_env_step_compact (u8 actions, one in/out flag byte, i8 rewards holding twice the return: 41 instead of 60 bytes per
+    connect_four environment) against osg_env_step, side by side over several episodes: the same states, step types, players,
+    rewards, masks and restarts step by step — the two-per-thread kernel (even batch) and the generic one (odd batch, wide
+    boards, poker with its chance sampling) —, illegal actions refused and counted the same way."""
+    import torch
+    import open_spiel_amd as osa
+    from open_spiel_amd._abi import check, lib
+    for n in (1 << 11, (1 << 11) + 1):
+        std = osa.StateBatch(ctx, game, n)
+        cmp_ = osa.StateBatch(ctx, game, n)
+        W = std.desc.mask_words
+        reset = torch.ones(n, dtype=torch.uint8, device="cuda")
+        cur = torch.empty(n, dtype=torch.int8, device="cuda"); typ = torch.empty(n, dtype=torch.uint8, device="cuda")
+        rew = torch.empty((n, P), dtype=torch.float64, device="cuda")
+        msk = torch.empty((n, W), dtype=torch.int32, device="cuda")
+        flags = torch.full((n,), 2, dtype=torch.uint8, device="cuda")
+        rew2 = torch.empty((n, P), dtype=torch.int8, device="cuda")
+        msk2 = torch.empty((n, W), dtype=torch.int32, device="cuda")
+        gen = torch.Generator(device="cuda"); gen.manual_seed(9)
+        acts = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        lasts = 0
+        for t in range(190 if game.startswith("hex") else 70):
+            a8 = torch.where(acts < 0, torch.full_like(acts, 255), acts).to(torch.uint8)
+            check(lib().osg_env_step(std._h, acts.data_ptr(), reset.data_ptr(), 77, 5, t, cur.data_ptr(), typ.data_ptr(),
+                                     rew.data_ptr(), msk.data_ptr()))
+            check(lib().osg_env_step_compact(cmp_._h, a8.data_ptr(), flags.data_ptr(), 77, 5, t, rew2.data_ptr(), msk2.data_ptr()))
+            torch.cuda.synchronize()   # (ctx.synchronize() would report the illegal actions of the previous step)
+            assert torch.equal(flags & 3, typ), (game, n, t)
+            assert torch.equal((flags >> 2).to(torch.int8) - 4, cur), (game, n, t)
+            assert torch.equal(rew2.to(torch.float64) * 0.5, rew), (game, n, t)
+            assert torch.equal(msk2, msk), (game, n, t)
+            assert torch.equal((flags & 3) == 2, reset.bool()), (game, n, t)
+            assert (std.raw_words() == cmp_.raw_words()).all(), (game, n, t)
+            lasts += int((typ == 2).sum())
+            # next actions: a random legal action, every 41st environment an illegal one, every 29th left as it is
+            A = std.desc.num_distinct_actions
+            shifts = torch.arange(32, device="cuda", dtype=torch.int32)
+            bits = ((msk.unsqueeze(-1) >> shifts) & 1).reshape(n, -1)[:, :A].to(torch.float32)
+            pick = (bits * (torch.rand(bits.shape, device="cuda", generator=gen) + 0.01)).argmax(1).to(torch.int32)
+            pick = torch.where(bits.sum(1) > 0, pick, torch.full_like(pick, -1))
+            if A + 3 < 255:
+                pick[::41] = A + 3
+            pick[::29] = -1
+            acts = pick
+        assert lasts > (0 if game.startswith("hex") else n), "the run must cover episode ends and restarts"
+        with pytest.raises(osa.OsgError, match="illegal"):
+            ctx.synchronize()
+
+
+def test_env_step_compact_refuses_returns_beyond_a_byte(ctx):
+    import torch
+    import open_spiel_amd as osa
+    from open_spiel_amd._abi import lib
+    b = osa.StateBatch(ctx, "leduc_poker(players=6)", 8)       # wins up to 5 x 13 = 65: 130 does not fit
+    z = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    rc = lib().osg_env_step_compact(b._h, z.data_ptr(), z.data_ptr(), 0, 0, 0, z.data_ptr(), z.data_ptr())
+    assert rc != 0 and "signed byte" in lib().osg_last_error().decode()

@@ -34,6 +34,7 @@ HOT = [
     "k_cfr_small<true, true, 3, 2, 2>", "k_cfr_split<3, false, 512, 3>", "k_cfr_split<3, false, 512, 0>", "k_cfr_split<3, true, 512, 0>",
     "k_env_step_x2<osg::C4T<6, 7, 4, unsigned long> >",
     "k_env_step<osg::C4T<6, 7, 4, unsigned long> >",
+    "k_env_step_compact_x2<osg::C4T<6, 7, 4, unsigned long> >",
     "k_random_steps<osg::C4T<6, 7, 4, unsigned long> >",
     "k_cfr_sub<8, false>", "k_cfr_sub<8, true>", "k_mccfr_resident_flat<3>", "k_mcts_advance<osg::Ttt, true, true>", "k_mcts_wave<osg::HexT<3>, true, true, false>",
     "k_rollout<osg::HexT<3> >", "k_eval_jobs", "k_geval_", "k_policy_eval", "k_oneshot_allreduce<double>",

@@ -237,7 +237,8 @@ int osg_env_step(osg_batch* b, const int32_t* d_actions, uint8_t* d_should_reset
  * player + 4 (chance -1 -> 3, terminal -4 -> 0); an environment whose flag byte says LAST on input starts a new episode
  * and ignores its action (initialise the array to 2 to start every environment).  d_rewards_x2 [n, P] i8 = TWICE the
  * reward (the returns of the games served are multiples of 0.5): terminal returns at LAST, zeros otherwise; a game whose
- * doubled returns do not fit a signed byte (leduc_poker with 6+ players) answers OSG_ERR_UNSUPPORTED.  d_mask, the chance
+ * doubled returns do not fit a signed byte (leduc_poker with 6+ players), or with more than 255 actions (hex from 16 x 16),
+ * answers OSG_ERR_UNSUPPORTED.  d_mask, the chance
  * sampling, the counter streams and the illegal-action report are osg_env_step's: the two forms step identically. */
 int osg_env_step_compact(osg_batch* b, const uint8_t* d_actions, uint8_t* d_flags, uint64_t seed, int64_t index_offset,
                          int64_t step_index, int8_t* d_rewards_x2, uint32_t* d_mask);

@@ -2352,6 +2352,9 @@ int osg_env_step(osg_batch* b, const int32_t* d_actions, uint8_t* d_should_reset
 int osg_env_step_compact(osg_batch* b, const uint8_t* d_actions, uint8_t* d_flags, uint64_t seed, int64_t index_offset,
                          int64_t step_index, int8_t* d_rewards_x2, uint32_t* d_mask) {
   if (!b || !d_actions || !d_flags || !d_rewards_x2 || !d_mask) return set_error(OSG_ERR_INVALID, "osg_env_step_compact: null argument");
+  if (b->spec.desc.num_distinct_actions > 255)
+    return set_error(OSG_ERR_UNSUPPORTED, "osg_env_step_compact: action ids travel as one byte here (0xFF = leave); games with more than 255 "
+                                          "actions (hex from 16 x 16) take osg_env_step");
   if (2.0 * b->spec.desc.max_utility > 127.0 || 2.0 * b->spec.desc.min_utility < -128.0)
     return set_error(OSG_ERR_UNSUPPORTED, "osg_env_step_compact: twice the game's returns do not fit a signed byte (use osg_env_step)");
   osg_ctx* ctx = b->ctx;

@@ -251,3 +251,6 @@ def test_env_step_compact_refuses_returns_beyond_a_byte(ctx):
     z = torch.zeros(64, dtype=torch.uint8, device="cuda")
     rc = lib().osg_env_step_compact(b._h, z.data_ptr(), z.data_ptr(), 0, 0, 0, z.data_ptr(), z.data_ptr())
     assert rc != 0 and "signed byte" in lib().osg_last_error().decode()
+    b = osa.StateBatch(ctx, "hex(board_size=16)", 8)           # 256 actions: one byte cannot name them beside 0xFF
+    rc = lib().osg_env_step_compact(b._h, z.data_ptr(), z.data_ptr(), 0, 0, 0, z.data_ptr(), z.data_ptr())
+    assert rc != 0 and "one byte" in lib().osg_last_error().decode()

@@ -134,6 +134,7 @@ template <> struct BitboardOps<uint64_t> {
   static constexpr int kWords = 1;
   OSG_HD static int popcount(uint64_t v) { return __builtin_popcountll(v); }
   OSG_HD static uint64_t make(uint64_t lo, uint64_t) { return lo; }
+  OSG_HD static uint64_t shr_small(uint64_t v, int s) { return v >> s; }   // 0 < s < 64
 };
 template <> struct BitboardOps<osg_u128> {
   static constexpr int kWords = 2;
@@ -141,6 +142,12 @@ template <> struct BitboardOps<osg_u128> {
     return __builtin_popcountll(static_cast<uint64_t>(v)) + __builtin_popcountll(static_cast<uint64_t>(v >> 64));
   }
   OSG_HD static osg_u128 make(uint64_t lo, uint64_t hi) { return (static_cast<osg_u128>(hi) << 64) | lo; }
+  // v >> s for 0 < s < 64, on the two halves: three 64-bit shifts and an or — the generic 128-bit shift by a run-time
+  // amount also handles s >= 64 with a compare and four selects (round 6: the wide boards' step is instruction-bound)
+  OSG_HD static osg_u128 shr_small(osg_u128 v, int s) {
+    const uint64_t lo = static_cast<uint64_t>(v), hi = static_cast<uint64_t>(v >> 64);
+    return make((lo >> s) | (hi << (64 - s)), hi >> s);
+  }
 };
 // R_/C_/K_ = 0: geometry read from Params at run time.  The default 6x7x4 game
 // is instantiated with compile-time constants (shifts by immediates, the
@@ -195,6 +202,14 @@ struct C4T {
     const int H = R(p) + 1;
     const int dirs[4] = {1, H, H - 1, H + 1};
     BB hit = 0;
+    if (R_ == 0 && K(p) == 4 && 2 * (H + 1) < 64) {   // run-time geometry (wave-uniform): every shift amount is in [1, 63]
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        BB m = b & Ops::shr_small(b, dirs[d]);
+        hit |= m & Ops::shr_small(m, 2 * dirs[d]);
+      }
+      return hit != 0;
+    }
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       BB m = b;
@@ -238,7 +253,12 @@ struct C4T {
 #pragma unroll
       for (int c = 0; c < C_; ++c) m |= static_cast<uint32_t>((free_top >> (c * H + R(p) - 1)) & BB(1)) << c;
     } else {
-      for (int c = 0; c < p.cols; ++c) m |= static_cast<uint32_t>((free_top >> (c * H + R(p) - 1)) & BB(1)) << c;
+      // a running shift by H (< 64) per column instead of a 128-bit shift by c * H + R - 1 per column
+      BB t = free_top >> (R(p) - 1);
+      for (int c = 0; c < p.cols; ++c) {
+        m |= (static_cast<uint32_t>(t) & 1u) << c;
+        t = H < 64 ? Ops::shr_small(t, H) : (t >> H);
+      }
     }
     return m;
   }
@@ -259,6 +279,42 @@ struct C4T {
       const bool done = win | full(p, s);
       s.flags = done ? (1u | (static_cast<uint32_t>(win ? mover : 2) << 1)) : 0u;
     }
+  }
+  // The whole step of k_step in one pass (round 6; the geometries without a stored result: run-time sizes, boards above
+  // 56 bits): the generic sequence legal / apply / terminal / legal / outcome runs the line test on BOTH colours three
+  // times over; here the non-mover's plane is tested once (it does not change), the mover's once AFTER the tentative
+  // placement — a line it has not got then, it had not got before either (a subset) — and only where that test fires
+  // (a winning move, or an uploaded position that was over already) the plane as it was is tested too.  Returns the
+  // successor's open columns (0 when the game is over); same results as the generic sequence, case by case
+  // (tests/test_gpu_parity.py steps these boards against the oracle at every ply).
+  OSG_D static uint32_t fused_step(const Params& p, State& s, int a, bool& illegal, bool& term, int& outcome) {
+    const int H = R(p) + 1;
+    const BB all = s.x | s.o, tp = top(p);
+    const int mover = Ops::popcount(all) & 1;
+    const BB mine = mover ? s.o : s.x, theirs = mover ? s.x : s.o;
+    BB cell = 0;
+    if (a != 0xFF && a < C(p)) {
+      const BB colmask = ((BB(1) << R(p)) - BB(1)) << (a * H);
+      cell = (all + (BB(1) << (a * H))) & colmask;   // the lowest empty cell of the column; 0 when it is full
+    }
+    const bool their_line = line(p, theirs);
+    const bool full_before = (all & tp) == tp;
+    bool my_line_after = line(p, mine | cell), my_line_before = false;
+    if (my_line_after && cell != 0) my_line_before = line(p, mine);
+    else my_line_before = my_line_after;              // (no cell placed: the same plane)
+    const bool term_before = their_line | my_line_before | full_before;
+    const bool placed = cell != 0 && !term_before;
+    illegal = a != 0xFF && !placed;
+    const BB mine2 = placed ? (mine | cell) : mine;
+    const bool my_line = placed ? my_line_after : my_line_before;
+    if (mover) s.o = mine2; else s.x = mine2;
+    const BB all2 = placed ? (all | cell) : all;
+    term = their_line | my_line | ((all2 & tp) == tp);
+    const bool x_line = mover ? their_line : my_line, o_line = mover ? my_line : their_line;
+    outcome = x_line ? 0 : (o_line ? 1 : 2);
+    if (term) return 0u;
+    State t{mover ? theirs : mine2, mover ? mine2 : theirs, 0u};
+    return open_columns(p, t);
   }
   // A position from its cells ('.', 'x', 'o'; cell r * cols + c, row 0 = the bottom row: ConnectFourStateStruct::board,
   // connect_four.h:72-79): ConnectFourState(game, struct, strict) / ConnectFourState(game, string),

@@ -129,6 +129,9 @@ OSG_D uint8_t encode_status(bool terminal, bool illegal, int cur, int outcome) {
   if (terminal) return v | 0x80 | static_cast<uint8_t>(outcome & 7);
   return v | static_cast<uint8_t>((cur + 1) & 15);
 }
+// (connect_four geometries without a stored result take C4T::fused_step: one pass instead of the generic sequence)
+template <class G> struct has_fused_step : std::false_type {};
+template <int R, int C, int K, class BB> struct has_fused_step<C4T<R, C, K, BB>> : std::integral_constant<bool, !C4T<R, C, K, BB>::kStored> {};
 template <class G, typename MaskT>
 __global__ void __launch_bounds__(kBlock)
 k_step(typename G::Params p, const typename G::word_t* src, typename G::word_t* dst, int64_t n,
@@ -137,6 +140,21 @@ k_step(typename G::Params p, const typename G::word_t* src, typename G::word_t* 
   if (i >= n) return;
   typename G::State s = G::load(p, src, n, i);
   int a = actions[i];
+  if constexpr (has_fused_step<G>::value) {
+    bool illegal_f, term_f;
+    int outcome_f;
+    const uint32_t open = G::fused_step(p, s, a, illegal_f, term_f, outcome_f);
+    G::store(p, dst, n, i, s);
+    if (sizeof(MaskT) < 4) {
+      mask_out[i] = static_cast<MaskT>(open);
+    } else {
+#pragma unroll
+      for (int w = 0; w < G::kMaskW; ++w)
+        if (w < mask_elems) mask_out[i * mask_elems + w] = static_cast<MaskT>(w == 0 ? open : 0u);
+    }
+    status[i] = encode_status(term_f, illegal_f, term_f ? 0 : (G::plies(s) & 1), term_f ? outcome_f : 0);
+    return;
+  }
   bool illegal = false;
   if (a != 0xFF) {
     auto before = G::legal(p, s);

@@ -415,11 +415,16 @@ k_mccfr_resident_flat(int H, int I, int P, ResidentTree rt, const int32_t* __res
     // those with the same traverser (index = lane * P + w), so that the 64 lanes of a wavefront agree at every node
     // on whether they walk all actions or sample one — half the divergence of the natural order, same set of
     // trajectories.  (The last, partial group keeps the natural order.)
-    int64_t j = j0;
+#if defined(OSG_MCCFR_DIAG_COHERENT) && OSG_MCCFR_DIAG_COHERENT == 1
+    const int64_t jj = j0 & ~static_cast<int64_t>(63);   // MEASUREMENT ONLY: a wavefront's lanes all walk its first lane's trajectory (no divergence at all)
+#else
+    const int64_t jj = j0;
+#endif
+    int64_t j = jj;
     {
-      const int64_t span = 64 * static_cast<int64_t>(P), group = j0 / span;
+      const int64_t span = 64 * static_cast<int64_t>(P), group = jj / span;
       if ((group + 1) * span <= count) {
-        const int r = static_cast<int>(j0 - group * span);
+        const int r = static_cast<int>(jj - group * span);
         j = group * span + static_cast<int64_t>(r & 63) * P + (r >> 6);
       }
     }
@@ -428,6 +433,12 @@ k_mccfr_resident_flat(int H, int I, int P, ResidentTree rt, const int32_t* __res
     const int trav = P == 2 ? static_cast<int>(g & 1) : static_cast<int>(g % P);
     const int next = trav + 1 == P ? 0 : trav + 1;
     Rng rng(seed, static_cast<uint64_t>(g), 0);
+#if defined(OSG_MCCFR_DIAG_COHERENT) && OSG_MCCFR_DIAG_COHERENT == 2
+    // MEASUREMENT ONLY: the first two draws of a trajectory (leduc: the two private cards) are the wavefront's, the rest
+    // its own — what sorting the trajectories by their deal would give a wavefront
+    Rng rng_w(seed, static_cast<uint64_t>(first + (j0 & ~static_cast<int64_t>(63))), 0);
+    int diag_draws = 0;
+#endif
     const uint64_t s0 = rng.s;   // the sub-streams of the traverser's first two levels are jumps of this counter (es_stream)
     int b1 = 0;
     // backing store of the frames below the top one
@@ -471,6 +482,10 @@ k_mccfr_resident_flat(int H, int I, int P, ResidentTree rt, const int32_t* __res
 #if OSG_MCCFR_PEEK
           const double z = z_peek;
           rng.s = s_peek;
+#elif defined(OSG_MCCFR_DIAG_COHERENT) && OSG_MCCFR_DIAG_COHERENT == 2
+          double z = rng.unit();
+          if (diag_draws < 2) z = rng_w.unit();
+          ++diag_draws;
 #else
           const double z = rng.unit();
 #endif

@@ -655,6 +655,65 @@ struct HexT {
     uint32_t first = ply == 0 ? static_cast<uint32_t>(move) : ((s.meta >> 16) & 0xFFFFu);
     s.meta = static_cast<uint32_t>(1 - player) | (res << 1) | (ply_next << 8) | (first << 16);
   }
+  // A uniformly random playout from `start` whose WINNER is all that is asked for (RandomRolloutEvaluator inside a search,
+  // mcts.cc:43-72; round 6): the same draws and the same moves as the move-by-move playout — legal[rng.below(count)] on
+  // the empty cells in ascending order — but no edge labels and no test for the end on the way: the stones are placed
+  // until the board is full and the winner is read off the filled board by ONE flood of black's stones from its first
+  // row.  A hex game cannot be un-won (the connected side stays connected, the other can no longer connect), so the
+  // filled board's winner is the winner at the ply where the reference's loop would have stopped; the draws beyond
+  // that ply belong to this playout's own counter stream and are seen by nobody else.  The move-by-move form relabels
+  // a group at every stone (neighbour sets, often a flood): ~4 x the instructions.  The swap rule's plies (the first
+  // two) run through the generic rules.  Returns 0 = black won, 1 = white won.  Boards with at least two rows and
+  // two columns (the entry points refuse the others for playouts).
+  template <class RngT>
+  OSG_D static int fill_playout_winner(const Params& p, const State& start, RngT& rng) {
+    State w = start;
+    if (p.swap) {
+      for (int g = 0; g < 2 && plies(w) < 2 && !terminal(p, w); ++g) {
+        const MaskType m = legal(p, w);
+        apply(p, w, select_action(m, static_cast<int>(rng.below(static_cast<uint32_t>(m.count())))));
+      }
+    }
+    if (terminal(p, w)) return result(w) == 1 ? 0 : 1;
+    Bits black = w.black;
+    Bits empty = bandn(p.board, bor(w.black, w.white));
+    int left = popcount(empty);
+    bool black_turn = to_move(w) == 0;
+    for (; left > 0; --left) {
+      int rem = static_cast<int>(rng.below(static_cast<uint32_t>(left)));
+      // the rem-th empty cell: its word by a running count (selects, no indexing: the planes stay in registers)
+      bool found = false;
+      uint32_t word = 0;
+      int wi = 0, kin = 0;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const int c = __builtin_popcount(empty.w[i]);
+        const bool here = !found && rem < c;
+        word = here ? empty.w[i] : word;
+        wi = here ? i : wi;
+        kin = here ? rem : kin;
+        found |= here;
+        rem -= c;
+      }
+      const uint32_t bit = 1u << select32(word, kin);
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const uint32_t m = i == wi ? bit : 0u;
+        empty.w[i] &= ~m;
+        black.w[i] |= black_turn ? m : 0u;
+      }
+      black_turn = !black_turn;
+    }
+    Bits reach = band(black, p.row_first), frontier = reach;
+    for (int it = 0; it < 32 * NW; ++it) {
+      if (any(band(reach, p.row_last))) return 0;
+      const Bits grow = bandn(band(neighbours(p, frontier), black), reach);
+      if (!any(grow)) return 1;
+      reach = bor(reach, grow);
+      frontier = grow;
+    }
+    return any(band(reach, p.row_last)) ? 0 : 1;
+  }
   OSG_D static int outcome_code(const Params&, const State& s) { return result(s) == 1 ? 0 : (result(s) == 2 ? 1 : 2); }
   OSG_D static void returns(const Params&, const State& s, double* out) {  // hex.cc:363-365
     double r = result(s) == 1 ? 1.0 : (result(s) == 2 ? -1.0 : 0.0);
@@ -721,6 +780,9 @@ struct HexT {
     }
   };
 };
+
+template <class G> struct is_hex : std::false_type {};
+template <int NW> struct is_hex<HexT<NW>> : std::true_type {};
 
 }  // namespace osg
 #endif  // OSG_GAME_BOARDS_H_

@@ -1553,6 +1553,43 @@ k_rollout(typename G::Params p, const typename G::word_t* base, int64_t n, int n
   }
 }
 
+// The same work items for hex when nobody asks for the ply counts (round 6): a playout is HexT::fill_playout_winner —
+// the stones placed with the same draws until the board is full, the winner read off by one flood — so every playout of
+// a root has the same length and the loop needs no retire / refill phase.  Same sums as k_rollout.
+#ifndef OSG_HEX_FILL_PLAYOUT
+#define OSG_HEX_FILL_PLAYOUT 1
+#endif
+template <class G>
+__global__ void __launch_bounds__(kBlock)
+k_rollout_hexfill(typename G::Params p, const typename G::word_t* base, int64_t n, uint64_t seed, int64_t index_offset,
+                  int n_rollouts, int group, double* sum_returns) {
+  const int64_t total = n * group;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t item = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; item < total; item += stride) {
+    const int64_t root = item / group;
+    const typename G::State s = G::load(p, base, n, root);
+    double acc = 0.0;
+    for (int r = static_cast<int>(item - root * group); r < n_rollouts; r += group) {
+      if (G::terminal(p, s)) {   // a finished root: Returns() as it stands
+        acc += G::result(s) == 1 ? 1.0 : -1.0;
+        continue;
+      }
+      Rng rng(seed, static_cast<uint64_t>(index_offset + root), static_cast<uint64_t>(r));
+      acc += G::fill_playout_winner(p, s, rng) == 0 ? 1.0 : -1.0;
+    }
+    sum_returns[item * 2] = acc;
+    sum_returns[item * 2 + 1] = -acc + 0.0;
+  }
+}
+
+template <class G>   // (a template so that the discarded branch is not instantiated for the other games)
+void launch_rollout_hexfill(const typename G::Params& p, const void* words, int64_t n, uint64_t seed, int64_t index_offset,
+                            int n_rollouts, int group, double* d_part, unsigned blocks, hipStream_t st) {
+  if constexpr (is_hex<G>::value)
+    k_rollout_hexfill<G><<<dim3(blocks), dim3(kBlock), 0, st>>>(p, static_cast<const typename G::word_t*>(words), n, seed,
+                                                              index_offset, n_rollouts, group, d_part);
+}
+
 // Sums the `group` share slots of every root: sum_returns [n, P] and, optionally, the ply counts [n].
 __global__ void __launch_bounds__(kBlock)
 k_rollout_fold(const double* __restrict__ part, const int32_t* __restrict__ part_steps, int64_t n, int num_players,
@@ -2316,10 +2353,15 @@ int osg_rollout(const osg_batch* roots, uint64_t seed, int64_t index_offset, int
   // Persistent grid: at most 8 blocks per CU x 256 CUs, grid-strided beyond that.
   int64_t blocks = (total + kBlock - 1) / kBlock;
   if (blocks > 2048) blocks = 2048;
+  if (OSG_HEX_FILL_PLAYOUT && !steps && roots->spec.desc.game_kind == kHex) {
+    OSG_DISPATCH_WIDE(roots->spec, launch_rollout_hexfill<G>(P, roots->d_words, n, seed, index_offset, n_rollouts,
+                                                             static_cast<int>(group), d_part, static_cast<unsigned>(blocks), ctx->stream));
+  } else {
   OSG_DISPATCH_WIDE(roots->spec, k_rollout<G><<<dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, ctx->stream>>>(P,
                                                 static_cast<const typename G::word_t*>(roots->d_words), n, P_, seed,
                                                 index_offset, n_rollouts, static_cast<int>(group), d_part,
                                                 d_part_steps));
+  }
   if (group > 1)
     k_rollout_fold<<<dim3(grid_for(n * P_)), dim3(kBlock), 0, ctx->stream>>>(d_part, d_part_steps, n, P_,
                                                                              static_cast<int>(group), d_sum, d_steps);

@@ -145,13 +145,8 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
       for (int q = 0; q < num_players; ++q) returns[q] = 0.0;
       for (int ro = 0; ro < cfg.n_rollouts; ++ro) {
         Rng rng(cfg.seed, gr, static_cast<uint64_t>(sim) * cfg.n_rollouts + ro);
-        typename G::State w = s;
-        for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
-          const LegalMask m = G::legal(p, w);
-          G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
-        }
         double rr[kMaxPlayers];
-        G::returns(p, w, rr);
+        playout_returns<G>(p, s, rng, rr);
         for (int q = 0; q < num_players; ++q) returns[q] += rr[q];
       }
       for (int q = 0; q < num_players; ++q) returns[q] /= cfg.n_rollouts;

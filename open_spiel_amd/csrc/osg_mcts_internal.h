@@ -75,6 +75,28 @@ OSG_D double outcome_value(uint32_t meta, uint32_t count, double total, int play
 }
 
 
+// One playout of RandomRolloutEvaluator::Evaluate (mcts.cc:45-56) from `s` on `rng`: Returns() of the finished game in
+// rr.  hex: the winner from the filled board (HexT::fill_playout_winner, round 6 — the same draws and moves without the
+// edge labels; OSG_HEX_FILL_PLAYOUT=0 at build time keeps the move-by-move rules); the other games move by move.
+#ifndef OSG_HEX_FILL_PLAYOUT
+#define OSG_HEX_FILL_PLAYOUT 1
+#endif
+template <class G>
+OSG_D void playout_returns(const typename G::Params& p, const typename G::State& s, Rng& rng, double* rr) {
+  if constexpr (is_hex<G>::value && OSG_HEX_FILL_PLAYOUT) {
+    const double r0 = G::fill_playout_winner(p, s, rng) == 0 ? 1.0 : -1.0;
+    rr[0] = r0;
+    rr[1] = -r0;
+  } else {
+    typename G::State w = s;
+    for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
+      const MaskT<G::kMaskW> m = G::legal(p, w);
+      G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
+    }
+    G::returns(p, w, rr);
+  }
+}
+
 // Device output pointers of a search (any may be null).
 struct MctsOut {
   int32_t* best_action;

@@ -202,13 +202,8 @@ OSG_D void coop_playouts(const typename G::Params& p, const osg_mcts_cfg& cfg, i
     for (int q = 0; q < num_players; ++q) sum[q] = 0.0;
     for (int ro = lane; ro < cfg.n_rollouts; ro += 64) {
       Rng rng(cfg.seed, gr, sim * cfg.n_rollouts + ro);
-      typename G::State w = s;
-      for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
-        const MaskT<G::kMaskW> m = G::legal(p, w);
-        G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
-      }
       double rr[kMaxPlayers];
-      G::returns(p, w, rr);
+      playout_returns<G>(p, s, rng, rr);
       for (int q = 0; q < num_players; ++q) sum[q] += rr[q];
     }
     for (int q = 0; q < num_players; ++q) {
@@ -522,13 +517,8 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
           for (int q = 0; q < num_players; ++q) sum[q] = 0.0;
           for (int ro = static_cast<int>(threadIdx.x); ro < cfg.n_rollouts; ro += 64) {
             Rng rng(cfg.seed, gr, static_cast<uint64_t>(sims_done) * cfg.n_rollouts + ro);
-            typename G::State w = s;
-            for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
-              const MaskT<G::kMaskW> m = G::legal(p, w);
-              G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
-            }
             double rr[kMaxPlayers];
-            G::returns(p, w, rr);
+            playout_returns<G>(p, s, rng, rr);
             for (int q = 0; q < num_players; ++q) sum[q] += rr[q];
           }
           for (int q = 0; q < num_players; ++q) {
@@ -539,13 +529,8 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
         }
         for (int ro = 0; !kCoop && ro < cfg.n_rollouts; ++ro) {
           Rng rng(cfg.seed, gr, static_cast<uint64_t>(sims_done) * cfg.n_rollouts + ro);
-          typename G::State w = s;
-          for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
-            const MaskT<G::kMaskW> m = G::legal(p, w);
-            G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
-          }
           double rr[kMaxPlayers];
-          G::returns(p, w, rr);
+          playout_returns<G>(p, s, rng, rr);
           for (int q = 0; q < num_players; ++q) returns[q] += rr[q];
         }
         for (int q = 0; q < num_players; ++q) returns[q] = returns[q] / cfg.n_rollouts;
@@ -650,13 +635,8 @@ k_mcts_tree_rollout(typename G::Params p, const typename G::word_t* leaf_words, 
   for (int q = 0; q < num_players; ++q) sum[q] = 0.0;
   for (int ro = 0; ro < cfg.n_rollouts; ++ro) {
     Rng rng(cfg.seed, gr, static_cast<uint64_t>(sims[r]) * cfg.n_rollouts + ro);
-    typename G::State w = s;
-    for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
-      const MaskT<G::kMaskW> m = G::legal(p, w);
-      G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
-    }
     double rr[kMaxPlayers];
-    G::returns(p, w, rr);
+    playout_returns<G>(p, s, rng, rr);
     for (int q = 0; q < num_players; ++q) sum[q] += rr[q];
   }
   for (int q = 0; q < num_players; ++q) value[r * num_players + q] = sum[q] / cfg.n_rollouts;

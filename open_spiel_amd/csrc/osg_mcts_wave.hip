@@ -900,12 +900,7 @@ OSG_D void wave_search(const typename G::Params& p, const typename G::word_t* ba
         for (int q = 0; q < num_players; ++q) rr[q] = 0.0;
         if (ro < cfg.n_rollouts) {
           Rng rng(cfg.seed, gr, static_cast<uint64_t>(sim) * cfg.n_rollouts + ro);
-          typename G::State w = s;
-          for (int ply = 0; ply < kMaxPlayoutPlies && !G::terminal(p, w); ++ply) {
-            const Mask m = G::legal(p, w);
-            G::apply(p, w, sample_action<G>(p, w, m, G::current_player(p, w), rng));
-          }
-          G::returns(p, w, rr);
+          playout_returns<G>(p, s, rng, rr);
         }
         // Returns() of these games are multiples of 0.5 with small magnitude: sums are exact in
         // any order, so the butterfly equals the reference's sequential accumulation.

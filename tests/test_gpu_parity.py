@@ -376,6 +376,34 @@ def test_rollout_replay_parity(oracle, ctx, game, n_rollouts):
         assert steps[i] == want_steps
 
 
+@pytest.mark.parametrize("game,n_rollouts", [("hex(board_size=9)", 6), ("hex", 3), ("hex(board_size=5,swap=True)", 9),
+                                             ("hex(num_cols=3,num_rows=4)", 8), ("hex(board_size=13)", 3),
+                                             ("hex(num_cols=17,num_rows=19,swap=True)", 2), ("hex(board_size=2)", 5)])
+def test_hex_rollouts_without_ply_counts_take_the_fill_kernel_and_sum_the_same(ctx, game, n_rollouts):
+    """osg_rollout with steps == NULL (what the mirror's RandomRolloutEvaluator asks for) runs hex playouts as
+    HexT::fill_playout_winner — the same draws and moves without edge labels, the winner read off the filled board —
+    and must hand back exactly the sums of the move-by-move kernel (which the test above replays on the oracle): roots at
+    every depth incl. the empty board (the swap rule's plies), finished games, boards of six-word planes."""
+    import torch
+    import open_spiel_amd as osa
+    n = 3000
+    roots = osa.StateBatch(ctx, game, n)
+    idx = torch.arange(n, device="cuda")
+    depth_cap = roots.desc.num_distinct_actions + 2
+    for t in range(depth_cap):                      # root i is advanced by (i mod depth_cap) random moves: some games end
+        m = roots.legal_actions_mask().to(torch.float32)
+        live = (m.sum(1) > 0) & (idx % depth_cap > t)
+        m[m.sum(1) == 0, 0] = 1.0
+        a = torch.multinomial(m, 1).squeeze(1).to(torch.int32)
+        roots.apply_actions(torch.where(live, a, torch.full_like(a, -1)))
+    assert bool(roots.is_terminal().any()) and not bool(roots.is_terminal().all())
+    seed, offset = 0xF111, 77
+    fill = roots.rollout(seed, n_rollouts, index_offset=offset)
+    stepwise, steps = roots.rollout(seed, n_rollouts, index_offset=offset, want_steps=True)
+    assert torch.equal(fill, stepwise), game
+    assert int(steps.sum()) > 0
+
+
 def test_random_steps_counters(ctx):
     import open_spiel_amd as osa
     b = osa.StateBatch(ctx, "connect_four", 1 << 12)

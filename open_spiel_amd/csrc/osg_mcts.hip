@@ -107,7 +107,19 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
         // time with clamped indices (24 independent loads, one round trip) instead of child by child behind the
         // branches of the value formula (see k_mcts_advance, osg_mcts_step.hip)
         constexpr int kChunk = 8;
-        for (int k0 = 0; k0 < c; k0 += kChunk) {
+        // Round 6.  Under UCT a child that was never visited scores +infinity (mcts.cc:95) and the FIRST such child wins:
+        // nothing behind it can score higher, nothing before it needs its value formed.  While a node still has
+        // unvisited children — most visits of a wide node (hex: ~100 children, visited in order) — the scan therefore
+        // only looks for the first one: counts and headers, no totals, none of the ~60 fp64 instructions per child.
+        // Whether that is the case is read off the LAST child (the children are first visited in order, so it is the
+        // last to go); if it was visited the full scan below runs, which is exact whatever the order was.
+        bool scan_only = false;
+        if (!puct) {
+          const uint32_t at = first + static_cast<uint32_t>(c - 1);
+          scan_only = COUNT(at) == 0 && !m_has_outcome(META(at));
+        }
+        bool settled = false;   // an unvisited child was found: the arg-max is decided
+        for (int k0 = 0; k0 < c && !settled; k0 += kChunk) {
           uint32_t cm[kChunk], cc[kChunk];
           double ct[kChunk];
 #pragma unroll
@@ -115,17 +127,20 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
             const uint32_t at = first + static_cast<uint32_t>(k0 + j < c ? k0 + j : c - 1);
             cm[j] = META(at);
             cc[j] = COUNT(at);
-            ct[j] = TOTAL(at);
+            ct[j] = scan_only ? 0.0 : TOTAL(at);
           }
 #pragma unroll
           for (int j = 0; j < kChunk; ++j) {
-            if (k0 + j >= c) continue;
+            if (k0 + j >= c || settled) continue;
+            const bool unvisited = !puct && cc[j] == 0 && !m_has_outcome(cm[j]);
+            if (scan_only && !unvisited) continue;
             double v;
             if (m_has_outcome(cm[j])) v = outcome_value<kBoard>(cm[j], cc[j], ct[j], m_player(cm[j]));
             else if (puct) v = (cc[j] != 0 ? ct[j] / cc[j] : 0.0) + cfg.uct_c * prior * sqrt_n / (cc[j] + 1);  // mcts.cc:103-112
             else if (cc[j] == 0) v = INFINITY;
             else v = ct[j] / cc[j] + cfg.uct_c * sqrt(logn / cc[j]);
             if (v > best) { best = v; chosen = first + static_cast<uint32_t>(k0 + j); chosen_meta = cm[j]; have_meta = true; }
+            settled = unvisited;
           }
         }
       }

@@ -463,7 +463,14 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
               have_chosen_meta = true;
             }
           }
-          for (int k0 = 0; !kCoop && k0 < c; k0 += kScanChunk) {
+          // (round 6, as in k_mcts) under UCT the first never-visited child wins with +infinity: while the LAST child is
+          // unvisited the scan only looks for the first such child, and any scan stops at one
+          bool scan_only = false, settled = false;
+          if (!kCoop && !puct) {
+            const uint32_t at = first + static_cast<uint32_t>(c - 1);
+            scan_only = COUNT(at) == 0 && !m_has_outcome(META(at));
+          }
+          for (int k0 = 0; !kCoop && k0 < c && !settled; k0 += kScanChunk) {
             uint32_t cm[kScanChunk], cc[kScanChunk], cf[kScanChunk];
             double ct[kScanChunk], cp[kScanChunk];
 #pragma unroll
@@ -472,12 +479,15 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
               cm[j] = META(at);
               cc[j] = COUNT(at);
               cf[j] = FIRST(at);
-              ct[j] = TOTAL(at);
-              cp[j] = PRIOR(at);
+              ct[j] = scan_only ? 0.0 : TOTAL(at);
+              cp[j] = scan_only ? 0.0 : PRIOR(at);
             }
 #pragma unroll
             for (int j = 0; j < kScanChunk; ++j) {
-              if (k0 + j >= c) continue;
+              if (k0 + j >= c || settled) continue;
+              const bool unvisited = !puct && cc[j] == 0 && !m_has_outcome(cm[j]);
+              if (scan_only && !unvisited) continue;
+              settled = unvisited;
               double v;
               if (m_has_outcome(cm[j])) v = outcome_value<kBoard>(cm[j], cc[j], ct[j], m_player(cm[j]));
               else if (puct) v = (cc[j] != 0 ? ct[j] / cc[j] : 0.0) + cfg.uct_c * cp[j] * sqrt_n / (cc[j] + 1);

@@ -439,7 +439,24 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
             // lowest index among equals, i.e. the sequential scan's "first maximum wins" (a NaN or -inf value never wins)
             double bv = -INFINITY;
             uint32_t bk = 0xFFFFFFFFu, bm = 0, bc = 0, bf = 0;
-            for (int k0 = 0; k0 < c; k0 += 64) {
+            // (round 6) under UCT the first never-visited child wins with +infinity: where one exists — a ballot — no
+            // value is formed at all (nodes of up to 64 children: one child per lane in one pass)
+            bool decided = false;
+            if (!puct && c <= 64) {
+              const int k = static_cast<int>(threadIdx.x);
+              const uint32_t at = first + static_cast<uint32_t>(k < c ? k : c - 1);
+              const uint32_t cm = META(at), cc = COUNT(at), cf = FIRST(at);
+              const unsigned long long unvisited = __ballot(k < c && cc == 0 && !m_has_outcome(cm));
+              if (unvisited != 0ull) {
+                const int src = __builtin_ctzll(unvisited);
+                bk = static_cast<uint32_t>(src);
+                bm = static_cast<uint32_t>(__shfl(static_cast<int>(cm), src, 64));
+                bc = 0;
+                bf = static_cast<uint32_t>(__shfl(static_cast<int>(cf), src, 64));
+                decided = true;
+              }
+            }
+            for (int k0 = 0; !decided && k0 < c; k0 += 64) {
               const int k = k0 + static_cast<int>(threadIdx.x);
               const uint32_t at = first + static_cast<uint32_t>(k < c ? k : c - 1);
               const uint32_t cm = META(at), cc = COUNT(at), cf = FIRST(at);
@@ -452,7 +469,7 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
               if (k < c && v > bv) { bv = v; bk = static_cast<uint32_t>(k); bm = cm; bc = cc; bf = cf; }
             }
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
+            for (int off = 32; !decided && off >= 1; off >>= 1) {
               const double ov = __shfl_xor(bv, off, 64);
               const uint32_t ok = __shfl_xor(bk, off, 64), om = __shfl_xor(bm, off, 64), oc = __shfl_xor(bc, off, 64),
                              of = __shfl_xor(bf, off, 64);

@@ -523,10 +523,22 @@ struct HexT {
   OSG_D static Bits neighbours(const Params& p, const Bits& s) {
     const int C = p.cols;
     Bits not_e = bandn(s, p.col_last), not_w = bandn(s, p.col_first);
+    const Bits east = shl(not_e, 1), west = shr(not_w, 1);   // +1, -1 (both stay inside their row)
+#ifndef OSG_HEX_NB6
+#define OSG_HEX_NB6 0   // 1: the six-shift form (A/B builds)
+#endif
+    if (!OSG_HEX_NB6 && C > 1 && C < 32) {
+      // -C and -C+1 are ONE shift of (s | east) by C, +C and +C-1 one shift of (s | west): four multiword shifts
+      // instead of six (round 6; the flood of an apply runs this per step)
+      Bits r = bor(east, west);
+      r = bor(r, shr(bor(s, east), C));
+      r = bor(r, shl(bor(s, west), C));
+      return band(r, p.board);
+    }
     Bits r = shr(s, C);                 // -C   (cells in the first row shift out)
     r = bor(r, shl(s, C));              // +C
-    r = bor(r, shl(not_e, 1));          // +1
-    r = bor(r, shr(not_w, 1));          // -1
+    r = bor(r, east);                   // +1
+    r = bor(r, west);                   // -1
     if (C > 1) {
       r = bor(r, shr(not_e, C - 1));    // -C+1
       r = bor(r, shl(not_w, C - 1));    // +C-1

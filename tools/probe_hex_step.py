@@ -2,6 +2,8 @@
 2^24 states.  Bytes per step as tools/probe_kernels.py counts them: 2 x 52 state + 1 action + 12 mask + 1 status = 118."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from open_spiel_amd import _abi
+if os.environ.get("OSG_VARIANT_LIB"): _abi.LIB_PATH = os.path.abspath(os.environ["OSG_VARIANT_LIB"])
 import torch, open_spiel_amd as osa
 ctx = osa.Context(0)
 def timeit(fn, iters, warm):

@@ -9,9 +9,9 @@
 // layout with children spread over lanes keeps 63 of 64 lanes idle during the
 // playout, which is >90 % of the work; see DESIGN.md.)
 //
-// Tree storage in HBM: a node pool of `cap` nodes per root, struct-of-arrays and
-// node-major / root-minor (field[node * n_roots + root]) so that lanes of a wave
-// touching the same node slot (the common case near the root) coalesce.
+// Tree storage in HBM: a node pool of `cap` nodes per root, struct-of-arrays and — since round 6 — root-major
+// (field[root * cap + node]): a lane scans and writes runs of its own tree (rounds 1-5: root-minor, which coalesces
+// across lanes only near the root; see the macros in k_mcts).
 //   meta   u32  action | (player+1)<<8 | nchild<<12 | has_outcome<<20 | code<<21 | terminal<<23
 //   first  u32  index of the first child (children are contiguous)
 //   parent u32
@@ -37,13 +37,30 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
   using LegalMask = MaskT<G::kMaskW>;
   const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlockM + threadIdx.x;
   if (r >= n) return;
+#ifndef OSG_MCTS_LDS_SHUFFLE
+#define OSG_MCTS_LDS_SHUFFLE 1
+#endif
+  // the lane's column of the shuffle stage: entry k at sh[k * kBlockM] (dynamic LDS: widest node x kBlockM entries)
+  using act_t = uint8_t;   // (boards of up to six plane words: at most 193 actions)
+  extern __shared__ unsigned char s_shuffle[];
+  act_t* sh = reinterpret_cast<act_t*>(s_shuffle) + threadIdx.x;
+  (void)sh;
   const uint64_t gr = static_cast<uint64_t>(cfg.index_offset + r);
-  const int64_t NR = pool.n_roots;
-#define META(i) pool.meta[static_cast<int64_t>(i) * NR + r]
-#define FIRST(i) pool.first[static_cast<int64_t>(i) * NR + r]
-#define PARENT(i) pool.parent[static_cast<int64_t>(i) * NR + r]
-#define COUNT(i) pool.count[static_cast<int64_t>(i) * NR + r]
-#define TOTAL(i) pool.total[static_cast<int64_t>(i) * NR + r]
+  // Node i of this lane's root in every plane: i * NR + RB.  Round 6: ROOT-MAJOR (field[root * cap + node], the wave layout's
+  // form: NR = 1, RB = root * cap) — a root's nodes are contiguous, so a lane's scan of a node's children and the stores of
+  // an expansion walk ONE run of memory (32 children's counts per 128-byte line) instead of one line per child and field;
+  // root-minor (field[node * n_roots + root]: NR = n_roots, RB = root; rounds 1-5) coalesces across lanes only while the
+  // lanes stand on the same node index, i.e. near the root.  2^16 roots (profiles/r06zf_*, r06zi_*): hex(9) x 512
+  // simulations 4.5e8 -> 7.2e8, 11 x 11 2.2e8 -> 4.4e8, 13 x 13 1.2e8 -> 2.9e8, tic_tac_toe x 1000 8.2e8 -> 9.9e8,
+  // connect_four x 256 1.35e9 -> 1.42e9 simulations/s; SHORT searches of narrow games stay near the root and keep
+  // root-minor (connect_four x 32: 2.78e9 against 2.27e9, tic_tac_toe x 100: 2.09e9 against 1.89e9): the host picks
+  // (pool.root_major; OSG_MCTS_ROOT_MAJOR=0/1 forces one).
+  const int64_t NR = pool.root_major ? 1 : pool.n_roots, RB = pool.root_major ? r * static_cast<int64_t>(pool.cap) : r;
+#define META(i) pool.meta[static_cast<int64_t>(i) * NR + RB]
+#define FIRST(i) pool.first[static_cast<int64_t>(i) * NR + RB]
+#define PARENT(i) pool.parent[static_cast<int64_t>(i) * NR + RB]
+#define COUNT(i) pool.count[static_cast<int64_t>(i) * NR + RB]
+#define TOTAL(i) pool.total[static_cast<int64_t>(i) * NR + RB]
 
   const typename G::State root_state = G::load(p, base, n, r);
   const int root_player = G::current_player(p, root_state);
@@ -52,7 +69,7 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
   uint32_t used = 1;       // = the reference's nodes_: 1 + the children blocks allocated (mcts.cc:299,354)
   int gc_limit = kMinGcLimit;
   int sims_done = 0;
-#define REMAP(i) pool.remap[static_cast<int64_t>(i) * NR + r]
+#define REMAP(i) pool.remap[static_cast<int64_t>(i) * NR + RB]
 
   for (int sim = 0; sim < cfg.max_simulations; ++sim) {
     Rng trng(cfg.seed ^ kTreeSalt, gr, static_cast<uint64_t>(sim));
@@ -74,6 +91,29 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
         if (c == 0 || used + static_cast<uint32_t>(c) > static_cast<uint32_t>(pool.cap)) break;
         const uint32_t first = used;
         used += c;
+        if constexpr (OSG_MCTS_LDS_SHUFFLE && G::kMaskW < 8) {
+        // Round 6: the children's order is formed in LDS and every header written ONCE.  The shuffle used to run on
+        // the pool — per child two loads and two stores of the lane's own, scattered node words on top of the five
+        // initialising stores — which is most of what an expansion of a wide node (hex: ~100 children) costs.
+        // Same draws, same swaps, same order.
+        {
+          int k = 0;
+#pragma unroll
+          for (int w = 0; w < G::kMaskW; ++w)
+            for (uint32_t bits = legal.w[w]; bits != 0u; bits &= bits - 1u)
+              sh[(k++) * kBlockM] = static_cast<act_t>(32 * w + __builtin_ctz(bits));
+        }
+        for (int i = c - 1; i >= 1; --i) {  // Fisher-Yates == std::shuffle's role (order only)
+          const int j = static_cast<int>(trng.below(static_cast<uint32_t>(i + 1)));
+          const act_t ai = sh[i * kBlockM], aj = sh[j * kBlockM];
+          sh[i * kBlockM] = aj;
+          sh[j * kBlockM] = ai;
+        }
+        for (int k = 0; k < c; ++k) {
+          META(first + k) = mw_make<kWide>(static_cast<int>(sh[k * kBlockM]), cur, 0);
+          FIRST(first + k) = 0; PARENT(first + k) = node; COUNT(first + k) = 0; TOTAL(first + k) = 0.0;
+        }
+        } else {   // (boards from 16 x 16 on: two-byte entries x 362 children x 64 lanes would cost the kernel a wavefront per CU — 19 x 19: 2.9e8 -> 1.5e8)
         for (int k = 0; k < c; ++k) {
           META(first + k) = mw_make<kWide>(select_action(legal, k), cur, 0);
           FIRST(first + k) = 0; PARENT(first + k) = node; COUNT(first + k) = 0; TOTAL(first + k) = 0.0;
@@ -83,6 +123,7 @@ k_mcts(typename G::Params p, const typename G::word_t* base, int64_t n, int num_
           const uint32_t mi = META(first + i), mj = META(first + j);
           META(first + i) = mj;
           META(first + j) = mi;
+        }
         }
         meta = mw_make<kWide>(static_cast<int>(mw_action<kWide>(meta)), m_player(meta), c) | (meta & kMetaOutcomeBits);
         META(node) = meta;
@@ -370,6 +411,10 @@ extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_i
   pool.count = pool.parent + slots;
   pool.remap = gc_nodes > 0 ? pool.count + slots : nullptr;
   pool.n_roots = n;
+  {
+    const char* e = std::getenv("OSG_MCTS_ROOT_MAJOR");
+    pool.root_major = e ? (e[0] == '1' ? 1 : 0) : ((widest <= 16 && cfg.max_simulations <= 128) ? 0 : 1);
+  }
   pool.cap = static_cast<int>(cap);
   pool.gc_nodes = static_cast<int>(gc_nodes);
 
@@ -415,12 +460,14 @@ extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_i
     if (rc) return rc;
   } else {
     const unsigned grid = static_cast<unsigned>((n + kBlockM - 1) / kBlockM);
+    // the expansion's shuffle stage: one entry per child of the widest node and lane (two bytes above 255 actions)
+    const size_t shuffle_lds = A > 32 * 6 ? 0 : static_cast<size_t>(widest) * kBlockM;   // (HexT<8>, HexT<12> shuffle on the pool)
     if (board) {
-      OSG_DISPATCH_WIDE(roots->spec, k_mcts<G, true><<<dim3(grid), dim3(kBlockM), 0, ctx->stream>>>(
+      OSG_DISPATCH_WIDE(roots->spec, k_mcts<G, true><<<dim3(grid), dim3(kBlockM), shuffle_lds, ctx->stream>>>(
                                     P, static_cast<const typename G::word_t*>(roots->d_words), n, d.num_players, A, cfg,
                                     d.max_utility, d_logs, pool, d_best, d_vis, d_rew, d_out, d_stats));
     } else {
-      OSG_DISPATCH_WIDE(roots->spec, k_mcts<G, false><<<dim3(grid), dim3(kBlockM), 0, ctx->stream>>>(
+      OSG_DISPATCH_WIDE(roots->spec, k_mcts<G, false><<<dim3(grid), dim3(kBlockM), shuffle_lds, ctx->stream>>>(
                                     P, static_cast<const typename G::word_t*>(roots->d_words), n, d.num_players, A, cfg,
                                     d.max_utility, d_logs, pool, d_best, d_vis, d_rew, d_out, d_stats));
     }

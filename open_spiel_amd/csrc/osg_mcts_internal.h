@@ -24,6 +24,7 @@ struct Pool {
   int64_t n_roots;
   int cap;           // slots per root
   int gc_nodes;      // the reference's max_nodes_ (mcts.cc:214): garbage-collect when nodes_ >= gc_nodes; 0 = never
+  int root_major = 1;  // lane-per-root kernel: a root's nodes contiguous (1) or field[node * n_roots + root] (0); the wave kernel is root-major
 };
 constexpr int kMinGcLimit = 5;  // mcts.cc:30 MIN_GC_LIMIT
 

@@ -68,6 +68,15 @@ struct StepPool {
   uint8_t* phase;
   int64_t n;
   int cap, gc_nodes;
+  // where node i of root r lives in every plane: root-minor (field[node * n + root]) by default — this kernel runs ONE
+  // simulation per launch for every root, the lanes stand on the same node indices near the root most of the time and
+  // root-minor coalesces those accesses; root-major (a root's nodes contiguous: what k_mcts gained a factor 2 from in
+  // round 6, whole searches in one launch) measured SLOWER here — hex(9) 1.39e8 -> 1.1e8, connect_four with a network
+  // 1.97e8 -> 1.70e8 simulations/s (profiles/r06zg_*, r06zh_*).  OSG_STEP_ROOT_MAJOR=1 selects it.
+  int root_major;
+  OSG_HD int64_t at(uint32_t i, int64_t r) const {
+    return root_major ? r * static_cast<int64_t>(cap) + static_cast<int64_t>(i) : static_cast<int64_t>(i) * n + r;
+  }
   double* stash;      // [n, stash_slots, A] or null (flag 8)
   int stash_slots;
 };
@@ -170,14 +179,14 @@ struct NodeRef {
 };
 // A store by the CALLING lane (the reference object's assignment is lane 0's alone): where lanes write different nodes.
 template <bool kCoop, class T>
-OSG_D void node_store(T* lds_plane, T* pool_plane, uint32_t i, int64_t NR, int64_t r, T v) {
+OSG_D void node_store(T* lds_plane, T* pool_plane, uint32_t i, int64_t NR, int64_t RB, T v) {   // (NR, RB: StepPool::at as stride and offset)
   if (kCoop && i < static_cast<uint32_t>(kLdsNodes)) lds_plane[i] = v;
-  else pool_plane[static_cast<int64_t>(i) * NR + r] = v;
+  else pool_plane[static_cast<int64_t>(i) * NR + RB] = v;
 }
 template <bool kCoop, class T>
-OSG_D NodeRef<T, kCoop> node_ref(T* lds_plane, T* pool_plane, uint32_t i, int64_t NR, int64_t r) {
+OSG_D NodeRef<T, kCoop> node_ref(T* lds_plane, T* pool_plane, uint32_t i, int64_t NR, int64_t RB) {
   const bool in_lds = kCoop && i < static_cast<uint32_t>(kLdsNodes);
-  return {lds_plane + (in_lds ? i : 0u), pool_plane + static_cast<int64_t>(i) * NR + r, in_lds};
+  return {lds_plane + (in_lds ? i : 0u), pool_plane + static_cast<int64_t>(i) * NR + RB, in_lds};
 }
 template <class G>
 OSG_D void coop_playouts(const typename G::Params& p, const osg_mcts_cfg& cfg, int num_players, uint64_t gr, CoopBox<G>* box,
@@ -253,19 +262,19 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
   const int64_t r = kCoop ? 0 : slot / lane_stride;
   if (r >= n) return;
   const uint64_t gr = static_cast<uint64_t>(cfg.index_offset + r);
-  const int64_t NR = pool.n;
+  const int64_t NR = pool.root_major ? 1 : pool.n, RB = pool.root_major ? r * static_cast<int64_t>(pool.cap) : r;   // node i at i * NR + RB (StepPool::at)
   const bool host_priors = (flags & 1) != 0, through_chance = (flags & 2) != 0, own_rollouts = (flags & 4) != 0;
   const bool stashing = pool.stash != nullptr;
 // (kCoop: node i < kLdsNodes lives in LDS, the others — and every node of the batch form — in the pool.  A reference
 // object that branches on the index: a select between the two ADDRESSES made every access a flat one, slower than the
 // pool itself — 5.1e4 against 7.3e4 simulations/s; with the branch the LDS side is a ds_read / ds_write.)
-#define META(i) node_ref<kCoop>(lt.meta, pool.meta, static_cast<uint32_t>(i), NR, r)
-#define FIRST(i) node_ref<kCoop>(lt.first, pool.first, static_cast<uint32_t>(i), NR, r)
-#define PARENT(i) node_ref<kCoop>(lt.parent, pool.parent, static_cast<uint32_t>(i), NR, r)
-#define COUNT(i) node_ref<kCoop>(lt.count, pool.count, static_cast<uint32_t>(i), NR, r)
-#define TOTAL(i) node_ref<kCoop>(lt.total, pool.total, static_cast<uint32_t>(i), NR, r)
-#define PRIOR(i) pool.prior[static_cast<int64_t>(i) * NR + r]   /* (the pool only: PUCT reads it, UCT with playouts never) */
-#define REMAP(i) pool.remap[static_cast<int64_t>(i) * NR + r]
+#define META(i) node_ref<kCoop>(lt.meta, pool.meta, static_cast<uint32_t>(i), NR, RB)
+#define FIRST(i) node_ref<kCoop>(lt.first, pool.first, static_cast<uint32_t>(i), NR, RB)
+#define PARENT(i) node_ref<kCoop>(lt.parent, pool.parent, static_cast<uint32_t>(i), NR, RB)
+#define COUNT(i) node_ref<kCoop>(lt.count, pool.count, static_cast<uint32_t>(i), NR, RB)
+#define TOTAL(i) node_ref<kCoop>(lt.total, pool.total, static_cast<uint32_t>(i), NR, RB)
+#define PRIOR(i) pool.prior[static_cast<int64_t>(i) * NR + RB]   /* (the pool only: PUCT reads it, UCT with playouts never) */
+#define REMAP(i) pool.remap[static_cast<int64_t>(i) * NR + RB]
   uint8_t phase = pool.phase[r];
   if (phase == kFinished) { request[r] = 0; return; }
   // A search parked on a request whose answer the caller did not bring (NULL prior / value pointer) stays
@@ -676,12 +685,12 @@ k_mcts_tree_results(StepPool pool, int64_t n, int num_actions, int32_t* best_act
                     double* child_reward, int8_t* child_outcome, double* child_prior, double* root_stats) {
   const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlockM + threadIdx.x;
   if (r >= n) return;
-  const int64_t NR = pool.n;
-#define META(i) pool.meta[static_cast<int64_t>(i) * NR + r]
-#define FIRST(i) pool.first[static_cast<int64_t>(i) * NR + r]
-#define COUNT(i) pool.count[static_cast<int64_t>(i) * NR + r]
-#define TOTAL(i) pool.total[static_cast<int64_t>(i) * NR + r]
-#define PRIOR(i) pool.prior[static_cast<int64_t>(i) * NR + r]
+  const int64_t NR = pool.root_major ? 1 : pool.n, RB = pool.root_major ? r * static_cast<int64_t>(pool.cap) : r;   // node i at i * NR + RB (StepPool::at)
+#define META(i) pool.meta[static_cast<int64_t>(i) * NR + RB]
+#define FIRST(i) pool.first[static_cast<int64_t>(i) * NR + RB]
+#define COUNT(i) pool.count[static_cast<int64_t>(i) * NR + RB]
+#define TOTAL(i) pool.total[static_cast<int64_t>(i) * NR + RB]
+#define PRIOR(i) pool.prior[static_cast<int64_t>(i) * NR + RB]
   const uint32_t rm = META(0);
   const int root_player = m_terminal(rm) ? -1 : m_player(rm);  // a terminal root has no player to move
   const int c = mw_nchild<true>(rm);
@@ -734,8 +743,9 @@ k_mcts_tree_results(StepPool pool, int64_t n, int num_actions, int32_t* best_act
 __global__ void __launch_bounds__(256) k_mcts_tree_init(StepPool pool, const int8_t* root_player, int64_t n) {
   const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (r >= n) return;
-  pool.meta[r] = make_meta(0xFF, root_player[r], 0);  // mcts.cc:356-357: root = (kInvalidAction, CurrentPlayer(), 1)
-  pool.first[r] = 0; pool.parent[r] = kNoNode; pool.count[r] = 0; pool.total[r] = 0.0; pool.prior[r] = 1.0;
+  const int64_t at0 = pool.at(0, r);
+  pool.meta[at0] = make_meta(0xFF, root_player[r], 0);  // mcts.cc:356-357: root = (kInvalidAction, CurrentPlayer(), 1)
+  pool.first[at0] = 0; pool.parent[at0] = kNoNode; pool.count[at0] = 0; pool.total[at0] = 0.0; pool.prior[at0] = 1.0;
   pool.rng[r] = 0; pool.used[r] = 1; pool.node[r] = 0; pool.gc_limit[r] = kMinGcLimit; pool.sims[r] = 0;
   pool.phase[r] = kNewSimulation;
 }
@@ -745,7 +755,7 @@ __global__ void k_mcts_tree_extract(StepPool pool, int64_t r, uint32_t* meta, ui
                                     double* prior) {
   const uint32_t used = pool.used[r];
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < used; i += gridDim.x * blockDim.x) {
-    const int64_t at = static_cast<int64_t>(i) * pool.n + r;
+    const int64_t at = pool.at(i, r);
     meta[i] = pool.meta[at]; first[i] = pool.first[at]; count[i] = pool.count[at]; total[i] = pool.total[at];
     prior[i] = pool.prior[at];
   }
@@ -770,6 +780,10 @@ StepPool make_pool(const osg_mcts_tree* t) {
   pool.phase = reinterpret_cast<uint8_t*>(m);
   pool.n = t->n;
   pool.cap = t->cap;
+  {
+    const char* e = std::getenv("OSG_STEP_ROOT_MAJOR");
+    pool.root_major = (e && e[0] == '1') ? 1 : 0;
+  }
   pool.gc_nodes = t->gc_nodes;
   pool.stash = t->d_stash;
   pool.stash_slots = t->stash_slots;
@@ -1069,8 +1083,8 @@ int osg_mcts_tree_leaf_path(osg_mcts_tree* t, int64_t root, int32_t* h_actions, 
   std::vector<int32_t> rev;
   while (node != 0 && node != kNoNode) {
     uint32_t meta = 0, parent = 0;
-    OSG_HIP(hipMemcpyAsync(&meta, pool.meta + static_cast<int64_t>(node) * t->n + root, 4, hipMemcpyDeviceToHost, st));
-    OSG_HIP(hipMemcpyAsync(&parent, pool.parent + static_cast<int64_t>(node) * t->n + root, 4, hipMemcpyDeviceToHost, st));
+    OSG_HIP(hipMemcpyAsync(&meta, pool.meta + pool.at(node, root), 4, hipMemcpyDeviceToHost, st));
+    OSG_HIP(hipMemcpyAsync(&parent, pool.parent + pool.at(node, root), 4, hipMemcpyDeviceToHost, st));
     OSG_HIP(hipStreamSynchronize(st));
     rev.push_back(static_cast<int32_t>(mw_action<true>(meta)));
     node = parent;

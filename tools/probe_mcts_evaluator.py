@@ -2,6 +2,8 @@
 value / policy network (random weights), PUCT with root noise, one forward per evaluator round."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from open_spiel_amd import _abi
+if os.environ.get("OSG_VARIANT_LIB"): _abi.LIB_PATH = os.path.abspath(os.environ["OSG_VARIANT_LIB"])
 import torch, open_spiel_amd as osa
 from open_spiel_amd import mcts
 

@@ -18,6 +18,11 @@ namespace {
 // of the counter streams: with the sequence the reference's std::mt19937 + uniform_real_distribution would
 // produce, one trajectory IS one UpdateRegrets call of the reference, draw for draw
 // (ExternalSamplingMCCFRSolver::RunIteration(std::mt19937*), external_sampling_mccfr.h:63-100).
+#ifdef OSG_MCCFR_DIAG_NOATOMIC   // MEASUREMENT ONLY: what the general kernel would last without its global atomics
+OSG_D void k_add_f64(double* p, double v) { *p = v; }
+#else
+OSG_D void k_add_f64(double* p, double v) { add_f64(p, v); }
+#endif
 template <bool kLdsDelta, bool kExtU = false>
 __global__ void __launch_bounds__(256)
 k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dpol, uint64_t seed,
@@ -80,7 +85,7 @@ k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dp
             acc += pr;
           }
           if (t.actor[node] == (trav + 1) % P)  // kSimple averaging at player+1's nodes (:177-183)
-            for (int a = 0; a < nc; ++a) add_f64(&dpol[i * A + a], pol[a]);
+            for (int a = 0; a < nc; ++a) k_add_f64(&dpol[i * A + a], pol[a]);
           node = fc + pick;
           continue;
         }
@@ -110,7 +115,7 @@ k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dp
           break;
         }
         const double v = f_value[sp - 1];
-        for (int b = 0; b < nc; ++b) add_f64(&dreg[i * A + b], f_cv[sp - 1][b] - v);  // (:167-172)
+        for (int b = 0; b < nc; ++b) k_add_f64(&dreg[i * A + b], f_cv[sp - 1][b] - v);  // (:167-172)
         ret = v;
         --sp;
       }
@@ -122,8 +127,8 @@ k_mccfr(Tree t, const double* __restrict__ regrets, double* g_dreg, double* g_dp
     __syncthreads();
     for (int k = threadIdx.x; k < IA; k += blockDim.x) {
       const double r = smem[k], q = smem[IA + k];
-      if (r != 0.0) add_f64(&g_dreg[k], r);
-      if (q != 0.0) add_f64(&g_dpol[k], q);
+      if (r != 0.0) k_add_f64(&g_dreg[k], r);
+      if (q != 0.0) k_add_f64(&g_dpol[k], q);
     }
   }
 }

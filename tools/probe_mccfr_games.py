@@ -1,5 +1,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from open_spiel_amd import _abi
+if os.environ.get("OSG_VARIANT_LIB"): _abi.LIB_PATH = os.path.abspath(os.environ["OSG_VARIANT_LIB"])
 import torch, open_spiel_amd as osa
 ctx = osa.Context(0)
 for game, n in [("kuhn_poker", 1 << 20), ("kuhn_poker(players=3)", 1 << 20), ("kuhn_poker(players=5)", 1 << 20), ("leduc_poker", 1 << 20),

@@ -247,7 +247,9 @@ int osg_env_step_compact(osg_batch* b, const uint8_t* d_actions, uint8_t* d_flag
  * for every root: n_rollouts uniform-random playouts to the end of the game.
  * sum_returns [n, P] fp64 = SUM over rollouts of Returns() (divide by n_rollouts
  * for Evaluate's mean); steps[n] i32 (may be NULL) = plies played.  Rollout r of
- * root i draws from the counter stream (seed, index_offset + i, r).
+ * root i draws from the counter stream (seed, index_offset + i, r).  hex with steps == NULL: the playouts place their
+ * stones with the same draws until the board is full and read the winner off the filled board (a hex game cannot be
+ * un-won) — the same sums, ~5 x the rate of the move-by-move rules, which a non-NULL steps keeps.
  * A playout is cut off after 512 moves (no game served here lasts longer than 130): a record the
  * rules cannot finish — uploaded, neither terminal nor with a legal action — contributes Returns()
  * of a running game (zeros) instead of spinning on the device.  hex boards with a single row or

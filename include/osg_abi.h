@@ -282,9 +282,13 @@ typedef struct {
                                wave-parallel random fill).  The two layouts define their
                                random streams differently (see osg_common.h), so results
                                are reproducible per layout, not across layouts.  Layout 2
-                               serves boards of up to 128 actions; hex above 11 x 11,
-                               connect_four above 64 board bits and leduc_poker with 4+
-                               players are searched with layout 1 (0 picks it).  A node
+                               serves games of up to 128 actions and (round 6) the hex boards
+                               above 128 cells WITHOUT the swap rule (to 19 x 19: 3 / 4 / 6
+                               64-cell sets per colour in scalar registers; 0 picks it there —
+                               2.1-2.6 x layout 1 on 12 x 12 ... 16 x 16); hex above 128 cells
+                               with the swap rule, connect_four above 64 board bits and
+                               leduc_poker with 4+ players are searched with layout 1 (0 picks
+                               it), and layout 2 answers OSG_ERR_UNSUPPORTED for them.  A node
                                holds up to 511 actions.  Layout 2 is TUNED for hex without the
                                swap rule (what 0 picks it for); its instantiations for the other
                                games are correct (replay parity in the tests) but spill 76-129

@@ -337,18 +337,29 @@ extern "C" int osg_mcts_search(const osg_batch* roots, const osg_mcts_cfg* cfg_i
   if (int rc = refuse_endless_playouts(roots->spec, "osg_mcts_search")) return rc;
   if (roots->spec.desc.num_distinct_actions > kMaxSearchActions)
     return set_error(OSG_ERR_UNSUPPORTED, "osg_mcts_search: a node holds up to 511 actions");
-  // the games beyond the 4-word mask / the two-word records (hex above 11 x 11, connect_four above 64 board bits,
-  // leduc_poker with 4+ players) are searched by the lane-per-root kernel; the wave-per-root kernel keeps boards of
-  // up to 128 cells in scalar registers
+  // the games beyond the 4-word mask / the two-word records (hex above 11 x 11 with the swap rule, connect_four above 64
+  // board bits, leduc_poker with 4+ players) are searched by the lane-per-root kernel; the wave-per-root kernel keeps a hex
+  // position in scalar registers (two 64-cell sets per colour up to 128 cells, three / four / six on the boards above)
   const bool wide_game = roots->spec.desc.num_distinct_actions > 32 * kMaskWords || roots->spec.c4_wide || roots->spec.leduc_big;
   if (cfg.solve && !board)
     return set_error(OSG_ERR_UNSUPPORTED, "solve=true needs win/draw/loss outcomes (tic_tac_toe, connect_four, hex)");
   int layout = cfg.layout;
-  if (layout == 0)  // auto: the wave layout where its parallel playout applies (hex without the swap rule)
-    layout = (!wide_game && d.game_kind == kHex && d.num_distinct_actions == d.obs_shape[1] * d.obs_shape[2]) ? 2 : 1;
-  if (layout != 1 && layout != 2) return set_error(OSG_ERR_INVALID, "osg_mcts_cfg.layout must be 0, 1 or 2");
-  if (layout == 2 && wide_game)
-    return set_error(OSG_ERR_UNSUPPORTED, "osg_mcts_search: layout 2 (a wavefront per root) serves boards of up to 128 actions; "
+  if (layout != 0 && layout != 1 && layout != 2) return set_error(OSG_ERR_INVALID, "osg_mcts_cfg.layout must be 0, 1 or 2");
+  // (round 6: the hex boards above 128 cells too — kS = 3 / 4 / 6 cell sets per colour in scalar registers and as many
+  // child slots per lane — in the random-fill form only: no swap rule, and at most 64 columns so that a cell's neighbours
+  // lie in the adjacent cell sets)
+  bool wide_hex_fill = false;
+  if (wide_game && d.game_kind == kHex && d.num_distinct_actions == d.obs_shape[1] * d.obs_shape[2]) {
+    int rows = 0, cols = 0, cells = 0;
+    hex_dims(roots->spec, &rows, &cols, &cells);
+    wide_hex_fill = rows >= 2 && cols >= 2 && cols <= 64;
+  }
+  if (layout == 0)  // auto: the wave layout where its parallel playout applies (hex without the swap rule; measured on the
+                    // boards above 128 cells too: 2.1-2.6 x the lane layout on 12 x 12 ... 16 x 16, profiles/r06zn_*)
+    layout = ((!wide_game || wide_hex_fill) && d.game_kind == kHex && d.num_distinct_actions == d.obs_shape[1] * d.obs_shape[2]) ? 2 : 1;
+  if (layout == 2 && wide_game && !wide_hex_fill)
+    return set_error(OSG_ERR_UNSUPPORTED, "osg_mcts_search: layout 2 (a wavefront per root) serves games of up to 128 actions and "
+                                          "the larger hex boards without the swap rule (2 ... 64 columns); "
                                           "this game is searched with layout 1 (or 0 = automatic)");
   if (cfg.child_selection_policy != 0 && cfg.child_selection_policy != 1)
     return set_error(OSG_ERR_INVALID, "osg_mcts_cfg.child_selection_policy must be 0 (UCT) or 1 (PUCT)");

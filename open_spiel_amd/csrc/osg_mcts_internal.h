@@ -109,7 +109,8 @@ struct MctsOut {
 
 // The wave-per-root search as a work queue: a persistent grid whose wavefronts take the next ticket from a counter
 // and search root order[ticket] (order == nullptr: root = ticket).  Results stay keyed by the root's index.
-constexpr int kQueueBuckets = 129;          // cost key = number of legal actions at the root (<= 128)
+constexpr int kQueueBuckets = 385;          // cost key = number of legal actions at the root (<= 384: twelve plane words)
+constexpr int kQueueHeader = 512;           // ints ahead of the order array: the ticket, then the buckets
 struct WaveQueue {
   int32_t* ticket;        // [1], zeroed before the launch
   const int32_t* order;   // [n] or nullptr

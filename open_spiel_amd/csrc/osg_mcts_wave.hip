@@ -239,7 +239,7 @@ struct Chosen {
   uint32_t meta, cnt, first;
   double tot;
 };
-template <int kSlots, bool kBoard>
+template <int kSlots, bool kBoard, bool kWide = false>
 OSG_D Chosen select_child(const uint32_t* __restrict__ META, const uint32_t* __restrict__ COUNT,
                           const uint32_t* __restrict__ FIRST, const double* __restrict__ TOTAL, uint32_t first, int c,
                           uint32_t cnt, const osg_mcts_cfg& cfg, const double* __restrict__ log_table, uint64_t obase,
@@ -319,7 +319,7 @@ OSG_D Chosen select_child(const uint32_t* __restrict__ META, const uint32_t* __r
     uint32_t km = 0xFFFFFFFFu;  // no candidate's key: the low byte of a key is an action, never 0xFF
 #pragma unroll
     for (int j = 0; j < kSlots; ++j) {
-      const uint32_t kj = order_key(obase, ph, static_cast<int>(m_action(cm[j])));
+      const uint32_t kj = order_key(obase, ph, static_cast<int>(mw_action<kWide>(cm[j])));
       key[j] = __builtin_amdgcn_inverse_ballot_w64(cand[j]) ? kj : 0xFFFFFFFFu;
       km = key[j] < km ? key[j] : km;
     }
@@ -335,7 +335,7 @@ OSG_D Chosen select_child(const uint32_t* __restrict__ META, const uint32_t* __r
     r.cnt = read_lane(cc[0], src);
     r.first = read_lane(cf[0], src);
     r.tot = read_lane_f64(ct[0], src);
-  } else {
+  } else if constexpr (kSlots == 2) {
     const bool hi = cand[0] == 0ull;
     const int src = uniform(static_cast<int>(__builtin_ctzll(hi ? cand[1] : cand[0])));
     r.k = src + (hi ? 64 : 0);
@@ -344,35 +344,76 @@ OSG_D Chosen select_child(const uint32_t* __restrict__ META, const uint32_t* __r
     r.cnt = read_lane(hi ? cc[1] : cc[0], src);
     r.first = read_lane(hi ? cf[1] : cf[0], src);
     r.tot = read_lane_f64(hi ? ct[1] : ct[0], src);
+  } else {
+    // the first slot that holds a candidate (children are in action order: the smallest action among equal keys)
+    int slot = kSlots - 1;
+    uint64_t set = cand[kSlots - 1];
+#pragma unroll
+    for (int j = kSlots - 2; j >= 0; --j) {
+      const bool here = cand[j] != 0ull;
+      slot = here ? j : slot;
+      set = here ? cand[j] : set;
+    }
+    const int src = uniform(static_cast<int>(__builtin_ctzll(set)));
+    r.k = src + 64 * slot;
+    uint32_t sm = cm[0], sc = cc[0], sf = cf[0];
+    double st = ct[0];
+#pragma unroll
+    for (int j = 1; j < kSlots; ++j) {
+      sm = slot == j ? cm[j] : sm;
+      sc = slot == j ? cc[j] : sc;
+      sf = slot == j ? cf[j] : sf;
+      st = slot == j ? ct[j] : st;
+    }
+    r.meta = read_lane(sm, src);
+    r.cnt = read_lane(sc, src);
+    r.first = read_lane(sf, src);
+    r.tot = read_lane_f64(st, src);
   }
   return r;
 }
 
 // --- hex playout as a wave-parallel random fill --------------------------------------------
-// Lane l owns cells l and l + 64.  Per lane: the set of each cell's (up to six) neighbours as a 128-bit
-// mask.  Per wavefront (uniform, in SGPRs): which cells are on the board / on black's two edges.  Sets of
-// cells travel as two 64-bit lane masks (cells 0-63, cells 64-127), so set algebra runs on the scalar
-// unit and the vector unit only does the per-cell tests.
-struct HexLane {
-  uint64_t nb_lo[2];  // neighbours among cells 0-63
-  uint64_t nb_hi[2];  // neighbours among cells 64-127
-  uint32_t edge;      // cell l: first row 1, last row 2, first column 4, last column 8; cell l + 64: the same << 4
-  uint64_t board[2], first_row[2], last_row[2];  // wave-uniform cell sets
+// Lane l owns cells l, l + 64, ... l + 64 (kS - 1): kS "slots" (kS = 2 for boards of up to 128 cells, 3 / 4 / 6 for the
+// boards with six / eight / twelve plane words: 13 x 13, 15 x 15, 19 x 19).  Per lane and slot: the set of the cell's (up
+// to six) neighbours as 64-bit masks over the cell sets it can reach.  Per wavefront (uniform, in SGPRs): which cells
+// are on the board / on black's two edges.  Sets of cells travel as kS 64-bit lane masks (cells 64 j ... 64 j + 63), so
+// set algebra runs on the scalar unit and the vector unit only does the per-cell tests.
+//
+// A cell's neighbours are at most `cols` cells away, so with cols <= 64 (the launcher's condition for kS > 2) the
+// neighbours of a cell of set j lie in sets j - 1, j, j + 1: a band of kB = min(kS, 3) masks per slot, the window of
+// slot j starting at set hex_win<kS>(j).  (kS = 2: both sets for both slots, as before.)
+template <int kS>
+constexpr int hex_band() { return kS < 3 ? kS : 3; }
+template <int kS>
+constexpr int hex_win(int j) { return j - 1 < 0 ? 0 : (j - 1 > kS - hex_band<kS>() ? kS - hex_band<kS>() : j - 1); }
+template <class G>
+constexpr int wave_sets() { return G::kMaskW <= kMaskWords ? 2 : (G::kMaskW + 1) / 2; }
+template <int kS>
+struct HexLaneT {
+  uint64_t nb[kS][hex_band<kS>()];  // slot j: neighbours among the cells of sets hex_win(j) ... hex_win(j) + kB - 1
+  uint32_t edge;      // slot j, bits 4 j ... 4 j + 3: first row 1, last row 2, first column 4, last column 8
+  uint64_t board[kS], first_row[kS], last_row[kS];  // wave-uniform cell sets
 };
 template <class G>
-OSG_D HexLane hex_lane_setup(const typename G::Params& p) {
-  HexLane hl;
+OSG_D HexLaneT<wave_sets<G>()> hex_lane_setup(const typename G::Params& p) {
+  constexpr int kS = wave_sets<G>(), kB = hex_band<kS>();
+  HexLaneT<kS> hl;
   const int lane = lane_id();
+  hl.edge = 0u;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < kS; ++j) {
     const int cell = lane + 64 * j;
     const bool on_board = cell < p.cells;
     const typename G::Bits nb = G::neighbours(p, G::single(on_board ? cell : 0));
-    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    constexpr int kWords = static_cast<int>(sizeof(nb.w) / sizeof(nb.w[0]));
 #pragma unroll
-    for (int i = 0; i < static_cast<int>(sizeof(nb.w) / sizeof(nb.w[0])); ++i) w[i] = nb.w[i];
-    hl.nb_lo[j] = on_board ? (static_cast<uint64_t>(w[1]) << 32 | w[0]) : 0ull;
-    hl.nb_hi[j] = on_board ? (static_cast<uint64_t>(w[3]) << 32 | w[2]) : 0ull;
+    for (int t = 0; t < kB; ++t) {
+      const int set = hex_win<kS>(j) + t;
+      const uint32_t lo = 2 * set < kWords ? nb.w[2 * set < kWords ? 2 * set : 0] : 0u;
+      const uint32_t hi = 2 * set + 1 < kWords ? nb.w[2 * set + 1 < kWords ? 2 * set + 1 : 0] : 0u;
+      hl.nb[j][t] = on_board ? (static_cast<uint64_t>(hi) << 32 | lo) : 0ull;
+    }
     hl.board[j] = uniform64(__ballot(on_board));
     hl.first_row[j] = uniform64(__ballot(on_board && G::test(p.row_first, cell)));
     hl.last_row[j] = uniform64(__ballot(on_board && G::test(p.row_last, cell)));
@@ -381,7 +422,7 @@ OSG_D HexLane hex_lane_setup(const typename G::Params& p) {
       e = (G::test(p.row_first, cell) ? 1u : 0u) | (G::test(p.row_last, cell) ? 2u : 0u) |
           (G::test(p.col_first, cell) ? 4u : 0u) | (G::test(p.col_last, cell) ? 8u : 0u);
     }
-    if (j == 0) hl.edge = e; else hl.edge |= e << 4;
+    hl.edge |= e << (4 * j);
   }
   return hl;
 }
@@ -393,9 +434,32 @@ OSG_D uint64_t hex_cells64(const typename G::Bits& b, int j) {
   const uint32_t hi = 2 * j + 1 < kWords ? b.w[2 * j + 1 < kWords ? 2 * j + 1 : 0] : 0u;
   return uniform64(static_cast<uint64_t>(hi) << 32 | lo);
 }
+// The cells of a slot's neighbour band that lie in `front` (kS sets): nonzero iff one of the cell's neighbours is there.
+template <int kS>
+OSG_D uint32_t hex_touch(const HexLaneT<kS>& hl, int j, const uint64_t* front) {
+  constexpr int kB = hex_band<kS>();
+  uint64_t x = 0ull;
+#pragma unroll
+  for (int t = 0; t < kB; ++t) x |= hl.nb[j][t] & front[hex_win<kS>(j) + t];
+  return static_cast<uint32_t>(x) | static_cast<uint32_t>(x >> 32);
+}
+template <int kS>
+OSG_D bool sets_meet(const uint64_t* a, const uint64_t* b) {  // (a & b) != 0 over the kS sets
+  uint64_t x = 0ull;
+#pragma unroll
+  for (int j = 0; j < kS; ++j) x |= a[j] & b[j];
+  return x != 0ull;
+}
+template <int kS>
+OSG_D bool sets_any(const uint64_t* a) {
+  uint64_t x = 0ull;
+#pragma unroll
+  for (int j = 0; j < kS; ++j) x |= a[j];
+  return x != 0ull;
+}
 
 // The hex position the search walks with (no swap rule, at least two rows and two columns): the two
-// colours' stones as pairs of 64-bit cell sets and the player to move, wave-uniform, so that the rules
+// colours' stones as kS 64-bit cell sets each and the player to move, wave-uniform, so that the rules
 // run as scalar set algebra plus lane-parallel neighbour tests against HexLane.
 //
 // The reference keeps an edge-connection label on every stone and relabels a group at every move
@@ -407,208 +471,267 @@ OSG_D uint64_t hex_cells64(const typename G::Bits& b, int j) {
 // edges — the labels' invariant (a stone carries an edge label iff its group reaches that edge; the
 // `else if` of hex.cc:122-126 only matters on a one-row / one-column board, which this kernel is not
 // launched for) makes the two statements the same.
-struct HexW {
-  uint64_t occ[2], blk[2];  // all stones, black's stones (white = occ & ~blk: one set to update per move)
-  uint32_t meta;            // to move [0], result [1:3) as HexT::State::meta
+template <int kS>
+struct HexWT {
+  uint64_t occ[kS], blk[kS];  // all stones, black's stones (white = occ & ~blk: one set to update per move)
+  uint32_t meta;              // to move [0], result [1:3) as HexT::State::meta
+};
+// The legal actions of a hex position without the swap rule: its empty cells, as kS lane masks (hex.cc:280-293).
+template <int kS>
+struct HexLegalT {
+  uint64_t e[kS];
+  OSG_D int count() const {
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < kS; ++j) c += __builtin_popcountll(e[j]);
+    return c;
+  }
 };
 template <class G>
-OSG_D HexW hexw_from_state(const typename G::State& s) {
-  HexW w;
+OSG_D HexWT<wave_sets<G>()> hexw_from_state(const typename G::State& s) {
+  constexpr int kS = wave_sets<G>();
+  HexWT<kS> w;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < kS; ++j) {
     w.blk[j] = hex_cells64<G>(s.black, j);
     w.occ[j] = w.blk[j] | hex_cells64<G>(s.white, j);
   }
   w.meta = uniform(s.meta) & 7u;
   return w;
 }
-OSG_D bool hexw_terminal(const HexW& w) { return ((w.meta >> 1) & 3u) != 0; }
-OSG_D int hexw_current_player(const HexW& w) { return hexw_terminal(w) ? kTerminalPlayer : static_cast<int>(w.meta & 1u); }
-OSG_D Mask hexw_legal(const HexLane& hl, const HexW& w) {  // hex.cc:280-293 without the swap action
-  Mask m;
-  if (hexw_terminal(w)) return m;
-  const uint64_t e0 = hl.board[0] & ~w.occ[0], e1 = hl.board[1] & ~w.occ[1];
-  m.w[0] = static_cast<uint32_t>(e0);
-  m.w[1] = static_cast<uint32_t>(e0 >> 32);
-  m.w[2] = static_cast<uint32_t>(e1);
-  m.w[3] = static_cast<uint32_t>(e1 >> 32);
+template <int kS>
+OSG_D bool hexw_terminal(const HexWT<kS>& w) { return ((w.meta >> 1) & 3u) != 0; }
+template <int kS>
+OSG_D int hexw_current_player(const HexWT<kS>& w) { return hexw_terminal(w) ? kTerminalPlayer : static_cast<int>(w.meta & 1u); }
+template <int kS>
+OSG_D HexLegalT<kS> hexw_legal(const HexLaneT<kS>& hl, const HexWT<kS>& w) {
+  HexLegalT<kS> m;
+  const bool over = hexw_terminal(w);
+#pragma unroll
+  for (int j = 0; j < kS; ++j) m.e[j] = over ? 0ull : hl.board[j] & ~w.occ[j];
   return m;
 }
-OSG_D void hexw_returns(const HexW& w, double* out) {  // hex.cc:363-365
+template <int kS>
+OSG_D void hexw_returns(const HexWT<kS>& w, double* out) {  // hex.cc:363-365
   const int res = (w.meta >> 1) & 3u;
   const double r = res == 1 ? 1.0 : (res == 2 ? -1.0 : 0.0);
   out[0] = r;
   out[1] = -r + 0.0;
 }
 // DoApplyAction (hex.cc:229-278) on the way down the tree: the stone and the turn, nothing else.
-OSG_D void hexw_apply(const HexLane&, HexW& w, int move) {
+template <int kS>
+OSG_D void hexw_apply(const HexLaneT<kS>&, HexWT<kS>& w, int move) {
   const uint64_t bit = 1ull << (move & 63);
-  const bool hi = move >= 64;
-  const uint64_t bit0 = hi ? 0ull : bit, bit1 = hi ? bit : 0ull;
   const uint64_t black = (w.meta & 1u) == 0 ? ~0ull : 0ull;
-  w.occ[0] |= bit0;
-  w.occ[1] |= bit1;
-  w.blk[0] |= bit0 & black;
-  w.blk[1] |= bit1 & black;
+  if constexpr (kS == 2) {
+    const bool hi = move >= 64;
+    const uint64_t bit0 = hi ? 0ull : bit, bit1 = hi ? bit : 0ull;
+    w.occ[0] |= bit0;
+    w.occ[1] |= bit1;
+    w.blk[0] |= bit0 & black;
+    w.blk[1] |= bit1 & black;
+  } else {
+    const int set = move >> 6;
+#pragma unroll
+    for (int j = 0; j < kS; ++j) {
+      const uint64_t bj = set == j ? bit : 0ull;
+      w.occ[j] |= bj;
+      w.blk[j] |= bj & black;
+    }
+  }
   w.meta ^= 1u;
 }
 // Did the stone just placed on `move` end the game?  (= would hex.cc:248 have labelled it Win.)  Lane-parallel
 // flood of its group: a stone of the same colour joins when one of its neighbours is in the frontier.
-OSG_D bool hexw_last_stone_wins(const HexLane& hl, const HexW& w, int move) {
+template <int kS>
+OSG_D bool hexw_last_stone_wins(const HexLaneT<kS>& hl, const HexWT<kS>& w, int move) {
   const bool black = (w.meta & 1u) != 0;  // the owner of the stone is the player who is NOT to move now
-  const uint64_t own0 = black ? w.blk[0] : w.occ[0] & ~w.blk[0], own1 = black ? w.blk[1] : w.occ[1] & ~w.blk[1];
+  uint64_t own[kS], f[kS], l[kS];
   // the colour's two edges as cell sets: from the lanes' edge flags (black: rows = bits 0, 1; white: columns = bits 2, 3)
   const uint32_t fbit = black ? 1u : 4u, lbit = black ? 2u : 8u;
-  const uint64_t f0 = __ballot((hl.edge & fbit) != 0u), f1 = __ballot((hl.edge & (fbit << 4)) != 0u);
-  const uint64_t l0 = __ballot((hl.edge & lbit) != 0u), l1 = __ballot((hl.edge & (lbit << 4)) != 0u);
+#pragma unroll
+  for (int j = 0; j < kS; ++j) {
+    own[j] = black ? w.blk[j] : w.occ[j] & ~w.blk[j];
+    f[j] = __ballot((hl.edge & (fbit << (4 * j))) != 0u);
+    l[j] = __ballot((hl.edge & (lbit << (4 * j))) != 0u);
+  }
   // a chain needs a stone on each of the two edges
-  if ((((own0 & f0) | (own1 & f1)) == 0ull) | (((own0 & l0) | (own1 & l1)) == 0ull)) return false;
+  if (!sets_meet<kS>(own, f) | !sets_meet<kS>(own, l)) return false;
   const uint64_t bit = 1ull << (move & 63);
-  const bool hi = move >= 64;
+  const int set = move >> 6;
   // (bookkeeping on the vector unit, as in the playout's flood: every lane keeps an all-ones word per own-colour cell
   // that has not joined yet; the scalar unit only sees the new frontier of a step)
-  uint64_t group0 = hi ? 0ull : bit, group1 = hi ? bit : 0ull;
-  uint64_t front0 = group0, front1 = group1;
-  uint32_t avail0 = __builtin_amdgcn_inverse_ballot_w64(own0 & ~group0) ? ~0u : 0u;
-  uint32_t avail1 = __builtin_amdgcn_inverse_ballot_w64(own1 & ~group1) ? ~0u : 0u;
-  for (int it = 0; it < 128; ++it) {
-    const uint64_t x0 = (hl.nb_lo[0] & front0) | (hl.nb_hi[0] & front1);
-    const uint64_t x1 = (hl.nb_lo[1] & front0) | (hl.nb_hi[1] & front1);
-    const uint32_t j0 = (static_cast<uint32_t>(x0) | static_cast<uint32_t>(x0 >> 32)) & avail0;
-    const uint32_t j1 = (static_cast<uint32_t>(x1) | static_cast<uint32_t>(x1 >> 32)) & avail1;
-    front0 = __ballot(j0 != 0u);
-    front1 = __ballot(j1 != 0u);
-    if ((front0 | front1) == 0ull) break;
-    group0 |= front0;
-    group1 |= front1;
-    avail0 = j0 != 0u ? 0u : avail0;
-    avail1 = j1 != 0u ? 0u : avail1;
+  uint64_t group[kS], front[kS];
+  uint32_t avail[kS];
+#pragma unroll
+  for (int j = 0; j < kS; ++j) {
+    group[j] = set == j ? bit : 0ull;
+    front[j] = group[j];
+    avail[j] = __builtin_amdgcn_inverse_ballot_w64(own[j] & ~group[j]) ? ~0u : 0u;
   }
-  return (((group0 & f0) | (group1 & f1)) != 0ull) & (((group0 & l0) | (group1 & l1)) != 0ull);
+  for (int it = 0; it < 64 * kS; ++it) {
+    uint32_t jn[kS];
+#pragma unroll
+    for (int j = 0; j < kS; ++j) jn[j] = hex_touch<kS>(hl, j, front) & avail[j];
+#pragma unroll
+    for (int j = 0; j < kS; ++j) front[j] = __ballot(jn[j] != 0u);
+    if (!sets_any<kS>(front)) break;
+#pragma unroll
+    for (int j = 0; j < kS; ++j) {
+      group[j] |= front[j];
+      avail[j] = jn[j] != 0u ? 0u : avail[j];
+    }
+  }
+  return sets_meet<kS>(group, f) & sets_meet<kS>(group, l);
 }
 
-// The rules as the search sees them: HexW for the hex fill kernel, G::State otherwise.
+// The rules as the search sees them: HexWT for the hex fill kernel, G::State otherwise.
 template <class G>
 OSG_D bool w_terminal(const typename G::Params& p, const typename G::State& s) { return G::terminal(p, s); }
-template <class G>
-OSG_D bool w_terminal(const typename G::Params&, const HexW& w) { return hexw_terminal(w); }
+template <class G, int kS>
+OSG_D bool w_terminal(const typename G::Params&, const HexWT<kS>& w) { return hexw_terminal(w); }
 template <class G>
 OSG_D int w_current_player(const typename G::Params& p, const typename G::State& s) { return G::current_player(p, s); }
-template <class G>
-OSG_D int w_current_player(const typename G::Params&, const HexW& w) { return hexw_current_player(w); }
-template <class G>
-OSG_D Mask w_legal(const typename G::Params& p, const HexLane&, const typename G::State& s) { return G::legal(p, s); }
-template <class G>
-OSG_D Mask w_legal(const typename G::Params&, const HexLane& hl, const HexW& w) { return hexw_legal(hl, w); }
-template <class G>
-OSG_D void w_apply(const typename G::Params& p, const HexLane&, typename G::State& s, int a) { G::apply(p, s, a); }
-template <class G>
-OSG_D void w_apply(const typename G::Params&, const HexLane& hl, HexW& w, int a) { hexw_apply(hl, w, a); }
+template <class G, int kS>
+OSG_D int w_current_player(const typename G::Params&, const HexWT<kS>& w) { return hexw_current_player(w); }
+template <class G, int kS>
+OSG_D Mask w_legal(const typename G::Params& p, const HexLaneT<kS>&, const typename G::State& s) { return G::legal(p, s); }
+template <class G, int kS>
+OSG_D HexLegalT<kS> w_legal(const typename G::Params&, const HexLaneT<kS>& hl, const HexWT<kS>& w) { return hexw_legal(hl, w); }
+template <class G, int kS>
+OSG_D void w_apply(const typename G::Params& p, const HexLaneT<kS>&, typename G::State& s, int a) { G::apply(p, s, a); }
+template <class G, int kS>
+OSG_D void w_apply(const typename G::Params&, const HexLaneT<kS>& hl, HexWT<kS>& w, int a) { hexw_apply(hl, w, a); }
 template <class G>
 OSG_D void w_returns(const typename G::Params& p, const typename G::State& s, double* out) { G::returns(p, s, out); }
-template <class G>
-OSG_D void w_returns(const typename G::Params&, const HexW& w, double* out) { hexw_returns(w, out); }
+template <class G, int kS>
+OSG_D void w_returns(const typename G::Params&, const HexWT<kS>& w, double* out) { hexw_returns(w, out); }
 
-OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl PT_ARGS) {
+// The key that orders the empty cells of a playout: fill_key (32 mixed bits | the low byte of the cell id); on boards
+// above 256 cells two cells 256 apart could tie, and the order is defined as (fill_key, cell) — here as ONE key with
+// the cell's ninth bit below everything else, so that the threshold search still sees distinct keys.
+template <int kS>
+constexpr int fill_bits() { return kS > 4 ? kFillKeyBits + 1 : kFillKeyBits; }
+template <int kS>
+OSG_D uint64_t wave_fill_key(uint64_t base, int cell) {
+  const uint64_t k = fill_key(base, cell);
+  if constexpr (kS > 4) return (k << 1) | static_cast<uint64_t>(cell >> 8);
+  else return k;
+}
+
+template <int kS>
+OSG_D int hex_fill_winner(const HexWT<kS>& s, uint64_t base, const HexLaneT<kS>& hl PT_ARGS) {
   const int lane = lane_id();
-  const uint64_t black0 = s.blk[0], black1 = s.blk[1];
-  const uint64_t empty0 = hl.board[0] & ~s.occ[0], empty1 = hl.board[1] & ~s.occ[1];
-  const uint64_t key0 = fill_key(base, lane), key1 = fill_key(base, lane + 64);
-  const int m = __builtin_popcountll(empty0) + __builtin_popcountll(empty1);
+  constexpr int kBits = fill_bits<kS>();
+  uint64_t empty[kS], key[kS];
+  int m = 0;
+#pragma unroll
+  for (int j = 0; j < kS; ++j) {
+    empty[j] = hl.board[j] & ~s.occ[j];
+    key[j] = wave_fill_key<kS>(base, lane + 64 * j);
+    m += __builtin_popcountll(empty[j]);
+  }
   const int want = (m + 1) >> 1;  // plies 0, 2, 4, ... belong to the player to move
   // The `want` smallest keys among the empty cells = the keys below a threshold T with exactly `want` keys
   // under it.  T is built most-significant bit first (a binary search on the key space): a bit stays
   // set while no more than `want` keys lie below.  Keys are distinct, so the search ends as soon as the
   // count is exact — about log2(m) + 2 steps of two compares and a handful of scalar instructions.
+  uint64_t sel[kS];
 #if defined(OSG_DIAG_NOTHR)  // measurement only: an arbitrary subset instead of the exact half
-  const uint64_t sel0 = __ballot((key0 >> 20) & 1ull) & empty0, sel1 = __ballot((key1 >> 20) & 1ull) & empty1;
+#pragma unroll
+  for (int j = 0; j < kS; ++j) sel[j] = __ballot((key[j] >> 20) & 1ull) & empty[j];
 #elif OSG_THR_MODE == 0
   uint64_t thr = 0ull;
   if (want > 0) {
-    uint64_t step = 1ull << (kFillKeyBits - 1);
+    uint64_t step = 1ull << (kBits - 1);
     bool exact;
     do {  // straight-line body: one select, no inner branch
       const uint64_t probe = thr | step;
-      const int below = __builtin_popcountll(__ballot(key0 < probe) & empty0) +
-                        __builtin_popcountll(__ballot(key1 < probe) & empty1);
+      int below = 0;
+#pragma unroll
+      for (int j = 0; j < kS; ++j) below += __builtin_popcountll(__ballot(key[j] < probe) & empty[j]);
       thr = below <= want ? probe : thr;
       exact = below == want;
       step >>= 1;
     } while (!exact && step != 0ull);
   }
-  const uint64_t sel0 = __ballot(key0 < thr) & empty0, sel1 = __ballot(key1 < thr) & empty1;
+#pragma unroll
+  for (int j = 0; j < kS; ++j) sel[j] = __ballot(key[j] < thr) & empty[j];
 #else
   // The search runs on the VECTOR unit (the kernel is bound by scalar issue): threshold and step live in
   // vector registers holding the same value in every lane, occupied cells carry the key 2^64 - 1 so that
   // the ballots need no masking, and only the counting and the loop branch are left to the scalar unit.
-  const uint64_t k0 = __builtin_amdgcn_inverse_ballot_w64(empty0) ? key0 : ~0ull;
-  const uint64_t k1 = __builtin_amdgcn_inverse_ballot_w64(empty1) ? key1 : ~0ull;
+  uint64_t k[kS];
+#pragma unroll
+  for (int j = 0; j < kS; ++j) k[j] = __builtin_amdgcn_inverse_ballot_w64(empty[j]) ? key[j] : ~0ull;
   const uint32_t vz = vector_zero();
   uint64_t thr = vz;
   if (want > 0) {
-    uint64_t step = (1ull << (kFillKeyBits - 1)) | vz;
+    uint64_t step = (1ull << (kBits - 1)) | vz;
     const uint32_t want_v = static_cast<uint32_t>(want) | vz;
-    for (int it = 0; it < kFillKeyBits; ++it) {
+    for (int it = 0; it < kBits; ++it) {
       const uint64_t probe = thr | step;
-      const uint64_t b0 = __ballot(k0 < probe), b1 = __ballot(k1 < probe);
-      const int below = __builtin_popcountll(b0) + __builtin_popcountll(b1);
+      int below = 0;
+#pragma unroll
+      for (int j = 0; j < kS; ++j) below += __builtin_popcountll(__ballot(k[j] < probe));
       const uint32_t below_v = static_cast<uint32_t>(below) | vz;
       thr = below_v <= want_v ? probe : thr;
       step >>= 1;
       if (below == want) break;
     }
   }
-  const uint64_t sel0 = __ballot(k0 < thr), sel1 = __ballot(k1 < thr);
+#pragma unroll
+  for (int j = 0; j < kS; ++j) sel[j] = __ballot(k[j] < thr);
 #endif
   PT_MARK(4);
   // The filled board: the mover's new stones are `sel`, the opponent's the other empty cells.
   const bool black_moves = (s.meta & 1u) == 0;
-  const uint64_t blk0 = black0 | (black_moves ? sel0 : empty0 & ~sel0);
-  const uint64_t blk1 = black1 | (black_moves ? sel1 : empty1 & ~sel1);
+  uint64_t blk[kS];
+#pragma unroll
+  for (int j = 0; j < kS; ++j) blk[j] = s.blk[j] | (black_moves ? sel[j] : empty[j] & ~sel[j]);
   // Black wins iff its stones join the first row to the last row (hex.cc:108-171 edge labels).
   // Lane-parallel flood: a black cell joins the region when one of its neighbours is in it.
   // Stops as soon as the last row is reached.
 #if defined(OSG_DIAG_NOFLOOD)  // measurement only
-  return static_cast<int>((blk0 ^ blk1 ^ (blk0 >> 17)) & 1ull);
+  return static_cast<int>((blk[0] ^ blk[1] ^ (blk[0] >> 17)) & 1ull);
 #elif OSG_FLOOD_MODE == 0
-  uint64_t reach0 = blk0 & hl.first_row[0], reach1 = blk1 & hl.first_row[1];
+  uint64_t reach[kS];
+#pragma unroll
+  for (int j = 0; j < kS; ++j) reach[j] = blk[j] & hl.first_row[j];
 #pragma unroll 4  // measured: 1 -> 7.80e8, compiler's choice (2) -> 7.93e8, 4 -> 8.01e8 sims/s
-  for (int it = 0; it < 128; ++it) {
-    if (((reach0 & hl.last_row[0]) | (reach1 & hl.last_row[1])) != 0ull) return 0;  // black
-    const bool n0 = ((hl.nb_lo[0] & reach0) | (hl.nb_hi[0] & reach1)) != 0ull;
-    const bool n1 = ((hl.nb_lo[1] & reach0) | (hl.nb_hi[1] & reach1)) != 0ull;
-    const uint64_t g0 = __ballot(n0) & blk0 & ~reach0, g1 = __ballot(n1) & blk1 & ~reach1;
-    if ((g0 | g1) == 0ull) break;
-    reach0 |= g0;
-    reach1 |= g1;
+  for (int it = 0; it < 64 * kS; ++it) {
+    if (sets_meet<kS>(reach, hl.last_row)) return 0;  // black
+    uint64_t g[kS];
+#pragma unroll
+    for (int j = 0; j < kS; ++j) g[j] = __ballot(hex_touch<kS>(hl, j, reach) != 0u) & blk[j] & ~reach[j];
+    if (!sets_any<kS>(g)) break;
+#pragma unroll
+    for (int j = 0; j < kS; ++j) reach[j] |= g[j];
   }
 #elif OSG_FLOOD_MODE == 2
+  static_assert(kS == 2, "flood mode 2 (a measurement variant) is written for boards of up to 128 cells");
   // As mode 1, with the two exits decided on the VECTOR unit too and only once per TWO steps: every lane remembers
   // whether one of its cells that joined lies on the last row (the "black arrived" exit) and whether its cells joined
   // in the second step (the "nothing new" exit); each exit is one compare into vcc and one branch.  Running one step
   // past either condition is harmless: an empty frontier stays empty, and a last-row cell that joined stays remembered.
-  uint64_t front0 = blk0 & hl.first_row[0], front1 = blk1 & hl.first_row[1];
-  uint32_t avail0 = __builtin_amdgcn_inverse_ballot_w64(blk0 & ~front0) ? ~0u : 0u;
-  uint32_t avail1 = __builtin_amdgcn_inverse_ballot_w64(blk1 & ~front1) ? ~0u : 0u;
-  if (((front0 & hl.last_row[0]) | (front1 & hl.last_row[1])) != 0ull) return 0;  // a one-row chain
+  uint64_t front[2] = {blk[0] & hl.first_row[0], blk[1] & hl.first_row[1]};
+  uint32_t avail0 = __builtin_amdgcn_inverse_ballot_w64(blk[0] & ~front[0]) ? ~0u : 0u;
+  uint32_t avail1 = __builtin_amdgcn_inverse_ballot_w64(blk[1] & ~front[1]) ? ~0u : 0u;
+  if (sets_meet<kS>(front, hl.last_row)) return 0;  // a one-row chain
   // all ones where the lane's cell is on the last row (edge bit 1 of cell l, bit 5 of cell l + 64)
   const uint32_t last0 = static_cast<uint32_t>(static_cast<int32_t>(hl.edge << 30) >> 31);
   const uint32_t last1 = static_cast<uint32_t>(static_cast<int32_t>(hl.edge << 26) >> 31);
   uint32_t hit;  // (lane-local) one of the lane's cells that joined in this pair of steps lies on the last row
   for (;;) {
-    const uint64_t x0 = (hl.nb_lo[0] & front0) | (hl.nb_hi[0] & front1);
-    const uint64_t x1 = (hl.nb_lo[1] & front0) | (hl.nb_hi[1] & front1);
-    const uint32_t ja0 = (static_cast<uint32_t>(x0) | static_cast<uint32_t>(x0 >> 32)) & avail0;
-    const uint32_t ja1 = (static_cast<uint32_t>(x1) | static_cast<uint32_t>(x1 >> 32)) & avail1;
-    const uint64_t mid0 = __ballot(ja0 != 0u), mid1 = __ballot(ja1 != 0u);
+    const uint32_t ja0 = hex_touch<kS>(hl, 0, front) & avail0;
+    const uint32_t ja1 = hex_touch<kS>(hl, 1, front) & avail1;
+    const uint64_t mid[2] = {__ballot(ja0 != 0u), __ballot(ja1 != 0u)};
     avail0 = ja0 != 0u ? 0u : avail0;
     avail1 = ja1 != 0u ? 0u : avail1;
-    const uint64_t y0 = (hl.nb_lo[0] & mid0) | (hl.nb_hi[0] & mid1);
-    const uint64_t y1 = (hl.nb_lo[1] & mid0) | (hl.nb_hi[1] & mid1);
-    const uint32_t jb0 = (static_cast<uint32_t>(y0) | static_cast<uint32_t>(y0 >> 32)) & avail0;
-    const uint32_t jb1 = (static_cast<uint32_t>(y1) | static_cast<uint32_t>(y1 >> 32)) & avail1;
-    front0 = __ballot(jb0 != 0u);
-    front1 = __ballot(jb1 != 0u);
+    const uint32_t jb0 = hex_touch<kS>(hl, 0, mid) & avail0;
+    const uint32_t jb1 = hex_touch<kS>(hl, 1, mid) & avail1;
+    front[0] = __ballot(jb0 != 0u);
+    front[1] = __ballot(jb1 != 0u);
     avail0 = jb0 != 0u ? 0u : avail0;
     avail1 = jb1 != 0u ? 0u : avail1;
     // (both exits lead to the same place and the answer is read off `hit` there: the loop stays two compares into
@@ -619,28 +742,31 @@ OSG_D int hex_fill_winner(const HexW& s, uint64_t base, const HexLane& hl PT_ARG
   }
   return __ballot(hit != 0u) != 0ull ? 0 : 1;
 #else
-  // The bookkeeping of the flood on the vector unit: every lane keeps, for its two cells, an all-ones word
+  // The bookkeeping of the flood on the vector unit: every lane keeps, for each of its cells, an all-ones word
   // while the cell is black and not reached yet ("available") and clears it when the cell joins; the scalar
-  // unit only sees the two ballots of a step (the new frontier) and decides the two exits.
-  uint64_t front0 = blk0 & hl.first_row[0], front1 = blk1 & hl.first_row[1];
-  uint32_t avail0 = __builtin_amdgcn_inverse_ballot_w64(blk0 & ~front0) ? ~0u : 0u;
-  uint32_t avail1 = __builtin_amdgcn_inverse_ballot_w64(blk1 & ~front1) ? ~0u : 0u;
-  if (((front0 & hl.last_row[0]) | (front1 & hl.last_row[1])) != 0ull) return 0;  // a one-row chain
+  // unit only sees the kS ballots of a step (the new frontier) and decides the two exits.
+  uint64_t front[kS];
+  uint32_t avail[kS];
+#pragma unroll
+  for (int j = 0; j < kS; ++j) {
+    front[j] = blk[j] & hl.first_row[j];
+    avail[j] = __builtin_amdgcn_inverse_ballot_w64(blk[j] & ~front[j]) ? ~0u : 0u;
+  }
+  if (sets_meet<kS>(front, hl.last_row)) return 0;  // a one-row chain
 #ifndef OSG_FLOOD_UNROLL
 #define OSG_FLOOD_UNROLL 2
 #endif
 #pragma unroll OSG_FLOOD_UNROLL
-  for (int it = 0; it < 128; ++it) {
-    const uint64_t x0 = (hl.nb_lo[0] & front0) | (hl.nb_hi[0] & front1);
-    const uint64_t x1 = (hl.nb_lo[1] & front0) | (hl.nb_hi[1] & front1);
-    const uint32_t j0 = (static_cast<uint32_t>(x0) | static_cast<uint32_t>(x0 >> 32)) & avail0;
-    const uint32_t j1 = (static_cast<uint32_t>(x1) | static_cast<uint32_t>(x1 >> 32)) & avail1;
-    front0 = __ballot(j0 != 0u);
-    front1 = __ballot(j1 != 0u);
-    if (((front0 & hl.last_row[0]) | (front1 & hl.last_row[1])) != 0ull) return 0;  // black reached its last row
-    if ((front0 | front1) == 0ull) break;
-    avail0 = j0 != 0u ? 0u : avail0;
-    avail1 = j1 != 0u ? 0u : avail1;
+  for (int it = 0; it < 64 * kS; ++it) {
+    uint32_t jn[kS];
+#pragma unroll
+    for (int j = 0; j < kS; ++j) jn[j] = hex_touch<kS>(hl, j, front) & avail[j];
+#pragma unroll
+    for (int j = 0; j < kS; ++j) front[j] = __ballot(jn[j] != 0u);
+    if (sets_meet<kS>(front, hl.last_row)) return 0;  // black reached its last row
+    if (!sets_any<kS>(front)) break;
+#pragma unroll
+    for (int j = 0; j < kS; ++j) avail[j] = jn[j] != 0u ? 0u : avail[j];
   }
 #endif
   return 1;  // white: on a filled board exactly one side connects
@@ -682,6 +808,22 @@ struct VisitPath {
 #ifndef OSG_HEX_WPE
 #define OSG_HEX_WPE 7
 #endif
+// Wavefronts per SIMD the hex fill kernel is compiled for, by the number of cell sets of the position (the boards above
+// 128 cells hold kS sets per colour in scalar registers and kS child slots per lane: fewer, fatter wavefronts).
+#ifndef OSG_HEX_WPE_3
+#define OSG_HEX_WPE_3 5
+#endif
+#ifndef OSG_HEX_WPE_4
+#define OSG_HEX_WPE_4 4
+#endif
+#ifndef OSG_HEX_WPE_6
+#define OSG_HEX_WPE_6 3
+#endif
+template <class G, bool kHexFill>
+constexpr int wave_wpe() {
+  if (!kHexFill) return 4;
+  return wave_sets<G>() == 2 ? OSG_HEX_WPE : (wave_sets<G>() == 3 ? OSG_HEX_WPE_3 : (wave_sets<G>() == 4 ? OSG_HEX_WPE_4 : OSG_HEX_WPE_6));
+}
 
 // The hex fill kernel at 7 waves per SIMD.  What the code object says (tools/kernel_resources.py ->
 // profiles/r05_kernel_resources.txt): 72 vector + 94 scalar registers, 44 scalar registers parked in the lanes of one
@@ -718,10 +860,13 @@ OSG_D void wave_search(const typename G::Params& p, const typename G::word_t* ba
   uint32_t* REMAP = kGc ? pool.remap + r * cap : nullptr;
   int gc_limit = kMinGcLimit;
   const uint64_t obase = order_base(cfg.seed, gr);
-  HexLane hl{};
+  constexpr int kS = wave_sets<G>();   // 64-cell sets per position (hex fill) = child slots per lane
+  constexpr bool kWide = kS > 2;       // nine-bit action / child-count fields in a node's header (osg_mcts_internal.h)
+  static_assert(kHexFill || !kWide, "the boards above 128 actions are searched as hex without the swap rule only");
+  HexLaneT<kS> hl{};
   if constexpr (kHexFill) hl = hex_lane_setup<G>(p);
 
-  using WState = std::conditional_t<kHexFill, HexW, typename G::State>;
+  using WState = std::conditional_t<kHexFill, HexWT<kS>, typename G::State>;
   const typename G::State loaded_root = G::load(p, base, n, r);
   WState root_state;
   if constexpr (kHexFill) root_state = hexw_from_state<G>(loaded_root);
@@ -729,7 +874,7 @@ OSG_D void wave_search(const typename G::Params& p, const typename G::word_t* ba
   const int root_player = w_current_player<G>(p, root_state);
   // The root's header stays in registers (its count / total in path slot 0); every other node's header
   // comes out of its parent's child scan by readlane, so a tree level costs ONE memory round trip.
-  uint32_t root_meta = make_meta(0xFF, root_player, 0);  // mcts.cc:356-357
+  uint32_t root_meta = mw_make<kWide>(kWide ? 0x1FF : 0xFF, root_player, 0);  // mcts.cc:356-357
   uint32_t root_first = 0;
   if (lane == 0) {
     META[0] = root_meta;
@@ -773,37 +918,65 @@ OSG_D void wave_search(const typename G::Params& p, const typename G::word_t* ba
         if (term || cnt == 0 || depth + 1 >= kPathLimit) break;
       }
       const int cur = w_current_player<G>(p, s);
-      const Mask legal = w_legal<G>(p, hl, s);
+      const auto legal = w_legal<G>(p, hl, s);
       PT_MARK(0);
-      if (m_nchild(meta) == 0) {  // expand: one child per Prior() entry, in action order
+      if (mw_nchild<kWide>(meta) == 0) {  // expand: one child per Prior() entry, in action order
         const int c = legal.count();
         // slots exhausted (unreachable unless the caller's HBM could not hold max_nodes + slack), or a record that is
         // not terminal and has no legal action (only an uploaded inconsistent one): leaf evaluation
         if (c == 0 || used + static_cast<uint32_t>(c) > static_cast<uint32_t>(cap)) break;
         first = used;
         used += c;
-        // Children in action order.  Lane l looks at actions l and l + 64: a legal action's slot is its
+        // Children in action order.  Lane l looks at actions l, l + 64, ...: a legal action's slot is its
         // rank among the legal ones (popcount of the mask below it) — the cheap direction of the
         // k <-> action mapping — so the writes are still one compacted, coalesced span.
+        if constexpr (kHexFill && kWide) {  // the legal set as lane masks: a rank is a running count + the lanes below
+          int before = 0;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int a = lane + 64 * j;
-          if (legal.test(a)) {
-            int rank = 0;
-#pragma unroll
-            for (int w = 0; w < kMaskWords; ++w) {
-              const int lo = 32 * w;
-              if (a >= lo + 32) rank += __builtin_popcount(legal.w[w]);
-              else if (a > lo) rank += __builtin_popcount(legal.w[w] & ((1u << (a - lo)) - 1u));
+          for (int j = 0; j < kS; ++j) {
+            const uint64_t e = legal.e[j];
+            if (__builtin_amdgcn_inverse_ballot_w64(e)) {
+              const int rank = before + static_cast<int>(__builtin_amdgcn_mbcnt_hi(
+                                            static_cast<uint32_t>(e >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(e), 0u)));
+              META[first + rank] = mw_make<true>(lane + 64 * j, cur, 0);
+              FIRST[first + rank] = 0;
+              COUNT[first + rank] = 0;
+              TOTAL[first + rank] = 0.0;
+              if constexpr (kGc) PARENT[first + rank] = node;
             }
-            META[first + rank] = make_meta(a, cur, 0);
-            FIRST[first + rank] = 0;
-            COUNT[first + rank] = 0;
-            TOTAL[first + rank] = 0.0;
-            if constexpr (kGc) PARENT[first + rank] = node;
+            before += __builtin_popcountll(e);
+          }
+        } else {
+          Mask lm;
+          if constexpr (kHexFill) {
+#pragma unroll
+            for (int j = 0; j < kS; ++j) {
+              lm.w[2 * j] = static_cast<uint32_t>(legal.e[j]);
+              lm.w[2 * j + 1] = static_cast<uint32_t>(legal.e[j] >> 32);
+            }
+          } else {
+            lm = legal;
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int a = lane + 64 * j;
+            if (lm.test(a)) {
+              int rank = 0;
+#pragma unroll
+              for (int w = 0; w < kMaskWords; ++w) {
+                const int lo = 32 * w;
+                if (a >= lo + 32) rank += __builtin_popcount(lm.w[w]);
+                else if (a > lo) rank += __builtin_popcount(lm.w[w] & ((1u << (a - lo)) - 1u));
+              }
+              META[first + rank] = make_meta(a, cur, 0);
+              FIRST[first + rank] = 0;
+              COUNT[first + rank] = 0;
+              TOTAL[first + rank] = 0.0;
+              if constexpr (kGc) PARENT[first + rank] = node;
+            }
           }
         }
-        meta = make_meta(m_action(meta), m_player(meta), c) | (meta & 0x00F00000u);
+        meta = mw_make<kWide>(static_cast<int>(mw_action<kWide>(meta)), m_player(meta), c) | (meta & kMetaOutcomeBits);
         if (lane == 0) {
           META[node] = meta;
           FIRST[node] = first;
@@ -815,35 +988,48 @@ OSG_D void wave_search(const typename G::Params& p, const typename G::word_t* ba
         wave_fence();
       }
       PT_MARK(1);
-      const int c = m_nchild(meta);
+      const int c = mw_nchild<kWide>(meta);
       int chosen_k, action;
       uint32_t n_meta, n_cnt, n_first;
       double n_tot;
-      if (!kHexFill && cur == kChancePlayer) {  // mcts.cc:311-322; children are in outcome order
+      bool at_chance = false;
+      if constexpr (!kHexFill) at_chance = cur == kChancePlayer;
+      if (at_chance) {  // mcts.cc:311-322; children are in outcome order
         action = 0;
-        if constexpr (!kHexFill) action = sample_action_chance<G>(p, s, legal, trng);
-        int below = 0;
+        chosen_k = 0;
+        if constexpr (!kHexFill) {
+          action = sample_action_chance<G>(p, s, legal, trng);
+          int below = 0;
 #pragma unroll
-        for (int w = 0; w < kMaskWords; ++w) {
-          const int lo = 32 * w;
-          if (action >= lo + 32) below += __builtin_popcount(legal.w[w]);
-          else if (action > lo) below += __builtin_popcount(legal.w[w] & ((1u << (action - lo)) - 1u));
+          for (int w = 0; w < kMaskWords; ++w) {
+            const int lo = 32 * w;
+            if (action >= lo + 32) below += __builtin_popcount(legal.w[w]);
+            else if (action > lo) below += __builtin_popcount(legal.w[w] & ((1u << (action - lo)) - 1u));
+          }
+          chosen_k = below;
         }
-        chosen_k = below;
         n_meta = uniform(META[first + chosen_k]);
         n_cnt = uniform(COUNT[first + chosen_k]);
         n_first = uniform(FIRST[first + chosen_k]);
         n_tot = uniform_f64(TOTAL[first + chosen_k]);
       } else {  // arg-max of UCTValue (mcts.cc:90-101), ties to the smallest order key
         Chosen ch;
-        if (c > 64) ch = select_child<2, kBoard>(META, COUNT, FIRST, TOTAL, first, c, cnt, cfg, log_table, obase, ph);
-        else ch = select_child<1, kBoard>(META, COUNT, FIRST, TOTAL, first, c, cnt, cfg, log_table, obase, ph);
+        if constexpr (kWide) {  // the instantiation by the child count: a late position of a big board scans one slot
+          if (c > 256 && kS > 4) ch = select_child<kS, kBoard, true>(META, COUNT, FIRST, TOTAL, first, c, cnt, cfg, log_table, obase, ph);
+          else if (c > 192 && kS > 3) ch = select_child<4, kBoard, true>(META, COUNT, FIRST, TOTAL, first, c, cnt, cfg, log_table, obase, ph);
+          else if (c > 128) ch = select_child<3, kBoard, true>(META, COUNT, FIRST, TOTAL, first, c, cnt, cfg, log_table, obase, ph);
+          else if (c > 64) ch = select_child<2, kBoard, true>(META, COUNT, FIRST, TOTAL, first, c, cnt, cfg, log_table, obase, ph);
+          else ch = select_child<1, kBoard, true>(META, COUNT, FIRST, TOTAL, first, c, cnt, cfg, log_table, obase, ph);
+        } else {
+          if (c > 64) ch = select_child<2, kBoard>(META, COUNT, FIRST, TOTAL, first, c, cnt, cfg, log_table, obase, ph);
+          else ch = select_child<1, kBoard>(META, COUNT, FIRST, TOTAL, first, c, cnt, cfg, log_table, obase, ph);
+        }
         chosen_k = ch.k;
         n_meta = ch.meta;
         n_cnt = ch.cnt;
         n_first = ch.first;
         n_tot = ch.tot;
-        action = static_cast<int>(m_action(n_meta));
+        action = static_cast<int>(mw_action<kWide>(n_meta));
       }
       PT_MARK(2);
       node = first + static_cast<uint32_t>(chosen_k);
@@ -866,7 +1052,7 @@ OSG_D void wave_search(const typename G::Params& p, const typename G::word_t* ba
       } else if (cnt == 0) {
         if (depth == 0) {
           term = hexw_terminal(s);
-        } else if (hexw_last_stone_wins(hl, s, static_cast<int>(m_action(meta)))) {
+        } else if (hexw_last_stone_wins(hl, s, static_cast<int>(mw_action<kWide>(meta)))) {
           s.meta |= ((s.meta & 1u) ? 1u : 2u) << 1;  // the player who moved last won
           term = true;
         }
@@ -954,7 +1140,7 @@ OSG_D void wave_search(const typename G::Params& p, const typename G::word_t* ba
       for (int d = depth; d >= 0 && solved; --d) {
         const uint32_t v = vp.node_at(d) & 0x0FFFFFFFu;
         const uint32_t meta = uniform(META[v]);
-        const int c = m_nchild(meta);
+        const int c = mw_nchild<kWide>(meta);
         if (c == 0) continue;
         const uint32_t first = uniform(FIRST[v]);
         const int mover = m_player(uniform(META[first]));
@@ -983,7 +1169,7 @@ OSG_D void wave_search(const typename G::Params& p, const typename G::word_t* ba
     }
     PT_MARK(6);
     ++sims_done;
-    if (m_has_outcome(root_meta) || m_nchild(root_meta) == 1) break;  // mcts.cc:437-440 (a terminal root has an outcome too)
+    if (m_has_outcome(root_meta) || mw_nchild<kWide>(root_meta) == 1) break;  // mcts.cc:437-440 (a terminal root has an outcome too)
     // ---- GarbageCollect (mcts.cc:441-482): when nodes_ >= max_nodes_, every node with explore_count <
     // gc_limit_ loses its children.  Visit counts never grow from parent to child, so a node survives exactly
     // when its parent's count reaches the limit: 64 nodes per step, a ballot prefix gives the survivors their
@@ -1010,8 +1196,8 @@ OSG_D void wave_search(const typename G::Params& p, const typename G::word_t* ba
           if (to != kNoNode) {
             nm = META[i]; nf = FIRST[i]; nc = COUNT[i]; nt = TOTAL[i];
             if (i != 0) np = REMAP[PARENT[i]];
-            if (m_nchild(nm) > 0) {
-              if (nc < limit) { nm &= ~(0xFFu << 12); nf = 0; }  // children.clear(); the outcome stays
+            if (mw_nchild<kWide>(nm) > 0) {
+              if (nc < limit) { nm = mw_clear_children<kWide>(nm); nf = 0; }  // children.clear(); the outcome stays
               else nf = REMAP[nf];
             }
           }
@@ -1032,7 +1218,7 @@ OSG_D void wave_search(const typename G::Params& p, const typename G::word_t* ba
   PT_FLUSH;
   // ---- results: BestChild (mcts.cc:114-143) + per-action statistics ----
   const uint32_t rm = root_meta;
-  const int c = m_nchild(rm);
+  const int c = mw_nchild<kWide>(rm);
   const uint32_t first = root_first;
   for (int a = lane; a < num_actions; a += 64) {
     if (out.child_visits) out.child_visits[r * num_actions + a] = 0;
@@ -1046,7 +1232,7 @@ OSG_D void wave_search(const typename G::Params& p, const typename G::word_t* ba
     const uint32_t cm = META[first + k];
     const uint32_t cc = COUNT[first + k];
     const double ct = TOTAL[first + k];
-    const int a = static_cast<int>(m_action(cm));
+    const int a = static_cast<int>(mw_action<kWide>(cm));
     const bool has = m_has_outcome(cm);
     const int pl = m_player(cm);
     const double o = (has && pl >= 0 && cc > 0) ? outcome_value<kBoard>(cm, cc, ct, pl)
@@ -1087,7 +1273,7 @@ OSG_D void wave_search(const typename G::Params& p, const typename G::word_t* ba
 
 // One wavefront per root, statically: wave w of workgroup b searches root 4 b + w.
 template <class G, bool kBoard, bool kHexFill, bool kGc>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(kHexFill ? OSG_HEX_WPE : 4, 8)))
+__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(wave_wpe<G, kHexFill>(), 8)))
 k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, int num_actions,
             osg_mcts_cfg cfg, double max_utility, const double* __restrict__ log_table, Pool pool, MctsOut out) {
   __shared__ uint32_t s_path[kWavesPerBlock][kMaxPath - kPathRegs];
@@ -1107,7 +1293,7 @@ k_mcts_wave(typename G::Params p, const typename G::word_t* base, int64_t n, int
 // number of legal actions, most first) the long searches start first and the short ones fill the gaps.  Results are
 // written under the root's own index: the outputs do not depend on the order or on which wavefront ran what.
 template <class G, bool kBoard, bool kHexFill, bool kGc>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(kHexFill ? OSG_HEX_WPE : 4, 8)))
+__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(wave_wpe<G, kHexFill>(), 8)))
 k_mcts_wave_queue(typename G::Params p, const typename G::word_t* base, int64_t n, int num_players, int num_actions,
                   osg_mcts_cfg cfg, double max_utility, const double* __restrict__ log_table, Pool pool, MctsOut out,
                   WaveQueue queue) {
@@ -1166,8 +1352,8 @@ __global__ void __launch_bounds__(256) k_queue_scatter(typename G::Params p, con
 // of the wave slots, one wavefront per root beyond.  OSG_MCTS_SCHEDULE (read at every launch; a tuning knob, results
 // do not depend on it) overrides: "static" | "queue" (index order) | "lpt", optionally ":<wavefronts per SIMD>".
 struct Schedule { int mode; int waves_per_simd; bool forced; };
-inline Schedule schedule_from_env(bool hex_fill) {
-  Schedule sc{2, hex_fill ? OSG_HEX_WPE : 4, false};
+inline Schedule schedule_from_env(int compiled_waves_per_simd) {
+  Schedule sc{2, compiled_waves_per_simd, false};
   const char* e = std::getenv("OSG_MCTS_SCHEDULE");
   if (!e || !*e) return sc;
   sc.forced = true;
@@ -1191,7 +1377,7 @@ int launch(const typename G::Params& P, const osg_batch* roots, const osg_mcts_c
   const int64_t n = roots->n;
   const auto* words = static_cast<const typename G::word_t*>(roots->d_words);
   const bool gc = pool.gc_nodes > 1 && pool.remap;
-  const Schedule sc = schedule_from_env(kHexFill);
+  const Schedule sc = schedule_from_env(wave_wpe<G, kHexFill>());
   if (ctx->num_cus == 0) {
     hipDeviceProp_t prop;
     OSG_HIP(hipGetDeviceProperties(&prop, ctx->device));
@@ -1216,13 +1402,13 @@ int launch(const typename G::Params& P, const osg_batch* roots, const osg_mcts_c
     if (ctx->d_mcts_queue) OSG_HIP(hipFree(ctx->d_mcts_queue));
     ctx->d_mcts_queue = nullptr;
     ctx->mcts_queue_roots = 0;
-    OSG_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_mcts_queue), sizeof(int32_t) * (256 + static_cast<size_t>(n))));
+    OSG_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_mcts_queue), sizeof(int32_t) * (kQueueHeader + static_cast<size_t>(n))));
     ctx->mcts_queue_roots = n;
   }
   int32_t* ticket = ctx->d_mcts_queue;
   int32_t* hist = ctx->d_mcts_queue + 1;
-  int32_t* order = ctx->d_mcts_queue + 256;
-  OSG_HIP(hipMemsetAsync(ctx->d_mcts_queue, 0, sizeof(int32_t) * 256, st));
+  int32_t* order = ctx->d_mcts_queue + kQueueHeader;
+  OSG_HIP(hipMemsetAsync(ctx->d_mcts_queue, 0, sizeof(int32_t) * kQueueHeader, st));
   WaveQueue queue{ticket, nullptr};
   if (sc.mode == 2) {
     const unsigned g = static_cast<unsigned>((n + 255) / 256);
@@ -1265,12 +1451,22 @@ int launch_mcts_wave(const osg_batch* roots, const osg_mcts_cfg& cfg, const doub
   if (spec.member.swap || spec.member.rows < 2 || spec.member.cols < 2)                      \
     rc = launch<HexT<NW>, true, false>(spec.member, roots, cfg, d_logs, pool, out);          \
   else rc = launch<HexT<NW>, true, true>(spec.member, roots, cfg, d_logs, pool, out)
+      // The boards above 128 cells (six / eight / twelve plane words) are searched in the fill form only (the caller,
+      // osg_mcts_search, has checked: no swap rule, two rows and columns at least, at most 64 columns).
+#define OSG_HEX_WIDE_CASE(NW, member)                                                        \
+  if (spec.member.swap || spec.member.rows < 2 || spec.member.cols < 2 || spec.member.cols > 64) \
+    return set_error(OSG_ERR_UNSUPPORTED, "wave-per-root search of a board above 128 cells: hex without the swap rule, 2 ... 64 columns"); \
+  rc = launch<HexT<NW>, true, true>(spec.member, roots, cfg, d_logs, pool, out)
       switch (spec.hex_nw) {   // (a folded record — HexT::folded — differs in the root load only)
         case 1: OSG_HEX_CASE(1, hex1); break;
         case 2: OSG_HEX_CASE(2, hex2); break;
         case 3: OSG_HEX_CASE(3, hex3); break;
-        default: OSG_HEX_CASE(4, hex4); break;
+        case 4: OSG_HEX_CASE(4, hex4); break;
+        case 6: OSG_HEX_WIDE_CASE(6, hex6); break;
+        case 8: OSG_HEX_WIDE_CASE(8, hex8); break;
+        default: OSG_HEX_WIDE_CASE(12, hex12); break;
       }
+#undef OSG_HEX_WIDE_CASE
 #undef OSG_HEX_CASE
       break;
     }

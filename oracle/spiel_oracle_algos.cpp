@@ -180,7 +180,10 @@ std::unique_ptr<State> MCTSBot::ApplyTreePolicy(
         const uint64_t ob = OrderBase(c_seed_, c_root_);
         std::sort(legal.begin(), legal.end(), [&](const std::pair<Action, double>& a,
                                                   const std::pair<Action, double>& b) {
-          return OrderKey(ob, ph, static_cast<int>(a.first)) < OrderKey(ob, ph, static_cast<int>(b.first));
+          // (key, action): the key's low byte is the action's low byte, so only actions 256 apart — the boards above
+          // 256 cells — can tie, and then the smaller action goes first (the kernel's children are in action order)
+          const uint32_t ka = OrderKey(ob, ph, static_cast<int>(a.first)), kb = OrderKey(ob, ph, static_cast<int>(b.first));
+          return ka != kb ? ka < kb : a.first < b.first;
         });
       } else if (counter_) {  // Fisher-Yates on the counter stream (the device's shuffle)
         for (int i = static_cast<int>(legal.size()) - 1; i >= 1; --i)
@@ -303,7 +306,8 @@ std::vector<double> MCTSBot::CounterEvaluate(const State& state, int sim) const 
       const uint64_t fb = FillBase(c_seed_, c_root_, static_cast<uint64_t>(sim) * c_rollouts_ + r);
       std::vector<Action> cells = w->LegalActions();
       std::sort(cells.begin(), cells.end(), [&](Action a, Action b) {
-        return FillKey(fb, static_cast<int>(a)) < FillKey(fb, static_cast<int>(b));
+        const uint64_t ka = FillKey(fb, static_cast<int>(a)), kb = FillKey(fb, static_cast<int>(b));
+        return ka != kb ? ka < kb : a < b;   // (FillKey, cell): cells 256 apart may share a key on the largest boards
       });
       const size_t h = (cells.size() + 1) / 2;
       for (size_t t = 0; !w->IsTerminal(); ++t) {

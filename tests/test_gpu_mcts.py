@@ -120,16 +120,19 @@ def test_mcts_replay_parity(oracle, ctx, game, n, sims, n_rollouts, solve, max_s
     ("leduc_poker(players=6)", 16, 80, 2, False, 14),
 ])
 def test_mcts_replay_parity_on_the_wide_games(oracle, ctx, game, n, sims, n_rollouts, solve, max_stop):
-    """The games beyond the four-word mask / the two-word records are searched by the lane-per-root kernel (layout 1;
-    layout 2 refuses them): the same replay parity as above — visits, rewards, outcomes, best action, root by root."""
+    """The games beyond the four-word mask / the two-word records are searched by the lane-per-root kernel (layout 1, what
+    layout 0 picks; layout 2 serves of them the hex boards without the swap rule — the test below — and refuses the others):
+    the same replay parity as above — visits, rewards, outcomes, best action, root by root."""
     import open_spiel_amd as osa
     players = int(game.split("players=")[1].rstrip(")")) if "players=" in game else 0
     og, roots, hists = _roots(oracle, ctx, game, n, 23, max_stop, players)   # (poker: past the private deals)
-    with pytest.raises(osa.OsgError):
-        roots.mcts_search(uct_c=2.0, max_simulations=4, n_rollouts=1, seed=1, layout=2)
+    if not game.startswith("hex") or "swap=True" in game:
+        with pytest.raises(osa.OsgError):
+            roots.mcts_search(uct_c=2.0, max_simulations=4, n_rollouts=1, seed=1, layout=2)
     seed, offset = 0xFEED5EED, 777
+    # (layout 0 = automatic picks the lane-per-root kernel for all of these but the hex boards without the swap rule)
     res = roots.mcts_search(uct_c=2.0, max_simulations=sims, n_rollouts=n_rollouts, solve=solve, seed=seed,
-                            index_offset=offset, layout=0)
+                            index_offset=offset, layout=0 if (not game.startswith("hex") or "swap=True" in game) else 1)
     best = res["best_action"].cpu().numpy()
     visits = res["child_visits"].cpu().numpy()
     reward = res["child_reward"].cpu().numpy()
@@ -154,6 +157,65 @@ def test_mcts_replay_parity_on_the_wide_games(oracle, ctx, game, n, sims, n_roll
             assert best[i] == want["best_action"], f"{game} root {i}: best action"
         checked += 1
     assert checked >= n // 3
+
+
+@pytest.mark.parametrize("game,n,sims,n_rollouts,solve,max_stop,puct,max_nodes", [
+    ("hex(board_size=12)", 10, 150, 1, False, 50, False, 0),     # 144 cells: three cell sets, six plane words
+    ("hex(board_size=13)", 10, 200, 1, False, 60, False, 0),     # 169 cells
+    ("hex(board_size=13)", 8, 200, 1, True, 165, False, 0),      # late positions: finished games in the tree, the solver
+    ("hex(board_size=13)", 6, 150, 2, True, 120, True, 0),       # PUCT
+    ("hex(board_size=13)", 6, 400, 1, False, 150, False, 60),    # few empty cells, deep trees, garbage collection
+    ("hex(board_size=14)", 8, 120, 1, False, 80, False, 0),      # 196 cells: four cell sets
+    ("hex(board_size=15)", 8, 120, 1, False, 100, False, 0),     # 225 cells
+    ("hex(board_size=16)", 6, 100, 1, True, 200, False, 0),      # 256 cells: a child count that needs the ninth bit
+    ("hex(board_size=16)", 6, 300, 1, False, 0, False, 0),       # ... from the empty board: 256 children of the root
+    ("hex(board_size=17)", 6, 80, 1, False, 140, False, 0),      # 289 cells: six cell sets, five of them used
+    ("hex(board_size=19)", 6, 80, 1, False, 120, False, 0),      # 361 cells: nine-bit actions, 41-bit fill keys
+    ("hex(board_size=19)", 4, 400, 1, False, 0, False, 0),       # 361 children of the root, all visited once and more
+    ("hex(board_size=19)", 6, 150, 3, True, 340, True, 0),       # nearly full boards
+    ("hex(num_cols=19,num_rows=7)", 8, 150, 1, True, 60, False, 0),     # 133 cells, long rows
+    ("hex(num_cols=5,num_rows=30)", 8, 150, 1, True, 80, False, 0),     # 150 cells, long columns
+    ("hex(num_cols=31,num_rows=5)", 6, 200, 1, True, 100, False, 0),    # 155 cells: the widest row with a device layout
+])
+def test_mcts_wave_layout_on_the_boards_above_128_cells(oracle, ctx, game, n, sims, n_rollouts, solve, max_stop, puct,
+                                                        max_nodes):
+    """Round 6: the wavefront-per-root search (layout 2) on hex boards of more than 128 cells — the position as 3 / 4 / 6
+    64-cell sets per colour in scalar registers, as many child slots per lane, the playout as one random fill ordered by
+    (fill_key, cell): every root's children, visits, rewards, proven outcomes and best action against the oracle's replay
+    of the same streams (counter_layout=2)."""
+    og, roots, hists = _roots(oracle, ctx, game, n, 29, max_stop, 0)
+    seed, offset = 0xFEED5EED, 4242
+    kw = dict(uct_c=2.0, max_simulations=sims, n_rollouts=n_rollouts, solve=solve, seed=seed, index_offset=offset, layout=2)
+    if puct:
+        kw["puct"] = True
+    if max_nodes:
+        kw["max_nodes"] = max_nodes
+    res = roots.mcts_search(**kw)
+    auto = roots.mcts_search(**dict(kw, layout=0))       # what "automatic" picks on these boards
+    assert bool((auto["child_visits"] == res["child_visits"]).all()) and bool((auto["child_reward"] == res["child_reward"]).all())
+    best = res["best_action"].cpu().numpy()
+    visits = res["child_visits"].cpu().numpy()
+    reward = res["child_reward"].cpu().numpy()
+    outcome = res["child_outcome"].cpu().numpy()
+    stats = res["root_stats"].cpu().numpy()
+    for i in range(n):
+        st = _oracle_state(og, hists[i])
+        want = st.mcts_search(2.0, sims, n_rollouts, -max_nodes if max_nodes else 4096, solve, 0, counter_root=offset + i,
+                              counter_seed=seed, counter_layout=2, puct=puct)
+        assert stats[i, 0] == want["root_visits"], f"{game} root {i}: root visits"
+        acts = want["children"][:, 0].astype(int)
+        assert sorted(acts.tolist()) == np.nonzero(outcome[i] != 3)[0].tolist(), f"{game} root {i}: children"
+        for a, cnt, tot, out in want["children"]:
+            a = int(a)
+            assert visits[i, a] == cnt and reward[i, a] == tot, f"{game} root {i} action {a}: {visits[i, a]} / {cnt}, {reward[i, a]} / {tot}"
+            if solve:
+                assert (outcome[i, a] == 2) == np.isnan(out)
+                if not np.isnan(out):
+                    assert outcome[i, a] == out
+        if len(acts):
+            assert best[i] == want["best_action"], f"{game} root {i}: best action"
+        if solve:
+            assert np.isnan(stats[i, 2]) == np.isnan(want["root_outcome"])
 
 
 @pytest.mark.parametrize("layout", [1, 2])

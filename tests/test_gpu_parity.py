@@ -309,18 +309,19 @@ def test_bad_game_strings(ctx):
 
 def test_hex_above_128_actions_where_the_boundary_stops(ctx):
     """hex(13) ... hex(19) are served by the batch entry points (the parity tests above run them through every one) and
-    by the lane-per-root search (tests/test_gpu_mcts.py); the wave-per-root search keeps boards of up to 128 cells, the
-    fused step its one-byte action ids and the solvers the games with a tree: each says so."""
+    by both search layouts (tests/test_gpu_mcts.py; the wave-per-root one without the swap rule only); the fused step keeps
+    its one-byte action ids and the solvers the games with a tree: each says so."""
     import torch
     import open_spiel_amd as osa
     b = osa.StateBatch(ctx, "hex(board_size=19)", 64)
     assert b.desc.num_distinct_actions == 361 and b.desc.mask_words == 12 and b.desc.state_words == 48   # (4 x 12 plane words; the meta word folded in)
     b.random_steps(5, 30)
     assert int(b.legal_actions_mask().sum()) == 64 * (361 - 30)
-    with pytest.raises(osa.OsgError, match="128 actions"):
-        b.mcts_search(max_simulations=8, layout=2)
-    res = b.mcts_search(max_simulations=8)                     # layout 0 picks the lane-per-root search
-    assert bool((res["child_visits"].sum(1) == 7).all())
+    for layout in (0, 1, 2):                                   # round 6: both layouts take the board (0 picks the wave-per-root one) ...
+        res = b.mcts_search(max_simulations=8, layout=layout)
+        assert bool((res["child_visits"].sum(1) == 7).all())
+    with pytest.raises(osa.OsgError, match="swap"):            # ... but not with the swap rule (its playout is a random fill)
+        osa.StateBatch(ctx, "hex(board_size=13,swap=True)", 8).mcts_search(max_simulations=8, layout=2)
     with pytest.raises(osa.OsgError):
         osa.TabularSolver(ctx, "leduc_poker(players=4)")
     with pytest.raises(osa.OsgError, match="one byte"):

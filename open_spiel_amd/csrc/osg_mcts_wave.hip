@@ -394,7 +394,18 @@ struct HexLaneT {
   uint64_t nb[kS][hex_band<kS>()];  // slot j: neighbours among the cells of sets hex_win(j) ... hex_win(j) + kB - 1
   uint32_t edge;      // slot j, bits 4 j ... 4 j + 3: first row 1, last row 2, first column 4, last column 8
   uint64_t board[kS], first_row[kS], last_row[kS];  // wave-uniform cell sets
+  // kS > 2 (the boards above 128 cells): the floods run on PACKED per-lane flags instead — bit kFlag0 + j of a lane's
+  // word = its cell of slot j — and a step PULLS the frontier flags of the six neighbour directions (+1, -1, +C, -C,
+  // +C-1, -C+1: hex.cc:316-329) from the lanes that hold them: six cross-lane reads whatever kS is, against kS neighbour
+  // bands of six 32-bit ANDs each.  fl_addr[d]: the byte address (lane * 4) of the lane holding cell + d;  fl_w[d]: bits
+  // kFlag0 + j = "the cell of slot j has a neighbour in direction d", bit 0 = the neighbour sits one slot further (d > 0)
+  // / one slot back (d < 0) because lane + d left 0 ... 63;  fl_edge[e]: the lane's cells on the first row, last row,
+  // first column, last column.
+  uint32_t fl_addr[6], fl_w[6], fl_edge[4];
 };
+constexpr int kFlag0 = 8;
+// (+1, -1, +C, -C, +C-1, -C+1 for C columns)
+OSG_D int hex_dir(int d, int cols) { return d == 0 ? 1 : d == 1 ? -1 : d == 2 ? cols : d == 3 ? -cols : d == 4 ? cols - 1 : 1 - cols; }
 template <class G>
 OSG_D HexLaneT<wave_sets<G>()> hex_lane_setup(const typename G::Params& p) {
   constexpr int kS = wave_sets<G>(), kB = hex_band<kS>();
@@ -423,8 +434,48 @@ OSG_D HexLaneT<wave_sets<G>()> hex_lane_setup(const typename G::Params& p) {
           (G::test(p.col_first, cell) ? 4u : 0u) | (G::test(p.col_last, cell) ? 8u : 0u);
     }
     hl.edge |= e << (4 * j);
+    if constexpr (kS > 2) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (j == 0) hl.fl_edge[q] = 0u;
+        hl.fl_edge[q] |= ((e >> q) & 1u) << (kFlag0 + j);
+      }
+#pragma unroll
+      for (int d = 0; d < 6; ++d) {
+        const int step = hex_dir(d, p.cols);
+        if (j == 0) {
+          const int to = lane + step;
+          hl.fl_addr[d] = static_cast<uint32_t>(to & 63) << 2;
+          hl.fl_w[d] = (to < 0 || to > 63) ? 1u : 0u;
+        }
+        const int other = cell + step;
+        const bool has = on_board && other >= 0 && other < p.cells && G::test(nb, other < 0 ? 0 : (other < p.cells ? other : 0));
+        hl.fl_w[d] |= (has ? 1u : 0u) << (kFlag0 + j);
+      }
+    }
   }
   return hl;
+}
+// Packed flags (kS > 2): the cells of kS wave-uniform sets as one word per lane, bit kFlag0 + j = the lane's cell of slot j.
+template <int kS>
+OSG_D uint32_t hex_pack(const uint64_t* sets) {
+  uint32_t bits = 0u;
+#pragma unroll
+  for (int j = 0; j < kS; ++j) bits |= __builtin_amdgcn_inverse_ballot_w64(sets[j]) ? (1u << (kFlag0 + j)) : 0u;
+  return bits;
+}
+// One flood step in the packed form: the cells that have a neighbour in `front`.
+template <int kS>
+OSG_D uint32_t hex_pull(const HexLaneT<kS>& hl, uint32_t front) {
+  uint32_t acc = 0u;
+#pragma unroll
+  for (int d = 0; d < 6; ++d) {
+    uint32_t g = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(hl.fl_addr[d]), static_cast<int>(front)));
+    // the neighbour's flag sits one slot off where lane + d wrapped (the shift reads bits [4:0] of fl_w: 0 or 1)
+    g = (d == 0 || d == 2 || d == 4) ? g >> (hl.fl_w[d] & 31u) : g << (hl.fl_w[d] & 31u);
+    acc |= g & hl.fl_w[d];   // (flags live at bits >= kFlag0, so fl_w's bit 0 never matches one)
+  }
+  return acc;
 }
 // Cells 64 j ... 64 j + 63 of a (wave-uniform) bitboard as one 64-bit set.
 template <class G>
@@ -546,6 +597,24 @@ OSG_D void hexw_apply(const HexLaneT<kS>&, HexWT<kS>& w, int move) {
 template <int kS>
 OSG_D bool hexw_last_stone_wins(const HexLaneT<kS>& hl, const HexWT<kS>& w, int move) {
   const bool black = (w.meta & 1u) != 0;  // the owner of the stone is the player who is NOT to move now
+  if constexpr (kS > 2) {  // packed flags (see HexLaneT)
+    uint64_t own_sets[kS];
+#pragma unroll
+    for (int j = 0; j < kS; ++j) own_sets[j] = black ? w.blk[j] : w.occ[j] & ~w.blk[j];
+    const uint32_t own = hex_pack<kS>(own_sets);
+    const uint32_t fe = black ? hl.fl_edge[0] : hl.fl_edge[2], le = black ? hl.fl_edge[1] : hl.fl_edge[3];
+    if ((__ballot((own & fe) != 0u) == 0ull) | (__ballot((own & le) != 0u) == 0ull)) return false;
+    uint32_t front = lane_id() == (move & 63) ? 1u << (kFlag0 + (move >> 6)) : 0u;
+    uint32_t group = front, avail = own & ~front;
+    for (int it = 0; it < 64 * kS; ++it) {
+      const uint32_t joined = hex_pull<kS>(hl, front) & avail;
+      if (__ballot(joined != 0u) == 0ull) break;
+      avail ^= joined;
+      group |= joined;
+      front = joined;
+    }
+    return (__ballot((group & fe) != 0u) != 0ull) & (__ballot((group & le) != 0u) != 0ull);
+  }
   uint64_t own[kS], f[kS], l[kS];
   // the colour's two edges as cell sets: from the lanes' edge flags (black: rows = bits 0, 1; white: columns = bits 2, 3)
   const uint32_t fbit = black ? 1u : 4u, lbit = black ? 2u : 8u;
@@ -742,6 +811,20 @@ OSG_D int hex_fill_winner(const HexWT<kS>& s, uint64_t base, const HexLaneT<kS>&
   }
   return __ballot(hit != 0u) != 0ull ? 0 : 1;
 #else
+  if constexpr (kS > 2) {  // packed flags (see HexLaneT): a step costs six cross-lane reads whatever kS is
+    const uint32_t black = hex_pack<kS>(blk);
+    uint32_t front = black & hl.fl_edge[0];
+    uint32_t avail = black & ~front;
+    if (__ballot((front & hl.fl_edge[1]) != 0u) != 0ull) return 0;  // a one-row chain
+    for (int it = 0; it < 64 * kS; ++it) {
+      const uint32_t joined = hex_pull<kS>(hl, front) & avail;
+      if (__ballot((joined & hl.fl_edge[1]) != 0u) != 0ull) return 0;  // black reached its last row
+      if (__ballot(joined != 0u) == 0ull) break;
+      avail ^= joined;
+      front = joined;
+    }
+    return 1;
+  }
   // The bookkeeping of the flood on the vector unit: every lane keeps, for each of its cells, an all-ones word
   // while the cell is black and not reached yet ("available") and clears it when the cell joins; the scalar
   // unit only sees the kS ballots of a step (the new frontier) and decides the two exits.
@@ -814,10 +897,10 @@ struct VisitPath {
 #define OSG_HEX_WPE_3 5
 #endif
 #ifndef OSG_HEX_WPE_4
-#define OSG_HEX_WPE_4 4
+#define OSG_HEX_WPE_4 5
 #endif
 #ifndef OSG_HEX_WPE_6
-#define OSG_HEX_WPE_6 3
+#define OSG_HEX_WPE_6 4
 #endif
 template <class G, bool kHexFill>
 constexpr int wave_wpe() {
@@ -1388,7 +1471,10 @@ int launch(const typename G::Params& P, const osg_batch* roots, const osg_mcts_c
   // 16 384 roots 1.00e9 -> 9.6e8, 32 768 roots 1.06e9 -> 1.03e9: with two or more rounds the static order's own
   // mixing balances the SIMDs and the queue's atomics and sort are pure cost)
   const int64_t slots = static_cast<int64_t>(ctx->num_cus) * 4 * sc.waves_per_simd;
-  if (sc.mode == 0 || n <= slots || n >= (int64_t{1} << 31) || (!sc.forced && n > slots + slots / 2)) {
+  // (the boards above 128 cells always launch statically: the queue's loop around the search costs the fat instantiations
+  // 50-180 vector registers in scratch, and its gain was 6 % on one-round batches of hex(9))
+  constexpr bool kQueue = wave_sets<G>() == 2;
+  if (!kQueue || sc.mode == 0 || n <= slots || n >= (int64_t{1} << 31) || (!sc.forced && n > slots + slots / 2)) {
     const unsigned grid = static_cast<unsigned>((n + kWavesPerBlock - 1) / kWavesPerBlock);
     if (gc)
       k_mcts_wave<G, kBoard, kHexFill, true><<<dim3(grid), dim3(64 * kWavesPerBlock), 0, st>>>(
@@ -1398,6 +1484,7 @@ int launch(const typename G::Params& P, const osg_batch* roots, const osg_mcts_c
           P, words, n, d.num_players, d.num_distinct_actions, cfg, d.max_utility, d_logs, pool, out);
     return OSG_OK;
   }
+  if constexpr (kQueue) {
   if (ctx->mcts_queue_roots < n) {
     if (ctx->d_mcts_queue) OSG_HIP(hipFree(ctx->d_mcts_queue));
     ctx->d_mcts_queue = nullptr;
@@ -1425,6 +1512,7 @@ int launch(const typename G::Params& P, const osg_batch* roots, const osg_mcts_c
   else
     k_mcts_wave_queue<G, kBoard, kHexFill, false><<<dim3(grid), dim3(64 * kWavesPerBlock), 0, st>>>(
         P, words, n, d.num_players, d.num_distinct_actions, cfg, d.max_utility, d_logs, pool, out, queue);
+  }
   return OSG_OK;
 }
 

@@ -43,8 +43,9 @@ HOT = [
 # Hot kernels whose parked registers / scratch are known, measured and kept (the note says where the decision is recorded).
 KNOWN = {
     "k_mcts_wave<osg::HexT<3>, true, true, false>":
-        "44 scalar registers parked in vector lanes + 2 vector registers in scratch at 7 waves per SIMD; the form without them "
-        "measured 2.7 % slower (profiles/r05_ab_register_work.txt, osg_mcts_wave.hip above wave_search)",
+        "38 scalar registers parked in vector lanes (v_readlane, no memory) at 7 waves per SIMD, no scratch since round 6's "
+        "templated position (1.105e9 -> 1.13e9 simulations/s against the previous object, profiles/r06zq_*); the form without "
+        "the parked registers measured 2.7 % slower (profiles/r05_ab_register_work.txt, osg_mcts_wave.hip above wave_search)",
     "k_geval_persist":
         "opt-in cross-check form of the large-tree evaluation (OSG_EVAL_PERSIST=1; the default is a launch per level, which "
         "measured faster: profiles/r06u_*): 16 scalar registers parked in vector lanes, no scratch",

@@ -89,13 +89,22 @@ constexpr int kMaxPath = 160;
 // per simulation against SQ_WAVE_CYCLES / 7 resident wavefronts = 503, SQ_ACTIVE_INST_SCA 382), so moving work across
 // no longer pays (profiles/r05y_hex_flood_exits_ab.txt).
 #ifndef OSG_THR_MODE
-#define OSG_THR_MODE 1
+#define OSG_THR_MODE 3
 #endif
 #ifndef OSG_FLOOD_MODE
 #define OSG_FLOOD_MODE 1
 #endif
 #ifndef OSG_HASH_VALU
 #define OSG_HASH_VALU 1
+#endif
+// The hex fill kernel's expansion from the legal cells as lane masks (1) or through the 4-word action mask (0, the form up
+// to round 5; the boards above 128 cells always take the lane masks).
+// The UCT arg-max through an fp32 filter (1) or always in fp64 (0): see select_child.
+#ifndef OSG_UCT_FILTER
+#define OSG_UCT_FILTER 1
+#endif
+#ifndef OSG_EXPAND_SETS
+#define OSG_EXPAND_SETS 1
 #endif
 
 OSG_D int lane_id() { return static_cast<int>(threadIdx.x & 63u); }
@@ -195,6 +204,20 @@ OSG_D uint32_t dpp_min_step(uint32_t v) {
   const uint32_t o = dpp_move<kCtrl, kRowMask>(0xFFFFFFFFu, v);
   return o < v ? o : v;
 }
+template <int kCtrl, int kRowMask>
+OSG_D float dpp_maxf_step(float v) {
+  const float o = __uint_as_float(dpp_move<kCtrl, kRowMask>(0xFF800000u, __float_as_uint(v)));   // identity: -infinity
+  return fmaxf(o, v);
+}
+OSG_D float wave_max_f32(float v) {  // never NaN-sensitive here: a NaN input loses every v_max and the caller falls back
+  v = dpp_maxf_step<0x111, 0xf>(v);
+  v = dpp_maxf_step<0x112, 0xf>(v);
+  v = dpp_maxf_step<0x114, 0xf>(v);
+  v = dpp_maxf_step<0x118, 0xf>(v);
+  v = dpp_maxf_step<0x142, 0xa>(v);
+  v = dpp_maxf_step<0x143, 0xc>(v);
+  return __uint_as_float(read_lane(__float_as_uint(v), 63));
+}
 OSG_D uint32_t wave_min_u32(uint32_t v) {
   v = dpp_min_step<0x111, 0xf>(v);
   v = dpp_min_step<0x112, 0xf>(v);
@@ -275,6 +298,70 @@ OSG_D Chosen select_child(const uint32_t* __restrict__ META, const uint32_t* __r
 #pragma unroll
     for (int j = 0; j < kSlots; ++j) cand[j] = unvisited[j];
   } else {
+    bool decided = false;
+#if OSG_UCT_FILTER
+    if constexpr (kBoard) {
+      if (!puct && any_outcome == 0ull) {
+        // The arg-max WITHOUT the fp64 divisions and square root where single precision already decides it.  Every value
+        // is computed in fp32 first (error below 2^-20 of 1 + |c| sqrt(log n): the returns of these games lie in
+        // [-1, 1], each of the five operations is good to an ulp or two).  Only children whose fp32 value is within 2^-18 of
+        // the largest (four times that bound) can hold the exact maximum.  One such child: it is the arg-max.  Several
+        // with IDENTICAL statistics (the usual case deep in the tree: siblings visited once or twice each): their exact
+        // values are the same number, so they are exactly the tied maxima, and the order key below picks among them as
+        // it would have.  Anything else (values that close from different statistics, overflow, NaN) takes the exact path.
+        const float lf = static_cast<float>(log_table[cnt]), cf = static_cast<float>(cfg.uct_c);
+        float a[kSlots];
+        float am = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+          const float rc = __builtin_amdgcn_rcpf(static_cast<float>(cc[j]));
+          const float val = static_cast<float>(ct[j]) * rc + cf * __builtin_amdgcn_sqrtf(lf * rc);
+          a[j] = in[j] ? val : -INFINITY;
+          am = fmaxf(am, a[j]);
+        }
+        const float top = wave_max_f32(am);
+        const float floor_v = top - 0x1p-18f * (1.0f + fabsf(cf) * __builtin_amdgcn_sqrtf(lf));
+        uint64_t near[kSlots];
+        int n_near = 0;
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+          near[j] = __ballot(a[j] >= floor_v);
+          n_near += __builtin_popcountll(near[j]);
+        }
+        decided = n_near == 1;
+        if (n_near > 1) {  // the same (count, total) in every one of them?
+          int slot = kSlots - 1;
+          uint64_t set = near[kSlots - 1];
+#pragma unroll
+          for (int j = kSlots - 2; j >= 0; --j) {
+            const bool here = near[j] != 0ull;
+            slot = here ? j : slot;
+            set = here ? near[j] : set;
+          }
+          const int src = uniform(static_cast<int>(__builtin_ctzll(set)));
+          uint32_t sc = cc[0];
+          double st = ct[0];
+#pragma unroll
+          for (int j = 1; j < kSlots; ++j) {
+            sc = slot == j ? cc[j] : sc;
+            st = slot == j ? ct[j] : st;
+          }
+          const uint32_t c0 = read_lane(sc, src);
+          const uint64_t t0 = read_lane_u64(static_cast<uint64_t>(__double_as_longlong(st)), src);
+          uint64_t odd = 0ull;
+#pragma unroll
+          for (int j = 0; j < kSlots; ++j)
+            odd |= near[j] & ~__ballot(cc[j] == c0 && static_cast<uint64_t>(__double_as_longlong(ct[j])) == t0);
+          decided = odd == 0ull;
+        }
+        if (decided) {
+#pragma unroll
+          for (int j = 0; j < kSlots; ++j) cand[j] = near[j];
+        }
+      }
+    }
+#endif
+    if (!decided) {
     double v[kSlots];
     if (!puct && any_outcome == 0ull) {
       // the common case, straight-line: every child has been visited, none has a proven outcome
@@ -310,6 +397,7 @@ OSG_D Chosen select_child(const uint32_t* __restrict__ META, const uint32_t* __r
     // (lanes without a child hold -infinity and c >= 1, so they never equal the maximum)
 #pragma unroll
     for (int j = 0; j < kSlots; ++j) cand[j] = __ballot(v[j] == vmax);
+    }
   }
   int total = 0;
 #pragma unroll
@@ -730,10 +818,40 @@ OSG_D int hex_fill_winner(const HexWT<kS>& s, uint64_t base, const HexLaneT<kS>&
   // The search runs on the VECTOR unit (the kernel is bound by scalar issue): threshold and step live in
   // vector registers holding the same value in every lane, occupied cells carry the key 2^64 - 1 so that
   // the ballots need no masking, and only the counting and the loop branch are left to the scalar unit.
+  const uint32_t vz = vector_zero();
+#if OSG_THR_MODE == 3
+  // First on the keys' 32 mixed bits alone (32-bit compares and selects; the cell-id bits below them only break ties):
+  // a threshold with exactly `want` of those words under it selects the same cells as the full keys do.  Where two
+  // empty cells share their 32 bits across the threshold (~m^2 / 2^33 of the playouts), or the largest word is all
+  // ones, no such threshold exists and the full-key search below runs.
+  bool found = want == 0;
+  {
+    uint32_t h[kS];
+#pragma unroll
+    for (int j = 0; j < kS; ++j)
+      h[j] = __builtin_amdgcn_inverse_ballot_w64(empty[j]) ? static_cast<uint32_t>(fill_key(base, lane + 64 * j) >> 8) : ~0u;
+    uint32_t t32 = vz, step32 = 0x80000000u | vz;
+    const uint32_t want32 = static_cast<uint32_t>(want) | vz;
+    if (want > 0) {
+      for (int it = 0; it < 32; ++it) {
+        const uint32_t probe = t32 | step32;
+        int below = 0;
+#pragma unroll
+        for (int j = 0; j < kS; ++j) below += __builtin_popcountll(__ballot(h[j] < probe));
+        const uint32_t below_v = static_cast<uint32_t>(below) | vz;
+        t32 = below_v <= want32 ? probe : t32;
+        step32 >>= 1;
+        if (below == want) { found = true; break; }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kS; ++j) sel[j] = __ballot(h[j] < t32);
+  }
+  if (!found) {
+#endif
   uint64_t k[kS];
 #pragma unroll
   for (int j = 0; j < kS; ++j) k[j] = __builtin_amdgcn_inverse_ballot_w64(empty[j]) ? key[j] : ~0ull;
-  const uint32_t vz = vector_zero();
   uint64_t thr = vz;
   if (want > 0) {
     uint64_t step = (1ull << (kBits - 1)) | vz;
@@ -751,6 +869,9 @@ OSG_D int hex_fill_winner(const HexWT<kS>& s, uint64_t base, const HexLaneT<kS>&
   }
 #pragma unroll
   for (int j = 0; j < kS; ++j) sel[j] = __ballot(k[j] < thr);
+#if OSG_THR_MODE == 3
+  }
+#endif
 #endif
   PT_MARK(4);
   // The filled board: the mover's new stones are `sel`, the opponent's the other empty cells.
@@ -1013,7 +1134,7 @@ OSG_D void wave_search(const typename G::Params& p, const typename G::word_t* ba
         // Children in action order.  Lane l looks at actions l, l + 64, ...: a legal action's slot is its
         // rank among the legal ones (popcount of the mask below it) — the cheap direction of the
         // k <-> action mapping — so the writes are still one compacted, coalesced span.
-        if constexpr (kHexFill && kWide) {  // the legal set as lane masks: a rank is a running count + the lanes below
+        if constexpr (kHexFill && (kWide || OSG_EXPAND_SETS)) {  // the legal set as lane masks: a rank is a running count + the lanes below
           int before = 0;
 #pragma unroll
           for (int j = 0; j < kS; ++j) {
@@ -1021,7 +1142,7 @@ OSG_D void wave_search(const typename G::Params& p, const typename G::word_t* ba
             if (__builtin_amdgcn_inverse_ballot_w64(e)) {
               const int rank = before + static_cast<int>(__builtin_amdgcn_mbcnt_hi(
                                             static_cast<uint32_t>(e >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(e), 0u)));
-              META[first + rank] = mw_make<true>(lane + 64 * j, cur, 0);
+              META[first + rank] = mw_make<kWide>(lane + 64 * j, cur, 0);
               FIRST[first + rank] = 0;
               COUNT[first + rank] = 0;
               TOTAL[first + rank] = 0.0;

@@ -285,7 +285,10 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
             # issue intervals per SIMD measured by tools/clock_probe.hip with every SIMD saturated
             # (profiles/r02_clock_probe.log): a scalar-unit instruction every 1.833 ns, a simple vector
             # instruction every 1.03 ns (64-bit shifts, multiplies, fp64: about twice that)
-            scalar_ns = (mix["salu"] + mix["branch"]) * 1.833
+            # (round 6: branches are NOT charged to the scalar ALU's issue slot any more — the search now runs faster
+            # than (salu + branch) x 1.833 ns per simulation, 841 ns against 816 measured, so they cannot share it; the
+            # branch unit is its own issue class)
+            scalar_ns = mix["salu"] * 1.833
             vector_ns = mix["valu"] * 1.03
             out["mcts"]["roofline"] = {
                 "bound": "scalar-unit instruction issue", "valu_per_sim": mix["valu"], "salu_per_sim": mix["salu"],
@@ -293,11 +296,11 @@ def secondary_workloads(osa, torch, dist, ctx, rank, world, with_cpu, host_barri
                 "ns_per_sim_per_simd": ns_per_sim,
                 "scalar_issue_ns_per_sim": scalar_ns, "vector_issue_ns_per_sim_at_least": vector_ns,
                 "frac_of_scalar_issue_bound": scalar_ns / ns_per_sim,
-                "note": "the scalar unit issues one instruction (ALU or branch) per 4 cycles per SIMD; with every wave "
-                        "slot busy the search runs at that rate, so fewer scalar instructions per simulation is the "
-                        "lever (round 2: 652 + 83 -> 387 + 88 per simulation, 7.97e8 -> 1.12e9 simulations/s; the vector unit is now as busy — "
-                        "SQ_ACTIVE_INST_VALU 549 quad-cycles per simulation against SQ_WAVE_CYCLES / 7 resident wavefronts = 503 — and "
-                        "moving more scalar work onto it measured slower in round 5, profiles/r05y_hex_flood_exits_ab.txt); "
+                "note": "the scalar ALU issues one instruction per 4 cycles per SIMD (1.833 ns measured with every wave slot "
+                        "busy); fewer instructions per simulation on both pipes is the lever (round 2: 652 -> 387 scalar, "
+                        "7.97e8 -> 1.12e9 simulations/s; round 6: 520 -> 442 vector — the UCT arg-max through an fp32 filter, "
+                        "the threshold search on 32-bit words, the expansion from lane masks — 381 -> 376 scalar, 1.10e9 -> "
+                        "1.256e9, profiles/r06zt_*); branches (83 per simulation) issue on their own port; "
                         "instruction counts are per simulation of an 8192-root search from the empty board"}
 
     # ---- config 3: kuhn_poker CFRSolver (full-tree regret / strategy update kernel) ----

@@ -477,6 +477,15 @@ template <int kS>
 constexpr int hex_win(int j) { return j - 1 < 0 ? 0 : (j - 1 > kS - hex_band<kS>() ? kS - hex_band<kS>() : j - 1); }
 template <class G>
 constexpr int wave_sets() { return G::kMaskW <= kMaskWords ? 2 : (G::kMaskW + 1) / 2; }
+// Which boards flood on packed per-lane flags (HexLaneT): those above 128 cells; OSG_PACKED_FLOOD_2=1 builds the form
+// for the smaller boards too (an A/B build: hex(9) config 4 1.255e9 -> 1.11e9 simulations/s at 7 and at 6 wavefronts per
+// SIMD, 10 / 4 vector registers in scratch — with two cell sets the neighbour bands are the cheaper step;
+// profiles/r06zw_*).
+#ifndef OSG_PACKED_FLOOD_2
+#define OSG_PACKED_FLOOD_2 0
+#endif
+template <int kS>
+constexpr bool hex_packed() { return kS > 2 || OSG_PACKED_FLOOD_2 != 0; }
 template <int kS>
 struct HexLaneT {
   uint64_t nb[kS][hex_band<kS>()];  // slot j: neighbours among the cells of sets hex_win(j) ... hex_win(j) + kB - 1
@@ -522,7 +531,7 @@ OSG_D HexLaneT<wave_sets<G>()> hex_lane_setup(const typename G::Params& p) {
           (G::test(p.col_first, cell) ? 4u : 0u) | (G::test(p.col_last, cell) ? 8u : 0u);
     }
     hl.edge |= e << (4 * j);
-    if constexpr (kS > 2) {
+    if constexpr (hex_packed<kS>()) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (j == 0) hl.fl_edge[q] = 0u;
@@ -685,7 +694,7 @@ OSG_D void hexw_apply(const HexLaneT<kS>&, HexWT<kS>& w, int move) {
 template <int kS>
 OSG_D bool hexw_last_stone_wins(const HexLaneT<kS>& hl, const HexWT<kS>& w, int move) {
   const bool black = (w.meta & 1u) != 0;  // the owner of the stone is the player who is NOT to move now
-  if constexpr (kS > 2) {  // packed flags (see HexLaneT)
+  if constexpr (hex_packed<kS>()) {  // packed flags (see HexLaneT)
     uint64_t own_sets[kS];
 #pragma unroll
     for (int j = 0; j < kS; ++j) own_sets[j] = black ? w.blk[j] : w.occ[j] & ~w.blk[j];
@@ -932,7 +941,7 @@ OSG_D int hex_fill_winner(const HexWT<kS>& s, uint64_t base, const HexLaneT<kS>&
   }
   return __ballot(hit != 0u) != 0ull ? 0 : 1;
 #else
-  if constexpr (kS > 2) {  // packed flags (see HexLaneT): a step costs six cross-lane reads whatever kS is
+  if constexpr (hex_packed<kS>()) {  // packed flags (see HexLaneT): a step costs six cross-lane reads whatever kS is
     const uint32_t black = hex_pack<kS>(blk);
     uint32_t front = black & hl.fl_edge[0];
     uint32_t avail = black & ~front;

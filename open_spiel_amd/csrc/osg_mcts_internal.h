@@ -76,6 +76,27 @@ OSG_D double outcome_value(uint32_t meta, uint32_t count, double total, int play
 }
 
 
+// Wave-wide maximum of an fp32 value as a DPP reduction (gfx9 row_shr 1, 2, 4, 8, row_bcast 15 / 31; identity -infinity),
+// handed back wave-uniform.  All 64 lanes must be active.  (The fp32 filter of the UCT arg-max: k_mcts_wave's
+// select_child, k_mcts_advance's lockstep search.)
+#ifndef OSG_UCT_FILTER_STEP
+#define OSG_UCT_FILTER_STEP 1   // k_mcts_advance's lockstep (one-root) search through the filter (1) or always fp64 (0)
+#endif
+template <int kCtrl, int kRowMask>
+OSG_D float dpp_maxf_step_(float v) {
+  const int o = __builtin_amdgcn_update_dpp(static_cast<int>(0xFF800000u), __float_as_int(v), kCtrl, kRowMask, 0xf, false);
+  return fmaxf(__int_as_float(o), v);
+}
+OSG_D float wave_max_f32_dpp(float v) {
+  v = dpp_maxf_step_<0x111, 0xf>(v);
+  v = dpp_maxf_step_<0x112, 0xf>(v);
+  v = dpp_maxf_step_<0x114, 0xf>(v);
+  v = dpp_maxf_step_<0x118, 0xf>(v);
+  v = dpp_maxf_step_<0x142, 0xa>(v);
+  v = dpp_maxf_step_<0x143, 0xc>(v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // One playout of RandomRolloutEvaluator::Evaluate (mcts.cc:45-56) from `s` on `rng`: Returns() of the finished game in
 // rr.  hex: the winner from the filled board (HexT::fill_playout_winner, round 6 — the same draws and moves without the
 // edge labels; OSG_HEX_FILL_PLAYOUT=0 at build time keeps the move-by-move rules); the other games move by move.

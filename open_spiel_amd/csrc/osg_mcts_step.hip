@@ -463,6 +463,38 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
                 bc = 0;
                 bf = static_cast<uint32_t>(__shfl(static_cast<int>(cf), src, 64));
                 decided = true;
+              } else if constexpr (kBoard && OSG_UCT_FILTER_STEP != 0) {
+                // (round 6, as in k_mcts_wave's select_child) the arg-max through an fp32 filter: every child's value in
+                // single precision (a proven outcome is a small integer, exact; the others within 2^-20 (1 + |c| sqrt(log
+                // n)) of the fp64 value: returns in [-1, 1]); only children within 2^-18 of the largest can hold the exact
+                // maximum.  One such child: the arg-max.  Several without a proven outcome and with IDENTICAL (count,
+                // total): their fp64 values are one number, the lowest index wins as in the scan.  Anything else takes the
+                // fp64 butterfly below — so the ~150 dependent fp64 instructions per level are rarely run.
+                const double ct = TOTAL(at);
+                const bool has = m_has_outcome(cm);
+                const float lf = static_cast<float>(logn), cf32 = static_cast<float>(cfg.uct_c);
+                const float rc = __builtin_amdgcn_rcpf(static_cast<float>(cc));
+                float a = has ? static_cast<float>(outcome_value<true>(cm, cc, ct, m_player(cm)))
+                              : static_cast<float>(ct) * rc + cf32 * __builtin_amdgcn_sqrtf(lf * rc);
+                a = k < c ? a : -INFINITY;
+                const float top = wave_max_f32_dpp(a);
+                const float floor_v = top - 0x1p-18f * (1.0f + fabsf(cf32) * __builtin_amdgcn_sqrtf(lf));
+                const unsigned long long near = __ballot(a >= floor_v);
+                const int n_near = __builtin_popcountll(near);
+                bool ok = n_near == 1;
+                const int src = near != 0ull ? __builtin_ctzll(near) : 0;
+                if (n_near > 1 && (__ballot(has) & near) == 0ull) {
+                  const uint32_t c0 = static_cast<uint32_t>(__shfl(static_cast<int>(cc), src, 64));
+                  const double t0 = __shfl(ct, src, 64);
+                  ok = (near & ~__ballot(cc == c0 && __double_as_longlong(ct) == __double_as_longlong(t0))) == 0ull;
+                }
+                if (ok) {
+                  bk = static_cast<uint32_t>(src);
+                  bm = static_cast<uint32_t>(__shfl(static_cast<int>(cm), src, 64));
+                  bc = static_cast<uint32_t>(__shfl(static_cast<int>(cc), src, 64));
+                  bf = static_cast<uint32_t>(__shfl(static_cast<int>(cf), src, 64));
+                  decided = true;
+                }
               }
             }
             for (int k0 = 0; !decided && k0 < c; k0 += 64) {

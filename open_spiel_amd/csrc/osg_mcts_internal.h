@@ -3,6 +3,8 @@
 #ifndef OSG_MCTS_INTERNAL_H_
 #define OSG_MCTS_INTERNAL_H_
 
+#include <type_traits>
+
 #include "osg_internal.h"
 
 namespace osg {
@@ -82,6 +84,9 @@ OSG_D double outcome_value(uint32_t meta, uint32_t count, double total, int play
 #ifndef OSG_UCT_FILTER_STEP
 #define OSG_UCT_FILTER_STEP 1   // k_mcts_advance's lockstep (one-root) search through the filter (1) or always fp64 (0)
 #endif
+#ifndef OSG_COOP_BACKUP
+#define OSG_COOP_BACKUP 1       // the one-root search's backup by one lane per path node (1) or up the parent links (0)
+#endif
 template <int kCtrl, int kRowMask>
 OSG_D float dpp_maxf_step_(float v) {
   const int o = __builtin_amdgcn_update_dpp(static_cast<int>(0xFF800000u), __float_as_int(v), kCtrl, kRowMask, 0xf, false);
@@ -103,9 +108,29 @@ OSG_D float wave_max_f32_dpp(float v) {
 #ifndef OSG_HEX_FILL_PLAYOUT
 #define OSG_HEX_FILL_PLAYOUT 1
 #endif
+#ifndef OSG_TTT_PLAYOUT
+#define OSG_TTT_PLAYOUT 1   // tic_tac_toe playouts test the mover's lines only (1) or run the generic rule calls (0)
+#endif
 template <class G>
 OSG_D void playout_returns(const typename G::Params& p, const typename G::State& s, Rng& rng, double* rr) {
-  if constexpr (is_hex<G>::value && OSG_HEX_FILL_PLAYOUT) {
+  if constexpr (std::is_same<G, Ttt>::value && OSG_TTT_PLAYOUT != 0) {
+    // The same draws and moves as the generic loop below (rng.below(number of empty cells), the k-th empty cell), with
+    // the rules' work cut to what a move can change: only the player who just moved can have completed a line, and the
+    // board is full after nine stones (tic_tac_toe.cc:109-136, 215-227).
+    typename G::State w = s;
+    if (!G::terminal(p, w)) {
+      uint32_t occ = w.x | w.o;
+      int n = __builtin_popcount(occ);
+      for (; n < 9; ++n) {
+        const uint32_t empties = ~occ & 0x1FFu;
+        const uint32_t bit = 1u << select32(empties, static_cast<int>(rng.below(static_cast<uint32_t>(9 - n))));
+        occ |= bit;
+        if (n & 1) { w.o |= bit; if (G::line(w.o)) break; }
+        else { w.x |= bit; if (G::line(w.x)) break; }
+      }
+    }
+    G::returns(p, w, rr);
+  } else if constexpr (is_hex<G>::value && OSG_HEX_FILL_PLAYOUT) {
     const double r0 = G::fill_playout_winner(p, s, rng) == 0 ? 1.0 : -1.0;
     rr[0] = r0;
     rr[1] = -r0;

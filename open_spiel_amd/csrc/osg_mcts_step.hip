@@ -292,6 +292,12 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
   double returns[kMaxPlayers];
   bool solved = false;
   int started = 0;
+  // kCoop (one root, lockstep): LANE d remembers the d-th node of the running simulation's visit path, so that the backup
+  // is one read-modify-write per lane side by side instead of a chain of them up the parent links.  Valid while the
+  // simulation ran inside this launch without parking (a resumed one walks the parent links as before).
+  uint32_t path_node = 0;
+  int path_depth = 0;
+  bool path_ok = false;
   auto park = [&](uint8_t ph, uint8_t req) {
     pool.phase[r] = ph; pool.used[r] = used; pool.gc_limit[r] = gc_limit; pool.sims[r] = sims_done;
     pool.node[r] = node; pool.rng[r] = trng.s;
@@ -381,8 +387,10 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
       trng = Rng(cfg.seed ^ kTreeSalt, gr, static_cast<uint64_t>(sims_done));
       s = root_state;
       node = 0;
+      path_node = 0; path_depth = 0; path_ok = kCoop && OSG_COOP_BACKUP != 0;
     } else {  // resume at the parked node: its state is in the leaf batch
       s = G::load(p, leaf_words, n, r);
+      path_ok = false;
     }
     if (phase == kWantValue) {
       for (int q = 0; q < num_players; ++q) returns[q] = value_in[r * num_players + q];
@@ -561,6 +569,11 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
         }
         G::apply(p, s, static_cast<int>(mw_action<kWide>(have_chosen_meta ? chosen_meta : META(chosen))));
         node = chosen;
+        if (kCoop) {
+          ++path_depth;
+          path_node = static_cast<int>(threadIdx.x) == path_depth ? chosen : path_node;
+          path_ok = path_ok && path_depth < 64;
+        }
         carried = have_chosen_meta;
         if (have_chosen_meta) { n_cnt = chosen_cnt; n_meta = chosen_meta; n_first = chosen_first; }
       }
@@ -589,10 +602,19 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
             playout_returns<G>(p, s, rng, rr);
             for (int q = 0; q < num_players; ++q) sum[q] += rr[q];
           }
-          for (int q = 0; q < num_players; ++q) {
-            double v = sum[q];
-            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-            returns[q] = v;
+          if (kBoard && cfg.n_rollouts <= 64 && OSG_COOP_BACKUP != 0) {
+            // win / draw / loss games, one playout per lane: the sum of player 0's returns (each -1, 0 or +1) is wins
+            // minus losses — two ballots instead of two 64-bit butterflies through the LDS crossbar — and player 1's
+            // is its negation (Returns() of these games: {r, -r + 0.0}; small integers, exact in any order)
+            const int wins = __builtin_popcountll(__ballot(sum[0] > 0.0)), losses = __builtin_popcountll(__ballot(sum[0] < 0.0));
+            returns[0] = static_cast<double>(wins - losses);
+            returns[1] = -returns[0] + 0.0;
+          } else {
+            for (int q = 0; q < num_players; ++q) {
+              double v = sum[q];
+              for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+              returns[q] = v;
+            }
           }
         }
         for (int ro = 0; !kCoop && ro < cfg.n_rollouts; ++ro) {
@@ -610,7 +632,20 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
     }
     OSG_PROF(2);
     // ---- backup (mcts.cc:383-435) ----
-    for (uint32_t v = node; v != kNoNode; v = PARENT(v)) {
+    bool counted = false;
+    if (kCoop && kBoard && path_ok) {   // two players, no chance nodes: a node's player is in its own header
+      if (static_cast<int>(threadIdx.x) <= path_depth) {
+        const uint32_t v = path_node;
+        const int pl = m_player(static_cast<uint32_t>(META(v)));
+        const double t = static_cast<double>(TOTAL(v)) + returns[(pl < 0 || pl >= num_players) ? 0 : pl];  // (a terminal root has no player)
+        const uint32_t cn = static_cast<uint32_t>(COUNT(v)) + 1u;
+        node_store<kCoop>(lt.total, pool.total, v, NR, RB, t);
+        node_store<kCoop>(lt.count, pool.count, v, NR, RB, cn);
+      }
+      asm volatile("" ::: "memory");
+      counted = true;
+    }
+    for (uint32_t v = node; v != kNoNode && !(counted && !solved); v = PARENT(v)) {
       uint32_t meta = META(v);
       int pl = m_player(meta);
       for (uint32_t up = v; pl == kChancePlayer;) {
@@ -618,8 +653,10 @@ k_mcts_advance(typename G::Params p, const typename G::word_t* root_words, typen
         if (up == kNoNode) { pl = 0; break; }
         pl = m_player(META(up));
       }
-      TOTAL(v) += returns[(pl < 0 || pl >= num_players) ? 0 : pl];  // (a terminal root has no player)
-      COUNT(v) += 1;
+      if (!counted) {
+        TOTAL(v) += returns[(pl < 0 || pl >= num_players) ? 0 : pl];  // (a terminal root has no player)
+        COUNT(v) += 1;
+      }
       if (kBoard && solved && mw_nchild<kWide>(meta) > 0) {
         const uint32_t first = FIRST(v);
         const int c = mw_nchild<kWide>(meta);

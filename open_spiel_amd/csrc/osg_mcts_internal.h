@@ -108,6 +108,20 @@ OSG_D float wave_max_f32_dpp(float v) {
 #ifndef OSG_HEX_FILL_PLAYOUT
 #define OSG_HEX_FILL_PLAYOUT 1
 #endif
+// The k-th (0-based) set bit of a 9-bit set; k < popcount(x).  (select32 without its two widest halvings.)
+OSG_D int select9(uint32_t x, int k) {
+  const int c8 = __builtin_popcount(x & 0xFFu);
+  if (k >= c8) return 8;
+  int pos = 0;
+#pragma unroll
+  for (int width = 4; width >= 1; width >>= 1) {
+    const uint32_t low = x & ((1u << width) - 1u);
+    const int c = __builtin_popcount(low);
+    if (k >= c) { k -= c; x >>= width; pos += width; }
+    else x = low;
+  }
+  return pos;
+}
 #ifndef OSG_TTT_PLAYOUT
 #define OSG_TTT_PLAYOUT 1   // tic_tac_toe playouts test the mover's lines only (1) or run the generic rule calls (0)
 #endif
@@ -123,7 +137,7 @@ OSG_D void playout_returns(const typename G::Params& p, const typename G::State&
       int n = __builtin_popcount(occ);
       for (; n < 9; ++n) {
         const uint32_t empties = ~occ & 0x1FFu;
-        const uint32_t bit = 1u << select32(empties, static_cast<int>(rng.below(static_cast<uint32_t>(9 - n))));
+        const uint32_t bit = 1u << select9(empties, static_cast<int>(rng.below(static_cast<uint32_t>(9 - n))));
         occ |= bit;
         if (n & 1) { w.o |= bit; if (G::line(w.o)) break; }
         else { w.x |= bit; if (G::line(w.x)) break; }

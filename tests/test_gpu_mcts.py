@@ -218,6 +218,39 @@ def test_mcts_wave_layout_on_the_boards_above_128_cells(oracle, ctx, game, n, si
             assert np.isnan(stats[i, 2]) == np.isnan(want["root_outcome"])
 
 
+@pytest.mark.parametrize("uct_c", [0.0, 1e-9, 1e-4, 0.37, 1e30])
+@pytest.mark.parametrize("game,n,sims,n_rollouts,solve,max_stop", [
+    ("hex(board_size=5)", 24, 400, 2, True, 10),
+    ("hex(board_size=9)", 12, 500, 1, False, 30),
+    ("hex(board_size=13)", 6, 300, 1, False, 120),
+])
+def test_wave_search_arg_max_is_exact_where_single_precision_cannot_decide(oracle, ctx, game, n, sims, n_rollouts, solve,
+                                                                           max_stop, uct_c):
+    """Round 6: the wave-per-root search forms every child's UCT value in fp32 first and takes the fp64 divisions and
+    square root only where that cannot name the maximum.  Exploration constants that put the children's values closer
+    than single precision resolves (1e-9, 1e-4), remove the exploration term (0: values are the mean returns, full of
+    near ties between different statistics), overflow fp32 (1e30) or are ordinary (0.37): the trees must still be the
+    oracle's, visit for visit."""
+    og, roots, hists = _roots(oracle, ctx, game, n, 41, max_stop, 0)
+    seed, offset = 0xABCDEF, 99
+    res = roots.mcts_search(uct_c=uct_c, max_simulations=sims, n_rollouts=n_rollouts, solve=solve, seed=seed,
+                            index_offset=offset, layout=2)
+    visits = res["child_visits"].cpu().numpy()
+    reward = res["child_reward"].cpu().numpy()
+    best = res["best_action"].cpu().numpy()
+    stats = res["root_stats"].cpu().numpy()
+    for i in range(n):
+        st = _oracle_state(og, hists[i])
+        want = st.mcts_search(uct_c, sims, n_rollouts, 4096, solve, 0, counter_root=offset + i, counter_seed=seed,
+                              counter_layout=2)
+        assert stats[i, 0] == want["root_visits"], f"{game} c={uct_c} root {i}: root visits"
+        for a, cnt, tot, out in want["children"]:
+            a = int(a)
+            assert visits[i, a] == cnt and reward[i, a] == tot, f"{game} c={uct_c} root {i} action {a}: {visits[i, a]} / {cnt}"
+        if len(want["children"]):
+            assert best[i] == want["best_action"], f"{game} c={uct_c} root {i}: best action"
+
+
 @pytest.mark.parametrize("layout", [1, 2])
 @pytest.mark.parametrize("game,n,sims,n_rollouts,solve,max_stop", [
     ("tic_tac_toe", 48, 150, 2, True, 5), ("connect_four", 32, 120, 1, False, 20),

@@ -18,12 +18,12 @@ import json, sys
 sys.path.insert(0, ROOT)
 from open_spiel_amd import pyspiel_hip as pyspiel
 out = {}
-for game_string, moves, sims, n_rollouts, solve in CASES:
+for game_string, moves, sims, n_rollouts, solve, uct_c in CASES:
     game = pyspiel.load_game(game_string)
     state = game.new_initial_state()
     for a in moves:
         state.apply_action(a)
-    bot = pyspiel.MCTSBot(game, pyspiel.RandomRolloutEvaluator(n_rollouts, 7), 2.0, sims, 50, solve, 0x5EED, False)
+    bot = pyspiel.MCTSBot(game, pyspiel.RandomRolloutEvaluator(n_rollouts, 7), uct_c, sims, 50, solve, 0x5EED, False)
     rows = []
     def walk(node, depth):
         rows.append([depth, int(node.action), int(node.player), int(node.explore_count), float(node.total_reward),
@@ -32,19 +32,27 @@ for game_string, moves, sims, n_rollouts, solve in CASES:
             walk(c, depth + 1)
     for _ in range(2):                       # two searches with one bot: the second one's streams start at search 1
         walk(bot.mcts_search(state), 0)
-    out[game_string + str(moves)] = rows
+    out[game_string + str(moves) + str(uct_c)] = rows
 print("TREES " + json.dumps(out))
 '''
 
 CASES = [
-    ("tic_tac_toe", [], 400, 20, True),
-    ("tic_tac_toe", [4, 0, 8], 300, 7, True),
-    ("connect_four", [3, 3, 2], 300, 70, False),        # more playouts than one round of lanes... (70 > 64)
-    ("hex(board_size=5)", [12, 6], 200, 5, True),
-    ("kuhn_poker", [0, 1], 150, 9, False),              # chance inside the playouts
-    ("leduc_poker", [0, 3, 1], 150, 4, False),
-    ("hex(board_size=13)", [84, 70], 60, 3, False),     # 167 children per node: the sequential expansion, nine-bit fields unused
-    ("hex(board_size=19)", [180], 30, 2, False),        # 360 children: the nine-bit action / child-count fields
+    ("tic_tac_toe", [], 400, 20, True, 2.0),
+    ("tic_tac_toe", [4, 0, 8], 300, 7, True, 2.0),
+    ("connect_four", [3, 3, 2], 300, 70, False, 2.0),        # more playouts than one round of lanes... (70 > 64)
+    ("hex(board_size=5)", [12, 6], 200, 5, True, 2.0),
+    ("kuhn_poker", [0, 1], 150, 9, False, 2.0),              # chance inside the playouts
+    ("leduc_poker", [0, 3, 1], 150, 4, False, 2.0),
+    ("hex(board_size=13)", [84, 70], 60, 3, False, 2.0),     # 167 children per node: the sequential expansion, nine-bit fields unused
+    ("hex(board_size=19)", [180], 30, 2, False, 2.0),        # 360 children: the nine-bit action / child-count fields
+    # round 6: the lockstep form's arg-max goes through an fp32 filter with an exact fallback; exploration constants at
+    # which single precision cannot separate the children (values apart by less than its resolution), overflows
+    # (1e30 * sqrt: +inf in fp32) or carries nothing (0) must still build the one-lane form's tree
+    ("tic_tac_toe", [], 400, 20, True, 1e-9),
+    ("tic_tac_toe", [4], 400, 3, False, 0.0),
+    ("tic_tac_toe", [], 300, 20, True, 1e30),
+    ("connect_four", [3, 3], 400, 5, True, 1e-5),
+    ("connect_four", [], 300, 2, False, 0.37),
 ]
 
 

@@ -43,8 +43,8 @@ HOT = [
 # Hot kernels whose parked registers / scratch are known, measured and kept (the note says where the decision is recorded).
 KNOWN = {
     "k_mcts_wave<osg::HexT<3>, true, true, false>":
-        "38 scalar registers parked in vector lanes (v_readlane, no memory) at 7 waves per SIMD, no scratch since round 6's "
-        "templated position (1.105e9 -> 1.13e9 simulations/s against the previous object, profiles/r06zq_*); the form without "
+        "26 scalar registers parked in vector lanes (v_readlane, no memory) at 7 waves per SIMD (44 up to round 5), no scratch "
+        "since round 6's templated position (1.105e9 -> 1.13e9 simulations/s against the previous object, profiles/r06zq_*); the form without "
         "the parked registers measured 2.7 % slower (profiles/r05_ab_register_work.txt, osg_mcts_wave.hip above wave_search)",
     "k_geval_persist":
         "opt-in cross-check form of the large-tree evaluation (OSG_EVAL_PERSIST=1; the default is a launch per level, which "

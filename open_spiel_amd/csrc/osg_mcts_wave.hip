@@ -475,8 +475,17 @@ template <int kS>
 constexpr int hex_band() { return kS < 3 ? kS : 3; }
 template <int kS>
 constexpr int hex_win(int j) { return j - 1 < 0 ? 0 : (j - 1 > kS - hex_band<kS>() ? kS - hex_band<kS>() : j - 1); }
+// (OSG_HEX_ONE_SET=1: hex boards of up to 64 cells — two plane words — walk with ONE cell set per colour and one child slot
+// per lane; 0 keeps two, the form up to round 6's first sessions)
+#ifndef OSG_HEX_ONE_SET
+#define OSG_HEX_ONE_SET 1
+#endif
+template <class G> struct hex_plane_words { static constexpr int value = kMaskWords; };
+template <int NW> struct hex_plane_words<HexT<NW>> { static constexpr int value = NW; };
 template <class G>
-constexpr int wave_sets() { return G::kMaskW <= kMaskWords ? 2 : (G::kMaskW + 1) / 2; }
+constexpr int wave_sets() {
+  return G::kMaskW > kMaskWords ? (G::kMaskW + 1) / 2 : ((OSG_HEX_ONE_SET != 0 && is_hex<G>::value && hex_plane_words<G>::value <= 2) ? 1 : 2);
+}
 // Which boards flood on packed per-lane flags (HexLaneT): those above 128 cells; OSG_PACKED_FLOOD_2=1 builds the form
 // for the smaller boards too (an A/B build: hex(9) config 4 1.255e9 -> 1.11e9 simulations/s at 7 and at 6 wavefronts per
 // SIMD, 10 / 4 vector registers in scratch — with two cell sets the neighbour bands are the cheaper step;
@@ -1035,7 +1044,7 @@ struct VisitPath {
 template <class G, bool kHexFill>
 constexpr int wave_wpe() {
   if (!kHexFill) return 4;
-  return wave_sets<G>() == 2 ? OSG_HEX_WPE : (wave_sets<G>() == 3 ? OSG_HEX_WPE_3 : (wave_sets<G>() == 4 ? OSG_HEX_WPE_4 : OSG_HEX_WPE_6));
+  return wave_sets<G>() <= 2 ? OSG_HEX_WPE : (wave_sets<G>() == 3 ? OSG_HEX_WPE_3 : (wave_sets<G>() == 4 ? OSG_HEX_WPE_4 : OSG_HEX_WPE_6));
 }
 
 // The hex fill kernel at 7 waves per SIMD.  What the code object says (tools/kernel_resources.py ->
@@ -1603,7 +1612,7 @@ int launch(const typename G::Params& P, const osg_batch* roots, const osg_mcts_c
   const int64_t slots = static_cast<int64_t>(ctx->num_cus) * 4 * sc.waves_per_simd;
   // (the boards above 128 cells always launch statically: the queue's loop around the search costs the fat instantiations
   // 50-180 vector registers in scratch, and its gain was 6 % on one-round batches of hex(9))
-  constexpr bool kQueue = wave_sets<G>() == 2;
+  constexpr bool kQueue = wave_sets<G>() <= 2;
   if (!kQueue || sc.mode == 0 || n <= slots || n >= (int64_t{1} << 31) || (!sc.forced && n > slots + slots / 2)) {
     const unsigned grid = static_cast<unsigned>((n + kWavesPerBlock - 1) / kWavesPerBlock);
     if (gc)

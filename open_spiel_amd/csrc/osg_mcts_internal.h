@@ -50,7 +50,7 @@ OSG_D uint32_t make_meta(int action, int player, int nchild) {
 // Games with more than 255 actions (hex above 15 x 15: the lane-per-root kernels serve boards up to 19 x 19) keep the
 // ninth bit of the action in bit 24 and the ninth bit of the child count in bit 25 of the same word; both are zero
 // for every other game, so a decoder that always reads them (the host's) is right for all.  The wave-per-root
-// kernel serves boards of up to 128 cells and keeps the narrow accessors above.
+// kernel takes the narrow accessors above for boards of up to 128 cells and these for the larger hex boards (round 6).
 template <bool kWide> OSG_HD uint32_t mw_action(uint32_t m) { return kWide ? ((m & 0xFFu) | ((m >> 16) & 0x100u)) : (m & 0xFFu); }
 template <bool kWide> OSG_HD int mw_nchild(uint32_t m) {
   return static_cast<int>(kWide ? (((m >> 12) & 0xFFu) | ((m >> 17) & 0x100u)) : ((m >> 12) & 0xFFu));

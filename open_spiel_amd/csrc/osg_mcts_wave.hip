@@ -2,11 +2,12 @@
 //
 // The 64 lanes of a wavefront cooperate on one search tree:
 //   * selection   (mcts.cc:324-341)  children of a node are contiguous; lane l scans
-//                 children l and l+64 (header + statistics, one branch-free round of
-//                 loads), scores them (UCTValue, mcts.cc:90-101), a DPP reduction finds
-//                 the maximum and a ballot who holds it; the chosen child's header is
-//                 handed down by readlane, so a tree level costs one memory round trip
-//   * expansion   (mcts.cc:281-299)  lane l initialises children l, l+64
+//                 children l, l+64, ... (header + statistics, one branch-free round of
+//                 loads), scores them (UCTValue, mcts.cc:90-101: in fp32 first, the fp64
+//                 formula only where that cannot name the maximum — select_child), a DPP
+//                 reduction finds the maximum and a ballot who holds it; the chosen child's
+//                 header is handed down by readlane, so a tree level costs one memory round trip
+//   * expansion   (mcts.cc:281-299)  lane l initialises children l, l+64, ...
 //   * evaluation  (mcts.cc:43-72)    n_rollouts playouts spread over the lanes; a
 //                 hex playout is ONE wave-parallel random fill of the board
 //                 (lane = cell): a binary search on the key threshold hands the mover
@@ -15,8 +16,8 @@
 //   * backup      (mcts.cc:383-395)  lane d updates the d-th node of the path from the
 //                 statistics the path carried down (stores only)
 //   * MCTS-Solver (mcts.cc:398-434)  lanes scan the children, ballot / shuffle reduce
-// The position itself is wave-uniform and kept in scalar registers (hex: HexW, pairs of
-// 64-bit cell sets), so the rule code is scalar set algebra plus per-lane neighbour
+// The position itself is wave-uniform and kept in scalar registers (hex: HexWT<kS>, kS
+// 64-bit cell sets per colour: 1 up to 64 cells, 2 up to 128, 3 / 4 / 6 up to 19 x 19), so the rule code is scalar set algebra plus per-lane neighbour
 // tests.  Everything the compiler must see as wave-uniform is made so explicitly
 // (readfirstlane / readlane / ballot); `opt -passes=print<uniformity>` on this file is
 // the check — a single lane-varying value on the loop-carried path turns the whole
